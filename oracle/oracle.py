@@ -1,0 +1,235 @@
+"""ORACLE loader — TEST INFRASTRUCTURE ONLY.
+
+ctypes/numpy front-end of oracle/liblili_oracle.so (the CPU restatement of the reference hot path).
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product (lili_om_amd) never does.  PARITY UNPINNED: see oracle/lo_math.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liblili_oracle.so")
+
+VARIANT_LIVOX, VARIANT_ROT, VARIANT_FRONTEND = 0, 1, 2
+LOSS_NONE, LOSS_CAUCHY, LOSS_HUBER = 0, 1, 2
+
+
+class Params(C.Structure):
+    _fields_ = [("variant", C.c_int), ("loss", C.c_int), ("loss_a", C.c_double), ("lidar_const", C.c_double),
+                ("kd_max_radius", C.c_double), ("edge_gate", C.c_double), ("surf_dist_thres", C.c_double),
+                ("reflect_thres", C.c_double), ("surf_weight_min", C.c_double), ("edge_dist_max", C.c_double),
+                ("q_lb", C.c_double * 4), ("t_lb", C.c_double * 3)]
+
+
+def params(variant="rot", **kw):
+    """Parameter sets of L/config/config_fr_iosb.yaml, R/config/config_fr_iosb.yaml."""
+    p = Params()
+    if variant == "livox":
+        p.variant, p.loss, p.loss_a = VARIANT_LIVOX, LOSS_CAUCHY, 1.0
+        p.lidar_const, p.kd_max_radius, p.edge_gate = 20.0, 1.0, 1.0
+        p.surf_dist_thres, p.reflect_thres, p.surf_weight_min, p.edge_dist_max = 0.12, 15.0, 0.2, 0.0
+        p.q_lb[:] = [0.0, 0.0, 0.0, 1.0]
+        p.t_lb[:] = [-0.0265, 0.0202, 0.05309]
+    elif variant == "rot":
+        p.variant, p.loss, p.loss_a = VARIANT_ROT, LOSS_CAUCHY, 1.0
+        p.lidar_const, p.kd_max_radius, p.edge_gate = 7.5, 1.0, 1.0
+        p.surf_dist_thres, p.reflect_thres, p.surf_weight_min, p.edge_dist_max = 0.12, 0.0, 0.3, 0.1
+        p.q_lb[:] = [0.7071, 0.0, 0.0, 0.7071]
+        p.t_lb[:] = [-0.18, 0.0, -0.095]
+    elif variant == "frontend":
+        p.variant, p.loss, p.loss_a = VARIANT_FRONTEND, LOSS_HUBER, 0.1
+        p.lidar_const, p.kd_max_radius, p.edge_gate = 1.0, 1.0, 1.0
+        p.surf_dist_thres, p.reflect_thres, p.surf_weight_min, p.edge_dist_max = 0.06, 0.0, 0.4, 0.0
+        p.q_lb[:] = [1.0, 0.0, 0.0, 0.0]
+        p.t_lb[:] = [0.0, 0.0, 0.0]
+    else:
+        raise ValueError(variant)
+    for k, v in kw.items():
+        if k in ("q_lb", "t_lb"):
+            getattr(p, k)[:] = list(v)
+        else:
+            setattr(p, k, v)
+    return p
+
+
+def build(force=False):
+    if force or not os.path.exists(_SO) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_SO)
+            for f in os.listdir(_HERE) if f.endswith((".cpp", ".h", "Makefile"))):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        _lib.lo_kdtree_build.restype = C.c_void_p
+        _lib.lo_kdtree_build.argtypes = [C.c_void_p, C.c_int]
+        _lib.lo_kdtree_free.argtypes = [C.c_void_p]
+        for name in ("lo_associate_surf", "lo_associate_edge", "lo_gn_step", "lo_eig3"):
+            getattr(_lib, name).restype = C.c_int
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a, cols=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if cols is not None:
+        a = a.reshape(-1, cols)
+    return a
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class KdTree:
+    """Exact kNN-5 (replaces pcl::KdTreeFLANN; L/src/BackendFusion.cpp:839-840,1541,1611)."""
+
+    def __init__(self, xyz):
+        self.xyz = _f32(xyz, 3)
+        self.n = self.xyz.shape[0]
+        self.h = lib().lo_kdtree_build(_p(self.xyz), self.n)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().lo_kdtree_free(C.c_void_p(self.h))
+            self.h = None
+
+    def knn5(self, q, nthreads=1):
+        q = _f32(q, 3)
+        m = q.shape[0]
+        idx = np.empty((m, 5), np.int32)
+        d2 = np.empty((m, 5), np.float32)
+        lib().lo_knn5(C.c_void_p(self.h), _p(q), m, _p(idx), _p(d2), int(nthreads))
+        return idx, d2
+
+
+def knn5_brute(xyz, q):
+    xyz, q = _f32(xyz, 3), _f32(q, 3)
+    m = q.shape[0]
+    idx = np.empty((m, 5), np.int32)
+    d2 = np.empty((m, 5), np.float32)
+    lib().lo_knn5_brute(_p(xyz), xyz.shape[0], _p(q), m, _p(idx), _p(d2))
+    return idx, d2
+
+
+def associate_surf(tree, map_refl, q_xyz, q_refl, pose_q, pose_t, P, nthreads=1):
+    q_xyz = _f32(q_xyz, 3)
+    n = q_xyz.shape[0]
+    map_refl = None if map_refl is None else _f32(map_refl)
+    q_refl = None if q_refl is None else _f32(q_refl)
+    out = dict(valid=np.zeros(n, np.uint8), nn_idx=np.full((n, 5), -1, np.int32), nn_d2=np.zeros((n, 5), np.float32),
+               cp=np.zeros((n, 3), np.float32), n=np.zeros((n, 3), np.float32), d=np.zeros(n, np.float32),
+               score=np.zeros(n, np.float64))
+    pq, pt = _f64(pose_q), _f64(pose_t)
+    cnt = lib().lo_associate_surf(C.c_void_p(tree.h), _p(tree.xyz), _p(map_refl), tree.n, _p(q_xyz), _p(q_refl), n,
+                                  _p(pq), _p(pt), C.byref(P), int(nthreads), _p(out["valid"]), _p(out["nn_idx"]),
+                                  _p(out["nn_d2"]), _p(out["cp"]), _p(out["n"]), _p(out["d"]), _p(out["score"]))
+    out["count"] = cnt
+    return out
+
+
+def associate_edge(tree, q_xyz, pose_q, pose_t, P, nthreads=1):
+    q_xyz = _f32(q_xyz, 3)
+    n = q_xyz.shape[0]
+    out = dict(valid=np.zeros(n, np.uint8), nn_idx=np.full((n, 5), -1, np.int32), nn_d2=np.zeros((n, 5), np.float32),
+               cp=np.zeros((n, 3), np.float32), a=np.zeros((n, 3), np.float32), b=np.zeros((n, 3), np.float32),
+               s=np.zeros(n, np.float32))
+    pq, pt = _f64(pose_q), _f64(pose_t)
+    cnt = lib().lo_associate_edge(C.c_void_p(tree.h), _p(tree.xyz), tree.n, _p(q_xyz), n, _p(pq), _p(pt), C.byref(P),
+                                  int(nthreads), _p(out["valid"]), _p(out["nn_idx"]), _p(out["nn_d2"]), _p(out["cp"]),
+                                  _p(out["a"]), _p(out["b"]), _p(out["s"]))
+    out["count"] = cnt
+    return out
+
+
+def linearize_surf(rec, t, q, P, scale=1.0):
+    gram = np.zeros(64, np.float64)
+    cost = C.c_double(0)
+    cnt = C.c_int(0)
+    t, q = _f64(t), _f64(q)
+    lib().lo_linearize_surf(_p(rec["valid"]), _p(rec["cp"]), _p(rec["n"]), _p(rec["d"]), _p(rec["score"]),
+                            rec["valid"].shape[0], _p(t), _p(q), C.byref(P), C.c_double(scale), _p(gram),
+                            C.byref(cost), C.byref(cnt))
+    return gram.reshape(8, 8), cost.value, cnt.value
+
+
+def linearize_edge(rec, t, q, P, scale=1.0):
+    gram = np.zeros(64, np.float64)
+    cost = C.c_double(0)
+    cnt = C.c_int(0)
+    t, q = _f64(t), _f64(q)
+    lib().lo_linearize_edge(_p(rec["valid"]), _p(rec["cp"]), _p(rec["a"]), _p(rec["b"]), _p(rec["s"]),
+                            rec["valid"].shape[0], _p(t), _p(q), C.byref(P), C.c_double(scale), _p(gram),
+                            C.byref(cost), C.byref(cnt))
+    return gram.reshape(8, 8), cost.value, cnt.value
+
+
+def gn_step(gram, t, q):
+    """Returns (status, t_new, q_new, delta)."""
+    g = _f64(gram).reshape(64)
+    t = _f64(t).copy()
+    q = _f64(q).copy()
+    d = np.zeros(6)
+    st = lib().lo_gn_step(_p(g), _p(t), _p(q), _p(d))
+    return st, t, q, d
+
+
+def eval_edge(t, q, cp, a, b, s):
+    out = np.zeros(8)
+    t, q = _f64(t), _f64(q)
+    cp, a, b = _f32(cp), _f32(a), _f32(b)
+    lib().lo_eval_edge(_p(t), _p(q), _p(cp), _p(a), _p(b), C.c_double(s), _p(out))
+    return out
+
+
+def eval_plane(t, q, cp, n, d, score, P, frontend=False):
+    out = np.zeros(8)
+    t, q = _f64(t), _f64(q)
+    cp, n = _f32(cp), _f32(n)
+    qlb = np.array(list(P.q_lb))
+    tlb = np.array(list(P.t_lb))
+    lib().lo_eval_plane(_p(t), _p(q), _p(cp), _p(n), C.c_float(d), C.c_double(score), _p(qlb), _p(tlb),
+                        int(bool(frontend)), _p(out))
+    return out
+
+
+def eig3(A):
+    A = _f64(A).reshape(9)
+    ev = np.zeros(3)
+    V = np.zeros(9)
+    st = lib().lo_eig3(_p(A), _p(ev), _p(V))
+    return st, ev, V.reshape(3, 3)
+
+
+def lstsq53(A, b):
+    A, b = _f64(A).reshape(15), _f64(b)
+    x = np.zeros(3)
+    lib().lo_lstsq53(_p(A), _p(b), _p(x))
+    return x
+
+
+def qrot(q, v):
+    out = np.zeros(3)
+    q, v = _f64(q), _f64(v)
+    lib().lo_qrot(_p(q), _p(v), _p(out))
+    return out
+
+
+def loss(kind, a, s):
+    rho = np.zeros(3)
+    lib().lo_loss(int(kind), C.c_double(a), C.c_double(s), _p(rho))
+    return rho
