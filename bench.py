@@ -1,0 +1,265 @@
+#!/usr/bin/env python
+"""bench.py — scan-to-map iterations/s on MI355X (BASELINE.json metric, config 2/3).
+
+One STEP = one outer scan-to-map iteration over one 200 k-point scan against the 5 M-point local map:
+re-associate (transform + exact 5-NN + plane fit + gates) -> linearise (residual + Jacobian + Cauchy
+corrector + Gram reduction) -> [all-reduce of counts and Gram when --gpus > 1] -> Gauss-Newton update
+of the pose, all on the device, inputs resident in HBM before the timed region starts.
+
+    python bench.py                      # 1 GPU, defaults finish within minutes
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see DESIGN.md §6 for the roofline / cpu_baseline definitions).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_MAP = 5_000_000
+N_AZ = 3125            # x 64 rings = 200 000 rays
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md §Chip-level parameters)
+BYTES_PER_QUERY = 96   # algorithmic bytes of one outer iteration per query: 16 B query + 5 x 16 B neighbours
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def body_pose_for_lidar(L, P, lidar_t):
+    """Body pose (T, Q) whose LiDAR frame coincides with the generator's LiDAR frame."""
+    qlb = np.array(list(P.q_lb))
+    qb = qlb / np.linalg.norm(qlb)
+    _, T2 = L.api.assoc_transform([0.0, 0.0, 0.0], qb, P)
+    return np.asarray(lidar_t) - T2, qb
+
+
+def ring_major(scan_xyz, ring):
+    """Order the extractor hands features over in: ring by ring (R/src/Preprocessing.cpp:377-382,401)."""
+    order = np.argsort(ring, kind="stable")
+    return scan_xyz[order]
+
+
+def cpu_baseline(w, queries, t0, q0, n_threads):
+    """The oracle (CPU restatement of the reference path) on this box's host cores: kd-tree build once,
+    then full outer iterations.  Used ONLY as the reported baseline."""
+    from oracle import oracle as O
+    import lili_om_amd as L
+    PO = O.params("rot")
+    P = L.make_params("rot")
+    t_build = time.perf_counter()
+    tree = O.KdTree(w["map_xyz"])
+    t_build = time.perf_counter() - t_build
+
+    def run(nth, iters):
+        t, q = t0.copy(), q0.copy()
+        tic = time.perf_counter()
+        for _ in range(iters):
+            Q2, T2 = L.api.assoc_transform(t, q, P)
+            rs = O.associate_surf(tree, None, queries, None, Q2, T2, PO, nthreads=nth)
+            G, _, _ = O.linearize_surf(rs, t, q, PO, 1000.0 / max(rs["count"], 1))
+            st, t, q, _ = O.gn_step(G, t, q)
+        return (time.perf_counter() - tic) / iters, t, q
+
+    it1, _, _ = run(1, 3)
+    itn, t_fin, q_fin = run(n_threads, 10)
+    return dict(value=1.0 / itn, unit="scan-to-map iterations/s", cores=n_threads, kind="port",
+                sample=(f"oracle (g++ -O3, no -march, exact kd-tree): 10 full outer iterations of the same 200k-query / "
+                        f"5M-point workload on {n_threads} threads (association threaded, Gram serial); single-thread = "
+                        f"{1.0 / it1:.3f} it/s; kd-tree build {t_build:.2f} s excluded (once per keyframe)")), t_fin, q_fin
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: every rank matches its own 200k-point shard of an (N x 200k)-point scan; "
+                         "strong: the 200k queries of one scan are block-sharded over the ranks (BASELINE config 3)")
+    ap.add_argument("--n-map", type=int, default=N_MAP)
+    ap.add_argument("--n-az", type=int, default=N_AZ)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import lili_om_amd as L
+    from lili_om_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    # ---------------- workload (synthetic, fixed seeds; identical on every rank) ----------------
+    t_gen = time.perf_counter()
+    half = (460.0, 380.0) if args.n_map >= 4_000_000 else (150.0, 150.0)
+    w = synth.make_workload(n_map=args.n_map, n_az=args.n_az, half_extent=half, verbose=(rank == 0))
+    P = L.make_params("rot")
+    t_body, q_body = body_pose_for_lidar(L, P, w["lidar_t"])
+    rng = np.random.default_rng(synth.SEED_POSE)
+    t0, q0 = synth.perturbed_pose(t_body, q_body, rng, 0.3, 2.0)
+    scan = ring_major(w["scan_xyz"], w["scan_ring"])
+    n_scan = scan.shape[0]
+    if world > 1 and args.scaling == "strong":
+        per = (n_scan + world - 1) // world
+        queries = scan[rank * per:(rank + 1) * per]
+    elif world > 1:
+        # weak: rank r holds the r-th 200k-point shard of an (N x 200k)-point scan (same rays, independent range noise)
+        d = scan / np.linalg.norm(scan, axis=1, keepdims=True)
+        noise = np.random.default_rng(w["seed"] + 100 + rank).normal(0, 0.02, n_scan)
+        queries = (scan + d * noise[:, None]).astype(np.float32) if rank > 0 else scan
+    else:
+        queries = scan
+    if rank == 0:
+        log(f"[bench] workload generated in {time.perf_counter() - t_gen:.1f} s; {queries.shape[0]} queries/rank, world {world}, scaling {args.scaling}")
+
+    # ---------------- device setup (untimed): map index + queries resident in HBM ----------------
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    ctx = L.Context(local_rank, stream=stream)
+    m = L.ScanToMapMatcher(ctx, P)
+    tic = time.perf_counter()
+    m.set_input_cloud(L.KIND_SURF, w["map_xyz"])
+    ctx.sync()
+    t_map = time.perf_counter() - tic
+    m.set_queries(0, L.KIND_SURF, queries)
+    gram = torch.zeros(L.api.GRAM_DOUBLES, dtype=torch.float64, device=dev)
+    m.pose_set(0, t0, q0)
+
+    def step_multi():
+        m.associate_dev(0, L.MASK_SURF)
+        _allreduce_counts(m, dist, dev)
+        m.linearize_dev(0, gram.data_ptr(), L.MASK_SURF)
+        dist.all_reduce(gram)
+        m.gn_update(0, gram.data_ptr())
+
+    def run_steps(k):
+        if world == 1:
+            m.iterate(0, k, L.MASK_SURF)      # one C call enqueues k x (associate, linearise, reduce, GN update)
+        else:
+            for _ in range(k):
+                step_multi()
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run_steps(args.warmup)
+    fence()
+    # every timed run starts from the same initial pose so that N=1,2,4,8 do identical work per step
+    m.pose_set(0, t0, q0)
+    fence()
+    tic = time.perf_counter()
+    run_steps(args.steps)
+    fence()
+    elapsed = time.perf_counter() - tic
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    t_fin, q_fin, gn_status = m.pose_get(0)
+
+    # ---------------- roofline of the dominant kernel (k_associate_surf), HIP events on its stream ----------------
+    roofline = None
+    if rank == 0:
+        reps = max(20, min(args.steps, 200))
+        m.pose_set(0, t0, q0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(5):
+            m.associate_dev(0, L.MASK_SURF)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            m.associate_dev(0, L.MASK_SURF)
+        e1.record()
+        torch.cuda.synchronize()
+        dt = e0.elapsed_time(e1) * 1e-3 / reps
+        alg_bytes = BYTES_PER_QUERY * queries.shape[0]
+        achieved = alg_bytes / dt / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("k_associate_surf", {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = dict(bound="hbm", kernel="k_associate_surf", achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic, us_per_launch=round(dt * 1e6, 2),
+                        algorithmic_bytes_per_launch=alg_bytes)
+    if dist is not None:
+        dist.barrier()
+
+    if rank == 0:
+        units = args.steps * (world if args.scaling == "weak" else 1)
+        value = units / elapsed
+        out = {
+            "metric": "scan-to-map iterations/s (200k-pt scan vs 5M-pt map)",
+            "value": round(value, 3), "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"configs[2]: synthetic 64-ring {n_scan}-pt scan vs {w['map_xyz'].shape[0]}-pt local map "
+                                   f"(variant A, seed {hex(w['seed'])}), ROT back-end matcher (surf), 1 outer GN iteration per step, "
+                                   f"{'queries block-sharded over ranks' if args.scaling == 'strong' else 'one 200k-pt shard per rank'}",
+                       "queries_per_rank": int(queries.shape[0]), "map_points": int(w["map_xyz"].shape[0]),
+                       "parallelism": f"queries sharded x{world}, map replicated, all-reduce(counts, Gram)" if world > 1 else "single GPU",
+                       "map_index_build_s": round(t_map, 4)},
+            "roofline": roofline,
+            "final_pose": {"t": [float(x) for x in t_fin], "q": [float(x) for x in q_fin], "gn_status": int(gn_status)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, t_cpu, q_cpu = cpu_baseline(w, queries, t0, q0, os.cpu_count() or 1)
+            out["cpu_baseline"] = cb
+            out["gpu_over_cpu"] = round(value / cb["value"], 1)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    ctx.close()
+
+
+_counts_tensor = None
+
+
+def _allreduce_counts(m, dist, dev):
+    """All-reduce (sum) the slot's two correspondence counters in place (ROT residual scale = num / GLOBAL N)."""
+    global _counts_tensor
+    import torch
+    if _counts_tensor is None:
+        _counts_tensor = _tensor_from_ptr(m.counts_ptr(0), 2, dev)
+    dist.all_reduce(_counts_tensor)
+
+
+def _tensor_from_ptr(ptr, n_int32, dev):
+    """Zero-copy int32 view of device memory owned by the lili context (via __cuda_array_interface__)."""
+    import torch
+
+    class _Holder:
+        pass
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": (n_int32,), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(h, device=dev)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,170 @@
+/*
+ * lili_hip.h — C ABI of the MI355X (gfx950) hot path of LiLi-OM.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types, no
+ * exceptions.  Every entry point names the reference code it replaces
+ * (L/ = LiLi-OM/, R/ = LiLi-OM-ROT/ of KIT-ISAS/lili-om).  INTEGRATION.md shows the ROS-node /
+ * ceres::CostFunction side binding.
+ *
+ * Conventions
+ *   - quaternions are double[4] in (w, x, y, z) order — the order of the reference's Ceres parameter
+ *     blocks (tmpQuat, L/src/BackendFusion.cpp:853-856); translations double[3].
+ *   - point clouds are described by (pointer, count, stride, memory space): x,y,z are 3 floats at byte
+ *     offset 0 of every point — true for pcl::PointXYZI (32 B) and pcl::PointXYZINormal (48 B,
+ *     L/include/utils/common.h:71-73); `aux_offset` is the byte offset of one extra float per point
+ *     (Livox: curvature = 0.1*reflectivity at 36; ROT: intensity at 16) or -1.
+ *   - every function returns LILI_OK (0) or a negative error code and never throws;
+ *     lili_last_error() gives the message of the last failure on that context.
+ *   - a context owns one HIP stream (or borrows the caller's); it is NOT thread-safe; all work of a
+ *     context is ordered on that stream.  Functions documented "async" only enqueue.
+ *   - results are deterministic: no floating-point atomics anywhere; reductions have a fixed order.
+ */
+#ifndef LILI_HIP_H
+#define LILI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LILI_ABI_VERSION 1
+
+typedef struct lili_ctx lili_ctx;
+
+enum {
+    LILI_OK = 0,
+    LILI_E_ARG = -1,      /* bad argument */
+    LILI_E_HIP = -2,      /* HIP runtime error (message in lili_last_error) */
+    LILI_E_STATE = -3,    /* call order violated (e.g. associate before map_set) */
+    LILI_E_NOMEM = -4,
+    LILI_E_NODEVICE = -5  /* no usable gfx950 device: there is no CPU fallback */
+};
+enum { LILI_KIND_SURF = 0, LILI_KIND_EDGE = 1 };
+enum { LILI_MASK_SURF = 1, LILI_MASK_EDGE = 2 };
+enum { LILI_VARIANT_LIVOX = 0, LILI_VARIANT_ROT = 1, LILI_VARIANT_FRONTEND = 2 };
+enum { LILI_LOSS_NONE = 0, LILI_LOSS_CAUCHY = 1, LILI_LOSS_HUBER = 2 };
+enum { LILI_MEM_HOST = 0, LILI_MEM_DEVICE = 1 };
+
+#define LILI_MAX_SLOTS 8       /* sliding-window keyframes handled per context (slide_window_width = 3) */
+#define LILI_GRAM_DOUBLES 72   /* device-side reduction record: 64 Gram + cost + 7 spare */
+
+typedef struct lili_cloud {
+    const void* data;   /* first point */
+    size_t n;           /* number of points */
+    size_t stride;      /* bytes between points (>= 12) */
+    int aux_offset;     /* byte offset of the per-point auxiliary float, or -1 */
+    int mem;            /* LILI_MEM_HOST or LILI_MEM_DEVICE */
+} lili_cloud;
+
+/* Matcher parameters — the ★ rows of SURVEY.md App. C. */
+typedef struct lili_s2m_params {
+    int variant;             /* LILI_VARIANT_*: which findCorresponding* / factor flavour */
+    int loss;                /* LILI_LOSS_*: CauchyLoss(1.0) L/src/BackendFusion.cpp:845; HuberLoss(0.1) L/src/LidarOdometry.cpp:507 */
+    double loss_a;
+    double lidar_const;      /* L/config/config_fr_iosb.yaml:18 (20), R/config/config_fr_iosb.yaml:30 (7.5) */
+    double kd_max_radius;    /* compared with a SQUARED distance, L/src/BackendFusion.cpp:1615 */
+    double edge_gate;        /* 1.0, L/src/BackendFusion.cpp:1543 (squared distance too) */
+    double surf_dist_thres;  /* L:1651 */
+    double reflect_thres;    /* Livox only, L:1628 */
+    double surf_weight_min;  /* 0.2 L:1665 / 0.3 R/src/BackendFusion.cpp:1504 / 0.4 L/src/LidarOdometry.cpp:400 */
+    double edge_dist_max;    /* ROT only, R/src/BackendFusion.cpp:1443 (0.1); <= 0 disables */
+    double q_lb[4];          /* extrinsic rotation, (w,x,y,z), L/config/config_fr_iosb.yaml:35-38 */
+    double t_lb[3];          /* extrinsic translation */
+    double scale_surf_num;   /* ROT: residual scale = num / N_surf (1000, R/src/BackendFusion.cpp:861); 0 = no count scaling */
+    double scale_edge_num;   /* ROT: 200 / N_edge (R/src/BackendFusion.cpp:843); 0 = none */
+} lili_s2m_params;
+
+/* ---- context -------------------------------------------------------------------------------- */
+
+/* Creates a context on HIP device `device`.  `stream` is a hipStream_t to enqueue on (e.g. the
+ * caller's current stream so that RCCL collectives interleave correctly), or NULL to create one.
+ * Fails with LILI_E_NODEVICE when no gfx950 device is usable — there is no CPU path. */
+int lili_ctx_create(lili_ctx** out, int device, void* stream);
+void lili_ctx_destroy(lili_ctx* ctx);
+const char* lili_last_error(const lili_ctx* ctx);
+int lili_abi_version(void);
+/* Blocks until everything enqueued on the context's stream has finished. */
+int lili_sync(lili_ctx* ctx);
+/* When enabled, associate also stores the 5 neighbour indices / squared distances per query so that
+ * lili_s2m_get_neighbors can return them (parity tests).  Off by default (extra HBM writes). */
+int lili_set_debug(lili_ctx* ctx, int keep_neighbors);
+
+/* ---- local map index ------------------------------------------------------------------------ */
+
+/* Replaces kd_tree_{surf,edge}_local_map->setInputCloud(...) (L/src/BackendFusion.cpp:839-840,
+ * L/src/LidarOdometry.cpp:490).  Copies the cloud (if on the host), bins it into a uniform grid whose
+ * cell edge covers sqrt(max_sq_radius) so that the 27-cell neighbourhood of a query contains every
+ * point the reference's gate `d2[4] < max_sq_radius` can accept — the search is EXACT for all queries
+ * the reference keeps.  Blocking (reads the bounding box back once). */
+int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq_radius);
+/* Number of points / grid cells of the current index (diagnostics). */
+int lili_map_info(lili_ctx* ctx, int kind, int64_t* n_points, int64_t* n_cells, double* cell_edge);
+
+/* ---- scan-to-map matcher -------------------------------------------------------------------- */
+
+/* Uploads the feature points of keyframe `slot` (surf_lasts_ds[idx] / edge_lasts_ds[idx],
+ * L/src/BackendFusion.cpp:1536,1606).  Async when the cloud is already on the device. */
+int lili_s2m_set_queries(lili_ctx* ctx, int slot, int kind, const lili_cloud* cloud);
+
+/* Replaces findCorresponding{Surf,Corner}Features(idx, q, t) (L/src/BackendFusion.cpp:1531-1681,
+ * R/src/BackendFusion.cpp:1394-1520, L/src/LidarOdometry.cpp:352-413): transform with (q_assoc,
+ * t_assoc), exact 5-NN, line / plane fit, gates, weights.  Correspondence records stay on the device.
+ * n_res (optional) receives the number of correspondences — passing it makes the call blocking. */
+int lili_s2m_associate(lili_ctx* ctx, int slot, int kind, const double t_assoc[3], const double q_assoc[4],
+                       const lili_s2m_params* params, int* n_res);
+
+/* Replaces N x (AutoDiffCostFunction::Evaluate + loss corrector) and the J^T J / J^T r accumulation
+ * (L/include/factors/LidarKeyframeFactor.h:12-139, L/src/MarginalizationFactor.cpp:3-29,44-70) for the
+ * records of `slot` selected by `kind_mask`, at the body pose (t, q).
+ *   gram[64] : row-major 8x8, sum over residuals of [J r]^T [J r] after robustification, with J the
+ *              1x7 GLOBAL Jacobian ordered (t0,t1,t2,qw,qx,qy,qz) and r the residual;
+ *   cost     : sum of 1/2 rho(r^2);  counts[0] = surf residuals, counts[1] = edge residuals.
+ * Blocking. */
+int lili_s2m_linearize(lili_ctx* ctx, int slot, int kind_mask, const double t[3], const double q[4],
+                       const lili_s2m_params* params, double gram[64], double* cost, int counts[2]);
+
+/* Copy-out of the ordered correspondence lists (the vec_surf_cur_pts / vec_surf_normal /
+ * vec_surf_scores and vec_edge_cur_pts / vec_edge_match_j / vec_edge_match_l of the reference).
+ * Arrays may be NULL; capacity in records; *n_out = number of records available.  Blocking. */
+int lili_s2m_get_surf_records(lili_ctx* ctx, int slot, size_t capacity, int32_t* query_index, float* cur_pt /*3*/,
+                              float* normal /*3, weight-scaled*/, float* neg_oa_dot_norm, double* score, size_t* n_out);
+int lili_s2m_get_edge_records(lili_ctx* ctx, int slot, size_t capacity, int32_t* query_index, float* cur_pt /*3*/,
+                              float* pt_a /*3*/, float* pt_b /*3*/, float* s, size_t* n_out);
+/* Per-query neighbour lists of the last associate (requires lili_set_debug(ctx, 1)): idx/d2 are n_q x 5. */
+int lili_s2m_get_neighbors(lili_ctx* ctx, int slot, int kind, size_t n_q, int32_t* idx, float* d2);
+
+/* ---- device-resident outer iterations (no host round trip) ----------------------------------- */
+
+/* Body pose of `slot` kept in device memory. */
+int lili_s2m_pose_set(lili_ctx* ctx, int slot, const double t[3], const double q[4]);
+int lili_s2m_pose_get(lili_ctx* ctx, int slot, double t[3], double q[4], int* gn_status /*0 ok, 1 singular*/);
+
+/* One outer iteration, first half (async): re-associate at the device pose (association transform
+ * Q2 = Q*q_lb^-1, T2 = T - Q2*t_lb as in L/src/BackendFusion.cpp:929-930), linearise, and reduce this
+ * rank's partial into d_gram (DEVICE pointer to LILI_GRAM_DOUBLES doubles owned by the caller:
+ * [0..63] Gram, [64] cost, [65] n_surf, [66] n_edge).  Between the two halves a multi-GPU caller
+ * all-reduces d_gram (sum) over ranks on the same stream. */
+int lili_s2m_accumulate(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, double* d_gram);
+/* The same in two steps, for callers that shard the queries of one scan over several GPUs AND use the
+ * ROT residual scaling num / N (R/src/BackendFusion.cpp:843,861), where N must be the GLOBAL count:
+ *   lili_s2m_associate_dev  -> counts of this rank in device memory (lili_s2m_counts_ptr: int[2])
+ *   [caller: all-reduce(sum) the two ints in place]
+ *   lili_s2m_linearize_dev  -> d_gram as above (and resets the counts for the next iteration).     */
+int lili_s2m_associate_dev(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params);
+int lili_s2m_counts_ptr(lili_ctx* ctx, int slot, int** d_counts);
+int lili_s2m_linearize_dev(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, double* d_gram);
+/* Second half (async): one Gauss-Newton step on the 6-dof local parameterisation
+ * (ceres::QuaternionParameterization plus-Jacobian and Plus()), pose updated in device memory. */
+int lili_s2m_gn_update(lili_ctx* ctx, int slot, const double* d_gram);
+/* Convenience: n_iters x (accumulate + gn_update) on an internal buffer.  Async. */
+int lili_s2m_iterate(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, int n_iters);
+
+/* Host-side helper used by the ceres adapter and the host LM: Gauss-Newton step from a host Gram. */
+int lili_gn_step_host(const double gram[64], double t[3], double q[4], double delta[6]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LILI_HIP_H */

@@ -1,0 +1,322 @@
+"""ctypes binding of include/lili_hip.h (liblili_hip.so) plus a thin host-side mirror of the reference's
+matcher interface.  There is NO fallback: if the HIP library is missing or no gfx950 device is present
+every entry point raises.  Nothing here imports oracle/.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblili_hip.so")
+
+OK = 0
+KIND_SURF, KIND_EDGE = 0, 1
+MASK_SURF, MASK_EDGE = 1, 2
+VARIANT_LIVOX, VARIANT_ROT, VARIANT_FRONTEND = 0, 1, 2
+LOSS_NONE, LOSS_CAUCHY, LOSS_HUBER = 0, 1, 2
+MEM_HOST, MEM_DEVICE = 0, 1
+MAX_SLOTS = 8
+GRAM_DOUBLES = 72
+
+
+class LiliError(RuntimeError):
+    pass
+
+
+class Cloud(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("n", C.c_size_t), ("stride", C.c_size_t), ("aux_offset", C.c_int), ("mem", C.c_int)]
+
+
+class S2MParams(C.Structure):
+    _fields_ = [("variant", C.c_int), ("loss", C.c_int), ("loss_a", C.c_double), ("lidar_const", C.c_double),
+                ("kd_max_radius", C.c_double), ("edge_gate", C.c_double), ("surf_dist_thres", C.c_double),
+                ("reflect_thres", C.c_double), ("surf_weight_min", C.c_double), ("edge_dist_max", C.c_double),
+                ("q_lb", C.c_double * 4), ("t_lb", C.c_double * 3), ("scale_surf_num", C.c_double),
+                ("scale_edge_num", C.c_double)]
+
+
+def make_params(variant="rot", **kw):
+    """Matcher parameters of the reference configs:
+    L/config/config_fr_iosb.yaml ('livox'), R/config/config_fr_iosb.yaml ('rot'),
+    L/src/LidarOdometry.cpp:365,389,400,507 ('frontend')."""
+    p = S2MParams()
+    if variant == "livox":
+        p.variant, p.loss, p.loss_a = VARIANT_LIVOX, LOSS_CAUCHY, 1.0
+        p.lidar_const, p.kd_max_radius, p.edge_gate = 20.0, 1.0, 1.0
+        p.surf_dist_thres, p.reflect_thres, p.surf_weight_min, p.edge_dist_max = 0.12, 15.0, 0.2, 0.0
+        p.q_lb[:] = [0.0, 0.0, 0.0, 1.0]
+        p.t_lb[:] = [-0.0265, 0.0202, 0.05309]
+        p.scale_surf_num = p.scale_edge_num = 0.0
+    elif variant == "rot":
+        p.variant, p.loss, p.loss_a = VARIANT_ROT, LOSS_CAUCHY, 1.0
+        p.lidar_const, p.kd_max_radius, p.edge_gate = 7.5, 1.0, 1.0
+        p.surf_dist_thres, p.reflect_thres, p.surf_weight_min, p.edge_dist_max = 0.12, 0.0, 0.3, 0.1
+        p.q_lb[:] = [0.7071, 0.0, 0.0, 0.7071]
+        p.t_lb[:] = [-0.18, 0.0, -0.095]
+        p.scale_surf_num, p.scale_edge_num = 1000.0, 200.0
+    elif variant == "frontend":
+        p.variant, p.loss, p.loss_a = VARIANT_FRONTEND, LOSS_HUBER, 0.1
+        p.lidar_const, p.kd_max_radius, p.edge_gate = 1.0, 1.0, 1.0
+        p.surf_dist_thres, p.reflect_thres, p.surf_weight_min, p.edge_dist_max = 0.06, 0.0, 0.4, 0.0
+        p.q_lb[:] = [1.0, 0.0, 0.0, 0.0]
+        p.t_lb[:] = [0.0, 0.0, 0.0]
+        p.scale_surf_num = p.scale_edge_num = 0.0
+    else:
+        raise ValueError(variant)
+    for k, v in kw.items():
+        if k in ("q_lb", "t_lb"):
+            getattr(p, k)[:] = list(v)
+        else:
+            setattr(p, k, v)
+    return p
+
+
+_lib = None
+
+_SIGS = {
+    "lili_abi_version": (C.c_int, []),
+    "lili_ctx_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]),
+    "lili_ctx_destroy": (None, [C.c_void_p]),
+    "lili_last_error": (C.c_char_p, [C.c_void_p]),
+    "lili_sync": (C.c_int, [C.c_void_p]),
+    "lili_set_debug": (C.c_int, [C.c_void_p, C.c_int]),
+    "lili_map_set": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Cloud), C.c_double]),
+    "lili_map_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "lili_s2m_set_queries": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Cloud)]),
+    "lili_s2m_associate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(S2MParams), C.POINTER(C.c_int)]),
+    "lili_s2m_linearize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(S2MParams), C.c_void_p, C.POINTER(C.c_double), C.c_void_p]),
+    "lili_s2m_get_surf_records": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]),
+    "lili_s2m_get_edge_records": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]),
+    "lili_s2m_get_neighbors": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "lili_s2m_pose_set": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "lili_s2m_pose_get": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "lili_s2m_accumulate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams), C.c_void_p]),
+    "lili_s2m_associate_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams)]),
+    "lili_s2m_counts_ptr": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "lili_s2m_linearize_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams), C.c_void_p]),
+    "lili_s2m_gn_update": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "lili_s2m_iterate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams), C.c_int]),
+    "lili_gn_step_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+
+def exported_symbols():
+    """Names include/lili_hip.h declares (used by the CPU-side symbol test)."""
+    return sorted(_SIGS)
+
+
+def load_library():
+    """Loads liblili_hip.so.  Raises LiliError if it has not been built — there is no other backend."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LiliError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950). The hot path has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)      # AttributeError here = ABI mismatch between header and library
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def _f64(a, n):
+    a = np.ascontiguousarray(a, dtype=np.float64).reshape(-1)
+    if a.size != n:
+        raise ValueError(f"expected {n} doubles")
+    return a
+
+
+def cloud_from_numpy(arr, aux_col=None):
+    """Describes a contiguous float32 (n, k>=3) host array as a lili_cloud (stride = 4k bytes)."""
+    arr = np.ascontiguousarray(arr, dtype=np.float32)
+    if arr.ndim != 2 or arr.shape[1] < 3:
+        raise ValueError("cloud array must be (n, >=3) float32")
+    c = Cloud(arr.ctypes.data if arr.size else None, arr.shape[0], arr.shape[1] * 4,
+              -1 if aux_col is None else int(aux_col) * 4, MEM_HOST)
+    c._keep = arr
+    return c
+
+
+def cloud_from_device(ptr, n, stride, aux_offset=-1):
+    return Cloud(ptr, n, stride, aux_offset, MEM_DEVICE)
+
+
+class Context:
+    """One HIP stream + device buffers (lili_ctx)."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.lili_ctx_create(C.byref(h), int(device), C.c_void_p(stream) if stream else None)
+        if rc != OK:
+            raise LiliError(f"lili_ctx_create failed ({rc}): no usable gfx950 device — the hot path has no CPU fallback")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lili_ctx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise LiliError(f"lili error {rc}: {self.lib.lili_last_error(self.h).decode()}")
+
+    def sync(self):
+        self._chk(self.lib.lili_sync(self.h))
+
+    def set_debug(self, keep_neighbors=True):
+        self._chk(self.lib.lili_set_debug(self.h, int(bool(keep_neighbors))))
+
+
+class ScanToMapMatcher:
+    """Host-side mirror of the reference's matcher calls (names follow BackendFusion.cpp):
+
+        setInputCloud            -> set_input_cloud            (L/src/BackendFusion.cpp:839-840)
+        findCorrespondingSurfFeatures   -> find_corresponding_surf_features     (L:1601)
+        findCorrespondingCornerFeatures -> find_corresponding_corner_features   (L:1531)
+        N x CostFunction::Evaluate + JtJ -> linearize                            (LidarKeyframeFactor.h, MarginalizationFactor.cpp:3-71)
+    """
+
+    def __init__(self, ctx, params):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.params = params
+
+    # -- map ------------------------------------------------------------------------------------
+    def set_input_cloud(self, kind, cloud, max_sq_radius=None):
+        if not isinstance(cloud, Cloud):
+            cloud = cloud_from_numpy(cloud, aux_col=3 if (np.ndim(cloud) == 2 and np.shape(cloud)[1] > 3) else None)
+        if max_sq_radius is None:
+            max_sq_radius = self.params.kd_max_radius if kind == KIND_SURF else self.params.edge_gate
+        self.ctx._chk(self.lib.lili_map_set(self.ctx.h, kind, C.byref(cloud), float(max_sq_radius)))
+
+    def map_info(self, kind):
+        n, nc, ce = C.c_int64(), C.c_int64(), C.c_double()
+        self.ctx._chk(self.lib.lili_map_info(self.ctx.h, kind, C.byref(n), C.byref(nc), C.byref(ce)))
+        return n.value, nc.value, ce.value
+
+    # -- queries --------------------------------------------------------------------------------
+    def set_queries(self, slot, kind, cloud):
+        if not isinstance(cloud, Cloud):
+            cloud = cloud_from_numpy(cloud, aux_col=3 if (np.ndim(cloud) == 2 and np.shape(cloud)[1] > 3) else None)
+        self.ctx._chk(self.lib.lili_s2m_set_queries(self.ctx.h, slot, kind, C.byref(cloud)))
+
+    def _associate(self, slot, kind, q, t, want_count):
+        t, q = _f64(t, 3), _f64(q, 4)
+        n = C.c_int(0)
+        self.ctx._chk(self.lib.lili_s2m_associate(self.ctx.h, slot, kind, _ptr(t), _ptr(q), C.byref(self.params),
+                                                  C.byref(n) if want_count else None))
+        return n.value if want_count else None
+
+    def find_corresponding_surf_features(self, slot, q, t, want_count=True):
+        return self._associate(slot, KIND_SURF, q, t, want_count)
+
+    def find_corresponding_corner_features(self, slot, q, t, want_count=True):
+        return self._associate(slot, KIND_EDGE, q, t, want_count)
+
+    def linearize(self, slot, t, q, kind_mask=MASK_SURF | MASK_EDGE):
+        t, q = _f64(t, 3), _f64(q, 4)
+        gram = np.zeros(64)
+        cost = C.c_double(0)
+        counts = np.zeros(2, np.int32)
+        self.ctx._chk(self.lib.lili_s2m_linearize(self.ctx.h, slot, kind_mask, _ptr(t), _ptr(q), C.byref(self.params),
+                                                  _ptr(gram), C.byref(cost), _ptr(counts)))
+        return gram.reshape(8, 8), cost.value, counts
+
+    # -- copy-outs ------------------------------------------------------------------------------
+    def surf_records(self, slot, capacity):
+        qi = np.zeros(capacity, np.int32)
+        cp = np.zeros((capacity, 3), np.float32)
+        nn = np.zeros((capacity, 3), np.float32)
+        d = np.zeros(capacity, np.float32)
+        sc = np.zeros(capacity, np.float64)
+        n = C.c_size_t(0)
+        self.ctx._chk(self.lib.lili_s2m_get_surf_records(self.ctx.h, slot, capacity, _ptr(qi), _ptr(cp), _ptr(nn), _ptr(d), _ptr(sc), C.byref(n)))
+        k = min(n.value, capacity)
+        return dict(count=n.value, query_index=qi[:k], cp=cp[:k], n=nn[:k], d=d[:k], score=sc[:k])
+
+    def edge_records(self, slot, capacity):
+        qi = np.zeros(capacity, np.int32)
+        cp = np.zeros((capacity, 3), np.float32)
+        a = np.zeros((capacity, 3), np.float32)
+        b = np.zeros((capacity, 3), np.float32)
+        s = np.zeros(capacity, np.float32)
+        n = C.c_size_t(0)
+        self.ctx._chk(self.lib.lili_s2m_get_edge_records(self.ctx.h, slot, capacity, _ptr(qi), _ptr(cp), _ptr(a), _ptr(b), _ptr(s), C.byref(n)))
+        k = min(n.value, capacity)
+        return dict(count=n.value, query_index=qi[:k], cp=cp[:k], a=a[:k], b=b[:k], s=s[:k])
+
+    def neighbors(self, slot, kind, n_q):
+        idx = np.zeros((n_q, 5), np.int32)
+        d2 = np.zeros((n_q, 5), np.float32)
+        self.ctx._chk(self.lib.lili_s2m_get_neighbors(self.ctx.h, slot, kind, n_q, _ptr(idx), _ptr(d2)))
+        return idx, d2
+
+    # -- device-resident iterations -------------------------------------------------------------
+    def pose_set(self, slot, t, q):
+        t, q = _f64(t, 3), _f64(q, 4)
+        self.ctx._chk(self.lib.lili_s2m_pose_set(self.ctx.h, slot, _ptr(t), _ptr(q)))
+
+    def pose_get(self, slot):
+        t, q = np.zeros(3), np.zeros(4)
+        st = C.c_int(0)
+        self.ctx._chk(self.lib.lili_s2m_pose_get(self.ctx.h, slot, _ptr(t), _ptr(q), C.byref(st)))
+        return t, q, st.value
+
+    def accumulate(self, slot, d_gram_ptr, kind_mask=MASK_SURF):
+        self.ctx._chk(self.lib.lili_s2m_accumulate(self.ctx.h, slot, kind_mask, C.byref(self.params), C.c_void_p(d_gram_ptr)))
+
+    def associate_dev(self, slot, kind_mask=MASK_SURF):
+        self.ctx._chk(self.lib.lili_s2m_associate_dev(self.ctx.h, slot, kind_mask, C.byref(self.params)))
+
+    def counts_ptr(self, slot):
+        p = C.c_void_p()
+        self.ctx._chk(self.lib.lili_s2m_counts_ptr(self.ctx.h, slot, C.byref(p)))
+        return p.value
+
+    def linearize_dev(self, slot, d_gram_ptr, kind_mask=MASK_SURF):
+        self.ctx._chk(self.lib.lili_s2m_linearize_dev(self.ctx.h, slot, kind_mask, C.byref(self.params), C.c_void_p(d_gram_ptr)))
+
+    def gn_update(self, slot, d_gram_ptr):
+        self.ctx._chk(self.lib.lili_s2m_gn_update(self.ctx.h, slot, C.c_void_p(d_gram_ptr)))
+
+    def iterate(self, slot, n_iters, kind_mask=MASK_SURF):
+        self.ctx._chk(self.lib.lili_s2m_iterate(self.ctx.h, slot, kind_mask, C.byref(self.params), int(n_iters)))
+
+
+def gn_step_host(gram, t, q):
+    lib = load_library()
+    g = _f64(gram, 64)
+    t = _f64(t, 3).copy()
+    q = _f64(q, 4).copy()
+    d = np.zeros(6)
+    st = lib.lili_gn_step_host(_ptr(g), _ptr(t), _ptr(q), _ptr(d))
+    return st, t, q, d
+
+
+def assoc_transform(t, q, params):
+    """(Q2, T2) = (Q * q_lb^-1, T - Q2 * t_lb): L/src/BackendFusion.cpp:929-930 (host-side pose algebra)."""
+    q = np.asarray(q, np.float64)
+    qlb = np.array(list(params.q_lb))
+    tlb = np.array(list(params.t_lb))
+    n2 = float((qlb * qlb).sum())
+    qi = np.array([qlb[0], -qlb[1], -qlb[2], -qlb[3]]) / n2
+    a, b = q, qi
+    Q2 = np.array([a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3],
+                   a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                   a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3],
+                   a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1]])
+    u = Q2[1:4]
+    uv = 2 * np.cross(u, tlb)
+    rot = tlb + Q2[0] * uv + np.cross(u, uv)
+    return Q2, np.asarray(t, np.float64) - rot

@@ -1,0 +1,632 @@
+// C-ABI of liblili_hip.so (include/lili_hip.h): context, buffers, launches.  Host code only; the
+// kernels live in lili_s2m.hip / lili_extract.hip.  There is no CPU fallback anywhere in this file:
+// without a gfx950 device lili_ctx_create fails with LILI_E_NODEVICE.
+#include "../../include/lili_hip.h"
+#include "lili_kernels.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace lili {
+// kernels (lili_s2m.hip)
+__global__ void k_cloud_to_f4(const unsigned char*, int, int, int, float4*);
+__global__ void k_bbox(const float4*, int, unsigned*);
+__global__ void k_cell_count(const float4*, int, GridView, int*, int*);
+__global__ void k_scan_block_sums(const int*, int64_t, int*);
+__global__ void k_scan_sums(int*, int);
+__global__ void k_scan_apply(const int*, int64_t, const int*, int*);
+__global__ void k_scatter(const float4*, int, const int*, const int*, int*, float4*, float*);
+__global__ void k_associate_surf(const float4*, const int*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, SlotState*);
+__global__ void k_associate_edge(const float4*, const int*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, SlotState*);
+__global__ void k_linearize_surf(const float4*, int, const float4*, const double*, const unsigned char*, PoseArg, MatchParams, const SlotState*, double*);
+__global__ void k_linearize_edge(const float4*, int, const float4*, const float4*, const unsigned char*, PoseArg, MatchParams, const SlotState*, double*);
+__global__ void k_reduce_partials(const double*, int, const double*, int, double*, SlotState*, int);
+__global__ void k_gn_update(const double*, SlotState*);
+}  // namespace lili
+
+using namespace lili;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct MapIndex {
+    bool valid = false;
+    int64_t n = 0, n_cells = 0;
+    double cell = 0;
+    GridView view{};
+    DevBuf pts, sorted, aux_sorted, cell_start, cell_tmp, pt_cell, block_sums;
+    bool has_aux = false;
+};
+
+struct KindSlot {
+    int64_t n_q = 0;
+    bool has_queries = false, has_records = false;
+    DevBuf q, rec0, rec1, valid, dbg_idx, dbg_d2, partials;
+    int n_blocks = 0;
+};
+
+struct Slot {
+    KindSlot k[2];
+    bool counts_clean = true;   // device n_res[] known to be zero
+};
+
+constexpr size_t kLdsLinearize = (size_t)(kBlock * 9 + 4 * 40) * sizeof(double);
+
+}  // namespace
+
+struct lili_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool keep_nn = false;
+    std::string err;
+    MapIndex map[2];
+    Slot slots[LILI_MAX_SLOTS];
+    DevBuf states;       // SlotState[LILI_MAX_SLOTS]
+    DevBuf staging;      // raw host clouds
+    DevBuf gram;         // LILI_GRAM_DOUBLES per slot
+    DevBuf misc;         // bbox words etc.
+    int max_cells = 1 << 26;
+
+    int fail(int code, const std::string& m) { err = m; return code; }
+    SlotState* state(int slot) { return states.as<SlotState>() + slot; }
+    double* gram_of(int slot) { return gram.as<double>() + (size_t)slot * LILI_GRAM_DOUBLES; }
+};
+
+#define HIPCHK(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t _e = (expr);                                                                              \
+        if (_e != hipSuccess) return ctx->fail(LILI_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+#define ARGCHK(cond, msg) do { if (!(cond)) return ctx->fail(LILI_E_ARG, msg); } while (0)
+
+static inline int nblocks(int64_t n, int per) { return (int)((n + per - 1) / per); }
+
+static MatchParams to_device_params(const lili_s2m_params* p) {
+    MatchParams m{};
+    m.variant = p->variant; m.loss = p->loss; m.loss_a = p->loss_a; m.lidar_const = p->lidar_const;
+    m.kd_max_radius = p->kd_max_radius; m.edge_gate = p->edge_gate; m.surf_dist_thres = p->surf_dist_thres;
+    m.reflect_thres = p->reflect_thres; m.surf_weight_min = p->surf_weight_min; m.edge_dist_max = p->edge_dist_max;
+    for (int i = 0; i < 4; i++) m.q_lb[i] = p->q_lb[i];
+    for (int i = 0; i < 3; i++) m.t_lb[i] = p->t_lb[i];
+    m.scale_surf_num = p->scale_surf_num; m.scale_edge_num = p->scale_edge_num;
+    return m;
+}
+
+// copies / converts a described cloud into a device float4 array (x, y, z, aux)
+static int ingest_cloud(lili_ctx* ctx, const lili_cloud* c, DevBuf& out_f4) {
+    ARGCHK(c && (c->n == 0 || c->data), "cloud: null data");
+    ARGCHK(c->stride >= 12 && c->stride % 4 == 0, "cloud: stride must be a multiple of 4 and >= 12");
+    ARGCHK(c->aux_offset < 0 || (size_t)c->aux_offset + 4 <= c->stride, "cloud: aux_offset outside the point");
+    ARGCHK(c->n < (size_t)1 << 31, "cloud: too many points");
+    if (c->n == 0) return LILI_OK;
+    HIPCHK(out_f4.ensure(c->n * sizeof(float4)));
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(c->data);
+    if (c->mem == LILI_MEM_HOST) {
+        HIPCHK(ctx->staging.ensure(c->n * c->stride));
+        HIPCHK(hipMemcpyAsync(ctx->staging.p, c->data, c->n * c->stride, hipMemcpyHostToDevice, ctx->stream));
+        src = ctx->staging.as<unsigned char>();
+    } else ARGCHK(c->mem == LILI_MEM_DEVICE, "cloud: bad mem");
+    hipLaunchKernelGGL(k_cloud_to_f4, dim3(nblocks((int64_t)c->n, kBlock)), dim3(kBlock), 0, ctx->stream, src, (int)c->n, (int)c->stride,
+                       c->aux_offset, out_f4.as<float4>());
+    HIPCHK(hipGetLastError());
+    return LILI_OK;
+}
+
+extern "C" {
+
+int lili_abi_version(void) { return LILI_ABI_VERSION; }
+
+int lili_ctx_create(lili_ctx** out, int device, void* stream) {
+    if (!out) return LILI_E_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return LILI_E_NODEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return LILI_E_NODEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return LILI_E_NODEVICE;   // kernels are built for gfx950 only
+    if (hipSetDevice(device) != hipSuccess) return LILI_E_NODEVICE;
+    lili_ctx* ctx = new (std::nothrow) lili_ctx();
+    if (!ctx) return LILI_E_NOMEM;
+    ctx->device = device;
+    if (stream) ctx->stream = reinterpret_cast<hipStream_t>(stream);
+    else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LILI_E_HIP; }
+        ctx->own_stream = true;
+    }
+    bool ok = ctx->states.ensure(sizeof(SlotState) * LILI_MAX_SLOTS) == hipSuccess &&
+              ctx->gram.ensure(sizeof(double) * LILI_GRAM_DOUBLES * LILI_MAX_SLOTS) == hipSuccess &&
+              ctx->misc.ensure(256) == hipSuccess &&
+              hipMemsetAsync(ctx->states.p, 0, sizeof(SlotState) * LILI_MAX_SLOTS, ctx->stream) == hipSuccess &&
+              hipMemsetAsync(ctx->gram.p, 0, sizeof(double) * LILI_GRAM_DOUBLES * LILI_MAX_SLOTS, ctx->stream) == hipSuccess;
+    if (!ok) { lili_ctx_destroy(ctx); return LILI_E_HIP; }
+    *out = ctx;
+    return LILI_OK;
+}
+
+void lili_ctx_destroy(lili_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& m : ctx->map) { m.pts.release(); m.sorted.release(); m.aux_sorted.release(); m.cell_start.release(); m.cell_tmp.release(); m.pt_cell.release(); m.block_sums.release(); }
+    for (auto& s : ctx->slots) for (auto& k : s.k) { k.q.release(); k.rec0.release(); k.rec1.release(); k.valid.release(); k.dbg_idx.release(); k.dbg_d2.release(); k.partials.release(); }
+    ctx->states.release(); ctx->staging.release(); ctx->gram.release(); ctx->misc.release();
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* lili_last_error(const lili_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int lili_sync(lili_ctx* ctx) {
+    if (!ctx) return LILI_E_ARG;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return LILI_OK;
+}
+
+int lili_set_debug(lili_ctx* ctx, int keep_neighbors) {
+    if (!ctx) return LILI_E_ARG;
+    ctx->keep_nn = keep_neighbors != 0;
+    return LILI_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// map index
+// --------------------------------------------------------------------------------------------
+int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq_radius) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(kind == LILI_KIND_SURF || kind == LILI_KIND_EDGE, "map_set: bad kind");
+    ARGCHK(cloud, "map_set: null cloud");
+    ARGCHK(max_sq_radius > 0 && std::isfinite(max_sq_radius), "map_set: max_sq_radius must be positive");
+    HIPCHK(hipSetDevice(ctx->device));
+    MapIndex& m = ctx->map[kind];
+    m.valid = false;
+    int rc = ingest_cloud(ctx, cloud, m.pts);
+    if (rc != LILI_OK) return rc;
+    m.n = (int64_t)cloud->n;
+    m.has_aux = cloud->aux_offset >= 0;
+    m.view = GridView{};
+    m.n_cells = 0; m.cell = 0;
+    if (m.n == 0) { m.valid = true; return LILI_OK; }
+    const int n = (int)m.n;
+    // bounding box
+    unsigned init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+    unsigned* d_mm = ctx->misc.as<unsigned>();
+    HIPCHK(hipMemcpyAsync(d_mm, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_bbox, dim3(std::min(nblocks(n, kBlock), 2048)), dim3(kBlock), 0, ctx->stream, m.pts.as<float4>(), n, d_mm);
+    HIPCHK(hipGetLastError());
+    unsigned mm[6];
+    HIPCHK(hipMemcpyAsync(mm, d_mm, sizeof(mm), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    auto dec = [](unsigned u) { unsigned b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u; float f; std::memcpy(&f, &b, 4); return f; };
+    double mn[3], mx[3];
+    bool any = true;
+    for (int k = 0; k < 3; k++) { mn[k] = dec(mm[k]); mx[k] = dec(mm[3 + k]); if (!(mn[k] <= mx[k])) any = false; }
+    if (!any) { mn[0] = mn[1] = mn[2] = 0; mx[0] = mx[1] = mx[2] = 0; }   // no finite point: one empty-ish cell
+    // cell edge: >= 1.01 * gate radius so that the 27-cell neighbourhood covers the gate ball
+    double cell = std::sqrt(max_sq_radius) * 1.01;
+    if (!(cell > 1e-6)) cell = 1e-6;
+    int64_t nx, ny, nz;
+    for (;;) {
+        nx = (int64_t)std::floor((mx[0] - mn[0]) / cell) + 1;
+        ny = (int64_t)std::floor((mx[1] - mn[1]) / cell) + 1;
+        nz = (int64_t)std::floor((mx[2] - mn[2]) / cell) + 1;
+        double total = (double)nx * (double)ny * (double)nz;
+        if (total <= (double)ctx->max_cells) break;
+        cell *= std::cbrt(total / (double)ctx->max_cells) * 1.02;   // coarser cells stay exact, only slower
+    }
+    m.cell = cell;
+    m.n_cells = nx * ny * nz;
+    GridView g{};
+    g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2]; g.inv_cell = 1.0 / cell;
+    g.nx = (int)nx; g.ny = (int)ny; g.nz = (int)nz; g.n_points = n;
+    const int64_t nc = m.n_cells;
+    HIPCHK(m.cell_tmp.ensure((size_t)nc * sizeof(int)));
+    HIPCHK(m.cell_start.ensure((size_t)(nc + 1) * sizeof(int)));
+    HIPCHK(m.pt_cell.ensure((size_t)n * sizeof(int)));
+    HIPCHK(m.sorted.ensure((size_t)n * sizeof(float4)));
+    if (m.has_aux) HIPCHK(m.aux_sorted.ensure((size_t)n * sizeof(float)));
+    const int nb_scan = nblocks(nc, 2048);
+    HIPCHK(m.block_sums.ensure((size_t)nb_scan * sizeof(int)));
+    HIPCHK(hipMemsetAsync(m.cell_tmp.p, 0, (size_t)nc * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_cell_count, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, m.pts.as<float4>(), n, g, m.cell_tmp.as<int>(), m.pt_cell.as<int>());
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb_scan), dim3(kBlock), 0, ctx->stream, m.cell_tmp.as<int>(), nc, m.block_sums.as<int>());
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, ctx->stream, m.block_sums.as<int>(), nb_scan);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb_scan), dim3(kBlock), 0, ctx->stream, m.cell_tmp.as<int>(), nc, m.block_sums.as<int>(), m.cell_start.as<int>());
+    HIPCHK(hipMemsetAsync(m.cell_tmp.p, 0, (size_t)nc * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_scatter, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, m.pts.as<float4>(), n, m.pt_cell.as<int>(), m.cell_start.as<int>(),
+                       m.cell_tmp.as<int>(), m.sorted.as<float4>(), m.has_aux ? m.aux_sorted.as<float>() : nullptr);
+    HIPCHK(hipGetLastError());
+    g.pts = m.sorted.as<float4>();
+    g.aux = m.has_aux ? m.aux_sorted.as<float>() : nullptr;
+    g.cell_start = m.cell_start.as<int>();
+    m.view = g;
+    m.valid = true;
+    return LILI_OK;
+}
+
+int lili_map_info(lili_ctx* ctx, int kind, int64_t* n_points, int64_t* n_cells, double* cell_edge) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(kind == 0 || kind == 1, "map_info: bad kind");
+    if (!ctx->map[kind].valid) return ctx->fail(LILI_E_STATE, "map_info: no map set");
+    if (n_points) *n_points = ctx->map[kind].n;
+    if (n_cells) *n_cells = ctx->map[kind].n_cells;
+    if (cell_edge) *cell_edge = ctx->map[kind].cell;
+    return LILI_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// queries / associate / linearize
+// --------------------------------------------------------------------------------------------
+int lili_s2m_set_queries(lili_ctx* ctx, int slot, int kind, const lili_cloud* cloud) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS, "set_queries: bad slot");
+    ARGCHK(kind == 0 || kind == 1, "set_queries: bad kind");
+    ARGCHK(cloud, "set_queries: null cloud");
+    HIPCHK(hipSetDevice(ctx->device));
+    KindSlot& ks = ctx->slots[slot].k[kind];
+    ks.has_queries = false; ks.has_records = false;
+    int rc = ingest_cloud(ctx, cloud, ks.q);
+    if (rc != LILI_OK) return rc;
+    ks.n_q = (int64_t)cloud->n;
+    ks.n_blocks = nblocks(ks.n_q, kBlock);
+    size_t n = (size_t)ks.n_q;
+    if (n) {
+        HIPCHK(ks.rec0.ensure(n * sizeof(float4)));
+        HIPCHK(ks.rec1.ensure(n * sizeof(float4)));   // surf: doubles (8 B) fit in the float4 budget
+        HIPCHK(ks.valid.ensure(n));
+        HIPCHK(ks.partials.ensure((size_t)ks.n_blocks * kPartialDoubles * sizeof(double)));
+    }
+    ks.has_queries = true;
+    return LILI_OK;
+}
+
+static int launch_associate(lili_ctx* ctx, int slot, int kind, const PoseArg& pa, const MatchParams& P) {
+    KindSlot& ks = ctx->slots[slot].k[kind];
+    if (!ks.has_queries) return ctx->fail(LILI_E_STATE, "associate: set_queries first");
+    MapIndex& m = ctx->map[kind];
+    if (!m.valid) return ctx->fail(LILI_E_STATE, "associate: map_set first");
+    double gate = kind == LILI_KIND_SURF ? P.kd_max_radius : P.edge_gate;
+    if (m.n > 0 && !(std::sqrt(gate) * 1.0099 <= m.cell))
+        return ctx->fail(LILI_E_STATE, "associate: gate radius exceeds the radius the map index was built for");
+    ks.has_records = true;
+    if (ks.n_q == 0) return LILI_OK;
+    const int n = (int)ks.n_q;
+    int* dbg_i = nullptr; float* dbg_d = nullptr;
+    if (ctx->keep_nn) {
+        HIPCHK(ks.dbg_idx.ensure((size_t)n * 5 * sizeof(int)));
+        HIPCHK(ks.dbg_d2.ensure((size_t)n * 5 * sizeof(float)));
+        dbg_i = ks.dbg_idx.as<int>(); dbg_d = ks.dbg_d2.as<float>();
+    }
+    if (m.n < 5) {   // fewer than 5 map points: the reference reads pt_search_sq_dists[4] out of bounds; we reject all
+        HIPCHK(hipMemsetAsync(ks.valid.p, 0, (size_t)n, ctx->stream));
+        if (dbg_i) { HIPCHK(hipMemsetAsync(dbg_i, 0xFF, (size_t)n * 5 * sizeof(int), ctx->stream)); HIPCHK(hipMemsetAsync(dbg_d, 0x7F, (size_t)n * 5 * sizeof(float), ctx->stream)); }
+        return LILI_OK;
+    }
+    if (kind == LILI_KIND_SURF) {
+        if (P.variant == LILI_VARIANT_LIVOX && !m.has_aux) return ctx->fail(LILI_E_STATE, "associate: Livox variant needs reflectivity (aux_offset) on the surf map");
+        hipLaunchKernelGGL(k_associate_surf, dim3(ks.n_blocks), dim3(kBlock), 0, ctx->stream, ks.q.as<float4>(), (const int*)nullptr, n, m.view, pa, P,
+                           ks.rec0.as<float4>(), ks.rec1.as<double>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ctx->state(slot));
+    } else {
+        hipLaunchKernelGGL(k_associate_edge, dim3(ks.n_blocks), dim3(kBlock), 0, ctx->stream, ks.q.as<float4>(), (const int*)nullptr, n, m.view, pa, P,
+                           ks.rec0.as<float4>(), ks.rec1.as<float4>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ctx->state(slot));
+    }
+    HIPCHK(hipGetLastError());
+    return LILI_OK;
+}
+
+static int launch_linearize(lili_ctx* ctx, int slot, int kind, const PoseArg& pa, const MatchParams& P) {
+    KindSlot& ks = ctx->slots[slot].k[kind];
+    if (!ks.has_records) return ctx->fail(LILI_E_STATE, "linearize: associate first");
+    if (ks.n_q == 0) return LILI_OK;
+    const int n = (int)ks.n_q;
+    if (kind == LILI_KIND_SURF)
+        hipLaunchKernelGGL(k_linearize_surf, dim3(ks.n_blocks), dim3(kBlock), kLdsLinearize, ctx->stream, ks.q.as<float4>(), n, ks.rec0.as<float4>(),
+                           ks.rec1.as<double>(), ks.valid.as<unsigned char>(), pa, P, ctx->state(slot), ks.partials.as<double>());
+    else
+        hipLaunchKernelGGL(k_linearize_edge, dim3(ks.n_blocks), dim3(kBlock), kLdsLinearize, ctx->stream, ks.q.as<float4>(), n, ks.rec0.as<float4>(),
+                           ks.rec1.as<float4>(), ks.valid.as<unsigned char>(), pa, P, ctx->state(slot), ks.partials.as<double>());
+    HIPCHK(hipGetLastError());
+    return LILI_OK;
+}
+
+static int launch_reduce(lili_ctx* ctx, int slot, int kind_mask, double* d_out, int reset_counts) {
+    Slot& s = ctx->slots[slot];
+    const double* ps = nullptr; const double* pe = nullptr; int nbs = 0, nbe = 0;
+    if ((kind_mask & LILI_MASK_SURF) && s.k[0].n_q > 0) { ps = s.k[0].partials.as<double>(); nbs = s.k[0].n_blocks; }
+    if ((kind_mask & LILI_MASK_EDGE) && s.k[1].n_q > 0) { pe = s.k[1].partials.as<double>(); nbe = s.k[1].n_blocks; }
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, ctx->stream, ps, nbs, pe, nbe, d_out, ctx->state(slot), reset_counts);
+    HIPCHK(hipGetLastError());
+    return LILI_OK;
+}
+
+int lili_s2m_associate(lili_ctx* ctx, int slot, int kind, const double t_assoc[3], const double q_assoc[4],
+                       const lili_s2m_params* params, int* n_res) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS, "associate: bad slot");
+    ARGCHK(kind == 0 || kind == 1, "associate: bad kind");
+    ARGCHK(t_assoc && q_assoc && params, "associate: null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    PoseArg pa{};
+    for (int i = 0; i < 3; i++) pa.t[i] = t_assoc[i];
+    for (int i = 0; i < 4; i++) pa.q[i] = q_assoc[i];
+    pa.state = nullptr; pa.derive_assoc = 0;
+    MatchParams P = to_device_params(params);
+    HIPCHK(hipMemsetAsync(&ctx->state(slot)->n_res[kind], 0, sizeof(int), ctx->stream));
+    ctx->slots[slot].counts_clean = false;
+    int rc = launch_associate(ctx, slot, kind, pa, P);
+    if (rc != LILI_OK) return rc;
+    if (n_res) {
+        HIPCHK(hipMemcpyAsync(n_res, &ctx->state(slot)->n_res[kind], sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    return LILI_OK;
+}
+
+int lili_s2m_linearize(lili_ctx* ctx, int slot, int kind_mask, const double t[3], const double q[4],
+                       const lili_s2m_params* params, double gram[64], double* cost, int counts[2]) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS, "linearize: bad slot");
+    ARGCHK((kind_mask & ~3) == 0 && kind_mask != 0, "linearize: bad kind mask");
+    ARGCHK(t && q && params && gram, "linearize: null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    PoseArg pa{};
+    for (int i = 0; i < 3; i++) pa.t[i] = t[i];
+    for (int i = 0; i < 4; i++) pa.q[i] = q[i];
+    MatchParams P = to_device_params(params);
+    for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) { int rc = launch_linearize(ctx, slot, kind, pa, P); if (rc != LILI_OK) return rc; }
+    int rc = launch_reduce(ctx, slot, kind_mask, ctx->gram_of(slot), 0);
+    if (rc != LILI_OK) return rc;
+    double host[LILI_GRAM_DOUBLES];
+    HIPCHK(hipMemcpyAsync(host, ctx->gram_of(slot), sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    std::memcpy(gram, host, 64 * sizeof(double));
+    if (cost) *cost = host[64];
+    if (counts) { counts[0] = (int)host[65]; counts[1] = (int)host[66]; }
+    return LILI_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// record copy-out (debug / parity; ordered like the reference's push_back lists)
+// --------------------------------------------------------------------------------------------
+int lili_s2m_get_surf_records(lili_ctx* ctx, int slot, size_t capacity, int32_t* query_index, float* cur_pt, float* normal,
+                              float* neg_oa_dot_norm, double* score, size_t* n_out) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS, "get_surf_records: bad slot");
+    KindSlot& ks = ctx->slots[slot].k[0];
+    if (!ks.has_records) return ctx->fail(LILI_E_STATE, "get_surf_records: associate first");
+    HIPCHK(hipSetDevice(ctx->device));
+    size_t n = (size_t)ks.n_q;
+    std::vector<unsigned char> v(n); std::vector<float4> q(n), nd(n); std::vector<double> sc(n);
+    if (n) {
+        HIPCHK(hipMemcpyAsync(v.data(), ks.valid.p, n, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(q.data(), ks.q.p, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(nd.data(), ks.rec0.p, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(sc.data(), ks.rec1.p, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    size_t k = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (!v[i]) continue;
+        if (k < capacity) {
+            if (query_index) query_index[k] = (int32_t)i;
+            if (cur_pt) { cur_pt[3 * k] = q[i].x; cur_pt[3 * k + 1] = q[i].y; cur_pt[3 * k + 2] = q[i].z; }
+            if (normal) { normal[3 * k] = nd[i].x; normal[3 * k + 1] = nd[i].y; normal[3 * k + 2] = nd[i].z; }
+            if (neg_oa_dot_norm) neg_oa_dot_norm[k] = nd[i].w;
+            if (score) score[k] = sc[i];
+        }
+        k++;
+    }
+    if (n_out) *n_out = k;
+    return LILI_OK;
+}
+
+int lili_s2m_get_edge_records(lili_ctx* ctx, int slot, size_t capacity, int32_t* query_index, float* cur_pt, float* pt_a, float* pt_b,
+                              float* s, size_t* n_out) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS, "get_edge_records: bad slot");
+    KindSlot& ks = ctx->slots[slot].k[1];
+    if (!ks.has_records) return ctx->fail(LILI_E_STATE, "get_edge_records: associate first");
+    HIPCHK(hipSetDevice(ctx->device));
+    size_t n = (size_t)ks.n_q;
+    std::vector<unsigned char> v(n); std::vector<float4> q(n), a(n), b(n);
+    if (n) {
+        HIPCHK(hipMemcpyAsync(v.data(), ks.valid.p, n, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(q.data(), ks.q.p, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(a.data(), ks.rec0.p, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(b.data(), ks.rec1.p, n * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    size_t k = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (!v[i]) continue;
+        if (k < capacity) {
+            if (query_index) query_index[k] = (int32_t)i;
+            if (cur_pt) { cur_pt[3 * k] = q[i].x; cur_pt[3 * k + 1] = q[i].y; cur_pt[3 * k + 2] = q[i].z; }
+            if (pt_a) { pt_a[3 * k] = a[i].x; pt_a[3 * k + 1] = a[i].y; pt_a[3 * k + 2] = a[i].z; }
+            if (pt_b) { pt_b[3 * k] = b[i].x; pt_b[3 * k + 1] = b[i].y; pt_b[3 * k + 2] = b[i].z; }
+            if (s) s[k] = a[i].w;
+        }
+        k++;
+    }
+    if (n_out) *n_out = k;
+    return LILI_OK;
+}
+
+int lili_s2m_get_neighbors(lili_ctx* ctx, int slot, int kind, size_t n_q, int32_t* idx, float* d2) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS && (kind == 0 || kind == 1), "get_neighbors: bad slot/kind");
+    KindSlot& ks = ctx->slots[slot].k[kind];
+    if (!ks.has_records || !ctx->keep_nn || !ks.dbg_idx.p) return ctx->fail(LILI_E_STATE, "get_neighbors: enable lili_set_debug before associate");
+    ARGCHK(n_q == (size_t)ks.n_q, "get_neighbors: n_q mismatch");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (n_q) {
+        if (idx) HIPCHK(hipMemcpyAsync(idx, ks.dbg_idx.p, n_q * 5 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        if (d2) HIPCHK(hipMemcpyAsync(d2, ks.dbg_d2.p, n_q * 5 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    return LILI_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// device-resident iterations
+// --------------------------------------------------------------------------------------------
+int lili_s2m_pose_set(lili_ctx* ctx, int slot, const double t[3], const double q[4]) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS && t && q, "pose_set: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    SlotState s{};
+    for (int i = 0; i < 3; i++) s.pose[i] = t[i];
+    for (int i = 0; i < 4; i++) s.pose[3 + i] = q[i];
+    HIPCHK(hipMemcpyAsync(ctx->state(slot), &s, sizeof(s), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));   // `s` is on this stack frame
+    ctx->slots[slot].counts_clean = true;
+    return LILI_OK;
+}
+
+int lili_s2m_pose_get(lili_ctx* ctx, int slot, double t[3], double q[4], int* gn_status) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS, "pose_get: bad slot");
+    HIPCHK(hipSetDevice(ctx->device));
+    SlotState s{};
+    HIPCHK(hipMemcpyAsync(&s, ctx->state(slot), sizeof(s), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (t) for (int i = 0; i < 3; i++) t[i] = s.pose[i];
+    if (q) for (int i = 0; i < 4; i++) q[i] = s.pose[3 + i];
+    if (gn_status) *gn_status = s.gn_status;
+    return LILI_OK;
+}
+
+int lili_s2m_associate_dev(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS, "associate_dev: bad slot");
+    ARGCHK((kind_mask & ~3) == 0 && kind_mask != 0, "associate_dev: bad kind mask");
+    ARGCHK(params, "associate_dev: null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    Slot& s = ctx->slots[slot];
+    if (!s.counts_clean) { HIPCHK(hipMemsetAsync(ctx->state(slot)->n_res, 0, 2 * sizeof(int), ctx->stream)); }
+    s.counts_clean = false;
+    PoseArg pa{};
+    pa.state = ctx->state(slot);
+    pa.derive_assoc = params->variant == LILI_VARIANT_FRONTEND ? 0 : 1;
+    MatchParams P = to_device_params(params);
+    for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) {
+        int rc = launch_associate(ctx, slot, kind, pa, P);
+        if (rc != LILI_OK) return rc;
+    }
+    return LILI_OK;
+}
+
+int lili_s2m_counts_ptr(lili_ctx* ctx, int slot, int** d_counts) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS && d_counts, "counts_ptr: bad argument");
+    *d_counts = ctx->state(slot)->n_res;
+    return LILI_OK;
+}
+
+int lili_s2m_linearize_dev(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, double* d_gram) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS, "linearize_dev: bad slot");
+    ARGCHK((kind_mask & ~3) == 0 && kind_mask != 0, "linearize_dev: bad kind mask");
+    ARGCHK(params && d_gram, "linearize_dev: null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    PoseArg pa{};
+    pa.state = ctx->state(slot);
+    MatchParams P = to_device_params(params);
+    for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) {
+        int rc = launch_linearize(ctx, slot, kind, pa, P);
+        if (rc != LILI_OK) return rc;
+    }
+    int rc = launch_reduce(ctx, slot, kind_mask, d_gram, 1);
+    if (rc != LILI_OK) return rc;
+    ctx->slots[slot].counts_clean = true;
+    return LILI_OK;
+}
+
+int lili_s2m_accumulate(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, double* d_gram) {
+    int rc = lili_s2m_associate_dev(ctx, slot, kind_mask, params);
+    if (rc != LILI_OK) return rc;
+    return lili_s2m_linearize_dev(ctx, slot, kind_mask, params, d_gram);
+}
+
+int lili_s2m_gn_update(lili_ctx* ctx, int slot, const double* d_gram) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS && d_gram, "gn_update: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_gn_update, dim3(1), dim3(64), 0, ctx->stream, d_gram, ctx->state(slot));
+    HIPCHK(hipGetLastError());
+    return LILI_OK;
+}
+
+int lili_s2m_iterate(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, int n_iters) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(n_iters >= 0, "iterate: negative n_iters");
+    for (int it = 0; it < n_iters; it++) {
+        int rc = lili_s2m_accumulate(ctx, slot, kind_mask, params, ctx->gram_of(slot));
+        if (rc != LILI_OK) return rc;
+        rc = lili_s2m_gn_update(ctx, slot, ctx->gram_of(slot));
+        if (rc != LILI_OK) return rc;
+    }
+    return LILI_OK;
+}
+
+// host mirror of k_gn_update (used by the ceres adapter / host LM; plain C++ on the host by design —
+// a 6x6 solve is O(1) work outside the data-parallel path)
+int lili_gn_step_host(const double gram[64], double t[3], double q[4], double delta[6]) {
+    if (!gram || !t || !q) return LILI_E_ARG;
+    double Pm[7][6] = {};
+    Pm[0][0] = Pm[1][1] = Pm[2][2] = 1.0;
+    const double x0 = q[0], x1 = q[1], x2 = q[2], x3 = q[3];
+    const double tab[4][3] = {{-x1, -x2, -x3}, {x0, x3, -x2}, {-x3, x0, x1}, {x2, -x1, x0}};
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 3; c++) Pm[3 + r][3 + c] = tab[r][c];
+    double H[6][6], g[6];
+    for (int a = 0; a < 6; a++) {
+        for (int b = 0; b < 6; b++) {
+            double s = 0;
+            for (int i = 0; i < 7; i++) { double gi = 0; for (int j = 0; j < 7; j++) gi += gram[i * 8 + j] * Pm[j][b]; s += Pm[i][a] * gi; }
+            H[a][b] = s;
+        }
+        double s = 0; for (int i = 0; i < 7; i++) s += Pm[i][a] * gram[i * 8 + 7];
+        g[a] = -s;
+    }
+    for (int j = 0; j < 6; j++) {
+        double d = H[j][j];
+        for (int k = 0; k < j; k++) d -= H[j][k] * H[j][k];
+        if (!(d > 0)) return 1;
+        d = std::sqrt(d); H[j][j] = d;
+        for (int i = j + 1; i < 6; i++) { double s = H[i][j]; for (int k = 0; k < j; k++) s -= H[i][k] * H[j][k]; H[i][j] = s / d; }
+    }
+    double d[6];
+    for (int i = 0; i < 6; i++) { double s = g[i]; for (int k = 0; k < i; k++) s -= H[i][k] * d[k]; d[i] = s / H[i][i]; }
+    for (int i = 5; i >= 0; i--) { double s = d[i]; for (int k = i + 1; k < 6; k++) s -= H[k][i] * d[k]; d[i] = s / H[i][i]; }
+    for (int i = 0; i < 6; i++) if (!(d[i] == d[i])) return 1;
+    if (delta) for (int i = 0; i < 6; i++) delta[i] = d[i];
+    t[0] += d[0]; t[1] += d[1]; t[2] += d[2];
+    double nd = std::sqrt(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+    if (nd > 0.0) {
+        double sbd = std::sin(nd) / nd, cw = std::cos(nd);
+        double a[4] = {cw, sbd * d[3], sbd * d[4], sbd * d[5]};
+        double r[4] = {a[0] * x0 - a[1] * x1 - a[2] * x2 - a[3] * x3, a[0] * x1 + a[1] * x0 + a[2] * x3 - a[3] * x2,
+                       a[0] * x2 + a[2] * x0 + a[3] * x1 - a[1] * x3, a[0] * x3 + a[3] * x0 + a[1] * x2 - a[2] * x1};
+        for (int i = 0; i < 4; i++) q[i] = r[i];
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,48 @@
+// Kernel-side declarations shared by the translation units of liblili_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lili {
+
+// Uniform-grid index over the local map (replaces the FLANN kd-tree).
+// Points are stored cell-sorted as float4 (x, y, z, bitcast(original index)); cell_start has
+// n_cells+1 entries; cells are x-fastest so the 3 x-neighbours of a cell are one contiguous run.
+struct GridView {
+    const float4* pts;      // cell-sorted map points
+    const float* aux;       // cell-sorted auxiliary float (Livox reflectivity) or nullptr
+    const int* cell_start;  // [n_cells + 1]
+    double ox, oy, oz;      // grid origin
+    double inv_cell;        // 1 / cell edge
+    int nx, ny, nz;
+    int n_points;
+};
+
+// Per-slot state that lives in device memory so that outer iterations need no host round trip.
+struct SlotState {
+    double pose[7];   // body pose: t(3), q(w,x,y,z)
+    int n_res[2];     // correspondences of the last associate: [surf, edge]
+    int gn_status;    // 0 ok, 1 = normal matrix not positive definite (pose left unchanged)
+    int iters;        // GN updates applied since pose_set
+    double last_delta[6];
+};
+
+// Pose argument of a kernel: either by value (host-provided) or read from SlotState.
+struct PoseArg {
+    double t[3];
+    double q[4];
+    const SlotState* state;  // if non-null, the body pose is read from state->pose
+    int derive_assoc;        // associate only: derive (Q2,T2) = (Q*q_lb^-1, T - Q2*t_lb) from the body pose
+};
+
+struct MatchParams {     // device copy of lili_s2m_params (+ derived values)
+    int variant, loss;
+    double loss_a, lidar_const, kd_max_radius, edge_gate, surf_dist_thres, reflect_thres, surf_weight_min, edge_dist_max;
+    double q_lb[4], t_lb[3];
+    double scale_surf_num, scale_edge_num;
+};
+
+constexpr int kPartialDoubles = 40;  // per-block partial: 36 upper-triangle Gram entries, cost, count, 2 spare
+constexpr int kBlock = 256;
+
+}  // namespace lili

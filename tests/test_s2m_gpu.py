@@ -1,0 +1,304 @@
+"""GPU parity tests of the scan-to-map matcher: HIP path (through the C ABI) vs the CPU oracle on the
+same seeded inputs.  Bars: neighbour indices / valid flags exact; f32 record fields within 1 ulp-ish
+(the f64 plane fit differs in the last bits between the two independent QR codes); Gram 1e-10
+relative; pose after 10 Gauss-Newton iterations within 1e-4 m / 1e-4 rad (north-star tolerance).
+"""
+import numpy as np
+import pytest
+
+import lili_om_amd as L
+from lili_om_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = ["rot", "livox", "frontend"]
+
+
+def _setup(gpu_ctx, oracle, variant, room, with_refl):
+    P = L.make_params(variant)
+    PO = oracle.params(variant)
+    m = L.ScanToMapMatcher(gpu_ctx, P)
+    gpu_ctx.set_debug(True)
+    if with_refl:
+        m.set_input_cloud(L.KIND_SURF, np.concatenate([room["map_xyz"], room["map_refl"][:, None]], 1))
+        m.set_queries(0, L.KIND_SURF, np.concatenate([room["q_xyz"], room["q_refl"][:, None]], 1))
+    else:
+        m.set_input_cloud(L.KIND_SURF, room["map_xyz"])
+        m.set_queries(0, L.KIND_SURF, room["q_xyz"])
+    m.set_input_cloud(L.KIND_EDGE, room["edge_map_xyz"])
+    m.set_queries(0, L.KIND_EDGE, room["eq_xyz"])
+    return P, PO, m
+
+
+def _pose(room, P, variant, rng=None, dt=0.0, dang=0.0):
+    t, q = room["t_true"].copy(), room["q_true"].copy()
+    if rng is not None:
+        t, q = synth.perturbed_pose(t, q, rng, dt, dang)
+    if variant == "frontend":
+        return t, q, q.copy(), t.copy()
+    Q2, T2 = L.api.assoc_transform(t, q, P)
+    return t, q, Q2, T2
+
+
+def _scales(variant, n_s, n_e):
+    if variant == "rot":
+        return 1000.0 / max(n_s, 1), 200.0 / max(n_e, 1)
+    return 1.0, 1.0
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_association_parity(gpu_ctx, oracle, variant):
+    room = synth.make_room(seed=11, n_query=6000, n_edge_query=600)
+    P, PO, m = _setup(gpu_ctx, oracle, variant, room, with_refl=(variant == "livox"))
+    rng = np.random.default_rng(5)
+    t, q, Q2, T2 = _pose(room, P, variant, rng, 0.05, 0.5)
+    n_s = m.find_corresponding_surf_features(0, Q2, T2)
+    n_e = m.find_corresponding_corner_features(0, Q2, T2)
+    tree = oracle.KdTree(room["map_xyz"])
+    etree = oracle.KdTree(room["edge_map_xyz"])
+    rs = oracle.associate_surf(tree, room["map_refl"] if variant == "livox" else None, room["q_xyz"],
+                               room["q_refl"] if variant == "livox" else None, Q2, T2, PO)
+    re_ = oracle.associate_edge(etree, room["eq_xyz"], Q2, T2, PO)
+    assert rs["count"] > 1000 and re_["count"] > 50, "test scene must produce correspondences"
+    assert n_s == rs["count"] and n_e == re_["count"]
+    # neighbour lists: exact wherever the reference's gate can pass
+    for kind, rec, gate, nq in ((L.KIND_SURF, rs, PO.kd_max_radius, room["q_xyz"].shape[0]),
+                                (L.KIND_EDGE, re_, PO.edge_gate, room["eq_xyz"].shape[0])):
+        idx, d2 = m.neighbors(0, kind, nq)
+        inside = rec["nn_d2"][:, 4] < gate
+        assert inside.sum() > 0
+        assert np.array_equal(idx[inside], rec["nn_idx"][inside])
+        assert np.array_equal(d2[inside], rec["nn_d2"][inside])          # bit-exact f32 distances
+        assert np.all(~(d2[~inside][:, 4] < gate))                        # never a false accept
+    # ordered record lists
+    g = m.surf_records(0, room["q_xyz"].shape[0])
+    sel = np.nonzero(rs["valid"])[0]
+    assert np.array_equal(g["query_index"], sel)
+    assert np.array_equal(g["cp"], rs["cp"][sel])
+    np.testing.assert_allclose(g["n"], rs["n"][sel], rtol=3e-7, atol=1e-9)
+    np.testing.assert_allclose(g["d"], rs["d"][sel], rtol=3e-7, atol=1e-9)
+    np.testing.assert_allclose(g["score"], rs["score"][sel], rtol=3e-7)
+    ge = m.edge_records(0, room["eq_xyz"].shape[0])
+    sel = np.nonzero(re_["valid"])[0]
+    assert np.array_equal(ge["query_index"], sel)
+    assert np.array_equal(ge["cp"], re_["cp"][sel])
+    np.testing.assert_allclose(ge["a"], re_["a"][sel], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(ge["b"], re_["b"][sel], rtol=0, atol=2e-6)
+    assert np.array_equal(ge["s"], re_["s"][sel])
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_linearize_gram_parity(gpu_ctx, oracle, variant):
+    room = synth.make_room(seed=12, n_query=5000, n_edge_query=500)
+    P, PO, m = _setup(gpu_ctx, oracle, variant, room, with_refl=(variant == "livox"))
+    rng = np.random.default_rng(6)
+    t, q, Q2, T2 = _pose(room, P, variant, rng, 0.08, 1.0)
+    n_s = m.find_corresponding_surf_features(0, Q2, T2)
+    n_e = m.find_corresponding_corner_features(0, Q2, T2)
+    tree = oracle.KdTree(room["map_xyz"])
+    etree = oracle.KdTree(room["edge_map_xyz"])
+    rs = oracle.associate_surf(tree, room["map_refl"] if variant == "livox" else None, room["q_xyz"],
+                               room["q_refl"] if variant == "livox" else None, Q2, T2, PO)
+    re_ = oracle.associate_edge(etree, room["eq_xyz"], Q2, T2, PO)
+    ss, se = _scales(variant, rs["count"], re_["count"])
+    # the GPU linearises ITS OWN records; to isolate the linearisation the oracle uses its own too and
+    # the association test above bounds the record differences
+    for mask, want in ((L.MASK_SURF, "s"), (L.MASK_EDGE, "e"), (L.MASK_SURF | L.MASK_EDGE, "se")):
+        if variant == "frontend" and "e" in want:
+            continue   # the front-end has no edge factors (L/src/LidarOdometry.cpp:513-526)
+        # linearise at a pose different from the association pose, like the LM iterations do
+        t2, q2 = synth.perturbed_pose(t, q, np.random.default_rng(7), 0.02, 0.2)
+        G, cost, counts = m.linearize(0, t2, q2, mask)
+        Go = np.zeros((8, 8)); co = 0.0
+        if "s" in want:
+            g1, c1, n1 = oracle.linearize_surf(rs, t2, q2, PO, ss)
+            Go += g1; co += c1
+            assert counts[0] == n1 == n_s
+        if "e" in want:
+            g2, c2, n2 = oracle.linearize_edge(re_, t2, q2, PO, se)
+            Go += g2; co += c2
+            assert counts[1] == n2 == n_e
+        scale = np.abs(Go).max()
+        assert np.abs(G - Go).max() <= 2e-6 * scale      # f32 record ulps dominate; see exact-record check below
+        assert abs(cost - co) <= 2e-6 * max(abs(co), 1e-12)
+        assert np.allclose(G, G.T, rtol=0, atol=0)
+
+
+def test_linearize_exact_records(gpu_ctx, oracle):
+    """Same records on both sides (GPU records fed to the oracle): Gram must agree to 1e-12 relative."""
+    room = synth.make_room(seed=13, n_query=5000, n_edge_query=500)
+    variant = "rot"
+    P, PO, m = _setup(gpu_ctx, oracle, variant, room, with_refl=False)
+    t, q, Q2, T2 = _pose(room, P, variant, np.random.default_rng(8), 0.05, 0.7)
+    n_s = m.find_corresponding_surf_features(0, Q2, T2)
+    n_e = m.find_corresponding_corner_features(0, Q2, T2)
+    nq, ne = room["q_xyz"].shape[0], room["eq_xyz"].shape[0]
+    g = m.surf_records(0, nq)
+    ge = m.edge_records(0, ne)
+    rs = dict(valid=np.zeros(nq, np.uint8), cp=np.zeros((nq, 3), np.float32), n=np.zeros((nq, 3), np.float32),
+              d=np.zeros(nq, np.float32), score=np.zeros(nq))
+    rs["valid"][g["query_index"]] = 1
+    rs["cp"][g["query_index"]] = g["cp"]; rs["n"][g["query_index"]] = g["n"]
+    rs["d"][g["query_index"]] = g["d"]; rs["score"][g["query_index"]] = g["score"]
+    re_ = dict(valid=np.zeros(ne, np.uint8), cp=np.zeros((ne, 3), np.float32), a=np.zeros((ne, 3), np.float32),
+               b=np.zeros((ne, 3), np.float32), s=np.zeros(ne, np.float32))
+    re_["valid"][ge["query_index"]] = 1
+    re_["cp"][ge["query_index"]] = ge["cp"]; re_["a"][ge["query_index"]] = ge["a"]
+    re_["b"][ge["query_index"]] = ge["b"]; re_["s"][ge["query_index"]] = ge["s"]
+    G, cost, counts = m.linearize(0, t, q, L.MASK_SURF | L.MASK_EDGE)
+    g1, c1, n1 = oracle.linearize_surf(rs, t, q, PO, 1000.0 / n_s)
+    g2, c2, n2 = oracle.linearize_edge(re_, t, q, PO, 200.0 / n_e)
+    Go = g1 + g2
+    assert (counts[0], counts[1]) == (n1, n2)
+    assert np.abs(G - Go).max() <= 1e-12 * np.abs(Go).max()
+    assert abs(cost - (c1 + c2)) <= 1e-12 * abs(c1 + c2)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_gauss_newton_pose_parity(gpu_ctx, oracle, variant):
+    """10 outer iterations (re-associate + linearise + GN step) entirely on the device vs the oracle loop."""
+    room = synth.make_room(seed=14, n_query=8000, n_edge_query=800, noise=0.005)
+    P, PO, m = _setup(gpu_ctx, oracle, variant, room, with_refl=(variant == "livox"))
+    rng = np.random.default_rng(synth.SEED_POSE)
+    t0, q0 = synth.perturbed_pose(room["t_true"], room["q_true"], rng, 0.15, 1.0)
+    mask = L.MASK_SURF if variant == "frontend" else (L.MASK_SURF | L.MASK_EDGE)
+    m.pose_set(0, t0, q0)
+    m.iterate(0, 10, mask)
+    tg, qg, status = m.pose_get(0)
+    assert status == 0
+    # oracle loop
+    tree = oracle.KdTree(room["map_xyz"])
+    etree = oracle.KdTree(room["edge_map_xyz"])
+    t, q = t0.copy(), q0.copy()
+    for _ in range(10):
+        if variant == "frontend":
+            Q2, T2 = q, t
+        else:
+            Q2, T2 = L.api.assoc_transform(t, q, P)
+        rs = oracle.associate_surf(tree, room["map_refl"] if variant == "livox" else None, room["q_xyz"],
+                                   room["q_refl"] if variant == "livox" else None, Q2, T2, PO)
+        ss, se = 1.0, 1.0
+        G, _, _ = None, None, None
+        if mask & L.MASK_EDGE:
+            re_ = oracle.associate_edge(etree, room["eq_xyz"], Q2, T2, PO)
+            ss, se = _scales(variant, rs["count"], re_["count"])
+            G = oracle.linearize_surf(rs, t, q, PO, ss)[0] + oracle.linearize_edge(re_, t, q, PO, se)[0]
+        else:
+            ss, _ = _scales(variant, rs["count"], 1)
+            G = oracle.linearize_surf(rs, t, q, PO, ss)[0]
+        st, t, q, _ = oracle.gn_step(G, t, q)
+        assert st == 0
+    assert np.abs(tg - t).max() < 1e-4
+    dq = synth.quat_mul(qg * np.array([1, -1, -1, -1]), q)
+    ang = 2 * np.arcsin(min(1.0, np.linalg.norm(dq[1:])))
+    assert ang < 1e-4
+    # and the iteration did converge towards the truth
+    assert np.linalg.norm(tg - room["t_true"]) < np.linalg.norm(t0 - room["t_true"])
+
+
+def test_host_pose_and_device_pose_paths_agree(gpu_ctx, oracle):
+    room = synth.make_room(seed=15, n_query=3000, n_edge_query=300)
+    P, PO, m = _setup(gpu_ctx, oracle, "rot", room, with_refl=False)
+    t0, q0 = synth.perturbed_pose(room["t_true"], room["q_true"], np.random.default_rng(3), 0.1, 0.5)
+    Q2, T2 = L.api.assoc_transform(t0, q0, P)
+    m.find_corresponding_surf_features(0, Q2, T2)
+    G, cost, counts = m.linearize(0, t0, q0, L.MASK_SURF)
+    st, t1, q1, _ = L.api.gn_step_host(G, t0, q0)
+    assert st == 0
+    m.pose_set(0, t0, q0)
+    m.iterate(0, 1, L.MASK_SURF)
+    t2, q2, st2 = m.pose_get(0)
+    assert st2 == 0
+    assert np.abs(t1 - t2).max() < 1e-12 and np.abs(q1 - q2).max() < 1e-12
+
+
+def test_edge_cases(gpu_ctx, oracle):
+    P = L.make_params("rot")
+    PO = oracle.params("rot")
+    m = L.ScanToMapMatcher(gpu_ctx, P)
+    gpu_ctx.set_debug(True)
+    ident_q, zero_t = [1.0, 0, 0, 0], [0.0, 0, 0]
+    room = synth.make_room(seed=16, n_query=500, n_edge_query=50)
+    # (a) empty query set
+    m.set_input_cloud(L.KIND_SURF, room["map_xyz"])
+    m.set_queries(0, L.KIND_SURF, np.zeros((0, 3), np.float32))
+    assert m.find_corresponding_surf_features(0, ident_q, zero_t) == 0
+    G, cost, counts = m.linearize(0, zero_t, ident_q, L.MASK_SURF)
+    assert not G.any() and cost == 0 and counts[0] == 0
+    # (b) empty map and a map with fewer than 5 points: no correspondences
+    for nmap in (0, 3):
+        m.set_input_cloud(L.KIND_SURF, room["map_xyz"][:nmap])
+        m.set_queries(0, L.KIND_SURF, room["q_xyz"])
+        assert m.find_corresponding_surf_features(0, ident_q, zero_t) == 0
+    # (c) queries far outside the map's bounding box, NaN query
+    m.set_input_cloud(L.KIND_SURF, room["map_xyz"])
+    far = room["q_xyz"].copy()
+    far[:100] += 1000.0
+    far[100] = np.nan
+    m.set_queries(0, L.KIND_SURF, far)
+    Q2, T2 = L.api.assoc_transform(room["t_true"], room["q_true"], P)
+    n = m.find_corresponding_surf_features(0, Q2, T2)
+    tree = oracle.KdTree(room["map_xyz"])
+    rs = oracle.associate_surf(tree, None, far, None, Q2, T2, PO)
+    assert n == rs["count"]
+    g = m.surf_records(0, far.shape[0])
+    assert np.array_equal(g["query_index"], np.nonzero(rs["valid"])[0])
+    assert g["query_index"].min() > 100
+    # (d) exact distance ties: duplicated map points -> lower original index wins, like the oracle
+    dup = np.concatenate([room["map_xyz"][:2000], room["map_xyz"][:2000]], 0)
+    m.set_input_cloud(L.KIND_SURF, dup)
+    m.set_queries(0, L.KIND_SURF, room["q_xyz"])
+    m.find_corresponding_surf_features(0, Q2, T2)
+    idx, d2 = m.neighbors(0, L.KIND_SURF, room["q_xyz"].shape[0])
+    tree2 = oracle.KdTree(dup)
+    r2 = oracle.associate_surf(tree2, None, room["q_xyz"], None, Q2, T2, PO)
+    inside = r2["nn_d2"][:, 4] < 1.0
+    assert inside.sum() > 10
+    assert np.array_equal(idx[inside], r2["nn_idx"][inside])
+    # (e) a larger gate than the map index was built for is refused, not silently wrong
+    P2 = L.make_params("rot", kd_max_radius=4.0)
+    m2 = L.ScanToMapMatcher(gpu_ctx, P2)
+    with pytest.raises(L.LiliError):
+        m2.find_corresponding_surf_features(0, Q2, T2)
+    # ... and accepted once the map is rebuilt for it (kd_max_radius = 1.5 of config_utbm.yaml)
+    P3 = L.make_params("rot", kd_max_radius=1.5)
+    PO3 = oracle.params("rot", kd_max_radius=1.5)
+    m3 = L.ScanToMapMatcher(gpu_ctx, P3)
+    m3.set_input_cloud(L.KIND_SURF, room["map_xyz"])
+    m3.set_queries(0, L.KIND_SURF, room["q_xyz"])
+    n3 = m3.find_corresponding_surf_features(0, Q2, T2)
+    r3 = oracle.associate_surf(tree, None, room["q_xyz"], None, Q2, T2, PO3)
+    assert n3 == r3["count"]
+
+
+def test_mid_size_outdoor_scene(gpu_ctx, oracle):
+    """Reduced config-2 scene (same generator, ~0.6 M map points, 25 k queries): neighbours + counts exact."""
+    w = synth.make_workload(n_map=600_000, n_az=391, half_extent=(150.0, 150.0))
+    P = L.make_params("rot")
+    PO = oracle.params("rot")
+    m = L.ScanToMapMatcher(gpu_ctx, P)
+    gpu_ctx.set_debug(True)
+    m.set_input_cloud(L.KIND_SURF, w["map_xyz"])
+    m.set_queries(0, L.KIND_SURF, w["scan_xyz"])
+    rng = np.random.default_rng(synth.SEED_POSE)
+    # body pose whose LiDAR sits at the generator's true LiDAR pose, then perturbed by 0.3 m / 2 deg
+    qlb = np.array(list(P.q_lb)); qb = qlb / np.linalg.norm(qlb)
+    Q2, T2 = L.api.assoc_transform([0, 0, 0], qb, P)
+    t_body = w["lidar_t"] - T2
+    t0, q0 = synth.perturbed_pose(t_body, qb, rng, 0.3, 2.0)
+    Q2, T2 = L.api.assoc_transform(t0, q0, P)
+    n = m.find_corresponding_surf_features(0, Q2, T2)
+    tree = oracle.KdTree(w["map_xyz"])
+    rs = oracle.associate_surf(tree, None, w["scan_xyz"], None, Q2, T2, PO, nthreads=8)
+    assert rs["count"] > 5000
+    assert n == rs["count"]
+    idx, d2 = m.neighbors(0, L.KIND_SURF, w["scan_xyz"].shape[0])
+    inside = rs["nn_d2"][:, 4] < 1.0
+    assert np.array_equal(idx[inside], rs["nn_idx"][inside])
+    assert np.array_equal(d2[inside], rs["nn_d2"][inside])
+    g = m.surf_records(0, w["scan_xyz"].shape[0])
+    assert np.array_equal(g["query_index"], np.nonzero(rs["valid"])[0])
+    G, cost, counts = m.linearize(0, t0, q0, L.MASK_SURF)
+    Go, co, no = oracle.linearize_surf(rs, t0, q0, PO, 1000.0 / rs["count"])
+    assert counts[0] == no
+    assert np.abs(G - Go).max() <= 2e-6 * np.abs(Go).max()
