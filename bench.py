@@ -134,8 +134,11 @@ def main():
         log(f"[bench] workload generated in {time.perf_counter() - t_gen:.1f} s; {queries.shape[0]} queries/rank, world {world}, scaling {args.scaling}")
 
     # ---------------- device setup (untimed): map index + queries resident in HBM ----------------
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    ctx = L.Context(local_rank, stream=stream)
+    # a non-default torch stream: the lili context, the RCCL collectives and the timing events all run on it
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(tstream)
+    assert tstream.cuda_stream != 0
+    ctx = L.Context(local_rank, stream=tstream.cuda_stream)
     m = L.ScanToMapMatcher(ctx, P)
     tic = time.perf_counter()
     m.set_input_cloud(L.KIND_SURF, w["map_xyz"])

@@ -320,3 +320,17 @@ def assoc_transform(t, q, params):
     uv = 2 * np.cross(u, tlb)
     rot = tlb + Q2[0] * uv + np.cross(u, uv)
     return Q2, np.asarray(t, np.float64) - rot
+
+
+def body_pose_from_lidar(t_lidar, q_lidar, params):
+    """Body pose (T, Q) whose association transform (Q*q_lb^-1, T - Q2*t_lb) equals the given LiDAR pose
+    (up to the non-unit norm of the configured q_lb, which the reference does not normalise either)."""
+    qlb = np.array(list(params.q_lb))
+    qn = qlb / np.linalg.norm(qlb)
+    a, b = np.asarray(q_lidar, np.float64), qn
+    Q = np.array([a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3],
+                  a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                  a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3],
+                  a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1]])
+    _, T2 = assoc_transform([0.0, 0.0, 0.0], Q, params)
+    return np.asarray(t_lidar, np.float64) - T2, Q

@@ -23,7 +23,7 @@ __global__ void k_associate_surf(const float4*, const int*, int, GridView, PoseA
 __global__ void k_associate_edge(const float4*, const int*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, SlotState*);
 __global__ void k_linearize_surf(const float4*, int, const float4*, const double*, const unsigned char*, PoseArg, MatchParams, const SlotState*, double*);
 __global__ void k_linearize_edge(const float4*, int, const float4*, const float4*, const unsigned char*, PoseArg, MatchParams, const SlotState*, double*);
-__global__ void k_reduce_partials(const double*, int, const double*, int, double*, SlotState*, int);
+__global__ void k_reduce_partials(const double*, int, const double*, int, double*, SlotState*, int, int);
 __global__ void k_gn_update(const double*, SlotState*);
 }  // namespace lili
 
@@ -59,7 +59,8 @@ struct KindSlot {
     int64_t n_q = 0;
     bool has_queries = false, has_records = false;
     DevBuf q, rec0, rec1, valid, dbg_idx, dbg_d2, partials;
-    int n_blocks = 0;
+    int n_blocks = 0;      // association grid (one thread per query)
+    int n_lin_blocks = 0;  // linearisation grid (grid-stride, <= kMaxLinBlocks partials)
 };
 
 struct Slot {
@@ -67,6 +68,7 @@ struct Slot {
     bool counts_clean = true;   // device n_res[] known to be zero
 };
 
+constexpr int kMaxLinBlocks = 256;
 constexpr size_t kLdsLinearize = (size_t)(kBlock * 9 + 4 * 40) * sizeof(double);
 
 }  // namespace
@@ -286,6 +288,7 @@ int lili_s2m_set_queries(lili_ctx* ctx, int slot, int kind, const lili_cloud* cl
     if (rc != LILI_OK) return rc;
     ks.n_q = (int64_t)cloud->n;
     ks.n_blocks = nblocks(ks.n_q, kBlock);
+    ks.n_lin_blocks = std::min(ks.n_blocks, kMaxLinBlocks);
     size_t n = (size_t)ks.n_q;
     if (n) {
         HIPCHK(ks.rec0.ensure(n * sizeof(float4)));
@@ -337,21 +340,21 @@ static int launch_linearize(lili_ctx* ctx, int slot, int kind, const PoseArg& pa
     if (ks.n_q == 0) return LILI_OK;
     const int n = (int)ks.n_q;
     if (kind == LILI_KIND_SURF)
-        hipLaunchKernelGGL(k_linearize_surf, dim3(ks.n_blocks), dim3(kBlock), kLdsLinearize, ctx->stream, ks.q.as<float4>(), n, ks.rec0.as<float4>(),
+        hipLaunchKernelGGL(k_linearize_surf, dim3(ks.n_lin_blocks), dim3(kBlock), kLdsLinearize, ctx->stream, ks.q.as<float4>(), n, ks.rec0.as<float4>(),
                            ks.rec1.as<double>(), ks.valid.as<unsigned char>(), pa, P, ctx->state(slot), ks.partials.as<double>());
     else
-        hipLaunchKernelGGL(k_linearize_edge, dim3(ks.n_blocks), dim3(kBlock), kLdsLinearize, ctx->stream, ks.q.as<float4>(), n, ks.rec0.as<float4>(),
+        hipLaunchKernelGGL(k_linearize_edge, dim3(ks.n_lin_blocks), dim3(kBlock), kLdsLinearize, ctx->stream, ks.q.as<float4>(), n, ks.rec0.as<float4>(),
                            ks.rec1.as<float4>(), ks.valid.as<unsigned char>(), pa, P, ctx->state(slot), ks.partials.as<double>());
     HIPCHK(hipGetLastError());
     return LILI_OK;
 }
 
-static int launch_reduce(lili_ctx* ctx, int slot, int kind_mask, double* d_out, int reset_counts) {
+static int launch_reduce(lili_ctx* ctx, int slot, int kind_mask, double* d_out, int reset_counts, int do_gn) {
     Slot& s = ctx->slots[slot];
     const double* ps = nullptr; const double* pe = nullptr; int nbs = 0, nbe = 0;
-    if ((kind_mask & LILI_MASK_SURF) && s.k[0].n_q > 0) { ps = s.k[0].partials.as<double>(); nbs = s.k[0].n_blocks; }
-    if ((kind_mask & LILI_MASK_EDGE) && s.k[1].n_q > 0) { pe = s.k[1].partials.as<double>(); nbe = s.k[1].n_blocks; }
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, ctx->stream, ps, nbs, pe, nbe, d_out, ctx->state(slot), reset_counts);
+    if ((kind_mask & LILI_MASK_SURF) && s.k[0].n_q > 0) { ps = s.k[0].partials.as<double>(); nbs = s.k[0].n_lin_blocks; }
+    if ((kind_mask & LILI_MASK_EDGE) && s.k[1].n_q > 0) { pe = s.k[1].partials.as<double>(); nbe = s.k[1].n_lin_blocks; }
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, ctx->stream, ps, nbs, pe, nbe, d_out, ctx->state(slot), reset_counts, do_gn);
     HIPCHK(hipGetLastError());
     return LILI_OK;
 }
@@ -391,7 +394,7 @@ int lili_s2m_linearize(lili_ctx* ctx, int slot, int kind_mask, const double t[3]
     for (int i = 0; i < 4; i++) pa.q[i] = q[i];
     MatchParams P = to_device_params(params);
     for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) { int rc = launch_linearize(ctx, slot, kind, pa, P); if (rc != LILI_OK) return rc; }
-    int rc = launch_reduce(ctx, slot, kind_mask, ctx->gram_of(slot), 0);
+    int rc = launch_reduce(ctx, slot, kind_mask, ctx->gram_of(slot), 0, 0);
     if (rc != LILI_OK) return rc;
     double host[LILI_GRAM_DOUBLES];
     HIPCHK(hipMemcpyAsync(host, ctx->gram_of(slot), sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
@@ -540,7 +543,7 @@ int lili_s2m_counts_ptr(lili_ctx* ctx, int slot, int** d_counts) {
     return LILI_OK;
 }
 
-int lili_s2m_linearize_dev(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, double* d_gram) {
+static int linearize_dev_impl(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, double* d_gram, int do_gn) {
     if (!ctx) return LILI_E_ARG;
     ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS, "linearize_dev: bad slot");
     ARGCHK((kind_mask & ~3) == 0 && kind_mask != 0, "linearize_dev: bad kind mask");
@@ -553,10 +556,14 @@ int lili_s2m_linearize_dev(lili_ctx* ctx, int slot, int kind_mask, const lili_s2
         int rc = launch_linearize(ctx, slot, kind, pa, P);
         if (rc != LILI_OK) return rc;
     }
-    int rc = launch_reduce(ctx, slot, kind_mask, d_gram, 1);
+    int rc = launch_reduce(ctx, slot, kind_mask, d_gram, 1, do_gn);
     if (rc != LILI_OK) return rc;
     ctx->slots[slot].counts_clean = true;
     return LILI_OK;
+}
+
+int lili_s2m_linearize_dev(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, double* d_gram) {
+    return linearize_dev_impl(ctx, slot, kind_mask, params, d_gram, 0);
 }
 
 int lili_s2m_accumulate(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, double* d_gram) {
@@ -577,10 +584,10 @@ int lili_s2m_gn_update(lili_ctx* ctx, int slot, const double* d_gram) {
 int lili_s2m_iterate(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, int n_iters) {
     if (!ctx) return LILI_E_ARG;
     ARGCHK(n_iters >= 0, "iterate: negative n_iters");
-    for (int it = 0; it < n_iters; it++) {
-        int rc = lili_s2m_accumulate(ctx, slot, kind_mask, params, ctx->gram_of(slot));
+    for (int it = 0; it < n_iters; it++) {   // 3 launches per outer iteration: associate, linearise, reduce+GN
+        int rc = lili_s2m_associate_dev(ctx, slot, kind_mask, params);
         if (rc != LILI_OK) return rc;
-        rc = lili_s2m_gn_update(ctx, slot, ctx->gram_of(slot));
+        rc = linearize_dev_impl(ctx, slot, kind_mask, params, ctx->gram_of(slot), 1);
         if (rc != LILI_OK) return rc;
     }
     return LILI_OK;

@@ -369,36 +369,52 @@ __global__ __launch_bounds__(kBlock) void k_associate_edge(
 // block writes one 40-double partial; k_reduce_gn adds the partials in a fixed order.
 // ================================================================================================
 constexpr int kRow = 9;
-__device__ __forceinline__ void gram_block_reduce(const double Jr[8], double cost, bool ok, double* lds /*[kBlock*kRow + 4*40]*/,
-                                                  double* __restrict__ partial_out) {
-    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double* rows = lds + wave * 64 * kRow;
-    double* myrow = rows + lane * kRow;
+// Lane l < 36 owns the upper-triangle entry (a, b); lane 36 the cost column; lane 37 the count.
+struct GramAcc {
+    double acc; int a, b;
+    __device__ __forceinline__ void init() {
+        int lane = threadIdx.x & 63;
+        a = 0; int l = lane;
+        while (a < 8 && l >= 8 - a) { l -= 8 - a; a++; }
+        b = a + l;
+        if (lane >= 36) { a = 8; b = 8; }
+        acc = 0.0;
+    }
+    // all threads of the block must call this (it synchronises)
+    __device__ __forceinline__ void add_rows(const double Jr[8], double cost, bool ok, double* lds) {
+        int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        double* rows = lds + wave * 64 * kRow;
+        double* myrow = rows + lane * kRow;
 #pragma unroll
-    for (int k = 0; k < 8; k++) myrow[k] = ok ? Jr[k] : 0.0;
-    myrow[8] = ok ? cost : 0.0;
-    unsigned long long bal = __ballot(ok);
-    __syncthreads();
-    int a = 0, l = lane;
-    while (a < 8 && l >= 8 - a) { l -= 8 - a; a++; }
-    int b = a + l;
-    double acc = 0.0;
-    if (lane < 36) {
-        for (int q = 0; q < 64; q++) acc += rows[q * kRow + a] * rows[q * kRow + b];
-    } else if (lane == 36) {
-        for (int q = 0; q < 64; q++) acc += rows[q * kRow + 8];
-    } else if (lane == 37) {
-        acc = (double)__popcll(bal);
+        for (int k = 0; k < 8; k++) myrow[k] = ok ? Jr[k] : 0.0;
+        myrow[8] = ok ? cost : 0.0;
+        unsigned long long bal = __ballot(ok);
+        __syncthreads();
+        if (lane < 36) {
+            double s = 0.0;
+            for (int q = 0; q < 64; q++) s += rows[q * kRow + a] * rows[q * kRow + b];
+            acc += s;
+        } else if (lane == 36) {
+            double s = 0.0;
+            for (int q = 0; q < 64; q++) s += rows[q * kRow + 8];
+            acc += s;
+        } else if (lane == 37) {
+            acc += (double)__popcll(bal);
+        }
+        __syncthreads();
     }
-    double* wsum = lds + kBlock * kRow;
-    if (lane < 40) wsum[wave * 40 + lane] = lane < 38 ? acc : 0.0;
-    __syncthreads();
-    if (threadIdx.x < 40) {
-        double s = 0.0;
-        for (int w = 0; w < kBlock / 64; w++) s += wsum[w * 40 + threadIdx.x];
-        partial_out[threadIdx.x] = s;
+    __device__ __forceinline__ void finish(double* lds, double* __restrict__ partial_out) {
+        int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        double* wsum = lds + kBlock * kRow;
+        if (lane < 40) wsum[wave * 40 + lane] = lane < 38 ? acc : 0.0;
+        __syncthreads();
+        if (threadIdx.x < 40) {
+            double s = 0.0;
+            for (int w = 0; w < kBlock / 64; w++) s += wsum[w * 40 + threadIdx.x];
+            partial_out[threadIdx.x] = s;
+        }
     }
-}
+};
 
 __device__ __forceinline__ void load_body_pose(const PoseArg& pa, dq& Q, d3& T) {
     if (pa.state) { const double* s = pa.state->pose; T = d3{s[0], s[1], s[2]}; Q = dq{s[3], s[4], s[5], s[6]}; }
@@ -410,32 +426,38 @@ __global__ __launch_bounds__(kBlock) void k_linearize_surf(
         const unsigned char* __restrict__ valid, PoseArg pa, MatchParams P, const SlotState* __restrict__ state,
         double* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool ok = i < n_q && valid[i];
-    double Jr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    double cost = 0.0;
-    if (ok) {
-        dq Q; d3 T;
-        load_body_pose(pa, Q, T);
-        float4 ql = queries[i]; float4 nd = rec_nd[i];
-        double score = rec_score[i];
-        if (P.scale_surf_num > 0) score = score * P.scale_surf_num / (double)state->n_res[0];   // R:861
-        d3 cp{(double)ql.x, (double)ql.y, (double)ql.z};
-        d3 n{(double)nd.x, (double)nd.y, (double)nd.z};
-        d3 v;
-        if (P.variant == 2) { v = cp; score = 1.0; }   // LidarPlaneNormIncreFactor, LidarKeyframeFactor.h:118-128
-        else v = qrot(qinv(dq{P.q_lb[0], P.q_lb[1], P.q_lb[2], P.q_lb[3]}), cp - d3{P.t_lb[0], P.t_lb[1], P.t_lb[2]});   // :86
-        d3 pw = qrot(Q, v) + T;                                                                                            // :87
-        double r = score * (dot3(n, pw) + (double)nd.w);                                                                  // :90
-        double jq[4];
-        qrot_jac_row(Q, v, n, jq);
-        double J[7] = {score * n.x, score * n.y, score * n.z, score * jq[0], score * jq[1], score * jq[2], score * jq[3]};
-        cost = robustify(P.loss, P.loss_a, J, r);
+    GramAcc ga; ga.init();
+    dq Q; d3 T;
+    load_body_pose(pa, Q, T);
+    const dq qlb_inv = qinv(dq{P.q_lb[0], P.q_lb[1], P.q_lb[2], P.q_lb[3]});
+    const double nscale = P.scale_surf_num > 0 ? P.scale_surf_num / (double)state->n_res[0] : 1.0;   // R:861
+    for (int base = blockIdx.x * kBlock; base < n_q; base += gridDim.x * kBlock) {
+        int i = base + threadIdx.x;
+        bool ok = i < n_q && valid[i];
+        double Jr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double cost = 0.0;
+        if (ok) {
+            float4 ql = queries[i]; float4 nd = rec_nd[i];
+            double score = rec_score[i];
+            if (P.scale_surf_num > 0) score = score * nscale;
+            d3 cp{(double)ql.x, (double)ql.y, (double)ql.z};
+            d3 n{(double)nd.x, (double)nd.y, (double)nd.z};
+            d3 v;
+            if (P.variant == 2) { v = cp; score = 1.0; }   // LidarPlaneNormIncreFactor, LidarKeyframeFactor.h:118-128
+            else v = qrot(qlb_inv, cp - d3{P.t_lb[0], P.t_lb[1], P.t_lb[2]});                                  // :86
+            d3 pw = qrot(Q, v) + T;                                                                              // :87
+            double r = score * (dot3(n, pw) + (double)nd.w);                                                    // :90
+            double jq[4];
+            qrot_jac_row(Q, v, n, jq);
+            double J[7] = {score * n.x, score * n.y, score * n.z, score * jq[0], score * jq[1], score * jq[2], score * jq[3]};
+            cost = robustify(P.loss, P.loss_a, J, r);
 #pragma unroll
-        for (int k = 0; k < 7; k++) Jr[k] = J[k];
-        Jr[7] = r;
+            for (int k = 0; k < 7; k++) Jr[k] = J[k];
+            Jr[7] = r;
+        }
+        ga.add_rows(Jr, cost, ok, lds);
     }
-    gram_block_reduce(Jr, cost, ok, lds, partials + (size_t)blockIdx.x * kPartialDoubles);
+    ga.finish(lds, partials + (size_t)blockIdx.x * kPartialDoubles);
 }
 
 __global__ __launch_bounds__(kBlock) void k_linearize_edge(
@@ -443,82 +465,53 @@ __global__ __launch_bounds__(kBlock) void k_linearize_edge(
         const unsigned char* __restrict__ valid, PoseArg pa, MatchParams P, const SlotState* __restrict__ state,
         double* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool ok = i < n_q && valid[i];
-    double Jr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    double cost = 0.0;
-    if (ok) {
-        dq Q; d3 T;
-        load_body_pose(pa, Q, T);
-        float4 ql = queries[i]; float4 fa = rec_a[i], fb = rec_b[i];
-        double s = (double)fa.w;
-        if (P.scale_edge_num > 0) s = s * P.scale_edge_num / (double)state->n_res[1];   // R:843
-        d3 cp{(double)ql.x, (double)ql.y, (double)ql.z};
-        d3 A{(double)fa.x, (double)fa.y, (double)fa.z}, B{(double)fb.x, (double)fb.y, (double)fb.z};
-        d3 lp = qrot(Q, cp) + T;                    // LidarKeyframeFactor.h:38 (no extrinsic: SURVEY F6)
-        d3 nu = cross3(lp - A, lp - B);             // :40
-        d3 de = A - B;                              // :41
-        double nn = sqrt(dot3(nu, nu)), dn = sqrt(dot3(de, de));
-        double r = s * (nn / dn);                   // :43-44
-        // d|nu|/dlp = nu^T [a-b]x / |nu| = (nu x (B - A))^T / |nu|
-        d3 g = cross3(nu, B - A);
-        double k = s / (nn * dn);
-        g = k * g;
-        double jq[4];
-        qrot_jac_row(Q, cp, g, jq);
-        double J[7] = {g.x, g.y, g.z, jq[0], jq[1], jq[2], jq[3]};
-        cost = robustify(P.loss, P.loss_a, J, r);
+    GramAcc ga; ga.init();
+    dq Q; d3 T;
+    load_body_pose(pa, Q, T);
+    const double nscale = P.scale_edge_num > 0 ? P.scale_edge_num / (double)state->n_res[1] : 1.0;   // R:843
+    for (int base = blockIdx.x * kBlock; base < n_q; base += gridDim.x * kBlock) {
+        int i = base + threadIdx.x;
+        bool ok = i < n_q && valid[i];
+        double Jr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double cost = 0.0;
+        if (ok) {
+            float4 ql = queries[i]; float4 fa = rec_a[i], fb = rec_b[i];
+            double s = (double)fa.w;
+            if (P.scale_edge_num > 0) s = s * nscale;
+            d3 cp{(double)ql.x, (double)ql.y, (double)ql.z};
+            d3 A{(double)fa.x, (double)fa.y, (double)fa.z}, B{(double)fb.x, (double)fb.y, (double)fb.z};
+            d3 lp = qrot(Q, cp) + T;                    // LidarKeyframeFactor.h:38 (no extrinsic: SURVEY F6)
+            d3 nu = cross3(lp - A, lp - B);             // :40
+            d3 de = A - B;                              // :41
+            double nn = sqrt(dot3(nu, nu)), dn = sqrt(dot3(de, de));
+            double r = s * (nn / dn);                   // :43-44
+            // d|nu|/dlp = nu^T [a-b]x / |nu| = (nu x (B - A))^T / |nu|
+            d3 g = cross3(nu, B - A);
+            double k = s / (nn * dn);
+            g = k * g;
+            double jq[4];
+            qrot_jac_row(Q, cp, g, jq);
+            double J[7] = {g.x, g.y, g.z, jq[0], jq[1], jq[2], jq[3]};
+            cost = robustify(P.loss, P.loss_a, J, r);
 #pragma unroll
-        for (int kk = 0; kk < 7; kk++) Jr[kk] = J[kk];
-        Jr[7] = r;
+            for (int kk = 0; kk < 7; kk++) Jr[kk] = J[kk];
+            Jr[7] = r;
+        }
+        ga.add_rows(Jr, cost, ok, lds);
     }
-    gram_block_reduce(Jr, cost, ok, lds, partials + (size_t)blockIdx.x * kPartialDoubles);
+    ga.finish(lds, partials + (size_t)blockIdx.x * kPartialDoubles);
 }
 
 // ================================================================================================
-// Final reduction of block partials (fixed order) -> 72-double record, and the Gauss-Newton update.
+// Final reduction of block partials (fixed order) -> 72-double record, optionally followed by the
+// Gauss-Newton update in the same launch (single-GPU path; multi-GPU callers all-reduce in between).
 // out: [0..63] full symmetric 8x8 Gram (row-major), [64] cost, [65] n_surf, [66] n_edge.
+//
+// GN step (device mirror of ceres::QuaternionParameterization):
+//   P = blockdiag(I3, plusJacobian(q) 4x3); H = P^T G77 P, g = P^T G7r; solve H d = -g (Cholesky);
+//   t += d[0:3]; q = [cos|dq|, sin|dq|/|dq| dq] (x) q
 // ================================================================================================
-__global__ __launch_bounds__(kBlock) void k_reduce_partials(const double* __restrict__ part_surf, int nb_surf,
-                                                            const double* __restrict__ part_edge, int nb_edge,
-                                                            double* __restrict__ out, SlotState* __restrict__ state, int reset_counts) {
-    __shared__ double acc[4][2][40];
-    int e = threadIdx.x & 63, g = threadIdx.x >> 6;
-    if (e < 40) {
-        double s = 0.0, s2 = 0.0;
-        for (int b = g; b < nb_surf; b += 4) s += part_surf[(size_t)b * kPartialDoubles + e];
-        for (int b = g; b < nb_edge; b += 4) s2 += part_edge[(size_t)b * kPartialDoubles + e];
-        acc[g][0][e] = s; acc[g][1][e] = s2;
-    }
-    __syncthreads();
-    __shared__ double tri[40];
-    if (threadIdx.x < 40) {
-        int k = threadIdx.x;
-        double ss = ((acc[0][0][k] + acc[1][0][k]) + (acc[2][0][k] + acc[3][0][k]));
-        double se = ((acc[0][1][k] + acc[1][1][k]) + (acc[2][1][k] + acc[3][1][k]));
-        tri[k] = ss + se;
-        if (k == 37) { out[65] = ss; out[66] = se; }
-    }
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        int r = threadIdx.x >> 3, c = threadIdx.x & 7;
-        int a = r < c ? r : c, b = r < c ? c : r;
-        int idx = a * 8 - a * (a - 1) / 2 + (b - a);
-        out[threadIdx.x] = tri[idx];
-    }
-    if (threadIdx.x == 64) out[64] = tri[36];
-    if (threadIdx.x >= 67 && threadIdx.x < 72) out[threadIdx.x] = 0.0;
-    // the correspondence counters are consumed: reset them for the next associate of this slot
-    if (threadIdx.x == 0 && state && reset_counts) { state->n_res[0] = 0; state->n_res[1] = 0; }
-}
-
-// One Gauss-Newton step (device mirror of the host/reference parameterisation):
-//   P = blockdiag(I3, plusJacobian(q) 4x3)  [ceres::QuaternionParameterization::ComputeJacobian]
-//   H = P^T G77 P, g = P^T G7r, solve H d = -g (Cholesky), t += d[0:3], q = [cos|dq|, sin|dq|/|dq| dq] (x) q
-__global__ void k_gn_update(const double* __restrict__ gram, SlotState* __restrict__ state) {
-    __shared__ double Pm[7][6];
-    __shared__ double H[6][6];
-    __shared__ double gvec[6];
+__device__ void gn_update_block(const double* gram /*LDS or global, 64+*/, SlotState* __restrict__ state, double (*Pm)[6], double (*H)[6], double* gvec) {
     int tid = threadIdx.x;
     const double x0 = state->pose[3], x1 = state->pose[4], x2 = state->pose[5], x3 = state->pose[6];
     if (tid < 42) {
@@ -527,8 +520,11 @@ __global__ void k_gn_update(const double* __restrict__ gram, SlotState* __restri
         if (r < 3) v = (r == c) ? 1.0 : 0.0;
         else if (c >= 3) {
             int rr = r - 3, cc = c - 3;
-            const double tab[4][3] = {{-x1, -x2, -x3}, {x0, x3, -x2}, {-x3, x0, x1}, {x2, -x1, x0}};
-            v = tab[rr][cc];
+            // rows of the plus-Jacobian: [-x1 -x2 -x3; x0 x3 -x2; -x3 x0 x1; x2 -x1 x0]
+            double e0 = rr == 0 ? -x1 : rr == 1 ? x0 : rr == 2 ? -x3 : x2;
+            double e1 = rr == 0 ? -x2 : rr == 1 ? x3 : rr == 2 ? x0 : -x1;
+            double e2 = rr == 0 ? -x3 : rr == 1 ? -x2 : rr == 2 ? x1 : x0;
+            v = cc == 0 ? e0 : cc == 1 ? e1 : e2;
         }
         Pm[r][c] = v;
     }
@@ -558,26 +554,71 @@ __global__ void k_gn_update(const double* __restrict__ gram, SlotState* __restri
                 H[i][j] = s / d;
             }
         }
-        double d[6];
         if (okc) {
-            for (int i = 0; i < 6; i++) { double s = gvec[i]; for (int k = 0; k < i; k++) s -= H[i][k] * d[k]; d[i] = s / H[i][i]; }
-            for (int i = 5; i >= 0; i--) { double s = d[i]; for (int k = i + 1; k < 6; k++) s -= H[k][i] * d[k]; d[i] = s / H[i][i]; }
-            for (int i = 0; i < 6; i++) if (!(d[i] == d[i])) okc = false;
+            for (int i = 0; i < 6; i++) { double s = gvec[i]; for (int k = 0; k < i; k++) s -= H[i][k] * gvec[k]; gvec[i] = s / H[i][i]; }
+            for (int i = 5; i >= 0; i--) { double s = gvec[i]; for (int k = i + 1; k < 6; k++) s -= H[k][i] * gvec[k]; gvec[i] = s / H[i][i]; }
+            for (int i = 0; i < 6; i++) if (!(gvec[i] == gvec[i])) okc = false;
         }
         if (okc) {
-            state->pose[0] += d[0]; state->pose[1] += d[1]; state->pose[2] += d[2];
-            double nd = sqrt(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+            state->pose[0] += gvec[0]; state->pose[1] += gvec[1]; state->pose[2] += gvec[2];
+            double nd = sqrt(gvec[3] * gvec[3] + gvec[4] * gvec[4] + gvec[5] * gvec[5]);
             if (nd > 0.0) {
                 double sbd = sin(nd) / nd;
-                dq qd{cos(nd), sbd * d[3], sbd * d[4], sbd * d[5]};
+                dq qd{cos(nd), sbd * gvec[3], sbd * gvec[4], sbd * gvec[5]};
                 dq r = qmul(qd, dq{x0, x1, x2, x3});
                 state->pose[3] = r.w; state->pose[4] = r.x; state->pose[5] = r.y; state->pose[6] = r.z;
             }
-            for (int i = 0; i < 6; i++) state->last_delta[i] = d[i];
+            for (int i = 0; i < 6; i++) state->last_delta[i] = gvec[i];
             state->gn_status = 0;
         } else state->gn_status = 1;
         state->iters += 1;
     }
+}
+
+__global__ __launch_bounds__(kBlock) void k_reduce_partials(const double* __restrict__ part_surf, int nb_surf,
+                                                            const double* __restrict__ part_edge, int nb_edge,
+                                                            double* __restrict__ out, SlotState* __restrict__ state, int reset_counts, int do_gn) {
+    __shared__ double acc[4][2][40];
+    __shared__ double tri[40];
+    __shared__ double full[72];
+    __shared__ double Pm[7][6];
+    __shared__ double H[6][6];
+    __shared__ double gvec[6];
+    int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+    if (e < 40) {
+        double s = 0.0, s2 = 0.0;
+        for (int b = g; b < nb_surf; b += 4) s += part_surf[(size_t)b * kPartialDoubles + e];
+        for (int b = g; b < nb_edge; b += 4) s2 += part_edge[(size_t)b * kPartialDoubles + e];
+        acc[g][0][e] = s; acc[g][1][e] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x < 40) {
+        int k = threadIdx.x;
+        double ss = ((acc[0][0][k] + acc[1][0][k]) + (acc[2][0][k] + acc[3][0][k]));
+        double se = ((acc[0][1][k] + acc[1][1][k]) + (acc[2][1][k] + acc[3][1][k]));
+        tri[k] = ss + se;
+        if (k == 37) { full[65] = ss; full[66] = se; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        int r = threadIdx.x >> 3, c = threadIdx.x & 7;
+        int a = r < c ? r : c, b = r < c ? c : r;
+        full[threadIdx.x] = tri[a * 8 - a * (a - 1) / 2 + (b - a)];
+    }
+    if (threadIdx.x == 64) full[64] = tri[36];
+    if (threadIdx.x >= 67 && threadIdx.x < 72) full[threadIdx.x] = 0.0;
+    __syncthreads();
+    if (threadIdx.x < 72) out[threadIdx.x] = full[threadIdx.x];
+    // the correspondence counters are consumed: reset them for the next associate of this slot
+    if (threadIdx.x == 0 && state && reset_counts) { state->n_res[0] = 0; state->n_res[1] = 0; }
+    if (do_gn) gn_update_block(full, state, Pm, H, gvec);
+}
+
+__global__ void k_gn_update(const double* __restrict__ gram, SlotState* __restrict__ state) {
+    __shared__ double Pm[7][6];
+    __shared__ double H[6][6];
+    __shared__ double gvec[6];
+    gn_update_block(gram, state, Pm, H, gvec);
 }
 
 }  // namespace lili

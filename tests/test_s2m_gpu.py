@@ -32,6 +32,8 @@ def _setup(gpu_ctx, oracle, variant, room, with_refl):
 
 def _pose(room, P, variant, rng=None, dt=0.0, dang=0.0):
     t, q = room["t_true"].copy(), room["q_true"].copy()
+    if variant != "frontend":
+        t, q = L.api.body_pose_from_lidar(t, q, P)      # room poses are LiDAR poses
     if rng is not None:
         t, q = synth.perturbed_pose(t, q, rng, dt, dang)
     if variant == "frontend":
@@ -51,7 +53,7 @@ def test_association_parity(gpu_ctx, oracle, variant):
     room = synth.make_room(seed=11, n_query=6000, n_edge_query=600)
     P, PO, m = _setup(gpu_ctx, oracle, variant, room, with_refl=(variant == "livox"))
     rng = np.random.default_rng(5)
-    t, q, Q2, T2 = _pose(room, P, variant, rng, 0.05, 0.5)
+    t, q, Q2, T2 = _pose(room, P, variant, rng, 0.02, 0.1)   # ROT keeps edges only within 0.1 m of the line
     n_s = m.find_corresponding_surf_features(0, Q2, T2)
     n_e = m.find_corresponding_corner_features(0, Q2, T2)
     tree = oracle.KdTree(room["map_xyz"])
@@ -160,7 +162,8 @@ def test_gauss_newton_pose_parity(gpu_ctx, oracle, variant):
     room = synth.make_room(seed=14, n_query=8000, n_edge_query=800, noise=0.005)
     P, PO, m = _setup(gpu_ctx, oracle, variant, room, with_refl=(variant == "livox"))
     rng = np.random.default_rng(synth.SEED_POSE)
-    t0, q0 = synth.perturbed_pose(room["t_true"], room["q_true"], rng, 0.15, 1.0)
+    t_ref, q_ref, _, _ = _pose(room, P, variant)
+    t0, q0 = synth.perturbed_pose(t_ref, q_ref, rng, 0.15, 1.0)
     mask = L.MASK_SURF if variant == "frontend" else (L.MASK_SURF | L.MASK_EDGE)
     m.pose_set(0, t0, q0)
     m.iterate(0, 10, mask)
@@ -192,14 +195,17 @@ def test_gauss_newton_pose_parity(gpu_ctx, oracle, variant):
     dq = synth.quat_mul(qg * np.array([1, -1, -1, -1]), q)
     ang = 2 * np.arcsin(min(1.0, np.linalg.norm(dq[1:])))
     assert ang < 1e-4
-    # and the iteration did converge towards the truth
-    assert np.linalg.norm(tg - room["t_true"]) < np.linalg.norm(t0 - room["t_true"])
+    # and the iteration did converge towards the truth (the edge factor ignores the extrinsic — SURVEY F6 —
+    # so with a non-trivial q_lb it pulls away from it; only the plane-only variant is asserted)
+    if variant == "frontend":
+        assert np.linalg.norm(tg - t_ref) < 0.3 * np.linalg.norm(t0 - t_ref)
 
 
 def test_host_pose_and_device_pose_paths_agree(gpu_ctx, oracle):
     room = synth.make_room(seed=15, n_query=3000, n_edge_query=300)
     P, PO, m = _setup(gpu_ctx, oracle, "rot", room, with_refl=False)
-    t0, q0 = synth.perturbed_pose(room["t_true"], room["q_true"], np.random.default_rng(3), 0.1, 0.5)
+    tb, qb = L.api.body_pose_from_lidar(room["t_true"], room["q_true"], P)
+    t0, q0 = synth.perturbed_pose(tb, qb, np.random.default_rng(3), 0.1, 0.5)
     Q2, T2 = L.api.assoc_transform(t0, q0, P)
     m.find_corresponding_surf_features(0, Q2, T2)
     G, cost, counts = m.linearize(0, t0, q0, L.MASK_SURF)
@@ -236,7 +242,7 @@ def test_edge_cases(gpu_ctx, oracle):
     far[:100] += 1000.0
     far[100] = np.nan
     m.set_queries(0, L.KIND_SURF, far)
-    Q2, T2 = L.api.assoc_transform(room["t_true"], room["q_true"], P)
+    Q2, T2 = room["q_true"], room["t_true"]       # association transform = LiDAR pose
     n = m.find_corresponding_surf_features(0, Q2, T2)
     tree = oracle.KdTree(room["map_xyz"])
     rs = oracle.associate_surf(tree, None, far, None, Q2, T2, PO)
