@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--n-map", type=int, default=N_MAP)
     ap.add_argument("--n-az", type=int, default=N_AZ)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bin", action="store_true", help="disable the once-per-scan query binning (A/B only)")
     args = ap.parse_args()
 
     import torch
@@ -139,6 +140,8 @@ def main():
     torch.cuda.set_stream(tstream)
     assert tstream.cuda_stream != 0
     ctx = L.Context(local_rank, stream=tstream.cuda_stream)
+    if args.no_bin:
+        ctx.set_option("bin_queries", 0)
     m = L.ScanToMapMatcher(ctx, P)
     tic = time.perf_counter()
     m.set_input_cloud(L.KIND_SURF, w["map_xyz"])
@@ -248,8 +251,9 @@ def _allreduce_counts(m, dist, dev):
     """All-reduce (sum) the slot's two correspondence counters in place (ROT residual scale = num / GLOBAL N)."""
     global _counts_tensor
     import torch
+    ptr = m.counts_ptr(0)          # enqueues the reduction of this rank's per-block counts into int[2]
     if _counts_tensor is None:
-        _counts_tensor = _tensor_from_ptr(m.counts_ptr(0), 2, dev)
+        _counts_tensor = _tensor_from_ptr(ptr, 2, dev)
     dist.all_reduce(_counts_tensor)
 
 

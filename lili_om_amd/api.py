@@ -81,6 +81,7 @@ _SIGS = {
     "lili_last_error": (C.c_char_p, [C.c_void_p]),
     "lili_sync": (C.c_int, [C.c_void_p]),
     "lili_set_debug": (C.c_int, [C.c_void_p, C.c_int]),
+    "lili_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "lili_map_set": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Cloud), C.c_double]),
     "lili_map_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "lili_s2m_set_queries": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Cloud)]),
@@ -173,6 +174,9 @@ class Context:
 
     def sync(self):
         self._chk(self.lib.lili_sync(self.h))
+
+    def set_option(self, name, value):
+        self._chk(self.lib.lili_set_option(self.h, name.encode(), int(value)))
 
     def set_debug(self, keep_neighbors=True):
         self._chk(self.lib.lili_set_debug(self.h, int(bool(keep_neighbors))))

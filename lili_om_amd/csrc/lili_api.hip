@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -19,11 +20,14 @@ __global__ void k_scan_block_sums(const int*, int64_t, int*);
 __global__ void k_scan_sums(int*, int);
 __global__ void k_scan_apply(const int*, int64_t, const int*, int*);
 __global__ void k_scatter(const float4*, int, const int*, const int*, int*, float4*, float*);
-__global__ void k_associate_surf(const float4*, const int*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, SlotState*);
-__global__ void k_associate_edge(const float4*, const int*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, SlotState*);
-__global__ void k_linearize_surf(const float4*, int, const float4*, const double*, const unsigned char*, PoseArg, MatchParams, const SlotState*, double*);
-__global__ void k_linearize_edge(const float4*, int, const float4*, const float4*, const unsigned char*, PoseArg, MatchParams, const SlotState*, double*);
-__global__ void k_reduce_partials(const double*, int, const double*, int, double*, SlotState*, int, int);
+__global__ void k_bin_count(const float4*, int, GridView, PoseArg, MatchParams, int, int, int*, int*);
+__global__ void k_bin_scatter(const int*, int, const int*, int*, int*);
+__global__ void k_associate_surf(const float4*, const int*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, int*);
+__global__ void k_associate_edge(const float4*, const int*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, int*);
+__global__ void k_linearize_surf(const float4*, int, const float4*, const double*, const unsigned char*, PoseArg, MatchParams, const SlotState*, const int*, int, double*);
+__global__ void k_linearize_edge(const float4*, int, const float4*, const float4*, const unsigned char*, PoseArg, MatchParams, const SlotState*, const int*, int, double*);
+__global__ void k_reduce_partials(const double*, int, const double*, int, double*, SlotState*, int);
+__global__ void k_sum_counts(const int*, int, const int*, int, SlotState*);
 __global__ void k_gn_update(const double*, SlotState*);
 }  // namespace lili
 
@@ -58,17 +62,18 @@ struct MapIndex {
 struct KindSlot {
     int64_t n_q = 0;
     bool has_queries = false, has_records = false;
-    DevBuf q, rec0, rec1, valid, dbg_idx, dbg_d2, partials;
+    DevBuf q, rec0, rec1, valid, dbg_idx, dbg_d2, partials, perm, keys, block_counts;
+    bool binned = false;   // perm holds the super-cell (Morton) order of the queries for the current scan
     int n_blocks = 0;      // association grid (one thread per query)
     int n_lin_blocks = 0;  // linearisation grid (grid-stride, <= kMaxLinBlocks partials)
 };
 
 struct Slot {
     KindSlot k[2];
-    bool counts_clean = true;   // device n_res[] known to be zero
+    bool use_global_counts = false;   // next linearize_dev reads the (all-reduced) counts in SlotState::n_res
 };
 
-constexpr int kMaxLinBlocks = 256;
+constexpr int kMaxLinBlocks = 1024;
 constexpr size_t kLdsLinearize = (size_t)(kBlock * 9 + 4 * 40) * sizeof(double);
 
 }  // namespace
@@ -85,6 +90,8 @@ struct lili_ctx {
     DevBuf staging;      // raw host clouds
     DevBuf gram;         // LILI_GRAM_DOUBLES per slot
     DevBuf misc;         // bbox words etc.
+    DevBuf bin_hist, bin_start, bin_sums;   // query binning scratch
+    bool bin_queries = true;
     int max_cells = 1 << 26;
 
     int fail(int code, const std::string& m) { err = m; return code; }
@@ -109,6 +116,8 @@ static MatchParams to_device_params(const lili_s2m_params* p) {
     for (int i = 0; i < 4; i++) m.q_lb[i] = p->q_lb[i];
     for (int i = 0; i < 3; i++) m.t_lb[i] = p->t_lb[i];
     m.scale_surf_num = p->scale_surf_num; m.scale_edge_num = p->scale_edge_num;
+    static const int dbg = std::getenv("LILI_DEBUG") ? std::atoi(std::getenv("LILI_DEBUG")) : 0;
+    m.debug = dbg;
     return m;
 }
 
@@ -168,8 +177,8 @@ void lili_ctx_destroy(lili_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& m : ctx->map) { m.pts.release(); m.sorted.release(); m.aux_sorted.release(); m.cell_start.release(); m.cell_tmp.release(); m.pt_cell.release(); m.block_sums.release(); }
-    for (auto& s : ctx->slots) for (auto& k : s.k) { k.q.release(); k.rec0.release(); k.rec1.release(); k.valid.release(); k.dbg_idx.release(); k.dbg_d2.release(); k.partials.release(); }
-    ctx->states.release(); ctx->staging.release(); ctx->gram.release(); ctx->misc.release();
+    for (auto& s : ctx->slots) for (auto& k : s.k) { k.q.release(); k.rec0.release(); k.rec1.release(); k.valid.release(); k.dbg_idx.release(); k.dbg_d2.release(); k.partials.release(); k.perm.release(); k.keys.release(); k.block_counts.release(); }
+    ctx->states.release(); ctx->staging.release(); ctx->gram.release(); ctx->misc.release(); ctx->bin_hist.release(); ctx->bin_start.release(); ctx->bin_sums.release();
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -188,6 +197,13 @@ int lili_set_debug(lili_ctx* ctx, int keep_neighbors) {
     return LILI_OK;
 }
 
+int lili_set_option(lili_ctx* ctx, const char* name, int value) {
+    if (!ctx || !name) return LILI_E_ARG;
+    if (std::strcmp(name, "bin_queries") == 0) { ctx->bin_queries = value != 0; for (auto& s : ctx->slots) for (auto& k : s.k) k.binned = false; return LILI_OK; }
+    if (std::strcmp(name, "max_cells") == 0) { if (value < 1) return ctx->fail(LILI_E_ARG, "max_cells must be positive"); ctx->max_cells = value; return LILI_OK; }
+    return ctx->fail(LILI_E_ARG, std::string("unknown option ") + name);
+}
+
 // --------------------------------------------------------------------------------------------
 // map index
 // --------------------------------------------------------------------------------------------
@@ -199,6 +215,7 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
     HIPCHK(hipSetDevice(ctx->device));
     MapIndex& m = ctx->map[kind];
     m.valid = false;
+    for (auto& s : ctx->slots) s.k[kind].binned = false;
     int rc = ingest_cloud(ctx, cloud, m.pts);
     if (rc != LILI_OK) return rc;
     m.n = (int64_t)cloud->n;
@@ -211,7 +228,7 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
     unsigned init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
     unsigned* d_mm = ctx->misc.as<unsigned>();
     HIPCHK(hipMemcpyAsync(d_mm, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_bbox, dim3(std::min(nblocks(n, kBlock), 2048)), dim3(kBlock), 0, ctx->stream, m.pts.as<float4>(), n, d_mm);
+    hipLaunchKernelGGL(k_bbox, dim3(std::min(nblocks(n, kBlock), 512)), dim3(kBlock), 0, ctx->stream, m.pts.as<float4>(), n, d_mm);
     HIPCHK(hipGetLastError());
     unsigned mm[6];
     HIPCHK(hipMemcpyAsync(mm, d_mm, sizeof(mm), hipMemcpyDeviceToHost, ctx->stream));
@@ -283,7 +300,7 @@ int lili_s2m_set_queries(lili_ctx* ctx, int slot, int kind, const lili_cloud* cl
     ARGCHK(cloud, "set_queries: null cloud");
     HIPCHK(hipSetDevice(ctx->device));
     KindSlot& ks = ctx->slots[slot].k[kind];
-    ks.has_queries = false; ks.has_records = false;
+    ks.has_queries = false; ks.has_records = false; ks.binned = false;
     int rc = ingest_cloud(ctx, cloud, ks.q);
     if (rc != LILI_OK) return rc;
     ks.n_q = (int64_t)cloud->n;
@@ -295,8 +312,43 @@ int lili_s2m_set_queries(lili_ctx* ctx, int slot, int kind, const lili_cloud* cl
         HIPCHK(ks.rec1.ensure(n * sizeof(float4)));   // surf: doubles (8 B) fit in the float4 budget
         HIPCHK(ks.valid.ensure(n));
         HIPCHK(ks.partials.ensure((size_t)ks.n_blocks * kPartialDoubles * sizeof(double)));
+        HIPCHK(ks.block_counts.ensure((size_t)ks.n_blocks * sizeof(int)));
     }
     ks.has_queries = true;
+    return LILI_OK;
+}
+
+// Orders the queries of one scan by the Morton code of the map super-cell they fall into at the pose of
+// their first association (counting sort: histogram, exclusive scan, scatter).  Done once per set_queries;
+// later poses of the same scan move the points by centimetres..metres, which keeps the order coherent.
+static int bin_queries(lili_ctx* ctx, KindSlot& ks, MapIndex& m, const PoseArg& pa, const MatchParams& P) {
+    const int n = (int)ks.n_q;
+    int sb_shift = 3;   // 8 x 8 cells per super-cell
+    int bits;
+    for (;;) {
+        int nsx = ((m.view.nx - 1) >> sb_shift) + 1, nsy = ((m.view.ny - 1) >> sb_shift) + 1;
+        int mx = std::max(nsx, nsy);
+        bits = 0; while ((1 << bits) < mx) bits++;
+        if (2 * bits <= 20) break;
+        sb_shift++;
+    }
+    const int n_bins = (1 << (2 * bits)) + 1;
+    HIPCHK(ks.perm.ensure((size_t)n * sizeof(int)));
+    HIPCHK(ks.keys.ensure((size_t)n * sizeof(int)));
+    HIPCHK(ctx->bin_hist.ensure((size_t)n_bins * sizeof(int)));
+    HIPCHK(ctx->bin_start.ensure((size_t)(n_bins + 1) * sizeof(int)));
+    const int nb_scan = nblocks(n_bins, 2048);
+    HIPCHK(ctx->bin_sums.ensure((size_t)nb_scan * sizeof(int)));
+    HIPCHK(hipMemsetAsync(ctx->bin_hist.p, 0, (size_t)n_bins * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_bin_count, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, ks.q.as<float4>(), n, m.view, pa, P, sb_shift, n_bins,
+                       ks.keys.as<int>(), ctx->bin_hist.as<int>());
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb_scan), dim3(kBlock), 0, ctx->stream, ctx->bin_hist.as<int>(), (int64_t)n_bins, ctx->bin_sums.as<int>());
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->bin_sums.as<int>(), nb_scan);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb_scan), dim3(kBlock), 0, ctx->stream, ctx->bin_hist.as<int>(), (int64_t)n_bins, ctx->bin_sums.as<int>(), ctx->bin_start.as<int>());
+    HIPCHK(hipMemsetAsync(ctx->bin_hist.p, 0, (size_t)n_bins * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_bin_scatter, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, ks.keys.as<int>(), n, ctx->bin_start.as<int>(), ctx->bin_hist.as<int>(), ks.perm.as<int>());
+    HIPCHK(hipGetLastError());
+    ks.binned = true;
     return LILI_OK;
 }
 
@@ -319,16 +371,22 @@ static int launch_associate(lili_ctx* ctx, int slot, int kind, const PoseArg& pa
     }
     if (m.n < 5) {   // fewer than 5 map points: the reference reads pt_search_sq_dists[4] out of bounds; we reject all
         HIPCHK(hipMemsetAsync(ks.valid.p, 0, (size_t)n, ctx->stream));
+        HIPCHK(hipMemsetAsync(ks.block_counts.p, 0, (size_t)ks.n_blocks * sizeof(int), ctx->stream));
         if (dbg_i) { HIPCHK(hipMemsetAsync(dbg_i, 0xFF, (size_t)n * 5 * sizeof(int), ctx->stream)); HIPCHK(hipMemsetAsync(dbg_d, 0x7F, (size_t)n * 5 * sizeof(float), ctx->stream)); }
         return LILI_OK;
     }
+    const int* perm = nullptr;
+    if (ctx->bin_queries && n >= 4 * kBlock) {
+        if (!ks.binned) { int rc = bin_queries(ctx, ks, m, pa, P); if (rc != LILI_OK) return rc; }
+        perm = ks.perm.as<int>();
+    }
     if (kind == LILI_KIND_SURF) {
         if (P.variant == LILI_VARIANT_LIVOX && !m.has_aux) return ctx->fail(LILI_E_STATE, "associate: Livox variant needs reflectivity (aux_offset) on the surf map");
-        hipLaunchKernelGGL(k_associate_surf, dim3(ks.n_blocks), dim3(kBlock), 0, ctx->stream, ks.q.as<float4>(), (const int*)nullptr, n, m.view, pa, P,
-                           ks.rec0.as<float4>(), ks.rec1.as<double>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ctx->state(slot));
+        hipLaunchKernelGGL(k_associate_surf, dim3(ks.n_blocks), dim3(kBlock), 0, ctx->stream, ks.q.as<float4>(), perm, n, m.view, pa, P,
+                           ks.rec0.as<float4>(), ks.rec1.as<double>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>());
     } else {
-        hipLaunchKernelGGL(k_associate_edge, dim3(ks.n_blocks), dim3(kBlock), 0, ctx->stream, ks.q.as<float4>(), (const int*)nullptr, n, m.view, pa, P,
-                           ks.rec0.as<float4>(), ks.rec1.as<float4>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ctx->state(slot));
+        hipLaunchKernelGGL(k_associate_edge, dim3(ks.n_blocks), dim3(kBlock), 0, ctx->stream, ks.q.as<float4>(), perm, n, m.view, pa, P,
+                           ks.rec0.as<float4>(), ks.rec1.as<float4>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>());
     }
     HIPCHK(hipGetLastError());
     return LILI_OK;
@@ -339,22 +397,35 @@ static int launch_linearize(lili_ctx* ctx, int slot, int kind, const PoseArg& pa
     if (!ks.has_records) return ctx->fail(LILI_E_STATE, "linearize: associate first");
     if (ks.n_q == 0) return LILI_OK;
     const int n = (int)ks.n_q;
+    const int* bc = ctx->slots[slot].use_global_counts ? nullptr : ks.block_counts.as<int>();
     if (kind == LILI_KIND_SURF)
         hipLaunchKernelGGL(k_linearize_surf, dim3(ks.n_lin_blocks), dim3(kBlock), kLdsLinearize, ctx->stream, ks.q.as<float4>(), n, ks.rec0.as<float4>(),
-                           ks.rec1.as<double>(), ks.valid.as<unsigned char>(), pa, P, ctx->state(slot), ks.partials.as<double>());
+                           ks.rec1.as<double>(), ks.valid.as<unsigned char>(), pa, P, ctx->state(slot), bc, ks.n_blocks, ks.partials.as<double>());
     else
         hipLaunchKernelGGL(k_linearize_edge, dim3(ks.n_lin_blocks), dim3(kBlock), kLdsLinearize, ctx->stream, ks.q.as<float4>(), n, ks.rec0.as<float4>(),
-                           ks.rec1.as<float4>(), ks.valid.as<unsigned char>(), pa, P, ctx->state(slot), ks.partials.as<double>());
+                           ks.rec1.as<float4>(), ks.valid.as<unsigned char>(), pa, P, ctx->state(slot), bc, ks.n_blocks, ks.partials.as<double>());
     HIPCHK(hipGetLastError());
     return LILI_OK;
 }
 
-static int launch_reduce(lili_ctx* ctx, int slot, int kind_mask, double* d_out, int reset_counts, int do_gn) {
+// sums the per-block correspondence counts of the last association(s) into SlotState::n_res
+static int launch_sum_counts(lili_ctx* ctx, int slot, int kind_mask) {
+    Slot& s = ctx->slots[slot];
+    const int* bs = nullptr; const int* be = nullptr; int nbs = 0, nbe = 0;
+    if ((kind_mask & LILI_MASK_SURF) && s.k[0].has_records && s.k[0].n_q > 0) { bs = s.k[0].block_counts.as<int>(); nbs = s.k[0].n_blocks; }
+    if ((kind_mask & LILI_MASK_EDGE) && s.k[1].has_records && s.k[1].n_q > 0) { be = s.k[1].block_counts.as<int>(); nbe = s.k[1].n_blocks; }
+    HIPCHK(hipMemsetAsync(ctx->state(slot)->n_res, 0, 2 * sizeof(int), ctx->stream));
+    if (bs || be) hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(kBlock), 0, ctx->stream, bs, nbs, be, nbe, ctx->state(slot));
+    HIPCHK(hipGetLastError());
+    return LILI_OK;
+}
+
+static int launch_reduce(lili_ctx* ctx, int slot, int kind_mask, double* d_out, int do_gn) {
     Slot& s = ctx->slots[slot];
     const double* ps = nullptr; const double* pe = nullptr; int nbs = 0, nbe = 0;
     if ((kind_mask & LILI_MASK_SURF) && s.k[0].n_q > 0) { ps = s.k[0].partials.as<double>(); nbs = s.k[0].n_lin_blocks; }
     if ((kind_mask & LILI_MASK_EDGE) && s.k[1].n_q > 0) { pe = s.k[1].partials.as<double>(); nbe = s.k[1].n_lin_blocks; }
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, ctx->stream, ps, nbs, pe, nbe, d_out, ctx->state(slot), reset_counts, do_gn);
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx->stream, ps, nbs, pe, nbe, d_out, ctx->state(slot), do_gn);
     HIPCHK(hipGetLastError());
     return LILI_OK;
 }
@@ -371,11 +442,12 @@ int lili_s2m_associate(lili_ctx* ctx, int slot, int kind, const double t_assoc[3
     for (int i = 0; i < 4; i++) pa.q[i] = q_assoc[i];
     pa.state = nullptr; pa.derive_assoc = 0;
     MatchParams P = to_device_params(params);
-    HIPCHK(hipMemsetAsync(&ctx->state(slot)->n_res[kind], 0, sizeof(int), ctx->stream));
-    ctx->slots[slot].counts_clean = false;
+    ctx->slots[slot].use_global_counts = false;
     int rc = launch_associate(ctx, slot, kind, pa, P);
     if (rc != LILI_OK) return rc;
     if (n_res) {
+        rc = launch_sum_counts(ctx, slot, 1 << kind);
+        if (rc != LILI_OK) return rc;
         HIPCHK(hipMemcpyAsync(n_res, &ctx->state(slot)->n_res[kind], sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
     }
@@ -394,7 +466,7 @@ int lili_s2m_linearize(lili_ctx* ctx, int slot, int kind_mask, const double t[3]
     for (int i = 0; i < 4; i++) pa.q[i] = q[i];
     MatchParams P = to_device_params(params);
     for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) { int rc = launch_linearize(ctx, slot, kind, pa, P); if (rc != LILI_OK) return rc; }
-    int rc = launch_reduce(ctx, slot, kind_mask, ctx->gram_of(slot), 0, 0);
+    int rc = launch_reduce(ctx, slot, kind_mask, ctx->gram_of(slot), 0);
     if (rc != LILI_OK) return rc;
     double host[LILI_GRAM_DOUBLES];
     HIPCHK(hipMemcpyAsync(host, ctx->gram_of(slot), sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
@@ -499,7 +571,6 @@ int lili_s2m_pose_set(lili_ctx* ctx, int slot, const double t[3], const double q
     for (int i = 0; i < 4; i++) s.pose[3 + i] = q[i];
     HIPCHK(hipMemcpyAsync(ctx->state(slot), &s, sizeof(s), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));   // `s` is on this stack frame
-    ctx->slots[slot].counts_clean = true;
     return LILI_OK;
 }
 
@@ -523,8 +594,7 @@ int lili_s2m_associate_dev(lili_ctx* ctx, int slot, int kind_mask, const lili_s2
     ARGCHK(params, "associate_dev: null argument");
     HIPCHK(hipSetDevice(ctx->device));
     Slot& s = ctx->slots[slot];
-    if (!s.counts_clean) { HIPCHK(hipMemsetAsync(ctx->state(slot)->n_res, 0, 2 * sizeof(int), ctx->stream)); }
-    s.counts_clean = false;
+    s.use_global_counts = false;
     PoseArg pa{};
     pa.state = ctx->state(slot);
     pa.derive_assoc = params->variant == LILI_VARIANT_FRONTEND ? 0 : 1;
@@ -539,6 +609,10 @@ int lili_s2m_associate_dev(lili_ctx* ctx, int slot, int kind_mask, const lili_s2
 int lili_s2m_counts_ptr(lili_ctx* ctx, int slot, int** d_counts) {
     if (!ctx) return LILI_E_ARG;
     ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS && d_counts, "counts_ptr: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc = launch_sum_counts(ctx, slot, LILI_MASK_SURF | LILI_MASK_EDGE);
+    if (rc != LILI_OK) return rc;
+    ctx->slots[slot].use_global_counts = true;   // the next linearize_dev scales with these (possibly all-reduced) counts
     *d_counts = ctx->state(slot)->n_res;
     return LILI_OK;
 }
@@ -556,9 +630,9 @@ static int linearize_dev_impl(lili_ctx* ctx, int slot, int kind_mask, const lili
         int rc = launch_linearize(ctx, slot, kind, pa, P);
         if (rc != LILI_OK) return rc;
     }
-    int rc = launch_reduce(ctx, slot, kind_mask, d_gram, 1, do_gn);
+    int rc = launch_reduce(ctx, slot, kind_mask, d_gram, do_gn);
     if (rc != LILI_OK) return rc;
-    ctx->slots[slot].counts_clean = true;
+    ctx->slots[slot].use_global_counts = false;
     return LILI_OK;
 }
 

@@ -45,9 +45,18 @@ __global__ void k_bbox(const float4* __restrict__ pts, int n, unsigned* __restri
     for (int k = 0; k < 3; k++) {
         for (int o = 32; o > 0; o >>= 1) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], o)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o)); }
     }
+    // one atomic set per BLOCK (same-address atomics serialise at ~12 ns each on MI355X)
+    __shared__ float smn[kBlock / 64][3], smx[kBlock / 64][3];
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) { atomicMin(&mm[k], f2ord(mn[k])); atomicMax(&mm[3 + k], f2ord(mx[k])); }
+        for (int k = 0; k < 3; k++) { smn[threadIdx.x >> 6][k] = mn[k]; smx[threadIdx.x >> 6][k] = mx[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        int k = threadIdx.x;
+        float a = smn[0][k], b = smx[0][k];
+        for (int w = 1; w < kBlock / 64; w++) { a = fminf(a, smn[w][k]); b = fmaxf(b, smx[w][k]); }
+        atomicMin(&mm[k], f2ord(a)); atomicMax(&mm[3 + k], f2ord(b));
     }
 }
 
@@ -131,6 +140,76 @@ __global__ void k_scatter(const float4* __restrict__ pts, int n, const int* __re
 }
 
 // ================================================================================================
+// Query binning (once per scan): order the queries by the Morton code of the map super-cell
+// (sb x sb cells in x,y) they fall into at the association pose, so that the 64 lanes of a wave walk
+// the same cell runs (coalesced / broadcast loads, uniform loop trip counts).  The order only decides
+// which thread handles which query — every per-query result is written at the query's own index, so
+// results do not depend on it.
+// ================================================================================================
+__device__ __forceinline__ unsigned part1by1(unsigned x) {
+    x &= 0x0000ffffu;
+    x = (x | (x << 8)) & 0x00ff00ffu;
+    x = (x | (x << 4)) & 0x0f0f0f0fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+__device__ __forceinline__ void load_assoc_pose(const PoseArg& pa, const MatchParams& P, dq& Q2, d3& T2);
+
+// atomicAdd(&arr[key], 1) for every active lane, issued as ONE atomic per distinct key per wave (queries
+// of a wave mostly share a bin; 200 k same-address atomics cost milliseconds).  Returns the value before
+// this wave's add for the lane's key; rank = the lane's position among the wave's lanes with that key.
+// Must be called by all 64 lanes.
+__device__ __forceinline__ int wave_aggregated_add(int* __restrict__ arr, int key, bool active, int& rank) {
+    const int lane = threadIdx.x & 63;
+    int result = 0;
+    rank = 0;
+    unsigned long long todo = __ballot(active);
+    while (todo) {
+        int leader = __ffsll((long long)todo) - 1;
+        int k0 = __shfl(key, leader);
+        unsigned long long m = __ballot(active && key == k0);
+        int old = 0;
+        if (lane == leader) old = atomicAdd(&arr[k0], __popcll(m));
+        old = __shfl(old, leader);
+        if (active && key == k0) { result = old; rank = __popcll(m & ((1ull << lane) - 1ull)); }
+        todo &= ~m;
+    }
+    return result;
+}
+
+__global__ void k_bin_count(const float4* __restrict__ queries, int n_q, GridView g, PoseArg pa, MatchParams P, int sb_shift, int n_bins,
+                            int* __restrict__ keys, int* __restrict__ hist) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_q) i = n_q - 1;   // keep whole waves alive for the aggregated atomics; duplicates are masked below
+    const bool live = blockIdx.x * blockDim.x + threadIdx.x < n_q;
+    dq Q2; d3 T2;
+    load_assoc_pose(pa, P, Q2, T2);
+    float4 ql = queries[i];
+    d3 pm = qrot(Q2, d3{(double)ql.x, (double)ql.y, (double)ql.z}) + T2;
+    float px = (float)pm.x, py = (float)pm.y;
+    int key = n_bins - 1;   // non-finite queries go last
+    if (isfinite(px) && isfinite(py)) {
+        double fx = ((double)px - g.ox) * g.inv_cell, fy = ((double)py - g.oy) * g.inv_cell;
+        int cx = (int)fmin(fmax(fx, 0.0), (double)(g.nx - 1));
+        int cy = (int)fmin(fmax(fy, 0.0), (double)(g.ny - 1));
+        unsigned k = part1by1((unsigned)(cx >> sb_shift)) | (part1by1((unsigned)(cy >> sb_shift)) << 1);
+        key = (int)min(k, (unsigned)(n_bins - 1));
+    }
+    if (live) keys[i] = key;
+    int rank;
+    wave_aggregated_add(hist, key, live, rank);
+}
+__global__ void k_bin_scatter(const int* __restrict__ keys, int n_q, const int* __restrict__ starts, int* __restrict__ fill, int* __restrict__ perm) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n_q;
+    int k = live ? keys[i] : 0;
+    int rank;
+    int base = wave_aggregated_add(fill, k, live, rank);
+    if (live) perm[starts[k] + base + rank] = i;
+}
+
+// ================================================================================================
 // exact 5-NN inside the 27-cell neighbourhood
 // ================================================================================================
 struct Top5 {
@@ -192,6 +271,40 @@ __device__ __forceinline__ void knn5_grid(const GridView& g, float qx, float qy,
     }
 }
 
+// Correspondence counting without atomics on a shared word (3128 same-address atomics cost ~40 us on
+// MI355X): each block stores its own count; consumers add the <= few-thousand block counts themselves.
+__device__ __forceinline__ void store_block_count(bool ok, int* __restrict__ block_counts) {
+    __shared__ int wave_cnt[kBlock / 64];
+    unsigned long long bal = __ballot(ok);
+    if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = __popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int s = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; w++) s += wave_cnt[w];
+        block_counts[blockIdx.x] = s;
+    }
+}
+// Sum of the per-block counts of one association launch (every thread of the block gets the total).
+__device__ __forceinline__ int sum_block_counts(const int* __restrict__ block_counts, int nb) {
+    __shared__ int part[kBlock / 64];
+    __shared__ int total;
+    int s = 0;
+    for (int b = threadIdx.x; b < nb; b += kBlock) s += block_counts[b];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < kBlock / 64; w++) t += part[w]; total = t; }
+    __syncthreads();
+    return total;
+}
+__global__ __launch_bounds__(kBlock) void k_sum_counts(const int* __restrict__ bc_surf, int nb_surf, const int* __restrict__ bc_edge, int nb_edge,
+                                                      SlotState* __restrict__ state) {
+    if (bc_surf) { int t = sum_block_counts(bc_surf, nb_surf); if (threadIdx.x == 0) state->n_res[0] = t; }
+    __syncthreads();
+    if (bc_edge) { int t = sum_block_counts(bc_edge, nb_edge); if (threadIdx.x == 0) state->n_res[1] = t; }
+}
+
 __device__ __forceinline__ void load_assoc_pose(const PoseArg& pa, const MatchParams& P, dq& Q2, d3& T2) {
     if (pa.state) {
         const double* s = pa.state->pose;
@@ -214,7 +327,7 @@ __device__ __forceinline__ void load_assoc_pose(const PoseArg& pa, const MatchPa
 __global__ __launch_bounds__(kBlock) void k_associate_surf(
         const float4* __restrict__ queries, const int* __restrict__ perm, int n_q, GridView g, PoseArg pa, MatchParams P,
         float4* __restrict__ rec_nd, double* __restrict__ rec_score, unsigned char* __restrict__ valid,
-        int* __restrict__ dbg_idx, float* __restrict__ dbg_d2, SlotState* __restrict__ state) {
+        int* __restrict__ dbg_idx, float* __restrict__ dbg_d2, int* __restrict__ block_counts) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     bool ok = false;
     if (t < n_q) {
@@ -225,7 +338,10 @@ __global__ __launch_bounds__(kBlock) void k_associate_surf(
         d3 pmd = qrot(Q2, d3{(double)ql.x, (double)ql.y, (double)ql.z}) + T2;   // transformPoint, L:695-711
         float px = (float)pmd.x, py = (float)pmd.y, pz = (float)pmd.z;
         Top5 nn;
-        knn5_grid(g, px, py, pz, nn);
+        if (P.debug & 2) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) { nn.d[k] = 0.01f * (k + 1); nn.j[k] = (i * 7 + k) % g.n_points; }
+        } else knn5_grid(g, px, py, pz, nn);
         if (dbg_idx) {
 #pragma unroll
             for (int k = 0; k < 5; k++) {
@@ -235,7 +351,8 @@ __global__ __launch_bounds__(kBlock) void k_associate_surf(
         }
         float4 rn = make_float4(0.f, 0.f, 0.f, 0.f);
         double score = 0.0;
-        if (nn.j[4] >= 0 && (double)nn.d[4] < P.kd_max_radius) {   // L:1615
+        if ((P.debug & 1) && nn.j[4] >= 0) { rn.x = nn.d[4]; ok = nn.d[4] < 0.5f; }
+        else if (nn.j[4] >= 0 && (double)nn.d[4] < P.kd_max_radius) {   // L:1615
             float4 m[5];
 #pragma unroll
             for (int k = 0; k < 5; k++) m[k] = g.pts[nn.j[k]];
@@ -293,8 +410,7 @@ __global__ __launch_bounds__(kBlock) void k_associate_surf(
         rec_score[i] = score;
         valid[i] = ok ? 1 : 0;
     }
-    unsigned long long bal = __ballot(ok);
-    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&state->n_res[0], __popcll(bal));
+    store_block_count(ok, block_counts);
 }
 
 // ================================================================================================
@@ -303,7 +419,7 @@ __global__ __launch_bounds__(kBlock) void k_associate_surf(
 __global__ __launch_bounds__(kBlock) void k_associate_edge(
         const float4* __restrict__ queries, const int* __restrict__ perm, int n_q, GridView g, PoseArg pa, MatchParams P,
         float4* __restrict__ rec_a, float4* __restrict__ rec_b, unsigned char* __restrict__ valid,
-        int* __restrict__ dbg_idx, float* __restrict__ dbg_d2, SlotState* __restrict__ state) {
+        int* __restrict__ dbg_idx, float* __restrict__ dbg_d2, int* __restrict__ block_counts) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     bool ok = false;
     if (t < n_q) {
@@ -356,8 +472,7 @@ __global__ __launch_bounds__(kBlock) void k_associate_edge(
         }
         rec_a[i] = ra; rec_b[i] = rb; valid[i] = ok ? 1 : 0;
     }
-    unsigned long long bal = __ballot(ok);
-    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&state->n_res[1], __popcll(bal));
+    store_block_count(ok, block_counts);
 }
 
 // ================================================================================================
@@ -392,10 +507,12 @@ struct GramAcc {
         __syncthreads();
         if (lane < 36) {
             double s = 0.0;
+#pragma unroll 16
             for (int q = 0; q < 64; q++) s += rows[q * kRow + a] * rows[q * kRow + b];
             acc += s;
         } else if (lane == 36) {
             double s = 0.0;
+#pragma unroll 16
             for (int q = 0; q < 64; q++) s += rows[q * kRow + 8];
             acc += s;
         } else if (lane == 37) {
@@ -424,13 +541,16 @@ __device__ __forceinline__ void load_body_pose(const PoseArg& pa, dq& Q, d3& T) 
 __global__ __launch_bounds__(kBlock) void k_linearize_surf(
         const float4* __restrict__ queries, int n_q, const float4* __restrict__ rec_nd, const double* __restrict__ rec_score,
         const unsigned char* __restrict__ valid, PoseArg pa, MatchParams P, const SlotState* __restrict__ state,
-        double* __restrict__ partials) {
+        const int* __restrict__ block_counts, int n_bc, double* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     GramAcc ga; ga.init();
     dq Q; d3 T;
     load_body_pose(pa, Q, T);
     const dq qlb_inv = qinv(dq{P.q_lb[0], P.q_lb[1], P.q_lb[2], P.q_lb[3]});
-    const double nscale = P.scale_surf_num > 0 ? P.scale_surf_num / (double)state->n_res[0] : 1.0;   // R:861
+    // N of R:861: this rank's count (sum of the association's block counts) or, when a multi-GPU caller has
+    // all-reduced it, the global count in state->n_res
+    double nscale = 1.0;
+    if (P.scale_surf_num > 0) nscale = P.scale_surf_num / (double)(block_counts ? sum_block_counts(block_counts, n_bc) : state->n_res[0]);
     for (int base = blockIdx.x * kBlock; base < n_q; base += gridDim.x * kBlock) {
         int i = base + threadIdx.x;
         bool ok = i < n_q && valid[i];
@@ -463,12 +583,13 @@ __global__ __launch_bounds__(kBlock) void k_linearize_surf(
 __global__ __launch_bounds__(kBlock) void k_linearize_edge(
         const float4* __restrict__ queries, int n_q, const float4* __restrict__ rec_a, const float4* __restrict__ rec_b,
         const unsigned char* __restrict__ valid, PoseArg pa, MatchParams P, const SlotState* __restrict__ state,
-        double* __restrict__ partials) {
+        const int* __restrict__ block_counts, int n_bc, double* __restrict__ partials) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     GramAcc ga; ga.init();
     dq Q; d3 T;
     load_body_pose(pa, Q, T);
-    const double nscale = P.scale_edge_num > 0 ? P.scale_edge_num / (double)state->n_res[1] : 1.0;   // R:843
+    double nscale = 1.0;   // R:843
+    if (P.scale_edge_num > 0) nscale = P.scale_edge_num / (double)(block_counts ? sum_block_counts(block_counts, n_bc) : state->n_res[1]);
     for (int base = blockIdx.x * kBlock; base < n_q; base += gridDim.x * kBlock) {
         int i = base + threadIdx.x;
         bool ok = i < n_q && valid[i];
@@ -511,91 +632,134 @@ __global__ __launch_bounds__(kBlock) void k_linearize_edge(
 //   P = blockdiag(I3, plusJacobian(q) 4x3); H = P^T G77 P, g = P^T G7r; solve H d = -g (Cholesky);
 //   t += d[0:3]; q = [cos|dq|, sin|dq|/|dq| dq] (x) q
 // ================================================================================================
-__device__ void gn_update_block(const double* gram /*LDS or global, 64+*/, SlotState* __restrict__ state, double (*Pm)[6], double (*H)[6], double* gvec) {
+__device__ void gn_update_block(const double* gram /*LDS or global, 64+*/, SlotState* __restrict__ state) {
+    __shared__ double Jq[4][3];   // plus-Jacobian rows: [-x1 -x2 -x3; x0 x3 -x2; -x3 x0 x1; x2 -x1 x0]
+    __shared__ double M[7][6];    // M = G77 * P   (P = blockdiag(I3, Jq): only 4 terms per entry)
+    __shared__ double H[6][6];
+    __shared__ double gvec[6];
     int tid = threadIdx.x;
     const double x0 = state->pose[3], x1 = state->pose[4], x2 = state->pose[5], x3 = state->pose[6];
+    if (tid < 12) {
+        int rr = tid / 3, cc = tid % 3;
+        double e0 = rr == 0 ? -x1 : rr == 1 ? x0 : rr == 2 ? -x3 : x2;
+        double e1 = rr == 0 ? -x2 : rr == 1 ? x3 : rr == 2 ? x0 : -x1;
+        double e2 = rr == 0 ? -x3 : rr == 1 ? -x2 : rr == 2 ? x1 : x0;
+        Jq[rr][cc] = cc == 0 ? e0 : cc == 1 ? e1 : e2;
+    }
+    __syncthreads();
     if (tid < 42) {
-        int r = tid / 6, c = tid % 6;
-        double v = 0.0;
-        if (r < 3) v = (r == c) ? 1.0 : 0.0;
-        else if (c >= 3) {
-            int rr = r - 3, cc = c - 3;
-            // rows of the plus-Jacobian: [-x1 -x2 -x3; x0 x3 -x2; -x3 x0 x1; x2 -x1 x0]
-            double e0 = rr == 0 ? -x1 : rr == 1 ? x0 : rr == 2 ? -x3 : x2;
-            double e1 = rr == 0 ? -x2 : rr == 1 ? x3 : rr == 2 ? x0 : -x1;
-            double e2 = rr == 0 ? -x3 : rr == 1 ? -x2 : rr == 2 ? x1 : x0;
-            v = cc == 0 ? e0 : cc == 1 ? e1 : e2;
-        }
-        Pm[r][c] = v;
+        int i = tid / 6, b = tid % 6;
+        double v;
+        if (b < 3) v = gram[i * 8 + b];
+        else v = ((gram[i * 8 + 3] * Jq[0][b - 3] + gram[i * 8 + 4] * Jq[1][b - 3]) + gram[i * 8 + 5] * Jq[2][b - 3]) + gram[i * 8 + 6] * Jq[3][b - 3];
+        M[i][b] = v;
     }
     __syncthreads();
     if (tid < 36) {
         int a = tid / 6, b = tid % 6;
-        double s = 0.0;
-        for (int i = 0; i < 7; i++) { double gi = 0.0; for (int j = 0; j < 7; j++) gi += gram[i * 8 + j] * Pm[j][b]; s += Pm[i][a] * gi; }
-        H[a][b] = s;
+        double v;
+        if (a < 3) v = M[a][b];
+        else v = ((Jq[0][a - 3] * M[3][b] + Jq[1][a - 3] * M[4][b]) + Jq[2][a - 3] * M[5][b]) + Jq[3][a - 3] * M[6][b];
+        H[a][b] = v;
     } else if (tid < 42) {
         int a = tid - 36;
-        double s = 0.0;
-        for (int i = 0; i < 7; i++) s += Pm[i][a] * gram[i * 8 + 7];
-        gvec[a] = -s;
+        double v;
+        if (a < 3) v = gram[a * 8 + 7];
+        else v = ((Jq[0][a - 3] * gram[3 * 8 + 7] + Jq[1][a - 3] * gram[4 * 8 + 7]) + Jq[2][a - 3] * gram[5 * 8 + 7]) + Jq[3][a - 3] * gram[6 * 8 + 7];
+        gvec[a] = -v;
     }
     __syncthreads();
     if (tid == 0) {
+        // 6x6 Cholesky solve entirely in registers (all indices are compile-time constants after unrolling)
+        double L[6][6], d[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            d[i] = gvec[i];
+#pragma unroll
+            for (int j = 0; j <= i; j++) L[i][j] = H[i][j];
+        }
         bool okc = true;
-        for (int j = 0; j < 6 && okc; j++) {
-            double d = H[j][j];
-            for (int k = 0; k < j; k++) d -= H[j][k] * H[j][k];
-            if (!(d > 0)) { okc = false; break; }
-            d = sqrt(d); H[j][j] = d;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            double dj = L[j][j];
+#pragma unroll
+            for (int k = 0; k < j; k++) dj -= L[j][k] * L[j][k];
+            if (!(dj > 0)) okc = false;
+            dj = sqrt(dj); L[j][j] = dj;
+#pragma unroll
             for (int i = j + 1; i < 6; i++) {
-                double s = H[i][j];
-                for (int k = 0; k < j; k++) s -= H[i][k] * H[j][k];
-                H[i][j] = s / d;
+                double sv = L[i][j];
+#pragma unroll
+                for (int k = 0; k < j; k++) sv -= L[i][k] * L[j][k];
+                L[i][j] = sv / dj;
             }
         }
-        if (okc) {
-            for (int i = 0; i < 6; i++) { double s = gvec[i]; for (int k = 0; k < i; k++) s -= H[i][k] * gvec[k]; gvec[i] = s / H[i][i]; }
-            for (int i = 5; i >= 0; i--) { double s = gvec[i]; for (int k = i + 1; k < 6; k++) s -= H[k][i] * gvec[k]; gvec[i] = s / H[i][i]; }
-            for (int i = 0; i < 6; i++) if (!(gvec[i] == gvec[i])) okc = false;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            double sv = d[i];
+#pragma unroll
+            for (int k = 0; k < i; k++) sv -= L[i][k] * d[k];
+            d[i] = sv / L[i][i];
         }
+#pragma unroll
+        for (int i = 5; i >= 0; i--) {
+            double sv = d[i];
+#pragma unroll
+            for (int k = i + 1; k < 6; k++) sv -= L[k][i] * d[k];
+            d[i] = sv / L[i][i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) if (!(d[i] == d[i])) okc = false;
         if (okc) {
-            state->pose[0] += gvec[0]; state->pose[1] += gvec[1]; state->pose[2] += gvec[2];
-            double nd = sqrt(gvec[3] * gvec[3] + gvec[4] * gvec[4] + gvec[5] * gvec[5]);
+            state->pose[0] += d[0]; state->pose[1] += d[1]; state->pose[2] += d[2];
+            double nd = sqrt(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
             if (nd > 0.0) {
                 double sbd = sin(nd) / nd;
-                dq qd{cos(nd), sbd * gvec[3], sbd * gvec[4], sbd * gvec[5]};
+                dq qd{cos(nd), sbd * d[3], sbd * d[4], sbd * d[5]};
                 dq r = qmul(qd, dq{x0, x1, x2, x3});
                 state->pose[3] = r.w; state->pose[4] = r.x; state->pose[5] = r.y; state->pose[6] = r.z;
             }
-            for (int i = 0; i < 6; i++) state->last_delta[i] = gvec[i];
+#pragma unroll
+            for (int i = 0; i < 6; i++) state->last_delta[i] = d[i];
             state->gn_status = 0;
         } else state->gn_status = 1;
         state->iters += 1;
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_reduce_partials(const double* __restrict__ part_surf, int nb_surf,
+constexpr int kReduceThreads = 1024;
+__global__ __launch_bounds__(kReduceThreads) void k_reduce_partials(const double* __restrict__ part_surf, int nb_surf,
                                                             const double* __restrict__ part_edge, int nb_edge,
-                                                            double* __restrict__ out, SlotState* __restrict__ state, int reset_counts, int do_gn) {
-    __shared__ double acc[4][2][40];
+                                                            double* __restrict__ out, SlotState* __restrict__ state, int do_gn) {
+    constexpr int kGroups = kReduceThreads / 40;   // 25 groups of 40 lanes, group g adds partials g, g+25, ...
+    __shared__ double acc[kGroups][2][40];
     __shared__ double tri[40];
     __shared__ double full[72];
-    __shared__ double Pm[7][6];
-    __shared__ double H[6][6];
-    __shared__ double gvec[6];
-    int e = threadIdx.x & 63, g = threadIdx.x >> 6;
-    if (e < 40) {
+    int e = threadIdx.x % 40, g = threadIdx.x / 40;
+    if (g < kGroups) {
+        // independent loads first (8 in flight per lane), adds in a fixed order afterwards
         double s = 0.0, s2 = 0.0;
-        for (int b = g; b < nb_surf; b += 4) s += part_surf[(size_t)b * kPartialDoubles + e];
-        for (int b = g; b < nb_edge; b += 4) s2 += part_edge[(size_t)b * kPartialDoubles + e];
+        for (int b0 = g; b0 < nb_surf; b0 += kGroups * 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { int b = b0 + u * kGroups; v[u] = b < nb_surf ? part_surf[(size_t)b * kPartialDoubles + e] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) s += v[u];
+        }
+        for (int b0 = g; b0 < nb_edge; b0 += kGroups * 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { int b = b0 + u * kGroups; v[u] = b < nb_edge ? part_edge[(size_t)b * kPartialDoubles + e] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) s2 += v[u];
+        }
         acc[g][0][e] = s; acc[g][1][e] = s2;
     }
     __syncthreads();
     if (threadIdx.x < 40) {
         int k = threadIdx.x;
-        double ss = ((acc[0][0][k] + acc[1][0][k]) + (acc[2][0][k] + acc[3][0][k]));
-        double se = ((acc[0][1][k] + acc[1][1][k]) + (acc[2][1][k] + acc[3][1][k]));
+        double ss = 0.0, se = 0.0;
+        for (int gg = 0; gg < kGroups; gg++) { ss += acc[gg][0][k]; se += acc[gg][1][k]; }
         tri[k] = ss + se;
         if (k == 37) { full[65] = ss; full[66] = se; }
     }
@@ -609,16 +773,11 @@ __global__ __launch_bounds__(kBlock) void k_reduce_partials(const double* __rest
     if (threadIdx.x >= 67 && threadIdx.x < 72) full[threadIdx.x] = 0.0;
     __syncthreads();
     if (threadIdx.x < 72) out[threadIdx.x] = full[threadIdx.x];
-    // the correspondence counters are consumed: reset them for the next associate of this slot
-    if (threadIdx.x == 0 && state && reset_counts) { state->n_res[0] = 0; state->n_res[1] = 0; }
-    if (do_gn) gn_update_block(full, state, Pm, H, gvec);
+    if (do_gn) gn_update_block(full, state);
 }
 
 __global__ void k_gn_update(const double* __restrict__ gram, SlotState* __restrict__ state) {
-    __shared__ double Pm[7][6];
-    __shared__ double H[6][6];
-    __shared__ double gvec[6];
-    gn_update_block(gram, state, Pm, H, gvec);
+    gn_update_block(gram, state);
 }
 
 }  // namespace lili

@@ -13,6 +13,7 @@ Pure numpy; deterministic for a given seed.  This module is data generation only
 part of the hot path and no oracle code.
 """
 import math
+import sys
 
 import numpy as np
 
@@ -334,7 +335,7 @@ def make_workload(n_map=5_000_000, n_az=3125, seed=SEED_SCENE, half_extent=(460.
     pts = dirs * t[:, None]
     if verbose:
         print(f"[synth] map {surf.shape[0]} pts (extent frac {extent_used:.3f} of {half_extent}), edge map {edge.shape[0]}, "
-              f"scan {int(ok.sum())}/{ok.size} returns, range {np.nanmin(t[ok]):.1f}..{np.nanmax(t[ok]):.1f} m")
+              f"scan {int(ok.sum())}/{ok.size} returns, range {np.nanmin(t[ok]):.1f}..{np.nanmax(t[ok]):.1f} m", file=sys.stderr)
     return dict(map_xyz=surf.astype(np.float32), edge_map_xyz=edge.astype(np.float32),
                 scan_xyz=pts[ok].astype(np.float32), scan_ring=ring[ok], scan_reltime=rel[ok].astype(np.float32),
                 lidar_t=origin, lidar_q=np.array([1.0, 0, 0, 0]), seed=seed, half_extent=half_extent,
