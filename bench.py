@@ -88,7 +88,8 @@ def main():
     ap.add_argument("--n-map", type=int, default=N_MAP)
     ap.add_argument("--n-az", type=int, default=N_AZ)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-bin", action="store_true", help="disable the once-per-scan query binning (A/B only)")
+    ap.add_argument("--bin", action="store_true", help="enable the once-per-scan query binning (A/B only)")
+    ap.add_argument("--tile", action="store_true", help="enable the LDS-tiled search (A/B only; implies --bin)")
     args = ap.parse_args()
 
     import torch
@@ -140,8 +141,10 @@ def main():
     torch.cuda.set_stream(tstream)
     assert tstream.cuda_stream != 0
     ctx = L.Context(local_rank, stream=tstream.cuda_stream)
-    if args.no_bin:
-        ctx.set_option("bin_queries", 0)
+    if args.bin or args.tile:
+        ctx.set_option("bin_queries", 1)
+    if args.tile:
+        ctx.set_option("tiled", 1)
     m = L.ScanToMapMatcher(ctx, P)
     tic = time.perf_counter()
     m.set_input_cloud(L.KIND_SURF, w["map_xyz"])

@@ -90,8 +90,9 @@ int lili_sync(lili_ctx* ctx);
 /* When enabled, associate also stores the 5 neighbour indices / squared distances per query so that
  * lili_s2m_get_neighbors can return them (parity tests).  Off by default (extra HBM writes). */
 int lili_set_debug(lili_ctx* ctx, int keep_neighbors);
-/* Tuning knobs that never change results: "bin_queries" (1 = order queries by map super-cell once per scan,
- * default 1), "max_cells" (cap on grid cells of the map index; coarser cells stay exact). */
+/* Tuning knobs that never change results: "bin_queries" (1 = order queries by map super-cell once per scan; use it
+ * when the query order is not spatially coherent; default 0), "tiled" (1 = LDS-staged neighbourhood tiles, needs
+ * bin_queries; default 0), "max_cells" (cap on grid cells of the map index; coarser cells stay exact). */
 int lili_set_option(lili_ctx* ctx, const char* name, int value);
 
 /* ---- local map index ------------------------------------------------------------------------ */

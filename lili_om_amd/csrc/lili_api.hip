@@ -22,8 +22,10 @@ __global__ void k_scan_apply(const int*, int64_t, const int*, int*);
 __global__ void k_scatter(const float4*, int, const int*, const int*, int*, float4*, float*);
 __global__ void k_bin_count(const float4*, int, GridView, PoseArg, MatchParams, int, int, int*, int*);
 __global__ void k_bin_scatter(const int*, int, const int*, int*, int*);
-__global__ void k_associate_surf(const float4*, const int*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, int*);
-__global__ void k_associate_edge(const float4*, const int*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, int*);
+__global__ void k_tile_count(const int*, int, int*);
+__global__ void k_tile_fill(const int*, const int*, const int*, int, int2*);
+template <bool TILED> __global__ void k_associate_surf(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, int*);
+template <bool TILED> __global__ void k_associate_edge(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, int*);
 __global__ void k_linearize_surf(const float4*, int, const float4*, const double*, const unsigned char*, PoseArg, MatchParams, const SlotState*, const int*, int, double*);
 __global__ void k_linearize_edge(const float4*, int, const float4*, const float4*, const unsigned char*, PoseArg, MatchParams, const SlotState*, const int*, int, double*);
 __global__ void k_reduce_partials(const double*, int, const double*, int, double*, SlotState*, int);
@@ -62,7 +64,9 @@ struct MapIndex {
 struct KindSlot {
     int64_t n_q = 0;
     bool has_queries = false, has_records = false;
-    DevBuf q, rec0, rec1, valid, dbg_idx, dbg_d2, partials, perm, keys, block_counts;
+    DevBuf q, rec0, rec1, valid, dbg_idx, dbg_d2, partials, perm, keys, block_counts, tiles;
+    int n_assoc_blocks = 0;  // grid of the last association launch (= number of per-block counts)
+    int n_tiles = 0;       // association grid when binned (tiles never span two super-cells)
     bool binned = false;   // perm holds the super-cell (Morton) order of the queries for the current scan
     int n_blocks = 0;      // association grid (one thread per query)
     int n_lin_blocks = 0;  // linearisation grid (grid-stride, <= kMaxLinBlocks partials)
@@ -73,8 +77,9 @@ struct Slot {
     bool use_global_counts = false;   // next linearize_dev reads the (all-reduced) counts in SlotState::n_res
 };
 
-constexpr int kMaxLinBlocks = 1024;
-constexpr size_t kLdsLinearize = (size_t)(kBlock * 9 + 4 * 40) * sizeof(double);
+constexpr int kLinBlock = 1024;      // must match lili_s2m.hip
+constexpr int kMaxLinBlocks = 256;
+constexpr size_t kLdsLinearize = (size_t)(kLinBlock * 10) * sizeof(double);   // rows [J r 1 cost]; reused for the 16x16 wave results
 
 }  // namespace
 
@@ -90,8 +95,9 @@ struct lili_ctx {
     DevBuf staging;      // raw host clouds
     DevBuf gram;         // LILI_GRAM_DOUBLES per slot
     DevBuf misc;         // bbox words etc.
-    DevBuf bin_hist, bin_start, bin_sums;   // query binning scratch
-    bool bin_queries = true;
+    DevBuf bin_hist, bin_start, bin_sums, bin_tcnt, bin_toff;   // query binning scratch
+    bool bin_queries = false;   // trust the caller's order (extractor output is ring-/voxel-ordered, i.e. coherent)
+    bool tiled = false;         // LDS-staged tiles: measured slower than the direct path once selection is branch-free
     int max_cells = 1 << 26;
 
     int fail(int code, const std::string& m) { err = m; return code; }
@@ -177,8 +183,8 @@ void lili_ctx_destroy(lili_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& m : ctx->map) { m.pts.release(); m.sorted.release(); m.aux_sorted.release(); m.cell_start.release(); m.cell_tmp.release(); m.pt_cell.release(); m.block_sums.release(); }
-    for (auto& s : ctx->slots) for (auto& k : s.k) { k.q.release(); k.rec0.release(); k.rec1.release(); k.valid.release(); k.dbg_idx.release(); k.dbg_d2.release(); k.partials.release(); k.perm.release(); k.keys.release(); k.block_counts.release(); }
-    ctx->states.release(); ctx->staging.release(); ctx->gram.release(); ctx->misc.release(); ctx->bin_hist.release(); ctx->bin_start.release(); ctx->bin_sums.release();
+    for (auto& s : ctx->slots) for (auto& k : s.k) { k.q.release(); k.rec0.release(); k.rec1.release(); k.valid.release(); k.dbg_idx.release(); k.dbg_d2.release(); k.partials.release(); k.perm.release(); k.keys.release(); k.block_counts.release(); k.tiles.release(); }
+    ctx->states.release(); ctx->staging.release(); ctx->gram.release(); ctx->misc.release(); ctx->bin_hist.release(); ctx->bin_start.release(); ctx->bin_sums.release(); ctx->bin_tcnt.release(); ctx->bin_toff.release();
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -200,6 +206,7 @@ int lili_set_debug(lili_ctx* ctx, int keep_neighbors) {
 int lili_set_option(lili_ctx* ctx, const char* name, int value) {
     if (!ctx || !name) return LILI_E_ARG;
     if (std::strcmp(name, "bin_queries") == 0) { ctx->bin_queries = value != 0; for (auto& s : ctx->slots) for (auto& k : s.k) k.binned = false; return LILI_OK; }
+    if (std::strcmp(name, "tiled") == 0) { ctx->tiled = value != 0; return LILI_OK; }
     if (std::strcmp(name, "max_cells") == 0) { if (value < 1) return ctx->fail(LILI_E_ARG, "max_cells must be positive"); ctx->max_cells = value; return LILI_OK; }
     return ctx->fail(LILI_E_ARG, std::string("unknown option ") + name);
 }
@@ -305,13 +312,13 @@ int lili_s2m_set_queries(lili_ctx* ctx, int slot, int kind, const lili_cloud* cl
     if (rc != LILI_OK) return rc;
     ks.n_q = (int64_t)cloud->n;
     ks.n_blocks = nblocks(ks.n_q, kBlock);
-    ks.n_lin_blocks = std::min(ks.n_blocks, kMaxLinBlocks);
+    ks.n_lin_blocks = std::min(nblocks(ks.n_q, kLinBlock), kMaxLinBlocks);
     size_t n = (size_t)ks.n_q;
     if (n) {
         HIPCHK(ks.rec0.ensure(n * sizeof(float4)));
         HIPCHK(ks.rec1.ensure(n * sizeof(float4)));   // surf: doubles (8 B) fit in the float4 budget
         HIPCHK(ks.valid.ensure(n));
-        HIPCHK(ks.partials.ensure((size_t)ks.n_blocks * kPartialDoubles * sizeof(double)));
+        HIPCHK(ks.partials.ensure((size_t)ks.n_lin_blocks * kPartialDoubles * sizeof(double)));
         HIPCHK(ks.block_counts.ensure((size_t)ks.n_blocks * sizeof(int)));
     }
     ks.has_queries = true;
@@ -347,7 +354,23 @@ static int bin_queries(lili_ctx* ctx, KindSlot& ks, MapIndex& m, const PoseArg& 
     hipLaunchKernelGGL(k_scan_apply, dim3(nb_scan), dim3(kBlock), 0, ctx->stream, ctx->bin_hist.as<int>(), (int64_t)n_bins, ctx->bin_sums.as<int>(), ctx->bin_start.as<int>());
     HIPCHK(hipMemsetAsync(ctx->bin_hist.p, 0, (size_t)n_bins * sizeof(int), ctx->stream));
     hipLaunchKernelGGL(k_bin_scatter, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, ks.keys.as<int>(), n, ctx->bin_start.as<int>(), ctx->bin_hist.as<int>(), ks.perm.as<int>());
+    // tile list: after the scatter bin_hist holds the per-bin counts again
+    HIPCHK(ctx->bin_tcnt.ensure((size_t)n_bins * sizeof(int)));
+    HIPCHK(ctx->bin_toff.ensure((size_t)(n_bins + 1) * sizeof(int)));
+    hipLaunchKernelGGL(k_tile_count, dim3(nblocks(n_bins, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->bin_hist.as<int>(), n_bins, ctx->bin_tcnt.as<int>());
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb_scan), dim3(kBlock), 0, ctx->stream, ctx->bin_tcnt.as<int>(), (int64_t)n_bins, ctx->bin_sums.as<int>());
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->bin_sums.as<int>(), nb_scan);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb_scan), dim3(kBlock), 0, ctx->stream, ctx->bin_tcnt.as<int>(), (int64_t)n_bins, ctx->bin_sums.as<int>(), ctx->bin_toff.as<int>());
     HIPCHK(hipGetLastError());
+    int n_tiles = 0;
+    HIPCHK(hipMemcpyAsync(&n_tiles, ctx->bin_toff.as<int>() + n_bins, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));   // once per scan
+    if (n_tiles <= 0 || n_tiles > n) return ctx->fail(LILI_E_HIP, "bin_queries: inconsistent tile count");
+    HIPCHK(ks.tiles.ensure((size_t)n_tiles * sizeof(int2)));
+    HIPCHK(ks.block_counts.ensure((size_t)std::max(n_tiles, ks.n_blocks) * sizeof(int)));
+    hipLaunchKernelGGL(k_tile_fill, dim3(nblocks(n_bins, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->bin_hist.as<int>(), ctx->bin_start.as<int>(), ctx->bin_toff.as<int>(), n_bins, ks.tiles.as<int2>());
+    HIPCHK(hipGetLastError());
+    ks.n_tiles = n_tiles;
     ks.binned = true;
     return LILI_OK;
 }
@@ -371,21 +394,31 @@ static int launch_associate(lili_ctx* ctx, int slot, int kind, const PoseArg& pa
     }
     if (m.n < 5) {   // fewer than 5 map points: the reference reads pt_search_sq_dists[4] out of bounds; we reject all
         HIPCHK(hipMemsetAsync(ks.valid.p, 0, (size_t)n, ctx->stream));
+        ks.n_assoc_blocks = ks.n_blocks;
         HIPCHK(hipMemsetAsync(ks.block_counts.p, 0, (size_t)ks.n_blocks * sizeof(int), ctx->stream));
         if (dbg_i) { HIPCHK(hipMemsetAsync(dbg_i, 0xFF, (size_t)n * 5 * sizeof(int), ctx->stream)); HIPCHK(hipMemsetAsync(dbg_d, 0x7F, (size_t)n * 5 * sizeof(float), ctx->stream)); }
         return LILI_OK;
     }
     const int* perm = nullptr;
+    const int2* tiles = nullptr;
+    ks.n_assoc_blocks = ks.n_blocks;
+    const bool tiled = ctx->tiled && ctx->bin_queries && n >= 4 * kBlock;   // tiles need spatially compact blocks
     if (ctx->bin_queries && n >= 4 * kBlock) {
         if (!ks.binned) { int rc = bin_queries(ctx, ks, m, pa, P); if (rc != LILI_OK) return rc; }
         perm = ks.perm.as<int>();
+        tiles = ks.tiles.as<int2>();
+        ks.n_assoc_blocks = ks.n_tiles;
     }
     if (kind == LILI_KIND_SURF) {
         if (P.variant == LILI_VARIANT_LIVOX && !m.has_aux) return ctx->fail(LILI_E_STATE, "associate: Livox variant needs reflectivity (aux_offset) on the surf map");
-        hipLaunchKernelGGL(k_associate_surf, dim3(ks.n_blocks), dim3(kBlock), 0, ctx->stream, ks.q.as<float4>(), perm, n, m.view, pa, P,
+        if (tiled) hipLaunchKernelGGL(k_associate_surf<true>, dim3(ks.n_assoc_blocks), dim3(kBlock), 0, ctx->stream, ks.q.as<float4>(), perm, tiles, n, m.view, pa, P,
+                           ks.rec0.as<float4>(), ks.rec1.as<double>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>());
+        else hipLaunchKernelGGL(k_associate_surf<false>, dim3(ks.n_assoc_blocks), dim3(kBlock), 0, ctx->stream, ks.q.as<float4>(), perm, tiles, n, m.view, pa, P,
                            ks.rec0.as<float4>(), ks.rec1.as<double>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>());
     } else {
-        hipLaunchKernelGGL(k_associate_edge, dim3(ks.n_blocks), dim3(kBlock), 0, ctx->stream, ks.q.as<float4>(), perm, n, m.view, pa, P,
+        if (tiled) hipLaunchKernelGGL(k_associate_edge<true>, dim3(ks.n_assoc_blocks), dim3(kBlock), 0, ctx->stream, ks.q.as<float4>(), perm, tiles, n, m.view, pa, P,
+                           ks.rec0.as<float4>(), ks.rec1.as<float4>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>());
+        else hipLaunchKernelGGL(k_associate_edge<false>, dim3(ks.n_assoc_blocks), dim3(kBlock), 0, ctx->stream, ks.q.as<float4>(), perm, tiles, n, m.view, pa, P,
                            ks.rec0.as<float4>(), ks.rec1.as<float4>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>());
     }
     HIPCHK(hipGetLastError());
@@ -399,11 +432,11 @@ static int launch_linearize(lili_ctx* ctx, int slot, int kind, const PoseArg& pa
     const int n = (int)ks.n_q;
     const int* bc = ctx->slots[slot].use_global_counts ? nullptr : ks.block_counts.as<int>();
     if (kind == LILI_KIND_SURF)
-        hipLaunchKernelGGL(k_linearize_surf, dim3(ks.n_lin_blocks), dim3(kBlock), kLdsLinearize, ctx->stream, ks.q.as<float4>(), n, ks.rec0.as<float4>(),
-                           ks.rec1.as<double>(), ks.valid.as<unsigned char>(), pa, P, ctx->state(slot), bc, ks.n_blocks, ks.partials.as<double>());
+        hipLaunchKernelGGL(k_linearize_surf, dim3(ks.n_lin_blocks), dim3(kLinBlock), kLdsLinearize, ctx->stream, ks.q.as<float4>(), n, ks.rec0.as<float4>(),
+                           ks.rec1.as<double>(), ks.valid.as<unsigned char>(), pa, P, ctx->state(slot), bc, ks.n_assoc_blocks, ks.partials.as<double>());
     else
-        hipLaunchKernelGGL(k_linearize_edge, dim3(ks.n_lin_blocks), dim3(kBlock), kLdsLinearize, ctx->stream, ks.q.as<float4>(), n, ks.rec0.as<float4>(),
-                           ks.rec1.as<float4>(), ks.valid.as<unsigned char>(), pa, P, ctx->state(slot), bc, ks.n_blocks, ks.partials.as<double>());
+        hipLaunchKernelGGL(k_linearize_edge, dim3(ks.n_lin_blocks), dim3(kLinBlock), kLdsLinearize, ctx->stream, ks.q.as<float4>(), n, ks.rec0.as<float4>(),
+                           ks.rec1.as<float4>(), ks.valid.as<unsigned char>(), pa, P, ctx->state(slot), bc, ks.n_assoc_blocks, ks.partials.as<double>());
     HIPCHK(hipGetLastError());
     return LILI_OK;
 }
@@ -412,8 +445,8 @@ static int launch_linearize(lili_ctx* ctx, int slot, int kind, const PoseArg& pa
 static int launch_sum_counts(lili_ctx* ctx, int slot, int kind_mask) {
     Slot& s = ctx->slots[slot];
     const int* bs = nullptr; const int* be = nullptr; int nbs = 0, nbe = 0;
-    if ((kind_mask & LILI_MASK_SURF) && s.k[0].has_records && s.k[0].n_q > 0) { bs = s.k[0].block_counts.as<int>(); nbs = s.k[0].n_blocks; }
-    if ((kind_mask & LILI_MASK_EDGE) && s.k[1].has_records && s.k[1].n_q > 0) { be = s.k[1].block_counts.as<int>(); nbe = s.k[1].n_blocks; }
+    if ((kind_mask & LILI_MASK_SURF) && s.k[0].has_records && s.k[0].n_q > 0) { bs = s.k[0].block_counts.as<int>(); nbs = s.k[0].n_assoc_blocks; }
+    if ((kind_mask & LILI_MASK_EDGE) && s.k[1].has_records && s.k[1].n_q > 0) { be = s.k[1].block_counts.as<int>(); nbe = s.k[1].n_assoc_blocks; }
     HIPCHK(hipMemsetAsync(ctx->state(slot)->n_res, 0, 2 * sizeof(int), ctx->stream));
     if (bs || be) hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(kBlock), 0, ctx->stream, bs, nbs, be, nbe, ctx->state(slot));
     HIPCHK(hipGetLastError());

@@ -209,6 +209,20 @@ __global__ void k_bin_scatter(const int* __restrict__ keys, int n_q, const int* 
     if (live) perm[starts[k] + base + rank] = i;
 }
 
+// Tile list: a tile is <= kBlock consecutive entries of `perm` that all belong to ONE bin (super-cell), so a
+// block's neighbourhood is bounded by the super-cell size.  counts[b] = queries in bin b.
+__global__ void k_tile_count(const int* __restrict__ counts, int n_bins, int* __restrict__ tile_cnt) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < n_bins) tile_cnt[b] = (counts[b] + kBlock - 1) / kBlock;
+}
+__global__ void k_tile_fill(const int* __restrict__ counts, const int* __restrict__ starts, const int* __restrict__ tile_off, int n_bins,
+                            int2* __restrict__ tiles) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_bins) return;
+    int c = counts[b], s0 = starts[b], t0 = tile_off[b];
+    for (int k = 0; k * kBlock < c; k++) tiles[t0 + k] = make_int2(s0 + k * kBlock, min(kBlock, c - k * kBlock));
+}
+
 // ================================================================================================
 // exact 5-NN inside the 27-cell neighbourhood
 // ================================================================================================
@@ -224,51 +238,82 @@ __device__ __forceinline__ float dist2(float4 p, float qx, float qy, float qz) {
     float dz = qz - p.z; r += dz * dz;
     return r;
 }
-// ascending (d2, original index): ties on d2 are resolved by the map point's original index so that
-// the result does not depend on the traversal order (FLANN's own tie order is unspecified, App. B1).
-// The index is only fetched on an exact tie.
-__device__ __forceinline__ bool less_dj(float da, int ja, float db, int jb, const float4* __restrict__ pts) {
-    if (da < db) return true;
-    if (!(da == db)) return false;
-    int ia = ja < 0 ? 0x7fffffff : __float_as_int(pts[ja].w);
-    int ib = jb < 0 ? 0x7fffffff : __float_as_int(pts[jb].w);
-    return ia < ib;
-}
-__device__ __forceinline__ void top5_insert(Top5& t, float d, int j, const float4* __restrict__ pts) {
-    if (!less_dj(d, j, t.d[4], t.j[4], pts)) return;
-    t.d[4] = d; t.j[4] = j;
+// Running 5 best as a sorted list of packed keys (f32 distance bits << 32 | original map index): squared
+// distances are >= 0 so their bit patterns order like the values, and the low word makes the order the
+// oracle's lexicographic (d2, index) — FLANN's own tie order is unspecified (App. B1).  Insertion is a
+// 5-stage compare-exchange chain without branches: on a 64-lane wave some lane inserts at almost every
+// candidate, so a branchy insertion path is executed (and stalls) nearly every iteration anyway.
+// NaN distances have bit patterns above +inf and therefore never displace the initial (+inf, INT_MAX) keys.
+struct Sel5 {
+    unsigned long long k[5];
+    int j[5];
+    __device__ __forceinline__ void init() {
 #pragma unroll
-    for (int k = 4; k > 0; k--) {
-        if (!less_dj(t.d[k], t.j[k], t.d[k - 1], t.j[k - 1], pts)) break;
-        float td = t.d[k]; t.d[k] = t.d[k - 1]; t.d[k - 1] = td;
-        int tj = t.j[k]; t.j[k] = t.j[k - 1]; t.j[k - 1] = tj;
+        for (int s = 0; s < 5; s++) { k[s] = 0x7f8000007fffffffull; j[s] = -1; }
     }
+    __device__ __forceinline__ void insert(float d, float4 p, int jpos) {
+        unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w);
+        int jj = jpos;
+#pragma unroll
+        for (int s = 0; s < 5; s++) {
+            bool c = key < k[s];
+            unsigned long long nk = c ? key : k[s];
+            int nj = c ? jj : j[s];
+            key = c ? k[s] : key;
+            jj = c ? j[s] : jj;
+            k[s] = nk; j[s] = nj;
+        }
+    }
+    __device__ __forceinline__ float worst() const { return __uint_as_float((unsigned)(k[4] >> 32)); }
+    __device__ __forceinline__ void to_top5(Top5& t) const {
+#pragma unroll
+        for (int s = 0; s < 5; s++) { t.d[s] = __uint_as_float((unsigned)(k[s] >> 32)); t.j[s] = j[s]; }
+    }
+};
+
+// Lower bound (conservative by 0.1 %) of the f32 squared distance from the query to any point of the cell row
+// (cy+dy, cz+dz): the gap to the own cell's boundary in y and z.  Rows whose bound exceeds the current 5th best
+// cannot contribute (a candidate enters only with d <= that value) — skipping them keeps the search exact.
+__device__ __forceinline__ float row_lower_bound(const GridView& g, float qy, float qz, int cy, int cz, int dy, int dz) {
+    const double c = 1.0 / g.inv_cell;
+    double gy = dy == 0 ? 0.0 : (dy < 0 ? (double)qy - (g.oy + (double)cy * c) : (g.oy + (double)(cy + 1) * c) - (double)qy);
+    double gz = dz == 0 ? 0.0 : (dz < 0 ? (double)qz - (g.oz + (double)cz * c) : (g.oz + (double)(cz + 1) * c) - (double)qz);
+    gy = fmax(gy, 0.0); gz = fmax(gz, 0.0);
+    return (float)(0.999 * (gy * gy + gz * gz));
 }
+// visiting order of the 9 (dy,dz) rows: centre, faces, diagonals (w = (dy+1)*3 + (dz+1))
+__device__ __forceinline__ int row_order(int n) { return n == 0 ? 4 : n == 1 ? 1 : n == 2 ? 3 : n == 3 ? 5 : n == 4 ? 7 : n == 5 ? 0 : n == 6 ? 2 : n == 7 ? 6 : 8; }
 
 __device__ __forceinline__ void knn5_grid(const GridView& g, float qx, float qy, float qz, Top5& best) {
-#pragma unroll
-    for (int k = 0; k < 5; k++) { best.d[k] = INFINITY; best.j[k] = -1; }
+    Sel5 sel; sel.init();
+    sel.to_top5(best);
     if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) return;
     int cx = cell_coord(qx, g.ox, g.inv_cell), cy = cell_coord(qy, g.oy, g.inv_cell), cz = cell_coord(qz, g.oz, g.inv_cell);
     // queries more than one cell outside the grid cannot have a neighbour within the gate radius
     if (cx < -1 || cx > g.nx || cy < -1 || cy > g.ny || cz < -1 || cz > g.nz) return;
     int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
     if (x0 > x1) return;
-    for (int dz = -1; dz <= 1; dz++) {
-        int z = cz + dz;
-        if (z < 0 || z >= g.nz) continue;
-        for (int dy = -1; dy <= 1; dy++) {
-            int y = cy + dy;
-            if (y < 0 || y >= g.ny) continue;
-            int row = (z * g.ny + y) * g.nx;
-            int beg = g.cell_start[row + x0], end = g.cell_start[row + x1 + 1];
-            for (int j = beg; j < end; j++) {
-                float4 p = g.pts[j];
-                float d = dist2(p, qx, qy, qz);
-                if (d <= best.d[4]) top5_insert(best, d, j, g.pts);
+    for (int n = 0; n < 9; n++) {
+        int w = row_order(n);
+        int dy = w / 3 - 1, dz = w % 3 - 1;
+        int y = cy + dy, z = cz + dz;
+        if (z < 0 || z >= g.nz || y < 0 || y >= g.ny) continue;
+        if (row_lower_bound(g, qy, qz, cy, cz, dy, dz) > sel.worst()) continue;
+        int row = (z * g.ny + y) * g.nx;
+        int beg = g.cell_start[row + x0], end = g.cell_start[row + x1 + 1];
+        int j = beg;
+        for (; j + 1 < end; j += 2) {
+            float4 p0 = g.pts[j], p1 = g.pts[j + 1];
+            float d0 = dist2(p0, qx, qy, qz), d1 = dist2(p1, qx, qy, qz);
+            float wv = sel.worst();
+            if (d0 <= wv || d1 <= wv) {   // the compiler turns this into a wave-level skip of the exchange network
+                sel.insert(d0, p0, j);
+                sel.insert(d1, p1, j + 1);
             }
         }
+        if (j < end) { float4 p0 = g.pts[j]; float d0 = dist2(p0, qx, qy, qz); if (d0 <= sel.worst()) sel.insert(d0, p0, j); }
     }
+    sel.to_top5(best);
 }
 
 // Correspondence counting without atomics on a shared word (3128 same-address atomics cost ~40 us on
@@ -287,14 +332,14 @@ __device__ __forceinline__ void store_block_count(bool ok, int* __restrict__ blo
 }
 // Sum of the per-block counts of one association launch (every thread of the block gets the total).
 __device__ __forceinline__ int sum_block_counts(const int* __restrict__ block_counts, int nb) {
-    __shared__ int part[kBlock / 64];
+    __shared__ int part[16];
     __shared__ int total;
     int s = 0;
-    for (int b = threadIdx.x; b < nb; b += kBlock) s += block_counts[b];
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) s += block_counts[b];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < kBlock / 64; w++) t += part[w]; total = t; }
+    if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += part[w]; total = t; }
     __syncthreads();
     return total;
 }
@@ -321,91 +366,292 @@ __device__ __forceinline__ void load_assoc_pose(const PoseArg& pa, const MatchPa
 }
 
 // ================================================================================================
-// K5 — surf association.  One thread per query.
-// records: rec_nd[i] = (w*nx, w*ny, w*nz, w*normInverse) as floats, rec_score[i] (f64), valid[i]
+// K5 / K6 — association.  The per-query fits are shared by the tiled (LDS) and the direct search path.
+// surf records: rec_nd[i] = (w*nx, w*ny, w*nz, w*normInverse) as floats, rec_score[i] (f64), valid[i]
+// edge records: rec_a[i] = (Ax, Ay, Az, s), rec_b[i] = (Bx, By, Bz, 0), valid[i]
 // ================================================================================================
+__device__ __forceinline__ void store_debug_nn(const GridView& g, const Top5& nn, int i, int* __restrict__ dbg_idx, float* __restrict__ dbg_d2) {
+    if (!dbg_idx) return;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        dbg_idx[(size_t)i * 5 + k] = nn.j[k] >= 0 ? __float_as_int(g.pts[nn.j[k]].w) : -1;
+        dbg_d2[(size_t)i * 5 + k] = nn.d[k];
+    }
+}
+
+// findCorrespondingSurfFeatures body after the kNN (L/src/BackendFusion.cpp:1613-1679 and variants)
+__device__ __forceinline__ bool surf_fit(const GridView& g, const MatchParams& P, const Top5& nn, float4 ql, float px, float py, float pz,
+                                         float4& rn, double& score) {
+    rn = make_float4(0.f, 0.f, 0.f, 0.f);
+    score = 0.0;
+    if ((P.debug & 1) && nn.j[4] >= 0) { rn.x = nn.d[4]; return nn.d[4] < 0.5f; }
+    if (!(nn.j[4] >= 0 && (double)nn.d[4] < P.kd_max_radius)) return false;   // L:1615
+    float4 m[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) m[k] = g.pts[nn.j[k]];
+    col5 c0, c1, c2, b;
+    double sum_w = 0.0;
+    if (P.variant == 0) {   // Livox reflectivity weighting, L:1617-1638
+        double w[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            float diff = ql.w - g.aux[nn.j[k]];
+            double tmp_w = (double)fabsf(diff);
+            sum_w += tmp_w;
+            w[k] = 1.0 / tmp_w;
+        }
+        if (sum_w > P.reflect_thres) return false;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            double wk = w[k] / sum_w;
+            c0.v[k] = wk * (double)m[k].x; c1.v[k] = wk * (double)m[k].y; c2.v[k] = wk * (double)m[k].z;
+            b.v[k] = -1.0 * wk;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 5; k++) { c0.v[k] = (double)m[k].x; c1.v[k] = (double)m[k].y; c2.v[k] = (double)m[k].z; b.v[k] = -1.0; }
+    }
+    double nv[3];
+    lstsq53(c0, c1, c2, b, nv);
+    double nn_ = sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
+    double normInverse = 1.0 / nn_;
+    nv[0] /= nn_; nv[1] /= nn_; nv[2] /= nn_;
+    bool planeValid = true;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        if (fabs(nv[0] * (double)m[k].x + nv[1] * (double)m[k].y + nv[2] * (double)m[k].z + normInverse) > P.surf_dist_thres) planeValid = false;
+    }
+    if (!planeValid) return false;
+    // L:1661-1662: float pd, float weight; sqrt(sqrt()) on a float argument is the float overload
+    float pd = (float)(nv[0] * (double)px + nv[1] * (double)py + nv[2] * (double)pz + normInverse);
+    float r2 = px * px + py * py + pz * pz;
+    float weight = (float)(1.0 - 0.9 * (double)fabsf(pd) / (double)sqrtf(sqrtf(r2)));
+    if (!((double)weight > P.surf_weight_min)) return false;
+    rn.x = (float)((double)weight * nv[0]); rn.y = (float)((double)weight * nv[1]); rn.z = (float)((double)weight * nv[2]);
+    rn.w = (float)((double)weight * normInverse);
+    if (P.variant == 0) score = P.lidar_const * ((double)weight + exp(-sum_w));   // L:1676
+    else if (P.variant == 1) score = P.lidar_const * (double)weight;                // R:1515
+    else score = 1.0;
+    return true;
+}
+
+// findCorrespondingCornerFeatures body after the kNN (L/src/BackendFusion.cpp:1543-1596, R:1404-1458)
+__device__ __forceinline__ bool edge_fit(const GridView& g, const MatchParams& P, const Top5& nn, float px, float py, float pz,
+                                         float4& ra, float4& rb) {
+    ra = make_float4(0.f, 0.f, 0.f, 0.f); rb = ra;
+    if (!(nn.j[4] >= 0 && (double)nn.d[4] < P.edge_gate)) return false;   // L:1543
+    d3 m[5]; d3 c{0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 5; k++) { float4 p = g.pts[nn.j[k]]; m[k] = d3{(double)p.x, (double)p.y, (double)p.z}; c = c + m[k]; }
+    c = d3{c.x / 5.0, c.y / 5.0, c.z / 5.0};
+    double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        d3 z = m[k] - c;
+        a00 += z.x * z.x; a01 += z.x * z.y; a02 += z.x * z.z; a11 += z.y * z.y; a12 += z.y * z.z; a22 += z.z * z.z;
+    }
+    double ev[3]; d3 vmin, vmax;
+    eig3_sym(a00, a01, a02, a11, a12, a22, ev, vmin, vmax);
+    if (!(ev[2] > 3.0 * ev[1])) return false;   // L:1575
+    d3 u = canon_sign(vmax);
+    d3 A = c + 0.1 * u, B = c - 0.1 * u;
+    if (P.edge_dist_max > 0) {   // R:1437-1443
+        d3 lp{(double)px, (double)py, (double)pz};
+        d3 nu = cross3(lp - A, lp - B);
+        d3 de = A - B;
+        double dist = sqrt(dot3(nu, nu)) / sqrt(dot3(de, de));
+        if (!(dist < P.edge_dist_max)) return false;
+    }
+    ra = make_float4((float)A.x, (float)A.y, (float)A.z, (float)P.lidar_const);
+    rb = make_float4((float)B.x, (float)B.y, (float)B.z, 0.f);
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tiled exact 5-NN: the 256 queries of a block (consecutive in the binned order, hence spatially
+// compact) share one neighbourhood = bounding box of their cells +-1.  Each (y,z) row of that box is ONE
+// contiguous run of the cell-sorted map (x-fastest cells), so the block stages the rows in LDS with
+// coalesced 16-B loads and every thread then scans its own 3x3x3-cell window from LDS instead of
+// issuing ~100 dependent, divergent global loads.  Rows are staged in batches of <= kTileCap points;
+// degenerate tiles (too many rows / batches) use the direct path.  The candidate set per query is exactly
+// the 27-cell set of knn5_grid, so results are identical.
+// ------------------------------------------------------------------------------------------------
+constexpr int kTileCap = 2048;        // float4 slots staged per batch (32 KiB)
+constexpr int kTileHalf = kTileCap / 2;
+constexpr int kTileRows = kBlock;     // one row descriptor per thread
+constexpr int kTileBatches = 32;
+
+struct TileLds {
+    float4 pts[kTileCap];
+    int row_gbeg[kTileRows];
+    int row_len[kTileRows];
+    int row_off[kTileRows];
+    int batch_base[kTileBatches];
+    int bbox[6];
+    int scan[kBlock / 64 + 1];
+};
+
+__device__ __forceinline__ void knn5_tiled(const GridView& g, TileLds& L, bool live, float qx, float qy, float qz, Top5& best, int dbg) {
+    const int tid = threadIdx.x;
+    Sel5 sel; sel.init();
+    sel.to_top5(best);
+    // ---- phase 0: cell of every query, block bounding box
+    int cx = 0, cy = 0, cz = 0;
+    bool inr = false;
+    if (live && isfinite(qx) && isfinite(qy) && isfinite(qz)) {
+        cx = cell_coord(qx, g.ox, g.inv_cell); cy = cell_coord(qy, g.oy, g.inv_cell); cz = cell_coord(qz, g.oz, g.inv_cell);
+        inr = !(cx < -1 || cx > g.nx || cy < -1 || cy > g.ny || cz < -1 || cz > g.nz);
+    }
+    if (tid < 3) { L.bbox[tid] = 0x7fffffff; L.bbox[3 + tid] = -0x7fffffff; }
+    if (tid < kTileBatches) L.batch_base[tid] = 0x7fffffff;
+    __syncthreads();
+    {
+        int mnx = inr ? cx : 0x7fffffff, mny = inr ? cy : 0x7fffffff, mnz = inr ? cz : 0x7fffffff;
+        int mxx = inr ? cx : -0x7fffffff, mxy = inr ? cy : -0x7fffffff, mxz = inr ? cz : -0x7fffffff;
+        for (int o = 32; o > 0; o >>= 1) {
+            mnx = min(mnx, __shfl_xor(mnx, o)); mny = min(mny, __shfl_xor(mny, o)); mnz = min(mnz, __shfl_xor(mnz, o));
+            mxx = max(mxx, __shfl_xor(mxx, o)); mxy = max(mxy, __shfl_xor(mxy, o)); mxz = max(mxz, __shfl_xor(mxz, o));
+        }
+        if ((tid & 63) == 0) {
+            atomicMin(&L.bbox[0], mnx); atomicMin(&L.bbox[1], mny); atomicMin(&L.bbox[2], mnz);
+            atomicMax(&L.bbox[3], mxx); atomicMax(&L.bbox[4], mxy); atomicMax(&L.bbox[5], mxz);
+        }
+    }
+    __syncthreads();
+    if (L.bbox[0] > L.bbox[3]) return;   // no query of this block can have a neighbour (uniform exit)
+    const int xa = max(L.bbox[0] - 1, 0), xb = min(L.bbox[3] + 1, g.nx - 1);
+    const int ya = max(L.bbox[1] - 1, 0), yb = min(L.bbox[4] + 1, g.ny - 1);
+    const int za = max(L.bbox[2] - 1, 0), zb = min(L.bbox[5] + 1, g.nz - 1);
+    const int nyt = yb - ya + 1, nzt = zb - za + 1;
+    const long long nrows_ll = (long long)nyt * (long long)nzt;
+    bool direct = xa > xb || nyt <= 0 || nzt <= 0 || nrows_ll > kTileRows;
+    int total = 0;
+    if (!direct) {
+        // ---- phase 1: row descriptors (one per thread) + exclusive scan of the row lengths
+        const int nrows = (int)nrows_ll;
+        int len = 0, gbeg = 0;
+        if (tid < nrows) {
+            int y = ya + tid / nzt, z = za + tid % nzt;
+            int row = (z * g.ny + y) * g.nx;
+            gbeg = g.cell_start[row + xa];
+            len = g.cell_start[row + xb + 1] - gbeg;
+        }
+        int off = block_exclusive_scan(len, L.scan, total);
+        if (tid < nrows) {
+            L.row_gbeg[tid] = gbeg; L.row_len[tid] = len; L.row_off[tid] = off;
+            if (len > 0 && len <= kTileHalf) {
+                int bq = (off + len - 1) / kTileHalf;
+                if (bq < kTileBatches) atomicMin(&L.batch_base[bq], off);
+            }
+        }
+        if ((total + kTileHalf - 1) / kTileHalf > kTileBatches) direct = true;   // uniform: `total` is block-wide
+        __syncthreads();
+    }
+    if (direct) {   // degenerate tile: per-thread search in global memory (identical candidate set)
+        if (inr) {
+            Top5 t; knn5_grid(g, qx, qy, qz, t);
+            best = t;
+        }
+        return;
+    }
+    if (dbg & 16) return;
+    // ---- phase 2: this thread's 9 windows (global index ranges) and the tile rows they live in
+    int wbeg[9], wend[9], wrow[9];
+    float wlb[9];
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+#pragma unroll
+    for (int n = 0; n < 9; n++) {
+        const int w = n;   // slot n holds row row_order(n): centre first, so later rows can be pruned
+        const int ro = row_order(n);
+        int y = cy + (ro / 3 - 1), z = cz + (ro % 3 - 1);
+        wlb[n] = row_lower_bound(g, qy, qz, cy, cz, ro / 3 - 1, ro % 3 - 1);
+        bool okw = inr && x0 <= x1 && y >= 0 && y < g.ny && z >= 0 && z < g.nz;
+        wrow[w] = okw ? (y - ya) * nzt + (z - za) : -1;
+        int row = (z * g.ny + y) * g.nx;
+        wbeg[w] = okw ? g.cell_start[row + x0] : 0;
+        wend[w] = okw ? g.cell_start[row + x1 + 1] : 0;
+    }
+    if (dbg & 32) return;
+    // ---- phase 3: batches of rows through LDS
+    const int nrows = (int)nrows_ll;
+    const int nbatch = (total + kTileHalf - 1) / kTileHalf;
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int k = 0; k < nbatch; k++) {
+        const int base = L.batch_base[k];
+        if (base != 0x7fffffff && !(dbg & 8)) {
+            for (int r = wave; r < nrows; r += kBlock / 64) {
+                int len = L.row_len[r];
+                if (len <= 0 || len > kTileHalf) continue;
+                int off = L.row_off[r];
+                if ((off + len - 1) / kTileHalf != k) continue;
+                const float4* src = g.pts + L.row_gbeg[r];
+                float4* dst = L.pts + (off - base);
+                for (int l = lane; l < len; l += 64) dst[l] = src[l];
+            }
+        }
+        __syncthreads();
+        if (base != 0x7fffffff && !(dbg & 4)) {
+#pragma unroll
+            for (int w = 0; w < 9; w++) {
+                int r = wrow[w];
+                if (r < 0 || wbeg[w] >= wend[w]) continue;
+                int len = L.row_len[r], off = L.row_off[r];
+                if (len > kTileHalf || (off + len - 1) / kTileHalf != k) continue;
+                if (wlb[w] > sel.worst()) continue;
+                const int shift = (off - base) - L.row_gbeg[r];   // LDS slot = global index + shift
+                int j = wbeg[w];
+                for (; j + 1 < wend[w]; j += 2) {
+                    float4 p0 = L.pts[j + shift], p1 = L.pts[j + 1 + shift];
+                    float d0 = dist2(p0, qx, qy, qz), d1 = dist2(p1, qx, qy, qz);
+                    sel.insert(d0, p0, j);
+                    sel.insert(d1, p1, j + 1);
+                }
+                if (j < wend[w]) { float4 p0 = L.pts[j + shift]; sel.insert(dist2(p0, qx, qy, qz), p0, j); }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- phase 4: rows longer than half a batch are scanned straight from global memory
+#pragma unroll
+    for (int w = 0; w < 9; w++) {
+        int r = wrow[w];
+        if (r < 0 || wbeg[w] >= wend[w]) continue;
+        if (L.row_len[r] <= kTileHalf) continue;
+        if (wlb[w] > sel.worst()) continue;
+        for (int j = wbeg[w]; j < wend[w]; j++) {
+            float4 p = g.pts[j];
+            sel.insert(dist2(p, qx, qy, qz), p, j);
+        }
+    }
+    sel.to_top5(best);
+}
+
+template <bool TILED>
 __global__ __launch_bounds__(kBlock) void k_associate_surf(
-        const float4* __restrict__ queries, const int* __restrict__ perm, int n_q, GridView g, PoseArg pa, MatchParams P,
+        const float4* __restrict__ queries, const int* __restrict__ perm, const int2* __restrict__ tiles, int n_q, GridView g, PoseArg pa, MatchParams P,
         float4* __restrict__ rec_nd, double* __restrict__ rec_score, unsigned char* __restrict__ valid,
         int* __restrict__ dbg_idx, float* __restrict__ dbg_d2, int* __restrict__ block_counts) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ TileLds L;
+    const int2 tile = tiles ? tiles[blockIdx.x] : make_int2(blockIdx.x * kBlock, min(kBlock, n_q - (int)blockIdx.x * kBlock));
+    const bool live = (int)threadIdx.x < tile.y;
+    int t = tile.x + threadIdx.x;
+    int i = live ? (perm ? perm[t] : t) : 0;
+    dq Q2; d3 T2;
+    load_assoc_pose(pa, P, Q2, T2);
+    float4 ql = queries[live ? i : 0];
+    d3 pmd = qrot(Q2, d3{(double)ql.x, (double)ql.y, (double)ql.z}) + T2;   // transformPoint, L:695-711
+    float px = (float)pmd.x, py = (float)pmd.y, pz = (float)pmd.z;
+    Top5 nn;
+    if (P.debug & 2) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) { nn.d[k] = 0.01f * (k + 1); nn.j[k] = (i * 7 + k) % g.n_points; }
+    } else if (TILED) knn5_tiled(g, L, live, px, py, pz, nn, P.debug);
+    else if (live) knn5_grid(g, px, py, pz, nn);
     bool ok = false;
-    if (t < n_q) {
-        int i = perm ? perm[t] : t;
-        dq Q2; d3 T2;
-        load_assoc_pose(pa, P, Q2, T2);
-        float4 ql = queries[i];
-        d3 pmd = qrot(Q2, d3{(double)ql.x, (double)ql.y, (double)ql.z}) + T2;   // transformPoint, L:695-711
-        float px = (float)pmd.x, py = (float)pmd.y, pz = (float)pmd.z;
-        Top5 nn;
-        if (P.debug & 2) {
-#pragma unroll
-            for (int k = 0; k < 5; k++) { nn.d[k] = 0.01f * (k + 1); nn.j[k] = (i * 7 + k) % g.n_points; }
-        } else knn5_grid(g, px, py, pz, nn);
-        if (dbg_idx) {
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                dbg_idx[(size_t)i * 5 + k] = nn.j[k] >= 0 ? __float_as_int(g.pts[nn.j[k]].w) : -1;
-                dbg_d2[(size_t)i * 5 + k] = nn.d[k];
-            }
-        }
-        float4 rn = make_float4(0.f, 0.f, 0.f, 0.f);
-        double score = 0.0;
-        if ((P.debug & 1) && nn.j[4] >= 0) { rn.x = nn.d[4]; ok = nn.d[4] < 0.5f; }
-        else if (nn.j[4] >= 0 && (double)nn.d[4] < P.kd_max_radius) {   // L:1615
-            float4 m[5];
-#pragma unroll
-            for (int k = 0; k < 5; k++) m[k] = g.pts[nn.j[k]];
-            col5 c0, c1, c2, b;
-            double sum_w = 0.0;
-            bool go = true;
-            if (P.variant == 0) {   // Livox reflectivity weighting, L:1617-1638
-                double w[5];
-#pragma unroll
-                for (int k = 0; k < 5; k++) {
-                    float diff = ql.w - g.aux[nn.j[k]];
-                    double tmp_w = (double)fabsf(diff);
-                    sum_w += tmp_w;
-                    w[k] = 1.0 / tmp_w;
-                }
-                if (sum_w > P.reflect_thres) go = false;
-#pragma unroll
-                for (int k = 0; k < 5; k++) {
-                    double wk = w[k] / sum_w;
-                    c0.v[k] = wk * (double)m[k].x; c1.v[k] = wk * (double)m[k].y; c2.v[k] = wk * (double)m[k].z;
-                    b.v[k] = -1.0 * wk;
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 5; k++) { c0.v[k] = (double)m[k].x; c1.v[k] = (double)m[k].y; c2.v[k] = (double)m[k].z; b.v[k] = -1.0; }
-            }
-            if (go) {
-                double nv[3];
-                lstsq53(c0, c1, c2, b, nv);
-                double nn_ = sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
-                double normInverse = 1.0 / nn_;
-                nv[0] /= nn_; nv[1] /= nn_; nv[2] /= nn_;
-                bool planeValid = true;
-#pragma unroll
-                for (int k = 0; k < 5; k++) {
-                    if (fabs(nv[0] * (double)m[k].x + nv[1] * (double)m[k].y + nv[2] * (double)m[k].z + normInverse) > P.surf_dist_thres) planeValid = false;
-                }
-                if (planeValid) {
-                    // L:1661-1662: float pd, float weight; sqrt(sqrt()) on a float argument is the float overload
-                    float pd = (float)(nv[0] * (double)px + nv[1] * (double)py + nv[2] * (double)pz + normInverse);
-                    float r2 = px * px + py * py + pz * pz;
-                    float weight = (float)(1.0 - 0.9 * (double)fabsf(pd) / (double)sqrtf(sqrtf(r2)));
-                    if ((double)weight > P.surf_weight_min) {
-                        ok = true;
-                        rn.x = (float)((double)weight * nv[0]); rn.y = (float)((double)weight * nv[1]); rn.z = (float)((double)weight * nv[2]);
-                        rn.w = (float)((double)weight * normInverse);
-                        if (P.variant == 0) score = P.lidar_const * ((double)weight + exp(-sum_w));   // L:1676
-                        else if (P.variant == 1) score = P.lidar_const * (double)weight;                // R:1515
-                        else score = 1.0;
-                    }
-                }
-            }
-        }
+    if (live) {
+        store_debug_nn(g, nn, i, dbg_idx, dbg_d2);
+        float4 rn; double score;
+        ok = surf_fit(g, P, nn, ql, px, py, pz, rn, score);
         rec_nd[i] = rn;
         rec_score[i] = score;
         valid[i] = ok ? 1 : 0;
@@ -413,67 +659,37 @@ __global__ __launch_bounds__(kBlock) void k_associate_surf(
     store_block_count(ok, block_counts);
 }
 
-// ================================================================================================
-// K6 — edge association.  records: rec_a[i] = (Ax, Ay, Az, s), rec_b[i] = (Bx, By, Bz, 0), valid[i]
-// ================================================================================================
+template <bool TILED>
 __global__ __launch_bounds__(kBlock) void k_associate_edge(
-        const float4* __restrict__ queries, const int* __restrict__ perm, int n_q, GridView g, PoseArg pa, MatchParams P,
+        const float4* __restrict__ queries, const int* __restrict__ perm, const int2* __restrict__ tiles, int n_q, GridView g, PoseArg pa, MatchParams P,
         float4* __restrict__ rec_a, float4* __restrict__ rec_b, unsigned char* __restrict__ valid,
         int* __restrict__ dbg_idx, float* __restrict__ dbg_d2, int* __restrict__ block_counts) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ TileLds L;
+    const int2 tile = tiles ? tiles[blockIdx.x] : make_int2(blockIdx.x * kBlock, min(kBlock, n_q - (int)blockIdx.x * kBlock));
+    const bool live = (int)threadIdx.x < tile.y;
+    int t = tile.x + threadIdx.x;
+    int i = live ? (perm ? perm[t] : t) : 0;
+    dq Q2; d3 T2;
+    load_assoc_pose(pa, P, Q2, T2);
+    float4 ql = queries[live ? i : 0];
+    d3 pmd = qrot(Q2, d3{(double)ql.x, (double)ql.y, (double)ql.z}) + T2;
+    float px = (float)pmd.x, py = (float)pmd.y, pz = (float)pmd.z;
+    Top5 nn;
+    if (TILED) knn5_tiled(g, L, live, px, py, pz, nn, P.debug);
+    else if (live) knn5_grid(g, px, py, pz, nn);
     bool ok = false;
-    if (t < n_q) {
-        int i = perm ? perm[t] : t;
-        dq Q2; d3 T2;
-        load_assoc_pose(pa, P, Q2, T2);
-        float4 ql = queries[i];
-        d3 pmd = qrot(Q2, d3{(double)ql.x, (double)ql.y, (double)ql.z}) + T2;
-        float px = (float)pmd.x, py = (float)pmd.y, pz = (float)pmd.z;
-        Top5 nn;
-        knn5_grid(g, px, py, pz, nn);
-        if (dbg_idx) {
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                dbg_idx[(size_t)i * 5 + k] = nn.j[k] >= 0 ? __float_as_int(g.pts[nn.j[k]].w) : -1;
-                dbg_d2[(size_t)i * 5 + k] = nn.d[k];
-            }
-        }
-        float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra;
-        if (nn.j[4] >= 0 && (double)nn.d[4] < P.edge_gate) {   // L:1543
-            d3 m[5]; d3 c{0, 0, 0};
-#pragma unroll
-            for (int k = 0; k < 5; k++) { float4 p = g.pts[nn.j[k]]; m[k] = d3{(double)p.x, (double)p.y, (double)p.z}; c = c + m[k]; }
-            c = d3{c.x / 5.0, c.y / 5.0, c.z / 5.0};
-            double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                d3 z = m[k] - c;
-                a00 += z.x * z.x; a01 += z.x * z.y; a02 += z.x * z.z; a11 += z.y * z.y; a12 += z.y * z.z; a22 += z.z * z.z;
-            }
-            double ev[3]; d3 vmin, vmax;
-            eig3_sym(a00, a01, a02, a11, a12, a22, ev, vmin, vmax);
-            if (ev[2] > 3.0 * ev[1]) {   // L:1575
-                d3 u = canon_sign(vmax);
-                d3 A = c + 0.1 * u, B = c - 0.1 * u;
-                bool keep = true;
-                if (P.edge_dist_max > 0) {   // R:1437-1443
-                    d3 lp{(double)px, (double)py, (double)pz};
-                    d3 nu = cross3(lp - A, lp - B);
-                    d3 de = A - B;
-                    double dist = sqrt(dot3(nu, nu)) / sqrt(dot3(de, de));
-                    keep = dist < P.edge_dist_max;
-                }
-                if (keep) {
-                    ok = true;
-                    ra = make_float4((float)A.x, (float)A.y, (float)A.z, (float)P.lidar_const);
-                    rb = make_float4((float)B.x, (float)B.y, (float)B.z, 0.f);
-                }
-            }
-        }
+    if (live) {
+        store_debug_nn(g, nn, i, dbg_idx, dbg_d2);
+        float4 ra, rb;
+        ok = edge_fit(g, P, nn, px, py, pz, ra, rb);
         rec_a[i] = ra; rec_b[i] = rb; valid[i] = ok ? 1 : 0;
     }
     store_block_count(ok, block_counts);
 }
+template __global__ void k_associate_surf<true>(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, int*);
+template __global__ void k_associate_surf<false>(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, int*);
+template __global__ void k_associate_edge<true>(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, int*);
+template __global__ void k_associate_edge<false>(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, int*);
 
 // ================================================================================================
 // Linearisation: residual + 1x7 global Jacobian per record, loss corrector, Gram reduction.
@@ -483,52 +699,55 @@ __global__ __launch_bounds__(kBlock) void k_associate_edge(
 // q = 0..63 in order; lane 36 sums the cost column.  Waves of a block are then added in order and the
 // block writes one 40-double partial; k_reduce_gn adds the partials in a fixed order.
 // ================================================================================================
-constexpr int kRow = 9;
-// Lane l < 36 owns the upper-triangle entry (a, b); lane 36 the cost column; lane 37 the count.
+constexpr int kRow = 10;          // LDS row: [J0..J6, r, 1, cost]
+constexpr int kLinBlock = 1024;   // linearisation block: 16 waves per CU, <= 256 partials for the final reduce
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+// Gram accumulation on the f64 matrix cores: for every wave, G += V^T V with V = 64 rows x 16 columns
+// (v = [J0..J6, r, 1, cost, 0...]), issued as 16 x v_mfma_f64_16x16x4_f64 (K = 4 rows per instruction).
+// A[i][k] and B[k][j] of that instruction are both V[row 4s+k][column i or j], i.e. every lane feeds the SAME
+// double to both operands: lane l supplies V[4s + l/16][l%16].  G[8][8] counts the residuals and G[8][9] is the
+// sum of the costs.  This is a reduction, not a GEMM re-shaping of the path: the 16 MFMAs replace a 64-step
+// LDS loop; summation order is fixed by the hardware, so results stay deterministic.
+// C/D layout of the f64 form: col = lane & 15, row = (lane >> 4) + 4 * reg (cdna_hip_programming.md §3).
 struct GramAcc {
-    double acc; int a, b;
-    __device__ __forceinline__ void init() {
-        int lane = threadIdx.x & 63;
-        a = 0; int l = lane;
-        while (a < 8 && l >= 8 - a) { l -= 8 - a; a++; }
-        b = a + l;
-        if (lane >= 36) { a = 8; b = 8; }
-        acc = 0.0;
-    }
+    v4f64 acc;
+    __device__ __forceinline__ void init() { acc = v4f64{0.0, 0.0, 0.0, 0.0}; }
     // all threads of the block must call this (it synchronises)
     __device__ __forceinline__ void add_rows(const double Jr[8], double cost, bool ok, double* lds) {
-        int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         double* rows = lds + wave * 64 * kRow;
         double* myrow = rows + lane * kRow;
 #pragma unroll
         for (int k = 0; k < 8; k++) myrow[k] = ok ? Jr[k] : 0.0;
-        myrow[8] = ok ? cost : 0.0;
-        unsigned long long bal = __ballot(ok);
+        myrow[8] = ok ? 1.0 : 0.0;
+        myrow[9] = ok ? cost : 0.0;
         __syncthreads();
-        if (lane < 36) {
-            double s = 0.0;
-#pragma unroll 16
-            for (int q = 0; q < 64; q++) s += rows[q * kRow + a] * rows[q * kRow + b];
-            acc += s;
-        } else if (lane == 36) {
-            double s = 0.0;
-#pragma unroll 16
-            for (int q = 0; q < 64; q++) s += rows[q * kRow + 8];
-            acc += s;
-        } else if (lane == 37) {
-            acc += (double)__popcll(bal);
+        const int col = lane & 15, kq = lane >> 4;
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            double a = col < kRow ? rows[(4 * s + kq) * kRow + col] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
         }
         __syncthreads();
     }
+    // block partial: 36 upper-triangle entries of the 8x8 Gram, [36] = cost, [37] = count
     __device__ __forceinline__ void finish(double* lds, double* __restrict__ partial_out) {
-        int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        double* wsum = lds + kBlock * kRow;
-        if (lane < 40) wsum[wave * 40 + lane] = lane < 38 ? acc : 0.0;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        double* dm = lds + wave * 256;   // this wave's 16x16 result, row-major
+        const int col = lane & 15, r0 = lane >> 4;
+#pragma unroll
+        for (int r = 0; r < 4; r++) dm[(r0 + 4 * r) * 16 + col] = acc[r];
         __syncthreads();
         if (threadIdx.x < 40) {
+            int e = threadIdx.x;
+            int row, cl;
+            if (e < 36) { int a = 0, l = e; while (l >= 8 - a) { l -= 8 - a; a++; } row = a; cl = a + l; }
+            else if (e == 36) { row = 8; cl = 9; }
+            else if (e == 37) { row = 8; cl = 8; }
+            else { row = 15; cl = 15; }   // spare slots: always zero
             double s = 0.0;
-            for (int w = 0; w < kBlock / 64; w++) s += wsum[w * 40 + threadIdx.x];
-            partial_out[threadIdx.x] = s;
+            for (int w = 0; w < kLinBlock / 64; w++) s += lds[w * 256 + row * 16 + cl];
+            partial_out[e] = s;
         }
     }
 };
@@ -538,7 +757,7 @@ __device__ __forceinline__ void load_body_pose(const PoseArg& pa, dq& Q, d3& T) 
     else { T = d3{pa.t[0], pa.t[1], pa.t[2]}; Q = dq{pa.q[0], pa.q[1], pa.q[2], pa.q[3]}; }
 }
 
-__global__ __launch_bounds__(kBlock) void k_linearize_surf(
+__global__ __launch_bounds__(kLinBlock) void k_linearize_surf(
         const float4* __restrict__ queries, int n_q, const float4* __restrict__ rec_nd, const double* __restrict__ rec_score,
         const unsigned char* __restrict__ valid, PoseArg pa, MatchParams P, const SlotState* __restrict__ state,
         const int* __restrict__ block_counts, int n_bc, double* __restrict__ partials) {
@@ -550,8 +769,9 @@ __global__ __launch_bounds__(kBlock) void k_linearize_surf(
     // N of R:861: this rank's count (sum of the association's block counts) or, when a multi-GPU caller has
     // all-reduced it, the global count in state->n_res
     double nscale = 1.0;
-    if (P.scale_surf_num > 0) nscale = P.scale_surf_num / (double)(block_counts ? sum_block_counts(block_counts, n_bc) : state->n_res[0]);
-    for (int base = blockIdx.x * kBlock; base < n_q; base += gridDim.x * kBlock) {
+    if (P.debug & 128) nscale = 1000.0 / 190000.0;
+    else if (P.scale_surf_num > 0) nscale = P.scale_surf_num / (double)(block_counts ? sum_block_counts(block_counts, n_bc) : state->n_res[0]);
+    for (int base = blockIdx.x * kLinBlock; base < n_q; base += gridDim.x * kLinBlock) {
         int i = base + threadIdx.x;
         bool ok = i < n_q && valid[i];
         double Jr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -580,7 +800,7 @@ __global__ __launch_bounds__(kBlock) void k_linearize_surf(
     ga.finish(lds, partials + (size_t)blockIdx.x * kPartialDoubles);
 }
 
-__global__ __launch_bounds__(kBlock) void k_linearize_edge(
+__global__ __launch_bounds__(kLinBlock) void k_linearize_edge(
         const float4* __restrict__ queries, int n_q, const float4* __restrict__ rec_a, const float4* __restrict__ rec_b,
         const unsigned char* __restrict__ valid, PoseArg pa, MatchParams P, const SlotState* __restrict__ state,
         const int* __restrict__ block_counts, int n_bc, double* __restrict__ partials) {
@@ -590,7 +810,7 @@ __global__ __launch_bounds__(kBlock) void k_linearize_edge(
     load_body_pose(pa, Q, T);
     double nscale = 1.0;   // R:843
     if (P.scale_edge_num > 0) nscale = P.scale_edge_num / (double)(block_counts ? sum_block_counts(block_counts, n_bc) : state->n_res[1]);
-    for (int base = blockIdx.x * kBlock; base < n_q; base += gridDim.x * kBlock) {
+    for (int base = blockIdx.x * kLinBlock; base < n_q; base += gridDim.x * kLinBlock) {
         int i = base + threadIdx.x;
         bool ok = i < n_q && valid[i];
         double Jr[8] = {0, 0, 0, 0, 0, 0, 0, 0};

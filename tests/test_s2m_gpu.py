@@ -308,3 +308,45 @@ def test_mid_size_outdoor_scene(gpu_ctx, oracle):
     Go, co, no = oracle.linearize_surf(rs, t0, q0, PO, 1000.0 / rs["count"])
     assert counts[0] == no
     assert np.abs(G - Go).max() <= 2e-6 * np.abs(Go).max()
+
+
+@pytest.mark.parametrize("opts", [dict(bin_queries=1, tiled=0), dict(bin_queries=1, tiled=1)])
+def test_query_order_options_do_not_change_results(gpu_ctx, oracle, opts):
+    """Binning / LDS tiling only change which thread handles which query: neighbour lists, records and the
+    Gram must be identical to the default path (and to the oracle)."""
+    w = synth.make_workload(n_map=600_000, n_az=391, half_extent=(150.0, 150.0))
+    P = L.make_params("rot")
+    PO = oracle.params("rot")
+    rng = np.random.default_rng(4)
+    scan = w["scan_xyz"][rng.permutation(w["scan_xyz"].shape[0])]     # incoherent order on purpose
+    tb, qb = L.api.body_pose_from_lidar(w["lidar_t"], w["lidar_q"], P)
+    t0, q0 = synth.perturbed_pose(tb, qb, np.random.default_rng(synth.SEED_POSE), 0.3, 2.0)
+    Q2, T2 = L.api.assoc_transform(t0, q0, P)
+    out = []
+    try:
+        for o in (dict(bin_queries=0, tiled=0), opts):
+            for k, v in o.items():
+                gpu_ctx.set_option(k, v)
+            gpu_ctx.set_debug(True)
+            m = L.ScanToMapMatcher(gpu_ctx, P)
+            m.set_input_cloud(L.KIND_SURF, w["map_xyz"])
+            m.set_queries(0, L.KIND_SURF, scan)
+            n = m.find_corresponding_surf_features(0, Q2, T2)
+            idx, d2 = m.neighbors(0, L.KIND_SURF, scan.shape[0])
+            rec = m.surf_records(0, scan.shape[0])
+            G, cost, counts = m.linearize(0, t0, q0, L.MASK_SURF)
+            out.append((n, idx, d2, rec, G, cost))
+    finally:
+        gpu_ctx.set_option("bin_queries", 0)
+        gpu_ctx.set_option("tiled", 0)
+    a, b = out
+    assert a[0] == b[0] > 5000
+    inside = a[2][:, 4] < 1.0
+    assert np.array_equal(a[1][inside], b[1][inside]) and np.array_equal(a[2][inside], b[2][inside])
+    for k in ("query_index", "cp", "n", "d", "score"):
+        assert np.array_equal(a[3][k], b[3][k])
+    assert np.array_equal(a[4], b[4]) and a[5] == b[5]
+    tree = oracle.KdTree(w["map_xyz"])
+    rs = oracle.associate_surf(tree, None, scan, None, Q2, T2, PO, nthreads=8)
+    assert rs["count"] == b[0]
+    assert np.array_equal(b[1][inside], rs["nn_idx"][inside])

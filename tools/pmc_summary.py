@@ -9,4 +9,4 @@ for path in sys.argv[1:]:
     for k, d in acc.items():
         if not k.startswith("lili::"):
             continue
-        print(path.split("/")[-2], k, " ".join(f"{c}={sum(v)/len(v):.4g}(n={len(v)})" for c, v in d.items()))
+        print(path.split("/")[-1][:2], k, " ".join(f"{c}={sum(v)/len(v):.4g}(n={len(v)})" for c, v in d.items()))
