@@ -1,0 +1,66 @@
+// lili_ceres_adapter.h — header-only glue between ceres::Solve and liblili_hip.so.
+//
+// Compiled only inside the reference's catkin workspace (needs <ceres/ceres.h>; Ceres is not available in the
+// build image of this repository, so this header is NOT built here — its algebra, lili_gram_to_factor(), lives
+// in the library and is unit-tested in tests/test_abi_cpu.py::test_gram_to_factor_reproduces_normal_equations).
+//
+// What it replaces in the reference (L/ = LiLi-OM/):
+//   for every correspondence:  new AutoDiffCostFunction<LidarEdgeFactor|LidarPlaneNormFactor,1,3,4>(...)
+//                              problem.AddResidualBlock(cost, CauchyLoss(1.0), t_ptr, q_ptr)
+//                                                          — L/src/BackendFusion.cpp:938-974
+// by ONE cost function per keyframe:
+//   problem.AddResidualBlock(new lili::LidarBatchFactor(ctx, slot, mask, params), nullptr, t_ptr, q_ptr);
+//
+// Contract mirrored from ceres::CostFunction: Evaluate(parameters, residuals, jacobians) with
+// parameters[0] = t[3], parameters[1] = q[4] (w,x,y,z); jacobians / jacobians[i] may be NULL; row-major
+// num_residuals x block_size; returning false makes Ceres reject the step.  The block has 9 residuals:
+// 8 rows of the square-root factor of the robustified Gram and one zero-Jacobian row that pads the cost to
+// sum 1/2 rho(r_i^2) (so Ceres' step-acceptance ratio sees the same cost as with per-point blocks); the loss is
+// already applied per residual on the GPU (same corrector as L/src/MarginalizationFactor.cpp:44-70), hence
+// loss_function = nullptr.  Ownership: ceres::Problem owns the factor (default options); the factor does not
+// own the lili context.  Threading: Ceres' num_threads stays 1 (the reference never sets it); one context per
+// thread otherwise.
+#pragma once
+#include <ceres/ceres.h>
+
+#include "lili_hip.h"
+
+namespace lili {
+
+class LidarBatchFactor : public ceres::SizedCostFunction<9, 3, 4> {
+public:
+    LidarBatchFactor(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params& params)
+        : ctx_(ctx), slot_(slot), mask_(kind_mask), params_(params) {}
+
+    bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const override {
+        double gram[64], cost = 0.0;
+        int counts[2] = {0, 0};
+        if (lili_s2m_linearize(ctx_, slot_, mask_, parameters[0], parameters[1], &params_, gram, &cost, counts) != LILI_OK)
+            return false;
+        double res[9], jac[63];
+        if (lili_gram_to_factor(gram, cost, res, jac) != LILI_OK) return false;
+        for (int i = 0; i < 9; ++i) residuals[i] = res[i];
+        if (jacobians) {
+            if (jacobians[0]) for (int r = 0; r < 9; ++r) for (int c = 0; c < 3; ++c) jacobians[0][r * 3 + c] = jac[r * 7 + c];
+            if (jacobians[1]) for (int r = 0; r < 9; ++r) for (int c = 0; c < 4; ++c) jacobians[1][r * 4 + c] = jac[r * 7 + 3 + c];
+        }
+        return true;
+    }
+
+    // Lidar contribution to MarginalizationInfo's A, b (L/src/MarginalizationFactor.cpp:3-29 uses rightCols(3) of
+    // the 1x4 quaternion Jacobian): rows/cols {0,1,2} and {4,5,6} of the Gram, b from column 7.
+    static void MarginalizationBlocks(const double gram[64], double A[36], double b[6]) {
+        const int idx[6] = {0, 1, 2, 4, 5, 6};
+        for (int i = 0; i < 6; ++i) {
+            for (int j = 0; j < 6; ++j) A[i * 6 + j] = gram[idx[i] * 8 + idx[j]];
+            b[i] = gram[idx[i] * 8 + 7];
+        }
+    }
+
+private:
+    lili_ctx* ctx_;
+    int slot_, mask_;
+    lili_s2m_params params_;
+};
+
+}  // namespace lili

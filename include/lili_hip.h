@@ -168,6 +168,10 @@ int lili_s2m_iterate(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_para
 /* Host-side helper used by the ceres adapter and the host LM: Gauss-Newton step from a host Gram. */
 int lili_gn_step_host(const double gram[64], double t[3], double q[4], double delta[6]);
 
+/* Square-root form of a Gram record for ceres (see include/lili_ceres_adapter.h): a 9-residual block whose
+ * J^T J, J^T r and cost equal those of the N robustified lidar residuals the Gram was reduced from. */
+int lili_gram_to_factor(const double gram[64], double cost, double residuals[9], double jacobian[63]);
+
 #ifdef __cplusplus
 }
 #endif

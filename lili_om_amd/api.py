@@ -99,6 +99,7 @@ _SIGS = {
     "lili_s2m_gn_update": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "lili_s2m_iterate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams), C.c_int]),
     "lili_gn_step_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lili_gram_to_factor": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
 }
 
 
@@ -306,6 +307,18 @@ def gn_step_host(gram, t, q):
     d = np.zeros(6)
     st = lib.lili_gn_step_host(_ptr(g), _ptr(t), _ptr(q), _ptr(d))
     return st, t, q, d
+
+
+def gram_to_factor(gram, cost):
+    """(residuals[9], jacobian[9,7]) of the ceres adapter block (include/lili_ceres_adapter.h)."""
+    lib = load_library()
+    g = _f64(gram, 64)
+    res = np.zeros(9)
+    jac = np.zeros(63)
+    rc = lib.lili_gram_to_factor(_ptr(g), float(cost), _ptr(res), _ptr(jac))
+    if rc != OK:
+        raise LiliError(f"lili_gram_to_factor failed ({rc})")
+    return res, jac.reshape(9, 7)
 
 
 def assoc_transform(t, q, params):

@@ -743,4 +743,39 @@ int lili_gn_step_host(const double gram[64], double t[3], double q[4], double de
     return 0;
 }
 
+
+// Square-root form of a Gram for the ceres adapter: returns a 9-residual block (residuals[9], jacobian 9x7
+// row-major) with  J~^T J~ = G[0:7,0:7],  J~^T r~ = G[0:7,7],  |r~|^2 = 2*cost  (the 9th residual pads the cost
+// to sum 1/2 rho(s_i); its Jacobian row is zero).  Uses a symmetric Jacobi eigen-decomposition G = V L V^T
+// (rank-deficient Grams are fine), [J~ r~] = L^1/2 V^T.  Host-side O(1) algebra by design.
+int lili_gram_to_factor(const double gram[64], double cost, double residuals[9], double jacobian[63]) {
+    if (!gram || !residuals || !jacobian) return LILI_E_ARG;
+    double A[8][8], V[8][8];
+    for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) { A[i][j] = 0.5 * (gram[i * 8 + j] + gram[j * 8 + i]); V[i][j] = i == j ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0, diag = 0;
+        for (int i = 0; i < 8; i++) { diag += std::fabs(A[i][i]); for (int j = i + 1; j < 8; j++) off += std::fabs(A[i][j]); }
+        if (!(off > 1e-300) || off <= 1e-17 * diag) break;
+        for (int p = 0; p < 7; p++) for (int q = p + 1; q < 8; q++) {
+            if (A[p][q] == 0.0) continue;
+            double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+            double tt = 1.0 / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+            if (theta < 0) tt = -tt;
+            double c = 1.0 / std::sqrt(tt * tt + 1.0), s = tt * c;
+            for (int k = 0; k < 8; k++) { double akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq; }
+            for (int k = 0; k < 8; k++) { double apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk; }
+            for (int k = 0; k < 8; k++) { double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq; }
+        }
+    }
+    for (int r = 0; r < 8; r++) {
+        double lam = A[r][r] > 0 ? std::sqrt(A[r][r]) : 0.0;   // tiny negative eigenvalues are rounding noise
+        for (int c = 0; c < 7; c++) jacobian[r * 7 + c] = lam * V[c][r];
+        residuals[r] = lam * V[7][r];
+    }
+    for (int c = 0; c < 7; c++) jacobian[8 * 7 + c] = 0.0;
+    double pad = 2.0 * cost - gram[63];
+    residuals[8] = pad > 0 ? std::sqrt(pad) : 0.0;   // rho concave => sum rho(s) >= sum rho'(s) s, so pad >= 0 up to rounding
+    return LILI_OK;
+}
+
 }  // extern "C"

@@ -139,9 +139,9 @@ template <int K> __device__ __forceinline__ void house_apply(col5& c, col5* o1, 
     } else {
         beta = sqrt(c0 * c0 + tailSq);
         if (c0 >= 0) beta = -beta;
-        double den = c0 - beta;
+        double inv_den = 1.0 / (c0 - beta);
 #pragma unroll
-        for (int i = K + 1; i < 5; i++) c.v[i] /= den;
+        for (int i = K + 1; i < 5; i++) c.v[i] *= inv_den;
         tau = (beta - c0) / beta;
     }
     c.v[K] = beta;
@@ -160,33 +160,34 @@ template <int K> __device__ __forceinline__ void house_apply(col5& c, col5* o1, 
     }
 }
 __device__ __forceinline__ void lstsq53(col5 c0, col5 c1, col5 c2, col5 b, double x[3]) {
+    // pivoting compares SQUARED column norms (same order as the norms, no sqrt needed)
     const double eps = 2.220446049250313e-16;
-    double n0 = sqrt(tail_sq<0>(c0)), n1 = sqrt(tail_sq<0>(c1)), n2 = sqrt(tail_sq<0>(c2));
+    double n0 = tail_sq<0>(c0), n1 = tail_sq<0>(c1), n2 = tail_sq<0>(c2);
     double maxn = fmax(n0, fmax(n1, n2));
-    double thr = (maxn * eps) * (maxn * eps) / 5.0;
+    double thr = maxn * (eps * eps) / 5.0;   // (max_norm * eps)^2 / rows
     int p0 = 0, p1 = 1, p2 = 2;   // original column index held in position 0,1,2
     int nz = 3;
     // ---- k = 0 : pivot among {0,1,2}
     {
         bool s1 = n1 > n0 && n1 >= n2;           // first maximum wins, like maxCoeff
         bool s2 = n2 > n0 && n2 > n1;
-        if (n0 * n0 < thr * 5.0 && n1 * n1 < thr * 5.0 && n2 * n2 < thr * 5.0) nz = 0;
-        swap_col(c0, c1, s1); if (s1) { double t = n0; n0 = n1; n1 = t; int ti = p0; p0 = p1; p1 = ti; }
-        swap_col(c0, c2, s2); if (s2) { double t = n0; n0 = n2; n2 = t; int ti = p0; p0 = p2; p2 = ti; }
+        if (maxn < thr * 5.0) nz = 0;
+        swap_col(c0, c1, s1); if (s1) { int ti = p0; p0 = p1; p1 = ti; }
+        swap_col(c0, c2, s2); if (s2) { int ti = p0; p0 = p2; p2 = ti; }
         house_apply<0>(c0, &c1, &c2, b);
     }
     // remaining column norms are recomputed exactly on the trailing rows (Eigen down-dates them and
     // recomputes when cancellation is detected; the pivot choice can differ only on near-ties)
-    n1 = sqrt(tail_sq<1>(c1)); n2 = sqrt(tail_sq<1>(c2));
+    n1 = tail_sq<1>(c1); n2 = tail_sq<1>(c2);
     {
         bool s2 = n2 > n1;
-        if (nz == 3 && fmax(n1, n2) * fmax(n1, n2) < thr * 4.0) nz = 1;
-        swap_col(c1, c2, s2); if (s2) { double t = n1; n1 = n2; n2 = t; int ti = p1; p1 = p2; p2 = ti; }
+        if (nz == 3 && fmax(n1, n2) < thr * 4.0) nz = 1;
+        swap_col(c1, c2, s2); if (s2) { int ti = p1; p1 = p2; p2 = ti; }
         house_apply<1>(c1, &c2, nullptr, b);
     }
-    n2 = sqrt(tail_sq<2>(c2));
+    n2 = tail_sq<2>(c2);
     {
-        if (nz == 3 && n2 * n2 < thr * 3.0) nz = 2;
+        if (nz == 3 && n2 < thr * 3.0) nz = 2;
         house_apply<2>(c2, nullptr, nullptr, b);
     }
     // back substitution on the leading nz pivots; R = [[c0[0], c1[0], c2[0]], [0, c1[1], c2[1]], [0, 0, c2[2]]]
@@ -194,12 +195,10 @@ __device__ __forceinline__ void lstsq53(col5 c0, col5 c1, col5 c2, col5 b, doubl
     if (nz >= 3) y2 = b.v[2] / c2.v[2];
     if (nz >= 2) y1 = (b.v[1] - c2.v[1] * y2) / c1.v[1];
     if (nz >= 1) y0 = (b.v[0] - c1.v[0] * y1 - c2.v[0] * y2) / c0.v[0];
-    double r0 = 0, r1 = 0, r2 = 0;
     // x[perm[i]] = y[i]
-    r0 = (p0 == 0) ? y0 : ((p1 == 0) ? y1 : y2);
-    r1 = (p0 == 1) ? y0 : ((p1 == 1) ? y1 : y2);
-    r2 = (p0 == 2) ? y0 : ((p1 == 2) ? y1 : y2);
-    x[0] = r0; x[1] = r1; x[2] = r2;
+    x[0] = (p0 == 0) ? y0 : ((p1 == 0) ? y1 : y2);
+    x[1] = (p0 == 1) ? y0 : ((p1 == 1) ? y1 : y2);
+    x[2] = (p0 == 2) ? y0 : ((p1 == 2) ? y1 : y2);
 }
 
 // ceres loss functions: rho[0..2] = rho(s), rho'(s), rho''(s)

@@ -415,7 +415,7 @@ __device__ __forceinline__ bool surf_fit(const GridView& g, const MatchParams& P
     lstsq53(c0, c1, c2, b, nv);
     double nn_ = sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
     double normInverse = 1.0 / nn_;
-    nv[0] /= nn_; nv[1] /= nn_; nv[2] /= nn_;
+    nv[0] *= normInverse; nv[1] *= normInverse; nv[2] *= normInverse;
     bool planeValid = true;
 #pragma unroll
     for (int k = 0; k < 5; k++) {

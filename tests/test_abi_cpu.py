@@ -90,3 +90,21 @@ def test_assoc_transform_matches_reference_algebra(oracle):
     assert np.allclose(oracle.qrot(Q2, tlb) + T2, t)
     back = np.array([Q2[0] * qlb[0] - Q2[1:] @ qlb[1:], *(Q2[0] * qlb[1:] + qlb[0] * Q2[1:] + np.cross(Q2[1:], qlb[1:]))])
     assert np.allclose(back, q)
+
+
+def test_gram_to_factor_reproduces_normal_equations():
+    """The ceres adapter's square-root block has the same J^T J, J^T r and cost as the residuals it replaces."""
+    rng = np.random.default_rng(1)
+    for n in (3, 7, 400):                      # n < 8 gives a rank-deficient Gram
+        Jr = rng.normal(size=(n, 8)) * rng.uniform(0.1, 10, size=8)
+        s = Jr[:, 7] ** 2
+        rho1 = 1.0 / (1.0 + s)                 # Cauchy: corrected rows = sqrt(rho') [J r]
+        Jc = Jr * np.sqrt(rho1)[:, None]
+        G = Jc.T @ Jc
+        cost = 0.5 * np.log1p(s).sum()
+        res, jac = L.api.gram_to_factor(G, cost)
+        scale = np.abs(G).max()
+        assert np.abs(jac.T @ jac - G[:7, :7]).max() <= 1e-12 * scale
+        assert np.abs(jac.T @ res - G[:7, 7]).max() <= 1e-12 * scale
+        assert abs(0.5 * res @ res - cost) <= 1e-12 * max(cost, 1.0)
+        assert not jac[8].any()
