@@ -106,6 +106,44 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
 /* Number of points / grid cells of the current index (diagnostics). */
 int lili_map_info(lili_ctx* ctx, int kind, int64_t* n_points, int64_t* n_cells, double* cell_edge);
 
+/* ---- feature extraction ----------------------------------------------------------------------- */
+
+/* Caller-owned output cloud: `capacity` points of `stride` bytes (>= 16; 32 for pcl::PointXYZI, whose x,y,z
+ * are floats at 0/4/8 — the 4th float written at offset 12 is the intensity, copy it to offset 16 for PCL or
+ * pass stride 16 and repack); `count` receives the number of points available (may exceed capacity). */
+typedef struct lili_feature_out {
+    void* data;
+    size_t capacity;
+    size_t stride;
+    int mem;          /* LILI_MEM_HOST or LILI_MEM_DEVICE */
+    size_t count;     /* out */
+} lili_feature_out;
+
+typedef struct lili_rot_params {
+    int n_scans;       /* 16 / 32 / 64  (R/src/Preprocessing.cpp:46, config line_num) */
+    int ds_rate;       /* R/config/config_fr_iosb.yaml:13 */
+    float ds_v;        /* 0.6, R/src/Preprocessing.cpp:14 */
+    float near_range;  /* 3.0, R/src/Preprocessing.cpp:281 */
+} lili_rot_params;
+
+/* Replaces the body of Preprocessing::cloudHandler of LiLi-OM-ROT (R/src/Preprocessing.cpp:277-527) for one
+ * scan: NaN / near-range filter, ring id + relative time, IMU deskew (q_imu = the integrated gyro quaternion of
+ * R:179-223, computed by the caller; q_lb the extrinsic), ring concatenation, 11-tap curvature, per-segment
+ * sharp / less-sharp / flat selection, per-ring VoxelGrid of the less-flat points.
+ *   scan  : raw points in firing order, aux_offset = byte offset of the intensity field;
+ *   full  : the ring-concatenated, deskewed cloud          (/lidar_cloud_cutted)
+ *   edge  : cornerPointsLessSharp, in push order            (/edge_features)
+ *   surf  : voxel-filtered less-flat points, ring by ring   (/surf_features)
+ * Points are written as (x, y, z, intensity = ring + 0.1 * relTime).  Blocking. */
+int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4], const double q_lb[4], const lili_rot_params* params,
+                     lili_feature_out* full, lili_feature_out* edge, lili_feature_out* surf);
+/* Intermediate products of the last lili_extract_rot for parity tests (any pointer may be NULL):
+ * counts = {n_full, n_edge, n_sharp, n_flat, n_lessflat, n_surf, halfPassed index, first valid index};
+ * ring_start/ring_end: 64 ints (scanStartInd / scanEndInd); per-point arrays are n_full long; index lists point
+ * into the full cloud. */
+int lili_extract_rot_debug(lili_ctx* ctx, int32_t counts[8], int32_t* ring_start, int32_t* ring_end, int32_t* full_src, float* curvature,
+                           int32_t* label, int32_t* edge_idx, int32_t* sharp_idx, int32_t* flat_idx, int32_t* lessflat_idx, int32_t* surf_cnt);
+
 /* ---- scan-to-map matcher -------------------------------------------------------------------- */
 
 /* Uploads the feature points of keyframe `slot` (surf_lasts_ds[idx] / edge_lasts_ds[idx],

@@ -28,6 +28,14 @@ class Cloud(C.Structure):
     _fields_ = [("data", C.c_void_p), ("n", C.c_size_t), ("stride", C.c_size_t), ("aux_offset", C.c_int), ("mem", C.c_int)]
 
 
+class FeatureOut(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("capacity", C.c_size_t), ("stride", C.c_size_t), ("mem", C.c_int), ("count", C.c_size_t)]
+
+
+class RotParams(C.Structure):
+    _fields_ = [("n_scans", C.c_int), ("ds_rate", C.c_int), ("ds_v", C.c_float), ("near_range", C.c_float)]
+
+
 class S2MParams(C.Structure):
     _fields_ = [("variant", C.c_int), ("loss", C.c_int), ("loss_a", C.c_double), ("lidar_const", C.c_double),
                 ("kd_max_radius", C.c_double), ("edge_gate", C.c_double), ("surf_dist_thres", C.c_double),
@@ -82,6 +90,8 @@ _SIGS = {
     "lili_sync": (C.c_int, [C.c_void_p]),
     "lili_set_debug": (C.c_int, [C.c_void_p, C.c_int]),
     "lili_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "lili_extract_rot": (C.c_int, [C.c_void_p, C.POINTER(Cloud), C.c_void_p, C.c_void_p, C.POINTER(RotParams), C.POINTER(FeatureOut), C.POINTER(FeatureOut), C.POINTER(FeatureOut)]),
+    "lili_extract_rot_debug": (C.c_int, [C.c_void_p] + [C.c_void_p] * 11),
     "lili_map_set": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Cloud), C.c_double]),
     "lili_map_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "lili_s2m_set_queries": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Cloud)]),
@@ -297,6 +307,42 @@ class ScanToMapMatcher:
 
     def iterate(self, slot, n_iters, kind_mask=MASK_SURF):
         self.ctx._chk(self.lib.lili_s2m_iterate(self.ctx.h, slot, kind_mask, C.byref(self.params), int(n_iters)))
+
+
+class RotExtractor:
+    """Host-side mirror of LiLi-OM-ROT's Preprocessing::cloudHandler (R/src/Preprocessing.cpp:248-535)."""
+
+    def __init__(self, ctx, n_scans=64, ds_rate=4, ds_v=0.6, near_range=3.0):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.params = RotParams(n_scans, ds_rate, ds_v, near_range)
+
+    def extract(self, pts_xyzi, q_imu=(1.0, 0, 0, 0), q_lb=(1.0, 0, 0, 0), debug=False):
+        pts = np.ascontiguousarray(pts_xyzi, dtype=np.float32)
+        n = pts.shape[0]
+        cloud = cloud_from_numpy(pts, aux_col=3)
+        cap = max(n, 1)
+        bufs = [np.zeros((cap, 4), np.float32) for _ in range(3)]
+        outs = [FeatureOut(b.ctypes.data, cap, 16, MEM_HOST, 0) for b in bufs]
+        qi, ql = _f64(q_imu, 4), _f64(q_lb, 4)
+        self.ctx._chk(self.lib.lili_extract_rot(self.ctx.h, C.byref(cloud), _ptr(qi), _ptr(ql), C.byref(self.params),
+                                                C.byref(outs[0]), C.byref(outs[1]), C.byref(outs[2])))
+        res = dict(full=bufs[0][:outs[0].count], edge=bufs[1][:outs[1].count], surf=bufs[2][:outs[2].count])
+        if debug:
+            counts = np.zeros(8, np.int32)
+            rs, re_ = np.zeros(64, np.int32), np.zeros(64, np.int32)
+            self.ctx._chk(self.lib.lili_extract_rot_debug(self.ctx.h, _ptr(counts), _ptr(rs), _ptr(re_), *([None] * 8)))
+            nf, ne, ns, nfl, nlf, nsu = [int(v) for v in counts[:6]]
+            arr = dict(full_src=np.zeros(nf, np.int32), curvature=np.zeros(nf, np.float32), label=np.zeros(nf, np.int32),
+                       edge_idx=np.zeros(ne, np.int32), sharp_idx=np.zeros(ns, np.int32), flat_idx=np.zeros(nfl, np.int32),
+                       lessflat_idx=np.zeros(nlf, np.int32), surf_cnt=np.zeros(nsu, np.int32))
+            self.ctx._chk(self.lib.lili_extract_rot_debug(self.ctx.h, _ptr(counts), _ptr(rs), _ptr(re_), _ptr(arr["full_src"]),
+                                                          _ptr(arr["curvature"]), _ptr(arr["label"]), _ptr(arr["edge_idx"]),
+                                                          _ptr(arr["sharp_idx"]), _ptr(arr["flat_idx"]), _ptr(arr["lessflat_idx"]),
+                                                          _ptr(arr["surf_cnt"])))
+            res.update(arr)
+            res.update(ring_start=rs[:self.params.n_scans], ring_end=re_[:self.params.n_scans], half_idx=int(counts[6]))
+        return res
 
 
 def gn_step_host(gram, t, q):

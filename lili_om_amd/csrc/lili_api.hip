@@ -1,8 +1,7 @@
 // C-ABI of liblili_hip.so (include/lili_hip.h): context, buffers, launches.  Host code only; the
 // kernels live in lili_s2m.hip / lili_extract.hip.  There is no CPU fallback anywhere in this file:
 // without a gfx950 device lili_ctx_create fails with LILI_E_NODEVICE.
-#include "../../include/lili_hip.h"
-#include "lili_kernels.h"
+#include "lili_ctx.h"
 
 #include <cmath>
 #include <cstdio>
@@ -33,86 +32,8 @@ __global__ void k_sum_counts(const int*, int, const int*, int, SlotState*);
 __global__ void k_gn_update(const double*, SlotState*);
 }  // namespace lili
 
-using namespace lili;
+#include "lili_ctx.h"
 
-namespace {
-
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    hipError_t ensure(size_t bytes) {
-        if (bytes <= cap) return hipSuccess;
-        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
-        size_t want = bytes + bytes / 8 + 256;
-        hipError_t e = hipMalloc(&p, want);
-        if (e == hipSuccess) cap = want;
-        return e;
-    }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
-    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
-};
-
-struct MapIndex {
-    bool valid = false;
-    int64_t n = 0, n_cells = 0;
-    double cell = 0;
-    GridView view{};
-    DevBuf pts, sorted, aux_sorted, cell_start, cell_tmp, pt_cell, block_sums;
-    bool has_aux = false;
-};
-
-struct KindSlot {
-    int64_t n_q = 0;
-    bool has_queries = false, has_records = false;
-    DevBuf q, rec0, rec1, valid, dbg_idx, dbg_d2, partials, perm, keys, block_counts, tiles;
-    int n_assoc_blocks = 0;  // grid of the last association launch (= number of per-block counts)
-    int n_tiles = 0;       // association grid when binned (tiles never span two super-cells)
-    bool binned = false;   // perm holds the super-cell (Morton) order of the queries for the current scan
-    int n_blocks = 0;      // association grid (one thread per query)
-    int n_lin_blocks = 0;  // linearisation grid (grid-stride, <= kMaxLinBlocks partials)
-};
-
-struct Slot {
-    KindSlot k[2];
-    bool use_global_counts = false;   // next linearize_dev reads the (all-reduced) counts in SlotState::n_res
-};
-
-constexpr int kLinBlock = 1024;      // must match lili_s2m.hip
-constexpr int kMaxLinBlocks = 256;
-constexpr size_t kLdsLinearize = (size_t)(kLinBlock * 10) * sizeof(double);   // rows [J r 1 cost]; reused for the 16x16 wave results
-
-}  // namespace
-
-struct lili_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    bool keep_nn = false;
-    std::string err;
-    MapIndex map[2];
-    Slot slots[LILI_MAX_SLOTS];
-    DevBuf states;       // SlotState[LILI_MAX_SLOTS]
-    DevBuf staging;      // raw host clouds
-    DevBuf gram;         // LILI_GRAM_DOUBLES per slot
-    DevBuf misc;         // bbox words etc.
-    DevBuf bin_hist, bin_start, bin_sums, bin_tcnt, bin_toff;   // query binning scratch
-    bool bin_queries = false;   // trust the caller's order (extractor output is ring-/voxel-ordered, i.e. coherent)
-    bool tiled = false;         // LDS-staged tiles: measured slower than the direct path once selection is branch-free
-    int max_cells = 1 << 26;
-
-    int fail(int code, const std::string& m) { err = m; return code; }
-    SlotState* state(int slot) { return states.as<SlotState>() + slot; }
-    double* gram_of(int slot) { return gram.as<double>() + (size_t)slot * LILI_GRAM_DOUBLES; }
-};
-
-#define HIPCHK(expr)                                                                                         \
-    do {                                                                                                     \
-        hipError_t _e = (expr);                                                                              \
-        if (_e != hipSuccess) return ctx->fail(LILI_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
-    } while (0)
-#define ARGCHK(cond, msg) do { if (!(cond)) return ctx->fail(LILI_E_ARG, msg); } while (0)
-
-static inline int nblocks(int64_t n, int per) { return (int)((n + per - 1) / per); }
 
 static MatchParams to_device_params(const lili_s2m_params* p) {
     MatchParams m{};
@@ -128,7 +49,7 @@ static MatchParams to_device_params(const lili_s2m_params* p) {
 }
 
 // copies / converts a described cloud into a device float4 array (x, y, z, aux)
-static int ingest_cloud(lili_ctx* ctx, const lili_cloud* c, DevBuf& out_f4) {
+int lili_ingest_cloud(lili_ctx* ctx, const lili_cloud* c, DevBuf& out_f4) {
     ARGCHK(c && (c->n == 0 || c->data), "cloud: null data");
     ARGCHK(c->stride >= 12 && c->stride % 4 == 0, "cloud: stride must be a multiple of 4 and >= 12");
     ARGCHK(c->aux_offset < 0 || (size_t)c->aux_offset + 4 <= c->stride, "cloud: aux_offset outside the point");
@@ -185,6 +106,8 @@ void lili_ctx_destroy(lili_ctx* ctx) {
     for (auto& m : ctx->map) { m.pts.release(); m.sorted.release(); m.aux_sorted.release(); m.cell_start.release(); m.cell_tmp.release(); m.pt_cell.release(); m.block_sums.release(); }
     for (auto& s : ctx->slots) for (auto& k : s.k) { k.q.release(); k.rec0.release(); k.rec1.release(); k.valid.release(); k.dbg_idx.release(); k.dbg_d2.release(); k.partials.release(); k.perm.release(); k.keys.release(); k.block_counts.release(); k.tiles.release(); }
     ctx->states.release(); ctx->staging.release(); ctx->gram.release(); ctx->misc.release(); ctx->bin_hist.release(); ctx->bin_start.release(); ctx->bin_sums.release(); ctx->bin_tcnt.release(); ctx->bin_toff.release();
+    if (ctx->ext_rot && ctx->ext_rot_free) ctx->ext_rot_free(ctx->ext_rot);
+    if (ctx->ext_livox && ctx->ext_livox_free) ctx->ext_livox_free(ctx->ext_livox);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -223,7 +146,7 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
     MapIndex& m = ctx->map[kind];
     m.valid = false;
     for (auto& s : ctx->slots) s.k[kind].binned = false;
-    int rc = ingest_cloud(ctx, cloud, m.pts);
+    int rc = lili_ingest_cloud(ctx, cloud, m.pts);
     if (rc != LILI_OK) return rc;
     m.n = (int64_t)cloud->n;
     m.has_aux = cloud->aux_offset >= 0;
@@ -308,7 +231,7 @@ int lili_s2m_set_queries(lili_ctx* ctx, int slot, int kind, const lili_cloud* cl
     HIPCHK(hipSetDevice(ctx->device));
     KindSlot& ks = ctx->slots[slot].k[kind];
     ks.has_queries = false; ks.has_records = false; ks.binned = false;
-    int rc = ingest_cloud(ctx, cloud, ks.q);
+    int rc = lili_ingest_cloud(ctx, cloud, ks.q);
     if (rc != LILI_OK) return rc;
     ks.n_q = (int64_t)cloud->n;
     ks.n_blocks = nblocks(ks.n_q, kBlock);

@@ -1,0 +1,100 @@
+// Internal: context and buffer types shared by the translation units of liblili_hip.so (not part of the ABI).
+#pragma once
+#include "../../include/lili_hip.h"
+#include "lili_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace lili;
+
+namespace lili_detail {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct MapIndex {
+    bool valid = false;
+    int64_t n = 0, n_cells = 0;
+    double cell = 0;
+    GridView view{};
+    DevBuf pts, sorted, aux_sorted, cell_start, cell_tmp, pt_cell, block_sums;
+    bool has_aux = false;
+};
+
+struct KindSlot {
+    int64_t n_q = 0;
+    bool has_queries = false, has_records = false;
+    DevBuf q, rec0, rec1, valid, dbg_idx, dbg_d2, partials, perm, keys, block_counts, tiles;
+    int n_assoc_blocks = 0;  // grid of the last association launch (= number of per-block counts)
+    int n_tiles = 0;       // association grid when binned (tiles never span two super-cells)
+    bool binned = false;   // perm holds the super-cell (Morton) order of the queries for the current scan
+    int n_blocks = 0;      // association grid (one thread per query)
+    int n_lin_blocks = 0;  // linearisation grid (grid-stride, <= kMaxLinBlocks partials)
+};
+
+struct Slot {
+    KindSlot k[2];
+    bool use_global_counts = false;   // next linearize_dev reads the (all-reduced) counts in SlotState::n_res
+};
+
+constexpr int kLinBlock = 1024;      // must match lili_s2m.hip
+constexpr int kMaxLinBlocks = 256;
+constexpr size_t kLdsLinearize = (size_t)(kLinBlock * 10) * sizeof(double);   // rows [J r 1 cost]; reused for the 16x16 wave results
+
+}  // namespace lili_detail
+using namespace lili_detail;
+
+struct lili_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool keep_nn = false;
+    std::string err;
+    MapIndex map[2];
+    Slot slots[LILI_MAX_SLOTS];
+    DevBuf states;       // SlotState[LILI_MAX_SLOTS]
+    DevBuf staging;      // raw host clouds
+    DevBuf gram;         // LILI_GRAM_DOUBLES per slot
+    DevBuf misc;         // bbox words etc.
+    DevBuf bin_hist, bin_start, bin_sums, bin_tcnt, bin_toff;   // query binning scratch
+    bool bin_queries = false;   // trust the caller's order (extractor output is ring-/voxel-ordered, i.e. coherent)
+    bool tiled = false;         // LDS-staged tiles: measured slower than the direct path once selection is branch-free
+    int max_cells = 1 << 26;
+    void* ext_rot = nullptr;                 // extractor state (lili_extract_rot.hip), freed through ext_rot_free
+    void (*ext_rot_free)(void*) = nullptr;
+    void* ext_livox = nullptr;
+    void (*ext_livox_free)(void*) = nullptr;
+
+    int fail(int code, const std::string& m) { err = m; return code; }
+    SlotState* state(int slot) { return states.as<SlotState>() + slot; }
+    double* gram_of(int slot) { return gram.as<double>() + (size_t)slot * LILI_GRAM_DOUBLES; }
+};
+
+#define HIPCHK(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t _e = (expr);                                                                              \
+        if (_e != hipSuccess) return ctx->fail(LILI_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+#define ARGCHK(cond, msg) do { if (!(cond)) return ctx->fail(LILI_E_ARG, msg); } while (0)
+
+static inline int nblocks(int64_t n, int per) { return (int)((n + per - 1) / per); }
+
+int lili_ingest_cloud(lili_ctx* ctx, const lili_cloud* c, lili_detail::DevBuf& out_f4);

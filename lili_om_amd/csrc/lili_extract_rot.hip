@@ -1,0 +1,591 @@
+// LOAM-style feature extractor of LiLi-OM-ROT on gfx950 — replaces R/src/Preprocessing.cpp:277-509
+// (R/ = LiLi-OM-ROT/) behind lili_extract_rot():
+//   k_rot_valid      NaN / near-range filter, first & last surviving point            (R:280-294)
+//   k_rot_classify   elevation -> ring id, azimuth, `halfPassed` latch index, per-block ring histogram   (R:308-365)
+//   k_rot_ring_scan  ring offsets (stable per-ring compaction = laserCloudScans[] + concatenation)        (R:371-382)
+//   k_rot_scatter    relTime / intensity, IMU deskew (slerp, f64), scatter into the ring-concatenated cloud (R:367-372,153-177)
+//   k_rot_curvature  11-tap curvature over the concatenated cloud, LDS-staged tile + 5-point halo         (R:385-394)
+//   k_rot_select     one workgroup per ring: 6 segments rank-sorted by (curvature, index), greedy sharp /
+//                    less-sharp / flat picks with +-5 neighbour suppression, less-flat list, per-ring
+//                    VoxelGrid(ds_v) (bitonic sort of (voxel, index) keys in LDS, in-order centroids)     (R:401-508)
+//   k_rot_compact    ordered concatenation of the per-ring lists
+// Decisions are integer / f32 exact; the only transcendental inputs to a decision (atan for the ring id,
+// atan2 for relTime) are evaluated in f64 and rounded to f32 — the "reproducible" definition the oracle
+// offers as atan_mode = 1 (glibc's float overloads are not correctly rounded).
+// Sort ties: (curvature, index) / (voxel, index) — std::sort's order on ties is unspecified.
+#include "lili_ctx.h"
+#include "lili_device_math.h"
+
+namespace lili {
+
+constexpr int kRotBlock = 1024;
+constexpr int kMaxRings = 64;
+constexpr int kSegEdgeCap = 10;   // <= 10 less-sharp picks per segment (R:425)
+constexpr int kRingEdgeCap = 6 * kSegEdgeCap;
+constexpr int kRingFlatCap = 6 * 4;
+constexpr int kRingSharpCap = 6 * 2;
+
+struct RotDev {
+    int n_scans, ds_rate;
+    float ds_v, near_thres;
+    double q_imu[4], q_lb[4];
+};
+
+struct RotState {
+    int first_valid, last_valid, half_idx, n_full;
+    int ring_count[kMaxRings], ring_base[kMaxRings], ring_start[kMaxRings], ring_end[kMaxRings];
+    int ring_nedge[kMaxRings], ring_nsharp[kMaxRings], ring_nflat[kMaxRings], ring_nlf[kMaxRings], ring_nsurf[kMaxRings];
+    int n_edge, n_sharp, n_flat, n_lessflat, n_surf;
+    int fallback_rings;   // rings that did not fit the LDS budget and took the global-memory path
+};
+
+// f32 atan / atan2 defined as the f64 function rounded to f32
+__device__ __forceinline__ float atan_r(float v) { return (float)atan((double)v); }
+__device__ __forceinline__ float atan2_r(float y, float x) { return (float)atan2((double)y, (double)x); }
+
+__device__ __forceinline__ dq qslerp_identity(double t, dq b) {   // Eigen 3.3 slerp of Identity towards b
+    const double one = 1.0 - 2.220446049250313e-16;
+    double d = b.w;
+    double absD = fabs(d);
+    double s0, s1;
+    if (absD >= one) { s0 = 1.0 - t; s1 = t; }
+    else {
+        double theta = acos(absD);
+        double sinTheta = sin(theta);
+        s0 = sin((1.0 - t) * theta) / sinTheta;
+        s1 = sin(t * theta) / sinTheta;
+    }
+    if (d < 0) s1 = -s1;
+    return dq{s0 + s1 * b.w, s1 * b.x, s1 * b.y, s1 * b.z};
+}
+
+__global__ void k_rot_init(RotState* st) {
+    int t = threadIdx.x;
+    if (t == 0) { st->first_valid = 0x7fffffff; st->last_valid = -1; st->half_idx = 0x7fffffff; st->n_full = 0;
+                  st->n_edge = st->n_sharp = st->n_flat = st->n_lessflat = st->n_surf = 0; st->fallback_rings = 0; }
+    if (t < kMaxRings) { st->ring_count[t] = 0; st->ring_base[t] = 0; st->ring_start[t] = 0; st->ring_end[t] = 0;
+                         st->ring_nedge[t] = st->ring_nsharp[t] = st->ring_nflat[t] = st->ring_nlf[t] = st->ring_nsurf[t] = 0; }
+}
+
+__global__ __launch_bounds__(256) void k_rot_valid(const float4* __restrict__ in, int n, float thres, unsigned char* __restrict__ valid, RotState* st) {
+    int first = 0x7fffffff, last = -1;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float4 p = in[i];
+        bool ok = isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && !(p.x * p.x + p.y * p.y + p.z * p.z < thres * thres);   // R:131-134
+        valid[i] = ok;
+        if (ok) { first = min(first, i); last = max(last, i); }
+    }
+    for (int o = 32; o > 0; o >>= 1) { first = min(first, __shfl_xor(first, o)); last = max(last, __shfl_xor(last, o)); }
+    __shared__ int sf[4], sl[4];
+    if ((threadIdx.x & 63) == 0) { sf[threadIdx.x >> 6] = first; sl[threadIdx.x >> 6] = last; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int f = min(min(sf[0], sf[1]), min(sf[2], sf[3])), l = max(max(sl[0], sl[1]), max(sl[2], sl[3]));
+        if (f != 0x7fffffff) atomicMin(&st->first_valid, f);
+        if (l >= 0) atomicMax(&st->last_valid, l);
+    }
+}
+
+__device__ __forceinline__ void start_end_ori(const float4* __restrict__ in, const RotState* st, float& startOri, float& endOri) {
+    float4 a = in[st->first_valid], b = in[st->last_valid];
+    startOri = -atan2_r(a.y, a.x);                                    // R:285
+    endOri = (float)((double)(-atan2_r(b.y, b.x)) + 2 * M_PI);       // R:286-288
+    if ((double)(endOri - startOri) > 3 * M_PI) endOri = (float)((double)endOri - 2 * M_PI);
+    else if ((double)(endOri - startOri) < M_PI) endOri = (float)((double)endOri + 2 * M_PI);
+}
+
+// ring id (R:315-343); returns -1 when the point is dropped
+__device__ __forceinline__ int ring_of(float4 p, int n_scans) {
+    float at = atan_r(p.z / sqrtf(p.x * p.x + p.y * p.y));
+    float angle = (float)((double)(at * 180.0f) / M_PI);    // float product, double division, narrowed (R:315)
+    int scanID;
+    if (n_scans == 16) {
+        scanID = (int)((double)((angle + 15.0f) / 2.0f) + 0.5);
+        if (scanID > 15 || scanID < 0) return -1;
+    } else if (n_scans == 32) {
+        scanID = (int)(((double)angle + 92.0 / 3.0) * 3.0 / 4.0);
+        if (scanID > 31 || scanID < 0) return -1;
+    } else {
+        if ((double)angle >= -8.83) scanID = (int)((double)(2.0f - angle) * 3.0 + 0.5);
+        else scanID = 32 + (int)((-8.83 - (double)angle) * 2.0 + 0.5);
+        if ((double)angle > 2.0 || (double)angle < -24.33 || scanID > 50 || scanID < 0) return -1;
+    }
+    return scanID;
+}
+
+__global__ __launch_bounds__(kRotBlock) void k_rot_classify(const float4* __restrict__ in, int n, const unsigned char* __restrict__ valid,
+                                                            RotDev P, RotState* st, signed char* __restrict__ scan_id, float* __restrict__ ori_raw,
+                                                            int* __restrict__ block_hist /*[nb][64]*/) {
+    __shared__ int hist[kMaxRings];
+    __shared__ int half_min;
+    if (threadIdx.x < kMaxRings) hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) half_min = 0x7fffffff;
+    __syncthreads();
+    if (st->last_valid < 0) { if (threadIdx.x < kMaxRings) block_hist[blockIdx.x * kMaxRings + threadIdx.x] = 0; return; }
+    float startOri, endOri;
+    start_end_ori(in, st, startOri, endOri);
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int id = -1;
+    if (i < n && valid[i]) {
+        float4 p = in[i];
+        id = ring_of(p, P.n_scans);
+        if (id >= 0) {
+            float ori = -atan2_r(p.y, p.x);                         // R:349
+            ori_raw[i] = ori;
+            // would this point set halfPassed if it were reached with halfPassed == false?  (R:351-357)
+            float o1 = ori;
+            if ((double)o1 < (double)startOri - M_PI / 2) o1 = (float)((double)o1 + 2 * M_PI);
+            else if ((double)o1 > (double)startOri + M_PI * 3 / 2) o1 = (float)((double)o1 - 2 * M_PI);
+            if ((double)(o1 - startOri) > M_PI) atomicMin(&half_min, i);
+            atomicAdd(&hist[id], 1);
+        }
+    }
+    if (i < n) scan_id[i] = (signed char)id;
+    __syncthreads();
+    if (threadIdx.x < kMaxRings) block_hist[blockIdx.x * kMaxRings + threadIdx.x] = hist[threadIdx.x];
+    if (threadIdx.x == 0 && half_min != 0x7fffffff) atomicMin(&st->half_idx, half_min);
+}
+
+__global__ void k_rot_ring_scan(int* __restrict__ block_hist, int nb, RotDev P, RotState* st) {
+    __shared__ int cnt[kMaxRings];
+    int r = threadIdx.x;
+    if (r < kMaxRings) {
+        int run = 0;
+        for (int b = 0; b < nb; b++) { int c = block_hist[b * kMaxRings + r]; block_hist[b * kMaxRings + r] = run; run += c; }
+        cnt[r] = run;
+    }
+    __syncthreads();
+    if (r == 0) {
+        int base = 0;
+        for (int k = 0; k < kMaxRings; k++) {
+            st->ring_count[k] = cnt[k]; st->ring_base[k] = base;
+            if (k < P.n_scans) { st->ring_start[k] = base + 5; st->ring_end[k] = base + cnt[k] - 6; }   // R:379-381
+            base += cnt[k];
+        }
+        st->n_full = base;
+    }
+}
+
+__global__ __launch_bounds__(kRotBlock) void k_rot_scatter(const float4* __restrict__ in, int n, const signed char* __restrict__ scan_id,
+                                                           const float* __restrict__ ori_raw, RotDev P, const RotState* __restrict__ st,
+                                                           const int* __restrict__ block_base, float4* __restrict__ full, int* __restrict__ full_src) {
+    __shared__ int wave_hist[kRotBlock / 64][kMaxRings];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = threadIdx.x; k < (kRotBlock / 64) * kMaxRings; k += blockDim.x) (&wave_hist[0][0])[k] = 0;
+    __syncthreads();
+    if (st->last_valid < 0) return;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int id = i < n ? (int)scan_id[i] : -1;
+    // stable rank of the point among the points of its ring inside this wave
+    int rank = 0;
+    unsigned long long todo = __ballot(id >= 0);
+    while (todo) {
+        int leader = __ffsll((long long)todo) - 1;
+        int r0 = __shfl(id, leader);
+        unsigned long long m = __ballot(id == r0);
+        if (id == r0) rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == leader) wave_hist[wave][r0] = __popcll(m);
+        todo &= ~m;
+    }
+    __syncthreads();
+    if (threadIdx.x < kMaxRings) {   // exclusive prefix over the waves of the block, per ring
+        int run = 0;
+        for (int w = 0; w < kRotBlock / 64; w++) { int c = wave_hist[w][threadIdx.x]; wave_hist[w][threadIdx.x] = run; run += c; }
+    }
+    __syncthreads();
+    if (id < 0) return;
+    int pos = st->ring_base[id] + block_base[blockIdx.x * kMaxRings + id] + wave_hist[wave][id] + rank;
+    float startOri, endOri;
+    start_end_ori(in, st, startOri, endOri);
+    float ori = ori_raw[i];
+    if (i <= st->half_idx) {   // halfPassed was still false when the reference reached this point (R:350-358)
+        if ((double)ori < (double)startOri - M_PI / 2) ori = (float)((double)ori + 2 * M_PI);
+        else if ((double)ori > (double)startOri + M_PI * 3 / 2) ori = (float)((double)ori - 2 * M_PI);
+    } else {                    // R:359-365
+        ori = (float)((double)ori + 2 * M_PI);
+        if ((double)ori < (double)endOri - M_PI * 3 / 2) ori = (float)((double)ori + 2 * M_PI);
+        else if ((double)ori > (double)endOri + M_PI / 2) ori = (float)((double)ori - 2 * M_PI);
+    }
+    float relTime = (ori - startOri) / (endOri - startOri);          // R:367
+    float intensity = (float)((double)id + 0.1 * (double)relTime);  // R:368
+    // undistortion, R:153-177
+    float4 p = in[i];
+    int line = (int)intensity;
+    double dt_i = (double)(intensity - (float)line);
+    double ratio = dt_i / 0.1;
+    if (ratio >= 1.0) ratio = 1.0;
+    dq qimu{P.q_imu[0], P.q_imu[1], P.q_imu[2], P.q_imu[3]}, qlb{P.q_lb[0], P.q_lb[1], P.q_lb[2], P.q_lb[3]};
+    dq qs = qslerp_identity(ratio, qimu);
+    qs = qmul(qmul(qlb, qs), qinv(qlb));
+    d3 r = qrot(qs, d3{(double)p.x, (double)p.y, (double)p.z});
+    full[pos] = make_float4((float)r.x, (float)r.y, (float)r.z, intensity);
+    full_src[pos] = i;
+}
+
+// 11-tap curvature (R:385-394): strictly left-to-right f32 sums, tile of 256 + 5-point halo in LDS
+__global__ __launch_bounds__(256) void k_rot_curvature(const float4* __restrict__ full, const RotState* __restrict__ st, float* __restrict__ curv) {
+    __shared__ float sx[256 + 10], sy[256 + 10], sz[256 + 10];
+    const int n = st->n_full;
+    const int base = blockIdx.x * 256;
+    if (base >= n) return;
+    for (int k = threadIdx.x; k < 256 + 10; k += 256) {
+        int g = base - 5 + k;
+        float4 p = (g >= 0 && g < n) ? full[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+        sx[k] = p.x; sy[k] = p.y; sz[k] = p.z;
+    }
+    __syncthreads();
+    int i = base + threadIdx.x;
+    if (i >= n) return;
+    float c = 0.f;
+    if (i >= 5 && i < n - 5) {
+        const int k = threadIdx.x + 5;
+        float dX = sx[k - 5] + sx[k - 4] + sx[k - 3] + sx[k - 2] + sx[k - 1] - 10 * sx[k] + sx[k + 1] + sx[k + 2] + sx[k + 3] + sx[k + 4] + sx[k + 5];
+        float dY = sy[k - 5] + sy[k - 4] + sy[k - 3] + sy[k - 2] + sy[k - 1] - 10 * sy[k] + sy[k + 1] + sy[k + 2] + sy[k + 3] + sy[k + 4] + sy[k + 5];
+        float dZ = sz[k - 5] + sz[k - 4] + sz[k - 3] + sz[k - 2] + sz[k - 1] - 10 * sz[k] + sz[k + 1] + sz[k + 2] + sz[k + 3] + sz[k + 4] + sz[k + 5];
+        c = dX * dX + dY * dY + dZ * dZ;
+    }
+    curv[i] = c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-ring selection
+// ------------------------------------------------------------------------------------------------
+constexpr int kRingLdsCap = 4096;   // ring points held in LDS (SYN: 3125, HDL-64E: ~2100, VLP-16: ~1800)
+
+__device__ __forceinline__ float gap2(const float4* __restrict__ P, int a, int b) {   // R:435-438
+    float dX = P[a].x - P[b].x, dY = P[a].y - P[b].y, dZ = P[a].z - P[b].z;
+    return dX * dX + dY * dY + dZ * dZ;
+}
+__device__ __forceinline__ float range2(const float4* __restrict__ P, int k) { return P[k].x * P[k].x + P[k].y * P[k].y + P[k].z * P[k].z; }
+
+struct RingLds {
+    float4 pts[kRingLdsCap + 16];          // ring points incl. the +-5 margins used by the suppression loops
+    unsigned long long keys[kRingLdsCap];  // bitonic (voxel, index) keys
+    float curv[kRingLdsCap + 16];
+    int sort_ind[kRingLdsCap + 16];
+    signed char picked[kRingLdsCap + 16];
+    signed char label[kRingLdsCap + 16];
+    int scan[kRotBlock / 64 + 1];
+    float red[6][kRotBlock / 64];
+    int misc[8];
+};
+
+__device__ __forceinline__ int block_excl_scan_1024(int v, int* lds, int& total) {
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) lds[wave] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < kRotBlock / 64; w++) { int s = lds[w]; if (w < wave) base += s; tot += s; }
+    __syncthreads();
+    total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(kRotBlock) void k_rot_select(const float4* __restrict__ full, const float* __restrict__ curv_g, RotDev P, RotState* st,
+                                                          int* __restrict__ label_g, int* __restrict__ ring_edge /*[64][60]*/,
+                                                          int* __restrict__ ring_sharp /*[64][12]*/, int* __restrict__ ring_flat /*[64][24]*/,
+                                                          int* __restrict__ lessflat_tmp /*[n]*/, float4* __restrict__ surf_tmp /*[n]*/,
+                                                          int* __restrict__ surf_cnt_tmp /*[n]*/) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    RingLds& L = *reinterpret_cast<RingLds*>(smem);
+    const int ring = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int rbase = st->ring_base[ring], rcount = st->ring_count[ring];
+    const int rs = st->ring_start[ring], re = st->ring_end[ring];
+    // labels of every point of the ring default to 0 (R:393)
+    for (int k = tid; k < rcount; k += kRotBlock) label_g[rbase + k] = 0;
+    if (ring >= P.n_scans || re - rs < 6 || ring % P.ds_rate != 0) return;      // R:402
+    if (rcount > kRingLdsCap) {     // does not fit the LDS budget: not supported by this kernel version
+        if (tid == 0) atomicAdd(&st->fallback_rings, 1);
+        return;
+    }
+    // ---- stage the ring: local index l <-> global index rbase + l
+    for (int k = tid; k < rcount; k += kRotBlock) {
+        L.pts[k] = full[rbase + k]; L.curv[k] = curv_g[rbase + k];
+        L.picked[k] = 0; L.label[k] = 0; L.sort_ind[k] = k;
+    }
+    __syncthreads();
+    const int s0 = rs - rbase, e0 = re - rbase;   // local scanStartInd / scanEndInd
+    // ---- rank sort of every segment by (curvature, index)  (std::sort, R:409-410)
+    for (int k = s0 + tid; k <= e0 - 1; k += kRotBlock) {
+        // which segment holds k?  sp_j = s0 + (e0 - s0) * j / 6
+        int j = 0;
+#pragma unroll
+        for (int jj = 1; jj < 6; jj++) if (k >= s0 + (e0 - s0) * jj / 6) j = jj;
+        int sp = s0 + (e0 - s0) * j / 6, ep = s0 + (e0 - s0) * (j + 1) / 6 - 1;
+        float ck = L.curv[k];
+        int rank = 0;
+        for (int m = sp; m <= ep; m++) { float cm = L.curv[m]; rank += (cm < ck || (cm == ck && m < k)) ? 1 : 0; }
+        L.sort_ind[sp + rank] = k;
+    }
+    __syncthreads();
+    // ---- greedy picks, sequential by construction (suppression spills across segment borders, A4 iv)
+    if (tid == 0) {
+        int ne = 0, nsh = 0, nfl = 0;
+        const float4* Pp = L.pts;
+        for (int j = 0; j < 6; j++) {
+            int sp = s0 + (e0 - s0) * j / 6, ep = s0 + (e0 - s0) * (j + 1) / 6 - 1;
+            int largest = 0;
+            for (int k = ep; k >= sp; k--) {                                    // R:413-453
+                int ind = L.sort_ind[k];
+                if (!((double)L.curv[ind] > 2.0)) break;                        // sorted: nothing further can qualify
+                if (L.picked[ind] == 0) {
+                    largest++;
+                    if (largest <= 2) { L.label[ind] = 2; ring_sharp[ring * kRingSharpCap + nsh++] = rbase + ind; ring_edge[ring * kRingEdgeCap + ne++] = rbase + ind; }
+                    else if (largest <= 10) { L.label[ind] = 1; ring_edge[ring * kRingEdgeCap + ne++] = rbase + ind; }
+                    else break;
+                    L.picked[ind] = 1;
+                    for (int l = 1; l <= 5; l++) { if ((double)gap2(Pp, ind + l, ind + l - 1) > 0.05) break; L.picked[ind + l] = 1; }
+                    for (int l = -1; l >= -5; l--) { if ((double)gap2(Pp, ind + l, ind + l + 1) > 0.05) break; L.picked[ind + l] = 1; }
+                }
+            }
+            int smallest = 0;
+            for (int k = sp; k <= ep; k++) {                                    // R:456-492
+                int ind = L.sort_ind[k];
+                if (!((double)L.curv[ind] < 0.1)) break;                        // sorted ascending
+                if ((double)range2(Pp, ind) < 0.25) continue;
+                if (L.picked[ind] == 0) {
+                    L.label[ind] = -1; ring_flat[ring * kRingFlatCap + nfl++] = rbase + ind;
+                    smallest++;
+                    if (smallest >= 4) break;                                   // before the suppression (R:468-470)
+                    L.picked[ind] = 1;
+                    for (int l = 1; l <= 5; l++) { if ((double)gap2(Pp, ind + l, ind + l - 1) > 0.05) break; L.picked[ind + l] = 1; }
+                    for (int l = -1; l >= -5; l--) { if ((double)gap2(Pp, ind + l, ind + l + 1) > 0.05) break; L.picked[ind + l] = 1; }
+                }
+            }
+        }
+        st->ring_nedge[ring] = ne; st->ring_nsharp[ring] = nsh; st->ring_nflat[ring] = nfl;
+    }
+    __syncthreads();
+    for (int k = tid; k < rcount; k += kRotBlock) label_g[rbase + k] = L.label[k];
+    // ---- less-flat list in index order (R:494-499), compacted with a block scan
+    int n_lf = 0;
+    for (int k0 = s0; k0 <= e0 - 1; k0 += kRotBlock) {
+        int k = k0 + tid;
+        bool keep = k <= e0 - 1 && !((double)range2(L.pts, k) < 0.25) && L.label[k] <= 0;
+        int tot; int off = block_excl_scan_1024(keep ? 1 : 0, L.scan, tot);
+        if (keep) { lessflat_tmp[rbase + n_lf + off] = rbase + k; L.sort_ind[n_lf + off] = k; }   // sort_ind is free again: local less-flat list
+        n_lf += tot;
+    }
+    __syncthreads();
+    if (tid == 0) st->ring_nlf[ring] = n_lf;
+    // ---- pcl::VoxelGrid(ds_v) on the ring's less-flat points (R:502-508; PCL >= 1.8 semantics)
+    if (n_lf == 0) { if (tid == 0) st->ring_nsurf[ring] = 0; return; }
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int q = tid; q < n_lf; q += kRotBlock) {
+        float4 p = L.pts[L.sort_ind[q]];
+        mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+        mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) for (int o = 32; o > 0; o >>= 1) { mn[c] = fminf(mn[c], __shfl_xor(mn[c], o)); mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o)); }
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { L.red[c][tid >> 6] = mn[c]; L.red[3 + c][tid >> 6] = mx[c]; }
+    }
+    __syncthreads();
+    const float inv = 1.0f / P.ds_v;
+    int min_b[3], div_b[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float a = L.red[c][0], b = L.red[3 + c][0];
+        for (int w = 1; w < kRotBlock / 64; w++) { a = fminf(a, L.red[c][w]); b = fmaxf(b, L.red[3 + c][w]); }
+        min_b[c] = (int)floorf(a * inv);
+        div_b[c] = (int)floorf(b * inv) - min_b[c] + 1;
+    }
+    // keys: (voxel index << 32) | position in the less-flat list; padded with all-ones to the next power of two
+    int npow = 1; while (npow < n_lf) npow <<= 1;
+    for (int q = tid; q < npow; q += kRotBlock) {
+        unsigned long long key = ~0ull;
+        if (q < n_lf) {
+            float4 p = L.pts[L.sort_ind[q]];
+            int i0 = (int)(floorf(p.x * inv) - (float)min_b[0]);
+            int i1 = (int)(floorf(p.y * inv) - (float)min_b[1]);
+            int i2 = (int)(floorf(p.z * inv) - (float)min_b[2]);
+            unsigned idx = (unsigned)(i0 + i1 * div_b[0] + i2 * div_b[0] * div_b[1]);
+            key = ((unsigned long long)idx << 32) | (unsigned)q;
+        }
+        L.keys[q] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= npow; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int q = tid; q < npow; q += kRotBlock) {
+                int partner = q ^ j;
+                if (partner > q) {
+                    unsigned long long a = L.keys[q], b = L.keys[partner];
+                    bool up = (q & k) == 0;
+                    if ((a > b) == up) { L.keys[q] = b; L.keys[partner] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // run heads -> output slots; each head accumulates its voxel in list order (f32, like CentroidPoint)
+    int n_out = 0;
+    for (int q0 = 0; q0 < n_lf; q0 += kRotBlock) {
+        int q = q0 + tid;
+        bool head = q < n_lf && (q == 0 || (unsigned)(L.keys[q] >> 32) != (unsigned)(L.keys[q - 1] >> 32));
+        int tot; int off = block_excl_scan_1024(head ? 1 : 0, L.scan, tot);
+        if (head) {
+            unsigned vox = (unsigned)(L.keys[q] >> 32);
+            float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f; int cnt = 0;
+            for (int m = q; m < n_lf && (unsigned)(L.keys[m] >> 32) == vox; m++) {
+                float4 p = L.pts[L.sort_ind[(unsigned)L.keys[m]]];
+                sx += p.x; sy += p.y; sz += p.z; si += p.w; cnt++;
+            }
+            float fn = (float)cnt;
+            surf_tmp[rbase + n_out + off] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
+            surf_cnt_tmp[rbase + n_out + off] = cnt;
+        }
+        n_out += tot;
+    }
+    if (tid == 0) st->ring_nsurf[ring] = n_out;
+}
+
+// ordered concatenation of the per-ring lists (rings ascending, then push order inside the ring)
+__global__ __launch_bounds__(kRotBlock) void k_rot_compact(RotState* st, const float4* __restrict__ full,
+                                                           const int* __restrict__ ring_edge, const int* __restrict__ ring_sharp, const int* __restrict__ ring_flat,
+                                                           const int* __restrict__ lessflat_tmp, const float4* __restrict__ surf_tmp, const int* __restrict__ surf_cnt_tmp,
+                                                           int* __restrict__ edge_idx, float4* __restrict__ edge_pts, int* __restrict__ sharp_idx, int* __restrict__ flat_idx,
+                                                           int* __restrict__ lessflat_idx, float4* __restrict__ surf, int* __restrict__ surf_cnt) {
+    __shared__ int off[5][kMaxRings + 1];
+    if (threadIdx.x == 0) {
+        int a = 0, b = 0, c = 0, d = 0, e = 0;
+        for (int r = 0; r < kMaxRings; r++) {
+            off[0][r] = a; off[1][r] = b; off[2][r] = c; off[3][r] = d; off[4][r] = e;
+            a += st->ring_nedge[r]; b += st->ring_nsharp[r]; c += st->ring_nflat[r]; d += st->ring_nlf[r]; e += st->ring_nsurf[r];
+        }
+        off[0][kMaxRings] = a; off[1][kMaxRings] = b; off[2][kMaxRings] = c; off[3][kMaxRings] = d; off[4][kMaxRings] = e;
+        st->n_edge = a; st->n_sharp = b; st->n_flat = c; st->n_lessflat = d; st->n_surf = e;
+    }
+    __syncthreads();
+    for (int r = 0; r < kMaxRings; r++) {
+        const int rb = st->ring_base[r];
+        for (int k = threadIdx.x; k < st->ring_nedge[r]; k += blockDim.x) { int g = ring_edge[r * kRingEdgeCap + k]; edge_idx[off[0][r] + k] = g; edge_pts[off[0][r] + k] = full[g]; }
+        for (int k = threadIdx.x; k < st->ring_nsharp[r]; k += blockDim.x) sharp_idx[off[1][r] + k] = ring_sharp[r * kRingSharpCap + k];
+        for (int k = threadIdx.x; k < st->ring_nflat[r]; k += blockDim.x) flat_idx[off[2][r] + k] = ring_flat[r * kRingFlatCap + k];
+        for (int k = threadIdx.x; k < st->ring_nlf[r]; k += blockDim.x) lessflat_idx[off[3][r] + k] = lessflat_tmp[rb + k];
+        for (int k = threadIdx.x; k < st->ring_nsurf[r]; k += blockDim.x) { surf[off[4][r] + k] = surf_tmp[rb + k]; surf_cnt[off[4][r] + k] = surf_cnt_tmp[rb + k]; }
+    }
+}
+
+}  // namespace lili
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+namespace lili_detail {
+struct RotBuffers {
+    DevBuf in, valid, scan_id, ori_raw, block_hist, state, full, full_src, curv, label;
+    DevBuf ring_edge, ring_sharp, ring_flat, lessflat_tmp, surf_tmp, surf_cnt_tmp;
+    DevBuf edge_idx, edge_pts, sharp_idx, flat_idx, lessflat_idx, surf, surf_cnt;
+    lili::RotState host{};
+    int n_in = 0;
+    bool have = false;
+    void release() {
+        for (DevBuf* b : {&in, &valid, &scan_id, &ori_raw, &block_hist, &state, &full, &full_src, &curv, &label, &ring_edge, &ring_sharp, &ring_flat,
+                          &lessflat_tmp, &surf_tmp, &surf_cnt_tmp, &edge_idx, &edge_pts, &sharp_idx, &flat_idx, &lessflat_idx, &surf, &surf_cnt}) b->release();
+    }
+};
+}  // namespace lili_detail
+
+static lili_detail::RotBuffers* rot_of(lili_ctx* ctx) {
+    if (!ctx->ext_rot) { ctx->ext_rot = new lili_detail::RotBuffers(); ctx->ext_rot_free = [](void* p) { auto* r = static_cast<lili_detail::RotBuffers*>(p); r->release(); delete r; }; }
+    return static_cast<lili_detail::RotBuffers*>(ctx->ext_rot);
+}
+
+static int copy_out_f4(lili_ctx* ctx, const lili_feature_out* o, const float4* d_src, size_t count) {
+    if (!o || !o->data || count == 0) return LILI_OK;
+    size_t k = std::min(count, o->capacity);
+    if (k == 0) return LILI_OK;
+    size_t stride = o->stride ? o->stride : sizeof(float4);
+    ARGCHK(stride >= sizeof(float4), "feature_out: stride must be >= 16");
+    hipMemcpyKind kind = o->mem == LILI_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    HIPCHK(hipMemcpy2DAsync(o->data, stride, d_src, sizeof(float4), sizeof(float4), k, kind, ctx->stream));
+    return LILI_OK;
+}
+
+extern "C" {
+
+int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4], const double q_lb[4], const lili_rot_params* params,
+                     lili_feature_out* full, lili_feature_out* edge, lili_feature_out* surf) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(scan && q_imu && q_lb && params, "extract_rot: null argument");
+    ARGCHK(params->n_scans == 16 || params->n_scans == 32 || params->n_scans == 64, "extract_rot: n_scans must be 16, 32 or 64");
+    ARGCHK(params->ds_rate >= 1, "extract_rot: ds_rate must be >= 1");
+    ARGCHK(params->ds_v > 0, "extract_rot: ds_v must be positive");
+    ARGCHK(scan->n <= 400000, "extract_rot: more than 400000 points (the reference's fixed arrays, R/src/Preprocessing.cpp:9-12)");
+    HIPCHK(hipSetDevice(ctx->device));
+    auto* R = rot_of(ctx);
+    R->have = false;
+    int rc = lili_ingest_cloud(ctx, scan, R->in);
+    if (rc != LILI_OK) return rc;
+    const int n = (int)scan->n;
+    R->n_in = n;
+    HIPCHK(R->state.ensure(sizeof(RotState)));
+    RotState* st = R->state.as<RotState>();
+    hipLaunchKernelGGL(k_rot_init, dim3(1), dim3(64), 0, ctx->stream, st);
+    if (n > 0) {
+        const size_t cap = (size_t)n;
+        const int nb = nblocks(n, kRotBlock);
+        HIPCHK(R->valid.ensure(cap)); HIPCHK(R->scan_id.ensure(cap)); HIPCHK(R->ori_raw.ensure(cap * 4));
+        HIPCHK(R->block_hist.ensure((size_t)nb * kMaxRings * 4));
+        HIPCHK(R->full.ensure(cap * 16)); HIPCHK(R->full_src.ensure(cap * 4)); HIPCHK(R->curv.ensure(cap * 4)); HIPCHK(R->label.ensure(cap * 4));
+        HIPCHK(R->ring_edge.ensure(kMaxRings * kRingEdgeCap * 4)); HIPCHK(R->ring_sharp.ensure(kMaxRings * kRingSharpCap * 4)); HIPCHK(R->ring_flat.ensure(kMaxRings * kRingFlatCap * 4));
+        HIPCHK(R->lessflat_tmp.ensure(cap * 4)); HIPCHK(R->surf_tmp.ensure(cap * 16)); HIPCHK(R->surf_cnt_tmp.ensure(cap * 4));
+        HIPCHK(R->edge_idx.ensure(kMaxRings * kRingEdgeCap * 4)); HIPCHK(R->edge_pts.ensure(kMaxRings * kRingEdgeCap * 16));
+        HIPCHK(R->sharp_idx.ensure(kMaxRings * kRingSharpCap * 4)); HIPCHK(R->flat_idx.ensure(kMaxRings * kRingFlatCap * 4));
+        HIPCHK(R->lessflat_idx.ensure(cap * 4)); HIPCHK(R->surf.ensure(cap * 16)); HIPCHK(R->surf_cnt.ensure(cap * 4));
+        RotDev P{};
+        P.n_scans = params->n_scans; P.ds_rate = params->ds_rate; P.ds_v = params->ds_v; P.near_thres = params->near_range;
+        for (int i = 0; i < 4; i++) { P.q_imu[i] = q_imu[i]; P.q_lb[i] = q_lb[i]; }
+        const float4* in = R->in.as<float4>();
+        hipLaunchKernelGGL(k_rot_valid, dim3(std::min(nblocks(n, 256), 128)), dim3(256), 0, ctx->stream, in, n, P.near_thres, R->valid.as<unsigned char>(), st);
+        hipLaunchKernelGGL(k_rot_classify, dim3(nb), dim3(kRotBlock), 0, ctx->stream, in, n, R->valid.as<unsigned char>(), P, st,
+                           R->scan_id.as<signed char>(), R->ori_raw.as<float>(), R->block_hist.as<int>());
+        hipLaunchKernelGGL(k_rot_ring_scan, dim3(1), dim3(64), 0, ctx->stream, R->block_hist.as<int>(), nb, P, st);
+        hipLaunchKernelGGL(k_rot_scatter, dim3(nb), dim3(kRotBlock), 0, ctx->stream, in, n, R->scan_id.as<signed char>(), R->ori_raw.as<float>(), P, st,
+                           R->block_hist.as<int>(), R->full.as<float4>(), R->full_src.as<int>());
+        hipLaunchKernelGGL(k_rot_curvature, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, R->full.as<float4>(), st, R->curv.as<float>());
+        hipLaunchKernelGGL(k_rot_select, dim3(kMaxRings), dim3(kRotBlock), sizeof(RingLds), ctx->stream, R->full.as<float4>(), R->curv.as<float>(), P, st,
+                           R->label.as<int>(), R->ring_edge.as<int>(), R->ring_sharp.as<int>(), R->ring_flat.as<int>(), R->lessflat_tmp.as<int>(),
+                           R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>());
+        hipLaunchKernelGGL(k_rot_compact, dim3(1), dim3(kRotBlock), 0, ctx->stream, st, R->full.as<float4>(), R->ring_edge.as<int>(), R->ring_sharp.as<int>(),
+                           R->ring_flat.as<int>(), R->lessflat_tmp.as<int>(), R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>(), R->edge_idx.as<int>(),
+                           R->edge_pts.as<float4>(), R->sharp_idx.as<int>(), R->flat_idx.as<int>(), R->lessflat_idx.as<int>(), R->surf.as<float4>(), R->surf_cnt.as<int>());
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipMemcpyAsync(&R->host, st, sizeof(RotState), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (R->host.fallback_rings > 0) return ctx->fail(LILI_E_STATE, "extract_rot: a ring holds more than 4096 points (not supported yet)");
+    R->have = true;
+    if (full) { full->count = (size_t)R->host.n_full; rc = copy_out_f4(ctx, full, R->full.as<float4>(), full->count); if (rc) return rc; }
+    if (edge) { edge->count = (size_t)R->host.n_edge; rc = copy_out_f4(ctx, edge, R->edge_pts.as<float4>(), edge->count); if (rc) return rc; }
+    if (surf) { surf->count = (size_t)R->host.n_surf; rc = copy_out_f4(ctx, surf, R->surf.as<float4>(), surf->count); if (rc) return rc; }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return LILI_OK;
+}
+
+// Intermediate products of the last lili_extract_rot (parity tests / debugging).  Any pointer may be NULL.
+int lili_extract_rot_debug(lili_ctx* ctx, int32_t counts[8], int32_t* ring_start, int32_t* ring_end, int32_t* full_src, float* curvature, int32_t* label,
+                           int32_t* edge_idx, int32_t* sharp_idx, int32_t* flat_idx, int32_t* lessflat_idx, int32_t* surf_cnt) {
+    if (!ctx) return LILI_E_ARG;
+    auto* R = rot_of(ctx);
+    if (!R->have) return ctx->fail(LILI_E_STATE, "extract_rot_debug: run lili_extract_rot first");
+    HIPCHK(hipSetDevice(ctx->device));
+    const RotState& h = R->host;
+    if (counts) { counts[0] = h.n_full; counts[1] = h.n_edge; counts[2] = h.n_sharp; counts[3] = h.n_flat; counts[4] = h.n_lessflat; counts[5] = h.n_surf; counts[6] = h.half_idx; counts[7] = h.first_valid; }
+    if (ring_start) std::memcpy(ring_start, h.ring_start, sizeof(int) * kMaxRings);
+    if (ring_end) std::memcpy(ring_end, h.ring_end, sizeof(int) * kMaxRings);
+    auto dl = [&](void* dst, const DevBuf& src, size_t bytes) -> hipError_t { return (dst && bytes) ? hipMemcpyAsync(dst, src.p, bytes, hipMemcpyDeviceToHost, ctx->stream) : hipSuccess; };
+    HIPCHK(dl(full_src, R->full_src, (size_t)h.n_full * 4)); HIPCHK(dl(curvature, R->curv, (size_t)h.n_full * 4)); HIPCHK(dl(label, R->label, (size_t)h.n_full * 4));
+    HIPCHK(dl(edge_idx, R->edge_idx, (size_t)h.n_edge * 4)); HIPCHK(dl(sharp_idx, R->sharp_idx, (size_t)h.n_sharp * 4)); HIPCHK(dl(flat_idx, R->flat_idx, (size_t)h.n_flat * 4));
+    HIPCHK(dl(lessflat_idx, R->lessflat_idx, (size_t)h.n_lessflat * 4)); HIPCHK(dl(surf_cnt, R->surf_cnt, (size_t)h.n_surf * 4));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return LILI_OK;
+}
+
+}  // extern "C"

@@ -233,3 +233,52 @@ def loss(kind, a, s):
     rho = np.zeros(3)
     lib().lo_loss(int(kind), C.c_double(a), C.c_double(s), _p(rho))
     return rho
+
+
+# ---------------------------------------------------------------------------------------------------------
+# feature extraction (lo_extract.cpp)
+# ---------------------------------------------------------------------------------------------------------
+class RotParams(C.Structure):
+    _fields_ = [("n_scans", C.c_int), ("ds_rate", C.c_int), ("ds_v", C.c_float), ("near_thres", C.c_float),
+                ("atan_mode", C.c_int), ("stable_sort", C.c_int)]
+
+
+def rot_params(n_scans=64, ds_rate=4, ds_v=0.6, near_thres=3.0, atan_mode=0, stable_sort=0):
+    """R/config/config_fr_iosb.yaml:13-14 (line_num 64, ds_rate 4), R/src/Preprocessing.cpp:14,281."""
+    return RotParams(n_scans, ds_rate, ds_v, near_thres, atan_mode, stable_sort)
+
+
+def extract_rot(pts_xyzi, q_imu=(1.0, 0, 0, 0), q_lb=(1.0, 0, 0, 0), P=None):
+    """LOAM-style extractor of LiLi-OM-ROT.  pts_xyzi: (n,4) float32 in sensor firing order."""
+    P = P or rot_params()
+    pts = _f32(pts_xyzi, 4)
+    n = pts.shape[0]
+    cap = max(n, 1)
+    full = np.zeros((cap, 4), np.float32); full_src = np.zeros(cap, np.int32)
+    ring_start = np.zeros(P.n_scans, np.int32); ring_end = np.zeros(P.n_scans, np.int32)
+    curv = np.zeros(cap, np.float32); label = np.zeros(cap, np.int32)
+    edge_idx = np.zeros(cap, np.int32); sharp_idx = np.zeros(cap, np.int32); flat_idx = np.zeros(cap, np.int32)
+    surf = np.zeros((cap, 4), np.float32); surf_cnt = np.zeros(cap, np.int32); lf_idx = np.zeros(cap, np.int32)
+    ints = [C.c_int(0) for _ in range(7)]   # n_full, n_edge, n_sharp, n_flat, n_surf, n_lessflat, n_ties
+    qi, ql = _f64(q_imu), _f64(q_lb)
+    lib().lo_extract_rot.restype = C.c_int
+    rc = lib().lo_extract_rot(_p(pts), n, _p(qi), _p(ql), C.byref(P), _p(full), _p(full_src), C.byref(ints[0]),
+                              _p(ring_start), _p(ring_end), _p(curv), _p(label), _p(edge_idx), C.byref(ints[1]),
+                              _p(sharp_idx), C.byref(ints[2]), _p(flat_idx), C.byref(ints[3]), _p(surf), _p(surf_cnt),
+                              C.byref(ints[4]), _p(lf_idx), C.byref(ints[5]), C.byref(ints[6]))
+    if rc != 0:
+        raise RuntimeError(f"lo_extract_rot failed ({rc})")
+    nf, ne, ns, nfl, nsu, nlf, nt = [v.value for v in ints]
+    return dict(full=full[:nf], full_src=full_src[:nf], ring_start=ring_start, ring_end=ring_end, curvature=curv[:nf],
+                label=label[:nf], edge_idx=edge_idx[:ne], sharp_idx=sharp_idx[:ns], flat_idx=flat_idx[:nfl],
+                surf=surf[:nsu], surf_cnt=surf_cnt[:nsu], lessflat_idx=lf_idx[:nlf], n_ties=nt)
+
+
+def voxel_grid(pts_xyzi, leaf, stable=False):
+    pts = _f32(pts_xyzi, 4)
+    n = pts.shape[0]
+    out = np.zeros((max(n, 1), 4), np.float32)
+    cnt = np.zeros(max(n, 1), np.int32)
+    lib().lo_voxel_grid.restype = C.c_int
+    m = lib().lo_voxel_grid(_p(pts), n, C.c_float(leaf), int(bool(stable)), _p(out), _p(cnt))
+    return out[:m], cnt[:m]
