@@ -146,23 +146,31 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_classify(const float4* __rest
     if (threadIdx.x == 0 && half_min != 0x7fffffff) atomicMin(&st->half_idx, half_min);
 }
 
-__global__ void k_rot_ring_scan(int* __restrict__ block_hist, int nb, RotDev P, RotState* st) {
+// exclusive prefix of the per-block ring histograms (per ring, over blocks): 1024 threads = 64 rings x 16 parts
+__global__ __launch_bounds__(kRotBlock) void k_rot_ring_scan(int* __restrict__ block_hist, int nb, RotDev P, RotState* st) {
+    __shared__ int part_sum[16][kMaxRings];
     __shared__ int cnt[kMaxRings];
-    int r = threadIdx.x;
-    if (r < kMaxRings) {
-        int run = 0;
-        for (int b = 0; b < nb; b++) { int c = block_hist[b * kMaxRings + r]; block_hist[b * kMaxRings + r] = run; run += c; }
-        cnt[r] = run;
-    }
+    const int r = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int per = (nb + 15) / 16;
+    const int b0 = part * per, b1 = min(nb, b0 + per);
+    int run = 0;
+    for (int b = b0; b < b1; b++) run += block_hist[b * kMaxRings + r];
+    part_sum[part][r] = run;
     __syncthreads();
-    if (r == 0) {
-        int base = 0;
+    int base = 0;
+    for (int q = 0; q < part; q++) base += part_sum[q][r];
+    if (part == 15) cnt[r] = base + run;
+    run = base;
+    for (int b = b0; b < b1; b++) { int c = block_hist[b * kMaxRings + r]; block_hist[b * kMaxRings + r] = run; run += c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int bs = 0;
         for (int k = 0; k < kMaxRings; k++) {
-            st->ring_count[k] = cnt[k]; st->ring_base[k] = base;
-            if (k < P.n_scans) { st->ring_start[k] = base + 5; st->ring_end[k] = base + cnt[k] - 6; }   // R:379-381
-            base += cnt[k];
+            st->ring_count[k] = cnt[k]; st->ring_base[k] = bs;
+            if (k < P.n_scans) { st->ring_start[k] = bs + 5; st->ring_end[k] = bs + cnt[k] - 6; }   // R:379-381
+            bs += cnt[k];
         }
-        st->n_full = base;
+        st->n_full = bs;
     }
 }
 
@@ -445,31 +453,28 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_select(const float4* __restri
     if (tid == 0) st->ring_nsurf[ring] = n_out;
 }
 
-// ordered concatenation of the per-ring lists (rings ascending, then push order inside the ring)
-__global__ __launch_bounds__(kRotBlock) void k_rot_compact(RotState* st, const float4* __restrict__ full,
-                                                           const int* __restrict__ ring_edge, const int* __restrict__ ring_sharp, const int* __restrict__ ring_flat,
-                                                           const int* __restrict__ lessflat_tmp, const float4* __restrict__ surf_tmp, const int* __restrict__ surf_cnt_tmp,
-                                                           int* __restrict__ edge_idx, float4* __restrict__ edge_pts, int* __restrict__ sharp_idx, int* __restrict__ flat_idx,
-                                                           int* __restrict__ lessflat_idx, float4* __restrict__ surf, int* __restrict__ surf_cnt) {
-    __shared__ int off[5][kMaxRings + 1];
-    if (threadIdx.x == 0) {
-        int a = 0, b = 0, c = 0, d = 0, e = 0;
-        for (int r = 0; r < kMaxRings; r++) {
-            off[0][r] = a; off[1][r] = b; off[2][r] = c; off[3][r] = d; off[4][r] = e;
-            a += st->ring_nedge[r]; b += st->ring_nsharp[r]; c += st->ring_nflat[r]; d += st->ring_nlf[r]; e += st->ring_nsurf[r];
-        }
-        off[0][kMaxRings] = a; off[1][kMaxRings] = b; off[2][kMaxRings] = c; off[3][kMaxRings] = d; off[4][kMaxRings] = e;
-        st->n_edge = a; st->n_sharp = b; st->n_flat = c; st->n_lessflat = d; st->n_surf = e;
+// ordered concatenation of the per-ring lists (rings ascending, then push order inside the ring): one block per ring
+__global__ __launch_bounds__(256) void k_rot_compact(RotState* st, const float4* __restrict__ full,
+                                                     const int* __restrict__ ring_edge, const int* __restrict__ ring_sharp, const int* __restrict__ ring_flat,
+                                                     const int* __restrict__ lessflat_tmp, const float4* __restrict__ surf_tmp, const int* __restrict__ surf_cnt_tmp,
+                                                     int* __restrict__ edge_idx, float4* __restrict__ edge_pts, int* __restrict__ sharp_idx, int* __restrict__ flat_idx,
+                                                     int* __restrict__ lessflat_idx, float4* __restrict__ surf, int* __restrict__ surf_cnt) {
+    __shared__ int off[5], tot[5];
+    const int r = blockIdx.x;
+    if (threadIdx.x < 5) {
+        const int* arr = threadIdx.x == 0 ? st->ring_nedge : threadIdx.x == 1 ? st->ring_nsharp : threadIdx.x == 2 ? st->ring_nflat : threadIdx.x == 3 ? st->ring_nlf : st->ring_nsurf;
+        int a = 0, t = 0;
+        for (int k = 0; k < kMaxRings; k++) { int c = arr[k]; if (k < r) a += c; t += c; }
+        off[threadIdx.x] = a; tot[threadIdx.x] = t;
     }
     __syncthreads();
-    for (int r = 0; r < kMaxRings; r++) {
-        const int rb = st->ring_base[r];
-        for (int k = threadIdx.x; k < st->ring_nedge[r]; k += blockDim.x) { int g = ring_edge[r * kRingEdgeCap + k]; edge_idx[off[0][r] + k] = g; edge_pts[off[0][r] + k] = full[g]; }
-        for (int k = threadIdx.x; k < st->ring_nsharp[r]; k += blockDim.x) sharp_idx[off[1][r] + k] = ring_sharp[r * kRingSharpCap + k];
-        for (int k = threadIdx.x; k < st->ring_nflat[r]; k += blockDim.x) flat_idx[off[2][r] + k] = ring_flat[r * kRingFlatCap + k];
-        for (int k = threadIdx.x; k < st->ring_nlf[r]; k += blockDim.x) lessflat_idx[off[3][r] + k] = lessflat_tmp[rb + k];
-        for (int k = threadIdx.x; k < st->ring_nsurf[r]; k += blockDim.x) { surf[off[4][r] + k] = surf_tmp[rb + k]; surf_cnt[off[4][r] + k] = surf_cnt_tmp[rb + k]; }
-    }
+    if (r == 0 && threadIdx.x == 0) { st->n_edge = tot[0]; st->n_sharp = tot[1]; st->n_flat = tot[2]; st->n_lessflat = tot[3]; st->n_surf = tot[4]; }
+    const int rb = st->ring_base[r];
+    for (int k = threadIdx.x; k < st->ring_nedge[r]; k += blockDim.x) { int g = ring_edge[r * kRingEdgeCap + k]; edge_idx[off[0] + k] = g; edge_pts[off[0] + k] = full[g]; }
+    for (int k = threadIdx.x; k < st->ring_nsharp[r]; k += blockDim.x) sharp_idx[off[1] + k] = ring_sharp[r * kRingSharpCap + k];
+    for (int k = threadIdx.x; k < st->ring_nflat[r]; k += blockDim.x) flat_idx[off[2] + k] = ring_flat[r * kRingFlatCap + k];
+    for (int k = threadIdx.x; k < st->ring_nlf[r]; k += blockDim.x) lessflat_idx[off[3] + k] = lessflat_tmp[rb + k];
+    for (int k = threadIdx.x; k < st->ring_nsurf[r]; k += blockDim.x) { surf[off[4] + k] = surf_tmp[rb + k]; surf_cnt[off[4] + k] = surf_cnt_tmp[rb + k]; }
 }
 
 }  // namespace lili
@@ -546,14 +551,14 @@ int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4
         hipLaunchKernelGGL(k_rot_valid, dim3(std::min(nblocks(n, 256), 128)), dim3(256), 0, ctx->stream, in, n, P.near_thres, R->valid.as<unsigned char>(), st);
         hipLaunchKernelGGL(k_rot_classify, dim3(nb), dim3(kRotBlock), 0, ctx->stream, in, n, R->valid.as<unsigned char>(), P, st,
                            R->scan_id.as<signed char>(), R->ori_raw.as<float>(), R->block_hist.as<int>());
-        hipLaunchKernelGGL(k_rot_ring_scan, dim3(1), dim3(64), 0, ctx->stream, R->block_hist.as<int>(), nb, P, st);
+        hipLaunchKernelGGL(k_rot_ring_scan, dim3(1), dim3(kRotBlock), 0, ctx->stream, R->block_hist.as<int>(), nb, P, st);
         hipLaunchKernelGGL(k_rot_scatter, dim3(nb), dim3(kRotBlock), 0, ctx->stream, in, n, R->scan_id.as<signed char>(), R->ori_raw.as<float>(), P, st,
                            R->block_hist.as<int>(), R->full.as<float4>(), R->full_src.as<int>());
         hipLaunchKernelGGL(k_rot_curvature, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, R->full.as<float4>(), st, R->curv.as<float>());
         hipLaunchKernelGGL(k_rot_select, dim3(kMaxRings), dim3(kRotBlock), sizeof(RingLds), ctx->stream, R->full.as<float4>(), R->curv.as<float>(), P, st,
                            R->label.as<int>(), R->ring_edge.as<int>(), R->ring_sharp.as<int>(), R->ring_flat.as<int>(), R->lessflat_tmp.as<int>(),
                            R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>());
-        hipLaunchKernelGGL(k_rot_compact, dim3(1), dim3(kRotBlock), 0, ctx->stream, st, R->full.as<float4>(), R->ring_edge.as<int>(), R->ring_sharp.as<int>(),
+        hipLaunchKernelGGL(k_rot_compact, dim3(kMaxRings), dim3(256), 0, ctx->stream, st, R->full.as<float4>(), R->ring_edge.as<int>(), R->ring_sharp.as<int>(),
                            R->ring_flat.as<int>(), R->lessflat_tmp.as<int>(), R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>(), R->edge_idx.as<int>(),
                            R->edge_pts.as<float4>(), R->sharp_idx.as<int>(), R->flat_idx.as<int>(), R->lessflat_idx.as<int>(), R->surf.as<float4>(), R->surf_cnt.as<int>());
         HIPCHK(hipGetLastError());
