@@ -144,6 +144,25 @@ int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4
 int lili_extract_rot_debug(lili_ctx* ctx, int32_t counts[8], int32_t* ring_start, int32_t* ring_end, int32_t* full_src, float* curvature,
                            int32_t* label, int32_t* edge_idx, int32_t* sharp_idx, int32_t* flat_idx, int32_t* lessflat_idx, int32_t* surf_cnt);
 
+typedef struct lili_livox_params {
+    double surf_thres;   /* L/config/config_fr_iosb.yaml:5 (0.28) */
+    double edge_thres;   /* L/config/config_fr_iosb.yaml:6 (4)    */
+    float near_range;    /* 0.1, L/src/Preprocessing.cpp:226      */
+} lili_livox_params;
+
+/* Replaces the body of Preprocessing::cloudHandler of LiLi-OM (L/src/Preprocessing.cpp:219-401) for one Livox
+ * Horizon scan in FormatConvert's layout (L/src/FormatConvert.cpp:14-23): scan->aux_offset = byte offset of
+ * `intensity` (line + 0.1 * t), curvature_offset = byte offset of `curvature` (0.1 * reflectivity) — 32 and 36 for
+ * pcl::PointXYZINormal.  q_imu = the gyro quaternion integrated over the scan (L:129-171, caller side).
+ * Outputs are records of 32 B (x,y,z,nx,ny,nz,intensity,curvature; stride 32) or pcl::PointXYZINormal (stride 48):
+ *   cutted: every deskewed point with a valid line (/lidar_cloud_cutted), edge: /edge_features (normal = line
+ *   direction), surf: /surf_features (normal = plane normal).  Blocking. */
+int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offset, const double q_imu[4], const lili_livox_params* params,
+                       lili_feature_out* cutted, lili_feature_out* edge, lili_feature_out* surf);
+/* counts = {n_cutted, n_edge, n_surf}; cut_src[n_cutted]; cell_src[24000] (input index owning each grid cell or -1);
+ * edge_cell / surf_cell: cell (line * 4000 + column) of each emitted feature.  Any pointer may be NULL. */
+int lili_extract_livox_debug(lili_ctx* ctx, int32_t counts[3], int32_t* cut_src, int32_t* cell_src, int32_t* edge_cell, int32_t* surf_cell);
+
 /* ---- scan-to-map matcher -------------------------------------------------------------------- */
 
 /* Uploads the feature points of keyframe `slot` (surf_lasts_ds[idx] / edge_lasts_ds[idx],

@@ -36,6 +36,10 @@ class RotParams(C.Structure):
     _fields_ = [("n_scans", C.c_int), ("ds_rate", C.c_int), ("ds_v", C.c_float), ("near_range", C.c_float)]
 
 
+class LivoxParams(C.Structure):
+    _fields_ = [("surf_thres", C.c_double), ("edge_thres", C.c_double), ("near_range", C.c_float)]
+
+
 class S2MParams(C.Structure):
     _fields_ = [("variant", C.c_int), ("loss", C.c_int), ("loss_a", C.c_double), ("lidar_const", C.c_double),
                 ("kd_max_radius", C.c_double), ("edge_gate", C.c_double), ("surf_dist_thres", C.c_double),
@@ -92,6 +96,8 @@ _SIGS = {
     "lili_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "lili_extract_rot": (C.c_int, [C.c_void_p, C.POINTER(Cloud), C.c_void_p, C.c_void_p, C.POINTER(RotParams), C.POINTER(FeatureOut), C.POINTER(FeatureOut), C.POINTER(FeatureOut)]),
     "lili_extract_rot_debug": (C.c_int, [C.c_void_p] + [C.c_void_p] * 11),
+    "lili_extract_livox": (C.c_int, [C.c_void_p, C.POINTER(Cloud), C.c_int, C.c_void_p, C.POINTER(LivoxParams), C.POINTER(FeatureOut), C.POINTER(FeatureOut), C.POINTER(FeatureOut)]),
+    "lili_extract_livox_debug": (C.c_int, [C.c_void_p] * 6),
     "lili_map_set": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Cloud), C.c_double]),
     "lili_map_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "lili_s2m_set_queries": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Cloud)]),
@@ -342,6 +348,39 @@ class RotExtractor:
                                                           _ptr(arr["surf_cnt"])))
             res.update(arr)
             res.update(ring_start=rs[:self.params.n_scans], ring_end=re_[:self.params.n_scans], half_idx=int(counts[6]))
+        return res
+
+
+class LivoxExtractor:
+    """Host-side mirror of LiLi-OM's Preprocessing::cloudHandler (L/src/Preprocessing.cpp:194-408)."""
+
+    def __init__(self, ctx, surf_thres=0.28, edge_thres=4.0, near_range=0.1):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        self.params = LivoxParams(surf_thres, edge_thres, near_range)
+
+    def extract(self, pts5, q_imu=(1.0, 0, 0, 0), debug=False, pcl_layout=False):
+        """pts5: (n,5) float32 = x, y, z, intensity, curvature."""
+        pts = np.ascontiguousarray(pts5, dtype=np.float32)
+        n = pts.shape[0]
+        cloud = Cloud(pts.ctypes.data if n else None, n, 20, 12, MEM_HOST)
+        cap = max(n, 24000)
+        w = 12 if pcl_layout else 8
+        bufs = [np.zeros((cap, w), np.float32) for _ in range(3)]
+        outs = [FeatureOut(b.ctypes.data, cap, 4 * w, MEM_HOST, 0) for b in bufs]
+        qi = _f64(q_imu, 4)
+        self.ctx._chk(self.lib.lili_extract_livox(self.ctx.h, C.byref(cloud), 16, _ptr(qi), C.byref(self.params),
+                                                  C.byref(outs[0]), C.byref(outs[1]), C.byref(outs[2])))
+        res = dict(cutted=bufs[0][:outs[0].count], edge=bufs[1][:outs[1].count], surf=bufs[2][:outs[2].count])
+        if debug:
+            counts = np.zeros(3, np.int32)
+            self.ctx._chk(self.lib.lili_extract_livox_debug(self.ctx.h, _ptr(counts), None, None, None, None))
+            arr = dict(cut_src=np.zeros(counts[0], np.int32), cell_src=np.zeros(24000, np.int32),
+                       edge_cell=np.zeros(counts[1], np.int32), surf_cell=np.zeros(counts[2], np.int32))
+            self.ctx._chk(self.lib.lili_extract_livox_debug(self.ctx.h, _ptr(counts), _ptr(arr["cut_src"]), _ptr(arr["cell_src"]),
+                                                            _ptr(arr["edge_cell"]), _ptr(arr["surf_cell"])))
+            arr["cell_src"] = arr["cell_src"].reshape(6, 4000)
+            res.update(arr)
         return res
 
 

@@ -1,0 +1,351 @@
+// Livox Horizon feature extractor on gfx950 — replaces L/src/Preprocessing.cpp:219-383 (L/ = LiLi-OM/) behind
+// lili_extract_livox():
+//   k_livox_prep     NaN / near filter, line id, IMU deskew (slerp, f64), range / reflectivity gates, time-slot
+//                    column, first-writer-wins grid fill as atomicMin(source index) per cell          (L:243-268)
+//   k_livox_cut      ordered compaction of every deskewed point with a valid line (/lidar_cloud_cutted, L:253-257)
+//   k_livox_grid     gather the winning point of each of the 6 x 4000 cells
+//   k_livox_blocks   one thread per 6-column block (664 of them): 36-cell covariance + 3x3 symmetric eigen (f64),
+//                    depth-Laplacian edge candidate per line, edge PCA, edge / plane emission with the block-local
+//                    tombstones of the reference (L:270-383)
+//   k_livox_compact  ordered concatenation (block, then line | column, line)
+// 24 k points per scan: this path is latency-, not bandwidth-bound; the grid (1.15 MB in the reference) never
+// leaves L2.  Eigenvector signs (stored as normal / direction) are canonicalised — Eigen's are arbitrary.
+#include "lili_ctx.h"
+#include "lili_device_math.h"
+
+namespace lili {
+
+constexpr int kLvLines = 6, kLvCols = 4000, kLvCells = kLvLines * kLvCols;
+constexpr int kLvBlocks = 664;   // i = 5, 11, ... < 3988 (L:270)
+
+struct LivoxDev { double q_imu[4]; double surf_thres, edge_thres; float near_thres; };
+struct LivoxState { int n_cut, n_edge, n_surf; };
+
+__device__ __forceinline__ dq lv_slerp_identity(double t, dq b) {
+    const double one = 1.0 - 2.220446049250313e-16;
+    double d = b.w, absD = fabs(d), s0, s1;
+    if (absD >= one) { s0 = 1.0 - t; s1 = t; }
+    else { double th = acos(absD), sn = sin(th); s0 = sin((1.0 - t) * th) / sn; s1 = sin(t * th) / sn; }
+    if (d < 0) s1 = -s1;
+    return dq{s0 + s1 * b.w, s1 * b.x, s1 * b.y, s1 * b.z};
+}
+
+__global__ void k_livox_init(int* __restrict__ owner, LivoxState* st) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < kLvCells) owner[i] = 0x7fffffff;
+    if (i == 0) { st->n_cut = 0; st->n_edge = 0; st->n_surf = 0; }
+}
+
+__global__ __launch_bounds__(256) void k_livox_prep(const float4* __restrict__ in_i /*x,y,z,intensity*/, const float4* __restrict__ in_c /*x,y,z,curvature*/, int n,
+                                                    LivoxDev P, float4* __restrict__ und, float* __restrict__ curv, unsigned char* __restrict__ keep,
+                                                    int* __restrict__ owner) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 p = in_i[i];
+    float c = in_c[i].w;
+    bool ok = isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && !(p.x * p.x + p.y * p.y + p.z * p.z < P.near_thres * P.near_thres);   // L:225-226
+    int scan_id = (int)p.w;                                                                                                          // L:252
+    ok = ok && scan_id >= 0 && scan_id < kLvLines;   // lines >= 6 would index mat[] out of bounds in the reference
+    keep[i] = ok;
+    if (!ok) return;
+    // undistortion, L:104-127
+    double dt_i = (double)(p.w - (float)scan_id);
+    double ratio = dt_i / 0.1;
+    if (ratio >= 1.0) ratio = 1.0;
+    dq qs = lv_slerp_identity(ratio, dq{P.q_imu[0], P.q_imu[1], P.q_imu[2], P.q_imu[3]});
+    d3 r = qrot(qs, d3{(double)p.x, (double)p.y, (double)p.z});
+    float ux = (float)r.x, uy = (float)r.y, uz = (float)r.z;
+    und[i] = make_float4(ux, uy, uz, p.w);
+    curv[i] = c;
+    double dep = (double)(ux * ux + uy * uy + uz * uz);                                            // float expression widened (L:259)
+    if (dep > 40000.0 || dep < 4.0 || (double)c < 0.05 || (double)c > 25.45) return;              // L:260
+    const double t_interval = 0.1 / (double)(kLvCols - 1);
+    int col = (int)round((double)(p.w - (float)scan_id) / t_interval);                            // L:262
+    if (col >= kLvCols || col < 0) return;
+    atomicMin(&owner[scan_id * kLvCols + col], i);                                                 // first point of the stream wins (L:265-267)
+}
+
+// ordered compaction, single block (24 k points): cutted[rank] = deskewed point, cut_src[rank] = i
+__global__ __launch_bounds__(1024) void k_livox_cut(const float4* __restrict__ und, const float* __restrict__ curv, const unsigned char* __restrict__ keep, int n,
+                                                    float4* __restrict__ cut_a, float4* __restrict__ cut_b, int* __restrict__ cut_src, LivoxState* st) {
+    __shared__ int ws[17];
+    int run = 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int b0 = 0; b0 < n; b0 += 1024) {
+        int i = b0 + threadIdx.x;
+        int f = i < n ? (int)keep[i] : 0;
+        int inc = f;
+        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+        if (lane == 63) ws[wave] = inc;
+        __syncthreads();
+        int base = 0, tot = 0;
+        for (int w = 0; w < 16; w++) { int s = ws[w]; if (w < wave) base += s; tot += s; }
+        __syncthreads();
+        if (f) {
+            int pos = run + base + inc - 1;
+            float4 u = und[i];
+            cut_a[pos] = make_float4(u.x, u.y, u.z, 0.f);          // x, y, z, normal_x
+            cut_b[pos] = make_float4(0.f, 0.f, u.w, curv[i]);       // normal_y, normal_z, intensity, curvature
+            cut_src[pos] = i;
+        }
+        run += tot;
+    }
+    if (threadIdx.x == 0) st->n_cut = run;
+}
+
+__global__ void k_livox_grid(const int* __restrict__ owner, const float4* __restrict__ und, const float* __restrict__ curv,
+                             float4* __restrict__ cell_pt, float* __restrict__ cell_curv, int* __restrict__ cell_src) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= kLvCells) return;
+    int o = owner[c];
+    if (o == 0x7fffffff) { cell_pt[c] = make_float4(0.f, 0.f, 0.f, 0.f); cell_curv[c] = 0.f; cell_src[c] = -1; }
+    else { cell_pt[c] = und[o]; cell_curv[c] = curv[o]; cell_src[c] = o; }
+}
+
+__device__ __forceinline__ double lv_depth(const float4* __restrict__ cell_pt, int k, int c) {   // getDepth: float sqrt, widened
+    float4 p = cell_pt[k * kLvCols + c];
+    return (double)sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);
+}
+
+// per-block outputs: edges [block][6] and surfs [block][36] as cell ids + the shared direction / normal
+__global__ __launch_bounds__(64) void k_livox_blocks(const float4* __restrict__ cell_pt, const float* __restrict__ cell_curv, LivoxDev P,
+                                                     int* __restrict__ blk_nedge, int* __restrict__ blk_edge_cell, float* __restrict__ blk_edge_dir,
+                                                     int* __restrict__ blk_nsurf, int* __restrict__ blk_surf_cell, float* __restrict__ blk_surf_nrm) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= kLvBlocks) return;
+    const int i = 5 + 6 * b;
+    blk_nedge[b] = 0; blk_nsurf[b] = 0;
+    // 36-cell centroid + scatter (L:271-296)
+    int num = 36;
+    d3 center{0, 0, 0};
+    for (int j = 0; j < 6; j++) for (int k = 0; k < kLvLines; k++) {
+        int c = k * kLvCols + i + j;
+        if (cell_curv[c] <= 0.f) { num--; continue; }
+        float4 p = cell_pt[c];
+        center = center + d3{(double)p.x, (double)p.y, (double)p.z};
+    }
+    if (num < 25) return;
+    center = d3{center.x / num, center.y / num, center.z / num};
+    double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;
+    for (int j = 0; j < 6; j++) for (int k = 0; k < kLvLines; k++) {
+        int c = k * kLvCols + i + j;
+        if (cell_curv[c] <= 0.f) continue;
+        float4 p = cell_pt[c];
+        d3 z = d3{(double)p.x, (double)p.y, (double)p.z} - center;
+        a00 += z.x * z.x; a01 += z.x * z.y; a02 += z.x * z.z; a11 += z.y * z.y; a12 += z.y * z.z; a22 += z.z * z.z;
+    }
+    double ev[3]; d3 vmin, vmax;
+    eig3_sym(a00, a01, a02, a11, a12, a22, ev, vmin, vmax);
+    // edge candidate per line (L:302-331)
+    int ex[kLvLines], ey[kLvLines], ne = 0;
+    for (int k = 0; k < kLvLines; k++) {
+        double max_s = 0; int idx = i;
+        for (int j = 0; j < 6; j++) {
+            int col = i + j;
+            if (cell_curv[k * kLvCols + col] <= 0.f) continue;
+            double d0 = lv_depth(cell_pt, k, col);
+            double g1 = lv_depth(cell_pt, k, col - 4) + lv_depth(cell_pt, k, col - 3) + lv_depth(cell_pt, k, col - 2) + lv_depth(cell_pt, k, col - 1) - 8 * d0 +
+                        lv_depth(cell_pt, k, col + 1) + lv_depth(cell_pt, k, col + 2) + lv_depth(cell_pt, k, col + 3) + lv_depth(cell_pt, k, col + 4);
+            g1 = g1 / (8 * d0 + 1e-3);
+            if (g1 > 0.06 && g1 > max_s) { max_s = g1; idx = col; }
+        }
+        if (max_s != 0) { ex[ne] = k; ey[ne] = idx; ne++; }
+    }
+    bool tomb[kLvLines];   // edge cells of this block removed from its plane set (curvature *= -1, L:363)
+    for (int k = 0; k < kLvLines; k++) tomb[k] = false;
+    if (ne > 3) {          // with <= 3 candidates the reference's test fails whatever the eigenvalues are (App. A6)
+        d3 ce{0, 0, 0};
+        for (int q = 0; q < ne; q++) { float4 p = cell_pt[ex[q] * kLvCols + ey[q]]; ce = ce + d3{(double)p.x, (double)p.y, (double)p.z}; }
+        double nd = (double)ne;
+        ce = d3{ce.x / nd, ce.y / nd, ce.z / nd};
+        double e00 = 0, e01 = 0, e02 = 0, e11 = 0, e12 = 0, e22 = 0;
+        for (int q = 0; q < ne; q++) {
+            float4 p = cell_pt[ex[q] * kLvCols + ey[q]];
+            d3 z = d3{(double)p.x, (double)p.y, (double)p.z} - ce;
+            e00 += z.x * z.x; e01 += z.x * z.y; e02 += z.x * z.z; e11 += z.y * z.y; e12 += z.y * z.z; e22 += z.z * z.z;
+        }
+        double eve[3]; d3 vmn, vmx;
+        eig3_sym(e00, e01, e02, e11, e12, e22, eve, vmn, vmx);
+        if (eve[2] > P.edge_thres * eve[1]) {                                                    // L:353
+            d3 u = canon_sign(vmx);
+            blk_edge_dir[3 * b] = (float)u.x; blk_edge_dir[3 * b + 1] = (float)u.y; blk_edge_dir[3 * b + 2] = (float)u.z;
+            int w = 0;
+            for (int q = 0; q < ne; q++) {
+                int c = ex[q] * kLvCols + ey[q];
+                // the reference's `curvature <= 0 && intensity <= 0` skip can never fire here: candidates have curvature > 0
+                blk_edge_cell[b * kLvLines + w++] = c;
+                tomb[ex[q]] = true;   // at most one candidate per line, so the line id identifies the tombstoned cell
+            }
+            blk_nedge[b] = w;
+        }
+    }
+    if (ev[0] < P.surf_thres * ev[1]) {                                                          // L:367
+        d3 u = canon_sign(vmin);
+        blk_surf_nrm[3 * b] = (float)u.x; blk_surf_nrm[3 * b + 1] = (float)u.y; blk_surf_nrm[3 * b + 2] = (float)u.z;
+        int w = 0;
+        for (int j = 0; j < 6; j++) for (int k = 0; k < kLvLines; k++) {
+            int c = k * kLvCols + i + j;
+            if (cell_curv[c] <= 0.f) continue;
+            bool is_tomb = false;
+            if (tomb[k]) { for (int q = 0; q < ne; q++) if (ex[q] == k && ey[q] == i + j) is_tomb = true; }
+            if (is_tomb) continue;
+            blk_surf_cell[b * 36 + w++] = c;
+        }
+        blk_nsurf[b] = w;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_livox_compact(const float4* __restrict__ cell_pt, const float* __restrict__ cell_curv,
+                                                        const int* __restrict__ blk_nedge, const int* __restrict__ blk_edge_cell, const float* __restrict__ blk_edge_dir,
+                                                        const int* __restrict__ blk_nsurf, const int* __restrict__ blk_surf_cell, const float* __restrict__ blk_surf_nrm,
+                                                        float4* __restrict__ edge_a, float4* __restrict__ edge_b, int* __restrict__ edge_cell,
+                                                        float4* __restrict__ surf_a, float4* __restrict__ surf_b, int* __restrict__ surf_cell, LivoxState* st) {
+    __shared__ int eoff[kLvBlocks + 1], soff[kLvBlocks + 1];
+    if (threadIdx.x == 0) {
+        int a = 0, s = 0;
+        for (int b = 0; b < kLvBlocks; b++) { eoff[b] = a; soff[b] = s; a += blk_nedge[b]; s += blk_nsurf[b]; }
+        eoff[kLvBlocks] = a; soff[kLvBlocks] = s;
+        st->n_edge = a; st->n_surf = s;
+    }
+    __syncthreads();
+    for (int b = threadIdx.x >> 6; b < kLvBlocks; b += 16) {
+        int lane = threadIdx.x & 63;
+        if (lane < blk_nedge[b]) {
+            int c = blk_edge_cell[b * kLvLines + lane];
+            float4 p = cell_pt[c];
+            int o = eoff[b] + lane;
+            edge_a[o] = make_float4(p.x, p.y, p.z, blk_edge_dir[3 * b]);
+            edge_b[o] = make_float4(blk_edge_dir[3 * b + 1], blk_edge_dir[3 * b + 2], p.w, cell_curv[c]);
+            edge_cell[o] = c;
+        }
+        if (lane < blk_nsurf[b]) {
+            int c = blk_surf_cell[b * 36 + lane];
+            float4 p = cell_pt[c];
+            int o = soff[b] + lane;
+            surf_a[o] = make_float4(p.x, p.y, p.z, blk_surf_nrm[3 * b]);
+            surf_b[o] = make_float4(blk_surf_nrm[3 * b + 1], blk_surf_nrm[3 * b + 2], p.w, cell_curv[c]);
+            surf_cell[o] = c;
+        }
+    }
+}
+
+// (x,y,z,nx | ny,nz,intensity,curvature) pairs -> packed 8-float records or pcl::PointXYZINormal (48 B)
+__global__ void k_livox_pack(const float4* __restrict__ a, const float4* __restrict__ b, int n, int pcl_layout, float* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 u = a[i], v = b[i];
+    if (pcl_layout) {
+        float* o = out + (size_t)i * 12;
+        o[0] = u.x; o[1] = u.y; o[2] = u.z; o[3] = 1.f; o[4] = u.w; o[5] = v.x; o[6] = v.y; o[7] = 0.f; o[8] = v.z; o[9] = v.w; o[10] = 0.f; o[11] = 0.f;
+    } else {
+        float* o = out + (size_t)i * 8;
+        o[0] = u.x; o[1] = u.y; o[2] = u.z; o[3] = u.w; o[4] = v.x; o[5] = v.y; o[6] = v.z; o[7] = v.w;
+    }
+}
+
+}  // namespace lili
+
+namespace lili_detail {
+struct LivoxBuffers {
+    DevBuf in_i, in_c, und, curv, keep, owner, state, cut_a, cut_b, cut_src, cell_pt, cell_curv, cell_src;
+    DevBuf blk_nedge, blk_edge_cell, blk_edge_dir, blk_nsurf, blk_surf_cell, blk_surf_nrm;
+    DevBuf edge_a, edge_b, edge_cell, surf_a, surf_b, surf_cell, pack;
+    lili::LivoxState host{};
+    bool have = false;
+    void release() {
+        for (DevBuf* b : {&in_i, &in_c, &und, &curv, &keep, &owner, &state, &cut_a, &cut_b, &cut_src, &cell_pt, &cell_curv, &cell_src, &blk_nedge, &blk_edge_cell,
+                          &blk_edge_dir, &blk_nsurf, &blk_surf_cell, &blk_surf_nrm, &edge_a, &edge_b, &edge_cell, &surf_a, &surf_b, &surf_cell, &pack}) b->release();
+    }
+};
+}  // namespace lili_detail
+
+static lili_detail::LivoxBuffers* livox_of(lili_ctx* ctx) {
+    if (!ctx->ext_livox) { ctx->ext_livox = new lili_detail::LivoxBuffers(); ctx->ext_livox_free = [](void* p) { auto* r = static_cast<lili_detail::LivoxBuffers*>(p); r->release(); delete r; }; }
+    return static_cast<lili_detail::LivoxBuffers*>(ctx->ext_livox);
+}
+
+static int livox_copy_out(lili_ctx* ctx, lili_detail::LivoxBuffers* B, const lili_feature_out* o, const float4* a, const float4* b, size_t count) {
+    if (!o || !o->data || count == 0) return LILI_OK;
+    size_t k = std::min(count, o->capacity);
+    if (k == 0) return LILI_OK;
+    size_t stride = o->stride ? o->stride : 32;
+    ARGCHK(stride == 32 || stride == 48, "feature_out: Livox records are 32 B (packed x,y,z,nx,ny,nz,intensity,curvature) or 48 B (pcl::PointXYZINormal)");
+    HIPCHK(B->pack.ensure(k * stride));
+    hipLaunchKernelGGL(k_livox_pack, dim3(nblocks((int64_t)k, 256)), dim3(256), 0, ctx->stream, a, b, (int)k, stride == 48 ? 1 : 0, B->pack.as<float>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(o->data, B->pack.p, k * stride, o->mem == LILI_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));   // the pack buffer is reused by the next copy-out
+    return LILI_OK;
+}
+
+extern "C" {
+
+int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offset, const double q_imu[4], const lili_livox_params* params,
+                       lili_feature_out* cutted, lili_feature_out* edge, lili_feature_out* surf) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(scan && q_imu && params, "extract_livox: null argument");
+    ARGCHK(scan->aux_offset >= 0 && curvature_offset >= 0 && (size_t)curvature_offset + 4 <= scan->stride, "extract_livox: intensity (aux_offset) and curvature offsets are required");
+    HIPCHK(hipSetDevice(ctx->device));
+    auto* B = livox_of(ctx);
+    B->have = false;
+    int rc = lili_ingest_cloud(ctx, scan, B->in_i);
+    if (rc != LILI_OK) return rc;
+    lili_cloud c2 = *scan; c2.aux_offset = curvature_offset;
+    if (scan->mem == LILI_MEM_HOST) HIPCHK(hipStreamSynchronize(ctx->stream));   // the staging buffer is shared by the two ingests
+    rc = lili_ingest_cloud(ctx, &c2, B->in_c);
+    if (rc != LILI_OK) return rc;
+    const int n = (int)scan->n;
+    HIPCHK(B->state.ensure(sizeof(LivoxState))); HIPCHK(B->owner.ensure(kLvCells * 4));
+    HIPCHK(B->cell_pt.ensure(kLvCells * 16)); HIPCHK(B->cell_curv.ensure(kLvCells * 4)); HIPCHK(B->cell_src.ensure(kLvCells * 4));
+    HIPCHK(B->blk_nedge.ensure(kLvBlocks * 4)); HIPCHK(B->blk_edge_cell.ensure(kLvBlocks * kLvLines * 4)); HIPCHK(B->blk_edge_dir.ensure(kLvBlocks * 12));
+    HIPCHK(B->blk_nsurf.ensure(kLvBlocks * 4)); HIPCHK(B->blk_surf_cell.ensure(kLvBlocks * 36 * 4)); HIPCHK(B->blk_surf_nrm.ensure(kLvBlocks * 12));
+    HIPCHK(B->edge_a.ensure(kLvCells * 16)); HIPCHK(B->edge_b.ensure(kLvCells * 16)); HIPCHK(B->edge_cell.ensure(kLvCells * 4));
+    HIPCHK(B->surf_a.ensure(kLvCells * 16)); HIPCHK(B->surf_b.ensure(kLvCells * 16)); HIPCHK(B->surf_cell.ensure(kLvCells * 4));
+    const size_t cap = (size_t)std::max(n, 1);
+    HIPCHK(B->und.ensure(cap * 16)); HIPCHK(B->curv.ensure(cap * 4)); HIPCHK(B->keep.ensure(cap));
+    HIPCHK(B->cut_a.ensure(cap * 16)); HIPCHK(B->cut_b.ensure(cap * 16)); HIPCHK(B->cut_src.ensure(cap * 4));
+    LivoxState* st = B->state.as<LivoxState>();
+    LivoxDev P{};
+    for (int i = 0; i < 4; i++) P.q_imu[i] = q_imu[i];
+    P.surf_thres = params->surf_thres; P.edge_thres = params->edge_thres; P.near_thres = params->near_range;
+    hipLaunchKernelGGL(k_livox_init, dim3(nblocks(kLvCells, 256)), dim3(256), 0, ctx->stream, B->owner.as<int>(), st);
+    if (n > 0) {
+        hipLaunchKernelGGL(k_livox_prep, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, B->in_i.as<float4>(), B->in_c.as<float4>(), n, P, B->und.as<float4>(),
+                           B->curv.as<float>(), B->keep.as<unsigned char>(), B->owner.as<int>());
+        hipLaunchKernelGGL(k_livox_cut, dim3(1), dim3(1024), 0, ctx->stream, B->und.as<float4>(), B->curv.as<float>(), B->keep.as<unsigned char>(), n,
+                           B->cut_a.as<float4>(), B->cut_b.as<float4>(), B->cut_src.as<int>(), st);
+    }
+    hipLaunchKernelGGL(k_livox_grid, dim3(nblocks(kLvCells, 256)), dim3(256), 0, ctx->stream, B->owner.as<int>(), B->und.as<float4>(), B->curv.as<float>(),
+                       B->cell_pt.as<float4>(), B->cell_curv.as<float>(), B->cell_src.as<int>());
+    hipLaunchKernelGGL(k_livox_blocks, dim3(nblocks(kLvBlocks, 64)), dim3(64), 0, ctx->stream, B->cell_pt.as<float4>(), B->cell_curv.as<float>(), P,
+                       B->blk_nedge.as<int>(), B->blk_edge_cell.as<int>(), B->blk_edge_dir.as<float>(), B->blk_nsurf.as<int>(), B->blk_surf_cell.as<int>(),
+                       B->blk_surf_nrm.as<float>());
+    hipLaunchKernelGGL(k_livox_compact, dim3(1), dim3(1024), 0, ctx->stream, B->cell_pt.as<float4>(), B->cell_curv.as<float>(), B->blk_nedge.as<int>(),
+                       B->blk_edge_cell.as<int>(), B->blk_edge_dir.as<float>(), B->blk_nsurf.as<int>(), B->blk_surf_cell.as<int>(), B->blk_surf_nrm.as<float>(),
+                       B->edge_a.as<float4>(), B->edge_b.as<float4>(), B->edge_cell.as<int>(), B->surf_a.as<float4>(), B->surf_b.as<float4>(), B->surf_cell.as<int>(), st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&B->host, st, sizeof(LivoxState), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    B->have = true;
+    if (cutted) { cutted->count = (size_t)B->host.n_cut; rc = livox_copy_out(ctx, B, cutted, B->cut_a.as<float4>(), B->cut_b.as<float4>(), cutted->count); if (rc) return rc; }
+    if (edge) { edge->count = (size_t)B->host.n_edge; rc = livox_copy_out(ctx, B, edge, B->edge_a.as<float4>(), B->edge_b.as<float4>(), edge->count); if (rc) return rc; }
+    if (surf) { surf->count = (size_t)B->host.n_surf; rc = livox_copy_out(ctx, B, surf, B->surf_a.as<float4>(), B->surf_b.as<float4>(), surf->count); if (rc) return rc; }
+    return LILI_OK;
+}
+
+// Intermediate products of the last lili_extract_livox (parity tests): counts = {n_cut, n_edge, n_surf};
+// cut_src[n_cut], cell_src[24000] (-1 = empty), edge_cell[n_edge], surf_cell[n_surf] (cell = line * 4000 + column).
+int lili_extract_livox_debug(lili_ctx* ctx, int32_t counts[3], int32_t* cut_src, int32_t* cell_src, int32_t* edge_cell, int32_t* surf_cell) {
+    if (!ctx) return LILI_E_ARG;
+    auto* B = livox_of(ctx);
+    if (!B->have) return ctx->fail(LILI_E_STATE, "extract_livox_debug: run lili_extract_livox first");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (counts) { counts[0] = B->host.n_cut; counts[1] = B->host.n_edge; counts[2] = B->host.n_surf; }
+    auto dl = [&](void* dst, const DevBuf& src, size_t bytes) -> hipError_t { return (dst && bytes) ? hipMemcpyAsync(dst, src.p, bytes, hipMemcpyDeviceToHost, ctx->stream) : hipSuccess; };
+    HIPCHK(dl(cut_src, B->cut_src, (size_t)B->host.n_cut * 4)); HIPCHK(dl(cell_src, B->cell_src, (size_t)kLvCells * 4));
+    HIPCHK(dl(edge_cell, B->edge_cell, (size_t)B->host.n_edge * 4)); HIPCHK(dl(surf_cell, B->surf_cell, (size_t)B->host.n_surf * 4));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return LILI_OK;
+}
+
+}  // extern "C"

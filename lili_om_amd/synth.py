@@ -393,3 +393,43 @@ def make_room(seed=1, size=(24.0, 18.0, 6.0), leaf=0.4, n_query=4000, n_edge_que
     return dict(map_xyz=surf.astype(np.float32), map_refl=map_refl, edge_map_xyz=edge.astype(np.float32),
                 q_xyz=q_local.astype(np.float32), q_refl=q_refl, eq_xyz=e_local.astype(np.float32),
                 t_true=t_true, q_true=q_true)
+
+
+# ------------------------------------------------------------------------------------------------
+# Livox-Horizon-like scan (6 lines x 4000 time slots, FormatConvert's field layout)
+# ------------------------------------------------------------------------------------------------
+def make_livox_scan(seed=0, n_slots=4000, dup_frac=0.03, noise=0.02):
+    """Returns (n,5) float32: x, y, z, intensity = line + 0.1 * t, curvature = 0.1 * reflectivity
+    (L/src/FormatConvert.cpp:14-23).  6 close scan lines following a Lissajous pattern over an 80 x 20 deg field of
+    view of the outdoor scene; a few duplicated time slots (first-writer-wins), out-of-range reflectivities,
+    near-range points and a NaN are mixed in to exercise every filter of L/src/Preprocessing.cpp:243-268."""
+    rng = np.random.default_rng(seed)
+    sc = OutdoorScene()
+    s = np.repeat(np.arange(n_slots), 6)
+    line = np.tile(np.arange(6), n_slots)
+    t = s / float(n_slots - 1)
+    az = np.deg2rad(40.0 * np.sin(2 * np.pi * 1.0 * t + 0.4))
+    el = np.deg2rad(-6.0 + 9.0 * np.sin(2 * np.pi * 9.3 * t) + 0.25 * line)
+    d = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)], 1)
+    origin = np.array([0.0, 0.0, 1.8])
+    rng_t = sc.raycast(origin, d)
+    ok = np.isfinite(rng_t)
+    rng_t = np.where(ok, rng_t + rng.normal(0, noise, rng_t.shape), 1.0)
+    pts = d * rng_t[:, None]
+    refl = rng.integers(1, 255, pts.shape[0]).astype(np.float32)
+    refl[rng.random(pts.shape[0]) < 0.01] = 0.0          # curvature 0.0 < 0.05 -> filtered, but still in lidar_cloud_cutted
+    refl[rng.random(pts.shape[0]) < 0.01] = 255.0        # 25.5 > 25.45 -> filtered
+    time_end = np.float32(t[-1] if t[-1] > 0 else 1.0)
+    sfrac = (t.astype(np.float32) / time_end).astype(np.float32)
+    intensity = (line + sfrac.astype(np.float64) * 0.1).astype(np.float32)       # uint8 + float * double -> float
+    out = np.concatenate([pts, intensity[:, None], (0.1 * refl)[:, None]], 1).astype(np.float32)
+    out = out[ok]
+    # duplicates of earlier time slots appended later in the stream: they must lose their grid cell
+    nd = int(dup_frac * out.shape[0])
+    dup = out[rng.choice(out.shape[0], nd, replace=False)].copy()
+    dup[:, :3] += rng.normal(0, 0.05, (nd, 3)).astype(np.float32)
+    pos = np.sort(rng.choice(out.shape[0], nd, replace=False))
+    out = np.insert(out, pos, dup, axis=0)
+    out[5, :3] *= 0.001                                   # near point (< 0.1 m)
+    out[17, 0] = np.nan
+    return np.ascontiguousarray(out, np.float32)

@@ -261,3 +261,140 @@ extern "C" int lo_voxel_grid(const float* pts, int n, float leaf, int stable, fl
     for (size_t k = 0; k < o.size(); k++) { out[4 * k] = o[k].x; out[4 * k + 1] = o[k].y; out[4 * k + 2] = o[k].z; out[4 * k + 3] = o[k].i; counts[k] = c[k]; }
     return (int)o.size();
 }
+
+// =================================================================================================
+// Livox Horizon extractor — L/src/Preprocessing.cpp:219-383
+// =================================================================================================
+struct lo_livox_params {
+    double surf_thres;   // L/config/config_fr_iosb.yaml:5 (0.28)
+    double edge_thres;   // :6 (4)
+    float near_thres;    // 0.1 (L:226)
+};
+
+namespace {
+struct PN { float x, y, z, nx, ny, nz, intensity, curvature; };   // pcl::PointXYZINormal payload
+static inline void canon3(double v[3]) {
+    int k = 0; double m = std::fabs(v[0]);
+    if (std::fabs(v[1]) > m) { m = std::fabs(v[1]); k = 1; }
+    if (std::fabs(v[2]) > m) { k = 2; }
+    if (v[k] < 0) { v[0] = -v[0]; v[1] = -v[1]; v[2] = -v[2]; }
+}
+static inline double depth_of(const PN& p) { return (double)std::sqrt(p.x * p.x + p.y * p.y + p.z * p.z); }   // getDepth: float sqrt, widened (App. A1)
+}  // namespace
+
+// pts: n x 5 floats (x, y, z, intensity = line + 0.1 * t, curvature = 0.1 * reflectivity) — FormatConvert's layout
+// (L/src/FormatConvert.cpp:14-23).  Outputs, 8 floats per point (x,y,z,nx,ny,nz,intensity,curvature):
+//   cutted[n_cut*8]  every undistorted point with a valid line  (/lidar_cloud_cutted), cut_src its input index
+//   edge[n_edge*8], edge_cell[n_edge] (line * 4000 + column)    (/edge_features)
+//   surf[n_surf*8], surf_cell[n_surf]                           (/surf_features)
+//   cell_src[24000]  input index of the point that won each grid cell, or -1
+// The eigenvector sign (stored as normal / direction) is canonicalised: Eigen's is arbitrary (App. B4).
+extern "C" int lo_extract_livox(const float* pts, int n, const double q_imu_[4], const lo_livox_params* P,
+                                float* cutted, int* cut_src, int* n_cut, float* edge, int* edge_cell, int* n_edge,
+                                float* surf, int* surf_cell, int* n_surf, int* cell_src) {
+    const int N_SCANS = 6, H_SCANS = 4000;
+    Q4 qIMU{q_imu_[0], q_imu_[1], q_imu_[2], q_imu_[3]};
+    std::vector<PN> mat((size_t)N_SCANS * H_SCANS, PN{0, 0, 0, 0, 0, 0, 0, 0});   // PCL point ctor zero-initialises (L:238)
+    auto M = [&](int k, int c) -> PN& { return mat[(size_t)k * H_SCANS + c]; };
+    for (int c = 0; c < N_SCANS * H_SCANS; c++) cell_src[c] = -1;
+    double t_interval = 0.1 / (H_SCANS - 1);
+    int nc = 0;
+    float thres = P->near_thres;
+    for (int i = 0; i < n; i++) {
+        P4 p{pts[5 * i], pts[5 * i + 1], pts[5 * i + 2], pts[5 * i + 3]};
+        float curv = pts[5 * i + 4];
+        if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) continue;       // L:225
+        if (p.x * p.x + p.y * p.y + p.z * p.z < thres * thres) continue;                        // L:226
+        int scan_id = (int)p.i;                                                                  // L:252
+        if (scan_id < 0) continue;
+        if (scan_id >= N_SCANS) continue;    // the reference would index mat[] out of bounds; Horizon lines are 0..5
+        P4 u = undistort(p, qIMU, Q4{1, 0, 0, 0}, false);                                        // L:256
+        PN pu{u.x, u.y, u.z, 0, 0, 0, u.i, curv};
+        float* o = cutted + 8 * (size_t)nc;
+        o[0] = pu.x; o[1] = pu.y; o[2] = pu.z; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = pu.intensity; o[7] = pu.curvature;
+        cut_src[nc++] = i;
+        double dep = pu.x * pu.x + pu.y * pu.y + pu.z * pu.z;                                    // float expression widened (L:259)
+        if (dep > 40000.0 || dep < 4.0 || pu.curvature < 0.05 || pu.curvature > 25.45) continue;
+        int col = int(std::round((pu.intensity - scan_id) / t_interval));                        // L:262
+        if (col >= H_SCANS || col < 0) continue;
+        if (M(scan_id, col).curvature != 0) continue;                                            // first writer wins
+        M(scan_id, col) = pu;
+        cell_src[scan_id * H_SCANS + col] = i;
+    }
+    *n_cut = nc;
+    int ne = 0, ns = 0;
+    for (int i = 5; i < H_SCANS - 12; i = i + 6) {                                              // L:270
+        V3 center{0, 0, 0};
+        int num = 36;
+        std::vector<V3> near_pts;
+        for (int j = 0; j < 6; j++) for (int k = 0; k < N_SCANS; k++) {
+            if (M(k, i + j).curvature <= 0) { num--; continue; }
+            V3 pt{(double)M(k, i + j).x, (double)M(k, i + j).y, (double)M(k, i + j).z};
+            center = center + pt; near_pts.push_back(pt);
+        }
+        if (num < 25) continue;
+        center = V3{center.x / num, center.y / num, center.z / num};
+        double A1[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        for (size_t j = 0; j < near_pts.size(); j++) {
+            V3 z = near_pts[j] - center; double zz[3] = {z.x, z.y, z.z};
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) A1[r][c] += zz[r] * zz[c];
+        }
+        double ev[3], evec[3][3];
+        eig3_sym(A1, ev, evec);
+        std::vector<int> idsx, idsy;
+        for (int k = 0; k < N_SCANS; k++) {                                                      // L:302-331
+            double max_s = 0; int idx = i;
+            for (int j = 0; j < 6; j++) {
+                if (M(k, i + j).curvature <= 0) continue;
+                double g1 = depth_of(M(k, i + j - 4)) + depth_of(M(k, i + j - 3)) + depth_of(M(k, i + j - 2)) + depth_of(M(k, i + j - 1)) - 8 * depth_of(M(k, i + j)) +
+                            depth_of(M(k, i + j + 1)) + depth_of(M(k, i + j + 2)) + depth_of(M(k, i + j + 3)) + depth_of(M(k, i + j + 4));
+                g1 = g1 / (8 * depth_of(M(k, i + j)) + 1e-3);
+                if (g1 > 0.06) { if (g1 > max_s) { max_s = g1; idx = i + j; } }
+            }
+            if (max_s != 0) { idsx.push_back(k); idsy.push_back(idx); }
+        }
+        V3 ce{0, 0, 0};
+        std::vector<V3> near_e;
+        for (size_t j = 0; j < idsx.size(); j++) {
+            V3 pt{(double)M(idsx[j], idsy[j]).x, (double)M(idsx[j], idsy[j]).y, (double)M(idsx[j], idsy[j]).z};
+            ce = ce + pt; near_e.push_back(pt);
+        }
+        double ne_d = (double)idsx.size();
+        ce = V3{ce.x / ne_d, ce.y / ne_d, ce.z / ne_d};                                          // 0/0 = NaN when there is no candidate (App. A6)
+        double AE[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        for (size_t j = 0; j < near_e.size(); j++) {
+            V3 z = near_e[j] - ce; double zz[3] = {z.x, z.y, z.z};
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) AE[r][c] += zz[r] * zz[c];
+        }
+        double eve[3], evece[3][3];
+        eig3_sym(AE, eve, evece);
+        if (eve[2] > P->edge_thres * eve[1] && idsx.size() > 3) {                                // L:353
+            double u[3] = {evece[2][0], evece[2][1], evece[2][2]};
+            canon3(u);
+            for (size_t j = 0; j < idsx.size(); j++) {
+                PN& m = M(idsx[j], idsy[j]);
+                if (m.curvature <= 0 && m.intensity <= 0) continue;
+                m.nx = (float)u[0]; m.ny = (float)u[1]; m.nz = (float)u[2];
+                float* o = edge + 8 * (size_t)ne;
+                o[0] = m.x; o[1] = m.y; o[2] = m.z; o[3] = m.nx; o[4] = m.ny; o[5] = m.nz; o[6] = m.intensity; o[7] = m.curvature;
+                edge_cell[ne++] = idsx[j] * H_SCANS + idsy[j];
+                m.curvature *= -1;
+            }
+        }
+        if (ev[0] < P->surf_thres * ev[1]) {                                                     // L:367
+            double u[3] = {evec[0][0], evec[0][1], evec[0][2]};
+            canon3(u);
+            for (int j = 0; j < 6; j++) for (int k = 0; k < N_SCANS; k++) {
+                PN& m = M(k, i + j);
+                if (m.curvature <= 0) continue;
+                m.nx = (float)u[0]; m.ny = (float)u[1]; m.nz = (float)u[2];
+                float* o = surf + 8 * (size_t)ns;
+                o[0] = m.x; o[1] = m.y; o[2] = m.z; o[3] = m.nx; o[4] = m.ny; o[5] = m.nz; o[6] = m.intensity; o[7] = m.curvature;
+                surf_cell[ns++] = k * H_SCANS + (i + j);
+                m.curvature *= -1;
+            }
+        }
+    }
+    *n_edge = ne; *n_surf = ns;
+    return 0;
+}

@@ -282,3 +282,33 @@ def voxel_grid(pts_xyzi, leaf, stable=False):
     lib().lo_voxel_grid.restype = C.c_int
     m = lib().lo_voxel_grid(_p(pts), n, C.c_float(leaf), int(bool(stable)), _p(out), _p(cnt))
     return out[:m], cnt[:m]
+
+
+class LivoxParams(C.Structure):
+    _fields_ = [("surf_thres", C.c_double), ("edge_thres", C.c_double), ("near_thres", C.c_float)]
+
+
+def livox_params(surf_thres=0.28, edge_thres=4.0, near_thres=0.1):
+    """L/config/config_fr_iosb.yaml:5-6, L/src/Preprocessing.cpp:226."""
+    return LivoxParams(surf_thres, edge_thres, near_thres)
+
+
+def extract_livox(pts5, q_imu=(1.0, 0, 0, 0), P=None):
+    """Livox Horizon extractor.  pts5: (n,5) float32 = x, y, z, intensity (line + 0.1 t), curvature (0.1 reflectivity)."""
+    P = P or livox_params()
+    pts = _f32(pts5, 5)
+    n = pts.shape[0]
+    cap = max(n, 1)
+    cut = np.zeros((cap, 8), np.float32); cut_src = np.zeros(cap, np.int32)
+    edge = np.zeros((24000, 8), np.float32); edge_cell = np.zeros(24000, np.int32)
+    surf = np.zeros((24000, 8), np.float32); surf_cell = np.zeros(24000, np.int32)
+    cell_src = np.zeros(24000, np.int32)
+    nc, ne, ns = C.c_int(0), C.c_int(0), C.c_int(0)
+    qi = _f64(q_imu)
+    lib().lo_extract_livox.restype = C.c_int
+    rc = lib().lo_extract_livox(_p(pts), n, _p(qi), C.byref(P), _p(cut), _p(cut_src), C.byref(nc), _p(edge), _p(edge_cell),
+                                C.byref(ne), _p(surf), _p(surf_cell), C.byref(ns), _p(cell_src))
+    if rc != 0:
+        raise RuntimeError("lo_extract_livox failed")
+    return dict(cutted=cut[:nc.value], cut_src=cut_src[:nc.value], edge=edge[:ne.value], edge_cell=edge_cell[:ne.value],
+                surf=surf[:ns.value], surf_cell=surf_cell[:ns.value], cell_src=cell_src.reshape(6, 4000))
