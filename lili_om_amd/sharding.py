@@ -1,0 +1,43 @@
+"""Host-side sharding algebra of the multi-GPU scan-to-map iteration.
+
+The data path is: every rank associates + linearises its block of the query array against the replicated map,
+then ONE all-reduce(sum) of the 72-double Gram record (and, for the ROT residual scale num/N, one of the two
+correspondence counters) makes every rank hold the same normal equations; each rank applies the same
+Gauss-Newton update.  This module holds the pieces that do not depend on the device so that they can be tested
+with gloo on CPU; bench.py drives the same functions with the HIP kernels in between.
+"""
+import numpy as np
+
+
+def shard_bounds(n_items, world, rank):
+    """Contiguous block shard [lo, hi) of rank `rank` (rank r gets [r*ceil(N/P), ...))."""
+    per = (n_items + world - 1) // world
+    lo = min(n_items, rank * per)
+    return lo, min(n_items, lo + per)
+
+
+def allreduce_counts(dist, counts):
+    """In-place sum of the [n_surf, n_edge] tensor over ranks (ROT: scale = num / GLOBAL N)."""
+    dist.all_reduce(counts)
+    return counts
+
+
+def allreduce_gram(dist, gram):
+    """In-place sum of the 72-double record [64 Gram | cost | n_surf | n_edge | ...] over ranks."""
+    dist.all_reduce(gram)
+    return gram
+
+
+def plus_jacobian(q):
+    """ceres::QuaternionParameterization::ComputeJacobian for q = (w,x,y,z): 4x3."""
+    w, x, y, z = q
+    return np.array([[-x, -y, -z], [w, z, -y], [-z, w, x], [y, -x, w]], dtype=np.float64)
+
+
+def project_gram(gram8, q):
+    """(H 6x6, g 6) of the local parameterisation from the global 8x8 Gram: H = P^T G77 P, g = P^T G7r."""
+    G = np.asarray(gram8, np.float64).reshape(8, 8)
+    P = np.zeros((7, 6))
+    P[:3, :3] = np.eye(3)
+    P[3:, 3:] = plus_jacobian(q)
+    return P.T @ G[:7, :7] @ P, P.T @ G[:7, 7]

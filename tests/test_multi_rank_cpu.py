@@ -1,0 +1,99 @@
+"""World-size-2 gloo test (CPU) of the sharded scan-to-map iteration: block-sharding the queries, all-reducing the
+counts and the Gram record, and applying the same GN step on every rank reproduces the single-rank result.
+The per-shard association / linearisation is done by the ORACLE here (the HIP kernels need a GPU); what is under
+test is the sharding + reduction algebra that bench.py --gpus N uses (lili_om_amd/sharding.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from lili_om_amd import sharding, synth
+import lili_om_amd as L
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _one_iteration(O, room, lo, hi, t, q, P, PO, reduce_fn):
+    tree = O.KdTree(room["map_xyz"])
+    Q2, T2 = L.api.assoc_transform(t, q, P)
+    rs = O.associate_surf(tree, None, room["q_xyz"][lo:hi], None, Q2, T2, PO)
+    counts = torch.tensor([rs["count"], 0], dtype=torch.int32)
+    counts = reduce_fn("counts", counts)
+    G, cost, n = O.linearize_surf(rs, t, q, PO, 1000.0 / max(int(counts[0]), 1))
+    rec = torch.zeros(72, dtype=torch.float64)
+    rec[:64] = torch.from_numpy(G.reshape(-1))
+    rec[64], rec[65] = cost, n
+    rec = reduce_fn("gram", rec)
+    st, t2, q2, _ = L.api.gn_step_host(rec[:64].numpy(), t, q)
+    return st, t2, q2, rec
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    room = synth.make_room(seed=21, n_query=3001, n_edge_query=10)
+    P, PO = L.make_params("rot"), O.params("rot")
+    tb, qb = L.api.body_pose_from_lidar(room["t_true"], room["q_true"], P)
+    t, q = synth.perturbed_pose(tb, qb, np.random.default_rng(2), 0.1, 0.5)
+    lo, hi = sharding.shard_bounds(room["q_xyz"].shape[0], world, rank)
+
+    def red(kind, x):
+        return sharding.allreduce_counts(dist, x) if kind == "counts" else sharding.allreduce_gram(dist, x)
+    for _ in range(3):
+        st, t, q, rec = _one_iteration(O, room, lo, hi, t, q, P, PO, red)
+        assert st == 0
+    out[rank] = (t.copy(), q.copy(), rec.numpy().copy())
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_iteration_matches_single_rank(oracle):
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    # single-rank reference
+    room = synth.make_room(seed=21, n_query=3001, n_edge_query=10)
+    P, PO = L.make_params("rot"), oracle.params("rot")
+    tb, qb = L.api.body_pose_from_lidar(room["t_true"], room["q_true"], P)
+    t, q = synth.perturbed_pose(tb, qb, np.random.default_rng(2), 0.1, 0.5)
+    for _ in range(3):
+        st, t, q, rec = _one_iteration(oracle, room, 0, room["q_xyz"].shape[0], t, q, P, PO, lambda k, x: x)
+    for r in range(world):
+        tr, qr, recr = out[r]
+        assert np.abs(tr - t).max() < 1e-12 and np.abs(qr - q).max() < 1e-12      # summation tree differs: ~1e-16 relative
+        assert np.abs(recr[:64] - rec[:64].numpy()).max() <= 1e-12 * np.abs(rec[:64].numpy()).max()
+        assert recr[65] == rec[65]
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])   # ranks agree bit for bit
+
+
+def test_shard_bounds_cover_everything_once():
+    for n in (0, 1, 7, 200000, 200001):
+        for world in (1, 2, 4, 8):
+            seen = np.zeros(n, int)
+            for r in range(world):
+                lo, hi = sharding.shard_bounds(n, world, r)
+                assert 0 <= lo <= hi <= n
+                seen[lo:hi] += 1
+            assert (seen == 1).all()
+
+
+def test_project_gram_matches_host_gn_step(oracle):
+    rng = np.random.default_rng(0)
+    J = rng.normal(size=(100, 8))
+    G = J.T @ J
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    H, g = sharding.project_gram(G, q)
+    d = np.linalg.solve(H, -g)
+    st, t2, q2, delta = L.api.gn_step_host(G, np.zeros(3), q)
+    assert st == 0 and np.allclose(delta, d, rtol=1e-9, atol=1e-12)
