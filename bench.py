@@ -123,8 +123,9 @@ def main():
     scan = ring_major(w["scan_xyz"], w["scan_ring"])
     n_scan = scan.shape[0]
     if world > 1 and args.scaling == "strong":
-        per = (n_scan + world - 1) // world
-        queries = scan[rank * per:(rank + 1) * per]
+        from lili_om_amd import sharding
+        lo, hi = sharding.shard_bounds(n_scan, world, rank)
+        queries = scan[lo:hi]
     elif world > 1:
         # weak: rank r holds the r-th 200k-point shard of an (N x 200k)-point scan (same rays, independent range noise)
         d = scan / np.linalg.norm(scan, axis=1, keepdims=True)
