@@ -65,7 +65,7 @@ def cpu_baseline(w, queries, t0, q0, n_threads):
         for _ in range(iters):
             Q2, T2 = L.api.assoc_transform(t, q, P)
             rs = O.associate_surf(tree, None, queries, None, Q2, T2, PO, nthreads=nth)
-            G, _, _ = O.linearize_surf(rs, t, q, PO, 1000.0 / max(rs["count"], 1))
+            G, _, _ = O.linearize_surf(rs, t, q, PO, 1000.0 / max(rs["count"], 1), nthreads=nth)
             st, t, q, _ = O.gn_step(G, t, q)
         return (time.perf_counter() - tic) / iters, t, q
 
@@ -73,7 +73,7 @@ def cpu_baseline(w, queries, t0, q0, n_threads):
     itn, t_fin, q_fin = run(n_threads, 10)
     return dict(value=1.0 / itn, unit="scan-to-map iterations/s", cores=n_threads, kind="port",
                 sample=(f"oracle (g++ -O3, no -march, exact kd-tree): 10 full outer iterations of the same 200k-query / "
-                        f"5M-point workload on {n_threads} threads (association threaded, Gram serial); single-thread = "
+                        f"5M-point workload on {n_threads} threads (association and Gram threaded); single-thread = "
                         f"{1.0 / it1:.3f} it/s; kd-tree build {t_build:.2f} s excluded (once per keyframe)")), t_fin, q_fin
 
 

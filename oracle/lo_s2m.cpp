@@ -496,3 +496,38 @@ extern "C" void lo_qrot(const double q[4], const double v[3], double out[3]) {
 }
 extern "C" void lo_loss(int loss, double a, double s, double rho[3]) { loss_eval(loss, a, s, rho); }
 
+
+// Multi-threaded variant of lo_linearize_surf for the all-cores CPU baseline: per-thread partial Grams over
+// contiguous query ranges, added in thread order (the reference itself sums per-thread A, b after joining its 4
+// marginalisation threads, L/src/MarginalizationFactor.cpp:159-174).
+extern "C" void lo_linearize_surf_mt(const unsigned char* valid, const float* rec_cp, const float* rec_n, const float* rec_d, const double* rec_score,
+                                     int n_q, const double t[3], const double q[4], const lo_params* P, double scale, int nthreads,
+                                     double gram[64], double* cost, int* count) {
+    if (nthreads < 1) nthreads = 1;
+    std::vector<double> G((size_t)nthreads * 64, 0.0), C(nthreads, 0.0);
+    std::vector<int> N(nthreads, 0);
+    int chunk = (n_q + nthreads - 1) / nthreads;
+    std::vector<std::thread> th;
+    for (int w = 0; w < nthreads; w++) {
+        int lo = w * chunk, hi = std::min(n_q, lo + chunk);
+        if (lo >= hi) break;
+        th.emplace_back([=, &G, &C, &N]() {
+            double* g = G.data() + (size_t)w * 64; double c = 0; int cnt = 0;
+            for (int i = lo; i < hi; i++) {
+                if (!valid[i]) continue;
+                double Jr[8];
+                lo_eval_plane(t, q, rec_cp + 3 * (size_t)i, rec_n + 3 * (size_t)i, rec_d[i], rec_score[i] * scale, P->q_lb, P->t_lb,
+                              P->variant == LO_VARIANT_FRONTEND, Jr);
+                double ci; robustify(P->loss, P->loss_a, Jr, &ci);
+                c += ci; cnt++;
+                for (int a = 0; a < 8; a++) for (int b = 0; b < 8; b++) g[a * 8 + b] += Jr[a] * Jr[b];
+            }
+            C[w] = c; N[w] = cnt;
+        });
+    }
+    for (auto& x : th) x.join();
+    for (int k = 0; k < 64; k++) gram[k] = 0;
+    double c = 0; int cnt = 0;
+    for (int w = 0; w < nthreads; w++) { for (int k = 0; k < 64; k++) gram[k] += G[(size_t)w * 64 + k]; c += C[w]; cnt += N[w]; }
+    *cost = c; *count = cnt;
+}

@@ -156,11 +156,16 @@ def associate_edge(tree, q_xyz, pose_q, pose_t, P, nthreads=1):
     return out
 
 
-def linearize_surf(rec, t, q, P, scale=1.0):
+def linearize_surf(rec, t, q, P, scale=1.0, nthreads=1):
     gram = np.zeros(64, np.float64)
     cost = C.c_double(0)
     cnt = C.c_int(0)
     t, q = _f64(t), _f64(q)
+    if nthreads > 1:
+        lib().lo_linearize_surf_mt(_p(rec["valid"]), _p(rec["cp"]), _p(rec["n"]), _p(rec["d"]), _p(rec["score"]),
+                                   rec["valid"].shape[0], _p(t), _p(q), C.byref(P), C.c_double(scale), int(nthreads),
+                                   _p(gram), C.byref(cost), C.byref(cnt))
+        return gram.reshape(8, 8), cost.value, cnt.value
     lib().lo_linearize_surf(_p(rec["valid"]), _p(rec["cp"]), _p(rec["n"]), _p(rec["d"]), _p(rec["score"]),
                             rec["valid"].shape[0], _p(t), _p(q), C.byref(P), C.c_double(scale), _p(gram),
                             C.byref(cost), C.byref(cnt))
