@@ -398,7 +398,7 @@ def make_room(seed=1, size=(24.0, 18.0, 6.0), leaf=0.4, n_query=4000, n_edge_que
 # ------------------------------------------------------------------------------------------------
 # Livox-Horizon-like scan (6 lines x 4000 time slots, FormatConvert's field layout)
 # ------------------------------------------------------------------------------------------------
-def make_livox_scan(seed=0, n_slots=4000, dup_frac=0.03, noise=0.02):
+def make_livox_scan(seed=0, n_slots=4000, dup_frac=0.03, noise=0.02, origin=(0.0, 0.0, 1.8), yaw=0.0, inject_bad=True):
     """Returns (n,5) float32: x, y, z, intensity = line + 0.1 * t, curvature = 0.1 * reflectivity
     (L/src/FormatConvert.cpp:14-23).  6 close scan lines following a Lissajous pattern over an 80 x 20 deg field of
     view of the outdoor scene; a few duplicated time slots (first-writer-wins), out-of-range reflectivities,
@@ -410,10 +410,12 @@ def make_livox_scan(seed=0, n_slots=4000, dup_frac=0.03, noise=0.02):
     t = s / float(n_slots - 1)
     az = np.deg2rad(40.0 * np.sin(2 * np.pi * 1.0 * t + 0.4))
     el = np.deg2rad(-6.0 + 9.0 * np.sin(2 * np.pi * 9.3 * t) + 0.25 * line)
-    d = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)], 1)
-    origin = np.array([0.0, 0.0, 1.8])
-    rng_t = sc.raycast(origin, d)
-    ok = np.isfinite(rng_t)
+    d = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)], 1)      # sensor frame
+    cy, sy = math.cos(yaw), math.sin(yaw)
+    dw = np.stack([cy * d[:, 0] - sy * d[:, 1], sy * d[:, 0] + cy * d[:, 1], d[:, 2]], 1)  # world frame
+    origin = np.asarray(origin, np.float64)
+    rng_t = sc.raycast(origin, dw, t_max=400.0)
+    ok = np.isfinite(rng_t) & (rng_t < 190.0)
     rng_t = np.where(ok, rng_t + rng.normal(0, noise, rng_t.shape), 1.0)
     pts = d * rng_t[:, None]
     refl = rng.integers(1, 255, pts.shape[0]).astype(np.float32)
@@ -424,6 +426,8 @@ def make_livox_scan(seed=0, n_slots=4000, dup_frac=0.03, noise=0.02):
     intensity = (line + sfrac.astype(np.float64) * 0.1).astype(np.float32)       # uint8 + float * double -> float
     out = np.concatenate([pts, intensity[:, None], (0.1 * refl)[:, None]], 1).astype(np.float32)
     out = out[ok]
+    if not inject_bad:
+        return np.ascontiguousarray(out, np.float32)
     # duplicates of earlier time slots appended later in the stream: they must lose their grid cell
     nd = int(dup_frac * out.shape[0])
     dup = out[rng.choice(out.shape[0], nd, replace=False)].copy()
