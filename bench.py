@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--n-map", type=int, default=N_MAP)
     ap.add_argument("--n-az", type=int, default=N_AZ)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--split-path", action="store_true", help="use the multi-GPU code path (export/import counts, separate GN kernel) even at N=1")
     ap.add_argument("--bin", action="store_true", help="enable the once-per-scan query binning (A/B only)")
     ap.add_argument("--tile", action="store_true", help="enable the LDS-tiled search (A/B only; implies --bin)")
     args = ap.parse_args()
@@ -155,15 +156,22 @@ def main():
     gram = torch.zeros(L.api.GRAM_DOUBLES, dtype=torch.float64, device=dev)
     m.pose_set(0, t0, q0)
 
+    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+
     def step_multi():
+        # the sharded iteration: two tiny all-reduces (counts, Gram record) between the three device stages
         m.associate_dev(0, L.MASK_SURF)
-        _allreduce_counts(m, dist, dev)
+        m.counts_export(0, counts.data_ptr())
+        if dist is not None:
+            dist.all_reduce(counts)
+        m.counts_import(0, counts.data_ptr())
         m.linearize_dev(0, gram.data_ptr(), L.MASK_SURF)
-        dist.all_reduce(gram)
+        if dist is not None:
+            dist.all_reduce(gram)
         m.gn_update(0, gram.data_ptr())
 
     def run_steps(k):
-        if world == 1:
+        if world == 1 and not args.split_path:
             m.iterate(0, k, L.MASK_SURF)      # one C call enqueues k x (associate, linearise, reduce, GN update)
         else:
             for _ in range(k):
@@ -246,30 +254,6 @@ def main():
     if dist is not None:
         dist.destroy_process_group()
     ctx.close()
-
-
-_counts_tensor = None
-
-
-def _allreduce_counts(m, dist, dev):
-    """All-reduce (sum) the slot's two correspondence counters in place (ROT residual scale = num / GLOBAL N)."""
-    global _counts_tensor
-    import torch
-    ptr = m.counts_ptr(0)          # enqueues the reduction of this rank's per-block counts into int[2]
-    if _counts_tensor is None:
-        _counts_tensor = _tensor_from_ptr(ptr, 2, dev)
-    dist.all_reduce(_counts_tensor)
-
-
-def _tensor_from_ptr(ptr, n_int32, dev):
-    """Zero-copy int32 view of device memory owned by the lili context (via __cuda_array_interface__)."""
-    import torch
-
-    class _Holder:
-        pass
-    h = _Holder()
-    h.__cuda_array_interface__ = {"shape": (n_int32,), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
-    return torch.as_tensor(h, device=dev)
 
 
 if __name__ == "__main__":

@@ -210,11 +210,14 @@ int lili_s2m_pose_get(lili_ctx* ctx, int slot, double t[3], double q[4], int* gn
 int lili_s2m_accumulate(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, double* d_gram);
 /* The same in two steps, for callers that shard the queries of one scan over several GPUs AND use the
  * ROT residual scaling num / N (R/src/BackendFusion.cpp:843,861), where N must be the GLOBAL count:
- *   lili_s2m_associate_dev  -> counts of this rank in device memory (lili_s2m_counts_ptr: int[2])
- *   [caller: all-reduce(sum) the two ints in place]
- *   lili_s2m_linearize_dev  -> d_gram as above (and resets the counts for the next iteration).     */
+ *   lili_s2m_associate_dev   -> per-block counts of this rank in device memory
+ *   lili_s2m_counts_export   -> this rank's {n_surf, n_edge} into a caller-owned DEVICE int32[2]   (async)
+ *   [caller: all-reduce(sum) that buffer over ranks on the same stream]
+ *   lili_s2m_counts_import   -> hands the global counts back                                       (async)
+ *   lili_s2m_linearize_dev   -> d_gram as above.                                                          */
 int lili_s2m_associate_dev(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params);
-int lili_s2m_counts_ptr(lili_ctx* ctx, int slot, int** d_counts);
+int lili_s2m_counts_export(lili_ctx* ctx, int slot, int32_t* d_counts);
+int lili_s2m_counts_import(lili_ctx* ctx, int slot, const int32_t* d_counts);
 int lili_s2m_linearize_dev(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, double* d_gram);
 /* Second half (async): one Gauss-Newton step on the 6-dof local parameterisation
  * (ceres::QuaternionParameterization plus-Jacobian and Plus()), pose updated in device memory. */

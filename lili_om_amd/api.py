@@ -110,7 +110,8 @@ _SIGS = {
     "lili_s2m_pose_get": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "lili_s2m_accumulate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams), C.c_void_p]),
     "lili_s2m_associate_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams)]),
-    "lili_s2m_counts_ptr": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "lili_s2m_counts_export": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "lili_s2m_counts_import": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "lili_s2m_linearize_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams), C.c_void_p]),
     "lili_s2m_gn_update": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "lili_s2m_iterate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams), C.c_int]),
@@ -300,10 +301,11 @@ class ScanToMapMatcher:
     def associate_dev(self, slot, kind_mask=MASK_SURF):
         self.ctx._chk(self.lib.lili_s2m_associate_dev(self.ctx.h, slot, kind_mask, C.byref(self.params)))
 
-    def counts_ptr(self, slot):
-        p = C.c_void_p()
-        self.ctx._chk(self.lib.lili_s2m_counts_ptr(self.ctx.h, slot, C.byref(p)))
-        return p.value
+    def counts_export(self, slot, d_counts_ptr):
+        self.ctx._chk(self.lib.lili_s2m_counts_export(self.ctx.h, slot, C.c_void_p(d_counts_ptr)))
+
+    def counts_import(self, slot, d_counts_ptr):
+        self.ctx._chk(self.lib.lili_s2m_counts_import(self.ctx.h, slot, C.c_void_p(d_counts_ptr)))
 
     def linearize_dev(self, slot, d_gram_ptr, kind_mask=MASK_SURF):
         self.ctx._chk(self.lib.lili_s2m_linearize_dev(self.ctx.h, slot, kind_mask, C.byref(self.params), C.c_void_p(d_gram_ptr)))

@@ -562,14 +562,22 @@ int lili_s2m_associate_dev(lili_ctx* ctx, int slot, int kind_mask, const lili_s2
     return LILI_OK;
 }
 
-int lili_s2m_counts_ptr(lili_ctx* ctx, int slot, int** d_counts) {
+int lili_s2m_counts_export(lili_ctx* ctx, int slot, int32_t* d_counts) {
     if (!ctx) return LILI_E_ARG;
-    ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS && d_counts, "counts_ptr: bad argument");
+    ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS && d_counts, "counts_export: bad argument");
     HIPCHK(hipSetDevice(ctx->device));
     int rc = launch_sum_counts(ctx, slot, LILI_MASK_SURF | LILI_MASK_EDGE);
     if (rc != LILI_OK) return rc;
-    ctx->slots[slot].use_global_counts = true;   // the next linearize_dev scales with these (possibly all-reduced) counts
-    *d_counts = ctx->state(slot)->n_res;
+    HIPCHK(hipMemcpyAsync(d_counts, ctx->state(slot)->n_res, 2 * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+    return LILI_OK;
+}
+
+int lili_s2m_counts_import(lili_ctx* ctx, int slot, const int32_t* d_counts) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS && d_counts, "counts_import: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(ctx->state(slot)->n_res, d_counts, 2 * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+    ctx->slots[slot].use_global_counts = true;   // the next linearize_dev scales with these (all-reduced) counts
     return LILI_OK;
 }
 

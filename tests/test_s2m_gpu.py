@@ -350,3 +350,33 @@ def test_query_order_options_do_not_change_results(gpu_ctx, oracle, opts):
     rs = oracle.associate_surf(tree, None, scan, None, Q2, T2, PO, nthreads=8)
     assert rs["count"] == b[0]
     assert np.array_equal(b[1][inside], rs["nn_idx"][inside])
+
+
+def test_split_multi_gpu_path_equals_fused_path(gpu_ctx, oracle):
+    """The stage-by-stage path a multi-GPU caller uses (associate_dev, counts export / [all-reduce] / import,
+    linearize_dev, [all-reduce], gn_update) with world size 1 must give exactly the fused iterate() result."""
+    import torch
+    room = synth.make_room(seed=17, n_query=6000, n_edge_query=100)
+    P, PO, m = _setup(gpu_ctx, oracle, "rot", room, with_refl=False)
+    tb, qb = L.api.body_pose_from_lidar(room["t_true"], room["q_true"], P)
+    t0, q0 = synth.perturbed_pose(tb, qb, np.random.default_rng(5), 0.1, 0.8)
+    m.pose_set(0, t0, q0)
+    m.iterate(0, 4, L.MASK_SURF)
+    tf, qf, st = m.pose_get(0)
+    assert st == 0
+    dev = torch.device("cuda", 0)
+    gram = torch.zeros(L.api.GRAM_DOUBLES, dtype=torch.float64, device=dev)
+    counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    m.pose_set(0, t0, q0)
+    for _ in range(4):
+        m.associate_dev(0, L.MASK_SURF)
+        m.counts_export(0, counts.data_ptr())
+        gpu_ctx.sync()                       # (a real caller all-reduces `counts` on the context's stream here)
+        m.counts_import(0, counts.data_ptr())
+        m.linearize_dev(0, gram.data_ptr(), L.MASK_SURF)
+        gpu_ctx.sync()
+        m.gn_update(0, gram.data_ptr())
+    ts, qs, st = m.pose_get(0)
+    assert st == 0
+    assert np.array_equal(tf, ts) and np.array_equal(qf, qs)
+    assert int(counts[0]) == int(gram[65].item()) > 1000
