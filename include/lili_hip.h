@@ -163,6 +163,21 @@ int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offs
  * edge_cell / surf_cell: cell (line * 4000 + column) of each emitted feature.  Any pointer may be NULL. */
 int lili_extract_livox_debug(lili_ctx* ctx, int32_t counts[3], int32_t* cut_src, int32_t* cell_src, int32_t* edge_cell, int32_t* surf_cell);
 
+/* ---- local map: keyframe ring buffer + VoxelGrid + index ------------------------------------ */
+
+/* pcl::VoxelGrid<PointT>::filter with leaf (leaf, leaf, leaf) on (x, y, z, aux) points: one centroid per occupied
+ * voxel (aux averaged too), output ordered by ascending voxel index, f32 accumulation in input order
+ * (L/src/BackendFusion.cpp:1488-1511, R/src/Preprocessing.cpp:502-506).  `counts` (optional, capacity ints) receives
+ * the number of points merged into each output point.  Blocking. */
+int lili_voxel_filter(lili_ctx* ctx, const lili_cloud* cloud, float leaf, lili_feature_out* out, int32_t* counts);
+/* Keyframe ring buffer of one map kind (recent_surf_keyframes / recent_edge_keyframes, L:1407-1477):
+ * push = transformCloud(features, pose) appended, oldest dropped beyond `width` (local_map_width);
+ * commit = concatenate (L:1479-1483) + VoxelGrid(leaf) (L:1488-1492) + lili_map_set on the result (L:839-840),
+ * all on the device.  n_raw / n_map (optional) receive the point counts before / after the filter. */
+int lili_localmap_reset(lili_ctx* ctx, int kind);
+int lili_localmap_push(lili_ctx* ctx, int kind, const lili_cloud* features, const double t[3], const double q[4], int width);
+int lili_localmap_commit(lili_ctx* ctx, int kind, float leaf, double max_sq_radius, int64_t* n_raw, int64_t* n_map);
+
 /* ---- scan-to-map matcher -------------------------------------------------------------------- */
 
 /* Uploads the feature points of keyframe `slot` (surf_lasts_ds[idx] / edge_lasts_ds[idx],

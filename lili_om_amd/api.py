@@ -98,6 +98,10 @@ _SIGS = {
     "lili_extract_rot_debug": (C.c_int, [C.c_void_p] + [C.c_void_p] * 11),
     "lili_extract_livox": (C.c_int, [C.c_void_p, C.POINTER(Cloud), C.c_int, C.c_void_p, C.POINTER(LivoxParams), C.POINTER(FeatureOut), C.POINTER(FeatureOut), C.POINTER(FeatureOut)]),
     "lili_extract_livox_debug": (C.c_int, [C.c_void_p] * 6),
+    "lili_voxel_filter": (C.c_int, [C.c_void_p, C.POINTER(Cloud), C.c_float, C.POINTER(FeatureOut), C.c_void_p]),
+    "lili_localmap_reset": (C.c_int, [C.c_void_p, C.c_int]),
+    "lili_localmap_push": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Cloud), C.c_void_p, C.c_void_p, C.c_int]),
+    "lili_localmap_commit": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_double, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "lili_map_set": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Cloud), C.c_double]),
     "lili_map_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "lili_s2m_set_queries": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Cloud)]),
@@ -315,6 +319,38 @@ class ScanToMapMatcher:
 
     def iterate(self, slot, n_iters, kind_mask=MASK_SURF):
         self.ctx._chk(self.lib.lili_s2m_iterate(self.ctx.h, slot, kind_mask, C.byref(self.params), int(n_iters)))
+
+
+def voxel_filter(ctx, pts_xyza, leaf):
+    """pcl::VoxelGrid on (n,4) float32 rows (x, y, z, aux).  Returns (centroids (m,4), counts (m,))."""
+    pts = np.ascontiguousarray(pts_xyza, dtype=np.float32)
+    cloud = cloud_from_numpy(pts, aux_col=3)
+    cap = max(pts.shape[0], 1)
+    out = np.zeros((cap, 4), np.float32)
+    cnt = np.zeros(cap, np.int32)
+    fo = FeatureOut(out.ctypes.data, cap, 16, MEM_HOST, 0)
+    ctx._chk(ctx.lib.lili_voxel_filter(ctx.h, C.byref(cloud), float(leaf), C.byref(fo), _ptr(cnt)))
+    return out[:fo.count], cnt[:fo.count]
+
+
+class LocalMap:
+    """Keyframe ring buffer + VoxelGrid + map index on the device (buildLocalMapWithLandMark / downSampleCloud /
+    setInputCloud, L/src/BackendFusion.cpp:1387-1528, 839-840)."""
+
+    def __init__(self, ctx, kind, width, leaf, max_sq_radius=1.0):
+        self.ctx, self.kind, self.width, self.leaf, self.max_sq_radius = ctx, kind, int(width), float(leaf), float(max_sq_radius)
+        ctx._chk(ctx.lib.lili_localmap_reset(ctx.h, kind))
+
+    def push(self, feats_xyza, t, q):
+        pts = np.ascontiguousarray(feats_xyza, dtype=np.float32)
+        cloud = cloud_from_numpy(pts, aux_col=3 if pts.shape[1] > 3 else None)
+        t, q = _f64(t, 3), _f64(q, 4)
+        self.ctx._chk(self.ctx.lib.lili_localmap_push(self.ctx.h, self.kind, C.byref(cloud), _ptr(t), _ptr(q), self.width))
+
+    def commit(self):
+        a, b = C.c_int64(0), C.c_int64(0)
+        self.ctx._chk(self.ctx.lib.lili_localmap_commit(self.ctx.h, self.kind, self.leaf, self.max_sq_radius, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
 
 class RotExtractor:

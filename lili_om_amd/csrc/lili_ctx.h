@@ -82,6 +82,8 @@ struct lili_ctx {
     void (*ext_rot_free)(void*) = nullptr;
     void* ext_livox = nullptr;
     void (*ext_livox_free)(void*) = nullptr;
+    void* ext_voxel = nullptr;               // voxel filter / local-map ring buffer (lili_voxel.hip)
+    void (*ext_voxel_free)(void*) = nullptr;
 
     int fail(int code, const std::string& m) { err = m; return code; }
     SlotState* state(int slot) { return states.as<SlotState>() + slot; }

@@ -1,0 +1,301 @@
+// Local-map assembly and pcl::VoxelGrid down-sampling on gfx950:
+//   buildLocalMapWithLandMark + downSampleCloud + kd_tree->setInputCloud   — L/src/BackendFusion.cpp:1387-1528, 839-840
+//   (front-end: buildLocalMap + downSampleCloud                            — L/src/LidarOdometry.cpp:280-323)
+// Pieces:
+//   * stable LSD radix sort of (u32 key, i32 value) pairs, 4-bit digits: per-tile digit histograms, one exclusive
+//     scan over the digit-major table, stable scatter with ballot-based in-wave ranks (no atomics on the data path)
+//   * VoxelGrid with PCL >= 1.8 semantics (App. B2): idx from f32 floor(x * inv_leaf) - min_b, output ordered by
+//     voxel idx, centroid = f32 sums in INPUT ORDER / count (the stable sort keeps input order inside a voxel;
+//     PCL's std::sort leaves that order unspecified — oracle mode stable_sort = 1)
+//   * keyframe ring buffer: transformCloud (f64 rotate + translate, stored f32) of each pushed feature cloud,
+//     oldest dropped beyond `width`, commit = concatenate + voxel filter + uniform-grid index (lili_map_set path)
+#include "lili_ctx.h"
+#include "lili_device_math.h"
+
+namespace lili {
+__global__ void k_scan_block_sums(const int*, int64_t, int*);
+__global__ void k_scan_sums(int*, int);
+__global__ void k_scan_apply(const int*, int64_t, const int*, int*);
+__global__ void k_bbox(const float4*, int, unsigned*);
+
+constexpr int kSortBlock = 256, kSortItems = 8, kSortTile = kSortBlock * kSortItems;
+
+__global__ __launch_bounds__(kSortBlock) void k_sort_hist(const unsigned* __restrict__ keys, int n, int shift, int nb, int* __restrict__ hist /*[16][nb]*/) {
+    __shared__ int h[16];
+    if (threadIdx.x < 16) h[threadIdx.x] = 0;
+    __syncthreads();
+    int base = blockIdx.x * kSortTile;
+    int cnt[16];
+#pragma unroll
+    for (int d = 0; d < 16; d++) cnt[d] = 0;
+    for (int r = 0; r < kSortItems; r++) {
+        int i = base + r * kSortBlock + threadIdx.x;
+        if (i < n) {
+            int d = (keys[i] >> shift) & 15;
+#pragma unroll
+            for (int q = 0; q < 16; q++) cnt[q] += (q == d) ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 16; d++) {
+        int v = cnt[d];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&h[d], v);   // LDS integer atomics: 4 waves x 16 words
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) hist[threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(kSortBlock) void k_sort_scatter(const unsigned* __restrict__ keys_in, const int* __restrict__ vals_in, int n, int shift, int nb,
+                                                             const int* __restrict__ offs /*[16][nb] exclusive*/, unsigned* __restrict__ keys_out, int* __restrict__ vals_out) {
+    __shared__ int base[16];                  // running offset of each digit inside this tile
+    __shared__ int wcnt[kSortBlock / 64][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 16) base[threadIdx.x] = offs[threadIdx.x * nb + blockIdx.x];
+    __syncthreads();
+    const int tile = blockIdx.x * kSortTile;
+    for (int r = 0; r < kSortItems; r++) {
+        int i = tile + r * kSortBlock + threadIdx.x;
+        bool live = i < n;
+        unsigned key = live ? keys_in[i] : 0u;
+        int val = live ? vals_in[i] : 0;
+        int d = live ? (int)((key >> shift) & 15) : 16;
+        // lanes of this wave with the same digit (4 ballots) -> stable in-wave rank
+        unsigned long long peers = __ballot(live);
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            unsigned long long m = __ballot((d >> b) & 1);
+            peers &= ((d >> b) & 1) ? m : ~m;
+        }
+        int rank = __popcll(peers & ((1ull << lane) - 1ull));
+        if (threadIdx.x < (kSortBlock / 64) * 16) (&wcnt[0][0])[threadIdx.x] = 0;
+        __syncthreads();
+        if (live && rank == 0) wcnt[wave][d] = __popcll(peers);
+        __syncthreads();
+        if (live) {
+            int off = base[d];
+            for (int w = 0; w < wave; w++) off += wcnt[w][d];
+            keys_out[off + rank] = key;
+            vals_out[off + rank] = val;
+        }
+        __syncthreads();
+        if (threadIdx.x < 16) { int s = 0; for (int w = 0; w < kSortBlock / 64; w++) s += wcnt[w][threadIdx.x]; base[threadIdx.x] += s; }
+        __syncthreads();
+    }
+}
+
+struct VoxDev { float inv_leaf; int min_b[3]; int mul[3]; };
+
+__global__ void k_vox_key(const float4* __restrict__ pts, int n, VoxDev V, unsigned* __restrict__ keys, int* __restrict__ vals) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 p = pts[i];
+    // pcl::VoxelGrid::applyFilter: static_cast<int>(floor(x * inverse_leaf_size) - static_cast<float>(min_b))
+    int i0 = (int)(floorf(p.x * V.inv_leaf) - (float)V.min_b[0]);
+    int i1 = (int)(floorf(p.y * V.inv_leaf) - (float)V.min_b[1]);
+    int i2 = (int)(floorf(p.z * V.inv_leaf) - (float)V.min_b[2]);
+    keys[i] = (unsigned)(i0 * V.mul[0] + i1 * V.mul[1] + i2 * V.mul[2]);
+    vals[i] = i;
+}
+__global__ void k_vox_heads(const unsigned* __restrict__ keys, int n, int* __restrict__ flags) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+}
+__global__ void k_vox_centroid(const unsigned* __restrict__ keys, const int* __restrict__ vals, const int* __restrict__ slot /*exclusive scan of flags, [n+1]*/,
+                               const float4* __restrict__ pts, int n, float4* __restrict__ out, int* __restrict__ out_cnt) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (!(i == 0 || keys[i] != keys[i - 1])) return;
+    unsigned k = keys[i];
+    float sx = 0.f, sy = 0.f, sz = 0.f, sa = 0.f; int c = 0;
+    for (int m = i; m < n && keys[m] == k; m++) { float4 p = pts[vals[m]]; sx += p.x; sy += p.y; sz += p.z; sa += p.w; c++; }   // CentroidPoint: float accumulators
+    float fn = (float)c;
+    int o = slot[i];
+    out[o] = make_float4(sx / fn, sy / fn, sz / fn, sa / fn);
+    if (out_cnt) out_cnt[o] = c;
+}
+
+// transformCloud — L/src/BackendFusion.cpp:713-790: p' = q * p + t in f64, stored f32; aux carried along
+__global__ void k_transform_cloud(const float4* __restrict__ in, int n, dq q, d3 t, float4* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 p = in[i];
+    d3 r = qrot(q, d3{(double)p.x, (double)p.y, (double)p.z}) + t;
+    out[i] = make_float4((float)r.x, (float)r.y, (float)r.z, p.w);
+}
+
+}  // namespace lili
+
+namespace lili_detail {
+struct Keyframe { DevBuf pts; int n = 0; };
+struct VoxelBuffers {
+    DevBuf keys_a, keys_b, vals_a, vals_b, hist, hist_scan, sums, flags, slots, out, out_cnt, in, concat;
+    std::vector<Keyframe*> ring[2];    // per kind, oldest first
+    int n_out = 0;
+    void release() {
+        for (DevBuf* b : {&keys_a, &keys_b, &vals_a, &vals_b, &hist, &hist_scan, &sums, &flags, &slots, &out, &out_cnt, &in, &concat}) b->release();
+        for (auto& r : ring) { for (auto* k : r) { k->pts.release(); delete k; } r.clear(); }
+    }
+};
+}  // namespace lili_detail
+
+static lili_detail::VoxelBuffers* vox_of(lili_ctx* ctx) {
+    if (!ctx->ext_voxel) { ctx->ext_voxel = new lili_detail::VoxelBuffers(); ctx->ext_voxel_free = [](void* p) { auto* r = static_cast<lili_detail::VoxelBuffers*>(p); r->release(); delete r; }; }
+    return static_cast<lili_detail::VoxelBuffers*>(ctx->ext_voxel);
+}
+
+static int exclusive_scan(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const int* in, int64_t n, int* out /*[n+1]*/) {
+    const int nb = nblocks(n, 2048);
+    HIPCHK(V->sums.ensure((size_t)nb * sizeof(int)));
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(256), 0, ctx->stream, in, n, V->sums.as<int>());
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(256), 0, ctx->stream, V->sums.as<int>(), nb);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, ctx->stream, in, n, V->sums.as<int>(), out);
+    HIPCHK(hipGetLastError());
+    return LILI_OK;
+}
+
+// sorts (keys_a, vals_a) by the low `bits` bits; result ends in (keys_a, vals_a)
+static int radix_sort(lili_ctx* ctx, lili_detail::VoxelBuffers* V, int n, int bits) {
+    const int nb = nblocks(n, kSortTile);
+    HIPCHK(V->hist.ensure((size_t)16 * nb * sizeof(int)));
+    HIPCHK(V->hist_scan.ensure(((size_t)16 * nb + 1) * sizeof(int)));
+    HIPCHK(V->keys_b.ensure((size_t)n * 4)); HIPCHK(V->vals_b.ensure((size_t)n * 4));
+    unsigned *ka = V->keys_a.as<unsigned>(), *kb = V->keys_b.as<unsigned>();
+    int *va = V->vals_a.as<int>(), *vb = V->vals_b.as<int>();
+    int passes = (bits + 3) / 4;
+    if (passes & 1) passes++;   // even number of passes so that the result lands in the `a` buffers (extra pass sorts zero digits: identity)
+    for (int p = 0; p < passes; p++) {
+        const int shift = 4 * p;   // <= 28: bits <= 31 because the voxel index fits int32
+        hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(kSortBlock), 0, ctx->stream, ka, n, shift, nb, V->hist.as<int>());
+        int rc = exclusive_scan(ctx, V, V->hist.as<int>(), (int64_t)16 * nb, V->hist_scan.as<int>());
+        if (rc != LILI_OK) return rc;
+        hipLaunchKernelGGL(k_sort_scatter, dim3(nb), dim3(kSortBlock), 0, ctx->stream, ka, va, n, shift, nb, V->hist_scan.as<int>(), kb, vb);
+        HIPCHK(hipGetLastError());
+        std::swap(ka, kb); std::swap(va, vb);
+    }
+    return LILI_OK;
+}
+
+// VoxelGrid of a device float4 cloud; result in V->out / V->out_cnt, V->n_out.  Blocking (two small read-backs).
+static int voxel_filter_device(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const float4* d_pts, int n, float leaf) {
+    V->n_out = 0;
+    if (n == 0) return LILI_OK;
+    unsigned init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+    unsigned* d_mm = ctx->misc.as<unsigned>();
+    HIPCHK(hipMemcpyAsync(d_mm, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_bbox, dim3(std::min(nblocks(n, kBlock), 512)), dim3(kBlock), 0, ctx->stream, d_pts, n, d_mm);
+    unsigned mm[6];
+    HIPCHK(hipMemcpyAsync(mm, d_mm, sizeof(mm), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    auto dec = [](unsigned u) { unsigned b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u; float f; std::memcpy(&f, &b, 4); return f; };
+    VoxDev P{};
+    P.inv_leaf = 1.0f / leaf;
+    int div_b[3];
+    for (int k = 0; k < 3; k++) {
+        float mn = dec(mm[k]), mx = dec(mm[3 + k]);
+        if (!(mn <= mx)) return ctx->fail(LILI_E_ARG, "voxel_filter: cloud holds no finite point");
+        P.min_b[k] = (int)std::floor(mn * P.inv_leaf);
+        div_b[k] = (int)std::floor(mx * P.inv_leaf) - P.min_b[k] + 1;
+    }
+    const double total = (double)div_b[0] * (double)div_b[1] * (double)div_b[2];
+    if (total > 2147483647.0) return ctx->fail(LILI_E_ARG, "voxel_filter: leaf size too small for the cloud extent (voxel index would overflow int32, as in PCL)");
+    P.mul[0] = 1; P.mul[1] = div_b[0]; P.mul[2] = div_b[0] * div_b[1];
+    int bits = 1; while (bits < 32 && (1ull << bits) < (unsigned long long)total) bits++;
+    HIPCHK(V->keys_a.ensure((size_t)n * 4)); HIPCHK(V->vals_a.ensure((size_t)n * 4));
+    HIPCHK(V->flags.ensure((size_t)n * 4)); HIPCHK(V->slots.ensure(((size_t)n + 1) * 4));
+    HIPCHK(V->out.ensure((size_t)n * 16)); HIPCHK(V->out_cnt.ensure((size_t)n * 4));
+    hipLaunchKernelGGL(k_vox_key, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, d_pts, n, P, V->keys_a.as<unsigned>(), V->vals_a.as<int>());
+    int rc = radix_sort(ctx, V, n, bits);
+    if (rc != LILI_OK) return rc;
+    hipLaunchKernelGGL(k_vox_heads, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, V->keys_a.as<unsigned>(), n, V->flags.as<int>());
+    rc = exclusive_scan(ctx, V, V->flags.as<int>(), n, V->slots.as<int>());
+    if (rc != LILI_OK) return rc;
+    hipLaunchKernelGGL(k_vox_centroid, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, V->keys_a.as<unsigned>(), V->vals_a.as<int>(), V->slots.as<int>(), d_pts, n,
+                       V->out.as<float4>(), V->out_cnt.as<int>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&V->n_out, V->slots.as<int>() + n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return LILI_OK;
+}
+
+extern "C" {
+
+int lili_voxel_filter(lili_ctx* ctx, const lili_cloud* cloud, float leaf, lili_feature_out* out, int32_t* counts) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(cloud && out && leaf > 0, "voxel_filter: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    auto* V = vox_of(ctx);
+    int rc = lili_ingest_cloud(ctx, cloud, V->in);
+    if (rc != LILI_OK) return rc;
+    rc = voxel_filter_device(ctx, V, V->in.as<float4>(), (int)cloud->n, leaf);
+    if (rc != LILI_OK) return rc;
+    out->count = (size_t)V->n_out;
+    size_t k = std::min(out->count, out->capacity);
+    if (out->data && k) {
+        size_t stride = out->stride ? out->stride : 16;
+        ARGCHK(stride >= 16, "voxel_filter: stride must be >= 16");
+        HIPCHK(hipMemcpy2DAsync(out->data, stride, V->out.p, 16, 16, k, out->mem == LILI_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+        if (counts) HIPCHK(hipMemcpyAsync(counts, V->out_cnt.p, k * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    return LILI_OK;
+}
+
+int lili_localmap_reset(lili_ctx* ctx, int kind) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(kind == 0 || kind == 1, "localmap_reset: bad kind");
+    auto* V = vox_of(ctx);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (auto* k : V->ring[kind]) { k->pts.release(); delete k; }
+    V->ring[kind].clear();
+    return LILI_OK;
+}
+
+int lili_localmap_push(lili_ctx* ctx, int kind, const lili_cloud* features, const double t[3], const double q[4], int width) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK((kind == 0 || kind == 1) && features && t && q && width >= 1, "localmap_push: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    auto* V = vox_of(ctx);
+    int rc = lili_ingest_cloud(ctx, features, V->in);
+    if (rc != LILI_OK) return rc;
+    auto* kf = new lili_detail::Keyframe();
+    kf->n = (int)features->n;
+    if (kf->n > 0) {
+        hipError_t e = kf->pts.ensure((size_t)kf->n * 16);
+        if (e != hipSuccess) { delete kf; return ctx->fail(LILI_E_HIP, "localmap_push: allocation failed"); }
+        hipLaunchKernelGGL(k_transform_cloud, dim3(nblocks(kf->n, 256)), dim3(256), 0, ctx->stream, V->in.as<float4>(), kf->n,
+                           dq{q[0], q[1], q[2], q[3]}, d3{t[0], t[1], t[2]}, kf->pts.as<float4>());
+        HIPCHK(hipGetLastError());
+    }
+    V->ring[kind].push_back(kf);
+    while ((int)V->ring[kind].size() > width) {   // recent_*_keyframes.pop_front() (L:1449-1450)
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        auto* old = V->ring[kind].front();
+        old->pts.release(); delete old;
+        V->ring[kind].erase(V->ring[kind].begin());
+    }
+    return LILI_OK;
+}
+
+int lili_localmap_commit(lili_ctx* ctx, int kind, float leaf, double max_sq_radius, int64_t* n_raw, int64_t* n_map) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK((kind == 0 || kind == 1) && leaf > 0, "localmap_commit: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    auto* V = vox_of(ctx);
+    size_t total = 0;
+    for (auto* k : V->ring[kind]) total += (size_t)k->n;
+    if (n_raw) *n_raw = (int64_t)total;
+    HIPCHK(V->concat.ensure(std::max<size_t>(total, 1) * 16));
+    size_t off = 0;
+    for (auto* k : V->ring[kind]) {   // *surf_local_map += *recent_surf_keyframes[i] (L:1479-1483)
+        if (k->n) HIPCHK(hipMemcpyAsync(V->concat.as<float4>() + off, k->pts.p, (size_t)k->n * 16, hipMemcpyDeviceToDevice, ctx->stream));
+        off += (size_t)k->n;
+    }
+    int rc = voxel_filter_device(ctx, V, V->concat.as<float4>(), (int)total, leaf);   // ds_filter_*_map.filter (L:1488-1492)
+    if (rc != LILI_OK) return rc;
+    if (n_map) *n_map = V->n_out;
+    lili_cloud c{V->out.p, (size_t)V->n_out, 16, 12, LILI_MEM_DEVICE};
+    return lili_map_set(ctx, kind, &c, max_sq_radius);                                   // setInputCloud (L:839-840)
+}
+
+}  // extern "C"

@@ -1,0 +1,76 @@
+"""GPU parity of the VoxelGrid filter and the local-map assembly vs the oracle's PCL restatement
+(in-order accumulation mode): voxel membership, order, counts and f32 centroids bit-exact."""
+import numpy as np
+import pytest
+
+import lili_om_amd as L
+from lili_om_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,leaf,scale", [(1000, 0.4, 5.0), (200_000, 0.4, 60.0), (1_500_000, 0.2, 40.0), (50_000, 0.6, 300.0)])
+def test_voxel_filter_matches_pcl_restatement(gpu_ctx, oracle, n, leaf, scale):
+    rng = np.random.default_rng(n)
+    pts = np.concatenate([rng.uniform(-scale, scale, (n, 2)), rng.normal(0, 0.5, (n, 1)), rng.uniform(0, 25, (n, 1))], 1).astype(np.float32)
+    pts[: n // 10] = pts[n // 10: 2 * (n // 10)][: n // 10]      # exact duplicates -> multi-point voxels for sure
+    g, gc = L.api.voxel_filter(gpu_ctx, pts, leaf)
+    o, oc = oracle.voxel_grid(pts, leaf, stable=True)
+    assert g.shape == o.shape and g.shape[0] < n
+    assert np.array_equal(gc, oc)
+    assert np.array_equal(g.view(np.uint32), o.view(np.uint32))
+    # PCL's own (unstable) sort may only change the summation order inside a voxel
+    o2, oc2 = oracle.voxel_grid(pts, leaf, stable=False)
+    assert np.array_equal(oc2, oc)
+    np.testing.assert_allclose(o2, o, rtol=1e-6, atol=1e-5 * scale)
+
+
+def test_voxel_filter_edge_cases(gpu_ctx, oracle):
+    one = np.array([[1.0, 2.0, 3.0, 4.0]], np.float32)
+    g, c = L.api.voxel_filter(gpu_ctx, one, 0.4)
+    assert np.array_equal(g, one) and c[0] == 1
+    g, c = L.api.voxel_filter(gpu_ctx, np.zeros((0, 4), np.float32), 0.4)
+    assert g.shape[0] == 0
+    with pytest.raises(L.LiliError):                              # PCL refuses too ("leaf size is too small")
+        L.api.voxel_filter(gpu_ctx, np.array([[0, 0, 0, 0], [1e6, 1e6, 1e6, 0]], np.float32), 0.01)
+
+
+def test_local_map_assembly_and_match(gpu_ctx, oracle):
+    """push 5 keyframes (ring of width 4), commit, then match a scan against the device-built map: identical to
+    assembling / filtering on the host with the oracle and calling set_input_cloud."""
+    room = synth.make_room(seed=23, n_query=3000, n_edge_query=50)
+    rng = np.random.default_rng(1)
+    kfs, poses = [], []
+    for k in range(5):
+        sel = rng.choice(room["map_xyz"].shape[0], 6000, replace=False)
+        t = np.array([0.3 * k, -0.1 * k, 0.02 * k])
+        ang = 0.05 * k
+        q = np.array([np.cos(ang / 2), 0.0, 0.0, np.sin(ang / 2)])
+        world = room["map_xyz"][sel].astype(np.float64)
+        local = synth.quat_rot(q * np.array([1, -1, -1, -1]), world - t)                  # keyframe-frame features
+        kfs.append(np.concatenate([local, rng.uniform(1, 20, (6000, 1))], 1).astype(np.float32))
+        poses.append((t, q))
+    lm = L.LocalMap(gpu_ctx, L.KIND_SURF, width=4, leaf=0.4, max_sq_radius=1.0)
+    for f, (t, q) in zip(kfs, poses):
+        lm.push(f, t, q)
+    n_raw, n_map = lm.commit()
+    assert n_raw == 4 * 6000                                       # the oldest keyframe was dropped
+    # host restatement: transformCloud (f64 -> f32), concatenate oldest..newest, VoxelGrid
+    parts = []
+    for f, (t, q) in list(zip(kfs, poses))[1:]:
+        w = np.stack([oracle.qrot(q, p[:3].astype(np.float64)) + t for p in f[:200]])     # spot-check the transform
+        parts.append(np.concatenate([(synth.quat_rot(q, f[:, :3].astype(np.float64)) + t).astype(np.float32), f[:, 3:4]], 1))
+        assert np.array_equal(parts[-1][:200, :3], w.astype(np.float32))
+    cat = np.concatenate(parts, 0)
+    ref_map, _ = oracle.voxel_grid(cat, 0.4, stable=True)
+    assert n_map == ref_map.shape[0]
+    P, PO = L.make_params("frontend"), oracle.params("frontend")
+    m = L.ScanToMapMatcher(gpu_ctx, P)
+    gpu_ctx.set_debug(True)
+    m.set_queries(0, L.KIND_SURF, room["q_xyz"])
+    n1 = m.find_corresponding_surf_features(0, room["q_true"], room["t_true"])
+    idx1, d1 = m.neighbors(0, L.KIND_SURF, room["q_xyz"].shape[0])
+    rs = oracle.associate_surf(oracle.KdTree(ref_map[:, :3]), None, room["q_xyz"], None, room["q_true"], room["t_true"], PO)
+    assert n1 == rs["count"] > 500
+    inside = rs["nn_d2"][:, 4] < 1.0
+    assert np.array_equal(idx1[inside], rs["nn_idx"][inside]) and np.array_equal(d1[inside], rs["nn_d2"][inside])
