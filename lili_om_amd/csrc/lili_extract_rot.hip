@@ -15,6 +15,7 @@
 // Sort ties: (curvature, index) / (voxel, index) — std::sort's order on ties is unspecified.
 #include "lili_ctx.h"
 #include "lili_device_math.h"
+#include <cstdio>
 
 namespace lili {
 
@@ -37,6 +38,7 @@ struct RotState {
     int ring_nedge[kMaxRings], ring_nsharp[kMaxRings], ring_nflat[kMaxRings], ring_nlf[kMaxRings], ring_nsurf[kMaxRings];
     int n_edge, n_sharp, n_flat, n_lessflat, n_surf;
     int fallback_rings;   // rings that did not fit the LDS budget and took the global-memory path
+    long long tphase[8];  // profiling: per-phase clock ticks of ring 0's workgroup (wall_clock64)
 };
 
 // f32 atan / atan2 defined as the f64 function rounded to f32
@@ -291,7 +293,33 @@ __device__ __forceinline__ int block_excl_scan_1024(int v, int* lds, int& total)
     return base + inc - v;
 }
 
-__global__ __launch_bounds__(kRotBlock) void k_rot_select(const float4* __restrict__ full, const float* __restrict__ curv_g, RotDev P, RotState* st,
+// Rank sort of one segment of one ring by (curvature, index) — std::sort of R:409-410 with ties broken by index.
+// One workgroup per (ring, segment, chunk of 256 elements): O(L^2/6) compares per ring spread over the whole chip
+// instead of the single CU that owns the ring in k_rot_select.  sort_ind holds GLOBAL indices (into `full`).
+__global__ __launch_bounds__(256) void k_rot_rank(const float* __restrict__ curv, RotDev P, const RotState* __restrict__ st, int* __restrict__ sort_ind) {
+    __shared__ float seg[kRingLdsCap];
+    const int ring = blockIdx.x, j = blockIdx.y;
+    const int rs = st->ring_start[ring], re = st->ring_end[ring];
+    if (ring >= P.n_scans || re - rs < 6 || ring % P.ds_rate != 0) return;
+    const int sp = rs + (re - rs) * j / 6, ep = rs + (re - rs) * (j + 1) / 6 - 1;
+    const int len = ep - sp + 1;
+    if (len <= 0 || len > kRingLdsCap) return;
+    for (int m = threadIdx.x; m < len; m += 256) seg[m] = curv[sp + m];
+    __syncthreads();
+    for (int e = blockIdx.z * 256 + threadIdx.x; e < len; e += gridDim.z * 256) {
+        const float ck = seg[e];
+        int rank = 0, m = 0;
+        for (; m + 3 < len; m += 4) {
+            float c0 = seg[m], c1 = seg[m + 1], c2 = seg[m + 2], c3 = seg[m + 3];
+            rank += ((c0 < ck || (c0 == ck && m < e)) ? 1 : 0) + ((c1 < ck || (c1 == ck && m + 1 < e)) ? 1 : 0) +
+                    ((c2 < ck || (c2 == ck && m + 2 < e)) ? 1 : 0) + ((c3 < ck || (c3 == ck && m + 3 < e)) ? 1 : 0);
+        }
+        for (; m < len; m++) { float cm = seg[m]; rank += (cm < ck || (cm == ck && m < e)) ? 1 : 0; }
+        sort_ind[sp + rank] = sp + e;
+    }
+}
+
+__global__ __launch_bounds__(kRotBlock) void k_rot_select(const float4* __restrict__ full, const float* __restrict__ curv_g, const int* __restrict__ sort_ind_g, RotDev P, RotState* st,
                                                           int* __restrict__ label_g, int* __restrict__ ring_edge /*[64][60]*/,
                                                           int* __restrict__ ring_sharp /*[64][12]*/, int* __restrict__ ring_flat /*[64][24]*/,
                                                           int* __restrict__ lessflat_tmp /*[n]*/, float4* __restrict__ surf_tmp /*[n]*/,
@@ -310,26 +338,19 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_select(const float4* __restri
         return;
     }
     // ---- stage the ring: local index l <-> global index rbase + l
+    if (ring == 0 && tid == 0) st->tphase[0] = wall_clock64();
     for (int k = tid; k < rcount; k += kRotBlock) {
         L.pts[k] = full[rbase + k]; L.curv[k] = curv_g[rbase + k];
-        L.picked[k] = 0; L.label[k] = 0; L.sort_ind[k] = k;
+        L.picked[k] = 0; L.label[k] = 0;
     }
     __syncthreads();
     const int s0 = rs - rbase, e0 = re - rbase;   // local scanStartInd / scanEndInd
-    // ---- rank sort of every segment by (curvature, index)  (std::sort, R:409-410)
-    for (int k = s0 + tid; k <= e0 - 1; k += kRotBlock) {
-        // which segment holds k?  sp_j = s0 + (e0 - s0) * j / 6
-        int j = 0;
-#pragma unroll
-        for (int jj = 1; jj < 6; jj++) if (k >= s0 + (e0 - s0) * jj / 6) j = jj;
-        int sp = s0 + (e0 - s0) * j / 6, ep = s0 + (e0 - s0) * (j + 1) / 6 - 1;
-        float ck = L.curv[k];
-        int rank = 0;
-        for (int m = sp; m <= ep; m++) { float cm = L.curv[m]; rank += (cm < ck || (cm == ck && m < k)) ? 1 : 0; }
-        L.sort_ind[sp + rank] = k;
-    }
+    // ---- sorted order of every segment (k_rot_rank): global -> local indices
+    if (ring == 0 && tid == 0) st->tphase[1] = wall_clock64();
+    for (int k = s0 + tid; k <= e0 - 1; k += kRotBlock) L.sort_ind[k] = sort_ind_g[rbase + k] - rbase;
     __syncthreads();
     // ---- greedy picks, sequential by construction (suppression spills across segment borders, A4 iv)
+    if (ring == 0 && tid == 0) st->tphase[2] = wall_clock64();
     if (tid == 0) {
         int ne = 0, nsh = 0, nfl = 0;
         const float4* Pp = L.pts;
@@ -369,6 +390,7 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_select(const float4* __restri
     __syncthreads();
     for (int k = tid; k < rcount; k += kRotBlock) label_g[rbase + k] = L.label[k];
     // ---- less-flat list in index order (R:494-499), compacted with a block scan
+    if (ring == 0 && tid == 0) st->tphase[3] = wall_clock64();
     int n_lf = 0;
     for (int k0 = s0; k0 <= e0 - 1; k0 += kRotBlock) {
         int k = k0 + tid;
@@ -380,6 +402,7 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_select(const float4* __restri
     __syncthreads();
     if (tid == 0) st->ring_nlf[ring] = n_lf;
     // ---- pcl::VoxelGrid(ds_v) on the ring's less-flat points (R:502-508; PCL >= 1.8 semantics)
+    if (ring == 0 && tid == 0) st->tphase[4] = wall_clock64();
     if (n_lf == 0) { if (tid == 0) st->ring_nsurf[ring] = 0; return; }
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int q = tid; q < n_lf; q += kRotBlock) {
@@ -432,6 +455,7 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_select(const float4* __restri
         }
     }
     // run heads -> output slots; each head accumulates its voxel in list order (f32, like CentroidPoint)
+    if (ring == 0 && tid == 0) st->tphase[5] = wall_clock64();
     int n_out = 0;
     for (int q0 = 0; q0 < n_lf; q0 += kRotBlock) {
         int q = q0 + tid;
@@ -451,6 +475,7 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_select(const float4* __restri
         n_out += tot;
     }
     if (tid == 0) st->ring_nsurf[ring] = n_out;
+    if (ring == 0 && tid == 0) st->tphase[6] = wall_clock64();
 }
 
 // ordered concatenation of the per-ring lists (rings ascending, then push order inside the ring): one block per ring
@@ -484,14 +509,14 @@ __global__ __launch_bounds__(256) void k_rot_compact(RotState* st, const float4*
 // ================================================================================================
 namespace lili_detail {
 struct RotBuffers {
-    DevBuf in, valid, scan_id, ori_raw, block_hist, state, full, full_src, curv, label;
+    DevBuf in, valid, scan_id, ori_raw, block_hist, state, full, full_src, curv, label, sort_ind;
     DevBuf ring_edge, ring_sharp, ring_flat, lessflat_tmp, surf_tmp, surf_cnt_tmp;
     DevBuf edge_idx, edge_pts, sharp_idx, flat_idx, lessflat_idx, surf, surf_cnt;
     lili::RotState host{};
     int n_in = 0;
     bool have = false;
     void release() {
-        for (DevBuf* b : {&in, &valid, &scan_id, &ori_raw, &block_hist, &state, &full, &full_src, &curv, &label, &ring_edge, &ring_sharp, &ring_flat,
+        for (DevBuf* b : {&in, &valid, &scan_id, &ori_raw, &block_hist, &state, &full, &full_src, &curv, &label, &sort_ind, &ring_edge, &ring_sharp, &ring_flat,
                           &lessflat_tmp, &surf_tmp, &surf_cnt_tmp, &edge_idx, &edge_pts, &sharp_idx, &flat_idx, &lessflat_idx, &surf, &surf_cnt}) b->release();
     }
 };
@@ -538,7 +563,7 @@ int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4
         const int nb = nblocks(n, kRotBlock);
         HIPCHK(R->valid.ensure(cap)); HIPCHK(R->scan_id.ensure(cap)); HIPCHK(R->ori_raw.ensure(cap * 4));
         HIPCHK(R->block_hist.ensure((size_t)nb * kMaxRings * 4));
-        HIPCHK(R->full.ensure(cap * 16)); HIPCHK(R->full_src.ensure(cap * 4)); HIPCHK(R->curv.ensure(cap * 4)); HIPCHK(R->label.ensure(cap * 4));
+        HIPCHK(R->full.ensure(cap * 16)); HIPCHK(R->full_src.ensure(cap * 4)); HIPCHK(R->curv.ensure(cap * 4)); HIPCHK(R->label.ensure(cap * 4)); HIPCHK(R->sort_ind.ensure(cap * 4));
         HIPCHK(R->ring_edge.ensure(kMaxRings * kRingEdgeCap * 4)); HIPCHK(R->ring_sharp.ensure(kMaxRings * kRingSharpCap * 4)); HIPCHK(R->ring_flat.ensure(kMaxRings * kRingFlatCap * 4));
         HIPCHK(R->lessflat_tmp.ensure(cap * 4)); HIPCHK(R->surf_tmp.ensure(cap * 16)); HIPCHK(R->surf_cnt_tmp.ensure(cap * 4));
         HIPCHK(R->edge_idx.ensure(kMaxRings * kRingEdgeCap * 4)); HIPCHK(R->edge_pts.ensure(kMaxRings * kRingEdgeCap * 16));
@@ -555,7 +580,8 @@ int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4
         hipLaunchKernelGGL(k_rot_scatter, dim3(nb), dim3(kRotBlock), 0, ctx->stream, in, n, R->scan_id.as<signed char>(), R->ori_raw.as<float>(), P, st,
                            R->block_hist.as<int>(), R->full.as<float4>(), R->full_src.as<int>());
         hipLaunchKernelGGL(k_rot_curvature, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, R->full.as<float4>(), st, R->curv.as<float>());
-        hipLaunchKernelGGL(k_rot_select, dim3(kMaxRings), dim3(kRotBlock), sizeof(RingLds), ctx->stream, R->full.as<float4>(), R->curv.as<float>(), P, st,
+        hipLaunchKernelGGL(k_rot_rank, dim3(kMaxRings, 6, 2), dim3(256), 0, ctx->stream, R->curv.as<float>(), P, st, R->sort_ind.as<int>());
+        hipLaunchKernelGGL(k_rot_select, dim3(kMaxRings), dim3(kRotBlock), sizeof(RingLds), ctx->stream, R->full.as<float4>(), R->curv.as<float>(), R->sort_ind.as<int>(), P, st,
                            R->label.as<int>(), R->ring_edge.as<int>(), R->ring_sharp.as<int>(), R->ring_flat.as<int>(), R->lessflat_tmp.as<int>(),
                            R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>());
         hipLaunchKernelGGL(k_rot_compact, dim3(kMaxRings), dim3(256), 0, ctx->stream, st, R->full.as<float4>(), R->ring_edge.as<int>(), R->ring_sharp.as<int>(),
@@ -582,6 +608,7 @@ int lili_extract_rot_debug(lili_ctx* ctx, int32_t counts[8], int32_t* ring_start
     if (!R->have) return ctx->fail(LILI_E_STATE, "extract_rot_debug: run lili_extract_rot first");
     HIPCHK(hipSetDevice(ctx->device));
     const RotState& h = R->host;
+    if (getenv("LILI_ROT_PHASES")) { fprintf(stderr, "rot_select phases (100 MHz ticks):"); for (int k = 1; k < 7; k++) fprintf(stderr, " %lld", h.tphase[k] - h.tphase[k-1]); fprintf(stderr, "\n"); }
     if (counts) { counts[0] = h.n_full; counts[1] = h.n_edge; counts[2] = h.n_sharp; counts[3] = h.n_flat; counts[4] = h.n_lessflat; counts[5] = h.n_surf; counts[6] = h.half_idx; counts[7] = h.first_valid; }
     if (ring_start) std::memcpy(ring_start, h.ring_start, sizeof(int) * kMaxRings);
     if (ring_end) std::memcpy(ring_end, h.ring_end, sizeof(int) * kMaxRings);
