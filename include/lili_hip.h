@@ -163,6 +163,12 @@ int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offs
  * edge_cell / surf_cell: cell (line * 4000 + column) of each emitted feature.  Any pointer may be NULL. */
 int lili_extract_livox_debug(lili_ctx* ctx, int32_t counts[3], int32_t* cut_src, int32_t* cell_src, int32_t* edge_cell, int32_t* surf_cell);
 
+/* Device views (float4 x,y,z,aux; LILI_MEM_DEVICE clouds, valid until the next extract call on the context) of the last
+ * extraction, so that features go from the extractor to lili_voxel_filter / lili_s2m_set_queries / lili_localmap_push
+ * without leaving HBM.  ROT: aux = intensity (ring + 0.1 relTime); Livox: aux = curvature (0.1 * reflectivity). */
+int lili_extract_rot_device(lili_ctx* ctx, lili_cloud* full, lili_cloud* edge, lili_cloud* surf);
+int lili_extract_livox_device(lili_ctx* ctx, lili_cloud* edge, lili_cloud* surf);
+
 /* ---- local map: keyframe ring buffer + VoxelGrid + index ------------------------------------ */
 
 /* pcl::VoxelGrid<PointT>::filter with leaf (leaf, leaf, leaf) on (x, y, z, aux) points: one centroid per occupied

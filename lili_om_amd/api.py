@@ -98,6 +98,8 @@ _SIGS = {
     "lili_extract_rot_debug": (C.c_int, [C.c_void_p] + [C.c_void_p] * 11),
     "lili_extract_livox": (C.c_int, [C.c_void_p, C.POINTER(Cloud), C.c_int, C.c_void_p, C.POINTER(LivoxParams), C.POINTER(FeatureOut), C.POINTER(FeatureOut), C.POINTER(FeatureOut)]),
     "lili_extract_livox_debug": (C.c_int, [C.c_void_p] * 6),
+    "lili_extract_rot_device": (C.c_int, [C.c_void_p, C.POINTER(Cloud), C.POINTER(Cloud), C.POINTER(Cloud)]),
+    "lili_extract_livox_device": (C.c_int, [C.c_void_p, C.POINTER(Cloud), C.POINTER(Cloud)]),
     "lili_voxel_filter": (C.c_int, [C.c_void_p, C.POINTER(Cloud), C.c_float, C.POINTER(FeatureOut), C.c_void_p]),
     "lili_localmap_reset": (C.c_int, [C.c_void_p, C.c_int]),
     "lili_localmap_push": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Cloud), C.c_void_p, C.c_void_p, C.c_int]),
@@ -137,6 +139,13 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise LiliError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(hipcc --offload-arch=gfx950). The hot path has no CPU fallback.")
+    # PyTorch wheels bundle their own libamdhip64 (same soname, different file name).  If this library pulled in the
+    # system copy first, a later `import torch` would start a SECOND HIP runtime in the process and find no GPU.
+    # Importing torch first makes both share one runtime.  (C/C++ hosts without torch are unaffected.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)      # AttributeError here = ABI mismatch between header and library
@@ -319,6 +328,26 @@ class ScanToMapMatcher:
 
     def iterate(self, slot, n_iters, kind_mask=MASK_SURF):
         self.ctx._chk(self.lib.lili_s2m_iterate(self.ctx.h, slot, kind_mask, C.byref(self.params), int(n_iters)))
+
+
+def extract_rot_device(ctx):
+    """(full, edge, surf) device clouds of the last RotExtractor.extract on this context."""
+    f, e, s = Cloud(), Cloud(), Cloud()
+    ctx._chk(ctx.lib.lili_extract_rot_device(ctx.h, C.byref(f), C.byref(e), C.byref(s)))
+    return f, e, s
+
+
+def extract_livox_device(ctx):
+    e, s = Cloud(), Cloud()
+    ctx._chk(ctx.lib.lili_extract_livox_device(ctx.h, C.byref(e), C.byref(s)))
+    return e, s
+
+
+def voxel_filter_device(ctx, cloud, leaf, d_out_ptr, capacity):
+    """VoxelGrid of a device cloud into a caller-owned device float4 buffer; returns the output device cloud."""
+    fo = FeatureOut(d_out_ptr, capacity, 16, MEM_DEVICE, 0)
+    ctx._chk(ctx.lib.lili_voxel_filter(ctx.h, C.byref(cloud), float(leaf), C.byref(fo), None))
+    return Cloud(d_out_ptr, min(fo.count, capacity), 16, 12, MEM_DEVICE)
 
 
 def voxel_filter(ctx, pts_xyza, leaf):

@@ -243,18 +243,23 @@ __global__ void k_livox_pack(const float4* __restrict__ a, const float4* __restr
     }
 }
 
+__global__ void k_livox_xyzc(const float4* __restrict__ a, const float4* __restrict__ b, int n, float4* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { float4 u = a[i]; out[i] = make_float4(u.x, u.y, u.z, b[i].w); }
+}
+
 }  // namespace lili
 
 namespace lili_detail {
 struct LivoxBuffers {
     DevBuf in_i, in_c, und, curv, keep, owner, state, cut_a, cut_b, cut_src, cell_pt, cell_curv, cell_src;
     DevBuf blk_nedge, blk_edge_cell, blk_edge_dir, blk_nsurf, blk_surf_cell, blk_surf_nrm;
-    DevBuf edge_a, edge_b, edge_cell, surf_a, surf_b, surf_cell, pack;
+    DevBuf edge_a, edge_b, edge_cell, surf_a, surf_b, surf_cell, pack, xyzc_edge, xyzc_surf;
     lili::LivoxState host{};
     bool have = false;
     void release() {
         for (DevBuf* b : {&in_i, &in_c, &und, &curv, &keep, &owner, &state, &cut_a, &cut_b, &cut_src, &cell_pt, &cell_curv, &cell_src, &blk_nedge, &blk_edge_cell,
-                          &blk_edge_dir, &blk_nsurf, &blk_surf_cell, &blk_surf_nrm, &edge_a, &edge_b, &edge_cell, &surf_a, &surf_b, &surf_cell, &pack}) b->release();
+                          &blk_edge_dir, &blk_nsurf, &blk_surf_cell, &blk_surf_nrm, &edge_a, &edge_b, &edge_cell, &surf_a, &surf_b, &surf_cell, &pack, &xyzc_edge, &xyzc_surf}) b->release();
     }
 };
 }  // namespace lili_detail
@@ -345,6 +350,24 @@ int lili_extract_livox_debug(lili_ctx* ctx, int32_t counts[3], int32_t* cut_src,
     HIPCHK(dl(cut_src, B->cut_src, (size_t)B->host.n_cut * 4)); HIPCHK(dl(cell_src, B->cell_src, (size_t)kLvCells * 4));
     HIPCHK(dl(edge_cell, B->edge_cell, (size_t)B->host.n_edge * 4)); HIPCHK(dl(surf_cell, B->surf_cell, (size_t)B->host.n_surf * 4));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return LILI_OK;
+}
+
+
+// Device views of the last lili_extract_livox results as (x, y, z, curvature) float4 arrays — the fields the
+// Livox matcher consumes (L/src/BackendFusion.cpp:1608-1622); valid until the next extract on this context.
+int lili_extract_livox_device(lili_ctx* ctx, lili_cloud* edge, lili_cloud* surf) {
+    if (!ctx) return LILI_E_ARG;
+    auto* B = livox_of(ctx);
+    if (!B->have) return ctx->fail(LILI_E_STATE, "extract_livox_device: run lili_extract_livox first");
+    HIPCHK(hipSetDevice(ctx->device));
+    const int ne = B->host.n_edge, ns = B->host.n_surf;
+    HIPCHK(B->xyzc_edge.ensure((size_t)std::max(ne, 1) * 16)); HIPCHK(B->xyzc_surf.ensure((size_t)std::max(ns, 1) * 16));
+    if (ne) hipLaunchKernelGGL(k_livox_xyzc, dim3(nblocks(ne, 256)), dim3(256), 0, ctx->stream, B->edge_a.as<float4>(), B->edge_b.as<float4>(), ne, B->xyzc_edge.as<float4>());
+    if (ns) hipLaunchKernelGGL(k_livox_xyzc, dim3(nblocks(ns, 256)), dim3(256), 0, ctx->stream, B->surf_a.as<float4>(), B->surf_b.as<float4>(), ns, B->xyzc_surf.as<float4>());
+    HIPCHK(hipGetLastError());
+    if (edge) *edge = lili_cloud{B->xyzc_edge.p, (size_t)ne, 16, 12, LILI_MEM_DEVICE};
+    if (surf) *surf = lili_cloud{B->xyzc_surf.p, (size_t)ns, 16, 12, LILI_MEM_DEVICE};
     return LILI_OK;
 }
 

@@ -620,4 +620,18 @@ int lili_extract_rot_debug(lili_ctx* ctx, int32_t counts[8], int32_t* ring_start
     return LILI_OK;
 }
 
+
+// Device views of the last lili_extract_rot results (float4 x,y,z,intensity; valid until the next extract on this
+// context): feed them back as lili_cloud{ptr, n, 16, 12, LILI_MEM_DEVICE} into lili_voxel_filter /
+// lili_s2m_set_queries / lili_localmap_push so that a scan never leaves HBM between extraction and matching.
+int lili_extract_rot_device(lili_ctx* ctx, lili_cloud* full, lili_cloud* edge, lili_cloud* surf) {
+    if (!ctx) return LILI_E_ARG;
+    auto* R = rot_of(ctx);
+    if (!R->have) return ctx->fail(LILI_E_STATE, "extract_rot_device: run lili_extract_rot first");
+    if (full) *full = lili_cloud{R->full.p, (size_t)R->host.n_full, 16, 12, LILI_MEM_DEVICE};
+    if (edge) *edge = lili_cloud{R->edge_pts.p, (size_t)R->host.n_edge, 16, 12, LILI_MEM_DEVICE};
+    if (surf) *surf = lili_cloud{R->surf.p, (size_t)R->host.n_surf, 16, 12, LILI_MEM_DEVICE};
+    return LILI_OK;
+}
+
 }  // extern "C"

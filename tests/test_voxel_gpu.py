@@ -74,3 +74,43 @@ def test_local_map_assembly_and_match(gpu_ctx, oracle):
     assert n1 == rs["count"] > 500
     inside = rs["nn_d2"][:, 4] < 1.0
     assert np.array_equal(idx1[inside], rs["nn_idx"][inside]) and np.array_equal(d1[inside], rs["nn_d2"][inside])
+
+
+def test_device_resident_pipeline_equals_host_round_trip(gpu_ctx, oracle):
+    """scan -> lili_extract_rot -> (device views) -> VoxelGrid(0.4) -> queries -> 5 outer iterations, without the
+    features leaving HBM, must equal the same pipeline with host round trips between the stages."""
+    import ctypes as C
+    import torch
+    w = synth.make_workload(n_map=400_000, n_az=600, half_extent=(150.0, 150.0))
+    raw = np.concatenate([w["scan_xyz"], np.full((w["scan_xyz"].shape[0], 1), 9.0, np.float32)], 1).astype(np.float32)
+    P = L.make_params("rot")
+    tb, qb = L.api.body_pose_from_lidar(w["lidar_t"], w["lidar_q"], P)
+    t0, q0 = synth.perturbed_pose(tb, qb, np.random.default_rng(1), 0.2, 1.0)
+    ex = L.RotExtractor(gpu_ctx, ds_rate=2)
+    m = L.ScanToMapMatcher(gpu_ctx, P)
+    m.set_input_cloud(L.KIND_SURF, w["map_xyz"])
+    # host round trips
+    feats = ex.extract(raw)
+    qh, _ = L.api.voxel_filter(gpu_ctx, feats["surf"], 0.4)
+    m.set_queries(0, L.KIND_SURF, qh)
+    m.pose_set(0, t0, q0); m.iterate(0, 5, L.MASK_SURF)
+    t_h, q_h, st = m.pose_get(0)
+    assert st == 0
+    # device resident
+    d_scan = torch.from_numpy(raw).cuda()
+    cloud = L.api.cloud_from_device(d_scan.data_ptr(), raw.shape[0], 16, 12)
+    outs = [L.api.FeatureOut(None, 0, 16, L.api.MEM_HOST, 0) for _ in range(3)]
+    qi, ql = np.array([1.0, 0, 0, 0]), np.array([1.0, 0, 0, 0])
+    gpu_ctx._chk(gpu_ctx.lib.lili_extract_rot(gpu_ctx.h, C.byref(cloud), qi.ctypes.data_as(C.c_void_p), ql.ctypes.data_as(C.c_void_p),
+                                              C.byref(ex.params), C.byref(outs[0]), C.byref(outs[1]), C.byref(outs[2])))
+    _, _, d_surf = L.api.extract_rot_device(gpu_ctx)
+    assert d_surf.n == feats["surf"].shape[0]
+    d_q = torch.empty((d_surf.n, 4), dtype=torch.float32, device="cuda")
+    qd = L.api.voxel_filter_device(gpu_ctx, d_surf, 0.4, d_q.data_ptr(), d_surf.n)
+    assert qd.n == qh.shape[0]
+    m.set_queries(0, L.KIND_SURF, qd)
+    m.pose_set(0, t0, q0); m.iterate(0, 5, L.MASK_SURF)
+    t_d, q_d, st = m.pose_get(0)
+    assert st == 0
+    assert np.array_equal(t_h, t_d) and np.array_equal(q_h, q_d)
+    assert np.linalg.norm(t_d - tb) < 0.5 * np.linalg.norm(t0 - tb)
