@@ -87,9 +87,16 @@ def main():
                          "strong: the 200k queries of one scan are block-sharded over the ranks (BASELINE config 3)")
     ap.add_argument("--n-map", type=int, default=N_MAP)
     ap.add_argument("--n-az", type=int, default=N_AZ)
+    ap.add_argument("--iters-per-scan", type=int, default=10,
+                    help="one scan registration = this many outer GN iterations from the perturbed initial pose (BASELINE configs[1]: 10); "
+                         "the pose is re-initialised on the device every this-many steps")
+    ap.add_argument("--assoc-only", type=int, default=0, help="profiling aid: only this many association launches at a fixed pose, then exit")
+    ap.add_argument("--assoc-after", type=int, default=0, help="with --assoc-only: run this many GN iterations first (pose then stays fixed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--split-path", action="store_true", help="use the multi-GPU code path (export/import counts, separate GN kernel) even at N=1")
     ap.add_argument("--bin", action="store_true", help="enable the once-per-scan query binning (A/B only)")
+    ap.add_argument("--reach", type=int, default=0, help="map grid reach (1 = cells of the gate radius, 2 = half-size cells); 0 = library default")
+    ap.add_argument("--cell-pct", type=int, default=0, help="reach-2 cell edge in %% of the gate radius (50..100); 0 = library default")
     ap.add_argument("--tile", action="store_true", help="enable the LDS-tiled search (A/B only; implies --bin)")
     args = ap.parse_args()
 
@@ -143,6 +150,10 @@ def main():
     torch.cuda.set_stream(tstream)
     assert tstream.cuda_stream != 0
     ctx = L.Context(local_rank, stream=tstream.cuda_stream)
+    if args.reach:
+        ctx.set_option("grid_reach", args.reach)
+    if args.cell_pct:
+        ctx.set_option("cell_pct", args.cell_pct)
     if args.bin or args.tile:
         ctx.set_option("bin_queries", 1)
     if args.tile:
@@ -155,6 +166,21 @@ def main():
     m.set_queries(0, L.KIND_SURF, queries)
     gram = torch.zeros(L.api.GRAM_DOUBLES, dtype=torch.float64, device=dev)
     m.pose_set(0, t0, q0)
+    m.pose_set(1, t0, q0)       # slot 1 only holds the initial guess; slot 0 is restarted from it on the device
+    ips = max(1, args.iters_per_scan)
+
+    if args.assoc_only:
+        m.iterate(0, args.assoc_after, L.MASK_SURF)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        m.associate_dev(0, L.MASK_SURF)
+        e0.record()
+        for _ in range(args.assoc_only):
+            m.associate_dev(0, L.MASK_SURF)
+        e1.record()
+        torch.cuda.synchronize()
+        print(json.dumps({"assoc_only_us": e0.elapsed_time(e1) * 1e3 / args.assoc_only, "after_iters": args.assoc_after}), flush=True)
+        ctx.close()
+        return
 
     counts = torch.zeros(2, dtype=torch.int32, device=dev)
 
@@ -171,10 +197,13 @@ def main():
         m.gn_update(0, gram.data_ptr())
 
     def run_steps(k):
+        # every `ips` steps a new registration starts from the initial guess (async device-to-device pose copy)
         if world == 1 and not args.split_path:
-            m.iterate(0, k, L.MASK_SURF)      # one C call enqueues k x (associate, linearise, reduce, GN update)
+            m.iterate_restart(0, k, ips, 1, L.MASK_SURF)   # one C call enqueues k x (associate, linearise, reduce+GN update)
         else:
-            for _ in range(k):
+            for i in range(k):
+                if i % ips == 0:
+                    m.pose_copy(0, 1)
                 step_multi()
 
     def fence():
@@ -184,8 +213,7 @@ def main():
 
     run_steps(args.warmup)
     fence()
-    # every timed run starts from the same initial pose so that N=1,2,4,8 do identical work per step
-    m.pose_set(0, t0, q0)
+    # every timed run starts a fresh registration at step 0, so N=1,2,4,8 do identical work per step
     fence()
     tic = time.perf_counter()
     run_steps(args.steps)
@@ -200,18 +228,12 @@ def main():
     # ---------------- roofline of the dominant kernel (k_associate_surf), HIP events on its stream ----------------
     roofline = None
     if rank == 0:
-        reps = max(20, min(args.steps, 200))
-        m.pose_set(0, t0, q0)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for _ in range(5):
-            m.associate_dev(0, L.MASK_SURF)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(reps):
-            m.associate_dev(0, L.MASK_SURF)
-        e1.record()
-        torch.cuda.synchronize()
-        dt = e0.elapsed_time(e1) * 1e-3 / reps
+        # same schedule as the timed region (restart every `ips` steps), association launches bracketed by HIP events
+        # on the context's stream inside the C library; average over all launches of that schedule
+        reps = max(2 * ips, min(args.steps, 200))
+        m.iterate_restart(0, ips, ips, 1, L.MASK_SURF)
+        ms = m.iterate_restart(0, reps, ips, 1, L.MASK_SURF, time_association=True)
+        dt = ms * 1e-3 / reps
         alg_bytes = BYTES_PER_QUERY * queries.shape[0]
         achieved = alg_bytes / dt / 1e9
         traffic = None
@@ -236,7 +258,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"configs[2]: synthetic 64-ring {n_scan}-pt scan vs {w['map_xyz'].shape[0]}-pt local map "
-                                   f"(variant A, seed {hex(w['seed'])}), ROT back-end matcher (surf), 1 outer GN iteration per step, "
+                                   f"(variant A, seed {hex(w['seed'])}), ROT back-end matcher (surf), 1 outer GN iteration per step, a new registration from the perturbed pose every {ips} steps, "
                                    f"{'queries block-sharded over ranks' if args.scaling == 'strong' else 'one 200k-pt shard per rank'}",
                        "queries_per_rank": int(queries.shape[0]), "map_points": int(w["map_xyz"].shape[0]),
                        "parallelism": f"queries sharded x{world}, map replicated, all-reduce(counts, Gram)" if world > 1 else "single GPU",

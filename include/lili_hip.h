@@ -246,6 +246,15 @@ int lili_s2m_gn_update(lili_ctx* ctx, int slot, const double* d_gram);
 /* Convenience: n_iters x (accumulate + gn_update) on an internal buffer.  Async. */
 int lili_s2m_iterate(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, int n_iters);
 
+/* Async device-to-device copy of the body pose of src_slot into dst_slot (no host round trip). */
+int lili_s2m_pose_copy(lili_ctx* ctx, int dst_slot, int src_slot);
+/* lili_s2m_iterate that re-initialises the pose from restart_slot before iterations 0, restart_every, 2*restart_every...
+ * ("one scan registration = restart_every GN iterations"; restart_every = 0 disables).  If assoc_ms is non-NULL the
+ * association launches are bracketed by HIP events on the context's stream, their total duration (ms) is returned and
+ * the call synchronises; with NULL it is async like lili_s2m_iterate. */
+int lili_s2m_iterate_restart(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, int n_iters, int restart_every,
+                             int restart_slot, float* assoc_ms);
+
 /* Host-side helper used by the ceres adapter and the host LM: Gauss-Newton step from a host Gram. */
 int lili_gn_step_host(const double gram[64], double t[3], double q[4], double delta[6]);
 

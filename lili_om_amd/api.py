@@ -121,6 +121,8 @@ _SIGS = {
     "lili_s2m_linearize_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams), C.c_void_p]),
     "lili_s2m_gn_update": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "lili_s2m_iterate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams), C.c_int]),
+    "lili_s2m_pose_copy": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "lili_s2m_iterate_restart": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "lili_gn_step_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lili_gram_to_factor": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
 }
@@ -325,6 +327,16 @@ class ScanToMapMatcher:
 
     def gn_update(self, slot, d_gram_ptr):
         self.ctx._chk(self.lib.lili_s2m_gn_update(self.ctx.h, slot, C.c_void_p(d_gram_ptr)))
+
+    def pose_copy(self, dst_slot, src_slot):
+        self.ctx._chk(self.lib.lili_s2m_pose_copy(self.ctx.h, dst_slot, src_slot))
+
+    def iterate_restart(self, slot, n_iters, restart_every, restart_slot, kind_mask=MASK_SURF, time_association=False):
+        """Returns the summed association-kernel time in ms when time_association (blocking), else None (async)."""
+        ms = C.c_float(0)
+        self.ctx._chk(self.lib.lili_s2m_iterate_restart(self.ctx.h, slot, kind_mask, C.byref(self.params), int(n_iters), int(restart_every),
+                                                        int(restart_slot), C.byref(ms) if time_association else None))
+        return ms.value if time_association else None
 
     def iterate(self, slot, n_iters, kind_mask=MASK_SURF):
         self.ctx._chk(self.lib.lili_s2m_iterate(self.ctx.h, slot, kind_mask, C.byref(self.params), int(n_iters)))

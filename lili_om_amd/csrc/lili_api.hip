@@ -130,6 +130,8 @@ int lili_set_debug(lili_ctx* ctx, int keep_neighbors) {
 int lili_set_option(lili_ctx* ctx, const char* name, int value) {
     if (!ctx || !name) return LILI_E_ARG;
     if (std::strcmp(name, "bin_queries") == 0) { ctx->bin_queries = value != 0; for (auto& s : ctx->slots) for (auto& k : s.k) k.binned = false; return LILI_OK; }
+    if (std::strcmp(name, "grid_reach") == 0) { if (value != 1 && value != 2) return ctx->fail(LILI_E_ARG, "grid_reach must be 1 or 2"); ctx->grid_reach = value; return LILI_OK; }
+    if (std::strcmp(name, "cell_pct") == 0) { if (value < 50 || value > 100) return ctx->fail(LILI_E_ARG, "cell_pct must be in 50..100"); ctx->cell_pct = value; return LILI_OK; }
     if (std::strcmp(name, "tiled") == 0) { ctx->tiled = value != 0; return LILI_OK; }
     if (std::strcmp(name, "max_cells") == 0) { if (value < 1) return ctx->fail(LILI_E_ARG, "max_cells must be positive"); ctx->max_cells = value; return LILI_OK; }
     return ctx->fail(LILI_E_ARG, std::string("unknown option ") + name);
@@ -170,7 +172,9 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
     for (int k = 0; k < 3; k++) { mn[k] = dec(mm[k]); mx[k] = dec(mm[3 + k]); if (!(mn[k] <= mx[k])) any = false; }
     if (!any) { mn[0] = mn[1] = mn[2] = 0; mx[0] = mx[1] = mx[2] = 0; }   // no finite point: one empty-ish cell
     // cell edge: >= 1.01 * gate radius so that the 27-cell neighbourhood covers the gate ball
-    double cell = std::sqrt(max_sq_radius) * 1.01;
+    const int reach = ctx->grid_reach == 2 ? 2 : 1;
+    // reach * cell >= 1.01 * gate radius; with reach 2 the cell edge is cell_pct % of the gate radius (50..100)
+    double cell = std::sqrt(max_sq_radius) * 1.01 * (reach == 2 ? (double)ctx->cell_pct / 100.0 : 1.0);
     if (!(cell > 1e-6)) cell = 1e-6;
     int64_t nx, ny, nz;
     for (;;) {
@@ -185,7 +189,7 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
     m.n_cells = nx * ny * nz;
     GridView g{};
     g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2]; g.inv_cell = 1.0 / cell;
-    g.nx = (int)nx; g.ny = (int)ny; g.nz = (int)nz; g.n_points = n;
+    g.nx = (int)nx; g.ny = (int)ny; g.nz = (int)nz; g.n_points = n; g.reach = reach;
     const int64_t nc = m.n_cells;
     HIPCHK(m.cell_tmp.ensure((size_t)nc * sizeof(int)));
     HIPCHK(m.cell_start.ensure((size_t)(nc + 1) * sizeof(int)));
@@ -305,7 +309,7 @@ static int launch_associate(lili_ctx* ctx, int slot, int kind, const PoseArg& pa
     MapIndex& m = ctx->map[kind];
     if (!m.valid) return ctx->fail(LILI_E_STATE, "associate: map_set first");
     double gate = kind == LILI_KIND_SURF ? P.kd_max_radius : P.edge_gate;
-    if (m.n > 0 && !(std::sqrt(gate) * 1.0099 <= m.cell))
+    if (m.n > 0 && !(std::sqrt(gate) * 1.0099 <= m.cell * (double)m.view.reach))
         return ctx->fail(LILI_E_STATE, "associate: gate radius exceeds the radius the map index was built for");
     ks.has_records = true;
     if (ks.n_q == 0) return LILI_OK;
@@ -326,7 +330,7 @@ static int launch_associate(lili_ctx* ctx, int slot, int kind, const PoseArg& pa
     const int* perm = nullptr;
     const int2* tiles = nullptr;
     ks.n_assoc_blocks = ks.n_blocks;
-    const bool tiled = ctx->tiled && ctx->bin_queries && n >= 4 * kBlock;   // tiles need spatially compact blocks
+    const bool tiled = ctx->tiled && ctx->bin_queries && n >= 4 * kBlock && m.view.reach == 1;   // tiles need spatially compact blocks
     if (ctx->bin_queries && n >= 4 * kBlock) {
         if (!ks.binned) { int rc = bin_queries(ctx, ks, m, pa, P); if (rc != LILI_OK) return rc; }
         perm = ks.perm.as<int>();
@@ -620,16 +624,52 @@ int lili_s2m_gn_update(lili_ctx* ctx, int slot, const double* d_gram) {
     return LILI_OK;
 }
 
-int lili_s2m_iterate(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, int n_iters) {
+int lili_s2m_pose_copy(lili_ctx* ctx, int dst_slot, int src_slot) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(dst_slot >= 0 && dst_slot < LILI_MAX_SLOTS && src_slot >= 0 && src_slot < LILI_MAX_SLOTS, "pose_copy: bad slot");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyAsync(ctx->state(dst_slot)->pose, ctx->state(src_slot)->pose, 7 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return LILI_OK;
+}
+
+// n_iters outer iterations; if restart_every > 0 the pose of `slot` is re-initialised from `restart_slot` before
+// iterations 0, restart_every, 2*restart_every, ... (device-to-device, async) — "one registration = restart_every
+// GN iterations".  If assoc_ms is non-NULL the association launches are bracketed by HIP events on the context's
+// stream and their total duration is returned (this variant synchronises at the end).
+static int iterate_impl(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, int n_iters, int restart_every, int restart_slot, float* assoc_ms) {
     if (!ctx) return LILI_E_ARG;
     ARGCHK(n_iters >= 0, "iterate: negative n_iters");
+    ARGCHK(restart_every >= 0 && (restart_every == 0 || (restart_slot >= 0 && restart_slot < LILI_MAX_SLOTS && restart_slot != slot)), "iterate: bad restart arguments");
+    std::vector<hipEvent_t> ev;
+    if (assoc_ms) {
+        ev.resize((size_t)2 * n_iters);
+        for (auto& e : ev) HIPCHK(hipEventCreate(&e));
+    }
     for (int it = 0; it < n_iters; it++) {   // 3 launches per outer iteration: associate, linearise, reduce+GN
+        if (restart_every > 0 && it % restart_every == 0) { int rc = lili_s2m_pose_copy(ctx, slot, restart_slot); if (rc != LILI_OK) return rc; }
+        if (assoc_ms) HIPCHK(hipEventRecord(ev[2 * it], ctx->stream));
         int rc = lili_s2m_associate_dev(ctx, slot, kind_mask, params);
         if (rc != LILI_OK) return rc;
+        if (assoc_ms) HIPCHK(hipEventRecord(ev[2 * it + 1], ctx->stream));
         rc = linearize_dev_impl(ctx, slot, kind_mask, params, ctx->gram_of(slot), 1);
         if (rc != LILI_OK) return rc;
     }
+    if (assoc_ms) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        double tot = 0;
+        for (int it = 0; it < n_iters; it++) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev[2 * it], ev[2 * it + 1])); tot += ms; }
+        for (auto& e : ev) (void)hipEventDestroy(e);
+        *assoc_ms = (float)tot;
+    }
     return LILI_OK;
+}
+
+int lili_s2m_iterate(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, int n_iters) {
+    return iterate_impl(ctx, slot, kind_mask, params, n_iters, 0, 0, nullptr);
+}
+
+int lili_s2m_iterate_restart(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, int n_iters, int restart_every, int restart_slot, float* assoc_ms) {
+    return iterate_impl(ctx, slot, kind_mask, params, n_iters, restart_every, restart_slot, assoc_ms);
 }
 
 // host mirror of k_gn_update (used by the ceres adapter / host LM; plain C++ on the host by design —

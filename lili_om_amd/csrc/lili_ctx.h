@@ -77,7 +77,9 @@ struct lili_ctx {
     DevBuf bin_hist, bin_start, bin_sums, bin_tcnt, bin_toff;   // query binning scratch
     bool bin_queries = false;   // trust the caller's order (extractor output is ring-/voxel-ordered, i.e. coherent)
     bool tiled = false;         // LDS-staged tiles: measured slower than the direct path once selection is branch-free
-    int max_cells = 1 << 26;
+    int max_cells = 1 << 27;
+    int grid_reach = 2;          // 2: cells smaller than the gate radius, inner 3x3x3 block first, shell on demand (knn5_grid)
+    int cell_pct = 65;           // reach 2: cell edge in % of 1.01 * gate radius (>= 50)
     void* ext_rot = nullptr;                 // extractor state (lili_extract_rot.hip), freed through ext_rot_free
     void (*ext_rot_free)(void*) = nullptr;
     void* ext_livox = nullptr;

@@ -16,6 +16,7 @@ struct GridView {
     double inv_cell;        // 1 / cell edge
     int nx, ny, nz;
     int n_points;
+    int reach;              // neighbourhood half-width in cells: reach * cell edge >= 1.01 * gate radius (1 or 2)
 };
 
 // Per-slot state that lives in device memory so that outer iterations need no host round trip.

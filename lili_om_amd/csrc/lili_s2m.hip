@@ -247,9 +247,12 @@ __device__ __forceinline__ float dist2(float4 p, float qx, float qy, float qz) {
 struct Sel5 {
     unsigned long long k[5];
     int j[5];
-    __device__ __forceinline__ void init() {
+    // `bound`: candidates enter only with d <= bound.  +inf gives the plain 5-NN; the association passes the gate of the
+    // reference (`pointSearchSqDis[4] < gate`, rounded UP to f32), so that rows and shell cells beyond the gate are pruned
+    // from the first candidate on — queries without 5 neighbours inside the gate then end with d[4] = bound >= gate, j = -1.
+    __device__ __forceinline__ void init(float bound = __uint_as_float(0x7f800000u)) {
 #pragma unroll
-        for (int s = 0; s < 5; s++) { k[s] = 0x7f8000007fffffffull; j[s] = -1; }
+        for (int s = 0; s < 5; s++) { k[s] = ((unsigned long long)__float_as_uint(bound) << 32) | 0x7fffffffull; j[s] = -1; }
     }
     __device__ __forceinline__ void insert(float d, float4 p, int jpos) {
         unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w);
@@ -284,34 +287,104 @@ __device__ __forceinline__ float row_lower_bound(const GridView& g, float qy, fl
 // visiting order of the 9 (dy,dz) rows: centre, faces, diagonals (w = (dy+1)*3 + (dz+1))
 __device__ __forceinline__ int row_order(int n) { return n == 0 ? 4 : n == 1 ? 1 : n == 2 ? 3 : n == 3 ? 5 : n == 4 ? 7 : n == 5 ? 0 : n == 6 ? 2 : n == 7 ? 6 : 8; }
 
-__device__ __forceinline__ void knn5_grid(const GridView& g, float qx, float qy, float qz, Top5& best) {
-    Sel5 sel; sel.init();
+// One run of consecutive cell-sorted map points.  Four independent loads are in flight per trip (the search is bound
+// by the length of its dependent-load chain, not by bandwidth); lanes past their run end re-load the run's last point
+// and give it a NaN distance, whose key can never enter the selection.
+__device__ __forceinline__ void scan_run(const GridView& g, Sel5& sel, int beg, int end, float qx, float qy, float qz) {
+    const float kNaN = __uint_as_float(0x7fc00000u);
+    for (int j = beg; j < end; j += 4) {
+        const int last = end - 1;
+        const int j1 = min(j + 1, last), j2 = min(j + 2, last), j3 = min(j + 3, last);
+        float4 p0 = g.pts[j], p1 = g.pts[j1], p2 = g.pts[j2], p3 = g.pts[j3];
+        float d0 = dist2(p0, qx, qy, qz);
+        float d1 = j + 1 < end ? dist2(p1, qx, qy, qz) : kNaN;
+        float d2 = j + 2 < end ? dist2(p2, qx, qy, qz) : kNaN;
+        float d3 = j + 3 < end ? dist2(p3, qx, qy, qz) : kNaN;
+        float wv = sel.worst();
+        if (d0 <= wv || d1 <= wv) {   // the compiler turns these into wave-level skips of the exchange network
+            sel.insert(d0, p0, j);
+            sel.insert(d1, p1, j1);
+        }
+        wv = sel.worst();
+        if (d2 <= wv || d3 <= wv) {
+            sel.insert(d2, p2, j2);
+            sel.insert(d3, p3, j3);
+        }
+    }
+}
+
+// Exact 5-NN among the map points of the (2*reach+1)^3 cells around the query.  reach = 1: the 27 cells (9 runs).
+// reach = 2 (cells of half the size): the inner 27 cells first — about 2.4x fewer candidates than 27 full-size
+// cells — and the outer shell of the 5x5x5 block only if the current 5th-best distance does not rule it out:
+// every point outside the inner block is at least `margin` away (margin = one cell + the query's gap to the nearest
+// face of its own cell), so worst < 0.999 * margin^2 makes the shell irrelevant.  All bounds are conservative by
+// 0.1 % against f32 rounding of the distances; ties (d == worst) never skip.
+__device__ __forceinline__ float gate_bound(double gate) {   // smallest f32 >= gate
+    float gf = (float)gate;
+    if ((double)gf < gate) gf = __uint_as_float(__float_as_uint(gf) + 1u);
+    return gf;
+}
+__device__ __forceinline__ void knn5_grid(const GridView& g, float qx, float qy, float qz, float bound, Top5& best) {
+    Sel5 sel; sel.init(bound);
     sel.to_top5(best);
     if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) return;
+    const int R = g.reach;
     int cx = cell_coord(qx, g.ox, g.inv_cell), cy = cell_coord(qy, g.oy, g.inv_cell), cz = cell_coord(qz, g.oz, g.inv_cell);
-    // queries more than one cell outside the grid cannot have a neighbour within the gate radius
-    if (cx < -1 || cx > g.nx || cy < -1 || cy > g.ny || cz < -1 || cz > g.nz) return;
-    int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
-    if (x0 > x1) return;
-    for (int n = 0; n < 9; n++) {
-        int w = row_order(n);
-        int dy = w / 3 - 1, dz = w % 3 - 1;
-        int y = cy + dy, z = cz + dz;
-        if (z < 0 || z >= g.nz || y < 0 || y >= g.ny) continue;
-        if (row_lower_bound(g, qy, qz, cy, cz, dy, dz) > sel.worst()) continue;
-        int row = (z * g.ny + y) * g.nx;
-        int beg = g.cell_start[row + x0], end = g.cell_start[row + x1 + 1];
-        int j = beg;
-        for (; j + 1 < end; j += 2) {
-            float4 p0 = g.pts[j], p1 = g.pts[j + 1];
-            float d0 = dist2(p0, qx, qy, qz), d1 = dist2(p1, qx, qy, qz);
-            float wv = sel.worst();
-            if (d0 <= wv || d1 <= wv) {   // the compiler turns this into a wave-level skip of the exchange network
-                sel.insert(d0, p0, j);
-                sel.insert(d1, p1, j + 1);
+    // queries more than `reach` cells outside the grid cannot have a neighbour within the gate radius
+    if (cx < -R || cx > g.nx - 1 + R || cy < -R || cy > g.ny - 1 + R || cz < -R || cz > g.nz - 1 + R) return;
+    {
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+        if (x0 <= x1) {
+            // all nine row ranges are fetched before any row is scanned: 18 independent loads instead of nine
+            // load -> scan -> load hops on the critical path
+            int rb[9], re[9];
+#pragma unroll
+            for (int n = 0; n < 9; n++) {
+                const int w = row_order(n);
+                const int y = cy + w / 3 - 1, z = cz + w % 3 - 1;
+                const bool in = z >= 0 && z < g.nz && y >= 0 && y < g.ny;
+                const int* cs = g.cell_start + (size_t)(min(max(z, 0), g.nz - 1) * g.ny + min(max(y, 0), g.ny - 1)) * g.nx;
+                const int b = cs[x0], e = cs[x1 + 1];
+                rb[n] = b; re[n] = in ? e : b;
+            }
+#pragma unroll
+            for (int n = 0; n < 9; n++) {
+                const int w = row_order(n);
+                if (rb[n] >= re[n]) continue;
+                if (row_lower_bound(g, qy, qz, cy, cz, w / 3 - 1, w % 3 - 1) > sel.worst()) continue;
+                scan_run(g, sel, rb[n], re[n], qx, qy, qz);
             }
         }
-        if (j < end) { float4 p0 = g.pts[j]; float d0 = dist2(p0, qx, qy, qz); if (d0 <= sel.worst()) sel.insert(d0, p0, j); }
+    }
+    if (R == 2) {
+        const double c = 1.0 / g.inv_cell;
+        const double fxm = (double)qx - (g.ox + (double)cx * c), fxp = (g.ox + (double)(cx + 1) * c) - (double)qx;
+        const double fym = (double)qy - (g.oy + (double)cy * c), fyp = (g.oy + (double)(cy + 1) * c) - (double)qy;
+        const double fzm = (double)qz - (g.oz + (double)cz * c), fzp = (g.oz + (double)(cz + 1) * c) - (double)qz;
+        const double margin = c + fmax(fmin(fmin(fmin(fxm, fxp), fmin(fym, fyp)), fmin(fzm, fzp)), 0.0);
+        if (!(sel.worst() < (float)(0.999 * margin * margin))) {
+            for (int dz = -2; dz <= 2; dz++) {
+                const int z = cz + dz;
+                if (z < 0 || z >= g.nz) continue;
+                const double gz = dz == 0 ? 0.0 : fmax(dz < 0 ? fzm + (double)(-dz - 1) * c : fzp + (double)(dz - 1) * c, 0.0);
+                for (int dy = -2; dy <= 2; dy++) {
+                    const int y = cy + dy;
+                    if (y < 0 || y >= g.ny) continue;
+                    const double gy = dy == 0 ? 0.0 : fmax(dy < 0 ? fym + (double)(-dy - 1) * c : fyp + (double)(dy - 1) * c, 0.0);
+                    const double lbr = 0.999 * (gy * gy + gz * gz);
+                    if ((float)lbr > sel.worst()) continue;
+                    const int* cs = g.cell_start + (size_t)(z * g.ny + y) * g.nx;
+                    if (dy == -2 || dy == 2 || dz == -2 || dz == 2) {            // a row of the shell: all 5 cells
+                        const int x0 = max(cx - 2, 0), x1 = min(cx + 2, g.nx - 1);
+                        if (x0 <= x1) scan_run(g, sel, cs[x0], cs[x1 + 1], qx, qy, qz);
+                    } else {                                                     // inner row: only its two outer cells are new
+                        const int xl = cx - 2, xr = cx + 2;
+                        if (xl >= 0 && xl < g.nx) { double gx = fmax(fxm + c, 0.0); if (!((float)(lbr + 0.999 * gx * gx) > sel.worst())) scan_run(g, sel, cs[xl], cs[xl + 1], qx, qy, qz); }
+                        if (xr >= 0 && xr < g.nx) { double gx = fmax(fxp + c, 0.0); if (!((float)(lbr + 0.999 * gx * gx) > sel.worst())) scan_run(g, sel, cs[xr], cs[xr + 1], qx, qy, qz); }
+                    }
+                }
+            }
+        }
     }
     sel.to_top5(best);
 }
@@ -549,7 +622,7 @@ __device__ __forceinline__ void knn5_tiled(const GridView& g, TileLds& L, bool l
     }
     if (direct) {   // degenerate tile: per-thread search in global memory (identical candidate set)
         if (inr) {
-            Top5 t; knn5_grid(g, qx, qy, qz, t);
+            Top5 t; knn5_grid(g, qx, qy, qz, __uint_as_float(0x7f800000u), t);
             best = t;
         }
         return;
@@ -646,7 +719,7 @@ __global__ __launch_bounds__(kBlock) void k_associate_surf(
 #pragma unroll
         for (int k = 0; k < 5; k++) { nn.d[k] = 0.01f * (k + 1); nn.j[k] = (i * 7 + k) % g.n_points; }
     } else if (TILED) knn5_tiled(g, L, live, px, py, pz, nn, P.debug);
-    else if (live) knn5_grid(g, px, py, pz, nn);
+    else if (live) knn5_grid(g, px, py, pz, gate_bound(P.kd_max_radius), nn);
     bool ok = false;
     if (live) {
         store_debug_nn(g, nn, i, dbg_idx, dbg_d2);
@@ -676,7 +749,7 @@ __global__ __launch_bounds__(kBlock) void k_associate_edge(
     float px = (float)pmd.x, py = (float)pmd.y, pz = (float)pmd.z;
     Top5 nn;
     if (TILED) knn5_tiled(g, L, live, px, py, pz, nn, P.debug);
-    else if (live) knn5_grid(g, px, py, pz, nn);
+    else if (live) knn5_grid(g, px, py, pz, gate_bound(P.edge_gate), nn);
     bool ok = false;
     if (live) {
         store_debug_nn(g, nn, i, dbg_idx, dbg_d2);

@@ -4,7 +4,7 @@ import csv, sys, collections, glob
 for path in sys.argv[1:]:
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
-        k = r["Kernel_Name"].split("(")[0]
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, d in acc.items():
         if not k.startswith("lili::"):
