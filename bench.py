@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--bin", action="store_true", help="enable the once-per-scan query binning (A/B only)")
     ap.add_argument("--reach", type=int, default=0, help="map grid reach (1 = cells of the gate radius, 2 = half-size cells); 0 = library default")
     ap.add_argument("--cell-pct", type=int, default=0, help="reach-2 cell edge in %% of the gate radius (50..100); 0 = library default")
+    ap.add_argument("--no-nn-cache", action="store_true", help="A/B: do not seed the search bound with the previous neighbours")
     ap.add_argument("--tile", action="store_true", help="enable the LDS-tiled search (A/B only; implies --bin)")
     args = ap.parse_args()
 
@@ -154,6 +155,8 @@ def main():
         ctx.set_option("grid_reach", args.reach)
     if args.cell_pct:
         ctx.set_option("cell_pct", args.cell_pct)
+    if args.no_nn_cache:
+        ctx.set_option("nn_cache", 0)
     if args.bin or args.tile:
         ctx.set_option("bin_queries", 1)
     if args.tile:

@@ -138,8 +138,9 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise LiliError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+    path = os.environ.get("LILI_HIP_LIBRARY", LIB_PATH)   # A/B builds of the SAME library (tools/); never another backend
+    if not os.path.exists(path):
+        raise LiliError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(hipcc --offload-arch=gfx950). The hot path has no CPU fallback.")
     # PyTorch wheels bundle their own libamdhip64 (same soname, different file name).  If this library pulled in the
     # system copy first, a later `import torch` would start a SECOND HIP runtime in the process and find no GPU.
@@ -148,7 +149,7 @@ def load_library():
         import torch  # noqa: F401
     except ImportError:
         pass
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)      # AttributeError here = ABI mismatch between header and library
         fn.restype = res

@@ -23,8 +23,8 @@ __global__ void k_bin_count(const float4*, int, GridView, PoseArg, MatchParams, 
 __global__ void k_bin_scatter(const int*, int, const int*, int*, int*);
 __global__ void k_tile_count(const int*, int, int*);
 __global__ void k_tile_fill(const int*, const int*, const int*, int, int2*);
-template <bool TILED> __global__ void k_associate_surf(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, int*);
-template <bool TILED> __global__ void k_associate_edge(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, int*);
+template <bool TILED> __global__ void k_associate_surf(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, int*, int*);
+template <bool TILED> __global__ void k_associate_edge(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, int*, int*);
 __global__ void k_linearize_surf(const float4*, int, const float4*, const double*, const unsigned char*, PoseArg, MatchParams, const SlotState*, const int*, int, double*);
 __global__ void k_linearize_edge(const float4*, int, const float4*, const float4*, const unsigned char*, PoseArg, MatchParams, const SlotState*, const int*, int, double*);
 __global__ void k_reduce_partials(const double*, int, const double*, int, double*, SlotState*, int);
@@ -133,6 +133,7 @@ int lili_set_option(lili_ctx* ctx, const char* name, int value) {
     if (std::strcmp(name, "grid_reach") == 0) { if (value != 1 && value != 2) return ctx->fail(LILI_E_ARG, "grid_reach must be 1 or 2"); ctx->grid_reach = value; return LILI_OK; }
     if (std::strcmp(name, "cell_pct") == 0) { if (value < 50 || value > 100) return ctx->fail(LILI_E_ARG, "cell_pct must be in 50..100"); ctx->cell_pct = value; return LILI_OK; }
     if (std::strcmp(name, "tiled") == 0) { ctx->tiled = value != 0; return LILI_OK; }
+    if (std::strcmp(name, "nn_cache") == 0) { ctx->nn_cache = value != 0; for (auto& s : ctx->slots) for (auto& k : s.k) k.nn_cache_valid = false; return LILI_OK; }
     if (std::strcmp(name, "max_cells") == 0) { if (value < 1) return ctx->fail(LILI_E_ARG, "max_cells must be positive"); ctx->max_cells = value; return LILI_OK; }
     return ctx->fail(LILI_E_ARG, std::string("unknown option ") + name);
 }
@@ -145,10 +146,11 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
     ARGCHK(kind == LILI_KIND_SURF || kind == LILI_KIND_EDGE, "map_set: bad kind");
     ARGCHK(cloud, "map_set: null cloud");
     ARGCHK(max_sq_radius > 0 && std::isfinite(max_sq_radius), "map_set: max_sq_radius must be positive");
+    ARGCHK(cloud->n < (1ll << 28), "map_set: at most 2^28 - 1 map points (32-bit byte offsets into the sorted array)");
     HIPCHK(hipSetDevice(ctx->device));
     MapIndex& m = ctx->map[kind];
     m.valid = false;
-    for (auto& s : ctx->slots) s.k[kind].binned = false;
+    for (auto& s : ctx->slots) { s.k[kind].binned = false; s.k[kind].nn_cache_valid = false; }
     int rc = lili_ingest_cloud(ctx, cloud, m.pts);
     if (rc != LILI_OK) return rc;
     m.n = (int64_t)cloud->n;
@@ -188,7 +190,7 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
     m.cell = cell;
     m.n_cells = nx * ny * nz;
     GridView g{};
-    g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2]; g.inv_cell = 1.0 / cell;
+    g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2]; g.inv_cell = 1.0 / cell; g.cell = 1.0 / g.inv_cell;
     g.nx = (int)nx; g.ny = (int)ny; g.nz = (int)nz; g.n_points = n; g.reach = reach;
     const int64_t nc = m.n_cells;
     HIPCHK(m.cell_tmp.ensure((size_t)nc * sizeof(int)));
@@ -235,7 +237,7 @@ int lili_s2m_set_queries(lili_ctx* ctx, int slot, int kind, const lili_cloud* cl
     ARGCHK(cloud, "set_queries: null cloud");
     HIPCHK(hipSetDevice(ctx->device));
     KindSlot& ks = ctx->slots[slot].k[kind];
-    ks.has_queries = false; ks.has_records = false; ks.binned = false;
+    ks.has_queries = false; ks.has_records = false; ks.binned = false; ks.nn_cache_valid = false;
     int rc = lili_ingest_cloud(ctx, cloud, ks.q);
     if (rc != LILI_OK) return rc;
     ks.n_q = (int64_t)cloud->n;
@@ -330,6 +332,13 @@ static int launch_associate(lili_ctx* ctx, int slot, int kind, const PoseArg& pa
     const int* perm = nullptr;
     const int2* tiles = nullptr;
     ks.n_assoc_blocks = ks.n_blocks;
+    // neighbour cache of the previous association of this scan against this map index (seeds the search bound)
+    int* nnc = nullptr;
+    if (ctx->nn_cache) {
+        HIPCHK(ks.nn_cache.ensure((size_t)n * 5 * sizeof(int)));
+        if (!ks.nn_cache_valid) { HIPCHK(hipMemsetAsync(ks.nn_cache.p, 0xFF, (size_t)n * 5 * sizeof(int), ctx->stream)); ks.nn_cache_valid = true; }
+        nnc = ks.nn_cache.as<int>();
+    }
     const bool tiled = ctx->tiled && ctx->bin_queries && n >= 4 * kBlock && m.view.reach == 1;   // tiles need spatially compact blocks
     if (ctx->bin_queries && n >= 4 * kBlock) {
         if (!ks.binned) { int rc = bin_queries(ctx, ks, m, pa, P); if (rc != LILI_OK) return rc; }
@@ -340,14 +349,14 @@ static int launch_associate(lili_ctx* ctx, int slot, int kind, const PoseArg& pa
     if (kind == LILI_KIND_SURF) {
         if (P.variant == LILI_VARIANT_LIVOX && !m.has_aux) return ctx->fail(LILI_E_STATE, "associate: Livox variant needs reflectivity (aux_offset) on the surf map");
         if (tiled) hipLaunchKernelGGL(k_associate_surf<true>, dim3(ks.n_assoc_blocks), dim3(kBlock), 0, ctx->stream, ks.q.as<float4>(), perm, tiles, n, m.view, pa, P,
-                           ks.rec0.as<float4>(), ks.rec1.as<double>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>());
+                           ks.rec0.as<float4>(), ks.rec1.as<double>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>(), nnc);
         else hipLaunchKernelGGL(k_associate_surf<false>, dim3(ks.n_assoc_blocks), dim3(kBlock), 0, ctx->stream, ks.q.as<float4>(), perm, tiles, n, m.view, pa, P,
-                           ks.rec0.as<float4>(), ks.rec1.as<double>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>());
+                           ks.rec0.as<float4>(), ks.rec1.as<double>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>(), nnc);
     } else {
         if (tiled) hipLaunchKernelGGL(k_associate_edge<true>, dim3(ks.n_assoc_blocks), dim3(kBlock), 0, ctx->stream, ks.q.as<float4>(), perm, tiles, n, m.view, pa, P,
-                           ks.rec0.as<float4>(), ks.rec1.as<float4>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>());
+                           ks.rec0.as<float4>(), ks.rec1.as<float4>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>(), nnc);
         else hipLaunchKernelGGL(k_associate_edge<false>, dim3(ks.n_assoc_blocks), dim3(kBlock), 0, ctx->stream, ks.q.as<float4>(), perm, tiles, n, m.view, pa, P,
-                           ks.rec0.as<float4>(), ks.rec1.as<float4>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>());
+                           ks.rec0.as<float4>(), ks.rec1.as<float4>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>(), nnc);
     }
     HIPCHK(hipGetLastError());
     return LILI_OK;

@@ -42,7 +42,8 @@ struct MapIndex {
 struct KindSlot {
     int64_t n_q = 0;
     bool has_queries = false, has_records = false;
-    DevBuf q, rec0, rec1, valid, dbg_idx, dbg_d2, partials, perm, keys, block_counts, tiles;
+    DevBuf q, rec0, rec1, valid, dbg_idx, dbg_d2, partials, perm, keys, block_counts, tiles, nn_cache;
+    bool nn_cache_valid = false;   // nn_cache holds the neighbours of the last association of THIS scan against the CURRENT map index
     int n_assoc_blocks = 0;  // grid of the last association launch (= number of per-block counts)
     int n_tiles = 0;       // association grid when binned (tiles never span two super-cells)
     bool binned = false;   // perm holds the super-cell (Morton) order of the queries for the current scan
@@ -79,6 +80,7 @@ struct lili_ctx {
     bool tiled = false;         // LDS-staged tiles: measured slower than the direct path once selection is branch-free
     int max_cells = 1 << 27;
     int grid_reach = 2;          // 2: cells smaller than the gate radius, inner 3x3x3 block first, shell on demand (knn5_grid)
+    bool nn_cache = false;       // seed each query's search bound with its previous 5 neighbours (exact for any pose change)
     int cell_pct = 65;           // reach 2: cell edge in % of 1.01 * gate radius (>= 50)
     void* ext_rot = nullptr;                 // extractor state (lili_extract_rot.hip), freed through ext_rot_free
     void (*ext_rot_free)(void*) = nullptr;

@@ -14,6 +14,7 @@ struct GridView {
     const int* cell_start;  // [n_cells + 1]
     double ox, oy, oz;      // grid origin
     double inv_cell;        // 1 / cell edge
+    double cell;            // 1 / inv_cell (the value the pruning bounds use)
     int nx, ny, nz;
     int n_points;
     int reach;              // neighbourhood half-width in cells: reach * cell edge >= 1.01 * gate radius (1 or 2)

@@ -250,27 +250,66 @@ struct Sel5 {
     // `bound`: candidates enter only with d <= bound.  +inf gives the plain 5-NN; the association passes the gate of the
     // reference (`pointSearchSqDis[4] < gate`, rounded UP to f32), so that rows and shell cells beyond the gate are pruned
     // from the first candidate on — queries without 5 neighbours inside the gate then end with d[4] = bound >= gate, j = -1.
-    __device__ __forceinline__ void init(float bound = __uint_as_float(0x7f800000u)) {
+    __device__ __forceinline__ void init(float bound = 3.0e38f) {
+        bound = fminf(bound, 3.0e38f);   // finite, so that the +inf of masked slots never qualifies
 #pragma unroll
         for (int s = 0; s < 5; s++) { k[s] = ((unsigned long long)__float_as_uint(bound) << 32) | 0x7fffffffull; j[s] = -1; }
     }
+    // Sorted insertion by rank: the five comparisons are independent (no compare-exchange chain), slot s takes its left
+    // neighbour if the key ranks before s-1, the key itself if it ranks exactly at s, else keeps its value.
     __device__ __forceinline__ void insert(float d, float4 p, int jpos) {
-        unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w);
-        int jj = jpos;
-#pragma unroll
-        for (int s = 0; s < 5; s++) {
-            bool c = key < k[s];
-            unsigned long long nk = c ? key : k[s];
-            int nj = c ? jj : j[s];
-            key = c ? k[s] : key;
-            jj = c ? j[s] : jj;
-            k[s] = nk; j[s] = nj;
-        }
+        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(p.w);
+        const bool c0 = key < k[0], c1 = key < k[1], c2 = key < k[2], c3 = key < k[3], c4 = key < k[4];
+        k[4] = c3 ? k[3] : (c4 ? key : k[4]);  j[4] = c3 ? j[3] : (c4 ? jpos : j[4]);
+        k[3] = c2 ? k[2] : (c3 ? key : k[3]);  j[3] = c2 ? j[2] : (c3 ? jpos : j[3]);
+        k[2] = c1 ? k[1] : (c2 ? key : k[2]);  j[2] = c1 ? j[1] : (c2 ? jpos : j[2]);
+        k[1] = c0 ? k[0] : (c1 ? key : k[1]);  j[1] = c0 ? j[0] : (c1 ? jpos : j[1]);
+        k[0] = c0 ? key : k[0];                j[0] = c0 ? jpos : j[0];
     }
     __device__ __forceinline__ float worst() const { return __uint_as_float((unsigned)(k[4] >> 32)); }
+    __device__ __forceinline__ bool final_tie() const { return false; }
     __device__ __forceinline__ void to_top5(Top5& t) const {
 #pragma unroll
         for (int s = 0; s < 5; s++) { t.d[s] = __uint_as_float((unsigned)(k[s] >> 32)); t.j[s] = j[s]; }
+    }
+};
+
+// Fast selector: the five distances are kept sorted with min / med3 (slot s' = median(slot s-1, slot s, candidate)),
+// the payload is the position in the cell-sorted array only, moved by rank.  Candidates of EQUAL distance are ordered by
+// arrival here, not by original index, so every situation in which that could change the result raises `tie`:
+//  * a candidate that is rejected or an entry that is pushed out with exactly the distance of the (new) 5th best, and
+//  * two equal distances in the final list (checked by the caller);
+// the caller then repeats the query with the exact selector (Sel5).  Proof sketch: a wrongly excluded candidate Y ties
+// with the final 5th-best distance w; when Y left, the then-5th-best W had w <= W.d <= Y.d = w.  Sentinels carry five
+// DISTINCT values just above the bound so that they never tie with each other.
+struct Sel5F {
+    float d[5];
+    int j[5];
+    bool tie;
+    __device__ __forceinline__ void init(float bound) {
+        bound = fminf(bound, 3.0e38f);
+#pragma unroll
+        for (int s = 0; s < 5; s++) { d[s] = __uint_as_float(__float_as_uint(bound) + (unsigned)s); j[s] = -1; }
+        tie = false;
+    }
+    __device__ __forceinline__ void insert(float dc, float4, int jc) {
+        const bool c0 = dc < d[0], c1 = dc < d[1], c2 = dc < d[2], c3 = dc < d[3], c4 = dc < d[4];
+        const float popped = fmaxf(d[4], dc);
+        j[4] = c3 ? j[3] : (c4 ? jc : j[4]);
+        j[3] = c2 ? j[2] : (c3 ? jc : j[3]);
+        j[2] = c1 ? j[1] : (c2 ? jc : j[2]);
+        j[1] = c0 ? j[0] : (c1 ? jc : j[1]);
+        j[0] = c0 ? jc : j[0];
+        const float n4 = __builtin_amdgcn_fmed3f(d[3], d[4], dc), n3 = __builtin_amdgcn_fmed3f(d[2], d[3], dc);
+        const float n2 = __builtin_amdgcn_fmed3f(d[1], d[2], dc), n1 = __builtin_amdgcn_fmed3f(d[0], d[1], dc);
+        d[0] = fminf(d[0], dc); d[1] = n1; d[2] = n2; d[3] = n3; d[4] = n4;
+        tie |= popped == n4;
+    }
+    __device__ __forceinline__ float worst() const { return d[4]; }
+    __device__ __forceinline__ bool final_tie() const { return tie || d[0] == d[1] || d[1] == d[2] || d[2] == d[3] || d[3] == d[4]; }
+    __device__ __forceinline__ void to_top5(Top5& t) const {
+#pragma unroll
+        for (int s = 0; s < 5; s++) { t.d[s] = d[s]; t.j[s] = j[s]; }
     }
 };
 
@@ -278,7 +317,7 @@ struct Sel5 {
 // (cy+dy, cz+dz): the gap to the own cell's boundary in y and z.  Rows whose bound exceeds the current 5th best
 // cannot contribute (a candidate enters only with d <= that value) — skipping them keeps the search exact.
 __device__ __forceinline__ float row_lower_bound(const GridView& g, float qy, float qz, int cy, int cz, int dy, int dz) {
-    const double c = 1.0 / g.inv_cell;
+    const double c = g.cell;
     double gy = dy == 0 ? 0.0 : (dy < 0 ? (double)qy - (g.oy + (double)cy * c) : (g.oy + (double)(cy + 1) * c) - (double)qy);
     double gz = dz == 0 ? 0.0 : (dz < 0 ? (double)qz - (g.oz + (double)cz * c) : (g.oz + (double)(cz + 1) * c) - (double)qz);
     gy = fmax(gy, 0.0); gz = fmax(gz, 0.0);
@@ -290,26 +329,27 @@ __device__ __forceinline__ int row_order(int n) { return n == 0 ? 4 : n == 1 ? 1
 // One run of consecutive cell-sorted map points.  Four independent loads are in flight per trip (the search is bound
 // by the length of its dependent-load chain, not by bandwidth); lanes past their run end re-load the run's last point
 // and give it a NaN distance, whose key can never enter the selection.
-__device__ __forceinline__ void scan_run(const GridView& g, Sel5& sel, int beg, int end, float qx, float qy, float qz) {
-    const float kNaN = __uint_as_float(0x7fc00000u);
+__device__ __forceinline__ float4 load_pt(const GridView& g, int j) {   // 32-bit byte offset from the uniform base (map < 2^28 points)
+    return *(const float4*)((const char*)g.pts + ((unsigned)j << 4));
+}
+template <class SEL>
+__device__ __forceinline__ void scan_run(const GridView& g, SEL& sel, int beg, int end, float qx, float qy, float qz) {
+    const int last = end - 1;
     for (int j = beg; j < end; j += 4) {
-        const int last = end - 1;
         const int j1 = min(j + 1, last), j2 = min(j + 2, last), j3 = min(j + 3, last);
-        float4 p0 = g.pts[j], p1 = g.pts[j1], p2 = g.pts[j2], p3 = g.pts[j3];
-        float d0 = dist2(p0, qx, qy, qz);
-        float d1 = j + 1 < end ? dist2(p1, qx, qy, qz) : kNaN;
-        float d2 = j + 2 < end ? dist2(p2, qx, qy, qz) : kNaN;
-        float d3 = j + 3 < end ? dist2(p3, qx, qy, qz) : kNaN;
-        float wv = sel.worst();
-        if (d0 <= wv || d1 <= wv) {   // the compiler turns these into wave-level skips of the exchange network
-            sel.insert(d0, p0, j);
-            sel.insert(d1, p1, j1);
-        }
-        wv = sel.worst();
-        if (d2 <= wv || d3 <= wv) {
-            sel.insert(d2, p2, j2);
-            sel.insert(d3, p3, j3);
-        }
+        float4 p0 = load_pt(g, j), p1 = load_pt(g, j1), p2 = load_pt(g, j2), p3 = load_pt(g, j3);
+        // slots past the run end get +inf, which no selector accepts (NaN distances of non-finite map points likewise: fminf)
+        const float kInf = __uint_as_float(0x7f800000u);
+        float d0 = fminf(dist2(p0, qx, qy, qz), kInf);
+        float d1 = j + 1 < end ? fminf(dist2(p1, qx, qy, qz), kInf) : kInf;
+        float d2 = j + 2 < end ? fminf(dist2(p2, qx, qy, qz), kInf) : kInf;
+        float d3 = j + 3 < end ? fminf(dist2(p3, qx, qy, qz), kInf) : kInf;
+        asm volatile("" : "+v"(p0.w), "+v"(p1.w), "+v"(p2.w), "+v"(p3.w));   // keep each point ONE 16-byte load (no re-load of .w inside the branches)
+        // each test is a wave-level skip of the selection code (taken if any lane qualifies)
+        if (d0 <= sel.worst()) sel.insert(d0, p0, j);
+        if (d1 <= sel.worst()) sel.insert(d1, p1, j1);
+        if (d2 <= sel.worst()) sel.insert(d2, p2, j2);
+        if (d3 <= sel.worst()) sel.insert(d3, p3, j3);
     }
 }
 
@@ -324,14 +364,15 @@ __device__ __forceinline__ float gate_bound(double gate) {   // smallest f32 >= 
     if ((double)gf < gate) gf = __uint_as_float(__float_as_uint(gf) + 1u);
     return gf;
 }
-__device__ __forceinline__ void knn5_grid(const GridView& g, float qx, float qy, float qz, float bound, Top5& best) {
-    Sel5 sel; sel.init(bound);
+template <class SEL>
+__device__ __forceinline__ bool knn5_grid_sel(const GridView& g, float qx, float qy, float qz, float bound, Top5& best) {
+    SEL sel; sel.init(bound);
     sel.to_top5(best);
-    if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) return;
+    if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) return false;
     const int R = g.reach;
     int cx = cell_coord(qx, g.ox, g.inv_cell), cy = cell_coord(qy, g.oy, g.inv_cell), cz = cell_coord(qz, g.oz, g.inv_cell);
     // queries more than `reach` cells outside the grid cannot have a neighbour within the gate radius
-    if (cx < -R || cx > g.nx - 1 + R || cy < -R || cy > g.ny - 1 + R || cz < -R || cz > g.nz - 1 + R) return;
+    if (cx < -R || cx > g.nx - 1 + R || cy < -R || cy > g.ny - 1 + R || cz < -R || cz > g.nz - 1 + R) return false;
     {
         const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
         if (x0 <= x1) {
@@ -357,7 +398,7 @@ __device__ __forceinline__ void knn5_grid(const GridView& g, float qx, float qy,
         }
     }
     if (R == 2) {
-        const double c = 1.0 / g.inv_cell;
+        const double c = g.cell;
         const double fxm = (double)qx - (g.ox + (double)cx * c), fxp = (g.ox + (double)(cx + 1) * c) - (double)qx;
         const double fym = (double)qy - (g.oy + (double)cy * c), fyp = (g.oy + (double)(cy + 1) * c) - (double)qy;
         const double fzm = (double)qz - (g.oz + (double)cz * c), fzp = (g.oz + (double)(cz + 1) * c) - (double)qz;
@@ -374,8 +415,13 @@ __device__ __forceinline__ void knn5_grid(const GridView& g, float qx, float qy,
                     const double lbr = 0.999 * (gy * gy + gz * gz);
                     if ((float)lbr > sel.worst()) continue;
                     const int* cs = g.cell_start + (size_t)(z * g.ny + y) * g.nx;
-                    if (dy == -2 || dy == 2 || dz == -2 || dz == 2) {            // a row of the shell: all 5 cells
-                        const int x0 = max(cx - 2, 0), x1 = min(cx + 2, g.nx - 1);
+                    if (dy == -2 || dy == 2 || dz == -2 || dz == 2) {            // a row of the shell: up to 5 cells,
+                        // trimmed to the cells whose box distance (row gap + x gap) can still beat the 5th best
+                        const float wv = sel.worst();
+                        const double g1m = fmax(fxm, 0.0), g1p = fmax(fxp, 0.0), g2m = fmax(fxm + c, 0.0), g2p = fmax(fxp + c, 0.0);
+                        const int dl = (float)(lbr + 0.999 * g2m * g2m) > wv ? ((float)(lbr + 0.999 * g1m * g1m) > wv ? 0 : 1) : 2;
+                        const int dr = (float)(lbr + 0.999 * g2p * g2p) > wv ? ((float)(lbr + 0.999 * g1p * g1p) > wv ? 0 : 1) : 2;
+                        const int x0 = max(cx - dl, 0), x1 = min(cx + dr, g.nx - 1);
                         if (x0 <= x1) scan_run(g, sel, cs[x0], cs[x1 + 1], qx, qy, qz);
                     } else {                                                     // inner row: only its two outer cells are new
                         const int xl = cx - 2, xr = cx + 2;
@@ -387,6 +433,12 @@ __device__ __forceinline__ void knn5_grid(const GridView& g, float qx, float qy,
         }
     }
     sel.to_top5(best);
+    return sel.final_tie();
+}
+// Fast selection first; the rare queries with an exact distance tie that could matter are repeated with the exact
+// (distance, original index) selector, so the result is always the oracle's.
+__device__ __forceinline__ void knn5_grid(const GridView& g, float qx, float qy, float qz, float bound, Top5& best) {
+    if (knn5_grid_sel<Sel5F>(g, qx, qy, qz, bound, best)) knn5_grid_sel<Sel5>(g, qx, qy, qz, bound, best);
 }
 
 // Correspondence counting without atomics on a shared word (3128 same-address atomics cost ~40 us on
@@ -450,6 +502,34 @@ __device__ __forceinline__ void store_debug_nn(const GridView& g, const Top5& nn
         dbg_idx[(size_t)i * 5 + k] = nn.j[k] >= 0 ? __float_as_int(g.pts[nn.j[k]].w) : -1;
         dbg_d2[(size_t)i * 5 + k] = nn.d[k];
     }
+}
+
+// Search bound of one query: the reference's gate, tightened by the query's 5 neighbours of the previous association
+// of the same scan against the same map index (positions in the cell-sorted array, -1 = none).  Those are five real
+// map points, so the true 5th-nearest distance cannot exceed their largest distance w at the new pose; everything
+// farther is irrelevant and rows / shell cells beyond it are pruned from the first candidate on.  The result is the
+// same exact 5-NN for any pose change — the cache only makes the bound tight when the pose moved little.
+__device__ __forceinline__ float seeded_bound(const GridView& g, double gate, const int* __restrict__ nn_cache, int n_q, int i,
+                                              float px, float py, float pz) {
+    float bound = gate_bound(gate);
+    if (nn_cache) {
+        int c0 = nn_cache[i], c1 = nn_cache[(size_t)n_q + i], c2 = nn_cache[(size_t)2 * n_q + i], c3 = nn_cache[(size_t)3 * n_q + i],
+            c4 = nn_cache[(size_t)4 * n_q + i];
+        if ((c0 | c1 | c2 | c3 | c4) >= 0) {
+            float w = dist2(load_pt(g, c0), px, py, pz);
+            w = fmaxf(w, dist2(load_pt(g, c1), px, py, pz));
+            w = fmaxf(w, dist2(load_pt(g, c2), px, py, pz));
+            w = fmaxf(w, dist2(load_pt(g, c3), px, py, pz));
+            w = fmaxf(w, dist2(load_pt(g, c4), px, py, pz));
+            if (w < bound) bound = __uint_as_float(__float_as_uint(w) + 1u);   // strictly above w: the five seeds themselves must enter
+        }
+    }
+    return bound;
+}
+__device__ __forceinline__ void store_nn_cache(int* __restrict__ nn_cache, int n_q, int i, const Top5& nn) {
+    if (!nn_cache) return;
+#pragma unroll
+    for (int k = 0; k < 5; k++) nn_cache[(size_t)k * n_q + i] = nn.j[k];
 }
 
 // findCorrespondingSurfFeatures body after the kNN (L/src/BackendFusion.cpp:1613-1679 and variants)
@@ -703,7 +783,7 @@ template <bool TILED>
 __global__ __launch_bounds__(kBlock) void k_associate_surf(
         const float4* __restrict__ queries, const int* __restrict__ perm, const int2* __restrict__ tiles, int n_q, GridView g, PoseArg pa, MatchParams P,
         float4* __restrict__ rec_nd, double* __restrict__ rec_score, unsigned char* __restrict__ valid,
-        int* __restrict__ dbg_idx, float* __restrict__ dbg_d2, int* __restrict__ block_counts) {
+        int* __restrict__ dbg_idx, float* __restrict__ dbg_d2, int* __restrict__ block_counts, int* __restrict__ nn_cache) {
     __shared__ TileLds L;
     const int2 tile = tiles ? tiles[blockIdx.x] : make_int2(blockIdx.x * kBlock, min(kBlock, n_q - (int)blockIdx.x * kBlock));
     const bool live = (int)threadIdx.x < tile.y;
@@ -719,7 +799,7 @@ __global__ __launch_bounds__(kBlock) void k_associate_surf(
 #pragma unroll
         for (int k = 0; k < 5; k++) { nn.d[k] = 0.01f * (k + 1); nn.j[k] = (i * 7 + k) % g.n_points; }
     } else if (TILED) knn5_tiled(g, L, live, px, py, pz, nn, P.debug);
-    else if (live) knn5_grid(g, px, py, pz, gate_bound(P.kd_max_radius), nn);
+    else if (live) { knn5_grid(g, px, py, pz, seeded_bound(g, P.kd_max_radius, nn_cache, n_q, i, px, py, pz), nn); store_nn_cache(nn_cache, n_q, i, nn); }
     bool ok = false;
     if (live) {
         store_debug_nn(g, nn, i, dbg_idx, dbg_d2);
@@ -736,7 +816,7 @@ template <bool TILED>
 __global__ __launch_bounds__(kBlock) void k_associate_edge(
         const float4* __restrict__ queries, const int* __restrict__ perm, const int2* __restrict__ tiles, int n_q, GridView g, PoseArg pa, MatchParams P,
         float4* __restrict__ rec_a, float4* __restrict__ rec_b, unsigned char* __restrict__ valid,
-        int* __restrict__ dbg_idx, float* __restrict__ dbg_d2, int* __restrict__ block_counts) {
+        int* __restrict__ dbg_idx, float* __restrict__ dbg_d2, int* __restrict__ block_counts, int* __restrict__ nn_cache) {
     __shared__ TileLds L;
     const int2 tile = tiles ? tiles[blockIdx.x] : make_int2(blockIdx.x * kBlock, min(kBlock, n_q - (int)blockIdx.x * kBlock));
     const bool live = (int)threadIdx.x < tile.y;
@@ -749,7 +829,7 @@ __global__ __launch_bounds__(kBlock) void k_associate_edge(
     float px = (float)pmd.x, py = (float)pmd.y, pz = (float)pmd.z;
     Top5 nn;
     if (TILED) knn5_tiled(g, L, live, px, py, pz, nn, P.debug);
-    else if (live) knn5_grid(g, px, py, pz, gate_bound(P.edge_gate), nn);
+    else if (live) { knn5_grid(g, px, py, pz, seeded_bound(g, P.edge_gate, nn_cache, n_q, i, px, py, pz), nn); store_nn_cache(nn_cache, n_q, i, nn); }
     bool ok = false;
     if (live) {
         store_debug_nn(g, nn, i, dbg_idx, dbg_d2);
@@ -759,10 +839,10 @@ __global__ __launch_bounds__(kBlock) void k_associate_edge(
     }
     store_block_count(ok, block_counts);
 }
-template __global__ void k_associate_surf<true>(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, int*);
-template __global__ void k_associate_surf<false>(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, int*);
-template __global__ void k_associate_edge<true>(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, int*);
-template __global__ void k_associate_edge<false>(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, int*);
+template __global__ void k_associate_surf<true>(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, int*, int*);
+template __global__ void k_associate_surf<false>(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, int*, int*);
+template __global__ void k_associate_edge<true>(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, int*, int*);
+template __global__ void k_associate_edge<false>(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, int*, int*);
 
 // ================================================================================================
 // Linearisation: residual + 1x7 global Jacobian per record, loss corrector, Gram reduction.
