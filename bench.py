@@ -174,6 +174,9 @@ def main():
 
     if args.assoc_only:
         m.iterate(0, args.assoc_after, L.MASK_SURF)
+        torch.cuda.synchronize()
+        if os.environ.get("LILI_DEBUG_AFTER"):
+            os.environ["LILI_DEBUG"] = os.environ["LILI_DEBUG_AFTER"]
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         m.associate_dev(0, L.MASK_SURF)
         e0.record()

@@ -92,7 +92,12 @@ int lili_sync(lili_ctx* ctx);
 int lili_set_debug(lili_ctx* ctx, int keep_neighbors);
 /* Tuning knobs that never change results: "bin_queries" (1 = order queries by map super-cell once per scan; use it
  * when the query order is not spatially coherent; default 0), "tiled" (1 = LDS-staged neighbourhood tiles, needs
- * bin_queries; default 0), "max_cells" (cap on grid cells of the map index; coarser cells stay exact). */
+ * bin_queries; default 0), "max_cells" (cap on grid cells of the map index; coarser cells stay exact),
+ * "grid_reach" (1 = cells of the gate radius, 27-cell search; 2 = smaller cells, inner 27 cells first and the shell of
+ * the 125-cell block on demand; default 2; takes effect at the next lili_map_set), "cell_pct" (reach 2: cell edge in %
+ * of the gate radius, 50..100, default 65), "nn_cache" (1 = tighten each query's search bound with its neighbours of
+ * the previous association of the same scan; default 0, measured slower), "fuse_tail" (1 = reduce + GN update inside
+ * the last linearisation launch; default 0, measured slower). */
 int lili_set_option(lili_ctx* ctx, const char* name, int value);
 
 /* ---- local map index ------------------------------------------------------------------------ */

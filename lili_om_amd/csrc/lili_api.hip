@@ -23,10 +23,10 @@ __global__ void k_bin_count(const float4*, int, GridView, PoseArg, MatchParams, 
 __global__ void k_bin_scatter(const int*, int, const int*, int*, int*);
 __global__ void k_tile_count(const int*, int, int*);
 __global__ void k_tile_fill(const int*, const int*, const int*, int, int2*);
-template <bool TILED> __global__ void k_associate_surf(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, int*, int*);
-template <bool TILED> __global__ void k_associate_edge(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, int*, int*);
-__global__ void k_linearize_surf(const float4*, int, const float4*, const double*, const unsigned char*, PoseArg, MatchParams, const SlotState*, const int*, int, double*);
-__global__ void k_linearize_edge(const float4*, int, const float4*, const float4*, const unsigned char*, PoseArg, MatchParams, const SlotState*, const int*, int, double*);
+template <bool TILED, int BS> __global__ void k_associate_surf(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, int*, int*);
+template <bool TILED, int BS> __global__ void k_associate_edge(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, int*, int*);
+__global__ void k_linearize_surf(const float4*, int, const float4*, const double*, const unsigned char*, PoseArg, MatchParams, const SlotState*, const int*, int, double*, FuseTail);
+__global__ void k_linearize_edge(const float4*, int, const float4*, const float4*, const unsigned char*, PoseArg, MatchParams, const SlotState*, const int*, int, double*, FuseTail);
 __global__ void k_reduce_partials(const double*, int, const double*, int, double*, SlotState*, int);
 __global__ void k_sum_counts(const int*, int, const int*, int, SlotState*);
 __global__ void k_gn_update(const double*, SlotState*);
@@ -43,8 +43,10 @@ static MatchParams to_device_params(const lili_s2m_params* p) {
     for (int i = 0; i < 4; i++) m.q_lb[i] = p->q_lb[i];
     for (int i = 0; i < 3; i++) m.t_lb[i] = p->t_lb[i];
     m.scale_surf_num = p->scale_surf_num; m.scale_edge_num = p->scale_edge_num;
-    static const int dbg = std::getenv("LILI_DEBUG") ? std::atoi(std::getenv("LILI_DEBUG")) : 0;
-    m.debug = dbg;
+    // profiling aid only (tools/): skip phases of the association kernels; re-read at every call so that a tool can
+    // switch it on after the pose has converged
+    const char* dbg = std::getenv("LILI_DEBUG");
+    m.debug = dbg ? std::atoi(dbg) : 0;
     return m;
 }
 
@@ -133,6 +135,7 @@ int lili_set_option(lili_ctx* ctx, const char* name, int value) {
     if (std::strcmp(name, "grid_reach") == 0) { if (value != 1 && value != 2) return ctx->fail(LILI_E_ARG, "grid_reach must be 1 or 2"); ctx->grid_reach = value; return LILI_OK; }
     if (std::strcmp(name, "cell_pct") == 0) { if (value < 50 || value > 100) return ctx->fail(LILI_E_ARG, "cell_pct must be in 50..100"); ctx->cell_pct = value; return LILI_OK; }
     if (std::strcmp(name, "tiled") == 0) { ctx->tiled = value != 0; return LILI_OK; }
+    if (std::strcmp(name, "fuse_tail") == 0) { ctx->fuse_tail = value != 0; return LILI_OK; }
     if (std::strcmp(name, "nn_cache") == 0) { ctx->nn_cache = value != 0; for (auto& s : ctx->slots) for (auto& k : s.k) k.nn_cache_valid = false; return LILI_OK; }
     if (std::strcmp(name, "max_cells") == 0) { if (value < 1) return ctx->fail(LILI_E_ARG, "max_cells must be positive"); ctx->max_cells = value; return LILI_OK; }
     return ctx->fail(LILI_E_ARG, std::string("unknown option ") + name);
@@ -241,7 +244,7 @@ int lili_s2m_set_queries(lili_ctx* ctx, int slot, int kind, const lili_cloud* cl
     int rc = lili_ingest_cloud(ctx, cloud, ks.q);
     if (rc != LILI_OK) return rc;
     ks.n_q = (int64_t)cloud->n;
-    ks.n_blocks = nblocks(ks.n_q, kBlock);
+    ks.n_blocks = nblocks(ks.n_q, kAssocBlock);
     ks.n_lin_blocks = std::min(nblocks(ks.n_q, kLinBlock), kMaxLinBlocks);
     size_t n = (size_t)ks.n_q;
     if (n) {
@@ -346,23 +349,29 @@ static int launch_associate(lili_ctx* ctx, int slot, int kind, const PoseArg& pa
         tiles = ks.tiles.as<int2>();
         ks.n_assoc_blocks = ks.n_tiles;
     }
+    // default: one wave per workgroup (kAssocBlock); the binned / tiled variants keep kBlock-sized tiles
+    const dim3 grid(ks.n_assoc_blocks);
+#define LILI_LAUNCH_ASSOC(KERNEL, REC1T)                                                                                                   \
+    do {                                                                                                                                   \
+        if (tiled) hipLaunchKernelGGL((KERNEL<true, kBlock>), grid, dim3(kBlock), 0, ctx->stream, ks.q.as<float4>(), perm, tiles, n, m.view, pa, P, \
+                                      ks.rec0.as<float4>(), ks.rec1.as<REC1T>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>(), nnc); \
+        else if (perm) hipLaunchKernelGGL((KERNEL<false, kBlock>), grid, dim3(kBlock), 0, ctx->stream, ks.q.as<float4>(), perm, tiles, n, m.view, pa, P, \
+                                      ks.rec0.as<float4>(), ks.rec1.as<REC1T>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>(), nnc); \
+        else hipLaunchKernelGGL((KERNEL<false, kAssocBlock>), grid, dim3(kAssocBlock), 0, ctx->stream, ks.q.as<float4>(), perm, tiles, n, m.view, pa, P, \
+                                      ks.rec0.as<float4>(), ks.rec1.as<REC1T>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>(), nnc); \
+    } while (0)
     if (kind == LILI_KIND_SURF) {
         if (P.variant == LILI_VARIANT_LIVOX && !m.has_aux) return ctx->fail(LILI_E_STATE, "associate: Livox variant needs reflectivity (aux_offset) on the surf map");
-        if (tiled) hipLaunchKernelGGL(k_associate_surf<true>, dim3(ks.n_assoc_blocks), dim3(kBlock), 0, ctx->stream, ks.q.as<float4>(), perm, tiles, n, m.view, pa, P,
-                           ks.rec0.as<float4>(), ks.rec1.as<double>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>(), nnc);
-        else hipLaunchKernelGGL(k_associate_surf<false>, dim3(ks.n_assoc_blocks), dim3(kBlock), 0, ctx->stream, ks.q.as<float4>(), perm, tiles, n, m.view, pa, P,
-                           ks.rec0.as<float4>(), ks.rec1.as<double>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>(), nnc);
+        LILI_LAUNCH_ASSOC(k_associate_surf, double);
     } else {
-        if (tiled) hipLaunchKernelGGL(k_associate_edge<true>, dim3(ks.n_assoc_blocks), dim3(kBlock), 0, ctx->stream, ks.q.as<float4>(), perm, tiles, n, m.view, pa, P,
-                           ks.rec0.as<float4>(), ks.rec1.as<float4>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>(), nnc);
-        else hipLaunchKernelGGL(k_associate_edge<false>, dim3(ks.n_assoc_blocks), dim3(kBlock), 0, ctx->stream, ks.q.as<float4>(), perm, tiles, n, m.view, pa, P,
-                           ks.rec0.as<float4>(), ks.rec1.as<float4>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>(), nnc);
+        LILI_LAUNCH_ASSOC(k_associate_edge, float4);
     }
+#undef LILI_LAUNCH_ASSOC
     HIPCHK(hipGetLastError());
     return LILI_OK;
 }
 
-static int launch_linearize(lili_ctx* ctx, int slot, int kind, const PoseArg& pa, const MatchParams& P) {
+static int launch_linearize(lili_ctx* ctx, int slot, int kind, const PoseArg& pa, const MatchParams& P, const FuseTail& fz) {
     KindSlot& ks = ctx->slots[slot].k[kind];
     if (!ks.has_records) return ctx->fail(LILI_E_STATE, "linearize: associate first");
     if (ks.n_q == 0) return LILI_OK;
@@ -370,10 +379,10 @@ static int launch_linearize(lili_ctx* ctx, int slot, int kind, const PoseArg& pa
     const int* bc = ctx->slots[slot].use_global_counts ? nullptr : ks.block_counts.as<int>();
     if (kind == LILI_KIND_SURF)
         hipLaunchKernelGGL(k_linearize_surf, dim3(ks.n_lin_blocks), dim3(kLinBlock), kLdsLinearize, ctx->stream, ks.q.as<float4>(), n, ks.rec0.as<float4>(),
-                           ks.rec1.as<double>(), ks.valid.as<unsigned char>(), pa, P, ctx->state(slot), bc, ks.n_assoc_blocks, ks.partials.as<double>());
+                           ks.rec1.as<double>(), ks.valid.as<unsigned char>(), pa, P, ctx->state(slot), bc, ks.n_assoc_blocks, ks.partials.as<double>(), fz);
     else
         hipLaunchKernelGGL(k_linearize_edge, dim3(ks.n_lin_blocks), dim3(kLinBlock), kLdsLinearize, ctx->stream, ks.q.as<float4>(), n, ks.rec0.as<float4>(),
-                           ks.rec1.as<float4>(), ks.valid.as<unsigned char>(), pa, P, ctx->state(slot), bc, ks.n_assoc_blocks, ks.partials.as<double>());
+                           ks.rec1.as<float4>(), ks.valid.as<unsigned char>(), pa, P, ctx->state(slot), bc, ks.n_assoc_blocks, ks.partials.as<double>(), fz);
     HIPCHK(hipGetLastError());
     return LILI_OK;
 }
@@ -390,13 +399,29 @@ static int launch_sum_counts(lili_ctx* ctx, int slot, int kind_mask) {
     return LILI_OK;
 }
 
-static int launch_reduce(lili_ctx* ctx, int slot, int kind_mask, double* d_out, int do_gn) {
+// Linearisation of the kinds in kind_mask followed by the reduction of their block partials to the 72-double record
+// (and the GN update if do_gn): k_reduce_partials, or — option fuse_tail, measured SLOWER on MI355X (46.1 vs 43.0 us per
+// iteration: the device-scope release/acquire fences cost more than the kernel boundary they save) — the fused tail of
+// the last linearisation launch.
+static int launch_linearize_reduce(lili_ctx* ctx, int slot, int kind_mask, const PoseArg& pa, const MatchParams& P, double* d_out, int do_gn) {
     Slot& s = ctx->slots[slot];
-    const double* ps = nullptr; const double* pe = nullptr; int nbs = 0, nbe = 0;
-    if ((kind_mask & LILI_MASK_SURF) && s.k[0].n_q > 0) { ps = s.k[0].partials.as<double>(); nbs = s.k[0].n_lin_blocks; }
-    if ((kind_mask & LILI_MASK_EDGE) && s.k[1].n_q > 0) { pe = s.k[1].partials.as<double>(); nbe = s.k[1].n_lin_blocks; }
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx->stream, ps, nbs, pe, nbe, d_out, ctx->state(slot), do_gn);
-    HIPCHK(hipGetLastError());
+    FuseTail fz{};
+    fz.mode = ctx->fuse_tail ? (do_gn ? 2 : 1) : 0; fz.out = d_out; fz.state = ctx->state(slot);
+    int last_kind = -1;
+    for (int kind = 0; kind < 2; kind++) if ((kind_mask & (1 << kind)) && s.k[kind].n_q > 0) {
+        if (kind == 0) { fz.part_surf = s.k[0].partials.as<double>(); fz.nb_surf = s.k[0].n_lin_blocks; }
+        else { fz.part_edge = s.k[1].partials.as<double>(); fz.nb_edge = s.k[1].n_lin_blocks; }
+        last_kind = kind;
+    }
+    const FuseTail off{};
+    for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) {
+        int rc = launch_linearize(ctx, slot, kind, pa, P, kind == last_kind ? fz : off);
+        if (rc != LILI_OK) return rc;
+    }
+    if (last_kind < 0 || !ctx->fuse_tail) {
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx->stream, fz.part_surf, fz.nb_surf, fz.part_edge, fz.nb_edge, d_out, ctx->state(slot), do_gn);
+        HIPCHK(hipGetLastError());
+    }
     return LILI_OK;
 }
 
@@ -435,8 +460,7 @@ int lili_s2m_linearize(lili_ctx* ctx, int slot, int kind_mask, const double t[3]
     for (int i = 0; i < 3; i++) pa.t[i] = t[i];
     for (int i = 0; i < 4; i++) pa.q[i] = q[i];
     MatchParams P = to_device_params(params);
-    for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) { int rc = launch_linearize(ctx, slot, kind, pa, P); if (rc != LILI_OK) return rc; }
-    int rc = launch_reduce(ctx, slot, kind_mask, ctx->gram_of(slot), 0);
+    int rc = launch_linearize_reduce(ctx, slot, kind_mask, pa, P, ctx->gram_of(slot), 0);
     if (rc != LILI_OK) return rc;
     double host[LILI_GRAM_DOUBLES];
     HIPCHK(hipMemcpyAsync(host, ctx->gram_of(slot), sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
@@ -604,11 +628,7 @@ static int linearize_dev_impl(lili_ctx* ctx, int slot, int kind_mask, const lili
     PoseArg pa{};
     pa.state = ctx->state(slot);
     MatchParams P = to_device_params(params);
-    for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) {
-        int rc = launch_linearize(ctx, slot, kind, pa, P);
-        if (rc != LILI_OK) return rc;
-    }
-    int rc = launch_reduce(ctx, slot, kind_mask, d_gram, do_gn);
+    int rc = launch_linearize_reduce(ctx, slot, kind_mask, pa, P, d_gram, do_gn);
     if (rc != LILI_OK) return rc;
     ctx->slots[slot].use_global_counts = false;
     return LILI_OK;

@@ -27,7 +27,18 @@ struct SlotState {
     int gn_status;    // 0 ok, 1 = normal matrix not positive definite (pose left unchanged)
     int iters;        // GN updates applied since pose_set
     double last_delta[6];
+    unsigned int ticket;   // fused tail of the linearisation kernels: blocks finished so far (self-resetting)
 };
+
+// Fused tail of a linearisation launch (see fused_tail in lili_s2m.hip)
+struct FuseTail {
+    int mode;                  // 0 = off, 1 = reduce to `out`, 2 = reduce + GN update
+    const double* part_surf; int nb_surf;
+    const double* part_edge; int nb_edge;
+    double* out;
+    SlotState* state;
+};
+
 
 // Pose argument of a kernel: either by value (host-provided) or read from SlotState.
 struct PoseArg {
@@ -47,5 +58,6 @@ struct MatchParams {     // device copy of lili_s2m_params (+ derived values)
 
 constexpr int kPartialDoubles = 40;  // per-block partial: 36 upper-triangle Gram entries, cost, count, 2 spare
 constexpr int kBlock = 256;
+constexpr int kAssocBlock = 64;   // association (one query per thread): one wave per workgroup, so the dispatcher balances SIMDs wave by wave
 
 }  // namespace lili

@@ -294,7 +294,8 @@ struct Sel5F {
     }
     __device__ __forceinline__ void insert(float dc, float4, int jc) {
         const bool c0 = dc < d[0], c1 = dc < d[1], c2 = dc < d[2], c3 = dc < d[3], c4 = dc < d[4];
-        const float popped = fmaxf(d[4], dc);
+        const float kInf = __uint_as_float(0x7f800000u);
+        const float popped = __builtin_amdgcn_fmed3f(d[4], dc, kInf);   // max(d[4], dc)
         j[4] = c3 ? j[3] : (c4 ? jc : j[4]);
         j[3] = c2 ? j[2] : (c3 ? jc : j[3]);
         j[2] = c1 ? j[1] : (c2 ? jc : j[2]);
@@ -302,7 +303,7 @@ struct Sel5F {
         j[0] = c0 ? jc : j[0];
         const float n4 = __builtin_amdgcn_fmed3f(d[3], d[4], dc), n3 = __builtin_amdgcn_fmed3f(d[2], d[3], dc);
         const float n2 = __builtin_amdgcn_fmed3f(d[1], d[2], dc), n1 = __builtin_amdgcn_fmed3f(d[0], d[1], dc);
-        d[0] = fminf(d[0], dc); d[1] = n1; d[2] = n2; d[3] = n3; d[4] = n4;
+        d[0] = __builtin_amdgcn_fmed3f(d[0], dc, -kInf); d[1] = n1; d[2] = n2; d[3] = n3; d[4] = n4;
         tie |= popped == n4;
     }
     __device__ __forceinline__ float worst() const { return d[4]; }
@@ -332,26 +333,41 @@ __device__ __forceinline__ int row_order(int n) { return n == 0 ? 4 : n == 1 ? 1
 __device__ __forceinline__ float4 load_pt(const GridView& g, int j) {   // 32-bit byte offset from the uniform base (map < 2^28 points)
     return *(const float4*)((const char*)g.pts + ((unsigned)j << 4));
 }
+// Four consecutive candidates [j, j+4) of a run ending at `end` (slots past the end were loaded from the run's last point
+// and get +inf, which no selector accepts; NaN distances of non-finite map points likewise: fminf).
+template <class SEL>
+__device__ __forceinline__ void process_chunk(SEL& sel, float4 p0, float4 p1, float4 p2, float4 p3, int j, int end, float qx, float qy, float qz) {
+    const float kInf = __uint_as_float(0x7f800000u);
+    const int last = end - 1;
+    asm volatile("" : "+v"(p0.w), "+v"(p1.w), "+v"(p2.w), "+v"(p3.w));   // keep each point ONE 16-byte load (no re-load of .w inside the branches)
+    float d0 = fminf(dist2(p0, qx, qy, qz), kInf);
+    float d1 = j + 1 < end ? fminf(dist2(p1, qx, qy, qz), kInf) : kInf;
+    float d2 = j + 2 < end ? fminf(dist2(p2, qx, qy, qz), kInf) : kInf;
+    float d3 = j + 3 < end ? fminf(dist2(p3, qx, qy, qz), kInf) : kInf;
+    // each test is a wave-level skip of the selection code (taken if any lane qualifies)
+    if (d0 <= sel.worst()) sel.insert(d0, p0, j);
+    if (d1 <= sel.worst()) sel.insert(d1, p1, min(j + 1, last));
+    if (d2 <= sel.worst()) sel.insert(d2, p2, min(j + 2, last));
+    if (d3 <= sel.worst()) sel.insert(d3, p3, min(j + 3, last));
+}
+// One run of consecutive cell-sorted map points, four independent loads in flight per trip (shell phase).
 template <class SEL>
 __device__ __forceinline__ void scan_run(const GridView& g, SEL& sel, int beg, int end, float qx, float qy, float qz) {
     const int last = end - 1;
     for (int j = beg; j < end; j += 4) {
-        const int j1 = min(j + 1, last), j2 = min(j + 2, last), j3 = min(j + 3, last);
-        float4 p0 = load_pt(g, j), p1 = load_pt(g, j1), p2 = load_pt(g, j2), p3 = load_pt(g, j3);
-        // slots past the run end get +inf, which no selector accepts (NaN distances of non-finite map points likewise: fminf)
-        const float kInf = __uint_as_float(0x7f800000u);
-        float d0 = fminf(dist2(p0, qx, qy, qz), kInf);
-        float d1 = j + 1 < end ? fminf(dist2(p1, qx, qy, qz), kInf) : kInf;
-        float d2 = j + 2 < end ? fminf(dist2(p2, qx, qy, qz), kInf) : kInf;
-        float d3 = j + 3 < end ? fminf(dist2(p3, qx, qy, qz), kInf) : kInf;
-        asm volatile("" : "+v"(p0.w), "+v"(p1.w), "+v"(p2.w), "+v"(p3.w));   // keep each point ONE 16-byte load (no re-load of .w inside the branches)
-        // each test is a wave-level skip of the selection code (taken if any lane qualifies)
-        if (d0 <= sel.worst()) sel.insert(d0, p0, j);
-        if (d1 <= sel.worst()) sel.insert(d1, p1, j1);
-        if (d2 <= sel.worst()) sel.insert(d2, p2, j2);
-        if (d3 <= sel.worst()) sel.insert(d3, p3, j3);
+        float4 p0 = load_pt(g, j), p1 = load_pt(g, min(j + 1, last)), p2 = load_pt(g, min(j + 2, last)), p3 = load_pt(g, min(j + 3, last));
+        process_chunk(sel, p0, p1, p2, p3, j, end, qx, qy, qz);
     }
 }
+
+// Per-thread table of the non-empty rows of the inner 3x3 block (LDS, one column per thread): run begin / end in the
+// cell-sorted array and the row's lower distance bound.
+template <int BS>
+struct RowTabT {
+    int b[9][BS];
+    int e[9][BS];
+    float lb[9][BS];
+};
 
 // Exact 5-NN among the map points of the (2*reach+1)^3 cells around the query.  reach = 1: the 27 cells (9 runs).
 // reach = 2 (cells of half the size): the inner 27 cells first — about 2.4x fewer candidates than 27 full-size
@@ -364,8 +380,8 @@ __device__ __forceinline__ float gate_bound(double gate) {   // smallest f32 >= 
     if ((double)gf < gate) gf = __uint_as_float(__float_as_uint(gf) + 1u);
     return gf;
 }
-template <class SEL>
-__device__ __forceinline__ bool knn5_grid_sel(const GridView& g, float qx, float qy, float qz, float bound, Top5& best) {
+template <class SEL, class TAB>
+__device__ __forceinline__ bool knn5_grid_sel(const GridView& g, TAB& tab, float qx, float qy, float qz, float bound, Top5& best) {
     SEL sel; sel.init(bound);
     sel.to_top5(best);
     if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) return false;
@@ -376,8 +392,8 @@ __device__ __forceinline__ bool knn5_grid_sel(const GridView& g, float qx, float
     {
         const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
         if (x0 <= x1) {
-            // all nine row ranges are fetched before any row is scanned: 18 independent loads instead of nine
-            // load -> scan -> load hops on the critical path
+            // All nine row ranges are fetched at once (18 independent loads); the non-empty rows go to this thread's
+            // column of the LDS table in visiting order (centre, faces, diagonals) with their lower bounds.
             int rb[9], re[9];
 #pragma unroll
             for (int n = 0; n < 9; n++) {
@@ -388,12 +404,47 @@ __device__ __forceinline__ bool knn5_grid_sel(const GridView& g, float qx, float
                 const int b = cs[x0], e = cs[x1 + 1];
                 rb[n] = b; re[n] = in ? e : b;
             }
+            const int tid = threadIdx.x;
+            int cnt = 0;
 #pragma unroll
             for (int n = 0; n < 9; n++) {
                 const int w = row_order(n);
-                if (rb[n] >= re[n]) continue;
-                if (row_lower_bound(g, qy, qz, cy, cz, w / 3 - 1, w % 3 - 1) > sel.worst()) continue;
-                scan_run(g, sel, rb[n], re[n], qx, qy, qz);
+                if (rb[n] < re[n]) {
+                    tab.b[cnt][tid] = rb[n]; tab.e[cnt][tid] = re[n];
+                    tab.lb[cnt][tid] = row_lower_bound(g, qy, qz, cy, cz, w / 3 - 1, w % 3 - 1);
+                    cnt++;
+                }
+            }
+            // Each lane walks ITS OWN rows (a wave takes max-over-lanes of the summed trips, not the sum of per-row maxima)
+            // and the four loads of the next chunk are issued before the current chunk is processed.  The row for the
+            // next chunk is chosen with the 5th-best distance of one chunk ago: a stale (larger) value can only keep a
+            // row that the fresh one would prune — extra candidates, never a missing one.
+            int n = 0, cj = 0, ce = 0;
+            auto fetch = [&](float wv, float4& p0, float4& p1, float4& p2, float4& p3, int& pj, int& pe) {
+                while (cj >= ce && n < cnt) {
+                    const int b = tab.b[n][tid], e = tab.e[n][tid];
+                    const float lb = tab.lb[n][tid];
+                    n++;
+                    if (!(lb > wv)) { cj = b; ce = e; }
+                }
+                pj = cj; pe = ce;
+                if (cj < ce) {
+                    const int last = ce - 1;
+                    p0 = load_pt(g, cj); p1 = load_pt(g, min(cj + 1, last)); p2 = load_pt(g, min(cj + 2, last)); p3 = load_pt(g, min(cj + 3, last));
+                    cj += 4;
+                }
+            };
+            // two chunk buffers in ping-pong, so that the loads of one are in flight while the other is processed
+            float4 a0, a1, a2, a3, b0, b1, b2, b3;
+            int aj = 0, ae = 0, bj = 0, be = 0;
+            fetch(sel.worst(), a0, a1, a2, a3, aj, ae);
+            for (;;) {
+                if (!(aj < ae)) break;
+                fetch(sel.worst(), b0, b1, b2, b3, bj, be);
+                process_chunk(sel, a0, a1, a2, a3, aj, ae, qx, qy, qz);
+                if (!(bj < be)) break;
+                fetch(sel.worst(), a0, a1, a2, a3, aj, ae);
+                process_chunk(sel, b0, b1, b2, b3, bj, be, qx, qy, qz);
             }
         }
     }
@@ -437,21 +488,23 @@ __device__ __forceinline__ bool knn5_grid_sel(const GridView& g, float qx, float
 }
 // Fast selection first; the rare queries with an exact distance tie that could matter are repeated with the exact
 // (distance, original index) selector, so the result is always the oracle's.
-__device__ __forceinline__ void knn5_grid(const GridView& g, float qx, float qy, float qz, float bound, Top5& best) {
-    if (knn5_grid_sel<Sel5F>(g, qx, qy, qz, bound, best)) knn5_grid_sel<Sel5>(g, qx, qy, qz, bound, best);
+template <class TAB>
+__device__ __forceinline__ void knn5_grid(const GridView& g, TAB& tab, float qx, float qy, float qz, float bound, Top5& best) {
+    if (knn5_grid_sel<Sel5F>(g, tab, qx, qy, qz, bound, best)) knn5_grid_sel<Sel5>(g, tab, qx, qy, qz, bound, best);
 }
 
 // Correspondence counting without atomics on a shared word (3128 same-address atomics cost ~40 us on
 // MI355X): each block stores its own count; consumers add the <= few-thousand block counts themselves.
+template <int BS>
 __device__ __forceinline__ void store_block_count(bool ok, int* __restrict__ block_counts) {
-    __shared__ int wave_cnt[kBlock / 64];
+    __shared__ int wave_cnt[BS / 64];
     unsigned long long bal = __ballot(ok);
     if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = __popcll(bal);
     __syncthreads();
     if (threadIdx.x == 0) {
         int s = 0;
 #pragma unroll
-        for (int w = 0; w < kBlock / 64; w++) s += wave_cnt[w];
+        for (int w = 0; w < BS / 64; w++) s += wave_cnt[w];
         block_counts[blockIdx.x] = s;
     }
 }
@@ -644,7 +697,8 @@ struct TileLds {
     int scan[kBlock / 64 + 1];
 };
 
-__device__ __forceinline__ void knn5_tiled(const GridView& g, TileLds& L, bool live, float qx, float qy, float qz, Top5& best, int dbg) {
+template <class TAB>
+__device__ __forceinline__ void knn5_tiled(const GridView& g, TileLds& L, TAB& tab, bool live, float qx, float qy, float qz, Top5& best, int dbg) {
     const int tid = threadIdx.x;
     Sel5 sel; sel.init();
     sel.to_top5(best);
@@ -702,7 +756,7 @@ __device__ __forceinline__ void knn5_tiled(const GridView& g, TileLds& L, bool l
     }
     if (direct) {   // degenerate tile: per-thread search in global memory (identical candidate set)
         if (inr) {
-            Top5 t; knn5_grid(g, qx, qy, qz, __uint_as_float(0x7f800000u), t);
+            Top5 t; knn5_grid(g, tab, qx, qy, qz, __uint_as_float(0x7f800000u), t);
             best = t;
         }
         return;
@@ -779,13 +833,14 @@ __device__ __forceinline__ void knn5_tiled(const GridView& g, TileLds& L, bool l
     sel.to_top5(best);
 }
 
-template <bool TILED>
-__global__ __launch_bounds__(kBlock) void k_associate_surf(
+template <bool TILED, int BS>
+__global__ __launch_bounds__(BS) void k_associate_surf(
         const float4* __restrict__ queries, const int* __restrict__ perm, const int2* __restrict__ tiles, int n_q, GridView g, PoseArg pa, MatchParams P,
         float4* __restrict__ rec_nd, double* __restrict__ rec_score, unsigned char* __restrict__ valid,
         int* __restrict__ dbg_idx, float* __restrict__ dbg_d2, int* __restrict__ block_counts, int* __restrict__ nn_cache) {
     __shared__ TileLds L;
-    const int2 tile = tiles ? tiles[blockIdx.x] : make_int2(blockIdx.x * kBlock, min(kBlock, n_q - (int)blockIdx.x * kBlock));
+    __shared__ RowTabT<BS> tab;
+    const int2 tile = tiles ? tiles[blockIdx.x] : make_int2(blockIdx.x * BS, min(BS, n_q - (int)blockIdx.x * BS));
     const bool live = (int)threadIdx.x < tile.y;
     int t = tile.x + threadIdx.x;
     int i = live ? (perm ? perm[t] : t) : 0;
@@ -798,8 +853,8 @@ __global__ __launch_bounds__(kBlock) void k_associate_surf(
     if (P.debug & 2) {
 #pragma unroll
         for (int k = 0; k < 5; k++) { nn.d[k] = 0.01f * (k + 1); nn.j[k] = (i * 7 + k) % g.n_points; }
-    } else if (TILED) knn5_tiled(g, L, live, px, py, pz, nn, P.debug);
-    else if (live) { knn5_grid(g, px, py, pz, seeded_bound(g, P.kd_max_radius, nn_cache, n_q, i, px, py, pz), nn); store_nn_cache(nn_cache, n_q, i, nn); }
+    } else if (TILED) knn5_tiled(g, L, tab, live, px, py, pz, nn, P.debug);
+    else if (live) { knn5_grid(g, tab, px, py, pz, seeded_bound(g, P.kd_max_radius, nn_cache, n_q, i, px, py, pz), nn); store_nn_cache(nn_cache, n_q, i, nn); }
     bool ok = false;
     if (live) {
         store_debug_nn(g, nn, i, dbg_idx, dbg_d2);
@@ -809,16 +864,17 @@ __global__ __launch_bounds__(kBlock) void k_associate_surf(
         rec_score[i] = score;
         valid[i] = ok ? 1 : 0;
     }
-    store_block_count(ok, block_counts);
+    store_block_count<BS>(ok, block_counts);
 }
 
-template <bool TILED>
-__global__ __launch_bounds__(kBlock) void k_associate_edge(
+template <bool TILED, int BS>
+__global__ __launch_bounds__(BS) void k_associate_edge(
         const float4* __restrict__ queries, const int* __restrict__ perm, const int2* __restrict__ tiles, int n_q, GridView g, PoseArg pa, MatchParams P,
         float4* __restrict__ rec_a, float4* __restrict__ rec_b, unsigned char* __restrict__ valid,
         int* __restrict__ dbg_idx, float* __restrict__ dbg_d2, int* __restrict__ block_counts, int* __restrict__ nn_cache) {
     __shared__ TileLds L;
-    const int2 tile = tiles ? tiles[blockIdx.x] : make_int2(blockIdx.x * kBlock, min(kBlock, n_q - (int)blockIdx.x * kBlock));
+    __shared__ RowTabT<BS> tab;
+    const int2 tile = tiles ? tiles[blockIdx.x] : make_int2(blockIdx.x * BS, min(BS, n_q - (int)blockIdx.x * BS));
     const bool live = (int)threadIdx.x < tile.y;
     int t = tile.x + threadIdx.x;
     int i = live ? (perm ? perm[t] : t) : 0;
@@ -828,8 +884,8 @@ __global__ __launch_bounds__(kBlock) void k_associate_edge(
     d3 pmd = qrot(Q2, d3{(double)ql.x, (double)ql.y, (double)ql.z}) + T2;
     float px = (float)pmd.x, py = (float)pmd.y, pz = (float)pmd.z;
     Top5 nn;
-    if (TILED) knn5_tiled(g, L, live, px, py, pz, nn, P.debug);
-    else if (live) { knn5_grid(g, px, py, pz, seeded_bound(g, P.edge_gate, nn_cache, n_q, i, px, py, pz), nn); store_nn_cache(nn_cache, n_q, i, nn); }
+    if (TILED) knn5_tiled(g, L, tab, live, px, py, pz, nn, P.debug);
+    else if (live) { knn5_grid(g, tab, px, py, pz, seeded_bound(g, P.edge_gate, nn_cache, n_q, i, px, py, pz), nn); store_nn_cache(nn_cache, n_q, i, nn); }
     bool ok = false;
     if (live) {
         store_debug_nn(g, nn, i, dbg_idx, dbg_d2);
@@ -837,12 +893,16 @@ __global__ __launch_bounds__(kBlock) void k_associate_edge(
         ok = edge_fit(g, P, nn, px, py, pz, ra, rb);
         rec_a[i] = ra; rec_b[i] = rb; valid[i] = ok ? 1 : 0;
     }
-    store_block_count(ok, block_counts);
+    store_block_count<BS>(ok, block_counts);
 }
-template __global__ void k_associate_surf<true>(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, int*, int*);
-template __global__ void k_associate_surf<false>(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, int*, int*);
-template __global__ void k_associate_edge<true>(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, int*, int*);
-template __global__ void k_associate_edge<false>(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, int*, int*);
+#define LILI_ASSOC_ARGS_SURF const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, int*, int*
+#define LILI_ASSOC_ARGS_EDGE const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, int*, int*
+template __global__ void k_associate_surf<true, kBlock>(LILI_ASSOC_ARGS_SURF);
+template __global__ void k_associate_surf<false, kBlock>(LILI_ASSOC_ARGS_SURF);
+template __global__ void k_associate_surf<false, kAssocBlock>(LILI_ASSOC_ARGS_SURF);
+template __global__ void k_associate_edge<true, kBlock>(LILI_ASSOC_ARGS_EDGE);
+template __global__ void k_associate_edge<false, kBlock>(LILI_ASSOC_ARGS_EDGE);
+template __global__ void k_associate_edge<false, kAssocBlock>(LILI_ASSOC_ARGS_EDGE);
 
 // ================================================================================================
 // Linearisation: residual + 1x7 global Jacobian per record, loss corrector, Gram reduction.
@@ -905,6 +965,29 @@ struct GramAcc {
     }
 };
 
+// ---- fused tail: the LAST block of a linearisation launch to finish adds all block partials (fixed order, so the
+// result does not depend on which block that is) and, optionally, applies the Gauss-Newton update — one kernel
+// boundary less per outer iteration.  Release / acquire at device scope around a ticket counter in SlotState.
+__device__ void reduce_partials_block(const double* part_surf, int nb_surf, const double* part_edge, int nb_edge,
+                                      double* __restrict__ out, SlotState* __restrict__ state, int do_gn);   // defined below
+__device__ __forceinline__ void fused_tail(const FuseTail& fz) {
+    if (!fz.mode) return;
+    __shared__ int s_last;
+    __syncthreads();                          // the block's partial has been stored (by threads < 40)
+    if (threadIdx.x == 0) {
+        __threadfence();                      // release (cumulative over the barrier): the partial is visible device-wide
+        unsigned t = atomicAdd(&fz.state->ticket, 1u);
+        s_last = t == gridDim.x - 1 ? 1 : 0;
+        if (s_last) {
+            fz.state->ticket = 0;             // ready for the next launch (stream order)
+            __threadfence();                  // acquire: every other block's partial (invalidates this CU's L1 / the XCD's stale L2 lines)
+        }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    reduce_partials_block(fz.part_surf, fz.nb_surf, fz.part_edge, fz.nb_edge, fz.out, fz.state, fz.mode == 2);
+}
+
 __device__ __forceinline__ void load_body_pose(const PoseArg& pa, dq& Q, d3& T) {
     if (pa.state) { const double* s = pa.state->pose; T = d3{s[0], s[1], s[2]}; Q = dq{s[3], s[4], s[5], s[6]}; }
     else { T = d3{pa.t[0], pa.t[1], pa.t[2]}; Q = dq{pa.q[0], pa.q[1], pa.q[2], pa.q[3]}; }
@@ -913,7 +996,7 @@ __device__ __forceinline__ void load_body_pose(const PoseArg& pa, dq& Q, d3& T) 
 __global__ __launch_bounds__(kLinBlock) void k_linearize_surf(
         const float4* __restrict__ queries, int n_q, const float4* __restrict__ rec_nd, const double* __restrict__ rec_score,
         const unsigned char* __restrict__ valid, PoseArg pa, MatchParams P, const SlotState* __restrict__ state,
-        const int* __restrict__ block_counts, int n_bc, double* __restrict__ partials) {
+        const int* __restrict__ block_counts, int n_bc, double* partials, FuseTail fz) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     GramAcc ga; ga.init();
     dq Q; d3 T;
@@ -951,12 +1034,13 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize_surf(
         ga.add_rows(Jr, cost, ok, lds);
     }
     ga.finish(lds, partials + (size_t)blockIdx.x * kPartialDoubles);
+    fused_tail(fz);
 }
 
 __global__ __launch_bounds__(kLinBlock) void k_linearize_edge(
         const float4* __restrict__ queries, int n_q, const float4* __restrict__ rec_a, const float4* __restrict__ rec_b,
         const unsigned char* __restrict__ valid, PoseArg pa, MatchParams P, const SlotState* __restrict__ state,
-        const int* __restrict__ block_counts, int n_bc, double* __restrict__ partials) {
+        const int* __restrict__ block_counts, int n_bc, double* partials, FuseTail fz) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     GramAcc ga; ga.init();
     dq Q; d3 T;
@@ -994,6 +1078,7 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize_edge(
         ga.add_rows(Jr, cost, ok, lds);
     }
     ga.finish(lds, partials + (size_t)blockIdx.x * kPartialDoubles);
+    fused_tail(fz);
 }
 
 // ================================================================================================
@@ -1101,9 +1186,9 @@ __device__ void gn_update_block(const double* gram /*LDS or global, 64+*/, SlotS
 }
 
 constexpr int kReduceThreads = 1024;
-__global__ __launch_bounds__(kReduceThreads) void k_reduce_partials(const double* __restrict__ part_surf, int nb_surf,
-                                                            const double* __restrict__ part_edge, int nb_edge,
-                                                            double* __restrict__ out, SlotState* __restrict__ state, int do_gn) {
+// all kReduceThreads threads of ONE block; partials may have been written by other blocks of the same launch (fused tail)
+__device__ void reduce_partials_block(const double* part_surf, int nb_surf, const double* part_edge, int nb_edge,
+                                      double* __restrict__ out, SlotState* __restrict__ state, int do_gn) {
     constexpr int kGroups = kReduceThreads / 40;   // 25 groups of 40 lanes, group g adds partials g, g+25, ...
     __shared__ double acc[kGroups][2][40];
     __shared__ double tri[40];
@@ -1147,6 +1232,12 @@ __global__ __launch_bounds__(kReduceThreads) void k_reduce_partials(const double
     __syncthreads();
     if (threadIdx.x < 72) out[threadIdx.x] = full[threadIdx.x];
     if (do_gn) gn_update_block(full, state);
+}
+
+__global__ __launch_bounds__(kReduceThreads) void k_reduce_partials(const double* __restrict__ part_surf, int nb_surf,
+                                                            const double* __restrict__ part_edge, int nb_edge,
+                                                            double* __restrict__ out, SlotState* __restrict__ state, int do_gn) {
+    reduce_partials_block(part_surf, nb_surf, part_edge, nb_edge, out, state, do_gn);
 }
 
 __global__ void k_gn_update(const double* __restrict__ gram, SlotState* __restrict__ state) {
