@@ -172,6 +172,17 @@ def main():
     m.pose_set(1, t0, q0)       # slot 1 only holds the initial guess; slot 0 is restarted from it on the device
     ips = max(1, args.iters_per_scan)
 
+    if os.environ.get("LILI_PHASES"):
+        os.environ["LILI_DEBUG"] = "256"
+        m.iterate(0, 8, L.MASK_SURF)
+        tp = m.debug_times(0)
+        names = {0: "lin start", 1: "lin counts+loads done", 2: "lin math done", 3: "lin gram done", 4: "lin partial stored",
+                 8: "red start", 9: "red loads done", 10: "red record built", 11: "red gn done"}
+        base = tp[0]
+        for k in sorted(names):
+            print(f"{names[k]:26s} {(tp[k] - base) * 0.01:8.2f} us", file=sys.stderr)
+        ctx.close()
+        return
     if args.assoc_only:
         m.iterate(0, args.assoc_after, L.MASK_SURF)
         torch.cuda.synchronize()
@@ -234,12 +245,27 @@ def main():
     # ---------------- roofline of the dominant kernel (k_associate_surf), HIP events on its stream ----------------
     roofline = None
     if rank == 0:
-        # same schedule as the timed region (restart every `ips` steps), association launches bracketed by HIP events
-        # on the context's stream inside the C library; average over all launches of that schedule
+        # The poses the association kernel sees over the timed schedule (restart every `ips` steps) are logged first;
+        # then exactly those launches are replayed back to back on the context's stream between ONE pair of HIP events,
+        # so the per-launch figure carries no inter-kernel event overhead and is comparable with rocprofv3's average.
         reps = max(2 * ips, min(args.steps, 200))
-        m.iterate_restart(0, ips, ips, 1, L.MASK_SURF)
-        ms = m.iterate_restart(0, reps, ips, 1, L.MASK_SURF, time_association=True)
-        dt = ms * 1e-3 / reps
+        poses = []
+        for it in range(reps):
+            if it % ips == 0:
+                m.pose_copy(0, 1)
+            tl, ql, _ = m.pose_get(0)
+            poses.append(L.api.assoc_transform(tl, ql, P))
+            m.iterate(0, 1, L.MASK_SURF)
+        for Q2, T2 in poses[:5]:
+            m.find_corresponding_surf_features(0, Q2, T2, want_count=False)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for Q2, T2 in poses:
+            m.find_corresponding_surf_features(0, Q2, T2, want_count=False)
+        e1.record()
+        torch.cuda.synchronize()
+        dt = e0.elapsed_time(e1) * 1e-3 / reps
         alg_bytes = BYTES_PER_QUERY * queries.shape[0]
         achieved = alg_bytes / dt / 1e9
         traffic = None

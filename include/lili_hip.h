@@ -251,6 +251,8 @@ int lili_s2m_gn_update(lili_ctx* ctx, int slot, const double* d_gram);
 /* Convenience: n_iters x (accumulate + gn_update) on an internal buffer.  Async. */
 int lili_s2m_iterate(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, int n_iters);
 
+/* Profiling aid: with LILI_DEBUG bit 256 set, kernels stamp a 100 MHz device clock at their phases; returns the 16 stamps. */
+int lili_s2m_debug_times(lili_ctx* ctx, int slot, long long out[16]);
 /* Async device-to-device copy of the body pose of src_slot into dst_slot (no host round trip). */
 int lili_s2m_pose_copy(lili_ctx* ctx, int dst_slot, int src_slot);
 /* lili_s2m_iterate that re-initialises the pose from restart_slot before iterations 0, restart_every, 2*restart_every...

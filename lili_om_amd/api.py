@@ -121,6 +121,7 @@ _SIGS = {
     "lili_s2m_linearize_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams), C.c_void_p]),
     "lili_s2m_gn_update": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "lili_s2m_iterate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams), C.c_int]),
+    "lili_s2m_debug_times": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_longlong)]),
     "lili_s2m_pose_copy": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "lili_s2m_iterate_restart": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "lili_gn_step_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -328,6 +329,11 @@ class ScanToMapMatcher:
 
     def gn_update(self, slot, d_gram_ptr):
         self.ctx._chk(self.lib.lili_s2m_gn_update(self.ctx.h, slot, C.c_void_p(d_gram_ptr)))
+
+    def debug_times(self, slot):
+        out = (C.c_longlong * 16)()
+        self.ctx._chk(self.lib.lili_s2m_debug_times(self.ctx.h, slot, out))
+        return list(out)
 
     def pose_copy(self, dst_slot, src_slot):
         self.ctx._chk(self.lib.lili_s2m_pose_copy(self.ctx.h, dst_slot, src_slot))

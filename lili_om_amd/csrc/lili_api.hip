@@ -419,7 +419,7 @@ static int launch_linearize_reduce(lili_ctx* ctx, int slot, int kind_mask, const
         if (rc != LILI_OK) return rc;
     }
     if (last_kind < 0 || !ctx->fuse_tail) {
-        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx->stream, fz.part_surf, fz.nb_surf, fz.part_edge, fz.nb_edge, d_out, ctx->state(slot), do_gn);
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx->stream, fz.part_surf, fz.nb_surf, fz.part_edge, fz.nb_edge, d_out, ctx->state(slot), (do_gn ? 1 : 0) | (P.debug & 256));
         HIPCHK(hipGetLastError());
     }
     return LILI_OK;
@@ -581,6 +581,18 @@ int lili_s2m_pose_get(lili_ctx* ctx, int slot, double t[3], double q[4], int* gn
     return LILI_OK;
 }
 
+// profiling aid (LILI_DEBUG bit 256): the 16 device timestamps (100 MHz ticks) of the slot's last launches
+int lili_s2m_debug_times(lili_ctx* ctx, int slot, long long out[16]) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS && out, "debug_times: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    SlotState s{};
+    HIPCHK(hipMemcpyAsync(&s, ctx->state(slot), sizeof(s), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 16; i++) out[i] = s.tprof[i];
+    return LILI_OK;
+}
+
 int lili_s2m_associate_dev(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params) {
     if (!ctx) return LILI_E_ARG;
     ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS, "associate_dev: bad slot");
@@ -720,16 +732,23 @@ int lili_gn_step_host(const double gram[64], double t[3], double q[4], double de
         double s = 0; for (int i = 0; i < 7; i++) s += Pm[i][a] * gram[i * 8 + 7];
         g[a] = -s;
     }
+    // LDL^T with reciprocal pivots, the same operation order as gn_update_block on the device
+    double W[6][6], dinv[6];
     for (int j = 0; j < 6; j++) {
-        double d = H[j][j];
-        for (int k = 0; k < j; k++) d -= H[j][k] * H[j][k];
-        if (!(d > 0)) return 1;
-        d = std::sqrt(d); H[j][j] = d;
-        for (int i = j + 1; i < 6; i++) { double s = H[i][j]; for (int k = 0; k < j; k++) s -= H[i][k] * H[j][k]; H[i][j] = s / d; }
+        double dj = H[j][j];
+        for (int k = 0; k < j; k++) dj -= H[j][k] * W[j][k];
+        if (!(dj > 0)) return 1;
+        dinv[j] = 1.0 / dj;
+        for (int i = j + 1; i < 6; i++) {
+            double sv = H[i][j];
+            for (int k = 0; k < j; k++) sv -= H[i][k] * W[j][k];
+            W[i][j] = sv; H[i][j] = sv * dinv[j];
+        }
     }
     double d[6];
-    for (int i = 0; i < 6; i++) { double s = g[i]; for (int k = 0; k < i; k++) s -= H[i][k] * d[k]; d[i] = s / H[i][i]; }
-    for (int i = 5; i >= 0; i--) { double s = d[i]; for (int k = i + 1; k < 6; k++) s -= H[k][i] * d[k]; d[i] = s / H[i][i]; }
+    for (int i = 0; i < 6; i++) { double sv = g[i]; for (int k = 0; k < i; k++) sv -= H[i][k] * d[k]; d[i] = sv; }
+    for (int i = 0; i < 6; i++) d[i] = d[i] * dinv[i];
+    for (int i = 5; i >= 0; i--) { double sv = d[i]; for (int k = i + 1; k < 6; k++) sv -= H[k][i] * d[k]; d[i] = sv; }
     for (int i = 0; i < 6; i++) if (!(d[i] == d[i])) return 1;
     if (delta) for (int i = 0; i < 6; i++) delta[i] = d[i];
     t[0] += d[0]; t[1] += d[1]; t[2] += d[2];

@@ -27,6 +27,7 @@ struct SlotState {
     int gn_status;    // 0 ok, 1 = normal matrix not positive definite (pose left unchanged)
     int iters;        // GN updates applied since pose_set
     double last_delta[6];
+    long long tprof[16];   // profiling aid (LILI_DEBUG bit 256): s_memrealtime stamps (100 MHz) of one block per kernel
     unsigned int ticket;   // fused tail of the linearisation kernels: blocks finished so far (self-resetting)
 };
 

@@ -922,6 +922,11 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 // sum of the costs.  This is a reduction, not a GEMM re-shaping of the path: the 16 MFMAs replace a 64-step
 // LDS loop; summation order is fixed by the hardware, so results stay deterministic.
 // C/D layout of the f64 form: col = lane & 15, row = (lane >> 4) + 4 * reg (cdna_hip_programming.md §3).
+// profiling aid: thread 0 of one probe block stamps the constant 100 MHz clock into SlotState::tprof[slot]
+__device__ __forceinline__ void tstamp(const SlotState* state, int debug, int probe_block, int slot) {
+    if ((debug & 256) && (int)blockIdx.x == probe_block && threadIdx.x == 0)
+        const_cast<SlotState*>(state)->tprof[slot] = (long long)__builtin_amdgcn_s_memrealtime();
+}
 struct GramAcc {
     v4f64 acc;
     __device__ __forceinline__ void init() { acc = v4f64{0.0, 0.0, 0.0, 0.0}; }
@@ -998,23 +1003,34 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize_surf(
         const unsigned char* __restrict__ valid, PoseArg pa, MatchParams P, const SlotState* __restrict__ state,
         const int* __restrict__ block_counts, int n_bc, double* partials, FuseTail fz) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    tstamp(state, P.debug, 100, 0);
     GramAcc ga; ga.init();
     dq Q; d3 T;
     load_body_pose(pa, Q, T);
     const dq qlb_inv = qinv(dq{P.q_lb[0], P.q_lb[1], P.q_lb[2], P.q_lb[3]});
     // N of R:861: this rank's count (sum of the association's block counts) or, when a multi-GPU caller has
     // all-reduced it, the global count in state->n_res
+    // the first tile's records are requested before the count reduction below (which synchronises the block twice), and
+    // unconditionally — one memory round trip instead of valid -> record
+    const int i0 = blockIdx.x * kLinBlock + threadIdx.x;
+    const int i0c = min(i0, n_q - 1);
+    unsigned char v0 = valid[i0c];
+    float4 ql0 = queries[i0c], nd0 = rec_nd[i0c];
+    double sc0 = rec_score[i0c];
     double nscale = 1.0;
     if (P.debug & 128) nscale = 1000.0 / 190000.0;
     else if (P.scale_surf_num > 0) nscale = P.scale_surf_num / (double)(block_counts ? sum_block_counts(block_counts, n_bc) : state->n_res[0]);
+    tstamp(state, P.debug, 100, 1);
     for (int base = blockIdx.x * kLinBlock; base < n_q; base += gridDim.x * kLinBlock) {
         int i = base + threadIdx.x;
-        bool ok = i < n_q && valid[i];
+        const bool first = base == (int)blockIdx.x * kLinBlock;
+        const int ic = min(i, n_q - 1);
+        bool ok = i < n_q && (first ? v0 : valid[ic]);
         double Jr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         double cost = 0.0;
         if (ok) {
-            float4 ql = queries[i]; float4 nd = rec_nd[i];
-            double score = rec_score[i];
+            float4 ql = first ? ql0 : queries[i]; float4 nd = first ? nd0 : rec_nd[i];
+            double score = first ? sc0 : rec_score[i];
             if (P.scale_surf_num > 0) score = score * nscale;
             d3 cp{(double)ql.x, (double)ql.y, (double)ql.z};
             d3 n{(double)nd.x, (double)nd.y, (double)nd.z};
@@ -1031,9 +1047,12 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize_surf(
             for (int k = 0; k < 7; k++) Jr[k] = J[k];
             Jr[7] = r;
         }
+        tstamp(state, P.debug, 100, 2);
         ga.add_rows(Jr, cost, ok, lds);
+        tstamp(state, P.debug, 100, 3);
     }
     ga.finish(lds, partials + (size_t)blockIdx.x * kPartialDoubles);
+    tstamp(state, P.debug, 100, 4);
     fused_tail(fz);
 }
 
@@ -1090,13 +1109,14 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize_edge(
 //   P = blockdiag(I3, plusJacobian(q) 4x3); H = P^T G77 P, g = P^T G7r; solve H d = -g (Cholesky);
 //   t += d[0:3]; q = [cos|dq|, sin|dq|/|dq| dq] (x) q
 // ================================================================================================
-__device__ void gn_update_block(const double* gram /*LDS or global, 64+*/, SlotState* __restrict__ state) {
+// xq: the quaternion of state->pose, loaded by the caller at kernel start (its latency hides behind the partial loads)
+__device__ void gn_update_block(const double* gram /*LDS or global, 64+*/, SlotState* __restrict__ state, const double xq[4]) {
     __shared__ double Jq[4][3];   // plus-Jacobian rows: [-x1 -x2 -x3; x0 x3 -x2; -x3 x0 x1; x2 -x1 x0]
     __shared__ double M[7][6];    // M = G77 * P   (P = blockdiag(I3, Jq): only 4 terms per entry)
     __shared__ double H[6][6];
     __shared__ double gvec[6];
     int tid = threadIdx.x;
-    const double x0 = state->pose[3], x1 = state->pose[4], x2 = state->pose[5], x3 = state->pose[6];
+    const double x0 = xq[0], x1 = xq[1], x2 = xq[2], x3 = xq[3];
     if (tid < 12) {
         int rr = tid / 3, cc = tid % 3;
         double e0 = rr == 0 ? -x1 : rr == 1 ? x0 : rr == 2 ? -x3 : x2;
@@ -1128,8 +1148,10 @@ __device__ void gn_update_block(const double* gram /*LDS or global, 64+*/, SlotS
     }
     __syncthreads();
     if (tid == 0) {
-        // 6x6 Cholesky solve entirely in registers (all indices are compile-time constants after unrolling)
-        double L[6][6], d[6];
+        // 6x6 LDL^T solve entirely in registers (all indices are compile-time constants after unrolling): six dependent
+        // divisions (1/d_j) instead of the 6 square roots + 27 divisions of a Cholesky with per-element divides — the
+        // f64 divide / sqrt sequences dominated this kernel's critical path
+        double L[6][6], W[6][6], dinv[6], d[6];
 #pragma unroll
         for (int i = 0; i < 6; i++) {
             d[i] = gvec[i];
@@ -1141,30 +1163,33 @@ __device__ void gn_update_block(const double* gram /*LDS or global, 64+*/, SlotS
         for (int j = 0; j < 6; j++) {
             double dj = L[j][j];
 #pragma unroll
-            for (int k = 0; k < j; k++) dj -= L[j][k] * L[j][k];
+            for (int k = 0; k < j; k++) dj -= L[j][k] * W[j][k];     // W[j][k] = L[j][k] * d_k
             if (!(dj > 0)) okc = false;
-            dj = sqrt(dj); L[j][j] = dj;
+            dinv[j] = 1.0 / dj;
 #pragma unroll
             for (int i = j + 1; i < 6; i++) {
                 double sv = L[i][j];
 #pragma unroll
-                for (int k = 0; k < j; k++) sv -= L[i][k] * L[j][k];
-                L[i][j] = sv / dj;
+                for (int k = 0; k < j; k++) sv -= L[i][k] * W[j][k];
+                W[i][j] = sv;
+                L[i][j] = sv * dinv[j];
             }
         }
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
+        for (int i = 0; i < 6; i++) {          // L z = g
             double sv = d[i];
 #pragma unroll
             for (int k = 0; k < i; k++) sv -= L[i][k] * d[k];
-            d[i] = sv / L[i][i];
+            d[i] = sv;
         }
 #pragma unroll
-        for (int i = 5; i >= 0; i--) {
+        for (int i = 0; i < 6; i++) d[i] = d[i] * dinv[i];   // D y = z
+#pragma unroll
+        for (int i = 5; i >= 0; i--) {         // L^T x = y
             double sv = d[i];
 #pragma unroll
             for (int k = i + 1; k < 6; k++) sv -= L[k][i] * d[k];
-            d[i] = sv / L[i][i];
+            d[i] = sv;
         }
 #pragma unroll
         for (int i = 0; i < 6; i++) if (!(d[i] == d[i])) okc = false;
@@ -1189,6 +1214,8 @@ constexpr int kReduceThreads = 1024;
 // all kReduceThreads threads of ONE block; partials may have been written by other blocks of the same launch (fused tail)
 __device__ void reduce_partials_block(const double* part_surf, int nb_surf, const double* part_edge, int nb_edge,
                                       double* __restrict__ out, SlotState* __restrict__ state, int do_gn) {
+    tstamp(state, do_gn, 0, 8);
+    const double xq[4] = {state->pose[3], state->pose[4], state->pose[5], state->pose[6]};
     constexpr int kGroups = kReduceThreads / 40;   // 25 groups of 40 lanes, group g adds partials g, g+25, ...
     __shared__ double acc[kGroups][2][40];
     __shared__ double tri[40];
@@ -1213,6 +1240,7 @@ __device__ void reduce_partials_block(const double* part_surf, int nb_surf, cons
         }
         acc[g][0][e] = s; acc[g][1][e] = s2;
     }
+    tstamp(state, do_gn, 0, 9);
     __syncthreads();
     if (threadIdx.x < 40) {
         int k = threadIdx.x;
@@ -1231,7 +1259,9 @@ __device__ void reduce_partials_block(const double* part_surf, int nb_surf, cons
     if (threadIdx.x >= 67 && threadIdx.x < 72) full[threadIdx.x] = 0.0;
     __syncthreads();
     if (threadIdx.x < 72) out[threadIdx.x] = full[threadIdx.x];
-    if (do_gn) gn_update_block(full, state);
+    tstamp(state, do_gn, 0, 10);
+    if (do_gn & 1) gn_update_block(full, state, xq);
+    tstamp(state, do_gn, 0, 11);
 }
 
 __global__ __launch_bounds__(kReduceThreads) void k_reduce_partials(const double* __restrict__ part_surf, int nb_surf,
@@ -1241,7 +1271,8 @@ __global__ __launch_bounds__(kReduceThreads) void k_reduce_partials(const double
 }
 
 __global__ void k_gn_update(const double* __restrict__ gram, SlotState* __restrict__ state) {
-    gn_update_block(gram, state);
+    const double xq[4] = {state->pose[3], state->pose[4], state->pose[5], state->pose[6]};
+    gn_update_block(gram, state, xq);
 }
 
 }  // namespace lili
