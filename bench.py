@@ -173,6 +173,13 @@ def main():
     ips = max(1, args.iters_per_scan)
 
     if os.environ.get("LILI_PHASES"):
+        if os.environ["LILI_PHASES"] == "waves":
+            os.environ["LILI_DEBUG"] = "512"
+            m.iterate(0, 8, L.MASK_SURF)
+            tp = m.debug_times(0)
+            print("wave gram-done times (us after block start):", [round((x - tp[15]) * 0.01, 2) for x in tp[:13]], file=sys.stderr)
+            ctx.close()
+            return
         os.environ["LILI_DEBUG"] = "256"
         m.iterate(0, 8, L.MASK_SURF)
         tp = m.debug_times(0)

@@ -269,6 +269,42 @@ int lili_gn_step_host(const double gram[64], double t[3], double q[4], double de
  * J^T J, J^T r and cost equal those of the N robustified lidar residuals the Gram was reduced from. */
 int lili_gram_to_factor(const double gram[64], double cost, double residuals[9], double jacobian[63]);
 
+/* ---- callers / data formats either side of the path ------------------------- */
+
+/* Livox CustomMsg points -> the PointXYZINormal cloud the Livox extractor consumes; replaces livoxLidarHandler
+ * (L/src/FormatConvert.cpp:11-35).  `points` = point_num records of the serialised livox_ros_driver/CustomPoint
+ * (little endian: uint32 offset_time, float32 x, y, z, uint8 reflectivity, tag, line; `stride` >= 19 bytes).
+ * Output: pcl::PointXYZINormal records (48 B: x y z 1.0 | normal 0 0 0 0 | intensity curvature 0 0) with
+ *   intensity = line + 0.1 * (float(offset_time) / float(offset_time of the LAST point)),  curvature = 0.1 * reflectivity
+ * (float / double expression widths of the reference).  in_mem / out_mem: LILI_MEM_HOST or LILI_MEM_DEVICE; the output
+ * can be handed to lili_extract_livox as {data = out, stride = 48, aux_offset = 32, curvature_offset = 36}.  Blocking for
+ * host memory, asynchronous on the context's stream when both sides are device memory. */
+int lili_livox_custom_to_cloud(lili_ctx* ctx, const void* points, size_t point_num, size_t stride, int in_mem, void* out, int out_mem);
+
+/* Gyro integration over one scan, host side (L/src/Preprocessing.cpp:129-171 processIMU / solveRotation, 176-191
+ * imuHandler state, 232-234 NaN reset, 403 identity reset; deltaQ = utils/math_tools.h:125-138): mid-point rule on the
+ * un-normalised small-angle quaternion, linear interpolation of the rate at the scan boundary.  The caller keeps the IMU
+ * samples (stamps[n] seconds, gyr[n*3] rad/s, in arrival order, n may grow between calls) and one lili_imu_state per
+ * sensor; q_out (w,x,y,z) is the q_imu argument of lili_extract_livox / lili_extract_rot for the scan ending at
+ * t_scan_next.  Zero-initialise the state (or lili_imu_reset) before the first call. */
+typedef struct lili_imu_state {
+    int64_t idx;        /* idx_imu: first sample not yet consumed */
+    double t_cur;       /* current_time_imu (< 0: unset) */
+    double gyr0[3];     /* gyr_0 */
+    int32_t first;      /* first_imu seen */
+    int32_t reserved;
+} lili_imu_state;
+void lili_imu_reset(lili_imu_state* st);
+int lili_imu_integrate(lili_imu_state* st, const double* stamps, const double* gyr, size_t n, double t_scan_next, double q_out[4]);
+
+/* Lidar contribution of one keyframe to MarginalizationInfo's A, b (L/src/MarginalizationFactor.cpp:3-29, 151-174):
+ * the reference evaluates every lidar residual again and adds J_i^T J_j / J_i^T r per block with rightCols(3) of the
+ * 1x4 quaternion Jacobian; the same sums are rows / columns {0,1,2} (t) and {4,5,6} (q: x,y,z) of the Gram record
+ * and its column 7.  A is a dense pos x pos matrix with leading dimension ld (symmetric: both triangles are
+ * updated, so row- and column-major callers are served alike), b has pos entries; idx_t / idx_q are
+ * parameter_block_idx of the keyframe's translation / rotation block.  Host function. */
+int lili_marg_add_lidar(const double gram[64], double* A, size_t ld, double* b, size_t pos, size_t idx_t, size_t idx_q);
+
 #ifdef __cplusplus
 }
 #endif

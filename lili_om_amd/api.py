@@ -124,6 +124,10 @@ _SIGS = {
     "lili_s2m_debug_times": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_longlong)]),
     "lili_s2m_pose_copy": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "lili_s2m_iterate_restart": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "lili_livox_custom_to_cloud": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_int]),
+    "lili_imu_reset": (None, [C.c_void_p]),
+    "lili_imu_integrate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_void_p]),
+    "lili_marg_add_lidar": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t]),
     "lili_gn_step_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lili_gram_to_factor": (C.c_int, [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
 }
@@ -522,3 +526,55 @@ def body_pose_from_lidar(t_lidar, q_lidar, params):
                   a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1]])
     _, T2 = assoc_transform([0.0, 0.0, 0.0], Q, params)
     return np.asarray(t_lidar, np.float64) - T2, Q
+
+
+# ------------------------------------------------------------------------------------------------
+# callers / data formats either side of the path
+# ------------------------------------------------------------------------------------------------
+CUSTOM_POINT = np.dtype([("offset_time", "<u4"), ("x", "<f4"), ("y", "<f4"), ("z", "<f4"),
+                         ("reflectivity", "u1"), ("tag", "u1"), ("line", "u1")])   # livox_ros_driver/CustomPoint, 19 B
+
+
+def livox_custom_to_cloud(ctx, points):
+    """Livox CustomMsg points (CUSTOM_POINT array or raw bytes, 19 B each) -> (n, 12) float32 PointXYZINormal rows
+    (L/src/FormatConvert.cpp:11-35), converted on the device."""
+    pts = np.ascontiguousarray(np.asarray(points, dtype=CUSTOM_POINT))
+    n = pts.shape[0]
+    out = np.zeros((n, 12), np.float32)
+    ctx._chk(ctx.lib.lili_livox_custom_to_cloud(ctx.h, pts.ctypes.data if n else None, n, CUSTOM_POINT.itemsize, MEM_HOST,
+                                                out.ctypes.data if n else None, MEM_HOST))
+    return out
+
+
+class ImuState(C.Structure):
+    _fields_ = [("idx", C.c_int64), ("t_cur", C.c_double), ("gyr0", C.c_double * 3), ("first", C.c_int32), ("reserved", C.c_int32)]
+
+
+class ImuIntegrator:
+    """Host-side gyro integration over one scan (L/src/Preprocessing.cpp:129-171); returns q_imu (w,x,y,z)."""
+
+    def __init__(self):
+        self.lib = load_library()
+        self.state = ImuState()
+        self.lib.lili_imu_reset(C.byref(self.state))
+
+    def integrate(self, stamps, gyr, t_scan_next):
+        st = np.ascontiguousarray(stamps, dtype=np.float64)
+        g = np.ascontiguousarray(gyr, dtype=np.float64).reshape(-1, 3)
+        q = np.zeros(4, np.float64)
+        rc = self.lib.lili_imu_integrate(C.byref(self.state), st.ctypes.data if st.size else None, g.ctypes.data if g.size else None,
+                                         st.shape[0], float(t_scan_next), q.ctypes.data)
+        if rc != 0:
+            raise LiliError(f"lili_imu_integrate failed ({rc})")
+        return q
+
+
+def marg_add_lidar(gram, A, b, idx_t, idx_q):
+    """Adds the lidar blocks of one keyframe's Gram record into MarginalizationInfo's dense A (pos x pos, C order), b."""
+    lib = load_library()
+    G = np.ascontiguousarray(gram, dtype=np.float64).reshape(64)
+    assert A.flags.c_contiguous and A.dtype == np.float64 and b.dtype == np.float64 and A.shape[0] == A.shape[1] == b.shape[0]
+    rc = lib.lili_marg_add_lidar(G.ctypes.data, A.ctypes.data, A.shape[1], b.ctypes.data, A.shape[0], int(idx_t), int(idx_q))
+    if rc != 0:
+        raise LiliError(f"lili_marg_add_lidar failed ({rc})")
+    return A, b

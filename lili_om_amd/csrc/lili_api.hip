@@ -135,7 +135,7 @@ int lili_set_option(lili_ctx* ctx, const char* name, int value) {
     if (std::strcmp(name, "grid_reach") == 0) { if (value != 1 && value != 2) return ctx->fail(LILI_E_ARG, "grid_reach must be 1 or 2"); ctx->grid_reach = value; return LILI_OK; }
     if (std::strcmp(name, "cell_pct") == 0) { if (value < 50 || value > 100) return ctx->fail(LILI_E_ARG, "cell_pct must be in 50..100"); ctx->cell_pct = value; return LILI_OK; }
     if (std::strcmp(name, "tiled") == 0) { ctx->tiled = value != 0; return LILI_OK; }
-    if (std::strcmp(name, "fuse_tail") == 0) { ctx->fuse_tail = value != 0; return LILI_OK; }
+    if (std::strcmp(name, "fuse_tail") == 0) { ctx->fuse_tail = value != 0; return LILI_OK; }   // takes effect at the next set_queries
     if (std::strcmp(name, "nn_cache") == 0) { ctx->nn_cache = value != 0; for (auto& s : ctx->slots) for (auto& k : s.k) k.nn_cache_valid = false; return LILI_OK; }
     if (std::strcmp(name, "max_cells") == 0) { if (value < 1) return ctx->fail(LILI_E_ARG, "max_cells must be positive"); ctx->max_cells = value; return LILI_OK; }
     return ctx->fail(LILI_E_ARG, std::string("unknown option ") + name);
@@ -245,7 +245,10 @@ int lili_s2m_set_queries(lili_ctx* ctx, int slot, int kind, const lili_cloud* cl
     if (rc != LILI_OK) return rc;
     ks.n_q = (int64_t)cloud->n;
     ks.n_blocks = nblocks(ks.n_q, kAssocBlock);
-    ks.n_lin_blocks = std::min(nblocks(ks.n_q, kLinBlock), kMaxLinBlocks);
+    // one linearisation block per CU where possible: threads = n_q / 256 rounded up to a wave multiple, within [256, 1024]
+    // (the fused-tail option needs the full 1024 threads for its reduction)
+    ks.lin_threads = ctx->fuse_tail ? kLinBlock : std::min(kLinBlock, std::max(256, (int)((ks.n_q + 256 * 64 - 1) / (256 * 64)) * 64));
+    ks.n_lin_blocks = std::min(nblocks(ks.n_q, ks.lin_threads), kMaxLinBlocks);
     size_t n = (size_t)ks.n_q;
     if (n) {
         HIPCHK(ks.rec0.ensure(n * sizeof(float4)));
@@ -378,10 +381,10 @@ static int launch_linearize(lili_ctx* ctx, int slot, int kind, const PoseArg& pa
     const int n = (int)ks.n_q;
     const int* bc = ctx->slots[slot].use_global_counts ? nullptr : ks.block_counts.as<int>();
     if (kind == LILI_KIND_SURF)
-        hipLaunchKernelGGL(k_linearize_surf, dim3(ks.n_lin_blocks), dim3(kLinBlock), kLdsLinearize, ctx->stream, ks.q.as<float4>(), n, ks.rec0.as<float4>(),
+        hipLaunchKernelGGL(k_linearize_surf, dim3(ks.n_lin_blocks), dim3(ks.lin_threads), lds_linearize(ks.lin_threads), ctx->stream, ks.q.as<float4>(), n, ks.rec0.as<float4>(),
                            ks.rec1.as<double>(), ks.valid.as<unsigned char>(), pa, P, ctx->state(slot), bc, ks.n_assoc_blocks, ks.partials.as<double>(), fz);
     else
-        hipLaunchKernelGGL(k_linearize_edge, dim3(ks.n_lin_blocks), dim3(kLinBlock), kLdsLinearize, ctx->stream, ks.q.as<float4>(), n, ks.rec0.as<float4>(),
+        hipLaunchKernelGGL(k_linearize_edge, dim3(ks.n_lin_blocks), dim3(ks.lin_threads), lds_linearize(ks.lin_threads), ctx->stream, ks.q.as<float4>(), n, ks.rec0.as<float4>(),
                            ks.rec1.as<float4>(), ks.valid.as<unsigned char>(), pa, P, ctx->state(slot), bc, ks.n_assoc_blocks, ks.partials.as<double>(), fz);
     HIPCHK(hipGetLastError());
     return LILI_OK;

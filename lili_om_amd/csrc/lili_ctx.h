@@ -49,6 +49,7 @@ struct KindSlot {
     bool binned = false;   // perm holds the super-cell (Morton) order of the queries for the current scan
     int n_blocks = 0;      // association grid (one thread per query)
     int n_lin_blocks = 0;  // linearisation grid (grid-stride, <= kMaxLinBlocks partials)
+    int lin_threads = 1024; // linearisation block: multiple of 64 chosen so that ~all 256 CUs get one block each
 };
 
 struct Slot {
@@ -58,7 +59,7 @@ struct Slot {
 
 constexpr int kLinBlock = 1024;      // must match lili_s2m.hip
 constexpr int kMaxLinBlocks = 256;
-constexpr size_t kLdsLinearize = (size_t)(kLinBlock * 10) * sizeof(double);   // rows [J r 1 cost]; reused for the 16x16 wave results
+inline size_t lds_linearize(int threads) { return (size_t)threads * 10 * sizeof(double); }   // rows [J r 1 cost]; reused for the 16x16 wave results
 
 }  // namespace lili_detail
 using namespace lili_detail;
@@ -73,6 +74,7 @@ struct lili_ctx {
     Slot slots[LILI_MAX_SLOTS];
     DevBuf states;       // SlotState[LILI_MAX_SLOTS]
     DevBuf staging;      // raw host clouds
+    DevBuf fmt_out;      // lili_livox_custom_to_cloud output when the caller wants it on the host
     DevBuf gram;         // LILI_GRAM_DOUBLES per slot
     DevBuf misc;         // bbox words etc.
     DevBuf bin_hist, bin_start, bin_sums, bin_tcnt, bin_toff;   // query binning scratch

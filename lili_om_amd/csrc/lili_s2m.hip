@@ -913,7 +913,7 @@ template __global__ void k_associate_edge<false, kAssocBlock>(LILI_ASSOC_ARGS_ED
 // block writes one 40-double partial; k_reduce_gn adds the partials in a fixed order.
 // ================================================================================================
 constexpr int kRow = 10;          // LDS row: [J0..J6, r, 1, cost]
-constexpr int kLinBlock = 1024;   // linearisation block: 16 waves per CU, <= 256 partials for the final reduce
+constexpr int kLinBlock = 1024;   // largest linearisation block (the launch picks a multiple of 64 so that <= 256 blocks cover the queries)
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 // Gram accumulation on the f64 matrix cores: for every wave, G += V^T V with V = 64 rows x 16 columns
 // (v = [J0..J6, r, 1, cost, 0...]), issued as 16 x v_mfma_f64_16x16x4_f64 (K = 4 rows per instruction).
@@ -930,27 +930,32 @@ __device__ __forceinline__ void tstamp(const SlotState* state, int debug, int pr
 struct GramAcc {
     v4f64 acc;
     __device__ __forceinline__ void init() { acc = v4f64{0.0, 0.0, 0.0, 0.0}; }
-    // all threads of the block must call this (it synchronises)
+    // Every wave stages and consumes ITS OWN 64 rows, so only wave-level ordering is needed here (LDS operations of
+    // one wave execute in order; the fences keep the compiler from moving them) — no block barrier: fast waves do
+    // their MFMAs while slow ones still wait for their records.  All lanes of the wave must call this.
     __device__ __forceinline__ void add_rows(const double Jr[8], double cost, bool ok, double* lds) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         double* rows = lds + wave * 64 * kRow;
         double* myrow = rows + lane * kRow;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the previous tile's reads are done before the rows are overwritten
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int k = 0; k < 8; k++) myrow[k] = ok ? Jr[k] : 0.0;
         myrow[8] = ok ? 1.0 : 0.0;
         myrow[9] = ok ? cost : 0.0;
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         const int col = lane & 15, kq = lane >> 4;
 #pragma unroll
         for (int s = 0; s < 16; s++) {
             double a = col < kRow ? rows[(4 * s + kq) * kRow + col] : 0.0;
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
         }
-        __syncthreads();
     }
     // block partial: 36 upper-triangle entries of the 8x8 Gram, [36] = cost, [37] = count
     __device__ __forceinline__ void finish(double* lds, double* __restrict__ partial_out) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        __syncthreads();                 // every wave is done with its row area before the LDS is reused for the wave results
         double* dm = lds + wave * 256;   // this wave's 16x16 result, row-major
         const int col = lane & 15, r0 = lane >> 4;
 #pragma unroll
@@ -964,7 +969,7 @@ struct GramAcc {
             else if (e == 37) { row = 8; cl = 8; }
             else { row = 15; cl = 15; }   // spare slots: always zero
             double s = 0.0;
-            for (int w = 0; w < kLinBlock / 64; w++) s += lds[w * 256 + row * 16 + cl];
+            for (int w = 0; w < (int)(blockDim.x >> 6); w++) s += lds[w * 256 + row * 16 + cl];
             partial_out[e] = s;
         }
     }
@@ -1004,6 +1009,7 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize_surf(
         const int* __restrict__ block_counts, int n_bc, double* partials, FuseTail fz) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     tstamp(state, P.debug, 100, 0);
+    if ((P.debug & 512) && blockIdx.x == 100 && threadIdx.x == 0) const_cast<SlotState*>(state)->tprof[15] = (long long)__builtin_amdgcn_s_memrealtime();
     GramAcc ga; ga.init();
     dq Q; d3 T;
     load_body_pose(pa, Q, T);
@@ -1012,7 +1018,8 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize_surf(
     // all-reduced it, the global count in state->n_res
     // the first tile's records are requested before the count reduction below (which synchronises the block twice), and
     // unconditionally — one memory round trip instead of valid -> record
-    const int i0 = blockIdx.x * kLinBlock + threadIdx.x;
+    const int BS = blockDim.x;
+    const int i0 = blockIdx.x * BS + threadIdx.x;
     const int i0c = min(i0, n_q - 1);
     unsigned char v0 = valid[i0c];
     float4 ql0 = queries[i0c], nd0 = rec_nd[i0c];
@@ -1021,9 +1028,9 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize_surf(
     if (P.debug & 128) nscale = 1000.0 / 190000.0;
     else if (P.scale_surf_num > 0) nscale = P.scale_surf_num / (double)(block_counts ? sum_block_counts(block_counts, n_bc) : state->n_res[0]);
     tstamp(state, P.debug, 100, 1);
-    for (int base = blockIdx.x * kLinBlock; base < n_q; base += gridDim.x * kLinBlock) {
+    for (int base = blockIdx.x * BS; base < n_q; base += gridDim.x * BS) {
         int i = base + threadIdx.x;
-        const bool first = base == (int)blockIdx.x * kLinBlock;
+        const bool first = base == (int)blockIdx.x * BS;
         const int ic = min(i, n_q - 1);
         bool ok = i < n_q && (first ? v0 : valid[ic]);
         double Jr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1050,6 +1057,7 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize_surf(
         tstamp(state, P.debug, 100, 2);
         ga.add_rows(Jr, cost, ok, lds);
         tstamp(state, P.debug, 100, 3);
+        if ((P.debug & 512) && blockIdx.x == 100 && (threadIdx.x & 63) == 0) const_cast<SlotState*>(state)->tprof[threadIdx.x >> 6] = (long long)__builtin_amdgcn_s_memrealtime();
     }
     ga.finish(lds, partials + (size_t)blockIdx.x * kPartialDoubles);
     tstamp(state, P.debug, 100, 4);
@@ -1066,7 +1074,7 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize_edge(
     load_body_pose(pa, Q, T);
     double nscale = 1.0;   // R:843
     if (P.scale_edge_num > 0) nscale = P.scale_edge_num / (double)(block_counts ? sum_block_counts(block_counts, n_bc) : state->n_res[1]);
-    for (int base = blockIdx.x * kLinBlock; base < n_q; base += gridDim.x * kLinBlock) {
+    for (int base = blockIdx.x * blockDim.x; base < n_q; base += gridDim.x * blockDim.x) {
         int i = base + threadIdx.x;
         bool ok = i < n_q && valid[i];
         double Jr[8] = {0, 0, 0, 0, 0, 0, 0, 0};

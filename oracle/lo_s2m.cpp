@@ -497,6 +497,33 @@ extern "C" void lo_qrot(const double q[4], const double v[3], double out[3]) {
 extern "C" void lo_loss(int loss, double a, double s, double rho[3]) { loss_eval(loss, a, s, rho); }
 
 
+// Per-residual robustified rows [J(7) r] (test aid for the marginalisation assembly, L/src/MarginalizationFactor.cpp:3-71)
+extern "C" void lo_rows_surf(const unsigned char* valid, const float* rec_cp, const float* rec_n, const float* rec_d, const double* rec_score,
+                             int n_q, const double t[3], const double q[4], const lo_params* P, double scale, double* rows, int* count) {
+    int cnt = 0;
+    for (int i = 0; i < n_q; i++) {
+        if (!valid[i]) continue;
+        double* Jr = rows + 8 * (size_t)cnt;
+        lo_eval_plane(t, q, rec_cp + 3 * (size_t)i, rec_n + 3 * (size_t)i, rec_d[i], rec_score[i] * scale, P->q_lb, P->t_lb,
+                      P->variant == LO_VARIANT_FRONTEND, Jr);
+        double ci; robustify(P->loss, P->loss_a, Jr, &ci);
+        cnt++;
+    }
+    *count = cnt;
+}
+extern "C" void lo_rows_edge(const unsigned char* valid, const float* rec_cp, const float* rec_a, const float* rec_b, const float* rec_s,
+                             int n_q, const double t[3], const double q[4], const lo_params* P, double scale, double* rows, int* count) {
+    int cnt = 0;
+    for (int i = 0; i < n_q; i++) {
+        if (!valid[i]) continue;
+        double* Jr = rows + 8 * (size_t)cnt;
+        lo_eval_edge(t, q, rec_cp + 3 * (size_t)i, rec_a + 3 * (size_t)i, rec_b + 3 * (size_t)i, (double)rec_s[i] * scale, Jr);
+        double ci; robustify(P->loss, P->loss_a, Jr, &ci);
+        cnt++;
+    }
+    *count = cnt;
+}
+
 // Multi-threaded variant of lo_linearize_surf for the all-cores CPU baseline: per-thread partial Grams over
 // contiguous query ranges, added in thread order (the reference itself sums per-thread A, b after joining its 4
 // marginalisation threads, L/src/MarginalizationFactor.cpp:159-174).

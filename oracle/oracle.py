@@ -317,3 +317,125 @@ def extract_livox(pts5, q_imu=(1.0, 0, 0, 0), P=None):
         raise RuntimeError("lo_extract_livox failed")
     return dict(cutted=cut[:nc.value], cut_src=cut_src[:nc.value], edge=edge[:ne.value], edge_cell=edge_cell[:ne.value],
                 surf=surf[:ns.value], surf_cell=surf_cell[:ns.value], cell_src=cell_src.reshape(6, 4000))
+
+
+# ------------------------------------------------------------------------------------------------
+# callers / data formats either side of the path — small, so numpy / pure Python
+# ------------------------------------------------------------------------------------------------
+CUSTOM_POINT = np.dtype([("offset_time", "<u4"), ("x", "<f4"), ("y", "<f4"), ("z", "<f4"),
+                         ("reflectivity", "u1"), ("tag", "u1"), ("line", "u1")])   # livox_ros_driver/CustomPoint, 19 B
+
+
+def livox_custom_to_cloud(points):
+    """livoxLidarHandler (L/src/FormatConvert.cpp:11-35) on a CUSTOM_POINT array -> (n, 12) float32 rows of
+    pcl::PointXYZINormal (x y z 1 | 0 0 0 0 | intensity curvature 0 0).
+      float s = float(offset_time / (float)time_end);   pt.intensity = line + s*0.1;   pt.curvature = 0.1 * reflectivity;"""
+    pts = np.asarray(points, dtype=CUSTOM_POINT)
+    n = pts.shape[0]
+    out = np.zeros((n, 12), np.float32)
+    if n == 0:
+        return out
+    time_end = np.float32(pts["offset_time"][-1])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        s = pts["offset_time"].astype(np.float32) / time_end                       # float / float
+    out[:, 0], out[:, 1], out[:, 2], out[:, 3] = pts["x"], pts["y"], pts["z"], 1.0
+    out[:, 8] = (pts["line"].astype(np.float64) + s.astype(np.float64) * 0.1).astype(np.float32)
+    out[:, 9] = (0.1 * pts["reflectivity"].astype(np.float64)).astype(np.float32)
+    return out
+
+
+class ImuIntegrator:
+    """Preprocessing's gyro integration (L/src/Preprocessing.cpp:129-171 processIMU/solveRotation, 176-191 imuHandler,
+    232-234, 403; deltaQ: L/include/utils/math_tools.h:125-138).  Pure-Python doubles, operation for operation."""
+
+    def __init__(self):
+        self.idx = 0
+        self.t_cur = -1.0
+        self.gyr0 = [0.0, 0.0, 0.0]
+        self.first = False
+
+    def _solve_rotation(self, q, dt, w):
+        th = [0.5 * (self.gyr0[k] + w[k]) * dt for k in range(3)]
+        bw, bx, by, bz = 1.0, th[0] / 2.0, th[1] / 2.0, th[2] / 2.0
+        aw, ax, ay, az = q
+        q[0] = aw * bw - ax * bx - ay * by - az * bz
+        q[1] = aw * bx + ax * bw + ay * bz - az * by
+        q[2] = aw * by + ay * bw + az * bx - ax * bz
+        q[3] = aw * bz + az * bw + ax * by - ay * bx
+        self.gyr0 = [float(w[0]), float(w[1]), float(w[2])]
+
+    def integrate(self, stamps, gyr, t_scan_next):
+        stamps = [float(x) for x in stamps]
+        gyr = [[float(v) for v in row] for row in gyr]
+        n = len(stamps)
+        q = [1.0, 0.0, 0.0, 0.0]
+        if n > 0:
+            if self.t_cur < 0:
+                self.t_cur = stamps[0]
+            if not self.first:
+                self.first = True
+                self.gyr0 = list(gyr[0])
+            r = [0.0, 0.0, 0.0]
+            i = self.idx
+            if i >= n:
+                i -= 1
+            while stamps[i] < t_scan_next:
+                t = stamps[i]
+                if self.t_cur < 0:
+                    self.t_cur = t
+                dt = t - self.t_cur
+                self.t_cur = stamps[i]
+                r = list(gyr[i])
+                self._solve_rotation(q, dt, r)
+                i += 1
+                if i >= n:
+                    break
+            if i < n:
+                dt1 = t_scan_next - self.t_cur
+                dt2 = stamps[i] - t_scan_next
+                with np.errstate(divide="ignore", invalid="ignore"):      # C semantics for a zero denominator
+                    w1 = float(np.float64(dt2) / np.float64(dt1 + dt2))
+                    w2 = float(np.float64(dt1) / np.float64(dt1 + dt2))
+                r = [w1 * r[k] + w2 * gyr[i][k] for k in range(3)]
+                self._solve_rotation(q, dt1, r)
+            self.t_cur = t_scan_next
+            self.idx = i
+        if any(v != v for v in q):
+            q = [1.0, 0.0, 0.0, 0.0]
+        return np.array(q, np.float64)
+
+
+def marg_accumulate(J, r, pos, idx_t, idx_q, A=None, b=None):
+    """ThreadsConstructA (L/src/MarginalizationFactor.cpp:3-29) for lidar blocks with parameter blocks (t[3], q[4]):
+    J (n,7) robustified 1x7 Jacobians (t, then q = w,x,y,z), r (n,) robustified residuals.  size 4 -> rightCols(3)."""
+    A = np.zeros((pos, pos)) if A is None else A
+    b = np.zeros(pos) if b is None else b
+    for k in range(J.shape[0]):
+        jt = J[k, 0:3].reshape(1, 3)
+        jq = J[k, 4:7].reshape(1, 3)
+        blocks = ((idx_t, jt), (idx_q, jq))
+        for i in range(2):
+            ii, ji = blocks[i]
+            for j in range(i, 2):
+                ij, jj = blocks[j]
+                A[ii:ii + 3, ij:ij + 3] += ji.T @ jj
+                if i != j:
+                    A[ij:ij + 3, ii:ii + 3] = A[ii:ii + 3, ij:ij + 3].T
+            b[ii:ii + 3] += ji.T[:, 0] * r[k]
+    return A, b
+
+
+def linearize_rows(rec, t, q, P, scale=1.0, kind="surf"):
+    """Per-residual robustified rows [J(7) r] of the valid records, in record order (what ResidualBlockInfo::Evaluate
+    leaves in jacobians / residuals, L/src/MarginalizationFactor.cpp:31-71)."""
+    n = rec["valid"].shape[0]
+    rows = np.zeros((n, 8), np.float64)
+    cnt = C.c_int(0)
+    t, q = _f64(t), _f64(q)
+    if kind == "surf":
+        lib().lo_rows_surf(_p(rec["valid"]), _p(rec["cp"]), _p(rec["n"]), _p(rec["d"]), _p(rec["score"]), n, _p(t), _p(q),
+                           C.byref(P), C.c_double(scale), _p(rows), C.byref(cnt))
+    else:
+        lib().lo_rows_edge(_p(rec["valid"]), _p(rec["cp"]), _p(rec["a"]), _p(rec["b"]), _p(rec["s"]), n, _p(t), _p(q),
+                           C.byref(P), C.c_double(scale), _p(rows), C.byref(cnt))
+    return rows[:cnt.value]
