@@ -1,0 +1,96 @@
+"""Adversarial inputs for the exact 5-NN of the map index (reach-2 grid with on-demand shell, gate-bounded two-tier
+selection, conservative pruning): the neighbour lists of every query the gate can accept must equal the brute-force
+restatement — indices in (d², original index) order and f32 distances bit for bit."""
+import numpy as np
+import pytest
+
+import lili_om_amd as L
+
+pytestmark = pytest.mark.gpu
+
+IDENT_Q, ZERO_T = [1.0, 0.0, 0.0, 0.0], [0.0, 0.0, 0.0]
+
+
+def _check(gpu_ctx, oracle, map_xyz, q_xyz, gate=1.0, min_inside=10, reach=None, cell_pct=None):
+    P = L.make_params("frontend", kd_max_radius=gate)          # identity extrinsic: queries are map-frame points
+    try:
+        if reach is not None:
+            gpu_ctx.set_option("grid_reach", reach)
+        if cell_pct is not None:
+            gpu_ctx.set_option("cell_pct", cell_pct)
+        m = L.ScanToMapMatcher(gpu_ctx, P)
+        gpu_ctx.set_debug(True)
+        m.set_input_cloud(L.KIND_SURF, map_xyz)
+        m.set_queries(0, L.KIND_SURF, q_xyz)
+        m.find_corresponding_surf_features(0, IDENT_Q, ZERO_T)
+        idx, d2 = m.neighbors(0, L.KIND_SURF, q_xyz.shape[0])
+    finally:
+        gpu_ctx.set_option("grid_reach", 2)
+        gpu_ctx.set_option("cell_pct", 65)
+    bi, bd = oracle.knn5_brute(map_xyz, q_xyz)
+    inside = bd[:, 4] < gate
+    assert inside.sum() >= min_inside
+    assert np.array_equal(idx[inside], bi[inside])
+    assert np.array_equal(d2[inside].view(np.uint32), bd[inside].view(np.uint32))
+    assert np.all(~(d2[~inside][:, 4] < gate))                 # never a false accept
+    return inside
+
+
+@pytest.mark.parametrize("reach,pct", [(2, 65), (2, 50), (2, 100), (1, 65)])
+def test_lattice_with_massive_exact_ties(gpu_ctx, oracle, reach, pct):
+    """Integer lattice (spacing 0.25 m): queries on lattice points / edge midpoints / cell centres see 6-, 8-, 12-fold
+    exact distance ties, many of them ACROSS grid cells — the tie fallback must reproduce the index order."""
+    g = np.arange(-12, 13, dtype=np.float32) * np.float32(0.25)
+    X, Y, Z = np.meshgrid(g, g, g[:9], indexing="ij")
+    lattice = np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1).astype(np.float32)
+    rng = np.random.default_rng(3)
+    lattice = lattice[rng.permutation(lattice.shape[0])]        # original index order unrelated to position
+    base = lattice[rng.integers(0, lattice.shape[0], 3000)]
+    off = rng.choice(np.array([0.0, 0.125, 0.25], np.float32), (3000, 3))
+    q = (base + off).astype(np.float32)
+    _check(gpu_ctx, oracle, lattice, q, gate=1.0, min_inside=2500, reach=reach, cell_pct=pct)
+
+
+def test_dense_cluster_and_sparse_halo(gpu_ctx, oracle):
+    """20 000 points inside one 0.3 m blob (thousands per cell) plus a sparse halo: long runs, shell visits, and
+    queries whose 5th neighbour sits just inside / just outside the gate."""
+    rng = np.random.default_rng(4)
+    blob = rng.normal(0, 0.08, (20000, 3)).astype(np.float32)
+    halo = rng.uniform(-6, 6, (4000, 3)).astype(np.float32)
+    m = np.concatenate([blob, halo]).astype(np.float32)
+    q = np.concatenate([rng.normal(0, 0.5, (2000, 3)), rng.uniform(-7, 7, (4000, 3))]).astype(np.float32)
+    inside = _check(gpu_ctx, oracle, m, q, gate=1.0, min_inside=1500)
+    assert (~inside).sum() > 500
+
+
+def test_points_on_cell_boundaries_and_outside_the_grid(gpu_ctx, oracle):
+    """Map points and queries exactly on multiples of the cell edge (0.6565 m at 65 %), queries far outside the map's
+    bounding box, and non-finite queries."""
+    c = np.float32(1.01 * 0.65)
+    k = np.arange(-6, 7, dtype=np.float32)
+    X, Y, Z = np.meshgrid(k, k, k[4:9], indexing="ij")
+    grid_pts = (np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1) * c).astype(np.float32)
+    rng = np.random.default_rng(5)
+    extra = rng.uniform(-4, 4, (3000, 3)).astype(np.float32)
+    m = np.concatenate([grid_pts, extra]).astype(np.float32)
+    q = np.concatenate([grid_pts[rng.integers(0, grid_pts.shape[0], 1500)],
+                        (grid_pts[rng.integers(0, grid_pts.shape[0], 1500)] + np.float32(0.5) * c).astype(np.float32),
+                        rng.uniform(-30, 30, (500, 3)).astype(np.float32),
+                        np.array([[np.nan, 0, 0], [np.inf, 1, 1], [1e30, 0, 0]], np.float32)]).astype(np.float32)
+    ok = np.all(np.isfinite(q), 1)
+    _check(gpu_ctx, oracle, m, q[ok], gate=1.0, min_inside=2000)
+    # non-finite queries: rejected, no crash
+    P = L.make_params("frontend")
+    mm = L.ScanToMapMatcher(gpu_ctx, P)
+    mm.set_input_cloud(L.KIND_SURF, m)
+    mm.set_queries(0, L.KIND_SURF, q[~ok])
+    assert mm.find_corresponding_surf_features(0, IDENT_Q, ZERO_T) == 0
+
+
+def test_large_gate_radius(gpu_ctx, oracle):
+    """kd_max_radius of config_utbm.yaml (1.5, compared with a SQUARED distance): the index is rebuilt for the larger ball."""
+    rng = np.random.default_rng(6)
+    m = rng.uniform(-10, 10, (30000, 3)).astype(np.float32)
+    q = rng.uniform(-11, 11, (5000, 3)).astype(np.float32)
+    _check(gpu_ctx, oracle, m, q, gate=1.5, min_inside=1000)
+    _check(gpu_ctx, oracle, m, q, gate=0.25, min_inside=5)
