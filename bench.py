@@ -112,7 +112,7 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("LILI_BENCH_FORCE_DIST"):    # the env switch exercises the collective path on ONE rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -222,7 +222,7 @@ def main():
 
     def run_steps(k):
         # every `ips` steps a new registration starts from the initial guess (async device-to-device pose copy)
-        if world == 1 and not args.split_path:
+        if world == 1 and not args.split_path and dist is None:
             m.iterate_restart(0, k, ips, 1, L.MASK_SURF)   # one C call enqueues k x (associate, linearise, reduce+GN update)
         else:
             for i in range(k):
@@ -241,8 +241,11 @@ def main():
     fence()
     tic = time.perf_counter()
     run_steps(args.steps)
+    t_enqueue = time.perf_counter() - tic
     fence()
     elapsed = time.perf_counter() - tic
+    if rank == 0:
+        log(f"[bench] host enqueue {t_enqueue / args.steps * 1e6:.1f} us/step, wall {elapsed / args.steps * 1e6:.1f} us/step")
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

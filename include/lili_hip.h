@@ -239,7 +239,8 @@ int lili_s2m_accumulate(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_p
  *   lili_s2m_associate_dev   -> per-block counts of this rank in device memory
  *   lili_s2m_counts_export   -> this rank's {n_surf, n_edge} into a caller-owned DEVICE int32[2]   (async)
  *   [caller: all-reduce(sum) that buffer over ranks on the same stream]
- *   lili_s2m_counts_import   -> hands the global counts back                                       (async)
+ *   lili_s2m_counts_import   -> the next linearize_dev scales with that buffer (read by its kernels, no copy:
+ *                               keep it valid and unchanged until that call's work has run)            (async)
  *   lili_s2m_linearize_dev   -> d_gram as above.                                                          */
 int lili_s2m_associate_dev(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params);
 int lili_s2m_counts_export(lili_ctx* ctx, int slot, int32_t* d_counts);

@@ -25,10 +25,10 @@ __global__ void k_tile_count(const int*, int, int*);
 __global__ void k_tile_fill(const int*, const int*, const int*, int, int2*);
 template <bool TILED, int BS> __global__ void k_associate_surf(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, int*, int*);
 template <bool TILED, int BS> __global__ void k_associate_edge(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, int*, int*);
-__global__ void k_linearize_surf(const float4*, int, const float4*, const double*, const unsigned char*, PoseArg, MatchParams, const SlotState*, const int*, int, double*, FuseTail);
-__global__ void k_linearize_edge(const float4*, int, const float4*, const float4*, const unsigned char*, PoseArg, MatchParams, const SlotState*, const int*, int, double*, FuseTail);
+__global__ void k_linearize_surf(const float4*, int, const float4*, const double*, const unsigned char*, PoseArg, MatchParams, const SlotState*, const int*, int, const int*, double*, FuseTail);
+__global__ void k_linearize_edge(const float4*, int, const float4*, const float4*, const unsigned char*, PoseArg, MatchParams, const SlotState*, const int*, int, const int*, double*, FuseTail);
 __global__ void k_reduce_partials(const double*, int, const double*, int, double*, SlotState*, int);
-__global__ void k_sum_counts(const int*, int, const int*, int, SlotState*);
+__global__ void k_sum_counts(const int*, int, const int*, int, SlotState*, int*);
 __global__ void k_gn_update(const double*, SlotState*);
 }  // namespace lili
 
@@ -382,22 +382,21 @@ static int launch_linearize(lili_ctx* ctx, int slot, int kind, const PoseArg& pa
     const int* bc = ctx->slots[slot].use_global_counts ? nullptr : ks.block_counts.as<int>();
     if (kind == LILI_KIND_SURF)
         hipLaunchKernelGGL(k_linearize_surf, dim3(ks.n_lin_blocks), dim3(ks.lin_threads), lds_linearize(ks.lin_threads), ctx->stream, ks.q.as<float4>(), n, ks.rec0.as<float4>(),
-                           ks.rec1.as<double>(), ks.valid.as<unsigned char>(), pa, P, ctx->state(slot), bc, ks.n_assoc_blocks, ks.partials.as<double>(), fz);
+                           ks.rec1.as<double>(), ks.valid.as<unsigned char>(), pa, P, ctx->state(slot), bc, ks.n_assoc_blocks, ctx->slots[slot].use_global_counts ? ctx->slots[slot].global_counts : nullptr, ks.partials.as<double>(), fz);
     else
         hipLaunchKernelGGL(k_linearize_edge, dim3(ks.n_lin_blocks), dim3(ks.lin_threads), lds_linearize(ks.lin_threads), ctx->stream, ks.q.as<float4>(), n, ks.rec0.as<float4>(),
-                           ks.rec1.as<float4>(), ks.valid.as<unsigned char>(), pa, P, ctx->state(slot), bc, ks.n_assoc_blocks, ks.partials.as<double>(), fz);
+                           ks.rec1.as<float4>(), ks.valid.as<unsigned char>(), pa, P, ctx->state(slot), bc, ks.n_assoc_blocks, ctx->slots[slot].use_global_counts ? ctx->slots[slot].global_counts : nullptr, ks.partials.as<double>(), fz);
     HIPCHK(hipGetLastError());
     return LILI_OK;
 }
 
 // sums the per-block correspondence counts of the last association(s) into SlotState::n_res
-static int launch_sum_counts(lili_ctx* ctx, int slot, int kind_mask) {
+static int launch_sum_counts(lili_ctx* ctx, int slot, int kind_mask, int* d_out = nullptr) {
     Slot& s = ctx->slots[slot];
     const int* bs = nullptr; const int* be = nullptr; int nbs = 0, nbe = 0;
     if ((kind_mask & LILI_MASK_SURF) && s.k[0].has_records && s.k[0].n_q > 0) { bs = s.k[0].block_counts.as<int>(); nbs = s.k[0].n_assoc_blocks; }
     if ((kind_mask & LILI_MASK_EDGE) && s.k[1].has_records && s.k[1].n_q > 0) { be = s.k[1].block_counts.as<int>(); nbe = s.k[1].n_assoc_blocks; }
-    HIPCHK(hipMemsetAsync(ctx->state(slot)->n_res, 0, 2 * sizeof(int), ctx->stream));
-    if (bs || be) hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(kBlock), 0, ctx->stream, bs, nbs, be, nbe, ctx->state(slot));
+    hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(kBlock), 0, ctx->stream, bs, nbs, be, nbe, ctx->state(slot), d_out);
     HIPCHK(hipGetLastError());
     return LILI_OK;
 }
@@ -619,18 +618,15 @@ int lili_s2m_counts_export(lili_ctx* ctx, int slot, int32_t* d_counts) {
     if (!ctx) return LILI_E_ARG;
     ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS && d_counts, "counts_export: bad argument");
     HIPCHK(hipSetDevice(ctx->device));
-    int rc = launch_sum_counts(ctx, slot, LILI_MASK_SURF | LILI_MASK_EDGE);
-    if (rc != LILI_OK) return rc;
-    HIPCHK(hipMemcpyAsync(d_counts, ctx->state(slot)->n_res, 2 * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
-    return LILI_OK;
+    return launch_sum_counts(ctx, slot, LILI_MASK_SURF | LILI_MASK_EDGE, d_counts);   // the kernel writes the caller's buffer directly
 }
 
 int lili_s2m_counts_import(lili_ctx* ctx, int slot, const int32_t* d_counts) {
     if (!ctx) return LILI_E_ARG;
     ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS && d_counts, "counts_import: bad argument");
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(hipMemcpyAsync(ctx->state(slot)->n_res, d_counts, 2 * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
-    ctx->slots[slot].use_global_counts = true;   // the next linearize_dev scales with these (all-reduced) counts
+    ctx->slots[slot].global_counts = d_counts;   // read by the next linearize_dev's kernels (no copy): keep it valid until then
+    ctx->slots[slot].use_global_counts = true;
     return LILI_OK;
 }
 

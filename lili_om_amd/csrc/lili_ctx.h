@@ -54,7 +54,8 @@ struct KindSlot {
 
 struct Slot {
     KindSlot k[2];
-    bool use_global_counts = false;   // next linearize_dev reads the (all-reduced) counts in SlotState::n_res
+    bool use_global_counts = false;   // next linearize_dev scales with the caller's (all-reduced) counts instead of its own
+    const int32_t* global_counts = nullptr;
 };
 
 constexpr int kLinBlock = 1024;      // must match lili_s2m.hip

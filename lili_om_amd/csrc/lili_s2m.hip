@@ -521,11 +521,17 @@ __device__ __forceinline__ int sum_block_counts(const int* __restrict__ block_co
     __syncthreads();
     return total;
 }
+// A kind without records counts 0.  `out` (optional): a caller-owned int[2] that receives the same totals (multi-GPU
+// callers all-reduce it in place).
 __global__ __launch_bounds__(kBlock) void k_sum_counts(const int* __restrict__ bc_surf, int nb_surf, const int* __restrict__ bc_edge, int nb_edge,
-                                                      SlotState* __restrict__ state) {
-    if (bc_surf) { int t = sum_block_counts(bc_surf, nb_surf); if (threadIdx.x == 0) state->n_res[0] = t; }
+                                                      SlotState* __restrict__ state, int* __restrict__ out) {
+    int t0 = bc_surf ? sum_block_counts(bc_surf, nb_surf) : 0;
     __syncthreads();
-    if (bc_edge) { int t = sum_block_counts(bc_edge, nb_edge); if (threadIdx.x == 0) state->n_res[1] = t; }
+    int t1 = bc_edge ? sum_block_counts(bc_edge, nb_edge) : 0;
+    if (threadIdx.x == 0) {
+        state->n_res[0] = t0; state->n_res[1] = t1;
+        if (out) { out[0] = t0; out[1] = t1; }
+    }
 }
 
 __device__ __forceinline__ void load_assoc_pose(const PoseArg& pa, const MatchParams& P, dq& Q2, d3& T2) {
@@ -1006,7 +1012,7 @@ __device__ __forceinline__ void load_body_pose(const PoseArg& pa, dq& Q, d3& T) 
 __global__ __launch_bounds__(kLinBlock) void k_linearize_surf(
         const float4* __restrict__ queries, int n_q, const float4* __restrict__ rec_nd, const double* __restrict__ rec_score,
         const unsigned char* __restrict__ valid, PoseArg pa, MatchParams P, const SlotState* __restrict__ state,
-        const int* __restrict__ block_counts, int n_bc, double* partials, FuseTail fz) {
+        const int* __restrict__ block_counts, int n_bc, const int* __restrict__ n_global, double* partials, FuseTail fz) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     tstamp(state, P.debug, 100, 0);
     if ((P.debug & 512) && blockIdx.x == 100 && threadIdx.x == 0) const_cast<SlotState*>(state)->tprof[15] = (long long)__builtin_amdgcn_s_memrealtime();
@@ -1026,7 +1032,7 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize_surf(
     double sc0 = rec_score[i0c];
     double nscale = 1.0;
     if (P.debug & 128) nscale = 1000.0 / 190000.0;
-    else if (P.scale_surf_num > 0) nscale = P.scale_surf_num / (double)(block_counts ? sum_block_counts(block_counts, n_bc) : state->n_res[0]);
+    else if (P.scale_surf_num > 0) nscale = P.scale_surf_num / (double)(block_counts ? sum_block_counts(block_counts, n_bc) : (n_global ? n_global[0] : state->n_res[0]));
     tstamp(state, P.debug, 100, 1);
     for (int base = blockIdx.x * BS; base < n_q; base += gridDim.x * BS) {
         int i = base + threadIdx.x;
@@ -1067,13 +1073,13 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize_surf(
 __global__ __launch_bounds__(kLinBlock) void k_linearize_edge(
         const float4* __restrict__ queries, int n_q, const float4* __restrict__ rec_a, const float4* __restrict__ rec_b,
         const unsigned char* __restrict__ valid, PoseArg pa, MatchParams P, const SlotState* __restrict__ state,
-        const int* __restrict__ block_counts, int n_bc, double* partials, FuseTail fz) {
+        const int* __restrict__ block_counts, int n_bc, const int* __restrict__ n_global, double* partials, FuseTail fz) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     GramAcc ga; ga.init();
     dq Q; d3 T;
     load_body_pose(pa, Q, T);
     double nscale = 1.0;   // R:843
-    if (P.scale_edge_num > 0) nscale = P.scale_edge_num / (double)(block_counts ? sum_block_counts(block_counts, n_bc) : state->n_res[1]);
+    if (P.scale_edge_num > 0) nscale = P.scale_edge_num / (double)(block_counts ? sum_block_counts(block_counts, n_bc) : (n_global ? n_global[1] : state->n_res[1]));
     for (int base = blockIdx.x * blockDim.x; base < n_q; base += gridDim.x * blockDim.x) {
         int i = base + threadIdx.x;
         bool ok = i < n_q && valid[i];
