@@ -268,6 +268,7 @@ struct Sel5 {
     }
     __device__ __forceinline__ float worst() const { return __uint_as_float((unsigned)(k[4] >> 32)); }
     __device__ __forceinline__ bool final_tie() const { return false; }
+    __device__ __forceinline__ unsigned worst_bits() const { return (unsigned)(k[4] >> 32); }
     __device__ __forceinline__ void to_top5(Top5& t) const {
 #pragma unroll
         for (int s = 0; s < 5; s++) { t.d[s] = __uint_as_float((unsigned)(k[s] >> 32)); t.j[s] = j[s]; }
@@ -282,35 +283,42 @@ struct Sel5 {
 // the caller then repeats the query with the exact selector (Sel5).  Proof sketch: a wrongly excluded candidate Y ties
 // with the final 5th-best distance w; when Y left, the then-5th-best W had w <= W.d <= Y.d = w.  Sentinels carry five
 // DISTINCT values just above the bound so that they never tie with each other.
+__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {   // no clang builtin for the integer median
+    unsigned r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 struct Sel5F {
-    float d[5];
-    int j[5];
+    unsigned d[5];   // bit patterns of the non-negative f32 distances: unsigned order == float order, NaN sorts above +inf,
+    int j[5];        // and integer min / max / med3 need no NaN canonicalisation (v_max x,x) around them
     bool tie;
     __device__ __forceinline__ void init(float bound) {
-        bound = fminf(bound, 3.0e38f);
+        const unsigned b = min(__float_as_uint(bound), __float_as_uint(3.0e38f));
 #pragma unroll
-        for (int s = 0; s < 5; s++) { d[s] = __uint_as_float(__float_as_uint(bound) + (unsigned)s); j[s] = -1; }
+        for (int s = 0; s < 5; s++) { d[s] = b + (unsigned)s; j[s] = -1; }
         tie = false;
     }
-    __device__ __forceinline__ void insert(float dc, float4, int jc) {
+    __device__ __forceinline__ void insert(float dcf, float4, int jc) {
+        const unsigned dc = __float_as_uint(dcf);
         const bool c0 = dc < d[0], c1 = dc < d[1], c2 = dc < d[2], c3 = dc < d[3], c4 = dc < d[4];
-        const float kInf = __uint_as_float(0x7f800000u);
-        const float popped = __builtin_amdgcn_fmed3f(d[4], dc, kInf);   // max(d[4], dc)
-        j[4] = c3 ? j[3] : (c4 ? jc : j[4]);
-        j[3] = c2 ? j[2] : (c3 ? jc : j[3]);
-        j[2] = c1 ? j[1] : (c2 ? jc : j[2]);
-        j[1] = c0 ? j[0] : (c1 ? jc : j[1]);
-        j[0] = c0 ? jc : j[0];
-        const float n4 = __builtin_amdgcn_fmed3f(d[3], d[4], dc), n3 = __builtin_amdgcn_fmed3f(d[2], d[3], dc);
-        const float n2 = __builtin_amdgcn_fmed3f(d[1], d[2], dc), n1 = __builtin_amdgcn_fmed3f(d[0], d[1], dc);
-        d[0] = __builtin_amdgcn_fmed3f(d[0], dc, -kInf); d[1] = n1; d[2] = n2; d[3] = n3; d[4] = n4;
-        tie |= popped == n4;
+        const unsigned popped = max(d[4], dc);
+        int n4 = c4 ? jc : j[4]; n4 = c3 ? j[3] : n4;      // two straight-line selects per slot (no nested control flow)
+        int n3 = c3 ? jc : j[3]; n3 = c2 ? j[2] : n3;
+        int n2 = c2 ? jc : j[2]; n2 = c1 ? j[1] : n2;
+        int n1 = c1 ? jc : j[1]; n1 = c0 ? j[0] : n1;
+        const int n0 = c0 ? jc : j[0];
+        j[0] = n0; j[1] = n1; j[2] = n2; j[3] = n3; j[4] = n4;
+        const unsigned m4 = umed3(d[3], d[4], dc), m3 = umed3(d[2], d[3], dc);
+        const unsigned m2 = umed3(d[1], d[2], dc), m1 = umed3(d[0], d[1], dc);
+        d[0] = min(d[0], dc); d[1] = m1; d[2] = m2; d[3] = m3; d[4] = m4;
+        tie |= popped == m4;
     }
-    __device__ __forceinline__ float worst() const { return d[4]; }
+    __device__ __forceinline__ float worst() const { return __uint_as_float(d[4]); }
+    __device__ __forceinline__ unsigned worst_bits() const { return d[4]; }
     __device__ __forceinline__ bool final_tie() const { return tie || d[0] == d[1] || d[1] == d[2] || d[2] == d[3] || d[3] == d[4]; }
     __device__ __forceinline__ void to_top5(Top5& t) const {
 #pragma unroll
-        for (int s = 0; s < 5; s++) { t.d[s] = d[s]; t.j[s] = j[s]; }
+        for (int s = 0; s < 5; s++) { t.d[s] = __uint_as_float(d[s]); t.j[s] = j[s]; }
     }
 };
 
@@ -337,18 +345,19 @@ __device__ __forceinline__ float4 load_pt(const GridView& g, int j) {   // 32-bi
 // and get +inf, which no selector accepts; NaN distances of non-finite map points likewise: fminf).
 template <class SEL>
 __device__ __forceinline__ void process_chunk(SEL& sel, float4 p0, float4 p1, float4 p2, float4 p3, int j, int end, float qx, float qy, float qz) {
-    const float kInf = __uint_as_float(0x7f800000u);
     const int last = end - 1;
     asm volatile("" : "+v"(p0.w), "+v"(p1.w), "+v"(p2.w), "+v"(p3.w));   // keep each point ONE 16-byte load (no re-load of .w inside the branches)
-    float d0 = fminf(dist2(p0, qx, qy, qz), kInf);
-    float d1 = j + 1 < end ? fminf(dist2(p1, qx, qy, qz), kInf) : kInf;
-    float d2 = j + 2 < end ? fminf(dist2(p2, qx, qy, qz), kInf) : kInf;
-    float d3 = j + 3 < end ? fminf(dist2(p3, qx, qy, qz), kInf) : kInf;
+    // distances as bit patterns (non-negative floats order like unsigned integers; a NaN distance — non-finite map point —
+    // sorts above every bound and is never accepted); slots past the run end get +inf
+    const unsigned u0 = __float_as_uint(dist2(p0, qx, qy, qz));
+    const unsigned u1 = j + 1 < end ? __float_as_uint(dist2(p1, qx, qy, qz)) : 0x7f800000u;
+    const unsigned u2 = j + 2 < end ? __float_as_uint(dist2(p2, qx, qy, qz)) : 0x7f800000u;
+    const unsigned u3 = j + 3 < end ? __float_as_uint(dist2(p3, qx, qy, qz)) : 0x7f800000u;
     // each test is a wave-level skip of the selection code (taken if any lane qualifies)
-    if (d0 <= sel.worst()) sel.insert(d0, p0, j);
-    if (d1 <= sel.worst()) sel.insert(d1, p1, min(j + 1, last));
-    if (d2 <= sel.worst()) sel.insert(d2, p2, min(j + 2, last));
-    if (d3 <= sel.worst()) sel.insert(d3, p3, min(j + 3, last));
+    if (u0 <= sel.worst_bits()) sel.insert(__uint_as_float(u0), p0, j);
+    if (u1 <= sel.worst_bits()) sel.insert(__uint_as_float(u1), p1, min(j + 1, last));
+    if (u2 <= sel.worst_bits()) sel.insert(__uint_as_float(u2), p2, min(j + 2, last));
+    if (u3 <= sel.worst_bits()) sel.insert(__uint_as_float(u3), p3, min(j + 3, last));
 }
 // One run of consecutive cell-sorted map points, four independent loads in flight per trip (shell phase).
 template <class SEL>
