@@ -92,6 +92,8 @@ def main():
                          "the pose is re-initialised on the device every this-many steps")
     ap.add_argument("--assoc-only", type=int, default=0, help="profiling aid: only this many association launches at a fixed pose, then exit")
     ap.add_argument("--assoc-after", type=int, default=0, help="with --assoc-only: run this many GN iterations first (pose then stays fixed)")
+    ap.add_argument("--window", type=int, default=0, help="extra measurement (not the headline): K independent registrations of the same "
+                    "scan in K slots advanced concurrently with lili_s2m_iterate_window; prints window iterations/s and exits")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--split-path", action="store_true", help="use the multi-GPU code path (export/import counts, separate GN kernel) even at N=1")
     ap.add_argument("--bin", action="store_true", help="enable the once-per-scan query binning (A/B only)")
@@ -172,6 +174,27 @@ def main():
     m.pose_set(1, t0, q0)       # slot 1 only holds the initial guess; slot 0 is restarted from it on the device
     ips = max(1, args.iters_per_scan)
 
+    if args.window:
+        K = args.window
+        for k in range(1, K):
+            m.set_queries(k, L.KIND_SURF, queries)
+        assert 1 <= K <= 7
+        m.pose_set(7, t0, q0)          # every slot restarts its registrations from this copy of the initial guess
+        def run(n):
+            for _ in range(n // ips):
+                for k in range(K):
+                    m.pose_copy(k, 7)
+                m.iterate_window(list(range(K)), ips, L.MASK_SURF)
+        run(args.warmup)
+        torch.cuda.synchronize()
+        tic = time.perf_counter()
+        run(args.steps)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - tic
+        n_it = (args.steps // ips) * ips
+        print(json.dumps({"window_slots": K, "us_per_window_iteration": el / n_it * 1e6, "slot_iterations_per_s": K * n_it / el}), flush=True)
+        ctx.close()
+        return
     if os.environ.get("LILI_PHASES"):
         if os.environ["LILI_PHASES"] == "waves":
             os.environ["LILI_DEBUG"] = "512"

@@ -252,6 +252,11 @@ int lili_s2m_gn_update(lili_ctx* ctx, int slot, const double* d_gram);
 /* Convenience: n_iters x (accumulate + gn_update) on an internal buffer.  Async. */
 int lili_s2m_iterate(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, int n_iters);
 
+/* lili_s2m_iterate for several slots at once (the keyframes of one sliding window, or several sensors): every slot
+ * runs its own chain on its own stream, forked from / joined to the context's stream, so the latency-bound linearise /
+ * reduce launches of one slot overlap the association of another.  Same results as iterating the slots one after the
+ * other; all slots share the map index.  Async. */
+int lili_s2m_iterate_window(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, const lili_s2m_params* params, int n_iters);
 /* Profiling aid: with LILI_DEBUG bit 256 set, kernels stamp a 100 MHz device clock at their phases; returns the 16 stamps. */
 int lili_s2m_debug_times(lili_ctx* ctx, int slot, long long out[16]);
 /* Async device-to-device copy of the body pose of src_slot into dst_slot (no host round trip). */

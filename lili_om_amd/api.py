@@ -121,6 +121,7 @@ _SIGS = {
     "lili_s2m_linearize_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams), C.c_void_p]),
     "lili_s2m_gn_update": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "lili_s2m_iterate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams), C.c_int]),
+    "lili_s2m_iterate_window": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(S2MParams), C.c_int]),
     "lili_s2m_debug_times": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_longlong)]),
     "lili_s2m_pose_copy": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "lili_s2m_iterate_restart": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
@@ -333,6 +334,10 @@ class ScanToMapMatcher:
 
     def gn_update(self, slot, d_gram_ptr):
         self.ctx._chk(self.lib.lili_s2m_gn_update(self.ctx.h, slot, C.c_void_p(d_gram_ptr)))
+
+    def iterate_window(self, slots, n_iters, kind_mask=MASK_SURF):
+        arr = (C.c_int * len(slots))(*[int(s) for s in slots])
+        self.ctx._chk(self.lib.lili_s2m_iterate_window(self.ctx.h, arr, len(slots), kind_mask, C.byref(self.params), int(n_iters)))
 
     def debug_times(self, slot):
         out = (C.c_longlong * 16)()

@@ -111,6 +111,9 @@ void lili_ctx_destroy(lili_ctx* ctx) {
     if (ctx->ext_rot && ctx->ext_rot_free) ctx->ext_rot_free(ctx->ext_rot);
     if (ctx->ext_livox && ctx->ext_livox_free) ctx->ext_livox_free(ctx->ext_livox);
     if (ctx->ext_voxel && ctx->ext_voxel_free) ctx->ext_voxel_free(ctx->ext_voxel);
+    for (auto& st : ctx->side) if (st) (void)hipStreamDestroy(st);
+    if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
+    for (auto& e : ctx->join_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -702,6 +705,42 @@ static int iterate_impl(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_p
         *assoc_ms = (float)tot;
     }
     return LILI_OK;
+}
+
+// Several independent registrations (the keyframes of one sliding window, L/src/BackendFusion.cpp:843-1007 loops over
+// them per outer iteration; or several sensors) advanced concurrently: slot i runs its own associate / linearise /
+// reduce+GN chain on its own stream, forked from and joined to the context's stream with events.  The association
+// kernel fills the chip by itself, but the latency-bound linearise / reduce launches of one slot overlap the
+// association of another.  Results are identical to calling lili_s2m_iterate slot after slot.
+int lili_s2m_iterate_window(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, const lili_s2m_params* params, int n_iters) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(slots && n_slots >= 1 && n_slots <= LILI_MAX_SLOTS, "iterate_window: 1..LILI_MAX_SLOTS slots");
+    for (int i = 0; i < n_slots; i++) {
+        ARGCHK(slots[i] >= 0 && slots[i] < LILI_MAX_SLOTS, "iterate_window: bad slot");
+        for (int k = 0; k < i; k++) ARGCHK(slots[k] != slots[i], "iterate_window: duplicate slot");
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    if (!ctx->fork_ev) HIPCHK(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ctx->fork_ev, ctx->stream));
+    hipStream_t main_stream = ctx->stream;
+    int rc = LILI_OK;
+    for (int i = 0; i < n_slots && rc == LILI_OK; i++) {
+        if (i > 0) {
+            if (!ctx->side[i]) HIPCHK(hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking));
+            if (!ctx->join_ev[i]) HIPCHK(hipEventCreateWithFlags(&ctx->join_ev[i], hipEventDisableTiming));
+            HIPCHK(hipStreamWaitEvent(ctx->side[i], ctx->fork_ev, 0));
+            ctx->stream = ctx->side[i];          // the launch helpers enqueue on ctx->stream (one thread per context)
+        }
+        rc = iterate_impl(ctx, slots[i], kind_mask, params, n_iters, 0, 0, nullptr);
+        if (i > 0) {
+            hipError_t e = hipEventRecord(ctx->join_ev[i], ctx->side[i]);
+            ctx->stream = main_stream;
+            if (e != hipSuccess) return ctx->fail(LILI_E_HIP, "iterate_window: hipEventRecord failed");
+            HIPCHK(hipStreamWaitEvent(main_stream, ctx->join_ev[i], 0));
+        }
+    }
+    ctx->stream = main_stream;
+    return rc;
 }
 
 int lili_s2m_iterate(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, int n_iters) {

@@ -27,6 +27,10 @@ struct DevBuf {
         return e;
     }
     void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }   // lili_ctx_destroy deletes the context with its device current
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
@@ -69,6 +73,8 @@ struct lili_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t side[LILI_MAX_SLOTS] = {};   // lili_s2m_iterate_window: one extra stream per concurrently iterated slot (lazy)
+    hipEvent_t fork_ev = nullptr, join_ev[LILI_MAX_SLOTS] = {};
     bool keep_nn = false;
     std::string err;
     MapIndex map[2];

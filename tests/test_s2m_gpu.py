@@ -380,3 +380,29 @@ def test_split_multi_gpu_path_equals_fused_path(gpu_ctx, oracle):
     assert st == 0
     assert np.array_equal(tf, ts) and np.array_equal(qf, qs)
     assert int(counts[0]) == int(gram[65].item()) > 1000
+
+
+def test_window_iteration_equals_sequential(gpu_ctx, oracle):
+    """lili_s2m_iterate_window (one stream per slot, forked/joined on the context's stream) gives exactly the poses of
+    iterating the slots one after the other."""
+    room = synth.make_room(seed=23, n_query=6000, n_edge_query=100)
+    P, PO, m = _setup(gpu_ctx, oracle, "rot", room, with_refl=False)
+    tb, qb = L.api.body_pose_from_lidar(room["t_true"], room["q_true"], P)
+    rng = np.random.default_rng(11)
+    starts = [synth.perturbed_pose(tb, qb, rng, 0.1, 0.8) for _ in range(3)]
+    shards = [room["q_xyz"][k::3] for k in range(3)]
+    for k in range(3):
+        m.set_queries(k, L.KIND_SURF, shards[k])
+    ref = []
+    for k in range(3):
+        m.pose_set(k, *starts[k])
+        m.iterate(k, 5, L.MASK_SURF)
+        ref.append(m.pose_get(k))
+    for k in range(3):
+        m.pose_set(k, *starts[k])
+    m.iterate_window([0, 1, 2], 5, L.MASK_SURF)
+    for k in range(3):
+        t, q, st = m.pose_get(k)
+        assert st == 0 and np.array_equal(t, ref[k][0]) and np.array_equal(q, ref[k][1])
+    with pytest.raises(L.LiliError):
+        m.iterate_window([0, 0], 1, L.MASK_SURF)
