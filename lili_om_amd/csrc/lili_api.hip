@@ -41,6 +41,12 @@ static MatchParams to_device_params(const lili_s2m_params* p) {
     m.kd_max_radius = p->kd_max_radius; m.edge_gate = p->edge_gate; m.surf_dist_thres = p->surf_dist_thres;
     m.reflect_thres = p->reflect_thres; m.surf_weight_min = p->surf_weight_min; m.edge_dist_max = p->edge_dist_max;
     for (int i = 0; i < 4; i++) m.q_lb[i] = p->q_lb[i];
+    {   // the same expression as qinv() in lili_device_math.h (this file is compiled with -ffp-contract=off as well)
+        const double w = p->q_lb[0], qx = p->q_lb[1], qy = p->q_lb[2], qz = p->q_lb[3];
+        const double n2 = w * w + qx * qx + qy * qy + qz * qz;
+        if (n2 > 0) { m.q_lb_inv[0] = w / n2; m.q_lb_inv[1] = -qx / n2; m.q_lb_inv[2] = -qy / n2; m.q_lb_inv[3] = -qz / n2; }
+        else m.q_lb_inv[0] = m.q_lb_inv[1] = m.q_lb_inv[2] = m.q_lb_inv[3] = 0.0;
+    }
     for (int i = 0; i < 3; i++) m.t_lb[i] = p->t_lb[i];
     m.scale_surf_num = p->scale_surf_num; m.scale_edge_num = p->scale_edge_num;
     // profiling aid only (tools/): skip phases of the association kernels; re-read at every call so that a tool can

@@ -549,7 +549,7 @@ __device__ __forceinline__ void load_assoc_pose(const PoseArg& pa, const MatchPa
         dq Q{s[3], s[4], s[5], s[6]};
         d3 T{s[0], s[1], s[2]};
         if (pa.derive_assoc) {   // L/src/BackendFusion.cpp:929-930
-            Q2 = qmul(Q, qinv(dq{P.q_lb[0], P.q_lb[1], P.q_lb[2], P.q_lb[3]}));
+            Q2 = qmul(Q, dq{P.q_lb_inv[0], P.q_lb_inv[1], P.q_lb_inv[2], P.q_lb_inv[3]});
             T2 = T - qrot(Q2, d3{P.t_lb[0], P.t_lb[1], P.t_lb[2]});
         } else { Q2 = Q; T2 = T; }
     } else {
@@ -1028,7 +1028,7 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize_surf(
     GramAcc ga; ga.init();
     dq Q; d3 T;
     load_body_pose(pa, Q, T);
-    const dq qlb_inv = qinv(dq{P.q_lb[0], P.q_lb[1], P.q_lb[2], P.q_lb[3]});
+    const dq qlb_inv{P.q_lb_inv[0], P.q_lb_inv[1], P.q_lb_inv[2], P.q_lb_inv[3]};
     // N of R:861: this rank's count (sum of the association's block counts) or, when a multi-GPU caller has
     // all-reduced it, the global count in state->n_res
     // the first tile's records are requested before the count reduction below (which synchronises the block twice), and
