@@ -110,6 +110,24 @@ def test_kdtree_equals_brute_force(oracle, seed):
     assert np.array_equal(i1, i3)
 
 
+def test_kdtree_agrees_with_scipy_ckdtree(oracle):
+    """Independent implementation (scipy's cKDTree, f64 Euclidean distances) as a pin for the restated nearestKSearch:
+    same neighbour SETS wherever the 5th/6th distances are not within f32 rounding of each other, and the f32
+    L2_Simple distances within f32 rounding of scipy's squared f64 distances."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(7)
+    pts = np.concatenate([rng.uniform(-20, 20, (30000, 3)), rng.normal(0, 0.3, (5000, 3))]).astype(np.float32)
+    q = np.concatenate([rng.uniform(-21, 21, (1500, 3)), rng.normal(0, 0.5, (500, 3))]).astype(np.float32)
+    idx, d2 = oracle.KdTree(pts).knn5(q, nthreads=4)
+    ds, js = cKDTree(pts.astype(np.float64)).query(q.astype(np.float64), k=6)
+    clear = (ds[:, 5] - ds[:, 4]) > 1e-5 * np.maximum(ds[:, 5], 1.0)          # unambiguous 5-sets
+    assert clear.mean() > 0.99
+    assert np.array_equal(np.sort(idx[clear], 1), np.sort(js[clear, :5], 1))
+    np.testing.assert_allclose(d2[clear], ds[clear, :5] ** 2, rtol=2e-6, atol=1e-9)
+    order_clear = clear & np.all(np.diff(ds[:, :5], axis=1) > 1e-5 * np.maximum(ds[:, 1:5], 1.0), axis=1)
+    assert np.array_equal(idx[order_clear], js[order_clear, :5])             # and the same ascending order
+
+
 def test_kdtree_small_maps(oracle):
     pts = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
     tree = oracle.KdTree(pts)
