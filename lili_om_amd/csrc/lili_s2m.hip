@@ -291,12 +291,12 @@ __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) { 
 struct Sel5F {
     unsigned d[5];   // bit patterns of the non-negative f32 distances: unsigned order == float order, NaN sorts above +inf,
     int j[5];        // and integer min / max / med3 need no NaN canonicalisation (v_max x,x) around them
-    bool tie;
+    unsigned long long tie_mask;   // one bit per lane, kept in scalar registers (v_cmp -> s_or, no VALU bookkeeping)
     __device__ __forceinline__ void init(float bound) {
         const unsigned b = min(__float_as_uint(bound), __float_as_uint(3.0e38f));
 #pragma unroll
         for (int s = 0; s < 5; s++) { d[s] = b + (unsigned)s; j[s] = -1; }
-        tie = false;
+        tie_mask = 0ull;
     }
     __device__ __forceinline__ void insert(float dcf, float4, int jc) {
         const unsigned dc = __float_as_uint(dcf);
@@ -311,11 +311,14 @@ struct Sel5F {
         const unsigned m4 = umed3(d[3], d[4], dc), m3 = umed3(d[2], d[3], dc);
         const unsigned m2 = umed3(d[1], d[2], dc), m1 = umed3(d[0], d[1], dc);
         d[0] = min(d[0], dc); d[1] = m1; d[2] = m2; d[3] = m3; d[4] = m4;
-        tie |= popped == m4;
+        tie_mask |= __ballot(popped == m4);
     }
     __device__ __forceinline__ float worst() const { return __uint_as_float(d[4]); }
     __device__ __forceinline__ unsigned worst_bits() const { return d[4]; }
-    __device__ __forceinline__ bool final_tie() const { return tie || d[0] == d[1] || d[1] == d[2] || d[2] == d[3] || d[3] == d[4]; }
+    __device__ __forceinline__ bool final_tie() const {
+        const bool tie = (tie_mask >> (threadIdx.x & 63)) & 1ull;
+        return tie || d[0] == d[1] || d[1] == d[2] || d[2] == d[3] || d[3] == d[4];
+    }
     __device__ __forceinline__ void to_top5(Top5& t) const {
 #pragma unroll
         for (int s = 0; s < 5; s++) { t.d[s] = __uint_as_float(d[s]); t.j[s] = j[s]; }
