@@ -862,9 +862,9 @@ __global__ __launch_bounds__(BS) void k_associate_surf(
     const bool live = (int)threadIdx.x < tile.y;
     int t = tile.x + threadIdx.x;
     int i = live ? (perm ? perm[t] : t) : 0;
+    float4 ql = queries[live ? i : 0];     // requested before the (dependent, scalar) pose loads: the two latencies overlap
     dq Q2; d3 T2;
     load_assoc_pose(pa, P, Q2, T2);
-    float4 ql = queries[live ? i : 0];
     d3 pmd = qrot(Q2, d3{(double)ql.x, (double)ql.y, (double)ql.z}) + T2;   // transformPoint, L:695-711
     float px = (float)pmd.x, py = (float)pmd.y, pz = (float)pmd.z;
     Top5 nn;
@@ -896,9 +896,9 @@ __global__ __launch_bounds__(BS) void k_associate_edge(
     const bool live = (int)threadIdx.x < tile.y;
     int t = tile.x + threadIdx.x;
     int i = live ? (perm ? perm[t] : t) : 0;
+    float4 ql = queries[live ? i : 0];     // requested before the (dependent, scalar) pose loads: the two latencies overlap
     dq Q2; d3 T2;
     load_assoc_pose(pa, P, Q2, T2);
-    float4 ql = queries[live ? i : 0];
     d3 pmd = qrot(Q2, d3{(double)ql.x, (double)ql.y, (double)ql.z}) + T2;
     float px = (float)pmd.x, py = (float)pmd.y, pz = (float)pmd.z;
     Top5 nn;
