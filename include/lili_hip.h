@@ -90,7 +90,8 @@ int lili_sync(lili_ctx* ctx);
 /* When enabled, associate also stores the 5 neighbour indices / squared distances per query so that
  * lili_s2m_get_neighbors can return them (parity tests).  Off by default (extra HBM writes). */
 int lili_set_debug(lili_ctx* ctx, int keep_neighbors);
-/* Tuning knobs that never change results: "bin_queries" (1 = order queries by map super-cell once per scan; use it
+/* Tuning knobs that never change which correspondences are found ("fuse_tail" changes the block partition of the
+ * Gram sum, i.e. its rounding at the 1e-16 level; all others are bit-identical): "bin_queries" (1 = order queries by map super-cell once per scan; use it
  * when the query order is not spatially coherent; default 0), "tiled" (1 = LDS-staged neighbourhood tiles, needs
  * bin_queries; default 0), "max_cells" (cap on grid cells of the map index; coarser cells stay exact),
  * "grid_reach" (1 = cells of the gate radius, 27-cell search; 2 = smaller cells, inner 27 cells first and the shell of

@@ -406,3 +406,43 @@ def test_window_iteration_equals_sequential(gpu_ctx, oracle):
         assert st == 0 and np.array_equal(t, ref[k][0]) and np.array_equal(q, ref[k][1])
     with pytest.raises(L.LiliError):
         m.iterate_window([0, 0], 1, L.MASK_SURF)
+
+
+@pytest.mark.parametrize("opt", ["nn_cache", "fuse_tail"])
+def test_tuning_options_do_not_change_results(gpu_ctx, oracle, opt):
+    """The measured-and-rejected switches stay exact: neighbour-cache bound seeding gives bit-identical
+    poses, neighbour lists and counts over several iterations; the fused reduce+GN tail the same up to its different
+    (still deterministic) block partition of the Gram sum."""
+    room = synth.make_room(seed=24, n_query=8000, n_edge_query=200)
+    P = L.make_params("rot")
+    tb, qb = L.api.body_pose_from_lidar(room["t_true"], room["q_true"], P)
+    t0, q0 = synth.perturbed_pose(tb, qb, np.random.default_rng(13), 0.15, 1.0)
+    res = []
+    try:
+        for val in (0, 1):
+            gpu_ctx.set_option(opt, val)
+            m = L.ScanToMapMatcher(gpu_ctx, P)
+            gpu_ctx.set_debug(True)
+            m.set_input_cloud(L.KIND_SURF, room["map_xyz"])
+            m.set_input_cloud(L.KIND_EDGE, room["edge_map_xyz"])
+            m.set_queries(0, L.KIND_SURF, room["q_xyz"])
+            m.set_queries(0, L.KIND_EDGE, room["eq_xyz"])
+            m.pose_set(0, t0, q0)
+            m.iterate(0, 6, L.MASK_SURF | L.MASK_EDGE)
+            t, q, st = m.pose_get(0)
+            idx, d2 = m.neighbors(0, L.KIND_SURF, room["q_xyz"].shape[0])
+            G, cost, counts = m.linearize(0, t, q, L.MASK_SURF | L.MASK_EDGE)
+            res.append((t, q, st, idx, d2, G, counts))
+    finally:
+        gpu_ctx.set_option(opt, 0)
+    a, b = res
+    assert a[2] == b[2] == 0
+    inside = a[4][:, 4] < 1.0
+    assert inside.sum() > 1000
+    if opt == "nn_cache":         # only changes the pruning bound: bit-identical everything
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        assert np.array_equal(a[3][inside], b[3][inside]) and np.array_equal(a[4][inside], b[4][inside])
+        assert np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6])
+    else:                         # fuse_tail uses 1024-thread linearisation blocks: another (fixed) summation order
+        assert np.abs(a[0] - b[0]).max() < 1e-12 and np.abs(a[1] - b[1]).max() < 1e-12
+        assert np.abs(a[5] - b[5]).max() <= 1e-12 * np.abs(a[5]).max() and np.array_equal(a[6], b[6])
