@@ -1,0 +1,49 @@
+"""The C ABI driven by a plain C++ host program (examples/s2m_demo.cpp: no Python, no PyTorch in that process):
+its result must be bit-identical to the same calls made through the ctypes binding."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import lili_om_amd as L
+from lili_om_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEMO = os.path.join(ROOT, "examples", "s2m_demo")
+
+
+@pytest.mark.parametrize("variant", ["rot", "frontend"])
+def test_cpp_host_matches_python_binding(gpu_ctx, tmp_path, variant):
+    if not os.path.exists(DEMO):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "-s"])
+    room = synth.make_room(seed=31, n_query=7000, n_edge_query=100)
+    P = L.make_params(variant)
+    t, q = room["t_true"], room["q_true"]
+    if variant == "rot":
+        t, q = L.api.body_pose_from_lidar(t, q, P)
+    t0, q0 = synth.perturbed_pose(t, q, np.random.default_rng(17), 0.1, 0.8)
+    path = tmp_path / "in.bin"
+    with open(path, "wb") as f:
+        f.write(struct.pack("<qqii", room["map_xyz"].shape[0], room["q_xyz"].shape[0], int(P.variant), 0))
+        f.write(np.concatenate([t0, q0]).astype("<f8").tobytes())
+        f.write(np.ascontiguousarray(room["map_xyz"], "<f4").tobytes())
+        f.write(np.ascontiguousarray(room["q_xyz"], "<f4").tobytes())
+    out = subprocess.run([DEMO, str(path), "7"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    tok = out.stdout.split()
+    pose_c = np.array([float(v) for v in tok[:7]])
+    status_c, n_c = int(tok[8]), int(tok[10])
+    m = L.ScanToMapMatcher(gpu_ctx, P)
+    m.set_input_cloud(L.KIND_SURF, room["map_xyz"])
+    m.set_queries(0, L.KIND_SURF, room["q_xyz"])
+    m.pose_set(0, t0, q0)
+    m.iterate(0, 7, L.MASK_SURF)
+    tp, qp, st = m.pose_get(0)
+    Q2, T2 = L.api.assoc_transform(tp, qp, P) if variant == "rot" else (qp, tp)
+    n_p = m.find_corresponding_surf_features(0, Q2, T2)
+    assert status_c == st == 0
+    assert np.array_equal(pose_c, np.concatenate([tp, qp]))          # %.17g round-trips doubles exactly
+    assert n_c == n_p > 1000
