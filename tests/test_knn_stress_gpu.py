@@ -94,3 +94,24 @@ def test_large_gate_radius(gpu_ctx, oracle):
     q = rng.uniform(-11, 11, (5000, 3)).astype(np.float32)
     _check(gpu_ctx, oracle, m, q, gate=1.5, min_inside=1000)
     _check(gpu_ctx, oracle, m, q, gate=0.25, min_inside=5)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_randomised_scenes_and_index_settings(gpu_ctx, oracle, seed):
+    """Seeded differential sweep: random map sizes / extents / anisotropy / clustering, random gates and index settings."""
+    rng = np.random.default_rng(1000 + seed)
+    n_map = int(rng.integers(2000, 60000))
+    ext = rng.uniform(2.0, 40.0, 3) * np.array([1.0, 1.0, rng.choice([1.0, 0.05])])     # sometimes nearly planar
+    pts = rng.uniform(-1, 1, (n_map, 3)) * ext
+    k = int(rng.integers(0, 4))
+    if k:                                                                                # a few dense clusters
+        centres = rng.uniform(-1, 1, (k, 3)) * ext
+        extra = np.concatenate([c + rng.normal(0, rng.uniform(0.02, 0.5), (n_map // 4, 3)) for c in centres])
+        pts = np.concatenate([pts, extra])
+    pts = (pts + rng.uniform(-500, 500, 3)).astype(np.float32)                           # away from the origin: f32 grid effects
+    q = (pts[rng.integers(0, pts.shape[0], 4000)] + rng.normal(0, rng.uniform(0.01, 1.0), (4000, 3))).astype(np.float32)
+    gate = float(rng.choice([0.25, 0.64, 1.0, 1.5, 2.25]))
+    reach = int(rng.choice([1, 2]))
+    pct = int(rng.integers(50, 101))
+    inside = _check(gpu_ctx, oracle, pts, q, gate=gate, min_inside=0, reach=reach, cell_pct=pct)
+    assert inside.sum() + (~inside).sum() == 4000
