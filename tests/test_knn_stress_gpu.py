@@ -115,3 +115,19 @@ def test_randomised_scenes_and_index_settings(gpu_ctx, oracle, seed):
     pct = int(rng.integers(50, 101))
     inside = _check(gpu_ctx, oracle, pts, q, gate=gate, min_inside=0, reach=reach, cell_pct=pct)
     assert inside.sum() + (~inside).sum() == 4000
+
+
+def test_capped_cell_count_stays_exact(gpu_ctx, oracle):
+    """max_cells smaller than the bounding box needs: the cell edge grows (coarser cells, same exact result)."""
+    rng = np.random.default_rng(77)
+    pts = rng.uniform(-8, 8, (40000, 3)).astype(np.float32)
+    q = (pts[rng.integers(0, 40000, 3000)] + rng.normal(0, 0.3, (3000, 3))).astype(np.float32)
+    try:
+        gpu_ctx.set_option("max_cells", 2000)
+        m = L.ScanToMapMatcher(gpu_ctx, L.make_params("frontend"))
+        m.set_input_cloud(L.KIND_SURF, pts)
+        n, n_cells, cell = m.map_info(L.KIND_SURF)
+        assert n_cells <= 2000 and cell > 1.2          # 0.66 m would need ~15 000 cells
+        _check(gpu_ctx, oracle, pts, q, gate=1.0, min_inside=100)
+    finally:
+        gpu_ctx.set_option("max_cells", 1 << 27)
