@@ -525,7 +525,13 @@ __device__ __forceinline__ int sum_block_counts(const int* __restrict__ block_co
     __shared__ int part[16];
     __shared__ int total;
     int s = 0;
-    for (int b = threadIdx.x; b < nb; b += blockDim.x) s += block_counts[b];
+    // four independent loads per trip (the plain strided loop serialises one L2 round trip per element)
+    const int bd = blockDim.x;
+    for (int b0 = threadIdx.x; b0 < nb; b0 += 4 * bd) {
+        const int b1 = b0 + bd, b2 = b0 + 2 * bd, b3 = b0 + 3 * bd;
+        const int v0 = block_counts[b0], v1 = b1 < nb ? block_counts[b1] : 0, v2 = b2 < nb ? block_counts[b2] : 0, v3 = b3 < nb ? block_counts[b3] : 0;
+        s += (v0 + v1) + (v2 + v3);
+    }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -1268,6 +1274,7 @@ __device__ void reduce_partials_block(const double* part_surf, int nb_surf, cons
     }
     tstamp(state, do_gn, 0, 9);
     __syncthreads();
+    if (threadIdx.x >= 128) return;     // the rest is two waves' work (threads < 72): the later barriers then involve only them
     if (threadIdx.x < 40) {
         int k = threadIdx.x;
         double ss = 0.0, se = 0.0;
