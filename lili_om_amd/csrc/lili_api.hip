@@ -46,6 +46,10 @@ static MatchParams to_device_params(const lili_s2m_params* p) {
         const double n2 = w * w + qx * qx + qy * qy + qz * qz;
         if (n2 > 0) { m.q_lb_inv[0] = w / n2; m.q_lb_inv[1] = -qx / n2; m.q_lb_inv[2] = -qy / n2; m.q_lb_inv[3] = -qz / n2; }
         else m.q_lb_inv[0] = m.q_lb_inv[1] = m.q_lb_inv[2] = m.q_lb_inv[3] = 0.0;
+        // ceres::Jet's operator/ multiplies by the reciprocal (tests/golden/ref_factors.npz pins this against the reference functor)
+        const double gi = 1.0 / n2;
+        if (n2 > 0) { m.q_lb_inv_jet[0] = w * gi; m.q_lb_inv_jet[1] = (-qx) * gi; m.q_lb_inv_jet[2] = (-qy) * gi; m.q_lb_inv_jet[3] = (-qz) * gi; }
+        else m.q_lb_inv_jet[0] = m.q_lb_inv_jet[1] = m.q_lb_inv_jet[2] = m.q_lb_inv_jet[3] = 0.0;
     }
     for (int i = 0; i < 3; i++) m.t_lb[i] = p->t_lb[i];
     m.scale_surf_num = p->scale_surf_num; m.scale_edge_num = p->scale_edge_num;

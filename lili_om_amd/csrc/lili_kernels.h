@@ -54,6 +54,7 @@ struct MatchParams {     // device copy of lili_s2m_params (+ derived values)
     double loss_a, lidar_const, kd_max_radius, edge_gate, surf_dist_thres, reflect_thres, surf_weight_min, edge_dist_max;
     double q_lb[4], t_lb[3];
     double q_lb_inv[4];   // Eigen inverse() of q_lb (conjugate / squared norm), computed once on the host: IEEE divisions, same bits
+    double q_lb_inv_jet[4];   // the same inverse as the plane factor sees it on ceres::Jet (LidarKeyframeFactor.h:86): conjugate * (1 / n2)
     double scale_surf_num, scale_edge_num;
     int debug;   // ablation switches for profiling only (LILI_DEBUG env): 1 = skip the plane/line fit, 2 = skip the search
 };

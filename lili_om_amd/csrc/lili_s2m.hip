@@ -1037,7 +1037,7 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize_surf(
     GramAcc ga; ga.init();
     dq Q; d3 T;
     load_body_pose(pa, Q, T);
-    const dq qlb_inv{P.q_lb_inv[0], P.q_lb_inv[1], P.q_lb_inv[2], P.q_lb_inv[3]};
+    const dq qlb_inv{P.q_lb_inv_jet[0], P.q_lb_inv_jet[1], P.q_lb_inv_jet[2], P.q_lb_inv_jet[3]};
     // N of R:861: this rank's count (sum of the association's block counts) or, when a multi-GPU caller has
     // all-reduced it, the global count in state->n_res
     // the first tile's records are requested before the count reduction below (which synchronises the block twice), and

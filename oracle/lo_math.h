@@ -3,9 +3,11 @@
 //
 // Small dependency-free f64 linear algebra that restates, on the CPU, the third-party arithmetic
 // the reference calls on its hot path (Eigen 3.3 / Ceres 2.0 — NOT present under /root/reference,
-// unpinned: see SURVEY.md §8c, App. B).  PARITY UNPINNED: the reference ships no golden vectors
-// and cannot be built here, so this restatement is checked against semantics (brute force,
-// finite differences, hand-checkable cases), not against reference outputs.
+// unpinned: see SURVEY.md §8c, App. B).  PARITY: the extractor and factor-functor restatements built
+// on this file are pinned bit for bit against the reference's own sources compiled as-is
+// (oracle/refshim/README.md, tests/test_reference_cpu.py); the third-party arithmetic restated HERE
+// (Eigen / Ceres / PCL rules) and the matcher's association remain checked against semantics only
+// (brute force, LAPACK, complex-step differences, hand-checkable cases).
 //
 // Compile with -ffp-contract=off and without -ffast-math (reference build: L/CMakeLists.txt:5,62).
 #pragma once

@@ -341,7 +341,12 @@ static Jet7 edge_factor(const double t[3], const double q[4], V3 cp, V3 lpa, V3 
 static Jet7 plane_factor(const double t[3], const double q[4], V3 cp, V3 n, Q4 qlb, V3 tlb, double d, double score) {
     JV3 jt{Jet7(t[0], 0), Jet7(t[1], 1), Jet7(t[2], 2)};
     JQ4 jq{Jet7(q[0], 3), Jet7(q[1], 4), Jet7(q[2], 5), Jet7(q[3], 6)};
-    Q4 qi = qinv(qlb);
+    // q_l_b.inverse() runs on Jets there (:86): Eigen's conjugate().coeffs() / squaredNorm() with ceres::Jet's operator/,
+    // which multiplies by the reciprocal of the denominator (ceres/jet.h) — one ulp away from a plain division for the
+    // non-unit q_lb of the configs; pinned by tests/golden/ref_factors.npz (the functor itself, compiled from the reference).
+    double n2 = qlb.x * qlb.x + qlb.y * qlb.y + qlb.z * qlb.z + qlb.w * qlb.w;
+    double gi = 1.0 / n2;
+    Q4 qi = n2 > 0 ? Q4{qlb.w * gi, (-qlb.x) * gi, (-qlb.y) * gi, (-qlb.z) * gi} : Q4{0, 0, 0, 0};
     JQ4 jqi{Jet7(qi.w), Jet7(qi.x), Jet7(qi.y), Jet7(qi.z)};
     JV3 pw = jqrot(jqi, jv3c(cp) - jv3c(tlb));
     pw = jqrot(jq, pw) + jt;

@@ -1,0 +1,159 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  ctypes access to oracle/_ref/: the reference's OWN hot-path sources
+(LiLi-OM-ROT/src/Preprocessing.cpp, LiLi-OM/src/Preprocessing.cpp, include/factors/LidarKeyframeFactor.h) compiled
+unmodified from /root/reference against the stand-in third-party headers of oracle/refshim/ (recipe:
+oracle/refshim/Makefile).  Used to pin the restatement in oracle/*.cpp and to generate tests/golden/ref_*.npz;
+never loaded by the product.  /root/reference does not exist on the GPU box: the prebuilt .so files travel, the
+sources do not, and nothing here reads /root/reference at run time."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_DIR = os.path.join(HERE, "_ref")
+REFERENCE_ROOT = "/root/reference"
+_LIBS = {}
+
+
+def build():
+    """Build oracle/_ref when the reference sources are present (the build container); no-op otherwise."""
+    if not os.path.isdir(REFERENCE_ROOT):
+        return False
+    subprocess.check_call(["make", "-C", os.path.join(HERE, "refshim"), "-s"])
+    return True
+
+
+def available():
+    return all(os.path.exists(os.path.join(REF_DIR, f"libref_{n}.so")) for n in ("rot", "livox", "factors"))
+
+
+def _lib(name):
+    if name not in _LIBS:
+        _LIBS[name] = C.CDLL(os.path.join(REF_DIR, f"libref_{name}.so"))
+    return _LIBS[name]
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Preprocessing:
+    """The reference's Preprocessing node (flavour 'rot' or 'livox') driven in-process.  ROS parameters are the
+    yaml keys the node reads in its constructor, e.g. {'/preprocessing/line_num': 64, '/preprocessing/ds_rate': 4}."""
+
+    def __init__(self, flavour, params=None, verbose=False):
+        self.flavour = flavour
+        self.lib = _lib(flavour)
+        L = self.lib
+        L.ref_pre_create.restype = C.c_void_p
+        L.ref_param_num.argtypes = [C.c_char_p, C.c_double]
+        L.ref_param_str.argtypes = [C.c_char_p, C.c_char_p]
+        L.ref_pre_imu.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.ref_pre_cloud.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_int]
+        L.ref_pre_n_published.argtypes = [C.c_void_p]
+        L.ref_pre_msg_info.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.ref_pre_msg_data.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.ref_pre_destroy.argtypes = [C.c_void_p]
+        L.ref_set_verbose(int(bool(verbose)))
+        L.ref_param_clear()
+        for k, v in (params or {}).items():
+            if isinstance(v, str):
+                L.ref_param_str(k.encode(), v.encode())
+            else:
+                L.ref_param_num(k.encode(), float(v))
+        self.h = C.c_void_p(L.ref_pre_create())
+        self.step = 32 if flavour == "rot" else 48
+
+    def close(self):
+        if self.h:
+            self.lib.ref_pre_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def imu(self, t, gyr):
+        self.lib.ref_pre_imu(self.h, float(t), float(gyr[0]), float(gyr[1]), float(gyr[2]))
+
+    def cloud(self, t, pts):
+        """pts: rot — (n,4) float32 x,y,z,intensity;  livox — (n,5) float32 x,y,z,intensity,curvature.
+        Packed into the PCL wire layout before it is handed to cloudHandler."""
+        pts = np.ascontiguousarray(pts, np.float32)
+        n = pts.shape[0]
+        buf = np.zeros((n, self.step // 4), np.float32)
+        buf[:, 0:3] = pts[:, 0:3]
+        buf[:, 3] = 1.0
+        if self.flavour == "rot":
+            buf[:, 4] = pts[:, 3]
+        else:
+            buf[:, 8] = pts[:, 3]
+            buf[:, 9] = pts[:, 4]
+        self.lib.ref_pre_cloud(self.h, float(t), _p(buf), n, self.step)
+
+    def published(self):
+        """[(topic, stamp, (n, point_step/4) float32 array)] in publication order."""
+        out = []
+        for i in range(self.lib.ref_pre_n_published(self.h)):
+            topic = C.create_string_buffer(64)
+            stamp, step = C.c_double(0), C.c_int(0)
+            n = self.lib.ref_pre_msg_info(self.h, i, topic, C.byref(stamp), C.byref(step))
+            a = np.zeros((n, max(step.value // 4, 1)), np.float32)
+            if n:
+                self.lib.ref_pre_msg_data(self.h, i, _p(a))
+            out.append((topic.value.decode(), stamp.value, a))
+        return out
+
+
+def run_scans(flavour, params, scans, scan_stamps, imu_stamps, imu_gyr):
+    """Replay: IMU samples and clouds are delivered in time order (IMU first on ties, like a 200 Hz stream ahead of a
+    10 Hz one).  Returns a list with one dict per PROCESSED scan: {'stamp', 'cutted', 'edge', 'surf'} — cutted/edge/surf
+    are the float payloads of /lidar_cloud_cutted, /edge_features, /surf_features."""
+    node = Preprocessing(flavour, params)
+    ev = [(float(t), 0, i) for i, t in enumerate(imu_stamps)] + [(float(t), 1, i) for i, t in enumerate(scan_stamps)]
+    ev.sort()
+    for t, kind, i in ev:
+        if kind == 0:
+            node.imu(t, imu_gyr[i])
+        else:
+            node.cloud(t, scans[i])
+    msgs = node.published()
+    node.close()
+    res = {}
+    for topic, stamp, a in msgs:
+        res.setdefault(stamp, {"stamp": stamp})[topic.strip("/").replace("lidar_cloud_", "").replace("_features", "")] = a
+    return [res[k] for k in sorted(res)]
+
+
+def _factor(fn, *args):
+    out = np.zeros(8, np.float64)
+    a = []
+    for x in args:
+        if isinstance(x, (float, int)):
+            a.append(C.c_double(float(x)))
+        else:
+            arr = np.ascontiguousarray(x, np.float64)
+            a.append(arr)
+    cargs = [(_p(x) if isinstance(x, np.ndarray) else x) for x in a]
+    rc = fn(*cargs, _p(out), 1)
+    if rc != 0:
+        raise RuntimeError("Evaluate returned false")
+    return out
+
+
+def edge_factor(cp, a, b, qlb, tlb, s, t, q):
+    """LidarEdgeFactor::Create(...)->Evaluate: [r, dr/dt(3), dr/dq(4, wxyz)]."""
+    return _factor(_lib("factors").ref_edge_factor, cp, a, b, qlb, tlb, float(s), t, q)
+
+
+def plane_factor(cp, n, qlb, tlb, d, score, t, q):
+    """LidarPlaneNormFactor::Create(...)->Evaluate: [r, dr/dt(3), dr/dq(4)]."""
+    return _factor(_lib("factors").ref_plane_factor, cp, n, qlb, tlb, float(d), float(score), t, q)
+
+
+def plane_incre_factor(cp, n, d, q, t):
+    """LidarPlaneNormIncreFactor::Create(...)->Evaluate: [r, dr/dq(4), dr/dt(3)]."""
+    return _factor(_lib("factors").ref_plane_incre_factor, cp, n, float(d), q, t)

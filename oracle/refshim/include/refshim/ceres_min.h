@@ -1,0 +1,110 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle/refshim/README.md).
+//
+// Stand-in for the part of Ceres Solver 2.0 that include/factors/LidarKeyframeFactor.h of the reference
+// touches: ceres::Jet<T, N> (value + N partials, arithmetic as published in ceres/jet.h: product rule,
+// quotient via the reciprocal of g.a, sqrt via 1 / (2 sqrt a)), ceres::CostFunction's Evaluate contract
+//  and ceres::AutoDiffCostFunction<Functor, kNumResiduals, N0, N1>, which seeds one Jet per
+// parameter scalar and copies the partials out row-major.  Loss functions are given for the losses
+// the reference names (closed forms from ceres/loss_function.h).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <vector>
+
+namespace ceres {
+
+template <class T, int N> struct Jet {
+    T a; T v[N];
+    Jet() : a(), v() {}
+    Jet(const T& value) : a(value), v() {}   // NOLINT: implicit like ceres
+    Jet(const T& value, int k) : a(value), v() { v[k] = T(1); }
+    Jet& operator+=(const Jet& g) { *this = *this + g; return *this; }
+    Jet& operator-=(const Jet& g) { *this = *this - g; return *this; }
+    Jet& operator*=(const Jet& g) { *this = *this * g; return *this; }
+    Jet& operator/=(const Jet& g) { *this = *this / g; return *this; }
+};
+template <class T, int N> Jet<T, N> operator+(const Jet<T, N>& f) { return f; }
+template <class T, int N> Jet<T, N> operator-(const Jet<T, N>& f) { Jet<T, N> r; r.a = -f.a; for (int i = 0; i < N; i++) r.v[i] = -f.v[i]; return r; }
+template <class T, int N> Jet<T, N> operator+(const Jet<T, N>& f, const Jet<T, N>& g) { Jet<T, N> r; r.a = f.a + g.a; for (int i = 0; i < N; i++) r.v[i] = f.v[i] + g.v[i]; return r; }
+template <class T, int N> Jet<T, N> operator-(const Jet<T, N>& f, const Jet<T, N>& g) { Jet<T, N> r; r.a = f.a - g.a; for (int i = 0; i < N; i++) r.v[i] = f.v[i] - g.v[i]; return r; }
+template <class T, int N> Jet<T, N> operator*(const Jet<T, N>& f, const Jet<T, N>& g) { Jet<T, N> r; r.a = f.a * g.a; for (int i = 0; i < N; i++) r.v[i] = f.a * g.v[i] + f.v[i] * g.a; return r; }
+template <class T, int N> Jet<T, N> operator/(const Jet<T, N>& f, const Jet<T, N>& g) {
+    const T g_a_inverse = T(1.0) / g.a;
+    const T f_a_by_g_a = f.a * g_a_inverse;
+    Jet<T, N> r; r.a = f_a_by_g_a;
+    for (int i = 0; i < N; i++) r.v[i] = (f.v[i] - f_a_by_g_a * g.v[i]) * g_a_inverse;
+    return r;
+}
+template <class T, int N> Jet<T, N> operator+(const Jet<T, N>& f, T s) { Jet<T, N> r = f; r.a = f.a + s; return r; }
+template <class T, int N> Jet<T, N> operator+(T s, const Jet<T, N>& f) { Jet<T, N> r = f; r.a = s + f.a; return r; }
+template <class T, int N> Jet<T, N> operator-(const Jet<T, N>& f, T s) { Jet<T, N> r = f; r.a = f.a - s; return r; }
+template <class T, int N> Jet<T, N> operator-(T s, const Jet<T, N>& f) { Jet<T, N> r; r.a = s - f.a; for (int i = 0; i < N; i++) r.v[i] = -f.v[i]; return r; }
+template <class T, int N> Jet<T, N> operator*(const Jet<T, N>& f, T s) { Jet<T, N> r; r.a = f.a * s; for (int i = 0; i < N; i++) r.v[i] = f.v[i] * s; return r; }
+template <class T, int N> Jet<T, N> operator*(T s, const Jet<T, N>& f) { Jet<T, N> r; r.a = f.a * s; for (int i = 0; i < N; i++) r.v[i] = f.v[i] * s; return r; }
+template <class T, int N> Jet<T, N> operator/(const Jet<T, N>& f, T s) { const T inv = T(1.0) / s; Jet<T, N> r; r.a = f.a * inv; for (int i = 0; i < N; i++) r.v[i] = f.v[i] * inv; return r; }
+template <class T, int N> bool operator<(const Jet<T, N>& f, const Jet<T, N>& g) { return f.a < g.a; }
+template <class T, int N> bool operator>(const Jet<T, N>& f, const Jet<T, N>& g) { return f.a > g.a; }
+template <class T, int N> bool operator>=(const Jet<T, N>& f, const Jet<T, N>& g) { return f.a >= g.a; }
+template <class T, int N> bool operator<=(const Jet<T, N>& f, const Jet<T, N>& g) { return f.a <= g.a; }
+template <class T, int N> Jet<T, N> sqrt(const Jet<T, N>& f) {
+    const T tmp = std::sqrt(f.a);
+    const T two_a_inverse = T(1.0) / (T(2.0) * tmp);
+    Jet<T, N> r; r.a = tmp; for (int i = 0; i < N; i++) r.v[i] = f.v[i] * two_a_inverse;
+    return r;
+}
+template <class T, int N> Jet<T, N> abs(const Jet<T, N>& f) { return f.a < T(0) ? -f : f; }
+
+class CostFunction {
+public:
+    virtual ~CostFunction() {}
+    virtual bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const = 0;
+    const std::vector<int>& parameter_block_sizes() const { return sizes_; }
+    int num_residuals() const { return nres_; }
+protected:
+    std::vector<int> sizes_; int nres_ = 0;
+};
+
+template <class Functor, int kNumResiduals, int N0, int N1> class AutoDiffCostFunction : public CostFunction {
+public:
+    explicit AutoDiffCostFunction(Functor* f) : f_(f) { sizes_ = {N0, N1}; nres_ = kNumResiduals; }
+    ~AutoDiffCostFunction() override { delete f_; }
+    bool Evaluate(double const* const* p, double* residuals, double** jacobians) const override {
+        static_assert(kNumResiduals == 1, "the lidar factors have one residual");
+        if (!jacobians) return (*f_)(p[0], p[1], residuals);
+        typedef Jet<double, N0 + N1> J;
+        J x0[N0], x1[N1], out[kNumResiduals];
+        for (int i = 0; i < N0; i++) x0[i] = J(p[0][i], i);
+        for (int i = 0; i < N1; i++) x1[i] = J(p[1][i], N0 + i);
+        if (!(*f_)(x0, x1, out)) return false;
+        residuals[0] = out[0].a;
+        if (jacobians[0]) for (int i = 0; i < N0; i++) jacobians[0][i] = out[0].v[i];
+        if (jacobians[1]) for (int i = 0; i < N1; i++) jacobians[1][i] = out[0].v[N0 + i];
+        return true;
+    }
+private:
+    Functor* f_;
+};
+
+// ceres/loss_function.h closed forms: rho[0] = rho(s), rho[1] = rho'(s), rho[2] = rho''(s)
+class LossFunction { public: virtual ~LossFunction() {} virtual void Evaluate(double s, double rho[3]) const = 0; };
+class CauchyLoss : public LossFunction {
+public:
+    explicit CauchyLoss(double a) : b_(a * a), c_(1 / b_) {}
+    void Evaluate(double s, double rho[3]) const override {
+        const double sum = 1.0 + s * c_; const double inv = 1.0 / sum;
+        rho[0] = b_ * std::log(sum); rho[1] = std::max(std::numeric_limits<double>::min(), inv); rho[2] = -c_ * (inv * inv);
+    }
+private: const double b_, c_;
+};
+class HuberLoss : public LossFunction {
+public:
+    explicit HuberLoss(double a) : a_(a), b_(a * a) {}
+    void Evaluate(double s, double rho[3]) const override {
+        if (s > b_) { const double r = std::sqrt(s); rho[0] = 2.0 * a_ * r - b_; rho[1] = std::max(std::numeric_limits<double>::min(), a_ / r); rho[2] = -rho[1] / (2.0 * s); }
+        else { rho[0] = s; rho[1] = 1.0; rho[2] = 0.0; }
+    }
+private: const double a_, b_;
+};
+
+}  // namespace ceres

@@ -1,0 +1,127 @@
+#!/usr/bin/env python
+"""Generates tests/golden/ref_*.npz by running the REFERENCE'S OWN sources (oracle/_ref, built from /root/reference by
+oracle/refshim/Makefile against stand-in third-party headers) on fixed-seed synthetic inputs.  These fixtures — unlike
+tests/golden/{s2m,extract}_*.npz, which come from the oracle — pin the oracle and the HIP path to code of the reference:
+
+  ref_rot.npz      LiLi-OM-ROT/src/Preprocessing.cpp driven with 4 clouds + a 200 Hz gyro stream: the three published
+                   clouds of the 2 processed scans (/lidar_cloud_cutted, /edge_features, /surf_features)
+  ref_livox.npz    LiLi-OM/src/Preprocessing.cpp, same protocol (large clouds stored as sha256 + every 8th row)
+  ref_factors.npz  LidarEdgeFactor / LidarPlaneNormFactor / LidarPlaneNormIncreFactor ::Create()->Evaluate() on random
+                   records: residual + both Jacobian blocks
+
+Only runs where /root/reference exists (the build container).  Run from the repository root:
+    python tests/golden/make_ref_golden.py
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from lili_om_amd import synth          # noqa: E402
+from oracle import ref as R            # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+ROT_QLB = [0.7071, 0.0, 0.0, 0.7071]                     # R/config/config_fr_iosb.yaml:38-41
+ROT_PARAMS = {"/preprocessing/lidar_topic": "/velodyne_points", "/preprocessing/line_num": 64, "/preprocessing/ds_rate": 4,
+              "/common/frame_id": "lili_om_rot", "/backend_fusion/imu_topic": "/imu/data",
+              "/backend_fusion/ql2b_w": ROT_QLB[0], "/backend_fusion/ql2b_x": ROT_QLB[1],
+              "/backend_fusion/ql2b_y": ROT_QLB[2], "/backend_fusion/ql2b_z": ROT_QLB[3]}
+LIVOX_PARAMS = {"/preprocessing/surf_thres": 0.28, "/preprocessing/edge_thres": 4.0, "/common/frame_id": "lili_om"}
+N_SCANS_IN = 4          # the node holds back two clouds (cloudHandler's queue): 4 in -> 2 processed
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def rot_inputs():
+    scans = []
+    for s in range(N_SCANS_IN):
+        w = synth.make_workload(n_map=200_000, n_az=200, half_extent=(150.0, 150.0), seed=synth.SEED_SCENE + 40 + s)
+        refl = np.random.default_rng(40 + s).integers(1, 255, w["scan_xyz"].shape[0]).astype(np.float32)
+        scans.append(np.concatenate([w["scan_xyz"], refl[:, None]], 1).astype(np.float32))
+    stamps = 100.0 + 0.1 * np.arange(N_SCANS_IN)
+    imu_t = 99.95 + 0.005 * np.arange(100)
+    gyr = 0.2 * np.random.default_rng(5).standard_normal((100, 3)) + np.array([0.1, -0.05, 0.3])
+    return scans, stamps, imu_t, gyr
+
+
+def livox_inputs():
+    scans = [synth.make_livox_scan(20 + s) for s in range(N_SCANS_IN)]
+    stamps = 50.0 + 0.1 * np.arange(N_SCANS_IN)
+    imu_t = 49.97 + 0.005 * np.arange(100)
+    gyr = 0.2 * np.random.default_rng(6).standard_normal((100, 3)) + np.array([0.1, -0.05, 0.3])
+    return scans, stamps, imu_t, gyr
+
+
+def factor_inputs(n=64, seed=77):
+    rng = np.random.default_rng(seed)
+    u = lambda *s: rng.uniform(-1.0, 1.0, s)                                           # noqa: E731
+    q = u(n, 4) + np.array([2.0, 0, 0, 0])
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    nrm = u(n, 3)
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    return dict(cp=(20 * u(n, 3)).astype(np.float32).astype(np.float64), a=(20 * u(n, 3)).astype(np.float32).astype(np.float64),
+                b=(20 * u(n, 3)).astype(np.float32).astype(np.float64), n=nrm.astype(np.float32).astype(np.float64),
+                d=u(n).astype(np.float32).astype(np.float64), s=rng.uniform(0.1, 20.0, n), t=3 * u(n, 3), q=q,
+                qlb=np.array(ROT_QLB), tlb=np.array([-0.18, 0.0, -0.095]))
+
+
+PAYLOAD_ROT = [0, 1, 2, 4]                       # x y z intensity of the 32-byte PointXYZI
+PAYLOAD_LIVOX = [0, 1, 2, 4, 5, 6, 8, 9]         # x y z | normal | intensity curvature of the 48-byte PointXYZINormal
+
+
+def run_rot():
+    scans, stamps, imu_t, gyr = rot_inputs()
+    out = R.run_scans("rot", ROT_PARAMS, scans, stamps, imu_t, gyr)
+    d = dict(n_processed=len(out))
+    for k, o in enumerate(out):
+        d[f"stamp{k}"] = o["stamp"]
+        for name in ("cutted", "edge", "surf"):
+            d[f"{name}{k}"] = o[name][:, PAYLOAD_ROT]
+    return d
+
+
+def run_livox():
+    scans, stamps, imu_t, gyr = livox_inputs()
+    out = R.run_scans("livox", LIVOX_PARAMS, scans, stamps, imu_t, gyr)
+    d = dict(n_processed=len(out))
+    for k, o in enumerate(out):
+        d[f"stamp{k}"] = o["stamp"]
+        d[f"edge{k}"] = o["edge"][:, PAYLOAD_LIVOX]
+        for name in ("cutted", "surf"):
+            a = o[name][:, PAYLOAD_LIVOX]
+            d[f"{name}{k}_n"] = a.shape[0]
+            d[f"{name}{k}_sha_payload"] = sha(a[:, [0, 1, 2, 6, 7]])        # x y z intensity curvature
+            d[f"{name}{k}_sha_absn"] = sha(np.abs(a[:, 3:6]))               # stored normal / direction, sign-free (Eigen's sign is arbitrary)
+            d[f"{name}{k}_every8"] = a[::8]
+    return d
+
+
+def run_factors():
+    f = factor_inputs()
+    n = f["cp"].shape[0]
+    e, p, pi = np.zeros((n, 8)), np.zeros((n, 8)), np.zeros((n, 8))
+    for i in range(n):
+        e[i] = R.edge_factor(f["cp"][i], f["a"][i], f["b"][i], f["qlb"], f["tlb"], f["s"][i], f["t"][i], f["q"][i])
+        p[i] = R.plane_factor(f["cp"][i], f["n"][i], f["qlb"], f["tlb"], f["d"][i], f["s"][i], f["t"][i], f["q"][i])
+        pi[i] = R.plane_incre_factor(f["cp"][i], f["n"][i], f["d"][i], f["q"][i], f["t"][i])
+    return dict(edge=e, plane=p, plane_incre=pi)
+
+
+def main():
+    if not R.build():
+        raise SystemExit("/root/reference is not present: the reference fixtures can only be generated in the build container")
+    np.savez_compressed(os.path.join(HERE, "ref_rot.npz"), **run_rot())
+    np.savez_compressed(os.path.join(HERE, "ref_livox.npz"), **run_livox())
+    np.savez_compressed(os.path.join(HERE, "ref_factors.npz"), **run_factors())
+    for f in ("ref_rot.npz", "ref_livox.npz", "ref_factors.npz"):
+        print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,122 @@
+"""HIP path vs the REFERENCE'S OWN outputs (tests/golden/ref_*.npz, produced by oracle/_ref from the reference's unmodified
+Preprocessing.cpp / LidarKeyframeFactor.h — see tests/golden/make_ref_golden.py).  No oracle in the loop.
+
+Bars: Livox — every published point bit-exact in its payload (x, y, z, intensity, curvature) and in list order, stored
+normals within 2e-6 up to Eigen's arbitrary sign.  ROT — the same features in the same order (counts + positions);
+positions bit-identical except where glibc's float atan2f (not correctly rounded, libm-version dependent) and the
+correctly rounded value the GPU uses differ in the last bit of relTime (<= 1 ulp of the deskewed coordinate, < 1 % of rows).
+Factors — the analytic residual/Jacobian rows behind lili_s2m_linearize vs Create()->Evaluate() of the three functors."""
+import hashlib
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+import lili_om_amd as L
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+_spec = importlib.util.spec_from_file_location("make_ref_golden", os.path.join(G, "make_ref_golden.py"))
+M = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(M)
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _q_imu(integ, stamps, imu_t, gyr, k):
+    m = imu_t <= stamps[k + 2]
+    return integ.integrate(imu_t[m], gyr[m], stamps[k + 1])
+
+
+def test_gpu_rot_extractor_vs_reference(gpu_ctx):
+    g = np.load(os.path.join(G, "ref_rot.npz"))
+    scans, stamps, imu_t, gyr = M.rot_inputs()
+    integ = L.api.ImuIntegrator()
+    ex = L.RotExtractor(gpu_ctx, n_scans=64, ds_rate=4)
+    for k in range(int(g["n_processed"])):
+        out = ex.extract(scans[k], _q_imu(integ, stamps, imu_t, gyr, k), M.ROT_QLB, debug=True)
+        for mine, ref in ((out["full"], g[f"cutted{k}"]), (out["edge"], g[f"edge{k}"]), (out["surf"], g[f"surf{k}"])):
+            assert mine.shape == ref.shape                                   # same features, same order
+            np.testing.assert_allclose(mine, ref, rtol=2e-6, atol=2e-5)
+        same = (_bits(out["full"]) == _bits(g[f"cutted{k}"])).all(1).mean()
+        assert same > 0.99, same
+        assert (_bits(out["edge"]) == _bits(g[f"edge{k}"])).all(1).mean() > 0.97
+
+
+def test_gpu_livox_extractor_vs_reference(gpu_ctx):
+    g = np.load(os.path.join(G, "ref_livox.npz"))
+    scans, stamps, imu_t, gyr = M.livox_inputs()
+    integ = L.api.ImuIntegrator()
+    ex = L.LivoxExtractor(gpu_ctx)
+    pay = [0, 1, 2, 6, 7]
+    for k in range(int(g["n_processed"])):
+        out = ex.extract(scans[k], _q_imu(integ, stamps, imu_t, gyr, k), debug=True)
+        for name in ("cutted", "surf"):
+            a = out[name]
+            assert a.shape[0] == int(g[f"{name}{k}_n"])
+            assert _sha(a[:, pay]) == str(g[f"{name}{k}_sha_payload"]), name          # every point, bit-exact, in order
+            np.testing.assert_allclose(np.abs(a[::8, 3:6]), np.abs(g[f"{name}{k}_every8"][:, 3:6]), rtol=0, atol=2e-6)
+        e, ge = out["edge"], g[f"edge{k}"]
+        assert e.shape == ge.shape
+        assert np.array_equal(_bits(e[:, pay]), _bits(ge[:, pay]))
+        np.testing.assert_allclose(np.abs(e[:, 3:6]), np.abs(ge[:, 3:6]), rtol=0, atol=2e-6)
+
+
+def _cauchy_rows(rows):
+    """ResidualBlockInfo::Evaluate's corrector for CauchyLoss(1.0) (L/src/MarginalizationFactor.cpp:44-70): rho'' < 0 always,
+    so residual and Jacobian are both scaled by sqrt(rho') = 1 / sqrt(1 + r^2).  rows: (n, 8) = [J(7), r]."""
+    return rows / np.sqrt(1.0 + rows[:, 7:8] ** 2)
+
+
+@pytest.mark.parametrize("variant", ["livox", "rot"])
+def test_gpu_linearize_vs_reference_functors(gpu_ctx, variant):
+    """lili_s2m_linearize (analytic Jacobians, MFMA Gram) vs the reference's OWN functors: the records the GPU association
+    produced are evaluated one by one through LidarPlaneNormFactor / LidarEdgeFactor ::Create()->Evaluate() of
+    oracle/_ref/libref_factors.so (prebuilt from /root/reference's header; it travels with the snapshot), robustified and
+    summed in numpy.  No oracle restatement in the loop."""
+    from oracle import ref as R
+    from lili_om_amd import synth
+    if not R.available():
+        pytest.skip("oracle/_ref not built")
+    room = synth.make_room(seed=12, n_query=1500, n_edge_query=200)
+    P = L.make_params(variant)
+    m = L.ScanToMapMatcher(gpu_ctx, P)
+    m.set_input_cloud(L.KIND_SURF, np.c_[room["map_xyz"], room["map_refl"]] if variant == "livox" else room["map_xyz"])
+    m.set_input_cloud(L.KIND_EDGE, room["edge_map_xyz"])
+    m.set_queries(0, L.KIND_SURF, np.c_[room["q_xyz"], room["q_refl"]] if variant == "livox" else room["q_xyz"])
+    m.set_queries(0, L.KIND_EDGE, room["eq_xyz"])
+    tb, qb = L.api.body_pose_from_lidar(room["t_true"], room["q_true"], P)
+    t0, q0 = synth.perturbed_pose(tb, qb, np.random.default_rng(3), 0.05, 0.5)
+    Q2, T2 = L.api.assoc_transform(t0, q0, P)
+    ns = m.find_corresponding_surf_features(0, Q2, T2)
+    ne = m.find_corresponding_corner_features(0, Q2, T2)
+    assert ns > 500 and ne > 20
+    rs, re_ = m.surf_records(0, ns), m.edge_records(0, ne)
+    qlb, tlb = np.array(list(P.q_lb)), np.array(list(P.t_lb))
+    ss = P.scale_surf_num / ns if P.scale_surf_num else 1.0
+    se = P.scale_edge_num / ne if P.scale_edge_num else 1.0
+    rows_s = np.zeros((ns, 8))
+    for i in range(ns):
+        o = R.plane_factor(rs["cp"][i].astype(np.float64), rs["n"][i].astype(np.float64), qlb, tlb, float(rs["d"][i]),
+                           float(rs["score"][i]) * ss, t0, q0)
+        rows_s[i] = np.r_[o[1:8], o[0]]
+    rows_e = np.zeros((ne, 8))
+    for i in range(ne):
+        o = R.edge_factor(re_["cp"][i].astype(np.float64), re_["a"][i].astype(np.float64), re_["b"][i].astype(np.float64), qlb, tlb,
+                          float(re_["s"][i]) * se, t0, q0)
+        rows_e[i] = np.r_[o[1:8], o[0]]
+    for mask, rows in ((L.MASK_SURF, rows_s), (L.MASK_EDGE, rows_e)):
+        Gg, cost, counts = m.linearize(0, t0, q0, mask)
+        rr = _cauchy_rows(rows)
+        Gr = rr.T @ rr
+        assert np.abs(Gg - Gr).max() <= 1e-9 * np.abs(Gr).max(), (variant, mask, np.abs(Gg - Gr).max() / np.abs(Gr).max())
+        cost_ref = 0.5 * np.log1p(rows[:, 7] ** 2).sum()
+        assert abs(cost - cost_ref) <= 1e-9 * max(1.0, cost_ref)
