@@ -25,7 +25,7 @@ def build():
 
 
 def available():
-    return all(os.path.exists(os.path.join(REF_DIR, f"libref_{n}.so")) for n in ("rot", "livox", "factors"))
+    return all(os.path.exists(os.path.join(REF_DIR, f"libref_{n}.so")) for n in ("rot", "livox", "factors", "lo"))
 
 
 def _lib(name):
@@ -157,3 +157,73 @@ def plane_factor(cp, n, qlb, tlb, d, score, t, q):
 def plane_incre_factor(cp, n, d, q, t):
     """LidarPlaneNormIncreFactor::Create(...)->Evaluate: [r, dr/dq(4), dr/dt(3)]."""
     return _factor(_lib("factors").ref_plane_incre_factor, cp, n, float(d), q, t)
+
+
+class LidarOdometry:
+    """The reference's front-end node (LiLi-OM/src/LidarOdometry.cpp, compiled unmodified) driven frame by frame.
+    ceres::Solve is the documented stand-in: it logs the residual blocks the reference built and takes ONE Gauss-Newton
+    step (oracle/refshim/ref_lo.cpp).  frame() takes the three clouds of Preprocessing as (n, 12) float32 rows in the
+    48-byte PointXYZINormal layout."""
+
+    def __init__(self, params=None, verbose=False):
+        L = self.lib = _lib("lo")
+        L.ref_lo_create.restype = C.c_void_p
+        L.ref_param_num.argtypes = [C.c_char_p, C.c_double]
+        L.ref_param_str.argtypes = [C.c_char_p, C.c_char_p]
+        L.ref_lo_frame.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.ref_lo_pose.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.ref_lo_destroy.argtypes = [C.c_void_p]
+        L.ref_lo_solve_info.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_lo_solve_data.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_msg_info.argtypes = [C.c_int, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.ref_msg_data.argtypes = [C.c_int, C.c_void_p]
+        L.ref_set_verbose(int(bool(verbose)))
+        L.ref_param_clear()
+        for k, v in (params or {}).items():
+            if isinstance(v, str):
+                L.ref_param_str(k.encode(), v.encode())
+            else:
+                L.ref_param_num(k.encode(), float(v))
+        self.h = C.c_void_p(L.ref_lo_create())
+
+    def close(self):
+        if self.h:
+            self.lib.ref_lo_destroy(self.h)
+            self.h = None
+
+    def frame(self, stamp, edge12, surf12, full12):
+        a = [np.ascontiguousarray(x, np.float32).reshape(-1, 12) for x in (edge12, surf12, full12)]
+        self.lib.ref_lo_frame(self.h, float(stamp), _p(a[0]), a[0].shape[0], _p(a[1]), a[1].shape[0], _p(a[2]), a[2].shape[0])
+        ap, rp, kf = np.zeros(7), np.zeros(7), C.c_int(0)
+        self.lib.ref_lo_pose(self.h, _p(ap), _p(rp), C.byref(kf))
+        return ap, rp, bool(kf.value)          # abs_pose / rel_pose: qw qx qy qz | x y z
+
+    def solves(self, first=0):
+        """Every ceres::Solve call so far: dict(pose_in, pose_out (qw qx qy qz x y z), records (n,7) = cp, weight*n,
+        weight*d; rows (n,8) = r, dr/dq(4), dr/dt(3) raw; map (m,4), queries (k,4) = x y z curvature; gn_status)."""
+        out = []
+        for i in range(first, self.lib.ref_lo_n_solves()):
+            sizes = np.zeros(4, np.int32)
+            pin, pout = np.zeros(7), np.zeros(7)
+            self.lib.ref_lo_solve_info(i, _p(sizes), _p(pin), _p(pout))
+            nb, nm, nq, st = [int(v) for v in sizes]
+            rec, rows = np.zeros((nb, 7)), np.zeros((nb, 8))
+            mp, qs = np.zeros((nm, 4), np.float32), np.zeros((nq, 4), np.float32)
+            self.lib.ref_lo_solve_data(i, _p(rec), _p(rows), _p(mp), _p(qs))
+            out.append(dict(pose_in=pin, pose_out=pout, records=rec, rows=rows, map=mp, queries=qs, gn_status=st))
+        return out
+
+    def published(self):
+        out = []
+        for i in range(self.lib.ref_n_published()):
+            topic = C.create_string_buffer(64)
+            stamp, step = C.c_double(0), C.c_int(0)
+            n = self.lib.ref_msg_info(i, topic, C.byref(stamp), C.byref(step))
+            if step.value:
+                a = np.zeros((n, step.value // 4), np.float32)
+            else:
+                a = np.zeros(n, np.float64)
+            if n:
+                self.lib.ref_msg_data(i, _p(a))
+            out.append((topic.value.decode(), stamp.value, a))
+        return out

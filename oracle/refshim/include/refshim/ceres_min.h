@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
+#include <string>
 #include <vector>
 
 namespace ceres {
@@ -82,6 +83,7 @@ public:
         if (jacobians[1]) for (int i = 0; i < N1; i++) jacobians[1][i] = out[0].v[N0 + i];
         return true;
     }
+    const Functor* functor() const { return f_; }   // shim-only accessor: lets the driver read the record a block was built from
 private:
     Functor* f_;
 };
@@ -106,5 +108,44 @@ public:
     }
 private: const double a_, b_;
 };
+
+
+// ---- ceres::Problem / ceres::Solve surface --------------------------------------------------------------------
+// The reference's nodes build a Problem (AddParameterBlock / AddResidualBlock) and call ceres::Solve.  The Ceres
+// trust-region solver itself is NOT restated: Solve() hands the problem to a hook the driver installs, which records the
+// residual blocks the reference created (that is the product of the reference's own code) and writes back whatever
+// step the test protocol prescribes.
+struct LocalParameterization { virtual ~LocalParameterization() {} };
+struct QuaternionParameterization : LocalParameterization {};
+enum LinearSolverType { DENSE_NORMAL_CHOLESKY, DENSE_QR, SPARSE_NORMAL_CHOLESKY, DENSE_SCHUR, SPARSE_SCHUR, ITERATIVE_SCHUR, CGNR };
+enum TrustRegionStrategyType { LEVENBERG_MARQUARDT, DOGLEG };
+struct ResidualBlock { CostFunction* cost; LossFunction* loss; std::vector<double*> params; };
+class Problem {
+public:
+    std::vector<ResidualBlock> blocks;
+    std::vector<LocalParameterization*> parameterizations;
+    void AddParameterBlock(double*, int, LocalParameterization* p = nullptr) { if (p) parameterizations.push_back(p); }
+    template <class... P> void AddResidualBlock(CostFunction* c, LossFunction* l, P*... ps) { blocks.push_back(ResidualBlock{c, l, {ps...}}); }
+    ~Problem() {   // ceres::Problem owns cost functions, loss functions and parameterizations (each deleted once)
+        std::vector<const void*> seen;
+        auto once = [&](const void* p) { if (!p || std::find(seen.begin(), seen.end(), p) != seen.end()) return false; seen.push_back(p); return true; };
+        for (auto& b : blocks) { if (once(b.cost)) delete b.cost; }
+        for (auto& b : blocks) { if (once(b.loss)) delete b.loss; }
+        for (auto* p : parameterizations) if (once(p)) delete p;
+    }
+};
+struct Solver {
+    struct Options {
+        LinearSolverType linear_solver_type = DENSE_QR;
+        TrustRegionStrategyType trust_region_strategy_type = LEVENBERG_MARQUARDT;
+        int max_num_iterations = 50, num_threads = 1;
+        double max_solver_time_in_seconds = 1e9, gradient_check_relative_precision = 1e-8;
+        bool minimizer_progress_to_stdout = false, check_gradients = false;
+    };
+    struct Summary { int num_blocks = 0; std::string BriefReport() const { return "refshim"; } std::string FullReport() const { return "refshim"; } };
+};
+typedef void (*SolveHook)(const Solver::Options&, Problem*, Solver::Summary*);
+inline SolveHook& solve_hook() { static SolveHook h = nullptr; return h; }
+inline void Solve(const Solver::Options& o, Problem* p, Solver::Summary* s) { if (solve_hook()) solve_hook()(o, p, s); }
 
 }  // namespace ceres

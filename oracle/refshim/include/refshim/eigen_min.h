@@ -42,6 +42,11 @@ template <class T, int R, int C> struct Matrix : MatrixBase<Matrix<T, R, C>> {
     T& z() { return d[2]; } const T& z() const { return d[2]; }
     static Matrix Zero() { Matrix m; for (int i = 0; i < R * C; i++) m.d[i] = T(0); return m; }
     static Matrix Identity() { Matrix m = Zero(); for (int i = 0; i < (R < C ? R : C); i++) m(i, i) = T(1); return m; }
+    static Matrix Ones() { Matrix m; for (int i = 0; i < R * C; i++) m.d[i] = T(1); return m; }
+    T sum() const { T s = d[0]; for (int i = 1; i < R * C; i++) s = s + d[i]; return s; }   // association order unspecified in Eigen; only used for values the reference never reads
+    void normalize() { T n = norm(); for (int i = 0; i < R * C; i++) d[i] = d[i] / n; }        // *this /= norm()
+    struct ColPivQR53;   // colPivHouseholderQr() of the 5x3 plane-fit matrix
+    ColPivQR53 colPivHouseholderQr() const;
     Matrix operator+(const Matrix& o) const { Matrix r; for (int i = 0; i < R * C; i++) r.d[i] = d[i] + o.d[i]; return r; }
     Matrix operator-(const Matrix& o) const { Matrix r; for (int i = 0; i < R * C; i++) r.d[i] = d[i] - o.d[i]; return r; }
     Matrix operator-() const { Matrix r; for (int i = 0; i < R * C; i++) r.d[i] = -d[i]; return r; }
@@ -135,6 +140,24 @@ template <class T> struct Quaternion : QuaternionBase<Quaternion<T>> {
     }
 };
 typedef Quaternion<double> Quaterniond;
+
+// Matrix<double,5,3>::colPivHouseholderQr().solve(b) — delegated to the oracle's restatement of Eigen 3.3's
+// ColPivHouseholderQR (lo::lstsq_5x3_colpiv); any other shape is a compile error.
+template <class T, int R, int C> struct Matrix<T, R, C>::ColPivQR53 {
+    static_assert(R == 5 && C == 3, "only the 5x3 plane fit is stood in for");
+    double A[5][3];
+    Matrix<double, 3, 1> solve(const Matrix<double, 5, 1>& b) const {
+        double bb[5], x[3];
+        for (int i = 0; i < 5; i++) bb[i] = b.d[i];
+        lo::lstsq_5x3_colpiv(A, bb, x);
+        return Matrix<double, 3, 1>(x[0], x[1], x[2]);
+    }
+};
+template <class T, int R, int C> typename Matrix<T, R, C>::ColPivQR53 Matrix<T, R, C>::colPivHouseholderQr() const {
+    ColPivQR53 q;
+    for (int i = 0; i < 5; i++) for (int j = 0; j < 3; j++) q.A[i][j] = (*this)(i, j);
+    return q;
+}
 
 // SelfAdjointEigenSolver<Matrix3d>(A): iterative compute() — delegated to the oracle's restatement.
 template <class M> struct SelfAdjointEigenSolver;

@@ -48,9 +48,7 @@ struct Time {
 struct Subscriber {};
 struct Publisher {
     std::string topic;
-    template <class M> void publish(const M& m) const {
-        refshim::sink().push_back(refshim::PubMsg{topic, m.header.stamp.toSec(), m.point_step, m.data});
-    }
+    template <class M> void publish(const M& m) const { refshim_publish(topic, m); }   // overloads below, found by ADL at instantiation
 };
 struct NodeHandle {
     explicit NodeHandle(const std::string& = "") {}
@@ -68,7 +66,11 @@ inline bool get(const std::string& key, std::string& v) { auto& p = refshim::par
 }  // namespace param
 inline void init(int, char**, const std::string&) {}
 inline void spin() {}
+inline void spinOnce() {}
+inline bool ok() { return false; }
+struct Rate { explicit Rate(double) {} void sleep() {} };
 }  // namespace ros
+namespace google { inline void InitGoogleLogging(const char*) {} }
 
 namespace std_msgs {
 struct Header { uint32_t seq = 0; ros::Time stamp; std::string frame_id; };
@@ -92,6 +94,33 @@ struct Imu {
 };
 typedef std::shared_ptr<const Imu> ImuConstPtr;
 }  // namespace sensor_msgs
+
+namespace geometry_msgs {
+struct Point { double x = 0, y = 0, z = 0; };
+struct Pose { Point position; Quaternion orientation; };
+struct PoseStamped { std_msgs::Header header; Pose pose; };
+struct PoseWithCovariance { Pose pose; };
+}
+namespace nav_msgs {
+struct Odometry { std_msgs::Header header; std::string child_frame_id; geometry_msgs::PoseWithCovariance pose; };
+struct Path { std_msgs::Header header; std::vector<geometry_msgs::PoseStamped> poses; };
+}
+namespace sensor_msgs {
+inline void refshim_publish(const std::string& topic, const PointCloud2& m) {
+    refshim::sink().push_back(refshim::PubMsg{topic, m.header.stamp.toSec(), m.point_step, m.data});
+}
+}
+namespace nav_msgs {
+// pose messages land in the sink as 7 doubles (qw qx qy qz | x y z), point_step 0
+inline void refshim_publish(const std::string& topic, const Odometry& m) {
+    double v[7] = {m.pose.pose.orientation.w, m.pose.pose.orientation.x, m.pose.pose.orientation.y, m.pose.pose.orientation.z,
+                   m.pose.pose.position.x, m.pose.pose.position.y, m.pose.pose.position.z};
+    refshim::PubMsg p{topic, m.header.stamp.toSec(), 0, {}};
+    p.data.assign((const uint8_t*)v, (const uint8_t*)v + sizeof(v));
+    refshim::sink().push_back(p);
+}
+inline void refshim_publish(const std::string&, const Path&) {}   // the path repeats the odometry poses
+}
 
 // ---------------------------------------------------------------------------------------------- PCL
 #define POINT_CLOUD_REGISTER_POINT_STRUCT(...)
@@ -122,6 +151,8 @@ template <class P> struct PointCloud {
     uint32_t width = 0, height = 0;
     bool is_dense = true;
     size_t size() const { return points.size(); }
+    bool empty() const { return points.empty(); }
+    void resize(size_t n) { points.resize(n); width = (uint32_t)n; height = 1; }
     void clear() { points.clear(); width = 0; height = 0; }
     void push_back(const P& p) { points.push_back(p); width = (uint32_t)points.size(); height = 1; }
     PointCloud& operator+=(const PointCloud& o) {
@@ -174,5 +205,87 @@ template <> struct VoxelGrid<PointXYZI> {
         out.width = (uint32_t)m; out.height = 1; out.is_dense = true;
     }
 };
-template <class P> struct KdTreeFLANN;   // named by common.h's includes only
+template <class A, class B> void copyPointCloud(const PointCloud<A>& in, PointCloud<B>& out) {
+    out.header = in.header; out.width = in.width; out.height = in.height; out.is_dense = in.is_dense;
+    out.points.resize(in.points.size());
+    for (size_t i = 0; i < in.points.size(); i++) out.points[i] = in.points[i];   // same type at every call site of the reference
+}
+
+// pcl::VoxelGrid<PointXYZINormal>: x, y, z, intensity, curvature are PCL's float-accumulated centroids (the oracle's
+// applyFilter restatement, one pass per extra field over identical voxel membership and order); the normal is the
+// normalised sum (PCL's AccumulatorNormal).  Nothing downstream of the filter in the reference's matchers reads the
+// normal or intensity of a filtered point, only x, y, z and (back-end, Livox) curvature.
+template <> struct VoxelGrid<PointXYZINormal> {
+    PointCloud<PointXYZINormal>::Ptr in;
+    float leaf = 0;
+    void setInputCloud(const PointCloud<PointXYZINormal>::Ptr& c) { in = c; }
+    void setLeafSize(float lx, float, float) { leaf = lx; }
+    void filter(PointCloud<PointXYZINormal>& out) {
+        size_t n = in->points.size();
+        std::vector<float> p(4 * n + 4), o[5];
+        std::vector<int> cnt(n + 1);
+        int m = 0;
+        for (int f = 0; f < 5; f++) {
+            o[f].resize(4 * n + 4);
+            for (size_t i = 0; i < n; i++) {
+                const PointXYZINormal& q = in->points[i];
+                const float aux[5] = {q.intensity, q.curvature, q.normal_x, q.normal_y, q.normal_z};
+                p[4 * i] = q.x; p[4 * i + 1] = q.y; p[4 * i + 2] = q.z; p[4 * i + 3] = aux[f];
+            }
+            m = lo_voxel_grid(p.data(), (int)n, leaf, /*stable=*/0, o[f].data(), cnt.data());
+        }
+        out.points.resize(m);
+        for (int k = 0; k < m; k++) {
+            PointXYZINormal q;
+            q.x = o[0][4 * k]; q.y = o[0][4 * k + 1]; q.z = o[0][4 * k + 2];
+            q.intensity = o[0][4 * k + 3]; q.curvature = o[1][4 * k + 3];
+            float nx = o[2][4 * k + 3], ny = o[3][4 * k + 3], nz = o[4][4 * k + 3];
+            float nn = std::sqrt(nx * nx + ny * ny + nz * nz);
+            if (nn > 0) { q.normal_x = nx / nn; q.normal_y = ny / nn; q.normal_z = nz / nn; }
+            out.points[k] = q;
+        }
+        out.width = (uint32_t)m; out.height = 1; out.is_dense = true;
+    }
+};
+
+// pcl::KdTreeFLANN<P>::nearestKSearch(p, 5, idx, d2): exact 5-NN, FLANN's L2_Simple f32 distance, ascending —
+// the oracle's kd-tree (ties by (d2, index); FLANN's own tie order is traversal-dependent).
+extern "C" void* lo_kdtree_build(const float* xyz, int n);
+extern "C" void lo_kdtree_free(void* t);
+extern "C" void lo_knn5(void* tree, const float* q, int m, int* idx, float* d2, int nthreads);
+}  // namespace pcl
+namespace refshim {
+// the cloud most recently handed to any KdTreeFLANN::setInputCloud, as x y z aux rows (aux = curvature or intensity):
+// lets the driver report the exact map a reference node searched
+inline std::vector<float>& last_tree_input() { static std::vector<float> v; return v; }
+template <class P> float aux_of(const P& p);
+template <> inline float aux_of(const pcl::PointXYZI& p) { return p.intensity; }
+template <> inline float aux_of(const pcl::PointXYZINormal& p) { return p.curvature; }
+}
+namespace pcl {
+template <class P> struct KdTreeFLANN {
+    typedef std::shared_ptr<KdTreeFLANN<P>> Ptr;
+    std::vector<float> xyz;
+    void* tree = nullptr;
+    ~KdTreeFLANN() { if (tree) lo_kdtree_free(tree); }
+    void setInputCloud(const typename PointCloud<P>::Ptr& c) {
+        if (tree) { lo_kdtree_free(tree); tree = nullptr; }
+        size_t n = c->points.size();
+        xyz.resize(3 * n);
+        std::vector<float>& keep = refshim::last_tree_input();
+        keep.resize(4 * n);
+        for (size_t i = 0; i < n; i++) {
+            xyz[3 * i] = c->points[i].x; xyz[3 * i + 1] = c->points[i].y; xyz[3 * i + 2] = c->points[i].z;
+            keep[4 * i] = c->points[i].x; keep[4 * i + 1] = c->points[i].y; keep[4 * i + 2] = c->points[i].z; keep[4 * i + 3] = refshim::aux_of(c->points[i]);
+        }
+        tree = lo_kdtree_build(xyz.data(), (int)n);
+    }
+    int nearestKSearch(const P& p, int k, std::vector<int>& idx, std::vector<float>& d2) const {
+        if (k != 5) abort();
+        idx.resize(5); d2.resize(5);
+        float q[3] = {p.x, p.y, p.z};
+        lo_knn5(tree, q, 1, idx.data(), d2.data(), 1);
+        return 5;
+    }
+};
 }  // namespace pcl

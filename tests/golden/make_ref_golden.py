@@ -6,6 +6,10 @@ tests/golden/{s2m,extract}_*.npz, which come from the oracle — pin the oracle 
   ref_rot.npz      LiLi-OM-ROT/src/Preprocessing.cpp driven with 4 clouds + a 200 Hz gyro stream: the three published
                    clouds of the 2 processed scans (/lidar_cloud_cutted, /edge_features, /surf_features)
   ref_livox.npz    LiLi-OM/src/Preprocessing.cpp, same protocol (large clouds stored as sha256 + every 8th row)
+  ref_frontend.npz LiLi-OM/src/LidarOdometry.cpp (the whole front-end node) fed with the Livox node's output for 6 frames of a
+                   moving synthetic sequence; ceres::Solve = the documented one-GN-step stand-in (oracle/refshim/ref_lo.cpp):
+                   per solve the pose in/out and a hash of the residual-block records the reference built, per frame the
+                   node's abs/rel pose and keyframe flag; two solves are stored completely (map, queries, records, raw rows)
   ref_factors.npz  LidarEdgeFactor / LidarPlaneNormFactor / LidarPlaneNormIncreFactor ::Create()->Evaluate() on random
                    records: residual + both Jacobian blocks
 
@@ -102,6 +106,48 @@ def run_livox():
     return d
 
 
+FRONTEND_PARAMS = {"/common/frame_id": "lili_om", "/lidar_odometry/if_to_deskew": 0, "/lidar_odometry/max_num_iter": 12,
+                   "/lidar_odometry/scan_match_cnt": 6}
+FRONTEND_FRAMES = 6
+FRONTEND_FULL_SOLVES = (0, 8, 20)      # first solve of frame 1 (8 re-associations there, L/src/LidarOdometry.cpp:498-502), frames 2 and 4
+
+
+def frontend_inputs():
+    """Moving Livox-like sequence (tests/seq_harness.py) + zero-rate gyro stream (the node waits for IMU data)."""
+    sys.path.insert(0, ROOT)
+    from tests import seq_harness as H
+    n = FRONTEND_FRAMES + 2
+    frames = H.make_frames(n)
+    stamps = 10.0 + 0.1 * np.arange(n)
+    imu_t = 9.97 + 0.005 * np.arange(20 * n + 20)
+    return frames, stamps, imu_t, np.zeros((imu_t.shape[0], 3))
+
+
+def run_frontend():
+    frames, stamps, imu_t, gyr = frontend_inputs()
+    pre = R.run_scans("livox", LIVOX_PARAMS, frames, stamps, imu_t, gyr)
+    lo = R.LidarOdometry(FRONTEND_PARAMS)
+    d = dict(n_frames=len(pre))
+    abs_pose, rel_pose, kf = [], [], []
+    for o in pre:
+        ap, rp, k = lo.frame(o["stamp"], o["edge"], o["surf"], o["cutted"])
+        abs_pose.append(ap); rel_pose.append(rp); kf.append(k)
+    S = lo.solves()
+    d.update(abs_pose=np.array(abs_pose), rel_pose=np.array(rel_pose), kf=np.array(kf), n_solves=len(S),
+             pose_in=np.array([s["pose_in"] for s in S]), pose_out=np.array([s["pose_out"] for s in S]),
+             n_blocks=np.array([len(s["records"]) for s in S]), n_map=np.array([len(s["map"]) for s in S]),
+             n_queries=np.array([len(s["queries"]) for s in S]), gn_status=np.array([s["gn_status"] for s in S]),
+             records_sha=np.array([sha(s["records"]) for s in S]), rows_sha=np.array([sha(s["rows"]) for s in S]),
+             map_sha=np.array([sha(s["map"]) for s in S]), queries_sha=np.array([sha(s["queries"]) for s in S]))
+    for i in FRONTEND_FULL_SOLVES:
+        for k in ("map", "queries", "records", "rows"):
+            d[f"solve{i}_{k}"] = S[i][k]
+    odom = [(st, a) for (topic, st, a) in lo.published() if topic == "/odom"]
+    d["odom_stamp"] = np.array([st for st, _ in odom]); d["odom"] = np.array([a for _, a in odom])
+    lo.close()
+    return d
+
+
 def run_factors():
     f = factor_inputs()
     n = f["cp"].shape[0]
@@ -119,7 +165,8 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ref_rot.npz"), **run_rot())
     np.savez_compressed(os.path.join(HERE, "ref_livox.npz"), **run_livox())
     np.savez_compressed(os.path.join(HERE, "ref_factors.npz"), **run_factors())
-    for f in ("ref_rot.npz", "ref_livox.npz", "ref_factors.npz"):
+    np.savez_compressed(os.path.join(HERE, "ref_frontend.npz"), **run_frontend())
+    for f in ("ref_rot.npz", "ref_livox.npz", "ref_factors.npz", "ref_frontend.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

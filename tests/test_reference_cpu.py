@@ -41,11 +41,11 @@ def _same_npz(d, g):
 
 
 # ------------------------------------------------------------------ the reference build itself
-@pytest.mark.parametrize("which", ["rot", "livox", "factors"])
+@pytest.mark.parametrize("which", ["rot", "livox", "factors", "frontend"])
 def test_reference_build_reproduces_fixtures(which):
     if not M.R.available():
         pytest.skip("oracle/_ref not built (needs /root/reference; build container only)")
-    d = {"rot": M.run_rot, "livox": M.run_livox, "factors": M.run_factors}[which]()
+    d = {"rot": M.run_rot, "livox": M.run_livox, "factors": M.run_factors, "frontend": M.run_frontend}[which]()
     _same_npz(d, np.load(os.path.join(G, f"ref_{which}.npz")))
 
 
@@ -116,6 +116,54 @@ def test_oracle_equals_reference_factors(oracle):
                           (np.r_[pi[7], pi[3:7], pi[0:3]], ref_pi)):             # Incre: parameter order (q, t)
             worst = max(worst, np.abs(mine - ref).max())
     assert worst == 0.0, worst          # bit-exact, incl. the Jet-style q_lb inverse of the plane factor
+
+
+# ------------------------------------------------------------------ front-end node (LidarOdometry.cpp) vs oracle
+def _frontend_surf_features(oracle):
+    frames, stamps, imu_t, gyr = M.frontend_inputs()
+    integ = oracle.ImuIntegrator()
+    return [oracle.extract_livox(frames[k], _q_imu_per_scan(integ, stamps, imu_t, gyr, k))["surf"][:, [0, 1, 2, 7]]
+            for k in range(M.FRONTEND_FRAMES)]
+
+
+def test_oracle_association_equals_reference_frontend(oracle):
+    """findCorrespondingSurfFeatures + LidarPlaneNormIncreFactor + HuberLoss as the reference's node ran them (three solves
+    stored completely): the oracle builds the same correspondence records (cp, weight*n, weight*d: bit-exact), the same raw
+    residual/Jacobian rows, and the same Gauss-Newton step."""
+    g = np.load(os.path.join(G, "ref_frontend.npz"))
+    PO = oracle.params("frontend")
+    for i in M.FRONTEND_FULL_SOLVES:
+        mp, qs, rec, rows = (g[f"solve{i}_{k}"] for k in ("map", "queries", "records", "rows"))
+        assert _sha(mp) == str(g["map_sha"][i]) and _sha(rec) == str(g["records_sha"][i])
+        q, t = g["pose_in"][i][:4], g["pose_in"][i][4:]
+        rs = oracle.associate_surf(oracle.KdTree(np.ascontiguousarray(mp[:, :3])), None, np.ascontiguousarray(qs[:, :3]), None, q, t, PO)
+        v = rs["valid"].astype(bool)
+        mine = np.c_[rs["cp"][v], rs["n"][v], rs["d"][v]].astype(np.float64)
+        assert mine.shape == rec.shape and np.array_equal(mine, rec) and rec.shape[0] > 1000
+        for k in range(0, rec.shape[0], 37):          # raw rows: reference (r, dq4, dt3) vs oracle (J: t3 q4, r)
+            o = oracle.eval_plane(t, q, rec[k, 0:3], rec[k, 3:6], rec[k, 6], 1.0, PO, frontend=True)
+            assert np.array_equal(np.r_[o[7], o[3:7], o[0:3]], rows[k]), k
+        Gm, _, _ = oracle.linearize_surf(rs, t, q, PO)
+        st, t2, q2, _ = oracle.gn_step(Gm, t, q)
+        assert st == 0 and np.array_equal(np.r_[q2, t2], g["pose_out"][i])
+
+
+def test_frontend_chain_on_oracle_equals_reference_node(oracle):
+    """The whole front-end loop (tests/frontend_chain.py on oracle primitives, literal PCL mode) reproduces the poses of the
+    reference's LidarOdometry node bit for bit over the sequence, and every solve's pose and residual-block count;
+    the GPU path's definition (in-order voxel centroids) stays within 1e-5."""
+    from tests import frontend_chain as F
+    g = np.load(os.path.join(G, "ref_frontend.npz"))
+    surf = _frontend_surf_features(oracle)
+    be = F.OracleBackend(oracle, stable=False)
+    a, r = F.run_frontend_chain(be, surf, scan_match_cnt=int(M.FRONTEND_PARAMS["/lidar_odometry/scan_match_cnt"]))
+    assert np.array_equal(a, g["abs_pose"]) and np.array_equal(r, g["rel_pose"])
+    assert len(be.log) == int(g["n_solves"])
+    assert [l["n_blocks"] for l in be.log] == list(g["n_blocks"]) and [l["n_map"] for l in be.log] == list(g["n_map"])
+    assert all(np.array_equal(l["pose_out"], g["pose_out"][i]) for i, l in enumerate(be.log))
+    assert np.linalg.norm(a[-1][4:] - a[1][4:]) > 1.5           # the sensor really moved (0.5 m per frame)
+    a2, _ = F.run_frontend_chain(F.OracleBackend(oracle, stable=True), surf, scan_match_cnt=6)
+    assert np.abs(a2 - g["abs_pose"]).max() < 1e-5
 
 
 # ------------------------------------------------------------------ product host logic vs reference

@@ -120,3 +120,47 @@ def test_gpu_linearize_vs_reference_functors(gpu_ctx, variant):
         assert np.abs(Gg - Gr).max() <= 1e-9 * np.abs(Gr).max(), (variant, mask, np.abs(Gg - Gr).max() / np.abs(Gr).max())
         cost_ref = 0.5 * np.log1p(rows[:, 7] ** 2).sum()
         assert abs(cost - cost_ref) <= 1e-9 * max(1.0, cost_ref)
+
+
+class _GpuBackend:
+    """tests/frontend_chain.py backend on the HIP path: lili_voxel_filter, lili_map_set, lili_s2m_iterate (front-end flavour)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.m = L.ScanToMapMatcher(ctx, L.make_params("frontend"))
+
+    def voxel(self, pts4, leaf=0.4):
+        return L.api.voxel_filter(self.ctx, np.ascontiguousarray(pts4, np.float32), leaf)[0] if pts4.shape[0] else pts4
+
+    def set_map(self, clouds_world, leaf=0.4):
+        cat = np.ascontiguousarray(np.concatenate(clouds_world, 0), np.float32)
+        mp = self.voxel(cat, leaf)
+        self.m.set_input_cloud(L.KIND_SURF, mp)
+        return mp.shape[0]
+
+    def match(self, queries4, q, t, n_iter):
+        self.m.set_queries(0, L.KIND_SURF, np.ascontiguousarray(queries4, np.float32))
+        self.m.pose_set(0, t, q)
+        self.m.iterate(0, n_iter, L.MASK_SURF)
+        t2, q2, st = self.m.pose_get(0)
+        assert st == 0
+        return (q2 if q2[0] >= 0 else -q2), t2
+
+
+def test_gpu_frontend_chain_vs_reference_node(gpu_ctx):
+    """Pose parity with the reference's OWN front-end node (LiLi-OM/src/LidarOdometry.cpp compiled unmodified, one GN step per
+    ceres::Solve — tests/golden/ref_frontend.npz): Livox extractor -> voxel filter -> local map of the last 20 frames ->
+    6 (8 on the first frame) re-association + Gauss-Newton iterations per frame, all on the HIP path, against the poses the
+    reference node held after every frame.  Tolerance = north star (1e-4 m / 1e-4 rad)."""
+    from tests import frontend_chain as F
+    g = np.load(os.path.join(G, "ref_frontend.npz"))
+    frames, stamps, imu_t, gyr = M.frontend_inputs()
+    integ = L.api.ImuIntegrator()
+    ex = L.LivoxExtractor(gpu_ctx)
+    surf = [ex.extract(frames[k], _q_imu(integ, stamps, imu_t, gyr, k))["surf"][:, [0, 1, 2, 7]] for k in range(M.FRONTEND_FRAMES)]
+    a, r = F.run_frontend_chain(_GpuBackend(gpu_ctx), surf, scan_match_cnt=int(M.FRONTEND_PARAMS["/lidar_odometry/scan_match_cnt"]))
+    ref = g["abs_pose"]
+    assert np.abs(a[:, 4:] - ref[:, 4:]).max() < 1e-4, np.abs(a[:, 4:] - ref[:, 4:]).max()
+    assert np.abs(a[:, :4] - ref[:, :4]).max() < 5e-5           # quaternion components: < 1e-4 rad
+    assert np.abs(r - g["rel_pose"]).max() < 1e-4
+    print("GPU front-end chain vs reference node: max |dt| = %.3g m, max |dq| = %.3g" % (np.abs(a[:, 4:] - ref[:, 4:]).max(), np.abs(a[:, :4] - ref[:, :4]).max()))
