@@ -65,7 +65,7 @@ def cpu_baseline(w, queries, t0, q0, n_threads):
         for _ in range(iters):
             Q2, T2 = L.api.assoc_transform(t, q, P)
             rs = O.associate_surf(tree, None, queries, None, Q2, T2, PO, nthreads=nth)
-            G, _, _ = O.linearize_surf(rs, t, q, PO, 1000.0 / max(rs["count"], 1), nthreads=nth)
+            G, _, _ = O.linearize_surf(rs, t, q, PO, (1000.0, max(rs["count"], 1)), nthreads=nth)
             st, t, q, _ = O.gn_step(G, t, q)
         return (time.perf_counter() - tic) / iters, t, q
 

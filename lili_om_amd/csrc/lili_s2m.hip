@@ -1048,9 +1048,11 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize_surf(
     unsigned char v0 = valid[i0c];
     float4 ql0 = queries[i0c], nd0 = rec_nd[i0c];
     double sc0 = rec_score[i0c];
-    double nscale = 1.0;
-    if (P.debug & 128) nscale = 1000.0 / 190000.0;
-    else if (P.scale_surf_num > 0) nscale = P.scale_surf_num / (double)(block_counts ? sum_block_counts(block_counts, n_bc) : (n_global ? n_global[0] : state->n_res[0]));
+    // ROT count scaling exactly as the reference writes it (R/src/BackendFusion.cpp:861, pinned by tests/test_reference_*.py against the reference text):
+    // vec_surf_scores[i] * 1000 / vec_surf_res_cnt  =  (score * 1000.0) / (double)N — a multiply, then a true division
+    double n_den = 1.0;
+    if (P.debug & 128) n_den = 190000.0;
+    else if (P.scale_surf_num > 0) n_den = (double)(block_counts ? sum_block_counts(block_counts, n_bc) : (n_global ? n_global[0] : state->n_res[0]));
     tstamp(state, P.debug, 100, 1);
     for (int base = blockIdx.x * BS; base < n_q; base += gridDim.x * BS) {
         int i = base + threadIdx.x;
@@ -1062,7 +1064,7 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize_surf(
         if (ok) {
             float4 ql = first ? ql0 : queries[i]; float4 nd = first ? nd0 : rec_nd[i];
             double score = first ? sc0 : rec_score[i];
-            if (P.scale_surf_num > 0) score = score * nscale;
+            if (P.scale_surf_num > 0) score = score * P.scale_surf_num / n_den;
             d3 cp{(double)ql.x, (double)ql.y, (double)ql.z};
             d3 n{(double)nd.x, (double)nd.y, (double)nd.z};
             d3 v;
@@ -1096,8 +1098,10 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize_edge(
     GramAcc ga; ga.init();
     dq Q; d3 T;
     load_body_pose(pa, Q, T);
-    double nscale = 1.0;   // R:843
-    if (P.scale_edge_num > 0) nscale = P.scale_edge_num / (double)(block_counts ? sum_block_counts(block_counts, n_bc) : (n_global ? n_global[1] : state->n_res[1]));
+    // R:843: points[i].intensity * 200 / vec_edge_res_cnt — float * int / int, i.e. FLOAT arithmetic (pinned by tests/test_reference_*.py against the reference text)
+    float n_den = 1.0f;
+    if (P.scale_edge_num > 0) n_den = (float)(block_counts ? sum_block_counts(block_counts, n_bc) : (n_global ? n_global[1] : state->n_res[1]));
+    const float n_num = (float)P.scale_edge_num;
     for (int base = blockIdx.x * blockDim.x; base < n_q; base += gridDim.x * blockDim.x) {
         int i = base + threadIdx.x;
         bool ok = i < n_q && valid[i];
@@ -1106,7 +1110,7 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize_edge(
         if (ok) {
             float4 ql = queries[i]; float4 fa = rec_a[i], fb = rec_b[i];
             double s = (double)fa.w;
-            if (P.scale_edge_num > 0) s = s * nscale;
+            if (P.scale_edge_num > 0) s = (double)__fdiv_rn(__fmul_rn(fa.w, n_num), n_den);
             d3 cp{(double)ql.x, (double)ql.y, (double)ql.z};
             d3 A{(double)fa.x, (double)fa.y, (double)fa.z}, B{(double)fb.x, (double)fb.y, (double)fb.z};
             d3 lp = qrot(Q, cp) + T;                    // LidarKeyframeFactor.h:38 (no extrinsic: SURVEY F6)

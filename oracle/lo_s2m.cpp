@@ -410,17 +410,24 @@ static inline void robustify(int loss, double a, double Jr[8], double* cost) {
     Jr[7] *= residual_scaling;
 }
 
+// ROT count scaling as the reference writes it (R/src/BackendFusion.cpp:843,861; pinned by oracle/_ref/libref_backend_R.so):
+//   plane:  vec_surf_scores[idVec][i] * 1000 / vec_surf_res_cnt[idVec]      double * int / int  -> (score * 1000.0) / N in double
+//   edge:   points[i].intensity * 200 / vec_edge_res_cnt[idVec]              float * int / int   -> (s * 200.0f) / (float)N in FLOAT
+// scale_den > 0: `scale` is the numerator (1000 / 200) and scale_den the correspondence count; scale_den == 0: plain factor.
+static inline double scaled_score(double score, double scale, int den) { return den > 0 ? score * scale / (double)den : score * scale; }
+static inline double scaled_s(float s, double scale, int den) { return den > 0 ? (double)(s * (float)scale / (float)den) : (double)s * scale; }
+
 // Gram accumulation G += [J r]^T [J r] over all valid records in query order (8x8 row-major, full),
-// cost += 1/2 rho(r^2).  scale multiplies s / score first (ROT: 200/N_e, 1000/N_s — R:843,861).
+// cost += 1/2 rho(r^2).
 extern "C" void lo_linearize_surf(const unsigned char* valid, const float* rec_cp, const float* rec_n, const float* rec_d, const double* rec_score,
-                       int n_q, const double t[3], const double q[4], const lo_params* P, double scale,
+                       int n_q, const double t[3], const double q[4], const lo_params* P, double scale, int scale_den,
                        double gram[64], double* cost, int* count) {
     for (int k = 0; k < 64; k++) gram[k] = 0;
     double c = 0; int cnt = 0;
     for (int i = 0; i < n_q; i++) {
         if (!valid[i]) continue;
         double Jr[8];
-        lo_eval_plane(t, q, rec_cp + 3 * (size_t)i, rec_n + 3 * (size_t)i, rec_d[i], rec_score[i] * scale, P->q_lb, P->t_lb,
+        lo_eval_plane(t, q, rec_cp + 3 * (size_t)i, rec_n + 3 * (size_t)i, rec_d[i], scaled_score(rec_score[i], scale, scale_den), P->q_lb, P->t_lb,
                       P->variant == LO_VARIANT_FRONTEND, Jr);
         double ci; robustify(P->loss, P->loss_a, Jr, &ci);
         c += ci; cnt++;
@@ -429,14 +436,14 @@ extern "C" void lo_linearize_surf(const unsigned char* valid, const float* rec_c
     *cost = c; *count = cnt;
 }
 extern "C" void lo_linearize_edge(const unsigned char* valid, const float* rec_cp, const float* rec_a, const float* rec_b, const float* rec_s,
-                       int n_q, const double t[3], const double q[4], const lo_params* P, double scale,
+                       int n_q, const double t[3], const double q[4], const lo_params* P, double scale, int scale_den,
                        double gram[64], double* cost, int* count) {
     for (int k = 0; k < 64; k++) gram[k] = 0;
     double c = 0; int cnt = 0;
     for (int i = 0; i < n_q; i++) {
         if (!valid[i]) continue;
         double Jr[8];
-        lo_eval_edge(t, q, rec_cp + 3 * (size_t)i, rec_a + 3 * (size_t)i, rec_b + 3 * (size_t)i, (double)rec_s[i] * scale, Jr);
+        lo_eval_edge(t, q, rec_cp + 3 * (size_t)i, rec_a + 3 * (size_t)i, rec_b + 3 * (size_t)i, scaled_s(rec_s[i], scale, scale_den), Jr);
         double ci; robustify(P->loss, P->loss_a, Jr, &ci);
         c += ci; cnt++;
         for (int a = 0; a < 8; a++) for (int b = 0; b < 8; b++) gram[a * 8 + b] += Jr[a] * Jr[b];
@@ -504,12 +511,12 @@ extern "C" void lo_loss(int loss, double a, double s, double rho[3]) { loss_eval
 
 // Per-residual robustified rows [J(7) r] (test aid for the marginalisation assembly, L/src/MarginalizationFactor.cpp:3-71)
 extern "C" void lo_rows_surf(const unsigned char* valid, const float* rec_cp, const float* rec_n, const float* rec_d, const double* rec_score,
-                             int n_q, const double t[3], const double q[4], const lo_params* P, double scale, double* rows, int* count) {
+                             int n_q, const double t[3], const double q[4], const lo_params* P, double scale, int scale_den, double* rows, int* count) {
     int cnt = 0;
     for (int i = 0; i < n_q; i++) {
         if (!valid[i]) continue;
         double* Jr = rows + 8 * (size_t)cnt;
-        lo_eval_plane(t, q, rec_cp + 3 * (size_t)i, rec_n + 3 * (size_t)i, rec_d[i], rec_score[i] * scale, P->q_lb, P->t_lb,
+        lo_eval_plane(t, q, rec_cp + 3 * (size_t)i, rec_n + 3 * (size_t)i, rec_d[i], scaled_score(rec_score[i], scale, scale_den), P->q_lb, P->t_lb,
                       P->variant == LO_VARIANT_FRONTEND, Jr);
         double ci; robustify(P->loss, P->loss_a, Jr, &ci);
         cnt++;
@@ -517,12 +524,12 @@ extern "C" void lo_rows_surf(const unsigned char* valid, const float* rec_cp, co
     *count = cnt;
 }
 extern "C" void lo_rows_edge(const unsigned char* valid, const float* rec_cp, const float* rec_a, const float* rec_b, const float* rec_s,
-                             int n_q, const double t[3], const double q[4], const lo_params* P, double scale, double* rows, int* count) {
+                             int n_q, const double t[3], const double q[4], const lo_params* P, double scale, int scale_den, double* rows, int* count) {
     int cnt = 0;
     for (int i = 0; i < n_q; i++) {
         if (!valid[i]) continue;
         double* Jr = rows + 8 * (size_t)cnt;
-        lo_eval_edge(t, q, rec_cp + 3 * (size_t)i, rec_a + 3 * (size_t)i, rec_b + 3 * (size_t)i, (double)rec_s[i] * scale, Jr);
+        lo_eval_edge(t, q, rec_cp + 3 * (size_t)i, rec_a + 3 * (size_t)i, rec_b + 3 * (size_t)i, scaled_s(rec_s[i], scale, scale_den), Jr);
         double ci; robustify(P->loss, P->loss_a, Jr, &ci);
         cnt++;
     }
@@ -533,7 +540,7 @@ extern "C" void lo_rows_edge(const unsigned char* valid, const float* rec_cp, co
 // contiguous query ranges, added in thread order (the reference itself sums per-thread A, b after joining its 4
 // marginalisation threads, L/src/MarginalizationFactor.cpp:159-174).
 extern "C" void lo_linearize_surf_mt(const unsigned char* valid, const float* rec_cp, const float* rec_n, const float* rec_d, const double* rec_score,
-                                     int n_q, const double t[3], const double q[4], const lo_params* P, double scale, int nthreads,
+                                     int n_q, const double t[3], const double q[4], const lo_params* P, double scale, int scale_den, int nthreads,
                                      double gram[64], double* cost, int* count) {
     if (nthreads < 1) nthreads = 1;
     std::vector<double> G((size_t)nthreads * 64, 0.0), C(nthreads, 0.0);
@@ -548,7 +555,7 @@ extern "C" void lo_linearize_surf_mt(const unsigned char* valid, const float* re
             for (int i = lo; i < hi; i++) {
                 if (!valid[i]) continue;
                 double Jr[8];
-                lo_eval_plane(t, q, rec_cp + 3 * (size_t)i, rec_n + 3 * (size_t)i, rec_d[i], rec_score[i] * scale, P->q_lb, P->t_lb,
+                lo_eval_plane(t, q, rec_cp + 3 * (size_t)i, rec_n + 3 * (size_t)i, rec_d[i], scaled_score(rec_score[i], scale, scale_den), P->q_lb, P->t_lb,
                               P->variant == LO_VARIANT_FRONTEND, Jr);
                 double ci; robustify(P->loss, P->loss_a, Jr, &ci);
                 c += ci; cnt++;

@@ -91,6 +91,14 @@ def _f32(a, cols=None):
     return a
 
 
+def _scale(scale):
+    """scale: a plain factor, or (numerator, count) for the reference's ROT expressions (score * 1000 / N in double,
+    intensity * 200 / N in float — R/src/BackendFusion.cpp:843,861)."""
+    if isinstance(scale, tuple):
+        return float(scale[0]), int(scale[1])
+    return float(scale), 0
+
+
 def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
@@ -163,11 +171,11 @@ def linearize_surf(rec, t, q, P, scale=1.0, nthreads=1):
     t, q = _f64(t), _f64(q)
     if nthreads > 1:
         lib().lo_linearize_surf_mt(_p(rec["valid"]), _p(rec["cp"]), _p(rec["n"]), _p(rec["d"]), _p(rec["score"]),
-                                   rec["valid"].shape[0], _p(t), _p(q), C.byref(P), C.c_double(scale), int(nthreads),
+                                   rec["valid"].shape[0], _p(t), _p(q), C.byref(P), C.c_double(_scale(scale)[0]), _scale(scale)[1], int(nthreads),
                                    _p(gram), C.byref(cost), C.byref(cnt))
         return gram.reshape(8, 8), cost.value, cnt.value
     lib().lo_linearize_surf(_p(rec["valid"]), _p(rec["cp"]), _p(rec["n"]), _p(rec["d"]), _p(rec["score"]),
-                            rec["valid"].shape[0], _p(t), _p(q), C.byref(P), C.c_double(scale), _p(gram),
+                            rec["valid"].shape[0], _p(t), _p(q), C.byref(P), C.c_double(_scale(scale)[0]), _scale(scale)[1], _p(gram),
                             C.byref(cost), C.byref(cnt))
     return gram.reshape(8, 8), cost.value, cnt.value
 
@@ -178,7 +186,7 @@ def linearize_edge(rec, t, q, P, scale=1.0):
     cnt = C.c_int(0)
     t, q = _f64(t), _f64(q)
     lib().lo_linearize_edge(_p(rec["valid"]), _p(rec["cp"]), _p(rec["a"]), _p(rec["b"]), _p(rec["s"]),
-                            rec["valid"].shape[0], _p(t), _p(q), C.byref(P), C.c_double(scale), _p(gram),
+                            rec["valid"].shape[0], _p(t), _p(q), C.byref(P), C.c_double(_scale(scale)[0]), _scale(scale)[1], _p(gram),
                             C.byref(cost), C.byref(cnt))
     return gram.reshape(8, 8), cost.value, cnt.value
 
@@ -434,8 +442,8 @@ def linearize_rows(rec, t, q, P, scale=1.0, kind="surf"):
     t, q = _f64(t), _f64(q)
     if kind == "surf":
         lib().lo_rows_surf(_p(rec["valid"]), _p(rec["cp"]), _p(rec["n"]), _p(rec["d"]), _p(rec["score"]), n, _p(t), _p(q),
-                           C.byref(P), C.c_double(scale), _p(rows), C.byref(cnt))
+                           C.byref(P), C.c_double(_scale(scale)[0]), _scale(scale)[1], _p(rows), C.byref(cnt))
     else:
         lib().lo_rows_edge(_p(rec["valid"]), _p(rec["cp"]), _p(rec["a"]), _p(rec["b"]), _p(rec["s"]), n, _p(t), _p(q),
-                           C.byref(P), C.c_double(scale), _p(rows), C.byref(cnt))
+                           C.byref(P), C.c_double(_scale(scale)[0]), _scale(scale)[1], _p(rows), C.byref(cnt))
     return rows[:cnt.value]

@@ -25,7 +25,7 @@ def build():
 
 
 def available():
-    return all(os.path.exists(os.path.join(REF_DIR, f"libref_{n}.so")) for n in ("rot", "livox", "factors", "lo"))
+    return all(os.path.exists(os.path.join(REF_DIR, f"libref_{n}.so")) for n in ("rot", "livox", "factors", "lo", "backend_L", "backend_R"))
 
 
 def _lib(name):
@@ -227,3 +227,31 @@ class LidarOdometry:
                 self.lib.ref_msg_data(i, _p(a))
             out.append((topic.value.decode(), stamp.value, a))
         return out
+
+
+def backend_associate(flavour, surf_map4, edge_map4, surf_q4, edge_q4, q_assoc, t_assoc, kd_max_radius, surf_dist_thres,
+                      lidar_const, reflect_thres=0.0):
+    """findCorrespondingSurfFeatures / findCorrespondingCornerFeatures / transformPoint of the reference's BackendFusion.cpp
+    (flavour 'livox' = LiLi-OM, 'rot' = LiLi-OM-ROT), member-function text sliced out of the file at build time
+    (oracle/refshim/ref_backend.cpp).  Clouds are (n,4) float32 rows x y z aux.  Returns (surf_records (n,8) = cp, weight*n,
+    weight*d, score; edge_records (n,10) = cp, A, B, s)."""
+    L = _lib("backend_L" if flavour == "livox" else "backend_R")
+    a = [np.ascontiguousarray(x, np.float32).reshape(-1, 4) for x in (surf_map4, edge_map4, surf_q4, edge_q4)]
+    q, t = np.ascontiguousarray(q_assoc, np.float64), np.ascontiguousarray(t_assoc, np.float64)
+    srec, erec = np.zeros((max(a[2].shape[0], 1), 8)), np.zeros((max(a[3].shape[0], 1), 10))
+    ns, ne = C.c_int(0), C.c_int(0)
+    L.ref_backend_associate(_p(a[0]), a[0].shape[0], _p(a[1]), a[1].shape[0], _p(a[2]), a[2].shape[0], _p(a[3]), a[3].shape[0],
+                            _p(q), _p(t), C.c_double(kd_max_radius), C.c_double(surf_dist_thres), C.c_double(lidar_const),
+                            C.c_double(reflect_thres), _p(srec), C.byref(ns), _p(erec), C.byref(ne))
+    return srec[:ns.value].copy(), erec[:ne.value].copy()
+
+
+def backend_rows(flavour, surf_rec, edge_rec, qlb, tlb, t, q):
+    """The residual blocks the reference's optimisation loop would add for those records (L/src/BackendFusion.cpp:936-972,
+    R:836-866, count scaling included for 'rot'), evaluated at (t, q): (surf_rows, edge_rows), each (n,8) = r, dr/dt, dr/dq."""
+    L = _lib("backend_L" if flavour == "livox" else "backend_R")
+    s, e = np.ascontiguousarray(surf_rec, np.float64), np.ascontiguousarray(edge_rec, np.float64)
+    sr, er = np.zeros((max(s.shape[0], 1), 8)), np.zeros((max(e.shape[0], 1), 8))
+    a = [np.ascontiguousarray(x, np.float64) for x in (qlb, tlb, t, q)]
+    L.ref_backend_rows(_p(s), s.shape[0], _p(e), e.shape[0], _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(sr), _p(er))
+    return sr[:s.shape[0]], er[:e.shape[0]]

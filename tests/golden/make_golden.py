@@ -32,8 +32,8 @@ def s2m_case(variant):
     refl = variant == "livox"
     rs = O.associate_surf(tree, room["map_refl"] if refl else None, room["q_xyz"], room["q_refl"] if refl else None, Q2, T2, PO)
     re_ = O.associate_edge(etree, room["eq_xyz"], Q2, T2, PO)
-    ss = 1000.0 / max(rs["count"], 1) if variant == "rot" else 1.0
-    se = 200.0 / max(re_["count"], 1) if variant == "rot" else 1.0
+    ss = (1000.0, max(rs["count"], 1)) if variant == "rot" else 1.0
+    se = (200.0, max(re_["count"], 1)) if variant == "rot" else 1.0
     Gs, cs, _ = O.linearize_surf(rs, t0, q0, PO, ss)
     Ge, ce, _ = O.linearize_edge(re_, t0, q0, PO, se)
     out = dict(t0=t0, q0=q0, Q2=np.asarray(Q2), T2=np.asarray(T2), surf_valid=rs["valid"], surf_nn=rs["nn_idx"], surf_d2=rs["nn_d2"],
@@ -44,7 +44,7 @@ def s2m_case(variant):
     for _ in range(3):
         Q2i, T2i = (q, t) if variant == "frontend" else L.api.assoc_transform(t, q, P)
         r = O.associate_surf(tree, room["map_refl"] if refl else None, room["q_xyz"], room["q_refl"] if refl else None, Q2i, T2i, PO)
-        G, _, _ = O.linearize_surf(r, t, q, PO, 1000.0 / max(r["count"], 1) if variant == "rot" else 1.0)
+        G, _, _ = O.linearize_surf(r, t, q, PO, (1000.0, max(r["count"], 1)) if variant == "rot" else 1.0)
         st, t, q, _ = O.gn_step(G, t, q)
         assert st == 0
     out.update(t3=t, q3=q)

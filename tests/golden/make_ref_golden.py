@@ -10,6 +10,9 @@ tests/golden/{s2m,extract}_*.npz, which come from the oracle — pin the oracle 
                    moving synthetic sequence; ceres::Solve = the documented one-GN-step stand-in (oracle/refshim/ref_lo.cpp):
                    per solve the pose in/out and a hash of the residual-block records the reference built, per frame the
                    node's abs/rel pose and keyframe flag; two solves are stored completely (map, queries, records, raw rows)
+  ref_backend.npz  BackendFusion.cpp's transformPoint / findCorrespondingCornerFeatures / findCorrespondingSurfFeatures (both
+                   flavours; member-function text sliced out of the file at build time, oracle/refshim/ref_backend.cpp) on a
+                   room scene: the correspondence records and the residual blocks (raw r, dr/dt, dr/dq) created from them
   ref_factors.npz  LidarEdgeFactor / LidarPlaneNormFactor / LidarPlaneNormIncreFactor ::Create()->Evaluate() on random
                    records: residual + both Jacobian blocks
 
@@ -148,6 +151,45 @@ def run_frontend():
     return d
 
 
+BACKEND_PARAMS = {   # L/config/config_fr_iosb.yaml, R/config/config_fr_iosb.yaml: kd_max_radius, surf_dist_thres, lidar_const, reflect_thres, q_lb, t_lb
+    "livox": dict(kd_max_radius=1.0, surf_dist_thres=0.12, lidar_const=20.0, reflect_thres=15.0, q_lb=[0.0, 0.0, 0.0, 1.0], t_lb=[-0.0265, 0.0202, 0.05309]),
+    "rot": dict(kd_max_radius=1.0, surf_dist_thres=0.12, lidar_const=7.5, reflect_thres=0.0, q_lb=[0.7071, 0.0, 0.0, 0.7071], t_lb=[-0.18, 0.0, -0.095]),
+}
+
+
+def backend_inputs(flavour):
+    """Room scene + a body pose 5 cm / 0.5 deg off; (Q2, T2) = the LiDAR pose handed to the find* functions
+    (Q2 = q * q_lb^-1, T2 = t - Q2 t_lb, L/src/BackendFusion.cpp:929-930), all in numpy f64 with Eigen's expressions."""
+    from tests import frontend_chain as F
+    room = synth.make_room(seed=12, n_query=1500, n_edge_query=200)
+    B = BACKEND_PARAMS[flavour]
+    qlb, tlb = np.array(B["q_lb"]), np.array(B["t_lb"])
+    # body pose from the scene's LiDAR pose: q_b = q_l * q_lb, t_b = t_l + q_l * t_lb  (inverse of the two lines above for unit q_lb)
+    q_l, t_l = room["q_true"], room["t_true"]
+    qb, tb = F.eigen_qmul(q_l, qlb), t_l + F.eigen_qrot(q_l, tlb[None, :])[0]
+    t0, q0 = synth.perturbed_pose(tb, qb, np.random.default_rng(3), 0.05, 0.5)
+    Q2 = F.eigen_qmul(q0, F.eigen_qinv(qlb))
+    T2 = t0 - F.eigen_qrot(Q2, tlb[None, :])[0]
+    z = lambda a: np.zeros((a.shape[0], 1), np.float32)                                 # noqa: E731
+    return dict(surf_map=np.c_[room["map_xyz"], room["map_refl"]].astype(np.float32), edge_map=np.c_[room["edge_map_xyz"], z(room["edge_map_xyz"])].astype(np.float32),
+                surf_q=np.c_[room["q_xyz"], room["q_refl"]].astype(np.float32), edge_q=np.c_[room["eq_xyz"], z(room["eq_xyz"])].astype(np.float32),
+                t0=t0, q0=q0, Q2=Q2, T2=T2, qlb=qlb, tlb=tlb)
+
+
+def run_backend():
+    d = {}
+    for fl in ("livox", "rot"):
+        i, B = backend_inputs(fl), BACKEND_PARAMS[fl]
+        srec, erec = R.backend_associate(fl, i["surf_map"], i["edge_map"], i["surf_q"], i["edge_q"], i["Q2"], i["T2"], B["kd_max_radius"],
+                                         B["surf_dist_thres"], B["lidar_const"], B["reflect_thres"])
+        srows, erows = R.backend_rows(fl, srec, erec, i["qlb"], i["tlb"], i["t0"], i["q0"])
+        d.update({f"{fl}_t0": i["t0"], f"{fl}_q0": i["q0"], f"{fl}_Q2": i["Q2"], f"{fl}_T2": i["T2"],
+                  f"{fl}_surf_rec": srec[:, :7].astype(np.float32), f"{fl}_surf_score": srec[:, 7], f"{fl}_edge_rec": erec.astype(np.float32),
+                  f"{fl}_surf_rows": srows, f"{fl}_edge_rows": erows})
+        assert np.array_equal(srec[:, :7].astype(np.float32).astype(np.float64), srec[:, :7]) and np.array_equal(erec.astype(np.float32).astype(np.float64), erec)
+    return d
+
+
 def run_factors():
     f = factor_inputs()
     n = f["cp"].shape[0]
@@ -166,7 +208,8 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ref_livox.npz"), **run_livox())
     np.savez_compressed(os.path.join(HERE, "ref_factors.npz"), **run_factors())
     np.savez_compressed(os.path.join(HERE, "ref_frontend.npz"), **run_frontend())
-    for f in ("ref_rot.npz", "ref_livox.npz", "ref_factors.npz", "ref_frontend.npz"):
+    np.savez_compressed(os.path.join(HERE, "ref_backend.npz"), **run_backend())
+    for f in ("ref_rot.npz", "ref_livox.npz", "ref_factors.npz", "ref_frontend.npz", "ref_backend.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

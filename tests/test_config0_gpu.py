@@ -44,8 +44,8 @@ def test_config0_extract_and_one_iteration(gpu_ctx, oracle):
     rs = oracle.associate_surf(tree, None, surf_q, None, Q2, T2, PO, nthreads=8)
     re_ = oracle.associate_edge(etree, edge_q, Q2, T2, PO)
     assert rs["count"] > 500
-    Gs, _, _ = oracle.linearize_surf(rs, t0, q0, PO, 1000.0 / max(rs["count"], 1))
-    Ge, _, _ = oracle.linearize_edge(re_, t0, q0, PO, 200.0 / max(re_["count"], 1))
+    Gs, _, _ = oracle.linearize_surf(rs, t0, q0, PO, (1000.0, max(rs["count"], 1)))
+    Ge, _, _ = oracle.linearize_edge(re_, t0, q0, PO, (200.0, max(re_["count"], 1)))
     sto, to, qo, _ = oracle.gn_step(Gs + Ge, t0, q0)
     assert sto == 0
     assert np.abs(tg - to).max() < 1e-4

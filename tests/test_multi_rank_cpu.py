@@ -29,7 +29,7 @@ def _one_iteration(O, room, lo, hi, t, q, P, PO, reduce_fn):
     rs = O.associate_surf(tree, None, room["q_xyz"][lo:hi], None, Q2, T2, PO)
     counts = torch.tensor([rs["count"], 0], dtype=torch.int32)
     counts = reduce_fn("counts", counts)
-    G, cost, n = O.linearize_surf(rs, t, q, PO, 1000.0 / max(int(counts[0]), 1))
+    G, cost, n = O.linearize_surf(rs, t, q, PO, (1000.0, max(int(counts[0]), 1)))
     rec = torch.zeros(72, dtype=torch.float64)
     rec[:64] = torch.from_numpy(G.reshape(-1))
     rec[64], rec[65] = cost, n

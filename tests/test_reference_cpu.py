@@ -41,11 +41,11 @@ def _same_npz(d, g):
 
 
 # ------------------------------------------------------------------ the reference build itself
-@pytest.mark.parametrize("which", ["rot", "livox", "factors", "frontend"])
+@pytest.mark.parametrize("which", ["rot", "livox", "factors", "frontend", "backend"])
 def test_reference_build_reproduces_fixtures(which):
     if not M.R.available():
         pytest.skip("oracle/_ref not built (needs /root/reference; build container only)")
-    d = {"rot": M.run_rot, "livox": M.run_livox, "factors": M.run_factors, "frontend": M.run_frontend}[which]()
+    d = {"rot": M.run_rot, "livox": M.run_livox, "factors": M.run_factors, "frontend": M.run_frontend, "backend": M.run_backend}[which]()
     _same_npz(d, np.load(os.path.join(G, f"ref_{which}.npz")))
 
 
@@ -164,6 +164,46 @@ def test_frontend_chain_on_oracle_equals_reference_node(oracle):
     assert np.linalg.norm(a[-1][4:] - a[1][4:]) > 1.5           # the sensor really moved (0.5 m per frame)
     a2, _ = F.run_frontend_chain(F.OracleBackend(oracle, stable=True), surf, scan_match_cnt=6)
     assert np.abs(a2 - g["abs_pose"]).max() < 1e-5
+
+
+# ------------------------------------------------------------------ back-end matcher (BackendFusion.cpp slices) vs oracle
+def _sorted_ab(e):
+    """edge records with (A, B) in a canonical order: A = c + 0.1 v, B = c - 0.1 v and the sign of an eigenvector is arbitrary"""
+    a, b = e[:, 3:6].copy(), e[:, 6:9].copy()
+    swap = np.array([tuple(x) > tuple(y) for x, y in zip(a, b)])
+    a[swap], b[swap] = e[swap, 6:9], e[swap, 3:6]
+    return np.c_[e[:, 0:3], a, b, e[:, 9:10]]
+
+
+@pytest.mark.parametrize("flavour", ["livox", "rot"])
+def test_oracle_association_equals_reference_backend(oracle, flavour):
+    """transformPoint + findCorrespondingSurfFeatures + findCorrespondingCornerFeatures of the reference's back-end (both
+    flavours: reflectivity-weighted LS and score for Livox, point-to-line gate for ROT) and the residual blocks built from
+    them (count scaling with the reference's float / double promotions for ROT): records and raw rows bit-exact."""
+    g = np.load(os.path.join(G, "ref_backend.npz"))
+    i = M.backend_inputs(flavour)
+    PO = oracle.params(flavour)
+    B = M.BACKEND_PARAMS[flavour]
+    assert (PO.kd_max_radius, PO.surf_dist_thres, PO.lidar_const, PO.reflect_thres) == (B["kd_max_radius"], B["surf_dist_thres"], B["lidar_const"], B["reflect_thres"])
+    assert list(PO.q_lb) == B["q_lb"] and list(PO.t_lb) == B["t_lb"]
+    assert np.array_equal(i["Q2"], g[f"{flavour}_Q2"]) and np.array_equal(i["t0"], g[f"{flavour}_t0"])
+    refl = flavour == "livox"
+    rs = oracle.associate_surf(oracle.KdTree(np.ascontiguousarray(i["surf_map"][:, :3])), np.ascontiguousarray(i["surf_map"][:, 3]) if refl else None,
+                               np.ascontiguousarray(i["surf_q"][:, :3]), np.ascontiguousarray(i["surf_q"][:, 3]) if refl else None, i["Q2"], i["T2"], PO)
+    re_ = oracle.associate_edge(oracle.KdTree(np.ascontiguousarray(i["edge_map"][:, :3])), np.ascontiguousarray(i["edge_q"][:, :3]), i["Q2"], i["T2"], PO)
+    v, ve = rs["valid"].astype(bool), re_["valid"].astype(bool)
+    assert v.sum() > 1000 and ve.sum() > 100
+    assert np.array_equal(np.c_[rs["cp"][v], rs["n"][v], rs["d"][v]], g[f"{flavour}_surf_rec"])
+    assert np.array_equal(rs["score"][v], g[f"{flavour}_surf_score"])
+    mine_e = np.c_[re_["cp"][ve], re_["a"][ve], re_["b"][ve], re_["s"][ve]]
+    assert np.array_equal(_sorted_ab(mine_e), _sorted_ab(g[f"{flavour}_edge_rec"]))
+    ss = (1000.0, int(v.sum())) if flavour == "rot" else 1.0
+    se = (200.0, int(ve.sum())) if flavour == "rot" else 1.0
+    raw = oracle.params(flavour, loss=0)
+    rows_s = oracle.linearize_rows(rs, i["t0"], i["q0"], raw, ss, "surf")
+    rows_e = oracle.linearize_rows(re_, i["t0"], i["q0"], raw, se, "edge")
+    assert np.array_equal(np.c_[rows_s[:, 7], rows_s[:, :7]], g[f"{flavour}_surf_rows"])
+    assert np.array_equal(np.c_[rows_e[:, 7], rows_e[:, :7]], g[f"{flavour}_edge_rows"])
 
 
 # ------------------------------------------------------------------ product host logic vs reference

@@ -164,3 +164,43 @@ def test_gpu_frontend_chain_vs_reference_node(gpu_ctx):
     assert np.abs(a[:, :4] - ref[:, :4]).max() < 5e-5           # quaternion components: < 1e-4 rad
     assert np.abs(r - g["rel_pose"]).max() < 1e-4
     print("GPU front-end chain vs reference node: max |dt| = %.3g m, max |dq| = %.3g" % (np.abs(a[:, 4:] - ref[:, 4:]).max(), np.abs(a[:, :4] - ref[:, :4]).max()))
+
+
+@pytest.mark.parametrize("flavour", ["livox", "rot"])
+def test_gpu_backend_matcher_vs_reference(gpu_ctx, flavour):
+    """k_associate_surf / k_associate_edge / k_linearize_* vs the reference's OWN back-end association functions and residual
+    blocks (tests/golden/ref_backend.npz: BackendFusion.cpp member functions compiled from the reference text): the same
+    correspondences in the same order (cp bit-exact), plane / line parameters within the f32-record tolerance, scores to
+    3e-7, and the Gram of lili_s2m_linearize equal to the robustified sum over the reference's raw residual blocks."""
+    g = np.load(os.path.join(G, "ref_backend.npz"))
+    i = M.backend_inputs(flavour)
+    P = L.make_params(flavour)
+    m = L.ScanToMapMatcher(gpu_ctx, P)
+    m.set_input_cloud(L.KIND_SURF, i["surf_map"] if flavour == "livox" else np.ascontiguousarray(i["surf_map"][:, :3]))
+    m.set_input_cloud(L.KIND_EDGE, np.ascontiguousarray(i["edge_map"][:, :3]))
+    m.set_queries(0, L.KIND_SURF, i["surf_q"] if flavour == "livox" else np.ascontiguousarray(i["surf_q"][:, :3]))
+    m.set_queries(0, L.KIND_EDGE, np.ascontiguousarray(i["edge_q"][:, :3]))
+    Q2, T2 = L.api.assoc_transform(i["t0"], i["q0"], P)             # the product's own derivation of the association pose
+    assert np.abs(np.asarray(Q2) - i["Q2"]).max() < 1e-15 and np.abs(np.asarray(T2) - i["T2"]).max() < 1e-14
+    ns = m.find_corresponding_surf_features(0, Q2, T2)
+    ne = m.find_corresponding_corner_features(0, Q2, T2)
+    rs, re_ = m.surf_records(0, ns), m.edge_records(0, ne)
+    ref_s, ref_sc, ref_e = g[f"{flavour}_surf_rec"], g[f"{flavour}_surf_score"], g[f"{flavour}_edge_rec"]
+    assert ns == ref_s.shape[0] and ne == ref_e.shape[0]
+    assert np.array_equal(rs["cp"], ref_s[:, 0:3]) and np.array_equal(re_["cp"], ref_e[:, 0:3])     # same queries kept, same order
+    np.testing.assert_allclose(rs["n"], ref_s[:, 3:6], rtol=3e-7, atol=1e-9)
+    np.testing.assert_allclose(rs["d"], ref_s[:, 6], rtol=3e-7, atol=1e-9)
+    np.testing.assert_allclose(rs["score"], ref_sc, rtol=3e-7)
+    ga, gb = re_["a"], re_["b"]
+    swap = np.abs(ga - ref_e[:, 3:6]).max(1) > np.abs(ga - ref_e[:, 6:9]).max(1)        # eigenvector sign is arbitrary
+    ra = np.where(swap[:, None], ref_e[:, 6:9], ref_e[:, 3:6]); rb = np.where(swap[:, None], ref_e[:, 3:6], ref_e[:, 6:9])
+    np.testing.assert_allclose(ga, ra, rtol=0, atol=2e-6)
+    np.testing.assert_allclose(gb, rb, rtol=0, atol=2e-6)
+    assert np.array_equal(re_["s"], ref_e[:, 9])
+    for mask, rows in ((L.MASK_SURF, g[f"{flavour}_surf_rows"]), (L.MASK_EDGE, g[f"{flavour}_edge_rows"])):
+        Gg, cost, counts = m.linearize(0, i["t0"], i["q0"], mask)
+        rr = _cauchy_rows(np.c_[rows[:, 1:8], rows[:, 0]])
+        Gr = rr.T @ rr
+        assert np.abs(Gg - Gr).max() <= 2e-6 * np.abs(Gr).max(), (flavour, mask, np.abs(Gg - Gr).max() / np.abs(Gr).max())
+        cost_ref = 0.5 * np.log1p(rows[:, 0] ** 2).sum()
+        assert abs(cost - cost_ref) <= 2e-6 * max(1.0, cost_ref)

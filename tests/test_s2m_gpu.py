@@ -44,7 +44,7 @@ def _pose(room, P, variant, rng=None, dt=0.0, dang=0.0):
 
 def _scales(variant, n_s, n_e):
     if variant == "rot":
-        return 1000.0 / max(n_s, 1), 200.0 / max(n_e, 1)
+        return (1000.0, max(n_s, 1)), (200.0, max(n_e, 1))
     return 1.0, 1.0
 
 
@@ -148,8 +148,8 @@ def test_linearize_exact_records(gpu_ctx, oracle):
     re_["cp"][ge["query_index"]] = ge["cp"]; re_["a"][ge["query_index"]] = ge["a"]
     re_["b"][ge["query_index"]] = ge["b"]; re_["s"][ge["query_index"]] = ge["s"]
     G, cost, counts = m.linearize(0, t, q, L.MASK_SURF | L.MASK_EDGE)
-    g1, c1, n1 = oracle.linearize_surf(rs, t, q, PO, 1000.0 / n_s)
-    g2, c2, n2 = oracle.linearize_edge(re_, t, q, PO, 200.0 / n_e)
+    g1, c1, n1 = oracle.linearize_surf(rs, t, q, PO, (1000.0, n_s))
+    g2, c2, n2 = oracle.linearize_edge(re_, t, q, PO, (200.0, n_e))
     Go = g1 + g2
     assert (counts[0], counts[1]) == (n1, n2)
     assert np.abs(G - Go).max() <= 1e-12 * np.abs(Go).max()
@@ -305,7 +305,7 @@ def test_mid_size_outdoor_scene(gpu_ctx, oracle):
     g = m.surf_records(0, w["scan_xyz"].shape[0])
     assert np.array_equal(g["query_index"], np.nonzero(rs["valid"])[0])
     G, cost, counts = m.linearize(0, t0, q0, L.MASK_SURF)
-    Go, co, no = oracle.linearize_surf(rs, t0, q0, PO, 1000.0 / rs["count"])
+    Go, co, no = oracle.linearize_surf(rs, t0, q0, PO, (1000.0, rs["count"]))
     assert counts[0] == no
     assert np.abs(G - Go).max() <= 2e-6 * np.abs(Go).max()
 
