@@ -201,6 +201,58 @@ __device__ __forceinline__ void lstsq53(col5 c0, col5 c1, col5 c2, col5 b, doubl
     x[2] = (p0 == 2) ? y0 : ((p1 == 2) ? y1 : y2);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fast path of the 5-point plane fit  min sum_k w_k^2 (p_k . n + 1)^2  (the least-squares problem the reference hands to
+// colPivHouseholderQr): centred normal equations.  With c = weighted centroid, e_k = p_k - c, S = sum w_k^2 e_k e_k^T
+// (3x3, entries O(neighbourhood size^2) — no 500 m offsets left in it) the cross term vanishes and
+//     (S + W c c^T) n = -W c     =>     n = -W adj(S) c / (det S + W c^T adj(S) c)          (Sherman-Morrison / determinant lemma)
+// ~110 f64 instructions, one division, no square root, no pivot bookkeeping — against ~450 for the pivoted Householder QR.
+// The denominator equals det(A^T A); when it is small against the size of its terms (nearly collinear neighbours, or a
+// plane through the origin) the caller falls back to lstsq53, which follows Eigen's rank-revealing procedure, so
+// ill-conditioned and rank-deficient fits keep the reference's behaviour.  Elsewhere both paths agree to ~1e-9 relative
+// (error <= eps / 1e-7), far below the f32 rounding of the stored record.
+// ------------------------------------------------------------------------------------------------
+template <bool WEIGHTED>
+__device__ __forceinline__ bool plane_fit_centered(const double x[5], const double y[5], const double z[5], const double w2[5], double n[3]) {
+    double W, cx, cy, cz;
+    if (WEIGHTED) {
+        W = ((w2[0] + w2[1]) + (w2[2] + w2[3])) + w2[4];
+        cx = fma(w2[4], x[4], fma(w2[3], x[3], fma(w2[2], x[2], fma(w2[1], x[1], w2[0] * x[0]))));
+        cy = fma(w2[4], y[4], fma(w2[3], y[3], fma(w2[2], y[2], fma(w2[1], y[1], w2[0] * y[0]))));
+        cz = fma(w2[4], z[4], fma(w2[3], z[3], fma(w2[2], z[2], fma(w2[1], z[1], w2[0] * z[0]))));
+        const double rW = 1.0 / W;
+        cx *= rW; cy *= rW; cz *= rW;
+    } else {
+        W = 5.0;
+        cx = (((x[0] + x[1]) + (x[2] + x[3])) + x[4]) * 0.2;
+        cy = (((y[0] + y[1]) + (y[2] + y[3])) + y[4]) * 0.2;
+        cz = (((z[0] + z[1]) + (z[2] + z[3])) + z[4]) * 0.2;
+    }
+    double sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const double ex = x[k] - cx, ey = y[k] - cy, ez = z[k] - cz;
+        const double wx = WEIGHTED ? w2[k] * ex : ex, wy = WEIGHTED ? w2[k] * ey : ey, wz = WEIGHTED ? w2[k] * ez : ez;
+        sxx = fma(wx, ex, sxx); sxy = fma(wx, ey, sxy); sxz = fma(wx, ez, sxz);
+        syy = fma(wy, ey, syy); syz = fma(wy, ez, syz); szz = fma(wz, ez, szz);
+    }
+    const double a00 = fma(syy, szz, -(syz * syz)), a01 = fma(sxz, syz, -(sxy * szz)), a02 = fma(sxy, syz, -(sxz * syy));
+    const double a11 = fma(sxx, szz, -(sxz * sxz)), a12 = fma(sxy, sxz, -(sxx * syz)), a22 = fma(sxx, syy, -(sxy * sxy));
+    const double det = fma(sxz, a02, fma(sxy, a01, sxx * a00));
+    const double ux = fma(a02, cz, fma(a01, cy, a00 * cx));
+    const double uy = fma(a12, cz, fma(a11, cy, a01 * cx));
+    const double uz = fma(a22, cz, fma(a12, cy, a02 * cx));
+    const double cu = fma(cz, uz, fma(cy, uy, cx * ux));
+    const double c2 = fma(cz, cz, fma(cy, cy, cx * cx));
+    const double tr = sxx + syy + szz;
+    const double denom = fma(W, cu, det);
+    const double scale = tr * tr * fma(W, c2, tr);
+    if (!(denom > 1e-7 * scale)) return false;          // also catches NaN / inf inputs
+    const double f = -W / denom;
+    n[0] = f * ux; n[1] = f * uy; n[2] = f * uz;
+    return true;
+}
+
 // ceres loss functions: rho[0..2] = rho(s), rho'(s), rho''(s)
 __device__ __forceinline__ void loss_eval(int loss, double a, double s, double rho[3]) {
     if (loss == 1) {  // Cauchy

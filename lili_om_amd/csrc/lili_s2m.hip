@@ -9,6 +9,7 @@
 //   LidarEdgeFactor / LidarPlaneNormFactor / LidarPlaneNormIncreFactor   L/include/factors/LidarKeyframeFactor.h:12-139
 //   loss corrector + J^T J accumulation   L/src/MarginalizationFactor.cpp:3-29,44-70
 // HBM-bound gather work: no MFMA (the J^T J contraction is N x 8 -> 8 x 8), f64 on the vector ALUs.
+#include <type_traits>
 #include "lili_kernels.h"
 #include "lili_device_math.h"
 
@@ -325,6 +326,94 @@ struct Sel5F {
     }
 };
 
+// Key selector (default fast tier): ONE 32-bit key per candidate and no payload moves.
+//   key = (distance bits & ~63) | code        code = ((chunk & 7) << 2) | slot-in-chunk      (a "bucket" = 64 f32 ulps of d^2)
+// The SIX smallest keys are kept sorted with five v_med3_u32 and one v_min_u32 per candidate — no comparisons, no selects,
+// no wave-level branch.  Where a key came from is recovered afterwards from a small per-lane LDS table
+// (T[0..7] = first array position of the last eight chunks, T[8..13] = positions resolved so far, T[15] = -4 for the
+// sentinel code 63): position = T[code >> 2] + (code & 3); every eight chunks the six held keys are re-pointed to T[8..13].
+// Exactness: buckets are monotone in the distance, so every candidate outside the held six has a bucket >= the sixth's.
+// If the sixth key's bucket differs from the fifth's, the five best are exactly the five smallest distances (as a set);
+// their exact f32 distances are then recomputed from the re-loaded points and put into the oracle's (d2, index) order.
+// If the buckets coincide, or the fifth lies in the bucket of the search bound, the query is repeated with the exact
+// selector (about once in 1e5 queries on voxel-filtered maps; always on lattice ties).
+struct Sel5K {
+    unsigned k[6];
+    int tc;          // chunks processed by this lane
+    int* T;          // this lane's column of the chunk table (row stride ts ints)
+    int ts;
+    unsigned bb;     // bucket of the bound
+    float bnd;
+    __device__ __forceinline__ void init(float bound) {
+        bnd = fminf(bound, 3.0e38f);
+        bb = __float_as_uint(bnd) >> 6;
+#pragma unroll
+        for (int s = 0; s < 6; s++) k[s] = ((bb + 1u + (unsigned)s) << 6) | 63u;   // six distinct buckets above the bound
+        tc = 0; T = nullptr; ts = 0;
+    }
+    __device__ __forceinline__ void attach(int* col, int stride) { T = col; ts = stride; T[15 * stride] = -4; }
+    __device__ __forceinline__ float worst() const { return __uint_as_float(k[4] | 63u); }   // upper end of the bucket: pruning stays conservative
+    __device__ __forceinline__ unsigned worst_bits() const { return k[4] | 63u; }
+    __device__ __forceinline__ void to_top5(Top5& t) const {   // only meaningful right after init (early exits)
+#pragma unroll
+        for (int s = 0; s < 5; s++) { t.d[s] = bnd; t.j[s] = -1; }
+    }
+    __device__ __forceinline__ void push(unsigned key) {
+        const unsigned m5 = umed3(k[4], k[5], key), m4 = umed3(k[3], k[4], key), m3 = umed3(k[2], k[3], key);
+        const unsigned m2 = umed3(k[1], k[2], key), m1 = umed3(k[0], k[1], key);
+        k[0] = min(k[0], key); k[1] = m1; k[2] = m2; k[3] = m3; k[4] = m4; k[5] = m5;
+    }
+    __device__ __forceinline__ int where(unsigned key) const { const unsigned c = key & 63u; return T[(int)(c >> 2) * ts] + (int)(c & 3u); }
+    __device__ __forceinline__ void repoint() {
+        int jr[6];
+#pragma unroll
+        for (int s = 0; s < 6; s++) jr[s] = where(k[s]);
+#pragma unroll
+        for (int s = 0; s < 6; s++) { T[(8 + s) * ts] = jr[s]; k[s] = (k[s] & ~63u) | (unsigned)(32 + 4 * s); }
+    }
+    __device__ __forceinline__ void chunk(float4 p0, float4 p1, float4 p2, float4 p3, int j, int end, float qx, float qy, float qz) {
+        if (tc >= 8 && (tc & 7) == 0) repoint();
+        T[(tc & 7) * ts] = j;
+        const unsigned code = (unsigned)(tc & 7) << 2;
+        tc++;
+        const unsigned u0 = __float_as_uint(dist2(p0, qx, qy, qz));
+        const unsigned u1 = j + 1 < end ? __float_as_uint(dist2(p1, qx, qy, qz)) : 0x7f800000u;
+        const unsigned u2 = j + 2 < end ? __float_as_uint(dist2(p2, qx, qy, qz)) : 0x7f800000u;
+        const unsigned u3 = j + 3 < end ? __float_as_uint(dist2(p3, qx, qy, qz)) : 0x7f800000u;
+        push((u0 & ~63u) | code); push((u1 & ~63u) | (code + 1u)); push((u2 & ~63u) | (code + 2u)); push((u3 & ~63u) | (code + 3u));
+    }
+    // Resolves the five best, recomputes their exact distances and orders them by (d2, original index).
+    // Returns true if the query has to be repeated with the exact selector.
+    __device__ __forceinline__ bool finish(const GridView& g, float qx, float qy, float qz, Top5& t) const {
+        const bool redo = ((k[5] ^ k[4]) < 64u) || ((k[4] >> 6) == bb);
+        unsigned long long e[5];
+        int jr[5];
+#pragma unroll
+        for (int s = 0; s < 5; s++) {
+            jr[s] = where(k[s]);
+            const bool real = jr[s] >= 0;
+            const float4 p = g.pts[real ? jr[s] : 0];
+            const unsigned du = real ? __float_as_uint(dist2(p, qx, qy, qz)) : __float_as_uint(bnd);
+            const unsigned lo = real ? (unsigned)__float_as_int(p.w) : 0x7fffffffu;
+            e[s] = ((unsigned long long)du << 32) | lo;
+        }
+        const bool unsorted = !(e[0] < e[1] && e[1] < e[2] && e[2] < e[3] && e[3] < e[4]);
+        if (__any(unsorted)) {   // within-bucket inversion somewhere in the wave (rare): 9 compare-exchanges
+#define LILI_CE(a, b) { const bool sw = e[b] < e[a]; const unsigned long long ea = e[a], eb = e[b]; const int ja = jr[a], jb = jr[b]; \
+                        e[a] = sw ? eb : ea; e[b] = sw ? ea : eb; jr[a] = sw ? jb : ja; jr[b] = sw ? ja : jb; }
+            LILI_CE(0, 1) LILI_CE(3, 4) LILI_CE(2, 4) LILI_CE(2, 3) LILI_CE(0, 3) LILI_CE(0, 2) LILI_CE(1, 4) LILI_CE(1, 3) LILI_CE(1, 2)
+#undef LILI_CE
+        }
+#pragma unroll
+        for (int s = 0; s < 5; s++) { t.d[s] = __uint_as_float((unsigned)(e[s] >> 32)); t.j[s] = jr[s]; }
+        return redo;
+    }
+};
+__device__ __forceinline__ void process_chunk(Sel5K& sel, float4 p0, float4 p1, float4 p2, float4 p3, int j, int end, float qx, float qy, float qz) {
+    asm volatile("" : "+v"(p0.w), "+v"(p1.w), "+v"(p2.w), "+v"(p3.w));
+    sel.chunk(p0, p1, p2, p3, j, end, qx, qy, qz);
+}
+
 // Lower bound (conservative by 0.1 %) of the f32 squared distance from the query to any point of the cell row
 // (cy+dy, cz+dz): the gap to the own cell's boundary in y and z.  Rows whose bound exceeds the current 5th best
 // cannot contribute (a candidate enters only with d <= that value) — skipping them keeps the search exact.
@@ -379,6 +468,7 @@ struct RowTabT {
     int b[9][BS];
     int e[9][BS];
     float lb[9][BS];
+    int cj[16][BS];   // Sel5K: array positions of the last eight chunks / resolved positions / sentinel
 };
 
 // Exact 5-NN among the map points of the (2*reach+1)^3 cells around the query.  reach = 1: the 27 cells (9 runs).
@@ -397,6 +487,7 @@ __device__ __forceinline__ bool knn5_grid_sel(const GridView& g, TAB& tab, float
     SEL sel; sel.init(bound);
     sel.to_top5(best);
     if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) return false;
+    if constexpr (std::is_same<SEL, Sel5K>::value) sel.attach(&tab.cj[0][threadIdx.x], (int)(sizeof(tab.cj[0]) / sizeof(int)));
     const int R = g.reach;
     int cx = cell_coord(qx, g.ox, g.inv_cell), cy = cell_coord(qy, g.oy, g.inv_cell), cz = cell_coord(qz, g.oz, g.inv_cell);
     // queries more than `reach` cells outside the grid cannot have a neighbour within the gate radius
@@ -495,14 +586,14 @@ __device__ __forceinline__ bool knn5_grid_sel(const GridView& g, TAB& tab, float
             }
         }
     }
-    sel.to_top5(best);
-    return sel.final_tie();
+    if constexpr (std::is_same<SEL, Sel5K>::value) return sel.finish(g, qx, qy, qz, best);
+    else { sel.to_top5(best); return sel.final_tie(); }
 }
 // Fast selection first; the rare queries with an exact distance tie that could matter are repeated with the exact
 // (distance, original index) selector, so the result is always the oracle's.
 template <class TAB>
 __device__ __forceinline__ void knn5_grid(const GridView& g, TAB& tab, float qx, float qy, float qz, float bound, Top5& best) {
-    if (knn5_grid_sel<Sel5F>(g, tab, qx, qy, qz, bound, best)) knn5_grid_sel<Sel5>(g, tab, qx, qy, qz, bound, best);
+    if (knn5_grid_sel<Sel5K>(g, tab, qx, qy, qz, bound, best)) knn5_grid_sel<Sel5>(g, tab, qx, qy, qz, bound, best);
 }
 
 // Correspondence counting without atomics on a shared word (3128 same-address atomics cost ~40 us on
@@ -619,8 +710,10 @@ __device__ __forceinline__ bool surf_fit(const GridView& g, const MatchParams& P
     float4 m[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) m[k] = g.pts[nn.j[k]];
-    col5 c0, c1, c2, b;
     double sum_w = 0.0;
+    double mx[5], my[5], mz[5], wk[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) { mx[k] = (double)m[k].x; my[k] = (double)m[k].y; mz[k] = (double)m[k].z; wk[k] = 1.0; }
     if (P.variant == 0) {   // Livox reflectivity weighting, L:1617-1638
         double w[5];
 #pragma unroll
@@ -632,17 +725,24 @@ __device__ __forceinline__ bool surf_fit(const GridView& g, const MatchParams& P
         }
         if (sum_w > P.reflect_thres) return false;
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
-            double wk = w[k] / sum_w;
-            c0.v[k] = wk * (double)m[k].x; c1.v[k] = wk * (double)m[k].y; c2.v[k] = wk * (double)m[k].z;
-            b.v[k] = -1.0 * wk;
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < 5; k++) { c0.v[k] = (double)m[k].x; c1.v[k] = (double)m[k].y; c2.v[k] = (double)m[k].z; b.v[k] = -1.0; }
+        for (int k = 0; k < 5; k++) wk[k] = w[k] / sum_w;
     }
     double nv[3];
-    lstsq53(c0, c1, c2, b, nv);
+    bool fitted = false;
+    if (!(P.debug & 512)) {   // LILI_DEBUG bit 512: always take the pivoted QR (A/B and parity of the two paths)
+        if (P.variant == 0) {
+            double w2[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) w2[k] = wk[k] * wk[k];
+            fitted = plane_fit_centered<true>(mx, my, mz, w2, nv);
+        } else fitted = plane_fit_centered<false>(mx, my, mz, wk, nv);
+    }
+    if (!fitted) {            // ill-conditioned or rank-deficient: Eigen's rank-revealing procedure (rare, wave-divergent)
+        col5 c0, c1, c2, b;
+#pragma unroll
+        for (int k = 0; k < 5; k++) { c0.v[k] = wk[k] * mx[k]; c1.v[k] = wk[k] * my[k]; c2.v[k] = wk[k] * mz[k]; b.v[k] = -1.0 * wk[k]; }
+        lstsq53(c0, c1, c2, b, nv);
+    }
     double nn_ = sqrt(nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2]);
     double normInverse = 1.0 / nn_;
     nv[0] *= normInverse; nv[1] *= normInverse; nv[2] *= normInverse;
