@@ -23,8 +23,9 @@ __global__ void k_bin_count(const float4*, int, GridView, PoseArg, MatchParams, 
 __global__ void k_bin_scatter(const int*, int, const int*, int*, int*);
 __global__ void k_tile_count(const int*, int, int*);
 __global__ void k_tile_fill(const int*, const int*, const int*, int, int2*);
-template <bool TILED, int BS> __global__ void k_associate_surf(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, int*, int*);
-template <bool TILED, int BS> __global__ void k_associate_edge(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, int*, int*);
+template <bool TILED, int BS> __global__ void k_associate_surf(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, int*, int*, AssocSched);
+template <bool TILED, int BS> __global__ void k_associate_edge(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, int*, int*, AssocSched);
+__global__ void k_block_order(const int*, int, int, int*);
 __global__ void k_linearize_surf(const float4*, int, const float4*, const double*, const unsigned char*, PoseArg, MatchParams, const SlotState*, const int*, int, const int*, double*, FuseTail);
 __global__ void k_linearize_edge(const float4*, int, const float4*, const float4*, const unsigned char*, PoseArg, MatchParams, const SlotState*, const int*, int, const int*, double*, FuseTail);
 __global__ void k_reduce_partials(const double*, int, const double*, int, double*, SlotState*, int);
@@ -96,6 +97,7 @@ int lili_ctx_create(lili_ctx** out, int device, void* stream) {
     lili_ctx* ctx = new (std::nothrow) lili_ctx();
     if (!ctx) return LILI_E_NOMEM;
     ctx->device = device;
+    ctx->n_simd = prop.multiProcessorCount * 4;   // CDNA: four SIMDs per CU
     if (stream) ctx->stream = reinterpret_cast<hipStream_t>(stream);
     else {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LILI_E_HIP; }
@@ -148,6 +150,7 @@ int lili_set_option(lili_ctx* ctx, const char* name, int value) {
     if (std::strcmp(name, "grid_reach") == 0) { if (value != 1 && value != 2) return ctx->fail(LILI_E_ARG, "grid_reach must be 1 or 2"); ctx->grid_reach = value; return LILI_OK; }
     if (std::strcmp(name, "cell_pct") == 0) { if (value < 50 || value > 100) return ctx->fail(LILI_E_ARG, "cell_pct must be in 50..100"); ctx->cell_pct = value; return LILI_OK; }
     if (std::strcmp(name, "tiled") == 0) { ctx->tiled = value != 0; return LILI_OK; }
+    if (std::strcmp(name, "balance") == 0) { ctx->balance = value != 0; for (auto& sl : ctx->slots) for (auto& k : sl.k) { k.order_valid = false; k.launches = 0; } return LILI_OK; }
     if (std::strcmp(name, "fuse_tail") == 0) { ctx->fuse_tail = value != 0; return LILI_OK; }   // takes effect at the next set_queries
     if (std::strcmp(name, "nn_cache") == 0) { ctx->nn_cache = value != 0; for (auto& s : ctx->slots) for (auto& k : s.k) k.nn_cache_valid = false; return LILI_OK; }
     if (std::strcmp(name, "max_cells") == 0) { if (value < 1) return ctx->fail(LILI_E_ARG, "max_cells must be positive"); ctx->max_cells = value; return LILI_OK; }
@@ -166,7 +169,7 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
     HIPCHK(hipSetDevice(ctx->device));
     MapIndex& m = ctx->map[kind];
     m.valid = false;
-    for (auto& s : ctx->slots) { s.k[kind].binned = false; s.k[kind].nn_cache_valid = false; }
+    for (auto& s : ctx->slots) { s.k[kind].binned = false; s.k[kind].nn_cache_valid = false; s.k[kind].order_valid = false; s.k[kind].launches = 0; }
     int rc = lili_ingest_cloud(ctx, cloud, m.pts);
     if (rc != LILI_OK) return rc;
     m.n = (int64_t)cloud->n;
@@ -253,7 +256,7 @@ int lili_s2m_set_queries(lili_ctx* ctx, int slot, int kind, const lili_cloud* cl
     ARGCHK(cloud, "set_queries: null cloud");
     HIPCHK(hipSetDevice(ctx->device));
     KindSlot& ks = ctx->slots[slot].k[kind];
-    ks.has_queries = false; ks.has_records = false; ks.binned = false; ks.nn_cache_valid = false;
+    ks.has_queries = false; ks.has_records = false; ks.binned = false; ks.nn_cache_valid = false; ks.order_valid = false; ks.launches = 0;
     int rc = lili_ingest_cloud(ctx, cloud, ks.q);
     if (rc != LILI_OK) return rc;
     ks.n_q = (int64_t)cloud->n;
@@ -365,16 +368,29 @@ static int launch_associate(lili_ctx* ctx, int slot, int kind, const PoseArg& pa
         tiles = ks.tiles.as<int2>();
         ks.n_assoc_blocks = ks.n_tiles;
     }
+    // cost-ordered dispatch (one-wave workgroups only): costs of launch k order launch k+1; rebuilt before launches 2 and 4 of a scan
+    AssocSched sched{nullptr, nullptr};
+    if (ctx->balance && !perm && kind == LILI_KIND_SURF && ks.n_blocks > ctx->n_simd && ks.n_blocks <= 8192 && ctx->n_simd > 0) {
+        HIPCHK(ks.block_cost.ensure((size_t)ks.n_blocks * sizeof(int)));
+        HIPCHK(ks.order.ensure((size_t)ks.n_blocks * sizeof(int)));
+        if (ks.launches == 1 || ks.launches == 3) {
+            hipLaunchKernelGGL(k_block_order, dim3(1), dim3(1024), 0, ctx->stream, ks.block_cost.as<int>(), ks.n_blocks, ctx->n_simd, ks.order.as<int>());
+            ks.order_valid = true;
+        }
+        sched.block_cost = ks.block_cost.as<int>();
+        if (ks.order_valid) sched.order = ks.order.as<int>();
+    }
+    ks.launches++;
     // default: one wave per workgroup (kAssocBlock); the binned / tiled variants keep kBlock-sized tiles
     const dim3 grid(ks.n_assoc_blocks);
 #define LILI_LAUNCH_ASSOC(KERNEL, REC1T)                                                                                                   \
     do {                                                                                                                                   \
         if (tiled) hipLaunchKernelGGL((KERNEL<true, kBlock>), grid, dim3(kBlock), 0, ctx->stream, ks.q.as<float4>(), perm, tiles, n, m.view, pa, P, \
-                                      ks.rec0.as<float4>(), ks.rec1.as<REC1T>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>(), nnc); \
+                                      ks.rec0.as<float4>(), ks.rec1.as<REC1T>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>(), nnc, sched); \
         else if (perm) hipLaunchKernelGGL((KERNEL<false, kBlock>), grid, dim3(kBlock), 0, ctx->stream, ks.q.as<float4>(), perm, tiles, n, m.view, pa, P, \
-                                      ks.rec0.as<float4>(), ks.rec1.as<REC1T>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>(), nnc); \
+                                      ks.rec0.as<float4>(), ks.rec1.as<REC1T>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>(), nnc, sched); \
         else hipLaunchKernelGGL((KERNEL<false, kAssocBlock>), grid, dim3(kAssocBlock), 0, ctx->stream, ks.q.as<float4>(), perm, tiles, n, m.view, pa, P, \
-                                      ks.rec0.as<float4>(), ks.rec1.as<REC1T>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>(), nnc); \
+                                      ks.rec0.as<float4>(), ks.rec1.as<REC1T>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>(), nnc, sched); \
     } while (0)
     if (kind == LILI_KIND_SURF) {
         if (P.variant == LILI_VARIANT_LIVOX && !m.has_aux) return ctx->fail(LILI_E_STATE, "associate: Livox variant needs reflectivity (aux_offset) on the surf map");

@@ -46,7 +46,9 @@ struct MapIndex {
 struct KindSlot {
     int64_t n_q = 0;
     bool has_queries = false, has_records = false;
-    DevBuf q, rec0, rec1, valid, dbg_idx, dbg_d2, partials, perm, keys, block_counts, tiles, nn_cache;
+    DevBuf q, rec0, rec1, valid, dbg_idx, dbg_d2, partials, perm, keys, block_counts, tiles, nn_cache, order, block_cost;
+    int launches = 0;        // association launches since set_queries (the dispatch order is rebuilt before launches 2 and 4)
+    bool order_valid = false;
     bool nn_cache_valid = false;   // nn_cache holds the neighbours of the last association of THIS scan against the CURRENT map index
     int n_assoc_blocks = 0;  // grid of the last association launch (= number of per-block counts)
     int n_tiles = 0;       // association grid when binned (tiles never span two super-cells)
@@ -92,6 +94,8 @@ struct lili_ctx {
     bool fuse_tail = false;      // reduce + GN as the tail of the last linearisation launch (slower than a separate launch; A/B only)
     bool nn_cache = false;       // seed each query's search bound with its previous 5 neighbours (exact for any pose change)
     int cell_pct = 65;           // reach 2: cell edge in % of 1.01 * gate radius (>= 50)
+    bool balance = false;        // cost-ordered dispatch of the association workgroups (AssocSched): measured, no gain — A/B only
+    int n_simd = 0;              // SIMDs of the device (CUs x 4)
     void* ext_rot = nullptr;                 // extractor state (lili_extract_rot.hip), freed through ext_rot_free
     void (*ext_rot_free)(void*) = nullptr;
     void* ext_livox = nullptr;

@@ -213,7 +213,7 @@ __device__ __forceinline__ void lstsq53(col5 c0, col5 c1, col5 c2, col5 b, doubl
 // (error <= eps / 1e-7), far below the f32 rounding of the stored record.
 // ------------------------------------------------------------------------------------------------
 template <bool WEIGHTED>
-__device__ __forceinline__ bool plane_fit_centered(const double x[5], const double y[5], const double z[5], const double w2[5], double n[3]) {
+__device__ __forceinline__ bool plane_fit_centered(const double x[5], const double y[5], const double z[5], const double w2[5], double n[3], double tol = 1e-7) {
     double W, cx, cy, cz;
     if (WEIGHTED) {
         W = ((w2[0] + w2[1]) + (w2[2] + w2[3])) + w2[4];
@@ -247,7 +247,7 @@ __device__ __forceinline__ bool plane_fit_centered(const double x[5], const doub
     const double tr = sxx + syy + szz;
     const double denom = fma(W, cu, det);
     const double scale = tr * tr * fma(W, c2, tr);
-    if (!(denom > 1e-7 * scale)) return false;          // also catches NaN / inf inputs
+    if (!(denom > tol * scale)) return false;          // also catches NaN / inf inputs
     const double f = -W / denom;
     n[0] = f * ux; n[1] = f * uy; n[2] = f * uz;
     return true;

@@ -230,6 +230,7 @@ __global__ void k_tile_fill(const int* __restrict__ counts, const int* __restric
 struct Top5 {
     float d[5];
     int j[5];     // position in the cell-sorted array
+    int aux;      // profiling only: chunks of four candidates this query went through
 };
 // FLANN L2_Simple on 3 floats (f32, x then y then z, no FMA)
 __device__ __forceinline__ float dist2(float4 p, float qx, float qy, float qz) {
@@ -406,6 +407,7 @@ struct Sel5K {
         }
 #pragma unroll
         for (int s = 0; s < 5; s++) { t.d[s] = __uint_as_float((unsigned)(e[s] >> 32)); t.j[s] = jr[s]; }
+        t.aux = tc;
         return redo;
     }
 };
@@ -592,8 +594,10 @@ __device__ __forceinline__ bool knn5_grid_sel(const GridView& g, TAB& tab, float
 // Fast selection first; the rare queries with an exact distance tie that could matter are repeated with the exact
 // (distance, original index) selector, so the result is always the oracle's.
 template <class TAB>
-__device__ __forceinline__ void knn5_grid(const GridView& g, TAB& tab, float qx, float qy, float qz, float bound, Top5& best) {
-    if (knn5_grid_sel<Sel5K>(g, tab, qx, qy, qz, bound, best)) knn5_grid_sel<Sel5>(g, tab, qx, qy, qz, bound, best);
+__device__ __forceinline__ void knn5_grid(const GridView& g, TAB& tab, float qx, float qy, float qz, float bound, Top5& best, int dbg = 0) {
+    if (dbg & 32768) { knn5_grid_sel<Sel5>(g, tab, qx, qy, qz, bound, best); return; }   // A/B: exact selector only
+    const bool redo = knn5_grid_sel<Sel5K>(g, tab, qx, qy, qz, bound, best);
+    if (redo && !(dbg & 8192)) knn5_grid_sel<Sel5>(g, tab, qx, qy, qz, bound, best);   // bit 8192: profiling only (results then inexact on ties)
 }
 
 // Correspondence counting without atomics on a shared word (3128 same-address atomics cost ~40 us on
@@ -729,13 +733,13 @@ __device__ __forceinline__ bool surf_fit(const GridView& g, const MatchParams& P
     }
     double nv[3];
     bool fitted = false;
-    if (!(P.debug & 512)) {   // LILI_DEBUG bit 512: always take the pivoted QR (A/B and parity of the two paths)
+    if (!(P.debug & 16384)) {   // LILI_DEBUG bit 16384: always take the pivoted QR (A/B and parity of the two paths)
         if (P.variant == 0) {
             double w2[5];
 #pragma unroll
             for (int k = 0; k < 5; k++) w2[k] = wk[k] * wk[k];
-            fitted = plane_fit_centered<true>(mx, my, mz, w2, nv);
-        } else fitted = plane_fit_centered<false>(mx, my, mz, wk, nv);
+            fitted = plane_fit_centered<true>(mx, my, mz, w2, nv, (P.debug & 2048) ? 0.0 : 1e-7);
+        } else fitted = plane_fit_centered<false>(mx, my, mz, wk, nv, (P.debug & 2048) ? 0.0 : 1e-7);
     }
     if (!fitted) {            // ill-conditioned or rank-deficient: Eigen's rank-revealing procedure (rare, wave-divergent)
         col5 c0, c1, c2, b;
@@ -961,10 +965,12 @@ template <bool TILED, int BS>
 __global__ __launch_bounds__(BS) void k_associate_surf(
         const float4* __restrict__ queries, const int* __restrict__ perm, const int2* __restrict__ tiles, int n_q, GridView g, PoseArg pa, MatchParams P,
         float4* __restrict__ rec_nd, double* __restrict__ rec_score, unsigned char* __restrict__ valid,
-        int* __restrict__ dbg_idx, float* __restrict__ dbg_d2, int* __restrict__ block_counts, int* __restrict__ nn_cache) {
+        int* __restrict__ dbg_idx, float* __restrict__ dbg_d2, int* __restrict__ block_counts, int* __restrict__ nn_cache, AssocSched sched) {
     __shared__ TileLds L;
     __shared__ RowTabT<BS> tab;
-    const int2 tile = tiles ? tiles[blockIdx.x] : make_int2(blockIdx.x * BS, min(BS, n_q - (int)blockIdx.x * BS));
+    const long long t_begin = (P.debug & 4096) ? (long long)__builtin_amdgcn_s_memrealtime() : 0ll;   // profiling aid (tools/assoc_blocks.py)
+    const int bid = sched.order ? sched.order[blockIdx.x] : (int)blockIdx.x;
+    const int2 tile = tiles ? tiles[bid] : make_int2(bid * BS, min(BS, n_q - bid * BS));
     const bool live = (int)threadIdx.x < tile.y;
     int t = tile.x + threadIdx.x;
     int i = live ? (perm ? perm[t] : t) : 0;
@@ -973,12 +979,18 @@ __global__ __launch_bounds__(BS) void k_associate_surf(
     load_assoc_pose(pa, P, Q2, T2);
     d3 pmd = qrot(Q2, d3{(double)ql.x, (double)ql.y, (double)ql.z}) + T2;   // transformPoint, L:695-711
     float px = (float)pmd.x, py = (float)pmd.y, pz = (float)pmd.z;
-    Top5 nn;
+    Top5 nn; nn.aux = 0;
     if (P.debug & 2) {
 #pragma unroll
         for (int k = 0; k < 5; k++) { nn.d[k] = 0.01f * (k + 1); nn.j[k] = (i * 7 + k) % g.n_points; }
     } else if (TILED) knn5_tiled(g, L, tab, live, px, py, pz, nn, P.debug);
-    else if (live) { knn5_grid(g, tab, px, py, pz, seeded_bound(g, P.kd_max_radius, nn_cache, n_q, i, px, py, pz), nn); store_nn_cache(nn_cache, n_q, i, nn); }
+    else if (live) { knn5_grid(g, tab, px, py, pz, seeded_bound(g, P.kd_max_radius, nn_cache, n_q, i, px, py, pz), nn, P.debug); store_nn_cache(nn_cache, n_q, i, nn); }
+    if (BS == 64 && !TILED && sched.block_cost) {   // cost of this block for the next launch's dispatch order
+        int c = live ? nn.aux : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c = max(c, __shfl_xor(c, o));
+        if (threadIdx.x == 0) sched.block_cost[bid] = c;
+    }
     bool ok = false;
     if (live) {
         store_debug_nn(g, nn, i, dbg_idx, dbg_d2);
@@ -989,16 +1001,26 @@ __global__ __launch_bounds__(BS) void k_associate_surf(
         valid[i] = ok ? 1 : 0;
     }
     store_block_count<BS>(ok, block_counts);
+    if ((P.debug & 4096) && dbg_idx && threadIdx.x == 0) {   // per-workgroup begin / end ticks (100 MHz) and hardware id into the debug rows of the block's first query
+        long long* o = (long long*)(dbg_idx + (size_t)tile.x * 5);
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        o[0] = t_begin; o[1] = (long long)__builtin_amdgcn_s_memrealtime();
+        dbg_idx[(size_t)tile.x * 5 + 4] = (int)((hw & 0xffffu) | (xcc << 16));
+    }
+    if ((P.debug & 4096) && dbg_idx && live && threadIdx.x != 0) dbg_idx[(size_t)i * 5] = nn.aux;
 }
 
 template <bool TILED, int BS>
 __global__ __launch_bounds__(BS) void k_associate_edge(
         const float4* __restrict__ queries, const int* __restrict__ perm, const int2* __restrict__ tiles, int n_q, GridView g, PoseArg pa, MatchParams P,
         float4* __restrict__ rec_a, float4* __restrict__ rec_b, unsigned char* __restrict__ valid,
-        int* __restrict__ dbg_idx, float* __restrict__ dbg_d2, int* __restrict__ block_counts, int* __restrict__ nn_cache) {
+        int* __restrict__ dbg_idx, float* __restrict__ dbg_d2, int* __restrict__ block_counts, int* __restrict__ nn_cache, AssocSched sched) {
     __shared__ TileLds L;
     __shared__ RowTabT<BS> tab;
-    const int2 tile = tiles ? tiles[blockIdx.x] : make_int2(blockIdx.x * BS, min(BS, n_q - (int)blockIdx.x * BS));
+    const int bid = sched.order ? sched.order[blockIdx.x] : (int)blockIdx.x;
+    const int2 tile = tiles ? tiles[bid] : make_int2(bid * BS, min(BS, n_q - bid * BS));
     const bool live = (int)threadIdx.x < tile.y;
     int t = tile.x + threadIdx.x;
     int i = live ? (perm ? perm[t] : t) : 0;
@@ -1019,14 +1041,55 @@ __global__ __launch_bounds__(BS) void k_associate_edge(
     }
     store_block_count<BS>(ok, block_counts);
 }
-#define LILI_ASSOC_ARGS_SURF const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, int*, int*
-#define LILI_ASSOC_ARGS_EDGE const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, int*, int*
+#define LILI_ASSOC_ARGS_SURF const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, int*, int*, AssocSched
+#define LILI_ASSOC_ARGS_EDGE const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, int*, int*, AssocSched
 template __global__ void k_associate_surf<true, kBlock>(LILI_ASSOC_ARGS_SURF);
 template __global__ void k_associate_surf<false, kBlock>(LILI_ASSOC_ARGS_SURF);
 template __global__ void k_associate_surf<false, kAssocBlock>(LILI_ASSOC_ARGS_SURF);
 template __global__ void k_associate_edge<true, kBlock>(LILI_ASSOC_ARGS_EDGE);
 template __global__ void k_associate_edge<false, kBlock>(LILI_ASSOC_ARGS_EDGE);
 template __global__ void k_associate_edge<false, kAssocBlock>(LILI_ASSOC_ARGS_EDGE);
+
+// Dispatch order for the next association launch of the same scan (see AssocSched).  One workgroup: bitonic sort of
+// (cost descending, block index) keys in LDS, then the assignment
+//   * the r = n mod S SIMDs that receive one wave more than the others (slots s, S+s, ... with s < r) take the (q+1) r
+//     LIGHTEST blocks (q = n / S),
+//   * the other S - r SIMDs take q blocks each from the rest in snake order (heaviest with lightest).
+// n <= kMaxOrderBlocks.  Cost model: a block's work ~ kCostBase + its chunk count (skeleton + fit + chunks).
+constexpr int kMaxOrderBlocks = 8192;
+__global__ __launch_bounds__(1024) void k_block_order(const int* __restrict__ block_cost, int n, int S, int* __restrict__ order) {
+    __shared__ unsigned key[kMaxOrderBlocks];
+    int np2 = 1; while (np2 < n) np2 <<= 1;
+    for (int i = threadIdx.x; i < np2; i += blockDim.x)
+        key[i] = i < n ? ((unsigned)(255 - min(max(block_cost[i], 0), 255)) << 16) | (unsigned)i : 0xffffffffu;
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < np2; i += blockDim.x) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned a = key[i], b = key[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { key[i] = b; key[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    const int q = n / S, r = n % S;
+    const int nl = (q + 1) * r, nh = n - nl;          // light blocks: ranks nh .. n-1 of the descending order
+    for (int rank = threadIdx.x; rank < n; rank += blockDim.x) {
+        const int blk = (int)(key[rank] & 0xffffu);
+        int slot;
+        if (rank >= nh) { const int t = rank - nh; slot = (t / r) * S + (t % r); }
+        else {
+            const int w = S - r, tier = rank / w;
+            int pos = rank % w;
+            if (tier & 1) pos = w - 1 - pos;
+            slot = tier * S + r + pos;
+        }
+        order[slot] = blk;
+    }
+}
 
 // ================================================================================================
 // Linearisation: residual + 1x7 global Jacobian per record, loss corrector, Gram reduction.

@@ -446,3 +446,40 @@ def test_tuning_options_do_not_change_results(gpu_ctx, oracle, opt):
     else:                         # fuse_tail uses 1024-thread linearisation blocks: another (fixed) summation order
         assert np.abs(a[0] - b[0]).max() < 1e-12 and np.abs(a[1] - b[1]).max() < 1e-12
         assert np.abs(a[5] - b[5]).max() <= 1e-12 * np.abs(a[5]).max() and np.array_equal(a[6], b[6])
+
+
+def test_fast_tiers_equal_exact_tiers(gpu_ctx, oracle):
+    """The default association uses two fast tiers with exact fall-backs — the 32-bit key selector (Sel5K) and the centred
+    normal-equation plane fit.  Forcing the slow tiers (LILI_DEBUG 32768: exact (d2, index) selector; 16384: pivoted
+    Householder QR) must give the same neighbours bit for bit and the same records to the f32 rounding of the fit."""
+    import os
+    room = synth.make_room(seed=21, n_query=8000, n_edge_query=300)
+    variant = "livox"
+    P, PO, m = _setup(gpu_ctx, oracle, variant, room, with_refl=True)
+    t, q, Q2, T2 = _pose(room, P, variant, np.random.default_rng(4), 0.05, 0.5)
+    nq = room["q_xyz"].shape[0]
+    out = {}
+    old = os.environ.get("LILI_DEBUG")
+    try:
+        for name, bits in (("fast", 0), ("exact_sel", 32768), ("qr", 16384)):
+            os.environ["LILI_DEBUG"] = str(bits)
+            n = m.find_corresponding_surf_features(0, Q2, T2)
+            idx, d2 = m.neighbors(0, L.KIND_SURF, nq)
+            out[name] = (n, idx.copy(), d2.copy(), m.surf_records(0, nq))
+    finally:
+        if old is None:
+            os.environ.pop("LILI_DEBUG", None)
+        else:
+            os.environ["LILI_DEBUG"] = old
+    n0, i0, d0, r0 = out["fast"]
+    assert n0 > 3000
+    inside = d0[:, 4] < P.kd_max_radius
+    n1, i1, d1, r1 = out["exact_sel"]
+    assert n1 == n0 and np.array_equal(i0[inside], i1[inside]) and np.array_equal(d0[inside].view(np.uint32), d1[inside].view(np.uint32))
+    assert np.array_equal(r0["query_index"], r1["query_index"]) and np.array_equal(r0["n"], r1["n"]) and np.array_equal(r0["score"], r1["score"])
+    n2, i2, d2_, r2 = out["qr"]
+    assert n2 == n0 and np.array_equal(r0["query_index"], r2["query_index"])
+    np.testing.assert_allclose(r0["n"], r2["n"], rtol=2e-7, atol=1e-9)
+    np.testing.assert_allclose(r0["d"], r2["d"], rtol=2e-7, atol=1e-9)
+    np.testing.assert_allclose(r0["score"], r2["score"], rtol=2e-7)
+    assert (r0["n"].view(np.uint32) == r2["n"].view(np.uint32)).mean() > 0.99       # almost always the same f32
