@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--split-path", action="store_true", help="use the multi-GPU code path (export/import counts, separate GN kernel) even at N=1")
     ap.add_argument("--bin", action="store_true", help="enable the once-per-scan query binning (A/B only)")
+    ap.add_argument("--opt", action="append", default=[], help="A/B: lili_set_option name=value (repeatable), e.g. --opt warm=0")
     ap.add_argument("--reach", type=int, default=0, help="map grid reach (1 = cells of the gate radius, 2 = half-size cells); 0 = library default")
     ap.add_argument("--cell-pct", type=int, default=0, help="reach-2 cell edge in %% of the gate radius (50..100); 0 = library default")
     ap.add_argument("--no-nn-cache", action="store_true", help="A/B: do not seed the search bound with the previous neighbours")
@@ -159,6 +160,9 @@ def main():
         ctx.set_option("cell_pct", args.cell_pct)
     if args.no_nn_cache:
         ctx.set_option("nn_cache", 0)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
     if args.bin or args.tile:
         ctx.set_option("bin_queries", 1)
     if args.tile:

@@ -277,56 +277,11 @@ struct Sel5 {
     }
 };
 
-// Fast selector: the five distances are kept sorted with min / med3 (slot s' = median(slot s-1, slot s, candidate)),
-// the payload is the position in the cell-sorted array only, moved by rank.  Candidates of EQUAL distance are ordered by
-// arrival here, not by original index, so every situation in which that could change the result raises `tie`:
-//  * a candidate that is rejected or an entry that is pushed out with exactly the distance of the (new) 5th best, and
-//  * two equal distances in the final list (checked by the caller);
-// the caller then repeats the query with the exact selector (Sel5).  Proof sketch: a wrongly excluded candidate Y ties
-// with the final 5th-best distance w; when Y left, the then-5th-best W had w <= W.d <= Y.d = w.  Sentinels carry five
-// DISTINCT values just above the bound so that they never tie with each other.
 __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {   // no clang builtin for the integer median
     unsigned r;
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-struct Sel5F {
-    unsigned d[5];   // bit patterns of the non-negative f32 distances: unsigned order == float order, NaN sorts above +inf,
-    int j[5];        // and integer min / max / med3 need no NaN canonicalisation (v_max x,x) around them
-    unsigned long long tie_mask;   // one bit per lane, kept in scalar registers (v_cmp -> s_or, no VALU bookkeeping)
-    __device__ __forceinline__ void init(float bound) {
-        const unsigned b = min(__float_as_uint(bound), __float_as_uint(3.0e38f));
-#pragma unroll
-        for (int s = 0; s < 5; s++) { d[s] = b + (unsigned)s; j[s] = -1; }
-        tie_mask = 0ull;
-    }
-    __device__ __forceinline__ void insert(float dcf, float4, int jc) {
-        const unsigned dc = __float_as_uint(dcf);
-        const bool c0 = dc < d[0], c1 = dc < d[1], c2 = dc < d[2], c3 = dc < d[3], c4 = dc < d[4];
-        const unsigned popped = max(d[4], dc);
-        int n4 = c4 ? jc : j[4]; n4 = c3 ? j[3] : n4;      // two straight-line selects per slot (no nested control flow)
-        int n3 = c3 ? jc : j[3]; n3 = c2 ? j[2] : n3;
-        int n2 = c2 ? jc : j[2]; n2 = c1 ? j[1] : n2;
-        int n1 = c1 ? jc : j[1]; n1 = c0 ? j[0] : n1;
-        const int n0 = c0 ? jc : j[0];
-        j[0] = n0; j[1] = n1; j[2] = n2; j[3] = n3; j[4] = n4;
-        const unsigned m4 = umed3(d[3], d[4], dc), m3 = umed3(d[2], d[3], dc);
-        const unsigned m2 = umed3(d[1], d[2], dc), m1 = umed3(d[0], d[1], dc);
-        d[0] = min(d[0], dc); d[1] = m1; d[2] = m2; d[3] = m3; d[4] = m4;
-        tie_mask |= __ballot(popped == m4);
-    }
-    __device__ __forceinline__ float worst() const { return __uint_as_float(d[4]); }
-    __device__ __forceinline__ unsigned worst_bits() const { return d[4]; }
-    __device__ __forceinline__ bool final_tie() const {
-        const bool tie = (tie_mask >> (threadIdx.x & 63)) & 1ull;
-        return tie || d[0] == d[1] || d[1] == d[2] || d[2] == d[3] || d[3] == d[4];
-    }
-    __device__ __forceinline__ void to_top5(Top5& t) const {
-#pragma unroll
-        for (int s = 0; s < 5; s++) { t.d[s] = __uint_as_float(d[s]); t.j[s] = j[s]; }
-    }
-};
-
 // Key selector (default fast tier): ONE 32-bit key per candidate and no payload moves.
 //   key = (distance bits & ~63) | code        code = ((chunk & 7) << 2) | slot-in-chunk      (a "bucket" = 64 f32 ulps of d^2)
 // The SIX smallest keys are kept sorted with five v_med3_u32 and one v_min_u32 per candidate — no comparisons, no selects,
