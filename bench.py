@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--window", type=int, default=0, help="extra measurement (not the headline): K independent registrations of the same "
                     "scan in K slots advanced concurrently with lili_s2m_iterate_window; prints window iterations/s and exits")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-native-rccl", action="store_true", help="A/B: keep the two all-reduces in the Python loop (torch.distributed)")
     ap.add_argument("--split-path", action="store_true", help="use the multi-GPU code path (export/import counts, separate GN kernel) even at N=1")
     ap.add_argument("--bin", action="store_true", help="enable the once-per-scan query binning (A/B only)")
     ap.add_argument("--opt", action="append", default=[], help="A/B: lili_set_option name=value (repeatable), e.g. --opt warm=0")
@@ -247,10 +248,42 @@ def main():
             dist.all_reduce(gram)
         m.gn_update(0, gram.data_ptr())
 
+    # Native collectives: lili_s2m_iterate_sharded enqueues the two RCCL all-reduces from C between the kernels (no host code on
+    # the critical path).  The communicator is created next to torch's; it is used only if EVERY rank created it and the native
+    # loop reproduces the torch.distributed iteration from the same pose — otherwise the Python loop above stays.
+    native = None
+    if dist is not None and not args.no_native_rccl:
+        comm = None
+        try:
+            from lili_om_amd import rccl
+            comm = rccl.Communicator(rank, world)
+        except Exception as e:          # noqa: BLE001
+            log(f"[bench] rank {rank}: native RCCL communicator unavailable ({e!r})")
+        flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            m.pose_copy(0, 1); step_multi(); torch.cuda.synchronize()
+            ta, qa, _ = m.pose_get(0)
+            m.pose_copy(0, 1)
+            m.iterate_sharded(0, 1, counts.data_ptr(), gram.data_ptr(), comm.allreduce_fn, comm.handle)
+            torch.cuda.synchronize()
+            tb, qb, _ = m.pose_get(0)
+            same = bool(np.abs(ta - tb).max() <= 1e-12 and np.abs(qa - qb).max() <= 1e-12)
+            flag = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                native = comm
+            elif rank == 0:
+                log("[bench] native RCCL loop did not reproduce the torch.distributed iteration: staying on the Python loop")
+    if rank == 0 and dist is not None:
+        log(f"[bench] collectives: {'RCCL enqueued from C (lili_s2m_iterate_sharded)' if native else 'torch.distributed from the Python loop'}")
+
     def run_steps(k):
         # every `ips` steps a new registration starts from the initial guess (async device-to-device pose copy)
         if world == 1 and not args.split_path and dist is None:
             m.iterate_restart(0, k, ips, 1, L.MASK_SURF)   # one C call enqueues k x (associate, linearise, reduce+GN update)
+        elif native is not None:
+            m.iterate_sharded(0, k, counts.data_ptr(), gram.data_ptr(), native.allreduce_fn, native.handle, restart_every=ips, restart_slot=1)
         else:
             for i in range(k):
                 if i % ips == 0:
@@ -331,6 +364,7 @@ def main():
                                    f"{'queries block-sharded over ranks' if args.scaling == 'strong' else 'one 200k-pt shard per rank'}",
                        "queries_per_rank": int(queries.shape[0]), "map_points": int(w["map_xyz"].shape[0]),
                        "parallelism": f"queries sharded x{world}, map replicated, all-reduce(counts, Gram)" if world > 1 else "single GPU",
+                       "collectives": ("rccl enqueued from C (lili_s2m_iterate_sharded)" if native is not None else "torch.distributed in the Python loop") if dist is not None else "none",
                        "map_index_build_s": round(t_map, 4)},
             "roofline": roofline,
             "final_pose": {"t": [float(x) for x in t_fin], "q": [float(x) for x in q_fin], "gn_status": int(gn_status)},

@@ -250,6 +250,21 @@ int lili_s2m_linearize_dev(lili_ctx* ctx, int slot, int kind_mask, const lili_s2
 /* Second half (async): one Gauss-Newton step on the 6-dof local parameterisation
  * (ceres::QuaternionParameterization plus-Jacobian and Plus()), pose updated in device memory. */
 int lili_s2m_gn_update(lili_ctx* ctx, int slot, const double* d_gram);
+
+/* The sharded iteration loop in ONE host call (queries block-sharded over the GPUs of a node, map replicated):
+ * n_iters x [ associate_dev -> (count-scaled flavours only: counts_export -> all-reduce(int32[2]) -> counts_import) ->
+ *             linearize_dev(d_gram) -> all-reduce(f64[LILI_GRAM_DOUBLES]) -> gn_update ]
+ * everything enqueued on the context's stream, so that no host code sits between the kernels and the two collectives.
+ * `allreduce` has the signature of ncclAllReduce (RCCL: sendbuff, recvbuff, count, ncclDataType_t, ncclRedOp_t, ncclComm_t,
+ * hipStream_t) and is called in place with datatype 2 (ncclInt32) / 8 (ncclFloat64) and op 0 (ncclSum); the library does not
+ * link RCCL — the caller hands over the function and its communicator (lili_om_amd/rccl.py does it with the librccl.so that
+ * PyTorch loaded).  allreduce == NULL runs the same staged launches without collectives (one rank).  restart_every /
+ * restart_slot as in lili_s2m_iterate_restart.  d_counts: DEVICE int32[2], d_gram: DEVICE double[LILI_GRAM_DOUBLES],
+ * both caller-owned and valid until the stream has drained.  Every rank then holds the same pose (same reduced Gram, same
+ * GN step), no broadcast is needed. */
+typedef int (*lili_allreduce_fn)(const void* sendbuff, void* recvbuff, size_t count, int datatype, int op, void* comm, void* stream);
+int lili_s2m_iterate_sharded(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, int n_iters, int restart_every,
+                             int restart_slot, lili_allreduce_fn allreduce, void* comm, int32_t* d_counts, double* d_gram);
 /* Convenience: n_iters x (accumulate + gn_update) on an internal buffer.  Async. */
 int lili_s2m_iterate(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, int n_iters);
 

@@ -125,6 +125,7 @@ _SIGS = {
     "lili_s2m_debug_times": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_longlong)]),
     "lili_s2m_pose_copy": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "lili_s2m_iterate_restart": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "lili_s2m_iterate_sharded": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lili_livox_custom_to_cloud": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_int]),
     "lili_imu_reset": (None, [C.c_void_p]),
     "lili_imu_integrate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_void_p]),
@@ -334,6 +335,14 @@ class ScanToMapMatcher:
 
     def gn_update(self, slot, d_gram_ptr):
         self.ctx._chk(self.lib.lili_s2m_gn_update(self.ctx.h, slot, C.c_void_p(d_gram_ptr)))
+
+    def iterate_sharded(self, slot, n_iters, d_counts_ptr, d_gram_ptr, allreduce_fn=None, comm=None, restart_every=0, restart_slot=1,
+                        kind_mask=MASK_SURF):
+        """n_iters staged iterations with the two collectives enqueued from C (lili_s2m_iterate_sharded).  allreduce_fn: address
+        of an ncclAllReduce-compatible function (int), comm: its communicator handle (int); None = single rank."""
+        self.ctx._chk(self.lib.lili_s2m_iterate_sharded(self.ctx.h, slot, kind_mask, C.byref(self.params), int(n_iters), int(restart_every),
+                                                        int(restart_slot), C.c_void_p(allreduce_fn), C.c_void_p(comm),
+                                                        C.c_void_p(d_counts_ptr), C.c_void_p(d_gram_ptr)))
 
     def iterate_window(self, slots, n_iters, kind_mask=MASK_SURF):
         arr = (C.c_int * len(slots))(*[int(s) for s in slots])

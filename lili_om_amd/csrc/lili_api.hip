@@ -733,6 +733,30 @@ static int iterate_impl(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_p
     return LILI_OK;
 }
 
+int lili_s2m_iterate_sharded(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, int n_iters, int restart_every,
+                             int restart_slot, lili_allreduce_fn allreduce, void* comm, int32_t* d_counts, double* d_gram) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(n_iters >= 0 && params && d_counts && d_gram, "iterate_sharded: bad argument");
+    ARGCHK(restart_every >= 0 && (restart_every == 0 || (restart_slot >= 0 && restart_slot < LILI_MAX_SLOTS && restart_slot != slot)), "iterate_sharded: bad restart arguments");
+    const bool count_scaled = params->scale_surf_num > 0 || params->scale_edge_num > 0;   // ROT: residual scale = num / GLOBAL count
+    for (int it = 0; it < n_iters; it++) {
+        int rc;
+        if (restart_every > 0 && it % restart_every == 0 && (rc = lili_s2m_pose_copy(ctx, slot, restart_slot)) != LILI_OK) return rc;
+        if ((rc = lili_s2m_associate_dev(ctx, slot, kind_mask, params)) != LILI_OK) return rc;
+        if (count_scaled) {
+            if ((rc = lili_s2m_counts_export(ctx, slot, d_counts)) != LILI_OK) return rc;
+            if (allreduce && allreduce(d_counts, d_counts, 2, /*ncclInt32*/ 2, /*ncclSum*/ 0, comm, (void*)ctx->stream) != 0)
+                return ctx->fail(LILI_E_HIP, "iterate_sharded: all-reduce of the correspondence counts failed");
+            if ((rc = lili_s2m_counts_import(ctx, slot, d_counts)) != LILI_OK) return rc;
+        }
+        if ((rc = lili_s2m_linearize_dev(ctx, slot, kind_mask, params, d_gram)) != LILI_OK) return rc;
+        if (allreduce && allreduce(d_gram, d_gram, LILI_GRAM_DOUBLES, /*ncclFloat64*/ 8, /*ncclSum*/ 0, comm, (void*)ctx->stream) != 0)
+            return ctx->fail(LILI_E_HIP, "iterate_sharded: all-reduce of the Gram record failed");
+        if ((rc = lili_s2m_gn_update(ctx, slot, d_gram)) != LILI_OK) return rc;
+    }
+    return LILI_OK;
+}
+
 // Several independent registrations (the keyframes of one sliding window, L/src/BackendFusion.cpp:843-1007 loops over
 // them per outer iteration; or several sensors) advanced concurrently: slot i runs its own associate / linearise /
 // reduce+GN chain on its own stream, forked from and joined to the context's stream with events.  The association

@@ -483,3 +483,72 @@ def test_fast_tiers_equal_exact_tiers(gpu_ctx, oracle):
     np.testing.assert_allclose(r0["d"], r2["d"], rtol=2e-7, atol=1e-9)
     np.testing.assert_allclose(r0["score"], r2["score"], rtol=2e-7)
     assert (r0["n"].view(np.uint32) == r2["n"].view(np.uint32)).mean() > 0.99       # almost always the same f32
+
+
+def test_sharded_loop_equals_fused_iterations(gpu_ctx, oracle):
+    """lili_s2m_iterate_sharded (the multi-GPU loop with the collectives enqueued from C) on ONE rank — without collectives and
+    with a host callback standing in for ncclAllReduce — gives the pose of the fused single-GPU iterations bit for bit."""
+    import ctypes as C
+    import torch
+    room = synth.make_room(seed=14, n_query=6000, n_edge_query=300)
+    variant = "rot"
+    P, PO, m = _setup(gpu_ctx, oracle, variant, room, with_refl=False)
+    t, q, Q2, T2 = _pose(room, P, variant, np.random.default_rng(9), 0.05, 0.6)
+    m.pose_set(1, t, q)
+    m.pose_copy(0, 1)
+    m.iterate(0, 4, L.MASK_SURF)
+    t_ref, q_ref, st = m.pose_get(0)
+    assert st == 0 and np.abs(t_ref - t).max() > 1e-4
+    counts = torch.zeros(2, dtype=torch.int32, device="cuda")
+    gram = torch.zeros(L.api.GRAM_DOUBLES, dtype=torch.float64, device="cuda")
+    calls = []
+    CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p)
+
+    def fake_allreduce(send, recv, count, dtype, op, comm, stream):     # one rank: the sum is the buffer itself
+        calls.append((count, dtype, op, send == recv))
+        return 0
+
+    cb = CB(fake_allreduce)
+    for fn in (None, C.cast(cb, C.c_void_p).value):
+        m.pose_copy(0, 1)
+        m.iterate_sharded(0, 4, counts.data_ptr(), gram.data_ptr(), fn, None)
+        gpu_ctx.sync()
+        t2, q2, st = m.pose_get(0)
+        assert st == 0 and np.array_equal(t2, t_ref) and np.array_equal(q2, q_ref)
+    assert calls == [(2, 2, 0, True), (L.api.GRAM_DOUBLES, 8, 0, True)] * 4          # ncclInt32 counts, ncclFloat64 Gram, ncclSum, in place
+    m.pose_copy(0, 1)
+    m.iterate_sharded(0, 8, counts.data_ptr(), gram.data_ptr(), None, None, restart_every=4, restart_slot=1)
+    gpu_ctx.sync()
+    t3, q3, _ = m.pose_get(0)
+    assert np.array_equal(t3, t_ref) and np.array_equal(q3, q_ref)                      # two registrations of four iterations
+
+
+def test_native_rccl_communicator_single_rank(gpu_ctx, oracle):
+    """lili_om_amd/rccl.py: a one-rank RCCL communicator next to PyTorch's runtime; the sharded loop with the real ncclAllReduce
+    enqueued from C reproduces the fused iterations (a sum over one rank is the identity)."""
+    import torch
+    from lili_om_amd import rccl
+    comm = rccl.Communicator(0, 1)
+    try:
+        x = torch.arange(8, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        comm.all_reduce(x.data_ptr(), 8, rccl.ncclFloat64, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert x.tolist() == list(range(8))
+        room = synth.make_room(seed=15, n_query=4000, n_edge_query=200)
+        P, PO, m = _setup(gpu_ctx, oracle, "rot", room, with_refl=False)
+        t, q, Q2, T2 = _pose(room, P, "rot", np.random.default_rng(10), 0.05, 0.6)
+        m.pose_set(1, t, q)
+        m.pose_copy(0, 1)
+        m.iterate(0, 3, L.MASK_SURF)
+        t_ref, q_ref, _ = m.pose_get(0)
+        counts = torch.zeros(2, dtype=torch.int32, device="cuda")
+        gram = torch.zeros(L.api.GRAM_DOUBLES, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        m.pose_copy(0, 1)
+        m.iterate_sharded(0, 3, counts.data_ptr(), gram.data_ptr(), comm.allreduce_fn, comm.handle)
+        gpu_ctx.sync()
+        t2, q2, st = m.pose_get(0)
+        assert st == 0 and np.array_equal(t2, t_ref) and np.array_equal(q2, q_ref)
+    finally:
+        comm.close()
