@@ -256,7 +256,7 @@ def main():
         comm = None
         try:
             from lili_om_amd import rccl
-            comm = rccl.Communicator(rank, world)
+            comm = rccl.Communicator(rank, world, device=local_rank)
         except Exception as e:          # noqa: BLE001
             log(f"[bench] rank {rank}: native RCCL communicator unavailable ({e!r})")
         flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)

@@ -3,7 +3,7 @@ are enqueued by lili_s2m_iterate_sharded from C, directly between the kernels on
 `ncclAllReduce` of the librccl.so this process already has (PyTorch's).  This module only creates the communicator — the
 library itself does not link RCCL.  One process per GPU; the ncclUniqueId travels over the existing torch.distributed group.
 
-    comm = rccl.Communicator(rank, world)        # collective: every rank calls it
+    comm = rccl.Communicator(rank, world, device=local_gpu)        # collective: every rank calls it
     matcher.iterate_sharded(slot, n, counts_ptr, gram_ptr, comm.allreduce_fn, comm.handle, ...)
 """
 import ctypes as C
@@ -31,8 +31,13 @@ def find_library():
 
 
 class Communicator:
-    def __init__(self, rank, world, timeout_s=120.0):
+    def __init__(self, rank, world, device=None, timeout_s=120.0):
+        """device: HIP device ordinal of this rank (default: torch's current device).  The communicator is created in a helper
+        thread (so that a stuck bootstrap cannot hang the caller); the HIP current device is per thread, hence set there too."""
+        import torch
         import torch.distributed as dist
+        if device is None:
+            device = torch.cuda.current_device()
         self.lib = C.CDLL(find_library())
         L = self.lib
         L.ncclGetUniqueId.restype = C.c_int
@@ -44,18 +49,19 @@ class Communicator:
         L.ncclAllReduce.restype = C.c_int
         L.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         uid = _UniqueId()
-        if rank == 0:
-            rc = L.ncclGetUniqueId(C.byref(uid))
-            if rc != 0:
-                raise RuntimeError(f"ncclGetUniqueId failed ({rc})")
-        box = [bytes(uid.internal) if rank == 0 else None]
+        box = [None]
+        if rank == 0 and L.ncclGetUniqueId(C.byref(uid)) == 0:
+            box = [bytes(uid.internal)]
         if world > 1:
-            dist.broadcast_object_list(box, src=0)
+            dist.broadcast_object_list(box, src=0)      # always reached by every rank, also when rank 0 has no id to offer
+        if box[0] is None:
+            raise RuntimeError("ncclGetUniqueId failed on rank 0")
         C.memmove(C.byref(uid), box[0], NCCL_UNIQUE_ID_BYTES)
         comm = C.c_void_p()
         result = {}
 
         def init():
+            torch.cuda.set_device(device)
             result["rc"] = L.ncclCommInitRank(C.byref(comm), int(world), uid, int(rank))
 
         th = threading.Thread(target=init, daemon=True)
