@@ -375,6 +375,11 @@ def main():
             out["gpu_over_cpu"] = round(value / cb["value"], 1)
         else:
             out["cpu_baseline"] = None
+        try:        # RCCL prints its version banner through C stdio, which is flushed at exit: push it out BEFORE the JSON line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:   # noqa: BLE001
+            pass
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
