@@ -1,0 +1,104 @@
+"""BASELINE configs[2] at FULL size (200 k-point 64-ring scan vs 5 M-point map) through size-independent properties and an
+oracle spot check — the bench workload itself, not a scaled-down scene:
+
+  * self-queries: map points fed back as queries at the identity pose find themselves first (d2 = 0) and the five
+    distances ascend; a random sample agrees with a brute-force scan of all 5 M points (indices and f32 distances, bit-exact);
+  * oracle spot check: the association records of 3 000 random scan points equal the oracle's on the full map;
+  * linearity of the reduction (the property the multi-GPU sharding rests on): Gram(whole scan) = Gram(first half) +
+    Gram(second half) to 1e-12, counts add up;
+  * 10 Gauss-Newton iterations from the 0.3 m / 2 deg perturbed pose return to the generating pose.
+"""
+import numpy as np
+import pytest
+
+import lili_om_amd as L
+from lili_om_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def workload():
+    import bench
+    w = synth.make_workload(n_map=bench.N_MAP, n_az=bench.N_AZ, half_extent=(460.0, 380.0))
+    w["scan"] = bench.ring_major(w["scan_xyz"], w["scan_ring"])
+    assert w["map_xyz"].shape[0] == 5_000_000 and w["scan"].shape[0] == 200_000
+    return w
+
+
+def test_fullsize_self_queries_and_bruteforce(gpu_ctx, workload):
+    P = L.make_params("frontend")
+    m = L.ScanToMapMatcher(gpu_ctx, P)
+    gpu_ctx.set_debug(True)
+    mp = workload["map_xyz"]
+    m.set_input_cloud(L.KIND_SURF, mp)
+    rng = np.random.default_rng(5)
+    pick = np.sort(rng.choice(mp.shape[0], 200_000, replace=False))
+    q = np.ascontiguousarray(mp[pick])
+    m.set_queries(0, L.KIND_SURF, q)
+    m.find_corresponding_surf_features(0, [1.0, 0, 0, 0], [0.0, 0, 0])
+    idx, d2 = m.neighbors(0, L.KIND_SURF, q.shape[0])
+    inside = d2[:, 4] < P.kd_max_radius
+    assert inside.mean() > 0.5
+    assert np.all(d2[inside, 0] == 0.0)                              # every query finds a point at its own position
+    assert np.all(np.diff(d2[inside], axis=1) >= 0)                  # ascending
+    own = idx[inside, 0] == pick[inside]
+    assert own.mean() > 0.999                                        # itself, except exact duplicates with a lower index
+    sample = rng.choice(np.nonzero(inside)[0], 64, replace=False)
+    for s in sample:                                                 # FLANN's L2_Simple in f32 over ALL map points
+        dx = q[s, 0] - mp[:, 0]; dy = q[s, 1] - mp[:, 1]; dz = q[s, 2] - mp[:, 2]
+        dd = (dx * dx + dy * dy) + dz * dz
+        cand = np.argpartition(dd, 8)[:9]
+        order = cand[np.lexsort((cand, dd[cand]))][:5]
+        assert np.array_equal(order, idx[s]), s
+        assert np.array_equal(dd[order].view(np.uint32), d2[s].view(np.uint32)), s
+    gpu_ctx.set_debug(False)
+
+
+def test_fullsize_oracle_spot_check_linearity_and_convergence(gpu_ctx, oracle, workload):
+    import bench
+    variant = "livox"      # no count scaling: Grams of disjoint query sets simply add; reflectivity = a constant column
+    P, PO = L.make_params(variant), oracle.params(variant, reflect_thres=1e30)
+    P.reflect_thres = 1e30
+    mp = workload["map_xyz"]
+    scan = workload["scan"]
+    rng = np.random.default_rng(6)
+    refl_m = rng.uniform(1.0, 25.0, mp.shape[0]).astype(np.float32)
+    refl_q = rng.uniform(1.0, 25.0, scan.shape[0]).astype(np.float32)
+    m = L.ScanToMapMatcher(gpu_ctx, P)
+    m.set_input_cloud(L.KIND_SURF, np.c_[mp, refl_m])
+    t_body, q_body = bench.body_pose_for_lidar(L, P, workload["lidar_t"])
+    t0, q0 = synth.perturbed_pose(t_body, q_body, np.random.default_rng(synth.SEED_POSE), 0.3, 2.0)
+    Q2, T2 = L.api.assoc_transform(t_body, q_body, P)
+    # --- oracle spot check on the full map
+    sel = np.sort(rng.choice(scan.shape[0], 3000, replace=False))
+    m.set_queries(0, L.KIND_SURF, np.c_[scan[sel], refl_q[sel]])
+    n_gpu = m.find_corresponding_surf_features(0, Q2, T2)
+    g = m.surf_records(0, sel.shape[0])
+    rs = oracle.associate_surf(oracle.KdTree(mp), refl_m, np.ascontiguousarray(scan[sel]), np.ascontiguousarray(refl_q[sel]), Q2, T2, PO)
+    v = np.nonzero(rs["valid"])[0]
+    assert n_gpu == rs["count"] > 1500 and np.array_equal(g["query_index"], v)
+    np.testing.assert_allclose(g["n"], rs["n"][v], rtol=3e-7, atol=1e-9)
+    np.testing.assert_allclose(g["d"], rs["d"][v], rtol=3e-7, atol=1e-9)
+    np.testing.assert_allclose(g["score"], rs["score"][v], rtol=3e-7)
+    # --- linearity: whole scan vs its two halves (same pose)
+    half = scan.shape[0] // 2
+    grams, counts = [], []
+    for lo, hi in ((0, scan.shape[0]), (0, half), (half, scan.shape[0])):
+        m.set_queries(0, L.KIND_SURF, np.c_[scan[lo:hi], refl_q[lo:hi]])
+        counts.append(m.find_corresponding_surf_features(0, Q2, T2))
+        G, cost, c = m.linearize(0, t0, q0, L.MASK_SURF)
+        grams.append((G, cost))
+    assert counts[0] == counts[1] + counts[2] and counts[0] > 100_000
+    Gs = grams[1][0] + grams[2][0]
+    assert np.abs(grams[0][0] - Gs).max() <= 1e-12 * np.abs(Gs).max()
+    assert abs(grams[0][1] - (grams[1][1] + grams[2][1])) <= 1e-12 * abs(grams[0][1])
+    # --- convergence of the full-size registration
+    m.set_queries(0, L.KIND_SURF, np.c_[scan, refl_q])
+    m.pose_set(0, t0, q0)
+    m.iterate(0, 10, L.MASK_SURF)
+    t, q, st = m.pose_get(0)
+    assert st == 0
+    assert np.abs(t - t_body).max() < 2e-3, np.abs(t - t_body).max()       # noisy synthetic scan: millimetres, from 0.3 m off
+    dq = synth.quat_mul(q_body * np.array([1, -1, -1, -1]), q / np.linalg.norm(q))
+    assert 2 * np.arcsin(min(1.0, np.linalg.norm(dq[1:]))) < 2e-4
