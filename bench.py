@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--window", type=int, default=0, help="extra measurement (not the headline): K independent registrations of the same "
                     "scan in K slots advanced concurrently with lili_s2m_iterate_window; prints window iterations/s and exits")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (window of 3 slots, ROT extractor)")
     ap.add_argument("--no-native-rccl", action="store_true", help="A/B: keep the two all-reduces in the Python loop (torch.distributed)")
     ap.add_argument("--split-path", action="store_true", help="use the multi-GPU code path (export/import counts, separate GN kernel) even at N=1")
     ap.add_argument("--bin", action="store_true", help="enable the once-per-scan query binning (A/B only)")
@@ -369,6 +370,41 @@ def main():
             "roofline": roofline,
             "final_pose": {"t": [float(x) for x in t_fin], "q": [float(x) for x in q_fin], "gn_status": int(gn_status)},
         }
+        if world == 1 and dist is None and not args.no_extras:
+            # Secondary measurements of the same workload (NOT the headline): the 3-keyframe window of configs[4] advanced
+            # concurrently (lili_s2m_iterate_window), and the ROT feature extractor on the raw 200 k-point scan.
+            extras = {}
+            try:
+                K = 3
+                for k in range(1, K):
+                    m.set_queries(k, L.KIND_SURF, queries)
+                m.pose_set(7, t0, q0)
+
+                def run_window(n):
+                    for _ in range(n // ips):
+                        for k in range(K):
+                            m.pose_copy(k, 7)
+                        m.iterate_window(list(range(K)), ips, L.MASK_SURF)
+                run_window(ips)
+                torch.cuda.synchronize()
+                tw = time.perf_counter()
+                run_window(10 * ips)
+                torch.cuda.synchronize()
+                el = time.perf_counter() - tw
+                extras["window3_slot_iterations_per_s"] = round(K * 10 * ips / el, 1)
+                extras["window3_us_per_window_iteration"] = round(el / (10 * ips) * 1e6, 2)
+                raw = np.concatenate([w["scan_xyz"], np.full((w["scan_xyz"].shape[0], 1), 10.0, np.float32)], 1)
+                ex = L.RotExtractor(ctx, n_scans=64, ds_rate=4)
+                ex.extract(raw)
+                tw = time.perf_counter()
+                for _ in range(20):
+                    r = ex.extract(raw)
+                el = (time.perf_counter() - tw) / 20
+                extras["extract_rot_scans_per_s_incl_h2d_d2h"] = round(1.0 / el, 1)
+                extras["extract_rot_features"] = {"edge": int(len(r["edge"])), "surf": int(len(r["surf"])), "points": int(raw.shape[0])}
+            except Exception as e:      # noqa: BLE001  (secondary numbers must never cost the headline line)
+                extras["error"] = repr(e)
+            out["extras"] = extras
         if world == 1 and not args.no_cpu_baseline:
             cb, t_cpu, q_cpu = cpu_baseline(w, queries, t0, q0, os.cpu_count() or 1)
             out["cpu_baseline"] = cb
