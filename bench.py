@@ -418,6 +418,12 @@ def main():
             pass
         print(json.dumps(out), flush=True)
     if dist is not None:
+        try:
+            torch.cuda.synchronize()
+            if native is not None:
+                native.close()
+        except Exception:   # noqa: BLE001
+            pass
         dist.destroy_process_group()
     ctx.close()
 

@@ -31,7 +31,7 @@ def find_library():
 
 
 class Communicator:
-    def __init__(self, rank, world, device=None, timeout_s=120.0):
+    def __init__(self, rank, world, device=None, timeout_s=60.0):
         """device: HIP device ordinal of this rank (default: torch's current device).  The communicator is created in a helper
         thread (so that a stuck bootstrap cannot hang the caller); the HIP current device is per thread, hence set there too."""
         import torch
