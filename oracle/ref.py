@@ -25,7 +25,7 @@ def build():
 
 
 def available():
-    return all(os.path.exists(os.path.join(REF_DIR, f"libref_{n}.so")) for n in ("rot", "livox", "factors", "lo", "backend_L", "backend_R"))
+    return all(os.path.exists(os.path.join(REF_DIR, f"libref_{n}.so")) for n in ("rot", "livox", "factors", "lo", "backend_L", "backend_R", "format", "marg"))
 
 
 def _lib(name):
@@ -255,3 +255,27 @@ def backend_rows(flavour, surf_rec, edge_rec, qlb, tlb, t, q):
     a = [np.ascontiguousarray(x, np.float64) for x in (qlb, tlb, t, q)]
     L.ref_backend_rows(_p(s), s.shape[0], _p(e), e.shape[0], _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(sr), _p(er))
     return sr[:s.shape[0]], er[:e.shape[0]]
+
+
+def format_convert(points19, stamp=0.0):
+    """livoxLidarHandler of the reference's FormatConvert.cpp (compiled unmodified): CUSTOM_POINT records (19 bytes each, see
+    oracle.CUSTOM_POINT) -> (n, 12) float32 rows of the published pcl::PointXYZINormal cloud."""
+    L = _lib("format")
+    raw = np.ascontiguousarray(points19).view(np.uint8).reshape(-1, 19)
+    out = np.zeros((max(raw.shape[0], 1), 12), np.float32)
+    n = L.ref_format_convert(_p(raw), raw.shape[0], C.c_double(stamp), _p(out))
+    return out[:n]
+
+
+def marg_lidar(surf_rec, edge_rec, qlb, tlb, t, q, pos, idx_t, idx_q):
+    """ResidualBlockInfo::Evaluate + ThreadsConstructA of the reference's MarginalizationFactor.cpp (text sliced at build time)
+    over the lidar blocks of one keyframe with CauchyLoss(1.0): returns (rows (n, 8) = robustified r, J_t, J_q — edge blocks
+    first, then surf, like L/src/BackendFusion.cpp adds them —, A (pos, pos), b (pos))."""
+    L = _lib("marg")
+    s, e = np.ascontiguousarray(surf_rec, np.float64).reshape(-1, 8), np.ascontiguousarray(edge_rec, np.float64).reshape(-1, 10)
+    rows = np.zeros((max(s.shape[0] + e.shape[0], 1), 8))
+    A, b = np.zeros((pos, pos)), np.zeros(pos)
+    a = [np.ascontiguousarray(x, np.float64) for x in (qlb, tlb, t, q)]
+    L.ref_marg_lidar(_p(s), s.shape[0], _p(e), e.shape[0], _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), int(pos), int(idx_t), int(idx_q),
+                     _p(rows), _p(A), _p(b))
+    return rows[:s.shape[0] + e.shape[0]], A, b

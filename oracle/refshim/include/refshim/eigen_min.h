@@ -11,7 +11,9 @@
 // is that the REFERENCE'S OWN statements run as written.
 #pragma once
 #include <cmath>
+#include <algorithm>
 #include <cstddef>
+#include <vector>
 #include "../../../lo_math.h"
 
 #define EIGEN_MAKE_ALIGNED_OPERATOR_NEW
@@ -24,7 +26,9 @@ template <class Derived> struct MatrixBase {
     Derived& derived() { return *static_cast<Derived*>(this); }
 };
 
-template <class T, int R, int C> struct Matrix : MatrixBase<Matrix<T, R, C>> {
+enum { Dynamic = -1, ColMajor = 0, RowMajor = 1 };
+template <class T, int R, int C, int O = 0> struct Matrix;
+template <class T, int R, int C> struct Matrix<T, R, C, 0> : MatrixBase<Matrix<T, R, C, 0>> {
     typedef T Scalar;
     enum { Rows = R, Cols = C, Size = R * C };
     T d[R * C];   // column-major like Eigen's default
@@ -174,5 +178,67 @@ template <> struct SelfAdjointEigenSolver<Matrix3d> {
     const Vector3d& eigenvalues() const { return vals; }
     const Matrix3d& eigenvectors() const { return vecs; }
 };
+
+
+// ---- run-time sized matrices: just enough for MarginalizationFactor.cpp:3-71 (ThreadsConstructA, ResidualBlockInfo::Evaluate).
+// Eager evaluation, row-major storage; every product / sum is the textbook element-wise definition evaluated left to right,
+// which is what Eigen does for these 1-residual blocks (outer products and 1x1 scalings: no reduction order to choose).
+struct Dyn {
+    int r = 0, c = 0;
+    std::vector<double> v;
+    Dyn() {}
+    Dyn(int r_, int c_) : r(r_), c(c_), v((size_t)r_ * c_, 0.0) {}
+    double& operator()(int i, int j) { return v[(size_t)i * c + j]; }
+    const double& operator()(int i, int j) const { return v[(size_t)i * c + j]; }
+    double& operator()(int i) { return v[i]; }
+    const double& operator()(int i) const { return v[i]; }
+    double& operator[](int i) { return v[i]; }
+    const double& operator[](int i) const { return v[i]; }
+    int rows() const { return r; }
+    int cols() const { return c; }
+    int size() const { return r * c; }
+    double* data() { return v.data(); }
+    const double* data() const { return v.data(); }
+    void resize(int r_, int c_) { r = r_; c = c_; v.assign((size_t)r_ * c_, 0.0); }
+    void resize(int n) { resize(n, 1); }
+    void setZero() { std::fill(v.begin(), v.end(), 0.0); }
+    Dyn transpose() const { Dyn t(c, r); for (int i = 0; i < r; i++) for (int j = 0; j < c; j++) t(j, i) = (*this)(i, j); return t; }
+    Dyn rightCols(int n) const { Dyn t(r, n); for (int i = 0; i < r; i++) for (int j = 0; j < n; j++) t(i, j) = (*this)(i, c - n + j); return t; }
+    double squaredNorm() const { double s = 0; for (double x : v) s += x * x; return s; }
+    Dyn& operator*=(double s) { for (double& x : v) x *= s; return *this; }
+    Dyn& operator+=(const Dyn& o) { for (size_t k = 0; k < v.size(); k++) v[k] += o.v[k]; return *this; }
+    struct Block {
+        Dyn& m; int i0, j0, nr, nc;
+        Dyn eval() const { Dyn t(nr, nc); for (int i = 0; i < nr; i++) for (int j = 0; j < nc; j++) t(i, j) = m(i0 + i, j0 + j); return t; }
+        Dyn transpose() const { return eval().transpose(); }
+        Block& operator+=(const Dyn& o) { for (int i = 0; i < nr; i++) for (int j = 0; j < nc; j++) m(i0 + i, j0 + j) += o(i, j); return *this; }
+        Block& operator=(const Dyn& o) { for (int i = 0; i < nr; i++) for (int j = 0; j < nc; j++) m(i0 + i, j0 + j) = o(i, j); return *this; }
+    };
+    Block block(int i0, int j0, int nr, int nc) { return Block{*this, i0, j0, nr, nc}; }
+    Block segment(int i0, int n) { return Block{*this, i0, 0, n, 1}; }
+};
+inline Dyn operator*(const Dyn& a, const Dyn& b) {
+    Dyn t(a.r, b.c);
+    for (int i = 0; i < a.r; i++) for (int j = 0; j < b.c; j++) { double s = a(i, 0) * b(0, j); for (int k = 1; k < a.c; k++) s += a(i, k) * b(k, j); t(i, j) = s; }
+    return t;
+}
+inline Dyn operator*(double s, const Dyn& a) { Dyn t = a; for (double& x : t.v) x = s * x; return t; }
+inline Dyn operator*(const Dyn& a, double s) { Dyn t = a; for (double& x : t.v) x = x * s; return t; }
+inline Dyn operator-(const Dyn& a, const Dyn& b) { Dyn t = a; for (size_t k = 0; k < t.v.size(); k++) t.v[k] = a.v[k] - b.v[k]; return t; }
+inline Dyn operator+(const Dyn& a, const Dyn& b) { Dyn t = a; for (size_t k = 0; k < t.v.size(); k++) t.v[k] = a.v[k] + b.v[k]; return t; }
+#define REFSHIM_DYN_MATRIX(C_, O_)                                                         \
+    template <> struct Matrix<double, Dynamic, C_, O_> : Dyn {                             \
+        Matrix() {}                                                                        \
+        Matrix(int r_, int c_) : Dyn(r_, c_) {}                                            \
+        explicit Matrix(int n) : Dyn(n, 1) {}                                              \
+        Matrix(const Dyn& d) : Dyn(d) {}                                                   \
+        Matrix& operator=(const Dyn& d) { Dyn::operator=(d); return *this; }               \
+    };
+REFSHIM_DYN_MATRIX(Dynamic, 0)
+REFSHIM_DYN_MATRIX(Dynamic, 1)
+REFSHIM_DYN_MATRIX(1, 0)
+#undef REFSHIM_DYN_MATRIX
+typedef Matrix<double, Dynamic, Dynamic, 0> MatrixXd;
+typedef Matrix<double, Dynamic, 1, 0> VectorXd;
 
 }  // namespace Eigen

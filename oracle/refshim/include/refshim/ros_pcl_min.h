@@ -43,6 +43,8 @@ inline std::map<std::string, ParamVal>& params() { static std::map<std::string, 
 namespace ros {
 struct Time {
     double t = 0;
+    Time() {}
+    explicit Time(double sec) : t(sec) {}
     double toSec() const { return t; }
 };
 struct Subscriber {};
@@ -53,6 +55,7 @@ struct Publisher {
 struct NodeHandle {
     explicit NodeHandle(const std::string& = "") {}
     template <class M, class C> Subscriber subscribe(const std::string&, int, void (C::*)(const std::shared_ptr<const M>&), C*) { return Subscriber(); }
+    template <class M> Subscriber subscribe(const std::string&, int, void (*)(const std::shared_ptr<const M>&)) { return Subscriber(); }
     template <class M> Publisher advertise(const std::string& topic, int) { Publisher p; p.topic = topic; return p; }
 };
 namespace this_node { inline std::string getName() { return "refshim"; } }

@@ -13,6 +13,10 @@ tests/golden/{s2m,extract}_*.npz, which come from the oracle — pin the oracle 
   ref_backend.npz  BackendFusion.cpp's transformPoint / findCorrespondingCornerFeatures / findCorrespondingSurfFeatures (both
                    flavours; member-function text sliced out of the file at build time, oracle/refshim/ref_backend.cpp) on a
                    room scene: the correspondence records and the residual blocks (raw r, dr/dt, dr/dq) created from them
+  ref_format.npz   LiLi-OM/src/FormatConvert.cpp (livoxLidarHandler): 5 000 random livox CustomPoints -> the published cloud
+                   (hash + every 16th row), plus the all-zero offset_time case (0/0 and x/0)
+  ref_marg.npz     ResidualBlockInfo::Evaluate + ThreadsConstructA (MarginalizationFactor.cpp:3-71, text sliced at build time)
+                   over the lidar blocks of ref_backend.npz's Livox keyframe: robustified rows, dense A and b
   ref_factors.npz  LidarEdgeFactor / LidarPlaneNormFactor / LidarPlaneNormIncreFactor ::Create()->Evaluate() on random
                    records: residual + both Jacobian blocks
 
@@ -190,6 +194,44 @@ def run_backend():
     return d
 
 
+def format_inputs(n=5000, seed=3):
+    from oracle import oracle as O
+    rng = np.random.default_rng(seed)
+    pts = np.zeros(n, O.CUSTOM_POINT)
+    pts["offset_time"] = np.sort(rng.integers(0, 100_000_000, n)).astype(np.uint32)
+    for k in ("x", "y", "z"):
+        pts[k] = rng.normal(0, 20, n).astype(np.float32)
+    pts["reflectivity"] = rng.integers(0, 256, n)
+    pts["line"] = rng.integers(0, 6, n)
+    pts["tag"] = rng.integers(0, 256, n)
+    zero = pts[:64].copy()
+    zero["offset_time"] = 0
+    return pts, zero
+
+
+def run_format():
+    pts, zero = format_inputs()
+    a, z = R.format_convert(pts), R.format_convert(zero)
+    return dict(n=a.shape[0], sha=sha(a), every16=a[::16], zero_case=z)
+
+
+MARG_POS, MARG_IDX_T, MARG_IDX_Q = 15, 6, 9      # a 15-dof window state with this keyframe's translation / rotation at 6 / 9
+
+
+def marg_inputs():
+    g = np.load(os.path.join(HERE, "ref_backend.npz"))
+    i = backend_inputs("livox")
+    srec = np.c_[g["livox_surf_rec"].astype(np.float64), g["livox_surf_score"]]
+    erec = g["livox_edge_rec"].astype(np.float64)
+    return i, srec, erec
+
+
+def run_marg():
+    i, srec, erec = marg_inputs()
+    rows, A, b = R.marg_lidar(srec, erec, i["qlb"], i["tlb"], i["t0"], i["q0"], MARG_POS, MARG_IDX_T, MARG_IDX_Q)
+    return dict(n_rows=rows.shape[0], rows_sha=sha(rows), rows_every8=rows[::8], A=A, b=b)
+
+
 def run_factors():
     f = factor_inputs()
     n = f["cp"].shape[0]
@@ -209,7 +251,9 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ref_factors.npz"), **run_factors())
     np.savez_compressed(os.path.join(HERE, "ref_frontend.npz"), **run_frontend())
     np.savez_compressed(os.path.join(HERE, "ref_backend.npz"), **run_backend())
-    for f in ("ref_rot.npz", "ref_livox.npz", "ref_factors.npz", "ref_frontend.npz", "ref_backend.npz"):
+    np.savez_compressed(os.path.join(HERE, "ref_format.npz"), **run_format())
+    np.savez_compressed(os.path.join(HERE, "ref_marg.npz"), **run_marg())
+    for f in ("ref_rot.npz", "ref_livox.npz", "ref_factors.npz", "ref_frontend.npz", "ref_backend.npz", "ref_format.npz", "ref_marg.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

@@ -41,11 +41,12 @@ def _same_npz(d, g):
 
 
 # ------------------------------------------------------------------ the reference build itself
-@pytest.mark.parametrize("which", ["rot", "livox", "factors", "frontend", "backend"])
+@pytest.mark.parametrize("which", ["rot", "livox", "factors", "frontend", "backend", "format", "marg"])
 def test_reference_build_reproduces_fixtures(which):
     if not M.R.available():
         pytest.skip("oracle/_ref not built (needs /root/reference; build container only)")
-    d = {"rot": M.run_rot, "livox": M.run_livox, "factors": M.run_factors, "frontend": M.run_frontend, "backend": M.run_backend}[which]()
+    d = {"rot": M.run_rot, "livox": M.run_livox, "factors": M.run_factors, "frontend": M.run_frontend, "backend": M.run_backend, "format": M.run_format,
+         "marg": M.run_marg}[which]()
     _same_npz(d, np.load(os.path.join(G, f"ref_{which}.npz")))
 
 
@@ -204,6 +205,50 @@ def test_oracle_association_equals_reference_backend(oracle, flavour):
     rows_e = oracle.linearize_rows(re_, i["t0"], i["q0"], raw, se, "edge")
     assert np.array_equal(np.c_[rows_s[:, 7], rows_s[:, :7]], g[f"{flavour}_surf_rows"])
     assert np.array_equal(np.c_[rows_e[:, 7], rows_e[:, :7]], g[f"{flavour}_edge_rows"])
+
+
+# ------------------------------------------------------------------ wire format and marginalisation feed vs oracle / product
+def test_oracle_equals_reference_format_convert(oracle):
+    """livoxLidarHandler (FormatConvert.cpp compiled unmodified) vs the numpy restatement: every published row bit for bit,
+    including the 0/0 and x/0 rows of an all-zero offset_time."""
+    g = np.load(os.path.join(G, "ref_format.npz"))
+    pts, zero = M.format_inputs()
+    a = oracle.livox_custom_to_cloud(pts)
+    assert a.shape[0] == int(g["n"]) and _sha(a) == str(g["sha"])
+    assert np.array_equal(_bits(a[::16]), _bits(g["every16"]))
+    assert np.array_equal(_bits(oracle.livox_custom_to_cloud(zero)), _bits(g["zero_case"]))
+
+
+def _rec_dicts(srec, erec):
+    rs = dict(valid=np.ones(len(srec), np.uint8), cp=srec[:, 0:3].astype(np.float32), n=srec[:, 3:6].astype(np.float32),
+              d=srec[:, 6].astype(np.float32), score=srec[:, 7].copy())
+    re_ = dict(valid=np.ones(len(erec), np.uint8), cp=erec[:, 0:3].astype(np.float32), a=erec[:, 3:6].astype(np.float32),
+               b=erec[:, 6:9].astype(np.float32), s=erec[:, 9].astype(np.float32))
+    return rs, re_
+
+
+def test_oracle_and_product_equal_reference_marginalisation_feed(oracle):
+    """ResidualBlockInfo::Evaluate (the loss corrector every lidar block goes through) and ThreadsConstructA (A += J_i^T J_j with
+    rightCols(3) of the quaternion block, b += J_i^T r), compiled from the reference text, vs (1) the oracle's robustified rows
+    and per-residual accumulation: bit for bit; (2) the product's lili_marg_add_lidar fed with the Gram of the same rows: 1e-12."""
+    import lili_om_amd as L
+    g = np.load(os.path.join(G, "ref_marg.npz"))
+    i, srec, erec = M.marg_inputs()
+    PO = oracle.params("livox")
+    rs, re_ = _rec_dicts(srec, erec)
+    rows = np.r_[oracle.linearize_rows(re_, i["t0"], i["q0"], PO, 1.0, "edge"), oracle.linearize_rows(rs, i["t0"], i["q0"], PO, 1.0, "surf")]
+    mine = np.c_[rows[:, 7], rows[:, :7]]                       # r, J_t, J_q like the reference's ResidualBlockInfo
+    assert mine.shape[0] == int(g["n_rows"]) and _sha(mine) == str(g["rows_sha"])
+    assert np.array_equal(mine[::8], g["rows_every8"])
+    A, b = oracle.marg_accumulate(rows[:, :7], rows[:, 7], M.MARG_POS, M.MARG_IDX_T, M.MARG_IDX_Q)
+    assert np.array_equal(A, g["A"]) and np.array_equal(b, g["b"])
+    # product: one Gram record -> A, b
+    Jr = np.c_[rows[:, :7], rows[:, 7]]
+    Gm = Jr.T @ Jr
+    A2, b2 = np.zeros((M.MARG_POS, M.MARG_POS)), np.zeros(M.MARG_POS)
+    L.api.marg_add_lidar(Gm, A2, b2, M.MARG_IDX_T, M.MARG_IDX_Q)
+    assert np.abs(A2 - g["A"]).max() <= 1e-12 * np.abs(g["A"]).max()
+    assert np.abs(b2 - g["b"]).max() <= 1e-12 * np.abs(g["b"]).max()
 
 
 # ------------------------------------------------------------------ product host logic vs reference

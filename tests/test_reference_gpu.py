@@ -204,3 +204,35 @@ def test_gpu_backend_matcher_vs_reference(gpu_ctx, flavour):
         assert np.abs(Gg - Gr).max() <= 2e-6 * np.abs(Gr).max(), (flavour, mask, np.abs(Gg - Gr).max() / np.abs(Gr).max())
         cost_ref = 0.5 * np.log1p(rows[:, 0] ** 2).sum()
         assert abs(cost - cost_ref) <= 2e-6 * max(1.0, cost_ref)
+
+
+def test_gpu_format_convert_vs_reference(gpu_ctx):
+    """k_custom_to_pcl (lili_livox_custom_to_cloud) vs the reference's livoxLidarHandler (tests/golden/ref_format.npz)."""
+    g = np.load(os.path.join(G, "ref_format.npz"))
+    pts, zero = M.format_inputs()
+    a = L.api.livox_custom_to_cloud(gpu_ctx, pts)
+    assert a.shape[0] == int(g["n"]) and _sha(a) == str(g["sha"])
+    assert np.array_equal(_bits(a[::16]), _bits(g["every16"]))
+    assert np.array_equal(_bits(L.api.livox_custom_to_cloud(gpu_ctx, zero)), _bits(g["zero_case"]))
+
+
+def test_gpu_marginalisation_feed_vs_reference(gpu_ctx):
+    """lili_s2m_linearize + lili_marg_add_lidar on the GPU's own records of the ref_backend Livox keyframe vs the A, b the
+    reference's ResidualBlockInfo::Evaluate + ThreadsConstructA build from the reference's records (f32-record tolerance)."""
+    g = np.load(os.path.join(G, "ref_marg.npz"))
+    i = M.backend_inputs("livox")
+    P = L.make_params("livox")
+    m = L.ScanToMapMatcher(gpu_ctx, P)
+    m.set_input_cloud(L.KIND_SURF, i["surf_map"])
+    m.set_input_cloud(L.KIND_EDGE, np.ascontiguousarray(i["edge_map"][:, :3]))
+    m.set_queries(0, L.KIND_SURF, i["surf_q"])
+    m.set_queries(0, L.KIND_EDGE, np.ascontiguousarray(i["edge_q"][:, :3]))
+    Q2, T2 = L.api.assoc_transform(i["t0"], i["q0"], P)
+    m.find_corresponding_surf_features(0, Q2, T2)
+    m.find_corresponding_corner_features(0, Q2, T2)
+    Gm, cost, counts = m.linearize(0, i["t0"], i["q0"], L.MASK_SURF | L.MASK_EDGE)
+    assert int(counts[0]) + int(counts[1]) == int(g["n_rows"])
+    A, b = np.zeros((M.MARG_POS, M.MARG_POS)), np.zeros(M.MARG_POS)
+    L.api.marg_add_lidar(Gm, A, b, M.MARG_IDX_T, M.MARG_IDX_Q)
+    assert np.abs(A - g["A"]).max() <= 2e-5 * np.abs(g["A"]).max()
+    assert np.abs(b - g["b"]).max() <= 2e-5 * np.abs(g["b"]).max()
