@@ -5,7 +5,8 @@
 //     transformPoint(pi, po, quaternion, transition)      L/src/BackendFusion.cpp:695-711   R/src/BackendFusion.cpp:624-632
 //     findCorrespondingCornerFeatures(idx, q, t)          L:1531-1599                        R:1394-1462
 //     findCorrespondingSurfFeatures(idx, q, t)            L:1601-1681                        R:1464-1520
-// — into oracle/_ref/gen/backend_{L,R}.inc (git-ignored, never committed) and this file #includes that text, unmodified,
+// — into a temporary oracle/_ref/gen/backend_{L,R}.inc that exists only while this file is compiled (the Makefile removes it
+// again; no reference text stays in the tree) and this file #includes that text, unmodified,
 // inside a harness class whose data members carry the names and types the reference's class declares for them
 // (L:62-76,93,105-110,119-120,154,157,216-223).  The Makefile checks that each slice starts with the expected signature.
 // The residual blocks are then created exactly as the reference's optimisation loop does (L:936-972, R:836-866: the
