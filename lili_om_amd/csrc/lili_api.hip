@@ -668,6 +668,7 @@ static int linearize_dev_impl(lili_ctx* ctx, int slot, int kind_mask, const lili
     PoseArg pa{};
     pa.state = ctx->state(slot);
     MatchParams P = to_device_params(params);
+    if (do_gn && d_gram == ctx->gram_of(slot)) P.no_cost = 1;   // lili_s2m_iterate*: the record stays inside the library, only the GN step is used
     int rc = launch_linearize_reduce(ctx, slot, kind_mask, pa, P, d_gram, do_gn);
     if (rc != LILI_OK) return rc;
     ctx->slots[slot].use_global_counts = false;

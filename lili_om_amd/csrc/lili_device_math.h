@@ -254,11 +254,12 @@ __device__ __forceinline__ bool plane_fit_centered(const double x[5], const doub
 }
 
 // ceres loss functions: rho[0..2] = rho(s), rho'(s), rho''(s)
-__device__ __forceinline__ void loss_eval(int loss, double a, double s, double rho[3]) {
+__device__ __forceinline__ void loss_eval(int loss, double a, double s, double rho[3], bool want_rho0 = true) {
     if (loss == 1) {  // Cauchy
         double b = a * a, c = 1.0 / b;
         double sum = 1.0 + s * c, inv = 1.0 / sum;
-        rho[0] = b * log(sum); rho[1] = fmax(2.2250738585072014e-308, inv); rho[2] = -c * (inv * inv);
+        rho[0] = want_rho0 ? b * log(sum) : 0.0;   // the cost value is not needed by a Gauss-Newton step (f64 log: ~60 instructions)
+        rho[1] = fmax(2.2250738585072014e-308, inv); rho[2] = -c * (inv * inv);
     } else if (loss == 2) {  // Huber
         double b = a * a;
         if (s > b) { double r = sqrt(s); rho[0] = 2.0 * a * r - b; rho[1] = fmax(2.2250738585072014e-308, a / r); rho[2] = -rho[1] / (2.0 * s); }
@@ -266,10 +267,10 @@ __device__ __forceinline__ void loss_eval(int loss, double a, double s, double r
     } else { rho[0] = s; rho[1] = 1.0; rho[2] = 0.0; }
 }
 // Corrector of L/src/MarginalizationFactor.cpp:44-70 for a 1-residual block: scales J (7) and r in place.
-__device__ __forceinline__ double robustify(int loss, double a, double J[7], double& r) {
+__device__ __forceinline__ double robustify(int loss, double a, double J[7], double& r, bool want_cost = true) {
     double sq = r * r;
     double rho[3];
-    loss_eval(loss, a, sq, rho);
+    loss_eval(loss, a, sq, rho, want_cost);
     double cost = 0.5 * rho[0];
     if (loss == 0) return cost;
     double sqrt_rho1 = sqrt(rho[1]);

@@ -1193,7 +1193,7 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize_surf(
             double jq[4];
             qrot_jac_row(Q, v, n, jq);
             double J[7] = {score * n.x, score * n.y, score * n.z, score * jq[0], score * jq[1], score * jq[2], score * jq[3]};
-            cost = robustify(P.loss, P.loss_a, J, r);
+            cost = robustify(P.loss, P.loss_a, J, r, P.no_cost == 0);
 #pragma unroll
             for (int k = 0; k < 7; k++) Jr[k] = J[k];
             Jr[7] = r;
@@ -1243,7 +1243,7 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize_edge(
             double jq[4];
             qrot_jac_row(Q, cp, g, jq);
             double J[7] = {g.x, g.y, g.z, jq[0], jq[1], jq[2], jq[3]};
-            cost = robustify(P.loss, P.loss_a, J, r);
+            cost = robustify(P.loss, P.loss_a, J, r, P.no_cost == 0);
 #pragma unroll
             for (int kk = 0; kk < 7; kk++) Jr[kk] = J[kk];
             Jr[7] = r;
