@@ -7,8 +7,10 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 TAG=${1:-r01}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- python bench.py --steps 200 --warmup 20 > $OUT/bench.json 2> $OUT/bench.err
-B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+# --no-extras: the secondary measurements (3-slot window, ROT extractor) launch the same kernels concurrently from three streams and
+# would skew the per-launch averages this trace is compared with
+timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- python bench.py --steps 200 --warmup 20 --no-extras > $OUT/bench.json 2> $OUT/bench.err
+B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras"
 timeout 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT -o p_fetch -- $B > /dev/null 2> $OUT/p_fetch.err
 timeout 240 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT -o p_write -- $B > /dev/null 2> $OUT/p_write.err
 timeout 240 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_LDS --kernel-trace --output-format csv -d $OUT -o p_sq -- $B > /dev/null 2> $OUT/p_sq.err
