@@ -31,6 +31,7 @@ __global__ void k_linearize_edge(const float4*, int, const float4*, const float4
 __global__ void k_reduce_partials(const double*, int, const double*, int, double*, SlotState*, int);
 __global__ void k_sum_counts(const int*, int, const int*, int, SlotState*, int*);
 __global__ void k_gn_update(const double*, SlotState*);
+__global__ void k_pose_copy(SlotState*, const SlotState*);
 }  // namespace lili
 
 #include "lili_ctx.h"
@@ -698,7 +699,8 @@ int lili_s2m_pose_copy(lili_ctx* ctx, int dst_slot, int src_slot) {
     if (!ctx) return LILI_E_ARG;
     ARGCHK(dst_slot >= 0 && dst_slot < LILI_MAX_SLOTS && src_slot >= 0 && src_slot < LILI_MAX_SLOTS, "pose_copy: bad slot");
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(hipMemcpyAsync(ctx->state(dst_slot)->pose, ctx->state(src_slot)->pose, 7 * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_pose_copy, dim3(1), dim3(8), 0, ctx->stream, ctx->state(dst_slot), ctx->state(src_slot));
+    HIPCHK(hipGetLastError());
     return LILI_OK;
 }
 

@@ -1425,6 +1425,12 @@ __global__ __launch_bounds__(kReduceThreads) void k_reduce_partials(const double
     reduce_partials_block(part_surf, nb_surf, part_edge, nb_edge, out, state, do_gn);
 }
 
+// Restart of a registration: 56 bytes device to device.  hipMemcpyAsync(D2D) costs a 4.5 us copy kernel for this; one 8-lane
+// workgroup of our own is done in well under half of that.
+__global__ void k_pose_copy(SlotState* __restrict__ dst, const SlotState* __restrict__ src) {
+    if (threadIdx.x < 7) dst->pose[threadIdx.x] = src->pose[threadIdx.x];
+}
+
 __global__ void k_gn_update(const double* __restrict__ gram, SlotState* __restrict__ state) {
     const double xq[4] = {state->pose[3], state->pose[4], state->pose[5], state->pose[6]};
     gn_update_block(gram, state, xq);
