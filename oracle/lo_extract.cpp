@@ -1,4 +1,6 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see lo_math.h header).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see lo_math.h header).  PARITY: the literal mode of both extractors reproduces every cloud
+// the reference's own Preprocessing.cpp publishes bit for bit (oracle/_ref: libref_rot, libref_livox — tests/test_reference_cpu.py);
+// PCL's VoxelGrid and Eigen's quaternion / eigen-solver arithmetic are restated third-party code.
 //
 // CPU restatement of the reference's feature extractors:
 //   * LOAM-style 16/32/64-ring extractor      — R/src/Preprocessing.cpp:120-177 (filters, deskew), :277-509

@@ -1,5 +1,7 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see lo_math.h header).  PARITY UNPINNED (no reference
-// golden vectors exist).
+// ORACLE — TEST INFRASTRUCTURE ONLY (see lo_math.h header).  PARITY: association records, residual-block rows, loss
+// corrector and A/b assembly are pinned bit for bit against the reference's own functions compiled from their text
+// (oracle/_ref: libref_backend_{L,R}, libref_lo, libref_factors, libref_marg — tests/test_reference_cpu.py); the kd-tree, QR and
+// eigen-solver underneath restate third-party code and are checked against semantics only.
 //
 // CPU restatement of the reference's scan-to-map matcher:
 //   * exact kNN-5 over the local map          — pcl::KdTreeFLANN::nearestKSearch call sites

@@ -2,7 +2,9 @@
 
 ctypes/numpy front-end of oracle/liblili_oracle.so (the CPU restatement of the reference hot path).
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
-product (lili_om_amd) never does.  PARITY UNPINNED: see oracle/lo_math.h.
+product (lili_om_amd) never does.  PARITY: pinned bit for bit against the reference's own sources compiled as-is
+(oracle/refshim/README.md, tests/test_reference_cpu.py) on every hot-path row; third-party internals (FLANN, Eigen, PCL, Ceres)
+are restated and checked against semantics only (oracle/lo_math.h).
 """
 import ctypes as C
 import os

@@ -2,7 +2,8 @@
 """Generates tests/golden/*.npz from the ORACLE on fixed-seed synthetic inputs.
 
 The reference has no golden vectors, so these fixtures pin the oracle against regressions and give
-the GPU tests an oracle-free comparison target; they do NOT pin the oracle to the reference ("parity unpinned").
+the GPU tests an oracle-free comparison target; they do NOT pin the oracle to the reference — tests/golden/make_ref_golden.py
+and its ref_*.npz fixtures (outputs of the reference's own sources) do that.
 Run from the repository root:  python tests/golden/make_golden.py
 """
 import os

@@ -3,7 +3,9 @@
 The reference ships no tests or golden vectors and cannot be built offline, so the
 oracle is pinned against semantics: brute force for kNN, numpy/LAPACK for the small linear algebra,
 complex-step differentiation of the literal functor expressions for the Jacobians, closed forms for
-the loss functions, and hand-checkable geometric cases.  PARITY UNPINNED w.r.t. reference outputs.
+the loss functions, and hand-checkable geometric cases.  (The reference's OWN code is pinned separately: tests/test_reference_cpu.py
+compares the oracle with oracle/_ref — the reference's hot-path sources compiled as-is — bit for bit; this file covers the
+third-party arithmetic those builds share with the oracle.)
 """
 import numpy as np
 import pytest
