@@ -353,7 +353,7 @@ struct Sel5K {
             const unsigned lo = real ? (unsigned)__float_as_int(p.w) : 0x7fffffffu;
             e[s] = ((unsigned long long)du << 32) | lo;
         }
-        const bool unsorted = !(e[0] < e[1] && e[1] < e[2] && e[2] < e[3] && e[3] < e[4]);
+        const bool unsorted = !(e[0] <= e[1] && e[1] <= e[2] && e[2] <= e[3] && e[3] <= e[4]);   // real keys are unique (distinct indices); equal keys are sentinels
         if (__any(unsorted)) {   // within-bucket inversion somewhere in the wave (rare): 9 compare-exchanges
 #define LILI_CE(a, b) { const bool sw = e[b] < e[a]; const unsigned long long ea = e[a], eb = e[b]; const int ja = jr[a], jb = jr[b]; \
                         e[a] = sw ? eb : ea; e[b] = sw ? ea : eb; jr[a] = sw ? jb : ja; jr[b] = sw ? ja : jb; }
