@@ -552,3 +552,26 @@ def test_native_rccl_communicator_single_rank(gpu_ctx, oracle):
         assert st == 0 and np.array_equal(t2, t_ref) and np.array_equal(q2, q_ref)
     finally:
         comm.close()
+
+
+def test_balance_option_same_results(gpu_ctx, oracle):
+    """Cost-ordered dispatch (lili_set_option 'balance', off by default: measured without gain) only changes WHICH workgroup
+    handles which 64-query block — records, counts and the Gram are those of the default order bit for bit."""
+    room = synth.make_room(seed=16, n_query=80_000, n_edge_query=100)       # > 1024 one-wave workgroups, so that the order kernel runs
+    P, PO, m = _setup(gpu_ctx, oracle, "rot", room, with_refl=False)
+    t, q, Q2, T2 = _pose(room, P, "rot", np.random.default_rng(11), 0.05, 0.6)
+    nq = room["q_xyz"].shape[0]
+    out = []
+    try:
+        for bal in (0, 1):
+            gpu_ctx.set_option("balance", bal)
+            for _ in range(3):                                               # launches 2 and 4 of a scan rebuild the order
+                n = m.find_corresponding_surf_features(0, Q2, T2)
+            G, cost, counts = m.linearize(0, t, q, L.MASK_SURF)
+            out.append((n, m.surf_records(0, nq), G.copy(), cost))
+    finally:
+        gpu_ctx.set_option("balance", 0)
+    (n0, r0, G0, c0), (n1, r1, G1, c1) = out
+    assert n0 == n1 > 10_000 and np.array_equal(r0["query_index"], r1["query_index"])
+    assert np.array_equal(r0["n"], r1["n"]) and np.array_equal(r0["score"], r1["score"])
+    assert np.array_equal(G0, G1) and c0 == c1
