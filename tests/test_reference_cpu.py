@@ -263,3 +263,115 @@ def test_product_gyro_integration_feeds_reference_identically(oracle):
         q_imu = _q_imu_per_scan(integ, stamps, imu_t, gyr, k)
         r = oracle.extract_rot(scans[k], q_imu, M.ROT_QLB, oracle.rot_params(ds_rate=4, atan_mode=0, stable_sort=0))
         assert np.array_equal(_bits(r["full"]), _bits(g[f"cutted{k}"]))
+
+
+# ------------------------------------------------------------------ live differential tests against oracle/_ref (build container only)
+needs_ref = pytest.mark.skipif(not M.R.available(), reason="oracle/_ref not built (needs /root/reference; build container only)")
+
+
+def _rot_params(line_num, ds_rate, qlb):
+    p = dict(M.ROT_PARAMS)
+    p.update({"/preprocessing/line_num": line_num, "/preprocessing/ds_rate": ds_rate, "/backend_fusion/ql2b_w": qlb[0],
+              "/backend_fusion/ql2b_x": qlb[1], "/backend_fusion/ql2b_y": qlb[2], "/backend_fusion/ql2b_z": qlb[3]})
+    return p
+
+
+@needs_ref
+@pytest.mark.parametrize("line_num,ds_rate", [(16, 1), (32, 2), (64, 1)])
+def test_reference_rot_node_ring_tables_and_bad_points(oracle, line_num, ds_rate):
+    """The reference's ROT Preprocessing node with the 16- / 32- / 64-ring tables, every ring kept (ds_rate 1) or every second,
+    a unit and a non-unit extrinsic, and scans that contain NaN points, points closer than 3 m and points outside the ring
+    table: every published cloud equals the oracle's literal mode bit for bit."""
+    from lili_om_amd import synth
+    rng = np.random.default_rng(100 + line_num)
+    scans = []
+    for s_ in range(3):
+        w = synth.make_workload(n_map=50_000, n_az=150, half_extent=(120.0, 120.0), seed=synth.SEED_SCENE + 70 + s_)
+        raw = np.concatenate([w["scan_xyz"], rng.integers(1, 255, (w["scan_xyz"].shape[0], 1)).astype(np.float32)], 1).astype(np.float32)
+        bad = rng.choice(raw.shape[0], 90, replace=False)
+        raw[bad[:30], rng.integers(0, 3, 30)] = np.nan                      # removeNaNFromPointCloud
+        raw[bad[30:60], :3] *= 0.01                                          # closer than 3 m: removeClosedPointCloud
+        raw[bad[60:], 2] = np.abs(raw[bad[60:], 2]) + 60.0                   # far above the ring table
+        scans.append(raw)
+    stamps = 20.0 + 0.1 * np.arange(3)
+    imu_t = 19.96 + 0.005 * np.arange(70)
+    gyr = 0.3 * rng.standard_normal((70, 3))
+    qlb = [1.0, 0.0, 0.0, 0.0] if line_num == 32 else [0.7071, 0.0, 0.0, 0.7071]
+    out = M.R.run_scans("rot", _rot_params(line_num, ds_rate, qlb), scans, stamps, imu_t, gyr)
+    assert len(out) == 1
+    q_imu = oracle.ImuIntegrator().integrate(imu_t[imu_t <= stamps[2]], gyr[imu_t <= stamps[2]], stamps[1])
+    r = oracle.extract_rot(scans[0], q_imu, qlb, oracle.rot_params(n_scans=line_num, ds_rate=ds_rate, atan_mode=0, stable_sort=0))
+    o = out[0]
+    assert np.array_equal(_bits(r["full"]), _bits(o["cutted"][:, M.PAYLOAD_ROT]))
+    assert np.array_equal(_bits(r["full"][r["edge_idx"]]), _bits(o["edge"][:, M.PAYLOAD_ROT]))
+    assert np.array_equal(_bits(r["surf"]), _bits(o["surf"][:, M.PAYLOAD_ROT]))
+    assert r["full"].shape[0] > 3000 and len(r["edge_idx"]) > 20 and r["surf"].shape[0] > 100
+
+
+@needs_ref
+def test_reference_livox_node_bad_points(oracle):
+    """The Livox node on scans with NaNs, near points (< 0.1 m), far points (> 200 m), zero / saturated reflectivity and
+    duplicate time slots (synth.make_livox_scan(inject_bad=True) plus extra NaNs)."""
+    from lili_om_amd import synth
+    rng = np.random.default_rng(7)
+    scans = [synth.make_livox_scan(60 + s_, inject_bad=True) for s_ in range(3)]
+    for sc in scans:
+        bad = rng.choice(sc.shape[0], 40, replace=False)
+        sc[bad[:20], rng.integers(0, 3, 20)] = np.nan
+        sc[bad[20:], :3] *= 0.001
+    stamps = 30.0 + 0.1 * np.arange(3)
+    imu_t = 29.96 + 0.005 * np.arange(70)
+    gyr = 0.3 * rng.standard_normal((70, 3))
+    out = M.R.run_scans("livox", M.LIVOX_PARAMS, scans, stamps, imu_t, gyr)
+    assert len(out) == 1
+    q_imu = oracle.ImuIntegrator().integrate(imu_t[imu_t <= stamps[2]], gyr[imu_t <= stamps[2]], stamps[1])
+    r = oracle.extract_livox(scans[0], q_imu)
+    pay = [0, 1, 2, 6, 7]
+    for name in ("cutted", "edge", "surf"):
+        a, b = r[name], out[0][name][:, M.PAYLOAD_LIVOX]
+        assert a.shape == b.shape, name
+        assert np.array_equal(_bits(a[:, pay]), _bits(b[:, pay])), name
+        assert np.array_equal(_bits(np.abs(a[:, 3:6])), _bits(np.abs(b[:, 3:6]))), name
+
+
+@needs_ref
+@pytest.mark.parametrize("flavour", ["livox", "rot"])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_reference_backend_association_random_scenes(oracle, flavour, seed):
+    """Randomised differential test of the back-end association against the reference's functions: different rooms, noise levels,
+    pose errors (so that gates, plane-validity and weight thresholds are all exercised on both sides of their limits)."""
+    from lili_om_amd import synth
+    from tests import frontend_chain as F
+    rng = np.random.default_rng(1000 + seed)
+    room = synth.make_room(seed=200 + seed, size=(10.0 + 6 * seed, 8.0 + 3 * seed, 4.0 + seed), leaf=0.3 + 0.1 * (seed % 3),
+                           n_query=900, n_edge_query=150, noise=0.005 * seed * seed)
+    B = M.BACKEND_PARAMS[flavour]
+    PO = oracle.params(flavour)
+    qlb, tlb = np.array(B["q_lb"]), np.array(B["t_lb"])
+    qb, tb = F.eigen_qmul(room["q_true"], qlb), room["t_true"] + F.eigen_qrot(room["q_true"], tlb[None, :])[0]
+    t0, q0 = synth.perturbed_pose(tb, qb, rng, 0.02 * seed * seed, 0.3 * seed)
+    Q2 = F.eigen_qmul(q0, F.eigen_qinv(qlb))
+    T2 = t0 - F.eigen_qrot(Q2, tlb[None, :])[0]
+    z = lambda a: np.zeros((a.shape[0], 1), np.float32)                                 # noqa: E731
+    smap, sq = np.c_[room["map_xyz"], room["map_refl"]].astype(np.float32), np.c_[room["q_xyz"], room["q_refl"]].astype(np.float32)
+    emap, eq = np.c_[room["edge_map_xyz"], z(room["edge_map_xyz"])].astype(np.float32), np.c_[room["eq_xyz"], z(room["eq_xyz"])].astype(np.float32)
+    srec, erec = M.R.backend_associate(flavour, smap, emap, sq, eq, Q2, T2, B["kd_max_radius"], B["surf_dist_thres"], B["lidar_const"], B["reflect_thres"])
+    refl = flavour == "livox"
+    rs = oracle.associate_surf(oracle.KdTree(room["map_xyz"]), room["map_refl"] if refl else None, room["q_xyz"], room["q_refl"] if refl else None, Q2, T2, PO)
+    re_ = oracle.associate_edge(oracle.KdTree(room["edge_map_xyz"]), room["eq_xyz"], Q2, T2, PO)
+    v, ve = rs["valid"].astype(bool), re_["valid"].astype(bool)
+    mine_s = np.c_[rs["cp"][v], rs["n"][v], rs["d"][v], rs["score"][v]].astype(np.float64)
+    assert mine_s.shape == srec.shape and np.array_equal(mine_s, srec)
+    mine_e = np.c_[re_["cp"][ve], re_["a"][ve], re_["b"][ve], re_["s"][ve]].astype(np.float64)
+    assert mine_e.shape == erec.shape and np.array_equal(_sorted_ab(mine_e), _sorted_ab(erec))
+    assert 0 < v.sum() < v.size                                          # some queries accepted, some rejected
+    srows, erows = M.R.backend_rows(flavour, srec, erec, qlb, tlb, t0, q0)
+    raw = oracle.params(flavour, loss=0)
+    ss = (1000.0, int(v.sum())) if flavour == "rot" else 1.0
+    se = (200.0, max(int(ve.sum()), 1)) if flavour == "rot" else 1.0
+    rows_s = oracle.linearize_rows(rs, t0, q0, raw, ss, "surf")
+    assert np.array_equal(np.c_[rows_s[:, 7], rows_s[:, :7]], srows)
+    if ve.sum():
+        rows_e = oracle.linearize_rows(re_, t0, q0, raw, se, "edge")
+        # the reference builds the edge factor from ITS (A, B) order; the residual is symmetric in A <-> B, bit for bit
+        assert np.array_equal(np.c_[rows_e[:, 7], rows_e[:, :7]], erows)
