@@ -1,8 +1,11 @@
 // lili_ceres_adapter.h — header-only glue between ceres::Solve and liblili_hip.so.
 //
-// Compiled only inside the reference's catkin workspace (needs <ceres/ceres.h>; Ceres is not available in the
-// build image of this repository, so this header is NOT built here — its algebra, lili_gram_to_factor(), lives
-// in the library and is unit-tested in tests/test_abi_cpu.py::test_gram_to_factor_reproduces_normal_equations).
+// Meant for the reference's catkin workspace (needs <ceres/ceres.h>).  Ceres is not available in the build image of this
+// repository; the header is nevertheless compiled and exercised here against a stand-in ceres::CostFunction /
+// ceres::Problem together with the reference's own LidarKeyframeFactor.h (oracle/refshim/ref_seam.cpp, run by
+// tests/test_reference_gpu.py::test_ceres_seam_batch_factor_equals_reference_blocks: one LidarBatchFactor gives the normal
+// equations and cost of the reference's ~1 500 per-correspondence blocks to 1e-15).  Its algebra, lili_gram_to_factor(),
+// lives in the library and is unit-tested in tests/test_abi_cpu.py::test_gram_to_factor_reproduces_normal_equations.
 //
 // What it replaces in the reference (L/ = LiLi-OM/):
 //   for every correspondence:  new AutoDiffCostFunction<LidarEdgeFactor|LidarPlaneNormFactor,1,3,4>(...)

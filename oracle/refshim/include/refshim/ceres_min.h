@@ -66,6 +66,11 @@ protected:
     std::vector<int> sizes_; int nres_ = 0;
 };
 
+template <int kNumResiduals, int... Ns> class SizedCostFunction : public CostFunction {
+public:
+    SizedCostFunction() { sizes_ = {Ns...}; nres_ = kNumResiduals; }
+};
+
 template <class Functor, int kNumResiduals, int N0, int N1> class AutoDiffCostFunction : public CostFunction {
 public:
     explicit AutoDiffCostFunction(Functor* f) : f_(f) { sizes_ = {N0, N1}; nres_ = kNumResiduals; }

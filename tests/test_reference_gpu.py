@@ -236,3 +236,37 @@ def test_gpu_marginalisation_feed_vs_reference(gpu_ctx):
     L.api.marg_add_lidar(Gm, A, b, M.MARG_IDX_T, M.MARG_IDX_Q)
     assert np.abs(A - g["A"]).max() <= 2e-5 * np.abs(g["A"]).max()
     assert np.abs(b - g["b"]).max() <= 2e-5 * np.abs(g["b"]).max()
+
+
+@pytest.mark.parametrize("flavour", ["livox", "rot"])
+def test_ceres_seam_batch_factor_equals_reference_blocks(gpu_ctx, tmp_path, flavour):
+    """The drop-in claim at the Ceres seam, in C++ and with the reference's own factor header: inside one
+    ceres::Problem (stand-in) ONE lili::LidarBatchFactor — include/lili_ceres_adapter.h, the binding of INTEGRATION.md §1 —
+    presents the solver with the same J^T J, J^T r and cost as the thousands of AutoDiffCostFunction<LidarEdgeFactor |
+    LidarPlaneNormFactor> + CauchyLoss(1.0) blocks the reference adds for the same correspondences
+    (oracle/refshim/ref_seam.cpp -> oracle/_ref/seam_check, prebuilt against /root/reference's LidarKeyframeFactor.h)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(G), "..", "oracle", "_ref", "seam_check")
+    exe = os.path.abspath(exe)
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/seam_check not built")
+    i = M.backend_inputs(flavour)
+    P = L.make_params(flavour)
+    f = tmp_path / "seam.bin"
+    with open(f, "wb") as fh:
+        fh.write(np.array([i["surf_map"].shape[0], i["edge_map"].shape[0], i["surf_q"].shape[0], i["edge_q"].shape[0],
+                           1 if flavour == "rot" else 0], np.int32).tobytes())
+        fh.write(bytes(P))
+        for k in ("surf_map", "edge_map", "surf_q", "edge_q"):
+            fh.write(np.ascontiguousarray(i[k], np.float32).tobytes())
+        fh.write(np.r_[i["t0"], i["q0"]].astype(np.float64).tobytes())
+    out = subprocess.run([exe, str(f)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    kv = dict(line.split("=", 1) for line in out.stdout.strip().splitlines() if "=" in line)
+    assert "error" not in kv, kv
+    g = np.load(os.path.join(G, "ref_backend.npz"))
+    assert int(kv["n_surf"]) == g[f"{flavour}_surf_rec"].shape[0] and int(kv["n_edge"]) == g[f"{flavour}_edge_rec"].shape[0]
+    assert int(kv["blocks_batch"]) == 1 and int(kv["blocks_reference"]) == int(kv["n_surf"]) + int(kv["n_edge"]) > 1000
+    assert float(kv["H_rel_diff"]) < 1e-9 and float(kv["g_rel_diff"]) < 1e-9, kv
+    cb, cr = float(kv["cost_batch"]), float(kv["cost_reference"])
+    assert abs(cb - cr) <= 1e-9 * max(1.0, cr), kv
