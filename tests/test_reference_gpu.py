@@ -270,3 +270,31 @@ def test_ceres_seam_batch_factor_equals_reference_blocks(gpu_ctx, tmp_path, flav
     assert float(kv["H_rel_diff"]) < 1e-9 and float(kv["g_rel_diff"]) < 1e-9, kv
     cb, cr = float(kv["cost_batch"]), float(kv["cost_reference"])
     assert abs(cb - cr) <= 1e-9 * max(1.0, cr), kv
+
+
+def test_ros_node_seam_gpu_node_equals_reference_node(gpu_ctx, tmp_path):
+    """The drop-in claim at the ROS-node seam, in C++: the reference's LiLi-OM-ROT Preprocessing node (compiled
+    unmodified) and a node with the same topics whose cloud handler is the binding of INTEGRATION.md §3 (lili_imu_integrate +
+    lili_extract_rot through the C ABI) get the same ROS messages; every cloud the reference publishes comes out of the GPU node
+    on the same topic, with the same stamp, the same number of points and — up to glibc's float atan2f — the same bits
+    (oracle/refshim/ref_seam_pre.cpp -> oracle/_ref/seam_pre_check)."""
+    import subprocess
+    exe = os.path.abspath(os.path.join(os.path.dirname(G), "..", "oracle", "_ref", "seam_pre_check"))
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/seam_pre_check not built")
+    scans, stamps, imu_t, gyr = M.rot_inputs()
+    f = tmp_path / "pre.bin"
+    with open(f, "wb") as fh:
+        fh.write(np.array([len(scans), len(imu_t), 64, 4], np.int32).tobytes())
+        fh.write(np.array(M.ROT_QLB, np.float64).tobytes())
+        for s_, t_ in zip(scans, stamps):
+            fh.write(np.float64(t_).tobytes()); fh.write(np.int32(s_.shape[0]).tobytes()); fh.write(np.ascontiguousarray(s_, np.float32).tobytes())
+        fh.write(np.ascontiguousarray(imu_t, np.float64).tobytes()); fh.write(np.ascontiguousarray(gyr, np.float64).tobytes())
+    out = subprocess.run([exe, str(f)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    kv = dict(line.split("=", 1) for line in out.stdout.strip().splitlines() if "=" in line)
+    assert "error" not in kv, kv
+    assert int(kv["messages_reference"]) == int(kv["messages_gpu"]) == 6            # 2 processed scans x 3 topics
+    assert int(kv["same_topics_stamps"]) == 1 and int(kv["same_point_counts"]) == 1
+    assert int(kv["points"]) > 20_000 and int(kv["bit_identical_points"]) > 0.99 * int(kv["points"])
+    assert float(kv["max_abs_diff"]) < 2e-5, kv
