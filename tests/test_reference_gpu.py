@@ -298,3 +298,45 @@ def test_ros_node_seam_gpu_node_equals_reference_node(gpu_ctx, tmp_path):
     assert int(kv["same_topics_stamps"]) == 1 and int(kv["same_point_counts"]) == 1
     assert int(kv["points"]) > 20_000 and int(kv["bit_identical_points"]) > 0.99 * int(kv["points"])
     assert float(kv["max_abs_diff"]) < 2e-5, kv
+
+
+def test_ros_node_seam_livox_chain(gpu_ctx, tmp_path):
+    """The Livox chain at the ROS-node seam, in C++: the reference's FormatConvert + Preprocessing nodes (both compiled unmodified)
+    next to ONE node that converts the CustomMsg into device memory (lili_livox_custom_to_cloud), integrates the gyro
+    (lili_imu_integrate) and extracts from the device cloud (lili_extract_livox): same messages in, the same six messages out —
+    payload (x, y, z, intensity, curvature) of every point bit-identical, stored normals within 2e-6 up to sign
+    (oracle/refshim/ref_seam_livox.cpp -> oracle/_ref/seam_livox_check)."""
+    import subprocess
+    from lili_om_amd import synth
+    exe = os.path.abspath(os.path.join(os.path.dirname(G), "..", "oracle", "_ref", "seam_livox_check"))
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/seam_livox_check not built")
+    rng = np.random.default_rng(17)
+    stamps = 70.0 + 0.1 * np.arange(4)
+    imu_t = 69.97 + 0.005 * np.arange(100)
+    gyr = 0.2 * rng.standard_normal((100, 3)) + np.array([0.1, -0.05, 0.3])
+    f = tmp_path / "livox.bin"
+    dt = np.dtype([("offset_time", "<u4"), ("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("reflectivity", "u1"), ("tag", "u1"), ("line", "u1")])
+    with open(f, "wb") as fh:
+        fh.write(np.array([4, len(imu_t)], np.int32).tobytes())
+        for k in range(4):
+            s = synth.make_livox_scan(80 + k, inject_bad=False)                 # x y z intensity(line + 0.1 t) curvature(0.1 refl)
+            line = np.floor(s[:, 3]).astype(np.int64)
+            tfrac = np.clip((s[:, 3] - line) / 0.1, 0.0, 1.0)
+            order = np.argsort(tfrac, kind="stable")                            # CustomMsg points arrive in time order
+            pts = np.zeros(s.shape[0], dt)
+            pts["offset_time"] = np.round(tfrac[order] * 99_000_000).astype(np.uint32)
+            pts["x"], pts["y"], pts["z"] = s[order, 0], s[order, 1], s[order, 2]
+            pts["reflectivity"] = np.clip(np.round(s[order, 4] * 10), 0, 255).astype(np.uint8)
+            pts["line"] = np.clip(line[order], 0, 5).astype(np.uint8)
+            fh.write(np.float64(stamps[k]).tobytes()); fh.write(np.int32(pts.shape[0]).tobytes()); fh.write(pts.tobytes())
+        fh.write(np.ascontiguousarray(imu_t, np.float64).tobytes()); fh.write(np.ascontiguousarray(gyr, np.float64).tobytes())
+    assert dt.itemsize == 19
+    out = subprocess.run([exe, str(f)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    kv = dict(line.split("=", 1) for line in out.stdout.strip().splitlines() if "=" in line)
+    assert "error" not in kv, kv
+    assert int(kv["messages_reference"]) == int(kv["messages_gpu"]) == 6
+    assert int(kv["same_topics_stamps"]) == 1 and int(kv["same_point_counts"]) == 1
+    assert int(kv["points"]) > 60_000 and int(kv["bit_identical_payload"]) == int(kv["points"]), kv
+    assert float(kv["max_abs_normal_diff"]) < 2e-6, kv
