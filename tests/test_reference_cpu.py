@@ -375,3 +375,30 @@ def test_reference_backend_association_random_scenes(oracle, flavour, seed):
         rows_e = oracle.linearize_rows(re_, t0, q0, raw, se, "edge")
         # the reference builds the edge factor from ITS (A, B) order; the residual is symmetric in A <-> B, bit for bit
         assert np.array_equal(np.c_[rows_e[:, 7], rows_e[:, :7]], erows)
+
+
+@needs_ref
+@pytest.mark.parametrize("seed,match_cnt", [(300, 3), (400, 5)])
+def test_reference_frontend_node_other_sequences(oracle, seed, match_cnt):
+    """The front-end loop on oracle primitives against the reference's LidarOdometry node, live, on other sequences and
+    scan_match_cnt settings than the committed fixture: poses, residual-block counts and every solve's step bit for bit."""
+    from tests import frontend_chain as F
+    from tests import seq_harness as H
+    n = 5
+    frames = H.make_frames(n + 2, seed=seed)
+    stamps = 40.0 + 0.1 * np.arange(n + 2)
+    imu_t = 39.97 + 0.005 * np.arange(20 * (n + 2) + 20)
+    gyr = np.zeros((imu_t.shape[0], 3))
+    pre = M.R.run_scans("livox", M.LIVOX_PARAMS, frames, stamps, imu_t, gyr)
+    params = dict(M.FRONTEND_PARAMS)
+    params["/lidar_odometry/scan_match_cnt"] = match_cnt
+    lo = M.R.LidarOdometry(params)
+    ref_abs = np.array([lo.frame(o["stamp"], o["edge"], o["surf"], o["cutted"])[0] for o in pre])
+    S = lo.solves()
+    lo.close()
+    surf = [o["surf"][:, [0, 1, 2, 9]] for o in pre]                      # x y z curvature of the 48-byte rows the Livox node published
+    be = F.OracleBackend(oracle, stable=False)
+    a, _ = F.run_frontend_chain(be, surf, scan_match_cnt=match_cnt)
+    assert np.array_equal(a, ref_abs)
+    assert len(be.log) == len(S) and [l["n_blocks"] for l in be.log] == [len(s["records"]) for s in S]
+    assert all(np.array_equal(l["pose_out"], s["pose_out"]) for l, s in zip(be.log, S))
