@@ -528,6 +528,20 @@ def assoc_transform(t, q, params):
     return Q2, np.asarray(t, np.float64) - rot
 
 
+def keyframe_map_pose(t_po, q_po, t_bl, q_bl):
+    """Pose a stored keyframe's features are moved by when they enter the local map: (q_po * q_bl, q_po * t_bl + t_po),
+    L/src/BackendFusion.cpp:1425-1426, 1462-1463 (host-side pose algebra, f64).  Returns (t, q) as LocalMap.push takes them."""
+    a, b = np.asarray(q_po, np.float64), np.asarray(q_bl, np.float64)
+    q = np.array([a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3],
+                  a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                  a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3],
+                  a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1]])
+    u, v = a[1:4], np.asarray(t_bl, np.float64)
+    uv = np.cross(u, v)
+    uv = uv + uv
+    return (v + uv * a[0]) + np.cross(u, uv) + np.asarray(t_po, np.float64), q
+
+
 def body_pose_from_lidar(t_lidar, q_lidar, params):
     """Body pose (T, Q) whose association transform (Q*q_lb^-1, T - Q2*t_lb) equals the given LiDAR pose
     (up to the non-unit norm of the configured q_lb, which the reference does not normalise either)."""

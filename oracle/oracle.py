@@ -449,3 +449,71 @@ def linearize_rows(rec, t, q, P, scale=1.0, kind="surf"):
         lib().lo_rows_edge(_p(rec["valid"]), _p(rec["cp"]), _p(rec["a"]), _p(rec["b"]), _p(rec["s"]), n, _p(t), _p(q),
                            C.byref(P), C.c_double(_scale(scale)[0]), _scale(scale)[1], _p(rows), C.byref(cnt))
     return rows[:cnt.value]
+
+
+def _qmul(a, b):
+    """Eigen quaternion product, generic path (w, x, y, z), evaluated left to right."""
+    aw, ax, ay, az = (float(v) for v in a)
+    bw, bx, by, bz = (float(v) for v in b)
+    return np.array([aw * bw - ax * bx - ay * by - az * bz,
+                     aw * bx + ax * bw + ay * bz - az * by,
+                     aw * by + ay * bw + az * bx - ax * bz,
+                     aw * bz + az * bw + ax * by - ay * bx], np.float64)
+
+
+def transform_cloud(pts_xyza, q, t):
+    """transformCloud (L/src/BackendFusion.cpp:730-767): f32 point -> f64, q * p + t with Eigen's _transformVector
+    (uv = 2 u x p; p + w uv + u x uv), -> f32; the aux column (curvature) rides along."""
+    pts = _f32(pts_xyza, 4)
+    q, t = _f64(q), _f64(t)
+    v = pts[:, :3].astype(np.float64)
+    u = q[1:4]
+    uv = np.cross(u, v)
+    uv = uv + uv
+    w = (v + uv * q[0]) + np.cross(u, uv)
+    out = pts.copy()
+    out[:, :3] = (w + t).astype(np.float32)
+    return out
+
+
+class LocalMapAssembly:
+    """buildLocalMapWithLandMark + downSampleCloud (L/src/BackendFusion.cpp:1387-1484, 1486-1511) for one feature kind:
+    keyframe(features) -> (local map after VoxelGrid(map_leaf), features after VoxelGrid(leaf)); commit(pose_b) stores the
+    down-sampled features with the body pose (qw qx qy qz x y z), as saveKeyFramesAndFactors (L:1683-1760) does.
+    First keyframe: the map is the keyframe's own RAW features moved by T_bl (L:1390-1404).  While the ring is short it is
+    rebuilt from the newest `width` keyframes (L:1407-1443); once full, the oldest leaves and the newest enters (L:1445-1477)."""
+
+    def __init__(self, width, map_leaf, leaf, q_bl, t_bl, stable=False):
+        self.width, self.map_leaf, self.leaf, self.stable = int(width), float(map_leaf), float(leaf), stable
+        self.q_bl, self.t_bl = _f64(q_bl), _f64(t_bl)
+        self.frames, self.poses, self.recent, self.latest, self._last_ds = [], [], [], 0, None
+
+    def lidar_pose(self, pose_b):
+        q_po, t_po = _f64(pose_b[:4]), _f64(pose_b[4:7])
+        return _qmul(q_po, self.q_bl), qrot(q_po, self.t_bl) + t_po                       # L:1425-1426 / 1462-1463
+
+    def keyframe(self, feats_xyza):
+        feats = _f32(feats_xyza, 4)
+        if not self.poses:
+            raw = transform_cloud(feats, self.q_bl, self.t_bl)
+        else:
+            if len(self.recent) < self.width:
+                self.recent = []
+                for i in range(len(self.poses) - 1, -1, -1):
+                    q, t = self.lidar_pose(self.poses[i])
+                    self.recent.insert(0, transform_cloud(self.frames[i], q, t))
+                    if len(self.recent) >= self.width:
+                        break
+            elif self.latest != len(self.poses) - 1:
+                self.recent.pop(0)
+                self.latest = len(self.poses) - 1
+                q, t = self.lidar_pose(self.poses[self.latest])
+                self.recent.append(transform_cloud(self.frames[self.latest], q, t))
+            raw = np.concatenate(self.recent, 0) if self.recent else np.zeros((0, 4), np.float32)
+        self.raw = raw
+        self._last_ds = voxel_grid(feats, self.leaf, stable=self.stable)[0]
+        return voxel_grid(raw, self.map_leaf, stable=self.stable)[0], self._last_ds
+
+    def commit(self, pose_b):
+        self.frames.append(self._last_ds.copy())
+        self.poses.append(_f64(pose_b))

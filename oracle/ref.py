@@ -25,7 +25,7 @@ def build():
 
 
 def available():
-    return all(os.path.exists(os.path.join(REF_DIR, f"libref_{n}.so")) for n in ("rot", "livox", "factors", "lo", "backend_L", "backend_R", "format", "marg"))
+    return all(os.path.exists(os.path.join(REF_DIR, f"libref_{n}.so")) for n in ("rot", "livox", "factors", "lo", "backend_L", "backend_R", "format", "marg", "localmap"))
 
 
 def _lib(name):
@@ -279,3 +279,43 @@ def marg_lidar(surf_rec, edge_rec, qlb, tlb, t, q, pos, idx_t, idx_q):
     L.ref_marg_lidar(_p(s), s.shape[0], _p(e), e.shape[0], _p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), int(pos), int(idx_t), int(idx_q),
                      _p(rows), _p(A), _p(b))
     return rows[:s.shape[0] + e.shape[0]], A, b
+
+
+class LocalMapSlice:
+    """The back-end's local-map assembly from the reference text (transformCloud / buildLocalMapWithLandMark /
+    downSampleCloud, L/src/BackendFusion.cpp:730-767, 1387-1484, 1486-1528; oracle/refshim/ref_localmap.cpp).
+    keyframe(surf4, edge4) -> the four down-sampled clouds the matcher sees for this keyframe (x y z curvature rows):
+    surf map, edge map, surf_last_ds, edge_last_ds; commit(pose_b) records the keyframe with its optimised body pose
+    (qw qx qy qz x y z), as saveKeyFramesAndFactors does, before the next one arrives."""
+
+    def __init__(self, local_map_width, surf_map_leaf, edge_map_leaf, surf_leaf, edge_leaf, q_bl, t_bl):
+        L = self.lib = _lib("localmap")
+        L.ref_lm_create.restype = C.c_void_p
+        L.ref_lm_create.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+        L.ref_lm_destroy.argtypes = [C.c_void_p]
+        L.ref_lm_keyframe.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.ref_lm_get.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        L.ref_lm_commit.argtypes = [C.c_void_p, C.c_void_p]
+        q, t = np.ascontiguousarray(q_bl, np.float64), np.ascontiguousarray(t_bl, np.float64)
+        self.h = L.ref_lm_create(int(local_map_width), surf_map_leaf, edge_map_leaf, surf_leaf, edge_leaf, _p(q), _p(t))
+
+    def close(self):
+        if self.h:
+            self.lib.ref_lm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def keyframe(self, surf4, edge4):
+        s, e = np.ascontiguousarray(surf4, np.float32), np.ascontiguousarray(edge4, np.float32)
+        sizes = np.zeros(4, np.int32)
+        self.lib.ref_lm_keyframe(self.h, _p(s), s.shape[0], _p(e), e.shape[0], _p(sizes))
+        outs = [np.zeros((int(n), 4), np.float32) for n in sizes]
+        self.lib.ref_lm_get(self.h, *[_p(o) for o in outs])
+        return dict(surf_map=outs[0], edge_map=outs[1], surf_ds=outs[2], edge_ds=outs[3])
+
+    def commit(self, pose_b):
+        p = np.ascontiguousarray(pose_b, np.float64)
+        assert p.shape == (7,)
+        self.lib.ref_lm_commit(self.h, _p(p))

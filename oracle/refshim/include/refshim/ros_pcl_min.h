@@ -46,6 +46,7 @@ struct Time {
     Time() {}
     explicit Time(double sec) : t(sec) {}
     double toSec() const { return t; }
+    Time& fromSec(double sec) { t = sec; return *this; }
 };
 struct Subscriber {};
 struct Publisher {

@@ -232,6 +232,37 @@ def run_marg():
     return dict(n_rows=rows.shape[0], rows_sha=sha(rows), rows_every8=rows[::8], A=A, b=b)
 
 
+LM_WIDTH, LM_SURF_MAP_LEAF, LM_EDGE_MAP_LEAF, LM_SURF_LEAF, LM_EDGE_LEAF = 3, 0.4, 0.2, 0.4, 0.2
+
+
+def localmap_inputs(n_kf=7, n_surf=900, n_edge=160, seed=41):
+    """Keyframes of a small room (many multi-point voxels at these leaves), body poses along a gentle curve, a tilted extrinsic."""
+    rng = np.random.default_rng(seed)
+    q_bl = np.array([0.98, 0.05, -0.12, 0.1]); q_bl /= np.linalg.norm(q_bl)
+    t_bl = np.array([0.05, -0.02, 0.11])
+    surf, edge, poses = [], [], []
+    for k in range(n_kf):
+        surf.append(np.concatenate([rng.uniform(-3, 3, (n_surf, 2)), rng.normal(0, 0.3, (n_surf, 1)), rng.uniform(0, 25, (n_surf, 1))], 1).astype(np.float32))
+        edge.append(np.concatenate([rng.uniform(-3, 3, (n_edge, 3)), rng.uniform(0, 25, (n_edge, 1))], 1).astype(np.float32))
+        ang = 0.07 * k
+        q = np.array([np.cos(ang / 2), 0.02 * k, -0.01 * k, np.sin(ang / 2)]); q /= np.linalg.norm(q)
+        poses.append(np.concatenate([q, [0.4 * k, -0.15 * k, 0.03 * k]]))
+    return dict(q_bl=q_bl, t_bl=t_bl, surf=surf, edge=edge, poses=poses)
+
+
+def run_localmap():
+    i = localmap_inputs()
+    lm = R.LocalMapSlice(LM_WIDTH, LM_SURF_MAP_LEAF, LM_EDGE_MAP_LEAF, LM_SURF_LEAF, LM_EDGE_LEAF, i["q_bl"], i["t_bl"])
+    out = {}
+    for k, (s, e, p) in enumerate(zip(i["surf"], i["edge"], i["poses"])):
+        r = lm.keyframe(s, e)
+        for name, a in r.items():
+            out[f"kf{k}_{name}"] = a
+        lm.commit(p)
+    lm.close()
+    return out
+
+
 def run_factors():
     f = factor_inputs()
     n = f["cp"].shape[0]
@@ -253,7 +284,8 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ref_backend.npz"), **run_backend())
     np.savez_compressed(os.path.join(HERE, "ref_format.npz"), **run_format())
     np.savez_compressed(os.path.join(HERE, "ref_marg.npz"), **run_marg())
-    for f in ("ref_rot.npz", "ref_livox.npz", "ref_factors.npz", "ref_frontend.npz", "ref_backend.npz", "ref_format.npz", "ref_marg.npz"):
+    np.savez_compressed(os.path.join(HERE, "ref_localmap.npz"), **run_localmap())
+    for f in ("ref_rot.npz", "ref_livox.npz", "ref_factors.npz", "ref_frontend.npz", "ref_backend.npz", "ref_format.npz", "ref_marg.npz", "ref_localmap.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

@@ -41,12 +41,12 @@ def _same_npz(d, g):
 
 
 # ------------------------------------------------------------------ the reference build itself
-@pytest.mark.parametrize("which", ["rot", "livox", "factors", "frontend", "backend", "format", "marg"])
+@pytest.mark.parametrize("which", ["rot", "livox", "factors", "frontend", "backend", "format", "marg", "localmap"])
 def test_reference_build_reproduces_fixtures(which):
     if not M.R.available():
         pytest.skip("oracle/_ref not built (needs /root/reference; build container only)")
     d = {"rot": M.run_rot, "livox": M.run_livox, "factors": M.run_factors, "frontend": M.run_frontend, "backend": M.run_backend, "format": M.run_format,
-         "marg": M.run_marg}[which]()
+         "marg": M.run_marg, "localmap": M.run_localmap}[which]()
     _same_npz(d, np.load(os.path.join(G, f"ref_{which}.npz")))
 
 
@@ -205,6 +205,32 @@ def test_oracle_association_equals_reference_backend(oracle, flavour):
     rows_e = oracle.linearize_rows(re_, i["t0"], i["q0"], raw, se, "edge")
     assert np.array_equal(np.c_[rows_s[:, 7], rows_s[:, :7]], g[f"{flavour}_surf_rows"])
     assert np.array_equal(np.c_[rows_e[:, 7], rows_e[:, :7]], g[f"{flavour}_edge_rows"])
+
+
+# ------------------------------------------------------------------ local-map assembly
+def test_oracle_local_map_equals_reference_backend(oracle):
+    """transformCloud / buildLocalMapWithLandMark / downSampleCloud compiled from the reference text (7 keyframes through a ring of 3,
+    tilted extrinsic) vs the numpy restatement: the down-sampled surf / edge maps and keyframe features of every keyframe, bit for bit —
+    the first-keyframe special case (own raw features moved by T_bl), the rebuild-while-short branch, the pop/push branch, the
+    q_po * q_bl composition and the f64 -> f32 rounding of the moved points."""
+    g = np.load(os.path.join(G, "ref_localmap.npz"))
+    i = M.localmap_inputs()
+    os_ = oracle.LocalMapAssembly(M.LM_WIDTH, M.LM_SURF_MAP_LEAF, M.LM_SURF_LEAF, i["q_bl"], i["t_bl"])
+    oe = oracle.LocalMapAssembly(M.LM_WIDTH, M.LM_EDGE_MAP_LEAF, M.LM_EDGE_LEAF, i["q_bl"], i["t_bl"])
+    sizes = []
+    for k, (s, e, p) in enumerate(zip(i["surf"], i["edge"], i["poses"])):
+        ms, ds = os_.keyframe(s)
+        me, de = oe.keyframe(e)
+        for name, a in (("surf_map", ms), ("edge_map", me), ("surf_ds", ds), ("edge_ds", de)):
+            b = g[f"kf{k}_{name}"]
+            assert a.shape == b.shape and np.array_equal(_bits(a), _bits(b)), (k, name)
+        sizes.append(os_.raw.shape[0])
+        os_.commit(p)
+        oe.commit(p)
+    # before the filter: the first keyframe's own raw features, then the down-sampled features of the newest <= width earlier keyframes
+    ds_n = [g[f"kf{k}_surf_ds"].shape[0] for k in range(len(sizes))]
+    assert sizes == [900] + [sum(ds_n[max(0, k - M.LM_WIDTH):k]) for k in range(1, len(sizes))]
+    assert len(os_.recent) == M.LM_WIDTH
 
 
 # ------------------------------------------------------------------ wire format and marginalisation feed vs oracle / product
@@ -402,3 +428,29 @@ def test_reference_frontend_node_other_sequences(oracle, seed, match_cnt):
     assert np.array_equal(a, ref_abs)
     assert len(be.log) == len(S) and [l["n_blocks"] for l in be.log] == [len(s["records"]) for s in S]
     assert all(np.array_equal(l["pose_out"], s["pose_out"]) for l, s in zip(be.log, S))
+
+
+@needs_ref
+@pytest.mark.parametrize("width,seed", [(1, 5), (2, 6), (5, 7)])
+def test_reference_local_map_other_widths(oracle, width, seed):
+    """Live differential run of the local-map slice at other ring widths (1 = always the previous keyframe only), random poses,
+    keyframes of different sizes including an empty edge cloud."""
+    rng = np.random.default_rng(seed)
+    q_bl = rng.normal(size=4); q_bl /= np.linalg.norm(q_bl)
+    t_bl = rng.uniform(-0.2, 0.2, 3)
+    lm = M.R.LocalMapSlice(width, 0.4, 0.2, 0.4, 0.2, q_bl, t_bl)
+    os_ = oracle.LocalMapAssembly(width, 0.4, 0.4, q_bl, t_bl)
+    oe = oracle.LocalMapAssembly(width, 0.2, 0.2, q_bl, t_bl)
+    for k in range(width + 4):
+        ns, ne = int(rng.integers(200, 1500)), (0 if k == 2 else int(rng.integers(20, 200)))
+        s = np.concatenate([rng.uniform(-4, 4, (ns, 3)), rng.uniform(0, 25, (ns, 1))], 1).astype(np.float32)
+        e = np.concatenate([rng.uniform(-4, 4, (ne, 3)), rng.uniform(0, 25, (ne, 1))], 1).astype(np.float32)
+        r = lm.keyframe(s, e)
+        ms, ds = os_.keyframe(s)
+        me, de = oe.keyframe(e)
+        for a, b in ((r["surf_map"], ms), (r["edge_map"], me), (r["surf_ds"], ds), (r["edge_ds"], de)):
+            assert a.shape == b.shape and np.array_equal(_bits(a), _bits(b)), k
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        pose = np.concatenate([q, rng.uniform(-2, 2, 3)])
+        lm.commit(pose); os_.commit(pose); oe.commit(pose)
+    lm.close()

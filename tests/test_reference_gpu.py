@@ -216,6 +216,55 @@ def test_gpu_format_convert_vs_reference(gpu_ctx):
     assert np.array_equal(_bits(L.api.livox_custom_to_cloud(gpu_ctx, zero)), _bits(g["zero_case"]))
 
 
+@pytest.mark.parametrize("kind,name,map_leaf,leaf", [(L.KIND_SURF, "surf", M.LM_SURF_MAP_LEAF, M.LM_SURF_LEAF), (L.KIND_EDGE, "edge", M.LM_EDGE_MAP_LEAF, M.LM_EDGE_LEAF)])
+def test_gpu_local_map_vs_reference_backend(gpu_ctx, kind, name, map_leaf, leaf):
+    """lili_localmap_push / _commit (device ring buffer + transform + VoxelGrid + map index) fed the way INTEGRATION.md binds
+    buildLocalMapWithLandMark, vs the maps the reference's own text produced for the same 7 keyframes (tests/golden/ref_localmap.npz).
+    The device map is read back through the matcher: every reference map point, used as a query at the identity pose, must find ITSELF
+    (same index = same voxel order) at distance 0; points of >= 3-point voxels may differ in the last bit of the centroid (PCL's unstable
+    sort chooses the summation order), hence the 1e-11 m^2 allowance on a minority of points."""
+    g = np.load(os.path.join(G, "ref_localmap.npz"))
+    i = M.localmap_inputs()
+    feats = i[name]
+    P = L.make_params("livox")
+    m = L.ScanToMapMatcher(gpu_ctx, P)
+    gpu_ctx.set_debug(True)
+    find = m.find_corresponding_surf_features if kind == L.KIND_SURF else m.find_corresponding_corner_features
+    ident_q, ident_t = np.array([1.0, 0, 0, 0]), np.zeros(3)
+
+    def check(ref_map, n_map):
+        assert n_map == ref_map.shape[0]
+        m.set_queries(0, kind, np.ascontiguousarray(ref_map[:, :3]))
+        find(0, ident_q, ident_t)
+        idx, d2 = m.neighbors(0, kind, ref_map.shape[0])
+        assert np.array_equal(idx[:, 0], np.arange(ref_map.shape[0]))
+        assert d2[:, 0].max() < 1e-11 and (d2[:, 0] == 0).mean() > 0.75
+
+    # first keyframe: its own raw features moved by T_bl (L:1390-1404)
+    lm = L.LocalMap(gpu_ctx, kind, width=M.LM_WIDTH, leaf=map_leaf)
+    lm.push(feats[0], i["t_bl"], i["q_bl"])
+    n_raw, n_map = lm.commit()
+    assert n_raw == feats[0].shape[0]
+    check(g[f"kf0_{name}_map"], n_map)
+    # from then on: the down-sampled features of the previous keyframes under their optimised poses, ring of local_map_width
+    lm = L.LocalMap(gpu_ctx, kind, width=M.LM_WIDTH, leaf=map_leaf)
+    for k in range(1, len(feats)):
+        ds_prev = g[f"kf{k - 1}_{name}_ds"]
+        t, q = L.api.keyframe_map_pose(i["poses"][k - 1][4:7], i["poses"][k - 1][:4], i["t_bl"], i["q_bl"])
+        lm.push(ds_prev, t, q)
+        n_raw, n_map = lm.commit()
+        assert n_raw == sum(g[f"kf{j}_{name}_ds"].shape[0] for j in range(max(0, k - M.LM_WIDTH), k))
+        check(g[f"kf{k}_{name}_map"], n_map)
+    # the keyframe's own down-sampling (ds_filter_surf / ds_filter_edge, L:1502-1511)
+    for k in range(len(feats)):
+        ds, cnt = L.api.voxel_filter(gpu_ctx, feats[k], leaf)
+        ref = g[f"kf{k}_{name}_ds"]
+        assert ds.shape == ref.shape
+        same = (_bits(ds) == _bits(ref)).all(1)
+        assert same[cnt <= 2].all() and same.mean() > 0.85
+        np.testing.assert_allclose(ds, ref, rtol=1e-6, atol=1e-5)
+
+
 def test_gpu_marginalisation_feed_vs_reference(gpu_ctx):
     """lili_s2m_linearize + lili_marg_add_lidar on the GPU's own records of the ref_backend Livox keyframe vs the A, b the
     reference's ResidualBlockInfo::Evaluate + ThreadsConstructA build from the reference's records (f32-record tolerance)."""
