@@ -108,3 +108,20 @@ def test_gram_to_factor_reproduces_normal_equations():
         assert np.abs(jac.T @ res - G[:7, 7]).max() <= 1e-12 * scale
         assert abs(0.5 * res @ res - cost) <= 1e-12 * max(cost, 1.0)
         assert not jac[8].any()
+
+
+def test_keyframe_map_pose_is_the_reference_composition():
+    """lili_om_amd.api.keyframe_map_pose (host-side pose algebra of the local-map binding) vs the oracle's restatement of
+    L/src/BackendFusion.cpp:1425-1426, itself pinned to the reference text by tests/test_reference_cpu.py: bit for bit."""
+    import numpy as np
+    from lili_om_amd import api
+    from oracle import oracle
+    rng = np.random.default_rng(8)
+    for _ in range(50):
+        q_po, q_bl = rng.normal(size=4), rng.normal(size=4)
+        q_po /= np.linalg.norm(q_po)
+        t_po, t_bl = rng.uniform(-50, 50, 3), rng.uniform(-0.5, 0.5, 3)
+        asm = oracle.LocalMapAssembly(3, 0.4, 0.4, q_bl, t_bl)
+        q_ref, t_ref = asm.lidar_pose(np.concatenate([q_po, t_po]))
+        t, q = api.keyframe_map_pose(t_po, q_po, t_bl, q_bl)
+        assert q.tobytes() == q_ref.tobytes() and t.tobytes() == t_ref.tobytes()
