@@ -434,13 +434,22 @@ struct RowTabT {
 // every point outside the inner block is at least `margin` away (margin = one cell + the query's gap to the nearest
 // face of its own cell), so worst < 0.999 * margin^2 makes the shell irrelevant.  All bounds are conservative by
 // 0.1 % against f32 rounding of the distances; ties (d == worst) never skip.
+// Profiling aid, compiled only with -DLILI_PHASE_PROBE (tools/assoc_phases.sh builds such a copy of the library; the product
+// build has none of it): s_memrealtime stamps (100 MHz) of one wave at the phase boundaries of the association.  `dep` is a value
+// the phase produced, so that the stamp cannot be taken before it exists.
+struct PhaseProbe { long long t[8]; };
+#ifdef LILI_PHASE_PROBE
+#define PHASE_STAMP(pp, k, dep) do { if (pp) { long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(dep) : "memory"); (pp)->t[k] = t_; } } while (0)
+#else
+#define PHASE_STAMP(pp, k, dep) do {} while (0)
+#endif
 __device__ __forceinline__ float gate_bound(double gate) {   // smallest f32 >= gate
     float gf = (float)gate;
     if ((double)gf < gate) gf = __uint_as_float(__float_as_uint(gf) + 1u);
     return gf;
 }
 template <class SEL, class TAB>
-__device__ __forceinline__ bool knn5_grid_sel(const GridView& g, TAB& tab, float qx, float qy, float qz, float bound, Top5& best) {
+__device__ __forceinline__ bool knn5_grid_sel(const GridView& g, TAB& tab, float qx, float qy, float qz, float bound, Top5& best, PhaseProbe* pp = nullptr) {
     SEL sel; sel.init(bound);
     sel.to_top5(best);
     if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) return false;
@@ -479,6 +488,7 @@ __device__ __forceinline__ bool knn5_grid_sel(const GridView& g, TAB& tab, float
             // and the four loads of the next chunk are issued before the current chunk is processed.  The row for the
             // next chunk is chosen with the 5th-best distance of one chunk ago: a stale (larger) value can only keep a
             // row that the fresh one would prune — extra candidates, never a missing one.
+            PHASE_STAMP(pp, 2, cnt);                                        // row ranges loaded, table written
             int n = 0, cj = 0, ce = 0;
             auto fetch = [&](float wv, float4& p0, float4& p1, float4& p2, float4& p3, int& pj, int& pe) {
                 while (cj >= ce && n < cnt) {
@@ -508,6 +518,7 @@ __device__ __forceinline__ bool knn5_grid_sel(const GridView& g, TAB& tab, float
             }
         }
     }
+    PHASE_STAMP(pp, 3, sel.worst());                                        // inner 3x3x3 block walked
     if (R == 2) {
         const double c = g.cell;
         const double fxm = (double)qx - (g.ox + (double)cx * c), fxp = (g.ox + (double)(cx + 1) * c) - (double)qx;
@@ -543,15 +554,17 @@ __device__ __forceinline__ bool knn5_grid_sel(const GridView& g, TAB& tab, float
             }
         }
     }
+    PHASE_STAMP(pp, 4, sel.worst());                                        // shell decided / walked
     if constexpr (std::is_same<SEL, Sel5K>::value) return sel.finish(g, qx, qy, qz, best);
     else { sel.to_top5(best); return sel.final_tie(); }
 }
 // Fast selection first; the rare queries with an exact distance tie that could matter are repeated with the exact
 // (distance, original index) selector, so the result is always the oracle's.
 template <class TAB>
-__device__ __forceinline__ void knn5_grid(const GridView& g, TAB& tab, float qx, float qy, float qz, float bound, Top5& best, int dbg = 0) {
+__device__ __forceinline__ void knn5_grid(const GridView& g, TAB& tab, float qx, float qy, float qz, float bound, Top5& best, int dbg = 0, PhaseProbe* pp = nullptr) {
     if (dbg & 32768) { knn5_grid_sel<Sel5>(g, tab, qx, qy, qz, bound, best); return; }   // A/B: exact selector only
-    const bool redo = knn5_grid_sel<Sel5K>(g, tab, qx, qy, qz, bound, best);
+    const bool redo = knn5_grid_sel<Sel5K>(g, tab, qx, qy, qz, bound, best, pp);
+    PHASE_STAMP(pp, 5, best.d[4]);                                          // five winners resolved (exact distances, order)
     if (redo && !(dbg & 8192)) knn5_grid_sel<Sel5>(g, tab, qx, qy, qz, bound, best);   // bit 8192: profiling only (results then inexact on ties)
 }
 
@@ -935,11 +948,20 @@ __global__ __launch_bounds__(BS) void k_associate_surf(
     d3 pmd = qrot(Q2, d3{(double)ql.x, (double)ql.y, (double)ql.z}) + T2;   // transformPoint, L:695-711
     float px = (float)pmd.x, py = (float)pmd.y, pz = (float)pmd.z;
     Top5 nn; nn.aux = 0;
+#ifdef LILI_PHASE_PROBE
+    PhaseProbe probe;
+#pragma unroll
+    for (int k = 0; k < 8; k++) probe.t[k] = 0;
+    PhaseProbe* const pp = &probe;
+#else
+    PhaseProbe* const pp = nullptr;
+#endif
+    PHASE_STAMP(pp, 1, px);                                                 // query loaded and moved into the map frame
     if (P.debug & 2) {
 #pragma unroll
         for (int k = 0; k < 5; k++) { nn.d[k] = 0.01f * (k + 1); nn.j[k] = (i * 7 + k) % g.n_points; }
     } else if (TILED) knn5_tiled(g, L, tab, live, px, py, pz, nn, P.debug);
-    else if (live) { knn5_grid(g, tab, px, py, pz, seeded_bound(g, P.kd_max_radius, nn_cache, n_q, i, px, py, pz), nn, P.debug); store_nn_cache(nn_cache, n_q, i, nn); }
+    else if (live) { knn5_grid(g, tab, px, py, pz, seeded_bound(g, P.kd_max_radius, nn_cache, n_q, i, px, py, pz), nn, P.debug, pp); store_nn_cache(nn_cache, n_q, i, nn); }
     if (BS == 64 && !TILED && sched.block_cost) {   // cost of this block for the next launch's dispatch order
         int c = live ? nn.aux : 0;
 #pragma unroll
@@ -951,11 +973,17 @@ __global__ __launch_bounds__(BS) void k_associate_surf(
         store_debug_nn(g, nn, i, dbg_idx, dbg_d2);
         float4 rn; double score;
         ok = surf_fit(g, P, nn, ql, px, py, pz, rn, score);
+        PHASE_STAMP(pp, 6, rn.w);                                           // plane fitted, gates evaluated
         rec_nd[i] = rn;
         rec_score[i] = score;
         valid[i] = ok ? 1 : 0;
     }
     store_block_count<BS>(ok, block_counts);
+#ifdef LILI_PHASE_PROBE
+    if ((P.debug & 4096) && dbg_d2 && threadIdx.x == 0) {   // phase stamps as ticks since the block began, over the d2 debug rows of the block's first two queries
+        for (int k = 1; k <= 6; k++) dbg_d2[(size_t)tile.x * 5 + k] = probe.t[k] ? (float)(probe.t[k] - t_begin) : -1.0f;
+    }
+#endif
     if ((P.debug & 4096) && dbg_idx && threadIdx.x == 0) {   // per-workgroup begin / end ticks (100 MHz) and hardware id into the debug rows of the block's first query
         long long* o = (long long*)(dbg_idx + (size_t)tile.x * 5);
         unsigned hw, xcc;

@@ -15,7 +15,8 @@ import bench  # noqa: E402
 
 after = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 extra = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-w = synth.make_workload(n_map=bench.N_MAP, n_az=bench.N_AZ, half_extent=(460.0, 380.0))
+n_az = int(os.environ.get("LILI_N_AZ", bench.N_AZ))   # 3125 azimuth steps x 64 rings = the 200 k-point scan; other values scale the query count
+w = synth.make_workload(n_map=bench.N_MAP, n_az=n_az, half_extent=(460.0, 380.0))
 P = L.make_params("rot")
 t_body, q_body = bench.body_pose_for_lidar(L, P, w["lidar_t"])
 t0, q0 = synth.perturbed_pose(t_body, q_body, np.random.default_rng(synth.SEED_POSE), 0.3, 2.0)
@@ -34,7 +35,7 @@ if len(sys.argv) > 3:
 for rep in range(5):
     m.associate_dev(0, L.MASK_SURF)
     ctx.sync()
-idx, _ = m.neighbors(0, L.KIND_SURF, scan.shape[0])
+idx, d2dbg = m.neighbors(0, L.KIND_SURF, scan.shape[0])
 nb = (scan.shape[0] + 63) // 64
 rows = idx[::64][:nb].copy()                      # (nb, 5) int32: t_begin lo/hi, t_end lo/hi, hw
 tb = rows[:, 0:2].copy().view(np.int64)[:, 0]
@@ -74,5 +75,26 @@ print("chunks per query: mean %.2f p50 %d p90 %d p99 %d max %d" % (tcq[tcq > 0].
 print("per wave: max-lane chunks mean %.2f p50 %d p90 %d p99 %d max %d ; mean-lane chunks mean %.2f" % (tcb.mean(), *np.percentile(tcb, [50, 90, 99]), tcb.max(), tcm.mean()))
 print("corr(wave lifetime, max-lane chunks) = %.3f" % np.corrcoef(dur, tcb)[0, 1])
 print("slowest blocks max-lane chunks:", [(int(b), int(tcb[b]), round(float(tcm[b]), 1)) for b in order])
+if os.environ.get("LILI_PHASE_PROBE"):
+    # library built with -DLILI_PHASE_PROBE (tools/assoc_phases.sh): ticks since the block began at the phase boundaries, in the d2 debug
+    # floats 1..6 of the block's first query (spilling into the second query's row)
+    flat = d2dbg.reshape(-1)
+    ph = np.stack([flat[b * 64 * 5 + 1: b * 64 * 5 + 7] for b in range(nb)]).astype(np.float64) * 0.01      # us since block begin
+    names = ["query moved into map frame", "row ranges loaded, table built", "inner 3x3x3 block walked", "shell decided / walked",
+             "five winners resolved", "plane fitted"]
+    okb = (ph > 0).all(1)
+    print(f"phase probe: {okb.sum()} of {nb} blocks with all stamps")
+    prev = np.zeros(nb)
+    for k, nm in enumerate(names):
+        seg = ph[:, k] - prev
+        print("  %-34s  at %6.2f us (p50)   segment mean %5.2f  p10 %5.2f  p50 %5.2f  p90 %5.2f  max %5.2f" %
+              (nm, np.median(ph[okb, k]), seg[okb].mean(), *np.percentile(seg[okb], [10, 50, 90]), seg[okb].max()))
+        prev = ph[:, k]
+    seg = dur - prev
+    print("  %-34s  at %6.2f us (p50)   segment mean %5.2f  p10 %5.2f  p50 %5.2f  p90 %5.2f  max %5.2f" %
+          ("records stored, block count", np.median(dur[okb]), seg[okb].mean(), *np.percentile(seg[okb], [10, 50, 90]), seg[okb].max()))
+    slow = np.argsort(-dur)[:5]
+    for b in slow:
+        print("  slow block %5d: lifetime %.1f us, stamps" % (b, dur[b]), np.round(ph[b], 2))
 np.save("gpurun_out/assoc_blocks.npy", np.stack([start, end, key.astype(np.float64)], 1)) if os.path.isdir("gpurun_out") else None
 ctx.close()
