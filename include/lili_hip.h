@@ -90,15 +90,16 @@ int lili_sync(lili_ctx* ctx);
 /* When enabled, associate also stores the 5 neighbour indices / squared distances per query so that
  * lili_s2m_get_neighbors can return them (parity tests).  Off by default (extra HBM writes). */
 int lili_set_debug(lili_ctx* ctx, int keep_neighbors);
-/* Tuning knobs that never change which correspondences are found ("fuse_tail" changes the block partition of the
- * Gram sum, i.e. its rounding at the 1e-16 level; all others are bit-identical): "bin_queries" (1 = order queries by map super-cell once per scan; use it
+/* Tuning knobs that never change any result bit: "bin_queries" (1 = order queries by map super-cell once per scan; use it
  * when the query order is not spatially coherent; default 0), "tiled" (1 = LDS-staged neighbourhood tiles, needs
  * bin_queries; default 0), "max_cells" (cap on grid cells of the map index; coarser cells stay exact),
  * "grid_reach" (1 = cells of the gate radius, 27-cell search; 2 = smaller cells, inner 27 cells first and the shell of
  * the 125-cell block on demand; default 2; takes effect at the next lili_map_set), "cell_pct" (reach 2: cell edge in %
  * of the gate radius, 50..100, default 65), "nn_cache" (1 = tighten each query's search bound with its neighbours of
- * the previous association of the same scan; default 0, measured slower), "fuse_tail" (1 = reduce + GN update inside
- * the last linearisation launch; default 0, measured slower). */
+ * the previous association of the same scan; default 0, measured slower), "fuse_tail" (1 = the reduction of the block
+ * partials and the GN update run inside the linearisation launch, in its last block to finish; default 1; 0 = separate
+ * launch; may be changed at any time), "merge_kinds" (1 = surf and edge of a keyframe share ONE association launch and ONE
+ * linearisation launch; default 1). */
 int lili_set_option(lili_ctx* ctx, const char* name, int value);
 
 /* ---- local map index ------------------------------------------------------------------------ */
@@ -267,6 +268,12 @@ int lili_s2m_iterate_sharded(lili_ctx* ctx, int slot, int kind_mask, const lili_
                              int restart_slot, lili_allreduce_fn allreduce, void* comm, int32_t* d_counts, double* d_gram);
 /* Convenience: n_iters x (accumulate + gn_update) on an internal buffer.  Async. */
 int lili_s2m_iterate(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, int n_iters);
+
+/* The INNER iteration of the reference back-end (ceres::Solve on fixed correspondences, L/src/BackendFusion.cpp:984-992; the
+ * front-end's L/src/LidarOdometry.cpp:533): n_iters x [linearise the records of the LAST association at the device pose, reduce,
+ * Gauss-Newton update] — no re-association.  One launch per iteration.  want_cost != 0 also evaluates sum 1/2 rho (slot 64 of the
+ * internal record), as an LM caller needs it.  Async. */
+int lili_s2m_iterate_inner(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, int n_iters, int want_cost);
 
 /* lili_s2m_iterate for several slots at once (the keyframes of one sliding window, or several sensors): every slot
  * runs its own chain on its own stream, forked from / joined to the context's stream, so the latency-bound linearise /

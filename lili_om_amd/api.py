@@ -121,6 +121,7 @@ _SIGS = {
     "lili_s2m_linearize_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams), C.c_void_p]),
     "lili_s2m_gn_update": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "lili_s2m_iterate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams), C.c_int]),
+    "lili_s2m_iterate_inner": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams), C.c_int, C.c_int]),
     "lili_s2m_iterate_window": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(S2MParams), C.c_int]),
     "lili_s2m_debug_times": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_longlong)]),
     "lili_s2m_pose_copy": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
@@ -365,6 +366,10 @@ class ScanToMapMatcher:
 
     def iterate(self, slot, n_iters, kind_mask=MASK_SURF):
         self.ctx._chk(self.lib.lili_s2m_iterate(self.ctx.h, slot, kind_mask, C.byref(self.params), int(n_iters)))
+
+    def iterate_inner(self, slot, n_iters, kind_mask=MASK_SURF, want_cost=True):
+        """n_iters x (linearise + reduce + GN update) on the records of the last association (ceres::Solve's inner loop)."""
+        self.ctx._chk(self.lib.lili_s2m_iterate_inner(self.ctx.h, slot, kind_mask, C.byref(self.params), int(n_iters), 1 if want_cost else 0))
 
 
 def extract_rot_device(ctx):

@@ -26,8 +26,8 @@ __global__ void k_tile_fill(const int*, const int*, const int*, int, int2*);
 template <bool TILED, int BS> __global__ void k_associate_surf(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, int*, int*, AssocSched);
 template <bool TILED, int BS> __global__ void k_associate_edge(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, int*, int*, AssocSched);
 __global__ void k_block_order(const int*, int, int, int*);
-__global__ void k_linearize_surf(const float4*, int, const float4*, const double*, const unsigned char*, PoseArg, MatchParams, const SlotState*, const int*, int, const int*, double*, FuseTail);
-__global__ void k_linearize_edge(const float4*, int, const float4*, const float4*, const unsigned char*, PoseArg, MatchParams, const SlotState*, const int*, int, const int*, double*, FuseTail);
+__global__ void k_associate_both(AssocArgs, AssocArgs, PoseArg, MatchParams);
+__global__ void k_linearize(LinArgs, LinArgs, PoseArg, MatchParams, const SlotState*, const int*, FuseTail);
 __global__ void k_reduce_partials(const double*, int, const double*, int, double*, SlotState*, int);
 __global__ void k_sum_counts(const int*, int, const int*, int, SlotState*, int*);
 __global__ void k_gn_update(const double*, SlotState*);
@@ -107,6 +107,8 @@ int lili_ctx_create(lili_ctx** out, int device, void* stream) {
     bool ok = ctx->states.ensure(sizeof(SlotState) * LILI_MAX_SLOTS) == hipSuccess &&
               ctx->gram.ensure(sizeof(double) * LILI_GRAM_DOUBLES * LILI_MAX_SLOTS) == hipSuccess &&
               ctx->misc.ensure(256) == hipSuccess &&
+              ctx->tickets.ensure(sizeof(unsigned) * kTicketWordsPerSlot * LILI_MAX_SLOTS) == hipSuccess &&
+              hipMemsetAsync(ctx->tickets.p, 0, sizeof(unsigned) * kTicketWordsPerSlot * LILI_MAX_SLOTS, ctx->stream) == hipSuccess &&
               hipMemsetAsync(ctx->states.p, 0, sizeof(SlotState) * LILI_MAX_SLOTS, ctx->stream) == hipSuccess &&
               hipMemsetAsync(ctx->gram.p, 0, sizeof(double) * LILI_GRAM_DOUBLES * LILI_MAX_SLOTS, ctx->stream) == hipSuccess;
     if (!ok) { lili_ctx_destroy(ctx); return LILI_E_HIP; }
@@ -120,7 +122,7 @@ void lili_ctx_destroy(lili_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& m : ctx->map) { m.pts.release(); m.sorted.release(); m.aux_sorted.release(); m.cell_start.release(); m.cell_tmp.release(); m.pt_cell.release(); m.block_sums.release(); }
     for (auto& s : ctx->slots) for (auto& k : s.k) { k.q.release(); k.rec0.release(); k.rec1.release(); k.valid.release(); k.dbg_idx.release(); k.dbg_d2.release(); k.partials.release(); k.perm.release(); k.keys.release(); k.block_counts.release(); k.tiles.release(); }
-    ctx->states.release(); ctx->staging.release(); ctx->gram.release(); ctx->misc.release(); ctx->bin_hist.release(); ctx->bin_start.release(); ctx->bin_sums.release(); ctx->bin_tcnt.release(); ctx->bin_toff.release();
+    ctx->states.release(); ctx->tickets.release(); ctx->staging.release(); ctx->gram.release(); ctx->misc.release(); ctx->bin_hist.release(); ctx->bin_start.release(); ctx->bin_sums.release(); ctx->bin_tcnt.release(); ctx->bin_toff.release();
     if (ctx->ext_rot && ctx->ext_rot_free) ctx->ext_rot_free(ctx->ext_rot);
     if (ctx->ext_livox && ctx->ext_livox_free) ctx->ext_livox_free(ctx->ext_livox);
     if (ctx->ext_voxel && ctx->ext_voxel_free) ctx->ext_voxel_free(ctx->ext_voxel);
@@ -152,7 +154,8 @@ int lili_set_option(lili_ctx* ctx, const char* name, int value) {
     if (std::strcmp(name, "cell_pct") == 0) { if (value < 50 || value > 100) return ctx->fail(LILI_E_ARG, "cell_pct must be in 50..100"); ctx->cell_pct = value; return LILI_OK; }
     if (std::strcmp(name, "tiled") == 0) { ctx->tiled = value != 0; return LILI_OK; }
     if (std::strcmp(name, "balance") == 0) { ctx->balance = value != 0; for (auto& sl : ctx->slots) for (auto& k : sl.k) { k.order_valid = false; k.launches = 0; } return LILI_OK; }
-    if (std::strcmp(name, "fuse_tail") == 0) { ctx->fuse_tail = value != 0; return LILI_OK; }   // takes effect at the next set_queries
+    if (std::strcmp(name, "fuse_tail") == 0) { ctx->fuse_tail = value != 0; return LILI_OK; }   // any time: the block partition does not depend on it
+    if (std::strcmp(name, "merge_kinds") == 0) { ctx->merge_kinds = value != 0; return LILI_OK; }
     if (std::strcmp(name, "nn_cache") == 0) { ctx->nn_cache = value != 0; for (auto& s : ctx->slots) for (auto& k : s.k) k.nn_cache_valid = false; return LILI_OK; }
     if (std::strcmp(name, "max_cells") == 0) { if (value < 1) return ctx->fail(LILI_E_ARG, "max_cells must be positive"); ctx->max_cells = value; return LILI_OK; }
     return ctx->fail(LILI_E_ARG, std::string("unknown option ") + name);
@@ -261,11 +264,12 @@ int lili_s2m_set_queries(lili_ctx* ctx, int slot, int kind, const lili_cloud* cl
     int rc = lili_ingest_cloud(ctx, cloud, ks.q);
     if (rc != LILI_OK) return rc;
     ks.n_q = (int64_t)cloud->n;
+    ks.has_aux = cloud->aux_offset >= 0;
     ks.n_blocks = nblocks(ks.n_q, kAssocBlock);
-    // one linearisation block per CU where possible: threads = n_q / 256 rounded up to a wave multiple, within [256, 1024]
-    // (the fused-tail option needs the full 1024 threads for its reduction)
-    ks.lin_threads = ctx->fuse_tail ? kLinBlock : std::min(kLinBlock, std::max(256, (int)((ks.n_q + 256 * 64 - 1) / (256 * 64)) * 64));
-    ks.n_lin_blocks = std::min(nblocks(ks.n_q, ks.lin_threads), kMaxLinBlocks);
+    // linearisation: kLinBlock (1024) threads per block, at most kMaxLinBlocks partials.  The block size is FIXED (it was chosen
+    // per scan size in round 1): the block partition of the Gram sum — hence its rounding — must not depend on options that may
+    // change between set_queries and iterate (the fused tail needs all 1024 threads for its reduction).
+    ks.n_lin_blocks = std::min(nblocks(ks.n_q, kLinBlock), kMaxLinBlocks);
     size_t n = (size_t)ks.n_q;
     if (n) {
         HIPCHK(ks.rec0.ensure(n * sizeof(float4)));
@@ -395,27 +399,12 @@ static int launch_associate(lili_ctx* ctx, int slot, int kind, const PoseArg& pa
     } while (0)
     if (kind == LILI_KIND_SURF) {
         if (P.variant == LILI_VARIANT_LIVOX && !m.has_aux) return ctx->fail(LILI_E_STATE, "associate: Livox variant needs reflectivity (aux_offset) on the surf map");
+        if (P.variant == LILI_VARIANT_LIVOX && !ks.has_aux) return ctx->fail(LILI_E_STATE, "associate: Livox variant needs reflectivity (aux_offset) on the surf queries");
         LILI_LAUNCH_ASSOC(k_associate_surf, double);
     } else {
         LILI_LAUNCH_ASSOC(k_associate_edge, float4);
     }
 #undef LILI_LAUNCH_ASSOC
-    HIPCHK(hipGetLastError());
-    return LILI_OK;
-}
-
-static int launch_linearize(lili_ctx* ctx, int slot, int kind, const PoseArg& pa, const MatchParams& P, const FuseTail& fz) {
-    KindSlot& ks = ctx->slots[slot].k[kind];
-    if (!ks.has_records) return ctx->fail(LILI_E_STATE, "linearize: associate first");
-    if (ks.n_q == 0) return LILI_OK;
-    const int n = (int)ks.n_q;
-    const int* bc = ctx->slots[slot].use_global_counts ? nullptr : ks.block_counts.as<int>();
-    if (kind == LILI_KIND_SURF)
-        hipLaunchKernelGGL(k_linearize_surf, dim3(ks.n_lin_blocks), dim3(ks.lin_threads), lds_linearize(ks.lin_threads), ctx->stream, ks.q.as<float4>(), n, ks.rec0.as<float4>(),
-                           ks.rec1.as<double>(), ks.valid.as<unsigned char>(), pa, P, ctx->state(slot), bc, ks.n_assoc_blocks, ctx->slots[slot].use_global_counts ? ctx->slots[slot].global_counts : nullptr, ks.partials.as<double>(), fz);
-    else
-        hipLaunchKernelGGL(k_linearize_edge, dim3(ks.n_lin_blocks), dim3(ks.lin_threads), lds_linearize(ks.lin_threads), ctx->stream, ks.q.as<float4>(), n, ks.rec0.as<float4>(),
-                           ks.rec1.as<float4>(), ks.valid.as<unsigned char>(), pa, P, ctx->state(slot), bc, ks.n_assoc_blocks, ctx->slots[slot].use_global_counts ? ctx->slots[slot].global_counts : nullptr, ks.partials.as<double>(), fz);
     HIPCHK(hipGetLastError());
     return LILI_OK;
 }
@@ -431,26 +420,82 @@ static int launch_sum_counts(lili_ctx* ctx, int slot, int kind_mask, int* d_out 
     return LILI_OK;
 }
 
-// Linearisation of the kinds in kind_mask followed by the reduction of their block partials to the 72-double record
-// (and the GN update if do_gn): k_reduce_partials, or — option fuse_tail, measured SLOWER on MI355X (46.1 vs 43.0 us per
-// iteration: the device-scope release/acquire fences cost more than the kernel boundary they save) — the fused tail of
-// the last linearisation launch.
+// Both kinds of a keyframe in one launch (k_associate_both): only the plain direct path — one wave per workgroup, caller's
+// query order, no dispatch-order or binning experiments.  Returns 1 if the slot is not eligible (the caller then launches per kind).
+static int launch_associate_both(lili_ctx* ctx, int slot, const PoseArg& pa, const MatchParams& P) {
+    if (ctx->bin_queries || ctx->tiled || ctx->balance) return 1;
+    AssocArgs A[2];
+    for (int kind = 0; kind < 2; kind++) {
+        KindSlot& ks = ctx->slots[slot].k[kind];
+        MapIndex& m = ctx->map[kind];
+        if (!ks.has_queries || !m.valid || ks.n_q == 0 || m.n < 5) return 1;
+        const double gate = kind == LILI_KIND_SURF ? P.kd_max_radius : P.edge_gate;
+        if (!(std::sqrt(gate) * 1.0099 <= m.cell * (double)m.view.reach)) return 1;     // the per-kind path reports the error
+        if (kind == LILI_KIND_SURF && P.variant == LILI_VARIANT_LIVOX && (!m.has_aux || !ks.has_aux)) return 1;
+    }
+    for (int kind = 0; kind < 2; kind++) {
+        KindSlot& ks = ctx->slots[slot].k[kind];
+        const int n = (int)ks.n_q;
+        AssocArgs& a = A[kind];
+        a = AssocArgs{};
+        a.queries = ks.q.as<float4>(); a.n_q = n; a.g = ctx->map[kind].view;
+        a.rec0 = ks.rec0.as<float4>(); a.rec1 = ks.rec1.p; a.valid = ks.valid.as<unsigned char>();
+        if (ctx->keep_nn) {
+            HIPCHK(ks.dbg_idx.ensure((size_t)n * 5 * sizeof(int)));
+            HIPCHK(ks.dbg_d2.ensure((size_t)n * 5 * sizeof(float)));
+            a.dbg_idx = ks.dbg_idx.as<int>(); a.dbg_d2 = ks.dbg_d2.as<float>();
+        }
+        if (ctx->nn_cache) {
+            HIPCHK(ks.nn_cache.ensure((size_t)n * 5 * sizeof(int)));
+            if (!ks.nn_cache_valid) { HIPCHK(hipMemsetAsync(ks.nn_cache.p, 0xFF, (size_t)n * 5 * sizeof(int), ctx->stream)); ks.nn_cache_valid = true; }
+            a.nn_cache = ks.nn_cache.as<int>();
+        }
+        a.block_counts = ks.block_counts.as<int>(); a.nb = ks.n_blocks;
+        ks.n_assoc_blocks = ks.n_blocks; ks.has_records = true; ks.launches++;
+    }
+    hipLaunchKernelGGL(k_associate_both, dim3(A[0].nb + A[1].nb), dim3(kAssocBlock), 0, ctx->stream, A[0], A[1], pa, P);
+    HIPCHK(hipGetLastError());
+    return LILI_OK;
+}
+
+static LinArgs lin_args_of(lili_ctx* ctx, int slot, int kind) {
+    KindSlot& ks = ctx->slots[slot].k[kind];
+    LinArgs A{};
+    A.queries = ks.q.as<float4>(); A.n_q = (int)ks.n_q; A.rec0 = ks.rec0.as<float4>(); A.rec1 = ks.rec1.p; A.valid = ks.valid.as<unsigned char>();
+    A.block_counts = ctx->slots[slot].use_global_counts ? nullptr : ks.block_counts.as<int>(); A.n_bc = ks.n_assoc_blocks;
+    A.partials = ks.partials.as<double>(); A.nb = ks.n_lin_blocks;
+    return A;
+}
+
+// Linearisation of the kinds in kind_mask and the reduction of their block partials to the 72-double record (and the GN update
+// if do_gn).  Default: ONE launch — k_linearize covers both kinds and its last block to finish reduces (+ solves), see fused_tail.
+// Options for A/B: merge_kinds = 0 (one launch per kind), fuse_tail = 0 (k_reduce_partials as its own launch).  All variants
+// add the same numbers in the same order: the record is bit-identical.
 static int launch_linearize_reduce(lili_ctx* ctx, int slot, int kind_mask, const PoseArg& pa, const MatchParams& P, double* d_out, int do_gn) {
     Slot& s = ctx->slots[slot];
-    FuseTail fz{};
-    fz.mode = ctx->fuse_tail ? (do_gn ? 2 : 1) : 0; fz.out = d_out; fz.state = ctx->state(slot);
-    int last_kind = -1;
-    for (int kind = 0; kind < 2; kind++) if ((kind_mask & (1 << kind)) && s.k[kind].n_q > 0) {
-        if (kind == 0) { fz.part_surf = s.k[0].partials.as<double>(); fz.nb_surf = s.k[0].n_lin_blocks; }
-        else { fz.part_edge = s.k[1].partials.as<double>(); fz.nb_edge = s.k[1].n_lin_blocks; }
-        last_kind = kind;
-    }
-    const FuseTail off{};
+    LinArgs A[2] = {LinArgs{}, LinArgs{}};
+    int n_kinds = 0;
     for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) {
-        int rc = launch_linearize(ctx, slot, kind, pa, P, kind == last_kind ? fz : off);
-        if (rc != LILI_OK) return rc;
+        KindSlot& ks = s.k[kind];
+        if (!ks.has_records) return ctx->fail(LILI_E_STATE, "linearize: associate first");
+        if (ks.n_q == 0) continue;
+        A[kind] = lin_args_of(ctx, slot, kind);
+        n_kinds++;
     }
-    if (last_kind < 0 || !ctx->fuse_tail) {
+    const int* ng = s.use_global_counts ? s.global_counts : nullptr;
+    FuseTail fz{};
+    fz.mode = (ctx->fuse_tail && n_kinds > 0) ? (do_gn ? 2 : 1) : 0; fz.out = d_out; fz.state = ctx->state(slot); fz.tickets = ctx->tickets_of(slot);
+    fz.part_surf = A[0].partials; fz.nb_surf = A[0].nb; fz.part_edge = A[1].partials; fz.nb_edge = A[1].nb;
+    const FuseTail off{};
+    const size_t lds = lds_linearize(kLinBlock);
+    if (n_kinds == 2 && !ctx->merge_kinds) {       // A/B: one launch per kind, the tail on the second
+        hipLaunchKernelGGL(k_linearize, dim3(A[0].nb), dim3(kLinBlock), lds, ctx->stream, A[0], LinArgs{}, pa, P, ctx->state(slot), ng, off);
+        hipLaunchKernelGGL(k_linearize, dim3(A[1].nb), dim3(kLinBlock), lds, ctx->stream, LinArgs{}, A[1], pa, P, ctx->state(slot), ng, fz);
+    } else if (n_kinds > 0) {
+        hipLaunchKernelGGL(k_linearize, dim3(A[0].nb + A[1].nb), dim3(kLinBlock), lds, ctx->stream, A[0], A[1], pa, P, ctx->state(slot), ng, fz);
+    }
+    HIPCHK(hipGetLastError());
+    if (!fz.mode) {
         hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx->stream, fz.part_surf, fz.nb_surf, fz.part_edge, fz.nb_edge, d_out, ctx->state(slot), (do_gn ? 1 : 0) | (P.debug & 256));
         HIPCHK(hipGetLastError());
     }
@@ -637,6 +682,10 @@ int lili_s2m_associate_dev(lili_ctx* ctx, int slot, int kind_mask, const lili_s2
     pa.state = ctx->state(slot);
     pa.derive_assoc = params->variant == LILI_VARIANT_FRONTEND ? 0 : 1;
     MatchParams P = to_device_params(params);
+    if (kind_mask == (LILI_MASK_SURF | LILI_MASK_EDGE) && ctx->merge_kinds) {
+        int rc = launch_associate_both(ctx, slot, pa, P);
+        if (rc != 1) return rc;     // 1 = not eligible: one launch per kind below
+    }
     for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) {
         int rc = launch_associate(ctx, slot, kind, pa, P);
         if (rc != LILI_OK) return rc;
@@ -660,7 +709,7 @@ int lili_s2m_counts_import(lili_ctx* ctx, int slot, const int32_t* d_counts) {
     return LILI_OK;
 }
 
-static int linearize_dev_impl(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, double* d_gram, int do_gn) {
+static int linearize_dev_impl(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, double* d_gram, int do_gn, int want_cost = 0) {
     if (!ctx) return LILI_E_ARG;
     ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS, "linearize_dev: bad slot");
     ARGCHK((kind_mask & ~3) == 0 && kind_mask != 0, "linearize_dev: bad kind mask");
@@ -669,7 +718,7 @@ static int linearize_dev_impl(lili_ctx* ctx, int slot, int kind_mask, const lili
     PoseArg pa{};
     pa.state = ctx->state(slot);
     MatchParams P = to_device_params(params);
-    if (do_gn && d_gram == ctx->gram_of(slot)) P.no_cost = 1;   // lili_s2m_iterate*: the record stays inside the library, only the GN step is used
+    if (do_gn && d_gram == ctx->gram_of(slot) && !want_cost) P.no_cost = 1;   // lili_s2m_iterate*: the record stays inside the library, only the GN step is used
     int rc = launch_linearize_reduce(ctx, slot, kind_mask, pa, P, d_gram, do_gn);
     if (rc != LILI_OK) return rc;
     ctx->slots[slot].use_global_counts = false;
@@ -678,6 +727,20 @@ static int linearize_dev_impl(lili_ctx* ctx, int slot, int kind_mask, const lili
 
 int lili_s2m_linearize_dev(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, double* d_gram) {
     return linearize_dev_impl(ctx, slot, kind_mask, params, d_gram, 0);
+}
+
+// The reference back-end's INNER iteration (ceres::Solve's loop on fixed correspondences, L/src/BackendFusion.cpp:984-992: up to
+// max_num_iter evaluations of every residual block + one dense solve each): n_iters x [linearise at the device pose + reduce +
+// GN update] on the records of the last association, one launch each (fused tail).
+int lili_s2m_iterate_inner(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, int n_iters, int want_cost) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(n_iters >= 0, "iterate_inner: negative n_iters");
+    ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS, "iterate_inner: bad slot");
+    for (int it = 0; it < n_iters; it++) {
+        int rc = linearize_dev_impl(ctx, slot, kind_mask, params, ctx->gram_of(slot), 1, want_cost);
+        if (rc != LILI_OK) return rc;
+    }
+    return LILI_OK;
 }
 
 int lili_s2m_accumulate(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, double* d_gram) {
@@ -712,9 +775,13 @@ static int iterate_impl(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_p
     if (!ctx) return LILI_E_ARG;
     ARGCHK(n_iters >= 0, "iterate: negative n_iters");
     ARGCHK(restart_every >= 0 && (restart_every == 0 || (restart_slot >= 0 && restart_slot < LILI_MAX_SLOTS && restart_slot != slot)), "iterate: bad restart arguments");
-    std::vector<hipEvent_t> ev;
+    struct EventList {      // released on every return path
+        std::vector<hipEvent_t> v;
+        ~EventList() { for (auto e : v) if (e) (void)hipEventDestroy(e); }
+    } evl;
+    std::vector<hipEvent_t>& ev = evl.v;
     if (assoc_ms) {
-        ev.resize((size_t)2 * n_iters);
+        ev.assign((size_t)2 * n_iters, nullptr);
         for (auto& e : ev) HIPCHK(hipEventCreate(&e));
     }
     for (int it = 0; it < n_iters; it++) {   // 3 launches per outer iteration: associate, linearise, reduce+GN
@@ -730,7 +797,6 @@ static int iterate_impl(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_p
         HIPCHK(hipStreamSynchronize(ctx->stream));
         double tot = 0;
         for (int it = 0; it < n_iters; it++) { float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev[2 * it], ev[2 * it + 1])); tot += ms; }
-        for (auto& e : ev) (void)hipEventDestroy(e);
         *assoc_ms = (float)tot;
     }
     return LILI_OK;

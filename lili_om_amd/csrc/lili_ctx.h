@@ -46,6 +46,7 @@ struct MapIndex {
 struct KindSlot {
     int64_t n_q = 0;
     bool has_queries = false, has_records = false;
+    bool has_aux = false;    // the query cloud carried the auxiliary float (Livox: reflectivity)
     DevBuf q, rec0, rec1, valid, dbg_idx, dbg_d2, partials, perm, keys, block_counts, tiles, nn_cache, order, block_cost;
     int launches = 0;        // association launches since set_queries (the dispatch order is rebuilt before launches 2 and 4)
     bool order_valid = false;
@@ -55,7 +56,6 @@ struct KindSlot {
     bool binned = false;   // perm holds the super-cell (Morton) order of the queries for the current scan
     int n_blocks = 0;      // association grid (one thread per query)
     int n_lin_blocks = 0;  // linearisation grid (grid-stride, <= kMaxLinBlocks partials)
-    int lin_threads = 1024; // linearisation block: multiple of 64 chosen so that ~all 256 CUs get one block each
 };
 
 struct Slot {
@@ -65,6 +65,7 @@ struct Slot {
 };
 
 constexpr int kLinBlock = 1024;      // must match lili_s2m.hip
+constexpr int kTicketWordsPerSlot = 9 * 1024;   // fused tail: 8 shard counters + 1 top counter, 4 KiB apart (kTicketStride words, lili_s2m.hip)
 constexpr int kMaxLinBlocks = 256;
 inline size_t lds_linearize(int threads) { return (size_t)threads * 10 * sizeof(double); }   // rows [J r 1 cost]; reused for the 16x16 wave results
 
@@ -82,6 +83,7 @@ struct lili_ctx {
     MapIndex map[2];
     Slot slots[LILI_MAX_SLOTS];
     DevBuf states;       // SlotState[LILI_MAX_SLOTS]
+    DevBuf tickets;      // arrival counters of the fused linearise + reduce + GN launch, kTicketWordsPerSlot words per slot
     DevBuf staging;      // raw host clouds
     DevBuf fmt_out;      // lili_livox_custom_to_cloud output when the caller wants it on the host
     DevBuf gram;         // LILI_GRAM_DOUBLES per slot
@@ -91,7 +93,8 @@ struct lili_ctx {
     bool tiled = false;         // LDS-staged tiles: measured slower than the direct path once selection is branch-free
     int max_cells = 1 << 27;
     int grid_reach = 2;          // 2: cells smaller than the gate radius, inner 3x3x3 block first, shell on demand (knn5_grid)
-    bool fuse_tail = false;      // reduce + GN as the tail of the last linearisation launch (slower than a separate launch; A/B only)
+    bool fuse_tail = true;       // reduce (+ GN) inside the linearisation launch: the last block to arrive does it (write-through partials + sharded tickets)
+    bool merge_kinds = true;     // surf and edge of one keyframe in ONE association launch / ONE linearisation launch
     bool nn_cache = false;       // seed each query's search bound with its previous 5 neighbours (exact for any pose change)
     int cell_pct = 65;           // reach 2: cell edge in % of 1.01 * gate radius (>= 50)
     bool balance = false;        // cost-ordered dispatch of the association workgroups (AssocSched): measured, no gain — A/B only
@@ -106,6 +109,7 @@ struct lili_ctx {
     int fail(int code, const std::string& m) { err = m; return code; }
     SlotState* state(int slot) { return states.as<SlotState>() + slot; }
     double* gram_of(int slot) { return gram.as<double>() + (size_t)slot * LILI_GRAM_DOUBLES; }
+    unsigned* tickets_of(int slot) { return tickets.as<unsigned>() + (size_t)slot * kTicketWordsPerSlot; }
 };
 
 #define HIPCHK(expr)                                                                                         \

@@ -28,7 +28,7 @@ struct SlotState {
     int iters;        // GN updates applied since pose_set
     double last_delta[6];
     long long tprof[16];   // profiling aid (LILI_DEBUG bit 256): s_memrealtime stamps (100 MHz) of one block per kernel
-    unsigned int ticket;   // fused tail of the linearisation kernels: blocks finished so far (self-resetting)
+    unsigned int reserved_;
 };
 
 // Fused tail of a linearisation launch (see fused_tail in lili_s2m.hip)
@@ -38,6 +38,7 @@ struct FuseTail {
     const double* part_edge; int nb_edge;
     double* out;
     SlotState* state;
+    unsigned* tickets;         // this slot's arrival counters (kTicketShards + 1 words, kTicketStride apart; self-resetting)
 };
 
 
@@ -60,6 +61,24 @@ struct MatchParams {     // device copy of lili_s2m_params (+ derived values)
     int debug;   // ablation switches for profiling only (LILI_DEBUG env): 1 = skip the plane/line fit, 2 = skip the search,
                  // 2048 = never fall back to the pivoted QR, 4096 = per-workgroup timestamps (tools/assoc_blocks.py), 8192 = no exact-selector
                  // redo (inexact on ties), 16384 = always the pivoted QR, 32768 = exact (d2, index) selector only
+};
+
+// Arguments of one kind (surf or edge) of the combined linearisation launch k_linearize.
+struct LinArgs {
+    const float4* queries; int n_q;
+    const float4* rec0;            // surf: (w*n, w*d); edge: (A, s)
+    const void* rec1;              // surf: double score[]; edge: float4 (B, 0)
+    const unsigned char* valid;
+    const int* block_counts; int n_bc;   // per-block correspondence counts of the association launch (nullptr: use n_global / state)
+    double* partials;
+    int nb;                        // linearisation blocks of this kind
+};
+// Arguments of one kind of the combined association launch k_associate_both.
+struct AssocArgs {
+    const float4* queries; int n_q; GridView g;
+    float4* rec0; void* rec1; unsigned char* valid;
+    int* dbg_idx; float* dbg_d2; int* block_counts; int* nn_cache;
+    int nb;
 };
 
 constexpr int kPartialDoubles = 40;  // per-block partial: 36 upper-triangle Gram entries, cost, count, 2 spare

@@ -571,7 +571,7 @@ __device__ __forceinline__ void knn5_grid(const GridView& g, TAB& tab, float qx,
 // Correspondence counting without atomics on a shared word (3128 same-address atomics cost ~40 us on
 // MI355X): each block stores its own count; consumers add the <= few-thousand block counts themselves.
 template <int BS>
-__device__ __forceinline__ void store_block_count(bool ok, int* __restrict__ block_counts) {
+__device__ __forceinline__ void store_block_count(bool ok, int* __restrict__ block_counts, int bid) {
     __shared__ int wave_cnt[BS / 64];
     unsigned long long bal = __ballot(ok);
     if ((threadIdx.x & 63) == 0) wave_cnt[threadIdx.x >> 6] = __popcll(bal);
@@ -580,7 +580,7 @@ __device__ __forceinline__ void store_block_count(bool ok, int* __restrict__ blo
         int s = 0;
 #pragma unroll
         for (int w = 0; w < BS / 64; w++) s += wave_cnt[w];
-        block_counts[blockIdx.x] = s;
+        block_counts[bid] = s;
     }
 }
 // Sum of the per-block counts of one association launch (every thread of the block gets the total).
@@ -929,15 +929,14 @@ __device__ __forceinline__ void knn5_tiled(const GridView& g, TileLds& L, TAB& t
     sel.to_top5(best);
 }
 
-template <bool TILED, int BS>
-__global__ __launch_bounds__(BS) void k_associate_surf(
-        const float4* __restrict__ queries, const int* __restrict__ perm, const int2* __restrict__ tiles, int n_q, GridView g, PoseArg pa, MatchParams P,
+template <bool TILED, int BS, class TILE, class TAB>
+__device__ __forceinline__ void assoc_surf_body(
+        const float4* __restrict__ queries, const int* __restrict__ perm, const int2* __restrict__ tiles, int n_q, const GridView& g, const PoseArg& pa, const MatchParams& P,
         float4* __restrict__ rec_nd, double* __restrict__ rec_score, unsigned char* __restrict__ valid,
-        int* __restrict__ dbg_idx, float* __restrict__ dbg_d2, int* __restrict__ block_counts, int* __restrict__ nn_cache, AssocSched sched) {
-    __shared__ TileLds L;
-    __shared__ RowTabT<BS> tab;
+        int* __restrict__ dbg_idx, float* __restrict__ dbg_d2, int* __restrict__ block_counts, int* __restrict__ nn_cache, const AssocSched& sched,
+        int vbid, TILE& L, TAB& tab) {
     const long long t_begin = (P.debug & 4096) ? (long long)__builtin_amdgcn_s_memrealtime() : 0ll;   // profiling aid (tools/assoc_blocks.py)
-    const int bid = sched.order ? sched.order[blockIdx.x] : (int)blockIdx.x;
+    const int bid = sched.order ? sched.order[vbid] : vbid;
     const int2 tile = tiles ? tiles[bid] : make_int2(bid * BS, min(BS, n_q - bid * BS));
     const bool live = (int)threadIdx.x < tile.y;
     int t = tile.x + threadIdx.x;
@@ -960,7 +959,7 @@ __global__ __launch_bounds__(BS) void k_associate_surf(
     if (P.debug & 2) {
 #pragma unroll
         for (int k = 0; k < 5; k++) { nn.d[k] = 0.01f * (k + 1); nn.j[k] = (i * 7 + k) % g.n_points; }
-    } else if (TILED) knn5_tiled(g, L, tab, live, px, py, pz, nn, P.debug);
+    } else if constexpr (TILED) knn5_tiled(g, L, tab, live, px, py, pz, nn, P.debug);
     else if (live) { knn5_grid(g, tab, px, py, pz, seeded_bound(g, P.kd_max_radius, nn_cache, n_q, i, px, py, pz), nn, P.debug, pp); store_nn_cache(nn_cache, n_q, i, nn); }
     if (BS == 64 && !TILED && sched.block_cost) {   // cost of this block for the next launch's dispatch order
         int c = live ? nn.aux : 0;
@@ -978,7 +977,7 @@ __global__ __launch_bounds__(BS) void k_associate_surf(
         rec_score[i] = score;
         valid[i] = ok ? 1 : 0;
     }
-    store_block_count<BS>(ok, block_counts);
+    store_block_count<BS>(ok, block_counts, vbid);
 #ifdef LILI_PHASE_PROBE
     if ((P.debug & 4096) && dbg_d2 && threadIdx.x == 0) {   // phase stamps as ticks since the block began, over the d2 debug rows of the block's first two queries
         for (int k = 1; k <= 6; k++) dbg_d2[(size_t)tile.x * 5 + k] = probe.t[k] ? (float)(probe.t[k] - t_begin) : -1.0f;
@@ -994,15 +993,24 @@ __global__ __launch_bounds__(BS) void k_associate_surf(
     }
     if ((P.debug & 4096) && dbg_idx && live && threadIdx.x != 0) dbg_idx[(size_t)i * 5] = nn.aux;
 }
-
+struct NoTile {};
 template <bool TILED, int BS>
-__global__ __launch_bounds__(BS) void k_associate_edge(
+__global__ __launch_bounds__(BS) void k_associate_surf(
         const float4* __restrict__ queries, const int* __restrict__ perm, const int2* __restrict__ tiles, int n_q, GridView g, PoseArg pa, MatchParams P,
-        float4* __restrict__ rec_a, float4* __restrict__ rec_b, unsigned char* __restrict__ valid,
+        float4* __restrict__ rec_nd, double* __restrict__ rec_score, unsigned char* __restrict__ valid,
         int* __restrict__ dbg_idx, float* __restrict__ dbg_d2, int* __restrict__ block_counts, int* __restrict__ nn_cache, AssocSched sched) {
-    __shared__ TileLds L;
+    __shared__ typename std::conditional<TILED, TileLds, NoTile>::type L;
     __shared__ RowTabT<BS> tab;
-    const int bid = sched.order ? sched.order[blockIdx.x] : (int)blockIdx.x;
+    assoc_surf_body<TILED, BS>(queries, perm, tiles, n_q, g, pa, P, rec_nd, rec_score, valid, dbg_idx, dbg_d2, block_counts, nn_cache, sched, (int)blockIdx.x, L, tab);
+}
+
+template <bool TILED, int BS, class TILE, class TAB>
+__device__ __forceinline__ void assoc_edge_body(
+        const float4* __restrict__ queries, const int* __restrict__ perm, const int2* __restrict__ tiles, int n_q, const GridView& g, const PoseArg& pa, const MatchParams& P,
+        float4* __restrict__ rec_a, float4* __restrict__ rec_b, unsigned char* __restrict__ valid,
+        int* __restrict__ dbg_idx, float* __restrict__ dbg_d2, int* __restrict__ block_counts, int* __restrict__ nn_cache, const AssocSched& sched,
+        int vbid, TILE& L, TAB& tab) {
+    const int bid = sched.order ? sched.order[vbid] : vbid;
     const int2 tile = tiles ? tiles[bid] : make_int2(bid * BS, min(BS, n_q - bid * BS));
     const bool live = (int)threadIdx.x < tile.y;
     int t = tile.x + threadIdx.x;
@@ -1013,7 +1021,7 @@ __global__ __launch_bounds__(BS) void k_associate_edge(
     d3 pmd = qrot(Q2, d3{(double)ql.x, (double)ql.y, (double)ql.z}) + T2;
     float px = (float)pmd.x, py = (float)pmd.y, pz = (float)pmd.z;
     Top5 nn;
-    if (TILED) knn5_tiled(g, L, tab, live, px, py, pz, nn, P.debug);
+    if constexpr (TILED) knn5_tiled(g, L, tab, live, px, py, pz, nn, P.debug);
     else if (live) { knn5_grid(g, tab, px, py, pz, seeded_bound(g, P.edge_gate, nn_cache, n_q, i, px, py, pz), nn); store_nn_cache(nn_cache, n_q, i, nn); }
     bool ok = false;
     if (live) {
@@ -1022,7 +1030,30 @@ __global__ __launch_bounds__(BS) void k_associate_edge(
         ok = edge_fit(g, P, nn, px, py, pz, ra, rb);
         rec_a[i] = ra; rec_b[i] = rb; valid[i] = ok ? 1 : 0;
     }
-    store_block_count<BS>(ok, block_counts);
+    store_block_count<BS>(ok, block_counts, vbid);
+}
+template <bool TILED, int BS>
+__global__ __launch_bounds__(BS) void k_associate_edge(
+        const float4* __restrict__ queries, const int* __restrict__ perm, const int2* __restrict__ tiles, int n_q, GridView g, PoseArg pa, MatchParams P,
+        float4* __restrict__ rec_a, float4* __restrict__ rec_b, unsigned char* __restrict__ valid,
+        int* __restrict__ dbg_idx, float* __restrict__ dbg_d2, int* __restrict__ block_counts, int* __restrict__ nn_cache, AssocSched sched) {
+    __shared__ typename std::conditional<TILED, TileLds, NoTile>::type L;
+    __shared__ RowTabT<BS> tab;
+    assoc_edge_body<TILED, BS>(queries, perm, tiles, n_q, g, pa, P, rec_a, rec_b, valid, dbg_idx, dbg_d2, block_counts, nn_cache, sched, (int)blockIdx.x, L, tab);
+}
+
+// Both kinds of one keyframe in ONE launch (the reference back-end associates corners and planes of a keyframe back to back,
+// L/src/BackendFusion.cpp:935-936): workgroups [0, E.nb) take the (few) edge queries, the rest the surf queries — one wave per
+// workgroup, direct search path.  Saves a kernel boundary and the fill / drain of a second grid per outer iteration.
+__global__ __launch_bounds__(kAssocBlock) void k_associate_both(AssocArgs S, AssocArgs E, PoseArg pa, MatchParams P) {
+    __shared__ NoTile L;
+    __shared__ RowTabT<kAssocBlock> tab;
+    const AssocSched sched{nullptr, nullptr};
+    const int b = (int)blockIdx.x;
+    if (b < E.nb) assoc_edge_body<false, kAssocBlock>(E.queries, nullptr, nullptr, E.n_q, E.g, pa, P, E.rec0, reinterpret_cast<float4*>(E.rec1), E.valid, E.dbg_idx, E.dbg_d2,
+                                                      E.block_counts, E.nn_cache, sched, b, L, tab);
+    else assoc_surf_body<false, kAssocBlock>(S.queries, nullptr, nullptr, S.n_q, S.g, pa, P, S.rec0, reinterpret_cast<double*>(S.rec1), S.valid, S.dbg_idx, S.dbg_d2,
+                                             S.block_counts, S.nn_cache, sched, b - E.nb, L, tab);
 }
 #define LILI_ASSOC_ARGS_SURF const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, int*, int*, AssocSched
 #define LILI_ASSOC_ARGS_EDGE const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, int*, int*, AssocSched
@@ -1123,7 +1154,10 @@ struct GramAcc {
         }
     }
     // block partial: 36 upper-triangle entries of the 8x8 Gram, [36] = cost, [37] = count
-    __device__ __forceinline__ void finish(double* lds, double* __restrict__ partial_out) {
+    // `publish`: the partial is stored write-through (agent-scope relaxed atomic store = `global_store ... sc1`), so that another
+    // workgroup of the SAME launch may read it after the ticket hand-off of fused_tail without any L2 write-back fence
+    // (MI355X_MICROARCH.md, inter-workgroup visibility, form R1).
+    __device__ __forceinline__ void finish(double* lds, double* partial_out, bool publish = false) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         __syncthreads();                 // every wave is done with its row area before the LDS is reused for the wave results
         double* dm = lds + wave * 256;   // this wave's 16x16 result, row-major
@@ -1140,32 +1174,50 @@ struct GramAcc {
             else { row = 15; cl = 15; }   // spare slots: always zero
             double s = 0.0;
             for (int w = 0; w < (int)(blockDim.x >> 6); w++) s += lds[w * 256 + row * 16 + cl];
-            partial_out[e] = s;
+            if (publish) __hip_atomic_store(reinterpret_cast<unsigned long long*>(partial_out) + e, (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else partial_out[e] = s;
         }
     }
 };
 
 // ---- fused tail: the LAST block of a linearisation launch to finish adds all block partials (fixed order, so the
-// result does not depend on which block that is) and, optionally, applies the Gauss-Newton update — one kernel
-// boundary less per outer iteration.  Release / acquire at device scope around a ticket counter in SlotState.
+// result does not depend on which block that is) and, optionally, applies the Gauss-Newton update — the whole inner
+// iteration (linearise + reduce + solve + pose update) is ONE launch.
+// Hand-off (MI355X_MICROARCH.md "inter-workgroup visibility", form R1, and the fan-in row of the price list): the block
+// partials are stored write-through (sc1) by GramAcc::finish, the storing waves drain their stores (s_waitcnt vmcnt(0)),
+// one lane per block takes a ticket with a relaxed agent-scope atomic; the last arriver reads the partials with sc1 loads
+// (L1 bypassed, no acquire fence, no L2 write-back — round 1's __threadfence pair cost more than the kernel boundary it saved).
+// Tickets are sharded eight ways (block b arrives at shard b mod 8, the last of a shard arrives at the top counter): at most
+// 32 + 8 same-address atomics queue up (11-13 ns each) instead of 256.  Counters reset themselves; they are zeroed when the
+// context is created.  The words of one slot are 4 KiB apart (different channels).
+constexpr int kTicketStride = 1024;          // unsigned words between the counters of one slot
+constexpr int kTicketShards = 8;
 __device__ void reduce_partials_block(const double* part_surf, int nb_surf, const double* part_edge, int nb_edge,
-                                      double* __restrict__ out, SlotState* __restrict__ state, int do_gn);   // defined below
+                                      double* __restrict__ out, SlotState* __restrict__ state, int do_gn, bool coherent);   // defined below
 __device__ __forceinline__ void fused_tail(const FuseTail& fz) {
     if (!fz.mode) return;
     __shared__ int s_last;
-    __syncthreads();                          // the block's partial has been stored (by threads < 40)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave: its write-through stores have left (only threads < 40 stored)
+    __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();                      // release (cumulative over the barrier): the partial is visible device-wide
-        unsigned t = atomicAdd(&fz.state->ticket, 1u);
-        s_last = t == gridDim.x - 1 ? 1 : 0;
-        if (s_last) {
-            fz.state->ticket = 0;             // ready for the next launch (stream order)
-            __threadfence();                  // acquire: every other block's partial (invalidates this CU's L1 / the XCD's stale L2 lines)
+        const int nb = (int)gridDim.x, shard = (int)blockIdx.x % kTicketShards;
+        const int n_shards = nb < kTicketShards ? nb : kTicketShards;
+        const int in_shard = (nb - shard + kTicketShards - 1) / kTicketShards;
+        unsigned* tk = fz.tickets + (size_t)shard * kTicketStride;
+        unsigned* top = fz.tickets + (size_t)kTicketShards * kTicketStride;
+        int last = 0;
+        if (__hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(in_shard - 1)) {
+            __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // ready for the next launch (stream order)
+            if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(n_shards - 1)) {
+                __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = 1;
+            }
         }
+        s_last = last;
     }
     __syncthreads();
     if (!s_last) return;
-    reduce_partials_block(fz.part_surf, fz.nb_surf, fz.part_edge, fz.nb_edge, fz.out, fz.state, fz.mode == 2);
+    reduce_partials_block(fz.part_surf, fz.nb_surf, fz.part_edge, fz.nb_edge, fz.out, fz.state, fz.mode == 2 ? 1 : 0, true);
 }
 
 __device__ __forceinline__ void load_body_pose(const PoseArg& pa, dq& Q, d3& T) {
@@ -1173,13 +1225,15 @@ __device__ __forceinline__ void load_body_pose(const PoseArg& pa, dq& Q, d3& T) 
     else { T = d3{pa.t[0], pa.t[1], pa.t[2]}; Q = dq{pa.q[0], pa.q[1], pa.q[2], pa.q[3]}; }
 }
 
-__global__ __launch_bounds__(kLinBlock) void k_linearize_surf(
-        const float4* __restrict__ queries, int n_q, const float4* __restrict__ rec_nd, const double* __restrict__ rec_score,
-        const unsigned char* __restrict__ valid, PoseArg pa, MatchParams P, const SlotState* __restrict__ state,
-        const int* __restrict__ block_counts, int n_bc, const int* __restrict__ n_global, double* partials, FuseTail fz) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+// Linearisation bodies: `bid` of `nb` virtual blocks of one kind (the combined surf + edge launch maps its grid onto both).
+__device__ __forceinline__ void lin_surf_body(const LinArgs& A, int bid, const PoseArg& pa, const MatchParams& P, const SlotState* __restrict__ state,
+                                              const int* __restrict__ n_global, double* lds, bool publish) {
+    const float4* __restrict__ queries = A.queries; const float4* __restrict__ rec_nd = A.rec0;
+    const double* __restrict__ rec_score = reinterpret_cast<const double*>(A.rec1);
+    const unsigned char* __restrict__ valid = A.valid;
+    const int n_q = A.n_q;
     tstamp(state, P.debug, 100, 0);
-    if ((P.debug & 512) && blockIdx.x == 100 && threadIdx.x == 0) const_cast<SlotState*>(state)->tprof[15] = (long long)__builtin_amdgcn_s_memrealtime();
+    if ((P.debug & 512) && bid == 100 && threadIdx.x == 0) const_cast<SlotState*>(state)->tprof[15] = (long long)__builtin_amdgcn_s_memrealtime();
     GramAcc ga; ga.init();
     dq Q; d3 T;
     load_body_pose(pa, Q, T);
@@ -1189,7 +1243,7 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize_surf(
     // the first tile's records are requested before the count reduction below (which synchronises the block twice), and
     // unconditionally — one memory round trip instead of valid -> record
     const int BS = blockDim.x;
-    const int i0 = blockIdx.x * BS + threadIdx.x;
+    const int i0 = bid * BS + threadIdx.x;
     const int i0c = min(i0, n_q - 1);
     unsigned char v0 = valid[i0c];
     float4 ql0 = queries[i0c], nd0 = rec_nd[i0c];
@@ -1198,11 +1252,11 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize_surf(
     // vec_surf_scores[i] * 1000 / vec_surf_res_cnt  =  (score * 1000.0) / (double)N — a multiply, then a true division
     double n_den = 1.0;
     if (P.debug & 128) n_den = 190000.0;
-    else if (P.scale_surf_num > 0) n_den = (double)(block_counts ? sum_block_counts(block_counts, n_bc) : (n_global ? n_global[0] : state->n_res[0]));
+    else if (P.scale_surf_num > 0) n_den = (double)(A.block_counts ? sum_block_counts(A.block_counts, A.n_bc) : (n_global ? n_global[0] : state->n_res[0]));
     tstamp(state, P.debug, 100, 1);
-    for (int base = blockIdx.x * BS; base < n_q; base += gridDim.x * BS) {
+    for (int base = bid * BS; base < n_q; base += A.nb * BS) {
         int i = base + threadIdx.x;
-        const bool first = base == (int)blockIdx.x * BS;
+        const bool first = base == bid * BS;
         const int ic = min(i, n_q - 1);
         bool ok = i < n_q && (first ? v0 : valid[ic]);
         double Jr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1229,26 +1283,26 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize_surf(
         tstamp(state, P.debug, 100, 2);
         ga.add_rows(Jr, cost, ok, lds);
         tstamp(state, P.debug, 100, 3);
-        if ((P.debug & 512) && blockIdx.x == 100 && (threadIdx.x & 63) == 0) const_cast<SlotState*>(state)->tprof[threadIdx.x >> 6] = (long long)__builtin_amdgcn_s_memrealtime();
+        if ((P.debug & 512) && bid == 100 && (threadIdx.x & 63) == 0) const_cast<SlotState*>(state)->tprof[threadIdx.x >> 6] = (long long)__builtin_amdgcn_s_memrealtime();
     }
-    ga.finish(lds, partials + (size_t)blockIdx.x * kPartialDoubles);
+    ga.finish(lds, A.partials + (size_t)bid * kPartialDoubles, publish);
     tstamp(state, P.debug, 100, 4);
-    fused_tail(fz);
 }
 
-__global__ __launch_bounds__(kLinBlock) void k_linearize_edge(
-        const float4* __restrict__ queries, int n_q, const float4* __restrict__ rec_a, const float4* __restrict__ rec_b,
-        const unsigned char* __restrict__ valid, PoseArg pa, MatchParams P, const SlotState* __restrict__ state,
-        const int* __restrict__ block_counts, int n_bc, const int* __restrict__ n_global, double* partials, FuseTail fz) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+__device__ __forceinline__ void lin_edge_body(const LinArgs& A, int bid, const PoseArg& pa, const MatchParams& P, const SlotState* __restrict__ state,
+                                              const int* __restrict__ n_global, double* lds, bool publish) {
+    const float4* __restrict__ queries = A.queries; const float4* __restrict__ rec_a = A.rec0;
+    const float4* __restrict__ rec_b = reinterpret_cast<const float4*>(A.rec1);
+    const unsigned char* __restrict__ valid = A.valid;
+    const int n_q = A.n_q;
     GramAcc ga; ga.init();
     dq Q; d3 T;
     load_body_pose(pa, Q, T);
     // R:843: points[i].intensity * 200 / vec_edge_res_cnt — float * int / int, i.e. FLOAT arithmetic (pinned by tests/test_reference_*.py against the reference text)
     float n_den = 1.0f;
-    if (P.scale_edge_num > 0) n_den = (float)(block_counts ? sum_block_counts(block_counts, n_bc) : (n_global ? n_global[1] : state->n_res[1]));
+    if (P.scale_edge_num > 0) n_den = (float)(A.block_counts ? sum_block_counts(A.block_counts, A.n_bc) : (n_global ? n_global[1] : state->n_res[1]));
     const float n_num = (float)P.scale_edge_num;
-    for (int base = blockIdx.x * blockDim.x; base < n_q; base += gridDim.x * blockDim.x) {
+    for (int base = bid * blockDim.x; base < n_q; base += A.nb * blockDim.x) {
         int i = base + threadIdx.x;
         bool ok = i < n_q && valid[i];
         double Jr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1258,14 +1312,14 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize_edge(
             double s = (double)fa.w;
             if (P.scale_edge_num > 0) s = (double)__fdiv_rn(__fmul_rn(fa.w, n_num), n_den);
             d3 cp{(double)ql.x, (double)ql.y, (double)ql.z};
-            d3 A{(double)fa.x, (double)fa.y, (double)fa.z}, B{(double)fb.x, (double)fb.y, (double)fb.z};
+            d3 Av{(double)fa.x, (double)fa.y, (double)fa.z}, B{(double)fb.x, (double)fb.y, (double)fb.z};
             d3 lp = qrot(Q, cp) + T;                    // LidarKeyframeFactor.h:38 (no extrinsic: SURVEY F6)
-            d3 nu = cross3(lp - A, lp - B);             // :40
-            d3 de = A - B;                              // :41
+            d3 nu = cross3(lp - Av, lp - B);            // :40
+            d3 de = Av - B;                             // :41
             double nn = sqrt(dot3(nu, nu)), dn = sqrt(dot3(de, de));
             double r = s * (nn / dn);                   // :43-44
             // d|nu|/dlp = nu^T [a-b]x / |nu| = (nu x (B - A))^T / |nu|
-            d3 g = cross3(nu, B - A);
+            d3 g = cross3(nu, B - Av);
             double k = s / (nn * dn);
             g = k * g;
             double jq[4];
@@ -1278,7 +1332,17 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize_edge(
         }
         ga.add_rows(Jr, cost, ok, lds);
     }
-    ga.finish(lds, partials + (size_t)blockIdx.x * kPartialDoubles);
+    ga.finish(lds, A.partials + (size_t)bid * kPartialDoubles, publish);
+}
+
+// One launch for the kinds present: blocks [0, S.nb) linearise the surf records, blocks [S.nb, S.nb + E.nb) the edge records
+// (either count may be 0); with fz.mode != 0 the last block to finish reduces all partials and (mode 2) applies the GN update.
+__global__ __launch_bounds__(kLinBlock) void k_linearize(LinArgs S, LinArgs E, PoseArg pa, MatchParams P, const SlotState* __restrict__ state,
+                                                         const int* __restrict__ n_global, FuseTail fz) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int bid = (int)blockIdx.x;
+    if (bid < S.nb) lin_surf_body(S, bid, pa, P, state, n_global, lds, fz.mode != 0);
+    else lin_edge_body(E, bid - S.nb, pa, P, state, n_global, lds, fz.mode != 0);
     fused_tail(fz);
 }
 
@@ -1393,9 +1457,16 @@ __device__ void gn_update_block(const double* gram /*LDS or global, 64+*/, SlotS
 }
 
 constexpr int kReduceThreads = 1024;
-// all kReduceThreads threads of ONE block; partials may have been written by other blocks of the same launch (fused tail)
+__device__ __forceinline__ double load_partial(const double* p, bool coherent) {
+    // coherent: written by another workgroup of THIS launch with sc1 stores -> read with an sc1 load (bypasses this CU's L1)
+    if (coherent) return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return *p;
+}
+// all kReduceThreads threads of ONE block; partials may have been written by other blocks of the same launch (fused tail:
+// coherent = true).  The order of the additions is fixed (25 groups of 40 lanes, group g adds partials g, g+25, ... in
+// sequence, then the groups in sequence), so the record does not depend on which block runs this or on timing.
 __device__ void reduce_partials_block(const double* part_surf, int nb_surf, const double* part_edge, int nb_edge,
-                                      double* __restrict__ out, SlotState* __restrict__ state, int do_gn) {
+                                      double* __restrict__ out, SlotState* __restrict__ state, int do_gn, bool coherent) {
     tstamp(state, do_gn, 0, 8);
     const double xq[4] = {state->pose[3], state->pose[4], state->pose[5], state->pose[6]};
     constexpr int kGroups = kReduceThreads / 40;   // 25 groups of 40 lanes, group g adds partials g, g+25, ...
@@ -1409,14 +1480,14 @@ __device__ void reduce_partials_block(const double* part_surf, int nb_surf, cons
         for (int b0 = g; b0 < nb_surf; b0 += kGroups * 8) {
             double v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) { int b = b0 + u * kGroups; v[u] = b < nb_surf ? part_surf[(size_t)b * kPartialDoubles + e] : 0.0; }
+            for (int u = 0; u < 8; u++) { int b = b0 + u * kGroups; v[u] = b < nb_surf ? load_partial(part_surf + (size_t)b * kPartialDoubles + e, coherent) : 0.0; }
 #pragma unroll
             for (int u = 0; u < 8; u++) s += v[u];
         }
         for (int b0 = g; b0 < nb_edge; b0 += kGroups * 8) {
             double v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) { int b = b0 + u * kGroups; v[u] = b < nb_edge ? part_edge[(size_t)b * kPartialDoubles + e] : 0.0; }
+            for (int u = 0; u < 8; u++) { int b = b0 + u * kGroups; v[u] = b < nb_edge ? load_partial(part_edge + (size_t)b * kPartialDoubles + e, coherent) : 0.0; }
 #pragma unroll
             for (int u = 0; u < 8; u++) s2 += v[u];
         }
@@ -1450,7 +1521,7 @@ __device__ void reduce_partials_block(const double* part_surf, int nb_surf, cons
 __global__ __launch_bounds__(kReduceThreads) void k_reduce_partials(const double* __restrict__ part_surf, int nb_surf,
                                                             const double* __restrict__ part_edge, int nb_edge,
                                                             double* __restrict__ out, SlotState* __restrict__ state, int do_gn) {
-    reduce_partials_block(part_surf, nb_surf, part_edge, nb_edge, out, state, do_gn);
+    reduce_partials_block(part_surf, nb_surf, part_edge, nb_edge, out, state, do_gn, false);
 }
 
 // Restart of a registration: 56 bytes device to device.  hipMemcpyAsync(D2D) costs a 4.5 us copy kernel for this; one 8-lane

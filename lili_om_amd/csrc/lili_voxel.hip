@@ -84,29 +84,33 @@ __global__ __launch_bounds__(kSortBlock) void k_sort_scatter(const unsigned* __r
     }
 }
 
-struct VoxDev { float inv_leaf; int min_b[3]; int mul[3]; };
+struct VoxDev { float inv_leaf; int min_b[3]; int mul[3]; unsigned sentinel; };   // sentinel = number of voxels of the bounding box: key of non-finite points
 
 __global__ void k_vox_key(const float4* __restrict__ pts, int n, VoxDev V, unsigned* __restrict__ keys, int* __restrict__ vals) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float4 p = pts[i];
+    vals[i] = i;
+    // pcl::VoxelGrid skips non-finite points of a non-dense cloud (voxel_grid.hpp: `if (!isFinite(point)) continue`): they get a
+    // key above every voxel index, sort to the end and are left out of the output
+    if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) { keys[i] = V.sentinel; return; }
     // pcl::VoxelGrid::applyFilter: static_cast<int>(floor(x * inverse_leaf_size) - static_cast<float>(min_b))
     int i0 = (int)(floorf(p.x * V.inv_leaf) - (float)V.min_b[0]);
     int i1 = (int)(floorf(p.y * V.inv_leaf) - (float)V.min_b[1]);
     int i2 = (int)(floorf(p.z * V.inv_leaf) - (float)V.min_b[2]);
     keys[i] = (unsigned)(i0 * V.mul[0] + i1 * V.mul[1] + i2 * V.mul[2]);
-    vals[i] = i;
 }
-__global__ void k_vox_heads(const unsigned* __restrict__ keys, int n, int* __restrict__ flags) {
+__global__ void k_vox_heads(const unsigned* __restrict__ keys, int n, unsigned sentinel, int* __restrict__ flags) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+    if (i < n) flags[i] = (keys[i] != sentinel && (i == 0 || keys[i] != keys[i - 1])) ? 1 : 0;
 }
 __global__ void k_vox_centroid(const unsigned* __restrict__ keys, const int* __restrict__ vals, const int* __restrict__ slot /*exclusive scan of flags, [n+1]*/,
-                               const float4* __restrict__ pts, int n, float4* __restrict__ out, int* __restrict__ out_cnt) {
+                               const float4* __restrict__ pts, int n, unsigned sentinel, float4* __restrict__ out, int* __restrict__ out_cnt) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (!(i == 0 || keys[i] != keys[i - 1])) return;
     unsigned k = keys[i];
+    if (k == sentinel) return;
     float sx = 0.f, sy = 0.f, sz = 0.f, sa = 0.f; int c = 0;
     for (int m = i; m < n && keys[m] == k; m++) { float4 p = pts[vals[m]]; sx += p.x; sy += p.y; sz += p.z; sa += p.w; c++; }   // CentroidPoint: float accumulators
     float fn = (float)c;
@@ -200,17 +204,18 @@ static int voxel_filter_device(lili_ctx* ctx, lili_detail::VoxelBuffers* V, cons
     const double total = (double)div_b[0] * (double)div_b[1] * (double)div_b[2];
     if (total > 2147483647.0) return ctx->fail(LILI_E_ARG, "voxel_filter: leaf size too small for the cloud extent (voxel index would overflow int32, as in PCL)");
     P.mul[0] = 1; P.mul[1] = div_b[0]; P.mul[2] = div_b[0] * div_b[1];
-    int bits = 1; while (bits < 32 && (1ull << bits) < (unsigned long long)total) bits++;
+    P.sentinel = (unsigned)total;                 // <= 2^31 - 1
+    int bits = 1; while (bits < 32 && (1ull << bits) < (unsigned long long)total + 1ull) bits++;   // keys 0 .. total (sentinel included)
     HIPCHK(V->keys_a.ensure((size_t)n * 4)); HIPCHK(V->vals_a.ensure((size_t)n * 4));
     HIPCHK(V->flags.ensure((size_t)n * 4)); HIPCHK(V->slots.ensure(((size_t)n + 1) * 4));
     HIPCHK(V->out.ensure((size_t)n * 16)); HIPCHK(V->out_cnt.ensure((size_t)n * 4));
     hipLaunchKernelGGL(k_vox_key, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, d_pts, n, P, V->keys_a.as<unsigned>(), V->vals_a.as<int>());
     int rc = radix_sort(ctx, V, n, bits);
     if (rc != LILI_OK) return rc;
-    hipLaunchKernelGGL(k_vox_heads, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, V->keys_a.as<unsigned>(), n, V->flags.as<int>());
+    hipLaunchKernelGGL(k_vox_heads, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, V->keys_a.as<unsigned>(), n, P.sentinel, V->flags.as<int>());
     rc = exclusive_scan(ctx, V, V->flags.as<int>(), n, V->slots.as<int>());
     if (rc != LILI_OK) return rc;
-    hipLaunchKernelGGL(k_vox_centroid, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, V->keys_a.as<unsigned>(), V->vals_a.as<int>(), V->slots.as<int>(), d_pts, n,
+    hipLaunchKernelGGL(k_vox_centroid, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, V->keys_a.as<unsigned>(), V->vals_a.as<int>(), V->slots.as<int>(), d_pts, n, P.sentinel,
                        V->out.as<float4>(), V->out_cnt.as<int>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(&V->n_out, V->slots.as<int>() + n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -265,7 +270,8 @@ int lili_localmap_push(lili_ctx* ctx, int kind, const lili_cloud* features, cons
         if (e != hipSuccess) { delete kf; return ctx->fail(LILI_E_HIP, "localmap_push: allocation failed"); }
         hipLaunchKernelGGL(k_transform_cloud, dim3(nblocks(kf->n, 256)), dim3(256), 0, ctx->stream, V->in.as<float4>(), kf->n,
                            dq{q[0], q[1], q[2], q[3]}, d3{t[0], t[1], t[2]}, kf->pts.as<float4>());
-        HIPCHK(hipGetLastError());
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) { delete kf; return ctx->fail(LILI_E_HIP, std::string("localmap_push: ") + hipGetErrorString(le)); }
     }
     V->ring[kind].push_back(kf);
     while ((int)V->ring[kind].size() > width) {   // recent_*_keyframes.pop_front() (L:1449-1450)

@@ -102,3 +102,61 @@ def test_fullsize_oracle_spot_check_linearity_and_convergence(gpu_ctx, oracle, w
     assert np.abs(t - t_body).max() < 2e-3, np.abs(t - t_body).max()       # noisy synthetic scan: millimetres, from 0.3 m off
     dq = synth.quat_mul(q_body * np.array([1, -1, -1, -1]), q / np.linalg.norm(q))
     assert 2 * np.arcsin(min(1.0, np.linalg.norm(dq[1:]))) < 2e-4
+
+
+def test_fullsize_rot_surf_and_edge_pose_parity_with_oracle(gpu_ctx, oracle, workload):
+    """the BENCH workload in the flavour that is benchmarked — configs[2], 200 k surf queries vs the 5 M-point
+    map, ROT back-end (count-scaled residuals, Cauchy), PLUS the scan's edge features vs the edge map, 10 outer iterations from
+    the 0.3 m / 2 deg perturbed pose — against the oracle loop on the same inputs: every iteration's correspondence counts
+    equal, final pose within the north-star tolerance (1e-4 m / 1e-4 rad; measured ~1e-9)."""
+    import os
+    import bench
+    P, PO = L.make_params("rot"), oracle.params("rot")
+    mp, emap, scan = workload["map_xyz"], workload["edge_map_xyz"], workload["scan"]
+    # edge queries: cornerPointsLessSharp of the ROT extractor on the raw scan (oracle side, so that the test does not depend on the GPU extractor)
+    raw = np.concatenate([workload["scan_xyz"], np.full((workload["scan_xyz"].shape[0], 1), 10.0, np.float32)], 1)
+    ex = oracle.extract_rot(raw, P=oracle.rot_params(n_scans=64, ds_rate=1, atan_mode=1, stable_sort=1))
+    edge_q = np.ascontiguousarray(ex["full"][ex["edge_idx"]][:, :3])
+    assert edge_q.shape[0] > 500
+    t_body, q_body = bench.body_pose_for_lidar(L, P, workload["lidar_t"])
+    t0, q0 = synth.perturbed_pose(t_body, q_body, np.random.default_rng(synth.SEED_POSE), 0.3, 2.0)
+    mask = L.MASK_SURF | L.MASK_EDGE
+    m = L.ScanToMapMatcher(gpu_ctx, P)
+    m.set_input_cloud(L.KIND_SURF, mp)
+    m.set_input_cloud(L.KIND_EDGE, emap)
+    m.set_queries(0, L.KIND_SURF, scan)
+    m.set_queries(0, L.KIND_EDGE, edge_q)
+    # GPU: iteration by iteration so that the counts can be compared; then once more as ONE fused 10-iteration call
+    m.pose_set(0, t0, q0)
+    gpu_counts = []
+    for _ in range(10):
+        m.iterate(0, 1, mask)
+        t, q, st = m.pose_get(0)
+        assert st == 0
+        G, _, c = m.linearize(0, t, q, mask)        # records of the association this iteration used
+        gpu_counts.append((int(c[0]), int(c[1])))
+    tg, qg, _ = m.pose_get(0)
+    m.pose_set(0, t0, q0)
+    m.iterate(0, 10, mask)
+    tg2, qg2, st = m.pose_get(0)
+    assert st == 0 and np.array_equal(tg, tg2) and np.array_equal(qg, qg2)
+    # oracle loop
+    nth = os.cpu_count() or 1
+    tree, etree = oracle.KdTree(mp), oracle.KdTree(emap)
+    t, q = np.array(t0, np.float64), np.array(q0, np.float64)
+    for it in range(10):
+        Q2, T2 = L.api.assoc_transform(t, q, P)
+        rs = oracle.associate_surf(tree, None, scan, None, Q2, T2, PO, nthreads=nth)
+        re_ = oracle.associate_edge(etree, edge_q, Q2, T2, PO, nthreads=nth)
+        assert (rs["count"], re_["count"]) == gpu_counts[it], (it, rs["count"], re_["count"], gpu_counts[it])
+        Gs, _, _ = oracle.linearize_surf(rs, t, q, PO, (1000.0, max(rs["count"], 1)), nthreads=nth)
+        Ge, _, _ = oracle.linearize_edge(re_, t, q, PO, (200.0, max(re_["count"], 1)))
+        st, t, q, _ = oracle.gn_step(Gs + Ge, t, q)
+        assert st == 0
+    assert gpu_counts[-1][0] > 150_000 and gpu_counts[-1][1] > 50
+    dt = np.abs(tg - t).max()
+    dq = synth.quat_mul(qg * np.array([1, -1, -1, -1]), q)
+    dang = 2 * np.arcsin(min(1.0, np.linalg.norm(dq[1:])))
+    print(f"full-size ROT surf+edge, 10 iterations: |dt| {dt:.3e} m, dang {dang:.3e} rad vs oracle; counts {gpu_counts[-1]}")
+    assert dt < 1e-4 and dang < 1e-4
+    assert np.abs(tg - t_body).max() < 5e-3

@@ -226,7 +226,7 @@ def test_gpu_local_map_vs_reference_backend(gpu_ctx, kind, name, map_leaf, leaf)
     g = np.load(os.path.join(G, "ref_localmap.npz"))
     i = M.localmap_inputs()
     feats = i[name]
-    P = L.make_params("livox")
+    P = L.make_params("rot")        # only the neighbour lists are read back (the Livox flavour would require reflectivity on the queries)
     m = L.ScanToMapMatcher(gpu_ctx, P)
     gpu_ctx.set_debug(True)
     find = m.find_corresponding_surf_features if kind == L.KIND_SURF else m.find_corresponding_corner_features

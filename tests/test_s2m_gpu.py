@@ -408,11 +408,15 @@ def test_window_iteration_equals_sequential(gpu_ctx, oracle):
         m.iterate_window([0, 0], 1, L.MASK_SURF)
 
 
-@pytest.mark.parametrize("opt", ["nn_cache", "fuse_tail"])
+_OPTION_DEFAULTS = {"nn_cache": 0, "fuse_tail": 1, "merge_kinds": 1}
+
+
+@pytest.mark.parametrize("opt", ["nn_cache", "fuse_tail", "merge_kinds"])
 def test_tuning_options_do_not_change_results(gpu_ctx, oracle, opt):
-    """The measured-and-rejected switches stay exact: neighbour-cache bound seeding gives bit-identical
-    poses, neighbour lists and counts over several iterations; the fused reduce+GN tail the same up to its different
-    (still deterministic) block partition of the Gram sum."""
+    """Launch-structure switches change no result bit: neighbour-cache bound seeding, the reduction + GN update inside the
+    linearisation launch (fuse_tail: last block to arrive, write-through partials, sharded tickets) against the separate
+    k_reduce_partials launch, and one launch for both kinds (merge_kinds) against one launch per kind.  All add the same
+    numbers in the same order."""
     room = synth.make_room(seed=24, n_query=8000, n_edge_query=200)
     P = L.make_params("rot")
     tb, qb = L.api.body_pose_from_lidar(room["t_true"], room["q_true"], P)
@@ -432,20 +436,96 @@ def test_tuning_options_do_not_change_results(gpu_ctx, oracle, opt):
             t, q, st = m.pose_get(0)
             idx, d2 = m.neighbors(0, L.KIND_SURF, room["q_xyz"].shape[0])
             G, cost, counts = m.linearize(0, t, q, L.MASK_SURF | L.MASK_EDGE)
-            res.append((t, q, st, idx, d2, G, counts))
+            res.append((t, q, st, idx, d2, G, counts, cost))
     finally:
-        gpu_ctx.set_option(opt, 0)
+        gpu_ctx.set_option(opt, _OPTION_DEFAULTS[opt])
+        gpu_ctx.set_debug(False)
     a, b = res
     assert a[2] == b[2] == 0
     inside = a[4][:, 4] < 1.0
     assert inside.sum() > 1000
-    if opt == "nn_cache":         # only changes the pruning bound: bit-identical everything
-        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
-        assert np.array_equal(a[3][inside], b[3][inside]) and np.array_equal(a[4][inside], b[4][inside])
-        assert np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6])
-    else:                         # fuse_tail uses 1024-thread linearisation blocks: another (fixed) summation order
-        assert np.abs(a[0] - b[0]).max() < 1e-12 and np.abs(a[1] - b[1]).max() < 1e-12
-        assert np.abs(a[5] - b[5]).max() <= 1e-12 * np.abs(a[5]).max() and np.array_equal(a[6], b[6])
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.array_equal(a[3][inside], b[3][inside]) and np.array_equal(a[4][inside], b[4][inside])
+    assert np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6]) and a[7] == b[7]
+
+
+def test_fuse_tail_toggled_between_set_queries_and_iterate(gpu_ctx, oracle):
+    """the fused tail used to depend on a block size latched at set_queries.  The linearisation block is
+    fixed now, so the option may change at any time: toggling it after set_queries, in the middle of a registration, changes
+    no bit of the pose, and the fused launch repeated 200 times (tickets re-arm themselves) stays identical."""
+    room = synth.make_room(seed=31, n_query=9000, n_edge_query=150)
+    P = L.make_params("rot")
+    tb, qb = L.api.body_pose_from_lidar(room["t_true"], room["q_true"], P)
+    t0, q0 = synth.perturbed_pose(tb, qb, np.random.default_rng(17), 0.15, 1.0)
+    m = L.ScanToMapMatcher(gpu_ctx, P)
+    m.set_input_cloud(L.KIND_SURF, room["map_xyz"])
+    m.set_input_cloud(L.KIND_EDGE, room["edge_map_xyz"])
+    mask = L.MASK_SURF | L.MASK_EDGE
+    poses = []
+    try:
+        for pattern in ((1, 1, 1), (0, 0, 0), (0, 1, 0), (1, 0, 1)):
+            gpu_ctx.set_option("fuse_tail", pattern[0])
+            m.set_queries(0, L.KIND_SURF, room["q_xyz"])
+            m.set_queries(0, L.KIND_EDGE, room["eq_xyz"])
+            m.pose_set(0, t0, q0)
+            m.iterate(0, 2, mask)
+            gpu_ctx.set_option("fuse_tail", pattern[1])
+            m.iterate(0, 2, mask)
+            gpu_ctx.set_option("fuse_tail", pattern[2])
+            m.iterate(0, 2, mask)
+            poses.append(m.pose_get(0))
+        gpu_ctx.set_option("fuse_tail", 1)
+        m.pose_set(0, t0, q0)
+        m.iterate(0, 6, mask)
+        m.iterate_inner(0, 200, mask, want_cost=True)        # 200 fused launches on fixed records
+        a = m.pose_get(0)
+        gpu_ctx.set_option("fuse_tail", 0)
+        m.pose_set(0, t0, q0)
+        m.iterate(0, 6, mask)
+        m.iterate_inner(0, 200, mask, want_cost=True)
+        b = m.pose_get(0)
+    finally:
+        gpu_ctx.set_option("fuse_tail", 1)
+    for t, q, st in poses[1:]:
+        assert st == 0 and np.array_equal(t, poses[0][0]) and np.array_equal(q, poses[0][1])
+    assert a[2] == b[2] == 0 and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_inner_iterations_equal_host_gauss_newton(gpu_ctx, oracle):
+    """lili_s2m_iterate_inner = the reference's ceres::Solve loop shape (fixed correspondences, L/src/BackendFusion.cpp:984-992):
+    k device iterations equal k x [lili_s2m_linearize at the current pose -> lili_gn_step_host] on the same records."""
+    room = synth.make_room(seed=33, n_query=7000, n_edge_query=250)
+    for variant in ("rot", "livox"):
+        P, PO, m = _setup(gpu_ctx, oracle, variant, room, with_refl=(variant == "livox"))
+        tb, qb = L.api.body_pose_from_lidar(room["t_true"], room["q_true"], P)
+        t0, q0 = synth.perturbed_pose(tb, qb, np.random.default_rng(19), 0.05, 0.4)
+        mask = L.MASK_SURF | L.MASK_EDGE
+        m.pose_set(0, t0, q0)
+        m.associate_dev(0, mask)
+        m.iterate_inner(0, 4, mask, want_cost=True)
+        td, qd, st = m.pose_get(0)
+        assert st == 0
+        t, q = np.array(t0, np.float64), np.array(q0, np.float64)
+        for _ in range(4):
+            G, cost, counts = m.linearize(0, t, q, mask)
+            assert counts[0] > 1000 and counts[1] > 20
+            st, t, q, _ = L.api.gn_step_host(G, t, q)
+            assert st == 0
+        assert np.abs(td - t).max() < 1e-12 and np.abs(qd - q).max() < 1e-12
+        assert np.linalg.norm(td - np.asarray(t0)) > 1e-3          # the inner loop did move the pose
+
+
+def test_livox_flavour_needs_reflectivity_on_queries(gpu_ctx):
+    """queries without the auxiliary float used to be matched with reflectivity 0 (|0 - map curvature| weights)."""
+    room = synth.make_room(seed=5, n_query=500, n_edge_query=50)
+    P = L.make_params("livox")
+    m = L.ScanToMapMatcher(gpu_ctx, P)
+    m.set_input_cloud(L.KIND_SURF, np.c_[room["map_xyz"], room["map_refl"]])
+    m.set_queries(0, L.KIND_SURF, room["q_xyz"])                      # no aux column
+    with pytest.raises(L.LiliError):
+        m.find_corresponding_surf_features(0, [1.0, 0, 0, 0], [0.0, 0, 0])
+    m.set_queries(0, L.KIND_SURF, np.c_[room["q_xyz"], room["q_refl"]])
+    assert m.find_corresponding_surf_features(0, room["q_true"], room["t_true"]) > 0
 
 
 def test_fast_tiers_equal_exact_tiers(gpu_ctx, oracle):

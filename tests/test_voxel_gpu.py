@@ -35,6 +35,26 @@ def test_voxel_filter_edge_cases(gpu_ctx, oracle):
         L.api.voxel_filter(gpu_ctx, np.array([[0, 0, 0, 0], [1e6, 1e6, 1e6, 0]], np.float32), 0.01)
 
 
+def test_voxel_filter_skips_non_finite_points(gpu_ctx, oracle):
+    """NaN / Inf points used to get an arbitrary voxel key (UB cast) and could split or duplicate voxels.  PCL's
+    VoxelGrid skips non-finite points of a non-dense cloud: the result must equal the filter of the finite subset."""
+    rng = np.random.default_rng(77)
+    n = 60_000
+    pts = np.concatenate([rng.uniform(-40, 40, (n, 2)), rng.normal(0, 0.5, (n, 1)), rng.uniform(0, 25, (n, 1))], 1).astype(np.float32)
+    bad = rng.choice(n, 900, replace=False)
+    pts[bad[:300], 0] = np.nan
+    pts[bad[300:600], 1] = np.inf
+    pts[bad[600:], 2] = -np.inf
+    fin = np.isfinite(pts[:, :3]).all(1)
+    g, gc = L.api.voxel_filter(gpu_ctx, pts, 0.4)
+    o, oc = oracle.voxel_grid(np.ascontiguousarray(pts[fin]), 0.4, stable=True)
+    assert g.shape == o.shape and np.array_equal(gc, oc)
+    assert np.array_equal(g.view(np.uint32), o.view(np.uint32))
+    assert gc.sum() == fin.sum()
+    with pytest.raises(L.LiliError):                              # nothing finite at all
+        L.api.voxel_filter(gpu_ctx, np.full((4, 4), np.nan, np.float32), 0.4)
+
+
 def test_local_map_assembly_and_match(gpu_ctx, oracle):
     """push 5 keyframes (ring of width 4), commit, then match a scan against the device-built map: identical to
     assembling / filtering on the host with the oracle and calling set_input_cloud."""
