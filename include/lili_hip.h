@@ -97,8 +97,8 @@ int lili_set_debug(lili_ctx* ctx, int keep_neighbors);
  * the 125-cell block on demand; default 2; takes effect at the next lili_map_set), "cell_pct" (reach 2: cell edge in %
  * of the gate radius, 50..100, default 65), "nn_cache" (1 = tighten each query's search bound with its neighbours of
  * the previous association of the same scan; default 0, measured slower), "fuse_tail" (1 = the reduction of the block
- * partials and the GN update run inside the linearisation launch, in its last block to finish; default 1; 0 = separate
- * launch; may be changed at any time), "merge_kinds" (1 = surf and edge of a keyframe share ONE association launch and ONE
+ * partials and the GN update run inside the linearisation launch, in its last block; default 0 = separate launch, which is
+ * faster on MI355X; may be changed at any time), "merge_kinds" (1 = surf and edge of a keyframe share ONE association launch and ONE
  * linearisation launch; default 1). */
 int lili_set_option(lili_ctx* ctx, const char* name, int value);
 

@@ -4,6 +4,7 @@
 #include "lili_ctx.h"
 
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -107,8 +108,7 @@ int lili_ctx_create(lili_ctx** out, int device, void* stream) {
     bool ok = ctx->states.ensure(sizeof(SlotState) * LILI_MAX_SLOTS) == hipSuccess &&
               ctx->gram.ensure(sizeof(double) * LILI_GRAM_DOUBLES * LILI_MAX_SLOTS) == hipSuccess &&
               ctx->misc.ensure(256) == hipSuccess &&
-              ctx->tickets.ensure(sizeof(unsigned) * kTicketWordsPerSlot * LILI_MAX_SLOTS) == hipSuccess &&
-              hipMemsetAsync(ctx->tickets.p, 0, sizeof(unsigned) * kTicketWordsPerSlot * LILI_MAX_SLOTS, ctx->stream) == hipSuccess &&
+
               hipMemsetAsync(ctx->states.p, 0, sizeof(SlotState) * LILI_MAX_SLOTS, ctx->stream) == hipSuccess &&
               hipMemsetAsync(ctx->gram.p, 0, sizeof(double) * LILI_GRAM_DOUBLES * LILI_MAX_SLOTS, ctx->stream) == hipSuccess;
     if (!ok) { lili_ctx_destroy(ctx); return LILI_E_HIP; }
@@ -122,7 +122,7 @@ void lili_ctx_destroy(lili_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& m : ctx->map) { m.pts.release(); m.sorted.release(); m.aux_sorted.release(); m.cell_start.release(); m.cell_tmp.release(); m.pt_cell.release(); m.block_sums.release(); }
     for (auto& s : ctx->slots) for (auto& k : s.k) { k.q.release(); k.rec0.release(); k.rec1.release(); k.valid.release(); k.dbg_idx.release(); k.dbg_d2.release(); k.partials.release(); k.perm.release(); k.keys.release(); k.block_counts.release(); k.tiles.release(); }
-    ctx->states.release(); ctx->tickets.release(); ctx->staging.release(); ctx->gram.release(); ctx->misc.release(); ctx->bin_hist.release(); ctx->bin_start.release(); ctx->bin_sums.release(); ctx->bin_tcnt.release(); ctx->bin_toff.release();
+    ctx->states.release(); ctx->staging.release(); ctx->gram.release(); ctx->misc.release(); ctx->bin_hist.release(); ctx->bin_start.release(); ctx->bin_sums.release(); ctx->bin_tcnt.release(); ctx->bin_toff.release();
     if (ctx->ext_rot && ctx->ext_rot_free) ctx->ext_rot_free(ctx->ext_rot);
     if (ctx->ext_livox && ctx->ext_livox_free) ctx->ext_livox_free(ctx->ext_livox);
     if (ctx->ext_voxel && ctx->ext_voxel_free) ctx->ext_voxel_free(ctx->ext_voxel);
@@ -275,7 +275,7 @@ int lili_s2m_set_queries(lili_ctx* ctx, int slot, int kind, const lili_cloud* cl
         HIPCHK(ks.rec0.ensure(n * sizeof(float4)));
         HIPCHK(ks.rec1.ensure(n * sizeof(float4)));   // surf: doubles (8 B) fit in the float4 budget
         HIPCHK(ks.valid.ensure(n));
-        HIPCHK(ks.partials.ensure((size_t)ks.n_lin_blocks * kPartialDoubles * sizeof(double)));
+        HIPCHK(ks.partials.ensure((size_t)ks.n_lin_blocks * kPartialStride * sizeof(double)));
         HIPCHK(ks.block_counts.ensure((size_t)ks.n_blocks * sizeof(int)));
     }
     ks.has_queries = true;
@@ -484,12 +484,14 @@ static int launch_linearize_reduce(lili_ctx* ctx, int slot, int kind_mask, const
     }
     const int* ng = s.use_global_counts ? s.global_counts : nullptr;
     FuseTail fz{};
-    fz.mode = (ctx->fuse_tail && n_kinds > 0) ? (do_gn ? 2 : 1) : 0; fz.out = d_out; fz.state = ctx->state(slot); fz.tickets = ctx->tickets_of(slot);
+    fz.mode = (ctx->fuse_tail && n_kinds > 0) ? (do_gn ? 2 : 1) : 0; fz.out = d_out; fz.state = ctx->state(slot); fz.debug = P.debug;
     fz.part_surf = A[0].partials; fz.nb_surf = A[0].nb; fz.part_edge = A[1].partials; fz.nb_edge = A[1].nb;
     const FuseTail off{};
     const size_t lds = lds_linearize(kLinBlock);
     if (n_kinds == 2 && !ctx->merge_kinds) {       // A/B: one launch per kind, the tail on the second
-        hipLaunchKernelGGL(k_linearize, dim3(A[0].nb), dim3(kLinBlock), lds, ctx->stream, A[0], LinArgs{}, pa, P, ctx->state(slot), ng, off);
+        FuseTail pub = off;
+        if (fz.mode) { pub = fz; pub.mode = 3; }     // publish granules under the same key; the edge launch reduces both kinds
+        hipLaunchKernelGGL(k_linearize, dim3(A[0].nb), dim3(kLinBlock), lds, ctx->stream, A[0], LinArgs{}, pa, P, ctx->state(slot), ng, pub);
         hipLaunchKernelGGL(k_linearize, dim3(A[1].nb), dim3(kLinBlock), lds, ctx->stream, LinArgs{}, A[1], pa, P, ctx->state(slot), ng, fz);
     } else if (n_kinds > 0) {
         hipLaunchKernelGGL(k_linearize, dim3(A[0].nb + A[1].nb), dim3(kLinBlock), lds, ctx->stream, A[0], A[1], pa, P, ctx->state(slot), ng, fz);
@@ -640,7 +642,9 @@ int lili_s2m_pose_set(lili_ctx* ctx, int slot, const double t[3], const double q
     SlotState s{};
     for (int i = 0; i < 3; i++) s.pose[i] = t[i];
     for (int i = 0; i < 4; i++) s.pose[3 + i] = q[i];
-    HIPCHK(hipMemcpyAsync(ctx->state(slot), &s, sizeof(s), hipMemcpyHostToDevice, ctx->stream));
+    // everything but the launch epoch (the last member): its key tags the granules of the fused linearisation launches and must
+    // never repeat while stale granules of this slot's partial buffers may still carry it
+    HIPCHK(hipMemcpyAsync(ctx->state(slot), &s, offsetof(SlotState, epoch), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));   // `s` is on this stack frame
     return LILI_OK;
 }

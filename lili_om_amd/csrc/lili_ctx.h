@@ -65,7 +65,7 @@ struct Slot {
 };
 
 constexpr int kLinBlock = 1024;      // must match lili_s2m.hip
-constexpr int kTicketWordsPerSlot = 9 * 1024;   // fused tail: 8 shard counters + 1 top counter, 4 KiB apart (kTicketStride words, lili_s2m.hip)
+
 constexpr int kMaxLinBlocks = 256;
 inline size_t lds_linearize(int threads) { return (size_t)threads * 10 * sizeof(double); }   // rows [J r 1 cost]; reused for the 16x16 wave results
 
@@ -83,7 +83,6 @@ struct lili_ctx {
     MapIndex map[2];
     Slot slots[LILI_MAX_SLOTS];
     DevBuf states;       // SlotState[LILI_MAX_SLOTS]
-    DevBuf tickets;      // arrival counters of the fused linearise + reduce + GN launch, kTicketWordsPerSlot words per slot
     DevBuf staging;      // raw host clouds
     DevBuf fmt_out;      // lili_livox_custom_to_cloud output when the caller wants it on the host
     DevBuf gram;         // LILI_GRAM_DOUBLES per slot
@@ -93,7 +92,9 @@ struct lili_ctx {
     bool tiled = false;         // LDS-staged tiles: measured slower than the direct path once selection is branch-free
     int max_cells = 1 << 27;
     int grid_reach = 2;          // 2: cells smaller than the gate radius, inner 3x3x3 block first, shell on demand (knn5_grid)
-    bool fuse_tail = true;       // reduce (+ GN) inside the linearisation launch: the last block to arrive does it (write-through partials + sharded tickets)
+    bool fuse_tail = false;      // reduce (+ GN) inside the linearisation launch (its last block sweeps the other blocks' granule-tagged partials):
+                                 // bit-identical, measured SLOWER than the separate k_reduce_partials launch (41.1 vs 38.9 us per iteration: reading 125 KB
+                                 // of freshly published partials through sc1 loads costs one block 3.4 us, a kernel boundary 1.5 us) — A/B only
     bool merge_kinds = true;     // surf and edge of one keyframe in ONE association launch / ONE linearisation launch
     bool nn_cache = false;       // seed each query's search bound with its previous 5 neighbours (exact for any pose change)
     int cell_pct = 65;           // reach 2: cell edge in % of 1.01 * gate radius (>= 50)
@@ -109,7 +110,6 @@ struct lili_ctx {
     int fail(int code, const std::string& m) { err = m; return code; }
     SlotState* state(int slot) { return states.as<SlotState>() + slot; }
     double* gram_of(int slot) { return gram.as<double>() + (size_t)slot * LILI_GRAM_DOUBLES; }
-    unsigned* tickets_of(int slot) { return tickets.as<unsigned>() + (size_t)slot * kTicketWordsPerSlot; }
 };
 
 #define HIPCHK(expr)                                                                                         \

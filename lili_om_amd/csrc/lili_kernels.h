@@ -29,16 +29,17 @@ struct SlotState {
     double last_delta[6];
     long long tprof[16];   // profiling aid (LILI_DEBUG bit 256): s_memrealtime stamps (100 MHz) of one block per kernel
     unsigned int reserved_;
+    unsigned long long epoch;   // fused linearisation launches of this slot so far: launch_key(epoch) tags the granules of the next one
 };
 
 // Fused tail of a linearisation launch (see fused_tail in lili_s2m.hip)
 struct FuseTail {
-    int mode;                  // 0 = off, 1 = reduce to `out`, 2 = reduce + GN update
+    int mode;                  // 0 = off, 1 = reduce to `out`, 2 = reduce + GN update, 3 = publish the partials as granules only
     const double* part_surf; int nb_surf;
     const double* part_edge; int nb_edge;
     double* out;
     SlotState* state;
-    unsigned* tickets;         // this slot's arrival counters (kTicketShards + 1 words, kTicketStride apart; self-resetting)
+    int debug;                 // LILI_DEBUG bits (256: phase stamps of the reducer block)
 };
 
 
@@ -82,6 +83,7 @@ struct AssocArgs {
 };
 
 constexpr int kPartialDoubles = 40;  // per-block partial: 36 upper-triangle Gram entries, cost, count, 2 spare
+constexpr int kPartialStride = 80;   // doubles per block slot of the partial buffers: 40 plain doubles, or 40 16-byte granules {value, value ^ key}
 constexpr int kBlock = 256;
 // Dispatch-order control of the association kernels (one wave per workgroup).  The hardware places workgroup b on SIMD
 // (b mod #SIMDs) — measured: tools/assoc_blocks.py — so with 3125 waves on 1024 SIMDs the kernel ends when the SIMDs that

@@ -1128,6 +1128,19 @@ __device__ __forceinline__ void tstamp(const SlotState* state, int debug, int pr
     if ((debug & 256) && (int)blockIdx.x == probe_block && threadIdx.x == 0)
         const_cast<SlotState*>(state)->tprof[slot] = (long long)__builtin_amdgcn_s_memrealtime();
 }
+// 16-byte granule {value, value ^ key}: one write-through store / two relaxed agent-scope (sc1) loads
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned long long launch_key(unsigned long long epoch) { return (epoch + 1ull) * 0x9E3779B97F4A7C15ull; }   // never 0 for epoch < 2^64 - 1
+__device__ __forceinline__ void store_granule(double* g, double v, unsigned long long key) {
+    const unsigned long long lo = (unsigned long long)__double_as_longlong(v), hi = lo ^ key;
+    const u32x4 d = {(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(g), "v"(d) : "memory");
+}
+__device__ __forceinline__ void load_granule(const double* g, unsigned long long& lo, unsigned long long& hi) {
+    const unsigned long long* p = reinterpret_cast<const unsigned long long*>(g);
+    lo = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    hi = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 struct GramAcc {
     v4f64 acc;
     __device__ __forceinline__ void init() { acc = v4f64{0.0, 0.0, 0.0, 0.0}; }
@@ -1154,10 +1167,11 @@ struct GramAcc {
         }
     }
     // block partial: 36 upper-triangle entries of the 8x8 Gram, [36] = cost, [37] = count
-    // `publish`: the partial is stored write-through (agent-scope relaxed atomic store = `global_store ... sc1`), so that another
-    // workgroup of the SAME launch may read it after the ticket hand-off of fused_tail without any L2 write-back fence
-    // (MI355X_MICROARCH.md, inter-workgroup visibility, form R1).
-    __device__ __forceinline__ void finish(double* lds, double* partial_out, bool publish = false) {
+    // `key` != 0: the partial is PUBLISHED for the reducer block of the same launch (fused_tail) as 40 granules of 16 bytes,
+    // {value bits, value bits ^ key}, each written by ONE write-through (sc1) 16-byte store.  The data is its own flag: a granule
+    // whose halves satisfy hi == lo ^ key was written by THIS launch (key is unique per launch), so the reducer needs no ticket, no
+    // fence and no drained-store wait on the producer side (MI355X_MICROARCH.md, inter-workgroup visibility, form R2).
+    __device__ __forceinline__ void finish(double* lds, double* slot, unsigned long long key = 0ull) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         __syncthreads();                 // every wave is done with its row area before the LDS is reused for the wave results
         double* dm = lds + wave * 256;   // this wave's 16x16 result, row-major
@@ -1174,50 +1188,25 @@ struct GramAcc {
             else { row = 15; cl = 15; }   // spare slots: always zero
             double s = 0.0;
             for (int w = 0; w < (int)(blockDim.x >> 6); w++) s += lds[w * 256 + row * 16 + cl];
-            if (publish) __hip_atomic_store(reinterpret_cast<unsigned long long*>(partial_out) + e, (unsigned long long)__double_as_longlong(s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else partial_out[e] = s;
+            if (key) store_granule(slot + 2 * e, s, key);
+            else slot[e] = s;
         }
     }
 };
 
-// ---- fused tail: the LAST block of a linearisation launch to finish adds all block partials (fixed order, so the
-// result does not depend on which block that is) and, optionally, applies the Gauss-Newton update — the whole inner
-// iteration (linearise + reduce + solve + pose update) is ONE launch.
-// Hand-off (MI355X_MICROARCH.md "inter-workgroup visibility", form R1, and the fan-in row of the price list): the block
-// partials are stored write-through (sc1) by GramAcc::finish, the storing waves drain their stores (s_waitcnt vmcnt(0)),
-// one lane per block takes a ticket with a relaxed agent-scope atomic; the last arriver reads the partials with sc1 loads
-// (L1 bypassed, no acquire fence, no L2 write-back — round 1's __threadfence pair cost more than the kernel boundary it saved).
-// Tickets are sharded eight ways (block b arrives at shard b mod 8, the last of a shard arrives at the top counter): at most
-// 32 + 8 same-address atomics queue up (11-13 ns each) instead of 256.  Counters reset themselves; they are zeroed when the
-// context is created.  The words of one slot are 4 KiB apart (different channels).
-constexpr int kTicketStride = 1024;          // unsigned words between the counters of one slot
-constexpr int kTicketShards = 8;
+// ---- fused tail: the whole inner iteration (linearise + reduce + solve + pose update) is ONE launch.  The block with the highest
+// index is the REDUCER: after its own tile it sweeps the granules of all block partials until every one carries this launch's key
+// (GramAcc::finish), adds them in the fixed order of reduce_partials_block — so the record does not depend on timing — and applies
+// the Gauss-Newton update.  The other blocks just store and leave: no ticket, no fence, no drained-store wait
+// (round 1's __threadfence pair, and a first round-2 version with write-through partials + sharded tickets, both cost more than
+// the kernel boundary they saved: 46.1 / 39.9 vs 43.0 / 38.6 us per iteration — the chain store -> ack -> atomic -> atomic -> load is
+// four memory round trips; the granule sweep is one).  key = launch_key(state->epoch); the reducer advances the epoch.
 __device__ void reduce_partials_block(const double* part_surf, int nb_surf, const double* part_edge, int nb_edge,
-                                      double* __restrict__ out, SlotState* __restrict__ state, int do_gn, bool coherent);   // defined below
-__device__ __forceinline__ void fused_tail(const FuseTail& fz) {
-    if (!fz.mode) return;
-    __shared__ int s_last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave: its write-through stores have left (only threads < 40 stored)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int nb = (int)gridDim.x, shard = (int)blockIdx.x % kTicketShards;
-        const int n_shards = nb < kTicketShards ? nb : kTicketShards;
-        const int in_shard = (nb - shard + kTicketShards - 1) / kTicketShards;
-        unsigned* tk = fz.tickets + (size_t)shard * kTicketStride;
-        unsigned* top = fz.tickets + (size_t)kTicketShards * kTicketStride;
-        int last = 0;
-        if (__hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(in_shard - 1)) {
-            __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // ready for the next launch (stream order)
-            if (__hip_atomic_fetch_add(top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(n_shards - 1)) {
-                __hip_atomic_store(top, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                last = 1;
-            }
-        }
-        s_last = last;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    reduce_partials_block(fz.part_surf, fz.nb_surf, fz.part_edge, fz.nb_edge, fz.out, fz.state, fz.mode == 2 ? 1 : 0, true);
+                                      double* __restrict__ out, SlotState* __restrict__ state, int do_gn, unsigned long long key);   // defined below
+__device__ __forceinline__ void fused_tail(const FuseTail& fz, unsigned long long key) {
+    if (fz.mode != 1 && fz.mode != 2) return;      // 0: plain partials for k_reduce_partials; 3: publish only (the per-kind launches of merge_kinds = 0: the second launch reduces)
+    if (blockIdx.x != gridDim.x - 1) return;
+    reduce_partials_block(fz.part_surf, fz.nb_surf, fz.part_edge, fz.nb_edge, fz.out, fz.state, (fz.mode == 2 ? 1 : 0) | (fz.debug & 256), key);
 }
 
 __device__ __forceinline__ void load_body_pose(const PoseArg& pa, dq& Q, d3& T) {
@@ -1227,7 +1216,7 @@ __device__ __forceinline__ void load_body_pose(const PoseArg& pa, dq& Q, d3& T) 
 
 // Linearisation bodies: `bid` of `nb` virtual blocks of one kind (the combined surf + edge launch maps its grid onto both).
 __device__ __forceinline__ void lin_surf_body(const LinArgs& A, int bid, const PoseArg& pa, const MatchParams& P, const SlotState* __restrict__ state,
-                                              const int* __restrict__ n_global, double* lds, bool publish) {
+                                              const int* __restrict__ n_global, double* lds, unsigned long long key) {
     const float4* __restrict__ queries = A.queries; const float4* __restrict__ rec_nd = A.rec0;
     const double* __restrict__ rec_score = reinterpret_cast<const double*>(A.rec1);
     const unsigned char* __restrict__ valid = A.valid;
@@ -1285,12 +1274,12 @@ __device__ __forceinline__ void lin_surf_body(const LinArgs& A, int bid, const P
         tstamp(state, P.debug, 100, 3);
         if ((P.debug & 512) && bid == 100 && (threadIdx.x & 63) == 0) const_cast<SlotState*>(state)->tprof[threadIdx.x >> 6] = (long long)__builtin_amdgcn_s_memrealtime();
     }
-    ga.finish(lds, A.partials + (size_t)bid * kPartialDoubles, publish);
+    ga.finish(lds, A.partials + (size_t)bid * kPartialStride, key);
     tstamp(state, P.debug, 100, 4);
 }
 
 __device__ __forceinline__ void lin_edge_body(const LinArgs& A, int bid, const PoseArg& pa, const MatchParams& P, const SlotState* __restrict__ state,
-                                              const int* __restrict__ n_global, double* lds, bool publish) {
+                                              const int* __restrict__ n_global, double* lds, unsigned long long key) {
     const float4* __restrict__ queries = A.queries; const float4* __restrict__ rec_a = A.rec0;
     const float4* __restrict__ rec_b = reinterpret_cast<const float4*>(A.rec1);
     const unsigned char* __restrict__ valid = A.valid;
@@ -1332,7 +1321,7 @@ __device__ __forceinline__ void lin_edge_body(const LinArgs& A, int bid, const P
         }
         ga.add_rows(Jr, cost, ok, lds);
     }
-    ga.finish(lds, A.partials + (size_t)bid * kPartialDoubles, publish);
+    ga.finish(lds, A.partials + (size_t)bid * kPartialStride, key);
 }
 
 // One launch for the kinds present: blocks [0, S.nb) linearise the surf records, blocks [S.nb, S.nb + E.nb) the edge records
@@ -1341,9 +1330,11 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize(LinArgs S, LinArgs E, P
                                                          const int* __restrict__ n_global, FuseTail fz) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int bid = (int)blockIdx.x;
-    if (bid < S.nb) lin_surf_body(S, bid, pa, P, state, n_global, lds, fz.mode != 0);
-    else lin_edge_body(E, bid - S.nb, pa, P, state, n_global, lds, fz.mode != 0);
-    fused_tail(fz);
+    const unsigned long long key = fz.mode ? launch_key(state->epoch) : 0ull;
+    if (fz.mode && (fz.debug & 256) && bid == (int)gridDim.x - 1 && threadIdx.x == 0) fz.state->tprof[12] = (long long)__builtin_amdgcn_s_memrealtime();
+    if (bid < S.nb) lin_surf_body(S, bid, pa, P, state, n_global, lds, key);
+    else lin_edge_body(E, bid - S.nb, pa, P, state, n_global, lds, key);
+    fused_tail(fz, key);
 }
 
 // ================================================================================================
@@ -1355,13 +1346,17 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize(LinArgs S, LinArgs E, P
 //   P = blockdiag(I3, plusJacobian(q) 4x3); H = P^T G77 P, g = P^T G7r; solve H d = -g (Cholesky);
 //   t += d[0:3]; q = [cos|dq|, sin|dq|/|dq| dq] (x) q
 // ================================================================================================
-// xq: the quaternion of state->pose, loaded by the caller at kernel start (its latency hides behind the partial loads)
+// wave-level ordering of LDS traffic inside ONE wave (LDS operations of a wave execute in order; the fence keeps the compiler from
+// moving them) — the tail of the reduction and the GN update run in a single wave, without s_barrier
+#define LILI_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+// xq: the quaternion of state->pose, loaded by the caller at kernel start (its latency hides behind the partial loads).
+// Must be called by exactly ONE wave (lanes 0..63 of it).
 __device__ void gn_update_block(const double* gram /*LDS or global, 64+*/, SlotState* __restrict__ state, const double xq[4]) {
     __shared__ double Jq[4][3];   // plus-Jacobian rows: [-x1 -x2 -x3; x0 x3 -x2; -x3 x0 x1; x2 -x1 x0]
     __shared__ double M[7][6];    // M = G77 * P   (P = blockdiag(I3, Jq): only 4 terms per entry)
     __shared__ double H[6][6];
     __shared__ double gvec[6];
-    int tid = threadIdx.x;
+    int tid = threadIdx.x & 63;
     const double x0 = xq[0], x1 = xq[1], x2 = xq[2], x3 = xq[3];
     if (tid < 12) {
         int rr = tid / 3, cc = tid % 3;
@@ -1370,7 +1365,7 @@ __device__ void gn_update_block(const double* gram /*LDS or global, 64+*/, SlotS
         double e2 = rr == 0 ? -x3 : rr == 1 ? -x2 : rr == 2 ? x1 : x0;
         Jq[rr][cc] = cc == 0 ? e0 : cc == 1 ? e1 : e2;
     }
-    __syncthreads();
+    LILI_WAVE_SYNC();
     if (tid < 42) {
         int i = tid / 6, b = tid % 6;
         double v;
@@ -1378,7 +1373,7 @@ __device__ void gn_update_block(const double* gram /*LDS or global, 64+*/, SlotS
         else v = ((gram[i * 8 + 3] * Jq[0][b - 3] + gram[i * 8 + 4] * Jq[1][b - 3]) + gram[i * 8 + 5] * Jq[2][b - 3]) + gram[i * 8 + 6] * Jq[3][b - 3];
         M[i][b] = v;
     }
-    __syncthreads();
+    LILI_WAVE_SYNC();
     if (tid < 36) {
         int a = tid / 6, b = tid % 6;
         double v;
@@ -1392,7 +1387,7 @@ __device__ void gn_update_block(const double* gram /*LDS or global, 64+*/, SlotS
         else v = ((Jq[0][a - 3] * gram[3 * 8 + 7] + Jq[1][a - 3] * gram[4 * 8 + 7]) + Jq[2][a - 3] * gram[5 * 8 + 7]) + Jq[3][a - 3] * gram[6 * 8 + 7];
         gvec[a] = -v;
     }
-    __syncthreads();
+    LILI_WAVE_SYNC();
     if (tid == 0) {
         // 6x6 LDL^T solve entirely in registers (all indices are compile-time constants after unrolling): six dependent
         // divisions (1/d_j) instead of the 6 square roots + 27 divisions of a Cholesky with per-element divides — the
@@ -1457,71 +1452,110 @@ __device__ void gn_update_block(const double* gram /*LDS or global, 64+*/, SlotS
 }
 
 constexpr int kReduceThreads = 1024;
-__device__ __forceinline__ double load_partial(const double* p, bool coherent) {
-    // coherent: written by another workgroup of THIS launch with sc1 stores -> read with an sc1 load (bypasses this CU's L1)
-    if (coherent) return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    return *p;
+// One chunk of the fixed-order partial sum: lane (g, e) takes partials g + 25 c' (c' = 8 c .. 8 c + 7) of `part`.  key == 0: plain
+// 40-double partials written by an earlier launch.  key != 0: granules published by the blocks of THIS launch — the loads are
+// repeated until every granule of the chunk carries the key (block-wide vote), at most kMaxSweeps times.
+constexpr int kMaxSweeps = 1 << 16;
+__device__ __forceinline__ bool sum_partial_chunk(const double* part, int nb, int c, int g, int e, int groups, unsigned long long key, double& s) {
+    double v[8];
+    if (!key) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int b = g + (c * 8 + u) * groups; v[u] = (g < groups && b < nb) ? part[(size_t)b * kPartialStride + e] : 0.0; }
+    } else {
+        for (int sweep = 0;; sweep++) {
+            unsigned long long lo[8], hi[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int b = g + (c * 8 + u) * groups;
+                if (g < groups && b < nb) load_granule(part + (size_t)b * kPartialStride + 2 * e, lo[u], hi[u]);
+                else { lo[u] = 0ull; hi[u] = key; }
+            }
+            bool ok = true;
+#pragma unroll
+            for (int u = 0; u < 8; u++) ok = ok && ((lo[u] ^ hi[u]) == key);
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = __longlong_as_double((long long)lo[u]);
+            if (__syncthreads_and(ok ? 1 : 0)) break;
+            if (sweep >= kMaxSweeps) return false;          // uniform: a block of this launch never published (cannot happen unless the launch was cut short)
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) s += v[u];
+    return true;
 }
-// all kReduceThreads threads of ONE block; partials may have been written by other blocks of the same launch (fused tail:
-// coherent = true).  The order of the additions is fixed (25 groups of 40 lanes, group g adds partials g, g+25, ... in
-// sequence, then the groups in sequence), so the record does not depend on which block runs this or on timing.
+// all kReduceThreads threads of ONE block.  The order of the additions is fixed (25 groups of 40 lanes, group g adds partials
+// g, g+25, ... in sequence, then the groups in sequence), so the record does not depend on which launch structure produced the
+// partials or on timing.
 __device__ void reduce_partials_block(const double* part_surf, int nb_surf, const double* part_edge, int nb_edge,
-                                      double* __restrict__ out, SlotState* __restrict__ state, int do_gn, bool coherent) {
-    tstamp(state, do_gn, 0, 8);
+                                      double* __restrict__ out, SlotState* __restrict__ state, int do_gn, unsigned long long key) {
+    tstamp(state, do_gn, (int)blockIdx.x, 8);
     const double xq[4] = {state->pose[3], state->pose[4], state->pose[5], state->pose[6]};
     constexpr int kGroups = kReduceThreads / 40;   // 25 groups of 40 lanes, group g adds partials g, g+25, ...
     __shared__ double acc[kGroups][2][40];
     __shared__ double tri[40];
     __shared__ double full[72];
-    int e = threadIdx.x % 40, g = threadIdx.x / 40;
-    if (g < kGroups) {
-        // independent loads first (8 in flight per lane), adds in a fixed order afterwards
+    const int e = threadIdx.x % 40, g = threadIdx.x / 40;
+    bool ok = true;
+    if (key) {
+        // cheap wait first: ONE granule per block partial (its last one), one lane each, until all carry the key; the full
+        // sweep below (which verifies every granule it adds) then normally passes at once
+        const int nb_all = nb_surf + nb_edge;
+        for (int sweep = 0;; sweep++) {
+            bool seen = true;
+            for (int b = threadIdx.x; b < nb_all; b += blockDim.x) {
+                const double* gp = (b < nb_surf ? part_surf + (size_t)b * kPartialStride : part_edge + (size_t)(b - nb_surf) * kPartialStride) + 2 * 39;
+                unsigned long long lo, hi;
+                load_granule(gp, lo, hi);
+                seen = seen && ((lo ^ hi) == key);
+            }
+            if (__syncthreads_and(seen ? 1 : 0)) break;
+            if (sweep >= kMaxSweeps) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    tstamp(state, do_gn, (int)blockIdx.x, 13);
+    {
         double s = 0.0, s2 = 0.0;
-        for (int b0 = g; b0 < nb_surf; b0 += kGroups * 8) {
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { int b = b0 + u * kGroups; v[u] = b < nb_surf ? load_partial(part_surf + (size_t)b * kPartialDoubles + e, coherent) : 0.0; }
-#pragma unroll
-            for (int u = 0; u < 8; u++) s += v[u];
+        for (int c = 0; c * 8 * kGroups < nb_surf && ok; c++) ok = sum_partial_chunk(part_surf, nb_surf, c, g, e, kGroups, key, s);
+        for (int c = 0; c * 8 * kGroups < nb_edge && ok; c++) ok = sum_partial_chunk(part_edge, nb_edge, c, g, e, kGroups, key, s2);
+        if (!ok) {           // uniform
+            if (threadIdx.x == 0) { state->gn_status = 2; state->epoch = state->epoch + 1ull; }
+            return;
         }
-        for (int b0 = g; b0 < nb_edge; b0 += kGroups * 8) {
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { int b = b0 + u * kGroups; v[u] = b < nb_edge ? load_partial(part_edge + (size_t)b * kPartialDoubles + e, coherent) : 0.0; }
-#pragma unroll
-            for (int u = 0; u < 8; u++) s2 += v[u];
-        }
-        acc[g][0][e] = s; acc[g][1][e] = s2;
+        if (g < kGroups) { acc[g][0][e] = s; acc[g][1][e] = s2; }
     }
-    tstamp(state, do_gn, 0, 9);
+    tstamp(state, do_gn, (int)blockIdx.x, 9);
     __syncthreads();
-    if (threadIdx.x >= 128) return;     // the rest is two waves' work (threads < 72): the later barriers then involve only them
-    if (threadIdx.x < 40) {
-        int k = threadIdx.x;
+    if (threadIdx.x >= 64) return;      // the rest is ONE wave's work: no further block barriers
+    const int lane = threadIdx.x;
+    if (lane < 40) {
         double ss = 0.0, se = 0.0;
-        for (int gg = 0; gg < kGroups; gg++) { ss += acc[gg][0][k]; se += acc[gg][1][k]; }
-        tri[k] = ss + se;
-        if (k == 37) { full[65] = ss; full[66] = se; }
+        for (int gg = 0; gg < kGroups; gg++) { ss += acc[gg][0][lane]; se += acc[gg][1][lane]; }
+        tri[lane] = ss + se;
+        if (lane == 37) { full[65] = ss; full[66] = se; }
     }
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        int r = threadIdx.x >> 3, c = threadIdx.x & 7;
+    LILI_WAVE_SYNC();
+    {
+        int r = lane >> 3, c = lane & 7;
         int a = r < c ? r : c, b = r < c ? c : r;
-        full[threadIdx.x] = tri[a * 8 - a * (a - 1) / 2 + (b - a)];
+        full[lane] = tri[a * 8 - a * (a - 1) / 2 + (b - a)];
+        if (lane == 0) full[64] = tri[36];
+        if (lane >= 3 && lane < 8) full[64 + lane] = 0.0;     // 67..71
     }
-    if (threadIdx.x == 64) full[64] = tri[36];
-    if (threadIdx.x >= 67 && threadIdx.x < 72) full[threadIdx.x] = 0.0;
-    __syncthreads();
-    if (threadIdx.x < 72) out[threadIdx.x] = full[threadIdx.x];
-    tstamp(state, do_gn, 0, 10);
+    LILI_WAVE_SYNC();
+    out[lane] = full[lane];
+    if (lane < 8) out[64 + lane] = full[64 + lane];
+    if (key && lane == 0) state->epoch = state->epoch + 1ull;      // the next fused launch of this slot gets a new key (stream order)
+    tstamp(state, do_gn, (int)blockIdx.x, 10);
     if (do_gn & 1) gn_update_block(full, state, xq);
-    tstamp(state, do_gn, 0, 11);
+    tstamp(state, do_gn, (int)blockIdx.x, 11);
 }
 
 __global__ __launch_bounds__(kReduceThreads) void k_reduce_partials(const double* __restrict__ part_surf, int nb_surf,
                                                             const double* __restrict__ part_edge, int nb_edge,
                                                             double* __restrict__ out, SlotState* __restrict__ state, int do_gn) {
-    reduce_partials_block(part_surf, nb_surf, part_edge, nb_edge, out, state, do_gn, false);
+    reduce_partials_block(part_surf, nb_surf, part_edge, nb_edge, out, state, do_gn, 0ull);
 }
 
 // Restart of a registration: 56 bytes device to device.  hipMemcpyAsync(D2D) costs a 4.5 us copy kernel for this; one 8-lane

@@ -408,7 +408,7 @@ def test_window_iteration_equals_sequential(gpu_ctx, oracle):
         m.iterate_window([0, 0], 1, L.MASK_SURF)
 
 
-_OPTION_DEFAULTS = {"nn_cache": 0, "fuse_tail": 1, "merge_kinds": 1}
+_OPTION_DEFAULTS = {"nn_cache": 0, "fuse_tail": 0, "merge_kinds": 1}
 
 
 @pytest.mark.parametrize("opt", ["nn_cache", "fuse_tail", "merge_kinds"])
@@ -485,7 +485,7 @@ def test_fuse_tail_toggled_between_set_queries_and_iterate(gpu_ctx, oracle):
         m.iterate_inner(0, 200, mask, want_cost=True)
         b = m.pose_get(0)
     finally:
-        gpu_ctx.set_option("fuse_tail", 1)
+        gpu_ctx.set_option("fuse_tail", 0)
     for t, q, st in poses[1:]:
         assert st == 0 and np.array_equal(t, poses[0][0]) and np.array_equal(q, poses[0][1])
     assert a[2] == b[2] == 0 and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
