@@ -67,7 +67,7 @@ struct Slot {
 constexpr int kLinBlock = 1024;      // must match lili_s2m.hip
 
 constexpr int kMaxLinBlocks = 256;
-inline size_t lds_linearize(int threads) { return (size_t)threads * 10 * sizeof(double); }   // rows [J r 1 cost]; reused for the 16x16 wave results
+inline size_t lds_linearize(int threads) { return (size_t)threads * 12 * sizeof(double); }   // rows [J r | 1 cost 0 0]; reused for the per-wave result blocks
 
 }  // namespace lili_detail
 using namespace lili_detail;

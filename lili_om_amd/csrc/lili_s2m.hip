@@ -1113,16 +1113,17 @@ __global__ __launch_bounds__(1024) void k_block_order(const int* __restrict__ bl
 // q = 0..63 in order; lane 36 sums the cost column.  Waves of a block are then added in order and the
 // block writes one 40-double partial; k_reduce_gn adds the partials in a fixed order.
 // ================================================================================================
-constexpr int kRow = 10;          // LDS row: [J0..J6, r, 1, cost]
-constexpr int kLinBlock = 1024;   // largest linearisation block (the launch picks a multiple of 64 so that <= 256 blocks cover the queries)
-typedef double v4f64 __attribute__((ext_vector_type(4)));
-// Gram accumulation on the f64 matrix cores: for every wave, G += V^T V with V = 64 rows x 16 columns
-// (v = [J0..J6, r, 1, cost, 0...]), issued as 16 x v_mfma_f64_16x16x4_f64 (K = 4 rows per instruction).
-// A[i][k] and B[k][j] of that instruction are both V[row 4s+k][column i or j], i.e. every lane feeds the SAME
-// double to both operands: lane l supplies V[4s + l/16][l%16].  G[8][8] counts the residuals and G[8][9] is the
-// sum of the costs.  This is a reduction, not a GEMM re-shaping of the path: the 16 MFMAs replace a 64-step
-// LDS loop; summation order is fixed by the hardware, so results stay deterministic.
-// C/D layout of the f64 form: col = lane & 15, row = (lane >> 4) + 4 * reg (cdna_hip_programming.md §3).
+constexpr int kRow = 12;          // LDS row: [J0..J6, r | 1, cost, 0, 0]
+constexpr int kLinBlock = 1024;   // linearisation block (16 waves; the launch covers the queries with <= 256 blocks)
+// Gram accumulation on the f64 matrix cores.  Per wave, G += V^T V over its 64 rows v = [a | b | e] with a = (J0..J3),
+// b = (J4, J5, J6, r), e = (1, cost, 0, 0), issued as 16 x v_mfma_f64_4x4x4_4b_f64: ONE instruction contracts four rows (k)
+// into four independent 4x4 blocks — block 0: a a^T, block 1: a b^T, block 2: b b^T, block 3: e e^T (count and cost sum) —
+// i.e. exactly the 36 + 2 numbers of the upper triangle, where round 1's 16x16x4 form computed a 16x16 tile of which 55
+// entries were used (measured on MI355X, tools/probe_mfma.hip: 64 clocks per 16x16x4 against 20 per 4x4x4_4b, and the
+// 16 operand reads of a wave were issued one by one in front of their MFMA).  Lane map of the instruction (probed, same file):
+// operand lane l feeds row i (A) / column j (B) = l & 3 of block (l >> 2) & 3 at k = l >> 4; result lane o holds
+// D_block[o >> 4][o & 3] of block (o >> 2) & 3.  This is a reduction, not a GEMM re-shaping of the path; the summation
+// order is fixed by the instruction sequence, so results stay deterministic.
 // profiling aid: thread 0 of one probe block stamps the constant 100 MHz clock into SlotState::tprof[slot]
 __device__ __forceinline__ void tstamp(const SlotState* state, int debug, int probe_block, int slot) {
     if ((debug & 256) && (int)blockIdx.x == probe_block && threadIdx.x == 0)
@@ -1141,9 +1142,21 @@ __device__ __forceinline__ void load_granule(const double* g, unsigned long long
     lo = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     hi = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// result lane of partial entry e: e < 36 = upper triangle of the 8x8 Gram (row-major), 36 = cost, 37 = count, 38 / 39 = always zero
+__device__ __forceinline__ int gram_lane(int e) {
+    if (e == 36) return 16 + 12;        // block 3, [1][0] = sum cost * 1
+    if (e == 37) return 12;             // block 3, [0][0] = sum 1 * 1
+    if (e >= 38) return 2 * 16 + 12 + 2;   // block 3, [2][2] = 0
+    int a = 0, l = e;
+    while (l >= 8 - a) { l -= 8 - a; a++; }
+    const int b = a + l;
+    if (b < 4) return 16 * a + b;                       // a a^T
+    if (a < 4) return 16 * a + 4 + (b - 4);             // a b^T
+    return 16 * (a - 4) + 8 + (b - 4);                  // b b^T
+}
 struct GramAcc {
-    v4f64 acc;
-    __device__ __forceinline__ void init() { acc = v4f64{0.0, 0.0, 0.0, 0.0}; }
+    double acc;
+    __device__ __forceinline__ void init() { acc = 0.0; }
     // Every wave stages and consumes ITS OWN 64 rows, so only wave-level ordering is needed here (LDS operations of
     // one wave execute in order; the fences keep the compiler from moving them) — no block barrier: fast waves do
     // their MFMAs while slow ones still wait for their records.  All lanes of the wave must call this.
@@ -1157,14 +1170,19 @@ struct GramAcc {
         for (int k = 0; k < 8; k++) myrow[k] = ok ? Jr[k] : 0.0;
         myrow[8] = ok ? 1.0 : 0.0;
         myrow[9] = ok ? cost : 0.0;
+        myrow[10] = 0.0; myrow[11] = 0.0;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const int col = lane & 15, kq = lane >> 4;
+        const int kq = lane >> 4, blk = (lane >> 2) & 3, c = lane & 3;
+        const int ia = blk < 2 ? c : (blk == 2 ? 4 + c : 8 + c);
+        const int ib = blk == 0 ? c : (blk == 3 ? 8 + c : 4 + c);
+        const double* pa = rows + kq * kRow + ia;
+        const double* pb = rows + kq * kRow + ib;
+        double a[16], b[16];
 #pragma unroll
-        for (int s = 0; s < 16; s++) {
-            double a = col < kRow ? rows[(4 * s + kq) * kRow + col] : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, a, acc, 0, 0, 0);
-        }
+        for (int s = 0; s < 16; s++) { a[s] = pa[4 * s * kRow]; b[s] = pb[4 * s * kRow]; }   // all 32 operand reads in flight before the first MFMA
+#pragma unroll
+        for (int s = 0; s < 16; s++) acc = __builtin_amdgcn_mfma_f64_4x4x4f64(a[s], b[s], acc, 0, 0, 0);
     }
     // block partial: 36 upper-triangle entries of the 8x8 Gram, [36] = cost, [37] = count
     // `key` != 0: the partial is PUBLISHED for the reducer block of the same launch (fused_tail) as 40 granules of 16 bytes,
@@ -1174,22 +1192,14 @@ struct GramAcc {
     __device__ __forceinline__ void finish(double* lds, double* slot, unsigned long long key = 0ull) {
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         __syncthreads();                 // every wave is done with its row area before the LDS is reused for the wave results
-        double* dm = lds + wave * 256;   // this wave's 16x16 result, row-major
-        const int col = lane & 15, r0 = lane >> 4;
-#pragma unroll
-        for (int r = 0; r < 4; r++) dm[(r0 + 4 * r) * 16 + col] = acc[r];
+        lds[wave * 64 + lane] = acc;     // this wave's four 4x4 result blocks
         __syncthreads();
         if (threadIdx.x < 40) {
-            int e = threadIdx.x;
-            int row, cl;
-            if (e < 36) { int a = 0, l = e; while (l >= 8 - a) { l -= 8 - a; a++; } row = a; cl = a + l; }
-            else if (e == 36) { row = 8; cl = 9; }
-            else if (e == 37) { row = 8; cl = 8; }
-            else { row = 15; cl = 15; }   // spare slots: always zero
+            const int src = gram_lane(threadIdx.x);
             double s = 0.0;
-            for (int w = 0; w < (int)(blockDim.x >> 6); w++) s += lds[w * 256 + row * 16 + cl];
-            if (key) store_granule(slot + 2 * e, s, key);
-            else slot[e] = s;
+            for (int w = 0; w < (int)(blockDim.x >> 6); w++) s += lds[w * 64 + src];
+            if (key) store_granule(slot + 2 * threadIdx.x, s, key);
+            else slot[threadIdx.x] = s;
         }
     }
 };
@@ -1351,41 +1361,58 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize(LinArgs S, LinArgs E, P
 #define LILI_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 // xq: the quaternion of state->pose, loaded by the caller at kernel start (its latency hides behind the partial loads).
 // Must be called by exactly ONE wave (lanes 0..63 of it).
+// sin(x)/x and cos(x) from x^2 for the small rotation of a Gauss-Newton step (|x| < 0.5: the series are truncated below 1e-19
+// relative): 16 fused multiply-adds instead of two libm calls with argument reduction (~120 dependent f64 instructions at the
+// end of the latency-bound update chain).  ceres::QuaternionParameterization::Plus takes sin / cos from libm, which is not
+// correctly rounded either; the two agree to 1-2 ulp.
+__device__ __forceinline__ void sinc_cos_small(double x2, double& sinc, double& c) {
+    double s = -1.0 / 355687428096000.0;            // -1/17!
+    s = __fma_rn(s, x2, 1.0 / 1307674368000.0);      //  1/15!
+    s = __fma_rn(s, x2, -1.0 / 6227020800.0);        // -1/13!
+    s = __fma_rn(s, x2, 1.0 / 39916800.0);           //  1/11!
+    s = __fma_rn(s, x2, -1.0 / 362880.0);            // -1/9!
+    s = __fma_rn(s, x2, 1.0 / 5040.0);
+    s = __fma_rn(s, x2, -1.0 / 120.0);
+    s = __fma_rn(s, x2, 1.0 / 6.0);
+    sinc = __fma_rn(-s, x2, 1.0);
+    double k = 1.0 / 6402373705728000.0;             //  1/18!
+    k = __fma_rn(k, x2, -1.0 / 20922789888000.0);    // -1/16!
+    k = __fma_rn(k, x2, 1.0 / 87178291200.0);        //  1/14!
+    k = __fma_rn(k, x2, -1.0 / 479001600.0);         // -1/12!
+    k = __fma_rn(k, x2, 1.0 / 3628800.0);            //  1/10!
+    k = __fma_rn(k, x2, -1.0 / 40320.0);
+    k = __fma_rn(k, x2, 1.0 / 720.0);
+    k = __fma_rn(k, x2, -1.0 / 24.0);
+    k = __fma_rn(k, x2, 0.5);
+    c = __fma_rn(-k, x2, 1.0);
+}
 __device__ void gn_update_block(const double* gram /*LDS or global, 64+*/, SlotState* __restrict__ state, const double xq[4]) {
-    __shared__ double Jq[4][3];   // plus-Jacobian rows: [-x1 -x2 -x3; x0 x3 -x2; -x3 x0 x1; x2 -x1 x0]
-    __shared__ double M[7][6];    // M = G77 * P   (P = blockdiag(I3, Jq): only 4 terms per entry)
     __shared__ double H[6][6];
     __shared__ double gvec[6];
     int tid = threadIdx.x & 63;
     const double x0 = xq[0], x1 = xq[1], x2 = xq[2], x3 = xq[3];
-    if (tid < 12) {
-        int rr = tid / 3, cc = tid % 3;
-        double e0 = rr == 0 ? -x1 : rr == 1 ? x0 : rr == 2 ? -x3 : x2;
-        double e1 = rr == 0 ? -x2 : rr == 1 ? x3 : rr == 2 ? x0 : -x1;
-        double e2 = rr == 0 ? -x3 : rr == 1 ? -x2 : rr == 2 ? x1 : x0;
-        Jq[rr][cc] = cc == 0 ? e0 : cc == 1 ? e1 : e2;
-    }
-    LILI_WAVE_SYNC();
+    // plus-Jacobian Jq (4x3) of ceres::QuaternionParameterization, rows [-x1 -x2 -x3; x0 x3 -x2; -x3 x0 x1; x2 -x1 x0]; every lane
+    // builds the column(s) it needs in registers.  H = P^T G77 P and g = -P^T G7r with P = blockdiag(I3, Jq), evaluated as
+    // M = G P (4-term sums, left to right) and H = P^T M exactly like round 1's three LDS-staged steps — one step now.
+    auto jcol = [&](int c, double o[4]) {
+        o[0] = c == 0 ? -x1 : c == 1 ? -x2 : -x3;
+        o[1] = c == 0 ? x0 : c == 1 ? x3 : -x2;
+        o[2] = c == 0 ? -x3 : c == 1 ? x0 : x1;
+        o[3] = c == 0 ? x2 : c == 1 ? -x1 : x0;
+    };
     if (tid < 42) {
-        int i = tid / 6, b = tid % 6;
+        const int a = tid < 36 ? tid / 6 : tid - 36, b = tid < 36 ? tid % 6 : 7;   // b == 7: the J^T r column
+        double jb[4] = {0, 0, 0, 0}, ja[4] = {0, 0, 0, 0};
+        if (b >= 3 && b < 6) jcol(b - 3, jb);
+        if (a >= 3) jcol(a - 3, ja);
+        auto Mrow = [&](int i) -> double {      // (G P)[i][b];  for b == 7 the plain column G[i][7]
+            if (b < 3 || b == 7) return gram[i * 8 + b];
+            return ((gram[i * 8 + 3] * jb[0] + gram[i * 8 + 4] * jb[1]) + gram[i * 8 + 5] * jb[2]) + gram[i * 8 + 6] * jb[3];
+        };
         double v;
-        if (b < 3) v = gram[i * 8 + b];
-        else v = ((gram[i * 8 + 3] * Jq[0][b - 3] + gram[i * 8 + 4] * Jq[1][b - 3]) + gram[i * 8 + 5] * Jq[2][b - 3]) + gram[i * 8 + 6] * Jq[3][b - 3];
-        M[i][b] = v;
-    }
-    LILI_WAVE_SYNC();
-    if (tid < 36) {
-        int a = tid / 6, b = tid % 6;
-        double v;
-        if (a < 3) v = M[a][b];
-        else v = ((Jq[0][a - 3] * M[3][b] + Jq[1][a - 3] * M[4][b]) + Jq[2][a - 3] * M[5][b]) + Jq[3][a - 3] * M[6][b];
-        H[a][b] = v;
-    } else if (tid < 42) {
-        int a = tid - 36;
-        double v;
-        if (a < 3) v = gram[a * 8 + 7];
-        else v = ((Jq[0][a - 3] * gram[3 * 8 + 7] + Jq[1][a - 3] * gram[4 * 8 + 7]) + Jq[2][a - 3] * gram[5 * 8 + 7]) + Jq[3][a - 3] * gram[6 * 8 + 7];
-        gvec[a] = -v;
+        if (a < 3) v = Mrow(a);
+        else v = ((ja[0] * Mrow(3) + ja[1] * Mrow(4)) + ja[2] * Mrow(5)) + ja[3] * Mrow(6);
+        if (tid < 36) H[a][b] = v; else gvec[a] = -v;
     }
     LILI_WAVE_SYNC();
     if (tid == 0) {
@@ -1436,10 +1463,12 @@ __device__ void gn_update_block(const double* gram /*LDS or global, 64+*/, SlotS
         for (int i = 0; i < 6; i++) if (!(d[i] == d[i])) okc = false;
         if (okc) {
             state->pose[0] += d[0]; state->pose[1] += d[1]; state->pose[2] += d[2];
-            double nd = sqrt(d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
-            if (nd > 0.0) {
-                double sbd = sin(nd) / nd;
-                dq qd{cos(nd), sbd * d[3], sbd * d[4], sbd * d[5]};
+            const double nd2 = d[3] * d[3] + d[4] * d[4] + d[5] * d[5];
+            if (nd2 > 0.0) {
+                double sbd, cw;
+                if (nd2 < 0.25) sinc_cos_small(nd2, sbd, cw);
+                else { const double nd = sqrt(nd2); sbd = sin(nd) / nd; cw = cos(nd); }
+                dq qd{cw, sbd * d[3], sbd * d[4], sbd * d[5]};
                 dq r = qmul(qd, dq{x0, x1, x2, x3});
                 state->pose[3] = r.w; state->pose[4] = r.x; state->pose[5] = r.y; state->pose[6] = r.z;
             }
@@ -1531,7 +1560,8 @@ __device__ void reduce_partials_block(const double* part_surf, int nb_surf, cons
     const int lane = threadIdx.x;
     if (lane < 40) {
         double ss = 0.0, se = 0.0;
-        for (int gg = 0; gg < kGroups; gg++) { ss += acc[gg][0][lane]; se += acc[gg][1][lane]; }
+        for (int gg = 0; gg < kGroups; gg++) ss += acc[gg][0][lane];
+        if (nb_edge > 0) for (int gg = 0; gg < kGroups; gg++) se += acc[gg][1][lane];
         tri[lane] = ss + se;
         if (lane == 37) { full[65] = ss; full[66] = se; }
     }
