@@ -204,7 +204,9 @@ def main():
                     "scan in K slots advanced concurrently with lili_s2m_iterate_window; prints window iterations/s and exits")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (window of 3 slots, ROT extractor)")
-    ap.add_argument("--no-native-rccl", action="store_true", help="A/B: keep the two all-reduces in the Python loop (torch.distributed)")
+    ap.add_argument("--collective", choices=["auto", "p2p", "rccl", "torch"], default="auto",
+                    help="N > 1: who does the two tiny all-reduces per iteration — auto = lili_p2p, else RCCL from C, else torch.distributed")
+    ap.add_argument("--no-native-rccl", action="store_true", help="same as --collective torch (A/B: the two all-reduces stay in the Python loop)")
     ap.add_argument("--split-path", action="store_true", help="use the multi-GPU code path (export/import counts, separate GN kernel) even at N=1")
     ap.add_argument("--bin", action="store_true", help="enable the once-per-scan query binning (A/B only)")
     ap.add_argument("--opt", action="append", default=[], help="A/B: lili_set_option name=value (repeatable), e.g. --opt warm=0")
@@ -213,6 +215,8 @@ def main():
     ap.add_argument("--no-nn-cache", action="store_true", help="A/B: do not seed the search bound with the previous neighbours")
     ap.add_argument("--tile", action="store_true", help="enable the LDS-tiled search (A/B only; implies --bin)")
     args = ap.parse_args()
+    if args.no_native_rccl:
+        args.collective = "torch"
 
     import torch
     import lili_om_amd as L
@@ -228,7 +232,11 @@ def main():
     if world > 1 or os.environ.get("LILI_BENCH_FORCE_DIST"):    # the env switch exercises the collective path on ONE rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("LILI_BENCH_SHARE_GPU"):      # test aid: all ranks on GPU 0 (one-GPU box), gloo for the control plane;
+            local_rank = 0                              # RCCL refuses two ranks on one device, the p2p exchange does not care
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -359,20 +367,39 @@ def main():
             dist.all_reduce(gram)
         m.gn_update(0, gram.data_ptr())
 
-    # Native collectives: lili_s2m_iterate_sharded enqueues the two RCCL all-reduces from C between the kernels (no host code on
-    # the critical path).  The communicator is created next to torch's; it is used only if EVERY rank created it and the native
-    # loop reproduces the torch.distributed iteration from the same pose — otherwise the Python loop above stays.
-    native = None
-    if dist is not None and not args.no_native_rccl:
-        comm = None
-        try:
+    # Native collectives: lili_s2m_iterate_sharded enqueues the two all-reduces from C between the kernels (no host code on the
+    # critical path).  Candidates, in order: the library's own peer-to-peer exchange (lili_p2p: hipIpc-mapped mailboxes, one small
+    # kernel per all-reduce, sums in rank order = rank-identical bits), then RCCL's ncclAllReduce (communicator created next to
+    # torch's).  A candidate is used only if EVERY rank could set it up and one native iteration reproduces the torch.distributed
+    # iteration from the same pose — otherwise the Python loop above stays.
+    native, native_kind = None, "torch.distributed from the Python loop"
+    if dist is not None and args.collective != "torch":
+        def flag_all(ok):
+            f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+            return int(f.item()) == 1
+
+        def make_p2p():
+            from lili_om_amd import p2p
+            return p2p.Communicator(ctx, rank, world, dist)
+
+        def make_rccl():
             from lili_om_amd import rccl
-            comm = rccl.Communicator(rank, world, device=local_rank)
-        except Exception as e:          # noqa: BLE001
-            log(f"[bench] rank {rank}: native RCCL communicator unavailable ({e!r})")
-        flag = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
+            return rccl.Communicator(rank, world, device=local_rank)
+
+        cands = [("lili_p2p (hipIpc mailboxes, rank-order sums) enqueued from C", make_p2p), ("RCCL ncclAllReduce enqueued from C", make_rccl)]
+        if args.collective == "rccl":
+            cands = cands[1:]
+        elif args.collective == "p2p":
+            cands = cands[:1]
+        for kind, make in cands:
+            comm = None
+            try:
+                comm = make()
+            except Exception as e:          # noqa: BLE001
+                log(f"[bench] rank {rank}: {kind}: unavailable ({e!r})")
+            if not flag_all(comm is not None):
+                continue
             m.pose_copy(0, 1); step_multi(); torch.cuda.synchronize()
             ta, qa, _ = m.pose_get(0)
             m.pose_copy(0, 1)
@@ -380,14 +407,13 @@ def main():
             torch.cuda.synchronize()
             tb, qb, _ = m.pose_get(0)
             same = bool(np.abs(ta - tb).max() <= 1e-12 and np.abs(qa - qb).max() <= 1e-12)
-            flag = torch.tensor([1 if same else 0], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 1:
-                native = comm
-            elif rank == 0:
-                log("[bench] native RCCL loop did not reproduce the torch.distributed iteration: staying on the Python loop")
+            if flag_all(same):
+                native, native_kind = comm, kind
+                break
+            if rank == 0:
+                log(f"[bench] {kind}: did not reproduce the torch.distributed iteration, skipped")
     if rank == 0 and dist is not None:
-        log(f"[bench] collectives: {'RCCL enqueued from C (lili_s2m_iterate_sharded)' if native else 'torch.distributed from the Python loop'}")
+        log(f"[bench] collectives: {native_kind}")
 
     def run_steps(k):
         # every `ips` steps a new registration starts from the initial guess (async device-to-device pose copy)
@@ -490,7 +516,7 @@ def main():
                                    f"{'the 200k queries of the scan block-sharded over the ranks' if args.scaling == 'strong' else 'one 200k-pt shard per rank'}",
                        "queries_per_rank": int(queries.shape[0]), "map_points": int(w["map_xyz"].shape[0]),
                        "parallelism": f"queries sharded x{world}, map replicated, all-reduce(counts, Gram)" if world > 1 else "single GPU",
-                       "collectives": ("rccl enqueued from C (lili_s2m_iterate_sharded)" if native is not None else "torch.distributed in the Python loop") if dist is not None else "none",
+                       "collectives": native_kind if dist is not None else "none",
                        "map_index_build_s": round(t_map, 4)},
             "roofline": roofline,
             "final_pose": {"t": [float(x) for x in t_fin], "q": [float(x) for x in q_fin], "gn_status": int(gn_status)},

@@ -99,7 +99,8 @@ int lili_set_debug(lili_ctx* ctx, int keep_neighbors);
  * the previous association of the same scan; default 0, measured slower), "fuse_tail" (1 = the reduction of the block
  * partials and the GN update run inside the linearisation launch, in its last block; default 0 = separate launch, which is
  * faster on MI355X; may be changed at any time), "merge_kinds" (1 = surf and edge of a keyframe share ONE association launch and ONE
- * linearisation launch; default 1). */
+ * linearisation launch; default 1), "p2p_fusion" (0 = lili_s2m_iterate_sharded runs lili_p2p_allreduce as its own launches like any
+ * other lili_allreduce_fn instead of inside the count / reduce kernels; default 1). */
 int lili_set_option(lili_ctx* ctx, const char* name, int value);
 
 /* ---- local map index ------------------------------------------------------------------------ */
@@ -262,10 +263,29 @@ int lili_s2m_gn_update(lili_ctx* ctx, int slot, const double* d_gram);
  * PyTorch loaded).  allreduce == NULL runs the same staged launches without collectives (one rank).  restart_every /
  * restart_slot as in lili_s2m_iterate_restart.  d_counts: DEVICE int32[2], d_gram: DEVICE double[LILI_GRAM_DOUBLES],
  * both caller-owned and valid until the stream has drained.  Every rank then holds the same pose (same reduced Gram, same
- * GN step), no broadcast is needed. */
+ * GN step), no broadcast is needed.  With allreduce == lili_p2p_allreduce (below) the exchange is folded into the count kernel and
+ * into the reduce + Gauss-Newton kernel: associate, counts + exchange, linearise, reduce + exchange + GN = 4 launches per iteration. */
 typedef int (*lili_allreduce_fn)(const void* sendbuff, void* recvbuff, size_t count, int datatype, int op, void* comm, void* stream);
 int lili_s2m_iterate_sharded(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, int n_iters, int restart_every,
                              int restart_slot, lili_allreduce_fn allreduce, void* comm, int32_t* d_counts, double* d_gram);
+/* Peer-to-peer all-reduce for the two records of the sharded loop (the loop being sharded is
+ * L/src/BackendFusion.cpp:1536,1606): every rank owns a mailbox in its HBM that all peers map through hipIpc; one small kernel per
+ * all-reduce stores this rank's record into every peer's mailbox over xGMI, waits for the peers' records in its own, and adds them IN
+ * RANK ORDER — so all ranks hold bit-identical sums.  lili_p2p_allreduce has the signature of ncclAllReduce (lili_allreduce_fn) with
+ * comm = the lili_p2p*; records of at most 96 x 8 bytes, datatype 2 (int32) or 8 (f64), op 0 (sum).
+ *   lili_p2p_create   one per rank (rank, world <= 16), on the context's device
+ *   lili_p2p_handle   this rank's mailbox handle (LILI_P2P_HANDLE_BYTES, opaque) — the caller all-gathers the handles (MPI,
+ *                     torch.distributed, a file ...) and hands all of them, in rank order, to
+ *   lili_p2p_connect  (maps the peers' mailboxes; one process per GPU, or several processes on one GPU)
+ *   lili_p2p_status   0 = ok, 1 = a wait for a peer gave up after ~2 s of device time (the record is then undefined) */
+#define LILI_P2P_HANDLE_BYTES 64
+typedef struct lili_p2p lili_p2p;
+int lili_p2p_create(lili_ctx* ctx, int rank, int world, lili_p2p** out);
+int lili_p2p_handle(lili_p2p* comm, void* handle);
+int lili_p2p_connect(lili_p2p* comm, const void* all_handles);
+int lili_p2p_allreduce(const void* sendbuff, void* recvbuff, size_t count, int datatype, int op, void* comm, void* stream);
+int lili_p2p_status(lili_p2p* comm);
+void lili_p2p_destroy(lili_p2p* comm);
 /* Convenience: n_iters x (accumulate + gn_update) on an internal buffer.  Async. */
 int lili_s2m_iterate(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, int n_iters);
 

@@ -127,6 +127,12 @@ _SIGS = {
     "lili_s2m_pose_copy": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "lili_s2m_iterate_restart": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "lili_s2m_iterate_sharded": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lili_p2p_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "lili_p2p_handle": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lili_p2p_connect": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lili_p2p_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "lili_p2p_status": (C.c_int, [C.c_void_p]),
+    "lili_p2p_destroy": (None, [C.c_void_p]),
     "lili_livox_custom_to_cloud": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_int]),
     "lili_imu_reset": (None, [C.c_void_p]),
     "lili_imu_integrate": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_void_p]),

@@ -29,8 +29,8 @@ template <bool TILED, int BS> __global__ void k_associate_edge(const float4*, co
 __global__ void k_block_order(const int*, int, int, int*);
 __global__ void k_associate_both(AssocArgs, AssocArgs, PoseArg, MatchParams);
 __global__ void k_linearize(LinArgs, LinArgs, PoseArg, MatchParams, const SlotState*, const int*, FuseTail);
-__global__ void k_reduce_partials(const double*, int, const double*, int, double*, SlotState*, int);
-__global__ void k_sum_counts(const int*, int, const int*, int, SlotState*, int*);
+__global__ void k_reduce_partials(const double*, int, const double*, int, double*, SlotState*, int, P2PView);
+__global__ void k_sum_counts(const int*, int, const int*, int, SlotState*, int*, P2PView);
 __global__ void k_gn_update(const double*, SlotState*);
 __global__ void k_pose_copy(SlotState*, const SlotState*);
 }  // namespace lili
@@ -156,6 +156,7 @@ int lili_set_option(lili_ctx* ctx, const char* name, int value) {
     if (std::strcmp(name, "balance") == 0) { ctx->balance = value != 0; for (auto& sl : ctx->slots) for (auto& k : sl.k) { k.order_valid = false; k.launches = 0; } return LILI_OK; }
     if (std::strcmp(name, "fuse_tail") == 0) { ctx->fuse_tail = value != 0; return LILI_OK; }   // any time: the block partition does not depend on it
     if (std::strcmp(name, "merge_kinds") == 0) { ctx->merge_kinds = value != 0; return LILI_OK; }
+    if (std::strcmp(name, "p2p_fusion") == 0) { ctx->no_p2p_fusion = value == 0; return LILI_OK; }
     if (std::strcmp(name, "nn_cache") == 0) { ctx->nn_cache = value != 0; for (auto& s : ctx->slots) for (auto& k : s.k) k.nn_cache_valid = false; return LILI_OK; }
     if (std::strcmp(name, "max_cells") == 0) { if (value < 1) return ctx->fail(LILI_E_ARG, "max_cells must be positive"); ctx->max_cells = value; return LILI_OK; }
     return ctx->fail(LILI_E_ARG, std::string("unknown option ") + name);
@@ -410,12 +411,12 @@ static int launch_associate(lili_ctx* ctx, int slot, int kind, const PoseArg& pa
 }
 
 // sums the per-block correspondence counts of the last association(s) into SlotState::n_res
-static int launch_sum_counts(lili_ctx* ctx, int slot, int kind_mask, int* d_out = nullptr) {
+static int launch_sum_counts(lili_ctx* ctx, int slot, int kind_mask, int* d_out = nullptr, const P2PView* xv = nullptr) {
     Slot& s = ctx->slots[slot];
     const int* bs = nullptr; const int* be = nullptr; int nbs = 0, nbe = 0;
     if ((kind_mask & LILI_MASK_SURF) && s.k[0].has_records && s.k[0].n_q > 0) { bs = s.k[0].block_counts.as<int>(); nbs = s.k[0].n_assoc_blocks; }
     if ((kind_mask & LILI_MASK_EDGE) && s.k[1].has_records && s.k[1].n_q > 0) { be = s.k[1].block_counts.as<int>(); nbe = s.k[1].n_assoc_blocks; }
-    hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(kBlock), 0, ctx->stream, bs, nbs, be, nbe, ctx->state(slot), d_out);
+    hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(kBlock), 0, ctx->stream, bs, nbs, be, nbe, ctx->state(slot), d_out, xv ? *xv : P2PView{});
     HIPCHK(hipGetLastError());
     return LILI_OK;
 }
@@ -471,7 +472,8 @@ static LinArgs lin_args_of(lili_ctx* ctx, int slot, int kind) {
 // if do_gn).  Default: ONE launch — k_linearize covers both kinds and its last block to finish reduces (+ solves), see fused_tail.
 // Options for A/B: merge_kinds = 0 (one launch per kind), fuse_tail = 0 (k_reduce_partials as its own launch).  All variants
 // add the same numbers in the same order: the record is bit-identical.
-static int launch_linearize_reduce(lili_ctx* ctx, int slot, int kind_mask, const PoseArg& pa, const MatchParams& P, double* d_out, int do_gn) {
+static int launch_linearize_reduce(lili_ctx* ctx, int slot, int kind_mask, const PoseArg& pa, const MatchParams& P, double* d_out, int do_gn,
+                                   const P2PView* xv = nullptr) {
     Slot& s = ctx->slots[slot];
     LinArgs A[2] = {LinArgs{}, LinArgs{}};
     int n_kinds = 0;
@@ -484,7 +486,8 @@ static int launch_linearize_reduce(lili_ctx* ctx, int slot, int kind_mask, const
     }
     const int* ng = s.use_global_counts ? s.global_counts : nullptr;
     FuseTail fz{};
-    fz.mode = (ctx->fuse_tail && n_kinds > 0) ? (do_gn ? 2 : 1) : 0; fz.out = d_out; fz.state = ctx->state(slot); fz.debug = P.debug;
+    fz.mode = (ctx->fuse_tail && n_kinds > 0 && !xv) ? (do_gn ? 2 : 1) : 0;     // the exchange across ranks lives in k_reduce_partials
+    fz.out = d_out; fz.state = ctx->state(slot); fz.debug = P.debug;
     fz.part_surf = A[0].partials; fz.nb_surf = A[0].nb; fz.part_edge = A[1].partials; fz.nb_edge = A[1].nb;
     const FuseTail off{};
     const size_t lds = lds_linearize(kLinBlock);
@@ -498,7 +501,8 @@ static int launch_linearize_reduce(lili_ctx* ctx, int slot, int kind_mask, const
     }
     HIPCHK(hipGetLastError());
     if (!fz.mode) {
-        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx->stream, fz.part_surf, fz.nb_surf, fz.part_edge, fz.nb_edge, d_out, ctx->state(slot), (do_gn ? 1 : 0) | (P.debug & 256));
+        hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx->stream, fz.part_surf, fz.nb_surf, fz.part_edge, fz.nb_edge, d_out, ctx->state(slot), (do_gn ? 1 : 0) | (P.debug & 256),
+                           xv ? *xv : P2PView{});
         HIPCHK(hipGetLastError());
     }
     return LILI_OK;
@@ -812,10 +816,28 @@ int lili_s2m_iterate_sharded(lili_ctx* ctx, int slot, int kind_mask, const lili_
     ARGCHK(n_iters >= 0 && params && d_counts && d_gram, "iterate_sharded: bad argument");
     ARGCHK(restart_every >= 0 && (restart_every == 0 || (restart_slot >= 0 && restart_slot < LILI_MAX_SLOTS && restart_slot != slot)), "iterate_sharded: bad restart arguments");
     const bool count_scaled = params->scale_surf_num > 0 || params->scale_edge_num > 0;   // ROT: residual scale = num / GLOBAL count
+    // The library's own peer-to-peer exchange (lili_p2p_allreduce) is folded INTO the count kernel and INTO the partial-reduction /
+    // Gauss-Newton kernel: 4 launches per iteration (associate, counts + exchange, linearise, reduce + exchange + GN) instead of 7.
+    lili_p2p* p2p = (allreduce == &lili_p2p_allreduce && lili_p2p_usable(reinterpret_cast<lili_p2p*>(comm), ctx) && !ctx->no_p2p_fusion) ? reinterpret_cast<lili_p2p*>(comm) : nullptr;
     for (int it = 0; it < n_iters; it++) {
         int rc;
         if (restart_every > 0 && it % restart_every == 0 && (rc = lili_s2m_pose_copy(ctx, slot, restart_slot)) != LILI_OK) return rc;
         if ((rc = lili_s2m_associate_dev(ctx, slot, kind_mask, params)) != LILI_OK) return rc;
+        if (p2p) {
+            ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS && (kind_mask & ~3) == 0 && kind_mask != 0, "iterate_sharded: bad slot / kind mask");
+            if (count_scaled) {
+                const P2PView v = lili_p2p_next_view(p2p);
+                if ((rc = launch_sum_counts(ctx, slot, LILI_MASK_SURF | LILI_MASK_EDGE, d_counts, &v)) != LILI_OK) return rc;
+                if ((rc = lili_s2m_counts_import(ctx, slot, d_counts)) != LILI_OK) return rc;
+            }
+            PoseArg pa{};
+            pa.state = ctx->state(slot);
+            const MatchParams P = to_device_params(params);
+            const P2PView v = lili_p2p_next_view(p2p);
+            if ((rc = launch_linearize_reduce(ctx, slot, kind_mask, pa, P, d_gram, 1, &v)) != LILI_OK) return rc;
+            ctx->slots[slot].use_global_counts = false;
+            continue;
+        }
         if (count_scaled) {
             if ((rc = lili_s2m_counts_export(ctx, slot, d_counts)) != LILI_OK) return rc;
             if (allreduce && allreduce(d_counts, d_counts, 2, /*ncclInt32*/ 2, /*ncclSum*/ 0, comm, (void*)ctx->stream) != 0)

@@ -95,6 +95,7 @@ struct lili_ctx {
     bool fuse_tail = false;      // reduce (+ GN) inside the linearisation launch (its last block sweeps the other blocks' granule-tagged partials):
                                  // bit-identical, measured SLOWER than the separate k_reduce_partials launch (41.1 vs 38.9 us per iteration: reading 125 KB
                                  // of freshly published partials through sc1 loads costs one block 3.4 us, a kernel boundary 1.5 us) — A/B only
+    bool no_p2p_fusion = false;  // A/B: lili_s2m_iterate_sharded with lili_p2p_allreduce as separate launches (the generic path) instead of inside the count / reduce kernels
     bool merge_kinds = true;     // surf and edge of one keyframe in ONE association launch / ONE linearisation launch
     bool nn_cache = false;       // seed each query's search bound with its previous 5 neighbours (exact for any pose change)
     int cell_pct = 65;           // reach 2: cell edge in % of 1.01 * gate radius (>= 50)
@@ -122,3 +123,6 @@ struct lili_ctx {
 static inline int nblocks(int64_t n, int per) { return (int)((n + per - 1) / per); }
 
 int lili_ingest_cloud(lili_ctx* ctx, const lili_cloud* c, lili_detail::DevBuf& out_f4);
+// lili_p2p.hip: the view of the NEXT exchange of a communicator (advances its sequence number); usable = connected and on this context
+lili::P2PView lili_p2p_next_view(lili_p2p* c);
+bool lili_p2p_usable(const lili_p2p* c, const lili_ctx* ctx);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "lili_p2p_dev.h"
 
 namespace lili {
 

@@ -604,11 +604,20 @@ __device__ __forceinline__ int sum_block_counts(const int* __restrict__ block_co
 }
 // A kind without records counts 0.  `out` (optional): a caller-owned int[2] that receives the same totals (multi-GPU
 // callers all-reduce it in place).
+// `v.seq != 0`: the totals are all-reduced over the ranks inside this launch (lili_p2p_dev.h) — one launch instead of count kernel +
+// collective: state / out then hold the GLOBAL counts, identical on every rank.
 __global__ __launch_bounds__(kBlock) void k_sum_counts(const int* __restrict__ bc_surf, int nb_surf, const int* __restrict__ bc_edge, int nb_edge,
-                                                      SlotState* __restrict__ state, int* __restrict__ out) {
+                                                      SlotState* __restrict__ state, int* __restrict__ out, P2PView v) {
     int t0 = bc_surf ? sum_block_counts(bc_surf, nb_surf) : 0;
     __syncthreads();
     int t1 = bc_edge ? sum_block_counts(bc_edge, nb_edge) : 0;
+    if (threadIdx.x >= 64) return;
+    if (v.seq) {
+        unsigned long long s0, s1;
+        const int mine = threadIdx.x == 0 ? t0 : t1;
+        if (!p2p_exchange_wave<false>(v, 2, (unsigned long long)(unsigned)mine, 0ull, s0, s1)) { if (threadIdx.x == 0) state->gn_status = 2; return; }
+        t0 = (int)(unsigned)__shfl((int)(unsigned)s0, 0); t1 = (int)(unsigned)__shfl((int)(unsigned)s0, 1);
+    }
     if (threadIdx.x == 0) {
         state->n_res[0] = t0; state->n_res[1] = t1;
         if (out) { out[0] = t0; out[1] = t1; }
@@ -1211,12 +1220,14 @@ struct GramAcc {
 // (round 1's __threadfence pair, and a first round-2 version with write-through partials + sharded tickets, both cost more than
 // the kernel boundary they saved: 46.1 / 39.9 vs 43.0 / 38.6 us per iteration — the chain store -> ack -> atomic -> atomic -> load is
 // four memory round trips; the granule sweep is one).  key = launch_key(state->epoch); the reducer advances the epoch.
-__device__ void reduce_partials_block(const double* part_surf, int nb_surf, const double* part_edge, int nb_edge,
-                                      double* __restrict__ out, SlotState* __restrict__ state, int do_gn, unsigned long long key);   // defined below
+template <bool XCHG>
+__device__ __forceinline__ void reduce_partials_block(const double* part_surf, int nb_surf, const double* part_edge, int nb_edge,
+                                                      double* __restrict__ out, SlotState* __restrict__ state, int do_gn, unsigned long long key, const P2PView& xv);   // defined below
 __device__ __forceinline__ void fused_tail(const FuseTail& fz, unsigned long long key) {
     if (fz.mode != 1 && fz.mode != 2) return;      // 0: plain partials for k_reduce_partials; 3: publish only (the per-kind launches of merge_kinds = 0: the second launch reduces)
     if (blockIdx.x != gridDim.x - 1) return;
-    reduce_partials_block(fz.part_surf, fz.nb_surf, fz.part_edge, fz.nb_edge, fz.out, fz.state, (fz.mode == 2 ? 1 : 0) | (fz.debug & 256), key);
+    P2PView none{};       // the fused tail is the single-GPU structure: no exchange (seq = 0)
+    reduce_partials_block<false>(fz.part_surf, fz.nb_surf, fz.part_edge, fz.nb_edge, fz.out, fz.state, (fz.mode == 2 ? 1 : 0) | (fz.debug & 256), key, none);
 }
 
 __device__ __forceinline__ void load_body_pose(const PoseArg& pa, dq& Q, d3& T) {
@@ -1516,8 +1527,11 @@ __device__ __forceinline__ bool sum_partial_chunk(const double* part, int nb, in
 // all kReduceThreads threads of ONE block.  The order of the additions is fixed (25 groups of 40 lanes, group g adds partials
 // g, g+25, ... in sequence, then the groups in sequence), so the record does not depend on which launch structure produced the
 // partials or on timing.
-__device__ void reduce_partials_block(const double* part_surf, int nb_surf, const double* part_edge, int nb_edge,
-                                      double* __restrict__ out, SlotState* __restrict__ state, int do_gn, unsigned long long key) {
+// XCHG: compiled with the exchange across ranks (k_reduce_partials); the fused tail of the linearisation launch has none.  Inlined into
+// both kernels: the view is a by-value kernel argument and must not travel through memory.
+template <bool XCHG>
+__device__ __forceinline__ void reduce_partials_block(const double* part_surf, int nb_surf, const double* part_edge, int nb_edge,
+                                                      double* __restrict__ out, SlotState* __restrict__ state, int do_gn, unsigned long long key, const P2PView& xv) {
     tstamp(state, do_gn, (int)blockIdx.x, 8);
     const double xq[4] = {state->pose[3], state->pose[4], state->pose[5], state->pose[6]};
     constexpr int kGroups = kReduceThreads / 40;   // 25 groups of 40 lanes, group g adds partials g, g+25, ...
@@ -1574,6 +1588,15 @@ __device__ void reduce_partials_block(const double* part_surf, int nb_surf, cons
         if (lane >= 3 && lane < 8) full[64 + lane] = 0.0;     // 67..71
     }
     LILI_WAVE_SYNC();
+    if (XCHG && xv.seq) {      // multi-GPU: the record of every rank, added in rank order (identical bits everywhere), inside this launch
+        unsigned long long s0, s1;
+        const unsigned long long w0 = (unsigned long long)__double_as_longlong(full[lane]);
+        const unsigned long long w1 = lane < 8 ? (unsigned long long)__double_as_longlong(full[64 + lane]) : 0ull;
+        if (!p2p_exchange_wave<true>(xv, 72, w0, w1, s0, s1)) { if (lane == 0) state->gn_status = 2; return; }
+        full[lane] = __longlong_as_double((long long)s0);
+        if (lane < 8) full[64 + lane] = __longlong_as_double((long long)s1);
+        LILI_WAVE_SYNC();
+    }
     out[lane] = full[lane];
     if (lane < 8) out[64 + lane] = full[64 + lane];
     if (key && lane == 0) state->epoch = state->epoch + 1ull;      // the next fused launch of this slot gets a new key (stream order)
@@ -1584,8 +1607,8 @@ __device__ void reduce_partials_block(const double* part_surf, int nb_surf, cons
 
 __global__ __launch_bounds__(kReduceThreads) void k_reduce_partials(const double* __restrict__ part_surf, int nb_surf,
                                                             const double* __restrict__ part_edge, int nb_edge,
-                                                            double* __restrict__ out, SlotState* __restrict__ state, int do_gn) {
-    reduce_partials_block(part_surf, nb_surf, part_edge, nb_edge, out, state, do_gn, 0ull);
+                                                            double* __restrict__ out, SlotState* __restrict__ state, int do_gn, P2PView v) {
+    reduce_partials_block<true>(part_surf, nb_surf, part_edge, nb_edge, out, state, do_gn, 0ull, v);
 }
 
 // Restart of a registration: 56 bytes device to device.  hipMemcpyAsync(D2D) costs a 4.5 us copy kernel for this; one 8-lane
