@@ -100,7 +100,10 @@ int lili_set_debug(lili_ctx* ctx, int keep_neighbors);
  * partials and the GN update run inside the linearisation launch, in its last block; default 0 = separate launch, which is
  * faster on MI355X; may be changed at any time), "merge_kinds" (1 = surf and edge of a keyframe share ONE association launch and ONE
  * linearisation launch; default 1), "p2p_fusion" (0 = lili_s2m_iterate_sharded runs lili_p2p_allreduce as its own launches like any
- * other lili_allreduce_fn instead of inside the count / reduce kernels; default 1). */
+ * other lili_allreduce_fn instead of inside the count / reduce kernels; default 1).
+ * One knob that DOES choose between two definitions of a result: "rot_atan" — lili_extract_rot's atan / atan2 on float arguments
+ * (R/src/Preprocessing.cpp:285-288,315,349): 2 (default) = glibc's float routines statement for statement (atanf / atan2f of
+ * every glibc up to 2.40 — the bits a build of the reference produces), 1 = the f64 functions rounded to f32 (libm-independent). */
 int lili_set_option(lili_ctx* ctx, const char* name, int value);
 
 /* ---- local map index ------------------------------------------------------------------------ */

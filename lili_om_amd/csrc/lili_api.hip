@@ -156,6 +156,7 @@ int lili_set_option(lili_ctx* ctx, const char* name, int value) {
     if (std::strcmp(name, "balance") == 0) { ctx->balance = value != 0; for (auto& sl : ctx->slots) for (auto& k : sl.k) { k.order_valid = false; k.launches = 0; } return LILI_OK; }
     if (std::strcmp(name, "fuse_tail") == 0) { ctx->fuse_tail = value != 0; return LILI_OK; }   // any time: the block partition does not depend on it
     if (std::strcmp(name, "merge_kinds") == 0) { ctx->merge_kinds = value != 0; return LILI_OK; }
+    if (std::strcmp(name, "rot_atan") == 0) { if (value != 1 && value != 2) return ctx->fail(LILI_E_ARG, "rot_atan must be 1 or 2"); ctx->rot_atan = value; return LILI_OK; }
     if (std::strcmp(name, "p2p_fusion") == 0) { ctx->no_p2p_fusion = value == 0; return LILI_OK; }
     if (std::strcmp(name, "nn_cache") == 0) { ctx->nn_cache = value != 0; for (auto& s : ctx->slots) for (auto& k : s.k) k.nn_cache_valid = false; return LILI_OK; }
     if (std::strcmp(name, "max_cells") == 0) { if (value < 1) return ctx->fail(LILI_E_ARG, "max_cells must be positive"); ctx->max_cells = value; return LILI_OK; }

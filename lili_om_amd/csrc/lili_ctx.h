@@ -99,6 +99,7 @@ struct lili_ctx {
     bool merge_kinds = true;     // surf and edge of one keyframe in ONE association launch / ONE linearisation launch
     bool nn_cache = false;       // seed each query's search bound with its previous 5 neighbours (exact for any pose change)
     int cell_pct = 65;           // reach 2: cell edge in % of 1.01 * gate radius (>= 50)
+    int rot_atan = 2;            // ROT extractor: 2 = glibc fdlibm float atan / atan2 (the reference build's bits), 1 = f64 functions rounded to f32
     bool balance = false;        // cost-ordered dispatch of the association workgroups (AssocSched): measured, no gain — A/B only
     int n_simd = 0;              // SIMDs of the device (CUs x 4)
     void* ext_rot = nullptr;                 // extractor state (lili_extract_rot.hip), freed through ext_rot_free

@@ -10,8 +10,8 @@
 //                    VoxelGrid(ds_v) (bitonic sort of (voxel, index) keys in LDS, in-order centroids)     (R:401-508)
 //   k_rot_compact    ordered concatenation of the per-ring lists
 // Decisions are integer / f32 exact; the only transcendental inputs to a decision (atan for the ring id,
-// atan2 for relTime) are evaluated in f64 and rounded to f32 — the "reproducible" definition the oracle
-// offers as atan_mode = 1 (glibc's float overloads are not correctly rounded).
+// atan2 for relTime) follow glibc's float routines statement for statement (fd_atanf / fd_atan2f below) — the
+// reference build's bits; option "rot_atan" = 1 selects the f64 functions rounded to f32 instead.
 // Sort ties: (curvature, index) / (voxel, index) — std::sort's order on ties is unspecified.
 #include "lili_ctx.h"
 #include "lili_device_math.h"
@@ -28,6 +28,7 @@ constexpr int kRingSharpCap = 6 * 2;
 
 struct RotDev {
     int n_scans, ds_rate;
+    int atan_mode;      // 2 = glibc fdlibm float atan / atan2 (default), 1 = f64 function rounded to f32
     float ds_v, near_thres;
     double q_imu[4], q_lb[4];
 };
@@ -41,9 +42,97 @@ struct RotState {
     long long tphase[8];  // profiling: per-phase clock ticks of ring 0's workgroup (wall_clock64)
 };
 
-// f32 atan / atan2 defined as the f64 function rounded to f32
-__device__ __forceinline__ float atan_r(float v) { return (float)atan((double)v); }
-__device__ __forceinline__ float atan2_r(float y, float x) { return (float)atan2((double)y, (double)x); }
+// f32 atan / atan2.  Mode 2 (default): glibc's fdlibm float routines, statement for statement (sysdeps/ieee754/flt-32/s_atanf.c,
+// e_atan2f.c — every glibc up to 2.40, i.e. what a build of the reference calls on the ROS releases its README names): float-only
+// arithmetic, no FMA contraction, hence bit-identical to the reference build; the same statements live in oracle/lo_math.h, where
+// they are pinned against the image's libm on all 2^32 arguments (tools/check_fdlibm_atan.cpp).  Mode 1 ("rot_atan" = 1): the f64
+// function rounded to f32 — libm-independent (glibc >= 2.41 rounds atanf correctly, like this).
+__device__ float fd_atanf(float x) {
+    const float atanhi[] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
+    const float atanlo[] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
+    const float aT[] = {3.3333334327e-01f, -2.0000000298e-01f, 1.4285714924e-01f, -1.1111110449e-01f, 9.0908870101e-02f, -7.6918758452e-02f,
+                               6.6610731184e-02f, -5.8335702866e-02f, 4.9768779427e-02f, -3.6531571299e-02f, 1.6285819933e-02f};
+    const float one = 1.0f, huge = 1.0e30f;
+    float w, s1, s2, z;
+    int32_t ix, hx, id;
+    hx = __float_as_int(x);
+    ix = hx & 0x7fffffff;
+    if (ix >= 0x4c000000) {          /* |x| >= 2^25 */
+        if (ix > 0x7f800000) return x + x;
+        if (hx > 0) return atanhi[3] + atanlo[3];
+        else return -atanhi[3] - atanlo[3];
+    }
+    if (ix < 0x3ee00000) {           /* |x| < 0.4375 */
+        if (ix < 0x31000000) {       /* |x| < 2^-29 */
+            if (huge + x > one) return x;
+        }
+        id = -1;
+    } else {
+        x = fabsf(x);
+        if (ix < 0x3f980000) {       /* |x| < 1.1875 */
+            if (ix < 0x3f300000) { id = 0; x = (2.0f * x - one) / (2.0f + x); }
+            else { id = 1; x = (x - one) / (x + one); }
+        } else {
+            if (ix < 0x401c0000) { id = 2; x = (x - 1.5f) / (one + 1.5f * x); }
+            else { id = 3; x = -1.0f / x; }
+        }
+    }
+    z = x * x;
+    w = z * z;
+    s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
+    s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
+    if (id < 0) return x - x * (s1 + s2);
+    z = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
+    return (hx < 0) ? -z : z;
+}
+__device__ float fd_atan2f(float y, float x) {
+    const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    float z;
+    int32_t k, m, hx, hy, ix, iy;
+    hx = __float_as_int(x); ix = hx & 0x7fffffff;
+    hy = __float_as_int(y); iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
+    if (hx == 0x3f800000) return fd_atanf(y);
+    m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+    if (iy == 0) {
+        switch (m) {
+            case 0: case 1: return y;
+            case 2: return pi + tiny;
+            case 3: return -pi - tiny;
+        }
+    }
+    if (ix == 0) return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000) {
+        if (iy == 0x7f800000) {
+            switch (m) {
+                case 0: return pi_o_4 + tiny;
+                case 1: return -pi_o_4 - tiny;
+                case 2: return 3.0f * pi_o_4 + tiny;
+                case 3: return -3.0f * pi_o_4 - tiny;
+            }
+        } else {
+            switch (m) {
+                case 0: return 0.0f;
+                case 1: return -0.0f;
+                case 2: return pi + tiny;
+                case 3: return -pi - tiny;
+            }
+        }
+    }
+    if (iy == 0x7f800000) return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    k = (iy - ix) >> 23;
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
+    else if (hx < 0 && k < -60) z = 0.0f;
+    else z = fd_atanf(fabsf(y / x));
+    switch (m) {
+        case 0: return z;
+        case 1: return __uint_as_float(__float_as_uint(z) ^ 0x80000000u);
+        case 2: return pi - (z - pi_lo);
+        default: return (z - pi_lo) - pi;
+    }
+}
+__device__ __forceinline__ float atan_r(float v, int mode) { return mode == 2 ? fd_atanf(v) : (float)atan((double)v); }
+__device__ __forceinline__ float atan2_r(float y, float x, int mode) { return mode == 2 ? fd_atan2f(y, x) : (float)atan2((double)y, (double)x); }
 
 __device__ __forceinline__ dq qslerp_identity(double t, dq b) {   // Eigen 3.3 slerp of Identity towards b
     const double one = 1.0 - 2.220446049250313e-16;
@@ -88,17 +177,17 @@ __global__ __launch_bounds__(256) void k_rot_valid(const float4* __restrict__ in
     }
 }
 
-__device__ __forceinline__ void start_end_ori(const float4* __restrict__ in, const RotState* st, float& startOri, float& endOri) {
+__device__ __forceinline__ void start_end_ori(const float4* __restrict__ in, const RotState* st, int am, float& startOri, float& endOri) {
     float4 a = in[st->first_valid], b = in[st->last_valid];
-    startOri = -atan2_r(a.y, a.x);                                    // R:285
-    endOri = (float)((double)(-atan2_r(b.y, b.x)) + 2 * M_PI);       // R:286-288
+    startOri = -atan2_r(a.y, a.x, am);                                 // R:285
+    endOri = (float)((double)(-atan2_r(b.y, b.x, am)) + 2 * M_PI);       // R:286-288
     if ((double)(endOri - startOri) > 3 * M_PI) endOri = (float)((double)endOri - 2 * M_PI);
     else if ((double)(endOri - startOri) < M_PI) endOri = (float)((double)endOri + 2 * M_PI);
 }
 
 // ring id (R:315-343); returns -1 when the point is dropped
-__device__ __forceinline__ int ring_of(float4 p, int n_scans) {
-    float at = atan_r(p.z / sqrtf(p.x * p.x + p.y * p.y));
+__device__ __forceinline__ int ring_of(float4 p, int n_scans, int am) {
+    float at = atan_r(p.z / sqrtf(p.x * p.x + p.y * p.y), am);
     float angle = (float)((double)(at * 180.0f) / M_PI);    // float product, double division, narrowed (R:315)
     int scanID;
     if (n_scans == 16) {
@@ -125,14 +214,14 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_classify(const float4* __rest
     __syncthreads();
     if (st->last_valid < 0) { if (threadIdx.x < kMaxRings) block_hist[blockIdx.x * kMaxRings + threadIdx.x] = 0; return; }
     float startOri, endOri;
-    start_end_ori(in, st, startOri, endOri);
+    start_end_ori(in, st, P.atan_mode, startOri, endOri);
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int id = -1;
     if (i < n && valid[i]) {
         float4 p = in[i];
-        id = ring_of(p, P.n_scans);
+        id = ring_of(p, P.n_scans, P.atan_mode);
         if (id >= 0) {
-            float ori = -atan2_r(p.y, p.x);                         // R:349
+            float ori = -atan2_r(p.y, p.x, P.atan_mode);                       // R:349
             ori_raw[i] = ori;
             // would this point set halfPassed if it were reached with halfPassed == false?  (R:351-357)
             float o1 = ori;
@@ -206,7 +295,7 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_scatter(const float4* __restr
     if (id < 0) return;
     int pos = st->ring_base[id] + block_base[blockIdx.x * kMaxRings + id] + wave_hist[wave][id] + rank;
     float startOri, endOri;
-    start_end_ori(in, st, startOri, endOri);
+    start_end_ori(in, st, P.atan_mode, startOri, endOri);
     float ori = ori_raw[i];
     if (i <= st->half_idx) {   // halfPassed was still false when the reference reached this point (R:350-358)
         if ((double)ori < (double)startOri - M_PI / 2) ori = (float)((double)ori + 2 * M_PI);
@@ -571,6 +660,7 @@ int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4
         HIPCHK(R->lessflat_idx.ensure(cap * 4)); HIPCHK(R->surf.ensure(cap * 16)); HIPCHK(R->surf_cnt.ensure(cap * 4));
         RotDev P{};
         P.n_scans = params->n_scans; P.ds_rate = params->ds_rate; P.ds_v = params->ds_v; P.near_thres = params->near_range;
+        P.atan_mode = ctx->rot_atan;
         for (int i = 0; i < 4; i++) { P.q_imu[i] = q_imu[i]; P.q_lb[i] = q_lb[i]; }
         const float4* in = R->in.as<float4>();
         hipLaunchKernelGGL(k_rot_valid, dim3(std::min(nblocks(n, 256), 128)), dim3(256), 0, ctx->stream, in, n, P.near_thres, R->valid.as<unsigned char>(), st);

@@ -23,12 +23,12 @@ namespace {
 
 struct P4 { float x, y, z, i; };
 
-// atan / atan2 on float arguments.  mode 0: the float overloads of this libm (what the reference runs on a
-// given machine; glibc's atanf/atan2f are not correctly rounded, so this is libm-version dependent);
-// mode 1: the double function rounded to float (correctly rounded up to ~1e-9 probability) — the definition
-// the GPU path uses so that both sides are reproducible.  tests count where the two differ.
-static inline float atan_f(float v, int mode) { return mode ? (float)std::atan((double)v) : std::atan(v); }
-static inline float atan2_f(float y, float x, int mode) { return mode ? (float)std::atan2((double)y, (double)x) : std::atan2(y, x); }
+// atan / atan2 on float arguments.  mode 0: the float overloads of this libm (what the reference runs on a given machine);
+// mode 2: glibc's fdlibm float routines restated (lo_math.h: fd_atanf / fd_atan2f, bit-identical to this image's libm on every
+// input — the definition the GPU path uses by default); mode 1: the double function rounded to float (correctly rounded up
+// to ~1e-9 probability; libm-independent, the GPU path's "rot_atan" = 1 option).
+static inline float atan_f(float v, int mode) { return mode == 2 ? fd_atanf(v) : mode ? (float)std::atan((double)v) : std::atan(v); }
+static inline float atan2_f(float y, float x, int mode) { return mode == 2 ? fd_atan2f(y, x) : mode ? (float)std::atan2((double)y, (double)x) : std::atan2(y, x); }
 
 // undistortion — R/src/Preprocessing.cpp:153-177 (with_lb) and L/src/Preprocessing.cpp:104-127
 static inline P4 undistort(P4 pt, Q4 q_imu, Q4 q_lb, bool with_lb) {
@@ -97,7 +97,7 @@ struct lo_rot_params {
     int ds_rate;      // R/config/config_fr_iosb.yaml:13
     float ds_v;       // 0.6 (R:14)
     float near_thres; // 3.0 (R:281)
-    int atan_mode;    // 0 = libm float overloads (literal), 1 = double function rounded to float
+    int atan_mode;    // 0 = libm float overloads (literal), 1 = double function rounded to float, 2 = glibc fdlibm float routines restated
     int stable_sort;  // 0 = std::sort (literal), 1 = ties broken by index
 };
 
@@ -256,6 +256,24 @@ extern "C" int lo_extract_rot(const float* pts, int n, const double q_imu_[4], c
 }
 
 // stand-alone voxel filter (KATs)
+// Pin of the fdlibm restatement against THIS libm on a pseudo-random sample (the exhaustive run is tools/check_fdlibm_atan.cpp):
+// returns the number of inputs on which fd_atanf / fd_atan2f and atanf / atan2f differ in a bit (NaN results compare equal).
+extern "C" long long lo_fd_atan_mismatches(long long n, unsigned long long seed) {
+    unsigned long long x = seed * 0x9E3779B97F4A7C15ull + 1ull;
+    auto next = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    long long bad = 0;
+    for (long long i = 0; i < n; i++) {
+        const unsigned long long r = next();
+        float a, b;
+        if (i & 1) { a = bitsf((uint32_t)r); b = bitsf((uint32_t)(r >> 32)); }                          // any bit patterns
+        else { a = (float)((double)(r & 0xffffff) / 16777216.0 * 400.0 - 200.0); b = (float)((double)((r >> 32) & 0xffffff) / 16777216.0 * 400.0 - 200.0); }   // lidar coordinates
+        const float l1 = std::atan(a), f1 = fd_atanf(a), l2 = std::atan2(a, b), f2 = fd_atan2f(a, b);
+        if (fbits(l1) != fbits(f1) && !(l1 != l1 && f1 != f1)) bad++;
+        if (fbits(l2) != fbits(f2) && !(l2 != l2 && f2 != f2)) bad++;
+    }
+    return bad;
+}
+
 extern "C" int lo_voxel_grid(const float* pts, int n, float leaf, int stable, float* out, int* counts) {
     std::vector<P4> in(n), o; std::vector<int> c;
     for (int i = 0; i < n; i++) in[i] = P4{pts[4 * i], pts[4 * i + 1], pts[4 * i + 2], pts[4 * i + 3]};

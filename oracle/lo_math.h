@@ -306,4 +306,101 @@ static inline bool chol_solve(int n, double* H /*row-major n*n*/, double* rhs) {
     return true;
 }
 
+
+// ---- glibc's float atan / atan2 (third-party, NOT under /root/reference) ------------------------------------------------
+// R/src/Preprocessing.cpp:285-288,315,349 call atan / atan2 on float arguments = libm's atanf / atan2f.  The reference pins no
+// libm; every glibc up to 2.40 (Ubuntu 18.04 / 20.04 / 22.04 of the ROS releases the README names, and this image: 2.35) ships
+// the fdlibm float routines sysdeps/ieee754/flt-32/s_atanf.c and e_atan2f.c (Sun Microsystems' algorithm: argument reduction to
+// |x| < 7/16 by one float division, an 11-term odd/even polynomial, hi/lo table constants).  They are float-only arithmetic and
+// therefore reproducible instruction by instruction without FMA contraction; restated here from the published algorithm and
+// PINNED against this image's libm on all 2^32 atanf arguments and 3e8 atan2f pairs (tools/check_fdlibm_atan.cpp: 0 mismatches;
+// tests/test_oracle_cpu.py samples it).  The HIP extractor carries the same statements (lili_extract_rot.hip), so its ring /
+// relTime decisions are the reference build's bit for bit.  glibc >= 2.41 switched atanf to a correctly rounded routine.
+static inline uint32_t fbits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+static inline float bitsf(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+static inline float fd_atanf(float x) {
+    static const float atanhi[] = {4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f};
+    static const float atanlo[] = {5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f};
+    static const float aT[] = {3.3333334327e-01f, -2.0000000298e-01f, 1.4285714924e-01f, -1.1111110449e-01f, 9.0908870101e-02f, -7.6918758452e-02f,
+                               6.6610731184e-02f, -5.8335702866e-02f, 4.9768779427e-02f, -3.6531571299e-02f, 1.6285819933e-02f};
+    const float one = 1.0f, huge = 1.0e30f;
+    float w, s1, s2, z;
+    int32_t ix, hx, id;
+    hx = (int32_t)fbits(x);
+    ix = hx & 0x7fffffff;
+    if (ix >= 0x4c000000) {          /* |x| >= 2^25 */
+        if (ix > 0x7f800000) return x + x;
+        if (hx > 0) return atanhi[3] + atanlo[3];
+        else return -atanhi[3] - atanlo[3];
+    }
+    if (ix < 0x3ee00000) {           /* |x| < 0.4375 */
+        if (ix < 0x31000000) {       /* |x| < 2^-29 */
+            if (huge + x > one) return x;
+        }
+        id = -1;
+    } else {
+        x = fabsf(x);
+        if (ix < 0x3f980000) {       /* |x| < 1.1875 */
+            if (ix < 0x3f300000) { id = 0; x = (2.0f * x - one) / (2.0f + x); }
+            else { id = 1; x = (x - one) / (x + one); }
+        } else {
+            if (ix < 0x401c0000) { id = 2; x = (x - 1.5f) / (one + 1.5f * x); }
+            else { id = 3; x = -1.0f / x; }
+        }
+    }
+    z = x * x;
+    w = z * z;
+    s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
+    s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
+    if (id < 0) return x - x * (s1 + s2);
+    z = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
+    return (hx < 0) ? -z : z;
+}
+static inline float fd_atan2f(float y, float x) {
+    const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    float z;
+    int32_t k, m, hx, hy, ix, iy;
+    hx = (int32_t)fbits(x); ix = hx & 0x7fffffff;
+    hy = (int32_t)fbits(y); iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;
+    if (hx == 0x3f800000) return fd_atanf(y);
+    m = ((hy >> 31) & 1) | ((hx >> 30) & 2);
+    if (iy == 0) {
+        switch (m) {
+            case 0: case 1: return y;
+            case 2: return pi + tiny;
+            case 3: return -pi - tiny;
+        }
+    }
+    if (ix == 0) return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000) {
+        if (iy == 0x7f800000) {
+            switch (m) {
+                case 0: return pi_o_4 + tiny;
+                case 1: return -pi_o_4 - tiny;
+                case 2: return 3.0f * pi_o_4 + tiny;
+                case 3: return -3.0f * pi_o_4 - tiny;
+            }
+        } else {
+            switch (m) {
+                case 0: return 0.0f;
+                case 1: return -0.0f;
+                case 2: return pi + tiny;
+                case 3: return -pi - tiny;
+            }
+        }
+    }
+    if (iy == 0x7f800000) return (hy < 0) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    k = (iy - ix) >> 23;
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
+    else if (hx < 0 && k < -60) z = 0.0f;
+    else z = fd_atanf(fabsf(y / x));
+    switch (m) {
+        case 0: return z;
+        case 1: return bitsf(fbits(z) ^ 0x80000000u);
+        case 2: return pi - (z - pi_lo);
+        default: return (z - pi_lo) - pi;
+    }
+}
+
 }  // namespace lo

@@ -94,6 +94,14 @@ def run_rot():
         d[f"stamp{k}"] = o["stamp"]
         for name in ("cutted", "edge", "surf"):
             d[f"{name}{k}"] = o[name][:, PAYLOAD_ROT]
+        # Feature INDICES of the reference run (north star: "feature indices bit-exact").  The node publishes clouds, not indices; every
+        # /edge_features point is a copy of one /lidar_cloud_cutted point (R/src/Preprocessing.cpp:422-427), and a full-cloud row is unique
+        # (intensity = ring + 0.1 * relTime), so the row match IS the index the reference pushed.
+        full = np.ascontiguousarray(d[f"cutted{k}"], np.float32).view(np.uint32)
+        key = {row.tobytes(): i for i, row in enumerate(full)}
+        assert len(key) == full.shape[0], "duplicate rows in the reference's full cloud"
+        edge = np.ascontiguousarray(d[f"edge{k}"], np.float32).view(np.uint32)
+        d[f"edge_src{k}"] = np.array([key[row.tobytes()] for row in edge], np.int32)
     return d
 
 

@@ -19,7 +19,7 @@ def test_config0_extract_and_one_iteration(gpu_ctx, oracle):
     # --- extraction: indices bit-exact
     ex = L.RotExtractor(gpu_ctx, n_scans=64, ds_rate=4)
     g = ex.extract(raw, (1.0, 0, 0, 0), q_lb, debug=True)
-    o = oracle.extract_rot(raw, (1.0, 0, 0, 0), q_lb, oracle.rot_params(ds_rate=4, atan_mode=1, stable_sort=1))
+    o = oracle.extract_rot(raw, (1.0, 0, 0, 0), q_lb, oracle.rot_params(ds_rate=4, atan_mode=2, stable_sort=1))
     for k in ("full_src", "edge_idx", "flat_idx", "lessflat_idx", "label"):
         assert np.array_equal(g[k], o[k]), k
     assert np.array_equal(g["surf"].view(np.uint32), o["surf"].view(np.uint32))

@@ -37,13 +37,21 @@ def test_rot_extractor_parity(gpu_ctx, oracle, n_az, ds_rate):
     q_imu = [np.cos(ang / 2), np.sin(ang / 2) * 0.3, -np.sin(ang / 2) * 0.5, np.sin(ang / 2) * 0.81]   # un-normalised, like deltaQ products
     ex = L.RotExtractor(gpu_ctx, n_scans=64, ds_rate=ds_rate)
     g = ex.extract(raw, q_imu, q_lb, debug=True)
-    o = oracle.extract_rot(raw, q_imu, q_lb, oracle.rot_params(ds_rate=ds_rate, atan_mode=1, stable_sort=1))
-    assert o["n_ties"] == 0 or True
+    o = oracle.extract_rot(raw, q_imu, q_lb, oracle.rot_params(ds_rate=ds_rate, atan_mode=2, stable_sort=1))   # glibc float atan / atan2 restated
     assert len(o["edge_idx"]) > 20 and len(o["surf"]) > 200
     _compare(g, o)
-    # the literal oracle (libm float overloads, std::sort) selects the same features on this data
+    # the other definition ("rot_atan" = 1: f64 functions rounded to f32) against the oracle's mode 1
+    gpu_ctx.set_option("rot_atan", 1)
+    try:
+        g1 = ex.extract(raw, q_imu, q_lb, debug=True)
+    finally:
+        gpu_ctx.set_option("rot_atan", 2)
+    _compare(g1, oracle.extract_rot(raw, q_imu, q_lb, oracle.rot_params(ds_rate=ds_rate, atan_mode=1, stable_sort=1)))
+    # the literal oracle (THIS libm's float overloads, std::sort): the deskewed cloud is bit-identical to the GPU's — the restated
+    # routines ARE this libm's — and without sort ties so is every selected feature
     lit = oracle.extract_rot(raw, q_imu, q_lb, oracle.rot_params(ds_rate=ds_rate, atan_mode=0, stable_sort=0))
     assert np.array_equal(lit["full_src"], o["full_src"])
+    assert np.array_equal(lit["full"].view(np.uint32), g["full"].view(np.uint32))
     if lit["n_ties"] == 0:
         assert np.array_equal(lit["edge_idx"], o["edge_idx"]) and np.array_equal(lit["label"], o["label"])
         assert np.array_equal(lit["lessflat_idx"], o["lessflat_idx"]) and np.array_equal(lit["surf_cnt"], o["surf_cnt"])
@@ -59,7 +67,7 @@ def test_rot_extractor_edge_cases(gpu_ctx, oracle):
     bad[30:40, :3] *= 0.01
     bad[50:60, 2] = 50.0
     g = ex.extract(bad, debug=True)
-    o = oracle.extract_rot(bad, P=oracle.rot_params(ds_rate=1, atan_mode=1, stable_sort=1))
+    o = oracle.extract_rot(bad, P=oracle.rot_params(ds_rate=1, atan_mode=2, stable_sort=1))
     _compare(g, o)
     g0 = ex.extract(np.zeros((0, 4), np.float32), debug=True)
     assert g0["full"].shape[0] == 0 and g0["edge"].shape[0] == 0 and g0["surf"].shape[0] == 0
@@ -69,5 +77,5 @@ def test_rot_extractor_edge_cases(gpu_ctx, oracle):
     # 16-ring table
     ex16 = L.RotExtractor(gpu_ctx, n_scans=16, ds_rate=1)
     g16 = ex16.extract(raw, debug=True)
-    o16 = oracle.extract_rot(raw, P=oracle.rot_params(n_scans=16, ds_rate=1, atan_mode=1, stable_sort=1))
+    o16 = oracle.extract_rot(raw, P=oracle.rot_params(n_scans=16, ds_rate=1, atan_mode=2, stable_sort=1))
     _compare(g16, o16)

@@ -115,7 +115,7 @@ def test_fullsize_rot_surf_and_edge_pose_parity_with_oracle(gpu_ctx, oracle, wor
     mp, emap, scan = workload["map_xyz"], workload["edge_map_xyz"], workload["scan"]
     # edge queries: cornerPointsLessSharp of the ROT extractor on the raw scan (oracle side, so that the test does not depend on the GPU extractor)
     raw = np.concatenate([workload["scan_xyz"], np.full((workload["scan_xyz"].shape[0], 1), 10.0, np.float32)], 1)
-    ex = oracle.extract_rot(raw, P=oracle.rot_params(n_scans=64, ds_rate=1, atan_mode=1, stable_sort=1))
+    ex = oracle.extract_rot(raw, P=oracle.rot_params(n_scans=64, ds_rate=1, atan_mode=2, stable_sort=1))
     edge_q = np.ascontiguousarray(ex["full"][ex["edge_idx"]][:, :3])
     assert edge_q.shape[0] > 500
     t_body, q_body = bench.body_pose_for_lidar(L, P, workload["lidar_t"])

@@ -78,6 +78,14 @@ def test_oracle_equals_reference_rot(oracle):
         assert np.array_equal(d["full_src"], r["full_src"]) and np.array_equal(d["edge_idx"], r["edge_idx"])
         assert np.array_equal(d["surf_cnt"], r["surf_cnt"])
         np.testing.assert_allclose(d["surf"], g[f"surf{k}"], rtol=2e-6, atol=2e-5)
+        # the feature indices the reference run pushed (row match of /edge_features in /lidar_cloud_cutted, make_ref_golden.py)
+        assert np.array_equal(r["edge_idx"], g[f"edge_src{k}"])
+        # glibc's float atan / atan2 restated (lo_math.h fd_atanf / fd_atan2f — what the HIP extractor runs by default): the SAME bits
+        # as the libm the reference build called, in every published cloud
+        f = oracle.extract_rot(scans[k], q_imu, M.ROT_QLB, oracle.rot_params(ds_rate=4, atan_mode=2, stable_sort=0))
+        for key in ("full", "surf"):
+            assert np.array_equal(_bits(f[key]), _bits(r[key])), key
+        assert np.array_equal(f["edge_idx"], r["edge_idx"]) and np.array_equal(f["label"], r["label"])
 
 
 def test_oracle_equals_reference_livox(oracle):
