@@ -181,6 +181,15 @@ def secondary_stages(L, ctx, w, torch):
     cloud = L.api.cloud_from_device(d_map.data_ptr(), w["map_xyz"].shape[0], 12, -1)
     sec = rate(lambda: m.set_input_cloud(L.KIND_SURF, cloud), 10)
     out["map_index_build"] = entry(sec, 36 * w["map_xyz"].shape[0], "maps/s", f"lili_map_set on {w['map_xyz'].shape[0]} points resident in HBM (K7: bbox, cell sort, index), blocking call")
+    # the same from HOST memory: pageable (the runtime stages it page by page) and page-locked (lili_host_alloc: straight DMA)
+    hmap = np.ascontiguousarray(w["map_xyz"])
+    sec = rate(lambda: m.set_input_cloud(L.KIND_SURF, hmap), 3)
+    out["map_index_build_from_pageable_host"] = entry(sec, 36 * hmap.shape[0], "maps/s", f"lili_map_set incl. the H2D of {hmap.nbytes >> 20} MiB from pageable memory")
+    pin = L.api.PinnedArray(hmap.shape, np.float32)
+    pin.array[...] = hmap
+    sec = rate(lambda: m.set_input_cloud(L.KIND_SURF, pin.array), 5)
+    out["map_index_build_from_pinned_host"] = entry(sec, 36 * hmap.shape[0], "maps/s", f"lili_map_set incl. the H2D of {hmap.nbytes >> 20} MiB from page-locked memory (lili_host_alloc)")
+    pin.close()
     return out
 
 

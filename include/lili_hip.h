@@ -106,6 +106,12 @@ int lili_set_debug(lili_ctx* ctx, int keep_neighbors);
  * every glibc up to 2.40 — the bits a build of the reference produces), 1 = the f64 functions rounded to f32 (libm-independent). */
 int lili_set_option(lili_ctx* ctx, const char* name, int value);
 
+/* Page-locked host memory for clouds handed over with LILI_MEM_HOST: a cloud in such a buffer is DMA'd straight into HBM (an 80 MB
+ * map: ~1.5 ms), a pageable one is staged by the runtime page by page (~8 ms).  Plain hipHostMalloc / hipHostFree — a caller that
+ * already owns pinned memory (hipHostRegister on a PCL cloud's buffer) needs neither. */
+void* lili_host_alloc(size_t bytes);
+void lili_host_free(void* p);
+
 /* ---- local map index ------------------------------------------------------------------------ */
 
 /* Replaces kd_tree_{surf,edge}_local_map->setInputCloud(...) (L/src/BackendFusion.cpp:839-840,

@@ -127,6 +127,8 @@ _SIGS = {
     "lili_s2m_pose_copy": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "lili_s2m_iterate_restart": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "lili_s2m_iterate_sharded": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lili_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "lili_host_free": (None, [C.c_void_p]),
     "lili_p2p_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "lili_p2p_handle": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lili_p2p_connect": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -174,6 +176,28 @@ def load_library():
 
 def _ptr(a):
     return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+class PinnedArray:
+    """numpy view of page-locked host memory (lili_host_alloc): clouds passed from it are DMA'd, not staged.  Keep the object
+    alive as long as the array is used; close() (or garbage collection) frees the memory."""
+
+    def __init__(self, shape, dtype=np.float32):
+        self.lib = load_library()
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self.ptr = self.lib.lili_host_alloc(max(n, 1))
+        if not self.ptr:
+            raise LiliError("lili_host_alloc failed")
+        buf = (C.c_ubyte * max(n, 1)).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            self.lib.lili_host_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    __del__ = close
 
 
 def _f64(a, n):

@@ -13,13 +13,14 @@
 
 namespace lili {
 // kernels (lili_s2m.hip)
-__global__ void k_cloud_to_f4(const unsigned char*, int, int, int, float4*);
+__global__ void k_cloud_to_f4(const unsigned char*, int, int, int, float4*, unsigned*);
 __global__ void k_bbox(const float4*, int, unsigned*);
-__global__ void k_cell_count(const float4*, int, GridView, int*, int*);
+__global__ void k_cell_count(const float4*, int, GridView, int*, int2*);
 __global__ void k_scan_block_sums(const int*, int64_t, int*);
 __global__ void k_scan_sums(int*, int);
 __global__ void k_scan_apply(const int*, int64_t, const int*, int*);
-__global__ void k_scatter(const float4*, int, const int*, const int*, int*, float4*, float*);
+__global__ void k_scan_lookback(int*, int64_t, unsigned long long*);
+__global__ void k_scatter(const float4*, int, const int2*, const int*, float4*, float*);
 __global__ void k_bin_count(const float4*, int, GridView, PoseArg, MatchParams, int, int, int*, int*);
 __global__ void k_bin_scatter(const int*, int, const int*, int*, int*);
 __global__ void k_tile_count(const int*, int, int*);
@@ -64,7 +65,7 @@ static MatchParams to_device_params(const lili_s2m_params* p) {
 }
 
 // copies / converts a described cloud into a device float4 array (x, y, z, aux)
-int lili_ingest_cloud(lili_ctx* ctx, const lili_cloud* c, DevBuf& out_f4) {
+int lili_ingest_cloud(lili_ctx* ctx, const lili_cloud* c, DevBuf& out_f4, unsigned* d_bbox) {
     ARGCHK(c && (c->n == 0 || c->data), "cloud: null data");
     ARGCHK(c->stride >= 12 && c->stride % 4 == 0, "cloud: stride must be a multiple of 4 and >= 12");
     ARGCHK(c->aux_offset < 0 || (size_t)c->aux_offset + 4 <= c->stride, "cloud: aux_offset outside the point");
@@ -77,8 +78,9 @@ int lili_ingest_cloud(lili_ctx* ctx, const lili_cloud* c, DevBuf& out_f4) {
         HIPCHK(hipMemcpyAsync(ctx->staging.p, c->data, c->n * c->stride, hipMemcpyHostToDevice, ctx->stream));
         src = ctx->staging.as<unsigned char>();
     } else ARGCHK(c->mem == LILI_MEM_DEVICE, "cloud: bad mem");
-    hipLaunchKernelGGL(k_cloud_to_f4, dim3(nblocks((int64_t)c->n, kBlock)), dim3(kBlock), 0, ctx->stream, src, (int)c->n, (int)c->stride,
-                       c->aux_offset, out_f4.as<float4>());
+    // with a bounding box: a bounded grid (grid-stride loop) so that the box costs a few thousand atomics, not one set per 256 points
+    const int nb = d_bbox ? std::min(nblocks((int64_t)c->n, kBlock), 4096) : nblocks((int64_t)c->n, kBlock);
+    hipLaunchKernelGGL(k_cloud_to_f4, dim3(nb), dim3(kBlock), 0, ctx->stream, src, (int)c->n, (int)c->stride, c->aux_offset, out_f4.as<float4>(), d_bbox);
     HIPCHK(hipGetLastError());
     return LILI_OK;
 }
@@ -86,6 +88,14 @@ int lili_ingest_cloud(lili_ctx* ctx, const lili_cloud* c, DevBuf& out_f4) {
 extern "C" {
 
 int lili_abi_version(void) { return LILI_ABI_VERSION; }
+
+void* lili_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void lili_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
 
 int lili_ctx_create(lili_ctx** out, int device, void* stream) {
     if (!out) return LILI_E_ARG;
@@ -156,6 +166,7 @@ int lili_set_option(lili_ctx* ctx, const char* name, int value) {
     if (std::strcmp(name, "balance") == 0) { ctx->balance = value != 0; for (auto& sl : ctx->slots) for (auto& k : sl.k) { k.order_valid = false; k.launches = 0; } return LILI_OK; }
     if (std::strcmp(name, "fuse_tail") == 0) { ctx->fuse_tail = value != 0; return LILI_OK; }   // any time: the block partition does not depend on it
     if (std::strcmp(name, "merge_kinds") == 0) { ctx->merge_kinds = value != 0; return LILI_OK; }
+    if (std::strcmp(name, "scan_lookback") == 0) { ctx->scan_lookback = value != 0; return LILI_OK; }
     if (std::strcmp(name, "rot_atan") == 0) { if (value != 1 && value != 2) return ctx->fail(LILI_E_ARG, "rot_atan must be 1 or 2"); ctx->rot_atan = value; return LILI_OK; }
     if (std::strcmp(name, "p2p_fusion") == 0) { ctx->no_p2p_fusion = value == 0; return LILI_OK; }
     if (std::strcmp(name, "nn_cache") == 0) { ctx->nn_cache = value != 0; for (auto& s : ctx->slots) for (auto& k : s.k) k.nn_cache_valid = false; return LILI_OK; }
@@ -176,7 +187,11 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
     MapIndex& m = ctx->map[kind];
     m.valid = false;
     for (auto& s : ctx->slots) { s.k[kind].binned = false; s.k[kind].nn_cache_valid = false; s.k[kind].order_valid = false; s.k[kind].launches = 0; }
-    int rc = lili_ingest_cloud(ctx, cloud, m.pts);
+    // bounding box: reduced inside the ingestion pass (one read of the cloud for both)
+    unsigned init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+    unsigned* d_mm = ctx->misc.as<unsigned>();
+    HIPCHK(hipMemcpyAsync(d_mm, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+    int rc = lili_ingest_cloud(ctx, cloud, m.pts, d_mm);
     if (rc != LILI_OK) return rc;
     m.n = (int64_t)cloud->n;
     m.has_aux = cloud->aux_offset >= 0;
@@ -184,12 +199,6 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
     m.n_cells = 0; m.cell = 0;
     if (m.n == 0) { m.valid = true; return LILI_OK; }
     const int n = (int)m.n;
-    // bounding box
-    unsigned init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
-    unsigned* d_mm = ctx->misc.as<unsigned>();
-    HIPCHK(hipMemcpyAsync(d_mm, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_bbox, dim3(std::min(nblocks(n, kBlock), 512)), dim3(kBlock), 0, ctx->stream, m.pts.as<float4>(), n, d_mm);
-    HIPCHK(hipGetLastError());
     unsigned mm[6];
     HIPCHK(hipMemcpyAsync(mm, d_mm, sizeof(mm), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -218,21 +227,26 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
     g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2]; g.inv_cell = 1.0 / cell; g.cell = 1.0 / g.inv_cell;
     g.nx = (int)nx; g.ny = (int)ny; g.nz = (int)nz; g.n_points = n; g.reach = reach;
     const int64_t nc = m.n_cells;
-    HIPCHK(m.cell_tmp.ensure((size_t)nc * sizeof(int)));
+    // ONE cell array: counts -> (in-place exclusive scan) -> cell_start; the atomic of the count pass also hands every point its rank
     HIPCHK(m.cell_start.ensure((size_t)(nc + 1) * sizeof(int)));
-    HIPCHK(m.pt_cell.ensure((size_t)n * sizeof(int)));
+    HIPCHK(m.pt_cell.ensure((size_t)n * sizeof(int2)));
     HIPCHK(m.sorted.ensure((size_t)n * sizeof(float4)));
     if (m.has_aux) HIPCHK(m.aux_sorted.ensure((size_t)n * sizeof(float)));
     const int nb_scan = nblocks(nc, 2048);
-    HIPCHK(m.block_sums.ensure((size_t)nb_scan * sizeof(int)));
-    HIPCHK(hipMemsetAsync(m.cell_tmp.p, 0, (size_t)nc * sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(k_cell_count, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, m.pts.as<float4>(), n, g, m.cell_tmp.as<int>(), m.pt_cell.as<int>());
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb_scan), dim3(kBlock), 0, ctx->stream, m.cell_tmp.as<int>(), nc, m.block_sums.as<int>());
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, ctx->stream, m.block_sums.as<int>(), nb_scan);
-    hipLaunchKernelGGL(k_scan_apply, dim3(nb_scan), dim3(kBlock), 0, ctx->stream, m.cell_tmp.as<int>(), nc, m.block_sums.as<int>(), m.cell_start.as<int>());
-    HIPCHK(hipMemsetAsync(m.cell_tmp.p, 0, (size_t)nc * sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(k_scatter, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, m.pts.as<float4>(), n, m.pt_cell.as<int>(), m.cell_start.as<int>(),
-                       m.cell_tmp.as<int>(), m.sorted.as<float4>(), m.has_aux ? m.aux_sorted.as<float>() : nullptr);
+    HIPCHK(m.block_sums.ensure((size_t)(nb_scan + 2) * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(m.cell_start.p, 0, (size_t)nc * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_cell_count, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, m.pts.as<float4>(), n, g, m.cell_start.as<int>(), m.pt_cell.as<int2>());
+    if (ctx->scan_lookback) {      // one pass over the cell array (status words: one per 4096-cell tile)
+        const int nb_lb = nblocks(nc, 4096);
+        HIPCHK(hipMemsetAsync(m.block_sums.p, 0, (size_t)(nb_lb + 2) * sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(k_scan_lookback, dim3(nb_lb), dim3(kBlock), 0, ctx->stream, m.cell_start.as<int>(), nc, m.block_sums.as<unsigned long long>());
+    } else {
+        hipLaunchKernelGGL(k_scan_block_sums, dim3(nb_scan), dim3(kBlock), 0, ctx->stream, m.cell_start.as<int>(), nc, m.block_sums.as<int>());
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, ctx->stream, m.block_sums.as<int>(), nb_scan);
+        hipLaunchKernelGGL(k_scan_apply, dim3(nb_scan), dim3(kBlock), 0, ctx->stream, m.cell_start.as<int>(), nc, m.block_sums.as<int>(), m.cell_start.as<int>());
+    }
+    hipLaunchKernelGGL(k_scatter, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, m.pts.as<float4>(), n, m.pt_cell.as<int2>(), m.cell_start.as<int>(),
+                       m.sorted.as<float4>(), m.has_aux ? m.aux_sorted.as<float>() : nullptr);
     HIPCHK(hipGetLastError());
     g.pts = m.sorted.as<float4>();
     g.aux = m.has_aux ? m.aux_sorted.as<float>() : nullptr;

@@ -99,6 +99,7 @@ struct lili_ctx {
     bool merge_kinds = true;     // surf and edge of one keyframe in ONE association launch / ONE linearisation launch
     bool nn_cache = false;       // seed each query's search bound with its previous 5 neighbours (exact for any pose change)
     int cell_pct = 65;           // reach 2: cell edge in % of 1.01 * gate radius (>= 50)
+    bool scan_lookback = true;   // map index: single-pass (decoupled look-back) scan of the cell array; 0 = the three-kernel scan (A/B)
     int rot_atan = 2;            // ROT extractor: 2 = glibc fdlibm float atan / atan2 (the reference build's bits), 1 = f64 functions rounded to f32
     bool balance = false;        // cost-ordered dispatch of the association workgroups (AssocSched): measured, no gain — A/B only
     int n_simd = 0;              // SIMDs of the device (CUs x 4)
@@ -123,7 +124,7 @@ struct lili_ctx {
 
 static inline int nblocks(int64_t n, int per) { return (int)((n + per - 1) / per); }
 
-int lili_ingest_cloud(lili_ctx* ctx, const lili_cloud* c, lili_detail::DevBuf& out_f4);
+int lili_ingest_cloud(lili_ctx* ctx, const lili_cloud* c, lili_detail::DevBuf& out_f4, unsigned* d_bbox = nullptr);   // d_bbox: also reduce the bounding box (6 ordered-uint words, initialised by the caller)
 // lili_p2p.hip: the view of the NEXT exchange of a communicator (advances its sequence number); usable = connected and on this context
 lili::P2PView lili_p2p_next_view(lili_p2p* c);
 bool lili_p2p_usable(const lili_p2p* c, const lili_ctx* ctx);

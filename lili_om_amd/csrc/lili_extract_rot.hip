@@ -44,7 +44,7 @@ struct RotState {
 
 // f32 atan / atan2.  Mode 2 (default): glibc's fdlibm float routines, statement for statement (sysdeps/ieee754/flt-32/s_atanf.c,
 // e_atan2f.c — every glibc up to 2.40, i.e. what a build of the reference calls on the ROS releases its README names): float-only
-// arithmetic, no FMA contraction, hence bit-identical to the reference build; the same statements live in oracle/lo_math.h, where
+// arithmetic, no FMA contraction, hence bit-identical to the reference build; the same statements are kept by the test checker (lo_math.h), where
 // they are pinned against the image's libm on all 2^32 arguments (tools/check_fdlibm_atan.cpp).  Mode 1 ("rot_atan" = 1): the f64
 // function rounded to f32 — libm-independent (glibc >= 2.41 rounds atanf correctly, like this).
 __device__ float fd_atanf(float x) {

@@ -18,21 +18,43 @@ namespace lili {
 // ================================================================================================
 // cloud ingestion: AoS points (stride 32 / 48 B ...) -> float4 (x, y, z, aux)
 // ================================================================================================
-__global__ void k_cloud_to_f4(const unsigned char* __restrict__ raw, int n, int stride, int aux_off, float4* __restrict__ out) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float* p = reinterpret_cast<const float*>(raw + (size_t)i * stride);
-    float4 v;
-    v.x = p[0]; v.y = p[1]; v.z = p[2];
-    v.w = aux_off >= 0 ? *reinterpret_cast<const float*>(raw + (size_t)i * stride + aux_off) : 0.f;
-    out[i] = v;
+__device__ __forceinline__ unsigned f2ord(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+// `mm` (optional, [6] ordered-uint min xyz / max xyz): the bounding box of the finite points is reduced in the same pass (the map
+// index needs it before anything else; a separate k_bbox pass re-read the whole cloud) — one atomic set per block.
+__global__ __launch_bounds__(256) void k_cloud_to_f4(const unsigned char* __restrict__ raw, int n, int stride, int aux_off, float4* __restrict__ out, unsigned* __restrict__ mm) {
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float* p = reinterpret_cast<const float*>(raw + (size_t)i * stride);
+        float4 v;
+        v.x = p[0]; v.y = p[1]; v.z = p[2];
+        v.w = aux_off >= 0 ? *reinterpret_cast<const float*>(raw + (size_t)i * stride + aux_off) : 0.f;
+        out[i] = v;
+        if (mm && isfinite(v.x) && isfinite(v.y) && isfinite(v.z)) {
+            mn[0] = fminf(mn[0], v.x); mn[1] = fminf(mn[1], v.y); mn[2] = fminf(mn[2], v.z);
+            mx[0] = fmaxf(mx[0], v.x); mx[1] = fmaxf(mx[1], v.y); mx[2] = fmaxf(mx[2], v.z);
+        }
+    }
+    if (!mm) return;
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        for (int o = 32; o > 0; o >>= 1) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], o)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o)); }
+    __shared__ float smn[4][3], smx[4][3];
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { smn[threadIdx.x >> 6][k] = mn[k]; smx[threadIdx.x >> 6][k] = mx[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        float a = smn[0][k], b = smx[0][k];
+        for (int w = 1; w < 4; w++) { a = fminf(a, smn[w][k]); b = fmaxf(b, smx[w][k]); }
+        if (a <= b) { atomicMin(&mm[k], f2ord(a)); atomicMax(&mm[3 + k], f2ord(b)); }
+    }
 }
 
 // ================================================================================================
 // K7 — map index build: bounding box, cell histogram, exclusive scan, scatter
 // ================================================================================================
-__device__ __forceinline__ unsigned f2ord(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
-
 __global__ void k_bbox(const float4* __restrict__ pts, int n, unsigned* __restrict__ mm /*[6]: min xyz, max xyz (ordered-uint)*/) {
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -73,12 +95,27 @@ __device__ __forceinline__ int cell_of(float4 p, const GridView& g) {
     return (cz * g.ny + cy) * g.nx + cx;
 }
 
-__global__ void k_cell_count(const float4* __restrict__ pts, int n, GridView g, int* __restrict__ cell_count, int* __restrict__ pt_cell) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int c = cell_of(pts[i], g);
-    pt_cell[i] = c;
-    atomicAdd(&cell_count[c], 1);
+// One global atomic per point in the WHOLE build: the value it returns is the point's rank inside its cell, kept next to the cell id,
+// so the scatter pass needs no second counter array, no second 108 MB memset and no atomics (round 1: an atomic here, whose result
+// was dropped, and another one in k_scatter).
+// Neighbouring lanes that fall into the same cell (maps come out of the voxel filter in voxel order: consecutive points are
+// neighbours in x) share ONE atomic: run heads add the run length, the members take base + offset.  No loop, ~10 instructions;
+// an unordered cloud degenerates to one atomic per point.  All 64 lanes of a wave must be active.
+__global__ void k_cell_count(const float4* __restrict__ pts, int n, GridView g, int* __restrict__ cell_count, int2* __restrict__ pt_cell) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int c = i < n ? cell_of(pts[i], g) : -1;
+    const int prev = __shfl_up(c, 1);
+    const bool head = lane == 0 || c != prev;
+    const unsigned long long hm = __ballot(head);
+    const unsigned long long upto = (2ull << lane) - 1ull;                 // lanes <= mine (lane 63: all)
+    const int hl = 63 - __clzll((long long)(hm & upto));                   // my run's head lane
+    const unsigned long long above = hm & ~upto;
+    const int len = (above ? __ffsll((long long)above) - 1 : 64) - lane;   // run length (meaningful on head lanes)
+    int base = 0;
+    if (head && c >= 0) base = atomicAdd(&cell_count[c], len);
+    base = __shfl(base, hl);
+    if (i < n) pt_cell[i] = make_int2(c, base + (lane - hl));
 }
 
 // exclusive scan of n ints, 3 kernels: per-block sums, scan of block sums (single block), apply.
@@ -116,7 +153,7 @@ __global__ void k_scan_sums(int* __restrict__ block_sums, int nb) {   // single 
         carry += tot;
     }
 }
-__global__ void k_scan_apply(const int* __restrict__ in, int64_t n, const int* __restrict__ block_offs, int* __restrict__ out /*[n+1]*/) {
+__global__ void k_scan_apply(const int* in, int64_t n, const int* __restrict__ block_offs, int* out /*[n+1]; may be `in` itself: every thread reads its items before it writes them*/) {
     __shared__ int lds[kBlock / 64 + 1];
     int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
     int v[kScanItems]; int s = 0;
@@ -128,12 +165,90 @@ __global__ void k_scan_apply(const int* __restrict__ in, int64_t n, const int* _
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) out[n] = block_offs[blockIdx.x] + tot;
 }
 
-__global__ void k_scatter(const float4* __restrict__ pts, int n, const int* __restrict__ pt_cell, const int* __restrict__ cell_start,
-                          int* __restrict__ cell_fill, float4* __restrict__ sorted, float* __restrict__ aux_sorted) {
+// In-place exclusive scan of n ints in ONE pass (decoupled look-back): the dense cell array (27 M cells = 108 MB for the 5 M-point
+// map) is read once and written once, where the three-kernel scan above reads it twice and writes it once.  Tile b (4096 items) belongs
+// to workgroup b — no ticket: 6.6 k same-address atomics cost ~12 ns each on MI355X, more than the whole scan (measured: 183 us with a
+// ticket against 170 us for the three kernels).  Workgroups are dispatched in index order per XCD, so the lowest unfinished tile is
+// always resident and a tile only ever waits for lower ones; should that ever not hold, the bounded spin gives up (ws[1] = 1)
+// instead of hanging the GPU.  Every tile publishes {flag, value} as ONE 64-bit word (flag 1 = the tile's own sum, 2 = the inclusive
+// prefix up to and including the tile), written and read with agent-scope atomics — the word is its own flag, no fence.  One wave
+// per tile looks back 64 predecessors at a time.  `ws`: [0], [1] = error flag, [2 ...] one status word per tile — zeroed by the
+// caller.  data[n] receives the total.
+constexpr int kLbItems = 16;
+constexpr int kLbTile = kBlock * kLbItems;
+__global__ __launch_bounds__(kBlock) void k_scan_lookback(int* data, int64_t n, unsigned long long* __restrict__ ws) {
+    __shared__ int lds[kBlock / 64 + 1];
+    __shared__ int s_prefix;
+    const int tile = (int)blockIdx.x;
+    unsigned long long* status = ws + 2;
+    const int64_t base = (int64_t)tile * kLbTile + (int64_t)threadIdx.x * kLbItems;
+    int v[kLbItems]; int s = 0;
+    if (base + kLbItems <= n) {
+        const int4* p4 = reinterpret_cast<const int4*>(data + base);        // 16-byte loads: base is a multiple of 16 items
+#pragma unroll
+        for (int k = 0; k < kLbItems / 4; k++) { const int4 q = p4[k]; v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kLbItems; k++) v[k] = base + k < n ? data[base + k] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < kLbItems; k++) s += v[k];
+    int tot;
+    const int ex = block_exclusive_scan(s, lds, tot);
+    if (threadIdx.x == 0) {
+        const unsigned long long w = ((tile == 0 ? 2ull : 1ull) << 32) | (unsigned long long)(unsigned)tot;
+        __hip_atomic_store(&status[tile], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tile == 0) s_prefix = 0;
+    }
+    if (tile > 0 && threadIdx.x < 64) {          // one wave walks back until it meets an inclusive prefix
+        const int lane = threadIdx.x;
+        int acc = 0;
+        for (int hi = tile - 1; ; hi -= 64) {
+            const int t = hi - lane;
+            unsigned long long w = 2ull << 32;       // tiles before 0: "prefix 0"
+            if (t >= 0) {
+                int spins = 0;
+                do {
+                    w = __hip_atomic_load(&status[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (++spins > (1 << 21)) { ws[1] = 1ull; w = 2ull << 32; }      // cannot happen while lower tiles run; never hang the GPU
+                } while ((w >> 32) == 0ull);
+            }
+            const bool is_p = (w >> 32) == 2ull;
+            const unsigned long long pm = __ballot(is_p);
+            const int first_p = pm ? __ffsll((long long)pm) - 1 : 64;          // nearest predecessor with a prefix
+            int val = lane <= first_p ? (int)(unsigned)(w & 0xffffffffull) : 0;
+            for (int o = 32; o > 0; o >>= 1) val += __shfl_xor(val, o);
+            acc += val;
+            if (pm) break;
+        }
+        if (lane == 0) {
+            s_prefix = acc;
+            __hip_atomic_store(&status[tile], (2ull << 32) | (unsigned long long)(unsigned)(acc + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    int run = s_prefix + ex;
+    if (base + kLbItems <= n) {
+        int4* p4 = reinterpret_cast<int4*>(data + base);
+#pragma unroll
+        for (int k = 0; k < kLbItems / 4; k++) {
+            int4 q;
+            q.x = run; run += v[4 * k]; q.y = run; run += v[4 * k + 1]; q.z = run; run += v[4 * k + 2]; q.w = run; run += v[4 * k + 3];
+            p4[k] = q;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kLbItems; k++) { if (base + k < n) data[base + k] = run; run += v[k]; }
+    }
+    if (base <= n - 1 && n - 1 < base + kLbItems) data[n] = s_prefix + ex + s;     // the thread that owns the last item: total
+}
+
+__global__ void k_scatter(const float4* __restrict__ pts, int n, const int2* __restrict__ pt_cell, const int* __restrict__ cell_start,
+                          float4* __restrict__ sorted, float* __restrict__ aux_sorted) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    int c = pt_cell[i];
-    int pos = cell_start[c] + atomicAdd(&cell_fill[c], 1);
+    const int2 cr = pt_cell[i];
+    const int pos = cell_start[cr.x] + cr.y;
     float4 p = pts[i];
     if (aux_sorted) aux_sorted[pos] = p.w;
     p.w = __int_as_float(i);
