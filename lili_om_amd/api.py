@@ -462,12 +462,35 @@ class RotExtractor:
         self.lib = ctx.lib
         self.params = RotParams(n_scans, ds_rate, ds_v, near_range)
 
-    def extract(self, pts_xyzi, q_imu=(1.0, 0, 0, 0), q_lb=(1.0, 0, 0, 0), debug=False):
+    def extract_device(self, d_ptr, n, q_imu=(1.0, 0, 0, 0), q_lb=(1.0, 0, 0, 0)):
+        """The scan is already in HBM as float4 rows (x, y, z, intensity) at device address d_ptr; the features stay in HBM
+        (extract_rot_device() hands them on as device clouds).  Returns (n_full, n_edge, n_surf)."""
+        cloud = Cloud(d_ptr, n, 16, 12, MEM_DEVICE)
+        qi, ql = _f64(q_imu, 4), _f64(q_lb, 4)
+        outs = [FeatureOut(None, 0, 16, MEM_DEVICE, 0) for _ in range(3)]
+        self.ctx._chk(self.lib.lili_extract_rot(self.ctx.h, C.byref(cloud), _ptr(qi), _ptr(ql), C.byref(self.params),
+                                                C.byref(outs[0]), C.byref(outs[1]), C.byref(outs[2])))
+        return outs[0].count, outs[1].count, outs[2].count
+
+    def _out_buffers(self, cap, reuse):
+        """Three (cap, 4) float32 result buffers.  reuse: page-locked buffers owned by the extractor (DMA'd into, no per-call
+        allocation; the returned arrays are VIEWS that the next call overwrites — what a ROS node's callback would do with one
+        message in flight)."""
+        if not reuse:
+            return [np.zeros((cap, 4), np.float32) for _ in range(3)]
+        if getattr(self, "_pin_cap", 0) < cap:
+            for p in getattr(self, "_pins", []):
+                p.close()
+            self._pins = [PinnedArray((cap, 4), np.float32) for _ in range(3)]
+            self._pin_cap = cap
+        return [p.array[:cap] for p in self._pins]
+
+    def extract(self, pts_xyzi, q_imu=(1.0, 0, 0, 0), q_lb=(1.0, 0, 0, 0), debug=False, reuse=False):
         pts = np.ascontiguousarray(pts_xyzi, dtype=np.float32)
         n = pts.shape[0]
         cloud = cloud_from_numpy(pts, aux_col=3)
         cap = max(n, 1)
-        bufs = [np.zeros((cap, 4), np.float32) for _ in range(3)]
+        bufs = self._out_buffers(cap, reuse)
         outs = [FeatureOut(b.ctypes.data, cap, 16, MEM_HOST, 0) for b in bufs]
         qi, ql = _f64(q_imu, 4), _f64(q_lb, 4)
         self.ctx._chk(self.lib.lili_extract_rot(self.ctx.h, C.byref(cloud), _ptr(qi), _ptr(ql), C.byref(self.params),

@@ -4,7 +4,7 @@
 //                    column, first-writer-wins grid fill as atomicMin(source index) per cell          (L:243-268)
 //   k_livox_cut      ordered compaction of every deskewed point with a valid line (/lidar_cloud_cutted, L:253-257)
 //   k_livox_grid     gather the winning point of each of the 6 x 4000 cells
-//   k_livox_blocks   one thread per 6-column block (664 of them): 36-cell covariance + 3x3 symmetric eigen (f64),
+//   k_livox_blocks   one wave per 6-column block (664 of them): 36-cell covariance + 3x3 symmetric eigen (f64),
 //                    depth-Laplacian edge candidate per line, edge PCA, edge / plane emission with the block-local
 //                    tombstones of the reference (L:270-383)
 //   k_livox_compact  ordered concatenation (block, then line | column, line)
@@ -38,15 +38,17 @@ __global__ void k_livox_init(int* __restrict__ owner, LivoxState* st) {
 
 __global__ __launch_bounds__(256) void k_livox_prep(const float4* __restrict__ in_i /*x,y,z,intensity*/, const float4* __restrict__ in_c /*x,y,z,curvature*/, int n,
                                                     LivoxDev P, float4* __restrict__ und, float* __restrict__ curv, unsigned char* __restrict__ keep,
-                                                    int* __restrict__ owner) {
+                                                    int* __restrict__ owner, int* __restrict__ blk_keep /*[gridDim.x]: kept points of this block (for k_livox_cut)*/) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float4 p = in_i[i];
-    float c = in_c[i].w;
-    bool ok = isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && !(p.x * p.x + p.y * p.y + p.z * p.z < P.near_thres * P.near_thres);   // L:225-226
+    const bool live = i < n;
+    float4 p = live ? in_i[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float c = live ? in_c[i].w : 0.f;
+    bool ok = live && isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && !(p.x * p.x + p.y * p.y + p.z * p.z < P.near_thres * P.near_thres);   // L:225-226
     int scan_id = (int)p.w;                                                                                                          // L:252
     ok = ok && scan_id >= 0 && scan_id < kLvLines;   // lines >= 6 would index mat[] out of bounds in the reference
-    keep[i] = ok;
+    if (live) keep[i] = ok;
+    const int nk = __syncthreads_count(ok ? 1 : 0);
+    if (threadIdx.x == 0) blk_keep[blockIdx.x] = nk;
     if (!ok) return;
     // undistortion, L:104-127
     double dt_i = (double)(p.w - (float)scan_id);
@@ -65,32 +67,42 @@ __global__ __launch_bounds__(256) void k_livox_prep(const float4* __restrict__ i
     atomicMin(&owner[scan_id * kLvCols + col], i);                                                 // first point of the stream wins (L:265-267)
 }
 
-// ordered compaction, single block (24 k points): cutted[rank] = deskewed point, cut_src[rank] = i
-__global__ __launch_bounds__(1024) void k_livox_cut(const float4* __restrict__ und, const float* __restrict__ curv, const unsigned char* __restrict__ keep, int n,
-                                                    float4* __restrict__ cut_a, float4* __restrict__ cut_b, int* __restrict__ cut_src, LivoxState* st) {
-    __shared__ int ws[17];
-    int run = 0;
+// ordered compaction: cutted[rank] = deskewed point, cut_src[rank] = i.  Same grid as k_livox_prep (256 points per workgroup), which
+// left the number of kept points per workgroup: every workgroup adds up the counts in front of it and ranks its own 256 points —
+// no serial pass over the scan (round 1: ONE workgroup, 24 rounds of two barriers, 30 us).
+__global__ __launch_bounds__(256) void k_livox_cut(const float4* __restrict__ und, const float* __restrict__ curv, const unsigned char* __restrict__ keep, int n,
+                                                   const int* __restrict__ blk_keep, float4* __restrict__ cut_a, float4* __restrict__ cut_b, int* __restrict__ cut_src, LivoxState* st) {
+    __shared__ int ws[5];
+    __shared__ int s_base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int b0 = 0; b0 < n; b0 += 1024) {
-        int i = b0 + threadIdx.x;
-        int f = i < n ? (int)keep[i] : 0;
-        int inc = f;
-        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
-        if (lane == 63) ws[wave] = inc;
+    int before = 0, total = 0;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) { const int cnt = blk_keep[b]; total += cnt; if (b < (int)blockIdx.x) before += cnt; }
+    for (int o = 32; o > 0; o >>= 1) { before += __shfl_xor(before, o); total += __shfl_xor(total, o); }
+    if (lane == 0) { ws[wave] = before; }
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = ws[0] + ws[1] + ws[2] + ws[3];
+    __syncthreads();
+    if (blockIdx.x == 0) {      // n_cut: the grand total
+        if (lane == 0) ws[wave] = total;
         __syncthreads();
-        int base = 0, tot = 0;
-        for (int w = 0; w < 16; w++) { int s = ws[w]; if (w < wave) base += s; tot += s; }
+        if (threadIdx.x == 0) st->n_cut = ws[0] + ws[1] + ws[2] + ws[3];
         __syncthreads();
-        if (f) {
-            int pos = run + base + inc - 1;
-            float4 u = und[i];
-            cut_a[pos] = make_float4(u.x, u.y, u.z, 0.f);          // x, y, z, normal_x
-            cut_b[pos] = make_float4(0.f, 0.f, u.w, curv[i]);       // normal_y, normal_z, intensity, curvature
-            cut_src[pos] = i;
-        }
-        run += tot;
     }
-    if (threadIdx.x == 0) st->n_cut = run;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int f = i < n ? (int)keep[i] : 0;
+    int inc = f;
+    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) ws[wave] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; w++) base += ws[w];
+    if (f) {
+        const int pos = s_base + base + inc - 1;
+        float4 u = und[i];
+        cut_a[pos] = make_float4(u.x, u.y, u.z, 0.f);          // x, y, z, normal_x
+        cut_b[pos] = make_float4(0.f, 0.f, u.w, curv[i]);       // normal_y, normal_z, intensity, curvature
+        cut_src[pos] = i;
+    }
 }
 
 __global__ void k_livox_grid(const int* __restrict__ owner, const float4* __restrict__ und, const float* __restrict__ curv,
@@ -107,91 +119,106 @@ __device__ __forceinline__ double lv_depth(const float4* __restrict__ cell_pt, i
     return (double)sqrtf(p.x * p.x + p.y * p.y + p.z * p.z);
 }
 
-// per-block outputs: edges [block][6] and surfs [block][36] as cell ids + the shared direction / normal
+// value of lane `src` (wave-uniform index) as a double on every lane
+__device__ __forceinline__ double bcast_f64(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+// per-block outputs: edges [block][6] and surfs [block][36] as cell ids + the shared direction / normal.
+// ONE WAVE per 6-column block (round 1 ran one thread per block: 664 threads on a 256-CU part, 83 us): lane o = 6 j + k
+// owns cell (line k, column i + j) — the order in which the reference visits the 36 cells (L:271-296: j outer, k inner) — so all
+// loads are one round trip.  The f64 sums keep the reference's ORDER: every lane forms its own term, then the terms are added lane
+// by lane (v_readlane broadcast), i.e. exactly the sequence of additions the serial loop performs; empty cells contribute +0.0, which
+// leaves an accumulator that is never -0.0 unchanged.  The 3x3 eigen-decompositions run redundantly on all lanes (wave-uniform).
 __global__ __launch_bounds__(64) void k_livox_blocks(const float4* __restrict__ cell_pt, const float* __restrict__ cell_curv, LivoxDev P,
                                                      int* __restrict__ blk_nedge, int* __restrict__ blk_edge_cell, float* __restrict__ blk_edge_dir,
                                                      int* __restrict__ blk_nsurf, int* __restrict__ blk_surf_cell, float* __restrict__ blk_surf_nrm) {
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= kLvBlocks) return;
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
     const int i = 5 + 6 * b;
-    blk_nedge[b] = 0; blk_nsurf[b] = 0;
-    // 36-cell centroid + scatter (L:271-296)
-    int num = 36;
-    d3 center{0, 0, 0};
-    for (int j = 0; j < 6; j++) for (int k = 0; k < kLvLines; k++) {
-        int c = k * kLvCols + i + j;
-        if (cell_curv[c] <= 0.f) { num--; continue; }
-        float4 p = cell_pt[c];
-        center = center + d3{(double)p.x, (double)p.y, (double)p.z};
-    }
-    if (num < 25) return;
-    center = d3{center.x / num, center.y / num, center.z / num};
+    const bool cell = lane < 36;
+    const int j = cell ? lane / 6 : 0, k = cell ? lane % 6 : 0;
+    const int c = k * kLvCols + i + j;
+    const float cv = cell ? cell_curv[c] : 0.f;
+    const float4 p = cell ? cell_pt[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    // the nine depths of this lane's Laplacian (L:310-315) are requested now as well: one memory round trip for the whole block
+    float4 nb[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) nb[t] = cell ? cell_pt[k * kLvCols + i + j + t - 4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool valid = cell && !(cv <= 0.f);
+    const unsigned long long vm = __ballot(valid);
+    const int num = __popcll(vm);                                           // L:271-283
+    if (lane == 0) { blk_nedge[b] = 0; blk_nsurf[b] = 0; }
+    if (num < 25) return;                                                   // wave-uniform
+    const double px = valid ? (double)p.x : 0.0, py = valid ? (double)p.y : 0.0, pz = valid ? (double)p.z : 0.0;
+    double cx = 0, cy = 0, cz = 0;
+    for (int o = 0; o < 36; o++) { cx = cx + bcast_f64(px, o); cy = cy + bcast_f64(py, o); cz = cz + bcast_f64(pz, o); }
+    const double nd = (double)num;
+    const d3 center{cx / nd, cy / nd, cz / nd};
+    const d3 z = d3{(double)p.x, (double)p.y, (double)p.z} - center;
+    const double t00 = valid ? z.x * z.x : 0.0, t01 = valid ? z.x * z.y : 0.0, t02 = valid ? z.x * z.z : 0.0;
+    const double t11 = valid ? z.y * z.y : 0.0, t12 = valid ? z.y * z.z : 0.0, t22 = valid ? z.z * z.z : 0.0;
     double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;
-    for (int j = 0; j < 6; j++) for (int k = 0; k < kLvLines; k++) {
-        int c = k * kLvCols + i + j;
-        if (cell_curv[c] <= 0.f) continue;
-        float4 p = cell_pt[c];
-        d3 z = d3{(double)p.x, (double)p.y, (double)p.z} - center;
-        a00 += z.x * z.x; a01 += z.x * z.y; a02 += z.x * z.z; a11 += z.y * z.y; a12 += z.y * z.z; a22 += z.z * z.z;
+    for (int o = 0; o < 36; o++) {
+        a00 += bcast_f64(t00, o); a01 += bcast_f64(t01, o); a02 += bcast_f64(t02, o);
+        a11 += bcast_f64(t11, o); a12 += bcast_f64(t12, o); a22 += bcast_f64(t22, o);
     }
     double ev[3]; d3 vmin, vmax;
     eig3_sym(a00, a01, a02, a11, a12, a22, ev, vmin, vmax);
-    // edge candidate per line (L:302-331)
-    int ex[kLvLines], ey[kLvLines], ne = 0;
-    for (int k = 0; k < kLvLines; k++) {
-        double max_s = 0; int idx = i;
-        for (int j = 0; j < 6; j++) {
-            int col = i + j;
-            if (cell_curv[k * kLvCols + col] <= 0.f) continue;
-            double d0 = lv_depth(cell_pt, k, col);
-            double g1 = lv_depth(cell_pt, k, col - 4) + lv_depth(cell_pt, k, col - 3) + lv_depth(cell_pt, k, col - 2) + lv_depth(cell_pt, k, col - 1) - 8 * d0 +
-                        lv_depth(cell_pt, k, col + 1) + lv_depth(cell_pt, k, col + 2) + lv_depth(cell_pt, k, col + 3) + lv_depth(cell_pt, k, col + 4);
-            g1 = g1 / (8 * d0 + 1e-3);
-            if (g1 > 0.06 && g1 > max_s) { max_s = g1; idx = col; }
-        }
-        if (max_s != 0) { ex[ne] = k; ey[ne] = idx; ne++; }
+    // edge candidate per line (L:302-331): every lane scores its own cell, the line's winner is the FIRST column with the largest score
+    double g1 = 0.0;
+    if (valid) {
+        double dep[9];
+#pragma unroll
+        for (int t = 0; t < 9; t++) dep[t] = (double)sqrtf(nb[t].x * nb[t].x + nb[t].y * nb[t].y + nb[t].z * nb[t].z);     // getDepth: float sqrt, widened
+        const double d0 = dep[4];
+        g1 = dep[0] + dep[1] + dep[2] + dep[3] - 8 * d0 + dep[5] + dep[6] + dep[7] + dep[8];
+        g1 = g1 / (8 * d0 + 1e-3);
     }
-    bool tomb[kLvLines];   // edge cells of this block removed from its plane set (curvature *= -1, L:363)
-    for (int k = 0; k < kLvLines; k++) tomb[k] = false;
+    int ex[kLvLines], ey[kLvLines], ne = 0;
+    for (int kk = 0; kk < kLvLines; kk++) {
+        double max_s = 0; int idx = i;
+        for (int jj = 0; jj < 6; jj++) {
+            const int src = jj * 6 + kk;
+            const double g = bcast_f64(g1, src);
+            const bool ok = (vm >> src) & 1ull;
+            if (ok && g > 0.06 && g > max_s) { max_s = g; idx = i + jj; }
+        }
+        if (max_s != 0) { ex[ne] = kk; ey[ne] = idx; ne++; }
+    }
+    unsigned tomb_cells = 0u;   // bit (line): the edge cell of that line is removed from this block's plane set (curvature *= -1, L:363)
     if (ne > 3) {          // with <= 3 candidates the reference's test fails whatever the eigenvalues are (App. A6)
         d3 ce{0, 0, 0};
-        for (int q = 0; q < ne; q++) { float4 p = cell_pt[ex[q] * kLvCols + ey[q]]; ce = ce + d3{(double)p.x, (double)p.y, (double)p.z}; }
-        double nd = (double)ne;
-        ce = d3{ce.x / nd, ce.y / nd, ce.z / nd};
+        for (int q = 0; q < ne; q++) { float4 e = cell_pt[ex[q] * kLvCols + ey[q]]; ce = ce + d3{(double)e.x, (double)e.y, (double)e.z}; }
+        const double ned = (double)ne;
+        ce = d3{ce.x / ned, ce.y / ned, ce.z / ned};
         double e00 = 0, e01 = 0, e02 = 0, e11 = 0, e12 = 0, e22 = 0;
         for (int q = 0; q < ne; q++) {
-            float4 p = cell_pt[ex[q] * kLvCols + ey[q]];
-            d3 z = d3{(double)p.x, (double)p.y, (double)p.z} - ce;
-            e00 += z.x * z.x; e01 += z.x * z.y; e02 += z.x * z.z; e11 += z.y * z.y; e12 += z.y * z.z; e22 += z.z * z.z;
+            float4 e = cell_pt[ex[q] * kLvCols + ey[q]];
+            d3 zz = d3{(double)e.x, (double)e.y, (double)e.z} - ce;
+            e00 += zz.x * zz.x; e01 += zz.x * zz.y; e02 += zz.x * zz.z; e11 += zz.y * zz.y; e12 += zz.y * zz.z; e22 += zz.z * zz.z;
         }
         double eve[3]; d3 vmn, vmx;
         eig3_sym(e00, e01, e02, e11, e12, e22, eve, vmn, vmx);
         if (eve[2] > P.edge_thres * eve[1]) {                                                    // L:353
             d3 u = canon_sign(vmx);
-            blk_edge_dir[3 * b] = (float)u.x; blk_edge_dir[3 * b + 1] = (float)u.y; blk_edge_dir[3 * b + 2] = (float)u.z;
-            int w = 0;
+            if (lane == 0) { blk_edge_dir[3 * b] = (float)u.x; blk_edge_dir[3 * b + 1] = (float)u.y; blk_edge_dir[3 * b + 2] = (float)u.z; blk_nedge[b] = ne; }
             for (int q = 0; q < ne; q++) {
-                int c = ex[q] * kLvCols + ey[q];
                 // the reference's `curvature <= 0 && intensity <= 0` skip can never fire here: candidates have curvature > 0
-                blk_edge_cell[b * kLvLines + w++] = c;
-                tomb[ex[q]] = true;   // at most one candidate per line, so the line id identifies the tombstoned cell
+                if (lane == q) blk_edge_cell[b * kLvLines + q] = ex[q] * kLvCols + ey[q];
+                tomb_cells |= 1u << ex[q];   // at most one candidate per line, so the line id identifies the tombstoned cell
             }
-            blk_nedge[b] = w;
         }
     }
     if (ev[0] < P.surf_thres * ev[1]) {                                                          // L:367
         d3 u = canon_sign(vmin);
-        blk_surf_nrm[3 * b] = (float)u.x; blk_surf_nrm[3 * b + 1] = (float)u.y; blk_surf_nrm[3 * b + 2] = (float)u.z;
-        int w = 0;
-        for (int j = 0; j < 6; j++) for (int k = 0; k < kLvLines; k++) {
-            int c = k * kLvCols + i + j;
-            if (cell_curv[c] <= 0.f) continue;
-            bool is_tomb = false;
-            if (tomb[k]) { for (int q = 0; q < ne; q++) if (ex[q] == k && ey[q] == i + j) is_tomb = true; }
-            if (is_tomb) continue;
-            blk_surf_cell[b * 36 + w++] = c;
-        }
-        blk_nsurf[b] = w;
+        bool is_tomb = false;
+        if ((tomb_cells >> k) & 1u) { for (int q = 0; q < ne; q++) if (ex[q] == k && ey[q] == i + j) is_tomb = true; }
+        const bool emit = valid && !is_tomb;
+        const unsigned long long em = __ballot(emit);
+        if (emit) blk_surf_cell[b * 36 + __popcll(em & ((1ull << lane) - 1ull))] = c;          // (column, line) order = lane order
+        if (lane == 0) { blk_surf_nrm[3 * b] = (float)u.x; blk_surf_nrm[3 * b + 1] = (float)u.y; blk_surf_nrm[3 * b + 2] = (float)u.z; blk_nsurf[b] = __popcll(em); }
     }
 }
 
@@ -201,14 +228,23 @@ __global__ __launch_bounds__(1024) void k_livox_compact(const float4* __restrict
                                                         float4* __restrict__ edge_a, float4* __restrict__ edge_b, int* __restrict__ edge_cell,
                                                         float4* __restrict__ surf_a, float4* __restrict__ surf_b, int* __restrict__ surf_cell, LivoxState* st) {
     __shared__ int eoff[kLvBlocks + 1], soff[kLvBlocks + 1];
-    if (threadIdx.x == 0) {
-        int a = 0, s = 0;
-        for (int b = 0; b < kLvBlocks; b++) { eoff[b] = a; soff[b] = s; a += blk_nedge[b]; s += blk_nsurf[b]; }
-        eoff[kLvBlocks] = a; soff[kLvBlocks] = s;
-        st->n_edge = a; st->n_surf = s;
+    __shared__ int ws[2][17];
+    {   // exclusive prefix of the per-block counts: thread t = block t (664 <= 1024), one block scan for both lists
+        const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+        const int e = t < kLvBlocks ? blk_nedge[t] : 0, sf = t < kLvBlocks ? blk_nsurf[t] : 0;
+        int ie = e, is = sf;
+        for (int o = 1; o < 64; o <<= 1) { int a = __shfl_up(ie, o), c2 = __shfl_up(is, o); if (lane >= o) { ie += a; is += c2; } }
+        if (lane == 63) { ws[0][wave] = ie; ws[1][wave] = is; }
+        __syncthreads();
+        int be = 0, bs = 0, te = 0, ts = 0;
+        for (int w = 0; w < 16; w++) { const int a = ws[0][w], c2 = ws[1][w]; if (w < wave) { be += a; bs += c2; } te += a; ts += c2; }
+        if (t < kLvBlocks) { eoff[t] = be + ie - e; soff[t] = bs + is - sf; }
+        if (t == 0) { eoff[kLvBlocks] = te; soff[kLvBlocks] = ts; if (blockIdx.x == 0) { st->n_edge = te; st->n_surf = ts; } }
     }
     __syncthreads();
-    for (int b = threadIdx.x >> 6; b < kLvBlocks; b += 16) {
+    // every workgroup repeats the (tiny) prefix above and then copies the lists of ITS 16 blocks, one wave per block — a single
+    // workgroup walking all 664 blocks spent 42 dependent rounds on it (50 us)
+    for (int b = (int)blockIdx.x * 16 + (threadIdx.x >> 6); b < kLvBlocks; b += (int)gridDim.x * 16) {
         int lane = threadIdx.x & 63;
         if (lane < blk_nedge[b]) {
             int c = blk_edge_cell[b * kLvLines + lane];
@@ -252,7 +288,7 @@ __global__ void k_livox_xyzc(const float4* __restrict__ a, const float4* __restr
 
 namespace lili_detail {
 struct LivoxBuffers {
-    DevBuf in_i, in_c, und, curv, keep, owner, state, cut_a, cut_b, cut_src, cell_pt, cell_curv, cell_src;
+    DevBuf in_i, in_c, und, curv, keep, owner, state, cut_a, cut_b, cut_src, cell_pt, cell_curv, cell_src, blk_keep;
     DevBuf blk_nedge, blk_edge_cell, blk_edge_dir, blk_nsurf, blk_surf_cell, blk_surf_nrm;
     DevBuf edge_a, edge_b, edge_cell, surf_a, surf_b, surf_cell, pack, xyzc_edge, xyzc_surf;
     lili::LivoxState host{};
@@ -315,17 +351,18 @@ int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offs
     P.surf_thres = params->surf_thres; P.edge_thres = params->edge_thres; P.near_thres = params->near_range;
     hipLaunchKernelGGL(k_livox_init, dim3(nblocks(kLvCells, 256)), dim3(256), 0, ctx->stream, B->owner.as<int>(), st);
     if (n > 0) {
+        HIPCHK(B->blk_keep.ensure((size_t)nblocks(n, 256) * 4));
         hipLaunchKernelGGL(k_livox_prep, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, B->in_i.as<float4>(), B->in_c.as<float4>(), n, P, B->und.as<float4>(),
-                           B->curv.as<float>(), B->keep.as<unsigned char>(), B->owner.as<int>());
-        hipLaunchKernelGGL(k_livox_cut, dim3(1), dim3(1024), 0, ctx->stream, B->und.as<float4>(), B->curv.as<float>(), B->keep.as<unsigned char>(), n,
-                           B->cut_a.as<float4>(), B->cut_b.as<float4>(), B->cut_src.as<int>(), st);
+                           B->curv.as<float>(), B->keep.as<unsigned char>(), B->owner.as<int>(), B->blk_keep.as<int>());
+        hipLaunchKernelGGL(k_livox_cut, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, B->und.as<float4>(), B->curv.as<float>(), B->keep.as<unsigned char>(), n,
+                           B->blk_keep.as<int>(), B->cut_a.as<float4>(), B->cut_b.as<float4>(), B->cut_src.as<int>(), st);
     }
     hipLaunchKernelGGL(k_livox_grid, dim3(nblocks(kLvCells, 256)), dim3(256), 0, ctx->stream, B->owner.as<int>(), B->und.as<float4>(), B->curv.as<float>(),
                        B->cell_pt.as<float4>(), B->cell_curv.as<float>(), B->cell_src.as<int>());
-    hipLaunchKernelGGL(k_livox_blocks, dim3(nblocks(kLvBlocks, 64)), dim3(64), 0, ctx->stream, B->cell_pt.as<float4>(), B->cell_curv.as<float>(), P,
+    hipLaunchKernelGGL(k_livox_blocks, dim3(kLvBlocks), dim3(64), 0, ctx->stream, B->cell_pt.as<float4>(), B->cell_curv.as<float>(), P,
                        B->blk_nedge.as<int>(), B->blk_edge_cell.as<int>(), B->blk_edge_dir.as<float>(), B->blk_nsurf.as<int>(), B->blk_surf_cell.as<int>(),
                        B->blk_surf_nrm.as<float>());
-    hipLaunchKernelGGL(k_livox_compact, dim3(1), dim3(1024), 0, ctx->stream, B->cell_pt.as<float4>(), B->cell_curv.as<float>(), B->blk_nedge.as<int>(),
+    hipLaunchKernelGGL(k_livox_compact, dim3((kLvBlocks + 15) / 16), dim3(1024), 0, ctx->stream, B->cell_pt.as<float4>(), B->cell_curv.as<float>(), B->blk_nedge.as<int>(),
                        B->blk_edge_cell.as<int>(), B->blk_edge_dir.as<float>(), B->blk_nsurf.as<int>(), B->blk_surf_cell.as<int>(), B->blk_surf_nrm.as<float>(),
                        B->edge_a.as<float4>(), B->edge_b.as<float4>(), B->edge_cell.as<int>(), B->surf_a.as<float4>(), B->surf_b.as<float4>(), B->surf_cell.as<int>(), st);
     HIPCHK(hipGetLastError());

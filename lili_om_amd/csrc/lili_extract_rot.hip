@@ -39,6 +39,7 @@ struct RotState {
     int ring_nedge[kMaxRings], ring_nsharp[kMaxRings], ring_nflat[kMaxRings], ring_nlf[kMaxRings], ring_nsurf[kMaxRings];
     int n_edge, n_sharp, n_flat, n_lessflat, n_surf;
     int fallback_rings;   // rings that did not fit the LDS budget and took the global-memory path
+    int redo_segments;    // segments whose concurrent greedy run had to be repeated with the previous segment's marks (diagnostics)
     long long tphase[8];  // profiling: per-phase clock ticks of ring 0's workgroup (wall_clock64)
 };
 
@@ -153,7 +154,7 @@ __device__ __forceinline__ dq qslerp_identity(double t, dq b) {   // Eigen 3.3 s
 __global__ void k_rot_init(RotState* st) {
     int t = threadIdx.x;
     if (t == 0) { st->first_valid = 0x7fffffff; st->last_valid = -1; st->half_idx = 0x7fffffff; st->n_full = 0;
-                  st->n_edge = st->n_sharp = st->n_flat = st->n_lessflat = st->n_surf = 0; st->fallback_rings = 0; }
+                  st->n_edge = st->n_sharp = st->n_flat = st->n_lessflat = st->n_surf = 0; st->fallback_rings = 0; st->redo_segments = 0; }
     if (t < kMaxRings) { st->ring_count[t] = 0; st->ring_base[t] = 0; st->ring_start[t] = 0; st->ring_end[t] = 0;
                          st->ring_nedge[t] = st->ring_nsharp[t] = st->ring_nflat[t] = st->ring_nlf[t] = st->ring_nsurf[t] = 0; }
 }
@@ -357,18 +358,62 @@ __device__ __forceinline__ float gap2(const float4* __restrict__ P, int a, int b
 }
 __device__ __forceinline__ float range2(const float4* __restrict__ P, int k) { return P[k].x * P[k].x + P[k].y * P[k].y + P[k].z * P[k].z; }
 
+constexpr int kSegEdge = 10, kSegFlat = 4;
 struct RingLds {
     float4 pts[kRingLdsCap + 16];          // ring points incl. the +-5 margins used by the suppression loops
-    unsigned long long keys[kRingLdsCap];  // bitonic (voxel, index) keys
+    unsigned vidx[kRingLdsCap];            // voxel index of the q-th less-flat point
+    unsigned short ord_a[kRingLdsCap];     // radix-sort ping-pong: positions q in the less-flat list, ordered by (voxel, q)
+    unsigned short ord_b[kRingLdsCap];
+    int rcnt[32 * 4 * (kRotBlock / 64)];   // radix pass: counts / offsets [digit][slot][wave]
     float curv[kRingLdsCap + 16];
     int sort_ind[kRingLdsCap + 16];
-    signed char picked[kRingLdsCap + 16];
+    signed char mark[kRingLdsCap + 16 + 64];   // cloudNeighborPicked, one private stretch per segment (see greedy_segment)
     signed char label[kRingLdsCap + 16];
+    int seg_edge[6][kSegEdge], seg_flat[6][kSegFlat], seg_ne[6], seg_nf[6];
     int scan[kRotBlock / 64 + 1];
     float red[6][kRotBlock / 64];
     int misc[8];
 };
 
+// The greedy picks of ONE segment (R:413-492), run by one lane.  `M` = this segment's private view of cloudNeighborPicked: M[k] for
+// ring-local k in [sp - 5, ep + 5] (cleared by the caller; `spill` = bit l set <=> element sp + l was already marked by the previous
+// segment's picks).  Writes the labels of its own picks, its pick lists in push order and its marks.
+__device__ void greedy_segment(RingLds& L, signed char* M, int sp, int ep, unsigned spill, int j) {
+    const float4* Pp = L.pts;
+    for (int l = 0; l < 5; l++) if ((spill >> l) & 1u) M[sp + l] = 1;
+    int ne = 0, nf = 0;
+    int largest = 0;
+    for (int k = ep; k >= sp; k--) {                                    // R:413-453
+        int ind = L.sort_ind[k];
+        if (!((double)L.curv[ind] > 2.0)) break;                        // sorted: nothing further can qualify
+        if (M[ind] == 0) {
+            largest++;
+            if (largest <= 2) { L.label[ind] = 2; L.seg_edge[j][ne++] = ind; }
+            else if (largest <= 10) { L.label[ind] = 1; L.seg_edge[j][ne++] = ind; }
+            else break;
+            M[ind] = 1;
+            for (int l = 1; l <= 5; l++) { if ((double)gap2(Pp, ind + l, ind + l - 1) > 0.05) break; M[ind + l] = 1; }
+            for (int l = -1; l >= -5; l--) { if ((double)gap2(Pp, ind + l, ind + l + 1) > 0.05) break; M[ind + l] = 1; }
+        }
+    }
+    int smallest = 0;
+    for (int k = sp; k <= ep; k++) {                                    // R:456-492
+        int ind = L.sort_ind[k];
+        if (!((double)L.curv[ind] < 0.1)) break;                        // sorted ascending
+        if ((double)range2(Pp, ind) < 0.25) continue;
+        if (M[ind] == 0) {
+            L.label[ind] = -1; L.seg_flat[j][nf++] = ind;
+            smallest++;
+            if (smallest >= 4) break;                                   // before the suppression (R:468-470)
+            M[ind] = 1;
+            for (int l = 1; l <= 5; l++) { if ((double)gap2(Pp, ind + l, ind + l - 1) > 0.05) break; M[ind + l] = 1; }
+            for (int l = -1; l >= -5; l--) { if ((double)gap2(Pp, ind + l, ind + l + 1) > 0.05) break; M[ind + l] = 1; }
+        }
+    }
+    L.seg_ne[j] = ne; L.seg_nf[j] = nf;
+}
+
+#define LILI_ROT_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 __device__ __forceinline__ int block_excl_scan_1024(int v, int* lds, int& total) {
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int inc = v;
@@ -393,18 +438,18 @@ __global__ __launch_bounds__(256) void k_rot_rank(const float* __restrict__ curv
     const int sp = rs + (re - rs) * j / 6, ep = rs + (re - rs) * (j + 1) / 6 - 1;
     const int len = ep - sp + 1;
     if (len <= 0 || len > kRingLdsCap) return;
+    if ((int)blockIdx.z * 64 >= len) return;
     for (int m = threadIdx.x; m < len; m += 256) seg[m] = curv[sp + m];
     __syncthreads();
-    for (int e = blockIdx.z * 256 + threadIdx.x; e < len; e += gridDim.z * 256) {
+    // four lanes per element, each counting a quarter of the segment (interleaved by 4): the loop is a quarter as long, the partial
+    // ranks meet in two shuffles
+    const int sub = threadIdx.x & 3;
+    for (int e = blockIdx.z * 64 + (threadIdx.x >> 2); e < len; e += gridDim.z * 64) {
         const float ck = seg[e];
-        int rank = 0, m = 0;
-        for (; m + 3 < len; m += 4) {
-            float c0 = seg[m], c1 = seg[m + 1], c2 = seg[m + 2], c3 = seg[m + 3];
-            rank += ((c0 < ck || (c0 == ck && m < e)) ? 1 : 0) + ((c1 < ck || (c1 == ck && m + 1 < e)) ? 1 : 0) +
-                    ((c2 < ck || (c2 == ck && m + 2 < e)) ? 1 : 0) + ((c3 < ck || (c3 == ck && m + 3 < e)) ? 1 : 0);
-        }
-        for (; m < len; m++) { float cm = seg[m]; rank += (cm < ck || (cm == ck && m < e)) ? 1 : 0; }
-        sort_ind[sp + rank] = sp + e;
+        int rank = 0;
+        for (int m = sub; m < len; m += 4) { const float cm = seg[m]; rank += (cm < ck || (cm == ck && m < e)) ? 1 : 0; }
+        rank += __shfl_xor(rank, 1); rank += __shfl_xor(rank, 2);
+        if (sub == 0) sort_ind[sp + rank] = sp + e;
     }
 }
 
@@ -430,7 +475,7 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_select(const float4* __restri
     if (ring == 0 && tid == 0) st->tphase[0] = wall_clock64();
     for (int k = tid; k < rcount; k += kRotBlock) {
         L.pts[k] = full[rbase + k]; L.curv[k] = curv_g[rbase + k];
-        L.picked[k] = 0; L.label[k] = 0;
+        L.label[k] = 0;
     }
     __syncthreads();
     const int s0 = rs - rbase, e0 = re - rbase;   // local scanStartInd / scanEndInd
@@ -438,41 +483,57 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_select(const float4* __restri
     if (ring == 0 && tid == 0) st->tphase[1] = wall_clock64();
     for (int k = s0 + tid; k <= e0 - 1; k += kRotBlock) L.sort_ind[k] = sort_ind_g[rbase + k] - rbase;
     __syncthreads();
-    // ---- greedy picks, sequential by construction (suppression spills across segment borders, A4 iv)
+    // ---- greedy picks.  The reference runs the six segments one after the other and the +-5 neighbour suppression of a pick may
+    // reach across a segment border (A4 iv) — but only FORWARD matters (marks that land in an earlier segment are never read again),
+    // and only through the first five elements of the next segment.  So the six segments run concurrently, one wave each, every one
+    // on a private stretch of the mark array (segment j: mark[k + 10 j], k in [sp - 5, ep + 5] — the stretches do not overlap); then
+    // segment j is checked against what segment j - 1 finally marked in its first five elements: if none of j's picks is among
+    // them the sequential run would have picked exactly the same (a marked element is only ever skipped), otherwise j is redone
+    // with those marks in place (rare: a top-10 curvature within five points of both sides of a border).
     if (ring == 0 && tid == 0) st->tphase[2] = wall_clock64();
+    const bool par_seg = (e0 - s0) >= 64;      // every segment longer than the reach of a suppression (5): spills stop in the next segment
+    if (!par_seg) {                             // a nearly empty ring: the reference's order, one shared mark stretch
+        for (int k = s0 - 5 + tid; k <= e0 + 5; k += kRotBlock) L.mark[k] = 0;
+        __syncthreads();
+        if (tid == 0) for (int j = 0; j < 6; j++) greedy_segment(L, L.mark, s0 + (e0 - s0) * j / 6, s0 + (e0 - s0) * (j + 1) / 6 - 1, 0u, j);
+    } else {
+        const int wave = tid >> 6, lane = tid & 63;
+        if (wave < 6) {
+            const int j = wave;
+            const int sp = s0 + (e0 - s0) * j / 6, ep = s0 + (e0 - s0) * (j + 1) / 6 - 1;
+            signed char* M = L.mark + 10 * j;
+            for (int k = sp - 5 + lane; k <= ep + 5; k += 64) M[k] = 0;
+            LILI_ROT_WAVE_SYNC();
+            if (lane == 0) greedy_segment(L, M, sp, ep, 0u, j);
+        }
+    }
+    __syncthreads();
     if (tid == 0) {
+        for (int j = 1; j < 6 && par_seg; j++) {
+            const int sp = s0 + (e0 - s0) * j / 6, ep = s0 + (e0 - s0) * (j + 1) / 6 - 1;
+            const signed char* Mp = L.mark + 10 * (j - 1);
+            unsigned spill = 0;
+            for (int l = 0; l < 5 && sp + l <= ep + 5; l++) if (Mp[sp + l]) spill |= 1u << l;
+            if (!spill) continue;
+            bool hit = false;
+            for (int q = 0; q < L.seg_ne[j]; q++) { const int d = L.seg_edge[j][q] - sp; if (d >= 0 && d < 5 && ((spill >> d) & 1u)) hit = true; }
+            for (int q = 0; q < L.seg_nf[j]; q++) { const int d = L.seg_flat[j][q] - sp; if (d >= 0 && d < 5 && ((spill >> d) & 1u)) hit = true; }
+            if (!hit) continue;
+            for (int q = 0; q < L.seg_ne[j]; q++) L.label[L.seg_edge[j][q]] = 0;
+            for (int q = 0; q < L.seg_nf[j]; q++) L.label[L.seg_flat[j][q]] = 0;
+            signed char* M = L.mark + 10 * j;
+            for (int k = sp - 5; k <= ep + 5; k++) M[k] = 0;
+            greedy_segment(L, M, sp, ep, spill, j);
+            atomicAdd(&st->redo_segments, 1);
+        }
         int ne = 0, nsh = 0, nfl = 0;
-        const float4* Pp = L.pts;
         for (int j = 0; j < 6; j++) {
-            int sp = s0 + (e0 - s0) * j / 6, ep = s0 + (e0 - s0) * (j + 1) / 6 - 1;
-            int largest = 0;
-            for (int k = ep; k >= sp; k--) {                                    // R:413-453
-                int ind = L.sort_ind[k];
-                if (!((double)L.curv[ind] > 2.0)) break;                        // sorted: nothing further can qualify
-                if (L.picked[ind] == 0) {
-                    largest++;
-                    if (largest <= 2) { L.label[ind] = 2; ring_sharp[ring * kRingSharpCap + nsh++] = rbase + ind; ring_edge[ring * kRingEdgeCap + ne++] = rbase + ind; }
-                    else if (largest <= 10) { L.label[ind] = 1; ring_edge[ring * kRingEdgeCap + ne++] = rbase + ind; }
-                    else break;
-                    L.picked[ind] = 1;
-                    for (int l = 1; l <= 5; l++) { if ((double)gap2(Pp, ind + l, ind + l - 1) > 0.05) break; L.picked[ind + l] = 1; }
-                    for (int l = -1; l >= -5; l--) { if ((double)gap2(Pp, ind + l, ind + l + 1) > 0.05) break; L.picked[ind + l] = 1; }
-                }
+            for (int q = 0; q < L.seg_ne[j]; q++) {
+                const int g = rbase + L.seg_edge[j][q];
+                if (q < 2) ring_sharp[ring * kRingSharpCap + nsh++] = g;
+                ring_edge[ring * kRingEdgeCap + ne++] = g;
             }
-            int smallest = 0;
-            for (int k = sp; k <= ep; k++) {                                    // R:456-492
-                int ind = L.sort_ind[k];
-                if (!((double)L.curv[ind] < 0.1)) break;                        // sorted ascending
-                if ((double)range2(Pp, ind) < 0.25) continue;
-                if (L.picked[ind] == 0) {
-                    L.label[ind] = -1; ring_flat[ring * kRingFlatCap + nfl++] = rbase + ind;
-                    smallest++;
-                    if (smallest >= 4) break;                                   // before the suppression (R:468-470)
-                    L.picked[ind] = 1;
-                    for (int l = 1; l <= 5; l++) { if ((double)gap2(Pp, ind + l, ind + l - 1) > 0.05) break; L.picked[ind + l] = 1; }
-                    for (int l = -1; l >= -5; l--) { if ((double)gap2(Pp, ind + l, ind + l + 1) > 0.05) break; L.picked[ind + l] = 1; }
-                }
-            }
+            for (int q = 0; q < L.seg_nf[j]; q++) ring_flat[ring * kRingFlatCap + nfl++] = rbase + L.seg_flat[j][q];
         }
         st->ring_nedge[ring] = ne; st->ring_nsharp[ring] = nsh; st->ring_nflat[ring] = nfl;
     }
@@ -515,32 +576,56 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_select(const float4* __restri
         min_b[c] = (int)floorf(a * inv);
         div_b[c] = (int)floorf(b * inv) - min_b[c] + 1;
     }
-    // keys: (voxel index << 32) | position in the less-flat list; padded with all-ones to the next power of two
-    int npow = 1; while (npow < n_lf) npow <<= 1;
-    for (int q = tid; q < npow; q += kRotBlock) {
-        unsigned long long key = ~0ull;
-        if (q < n_lf) {
-            float4 p = L.pts[L.sort_ind[q]];
-            int i0 = (int)(floorf(p.x * inv) - (float)min_b[0]);
-            int i1 = (int)(floorf(p.y * inv) - (float)min_b[1]);
-            int i2 = (int)(floorf(p.z * inv) - (float)min_b[2]);
-            unsigned idx = (unsigned)(i0 + i1 * div_b[0] + i2 * div_b[0] * div_b[1]);
-            key = ((unsigned long long)idx << 32) | (unsigned)q;
-        }
-        L.keys[q] = key;
+    // order of the less-flat points by (voxel index, position in the list): stable LSD radix sort of the POSITIONS (16-bit) on 5-bit
+    // digits of the voxel index, one workgroup, in LDS — 4 block barriers per pass and ceil(bits / 5) passes, against the 78 barriers of
+    // the bitonic network on 64-bit (voxel, position) keys it replaces (55 -> ~12 us per ring).  Ranks inside a wave come from
+    // five ballots (the lanes that hold the same digit), across waves / slots from one scan of the [digit][slot][wave] count table.
+    for (int q = tid; q < n_lf; q += kRotBlock) {
+        float4 p = L.pts[L.sort_ind[q]];
+        int i0 = (int)(floorf(p.x * inv) - (float)min_b[0]);
+        int i1 = (int)(floorf(p.y * inv) - (float)min_b[1]);
+        int i2 = (int)(floorf(p.z * inv) - (float)min_b[2]);
+        L.vidx[q] = (unsigned)(i0 + i1 * div_b[0] + i2 * div_b[0] * div_b[1]);
+        L.ord_a[q] = (unsigned short)q;
     }
+    const unsigned n_vox = (unsigned)div_b[0] * (unsigned)div_b[1] * (unsigned)div_b[2];    // PCL itself rejects grids beyond 2^31 cells
+    int bits = 1; while (bits < 32 && (n_vox - 1u) >> bits) bits++;
+    unsigned short* src = L.ord_a;
+    unsigned short* dst = L.ord_b;
     __syncthreads();
-    for (int k = 2; k <= npow; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int q = tid; q < npow; q += kRotBlock) {
-                int partner = q ^ j;
-                if (partner > q) {
-                    unsigned long long a = L.keys[q], b = L.keys[partner];
-                    bool up = (q & k) == 0;
-                    if ((a > b) == up) { L.keys[q] = b; L.keys[partner] = a; }
-                }
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+        for (int shift = 0; shift < bits; shift += 5) {
+            L.rcnt[tid] = 0; L.rcnt[tid + kRotBlock] = 0;
+            __syncthreads();
+            int dig[4], rk[4], qq[4];
+#pragma unroll
+            for (int sl = 0; sl < 4; sl++) {
+                const int i = sl * kRotBlock + tid;
+                const bool act = i < n_lf;
+                qq[sl] = act ? (int)src[i] : 0;
+                const int d = act ? (int)((L.vidx[qq[sl]] >> shift) & 31u) : 0;
+                unsigned long long m = __ballot(act);
+#pragma unroll
+                for (int bb = 0; bb < 5; bb++) { const unsigned long long bal = __ballot(act && ((d >> bb) & 1)); m &= ((d >> bb) & 1) ? bal : ~bal; }
+                rk[sl] = __popcll(m & ((1ull << lane) - 1ull));
+                dig[sl] = d;
+                if (act && rk[sl] == 0) L.rcnt[(d * 4 + sl) * (kRotBlock / 64) + wave] = __popcll(m);
             }
             __syncthreads();
+            {
+                const int a = L.rcnt[2 * tid], b2 = L.rcnt[2 * tid + 1];
+                int tot; const int ex = block_excl_scan_1024(a + b2, L.scan, tot);
+                L.rcnt[2 * tid] = ex; L.rcnt[2 * tid + 1] = ex + a;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int sl = 0; sl < 4; sl++) {
+                const int i = sl * kRotBlock + tid;
+                if (i < n_lf) dst[L.rcnt[(dig[sl] * 4 + sl) * (kRotBlock / 64) + wave] + rk[sl]] = (unsigned short)qq[sl];
+            }
+            __syncthreads();
+            unsigned short* t2 = src; src = dst; dst = t2;
         }
     }
     // run heads -> output slots; each head accumulates its voxel in list order (f32, like CentroidPoint)
@@ -548,13 +633,13 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_select(const float4* __restri
     int n_out = 0;
     for (int q0 = 0; q0 < n_lf; q0 += kRotBlock) {
         int q = q0 + tid;
-        bool head = q < n_lf && (q == 0 || (unsigned)(L.keys[q] >> 32) != (unsigned)(L.keys[q - 1] >> 32));
+        bool head = q < n_lf && (q == 0 || L.vidx[src[q]] != L.vidx[src[q - 1]]);
         int tot; int off = block_excl_scan_1024(head ? 1 : 0, L.scan, tot);
         if (head) {
-            unsigned vox = (unsigned)(L.keys[q] >> 32);
+            unsigned vox = L.vidx[src[q]];
             float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f; int cnt = 0;
-            for (int m = q; m < n_lf && (unsigned)(L.keys[m] >> 32) == vox; m++) {
-                float4 p = L.pts[L.sort_ind[(unsigned)L.keys[m]]];
+            for (int m = q; m < n_lf && L.vidx[src[m]] == vox; m++) {
+                float4 p = L.pts[L.sort_ind[src[m]]];
                 sx += p.x; sy += p.y; sz += p.z; si += p.w; cnt++;
             }
             float fn = (float)cnt;
@@ -670,7 +755,7 @@ int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4
         hipLaunchKernelGGL(k_rot_scatter, dim3(nb), dim3(kRotBlock), 0, ctx->stream, in, n, R->scan_id.as<signed char>(), R->ori_raw.as<float>(), P, st,
                            R->block_hist.as<int>(), R->full.as<float4>(), R->full_src.as<int>());
         hipLaunchKernelGGL(k_rot_curvature, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, R->full.as<float4>(), st, R->curv.as<float>());
-        hipLaunchKernelGGL(k_rot_rank, dim3(kMaxRings, 6, 2), dim3(256), 0, ctx->stream, R->curv.as<float>(), P, st, R->sort_ind.as<int>());
+        hipLaunchKernelGGL(k_rot_rank, dim3(kMaxRings, 6, 12), dim3(256), 0, ctx->stream, R->curv.as<float>(), P, st, R->sort_ind.as<int>());
         hipLaunchKernelGGL(k_rot_select, dim3(kMaxRings), dim3(kRotBlock), sizeof(RingLds), ctx->stream, R->full.as<float4>(), R->curv.as<float>(), R->sort_ind.as<int>(), P, st,
                            R->label.as<int>(), R->ring_edge.as<int>(), R->ring_sharp.as<int>(), R->ring_flat.as<int>(), R->lessflat_tmp.as<int>(),
                            R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>());
