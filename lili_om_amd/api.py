@@ -521,14 +521,23 @@ class LivoxExtractor:
         self.lib = ctx.lib
         self.params = LivoxParams(surf_thres, edge_thres, near_range)
 
-    def extract(self, pts5, q_imu=(1.0, 0, 0, 0), debug=False, pcl_layout=False):
-        """pts5: (n,5) float32 = x, y, z, intensity, curvature."""
+    def extract(self, pts5, q_imu=(1.0, 0, 0, 0), debug=False, pcl_layout=False, reuse=False):
+        """pts5: (n,5) float32 = x, y, z, intensity, curvature.  reuse: results land in page-locked buffers owned by the extractor
+        (views that the next call overwrites), see RotExtractor._out_buffers."""
         pts = np.ascontiguousarray(pts5, dtype=np.float32)
         n = pts.shape[0]
         cloud = Cloud(pts.ctypes.data if n else None, n, 20, 12, MEM_HOST)
         cap = max(n, 24000)
         w = 12 if pcl_layout else 8
-        bufs = [np.zeros((cap, w), np.float32) for _ in range(3)]
+        if reuse:
+            if getattr(self, "_pin_key", None) != (cap, w):
+                for p_ in getattr(self, "_pins", []):
+                    p_.close()
+                self._pins = [PinnedArray((cap, w), np.float32) for _ in range(3)]
+                self._pin_key = (cap, w)
+            bufs = [p_.array for p_ in self._pins]
+        else:
+            bufs = [np.zeros((cap, w), np.float32) for _ in range(3)]
         outs = [FeatureOut(b.ctypes.data, cap, 4 * w, MEM_HOST, 0) for b in bufs]
         qi = _f64(q_imu, 4)
         self.ctx._chk(self.lib.lili_extract_livox(self.ctx.h, C.byref(cloud), 16, _ptr(qi), C.byref(self.params),

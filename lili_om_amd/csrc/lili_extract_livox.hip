@@ -290,7 +290,7 @@ namespace lili_detail {
 struct LivoxBuffers {
     DevBuf in_i, in_c, und, curv, keep, owner, state, cut_a, cut_b, cut_src, cell_pt, cell_curv, cell_src, blk_keep;
     DevBuf blk_nedge, blk_edge_cell, blk_edge_dir, blk_nsurf, blk_surf_cell, blk_surf_nrm;
-    DevBuf edge_a, edge_b, edge_cell, surf_a, surf_b, surf_cell, pack, xyzc_edge, xyzc_surf;
+    DevBuf edge_a, edge_b, edge_cell, surf_a, surf_b, surf_cell, pack, pack_e, pack_s, xyzc_edge, xyzc_surf;
     lili::LivoxState host{};
     bool have = false;
     void release() {
@@ -305,17 +305,16 @@ static lili_detail::LivoxBuffers* livox_of(lili_ctx* ctx) {
     return static_cast<lili_detail::LivoxBuffers*>(ctx->ext_livox);
 }
 
-static int livox_copy_out(lili_ctx* ctx, lili_detail::LivoxBuffers* B, const lili_feature_out* o, const float4* a, const float4* b, size_t count) {
+static int livox_copy_out(lili_ctx* ctx, DevBuf& pack, const lili_feature_out* o, const float4* a, const float4* b, size_t count) {   // async: one pack buffer per list
     if (!o || !o->data || count == 0) return LILI_OK;
     size_t k = std::min(count, o->capacity);
     if (k == 0) return LILI_OK;
     size_t stride = o->stride ? o->stride : 32;
     ARGCHK(stride == 32 || stride == 48, "feature_out: Livox records are 32 B (packed x,y,z,nx,ny,nz,intensity,curvature) or 48 B (pcl::PointXYZINormal)");
-    HIPCHK(B->pack.ensure(k * stride));
-    hipLaunchKernelGGL(k_livox_pack, dim3(nblocks((int64_t)k, 256)), dim3(256), 0, ctx->stream, a, b, (int)k, stride == 48 ? 1 : 0, B->pack.as<float>());
+    HIPCHK(pack.ensure(k * stride));
+    hipLaunchKernelGGL(k_livox_pack, dim3(nblocks((int64_t)k, 256)), dim3(256), 0, ctx->stream, a, b, (int)k, stride == 48 ? 1 : 0, pack.as<float>());
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(o->data, B->pack.p, k * stride, o->mem == LILI_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));   // the pack buffer is reused by the next copy-out
+    HIPCHK(hipMemcpyAsync(o->data, pack.p, k * stride, o->mem == LILI_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
     return LILI_OK;
 }
 
@@ -369,9 +368,10 @@ int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offs
     HIPCHK(hipMemcpyAsync(&B->host, st, sizeof(LivoxState), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     B->have = true;
-    if (cutted) { cutted->count = (size_t)B->host.n_cut; rc = livox_copy_out(ctx, B, cutted, B->cut_a.as<float4>(), B->cut_b.as<float4>(), cutted->count); if (rc) return rc; }
-    if (edge) { edge->count = (size_t)B->host.n_edge; rc = livox_copy_out(ctx, B, edge, B->edge_a.as<float4>(), B->edge_b.as<float4>(), edge->count); if (rc) return rc; }
-    if (surf) { surf->count = (size_t)B->host.n_surf; rc = livox_copy_out(ctx, B, surf, B->surf_a.as<float4>(), B->surf_b.as<float4>(), surf->count); if (rc) return rc; }
+    if (cutted) { cutted->count = (size_t)B->host.n_cut; rc = livox_copy_out(ctx, B->pack, cutted, B->cut_a.as<float4>(), B->cut_b.as<float4>(), cutted->count); if (rc) return rc; }
+    if (edge) { edge->count = (size_t)B->host.n_edge; rc = livox_copy_out(ctx, B->pack_e, edge, B->edge_a.as<float4>(), B->edge_b.as<float4>(), edge->count); if (rc) return rc; }
+    if (surf) { surf->count = (size_t)B->host.n_surf; rc = livox_copy_out(ctx, B->pack_s, surf, B->surf_a.as<float4>(), B->surf_b.as<float4>(), surf->count); if (rc) return rc; }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     return LILI_OK;
 }
 

@@ -708,7 +708,8 @@ static int copy_out_f4(lili_ctx* ctx, const lili_feature_out* o, const float4* d
     size_t stride = o->stride ? o->stride : sizeof(float4);
     ARGCHK(stride >= sizeof(float4), "feature_out: stride must be >= 16");
     hipMemcpyKind kind = o->mem == LILI_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-    HIPCHK(hipMemcpy2DAsync(o->data, stride, d_src, sizeof(float4), sizeof(float4), k, kind, ctx->stream));
+    if (stride == sizeof(float4)) HIPCHK(hipMemcpyAsync(o->data, d_src, k * sizeof(float4), kind, ctx->stream));      // one DMA; the 2-D form copies row by row
+    else HIPCHK(hipMemcpy2DAsync(o->data, stride, d_src, sizeof(float4), sizeof(float4), k, kind, ctx->stream));
     return LILI_OK;
 }
 

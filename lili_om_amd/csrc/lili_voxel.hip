@@ -254,7 +254,9 @@ int lili_voxel_filter(lili_ctx* ctx, const lili_cloud* cloud, float leaf, lili_f
     if (out->data && k) {
         size_t stride = out->stride ? out->stride : 16;
         ARGCHK(stride >= 16, "voxel_filter: stride must be >= 16");
-        HIPCHK(hipMemcpy2DAsync(out->data, stride, V->out.p, 16, 16, k, out->mem == LILI_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+        const hipMemcpyKind kind = out->mem == LILI_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+        if (stride == 16) HIPCHK(hipMemcpyAsync(out->data, V->out.p, k * 16, kind, ctx->stream));
+        else HIPCHK(hipMemcpy2DAsync(out->data, stride, V->out.p, 16, 16, k, kind, ctx->stream));
         if (counts) HIPCHK(hipMemcpyAsync(counts, V->out_cnt.p, k * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
     }
