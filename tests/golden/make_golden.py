@@ -59,7 +59,7 @@ def main():
     raw = np.concatenate([w["scan_xyz"], np.full((w["scan_xyz"].shape[0], 1), 7.0, np.float32)], 1).astype(np.float32)
     q_imu = [0.99995, 0.004, -0.006, 0.005]
     q_lb = [0.7071, 0.0, 0.0, 0.7071]
-    r = O.extract_rot(raw, q_imu, q_lb, O.rot_params(ds_rate=2, atan_mode=1, stable_sort=1))
+    r = O.extract_rot(raw, q_imu, q_lb, O.rot_params(ds_rate=2, atan_mode=2, stable_sort=1))   # glibc float atan / atan2 restated = the HIP default
     np.savez_compressed(os.path.join(HERE, "extract_rot.npz"), q_imu=q_imu, q_lb=q_lb, n_in=raw.shape[0], full_src=r["full_src"],
                         ring_start=r["ring_start"], ring_end=r["ring_end"], label=r["label"].astype(np.int8), edge_idx=r["edge_idx"],
                         flat_idx=r["flat_idx"], lessflat_idx=r["lessflat_idx"], surf=r["surf"], surf_cnt=r["surf_cnt"],
