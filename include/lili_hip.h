@@ -101,6 +101,8 @@ int lili_set_debug(lili_ctx* ctx, int keep_neighbors);
  * faster on MI355X; may be changed at any time), "merge_kinds" (1 = surf and edge of a keyframe share ONE association launch and ONE
  * linearisation launch; default 1), "p2p_fusion" (0 = lili_s2m_iterate_sharded runs lili_p2p_allreduce as its own launches like any
  * other lili_allreduce_fn instead of inside the count / reduce kernels; default 1).
+ * "fine_grid" (1 = lili_map_set measures the point density and gives a map with more than "fine_occupancy" (default 12) points per
+ * gate-sized cell a second index with density-sized cells that the association searches first — exact; default 1).
  * One knob that DOES choose between two definitions of a result: "rot_atan" — lili_extract_rot's atan / atan2 on float arguments
  * (R/src/Preprocessing.cpp:285-288,315,349): 2 (default) = glibc's float routines statement for statement (atanf / atan2f of
  * every glibc up to 2.40 — the bits a build of the reference produces), 1 = the f64 functions rounded to f32 (libm-independent). */
@@ -122,6 +124,11 @@ void lili_host_free(void* p);
 int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq_radius);
 /* Number of points / grid cells of the current index (diagnostics). */
 int lili_map_info(lili_ctx* ctx, int kind, int64_t* n_points, int64_t* n_cells, double* cell_edge);
+/* Density adaptation of the current index (diagnostics): the point-weighted mean number of points per gate-sized cell measured by
+ * lili_map_set (0 with option "fine_grid" = 0), and — if the map got the second, density-sized index — its cell edge and the squared
+ * radius it covers completely (both 0 otherwise).  Reference call sites: L/src/BackendFusion.cpp:839-840 (setInputCloud on maps
+ * down-sampled at L:1488-1511 — leaf sizes down to centimetres make a gate-sized cell hold hundreds of points). */
+int lili_map_density(lili_ctx* ctx, int kind, double* mean_occupancy, double* fine_cell_edge, double* fine_sq_radius);
 
 /* ---- feature extraction ----------------------------------------------------------------------- */
 

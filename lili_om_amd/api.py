@@ -105,6 +105,7 @@ _SIGS = {
     "lili_localmap_push": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Cloud), C.c_void_p, C.c_void_p, C.c_int]),
     "lili_localmap_commit": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_double, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "lili_map_set": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Cloud), C.c_double]),
+    "lili_map_density": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "lili_map_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "lili_s2m_set_queries": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Cloud)]),
     "lili_s2m_associate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(S2MParams), C.POINTER(C.c_int)]),
@@ -280,6 +281,12 @@ class ScanToMapMatcher:
         n, nc, ce = C.c_int64(), C.c_int64(), C.c_double()
         self.ctx._chk(self.lib.lili_map_info(self.ctx.h, kind, C.byref(n), C.byref(nc), C.byref(ce)))
         return n.value, nc.value, ce.value
+
+    def map_density(self, kind):
+        """(mean points per gate-sized cell, fine cell edge or 0, squared radius covered by the fine index or 0)."""
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        self.ctx._chk(self.lib.lili_map_density(self.ctx.h, kind, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     # -- queries --------------------------------------------------------------------------------
     def set_queries(self, slot, kind, cloud):

@@ -15,7 +15,8 @@ namespace lili {
 // kernels (lili_s2m.hip)
 __global__ void k_cloud_to_f4(const unsigned char*, int, int, int, float4*, unsigned*);
 __global__ void k_bbox(const float4*, int, unsigned*);
-__global__ void k_cell_count(const float4*, int, GridView, int*, int2*);
+__global__ void k_cell_count(const float4*, int, GridView, int*, int2*, unsigned long long*);
+__global__ void k_associate_fine(AssocArgs, GridView, float, int, PoseArg, MatchParams);
 __global__ void k_scan_block_sums(const int*, int64_t, int*);
 __global__ void k_scan_sums(int*, int);
 __global__ void k_scan_apply(const int*, int64_t, const int*, int*);
@@ -130,7 +131,7 @@ void lili_ctx_destroy(lili_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (auto& m : ctx->map) { m.pts.release(); m.sorted.release(); m.aux_sorted.release(); m.cell_start.release(); m.cell_tmp.release(); m.pt_cell.release(); m.block_sums.release(); }
+    for (auto& m : ctx->map) { m.sorted_f.release(); m.aux_sorted_f.release(); m.cell_start_f.release(); m.pts.release(); m.sorted.release(); m.aux_sorted.release(); m.cell_start.release(); m.cell_tmp.release(); m.pt_cell.release(); m.block_sums.release(); }
     for (auto& s : ctx->slots) for (auto& k : s.k) { k.q.release(); k.rec0.release(); k.rec1.release(); k.valid.release(); k.dbg_idx.release(); k.dbg_d2.release(); k.partials.release(); k.perm.release(); k.keys.release(); k.block_counts.release(); k.tiles.release(); }
     ctx->states.release(); ctx->staging.release(); ctx->gram.release(); ctx->misc.release(); ctx->bin_hist.release(); ctx->bin_start.release(); ctx->bin_sums.release(); ctx->bin_tcnt.release(); ctx->bin_toff.release();
     if (ctx->ext_rot && ctx->ext_rot_free) ctx->ext_rot_free(ctx->ext_rot);
@@ -166,6 +167,8 @@ int lili_set_option(lili_ctx* ctx, const char* name, int value) {
     if (std::strcmp(name, "balance") == 0) { ctx->balance = value != 0; for (auto& sl : ctx->slots) for (auto& k : sl.k) { k.order_valid = false; k.launches = 0; } return LILI_OK; }
     if (std::strcmp(name, "fuse_tail") == 0) { ctx->fuse_tail = value != 0; return LILI_OK; }   // any time: the block partition does not depend on it
     if (std::strcmp(name, "merge_kinds") == 0) { ctx->merge_kinds = value != 0; return LILI_OK; }
+    if (std::strcmp(name, "fine_grid") == 0) { ctx->fine_grid = value != 0; return LILI_OK; }
+    if (std::strcmp(name, "fine_occupancy") == 0) { if (value < 2) return ctx->fail(LILI_E_ARG, "fine_occupancy must be >= 2"); ctx->fine_occupancy = value; return LILI_OK; }
     if (std::strcmp(name, "scan_lookback") == 0) { ctx->scan_lookback = value != 0; return LILI_OK; }
     if (std::strcmp(name, "rot_atan") == 0) { if (value != 1 && value != 2) return ctx->fail(LILI_E_ARG, "rot_atan must be 1 or 2"); ctx->rot_atan = value; return LILI_OK; }
     if (std::strcmp(name, "p2p_fusion") == 0) { ctx->no_p2p_fusion = value == 0; return LILI_OK; }
@@ -177,6 +180,54 @@ int lili_set_option(lili_ctx* ctx, const char* name, int value) {
 // --------------------------------------------------------------------------------------------
 // map index
 // --------------------------------------------------------------------------------------------
+// Uniform-grid index of m.pts (already ingested) with cells of edge `cell` (grown if the bounding box needs more than max_cells cells):
+// count (one atomic per run of equal cells, the returned value = the point's rank), in-place single-pass scan, atomic-free scatter.
+static int build_grid(lili_ctx* ctx, MapIndex& m, const double mn[3], const double mx[3], double cell, int reach, DevBuf& sorted, DevBuf& aux_sorted,
+                      DevBuf& cell_start, GridView& out, int64_t& n_cells, double& cell_used, unsigned long long* d_rank_sum) {
+    const int n = (int)m.n;
+    int64_t nx, ny, nz;
+    for (;;) {
+        nx = (int64_t)std::floor((mx[0] - mn[0]) / cell) + 1;
+        ny = (int64_t)std::floor((mx[1] - mn[1]) / cell) + 1;
+        nz = (int64_t)std::floor((mx[2] - mn[2]) / cell) + 1;
+        double total = (double)nx * (double)ny * (double)nz;
+        if (total <= (double)ctx->max_cells) break;
+        cell *= std::cbrt(total / (double)ctx->max_cells) * 1.02;   // coarser cells stay exact, only slower
+    }
+    cell_used = cell;
+    n_cells = nx * ny * nz;
+    GridView g{};
+    g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2]; g.inv_cell = 1.0 / cell; g.cell = 1.0 / g.inv_cell;
+    g.nx = (int)nx; g.ny = (int)ny; g.nz = (int)nz; g.n_points = n; g.reach = reach;
+    const int64_t nc = n_cells;
+    // ONE cell array: counts -> (in-place exclusive scan) -> cell_start; the atomic of the count pass also hands every point its rank
+    HIPCHK(cell_start.ensure((size_t)(nc + 1) * sizeof(int)));
+    HIPCHK(m.pt_cell.ensure((size_t)n * sizeof(int2)));
+    HIPCHK(sorted.ensure((size_t)n * sizeof(float4)));
+    if (m.has_aux) HIPCHK(aux_sorted.ensure((size_t)n * sizeof(float)));
+    const int nb_scan = nblocks(nc, 2048);
+    HIPCHK(m.block_sums.ensure((size_t)(nb_scan + 2) * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(cell_start.p, 0, (size_t)nc * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_cell_count, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, m.pts.as<float4>(), n, g, cell_start.as<int>(), m.pt_cell.as<int2>(), d_rank_sum);
+    if (ctx->scan_lookback) {      // one pass over the cell array (status words: one per 4096-cell tile)
+        const int nb_lb = nblocks(nc, 4096);
+        HIPCHK(hipMemsetAsync(m.block_sums.p, 0, (size_t)(nb_lb + 2) * sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(k_scan_lookback, dim3(nb_lb), dim3(kBlock), 0, ctx->stream, cell_start.as<int>(), nc, m.block_sums.as<unsigned long long>());
+    } else {
+        hipLaunchKernelGGL(k_scan_block_sums, dim3(nb_scan), dim3(kBlock), 0, ctx->stream, cell_start.as<int>(), nc, m.block_sums.as<int>());
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, ctx->stream, m.block_sums.as<int>(), nb_scan);
+        hipLaunchKernelGGL(k_scan_apply, dim3(nb_scan), dim3(kBlock), 0, ctx->stream, cell_start.as<int>(), nc, m.block_sums.as<int>(), cell_start.as<int>());
+    }
+    hipLaunchKernelGGL(k_scatter, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, m.pts.as<float4>(), n, m.pt_cell.as<int2>(), cell_start.as<int>(),
+                       sorted.as<float4>(), m.has_aux ? aux_sorted.as<float>() : nullptr);
+    HIPCHK(hipGetLastError());
+    g.pts = sorted.as<float4>();
+    g.aux = m.has_aux ? aux_sorted.as<float>() : nullptr;
+    g.cell_start = cell_start.as<int>();
+    out = g;
+    return LILI_OK;
+}
+
 int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq_radius) {
     if (!ctx) return LILI_E_ARG;
     ARGCHK(kind == LILI_KIND_SURF || kind == LILI_KIND_EDGE, "map_set: bad kind");
@@ -212,46 +263,31 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
     // reach * cell >= 1.01 * gate radius; with reach 2 the cell edge is cell_pct % of the gate radius (50..100)
     double cell = std::sqrt(max_sq_radius) * 1.01 * (reach == 2 ? (double)ctx->cell_pct / 100.0 : 1.0);
     if (!(cell > 1e-6)) cell = 1e-6;
-    int64_t nx, ny, nz;
-    for (;;) {
-        nx = (int64_t)std::floor((mx[0] - mn[0]) / cell) + 1;
-        ny = (int64_t)std::floor((mx[1] - mn[1]) / cell) + 1;
-        nz = (int64_t)std::floor((mx[2] - mn[2]) / cell) + 1;
-        double total = (double)nx * (double)ny * (double)nz;
-        if (total <= (double)ctx->max_cells) break;
-        cell *= std::cbrt(total / (double)ctx->max_cells) * 1.02;   // coarser cells stay exact, only slower
+    m.has_fine = false; m.fview = GridView{}; m.fbound = 0.f; m.fine_cell = 0; m.mean_occupancy = 0;
+    unsigned long long* d_rank = ctx->fine_grid ? reinterpret_cast<unsigned long long*>(ctx->misc.as<char>() + 64) : nullptr;
+    if (d_rank) HIPCHK(hipMemsetAsync(d_rank, 0, sizeof(unsigned long long), ctx->stream));
+    rc = build_grid(ctx, m, mn, mx, cell, reach, m.sorted, m.aux_sorted, m.cell_start, m.view, m.n_cells, m.cell, d_rank);
+    if (rc != LILI_OK) return rc;
+    // Density adaptation (SURVEY §7 step 4, §8d Config 2 variant B): the point-weighted mean cell occupancy falls out of the count pass.
+    // A map with many points per gate-sized cell gets a second, fine index whose cells hold ~3 points; k_associate_fine searches it first.
+    if (d_rank) {
+        unsigned long long rank_sum = 0;
+        HIPCHK(hipMemcpyAsync(&rank_sum, d_rank, sizeof(rank_sum), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        m.mean_occupancy = 1.0 + 2.0 * (double)rank_sum / (double)n;
+        if (m.mean_occupancy > (double)ctx->fine_occupancy && m.cell == cell) {          // (a grid coarsened by max_cells is not refined)
+            // surfaces: occupancy ~ cell^2; aim at ~3 points per fine cell, at least 4x and at most 64x finer cells per axis ... clamped
+            double fc = cell * std::sqrt(3.0 / m.mean_occupancy);
+            fc = std::min(std::max(fc, cell / 16.0), cell / 1.5);
+            int64_t fcells = 0; double fcell_used = 0;
+            rc = build_grid(ctx, m, mn, mx, fc, reach, m.sorted_f, m.aux_sorted_f, m.cell_start_f, m.fview, fcells, fcell_used, nullptr);
+            if (rc != LILI_OK) return rc;
+            const double rb = (double)reach * fcell_used / 1.01;
+            float fb = (float)(rb * rb * (1.0 - 1e-6));
+            if ((double)fb > rb * rb * (1.0 - 1e-6)) fb = std::nextafter(fb, 0.0f);                    // rounded DOWN: the bound only ever shrinks
+            m.fbound = fb; m.fine_cell = fcell_used; m.has_fine = true;
+        }
     }
-    m.cell = cell;
-    m.n_cells = nx * ny * nz;
-    GridView g{};
-    g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2]; g.inv_cell = 1.0 / cell; g.cell = 1.0 / g.inv_cell;
-    g.nx = (int)nx; g.ny = (int)ny; g.nz = (int)nz; g.n_points = n; g.reach = reach;
-    const int64_t nc = m.n_cells;
-    // ONE cell array: counts -> (in-place exclusive scan) -> cell_start; the atomic of the count pass also hands every point its rank
-    HIPCHK(m.cell_start.ensure((size_t)(nc + 1) * sizeof(int)));
-    HIPCHK(m.pt_cell.ensure((size_t)n * sizeof(int2)));
-    HIPCHK(m.sorted.ensure((size_t)n * sizeof(float4)));
-    if (m.has_aux) HIPCHK(m.aux_sorted.ensure((size_t)n * sizeof(float)));
-    const int nb_scan = nblocks(nc, 2048);
-    HIPCHK(m.block_sums.ensure((size_t)(nb_scan + 2) * sizeof(unsigned long long)));
-    HIPCHK(hipMemsetAsync(m.cell_start.p, 0, (size_t)nc * sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(k_cell_count, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, m.pts.as<float4>(), n, g, m.cell_start.as<int>(), m.pt_cell.as<int2>());
-    if (ctx->scan_lookback) {      // one pass over the cell array (status words: one per 4096-cell tile)
-        const int nb_lb = nblocks(nc, 4096);
-        HIPCHK(hipMemsetAsync(m.block_sums.p, 0, (size_t)(nb_lb + 2) * sizeof(unsigned long long), ctx->stream));
-        hipLaunchKernelGGL(k_scan_lookback, dim3(nb_lb), dim3(kBlock), 0, ctx->stream, m.cell_start.as<int>(), nc, m.block_sums.as<unsigned long long>());
-    } else {
-        hipLaunchKernelGGL(k_scan_block_sums, dim3(nb_scan), dim3(kBlock), 0, ctx->stream, m.cell_start.as<int>(), nc, m.block_sums.as<int>());
-        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, ctx->stream, m.block_sums.as<int>(), nb_scan);
-        hipLaunchKernelGGL(k_scan_apply, dim3(nb_scan), dim3(kBlock), 0, ctx->stream, m.cell_start.as<int>(), nc, m.block_sums.as<int>(), m.cell_start.as<int>());
-    }
-    hipLaunchKernelGGL(k_scatter, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, m.pts.as<float4>(), n, m.pt_cell.as<int2>(), m.cell_start.as<int>(),
-                       m.sorted.as<float4>(), m.has_aux ? m.aux_sorted.as<float>() : nullptr);
-    HIPCHK(hipGetLastError());
-    g.pts = m.sorted.as<float4>();
-    g.aux = m.has_aux ? m.aux_sorted.as<float>() : nullptr;
-    g.cell_start = m.cell_start.as<int>();
-    m.view = g;
     m.valid = true;
     return LILI_OK;
 }
@@ -263,6 +299,17 @@ int lili_map_info(lili_ctx* ctx, int kind, int64_t* n_points, int64_t* n_cells, 
     if (n_points) *n_points = ctx->map[kind].n;
     if (n_cells) *n_cells = ctx->map[kind].n_cells;
     if (cell_edge) *cell_edge = ctx->map[kind].cell;
+    return LILI_OK;
+}
+
+int lili_map_density(lili_ctx* ctx, int kind, double* mean_occupancy, double* fine_cell_edge, double* fine_sq_radius) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(kind == 0 || kind == 1, "map_density: bad kind");
+    if (!ctx->map[kind].valid) return ctx->fail(LILI_E_STATE, "map_density: no map set");
+    const MapIndex& m = ctx->map[kind];
+    if (mean_occupancy) *mean_occupancy = m.mean_occupancy;
+    if (fine_cell_edge) *fine_cell_edge = m.has_fine ? m.fine_cell : 0.0;
+    if (fine_sq_radius) *fine_sq_radius = m.has_fine ? (double)m.fbound : 0.0;
     return LILI_OK;
 }
 
@@ -382,6 +429,18 @@ static int launch_associate(lili_ctx* ctx, int slot, int kind, const PoseArg& pa
         if (!ks.nn_cache_valid) { HIPCHK(hipMemsetAsync(ks.nn_cache.p, 0xFF, (size_t)n * 5 * sizeof(int), ctx->stream)); ks.nn_cache_valid = true; }
         nnc = ks.nn_cache.as<int>();
     }
+    if (m.has_fine && !ctx->bin_queries && !ctx->balance) {      // dense map: fine index first, gate-sized index for the queries it cannot settle
+        if (kind == LILI_KIND_SURF && P.variant == LILI_VARIANT_LIVOX && (!m.has_aux || !ks.has_aux))
+            return ctx->fail(LILI_E_STATE, "associate: Livox variant needs reflectivity (aux_offset) on the surf map and the surf queries");
+        AssocArgs a{};
+        a.queries = ks.q.as<float4>(); a.n_q = n; a.g = m.view;
+        a.rec0 = ks.rec0.as<float4>(); a.rec1 = ks.rec1.p; a.valid = ks.valid.as<unsigned char>();
+        a.dbg_idx = dbg_i; a.dbg_d2 = dbg_d; a.block_counts = ks.block_counts.as<int>(); a.nb = ks.n_blocks;
+        ks.launches++;
+        hipLaunchKernelGGL(k_associate_fine, dim3(ks.n_blocks), dim3(kAssocBlock), 0, ctx->stream, a, m.fview, m.fbound, kind, pa, P);
+        HIPCHK(hipGetLastError());
+        return LILI_OK;
+    }
     const bool tiled = ctx->tiled && ctx->bin_queries && n >= 4 * kBlock && m.view.reach == 1;   // tiles need spatially compact blocks
     if (ctx->bin_queries && n >= 4 * kBlock) {
         if (!ks.binned) { int rc = bin_queries(ctx, ks, m, pa, P); if (rc != LILI_OK) return rc; }
@@ -444,7 +503,7 @@ static int launch_associate_both(lili_ctx* ctx, int slot, const PoseArg& pa, con
     for (int kind = 0; kind < 2; kind++) {
         KindSlot& ks = ctx->slots[slot].k[kind];
         MapIndex& m = ctx->map[kind];
-        if (!ks.has_queries || !m.valid || ks.n_q == 0 || m.n < 5) return 1;
+        if (!ks.has_queries || !m.valid || ks.n_q == 0 || m.n < 5 || m.has_fine) return 1;
         const double gate = kind == LILI_KIND_SURF ? P.kd_max_radius : P.edge_gate;
         if (!(std::sqrt(gate) * 1.0099 <= m.cell * (double)m.view.reach)) return 1;     // the per-kind path reports the error
         if (kind == LILI_KIND_SURF && P.variant == LILI_VARIANT_LIVOX && (!m.has_aux || !ks.has_aux)) return 1;

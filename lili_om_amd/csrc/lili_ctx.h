@@ -41,6 +41,12 @@ struct MapIndex {
     GridView view{};
     DevBuf pts, sorted, aux_sorted, cell_start, cell_tmp, pt_cell, block_sums;
     bool has_aux = false;
+    // density adaptation: a second index with cells sized from the measured density (dense maps only), searched first
+    bool has_fine = false;
+    GridView fview{};
+    DevBuf sorted_f, aux_sorted_f, cell_start_f;
+    float fbound = 0.f;          // squared radius the fine index covers completely (rounded down)
+    double fine_cell = 0, mean_occupancy = 0;
 };
 
 struct KindSlot {
@@ -99,6 +105,8 @@ struct lili_ctx {
     bool merge_kinds = true;     // surf and edge of one keyframe in ONE association launch / ONE linearisation launch
     bool nn_cache = false;       // seed each query's search bound with its previous 5 neighbours (exact for any pose change)
     int cell_pct = 65;           // reach 2: cell edge in % of 1.01 * gate radius (>= 50)
+    bool fine_grid = true;       // measure the map density in lili_map_set and build the fine index when a gate-sized cell holds more than fine_occupancy points
+    int fine_occupancy = 12;
     bool scan_lookback = true;   // map index: single-pass (decoupled look-back) scan of the cell array; 0 = the three-kernel scan (A/B)
     int rot_atan = 2;            // ROT extractor: 2 = glibc fdlibm float atan / atan2 (the reference build's bits), 1 = f64 functions rounded to f32
     bool balance = false;        // cost-ordered dispatch of the association workgroups (AssocSched): measured, no gain — A/B only

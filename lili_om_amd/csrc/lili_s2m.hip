@@ -101,7 +101,8 @@ __device__ __forceinline__ int cell_of(float4 p, const GridView& g) {
 // Neighbouring lanes that fall into the same cell (maps come out of the voxel filter in voxel order: consecutive points are
 // neighbours in x) share ONE atomic: run heads add the run length, the members take base + offset.  No loop, ~10 instructions;
 // an unordered cloud degenerates to one atomic per point.  All 64 lanes of a wave must be active.
-__global__ void k_cell_count(const float4* __restrict__ pts, int n, GridView g, int* __restrict__ cell_count, int2* __restrict__ pt_cell) {
+__global__ void k_cell_count(const float4* __restrict__ pts, int n, GridView g, int* __restrict__ cell_count, int2* __restrict__ pt_cell,
+                             unsigned long long* __restrict__ rank_sum /*optional*/) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int c = i < n ? cell_of(pts[i], g) : -1;
@@ -115,7 +116,18 @@ __global__ void k_cell_count(const float4* __restrict__ pts, int n, GridView g, 
     int base = 0;
     if (head && c >= 0) base = atomicAdd(&cell_count[c], len);
     base = __shfl(base, hl);
-    if (i < n) pt_cell[i] = make_int2(c, base + (lane - hl));
+    const int rank = base + (lane - hl);
+    if (i < n) pt_cell[i] = make_int2(c, rank);
+    // density estimate for free: a point's rank is its position inside its cell, so sum(rank) = sum over cells of occ (occ - 1) / 2 and the
+    // point-weighted mean cell occupancy is 1 + 2 sum(rank) / n (lili_map_set decides on the fine grid with it).  One atomic per block.
+    if (rank_sum) {
+        unsigned long long r64 = i < n && c >= 0 ? (unsigned long long)rank : 0ull;
+        for (int o = 32; o > 0; o >>= 1) r64 += __shfl_xor(r64, o);
+        __shared__ unsigned long long wsum[kBlock / 64];
+        if (lane == 0) wsum[threadIdx.x >> 6] = r64;
+        __syncthreads();
+        if (threadIdx.x == 0) { unsigned long long t = 0; for (int w = 0; w < kBlock / 64; w++) t += wsum[w]; atomicAdd(rank_sum, t); }
+    }
 }
 
 // exclusive scan of n ints, 3 kernels: per-block sums, scan of block sums (single block), apply.
@@ -1178,6 +1190,45 @@ __global__ __launch_bounds__(kAssocBlock) void k_associate_both(AssocArgs S, Ass
                                                       E.block_counts, E.nn_cache, sched, b, L, tab);
     else assoc_surf_body<false, kAssocBlock>(S.queries, nullptr, nullptr, S.n_q, S.g, pa, P, S.rec0, reinterpret_cast<double*>(S.rec1), S.valid, S.dbg_idx, S.dbg_d2,
                                              S.block_counts, S.nn_cache, sched, b - E.nb, L, tab);
+}
+// Association on a map that is much denser than the gate radius (SURVEY §8d Config 2, variant B: 5 M points at a 0.05 m leaf — ~170
+// points per gate-sized cell, ~1500 candidates in the inner 27 cells).  The map then carries a SECOND index with cells sized from the
+// measured point density (lili_map_set: ~3 points per cell), searched first with the selection bounded by fbound = (reach * fine cell /
+// 1.01)^2: everything within sqrt(fbound) of the query lies inside the fine 5x5x5 block, so if five points are found strictly inside
+// fbound no unseen point can beat the fifth — they ARE the global 5 nearest.  Only queries that do not find five (map borders, holes)
+// repeat the search on the gate-sized index with the reference's gate; both searches are the exact knn5_grid.  `kind`: 0 surf, 1 edge.
+__global__ __launch_bounds__(kAssocBlock) void k_associate_fine(AssocArgs A, GridView gf, float fbound, int kind, PoseArg pa, MatchParams P) {
+    __shared__ RowTabT<kAssocBlock> tab;
+    const int i = (int)blockIdx.x * kAssocBlock + (int)threadIdx.x;
+    const bool live = i < A.n_q;
+    const float4 ql = A.queries[live ? i : 0];
+    dq Q2; d3 T2;
+    load_assoc_pose(pa, P, Q2, T2);
+    const d3 pmd = qrot(Q2, d3{(double)ql.x, (double)ql.y, (double)ql.z}) + T2;
+    const float px = (float)pmd.x, py = (float)pmd.y, pz = (float)pmd.z;
+    const float gate = gate_bound(kind == 0 ? P.kd_max_radius : P.edge_gate);
+    Top5 nn; nn.aux = 0;
+    bool fine_hit = false;
+    if (live) {
+        knn5_grid(gf, tab, px, py, pz, fminf(fbound, gate), nn, P.debug);
+        fine_hit = nn.j[4] >= 0 && nn.d[4] < fbound;
+    }
+    if (live && !fine_hit) knn5_grid(A.g, tab, px, py, pz, gate, nn, P.debug);
+    bool ok = false;
+    if (live) {
+        const GridView& u = fine_hit ? gf : A.g;
+        store_debug_nn(u, nn, i, A.dbg_idx, A.dbg_d2);
+        if (kind == 0) {
+            float4 rn; double score;
+            ok = surf_fit(u, P, nn, ql, px, py, pz, rn, score);
+            A.rec0[i] = rn; reinterpret_cast<double*>(A.rec1)[i] = score; A.valid[i] = ok ? 1 : 0;
+        } else {
+            float4 ra, rb;
+            ok = edge_fit(u, P, nn, px, py, pz, ra, rb);
+            A.rec0[i] = ra; reinterpret_cast<float4*>(A.rec1)[i] = rb; A.valid[i] = ok ? 1 : 0;
+        }
+    }
+    store_block_count<kAssocBlock>(ok, A.block_counts, (int)blockIdx.x);
 }
 #define LILI_ASSOC_ARGS_SURF const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, int*, int*, AssocSched
 #define LILI_ASSOC_ARGS_EDGE const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, int*, int*, AssocSched

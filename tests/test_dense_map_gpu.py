@@ -1,0 +1,101 @@
+"""SURVEY §8d Config 2, variant B — a map far denser than the gate radius (0.05 m spacing against a 1 m gate: ~170 points per gate-sized
+cell).  lili_map_set measures the density and builds the second, density-sized index; the association searches it first and falls back to
+the gate-sized index only where it cannot find five points inside the radius it covers.  Exactness: neighbours (indices, f32 distances),
+records and the Gram are those of the oracle's exact kd-tree, and identical — bit for bit — to the gate-sized index alone."""
+import time
+
+import numpy as np
+import pytest
+
+import lili_om_amd as L
+from lili_om_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _dense_room(seed=3, step=0.05, size=(12.0, 9.0, 4.0)):
+    rng = np.random.default_rng(seed)
+    sx, sy, sz = size
+
+    def grid(u0, u1, v0, v1):
+        U, V = np.meshgrid(np.arange(u0, u1, step), np.arange(v0, v1, step), indexing="ij")
+        return U.ravel() + rng.uniform(-0.02, 0.02, U.size), V.ravel() + rng.uniform(-0.02, 0.02, V.size)
+    faces = []
+    for z in (0.0, sz):
+        U, V = grid(-sx / 2, sx / 2, -sy / 2, sy / 2)
+        faces.append(np.stack([U, V, np.full_like(U, z) + rng.normal(0, 0.003, U.size)], 1))
+    for sg in (-1, 1):
+        U, V = grid(-sy / 2, sy / 2, 0, sz)
+        faces.append(np.stack([np.full_like(U, sg * sx / 2) + rng.normal(0, 0.003, U.size), U, V], 1))
+        U, V = grid(-sx / 2, sx / 2, 0, sz)
+        faces.append(np.stack([U, np.full_like(U, sg * sy / 2) + rng.normal(0, 0.003, U.size), V], 1))
+    pts = np.concatenate(faces).astype(np.float32)
+    # a sparse patch as well (a hole in the dense coverage): one wall is thinned to ~0.5 m spacing in a strip
+    strip = (np.abs(pts[:, 0] - sx / 2) < 0.05) & (pts[:, 1] > 0) & (pts[:, 1] < 3)
+    keep = ~strip | (rng.uniform(size=pts.shape[0]) < 0.01)
+    return pts[keep]
+
+
+def test_dense_map_fine_index_is_exact(gpu_ctx, oracle):
+    mp = _dense_room()
+    assert mp.shape[0] > 140_000
+    rng = np.random.default_rng(7)
+    pick = rng.choice(mp.shape[0], 6000)
+    qw = mp[pick].astype(np.float64) + rng.normal(0, 0.01, (6000, 3)) + rng.uniform(-0.1, 0.1, (6000, 3))
+    qw[:300] += rng.uniform(0.6, 2.5, (300, 3))                       # far from every surface: fail the gate / need the gate-sized index
+    qw[300:600, 0] = 6.0 + rng.uniform(-0.05, 0.05, 300); qw[300:600, 1] = rng.uniform(0, 3, 300)   # next to the thinned strip
+    t_true = np.array([0.4, -0.3, 1.5]); ang = np.radians(15.0)
+    q_true = np.array([np.cos(ang / 2), 0, 0, np.sin(ang / 2)])
+    q_local = synth.quat_rot(q_true * np.array([1, -1, -1, -1]), qw - t_true).astype(np.float32)
+    P, PO = L.make_params("rot"), oracle.params("rot")
+    res = {}
+    try:
+        for fine in (1, 0):
+            gpu_ctx.set_option("fine_grid", fine)
+            gpu_ctx.set_debug(True)
+            m = L.ScanToMapMatcher(gpu_ctx, P)
+            m.set_input_cloud(L.KIND_SURF, mp)
+            occ, fcell, fr2 = m.map_density(L.KIND_SURF)
+            if fine:
+                assert occ > 100 and 0.04 < fcell < 0.3 and fr2 > 4 * 0.04 ** 2, (occ, fcell, fr2)
+            else:
+                assert fcell == 0.0
+            m.set_queries(0, L.KIND_SURF, q_local)
+            n = m.find_corresponding_surf_features(0, q_true, t_true)
+            idx, d2 = m.neighbors(0, L.KIND_SURF, 6000)
+            rec = m.surf_records(0, 6000)
+            tb, qb = L.api.body_pose_from_lidar(t_true, q_true, P)
+            G, cost, counts = m.linearize(0, tb, qb, L.MASK_SURF)
+            # timing on the queries a scan consists of — points ON the mapped surfaces (slot 1; the 600 far / border queries above need the
+            # gate-sized index whatever comes first, and one such lane costs its wave the whole dense neighbourhood)
+            gpu_ctx.set_debug(False)
+            m.set_queries(1, L.KIND_SURF, q_local[600:])
+            m.find_corresponding_surf_features(1, q_true, t_true)
+            gpu_ctx.sync()
+            tic = time.perf_counter()
+            for _ in range(10):
+                m.find_corresponding_surf_features(1, q_true, t_true, want_count=False)
+            gpu_ctx.sync()
+            dt = (time.perf_counter() - tic) / 10
+            res[fine] = (n, idx, d2, rec, G, cost, dt, occ, fcell)
+    finally:
+        gpu_ctx.set_option("fine_grid", 1)
+        gpu_ctx.set_debug(False)
+    print(f"dense map: {mp.shape[0]} points, mean occupancy {res[1][7]:.0f} per gate-sized cell, fine cell {res[1][8]:.3f} m; "
+          f"associate 5400 on-surface queries: fine index {res[1][6] * 1e6:.0f} us, gate-sized index alone {res[0][6] * 1e6:.0f} us")
+    # against the oracle's exact kd-tree
+    tree = oracle.KdTree(mp)
+    o = oracle.associate_surf(tree, None, q_local, None, q_true, t_true, PO)
+    n, idx, d2, rec, G, cost, _, _, _ = res[1]
+    assert n == o["count"] and n > 4000
+    inside = o["nn_d2"][:, 4] < 1.0
+    assert inside.sum() > 5000 and (~inside).sum() > 100
+    assert np.array_equal(idx[inside], o["nn_idx"][inside]) and np.array_equal(d2[inside], o["nn_d2"][inside])
+    assert np.array_equal(rec["query_index"], np.nonzero(o["valid"])[0])
+    # ... and identical to the gate-sized index alone, bit for bit (same neighbours -> same fits -> same records -> same Gram)
+    a, b = res[1], res[0]
+    assert a[0] == b[0] and np.array_equal(a[1][inside], b[1][inside]) and np.array_equal(a[2][inside], b[2][inside])
+    for k in ("query_index", "n", "d", "score"):
+        assert np.array_equal(a[3][k], b[3][k]), k
+    assert np.array_equal(a[4], b[4]) and a[5] == b[5]
+    assert a[6] < b[6]                                                # and it is the faster of the two on this map
