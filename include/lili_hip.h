@@ -247,6 +247,13 @@ int lili_s2m_get_neighbors(lili_ctx* ctx, int slot, int kind, size_t n_q, int32_
 int lili_s2m_pose_set(lili_ctx* ctx, int slot, const double t[3], const double q[4]);
 int lili_s2m_pose_get(lili_ctx* ctx, int slot, double t[3], double q[4], int* gn_status /*0 ok, 1 singular*/);
 
+/* The last Gauss-Newton step of `slot`: delta[6] = (dt[3], rotation vector[3]) of the local parameterisation, the number of updates since
+ * lili_s2m_pose_set and the status of the last one (0 ok, 1 = normal matrix not positive definite: pose left unchanged, 2 = a multi-GPU
+ * exchange gave up).  The device loops take plain Gauss-Newton steps (one per re-association, like one accepted step of the reference's
+ * ceres::Solve, L/src/BackendFusion.cpp:984-992); callers that need Ceres' step acceptance drive lili_s2m_linearize from their own solver
+ * (include/lili_ceres_adapter.h) — this call lets the others at least see how far a step went.  Blocking. */
+int lili_s2m_last_step(lili_ctx* ctx, int slot, double delta[6], int* n_updates, int* gn_status);
+
 /* One outer iteration, first half (async): re-associate at the device pose (association transform
  * Q2 = Q*q_lb^-1, T2 = T - Q2*t_lb as in L/src/BackendFusion.cpp:929-930), linearise, and reduce this
  * rank's partial into d_gram (DEVICE pointer to LILI_GRAM_DOUBLES doubles owned by the caller:

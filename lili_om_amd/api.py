@@ -115,6 +115,7 @@ _SIGS = {
     "lili_s2m_get_neighbors": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]),
     "lili_s2m_pose_set": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "lili_s2m_pose_get": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "lili_s2m_last_step": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "lili_s2m_accumulate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams), C.c_void_p]),
     "lili_s2m_associate_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams)]),
     "lili_s2m_counts_export": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
@@ -355,6 +356,13 @@ class ScanToMapMatcher:
         st = C.c_int(0)
         self.ctx._chk(self.lib.lili_s2m_pose_get(self.ctx.h, slot, _ptr(t), _ptr(q), C.byref(st)))
         return t, q, st.value
+
+    def last_step(self, slot):
+        """(delta[6] = dt, rotation vector; number of GN updates since pose_set; status of the last one)."""
+        d = np.zeros(6)
+        n, st = C.c_int(0), C.c_int(0)
+        self.ctx._chk(self.lib.lili_s2m_last_step(self.ctx.h, slot, _ptr(d), C.byref(n), C.byref(st)))
+        return d, n.value, st.value
 
     def accumulate(self, slot, d_gram_ptr, kind_mask=MASK_SURF):
         self.ctx._chk(self.lib.lili_s2m_accumulate(self.ctx.h, slot, kind_mask, C.byref(self.params), C.c_void_p(d_gram_ptr)))

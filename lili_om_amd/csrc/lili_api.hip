@@ -740,6 +740,22 @@ int lili_s2m_pose_get(lili_ctx* ctx, int slot, double t[3], double q[4], int* gn
     return LILI_OK;
 }
 
+// The step the last Gauss-Newton update of `slot` took (lili_s2m_iterate* apply undamped GN steps; ceres::Solve in the reference rejects
+// steps that do not decrease the cost — a caller that starts far from the solution can guard with this, or drive
+// lili_s2m_linearize + its own trust region as include/lili_ceres_adapter.h does).
+int lili_s2m_last_step(lili_ctx* ctx, int slot, double delta[6], int* n_updates, int* gn_status) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS, "last_step: bad slot");
+    HIPCHK(hipSetDevice(ctx->device));
+    SlotState s{};
+    HIPCHK(hipMemcpyAsync(&s, ctx->state(slot), sizeof(s), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (delta) for (int i = 0; i < 6; i++) delta[i] = s.last_delta[i];
+    if (n_updates) *n_updates = s.iters;
+    if (gn_status) *gn_status = s.gn_status;
+    return LILI_OK;
+}
+
 // profiling aid (LILI_DEBUG bit 256): the 16 device timestamps (100 MHz ticks) of the slot's last launches
 int lili_s2m_debug_times(lili_ctx* ctx, int slot, long long out[16]) {
     if (!ctx) return LILI_E_ARG;

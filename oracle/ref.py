@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-REF_DIR = os.path.join(HERE, "_ref")
+REF_DIR = os.path.abspath(os.environ.get("LILI_REF_DIR", os.path.join(HERE, "_ref")))   # LILI_REF_DIR=oracle/_ref_real: the REAL_DEPS build (refshim/README.md)
 REFERENCE_ROOT = "/root/reference"
 _LIBS = {}
 

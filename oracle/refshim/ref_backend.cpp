@@ -16,8 +16,7 @@
 #include <cstring>
 #include <memory>
 #include <vector>
-#include "refshim/ros_pcl_min.h"
-#include "refshim/ceres_min.h"
+#include "refshim_deps.h"
 #include "utils/common.h"
 #include "utils/math_tools.h"
 #include "factors/LidarKeyframeFactor.h"

@@ -3,8 +3,7 @@
 // ceres::CostFunction::Evaluate — with the Jet / AutoDiffCostFunction stand-ins of
 // refshim/ceres_min.h.  Output layout of every call: out[0] = residual, out[1..] = the two Jacobian blocks in
 // the functor's parameter order, row-major.
-#include "refshim/eigen_min.h"
-#include "refshim/ceres_min.h"
+#include "refshim_deps.h"
 #include "factors/LidarKeyframeFactor.h"
 #include <memory>
 

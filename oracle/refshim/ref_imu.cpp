@@ -10,7 +10,11 @@
 using std::vector;
 namespace ros { struct NodeHandle {}; }          // Preintegration carries an (unused) ros::NodeHandle member
 #define ROS_WARN(...) do {} while (0)
+#if defined(LILI_WITH_REFERENCE_DEPS)
+#include <Eigen/Dense>                            // REAL_DEPS build: the machine's Eigen (and Ceres, through ImuFactor.h)
+#else
 #include "refshim_imu/eigen_imu.h"
+#endif
 #include "factors/ImuFactor.h"
 #include <memory>
 

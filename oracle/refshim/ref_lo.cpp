@@ -18,8 +18,7 @@
 #include <memory>
 #include <string>
 #include <vector>
-#include "refshim/ros_pcl_min.h"
-#include "refshim/ceres_min.h"
+#include "refshim_deps.h"
 #define private public
 #define main ref_lo_node_main
 #include "src/LidarOdometry.cpp"

@@ -13,7 +13,7 @@
 #include <memory>
 #include <string>
 #include <vector>
-#include "refshim/ros_pcl_min.h"
+#include "refshim_deps.h"
 #include "utils/common.h"
 
 class LocalMapSlice {

@@ -7,8 +7,7 @@
 #include <cstring>
 #include <memory>
 #include <vector>
-#include "refshim/ros_pcl_min.h"
-#include "refshim/ceres_min.h"
+#include "refshim_deps.h"
 #include "factors/MarginalizationFactor.h"
 #include "factors/LidarKeyframeFactor.h"
 #include "gen/marg_L.inc"

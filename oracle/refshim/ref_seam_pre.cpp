@@ -12,7 +12,7 @@
 #include <cstring>
 #include <deque>
 #include <vector>
-#include "refshim/ros_pcl_min.h"
+#include "refshim_deps.h"
 #include "utils/common.h"
 #include "utils/timer.h"
 #include "utils/math_tools.h"

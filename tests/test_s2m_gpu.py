@@ -216,6 +216,9 @@ def test_host_pose_and_device_pose_paths_agree(gpu_ctx, oracle):
     t2, q2, st2 = m.pose_get(0)
     assert st2 == 0
     assert np.abs(t1 - t2).max() < 1e-12 and np.abs(q1 - q2).max() < 1e-12
+    d, n_up, st3 = m.last_step(0)                      # the step the device took = the host mirror's
+    _, _, _, d_host = L.api.gn_step_host(G, t0, q0)
+    assert n_up == 1 and st3 == 0 and np.abs(d - d_host).max() < 1e-12 and np.abs(d[:3] - (t2 - t0)).max() < 1e-12
 
 
 def test_edge_cases(gpu_ctx, oracle):
