@@ -437,10 +437,22 @@ __global__ __launch_bounds__(256) void k_rot_rank(const float* __restrict__ curv
     if (ring >= P.n_scans || re - rs < 6 || ring % P.ds_rate != 0) return;
     const int sp = rs + (re - rs) * j / 6, ep = rs + (re - rs) * (j + 1) / 6 - 1;
     const int len = ep - sp + 1;
-    if (len <= 0 || len > kRingLdsCap) return;
+    if (len <= 0) return;
     if ((int)blockIdx.z * 64 >= len) return;
-    for (int m = threadIdx.x; m < len; m += 256) seg[m] = curv[sp + m];
+    const bool in_lds = len <= kRingLdsCap;
+    if (in_lds) for (int m = threadIdx.x; m < len; m += 256) seg[m] = curv[sp + m];
     __syncthreads();
+    if (!in_lds) {      // a segment of a ring with more than ~24 k points: the same count straight from global memory (rare; rings this long are not the product's fast case)
+        const int sub = threadIdx.x & 3;
+        for (int e = blockIdx.z * 64 + (threadIdx.x >> 2); e < len; e += gridDim.z * 64) {
+            const float ck = curv[sp + e];
+            int rank = 0;
+            for (int m = sub; m < len; m += 4) { const float cm = curv[sp + m]; rank += (cm < ck || (cm == ck && m < e)) ? 1 : 0; }
+            rank += __shfl_xor(rank, 1); rank += __shfl_xor(rank, 2);
+            if (sub == 0) sort_ind[sp + rank] = sp + e;
+        }
+        return;
+    }
     // four lanes per element, each counting a quarter of the segment (interleaved by 4): the loop is a quarter as long, the partial
     // ranks meet in two shuffles
     const int sub = threadIdx.x & 3;
@@ -467,7 +479,7 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_select(const float4* __restri
     // labels of every point of the ring default to 0 (R:393)
     for (int k = tid; k < rcount; k += kRotBlock) label_g[rbase + k] = 0;
     if (ring >= P.n_scans || re - rs < 6 || ring % P.ds_rate != 0) return;      // R:402
-    if (rcount > kRingLdsCap) {     // does not fit the LDS budget: not supported by this kernel version
+    if (rcount > kRingLdsCap) {     // does not fit the LDS working set: k_rot_select_big takes this ring (global-memory arrays)
         if (tid == 0) atomicAdd(&st->fallback_rings, 1);
         return;
     }
@@ -652,6 +664,181 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_select(const float4* __restri
     if (ring == 0 && tid == 0) st->tphase[6] = wall_clock64();
 }
 
+// ---- rings that do not fit the LDS working set (more than kRingLdsCap = 4096 points on one ring: a 16-ring sensor at 0.1 deg, merged
+// sweeps; the reference takes any ring up to its 400 000-point arrays, R/src/Preprocessing.cpp:9-12).  Same statements as k_rot_select with
+// the ring's arrays in GLOBAL memory (`full`, `curv_g`, `sort_ind_g`, `label_g` in place; marks / voxel ids / sort buffers / digit table in
+// a per-scan scratch area): the greedy picks run in the reference's serial order on one lane, the voxel ordering is the same stable LSD
+// radix sort with the slot loop no longer unrolled.  Correct and bit-identical to the LDS path; not tuned — a ring this long costs
+// ~1 ms.  One workgroup per ring; rings that fit LDS return immediately (k_rot_select handled them).
+struct RotBigScratch { signed char* mark; unsigned* vidx; unsigned* ord_a; unsigned* ord_b; int* rcnt; int rcnt_off[kMaxRings]; };   // rcnt_off: start of the ring's [digit table | sort buffer] stretch
+__global__ __launch_bounds__(kRotBlock) void k_rot_select_big(const float4* __restrict__ full, const float* __restrict__ curv_g, const int* __restrict__ sort_ind_g, RotDev P, RotState* st,
+                                                              int* __restrict__ label_g, int* __restrict__ ring_edge, int* __restrict__ ring_sharp, int* __restrict__ ring_flat,
+                                                              int* __restrict__ lessflat_tmp, float4* __restrict__ surf_tmp, int* __restrict__ surf_cnt_tmp, RotBigScratch B) {
+    __shared__ int scan[kRotBlock / 64 + 1];
+    __shared__ float red[6][kRotBlock / 64];
+    const int ring = blockIdx.x, tid = threadIdx.x;
+    const int rbase = st->ring_base[ring], rcount = st->ring_count[ring];
+    const int rs = st->ring_start[ring], re = st->ring_end[ring];
+    if (rcount <= kRingLdsCap) return;
+    if (ring >= P.n_scans || re - rs < 6 || ring % P.ds_rate != 0) return;      // labels were zeroed by k_rot_select
+    signed char* M = B.mark + rbase;                 // index = GLOBAL index - rbase
+    for (int k = tid; k < rcount; k += kRotBlock) M[k] = 0;
+    __syncthreads();
+    if (tid == 0) {                                   // R:401-492, the reference's order
+        int ne = 0, nsh = 0, nfl = 0;
+        auto gap2g = [&](int a, int b) { const float4 pa = full[a], pb = full[b]; const float dX = pa.x - pb.x, dY = pa.y - pb.y, dZ = pa.z - pb.z; return dX * dX + dY * dY + dZ * dZ; };
+        auto range2g = [&](int k) { const float4 p = full[k]; return p.x * p.x + p.y * p.y + p.z * p.z; };
+        for (int j = 0; j < 6; j++) {
+            const int sp = rs + (re - rs) * j / 6, ep = rs + (re - rs) * (j + 1) / 6 - 1;
+            int largest = 0;
+            for (int k = ep; k >= sp; k--) {
+                const int ind = sort_ind_g[k];
+                if (!((double)curv_g[ind] > 2.0)) break;
+                if (M[ind - rbase] == 0) {
+                    largest++;
+                    if (largest <= 2) { label_g[ind] = 2; if (nsh < kRingSharpCap) ring_sharp[ring * kRingSharpCap + nsh++] = ind; if (ne < kRingEdgeCap) ring_edge[ring * kRingEdgeCap + ne++] = ind; }
+                    else if (largest <= 10) { label_g[ind] = 1; if (ne < kRingEdgeCap) ring_edge[ring * kRingEdgeCap + ne++] = ind; }
+                    else break;
+                    M[ind - rbase] = 1;
+                    for (int l = 1; l <= 5; l++) { if ((double)gap2g(ind + l, ind + l - 1) > 0.05) break; M[ind + l - rbase] = 1; }
+                    for (int l = -1; l >= -5; l--) { if ((double)gap2g(ind + l, ind + l + 1) > 0.05) break; M[ind + l - rbase] = 1; }
+                }
+            }
+            int smallest = 0;
+            for (int k = sp; k <= ep; k++) {
+                const int ind = sort_ind_g[k];
+                if (!((double)curv_g[ind] < 0.1)) break;
+                if ((double)range2g(ind) < 0.25) continue;
+                if (M[ind - rbase] == 0) {
+                    label_g[ind] = -1; if (nfl < kRingFlatCap) ring_flat[ring * kRingFlatCap + nfl++] = ind;
+                    smallest++;
+                    if (smallest >= 4) break;
+                    M[ind - rbase] = 1;
+                    for (int l = 1; l <= 5; l++) { if ((double)gap2g(ind + l, ind + l - 1) > 0.05) break; M[ind + l - rbase] = 1; }
+                    for (int l = -1; l >= -5; l--) { if ((double)gap2g(ind + l, ind + l + 1) > 0.05) break; M[ind + l - rbase] = 1; }
+                }
+            }
+        }
+        st->ring_nedge[ring] = ne; st->ring_nsharp[ring] = nsh; st->ring_nflat[ring] = nfl;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // less-flat list in index order (R:494-499); B.ord_b doubles as the list of global indices
+    unsigned* lf = B.ord_b + rbase;
+    int n_lf = 0;
+    for (int k0 = rs; k0 <= re - 1; k0 += kRotBlock) {
+        const int k = k0 + tid;
+        bool keep = false;
+        if (k <= re - 1) { const float4 p = full[k]; keep = !((double)(p.x * p.x + p.y * p.y + p.z * p.z) < 0.25) && label_g[k] <= 0; }
+        int tot; const int off = block_excl_scan_1024(keep ? 1 : 0, scan, tot);
+        if (keep) { lessflat_tmp[rbase + n_lf + off] = k; lf[n_lf + off] = (unsigned)k; }
+        n_lf += tot;
+    }
+    __syncthreads();
+    if (tid == 0) st->ring_nlf[ring] = n_lf;
+    if (n_lf == 0) { if (tid == 0) st->ring_nsurf[ring] = 0; return; }
+    // pcl::VoxelGrid(ds_v) (R:502-508): bounding box, voxel ids, stable radix sort of the list positions, in-order centroids
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int q = tid; q < n_lf; q += kRotBlock) {
+        const float4 p = full[lf[q]];
+        mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+        mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) for (int o = 32; o > 0; o >>= 1) { mn[c] = fminf(mn[c], __shfl_xor(mn[c], o)); mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o)); }
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { red[c][tid >> 6] = mn[c]; red[3 + c][tid >> 6] = mx[c]; }
+    }
+    __syncthreads();
+    const float inv = 1.0f / P.ds_v;
+    int min_b[3], div_b[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float a = red[c][0], b = red[3 + c][0];
+        for (int w = 1; w < kRotBlock / 64; w++) { a = fminf(a, red[c][w]); b = fmaxf(b, red[3 + c][w]); }
+        min_b[c] = (int)floorf(a * inv);
+        div_b[c] = (int)floorf(b * inv) - min_b[c] + 1;
+    }
+    unsigned* vidx = B.vidx + rbase;
+    unsigned* src = B.ord_a + rbase;
+    unsigned* dst = B.ord_a + rbase;                  // set below (ping-pong with a second stretch)
+    for (int q = tid; q < n_lf; q += kRotBlock) {
+        const float4 p = full[lf[q]];
+        const int i0 = (int)(floorf(p.x * inv) - (float)min_b[0]);
+        const int i1 = (int)(floorf(p.y * inv) - (float)min_b[1]);
+        const int i2 = (int)(floorf(p.z * inv) - (float)min_b[2]);
+        vidx[q] = (unsigned)(i0 + i1 * div_b[0] + i2 * div_b[0] * div_b[1]);
+        src[q] = (unsigned)q;
+    }
+    const unsigned n_vox = (unsigned)div_b[0] * (unsigned)div_b[1] * (unsigned)div_b[2];
+    int bits = 1; while (bits < 32 && (n_vox - 1u) >> bits) bits++;
+    // second ping-pong buffer: the upper half of the ord_a area is not available (other rings), so the mark area's neighbour — a dedicated
+    // stretch of the digit table buffer — is used: B.rcnt holds [ring][table | n ints]
+    int* table = B.rcnt + B.rcnt_off[ring];
+    const int n_slots = (n_lf + kRotBlock - 1) / kRotBlock;
+    const int tsize = 32 * n_slots * (kRotBlock / 64);
+    dst = reinterpret_cast<unsigned*>(table + tsize);
+    __threadfence_block();
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int shift = 0; shift < bits; shift += 5) {
+        for (int k = tid; k < tsize; k += kRotBlock) table[k] = 0;
+        __threadfence_block();
+        __syncthreads();
+        for (int sl = 0; sl < n_slots; sl++) {
+            const int i = sl * kRotBlock + tid;
+            const bool act = i < n_lf;
+            const int d = act ? (int)((vidx[src[i]] >> shift) & 31u) : 0;
+            unsigned long long m = __ballot(act);
+#pragma unroll
+            for (int bb = 0; bb < 5; bb++) { const unsigned long long bal = __ballot(act && ((d >> bb) & 1)); m &= ((d >> bb) & 1) ? bal : ~bal; }
+            if (act && __popcll(m & ((1ull << lane) - 1ull)) == 0) table[(d * n_slots + sl) * (kRotBlock / 64) + wave] = __popcll(m);
+        }
+        __threadfence_block();
+        __syncthreads();
+        int carry = 0;                                 // exclusive scan of the table, kRotBlock entries per round
+        for (int k0 = 0; k0 < tsize; k0 += kRotBlock) {
+            const int k = k0 + tid;
+            const int v = k < tsize ? table[k] : 0;
+            int tot; const int ex = block_excl_scan_1024(v, scan, tot);
+            if (k < tsize) table[k] = carry + ex;
+            carry += tot;
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (int sl = 0; sl < n_slots; sl++) {
+            const int i = sl * kRotBlock + tid;
+            const bool act = i < n_lf;
+            const unsigned q = act ? src[i] : 0u;
+            const int d = act ? (int)((vidx[q] >> shift) & 31u) : 0;
+            unsigned long long m = __ballot(act);
+#pragma unroll
+            for (int bb = 0; bb < 5; bb++) { const unsigned long long bal = __ballot(act && ((d >> bb) & 1)); m &= ((d >> bb) & 1) ? bal : ~bal; }
+            if (act) dst[table[(d * n_slots + sl) * (kRotBlock / 64) + wave] + __popcll(m & ((1ull << lane) - 1ull))] = q;
+        }
+        __threadfence_block();
+        __syncthreads();
+        unsigned* t2 = src; src = dst; dst = t2;
+    }
+    int n_out = 0;
+    for (int q0 = 0; q0 < n_lf; q0 += kRotBlock) {
+        const int q = q0 + tid;
+        const bool head = q < n_lf && (q == 0 || vidx[src[q]] != vidx[src[q - 1]]);
+        int tot; const int off = block_excl_scan_1024(head ? 1 : 0, scan, tot);
+        if (head) {
+            const unsigned vox = vidx[src[q]];
+            float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f; int cnt = 0;
+            for (int m = q; m < n_lf && vidx[src[m]] == vox; m++) { const float4 p = full[lf[src[m]]]; sx += p.x; sy += p.y; sz += p.z; si += p.w; cnt++; }
+            const float fn = (float)cnt;
+            surf_tmp[rbase + n_out + off] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
+            surf_cnt_tmp[rbase + n_out + off] = cnt;
+        }
+        n_out += tot;
+    }
+    if (tid == 0) st->ring_nsurf[ring] = n_out;
+}
+
 // ordered concatenation of the per-ring lists (rings ascending, then push order inside the ring): one block per ring
 __global__ __launch_bounds__(256) void k_rot_compact(RotState* st, const float4* __restrict__ full,
                                                      const int* __restrict__ ring_edge, const int* __restrict__ ring_sharp, const int* __restrict__ ring_flat,
@@ -686,6 +873,7 @@ struct RotBuffers {
     DevBuf in, valid, scan_id, ori_raw, block_hist, state, full, full_src, curv, label, sort_ind;
     DevBuf ring_edge, ring_sharp, ring_flat, lessflat_tmp, surf_tmp, surf_cnt_tmp;
     DevBuf edge_idx, edge_pts, sharp_idx, flat_idx, lessflat_idx, surf, surf_cnt;
+    DevBuf big_mark, big_vidx, big_ord_a, big_ord_b, big_rcnt;   // working set of rings beyond the LDS budget (k_rot_select_big)
     lili::RotState host{};
     int n_in = 0;
     bool have = false;
@@ -767,7 +955,32 @@ int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4
     }
     HIPCHK(hipMemcpyAsync(&R->host, st, sizeof(RotState), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (R->host.fallback_rings > 0) return ctx->fail(LILI_E_STATE, "extract_rot: a ring holds more than 4096 points (not supported yet)");
+    if (R->host.fallback_rings > 0) {      // rings beyond the LDS working set: second pass with global-memory arrays, then the concatenation again
+        const size_t cap = (size_t)std::max(n, 1);
+        RotBigScratch B{};
+        size_t off = 0;
+        for (int r = 0; r < kMaxRings; r++) {
+            B.rcnt_off[r] = (int)off;
+            const int rc_ = R->host.ring_count[r];
+            if (rc_ > kRingLdsCap) off += (size_t)32 * (size_t)((rc_ + kRotBlock - 1) / kRotBlock) * (kRotBlock / 64) + (size_t)rc_ + 64;
+        }
+        HIPCHK(R->big_mark.ensure(cap + 64)); HIPCHK(R->big_vidx.ensure(cap * 4)); HIPCHK(R->big_ord_a.ensure(cap * 4)); HIPCHK(R->big_ord_b.ensure(cap * 4));
+        HIPCHK(R->big_rcnt.ensure(std::max<size_t>(off, 1) * 4));
+        B.mark = R->big_mark.as<signed char>(); B.vidx = R->big_vidx.as<unsigned>(); B.ord_a = R->big_ord_a.as<unsigned>(); B.ord_b = R->big_ord_b.as<unsigned>();
+        B.rcnt = R->big_rcnt.as<int>();
+        RotDev P{};
+        P.n_scans = params->n_scans; P.ds_rate = params->ds_rate; P.ds_v = params->ds_v; P.near_thres = params->near_range; P.atan_mode = ctx->rot_atan;
+        for (int i = 0; i < 4; i++) { P.q_imu[i] = q_imu[i]; P.q_lb[i] = q_lb[i]; }
+        hipLaunchKernelGGL(k_rot_select_big, dim3(kMaxRings), dim3(kRotBlock), 0, ctx->stream, R->full.as<float4>(), R->curv.as<float>(), R->sort_ind.as<int>(), P, st,
+                           R->label.as<int>(), R->ring_edge.as<int>(), R->ring_sharp.as<int>(), R->ring_flat.as<int>(), R->lessflat_tmp.as<int>(),
+                           R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>(), B);
+        hipLaunchKernelGGL(k_rot_compact, dim3(kMaxRings), dim3(256), 0, ctx->stream, st, R->full.as<float4>(), R->ring_edge.as<int>(), R->ring_sharp.as<int>(),
+                           R->ring_flat.as<int>(), R->lessflat_tmp.as<int>(), R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>(), R->edge_idx.as<int>(),
+                           R->edge_pts.as<float4>(), R->sharp_idx.as<int>(), R->flat_idx.as<int>(), R->lessflat_idx.as<int>(), R->surf.as<float4>(), R->surf_cnt.as<int>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&R->host, st, sizeof(RotState), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
     R->have = true;
     if (full) { full->count = (size_t)R->host.n_full; rc = copy_out_f4(ctx, full, R->full.as<float4>(), full->count); if (rc) return rc; }
     if (edge) { edge->count = (size_t)R->host.n_edge; rc = copy_out_f4(ctx, edge, R->edge_pts.as<float4>(), edge->count); if (rc) return rc; }

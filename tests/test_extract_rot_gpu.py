@@ -79,3 +79,25 @@ def test_rot_extractor_edge_cases(gpu_ctx, oracle):
     g16 = ex16.extract(raw, debug=True)
     o16 = oracle.extract_rot(raw, P=oracle.rot_params(n_scans=16, ds_rate=1, atan_mode=2, stable_sort=1))
     _compare(g16, o16)
+
+
+def test_rot_extractor_rings_beyond_the_lds_working_set(gpu_ctx, oracle):
+    """A 16-ring sensor at 0.04 deg azimuth resolution: ~9000 points per ring — more than the 4096-point LDS working set of k_rot_select
+    (such rings used to be refused; the reference takes any ring up to its 400 000-point arrays,
+    R/src/Preprocessing.cpp:9-12).  The global-memory pass gives the oracle's indices, labels and centroids bit for bit."""
+    sc = synth.OutdoorScene()
+    elev = -15.0 + 2.0 * np.arange(16)                       # the reference's 16-ring table: id = int((angle + 15) / 2 + 0.5)
+    dirs, ring, rel = synth.spinning_rays(9000, elev)
+    t = sc.raycast(np.array([0.0, 0.0, 1.8]), dirs)
+    ok = np.isfinite(t)
+    t = t + np.random.default_rng(5).normal(0, 0.02, t.shape)
+    pts = (dirs * t[:, None])[ok].astype(np.float32)
+    raw = np.concatenate([pts, np.full((pts.shape[0], 1), 10.0, np.float32)], 1)
+    assert raw.shape[0] > 100_000
+    for ds_rate in (1, 4):
+        ex = L.RotExtractor(gpu_ctx, n_scans=16, ds_rate=ds_rate)
+        g = ex.extract(raw, [0.9999, 0.003, -0.004, 0.002], [1.0, 0, 0, 0], debug=True)
+        o = oracle.extract_rot(raw, [0.9999, 0.003, -0.004, 0.002], [1.0, 0, 0, 0], oracle.rot_params(n_scans=16, ds_rate=ds_rate, atan_mode=2, stable_sort=1))
+        assert (o["ring_end"] - o["ring_start"]).max() > 4096 + 1000          # really beyond the LDS cap
+        assert len(o["edge_idx"]) > 20 and len(o["surf"]) > 1000
+        _compare(g, o)
