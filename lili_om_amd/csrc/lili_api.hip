@@ -21,7 +21,8 @@ __global__ void k_scan_block_sums(const int*, int64_t, int*);
 __global__ void k_scan_sums(int*, int);
 __global__ void k_scan_apply(const int*, int64_t, const int*, int*);
 __global__ void k_scan_lookback(int*, int64_t, unsigned long long*);
-__global__ void k_scatter(const float4*, int, const int2*, const int*, float4*, float*);
+__global__ void k_scatter(const float4*, int, const int2*, const int*, float4*, float*, GridView, const int*);
+__global__ void k_count9(int, const int2*, const int*, GridView, int*);
 __global__ void k_bin_count(const float4*, int, GridView, PoseArg, MatchParams, int, int, int*, int*);
 __global__ void k_bin_scatter(const int*, int, const int*, int*, int*);
 __global__ void k_tile_count(const int*, int, int*);
@@ -131,7 +132,7 @@ void lili_ctx_destroy(lili_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (auto& m : ctx->map) { m.sorted_f.release(); m.aux_sorted_f.release(); m.cell_start_f.release(); m.pts.release(); m.sorted.release(); m.aux_sorted.release(); m.cell_start.release(); m.cell_tmp.release(); m.pt_cell.release(); m.block_sums.release(); }
+    for (auto& m : ctx->map) { m.sorted_f.release(); m.aux_sorted_f.release(); m.cell_start_f.release(); m.cell_start9.release(); m.cell_start9_f.release(); m.pts.release(); m.sorted.release(); m.aux_sorted.release(); m.cell_start.release(); m.cell_tmp.release(); m.pt_cell.release(); m.block_sums.release(); }
     for (auto& s : ctx->slots) for (auto& k : s.k) { k.q.release(); k.rec0.release(); k.rec1.release(); k.valid.release(); k.dbg_idx.release(); k.dbg_d2.release(); k.partials.release(); k.perm.release(); k.keys.release(); k.block_counts.release(); k.tiles.release(); }
     ctx->states.release(); ctx->staging.release(); ctx->gram.release(); ctx->misc.release(); ctx->bin_hist.release(); ctx->bin_start.release(); ctx->bin_sums.release(); ctx->bin_tcnt.release(); ctx->bin_toff.release();
     if (ctx->ext_rot && ctx->ext_rot_free) ctx->ext_rot_free(ctx->ext_rot);
@@ -168,6 +169,7 @@ int lili_set_option(lili_ctx* ctx, const char* name, int value) {
     if (std::strcmp(name, "fuse_tail") == 0) { ctx->fuse_tail = value != 0; return LILI_OK; }   // any time: the block partition does not depend on it
     if (std::strcmp(name, "merge_kinds") == 0) { ctx->merge_kinds = value != 0; return LILI_OK; }
     if (std::strcmp(name, "fine_grid") == 0) { ctx->fine_grid = value != 0; return LILI_OK; }
+    if (std::strcmp(name, "super_rows") == 0) { ctx->super_rows = value != 0; return LILI_OK; }   // takes effect at the next lili_map_set
     if (std::strcmp(name, "fine_occupancy") == 0) { if (value < 2) return ctx->fail(LILI_E_ARG, "fine_occupancy must be >= 2"); ctx->fine_occupancy = value; return LILI_OK; }
     if (std::strcmp(name, "scan_lookback") == 0) { ctx->scan_lookback = value != 0; return LILI_OK; }
     if (std::strcmp(name, "rot_atan") == 0) { if (value != 1 && value != 2) return ctx->fail(LILI_E_ARG, "rot_atan must be 1 or 2"); ctx->rot_atan = value; return LILI_OK; }
@@ -183,7 +185,7 @@ int lili_set_option(lili_ctx* ctx, const char* name, int value) {
 // Uniform-grid index of m.pts (already ingested) with cells of edge `cell` (grown if the bounding box needs more than max_cells cells):
 // count (one atomic per run of equal cells, the returned value = the point's rank), in-place single-pass scan, atomic-free scatter.
 static int build_grid(lili_ctx* ctx, MapIndex& m, const double mn[3], const double mx[3], double cell, int reach, DevBuf& sorted, DevBuf& aux_sorted,
-                      DevBuf& cell_start, GridView& out, int64_t& n_cells, double& cell_used, unsigned long long* d_rank_sum) {
+                      DevBuf& cell_start, DevBuf& cell_start9, GridView& out, int64_t& n_cells, double& cell_used, unsigned long long* d_rank_sum) {
     const int n = (int)m.n;
     int64_t nx, ny, nz;
     for (;;) {
@@ -203,9 +205,14 @@ static int build_grid(lili_ctx* ctx, MapIndex& m, const double mn[3], const doub
     // ONE cell array: counts -> (in-place exclusive scan) -> cell_start; the atomic of the count pass also hands every point its rank
     HIPCHK(cell_start.ensure((size_t)(nc + 1) * sizeof(int)));
     HIPCHK(m.pt_cell.ensure((size_t)n * sizeof(int2)));
-    HIPCHK(sorted.ensure((size_t)n * sizeof(float4)));
-    if (m.has_aux) HIPCHK(aux_sorted.ensure((size_t)n * sizeof(float)));
-    const int nb_scan = nblocks(nc, 2048);
+    // super-rows: the sorted array continues with the 3x3-row copy (<= 9n entries); positions stay 32-bit byte offsets, so 10n < 2^28
+    const int64_t nc9 = nx * (ny + 2) * (nz + 2);
+    const bool srows = ctx->super_rows && (int64_t)n * 10 < (1ll << 28) && nc9 + 2 < (1ll << 31);
+    const size_t n_all = srows ? (size_t)n * 10 : (size_t)n;
+    HIPCHK(sorted.ensure(n_all * sizeof(float4)));
+    if (m.has_aux) HIPCHK(aux_sorted.ensure(n_all * sizeof(float)));
+    if (srows) HIPCHK(cell_start9.ensure((size_t)(nc9 + 2) * sizeof(int)));
+    const int nb_scan = nblocks(std::max(nc, nc9 + 1), 2048);
     HIPCHK(m.block_sums.ensure((size_t)(nb_scan + 2) * sizeof(unsigned long long)));
     HIPCHK(hipMemsetAsync(cell_start.p, 0, (size_t)nc * sizeof(int), ctx->stream));
     hipLaunchKernelGGL(k_cell_count, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, m.pts.as<float4>(), n, g, cell_start.as<int>(), m.pt_cell.as<int2>(), d_rank_sum);
@@ -218,12 +225,21 @@ static int build_grid(lili_ctx* ctx, MapIndex& m, const double mn[3], const doub
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, ctx->stream, m.block_sums.as<int>(), nb_scan);
         hipLaunchKernelGGL(k_scan_apply, dim3(nb_scan), dim3(kBlock), 0, ctx->stream, cell_start.as<int>(), nc, m.block_sums.as<int>(), cell_start.as<int>());
     }
+    if (srows) {      // populations of the super cells (nine atomics per non-empty cell), then their scan behind a dummy cell of n entries
+        HIPCHK(hipMemsetAsync(cell_start9.p, 0, (size_t)(nc9 + 2) * sizeof(int), ctx->stream));
+        HIPCHK(hipMemcpyAsync(cell_start9.p, &g.n_points, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_count9, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, n, m.pt_cell.as<int2>(), cell_start.as<int>(), g, cell_start9.as<int>());
+        const int nb_lb = nblocks(nc9 + 1, 4096);
+        HIPCHK(hipMemsetAsync(m.block_sums.p, 0, (size_t)(nb_lb + 2) * sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(k_scan_lookback, dim3(nb_lb), dim3(kBlock), 0, ctx->stream, cell_start9.as<int>(), nc9 + 1, m.block_sums.as<unsigned long long>());
+    }
     hipLaunchKernelGGL(k_scatter, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, m.pts.as<float4>(), n, m.pt_cell.as<int2>(), cell_start.as<int>(),
-                       sorted.as<float4>(), m.has_aux ? aux_sorted.as<float>() : nullptr);
+                       sorted.as<float4>(), m.has_aux ? aux_sorted.as<float>() : nullptr, g, srows ? cell_start9.as<int>() : nullptr);
     HIPCHK(hipGetLastError());
     g.pts = sorted.as<float4>();
     g.aux = m.has_aux ? aux_sorted.as<float>() : nullptr;
     g.cell_start = cell_start.as<int>();
+    g.cell_start9 = srows ? cell_start9.as<int>() : nullptr;
     out = g;
     return LILI_OK;
 }
@@ -266,7 +282,7 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
     m.has_fine = false; m.fview = GridView{}; m.fbound = 0.f; m.fine_cell = 0; m.mean_occupancy = 0;
     unsigned long long* d_rank = ctx->fine_grid ? reinterpret_cast<unsigned long long*>(ctx->misc.as<char>() + 64) : nullptr;
     if (d_rank) HIPCHK(hipMemsetAsync(d_rank, 0, sizeof(unsigned long long), ctx->stream));
-    rc = build_grid(ctx, m, mn, mx, cell, reach, m.sorted, m.aux_sorted, m.cell_start, m.view, m.n_cells, m.cell, d_rank);
+    rc = build_grid(ctx, m, mn, mx, cell, reach, m.sorted, m.aux_sorted, m.cell_start, m.cell_start9, m.view, m.n_cells, m.cell, d_rank);
     if (rc != LILI_OK) return rc;
     // Density adaptation (SURVEY §7 step 4, §8d Config 2 variant B): the point-weighted mean cell occupancy falls out of the count pass.
     // A map with many points per gate-sized cell gets a second, fine index whose cells hold ~3 points; k_associate_fine searches it first.
@@ -280,7 +296,7 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
             double fc = cell * std::sqrt(3.0 / m.mean_occupancy);
             fc = std::min(std::max(fc, cell / 16.0), cell / 1.5);
             int64_t fcells = 0; double fcell_used = 0;
-            rc = build_grid(ctx, m, mn, mx, fc, reach, m.sorted_f, m.aux_sorted_f, m.cell_start_f, m.fview, fcells, fcell_used, nullptr);
+            rc = build_grid(ctx, m, mn, mx, fc, reach, m.sorted_f, m.aux_sorted_f, m.cell_start_f, m.cell_start9_f, m.fview, fcells, fcell_used, nullptr);
             if (rc != LILI_OK) return rc;
             const double rb = (double)reach * fcell_used / 1.01;
             float fb = (float)(rb * rb * (1.0 - 1e-6));

@@ -9,10 +9,12 @@ namespace lili {
 // Uniform-grid index over the local map (replaces the FLANN kd-tree).
 // Points are stored cell-sorted as float4 (x, y, z, bitcast(original index)); cell_start has
 // n_cells+1 entries; cells are x-fastest so the 3 x-neighbours of a cell are one contiguous run.
+// With super-rows, `pts` / `aux` continue behind the n_points base entries with the super-row copy (same float4 layout).
 struct GridView {
     const float4* pts;      // cell-sorted map points
     const float* aux;       // cell-sorted auxiliary float (Livox reflectivity) or nullptr
     const int* cell_start;  // [n_cells + 1]
+    const int* cell_start9; // super-row index (k_scatter in lili_s2m.hip) or nullptr: [1 + nx*(ny+2)*(nz+2) + 1], positions in the unified array
     double ox, oy, oz;      // grid origin
     double inv_cell;        // 1 / cell edge
     double cell;            // 1 / inv_cell (the value the pruning bounds use)

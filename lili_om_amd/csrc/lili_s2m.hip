@@ -255,16 +255,69 @@ __global__ __launch_bounds__(kBlock) void k_scan_lookback(int* data, int64_t n, 
     if (base <= n - 1 && n - 1 < base + kLbItems) data[n] = s_prefix + ex + s;     // the thread that owns the last item: total
 }
 
+// Super-rows: a second copy of the map in which the points of the 3x3 (y,z) rows around a row are stored together, sorted by
+// x cell — "super cell" (x, y', z') holds the points of the nine cells (x, y'+dy, z'+dz) in the fixed order k = (dz+1)*3 + (dy+1), each in
+// its base order.  The 27-cell neighbourhood of a query in cell (cx, cy, cz) is then ONE contiguous run: super cells cx-1..cx+1 of super-row
+// (cy, cz) — two range words instead of eighteen, no row table, no per-row bounds, full chunks.  The super-row grid has one more row on each
+// side in y and z (queries up to one cell outside the map still have an inner block); start9 is its exclusive scan with one leading dummy
+// cell of n_points entries, so the positions it yields index the unified array [base points | super-row points] directly.
+__device__ __forceinline__ size_t srow_index(const GridView& g, int x, int y, int z) {
+    return (size_t)1 + ((size_t)(z + 1) * (size_t)(g.ny + 2) + (size_t)(y + 1)) * (size_t)g.nx + (size_t)x;
+}
+// The first point of every non-empty cell (rank 0) adds the cell's population to the nine super cells that contain it.
+__global__ void k_count9(int n, const int2* __restrict__ pt_cell, const int* __restrict__ cell_start, GridView g, int* __restrict__ start9) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int2 cr = pt_cell[i];
+    if (cr.y != 0) return;
+    const int cnt = cell_start[cr.x + 1] - cell_start[cr.x];
+    const int x = cr.x % g.nx, t = cr.x / g.nx, y = t % g.ny, z = t / g.ny;
+#pragma unroll
+    for (int dz = -1; dz <= 1; dz++)
+#pragma unroll
+        for (int dy = -1; dy <= 1; dy++) atomicAdd(&start9[srow_index(g, x, y - dy, z - dz)], cnt);
+}
+
 __global__ void k_scatter(const float4* __restrict__ pts, int n, const int2* __restrict__ pt_cell, const int* __restrict__ cell_start,
-                          float4* __restrict__ sorted, float* __restrict__ aux_sorted) {
+                          float4* __restrict__ sorted, float* __restrict__ aux_sorted, GridView g, const int* __restrict__ start9) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int2 cr = pt_cell[i];
     const int pos = cell_start[cr.x] + cr.y;
     float4 p = pts[i];
-    if (aux_sorted) aux_sorted[pos] = p.w;
+    const float aux = p.w;
+    if (aux_sorted) aux_sorted[pos] = aux;
     p.w = __int_as_float(i);
     sorted[pos] = p;
+    if (!start9) return;
+    // populations of the 5x5 (y,z) block of cells of this point's x column: everything the nine destination offsets need
+    const int x = cr.x % g.nx, t = cr.x / g.nx, y = t % g.ny, z = t / g.ny;
+    int cnt[5][5];
+#pragma unroll
+    for (int b = 0; b < 5; b++)
+#pragma unroll
+        for (int a = 0; a < 5; a++) {
+            const int yy = y + a - 2, zz = z + b - 2;
+            const bool in = yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz;
+            const int* cs = cell_start + ((size_t)(in ? zz : z) * g.ny + (in ? yy : y)) * g.nx + x;
+            const int c0 = cs[0], c1 = cs[1];
+            cnt[a][b] = in ? c1 - c0 : 0;
+        }
+#pragma unroll
+    for (int dz = -1; dz <= 1; dz++)
+#pragma unroll
+        for (int dy = -1; dy <= 1; dy++) {
+            // destination super cell (x, y - dy, z - dz): this point's cell is its source k = (dz+1)*3 + (dy+1); the sources before it
+            int off = cr.y;
+#pragma unroll
+            for (int k2 = 0; k2 < (dz + 1) * 3 + (dy + 1); k2++) {
+                const int dy2 = k2 % 3 - 1, dz2 = k2 / 3 - 1;
+                off += cnt[dy2 - dy + 2][dz2 - dz + 2];
+            }
+            const int d = start9[srow_index(g, x, y - dy, z - dz)] + off;
+            sorted[d] = p;
+            if (aux_sorted) aux_sorted[d] = aux;
+        }
 }
 
 // ================================================================================================
@@ -585,7 +638,35 @@ __device__ __forceinline__ bool knn5_grid_sel(const GridView& g, TAB& tab, float
     int cx = cell_coord(qx, g.ox, g.inv_cell), cy = cell_coord(qy, g.oy, g.inv_cell), cz = cell_coord(qz, g.oz, g.inv_cell);
     // queries more than `reach` cells outside the grid cannot have a neighbour within the gate radius
     if (cx < -R || cx > g.nx - 1 + R || cy < -R || cy > g.ny - 1 + R || cz < -R || cz > g.nz - 1 + R) return false;
-    {
+    if (g.cell_start9) {
+        // Super-row layout: the inner 27 cells are ONE run of the unified array (two range words, full chunks, no row table).
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+        if (x0 <= x1 && cy >= -1 && cy <= g.ny && cz >= -1 && cz <= g.nz) {
+            const int* row = g.cell_start9 + srow_index(g, 0, cy, cz);
+            int cj = row[x0];
+            const int ce = row[x1 + 1];
+            PHASE_STAMP(pp, 2, ce);
+            auto fetch = [&](float4& p0, float4& p1, float4& p2, float4& p3, int& pj) {
+                pj = cj;
+                if (cj < ce) {
+                    const int last = ce - 1;
+                    p0 = load_pt(g, cj); p1 = load_pt(g, min(cj + 1, last)); p2 = load_pt(g, min(cj + 2, last)); p3 = load_pt(g, min(cj + 3, last));
+                    cj += 4;
+                }
+            };
+            float4 a0, a1, a2, a3, b0, b1, b2, b3;
+            int aj = 0, bj = 0;
+            fetch(a0, a1, a2, a3, aj);
+            for (;;) {
+                if (!(aj < ce)) break;
+                fetch(b0, b1, b2, b3, bj);
+                process_chunk(sel, a0, a1, a2, a3, aj, ce, qx, qy, qz);
+                if (!(bj < ce)) break;
+                fetch(a0, a1, a2, a3, aj);
+                process_chunk(sel, b0, b1, b2, b3, bj, ce, qx, qy, qz);
+            }
+        }
+    } else {
         const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
         if (x0 <= x1) {
             // All nine row ranges are fetched at once (18 independent loads); the non-empty rows go to this thread's
