@@ -21,8 +21,9 @@ __global__ void k_scan_block_sums(const int*, int64_t, int*);
 __global__ void k_scan_sums(int*, int);
 __global__ void k_scan_apply(const int*, int64_t, const int*, int*);
 __global__ void k_scan_lookback(int*, int64_t, unsigned long long*);
-__global__ void k_scatter(const float4*, int, const int2*, const int*, float4*, float*, GridView, const int*);
-__global__ void k_count9(int, const int2*, const int*, GridView, int*);
+__global__ void k_scatter(const float4*, int, const int2*, const int*, float4*, float*);
+__global__ void k_start9(const int*, GridView, int*);
+__global__ void k_scatter9(const int*, GridView, const int*, float4*, float*);
 __global__ void k_bin_count(const float4*, int, GridView, PoseArg, MatchParams, int, int, int*, int*);
 __global__ void k_bin_scatter(const int*, int, const int*, int*, int*);
 __global__ void k_tile_count(const int*, int, int*);
@@ -119,7 +120,7 @@ int lili_ctx_create(lili_ctx** out, int device, void* stream) {
     }
     bool ok = ctx->states.ensure(sizeof(SlotState) * LILI_MAX_SLOTS) == hipSuccess &&
               ctx->gram.ensure(sizeof(double) * LILI_GRAM_DOUBLES * LILI_MAX_SLOTS) == hipSuccess &&
-              ctx->misc.ensure(256) == hipSuccess &&
+              ctx->misc.ensure(128 + 64 * 128) == hipSuccess &&
 
               hipMemsetAsync(ctx->states.p, 0, sizeof(SlotState) * LILI_MAX_SLOTS, ctx->stream) == hipSuccess &&
               hipMemsetAsync(ctx->gram.p, 0, sizeof(double) * LILI_GRAM_DOUBLES * LILI_MAX_SLOTS, ctx->stream) == hipSuccess;
@@ -209,10 +210,10 @@ static int build_grid(lili_ctx* ctx, MapIndex& m, const double mn[3], const doub
     const int64_t nc9 = nx * (ny + 2) * (nz + 2);
     const bool srows = ctx->super_rows && (int64_t)n * 10 < (1ll << 28) && nc9 + 2 < (1ll << 31);
     const size_t n_all = srows ? (size_t)n * 10 : (size_t)n;
-    HIPCHK(sorted.ensure(n_all * sizeof(float4)));
+    HIPCHK(sorted.ensure((n_all + 4) * sizeof(float4)));      // + slack: the super-row walk loads whole chunks of four
     if (m.has_aux) HIPCHK(aux_sorted.ensure(n_all * sizeof(float)));
     if (srows) HIPCHK(cell_start9.ensure((size_t)(nc9 + 2) * sizeof(int)));
-    const int nb_scan = nblocks(std::max(nc, nc9 + 1), 2048);
+    const int nb_scan = nblocks(nc, 2048);
     HIPCHK(m.block_sums.ensure((size_t)(nb_scan + 2) * sizeof(unsigned long long)));
     HIPCHK(hipMemsetAsync(cell_start.p, 0, (size_t)nc * sizeof(int), ctx->stream));
     hipLaunchKernelGGL(k_cell_count, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, m.pts.as<float4>(), n, g, cell_start.as<int>(), m.pt_cell.as<int2>(), d_rank_sum);
@@ -225,16 +226,13 @@ static int build_grid(lili_ctx* ctx, MapIndex& m, const double mn[3], const doub
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, ctx->stream, m.block_sums.as<int>(), nb_scan);
         hipLaunchKernelGGL(k_scan_apply, dim3(nb_scan), dim3(kBlock), 0, ctx->stream, cell_start.as<int>(), nc, m.block_sums.as<int>(), cell_start.as<int>());
     }
-    if (srows) {      // populations of the super cells (nine atomics per non-empty cell), then their scan behind a dummy cell of n entries
-        HIPCHK(hipMemsetAsync(cell_start9.p, 0, (size_t)(nc9 + 2) * sizeof(int), ctx->stream));
-        HIPCHK(hipMemcpyAsync(cell_start9.p, &g.n_points, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_count9, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, n, m.pt_cell.as<int2>(), cell_start.as<int>(), g, cell_start9.as<int>());
-        const int nb_lb = nblocks(nc9 + 1, 4096);
-        HIPCHK(hipMemsetAsync(m.block_sums.p, 0, (size_t)(nb_lb + 2) * sizeof(unsigned long long), ctx->stream));
-        hipLaunchKernelGGL(k_scan_lookback, dim3(nb_lb), dim3(kBlock), 0, ctx->stream, cell_start9.as<int>(), nc9 + 1, m.block_sums.as<unsigned long long>());
-    }
     hipLaunchKernelGGL(k_scatter, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, m.pts.as<float4>(), n, m.pt_cell.as<int2>(), cell_start.as<int>(),
-                       sorted.as<float4>(), m.has_aux ? aux_sorted.as<float>() : nullptr, g, srows ? cell_start9.as<int>() : nullptr);
+                       sorted.as<float4>(), m.has_aux ? aux_sorted.as<float>() : nullptr);
+    if (srows) {      // positions of the super cells (straight from cell_start: no population pass, no scan), then the copy
+        hipLaunchKernelGGL(k_start9, dim3(nblocks(nx, 64), nblocks(ny + 2, 4 * 8), (unsigned)(nz + 2)), dim3(256), 0, ctx->stream, cell_start.as<int>(), g, cell_start9.as<int>());
+        hipLaunchKernelGGL(k_scatter9, dim3(nblocks(nx, 64), nblocks(ny + 2, 4), nblocks(nz + 2, 4)), dim3(1024), 0, ctx->stream, cell_start.as<int>(), g, cell_start9.as<int>(),
+                           sorted.as<float4>(), m.has_aux ? aux_sorted.as<float>() : nullptr);
+    }
     HIPCHK(hipGetLastError());
     g.pts = sorted.as<float4>();
     g.aux = m.has_aux ? aux_sorted.as<float>() : nullptr;
@@ -280,16 +278,18 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
     double cell = std::sqrt(max_sq_radius) * 1.01 * (reach == 2 ? (double)ctx->cell_pct / 100.0 : 1.0);
     if (!(cell > 1e-6)) cell = 1e-6;
     m.has_fine = false; m.fview = GridView{}; m.fbound = 0.f; m.fine_cell = 0; m.mean_occupancy = 0;
-    unsigned long long* d_rank = ctx->fine_grid ? reinterpret_cast<unsigned long long*>(ctx->misc.as<char>() + 64) : nullptr;
-    if (d_rank) HIPCHK(hipMemsetAsync(d_rank, 0, sizeof(unsigned long long), ctx->stream));
+    constexpr size_t kRankBanks = 64, kRankBytes = kRankBanks * 128;                       // k_cell_count: one bank per 128 bytes
+    unsigned long long* d_rank = ctx->fine_grid ? reinterpret_cast<unsigned long long*>(ctx->misc.as<char>() + 128) : nullptr;
+    if (d_rank) HIPCHK(hipMemsetAsync(d_rank, 0, kRankBytes, ctx->stream));
     rc = build_grid(ctx, m, mn, mx, cell, reach, m.sorted, m.aux_sorted, m.cell_start, m.cell_start9, m.view, m.n_cells, m.cell, d_rank);
     if (rc != LILI_OK) return rc;
     // Density adaptation (SURVEY §7 step 4, §8d Config 2 variant B): the point-weighted mean cell occupancy falls out of the count pass.
     // A map with many points per gate-sized cell gets a second, fine index whose cells hold ~3 points; k_associate_fine searches it first.
     if (d_rank) {
-        unsigned long long rank_sum = 0;
-        HIPCHK(hipMemcpyAsync(&rank_sum, d_rank, sizeof(rank_sum), hipMemcpyDeviceToHost, ctx->stream));
+        unsigned long long banks[kRankBanks * 16], rank_sum = 0;
+        HIPCHK(hipMemcpyAsync(banks, d_rank, kRankBytes, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (size_t b = 0; b < kRankBanks; b++) rank_sum += banks[b * 16];
         m.mean_occupancy = 1.0 + 2.0 * (double)rank_sum / (double)n;
         if (m.mean_occupancy > (double)ctx->fine_occupancy && m.cell == cell) {          // (a grid coarsened by max_cells is not refined)
             // surfaces: occupancy ~ cell^2; aim at ~3 points per fine cell, at least 4x and at most 64x finer cells per axis ... clamped

@@ -14,7 +14,7 @@ struct GridView {
     const float4* pts;      // cell-sorted map points
     const float* aux;       // cell-sorted auxiliary float (Livox reflectivity) or nullptr
     const int* cell_start;  // [n_cells + 1]
-    const int* cell_start9; // super-row index (k_scatter in lili_s2m.hip) or nullptr: [1 + nx*(ny+2)*(nz+2) + 1], positions in the unified array
+    const int* cell_start9; // super-row index (k_start9 in lili_s2m.hip) or nullptr: [nx*(ny+2)*(nz+2) + 1] positions in the unified array
     double ox, oy, oz;      // grid origin
     double inv_cell;        // 1 / cell edge
     double cell;            // 1 / inv_cell (the value the pruning bounds use)

@@ -119,14 +119,16 @@ __global__ void k_cell_count(const float4* __restrict__ pts, int n, GridView g, 
     const int rank = base + (lane - hl);
     if (i < n) pt_cell[i] = make_int2(c, rank);
     // density estimate for free: a point's rank is its position inside its cell, so sum(rank) = sum over cells of occ (occ - 1) / 2 and the
-    // point-weighted mean cell occupancy is 1 + 2 sum(rank) / n (lili_map_set decides on the fine grid with it).  One atomic per block.
+    // point-weighted mean cell occupancy is 1 + 2 sum(rank) / n (lili_map_set decides on the fine grid with it).  One atomic per block,
+    // spread over 64 banks that the host adds up.
     if (rank_sum) {
         unsigned long long r64 = i < n && c >= 0 ? (unsigned long long)rank : 0ull;
         for (int o = 32; o > 0; o >>= 1) r64 += __shfl_xor(r64, o);
         __shared__ unsigned long long wsum[kBlock / 64];
         if (lane == 0) wsum[threadIdx.x >> 6] = r64;
         __syncthreads();
-        if (threadIdx.x == 0) { unsigned long long t = 0; for (int w = 0; w < kBlock / 64; w++) t += wsum[w]; atomicAdd(rank_sum, t); }
+        // 64 banks, 128 bytes apart (same-address atomics cost ~12 ns each: 19.5 k blocks on ONE word were 0.2 ms of a 5 M-point build)
+        if (threadIdx.x == 0) { unsigned long long t = 0; for (int w = 0; w < kBlock / 64; w++) t += wsum[w]; atomicAdd(rank_sum + (size_t)(blockIdx.x & 63) * 16, t); }
     }
 }
 
@@ -259,65 +261,116 @@ __global__ __launch_bounds__(kBlock) void k_scan_lookback(int* data, int64_t n, 
 // x cell — "super cell" (x, y', z') holds the points of the nine cells (x, y'+dy, z'+dz) in the fixed order k = (dz+1)*3 + (dy+1), each in
 // its base order.  The 27-cell neighbourhood of a query in cell (cx, cy, cz) is then ONE contiguous run: super cells cx-1..cx+1 of super-row
 // (cy, cz) — two range words instead of eighteen, no row table, no per-row bounds, full chunks.  The super-row grid has one more row on each
-// side in y and z (queries up to one cell outside the map still have an inner block); start9 is its exclusive scan with one leading dummy
-// cell of n_points entries, so the positions it yields index the unified array [base points | super-row points] directly.
+// side in y and z (queries up to one cell outside the map still have an inner block), so every point is stored exactly nine times and the
+// unified array [base points | super-row points] has 10 n entries; start9 holds positions in that array.
 __device__ __forceinline__ size_t srow_index(const GridView& g, int x, int y, int z) {
-    return (size_t)1 + ((size_t)(z + 1) * (size_t)(g.ny + 2) + (size_t)(y + 1)) * (size_t)g.nx + (size_t)x;
+    return ((size_t)(z + 1) * (size_t)(g.ny + 2) + (size_t)(y + 1)) * (size_t)g.nx + (size_t)x;
 }
-// The first point of every non-empty cell (rank 0) adds the cell's population to the nine super cells that contain it.
-__global__ void k_count9(int n, const int2* __restrict__ pt_cell, const int* __restrict__ cell_start, GridView g, int* __restrict__ start9) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int2 cr = pt_cell[i];
-    if (cr.y != 0) return;
-    const int cnt = cell_start[cr.x + 1] - cell_start[cr.x];
-    const int x = cr.x % g.nx, t = cr.x / g.nx, y = t % g.ny, z = t / g.ny;
+// start9 needs neither a population pass nor a scan: in super-grid order (z', y', x) the source rows (z'+dz, y'+dy) of one (dy, dz) are
+// visited in the base grid's own order, every base row exactly once, so the number of copies stored before super cell (x, y', z') is the
+// sum over the nine (dy, dz) of the base prefix cell_start[(x, y'+dy, z'+dz)] — clamped to the begin of the plane / of the next plane / 0 / n
+// where the source row lies outside the grid.  One wave per (64 x cells, kS9Rows super-rows, plane z'): (kS9Rows + 2) x 3 row loads.
+constexpr int kS9Rows = 8;
+__global__ __launch_bounds__(256) void k_start9(const int* __restrict__ cell_start, GridView g, int* __restrict__ start9) {
+    const int lane = threadIdx.x & 63;
+    const int x = blockIdx.x * 64 + lane;
+    const int zs = (int)blockIdx.z - 1;                                             // z' of the super cells
+    const int y0 = ((int)blockIdx.y * 4 + (int)(threadIdx.x >> 6)) * kS9Rows - 1;   // first y' of this wave
+    if (y0 > g.ny) return;
+    const int xc = min(x, g.nx - 1);
+    const size_t plane = (size_t)g.ny * g.nx;
+    int c3[kS9Rows + 2];                                                            // per source row y: sum over the three planes
 #pragma unroll
-    for (int dz = -1; dz <= 1; dz++)
+    for (int r = 0; r < kS9Rows + 2; r++) {
+        const int y = y0 - 1 + r;
+        int s = 0;
 #pragma unroll
-        for (int dy = -1; dy <= 1; dy++) atomicAdd(&start9[srow_index(g, x, y - dy, z - dz)], cnt);
+        for (int dz = -1; dz <= 1; dz++) {
+            const int z = zs + dz;
+            size_t idx;
+            if (z < 0) idx = 0;                                   // cell_start[0] = 0
+            else if (z >= g.nz) idx = plane * g.nz;               // = n
+            else if (y < 0) idx = plane * z;                      // begin of the plane
+            else if (y >= g.ny) idx = plane * (z + 1);            // begin of the next plane
+            else idx = plane * z + (size_t)y * g.nx + xc;
+            s += cell_start[idx];
+        }
+        c3[r] = s;
+    }
+    if (x >= g.nx) return;
+#pragma unroll
+    for (int k = 0; k < kS9Rows; k++) {
+        const int ys = y0 + k;
+        if (ys <= g.ny) start9[srow_index(g, x, ys, zs)] = g.n_points + c3[k] + c3[k + 1] + c3[k + 2];
+    }
+    if (x == 0 && zs == g.nz && y0 <= g.ny && y0 + kS9Rows > g.ny) start9[srow_index(g, 0, g.ny, g.nz) + g.nx] = 10 * g.n_points;   // end of the array
 }
 
 __global__ void k_scatter(const float4* __restrict__ pts, int n, const int2* __restrict__ pt_cell, const int* __restrict__ cell_start,
-                          float4* __restrict__ sorted, float* __restrict__ aux_sorted, GridView g, const int* __restrict__ start9) {
+                          float4* __restrict__ sorted, float* __restrict__ aux_sorted) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int2 cr = pt_cell[i];
     const int pos = cell_start[cr.x] + cr.y;
     float4 p = pts[i];
-    const float aux = p.w;
-    if (aux_sorted) aux_sorted[pos] = aux;
+    if (aux_sorted) aux_sorted[pos] = p.w;
     p.w = __int_as_float(i);
     sorted[pos] = p;
-    if (!start9) return;
-    // populations of the 5x5 (y,z) block of cells of this point's x column: everything the nine destination offsets need
-    const int x = cr.x % g.nx, t = cr.x / g.nx, y = t % g.ny, z = t / g.ny;
-    int cnt[5][5];
+}
+
+// Super-row copy, by DESTINATION: one wave owns the stretch of 64 consecutive super cells (x0..x0+63, y', z') — a contiguous piece of the
+// super-row array — and fills it from its nine source rows, each a contiguous run of the base array.  The nine runs are walked as ONE
+// sequence, 64 points per trip; a point finds its super cell through its own x cell and its place through a 9 x 64 table (LDS) of
+// "destination minus source" per (source row, cell).  The 16 waves of a workgroup take a 4 x 4 tile of (y', z'), whose 36 source rows
+// they share through the L2 of the XCD the workgroup runs on.
+__global__ __launch_bounds__(1024) void k_scatter9(const int* __restrict__ cell_start, GridView g, const int* __restrict__ start9,
+                                                   float4* __restrict__ sorted, float* __restrict__ aux_sorted) {
+    __shared__ int delta[16][9][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int x0 = blockIdx.x * 64;
+    const int ys = (int)blockIdx.y * 4 + (w & 3) - 1;
+    const int zs = (int)blockIdx.z * 4 + (w >> 2) - 1;
+    if (ys > g.ny || zs > g.nz) return;
+    const int xn = min(64, g.nx - x0);                     // cells of this stretch
+    const int* s9 = start9 + srow_index(g, x0, ys, zs);
+    const int lc = min(lane, xn - 1);
+    int dnext = s9[lc];                                    // where the next source's points of cell x0+lane go
+    const int d_end = s9[xn];
+    const int D0 = __shfl(dnext, 0);
+    const int len = d_end - D0;
+    if (len == 0) return;                                  // nothing lives here
+    int off[9], pre[10];
+    pre[0] = 0;
 #pragma unroll
-    for (int b = 0; b < 5; b++)
+    for (int k = 0; k < 9; k++) {
+        const int y = ys + k % 3 - 1, z = zs + k / 3 - 1;
+        const bool in = y >= 0 && y < g.ny && z >= 0 && z < g.nz;
+        const int* cs = cell_start + ((size_t)(in ? z : 0) * g.ny + (in ? y : 0)) * g.nx + x0;
+        const int a = cs[lc], b = cs[lc + 1], e = cs[xn];
+        delta[w][k][lane] = dnext - a;
+        dnext += in ? b - a : 0;
+        const int rb = in ? __shfl(a, 0) : 0, re = in ? e : 0;
+        off[k] = rb - pre[k];                              // position in the base array = position in the merged sequence + off[k]
+        pre[k + 1] = pre[k] + (re - rb);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int t0 = 0; t0 < len; t0 += 64) {                 // pre[9] == len
+        const int t = t0 + lane;
+        const bool live = t < len;
+        int k = 0, o = off[0];
 #pragma unroll
-        for (int a = 0; a < 5; a++) {
-            const int yy = y + a - 2, zz = z + b - 2;
-            const bool in = yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz;
-            const int* cs = cell_start + ((size_t)(in ? zz : z) * g.ny + (in ? yy : y)) * g.nx + x;
-            const int c0 = cs[0], c1 = cs[1];
-            cnt[a][b] = in ? c1 - c0 : 0;
-        }
-#pragma unroll
-    for (int dz = -1; dz <= 1; dz++)
-#pragma unroll
-        for (int dy = -1; dy <= 1; dy++) {
-            // destination super cell (x, y - dy, z - dz): this point's cell is its source k = (dz+1)*3 + (dy+1); the sources before it
-            int off = cr.y;
-#pragma unroll
-            for (int k2 = 0; k2 < (dz + 1) * 3 + (dy + 1); k2++) {
-                const int dy2 = k2 % 3 - 1, dz2 = k2 / 3 - 1;
-                off += cnt[dy2 - dy + 2][dz2 - dz + 2];
-            }
-            const int d = start9[srow_index(g, x, y - dy, z - dz)] + off;
+        for (int i = 1; i < 9; i++) { const bool ge = t >= pre[i]; k += ge ? 1 : 0; o = ge ? off[i] : o; }
+        const int j = live ? t + o : 0;
+        const float4 p = sorted[j];
+        int xc = 0;
+        if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) xc = min(max(cell_coord(p.x, g.ox, g.inv_cell), 0), g.nx - 1);   // as cell_of
+        const int l = min(max(xc - x0, 0), 63);
+        const int d = j + delta[w][k][l];
+        if (live) {
             sorted[d] = p;
-            if (aux_sorted) aux_sorted[d] = aux;
+            if (aux_sorted) aux_sorted[d] = aux_sorted[j];
         }
+    }
 }
 
 // ================================================================================================
@@ -648,9 +701,9 @@ __device__ __forceinline__ bool knn5_grid_sel(const GridView& g, TAB& tab, float
             PHASE_STAMP(pp, 2, ce);
             auto fetch = [&](float4& p0, float4& p1, float4& p2, float4& p3, int& pj) {
                 pj = cj;
-                if (cj < ce) {
-                    const int last = ce - 1;
-                    p0 = load_pt(g, cj); p1 = load_pt(g, min(cj + 1, last)); p2 = load_pt(g, min(cj + 2, last)); p3 = load_pt(g, min(cj + 3, last));
+                if (cj < ce) {      // slots past the run's end read the following entries (the array has 4 entries of slack) and are masked by position
+                    const float4* q = (const float4*)((const char*)g.pts + ((unsigned)cj << 4));
+                    p0 = q[0]; p1 = q[1]; p2 = q[2]; p3 = q[3];
                     cj += 4;
                 }
             };
