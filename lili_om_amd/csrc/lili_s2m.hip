@@ -787,6 +787,14 @@ __device__ __forceinline__ bool knn5_grid_sel(const GridView& g, TAB& tab, float
         const double fzm = (double)qz - (g.oz + (double)cz * c), fzp = (g.oz + (double)(cz + 1) * c) - (double)qz;
         const double margin = c + fmax(fmin(fmin(fmin(fxm, fxp), fmin(fym, fyp)), fmin(fzm, fzp)), 0.0);
         if (!(sel.worst() < (float)(0.999 * margin * margin))) {
+            // super-row layout: the 18 single-cell runs x = cx -+ 2 of the nine inner rows are two runs (one super cell each)
+            const bool side9 = g.cell_start9 && cy >= -1 && cy <= g.ny && cz >= -1 && cz <= g.nz;
+            if (side9) {
+                const int* row = g.cell_start9 + srow_index(g, 0, cy, cz);
+                const int xl = cx - 2, xr = cx + 2;
+                if (xl >= 0 && xl < g.nx) { const double gx = fmax(fxm + c, 0.0); if (!((float)(0.999 * gx * gx) > sel.worst())) scan_run(g, sel, row[xl], row[xl + 1], qx, qy, qz); }
+                if (xr >= 0 && xr < g.nx) { const double gx = fmax(fxp + c, 0.0); if (!((float)(0.999 * gx * gx) > sel.worst())) scan_run(g, sel, row[xr], row[xr + 1], qx, qy, qz); }
+            }
             for (int dz = -2; dz <= 2; dz++) {
                 const int z = cz + dz;
                 if (z < 0 || z >= g.nz) continue;
@@ -806,7 +814,7 @@ __device__ __forceinline__ bool knn5_grid_sel(const GridView& g, TAB& tab, float
                         const int dr = (float)(lbr + 0.999 * g2p * g2p) > wv ? ((float)(lbr + 0.999 * g1p * g1p) > wv ? 0 : 1) : 2;
                         const int x0 = max(cx - dl, 0), x1 = min(cx + dr, g.nx - 1);
                         if (x0 <= x1) scan_run(g, sel, cs[x0], cs[x1 + 1], qx, qy, qz);
-                    } else {                                                     // inner row: only its two outer cells are new
+                    } else if (!side9) {                                         // inner row: only its two outer cells are new
                         const int xl = cx - 2, xr = cx + 2;
                         if (xl >= 0 && xl < g.nx) { double gx = fmax(fxm + c, 0.0); if (!((float)(lbr + 0.999 * gx * gx) > sel.worst())) scan_run(g, sel, cs[xl], cs[xl + 1], qx, qy, qz); }
                         if (xr >= 0 && xr < g.nx) { double gx = fmax(fxp + c, 0.0); if (!((float)(lbr + 0.999 * gx * gx) > sel.worst())) scan_run(g, sel, cs[xr], cs[xr + 1], qx, qy, qz); }
