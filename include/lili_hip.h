@@ -130,6 +130,14 @@ int lili_map_info(lili_ctx* ctx, int kind, int64_t* n_points, int64_t* n_cells, 
  * down-sampled at L:1488-1511 — leaf sizes down to centimetres make a gate-sized cell hold hundreds of points). */
 int lili_map_density(lili_ctx* ctx, int kind, double* mean_occupancy, double* fine_cell_edge, double* fine_sq_radius);
 
+/* Performance hint (no reference counterpart: pcl::KdTreeFLANN indexes the whole cloud it is given, L/src/BackendFusion.cpp:839-840): a local
+ * map may cover far more ground than one scan reaches.  lili_map_set stores, next to the cell-sorted points, a "super-row" copy in which the
+ * 27-cell neighbourhood of a query is one contiguous run (option "super_rows", 9x the points); with a focus, that copy is built only for the
+ * cells within `radius` of `center` (map frame; e.g. the sensor position and its maximum range + the pose uncertainty) at the following
+ * lili_map_set calls.  Queries elsewhere take the nine-row walk over the base index: results never depend on the hint.  radius <= 0 or
+ * center == NULL: the whole map again. */
+int lili_map_focus(lili_ctx* ctx, const double center[3], double radius);
+
 /* ---- feature extraction ----------------------------------------------------------------------- */
 
 /* Caller-owned output cloud: `capacity` points of `stride` bytes (>= 16; 32 for pcl::PointXYZI, whose x,y,z

@@ -106,6 +106,7 @@ _SIGS = {
     "lili_localmap_commit": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_double, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "lili_map_set": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Cloud), C.c_double]),
     "lili_map_density": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "lili_map_focus": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_double]),
     "lili_map_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "lili_s2m_set_queries": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Cloud)]),
     "lili_s2m_associate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(S2MParams), C.POINTER(C.c_int)]),
@@ -282,6 +283,14 @@ class ScanToMapMatcher:
         n, nc, ce = C.c_int64(), C.c_int64(), C.c_double()
         self.ctx._chk(self.lib.lili_map_info(self.ctx.h, kind, C.byref(n), C.byref(nc), C.byref(ce)))
         return n.value, nc.value, ce.value
+
+    def map_focus(self, center=None, radius=0.0):
+        """Hint for the following set_input_cloud calls: build the super-row copy only within `radius` of `center` (None / 0: everywhere)."""
+        if center is None or not radius > 0:
+            self.ctx._chk(self.lib.lili_map_focus(self.ctx.h, None, 0.0))
+        else:
+            c = (C.c_double * 3)(*[float(v) for v in center])
+            self.ctx._chk(self.lib.lili_map_focus(self.ctx.h, c, float(radius)))
 
     def map_density(self, kind):
         """(mean points per gate-sized cell, fine cell edge or 0, squared radius covered by the fine index or 0)."""

@@ -22,7 +22,8 @@ __global__ void k_scan_sums(int*, int);
 __global__ void k_scan_apply(const int*, int64_t, const int*, int*);
 __global__ void k_scan_lookback(int*, int64_t, unsigned long long*);
 __global__ void k_scatter(const float4*, int, const int2*, const int*, float4*, float*);
-__global__ void k_start9(const int*, GridView, int*);
+__global__ void k_start9(const int*, GridView, const int*, int*);
+__global__ void k_rowtot9(const int*, GridView, int*);
 __global__ void k_scatter9(const int*, GridView, const int*, float4*, float*);
 __global__ void k_bin_count(const float4*, int, GridView, PoseArg, MatchParams, int, int, int*, int*);
 __global__ void k_bin_scatter(const int*, int, const int*, int*, int*);
@@ -133,7 +134,7 @@ void lili_ctx_destroy(lili_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (auto& m : ctx->map) { m.sorted_f.release(); m.aux_sorted_f.release(); m.cell_start_f.release(); m.cell_start9.release(); m.cell_start9_f.release(); m.pts.release(); m.sorted.release(); m.aux_sorted.release(); m.cell_start.release(); m.cell_tmp.release(); m.pt_cell.release(); m.block_sums.release(); }
+    for (auto& m : ctx->map) { m.sorted_f.release(); m.aux_sorted_f.release(); m.cell_start_f.release(); m.cell_start9.release(); m.cell_start9_f.release(); m.row9.release(); m.pts.release(); m.sorted.release(); m.aux_sorted.release(); m.cell_start.release(); m.cell_tmp.release(); m.pt_cell.release(); m.block_sums.release(); }
     for (auto& s : ctx->slots) for (auto& k : s.k) { k.q.release(); k.rec0.release(); k.rec1.release(); k.valid.release(); k.dbg_idx.release(); k.dbg_d2.release(); k.partials.release(); k.perm.release(); k.keys.release(); k.block_counts.release(); k.tiles.release(); }
     ctx->states.release(); ctx->staging.release(); ctx->gram.release(); ctx->misc.release(); ctx->bin_hist.release(); ctx->bin_start.release(); ctx->bin_sums.release(); ctx->bin_tcnt.release(); ctx->bin_toff.release();
     if (ctx->ext_rot && ctx->ext_rot_free) ctx->ext_rot_free(ctx->ext_rot);
@@ -206,13 +207,25 @@ static int build_grid(lili_ctx* ctx, MapIndex& m, const double mn[3], const doub
     // ONE cell array: counts -> (in-place exclusive scan) -> cell_start; the atomic of the count pass also hands every point its rank
     HIPCHK(cell_start.ensure((size_t)(nc + 1) * sizeof(int)));
     HIPCHK(m.pt_cell.ensure((size_t)n * sizeof(int2)));
-    // super-rows: the sorted array continues with the 3x3-row copy (<= 9n entries); positions stay 32-bit byte offsets, so 10n < 2^28
-    const int64_t nc9 = nx * (ny + 2) * (nz + 2);
+    // super-rows: the sorted array continues with the 3x3-row copy of the box (<= 9n entries); positions stay 32-bit byte offsets, so 10n < 2^28.
+    // The box: the whole grid, or the cells within the focus radius (+ one gate radius and a cell) of the focus point.
+    int b0[3] = {0, 0, 0}, b1[3] = {(int)nx - 1, (int)ny - 1, (int)nz - 1};
+    if (ctx->focus_radius > 0) {
+        const int64_t dims[3] = {nx, ny, nz};
+        for (int k = 0; k < 3; k++) {
+            const double lo = (ctx->focus[k] - ctx->focus_radius - mn[k]) / cell - 2.0, hi = (ctx->focus[k] + ctx->focus_radius - mn[k]) / cell + 2.0;
+            b0[k] = (int)std::min(std::max(std::floor(lo), 0.0), (double)(dims[k] - 1));
+            b1[k] = (int)std::min(std::max(std::floor(hi), (double)b0[k]), (double)(dims[k] - 1));
+        }
+    }
+    g.bx0 = b0[0]; g.by0 = b0[1]; g.bz0 = b0[2];
+    g.bnx = b1[0] - b0[0] + 1; g.bny = b1[1] - b0[1] + 1; g.bnz = b1[2] - b0[2] + 1;
+    const int64_t nc9 = (int64_t)g.bnx * g.bny * g.bnz, rows9 = (int64_t)g.bny * g.bnz;
     const bool srows = ctx->super_rows && (int64_t)n * 10 < (1ll << 28) && nc9 + 2 < (1ll << 31);
     const size_t n_all = srows ? (size_t)n * 10 : (size_t)n;
     HIPCHK(sorted.ensure((n_all + 4) * sizeof(float4)));      // + slack: the super-row walk loads whole chunks of four
     if (m.has_aux) HIPCHK(aux_sorted.ensure(n_all * sizeof(float)));
-    if (srows) HIPCHK(cell_start9.ensure((size_t)(nc9 + 2) * sizeof(int)));
+    if (srows) { HIPCHK(cell_start9.ensure((size_t)(nc9 + 2) * sizeof(int))); HIPCHK(m.row9.ensure((size_t)(rows9 + 2) * sizeof(int))); }
     const int nb_scan = nblocks(nc, 2048);
     HIPCHK(m.block_sums.ensure((size_t)(nb_scan + 2) * sizeof(unsigned long long)));
     HIPCHK(hipMemsetAsync(cell_start.p, 0, (size_t)nc * sizeof(int), ctx->stream));
@@ -228,9 +241,14 @@ static int build_grid(lili_ctx* ctx, MapIndex& m, const double mn[3], const doub
     }
     hipLaunchKernelGGL(k_scatter, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, m.pts.as<float4>(), n, m.pt_cell.as<int2>(), cell_start.as<int>(),
                        sorted.as<float4>(), m.has_aux ? aux_sorted.as<float>() : nullptr);
-    if (srows) {      // positions of the super cells (straight from cell_start: no population pass, no scan), then the copy
-        hipLaunchKernelGGL(k_start9, dim3(nblocks(nx, 64), nblocks(ny + 2, 4 * 8), (unsigned)(nz + 2)), dim3(256), 0, ctx->stream, cell_start.as<int>(), g, cell_start9.as<int>());
-        hipLaunchKernelGGL(k_scatter9, dim3(nblocks(nx, 64), nblocks(ny + 2, 4), nblocks(nz + 2, 4)), dim3(1024), 0, ctx->stream, cell_start.as<int>(), g, cell_start9.as<int>(),
+    if (srows) {      // first positions of the super-rows (populations -> scan), positions of the super cells, then the copy
+        hipLaunchKernelGGL(k_rowtot9, dim3(nblocks(rows9, kBlock)), dim3(kBlock), 0, ctx->stream, cell_start.as<int>(), g, m.row9.as<int>());
+        const int nb_lb = nblocks(rows9, 4096);
+        HIPCHK(hipMemsetAsync(m.block_sums.p, 0, (size_t)(nb_lb + 2) * sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(k_scan_lookback, dim3(nb_lb), dim3(kBlock), 0, ctx->stream, m.row9.as<int>(), rows9, m.block_sums.as<unsigned long long>());
+        hipLaunchKernelGGL(k_start9, dim3(nblocks(g.bnx, 64), nblocks(g.bny, 4 * 8), (unsigned)g.bnz), dim3(256), 0, ctx->stream, cell_start.as<int>(), g, m.row9.as<int>(),
+                           cell_start9.as<int>());
+        hipLaunchKernelGGL(k_scatter9, dim3(nblocks(g.bnx, 64), nblocks(g.bny, 4), nblocks(g.bnz, 4)), dim3(1024), 0, ctx->stream, cell_start.as<int>(), g, cell_start9.as<int>(),
                            sorted.as<float4>(), m.has_aux ? aux_sorted.as<float>() : nullptr);
     }
     HIPCHK(hipGetLastError());
@@ -305,6 +323,17 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
         }
     }
     m.valid = true;
+    return LILI_OK;
+}
+
+// Performance hint for maps much larger than a scan's footprint: the super-row copy (9x the points) is built only for the cells within
+// `radius` of `center` at the following lili_map_set calls; queries elsewhere take the nine-row walk.  Results never depend on it.
+int lili_map_focus(lili_ctx* ctx, const double center[3], double radius) {
+    if (!ctx) return LILI_E_ARG;
+    if (!(radius > 0) || !center) { ctx->focus_radius = 0; return LILI_OK; }
+    ARGCHK(std::isfinite(center[0]) && std::isfinite(center[1]) && std::isfinite(center[2]) && std::isfinite(radius), "map_focus: non-finite argument");
+    for (int k = 0; k < 3; k++) ctx->focus[k] = center[k];
+    ctx->focus_radius = radius;
     return LILI_OK;
 }
 

@@ -39,7 +39,7 @@ struct MapIndex {
     int64_t n = 0, n_cells = 0;
     double cell = 0;
     GridView view{};
-    DevBuf pts, sorted, aux_sorted, cell_start, cell_tmp, pt_cell, block_sums, cell_start9;
+    DevBuf pts, sorted, aux_sorted, cell_start, cell_tmp, pt_cell, block_sums, cell_start9, row9;
     bool has_aux = false;
     // density adaptation: a second index with cells sized from the measured density (dense maps only), searched first
     bool has_fine = false;
@@ -107,6 +107,7 @@ struct lili_ctx {
     int cell_pct = 65;           // reach 2: cell edge in % of 1.01 * gate radius (>= 50)
     bool fine_grid = true;       // measure the map density in lili_map_set and build the fine index when a gate-sized cell holds more than fine_occupancy points
     int fine_occupancy = 12;
+    double focus[3] = {0, 0, 0}, focus_radius = 0;   // lili_map_focus: where the super-row copy is built (radius 0: everywhere)
     bool super_rows = true;      // lili_map_set also stores the super-row copy of the map (9x the points): the inner 27-cell block of a query is one run
     bool scan_lookback = true;   // map index: single-pass (decoupled look-back) scan of the cell array; 0 = the three-kernel scan (A/B)
     int rot_atan = 2;            // ROT extractor: 2 = glibc fdlibm float atan / atan2 (the reference build's bits), 1 = f64 functions rounded to f32

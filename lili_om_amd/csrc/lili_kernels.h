@@ -14,7 +14,8 @@ struct GridView {
     const float4* pts;      // cell-sorted map points
     const float* aux;       // cell-sorted auxiliary float (Livox reflectivity) or nullptr
     const int* cell_start;  // [n_cells + 1]
-    const int* cell_start9; // super-row index (k_start9 in lili_s2m.hip) or nullptr: [nx*(ny+2)*(nz+2) + 1] positions in the unified array
+    const int* cell_start9; // super-row index (k_start9 in lili_s2m.hip) or nullptr: [bnx*bny*bnz + 1] positions in the unified array
+    int bx0, by0, bz0, bnx, bny, bnz;   // the box of cells that has super-rows (the whole grid, or the cells around lili_map_focus)
     double ox, oy, oz;      // grid origin
     double inv_cell;        // 1 / cell edge
     double cell;            // 1 / inv_cell (the value the pruning bounds use)

@@ -260,26 +260,38 @@ __global__ __launch_bounds__(kBlock) void k_scan_lookback(int* data, int64_t n, 
 // Super-rows: a second copy of the map in which the points of the 3x3 (y,z) rows around a row are stored together, sorted by
 // x cell — "super cell" (x, y', z') holds the points of the nine cells (x, y'+dy, z'+dz) in the fixed order k = (dz+1)*3 + (dy+1), each in
 // its base order.  The 27-cell neighbourhood of a query in cell (cx, cy, cz) is then ONE contiguous run: super cells cx-1..cx+1 of super-row
-// (cy, cz) — two range words instead of eighteen, no row table, no per-row bounds, full chunks.  The super-row grid has one more row on each
-// side in y and z (queries up to one cell outside the map still have an inner block), so every point is stored exactly nine times and the
-// unified array [base points | super-row points] has 10 n entries; start9 holds positions in that array.
+// (cy, cz) — two range words instead of eighteen, no row table, no per-row bounds, full chunks.  Super-rows exist for the cells of a box
+// (bx0.., by0.., bz0..; the whole grid unless lili_map_focus names a region): queries elsewhere take the nine-row walk.  The copy lives behind
+// the base points in the same array ([base | super-rows], at most 10 n entries); start9 holds positions in that array.
 __device__ __forceinline__ size_t srow_index(const GridView& g, int x, int y, int z) {
-    return ((size_t)(z + 1) * (size_t)(g.ny + 2) + (size_t)(y + 1)) * (size_t)g.nx + (size_t)x;
+    return ((size_t)(z - g.bz0) * (size_t)g.bny + (size_t)(y - g.by0)) * (size_t)g.bnx + (size_t)(x - g.bx0);
 }
-// start9 needs neither a population pass nor a scan: in super-grid order (z', y', x) the source rows (z'+dz, y'+dy) of one (dy, dz) are
-// visited in the base grid's own order, every base row exactly once, so the number of copies stored before super cell (x, y', z') is the
-// sum over the nine (dy, dz) of the base prefix cell_start[(x, y'+dy, z'+dz)] — clamped to the begin of the plane / of the next plane / 0 / n
-// where the source row lies outside the grid.  One wave per (64 x cells, kS9Rows super-rows, plane z'): (kS9Rows + 2) x 3 row loads.
+// Population of every super-row of the box (its nine source rows, box columns only); the scan of these is the row's first position.
+__global__ void k_rowtot9(const int* __restrict__ cell_start, GridView g, int* __restrict__ rowtot) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= g.bny * g.bnz) return;
+    const int ys = g.by0 + r % g.bny, zs = g.bz0 + r / g.bny;
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const int y = ys + k % 3 - 1, z = zs + k / 3 - 1;
+        if (y < 0 || y >= g.ny || z < 0 || z >= g.nz) continue;
+        const int* cs = cell_start + ((size_t)z * g.ny + y) * g.nx + g.bx0;
+        s += cs[g.bnx] - cs[0];
+    }
+    rowtot[r] = s;
+}
+// start9[(x, y', z')] = n + first position of the super-row + points of its nine source rows in the box columns before x.
+// One wave per (64 x cells, kS9Rows super-rows, plane z'): (kS9Rows + 2) x 3 row loads, shared by the rows of the wave.
 constexpr int kS9Rows = 8;
-__global__ __launch_bounds__(256) void k_start9(const int* __restrict__ cell_start, GridView g, int* __restrict__ start9) {
+__global__ __launch_bounds__(256) void k_start9(const int* __restrict__ cell_start, GridView g, const int* __restrict__ rowbase, int* __restrict__ start9) {
     const int lane = threadIdx.x & 63;
-    const int x = blockIdx.x * 64 + lane;
-    const int zs = (int)blockIdx.z - 1;                                             // z' of the super cells
-    const int y0 = ((int)blockIdx.y * 4 + (int)(threadIdx.x >> 6)) * kS9Rows - 1;   // first y' of this wave
-    if (y0 > g.ny) return;
-    const int xc = min(x, g.nx - 1);
-    const size_t plane = (size_t)g.ny * g.nx;
-    int c3[kS9Rows + 2];                                                            // per source row y: sum over the three planes
+    const int x = g.bx0 + blockIdx.x * 64 + lane;
+    const int zs = g.bz0 + (int)blockIdx.z;
+    const int y0 = g.by0 + ((int)blockIdx.y * 4 + (int)(threadIdx.x >> 6)) * kS9Rows;   // first y' of this wave
+    if (y0 >= g.by0 + g.bny) return;
+    const int xc = min(x, g.bx0 + g.bnx - 1);
+    int c3[kS9Rows + 2];                                                            // per source row y: box-relative prefix at x, summed over the three planes
 #pragma unroll
     for (int r = 0; r < kS9Rows + 2; r++) {
         const int y = y0 - 1 + r;
@@ -287,23 +299,21 @@ __global__ __launch_bounds__(256) void k_start9(const int* __restrict__ cell_sta
 #pragma unroll
         for (int dz = -1; dz <= 1; dz++) {
             const int z = zs + dz;
-            size_t idx;
-            if (z < 0) idx = 0;                                   // cell_start[0] = 0
-            else if (z >= g.nz) idx = plane * g.nz;               // = n
-            else if (y < 0) idx = plane * z;                      // begin of the plane
-            else if (y >= g.ny) idx = plane * (z + 1);            // begin of the next plane
-            else idx = plane * z + (size_t)y * g.nx + xc;
-            s += cell_start[idx];
+            const bool in = y >= 0 && y < g.ny && z >= 0 && z < g.nz;
+            const int* cs = cell_start + ((size_t)(in ? z : 0) * g.ny + (in ? y : 0)) * g.nx;
+            const int a = cs[g.bx0], b = cs[xc];
+            s += in ? b - a : 0;
         }
         c3[r] = s;
     }
-    if (x >= g.nx) return;
+    if (x >= g.bx0 + g.bnx) return;
 #pragma unroll
     for (int k = 0; k < kS9Rows; k++) {
         const int ys = y0 + k;
-        if (ys <= g.ny) start9[srow_index(g, x, ys, zs)] = g.n_points + c3[k] + c3[k + 1] + c3[k + 2];
+        if (ys < g.by0 + g.bny) start9[srow_index(g, x, ys, zs)] = g.n_points + rowbase[(zs - g.bz0) * g.bny + (ys - g.by0)] + c3[k] + c3[k + 1] + c3[k + 2];
     }
-    if (x == 0 && zs == g.nz && y0 <= g.ny && y0 + kS9Rows > g.ny) start9[srow_index(g, 0, g.ny, g.nz) + g.nx] = 10 * g.n_points;   // end of the array
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
+        start9[(size_t)g.bnx * g.bny * g.bnz] = g.n_points + rowbase[g.bny * g.bnz];          // end of the array
 }
 
 __global__ void k_scatter(const float4* __restrict__ pts, int n, const int2* __restrict__ pt_cell, const int* __restrict__ cell_start,
@@ -327,11 +337,11 @@ __global__ __launch_bounds__(1024) void k_scatter9(const int* __restrict__ cell_
                                                    float4* __restrict__ sorted, float* __restrict__ aux_sorted) {
     __shared__ int delta[16][9][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int x0 = blockIdx.x * 64;
-    const int ys = (int)blockIdx.y * 4 + (w & 3) - 1;
-    const int zs = (int)blockIdx.z * 4 + (w >> 2) - 1;
-    if (ys > g.ny || zs > g.nz) return;
-    const int xn = min(64, g.nx - x0);                     // cells of this stretch
+    const int x0 = g.bx0 + blockIdx.x * 64;
+    const int ys = g.by0 + (int)blockIdx.y * 4 + (w & 3);
+    const int zs = g.bz0 + (int)blockIdx.z * 4 + (w >> 2);
+    if (ys >= g.by0 + g.bny || zs >= g.bz0 + g.bnz) return;
+    const int xn = min(64, g.bx0 + g.bnx - x0);            // cells of this stretch
     const int* s9 = start9 + srow_index(g, x0, ys, zs);
     const int lc = min(lane, xn - 1);
     int dnext = s9[lc];                                    // where the next source's points of cell x0+lane go
@@ -691,11 +701,14 @@ __device__ __forceinline__ bool knn5_grid_sel(const GridView& g, TAB& tab, float
     int cx = cell_coord(qx, g.ox, g.inv_cell), cy = cell_coord(qy, g.oy, g.inv_cell), cz = cell_coord(qz, g.oz, g.inv_cell);
     // queries more than `reach` cells outside the grid cannot have a neighbour within the gate radius
     if (cx < -R || cx > g.nx - 1 + R || cy < -R || cy > g.ny - 1 + R || cz < -R || cz > g.nz - 1 + R) return false;
-    if (g.cell_start9) {
+    // the query's inner block lies in the box that has super-rows (x0 > x1: nothing to search either way)
+    const bool inner9 = g.cell_start9 && cy >= g.by0 && cy < g.by0 + g.bny && cz >= g.bz0 && cz < g.bz0 + g.bnz &&
+                        max(cx - 1, 0) >= g.bx0 && min(cx + 1, g.nx - 1) < g.bx0 + g.bnx;
+    if (inner9) {
         // Super-row layout: the inner 27 cells are ONE run of the unified array (two range words, full chunks, no row table).
         const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
-        if (x0 <= x1 && cy >= -1 && cy <= g.ny && cz >= -1 && cz <= g.nz) {
-            const int* row = g.cell_start9 + srow_index(g, 0, cy, cz);
+        if (x0 <= x1) {
+            const int* row = g.cell_start9 + srow_index(g, g.bx0, cy, cz) - g.bx0;
             int cj = row[x0];
             const int ce = row[x1 + 1];
             PHASE_STAMP(pp, 2, ce);
@@ -788,9 +801,9 @@ __device__ __forceinline__ bool knn5_grid_sel(const GridView& g, TAB& tab, float
         const double margin = c + fmax(fmin(fmin(fmin(fxm, fxp), fmin(fym, fyp)), fmin(fzm, fzp)), 0.0);
         if (!(sel.worst() < (float)(0.999 * margin * margin))) {
             // super-row layout: the 18 single-cell runs x = cx -+ 2 of the nine inner rows are two runs (one super cell each)
-            const bool side9 = g.cell_start9 && cy >= -1 && cy <= g.ny && cz >= -1 && cz <= g.nz;
+            const bool side9 = inner9 && (cx - 2 < 0 || cx - 2 >= g.bx0) && (cx + 2 >= g.nx || cx + 2 < g.bx0 + g.bnx);
             if (side9) {
-                const int* row = g.cell_start9 + srow_index(g, 0, cy, cz);
+                const int* row = g.cell_start9 + srow_index(g, g.bx0, cy, cz) - g.bx0;
                 const int xl = cx - 2, xr = cx + 2;
                 if (xl >= 0 && xl < g.nx) { const double gx = fmax(fxm + c, 0.0); if (!((float)(0.999 * gx * gx) > sel.worst())) scan_run(g, sel, row[xl], row[xl + 1], qx, qy, qz); }
                 if (xr >= 0 && xr < g.nx) { const double gx = fmax(fxp + c, 0.0); if (!((float)(0.999 * gx * gx) > sel.worst())) scan_run(g, sel, row[xr], row[xr + 1], qx, qy, qz); }

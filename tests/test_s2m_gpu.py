@@ -452,6 +452,58 @@ def test_tuning_options_do_not_change_results(gpu_ctx, oracle, opt):
     assert np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6]) and a[7] == b[7]
 
 
+@pytest.mark.parametrize("flavour", ["rot", "livox"])
+def test_super_row_layout_changes_no_result(gpu_ctx, oracle, flavour):
+    """The super-row copy of the map (the inner 27-cell block of a query as one run; the shell's side cells as two) is a layout, not an
+    algorithm: off, on for the whole map, and on for a focus box that only part of the queries fall into (the others take the
+    nine-row walk in the same launch) give bit-identical neighbours, distances, records, Gram and poses — from a pose 0.3 m / 2 deg
+    off, where a good part of the queries walks the shell.  Livox flavour: the reflectivity travels with the copy."""
+    room = synth.make_room(seed=41, n_query=9000, n_edge_query=300)
+    P = L.make_params(flavour)
+    tb, qb = L.api.body_pose_from_lidar(room["t_true"], room["q_true"], P)
+    t0, q0 = synth.perturbed_pose(tb, qb, np.random.default_rng(19), 0.3, 2.0)
+    rng = np.random.default_rng(7)
+    refl = lambda n: rng.uniform(0.0, 0.05, (n, 1)).astype(np.float32)
+    smap, emap, sq, eq = room["map_xyz"], room["edge_map_xyz"], room["q_xyz"], room["eq_xyz"]
+    if flavour == "livox":
+        smap, emap, sq, eq = [np.concatenate([a.astype(np.float32), refl(a.shape[0])], 1) for a in (smap, emap, sq, eq)]
+    centre = np.asarray(room["t_true"], np.float64)
+    res = []
+    try:
+        for mode in ("off", "all", "focus"):
+            gpu_ctx.set_option("super_rows", 0 if mode == "off" else 1)
+            m = L.ScanToMapMatcher(gpu_ctx, P)
+            m.map_focus(centre + [1.0, -0.5, 0.0], 2.5) if mode == "focus" else m.map_focus(None)
+            gpu_ctx.set_debug(True)
+            m.set_input_cloud(L.KIND_SURF, smap)
+            m.set_input_cloud(L.KIND_EDGE, emap)
+            m.set_queries(0, L.KIND_SURF, sq)
+            m.set_queries(0, L.KIND_EDGE, eq)
+            m.pose_set(0, t0, q0)
+            m.associate_dev(0, L.MASK_SURF | L.MASK_EDGE)
+            idx0, d20 = m.neighbors(0, L.KIND_SURF, sq.shape[0])
+            m.iterate(0, 6, L.MASK_SURF | L.MASK_EDGE)
+            t, q, st = m.pose_get(0)
+            idx, d2 = m.neighbors(0, L.KIND_SURF, sq.shape[0])
+            eidx, ed2 = m.neighbors(0, L.KIND_EDGE, eq.shape[0])
+            G, cost, counts = m.linearize(0, t, q, L.MASK_SURF | L.MASK_EDGE)
+            res.append((t, q, st, idx0, d20, idx, d2, eidx, ed2, G, counts, cost))
+    finally:
+        gpu_ctx.set_option("super_rows", 1)
+        gpu_ctx.set_debug(False)
+        L.ScanToMapMatcher(gpu_ctx, P).map_focus(None)
+    a = res[0]
+    assert a[2] == 0 and a[10][0] > 1000
+    gate = 1.0
+    assert ((a[4][:, 4] >= 0.4) & (a[4][:, 4] < gate)).sum() > 200      # queries whose 5th neighbour lies beyond the inner block: the shell matters
+    for b in res[1:]:
+        assert b[2] == 0 and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        for k in (3, 5, 7):          # neighbour ids / distances of the queries the reference keeps (inside the gate)
+            inside = a[k + 1][:, 4] < gate
+            assert np.array_equal(a[k][inside], b[k][inside]) and np.array_equal(a[k + 1][inside], b[k + 1][inside])
+        assert np.array_equal(a[9], b[9]) and np.array_equal(a[10], b[10]) and a[11] == b[11]
+
+
 def test_fuse_tail_toggled_between_set_queries_and_iterate(gpu_ctx, oracle):
     """the fused tail used to depend on a block size latched at set_queries.  The linearisation block is
     fixed now, so the option may change at any time: toggling it after set_queries, in the middle of a registration, changes
