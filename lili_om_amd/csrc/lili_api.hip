@@ -121,7 +121,7 @@ int lili_ctx_create(lili_ctx** out, int device, void* stream) {
     }
     bool ok = ctx->states.ensure(sizeof(SlotState) * LILI_MAX_SLOTS) == hipSuccess &&
               ctx->gram.ensure(sizeof(double) * LILI_GRAM_DOUBLES * LILI_MAX_SLOTS) == hipSuccess &&
-              ctx->misc.ensure(128 + 64 * 128) == hipSuccess &&
+              ctx->misc.ensure(2 * 64 * 128) == hipSuccess &&
 
               hipMemsetAsync(ctx->states.p, 0, sizeof(SlotState) * LILI_MAX_SLOTS, ctx->stream) == hipSuccess &&
               hipMemsetAsync(ctx->gram.p, 0, sizeof(double) * LILI_GRAM_DOUBLES * LILI_MAX_SLOTS, ctx->stream) == hipSuccess;
@@ -271,9 +271,10 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
     m.valid = false;
     for (auto& s : ctx->slots) { s.k[kind].binned = false; s.k[kind].nn_cache_valid = false; s.k[kind].order_valid = false; s.k[kind].launches = 0; }
     // bounding box: reduced inside the ingestion pass (one read of the cloud for both)
-    unsigned init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+    struct BboxInit { unsigned w[64 * 32]; BboxInit() { for (int i = 0; i < 64 * 32; i++) w[i] = (i & 31) < 3 ? 0xFFFFFFFFu : 0u; } };
+    static const BboxInit bbox_init;             // 64 banks of 128 bytes: min xyz = ~0, max xyz = 0 (ordered-uint encoding)
     unsigned* d_mm = ctx->misc.as<unsigned>();
-    HIPCHK(hipMemcpyAsync(d_mm, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d_mm, bbox_init.w, sizeof(bbox_init.w), hipMemcpyHostToDevice, ctx->stream));
     int rc = lili_ingest_cloud(ctx, cloud, m.pts, d_mm);
     if (rc != LILI_OK) return rc;
     m.n = (int64_t)cloud->n;
@@ -282,9 +283,10 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
     m.n_cells = 0; m.cell = 0;
     if (m.n == 0) { m.valid = true; return LILI_OK; }
     const int n = (int)m.n;
-    unsigned mm[6];
-    HIPCHK(hipMemcpyAsync(mm, d_mm, sizeof(mm), hipMemcpyDeviceToHost, ctx->stream));
+    unsigned banks[64 * 32], mm[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+    HIPCHK(hipMemcpyAsync(banks, d_mm, sizeof(banks), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int b = 0; b < 64; b++) for (int k = 0; k < 3; k++) { mm[k] = std::min(mm[k], banks[b * 32 + k]); mm[3 + k] = std::max(mm[3 + k], banks[b * 32 + 3 + k]); }
     auto dec = [](unsigned u) { unsigned b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u; float f; std::memcpy(&f, &b, 4); return f; };
     double mn[3], mx[3];
     bool any = true;
@@ -297,7 +299,7 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
     if (!(cell > 1e-6)) cell = 1e-6;
     m.has_fine = false; m.fview = GridView{}; m.fbound = 0.f; m.fine_cell = 0; m.mean_occupancy = 0;
     constexpr size_t kRankBanks = 64, kRankBytes = kRankBanks * 128;                       // k_cell_count: one bank per 128 bytes
-    unsigned long long* d_rank = ctx->fine_grid ? reinterpret_cast<unsigned long long*>(ctx->misc.as<char>() + 128) : nullptr;
+    unsigned long long* d_rank = ctx->fine_grid ? reinterpret_cast<unsigned long long*>(ctx->misc.as<char>() + 8192) : nullptr;
     if (d_rank) HIPCHK(hipMemsetAsync(d_rank, 0, kRankBytes, ctx->stream));
     rc = build_grid(ctx, m, mn, mx, cell, reach, m.sorted, m.aux_sorted, m.cell_start, m.cell_start9, m.view, m.n_cells, m.cell, d_rank);
     if (rc != LILI_OK) return rc;

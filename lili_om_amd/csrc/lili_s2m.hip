@@ -19,7 +19,7 @@ namespace lili {
 // cloud ingestion: AoS points (stride 32 / 48 B ...) -> float4 (x, y, z, aux)
 // ================================================================================================
 __device__ __forceinline__ unsigned f2ord(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
-// `mm` (optional, [6] ordered-uint min xyz / max xyz): the bounding box of the finite points is reduced in the same pass (the map
+// `mm` (optional, 64 banks x 32 words, words 0..5 of a bank = ordered-uint min xyz / max xyz): the bounding box of the finite points is reduced in the same pass (the map
 // index needs it before anything else; a separate k_bbox pass re-read the whole cloud) — one atomic set per block.
 __global__ __launch_bounds__(256) void k_cloud_to_f4(const unsigned char* __restrict__ raw, int n, int stride, int aux_off, float4* __restrict__ out, unsigned* __restrict__ mm) {
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -48,7 +48,9 @@ __global__ __launch_bounds__(256) void k_cloud_to_f4(const unsigned char* __rest
         const int k = threadIdx.x;
         float a = smn[0][k], b = smx[0][k];
         for (int w = 1; w < 4; w++) { a = fminf(a, smn[w][k]); b = fmaxf(b, smx[w][k]); }
-        if (a <= b) { atomicMin(&mm[k], f2ord(a)); atomicMax(&mm[3 + k], f2ord(b)); }
+        // 64 banks of 128 bytes (the host folds them): 4096 blocks on six words of ONE line were ~50 us of same-address atomics
+        unsigned* bank = mm + (size_t)(blockIdx.x & 63) * 32;
+        if (a <= b) { atomicMin(&bank[k], f2ord(a)); atomicMax(&bank[3 + k], f2ord(b)); }
     }
 }
 
