@@ -223,7 +223,7 @@ static int build_grid(lili_ctx* ctx, MapIndex& m, const double mn[3], const doub
     const int64_t nc9 = (int64_t)g.bnx * g.bny * g.bnz, rows9 = (int64_t)g.bny * g.bnz;
     const bool srows = ctx->super_rows && (int64_t)n * 10 < (1ll << 28) && nc9 + 2 < (1ll << 31);
     const size_t n_all = srows ? (size_t)n * 10 : (size_t)n;
-    HIPCHK(sorted.ensure((n_all + 4) * sizeof(float4)));      // + slack: the super-row walk loads whole chunks of four
+    HIPCHK(sorted.ensure((n_all + 8) * sizeof(float4)));      // + slack: the super-row walk loads whole chunks of four, one of them past the run's end
     if (m.has_aux) HIPCHK(aux_sorted.ensure(n_all * sizeof(float)));
     if (srows) { HIPCHK(cell_start9.ensure((size_t)(nc9 + 2) * sizeof(int))); HIPCHK(m.row9.ensure((size_t)(rows9 + 2) * sizeof(int))); }
     const int nb_scan = nblocks(nc, 2048);

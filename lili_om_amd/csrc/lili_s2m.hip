@@ -693,6 +693,9 @@ __device__ __forceinline__ float gate_bound(double gate) {   // smallest f32 >= 
     if ((double)gf < gate) gf = __uint_as_float(__float_as_uint(gf) + 1u);
     return gf;
 }
+// the 16 (dy, dz) rows of the 5x5x5 shell, nearest first (faces, then the rows next to them, then the corners), two batches of eight
+__device__ constexpr int kShellDy[16] = {0, 0, -2, 2, -1, 1, -1, 1, -2, -2, 2, 2, -2, -2, 2, 2};
+__device__ constexpr int kShellDz[16] = {-2, 2, 0, 0, -2, -2, 2, 2, -1, 1, -1, 1, -2, 2, -2, 2};
 template <class SEL, class TAB>
 __device__ __forceinline__ bool knn5_grid_sel(const GridView& g, TAB& tab, float qx, float qy, float qz, float bound, Top5& best, PhaseProbe* pp = nullptr) {
     SEL sel; sel.init(bound);
@@ -715,12 +718,13 @@ __device__ __forceinline__ bool knn5_grid_sel(const GridView& g, TAB& tab, float
             const int ce = row[x1 + 1];
             PHASE_STAMP(pp, 2, ce);
             auto fetch = [&](float4& p0, float4& p1, float4& p2, float4& p3, int& pj) {
+                // unconditional: no branch around the loads, so the waits the compiler inserts are exact.  Slots past the run's end — also the
+                // whole chunk requested after the last one — read the following entries (the array has 8 entries of slack) and are masked by
+                // position / never processed.
                 pj = cj;
-                if (cj < ce) {      // slots past the run's end read the following entries (the array has 4 entries of slack) and are masked by position
-                    const float4* q = (const float4*)((const char*)g.pts + ((unsigned)cj << 4));
-                    p0 = q[0]; p1 = q[1]; p2 = q[2]; p3 = q[3];
-                    cj += 4;
-                }
+                const float4* q = (const float4*)((const char*)g.pts + ((unsigned)cj << 4));
+                p0 = q[0]; p1 = q[1]; p2 = q[2]; p3 = q[3];
+                cj += 4;
             };
             float4 a0, a1, a2, a3, b0, b1, b2, b3;
             int aj = 0, bj = 0;
@@ -810,6 +814,44 @@ __device__ __forceinline__ bool knn5_grid_sel(const GridView& g, TAB& tab, float
                 if (xl >= 0 && xl < g.nx) { const double gx = fmax(fxm + c, 0.0); if (!((float)(0.999 * gx * gx) > sel.worst())) scan_run(g, sel, row[xl], row[xl + 1], qx, qy, qz); }
                 if (xr >= 0 && xr < g.nx) { const double gx = fmax(fxp + c, 0.0); if (!((float)(0.999 * gx * gx) > sel.worst())) scan_run(g, sel, row[xr], row[xr + 1], qx, qy, qz); }
             }
+            // How many lanes of the wave are here?  A handful (a converged pose: one lane in a few waves) is bound by the dependent round trips
+            // of the 16 shell rows — the batched form below; many (the first iterations of a registration) are bound by instruction issue on
+            // mostly idle lanes, where the row-by-row walk with its progressive pruning and x-trimming does less work.
+            const bool few = __popcll(__ballot(1)) <= 2;
+            if (side9 && few) {
+                // The 16 rows of the shell, nearest first, in two batches of eight: the range words of a batch are requested TOGETHER (one
+                // round trip instead of eight dependent ones; pruned and x-trimmed with the 5th best at that moment), parked in the lane's
+                // columns of the row table (idle in this layout), and only the non-empty rows that still matter are scanned.  The second
+                // batch sees the 5th best the first one left.
+                const double g1m = fmax(fxm, 0.0), g1p = fmax(fxp, 0.0), g2m = fmax(fxm + c, 0.0), g2p = fmax(fxp + c, 0.0);
+                const int tid = threadIdx.x;
+#pragma unroll
+                for (int batch = 0; batch < 2; batch++) {
+                    const float wv = sel.worst();
+                    int rb[8], re[8]; float rl[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const int dy = kShellDy[batch * 8 + i], dz = kShellDz[batch * 8 + i];
+                        const int y = cy + dy, z = cz + dz;
+                        const double gy = dy == 0 ? 0.0 : fmax(dy < 0 ? fym + (double)(-dy - 1) * c : fyp + (double)(dy - 1) * c, 0.0);
+                        const double gz = dz == 0 ? 0.0 : fmax(dz < 0 ? fzm + (double)(-dz - 1) * c : fzp + (double)(dz - 1) * c, 0.0);
+                        const double lbr = 0.999 * (gy * gy + gz * gz);
+                        const int dl = (float)(lbr + 0.999 * g2m * g2m) > wv ? ((float)(lbr + 0.999 * g1m * g1m) > wv ? 0 : 1) : 2;
+                        const int dr = (float)(lbr + 0.999 * g2p * g2p) > wv ? ((float)(lbr + 0.999 * g1p * g1p) > wv ? 0 : 1) : 2;
+                        const int x0 = max(cx - dl, 0), x1 = min(cx + dr, g.nx - 1);
+                        const bool keep = y >= 0 && y < g.ny && z >= 0 && z < g.nz && !((float)lbr > wv) && x0 <= x1;
+                        const int* cs = g.cell_start + (size_t)(keep ? z * g.ny + y : 0) * g.nx;
+                        const int b = cs[keep ? x0 : 0], e = cs[keep ? x1 + 1 : 0];
+                        rb[i] = b; re[i] = keep ? e : b; rl[i] = (float)lbr;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; i++) { tab.b[i][tid] = rb[i]; tab.e[i][tid] = re[i]; tab.lb[i][tid] = rl[i]; }
+                    for (int i = 0; i < 8; i++) {
+                        const int b = tab.b[i][tid], e = tab.e[i][tid];
+                        if (b < e && !(tab.lb[i][tid] > sel.worst())) scan_run(g, sel, b, e, qx, qy, qz);
+                    }
+                }
+            } else
             for (int dz = -2; dz <= 2; dz++) {
                 const int z = cz + dz;
                 if (z < 0 || z >= g.nz) continue;
