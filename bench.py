@@ -608,6 +608,38 @@ def main():
             except Exception as e:      # noqa: BLE001  (secondary numbers must never cost the headline line)
                 extras["window_error"] = repr(e)
             try:
+                # The same scan and map through the FRONT-END flavour (plain point-to-plane, no count scaling, L/src/LidarOdometry.cpp:352-413):
+                # flavours whose weights do not depend on the scan's correspondence count linearise inside the association launch
+                # (k_associate_lin: 2 launches per iteration); A/B against the three-launch path (option fuse_lin = 0).
+                Pf = L.make_params("frontend")
+                mf = L.ScanToMapMatcher(ctx, Pf)
+                mf.set_input_cloud(L.KIND_SURF, w["map_xyz"])
+                q_small = np.ascontiguousarray(queries[::10])          # 20 k queries: the size of a Livox scan's feature cloud
+                mf.set_queries(0, L.KIND_SURF, q_small)
+                tl = np.asarray(w["lidar_t"], np.float64)
+                ql = np.array([1.0, 0.0, 0.0, 0.0])
+                tp, qp = synth.perturbed_pose(tl, ql, np.random.default_rng(synth.SEED_POSE), 0.3, 2.0)
+                mf.pose_set(1, tp, qp)
+                fr = {}
+                for fuse in (1, 0):
+                    ctx.set_option("fuse_lin", fuse)
+                    mf.iterate_restart(0, 2 * ips, ips, 1, L.MASK_SURF)
+                    torch.cuda.synchronize()
+                    tw = time.perf_counter()
+                    mf.iterate_restart(0, 20 * ips, ips, 1, L.MASK_SURF)
+                    torch.cuda.synchronize()
+                    el = time.perf_counter() - tw
+                    tf_, qf_, stf = mf.pose_get(0)
+                    fr[fuse] = (20 * ips / el, el / (20 * ips) * 1e6, float(np.linalg.norm(tf_ - tl)), int(stf))
+                ctx.set_option("fuse_lin", 1)
+                extras["frontend_flavour"] = {"value": round(fr[1][0], 1), "unit": "iterations/s", "us_per_iteration": round(fr[1][1], 2),
+                                              "three_launch_path_us_per_iteration": round(fr[0][1], 2), "dt_truth_m": round(fr[1][2], 6), "gn_status": fr[1][3],
+                                              "queries": int(q_small.shape[0]),
+                                              "note": "front-end matcher flavour, every 10th point of the scan (a Livox scan's size) vs the 5 M-point map: association + linearisation in ONE launch, then reduce + GN (scans above ~100 k queries keep three launches)"}
+                m.set_input_cloud(L.KIND_SURF, w["map_xyz"])     # (the map index is per context: restore the back-end gate)
+            except Exception as e:      # noqa: BLE001
+                extras["frontend_flavour_error"] = repr(e)
+            try:
                 extras.update(secondary_stages(L, ctx, w, torch))
             except Exception as e:      # noqa: BLE001
                 extras["stages_error"] = repr(e)

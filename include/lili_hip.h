@@ -100,7 +100,10 @@ int lili_set_debug(lili_ctx* ctx, int keep_neighbors);
  * partials and the GN update run inside the linearisation launch, in its last block; default 0 = separate launch, which is
  * faster on MI355X; may be changed at any time), "merge_kinds" (1 = surf and edge of a keyframe share ONE association launch and ONE
  * linearisation launch; default 1), "p2p_fusion" (0 = lili_s2m_iterate_sharded runs lili_p2p_allreduce as its own launches like any
- * other lili_allreduce_fn instead of inside the count / reduce kernels; default 1).
+ * other lili_allreduce_fn instead of inside the count / reduce kernels; default 1), "fuse_lin" (1 = lili_s2m_iterate / _restart run the
+ * flavours without count scaling — Livox back end, front end — in two launches per iteration: the association launch linearises on the fly;
+ * scans above ~100 k queries and the ROT back end keep three launches; default 1), "super_rows" (1 = lili_map_set also stores the map in
+ * the super-row layout, see lili_map_focus; default 1; takes effect at the next lili_map_set).
  * "fine_grid" (1 = lili_map_set measures the point density and gives a map with more than "fine_occupancy" (default 12) points per
  * gate-sized cell a second index with density-sized cells that the association searches first — exact; default 1).
  * One knob that DOES choose between two definitions of a result: "rot_atan" — lili_extract_rot's atan / atan2 on float arguments

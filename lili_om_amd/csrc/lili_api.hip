@@ -24,6 +24,7 @@ __global__ void k_scan_lookback(int*, int64_t, unsigned long long*);
 __global__ void k_scatter(const float4*, int, const int2*, const int*, float4*, float*);
 __global__ void k_start9(const int*, GridView, const int*, int*);
 __global__ void k_rowtot9(const int*, GridView, int*);
+template <int BS> __global__ void k_associate_lin(AssocArgs, AssocArgs, PoseArg, MatchParams, double*, double*);
 __global__ void k_scatter9(const int*, GridView, const int*, float4*, float*);
 __global__ void k_bin_count(const float4*, int, GridView, PoseArg, MatchParams, int, int, int*, int*);
 __global__ void k_bin_scatter(const int*, int, const int*, int*, int*);
@@ -135,7 +136,7 @@ void lili_ctx_destroy(lili_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& m : ctx->map) { m.sorted_f.release(); m.aux_sorted_f.release(); m.cell_start_f.release(); m.cell_start9.release(); m.cell_start9_f.release(); m.row9.release(); m.pts.release(); m.sorted.release(); m.aux_sorted.release(); m.cell_start.release(); m.cell_tmp.release(); m.pt_cell.release(); m.block_sums.release(); }
-    for (auto& s : ctx->slots) for (auto& k : s.k) { k.q.release(); k.rec0.release(); k.rec1.release(); k.valid.release(); k.dbg_idx.release(); k.dbg_d2.release(); k.partials.release(); k.perm.release(); k.keys.release(); k.block_counts.release(); k.tiles.release(); }
+    for (auto& s : ctx->slots) for (auto& k : s.k) { k.q.release(); k.rec0.release(); k.rec1.release(); k.valid.release(); k.dbg_idx.release(); k.dbg_d2.release(); k.partials.release(); k.partials_wave.release(); k.perm.release(); k.keys.release(); k.block_counts.release(); k.tiles.release(); }
     ctx->states.release(); ctx->staging.release(); ctx->gram.release(); ctx->misc.release(); ctx->bin_hist.release(); ctx->bin_start.release(); ctx->bin_sums.release(); ctx->bin_tcnt.release(); ctx->bin_toff.release();
     if (ctx->ext_rot && ctx->ext_rot_free) ctx->ext_rot_free(ctx->ext_rot);
     if (ctx->ext_livox && ctx->ext_livox_free) ctx->ext_livox_free(ctx->ext_livox);
@@ -170,6 +171,8 @@ int lili_set_option(lili_ctx* ctx, const char* name, int value) {
     if (std::strcmp(name, "balance") == 0) { ctx->balance = value != 0; for (auto& sl : ctx->slots) for (auto& k : sl.k) { k.order_valid = false; k.launches = 0; } return LILI_OK; }
     if (std::strcmp(name, "fuse_tail") == 0) { ctx->fuse_tail = value != 0; return LILI_OK; }   // any time: the block partition does not depend on it
     if (std::strcmp(name, "merge_kinds") == 0) { ctx->merge_kinds = value != 0; return LILI_OK; }
+    if (std::strcmp(name, "fuse_lin") == 0) { ctx->fuse_lin = value != 0; return LILI_OK; }
+    if (std::strcmp(name, "fuse_lin_block") == 0) { if (value != 0 && value != kAssocBlock && value != kBlock) return ctx->fail(LILI_E_ARG, "fuse_lin_block must be 0 (auto), 64 or 256"); ctx->fuse_lin_block = value; return LILI_OK; }
     if (std::strcmp(name, "fine_grid") == 0) { ctx->fine_grid = value != 0; return LILI_OK; }
     if (std::strcmp(name, "super_rows") == 0) { ctx->super_rows = value != 0; return LILI_OK; }   // takes effect at the next lili_map_set
     if (std::strcmp(name, "fine_occupancy") == 0) { if (value < 2) return ctx->fail(LILI_E_ARG, "fine_occupancy must be >= 2"); ctx->fine_occupancy = value; return LILI_OK; }
@@ -593,6 +596,64 @@ static LinArgs lin_args_of(lili_ctx* ctx, int slot, int kind) {
 // if do_gn).  Default: ONE launch — k_linearize covers both kinds and its last block to finish reduces (+ solves), see fused_tail.
 // Options for A/B: merge_kinds = 0 (one launch per kind), fuse_tail = 0 (k_reduce_partials as its own launch).  All variants
 // add the same numbers in the same order: the record is bit-identical.
+// One outer iteration in TWO launches for the flavours without count scaling (k_associate_lin: association + linearisation, then the
+// reduction + GN update).  Returns 1 if the configuration is not eligible (the caller then takes the three-launch path).
+static int launch_associate_lin_reduce(lili_ctx* ctx, int slot, int kind_mask, const PoseArg& pa, const MatchParams& P, double* d_out) {
+    if (!ctx->fuse_lin || P.scale_surf_num > 0 || P.scale_edge_num > 0 || !pa.state) return 1;
+    if (ctx->bin_queries || ctx->tiled || ctx->balance || ctx->fuse_tail || (P.debug & 4096)) return 1;
+    Slot& sl = ctx->slots[slot];
+    AssocArgs A[2] = {AssocArgs{}, AssocArgs{}};
+    int n_kinds = 0;
+    for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) {
+        KindSlot& ks = sl.k[kind];
+        MapIndex& m = ctx->map[kind];
+        if (!ks.has_queries || !m.valid || ks.n_q == 0 || m.n < 5 || m.has_fine) return 1;
+        const double gate = kind == LILI_KIND_SURF ? P.kd_max_radius : P.edge_gate;
+        if (!(std::sqrt(gate) * 1.0099 <= m.cell * (double)m.view.reach)) return 1;     // the per-kind path reports the error
+        if (kind == LILI_KIND_SURF && P.variant == LILI_VARIANT_LIVOX && (!m.has_aux || !ks.has_aux)) return 1;
+        n_kinds++;
+    }
+    if (n_kinds == 0) return 1;
+    // one partial per workgroup: per wave while the reducer can take them in one round of loads (25 groups x 32), else per four waves
+    int waves = 0;
+    for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) waves += sl.k[kind].n_blocks;
+    // Measured (front-end flavour, 5 M-point map): 10 k queries 19.8 vs 23.3 us per iteration, 30 k 24.6 vs 26.5, 60 k 24.8 vs 27.4, 200 k 31.6 vs 30.8 —
+    // small scans are latency-bound and gain a launch; at 200 k the association waves are issue-bound and the extra rows cost more than the
+    // separate linearisation launch (which runs on otherwise idle SIMDs at four waves each).
+    if (waves > 1600 && !ctx->fuse_lin_block) return 1;
+    const int bs = ctx->fuse_lin_block ? ctx->fuse_lin_block : (waves <= 800 ? kAssocBlock : kBlock);
+    for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) {
+        KindSlot& ks = sl.k[kind];
+        const int n = (int)ks.n_q;
+        AssocArgs& a = A[kind];
+        a.queries = ks.q.as<float4>(); a.n_q = n; a.g = ctx->map[kind].view;
+        a.rec0 = ks.rec0.as<float4>(); a.rec1 = ks.rec1.p; a.valid = ks.valid.as<unsigned char>();
+        if (ctx->keep_nn) {
+            HIPCHK(ks.dbg_idx.ensure((size_t)n * 5 * sizeof(int)));
+            HIPCHK(ks.dbg_d2.ensure((size_t)n * 5 * sizeof(float)));
+            a.dbg_idx = ks.dbg_idx.as<int>(); a.dbg_d2 = ks.dbg_d2.as<float>();
+        }
+        if (ctx->nn_cache) {
+            HIPCHK(ks.nn_cache.ensure((size_t)n * 5 * sizeof(int)));
+            if (!ks.nn_cache_valid) { HIPCHK(hipMemsetAsync(ks.nn_cache.p, 0xFF, (size_t)n * 5 * sizeof(int), ctx->stream)); ks.nn_cache_valid = true; }
+            a.nn_cache = ks.nn_cache.as<int>();
+        }
+        HIPCHK(ks.partials_wave.ensure((size_t)ks.n_blocks * kPartialStride * sizeof(double)));
+        a.block_counts = ks.block_counts.as<int>(); a.nb = nblocks(n, bs);
+        ks.n_assoc_blocks = a.nb; ks.has_records = true; ks.launches++;
+    }
+    // k_associate_lin: blocks [0, E.nb) edge, the rest surf
+    if (bs == kAssocBlock) hipLaunchKernelGGL(k_associate_lin<kAssocBlock>, dim3(A[0].nb + A[1].nb), dim3(kAssocBlock), 0, ctx->stream, A[0], A[1], pa, P,
+                                              sl.k[0].partials_wave.as<double>(), sl.k[1].partials_wave.as<double>());
+    else hipLaunchKernelGGL(k_associate_lin<kBlock>, dim3(A[0].nb + A[1].nb), dim3(kBlock), 0, ctx->stream, A[0], A[1], pa, P,
+                            sl.k[0].partials_wave.as<double>(), sl.k[1].partials_wave.as<double>());
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx->stream, (const double*)sl.k[0].partials_wave.as<double>(), A[0].nb,
+                       (const double*)sl.k[1].partials_wave.as<double>(), A[1].nb, d_out, ctx->state(slot), 1 | (P.debug & 256), P2PView{});
+    HIPCHK(hipGetLastError());
+    sl.use_global_counts = false;
+    return LILI_OK;
+}
+
 static int launch_linearize_reduce(lili_ctx* ctx, int slot, int kind_mask, const PoseArg& pa, const MatchParams& P, double* d_out, int do_gn,
                                    const P2PView* xv = nullptr) {
     Slot& s = ctx->slots[slot];
@@ -916,6 +977,16 @@ int lili_s2m_pose_copy(lili_ctx* ctx, int dst_slot, int src_slot) {
 // iterations 0, restart_every, 2*restart_every, ... (device-to-device, async) — "one registration = restart_every
 // GN iterations".  If assoc_ms is non-NULL the association launches are bracketed by HIP events on the context's
 // stream and their total duration is returned (this variant synchronises at the end).
+// one outer iteration through k_associate_lin (see launch_associate_lin_reduce); 1 = not eligible
+static int iterate_fused_lin(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params) {
+    if (!ctx->fuse_lin || params->scale_surf_num > 0 || params->scale_edge_num > 0) return 1;
+    PoseArg pa{};
+    pa.state = ctx->state(slot);
+    pa.derive_assoc = params->variant == LILI_VARIANT_FRONTEND ? 0 : 1;
+    MatchParams P = to_device_params(params);
+    P.no_cost = 1;             // the record stays inside the library, only the GN step is used
+    return launch_associate_lin_reduce(ctx, slot, kind_mask, pa, P, ctx->gram_of(slot));
+}
 static int iterate_impl(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, int n_iters, int restart_every, int restart_slot, float* assoc_ms) {
     if (!ctx) return LILI_E_ARG;
     ARGCHK(n_iters >= 0, "iterate: negative n_iters");
@@ -931,6 +1002,11 @@ static int iterate_impl(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_p
     }
     for (int it = 0; it < n_iters; it++) {   // 3 launches per outer iteration: associate, linearise, reduce+GN
         if (restart_every > 0 && it % restart_every == 0) { int rc = lili_s2m_pose_copy(ctx, slot, restart_slot); if (rc != LILI_OK) return rc; }
+        if (!assoc_ms) {        // flavours without count scaling: association + linearisation in one launch (2 launches per iteration)
+            int rc2 = iterate_fused_lin(ctx, slot, kind_mask, params);
+            if (rc2 == LILI_OK) continue;
+            if (rc2 != 1) return rc2;
+        }
         if (assoc_ms) HIPCHK(hipEventRecord(ev[2 * it], ctx->stream));
         int rc = lili_s2m_associate_dev(ctx, slot, kind_mask, params);
         if (rc != LILI_OK) return rc;

@@ -53,7 +53,7 @@ struct KindSlot {
     int64_t n_q = 0;
     bool has_queries = false, has_records = false;
     bool has_aux = false;    // the query cloud carried the auxiliary float (Livox: reflectivity)
-    DevBuf q, rec0, rec1, valid, dbg_idx, dbg_d2, partials, perm, keys, block_counts, tiles, nn_cache, order, block_cost;
+    DevBuf q, rec0, rec1, valid, dbg_idx, dbg_d2, partials, partials_wave, perm, keys, block_counts, tiles, nn_cache, order, block_cost;
     int launches = 0;        // association launches since set_queries (the dispatch order is rebuilt before launches 2 and 4)
     bool order_valid = false;
     bool nn_cache_valid = false;   // nn_cache holds the neighbours of the last association of THIS scan against the CURRENT map index
@@ -108,6 +108,8 @@ struct lili_ctx {
     bool fine_grid = true;       // measure the map density in lili_map_set and build the fine index when a gate-sized cell holds more than fine_occupancy points
     int fine_occupancy = 12;
     double focus[3] = {0, 0, 0}, focus_radius = 0;   // lili_map_focus: where the super-row copy is built (radius 0: everywhere)
+    int fuse_lin_block = 0;      // 0 = by scan size, else 64 / 256 (A/B, tests)
+    bool fuse_lin = true;        // lili_s2m_iterate*: flavours without count scaling linearise inside the association launch (k_associate_lin)
     bool super_rows = true;      // lili_map_set also stores the super-row copy of the map (9x the points): the inner 27-cell block of a query is one run
     bool scan_lookback = true;   // map index: single-pass (decoupled look-back) scan of the cell array; 0 = the three-kernel scan (A/B)
     int rot_atan = 2;            // ROT extractor: 2 = glibc fdlibm float atan / atan2 (the reference build's bits), 1 = f64 functions rounded to f32

@@ -1264,12 +1264,15 @@ __device__ __forceinline__ void knn5_tiled(const GridView& g, TileLds& L, TAB& t
     sel.to_top5(best);
 }
 
+// What a lane of the association found, handed on in registers to the launch that linearises on the fly (k_associate_lin): the values
+// are the ROUNDED ones the record arrays receive, so the two-launch path sees the same numbers.
+struct LaneRec { bool ok; float4 ql, r0, r1; double score; };
 template <bool TILED, int BS, class TILE, class TAB>
 __device__ __forceinline__ void assoc_surf_body(
         const float4* __restrict__ queries, const int* __restrict__ perm, const int2* __restrict__ tiles, int n_q, const GridView& g, const PoseArg& pa, const MatchParams& P,
         float4* __restrict__ rec_nd, double* __restrict__ rec_score, unsigned char* __restrict__ valid,
         int* __restrict__ dbg_idx, float* __restrict__ dbg_d2, int* __restrict__ block_counts, int* __restrict__ nn_cache, const AssocSched& sched,
-        int vbid, TILE& L, TAB& tab) {
+        int vbid, TILE& L, TAB& tab, LaneRec* rec_out = nullptr) {
     const long long t_begin = (P.debug & 4096) ? (long long)__builtin_amdgcn_s_memrealtime() : 0ll;   // profiling aid (tools/assoc_blocks.py)
     const int bid = sched.order ? sched.order[vbid] : vbid;
     const int2 tile = tiles ? tiles[bid] : make_int2(bid * BS, min(BS, n_q - bid * BS));
@@ -1311,7 +1314,9 @@ __device__ __forceinline__ void assoc_surf_body(
         rec_nd[i] = rn;
         rec_score[i] = score;
         valid[i] = ok ? 1 : 0;
+        if (rec_out) { rec_out->ql = ql; rec_out->r0 = rn; rec_out->score = score; }
     }
+    if (rec_out) rec_out->ok = ok;
     store_block_count<BS>(ok, block_counts, vbid);
 #ifdef LILI_PHASE_PROBE
     if ((P.debug & 4096) && dbg_d2 && threadIdx.x == 0) {   // phase stamps as ticks since the block began, over the d2 debug rows of the block's first two queries
@@ -1344,7 +1349,7 @@ __device__ __forceinline__ void assoc_edge_body(
         const float4* __restrict__ queries, const int* __restrict__ perm, const int2* __restrict__ tiles, int n_q, const GridView& g, const PoseArg& pa, const MatchParams& P,
         float4* __restrict__ rec_a, float4* __restrict__ rec_b, unsigned char* __restrict__ valid,
         int* __restrict__ dbg_idx, float* __restrict__ dbg_d2, int* __restrict__ block_counts, int* __restrict__ nn_cache, const AssocSched& sched,
-        int vbid, TILE& L, TAB& tab) {
+        int vbid, TILE& L, TAB& tab, LaneRec* rec_out = nullptr) {
     const int bid = sched.order ? sched.order[vbid] : vbid;
     const int2 tile = tiles ? tiles[bid] : make_int2(bid * BS, min(BS, n_q - bid * BS));
     const bool live = (int)threadIdx.x < tile.y;
@@ -1364,7 +1369,9 @@ __device__ __forceinline__ void assoc_edge_body(
         float4 ra, rb;
         ok = edge_fit(g, P, nn, px, py, pz, ra, rb);
         rec_a[i] = ra; rec_b[i] = rb; valid[i] = ok ? 1 : 0;
+        if (rec_out) { rec_out->ql = ql; rec_out->r0 = ra; rec_out->r1 = rb; }
     }
+    if (rec_out) rec_out->ok = ok;
     store_block_count<BS>(ok, block_counts, vbid);
 }
 template <bool TILED, int BS>
@@ -1600,6 +1607,49 @@ __device__ __forceinline__ void load_body_pose(const PoseArg& pa, dq& Q, d3& T) 
     else { T = d3{pa.t[0], pa.t[1], pa.t[2]}; Q = dq{pa.q[0], pa.q[1], pa.q[2], pa.q[3]}; }
 }
 
+// Residual, 1x7 Jacobian row and loss corrector of ONE correspondence (Jr[0..6] = robustified Jacobian, Jr[7] = residual; returns the robust
+// cost) — shared by the linearisation launch and by the association launch that linearises on the fly (k_associate_lin).
+//   surf: LidarPlaneNormFactor / LidarPlaneNormIncreFactor, L/include/factors/LidarKeyframeFactor.h:86-90, 118-128; `score` is the (count-scaled) weight
+__device__ __forceinline__ double surf_lin_row(const MatchParams& P, const dq& Q, const d3& T, const dq& qlb_inv, float4 ql, float4 nd, double score, double Jr[8]) {
+    d3 cp{(double)ql.x, (double)ql.y, (double)ql.z};
+    d3 n{(double)nd.x, (double)nd.y, (double)nd.z};
+    d3 v;
+    if (P.variant == 2) { v = cp; score = 1.0; }   // LidarPlaneNormIncreFactor, LidarKeyframeFactor.h:118-128
+    else v = qrot(qlb_inv, cp - d3{P.t_lb[0], P.t_lb[1], P.t_lb[2]});                                  // :86
+    d3 pw = qrot(Q, v) + T;                                                                              // :87
+    double r = score * (dot3(n, pw) + (double)nd.w);                                                    // :90
+    double jq[4];
+    qrot_jac_row(Q, v, n, jq);
+    double J[7] = {score * n.x, score * n.y, score * n.z, score * jq[0], score * jq[1], score * jq[2], score * jq[3]};
+    const double cost = robustify(P.loss, P.loss_a, J, r, P.no_cost == 0);
+#pragma unroll
+    for (int k = 0; k < 7; k++) Jr[k] = J[k];
+    Jr[7] = r;
+    return cost;
+}
+//   edge: LidarEdgeFactor, LidarKeyframeFactor.h:38-44 (no extrinsic: SURVEY F6); `s` is the (count-scaled) weight
+__device__ __forceinline__ double edge_lin_row(const MatchParams& P, const dq& Q, const d3& T, float4 ql, float4 fa, float4 fb, double s, double Jr[8]) {
+    d3 cp{(double)ql.x, (double)ql.y, (double)ql.z};
+    d3 Av{(double)fa.x, (double)fa.y, (double)fa.z}, B{(double)fb.x, (double)fb.y, (double)fb.z};
+    d3 lp = qrot(Q, cp) + T;                    // :38
+    d3 nu = cross3(lp - Av, lp - B);            // :40
+    d3 de = Av - B;                             // :41
+    double nn = sqrt(dot3(nu, nu)), dn = sqrt(dot3(de, de));
+    double r = s * (nn / dn);                   // :43-44
+    // d|nu|/dlp = nu^T [a-b]x / |nu| = (nu x (B - A))^T / |nu|
+    d3 g = cross3(nu, B - Av);
+    double k = s / (nn * dn);
+    g = k * g;
+    double jq[4];
+    qrot_jac_row(Q, cp, g, jq);
+    double J[7] = {g.x, g.y, g.z, jq[0], jq[1], jq[2], jq[3]};
+    const double cost = robustify(P.loss, P.loss_a, J, r, P.no_cost == 0);
+#pragma unroll
+    for (int kk = 0; kk < 7; kk++) Jr[kk] = J[kk];
+    Jr[7] = r;
+    return cost;
+}
+
 // Linearisation bodies: `bid` of `nb` virtual blocks of one kind (the combined surf + edge launch maps its grid onto both).
 __device__ __forceinline__ void lin_surf_body(const LinArgs& A, int bid, const PoseArg& pa, const MatchParams& P, const SlotState* __restrict__ state,
                                               const int* __restrict__ n_global, double* lds, unsigned long long key) {
@@ -1640,20 +1690,7 @@ __device__ __forceinline__ void lin_surf_body(const LinArgs& A, int bid, const P
             float4 ql = first ? ql0 : queries[i]; float4 nd = first ? nd0 : rec_nd[i];
             double score = first ? sc0 : rec_score[i];
             if (P.scale_surf_num > 0) score = score * P.scale_surf_num / n_den;
-            d3 cp{(double)ql.x, (double)ql.y, (double)ql.z};
-            d3 n{(double)nd.x, (double)nd.y, (double)nd.z};
-            d3 v;
-            if (P.variant == 2) { v = cp; score = 1.0; }   // LidarPlaneNormIncreFactor, LidarKeyframeFactor.h:118-128
-            else v = qrot(qlb_inv, cp - d3{P.t_lb[0], P.t_lb[1], P.t_lb[2]});                                  // :86
-            d3 pw = qrot(Q, v) + T;                                                                              // :87
-            double r = score * (dot3(n, pw) + (double)nd.w);                                                    // :90
-            double jq[4];
-            qrot_jac_row(Q, v, n, jq);
-            double J[7] = {score * n.x, score * n.y, score * n.z, score * jq[0], score * jq[1], score * jq[2], score * jq[3]};
-            cost = robustify(P.loss, P.loss_a, J, r, P.no_cost == 0);
-#pragma unroll
-            for (int k = 0; k < 7; k++) Jr[k] = J[k];
-            Jr[7] = r;
+            cost = surf_lin_row(P, Q, T, qlb_inv, ql, nd, score, Jr);
         }
         tstamp(state, P.debug, 100, 2);
         ga.add_rows(Jr, cost, ok, lds);
@@ -1686,24 +1723,7 @@ __device__ __forceinline__ void lin_edge_body(const LinArgs& A, int bid, const P
             float4 ql = queries[i]; float4 fa = rec_a[i], fb = rec_b[i];
             double s = (double)fa.w;
             if (P.scale_edge_num > 0) s = (double)__fdiv_rn(__fmul_rn(fa.w, n_num), n_den);
-            d3 cp{(double)ql.x, (double)ql.y, (double)ql.z};
-            d3 Av{(double)fa.x, (double)fa.y, (double)fa.z}, B{(double)fb.x, (double)fb.y, (double)fb.z};
-            d3 lp = qrot(Q, cp) + T;                    // LidarKeyframeFactor.h:38 (no extrinsic: SURVEY F6)
-            d3 nu = cross3(lp - Av, lp - B);            // :40
-            d3 de = Av - B;                             // :41
-            double nn = sqrt(dot3(nu, nu)), dn = sqrt(dot3(de, de));
-            double r = s * (nn / dn);                   // :43-44
-            // d|nu|/dlp = nu^T [a-b]x / |nu| = (nu x (B - A))^T / |nu|
-            d3 g = cross3(nu, B - Av);
-            double k = s / (nn * dn);
-            g = k * g;
-            double jq[4];
-            qrot_jac_row(Q, cp, g, jq);
-            double J[7] = {g.x, g.y, g.z, jq[0], jq[1], jq[2], jq[3]};
-            cost = robustify(P.loss, P.loss_a, J, r, P.no_cost == 0);
-#pragma unroll
-            for (int kk = 0; kk < 7; kk++) Jr[kk] = J[kk];
-            Jr[7] = r;
+            cost = edge_lin_row(P, Q, T, ql, fa, fb, s, Jr);
         }
         ga.add_rows(Jr, cost, ok, lds);
     }
@@ -1735,6 +1755,45 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize(LinArgs S, LinArgs E, P
 // wave-level ordering of LDS traffic inside ONE wave (LDS operations of a wave execute in order; the fence keeps the compiler from
 // moving them) — the tail of the reduction and the GN update run in a single wave, without s_barrier
 #define LILI_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+// Association that LINEARISES ON THE FLY (VERDICT r1 #2 i): for the flavours whose residual weight does not depend on the correspondence
+// count of the whole scan (Livox back end, front end: scale_*_num == 0 — the ROT back end divides by N, which exists only after the last
+// wave), a lane that has just fitted its plane / line holds everything a linearisation lane would load again: query, record, body pose.
+// It computes the same row (surf_lin_row / edge_lin_row on the ROUNDED record values), the wave reduces its 64 rows on the f64 MFMA
+// exactly like a linearisation wave, and the per-wave partial goes where k_reduce_partials expects block partials.  The records are
+// still stored (API, marginalisation feed).  One launch less per iteration, no second pass over the records, no count sum.
+// Blocks [0, E.nb) take edge queries, the rest surf (either count may be 0).  The Gram staging rows reuse the row table's LDS.
+// BS = 64 (one partial per wave; scans up to ~50 k queries, where the reducer takes them in one round of loads) or 256 (one partial per
+// four waves, for larger scans).
+template <int BS>
+__global__ __launch_bounds__(BS) void k_associate_lin(AssocArgs S, AssocArgs E, PoseArg pa, MatchParams P, double* __restrict__ part_surf, double* __restrict__ part_edge) {
+    __shared__ NoTile L;
+    __shared__ __attribute__((aligned(16))) RowTabT<BS> tab;
+    static_assert(sizeof(RowTabT<BS>) >= (size_t)BS * kRow * sizeof(double), "Gram staging rows must fit the row table");
+    const AssocSched sched{nullptr, nullptr};
+    const int b = (int)blockIdx.x;
+    const bool edge = b < E.nb;
+    LaneRec rec{};
+    if (edge) assoc_edge_body<false, BS>(E.queries, nullptr, nullptr, E.n_q, E.g, pa, P, E.rec0, reinterpret_cast<float4*>(E.rec1), E.valid, E.dbg_idx, E.dbg_d2,
+                                         E.block_counts, E.nn_cache, sched, b, L, tab, &rec);
+    else assoc_surf_body<false, BS>(S.queries, nullptr, nullptr, S.n_q, S.g, pa, P, S.rec0, reinterpret_cast<double*>(S.rec1), S.valid, S.dbg_idx, S.dbg_d2,
+                                    S.block_counts, S.nn_cache, sched, b - E.nb, L, tab, &rec);
+    dq Q; d3 T;
+    load_body_pose(pa, Q, T);
+    double Jr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double cost = 0.0;
+    if (rec.ok) {
+        if (edge) cost = edge_lin_row(P, Q, T, rec.ql, rec.r0, rec.r1, (double)rec.r0.w, Jr);
+        else cost = surf_lin_row(P, Q, T, dq{P.q_lb_inv_jet[0], P.q_lb_inv_jet[1], P.q_lb_inv_jet[2], P.q_lb_inv_jet[3]}, rec.ql, rec.r0, rec.score, Jr);
+    }
+    __syncthreads();                                  // (one wave) the search is over: its table becomes the staging area
+    double* lds = reinterpret_cast<double*>(&tab);
+    GramAcc ga; ga.init();
+    ga.add_rows(Jr, cost, rec.ok, lds);
+    ga.finish(lds, edge ? part_edge + (size_t)b * kPartialStride : part_surf + (size_t)(b - E.nb) * kPartialStride);
+}
+template __global__ void k_associate_lin<kAssocBlock>(AssocArgs, AssocArgs, PoseArg, MatchParams, double*, double*);
+template __global__ void k_associate_lin<kBlock>(AssocArgs, AssocArgs, PoseArg, MatchParams, double*, double*);
+
 // xq: the quaternion of state->pose, loaded by the caller at kernel start (its latency hides behind the partial loads).
 // Must be called by exactly ONE wave (lanes 0..63 of it).
 // sin(x)/x and cos(x) from x^2 for the small rotation of a Gauss-Newton step (|x| < 0.5: the series are truncated below 1e-19
@@ -1861,6 +1920,15 @@ constexpr int kReduceThreads = 1024;
 // 40-double partials written by an earlier launch.  key != 0: granules published by the blocks of THIS launch — the loads are
 // repeated until every granule of the chunk carries the key (block-wide vote), at most kMaxSweeps times.
 constexpr int kMaxSweeps = 1 << 16;
+// Many plain partials (the per-wave partials of k_associate_lin: one per 64 queries): 32 loads in flight per lane instead of 8.  The
+// additions are the same sequence (partials g, g + 25, g + 50, ... one after the other), only the round trips are fewer.
+__device__ __forceinline__ void sum_partial_wide(const double* part, int nb, int c, int g, int e, int groups, double& s) {
+    double v[32];
+#pragma unroll
+    for (int u = 0; u < 32; u++) { const int b = g + (c * 32 + u) * groups; v[u] = (g < groups && b < nb) ? part[(size_t)b * kPartialStride + e] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < 32; u++) s += v[u];
+}
 __device__ __forceinline__ bool sum_partial_chunk(const double* part, int nb, int c, int g, int e, int groups, unsigned long long key, double& s) {
     double v[8];
     if (!key) {
@@ -1925,8 +1993,10 @@ __device__ __forceinline__ void reduce_partials_block(const double* part_surf, i
     tstamp(state, do_gn, (int)blockIdx.x, 13);
     {
         double s = 0.0, s2 = 0.0;
-        for (int c = 0; c * 8 * kGroups < nb_surf && ok; c++) ok = sum_partial_chunk(part_surf, nb_surf, c, g, e, kGroups, key, s);
-        for (int c = 0; c * 8 * kGroups < nb_edge && ok; c++) ok = sum_partial_chunk(part_edge, nb_edge, c, g, e, kGroups, key, s2);
+        if (!key && nb_surf > 8 * kGroups) { for (int c = 0; c * 32 * kGroups < nb_surf; c++) sum_partial_wide(part_surf, nb_surf, c, g, e, kGroups, s); }
+        else for (int c = 0; c * 8 * kGroups < nb_surf && ok; c++) ok = sum_partial_chunk(part_surf, nb_surf, c, g, e, kGroups, key, s);
+        if (!key && nb_edge > 8 * kGroups) { for (int c = 0; c * 32 * kGroups < nb_edge; c++) sum_partial_wide(part_edge, nb_edge, c, g, e, kGroups, s2); }
+        else for (int c = 0; c * 8 * kGroups < nb_edge && ok; c++) ok = sum_partial_chunk(part_edge, nb_edge, c, g, e, kGroups, key, s2);
         if (!ok) {           // uniform
             if (threadIdx.x == 0) { state->gn_status = 2; state->epoch = state->epoch + 1ull; }
             return;

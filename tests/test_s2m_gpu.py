@@ -452,6 +452,42 @@ def test_tuning_options_do_not_change_results(gpu_ctx, oracle, opt):
     assert np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6]) and a[7] == b[7]
 
 
+@pytest.mark.parametrize("variant", ["livox", "frontend"])
+def test_association_that_linearises_on_the_fly(gpu_ctx, oracle, variant):
+    """Flavours without count scaling run an outer iteration in TWO launches (k_associate_lin: the lane that fitted a plane / line
+    computes its residual row from the values in its registers, the wave reduces its 64 rows on the MFMA; then reduce + GN) instead of
+    three.  Same rows (computed from the ROUNDED record values), same robust loss; only the partition of the Gram sum differs (one
+    partial per 64 queries instead of one per 1024), so the poses agree to ~1e-13 with the three-launch path — and the records the
+    launch leaves behind are the same bits."""
+    room = synth.make_room(seed=52, n_query=9000, n_edge_query=700, noise=0.005)
+    P, PO, m0 = _setup(gpu_ctx, oracle, variant, room, with_refl=(variant == "livox"))
+    t_ref, q_ref, _, _ = _pose(room, P, variant)
+    t0, q0 = synth.perturbed_pose(t_ref, q_ref, np.random.default_rng(23), 0.15, 1.0)
+    res = []
+    try:
+        for mask in ((L.MASK_SURF,) if variant == "frontend" else (L.MASK_SURF | L.MASK_EDGE, L.MASK_SURF)):
+            for fuse in (0, 1, 2):          # 2: the fused launch with 256-thread workgroups (large scans)
+                gpu_ctx.set_option("fuse_lin", 1 if fuse else 0)
+                gpu_ctx.set_option("fuse_lin_block", 256 if fuse == 2 else 0)
+                _, _, m = _setup(gpu_ctx, oracle, variant, room, with_refl=(variant == "livox"))
+                m.pose_set(0, t0, q0)
+                m.iterate(0, 8, mask)
+                t, q, st = m.pose_get(0)
+                # the records of the last association, through the staged linearisation at a FIXED pose: identical bits <=> identical records
+                G, cost, counts = m.linearize(0, t0, q0, mask)
+                res.append((mask, fuse, t, q, st, G, cost, tuple(counts)))
+    finally:
+        gpu_ctx.set_option("fuse_lin", 1)
+        gpu_ctx.set_option("fuse_lin_block", 0)
+    for a, b, c in zip(res[0::3], res[1::3], res[2::3]):
+        for o in (b, c):
+            assert a[0] == o[0] and a[1] == 0 and o[1] in (1, 2) and a[4] == o[4] == 0
+            assert np.abs(a[2] - t0).max() > 1e-3                                        # the iterations moved the pose
+            assert np.abs(a[2] - o[2]).max() < 1e-11 and np.abs(a[3] - o[3]).max() < 1e-11
+            assert a[7] == o[7] and a[7][0] > 1000
+            assert np.abs(a[5] - o[5]).max() <= 1e-9 * np.abs(a[5]).max()              # (poses differ by ~1e-13, so the last association saw ~the same pose)
+
+
 @pytest.mark.parametrize("flavour", ["rot", "livox"])
 def test_super_row_layout_changes_no_result(gpu_ctx, oracle, flavour):
     """The super-row copy of the map (the inner 27-cell block of a query as one run; the shell's side cells as two) is a layout, not an
