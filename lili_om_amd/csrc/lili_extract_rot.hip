@@ -414,6 +414,79 @@ __device__ void greedy_segment(RingLds& L, signed char* M, int sp, int ep, unsig
 }
 
 #define LILI_ROT_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+// The same picks by a whole WAVE (all 64 lanes call it with the same arguments): the serial loops above spend their time in dependent
+// LDS round trips on one lane.  Here 64 candidates of the sorted order are examined at a time (the first eligible one = first set bit of a
+// ballot), and the +-5 suppression of a pick is ten gap tests on ten lanes followed by two "first break" bit scans.  Picks, labels,
+// lists and marks are exactly those of greedy_segment: a pick only ever ADDS marks, the candidates are visited in the same order, and
+// after every pick the eligibility of the remaining lanes is re-read.
+__device__ void greedy_segment_wave(RingLds& L, signed char* M, int sp, int ep, int j) {
+    const int lane = threadIdx.x & 63;
+    const float4* Pp = L.pts;
+    // marks the +-5 neighbourhood of `ind` up to the first gap > 0.05 on either side (R:441-452)
+    auto suppress = [&](int ind) {
+        bool brk = false;
+        if (lane < 5) brk = (double)gap2(Pp, ind + lane + 1, ind + lane) > 0.05;                  // l = lane + 1: gap(ind + l, ind + l - 1)
+        else if (lane >= 8 && lane < 13) brk = (double)gap2(Pp, ind - (lane - 8) - 1, ind - (lane - 8)) > 0.05;   // l = -(lane - 8) - 1: gap(ind + l, ind + l + 1)
+        const unsigned long long bal = __ballot(brk);
+        const unsigned fw = (unsigned)(bal & 31ull), bw = (unsigned)((bal >> 8) & 31ull);
+        const int nf = fw ? __ffs((int)fw) - 1 : 5, nb = bw ? __ffs((int)bw) - 1 : 5;               // marks before the first break
+        if (lane == 0) M[ind] = 1;
+        if (lane >= 1 && lane <= nf) M[ind + lane] = 1;
+        if (lane >= 16 && lane - 16 < nb) M[ind - (lane - 16) - 1] = 1;
+        LILI_ROT_WAVE_SYNC();
+    };
+    int ne = 0, nf_ = 0, largest = 0;
+    bool done = false;
+    for (int k0 = ep; k0 >= sp && !done; k0 -= 64) {                        // R:413-453, 64 candidates at a time
+        const int k = k0 - lane;
+        const bool in = k >= sp;
+        const int ind = in ? L.sort_ind[k] : 0;
+        const bool big = in && (double)L.curv[ind] > 2.0;
+        const unsigned long long stop = __ballot(!big);                     // first lane that ends the loop (curvature too small, or the segment's end)
+        const unsigned long long live = stop ? ((stop & (0ull - stop)) - 1ull) : ~0ull;       // lanes before it
+        unsigned long long todo = live;
+        while (todo) {
+            const unsigned long long el = __ballot(big && M[ind] == 0) & todo;
+            if (!el) break;
+            const int l = __ffsll((long long)el) - 1;
+            const int pick = __shfl(ind, l);
+            largest++;
+            if (largest > 10) { done = true; break; }
+            if (lane == 0) { L.label[pick] = largest <= 2 ? 2 : 1; L.seg_edge[j][ne] = pick; }
+            ne++;
+            suppress(pick);
+            todo &= ~((2ull << l) - 1ull);                                  // lanes behind the pick
+        }
+        if (stop) done = true;
+    }
+    int smallest = 0;
+    done = false;
+    for (int k0 = sp; k0 <= ep && !done; k0 += 64) {                        // R:456-492
+        const int k = k0 + lane;
+        const bool in = k <= ep;
+        const int ind = in ? L.sort_ind[k] : 0;
+        const bool small = in && (double)L.curv[ind] < 0.1;
+        const bool far = in && !((double)range2(Pp, ind) < 0.25);
+        const unsigned long long stop = __ballot(!small);
+        const unsigned long long live = stop ? ((stop & (0ull - stop)) - 1ull) : ~0ull;
+        unsigned long long todo = live;
+        while (todo) {
+            const unsigned long long el = __ballot(small && far && M[ind] == 0) & todo;
+            if (!el) break;
+            const int l = __ffsll((long long)el) - 1;
+            const int pick = __shfl(ind, l);
+            if (lane == 0) { L.label[pick] = -1; L.seg_flat[j][nf_] = pick; }
+            nf_++;
+            smallest++;
+            if (smallest >= 4) { done = true; break; }                      // before the suppression (R:468-470)
+            suppress(pick);
+            todo &= ~((2ull << l) - 1ull);
+        }
+        if (stop) done = true;
+    }
+    if (lane == 0) { L.seg_ne[j] = ne; L.seg_nf[j] = nf_; }
+}
 __device__ __forceinline__ int block_excl_scan_1024(int v, int* lds, int& total) {
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int inc = v;
@@ -516,7 +589,7 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_select(const float4* __restri
             signed char* M = L.mark + 10 * j;
             for (int k = sp - 5 + lane; k <= ep + 5; k += 64) M[k] = 0;
             LILI_ROT_WAVE_SYNC();
-            if (lane == 0) greedy_segment(L, M, sp, ep, 0u, j);
+            greedy_segment_wave(L, M, sp, ep, j);
         }
     }
     __syncthreads();
