@@ -11,14 +11,17 @@ pytestmark = pytest.mark.gpu
 IDENT_Q, ZERO_T = [1.0, 0.0, 0.0, 0.0], [0.0, 0.0, 0.0]
 
 
-def _check(gpu_ctx, oracle, map_xyz, q_xyz, gate=1.0, min_inside=10, reach=None, cell_pct=None):
+def _check(gpu_ctx, oracle, map_xyz, q_xyz, gate=1.0, min_inside=10, reach=None, cell_pct=None, focus=None, super_rows=None):
     P = L.make_params("frontend", kd_max_radius=gate)          # identity extrinsic: queries are map-frame points
     try:
         if reach is not None:
             gpu_ctx.set_option("grid_reach", reach)
         if cell_pct is not None:
             gpu_ctx.set_option("cell_pct", cell_pct)
+        if super_rows is not None:
+            gpu_ctx.set_option("super_rows", super_rows)
         m = L.ScanToMapMatcher(gpu_ctx, P)
+        m.map_focus(*focus) if focus is not None else m.map_focus(None)
         gpu_ctx.set_debug(True)
         m.set_input_cloud(L.KIND_SURF, map_xyz)
         m.set_queries(0, L.KIND_SURF, q_xyz)
@@ -27,6 +30,8 @@ def _check(gpu_ctx, oracle, map_xyz, q_xyz, gate=1.0, min_inside=10, reach=None,
     finally:
         gpu_ctx.set_option("grid_reach", 2)
         gpu_ctx.set_option("cell_pct", 65)
+        gpu_ctx.set_option("super_rows", 1)
+        L.ScanToMapMatcher(gpu_ctx, P).map_focus(None)
     bi, bd = oracle.knn5_brute(map_xyz, q_xyz)
     inside = bd[:, 4] < gate
     assert inside.sum() >= min_inside
@@ -115,6 +120,26 @@ def test_randomised_scenes_and_index_settings(gpu_ctx, oracle, seed):
     pct = int(rng.integers(50, 101))
     inside = _check(gpu_ctx, oracle, pts, q, gate=gate, min_inside=0, reach=reach, cell_pct=pct)
     assert inside.sum() + (~inside).sum() == 4000
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_randomised_focus_boxes(gpu_ctx, oracle, seed):
+    """lili_map_focus is a hint: whatever the box — centred inside or outside the map, smaller than a cell or larger than the map, flat
+    maps, reach 1 and 2 — queries inside it (one run of the super-row copy) and outside it (nine rows of the base index) get the
+    brute-force neighbours; with the copy switched off as well."""
+    rng = np.random.default_rng(7000 + seed)
+    n_map = int(rng.integers(3000, 40000))
+    ext = rng.uniform(3.0, 25.0, 3) * np.array([1.0, 1.0, rng.choice([1.0, 0.05])])
+    pts = (rng.uniform(-1, 1, (n_map, 3)) * ext + rng.uniform(-200, 200, 3)).astype(np.float32)
+    q = (pts[rng.integers(0, n_map, 3000)] + rng.normal(0, rng.uniform(0.05, 0.8), (3000, 3))).astype(np.float32)
+    q[:50] += 60.0                                                                        # some queries far outside the map
+    gate = float(rng.choice([0.36, 1.0, 2.25]))
+    centre = pts[rng.integers(0, n_map)].astype(np.float64) + rng.normal(0, rng.choice([0.5, 30.0]), 3)
+    radius = float(rng.choice([0.05, 2.0, 8.0, 500.0]))
+    reach = int(rng.choice([1, 2]))
+    _check(gpu_ctx, oracle, pts, q, gate=gate, min_inside=0, reach=reach, focus=(centre, radius))
+    if seed % 3 == 0:
+        _check(gpu_ctx, oracle, pts, q, gate=gate, min_inside=0, reach=reach, super_rows=0)
 
 
 def test_capped_cell_count_stays_exact(gpu_ctx, oracle):
