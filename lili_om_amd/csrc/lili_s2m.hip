@@ -476,6 +476,8 @@ struct Top5 {
     float d[5];
     int j[5];     // position in the cell-sorted array
     int aux;      // profiling only: chunks of four candidates this query went through
+    float4 p[5];  // the five points themselves when `have` (the key selector has just loaded them to recompute the exact distances:
+    bool have;    //  the fit then skips its own gather)
 };
 // FLANN L2_Simple on 3 floats (f32, x then y then z, no FMA)
 __device__ __forceinline__ float dist2(float4 p, float qx, float qy, float qz) {
@@ -519,6 +521,7 @@ struct Sel5 {
     __device__ __forceinline__ void to_top5(Top5& t) const {
 #pragma unroll
         for (int s = 0; s < 5; s++) { t.d[s] = __uint_as_float((unsigned)(k[s] >> 32)); t.j[s] = j[s]; }
+        t.have = false;
     }
 };
 
@@ -558,6 +561,7 @@ struct Sel5K {
     __device__ __forceinline__ void to_top5(Top5& t) const {   // only meaningful right after init (early exits)
 #pragma unroll
         for (int s = 0; s < 5; s++) { t.d[s] = bnd; t.j[s] = -1; }
+        t.have = false;
     }
     __device__ __forceinline__ void push(unsigned key) {
         const unsigned m5 = umed3(k[4], k[5], key), m4 = umed3(k[3], k[4], key), m3 = umed3(k[2], k[3], key);
@@ -589,11 +593,13 @@ struct Sel5K {
         const bool redo = ((k[5] ^ k[4]) < 64u) || ((k[4] >> 6) == bb);
         unsigned long long e[5];
         int jr[5];
+        float4 pp[5];
 #pragma unroll
         for (int s = 0; s < 5; s++) {
             jr[s] = where(k[s]);
             const bool real = jr[s] >= 0;
             const float4 p = g.pts[real ? jr[s] : 0];
+            pp[s] = p;
             const unsigned du = real ? __float_as_uint(dist2(p, qx, qy, qz)) : __float_as_uint(bnd);
             const unsigned lo = real ? (unsigned)__float_as_int(p.w) : 0x7fffffffu;
             e[s] = ((unsigned long long)du << 32) | lo;
@@ -601,13 +607,17 @@ struct Sel5K {
         const bool unsorted = !(e[0] <= e[1] && e[1] <= e[2] && e[2] <= e[3] && e[3] <= e[4]);   // real keys are unique (distinct indices); equal keys are sentinels
         if (__any(unsorted)) {   // within-bucket inversion somewhere in the wave (rare): 9 compare-exchanges
 #define LILI_CE(a, b) { const bool sw = e[b] < e[a]; const unsigned long long ea = e[a], eb = e[b]; const int ja = jr[a], jb = jr[b]; \
-                        e[a] = sw ? eb : ea; e[b] = sw ? ea : eb; jr[a] = sw ? jb : ja; jr[b] = sw ? ja : jb; }
+                        const float4 pa_ = pp[a], pb_ = pp[b]; \
+                        e[a] = sw ? eb : ea; e[b] = sw ? ea : eb; jr[a] = sw ? jb : ja; jr[b] = sw ? ja : jb; \
+                        pp[a].x = sw ? pb_.x : pa_.x; pp[a].y = sw ? pb_.y : pa_.y; pp[a].z = sw ? pb_.z : pa_.z; pp[a].w = sw ? pb_.w : pa_.w; \
+                        pp[b].x = sw ? pa_.x : pb_.x; pp[b].y = sw ? pa_.y : pb_.y; pp[b].z = sw ? pa_.z : pb_.z; pp[b].w = sw ? pa_.w : pb_.w; }
             LILI_CE(0, 1) LILI_CE(3, 4) LILI_CE(2, 4) LILI_CE(2, 3) LILI_CE(0, 3) LILI_CE(0, 2) LILI_CE(1, 4) LILI_CE(1, 3) LILI_CE(1, 2)
 #undef LILI_CE
         }
 #pragma unroll
-        for (int s = 0; s < 5; s++) { t.d[s] = __uint_as_float((unsigned)(e[s] >> 32)); t.j[s] = jr[s]; }
+        for (int s = 0; s < 5; s++) { t.d[s] = __uint_as_float((unsigned)(e[s] >> 32)); t.j[s] = jr[s]; t.p[s] = pp[s]; }
         t.aux = tc;
+        t.have = !redo;
         return redo;
     }
 };
@@ -1016,7 +1026,11 @@ __device__ __forceinline__ bool surf_fit(const GridView& g, const MatchParams& P
     if (!(nn.j[4] >= 0 && (double)nn.d[4] < P.kd_max_radius)) return false;   // L:1615
     float4 m[5];
 #pragma unroll
-    for (int k = 0; k < 5; k++) m[k] = g.pts[nn.j[k]];
+    for (int k = 0; k < 5; k++) m[k] = nn.p[k];
+    if (__any(!nn.have)) {           // exact-selector / tiled / debug paths: the points were not handed over
+#pragma unroll
+        for (int k = 0; k < 5; k++) if (!nn.have) m[k] = g.pts[nn.j[k]];
+    }
     double sum_w = 0.0;
     double mx[5], my[5], mz[5], wk[5];
 #pragma unroll
@@ -1284,7 +1298,7 @@ __device__ __forceinline__ void assoc_surf_body(
     load_assoc_pose(pa, P, Q2, T2);
     d3 pmd = qrot(Q2, d3{(double)ql.x, (double)ql.y, (double)ql.z}) + T2;   // transformPoint, L:695-711
     float px = (float)pmd.x, py = (float)pmd.y, pz = (float)pmd.z;
-    Top5 nn; nn.aux = 0;
+    Top5 nn; nn.aux = 0; nn.have = false;
 #ifdef LILI_PHASE_PROBE
     PhaseProbe probe;
 #pragma unroll
@@ -1360,7 +1374,7 @@ __device__ __forceinline__ void assoc_edge_body(
     load_assoc_pose(pa, P, Q2, T2);
     d3 pmd = qrot(Q2, d3{(double)ql.x, (double)ql.y, (double)ql.z}) + T2;
     float px = (float)pmd.x, py = (float)pmd.y, pz = (float)pmd.z;
-    Top5 nn;
+    Top5 nn; nn.have = false;
     if constexpr (TILED) knn5_tiled(g, L, tab, live, px, py, pz, nn, P.debug);
     else if (live) { knn5_grid(g, tab, px, py, pz, seeded_bound(g, P.edge_gate, nn_cache, n_q, i, px, py, pz), nn); store_nn_cache(nn_cache, n_q, i, nn); }
     bool ok = false;
@@ -1413,7 +1427,7 @@ __global__ __launch_bounds__(kAssocBlock) void k_associate_fine(AssocArgs A, Gri
     const d3 pmd = qrot(Q2, d3{(double)ql.x, (double)ql.y, (double)ql.z}) + T2;
     const float px = (float)pmd.x, py = (float)pmd.y, pz = (float)pmd.z;
     const float gate = gate_bound(kind == 0 ? P.kd_max_radius : P.edge_gate);
-    Top5 nn; nn.aux = 0;
+    Top5 nn; nn.aux = 0; nn.have = false;
     bool fine_hit = false;
     if (live) {
         knn5_grid(gf, tab, px, py, pz, fminf(fbound, gate), nn, P.debug);
