@@ -1093,7 +1093,7 @@ __device__ __forceinline__ bool edge_fit(const GridView& g, const MatchParams& P
     if (!(nn.j[4] >= 0 && (double)nn.d[4] < P.edge_gate)) return false;   // L:1543
     d3 m[5]; d3 c{0, 0, 0};
 #pragma unroll
-    for (int k = 0; k < 5; k++) { float4 p = g.pts[nn.j[k]]; m[k] = d3{(double)p.x, (double)p.y, (double)p.z}; c = c + m[k]; }
+    for (int k = 0; k < 5; k++) { float4 p = nn.p[k]; if (!nn.have) p = g.pts[nn.j[k]]; m[k] = d3{(double)p.x, (double)p.y, (double)p.z}; c = c + m[k]; }
     c = d3{c.x / 5.0, c.y / 5.0, c.z / 5.0};
     double a00 = 0, a01 = 0, a02 = 0, a11 = 0, a12 = 0, a22 = 0;
 #pragma unroll
