@@ -241,6 +241,11 @@ int lili_s2m_associate(lili_ctx* ctx, int slot, int kind, const double t_assoc[3
  * Blocking. */
 int lili_s2m_linearize(lili_ctx* ctx, int slot, int kind_mask, const double t[3], const double q[4],
                        const lili_s2m_params* params, double gram[64], double* cost, int counts[2]);
+/* The same for several slots at once — ONE evaluation of the joint sliding window (a Gram per keyframe; ceres::Solve evaluates the window up to 15
+ * times per keyframe, L/src/BackendFusion.cpp:919-992): t = 3, q = 4, gram = 64, cost = 1 (optional), counts = 2 (optional) values per slot, in the
+ * order of `slots`.  The slots run concurrently and the call synchronises once; results equal lili_s2m_linearize per slot bit for bit.  Blocking. */
+int lili_s2m_linearize_window(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, const double* t, const double* q,
+                              const lili_s2m_params* params, double* gram, double* cost, int* counts);
 
 /* Copy-out of the ordered correspondence lists (the vec_surf_cur_pts / vec_surf_normal /
  * vec_surf_scores and vec_edge_cur_pts / vec_edge_match_j / vec_edge_match_l of the reference).

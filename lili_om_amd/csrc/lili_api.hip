@@ -137,6 +137,7 @@ void lili_ctx_destroy(lili_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& m : ctx->map) { m.sorted_f.release(); m.aux_sorted_f.release(); m.cell_start_f.release(); m.cell_start9.release(); m.cell_start9_f.release(); m.row9.release(); m.pts.release(); m.sorted.release(); m.aux_sorted.release(); m.cell_start.release(); m.cell_tmp.release(); m.pt_cell.release(); m.block_sums.release(); }
     for (auto& s : ctx->slots) for (auto& k : s.k) { k.q.release(); k.rec0.release(); k.rec1.release(); k.valid.release(); k.dbg_idx.release(); k.dbg_d2.release(); k.partials.release(); k.partials_wave.release(); k.perm.release(); k.keys.release(); k.block_counts.release(); k.tiles.release(); }
+    if (ctx->h_records) { (void)hipHostFree(ctx->h_records); ctx->h_records = nullptr; }
     ctx->states.release(); ctx->staging.release(); ctx->gram.release(); ctx->misc.release(); ctx->bin_hist.release(); ctx->bin_start.release(); ctx->bin_sums.release(); ctx->bin_tcnt.release(); ctx->bin_toff.release();
     if (ctx->ext_rot && ctx->ext_rot_free) ctx->ext_rot_free(ctx->ext_rot);
     if (ctx->ext_livox && ctx->ext_livox_free) ctx->ext_livox_free(ctx->ext_livox);
@@ -710,6 +711,59 @@ int lili_s2m_associate(lili_ctx* ctx, int slot, int kind, const double t_assoc[3
         if (rc != LILI_OK) return rc;
         HIPCHK(hipMemcpyAsync(n_res, &ctx->state(slot)->n_res[kind], sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    return LILI_OK;
+}
+
+// Linearisation of SEVERAL slots in one call (one evaluation of the joint sliding window: a Gram per keyframe, L/src/BackendFusion.cpp:919-980 under
+// ceres::Solve's up to 15 evaluations): the slots' launches go out on forked streams like lili_s2m_iterate_window, the records come back in ONE
+// synchronisation instead of one per keyframe.  Results are those of lili_s2m_linearize per slot, bit for bit.
+int lili_s2m_linearize_window(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, const double* t /*3 per slot*/, const double* q /*4 per slot*/,
+                              const lili_s2m_params* params, double* gram /*64 per slot*/, double* cost /*1 per slot, optional*/, int* counts /*2 per slot, optional*/) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(slots && n_slots >= 1 && n_slots <= LILI_MAX_SLOTS, "linearize_window: 1..LILI_MAX_SLOTS slots");
+    ARGCHK((kind_mask & ~3) == 0 && kind_mask != 0, "linearize_window: bad kind mask");
+    ARGCHK(t && q && params && gram, "linearize_window: null argument");
+    for (int i = 0; i < n_slots; i++) {
+        ARGCHK(slots[i] >= 0 && slots[i] < LILI_MAX_SLOTS, "linearize_window: bad slot");
+        for (int k = 0; k < i; k++) ARGCHK(slots[k] != slots[i], "linearize_window: duplicate slot");
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    if (!ctx->fork_ev) HIPCHK(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ctx->fork_ev, ctx->stream));
+    hipStream_t main_stream = ctx->stream;
+    const MatchParams P = to_device_params(params);
+    if (!ctx->h_records) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_records), (size_t)LILI_MAX_SLOTS * LILI_GRAM_DOUBLES * sizeof(double), hipHostMallocDefault));
+    double* host = ctx->h_records;
+    int rc = LILI_OK;
+    for (int i = 0; i < n_slots && rc == LILI_OK; i++) {
+        if (i > 0) {
+            if (!ctx->side[i]) HIPCHK(hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking));
+            if (!ctx->join_ev[i]) HIPCHK(hipEventCreateWithFlags(&ctx->join_ev[i], hipEventDisableTiming));
+            HIPCHK(hipStreamWaitEvent(ctx->side[i], ctx->fork_ev, 0));
+            ctx->stream = ctx->side[i];          // the launch helpers enqueue on ctx->stream (one thread per context)
+        }
+        PoseArg pa{};
+        for (int k = 0; k < 3; k++) pa.t[k] = t[3 * i + k];
+        for (int k = 0; k < 4; k++) pa.q[k] = q[4 * i + k];
+        rc = launch_linearize_reduce(ctx, slots[i], kind_mask, pa, P, ctx->gram_of(slots[i]), 0);
+        hipError_t e = rc == LILI_OK ? hipMemcpyAsync(host + (size_t)i * LILI_GRAM_DOUBLES, ctx->gram_of(slots[i]), LILI_GRAM_DOUBLES * sizeof(double),
+                                                       hipMemcpyDeviceToHost, ctx->stream) : hipSuccess;
+        if (i > 0) {
+            if (e == hipSuccess) e = hipEventRecord(ctx->join_ev[i], ctx->side[i]);
+            ctx->stream = main_stream;
+            if (e == hipSuccess) e = hipStreamWaitEvent(main_stream, ctx->join_ev[i], 0);
+        }
+        if (e != hipSuccess) { ctx->stream = main_stream; return ctx->fail(LILI_E_HIP, std::string("linearize_window: ") + hipGetErrorString(e)); }
+    }
+    ctx->stream = main_stream;
+    HIPCHK(hipStreamSynchronize(ctx->stream));       // also when a launch failed: nothing of this call stays in flight
+    if (rc != LILI_OK) return rc;
+    for (int i = 0; i < n_slots; i++) {
+        const double* h = host + (size_t)i * LILI_GRAM_DOUBLES;
+        std::memcpy(gram + (size_t)64 * i, h, 64 * sizeof(double));
+        if (cost) cost[i] = h[64];
+        if (counts) { counts[2 * i] = (int)h[65]; counts[2 * i + 1] = (int)h[66]; }
     }
     return LILI_OK;
 }

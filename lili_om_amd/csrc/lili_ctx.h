@@ -93,6 +93,7 @@ struct lili_ctx {
     DevBuf fmt_out;      // lili_livox_custom_to_cloud output when the caller wants it on the host
     DevBuf gram;         // LILI_GRAM_DOUBLES per slot
     DevBuf misc;         // bbox words etc.
+    double* h_records = nullptr;   // page-locked landing area for LILI_MAX_SLOTS Gram records (lili_s2m_linearize_window: copies that do not block the host)
     DevBuf bin_hist, bin_start, bin_sums, bin_tcnt, bin_toff;   // query binning scratch
     bool bin_queries = false;   // trust the caller's order (extractor output is ring-/voxel-ordered, i.e. coherent)
     bool tiled = false;         // LDS-staged tiles: measured slower than the direct path once selection is branch-free

@@ -452,6 +452,45 @@ def test_tuning_options_do_not_change_results(gpu_ctx, oracle, opt):
     assert np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6]) and a[7] == b[7]
 
 
+def test_linearize_window_equals_per_slot_calls(gpu_ctx, oracle):
+    """lili_s2m_linearize_window (one evaluation of the joint window: a Gram per keyframe, one synchronisation) returns what
+    lili_s2m_linearize returns slot by slot, bit for bit — Gram, cost, counts — for three keyframes with different scans and poses."""
+    import time
+    room = synth.make_room(seed=61, n_query=9000, n_edge_query=600)
+    P = L.make_params("livox")
+    m = L.ScanToMapMatcher(gpu_ctx, P)
+    m.set_input_cloud(L.KIND_SURF, np.concatenate([room["map_xyz"], room["map_refl"][:, None]], 1))
+    m.set_input_cloud(L.KIND_EDGE, room["edge_map_xyz"])
+    tb, qb = L.api.body_pose_from_lidar(room["t_true"], room["q_true"], P)
+    rng = np.random.default_rng(4)
+    slots, ts, qs = [0, 2, 5], [], []
+    for k, s in enumerate(slots):
+        sel = rng.permutation(room["q_xyz"].shape[0])[: 7000 + 500 * k]
+        m.set_queries(s, L.KIND_SURF, np.concatenate([room["q_xyz"][sel], room["q_refl"][sel, None]], 1))
+        m.set_queries(s, L.KIND_EDGE, room["eq_xyz"][: 400 + 50 * k])
+        t, q = synth.perturbed_pose(tb, qb, rng, 0.03, 0.2)
+        Q2, T2 = L.api.assoc_transform(t, q, P)
+        assert m.find_corresponding_surf_features(s, Q2, T2) > 1000 and m.find_corresponding_corner_features(s, Q2, T2) > 50
+        t2, q2 = synth.perturbed_pose(t, q, rng, 0.01, 0.1)          # evaluated away from the association pose, like an LM trial point
+        ts.append(t2); qs.append(q2)
+    mask = L.MASK_SURF | L.MASK_EDGE
+    single = [m.linearize(s, ts[k], qs[k], mask) for k, s in enumerate(slots)]
+    batch = m.linearize_window(slots, ts, qs, mask)
+    for (G1, c1, n1), (G2, c2, n2) in zip(single, batch):
+        assert np.array_equal(G1, G2) and c1 == c2 and tuple(n1) == tuple(n2) and n2[0] > 1000
+    t0 = time.perf_counter()
+    for _ in range(50):
+        for k, s in enumerate(slots):
+            m.linearize(s, ts[k], qs[k], mask)
+    t1 = time.perf_counter()
+    for _ in range(50):
+        m.linearize_window(slots, ts, qs, mask)
+    t2_ = time.perf_counter()
+    print(f"window evaluation: {1e6 * (t1 - t0) / 50:.0f} us with three calls, {1e6 * (t2_ - t1) / 50:.0f} us with one")
+    with pytest.raises(L.LiliError):
+        m.linearize_window([0, 0], ts[:2], qs[:2], mask)
+
+
 @pytest.mark.parametrize("variant", ["livox", "frontend"])
 def test_association_that_linearises_on_the_fly(gpu_ctx, oracle, variant):
     """Flavours without count scaling run an outer iteration in TWO launches (k_associate_lin: the lane that fitted a plane / line

@@ -59,8 +59,22 @@ def test_window_lm_with_gpu_lidar_blocks_equals_oracle_rows(gpu_ctx, oracle):
             return r, [J[:, :3], J[:, 3:7]], cost
         return fn
 
+    def gpu_joint(*tq):          # the same lidar terms as ONE block fed by lili_s2m_linearize_window: one synchronisation per evaluation
+        ts, qs = tq[0::2], tq[1::2]
+        res, jacs = [], [np.zeros((9 * H.N_KF, 3 if i % 2 == 0 else 4)) for i in range(2 * H.N_KF)]
+        for k, (G, cost, counts) in enumerate(m.linearize_window(list(range(H.N_KF)), ts, qs, mask)):
+            r, jac = L.api.gram_to_factor(G, cost)
+            res.append(r)
+            jacs[2 * k][9 * k:9 * k + 9] = jac[:, :3]
+            jacs[2 * k + 1][9 * k:9 * k + 9] = jac[:, 3:7]
+        return np.concatenate(res), jacs
+
+    sol_j, info_j = W.ceres_lm(H.build_problem(win, None, joint_lidar=gpu_joint), max_num_iterations=15)
     log_g, log_o = [], []
     sol_g, info_g = W.ceres_lm(H.build_problem(win, gpu_block), max_num_iterations=15, log=log_g)
+    assert info_j["iterations"] == info_g["iterations"] and abs(info_j["cost"] - info_g["cost"]) <= 1e-9 * info_g["cost"]
+    for k in range(H.N_KF):
+        assert np.abs(sol_j[f"t{k}"] - sol_g[f"t{k}"]).max() < 1e-9 and np.abs(sol_j[f"q{k}"] - sol_g[f"q{k}"]).max() < 1e-9
     sol_o, info_o = W.ceres_lm(H.build_problem(win, oracle_block), max_num_iterations=15, log=log_o)
     assert evals[0] >= 3 * 10                                     # three Grams per solver evaluation
     assert info_g["iterations"] == info_o["iterations"] and info_g["successful_steps"] == info_o["successful_steps"]

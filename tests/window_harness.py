@@ -82,8 +82,9 @@ def robust_rows(rows, a=1.0):
     return rows[:, :7] * s1[:, None], r * s1, cost
 
 
-def build_problem(win, lidar_block):
-    """The reference's window problem; lidar_block(k) -> residual-block function of (t_k, q_k) for keyframe k."""
+def build_problem(win, lidar_block, joint_lidar=None):
+    """The reference's window problem; lidar_block(k) -> residual-block function of (t_k, q_k) for keyframe k.
+    joint_lidar (optional, instead): ONE residual-block function of (t_0, q_0, ..., t_K-1, q_K-1) for the lidar terms of all keyframes."""
     pb = W.Problem()
     for k, s in enumerate(win["init"]):
         pb.add_parameter(f"t{k}", s["t"])
@@ -96,6 +97,9 @@ def build_problem(win, lidar_block):
         pre = win["pres"][k]["pre"]
         pb.add_residual(lambda ti, qi, sbi, tj, qj, sbj, pre=pre: W.imu_factor(pre, ti, qi, sbi, tj, qj, sbj),
                         [f"t{k}", f"q{k}", f"sb{k}", f"t{k + 1}", f"q{k + 1}", f"sb{k + 1}"])
+    if joint_lidar is not None:
+        pb.add_residual(joint_lidar, [n for k in range(N_KF) for n in (f"t{k}", f"q{k}")])
+        return pb
     for k in range(N_KF):                                       # lidar blocks of every keyframe, CauchyLoss(1) (L:923-975)
         pb.add_residual(lidar_block(k), [f"t{k}", f"q{k}"])
     return pb
