@@ -64,7 +64,7 @@ int lili_p2p_create(lili_ctx* ctx, int rank, int world, lili_p2p** out) {
     lili_p2p* c = new (std::nothrow) lili_p2p();
     if (!c) return LILI_E_NOMEM;
     c->ctx = ctx; c->rank = rank; c->world = world;
-    const size_t bytes = (size_t)2 * kP2PMaxWorld * kP2PSlotBytes;
+    const size_t bytes = (size_t)2 * kP2PMaxWorld * kP2PSlotBytes + 128;      // slots + the sticky failure word (kP2PDeadWord)
     void* p = nullptr;
     // uncached / fine-grained: stores of a peer GPU must become visible to a kernel that is already running
     hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);

@@ -11,6 +11,7 @@ constexpr int kP2PSlotBytes = 1024;                 // 96 payload words + flag w
 constexpr int kP2PSlotWords = kP2PSlotBytes / 8;
 constexpr int kP2PFlagWord = 120;
 constexpr int kP2PMaxCount = 96;                    // 8-byte words per record (the Gram record has 72)
+constexpr int kP2PDeadWord = 2 * kP2PMaxWorld * kP2PSlotWords;   // behind the slots of a mailbox: set once a wait of its owner has given up
 
 struct P2PView {
     unsigned long long* box[kP2PMaxWorld];          // mailbox of every rank (own included), [2 parities][kP2PMaxWorld sources][kP2PSlotWords]
@@ -43,17 +44,21 @@ __device__ __forceinline__ bool p2p_exchange_wave(const P2PView& v, int count, u
         __hip_atomic_store(slot + kP2PFlagWord, v.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     // 3. every source's flag in MY mailbox
+    //    (a communicator whose owner has given up once stays dead: later exchanges return after one look instead of another 2 s —
+    //     the word is read alongside the first poll, so the healthy path pays nothing for it)
     bool ok = true;
+    unsigned long long* dead = v.box[v.rank] + kP2PDeadWord;
     if (lane < world) {
         const unsigned long long* flag = v.box[v.rank] + (size_t)(par * kP2PMaxWorld + lane) * kP2PSlotWords + kP2PFlagWord;
         const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();      // 100 MHz
+        const unsigned long long was_dead = __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (;;) {
             if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == v.seq) break;
-            if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > 200000000ll) { ok = false; break; }
+            if (was_dead || (long long)__builtin_amdgcn_s_memrealtime() - t0 > 200000000ll) { ok = false; break; }
             __builtin_amdgcn_s_sleep(2);
         }
     }
-    if (!__all(ok)) { if (lane == 0) *v.status = 1; return false; }
+    if (!__all(ok)) { if (lane == 0) { *v.status = 1; __hip_atomic_store(dead, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } return false; }
     // 4. sums in rank order; the payload is read with system-scope loads too (they bypass L1 / L2: nothing stale to invalidate)
     const unsigned long long* base = v.box[v.rank] + (size_t)(par * kP2PMaxWorld) * kP2PSlotWords;
     if (F64) {
