@@ -145,7 +145,8 @@ int lili_map_focus(lili_ctx* ctx, const double center[3], double radius);
 
 /* Caller-owned output cloud: `capacity` points of `stride` bytes (>= 16; 32 for pcl::PointXYZI, whose x,y,z
  * are floats at 0/4/8 — the 4th float written at offset 12 is the intensity, copy it to offset 16 for PCL or
- * pass stride 16 and repack); `count` receives the number of points available (may exceed capacity). */
+ * pass stride 16 and repack); `count` receives the number of points available (may exceed capacity); entries of the buffer behind
+ * `count` are unspecified (an extractor may have written there). */
 typedef struct lili_feature_out {
     void* data;
     size_t capacity;
