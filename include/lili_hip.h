@@ -232,6 +232,11 @@ int lili_s2m_set_queries(lili_ctx* ctx, int slot, int kind, const lili_cloud* cl
  * n_res (optional) receives the number of correspondences — passing it makes the call blocking. */
 int lili_s2m_associate(lili_ctx* ctx, int slot, int kind, const double t_assoc[3], const double q_assoc[4],
                        const lili_s2m_params* params, int* n_res);
+/* The same for the keyframes of the sliding window in one call (L/src/BackendFusion.cpp:919-936 calls both finders per keyframe): t_assoc = 3,
+ * q_assoc = 4 values per slot; n_res (optional) = 2 per slot, {surf, edge} (0 for a kind outside kind_mask).  Both kinds of a slot share a launch,
+ * the slots run concurrently, and with n_res the call synchronises once.  Records equal lili_s2m_associate per slot and kind. */
+int lili_s2m_associate_window(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, const double* t_assoc, const double* q_assoc,
+                              const lili_s2m_params* params, int* n_res);
 
 /* Replaces N x (AutoDiffCostFunction::Evaluate + loss corrector) and the J^T J / J^T r accumulation
  * (L/include/factors/LidarKeyframeFactor.h:12-139, L/src/MarginalizationFactor.cpp:3-29,44-70) for the

@@ -107,6 +107,7 @@ _SIGS = {
     "lili_map_set": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Cloud), C.c_double]),
     "lili_map_density": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "lili_s2m_linearize_window": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lili_s2m_associate_window": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lili_map_focus": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_double]),
     "lili_map_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "lili_s2m_set_queries": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Cloud)]),
@@ -418,6 +419,16 @@ class ScanToMapMatcher:
         self.ctx._chk(self.lib.lili_s2m_iterate_restart(self.ctx.h, slot, kind_mask, C.byref(self.params), int(n_iters), int(restart_every),
                                                         int(restart_slot), C.byref(ms) if time_association else None))
         return ms.value if time_association else None
+
+    def associate_window(self, slots, ts_assoc, qs_assoc, kind_mask=MASK_SURF | MASK_EDGE):
+        """findCorresponding{Surf,Corner}Features of all keyframes of the window at the association poses; returns [(n_surf, n_edge)] per slot."""
+        n = len(slots)
+        arr = (C.c_int * n)(*[int(s) for s in slots])
+        t = np.ascontiguousarray(np.asarray(ts_assoc, np.float64).reshape(n, 3))
+        q = np.ascontiguousarray(np.asarray(qs_assoc, np.float64).reshape(n, 4))
+        counts = np.zeros((n, 2), np.int32)
+        self.ctx._chk(self.lib.lili_s2m_associate_window(self.ctx.h, arr, n, int(kind_mask), _ptr(t), _ptr(q), C.byref(self.params), _ptr(counts)))
+        return [(int(counts[k, 0]), int(counts[k, 1])) for k in range(n)]
 
     def linearize_window(self, slots, ts, qs, kind_mask=MASK_SURF | MASK_EDGE):
         """One evaluation of the joint window: (Gram 8x8, cost, counts) per slot at the body poses (ts[k], qs[k]); one synchronisation for all."""

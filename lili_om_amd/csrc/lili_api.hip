@@ -715,6 +715,66 @@ int lili_s2m_associate(lili_ctx* ctx, int slot, int kind, const double t_assoc[3
     return LILI_OK;
 }
 
+// Association of SEVERAL slots in one call (the keyframes of the sliding window, L/src/BackendFusion.cpp:919-936: findCorrespondingSurfFeatures +
+// findCorrespondingCornerFeatures per keyframe): both kinds of a slot share a launch where possible, the slots run on forked streams, the
+// correspondence counts come back in ONE synchronisation.  Results are those of lili_s2m_associate per slot and kind.
+int lili_s2m_associate_window(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, const double* t_assoc /*3 per slot*/, const double* q_assoc /*4 per slot*/,
+                              const lili_s2m_params* params, int* n_res /*2 per slot: surf, edge; optional*/) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(slots && n_slots >= 1 && n_slots <= LILI_MAX_SLOTS, "associate_window: 1..LILI_MAX_SLOTS slots");
+    ARGCHK((kind_mask & ~3) == 0 && kind_mask != 0, "associate_window: bad kind mask");
+    ARGCHK(t_assoc && q_assoc && params, "associate_window: null argument");
+    for (int i = 0; i < n_slots; i++) {
+        ARGCHK(slots[i] >= 0 && slots[i] < LILI_MAX_SLOTS, "associate_window: bad slot");
+        for (int k = 0; k < i; k++) ARGCHK(slots[k] != slots[i], "associate_window: duplicate slot");
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    if (!ctx->fork_ev) HIPCHK(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ctx->fork_ev, ctx->stream));
+    hipStream_t main_stream = ctx->stream;
+    const MatchParams P = to_device_params(params);
+    if (!ctx->h_records) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_records), (size_t)LILI_MAX_SLOTS * LILI_GRAM_DOUBLES * sizeof(double), hipHostMallocDefault));
+    int* host = reinterpret_cast<int*>(ctx->h_records);
+    int rc = LILI_OK;
+    for (int i = 0; i < n_slots && rc == LILI_OK; i++) {
+        if (i > 0) {
+            if (!ctx->side[i]) HIPCHK(hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking));
+            if (!ctx->join_ev[i]) HIPCHK(hipEventCreateWithFlags(&ctx->join_ev[i], hipEventDisableTiming));
+            HIPCHK(hipStreamWaitEvent(ctx->side[i], ctx->fork_ev, 0));
+            ctx->stream = ctx->side[i];
+        }
+        PoseArg pa{};
+        for (int k = 0; k < 3; k++) pa.t[k] = t_assoc[3 * i + k];
+        for (int k = 0; k < 4; k++) pa.q[k] = q_assoc[4 * i + k];
+        ctx->slots[slots[i]].use_global_counts = false;
+        rc = 1;
+        if (kind_mask == (LILI_MASK_SURF | LILI_MASK_EDGE) && ctx->merge_kinds) rc = launch_associate_both(ctx, slots[i], pa, P);
+        if (rc == 1) {                                   // not eligible (or one kind only): one launch per kind
+            rc = LILI_OK;
+            for (int kind = 0; kind < 2 && rc == LILI_OK; kind++) if (kind_mask & (1 << kind)) rc = launch_associate(ctx, slots[i], kind, pa, P);
+        }
+        hipError_t e = hipSuccess;
+        if (rc == LILI_OK && n_res) {
+            rc = launch_sum_counts(ctx, slots[i], kind_mask);
+            if (rc == LILI_OK) e = hipMemcpyAsync(host + 2 * i, ctx->state(slots[i])->n_res, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+        }
+        if (i > 0) {
+            if (e == hipSuccess) e = hipEventRecord(ctx->join_ev[i], ctx->side[i]);
+            ctx->stream = main_stream;
+            if (e == hipSuccess) e = hipStreamWaitEvent(main_stream, ctx->join_ev[i], 0);
+        }
+        if (e != hipSuccess) { ctx->stream = main_stream; return ctx->fail(LILI_E_HIP, std::string("associate_window: ") + hipGetErrorString(e)); }
+    }
+    ctx->stream = main_stream;
+    if (n_res || rc != LILI_OK) HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (rc != LILI_OK) return rc;
+    if (n_res) for (int i = 0; i < n_slots; i++) {
+        n_res[2 * i] = (kind_mask & LILI_MASK_SURF) ? host[2 * i] : 0;
+        n_res[2 * i + 1] = (kind_mask & LILI_MASK_EDGE) ? host[2 * i + 1] : 0;
+    }
+    return LILI_OK;
+}
+
 // Linearisation of SEVERAL slots in one call (one evaluation of the joint sliding window: a Gram per keyframe, L/src/BackendFusion.cpp:919-980 under
 // ceres::Solve's up to 15 evaluations): the slots' launches go out on forked streams like lili_s2m_iterate_window, the records come back in ONE
 // synchronisation instead of one per keyframe.  Results are those of lili_s2m_linearize per slot, bit for bit.

@@ -463,18 +463,27 @@ def test_linearize_window_equals_per_slot_calls(gpu_ctx, oracle):
     m.set_input_cloud(L.KIND_EDGE, room["edge_map_xyz"])
     tb, qb = L.api.body_pose_from_lidar(room["t_true"], room["q_true"], P)
     rng = np.random.default_rng(4)
-    slots, ts, qs = [0, 2, 5], [], []
+    slots, ts, qs, ta, qa, counts_1 = [0, 2, 5], [], [], [], [], []
     for k, s in enumerate(slots):
         sel = rng.permutation(room["q_xyz"].shape[0])[: 7000 + 500 * k]
         m.set_queries(s, L.KIND_SURF, np.concatenate([room["q_xyz"][sel], room["q_refl"][sel, None]], 1))
         m.set_queries(s, L.KIND_EDGE, room["eq_xyz"][: 400 + 50 * k])
         t, q = synth.perturbed_pose(tb, qb, rng, 0.03, 0.2)
         Q2, T2 = L.api.assoc_transform(t, q, P)
-        assert m.find_corresponding_surf_features(s, Q2, T2) > 1000 and m.find_corresponding_corner_features(s, Q2, T2) > 50
+        counts_1.append((m.find_corresponding_surf_features(s, Q2, T2), m.find_corresponding_corner_features(s, Q2, T2)))
+        assert counts_1[-1][0] > 1000 and counts_1[-1][1] > 50
+        ta.append(t); qa.append(q)
         t2, q2 = synth.perturbed_pose(t, q, rng, 0.01, 0.1)          # evaluated away from the association pose, like an LM trial point
         ts.append(t2); qs.append(q2)
     mask = L.MASK_SURF | L.MASK_EDGE
     single = [m.linearize(s, ts[k], qs[k], mask) for k, s in enumerate(slots)]
+    # the association of the window in one call: same counts, and the records it leaves give the same Grams
+    assoc = [L.api.assoc_transform(ta[k], qa[k], P) for k in range(len(slots))]
+    counts_w = m.associate_window(slots, [a[1] for a in assoc], [a[0] for a in assoc], mask)
+    assert counts_w == counts_1
+    again = [m.linearize(s, ts[k], qs[k], mask) for k, s in enumerate(slots)]
+    for (G1, c1, n1), (G2, c2, n2) in zip(single, again):
+        assert np.array_equal(G1, G2) and c1 == c2 and tuple(n1) == tuple(n2)
     batch = m.linearize_window(slots, ts, qs, mask)
     for (G1, c1, n1), (G2, c2, n2) in zip(single, batch):
         assert np.array_equal(G1, G2) and c1 == c2 and tuple(n1) == tuple(n2) and n2[0] > 1000

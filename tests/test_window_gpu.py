@@ -27,12 +27,12 @@ def test_window_lm_with_gpu_lidar_blocks_equals_oracle_rows(gpu_ctx, oracle):
     m = L.ScanToMapMatcher(gpu_ctx, P)
     m.set_input_cloud(L.KIND_SURF, np.c_[room["map_xyz"], room["map_refl"]])
     m.set_input_cloud(L.KIND_EDGE, room["edge_map_xyz"])
-    n_gpu = []
+    assoc = []
     for k, kf in enumerate(win["kfs"]):
         m.set_queries(k, L.KIND_SURF, np.c_[kf["q_xyz"], kf["q_refl"]])
         m.set_queries(k, L.KIND_EDGE, kf["eq_xyz"])
-        Q2, T2 = L.api.assoc_transform(win["init"][k]["t"], win["init"][k]["q"], P)
-        n_gpu.append((m.find_corresponding_surf_features(k, Q2, T2), m.find_corresponding_corner_features(k, Q2, T2)))
+        assoc.append(L.api.assoc_transform(win["init"][k]["t"], win["init"][k]["q"], P))
+    n_gpu = m.associate_window(list(range(H.N_KF)), [a[1] for a in assoc], [a[0] for a in assoc], mask)       # both finders of every keyframe, one call
     evals = [0]
 
     def gpu_block(k):
