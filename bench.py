@@ -202,6 +202,39 @@ def secondary_stages(L, ctx, w, torch):
     out["map_index_build_base_only"] = entry(sec, 36 * w["map_xyz"].shape[0], "maps/s", "option super_rows = 0: the cell-sorted index alone")
     ctx.set_option("super_rows", 1)
     m.map_focus(w["lidar_t"], focus_r)
+    # A keyframe of a pipeline that rebuilds its local map every keyframe (L/src/BackendFusion.cpp:839-840): new index of the 5 M-point map +
+    # 30 outer iterations (3 registrations of 10).  Blocking build before the iterations vs the NEXT keyframe's build started on a side stream
+    # under this keyframe's iterations (lili_map_set_begin / _end).
+    try:
+        scan_q = np.ascontiguousarray(w["scan_xyz"])
+        m.set_queries(0, L.KIND_SURF, scan_q)
+        t_body, q_body = body_pose_for_lidar(L, P, w["lidar_t"])
+        tp, qp = synth.perturbed_pose(t_body, q_body, np.random.default_rng(synth.SEED_POSE), 0.3, 2.0)
+        m.pose_set(1, tp, qp)
+        n_kf = 12
+
+        def keyframes(pipelined):
+            m.set_input_cloud(L.KIND_SURF, cloud)
+            ctx.sync()
+            tic = time.perf_counter()
+            for k in range(n_kf):
+                m.iterate_restart(0, 30, 10, 1, L.MASK_SURF)
+                if pipelined:
+                    m.set_input_cloud_begin(L.KIND_SURF, cloud)
+                    m.set_input_cloud_end(L.KIND_SURF)
+                else:
+                    m.set_input_cloud(L.KIND_SURF, cloud)
+            ctx.sync()
+            return (time.perf_counter() - tic) / n_kf
+        keyframes(True)
+        s_seq, s_pipe = keyframes(False), keyframes(True)
+        tq = m.pose_get(0)
+        out["keyframe_pipeline"] = {"value": round(1.0 / s_pipe, 1), "unit": "keyframes/s", "ms": round(s_pipe * 1e3, 4), "blocking_build_ms": round(s_seq * 1e3, 4),
+                                    "gn_status": int(tq[2]),
+                                    "note": "per keyframe: index of the 5 M-point map (focused super-row copy) + 30 outer iterations of the 200 k-point scan; "
+                                            "the next keyframe's build runs on a side stream under the iterations (lili_map_set_begin / _end) vs blocking lili_map_set"}
+    except Exception as e:      # noqa: BLE001
+        out["keyframe_pipeline_error"] = repr(e)
     # the same from HOST memory: pageable (the runtime stages it page by page) and page-locked (lili_host_alloc: straight DMA)
     hmap = np.ascontiguousarray(w["map_xyz"])
     sec = rate(lambda: m.set_input_cloud(L.KIND_SURF, hmap), 3)

@@ -125,6 +125,13 @@ void lili_host_free(void* p);
  * point the reference's gate `d2[4] < max_sq_radius` can accept — the search is EXACT for all queries
  * the reference keeps.  Blocking (reads the bounding box back once). */
 int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq_radius);
+/* The same in two steps for pipelines that rebuild the local map every keyframe (L/src/BackendFusion.cpp:839-840 runs once per keyframe, before
+ * the window's iterations): _begin builds the NEXT index of `kind` on a side stream into a second set of buffers — work already enqueued on the
+ * context's stream (the previous keyframe's iterations, lili_s2m_iterate*) keeps the current index and overlaps with the build —, _end makes the
+ * new index the current one for everything enqueued after it.  _begin waits for the build's two small read-backs only (bounding box, density).
+ * The cloud must stay valid until _end.  Results are those of lili_map_set. */
+int lili_map_set_begin(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq_radius);
+int lili_map_set_end(lili_ctx* ctx, int kind);
 /* Number of points / grid cells of the current index (diagnostics). */
 int lili_map_info(lili_ctx* ctx, int kind, int64_t* n_points, int64_t* n_cells, double* cell_edge);
 /* Density adaptation of the current index (diagnostics): the point-weighted mean number of points per gate-sized cell measured by

@@ -108,6 +108,8 @@ _SIGS = {
     "lili_map_density": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "lili_s2m_linearize_window": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lili_s2m_associate_window": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lili_map_set_begin": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Cloud), C.c_double]),
+    "lili_map_set_end": (C.c_int, [C.c_void_p, C.c_int]),
     "lili_map_focus": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_double]),
     "lili_map_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "lili_s2m_set_queries": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Cloud)]),
@@ -280,6 +282,21 @@ class ScanToMapMatcher:
         if max_sq_radius is None:
             max_sq_radius = self.params.kd_max_radius if kind == KIND_SURF else self.params.edge_gate
         self.ctx._chk(self.lib.lili_map_set(self.ctx.h, kind, C.byref(cloud), float(max_sq_radius)))
+
+    def set_input_cloud_begin(self, kind, cloud, max_sq_radius=None):
+        """Starts building the NEXT index of `kind` on a side stream (work already enqueued keeps the current one); finish with
+        set_input_cloud_end.  The cloud's memory must stay valid until then (a reference is kept here)."""
+        if not isinstance(cloud, Cloud):
+            cloud = cloud_from_numpy(cloud, aux_col=3 if (np.ndim(cloud) == 2 and np.shape(cloud)[1] > 3) else None)
+        if max_sq_radius is None:
+            max_sq_radius = self.params.kd_max_radius if kind == KIND_SURF else self.params.edge_gate
+        self._pending_cloud = getattr(self, "_pending_cloud", {})
+        self._pending_cloud[kind] = cloud
+        self.ctx._chk(self.lib.lili_map_set_begin(self.ctx.h, kind, C.byref(cloud), float(max_sq_radius)))
+
+    def set_input_cloud_end(self, kind):
+        self.ctx._chk(self.lib.lili_map_set_end(self.ctx.h, kind))
+        getattr(self, "_pending_cloud", {}).pop(kind, None)
 
     def map_info(self, kind):
         n, nc, ce = C.c_int64(), C.c_int64(), C.c_double()

@@ -135,6 +135,8 @@ void lili_ctx_destroy(lili_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->build_stream) { (void)hipStreamSynchronize(ctx->build_stream); (void)hipStreamDestroy(ctx->build_stream); }
+    for (int k = 0; k < 2; k++) { if (ctx->build_done[k]) (void)hipEventDestroy(ctx->build_done[k]); if (ctx->main_mark[k]) (void)hipEventDestroy(ctx->main_mark[k]); }
     for (auto& m : ctx->map) { m.sorted_f.release(); m.aux_sorted_f.release(); m.cell_start_f.release(); m.cell_start9.release(); m.cell_start9_f.release(); m.row9.release(); m.pts.release(); m.sorted.release(); m.aux_sorted.release(); m.cell_start.release(); m.cell_tmp.release(); m.pt_cell.release(); m.block_sums.release(); }
     for (auto& s : ctx->slots) for (auto& k : s.k) { k.q.release(); k.rec0.release(); k.rec1.release(); k.valid.release(); k.dbg_idx.release(); k.dbg_d2.release(); k.partials.release(); k.partials_wave.release(); k.perm.release(); k.keys.release(); k.block_counts.release(); k.tiles.release(); }
     if (ctx->h_records) { (void)hipHostFree(ctx->h_records); ctx->h_records = nullptr; }
@@ -329,6 +331,50 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
         }
     }
     m.valid = true;
+    return LILI_OK;
+}
+
+// Double-buffered map index: lili_map_set_begin builds the NEXT index of `kind` on a side stream (own staging and scratch words), so the
+// kernels already enqueued on the context's stream — a keyframe's iterations — keep using the current index and run concurrently with
+// the build (bandwidth-bound kernels under latency-bound ones); lili_map_set_end makes the new index current for everything enqueued
+// after it.  The call itself still waits for the two small read-backs of the build (bounding box, density), not for the context's stream.
+int lili_map_set_begin(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq_radius) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(kind == LILI_KIND_SURF || kind == LILI_KIND_EDGE, "map_set_begin: bad kind");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (!ctx->build_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->build_stream, hipStreamNonBlocking));
+    if (!ctx->build_done[kind]) HIPCHK(hipEventCreateWithFlags(&ctx->build_done[kind], hipEventDisableTiming));
+    if (!ctx->main_mark[kind]) HIPCHK(hipEventCreateWithFlags(&ctx->main_mark[kind], hipEventDisableTiming));
+    if (ctx->misc_build.ensure(2 * 64 * 128) != hipSuccess) return ctx->fail(LILI_E_NOMEM, "map_set_begin: scratch allocation failed");
+    // the buffers being rebuilt are the ones the index before the current one lived in: everything enqueued up to the swap that retired
+    // them (main_mark, recorded by lili_map_set_end) has to be through before they are overwritten — NOT what was enqueued since, which
+    // uses the current index and is what the build overlaps with
+    if (ctx->main_marked[kind]) HIPCHK(hipStreamWaitEvent(ctx->build_stream, ctx->main_mark[kind], 0));
+    hipStream_t main_stream = ctx->stream;
+    // run the ordinary build with the context's stream, scratch and index slot pointed at the build side (one host thread per context)
+    ctx->stream = ctx->build_stream;
+    ctx->staging.swap(ctx->staging_build); ctx->misc.swap(ctx->misc_build); ctx->map[kind].swap(ctx->map_next[kind]);
+    const int rc = lili_map_set(ctx, kind, cloud, max_sq_radius);
+    hipError_t e = rc == LILI_OK ? hipEventRecord(ctx->build_done[kind], ctx->build_stream) : hipSuccess;
+    ctx->map[kind].swap(ctx->map_next[kind]); ctx->misc.swap(ctx->misc_build); ctx->staging.swap(ctx->staging_build);
+    ctx->stream = main_stream;
+    if (rc != LILI_OK) return rc;
+    if (e != hipSuccess) return ctx->fail(LILI_E_HIP, std::string("map_set_begin: ") + hipGetErrorString(e));
+    ctx->build_pending[kind] = true;
+    return LILI_OK;
+}
+
+int lili_map_set_end(lili_ctx* ctx, int kind) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(kind == LILI_KIND_SURF || kind == LILI_KIND_EDGE, "map_set_end: bad kind");
+    if (!ctx->build_pending[kind]) return ctx->fail(LILI_E_STATE, "map_set_end: no lili_map_set_begin pending for this kind");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->build_done[kind], 0));      // later work on the context's stream sees the finished index
+    ctx->map[kind].swap(ctx->map_next[kind]);
+    HIPCHK(hipEventRecord(ctx->main_mark[kind], ctx->stream));             // everything that may still read the retired index is before this mark
+    ctx->main_marked[kind] = true;
+    for (auto& s : ctx->slots) { s.k[kind].binned = false; s.k[kind].nn_cache_valid = false; s.k[kind].order_valid = false; s.k[kind].launches = 0; }
+    ctx->build_pending[kind] = false;
     return LILI_OK;
 }
 

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 using namespace lili;
@@ -27,6 +28,7 @@ struct DevBuf {
         return e;
     }
     void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+    void swap(DevBuf& o) { void* tp = p; p = o.p; o.p = tp; size_t tc = cap; cap = o.cap; o.cap = tc; }
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
@@ -47,6 +49,14 @@ struct MapIndex {
     DevBuf sorted_f, aux_sorted_f, cell_start_f, cell_start9_f;
     float fbound = 0.f;          // squared radius the fine index covers completely (rounded down)
     double fine_cell = 0, mean_occupancy = 0;
+    void swap(MapIndex& o) {     // lili_map_set_begin / _end: the index under construction and the current one trade places
+        std::swap(valid, o.valid); std::swap(n, o.n); std::swap(n_cells, o.n_cells); std::swap(cell, o.cell); std::swap(view, o.view);
+        pts.swap(o.pts); sorted.swap(o.sorted); aux_sorted.swap(o.aux_sorted); cell_start.swap(o.cell_start); cell_tmp.swap(o.cell_tmp); pt_cell.swap(o.pt_cell);
+        block_sums.swap(o.block_sums); cell_start9.swap(o.cell_start9); row9.swap(o.row9);
+        std::swap(has_aux, o.has_aux); std::swap(has_fine, o.has_fine); std::swap(fview, o.fview);
+        sorted_f.swap(o.sorted_f); aux_sorted_f.swap(o.aux_sorted_f); cell_start_f.swap(o.cell_start_f); cell_start9_f.swap(o.cell_start9_f);
+        std::swap(fbound, o.fbound); std::swap(fine_cell, o.fine_cell); std::swap(mean_occupancy, o.mean_occupancy);
+    }
 };
 
 struct KindSlot {
@@ -87,6 +97,13 @@ struct lili_ctx {
     bool keep_nn = false;
     std::string err;
     MapIndex map[2];
+    // lili_map_set_begin / _end: the NEXT index of a kind is built on its own stream (own scratch: staging, bbox / density words) while work
+    // already enqueued keeps using the current one
+    MapIndex map_next[2];
+    hipStream_t build_stream = nullptr;
+    hipEvent_t build_done[2] = {}, main_mark[2] = {};
+    bool build_pending[2] = {false, false}, main_marked[2] = {false, false};
+    DevBuf staging_build, misc_build;
     Slot slots[LILI_MAX_SLOTS];
     DevBuf states;       // SlotState[LILI_MAX_SLOTS]
     DevBuf staging;      // raw host clouds

@@ -452,6 +452,54 @@ def test_tuning_options_do_not_change_results(gpu_ctx, oracle, opt):
     assert np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6]) and a[7] == b[7]
 
 
+def test_map_set_begin_end_overlaps_and_equals_blocking_build(gpu_ctx, oracle):
+    """A pipeline that rebuilds its local map every keyframe: lili_map_set_begin builds the next index on a side stream while the iterations
+    already enqueued keep the current one, lili_map_set_end swaps.  Over six keyframes with different maps (sizes, a focus box on some) the
+    poses equal those of the blocking lili_map_set sequence bit for bit — including keyframes whose iterations are still in flight when the
+    next build starts and a build that re-uses the buffers of the index retired two keyframes earlier."""
+    room = synth.make_room(seed=71, n_query=8000, n_edge_query=300)
+    P = L.make_params("rot")
+    tb, qb = L.api.body_pose_from_lidar(room["t_true"], room["q_true"], P)
+    t0, q0 = synth.perturbed_pose(tb, qb, np.random.default_rng(29), 0.1, 0.6)
+    rng = np.random.default_rng(11)
+    n_all = room["map_xyz"].shape[0]
+    maps = [np.ascontiguousarray(room["map_xyz"][np.sort(rng.choice(n_all, int(n_all * f), replace=False))]) for f in (1.0, 0.8, 0.9, 0.7, 1.0, 0.85)]
+    mask = L.MASK_SURF | L.MASK_EDGE
+
+    def run(pipelined):
+        m = L.ScanToMapMatcher(gpu_ctx, P)
+        m.set_input_cloud(L.KIND_EDGE, room["edge_map_xyz"])
+        m.set_queries(0, L.KIND_SURF, room["q_xyz"]); m.set_queries(0, L.KIND_EDGE, room["eq_xyz"])
+        poses = []
+        m.set_input_cloud(L.KIND_SURF, maps[0])
+        for k in range(len(maps)):
+            m.map_focus(room["t_true"], 3.0) if k % 2 else m.map_focus(None)      # the hint applies to the NEXT build
+            m.pose_set(0, t0, q0)
+            m.iterate(0, 12, mask)                                                   # asynchronous: 36 launches in flight
+            if k + 1 < len(maps):
+                if pipelined:
+                    m.set_input_cloud_begin(L.KIND_SURF, maps[k + 1])                # builds while the iterations above run
+                    t, q, st = m.pose_get(0)                                         # (blocks on the context's stream only)
+                    m.set_input_cloud_end(L.KIND_SURF)
+                else:
+                    t, q, st = m.pose_get(0)
+                    m.set_input_cloud(L.KIND_SURF, maps[k + 1])
+            else:
+                t, q, st = m.pose_get(0)
+            assert st == 0
+            poses.append((t.copy(), q.copy()))
+        m.map_focus(None)
+        return poses
+
+    a, b = run(False), run(True)
+    assert len({tuple(np.round(p[0], 9)) for p in a}) > 1                                # different maps give different poses
+    for (ta, qa_), (tb_, qb_) in zip(a, b):
+        assert np.array_equal(ta, tb_) and np.array_equal(qa_, qb_)
+    m = L.ScanToMapMatcher(gpu_ctx, P)
+    with pytest.raises(L.LiliError):
+        m.set_input_cloud_end(L.KIND_SURF)                                               # nothing pending
+
+
 def test_linearize_window_equals_per_slot_calls(gpu_ctx, oracle):
     """lili_s2m_linearize_window (one evaluation of the joint window: a Gram per keyframe, one synchronisation) returns what
     lili_s2m_linearize returns slot by slot, bit for bit — Gram, cost, counts — for three keyframes with different scans and poses."""
