@@ -342,7 +342,11 @@ int lili_map_set_begin(lili_ctx* ctx, int kind, const lili_cloud* cloud, double 
     if (!ctx) return LILI_E_ARG;
     ARGCHK(kind == LILI_KIND_SURF || kind == LILI_KIND_EDGE, "map_set_begin: bad kind");
     HIPCHK(hipSetDevice(ctx->device));
-    if (!ctx->build_stream) HIPCHK(hipStreamCreateWithFlags(&ctx->build_stream, hipStreamNonBlocking));
+    if (!ctx->build_stream) {          // lowest priority: the latency-bound iteration kernels on the context's stream go first
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { (void)hipGetLastError(); lo = 0; }
+        HIPCHK(hipStreamCreateWithPriority(&ctx->build_stream, hipStreamNonBlocking, lo));
+    }
     if (!ctx->build_done[kind]) HIPCHK(hipEventCreateWithFlags(&ctx->build_done[kind], hipEventDisableTiming));
     if (!ctx->main_mark[kind]) HIPCHK(hipEventCreateWithFlags(&ctx->main_mark[kind], hipEventDisableTiming));
     if (ctx->misc_build.ensure(2 * 64 * 128) != hipSuccess) return ctx->fail(LILI_E_NOMEM, "map_set_begin: scratch allocation failed");
