@@ -26,6 +26,8 @@
 #pragma once
 #include <ceres/ceres.h>
 
+#include <vector>
+
 #include "lili_hip.h"
 
 namespace lili {
@@ -63,6 +65,50 @@ public:
 private:
     lili_ctx* ctx_;
     int slot_, mask_;
+    lili_s2m_params params_;
+};
+
+// The lidar terms of ALL keyframes of the sliding window as ONE cost function (L/src/BackendFusion.cpp:919-980 adds the per-correspondence
+// blocks keyframe by keyframe): parameter blocks (t_0, q_0, t_1, q_1, ...), 9 residuals per keyframe as in LidarBatchFactor, block-diagonal
+// Jacobian.  One Evaluate is ONE lili_s2m_linearize_window call — the keyframes run concurrently on the GPU and the host synchronises once
+// per evaluation instead of once per keyframe.  Numerically identical to one LidarBatchFactor per keyframe (oracle/refshim/ref_seam.cpp).
+class LidarWindowFactor : public ceres::CostFunction {
+public:
+    LidarWindowFactor(lili_ctx* ctx, const std::vector<int>& slots, int kind_mask, const lili_s2m_params& params)
+        : ctx_(ctx), slots_(slots), mask_(kind_mask), params_(params) {
+        set_num_residuals(9 * (int)slots_.size());
+        for (size_t k = 0; k < slots_.size(); ++k) { mutable_parameter_block_sizes()->push_back(3); mutable_parameter_block_sizes()->push_back(4); }
+    }
+
+    bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const override {
+        const int K = (int)slots_.size(), rows = 9 * K;
+        std::vector<double> t(3 * K), q(4 * K), gram(64 * K), cost(K);
+        for (int k = 0; k < K; ++k) {
+            for (int c = 0; c < 3; ++c) t[3 * k + c] = parameters[2 * k][c];
+            for (int c = 0; c < 4; ++c) q[4 * k + c] = parameters[2 * k + 1][c];
+        }
+        if (lili_s2m_linearize_window(ctx_, slots_.data(), K, mask_, t.data(), q.data(), &params_, gram.data(), cost.data(), nullptr) != LILI_OK) return false;
+        for (int k = 0; k < K; ++k) {
+            double res[9], jac[63];
+            if (lili_gram_to_factor(&gram[64 * k], cost[k], res, jac) != LILI_OK) return false;
+            for (int i = 0; i < 9; ++i) residuals[9 * k + i] = res[i];
+            if (!jacobians) continue;
+            if (double* jt = jacobians[2 * k]) {
+                for (int i = 0; i < rows * 3; ++i) jt[i] = 0.0;
+                for (int r = 0; r < 9; ++r) for (int c = 0; c < 3; ++c) jt[(9 * k + r) * 3 + c] = jac[r * 7 + c];
+            }
+            if (double* jq = jacobians[2 * k + 1]) {
+                for (int i = 0; i < rows * 4; ++i) jq[i] = 0.0;
+                for (int r = 0; r < 9; ++r) for (int c = 0; c < 4; ++c) jq[(9 * k + r) * 4 + c] = jac[r * 7 + 3 + c];
+            }
+        }
+        return true;
+    }
+
+private:
+    lili_ctx* ctx_;
+    std::vector<int> slots_;
+    int mask_;
     lili_s2m_params params_;
 };
 

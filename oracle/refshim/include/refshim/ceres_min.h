@@ -63,6 +63,8 @@ public:
     const std::vector<int>& parameter_block_sizes() const { return sizes_; }
     int num_residuals() const { return nres_; }
 protected:
+    std::vector<int>* mutable_parameter_block_sizes() { return &sizes_; }      // as in ceres/cost_function.h (dynamically sized cost functions)
+    void set_num_residuals(int n) { nres_ = n; }
     std::vector<int> sizes_; int nres_ = 0;
 };
 

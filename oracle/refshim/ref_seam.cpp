@@ -115,6 +115,48 @@ int main(int argc, char** argv) {
     for (int k = 0; k < 7; k++) { gmax = std::fmax(gmax, std::fabs(gb[k])); gdiff = std::fmax(gdiff, std::fabs(ga[k] - gb[k])); }
     std::printf("n_surf=%d\nn_edge=%d\nblocks_reference=%zu\nblocks_batch=%zu\nH_rel_diff=%.3e\ng_rel_diff=%.3e\ncost_batch=%.17g\ncost_reference=%.17g\n",
                 ns, ne, pb.blocks.size(), pa.blocks.size(), hdiff / hmax, gdiff / gmax, ca, cb);
+
+    // ---- problem C: the window — three keyframes (the same scan in three slots, evaluated at three different poses) as ONE LidarWindowFactor
+    //      against one LidarBatchFactor per keyframe: the same residuals and Jacobian entries, bit for bit
+    {
+        const int K = 3;
+        for (int k = 1; k < K; k++) {
+            rc = lili_s2m_set_queries(ctx, k, LILI_KIND_SURF, &sq) | lili_s2m_set_queries(ctx, k, LILI_KIND_EDGE, &eq);
+            int a = 0, b2 = 0;
+            rc |= lili_s2m_associate(ctx, k, LILI_KIND_SURF, t2, q2, &P, &a) | lili_s2m_associate(ctx, k, LILI_KIND_EDGE, t2, q2, &P, &b2);
+            if (rc != LILI_OK || a != ns || b2 != ne) { std::printf("error=window_setup\n"); return 6; }
+        }
+        double tw[3][3], qw[3][4];
+        for (int k = 0; k < K; k++) {
+            for (int c = 0; c < 3; c++) tw[k][c] = t[c] + 0.01 * (k + 1) * (c == 0 ? 1.0 : c == 1 ? -0.5 : 0.25);
+            const double ang = 0.002 * (k + 1);
+            Eigen::Quaterniond d(std::cos(ang / 2), 0.0, 0.0, std::sin(ang / 2));
+            Eigen::Quaterniond qq = Qb * d;
+            qw[k][0] = qq.w(); qw[k][1] = qq.x(); qw[k][2] = qq.y(); qw[k][3] = qq.z();
+        }
+        const int mask = LILI_MASK_SURF | LILI_MASK_EDGE;
+        lili::LidarWindowFactor wf(ctx, std::vector<int>{0, 1, 2}, mask, P);
+        const double* pw[6] = {tw[0], qw[0], tw[1], qw[1], tw[2], qw[2]};
+        std::vector<double> rw(9 * K), jw[6];
+        double* jwp[6];
+        for (int j = 0; j < 6; j++) { jw[j].assign((size_t)9 * K * (j % 2 ? 4 : 3), -1.0); jwp[j] = jw[j].data(); }
+        if (!wf.Evaluate(pw, rw.data(), jwp)) { std::printf("error=window_evaluate\n"); return 7; }
+        double wdiff = 0.0, off = 0.0;
+        for (int k = 0; k < K; k++) {
+            lili::LidarBatchFactor bf(ctx, k, mask, P);
+            const double* pk[2] = {tw[k], qw[k]};
+            double rk[9], jt[27], jq[36];
+            double* jk[2] = {jt, jq};
+            if (!bf.Evaluate(pk, rk, jk)) { std::printf("error=batch_evaluate\n"); return 8; }
+            for (int i = 0; i < 9; i++) wdiff = std::fmax(wdiff, std::fabs(rk[i] - rw[9 * k + i]));
+            for (int r = 0; r < 9 * K; r++) {
+                const bool own = r / 9 == k;
+                for (int c = 0; c < 3; c++) { const double v = jw[2 * k][r * 3 + c]; if (own) wdiff = std::fmax(wdiff, std::fabs(v - jt[(r % 9) * 3 + c])); else off = std::fmax(off, std::fabs(v)); }
+                for (int c = 0; c < 4; c++) { const double v = jw[2 * k + 1][r * 4 + c]; if (own) wdiff = std::fmax(wdiff, std::fabs(v - jq[(r % 9) * 4 + c])); else off = std::fmax(off, std::fabs(v)); }
+            }
+        }
+        std::printf("window_blocks=%d\nwindow_residuals=%d\nwindow_vs_batch_max_abs_diff=%.3e\nwindow_off_diagonal_max=%.3e\n", K, wf.num_residuals(), wdiff, off);
+    }
     lili_ctx_destroy(ctx);
     return 0;
 }

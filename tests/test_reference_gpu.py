@@ -324,6 +324,9 @@ def test_ceres_seam_batch_factor_equals_reference_blocks(gpu_ctx, tmp_path, flav
     assert float(kv["H_rel_diff"]) < 1e-9 and float(kv["g_rel_diff"]) < 1e-9, kv
     cb, cr = float(kv["cost_batch"]), float(kv["cost_reference"])
     assert abs(cb - cr) <= 1e-9 * max(1.0, cr), kv
+    # the window binding: ONE lili::LidarWindowFactor over three keyframes == one LidarBatchFactor per keyframe, bit for bit, block-diagonal
+    assert int(kv["window_blocks"]) == 3 and int(kv["window_residuals"]) == 27
+    assert float(kv["window_vs_batch_max_abs_diff"]) == 0.0 and float(kv["window_off_diagonal_max"]) == 0.0, kv
 
 
 def test_ros_node_seam_gpu_node_equals_reference_node(gpu_ctx, tmp_path):
