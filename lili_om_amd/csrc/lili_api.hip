@@ -236,8 +236,8 @@ static int build_grid(lili_ctx* ctx, MapIndex& m, const double mn[3], const doub
     HIPCHK(m.block_sums.ensure((size_t)(nb_scan + 2) * sizeof(unsigned long long)));
     HIPCHK(hipMemsetAsync(cell_start.p, 0, (size_t)nc * sizeof(int), ctx->stream));
     hipLaunchKernelGGL(k_cell_count, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, m.pts.as<float4>(), n, g, cell_start.as<int>(), m.pt_cell.as<int2>(), d_rank_sum);
-    if (ctx->scan_lookback) {      // one pass over the cell array (status words: one per 4096-cell tile)
-        const int nb_lb = nblocks(nc, 4096);
+    if (ctx->scan_lookback) {      // one pass over the cell array (status words: one per 16384-cell tile)
+        const int nb_lb = nblocks(nc, 16384);
         HIPCHK(hipMemsetAsync(m.block_sums.p, 0, (size_t)(nb_lb + 2) * sizeof(unsigned long long), ctx->stream));
         hipLaunchKernelGGL(k_scan_lookback, dim3(nb_lb), dim3(kBlock), 0, ctx->stream, cell_start.as<int>(), nc, m.block_sums.as<unsigned long long>());
     } else {
@@ -249,7 +249,7 @@ static int build_grid(lili_ctx* ctx, MapIndex& m, const double mn[3], const doub
                        sorted.as<float4>(), m.has_aux ? aux_sorted.as<float>() : nullptr);
     if (srows) {      // first positions of the super-rows (populations -> scan), positions of the super cells, then the copy
         hipLaunchKernelGGL(k_rowtot9, dim3(nblocks(rows9, kBlock)), dim3(kBlock), 0, ctx->stream, cell_start.as<int>(), g, m.row9.as<int>());
-        const int nb_lb = nblocks(rows9, 4096);
+        const int nb_lb = nblocks(rows9, 16384);
         HIPCHK(hipMemsetAsync(m.block_sums.p, 0, (size_t)(nb_lb + 2) * sizeof(unsigned long long), ctx->stream));
         hipLaunchKernelGGL(k_scan_lookback, dim3(nb_lb), dim3(kBlock), 0, ctx->stream, m.row9.as<int>(), rows9, m.block_sums.as<unsigned long long>());
         hipLaunchKernelGGL(k_start9, dim3(nblocks(g.bnx, 64), nblocks(g.bny, 4 * 8), (unsigned)g.bnz), dim3(256), 0, ctx->stream, cell_start.as<int>(), g, m.row9.as<int>(),

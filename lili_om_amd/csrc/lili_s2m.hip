@@ -190,7 +190,7 @@ __global__ void k_scan_apply(const int* in, int64_t n, const int* __restrict__ b
 // prefix up to and including the tile), written and read with agent-scope atomics — the word is its own flag, no fence.  One wave
 // per tile looks back 64 predecessors at a time.  `ws`: [0], [1] = error flag, [2 ...] one status word per tile — zeroed by the
 // caller.  data[n] receives the total.
-constexpr int kLbItems = 16;
+constexpr int kLbItems = 64;
 constexpr int kLbTile = kBlock * kLbItems;
 __global__ __launch_bounds__(kBlock) void k_scan_lookback(int* data, int64_t n, unsigned long long* __restrict__ ws) {
     __shared__ int lds[kBlock / 64 + 1];
