@@ -186,6 +186,27 @@ def secondary_stages(L, ctx, w, torch):
     kf = np.concatenate([w["scan_xyz"], np.zeros((w["scan_xyz"].shape[0], 1), np.float32)], 1)
     sec = rate(lambda: L.api.voxel_filter(ctx, kf, 0.4), 10)
     out["voxel_filter_200k"] = entry(sec, 36 * kf.shape[0], "clouds/s", "pcl::VoxelGrid(0.4) of the 200 k-point scan, host in / host out")
+    # --- the reference's per-keyframe local map (f-1: buildLocalMapWithLandMark + downSampleCloud + setInputCloud, L/src/BackendFusion.cpp:1387-1528,
+    #     839-840): a ring of 50 keyframes of ~20 k surf features each (local_map_width = 50), moved by their poses on push; commit = concatenate +
+    #     VoxelGrid(0.4) + map index, all on the device.  One keyframe = one push + one commit.
+    try:
+        rng = np.random.default_rng(77)
+        feats = np.ascontiguousarray(np.concatenate([w["scan_xyz"][::10], np.zeros((w["scan_xyz"][::10].shape[0], 1), np.float32)], 1))
+        lm = L.api.LocalMap(ctx, L.KIND_SURF, width=50, leaf=0.4, max_sq_radius=1.0)
+        for k in range(50):
+            lm.push(feats, [0.8 * k, 0.1 * k, 0.0], [1.0, 0.0, 0.0, 0.0])
+        n_raw, n_map = lm.commit()
+        kf = [0]
+
+        def one_keyframe():
+            kf[0] += 1
+            lm.push(feats, [0.8 * (50 + kf[0]), 0.1 * (50 + kf[0]), 0.0], [1.0, 0.0, 0.0, 0.0])
+            lm.commit()
+        sec = rate(one_keyframe, 10)
+        out["localmap_commit"] = entry(sec, 36 * n_raw + 36 * n_map, "keyframes/s",
+                                       f"push of a {feats.shape[0]}-point keyframe (host in) + commit of the 50-keyframe ring: {n_raw} points -> VoxelGrid(0.4) -> {n_map}-point map + index, on the device")
+    except Exception as e:      # noqa: BLE001
+        out["localmap_commit_error"] = repr(e)
     P = L.make_params("rot")
     m = L.ScanToMapMatcher(ctx, P)
     d_map = torch.from_numpy(np.ascontiguousarray(w["map_xyz"])).cuda()
