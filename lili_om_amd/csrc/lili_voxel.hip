@@ -173,7 +173,43 @@ static lili_detail::VoxelBuffers* vox_of(lili_ctx* ctx) {
     return static_cast<lili_detail::VoxelBuffers*>(ctx->ext_voxel);
 }
 
+// exclusive scan of a SHORT array (the digit histograms of a radix pass: 16 words per 2048 keys) by one workgroup in one launch — the
+// three-kernel scan spends ~10 us of launches on a few thousand words
+__global__ __launch_bounds__(1024) void k_scan_single(const int* __restrict__ in, int n, int* __restrict__ out /*[n+1]*/) {
+    __shared__ int wsum[16];
+    __shared__ int carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 4096) {
+        const int i0 = base + threadIdx.x * 4;
+        int v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = i0 + k < n ? in[i0 + k] : 0;
+        const int s = (v[0] + v[1]) + (v[2] + v[3]);
+        int inc = s;
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int wbase = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) { const int x = wsum[w]; if (w < wave) wbase += x; tot += x; }
+        int run = carry_s + wbase + inc - s;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { if (i0 + k < n) out[i0 + k] = run; run += v[k]; }
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[n] = carry_s;
+}
+
 static int exclusive_scan(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const int* in, int64_t n, int* out /*[n+1]*/) {
+    if (n <= 65536) {
+        hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, ctx->stream, in, (int)n, out);
+        HIPCHK(hipGetLastError());
+        return LILI_OK;
+    }
     const int nb = nblocks(n, 2048);
     HIPCHK(V->sums.ensure((size_t)nb * sizeof(int)));
     hipLaunchKernelGGL(k_scan_block_sums, dim3(nb), dim3(256), 0, ctx->stream, in, n, V->sums.as<int>());
