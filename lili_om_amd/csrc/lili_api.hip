@@ -39,6 +39,8 @@ __global__ void k_reduce_partials(const double*, int, const double*, int, double
 __global__ void k_sum_counts(const int*, int, const int*, int, SlotState*, int*, P2PView);
 __global__ void k_gn_update(const double*, SlotState*);
 __global__ void k_pose_copy(SlotState*, const SlotState*);
+// lili_s2m_coop.hip: L lanes per query (small launches)
+template <int L, bool LIN> __global__ void k_associate_coop(AssocArgs, AssocArgs, PoseArg, MatchParams, double*, double*);
 }  // namespace lili
 
 #include "lili_ctx.h"
@@ -175,6 +177,10 @@ int lili_set_option(lili_ctx* ctx, const char* name, int value) {
     if (std::strcmp(name, "fuse_tail") == 0) { ctx->fuse_tail = value != 0; return LILI_OK; }   // any time: the block partition does not depend on it
     if (std::strcmp(name, "merge_kinds") == 0) { ctx->merge_kinds = value != 0; return LILI_OK; }
     if (std::strcmp(name, "fuse_lin") == 0) { ctx->fuse_lin = value != 0; return LILI_OK; }
+    if (std::strcmp(name, "assoc_lpq") == 0) {      // lanes per query of the association: 0 = by launch size, 1 = always one lane per query, 2 / 4 / 8 / 16 forced
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16) return ctx->fail(LILI_E_ARG, "assoc_lpq must be 0 (auto), 1, 2, 4, 8 or 16");
+        ctx->assoc_lpq = value; return LILI_OK;
+    }
     if (std::strcmp(name, "fuse_lin_block") == 0) { if (value != 0 && value != kAssocBlock && value != kBlock) return ctx->fail(LILI_E_ARG, "fuse_lin_block must be 0 (auto), 64 or 256"); ctx->fuse_lin_block = value; return LILI_OK; }
     if (std::strcmp(name, "fine_grid") == 0) { ctx->fine_grid = value != 0; return LILI_OK; }
     if (std::strcmp(name, "super_rows") == 0) { ctx->super_rows = value != 0; return LILI_OK; }   // takes effect at the next lili_map_set
@@ -634,6 +640,64 @@ static int launch_associate_both(lili_ctx* ctx, int slot, const PoseArg& pa, con
     return LILI_OK;
 }
 
+// Lanes per query for an association launch over n queries (both kinds): small launches leave most SIMDs without a wave, so several lanes
+// share a query's candidate walk (k_associate_coop) as long as the launch still fits about one wave per SIMD.  1 = the one-lane kernels.
+static int coop_lanes(const lili_ctx* ctx, int64_t n) {
+    if (ctx->assoc_lpq) return ctx->assoc_lpq;
+    const int64_t lanes = (int64_t)std::max(ctx->n_simd, 256) * 64;      // one wave per SIMD
+    int L = 1;
+    while (L < 16 && n * (2 * L) <= lanes) L *= 2;
+    return L;
+}
+// Association of the kinds in kind_mask by k_associate_coop (lili_s2m_coop.hip); `lin`: also linearise (flavours without count scaling) and
+// reduce + GN-update in a second launch.  Returns 1 if the configuration is not eligible — the caller then takes the one-lane kernels.
+static int launch_associate_coop(lili_ctx* ctx, int slot, int kind_mask, const PoseArg& pa, const MatchParams& P, bool lin, double* d_out) {
+    if (ctx->bin_queries || ctx->tiled || ctx->balance || ctx->nn_cache || (P.debug & (1 | 2 | 4096))) return 1;
+    Slot& sl = ctx->slots[slot];
+    int64_t n_all = 0;
+    for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) {
+        KindSlot& ks = sl.k[kind];
+        MapIndex& m = ctx->map[kind];
+        if (!ks.has_queries || !m.valid || ks.n_q == 0 || m.n < 5 || m.has_fine) return 1;
+        const double gate = kind == LILI_KIND_SURF ? P.kd_max_radius : P.edge_gate;
+        if (!(std::sqrt(gate) * 1.0099 <= m.cell * (double)m.view.reach)) return 1;     // the per-kind path reports the error
+        if (kind == LILI_KIND_SURF && P.variant == LILI_VARIANT_LIVOX && (!m.has_aux || !ks.has_aux)) return 1;
+        n_all += ks.n_q;
+    }
+    const int L = coop_lanes(ctx, n_all);
+    if (L < 2 || n_all == 0) return 1;
+    const int qpb = 256 / L;
+    AssocArgs A[2] = {AssocArgs{}, AssocArgs{}};
+    for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) {
+        KindSlot& ks = sl.k[kind];
+        const int n = (int)ks.n_q;
+        AssocArgs& a = A[kind];
+        a.queries = ks.q.as<float4>(); a.n_q = n; a.g = ctx->map[kind].view;
+        a.rec0 = ks.rec0.as<float4>(); a.rec1 = ks.rec1.p; a.valid = ks.valid.as<unsigned char>();
+        if (ctx->keep_nn) {
+            HIPCHK(ks.dbg_idx.ensure((size_t)n * 5 * sizeof(int)));
+            HIPCHK(ks.dbg_d2.ensure((size_t)n * 5 * sizeof(float)));
+            a.dbg_idx = ks.dbg_idx.as<int>(); a.dbg_d2 = ks.dbg_d2.as<float>();
+        }
+        a.nb = nblocks(n, qpb);
+        HIPCHK(ks.block_counts.ensure((size_t)a.nb * sizeof(int)));
+        if (lin) HIPCHK(ks.partials_wave.ensure((size_t)a.nb * kPartialStride * sizeof(double)));
+        a.block_counts = ks.block_counts.as<int>();
+        ks.n_assoc_blocks = a.nb; ks.has_records = true; ks.launches++;
+    }
+    const dim3 grid(A[0].nb + A[1].nb), block(256);
+    double* ps = sl.k[0].partials_wave.as<double>(); double* pe = sl.k[1].partials_wave.as<double>();
+#define LILI_COOP_CASE(LL) case LL: if (lin) hipLaunchKernelGGL((k_associate_coop<LL, true>), grid, block, 0, ctx->stream, A[0], A[1], pa, P, ps, pe); \
+                                    else hipLaunchKernelGGL((k_associate_coop<LL, false>), grid, block, 0, ctx->stream, A[0], A[1], pa, P, ps, pe); break;
+    switch (L) { LILI_COOP_CASE(2) LILI_COOP_CASE(4) LILI_COOP_CASE(8) LILI_COOP_CASE(16) default: return 1; }
+#undef LILI_COOP_CASE
+    if (lin) hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx->stream, (const double*)ps, A[0].nb, (const double*)pe, A[1].nb, d_out, ctx->state(slot),
+                                1 | (P.debug & 256), P2PView{});
+    HIPCHK(hipGetLastError());
+    sl.use_global_counts = false;
+    return LILI_OK;
+}
+
 static LinArgs lin_args_of(lili_ctx* ctx, int slot, int kind) {
     KindSlot& ks = ctx->slots[slot].k[kind];
     LinArgs A{};
@@ -665,6 +729,10 @@ static int launch_associate_lin_reduce(lili_ctx* ctx, int slot, int kind_mask, c
         n_kinds++;
     }
     if (n_kinds == 0) return 1;
+    {   // small launches: several lanes per query (k_associate_coop, which linearises as well)
+        const int rc = launch_associate_coop(ctx, slot, kind_mask, pa, P, true, d_out);
+        if (rc != 1) return rc;
+    }
     // one partial per workgroup: per wave while the reducer can take them in one round of loads (25 groups x 32), else per four waves
     int waves = 0;
     for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) waves += sl.k[kind].n_blocks;
@@ -754,7 +822,8 @@ int lili_s2m_associate(lili_ctx* ctx, int slot, int kind, const double t_assoc[3
     pa.state = nullptr; pa.derive_assoc = 0;
     MatchParams P = to_device_params(params);
     ctx->slots[slot].use_global_counts = false;
-    int rc = launch_associate(ctx, slot, kind, pa, P);
+    int rc = launch_associate_coop(ctx, slot, 1 << kind, pa, P, false, nullptr);
+    if (rc == 1) rc = launch_associate(ctx, slot, kind, pa, P);
     if (rc != LILI_OK) return rc;
     if (n_res) {
         rc = launch_sum_counts(ctx, slot, 1 << kind);
@@ -797,8 +866,8 @@ int lili_s2m_associate_window(lili_ctx* ctx, const int* slots, int n_slots, int 
         for (int k = 0; k < 3; k++) pa.t[k] = t_assoc[3 * i + k];
         for (int k = 0; k < 4; k++) pa.q[k] = q_assoc[4 * i + k];
         ctx->slots[slots[i]].use_global_counts = false;
-        rc = 1;
-        if (kind_mask == (LILI_MASK_SURF | LILI_MASK_EDGE) && ctx->merge_kinds) rc = launch_associate_both(ctx, slots[i], pa, P);
+        rc = launch_associate_coop(ctx, slots[i], kind_mask, pa, P, false, nullptr);
+        if (rc == 1 && kind_mask == (LILI_MASK_SURF | LILI_MASK_EDGE) && ctx->merge_kinds) rc = launch_associate_both(ctx, slots[i], pa, P);
         if (rc == 1) {                                   // not eligible (or one kind only): one launch per kind
             rc = LILI_OK;
             for (int kind = 0; kind < 2 && rc == LILI_OK; kind++) if (kind_mask & (1 << kind)) rc = launch_associate(ctx, slots[i], kind, pa, P);
@@ -1052,6 +1121,10 @@ int lili_s2m_associate_dev(lili_ctx* ctx, int slot, int kind_mask, const lili_s2
     pa.state = ctx->state(slot);
     pa.derive_assoc = params->variant == LILI_VARIANT_FRONTEND ? 0 : 1;
     MatchParams P = to_device_params(params);
+    {   // small launches: several lanes per query
+        int rc = launch_associate_coop(ctx, slot, kind_mask, pa, P, false, nullptr);
+        if (rc != 1) return rc;
+    }
     if (kind_mask == (LILI_MASK_SURF | LILI_MASK_EDGE) && ctx->merge_kinds) {
         int rc = launch_associate_both(ctx, slot, pa, P);
         if (rc != 1) return rc;     // 1 = not eligible: one launch per kind below
