@@ -20,7 +20,7 @@ __global__ void k_associate_fine(AssocArgs, GridView, float, int, PoseArg, Match
 __global__ void k_scan_block_sums(const int*, int64_t, int*);
 __global__ void k_scan_sums(int*, int);
 __global__ void k_scan_apply(const int*, int64_t, const int*, int*);
-__global__ void k_scan_lookback(int*, int64_t, unsigned long long*);
+__global__ void k_scan_lookback(int*, int64_t, unsigned long long*, unsigned*);
 __global__ void k_scatter(const float4*, int, const int2*, const int*, float4*, float*);
 __global__ void k_start9(const int*, GridView, const int*, int*);
 __global__ void k_rowtot9(const int*, GridView, int*);
@@ -124,7 +124,7 @@ int lili_ctx_create(lili_ctx** out, int device, void* stream) {
     }
     bool ok = ctx->states.ensure(sizeof(SlotState) * LILI_MAX_SLOTS) == hipSuccess &&
               ctx->gram.ensure(sizeof(double) * LILI_GRAM_DOUBLES * LILI_MAX_SLOTS) == hipSuccess &&
-              ctx->misc.ensure(2 * 64 * 128) == hipSuccess &&
+              ctx->misc.ensure(2 * 64 * 128 + 256) == hipSuccess &&
 
               hipMemsetAsync(ctx->states.p, 0, sizeof(SlotState) * LILI_MAX_SLOTS, ctx->stream) == hipSuccess &&
               hipMemsetAsync(ctx->gram.p, 0, sizeof(double) * LILI_GRAM_DOUBLES * LILI_MAX_SLOTS, ctx->stream) == hipSuccess;
@@ -139,6 +139,7 @@ void lili_ctx_destroy(lili_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->build_stream) { (void)hipStreamSynchronize(ctx->build_stream); (void)hipStreamDestroy(ctx->build_stream); }
     for (int k = 0; k < 2; k++) { if (ctx->build_done[k]) (void)hipEventDestroy(ctx->build_done[k]); if (ctx->main_mark[k]) (void)hipEventDestroy(ctx->main_mark[k]); }
+    if (ctx->cloud_ready) (void)hipEventDestroy(ctx->cloud_ready);
     for (auto& m : ctx->map) { m.sorted_f.release(); m.aux_sorted_f.release(); m.cell_start_f.release(); m.cell_start9.release(); m.cell_start9_f.release(); m.row9.release(); m.pts.release(); m.sorted.release(); m.aux_sorted.release(); m.cell_start.release(); m.cell_tmp.release(); m.pt_cell.release(); m.block_sums.release(); }
     for (auto& s : ctx->slots) for (auto& k : s.k) { k.q.release(); k.rec0.release(); k.rec1.release(); k.valid.release(); k.dbg_idx.release(); k.dbg_d2.release(); k.partials.release(); k.partials_wave.release(); k.perm.release(); k.keys.release(); k.block_counts.release(); k.tiles.release(); }
     if (ctx->h_records) { (void)hipHostFree(ctx->h_records); ctx->h_records = nullptr; }
@@ -198,6 +199,9 @@ int lili_set_option(lili_ctx* ctx, const char* name, int value) {
 // --------------------------------------------------------------------------------------------
 // Uniform-grid index of m.pts (already ingested) with cells of edge `cell` (grown if the bounding box needs more than max_cells cells):
 // count (one atomic per run of equal cells, the returned value = the point's rank), in-place single-pass scan, atomic-free scatter.
+// scratch words of a map build (ctx->misc): [0, 8192) bounding-box banks, [8192, 16384) density banks, then the sticky error word of the look-back scans
+constexpr size_t kMiscBytes = 2 * 64 * 128 + 256;
+static unsigned* scan_err_word(lili_ctx* ctx) { return reinterpret_cast<unsigned*>(ctx->misc.as<char>() + 2 * 64 * 128); }
 static int build_grid(lili_ctx* ctx, MapIndex& m, const double mn[3], const double mx[3], double cell, int reach, DevBuf& sorted, DevBuf& aux_sorted,
                       DevBuf& cell_start, DevBuf& cell_start9, GridView& out, int64_t& n_cells, double& cell_used, unsigned long long* d_rank_sum) {
     const int n = (int)m.n;
@@ -245,7 +249,7 @@ static int build_grid(lili_ctx* ctx, MapIndex& m, const double mn[3], const doub
     if (ctx->scan_lookback) {      // one pass over the cell array (status words: one per 16384-cell tile)
         const int nb_lb = nblocks(nc, 16384);
         HIPCHK(hipMemsetAsync(m.block_sums.p, 0, (size_t)(nb_lb + 2) * sizeof(unsigned long long), ctx->stream));
-        hipLaunchKernelGGL(k_scan_lookback, dim3(nb_lb), dim3(kBlock), 0, ctx->stream, cell_start.as<int>(), nc, m.block_sums.as<unsigned long long>());
+        hipLaunchKernelGGL(k_scan_lookback, dim3(nb_lb), dim3(kBlock), 0, ctx->stream, cell_start.as<int>(), nc, m.block_sums.as<unsigned long long>(), scan_err_word(ctx));
     } else {
         hipLaunchKernelGGL(k_scan_block_sums, dim3(nb_scan), dim3(kBlock), 0, ctx->stream, cell_start.as<int>(), nc, m.block_sums.as<int>());
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, ctx->stream, m.block_sums.as<int>(), nb_scan);
@@ -257,7 +261,7 @@ static int build_grid(lili_ctx* ctx, MapIndex& m, const double mn[3], const doub
         hipLaunchKernelGGL(k_rowtot9, dim3(nblocks(rows9, kBlock)), dim3(kBlock), 0, ctx->stream, cell_start.as<int>(), g, m.row9.as<int>());
         const int nb_lb = nblocks(rows9, 16384);
         HIPCHK(hipMemsetAsync(m.block_sums.p, 0, (size_t)(nb_lb + 2) * sizeof(unsigned long long), ctx->stream));
-        hipLaunchKernelGGL(k_scan_lookback, dim3(nb_lb), dim3(kBlock), 0, ctx->stream, m.row9.as<int>(), rows9, m.block_sums.as<unsigned long long>());
+        hipLaunchKernelGGL(k_scan_lookback, dim3(nb_lb), dim3(kBlock), 0, ctx->stream, m.row9.as<int>(), rows9, m.block_sums.as<unsigned long long>(), scan_err_word(ctx));
         hipLaunchKernelGGL(k_start9, dim3(nblocks(g.bnx, 64), nblocks(g.bny, 4 * 8), (unsigned)g.bnz), dim3(256), 0, ctx->stream, cell_start.as<int>(), g, m.row9.as<int>(),
                            cell_start9.as<int>());
         hipLaunchKernelGGL(k_scatter9, dim3(nblocks(g.bnx, 64), nblocks(g.bny, 4), nblocks(g.bnz, 4)), dim3(1024), 0, ctx->stream, cell_start.as<int>(), g, cell_start9.as<int>(),
@@ -287,6 +291,7 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
     static const BboxInit bbox_init;             // 64 banks of 128 bytes: min xyz = ~0, max xyz = 0 (ordered-uint encoding)
     unsigned* d_mm = ctx->misc.as<unsigned>();
     HIPCHK(hipMemcpyAsync(d_mm, bbox_init.w, sizeof(bbox_init.w), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemsetAsync(scan_err_word(ctx), 0, sizeof(unsigned), ctx->stream));
     int rc = lili_ingest_cloud(ctx, cloud, m.pts, d_mm);
     if (rc != LILI_OK) return rc;
     m.n = (int64_t)cloud->n;
@@ -313,14 +318,18 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
     constexpr size_t kRankBanks = 64, kRankBytes = kRankBanks * 128;                       // k_cell_count: one bank per 128 bytes
     unsigned long long* d_rank = ctx->fine_grid ? reinterpret_cast<unsigned long long*>(ctx->misc.as<char>() + 8192) : nullptr;
     if (d_rank) HIPCHK(hipMemsetAsync(d_rank, 0, kRankBytes, ctx->stream));
+    unsigned scan_err = 0;
+    bool err_read = false;
     rc = build_grid(ctx, m, mn, mx, cell, reach, m.sorted, m.aux_sorted, m.cell_start, m.cell_start9, m.view, m.n_cells, m.cell, d_rank);
     if (rc != LILI_OK) return rc;
     // Density adaptation (SURVEY §7 step 4, §8d Config 2 variant B): the point-weighted mean cell occupancy falls out of the count pass.
     // A map with many points per gate-sized cell gets a second, fine index whose cells hold ~3 points; k_associate_fine searches it first.
     if (d_rank) {
-        unsigned long long banks[kRankBanks * 16], rank_sum = 0;
-        HIPCHK(hipMemcpyAsync(banks, d_rank, kRankBytes, hipMemcpyDeviceToHost, ctx->stream));
+        unsigned long long banks[kRankBanks * 16 + 1], rank_sum = 0;      // + the sticky error word of the look-back scans, which follows the banks
+        HIPCHK(hipMemcpyAsync(banks, d_rank, kRankBytes + sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
+        scan_err = (unsigned)banks[kRankBanks * 16];
+        err_read = true;
         for (size_t b = 0; b < kRankBanks; b++) rank_sum += banks[b * 16];
         m.mean_occupancy = 1.0 + 2.0 * (double)rank_sum / (double)n;
         if (m.mean_occupancy > (double)ctx->fine_occupancy && m.cell == cell) {          // (a grid coarsened by max_cells is not refined)
@@ -334,6 +343,25 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
             float fb = (float)(rb * rb * (1.0 - 1e-6));
             if ((double)fb > rb * rb * (1.0 - 1e-6)) fb = std::nextafter(fb, 0.0f);                    // rounded DOWN: the bound only ever shrinks
             m.fbound = fb; m.fine_cell = fcell_used; m.has_fine = true;
+            err_read = false;           // the fine index ran its own scans after the read-back
+        }
+    }
+    // The single-pass scans publish tile prefixes between workgroups and rely on lower tiles making progress (HIP promises no dispatch
+    // order); a look-back that gave up has left a wrong cell_start behind.  The sticky word travels with the density
+    // read-back above — the synchronisation lili_map_set has anyway; only a build without it (fine_grid = 0) or with a second, fine
+    // index pays a 4-byte read-back of its own.  If the word is set the whole index is rebuilt with the three-kernel scan, which has
+    // no inter-workgroup dependency.
+    if (ctx->scan_lookback) {
+        if (!err_read) {
+            HIPCHK(hipMemcpyAsync(&scan_err, scan_err_word(ctx), sizeof(scan_err), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+        }
+        if (scan_err) {
+            ctx->scan_lookback = false;
+            ctx->scan_fallbacks++;
+            rc = lili_map_set(ctx, kind, cloud, max_sq_radius);
+            ctx->scan_lookback = true;
+            return rc;
         }
     }
     m.valid = true;
@@ -355,11 +383,19 @@ int lili_map_set_begin(lili_ctx* ctx, int kind, const lili_cloud* cloud, double 
     }
     if (!ctx->build_done[kind]) HIPCHK(hipEventCreateWithFlags(&ctx->build_done[kind], hipEventDisableTiming));
     if (!ctx->main_mark[kind]) HIPCHK(hipEventCreateWithFlags(&ctx->main_mark[kind], hipEventDisableTiming));
-    if (ctx->misc_build.ensure(2 * 64 * 128) != hipSuccess) return ctx->fail(LILI_E_NOMEM, "map_set_begin: scratch allocation failed");
+    if (ctx->misc_build.ensure(kMiscBytes) != hipSuccess) return ctx->fail(LILI_E_NOMEM, "map_set_begin: scratch allocation failed");
     // the buffers being rebuilt are the ones the index before the current one lived in: everything enqueued up to the swap that retired
     // them (main_mark, recorded by lili_map_set_end) has to be through before they are overwritten — NOT what was enqueued since, which
     // uses the current index and is what the build overlaps with
     if (ctx->main_marked[kind]) HIPCHK(hipStreamWaitEvent(ctx->build_stream, ctx->main_mark[kind], 0));
+    // A cloud that already lives in device memory is normally produced by work enqueued on the context's stream (voxel filter, local-map
+    // commit, an extractor): the build reads it from ANOTHER stream, so it has to wait for everything enqueued there so far — lili_map_set
+    // got this ordering from the stream itself.  (Work on a third stream of the caller's is the caller's to order: synchronise it before _begin.)
+    if (cloud && cloud->mem == LILI_MEM_DEVICE) {
+        if (!ctx->cloud_ready) HIPCHK(hipEventCreateWithFlags(&ctx->cloud_ready, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(ctx->cloud_ready, ctx->stream));
+        HIPCHK(hipStreamWaitEvent(ctx->build_stream, ctx->cloud_ready, 0));
+    }
     hipStream_t main_stream = ctx->stream;
     // run the ordinary build with the context's stream, scratch and index slot pointed at the build side (one host thread per context)
     ctx->stream = ctx->build_stream;
@@ -709,8 +745,12 @@ static LinArgs lin_args_of(lili_ctx* ctx, int slot, int kind) {
 
 // Linearisation of the kinds in kind_mask and the reduction of their block partials to the 72-double record (and the GN update
 // if do_gn).  Default: ONE launch — k_linearize covers both kinds and its last block to finish reduces (+ solves), see fused_tail.
-// Options for A/B: merge_kinds = 0 (one launch per kind), fuse_tail = 0 (k_reduce_partials as its own launch).  All variants
-// add the same numbers in the same order: the record is bit-identical.
+// Options for A/B: merge_kinds = 0 (one launch per kind), fuse_tail = 0 (k_reduce_partials as its own launch).  These variants
+// add the same numbers in the same order: the record is bit-identical.  NOT so the paths that linearise inside the association launch
+// (fuse_lin / k_associate_lin, k_associate_coop<L, true>): there the PARTITION of the Gram sum follows the association's workgroups
+// (64 or 256 queries per partial, 256 / L with L lanes per query), so lili_s2m_iterate, lili_s2m_iterate_restart with assoc_ms (which
+// takes the three-launch path to bracket the association) and fuse_lin = 0 agree to ~1e-16 relative per entry, not bit for bit, and the
+// low-order bits can change across the size thresholds of launch_associate_lin_reduce / coop_lanes (tests: <= 1e-10 on the pose).
 // One outer iteration in TWO launches for the flavours without count scaling (k_associate_lin: association + linearisation, then the
 // reduction + GN update).  Returns 1 if the configuration is not eligible (the caller then takes the three-launch path).
 static int launch_associate_lin_reduce(lili_ctx* ctx, int slot, int kind_mask, const PoseArg& pa, const MatchParams& P, double* d_out) {

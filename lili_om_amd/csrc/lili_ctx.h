@@ -102,6 +102,8 @@ struct lili_ctx {
     MapIndex map_next[2];
     hipStream_t build_stream = nullptr;
     hipEvent_t build_done[2] = {}, main_mark[2] = {};
+    hipEvent_t cloud_ready = nullptr;      // lili_map_set_begin with a device cloud: the build stream waits for what the context's stream has enqueued so far
+    int scan_fallbacks = 0;                // map builds repeated with the three-kernel scan because a look-back scan gave up (never expected; lili_map_info reports it)
     bool build_pending[2] = {false, false}, main_marked[2] = {false, false};
     DevBuf staging_build, misc_build;
     Slot slots[LILI_MAX_SLOTS];

@@ -175,14 +175,15 @@ __global__ void k_scan_apply(const int* in, int64_t n, const int* __restrict__ b
 // map) is read once and written once, where the three-kernel scan above reads it twice and writes it once.  Tile b (4096 items) belongs
 // to workgroup b — no ticket: 6.6 k same-address atomics cost ~12 ns each on MI355X, more than the whole scan (measured: 183 us with a
 // ticket against 170 us for the three kernels).  Workgroups are dispatched in index order per XCD, so the lowest unfinished tile is
-// always resident and a tile only ever waits for lower ones; should that ever not hold, the bounded spin gives up (ws[1] = 1)
-// instead of hanging the GPU.  Every tile publishes {flag, value} as ONE 64-bit word (flag 1 = the tile's own sum, 2 = the inclusive
+// always resident and a tile only ever waits for lower ones; should that ever not hold (HIP promises no dispatch order), the bounded spin
+// gives up, raises the sticky word `err` and carries on with a wrong prefix instead of hanging the GPU: lili_map_set reads `err` back
+// at the synchronisation it has anyway and then repeats the build with the three-kernel scan.  Every tile publishes {flag, value} as ONE 64-bit word (flag 1 = the tile's own sum, 2 = the inclusive
 // prefix up to and including the tile), written and read with agent-scope atomics — the word is its own flag, no fence.  One wave
 // per tile looks back 64 predecessors at a time.  `ws`: [0], [1] = error flag, [2 ...] one status word per tile — zeroed by the
 // caller.  data[n] receives the total.
 constexpr int kLbItems = 64;
 constexpr int kLbTile = kBlock * kLbItems;
-__global__ __launch_bounds__(kBlock) void k_scan_lookback(int* data, int64_t n, unsigned long long* __restrict__ ws) {
+__global__ __launch_bounds__(kBlock) void k_scan_lookback(int* data, int64_t n, unsigned long long* __restrict__ ws, unsigned* __restrict__ err /*sticky: set if a look-back gave up*/) {
     __shared__ int lds[kBlock / 64 + 1];
     __shared__ int s_prefix;
     const int tile = (int)blockIdx.x;
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_lookback(int* data, int64_t n, 
                 int spins = 0;
                 do {
                     w = __hip_atomic_load(&status[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (++spins > (1 << 21)) { ws[1] = 1ull; w = 2ull << 32; }      // cannot happen while lower tiles run; never hang the GPU
+                    if (++spins > (1 << 21)) { ws[1] = 1ull; if (err) *err = 1u; w = 2ull << 32; }      // cannot happen while lower tiles run; never hang the GPU — lili_map_set reads `err` back and rebuilds with the three-kernel scan
                 } while ((w >> 32) == 0ull);
             }
             const bool is_p = (w >> 32) == 2ull;
