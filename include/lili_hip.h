@@ -283,6 +283,46 @@ int lili_s2m_pose_get(lili_ctx* ctx, int slot, double t[3], double q[4], int* gn
  * (include/lili_ceres_adapter.h) — this call lets the others at least see how far a step went.  Blocking. */
 int lili_s2m_last_step(lili_ctx* ctx, int slot, double delta[6], int* n_updates, int* gn_status);
 
+/* ---- Levenberg-Marquardt on the device (fixed correspondences) -------------------------------------
+ * The reference's inner loop: ceres::Solve on the residual blocks of the last association (L/src/BackendFusion.cpp:984-992: DENSE_QR,
+ * max_num_iterations = max_num_iter, otherwise Ceres 2.0 defaults — TRUST_REGION / LEVENBERG_MARQUARDT, initial radius 1e4, Jacobi scaling,
+ * monotonic steps, function / gradient / parameter tolerances 1e-6 / 1e-10 / 1e-8).  lili_s2m_solve_lm runs that loop for
+ * the lidar blocks of ONE slot — both kinds in kind_mask, robustified by params->loss — as ONE persistent launch: every iteration evaluates
+ * all records at the candidate pose (robust cost + Gram), the workgroups exchange their partials inside the launch and each takes the same
+ * accept / reject decision; the pose of the slot ends at the last accepted point.  Decisions and final pose equal the oracle's restatement
+ * of Ceres' loop on per-residual rows (oracle/lo_window.py::ceres_lm; tests/test_lm_gpu.py).  Needs lili_s2m_associate* first.
+ * options == NULL: the defaults above with max_iterations = 15.  summary (host memory, optional): filled after a synchronisation of the
+ * context's stream; with summary == NULL the call is asynchronous.  Not to be overlapped with other persistent launches of the same
+ * device beyond what lili_s2m_solve_lm_window does itself (every workgroup of the launch has to be resident; waits are bounded and end in
+ * LILI_LM_STALLED rather than a hang). */
+#define LILI_LM_MAX_LOG 32
+enum { LILI_LM_MAX_ITERATIONS = 0, LILI_LM_GRADIENT_TOLERANCE = 1, LILI_LM_PARAMETER_TOLERANCE = 2, LILI_LM_FUNCTION_TOLERANCE = 3,
+       LILI_LM_STALLED = 4, LILI_LM_NUMERICAL_FAILURE = 5 };
+typedef struct lili_lm_options {
+    int32_t max_iterations;
+    int32_t reserved_;
+    double function_tolerance, gradient_tolerance, parameter_tolerance;
+    double initial_radius, max_radius, min_radius, min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
+} lili_lm_options;
+typedef struct lili_lm_iteration {       /* one evaluated candidate */
+    double cost, new_cost, rho, radius, step_norm;
+    int32_t accepted, iteration;
+} lili_lm_iteration;
+typedef struct lili_lm_summary {
+    int32_t iterations, successful_steps, termination, n_logged;
+    int32_t n_surf, n_edge;              /* correspondences the rows were scaled with (ROT: num / N) */
+    double initial_cost, final_cost, final_radius;
+    lili_lm_iteration it[LILI_LM_MAX_LOG];
+} lili_lm_summary;
+void lili_lm_default_options(lili_lm_options* opt);
+int lili_s2m_solve_lm(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, const lili_lm_options* options,
+                      lili_lm_summary* summary);
+/* The same for several slots (the keyframes of the sliding window) concurrently, one launch per slot on forked streams; summaries:
+ * n_slots entries (optional).  The joint window of the reference couples the keyframes through the IMU factors, which stay with the
+ * caller's solver (include/lili_ceres_adapter.h); this call is for per-keyframe refinements and for the front-end. */
+int lili_s2m_solve_lm_window(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, const lili_s2m_params* params,
+                             const lili_lm_options* options, lili_lm_summary* summaries);
+
 /* One outer iteration, first half (async): re-associate at the device pose (association transform
  * Q2 = Q*q_lb^-1, T2 = T - Q2*t_lb as in L/src/BackendFusion.cpp:929-930), linearise, and reduce this
  * rank's partial into d_gram (DEVICE pointer to LILI_GRAM_DOUBLES doubles owned by the caller:
@@ -329,7 +369,11 @@ int lili_s2m_iterate_sharded(lili_ctx* ctx, int slot, int kind_mask, const lili_
  *   lili_p2p_handle   this rank's mailbox handle (LILI_P2P_HANDLE_BYTES, opaque) — the caller all-gathers the handles (MPI,
  *                     torch.distributed, a file ...) and hands all of them, in rank order, to
  *   lili_p2p_connect  (maps the peers' mailboxes; one process per GPU, or several processes on one GPU)
- *   lili_p2p_status   0 = ok, 1 = a wait for a peer gave up after ~2 s of device time (the record is then undefined) */
+ *   lili_p2p_status   0 = ok, 1 = a wait for a peer gave up (the record is then undefined, the slot's gn_status is 2).  The failure is
+ *                     sticky and contagious: the rank publishes nothing any more and raises the failure word of every peer, whose
+ *                     next exchange fails at its first look; lili_s2m_iterate_sharded then returns LILI_E_STATE on every rank.
+ *   lili_p2p_set_timeout  how long an exchange may wait for a peer (device time, default 10 s).  The FIRST exchange absorbs the ranks'
+ *                     start-up skew (code-object load, data loading): keep it generous, or barrier the control plane first. */
 #define LILI_P2P_HANDLE_BYTES 64
 typedef struct lili_p2p lili_p2p;
 int lili_p2p_create(lili_ctx* ctx, int rank, int world, lili_p2p** out);
@@ -337,6 +381,7 @@ int lili_p2p_handle(lili_p2p* comm, void* handle);
 int lili_p2p_connect(lili_p2p* comm, const void* all_handles);
 int lili_p2p_allreduce(const void* sendbuff, void* recvbuff, size_t count, int datatype, int op, void* comm, void* stream);
 int lili_p2p_status(lili_p2p* comm);
+int lili_p2p_set_timeout(lili_p2p* comm, double seconds);
 void lili_p2p_destroy(lili_p2p* comm);
 /* Convenience: n_iters x (accumulate + gn_update) on an internal buffer.  Async. */
 int lili_s2m_iterate(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, int n_iters);

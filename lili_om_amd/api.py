@@ -40,6 +40,33 @@ class LivoxParams(C.Structure):
     _fields_ = [("surf_thres", C.c_double), ("edge_thres", C.c_double), ("near_range", C.c_float)]
 
 
+LM_MAX_LOG = 32
+LM_TERMINATION = {0: "max_iterations", 1: "gradient_tolerance", 2: "parameter_tolerance", 3: "function_tolerance", 4: "stalled", 5: "numerical_failure"}
+
+
+class LmOptions(C.Structure):
+    _fields_ = [("max_iterations", C.c_int32), ("reserved_", C.c_int32), ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
+                ("parameter_tolerance", C.c_double), ("initial_radius", C.c_double), ("max_radius", C.c_double), ("min_radius", C.c_double),
+                ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double)]
+
+
+class LmIteration(C.Structure):
+    _fields_ = [("cost", C.c_double), ("new_cost", C.c_double), ("rho", C.c_double), ("radius", C.c_double), ("step_norm", C.c_double),
+                ("accepted", C.c_int32), ("iteration", C.c_int32)]
+
+
+class LmSummary(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("successful_steps", C.c_int32), ("termination", C.c_int32), ("n_logged", C.c_int32),
+                ("n_surf", C.c_int32), ("n_edge", C.c_int32), ("initial_cost", C.c_double), ("final_cost", C.c_double), ("final_radius", C.c_double),
+                ("it", LmIteration * LM_MAX_LOG)]
+
+    def as_dict(self):
+        return dict(iterations=self.iterations, successful_steps=self.successful_steps, termination=LM_TERMINATION.get(self.termination, self.termination),
+                    n_surf=self.n_surf, n_edge=self.n_edge, initial_cost=self.initial_cost, final_cost=self.final_cost, final_radius=self.final_radius,
+                    log=[dict(it=e.iteration, cost=e.cost, new_cost=e.new_cost, rho=e.rho, radius=e.radius, step=e.step_norm, accepted=bool(e.accepted))
+                         for e in self.it[:self.n_logged]])
+
+
 class S2MParams(C.Structure):
     _fields_ = [("variant", C.c_int), ("loss", C.c_int), ("loss_a", C.c_double), ("lidar_const", C.c_double),
                 ("kd_max_radius", C.c_double), ("edge_gate", C.c_double), ("surf_dist_thres", C.c_double),
@@ -134,6 +161,9 @@ _SIGS = {
     "lili_s2m_pose_copy": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "lili_s2m_iterate_restart": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams), C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "lili_s2m_iterate_sharded": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lili_lm_default_options": (None, [C.POINTER(LmOptions)]),
+    "lili_s2m_solve_lm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams), C.POINTER(LmOptions), C.POINTER(LmSummary)]),
+    "lili_s2m_solve_lm_window": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(S2MParams), C.POINTER(LmOptions), C.POINTER(LmSummary)]),
     "lili_host_alloc": (C.c_void_p, [C.c_size_t]),
     "lili_host_free": (None, [C.c_void_p]),
     "lili_p2p_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
@@ -141,6 +171,7 @@ _SIGS = {
     "lili_p2p_connect": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lili_p2p_allreduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "lili_p2p_status": (C.c_int, [C.c_void_p]),
+    "lili_p2p_set_timeout": (C.c_int, [C.c_void_p, C.c_double]),
     "lili_p2p_destroy": (None, [C.c_void_p]),
     "lili_livox_custom_to_cloud": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_int]),
     "lili_imu_reset": (None, [C.c_void_p]),
@@ -456,6 +487,29 @@ class ScanToMapMatcher:
         G = np.zeros((n, 64)); cost = np.zeros(n); counts = np.zeros((n, 2), np.int32)
         self.ctx._chk(self.lib.lili_s2m_linearize_window(self.ctx.h, arr, n, int(kind_mask), _ptr(t), _ptr(q), C.byref(self.params), _ptr(G), _ptr(cost), _ptr(counts)))
         return [(G[k].reshape(8, 8).copy(), float(cost[k]), (int(counts[k, 0]), int(counts[k, 1]))) for k in range(n)]
+
+    def lm_options(self, **kw):
+        """Ceres 2.0 defaults with max_iterations = 15 (what the reference's ceres::Solve runs with, L/src/BackendFusion.cpp:984-992), overridden by kw."""
+        o = LmOptions()
+        self.lib.lili_lm_default_options(C.byref(o))
+        for k, v in kw.items():
+            setattr(o, k, v)
+        return o
+
+    def solve_lm(self, slot, kind_mask=MASK_SURF | MASK_EDGE, options=None, want_summary=True):
+        """Levenberg-Marquardt on the records of the last association, one persistent launch (ceres::Solve's loop for the lidar blocks of one
+        keyframe); returns the summary as a dict (blocking) or None (asynchronous)."""
+        s = LmSummary() if want_summary else None
+        self.ctx._chk(self.lib.lili_s2m_solve_lm(self.ctx.h, slot, kind_mask, C.byref(self.params), C.byref(options) if options is not None else None,
+                                                     C.byref(s) if s is not None else None))
+        return s.as_dict() if s is not None else None
+
+    def solve_lm_window(self, slots, kind_mask=MASK_SURF | MASK_EDGE, options=None, want_summary=True):
+        arr = (C.c_int * len(slots))(*slots)
+        s = (LmSummary * len(slots))() if want_summary else None
+        self.ctx._chk(self.lib.lili_s2m_solve_lm_window(self.ctx.h, arr, len(slots), kind_mask, C.byref(self.params),
+                                                            C.byref(options) if options is not None else None, s))
+        return [x.as_dict() for x in s] if s is not None else None
 
     def iterate(self, slot, n_iters, kind_mask=MASK_SURF):
         self.ctx._chk(self.lib.lili_s2m_iterate(self.ctx.h, slot, kind_mask, C.byref(self.params), int(n_iters)))

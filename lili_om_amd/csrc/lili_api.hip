@@ -39,6 +39,20 @@ __global__ void k_reduce_partials(const double*, int, const double*, int, double
 __global__ void k_sum_counts(const int*, int, const int*, int, SlotState*, int*, P2PView);
 __global__ void k_gn_update(const double*, SlotState*);
 __global__ void k_pose_copy(SlotState*, const SlotState*);
+// lili_s2m_lm.hip: the Levenberg-Marquardt loop on fixed correspondences, one persistent launch
+struct LmArgs {      // must match lili_s2m_lm.hip
+    LinArgs S, E;
+    SlotState* state;
+    double* part;
+    double* gsum;
+    int nb, ng;
+    int max_iter;
+    unsigned long long launch;
+    lili_lm_summary* summary;
+    double function_tolerance, gradient_tolerance, parameter_tolerance;
+    double initial_radius, max_radius, min_radius, min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
+};
+__global__ void k_solve_lm(LmArgs, MatchParams);
 // lili_s2m_coop.hip: L lanes per query (small launches)
 template <int L, bool LIN> __global__ void k_associate_coop(AssocArgs, AssocArgs, PoseArg, MatchParams, double*, double*);
 }  // namespace lili
@@ -677,12 +691,18 @@ static int launch_associate_both(lili_ctx* ctx, int slot, const PoseArg& pa, con
 }
 
 // Lanes per query for an association launch over n queries (both kinds): small launches leave most SIMDs without a wave, so several lanes
-// share a query's candidate walk (k_associate_coop) as long as the launch still fits about one wave per SIMD.  1 = the one-lane kernels.
-static int coop_lanes(const lili_ctx* ctx, int64_t n) {
+// share a query's candidate walk (k_associate_coop).  Measured on MI355X against the 5 M-point map (tools/coop_sweep.py, wall time per
+// outer iteration, ROT / front-end flavour): the best L keeps n * L near two waves per SIMD (131 072 lanes) — 2 k queries L = 16
+// (25.8 -> 19.7 / 19.9 -> 15.1 us), 10 k L = 8, 20-25 k L = 4, 50 k L = 2, from 100 k on the one-lane kernels.  The FIRST association
+// after a pose reset is a different launch: a good part of the queries walks the shell of the 5x5x5 block (18 more runs per query), which
+// the lanes of a group split among themselves — twice the lanes pay there up to 200 k queries (200 k: 32.0 -> 25.8 us with L = 2,
+// 25 k: 30.3 -> 16.4 with L = 8).  1 = the one-lane kernels.
+static int coop_lanes(const lili_ctx* ctx, int64_t n, bool first_after_reset) {
     if (ctx->assoc_lpq) return ctx->assoc_lpq;
-    const int64_t lanes = (int64_t)std::max(ctx->n_simd, 256) * 64;      // one wave per SIMD
+    const int64_t lanes = (int64_t)std::max(ctx->n_simd, 256) * 64 * (first_after_reset ? 4 : 2);
     int L = 1;
     while (L < 16 && n * (2 * L) <= lanes) L *= 2;
+    if (first_after_reset && L == 1 && n * 2 <= lanes * 2) L = 2;
     return L;
 }
 // Association of the kinds in kind_mask by k_associate_coop (lili_s2m_coop.hip); `lin`: also linearise (flavours without count scaling) and
@@ -700,7 +720,9 @@ static int launch_associate_coop(lili_ctx* ctx, int slot, int kind_mask, const P
         if (kind == LILI_KIND_SURF && P.variant == LILI_VARIANT_LIVOX && (!m.has_aux || !ks.has_aux)) return 1;
         n_all += ks.n_q;
     }
-    const int L = coop_lanes(ctx, n_all);
+    const bool first = sl.assoc_since_pose == 0;      // the first association after lili_s2m_pose_set / _pose_copy: far from converged
+    sl.assoc_since_pose++;
+    const int L = coop_lanes(ctx, n_all, first);
     if (L < 2 || n_all == 0) return 1;
     const int qpb = 256 / L;
     AssocArgs A[2] = {AssocArgs{}, AssocArgs{}};
@@ -1105,6 +1127,7 @@ int lili_s2m_pose_set(lili_ctx* ctx, int slot, const double t[3], const double q
     // never repeat while stale granules of this slot's partial buffers may still carry it
     HIPCHK(hipMemcpyAsync(ctx->state(slot), &s, offsetof(SlotState, epoch), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));   // `s` is on this stack frame
+    ctx->slots[slot].assoc_since_pose = 0;
     return LILI_OK;
 }
 
@@ -1226,6 +1249,120 @@ int lili_s2m_iterate_inner(lili_ctx* ctx, int slot, int kind_mask, const lili_s2
     return LILI_OK;
 }
 
+// --------------------------------------------------------------------------------------------
+// Levenberg-Marquardt on the device (lili_s2m_lm.hip)
+// --------------------------------------------------------------------------------------------
+void lili_lm_default_options(lili_lm_options* o) {      // Ceres 2.0 Solver::Options defaults; max_num_iterations as the reference sets it (max_num_iter = 15)
+    if (!o) return;
+    o->max_iterations = 15; o->reserved_ = 0;
+    o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
+    o->initial_radius = 1e4; o->max_radius = 1e16; o->min_radius = 1e-32; o->min_relative_decrease = 1e-3;
+    o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32;
+}
+
+// enqueues the persistent launch of one slot on ctx->stream; max_blocks bounds the grid (all workgroups have to be resident)
+static int launch_solve_lm(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, const lili_lm_options* options, int max_blocks) {
+    ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS, "solve_lm: bad slot");
+    ARGCHK((kind_mask & ~3) == 0 && kind_mask != 0, "solve_lm: bad kind mask");
+    ARGCHK(params, "solve_lm: null params");
+    lili_lm_options opt;
+    if (options) opt = *options; else lili_lm_default_options(&opt);
+    ARGCHK(opt.max_iterations >= 1 && opt.max_iterations <= 1000, "solve_lm: max_iterations must be in 1..1000");
+    ARGCHK(opt.initial_radius > 0 && opt.max_radius >= opt.initial_radius && opt.min_radius > 0 && opt.min_lm_diagonal > 0 && opt.max_lm_diagonal >= opt.min_lm_diagonal,
+           "solve_lm: inconsistent trust-region options");
+    Slot& sl = ctx->slots[slot];
+    LmArgs a{};
+    int64_t n_all = 0;
+    for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) {
+        KindSlot& ks = sl.k[kind];
+        if (!ks.has_records) return ctx->fail(LILI_E_STATE, "solve_lm: associate first");
+        if (ks.n_q == 0) continue;
+        LinArgs A = lin_args_of(ctx, slot, kind);
+        A.block_counts = ks.block_counts.as<int>(); A.partials = nullptr;
+        (kind == 0 ? a.S : a.E) = A;
+        n_all += ks.n_q;
+    }
+    if (n_all == 0) return ctx->fail(LILI_E_STATE, "solve_lm: no records");
+    // workgroups: 1024 records each, split between the kinds in proportion, at most max_blocks in total (a kind that is present gets at least one)
+    const int want_s = a.S.n_q > 0 ? nblocks(a.S.n_q, kLinBlock) : 0, want_e = a.E.n_q > 0 ? nblocks(a.E.n_q, kLinBlock) : 0;
+    int nb_s = want_s, nb_e = want_e;
+    if (nb_s + nb_e > max_blocks) {
+        nb_e = want_e ? std::max(1, (int)((int64_t)max_blocks * want_e / (want_s + want_e))) : 0;
+        nb_s = want_s ? std::max(1, max_blocks - nb_e) : 0;
+    }
+    a.S.nb = nb_s; a.E.nb = nb_e;
+    a.nb = nb_s + nb_e;
+    a.ng = a.nb > 16 ? nblocks(a.nb, 16) : 1;
+    HIPCHK(sl.lm_part.ensure((size_t)2 * a.nb * kPartialStride * sizeof(double)));
+    HIPCHK(sl.lm_gsum.ensure((size_t)2 * a.ng * kPartialStride * sizeof(double)));
+    HIPCHK(sl.lm_summary.ensure(sizeof(lili_lm_summary)));
+    a.part = sl.lm_part.as<double>(); a.gsum = sl.lm_gsum.as<double>();
+    a.state = ctx->state(slot);
+    a.max_iter = opt.max_iterations;
+    a.launch = ++ctx->lm_launches;
+    a.summary = sl.lm_summary.as<lili_lm_summary>();
+    a.function_tolerance = opt.function_tolerance; a.gradient_tolerance = opt.gradient_tolerance; a.parameter_tolerance = opt.parameter_tolerance;
+    a.initial_radius = opt.initial_radius; a.max_radius = opt.max_radius; a.min_radius = opt.min_radius; a.min_relative_decrease = opt.min_relative_decrease;
+    a.min_lm_diagonal = opt.min_lm_diagonal; a.max_lm_diagonal = opt.max_lm_diagonal;
+    MatchParams P = to_device_params(params);
+    P.no_cost = 0;                              // the robust cost drives the accept / reject decisions
+    hipLaunchKernelGGL(k_solve_lm, dim3(a.nb), dim3(kLinBlock), lds_linearize(kLinBlock), ctx->stream, a, P);
+    HIPCHK(hipGetLastError());
+    sl.use_global_counts = false;
+    sl.assoc_since_pose = 1;                    // the pose moved, but stays near the association's: the next association is no "first" one
+    return LILI_OK;
+}
+
+int lili_s2m_solve_lm(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, const lili_lm_options* options, lili_lm_summary* summary) {
+    if (!ctx) return LILI_E_ARG;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int max_blocks = std::max(1, std::min(ctx->n_simd / 4 - 16, 240));     // one workgroup per CU, a few CUs left to whatever else runs
+    int rc = launch_solve_lm(ctx, slot, kind_mask, params, options, max_blocks);
+    if (rc != LILI_OK) return rc;
+    if (summary) {
+        HIPCHK(hipMemcpyAsync(summary, ctx->slots[slot].lm_summary.p, sizeof(lili_lm_summary), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    return LILI_OK;
+}
+
+int lili_s2m_solve_lm_window(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, const lili_s2m_params* params, const lili_lm_options* options,
+                             lili_lm_summary* summaries) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(slots && n_slots >= 1 && n_slots <= LILI_MAX_SLOTS, "solve_lm_window: 1..LILI_MAX_SLOTS slots");
+    for (int i = 0; i < n_slots; i++) {
+        ARGCHK(slots[i] >= 0 && slots[i] < LILI_MAX_SLOTS, "solve_lm_window: bad slot");
+        for (int k = 0; k < i; k++) ARGCHK(slots[k] != slots[i], "solve_lm_window: duplicate slot");
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    if (!ctx->fork_ev) HIPCHK(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ctx->fork_ev, ctx->stream));
+    hipStream_t main_stream = ctx->stream;
+    // the launches of the slots run side by side and every one needs all its workgroups resident: share the CUs out
+    const int max_blocks = std::max(1, std::min(ctx->n_simd / 4 - 16, 240) / n_slots);
+    int rc = LILI_OK;
+    for (int i = 0; i < n_slots && rc == LILI_OK; i++) {
+        if (i > 0) {
+            if (!ctx->side[i]) HIPCHK(hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking));
+            if (!ctx->join_ev[i]) HIPCHK(hipEventCreateWithFlags(&ctx->join_ev[i], hipEventDisableTiming));
+            HIPCHK(hipStreamWaitEvent(ctx->side[i], ctx->fork_ev, 0));
+            ctx->stream = ctx->side[i];
+        }
+        rc = launch_solve_lm(ctx, slots[i], kind_mask, params, options, max_blocks);
+        hipError_t e = hipSuccess;
+        if (rc == LILI_OK && summaries) e = hipMemcpyAsync(summaries + i, ctx->slots[slots[i]].lm_summary.p, sizeof(lili_lm_summary), hipMemcpyDeviceToHost, ctx->stream);
+        if (i > 0) {
+            if (e == hipSuccess) e = hipEventRecord(ctx->join_ev[i], ctx->side[i]);
+            ctx->stream = main_stream;
+            if (e == hipSuccess) e = hipStreamWaitEvent(main_stream, ctx->join_ev[i], 0);
+        }
+        if (e != hipSuccess) { ctx->stream = main_stream; return ctx->fail(LILI_E_HIP, std::string("solve_lm_window: ") + hipGetErrorString(e)); }
+    }
+    ctx->stream = main_stream;
+    if (summaries || rc != LILI_OK) HIPCHK(hipStreamSynchronize(ctx->stream));
+    return rc;
+}
+
 int lili_s2m_accumulate(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, double* d_gram) {
     int rc = lili_s2m_associate_dev(ctx, slot, kind_mask, params);
     if (rc != LILI_OK) return rc;
@@ -1247,6 +1384,7 @@ int lili_s2m_pose_copy(lili_ctx* ctx, int dst_slot, int src_slot) {
     HIPCHK(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_pose_copy, dim3(1), dim3(8), 0, ctx->stream, ctx->state(dst_slot), ctx->state(src_slot));
     HIPCHK(hipGetLastError());
+    ctx->slots[dst_slot].assoc_since_pose = 0;
     return LILI_OK;
 }
 
@@ -1309,6 +1447,9 @@ int lili_s2m_iterate_sharded(lili_ctx* ctx, int slot, int kind_mask, const lili_
     // The library's own peer-to-peer exchange (lili_p2p_allreduce) is folded INTO the count kernel and INTO the partial-reduction /
     // Gauss-Newton kernel: 4 launches per iteration (associate, counts + exchange, linearise, reduce + exchange + GN) instead of 7.
     lili_p2p* p2p = (allreduce == &lili_p2p_allreduce && lili_p2p_usable(reinterpret_cast<lili_p2p*>(comm), ctx) && !ctx->no_p2p_fusion) ? reinterpret_cast<lili_p2p*>(comm) : nullptr;
+    // a communicator on which an exchange has given up is dead for good (its ranks no longer hold the same pose): refuse, loudly
+    if (allreduce == &lili_p2p_allreduce && comm && lili_p2p_status(reinterpret_cast<lili_p2p*>(comm)) != 0)
+        return ctx->fail(LILI_E_STATE, "iterate_sharded: the lili_p2p communicator has failed (a peer's record did not arrive within its timeout); SlotState gn_status is 2 on the ranks that noticed");
     for (int it = 0; it < n_iters; it++) {
         int rc;
         if (restart_every > 0 && it % restart_every == 0 && (rc = lili_s2m_pose_copy(ctx, slot, restart_slot)) != LILI_OK) return rc;

@@ -78,6 +78,8 @@ struct Slot {
     KindSlot k[2];
     bool use_global_counts = false;   // next linearize_dev scales with the caller's (all-reduced) counts instead of its own
     const int32_t* global_counts = nullptr;
+    DevBuf lm_part, lm_gsum, lm_summary;      // lili_s2m_solve_lm: granule-tagged block partials / group sums (two parities each), device copy of the summary
+    int assoc_since_pose = 0;         // association launches since the slot's pose was (re)set: the first one is the far-from-converged launch (coop_lanes)
 };
 
 constexpr int kLinBlock = 1024;      // must match lili_s2m.hip
@@ -103,6 +105,7 @@ struct lili_ctx {
     hipStream_t build_stream = nullptr;
     hipEvent_t build_done[2] = {}, main_mark[2] = {};
     hipEvent_t cloud_ready = nullptr;      // lili_map_set_begin with a device cloud: the build stream waits for what the context's stream has enqueued so far
+    unsigned long long lm_launches = 0;    // lili_s2m_solve_lm launches of this context: part of the granule keys, so no launch ever sees an older one's partials as its own
     int scan_fallbacks = 0;                // map builds repeated with the three-kernel scan because a look-back scan gave up (never expected; lili_map_info reports it)
     bool build_pending[2] = {false, false}, main_marked[2] = {false, false};
     DevBuf staging_build, misc_build;

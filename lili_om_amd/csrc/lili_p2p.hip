@@ -13,8 +13,10 @@
 //
 // Slots are double-buffered by the parity of the sequence number: a rank can run at most one all-reduce ahead of the slowest
 // rank (call k+1 needs every rank's contribution to call k+1, which a rank sends only after its own call k has completed), so
-// the slot written for call k+2 (parity of k) is never still being read.  A wait that does not complete within ~2 s of device time
-// gives up (status word in pinned host memory, lili_p2p_status) instead of hanging the GPU.
+// the slot written for call k+2 (parity of k) is never still being read.  A wait that does not complete within the communicator's
+// timeout (lili_p2p_set_timeout, default 10 s of device time) gives up instead of hanging the GPU: the status word in pinned host memory
+// is raised (lili_p2p_status), the failure word of this rank's AND of every peer's mailbox is set, the rank publishes nothing any more,
+// and every later exchange on any rank fails at its first look — lili_s2m_iterate_sharded then reports LILI_E_STATE.
 #include "lili_ctx.h"
 #include "lili_p2p_dev.h"
 
@@ -25,17 +27,18 @@ namespace {
 // generic form: sendbuff / recvbuff hold `count` elements of 4 (int32) or 8 (f64) bytes; one wave
 __global__ __launch_bounds__(64) void k_p2p_allreduce(const void* __restrict__ send, void* __restrict__ recv, int count, int elem8, P2PView v) {
     const int t = threadIdx.x;
+    const unsigned long long was_dead = p2p_dead_word(v);
     unsigned long long w0 = 0, w1 = 0, s0, s1;
     if (elem8) {
         if (t < count) w0 = reinterpret_cast<const unsigned long long*>(send)[t];
         if (t + 64 < count) w1 = reinterpret_cast<const unsigned long long*>(send)[t + 64];
-        if (!p2p_exchange_wave<true>(v, count, w0, w1, s0, s1)) return;
+        if (!p2p_exchange_wave<true>(v, count, w0, w1, s0, s1, was_dead)) return;
         if (t < count) reinterpret_cast<unsigned long long*>(recv)[t] = s0;
         if (t + 64 < count) reinterpret_cast<unsigned long long*>(recv)[t + 64] = s1;
     } else {
         if (t < count) w0 = (unsigned long long)(unsigned)reinterpret_cast<const int*>(send)[t];
         if (t + 64 < count) w1 = (unsigned long long)(unsigned)reinterpret_cast<const int*>(send)[t + 64];
-        if (!p2p_exchange_wave<false>(v, count, w0, w1, s0, s1)) return;
+        if (!p2p_exchange_wave<false>(v, count, w0, w1, s0, s1, was_dead)) return;
         if (t < count) reinterpret_cast<int*>(recv)[t] = (int)(unsigned)s0;
         if (t + 64 < count) reinterpret_cast<int*>(recv)[t + 64] = (int)(unsigned)s1;
     }
@@ -52,6 +55,7 @@ struct lili_p2p {
     bool connected = false;
     unsigned long long seq = 0;
     int* status = nullptr;                    // pinned host word: 0 ok, 1 = a wait timed out
+    double timeout_s = 10.0;                  // lili_p2p_set_timeout
 };
 
 extern "C" {
@@ -77,6 +81,7 @@ int lili_p2p_create(lili_ctx* ctx, int rank, int world, lili_p2p** out) {
     }
     *c->status = 0;
     c->view.box[rank] = c->box; c->view.rank = rank; c->view.world = world; c->view.status = c->status;
+    c->view.timeout_ticks = (long long)(c->timeout_s * 1e8);
     if (world == 1) c->connected = true;
     *out = c;
     return LILI_OK;
@@ -123,6 +128,16 @@ int lili_p2p_allreduce(const void* sendbuff, void* recvbuff, size_t count, int d
 }
 
 int lili_p2p_status(lili_p2p* c) { return c && c->status ? *c->status : -1; }
+
+// How long an exchange waits for a peer's record before it gives up (device time; default 10 s).  The first exchange of a communicator
+// has to absorb whatever skew the ranks start with — lazy code-object loads, data loading, a host stall: keep this generous or put a
+// barrier of the control plane in front of the first lili_s2m_iterate_sharded.  Takes effect with the next exchange.
+int lili_p2p_set_timeout(lili_p2p* c, double seconds) {
+    if (!c || !(seconds > 0.0) || !(seconds <= 3600.0)) return LILI_E_ARG;
+    c->timeout_s = seconds;
+    c->view.timeout_ticks = (long long)(seconds * 1e8);
+    return LILI_OK;
+}
 
 void lili_p2p_destroy(lili_p2p* c) {
     if (!c) return;

@@ -18,17 +18,28 @@ struct P2PView {
     int rank, world;
     int* status;                                    // pinned host word: set to 1 when a wait gives up
     unsigned long long seq;                         // sequence number of THIS exchange (0 = no exchange: view unused)
+    long long timeout_ticks;                        // how long a wait may last, in 100 MHz ticks of s_memrealtime (lili_p2p_set_timeout)
 };
+
+// The sticky failure word of this rank's mailbox (0 = healthy).  Kernels that end with an exchange request it at their START, so that its
+// latency hides behind their own loads, and hand the value to p2p_exchange_wave: a rank whose communicator has failed must not publish
+// another record (its peers would keep adding the records of a rank that no longer applies the updates — ADVICE r2).
+__device__ __forceinline__ unsigned long long p2p_dead_word(const P2PView& v) {
+    return v.seq ? __hip_atomic_load(v.box[v.rank] + kP2PDeadWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
+}
 
 // All 64 lanes of ONE wave.  w0 / w1: this rank's words `lane` and `lane + 64` (ignored beyond count).  On return s0 / s1 hold the
 // sums over the ranks, added in rank order, as f64 (F64) or int32 in the low half of the word.  Returns false if a peer's record
-// did not arrive within ~2 s of device time (status word set).
+// did not arrive within the communicator's timeout (status word set), or if the communicator had failed before (`was_dead`, the value
+// of p2p_dead_word): then nothing is published.  A rank that gives up also raises the failure word in EVERY peer's mailbox, so that
+// the peers — which may be waiting for this rank's next record — fail at their next look instead of after their own timeout.
 template <bool F64>
 __device__ __forceinline__ bool p2p_exchange_wave(const P2PView& v, int count, unsigned long long w0, unsigned long long w1,
-                                                  unsigned long long& s0, unsigned long long& s1) {
+                                                  unsigned long long& s0, unsigned long long& s1, unsigned long long was_dead) {
     const int lane = threadIdx.x & 63;
     const int par = (int)(v.seq & 1ull);
     const int world = v.world;
+    if (__any(was_dead != 0ull)) { if (lane == 0) *v.status = 1; return false; }
     // 1. my record into slot[rank] of every mailbox (own included): write-through system-scope stores
     for (int p = 0; p < world; p++) {
         unsigned long long* slot = v.box[p] + (size_t)(par * kP2PMaxWorld + v.rank) * kP2PSlotWords;
@@ -44,21 +55,24 @@ __device__ __forceinline__ bool p2p_exchange_wave(const P2PView& v, int count, u
         __hip_atomic_store(slot + kP2PFlagWord, v.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     // 3. every source's flag in MY mailbox
-    //    (a communicator whose owner has given up once stays dead: later exchanges return after one look instead of another 2 s —
-    //     the word is read alongside the first poll, so the healthy path pays nothing for it)
     bool ok = true;
     unsigned long long* dead = v.box[v.rank] + kP2PDeadWord;
     if (lane < world) {
         const unsigned long long* flag = v.box[v.rank] + (size_t)(par * kP2PMaxWorld + lane) * kP2PSlotWords + kP2PFlagWord;
         const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();      // 100 MHz
-        const unsigned long long was_dead = __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (;;) {
+        for (unsigned spins = 0;; spins++) {
             if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == v.seq) break;
-            if (was_dead || (long long)__builtin_amdgcn_s_memrealtime() - t0 > 200000000ll) { ok = false; break; }
+            // a peer that gave up has raised my failure word: look at it now and then (it lives in my own memory)
+            if ((spins & 63u) == 63u && __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0ull) { ok = false; break; }
+            if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > v.timeout_ticks) { ok = false; break; }
             __builtin_amdgcn_s_sleep(2);
         }
     }
-    if (!__all(ok)) { if (lane == 0) { *v.status = 1; __hip_atomic_store(dead, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } return false; }
+    if (!__all(ok)) {
+        if (lane == 0) *v.status = 1;
+        if (lane < world) __hip_atomic_store(v.box[lane] + kP2PDeadWord, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // mine and every peer's
+        return false;
+    }
     // 4. sums in rank order; the payload is read with system-scope loads too (they bypass L1 / L2: nothing stale to invalidate)
     const unsigned long long* base = v.box[v.rank] + (size_t)(par * kP2PMaxWorld) * kP2PSlotWords;
     if (F64) {

@@ -457,6 +457,7 @@ __global__ void k_tile_fill(const int* __restrict__ counts, const int* __restric
 // collective: state / out then hold the GLOBAL counts, identical on every rank.
 __global__ __launch_bounds__(kBlock) void k_sum_counts(const int* __restrict__ bc_surf, int nb_surf, const int* __restrict__ bc_edge, int nb_edge,
                                                       SlotState* __restrict__ state, int* __restrict__ out, P2PView v) {
+    const unsigned long long was_dead = p2p_dead_word(v);      // requested first: the round trip hides behind the count loads
     int t0 = bc_surf ? sum_block_counts(bc_surf, nb_surf) : 0;
     __syncthreads();
     int t1 = bc_edge ? sum_block_counts(bc_edge, nb_edge) : 0;
@@ -464,7 +465,7 @@ __global__ __launch_bounds__(kBlock) void k_sum_counts(const int* __restrict__ b
     if (v.seq) {
         unsigned long long s0, s1;
         const int mine = threadIdx.x == 0 ? t0 : t1;
-        if (!p2p_exchange_wave<false>(v, 2, (unsigned long long)(unsigned)mine, 0ull, s0, s1)) { if (threadIdx.x == 0) state->gn_status = 2; return; }
+        if (!p2p_exchange_wave<false>(v, 2, (unsigned long long)(unsigned)mine, 0ull, s0, s1, was_dead)) { if (threadIdx.x == 0) state->gn_status = 2; return; }
         t0 = (int)(unsigned)__shfl((int)(unsigned)s0, 0); t1 = (int)(unsigned)__shfl((int)(unsigned)s0, 1);
     }
     if (threadIdx.x == 0) {
@@ -873,86 +874,6 @@ __device__ __forceinline__ void fused_tail(const FuseTail& fz, unsigned long lon
 }
 
 
-// Linearisation bodies: `bid` of `nb` virtual blocks of one kind (the combined surf + edge launch maps its grid onto both).
-__device__ __forceinline__ void lin_surf_body(const LinArgs& A, int bid, const PoseArg& pa, const MatchParams& P, const SlotState* __restrict__ state,
-                                              const int* __restrict__ n_global, double* lds, unsigned long long key) {
-    const float4* __restrict__ queries = A.queries; const float4* __restrict__ rec_nd = A.rec0;
-    const double* __restrict__ rec_score = reinterpret_cast<const double*>(A.rec1);
-    const unsigned char* __restrict__ valid = A.valid;
-    const int n_q = A.n_q;
-    tstamp(state, P.debug, 100, 0);
-    if ((P.debug & 512) && bid == 100 && threadIdx.x == 0) const_cast<SlotState*>(state)->tprof[15] = (long long)__builtin_amdgcn_s_memrealtime();
-    GramAcc ga; ga.init();
-    dq Q; d3 T;
-    load_body_pose(pa, Q, T);
-    const dq qlb_inv{P.q_lb_inv_jet[0], P.q_lb_inv_jet[1], P.q_lb_inv_jet[2], P.q_lb_inv_jet[3]};
-    // N of R:861: this rank's count (sum of the association's block counts) or, when a multi-GPU caller has
-    // all-reduced it, the global count in state->n_res
-    // the first tile's records are requested before the count reduction below (which synchronises the block twice), and
-    // unconditionally — one memory round trip instead of valid -> record
-    const int BS = blockDim.x;
-    const int i0 = bid * BS + threadIdx.x;
-    const int i0c = min(i0, n_q - 1);
-    unsigned char v0 = valid[i0c];
-    float4 ql0 = queries[i0c], nd0 = rec_nd[i0c];
-    double sc0 = rec_score[i0c];
-    // ROT count scaling exactly as the reference writes it (R/src/BackendFusion.cpp:861, pinned by tests/test_reference_*.py against the reference text):
-    // vec_surf_scores[i] * 1000 / vec_surf_res_cnt  =  (score * 1000.0) / (double)N — a multiply, then a true division
-    double n_den = 1.0;
-    if (P.debug & 128) n_den = 190000.0;
-    else if (P.scale_surf_num > 0) n_den = (double)(A.block_counts ? sum_block_counts(A.block_counts, A.n_bc) : (n_global ? n_global[0] : state->n_res[0]));
-    tstamp(state, P.debug, 100, 1);
-    for (int base = bid * BS; base < n_q; base += A.nb * BS) {
-        int i = base + threadIdx.x;
-        const bool first = base == bid * BS;
-        const int ic = min(i, n_q - 1);
-        bool ok = i < n_q && (first ? v0 : valid[ic]);
-        double Jr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        double cost = 0.0;
-        if (ok) {
-            float4 ql = first ? ql0 : queries[i]; float4 nd = first ? nd0 : rec_nd[i];
-            double score = first ? sc0 : rec_score[i];
-            if (P.scale_surf_num > 0) score = score * P.scale_surf_num / n_den;
-            cost = surf_lin_row(P, Q, T, qlb_inv, ql, nd, score, Jr);
-        }
-        tstamp(state, P.debug, 100, 2);
-        ga.add_rows(Jr, cost, ok, lds);
-        tstamp(state, P.debug, 100, 3);
-        if ((P.debug & 512) && bid == 100 && (threadIdx.x & 63) == 0) const_cast<SlotState*>(state)->tprof[threadIdx.x >> 6] = (long long)__builtin_amdgcn_s_memrealtime();
-    }
-    ga.finish(lds, A.partials + (size_t)bid * kPartialStride, key);
-    tstamp(state, P.debug, 100, 4);
-}
-
-__device__ __forceinline__ void lin_edge_body(const LinArgs& A, int bid, const PoseArg& pa, const MatchParams& P, const SlotState* __restrict__ state,
-                                              const int* __restrict__ n_global, double* lds, unsigned long long key) {
-    const float4* __restrict__ queries = A.queries; const float4* __restrict__ rec_a = A.rec0;
-    const float4* __restrict__ rec_b = reinterpret_cast<const float4*>(A.rec1);
-    const unsigned char* __restrict__ valid = A.valid;
-    const int n_q = A.n_q;
-    GramAcc ga; ga.init();
-    dq Q; d3 T;
-    load_body_pose(pa, Q, T);
-    // R:843: points[i].intensity * 200 / vec_edge_res_cnt — float * int / int, i.e. FLOAT arithmetic (pinned by tests/test_reference_*.py against the reference text)
-    float n_den = 1.0f;
-    if (P.scale_edge_num > 0) n_den = (float)(A.block_counts ? sum_block_counts(A.block_counts, A.n_bc) : (n_global ? n_global[1] : state->n_res[1]));
-    const float n_num = (float)P.scale_edge_num;
-    for (int base = bid * blockDim.x; base < n_q; base += A.nb * blockDim.x) {
-        int i = base + threadIdx.x;
-        bool ok = i < n_q && valid[i];
-        double Jr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        double cost = 0.0;
-        if (ok) {
-            float4 ql = queries[i]; float4 fa = rec_a[i], fb = rec_b[i];
-            double s = (double)fa.w;
-            if (P.scale_edge_num > 0) s = (double)__fdiv_rn(__fmul_rn(fa.w, n_num), n_den);
-            cost = edge_lin_row(P, Q, T, ql, fa, fb, s, Jr);
-        }
-        ga.add_rows(Jr, cost, ok, lds);
-    }
-    ga.finish(lds, A.partials + (size_t)bid * kPartialStride, key);
-}
-
 // One launch for the kinds present: blocks [0, S.nb) linearise the surf records, blocks [S.nb, S.nb + E.nb) the edge records
 // (either count may be 0); with fz.mode != 0 the last block to finish reduces all partials and (mode 2) applies the GN update.
 __global__ __launch_bounds__(kLinBlock) void k_linearize(LinArgs S, LinArgs E, PoseArg pa, MatchParams P, const SlotState* __restrict__ state,
@@ -1161,6 +1082,7 @@ template <bool XCHG>
 __device__ __forceinline__ void reduce_partials_block(const double* part_surf, int nb_surf, const double* part_edge, int nb_edge,
                                                       double* __restrict__ out, SlotState* __restrict__ state, int do_gn, unsigned long long key, const P2PView& xv) {
     tstamp(state, do_gn, (int)blockIdx.x, 8);
+    const unsigned long long was_dead = XCHG ? p2p_dead_word(xv) : 0ull;      // requested first: the round trip hides behind the partial loads
     const double xq[4] = {state->pose[3], state->pose[4], state->pose[5], state->pose[6]};
     constexpr int kGroups = kReduceThreads / 40;   // 25 groups of 40 lanes, group g adds partials g, g+25, ...
     __shared__ double acc[kGroups][2][40];
@@ -1222,7 +1144,7 @@ __device__ __forceinline__ void reduce_partials_block(const double* part_surf, i
         unsigned long long s0, s1;
         const unsigned long long w0 = (unsigned long long)__double_as_longlong(full[lane]);
         const unsigned long long w1 = lane < 8 ? (unsigned long long)__double_as_longlong(full[64 + lane]) : 0ull;
-        if (!p2p_exchange_wave<true>(xv, 72, w0, w1, s0, s1)) { if (lane == 0) state->gn_status = 2; return; }
+        if (!p2p_exchange_wave<true>(xv, 72, w0, w1, s0, s1, was_dead)) { if (lane == 0) state->gn_status = 2; return; }
         full[lane] = __longlong_as_double((long long)s0);
         if (lane < 8) full[64 + lane] = __longlong_as_double((long long)s1);
         LILI_WAVE_SYNC();

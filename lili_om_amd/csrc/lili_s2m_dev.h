@@ -840,4 +840,85 @@ __device__ __forceinline__ void sinc_cos_small(double x2, double& sinc, double& 
     c = __fma_rn(-k, x2, 1.0);
 }
 
+// Linearisation bodies: `bid` of `nb` virtual blocks of one kind (the combined surf + edge launch maps its grid onto both).
+__device__ __forceinline__ void lin_surf_body(const LinArgs& A, int bid, const PoseArg& pa, const MatchParams& P, const SlotState* __restrict__ state,
+                                              const int* __restrict__ n_global, double* lds, unsigned long long key) {
+    const float4* __restrict__ queries = A.queries; const float4* __restrict__ rec_nd = A.rec0;
+    const double* __restrict__ rec_score = reinterpret_cast<const double*>(A.rec1);
+    const unsigned char* __restrict__ valid = A.valid;
+    const int n_q = A.n_q;
+    tstamp(state, P.debug, 100, 0);
+    if ((P.debug & 512) && bid == 100 && threadIdx.x == 0) const_cast<SlotState*>(state)->tprof[15] = (long long)__builtin_amdgcn_s_memrealtime();
+    GramAcc ga; ga.init();
+    dq Q; d3 T;
+    load_body_pose(pa, Q, T);
+    const dq qlb_inv{P.q_lb_inv_jet[0], P.q_lb_inv_jet[1], P.q_lb_inv_jet[2], P.q_lb_inv_jet[3]};
+    // N of R:861: this rank's count (sum of the association's block counts) or, when a multi-GPU caller has
+    // all-reduced it, the global count in state->n_res
+    // the first tile's records are requested before the count reduction below (which synchronises the block twice), and
+    // unconditionally — one memory round trip instead of valid -> record
+    const int BS = blockDim.x;
+    const int i0 = bid * BS + threadIdx.x;
+    const int i0c = min(i0, n_q - 1);
+    unsigned char v0 = valid[i0c];
+    float4 ql0 = queries[i0c], nd0 = rec_nd[i0c];
+    double sc0 = rec_score[i0c];
+    // ROT count scaling exactly as the reference writes it (R/src/BackendFusion.cpp:861, pinned by tests/test_reference_*.py against the reference text):
+    // vec_surf_scores[i] * 1000 / vec_surf_res_cnt  =  (score * 1000.0) / (double)N — a multiply, then a true division
+    double n_den = 1.0;
+    if (P.debug & 128) n_den = 190000.0;
+    else if (P.scale_surf_num > 0) n_den = (double)(A.block_counts ? sum_block_counts(A.block_counts, A.n_bc) : (n_global ? n_global[0] : state->n_res[0]));
+    tstamp(state, P.debug, 100, 1);
+    for (int base = bid * BS; base < n_q; base += A.nb * BS) {
+        int i = base + threadIdx.x;
+        const bool first = base == bid * BS;
+        const int ic = min(i, n_q - 1);
+        bool ok = i < n_q && (first ? v0 : valid[ic]);
+        double Jr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double cost = 0.0;
+        if (ok) {
+            float4 ql = first ? ql0 : queries[i]; float4 nd = first ? nd0 : rec_nd[i];
+            double score = first ? sc0 : rec_score[i];
+            if (P.scale_surf_num > 0) score = score * P.scale_surf_num / n_den;
+            cost = surf_lin_row(P, Q, T, qlb_inv, ql, nd, score, Jr);
+        }
+        tstamp(state, P.debug, 100, 2);
+        ga.add_rows(Jr, cost, ok, lds);
+        tstamp(state, P.debug, 100, 3);
+        if ((P.debug & 512) && bid == 100 && (threadIdx.x & 63) == 0) const_cast<SlotState*>(state)->tprof[threadIdx.x >> 6] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
+    ga.finish(lds, A.partials + (size_t)bid * kPartialStride, key);
+    tstamp(state, P.debug, 100, 4);
+}
+
+__device__ __forceinline__ void lin_edge_body(const LinArgs& A, int bid, const PoseArg& pa, const MatchParams& P, const SlotState* __restrict__ state,
+                                              const int* __restrict__ n_global, double* lds, unsigned long long key) {
+    const float4* __restrict__ queries = A.queries; const float4* __restrict__ rec_a = A.rec0;
+    const float4* __restrict__ rec_b = reinterpret_cast<const float4*>(A.rec1);
+    const unsigned char* __restrict__ valid = A.valid;
+    const int n_q = A.n_q;
+    GramAcc ga; ga.init();
+    dq Q; d3 T;
+    load_body_pose(pa, Q, T);
+    // R:843: points[i].intensity * 200 / vec_edge_res_cnt — float * int / int, i.e. FLOAT arithmetic (pinned by tests/test_reference_*.py against the reference text)
+    float n_den = 1.0f;
+    if (P.scale_edge_num > 0) n_den = (float)(A.block_counts ? sum_block_counts(A.block_counts, A.n_bc) : (n_global ? n_global[1] : state->n_res[1]));
+    const float n_num = (float)P.scale_edge_num;
+    for (int base = bid * blockDim.x; base < n_q; base += A.nb * blockDim.x) {
+        int i = base + threadIdx.x;
+        bool ok = i < n_q && valid[i];
+        double Jr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double cost = 0.0;
+        if (ok) {
+            float4 ql = queries[i]; float4 fa = rec_a[i], fb = rec_b[i];
+            double s = (double)fa.w;
+            if (P.scale_edge_num > 0) s = (double)__fdiv_rn(__fmul_rn(fa.w, n_num), n_den);
+            cost = edge_lin_row(P, Q, T, ql, fa, fb, s, Jr);
+        }
+        ga.add_rows(Jr, cost, ok, lds);
+    }
+    ga.finish(lds, A.partials + (size_t)bid * kPartialStride, key);
+}
+
+
 }  // namespace lili

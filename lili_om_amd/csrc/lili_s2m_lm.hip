@@ -1,0 +1,333 @@
+// Device Levenberg-Marquardt on fixed correspondences, ONE launch.
+//
+// What it replaces: the reference hands the residual blocks of a keyframe to ceres::Solve (L/src/BackendFusion.cpp:984-992: DENSE_QR,
+// max_num_iterations = max_num_iter (15), everything else Ceres 2.0 defaults) — a trust-region loop that EVALUATES all
+// blocks once per iteration and accepts or rejects the step by the robust cost.  lili_s2m_iterate_inner ran plain Gauss-Newton steps,
+// one launch per evaluation (14.7 us at 200 k records); a caller that wanted Ceres' accept / reject had to come back to the host
+// after every evaluation.  Here the whole loop is one persistent kernel:
+//
+//   evaluation   every workgroup linearises its share of the records at the candidate pose (lin_surf_body / lin_edge_body of
+//                lili_s2m_dev.h: robustified rows, f64-MFMA Gram, block partial incl. the robust cost) and PUBLISHES the 40-double partial
+//                as 16-byte granules {value, value ^ key}, key unique per (launch, evaluation): the data is its own flag
+//                (cdna_hip_programming.md Guideline 16 form R2: one write-through store per granule, relaxed agent-scope loads, no fence)
+//   exchange     two hops, both by ONE polling wave per workgroup: the first workgroup of every group of 16 adds its members' partials in
+//                index order and publishes the group sum; every workgroup then adds the <= 15 group sums in index order.  Fixed order,
+//                so every workgroup holds the SAME 40 doubles bit for bit — no broadcast of the decision is needed: each workgroup
+//                runs the trust-region step itself (6x6 LDL^T in one lane) and arrives at the same candidate pose.  Partial / group
+//                buffers are double-buffered by the parity of the evaluation: a workgroup can start evaluation e + 1 only after it has
+//                read every partial of e, so nobody overwrites what somebody still reads.
+//   step logic   TrustRegionMinimizer + LevenbergMarquardtStrategy of Ceres 2.0 (the checker's restatement is what tests/test_lm_gpu.py compares with): Jacobi scaling from
+//                the first Jacobian, D^2 = clamp(diag) / radius, model cost change, relative decrease rho, parameter / function /
+//                gradient tolerances checked in Ceres' order, radius update radius / max(1/3, 1 - (2 rho - 1)^3) or halving with a
+//                doubling divisor.  The linear system is solved on the 6x6 normal equations (the Gram is what the evaluation produces);
+//                Ceres' DENSE_QR works on the stacked rows — the same minimiser up to rounding, which tests/test_lm_gpu.py bounds by
+//                comparing every accept / reject decision and the final pose with the CPU restatement's loop on per-residual rows.
+//
+// All workgroups must be co-resident (<= one per CU: 1024 threads, 96 KB LDS); every wait is bounded and ends the launch with
+// termination = LILI_LM_STALLED instead of hanging the GPU.
+#include "lili_s2m_dev.h"
+#include "../../include/lili_hip.h"
+
+namespace lili {
+
+constexpr int kLmThreads = 1024;
+constexpr int kLmGroup = 16;
+
+struct LmArgs {
+    LinArgs S, E;                 // records of the two kinds; S.nb / E.nb = workgroups of each kind (either may be 0)
+    SlotState* state;
+    double* part;                 // [2 parities][nb][kPartialStride]   block partials as granules
+    double* gsum;                 // [2 parities][ng][kPartialStride]   group sums as granules
+    int nb, ng;
+    int max_iter;
+    unsigned long long launch;    // host counter: makes the granule keys of this launch unique
+    lili_lm_summary* summary;     // device copy, written by workgroup 0
+    double function_tolerance, gradient_tolerance, parameter_tolerance;
+    double initial_radius, max_radius, min_radius, min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
+};
+
+__device__ __forceinline__ unsigned long long lm_key(unsigned long long launch, int eval) { return (launch * 4096ull + (unsigned long long)eval + 1ull) * 0x9E3779B97F4A7C15ull; }
+
+// ONE wave (lanes 0..63 of wave 0): waits until the `count` x 40 granules at `src` (stride kPartialStride doubles per source) carry `key`,
+// then out[e] = sum over the sources in index order.  `vals` = LDS scratch [kLmGroup][40].  Returns false if the wait gave up.
+__device__ __forceinline__ bool lm_gather(const double* src, int count, unsigned long long key, double (*vals)[40], double* out) {
+    const int lane = threadIdx.x & 63;
+    const int n = count * 40;
+    bool ok = false;
+    for (unsigned sweep = 0; sweep < (1u << 22); sweep++) {
+        bool all = true;
+        for (int g = lane; g < n; g += 64) {
+            const int m = g / 40, e = g - m * 40;
+            unsigned long long lo, hi;
+            load_granule(src + (size_t)m * kPartialStride + 2 * e, lo, hi);
+            all = all && ((lo ^ hi) == key);
+            vals[m][e] = __longlong_as_double((long long)lo);
+        }
+        if (__all(all)) { ok = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 40) {
+        double s = 0.0;
+        for (int m = 0; m < count; m++) s += vals[m][lane];
+        out[lane] = s;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return ok;
+}
+
+struct LmShared {
+    double vals[kLmGroup][40];
+    double tot[40];            // sum of all partials of the current evaluation (upper triangle of the 8x8 Gram, [36] cost, [37] rows)
+    double cur[40];            // the same at the accepted point x
+    double full[64];           // symmetric 8x8 Gram of `cur`
+    double H[6][6], gv[6];     // local-coordinate normal matrix P^T G P and gradient P^T G_7r at x
+    double x[7], xn[7];        // accepted point, candidate
+    double scale[6];
+    double cost, radius, decrease, model_change, step_norm;
+    int it, n_ok, term, go;    // go: 1 = evaluate the candidate next, 0 = finished
+    int counts[2];
+    int stalled;               // a bounded wait gave up
+    int take;                  // the candidate was accepted: `tot` becomes `cur`
+};
+
+// H = P^T G77 P, gv = P^T G7r at the quaternion xq (lanes 0..41 of ONE wave; gn_update_block of lili_s2m.hip builds the same)
+__device__ __forceinline__ void lm_local_system(LmShared& sh) {
+    const int tid = threadIdx.x & 63;
+    const double x0 = sh.x[3], x1 = sh.x[4], x2 = sh.x[5], x3 = sh.x[6];
+    const double* gram = sh.full;
+    auto jcol = [&](int c, double o[4]) {
+        o[0] = c == 0 ? -x1 : c == 1 ? -x2 : -x3;
+        o[1] = c == 0 ? x0 : c == 1 ? x3 : -x2;
+        o[2] = c == 0 ? -x3 : c == 1 ? x0 : x1;
+        o[3] = c == 0 ? x2 : c == 1 ? -x1 : x0;
+    };
+    if (tid < 42) {
+        const int a = tid < 36 ? tid / 6 : tid - 36, b = tid < 36 ? tid % 6 : 7;
+        double jb[4] = {0, 0, 0, 0}, ja[4] = {0, 0, 0, 0};
+        if (b >= 3 && b < 6) jcol(b - 3, jb);
+        if (a >= 3) jcol(a - 3, ja);
+        auto Mrow = [&](int i) -> double {
+            if (b < 3 || b == 7) return gram[i * 8 + b];
+            return ((gram[i * 8 + 3] * jb[0] + gram[i * 8 + 4] * jb[1]) + gram[i * 8 + 5] * jb[2]) + gram[i * 8 + 6] * jb[3];
+        };
+        double v;
+        if (a < 3) v = Mrow(a);
+        else v = ((ja[0] * Mrow(3) + ja[1] * Mrow(4)) + ja[2] * Mrow(5)) + ja[3] * Mrow(6);
+        if (tid < 36) sh.H[a][b] = v; else sh.gv[a] = v;
+    }
+}
+__device__ __forceinline__ void lm_tri_to_full(const double* tri, double* full) {      // lanes 0..63 of one wave
+    const int lane = threadIdx.x & 63;
+    const int r = lane >> 3, c = lane & 7;
+    const int a = r < c ? r : c, b = r < c ? c : r;
+    full[lane] = tri[a * 8 - a * (a - 1) / 2 + (b - a)];
+}
+
+// The trust-region step from the accepted point (ONE lane).  Returns with sh.go = 1 and sh.xn = candidate, or sh.go = 0 (finished).
+__device__ __forceinline__ void lm_propose(LmShared& sh, const LmArgs& a) {
+    for (;;) {
+        if (sh.it >= a.max_iter) { sh.term = LILI_LM_MAX_ITERATIONS; sh.go = 0; return; }
+        double gmax = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) gmax = fmax(gmax, fabs(sh.gv[i]));
+        if (gmax <= a.gradient_tolerance) { sh.term = LILI_LM_GRADIENT_TOLERANCE; sh.it++; sh.go = 0; return; }      // (Ceres counts the iteration it stops in)
+        double Hs[6][6], gs[6], A[6][6], W[6][6], dinv[6], d[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            gs[i] = sh.gv[i] * sh.scale[i];
+#pragma unroll
+            for (int j = 0; j <= i; j++) Hs[i][j] = sh.H[i][j] * sh.scale[i] * sh.scale[j];
+        }
+        // (Hs + D^2) d = -gs with D^2 = clamp(diag Hs, min_lm_diagonal, max_lm_diagonal) / radius: LDL^T with reciprocal pivots
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+#pragma unroll
+            for (int j = 0; j <= i; j++) A[i][j] = Hs[i][j];
+            A[i][i] = Hs[i][i] + fmin(fmax(Hs[i][i], a.min_lm_diagonal), a.max_lm_diagonal) / sh.radius;
+            d[i] = -gs[i];
+        }
+        bool okc = true;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            double dj = A[j][j];
+#pragma unroll
+            for (int k = 0; k < j; k++) dj -= A[j][k] * W[j][k];
+            if (!(dj > 0)) okc = false;
+            dinv[j] = 1.0 / dj;
+#pragma unroll
+            for (int i = j + 1; i < 6; i++) {
+                double sv = A[i][j];
+#pragma unroll
+                for (int k = 0; k < j; k++) sv -= A[i][k] * W[j][k];
+                W[i][j] = sv;
+                A[i][j] = sv * dinv[j];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) { double sv = d[i]; for (int k = 0; k < i; k++) sv -= A[i][k] * d[k]; d[i] = sv; }
+#pragma unroll
+        for (int i = 0; i < 6; i++) d[i] = d[i] * dinv[i];
+#pragma unroll
+        for (int i = 5; i >= 0; i--) { double sv = d[i]; for (int k = i + 1; k < 6; k++) sv -= A[k][i] * d[k]; d[i] = sv; }
+#pragma unroll
+        for (int i = 0; i < 6; i++) if (!(d[i] == d[i])) okc = false;
+        if (!okc) { sh.term = LILI_LM_NUMERICAL_FAILURE; sh.go = 0; return; }
+        // model_cost_change = -d^T (gs + Hs d / 2)
+        double mc = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            double hd = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; j++) hd += (j <= i ? Hs[i][j] : Hs[j][i]) * d[j];
+            mc += d[i] * (gs[i] + 0.5 * hd);
+        }
+        mc = -mc;
+        if (!(mc > 0.0)) {       // not a descent step of the model: shrink, no evaluation (the iteration counts)
+            sh.radius = fmax(a.min_radius, sh.radius / sh.decrease); sh.decrease *= 2.0;
+            sh.it++;
+            continue;
+        }
+        double delta[6], n2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) { delta[i] = d[i] * sh.scale[i]; n2 += delta[i] * delta[i]; }
+        sh.model_change = mc;
+        sh.step_norm = sqrt(n2);
+        // x (+) delta: ceres::QuaternionParameterization::Plus
+        sh.xn[0] = sh.x[0] + delta[0]; sh.xn[1] = sh.x[1] + delta[1]; sh.xn[2] = sh.x[2] + delta[2];
+        const double nd2 = delta[3] * delta[3] + delta[4] * delta[4] + delta[5] * delta[5];
+        if (nd2 > 0.0) {
+            double sbd, cw;
+            if (nd2 < 0.25) sinc_cos_small(nd2, sbd, cw);
+            else { const double nd = sqrt(nd2); sbd = sin(nd) / nd; cw = cos(nd); }
+            const dq r = qmul(dq{cw, sbd * delta[3], sbd * delta[4], sbd * delta[5]}, dq{sh.x[3], sh.x[4], sh.x[5], sh.x[6]});
+            sh.xn[3] = r.w; sh.xn[4] = r.x; sh.xn[5] = r.y; sh.xn[6] = r.z;
+        } else { sh.xn[3] = sh.x[3]; sh.xn[4] = sh.x[4]; sh.xn[5] = sh.x[5]; sh.xn[6] = sh.x[6]; }
+        sh.go = 1;
+        return;
+    }
+}
+
+// persistent launch: grid = S.nb + E.nb workgroups of kLmThreads threads; dynamic LDS = kLmThreads * kRow doubles (Gram staging rows)
+__global__ __launch_bounds__(kLmThreads) void k_solve_lm(LmArgs a, MatchParams P) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ LmShared sh;
+    const int b = (int)blockIdx.x;
+    const bool surf = b < a.S.nb;
+    const bool wave0 = threadIdx.x < 64;
+    const bool boss = b == 0 && threadIdx.x == 0;
+    // correspondence counts (ROT residual scale num / N): fixed for the whole solve, summed once from the association's block counts
+    {
+        const int n_s = (a.S.n_q > 0 && a.S.block_counts) ? sum_block_counts(a.S.block_counts, a.S.n_bc) : 0;
+        __syncthreads();
+        const int n_e = (a.E.n_q > 0 && a.E.block_counts) ? sum_block_counts(a.E.block_counts, a.E.n_bc) : 0;
+        if (threadIdx.x == 0) {
+            sh.counts[0] = n_s; sh.counts[1] = n_e;
+            for (int i = 0; i < 7; i++) { sh.x[i] = a.state->pose[i]; sh.xn[i] = sh.x[i]; }
+            sh.radius = a.initial_radius; sh.decrease = 2.0; sh.it = 0; sh.n_ok = 0; sh.term = LILI_LM_MAX_ITERATIONS; sh.go = 1; sh.stalled = 0; sh.take = 0;
+            sh.cost = 0.0; sh.model_change = 0.0; sh.step_norm = 0.0;
+        }
+        __syncthreads();
+    }
+    LinArgs S = a.S, E = a.E;
+    S.block_counts = nullptr; E.block_counts = nullptr;         // the bodies then take N from n_global (= sh.counts)
+    int n_log = 0;
+    double cost0 = 0.0;
+    for (int eval = 0;; eval++) {
+        const int par = eval & 1;
+        const unsigned long long key = lm_key(a.launch, eval);
+        double* part = a.part + (size_t)par * a.nb * kPartialStride;
+        double* gsum = a.gsum + (size_t)par * a.ng * kPartialStride;
+        PoseArg pa{};
+        for (int i = 0; i < 3; i++) pa.t[i] = sh.xn[i];
+        for (int i = 0; i < 4; i++) pa.q[i] = sh.xn[3 + i];
+        pa.state = nullptr; pa.derive_assoc = 0;
+        // ---- evaluation at the candidate: this workgroup's partial, published as granules
+        S.partials = part; E.partials = part + (size_t)a.S.nb * kPartialStride;
+        if (surf) lin_surf_body(S, b, pa, P, a.state, sh.counts, lds, key);
+        else lin_edge_body(E, b - a.S.nb, pa, P, a.state, sh.counts, lds, key);
+        // ---- exchange (wave 0): group sums, then the total, both in index order
+        if (wave0) {
+            bool ok = true;
+            if (a.ng > 1) {
+                if (b % kLmGroup == 0) {
+                    const int cnt = min(kLmGroup, a.nb - b);
+                    ok = lm_gather(part + (size_t)b * kPartialStride, cnt, key, sh.vals, sh.tot);
+                    if ((threadIdx.x & 63) < 40) store_granule(gsum + (size_t)(b / kLmGroup) * kPartialStride + 2 * (threadIdx.x & 63), sh.tot[threadIdx.x & 63], key);
+                }
+                ok = lm_gather(gsum, a.ng, key, sh.vals, sh.tot) && ok;
+            } else ok = lm_gather(part, a.nb, key, sh.vals, sh.tot);
+            if (!ok && threadIdx.x == 0) sh.stalled = 1;
+            // ---- step logic, identical in every workgroup
+            if (eval == 0) {
+                // first evaluation: x0 is the accepted point; Jacobi scaling 1 / (1 + sqrt(diag J^T J)) from this Jacobian, kept for the whole solve
+                if (threadIdx.x < 40) sh.cur[threadIdx.x] = sh.tot[threadIdx.x];
+                LILI_WAVE_SYNC();
+                lm_tri_to_full(sh.cur, sh.full);
+                LILI_WAVE_SYNC();
+                lm_local_system(sh);
+                LILI_WAVE_SYNC();
+                if (threadIdx.x < 6) sh.scale[threadIdx.x] = 1.0 / (1.0 + sqrt(sh.H[threadIdx.x][threadIdx.x]));
+                if (threadIdx.x == 0) { sh.cost = sh.cur[36]; cost0 = sh.cost; }
+                LILI_WAVE_SYNC();
+                if (threadIdx.x == 0) { if (sh.stalled) { sh.term = LILI_LM_STALLED; sh.go = 0; } else lm_propose(sh, a); }
+            } else {
+                // the candidate's cost is known: accept or reject (Ceres checks both tolerances on the candidate first)
+                int accepted = 0, stop = 0;
+                if (threadIdx.x == 0) {
+                    const double new_cost = sh.tot[36];
+                    const double rho = (sh.cost - new_cost) / sh.model_change;
+                    if (boss && a.summary && n_log < LILI_LM_MAX_LOG) {
+                        lili_lm_iteration& L = a.summary->it[n_log];
+                        L.cost = sh.cost; L.new_cost = new_cost; L.rho = rho; L.radius = sh.radius; L.step_norm = sh.step_norm; L.accepted = 0; L.iteration = sh.it;
+                    }
+                    const double xnorm = sqrt(sh.x[0] * sh.x[0] + sh.x[1] * sh.x[1] + sh.x[2] * sh.x[2] + sh.x[3] * sh.x[3] + sh.x[4] * sh.x[4] + sh.x[5] * sh.x[5] + sh.x[6] * sh.x[6]);
+                    if (sh.stalled) { sh.term = LILI_LM_STALLED; stop = 1; }
+                    else if (sh.step_norm <= a.parameter_tolerance * (xnorm + a.parameter_tolerance)) { sh.term = LILI_LM_PARAMETER_TOLERANCE; stop = 1; }
+                    else if (fabs(sh.cost - new_cost) <= a.function_tolerance * sh.cost) { sh.term = LILI_LM_FUNCTION_TOLERANCE; stop = 1; accepted = rho > a.min_relative_decrease ? 1 : 0; }
+                    else if (rho > a.min_relative_decrease) {
+                        accepted = 1;
+                        const double f = 2.0 * rho - 1.0;
+                        sh.radius = fmin(a.max_radius, sh.radius / fmax(1.0 / 3.0, 1.0 - f * f * f));
+                        sh.decrease = 2.0;
+                    } else { sh.radius = fmax(a.min_radius, sh.radius / sh.decrease); sh.decrease *= 2.0; }
+                    if (accepted) { for (int i = 0; i < 7; i++) sh.x[i] = sh.xn[i]; sh.cost = new_cost; sh.n_ok++; }
+                    if (boss && a.summary && n_log < LILI_LM_MAX_LOG) a.summary->it[n_log].accepted = accepted;
+                    n_log++;
+                    sh.it++;
+                    sh.go = stop ? 0 : 1;
+                    sh.take = accepted;
+                }
+                LILI_WAVE_SYNC();
+                const bool take = sh.take != 0;
+                if (take && threadIdx.x < 40) sh.cur[threadIdx.x] = sh.tot[threadIdx.x];
+                LILI_WAVE_SYNC();
+                if (take) {
+                    lm_tri_to_full(sh.cur, sh.full);
+                    LILI_WAVE_SYNC();
+                    lm_local_system(sh);
+                }
+                LILI_WAVE_SYNC();
+                if (threadIdx.x == 0 && sh.go) lm_propose(sh, a);
+            }
+            LILI_WAVE_SYNC();
+        }
+        __syncthreads();
+        if (!sh.go) break;
+    }
+    if (boss) {
+        for (int i = 0; i < 7; i++) a.state->pose[i] = sh.x[i];
+        a.state->gn_status = (sh.term == LILI_LM_STALLED || sh.term == LILI_LM_NUMERICAL_FAILURE) ? 1 : 0;
+        a.state->iters += sh.n_ok;
+        if (a.summary) {
+            a.summary->iterations = sh.it; a.summary->successful_steps = sh.n_ok; a.summary->termination = sh.term;
+            a.summary->initial_cost = cost0; a.summary->final_cost = sh.cost; a.summary->final_radius = sh.radius;
+            a.summary->n_logged = n_log < LILI_LM_MAX_LOG ? n_log : LILI_LM_MAX_LOG;
+            a.summary->n_surf = sh.counts[0]; a.summary->n_edge = sh.counts[1];
+        }
+    }
+}
+
+}  // namespace lili

@@ -62,6 +62,10 @@ class Communicator:
     def status(self):
         return self.lib.lili_p2p_status(C.c_void_p(self.handle))
 
+    def set_timeout(self, seconds):
+        """How long an exchange waits for a peer (device time, default 10 s) before the communicator fails for good."""
+        self.ctx._chk(self.lib.lili_p2p_set_timeout(C.c_void_p(self.handle), float(seconds)))
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.lili_p2p_destroy(C.c_void_p(self.handle))

@@ -1,0 +1,178 @@
+"""lili_s2m_solve_lm (lili_s2m_lm.hip): ceres::Solve's trust-region loop on the lidar blocks of one keyframe
+(L/src/BackendFusion.cpp:984-992, Ceres 2.0 defaults) as ONE persistent launch.
+
+Referee: oracle/lo_window.py::ceres_lm — the restatement of Ceres' TrustRegionMinimizer / LevenbergMarquardtStrategy that tests/test_window_*.py
+already pin — run on the ORACLE's per-residual rows of the same correspondences (CauchyLoss + Triggs corrector per row, DENSE_QR on the stacked
+rows).  The device loop works from the 8x8 Gram of the same rows (normal equations): every accept / reject decision, every trust-region radius and
+the iteration counts must be the same, costs agree to 1e-9 relative and the final pose to 1e-7 (north star: 1e-4 m / 1e-4 rad)."""
+import numpy as np
+import pytest
+
+import lili_om_amd as L
+from lili_om_amd import synth
+from oracle import lo_window as W
+from tests import window_harness as H
+
+pytestmark = pytest.mark.gpu
+MASK = L.MASK_SURF | L.MASK_EDGE
+
+
+def _angle(qa, qb):
+    d = W.qmul(W.qinv(qa), qb)
+    return 2.0 * np.arctan2(np.linalg.norm(d[1:]), abs(d[0]))
+
+
+def _setup(gpu_ctx, flavour, seed, n_surf, n_edge, off=(0.06, 0.6)):
+    room = synth.make_room(seed=seed, n_query=n_surf, n_edge_query=n_edge)
+    P = L.make_params(flavour)
+    tb, qb = L.api.body_pose_from_lidar(room["t_true"], room["q_true"], P)
+    t0, q0 = synth.perturbed_pose(tb, qb, np.random.default_rng(seed + 3), *off)
+    rng = np.random.default_rng(seed + 7)
+    refl = lambda n: rng.uniform(0.0, 0.05, n).astype(np.float32)
+    data = dict(room=room, P=P, t0=np.asarray(t0, np.float64), q0=np.asarray(q0, np.float64), tb=tb, qb=qb,
+                map_refl=refl(room["map_xyz"].shape[0]), q_refl=refl(room["q_xyz"].shape[0]))
+    m = L.ScanToMapMatcher(gpu_ctx, P)
+    if flavour == "livox":
+        m.set_input_cloud(L.KIND_SURF, np.c_[room["map_xyz"], data["map_refl"]])
+    else:
+        m.set_input_cloud(L.KIND_SURF, room["map_xyz"])
+    m.set_input_cloud(L.KIND_EDGE, room["edge_map_xyz"])
+    return m, data
+
+
+def _queries(m, data, slot, flavour):
+    room = data["room"]
+    m.set_queries(slot, L.KIND_SURF, np.c_[room["q_xyz"], data["q_refl"]] if flavour == "livox" else room["q_xyz"])
+    m.set_queries(slot, L.KIND_EDGE, room["eq_xyz"])
+
+
+def _oracle_problem(oracle, data, flavour):
+    room, P = data["room"], data["P"]
+    PO = oracle.params(flavour, loss=0)
+    Q2, T2 = L.api.assoc_transform(data["t0"], data["q0"], P)
+    tree_s, tree_e = oracle.KdTree(room["map_xyz"]), oracle.KdTree(room["edge_map_xyz"])
+    if flavour == "livox":
+        rs = oracle.associate_surf(tree_s, data["map_refl"], room["q_xyz"], data["q_refl"], Q2, T2, PO)
+    else:
+        rs = oracle.associate_surf(tree_s, None, room["q_xyz"], None, Q2, T2, PO)
+    re = oracle.associate_edge(tree_e, room["eq_xyz"], Q2, T2, PO)
+    sc_s = (1000.0, max(rs["count"], 1)) if flavour == "rot" else 1.0
+    sc_e = (200.0, max(re["count"], 1)) if flavour == "rot" else 1.0
+
+    def block(t, q):
+        rows = np.concatenate([oracle.linearize_rows(rs, t, q, PO, sc_s, kind="surf"), oracle.linearize_rows(re, t, q, PO, sc_e, kind="edge")])
+        J, r, cost = H.robust_rows(rows, a=1.0)
+        return r, [J[:, :3], J[:, 3:7]], cost
+    pb = W.Problem()
+    pb.add_parameter("t", data["t0"])
+    pb.add_parameter("q", data["q0"], quat=True)
+    pb.add_residual(block, ["t", "q"])
+    return pb, rs["count"], re["count"]
+
+
+def _compare(summ, log_o, info_o, tg, qg, sol_o):
+    assert summ["termination"] not in ("stalled", "numerical_failure"), summ
+    assert summ["iterations"] == info_o["iterations"] and summ["successful_steps"] == info_o["successful_steps"], (summ, info_o)
+    assert len(summ["log"]) == len(log_o)
+    for a, b in zip(summ["log"], log_o):
+        assert a["accepted"] == (b["rho"] > 1e-3) or abs(b["cost"] - b["new_cost"]) <= 1e-6 * b["cost"], (a, b)    # (a step inside the function tolerance may end the loop either way)
+        assert abs(a["radius"] - b["radius"]) <= 1e-9 * b["radius"], (a, b)
+        assert abs(a["cost"] - b["cost"]) <= 1e-9 * b["cost"] and abs(a["new_cost"] - b["new_cost"]) <= 1e-9 * b["cost"], (a, b)
+        assert abs(a["step"] - b["step"]) <= 1e-6 * max(b["step"], 1e-9), (a, b)
+    assert abs(summ["final_cost"] - info_o["cost"]) <= 1e-9 * info_o["cost"]
+    dt, da = np.linalg.norm(tg - sol_o["t"]), _angle(qg, sol_o["q"])
+    assert dt < 1e-7 and da < 1e-7, (dt, da)
+
+
+@pytest.mark.parametrize("flavour", ["livox", "rot"])
+def test_device_lm_takes_the_oracle_lm_decisions(gpu_ctx, oracle, flavour):
+    m, data = _setup(gpu_ctx, flavour, seed=61, n_surf=3000, n_edge=250)
+    _queries(m, data, 0, flavour)
+    m.pose_set(0, data["t0"], data["q0"])
+    m.associate_dev(0, MASK)
+    summ = m.solve_lm(0, MASK)
+    tg, qg, st = m.pose_get(0)
+    pb, n_s, n_e = _oracle_problem(oracle, data, flavour)
+    assert (summ["n_surf"], summ["n_edge"]) == (n_s, n_e) and n_s > 1500 and n_e > 50
+    log_o = []
+    sol_o, info_o = W.ceres_lm(pb, max_num_iterations=15, log=log_o)
+    assert st == 0 and info_o["successful_steps"] >= 2
+    _compare(summ, log_o, info_o, tg, qg, sol_o)
+    assert np.linalg.norm(tg - data["tb"]) < 0.2 * np.linalg.norm(data["t0"] - data["tb"])       # and it is the registration: back at the true pose
+    # the loop is deterministic: a second solve from the same start repeats every bit; and it leaves the records alone
+    m.pose_set(0, data["t0"], data["q0"])
+    summ2 = m.solve_lm(0, MASK)
+    t2, q2, _ = m.pose_get(0)
+    assert summ2 == summ and np.array_equal(t2, tg) and np.array_equal(q2, qg)
+
+
+def test_device_lm_few_iterations_and_tight_radius(gpu_ctx, oracle):
+    """Options travel: max_iterations = 3 stops where the oracle's loop stops; a tiny initial radius makes the first steps short and the
+    radius grow exactly as Ceres' rule says."""
+    flavour = "livox"
+    m, data = _setup(gpu_ctx, flavour, seed=67, n_surf=2000, n_edge=150)
+    _queries(m, data, 0, flavour)
+    pb, _, _ = _oracle_problem(oracle, data, flavour)
+    for kw_gpu, kw_cpu in ((dict(max_iterations=3), dict(max_num_iterations=3)),
+                           (dict(max_iterations=12, initial_radius=1e-2), dict(max_num_iterations=12, initial_radius=1e-2))):
+        m.pose_set(0, data["t0"], data["q0"])
+        m.associate_dev(0, MASK)
+        summ = m.solve_lm(0, MASK, options=m.lm_options(**kw_gpu))
+        tg, qg, _ = m.pose_get(0)
+        log_o = []
+        sol_o, info_o = W.ceres_lm(pb, log=log_o, **kw_cpu)
+        _compare(summ, log_o, info_o, tg, qg, sol_o)
+
+
+def test_device_lm_many_workgroups_equals_host_driven_lm(gpu_ctx, oracle):
+    """40 k + 3 k records: 43 workgroups, i.e. the two-hop exchange (group sums of 16, then the total).  Referee here: the same trust-region
+    loop on the host fed by lili_s2m_linearize (the Gram the one-launch-per-evaluation path produces) — same decisions, pose to 1e-9."""
+    flavour = "rot"
+    m, data = _setup(gpu_ctx, flavour, seed=71, n_surf=40000, n_edge=3000, off=(0.1, 1.0))
+    _queries(m, data, 0, flavour)
+    m.pose_set(0, data["t0"], data["q0"])
+    m.associate_dev(0, MASK)
+    summ = m.solve_lm(0, MASK)
+    tg, qg, st = m.pose_get(0)
+    assert st == 0 and summ["termination"] not in ("stalled", "numerical_failure")
+
+    def gpu_block(t, q):
+        G, cost, counts = m.linearize(0, t, q, MASK)
+        res, jac = L.api.gram_to_factor(G, cost)
+        return res, [jac[:, :3], jac[:, 3:7]]
+    pb = W.Problem()
+    pb.add_parameter("t", data["t0"])
+    pb.add_parameter("q", data["q0"], quat=True)
+    pb.add_residual(gpu_block, ["t", "q"])
+    log_h = []
+    sol_h, info_h = W.ceres_lm(pb, max_num_iterations=15, log=log_h)
+    assert summ["iterations"] == info_h["iterations"] and summ["successful_steps"] == info_h["successful_steps"]
+    for a, b in zip(summ["log"], log_h):
+        assert abs(a["radius"] - b["radius"]) <= 1e-9 * b["radius"] and abs(a["new_cost"] - b["new_cost"]) <= 1e-9 * b["cost"]
+    assert np.linalg.norm(tg - sol_h["t"]) < 1e-8 and _angle(qg, sol_h["q"]) < 1e-8
+
+
+def test_device_lm_window_equals_slot_by_slot(gpu_ctx, oracle):
+    """lili_s2m_solve_lm_window: three keyframes' solves side by side (one launch each on forked streams) end exactly where the solves
+    one after the other end."""
+    flavour = "livox"
+    m, data = _setup(gpu_ctx, flavour, seed=73, n_surf=2500, n_edge=200)
+    starts = []
+    for k in range(3):
+        _queries(m, data, k, flavour)
+        tk, qk = synth.perturbed_pose(data["tb"], data["qb"], np.random.default_rng(100 + k), 0.05, 0.5)
+        starts.append((np.asarray(tk, np.float64), np.asarray(qk, np.float64)))
+    res = []
+    for mode in ("single", "window"):
+        for k, (tk, qk) in enumerate(starts):
+            m.pose_set(k, tk, qk)
+            m.associate_dev(k, MASK)
+        if mode == "single":
+            summ = [m.solve_lm(k, MASK) for k in range(3)]
+        else:
+            summ = m.solve_lm_window([0, 1, 2], MASK)
+        res.append((summ, [m.pose_get(k) for k in range(3)]))
+    for k in range(3):
+        assert res[0][0][k] == res[1][0][k]
+        assert np.array_equal(res[0][1][k][0], res[1][1][k][0]) and np.array_equal(res[0][1][k][1], res[1][1][k][1])
+        assert res[0][0][k]["successful_steps"] >= 2

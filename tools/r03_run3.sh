@@ -1,0 +1,10 @@
+#!/bin/bash
+# round 3, GPU run 3: device LM tests, coop + p2p re-check, full suite, LM timing
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+OUT=gpurun_out/r03c; mkdir -p $OUT
+( time timeout 900 python -m pytest tests/test_lm_gpu.py -m gpu -x -q ) > $OUT/pytest_lm.log 2>&1
+tail -25 $OUT/pytest_lm.log
+( time timeout 900 python -m pytest tests -m gpu -q --deselect tests/test_lm_gpu.py ) > $OUT/pytest_all.log 2>&1
+tail -8 $OUT/pytest_all.log
+timeout 600 python tools/lm_time.py $OUT/lm_time.json > $OUT/lm_time.log 2> $OUT/lm_time.err
+cat $OUT/lm_time.log; tail -3 $OUT/lm_time.err
