@@ -360,11 +360,33 @@ int lili_s2m_gn_update(lili_ctx* ctx, int slot, const double* d_gram);
 typedef int (*lili_allreduce_fn)(const void* sendbuff, void* recvbuff, size_t count, int datatype, int op, void* comm, void* stream);
 int lili_s2m_iterate_sharded(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, int n_iters, int restart_every,
                              int restart_slot, lili_allreduce_fn allreduce, void* comm, int32_t* d_counts, double* d_gram);
+/* The sliding window across ranks (BASELINE configs[4]: the reference evaluates the lidar blocks of ALL keyframes of the window per solver
+ * evaluation, L/src/BackendFusion.cpp:919-992).  Every rank holds its shard of every slot's queries (set_queries with the shard) and the
+ * whole map; per evaluation ONE exchange of n_slots x LILI_GRAM_DOUBLES doubles makes every rank hold the same n Gram records bit for bit
+ * (lili_p2p: folded into the reduction launch; any other lili_allreduce_fn: one call on the n x 72 doubles; NULL: one rank).
+ *   lili_s2m_counts_window_sharded     after the slots' associations (lili_s2m_associate / _associate_dev per slot): the GLOBAL correspondence
+ *                                      counts of every slot in ONE exchange of 2 n int32 into d_counts (DEVICE, [surf, edge] per slot; kept valid
+ *                                      by the caller) — the count-scaled ROT flavour needs them, the others may skip the call.  They stay
+ *                                      in force for the slots' linearisations until the next association.  Async.
+ *   lili_s2m_linearize_window_dev      the n records at the slots' DEVICE poses into d_gram (DEVICE, n x LILI_GRAM_DOUBLES).  Async.
+ *   lili_s2m_linearize_window_sharded  the same at host poses t (3 per slot) / q (4 per slot), blocking, records copied out like
+ *                                      lili_s2m_linearize_window: one evaluation of the caller's solver.
+ *   lili_s2m_iterate_window_sharded    n_iters x [associate every slot, counts exchange (count-scaled flavours), linearise every slot, ONE
+ *                                      reduction launch + exchange + Gauss-Newton update of every slot]: the lidar-only registration of
+ *                                      every keyframe as in lili_s2m_iterate_window, 2 exchanges per iteration whatever n_slots is. */
+int lili_s2m_counts_window_sharded(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, lili_allreduce_fn allreduce, void* comm, int32_t* d_counts);
+int lili_s2m_linearize_window_dev(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, const lili_s2m_params* params,
+                                  lili_allreduce_fn allreduce, void* comm, double* d_gram);
+int lili_s2m_linearize_window_sharded(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, const double* t, const double* q,
+                                      const lili_s2m_params* params, lili_allreduce_fn allreduce, void* comm, double* d_gram,
+                                      double* gram, double* cost, int* counts);
+int lili_s2m_iterate_window_sharded(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, const lili_s2m_params* params, int n_iters,
+                                    lili_allreduce_fn allreduce, void* comm, int32_t* d_counts, double* d_gram);
 /* Peer-to-peer all-reduce for the two records of the sharded loop (the loop being sharded is
  * L/src/BackendFusion.cpp:1536,1606): every rank owns a mailbox in its HBM that all peers map through hipIpc; one small kernel per
  * all-reduce stores this rank's record into every peer's mailbox over xGMI, waits for the peers' records in its own, and adds them IN
  * RANK ORDER — so all ranks hold bit-identical sums.  lili_p2p_allreduce has the signature of ncclAllReduce (lili_allreduce_fn) with
- * comm = the lili_p2p*; records of at most 96 x 8 bytes, datatype 2 (int32) or 8 (f64), op 0 (sum).
+ * comm = the lili_p2p*; records of at most 640 elements (a window of 8 Gram records is 576 doubles), datatype 2 (int32) or 8 (f64), op 0 (sum).
  *   lili_p2p_create   one per rank (rank, world <= 16), on the context's device
  *   lili_p2p_handle   this rank's mailbox handle (LILI_P2P_HANDLE_BYTES, opaque) — the caller all-gathers the handles (MPI,
  *                     torch.distributed, a file ...) and hands all of them, in rank order, to

@@ -164,6 +164,11 @@ _SIGS = {
     "lili_lm_default_options": (None, [C.POINTER(LmOptions)]),
     "lili_s2m_solve_lm": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(S2MParams), C.POINTER(LmOptions), C.POINTER(LmSummary)]),
     "lili_s2m_solve_lm_window": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(S2MParams), C.POINTER(LmOptions), C.POINTER(LmSummary)]),
+    "lili_s2m_counts_window_sharded": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lili_s2m_linearize_window_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(S2MParams), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lili_s2m_linearize_window_sharded": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(S2MParams), C.c_void_p, C.c_void_p,
+                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lili_s2m_iterate_window_sharded": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(S2MParams), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lili_host_alloc": (C.c_void_p, [C.c_size_t]),
     "lili_host_free": (None, [C.c_void_p]),
     "lili_p2p_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
@@ -448,6 +453,26 @@ class ScanToMapMatcher:
         self.ctx._chk(self.lib.lili_s2m_iterate_sharded(self.ctx.h, slot, kind_mask, C.byref(self.params), int(n_iters), int(restart_every),
                                                         int(restart_slot), C.c_void_p(allreduce_fn), C.c_void_p(comm),
                                                         C.c_void_p(d_counts_ptr), C.c_void_p(d_gram_ptr)))
+
+    def counts_window_sharded(self, slots, d_counts_ptr, allreduce_fn=None, comm=None, kind_mask=MASK_SURF | MASK_EDGE):
+        arr = (C.c_int * len(slots))(*slots)
+        self.ctx._chk(self.lib.lili_s2m_counts_window_sharded(self.ctx.h, arr, len(slots), kind_mask, C.c_void_p(allreduce_fn), C.c_void_p(comm), C.c_void_p(d_counts_ptr)))
+
+    def linearize_window_sharded(self, slots, ts, qs, d_gram_ptr, allreduce_fn=None, comm=None, kind_mask=MASK_SURF | MASK_EDGE):
+        """One evaluation of the joint window with the queries of every slot sharded over the ranks: [(gram 8x8, cost, counts)] per slot,
+        the same bits on every rank."""
+        n = len(slots)
+        arr = (C.c_int * n)(*slots)
+        t = np.ascontiguousarray(np.asarray(ts, np.float64).reshape(n, 3)); q = np.ascontiguousarray(np.asarray(qs, np.float64).reshape(n, 4))
+        G = np.zeros((n, 64)); cost = np.zeros(n); cnt = np.zeros((n, 2), np.int32)
+        self.ctx._chk(self.lib.lili_s2m_linearize_window_sharded(self.ctx.h, arr, n, kind_mask, _ptr(t), _ptr(q), C.byref(self.params), C.c_void_p(allreduce_fn),
+                                                                 C.c_void_p(comm), C.c_void_p(d_gram_ptr), _ptr(G), _ptr(cost), _ptr(cnt)))
+        return [(G[i].reshape(8, 8), float(cost[i]), cnt[i].copy()) for i in range(n)]
+
+    def iterate_window_sharded(self, slots, n_iters, d_counts_ptr, d_gram_ptr, allreduce_fn=None, comm=None, kind_mask=MASK_SURF | MASK_EDGE):
+        arr = (C.c_int * len(slots))(*slots)
+        self.ctx._chk(self.lib.lili_s2m_iterate_window_sharded(self.ctx.h, arr, len(slots), kind_mask, C.byref(self.params), int(n_iters), C.c_void_p(allreduce_fn),
+                                                               C.c_void_p(comm), C.c_void_p(d_counts_ptr), C.c_void_p(d_gram_ptr)))
 
     def iterate_window(self, slots, n_iters, kind_mask=MASK_SURF):
         arr = (C.c_int * len(slots))(*[int(s) for s in slots])

@@ -39,6 +39,9 @@ __global__ void k_reduce_partials(const double*, int, const double*, int, double
 __global__ void k_sum_counts(const int*, int, const int*, int, SlotState*, int*, P2PView);
 __global__ void k_gn_update(const double*, SlotState*);
 __global__ void k_pose_copy(SlotState*, const SlotState*);
+__global__ void k_window_reduce(WindowArgs, double*, int, P2PView);
+__global__ void k_window_gn(WindowArgs, const double*);
+__global__ void k_window_counts(WindowArgs, int*, P2PView);
 // lili_s2m_lm.hip: the Levenberg-Marquardt loop on fixed correspondences, one persistent launch
 struct LmArgs {      // must match lili_s2m_lm.hip
     LinArgs S, E;
@@ -883,7 +886,7 @@ int lili_s2m_associate(lili_ctx* ctx, int slot, int kind, const double t_assoc[3
     for (int i = 0; i < 4; i++) pa.q[i] = q_assoc[i];
     pa.state = nullptr; pa.derive_assoc = 0;
     MatchParams P = to_device_params(params);
-    ctx->slots[slot].use_global_counts = false;
+    ctx->slots[slot].use_global_counts = false; ctx->slots[slot].sticky_global_counts = false;
     int rc = launch_associate_coop(ctx, slot, 1 << kind, pa, P, false, nullptr);
     if (rc == 1) rc = launch_associate(ctx, slot, kind, pa, P);
     if (rc != LILI_OK) return rc;
@@ -927,7 +930,7 @@ int lili_s2m_associate_window(lili_ctx* ctx, const int* slots, int n_slots, int 
         PoseArg pa{};
         for (int k = 0; k < 3; k++) pa.t[k] = t_assoc[3 * i + k];
         for (int k = 0; k < 4; k++) pa.q[k] = q_assoc[4 * i + k];
-        ctx->slots[slots[i]].use_global_counts = false;
+        ctx->slots[slots[i]].use_global_counts = false; ctx->slots[slots[i]].sticky_global_counts = false;
         rc = launch_associate_coop(ctx, slots[i], kind_mask, pa, P, false, nullptr);
         if (rc == 1 && kind_mask == (LILI_MASK_SURF | LILI_MASK_EDGE) && ctx->merge_kinds) rc = launch_associate_both(ctx, slots[i], pa, P);
         if (rc == 1) {                                   // not eligible (or one kind only): one launch per kind
@@ -1179,7 +1182,7 @@ int lili_s2m_associate_dev(lili_ctx* ctx, int slot, int kind_mask, const lili_s2
     ARGCHK(params, "associate_dev: null argument");
     HIPCHK(hipSetDevice(ctx->device));
     Slot& s = ctx->slots[slot];
-    s.use_global_counts = false;
+    s.use_global_counts = false; s.sticky_global_counts = false;
     PoseArg pa{};
     pa.state = ctx->state(slot);
     pa.derive_assoc = params->variant == LILI_VARIANT_FRONTEND ? 0 : 1;
@@ -1283,8 +1286,9 @@ static int launch_solve_lm(lili_ctx* ctx, int slot, int kind_mask, const lili_s2
         n_all += ks.n_q;
     }
     if (n_all == 0) return ctx->fail(LILI_E_STATE, "solve_lm: no records");
-    // workgroups: 1024 records each, split between the kinds in proportion, at most max_blocks in total (a kind that is present gets at least one)
-    const int want_s = a.S.n_q > 0 ? nblocks(a.S.n_q, kLinBlock) : 0, want_e = a.E.n_q > 0 ? nblocks(a.E.n_q, kLinBlock) : 0;
+    // workgroups: 512 records each, split between the kinds in proportion, at most max_blocks in total (a kind that is present gets at least one)
+    constexpr int kLmThreads = 512;      // must match lili_s2m_lm.hip
+    const int want_s = a.S.n_q > 0 ? nblocks(a.S.n_q, kLmThreads) : 0, want_e = a.E.n_q > 0 ? nblocks(a.E.n_q, kLmThreads) : 0;
     int nb_s = want_s, nb_e = want_e;
     if (nb_s + nb_e > max_blocks) {
         nb_e = want_e ? std::max(1, (int)((int64_t)max_blocks * want_e / (want_s + want_e))) : 0;
@@ -1306,7 +1310,7 @@ static int launch_solve_lm(lili_ctx* ctx, int slot, int kind_mask, const lili_s2
     a.min_lm_diagonal = opt.min_lm_diagonal; a.max_lm_diagonal = opt.max_lm_diagonal;
     MatchParams P = to_device_params(params);
     P.no_cost = 0;                              // the robust cost drives the accept / reject decisions
-    hipLaunchKernelGGL(k_solve_lm, dim3(a.nb), dim3(kLinBlock), lds_linearize(kLinBlock), ctx->stream, a, P);
+    hipLaunchKernelGGL(k_solve_lm, dim3(a.nb), dim3(kLmThreads), lds_linearize(kLmThreads), ctx->stream, a, P);
     HIPCHK(hipGetLastError());
     sl.use_global_counts = false;
     sl.assoc_since_pose = 1;                    // the pose moved, but stays near the association's: the next association is no "first" one
@@ -1479,6 +1483,151 @@ int lili_s2m_iterate_sharded(lili_ctx* ctx, int slot, int kind_mask, const lili_
         if (allreduce && allreduce(d_gram, d_gram, LILI_GRAM_DOUBLES, /*ncclFloat64*/ 8, /*ncclSum*/ 0, comm, (void*)ctx->stream) != 0)
             return ctx->fail(LILI_E_HIP, "iterate_sharded: all-reduce of the Gram record failed");
         if ((rc = lili_s2m_gn_update(ctx, slot, d_gram)) != LILI_OK) return rc;
+    }
+    return LILI_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// the sliding window across ranks (BASELINE configs[4])
+// --------------------------------------------------------------------------------------------
+static int window_args(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, WindowArgs& w, const char* who) {
+    ARGCHK(slots && n_slots >= 1 && n_slots <= LILI_MAX_SLOTS, std::string(who) + ": 1..LILI_MAX_SLOTS slots");
+    ARGCHK((kind_mask & ~3) == 0 && kind_mask != 0, std::string(who) + ": bad kind mask");
+    w = WindowArgs{};
+    w.n = n_slots;
+    for (int i = 0; i < n_slots; i++) {
+        ARGCHK(slots[i] >= 0 && slots[i] < LILI_MAX_SLOTS, std::string(who) + ": bad slot");
+        for (int k = 0; k < i; k++) ARGCHK(slots[k] != slots[i], std::string(who) + ": duplicate slot");
+        Slot& sl = ctx->slots[slots[i]];
+        WindowSlot& ws = w.s[i];
+        ws.state = ctx->state(slots[i]);
+        for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) {
+            KindSlot& ks = sl.k[kind];
+            if (!ks.has_records) return ctx->fail(LILI_E_STATE, std::string(who) + ": associate first");
+            if (ks.n_q == 0) continue;
+            if (kind == 0) { ws.part_surf = ks.partials.as<double>(); ws.nb_surf = ks.n_lin_blocks; ws.bc_surf = ks.block_counts.as<int>(); ws.nbc_surf = ks.n_assoc_blocks; }
+            else { ws.part_edge = ks.partials.as<double>(); ws.nb_edge = ks.n_lin_blocks; ws.bc_edge = ks.block_counts.as<int>(); ws.nbc_edge = ks.n_assoc_blocks; }
+        }
+    }
+    return LILI_OK;
+}
+// k_linearize of one slot at `pa`, block partials left in the slot's buffers (no reduction): the first half of launch_linearize_reduce
+static int launch_linearize_only(lili_ctx* ctx, int slot, int kind_mask, const PoseArg& pa, const MatchParams& P) {
+    Slot& s = ctx->slots[slot];
+    LinArgs A[2] = {LinArgs{}, LinArgs{}};
+    int n_kinds = 0;
+    for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) {
+        KindSlot& ks = s.k[kind];
+        if (!ks.has_records) return ctx->fail(LILI_E_STATE, "linearize: associate first");
+        if (ks.n_q == 0) continue;
+        A[kind] = lin_args_of(ctx, slot, kind);
+        n_kinds++;
+    }
+    if (n_kinds == 0) return LILI_OK;
+    const int* ng = s.use_global_counts ? s.global_counts : nullptr;
+    hipLaunchKernelGGL(k_linearize, dim3(A[0].nb + A[1].nb), dim3(kLinBlock), lds_linearize(kLinBlock), ctx->stream, A[0], A[1], pa, P, ctx->state(slot), ng, FuseTail{});
+    HIPCHK(hipGetLastError());
+    return LILI_OK;
+}
+static bool p2p_comm(lili_ctx* ctx, lili_allreduce_fn allreduce, void* comm, lili_p2p** out) {
+    *out = (allreduce == &lili_p2p_allreduce && lili_p2p_usable(reinterpret_cast<lili_p2p*>(comm), ctx) && !ctx->no_p2p_fusion) ? reinterpret_cast<lili_p2p*>(comm) : nullptr;
+    return !(allreduce == &lili_p2p_allreduce && comm && lili_p2p_status(reinterpret_cast<lili_p2p*>(comm)) != 0);      // false: the communicator has failed
+}
+
+// The correspondence counts of every slot, summed over the ranks in ONE exchange of 2 n int32, into d_counts ([surf, edge] per slot, DEVICE,
+// caller-owned) — the ROT residual scale needs the GLOBAL counts, R/src/BackendFusion.cpp:843,861.  The following linearisations of these
+// slots (until their next association) scale with d_counts: keep it valid and unchanged.  Async.
+int lili_s2m_counts_window_sharded(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, lili_allreduce_fn allreduce, void* comm, int32_t* d_counts) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(d_counts, "counts_window_sharded: null d_counts");
+    HIPCHK(hipSetDevice(ctx->device));
+    WindowArgs w;
+    int rc = window_args(ctx, slots, n_slots, kind_mask, w, "counts_window_sharded");
+    if (rc != LILI_OK) return rc;
+    lili_p2p* p2p = nullptr;
+    if (!p2p_comm(ctx, allreduce, comm, &p2p)) return ctx->fail(LILI_E_STATE, "counts_window_sharded: the lili_p2p communicator has failed");
+    hipLaunchKernelGGL(k_window_counts, dim3(1), dim3(kBlock), 0, ctx->stream, w, d_counts, p2p ? lili_p2p_next_view(p2p) : P2PView{});
+    HIPCHK(hipGetLastError());
+    if (!p2p && allreduce && allreduce(d_counts, d_counts, (size_t)2 * n_slots, /*ncclInt32*/ 2, /*ncclSum*/ 0, comm, (void*)ctx->stream) != 0)
+        return ctx->fail(LILI_E_HIP, "counts_window_sharded: all-reduce of the correspondence counts failed");
+    for (int i = 0; i < n_slots; i++) { ctx->slots[slots[i]].global_counts = d_counts + 2 * i; ctx->slots[slots[i]].use_global_counts = true; ctx->slots[slots[i]].sticky_global_counts = true; }
+    return LILI_OK;
+}
+
+// ONE evaluation of the joint window on the device: every slot linearised at its device pose (this rank's shard of its records), the
+// n x LILI_GRAM_DOUBLES records reduced in one launch and summed over the ranks in ONE exchange into d_gram (DEVICE, caller-owned).  Async.
+static int linearize_window_impl(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, const lili_s2m_params* params, const double* t, const double* q,
+                                 lili_allreduce_fn allreduce, void* comm, double* d_gram, int do_gn) {
+    WindowArgs w;
+    int rc = window_args(ctx, slots, n_slots, kind_mask, w, "linearize_window_sharded");
+    if (rc != LILI_OK) return rc;
+    lili_p2p* p2p = nullptr;
+    if (!p2p_comm(ctx, allreduce, comm, &p2p)) return ctx->fail(LILI_E_STATE, "linearize_window_sharded: the lili_p2p communicator has failed");
+    MatchParams P = to_device_params(params);
+    if (do_gn) P.no_cost = 1;
+    for (int i = 0; i < n_slots; i++) {
+        PoseArg pa{};
+        if (t && q) { for (int k = 0; k < 3; k++) pa.t[k] = t[3 * i + k]; for (int k = 0; k < 4; k++) pa.q[k] = q[4 * i + k]; }
+        else pa.state = ctx->state(slots[i]);
+        if ((rc = launch_linearize_only(ctx, slots[i], kind_mask, pa, P)) != LILI_OK) return rc;
+    }
+    const bool in_kernel = p2p != nullptr || allreduce == nullptr;        // exchange (or none: one rank) and GN inside the reduction launch
+    hipLaunchKernelGGL(k_window_reduce, dim3(1), dim3(1024), 0, ctx->stream, w, d_gram, (do_gn && in_kernel) ? 1 : 0, p2p ? lili_p2p_next_view(p2p) : P2PView{});
+    HIPCHK(hipGetLastError());
+    if (!in_kernel) {
+        if (allreduce(d_gram, d_gram, (size_t)LILI_GRAM_DOUBLES * n_slots, /*ncclFloat64*/ 8, /*ncclSum*/ 0, comm, (void*)ctx->stream) != 0)
+            return ctx->fail(LILI_E_HIP, "linearize_window_sharded: all-reduce of the Gram records failed");
+        if (do_gn) { hipLaunchKernelGGL(k_window_gn, dim3(1), dim3(64), 0, ctx->stream, w, (const double*)d_gram); HIPCHK(hipGetLastError()); }
+    }
+    for (int i = 0; i < n_slots; i++) if (!ctx->slots[slots[i]].sticky_global_counts) ctx->slots[slots[i]].use_global_counts = false;
+    return LILI_OK;
+}
+int lili_s2m_linearize_window_dev(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, const lili_s2m_params* params,
+                                  lili_allreduce_fn allreduce, void* comm, double* d_gram) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(params && d_gram, "linearize_window_dev: null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    return linearize_window_impl(ctx, slots, n_slots, kind_mask, params, nullptr, nullptr, allreduce, comm, d_gram, 0);
+}
+// The same at host-provided poses, blocking, records copied out: what one evaluation of the caller's solver costs on the lidar side when the
+// window is sharded over ranks (every rank calls it with the same poses and gets the same bits).
+int lili_s2m_linearize_window_sharded(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, const double* t, const double* q, const lili_s2m_params* params,
+                                      lili_allreduce_fn allreduce, void* comm, double* d_gram, double* gram, double* cost, int* counts) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(t && q && params && d_gram && gram, "linearize_window_sharded: null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc = linearize_window_impl(ctx, slots, n_slots, kind_mask, params, t, q, allreduce, comm, d_gram, 0);
+    if (rc != LILI_OK) return rc;
+    if (!ctx->h_records) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_records), (size_t)LILI_MAX_SLOTS * LILI_GRAM_DOUBLES * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipMemcpyAsync(ctx->h_records, d_gram, (size_t)n_slots * LILI_GRAM_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n_slots; i++) {
+        const double* h = ctx->h_records + (size_t)i * LILI_GRAM_DOUBLES;
+        std::memcpy(gram + (size_t)64 * i, h, 64 * sizeof(double));
+        if (cost) cost[i] = h[64];
+        if (counts) { counts[2 * i] = (int)h[65]; counts[2 * i + 1] = (int)h[66]; }
+    }
+    return LILI_OK;
+}
+// n_iters outer iterations of every slot of the window, queries sharded over the ranks: per iteration the slots' associations, ONE exchange
+// of the 2 n counts (count-scaled flavours only), the slots' linearisations, ONE reduction launch ending with ONE exchange of the n x 72
+// doubles and the Gauss-Newton update of every slot — 2 exchanges per iteration whatever the number of keyframes.  (The reference couples
+// the keyframes through IMU factors in its own solver; this loop is the lidar-only registration of each keyframe, as lili_s2m_iterate_window.)
+int lili_s2m_iterate_window_sharded(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, const lili_s2m_params* params, int n_iters,
+                                    lili_allreduce_fn allreduce, void* comm, int32_t* d_counts, double* d_gram) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(n_iters >= 0 && params && d_counts && d_gram, "iterate_window_sharded: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    const bool count_scaled = params->scale_surf_num > 0 || params->scale_edge_num > 0;
+    for (int it = 0; it < n_iters; it++) {
+        int rc;
+        for (int i = 0; i < n_slots; i++) {
+            ARGCHK(slots && slots[i] >= 0 && slots[i] < LILI_MAX_SLOTS, "iterate_window_sharded: bad slot");
+            ctx->slots[slots[i]].sticky_global_counts = false;
+            if ((rc = lili_s2m_associate_dev(ctx, slots[i], kind_mask, params)) != LILI_OK) return rc;
+        }
+        if (count_scaled && (rc = lili_s2m_counts_window_sharded(ctx, slots, n_slots, kind_mask, allreduce, comm, d_counts)) != LILI_OK) return rc;
+        if ((rc = linearize_window_impl(ctx, slots, n_slots, kind_mask, params, nullptr, nullptr, allreduce, comm, d_gram, 1)) != LILI_OK) return rc;
     }
     return LILI_OK;
 }

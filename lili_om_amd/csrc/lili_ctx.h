@@ -78,6 +78,7 @@ struct Slot {
     KindSlot k[2];
     bool use_global_counts = false;   // next linearize_dev scales with the caller's (all-reduced) counts instead of its own
     const int32_t* global_counts = nullptr;
+    bool sticky_global_counts = false;   // lili_s2m_counts_window_sharded: the global counts stay in force until the slot's next association
     DevBuf lm_part, lm_gsum, lm_summary;      // lili_s2m_solve_lm: granule-tagged block partials / group sums (two parities each), device copy of the summary
     int assoc_since_pose = 0;         // association launches since the slot's pose was (re)set: the first one is the far-from-converged launch (coop_lanes)
 };

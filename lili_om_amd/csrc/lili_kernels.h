@@ -86,6 +86,17 @@ struct AssocArgs {
     int nb;
 };
 
+// The slots of a sliding window handed to ONE reduction / count launch (k_window_reduce, k_window_counts in lili_s2m.hip)
+constexpr int kWindowMaxSlots = 8;       // = LILI_MAX_SLOTS
+struct WindowSlot {
+    const double* part_surf; int nb_surf;      // block partials of the slot's last linearisation (k_linearize)
+    const double* part_edge; int nb_edge;
+    const int* bc_surf; int nbc_surf;          // per-block correspondence counts of the slot's last association
+    const int* bc_edge; int nbc_edge;
+    SlotState* state;
+};
+struct WindowArgs { WindowSlot s[kWindowMaxSlots]; int n; };
+
 constexpr int kPartialDoubles = 40;  // per-block partial: 36 upper-triangle Gram entries, cost, count, 2 spare
 constexpr int kPartialStride = 80;   // doubles per block slot of the partial buffers: 40 plain doubles, or 40 16-byte granules {value, value ^ key}
 constexpr int kBlock = 256;

@@ -24,23 +24,26 @@
 
 namespace {
 
-// generic form: sendbuff / recvbuff hold `count` elements of 4 (int32) or 8 (f64) bytes; one wave
+// generic form: sendbuff / recvbuff hold `count` elements of 4 (int32) or 8 (f64) bytes; one wave, W words per lane
+template <int W>
 __global__ __launch_bounds__(64) void k_p2p_allreduce(const void* __restrict__ send, void* __restrict__ recv, int count, int elem8, P2PView v) {
     const int t = threadIdx.x;
     const unsigned long long was_dead = p2p_dead_word(v);
-    unsigned long long w0 = 0, w1 = 0, s0, s1;
+    unsigned long long w[W], s[W];
+#pragma unroll
+    for (int i = 0; i < W; i++) { w[i] = 0ull; s[i] = 0ull; }
     if (elem8) {
-        if (t < count) w0 = reinterpret_cast<const unsigned long long*>(send)[t];
-        if (t + 64 < count) w1 = reinterpret_cast<const unsigned long long*>(send)[t + 64];
-        if (!p2p_exchange_wave<true>(v, count, w0, w1, s0, s1, was_dead)) return;
-        if (t < count) reinterpret_cast<unsigned long long*>(recv)[t] = s0;
-        if (t + 64 < count) reinterpret_cast<unsigned long long*>(recv)[t + 64] = s1;
+#pragma unroll
+        for (int i = 0; i < W; i++) if (t + 64 * i < count) w[i] = reinterpret_cast<const unsigned long long*>(send)[t + 64 * i];
+        if (!p2p_exchange_words<true, W>(v, count, w, s, was_dead)) return;
+#pragma unroll
+        for (int i = 0; i < W; i++) if (t + 64 * i < count) reinterpret_cast<unsigned long long*>(recv)[t + 64 * i] = s[i];
     } else {
-        if (t < count) w0 = (unsigned long long)(unsigned)reinterpret_cast<const int*>(send)[t];
-        if (t + 64 < count) w1 = (unsigned long long)(unsigned)reinterpret_cast<const int*>(send)[t + 64];
-        if (!p2p_exchange_wave<false>(v, count, w0, w1, s0, s1, was_dead)) return;
-        if (t < count) reinterpret_cast<int*>(recv)[t] = (int)(unsigned)s0;
-        if (t + 64 < count) reinterpret_cast<int*>(recv)[t + 64] = (int)(unsigned)s1;
+#pragma unroll
+        for (int i = 0; i < W; i++) if (t + 64 * i < count) w[i] = (unsigned long long)(unsigned)reinterpret_cast<const int*>(send)[t + 64 * i];
+        if (!p2p_exchange_words<false, W>(v, count, w, s, was_dead)) return;
+#pragma unroll
+        for (int i = 0; i < W; i++) if (t + 64 * i < count) reinterpret_cast<int*>(recv)[t + 64 * i] = (int)(unsigned)s[i];
     }
 }
 
@@ -123,7 +126,8 @@ int lili_p2p_allreduce(const void* sendbuff, void* recvbuff, size_t count, int d
     if (hipSetDevice(c->ctx->device) != hipSuccess) return 1;
     P2PView v = c->view;
     v.seq = ++c->seq;
-    hipLaunchKernelGGL(k_p2p_allreduce, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), sendbuff, recvbuff, (int)count, datatype == 8 ? 1 : 0, v);
+    if (count <= 128) hipLaunchKernelGGL(k_p2p_allreduce<2>, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), sendbuff, recvbuff, (int)count, datatype == 8 ? 1 : 0, v);
+    else hipLaunchKernelGGL(k_p2p_allreduce<kP2PMaxPerLane>, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), sendbuff, recvbuff, (int)count, datatype == 8 ? 1 : 0, v);
     return hipGetLastError() == hipSuccess ? 0 : 1;
 }
 

@@ -1,16 +1,18 @@
 // Device side of the peer-to-peer exchange (lili_p2p.hip has the description and the host side).  ONE wave runs an exchange:
-// lane l carries the 8-byte words l and l + 64 of the record (count <= 96), so the collective can sit inside another kernel's
-// single-wave tail (the count kernel, the partial reduction + Gauss-Newton update) without block barriers.
+// lane l carries the 8-byte words l, l + 64, l + 128, ... of the record (W words per lane, count <= 64 W <= 640: the Gram records of a
+// whole sliding window, 8 slots x 72 doubles, go out as ONE exchange), so the collective can sit inside another kernel's single-wave
+// tail (the count kernel, the partial reduction + Gauss-Newton update) without block barriers.
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace lili {
 
 constexpr int kP2PMaxWorld = 16;
-constexpr int kP2PSlotBytes = 1024;                 // 96 payload words + flag word, padded
+constexpr int kP2PSlotBytes = 8192;                 // 640 payload words + flag word, padded
 constexpr int kP2PSlotWords = kP2PSlotBytes / 8;
-constexpr int kP2PFlagWord = 120;
-constexpr int kP2PMaxCount = 96;                    // 8-byte words per record (the Gram record has 72)
+constexpr int kP2PFlagWord = 1000;
+constexpr int kP2PMaxCount = 640;                   // 8-byte words per record (one Gram record has 72, a window of 8 slots 576)
+constexpr int kP2PMaxPerLane = kP2PMaxCount / 64;
 constexpr int kP2PDeadWord = 2 * kP2PMaxWorld * kP2PSlotWords;   // behind the slots of a mailbox: set once a wait of its owner has given up
 
 struct P2PView {
@@ -28,14 +30,14 @@ __device__ __forceinline__ unsigned long long p2p_dead_word(const P2PView& v) {
     return v.seq ? __hip_atomic_load(v.box[v.rank] + kP2PDeadWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
 }
 
-// All 64 lanes of ONE wave.  w0 / w1: this rank's words `lane` and `lane + 64` (ignored beyond count).  On return s0 / s1 hold the
-// sums over the ranks, added in rank order, as f64 (F64) or int32 in the low half of the word.  Returns false if a peer's record
-// did not arrive within the communicator's timeout (status word set), or if the communicator had failed before (`was_dead`, the value
-// of p2p_dead_word): then nothing is published.  A rank that gives up also raises the failure word in EVERY peer's mailbox, so that
-// the peers — which may be waiting for this rank's next record — fail at their next look instead of after their own timeout.
-template <bool F64>
-__device__ __forceinline__ bool p2p_exchange_wave(const P2PView& v, int count, unsigned long long w0, unsigned long long w1,
-                                                  unsigned long long& s0, unsigned long long& s1, unsigned long long was_dead) {
+// All 64 lanes of ONE wave.  w[i]: this rank's word `lane + 64 i` (ignored beyond count).  On return s[i] holds the sums over the ranks,
+// added in rank order, as f64 (F64) or int32 in the low half of the word.  Returns false if a peer's record did not arrive within the
+// communicator's timeout (status word set), or if the communicator had failed before (`was_dead`, the value of p2p_dead_word): then
+// nothing is published.  A rank that gives up also raises the failure word in EVERY peer's mailbox, so that the peers — which may be
+// waiting for this rank's next record — fail at their next look instead of after their own timeout.
+template <bool F64, int W>
+__device__ __forceinline__ bool p2p_exchange_words(const P2PView& v, int count, const unsigned long long (&w)[W], unsigned long long (&s)[W], unsigned long long was_dead) {
+    static_assert(W >= 1 && W <= kP2PMaxPerLane, "words per lane");
     const int lane = threadIdx.x & 63;
     const int par = (int)(v.seq & 1ull);
     const int world = v.world;
@@ -43,8 +45,8 @@ __device__ __forceinline__ bool p2p_exchange_wave(const P2PView& v, int count, u
     // 1. my record into slot[rank] of every mailbox (own included): write-through system-scope stores
     for (int p = 0; p < world; p++) {
         unsigned long long* slot = v.box[p] + (size_t)(par * kP2PMaxWorld + v.rank) * kP2PSlotWords;
-        if (lane < count) __hip_atomic_store(slot + lane, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        if (lane + 64 < count) __hip_atomic_store(slot + lane + 64, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+        for (int i = 0; i < W; i++) if (lane + 64 * i < count) __hip_atomic_store(slot + lane + 64 * i, w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     // 2. once the wave's store counter has drained the payload is in the peers' memory; then the flags
     //    (MI355X_MICROARCH.md, inter-workgroup visibility: "sc1 payload -> asm vmcnt(0) -> sc1 flag", here at system scope)
@@ -76,21 +78,39 @@ __device__ __forceinline__ bool p2p_exchange_wave(const P2PView& v, int count, u
     // 4. sums in rank order; the payload is read with system-scope loads too (they bypass L1 / L2: nothing stale to invalidate)
     const unsigned long long* base = v.box[v.rank] + (size_t)(par * kP2PMaxWorld) * kP2PSlotWords;
     if (F64) {
-        double a = 0.0, b = 0.0;
+        double a[W];
+#pragma unroll
+        for (int i = 0; i < W; i++) a[i] = 0.0;
         for (int r = 0; r < world; r++) {
-            if (lane < count) a += __longlong_as_double((long long)__hip_atomic_load(base + (size_t)r * kP2PSlotWords + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-            if (lane + 64 < count) b += __longlong_as_double((long long)__hip_atomic_load(base + (size_t)r * kP2PSlotWords + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+#pragma unroll
+            for (int i = 0; i < W; i++)
+                if (lane + 64 * i < count) a[i] += __longlong_as_double((long long)__hip_atomic_load(base + (size_t)r * kP2PSlotWords + lane + 64 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
         }
-        s0 = (unsigned long long)__double_as_longlong(a); s1 = (unsigned long long)__double_as_longlong(b);
+#pragma unroll
+        for (int i = 0; i < W; i++) s[i] = (unsigned long long)__double_as_longlong(a[i]);
     } else {
-        int a = 0, b = 0;
+        int a[W];
+#pragma unroll
+        for (int i = 0; i < W; i++) a[i] = 0;
         for (int r = 0; r < world; r++) {
-            if (lane < count) a += (int)(unsigned)__hip_atomic_load(base + (size_t)r * kP2PSlotWords + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (lane + 64 < count) b += (int)(unsigned)__hip_atomic_load(base + (size_t)r * kP2PSlotWords + lane + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+            for (int i = 0; i < W; i++)
+                if (lane + 64 * i < count) a[i] += (int)(unsigned)__hip_atomic_load(base + (size_t)r * kP2PSlotWords + lane + 64 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        s0 = (unsigned long long)(unsigned)a; s1 = (unsigned long long)(unsigned)b;
+#pragma unroll
+        for (int i = 0; i < W; i++) s[i] = (unsigned long long)(unsigned)a[i];
     }
     return true;
+}
+// two words per lane (one Gram record, the two counters)
+template <bool F64>
+__device__ __forceinline__ bool p2p_exchange_wave(const P2PView& v, int count, unsigned long long w0, unsigned long long w1,
+                                                  unsigned long long& s0, unsigned long long& s1, unsigned long long was_dead) {
+    const unsigned long long w[2] = {w0, w1};
+    unsigned long long s[2] = {0ull, 0ull};
+    const bool ok = p2p_exchange_words<F64, 2>(v, count, w, s, was_dead);
+    s0 = s[0]; s1 = s[1];
+    return ok;
 }
 
 }  // namespace lili

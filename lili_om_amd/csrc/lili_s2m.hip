@@ -1163,6 +1163,97 @@ __global__ __launch_bounds__(kReduceThreads) void k_reduce_partials(const double
     reduce_partials_block<true>(part_surf, nb_surf, part_edge, nb_edge, out, state, do_gn, 0ull, v);
 }
 
+// ================================================================================================
+// Sliding window across ranks (BASELINE configs[4]; the reference evaluates the lidar blocks of ALL keyframes of the window per solver
+// evaluation, L/src/BackendFusion.cpp:919-992): ONE launch reduces the block partials of every slot, and — with a lili_p2p view — ends
+// with ONE exchange of the n x 72 doubles (rank-order sums: identical bits on every rank), optionally followed by the Gauss-Newton update
+// of every slot.  The per-slot record is built with the additions of reduce_partials_block in the same order, so it equals what
+// lili_s2m_linearize returns for that slot bit for bit.
+// ================================================================================================
+__device__ __forceinline__ void reduce_partials_plain(const double* part_surf, int nb_surf, const double* part_edge, int nb_edge, double* __restrict__ rec /*LDS, 72*/) {
+    constexpr int kGroups = kReduceThreads / 40;
+    __shared__ double acc[kGroups][2][40];
+    __shared__ double tri[40];
+    const int e = threadIdx.x % 40, g = threadIdx.x / 40;
+    double s = 0.0, s2 = 0.0;
+    if (nb_surf > 8 * kGroups) { for (int c = 0; c * 32 * kGroups < nb_surf; c++) sum_partial_wide(part_surf, nb_surf, c, g, e, kGroups, s); }
+    else for (int c = 0; c * 8 * kGroups < nb_surf; c++) sum_partial_chunk(part_surf, nb_surf, c, g, e, kGroups, 0ull, s);
+    if (nb_edge > 8 * kGroups) { for (int c = 0; c * 32 * kGroups < nb_edge; c++) sum_partial_wide(part_edge, nb_edge, c, g, e, kGroups, s2); }
+    else for (int c = 0; c * 8 * kGroups < nb_edge; c++) sum_partial_chunk(part_edge, nb_edge, c, g, e, kGroups, 0ull, s2);
+    if (g < kGroups) { acc[g][0][e] = s; acc[g][1][e] = s2; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        if (lane < 40) {
+            double ss = 0.0, se = 0.0;
+            for (int gg = 0; gg < kGroups; gg++) ss += acc[gg][0][lane];
+            if (nb_edge > 0) for (int gg = 0; gg < kGroups; gg++) se += acc[gg][1][lane];
+            tri[lane] = ss + se;
+            if (lane == 37) { rec[65] = ss; rec[66] = se; }
+        }
+        LILI_WAVE_SYNC();
+        const int r = lane >> 3, c = lane & 7;
+        const int a = r < c ? r : c, b = r < c ? c : r;
+        rec[lane] = tri[a * 8 - a * (a - 1) / 2 + (b - a)];
+        if (lane == 0) rec[64] = tri[36];
+        if (lane >= 3 && lane < 8) rec[64 + lane] = 0.0;     // 67..71
+    }
+    __syncthreads();      // acc / tri are free for the next slot; rec is visible to the block
+}
+__global__ __launch_bounds__(kReduceThreads) void k_window_reduce(WindowArgs w, double* __restrict__ out /*n x 72*/, int do_gn, P2PView v) {
+    __shared__ double rec[kWindowMaxSlots * 72];
+    __shared__ double xq[kWindowMaxSlots][4];
+    const unsigned long long was_dead = p2p_dead_word(v);      // requested first: the round trip hides behind the partial loads
+    for (int i = 0; i < w.n; i++) if (threadIdx.x < 4) xq[i][threadIdx.x] = w.s[i].state->pose[3 + threadIdx.x];
+    for (int i = 0; i < w.n; i++) reduce_partials_plain(w.s[i].part_surf, w.s[i].nb_surf, w.s[i].part_edge, w.s[i].nb_edge, rec + 72 * i);
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x, count = 72 * w.n;
+    if (v.seq) {
+        unsigned long long ww[kWindowMaxSlots * 72 / 64], ss[kWindowMaxSlots * 72 / 64];
+#pragma unroll
+        for (int i = 0; i < kWindowMaxSlots * 72 / 64; i++) { ww[i] = lane + 64 * i < count ? (unsigned long long)__double_as_longlong(rec[lane + 64 * i]) : 0ull; ss[i] = 0ull; }
+        if (!p2p_exchange_words<true, kWindowMaxSlots * 72 / 64>(v, count, ww, ss, was_dead)) { if (lane == 0) for (int i = 0; i < w.n; i++) w.s[i].state->gn_status = 2; return; }
+#pragma unroll
+        for (int i = 0; i < kWindowMaxSlots * 72 / 64; i++) if (lane + 64 * i < count) rec[lane + 64 * i] = __longlong_as_double((long long)ss[i]);
+        LILI_WAVE_SYNC();
+    }
+    for (int i = lane; i < count; i += 64) out[i] = rec[i];
+    if (do_gn) for (int i = 0; i < w.n; i++) { gn_update_block(rec + 72 * i, w.s[i].state, xq[i]); LILI_WAVE_SYNC(); }
+}
+// the Gauss-Newton update of every slot from its (all-reduced) record: the generic-collective form of k_window_reduce's tail
+__global__ __launch_bounds__(64) void k_window_gn(WindowArgs w, const double* __restrict__ gram /*n x 72*/) {
+    for (int i = 0; i < w.n; i++) {
+        const double xq[4] = {w.s[i].state->pose[3], w.s[i].state->pose[4], w.s[i].state->pose[5], w.s[i].state->pose[6]};
+        gn_update_block(gram + 72 * i, w.s[i].state, xq);
+        LILI_WAVE_SYNC();
+    }
+}
+// correspondence counts of every slot ([surf, edge] per slot) in one launch; with a lili_p2p view the 2 n totals are all-reduced inside:
+// `out` and the slots' states then hold the GLOBAL counts (ROT: residual scale = num / global N, R/src/BackendFusion.cpp:843,861)
+__global__ __launch_bounds__(kBlock) void k_window_counts(WindowArgs w, int* __restrict__ out /*2 n*/, P2PView v) {
+    __shared__ int tot[2 * kWindowMaxSlots];
+    const unsigned long long was_dead = p2p_dead_word(v);
+    for (int i = 0; i < w.n; i++) {
+        const int t0 = w.s[i].bc_surf ? sum_block_counts(w.s[i].bc_surf, w.s[i].nbc_surf) : 0;
+        __syncthreads();
+        const int t1 = w.s[i].bc_edge ? sum_block_counts(w.s[i].bc_edge, w.s[i].nbc_edge) : 0;
+        __syncthreads();
+        if (threadIdx.x == 0) { tot[2 * i] = t0; tot[2 * i + 1] = t1; }
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x, count = 2 * w.n;
+    int val = lane < count ? tot[lane] : 0;
+    if (v.seq) {
+        const unsigned long long ww[1] = {(unsigned long long)(unsigned)val};
+        unsigned long long ss[1] = {0ull};
+        if (!p2p_exchange_words<false, 1>(v, count, ww, ss, was_dead)) { if (lane == 0) for (int i = 0; i < w.n; i++) w.s[i].state->gn_status = 2; return; }
+        val = (int)(unsigned)ss[0];
+    }
+    if (lane < count) out[lane] = val;
+    for (int i = 0; i < w.n; i++) if ((lane >> 1) == i && lane < count) w.s[i].state->n_res[lane & 1] = val;      // (uniform index into the argument struct)
+}
+
 // Restart of a registration: 56 bytes device to device.  hipMemcpyAsync(D2D) costs a 4.5 us copy kernel for this; one 8-lane
 // workgroup of our own is done in well under half of that.
 __global__ void k_pose_copy(SlotState* __restrict__ dst, const SlotState* __restrict__ src) {

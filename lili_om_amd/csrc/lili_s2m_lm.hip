@@ -23,14 +23,14 @@
 //                Ceres' DENSE_QR works on the stacked rows — the same minimiser up to rounding, which tests/test_lm_gpu.py bounds by
 //                comparing every accept / reject decision and the final pose with the CPU restatement's loop on per-residual rows.
 //
-// All workgroups must be co-resident (<= one per CU: 1024 threads, 96 KB LDS); every wait is bounded and ends the launch with
+// All workgroups must be co-resident (<= one per CU: 512 threads at up to 256 VGPRs, 48 KB LDS); every wait is bounded and ends the launch with
 // termination = LILI_LM_STALLED instead of hanging the GPU.
 #include "lili_s2m_dev.h"
 #include "../../include/lili_hip.h"
 
 namespace lili {
 
-constexpr int kLmThreads = 1024;
+constexpr int kLmThreads = 512;      // 8 waves: the launch may use 256 VGPRs per lane (1024-thread workgroups cap it at 128 and the loop spilled ~150 words)
 constexpr int kLmGroup = 16;
 
 struct LmArgs {
@@ -84,6 +84,7 @@ struct LmShared {
     double cur[40];            // the same at the accepted point x
     double full[64];           // symmetric 8x8 Gram of `cur`
     double H[6][6], gv[6];     // local-coordinate normal matrix P^T G P and gradient P^T G_7r at x
+    double Hs[6][6], gs[6];    // the same in Jacobi-scaled coordinates (S H S, S g): what the trust-region step works on
     double x[7], xn[7];        // accepted point, candidate
     double scale[6];
     double cost, radius, decrease, model_change, step_norm;
@@ -91,6 +92,10 @@ struct LmShared {
     int counts[2];
     int stalled;               // a bounded wait gave up
     int take;                  // the candidate was accepted: `tot` becomes `cur`
+    int max_iter;
+    // the solver options, parked here so that they are not live in registers across the whole launch
+    double function_tolerance, gradient_tolerance, parameter_tolerance;
+    double max_radius, min_radius, min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
 };
 
 // H = P^T G77 P, gv = P^T G7r at the quaternion xq (lanes 0..41 of ONE wave; gn_update_block of lili_s2m.hip builds the same)
@@ -126,52 +131,52 @@ __device__ __forceinline__ void lm_tri_to_full(const double* tri, double* full) 
     full[lane] = tri[a * 8 - a * (a - 1) / 2 + (b - a)];
 }
 
+// Jacobi-scaled system of the accepted point (lanes 0..41 of one wave, after lm_local_system and with sh.scale set)
+__device__ __forceinline__ void lm_scaled_system(LmShared& sh) {
+    const int tid = threadIdx.x & 63;
+    if (tid < 36) sh.Hs[tid / 6][tid % 6] = sh.H[tid / 6][tid % 6] * sh.scale[tid / 6] * sh.scale[tid % 6];
+    else if (tid < 42) sh.gs[tid - 36] = sh.gv[tid - 36] * sh.scale[tid - 36];
+}
 // The trust-region step from the accepted point (ONE lane).  Returns with sh.go = 1 and sh.xn = candidate, or sh.go = 0 (finished).
-__device__ __forceinline__ void lm_propose(LmShared& sh, const LmArgs& a) {
+// The 6x6 system lives in LDS (sh.Hs, sh.gs: they change only when a step is accepted) and only the factor being built is held in
+// registers — with everything in registers the launch (capped at 128 VGPRs by its 1024-thread workgroups) spilled 150 words to scratch
+// on the critical path of every evaluation.
+__device__ __forceinline__ void lm_propose(LmShared& sh) {
+    const LmShared& a = sh;
     for (;;) {
         if (sh.it >= a.max_iter) { sh.term = LILI_LM_MAX_ITERATIONS; sh.go = 0; return; }
         double gmax = 0.0;
 #pragma unroll
         for (int i = 0; i < 6; i++) gmax = fmax(gmax, fabs(sh.gv[i]));
         if (gmax <= a.gradient_tolerance) { sh.term = LILI_LM_GRADIENT_TOLERANCE; sh.it++; sh.go = 0; return; }      // (Ceres counts the iteration it stops in)
-        double Hs[6][6], gs[6], A[6][6], W[6][6], dinv[6], d[6];
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            gs[i] = sh.gv[i] * sh.scale[i];
-#pragma unroll
-            for (int j = 0; j <= i; j++) Hs[i][j] = sh.H[i][j] * sh.scale[i] * sh.scale[j];
-        }
-        // (Hs + D^2) d = -gs with D^2 = clamp(diag Hs, min_lm_diagonal, max_lm_diagonal) / radius: LDL^T with reciprocal pivots
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-#pragma unroll
-            for (int j = 0; j <= i; j++) A[i][j] = Hs[i][j];
-            A[i][i] = Hs[i][i] + fmin(fmax(Hs[i][i], a.min_lm_diagonal), a.max_lm_diagonal) / sh.radius;
-            d[i] = -gs[i];
-        }
+        // (Hs + D^2) d = -gs with D^2 = clamp(diag Hs, min_lm_diagonal, max_lm_diagonal) / radius: LDL^T with reciprocal pivots,
+        // L (unit lower triangle) in registers, column by column
+        double Lm[6][6], dv[6], dinv[6], d[6];
         bool okc = true;
+        const double rinv = 1.0 / sh.radius;
 #pragma unroll
         for (int j = 0; j < 6; j++) {
-            double dj = A[j][j];
+            const double hjj = sh.Hs[j][j];
+            double dj = hjj + fmin(fmax(hjj, a.min_lm_diagonal), a.max_lm_diagonal) * rinv;
 #pragma unroll
-            for (int k = 0; k < j; k++) dj -= A[j][k] * W[j][k];
+            for (int k = 0; k < j; k++) dj -= Lm[j][k] * Lm[j][k] * dv[k];
             if (!(dj > 0)) okc = false;
+            dv[j] = dj;
             dinv[j] = 1.0 / dj;
 #pragma unroll
             for (int i = j + 1; i < 6; i++) {
-                double sv = A[i][j];
+                double sv = sh.Hs[i][j];
 #pragma unroll
-                for (int k = 0; k < j; k++) sv -= A[i][k] * W[j][k];
-                W[i][j] = sv;
-                A[i][j] = sv * dinv[j];
+                for (int k = 0; k < j; k++) sv -= Lm[i][k] * Lm[j][k] * dv[k];
+                Lm[i][j] = sv * dinv[j];
             }
         }
 #pragma unroll
-        for (int i = 0; i < 6; i++) { double sv = d[i]; for (int k = 0; k < i; k++) sv -= A[i][k] * d[k]; d[i] = sv; }
+        for (int i = 0; i < 6; i++) { double sv = -sh.gs[i]; for (int k = 0; k < i; k++) sv -= Lm[i][k] * d[k]; d[i] = sv; }
 #pragma unroll
         for (int i = 0; i < 6; i++) d[i] = d[i] * dinv[i];
 #pragma unroll
-        for (int i = 5; i >= 0; i--) { double sv = d[i]; for (int k = i + 1; k < 6; k++) sv -= A[k][i] * d[k]; d[i] = sv; }
+        for (int i = 5; i >= 0; i--) { double sv = d[i]; for (int k = i + 1; k < 6; k++) sv -= Lm[k][i] * d[k]; d[i] = sv; }
 #pragma unroll
         for (int i = 0; i < 6; i++) if (!(d[i] == d[i])) okc = false;
         if (!okc) { sh.term = LILI_LM_NUMERICAL_FAILURE; sh.go = 0; return; }
@@ -181,28 +186,38 @@ __device__ __forceinline__ void lm_propose(LmShared& sh, const LmArgs& a) {
         for (int i = 0; i < 6; i++) {
             double hd = 0.0;
 #pragma unroll
-            for (int j = 0; j < 6; j++) hd += (j <= i ? Hs[i][j] : Hs[j][i]) * d[j];
-            mc += d[i] * (gs[i] + 0.5 * hd);
+            for (int j = 0; j < 6; j++) hd += sh.Hs[i][j] * d[j];
+            mc += d[i] * (sh.gs[i] + 0.5 * hd);
         }
         mc = -mc;
         if (!(mc > 0.0)) {       // not a descent step of the model: shrink, no evaluation (the iteration counts)
-            sh.radius = fmax(a.min_radius, sh.radius / sh.decrease); sh.decrease *= 2.0;
+            sh.radius = fmax(sh.min_radius, sh.radius / sh.decrease); sh.decrease *= 2.0;
             sh.it++;
             continue;
         }
-        double delta[6], n2 = 0.0;
+        double n2 = 0.0;
 #pragma unroll
-        for (int i = 0; i < 6; i++) { delta[i] = d[i] * sh.scale[i]; n2 += delta[i] * delta[i]; }
+        for (int i = 0; i < 6; i++) { d[i] = d[i] * sh.scale[i]; n2 += d[i] * d[i]; }      // delta in the unscaled local coordinates
         sh.model_change = mc;
         sh.step_norm = sqrt(n2);
         // x (+) delta: ceres::QuaternionParameterization::Plus
-        sh.xn[0] = sh.x[0] + delta[0]; sh.xn[1] = sh.x[1] + delta[1]; sh.xn[2] = sh.x[2] + delta[2];
-        const double nd2 = delta[3] * delta[3] + delta[4] * delta[4] + delta[5] * delta[5];
+        sh.xn[0] = sh.x[0] + d[0]; sh.xn[1] = sh.x[1] + d[1]; sh.xn[2] = sh.x[2] + d[2];
+        const double nd2 = d[3] * d[3] + d[4] * d[4] + d[5] * d[5];
         if (nd2 > 0.0) {
+            // sin(|d|) / |d| and cos(|d|): the series of sinc_cos_small below 0.5 rad, above it halve the angle first and double it back
+            // (libm's sin / cos bring a Payne-Hanek reduction with a scratch table into the launch; a trust-region step never turns that far anyway)
             double sbd, cw;
             if (nd2 < 0.25) sinc_cos_small(nd2, sbd, cw);
-            else { const double nd = sqrt(nd2); sbd = sin(nd) / nd; cw = cos(nd); }
-            const dq r = qmul(dq{cw, sbd * delta[3], sbd * delta[4], sbd * delta[5]}, dq{sh.x[3], sh.x[4], sh.x[5], sh.x[6]});
+            else {
+                double h2 = nd2; int k = 0;
+                while (h2 >= 0.25 && k < 60) { h2 *= 0.25; k++; }
+                double sc, c;
+                sinc_cos_small(h2, sc, c);
+                double sn = sc * sqrt(h2);
+                for (int i = 0; i < k; i++) { const double s2 = 2.0 * sn * c, c2 = c * c - sn * sn; sn = s2; c = c2; }
+                sbd = sn / sqrt(nd2); cw = c;
+            }
+            const dq r = qmul(dq{cw, sbd * d[3], sbd * d[4], sbd * d[5]}, dq{sh.x[3], sh.x[4], sh.x[5], sh.x[6]});
             sh.xn[3] = r.w; sh.xn[4] = r.x; sh.xn[5] = r.y; sh.xn[6] = r.z;
         } else { sh.xn[3] = sh.x[3]; sh.xn[4] = sh.x[4]; sh.xn[5] = sh.x[5]; sh.xn[6] = sh.x[6]; }
         sh.go = 1;
@@ -226,6 +241,10 @@ __global__ __launch_bounds__(kLmThreads) void k_solve_lm(LmArgs a, MatchParams P
         if (threadIdx.x == 0) {
             sh.counts[0] = n_s; sh.counts[1] = n_e;
             for (int i = 0; i < 7; i++) { sh.x[i] = a.state->pose[i]; sh.xn[i] = sh.x[i]; }
+            sh.max_iter = a.max_iter;
+            sh.function_tolerance = a.function_tolerance; sh.gradient_tolerance = a.gradient_tolerance; sh.parameter_tolerance = a.parameter_tolerance;
+            sh.max_radius = a.max_radius; sh.min_radius = a.min_radius; sh.min_relative_decrease = a.min_relative_decrease;
+            sh.min_lm_diagonal = a.min_lm_diagonal; sh.max_lm_diagonal = a.max_lm_diagonal;
             sh.radius = a.initial_radius; sh.decrease = 2.0; sh.it = 0; sh.n_ok = 0; sh.term = LILI_LM_MAX_ITERATIONS; sh.go = 1; sh.stalled = 0; sh.take = 0;
             sh.cost = 0.0; sh.model_change = 0.0; sh.step_norm = 0.0;
         }
@@ -272,7 +291,9 @@ __global__ __launch_bounds__(kLmThreads) void k_solve_lm(LmArgs a, MatchParams P
                 if (threadIdx.x < 6) sh.scale[threadIdx.x] = 1.0 / (1.0 + sqrt(sh.H[threadIdx.x][threadIdx.x]));
                 if (threadIdx.x == 0) { sh.cost = sh.cur[36]; cost0 = sh.cost; }
                 LILI_WAVE_SYNC();
-                if (threadIdx.x == 0) { if (sh.stalled) { sh.term = LILI_LM_STALLED; sh.go = 0; } else lm_propose(sh, a); }
+                lm_scaled_system(sh);
+                LILI_WAVE_SYNC();
+                if (threadIdx.x == 0 && sh.stalled) { sh.term = LILI_LM_STALLED; sh.go = 0; }
             } else {
                 // the candidate's cost is known: accept or reject (Ceres checks both tolerances on the candidate first)
                 int accepted = 0, stop = 0;
@@ -285,14 +306,14 @@ __global__ __launch_bounds__(kLmThreads) void k_solve_lm(LmArgs a, MatchParams P
                     }
                     const double xnorm = sqrt(sh.x[0] * sh.x[0] + sh.x[1] * sh.x[1] + sh.x[2] * sh.x[2] + sh.x[3] * sh.x[3] + sh.x[4] * sh.x[4] + sh.x[5] * sh.x[5] + sh.x[6] * sh.x[6]);
                     if (sh.stalled) { sh.term = LILI_LM_STALLED; stop = 1; }
-                    else if (sh.step_norm <= a.parameter_tolerance * (xnorm + a.parameter_tolerance)) { sh.term = LILI_LM_PARAMETER_TOLERANCE; stop = 1; }
-                    else if (fabs(sh.cost - new_cost) <= a.function_tolerance * sh.cost) { sh.term = LILI_LM_FUNCTION_TOLERANCE; stop = 1; accepted = rho > a.min_relative_decrease ? 1 : 0; }
-                    else if (rho > a.min_relative_decrease) {
+                    else if (sh.step_norm <= sh.parameter_tolerance * (xnorm + sh.parameter_tolerance)) { sh.term = LILI_LM_PARAMETER_TOLERANCE; stop = 1; }
+                    else if (fabs(sh.cost - new_cost) <= sh.function_tolerance * sh.cost) { sh.term = LILI_LM_FUNCTION_TOLERANCE; stop = 1; accepted = rho > sh.min_relative_decrease ? 1 : 0; }
+                    else if (rho > sh.min_relative_decrease) {
                         accepted = 1;
                         const double f = 2.0 * rho - 1.0;
-                        sh.radius = fmin(a.max_radius, sh.radius / fmax(1.0 / 3.0, 1.0 - f * f * f));
+                        sh.radius = fmin(sh.max_radius, sh.radius / fmax(1.0 / 3.0, 1.0 - f * f * f));
                         sh.decrease = 2.0;
-                    } else { sh.radius = fmax(a.min_radius, sh.radius / sh.decrease); sh.decrease *= 2.0; }
+                    } else { sh.radius = fmax(sh.min_radius, sh.radius / sh.decrease); sh.decrease *= 2.0; }
                     if (accepted) { for (int i = 0; i < 7; i++) sh.x[i] = sh.xn[i]; sh.cost = new_cost; sh.n_ok++; }
                     if (boss && a.summary && n_log < LILI_LM_MAX_LOG) a.summary->it[n_log].accepted = accepted;
                     n_log++;
@@ -308,10 +329,12 @@ __global__ __launch_bounds__(kLmThreads) void k_solve_lm(LmArgs a, MatchParams P
                     lm_tri_to_full(sh.cur, sh.full);
                     LILI_WAVE_SYNC();
                     lm_local_system(sh);
+                    LILI_WAVE_SYNC();
+                    lm_scaled_system(sh);
                 }
-                LILI_WAVE_SYNC();
-                if (threadIdx.x == 0 && sh.go) lm_propose(sh, a);
             }
+            LILI_WAVE_SYNC();
+            if (threadIdx.x == 0 && sh.go) lm_propose(sh);      // the next candidate (or the end), from the accepted point — ONE lane, ONE call site
             LILI_WAVE_SYNC();
         }
         __syncthreads();

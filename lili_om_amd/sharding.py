@@ -28,6 +28,23 @@ def allreduce_gram(dist, gram):
     return gram
 
 
+def pack_window_records(records):
+    """The Gram records of the K keyframes of a sliding window as ONE buffer of K x 72 doubles (BASELINE configs[4]: the reference evaluates
+    the lidar blocks of all keyframes per solver evaluation, L/src/BackendFusion.cpp:919-992) — one all-reduce per evaluation instead of K."""
+    return np.ascontiguousarray(np.concatenate([np.asarray(r, np.float64).reshape(72) for r in records]))
+
+
+def unpack_window_records(buf, k):
+    buf = np.asarray(buf, np.float64).reshape(k, 72)
+    return [(buf[i, :64].reshape(8, 8).copy(), float(buf[i, 64]), (int(buf[i, 65]), int(buf[i, 66]))) for i in range(k)]
+
+
+def allreduce_window(dist, tensor):
+    """In-place sum over ranks of the packed window buffer (K x 72 doubles) or of the packed counts (K x 2 int32): ONE collective each."""
+    dist.all_reduce(tensor)
+    return tensor
+
+
 def plus_jacobian(q):
     """ceres::QuaternionParameterization::ComputeJacobian for q = (w,x,y,z): 4x3."""
     w, x, y, z = q

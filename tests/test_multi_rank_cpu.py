@@ -97,3 +97,70 @@ def test_project_gram_matches_host_gn_step(oracle):
     d = np.linalg.solve(H, -g)
     st, t2, q2, delta = L.api.gn_step_host(G, np.zeros(3), q)
     assert st == 0 and np.allclose(delta, d, rtol=1e-9, atol=1e-12)
+
+
+# ---- the sliding window across ranks (BASELINE configs[4]): K keyframes, every rank holds its shard of every keyframe's queries; per
+# evaluation ONE all-reduce of the packed K x 2 counts and ONE of the packed K x 72 records
+N_KF = 3
+
+
+def _window_scene():
+    room = synth.make_room(seed=23, n_query=2401, n_edge_query=10)
+    P = L.make_params("rot")
+    tb, qb = L.api.body_pose_from_lidar(room["t_true"], room["q_true"], P)
+    poses = [synth.perturbed_pose(tb, qb, np.random.default_rng(40 + k), 0.08, 0.6) for k in range(N_KF)]
+    # keyframe k sees its own third of the feature cloud
+    qs = [room["q_xyz"][k::N_KF] for k in range(N_KF)]
+    return room, P, poses, qs
+
+
+def _window_evaluation(O, room, P, PO, poses, qs, world, rank, reduce_fn):
+    tree = O.KdTree(room["map_xyz"])
+    recs, counts = [], torch.zeros(2 * N_KF, dtype=torch.int32)
+    for k in range(N_KF):
+        lo, hi = sharding.shard_bounds(qs[k].shape[0], world, rank)
+        Q2, T2 = L.api.assoc_transform(poses[k][0], poses[k][1], P)
+        recs.append(O.associate_surf(tree, None, qs[k][lo:hi], None, Q2, T2, PO))
+        counts[2 * k] = recs[-1]["count"]
+    counts = reduce_fn(counts)                                     # ONE collective for the counts of all keyframes
+    rows = []
+    for k in range(N_KF):
+        G, cost, n = O.linearize_surf(recs[k], poses[k][0], poses[k][1], PO, (1000.0, max(int(counts[2 * k]), 1)))
+        rec = np.zeros(72)
+        rec[:64], rec[64], rec[65] = G.reshape(-1), cost, n
+        rows.append(rec)
+    buf = torch.from_numpy(sharding.pack_window_records(rows))
+    buf = reduce_fn(buf)                                           # ONE collective for the K records
+    return sharding.unpack_window_records(buf.numpy(), N_KF)
+
+
+def _window_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    room, P, poses, qs = _window_scene()
+    calls = [0]
+
+    def red(x):
+        calls[0] += 1
+        return sharding.allreduce_window(dist, x)
+    res = _window_evaluation(O, room, P, O.params("rot"), poses, qs, world, rank, red)
+    out[rank] = (res, calls[0])
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_window_evaluation_matches_single_rank(oracle, world):
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_window_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    room, P, poses, qs = _window_scene()
+    ref = _window_evaluation(oracle, room, P, oracle.params("rot"), poses, qs, 1, 0, lambda x: x)
+    for r in range(world):
+        res, calls = out[r]
+        assert calls == 2                                           # two collectives per evaluation whatever the number of keyframes
+        for k in range(N_KF):
+            G, cost, cnt = res[k]
+            assert cnt == ref[k][2] and cnt[0] > 400
+            assert np.abs(G - ref[k][0]).max() <= 1e-12 * np.abs(ref[k][0]).max() and abs(cost - ref[k][1]) <= 1e-12 * ref[k][1]
+            assert np.array_equal(G, out[0][0][k][0])               # the ranks agree bit for bit (gloo reduces in one order for all)
