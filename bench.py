@@ -286,6 +286,9 @@ def main():
     ap.add_argument("--assoc-after", type=int, default=0, help="with --assoc-only: run this many GN iterations first (pose then stays fixed)")
     ap.add_argument("--window", type=int, default=0, help="extra measurement (not the headline): K independent registrations of the same "
                     "scan in K slots advanced concurrently with lili_s2m_iterate_window; prints window iterations/s and exits")
+    ap.add_argument("--config", type=int, default=2, choices=[0, 1, 2, 4],
+                    help="BASELINE config to run: 2 (default) = the headline workload (with --gpus N: configs[3]); 0 / 1 / 4 = that config's own figure alone "
+                         "(bench_configs.py; the default run also reports them under extras.configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (window of 3 slots, ROT extractor)")
     ap.add_argument("--collective", choices=["auto", "p2p", "rccl", "torch"], default="auto",
@@ -326,6 +329,25 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+
+    if args.config != 2:
+        # one of the other BASELINE configs on its own (single GPU): same JSON contract, the config's own metric
+        import bench_configs as BC
+        tstream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(tstream)
+        ctx = L.Context(local_rank, stream=tstream.cuda_stream)
+        fn = {0: BC.config0, 1: BC.config1, 4: BC.config4}[args.config]
+        r = fn(L, ctx, torch, synth, cpu=not args.no_cpu_baseline)
+        ms = r.get("ms_per_scan") or r.get("ms_per_frame") or (r.get("us_per_window_evaluation", 0.0) * 1e-3)
+        line = {"metric": {0: "configs[0] scans/s (130k-pt scan: ROT extraction + 1 GN iteration vs 500k-pt map)", 1: "configs[1] frames/s (24k-pt Livox frames: extraction + scan-to-map)",
+                           4: "configs[4] window evaluations/s (3 keyframes, lidar blocks)"}[args.config],
+                "value": r["value"], "unit": r["unit"], "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 5), "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": {"workload": r["workload"]},
+                "roofline": dict(r["roofline"], achieved=round(r["algorithmic_bytes"] / (ms * 1e-3) / 1e9, 3), traffic=None, kernel="whole step (all kernels)"),
+                "cpu_baseline": r.get("cpu"), "details": {k: v for k, v in r.items() if k not in ("roofline", "cpu", "workload", "value", "unit")}}
+        print(json.dumps(line), flush=True)
+        ctx.close()
+        return
 
     # ---------------- workload (synthetic, fixed seeds; identical on every rank) ----------------
     t_gen = time.perf_counter()
@@ -541,6 +563,17 @@ def main():
     if rank == 0:
         log(f"[bench] host enqueue {t_enqueue / args.steps * 1e6:.1f} us/step, wall {elapsed / args.steps * 1e6:.1f} us/step")
     t_fin, q_fin, gn_status = m.pose_get(0)
+    # Run-to-run spread of the headline (a 20-step region is two registrations): five more regions of >= 200 steps each, same
+    # schedule; `value` stays the K-step region the contract asks for, the regions go to extras.headline_regions.
+    regions = None
+    if world == 1 and dist is None and not args.no_extras:
+        n_reg = max(200, args.steps)
+        regs = sorted(n_reg / timed(0, n_reg)[0] for _ in range(5))
+        regions = {"steps_per_region": n_reg, "iterations_per_s": [round(r, 1) for r in regs], "median": round(regs[2], 1),
+                   "spread_pct": round(100.0 * (regs[-1] - regs[0]) / regs[2], 2)}
+        m.pose_copy(0, 1)
+        m.iterate_restart(0, args.warmup + args.steps, ips, 1, L.MASK_SURF)      # leave slot 0 where the K-step region left it (final_pose below)
+        t_fin, q_fin, gn_status = m.pose_get(0)
 
     # ---------------- roofline of the dominant kernel (k_associate_surf), HIP events on its stream ----------------
     roofline = None
@@ -577,7 +610,9 @@ def main():
                 traffic = None
         roofline = dict(bound="hbm", kernel="k_associate_surf", achieved=round(achieved, 3), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 6), traffic=traffic, us_per_launch=round(dt * 1e6, 2),
-                        algorithmic_bytes_per_launch=alg_bytes)
+                        algorithmic_bytes_per_launch=alg_bytes,
+                        traffic_source=("profiles/pmc_traffic.json: rocprofv3 --pmc passes of this command collected by tools/make_profiles.sh (2 x FETCH_SIZE + WRITE_SIZE per the "
+                                        "guide's gfx950 correction) and committed — NOT measured inside this run") if traffic is not None else None)
     if dist is not None:
         dist.barrier()
 
@@ -592,6 +627,18 @@ def main():
                       "weak_scaling_note": f"{world} x {qw.shape[0]}-point shards of an (N x 200k)-point scan, value = steps x N / time"}
         m.set_queries(0, L.KIND_SURF, queries)
 
+    # Multi-GPU self-check: every rank must hold the SAME final pose, bit for bit (strong split: one scan, all ranks apply the same
+    # update to the same reduced record).  all-reduce MIN and MAX of the pose bit patterns: equal <=> identical on every rank.
+    multi = None
+    if dist is not None and args.scaling == "strong":
+        bits = torch.from_numpy(np.concatenate([np.asarray(t_fin, np.float64), np.asarray(q_fin, np.float64)]).view(np.int64).copy()).to(dev)
+        lo, hi = bits.clone(), bits.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        st_all = torch.tensor([int(gn_status)], dtype=torch.int32, device=dev)
+        dist.all_reduce(st_all, op=dist.ReduceOp.MAX)
+        multi = {"ranks": world, "rccl_ranks": world if dist.get_backend() == "nccl" else 0, "backend": dist.get_backend(),
+                 "final_pose_bit_identical_on_all_ranks": bool(torch.equal(lo, hi)), "max_gn_status": int(st_all.item())}
     if rank == 0:
         units = args.steps * (world if args.scaling == "weak" else 1)
         value = units / elapsed
@@ -611,7 +658,11 @@ def main():
             "roofline": roofline,
             "final_pose": {"t": [float(x) for x in t_fin], "q": [float(x) for x in q_fin], "gn_status": int(gn_status)},
         }
+        if multi:
+            out["multi_gpu_check"] = multi
         extras = dict(weak_extra or {})
+        if regions:
+            extras["headline_regions"] = regions
         if world == 1 and dist is None:
             # ---- the reference back-end's INNER iteration ("report it separately, never mix the two"): fixed correspondences,
             # linearise (residual + Jacobian + Cauchy corrector + cost) + reduce + 6x6 solve + pose update = ONE launch each
@@ -697,6 +748,30 @@ def main():
                 extras.update(secondary_stages(L, ctx, w, torch))
             except Exception as e:      # noqa: BLE001
                 extras["stages_error"] = repr(e)
+            # one timed figure per BASELINE config, the blocking seam calls, the small launch sizes (bench_configs.py)
+            import bench_configs as BC
+            try:
+                m.set_input_cloud(L.KIND_SURF, w["map_xyz"])
+                m.set_queries(0, L.KIND_SURF, queries)
+                extras["blocking_seam"] = BC.blocking_seam(L, ctx, torch, m, P, queries, t_body, q_body)
+            except Exception as e:      # noqa: BLE001
+                extras["blocking_seam_error"] = repr(e)
+            try:
+                extras["small_launches"] = BC.small_launches(L, ctx, torch, synth, w, scan, focus_r)
+            except Exception as e:      # noqa: BLE001
+                extras["small_launches_error"] = repr(e)
+            cfgs = {}
+            for key, fn in (("0", BC.config0), ("1", BC.config1), ("4", BC.config4)):
+                try:
+                    cfgs[key] = fn(L, ctx, torch, synth, cpu=not args.no_cpu_baseline)
+                except Exception as e:      # noqa: BLE001
+                    cfgs[key] = {"error": repr(e)}
+            extras["configs"] = cfgs
+            try:        # (the helpers above set their own maps / options: restore the headline's for the pose-parity check below)
+                m.map_focus(w["lidar_t"], focus_r) if not args.no_focus else m.map_focus(None)
+                m.set_input_cloud(L.KIND_SURF, w["map_xyz"])
+            except Exception as e:      # noqa: BLE001
+                extras["restore_error"] = repr(e)
         if extras:
             out["extras"] = extras
         if world == 1 and not args.no_cpu_baseline:

@@ -1,0 +1,311 @@
+"""Secondary bench lines of bench.py: one timed figure per BASELINE config next to the headline (configs[2]), the latency of
+the BLOCKING seam calls a Ceres cost function issues, and the small-launch sizes the reference itself produces.  Every figure carries its
+algorithmic-byte roofline (96 B per query and association, 41 B per record and linearisation, 20 B per raw ROT point, 48 B per raw
+Livox point) and — where the oracle is cheap enough — the oracle timed on the host beside it (`cpu`, bounded samples).  Never the headline.
+
+Only bench.py imports this; the oracle is touched by the cpu_* helpers alone (checker timed as a baseline, never the thing measured)."""
+import math
+import time
+
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0
+
+
+def _wall(fn, reps, torch, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    tic = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - tic) / reps
+
+
+def _frac(nbytes, sec):
+    return round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 6)
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# configs[0]: one HDL-64E-like scan (~130 k points): ROT extraction + 1 outer GN iteration (edge + surf) vs a 500 k-point map
+# ------------------------------------------------------------------------------------------------------------------------------
+def config0(L, ctx, torch, synth, cpu=True):
+    import ctypes as C
+    w = synth.make_workload(n_map=500_000, n_az=2031, half_extent=(150.0, 150.0), verbose=False)
+    raw = np.concatenate([w["scan_xyz"], np.full((w["scan_xyz"].shape[0], 1), 50.0, np.float32)], 1)
+    P = L.make_params("rot")
+    q_lb = np.array(list(P.q_lb))
+    ex = L.RotExtractor(ctx, n_scans=64, ds_rate=4)
+    m = L.ScanToMapMatcher(ctx, P)
+    m.map_focus(None)
+    m.set_input_cloud(L.KIND_SURF, w["map_xyz"])
+    m.set_input_cloud(L.KIND_EDGE, w["edge_map_xyz"])
+    tb, qb = L.api.body_pose_from_lidar(w["lidar_t"], w["lidar_q"], P)
+    t0, q0 = synth.perturbed_pose(tb, qb, np.random.default_rng(synth.SEED_POSE), 0.3, 2.0)
+    m.pose_set(1, t0, q0)
+    d_raw = torch.from_numpy(raw).cuda()
+    mask = L.MASK_SURF | L.MASK_EDGE
+    n_feat = [0, 0]
+
+    def scan():
+        ex.extract_device(d_raw.data_ptr(), raw.shape[0], (1.0, 0, 0, 0), q_lb)
+        _, d_edge, d_surf = L.api.extract_rot_device(ctx)
+        n_feat[0], n_feat[1] = int(d_surf.n), int(d_edge.n)
+        m.set_queries(0, L.KIND_SURF, d_surf)
+        m.set_queries(0, L.KIND_EDGE, d_edge)
+        m.pose_copy(0, 1)
+        m.iterate(0, 1, mask)
+    sec = _wall(scan, 30, torch)
+    tg, qg, st = m.pose_get(0)
+    alg = 20 * raw.shape[0] + 96 * (n_feat[0] + n_feat[1]) + 41 * (n_feat[0] + n_feat[1])
+    out = {"value": round(1.0 / sec, 1), "unit": "scans/s", "ms_per_scan": round(sec * 1e3, 4), "gn_status": int(st),
+           "workload": f"configs[0]: {raw.shape[0]}-pt 64-ring scan (already in HBM) -> LiLi-OM-ROT extraction (ds_rate 4) -> {n_feat[1]} edge + {n_feat[0]} surf features -> "
+                       f"1 outer GN iteration (edge + surf) vs {w['map_xyz'].shape[0]}-pt surf map + {w['edge_map_xyz'].shape[0]}-pt edge map",
+           "algorithmic_bytes": int(alg), "roofline": {"bound": "hbm", "frac": _frac(alg, sec), "peak": HBM_PEAK_GBS, "unit": "GB/s"},
+           "step_moves_pose_m": float(np.linalg.norm(tg - t0))}
+    if cpu:
+        try:
+            from oracle import oracle as O
+            PO = O.params("rot")
+            tic = time.perf_counter()
+            o = O.extract_rot(raw, (1.0, 0, 0, 0), list(P.q_lb), O.rot_params(ds_rate=4, atan_mode=2, stable_sort=1))
+            t_ex = time.perf_counter() - tic
+            surf_q, edge_q = o["surf"][:, :3], o["full"][o["edge_idx"]][:, :3]
+            tree, etree = O.KdTree(w["map_xyz"]), O.KdTree(w["edge_map_xyz"])
+            tic = time.perf_counter()
+            Q2, T2 = L.api.assoc_transform(t0, q0, P)
+            rs = O.associate_surf(tree, None, surf_q, None, Q2, T2, PO)
+            re_ = O.associate_edge(etree, edge_q, Q2, T2, PO)
+            Gs, _, _ = O.linearize_surf(rs, t0, q0, PO, (1000.0, max(rs["count"], 1)))
+            Ge, _, _ = O.linearize_edge(re_, t0, q0, PO, (200.0, max(re_["count"], 1)))
+            _, to, qo, _ = O.gn_step(Gs + Ge, t0, q0)
+            t_it = time.perf_counter() - tic
+            out["cpu"] = {"value": round(1.0 / (t_ex + t_it), 3), "unit": "scans/s", "cores": 1, "kind": "port", "extract_s": round(t_ex, 4), "iteration_s": round(t_it, 4),
+                          "sample": "the oracle, one thread, ONE scan: extraction + one outer iteration (kd-tree builds excluded)",
+                          "pose_delta_gpu_vs_cpu_m": float(np.abs(tg - to).max())}
+        except Exception as e:      # noqa: BLE001
+            out["cpu"] = {"error": repr(e)}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# configs[1]: Livox Horizon frames (~24 k points, 6 lines): extraction + voxel filter + local map + scan-to-map (front-end flavour)
+# ------------------------------------------------------------------------------------------------------------------------------
+def _circuit(f, radius=4.0, step=0.03):
+    a = step * f
+    yaw = a + math.pi / 2
+    return np.array([radius * math.cos(a), radius * math.sin(a), 1.8]), np.array([math.cos(yaw / 2), 0.0, 0.0, math.sin(yaw / 2)]), yaw
+
+
+def config1(L, ctx, torch, synth, n_frames=40, cpu=True):
+    frames = []
+    for f in range(n_frames):
+        t, q, yaw = _circuit(f)
+        frames.append(synth.make_livox_scan(100 + f, origin=t, yaw=yaw, inject_bad=False))
+    P = L.make_params("frontend")
+    ex = L.LivoxExtractor(ctx)
+    m = L.ScanToMapMatcher(ctx, P)
+    m.map_focus(None)
+    pins = []
+    for fr in frames:
+        p = L.api.PinnedArray(fr.shape, np.float32)
+        p.array[...] = fr
+        pins.append(p)
+
+    def run():
+        local = L.api.LocalMap(ctx, L.KIND_SURF, 20, 0.4, P.kd_max_radius)
+        poses, nq = [], []
+        for f in range(n_frames):
+            feats = ex.extract(pins[f].array, reuse=True)
+            surf = np.ascontiguousarray(feats["surf"][:, [0, 1, 2, 7]])
+            qry, _ = L.api.voxel_filter(ctx, surf, 0.4)
+            if f == 0:
+                t, q = _circuit(0)[:2]
+            else:
+                if f == 1:
+                    t0, q0 = poses[-1]
+                else:
+                    (ta, qa), (tb, qb) = poses[-2], poses[-1]
+                    qi = qa * np.array([1, -1, -1, -1]) / np.dot(qa, qa)
+                    dq = synth.quat_mul(qi, qb)
+                    q0 = synth.quat_mul(qb, dq); q0 = q0 / np.linalg.norm(q0)
+                    t0 = tb + synth.quat_rot(qb, synth.quat_rot(qi, tb - ta))
+                local.commit()
+                m.set_queries(0, L.KIND_SURF, qry)
+                m.pose_set(0, t0, q0)
+                m.iterate(0, 12 if f == 1 else 6, L.MASK_SURF)
+                t, q, st = m.pose_get(0)
+            poses.append((np.asarray(t, np.float64), np.asarray(q, np.float64)))
+            nq.append(int(qry.shape[0]))
+            local.push(qry, t, q)
+        return poses, nq
+    run()
+    torch.cuda.synchronize()
+    tic = time.perf_counter()
+    poses, nq = run()
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - tic) / n_frames
+    err = [float(np.linalg.norm(p[0] - _circuit(f)[0])) for f, p in enumerate(poses)]
+    n_pts = int(np.mean([fr.shape[0] for fr in frames]))
+    alg = 48 * n_pts + 48 * 24000 + 6 * (96 + 41) * int(np.mean(nq))
+    out = {"value": round(1.0 / sec, 1), "unit": "frames/s", "ms_per_frame": round(sec * 1e3, 4), "frames": n_frames,
+           "workload": f"configs[1] substitute (no FR_IOSB bag offline): {n_frames} synthetic Livox-Horizon frames (~{n_pts} points, 6 lines) on a circuit: extraction (host in / out, page-locked) -> "
+                       f"VoxelGrid(0.4) -> ~{int(np.mean(nq))} queries vs the local map of the last 20 frames (ring push + commit on the device) -> 6 outer iterations (front-end flavour), host loop as tools/replay_bag.py",
+           "ate_rms_m": round(float(np.sqrt(np.mean(np.square(err)))), 4), "ate_max_m": round(max(err), 4),
+           "algorithmic_bytes": int(alg), "roofline": {"bound": "hbm", "frac": _frac(alg, sec), "peak": HBM_PEAK_GBS, "unit": "GB/s"}}
+    if cpu:
+        try:
+            from oracle import oracle as O
+            PO = O.params("frontend")
+            # the oracle on one thread: extraction of one frame + 6 iterations against a local map of the same size
+            tic = time.perf_counter()
+            fo = O.extract_livox(frames[n_frames // 2])
+            t_ex = time.perf_counter() - tic
+            k = n_frames // 2
+            world = []
+            for j in range(max(0, k - 20), k):
+                fj = O.extract_livox(frames[j])["surf"]
+                world.append(synth.quat_rot(poses[j][1], fj[:, :3].astype(np.float64)) + poses[j][0])
+            local = np.concatenate(world, 0).astype(np.float32)
+            vox, _ = L.api.voxel_filter(ctx, np.c_[local, np.zeros(len(local), np.float32)], 0.4)
+            tree = O.KdTree(np.ascontiguousarray(vox[:, :3]))
+            qv, _ = L.api.voxel_filter(ctx, np.ascontiguousarray(fo["surf"][:, [0, 1, 2, 7]]), 0.4)
+            t, q = poses[k - 1]
+            tic = time.perf_counter()
+            for _ in range(6):
+                rs = O.associate_surf(tree, None, np.ascontiguousarray(qv[:, :3]), None, q, t, PO)
+                G, _, _ = O.linearize_surf(rs, t, q, PO)
+                _, t, q, _ = O.gn_step(G, t, q)
+            t_it = time.perf_counter() - tic
+            out["cpu"] = {"value": round(1.0 / (t_ex + t_it), 2), "unit": "frames/s", "cores": 1, "kind": "port", "extract_s": round(t_ex, 4), "iterations_s": round(t_it, 4),
+                          "sample": "the oracle, one thread, ONE frame: extraction + 6 outer iterations vs a 20-frame local map (kd-tree build excluded)"}
+        except Exception as e:      # noqa: BLE001
+            out["cpu"] = {"error": repr(e)}
+    for p in pins:
+        p.close()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# configs[4]: 3-keyframe window at FR_IOSB sizes: what ONE solver evaluation costs at the Ceres seam, and the device LM
+# ------------------------------------------------------------------------------------------------------------------------------
+def config4(L, ctx, torch, synth, cpu=True):
+    room = synth.make_room(seed=41, n_query=2500, n_edge_query=250)
+    P = L.make_params("livox")
+    rng = np.random.default_rng(7)
+    refl = lambda n: rng.uniform(0.0, 0.05, n).astype(np.float32)
+    m = L.ScanToMapMatcher(ctx, P)
+    m.map_focus(None)
+    m.set_input_cloud(L.KIND_SURF, np.c_[room["map_xyz"], refl(room["map_xyz"].shape[0])])
+    m.set_input_cloud(L.KIND_EDGE, room["edge_map_xyz"])
+    tb, qb = L.api.body_pose_from_lidar(room["t_true"], room["q_true"], P)
+    K = 3
+    mask = L.MASK_SURF | L.MASK_EDGE
+    slots = list(range(K))
+    sq = np.c_[room["q_xyz"], refl(room["q_xyz"].shape[0])]
+    poses = []
+    for k in range(K):
+        m.set_queries(k, L.KIND_SURF, sq)
+        m.set_queries(k, L.KIND_EDGE, room["eq_xyz"])
+        t0, q0 = synth.perturbed_pose(tb, qb, np.random.default_rng(90 + k), 0.04, 0.4)
+        poses.append((np.asarray(t0, np.float64), np.asarray(q0, np.float64)))
+    assoc = [L.api.assoc_transform(p[0], p[1], P) for p in poses]
+    ts, qs = [p[0] for p in poses], [p[1] for p in poses]
+    n_res = m.associate_window(slots, [a[1] for a in assoc], [a[0] for a in assoc], mask)
+    n_rec = int(sum(a + b for a, b in n_res))
+    sec_assoc = _wall(lambda: m.associate_window(slots, [a[1] for a in assoc], [a[0] for a in assoc], mask), 50, torch)
+    sec_eval = _wall(lambda: m.linearize_window(slots, ts, qs, mask), 100, torch)
+    sec_one = _wall(lambda: m.linearize(0, ts[0], qs[0], mask), 100, torch)
+
+    def lm():
+        for k in range(K):
+            m.pose_set(k, ts[k], qs[k])
+        return m.solve_lm_window(slots, mask)
+    summ = lm()
+    evals = sum(len(s["log"]) + 1 for s in summ) / K
+    sec_lm = _wall(lm, 20, torch)
+    t_pose = _wall(lambda: [m.pose_set(k, ts[k], qs[k]) for k in range(K)], 20, torch)
+    alg_eval = 41 * (room["q_xyz"].shape[0] + room["eq_xyz"].shape[0]) * K
+    out = {"value": round(1.0 / sec_eval, 1), "unit": "window evaluations/s", "us_per_window_evaluation": round(sec_eval * 1e6, 2),
+           "workload": f"configs[4] substitute (no FR_IOSB bag offline): sliding window of {K} keyframes x ({room['q_xyz'].shape[0]} surf + {room['eq_xyz'].shape[0]} edge features), Livox back-end flavour, "
+                       f"{n_rec} correspondences: ONE blocking lili_s2m_linearize_window = what one ceres evaluation of the lidar blocks costs through include/lili_ceres_adapter.h "
+                       "(IMU factors / marginalisation prior stay with the caller's solver)",
+           "us_per_single_keyframe_linearize_blocking": round(sec_one * 1e6, 2), "us_per_window_association_blocking": round(sec_assoc * 1e6, 2),
+           "device_lm": {"us_per_window_solve": round((sec_lm - t_pose) * 1e6, 2), "evaluations_per_keyframe": round(evals, 2),
+                         "us_per_evaluation": round((sec_lm - t_pose) * 1e6 / max(evals, 1), 2),
+                         "termination": [s["termination"] for s in summ], "successful_steps": [s["successful_steps"] for s in summ],
+                         "note": "lili_s2m_solve_lm_window: the three keyframes' lidar-only LM solves (Ceres defaults, <= 15 iterations) as three persistent launches side by side, no host round trip per evaluation"},
+           "algorithmic_bytes": int(alg_eval), "roofline": {"bound": "hbm", "frac": _frac(alg_eval, sec_eval), "peak": HBM_PEAK_GBS, "unit": "GB/s"}}
+    if cpu:
+        try:
+            from oracle import oracle as O
+            PO = O.params("livox")
+            tree_s, tree_e = O.KdTree(room["map_xyz"]), O.KdTree(room["edge_map_xyz"])
+            map_refl = np.zeros(room["map_xyz"].shape[0], np.float32); q_refl = np.zeros(room["q_xyz"].shape[0], np.float32)
+            recs = []
+            for k in range(K):
+                recs.append((O.associate_surf(tree_s, map_refl, room["q_xyz"], q_refl, assoc[k][0], assoc[k][1], PO), O.associate_edge(tree_e, room["eq_xyz"], assoc[k][0], assoc[k][1], PO)))
+            tic = time.perf_counter()
+            for _ in range(5):
+                for k in range(K):
+                    O.linearize_surf(recs[k][0], ts[k], qs[k], PO)
+                    O.linearize_edge(recs[k][1], ts[k], qs[k], PO)
+            t_ev = (time.perf_counter() - tic) / 5
+            out["cpu"] = {"value": round(1.0 / t_ev, 1), "unit": "window evaluations/s", "cores": 1, "kind": "port",
+                          "sample": "the oracle, one thread: residual + Jacobian + corrector + Gram of the same three keyframes, mean of 5"}
+        except Exception as e:      # noqa: BLE001
+            out["cpu"] = {"error": repr(e)}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# small launches (the sizes of a real keyframe, of a rank's shard) and the blocking seam at the bench size
+# ------------------------------------------------------------------------------------------------------------------------------
+def small_launches(L, ctx, torch, synth, w, scan_ring_major, focus_r):
+    """Per launch size: one outer iteration (wall time of the device loop, restart schedule of the headline) for the ROT back-end and the front-end
+    flavour, with the lanes-per-query choice of the library (option assoc_lpq = 0) next to the one-lane kernels (assoc_lpq = 1)."""
+    rows = []
+    for flavour in ("rot", "frontend"):
+        P = L.make_params(flavour)
+        m = L.ScanToMapMatcher(ctx, P)
+        m.map_focus(w["lidar_t"], focus_r)
+        m.set_input_cloud(L.KIND_SURF, w["map_xyz"])
+        if flavour == "rot":
+            tb, qb = L.api.body_pose_from_lidar(w["lidar_t"], w["lidar_q"], P)
+        else:
+            tb, qb = np.asarray(w["lidar_t"], np.float64), np.array([1.0, 0.0, 0.0, 0.0])
+        t0, q0 = synth.perturbed_pose(tb, qb, np.random.default_rng(synth.SEED_POSE), 0.3, 2.0)
+        m.pose_set(1, t0, q0)
+        for n in (2000, 20000, 25000, 200000):
+            q = scan_ring_major[:n] if n >= 25000 else np.ascontiguousarray(scan_ring_major[:: max(1, scan_ring_major.shape[0] // n)][:n])
+            m.set_queries(0, L.KIND_SURF, q)
+            row = {"flavour": flavour, "queries": int(q.shape[0])}
+            for lanes, key in ((0, "us_per_iteration"), (1, "us_per_iteration_one_lane_per_query")):
+                ctx.set_option("assoc_lpq", lanes)
+                m.iterate_restart(0, 20, 10, 1, L.MASK_SURF)
+                torch.cuda.synchronize()
+                tic = time.perf_counter()
+                m.iterate_restart(0, 200, 10, 1, L.MASK_SURF)
+                torch.cuda.synchronize()
+                row[key] = round((time.perf_counter() - tic) / 200 * 1e6, 2)
+            tt, qq, st = m.pose_get(0)
+            row["gn_status"] = int(st)
+            row["hbm_frac"] = _frac((96 + 41) * q.shape[0], row["us_per_iteration"] * 1e-6)
+            rows.append(row)
+        ctx.set_option("assoc_lpq", 0)
+    return rows
+
+
+def blocking_seam(L, ctx, torch, m, P, queries, t, q):
+    """The calls the b-2 seam actually issues (include/lili_ceres_adapter.h: LidarBatchFactor::Evaluate = one blocking lili_s2m_linearize): latency at
+    the bench size, correspondences fixed."""
+    Q2, T2 = L.api.assoc_transform(t, q, P)
+    m.find_corresponding_surf_features(0, Q2, T2, want_count=True)
+    sec_lin = _wall(lambda: m.linearize(0, t, q, L.MASK_SURF), 100, torch)
+    sec_as = _wall(lambda: m.find_corresponding_surf_features(0, Q2, T2, want_count=True), 50, torch)
+    n = int(queries.shape[0])
+    return {"linearize_blocking_us": round(sec_lin * 1e6, 2), "associate_blocking_us": round(sec_as * 1e6, 2), "queries": n,
+            "linearize_hbm_frac": _frac(41 * n, sec_lin), "associate_hbm_frac": _frac(96 * n, sec_as),
+            "note": "host-synchronous calls through the Python binding (ctypes adds ~10-30 us per call; a C++ caller sees less): lili_s2m_linearize = residual + Jacobian + corrector + "
+                    "Gram of all records at a host pose, result copied out; lili_s2m_associate with the count read back"}

@@ -1296,7 +1296,7 @@ static int launch_solve_lm(lili_ctx* ctx, int slot, int kind_mask, const lili_s2
     }
     a.S.nb = nb_s; a.E.nb = nb_e;
     a.nb = nb_s + nb_e;
-    a.ng = a.nb > 16 ? nblocks(a.nb, 16) : 1;
+    a.ng = a.nb > 32 ? nblocks(a.nb, 32) : 1;       // kLmGroup of lili_s2m_lm.hip
     HIPCHK(sl.lm_part.ensure((size_t)2 * a.nb * kPartialStride * sizeof(double)));
     HIPCHK(sl.lm_gsum.ensure((size_t)2 * a.ng * kPartialStride * sizeof(double)));
     HIPCHK(sl.lm_summary.ensure(sizeof(lili_lm_summary)));
