@@ -226,6 +226,13 @@ int lili_voxel_filter(lili_ctx* ctx, const lili_cloud* cloud, float leaf, lili_f
 int lili_localmap_reset(lili_ctx* ctx, int kind);
 int lili_localmap_push(lili_ctx* ctx, int kind, const lili_cloud* features, const double t[3], const double q[4], int width);
 int lili_localmap_commit(lili_ctx* ctx, int kind, float leaf, double max_sq_radius, int64_t* n_raw, int64_t* n_map);
+/* How the commits of this context were served: steps on the ring kept sorted by voxel (one keyframe popped / pushed since the last commit, the
+ * reference's steady state, L/src/BackendFusion.cpp:1407-1477) against full rebuilds (first commit, several keyframes pending, another leaf).
+ * The map is the same bit for bit either way (option "localmap_incremental" = 0 forces rebuilds). */
+int lili_localmap_stats(lili_ctx* ctx, int32_t* incremental_commits, int32_t* full_commits);
+/* The down-sampled local map of the last lili_localmap_commit as (x, y, z, aux) rows in map order (out->count = its size; at most
+ * out->capacity rows are copied).  Blocking. */
+int lili_localmap_get(lili_ctx* ctx, lili_feature_out* out);
 
 /* ---- scan-to-map matcher -------------------------------------------------------------------- */
 

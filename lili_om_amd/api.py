@@ -131,6 +131,8 @@ _SIGS = {
     "lili_localmap_reset": (C.c_int, [C.c_void_p, C.c_int]),
     "lili_localmap_push": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Cloud), C.c_void_p, C.c_void_p, C.c_int]),
     "lili_localmap_commit": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_double, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "lili_localmap_get": (C.c_int, [C.c_void_p, C.POINTER(FeatureOut)]),
+    "lili_localmap_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "lili_map_set": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Cloud), C.c_double]),
     "lili_map_density": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "lili_s2m_linearize_window": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -232,15 +234,30 @@ class PinnedArray:
         if not self.ptr:
             raise LiliError("lili_host_alloc failed")
         buf = (C.c_ubyte * max(n, 1)).from_address(self.ptr)
+        buf._lili_owner = _PinnedBlock(self.lib, self.ptr)      # the ctypes buffer is the base object of every numpy view: the block lives as long as any view
+        self._block = buf._lili_owner
         self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
     def close(self):
-        if getattr(self, "ptr", None):
-            self.array = None
-            self.lib.lili_host_free(C.c_void_p(self.ptr))
-            self.ptr = None
+        """Drops this object's reference; the memory is released once no numpy view of it is left (never under a live view)."""
+        self.array = None
+        self._block = None
+        self.ptr = None
 
     __del__ = close
+
+
+class _PinnedBlock:
+    def __init__(self, lib, ptr):
+        self.lib, self.ptr = lib, ptr
+
+    def __del__(self):
+        if self.ptr:
+            try:
+                self.lib.lili_host_free(C.c_void_p(self.ptr))
+            except Exception:   # noqa: BLE001  (interpreter shutdown)
+                pass
+            self.ptr = None
 
 
 def _f64(a, n):
@@ -590,6 +607,19 @@ class LocalMap:
         t, q = _f64(t, 3), _f64(q, 4)
         self.ctx._chk(self.ctx.lib.lili_localmap_push(self.ctx.h, self.kind, C.byref(cloud), _ptr(t), _ptr(q), self.width))
 
+    def get(self, capacity):
+        """The down-sampled local map of the last commit, (n, 4) float32 rows in map order."""
+        out = np.zeros((max(int(capacity), 1), 4), np.float32)
+        fo = FeatureOut(out.ctypes.data, out.shape[0], 16, MEM_HOST, 0)
+        self.ctx._chk(self.ctx.lib.lili_localmap_get(self.ctx.h, C.byref(fo)))
+        return out[:min(fo.count, out.shape[0])]
+
+    def stats(self):
+        """(incremental commits, full rebuilds) of this context so far."""
+        a, b = C.c_int32(0), C.c_int32(0)
+        self.ctx._chk(self.ctx.lib.lili_localmap_stats(self.ctx.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def commit(self):
         a, b = C.c_int64(0), C.c_int64(0)
         self.ctx._chk(self.ctx.lib.lili_localmap_commit(self.ctx.h, self.kind, self.leaf, self.max_sq_radius, C.byref(a), C.byref(b)))
@@ -621,8 +651,9 @@ class RotExtractor:
         if not reuse:
             return [np.zeros((cap, 4), np.float32) for _ in range(3)]
         if getattr(self, "_pin_cap", 0) < cap:
-            for p in getattr(self, "_pins", []):
-                p.close()
+            # the old blocks are RETIRED, not freed: arrays handed out by earlier calls are views of them (freeing them here
+            # left those views pointing at released page-locked memory); they go when the extractor does
+            self._retired = getattr(self, "_retired", []) + list(getattr(self, "_pins", []))
             self._pins = [PinnedArray((cap, 4), np.float32) for _ in range(3)]
             self._pin_cap = cap
         return [p.array[:cap] for p in self._pins]

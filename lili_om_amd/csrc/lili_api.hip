@@ -204,6 +204,8 @@ int lili_set_option(lili_ctx* ctx, const char* name, int value) {
     if (std::strcmp(name, "super_rows") == 0) { ctx->super_rows = value != 0; return LILI_OK; }   // takes effect at the next lili_map_set
     if (std::strcmp(name, "fine_occupancy") == 0) { if (value < 2) return ctx->fail(LILI_E_ARG, "fine_occupancy must be >= 2"); ctx->fine_occupancy = value; return LILI_OK; }
     if (std::strcmp(name, "scan_lookback") == 0) { ctx->scan_lookback = value != 0; return LILI_OK; }
+    if (std::strcmp(name, "localmap_incremental") == 0) { ctx->localmap_incremental = value != 0; return LILI_OK; }
+    if (std::strcmp(name, "sort_digit_bits") == 0) { if (value != 4 && value != 8) return ctx->fail(LILI_E_ARG, "sort_digit_bits must be 4 or 8"); ctx->sort_digit_bits = value; return LILI_OK; }
     if (std::strcmp(name, "rot_atan") == 0) { if (value != 1 && value != 2) return ctx->fail(LILI_E_ARG, "rot_atan must be 1 or 2"); ctx->rot_atan = value; return LILI_OK; }
     if (std::strcmp(name, "p2p_fusion") == 0) { ctx->no_p2p_fusion = value == 0; return LILI_OK; }
     if (std::strcmp(name, "nn_cache") == 0) { ctx->nn_cache = value != 0; for (auto& s : ctx->slots) for (auto& k : s.k) k.nn_cache_valid = false; return LILI_OK; }
@@ -1296,7 +1298,7 @@ static int launch_solve_lm(lili_ctx* ctx, int slot, int kind_mask, const lili_s2
     }
     a.S.nb = nb_s; a.E.nb = nb_e;
     a.nb = nb_s + nb_e;
-    a.ng = a.nb > 32 ? nblocks(a.nb, 32) : 1;       // kLmGroup of lili_s2m_lm.hip
+    a.ng = a.nb > 16 ? nblocks(a.nb, 16) : 1;       // kLmGroup of lili_s2m_lm.hip
     HIPCHK(sl.lm_part.ensure((size_t)2 * a.nb * kPartialStride * sizeof(double)));
     HIPCHK(sl.lm_gsum.ensure((size_t)2 * a.ng * kPartialStride * sizeof(double)));
     HIPCHK(sl.lm_summary.ensure(sizeof(lili_lm_summary)));

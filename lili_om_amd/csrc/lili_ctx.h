@@ -137,6 +137,8 @@ struct lili_ctx {
     bool fuse_lin = true;        // lili_s2m_iterate*: flavours without count scaling linearise inside the association launch (k_associate_lin)
     bool super_rows = true;      // lili_map_set also stores the super-row copy of the map (9x the points): the inner 27-cell block of a query is one run
     bool scan_lookback = true;   // map index: single-pass (decoupled look-back) scan of the cell array; 0 = the three-kernel scan (A/B)
+    bool localmap_incremental = true;   // lili_localmap_commit keeps the ring sorted by voxel and merges one keyframe per step (0: rebuild every time, A/B)
+    int sort_digit_bits = 8;     // radix sort of the voxel filter: 8-bit digits (4 = the round-2 passes, A/B)
     int rot_atan = 2;            // ROT extractor: 2 = glibc fdlibm float atan / atan2 (the reference build's bits), 1 = f64 functions rounded to f32
     bool balance = false;        // cost-ordered dispatch of the association workgroups (AssocSched): measured, no gain — A/B only
     int n_simd = 0;              // SIMDs of the device (CUs x 4)

@@ -10,9 +10,9 @@
 //                lili_s2m_dev.h: robustified rows, f64-MFMA Gram, block partial incl. the robust cost) and PUBLISHES the 40-double partial
 //                as 16-byte granules {value, value ^ key}, key unique per (launch, evaluation): the data is its own flag
 //                (cdna_hip_programming.md Guideline 16 form R2: one write-through store per granule, relaxed agent-scope loads, no fence)
-//   exchange     by ONE polling wave per workgroup.  Up to 32 workgroups (16 k records): one hop — everybody adds all partials in index order.
-//                More: two hops — the first workgroup of every group of 32 adds its members' partials in index order and publishes the
-//                group sum; every workgroup then adds the <= 8 group sums in index order.  Fixed order,
+//   exchange     by ONE polling wave per workgroup.  Up to 16 workgroups (8 k records): one hop — everybody adds all partials in index order.
+//                More: two hops — the first workgroup of every group of 16 adds its members' partials in index order and publishes the
+//                group sum; every workgroup then adds the <= 15 group sums in index order.  Fixed order,
 //                so every workgroup holds the SAME 40 doubles bit for bit — no broadcast of the decision is needed: each workgroup
 //                runs the trust-region step itself (6x6 LDL^T in one lane) and arrives at the same candidate pose.  Partial / group
 //                buffers are double-buffered by the parity of the evaluation: a workgroup can start evaluation e + 1 only after it has
@@ -32,7 +32,7 @@
 namespace lili {
 
 constexpr int kLmThreads = 512;      // 8 waves: the launch may use 256 VGPRs per lane (1024-thread workgroups cap it at 128 and the loop spilled ~150 words)
-constexpr int kLmGroup = 32;      // workgroups per group sum; up to this many workgroups exchange in ONE hop
+constexpr int kLmGroup = 16;      // workgroups per group sum; up to this many workgroups exchange in ONE hop (32: measured slower, one wave polls 1280 granules)
 
 struct LmArgs {
     LinArgs S, E;                 // records of the two kinds; S.nb / E.nb = workgroups of each kind (either may be 0)

@@ -12,6 +12,8 @@
 #include "lili_ctx.h"
 #include "lili_device_math.h"
 
+namespace lili_detail { struct ConcatSeg { const float4* src; long long first; }; }      // one keyframe of the ring: its points and where they start in the concatenation
+
 namespace lili {
 __global__ void k_scan_block_sums(const int*, int64_t, int*);
 __global__ void k_scan_sums(int*, int);
@@ -84,6 +86,59 @@ __global__ __launch_bounds__(kSortBlock) void k_sort_scatter(const unsigned* __r
     }
 }
 
+// The same sort with 8-bit digits (round 3): a quarter of the passes for the price of 256-entry digit tables — the passes are launch- and
+// latency-bound at the sizes of a keyframe ring (1 M keys: 8 x (hist + scan + scatter) 4-bit passes were ~25 launches for a 26-bit key).
+// Stability as above: keys of a tile keep their order inside a digit (ballot ranks inside a wave, wave counts in LDS, rounds in order).
+constexpr int kSortItems8 = 16, kSortTile8 = kSortBlock * kSortItems8;      // 4096 keys per tile: the 256 x tiles digit table of 1 M keys (62 k words) still takes the one-launch scan
+__global__ __launch_bounds__(kSortBlock) void k_sort_hist8(const unsigned* __restrict__ keys, int n, int shift, int nb, int* __restrict__ hist /*[256][nb]*/) {
+    __shared__ int h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int base = blockIdx.x * kSortTile8;
+    for (int r = 0; r < kSortItems8; r++) {
+        const int i = base + r * kSortBlock + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1);      // LDS integer atomics
+    }
+    __syncthreads();
+    hist[threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
+}
+__global__ __launch_bounds__(kSortBlock) void k_sort_scatter8(const unsigned* __restrict__ keys_in, const int* __restrict__ vals_in, int n, int shift, int nb,
+                                                              const int* __restrict__ offs /*[256][nb] exclusive*/, unsigned* __restrict__ keys_out, int* __restrict__ vals_out) {
+    __shared__ int base[256];                 // running offset of each digit inside this tile
+    __shared__ int wcnt[kSortBlock / 64][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    base[threadIdx.x] = offs[threadIdx.x * nb + blockIdx.x];
+    const int tile = blockIdx.x * kSortTile8;
+    for (int r = 0; r < kSortItems8; r++) {
+        const int i = tile + r * kSortBlock + threadIdx.x;
+        const bool live = i < n;
+        const unsigned key = live ? keys_in[i] : 0u;
+        const int val = live ? vals_in[i] : 0;
+        const int d = live ? (int)((key >> shift) & 255u) : 256;
+        unsigned long long peers = __ballot(live);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const unsigned long long m = __ballot((d >> b) & 1);
+            peers &= ((d >> b) & 1) ? m : ~m;
+        }
+        const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+#pragma unroll
+        for (int w = 0; w < kSortBlock / 64; w++) wcnt[w][threadIdx.x] = 0;
+        __syncthreads();
+        if (live && rank == 0) wcnt[wave][d] = __popcll(peers);
+        __syncthreads();
+        if (live) {
+            int off = base[d];
+            for (int w = 0; w < wave; w++) off += wcnt[w][d];
+            keys_out[off + rank] = key;
+            vals_out[off + rank] = val;
+        }
+        __syncthreads();
+        { int s = 0; for (int w = 0; w < kSortBlock / 64; w++) s += wcnt[w][threadIdx.x]; base[threadIdx.x] += s; }
+        __syncthreads();
+    }
+}
+
 struct VoxDev { float inv_leaf; int min_b[3]; int mul[3]; unsigned sentinel; };   // sentinel = number of voxels of the bounding box: key of non-finite points
 
 __global__ void k_vox_key(const float4* __restrict__ pts, int n, VoxDev V, unsigned* __restrict__ keys, int* __restrict__ vals) {
@@ -134,6 +189,101 @@ __global__ void k_vox_centroid(const unsigned* __restrict__ keys, const int* __r
     if (out_cnt) out_cnt[o] = c;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Incremental local map (round 3; the reference pops one keyframe and pushes one per step, L/src/BackendFusion.cpp:1407-1477, where
+// lili_localmap_commit used to re-concatenate, re-sort and re-reduce the whole ring).  The ring's points are kept SORTED by an absolute
+// voxel key — (k, j, i) = floor(p * inverse_leaf) packed lexicographically, which is the order pcl::VoxelGrid's box-relative index
+// induces whatever the bounding box is — with older keyframes first inside a voxel, i.e. exactly the order the stable sort of the
+// concatenated cloud produces.  A step then is: sort the NEW keyframe alone (20 k points), drop the popped keyframe's entries and merge the
+// new ones in one streaming pass (ranks by prefix sum and binary search, no comparison network), and run the centroid pass — the same f32
+// sums over the same members in the same order, so the map is bit-identical to the full rebuild (tests/test_voxel_gpu.py).
+// ------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long abs_voxel_key(float4 p, float inv_leaf) {
+    if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) return ~0ull;               // sorts last, never a voxel (voxel_grid.hpp: !isFinite -> skipped)
+    const long long i = (long long)floorf(p.x * inv_leaf) + (1ll << 20), j = (long long)floorf(p.y * inv_leaf) + (1ll << 20), k = (long long)floorf(p.z * inv_leaf) + (1ll << 20);
+    if ((i | j | k) < 0 || i >= (1ll << 21) || j >= (1ll << 21) || k >= (1ll << 21)) return ~0ull - 1ull;      // beyond +-2^20 voxels: the host falls back to the full rebuild (flagged)
+    return ((unsigned long long)k << 42) | ((unsigned long long)j << 21) | (unsigned long long)i;
+}
+// sorted copy of one cloud: out_pt[r] = pts[order[r]], its absolute key and a constant sequence number; *bad is raised if a point lies outside the key range
+__global__ void k_sorted_gather(const float4* __restrict__ pts, const int* __restrict__ order, int n, float inv_leaf, unsigned seq_const, const lili_detail::ConcatSeg* __restrict__ segs,
+                                const unsigned* __restrict__ seg_seq, int n_seg, float4* __restrict__ out_pt, unsigned long long* __restrict__ out_key, unsigned* __restrict__ out_seq,
+                                unsigned* __restrict__ bad) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int src = order[r];
+    const float4 p = pts[src];
+    const unsigned long long key = abs_voxel_key(p, inv_leaf);
+    if (key == ~0ull - 1ull) *bad = 1u;
+    unsigned sq = seq_const;
+    if (segs) {          // the cloud is the concatenation of the ring: the keyframe of a point by bisection over the segments' first positions
+        int lo = 0, hi = n_seg - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (segs[mid].first <= (long long)src) lo = mid; else hi = mid - 1; }
+        sq = seg_seq[lo];
+    }
+    out_pt[r] = p; out_key[r] = key; out_seq[r] = sq;
+}
+struct DropSeqs { unsigned s[4]; int n; };
+__global__ void k_keep_flags(const unsigned* __restrict__ seq, long long n, DropSeqs d, int* __restrict__ flags) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned q = seq[i];
+    bool drop = false;
+#pragma unroll
+    for (int k = 0; k < 4; k++) drop = drop || (k < d.n && q == d.s[k]);
+    flags[i] = drop ? 0 : 1;
+}
+// kept entry i of the old list goes to (kept entries before it) + (new entries with a SMALLER key: new ones follow old ones of the same voxel)
+__global__ void k_merge_old(const unsigned long long* __restrict__ key, const float4* __restrict__ pt, const unsigned* __restrict__ seq, const int* __restrict__ flags,
+                            const int* __restrict__ rank /*exclusive scan of flags, [n+1]*/, long long n, const unsigned long long* __restrict__ nkey, int n_new,
+                            unsigned long long* __restrict__ okey, float4* __restrict__ opt, unsigned* __restrict__ oseq) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flags[i]) return;
+    const unsigned long long k = key[i];
+    int lo = 0, hi = n_new;                       // lower_bound(nkey, k)
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (nkey[mid] < k) lo = mid + 1; else hi = mid; }
+    const long long pos = (long long)rank[i] + lo;
+    okey[pos] = k; opt[pos] = pt[i]; oseq[pos] = seq[i];
+}
+// new entry j goes to j + (kept old entries with key <= its key)
+__global__ void k_merge_new(const unsigned long long* __restrict__ nkey, const float4* __restrict__ npt, int n_new, unsigned nseq, const unsigned long long* __restrict__ key,
+                            const int* __restrict__ rank, long long n, unsigned long long* __restrict__ okey, float4* __restrict__ opt, unsigned* __restrict__ oseq) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_new) return;
+    const unsigned long long k = nkey[j];
+    long long lo = 0, hi = n;                     // upper_bound(key, k)
+    while (lo < hi) { const long long mid = (lo + hi) >> 1; if (key[mid] <= k) lo = mid + 1; else hi = mid; }
+    const long long pos = (long long)j + (long long)rank[lo];
+    okey[pos] = k; opt[pos] = npt[j]; oseq[pos] = nseq;
+}
+__global__ void k_vox_heads64(const unsigned long long* __restrict__ keys, long long n, int* __restrict__ flags) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = (keys[i] < ~0ull - 1ull && (i == 0 || keys[i] != keys[i - 1])) ? 1 : 0;
+}
+// k_vox_centroid on the sorted ring: members are consecutive, no indirection; the same sequential f32 sums
+__global__ void k_vox_centroid64(const unsigned long long* __restrict__ keys, const float4* __restrict__ pts, const int* __restrict__ slot, long long n,
+                                 float4* __restrict__ out, int* __restrict__ out_cnt) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long k = keys[i];
+    if (k >= ~0ull - 1ull || !(i == 0 || keys[i - 1] != k)) return;
+    float sx = 0.f, sy = 0.f, sz = 0.f, sa = 0.f; int c = 0;
+    bool more = true;
+    for (long long m = i; more && m < n; m += 8) {
+        unsigned long long kk[8]; float4 pp[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const long long mm = m + u < n ? m + u : n - 1; kk[u] = keys[mm]; pp[u] = pts[mm]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (more && m + u < n && kk[u] == k) { sx += pp[u].x; sy += pp[u].y; sz += pp[u].z; sa += pp[u].w; c++; }
+            else more = false;
+        }
+    }
+    const float fn = (float)c;
+    const int o = slot[i];
+    out[o] = make_float4(sx / fn, sy / fn, sz / fn, sa / fn);
+    if (out_cnt) out_cnt[o] = c;
+}
+
 // transformCloud — L/src/BackendFusion.cpp:713-790: p' = q * p + t in f64, stored f32; aux carried along
 __global__ void k_transform_cloud(const float4* __restrict__ in, int n, dq q, d3 t, float4* __restrict__ out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -146,15 +296,32 @@ __global__ void k_transform_cloud(const float4* __restrict__ in, int n, dq q, d3
 }  // namespace lili
 
 namespace lili_detail {
-struct Keyframe { DevBuf pts; int n = 0; };
-struct ConcatSeg { const float4* src; long long first; };      // one keyframe of the ring: its points and where they start in the concatenation
+struct Keyframe { DevBuf pts; int n = 0; unsigned seq = 0; };
+// the ring of one kind, sorted by absolute voxel key (older keyframes first inside a voxel): see k_merge_old / k_merge_new
+struct SortedRing {
+    DevBuf key[2], pt[2], seq[2];
+    int cur = 0;
+    long long n = 0;
+    float leaf = 0.f;
+    bool valid = false;
+    std::vector<std::pair<unsigned, int>> members;      // (sequence number, points) of the keyframes it holds, oldest first
+    void release() { for (int b = 0; b < 2; b++) { key[b].release(); pt[b].release(); seq[b].release(); } valid = false; n = 0; members.clear(); }
+};
 struct VoxelBuffers {
     DevBuf keys_a, keys_b, vals_a, vals_b, hist, hist_scan, sums, flags, slots, out, out_cnt, in, concat, concat_tab;
     std::vector<Keyframe*> ring[2];    // per kind, oldest first
+    SortedRing sorted[2];
+    unsigned next_seq = 1;
+    DevBuf kf_key, kf_pt, seg_seq;     // the new keyframe sorted by key; sequence numbers of the concatenation's segments
+    std::vector<unsigned> seg_seq_host;
+    int incremental_commits = 0, full_commits = 0;
+    std::vector<ConcatSeg> seg_host;   // the table k_concat reads, kept alive until the upload has certainly happened (an async copy from a local vector)
     int n_out = 0;
     void release() {
         for (DevBuf* b : {&keys_a, &keys_b, &vals_a, &vals_b, &hist, &hist_scan, &sums, &flags, &slots, &out, &out_cnt, &in, &concat, &concat_tab}) b->release();
         for (auto& r : ring) { for (auto* k : r) { k->pts.release(); delete k; } r.clear(); }
+        for (auto& sr : sorted) sr.release();
+        kf_key.release(); kf_pt.release(); seg_seq.release();
     }
 };
 }  // namespace lili_detail
@@ -219,32 +386,34 @@ static int exclusive_scan(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const int
     return LILI_OK;
 }
 
-// sorts (keys_a, vals_a) by the low `bits` bits; result ends in (keys_a, vals_a)
+// sorts (keys_a, vals_a) by the low `bits` bits, stable; result ends in (keys_a, vals_a).  8-bit digits (option sort_digit_bits = 4: the
+// round-2 passes, for A/B)
 static int radix_sort(lili_ctx* ctx, lili_detail::VoxelBuffers* V, int n, int bits) {
-    const int nb = nblocks(n, kSortTile);
-    HIPCHK(V->hist.ensure((size_t)16 * nb * sizeof(int)));
-    HIPCHK(V->hist_scan.ensure(((size_t)16 * nb + 1) * sizeof(int)));
+    const int dbits = ctx->sort_digit_bits == 4 ? 4 : 8, ndig = 1 << dbits;
+    const int nb = nblocks(n, dbits == 8 ? kSortTile8 : kSortTile);
+    HIPCHK(V->hist.ensure((size_t)ndig * nb * sizeof(int)));
+    HIPCHK(V->hist_scan.ensure(((size_t)ndig * nb + 1) * sizeof(int)));
     HIPCHK(V->keys_b.ensure((size_t)n * 4)); HIPCHK(V->vals_b.ensure((size_t)n * 4));
-    unsigned *ka = V->keys_a.as<unsigned>(), *kb = V->keys_b.as<unsigned>();
-    int *va = V->vals_a.as<int>(), *vb = V->vals_b.as<int>();
-    int passes = (bits + 3) / 4;
-    if (passes & 1) passes++;   // even number of passes so that the result lands in the `a` buffers (extra pass sorts zero digits: identity)
+    const int passes = std::max(1, (bits + dbits - 1) / dbits);
     for (int p = 0; p < passes; p++) {
-        const int shift = 4 * p;   // <= 28: bits <= 31 because the voxel index fits int32
-        hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(kSortBlock), 0, ctx->stream, ka, n, shift, nb, V->hist.as<int>());
-        int rc = exclusive_scan(ctx, V, V->hist.as<int>(), (int64_t)16 * nb, V->hist_scan.as<int>());
+        const int shift = dbits * p;
+        unsigned *ka = V->keys_a.as<unsigned>(), *kb = V->keys_b.as<unsigned>();
+        int *va = V->vals_a.as<int>(), *vb = V->vals_b.as<int>();
+        if (dbits == 8) hipLaunchKernelGGL(k_sort_hist8, dim3(nb), dim3(kSortBlock), 0, ctx->stream, ka, n, shift, nb, V->hist.as<int>());
+        else hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(kSortBlock), 0, ctx->stream, ka, n, shift, nb, V->hist.as<int>());
+        int rc = exclusive_scan(ctx, V, V->hist.as<int>(), (int64_t)ndig * nb, V->hist_scan.as<int>());
         if (rc != LILI_OK) return rc;
-        hipLaunchKernelGGL(k_sort_scatter, dim3(nb), dim3(kSortBlock), 0, ctx->stream, ka, va, n, shift, nb, V->hist_scan.as<int>(), kb, vb);
+        if (dbits == 8) hipLaunchKernelGGL(k_sort_scatter8, dim3(nb), dim3(kSortBlock), 0, ctx->stream, ka, va, n, shift, nb, V->hist_scan.as<int>(), kb, vb);
+        else hipLaunchKernelGGL(k_sort_scatter, dim3(nb), dim3(kSortBlock), 0, ctx->stream, ka, va, n, shift, nb, V->hist_scan.as<int>(), kb, vb);
         HIPCHK(hipGetLastError());
-        std::swap(ka, kb); std::swap(va, vb);
+        V->keys_a.swap(V->keys_b); V->vals_a.swap(V->vals_b);      // the sorted pairs are the new `a` (buffers trade places, nothing is copied)
     }
     return LILI_OK;
 }
 
-// VoxelGrid of a device float4 cloud; result in V->out / V->out_cnt, V->n_out.  Blocking (two small read-backs).
-static int voxel_filter_device(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const float4* d_pts, int n, float leaf) {
-    V->n_out = 0;
-    if (n == 0) return LILI_OK;
+// Stable order of a device cloud by pcl::VoxelGrid's voxel index (box-relative, App. B2): keys in V->keys_a, the order (source indices) in
+// V->vals_a.  Blocking: the bounding box is read back.
+static int voxel_sort(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const float4* d_pts, int n, float leaf, VoxDev& P) {
     unsigned init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
     unsigned* d_mm = ctx->misc.as<unsigned>();
     HIPCHK(hipMemcpyAsync(d_mm, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
@@ -253,7 +422,7 @@ static int voxel_filter_device(lili_ctx* ctx, lili_detail::VoxelBuffers* V, cons
     HIPCHK(hipMemcpyAsync(mm, d_mm, sizeof(mm), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     auto dec = [](unsigned u) { unsigned b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u; float f; std::memcpy(&f, &b, 4); return f; };
-    VoxDev P{};
+    P = VoxDev{};
     P.inv_leaf = 1.0f / leaf;
     int div_b[3];
     for (int k = 0; k < 3; k++) {
@@ -268,11 +437,19 @@ static int voxel_filter_device(lili_ctx* ctx, lili_detail::VoxelBuffers* V, cons
     P.sentinel = (unsigned)total;                 // <= 2^31 - 1
     int bits = 1; while (bits < 32 && (1ull << bits) < (unsigned long long)total + 1ull) bits++;   // keys 0 .. total (sentinel included)
     HIPCHK(V->keys_a.ensure((size_t)n * 4)); HIPCHK(V->vals_a.ensure((size_t)n * 4));
+    hipLaunchKernelGGL(k_vox_key, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, d_pts, n, P, V->keys_a.as<unsigned>(), V->vals_a.as<int>());
+    return radix_sort(ctx, V, n, bits);
+}
+
+// VoxelGrid of a device float4 cloud; result in V->out / V->out_cnt, V->n_out.  Blocking (two small read-backs).
+static int voxel_filter_device(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const float4* d_pts, int n, float leaf) {
+    V->n_out = 0;
+    if (n == 0) return LILI_OK;
+    VoxDev P;
+    int rc = voxel_sort(ctx, V, d_pts, n, leaf, P);
+    if (rc != LILI_OK) return rc;
     HIPCHK(V->flags.ensure((size_t)n * 4)); HIPCHK(V->slots.ensure(((size_t)n + 1) * 4));
     HIPCHK(V->out.ensure((size_t)n * 16)); HIPCHK(V->out_cnt.ensure((size_t)n * 4));
-    hipLaunchKernelGGL(k_vox_key, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, d_pts, n, P, V->keys_a.as<unsigned>(), V->vals_a.as<int>());
-    int rc = radix_sort(ctx, V, n, bits);
-    if (rc != LILI_OK) return rc;
     hipLaunchKernelGGL(k_vox_heads, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, V->keys_a.as<unsigned>(), n, P.sentinel, V->flags.as<int>());
     rc = exclusive_scan(ctx, V, V->flags.as<int>(), n, V->slots.as<int>());
     if (rc != LILI_OK) return rc;
@@ -316,6 +493,7 @@ int lili_localmap_reset(lili_ctx* ctx, int kind) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
     for (auto* k : V->ring[kind]) { k->pts.release(); delete k; }
     V->ring[kind].clear();
+    V->sorted[kind].valid = false; V->sorted[kind].n = 0; V->sorted[kind].members.clear();
     return LILI_OK;
 }
 
@@ -328,6 +506,7 @@ int lili_localmap_push(lili_ctx* ctx, int kind, const lili_cloud* features, cons
     if (rc != LILI_OK) return rc;
     auto* kf = new lili_detail::Keyframe();
     kf->n = (int)features->n;
+    kf->seq = V->next_seq++;
     if (kf->n > 0) {
         hipError_t e = kf->pts.ensure((size_t)kf->n * 16);
         if (e != hipSuccess) { delete kf; return ctx->fail(LILI_E_HIP, "localmap_push: allocation failed"); }
@@ -346,21 +525,105 @@ int lili_localmap_push(lili_ctx* ctx, int kind, const lili_cloud* features, cons
     return LILI_OK;
 }
 
+// One keyframe step on the sorted ring: drop the entries of the keyframes in `drop`, merge the keyframe `add` (may be null) in.
+static int sorted_ring_step(lili_ctx* ctx, lili_detail::VoxelBuffers* V, lili_detail::SortedRing& S, const DropSeqs& drop, long long n_drop, lili_detail::Keyframe* add, float leaf,
+                            unsigned* d_bad) {
+    int n_new = add ? add->n : 0;
+    if (n_new > 0) {       // the new keyframe alone, sorted by voxel (stable): 20 k points
+        VoxDev P;
+        int rc = voxel_sort(ctx, V, add->pts.as<float4>(), n_new, leaf, P);
+        if (rc != LILI_OK) return rc;
+        HIPCHK(V->kf_key.ensure((size_t)n_new * 8)); HIPCHK(V->kf_pt.ensure((size_t)n_new * 16)); HIPCHK(V->flags.ensure((size_t)std::max<long long>(n_new, S.n) * 4));
+        hipLaunchKernelGGL(k_sorted_gather, dim3(nblocks(n_new, 256)), dim3(256), 0, ctx->stream, add->pts.as<float4>(), V->vals_a.as<int>(), n_new, 1.0f / leaf, add->seq,
+                           (const lili_detail::ConcatSeg*)nullptr, (const unsigned*)nullptr, 0, V->kf_pt.as<float4>(), V->kf_key.as<unsigned long long>(), V->flags.as<unsigned>(), d_bad);
+    }
+    const long long n_old = S.n, n_out = n_old - n_drop + n_new;
+    const int dst = 1 - S.cur;
+    HIPCHK(S.key[dst].ensure((size_t)std::max<long long>(n_out, 1) * 8)); HIPCHK(S.pt[dst].ensure((size_t)std::max<long long>(n_out, 1) * 16)); HIPCHK(S.seq[dst].ensure((size_t)std::max<long long>(n_out, 1) * 4));
+    HIPCHK(V->flags.ensure((size_t)std::max<long long>(n_old, 1) * 4)); HIPCHK(V->slots.ensure(((size_t)n_old + 1) * 4));
+    if (n_old > 0) {
+        hipLaunchKernelGGL(k_keep_flags, dim3(nblocks(n_old, 256)), dim3(256), 0, ctx->stream, S.seq[S.cur].as<unsigned>(), n_old, drop, V->flags.as<int>());
+        int rc = exclusive_scan(ctx, V, V->flags.as<int>(), n_old, V->slots.as<int>());
+        if (rc != LILI_OK) return rc;
+        hipLaunchKernelGGL(k_merge_old, dim3(nblocks(n_old, 256)), dim3(256), 0, ctx->stream, S.key[S.cur].as<unsigned long long>(), S.pt[S.cur].as<float4>(), S.seq[S.cur].as<unsigned>(),
+                           V->flags.as<int>(), V->slots.as<int>(), n_old, V->kf_key.as<unsigned long long>(), n_new, S.key[dst].as<unsigned long long>(), S.pt[dst].as<float4>(),
+                           S.seq[dst].as<unsigned>());
+    } else HIPCHK(hipMemsetAsync(V->slots.p, 0, 4, ctx->stream));
+    if (n_new > 0)
+        hipLaunchKernelGGL(k_merge_new, dim3(nblocks(n_new, 256)), dim3(256), 0, ctx->stream, V->kf_key.as<unsigned long long>(), V->kf_pt.as<float4>(), n_new, add->seq,
+                           S.key[S.cur].as<unsigned long long>(), V->slots.as<int>(), n_old, S.key[dst].as<unsigned long long>(), S.pt[dst].as<float4>(), S.seq[dst].as<unsigned>());
+    HIPCHK(hipGetLastError());
+    S.cur = dst; S.n = n_out;
+    return LILI_OK;
+}
+
 int lili_localmap_commit(lili_ctx* ctx, int kind, float leaf, double max_sq_radius, int64_t* n_raw, int64_t* n_map) {
     if (!ctx) return LILI_E_ARG;
     ARGCHK((kind == 0 || kind == 1) && leaf > 0, "localmap_commit: bad argument");
     HIPCHK(hipSetDevice(ctx->device));
     auto* V = vox_of(ctx);
+    auto& ring = V->ring[kind];
+    lili_detail::SortedRing& S = V->sorted[kind];
     size_t total = 0;
-    for (auto* k : V->ring[kind]) total += (size_t)k->n;
+    for (auto* k : ring) total += (size_t)k->n;
     if (n_raw) *n_raw = (int64_t)total;
-    HIPCHK(V->concat.ensure(std::max<size_t>(total, 1) * 16));
-    // *surf_local_map += *recent_surf_keyframes[i] (L:1479-1483): ONE gather launch over a table of (source, first output position) per keyframe —
-    // fifty device-to-device copies of ~300 KB cost ~2 us each on the stream (0.12 ms per commit)
-    {
-        std::vector<lili_detail::ConcatSeg> segs;
+    unsigned* d_bad = reinterpret_cast<unsigned*>(ctx->misc.as<char>() + 256);      // (the bounding-box words of voxel_sort live in the first 24 bytes)
+    // ---- what changed since the sorted ring was built: keyframes popped at the front, keyframes pushed at the back
+    bool inc = ctx->localmap_incremental && S.valid && S.leaf == leaf && S.n > 0 && !ring.empty() && total < (1ull << 31);
+    DropSeqs drop{}; long long n_drop = 0;
+    std::vector<lili_detail::Keyframe*> add;
+    if (inc) {
+        size_t f = 0;
+        while (f < S.members.size() && S.members[f].first != ring.front()->seq) f++;
+        if (f == S.members.size() || f > 4) inc = false;
+        else {
+            for (size_t i = 0; i < f; i++) { drop.s[i] = S.members[i].first; n_drop += S.members[i].second; }
+            drop.n = (int)f;
+            size_t m = 0;
+            while (f + m < S.members.size() && m < ring.size() && S.members[f + m].first == ring[m]->seq) m++;
+            if (f + m != S.members.size()) inc = false;                    // the ring is not "old members, then new keyframes"
+            for (size_t i = m; i < ring.size(); i++) add.push_back(ring[i]);
+            if (add.size() > 2) inc = false;                               // several pending keyframes: the rebuild is cheaper than as many merge passes
+        }
+    }
+    if (inc) {
+        // ---- incremental step(s): the merge, then the centroid pass over the sorted ring
+        HIPCHK(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+        int rc = LILI_OK;
+        if (add.empty()) rc = sorted_ring_step(ctx, V, S, drop, n_drop, nullptr, leaf, d_bad);
+        for (size_t i = 0; i < add.size() && rc == LILI_OK; i++) rc = sorted_ring_step(ctx, V, S, i == 0 ? drop : DropSeqs{}, i == 0 ? n_drop : 0, add[i], leaf, d_bad);
+        if (rc != LILI_OK) { S.valid = false; return rc; }
+        S.members.clear();
+        for (auto* k : ring) S.members.push_back({k->seq, k->n});
+        const long long n = S.n;
+        V->n_out = 0;
+        unsigned bad = 0;
+        if (n > 0) {
+            HIPCHK(V->flags.ensure((size_t)n * 4)); HIPCHK(V->slots.ensure(((size_t)n + 1) * 4));
+            HIPCHK(V->out.ensure((size_t)n * 16)); HIPCHK(V->out_cnt.ensure((size_t)n * 4));
+            hipLaunchKernelGGL(k_vox_heads64, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, S.key[S.cur].as<unsigned long long>(), n, V->flags.as<int>());
+            rc = exclusive_scan(ctx, V, V->flags.as<int>(), n, V->slots.as<int>());
+            if (rc != LILI_OK) return rc;
+            hipLaunchKernelGGL(k_vox_centroid64, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, S.key[S.cur].as<unsigned long long>(), S.pt[S.cur].as<float4>(), V->slots.as<int>(), n,
+                               V->out.as<float4>(), V->out_cnt.as<int>());
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(&V->n_out, V->slots.as<int>() + n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        }
+        HIPCHK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (bad) { S.valid = false; inc = false; }      // a point beyond the absolute key range: the box-relative rebuild below handles it
+        else V->incremental_commits++;
+    }
+    if (!inc) {
+        // ---- full rebuild: concatenate, sort, reduce
+        HIPCHK(V->concat.ensure(std::max<size_t>(total, 1) * 16));
+        // *surf_local_map += *recent_surf_keyframes[i] (L:1479-1483): ONE gather launch over a table of (source, first output position) per keyframe —
+        // fifty device-to-device copies of ~300 KB cost ~2 us each on the stream (0.12 ms per commit)
+        std::vector<lili_detail::ConcatSeg>& segs = V->seg_host;      // members, not locals: hipMemcpyAsync may read them after this block
+        std::vector<unsigned>& sseq = V->seg_seq_host;
+        segs.clear(); sseq.clear();
         size_t off = 0;
-        for (auto* k : V->ring[kind]) { if (k->n) segs.push_back({k->pts.as<float4>(), (long long)off}); off += (size_t)k->n; }
+        for (auto* k : ring) { if (k->n) { segs.push_back({k->pts.as<float4>(), (long long)off}); sseq.push_back(k->seq); } off += (size_t)k->n; }
         if (!segs.empty()) {
             HIPCHK(V->concat_tab.ensure(segs.size() * sizeof(lili_detail::ConcatSeg)));
             HIPCHK(hipMemcpyAsync(V->concat_tab.p, segs.data(), segs.size() * sizeof(lili_detail::ConcatSeg), hipMemcpyHostToDevice, ctx->stream));
@@ -368,12 +631,60 @@ int lili_localmap_commit(lili_ctx* ctx, int kind, float leaf, double max_sq_radi
                                (long long)total, V->concat.as<float4>());
             HIPCHK(hipGetLastError());
         }
+        int rc = voxel_filter_device(ctx, V, V->concat.as<float4>(), (int)total, leaf);   // ds_filter_*_map.filter (L:1488-1492)
+        if (rc != LILI_OK) return rc;
+        V->full_commits++;
+        // the sorted ring for the following steps: the order the sort has just produced, with absolute keys and the keyframe of every point
+        S.valid = false;
+        if (ctx->localmap_incremental && total > 0 && total < (1ull << 31) && !segs.empty()) {
+            HIPCHK(S.key[0].ensure(total * 8)); HIPCHK(S.pt[0].ensure(total * 16)); HIPCHK(S.seq[0].ensure(total * 4));
+            HIPCHK(V->seg_seq.ensure(sseq.size() * 4));
+            HIPCHK(hipMemcpyAsync(V->seg_seq.p, sseq.data(), sseq.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+            hipLaunchKernelGGL(k_sorted_gather, dim3(nblocks((int64_t)total, 256)), dim3(256), 0, ctx->stream, V->concat.as<float4>(), V->vals_a.as<int>(), (int)total, 1.0f / leaf, 0u,
+                               V->concat_tab.as<lili_detail::ConcatSeg>(), V->seg_seq.as<unsigned>(), (int)segs.size(), S.pt[0].as<float4>(), S.key[0].as<unsigned long long>(),
+                               S.seq[0].as<unsigned>(), d_bad);
+            HIPCHK(hipGetLastError());
+            unsigned bad = 0;
+            HIPCHK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            S.cur = 0; S.n = (long long)total; S.leaf = leaf; S.valid = bad == 0;
+            S.members.clear();
+            for (auto* k : ring) S.members.push_back({k->seq, k->n});
+        }
     }
-    int rc = voxel_filter_device(ctx, V, V->concat.as<float4>(), (int)total, leaf);   // ds_filter_*_map.filter (L:1488-1492)
-    if (rc != LILI_OK) return rc;
     if (n_map) *n_map = V->n_out;
     lili_cloud c{V->out.p, (size_t)V->n_out, 16, 12, LILI_MEM_DEVICE};
     return lili_map_set(ctx, kind, &c, max_sq_radius);                                   // setInputCloud (L:839-840)
+}
+
+// The cloud the last lili_localmap_commit (or lili_voxel_filter) produced: the down-sampled local map in map order (what the reference
+// publishes as its local map and hands to setInputCloud).  Blocking.
+int lili_localmap_get(lili_ctx* ctx, lili_feature_out* out) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(out, "localmap_get: null out");
+    HIPCHK(hipSetDevice(ctx->device));
+    auto* V = vox_of(ctx);
+    out->count = (size_t)V->n_out;
+    const size_t k = std::min(out->count, out->capacity);
+    if (out->data && k) {
+        const size_t stride = out->stride ? out->stride : 16;
+        ARGCHK(stride >= 16, "localmap_get: stride must be >= 16");
+        const hipMemcpyKind kind = out->mem == LILI_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+        if (stride == 16) HIPCHK(hipMemcpyAsync(out->data, V->out.p, k * 16, kind, ctx->stream));
+        else HIPCHK(hipMemcpy2DAsync(out->data, stride, V->out.p, 16, 16, k, kind, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    return LILI_OK;
+}
+
+// how the commits of this context were served so far (tests, tools): incremental steps on the sorted ring / full rebuilds
+int lili_localmap_stats(lili_ctx* ctx, int32_t* incremental_commits, int32_t* full_commits) {
+    if (!ctx) return LILI_E_ARG;
+    auto* V = vox_of(ctx);
+    if (incremental_commits) *incremental_commits = V->incremental_commits;
+    if (full_commits) *full_commits = V->full_commits;
+    return LILI_OK;
 }
 
 }  // extern "C"

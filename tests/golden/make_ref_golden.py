@@ -299,3 +299,42 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+# ---- reference functor rows of given correspondence records (tests/test_reference_gpu.py::test_gpu_linearize_vs_reference_functors) ----
+def functor_rows(R, rs, re_, qlb, tlb, ss, se, t0, q0):
+    """[J(7) r] rows of LidarPlaneNormFactor / LidarEdgeFactor ::Create()->Evaluate() (oracle/_ref/libref_factors.so = the reference's
+    LidarKeyframeFactor.h compiled as is) for the surf records rs (cp, n, d, score) and the edge records re_ (cp, a, b, s)."""
+    ns, ne = len(rs["d"]), len(re_["s"])
+    rows_s = np.zeros((ns, 8))
+    for i in range(ns):
+        o = R.plane_factor(np.asarray(rs["cp"][i], np.float64), np.asarray(rs["n"][i], np.float64), qlb, tlb, float(rs["d"][i]), float(rs["score"][i]) * ss, t0, q0)
+        rows_s[i] = np.r_[o[1:8], o[0]]
+    rows_e = np.zeros((ne, 8))
+    for i in range(ne):
+        o = R.edge_factor(np.asarray(re_["cp"][i], np.float64), np.asarray(re_["a"][i], np.float64), np.asarray(re_["b"][i], np.float64), qlb, tlb, float(re_["s"][i]) * se, t0, q0)
+        rows_e[i] = np.r_[o[1:8], o[0]]
+    return rows_s, rows_e
+
+
+def make_functor_fixture(inputs_npz, out_npz):
+    """inputs: gpurun_out/functor_inputs.npz written by tools/dump_functor_inputs.py ON THE GPU (the records lili_s2m_associate produced for the
+    scene of the test, both variants); output: the same records + the reference functors' rows -> tests/golden/ref_functor_rows.npz."""
+    sys.path.insert(0, ROOT)
+    from oracle import ref as R
+    assert R.available(), "build oracle/_ref first (make -C oracle/refshim)"
+    d = np.load(inputs_npz)
+    out = {}
+    for variant in ("livox", "rot"):
+        rs = {k: d[f"{variant}_s_{k}"] for k in ("cp", "n", "d", "score")}
+        re_ = {k: d[f"{variant}_e_{k}"] for k in ("cp", "a", "b", "s")}
+        qlb, tlb, t0, q0 = d[f"{variant}_qlb"], d[f"{variant}_tlb"], d[f"{variant}_t0"], d[f"{variant}_q0"]
+        ss, se = float(d[f"{variant}_ss"]), float(d[f"{variant}_se"])
+        rows_s, rows_e = functor_rows(R, rs, re_, qlb, tlb, ss, se, t0, q0)
+        for k, v in rs.items():
+            out[f"{variant}_s_{k}"] = v
+        for k, v in re_.items():
+            out[f"{variant}_e_{k}"] = v
+        out[f"{variant}_rows_s"], out[f"{variant}_rows_e"] = rows_s, rows_e
+    np.savez_compressed(out_npz, **out)
+    return out

@@ -36,6 +36,24 @@ def _q_imu(integ, stamps, imu_t, gyr, k):
     return integ.integrate(imu_t[m], gyr[m], stamps[k + 1])
 
 
+def _surf_voxel_counts(full, lessflat_idx, leaf=0.6, n_rings=64):
+    """Points per output row of the per-ring pcl::VoxelGrid(leaf) over the less-flat points (R/src/Preprocessing.cpp:502-506): voxel indices in
+    PCL's own f32 arithmetic (floor(p * inverse_leaf), box offsets), rows in ascending voxel id ring after ring — the order of /surf_features."""
+    inv = np.float32(1.0) / np.float32(leaf)
+    ring = full[lessflat_idx, 3].astype(np.int32)
+    out = []
+    for r in range(n_rings):
+        p = full[lessflat_idx[ring == r]]
+        if p.shape[0] == 0:
+            continue
+        ijk = np.floor(p[:, :3].astype(np.float32) * inv).astype(np.int64)
+        mn = ijk.min(0)
+        d = ijk.max(0) - mn + 1
+        idx = (ijk[:, 0] - mn[0]) + (ijk[:, 1] - mn[1]) * d[0] + (ijk[:, 2] - mn[2]) * d[0] * d[1]
+        out.append(np.unique(idx, return_counts=True)[1])
+    return np.concatenate(out) if out else np.zeros(0, np.int64)
+
+
 def test_gpu_rot_extractor_vs_reference(gpu_ctx):
     g = np.load(os.path.join(G, "ref_rot.npz"))
     scans, stamps, imu_t, gyr = M.rot_inputs()
@@ -52,8 +70,14 @@ def test_gpu_rot_extractor_vs_reference(gpu_ctx):
         assert np.array_equal(_bits(out["edge"]), _bits(g[f"edge{k}"]))
         assert np.array_equal(out["edge_idx"], g[f"edge_src{k}"])
         # /surf_features are VoxelGrid centroids: PCL sums the points of a voxel in std::sort's (unspecified) order, the GPU in index
-        # order — last-bit differences in voxels of >= 3 points only
-        assert (_bits(out["surf"]) == _bits(g[f"surf{k}"])).all(1).mean() > 0.9
+        # order.  A sum of ONE or TWO f32 values does not depend on the order, so every row that differs must belong to a voxel of >= 3
+        # points — and differ by rounding only (the former `> 0.9` said neither).
+        same = (_bits(out["surf"]) == _bits(g[f"surf{k}"])).all(1)
+        counts = _surf_voxel_counts(out["full"], out["lessflat_idx"])
+        assert counts.shape[0] == out["surf"].shape[0] and (counts >= 1).all()
+        assert same.mean() > 0.95 and (counts[~same] >= 3).all(), (same.mean(), counts[~same].min() if (~same).any() else None)
+        ulp = np.abs(_bits(out["surf"])[~same].astype(np.int64) - _bits(g[f"surf{k}"])[~same].astype(np.int64))
+        assert ulp.max(initial=0) <= 4, ulp.max(initial=0)
 
 
 def test_gpu_livox_extractor_vs_reference(gpu_ctx):
@@ -89,8 +113,12 @@ def test_gpu_linearize_vs_reference_functors(gpu_ctx, variant):
     summed in numpy.  No oracle restatement in the loop."""
     from oracle import ref as R
     from lili_om_amd import synth
-    if not R.available():
-        pytest.skip("oracle/_ref not built")
+    # The functor rows of the records THIS kernel produces are committed (tests/golden/ref_functor_rows.npz, made by tools/dump_functor_inputs.py on
+    # the GPU + tests/golden/make_ref_golden.py::functor_rows here): the check runs even where the git-ignored oracle/_ref did not travel
+    # (VERDICT r2 #7).  Where it did, the functors are evaluated live as before.
+    fix = np.load(os.path.join(G, "ref_functor_rows.npz")) if os.path.exists(os.path.join(G, "ref_functor_rows.npz")) else None
+    if not R.available() and fix is None:
+        pytest.skip("neither oracle/_ref nor tests/golden/ref_functor_rows.npz")
     room = synth.make_room(seed=12, n_query=1500, n_edge_query=200)
     P = L.make_params(variant)
     m = L.ScanToMapMatcher(gpu_ctx, P)
@@ -108,16 +136,17 @@ def test_gpu_linearize_vs_reference_functors(gpu_ctx, variant):
     qlb, tlb = np.array(list(P.q_lb)), np.array(list(P.t_lb))
     ss = P.scale_surf_num / ns if P.scale_surf_num else 1.0
     se = P.scale_edge_num / ne if P.scale_edge_num else 1.0
-    rows_s = np.zeros((ns, 8))
-    for i in range(ns):
-        o = R.plane_factor(rs["cp"][i].astype(np.float64), rs["n"][i].astype(np.float64), qlb, tlb, float(rs["d"][i]),
-                           float(rs["score"][i]) * ss, t0, q0)
-        rows_s[i] = np.r_[o[1:8], o[0]]
-    rows_e = np.zeros((ne, 8))
-    for i in range(ne):
-        o = R.edge_factor(re_["cp"][i].astype(np.float64), re_["a"][i].astype(np.float64), re_["b"][i].astype(np.float64), qlb, tlb,
-                          float(re_["s"][i]) * se, t0, q0)
-        rows_e[i] = np.r_[o[1:8], o[0]]
+    live = R.available()
+    if live:
+        rows_s, rows_e = M.functor_rows(R, rs, re_, qlb, tlb, ss, se, t0, q0)
+    if fix is not None:
+        # the fixture belongs to exact records: the kernel is deterministic, so they must be the ones it was made from (regenerate it with the two
+        # scripts above when a kernel change moves a record — the assertion says so instead of comparing rows of other records)
+        for key, arr in (("s_cp", rs["cp"]), ("s_n", rs["n"]), ("s_d", rs["d"]), ("s_score", rs["score"]), ("e_cp", re_["cp"]), ("e_a", re_["a"]), ("e_b", re_["b"]), ("e_s", re_["s"])):
+            assert np.array_equal(np.asarray(arr), fix[f"{variant}_{key}"]), f"records changed ({key}): regenerate tests/golden/ref_functor_rows.npz"
+        if live:
+            assert np.array_equal(rows_s, fix[f"{variant}_rows_s"]) and np.array_equal(rows_e, fix[f"{variant}_rows_e"])      # the committed rows ARE the reference's
+        rows_s, rows_e = fix[f"{variant}_rows_s"], fix[f"{variant}_rows_e"]
     for mask, rows in ((L.MASK_SURF, rows_s), (L.MASK_EDGE, rows_e)):
         Gg, cost, counts = m.linearize(0, t0, q0, mask)
         rr = _cauchy_rows(rows)

@@ -134,3 +134,49 @@ def test_device_resident_pipeline_equals_host_round_trip(gpu_ctx, oracle):
     assert st == 0
     assert np.array_equal(t_h, t_d) and np.array_equal(q_h, q_d)
     assert np.linalg.norm(t_d - tb) < 0.5 * np.linalg.norm(t0 - tb)
+
+
+def test_incremental_local_map_equals_full_rebuild(gpu_ctx):
+    """lili_localmap_commit keeps the ring sorted by voxel and merges ONE keyframe per step (the reference pops / pushes one
+    keyframe per step, L/src/BackendFusion.cpp:1407-1477).  A/B against the rebuild-every-time path (option localmap_incremental = 0): the
+    same map, bit for bit and in the same order, at every step — while the ring fills, in the pop / push steady state, with keyframes of
+    different sizes, an empty one, NaN points, two keyframes pushed between commits, a leaf change, and with both radix digit widths."""
+    rng = np.random.default_rng(5)
+
+    def keyframe(k):
+        n = int(rng.integers(300, 4000)) if k != 6 else 0
+        pts = np.concatenate([rng.uniform(-12, 12, (n, 2)) + [0.9 * k, -0.4 * k], rng.uniform(-1.5, 2.5, (n, 1)), rng.uniform(0, 30, (n, 1))], 1).astype(np.float32)
+        if n and k % 4 == 1:
+            pts[rng.integers(0, n, 5), rng.integers(0, 3, 5)] = np.nan
+        ang = 0.07 * k
+        return pts, np.array([0.5 * k, 0.2 * k, 0.01 * k]), np.array([np.cos(ang / 2), 0.0, 0.0, np.sin(ang / 2)])
+    kfs = [keyframe(k) for k in range(18)]
+    # schedule: (keyframes pushed before this commit, leaf)
+    sched = [(1, 0.4)] * 3 + [(2, 0.4)] + [(1, 0.4)] * 6 + [(1, 0.2)] + [(1, 0.2)] * 2 + [(3, 0.2)]
+    runs = {}
+    try:
+        for mode, digits in (("full", 8), ("incremental", 8), ("incremental4", 4)):
+            gpu_ctx.set_option("localmap_incremental", 0 if mode == "full" else 1)
+            gpu_ctx.set_option("sort_digit_bits", digits)
+            lm = L.LocalMap(gpu_ctx, L.KIND_SURF, width=5, leaf=0.4, max_sq_radius=1.0)
+            inc0, full0 = lm.stats()
+            k, maps = 0, []
+            for n_push, leaf in sched:
+                for _ in range(n_push):
+                    lm.push(*kfs[k]); k += 1
+                lm.leaf = leaf
+                n_raw, n_map = lm.commit()
+                maps.append((n_raw, lm.get(n_map + 1)))
+            inc1, full1 = lm.stats()
+            runs[mode] = (maps, inc1 - inc0, full1 - full0)
+    finally:
+        gpu_ctx.set_option("localmap_incremental", 1)
+        gpu_ctx.set_option("sort_digit_bits", 8)
+    ref, n_inc_ref, n_full_ref = runs["full"]
+    assert n_inc_ref == 0 and n_full_ref == len(sched)
+    for mode in ("incremental", "incremental4"):
+        maps, n_inc, n_full = runs[mode]
+        assert n_inc >= 9 and n_full <= 5, (n_inc, n_full)              # rebuilds only: first commit, leaf change, three keyframes pending (+ nothing else)
+        for (ra, a), (rb, b) in zip(ref, maps):
+            assert ra == rb and a.shape == b.shape and a.shape[0] > 100
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
