@@ -57,7 +57,7 @@ struct LmArgs {      // must match lili_s2m_lm.hip
 };
 __global__ void k_solve_lm(LmArgs, MatchParams);
 // lili_s2m_coop.hip: L lanes per query (small launches)
-template <int L, bool LIN> __global__ void k_associate_coop(AssocArgs, AssocArgs, PoseArg, MatchParams, double*, double*);
+template <int L, bool LIN> __global__ void k_associate_coop(AssocArgs, AssocArgs, PoseArg, MatchParams, double*, double*, SlotState*, int);
 }  // namespace lili
 
 #include "lili_ctx.h"
@@ -195,6 +195,7 @@ int lili_set_option(lili_ctx* ctx, const char* name, int value) {
     if (std::strcmp(name, "fuse_tail") == 0) { ctx->fuse_tail = value != 0; return LILI_OK; }   // any time: the block partition does not depend on it
     if (std::strcmp(name, "merge_kinds") == 0) { ctx->merge_kinds = value != 0; return LILI_OK; }
     if (std::strcmp(name, "fuse_lin") == 0) { ctx->fuse_lin = value != 0; return LILI_OK; }
+    if (std::strcmp(name, "count_barrier") == 0) { ctx->count_barrier = value != 0; return LILI_OK; }      // ROT small launches: association + count barrier + linearisation in one launch (0: three launches, A/B)
     if (std::strcmp(name, "assoc_lpq") == 0) {      // lanes per query of the association: 0 = by launch size, 1 = always one lane per query, 2 / 4 / 8 / 16 forced
         if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16) return ctx->fail(LILI_E_ARG, "assoc_lpq must be 0 (auto), 1, 2, 4, 8 or 16");
         ctx->assoc_lpq = value; return LILI_OK;
@@ -730,6 +731,13 @@ static int launch_associate_coop(lili_ctx* ctx, int slot, int kind_mask, const P
     const int L = coop_lanes(ctx, n_all, first);
     if (L < 2 || n_all == 0) return 1;
     const int qpb = 256 / L;
+    // count-scaled flavours (ROT) may linearise in the association launch only through its in-launch count barrier: small grids
+    const bool scaled = P.scale_surf_num > 0 || P.scale_edge_num > 0;
+    int cb_blocks = 0;
+    if (lin && scaled) {
+        for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) cb_blocks += nblocks((int)sl.k[kind].n_q, qpb);
+        if (cb_blocks > 256 || !ctx->count_barrier) { sl.assoc_since_pose--; return 1; }      // (the caller's three-launch path calls in again and counts the launch itself)
+    }
     AssocArgs A[2] = {AssocArgs{}, AssocArgs{}};
     for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) {
         KindSlot& ks = sl.k[kind];
@@ -750,8 +758,8 @@ static int launch_associate_coop(lili_ctx* ctx, int slot, int kind_mask, const P
     }
     const dim3 grid(A[0].nb + A[1].nb), block(256);
     double* ps = sl.k[0].partials_wave.as<double>(); double* pe = sl.k[1].partials_wave.as<double>();
-#define LILI_COOP_CASE(LL) case LL: if (lin) hipLaunchKernelGGL((k_associate_coop<LL, true>), grid, block, 0, ctx->stream, A[0], A[1], pa, P, ps, pe); \
-                                    else hipLaunchKernelGGL((k_associate_coop<LL, false>), grid, block, 0, ctx->stream, A[0], A[1], pa, P, ps, pe); break;
+#define LILI_COOP_CASE(LL) case LL: if (lin) hipLaunchKernelGGL((k_associate_coop<LL, true>), grid, block, 0, ctx->stream, A[0], A[1], pa, P, ps, pe, ctx->state(slot), cb_blocks); \
+                                    else hipLaunchKernelGGL((k_associate_coop<LL, false>), grid, block, 0, ctx->stream, A[0], A[1], pa, P, ps, pe, ctx->state(slot), 0); break;
     switch (L) { LILI_COOP_CASE(2) LILI_COOP_CASE(4) LILI_COOP_CASE(8) LILI_COOP_CASE(16) default: return 1; }
 #undef LILI_COOP_CASE
     if (lin) hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx->stream, (const double*)ps, A[0].nb, (const double*)pe, A[1].nb, d_out, ctx->state(slot),
@@ -781,8 +789,9 @@ static LinArgs lin_args_of(lili_ctx* ctx, int slot, int kind) {
 // One outer iteration in TWO launches for the flavours without count scaling (k_associate_lin: association + linearisation, then the
 // reduction + GN update).  Returns 1 if the configuration is not eligible (the caller then takes the three-launch path).
 static int launch_associate_lin_reduce(lili_ctx* ctx, int slot, int kind_mask, const PoseArg& pa, const MatchParams& P, double* d_out) {
-    if (!ctx->fuse_lin || P.scale_surf_num > 0 || P.scale_edge_num > 0 || !pa.state) return 1;
+    if (!ctx->fuse_lin || !pa.state) return 1;
     if (ctx->bin_queries || ctx->tiled || ctx->balance || ctx->fuse_tail || (P.debug & 4096)) return 1;
+    const bool scaled = P.scale_surf_num > 0 || P.scale_edge_num > 0;      // ROT: only through the count barrier of the cooperative kernel (small launches)
     Slot& sl = ctx->slots[slot];
     AssocArgs A[2] = {AssocArgs{}, AssocArgs{}};
     int n_kinds = 0;
@@ -800,6 +809,7 @@ static int launch_associate_lin_reduce(lili_ctx* ctx, int slot, int kind_mask, c
         const int rc = launch_associate_coop(ctx, slot, kind_mask, pa, P, true, d_out);
         if (rc != 1) return rc;
     }
+    if (scaled) return 1;
     // one partial per workgroup: per wave while the reducer can take them in one round of loads (25 groups x 32), else per four waves
     int waves = 0;
     for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) waves += sl.k[kind].n_blocks;
@@ -1400,7 +1410,7 @@ int lili_s2m_pose_copy(lili_ctx* ctx, int dst_slot, int src_slot) {
 // stream and their total duration is returned (this variant synchronises at the end).
 // one outer iteration through k_associate_lin (see launch_associate_lin_reduce); 1 = not eligible
 static int iterate_fused_lin(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params) {
-    if (!ctx->fuse_lin || params->scale_surf_num > 0 || params->scale_edge_num > 0) return 1;
+    if (!ctx->fuse_lin) return 1;
     PoseArg pa{};
     pa.state = ctx->state(slot);
     pa.derive_assoc = params->variant == LILI_VARIANT_FRONTEND ? 0 : 1;

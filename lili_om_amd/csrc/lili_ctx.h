@@ -134,6 +134,7 @@ struct lili_ctx {
     double focus[3] = {0, 0, 0}, focus_radius = 0;   // lili_map_focus: where the super-row copy is built (radius 0: everywhere)
     int fuse_lin_block = 0;      // 0 = by scan size, else 64 / 256 (A/B, tests)
     int assoc_lpq = 0;           // lanes per query of the association: 0 = by launch size (coop_lanes), 1 = one lane per query always, 2 / 4 / 8 / 16 forced (A/B, tests)
+    bool count_barrier = true;   // count-scaled flavours (ROT), small launches: k_associate_coop counts, waits for all its workgroups' counts and linearises — 2 launches per iteration
     bool fuse_lin = true;        // lili_s2m_iterate*: flavours without count scaling linearise inside the association launch (k_associate_lin)
     bool super_rows = true;      // lili_map_set also stores the super-row copy of the map (9x the points): the inner 27-cell block of a query is one run
     bool scan_lookback = true;   // map index: single-pass (decoupled look-back) scan of the cell array; 0 = the three-kernel scan (A/B)

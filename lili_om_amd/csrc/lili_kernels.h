@@ -33,6 +33,7 @@ struct SlotState {
     double last_delta[6];
     long long tprof[16];   // profiling aid (LILI_DEBUG bit 256): s_memrealtime stamps (100 MHz) of one block per kernel
     unsigned int reserved_;
+    unsigned long long cnt_word;   // k_associate_coop's in-launch count barrier: [0,24) surf correspondences, [24,48) edge, [48,64) workgroups arrived; k_reduce_partials zeroes it
     unsigned long long epoch;   // fused linearisation launches of this slot so far: launch_key(epoch) tags the granules of the next one
 };
 

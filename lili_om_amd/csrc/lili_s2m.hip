@@ -1152,6 +1152,7 @@ __device__ __forceinline__ void reduce_partials_block(const double* part_surf, i
     out[lane] = full[lane];
     if (lane < 8) out[64 + lane] = full[64 + lane];
     if (key && lane == 0) state->epoch = state->epoch + 1ull;      // the next fused launch of this slot gets a new key (stream order)
+    if (lane == 0) state->cnt_word = 0ull;                          // re-arms the count barrier of k_associate_coop (the next association of this slot comes after this launch)
     tstamp(state, do_gn, (int)blockIdx.x, 10);
     if (do_gn & 1) gn_update_block(full, state, xq);
     tstamp(state, do_gn, (int)blockIdx.x, 11);

@@ -175,8 +175,14 @@ __device__ __forceinline__ void knn5_coop(const GridView& g, bool live, int sub,
 // Blocks [0, E.nb) take the edge queries, the rest the surf queries (either may be absent); kCoopBlock / L queries per block.
 // LIN: the lane that holds a group's record also linearises it (the flavours without count scaling, see k_associate_lin) and the block
 // stores ONE partial for k_reduce_partials.
+// cb_blocks > 0 (with LIN): the count-scaled flavour (ROT: residual weight = num / N with the scan's correspondence count N,
+// R/src/BackendFusion.cpp:843,861) linearises in this launch as well — N exists only after the last workgroup has counted, so every
+// workgroup adds its count and an arrival to ONE 64-bit word of the slot's state and waits until all cb_blocks workgroups have arrived
+// (a relaxed agent-scope atomic and a poll: only the VALUE is exchanged, no other data, hence no fence).  Small grids only (<= 256
+// workgroups, all resident); the wait is bounded — a workgroup that gives up contributes no rows and flags the slot.
 template <int L, bool LIN>
-__global__ __launch_bounds__(kCoopBlock) void k_associate_coop(AssocArgs S, AssocArgs E, PoseArg pa, MatchParams P, double* __restrict__ part_surf, double* __restrict__ part_edge) {
+__global__ __launch_bounds__(kCoopBlock) void k_associate_coop(AssocArgs S, AssocArgs E, PoseArg pa, MatchParams P, double* __restrict__ part_surf, double* __restrict__ part_edge,
+                                                               SlotState* cb_state, int cb_blocks) {
     constexpr int QPB = kCoopBlock / L;
     const int b = (int)blockIdx.x;
     const bool edge = b < E.nb;
@@ -214,22 +220,48 @@ __global__ __launch_bounds__(kCoopBlock) void k_associate_coop(AssocArgs S, Asso
     store_block_count<kCoopBlock>(rec.ok, A.block_counts, vb);
     if constexpr (LIN) {
         __shared__ __attribute__((aligned(16))) double lds[kCoopBlock * kRow];
+        __shared__ unsigned long long s_counts;
+        bool rows_ok = true;
+        if (cb_blocks > 0) {
+            if (threadIdx.x == 0) {
+                const unsigned long long mine = (unsigned long long)(unsigned)A.block_counts[vb];          // store_block_count has just written it (same thread)
+                __hip_atomic_fetch_add(&cb_state->cnt_word, (1ull << 48) | (edge ? mine << 24 : mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned long long w = 0ull;
+                for (unsigned spins = 0; spins < (1u << 22); spins++) {
+                    w = __hip_atomic_load(&cb_state->cnt_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((int)(w >> 48) >= cb_blocks) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                s_counts = (int)(w >> 48) >= cb_blocks ? w : ~0ull;
+            }
+            __syncthreads();
+            rows_ok = s_counts != ~0ull;
+            if (!rows_ok && threadIdx.x == 0 && b == 0) cb_state->gn_status = 2;
+        }
         dq Q; d3 T;
         load_body_pose(pa, Q, T);
         double Jr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         double cost = 0.0;
-        if (rec.ok) {
-            if (edge) cost = edge_lin_row(P, Q, T, rec.ql, rec.r0, rec.r1, (double)rec.r0.w, Jr);
-            else cost = surf_lin_row(P, Q, T, dq{P.q_lb_inv_jet[0], P.q_lb_inv_jet[1], P.q_lb_inv_jet[2], P.q_lb_inv_jet[3]}, rec.ql, rec.r0, rec.score, Jr);
+        if (rec.ok && rows_ok) {
+            if (edge) {
+                double sw = (double)rec.r0.w;
+                if (P.scale_edge_num > 0) sw = (double)__fdiv_rn(__fmul_rn(rec.r0.w, (float)P.scale_edge_num), (float)(int)((s_counts >> 24) & 0xffffffull));      // R:843, float arithmetic (lin_edge_body)
+                cost = edge_lin_row(P, Q, T, rec.ql, rec.r0, rec.r1, sw, Jr);
+            } else {
+                double score = rec.score;
+                if (P.scale_surf_num > 0) score = score * P.scale_surf_num / (double)(int)(s_counts & 0xffffffull);                                                 // R:861 (lin_surf_body)
+                cost = surf_lin_row(P, Q, T, dq{P.q_lb_inv_jet[0], P.q_lb_inv_jet[1], P.q_lb_inv_jet[2], P.q_lb_inv_jet[3]}, rec.ql, rec.r0, score, Jr);
+            }
         }
+        if (!rows_ok) rec.ok = false;
         GramAcc ga; ga.init();
         ga.add_rows(Jr, cost, rec.ok, lds);
         ga.finish(lds, edge ? part_edge + (size_t)vb * kPartialStride : part_surf + (size_t)vb * kPartialStride);
     }
 }
 #define LILI_COOP_INST(L) \
-    template __global__ void k_associate_coop<L, false>(AssocArgs, AssocArgs, PoseArg, MatchParams, double*, double*); \
-    template __global__ void k_associate_coop<L, true>(AssocArgs, AssocArgs, PoseArg, MatchParams, double*, double*);
+    template __global__ void k_associate_coop<L, false>(AssocArgs, AssocArgs, PoseArg, MatchParams, double*, double*, SlotState*, int); \
+    template __global__ void k_associate_coop<L, true>(AssocArgs, AssocArgs, PoseArg, MatchParams, double*, double*, SlotState*, int);
 LILI_COOP_INST(2)
 LILI_COOP_INST(4)
 LILI_COOP_INST(8)

@@ -155,6 +155,22 @@ __global__ void k_vox_key(const float4* __restrict__ pts, int n, VoxDev V, unsig
     int i2 = (int)(floorf(p.z * V.inv_leaf) - (float)V.min_b[2]);
     keys[i] = (unsigned)(i0 * V.mul[0] + i1 * V.mul[1] + i2 * V.mul[2]);
 }
+// Key of one keyframe's points for the sorted ring WITHOUT a host round trip: voxel coordinates relative to the keyframe's own bounding box
+// (ordered-uint words `mm` left in device memory by k_bbox), packed (i2 : 10 bits, i1 : 11, i0 : 11) — the same lexicographic order as the
+// box-relative voxel index.  A keyframe wider than 2047 x 2047 x 1023 voxels raises *bad (the commit then takes the full rebuild).
+__global__ void k_vox_key_packed(const float4* __restrict__ pts, int n, float inv_leaf, const unsigned* __restrict__ mm, unsigned* __restrict__ keys, int* __restrict__ vals,
+                                 unsigned* __restrict__ bad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    auto dec = [](unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); };
+    const float4 p = pts[i];
+    vals[i] = i;
+    if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) { keys[i] = 0xFFFFFFFFu; return; }
+    const int m0 = (int)floorf(dec(mm[0]) * inv_leaf), m1 = (int)floorf(dec(mm[1]) * inv_leaf), m2 = (int)floorf(dec(mm[2]) * inv_leaf);
+    const int i0 = (int)floorf(p.x * inv_leaf) - m0, i1 = (int)floorf(p.y * inv_leaf) - m1, i2 = (int)floorf(p.z * inv_leaf) - m2;
+    if (i0 < 0 || i0 > 2047 || i1 < 0 || i1 > 2047 || i2 < 0 || i2 > 1022) { *bad = 1u; keys[i] = 0xFFFFFFFEu; return; }
+    keys[i] = ((unsigned)i2 << 22) | ((unsigned)i1 << 11) | (unsigned)i0;
+}
 __global__ void k_vox_heads(const unsigned* __restrict__ keys, int n, unsigned sentinel, int* __restrict__ flags) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) flags[i] = (keys[i] != sentinel && (i == 0 || keys[i] != keys[i - 1])) ? 1 : 0;
@@ -311,6 +327,7 @@ struct VoxelBuffers {
     DevBuf keys_a, keys_b, vals_a, vals_b, hist, hist_scan, sums, flags, slots, out, out_cnt, in, concat, concat_tab;
     std::vector<Keyframe*> ring[2];    // per kind, oldest first
     SortedRing sorted[2];
+    std::vector<Keyframe*> pool;       // popped keyframes: their device buffers are reused by the next push (no hipMalloc / hipFree per keyframe: each is a device-wide synchronisation of ~100 us)
     unsigned next_seq = 1;
     DevBuf kf_key, kf_pt, seg_seq;     // the new keyframe sorted by key; sequence numbers of the concatenation's segments
     std::vector<unsigned> seg_seq_host;
@@ -320,6 +337,8 @@ struct VoxelBuffers {
     void release() {
         for (DevBuf* b : {&keys_a, &keys_b, &vals_a, &vals_b, &hist, &hist_scan, &sums, &flags, &slots, &out, &out_cnt, &in, &concat, &concat_tab}) b->release();
         for (auto& r : ring) { for (auto* k : r) { k->pts.release(); delete k; } r.clear(); }
+        for (auto* k : pool) { k->pts.release(); delete k; }
+        pool.clear();
         for (auto& sr : sorted) sr.release();
         kf_key.release(); kf_pt.release(); seg_seq.release();
     }
@@ -504,7 +523,10 @@ int lili_localmap_push(lili_ctx* ctx, int kind, const lili_cloud* features, cons
     auto* V = vox_of(ctx);
     int rc = lili_ingest_cloud(ctx, features, V->in);
     if (rc != LILI_OK) return rc;
-    auto* kf = new lili_detail::Keyframe();
+    // a buffer from the pool of popped keyframes if one is large enough (the steady state: keyframes of similar size), else a new one
+    lili_detail::Keyframe* kf = nullptr;
+    for (size_t i = 0; i < V->pool.size(); i++) if (V->pool[i]->pts.cap >= features->n * 16) { kf = V->pool[i]; V->pool.erase(V->pool.begin() + (long)i); break; }
+    if (!kf) kf = new lili_detail::Keyframe();
     kf->n = (int)features->n;
     kf->seq = V->next_seq++;
     if (kf->n > 0) {
@@ -517,10 +539,11 @@ int lili_localmap_push(lili_ctx* ctx, int kind, const lili_cloud* features, cons
     }
     V->ring[kind].push_back(kf);
     while ((int)V->ring[kind].size() > width) {   // recent_*_keyframes.pop_front() (L:1449-1450)
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        // the popped keyframe's buffer goes to the pool: everything that reads it was enqueued on this stream before whatever will overwrite it
         auto* old = V->ring[kind].front();
-        old->pts.release(); delete old;
         V->ring[kind].erase(V->ring[kind].begin());
+        if (V->pool.size() < 4) V->pool.push_back(old);
+        else { HIPCHK(hipStreamSynchronize(ctx->stream)); old->pts.release(); delete old; }
     }
     return LILI_OK;
 }
@@ -529,9 +552,15 @@ int lili_localmap_push(lili_ctx* ctx, int kind, const lili_cloud* features, cons
 static int sorted_ring_step(lili_ctx* ctx, lili_detail::VoxelBuffers* V, lili_detail::SortedRing& S, const DropSeqs& drop, long long n_drop, lili_detail::Keyframe* add, float leaf,
                             unsigned* d_bad) {
     int n_new = add ? add->n : 0;
-    if (n_new > 0) {       // the new keyframe alone, sorted by voxel (stable): 20 k points
-        VoxDev P;
-        int rc = voxel_sort(ctx, V, add->pts.as<float4>(), n_new, leaf, P);
+    if (n_new > 0) {       // the new keyframe alone, sorted by voxel (stable): 20 k points, no host round trip (the bounding box stays on the device)
+        static const unsigned init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+        unsigned* d_mm = ctx->misc.as<unsigned>();
+        HIPCHK(hipMemcpyAsync(d_mm, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_bbox, dim3(std::min(nblocks(n_new, kBlock), 512)), dim3(kBlock), 0, ctx->stream, add->pts.as<float4>(), n_new, d_mm);
+        HIPCHK(V->keys_a.ensure((size_t)n_new * 4)); HIPCHK(V->vals_a.ensure((size_t)n_new * 4));
+        hipLaunchKernelGGL(k_vox_key_packed, dim3(nblocks(n_new, 256)), dim3(256), 0, ctx->stream, add->pts.as<float4>(), n_new, 1.0f / leaf, (const unsigned*)d_mm,
+                           V->keys_a.as<unsigned>(), V->vals_a.as<int>(), d_bad);
+        int rc = radix_sort(ctx, V, n_new, 32);
         if (rc != LILI_OK) return rc;
         HIPCHK(V->kf_key.ensure((size_t)n_new * 8)); HIPCHK(V->kf_pt.ensure((size_t)n_new * 16)); HIPCHK(V->flags.ensure((size_t)std::max<long long>(n_new, S.n) * 4));
         hipLaunchKernelGGL(k_sorted_gather, dim3(nblocks(n_new, 256)), dim3(256), 0, ctx->stream, add->pts.as<float4>(), V->vals_a.as<int>(), n_new, 1.0f / leaf, add->seq,

@@ -90,11 +90,15 @@ def test_cooperative_lanes_change_no_result(gpu_ctx, flavour, mode):
         L.ScanToMapMatcher(gpu_ctx, P).map_focus(None)
 
 
-@pytest.mark.parametrize("flavour", ["rot", "frontend"])
+@pytest.mark.parametrize("flavour", ["rot", "rot_three_launches", "frontend"])
 def test_cooperative_iterations_follow_the_one_lane_iterations(gpu_ctx, flavour):
-    """Whole registrations: the ROT flavour linearises in its own launch on identical records, so its poses are bit-identical; the
-    flavours without count scaling linearise inside the association launch, where only the PARTITION of the Gram sum changes with the
-    lanes per query (one partial per 256 / L queries): poses agree to ~1e-11."""
+    """Whole registrations.  Where the linearisation is its own launch on identical records (ROT with option count_barrier = 0) the poses are
+    bit-identical; where it happens inside the association launch (the flavours without count scaling — and the count-scaled ROT flavour
+    through the in-launch count barrier of small launches) only the PARTITION of the Gram sum changes with the lanes per query (one
+    partial per 256 / L queries): poses agree to ~1e-11."""
+    three = flavour == "rot_three_launches"
+    flavour = "rot" if three else flavour
+    gpu_ctx.set_option("count_barrier", 0 if three else 1)
     room = synth.make_room(seed=47, n_query=3000, n_edge_query=250)
     P = L.make_params(flavour)
     tb, qb = L.api.body_pose_from_lidar(room["t_true"], room["q_true"], P)
@@ -107,12 +111,13 @@ def test_cooperative_iterations_follow_the_one_lane_iterations(gpu_ctx, flavour)
             got = _run(gpu_ctx, P, clouds, t0, q0, lanes, "all", centre, n_iter=8)
             (t_a, q_a, st_a), (t_b, q_b, st_b) = ref["pose"], got["pose"]
             assert st_a == 0 and st_b == 0
-            if flavour == "rot":
+            if three:
                 assert np.array_equal(t_a, t_b) and np.array_equal(q_a, q_b), lanes
             else:
                 assert np.abs(t_a - t_b).max() < 1e-10 and np.abs(q_a - q_b).max() < 1e-10, lanes
     finally:
         gpu_ctx.set_option("assoc_lpq", 0)
+        gpu_ctx.set_option("count_barrier", 1)
         gpu_ctx.set_debug(False)
 
 

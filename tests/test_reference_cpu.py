@@ -462,3 +462,27 @@ def test_reference_local_map_other_widths(oracle, width, seed):
         pose = np.concatenate([q, rng.uniform(-2, 2, 3)])
         lm.commit(pose); os_.commit(pose); oe.commit(pose)
     lm.close()
+
+
+def test_functor_row_fixture_is_the_reference_functors_output():
+    """tests/golden/ref_functor_rows.npz (the rows tests/test_reference_gpu.py::test_gpu_linearize_vs_reference_functors falls back on where the
+    git-ignored oracle/_ref did not travel): re-evaluated here through LidarPlaneNormFactor / LidarEdgeFactor of the reference's header
+    (oracle/_ref/libref_factors.so) on the records stored beside them — the committed rows are the reference's, bit for bit."""
+    from oracle import ref as R
+    if not R.available():
+        pytest.skip("oracle/_ref not built (no /root/reference on this machine)")
+    import lili_om_amd as L
+    from lili_om_amd import synth
+    d = np.load(os.path.join(G, "ref_functor_rows.npz"))
+    for variant in ("livox", "rot"):
+        P = L.make_params(variant)
+        room = synth.make_room(seed=12, n_query=1500, n_edge_query=200)
+        tb, qb = L.api.body_pose_from_lidar(room["t_true"], room["q_true"], P)
+        t0, q0 = synth.perturbed_pose(tb, qb, np.random.default_rng(3), 0.05, 0.5)
+        rs = {k: d[f"{variant}_s_{k}"] for k in ("cp", "n", "d", "score")}
+        re_ = {k: d[f"{variant}_e_{k}"] for k in ("cp", "a", "b", "s")}
+        ns, ne = len(rs["d"]), len(re_["s"])
+        ss = P.scale_surf_num / ns if P.scale_surf_num else 1.0
+        se = P.scale_edge_num / ne if P.scale_edge_num else 1.0
+        rows_s, rows_e = M.functor_rows(R, rs, re_, np.array(list(P.q_lb)), np.array(list(P.t_lb)), ss, se, np.asarray(t0, np.float64), np.asarray(q0, np.float64))
+        assert np.array_equal(rows_s, d[f"{variant}_rows_s"]) and np.array_equal(rows_e, d[f"{variant}_rows_e"])
