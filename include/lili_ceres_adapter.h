@@ -87,7 +87,7 @@ public:
             for (int c = 0; c < 3; ++c) t[3 * k + c] = parameters[2 * k][c];
             for (int c = 0; c < 4; ++c) q[4 * k + c] = parameters[2 * k + 1][c];
         }
-        if (lili_s2m_linearize_window(ctx_, slots_.data(), K, mask_, t.data(), q.data(), &params_, gram.data(), cost.data(), nullptr) != LILI_OK) return false;
+        if (linearize(t, q, gram, cost) != LILI_OK) return false;
         for (int k = 0; k < K; ++k) {
             double res[9], jac[63];
             if (lili_gram_to_factor(&gram[64 * k], cost[k], res, jac) != LILI_OK) return false;
@@ -105,11 +105,26 @@ public:
         return true;
     }
 
+    // The window SHARDED over the ranks of a node (BASELINE configs[4]; every rank holds its shard of every keyframe's features and runs the same
+    // solver): Evaluate becomes ONE lili_s2m_linearize_window_sharded — the records of all keyframes summed over the ranks in one exchange of
+    // K x 72 doubles, identical bits on every rank, so the ranks' solvers take identical steps.  allreduce / comm: lili_p2p_allreduce + the
+    // lili_p2p*, or ncclAllReduce + the ncclComm_t; d_gram: device buffer of K x LILI_GRAM_DOUBLES doubles owned by the caller.  Call
+    // lili_s2m_counts_window_sharded after the associations (ROT flavour) before the solve.
+    void shard_over_ranks(lili_allreduce_fn allreduce, void* comm, double* d_gram) { allreduce_ = allreduce; comm_ = comm; d_gram_ = d_gram; }
+
 private:
+    int linearize(const std::vector<double>& t, const std::vector<double>& q, std::vector<double>& gram, std::vector<double>& cost) const {
+        const int K = (int)slots_.size();
+        if (d_gram_) return lili_s2m_linearize_window_sharded(ctx_, slots_.data(), K, mask_, t.data(), q.data(), &params_, allreduce_, comm_, d_gram_, gram.data(), cost.data(), nullptr);
+        return lili_s2m_linearize_window(ctx_, slots_.data(), K, mask_, t.data(), q.data(), &params_, gram.data(), cost.data(), nullptr);
+    }
     lili_ctx* ctx_;
     std::vector<int> slots_;
     int mask_;
     lili_s2m_params params_;
+    lili_allreduce_fn allreduce_ = nullptr;
+    void* comm_ = nullptr;
+    double* d_gram_ = nullptr;
 };
 
 }  // namespace lili

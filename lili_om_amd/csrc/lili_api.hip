@@ -205,6 +205,7 @@ int lili_set_option(lili_ctx* ctx, const char* name, int value) {
     if (std::strcmp(name, "super_rows") == 0) { ctx->super_rows = value != 0; return LILI_OK; }   // takes effect at the next lili_map_set
     if (std::strcmp(name, "fine_occupancy") == 0) { if (value < 2) return ctx->fail(LILI_E_ARG, "fine_occupancy must be >= 2"); ctx->fine_occupancy = value; return LILI_OK; }
     if (std::strcmp(name, "scan_lookback") == 0) { ctx->scan_lookback = value != 0; return LILI_OK; }
+    if (std::strcmp(name, "localmap_super_rows") == 0) { ctx->localmap_super_rows = value != 0; return LILI_OK; }
     if (std::strcmp(name, "localmap_incremental") == 0) { ctx->localmap_incremental = value != 0; return LILI_OK; }
     if (std::strcmp(name, "sort_digit_bits") == 0) { if (value != 4 && value != 8) return ctx->fail(LILI_E_ARG, "sort_digit_bits must be 4 or 8"); ctx->sort_digit_bits = value; return LILI_OK; }
     if (std::strcmp(name, "rot_atan") == 0) { if (value != 1 && value != 2) return ctx->fail(LILI_E_ARG, "rot_atan must be 1 or 2"); ctx->rot_atan = value; return LILI_OK; }

@@ -134,10 +134,12 @@ struct lili_ctx {
     double focus[3] = {0, 0, 0}, focus_radius = 0;   // lili_map_focus: where the super-row copy is built (radius 0: everywhere)
     int fuse_lin_block = 0;      // 0 = by scan size, else 64 / 256 (A/B, tests)
     int assoc_lpq = 0;           // lanes per query of the association: 0 = by launch size (coop_lanes), 1 = one lane per query always, 2 / 4 / 8 / 16 forced (A/B, tests)
-    bool count_barrier = true;   // count-scaled flavours (ROT), small launches: k_associate_coop counts, waits for all its workgroups' counts and linearises — 2 launches per iteration
+    bool count_barrier = false;  // (measured: 19.4 vs 19.8 us per iteration at 2 k queries — the wait for the slowest workgroup costs what the launch saved; off by default)
+
     bool fuse_lin = true;        // lili_s2m_iterate*: flavours without count scaling linearise inside the association launch (k_associate_lin)
     bool super_rows = true;      // lili_map_set also stores the super-row copy of the map (9x the points): the inner 27-cell block of a query is one run
     bool scan_lookback = true;   // map index: single-pass (decoupled look-back) scan of the cell array; 0 = the three-kernel scan (A/B)
+    bool localmap_super_rows = false;   // lili_localmap_commit builds the super-row copy also for small maps (< 400 k points)
     bool localmap_incremental = true;   // lili_localmap_commit keeps the ring sorted by voxel and merges one keyframe per step (0: rebuild every time, A/B)
     int sort_digit_bits = 8;     // radix sort of the voxel filter: 8-bit digits (4 = the round-2 passes, A/B)
     int rot_atan = 2;            // ROT extractor: 2 = glibc fdlibm float atan / atan2 (the reference build's bits), 1 = f64 functions rounded to f32

@@ -90,26 +90,26 @@ __global__ __launch_bounds__(kSortBlock) void k_sort_scatter(const unsigned* __r
 // latency-bound at the sizes of a keyframe ring (1 M keys: 8 x (hist + scan + scatter) 4-bit passes were ~25 launches for a 26-bit key).
 // Stability as above: keys of a tile keep their order inside a digit (ballot ranks inside a wave, wave counts in LDS, rounds in order).
 constexpr int kSortItems8 = 16, kSortTile8 = kSortBlock * kSortItems8;      // 4096 keys per tile: the 256 x tiles digit table of 1 M keys (62 k words) still takes the one-launch scan
-__global__ __launch_bounds__(kSortBlock) void k_sort_hist8(const unsigned* __restrict__ keys, int n, int shift, int nb, int* __restrict__ hist /*[256][nb]*/) {
+__global__ __launch_bounds__(kSortBlock) void k_sort_hist8(const unsigned* __restrict__ keys, int n, int shift, int nb, int items, int* __restrict__ hist /*[256][nb]*/) {
     __shared__ int h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
-    const int base = blockIdx.x * kSortTile8;
-    for (int r = 0; r < kSortItems8; r++) {
+    const int base = blockIdx.x * kSortBlock * items;
+    for (int r = 0; r < items; r++) {
         const int i = base + r * kSortBlock + threadIdx.x;
         if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1);      // LDS integer atomics
     }
     __syncthreads();
     hist[threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
 }
-__global__ __launch_bounds__(kSortBlock) void k_sort_scatter8(const unsigned* __restrict__ keys_in, const int* __restrict__ vals_in, int n, int shift, int nb,
+__global__ __launch_bounds__(kSortBlock) void k_sort_scatter8(const unsigned* __restrict__ keys_in, const int* __restrict__ vals_in, int n, int shift, int nb, int items,
                                                               const int* __restrict__ offs /*[256][nb] exclusive*/, unsigned* __restrict__ keys_out, int* __restrict__ vals_out) {
     __shared__ int base[256];                 // running offset of each digit inside this tile
     __shared__ int wcnt[kSortBlock / 64][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     base[threadIdx.x] = offs[threadIdx.x * nb + blockIdx.x];
-    const int tile = blockIdx.x * kSortTile8;
-    for (int r = 0; r < kSortItems8; r++) {
+    const int tile = blockIdx.x * kSortBlock * items;
+    for (int r = 0; r < items; r++) {
         const int i = tile + r * kSortBlock + threadIdx.x;
         const bool live = i < n;
         const unsigned key = live ? keys_in[i] : 0u;
@@ -275,27 +275,32 @@ __global__ void k_vox_heads64(const unsigned long long* __restrict__ keys, long 
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) flags[i] = (keys[i] < ~0ull - 1ull && (i == 0 || keys[i] != keys[i - 1])) ? 1 : 0;
 }
-// k_vox_centroid on the sorted ring: members are consecutive, no indirection; the same sequential f32 sums
-__global__ void k_vox_centroid64(const unsigned long long* __restrict__ keys, const float4* __restrict__ pts, const int* __restrict__ slot, long long n,
-                                 float4* __restrict__ out, int* __restrict__ out_cnt) {
+// k_vox_centroid on the sorted ring, ONE THREAD PER VOXEL (members are consecutive, no indirection; the same sequential f32 sums in the same
+// order).  With one thread per POINT only the run heads worked — ~15 % of the lanes on a 50-keyframe ring (6.6 points per voxel), 55 us per
+// commit; the heads' positions are compacted first (k_vox_head_pos) and the launch is dense.
+__global__ void k_vox_head_pos(const int* __restrict__ flags, const int* __restrict__ slot, long long n, int* __restrict__ head_pos) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i < n && flags[i]) head_pos[slot[i]] = (int)i;
+}
+__global__ void k_vox_centroid64(const unsigned long long* __restrict__ keys, const float4* __restrict__ pts, const int* __restrict__ head_pos, const int* __restrict__ n_out_p, long long n,
+                                 float4* __restrict__ out, int* __restrict__ out_cnt) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= *n_out_p) return;
+    const long long i = head_pos[o];
     const unsigned long long k = keys[i];
-    if (k >= ~0ull - 1ull || !(i == 0 || keys[i - 1] != k)) return;
     float sx = 0.f, sy = 0.f, sz = 0.f, sa = 0.f; int c = 0;
     bool more = true;
-    for (long long m = i; more && m < n; m += 8) {
-        unsigned long long kk[8]; float4 pp[8];
+    for (long long m = i; more && m < n; m += 4) {
+        unsigned long long kk[4]; float4 pp[4];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const long long mm = m + u < n ? m + u : n - 1; kk[u] = keys[mm]; pp[u] = pts[mm]; }
+        for (int u = 0; u < 4; u++) { const long long mm = m + u < n ? m + u : n - 1; kk[u] = keys[mm]; pp[u] = pts[mm]; }
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < 4; u++) {
             if (more && m + u < n && kk[u] == k) { sx += pp[u].x; sy += pp[u].y; sz += pp[u].z; sa += pp[u].w; c++; }
             else more = false;
         }
     }
     const float fn = (float)c;
-    const int o = slot[i];
     out[o] = make_float4(sx / fn, sy / fn, sz / fn, sa / fn);
     if (out_cnt) out_cnt[o] = c;
 }
@@ -329,6 +334,7 @@ struct VoxelBuffers {
     SortedRing sorted[2];
     std::vector<Keyframe*> pool;       // popped keyframes: their device buffers are reused by the next push (no hipMalloc / hipFree per keyframe: each is a device-wide synchronisation of ~100 us)
     unsigned next_seq = 1;
+    DevBuf head_pos;
     DevBuf kf_key, kf_pt, seg_seq;     // the new keyframe sorted by key; sequence numbers of the concatenation's segments
     std::vector<unsigned> seg_seq_host;
     int incremental_commits = 0, full_commits = 0;
@@ -340,7 +346,7 @@ struct VoxelBuffers {
         for (auto* k : pool) { k->pts.release(); delete k; }
         pool.clear();
         for (auto& sr : sorted) sr.release();
-        kf_key.release(); kf_pt.release(); seg_seq.release();
+        kf_key.release(); kf_pt.release(); seg_seq.release(); head_pos.release();
     }
 };
 }  // namespace lili_detail
@@ -409,7 +415,10 @@ static int exclusive_scan(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const int
 // round-2 passes, for A/B)
 static int radix_sort(lili_ctx* ctx, lili_detail::VoxelBuffers* V, int n, int bits) {
     const int dbits = ctx->sort_digit_bits == 4 ? 4 : 8, ndig = 1 << dbits;
-    const int nb = nblocks(n, dbits == 8 ? kSortTile8 : kSortTile);
+    // 8-bit digits: keys per tile by size — a tile is walked in rounds of 256 keys (one block barrier set per round), so a keyframe's 20 k keys
+    // spread over 79 one-round tiles sort in a quarter of the time five 16-round tiles take; 1 M keys keep 4096-key tiles (digit table 62 k words)
+    const int items8 = n <= 65536 ? 1 : n <= 262144 ? 4 : kSortItems8;
+    const int nb = nblocks(n, dbits == 8 ? kSortBlock * items8 : kSortTile);
     HIPCHK(V->hist.ensure((size_t)ndig * nb * sizeof(int)));
     HIPCHK(V->hist_scan.ensure(((size_t)ndig * nb + 1) * sizeof(int)));
     HIPCHK(V->keys_b.ensure((size_t)n * 4)); HIPCHK(V->vals_b.ensure((size_t)n * 4));
@@ -418,11 +427,11 @@ static int radix_sort(lili_ctx* ctx, lili_detail::VoxelBuffers* V, int n, int bi
         const int shift = dbits * p;
         unsigned *ka = V->keys_a.as<unsigned>(), *kb = V->keys_b.as<unsigned>();
         int *va = V->vals_a.as<int>(), *vb = V->vals_b.as<int>();
-        if (dbits == 8) hipLaunchKernelGGL(k_sort_hist8, dim3(nb), dim3(kSortBlock), 0, ctx->stream, ka, n, shift, nb, V->hist.as<int>());
+        if (dbits == 8) hipLaunchKernelGGL(k_sort_hist8, dim3(nb), dim3(kSortBlock), 0, ctx->stream, ka, n, shift, nb, items8, V->hist.as<int>());
         else hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(kSortBlock), 0, ctx->stream, ka, n, shift, nb, V->hist.as<int>());
         int rc = exclusive_scan(ctx, V, V->hist.as<int>(), (int64_t)ndig * nb, V->hist_scan.as<int>());
         if (rc != LILI_OK) return rc;
-        if (dbits == 8) hipLaunchKernelGGL(k_sort_scatter8, dim3(nb), dim3(kSortBlock), 0, ctx->stream, ka, va, n, shift, nb, V->hist_scan.as<int>(), kb, vb);
+        if (dbits == 8) hipLaunchKernelGGL(k_sort_scatter8, dim3(nb), dim3(kSortBlock), 0, ctx->stream, ka, va, n, shift, nb, items8, V->hist_scan.as<int>(), kb, vb);
         else hipLaunchKernelGGL(k_sort_scatter, dim3(nb), dim3(kSortBlock), 0, ctx->stream, ka, va, n, shift, nb, V->hist_scan.as<int>(), kb, vb);
         HIPCHK(hipGetLastError());
         V->keys_a.swap(V->keys_b); V->vals_a.swap(V->vals_b);      // the sorted pairs are the new `a` (buffers trade places, nothing is copied)
@@ -633,8 +642,11 @@ int lili_localmap_commit(lili_ctx* ctx, int kind, float leaf, double max_sq_radi
             hipLaunchKernelGGL(k_vox_heads64, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, S.key[S.cur].as<unsigned long long>(), n, V->flags.as<int>());
             rc = exclusive_scan(ctx, V, V->flags.as<int>(), n, V->slots.as<int>());
             if (rc != LILI_OK) return rc;
-            hipLaunchKernelGGL(k_vox_centroid64, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, S.key[S.cur].as<unsigned long long>(), S.pt[S.cur].as<float4>(), V->slots.as<int>(), n,
-                               V->out.as<float4>(), V->out_cnt.as<int>());
+            HIPCHK(V->head_pos.ensure((size_t)n * 4));
+            hipLaunchKernelGGL(k_vox_head_pos, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, V->flags.as<int>(), V->slots.as<int>(), n, V->head_pos.as<int>());
+            // one thread per voxel: the grid covers the upper bound (every point its own voxel), threads beyond the count on the device leave at once
+            hipLaunchKernelGGL(k_vox_centroid64, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, S.key[S.cur].as<unsigned long long>(), S.pt[S.cur].as<float4>(), V->head_pos.as<int>(),
+                               (const int*)(V->slots.as<int>() + n), n, V->out.as<float4>(), V->out_cnt.as<int>());
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(&V->n_out, V->slots.as<int>() + n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         }
@@ -684,7 +696,14 @@ int lili_localmap_commit(lili_ctx* ctx, int kind, float leaf, double max_sq_radi
     }
     if (n_map) *n_map = V->n_out;
     lili_cloud c{V->out.p, (size_t)V->n_out, 16, 12, LILI_MEM_DEVICE};
-    return lili_map_set(ctx, kind, &c, max_sq_radius);                                   // setInputCloud (L:839-840)
+    // The super-row copy (9x the points, a layout that never changes a result) pays for maps that serve many large launches; a keyframe-ring map of
+    // a few hundred thousand points is rebuilt per keyframe and serves ~30 launches of 1-3 k queries: 70 us of copy against ~1 us saved per launch
+    // (measured: k_scatter9 45 + k_start9 12 + k_rowtot9 5 + scan 10 us on the 152 k-point ring map).  Option "localmap_super_rows" = 1 keeps it.
+    const bool srows = ctx->super_rows;
+    if (!ctx->localmap_super_rows && V->n_out < 400000 && !(ctx->focus_radius > 0)) ctx->super_rows = false;
+    const int rc_map = lili_map_set(ctx, kind, &c, max_sq_radius);                       // setInputCloud (L:839-840)
+    ctx->super_rows = srows;
+    return rc_map;
 }
 
 // The cloud the last lili_localmap_commit (or lili_voxel_filter) produced: the down-sampled local map in map order (what the reference
