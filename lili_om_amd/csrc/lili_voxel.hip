@@ -89,7 +89,7 @@ __global__ __launch_bounds__(kSortBlock) void k_sort_scatter(const unsigned* __r
 // The same sort with 8-bit digits (round 3): a quarter of the passes for the price of 256-entry digit tables — the passes are launch- and
 // latency-bound at the sizes of a keyframe ring (1 M keys: 8 x (hist + scan + scatter) 4-bit passes were ~25 launches for a 26-bit key).
 // Stability as above: keys of a tile keep their order inside a digit (ballot ranks inside a wave, wave counts in LDS, rounds in order).
-constexpr int kSortItems8 = 16, kSortTile8 = kSortBlock * kSortItems8;      // 4096 keys per tile: the 256 x tiles digit table of 1 M keys (62 k words) still takes the one-launch scan
+constexpr int kSortItems8 = 16;      // 4096 keys per tile: the 256 x tiles digit table of 1 M keys (62 k words) still takes the one-launch scan
 __global__ __launch_bounds__(kSortBlock) void k_sort_hist8(const unsigned* __restrict__ keys, int n, int shift, int nb, int items, int* __restrict__ hist /*[256][nb]*/) {
     __shared__ int h[256];
     h[threadIdx.x] = 0;
@@ -285,24 +285,25 @@ __global__ void k_vox_head_pos(const int* __restrict__ flags, const int* __restr
 __global__ void k_vox_centroid64(const unsigned long long* __restrict__ keys, const float4* __restrict__ pts, const int* __restrict__ head_pos, const int* __restrict__ n_out_p, long long n,
                                  float4* __restrict__ out, int* __restrict__ out_cnt) {
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= *n_out_p) return;
+    const int n_out = *n_out_p;
+    if (o >= n_out) return;
     const long long i = head_pos[o];
-    const unsigned long long k = keys[i];
-    float sx = 0.f, sy = 0.f, sz = 0.f, sa = 0.f; int c = 0;
-    bool more = true;
-    for (long long m = i; more && m < n; m += 4) {
-        unsigned long long kk[4]; float4 pp[4];
+    // the voxel's members are [i, end): up to the next voxel's head; the last voxel ends where the keys stop being voxels (non-finite points sort last)
+    long long end;
+    if (o + 1 < n_out) end = head_pos[o + 1];
+    else { const unsigned long long k = keys[i]; end = i + 1; while (end < n && keys[end] == k) end++; }
+    // sequential f32 sums in list order (CentroidPoint); the member count is known, so the loads of a trip do not wait for a key comparison
+    float sx = 0.f, sy = 0.f, sz = 0.f, sa = 0.f;
+    for (long long m = i; m < end; m += 8) {
+        float4 pp[8];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const long long mm = m + u < n ? m + u : n - 1; kk[u] = keys[mm]; pp[u] = pts[mm]; }
+        for (int u = 0; u < 8; u++) pp[u] = pts[m + u < end ? m + u : end - 1];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (more && m + u < n && kk[u] == k) { sx += pp[u].x; sy += pp[u].y; sz += pp[u].z; sa += pp[u].w; c++; }
-            else more = false;
-        }
+        for (int u = 0; u < 8; u++) if (m + u < end) { sx += pp[u].x; sy += pp[u].y; sz += pp[u].z; sa += pp[u].w; }
     }
-    const float fn = (float)c;
+    const float fn = (float)(int)(end - i);
     out[o] = make_float4(sx / fn, sy / fn, sz / fn, sa / fn);
-    if (out_cnt) out_cnt[o] = c;
+    if (out_cnt) out_cnt[o] = (int)(end - i);
 }
 
 // transformCloud — L/src/BackendFusion.cpp:713-790: p' = q * p + t in f64, stored f32; aux carried along
@@ -368,17 +369,18 @@ static lili_detail::VoxelBuffers* vox_of(lili_ctx* ctx) {
 // exclusive scan of a SHORT array (the digit histograms of a radix pass: 16 words per 2048 keys) by one workgroup in one launch — the
 // three-kernel scan spends ~10 us of launches on a few thousand words
 __global__ __launch_bounds__(1024) void k_scan_single(const int* __restrict__ in, int n, int* __restrict__ out /*[n+1]*/) {
+    constexpr int kItems = 16;                 // 16 384 words per trip: a trip costs ~3 us of barriers and wave scans whatever it holds
     __shared__ int wsum[16];
     __shared__ int carry_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    for (int base = 0; base < n; base += 4096) {
-        const int i0 = base + threadIdx.x * 4;
-        int v[4];
+    for (int base = 0; base < n; base += 1024 * kItems) {
+        const int i0 = base + threadIdx.x * kItems;
+        int v[kItems];
+        int s = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = i0 + k < n ? in[i0 + k] : 0;
-        const int s = (v[0] + v[1]) + (v[2] + v[3]);
+        for (int k = 0; k < kItems; k++) { v[k] = i0 + k < n ? in[i0 + k] : 0; s += v[k]; }
         int inc = s;
         for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
         if (lane == 63) wsum[wave] = inc;
@@ -388,7 +390,7 @@ __global__ __launch_bounds__(1024) void k_scan_single(const int* __restrict__ in
         for (int w = 0; w < 16; w++) { const int x = wsum[w]; if (w < wave) wbase += x; tot += x; }
         int run = carry_s + wbase + inc - s;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { if (i0 + k < n) out[i0 + k] = run; run += v[k]; }
+        for (int k = 0; k < kItems; k++) { if (i0 + k < n) out[i0 + k] = run; run += v[k]; }
         __syncthreads();
         if (threadIdx.x == 0) carry_s += tot;
         __syncthreads();
