@@ -369,18 +369,30 @@ static lili_detail::VoxelBuffers* vox_of(lili_ctx* ctx) {
 // exclusive scan of a SHORT array (the digit histograms of a radix pass: 16 words per 2048 keys) by one workgroup in one launch — the
 // three-kernel scan spends ~10 us of launches on a few thousand words
 __global__ __launch_bounds__(1024) void k_scan_single(const int* __restrict__ in, int n, int* __restrict__ out /*[n+1]*/) {
-    constexpr int kItems = 16;                 // 16 384 words per trip: a trip costs ~3 us of barriers and wave scans whatever it holds
     __shared__ int wsum[16];
     __shared__ int carry_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    for (int base = 0; base < n; base += 1024 * kItems) {
-        const int i0 = base + threadIdx.x * kItems;
-        int v[kItems];
-        int s = 0;
+    // 4096 words per trip, 16 bytes per lane; the NEXT trip's words are requested before this trip's barriers (a trip used to cost ~2.8 us, most of it
+    // the load round trip that started only after the previous trip's last barrier)
+    int nx[4];
+    {
+        const int i0 = threadIdx.x * 4;
 #pragma unroll
-        for (int k = 0; k < kItems; k++) { v[k] = i0 + k < n ? in[i0 + k] : 0; s += v[k]; }
+        for (int k = 0; k < 4; k++) nx[k] = i0 + k < n ? in[i0 + k] : 0;
+    }
+    for (int base = 0; base < n; base += 4096) {
+        const int i0 = base + threadIdx.x * 4;
+        int v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = nx[k];
+        {
+            const int j0 = i0 + 4096;
+#pragma unroll
+            for (int k = 0; k < 4; k++) nx[k] = j0 + k < n ? in[j0 + k] : 0;
+        }
+        const int s = (v[0] + v[1]) + (v[2] + v[3]);
         int inc = s;
         for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
         if (lane == 63) wsum[wave] = inc;
@@ -390,7 +402,7 @@ __global__ __launch_bounds__(1024) void k_scan_single(const int* __restrict__ in
         for (int w = 0; w < 16; w++) { const int x = wsum[w]; if (w < wave) wbase += x; tot += x; }
         int run = carry_s + wbase + inc - s;
 #pragma unroll
-        for (int k = 0; k < kItems; k++) { if (i0 + k < n) out[i0 + k] = run; run += v[k]; }
+        for (int k = 0; k < 4; k++) { if (i0 + k < n) out[i0 + k] = run; run += v[k]; }
         __syncthreads();
         if (threadIdx.x == 0) carry_s += tot;
         __syncthreads();
@@ -418,8 +430,8 @@ static int exclusive_scan(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const int
 static int radix_sort(lili_ctx* ctx, lili_detail::VoxelBuffers* V, int n, int bits) {
     const int dbits = ctx->sort_digit_bits == 4 ? 4 : 8, ndig = 1 << dbits;
     // 8-bit digits: keys per tile by size — a tile is walked in rounds of 256 keys (one block barrier set per round), so a keyframe's 20 k keys
-    // spread over 79 one-round tiles sort in a quarter of the time five 16-round tiles take; 1 M keys keep 4096-key tiles (digit table 62 k words)
-    const int items8 = n <= 65536 ? 1 : n <= 262144 ? 4 : kSortItems8;
+    // spread over 20 four-round tiles sort in a third of the time five 16-round tiles take; 1 M keys keep 4096-key tiles (digit table 62 k words)
+    const int items8 = n <= 262144 ? 4 : kSortItems8;      // (one-round tiles made the digit table — 256 words per tile — the bottleneck: its scan is one workgroup)
     const int nb = nblocks(n, dbits == 8 ? kSortBlock * items8 : kSortTile);
     HIPCHK(V->hist.ensure((size_t)ndig * nb * sizeof(int)));
     HIPCHK(V->hist_scan.ensure(((size_t)ndig * nb + 1) * sizeof(int)));
