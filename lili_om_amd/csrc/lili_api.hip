@@ -58,6 +58,15 @@ struct LmArgs {      // must match lili_s2m_lm.hip
 __global__ void k_solve_lm(LmArgs, MatchParams);
 // lili_s2m_coop.hip: L lanes per query (small launches)
 template <int L, bool LIN> __global__ void k_associate_coop(AssocArgs, AssocArgs, PoseArg, MatchParams, double*, double*, SlotState*, int);
+struct IterArgs {      // must match lili_s2m_coop.hip
+    SlotState* state;
+    double* part;
+    double* gsum;
+    double* cpart;
+    int nb, ng, n_iters, derive_assoc;
+    unsigned long long launch;
+};
+template <int L> __global__ void k_iterate_coop(AssocArgs, AssocArgs, MatchParams, IterArgs);
 }  // namespace lili
 
 #include "lili_ctx.h"
@@ -195,6 +204,7 @@ int lili_set_option(lili_ctx* ctx, const char* name, int value) {
     if (std::strcmp(name, "fuse_tail") == 0) { ctx->fuse_tail = value != 0; return LILI_OK; }   // any time: the block partition does not depend on it
     if (std::strcmp(name, "merge_kinds") == 0) { ctx->merge_kinds = value != 0; return LILI_OK; }
     if (std::strcmp(name, "fuse_lin") == 0) { ctx->fuse_lin = value != 0; return LILI_OK; }
+    if (std::strcmp(name, "persistent_iterate") == 0) { ctx->persistent_iterate = value != 0; return LILI_OK; }      // small scans: lili_s2m_iterate* as one persistent launch per registration (0: launch by launch, A/B)
     if (std::strcmp(name, "count_barrier") == 0) { ctx->count_barrier = value != 0; return LILI_OK; }      // ROT small launches: association + count barrier + linearisation in one launch (0: three launches, A/B)
     if (std::strcmp(name, "assoc_lpq") == 0) {      // lanes per query of the association: 0 = by launch size, 1 = always one lane per query, 2 / 4 / 8 / 16 forced
         if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16) return ctx->fail(LILI_E_ARG, "assoc_lpq must be 0 (auto), 1, 2, 4, 8 or 16");
@@ -767,6 +777,77 @@ static int launch_associate_coop(lili_ctx* ctx, int slot, int kind_mask, const P
                                 1 | (P.debug & 256), P2PView{});
     HIPCHK(hipGetLastError());
     sl.use_global_counts = false;
+    return LILI_OK;
+}
+
+// n_iters outer iterations of a SMALL scan as ONE persistent launch (k_iterate_coop, lili_s2m_coop.hip): every workgroup keeps the pose in LDS,
+// the workgroups exchange counts and Gram partials inside the launch and each applies the same Gauss-Newton step.  Returns 1 if not eligible
+// (the caller then iterates launch by launch).  Eligible: the configurations of launch_associate_coop with at most 256 workgroups.
+static int launch_iterate_persistent(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, int n_iters) {
+    if (!ctx->persistent_iterate || n_iters < 2 || n_iters > 2000) return 1;
+    if (ctx->bin_queries || ctx->tiled || ctx->balance || ctx->nn_cache || ctx->fuse_tail) return 1;
+    MatchParams P = to_device_params(params);
+    if (P.debug & (1 | 2 | 256 | 512 | 4096)) return 1;
+    P.no_cost = 1;
+    Slot& sl = ctx->slots[slot];
+    int64_t n_all = 0;
+    for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) {
+        KindSlot& ks = sl.k[kind];
+        MapIndex& m = ctx->map[kind];
+        if (!ks.has_queries || !m.valid || ks.n_q == 0 || m.n < 5 || m.has_fine) return 1;
+        const double gate = kind == LILI_KIND_SURF ? P.kd_max_radius : P.edge_gate;
+        if (!(std::sqrt(gate) * 1.0099 <= m.cell * (double)m.view.reach)) return 1;
+        if (kind == LILI_KIND_SURF && P.variant == LILI_VARIANT_LIVOX && (!m.has_aux || !ks.has_aux)) return 1;
+        n_all += ks.n_q;
+    }
+    if (n_all == 0) return 1;
+    // Lanes per query: one choice for the whole registration (the converged launches decide), halved until the launch has at most 128 workgroups —
+    // every workgroup has to be resident, two fit a CU, and up to four such launches may run side by side (lili_s2m_iterate_window).  The bound does
+    // not depend on what else runs, so a slot iterated alone and inside a window partitions its Gram sums identically (same bits).
+    int L = coop_lanes(ctx, n_all, false);
+    if (L < 2) return 1;
+    auto blocks_for = [&](int lanes) { int b = 0; for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) b += nblocks((int)sl.k[kind].n_q, 256 / lanes); return b; };
+    while (L > 2 && blocks_for(L) > 128) L /= 2;
+    const int qpb = 256 / L;
+    AssocArgs A[2] = {AssocArgs{}, AssocArgs{}};
+    const int nb = blocks_for(L);
+    if (nb > 128 || ctx->persistent_off_now) return 1;
+    for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) {
+        KindSlot& ks = sl.k[kind];
+        const int n = (int)ks.n_q;
+        AssocArgs& a = A[kind];
+        a.queries = ks.q.as<float4>(); a.n_q = n; a.g = ctx->map[kind].view;
+        a.rec0 = ks.rec0.as<float4>(); a.rec1 = ks.rec1.p; a.valid = ks.valid.as<unsigned char>();
+        if (ctx->keep_nn) {
+            HIPCHK(ks.dbg_idx.ensure((size_t)n * 5 * sizeof(int)));
+            HIPCHK(ks.dbg_d2.ensure((size_t)n * 5 * sizeof(float)));
+            a.dbg_idx = ks.dbg_idx.as<int>(); a.dbg_d2 = ks.dbg_d2.as<float>();
+        }
+        a.nb = nblocks(n, qpb);
+        HIPCHK(ks.block_counts.ensure((size_t)a.nb * sizeof(int)));
+        a.block_counts = ks.block_counts.as<int>();
+        ks.n_assoc_blocks = a.nb; ks.has_records = true; ks.launches += n_iters;
+    }
+    IterArgs it{};
+    it.state = ctx->state(slot);
+    it.nb = nb; it.ng = nb > 16 ? nblocks(nb, 16) : 1; it.n_iters = n_iters;
+    it.derive_assoc = params->variant == LILI_VARIANT_FRONTEND ? 0 : 1;
+    it.launch = ++ctx->lm_launches;
+    HIPCHK(sl.lm_part.ensure((size_t)2 * nb * kPartialStride * sizeof(double)));
+    HIPCHK(sl.lm_gsum.ensure((size_t)2 * it.ng * kPartialStride * sizeof(double)));
+    HIPCHK(sl.lm_cnt.ensure((size_t)2 * (nb + it.ng) * 4 * sizeof(double)));
+    it.part = sl.lm_part.as<double>(); it.gsum = sl.lm_gsum.as<double>(); it.cpart = sl.lm_cnt.as<double>();
+    const dim3 grid(nb), block(256);
+    switch (L) {
+        case 2: hipLaunchKernelGGL(k_iterate_coop<2>, grid, block, 0, ctx->stream, A[0], A[1], P, it); break;
+        case 4: hipLaunchKernelGGL(k_iterate_coop<4>, grid, block, 0, ctx->stream, A[0], A[1], P, it); break;
+        case 8: hipLaunchKernelGGL(k_iterate_coop<8>, grid, block, 0, ctx->stream, A[0], A[1], P, it); break;
+        case 16: hipLaunchKernelGGL(k_iterate_coop<16>, grid, block, 0, ctx->stream, A[0], A[1], P, it); break;
+        default: return 1;
+    }
+    HIPCHK(hipGetLastError());
+    sl.use_global_counts = false; sl.sticky_global_counts = false;
+    sl.assoc_since_pose += n_iters;
     return LILI_OK;
 }
 
@@ -1434,6 +1515,12 @@ static int iterate_impl(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_p
     }
     for (int it = 0; it < n_iters; it++) {   // 3 launches per outer iteration: associate, linearise, reduce+GN
         if (restart_every > 0 && it % restart_every == 0) { int rc = lili_s2m_pose_copy(ctx, slot, restart_slot); if (rc != LILI_OK) return rc; }
+        if (!assoc_ms) {        // small scans: the whole registration (up to the next restart) as ONE persistent launch
+            const int seg = restart_every > 0 ? std::min(restart_every - it % restart_every, n_iters - it) : n_iters - it;
+            const int rcp = launch_iterate_persistent(ctx, slot, kind_mask, params, seg);
+            if (rcp == LILI_OK) { it += seg - 1; continue; }
+            if (rcp != 1) return rcp;
+        }
         if (!assoc_ms) {        // flavours without count scaling: association + linearisation in one launch (2 launches per iteration)
             int rc2 = iterate_fused_lin(ctx, slot, kind_mask, params);
             if (rc2 == LILI_OK) continue;
@@ -1662,6 +1749,7 @@ int lili_s2m_iterate_window(lili_ctx* ctx, const int* slots, int n_slots, int ki
     HIPCHK(hipEventRecord(ctx->fork_ev, ctx->stream));
     hipStream_t main_stream = ctx->stream;
     int rc = LILI_OK;
+    ctx->persistent_off_now = n_slots > 4;       // more than four persistent launches side by side could not all be resident
     for (int i = 0; i < n_slots && rc == LILI_OK; i++) {
         if (i > 0) {
             if (!ctx->side[i]) HIPCHK(hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking));
@@ -1670,6 +1758,7 @@ int lili_s2m_iterate_window(lili_ctx* ctx, const int* slots, int n_slots, int ki
             ctx->stream = ctx->side[i];          // the launch helpers enqueue on ctx->stream (one thread per context)
         }
         rc = iterate_impl(ctx, slots[i], kind_mask, params, n_iters, 0, 0, nullptr);
+        if (i + 1 == n_slots || rc != LILI_OK) ctx->persistent_off_now = false;
         if (i > 0) {
             hipError_t e = hipEventRecord(ctx->join_ev[i], ctx->side[i]);
             ctx->stream = main_stream;

@@ -79,6 +79,7 @@ struct Slot {
     bool use_global_counts = false;   // next linearize_dev scales with the caller's (all-reduced) counts instead of its own
     const int32_t* global_counts = nullptr;
     bool sticky_global_counts = false;   // lili_s2m_counts_window_sharded: the global counts stay in force until the slot's next association
+    DevBuf lm_cnt;                            // k_iterate_coop: the correspondence counts of the workgroups as granules
     DevBuf lm_part, lm_gsum, lm_summary;      // lili_s2m_solve_lm: granule-tagged block partials / group sums (two parities each), device copy of the summary
     int assoc_since_pose = 0;         // association launches since the slot's pose was (re)set: the first one is the far-from-converged launch (coop_lanes)
 };
@@ -136,6 +137,10 @@ struct lili_ctx {
     int assoc_lpq = 0;           // lanes per query of the association: 0 = by launch size (coop_lanes), 1 = one lane per query always, 2 / 4 / 8 / 16 forced (A/B, tests)
     bool count_barrier = false;  // (measured: 19.4 vs 19.8 us per iteration at 2 k queries — the wait for the slowest workgroup costs what the launch saved; off by default)
 
+    bool persistent_off_now = false;  // set by lili_s2m_iterate_window for more than four slots
+    bool persistent_iterate = false;  // lili_s2m_iterate* of small scans (<= 128 cooperative workgroups): one persistent launch per registration (k_iterate_coop).
+                                      // Measured (tools/iter_time.py, profiles/r03_iter_time.json): 21.3 vs 19.6 us per outer iteration at 2 k queries (ROT), 17.2 vs 14.9
+                                      // (front end) — two exchange hops through memory across the XCDs cost more than the launch boundaries they replace; off by default
     bool fuse_lin = true;        // lili_s2m_iterate*: flavours without count scaling linearise inside the association launch (k_associate_lin)
     bool super_rows = true;      // lili_map_set also stores the super-row copy of the map (9x the points): the inner 27-cell block of a query is one run
     bool scan_lookback = true;   // map index: single-pass (decoupled look-back) scan of the cell array; 0 = the three-kernel scan (A/B)

@@ -259,6 +259,251 @@ __global__ __launch_bounds__(kCoopBlock) void k_associate_coop(AssocArgs S, Asso
         ga.finish(lds, edge ? part_edge + (size_t)vb * kPartialStride : part_surf + (size_t)vb * kPartialStride);
     }
 }
+// ================================================================================================
+// Persistent outer iterations for small scans (round 3): n_iters x [re-associate, linearise, reduce, Gauss-Newton update] in ONE launch.
+//
+// Why: at the sizes the reference itself produces (1-3 k surf + 0.1-1 k edge features per keyframe) an outer iteration is two or three launches
+// whose floor is ~4 us EACH in the kernel trace (an empty kernel costs 3.7-4.4 us there): 15.0 us per iteration for the front-end flavour at 2 k
+// queries, 19.9 us for ROT, of which only ~6 us is the cooperative association + rows.  Here the workgroups of k_associate_coop stay
+// resident for the whole registration: every iteration each workgroup associates its queries at the pose it holds in LDS, linearises its
+// records, publishes its 40-double partial as key-tagged granules, the partials are summed in index order (one hop up to 16 workgroups, else
+// group sums of 16 first) so that EVERY workgroup holds the same record bit for bit, and every workgroup applies the same Gauss-Newton step
+// itself — nothing is broadcast, nothing goes back to the host.  The count-scaled ROT flavour exchanges the correspondence counts the same way
+// before its rows.  Records, counts and debug rows are stored every iteration like the separate launches do; results equal lili_s2m_iterate's
+// up to the partition of the Gram sum (poses <= 1e-10, tests/test_coop_gpu.py).  All workgroups must be resident (<= 256 of 256 threads);
+// every wait is bounded and ends with gn_status = 2 instead of a hang.
+// ================================================================================================
+struct IterArgs {
+    SlotState* state;
+    double* part;                 // [2 parities][nb][kPartialStride]
+    double* gsum;                 // [2 parities][ng][kPartialStride]
+    double* cpart;                // [2 parities][nb + ng][4]            correspondence counts (surf, edge) as granules
+    int nb, ng, n_iters, derive_assoc;
+    unsigned long long launch;
+};
+struct IterShared {
+    double vals[16][40];
+    double cvals[16][2];
+    double tot[40];
+    double ctot[2];
+    double full[64];
+    double H[6][6], gv[6];
+    double pose[7];
+    double last_delta[6];
+    int status;                   // 0 ok, 1 = normal matrix not positive definite (pose kept), 2 = an exchange gave up
+    int n_updates;
+};
+// H d = g (no damping) on 42 lanes as in lili_s2m_lm.hip: returns false if a pivot is not positive or the step is not finite
+__device__ __forceinline__ bool gn_solve_wave(const double (*H)[6], const double* g, double d[6]) {
+    const int lane = threadIdx.x & 63;
+    const int ri = lane / 7, cj = lane - 7 * ri;
+    const bool in = lane < 42;
+    double a = 0.0;
+    if (in) a = cj < 6 ? H[ri][cj] : g[ri];
+    bool okc = true;
+    double pinv[6];
+#pragma unroll
+    for (int p = 0; p < 6; p++) {
+        const double piv = __shfl(a, p * 7 + p);
+        okc = okc && (piv > 0.0);
+        pinv[p] = 1.0 / piv;
+        const double rowp = __shfl(a, p * 7 + (in ? cj : 0));
+        const double colp = __shfl(a, (in ? ri : 0) * 7 + p);
+        if (in && ri > p) a -= (colp * pinv[p]) * rowp;
+    }
+#pragma unroll
+    for (int p = 5; p >= 0; p--) {
+        d[p] = __shfl(a, p * 7 + 6) * pinv[p];
+        const double up = __shfl(a, (in ? ri : 0) * 7 + p);
+        if (in && cj == 6 && ri < p) a -= up * d[p];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) okc = okc && (d[i] == d[i]);
+    return okc;
+}
+template <int L>
+__global__ __launch_bounds__(kCoopBlock, 2) void k_iterate_coop(AssocArgs S, AssocArgs E, MatchParams P, IterArgs a) {      // (two waves per SIMD: <= 256 registers, two workgroups per CU)
+    constexpr int QPB = kCoopBlock / L;
+    __shared__ __attribute__((aligned(16))) double lds[kCoopBlock * kRow];
+    __shared__ IterShared sh;
+    const int b = (int)blockIdx.x;
+    const bool edge = b < E.nb;
+    const AssocArgs& A = edge ? E : S;
+    const int vb = edge ? b : b - E.nb;
+    const int sub = (int)threadIdx.x & (L - 1);
+    const int i = vb * QPB + ((int)threadIdx.x / L);
+    const bool live = i < A.n_q;
+    const bool mine = live && sub == 0;
+    const bool wave0 = threadIdx.x < 64;
+    const bool scaled = P.scale_surf_num > 0 || P.scale_edge_num > 0;
+    const float4 ql = A.queries[live ? i : 0];
+    if (threadIdx.x < 7) sh.pose[threadIdx.x] = a.state->pose[threadIdx.x];
+    if (threadIdx.x == 0) { sh.status = 0; sh.n_updates = 0; }
+    for (int it = 0; it < a.n_iters; it++) {
+        __syncthreads();
+        if (sh.status == 2) break;                                        // uniform
+        const int par = it & 1;
+        const dq Q{sh.pose[3], sh.pose[4], sh.pose[5], sh.pose[6]};
+        const d3 T{sh.pose[0], sh.pose[1], sh.pose[2]};
+        dq Q2 = Q; d3 T2 = T;
+        if (a.derive_assoc) {      // L/src/BackendFusion.cpp:929-930 (load_assoc_pose)
+            Q2 = qmul(Q, dq{P.q_lb_inv[0], P.q_lb_inv[1], P.q_lb_inv[2], P.q_lb_inv[3]});
+            T2 = T - qrot(Q2, d3{P.t_lb[0], P.t_lb[1], P.t_lb[2]});
+        }
+        const d3 pmd = qrot(Q2, d3{(double)ql.x, (double)ql.y, (double)ql.z}) + T2;
+        const float px = (float)pmd.x, py = (float)pmd.y, pz = (float)pmd.z;
+        Top5 nn;
+        knn5_coop<L>(A.g, live, sub, px, py, pz, gate_bound(edge ? P.edge_gate : P.kd_max_radius), nn);
+        LaneRec rec{};
+        bool ok = false;
+        if (live) {
+            if (mine) store_debug_nn(A.g, nn, i, A.dbg_idx, A.dbg_d2);
+            if (edge) {
+                float4 ra, rb;
+                ok = edge_fit(A.g, P, nn, px, py, pz, ra, rb);
+                if (mine) { A.rec0[i] = ra; reinterpret_cast<float4*>(A.rec1)[i] = rb; A.valid[i] = ok ? 1 : 0; }
+                rec.r0 = ra; rec.r1 = rb;
+            } else {
+                float4 rn; double score;
+                ok = surf_fit(A.g, P, nn, ql, px, py, pz, rn, score);
+                if (mine) { A.rec0[i] = rn; reinterpret_cast<double*>(A.rec1)[i] = score; A.valid[i] = ok ? 1 : 0; }
+                rec.r0 = rn; rec.score = score;
+            }
+            rec.ql = ql;
+        }
+        rec.ok = ok && mine;
+        store_block_count<kCoopBlock>(rec.ok, A.block_counts, vb);          // (ends with the block's count in A.block_counts[vb], written by thread 0)
+        // ---- count-scaled flavour: the scan's correspondence counts, summed over the workgroups (round 2 it)
+        double n_surf = 1.0, n_edge = 1.0;
+        if (scaled) {
+            const unsigned long long ckey = xchg_key(a.launch, 2 * it);
+            double* cpart = a.cpart + (size_t)par * (a.nb + a.ng) * 4;
+            if (threadIdx.x == 0) {
+                const double c = (double)A.block_counts[vb];
+                store_granule(cpart + (size_t)b * 4, edge ? 0.0 : c, ckey);
+                store_granule(cpart + (size_t)b * 4 + 2, edge ? c : 0.0, ckey);
+            }
+            if (wave0) {
+                bool okx = true;
+                if (a.ng > 1) {
+                    if (b % 16 == 0) {
+                        okx = xchg_gather<2>(cpart + (size_t)b * 4, min(16, a.nb - b), ckey, sh.cvals, sh.ctot, 4);
+                        if ((threadIdx.x & 63) < 2) store_granule(cpart + (size_t)(a.nb + b / 16) * 4 + 2 * (threadIdx.x & 63), sh.ctot[threadIdx.x & 63], ckey);
+                    }
+                    okx = xchg_gather<2>(cpart + (size_t)a.nb * 4, a.ng, ckey, sh.cvals, sh.ctot, 4) && okx;
+                } else okx = xchg_gather<2>(cpart, a.nb, ckey, sh.cvals, sh.ctot, 4);
+                if (!okx && threadIdx.x == 0) sh.status = 2;
+            }
+            __syncthreads();
+            n_surf = sh.ctot[0]; n_edge = sh.ctot[1];
+        }
+        // ---- rows of this workgroup's records, Gram partial as granules (round 2 it + 1)
+        double Jr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double cost = 0.0;
+        if (rec.ok) {
+            if (edge) {
+                double sw = (double)rec.r0.w;
+                if (P.scale_edge_num > 0) sw = (double)__fdiv_rn(__fmul_rn(rec.r0.w, (float)P.scale_edge_num), (float)(int)n_edge);      // R:843 (lin_edge_body)
+                cost = edge_lin_row(P, Q, T, rec.ql, rec.r0, rec.r1, sw, Jr);
+            } else {
+                double score = rec.score;
+                if (P.scale_surf_num > 0) score = score * P.scale_surf_num / (double)(int)n_surf;                                       // R:861 (lin_surf_body)
+                cost = surf_lin_row(P, Q, T, dq{P.q_lb_inv_jet[0], P.q_lb_inv_jet[1], P.q_lb_inv_jet[2], P.q_lb_inv_jet[3]}, rec.ql, rec.r0, score, Jr);
+            }
+        }
+        const unsigned long long key = xchg_key(a.launch, 2 * it + 1);
+        double* part = a.part + (size_t)par * a.nb * kPartialStride;
+        double* gsum = a.gsum + (size_t)par * a.ng * kPartialStride;
+        GramAcc ga; ga.init();
+        ga.add_rows(Jr, cost, rec.ok, lds);
+        ga.finish(lds, part + (size_t)b * kPartialStride, key);
+        if (wave0) {
+            bool okx = true;
+            if (a.ng > 1) {
+                if (b % 16 == 0) {
+                    okx = xchg_gather<40>(part + (size_t)b * kPartialStride, min(16, a.nb - b), key, sh.vals, sh.tot);
+                    if ((threadIdx.x & 63) < 40) store_granule(gsum + (size_t)(b / 16) * kPartialStride + 2 * (threadIdx.x & 63), sh.tot[threadIdx.x & 63], key);
+                }
+                okx = xchg_gather<40>(gsum, a.ng, key, sh.vals, sh.tot) && okx;
+            } else okx = xchg_gather<40>(part, a.nb, key, sh.vals, sh.tot);
+            // ---- the Gauss-Newton step, identically in every workgroup: H = P^T G77 P, g = -P^T G7r, H d = g, x (+) d
+            {
+                const int lane = threadIdx.x;
+                const int r = lane >> 3, c = lane & 7;
+                const int aa = r < c ? r : c, bb = r < c ? c : r;
+                sh.full[lane] = sh.tot[aa * 8 - aa * (aa - 1) / 2 + (bb - aa)];
+            }
+            LILI_WAVE_SYNC();
+            {
+                const int tid = threadIdx.x;
+                const double x0 = sh.pose[3], x1 = sh.pose[4], x2 = sh.pose[5], x3 = sh.pose[6];
+                auto jcol = [&](int c, double o[4]) {
+                    o[0] = c == 0 ? -x1 : c == 1 ? -x2 : -x3;
+                    o[1] = c == 0 ? x0 : c == 1 ? x3 : -x2;
+                    o[2] = c == 0 ? -x3 : c == 1 ? x0 : x1;
+                    o[3] = c == 0 ? x2 : c == 1 ? -x1 : x0;
+                };
+                if (tid < 42) {
+                    const int ar = tid < 36 ? tid / 6 : tid - 36, bc = tid < 36 ? tid % 6 : 7;
+                    double jb[4] = {0, 0, 0, 0}, ja[4] = {0, 0, 0, 0};
+                    if (bc >= 3 && bc < 6) jcol(bc - 3, jb);
+                    if (ar >= 3) jcol(ar - 3, ja);
+                    const double* gram = sh.full;
+                    auto Mrow = [&](int ii) -> double {
+                        if (bc < 3 || bc == 7) return gram[ii * 8 + bc];
+                        return ((gram[ii * 8 + 3] * jb[0] + gram[ii * 8 + 4] * jb[1]) + gram[ii * 8 + 5] * jb[2]) + gram[ii * 8 + 6] * jb[3];
+                    };
+                    double v;
+                    if (ar < 3) v = Mrow(ar);
+                    else v = ((ja[0] * Mrow(3) + ja[1] * Mrow(4)) + ja[2] * Mrow(5)) + ja[3] * Mrow(6);
+                    if (tid < 36) sh.H[ar][bc] = v; else sh.gv[ar] = -v;
+                }
+            }
+            LILI_WAVE_SYNC();
+            double d[6];
+            const bool solved = gn_solve_wave(sh.H, sh.gv, d);
+            if (threadIdx.x == 0) {
+                if (!okx) sh.status = 2;
+                else if (!solved) sh.status = 1;
+                else {
+                    sh.status = 0;
+                    sh.pose[0] += d[0]; sh.pose[1] += d[1]; sh.pose[2] += d[2];
+                    const double nd2 = d[3] * d[3] + d[4] * d[4] + d[5] * d[5];
+                    if (nd2 > 0.0) {
+                        double sbd, cw;
+                        if (nd2 < 0.25) sinc_cos_small(nd2, sbd, cw);
+                        else {
+                            double h2 = nd2; int k = 0;
+                            while (h2 >= 0.25 && k < 60) { h2 *= 0.25; k++; }
+                            double sc, cc;
+                            sinc_cos_small(h2, sc, cc);
+                            double sn = sc * sqrt(h2);
+                            for (int q = 0; q < k; q++) { const double s2 = 2.0 * sn * cc, c2 = cc * cc - sn * sn; sn = s2; cc = c2; }
+                            sbd = sn / sqrt(nd2); cw = cc;
+                        }
+                        const dq rq = qmul(dq{cw, sbd * d[3], sbd * d[4], sbd * d[5]}, dq{sh.pose[3], sh.pose[4], sh.pose[5], sh.pose[6]});
+                        sh.pose[3] = rq.w; sh.pose[4] = rq.x; sh.pose[5] = rq.y; sh.pose[6] = rq.z;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 6; q++) sh.last_delta[q] = d[q];
+                }
+                sh.n_updates++;
+            }
+        }
+    }
+    __syncthreads();
+    if (b == 0 && threadIdx.x == 0) {
+        for (int q = 0; q < 7; q++) a.state->pose[q] = sh.pose[q];
+        for (int q = 0; q < 6; q++) a.state->last_delta[q] = sh.last_delta[q];
+        a.state->gn_status = sh.status;
+        a.state->iters += sh.n_updates;
+    }
+}
+template __global__ void k_iterate_coop<2>(AssocArgs, AssocArgs, MatchParams, IterArgs);
+template __global__ void k_iterate_coop<4>(AssocArgs, AssocArgs, MatchParams, IterArgs);
+template __global__ void k_iterate_coop<8>(AssocArgs, AssocArgs, MatchParams, IterArgs);
+template __global__ void k_iterate_coop<16>(AssocArgs, AssocArgs, MatchParams, IterArgs);
+
 #define LILI_COOP_INST(L) \
     template __global__ void k_associate_coop<L, false>(AssocArgs, AssocArgs, PoseArg, MatchParams, double*, double*, SlotState*, int); \
     template __global__ void k_associate_coop<L, true>(AssocArgs, AssocArgs, PoseArg, MatchParams, double*, double*, SlotState*, int);

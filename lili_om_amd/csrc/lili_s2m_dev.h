@@ -921,4 +921,38 @@ __device__ __forceinline__ void lin_edge_body(const LinArgs& A, int bid, const P
 }
 
 
+// ---- exchange between the workgroups of ONE persistent launch (lili_s2m_lm.hip, k_iterate_coop in lili_s2m_coop.hip): 16-byte granules
+// {value, value ^ key}, key unique per (launch, round) — the data is its own flag (cdna_hip_programming.md Guideline 16, form R2).
+__device__ __forceinline__ unsigned long long xchg_key(unsigned long long launch, int round) { return (launch * 4096ull + (unsigned long long)round + 1ull) * 0x9E3779B97F4A7C15ull; }
+// ONE wave (lanes 0..63): waits until the `count` x NE granules at `src` (`stride` doubles per source) carry `key`, then out[e] = sum over the
+// sources in index order.  `vals` = LDS scratch [>= count][NE].  Returns false if the (bounded) wait gave up.
+template <int NE>
+__device__ __forceinline__ bool xchg_gather(const double* src, int count, unsigned long long key, double (*vals)[NE], double* out, int stride = kPartialStride) {
+    const int lane = threadIdx.x & 63;
+    const int n = count * NE;
+    bool ok = false;
+    for (unsigned sweep = 0; sweep < (1u << 22); sweep++) {
+        bool all = true;
+        for (int g = lane; g < n; g += 64) {
+            const int m = g / NE, e = g - m * NE;
+            unsigned long long lo, hi;
+            load_granule(src + (size_t)m * stride + 2 * e, lo, hi);
+            all = all && ((lo ^ hi) == key);
+            vals[m][e] = __longlong_as_double((long long)lo);
+        }
+        if (__all(all)) { ok = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < NE) {
+        double s = 0.0;
+        for (int m = 0; m < count; m++) s += vals[m][lane];
+        out[lane] = s;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return ok;
+}
+
 }  // namespace lili

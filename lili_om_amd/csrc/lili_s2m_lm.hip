@@ -47,38 +47,6 @@ struct LmArgs {
     double initial_radius, max_radius, min_radius, min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
 };
 
-__device__ __forceinline__ unsigned long long lm_key(unsigned long long launch, int eval) { return (launch * 4096ull + (unsigned long long)eval + 1ull) * 0x9E3779B97F4A7C15ull; }
-
-// ONE wave (lanes 0..63 of wave 0): waits until the `count` x 40 granules at `src` (stride kPartialStride doubles per source) carry `key`,
-// then out[e] = sum over the sources in index order.  `vals` = LDS scratch [kLmGroup][40].  Returns false if the wait gave up.
-__device__ __forceinline__ bool lm_gather(const double* src, int count, unsigned long long key, double (*vals)[40], double* out) {
-    const int lane = threadIdx.x & 63;
-    const int n = count * 40;
-    bool ok = false;
-    for (unsigned sweep = 0; sweep < (1u << 22); sweep++) {
-        bool all = true;
-        for (int g = lane; g < n; g += 64) {
-            const int m = g / 40, e = g - m * 40;
-            unsigned long long lo, hi;
-            load_granule(src + (size_t)m * kPartialStride + 2 * e, lo, hi);
-            all = all && ((lo ^ hi) == key);
-            vals[m][e] = __longlong_as_double((long long)lo);
-        }
-        if (__all(all)) { ok = true; break; }
-        __builtin_amdgcn_s_sleep(1);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (lane < 40) {
-        double s = 0.0;
-        for (int m = 0; m < count; m++) s += vals[m][lane];
-        out[lane] = s;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    return ok;
-}
-
 struct LmShared {
     double vals[kLmGroup][40];
     double tot[40];            // sum of all partials of the current evaluation (upper triangle of the 8x8 Gram, [36] cost, [37] rows)
@@ -138,90 +106,100 @@ __device__ __forceinline__ void lm_scaled_system(LmShared& sh) {
     if (tid < 36) sh.Hs[tid / 6][tid % 6] = sh.H[tid / 6][tid % 6] * sh.scale[tid / 6] * sh.scale[tid % 6];
     else if (tid < 42) sh.gs[tid - 36] = sh.gv[tid - 36] * sh.scale[tid - 36];
 }
-// The trust-region step from the accepted point (ONE lane).  Returns with sh.go = 1 and sh.xn = candidate, or sh.go = 0 (finished).
-// The 6x6 system lives in LDS (sh.Hs, sh.gs: they change only when a step is accepted) and only the factor being built is held in
-// registers — with everything in registers the launch (capped at 128 VGPRs by its 1024-thread workgroups) spilled 150 words to scratch
-// on the critical path of every evaluation.
+// The trust-region step from the accepted point, by ONE WAVE (all 64 lanes call it, control flow uniform).  Returns with sh.go = 1 and sh.xn =
+// candidate, or sh.go = 0 (finished).  The 6x6 system (H_s + D^2) d = -g_s is eliminated on 42 lanes — lane (i, j) holds entry j of row i of the
+// augmented matrix [A | b] — with the pivot taken by v_readlane and the pivot row / column through ds_bpermute: six elimination and six substitution
+// steps of ~200 cycles instead of ~600 dependent f64 instructions on one lane (round 3 first version: ~3 us of the ~8.5 us an evaluation took).
+// Every workgroup runs the same instruction sequence on the same bits, so the candidates agree bit for bit across workgroups.
+__device__ __forceinline__ double lm_bcast(double v, int src_lane) { return __shfl(v, src_lane); }
 __device__ __forceinline__ void lm_propose(LmShared& sh) {
-    const LmShared& a = sh;
+    const int lane = threadIdx.x & 63;
+    const int ri = lane / 7, cj = lane - 7 * ri;             // row / column of the augmented 6 x 7 matrix (lanes >= 42 idle along)
+    const bool in = lane < 42;
     for (;;) {
-        if (sh.it >= a.max_iter) { sh.term = LILI_LM_MAX_ITERATIONS; sh.go = 0; return; }
+        const int it = sh.it;
+        if (it >= sh.max_iter) { if (lane == 0) { sh.term = LILI_LM_MAX_ITERATIONS; sh.go = 0; } return; }
         double gmax = 0.0;
 #pragma unroll
         for (int i = 0; i < 6; i++) gmax = fmax(gmax, fabs(sh.gv[i]));
-        if (gmax <= a.gradient_tolerance) { sh.term = LILI_LM_GRADIENT_TOLERANCE; sh.it++; sh.go = 0; return; }      // (Ceres counts the iteration it stops in)
-        // (Hs + D^2) d = -gs with D^2 = clamp(diag Hs, min_lm_diagonal, max_lm_diagonal) / radius: LDL^T with reciprocal pivots,
-        // L (unit lower triangle) in registers, column by column
-        double Lm[6][6], dv[6], dinv[6], d[6];
+        if (gmax <= sh.gradient_tolerance) { if (lane == 0) { sh.term = LILI_LM_GRADIENT_TOLERANCE; sh.it = it + 1; sh.go = 0; } return; }      // (Ceres counts the iteration it stops in)
+        const double radius = sh.radius;
+        double a = 0.0;
+        if (in) {
+            if (cj < 6) {
+                a = sh.Hs[ri][cj];
+                if (cj == ri) a += fmin(fmax(a, sh.min_lm_diagonal), sh.max_lm_diagonal) / radius;      // D^2 = clamp(diag H_s) / radius
+            } else a = -sh.gs[ri];
+        }
         bool okc = true;
-        const double rinv = 1.0 / sh.radius;
+        double pinv[6];
 #pragma unroll
-        for (int j = 0; j < 6; j++) {
-            const double hjj = sh.Hs[j][j];
-            double dj = hjj + fmin(fmax(hjj, a.min_lm_diagonal), a.max_lm_diagonal) * rinv;
+        for (int p = 0; p < 6; p++) {
+            const double piv = lm_bcast(a, p * 7 + p);
+            okc = okc && (piv > 0.0);
+            pinv[p] = 1.0 / piv;
+            const double rowp = lm_bcast(a, p * 7 + (in ? cj : 0));      // A[p][my column]
+            const double colp = lm_bcast(a, (in ? ri : 0) * 7 + p);      // A[my row][p]
+            if (in && ri > p) a -= (colp * pinv[p]) * rowp;
+        }
+        double d[6];
 #pragma unroll
-            for (int k = 0; k < j; k++) dj -= Lm[j][k] * Lm[j][k] * dv[k];
-            if (!(dj > 0)) okc = false;
-            dv[j] = dj;
-            dinv[j] = 1.0 / dj;
-#pragma unroll
-            for (int i = j + 1; i < 6; i++) {
-                double sv = sh.Hs[i][j];
-#pragma unroll
-                for (int k = 0; k < j; k++) sv -= Lm[i][k] * Lm[j][k] * dv[k];
-                Lm[i][j] = sv * dinv[j];
-            }
+        for (int p = 5; p >= 0; p--) {
+            d[p] = lm_bcast(a, p * 7 + 6) * pinv[p];
+            const double up = lm_bcast(a, (in ? ri : 0) * 7 + p);        // U[my row][p]
+            if (in && cj == 6 && ri < p) a -= up * d[p];
         }
 #pragma unroll
-        for (int i = 0; i < 6; i++) { double sv = -sh.gs[i]; for (int k = 0; k < i; k++) sv -= Lm[i][k] * d[k]; d[i] = sv; }
-#pragma unroll
-        for (int i = 0; i < 6; i++) d[i] = d[i] * dinv[i];
-#pragma unroll
-        for (int i = 5; i >= 0; i--) { double sv = d[i]; for (int k = i + 1; k < 6; k++) sv -= Lm[k][i] * d[k]; d[i] = sv; }
-#pragma unroll
-        for (int i = 0; i < 6; i++) if (!(d[i] == d[i])) okc = false;
-        if (!okc) { sh.term = LILI_LM_NUMERICAL_FAILURE; sh.go = 0; return; }
-        // model_cost_change = -d^T (gs + Hs d / 2)
-        double mc = 0.0;
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
+        for (int i = 0; i < 6; i++) okc = okc && (d[i] == d[i]);
+        if (!okc) { if (lane == 0) { sh.term = LILI_LM_NUMERICAL_FAILURE; sh.go = 0; } return; }
+        // model_cost_change = -d^T (g_s + H_s d / 2): row sums on six lanes, then a fixed-order sum
+        double tr = 0.0;
+        if (lane < 6) {
             double hd = 0.0;
 #pragma unroll
-            for (int j = 0; j < 6; j++) hd += sh.Hs[i][j] * d[j];
-            mc += d[i] * (sh.gs[i] + 0.5 * hd);
+            for (int j = 0; j < 6; j++) hd += sh.Hs[lane][j] * d[j];
+            double dl = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; j++) dl = lane == j ? d[j] : dl;
+            tr = dl * (sh.gs[lane] + 0.5 * hd);
         }
+        double mc = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) mc += lm_bcast(tr, i);
         mc = -mc;
         if (!(mc > 0.0)) {       // not a descent step of the model: shrink, no evaluation (the iteration counts)
-            sh.radius = fmax(sh.min_radius, sh.radius / sh.decrease); sh.decrease *= 2.0;
-            sh.it++;
+            if (lane == 0) { sh.radius = fmax(sh.min_radius, radius / sh.decrease); sh.decrease *= 2.0; sh.it = it + 1; }
+            LILI_WAVE_SYNC();
             continue;
         }
-        double n2 = 0.0;
+        if (lane == 0) {
+            double n2 = 0.0;
 #pragma unroll
-        for (int i = 0; i < 6; i++) { d[i] = d[i] * sh.scale[i]; n2 += d[i] * d[i]; }      // delta in the unscaled local coordinates
-        sh.model_change = mc;
-        sh.step_norm = sqrt(n2);
-        // x (+) delta: ceres::QuaternionParameterization::Plus
-        sh.xn[0] = sh.x[0] + d[0]; sh.xn[1] = sh.x[1] + d[1]; sh.xn[2] = sh.x[2] + d[2];
-        const double nd2 = d[3] * d[3] + d[4] * d[4] + d[5] * d[5];
-        if (nd2 > 0.0) {
-            // sin(|d|) / |d| and cos(|d|): the series of sinc_cos_small below 0.5 rad, above it halve the angle first and double it back
-            // (libm's sin / cos bring a Payne-Hanek reduction with a scratch table into the launch; a trust-region step never turns that far anyway)
-            double sbd, cw;
-            if (nd2 < 0.25) sinc_cos_small(nd2, sbd, cw);
-            else {
-                double h2 = nd2; int k = 0;
-                while (h2 >= 0.25 && k < 60) { h2 *= 0.25; k++; }
-                double sc, c;
-                sinc_cos_small(h2, sc, c);
-                double sn = sc * sqrt(h2);
-                for (int i = 0; i < k; i++) { const double s2 = 2.0 * sn * c, c2 = c * c - sn * sn; sn = s2; c = c2; }
-                sbd = sn / sqrt(nd2); cw = c;
-            }
-            const dq r = qmul(dq{cw, sbd * d[3], sbd * d[4], sbd * d[5]}, dq{sh.x[3], sh.x[4], sh.x[5], sh.x[6]});
-            sh.xn[3] = r.w; sh.xn[4] = r.x; sh.xn[5] = r.y; sh.xn[6] = r.z;
-        } else { sh.xn[3] = sh.x[3]; sh.xn[4] = sh.x[4]; sh.xn[5] = sh.x[5]; sh.xn[6] = sh.x[6]; }
-        sh.go = 1;
+            for (int i = 0; i < 6; i++) { d[i] = d[i] * sh.scale[i]; n2 += d[i] * d[i]; }      // delta in the unscaled local coordinates
+            sh.model_change = mc;
+            sh.step_norm = sqrt(n2);
+            // x (+) delta: ceres::QuaternionParameterization::Plus
+            sh.xn[0] = sh.x[0] + d[0]; sh.xn[1] = sh.x[1] + d[1]; sh.xn[2] = sh.x[2] + d[2];
+            const double nd2 = d[3] * d[3] + d[4] * d[4] + d[5] * d[5];
+            if (nd2 > 0.0) {
+                // sin(|d|) / |d| and cos(|d|): the series of sinc_cos_small below 0.5 rad, above it halve the angle first and double it back
+                // (libm's sin / cos bring a Payne-Hanek reduction with a scratch table into the launch; a trust-region step never turns that far anyway)
+                double sbd, cw;
+                if (nd2 < 0.25) sinc_cos_small(nd2, sbd, cw);
+                else {
+                    double h2 = nd2; int k = 0;
+                    while (h2 >= 0.25 && k < 60) { h2 *= 0.25; k++; }
+                    double sc, c;
+                    sinc_cos_small(h2, sc, c);
+                    double sn = sc * sqrt(h2);
+                    for (int i = 0; i < k; i++) { const double s2 = 2.0 * sn * c, c2 = c * c - sn * sn; sn = s2; c = c2; }
+                    sbd = sn / sqrt(nd2); cw = c;
+                }
+                const dq r = qmul(dq{cw, sbd * d[3], sbd * d[4], sbd * d[5]}, dq{sh.x[3], sh.x[4], sh.x[5], sh.x[6]});
+                sh.xn[3] = r.w; sh.xn[4] = r.x; sh.xn[5] = r.y; sh.xn[6] = r.z;
+            } else { sh.xn[3] = sh.x[3]; sh.xn[4] = sh.x[4]; sh.xn[5] = sh.x[5]; sh.xn[6] = sh.x[6]; }
+            sh.go = 1;
+        }
         return;
     }
 }
@@ -257,7 +235,7 @@ __global__ __launch_bounds__(kLmThreads) void k_solve_lm(LmArgs a, MatchParams P
     double cost0 = 0.0;
     for (int eval = 0;; eval++) {
         const int par = eval & 1;
-        const unsigned long long key = lm_key(a.launch, eval);
+        const unsigned long long key = xchg_key(a.launch, eval);
         double* part = a.part + (size_t)par * a.nb * kPartialStride;
         double* gsum = a.gsum + (size_t)par * a.ng * kPartialStride;
         PoseArg pa{};
@@ -274,11 +252,11 @@ __global__ __launch_bounds__(kLmThreads) void k_solve_lm(LmArgs a, MatchParams P
             if (a.ng > 1) {
                 if (b % kLmGroup == 0) {
                     const int cnt = min(kLmGroup, a.nb - b);
-                    ok = lm_gather(part + (size_t)b * kPartialStride, cnt, key, sh.vals, sh.tot);
+                    ok = xchg_gather<40>(part + (size_t)b * kPartialStride, cnt, key, sh.vals, sh.tot);
                     if ((threadIdx.x & 63) < 40) store_granule(gsum + (size_t)(b / kLmGroup) * kPartialStride + 2 * (threadIdx.x & 63), sh.tot[threadIdx.x & 63], key);
                 }
-                ok = lm_gather(gsum, a.ng, key, sh.vals, sh.tot) && ok;
-            } else ok = lm_gather(part, a.nb, key, sh.vals, sh.tot);
+                ok = xchg_gather<40>(gsum, a.ng, key, sh.vals, sh.tot) && ok;
+            } else ok = xchg_gather<40>(part, a.nb, key, sh.vals, sh.tot);
             if (!ok && threadIdx.x == 0) sh.stalled = 1;
             // ---- step logic, identical in every workgroup
             if (eval == 0) {
@@ -335,7 +313,7 @@ __global__ __launch_bounds__(kLmThreads) void k_solve_lm(LmArgs a, MatchParams P
                 }
             }
             LILI_WAVE_SYNC();
-            if (threadIdx.x == 0 && sh.go) lm_propose(sh);      // the next candidate (or the end), from the accepted point — ONE lane, ONE call site
+            if (sh.go) lm_propose(sh);      // the next candidate (or the end), from the accepted point — the whole wave, ONE call site
             LILI_WAVE_SYNC();
         }
         __syncthreads();

@@ -27,3 +27,13 @@ def gpu_ctx():
     ctx = L.Context(0)
     yield ctx
     ctx.close()
+
+
+@pytest.fixture
+def launch_by_launch(gpu_ctx):
+    """The launch-per-stage iteration loop (the default).  Option persistent_iterate = 1 runs small scans inside ONE persistent launch
+    (k_iterate_coop) whose Gram sums are partitioned per workgroup of 256 / L queries: poses then differ in the last bits.  Tests that assert
+    BIT-identity between launch structures of the launch-per-stage loop pin the option, whatever the default is."""
+    gpu_ctx.set_option("persistent_iterate", 0)
+    yield gpu_ctx
+    gpu_ctx.set_option("persistent_iterate", 0)

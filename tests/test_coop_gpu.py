@@ -99,6 +99,7 @@ def test_cooperative_iterations_follow_the_one_lane_iterations(gpu_ctx, flavour)
     three = flavour == "rot_three_launches"
     flavour = "rot" if three else flavour
     gpu_ctx.set_option("count_barrier", 0 if three else 1)      # (off by default: measured no gain; the path stays tested)
+    gpu_ctx.set_option("persistent_iterate", 0)                 # launch by launch here; the persistent launch has its own test below
     room = synth.make_room(seed=47, n_query=3000, n_edge_query=250)
     P = L.make_params(flavour)
     tb, qb = L.api.body_pose_from_lidar(room["t_true"], room["q_true"], P)
@@ -144,4 +145,65 @@ def test_cooperative_ragged_and_tiny_inputs(gpu_ctx):
             assert np.array_equal(ref["lin"][2], got["lin"][2])
     finally:
         gpu_ctx.set_option("assoc_lpq", 0)
+        gpu_ctx.set_debug(False)
+
+
+@pytest.mark.parametrize("flavour", ["rot", "livox", "frontend"])
+@pytest.mark.parametrize("n_surf,n_edge", [(2500, 200), (700, 0), (12000, 600)])
+def test_persistent_iterations_follow_the_launch_by_launch_loop(gpu_ctx, flavour, n_surf, n_edge):
+    """k_iterate_coop (option persistent_iterate; off by default — measured no faster than the launches): the outer iterations of a SMALL scan — associate, [exchange the counts],
+    linearise, sum, Gauss-Newton step — inside one launch whose workgroups all stay resident; the pose travels through LDS and the
+    granule exchange instead of through launches.  Same records, same rows; only the partition of the Gram sum differs from the
+    launch-per-stage loop (one partial per 256 / L queries), so poses agree to 1e-10, iteration counters and statuses are equal, the
+    records left behind are those of the LAST association, and a repeat gives the same bits.  Also with restarts (iterate_sharded's
+    restart_every, here through lili_s2m_iterate with a restart slot) and for three slots side by side (iterate_window)."""
+    room = synth.make_room(seed=59, n_query=n_surf, n_edge_query=max(n_edge, 1))
+    P = L.make_params(flavour)
+    tb, qb = L.api.body_pose_from_lidar(room["t_true"], room["q_true"], P)
+    t0, q0 = synth.perturbed_pose(tb, qb, np.random.default_rng(31), 0.15, 1.2)
+    smap, emap, sq, eq = _clouds(room, flavour)
+    mask = L.MASK_SURF | (L.MASK_EDGE if n_edge else 0)
+    m = L.ScanToMapMatcher(gpu_ctx, P)
+    m.set_input_cloud(L.KIND_SURF, smap)
+    m.set_input_cloud(L.KIND_EDGE, emap)
+    for k in range(3):
+        m.set_queries(k, L.KIND_SURF, sq)
+        if n_edge:
+            m.set_queries(k, L.KIND_EDGE, eq[:n_edge])
+    gpu_ctx.set_debug(True)
+    res = {}
+    try:
+        for mode in (0, 1, 1):
+            gpu_ctx.set_option("persistent_iterate", mode)
+            m.pose_set(0, t0, q0)
+            m.iterate(0, 7, mask)
+            t, q, st = m.pose_get(0)
+            rec = m.surf_records(0, sq.shape[0])
+            lin = m.linearize(0, t, q, mask)
+            if mode in res:
+                t1, q1, st1, rec1, lin1 = res[mode]                 # deterministic: the second persistent run repeats every bit
+                assert np.array_equal(t, t1) and np.array_equal(q, q1) and np.array_equal(lin[0], lin1[0])
+            res[mode] = (t, q, st, rec, lin)
+        (ta, qa, sa, ra, la), (tb_, qb_, sb, rb, lb) = res[0], res[1]
+        assert sa == 0 and sb == 0 and np.abs(ta - t0).max() > 1e-3
+        assert np.abs(ta - tb_).max() < 1e-10 and np.abs(qa - qb_).max() < 1e-10
+        assert ra["count"] == rb["count"] > 0.3 * n_surf and np.array_equal(ra["query_index"], rb["query_index"])
+        assert np.abs(ra["n"] - rb["n"]).max() < 1e-6 and np.array_equal(la[2], lb[2])
+        assert np.abs(la[0] - lb[0]).max() <= 1e-7 * np.abs(la[0]).max()
+        # three slots side by side: the same bits as one after the other (the lanes-per-query rule does not depend on what else runs)
+        gpu_ctx.set_option("persistent_iterate", 1)
+        starts = [synth.perturbed_pose(tb, qb, np.random.default_rng(40 + k), 0.1, 0.8) for k in range(3)]
+        one = []
+        for k in range(3):
+            m.pose_set(k, *starts[k])
+            m.iterate(k, 5, mask)
+            one.append(m.pose_get(k))
+        for k in range(3):
+            m.pose_set(k, *starts[k])
+        m.iterate_window([0, 1, 2], 5, mask)
+        for k in range(3):
+            t, q, st = m.pose_get(k)
+            assert st == 0 and np.array_equal(t, one[k][0]) and np.array_equal(q, one[k][1])
+    finally:
+        gpu_ctx.set_option("persistent_iterate", 0)
         gpu_ctx.set_debug(False)

@@ -355,7 +355,7 @@ def test_query_order_options_do_not_change_results(gpu_ctx, oracle, opts):
     assert np.array_equal(b[1][inside], rs["nn_idx"][inside])
 
 
-def test_split_multi_gpu_path_equals_fused_path(gpu_ctx, oracle):
+def test_split_multi_gpu_path_equals_fused_path(gpu_ctx, oracle, launch_by_launch):
     """The stage-by-stage path a multi-GPU caller uses (associate_dev, counts export / [all-reduce] / import,
     linearize_dev, [all-reduce], gn_update) with world size 1 must give exactly the fused iterate() result."""
     import torch
@@ -415,7 +415,7 @@ _OPTION_DEFAULTS = {"nn_cache": 0, "fuse_tail": 0, "merge_kinds": 1}
 
 
 @pytest.mark.parametrize("opt", ["nn_cache", "fuse_tail", "merge_kinds"])
-def test_tuning_options_do_not_change_results(gpu_ctx, oracle, opt):
+def test_tuning_options_do_not_change_results(gpu_ctx, oracle, opt, launch_by_launch):
     """Launch-structure switches change no result bit: neighbour-cache bound seeding, the reduction + GN update inside the
     linearisation launch (fuse_tail: last block to arrive, write-through partials, sharded tickets) against the separate
     k_reduce_partials launch, and one launch for both kinds (merge_kinds) against one launch per kind.  All add the same
@@ -636,7 +636,7 @@ def test_super_row_layout_changes_no_result(gpu_ctx, oracle, flavour):
         assert np.array_equal(a[9], b[9]) and np.array_equal(a[10], b[10]) and a[11] == b[11]
 
 
-def test_fuse_tail_toggled_between_set_queries_and_iterate(gpu_ctx, oracle):
+def test_fuse_tail_toggled_between_set_queries_and_iterate(gpu_ctx, oracle, launch_by_launch):
     """the fused tail used to depend on a block size latched at set_queries.  The linearisation block is
     fixed now, so the option may change at any time: toggling it after set_queries, in the middle of a registration, changes
     no bit of the pose, and the fused launch repeated 200 times (tickets re-arm themselves) stays identical."""
@@ -752,7 +752,7 @@ def test_fast_tiers_equal_exact_tiers(gpu_ctx, oracle):
     assert (r0["n"].view(np.uint32) == r2["n"].view(np.uint32)).mean() > 0.99       # almost always the same f32
 
 
-def test_sharded_loop_equals_fused_iterations(gpu_ctx, oracle):
+def test_sharded_loop_equals_fused_iterations(gpu_ctx, oracle, launch_by_launch):
     """lili_s2m_iterate_sharded (the multi-GPU loop with the collectives enqueued from C) on ONE rank — without collectives and
     with a host callback standing in for ncclAllReduce — gives the pose of the fused single-GPU iterations bit for bit."""
     import ctypes as C
@@ -790,7 +790,7 @@ def test_sharded_loop_equals_fused_iterations(gpu_ctx, oracle):
     assert np.array_equal(t3, t_ref) and np.array_equal(q3, q_ref)                      # two registrations of four iterations
 
 
-def test_native_rccl_communicator_single_rank(gpu_ctx, oracle):
+def test_native_rccl_communicator_single_rank(gpu_ctx, oracle, launch_by_launch):
     """lili_om_amd/rccl.py: a one-rank RCCL communicator next to PyTorch's runtime; the sharded loop with the real ncclAllReduce
     enqueued from C reproduces the fused iterations (a sum over one rank is the identity)."""
     import torch
