@@ -39,8 +39,12 @@ struct RotState {
     int ring_nedge[kMaxRings], ring_nsharp[kMaxRings], ring_nflat[kMaxRings], ring_nlf[kMaxRings], ring_nsurf[kMaxRings];
     int n_edge, n_sharp, n_flat, n_lessflat, n_surf;
     int fallback_rings;   // rings that did not fit the LDS budget and took the global-memory path
+    int vox_overflow;     // a point's voxel coordinates did not fit the packed 32-bit key (k_rot_scatter): the radix ordering pass takes over
     int redo_segments;    // segments whose concurrent greedy run had to be repeated with the previous segment's marks (diagnostics)
     long long tphase[8];  // profiling: per-phase clock ticks of ring 0's workgroup (wall_clock64)
+    int ring_ticks[kMaxRings];   // profiling: ticks k_rot_ring spent on each ring
+    int order_ticks[kMaxRings];  // profiling: ticks of the ring's voxel-ordering item; seg_ticks: its slowest segment item
+    int seg_ticks[kMaxRings];
 };
 
 // f32 atan / atan2.  Mode 2 (default): glibc's fdlibm float routines, statement for statement (sysdeps/ieee754/flt-32/s_atanf.c,
@@ -151,35 +155,38 @@ __device__ __forceinline__ dq qslerp_identity(double t, dq b) {   // Eigen 3.3 s
     return dq{s0 + s1 * b.w, s1 * b.x, s1 * b.y, s1 * b.z};
 }
 
-__global__ void k_rot_init(RotState* st) {
-    int t = threadIdx.x;
-    if (t == 0) { st->first_valid = 0x7fffffff; st->last_valid = -1; st->half_idx = 0x7fffffff; st->n_full = 0;
-                  st->n_edge = st->n_sharp = st->n_flat = st->n_lessflat = st->n_surf = 0; st->fallback_rings = 0; st->redo_segments = 0; }
-    if (t < kMaxRings) { st->ring_count[t] = 0; st->ring_base[t] = 0; st->ring_start[t] = 0; st->ring_end[t] = 0;
-                         st->ring_nedge[t] = st->ring_nsharp[t] = st->ring_nflat[t] = st->ring_nlf[t] = st->ring_nsurf[t] = 0; }
+__device__ __forceinline__ float range2(float4 p) { return p.x * p.x + p.y * p.y + p.z * p.z; }
+__device__ __forceinline__ bool rot_point_ok(float4 p, float thres) {      // R:131-134: finite and not inside the near range
+    return isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && !(p.x * p.x + p.y * p.y + p.z * p.z < thres * thres);
 }
 
-__global__ __launch_bounds__(256) void k_rot_valid(const float4* __restrict__ in, int n, float thres, unsigned char* __restrict__ valid, RotState* st) {
-    int first = 0x7fffffff, last = -1;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        float4 p = in[i];
-        bool ok = isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && !(p.x * p.x + p.y * p.y + p.z * p.z < thres * thres);   // R:131-134
-        valid[i] = ok;
-        if (ok) { first = min(first, i); last = max(last, i); }
-    }
-    for (int o = 32; o > 0; o >>= 1) { first = min(first, __shfl_xor(first, o)); last = max(last, __shfl_xor(last, o)); }
-    __shared__ int sf[4], sl[4];
-    if ((threadIdx.x & 63) == 0) { sf[threadIdx.x >> 6] = first; sl[threadIdx.x >> 6] = last; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int f = min(min(sf[0], sf[1]), min(sf[2], sf[3])), l = max(max(sl[0], sl[1]), max(sl[2], sl[3]));
-        if (f != 0x7fffffff) atomicMin(&st->first_valid, f);
-        if (l >= 0) atomicMax(&st->last_valid, l);
+// First and last surviving point of the scan (R:280-294), found by EVERY workgroup on its own instead of by a reduction launch: the whole block
+// looks at 1024 points from the front and 1024 from the back per trip — the first trip ends the search unless the scan starts / ends with
+// more than a thousand dropped points.  All threads return the same pair (0x7fffffff / -1 when nothing survives).
+__device__ void rot_first_last_valid(const float4* __restrict__ in, int n, float thres, int& first, int& last) {
+    __shared__ int s_first[kRotBlock / 64], s_last[kRotBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    first = 0x7fffffff; last = -1;
+    for (int b = 0; b < n && (first == 0x7fffffff || last < 0); b += kRotBlock) {
+        const int i = b + (int)threadIdx.x, k = n - 1 - b - (int)threadIdx.x;
+        const bool oi = first == 0x7fffffff && i < n && rot_point_ok(in[i], thres);
+        const bool ok = last < 0 && k >= 0 && rot_point_ok(in[k], thres);
+        const unsigned long long mi = __ballot(oi), mk = __ballot(ok);
+        if (lane == 0) {
+            s_first[wave] = mi ? b + wave * 64 + (__ffsll((long long)mi) - 1) : 0x7fffffff;
+            s_last[wave] = mk ? n - 1 - b - wave * 64 - (__ffsll((long long)mk) - 1) : -1;
+        }
+        __syncthreads();
+        int f = 0x7fffffff, l = -1;
+        for (int w = 0; w < kRotBlock / 64; w++) { f = min(f, s_first[w]); l = max(l, s_last[w]); }
+        if (first == 0x7fffffff) first = f;
+        if (last < 0) last = l;
+        __syncthreads();
     }
 }
 
-__device__ __forceinline__ void start_end_ori(const float4* __restrict__ in, const RotState* st, int am, float& startOri, float& endOri) {
-    float4 a = in[st->first_valid], b = in[st->last_valid];
+__device__ __forceinline__ void start_end_ori(const float4* __restrict__ in, int first_valid, int last_valid, int am, float& startOri, float& endOri) {
+    float4 a = in[first_valid], b = in[last_valid];
     startOri = -atan2_r(a.y, a.x, am);                                 // R:285
     endOri = (float)((double)(-atan2_r(b.y, b.x, am)) + 2 * M_PI);       // R:286-288
     if ((double)(endOri - startOri) > 3 * M_PI) endOri = (float)((double)endOri - 2 * M_PI);
@@ -205,77 +212,93 @@ __device__ __forceinline__ int ring_of(float4 p, int n_scans, int am) {
     return scanID;
 }
 
-__global__ __launch_bounds__(kRotBlock) void k_rot_classify(const float4* __restrict__ in, int n, const unsigned char* __restrict__ valid,
-                                                            RotDev P, RotState* st, signed char* __restrict__ scan_id, float* __restrict__ ori_raw,
-                                                            int* __restrict__ block_hist /*[nb][64]*/) {
+// Launch 1 of 5.  Per point: NaN / near-range filter, ring id, raw azimuth; per workgroup of 1024 points: ring histogram and the first point that
+// would latch `halfPassed` (R:351-357).  Nothing is read that another workgroup writes (start azimuth: rot_first_last_valid), nothing needs
+// zeroing first.
+__global__ __launch_bounds__(kRotBlock) void k_rot_classify(const float4* __restrict__ in, int n, RotDev P, RotState* st, signed char* __restrict__ scan_id,
+                                                            float* __restrict__ ori_raw, int* __restrict__ block_hist /*[nb][64]*/, int* __restrict__ block_half /*[nb]*/) {
     __shared__ int hist[kMaxRings];
     __shared__ int half_min;
     if (threadIdx.x < kMaxRings) hist[threadIdx.x] = 0;
     if (threadIdx.x == 0) half_min = 0x7fffffff;
-    __syncthreads();
-    if (st->last_valid < 0) { if (threadIdx.x < kMaxRings) block_hist[blockIdx.x * kMaxRings + threadIdx.x] = 0; return; }
-    float startOri, endOri;
-    start_end_ori(in, st, P.atan_mode, startOri, endOri);
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int first, last;
+    rot_first_last_valid(in, n, P.near_thres, first, last);          // (its barriers also publish the two initialisations above)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { st->first_valid = first; st->last_valid = last; st->vox_overflow = 0; }
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     int id = -1;
-    if (i < n && valid[i]) {
-        float4 p = in[i];
-        id = ring_of(p, P.n_scans, P.atan_mode);
-        if (id >= 0) {
-            float ori = -atan2_r(p.y, p.x, P.atan_mode);                       // R:349
-            ori_raw[i] = ori;
-            // would this point set halfPassed if it were reached with halfPassed == false?  (R:351-357)
-            float o1 = ori;
-            if ((double)o1 < (double)startOri - M_PI / 2) o1 = (float)((double)o1 + 2 * M_PI);
-            else if ((double)o1 > (double)startOri + M_PI * 3 / 2) o1 = (float)((double)o1 - 2 * M_PI);
-            if ((double)(o1 - startOri) > M_PI) atomicMin(&half_min, i);
-            atomicAdd(&hist[id], 1);
+    if (last >= 0 && i < n) {
+        const float4 p = in[i];
+        if (rot_point_ok(p, P.near_thres)) {
+            id = ring_of(p, P.n_scans, P.atan_mode);
+            if (id >= 0) {
+                float startOri, endOri;
+                start_end_ori(in, first, last, P.atan_mode, startOri, endOri);
+                float ori = -atan2_r(p.y, p.x, P.atan_mode);                       // R:349
+                ori_raw[i] = ori;
+                // would this point set halfPassed if it were reached with halfPassed == false?  (R:351-357)
+                float o1 = ori;
+                if ((double)o1 < (double)startOri - M_PI / 2) o1 = (float)((double)o1 + 2 * M_PI);
+                else if ((double)o1 > (double)startOri + M_PI * 3 / 2) o1 = (float)((double)o1 - 2 * M_PI);
+                if ((double)(o1 - startOri) > M_PI) atomicMin(&half_min, i);
+                atomicAdd(&hist[id], 1);
+            }
         }
     }
     if (i < n) scan_id[i] = (signed char)id;
     __syncthreads();
     if (threadIdx.x < kMaxRings) block_hist[blockIdx.x * kMaxRings + threadIdx.x] = hist[threadIdx.x];
-    if (threadIdx.x == 0 && half_min != 0x7fffffff) atomicMin(&st->half_idx, half_min);
+    if (threadIdx.x == 0) block_half[blockIdx.x] = half_min;
 }
 
-// exclusive prefix of the per-block ring histograms (per ring, over blocks): 1024 threads = 64 rings x 16 parts
-__global__ __launch_bounds__(kRotBlock) void k_rot_ring_scan(int* __restrict__ block_hist, int nb, RotDev P, RotState* st) {
-    __shared__ int part_sum[16][kMaxRings];
-    __shared__ int cnt[kMaxRings];
-    const int r = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int per = (nb + 15) / 16;
-    const int b0 = part * per, b1 = min(nb, b0 + per);
-    int run = 0;
-    for (int b = b0; b < b1; b++) run += block_hist[b * kMaxRings + r];
-    part_sum[part][r] = run;
-    __syncthreads();
-    int base = 0;
-    for (int q = 0; q < part; q++) base += part_sum[q][r];
-    if (part == 15) cnt[r] = base + run;
-    run = base;
-    for (int b = b0; b < b1; b++) { int c = block_hist[b * kMaxRings + r]; block_hist[b * kMaxRings + r] = run; run += c; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int bs = 0;
-        for (int k = 0; k < kMaxRings; k++) {
-            st->ring_count[k] = cnt[k]; st->ring_base[k] = bs;
-            if (k < P.n_scans) { st->ring_start[k] = bs + 5; st->ring_end[k] = bs + cnt[k] - 6; }   // R:379-381
-            bs += cnt[k];
-        }
-        st->n_full = bs;
-    }
-}
-
-__global__ __launch_bounds__(kRotBlock) void k_rot_scatter(const float4* __restrict__ in, int n, const signed char* __restrict__ scan_id,
-                                                           const float* __restrict__ ori_raw, RotDev P, const RotState* __restrict__ st,
-                                                           const int* __restrict__ block_base, float4* __restrict__ full, int* __restrict__ full_src) {
+// Launch 2 of 5.  Every workgroup sums the ring histograms itself (all of them: ring sizes; those of the workgroups before it: its own offsets) —
+// 50 KB of L2 reads instead of a one-workgroup scan launch in between —, then: relTime / intensity, IMU deskew (slerp, f64), stable scatter into
+// the ring-concatenated cloud (R:367-382, 153-177).  Workgroup 0 also writes the ring table of the scan state.
+__global__ __launch_bounds__(kRotBlock) void k_rot_scatter(const float4* __restrict__ in, int n, int nb, const signed char* __restrict__ scan_id,
+                                                           const float* __restrict__ ori_raw, RotDev P, RotState* st, const int* __restrict__ block_hist,
+                                                           const int* __restrict__ block_half, float4* __restrict__ full, int* __restrict__ full_src,
+                                                           unsigned* __restrict__ vkey, int* __restrict__ ring_ncand) {
     __shared__ int wave_hist[kRotBlock / 64][kMaxRings];
+    __shared__ int part_pre[kRotBlock / 64][kMaxRings], part_tot[kRotBlock / 64][kMaxRings];
+    __shared__ int ring_base[kMaxRings], ring_cnt[kMaxRings], my_base[kMaxRings];
+    __shared__ int half_w[kRotBlock / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int k = threadIdx.x; k < (kRotBlock / 64) * kMaxRings; k += blockDim.x) (&wave_hist[0][0])[k] = 0;
+    {
+        int pre = 0, tot = 0;
+        for (int b = wave; b < nb; b += kRotBlock / 64) { const int c = block_hist[b * kMaxRings + lane]; tot += c; if (b < (int)blockIdx.x) pre += c; }
+        part_pre[wave][lane] = pre; part_tot[wave][lane] = tot;
+        int hm = 0x7fffffff;
+        for (int b = threadIdx.x; b < nb; b += kRotBlock) hm = min(hm, block_half[b]);
+        for (int o = 32; o > 0; o >>= 1) hm = min(hm, __shfl_xor(hm, o));
+        if (lane == 0) half_w[wave] = hm;
+    }
     __syncthreads();
-    if (st->last_valid < 0) return;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int id = i < n ? (int)scan_id[i] : -1;
+    if (wave == 0) {
+        int pre = 0, tot = 0;
+        for (int w = 0; w < kRotBlock / 64; w++) { pre += part_pre[w][lane]; tot += part_tot[w][lane]; }
+        int inc = tot;
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+        ring_base[lane] = inc - tot; ring_cnt[lane] = tot; my_base[lane] = pre;
+    }
+    __syncthreads();
+    int half_idx = 0x7fffffff;
+    for (int w = 0; w < kRotBlock / 64; w++) half_idx = min(half_idx, half_w[w]);
+    const int first_valid = st->first_valid, last_valid = st->last_valid;       // k_rot_classify, workgroup 0
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < kMaxRings) {
+            const int r = threadIdx.x, bs = ring_base[r], c = ring_cnt[r];
+            st->ring_count[r] = c; st->ring_base[r] = bs;
+            st->ring_start[r] = r < P.n_scans ? bs + 5 : 0; st->ring_end[r] = r < P.n_scans ? bs + c - 6 : 0;       // R:379-381
+            st->ring_nedge[r] = st->ring_nsharp[r] = st->ring_nflat[r] = st->ring_nlf[r] = st->ring_nsurf[r] = 0;
+            ring_ncand[r] = 0; st->seg_ticks[r] = 0; st->order_ticks[r] = 0; st->ring_ticks[r] = 0;
+        }
+        if (threadIdx.x == 0) {
+            st->n_full = ring_base[kMaxRings - 1] + ring_cnt[kMaxRings - 1]; st->half_idx = half_idx;
+            st->n_edge = st->n_sharp = st->n_flat = st->n_lessflat = st->n_surf = 0; st->fallback_rings = 0; st->redo_segments = 0;
+        }
+    }
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int id = i < n ? (int)scan_id[i] : -1;
     // stable rank of the point among the points of its ring inside this wave
     int rank = 0;
     unsigned long long todo = __ballot(id >= 0);
@@ -294,11 +317,11 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_scatter(const float4* __restr
     }
     __syncthreads();
     if (id < 0) return;
-    int pos = st->ring_base[id] + block_base[blockIdx.x * kMaxRings + id] + wave_hist[wave][id] + rank;
+    const int pos = ring_base[id] + my_base[id] + wave_hist[wave][id] + rank;
     float startOri, endOri;
-    start_end_ori(in, st, P.atan_mode, startOri, endOri);
+    start_end_ori(in, first_valid, last_valid, P.atan_mode, startOri, endOri);
     float ori = ori_raw[i];
-    if (i <= st->half_idx) {   // halfPassed was still false when the reference reached this point (R:350-358)
+    if (i <= half_idx) {   // halfPassed was still false when the reference reached this point (R:350-358)
         if ((double)ori < (double)startOri - M_PI / 2) ori = (float)((double)ori + 2 * M_PI);
         else if ((double)ori > (double)startOri + M_PI * 3 / 2) ori = (float)((double)ori - 2 * M_PI);
     } else {                    // R:359-365
@@ -318,39 +341,38 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_scatter(const float4* __restr
     dq qs = qslerp_identity(ratio, qimu);
     qs = qmul(qmul(qlb, qs), qinv(qlb));
     d3 r = qrot(qs, d3{(double)p.x, (double)p.y, (double)p.z});
-    full[pos] = make_float4((float)r.x, (float)r.y, (float)r.z, intensity);
+    const float4 o = make_float4((float)r.x, (float)r.y, (float)r.z, intensity);
+    full[pos] = o;
     full_src[pos] = i;
+    // Key of the point for the VoxelGrid(ds_v) ordering of its ring (R:502-508): PCL orders the voxels by x + y * dx + z * dx * dy over the
+    // bounding box = lexicographically by (floor(z / v), floor(y / v), floor(x / v)), whatever the box — packed here as 9 | 11 | 11 offset-binary
+    // bits (+-153 m in z, +-614 m in x / y at v = 0.6).  0xffffffff: not a candidate of the less-flat list (outside [scanStartInd,
+    // scanEndInd) or nearer than 0.5 m, R:494-499; the picked edge points leave the list later, in k_rot_ring).
+    const int k = pos - ring_base[id];
+    unsigned key = 0xffffffffu;
+    if (k >= 5 && k <= ring_cnt[id] - 7 && !((double)range2(o) < 0.25)) {
+        const float inv = 1.0f / P.ds_v;
+        const float f0 = floorf(o.x * inv), f1 = floorf(o.y * inv), f2 = floorf(o.z * inv);
+        if (f0 >= -1024.f && f0 < 1024.f && f1 >= -1024.f && f1 < 1024.f && f2 >= -256.f && f2 < 256.f)
+            key = ((unsigned)((int)f2 + 256) << 22) | ((unsigned)((int)f1 + 1024) << 11) | (unsigned)((int)f0 + 1024);
+        else { key = 0u; atomicOr(&st->vox_overflow, 1); }
+    }
+    vkey[pos] = key;
 }
 
-// 11-tap curvature (R:385-394): strictly left-to-right f32 sums, tile of 256 + 5-point halo in LDS
-__global__ __launch_bounds__(256) void k_rot_curvature(const float4* __restrict__ full, const RotState* __restrict__ st, float* __restrict__ curv) {
-    __shared__ float sx[256 + 10], sy[256 + 10], sz[256 + 10];
-    const int n = st->n_full;
-    const int base = blockIdx.x * 256;
-    if (base >= n) return;
-    for (int k = threadIdx.x; k < 256 + 10; k += 256) {
-        int g = base - 5 + k;
-        float4 p = (g >= 0 && g < n) ? full[g] : make_float4(0.f, 0.f, 0.f, 0.f);
-        sx[k] = p.x; sy[k] = p.y; sz[k] = p.z;
-    }
-    __syncthreads();
-    int i = base + threadIdx.x;
-    if (i >= n) return;
-    float c = 0.f;
-    if (i >= 5 && i < n - 5) {
-        const int k = threadIdx.x + 5;
-        float dX = sx[k - 5] + sx[k - 4] + sx[k - 3] + sx[k - 2] + sx[k - 1] - 10 * sx[k] + sx[k + 1] + sx[k + 2] + sx[k + 3] + sx[k + 4] + sx[k + 5];
-        float dY = sy[k - 5] + sy[k - 4] + sy[k - 3] + sy[k - 2] + sy[k - 1] - 10 * sy[k] + sy[k + 1] + sy[k + 2] + sy[k + 3] + sy[k + 4] + sy[k + 5];
-        float dZ = sz[k - 5] + sz[k - 4] + sz[k - 3] + sz[k - 2] + sz[k - 1] - 10 * sz[k] + sz[k + 1] + sz[k + 2] + sz[k + 3] + sz[k + 4] + sz[k + 5];
-        c = dX * dX + dY * dY + dZ * dZ;
-    }
-    curv[i] = c;
+// 11-tap curvature (R:385-394): strictly left-to-right f32 sums.  `P` is indexed so that P[k] is the point itself.
+__device__ __forceinline__ float curvature11(const float4* __restrict__ P, int k) {
+    float dX = P[k - 5].x + P[k - 4].x + P[k - 3].x + P[k - 2].x + P[k - 1].x - 10 * P[k].x + P[k + 1].x + P[k + 2].x + P[k + 3].x + P[k + 4].x + P[k + 5].x;
+    float dY = P[k - 5].y + P[k - 4].y + P[k - 3].y + P[k - 2].y + P[k - 1].y - 10 * P[k].y + P[k + 1].y + P[k + 2].y + P[k + 3].y + P[k + 4].y + P[k + 5].y;
+    float dZ = P[k - 5].z + P[k - 4].z + P[k - 3].z + P[k - 2].z + P[k - 1].z - 10 * P[k].z + P[k + 1].z + P[k + 2].z + P[k + 3].z + P[k + 4].z + P[k + 5].z;
+    return dX * dX + dY * dY + dZ * dZ;
 }
 
 // ------------------------------------------------------------------------------------------------
 // per-ring selection
 // ------------------------------------------------------------------------------------------------
 constexpr int kRingLdsCap = 4096;   // ring points held in LDS (SYN: 3125, HDL-64E: ~2100, VLP-16: ~1800)
+constexpr int kSegCap = 720;                        // (multiple of 16)  window of ONE segment: its points (<= cap / 6 + 1), the ring's first / last five with segments 0 / 5, +-5 margins
 
 __device__ __forceinline__ float gap2(const float4* __restrict__ P, int a, int b) {   // R:435-438
     float dX = P[a].x - P[b].x, dY = P[a].y - P[b].y, dZ = P[a].z - P[b].z;
@@ -359,27 +381,30 @@ __device__ __forceinline__ float gap2(const float4* __restrict__ P, int a, int b
 __device__ __forceinline__ float range2(const float4* __restrict__ P, int k) { return P[k].x * P[k].x + P[k].y * P[k].y + P[k].z * P[k].z; }
 
 constexpr int kSegEdge = 10, kSegFlat = 4;
-struct RingLds {
-    float4 pts[kRingLdsCap + 16];          // ring points incl. the +-5 margins used by the suppression loops
-    unsigned vidx[kRingLdsCap];            // voxel index of the q-th less-flat point
-    unsigned short ord_a[kRingLdsCap];     // radix-sort ping-pong: positions q in the less-flat list, ordered by (voxel, q)
-    unsigned short ord_b[kRingLdsCap];
-    int rcnt[32 * 4 * (kRotBlock / 64)];   // radix pass: counts / offsets [digit][slot][wave]
-    float curv[kRingLdsCap + 16];
-    int sort_ind[kRingLdsCap + 16];
-    signed char mark[kRingLdsCap + 16 + 64];   // cloudNeighborPicked, one private stretch per segment (see greedy_segment)
-    signed char label[kRingLdsCap + 16];
-    int seg_edge[6][kSegEdge], seg_flat[6][kSegFlat], seg_ne[6], seg_nf[6];
-    int scan[kRotBlock / 64 + 1];
-    float red[6][kRotBlock / 64];
-    int misc[8];
-};
+constexpr int kProbeRing = 12;                     // LILI_ROT_PHASES: the ring whose k_rot_ring phases are recorded
+constexpr int kStage3Blocks = 480;                 // workgroups of k_rot_segments (two per CU are resident)
 
-// The greedy picks of ONE segment (R:413-492), run by one lane.  `M` = this segment's private view of cloudNeighborPicked: M[k] for
-// ring-local k in [sp - 5, ep + 5] (cleared by the caller; `spill` = bit l set <=> element sp + l was already marked by the previous
-// segment's picks).  Writes the labels of its own picks, its pick lists in push order and its marks.
-__device__ void greedy_segment(RingLds& L, signed char* M, int sp, int ep, unsigned spill, int j) {
+// One segment's working set in LDS, indexed in WINDOW coordinates (window = the segment, +-5 points, and the ring's first / last five with
+// its first / last segment; for a nearly empty ring the window is the whole ring).
+struct SegLds {
+    float4 pts[kSegCap];
+    float curv[kSegCap];
+    alignas(16) float key[kSegCap + 16];   // the segment's curvatures, 16-byte aligned and padded with +inf (rank sort)
+    int sort_ind[kSegCap];
+    int hrank[kSegCap];                    // rank sort: the count of the upper half of the keys
+    signed char mark[kSegCap + 16];        // cloudNeighborPicked of this segment: [sp - 5, ep + 5]
+    signed char label[kSegCap];
+    int edge[kSegEdge], flat[kSegFlat], ne, nf;      // picks in push order
+};
+// What k_rot_segments hands to k_rot_ring per (ring, segment): picks as RING-LOCAL indices, counts, and the marks spilled into the next segment.
+struct SegOut { int edge[kSegEdge]; int flat[kSegFlat]; int ne, nf, spill, pad; };
+
+// The greedy picks of ONE segment (R:413-492), run by one lane.  `M` = the segment's cloudNeighborPicked, M[k] for k in [sp - 5, ep + 5]
+// (cleared by the caller; `spill` = bit l set <=> element sp + l was already marked by the previous segment's picks).  Writes the labels
+// of its picks, the pick lists in push order and its marks.
+__device__ void greedy_segment(SegLds& L, int sp, int ep, unsigned spill) {
     const float4* Pp = L.pts;
+    signed char* M = L.mark;
     for (int l = 0; l < 5; l++) if ((spill >> l) & 1u) M[sp + l] = 1;
     int ne = 0, nf = 0;
     int largest = 0;
@@ -388,8 +413,8 @@ __device__ void greedy_segment(RingLds& L, signed char* M, int sp, int ep, unsig
         if (!((double)L.curv[ind] > 2.0)) break;                        // sorted: nothing further can qualify
         if (M[ind] == 0) {
             largest++;
-            if (largest <= 2) { L.label[ind] = 2; L.seg_edge[j][ne++] = ind; }
-            else if (largest <= 10) { L.label[ind] = 1; L.seg_edge[j][ne++] = ind; }
+            if (largest <= 2) { L.label[ind] = 2; L.edge[ne++] = ind; }
+            else if (largest <= 10) { L.label[ind] = 1; L.edge[ne++] = ind; }
             else break;
             M[ind] = 1;
             for (int l = 1; l <= 5; l++) { if ((double)gap2(Pp, ind + l, ind + l - 1) > 0.05) break; M[ind + l] = 1; }
@@ -402,7 +427,7 @@ __device__ void greedy_segment(RingLds& L, signed char* M, int sp, int ep, unsig
         if (!((double)L.curv[ind] < 0.1)) break;                        // sorted ascending
         if ((double)range2(Pp, ind) < 0.25) continue;
         if (M[ind] == 0) {
-            L.label[ind] = -1; L.seg_flat[j][nf++] = ind;
+            L.label[ind] = -1; L.flat[nf++] = ind;
             smallest++;
             if (smallest >= 4) break;                                   // before the suppression (R:468-470)
             M[ind] = 1;
@@ -410,7 +435,7 @@ __device__ void greedy_segment(RingLds& L, signed char* M, int sp, int ep, unsig
             for (int l = -1; l >= -5; l--) { if ((double)gap2(Pp, ind + l, ind + l + 1) > 0.05) break; M[ind + l] = 1; }
         }
     }
-    L.seg_ne[j] = ne; L.seg_nf[j] = nf;
+    L.ne = ne; L.nf = nf;
 }
 
 #define LILI_ROT_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
@@ -420,9 +445,12 @@ __device__ void greedy_segment(RingLds& L, signed char* M, int sp, int ep, unsig
 // ballot), and the +-5 suppression of a pick is ten gap tests on ten lanes followed by two "first break" bit scans.  Picks, labels,
 // lists and marks are exactly those of greedy_segment: a pick only ever ADDS marks, the candidates are visited in the same order, and
 // after every pick the eligibility of the remaining lanes is re-read.
-__device__ void greedy_segment_wave(RingLds& L, signed char* M, int sp, int ep, int j) {
+__device__ void greedy_segment_wave(SegLds& L, int sp, int ep, unsigned spill = 0u) {
     const int lane = threadIdx.x & 63;
     const float4* Pp = L.pts;
+    signed char* M = L.mark;
+    if (lane < 5 && ((spill >> lane) & 1u)) M[sp + lane] = 1;          // marks the previous segment's picks left in this one
+    LILI_ROT_WAVE_SYNC();
     // marks the +-5 neighbourhood of `ind` up to the first gap > 0.05 on either side (R:441-452)
     auto suppress = [&](int ind) {
         bool brk = false;
@@ -441,7 +469,7 @@ __device__ void greedy_segment_wave(RingLds& L, signed char* M, int sp, int ep, 
     for (int k0 = ep; k0 >= sp && !done; k0 -= 64) {                        // R:413-453, 64 candidates at a time
         const int k = k0 - lane;
         const bool in = k >= sp;
-        const int ind = in ? L.sort_ind[k] : 0;
+        const int ind = in ? L.sort_ind[k] : sp;
         const bool big = in && (double)L.curv[ind] > 2.0;
         const unsigned long long stop = __ballot(!big);                     // first lane that ends the loop (curvature too small, or the segment's end)
         const unsigned long long live = stop ? ((stop & (0ull - stop)) - 1ull) : ~0ull;       // lanes before it
@@ -453,7 +481,7 @@ __device__ void greedy_segment_wave(RingLds& L, signed char* M, int sp, int ep, 
             const int pick = __shfl(ind, l);
             largest++;
             if (largest > 10) { done = true; break; }
-            if (lane == 0) { L.label[pick] = largest <= 2 ? 2 : 1; L.seg_edge[j][ne] = pick; }
+            if (lane == 0) { L.label[pick] = largest <= 2 ? 2 : 1; L.edge[ne] = pick; }
             ne++;
             suppress(pick);
             todo &= ~((2ull << l) - 1ull);                                  // lanes behind the pick
@@ -465,7 +493,7 @@ __device__ void greedy_segment_wave(RingLds& L, signed char* M, int sp, int ep, 
     for (int k0 = sp; k0 <= ep && !done; k0 += 64) {                        // R:456-492
         const int k = k0 + lane;
         const bool in = k <= ep;
-        const int ind = in ? L.sort_ind[k] : 0;
+        const int ind = in ? L.sort_ind[k] : sp;
         const bool small = in && (double)L.curv[ind] < 0.1;
         const bool far = in && !((double)range2(Pp, ind) < 0.25);
         const unsigned long long stop = __ballot(!small);
@@ -476,7 +504,7 @@ __device__ void greedy_segment_wave(RingLds& L, signed char* M, int sp, int ep, 
             if (!el) break;
             const int l = __ffsll((long long)el) - 1;
             const int pick = __shfl(ind, l);
-            if (lane == 0) { L.label[pick] = -1; L.seg_flat[j][nf_] = pick; }
+            if (lane == 0) { L.label[pick] = -1; L.flat[nf_] = pick; }
             nf_++;
             smallest++;
             if (smallest >= 4) { done = true; break; }                      // before the suppression (R:468-470)
@@ -485,7 +513,7 @@ __device__ void greedy_segment_wave(RingLds& L, signed char* M, int sp, int ep, 
         }
         if (stop) done = true;
     }
-    if (lane == 0) { L.seg_ne[j] = ne; L.seg_nf[j] = nf_; }
+    if (lane == 0) { L.ne = ne; L.nf = nf_; }
 }
 __device__ __forceinline__ int block_excl_scan_1024(int v, int* lds, int& total) {
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -500,14 +528,14 @@ __device__ __forceinline__ int block_excl_scan_1024(int v, int* lds, int& total)
     return base + inc - v;
 }
 
-// Rank sort of one segment of one ring by (curvature, index) — std::sort of R:409-410 with ties broken by index.
-// One workgroup per (ring, segment, chunk of 256 elements): O(L^2/6) compares per ring spread over the whole chip
-// instead of the single CU that owns the ring in k_rot_select.  sort_ind holds GLOBAL indices (into `full`).
+// Rank sort of one segment of one ring by (curvature, index) — std::sort of R:409-410 with ties broken by index — for rings BEYOND the LDS
+// working set (k_rot_segments sorts the others itself).  One workgroup per (ring, segment, chunk of 256 elements); sort_ind holds GLOBAL
+// indices (into `full`).
 __global__ __launch_bounds__(256) void k_rot_rank(const float* __restrict__ curv, RotDev P, const RotState* __restrict__ st, int* __restrict__ sort_ind) {
     __shared__ float seg[kRingLdsCap];
     const int ring = blockIdx.x, j = blockIdx.y;
     const int rs = st->ring_start[ring], re = st->ring_end[ring];
-    if (ring >= P.n_scans || re - rs < 6 || ring % P.ds_rate != 0) return;
+    if (ring >= P.n_scans || re - rs < 6 || ring % P.ds_rate != 0 || st->ring_count[ring] <= kRingLdsCap) return;
     const int sp = rs + (re - rs) * j / 6, ep = rs + (re - rs) * (j + 1) / 6 - 1;
     const int len = ep - sp + 1;
     if (len <= 0) return;
@@ -515,226 +543,582 @@ __global__ __launch_bounds__(256) void k_rot_rank(const float* __restrict__ curv
     const bool in_lds = len <= kRingLdsCap;
     if (in_lds) for (int m = threadIdx.x; m < len; m += 256) seg[m] = curv[sp + m];
     __syncthreads();
-    if (!in_lds) {      // a segment of a ring with more than ~24 k points: the same count straight from global memory (rare; rings this long are not the product's fast case)
-        const int sub = threadIdx.x & 3;
-        for (int e = blockIdx.z * 64 + (threadIdx.x >> 2); e < len; e += gridDim.z * 64) {
-            const float ck = curv[sp + e];
-            int rank = 0;
-            for (int m = sub; m < len; m += 4) { const float cm = curv[sp + m]; rank += (cm < ck || (cm == ck && m < e)) ? 1 : 0; }
-            rank += __shfl_xor(rank, 1); rank += __shfl_xor(rank, 2);
-            if (sub == 0) sort_ind[sp + rank] = sp + e;
-        }
-        return;
-    }
-    // four lanes per element, each counting a quarter of the segment (interleaved by 4): the loop is a quarter as long, the partial
-    // ranks meet in two shuffles
+    // four lanes per element, each counting a quarter of the segment (interleaved by 4): the partial ranks meet in two shuffles
     const int sub = threadIdx.x & 3;
     for (int e = blockIdx.z * 64 + (threadIdx.x >> 2); e < len; e += gridDim.z * 64) {
-        const float ck = seg[e];
+        const float ck = in_lds ? seg[e] : curv[sp + e];
         int rank = 0;
-        for (int m = sub; m < len; m += 4) { const float cm = seg[m]; rank += (cm < ck || (cm == ck && m < e)) ? 1 : 0; }
+        for (int m = sub; m < len; m += 4) { const float cm = in_lds ? seg[m] : curv[sp + m]; rank += (cm < ck || (cm == ck && m < e)) ? 1 : 0; }
         rank += __shfl_xor(rank, 1); rank += __shfl_xor(rank, 2);
         if (sub == 0) sort_ind[sp + rank] = sp + e;
     }
 }
 
-__global__ __launch_bounds__(kRotBlock) void k_rot_select(const float4* __restrict__ full, const float* __restrict__ curv_g, const int* __restrict__ sort_ind_g, RotDev P, RotState* st,
-                                                          int* __restrict__ label_g, int* __restrict__ ring_edge /*[64][60]*/,
-                                                          int* __restrict__ ring_sharp /*[64][12]*/, int* __restrict__ ring_flat /*[64][24]*/,
-                                                          int* __restrict__ lessflat_tmp /*[n]*/, float4* __restrict__ surf_tmp /*[n]*/,
-                                                          int* __restrict__ surf_cnt_tmp /*[n]*/) {
+// Working set of the voxel ordering of one ring inside k_rot_segments.
+struct OrderLds {
+    unsigned key[kRingLdsCap + 8];         // dense voxel number per ring point (0xffffffff: not a candidate)
+    unsigned short rstart[kRingLdsCap], rend[kRingLdsCap];   // runs in index order: first / last point
+    unsigned rkey[kRingLdsCap];            //                       voxel number
+    int cnt[2 * kRotBlock + 1];            // runs per bin (2048 bins on the top bits of the ring's voxel numbers), then their exclusive prefix in place
+    unsigned short bidx[kRingLdsCap];      // runs grouped by bin (any order inside a bin): run number; their voxel numbers reuse `key`
+    unsigned wmin[3][kRotBlock / 64], wmax[3][kRotBlock / 64];
+    int scan[kRotBlock / 64 + 1];
+};
+
+// Working set of the radix ordering (k_rot_voxel_order).
+struct SortLds {
+    float4 pts[kRingLdsCap];
+    unsigned vidx[kRingLdsCap];            // voxel index of the q-th candidate
+    unsigned short cand[kRingLdsCap];      // ring-local index of the q-th candidate
+    unsigned short ord_a[kRingLdsCap];     // radix-sort ping-pong: positions q in the candidate list, ordered by (voxel, q)
+    unsigned short ord_b[kRingLdsCap];
+    int rcnt[32 * 4 * (kRotBlock / 64)];   // radix pass: counts / offsets [digit][slot][wave]
+    int scan[kRotBlock / 64 + 1];
+    float red[6][kRotBlock / 64];
+};
+
+struct RotRingScratch {        // products of k_rot_segments for k_rot_ring, all indexed like `full` unless noted
+    SegOut* seg_out;           // [64 * 6]
+    int* ring_ncand;           // [64]
+    int* sorted_k;             // the i-th run of the ring in (voxel, first index) order, at [ring_base + i]: ring-local index of its first point
+    int* sorted_len;           //   its number of points (consecutive indices)
+    unsigned* sorted_vox;      //   its voxel number
+};
+
+// The same ordering by a stable LSD radix sort with the voxel numbering of the ring's bounding box (what round 2 ran for every ring): second pass,
+// only for scans in which a point's voxel coordinates did not fit the packed key (RotState::vox_overflow: more than 614 m / v * 0.6 from the
+// sensor).  One workgroup per ring; positions (16-bit) sorted on 5-bit digits in LDS, ranks inside a wave from five ballots.
+__global__ __launch_bounds__(kRotBlock) void k_rot_voxel_order(const float4* __restrict__ full, RotDev P, RotState* st, RotRingScratch X) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    RingLds& L = *reinterpret_cast<RingLds*>(smem);
-    const int ring = blockIdx.x;
-    const int tid = threadIdx.x;
+    const int ring = blockIdx.x, tid = threadIdx.x;
     const int rbase = st->ring_base[ring], rcount = st->ring_count[ring];
     const int rs = st->ring_start[ring], re = st->ring_end[ring];
-    // labels of every point of the ring default to 0 (R:393)
-    for (int k = tid; k < rcount; k += kRotBlock) label_g[rbase + k] = 0;
+    if (!(ring < P.n_scans && re - rs >= 6 && ring % P.ds_rate == 0) || rcount > kRingLdsCap) return;
+    const int s0 = rs - rbase, e0 = re - rbase;
+    {
+        SortLds& L = *reinterpret_cast<SortLds*>(smem);
+        // ================= voxel ordering of the ring's candidates
+        for (int k = tid; k < rcount; k += kRotBlock) L.pts[k] = full[rbase + k];
+        __syncthreads();
+        int n_c = 0;
+        for (int k0 = s0; k0 <= e0 - 1; k0 += kRotBlock) {
+            const int k = k0 + tid;
+            const bool c = k <= e0 - 1 && !((double)range2(L.pts, k) < 0.25);
+            int tot; const int off = block_excl_scan_1024(c ? 1 : 0, L.scan, tot);
+            if (c) L.cand[n_c + off] = (unsigned short)k;
+            n_c += tot;
+        }
+        __syncthreads();
+        if (tid == 0) X.ring_ncand[ring] = n_c;
+        if (n_c == 0) return;
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int q = tid; q < n_c; q += kRotBlock) {
+            const float4 p = L.pts[L.cand[q]];
+            mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+            mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) for (int o = 32; o > 0; o >>= 1) { mn[c] = fminf(mn[c], __shfl_xor(mn[c], o)); mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o)); }
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) { L.red[c][tid >> 6] = mn[c]; L.red[3 + c][tid >> 6] = mx[c]; }
+        }
+        __syncthreads();
+        const float inv = 1.0f / P.ds_v;
+        int min_b[3], div_b[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            float a = L.red[c][0], b = L.red[3 + c][0];
+            for (int w = 1; w < kRotBlock / 64; w++) { a = fminf(a, L.red[c][w]); b = fmaxf(b, L.red[3 + c][w]); }
+            min_b[c] = (int)floorf(a * inv);
+            div_b[c] = (int)floorf(b * inv) - min_b[c] + 1;
+        }
+        for (int q = tid; q < n_c; q += kRotBlock) {
+            const float4 p = L.pts[L.cand[q]];
+            const int i0 = (int)(floorf(p.x * inv) - (float)min_b[0]);
+            const int i1 = (int)(floorf(p.y * inv) - (float)min_b[1]);
+            const int i2 = (int)(floorf(p.z * inv) - (float)min_b[2]);
+            L.vidx[q] = (unsigned)(i0 + i1 * div_b[0] + i2 * div_b[0] * div_b[1]);
+            L.ord_a[q] = (unsigned short)q;
+        }
+        const unsigned n_vox = (unsigned)div_b[0] * (unsigned)div_b[1] * (unsigned)div_b[2];    // PCL itself rejects grids beyond 2^31 cells
+        int bits = 1; while (bits < 32 && (n_vox - 1u) >> bits) bits++;
+        unsigned short* src = L.ord_a;
+        unsigned short* dst = L.ord_b;
+        __syncthreads();
+        // Ranks inside a wave come from five ballots (the lanes that hold the same digit), across waves / slots from one scan of the
+        // [digit][slot][wave] count table: 4 block barriers per pass and ceil(bits / 5) passes.
+        {
+            const int wave = tid >> 6, lane = tid & 63;
+            for (int shift = 0; shift < bits; shift += 5) {
+                L.rcnt[tid] = 0; L.rcnt[tid + kRotBlock] = 0;
+                __syncthreads();
+                int dig[4], rk[4], qq[4];
+#pragma unroll
+                for (int sl = 0; sl < 4; sl++) {
+                    const int i = sl * kRotBlock + tid;
+                    const bool act = i < n_c;
+                    qq[sl] = act ? (int)src[i] : 0;
+                    const int d = act ? (int)((L.vidx[qq[sl]] >> shift) & 31u) : 0;
+                    unsigned long long m = __ballot(act);
+#pragma unroll
+                    for (int bb = 0; bb < 5; bb++) { const unsigned long long bal = __ballot(act && ((d >> bb) & 1)); m &= ((d >> bb) & 1) ? bal : ~bal; }
+                    rk[sl] = __popcll(m & ((1ull << lane) - 1ull));
+                    dig[sl] = d;
+                    if (act && rk[sl] == 0) L.rcnt[(d * 4 + sl) * (kRotBlock / 64) + wave] = __popcll(m);
+                }
+                __syncthreads();
+                {
+                    const int a = L.rcnt[2 * tid], b2 = L.rcnt[2 * tid + 1];
+                    int tot; const int ex = block_excl_scan_1024(a + b2, L.scan, tot);
+                    L.rcnt[2 * tid] = ex; L.rcnt[2 * tid + 1] = ex + a;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int sl = 0; sl < 4; sl++) {
+                    const int i = sl * kRotBlock + tid;
+                    if (i < n_c) dst[L.rcnt[(dig[sl] * 4 + sl) * (kRotBlock / 64) + wave] + rk[sl]] = (unsigned short)qq[sl];
+                }
+                __syncthreads();
+                unsigned short* t2 = src; src = dst; dst = t2;
+            }
+        }
+        for (int i = tid; i < n_c; i += kRotBlock) {
+            const int q = src[i], k = L.cand[q];
+            X.sorted_k[rbase + i] = k; X.sorted_len[rbase + i] = 1; X.sorted_vox[rbase + i] = L.vidx[q];       // (every candidate a run of its own)
+        }
+    }
+}
+
+// Launch 3 of 5: everything about a ring that does not need the picks of the WHOLE ring.  Work items (ring, by):
+//   by < 6 — segment j:
+//   * the 11-tap curvatures of its stretch of the ring (R:385-394; the six workgroups cover the ring, also of rings that are not selected:
+//     the curvature array is complete);
+//   * rank sort of the segment by (curvature, index) (R:409-410): one lane per element and half of the keys, 16-byte LDS broadcast reads;
+//   * wave 0: greedy sharp / less-sharp / flat picks with +-5 suppression (R:401-492).  The reference runs the six segments one after
+//     the other and a suppression may reach across a border (A4 iv) — only FORWARD matters, and only through the first five elements of
+//     the next segment: every segment records the marks it spills, k_rot_ring checks them against the next segment's picks and redoes
+//     that segment serially if one of its picks was among them (rare: a top-10 curvature within five points of both sides of a border).
+//   by == 6 — the ordering pcl::VoxelGrid(ds_v) needs for the ring (R:502-508).  The grid runs over the less-flat points = the points of
+//     [scanStartInd, scanEndInd) at range >= 0.5 m that were NOT picked as edge points; the picks are not known yet, so ALL candidates are
+//     ordered by (voxel key, index) — a stable order, so dropping the picked ones later leaves exactly the order of the less-flat list.
+//     The keys (k_rot_scatter wrote them) are binned on the top 11 bits of the ring's key range with LDS atomics (one histogram, one
+//     scan, one scatter), then every key counts its exact rank among the few keys of its bin: ~6 us and 7 barriers per ring, where the
+//     LSD radix sort of round 2 (4-5 passes x 6 barriers, 15-25 us; still there as k_rot_voxel_order) was the longest step of the
+//     extractor.  (Counting every key against every key of the ring — no barriers at all — was tried first: 81 us x CU of compares per
+//     ring, fine for 16 selected rings spread over the chip, slower than the radix sort for 64.)
+// The curvature rank sort splits the keys into those before every element of the wave (count key' <= key), those behind (key' < key) and
+// the wave's own stretch (index compared too): two to three operations per pair instead of five.
+// One work item of k_rot_segments: by < 6 — segment `by` of `ring`; by >= 6 — voxel-ordering chunk by - 6.
+__device__ void rot_stage3_item(int ring, int by, unsigned char* smem, const float4* __restrict__ full, const unsigned* __restrict__ vkey_g, const RotDev& P, RotState* st,
+                                float* __restrict__ curv_g, int* __restrict__ sort_ind_g, int* __restrict__ label_g, const RotRingScratch& X) {
+    const int tid = threadIdx.x;
+    const int n = st->n_full;
+    const int rbase = st->ring_base[ring], rcount = st->ring_count[ring];
+    const int rs = st->ring_start[ring], re = st->ring_end[ring];
+    const bool selected = ring < P.n_scans && re - rs >= 6 && ring % P.ds_rate == 0;      // R:402
+    const bool in_lds = selected && rcount <= kRingLdsCap;                                 // longer rings: k_rot_rank + k_rot_select_big
+    const int s0 = rs - rbase, e0 = re - rbase;   // local scanStartInd / scanEndInd
+    if (by >= 6) {
+        // ================= voxel ordering of the ring: RUNS of consecutive candidates in one voxel, ordered by (voxel, first index)
+        if (!in_lds) return;
+        const long long t_rb = wall_clock64();
+        OrderLds& O = *reinterpret_cast<OrderLds*>(smem);
+        constexpr int kPer = kRingLdsCap / kRotBlock;                                  // points per thread, CONTIGUOUS: m = kPer * tid + i
+        unsigned key[kPer];
+        unsigned lo3[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi3[3] = {0u, 0u, 0u};      // x, y, z fields of the candidates' keys
+        {
+            const uint4 raw = kPer * tid + 3 < rcount && ((rbase & 3) == 0) ? *reinterpret_cast<const uint4*>(vkey_g + rbase + kPer * tid) : make_uint4(0, 0, 0, 0);
+            const bool fast = kPer * tid + 3 < rcount && ((rbase & 3) == 0);
+#pragma unroll
+            for (int i = 0; i < kPer; i++) {
+                const int m = kPer * tid + i;
+                key[i] = fast ? (i == 0 ? raw.x : i == 1 ? raw.y : i == 2 ? raw.z : raw.w) : (m < rcount ? vkey_g[rbase + m] : 0xffffffffu);   // (k_rot_scatter: 0xffffffff = not a candidate)
+                if (key[i] != 0xffffffffu) {
+                    const unsigned f[3] = {key[i] & 2047u, (key[i] >> 11) & 2047u, key[i] >> 22};
+#pragma unroll
+                    for (int c = 0; c < 3; c++) { lo3[c] = min(lo3[c], f[c]); hi3[c] = max(hi3[c], f[c]); }
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) for (int o = 32; o > 0; o >>= 1) { lo3[c] = min(lo3[c], (unsigned)__shfl_xor((int)lo3[c], o)); hi3[c] = max(hi3[c], (unsigned)__shfl_xor((int)hi3[c], o)); }
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) { O.wmin[c][tid >> 6] = lo3[c]; O.wmax[c][tid >> 6] = hi3[c]; }
+        }
+        O.cnt[tid] = 0; O.cnt[tid + kRotBlock] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 3; c++) for (int w = 0; w < kRotBlock / 64; w++) { lo3[c] = min(lo3[c], O.wmin[c][w]); hi3[c] = max(hi3[c], O.wmax[c][w]); }
+        if (lo3[0] == 0xffffffffu) return;                                             // no candidate (ring_ncand stays 0)
+        // dense voxel number over the ring's box (what PCL computes; below 2^31 by the packing)
+        const unsigned dx = hi3[0] - lo3[0] + 1, dy = hi3[1] - lo3[1] + 1, dz = hi3[2] - lo3[2] + 1;
+        const unsigned range = dx * dy * dz - 1u;
+        const int shift = max(0, 32 - __clz((int)range) - 11);                        // the bins: top 11 bits, (range >> shift) < 2048
+#pragma unroll
+        for (int i = 0; i < kPer; i++) {
+            if (key[i] != 0xffffffffu) key[i] = ((key[i] >> 22) - lo3[2]) * (dx * dy) + (((key[i] >> 11) & 2047u) - lo3[1]) * dx + ((key[i] & 2047u) - lo3[0]);
+            O.key[kPer * tid + i] = key[i];
+        }
+        __syncthreads();
+        // run heads and tails among this thread's points (the neighbours' keys come from LDS), numbered in index order by one scan:
+        // the r-th head and the r-th tail belong to the same run
+        const unsigned prev = tid > 0 ? O.key[kPer * tid - 1] : 0xffffffffu, next = tid < kRotBlock - 1 ? O.key[kPer * tid + kPer] : 0xffffffffu;
+        int nh = 0, nt = 0;
+        bool is_head[kPer], is_tail[kPer];
+#pragma unroll
+        for (int i = 0; i < kPer; i++) {
+            const unsigned before = i ? key[i - 1] : prev, after = i + 1 < kPer ? key[i + 1] : next;
+            is_head[i] = key[i] != 0xffffffffu && before != key[i];
+            is_tail[i] = key[i] != 0xffffffffu && after != key[i];
+            nh += is_head[i] ? 1 : 0; nt += is_tail[i] ? 1 : 0;
+        }
+        int n_runs;
+        {
+            int tot; const int ex = block_excl_scan_1024(nh | (nt << 16), O.scan, tot);
+            n_runs = tot & 0xffff;
+            int h = ex & 0xffff, t = ex >> 16;
+#pragma unroll
+            for (int i = 0; i < kPer; i++) {
+                if (is_head[i]) { O.rstart[h] = (unsigned short)(kPer * tid + i); O.rkey[h] = key[i]; h++; }
+                if (is_tail[i]) { O.rend[t] = (unsigned short)(kPer * tid + i); t++; }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) X.ring_ncand[ring] = n_runs;
+        // one pass of binning of the RUNS on the top bits of the voxel number, then exact ranks by (voxel, first index) inside the bins
+        int slot[kPer], rbin[kPer];
+#pragma unroll
+        for (int i = 0; i < kPer; i++) {
+            const int r = tid + i * kRotBlock;
+            rbin[i] = r < n_runs ? (int)(O.rkey[r] >> shift) : -1;
+            slot[i] = rbin[i] >= 0 ? atomicAdd(&O.cnt[rbin[i]], 1) : 0;
+        }
+        __syncthreads();
+        {
+            const int a = O.cnt[2 * tid], b2 = O.cnt[2 * tid + 1];
+            int tot; const int ex = block_excl_scan_1024(a + b2, O.scan, tot);
+            O.cnt[2 * tid] = ex; O.cnt[2 * tid + 1] = ex + a;          // (the scan's barriers lie between the reads above and these writes)
+            if (tid == kRotBlock - 1) O.cnt[2 * kRotBlock] = tot;
+        }
+        __syncthreads();
+        unsigned* bkey = O.key;                                                        // (the per-point keys are no longer needed)
+#pragma unroll
+        for (int i = 0; i < kPer; i++) if (rbin[i] >= 0) {
+            const int r = tid + i * kRotBlock, at = O.cnt[rbin[i]] + slot[i];
+            bkey[at] = O.rkey[r]; O.bidx[at] = (unsigned short)r;                    // (runs are numbered in index order: r orders equal voxels)
+        }
+        __syncthreads();
+        if (ring == 0 && tid == 0) st->tphase[3] = (wall_clock64() - t_rb) << 32;
+#pragma unroll
+        for (int i = 0; i < kPer; i++) if (rbin[i] >= 0) {
+            const int r = tid + i * kRotBlock;
+            const unsigned rk = O.rkey[r];
+            const int t0 = O.cnt[rbin[i]], t1 = O.cnt[rbin[i] + 1];
+            int rank = t0;
+            int t = t0;
+            for (; t + 4 <= t1; t += 4) {                                               // four independent loads in flight
+                const unsigned k0 = bkey[t], k1 = bkey[t + 1], k2 = bkey[t + 2], k3 = bkey[t + 3];
+                const int i0 = O.bidx[t], i1 = O.bidx[t + 1], i2 = O.bidx[t + 2], i3 = O.bidx[t + 3];
+                rank += ((k0 < rk || (k0 == rk && i0 < r)) ? 1 : 0) + ((k1 < rk || (k1 == rk && i1 < r)) ? 1 : 0)
+                      + ((k2 < rk || (k2 == rk && i2 < r)) ? 1 : 0) + ((k3 < rk || (k3 == rk && i3 < r)) ? 1 : 0);
+            }
+            for (; t < t1; t++) { const unsigned bk = bkey[t]; const int bi = O.bidx[t]; rank += (bk < rk || (bk == rk && bi < r)) ? 1 : 0; }
+            X.sorted_k[rbase + rank] = O.rstart[r]; X.sorted_len[rbase + rank] = (int)O.rend[r] - (int)O.rstart[r] + 1; X.sorted_vox[rbase + rank] = rk;
+        }
+        __syncthreads();
+        if (ring == 0 && tid == 0) st->tphase[3] |= (wall_clock64() - t_rb);
+        if (tid == 0) st->order_ticks[ring] = (int)(wall_clock64() - t_rb);
+        return;
+    }
+    // ================= segment j
+    const int j = by;
+    if (!in_lds) {       // not selected, or beyond the LDS working set: this sixth of the ring's curvatures and labels only
+        const int lo = (int)((long long)rcount * j / 6), hi = (int)((long long)rcount * (j + 1) / 6);
+        for (int k = lo + tid; k < hi; k += kRotBlock) {
+            const int g = rbase + k;
+            curv_g[g] = (g >= 5 && g < n - 5) ? curvature11(full, g) : 0.f;
+            label_g[g] = 0;                                                                 // R:393
+        }
+        return;
+    }
+    SegLds& L = *reinterpret_cast<SegLds*>(smem);
+    const int sp = s0 + (e0 - s0) * j / 6, ep = s0 + (e0 - s0) * (j + 1) / 6 - 1;           // ring-local, inclusive (R:404-405)
+    const int lo = j == 0 ? 0 : sp, hi = j == 5 ? rcount : ep + 1;                           // the stretch of the ring this workgroup answers for
+    const int w0 = lo - 5;                                                                   // window coordinate w <-> ring-local k = w0 + w
+    const int wlen = hi + 5 - w0;
+    const long long t_seg = wall_clock64();
+    if (ring == 0 && j == 0 && tid == 0) st->tphase[0] = t_seg;
+    for (int w = tid; w < wlen; w += kRotBlock) {
+        const int g = rbase + w0 + w;
+        L.pts[w] = (g >= 0 && g < n) ? full[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+        L.label[w] = 0; L.mark[w] = 0;
+    }
+    if (tid < 16) L.mark[wlen + tid] = 0;
+    __syncthreads();
+    const int spw = sp - w0, epw = ep - w0, len = ep - sp + 1;
+    for (int w = 5 + tid; w < wlen - 5; w += kRotBlock) {
+        const int g = rbase + w0 + w;
+        const float c = (g >= 5 && g < n - 5) ? curvature11(L.pts, w) : 0.f;
+        L.curv[w] = c;
+        curv_g[g] = c;
+    }
+    __syncthreads();
+    // rank sort of [sp, ep]: keys copied to a 16-byte aligned stretch padded with +inf; lane = (element, half of the keys)
+    const int len16 = (len + 15) & ~15;
+    for (int m = tid; m < len16; m += kRotBlock) L.key[m] = m < len ? L.curv[spw + m] : INFINITY;
+    __syncthreads();
+    {
+        const float4* K4 = reinterpret_cast<const float4*>(L.key);
+        const int half = __builtin_amdgcn_readfirstlane(tid >> 9), nc = len16 / 4, c0 = half * (nc / 2), c1 = half ? nc : nc / 2;
+        for (int et = 0; et < len; et += kRotBlock / 2) {           // (one trip for up to 512 elements, two for the longest segments)
+            const int e = et + (tid & 511);
+            const int eb = et + ((tid & 511) & ~63);                 // first element of this wave
+            int rank = 0;
+            if (eb < len) {
+                const float ck = e < len ? L.key[e] : INFINITY;
+                const int b0 = min(max(eb >> 2, c0), c1), b1 = min(max((eb + 64 + 3) >> 2, c0), c1);
+                for (int c = c0; c < b0; c++) { const float4 u = K4[c]; rank += (u.x <= ck ? 1 : 0) + (u.y <= ck ? 1 : 0) + (u.z <= ck ? 1 : 0) + (u.w <= ck ? 1 : 0); }
+                for (int c = b0; c < b1; c++) {
+                    const float4 u = K4[c];
+                    const int m = 4 * c;
+                    rank += (u.x < ck || (u.x == ck && m < e)) ? 1 : 0;
+                    rank += (u.y < ck || (u.y == ck && m + 1 < e)) ? 1 : 0;
+                    rank += (u.z < ck || (u.z == ck && m + 2 < e)) ? 1 : 0;
+                    rank += (u.w < ck || (u.w == ck && m + 3 < e)) ? 1 : 0;
+                }
+                for (int c = b1; c < c1; c++) { const float4 u = K4[c]; rank += (u.x < ck ? 1 : 0) + (u.y < ck ? 1 : 0) + (u.z < ck ? 1 : 0) + (u.w < ck ? 1 : 0); }
+            }
+            if (half && e < len) L.hrank[e] = rank;
+            __syncthreads();
+            if (!half && e < len) { rank += L.hrank[e]; L.sort_ind[spw + rank] = spw + e; sort_ind_g[rbase + sp + rank] = rbase + sp + e; }
+        }
+    }
+    __syncthreads();
+    const bool par_seg = (e0 - s0) >= 64;      // every segment longer than the reach of a suppression (5): spills stop in the next segment
+    if (ring == 0 && j == 0 && tid == 0) st->tphase[1] = wall_clock64();
+    if (tid < 64) {
+        if (par_seg) {
+            greedy_segment_wave(L, spw, epw);
+            LILI_ROT_WAVE_SYNC();
+            SegOut& O = X.seg_out[ring * 6 + j];
+            if (tid < L.ne) O.edge[tid] = L.edge[tid] + w0;
+            if (tid < L.nf) O.flat[tid] = L.flat[tid] + w0;
+            if (tid == 0) {
+                unsigned spill = 0;
+                for (int l = 0; l < 5; l++) if (L.mark[epw + 1 + l]) spill |= 1u << l;
+                O.ne = L.ne; O.nf = L.nf; O.spill = (int)spill; O.pad = 0;
+            }
+        }
+        if (ring == 0 && j == 0 && tid == 0) st->tphase[2] = wall_clock64();
+    }
+    __syncthreads();
+    // (a nearly empty ring takes the reference's serial order through all six segments in k_rot_ring; its labels stay 0 here)
+    for (int k = lo + tid; k < hi; k += kRotBlock) label_g[rbase + k] = L.label[k - w0];
+    if (tid == 0) atomicMax(&st->seg_ticks[ring], (int)(wall_clock64() - t_seg));
+}
+
+// The launch: a fixed number of workgroups (two per CU fit) share the work items — 6 segments for each of the 64 rings, then the
+// voxel ordering of each selected ring (which rings have work only the device knows: a grid with one workgroup per POSSIBLE item spent
+// most of its time dispatching workgroups that had nothing to do, ~27 ns each).
+__global__ __launch_bounds__(kRotBlock) void k_rot_segments(const float4* __restrict__ full, const unsigned* __restrict__ vkey_g, RotDev P, RotState* st, float* __restrict__ curv_g,
+                                                            int* __restrict__ sort_ind_g, int* __restrict__ label_g, RotRingScratch X) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int chunk_pref[kMaxRings + 1];
+    if (threadIdx.x < 64) {
+        const int r = threadIdx.x;
+        const int rc = st->ring_count[r], span = rc - 11;                                   // candidates live in [5, rcount - 7]
+        const int c = (r < P.n_scans && span >= 6 && r % P.ds_rate == 0 && rc <= kRingLdsCap && st->vox_overflow == 0) ? 1 : 0;   // (overflow: k_rot_voxel_order in a second pass)
+        int inc = c;
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (r >= o) inc += t; }
+        chunk_pref[r + 1] = inc;
+        if (r == 0) chunk_pref[0] = 0;
+    }
+    __syncthreads();
+    const int n_items = 6 * kMaxRings + chunk_pref[kMaxRings];
+    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+        if (it < 6 * kMaxRings) rot_stage3_item(it / 6, it % 6, smem, full, vkey_g, P, st, curv_g, sort_ind_g, label_g, X);
+        else {
+            const int c = it - 6 * kMaxRings;
+            int r = 0;
+            while (chunk_pref[r + 1] <= c) r++;
+            rot_stage3_item(r, 6 + c - chunk_pref[r], smem, full, vkey_g, P, st, curv_g, sort_ind_g, label_g, X);
+        }
+        __syncthreads();
+    }
+}
+
+struct RingLds {
+    SegLds seg;                              // redo of one segment / the serial run of a nearly empty ring
+    signed char label[kRingLdsCap];
+    float4 pts[kRingLdsCap];                 // the ring's points
+    unsigned rk[kRingLdsCap + 8];            // runs in (voxel, first index) order: voxel number (+ sentinels)
+    unsigned short rs[kRingLdsCap + 8], rl[kRingLdsCap + 8];   //                   first point, number of points
+    SegOut so[6];
+    int scan[kRotBlock / 64 + 1];
+    int flag, spill;
+};
+
+// Launch 4 of 5, one workgroup per selected ring: joins the six segments (spill check, R:401-492 order), writes the ring's pick lists, the
+// less-flat list in index order (R:494-499) and the VoxelGrid centroids of the less-flat points in the order k_rot_segments prepared
+// (f32 sums in list order, like pcl's CentroidPoint; PCL >= 1.8 semantics).
+__global__ __launch_bounds__(kRotBlock) void k_rot_ring(const float4* __restrict__ full, const float* __restrict__ curv_g, const int* __restrict__ sort_ind_g, RotDev P, RotState* st,
+                                                        int* __restrict__ label_g, int* __restrict__ ring_edge /*[64][60]*/,
+                                                        int* __restrict__ ring_sharp /*[64][12]*/, int* __restrict__ ring_flat /*[64][24]*/,
+                                                        int* __restrict__ lessflat_tmp /*[n]*/, float4* __restrict__ surf_tmp /*[n]*/,
+                                                        int* __restrict__ surf_cnt_tmp /*[n]*/, RotRingScratch X) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    RingLds& L = *reinterpret_cast<RingLds*>(smem);
+    const int ring = blockIdx.x, tid = threadIdx.x;
+    const int rbase = st->ring_base[ring], rcount = st->ring_count[ring];
+    const int rs = st->ring_start[ring], re = st->ring_end[ring];
     if (ring >= P.n_scans || re - rs < 6 || ring % P.ds_rate != 0) return;      // R:402
     if (rcount > kRingLdsCap) {     // does not fit the LDS working set: k_rot_select_big takes this ring (global-memory arrays)
         if (tid == 0) atomicAdd(&st->fallback_rings, 1);
         return;
     }
-    // ---- stage the ring: local index l <-> global index rbase + l
-    if (ring == 0 && tid == 0) st->tphase[0] = wall_clock64();
-    for (int k = tid; k < rcount; k += kRotBlock) {
-        L.pts[k] = full[rbase + k]; L.curv[k] = curv_g[rbase + k];
-        L.label[k] = 0;
+    const long long t_start = wall_clock64();
+    if (ring == kProbeRing && tid == 0) st->tphase[4] = t_start;
+    const int s0 = rs - rbase, e0 = re - rbase;
+    const bool par_seg = (e0 - s0) >= 64;
+    const int n_runs = X.ring_ncand[ring];       // (k_rot_segments ordered the runs of every selected ring that fits LDS, nearly empty ones included)
+    for (int k = tid; k < rcount; k += kRotBlock) { L.label[k] = (signed char)label_g[rbase + k]; L.pts[k] = full[rbase + k]; }
+    for (int i = tid; i < n_runs + 4; i += kRotBlock) {
+        const bool in = i < n_runs;
+        L.rk[i] = in ? X.sorted_vox[rbase + i] : 0xffffffffu;            // (sentinels end the last voxel)
+        L.rs[i] = in ? (unsigned short)X.sorted_k[rbase + i] : 0; L.rl[i] = in ? (unsigned short)X.sorted_len[rbase + i] : 0;
     }
+    if (par_seg && tid < 6 * (int)(sizeof(SegOut) / sizeof(int))) reinterpret_cast<int*>(L.so)[tid] = reinterpret_cast<const int*>(X.seg_out + ring * 6)[tid];
     __syncthreads();
-    const int s0 = rs - rbase, e0 = re - rbase;   // local scanStartInd / scanEndInd
-    // ---- sorted order of every segment (k_rot_rank): global -> local indices
-    if (ring == 0 && tid == 0) st->tphase[1] = wall_clock64();
-    for (int k = s0 + tid; k <= e0 - 1; k += kRotBlock) L.sort_ind[k] = sort_ind_g[rbase + k] - rbase;
-    __syncthreads();
-    // ---- greedy picks.  The reference runs the six segments one after the other and the +-5 neighbour suppression of a pick may
-    // reach across a segment border (A4 iv) — but only FORWARD matters (marks that land in an earlier segment are never read again),
-    // and only through the first five elements of the next segment.  So the six segments run concurrently, one wave each, every one
-    // on a private stretch of the mark array (segment j: mark[k + 10 j], k in [sp - 5, ep + 5] — the stretches do not overlap); then
-    // segment j is checked against what segment j - 1 finally marked in its first five elements: if none of j's picks is among
-    // them the sequential run would have picked exactly the same (a marked element is only ever skipped), otherwise j is redone
-    // with those marks in place (rare: a top-10 curvature within five points of both sides of a border).
-    if (ring == 0 && tid == 0) st->tphase[2] = wall_clock64();
-    const bool par_seg = (e0 - s0) >= 64;      // every segment longer than the reach of a suppression (5): spills stop in the next segment
-    if (!par_seg) {                             // a nearly empty ring: the reference's order, one shared mark stretch
-        for (int k = s0 - 5 + tid; k <= e0 + 5; k += kRotBlock) L.mark[k] = 0;
+    bool relabel = false;
+    // stages segment j's window (or the whole of a nearly empty ring) for a serial greedy run
+    auto stage = [&](int lo, int hi, int sp, int ep) {       // ring-local [lo, hi) answered for, segment [sp, ep]
+        const int w0 = lo - 5, wlen = hi + 5 - w0;
+        for (int w = tid; w < wlen; w += kRotBlock) {
+            const int g = rbase + w0 + w;
+            const bool in = g >= rbase && g < rbase + rcount;
+            L.seg.pts[w] = in ? full[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+            L.seg.curv[w] = in ? curv_g[g] : 0.f;
+            L.seg.label[w] = 0; L.seg.mark[w] = 0;
+        }
+        for (int k = sp + tid; k <= ep; k += kRotBlock) L.seg.sort_ind[k - w0] = sort_ind_g[rbase + k] - rbase - w0;
+        if (tid < 16) L.seg.mark[wlen + tid] = 0;
+        return w0;
+    };
+    if (!par_seg) {                             // a nearly empty ring (< 75 points): the reference's order, one shared mark array
+        const int w0 = stage(0, rcount, s0, e0 - 1);
         __syncthreads();
-        if (tid == 0) for (int j = 0; j < 6; j++) greedy_segment(L, L.mark, s0 + (e0 - s0) * j / 6, s0 + (e0 - s0) * (j + 1) / 6 - 1, 0u, j);
+        if (tid == 0) {
+            for (int j = 0; j < 6; j++) {
+                greedy_segment(L.seg, s0 + (e0 - s0) * j / 6 - w0, s0 + (e0 - s0) * (j + 1) / 6 - 1 - w0, 0u);
+                SegOut& O = L.so[j];
+                for (int q = 0; q < L.seg.ne; q++) O.edge[q] = L.seg.edge[q] + w0;
+                for (int q = 0; q < L.seg.nf; q++) O.flat[q] = L.seg.flat[q] + w0;
+                O.ne = L.seg.ne; O.nf = L.seg.nf;
+            }
+        }
+        __syncthreads();
+        for (int k = tid; k < rcount; k += kRotBlock) L.label[k] = L.seg.label[k - w0];
+        relabel = true;
+        __syncthreads();
     } else {
-        const int wave = tid >> 6, lane = tid & 63;
-        if (wave < 6) {
-            const int j = wave;
-            const int sp = s0 + (e0 - s0) * j / 6, ep = s0 + (e0 - s0) * (j + 1) / 6 - 1;
-            signed char* M = L.mark + 10 * j;
-            for (int k = sp - 5 + lane; k <= ep + 5; k += 64) M[k] = 0;
-            LILI_ROT_WAVE_SYNC();
-            greedy_segment_wave(L, M, sp, ep, j);
+        for (int j = 1; j < 6; j++) {           // (uniform trip count; the redo is rare)
+            if (tid == 0) {
+                const int sp = s0 + (e0 - s0) * j / 6;
+                const unsigned spill = (unsigned)L.so[j - 1].spill;
+                bool hit = false;
+                if (spill) {
+                    for (int q = 0; q < L.so[j].ne; q++) { const int d = L.so[j].edge[q] - sp; if (d >= 0 && d < 5 && ((spill >> d) & 1u)) hit = true; }
+                    for (int q = 0; q < L.so[j].nf; q++) { const int d = L.so[j].flat[q] - sp; if (d >= 0 && d < 5 && ((spill >> d) & 1u)) hit = true; }
+                }
+                L.flag = hit ? 1 : 0; L.spill = (int)spill;
+            }
+            __syncthreads();
+            if (L.flag) {
+                const int sp = s0 + (e0 - s0) * j / 6, ep = s0 + (e0 - s0) * (j + 1) / 6 - 1;
+                const int w0 = stage(sp, j == 5 ? rcount : ep + 1, sp, ep);
+                __syncthreads();
+                if (tid < 64) greedy_segment_wave(L.seg, sp - w0, ep - w0, (unsigned)L.spill);       // (wave 0; same picks as the serial loop)
+                __syncthreads();
+                if (tid == 0) {
+                    SegOut& O = L.so[j];
+                    for (int q = 0; q < O.ne; q++) L.label[O.edge[q]] = 0;
+                    for (int q = 0; q < O.nf; q++) L.label[O.flat[q]] = 0;
+                    for (int q = 0; q < L.seg.ne; q++) { O.edge[q] = L.seg.edge[q] + w0; L.label[O.edge[q]] = L.seg.label[L.seg.edge[q]]; }
+                    for (int q = 0; q < L.seg.nf; q++) { O.flat[q] = L.seg.flat[q] + w0; L.label[O.flat[q]] = L.seg.label[L.seg.flat[q]]; }
+                    O.ne = L.seg.ne; O.nf = L.seg.nf;
+                    unsigned spill = 0;
+                    for (int l = 0; l < 5; l++) if (L.seg.mark[ep - w0 + 1 + l]) spill |= 1u << l;
+                    O.spill = (int)spill;
+                    atomicAdd(&st->redo_segments, 1);
+                }
+                relabel = true;
+            }
+            __syncthreads();
         }
     }
-    __syncthreads();
     if (tid == 0) {
-        for (int j = 1; j < 6 && par_seg; j++) {
-            const int sp = s0 + (e0 - s0) * j / 6, ep = s0 + (e0 - s0) * (j + 1) / 6 - 1;
-            const signed char* Mp = L.mark + 10 * (j - 1);
-            unsigned spill = 0;
-            for (int l = 0; l < 5 && sp + l <= ep + 5; l++) if (Mp[sp + l]) spill |= 1u << l;
-            if (!spill) continue;
-            bool hit = false;
-            for (int q = 0; q < L.seg_ne[j]; q++) { const int d = L.seg_edge[j][q] - sp; if (d >= 0 && d < 5 && ((spill >> d) & 1u)) hit = true; }
-            for (int q = 0; q < L.seg_nf[j]; q++) { const int d = L.seg_flat[j][q] - sp; if (d >= 0 && d < 5 && ((spill >> d) & 1u)) hit = true; }
-            if (!hit) continue;
-            for (int q = 0; q < L.seg_ne[j]; q++) L.label[L.seg_edge[j][q]] = 0;
-            for (int q = 0; q < L.seg_nf[j]; q++) L.label[L.seg_flat[j][q]] = 0;
-            signed char* M = L.mark + 10 * j;
-            for (int k = sp - 5; k <= ep + 5; k++) M[k] = 0;
-            greedy_segment(L, M, sp, ep, spill, j);
-            atomicAdd(&st->redo_segments, 1);
-        }
         int ne = 0, nsh = 0, nfl = 0;
         for (int j = 0; j < 6; j++) {
-            for (int q = 0; q < L.seg_ne[j]; q++) {
-                const int g = rbase + L.seg_edge[j][q];
+            for (int q = 0; q < L.so[j].ne; q++) {
+                const int g = rbase + L.so[j].edge[q];
                 if (q < 2) ring_sharp[ring * kRingSharpCap + nsh++] = g;
                 ring_edge[ring * kRingEdgeCap + ne++] = g;
             }
-            for (int q = 0; q < L.seg_nf[j]; q++) ring_flat[ring * kRingFlatCap + nfl++] = rbase + L.seg_flat[j][q];
+            for (int q = 0; q < L.so[j].nf; q++) ring_flat[ring * kRingFlatCap + nfl++] = rbase + L.so[j].flat[q];
         }
         st->ring_nedge[ring] = ne; st->ring_nsharp[ring] = nsh; st->ring_nflat[ring] = nfl;
     }
-    __syncthreads();
-    for (int k = tid; k < rcount; k += kRotBlock) label_g[rbase + k] = L.label[k];
+    if (relabel) for (int k = tid; k < rcount; k += kRotBlock) label_g[rbase + k] = L.label[k];
     // ---- less-flat list in index order (R:494-499), compacted with a block scan
-    if (ring == 0 && tid == 0) st->tphase[3] = wall_clock64();
+    if (ring == kProbeRing && tid == 0) st->tphase[5] = wall_clock64();
     int n_lf = 0;
     for (int k0 = s0; k0 <= e0 - 1; k0 += kRotBlock) {
-        int k = k0 + tid;
-        bool keep = k <= e0 - 1 && !((double)range2(L.pts, k) < 0.25) && L.label[k] <= 0;
-        int tot; int off = block_excl_scan_1024(keep ? 1 : 0, L.scan, tot);
-        if (keep) { lessflat_tmp[rbase + n_lf + off] = rbase + k; L.sort_ind[n_lf + off] = k; }   // sort_ind is free again: local less-flat list
+        const int k = k0 + tid;
+        const bool keep = k <= e0 - 1 && L.label[k] <= 0 && !((double)range2(L.pts[k]) < 0.25);
+        int tot; const int off = block_excl_scan_1024(keep ? 1 : 0, L.scan, tot);
+        if (keep) lessflat_tmp[rbase + n_lf + off] = rbase + k;
         n_lf += tot;
     }
-    __syncthreads();
     if (tid == 0) st->ring_nlf[ring] = n_lf;
-    // ---- pcl::VoxelGrid(ds_v) on the ring's less-flat points (R:502-508; PCL >= 1.8 semantics)
-    if (ring == 0 && tid == 0) st->tphase[4] = wall_clock64();
-    if (n_lf == 0) { if (tid == 0) st->ring_nsurf[ring] = 0; return; }
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int q = tid; q < n_lf; q += kRotBlock) {
-        float4 p = L.pts[L.sort_ind[q]];
-        mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
-        mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
-    }
-#pragma unroll
-    for (int c = 0; c < 3; c++) for (int o = 32; o > 0; o >>= 1) { mn[c] = fminf(mn[c], __shfl_xor(mn[c], o)); mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o)); }
-    if ((tid & 63) == 0) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) { L.red[c][tid >> 6] = mn[c]; L.red[3 + c][tid >> 6] = mx[c]; }
-    }
-    __syncthreads();
-    const float inv = 1.0f / P.ds_v;
-    int min_b[3], div_b[3];
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        float a = L.red[c][0], b = L.red[3 + c][0];
-        for (int w = 1; w < kRotBlock / 64; w++) { a = fminf(a, L.red[c][w]); b = fmaxf(b, L.red[3 + c][w]); }
-        min_b[c] = (int)floorf(a * inv);
-        div_b[c] = (int)floorf(b * inv) - min_b[c] + 1;
-    }
-    // order of the less-flat points by (voxel index, position in the list): stable LSD radix sort of the POSITIONS (16-bit) on 5-bit
-    // digits of the voxel index, one workgroup, in LDS — 4 block barriers per pass and ceil(bits / 5) passes, against the 78 barriers of
-    // the bitonic network on 64-bit (voxel, position) keys it replaces (55 -> ~12 us per ring).  Ranks inside a wave come from
-    // five ballots (the lanes that hold the same digit), across waves / slots from one scan of the [digit][slot][wave] count table.
-    for (int q = tid; q < n_lf; q += kRotBlock) {
-        float4 p = L.pts[L.sort_ind[q]];
-        int i0 = (int)(floorf(p.x * inv) - (float)min_b[0]);
-        int i1 = (int)(floorf(p.y * inv) - (float)min_b[1]);
-        int i2 = (int)(floorf(p.z * inv) - (float)min_b[2]);
-        L.vidx[q] = (unsigned)(i0 + i1 * div_b[0] + i2 * div_b[0] * div_b[1]);
-        L.ord_a[q] = (unsigned short)q;
-    }
-    const unsigned n_vox = (unsigned)div_b[0] * (unsigned)div_b[1] * (unsigned)div_b[2];    // PCL itself rejects grids beyond 2^31 cells
-    int bits = 1; while (bits < 32 && (n_vox - 1u) >> bits) bits++;
-    unsigned short* src = L.ord_a;
-    unsigned short* dst = L.ord_b;
-    __syncthreads();
-    {
-        const int wave = tid >> 6, lane = tid & 63;
-        for (int shift = 0; shift < bits; shift += 5) {
-            L.rcnt[tid] = 0; L.rcnt[tid + kRotBlock] = 0;
-            __syncthreads();
-            int dig[4], rk[4], qq[4];
-#pragma unroll
-            for (int sl = 0; sl < 4; sl++) {
-                const int i = sl * kRotBlock + tid;
-                const bool act = i < n_lf;
-                qq[sl] = act ? (int)src[i] : 0;
-                const int d = act ? (int)((L.vidx[qq[sl]] >> shift) & 31u) : 0;
-                unsigned long long m = __ballot(act);
-#pragma unroll
-                for (int bb = 0; bb < 5; bb++) { const unsigned long long bal = __ballot(act && ((d >> bb) & 1)); m &= ((d >> bb) & 1) ? bal : ~bal; }
-                rk[sl] = __popcll(m & ((1ull << lane) - 1ull));
-                dig[sl] = d;
-                if (act && rk[sl] == 0) L.rcnt[(d * 4 + sl) * (kRotBlock / 64) + wave] = __popcll(m);
-            }
-            __syncthreads();
-            {
-                const int a = L.rcnt[2 * tid], b2 = L.rcnt[2 * tid + 1];
-                int tot; const int ex = block_excl_scan_1024(a + b2, L.scan, tot);
-                L.rcnt[2 * tid] = ex; L.rcnt[2 * tid + 1] = ex + a;
-            }
-            __syncthreads();
-#pragma unroll
-            for (int sl = 0; sl < 4; sl++) {
-                const int i = sl * kRotBlock + tid;
-                if (i < n_lf) dst[L.rcnt[(dig[sl] * 4 + sl) * (kRotBlock / 64) + wave] + rk[sl]] = (unsigned short)qq[sl];
-            }
-            __syncthreads();
-            unsigned short* t2 = src; src = dst; dst = t2;
-        }
-    }
-    // run heads -> output slots; each head accumulates its voxel in list order (f32, like CentroidPoint)
-    if (ring == 0 && tid == 0) st->tphase[5] = wall_clock64();
+    // ---- pcl::VoxelGrid(ds_v) on the less-flat points (R:502-508): the runs of candidates in (voxel, first index) order — a voxel's
+    // points in list order are its runs one after the other — minus the picked points (R:494-499)
+    if (ring == kProbeRing && tid == 0) st->tphase[6] = wall_clock64();
     int n_out = 0;
-    for (int q0 = 0; q0 < n_lf; q0 += kRotBlock) {
-        int q = q0 + tid;
-        bool head = q < n_lf && (q == 0 || L.vidx[src[q]] != L.vidx[src[q - 1]]);
-        int tot; int off = block_excl_scan_1024(head ? 1 : 0, L.scan, tot);
-        if (head) {
-            unsigned vox = L.vidx[src[q]];
-            float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f; int cnt = 0;
-            for (int m = q; m < n_lf && L.vidx[src[m]] == vox; m++) {
-                float4 p = L.pts[L.sort_ind[src[m]]];
-                sx += p.x; sy += p.y; sz += p.z; si += p.w; cnt++;
+    for (int i0 = 0; i0 < n_runs; i0 += kRotBlock) {
+        const int i = i0 + tid;
+        const bool first = i < n_runs && (i == 0 || L.rk[i - 1] != L.rk[i]);     // first run of its voxel
+        float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f; int cnt = 0;
+        if (first) {
+            const unsigned vox = L.rk[i];
+            unsigned nk = vox; int na = L.rs[i], nl = L.rl[i];          // (the next run's descriptor is loaded while this run is summed)
+            for (int j = i; nk == vox; j++) {
+                const int a = na, e = na + nl;
+                nk = L.rk[j + 1]; na = L.rs[j + 1]; nl = L.rl[j + 1];
+                int k = a;
+                for (; k + 4 <= e; k += 4) {          // four loads in flight; the sums stay strictly sequential (f32, like CentroidPoint)
+                    const float4 p0 = L.pts[k], p1 = L.pts[k + 1], p2 = L.pts[k + 2], p3 = L.pts[k + 3];
+                    const signed char l0 = L.label[k], l1 = L.label[k + 1], l2 = L.label[k + 2], l3 = L.label[k + 3];
+                    if (l0 <= 0) { sx += p0.x; sy += p0.y; sz += p0.z; si += p0.w; cnt++; }
+                    if (l1 <= 0) { sx += p1.x; sy += p1.y; sz += p1.z; si += p1.w; cnt++; }
+                    if (l2 <= 0) { sx += p2.x; sy += p2.y; sz += p2.z; si += p2.w; cnt++; }
+                    if (l3 <= 0) { sx += p3.x; sy += p3.y; sz += p3.z; si += p3.w; cnt++; }
+                }
+                for (; k < e; k++) if (L.label[k] <= 0) { const float4 p = L.pts[k]; sx += p.x; sy += p.y; sz += p.z; si += p.w; cnt++; }
             }
-            float fn = (float)cnt;
+        }
+        const bool out = cnt > 0;                     // (a voxel whose points were all picked as edge points has no centroid)
+        int tot; const int off = block_excl_scan_1024(out ? 1 : 0, L.scan, tot);
+        if (out) {
+            const float fn = (float)cnt;
             surf_tmp[rbase + n_out + off] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
             surf_cnt_tmp[rbase + n_out + off] = cnt;
         }
         n_out += tot;
     }
-    if (tid == 0) st->ring_nsurf[ring] = n_out;
-    if (ring == 0 && tid == 0) st->tphase[6] = wall_clock64();
+    if (tid == 0) { st->ring_nsurf[ring] = n_out; st->ring_ticks[ring] = (int)(wall_clock64() - t_start); }
+    if (ring == kProbeRing && tid == 0) st->tphase[7] = wall_clock64();
 }
 
 // ---- rings that do not fit the LDS working set (more than kRingLdsCap = 4096 points on one ring: a 16-ring sensor at 0.1 deg, merged
@@ -943,7 +1327,8 @@ __global__ __launch_bounds__(256) void k_rot_compact(RotState* st, const float4*
 // ================================================================================================
 namespace lili_detail {
 struct RotBuffers {
-    DevBuf in, valid, scan_id, ori_raw, block_hist, state, full, full_src, curv, label, sort_ind;
+    DevBuf in, scan_id, ori_raw, block_hist, block_half, state, full, full_src, curv, label, sort_ind;
+    DevBuf vkey, seg_out, ring_ncand, sorted_k, sorted_vox, sorted_len;      // k_rot_scatter -> k_rot_segments -> k_rot_ring
     DevBuf ring_edge, ring_sharp, ring_flat, lessflat_tmp, surf_tmp, surf_cnt_tmp;
     DevBuf edge_idx, edge_pts, sharp_idx, flat_idx, lessflat_idx, surf, surf_cnt;
     DevBuf big_mark, big_vidx, big_ord_a, big_ord_b, big_rcnt;   // working set of rings beyond the LDS budget (k_rot_select_big)
@@ -951,7 +1336,8 @@ struct RotBuffers {
     int n_in = 0;
     bool have = false;
     void release() {
-        for (DevBuf* b : {&in, &valid, &scan_id, &ori_raw, &block_hist, &state, &full, &full_src, &curv, &label, &sort_ind, &ring_edge, &ring_sharp, &ring_flat,
+        for (DevBuf* b : {&in, &scan_id, &ori_raw, &block_hist, &block_half, &state, &full, &full_src, &curv, &label, &sort_ind, &vkey, &seg_out, &ring_ncand, &sorted_k, &sorted_vox,
+                          &sorted_len, &big_mark, &big_vidx, &big_ord_a, &big_ord_b, &big_rcnt, &ring_edge, &ring_sharp, &ring_flat,
                           &lessflat_tmp, &surf_tmp, &surf_cnt_tmp, &edge_idx, &edge_pts, &sharp_idx, &flat_idx, &lessflat_idx, &surf, &surf_cnt}) b->release();
     }
 };
@@ -988,35 +1374,41 @@ int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4
     auto* R = rot_of(ctx);
     R->have = false;
     bool full_early = false;      // the full cloud's copy to the host was started behind k_rot_scatter (see there)
-    int rc = lili_ingest_cloud(ctx, scan, R->in);
+    // a scan that is already in HBM as float4 rows is read in place (no staging copy, one launch less)
+    const bool in_place = scan->mem == LILI_MEM_DEVICE && scan->stride == sizeof(float4) && scan->aux_offset == 12 && (reinterpret_cast<uintptr_t>(scan->data) & 15) == 0;
+    int rc = in_place ? LILI_OK : lili_ingest_cloud(ctx, scan, R->in);
     if (rc != LILI_OK) return rc;
     const int n = (int)scan->n;
     R->n_in = n;
     HIPCHK(R->state.ensure(sizeof(RotState)));
     RotState* st = R->state.as<RotState>();
-    hipLaunchKernelGGL(k_rot_init, dim3(1), dim3(64), 0, ctx->stream, st);
+    if (n == 0) HIPCHK(hipMemsetAsync(st, 0, sizeof(RotState), ctx->stream));      // (the kernels below write every field they later read; an empty scan launches none)
+    RotRingScratch X{};
     if (n > 0) {
         const size_t cap = (size_t)n;
         const int nb = nblocks(n, kRotBlock);
-        HIPCHK(R->valid.ensure(cap)); HIPCHK(R->scan_id.ensure(cap)); HIPCHK(R->ori_raw.ensure(cap * 4));
-        HIPCHK(R->block_hist.ensure((size_t)nb * kMaxRings * 4));
+        HIPCHK(R->scan_id.ensure(cap)); HIPCHK(R->ori_raw.ensure(cap * 4));
+        HIPCHK(R->block_hist.ensure((size_t)nb * kMaxRings * 4)); HIPCHK(R->block_half.ensure((size_t)nb * 4));
         HIPCHK(R->full.ensure(cap * 16)); HIPCHK(R->full_src.ensure(cap * 4)); HIPCHK(R->curv.ensure(cap * 4)); HIPCHK(R->label.ensure(cap * 4)); HIPCHK(R->sort_ind.ensure(cap * 4));
+        HIPCHK(R->seg_out.ensure(kMaxRings * 6 * sizeof(SegOut))); HIPCHK(R->ring_ncand.ensure(kMaxRings * 4));
+        HIPCHK(R->sorted_k.ensure(cap * 4)); HIPCHK(R->sorted_vox.ensure(cap * 4)); HIPCHK(R->sorted_len.ensure(cap * 4)); HIPCHK(R->vkey.ensure((cap + 16) * 4));
         HIPCHK(R->ring_edge.ensure(kMaxRings * kRingEdgeCap * 4)); HIPCHK(R->ring_sharp.ensure(kMaxRings * kRingSharpCap * 4)); HIPCHK(R->ring_flat.ensure(kMaxRings * kRingFlatCap * 4));
         HIPCHK(R->lessflat_tmp.ensure(cap * 4)); HIPCHK(R->surf_tmp.ensure(cap * 16)); HIPCHK(R->surf_cnt_tmp.ensure(cap * 4));
         HIPCHK(R->edge_idx.ensure(kMaxRings * kRingEdgeCap * 4)); HIPCHK(R->edge_pts.ensure(kMaxRings * kRingEdgeCap * 16));
         HIPCHK(R->sharp_idx.ensure(kMaxRings * kRingSharpCap * 4)); HIPCHK(R->flat_idx.ensure(kMaxRings * kRingFlatCap * 4));
         HIPCHK(R->lessflat_idx.ensure(cap * 4)); HIPCHK(R->surf.ensure(cap * 16)); HIPCHK(R->surf_cnt.ensure(cap * 4));
+        X.seg_out = R->seg_out.as<SegOut>(); X.ring_ncand = R->ring_ncand.as<int>(); X.sorted_k = R->sorted_k.as<int>(); X.sorted_vox = R->sorted_vox.as<unsigned>();
+        X.sorted_len = R->sorted_len.as<int>();
         RotDev P{};
         P.n_scans = params->n_scans; P.ds_rate = params->ds_rate; P.ds_v = params->ds_v; P.near_thres = params->near_range;
         P.atan_mode = ctx->rot_atan;
         for (int i = 0; i < 4; i++) { P.q_imu[i] = q_imu[i]; P.q_lb[i] = q_lb[i]; }
-        const float4* in = R->in.as<float4>();
-        hipLaunchKernelGGL(k_rot_valid, dim3(std::min(nblocks(n, 256), 128)), dim3(256), 0, ctx->stream, in, n, P.near_thres, R->valid.as<unsigned char>(), st);
-        hipLaunchKernelGGL(k_rot_classify, dim3(nb), dim3(kRotBlock), 0, ctx->stream, in, n, R->valid.as<unsigned char>(), P, st,
-                           R->scan_id.as<signed char>(), R->ori_raw.as<float>(), R->block_hist.as<int>());
-        hipLaunchKernelGGL(k_rot_ring_scan, dim3(1), dim3(kRotBlock), 0, ctx->stream, R->block_hist.as<int>(), nb, P, st);
-        hipLaunchKernelGGL(k_rot_scatter, dim3(nb), dim3(kRotBlock), 0, ctx->stream, in, n, R->scan_id.as<signed char>(), R->ori_raw.as<float>(), P, st,
-                           R->block_hist.as<int>(), R->full.as<float4>(), R->full_src.as<int>());
+        const float4* in = in_place ? static_cast<const float4*>(scan->data) : R->in.as<float4>();
+        // five launches (round 2: nine): classify | scatter | segments + voxel ordering (7 workgroups per ring) | ring | concatenation
+        hipLaunchKernelGGL(k_rot_classify, dim3(nb), dim3(kRotBlock), 0, ctx->stream, in, n, P, st, R->scan_id.as<signed char>(), R->ori_raw.as<float>(),
+                           R->block_hist.as<int>(), R->block_half.as<int>());
+        hipLaunchKernelGGL(k_rot_scatter, dim3(nb), dim3(kRotBlock), 0, ctx->stream, in, n, nb, R->scan_id.as<signed char>(), R->ori_raw.as<float>(), P, st,
+                           R->block_hist.as<int>(), R->block_half.as<int>(), R->full.as<float4>(), R->full_src.as<int>(), R->vkey.as<unsigned>(), X.ring_ncand);
         // the deskewed cloud is final here: its copy to the host (3.2 MB for a 200 k-point scan, ~60 us) runs on a side stream under the feature
         // selection instead of behind it.  All n entries travel (the count is known only at the end); entries behind `count` are unspecified.
         if (full && full->data && full->mem == LILI_MEM_HOST && (full->stride == 0 || full->stride == sizeof(float4)) && full->capacity > 0) {
@@ -1029,11 +1421,11 @@ int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4
             HIPCHK(hipEventRecord(ctx->join_ev[1], ctx->side[1]));
             full_early = true;
         }
-        hipLaunchKernelGGL(k_rot_curvature, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, R->full.as<float4>(), st, R->curv.as<float>());
-        hipLaunchKernelGGL(k_rot_rank, dim3(kMaxRings, 6, 12), dim3(256), 0, ctx->stream, R->curv.as<float>(), P, st, R->sort_ind.as<int>());
-        hipLaunchKernelGGL(k_rot_select, dim3(kMaxRings), dim3(kRotBlock), sizeof(RingLds), ctx->stream, R->full.as<float4>(), R->curv.as<float>(), R->sort_ind.as<int>(), P, st,
+        hipLaunchKernelGGL(k_rot_segments, dim3(kStage3Blocks), dim3(kRotBlock), std::max(sizeof(SegLds), sizeof(OrderLds)), ctx->stream, R->full.as<float4>(), R->vkey.as<unsigned>(), P, st, R->curv.as<float>(),
+                           R->sort_ind.as<int>(), R->label.as<int>(), X);
+        hipLaunchKernelGGL(k_rot_ring, dim3(kMaxRings), dim3(kRotBlock), sizeof(RingLds), ctx->stream, R->full.as<float4>(), R->curv.as<float>(), R->sort_ind.as<int>(), P, st,
                            R->label.as<int>(), R->ring_edge.as<int>(), R->ring_sharp.as<int>(), R->ring_flat.as<int>(), R->lessflat_tmp.as<int>(),
-                           R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>());
+                           R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>(), X);
         hipLaunchKernelGGL(k_rot_compact, dim3(kMaxRings), dim3(256), 0, ctx->stream, st, R->full.as<float4>(), R->ring_edge.as<int>(), R->ring_sharp.as<int>(),
                            R->ring_flat.as<int>(), R->lessflat_tmp.as<int>(), R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>(), R->edge_idx.as<int>(),
                            R->edge_pts.as<float4>(), R->sharp_idx.as<int>(), R->flat_idx.as<int>(), R->lessflat_idx.as<int>(), R->surf.as<float4>(), R->surf_cnt.as<int>());
@@ -1041,6 +1433,22 @@ int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4
     }
     HIPCHK(hipMemcpyAsync(&R->host, st, sizeof(RotState), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (n == 0) { R->host.first_valid = R->host.half_idx = 0x7fffffff; R->host.last_valid = -1; }
+    if (n > 0 && R->host.vox_overflow) {   // voxel coordinates beyond the packed keys: order by the radix pass, then the ring stage and the concatenation again
+        RotDev P{};
+        P.n_scans = params->n_scans; P.ds_rate = params->ds_rate; P.ds_v = params->ds_v; P.near_thres = params->near_range; P.atan_mode = ctx->rot_atan;
+        for (int i = 0; i < 4; i++) { P.q_imu[i] = q_imu[i]; P.q_lb[i] = q_lb[i]; }
+        hipLaunchKernelGGL(k_rot_voxel_order, dim3(kMaxRings), dim3(kRotBlock), sizeof(SortLds), ctx->stream, R->full.as<float4>(), P, st, X);
+        hipLaunchKernelGGL(k_rot_ring, dim3(kMaxRings), dim3(kRotBlock), sizeof(RingLds), ctx->stream, R->full.as<float4>(), R->curv.as<float>(), R->sort_ind.as<int>(), P, st,
+                           R->label.as<int>(), R->ring_edge.as<int>(), R->ring_sharp.as<int>(), R->ring_flat.as<int>(), R->lessflat_tmp.as<int>(),
+                           R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>(), X);
+        hipLaunchKernelGGL(k_rot_compact, dim3(kMaxRings), dim3(256), 0, ctx->stream, st, R->full.as<float4>(), R->ring_edge.as<int>(), R->ring_sharp.as<int>(),
+                           R->ring_flat.as<int>(), R->lessflat_tmp.as<int>(), R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>(), R->edge_idx.as<int>(),
+                           R->edge_pts.as<float4>(), R->sharp_idx.as<int>(), R->flat_idx.as<int>(), R->lessflat_idx.as<int>(), R->surf.as<float4>(), R->surf_cnt.as<int>());
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(&R->host, st, sizeof(RotState), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
     if (R->host.fallback_rings > 0) {      // rings beyond the LDS working set: second pass with global-memory arrays, then the concatenation again
         const size_t cap = (size_t)std::max(n, 1);
         RotBigScratch B{};
@@ -1057,6 +1465,7 @@ int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4
         RotDev P{};
         P.n_scans = params->n_scans; P.ds_rate = params->ds_rate; P.ds_v = params->ds_v; P.near_thres = params->near_range; P.atan_mode = ctx->rot_atan;
         for (int i = 0; i < 4; i++) { P.q_imu[i] = q_imu[i]; P.q_lb[i] = q_lb[i]; }
+        hipLaunchKernelGGL(k_rot_rank, dim3(kMaxRings, 6, 12), dim3(256), 0, ctx->stream, R->curv.as<float>(), P, st, R->sort_ind.as<int>());
         hipLaunchKernelGGL(k_rot_select_big, dim3(kMaxRings), dim3(kRotBlock), 0, ctx->stream, R->full.as<float4>(), R->curv.as<float>(), R->sort_ind.as<int>(), P, st,
                            R->label.as<int>(), R->ring_edge.as<int>(), R->ring_sharp.as<int>(), R->ring_flat.as<int>(), R->lessflat_tmp.as<int>(),
                            R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>(), B);
@@ -1087,7 +1496,12 @@ int lili_extract_rot_debug(lili_ctx* ctx, int32_t counts[8], int32_t* ring_start
     if (!R->have) return ctx->fail(LILI_E_STATE, "extract_rot_debug: run lili_extract_rot first");
     HIPCHK(hipSetDevice(ctx->device));
     const RotState& h = R->host;
-    if (getenv("LILI_ROT_PHASES")) { fprintf(stderr, "rot_select phases (100 MHz ticks):"); for (int k = 1; k < 7; k++) fprintf(stderr, " %lld", h.tphase[k] - h.tphase[k-1]); fprintf(stderr, "\n"); }
+    if (getenv("LILI_ROT_PHASES")) { fprintf(stderr, "ring 0, 100 MHz ticks: segment 0 (curvature + rank sort | greedy)"); fprintf(stderr, " %lld %lld; voxel ordering (binning | total) %lld %lld", h.tphase[1] - h.tphase[0], h.tphase[2] - h.tphase[1], h.tphase[3] >> 32, h.tphase[3] & 0xffffffff);
+                                    fprintf(stderr, "; ring (join | less-flat | centroids)"); for (int k = 5; k < 8; k++) fprintf(stderr, " %lld", h.tphase[k] - h.tphase[k-1]);
+                                    fprintf(stderr, "\n  from segment 0's start to k_rot_ring's start: %lld", h.tphase[4] - h.tphase[0]);
+                                    fprintf(stderr, "\n  k_rot_ring ticks per ring:"); for (int k = 0; k < kMaxRings; k++) if (h.ring_ticks[k]) fprintf(stderr, " %d", h.ring_ticks[k]);
+                                    fprintf(stderr, "\n  ordering ticks per ring:"); for (int k = 0; k < kMaxRings; k++) if (h.order_ticks[k]) fprintf(stderr, " %d", h.order_ticks[k]);
+                                    fprintf(stderr, "\n  slowest segment per ring:"); for (int k = 0; k < kMaxRings; k++) if (h.seg_ticks[k]) fprintf(stderr, " %d", h.seg_ticks[k]); fprintf(stderr, "\n"); }
     if (counts) { counts[0] = h.n_full; counts[1] = h.n_edge; counts[2] = h.n_sharp; counts[3] = h.n_flat; counts[4] = h.n_lessflat; counts[5] = h.n_surf; counts[6] = h.half_idx; counts[7] = h.first_valid; }
     if (ring_start) std::memcpy(ring_start, h.ring_start, sizeof(int) * kMaxRings);
     if (ring_end) std::memcpy(ring_end, h.ring_end, sizeof(int) * kMaxRings);

@@ -81,6 +81,19 @@ def test_rot_extractor_edge_cases(gpu_ctx, oracle):
     _compare(g16, o16)
 
 
+def test_rot_extractor_voxel_keys_beyond_the_packed_range(gpu_ctx, oracle):
+    """The voxel ordering normally comes from rank counting on packed 9 | 11 | 11-bit voxel coordinates (k_rot_scatter / k_rot_segments).  With a
+    5 cm leaf the coordinates of a 150 m scene leave that range: the scan is flagged (RotState::vox_overflow) and the radix ordering over
+    the ring's bounding box takes over in a second pass — same features, same centroids."""
+    raw = _raw_scan(391, seed=5)
+    for ds_v in (0.05, 0.6):
+        ex = L.RotExtractor(gpu_ctx, n_scans=64, ds_rate=2, ds_v=ds_v)
+        g = ex.extract(raw, debug=True)
+        o = oracle.extract_rot(raw, P=oracle.rot_params(ds_rate=2, ds_v=ds_v, atan_mode=2, stable_sort=1))
+        assert len(o["surf"]) > 200
+        _compare(g, o)
+
+
 def test_rot_extractor_rings_beyond_the_lds_working_set(gpu_ctx, oracle):
     """A 16-ring sensor at 0.04 deg azimuth resolution: ~9000 points per ring — more than the 4096-point LDS working set of k_rot_select
     (such rings used to be refused; the reference takes any ring up to its 400 000-point arrays,
