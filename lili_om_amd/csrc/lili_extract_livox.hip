@@ -331,7 +331,7 @@ int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offs
     int rc = lili_ingest_cloud(ctx, scan, B->in_i);
     if (rc != LILI_OK) return rc;
     lili_cloud c2 = *scan; c2.aux_offset = curvature_offset;
-    if (scan->mem == LILI_MEM_HOST) HIPCHK(hipStreamSynchronize(ctx->stream));   // the staging buffer is shared by the two ingests
+    if (scan->mem == LILI_MEM_HOST && scan->n) { c2.data = ctx->staging.p; c2.mem = LILI_MEM_DEVICE; }   // the rows are in the staging buffer already: second view, no second transfer
     rc = lili_ingest_cloud(ctx, &c2, B->in_c);
     if (rc != LILI_OK) return rc;
     const int n = (int)scan->n;
