@@ -139,22 +139,26 @@ __device__ float fd_atan2f(float y, float x) {
 __device__ __forceinline__ float atan_r(float v, int mode) { return mode == 2 ? fd_atanf(v) : (float)atan((double)v); }
 __device__ __forceinline__ float atan2_r(float y, float x, int mode) { return mode == 2 ? fd_atan2f(y, x) : (float)atan2((double)y, (double)x); }
 
-__device__ __forceinline__ dq qslerp_identity(double t, dq b) {   // Eigen 3.3 slerp of Identity towards b
+// Eigen 3.3 slerp of Identity towards b, in two parts: what depends on b alone (the angle and its sine: one acos and one sin, the same for every
+// point of a scan — computed once per workgroup) and what depends on t.
+struct SlerpConst { double theta, sin_theta; int linear; };
+__device__ __forceinline__ SlerpConst qslerp_prepare(dq b) {
     const double one = 1.0 - 2.220446049250313e-16;
-    double d = b.w;
-    double absD = fabs(d);
+    const double absD = fabs(b.w);
+    SlerpConst c{0.0, 1.0, 1};
+    if (!(absD >= one)) { c.theta = acos(absD); c.sin_theta = sin(c.theta); c.linear = 0; }
+    return c;
+}
+__device__ __forceinline__ dq qslerp_identity(double t, dq b, SlerpConst c) {
     double s0, s1;
-    if (absD >= one) { s0 = 1.0 - t; s1 = t; }
+    if (c.linear) { s0 = 1.0 - t; s1 = t; }
     else {
-        double theta = acos(absD);
-        double sinTheta = sin(theta);
-        s0 = sin((1.0 - t) * theta) / sinTheta;
-        s1 = sin(t * theta) / sinTheta;
+        s0 = sin((1.0 - t) * c.theta) / c.sin_theta;
+        s1 = sin(t * c.theta) / c.sin_theta;
     }
-    if (d < 0) s1 = -s1;
+    if (b.w < 0) s1 = -s1;
     return dq{s0 + s1 * b.w, s1 * b.x, s1 * b.y, s1 * b.z};
 }
-
 __device__ __forceinline__ float range2(float4 p) { return p.x * p.x + p.y * p.y + p.z * p.z; }
 __device__ __forceinline__ bool rot_point_ok(float4 p, float thres) {      // R:131-134: finite and not inside the near range
     return isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && !(p.x * p.x + p.y * p.y + p.z * p.z < thres * thres);
@@ -261,7 +265,9 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_scatter(const float4* __restr
     __shared__ int part_pre[kRotBlock / 64][kMaxRings], part_tot[kRotBlock / 64][kMaxRings];
     __shared__ int ring_base[kMaxRings], ring_cnt[kMaxRings], my_base[kMaxRings];
     __shared__ int half_w[kRotBlock / 64];
+    __shared__ SlerpConst slerp_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == kRotBlock - 1) slerp_s = qslerp_prepare(dq{P.q_imu[0], P.q_imu[1], P.q_imu[2], P.q_imu[3]});
     for (int k = threadIdx.x; k < (kRotBlock / 64) * kMaxRings; k += blockDim.x) (&wave_hist[0][0])[k] = 0;
     {
         int pre = 0, tot = 0;
@@ -284,6 +290,7 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_scatter(const float4* __restr
     int half_idx = 0x7fffffff;
     for (int w = 0; w < kRotBlock / 64; w++) half_idx = min(half_idx, half_w[w]);
     const int first_valid = st->first_valid, last_valid = st->last_valid;       // k_rot_classify, workgroup 0
+    const SlerpConst slerp_c = slerp_s;
     if (blockIdx.x == 0) {
         if (threadIdx.x < kMaxRings) {
             const int r = threadIdx.x, bs = ring_base[r], c = ring_cnt[r];
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_scatter(const float4* __restr
     double ratio = dt_i / 0.1;
     if (ratio >= 1.0) ratio = 1.0;
     dq qimu{P.q_imu[0], P.q_imu[1], P.q_imu[2], P.q_imu[3]}, qlb{P.q_lb[0], P.q_lb[1], P.q_lb[2], P.q_lb[3]};
-    dq qs = qslerp_identity(ratio, qimu);
+    dq qs = qslerp_identity(ratio, qimu, slerp_c);
     qs = qmul(qmul(qlb, qs), qinv(qlb));
     d3 r = qrot(qs, d3{(double)p.x, (double)p.y, (double)p.z});
     const float4 o = make_float4((float)r.x, (float)r.y, (float)r.z, intensity);
