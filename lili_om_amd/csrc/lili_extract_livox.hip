@@ -105,11 +105,14 @@ __global__ __launch_bounds__(256) void k_livox_cut(const float4* __restrict__ un
     }
 }
 
-__global__ void k_livox_grid(const int* __restrict__ owner, const float4* __restrict__ und, const float* __restrict__ curv,
-                             float4* __restrict__ cell_pt, float* __restrict__ cell_curv, int* __restrict__ cell_src) {
+// (also re-arms the ownership table for the NEXT scan — every cell is read exactly once, here — and clears n_cut of an empty scan: no init launch per scan)
+__global__ void k_livox_grid(int* __restrict__ owner, const float4* __restrict__ und, const float* __restrict__ curv,
+                             float4* __restrict__ cell_pt, float* __restrict__ cell_curv, int* __restrict__ cell_src, int n, LivoxState* st) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && n == 0) st->n_cut = 0;
     if (c >= kLvCells) return;
     int o = owner[c];
+    owner[c] = 0x7fffffff;
     if (o == 0x7fffffff) { cell_pt[c] = make_float4(0.f, 0.f, 0.f, 0.f); cell_curv[c] = 0.f; cell_src[c] = -1; }
     else { cell_pt[c] = und[o]; cell_curv[c] = curv[o]; cell_src[c] = o; }
 }
@@ -293,6 +296,7 @@ struct LivoxBuffers {
     DevBuf edge_a, edge_b, edge_cell, surf_a, surf_b, surf_cell, pack, pack_e, pack_s, xyzc_edge, xyzc_surf;
     lili::LivoxState host{};
     bool have = false;
+    bool armed = false;      // the ownership table holds "no owner" everywhere (k_livox_init once, k_livox_grid after every scan)
     void release() {
         for (DevBuf* b : {&in_i, &in_c, &und, &curv, &keep, &owner, &state, &cut_a, &cut_b, &cut_src, &cell_pt, &cell_curv, &cell_src, &blk_nedge, &blk_edge_cell,
                           &blk_edge_dir, &blk_nsurf, &blk_surf_cell, &blk_surf_nrm, &edge_a, &edge_b, &edge_cell, &surf_a, &surf_b, &surf_cell, &pack, &xyzc_edge, &xyzc_surf}) b->release();
@@ -348,7 +352,8 @@ int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offs
     LivoxDev P{};
     for (int i = 0; i < 4; i++) P.q_imu[i] = q_imu[i];
     P.surf_thres = params->surf_thres; P.edge_thres = params->edge_thres; P.near_thres = params->near_range;
-    hipLaunchKernelGGL(k_livox_init, dim3(nblocks(kLvCells, 256)), dim3(256), 0, ctx->stream, B->owner.as<int>(), st);
+    if (!B->armed) { hipLaunchKernelGGL(k_livox_init, dim3(nblocks(kLvCells, 256)), dim3(256), 0, ctx->stream, B->owner.as<int>(), st); }   // first scan (or after a failed call) only: k_livox_grid re-arms the table
+    B->armed = false;
     if (n > 0) {
         HIPCHK(B->blk_keep.ensure((size_t)nblocks(n, 256) * 4));
         hipLaunchKernelGGL(k_livox_prep, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, B->in_i.as<float4>(), B->in_c.as<float4>(), n, P, B->und.as<float4>(),
@@ -357,7 +362,8 @@ int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offs
                            B->blk_keep.as<int>(), B->cut_a.as<float4>(), B->cut_b.as<float4>(), B->cut_src.as<int>(), st);
     }
     hipLaunchKernelGGL(k_livox_grid, dim3(nblocks(kLvCells, 256)), dim3(256), 0, ctx->stream, B->owner.as<int>(), B->und.as<float4>(), B->curv.as<float>(),
-                       B->cell_pt.as<float4>(), B->cell_curv.as<float>(), B->cell_src.as<int>());
+                       B->cell_pt.as<float4>(), B->cell_curv.as<float>(), B->cell_src.as<int>(), n, st);
+    B->armed = true;
     hipLaunchKernelGGL(k_livox_blocks, dim3(kLvBlocks), dim3(64), 0, ctx->stream, B->cell_pt.as<float4>(), B->cell_curv.as<float>(), P,
                        B->blk_nedge.as<int>(), B->blk_edge_cell.as<int>(), B->blk_edge_dir.as<float>(), B->blk_nsurf.as<int>(), B->blk_surf_cell.as<int>(),
                        B->blk_surf_nrm.as<float>());
