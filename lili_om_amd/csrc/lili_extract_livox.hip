@@ -269,9 +269,10 @@ __global__ __launch_bounds__(1024) void k_livox_compact(const float4* __restrict
 }
 
 // (x,y,z,nx | ny,nz,intensity,curvature) pairs -> packed 8-float records or pcl::PointXYZINormal (48 B)
-__global__ void k_livox_pack(const float4* __restrict__ a, const float4* __restrict__ b, int n, int pcl_layout, float* __restrict__ out) {
+// (the list length is read on the device — n_dev — so that the three lists are packed BEFORE the host has seen the counts; cap = the caller's capacity)
+__global__ void k_livox_pack(const float4* __restrict__ a, const float4* __restrict__ b, const int* __restrict__ n_dev, int cap, int pcl_layout, float* __restrict__ out) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= min(*n_dev, cap)) return;
     float4 u = a[i], v = b[i];
     if (pcl_layout) {
         float* o = out + (size_t)i * 12;
@@ -309,15 +310,24 @@ static lili_detail::LivoxBuffers* livox_of(lili_ctx* ctx) {
     return static_cast<lili_detail::LivoxBuffers*>(ctx->ext_livox);
 }
 
-static int livox_copy_out(lili_ctx* ctx, DevBuf& pack, const lili_feature_out* o, const float4* a, const float4* b, size_t count) {   // async: one pack buffer per list
-    if (!o || !o->data || count == 0) return LILI_OK;
-    size_t k = std::min(count, o->capacity);
+// Packs one list into the caller's record layout (enqueued before the counts are read back; `bound` = an upper bound of the list length)...
+static int livox_pack(lili_ctx* ctx, DevBuf& pack, const lili_feature_out* o, const float4* a, const float4* b, const int* d_count, size_t bound) {
+    if (!o || !o->data) return LILI_OK;
+    const size_t k = std::min(bound, o->capacity);
     if (k == 0) return LILI_OK;
-    size_t stride = o->stride ? o->stride : 32;
+    const size_t stride = o->stride ? o->stride : 32;
     ARGCHK(stride == 32 || stride == 48, "feature_out: Livox records are 32 B (packed x,y,z,nx,ny,nz,intensity,curvature) or 48 B (pcl::PointXYZINormal)");
     HIPCHK(pack.ensure(k * stride));
-    hipLaunchKernelGGL(k_livox_pack, dim3(nblocks((int64_t)k, 256)), dim3(256), 0, ctx->stream, a, b, (int)k, stride == 48 ? 1 : 0, pack.as<float>());
+    hipLaunchKernelGGL(k_livox_pack, dim3(nblocks((int64_t)k, 256)), dim3(256), 0, ctx->stream, a, b, d_count, (int)k, stride == 48 ? 1 : 0, pack.as<float>());
     HIPCHK(hipGetLastError());
+    return LILI_OK;
+}
+// ... and copies it out once the count is known (async).
+static int livox_copy_out(lili_ctx* ctx, DevBuf& pack, const lili_feature_out* o, size_t count) {
+    if (!o || !o->data || count == 0) return LILI_OK;
+    const size_t k = std::min(count, o->capacity);
+    if (k == 0) return LILI_OK;
+    const size_t stride = o->stride ? o->stride : 32;
     HIPCHK(hipMemcpyAsync(o->data, pack.p, k * stride, o->mem == LILI_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
     return LILI_OK;
 }
@@ -372,11 +382,15 @@ int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offs
                        B->edge_a.as<float4>(), B->edge_b.as<float4>(), B->edge_cell.as<int>(), B->surf_a.as<float4>(), B->surf_b.as<float4>(), B->surf_cell.as<int>(), st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(&B->host, st, sizeof(LivoxState), hipMemcpyDeviceToHost, ctx->stream));
+    // the three lists are packed into the caller's layout while the counts travel
+    rc = livox_pack(ctx, B->pack, cutted, B->cut_a.as<float4>(), B->cut_b.as<float4>(), &st->n_cut, (size_t)n); if (rc) return rc;
+    rc = livox_pack(ctx, B->pack_e, edge, B->edge_a.as<float4>(), B->edge_b.as<float4>(), &st->n_edge, (size_t)kLvCells); if (rc) return rc;
+    rc = livox_pack(ctx, B->pack_s, surf, B->surf_a.as<float4>(), B->surf_b.as<float4>(), &st->n_surf, (size_t)kLvCells); if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     B->have = true;
-    if (cutted) { cutted->count = (size_t)B->host.n_cut; rc = livox_copy_out(ctx, B->pack, cutted, B->cut_a.as<float4>(), B->cut_b.as<float4>(), cutted->count); if (rc) return rc; }
-    if (edge) { edge->count = (size_t)B->host.n_edge; rc = livox_copy_out(ctx, B->pack_e, edge, B->edge_a.as<float4>(), B->edge_b.as<float4>(), edge->count); if (rc) return rc; }
-    if (surf) { surf->count = (size_t)B->host.n_surf; rc = livox_copy_out(ctx, B->pack_s, surf, B->surf_a.as<float4>(), B->surf_b.as<float4>(), surf->count); if (rc) return rc; }
+    if (cutted) { cutted->count = (size_t)B->host.n_cut; rc = livox_copy_out(ctx, B->pack, cutted, cutted->count); if (rc) return rc; }
+    if (edge) { edge->count = (size_t)B->host.n_edge; rc = livox_copy_out(ctx, B->pack_e, edge, edge->count); if (rc) return rc; }
+    if (surf) { surf->count = (size_t)B->host.n_surf; rc = livox_copy_out(ctx, B->pack_s, surf, surf->count); if (rc) return rc; }
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return LILI_OK;
 }
