@@ -114,3 +114,36 @@ def test_rot_extractor_rings_beyond_the_lds_working_set(gpu_ctx, oracle):
         assert (o["ring_end"] - o["ring_start"]).max() > 4096 + 1000          # really beyond the LDS cap
         assert len(o["edge_idx"]) > 20 and len(o["surf"]) > 1000
         _compare(g, o)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_rot_extractor_ragged_scans(gpu_ctx, oracle, seed):
+    """The paths of the five-launch chain that a clean scan does not reach: more than a thousand dropped points at either end of the scan
+    (the first / last surviving point is found in several trips), rings of every length from none to a few dozen points (fewer than six
+    usable points: not selected; fewer than ~75: the reference's serial order through the six segments in k_rot_ring), a scan cut to a
+    random stretch (a ring that starts / ends in the middle of a segment), whole rings inside ONE voxel (a single run of hundreds of
+    points) and points repeated many times (equal curvatures: ties by index; equal voxel keys: runs)."""
+    rng = np.random.default_rng(100 + seed)
+    raw = _raw_scan(391, seed=seed)
+    n = raw.shape[0]
+    kind = seed % 3
+    if kind == 0:          # dropped points at both ends, random NaNs and near points inside
+        a, b = int(rng.integers(1100, 3000)), int(rng.integers(1100, 2500))
+        raw[:a, rng.integers(0, 3)] = np.nan
+        raw[n - b:, :3] *= 0.001
+        raw[rng.integers(0, n, 500), 0] = np.nan
+    elif kind == 1:        # a short stretch of the scan: a few dozen points per ring, some rings empty
+        lo = int(rng.integers(0, n // 2))
+        raw = raw[lo:lo + int(rng.integers(300, 2500))].copy()
+        raw = raw[rng.random(raw.shape[0]) < 0.7]
+    else:                  # dense: the scene shrunk into a few voxels, points repeated
+        raw[:, :3] *= 0.04
+        raw[:, :3] += np.array([3.5, 0.2, 0.1], np.float32)
+        rep = rng.integers(0, n, n // 3)
+        raw[rep] = raw[(rep // 7) * 7 % n]
+    for ds_rate, ds_v in ((1, 0.6), (2, 0.3)):
+        ex = L.RotExtractor(gpu_ctx, n_scans=64, ds_rate=ds_rate, ds_v=ds_v)
+        g = ex.extract(raw, debug=True)
+        o = oracle.extract_rot(raw, P=oracle.rot_params(ds_rate=ds_rate, ds_v=ds_v, atan_mode=2, stable_sort=1))
+        assert o["full"].shape[0] > 100
+        _compare(g, o)
