@@ -97,6 +97,30 @@ static MatchParams to_device_params(const lili_s2m_params* p) {
     return m;
 }
 
+constexpr size_t kPinBytes = 64 * 1024;
+int lili_readback_add(lili_ctx* ctx, void* dst, const void* d_src, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return LILI_OK;
+    hipStream_t s = stream ? stream : ctx->stream;
+    if (!ctx->h_pin) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pin), kPinBytes, hipHostMallocDefault));
+    const size_t off = (ctx->h_pin_used + 15) & ~(size_t)15;
+    if (off + bytes > kPinBytes) {        // (does not happen with the library's own reads; a large one goes the plain way)
+        HIPCHK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, s));
+        return LILI_OK;
+    }
+    HIPCHK(hipMemcpyAsync(ctx->h_pin + off, d_src, bytes, hipMemcpyDeviceToHost, s));
+    ctx->h_pin_items.push_back({dst, off, bytes});
+    ctx->h_pin_used = off + bytes;
+    return LILI_OK;
+}
+int lili_readback_finish(lili_ctx* ctx, hipStream_t stream) {
+    const hipError_t e = hipStreamSynchronize(stream ? stream : ctx->stream);
+    if (e == hipSuccess) for (const auto& it : ctx->h_pin_items) std::memcpy(it.dst, ctx->h_pin + it.off, it.bytes);
+    ctx->h_pin_items.clear();
+    ctx->h_pin_used = 0;
+    HIPCHK(e);
+    return LILI_OK;
+}
+
 // copies / converts a described cloud into a device float4 array (x, y, z, aux)
 int lili_ingest_cloud(lili_ctx* ctx, const lili_cloud* c, DevBuf& out_f4, unsigned* d_bbox) {
     ARGCHK(c && (c->n == 0 || c->data), "cloud: null data");
@@ -169,6 +193,7 @@ void lili_ctx_destroy(lili_ctx* ctx) {
     for (auto& m : ctx->map) { m.sorted_f.release(); m.aux_sorted_f.release(); m.cell_start_f.release(); m.cell_start9.release(); m.cell_start9_f.release(); m.row9.release(); m.pts.release(); m.sorted.release(); m.aux_sorted.release(); m.cell_start.release(); m.cell_tmp.release(); m.pt_cell.release(); m.block_sums.release(); }
     for (auto& s : ctx->slots) for (auto& k : s.k) { k.q.release(); k.rec0.release(); k.rec1.release(); k.valid.release(); k.dbg_idx.release(); k.dbg_d2.release(); k.partials.release(); k.partials_wave.release(); k.perm.release(); k.keys.release(); k.block_counts.release(); k.tiles.release(); }
     if (ctx->h_records) { (void)hipHostFree(ctx->h_records); ctx->h_records = nullptr; }
+    if (ctx->h_pin) { (void)hipHostFree(ctx->h_pin); ctx->h_pin = nullptr; }
     ctx->states.release(); ctx->staging.release(); ctx->gram.release(); ctx->misc.release(); ctx->bin_hist.release(); ctx->bin_start.release(); ctx->bin_sums.release(); ctx->bin_tcnt.release(); ctx->bin_toff.release();
     if (ctx->ext_rot && ctx->ext_rot_free) ctx->ext_rot_free(ctx->ext_rot);
     if (ctx->ext_livox && ctx->ext_livox_free) ctx->ext_livox_free(ctx->ext_livox);
@@ -234,7 +259,8 @@ int lili_set_option(lili_ctx* ctx, const char* name, int value) {
 constexpr size_t kMiscBytes = 2 * 64 * 128 + 256;
 static unsigned* scan_err_word(lili_ctx* ctx) { return reinterpret_cast<unsigned*>(ctx->misc.as<char>() + 2 * 64 * 128); }
 static int build_grid(lili_ctx* ctx, MapIndex& m, const double mn[3], const double mx[3], double cell, int reach, DevBuf& sorted, DevBuf& aux_sorted,
-                      DevBuf& cell_start, DevBuf& cell_start9, GridView& out, int64_t& n_cells, double& cell_used, unsigned long long* d_rank_sum) {
+                      DevBuf& cell_start, DevBuf& cell_start9, GridView& out, int64_t& n_cells, double& cell_used, unsigned long long* d_rank_sum,
+                      const void* zeroed_p = nullptr, size_t zeroed_bytes = 0 /* the caller already cleared this much of cell_start (while the bounding box travelled) */) {
     const int n = (int)m.n;
     int64_t nx, ny, nz;
     for (;;) {
@@ -275,7 +301,7 @@ static int build_grid(lili_ctx* ctx, MapIndex& m, const double mn[3], const doub
     if (srows) { HIPCHK(cell_start9.ensure((size_t)(nc9 + 2) * sizeof(int))); HIPCHK(m.row9.ensure((size_t)(rows9 + 2) * sizeof(int))); }
     const int nb_scan = nblocks(nc, 2048);
     HIPCHK(m.block_sums.ensure((size_t)(nb_scan + 2) * sizeof(unsigned long long)));
-    HIPCHK(hipMemsetAsync(cell_start.p, 0, (size_t)nc * sizeof(int), ctx->stream));
+    if (!(cell_start.p == zeroed_p && (size_t)nc * sizeof(int) <= zeroed_bytes)) HIPCHK(hipMemsetAsync(cell_start.p, 0, (size_t)nc * sizeof(int), ctx->stream));
     hipLaunchKernelGGL(k_cell_count, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, m.pts.as<float4>(), n, g, cell_start.as<int>(), m.pt_cell.as<int2>(), d_rank_sum);
     if (ctx->scan_lookback) {      // one pass over the cell array (status words: one per 16384-cell tile)
         const int nb_lb = nblocks(nc, 16384);
@@ -332,8 +358,12 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
     if (m.n == 0) { m.valid = true; return LILI_OK; }
     const int n = (int)m.n;
     unsigned banks[64 * 32], mm[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
-    HIPCHK(hipMemcpyAsync(banks, d_mm, sizeof(banks), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    // the cell table of the previous build is cleared NOW, while the bounding box travels to the host and the GPU has nothing else to do (its size is only
+    // known afterwards; a table that has to grow is cleared again in build_grid)
+    const void* zeroed_p = m.cell_start.p;
+    const size_t zeroed_bytes = m.cell_start.p ? m.cell_start.cap : 0;
+    if (zeroed_bytes) HIPCHK(hipMemsetAsync(m.cell_start.p, 0, zeroed_bytes, ctx->stream));
+    { int rb = lili_readback_add(ctx, banks, d_mm, sizeof(banks)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }
     for (int b = 0; b < 64; b++) for (int k = 0; k < 3; k++) { mm[k] = std::min(mm[k], banks[b * 32 + k]); mm[3 + k] = std::max(mm[3 + k], banks[b * 32 + 3 + k]); }
     auto dec = [](unsigned u) { unsigned b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u; float f; std::memcpy(&f, &b, 4); return f; };
     double mn[3], mx[3];
@@ -351,14 +381,13 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
     if (d_rank) HIPCHK(hipMemsetAsync(d_rank, 0, kRankBytes, ctx->stream));
     unsigned scan_err = 0;
     bool err_read = false;
-    rc = build_grid(ctx, m, mn, mx, cell, reach, m.sorted, m.aux_sorted, m.cell_start, m.cell_start9, m.view, m.n_cells, m.cell, d_rank);
+    rc = build_grid(ctx, m, mn, mx, cell, reach, m.sorted, m.aux_sorted, m.cell_start, m.cell_start9, m.view, m.n_cells, m.cell, d_rank, zeroed_p, zeroed_bytes);
     if (rc != LILI_OK) return rc;
     // Density adaptation (SURVEY §7 step 4, §8d Config 2 variant B): the point-weighted mean cell occupancy falls out of the count pass.
     // A map with many points per gate-sized cell gets a second, fine index whose cells hold ~3 points; k_associate_fine searches it first.
     if (d_rank) {
         unsigned long long banks[kRankBanks * 16 + 1], rank_sum = 0;      // + the sticky error word of the look-back scans, which follows the banks
-        HIPCHK(hipMemcpyAsync(banks, d_rank, kRankBytes + sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        { int rb = lili_readback_add(ctx, banks, d_rank, kRankBytes + sizeof(unsigned long long)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }
         scan_err = (unsigned)banks[kRankBanks * 16];
         err_read = true;
         for (size_t b = 0; b < kRankBanks; b++) rank_sum += banks[b * 16];
@@ -384,8 +413,7 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
     // no inter-workgroup dependency.
     if (ctx->scan_lookback) {
         if (!err_read) {
-            HIPCHK(hipMemcpyAsync(&scan_err, scan_err_word(ctx), sizeof(scan_err), hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(hipStreamSynchronize(ctx->stream));
+            { int rb = lili_readback_add(ctx, &scan_err, scan_err_word(ctx), sizeof(scan_err)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }
         }
         if (scan_err) {
             ctx->scan_lookback = false;
@@ -1233,8 +1261,7 @@ int lili_s2m_pose_get(lili_ctx* ctx, int slot, double t[3], double q[4], int* gn
     ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS, "pose_get: bad slot");
     HIPCHK(hipSetDevice(ctx->device));
     SlotState s{};
-    HIPCHK(hipMemcpyAsync(&s, ctx->state(slot), sizeof(s), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    { int rb = lili_readback_add(ctx, &s, ctx->state(slot), sizeof(s)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }
     if (t) for (int i = 0; i < 3; i++) t[i] = s.pose[i];
     if (q) for (int i = 0; i < 4; i++) q[i] = s.pose[3 + i];
     if (gn_status) *gn_status = s.gn_status;
@@ -1249,8 +1276,7 @@ int lili_s2m_last_step(lili_ctx* ctx, int slot, double delta[6], int* n_updates,
     ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS, "last_step: bad slot");
     HIPCHK(hipSetDevice(ctx->device));
     SlotState s{};
-    HIPCHK(hipMemcpyAsync(&s, ctx->state(slot), sizeof(s), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    { int rb = lili_readback_add(ctx, &s, ctx->state(slot), sizeof(s)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }
     if (delta) for (int i = 0; i < 6; i++) delta[i] = s.last_delta[i];
     if (n_updates) *n_updates = s.iters;
     if (gn_status) *gn_status = s.gn_status;
@@ -1263,8 +1289,7 @@ int lili_s2m_debug_times(lili_ctx* ctx, int slot, long long out[16]) {
     ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS && out, "debug_times: bad argument");
     HIPCHK(hipSetDevice(ctx->device));
     SlotState s{};
-    HIPCHK(hipMemcpyAsync(&s, ctx->state(slot), sizeof(s), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    { int rb = lili_readback_add(ctx, &s, ctx->state(slot), sizeof(s)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }
     for (int i = 0; i < 16; i++) out[i] = s.tprof[i];
     return LILI_OK;
 }

@@ -117,6 +117,12 @@ struct lili_ctx {
     DevBuf fmt_out;      // lili_livox_custom_to_cloud output when the caller wants it on the host
     DevBuf gram;         // LILI_GRAM_DOUBLES per slot
     DevBuf misc;         // bbox words etc.
+    // Small device-to-host reads (counts, boxes, states) land in a page-locked scratch and are copied out after the synchronisation: a D2H into
+    // pageable memory is staged by the runtime and blocks, which costs ~10 us more per read (64 KB; lili_readback_* in lili_api.hip).
+    unsigned char* h_pin = nullptr;
+    size_t h_pin_used = 0;
+    struct PinItem { void* dst; size_t off, bytes; };
+    std::vector<PinItem> h_pin_items;
     double* h_records = nullptr;   // page-locked landing area for LILI_MAX_SLOTS Gram records (lili_s2m_linearize_window: copies that do not block the host)
     DevBuf bin_hist, bin_start, bin_sums, bin_tcnt, bin_toff;   // query binning scratch
     bool bin_queries = false;   // trust the caller's order (extractor output is ring-/voxel-ordered, i.e. coherent)
@@ -171,6 +177,10 @@ struct lili_ctx {
 
 static inline int nblocks(int64_t n, int per) { return (int)((n + per - 1) / per); }
 
+// enqueue a small read of device memory on `stream` (default: the context's) into the page-locked scratch; lili_readback_finish synchronises that stream and
+// copies every pending item to its destination.  One thread per context, items of one stream per finish.
+int lili_readback_add(lili_ctx* ctx, void* dst, const void* d_src, size_t bytes, hipStream_t stream = nullptr);
+int lili_readback_finish(lili_ctx* ctx, hipStream_t stream = nullptr);
 int lili_ingest_cloud(lili_ctx* ctx, const lili_cloud* c, lili_detail::DevBuf& out_f4, unsigned* d_bbox = nullptr);   // d_bbox: also reduce the bounding box (6 ordered-uint words, initialised by the caller)
 // lili_p2p.hip: the view of the NEXT exchange of a communicator (advances its sequence number); usable = connected and on this context
 lili::P2PView lili_p2p_next_view(lili_p2p* c);

@@ -381,12 +381,12 @@ int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offs
                        B->blk_edge_cell.as<int>(), B->blk_edge_dir.as<float>(), B->blk_nsurf.as<int>(), B->blk_surf_cell.as<int>(), B->blk_surf_nrm.as<float>(),
                        B->edge_a.as<float4>(), B->edge_b.as<float4>(), B->edge_cell.as<int>(), B->surf_a.as<float4>(), B->surf_b.as<float4>(), B->surf_cell.as<int>(), st);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(&B->host, st, sizeof(LivoxState), hipMemcpyDeviceToHost, ctx->stream));
+    rc = lili_readback_add(ctx, &B->host, st, sizeof(LivoxState)); if (rc) return rc;
     // the three lists are packed into the caller's layout while the counts travel
-    rc = livox_pack(ctx, B->pack, cutted, B->cut_a.as<float4>(), B->cut_b.as<float4>(), &st->n_cut, (size_t)n); if (rc) return rc;
-    rc = livox_pack(ctx, B->pack_e, edge, B->edge_a.as<float4>(), B->edge_b.as<float4>(), &st->n_edge, (size_t)kLvCells); if (rc) return rc;
-    rc = livox_pack(ctx, B->pack_s, surf, B->surf_a.as<float4>(), B->surf_b.as<float4>(), &st->n_surf, (size_t)kLvCells); if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    rc = livox_pack(ctx, B->pack, cutted, B->cut_a.as<float4>(), B->cut_b.as<float4>(), &st->n_cut, (size_t)n);
+    if (rc == LILI_OK) rc = livox_pack(ctx, B->pack_e, edge, B->edge_a.as<float4>(), B->edge_b.as<float4>(), &st->n_edge, (size_t)kLvCells);
+    if (rc == LILI_OK) rc = livox_pack(ctx, B->pack_s, surf, B->surf_a.as<float4>(), B->surf_b.as<float4>(), &st->n_surf, (size_t)kLvCells);
+    { const int rb = lili_readback_finish(ctx); if (rc) return rc; if (rb) return rb; }      // (the pending read is always finished)
     B->have = true;
     if (cutted) { cutted->count = (size_t)B->host.n_cut; rc = livox_copy_out(ctx, B->pack, cutted, cutted->count); if (rc) return rc; }
     if (edge) { edge->count = (size_t)B->host.n_edge; rc = livox_copy_out(ctx, B->pack_e, edge, edge->count); if (rc) return rc; }

@@ -1438,8 +1438,7 @@ int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4
                            R->edge_pts.as<float4>(), R->sharp_idx.as<int>(), R->flat_idx.as<int>(), R->lessflat_idx.as<int>(), R->surf.as<float4>(), R->surf_cnt.as<int>());
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipMemcpyAsync(&R->host, st, sizeof(RotState), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    { int rb = lili_readback_add(ctx, &R->host, st, sizeof(RotState)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }
     if (n == 0) { R->host.first_valid = R->host.half_idx = 0x7fffffff; R->host.last_valid = -1; }
     if (n > 0 && R->host.vox_overflow) {   // voxel coordinates beyond the packed keys: order by the radix pass, then the ring stage and the concatenation again
         RotDev P{};
@@ -1453,8 +1452,7 @@ int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4
                            R->ring_flat.as<int>(), R->lessflat_tmp.as<int>(), R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>(), R->edge_idx.as<int>(),
                            R->edge_pts.as<float4>(), R->sharp_idx.as<int>(), R->flat_idx.as<int>(), R->lessflat_idx.as<int>(), R->surf.as<float4>(), R->surf_cnt.as<int>());
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(&R->host, st, sizeof(RotState), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        { int rb = lili_readback_add(ctx, &R->host, st, sizeof(RotState)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }
     }
     if (R->host.fallback_rings > 0) {      // rings beyond the LDS working set: second pass with global-memory arrays, then the concatenation again
         const size_t cap = (size_t)std::max(n, 1);
@@ -1480,8 +1478,7 @@ int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4
                            R->ring_flat.as<int>(), R->lessflat_tmp.as<int>(), R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>(), R->edge_idx.as<int>(),
                            R->edge_pts.as<float4>(), R->sharp_idx.as<int>(), R->flat_idx.as<int>(), R->lessflat_idx.as<int>(), R->surf.as<float4>(), R->surf_cnt.as<int>());
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(&R->host, st, sizeof(RotState), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        { int rb = lili_readback_add(ctx, &R->host, st, sizeof(RotState)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }
     }
     R->have = true;
     if (full) {

@@ -461,8 +461,7 @@ static int voxel_sort(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const float4*
     HIPCHK(hipMemcpyAsync(d_mm, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_bbox, dim3(std::min(nblocks(n, kBlock), 512)), dim3(kBlock), 0, ctx->stream, d_pts, n, d_mm);
     unsigned mm[6];
-    HIPCHK(hipMemcpyAsync(mm, d_mm, sizeof(mm), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    { int rb = lili_readback_add(ctx, mm, d_mm, sizeof(mm)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }
     auto dec = [](unsigned u) { unsigned b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u; float f; std::memcpy(&f, &b, 4); return f; };
     P = VoxDev{};
     P.inv_leaf = 1.0f / leaf;
@@ -498,8 +497,7 @@ static int voxel_filter_device(lili_ctx* ctx, lili_detail::VoxelBuffers* V, cons
     hipLaunchKernelGGL(k_vox_centroid, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, V->keys_a.as<unsigned>(), V->vals_a.as<int>(), V->slots.as<int>(), d_pts, n, P.sentinel,
                        V->out.as<float4>(), V->out_cnt.as<int>());
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(&V->n_out, V->slots.as<int>() + n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    { int rb = lili_readback_add(ctx, &V->n_out, V->slots.as<int>() + n, sizeof(int)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }
     return LILI_OK;
 }
 
@@ -662,10 +660,10 @@ int lili_localmap_commit(lili_ctx* ctx, int kind, float leaf, double max_sq_radi
             hipLaunchKernelGGL(k_vox_centroid64, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, S.key[S.cur].as<unsigned long long>(), S.pt[S.cur].as<float4>(), V->head_pos.as<int>(),
                                (const int*)(V->slots.as<int>() + n), n, V->out.as<float4>(), V->out_cnt.as<int>());
             HIPCHK(hipGetLastError());
-            HIPCHK(hipMemcpyAsync(&V->n_out, V->slots.as<int>() + n, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            rc = lili_readback_add(ctx, &V->n_out, V->slots.as<int>() + n, sizeof(int));
         }
-        HIPCHK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (rc == LILI_OK) rc = lili_readback_add(ctx, &bad, d_bad, 4);
+        { const int rb = lili_readback_finish(ctx); if (rc != LILI_OK) return rc; if (rb != LILI_OK) return rb; }
         if (bad) { S.valid = false; inc = false; }      // a point beyond the absolute key range: the box-relative rebuild below handles it
         else V->incremental_commits++;
     }
@@ -701,8 +699,7 @@ int lili_localmap_commit(lili_ctx* ctx, int kind, float leaf, double max_sq_radi
                                S.seq[0].as<unsigned>(), d_bad);
             HIPCHK(hipGetLastError());
             unsigned bad = 0;
-            HIPCHK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(hipStreamSynchronize(ctx->stream));
+            { int rb = lili_readback_add(ctx, &bad, d_bad, 4); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }
             S.cur = 0; S.n = (long long)total; S.leaf = leaf; S.valid = bad == 0;
             S.members.clear();
             for (auto* k : ring) S.members.push_back({k->seq, k->n});
