@@ -585,8 +585,7 @@ static int bin_queries(lili_ctx* ctx, KindSlot& ks, MapIndex& m, const PoseArg& 
     hipLaunchKernelGGL(k_scan_apply, dim3(nb_scan), dim3(kBlock), 0, ctx->stream, ctx->bin_tcnt.as<int>(), (int64_t)n_bins, ctx->bin_sums.as<int>(), ctx->bin_toff.as<int>());
     HIPCHK(hipGetLastError());
     int n_tiles = 0;
-    HIPCHK(hipMemcpyAsync(&n_tiles, ctx->bin_toff.as<int>() + n_bins, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));   // once per scan
+    { int rb = lili_readback_add(ctx, &n_tiles, ctx->bin_toff.as<int>() + n_bins, sizeof(int)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }   // once per scan
     if (n_tiles <= 0 || n_tiles > n) return ctx->fail(LILI_E_HIP, "bin_queries: inconsistent tile count");
     HIPCHK(ks.tiles.ensure((size_t)n_tiles * sizeof(int2)));
     HIPCHK(ks.block_counts.ensure((size_t)std::max(n_tiles, ks.n_blocks) * sizeof(int)));
@@ -1015,8 +1014,9 @@ int lili_s2m_associate(lili_ctx* ctx, int slot, int kind, const double t_assoc[3
     if (n_res) {
         rc = launch_sum_counts(ctx, slot, 1 << kind);
         if (rc != LILI_OK) return rc;
-        HIPCHK(hipMemcpyAsync(n_res, &ctx->state(slot)->n_res[kind], sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        rc = lili_readback_add(ctx, n_res, &ctx->state(slot)->n_res[kind], sizeof(int));
+        if (rc == LILI_OK) rc = lili_readback_finish(ctx);
+        if (rc != LILI_OK) return rc;
     }
     return LILI_OK;
 }
@@ -1148,8 +1148,9 @@ int lili_s2m_linearize(lili_ctx* ctx, int slot, int kind_mask, const double t[3]
     int rc = launch_linearize_reduce(ctx, slot, kind_mask, pa, P, ctx->gram_of(slot), 0);
     if (rc != LILI_OK) return rc;
     double host[LILI_GRAM_DOUBLES];
-    HIPCHK(hipMemcpyAsync(host, ctx->gram_of(slot), sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    rc = lili_readback_add(ctx, host, ctx->gram_of(slot), sizeof(host));
+    if (rc == LILI_OK) rc = lili_readback_finish(ctx);
+    if (rc != LILI_OK) return rc;
     std::memcpy(gram, host, 64 * sizeof(double));
     if (cost) *cost = host[64];
     if (counts) { counts[0] = (int)host[65]; counts[1] = (int)host[66]; }
@@ -1443,8 +1444,9 @@ int lili_s2m_solve_lm(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_par
     int rc = launch_solve_lm(ctx, slot, kind_mask, params, options, max_blocks);
     if (rc != LILI_OK) return rc;
     if (summary) {
-        HIPCHK(hipMemcpyAsync(summary, ctx->slots[slot].lm_summary.p, sizeof(lili_lm_summary), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        rc = lili_readback_add(ctx, summary, ctx->slots[slot].lm_summary.p, sizeof(lili_lm_summary));
+        if (rc == LILI_OK) rc = lili_readback_finish(ctx);
+        if (rc != LILI_OK) return rc;
     }
     return LILI_OK;
 }
@@ -1473,16 +1475,16 @@ int lili_s2m_solve_lm_window(lili_ctx* ctx, const int* slots, int n_slots, int k
         }
         rc = launch_solve_lm(ctx, slots[i], kind_mask, params, options, max_blocks);
         hipError_t e = hipSuccess;
-        if (rc == LILI_OK && summaries) e = hipMemcpyAsync(summaries + i, ctx->slots[slots[i]].lm_summary.p, sizeof(lili_lm_summary), hipMemcpyDeviceToHost, ctx->stream);
+        if (rc == LILI_OK && summaries && lili_readback_add(ctx, summaries + i, ctx->slots[slots[i]].lm_summary.p, sizeof(lili_lm_summary), ctx->stream) != LILI_OK) e = hipErrorUnknown;
         if (i > 0) {
             if (e == hipSuccess) e = hipEventRecord(ctx->join_ev[i], ctx->side[i]);
             ctx->stream = main_stream;
             if (e == hipSuccess) e = hipStreamWaitEvent(main_stream, ctx->join_ev[i], 0);
         }
-        if (e != hipSuccess) { ctx->stream = main_stream; return ctx->fail(LILI_E_HIP, std::string("solve_lm_window: ") + hipGetErrorString(e)); }
+        if (e != hipSuccess) { ctx->stream = main_stream; (void)lili_readback_finish(ctx); return ctx->fail(LILI_E_HIP, std::string("solve_lm_window: ") + hipGetErrorString(e)); }
     }
     ctx->stream = main_stream;
-    if (summaries || rc != LILI_OK) HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (summaries || rc != LILI_OK) { const int rb = lili_readback_finish(ctx); if (rc == LILI_OK) rc = rb; }      // (the side streams were joined into this one)
     return rc;
 }
 
