@@ -36,13 +36,20 @@ __global__ void k_livox_init(int* __restrict__ owner, LivoxState* st) {
     if (i == 0) { st->n_cut = 0; st->n_edge = 0; st->n_surf = 0; }
 }
 
-__global__ __launch_bounds__(256) void k_livox_prep(const float4* __restrict__ in_i /*x,y,z,intensity*/, const float4* __restrict__ in_c /*x,y,z,curvature*/, int n,
+// (reads the caller's rows as they are — x, y, z at the start, intensity and curvature at their byte offsets — : no layout conversion launches in front)
+__global__ __launch_bounds__(256) void k_livox_prep(const unsigned char* __restrict__ raw, int stride, int off_intensity, int off_curvature, int n,
                                                     LivoxDev P, float4* __restrict__ und, float* __restrict__ curv, unsigned char* __restrict__ keep,
                                                     int* __restrict__ owner, int* __restrict__ blk_keep /*[gridDim.x]: kept points of this block (for k_livox_cut)*/) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < n;
-    float4 p = live ? in_i[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    float c = live ? in_c[i].w : 0.f;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    float c = 0.f;
+    if (live) {
+        const unsigned char* row = raw + (size_t)i * (size_t)stride;
+        const float* xyz = reinterpret_cast<const float*>(row);
+        p = make_float4(xyz[0], xyz[1], xyz[2], *reinterpret_cast<const float*>(row + off_intensity));
+        c = *reinterpret_cast<const float*>(row + off_curvature);
+    }
     bool ok = live && isfinite(p.x) && isfinite(p.y) && isfinite(p.z) && !(p.x * p.x + p.y * p.y + p.z * p.z < P.near_thres * P.near_thres);   // L:225-226
     int scan_id = (int)p.w;                                                                                                          // L:252
     ok = ok && scan_id >= 0 && scan_id < kLvLines;   // lines >= 6 would index mat[] out of bounds in the reference
@@ -292,14 +299,14 @@ __global__ void k_livox_xyzc(const float4* __restrict__ a, const float4* __restr
 
 namespace lili_detail {
 struct LivoxBuffers {
-    DevBuf in_i, in_c, und, curv, keep, owner, state, cut_a, cut_b, cut_src, cell_pt, cell_curv, cell_src, blk_keep;
+    DevBuf und, curv, keep, owner, state, cut_a, cut_b, cut_src, cell_pt, cell_curv, cell_src, blk_keep;
     DevBuf blk_nedge, blk_edge_cell, blk_edge_dir, blk_nsurf, blk_surf_cell, blk_surf_nrm;
     DevBuf edge_a, edge_b, edge_cell, surf_a, surf_b, surf_cell, pack, pack_e, pack_s, xyzc_edge, xyzc_surf;
     lili::LivoxState host{};
     bool have = false;
     bool armed = false;      // the ownership table holds "no owner" everywhere (k_livox_init once, k_livox_grid after every scan)
     void release() {
-        for (DevBuf* b : {&in_i, &in_c, &und, &curv, &keep, &owner, &state, &cut_a, &cut_b, &cut_src, &cell_pt, &cell_curv, &cell_src, &blk_nedge, &blk_edge_cell,
+        for (DevBuf* b : {&und, &curv, &keep, &owner, &state, &cut_a, &cut_b, &cut_src, &cell_pt, &cell_curv, &cell_src, &blk_nedge, &blk_edge_cell,
                           &blk_edge_dir, &blk_nsurf, &blk_surf_cell, &blk_surf_nrm, &edge_a, &edge_b, &edge_cell, &surf_a, &surf_b, &surf_cell, &pack, &xyzc_edge, &xyzc_surf}) b->release();
     }
 };
@@ -342,13 +349,18 @@ int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offs
     HIPCHK(hipSetDevice(ctx->device));
     auto* B = livox_of(ctx);
     B->have = false;
-    int rc = lili_ingest_cloud(ctx, scan, B->in_i);
-    if (rc != LILI_OK) return rc;
-    lili_cloud c2 = *scan; c2.aux_offset = curvature_offset;
-    if (scan->mem == LILI_MEM_HOST && scan->n) { c2.data = ctx->staging.p; c2.mem = LILI_MEM_DEVICE; }   // the rows are in the staging buffer already: second view, no second transfer
-    rc = lili_ingest_cloud(ctx, &c2, B->in_c);
-    if (rc != LILI_OK) return rc;
+    ARGCHK(scan->n == 0 || scan->data, "cloud: null data");
+    ARGCHK(scan->stride >= 12 && scan->stride % 4 == 0 && (size_t)scan->aux_offset + 4 <= scan->stride, "cloud: stride must be a multiple of 4 and >= 12, offsets inside the point");
+    ARGCHK(scan->n < (size_t)1 << 31, "cloud: too many points");
+    ARGCHK(scan->mem == LILI_MEM_HOST || scan->mem == LILI_MEM_DEVICE, "cloud: bad mem");
+    int rc = LILI_OK;
     const int n = (int)scan->n;
+    const unsigned char* raw = static_cast<const unsigned char*>(scan->data);
+    if (scan->mem == LILI_MEM_HOST && n > 0) {       // ONE transfer of the rows as they are; k_livox_prep picks the fields
+        HIPCHK(ctx->staging.ensure(scan->n * scan->stride));
+        HIPCHK(hipMemcpyAsync(ctx->staging.p, scan->data, scan->n * scan->stride, hipMemcpyHostToDevice, ctx->stream));
+        raw = ctx->staging.as<unsigned char>();
+    }
     HIPCHK(B->state.ensure(sizeof(LivoxState))); HIPCHK(B->owner.ensure(kLvCells * 4));
     HIPCHK(B->cell_pt.ensure(kLvCells * 16)); HIPCHK(B->cell_curv.ensure(kLvCells * 4)); HIPCHK(B->cell_src.ensure(kLvCells * 4));
     HIPCHK(B->blk_nedge.ensure(kLvBlocks * 4)); HIPCHK(B->blk_edge_cell.ensure(kLvBlocks * kLvLines * 4)); HIPCHK(B->blk_edge_dir.ensure(kLvBlocks * 12));
@@ -366,7 +378,7 @@ int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offs
     B->armed = false;
     if (n > 0) {
         HIPCHK(B->blk_keep.ensure((size_t)nblocks(n, 256) * 4));
-        hipLaunchKernelGGL(k_livox_prep, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, B->in_i.as<float4>(), B->in_c.as<float4>(), n, P, B->und.as<float4>(),
+        hipLaunchKernelGGL(k_livox_prep, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, raw, (int)scan->stride, (int)scan->aux_offset, curvature_offset, n, P, B->und.as<float4>(),
                            B->curv.as<float>(), B->keep.as<unsigned char>(), B->owner.as<int>(), B->blk_keep.as<int>());
         hipLaunchKernelGGL(k_livox_cut, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, B->und.as<float4>(), B->curv.as<float>(), B->keep.as<unsigned char>(), n,
                            B->blk_keep.as<int>(), B->cut_a.as<float4>(), B->cut_b.as<float4>(), B->cut_src.as<int>(), st);
