@@ -383,6 +383,21 @@ int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offs
         hipLaunchKernelGGL(k_livox_cut, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, B->und.as<float4>(), B->curv.as<float>(), B->keep.as<unsigned char>(), n,
                            B->blk_keep.as<int>(), B->cut_a.as<float4>(), B->cut_b.as<float4>(), B->cut_src.as<int>(), st);
     }
+    // lidar_cloud_cutted is final here: it is packed now and travels to the host on a side stream under the grid / block / compaction kernels (768 KB for
+    // a 24 k-point scan).  All min(n, capacity) records travel — the count is known only at the end; records behind `count` are unspecified.
+    bool cut_early = false;
+    if (n > 0 && cutted && cutted->data && cutted->mem == LILI_MEM_HOST && cutted->capacity > 0) {
+        rc = livox_pack(ctx, B->pack, cutted, B->cut_a.as<float4>(), B->cut_b.as<float4>(), &st->n_cut, (size_t)n);
+        if (rc != LILI_OK) return rc;
+        if (!ctx->fork_ev) HIPCHK(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
+        if (!ctx->side[1]) HIPCHK(hipStreamCreateWithFlags(&ctx->side[1], hipStreamNonBlocking));
+        if (!ctx->join_ev[1]) HIPCHK(hipEventCreateWithFlags(&ctx->join_ev[1], hipEventDisableTiming));
+        HIPCHK(hipEventRecord(ctx->fork_ev, ctx->stream));
+        HIPCHK(hipStreamWaitEvent(ctx->side[1], ctx->fork_ev, 0));
+        HIPCHK(hipMemcpyAsync(cutted->data, B->pack.p, std::min((size_t)n, cutted->capacity) * (cutted->stride ? cutted->stride : 32), hipMemcpyDeviceToHost, ctx->side[1]));
+        HIPCHK(hipEventRecord(ctx->join_ev[1], ctx->side[1]));
+        cut_early = true;
+    }
     hipLaunchKernelGGL(k_livox_grid, dim3(nblocks(kLvCells, 256)), dim3(256), 0, ctx->stream, B->owner.as<int>(), B->und.as<float4>(), B->curv.as<float>(),
                        B->cell_pt.as<float4>(), B->cell_curv.as<float>(), B->cell_src.as<int>(), n, st);
     B->armed = true;
@@ -395,12 +410,16 @@ int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offs
     HIPCHK(hipGetLastError());
     rc = lili_readback_add(ctx, &B->host, st, sizeof(LivoxState)); if (rc) return rc;
     // the three lists are packed into the caller's layout while the counts travel
-    rc = livox_pack(ctx, B->pack, cutted, B->cut_a.as<float4>(), B->cut_b.as<float4>(), &st->n_cut, (size_t)n);
+    if (!cut_early) rc = livox_pack(ctx, B->pack, cutted, B->cut_a.as<float4>(), B->cut_b.as<float4>(), &st->n_cut, (size_t)n);
     if (rc == LILI_OK) rc = livox_pack(ctx, B->pack_e, edge, B->edge_a.as<float4>(), B->edge_b.as<float4>(), &st->n_edge, (size_t)kLvCells);
     if (rc == LILI_OK) rc = livox_pack(ctx, B->pack_s, surf, B->surf_a.as<float4>(), B->surf_b.as<float4>(), &st->n_surf, (size_t)kLvCells);
     { const int rb = lili_readback_finish(ctx); if (rc) return rc; if (rb) return rb; }      // (the pending read is always finished)
     B->have = true;
-    if (cutted) { cutted->count = (size_t)B->host.n_cut; rc = livox_copy_out(ctx, B->pack, cutted, cutted->count); if (rc) return rc; }
+    if (cutted) {
+        cutted->count = (size_t)B->host.n_cut;
+        if (cut_early) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->join_ev[1], 0));
+        else { rc = livox_copy_out(ctx, B->pack, cutted, cutted->count); if (rc) return rc; }
+    }
     if (edge) { edge->count = (size_t)B->host.n_edge; rc = livox_copy_out(ctx, B->pack_e, edge, edge->count); if (rc) return rc; }
     if (surf) { surf->count = (size_t)B->host.n_surf; rc = livox_copy_out(ctx, B->pack_s, surf, surf->count); if (rc) return rc; }
     HIPCHK(hipStreamSynchronize(ctx->stream));
