@@ -77,25 +77,25 @@ __global__ __launch_bounds__(256) void k_livox_prep(const unsigned char* __restr
 // ordered compaction: cutted[rank] = deskewed point, cut_src[rank] = i.  Same grid as k_livox_prep (256 points per workgroup), which
 // left the number of kept points per workgroup: every workgroup adds up the counts in front of it and ranks its own 256 points —
 // no serial pass over the scan (round 1: ONE workgroup, 24 rounds of two barriers, 30 us).
-__global__ __launch_bounds__(256) void k_livox_cut(const float4* __restrict__ und, const float* __restrict__ curv, const unsigned char* __restrict__ keep, int n,
-                                                   const int* __restrict__ blk_keep, float4* __restrict__ cut_a, float4* __restrict__ cut_b, int* __restrict__ cut_src, LivoxState* st) {
+__device__ void livox_cut_block(int block, int n_blocks, const float4* __restrict__ und, const float* __restrict__ curv, const unsigned char* __restrict__ keep, int n,
+                                const int* __restrict__ blk_keep, float4* __restrict__ cut_a, float4* __restrict__ cut_b, int* __restrict__ cut_src, LivoxState* st) {
     __shared__ int ws[5];
     __shared__ int s_base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int before = 0, total = 0;
-    for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) { const int cnt = blk_keep[b]; total += cnt; if (b < (int)blockIdx.x) before += cnt; }
+    for (int b = threadIdx.x; b < n_blocks; b += 256) { const int cnt = blk_keep[b]; total += cnt; if (b < block) before += cnt; }
     for (int o = 32; o > 0; o >>= 1) { before += __shfl_xor(before, o); total += __shfl_xor(total, o); }
     if (lane == 0) { ws[wave] = before; }
     __syncthreads();
     if (threadIdx.x == 0) s_base = ws[0] + ws[1] + ws[2] + ws[3];
     __syncthreads();
-    if (blockIdx.x == 0) {      // n_cut: the grand total
+    if (block == 0) {      // n_cut: the grand total
         if (lane == 0) ws[wave] = total;
         __syncthreads();
         if (threadIdx.x == 0) st->n_cut = ws[0] + ws[1] + ws[2] + ws[3];
         __syncthreads();
     }
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = block * 256 + threadIdx.x;
     const int f = i < n ? (int)keep[i] : 0;
     int inc = f;
     for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
@@ -113,9 +113,13 @@ __global__ __launch_bounds__(256) void k_livox_cut(const float4* __restrict__ un
 }
 
 // (also re-arms the ownership table for the NEXT scan — every cell is read exactly once, here — and clears n_cut of an empty scan: no init launch per scan)
-__global__ void k_livox_grid(int* __restrict__ owner, const float4* __restrict__ und, const float* __restrict__ curv,
-                             float4* __restrict__ cell_pt, float* __restrict__ cell_curv, int* __restrict__ cell_src, int n, LivoxState* st) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
+// ONE launch for the ordered cut (workgroups [0, n_cut_blocks)) and the grid (the workgroups behind them): both only need k_livox_prep's products.
+__global__ __launch_bounds__(256) void k_livox_cut_grid(int n_cut_blocks, int* __restrict__ owner, const float4* __restrict__ und, const float* __restrict__ curv,
+                                                        const unsigned char* __restrict__ keep, const int* __restrict__ blk_keep, float4* __restrict__ cut_a,
+                                                        float4* __restrict__ cut_b, int* __restrict__ cut_src,
+                                                        float4* __restrict__ cell_pt, float* __restrict__ cell_curv, int* __restrict__ cell_src, int n, LivoxState* st) {
+    if ((int)blockIdx.x < n_cut_blocks) { livox_cut_block((int)blockIdx.x, n_cut_blocks, und, curv, keep, n, blk_keep, cut_a, cut_b, cut_src, st); return; }
+    int c = ((int)blockIdx.x - n_cut_blocks) * blockDim.x + threadIdx.x;
     if (c == 0 && n == 0) st->n_cut = 0;
     if (c >= kLvCells) return;
     int o = owner[c];
@@ -317,6 +321,24 @@ static lili_detail::LivoxBuffers* livox_of(lili_ctx* ctx) {
     return static_cast<lili_detail::LivoxBuffers*>(ctx->ext_livox);
 }
 
+// the edge and the surf list in ONE launch (workgroups [0, nb0): the first list)
+__device__ __forceinline__ void livox_pack_one(int i, const float4* __restrict__ a, const float4* __restrict__ b, int n, int pcl_layout, float* __restrict__ out) {
+    if (i >= n) return;
+    float4 u = a[i], v = b[i];
+    if (pcl_layout) {
+        float* o = out + (size_t)i * 12;
+        o[0] = u.x; o[1] = u.y; o[2] = u.z; o[3] = 1.f; o[4] = u.w; o[5] = v.x; o[6] = v.y; o[7] = 0.f; o[8] = v.z; o[9] = v.w; o[10] = 0.f; o[11] = 0.f;
+    } else {
+        float* o = out + (size_t)i * 8;
+        o[0] = u.x; o[1] = u.y; o[2] = u.z; o[3] = u.w; o[4] = v.x; o[5] = v.y; o[6] = v.z; o[7] = v.w;
+    }
+}
+__global__ void k_livox_pack2(int nb0, const float4* __restrict__ a0, const float4* __restrict__ b0, const int* __restrict__ n0_dev, int cap0, int layout0, float* __restrict__ out0,
+                              const float4* __restrict__ a1, const float4* __restrict__ b1, const int* __restrict__ n1_dev, int cap1, int layout1, float* __restrict__ out1) {
+    if ((int)blockIdx.x < nb0) livox_pack_one(blockIdx.x * blockDim.x + threadIdx.x, a0, b0, min(*n0_dev, cap0), layout0, out0);
+    else livox_pack_one(((int)blockIdx.x - nb0) * blockDim.x + threadIdx.x, a1, b1, min(*n1_dev, cap1), layout1, out1);
+}
+
 // Packs one list into the caller's record layout (enqueued before the counts are read back; `bound` = an upper bound of the list length)...
 static int livox_pack(lili_ctx* ctx, DevBuf& pack, const lili_feature_out* o, const float4* a, const float4* b, const int* d_count, size_t bound) {
     if (!o || !o->data) return LILI_OK;
@@ -380,9 +402,12 @@ int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offs
         HIPCHK(B->blk_keep.ensure((size_t)nblocks(n, 256) * 4));
         hipLaunchKernelGGL(k_livox_prep, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, raw, (int)scan->stride, (int)scan->aux_offset, curvature_offset, n, P, B->und.as<float4>(),
                            B->curv.as<float>(), B->keep.as<unsigned char>(), B->owner.as<int>(), B->blk_keep.as<int>());
-        hipLaunchKernelGGL(k_livox_cut, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, B->und.as<float4>(), B->curv.as<float>(), B->keep.as<unsigned char>(), n,
-                           B->blk_keep.as<int>(), B->cut_a.as<float4>(), B->cut_b.as<float4>(), B->cut_src.as<int>(), st);
     }
+    const int n_cut_blocks = n > 0 ? nblocks(n, 256) : 0;
+    hipLaunchKernelGGL(k_livox_cut_grid, dim3(n_cut_blocks + nblocks(kLvCells, 256)), dim3(256), 0, ctx->stream, n_cut_blocks, B->owner.as<int>(), B->und.as<float4>(), B->curv.as<float>(),
+                       B->keep.as<unsigned char>(), B->blk_keep.as<int>(), B->cut_a.as<float4>(), B->cut_b.as<float4>(), B->cut_src.as<int>(),
+                       B->cell_pt.as<float4>(), B->cell_curv.as<float>(), B->cell_src.as<int>(), n, st);
+    B->armed = true;
     // lidar_cloud_cutted is final here: it is packed now and travels to the host on a side stream under the grid / block / compaction kernels (768 KB for
     // a 24 k-point scan).  All min(n, capacity) records travel — the count is known only at the end; records behind `count` are unspecified.
     bool cut_early = false;
@@ -398,9 +423,6 @@ int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offs
         HIPCHK(hipEventRecord(ctx->join_ev[1], ctx->side[1]));
         cut_early = true;
     }
-    hipLaunchKernelGGL(k_livox_grid, dim3(nblocks(kLvCells, 256)), dim3(256), 0, ctx->stream, B->owner.as<int>(), B->und.as<float4>(), B->curv.as<float>(),
-                       B->cell_pt.as<float4>(), B->cell_curv.as<float>(), B->cell_src.as<int>(), n, st);
-    B->armed = true;
     hipLaunchKernelGGL(k_livox_blocks, dim3(kLvBlocks), dim3(64), 0, ctx->stream, B->cell_pt.as<float4>(), B->cell_curv.as<float>(), P,
                        B->blk_nedge.as<int>(), B->blk_edge_cell.as<int>(), B->blk_edge_dir.as<float>(), B->blk_nsurf.as<int>(), B->blk_surf_cell.as<int>(),
                        B->blk_surf_nrm.as<float>());
@@ -411,8 +433,20 @@ int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offs
     rc = lili_readback_add(ctx, &B->host, st, sizeof(LivoxState)); if (rc) return rc;
     // the three lists are packed into the caller's layout while the counts travel
     if (!cut_early) rc = livox_pack(ctx, B->pack, cutted, B->cut_a.as<float4>(), B->cut_b.as<float4>(), &st->n_cut, (size_t)n);
-    if (rc == LILI_OK) rc = livox_pack(ctx, B->pack_e, edge, B->edge_a.as<float4>(), B->edge_b.as<float4>(), &st->n_edge, (size_t)kLvCells);
-    if (rc == LILI_OK) rc = livox_pack(ctx, B->pack_s, surf, B->surf_a.as<float4>(), B->surf_b.as<float4>(), &st->n_surf, (size_t)kLvCells);
+    const bool both = edge && edge->data && edge->capacity && surf && surf->data && surf->capacity;
+    if (rc == LILI_OK && both) {
+        const size_t k0 = std::min((size_t)kLvCells, edge->capacity), k1 = std::min((size_t)kLvCells, surf->capacity);
+        const size_t s0 = edge->stride ? edge->stride : 32, s1 = surf->stride ? surf->stride : 32;
+        ARGCHK((s0 == 32 || s0 == 48) && (s1 == 32 || s1 == 48), "feature_out: Livox records are 32 B (packed x,y,z,nx,ny,nz,intensity,curvature) or 48 B (pcl::PointXYZINormal)");
+        HIPCHK(B->pack_e.ensure(k0 * s0)); HIPCHK(B->pack_s.ensure(k1 * s1));
+        const int nb0 = nblocks((int64_t)k0, 256), nb1 = nblocks((int64_t)k1, 256);
+        hipLaunchKernelGGL(k_livox_pack2, dim3(nb0 + nb1), dim3(256), 0, ctx->stream, nb0, B->edge_a.as<float4>(), B->edge_b.as<float4>(), &st->n_edge, (int)k0, s0 == 48 ? 1 : 0,
+                           B->pack_e.as<float>(), B->surf_a.as<float4>(), B->surf_b.as<float4>(), &st->n_surf, (int)k1, s1 == 48 ? 1 : 0, B->pack_s.as<float>());
+        if (hipGetLastError() != hipSuccess) rc = ctx->fail(LILI_E_HIP, "extract_livox: pack launch failed");
+    } else {
+        if (rc == LILI_OK) rc = livox_pack(ctx, B->pack_e, edge, B->edge_a.as<float4>(), B->edge_b.as<float4>(), &st->n_edge, (size_t)kLvCells);
+        if (rc == LILI_OK) rc = livox_pack(ctx, B->pack_s, surf, B->surf_a.as<float4>(), B->surf_b.as<float4>(), &st->n_surf, (size_t)kLvCells);
+    }
     { const int rb = lili_readback_finish(ctx); if (rc) return rc; if (rb) return rb; }      // (the pending read is always finished)
     B->have = true;
     if (cutted) {
