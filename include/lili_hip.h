@@ -177,7 +177,9 @@ typedef struct lili_rot_params {
  *   full  : the ring-concatenated, deskewed cloud          (/lidar_cloud_cutted)
  *   edge  : cornerPointsLessSharp, in push order            (/edge_features)
  *   surf  : voxel-filtered less-flat points, ring by ring   (/surf_features)
- * Points are written as (x, y, z, intensity = ring + 0.1 * relTime).  Blocking. */
+ * Points are written as (x, y, z, intensity = ring + 0.1 * relTime).  Blocking.  A LILI_MEM_DEVICE scan of 16-byte rows (x, y, z, intensity)
+ * is read in place; a `full` buffer in host memory receives min(scan->n, capacity) records while the features are selected — the records
+ * behind full->count are unspecified. */
 int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4], const double q_lb[4], const lili_rot_params* params,
                      lili_feature_out* full, lili_feature_out* edge, lili_feature_out* surf);
 /* Intermediate products of the last lili_extract_rot for parity tests (any pointer may be NULL):
@@ -199,7 +201,9 @@ typedef struct lili_livox_params {
  * pcl::PointXYZINormal.  q_imu = the gyro quaternion integrated over the scan (L:129-171, caller side).
  * Outputs are records of 32 B (x,y,z,nx,ny,nz,intensity,curvature; stride 32) or pcl::PointXYZINormal (stride 48):
  *   cutted: every deskewed point with a valid line (/lidar_cloud_cutted), edge: /edge_features (normal = line
- *   direction), surf: /surf_features (normal = plane normal).  Blocking. */
+ *   direction), surf: /surf_features (normal = plane normal).  Blocking.  The rows are read as they are (one transfer for host memory);
+ *   a `cutted` buffer in host memory receives min(scan->n, capacity) records while the features are selected — the records behind
+ *   cutted->count are unspecified. */
 int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offset, const double q_imu[4], const lili_livox_params* params,
                        lili_feature_out* cutted, lili_feature_out* edge, lili_feature_out* surf);
 /* counts = {n_cutted, n_edge, n_surf}; cut_src[n_cutted]; cell_src[24000] (input index owning each grid cell or -1);
