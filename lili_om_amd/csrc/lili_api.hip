@@ -302,7 +302,7 @@ static int build_grid(lili_ctx* ctx, MapIndex& m, const double mn[3], const doub
     const int nb_scan = nblocks(nc, 2048);
     HIPCHK(m.block_sums.ensure((size_t)(nb_scan + 2) * sizeof(unsigned long long)));
     if (!(cell_start.p == zeroed_p && (size_t)nc * sizeof(int) <= zeroed_bytes)) HIPCHK(hipMemsetAsync(cell_start.p, 0, (size_t)nc * sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(k_cell_count, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, m.pts.as<float4>(), n, g, cell_start.as<int>(), m.pt_cell.as<int2>(), d_rank_sum);
+    hipLaunchKernelGGL(k_cell_count, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, m.pts_ext ? static_cast<const float4*>(m.pts_ext) : m.pts.as<float4>(), n, g, cell_start.as<int>(), m.pt_cell.as<int2>(), d_rank_sum);
     if (ctx->scan_lookback) {      // one pass over the cell array (status words: one per 16384-cell tile)
         const int nb_lb = nblocks(nc, 16384);
         HIPCHK(hipMemsetAsync(m.block_sums.p, 0, (size_t)(nb_lb + 2) * sizeof(unsigned long long), ctx->stream));
@@ -312,7 +312,7 @@ static int build_grid(lili_ctx* ctx, MapIndex& m, const double mn[3], const doub
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, ctx->stream, m.block_sums.as<int>(), nb_scan);
         hipLaunchKernelGGL(k_scan_apply, dim3(nb_scan), dim3(kBlock), 0, ctx->stream, cell_start.as<int>(), nc, m.block_sums.as<int>(), cell_start.as<int>());
     }
-    hipLaunchKernelGGL(k_scatter, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, m.pts.as<float4>(), n, m.pt_cell.as<int2>(), cell_start.as<int>(),
+    hipLaunchKernelGGL(k_scatter, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, m.pts_ext ? static_cast<const float4*>(m.pts_ext) : m.pts.as<float4>(), n, m.pt_cell.as<int2>(), cell_start.as<int>(),
                        sorted.as<float4>(), m.has_aux ? aux_sorted.as<float>() : nullptr);
     if (srows) {      // first positions of the super-rows (populations -> scan), positions of the super cells, then the copy
         hipLaunchKernelGGL(k_rowtot9, dim3(nblocks(rows9, kBlock)), dim3(kBlock), 0, ctx->stream, cell_start.as<int>(), g, m.row9.as<int>());
@@ -333,7 +333,11 @@ static int build_grid(lili_ctx* ctx, MapIndex& m, const double mn[3], const doub
     return LILI_OK;
 }
 
-int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq_radius) {
+int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq_radius) { return lili_map_set_hinted(ctx, kind, cloud, max_sq_radius, nullptr, false); }
+
+}  // extern "C"
+
+int lili_map_set_hinted(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq_radius, const unsigned* box6, bool in_place) {
     if (!ctx) return LILI_E_ARG;
     ARGCHK(kind == LILI_KIND_SURF || kind == LILI_KIND_EDGE, "map_set: bad kind");
     ARGCHK(cloud, "map_set: null cloud");
@@ -347,9 +351,12 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
     struct BboxInit { unsigned w[64 * 32]; BboxInit() { for (int i = 0; i < 64 * 32; i++) w[i] = (i & 31) < 3 ? 0xFFFFFFFFu : 0u; } };
     static const BboxInit bbox_init;             // 64 banks of 128 bytes: min xyz = ~0, max xyz = 0 (ordered-uint encoding)
     unsigned* d_mm = ctx->misc.as<unsigned>();
-    HIPCHK(hipMemcpyAsync(d_mm, bbox_init.w, sizeof(bbox_init.w), hipMemcpyHostToDevice, ctx->stream));
+    if (!box6) HIPCHK(hipMemcpyAsync(d_mm, bbox_init.w, sizeof(bbox_init.w), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemsetAsync(scan_err_word(ctx), 0, sizeof(unsigned), ctx->stream));
-    int rc = lili_ingest_cloud(ctx, cloud, m.pts, d_mm);
+    in_place = in_place && box6 && cloud->n > 0 && cloud->mem == LILI_MEM_DEVICE && cloud->stride == sizeof(float4) && (cloud->aux_offset == 12 || cloud->aux_offset < 0) &&
+               (reinterpret_cast<uintptr_t>(cloud->data) & 15) == 0;
+    m.pts_ext = in_place ? cloud->data : nullptr;
+    int rc = in_place ? LILI_OK : lili_ingest_cloud(ctx, cloud, m.pts, box6 ? nullptr : d_mm);
     if (rc != LILI_OK) return rc;
     m.n = (int64_t)cloud->n;
     m.has_aux = cloud->aux_offset >= 0;
@@ -363,8 +370,11 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
     const void* zeroed_p = m.cell_start.p;
     const size_t zeroed_bytes = m.cell_start.p ? m.cell_start.cap : 0;
     if (zeroed_bytes) HIPCHK(hipMemsetAsync(m.cell_start.p, 0, zeroed_bytes, ctx->stream));
-    { int rb = lili_readback_add(ctx, banks, d_mm, sizeof(banks)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }
-    for (int b = 0; b < 64; b++) for (int k = 0; k < 3; k++) { mm[k] = std::min(mm[k], banks[b * 32 + k]); mm[3 + k] = std::max(mm[3 + k], banks[b * 32 + 3 + k]); }
+    if (box6) for (int k = 0; k < 6; k++) mm[k] = box6[k];
+    else {
+        int rb = lili_readback_add(ctx, banks, d_mm, sizeof(banks)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb;
+        for (int b = 0; b < 64; b++) for (int k = 0; k < 3; k++) { mm[k] = std::min(mm[k], banks[b * 32 + k]); mm[3 + k] = std::max(mm[3 + k], banks[b * 32 + 3 + k]); }
+    }
     auto dec = [](unsigned u) { unsigned b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u; float f; std::memcpy(&f, &b, 4); return f; };
     double mn[3], mx[3];
     bool any = true;
@@ -418,14 +428,17 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
         if (scan_err) {
             ctx->scan_lookback = false;
             ctx->scan_fallbacks++;
-            rc = lili_map_set(ctx, kind, cloud, max_sq_radius);
+            rc = lili_map_set_hinted(ctx, kind, cloud, max_sq_radius, box6, in_place);
             ctx->scan_lookback = true;
             return rc;
         }
     }
+    m.pts_ext = nullptr;
     m.valid = true;
     return LILI_OK;
 }
+
+extern "C" {
 
 // Double-buffered map index: lili_map_set_begin builds the NEXT index of `kind` on a side stream (own staging and scratch words), so the
 // kernels already enqueued on the context's stream — a keyframe's iterations — keep using the current index and run concurrently with

@@ -42,6 +42,7 @@ struct MapIndex {
     double cell = 0;
     GridView view{};
     DevBuf pts, sorted, aux_sorted, cell_start, cell_tmp, pt_cell, block_sums, cell_start9, row9;
+    const void* pts_ext = nullptr;   // during a build: the points are read in place from a library-owned float4 array instead of from `pts`
     bool has_aux = false;
     // density adaptation: a second index with cells sized from the measured density (dense maps only), searched first
     bool has_fine = false;
@@ -179,6 +180,10 @@ static inline int nblocks(int64_t n, int per) { return (int)((n + per - 1) / per
 
 // enqueue a small read of device memory on `stream` (default: the context's) into the page-locked scratch; lili_readback_finish synchronises that stream and
 // copies every pending item to its destination.  One thread per context, items of one stream per finish.
+// lili_map_set for clouds the library itself produced (the local map): `box6` = the points' bounding box as the six ordered-uint words k_bbox leaves
+// (min xyz, max xyz) already on the host — no read-back before the grid —, `in_place` = a device float4 array (16-byte rows, aux in w or none) that stays
+// untouched until the build is through — no ingestion copy.  Either may be off (nullptr / false).
+int lili_map_set_hinted(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq_radius, const unsigned* box6, bool in_place);
 int lili_readback_add(lili_ctx* ctx, void* dst, const void* d_src, size_t bytes, hipStream_t stream = nullptr);
 int lili_readback_finish(lili_ctx* ctx, hipStream_t stream = nullptr);
 int lili_ingest_cloud(lili_ctx* ctx, const lili_cloud* c, lili_detail::DevBuf& out_f4, unsigned* d_bbox = nullptr);   // d_bbox: also reduce the bounding box (6 ordered-uint words, initialised by the caller)

@@ -86,6 +86,36 @@ __global__ void k_bbox(const float4* __restrict__ pts, int n, unsigned* __restri
     }
 }
 
+// the same with the number of points read on the device (the local map's centroid count is not on the host yet)
+__global__ void k_bbox_dev(const float4* __restrict__ pts, const int* __restrict__ n_dev, int n_max, unsigned* __restrict__ mm /*[6]: min xyz, max xyz (ordered-uint)*/) {
+    const int n = min(*n_dev, n_max);
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float4 p = pts[i];
+        if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+            mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+            mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        for (int o = 32; o > 0; o >>= 1) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], o)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o)); }
+    }
+    // one atomic set per BLOCK (same-address atomics serialise at ~12 ns each on MI355X)
+    __shared__ float smn[kBlock / 64][3], smx[kBlock / 64][3];
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { smn[threadIdx.x >> 6][k] = mn[k]; smx[threadIdx.x >> 6][k] = mx[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        int k = threadIdx.x;
+        float a = smn[0][k], b = smx[0][k];
+        for (int w = 1; w < kBlock / 64; w++) { a = fminf(a, smn[w][k]); b = fmaxf(b, smx[w][k]); }
+        atomicMin(&mm[k], f2ord(a)); atomicMax(&mm[3 + k], f2ord(b));
+    }
+}
+
 
 // One global atomic per point in the WHOLE build: the value it returns is the point's rank inside its cell, kept next to the cell id,
 // so the scatter pass needs no second counter array, no second 108 MB memset and no atomics (round 1: an atomic here, whose result

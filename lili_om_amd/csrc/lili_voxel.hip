@@ -19,6 +19,7 @@ __global__ void k_scan_block_sums(const int*, int64_t, int*);
 __global__ void k_scan_sums(int*, int);
 __global__ void k_scan_apply(const int*, int64_t, const int*, int*);
 __global__ void k_bbox(const float4*, int, unsigned*);
+__global__ void k_bbox_dev(const float4*, const int*, int, unsigned*);
 
 constexpr int kSortBlock = 256, kSortItems = 8, kSortTile = kSortBlock * kSortItems;
 
@@ -341,6 +342,7 @@ struct VoxelBuffers {
     int incremental_commits = 0, full_commits = 0;
     std::vector<ConcatSeg> seg_host;   // the table k_concat reads, kept alive until the upload has certainly happened (an async copy from a local vector)
     int n_out = 0;
+    unsigned out_box[6] = {0, 0, 0, 0, 0, 0};   // bounding box of `out` (ordered-uint words, k_bbox_dev) after an incremental commit
     void release() {
         for (DevBuf* b : {&keys_a, &keys_b, &vals_a, &vals_b, &hist, &hist_scan, &sums, &flags, &slots, &out, &out_cnt, &in, &concat, &concat_tab}) b->release();
         for (auto& r : ring) { for (auto* k : r) { k->pts.release(); delete k; } r.clear(); }
@@ -636,6 +638,7 @@ int lili_localmap_commit(lili_ctx* ctx, int kind, float leaf, double max_sq_radi
             if (add.size() > 2) inc = false;                               // several pending keyframes: the rebuild is cheaper than as many merge passes
         }
     }
+    bool have_box = false;
     if (inc) {
         // ---- incremental step(s): the merge, then the centroid pass over the sorted ring
         HIPCHK(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
@@ -661,10 +664,21 @@ int lili_localmap_commit(lili_ctx* ctx, int kind, float leaf, double max_sq_radi
                                (const int*)(V->slots.as<int>() + n), n, V->out.as<float4>(), V->out_cnt.as<int>());
             HIPCHK(hipGetLastError());
             rc = lili_readback_add(ctx, &V->n_out, V->slots.as<int>() + n, sizeof(int));
+            // the bounding box of the centroids travels with their count: the index build below starts without a read-back of its own
+            if (rc == LILI_OK) {
+                static const unsigned init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+                unsigned* d_box = reinterpret_cast<unsigned*>(ctx->misc.as<char>() + 512);
+                HIPCHK(hipMemcpyAsync(d_box, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+                hipLaunchKernelGGL(k_bbox_dev, dim3((unsigned)std::min<long long>(nblocks(n, kBlock), 128)), dim3(kBlock), 0, ctx->stream, V->out.as<float4>(),
+                                   (const int*)(V->slots.as<int>() + n), (int)n, d_box);
+                HIPCHK(hipGetLastError());
+                rc = lili_readback_add(ctx, V->out_box, d_box, sizeof(V->out_box));
+                have_box = rc == LILI_OK;
+            }
         }
         if (rc == LILI_OK) rc = lili_readback_add(ctx, &bad, d_bad, 4);
         { const int rb = lili_readback_finish(ctx); if (rc != LILI_OK) return rc; if (rb != LILI_OK) return rb; }
-        if (bad) { S.valid = false; inc = false; }      // a point beyond the absolute key range: the box-relative rebuild below handles it
+        if (bad) { S.valid = false; inc = false; have_box = false; }      // a point beyond the absolute key range: the box-relative rebuild below handles it
         else V->incremental_commits++;
     }
     if (!inc) {
@@ -712,7 +726,8 @@ int lili_localmap_commit(lili_ctx* ctx, int kind, float leaf, double max_sq_radi
     // (measured: k_scatter9 45 + k_start9 12 + k_rowtot9 5 + scan 10 us on the 152 k-point ring map).  Option "localmap_super_rows" = 1 keeps it.
     const bool srows = ctx->super_rows;
     if (!ctx->localmap_super_rows && V->n_out < 400000 && !(ctx->focus_radius > 0)) ctx->super_rows = false;
-    const int rc_map = lili_map_set(ctx, kind, &c, max_sq_radius);                       // setInputCloud (L:839-840)
+    // setInputCloud (L:839-840).  After an incremental step the centroids are indexed where they lie (no ingestion copy) with the box that came with their count.
+    const int rc_map = have_box && V->n_out > 0 ? lili_map_set_hinted(ctx, kind, &c, max_sq_radius, V->out_box, true) : lili_map_set(ctx, kind, &c, max_sq_radius);
     ctx->super_rows = srows;
     return rc_map;
 }
