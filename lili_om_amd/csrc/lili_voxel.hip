@@ -103,11 +103,27 @@ __global__ __launch_bounds__(kSortBlock) void k_sort_hist8(const unsigned* __res
     __syncthreads();
     hist[threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
 }
+// `raw_hist`: `offs` is the COUNT table of k_sort_hist8 and every workgroup derives its offsets itself (digits before its digit: all tiles; its own digit:
+// the tiles before it) — for the short tables of a keyframe's sort (<= 64 tiles: 64 KB of L2 reads per workgroup) that is cheaper than the scan launch
+// between the two kernels (a pass = two launches instead of three; the launches, not the work, are what a 20 k-key sort costs).
 __global__ __launch_bounds__(kSortBlock) void k_sort_scatter8(const unsigned* __restrict__ keys_in, const int* __restrict__ vals_in, int n, int shift, int nb, int items,
-                                                              const int* __restrict__ offs /*[256][nb] exclusive*/, unsigned* __restrict__ keys_out, int* __restrict__ vals_out) {
+                                                              const int* __restrict__ offs /*[256][nb] exclusive, or counts*/, int raw_hist, unsigned* __restrict__ keys_out,
+                                                              int* __restrict__ vals_out) {
     __shared__ int base[256];                 // running offset of each digit inside this tile
     __shared__ int wcnt[kSortBlock / 64][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (raw_hist) {
+        __shared__ int wtot[kSortBlock / 64];
+        int row = 0, pre = 0;
+        for (int b = 0; b < nb; b++) { const int c = offs[threadIdx.x * nb + b]; row += c; if (b < (int)blockIdx.x) pre += c; }
+        int inc = row;
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wave; w++) before += wtot[w];
+        base[threadIdx.x] = before + inc - row + pre;
+    } else
     base[threadIdx.x] = offs[threadIdx.x * nb + blockIdx.x];
     const int tile = blockIdx.x * kSortBlock * items;
     for (int r = 0; r < items; r++) {
@@ -445,9 +461,10 @@ static int radix_sort(lili_ctx* ctx, lili_detail::VoxelBuffers* V, int n, int bi
         int *va = V->vals_a.as<int>(), *vb = V->vals_b.as<int>();
         if (dbits == 8) hipLaunchKernelGGL(k_sort_hist8, dim3(nb), dim3(kSortBlock), 0, ctx->stream, ka, n, shift, nb, items8, V->hist.as<int>());
         else hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(kSortBlock), 0, ctx->stream, ka, n, shift, nb, V->hist.as<int>());
-        int rc = exclusive_scan(ctx, V, V->hist.as<int>(), (int64_t)ndig * nb, V->hist_scan.as<int>());
-        if (rc != LILI_OK) return rc;
-        if (dbits == 8) hipLaunchKernelGGL(k_sort_scatter8, dim3(nb), dim3(kSortBlock), 0, ctx->stream, ka, va, n, shift, nb, items8, V->hist_scan.as<int>(), kb, vb);
+        const bool fused_scan = ctx->sort_fused_scan && dbits == 8 && nb <= 64;      // (see k_sort_scatter8)
+        if (!fused_scan) { const int rc = exclusive_scan(ctx, V, V->hist.as<int>(), (int64_t)ndig * nb, V->hist_scan.as<int>()); if (rc != LILI_OK) return rc; }
+        if (dbits == 8) hipLaunchKernelGGL(k_sort_scatter8, dim3(nb), dim3(kSortBlock), 0, ctx->stream, ka, va, n, shift, nb, items8,
+                                           fused_scan ? V->hist.as<int>() : V->hist_scan.as<int>(), fused_scan ? 1 : 0, kb, vb);
         else hipLaunchKernelGGL(k_sort_scatter, dim3(nb), dim3(kSortBlock), 0, ctx->stream, ka, va, n, shift, nb, V->hist_scan.as<int>(), kb, vb);
         HIPCHK(hipGetLastError());
         V->keys_a.swap(V->keys_b); V->vals_a.swap(V->vals_b);      // the sorted pairs are the new `a` (buffers trade places, nothing is copied)

@@ -25,6 +25,24 @@ def test_voxel_filter_matches_pcl_restatement(gpu_ctx, oracle, n, leaf, scale):
     np.testing.assert_allclose(o2, o, rtol=1e-6, atol=1e-5 * scale)
 
 
+@pytest.mark.parametrize("n", [1, 255, 1025, 20_000, 65_536, 65_537])
+def test_short_sorts_without_the_scan_launch(gpu_ctx, oracle, n):
+    """Radix passes of at most 64 tiles (<= 65 536 keys) derive the scatter offsets inside k_sort_scatter8 (option sort_fused_scan, on) instead of
+    in a scan launch between the two kernels: same order, same centroids, on both sides of the size limit and against the oracle."""
+    rng = np.random.default_rng(n + 7)
+    pts = np.concatenate([rng.uniform(-30, 30, (n, 2)), rng.normal(0, 0.5, (n, 1)), rng.uniform(0, 25, (n, 1))], 1).astype(np.float32)
+    res = []
+    try:
+        for opt in (1, 0):
+            gpu_ctx.set_option("sort_fused_scan", opt)
+            res.append(L.api.voxel_filter(gpu_ctx, pts, 0.4))
+    finally:
+        gpu_ctx.set_option("sort_fused_scan", 1)
+    o, oc = oracle.voxel_grid(pts, 0.4, stable=True)
+    for g, gc in res:
+        assert np.array_equal(gc, oc) and np.array_equal(g.view(np.uint32), o.view(np.uint32))
+
+
 def test_voxel_filter_edge_cases(gpu_ctx, oracle):
     one = np.array([[1.0, 2.0, 3.0, 4.0]], np.float32)
     g, c = L.api.voxel_filter(gpu_ctx, one, 0.4)
