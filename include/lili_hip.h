@@ -106,6 +106,13 @@ int lili_set_debug(lili_ctx* ctx, int keep_neighbors);
  * the super-row layout, see lili_map_focus; default 1; takes effect at the next lili_map_set).
  * "fine_grid" (1 = lili_map_set measures the point density and gives a map with more than "fine_occupancy" (default 12) points per
  * gate-sized cell a second index with density-sized cells that the association searches first — exact; default 1).
+ * Round 3: "assoc_lpq" (lanes of a wave per query in the association of small scans: 0 = by size (default), 1 / 2 / 4 / 8 / 16 forces a value),
+ * "count_barrier" (1 = small ROT launches exchange their counts inside the association launch; default 0, measured no gain), "persistent_iterate"
+ * (1 = lili_s2m_iterate* of scans of <= 128 cooperative workgroups run a whole registration as ONE persistent launch; default 0, measured slower
+ * than the launches; poses then differ from the launch-per-stage loop by the partition of the Gram sum, <= 1e-10), "localmap_incremental" (default 1,
+ * see lili_localmap_commit), "localmap_super_rows" (1 = ring maps below 400 k points get the super-row copy too; default 0), "sort_digit_bits"
+ * (8, or 4 = the round-2 radix passes), "sort_fused_scan" (1 = radix passes of at most 64 tiles derive their offsets inside the scatter kernel;
+ * default 1).
  * One knob that DOES choose between two definitions of a result: "rot_atan" — lili_extract_rot's atan / atan2 on float arguments
  * (R/src/Preprocessing.cpp:285-288,315,349): 2 (default) = glibc's float routines statement for statement (atanf / atan2f of
  * every glibc up to 2.40 — the bits a build of the reference produces), 1 = the f64 functions rounded to f32 (libm-independent). */
