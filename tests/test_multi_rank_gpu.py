@@ -142,11 +142,11 @@ def test_two_ranks_share_one_gpu(mode):
 
 
 # ------------------------------------------------------------------------------------------------
-# four ranks (world > 2 logic of the exchange: slots, flags, rank-order sums) — was tools/r02_share4.sh, now part of the suite
+# four and eight ranks (world > 2 logic of the exchange: slots, flags, rank-order sums) — was tools/r02_share4.sh, now part of the suite
 # ------------------------------------------------------------------------------------------------
-def test_four_ranks_share_one_gpu():
+@pytest.mark.parametrize("world", [4, 8])      # 8 = the world size of the driver's scaling run (one node)
+def test_four_and_eight_ranks_share_one_gpu(world):
     import torch.multiprocessing as mp
-    world = 4
     t_ref, q_ref = _single_rank()
     mgr = mp.Manager()
     out = mgr.dict()
