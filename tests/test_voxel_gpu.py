@@ -198,3 +198,50 @@ def test_incremental_local_map_equals_full_rebuild(gpu_ctx):
         for (ra, a), (rb, b) in zip(ref, maps):
             assert ra == rb and a.shape == b.shape and a.shape[0] > 100
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_index_behind_an_incremental_commit_equals_a_plain_map_set(gpu_ctx):
+    """After an incremental step lili_localmap_commit indexes the centroids where they lie, with the bounding box that travelled with their count
+    (lili_map_set_hinted: no ingestion copy, no read-back before the grid).  The index must be the one lili_map_set builds from the same points:
+    neighbours, distances, records and the Gram of a scan matched against it are identical bit for bit."""
+    rng = np.random.default_rng(11)
+
+    def keyframe(k):
+        n = int(rng.integers(1500, 4000))
+        pts = np.concatenate([rng.uniform(-15, 15, (n, 2)) + [0.8 * k, 0.3 * k], rng.normal(0, 0.03, (n, 1)), rng.uniform(0, 30, (n, 1))], 1).astype(np.float32)
+        pts[: n // 3, 2] = rng.uniform(0, 3, n // 3)          # some structure above the ground plane
+        return pts, np.array([0.0, 0.0, 0.0]), np.array([1.0, 0.0, 0.0, 0.0])
+    P = L.make_params("rot")
+    lm = L.LocalMap(gpu_ctx, L.KIND_SURF, width=6, leaf=0.4, max_sq_radius=1.0)
+    inc0, _ = lm.stats()
+    for k in range(9):
+        lm.push(*keyframe(k))
+        n_raw, n_map = lm.commit()
+    inc1, _ = lm.stats()
+    assert inc1 - inc0 >= 7                                   # the last commits were incremental steps: the hinted build
+    pts = lm.get(n_map + 1)
+    assert pts.shape[0] == n_map > 3000
+    q = (pts[rng.integers(0, n_map, 3000), :3] + rng.normal(0, 0.05, (3000, 3))).astype(np.float32)
+    m = L.ScanToMapMatcher(gpu_ctx, P)
+    t0, q0 = np.array([0.02, -0.01, 0.03]), np.array([1.0, 0.0, 0.0, 0.0])
+    res = []
+    gpu_ctx.set_debug(True)
+    try:
+        for plain in (False, True):
+            if plain:
+                m.set_input_cloud(L.KIND_SURF, np.ascontiguousarray(pts))     # lili_map_set on a host copy of the same centroids
+            m.set_queries(0, L.KIND_SURF, q)
+            m.pose_set(0, t0, q0)
+            m.associate_dev(0, L.MASK_SURF)
+            idx, d2 = m.neighbors(0, L.KIND_SURF, q.shape[0])
+            rec = m.surf_records(0, q.shape[0])
+            G, cost, counts = m.linearize(0, t0, q0, L.MASK_SURF)
+            res.append((idx, d2, rec, G, cost, counts))
+    finally:
+        gpu_ctx.set_debug(False)
+    a, b = res
+    inside = a[1][:, 4] < 1.0
+    assert inside.sum() > 1500 and a[5][0] > 500
+    assert np.array_equal(a[0][inside], b[0][inside]) and np.array_equal(a[1][inside], b[1][inside])
+    assert a[2]["count"] == b[2]["count"] and np.array_equal(a[2]["n"], b[2]["n"]) and np.array_equal(a[2]["query_index"], b[2]["query_index"])
+    assert np.array_equal(a[3], b[3]) and a[4] == b[4] and np.array_equal(a[5], b[5])
