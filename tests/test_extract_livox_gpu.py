@@ -52,3 +52,34 @@ def test_livox_extractor_edge_cases(gpu_ctx, oracle):
     _check(g, o)
     g0 = ex.extract(np.zeros((0, 5), np.float32), debug=True)
     assert g0["cutted"].shape[0] == 0 and g0["surf"].shape[0] == 0 and (g0["cell_src"] == -1).all()
+
+
+def test_livox_extractor_layouts_and_repeats(gpu_ctx, oracle):
+    """The rows are read as they are (k_livox_prep picks x, y, z, intensity, curvature at their byte offsets): the packed 20-byte rows from host memory,
+    the same rows already on the device, and pcl::PointXYZINormal rows (48 bytes, intensity at 32, curvature at 36) on the device give the same
+    features.  And the ownership table is re-armed by every scan (no init launch): scans of different sizes and an empty one in between change nothing."""
+    import ctypes as C
+    import torch
+    scan = synth.make_livox_scan(7)
+    ex = L.LivoxExtractor(gpu_ctx)
+    ref = ex.extract(scan, debug=True)
+    o = oracle.extract_livox(scan)
+    _check(ref, o)
+    for other in (scan[:5000], np.zeros((0, 5), np.float32), scan[::3], scan):
+        g = ex.extract(np.ascontiguousarray(other), debug=True)
+    for k in ("cutted", "edge", "surf", "cut_src", "cell_src", "edge_cell", "surf_cell"):
+        assert np.array_equal(g[k], ref[k]), k
+    n = scan.shape[0]
+    wide = np.zeros((n, 12), np.float32)
+    wide[:, :3] = scan[:, :3]; wide[:, 3] = 1.0; wide[:, 8] = scan[:, 3]; wide[:, 9] = scan[:, 4]
+    cap = max(n, 24000)
+    for rows, stride, off_i, off_c in ((scan, 20, 12, 16), (wide, 48, 32, 36)):
+        d = torch.from_numpy(np.ascontiguousarray(rows)).cuda()
+        cloud = L.api.Cloud(d.data_ptr(), n, stride, off_i, L.api.MEM_DEVICE)
+        bufs = [np.zeros((cap, 8), np.float32) for _ in range(3)]
+        outs = [L.api.FeatureOut(b.ctypes.data, cap, 32, L.api.MEM_HOST, 0) for b in bufs]
+        qi = np.array([1.0, 0.0, 0.0, 0.0])
+        gpu_ctx._chk(gpu_ctx.lib.lili_extract_livox(gpu_ctx.h, C.byref(cloud), off_c, qi.ctypes.data_as(C.c_void_p), C.byref(ex.params),
+                                                    C.byref(outs[0]), C.byref(outs[1]), C.byref(outs[2])))
+        for b, o_, k in zip(bufs, outs, ("cutted", "edge", "surf")):
+            assert o_.count == ref[k].shape[0] and np.array_equal(b[:o_.count], ref[k]), (stride, k)
