@@ -111,8 +111,8 @@ int lili_set_debug(lili_ctx* ctx, int keep_neighbors);
  * (1 = lili_s2m_iterate* of scans of <= 128 cooperative workgroups run a whole registration as ONE persistent launch; default 0, measured slower
  * than the launches; poses then differ from the launch-per-stage loop by the partition of the Gram sum, <= 1e-10), "localmap_incremental" (default 1,
  * see lili_localmap_commit), "localmap_super_rows" (1 = ring maps below 400 k points get the super-row copy too; default 0), "sort_digit_bits"
- * (8, or 4 = the round-2 radix passes), "sort_fused_scan" (1 = radix passes of at most 64 tiles derive their offsets inside the scatter kernel;
- * default 1).
+ * (8, or 4 = the round-2 radix passes), "sort_fused_scan" (1 = radix passes of at most "sort_fused_max_tiles" (256) tiles derive their offsets inside the scatter
+ * kernel instead of in a scan launch; default 1).
  * One knob that DOES choose between two definitions of a result: "rot_atan" — lili_extract_rot's atan / atan2 on float arguments
  * (R/src/Preprocessing.cpp:285-288,315,349): 2 (default) = glibc's float routines statement for statement (atanf / atan2f of
  * every glibc up to 2.40 — the bits a build of the reference produces), 1 = the f64 functions rounded to f32 (libm-independent). */

@@ -229,6 +229,7 @@ int lili_set_option(lili_ctx* ctx, const char* name, int value) {
     if (std::strcmp(name, "fuse_tail") == 0) { ctx->fuse_tail = value != 0; return LILI_OK; }   // any time: the block partition does not depend on it
     if (std::strcmp(name, "merge_kinds") == 0) { ctx->merge_kinds = value != 0; return LILI_OK; }
     if (std::strcmp(name, "fuse_lin") == 0) { ctx->fuse_lin = value != 0; return LILI_OK; }
+    if (std::strcmp(name, "sort_fused_max_tiles") == 0) { ctx->sort_fused_max_tiles = std::max(0, value); return LILI_OK; }
     if (std::strcmp(name, "sort_fused_scan") == 0) { ctx->sort_fused_scan = value != 0; return LILI_OK; }      // radix passes of short sorts without the scan launch (0: three launches per pass, A/B)
     if (std::strcmp(name, "persistent_iterate") == 0) { ctx->persistent_iterate = value != 0; return LILI_OK; }      // small scans: lili_s2m_iterate* as one persistent launch per registration (0: launch by launch, A/B)
     if (std::strcmp(name, "count_barrier") == 0) { ctx->count_barrier = value != 0; return LILI_OK; }      // ROT small launches: association + count barrier + linearisation in one launch (0: three launches, A/B)

@@ -104,8 +104,9 @@ __global__ __launch_bounds__(kSortBlock) void k_sort_hist8(const unsigned* __res
     hist[threadIdx.x * nb + blockIdx.x] = h[threadIdx.x];
 }
 // `raw_hist`: `offs` is the COUNT table of k_sort_hist8 and every workgroup derives its offsets itself (digits before its digit: all tiles; its own digit:
-// the tiles before it) — for the short tables of a keyframe's sort (<= 64 tiles: 64 KB of L2 reads per workgroup) that is cheaper than the scan launch
-// between the two kernels (a pass = two launches instead of three; the launches, not the work, are what a 20 k-key sort costs).
+// the tiles before it) — up to 256 tiles (256 KB of L2 reads per workgroup) that is cheaper than the scan launch between the two kernels (a pass = two
+// launches instead of three; the launches, not the work, are what a 20 k-key sort costs; 200 k keys: 212 -> 190 us per filter; beyond ~1 M keys the
+// table reads cost more than the scan, option sort_fused_max_tiles).
 __global__ __launch_bounds__(kSortBlock) void k_sort_scatter8(const unsigned* __restrict__ keys_in, const int* __restrict__ vals_in, int n, int shift, int nb, int items,
                                                               const int* __restrict__ offs /*[256][nb] exclusive, or counts*/, int raw_hist, unsigned* __restrict__ keys_out,
                                                               int* __restrict__ vals_out) {
@@ -461,7 +462,7 @@ static int radix_sort(lili_ctx* ctx, lili_detail::VoxelBuffers* V, int n, int bi
         int *va = V->vals_a.as<int>(), *vb = V->vals_b.as<int>();
         if (dbits == 8) hipLaunchKernelGGL(k_sort_hist8, dim3(nb), dim3(kSortBlock), 0, ctx->stream, ka, n, shift, nb, items8, V->hist.as<int>());
         else hipLaunchKernelGGL(k_sort_hist, dim3(nb), dim3(kSortBlock), 0, ctx->stream, ka, n, shift, nb, V->hist.as<int>());
-        const bool fused_scan = ctx->sort_fused_scan && dbits == 8 && nb <= 64;      // (see k_sort_scatter8)
+        const bool fused_scan = ctx->sort_fused_scan && dbits == 8 && nb <= ctx->sort_fused_max_tiles;      // (see k_sort_scatter8)
         if (!fused_scan) { const int rc = exclusive_scan(ctx, V, V->hist.as<int>(), (int64_t)ndig * nb, V->hist_scan.as<int>()); if (rc != LILI_OK) return rc; }
         if (dbits == 8) hipLaunchKernelGGL(k_sort_scatter8, dim3(nb), dim3(kSortBlock), 0, ctx->stream, ka, va, n, shift, nb, items8,
                                            fused_scan ? V->hist.as<int>() : V->hist_scan.as<int>(), fused_scan ? 1 : 0, kb, vb);

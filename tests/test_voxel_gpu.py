@@ -25,12 +25,13 @@ def test_voxel_filter_matches_pcl_restatement(gpu_ctx, oracle, n, leaf, scale):
     np.testing.assert_allclose(o2, o, rtol=1e-6, atol=1e-5 * scale)
 
 
-@pytest.mark.parametrize("n", [1, 255, 1025, 20_000, 65_536, 65_537])
+@pytest.mark.parametrize("n", [1, 255, 1025, 20_000, 262_144, 262_145, 1_100_000])
 def test_short_sorts_without_the_scan_launch(gpu_ctx, oracle, n):
-    """Radix passes of at most 64 tiles (<= 65 536 keys) derive the scatter offsets inside k_sort_scatter8 (option sort_fused_scan, on) instead of
-    in a scan launch between the two kernels: same order, same centroids, on both sides of the size limit and against the oracle."""
+    """Radix passes of at most 256 tiles (sorts up to ~1 M keys) derive the scatter offsets inside k_sort_scatter8 (option sort_fused_scan, on) instead of
+    in a scan launch between the two kernels: same order, same centroids, on both sides of the tile-size switch (262 144 keys), beyond the limit
+    (1.1 M keys = 269 tiles: the scan launch) and against the oracle."""
     rng = np.random.default_rng(n + 7)
-    pts = np.concatenate([rng.uniform(-30, 30, (n, 2)), rng.normal(0, 0.5, (n, 1)), rng.uniform(0, 25, (n, 1))], 1).astype(np.float32)
+    pts = np.concatenate([rng.uniform(-60, 60, (n, 2)), rng.normal(0, 0.5, (n, 1)), rng.uniform(0, 25, (n, 1))], 1).astype(np.float32)
     res = []
     try:
         for opt in (1, 0):
