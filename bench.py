@@ -27,6 +27,7 @@ if ROOT not in sys.path:
 N_MAP = 5_000_000
 N_AZ = 3125            # x 64 rings = 200 000 rays
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md §Chip-level parameters)
+POSE_TOL_M, POSE_TOL_RAD = 1e-4, 1e-4   # north star: pose deltas within 1e-4 m / 1e-4 rad of the reference CPU path
 BYTES_PER_QUERY = 96   # algorithmic bytes of one outer iteration per query: 16 B query + 5 x 16 B neighbours
 
 
@@ -345,8 +346,12 @@ def main():
                 "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "config": {"workload": r["workload"]},
                 "roofline": dict(r["roofline"], achieved=round(r["algorithmic_bytes"] / (ms * 1e-3) / 1e9, 3), traffic=None, kernel="whole step (all kernels)"),
                 "cpu_baseline": r.get("cpu"), "details": {k: v for k, v in r.items() if k not in ("roofline", "cpu", "workload", "value", "unit")}}
+        line["parity_failures"] = BC.parity_failures(r)
         print(json.dumps(line), flush=True)
         ctx.close()
+        if line["parity_failures"]:
+            log("[bench] PARITY / STATUS FAILURES: " + "; ".join(line["parity_failures"]))
+            sys.exit(3)
         return
 
     # ---------------- workload (synthetic, fixed seeds; identical on every rank) ----------------
@@ -465,6 +470,7 @@ def main():
         return
 
     counts = torch.zeros(2, dtype=torch.int32, device=dev)
+    exit_code = 0
 
     def step_multi():
         # the sharded iteration: two tiny all-reduces (counts, Gram record) between the three device stages
@@ -515,16 +521,18 @@ def main():
             ta, qa, _ = m.pose_get(0)
             m.pose_copy(0, 1)
             same = False
+            # The validation iteration is the communicator's FIRST exchange, which has to absorb the ranks' start-up skew (lazy code-object
+            # loads, first-touch of the mapped mailboxes — lili_p2p.hip): all ranks meet at a control-plane barrier with their queues
+            # drained first, and the communicator keeps its default timeout (a 2 s cut here made a spurious, sticky and
+            # contagious timeout drop the native candidate for good).
             try:        # an exchange that does not work on this box (a record that never becomes visible over the link: the communicator times out and
                         # fails, lili_s2m_iterate_sharded returns LILI_E_STATE) must cost this candidate, not the run
-                if hasattr(comm, "set_timeout"):
-                    comm.set_timeout(2.0)
+                torch.cuda.synchronize()
+                dist.barrier()
                 m.iterate_sharded(0, 1, counts.data_ptr(), gram.data_ptr(), comm.allreduce_fn, comm.handle)
                 torch.cuda.synchronize()
                 tb, qb, _ = m.pose_get(0)
                 same = bool(np.abs(ta - tb).max() <= 1e-12 and np.abs(qa - qb).max() <= 1e-12)
-                if hasattr(comm, "set_timeout"):
-                    comm.set_timeout(10.0)
             except Exception as e:          # noqa: BLE001
                 log(f"[bench] rank {rank}: {kind}: validation iteration failed ({e!r})")
             if flag_all(same):
@@ -572,6 +580,16 @@ def main():
     if rank == 0:
         log(f"[bench] host enqueue {t_enqueue / args.steps * 1e6:.1f} us/step, wall {elapsed / args.steps * 1e6:.1f} us/step")
     t_fin, q_fin, gn_status = m.pose_get(0)
+    # Pose-parity registration: ONE registration of `ips` outer iterations from the EXPLICIT start pose (t0, q0) — written
+    # into slot 0 here, never read from a slot a later helper could have touched — taken right after the timed region, before any secondary
+    # measurement runs.  Compared with the oracle's registration from the same start once cpu_baseline() has produced it.
+    reg_pose = None
+    if world == 1 and dist is None:
+        m.pose_set(0, t0, q0)
+        m.iterate(0, ips, L.MASK_SURF)
+        t_reg, q_reg, st_reg = m.pose_get(0)
+        reg_pose = (np.asarray(t_reg, np.float64).copy(), np.asarray(q_reg, np.float64).copy(), int(st_reg))
+        m.pose_set(1, t0, q0)
     # Run-to-run spread of the headline (a 20-step region is two registrations): five more regions of >= 200 steps each, same
     # schedule; `value` stays the K-step region the contract asks for, the regions go to extras.headline_regions.
     regions = None
@@ -580,6 +598,7 @@ def main():
         regs = sorted(n_reg / timed(0, n_reg)[0] for _ in range(5))
         regions = {"steps_per_region": n_reg, "iterations_per_s": [round(r, 1) for r in regs], "median": round(regs[2], 1),
                    "spread_pct": round(100.0 * (regs[-1] - regs[0]) / regs[2], 2)}
+        m.pose_set(1, t0, q0)
         m.pose_copy(0, 1)
         m.iterate_restart(0, args.warmup + args.steps, ips, 1, L.MASK_SURF)      # leave slot 0 where the K-step region left it (final_pose below)
         t_fin, q_fin, gn_status = m.pose_get(0)
@@ -667,8 +686,13 @@ def main():
             "roofline": roofline,
             "final_pose": {"t": [float(x) for x in t_fin], "q": [float(x) for x in q_fin], "gn_status": int(gn_status)},
         }
+        failures = []       # parity / solver-status violations: the JSON line is still printed, then the run exits with status 3
+        if int(gn_status) != 0:
+            failures.append(f"headline gn_status {int(gn_status)}")
         if multi:
             out["multi_gpu_check"] = multi
+            if not multi["final_pose_bit_identical_on_all_ranks"] or multi["max_gn_status"] != 0:
+                failures.append(f"multi_gpu_check {multi}")
         extras = dict(weak_extra or {})
         if regions:
             extras["headline_regions"] = regions
@@ -689,6 +713,8 @@ def main():
                 torch.cuda.synchronize()
                 us_in = e0.elapsed_time(e1) * 1e3 / n_in
                 _, _, st_in = m.pose_get(0)
+                if int(st_in) != 0:
+                    failures.append(f"inner_iteration gn_status {int(st_in)}")
                 out["inner_iteration"] = {"value": round(1e6 / us_in, 1), "unit": "inner iterations/s", "us_per_iteration": round(us_in, 3), "gn_status": int(st_in),
                                           "definition": "fixed correspondences (200k surf records of one association): linearise incl. robust cost + reduce + 6x6 solve + pose "
                                                         "update, one launch per iteration (lili_s2m_iterate_inner); the loop ceres::Solve runs up to 15x per keyframe, "
@@ -698,19 +724,33 @@ def main():
             except Exception as e:      # noqa: BLE001
                 out["inner_iteration"] = {"error": repr(e)}
         if world == 1 and dist is None and not args.no_extras:
-            # Secondary measurements of the same workload (NOT the headline): the 3-keyframe window of configs[4] advanced
-            # concurrently (lili_s2m_iterate_window), and the ROT feature extractor on the raw 200 k-point scan.
+            # Secondary measurements (NOT the headline).  Every block runs in ITS OWN lili context (pose slots, options, map focus and map
+            # indices are per context): nothing here can touch the headline context `ctx` / matcher `m` (VERDICT r3 #1 — the shared
+            # context let three helpers overwrite pose slot 1, which the parity check then started from).
+            def own_ctx():
+                return L.Context(local_rank, stream=tstream.cuda_stream)
+
+            def headline_matcher(c, params=P):
+                mm = L.ScanToMapMatcher(c, params)
+                if not args.no_focus:
+                    mm.map_focus(w["lidar_t"], focus_r)
+                mm.set_input_cloud(L.KIND_SURF, w["map_xyz"])
+                return mm
+            cx = None
             try:
+                # the 3-keyframe window of configs[4] advanced concurrently (lili_s2m_iterate_window)
+                cx = own_ctx()
+                mw = headline_matcher(cx)
                 K = 3
-                for k in range(1, K):
-                    m.set_queries(k, L.KIND_SURF, queries)
-                m.pose_set(7, t0, q0)
+                for k in range(K):
+                    mw.set_queries(k, L.KIND_SURF, queries)
+                mw.pose_set(7, t0, q0)
 
                 def run_window(n):
                     for _ in range(n // ips):
                         for k in range(K):
-                            m.pose_copy(k, 7)
-                        m.iterate_window(list(range(K)), ips, L.MASK_SURF)
+                            mw.pose_copy(k, 7)
+                        mw.iterate_window(list(range(K)), ips, L.MASK_SURF)
                 run_window(ips)
                 torch.cuda.synchronize()
                 tw = time.perf_counter()
@@ -721,13 +761,16 @@ def main():
                 extras["window3_us_per_window_iteration"] = round(el / (10 * ips) * 1e6, 2)
             except Exception as e:      # noqa: BLE001  (secondary numbers must never cost the headline line)
                 extras["window_error"] = repr(e)
+            finally:
+                if cx is not None:
+                    cx.close(); cx = None
             try:
                 # The same scan and map through the FRONT-END flavour (plain point-to-plane, no count scaling, L/src/LidarOdometry.cpp:352-413):
                 # flavours whose weights do not depend on the scan's correspondence count linearise inside the association launch
                 # (k_associate_lin: 2 launches per iteration); A/B against the three-launch path (option fuse_lin = 0).
+                cx = own_ctx()
                 Pf = L.make_params("frontend")
-                mf = L.ScanToMapMatcher(ctx, Pf)
-                mf.set_input_cloud(L.KIND_SURF, w["map_xyz"])
+                mf = headline_matcher(cx, Pf)
                 q_small = np.ascontiguousarray(queries[::10])          # 20 k queries: the size of a Livox scan's feature cloud
                 mf.set_queries(0, L.KIND_SURF, q_small)
                 tl = np.asarray(w["lidar_t"], np.float64)
@@ -736,7 +779,7 @@ def main():
                 mf.pose_set(1, tp, qp)
                 fr = {}
                 for fuse in (1, 0):
-                    ctx.set_option("fuse_lin", fuse)
+                    cx.set_option("fuse_lin", fuse)
                     mf.iterate_restart(0, 2 * ips, ips, 1, L.MASK_SURF)
                     torch.cuda.synchronize()
                     tw = time.perf_counter()
@@ -745,59 +788,82 @@ def main():
                     el = time.perf_counter() - tw
                     tf_, qf_, stf = mf.pose_get(0)
                     fr[fuse] = (20 * ips / el, el / (20 * ips) * 1e6, float(np.linalg.norm(tf_ - tl)), int(stf))
-                ctx.set_option("fuse_lin", 1)
                 extras["frontend_flavour"] = {"value": round(fr[1][0], 1), "unit": "iterations/s", "us_per_iteration": round(fr[1][1], 2),
                                               "three_launch_path_us_per_iteration": round(fr[0][1], 2), "dt_truth_m": round(fr[1][2], 6), "gn_status": fr[1][3],
                                               "queries": int(q_small.shape[0]),
                                               "note": "front-end matcher flavour, every 10th point of the scan (a Livox scan's size) vs the 5 M-point map: association + linearisation in ONE launch, then reduce + GN (scans above ~100 k queries keep three launches)"}
-                m.set_input_cloud(L.KIND_SURF, w["map_xyz"])     # (the map index is per context: restore the back-end gate)
+                if fr[1][3] != 0:
+                    failures.append(f"frontend_flavour gn_status {fr[1][3]}")
             except Exception as e:      # noqa: BLE001
                 extras["frontend_flavour_error"] = repr(e)
+            finally:
+                if cx is not None:
+                    cx.close(); cx = None
             try:
-                extras.update(secondary_stages(L, ctx, w, torch))
+                cx = own_ctx()
+                extras.update(secondary_stages(L, cx, w, torch))
             except Exception as e:      # noqa: BLE001
                 extras["stages_error"] = repr(e)
+            finally:
+                if cx is not None:
+                    cx.close(); cx = None
             # one timed figure per BASELINE config, the blocking seam calls, the small launch sizes (bench_configs.py)
             import bench_configs as BC
             try:
-                m.set_input_cloud(L.KIND_SURF, w["map_xyz"])
-                m.set_queries(0, L.KIND_SURF, queries)
-                extras["blocking_seam"] = BC.blocking_seam(L, ctx, torch, m, P, queries, t_body, q_body)
+                cx = own_ctx()
+                mb = headline_matcher(cx)
+                mb.set_queries(0, L.KIND_SURF, queries)
+                extras["blocking_seam"] = BC.blocking_seam(L, cx, torch, mb, P, queries, t_body, q_body)
             except Exception as e:      # noqa: BLE001
                 extras["blocking_seam_error"] = repr(e)
+            finally:
+                if cx is not None:
+                    cx.close(); cx = None
             try:
-                extras["small_launches"] = BC.small_launches(L, ctx, torch, synth, w, scan, focus_r)
+                cx = own_ctx()
+                extras["small_launches"] = BC.small_launches(L, cx, torch, synth, w, scan, focus_r)
+                for row in extras["small_launches"]:
+                    if row.get("gn_status", 0) != 0:
+                        failures.append(f"small_launches {row['flavour']} {row['queries']}: gn_status {row['gn_status']}")
             except Exception as e:      # noqa: BLE001
                 extras["small_launches_error"] = repr(e)
+            finally:
+                if cx is not None:
+                    cx.close(); cx = None
             cfgs = {}
             for key, fn in (("0", BC.config0), ("1", BC.config1), ("4", BC.config4)):
                 try:
-                    cfgs[key] = fn(L, ctx, torch, synth, cpu=not args.no_cpu_baseline)
+                    cx = own_ctx()
+                    cfgs[key] = fn(L, cx, torch, synth, cpu=not args.no_cpu_baseline)
+                    failures.extend(f"configs[{key}]: {f}" for f in BC.parity_failures(cfgs[key]))
                 except Exception as e:      # noqa: BLE001
                     cfgs[key] = {"error": repr(e)}
+                finally:
+                    if cx is not None:
+                        cx.close(); cx = None
             extras["configs"] = cfgs
-            try:        # (the helpers above set their own maps / options: restore the headline's for the pose-parity check below)
-                m.map_focus(w["lidar_t"], focus_r) if not args.no_focus else m.map_focus(None)
-                m.set_input_cloud(L.KIND_SURF, w["map_xyz"])
-            except Exception as e:      # noqa: BLE001
-                extras["restore_error"] = repr(e)
         if extras:
             out["extras"] = extras
         if world == 1 and not args.no_cpu_baseline:
             cb, t_cpu, q_cpu = cpu_baseline(w, queries, t0, q0)
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = round(value / cb["value"], 1)
-            # pose parity at the bench workload: ONE registration (ips outer iterations from the perturbed pose) on the GPU against the
-            # oracle's registration from the same pose (VERDICT r1 #1a)
-            m.set_queries(0, L.KIND_SURF, queries)
-            m.pose_copy(0, 1)
-            m.iterate(0, ips, L.MASK_SURF)
-            t_g, q_g, _ = m.pose_get(0)
-            dqv = synth.quat_mul(np.asarray(q_g) * np.array([1, -1, -1, -1]), np.asarray(q_cpu))
-            out["pose_delta_vs_cpu"] = {"dt_m": float(np.abs(np.asarray(t_g) - np.asarray(t_cpu)).max()),
-                                        "dang_rad": float(2 * np.arcsin(min(1.0, np.linalg.norm(dqv[1:])))),
-                                        "iterations": ips, "tolerance": "1e-4 m / 1e-4 rad (north star)",
-                                        "dt_truth_m": float(np.abs(np.asarray(t_g) - t_body).max())}
+            # pose parity at the bench workload (north star: 1e-4 m / 1e-4 rad): the registration taken right after the timed region
+            # (reg_pose: `ips` outer iterations from the explicit start t0, q0) against the oracle's registration from the same start.
+            if reg_pose is not None:
+                t_g, q_g, st_g = reg_pose
+                dqv = synth.quat_mul(np.asarray(q_g) * np.array([1, -1, -1, -1]), np.asarray(q_cpu))
+                pd = {"dt_m": float(np.abs(np.asarray(t_g) - np.asarray(t_cpu)).max()),
+                      "dang_rad": float(2 * np.arcsin(min(1.0, np.linalg.norm(dqv[1:])))),
+                      "iterations": ips, "tolerance": "1e-4 m / 1e-4 rad (north star)", "gn_status": st_g,
+                      "dt_truth_m": float(np.abs(np.asarray(t_g) - t_body).max()),
+                      "start": "explicit (t0, q0) written into slot 0 right after the timed region; oracle from the same (t0, q0)"}
+                if (args.warmup + args.steps) % ips == 0 and regions is None:
+                    pd["timed_region_final_pose_is_this_registration"] = bool(np.array_equal(np.asarray(t_fin), t_g) and np.array_equal(np.asarray(q_fin), q_g))
+                pd["pass"] = bool(pd["dt_m"] <= POSE_TOL_M and pd["dang_rad"] <= POSE_TOL_RAD and st_g == 0)
+                out["pose_delta_vs_cpu"] = pd
+                if not pd["pass"]:
+                    failures.append(f"pose_delta_vs_cpu {pd['dt_m']:.3e} m / {pd['dang_rad']:.3e} rad, gn_status {st_g}")
         else:
             out["cpu_baseline"] = None
         try:        # RCCL prints its version banner through C stdio, which is flushed at exit: push it out BEFORE the JSON line
@@ -805,7 +871,11 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except Exception:   # noqa: BLE001
             pass
+        out["parity_failures"] = failures
         print(json.dumps(out), flush=True)
+        exit_code = 3 if failures else 0
+        if failures:
+            log("[bench] PARITY / STATUS FAILURES: " + "; ".join(failures))
     if dist is not None:
         try:
             torch.cuda.synchronize()
@@ -815,6 +885,8 @@ def main():
             pass
         dist.destroy_process_group()
     ctx.close()
+    if exit_code:
+        sys.exit(exit_code)
 
 
 if __name__ == "__main__":

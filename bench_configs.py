@@ -27,6 +27,37 @@ def _frac(nbytes, sec):
     return round(nbytes / sec / 1e9 / HBM_PEAK_GBS, 6)
 
 
+POSE_TOL_M, POSE_TOL_RAD = 1e-4, 1e-4      # north star: pose deltas within 1e-4 m / 1e-4 rad of the reference CPU path
+
+
+def _pose_delta(tg, qg, tc, qc):
+    """(max |dt| in m, rotation angle between the two attitudes in rad)."""
+    qg, qc = np.asarray(qg, np.float64), np.asarray(qc, np.float64)
+    qg, qc = qg / np.linalg.norm(qg), qc / np.linalg.norm(qc)
+    w = abs(float(np.dot(qg, qc)))
+    cross = np.array([qg[0] * qc[1] - qg[1] * qc[0] - qg[2] * qc[3] + qg[3] * qc[2],
+                      qg[0] * qc[2] + qg[1] * qc[3] - qg[2] * qc[0] - qg[3] * qc[1],
+                      qg[0] * qc[3] - qg[1] * qc[2] + qg[2] * qc[1] - qg[3] * qc[0]])     # vector part of conj(qg) * qc
+    return float(np.abs(np.asarray(tg, np.float64) - np.asarray(tc, np.float64)).max()), float(2.0 * math.atan2(np.linalg.norm(cross), w))
+
+
+def _parity(dt, da, **extra):
+    return dict(dt_m=dt, dang_rad=da, tolerance="1e-4 m / 1e-4 rad (north star)", **extra, **{"pass": bool(dt <= POSE_TOL_M and da <= POSE_TOL_RAD)})
+
+
+def parity_failures(r):
+    """What bench.py turns into exit status 3: a config whose GPU-vs-oracle pose delta exceeds the north star's tolerance, or whose solver status is not 0."""
+    bad = []
+    if not isinstance(r, dict) or "error" in r:
+        return [f"did not run: {r.get('error') if isinstance(r, dict) else r!r}"]
+    if r.get("gn_status", 0) != 0:
+        bad.append(f"gn_status {r['gn_status']}")
+    par = r.get("parity")
+    if par is not None and not par.get("pass", False):
+        bad.append(f"pose delta vs oracle {par.get('dt_m')} m / {par.get('dang_rad')} rad")
+    return bad
+
+
 # ------------------------------------------------------------------------------------------------------------------------------
 # configs[0]: one HDL-64E-like scan (~130 k points): ROT extraction + 1 outer GN iteration (edge + surf) vs a 500 k-point map
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -82,8 +113,10 @@ def config0(L, ctx, torch, synth, cpu=True):
             _, to, qo, _ = O.gn_step(Gs + Ge, t0, q0)
             t_it = time.perf_counter() - tic
             out["cpu"] = {"value": round(1.0 / (t_ex + t_it), 3), "unit": "scans/s", "cores": 1, "kind": "port", "extract_s": round(t_ex, 4), "iteration_s": round(t_it, 4),
-                          "sample": "the oracle, one thread, ONE scan: extraction + one outer iteration (kd-tree builds excluded)",
-                          "pose_delta_gpu_vs_cpu_m": float(np.abs(tg - to).max())}
+                          "sample": "the oracle, one thread, ONE scan: extraction + one outer iteration (kd-tree builds excluded)"}
+            dt, da = _pose_delta(tg, qg, to, qo)
+            out["parity"] = _parity(dt, da, what="pose after the scan's outer iteration (GPU extraction + GPU matcher) vs the oracle's extraction + iteration from the same start",
+                                    features_gpu=[n_feat[1], n_feat[0]], features_oracle=[int(edge_q.shape[0]), int(surf_q.shape[0])])
         except Exception as e:      # noqa: BLE001
             out["cpu"] = {"error": repr(e)}
     return out
@@ -98,7 +131,7 @@ def _circuit(f, radius=4.0, step=0.03):
     return np.array([radius * math.cos(a), radius * math.sin(a), 1.8]), np.array([math.cos(yaw / 2), 0.0, 0.0, math.sin(yaw / 2)]), yaw
 
 
-def config1(L, ctx, torch, synth, n_frames=40, cpu=True):
+def config1(L, ctx, torch, synth, n_frames=100, cpu=True):
     frames = []
     for f in range(n_frames):
         t, q, yaw = _circuit(f)
@@ -112,6 +145,8 @@ def config1(L, ctx, torch, synth, n_frames=40, cpu=True):
         p = L.api.PinnedArray(fr.shape, np.float32)
         p.array[...] = fr
         pins.append(p)
+
+    worst = [0]
 
     def run():
         local = L.api.LocalMap(ctx, L.KIND_SURF, 20, 0.4, P.kd_max_radius)
@@ -136,6 +171,7 @@ def config1(L, ctx, torch, synth, n_frames=40, cpu=True):
                 m.pose_set(0, t0, q0)
                 m.iterate(0, 12 if f == 1 else 6, L.MASK_SURF)
                 t, q, st = m.pose_get(0)
+                worst[0] = max(worst[0], int(st))
             poses.append((np.asarray(t, np.float64), np.asarray(q, np.float64)))
             nq.append(int(qry.shape[0]))
             local.push(qry, t, q)
@@ -149,7 +185,7 @@ def config1(L, ctx, torch, synth, n_frames=40, cpu=True):
     err = [float(np.linalg.norm(p[0] - _circuit(f)[0])) for f, p in enumerate(poses)]
     n_pts = int(np.mean([fr.shape[0] for fr in frames]))
     alg = 48 * n_pts + 48 * 24000 + 6 * (96 + 41) * int(np.mean(nq))
-    out = {"value": round(1.0 / sec, 1), "unit": "frames/s", "ms_per_frame": round(sec * 1e3, 4), "frames": n_frames,
+    out = {"value": round(1.0 / sec, 1), "unit": "frames/s", "ms_per_frame": round(sec * 1e3, 4), "frames": n_frames, "gn_status": worst[0],
            "workload": f"configs[1] substitute (no FR_IOSB bag offline): {n_frames} synthetic Livox-Horizon frames (~{n_pts} points, 6 lines) on a circuit: extraction (host in / out, page-locked) -> "
                        f"VoxelGrid(0.4) -> ~{int(np.mean(nq))} queries vs the local map of the last 20 frames (ring push + commit on the device) -> 6 outer iterations (front-end flavour), host loop as tools/replay_bag.py",
            "ate_rms_m": round(float(np.sqrt(np.mean(np.square(err)))), 4), "ate_max_m": round(max(err), 4),
@@ -180,6 +216,38 @@ def config1(L, ctx, torch, synth, n_frames=40, cpu=True):
             t_it = time.perf_counter() - tic
             out["cpu"] = {"value": round(1.0 / (t_ex + t_it), 2), "unit": "frames/s", "cores": 1, "kind": "port", "extract_s": round(t_ex, 4), "iterations_s": round(t_it, 4),
                           "sample": "the oracle, one thread, ONE frame: extraction + 6 outer iterations vs a 20-frame local map (kd-tree build excluded)"}
+            # the whole chain on the oracle (extraction -> VoxelGrid -> 20-frame ring local map -> outer iterations, same host loop): pose delta at EVERY frame
+            import os
+            nth = min(32, os.cpu_count() or 1)
+            po, kept = [], []
+            for f in range(n_frames):
+                fo = O.extract_livox(frames[f])
+                qv = O.voxel_grid(np.ascontiguousarray(fo["surf"][:, [0, 1, 2, 7]]), 0.4, stable=True)[0]
+                if f == 0:
+                    t, q = _circuit(0)[:2]
+                else:
+                    if f == 1:
+                        t0, q0 = po[-1]
+                    else:
+                        (ta, qa), (tb, qb) = po[-2], po[-1]
+                        qi = qa * np.array([1, -1, -1, -1]) / np.dot(qa, qa)
+                        dq = synth.quat_mul(qi, qb)
+                        q0 = synth.quat_mul(qb, dq); q0 = q0 / np.linalg.norm(q0)
+                        t0 = tb + synth.quat_rot(qb, synth.quat_rot(qi, tb - ta))
+                    ring = np.concatenate([O.transform_cloud(kq, pq, pt) for kq, (pt, pq) in zip(kept[-20:], po[-20:])], 0)
+                    tree = O.KdTree(np.ascontiguousarray(O.voxel_grid(ring, 0.4, stable=True)[0][:, :3]))
+                    t, q = np.asarray(t0, np.float64), np.asarray(q0, np.float64)
+                    for _ in range(12 if f == 1 else 6):
+                        rs = O.associate_surf(tree, None, np.ascontiguousarray(qv[:, :3]), None, q, t, PO, nthreads=nth)
+                        G, _, _ = O.linearize_surf(rs, t, q, PO)
+                        _, t, q, _ = O.gn_step(G, t, q)
+                po.append((np.asarray(t, np.float64), np.asarray(q, np.float64)))
+                kept.append(qv)
+            deltas = [_pose_delta(pg[0], pg[1], pc[0], pc[1]) for pg, pc in zip(poses, po)]
+            dt, da = max(d[0] for d in deltas), max(d[1] for d in deltas)
+            out["parity"] = _parity(dt, da, what=f"max over all {n_frames} frames of the GPU chain's pose vs the oracle chain's pose (same host loop; extraction, VoxelGrid, ring local map, "
+                                                 "matcher each on its own side)", frames=n_frames,
+                                    oracle_ate_rms_m=round(float(np.sqrt(np.mean([np.sum((p[0] - _circuit(f)[0]) ** 2) for f, p in enumerate(po)]))), 4))
         except Exception as e:      # noqa: BLE001
             out["cpu"] = {"error": repr(e)}
     for p in pins:
@@ -197,13 +265,14 @@ def config4(L, ctx, torch, synth, cpu=True):
     refl = lambda n: rng.uniform(0.0, 0.05, n).astype(np.float32)
     m = L.ScanToMapMatcher(ctx, P)
     m.map_focus(None)
-    m.set_input_cloud(L.KIND_SURF, np.c_[room["map_xyz"], refl(room["map_xyz"].shape[0])])
+    map_refl, q_refl = refl(room["map_xyz"].shape[0]), refl(room["q_xyz"].shape[0])
+    m.set_input_cloud(L.KIND_SURF, np.c_[room["map_xyz"], map_refl])
     m.set_input_cloud(L.KIND_EDGE, room["edge_map_xyz"])
     tb, qb = L.api.body_pose_from_lidar(room["t_true"], room["q_true"], P)
     K = 3
     mask = L.MASK_SURF | L.MASK_EDGE
     slots = list(range(K))
-    sq = np.c_[room["q_xyz"], refl(room["q_xyz"].shape[0])]
+    sq = np.c_[room["q_xyz"], q_refl]
     poses = []
     for k in range(K):
         m.set_queries(k, L.KIND_SURF, sq)
@@ -215,6 +284,7 @@ def config4(L, ctx, torch, synth, cpu=True):
     n_res = m.associate_window(slots, [a[1] for a in assoc], [a[0] for a in assoc], mask)
     n_rec = int(sum(a + b for a, b in n_res))
     sec_assoc = _wall(lambda: m.associate_window(slots, [a[1] for a in assoc], [a[0] for a in assoc], mask), 50, torch)
+    win = m.linearize_window(slots, ts, qs, mask)
     sec_eval = _wall(lambda: m.linearize_window(slots, ts, qs, mask), 100, torch)
     sec_one = _wall(lambda: m.linearize(0, ts[0], qs[0], mask), 100, torch)
 
@@ -242,7 +312,6 @@ def config4(L, ctx, torch, synth, cpu=True):
             from oracle import oracle as O
             PO = O.params("livox")
             tree_s, tree_e = O.KdTree(room["map_xyz"]), O.KdTree(room["edge_map_xyz"])
-            map_refl = np.zeros(room["map_xyz"].shape[0], np.float32); q_refl = np.zeros(room["q_xyz"].shape[0], np.float32)
             recs = []
             for k in range(K):
                 recs.append((O.associate_surf(tree_s, map_refl, room["q_xyz"], q_refl, assoc[k][0], assoc[k][1], PO), O.associate_edge(tree_e, room["eq_xyz"], assoc[k][0], assoc[k][1], PO)))
@@ -254,6 +323,24 @@ def config4(L, ctx, torch, synth, cpu=True):
             t_ev = (time.perf_counter() - tic) / 5
             out["cpu"] = {"value": round(1.0 / t_ev, 1), "unit": "window evaluations/s", "cores": 1, "kind": "port",
                           "sample": "the oracle, one thread: residual + Jacobian + corrector + Gram of the same three keyframes, mean of 5"}
+            # seam parity: per keyframe, the Gauss-Newton step the GPU's window Gram implies vs the step the oracle's Gram implies (same start pose),
+            # the Gram / cost themselves relative, and the correspondence counts
+            dts, das, rel, cnt_ok = [], [], [], True
+            for k in range(K):
+                Gs, cs, ns = O.linearize_surf(recs[k][0], ts[k], qs[k], PO)
+                Ge, ce, ne = O.linearize_edge(recs[k][1], ts[k], qs[k], PO)
+                Go = Gs + Ge
+                Gg = np.asarray(win[k][0], np.float64).reshape(Go.shape)
+                rel.append(float(np.abs(Gg - Go).max() / np.abs(Go).max()))
+                cnt_ok = cnt_ok and (int(n_res[k][0]), int(n_res[k][1])) == (int(recs[k][0]["count"]), int(recs[k][1]["count"]))
+                _, tg_, qg_, _ = O.gn_step(Gg, ts[k], qs[k])
+                _, to_, qo_, _ = O.gn_step(Go, ts[k], qs[k])
+                d = _pose_delta(tg_, qg_, to_, qo_)
+                dts.append(d[0]); das.append(d[1])
+            out["parity"] = _parity(max(dts), max(das), what="per keyframe: Gauss-Newton step from the GPU's window Gram vs from the oracle's Gram of the same correspondences, same start",
+                                    gram_max_rel_diff=max(rel), counts_equal=bool(cnt_ok))
+            if not cnt_ok:
+                out["parity"]["pass"] = False
         except Exception as e:      # noqa: BLE001
             out["cpu"] = {"error": repr(e)}
     return out

@@ -32,6 +32,12 @@ def hdl64_elevations_deg():
     return np.where(ids <= 32, upper, lower)
 
 
+def hdl32_elevations_deg():
+    """Ring id -> elevation at the centre of the bin R/src/Preprocessing.cpp:325-326 maps back to the same id: id = int((angle + 92/3) * 3/4)
+    (truncation, no + 0.5), i.e. -30.67 .. +10.67 deg in steps of 4/3 deg — an HDL-32E."""
+    return -92.0 / 3.0 + (np.arange(32) + 0.5) * 4.0 / 3.0
+
+
 def spinning_rays(n_az=3125, elev_deg=None, az0=0.0):
     """Azimuth-major firing order (all rings per azimuth step), clockwise like a Velodyne:
     ori = -atan2(y, x) increases with time (R/src/Preprocessing.cpp:285-294,349)."""

@@ -20,6 +20,12 @@ tests/golden/{s2m,extract}_*.npz, which come from the oracle — pin the oracle 
   ref_factors.npz  LidarEdgeFactor / LidarPlaneNormFactor / LidarPlaneNormIncreFactor ::Create()->Evaluate() on random
                    records: residual + both Jacobian blocks
 
+  ref_cfg2.npz     the reference's OTHER configurations: the ROT node with the 32-ring table at ds_rate 2 and the identity
+                   extrinsic (LiLi-OM-ROT/config/config_utbm.yaml:13-14,37-40) on HDL-32E-like scans; the ROT back-end association at
+                   kd_max_radius 1.5 with utbm's extrinsic (config_utbm.yaml:34-44) on a sparser map (5th neighbours between 1.0 and 1.5 m^2);
+                   the Livox node at surf_thres 0.17 and the front-end node at scan_match_cnt 2 / max_num_iter 15 and the Livox back-end
+                   association with ka_urban_campus' constants (LiLi-OM/config/config_ka_urban_campus.yaml:5,9-10,17-19,29-36)
+
 Only runs where /root/reference exists (the build container).  Run from the repository root:
     python tests/golden/make_ref_golden.py
 """
@@ -86,9 +92,9 @@ PAYLOAD_ROT = [0, 1, 2, 4]                       # x y z intensity of the 32-byt
 PAYLOAD_LIVOX = [0, 1, 2, 4, 5, 6, 8, 9]         # x y z | normal | intensity curvature of the 48-byte PointXYZINormal
 
 
-def run_rot():
-    scans, stamps, imu_t, gyr = rot_inputs()
-    out = R.run_scans("rot", ROT_PARAMS, scans, stamps, imu_t, gyr)
+def run_rot(params=None, inputs=None):
+    scans, stamps, imu_t, gyr = (inputs or rot_inputs)()
+    out = R.run_scans("rot", params or ROT_PARAMS, scans, stamps, imu_t, gyr)
     d = dict(n_processed=len(out))
     for k, o in enumerate(out):
         d[f"stamp{k}"] = o["stamp"]
@@ -105,9 +111,9 @@ def run_rot():
     return d
 
 
-def run_livox():
+def run_livox(params=None):
     scans, stamps, imu_t, gyr = livox_inputs()
-    out = R.run_scans("livox", LIVOX_PARAMS, scans, stamps, imu_t, gyr)
+    out = R.run_scans("livox", params or LIVOX_PARAMS, scans, stamps, imu_t, gyr)
     d = dict(n_processed=len(out))
     for k, o in enumerate(out):
         d[f"stamp{k}"] = o["stamp"]
@@ -138,10 +144,10 @@ def frontend_inputs():
     return frames, stamps, imu_t, np.zeros((imu_t.shape[0], 3))
 
 
-def run_frontend():
+def run_frontend(pre_params=None, lo_params=None, full_solves=None):
     frames, stamps, imu_t, gyr = frontend_inputs()
-    pre = R.run_scans("livox", LIVOX_PARAMS, frames, stamps, imu_t, gyr)
-    lo = R.LidarOdometry(FRONTEND_PARAMS)
+    pre = R.run_scans("livox", pre_params or LIVOX_PARAMS, frames, stamps, imu_t, gyr)
+    lo = R.LidarOdometry(lo_params or FRONTEND_PARAMS)
     d = dict(n_frames=len(pre))
     abs_pose, rel_pose, kf = [], [], []
     for o in pre:
@@ -154,7 +160,7 @@ def run_frontend():
              n_queries=np.array([len(s["queries"]) for s in S]), gn_status=np.array([s["gn_status"] for s in S]),
              records_sha=np.array([sha(s["records"]) for s in S]), rows_sha=np.array([sha(s["rows"]) for s in S]),
              map_sha=np.array([sha(s["map"]) for s in S]), queries_sha=np.array([sha(s["queries"]) for s in S]))
-    for i in FRONTEND_FULL_SOLVES:
+    for i in (FRONTEND_FULL_SOLVES if full_solves is None else full_solves):
         for k in ("map", "queries", "records", "rows"):
             d[f"solve{i}_{k}"] = S[i][k]
     odom = [(st, a) for (topic, st, a) in lo.published() if topic == "/odom"]
@@ -166,15 +172,71 @@ def run_frontend():
 BACKEND_PARAMS = {   # L/config/config_fr_iosb.yaml, R/config/config_fr_iosb.yaml: kd_max_radius, surf_dist_thres, lidar_const, reflect_thres, q_lb, t_lb
     "livox": dict(kd_max_radius=1.0, surf_dist_thres=0.12, lidar_const=20.0, reflect_thres=15.0, q_lb=[0.0, 0.0, 0.0, 1.0], t_lb=[-0.0265, 0.0202, 0.05309]),
     "rot": dict(kd_max_radius=1.0, surf_dist_thres=0.12, lidar_const=7.5, reflect_thres=0.0, q_lb=[0.7071, 0.0, 0.0, 0.7071], t_lb=[-0.18, 0.0, -0.095]),
+    # R/config/config_utbm.yaml:30-44 (= config_urban_hk.yaml's matcher constants): the gate is 1.5 m^2; the map is voxelised at 0.8 m here so that a good
+    # part of the queries has its fifth neighbour BETWEEN 1.0 and 1.5 m^2 (kept at 1.5, dropped at 1.0)
+    "rot_utbm": dict(kd_max_radius=1.5, surf_dist_thres=0.12, lidar_const=7.5, reflect_thres=0.0, q_lb=[1.0, 0.0, 0.0, 0.0], t_lb=[0.5, -1.4, -1.5],
+                     room=dict(seed=14, leaf=0.8, n_query=1500, n_edge_query=200)),
+    # L/config/config_ka_urban_campus.yaml:17-19,29-36
+    "livox_ka": dict(kd_max_radius=1.0, surf_dist_thres=0.08, lidar_const=15.0, reflect_thres=15.0, q_lb=[0.0, 0.0, 1.0, 0.0], t_lb=[-0.05, -0.0202, -0.13],
+                     room=dict(seed=15, n_query=1500, n_edge_query=200)),
 }
 
 
+# ---- the reference's other configurations -> ref_cfg2.npz
+ROT32_QLB = [1.0, 0.0, 0.0, 0.0]                       # R/config/config_utbm.yaml:37-40
+ROT32_PARAMS = dict(ROT_PARAMS, **{"/preprocessing/line_num": 32, "/preprocessing/ds_rate": 2, "/backend_fusion/ql2b_w": 1.0, "/backend_fusion/ql2b_x": 0.0,
+                                   "/backend_fusion/ql2b_y": 0.0, "/backend_fusion/ql2b_z": 0.0})
+LIVOX_KA_PARAMS = {"/preprocessing/surf_thres": 0.17, "/preprocessing/edge_thres": 4.0, "/common/frame_id": "lili_om"}     # config_ka_urban_campus.yaml:5-6
+FRONTEND_KA_PARAMS = {"/common/frame_id": "lili_om", "/lidar_odometry/if_to_deskew": 0, "/lidar_odometry/max_num_iter": 15,
+                      "/lidar_odometry/scan_match_cnt": 2}                                                                   # config_ka_urban_campus.yaml:9-11
+
+
+def rot32_inputs():
+    """HDL-32E-like scans: 32 rings at the elevations the reference's 32-ring table maps back to their ids (R/src/Preprocessing.cpp:325-331), 700
+    azimuth steps, the outdoor scene, and a few points outside the table (id < 0 or > 31: dropped by the node)."""
+    sc = synth.OutdoorScene()
+    scans = []
+    for s in range(N_SCANS_IN):
+        rng = np.random.default_rng(140 + s)
+        dirs, ring, rel = synth.spinning_rays(700, synth.hdl32_elevations_deg(), az0=0.013 * s)
+        t = sc.raycast(np.array([0.4 * s, 0.1 * s, 1.8]), dirs)
+        ok = np.isfinite(t)
+        t = t + rng.normal(0, 0.02, t.shape)
+        pts = (dirs * t[:, None])[ok].astype(np.float32)
+        refl = rng.integers(1, 255, pts.shape[0]).astype(np.float32)
+        raw = np.concatenate([pts, refl[:, None]], 1).astype(np.float32)
+        bad = rng.choice(raw.shape[0], 60, replace=False)
+        raw[bad[:30], 2] = np.abs(raw[bad[:30], 2]) + 0.35 * np.linalg.norm(raw[bad[:30], :2], axis=1)      # above +10.67 deg: id > 31
+        raw[bad[30:], 2] = -np.abs(raw[bad[30:], 2]) - 0.8 * np.linalg.norm(raw[bad[30:], :2], axis=1)      # below -30.67 deg: id < 0
+        scans.append(raw)
+    stamps = 200.0 + 0.1 * np.arange(N_SCANS_IN)
+    imu_t = 199.95 + 0.005 * np.arange(100)
+    gyr = 0.2 * np.random.default_rng(15).standard_normal((100, 3)) + np.array([-0.1, 0.05, 0.25])
+    return scans, stamps, imu_t, gyr
+
+
+def run_cfg2():
+    d = {}
+    for k, v in run_rot(ROT32_PARAMS, rot32_inputs).items():
+        d[f"rot32_{k}"] = v
+    for k, v in run_backend(("rot_utbm", "livox_ka")).items():
+        d[k] = v
+    lv = run_livox(LIVOX_KA_PARAMS)
+    for k, v in lv.items():
+        d[f"livoxka_{k}"] = v
+    fe = run_frontend(LIVOX_KA_PARAMS, FRONTEND_KA_PARAMS, full_solves=())
+    for k in ("n_frames", "abs_pose", "rel_pose", "kf", "n_solves", "pose_in", "pose_out", "n_blocks", "n_queries", "gn_status", "records_sha"):
+        d[f"frontendka_{k}"] = fe[k]
+    return d
+
+
+
 def backend_inputs(flavour):
-    """Room scene + a body pose 5 cm / 0.5 deg off; (Q2, T2) = the LiDAR pose handed to the find* functions
+    """Room scene (BACKEND_PARAMS[flavour]["room"]: seed / map leaf) + a body pose 5 cm / 0.5 deg off; (Q2, T2) = the LiDAR pose handed to the find* functions
     (Q2 = q * q_lb^-1, T2 = t - Q2 t_lb, L/src/BackendFusion.cpp:929-930), all in numpy f64 with Eigen's expressions."""
     from tests import frontend_chain as F
-    room = synth.make_room(seed=12, n_query=1500, n_edge_query=200)
     B = BACKEND_PARAMS[flavour]
+    room = synth.make_room(**dict(dict(seed=12, n_query=1500, n_edge_query=200), **B.get("room", {})))
     qlb, tlb = np.array(B["q_lb"]), np.array(B["t_lb"])
     # body pose from the scene's LiDAR pose: q_b = q_l * q_lb, t_b = t_l + q_l * t_lb  (inverse of the two lines above for unit q_lb)
     q_l, t_l = room["q_true"], room["t_true"]
@@ -188,16 +250,17 @@ def backend_inputs(flavour):
                 t0=t0, q0=q0, Q2=Q2, T2=T2, qlb=qlb, tlb=tlb)
 
 
-def run_backend():
+def run_backend(flavours=("livox", "rot")):
     d = {}
-    for fl in ("livox", "rot"):
-        i, B = backend_inputs(fl), BACKEND_PARAMS[fl]
+    for key in flavours:
+        fl = key.split("_")[0]
+        i, B = backend_inputs(key), BACKEND_PARAMS[key]
         srec, erec = R.backend_associate(fl, i["surf_map"], i["edge_map"], i["surf_q"], i["edge_q"], i["Q2"], i["T2"], B["kd_max_radius"],
                                          B["surf_dist_thres"], B["lidar_const"], B["reflect_thres"])
         srows, erows = R.backend_rows(fl, srec, erec, i["qlb"], i["tlb"], i["t0"], i["q0"])
-        d.update({f"{fl}_t0": i["t0"], f"{fl}_q0": i["q0"], f"{fl}_Q2": i["Q2"], f"{fl}_T2": i["T2"],
-                  f"{fl}_surf_rec": srec[:, :7].astype(np.float32), f"{fl}_surf_score": srec[:, 7], f"{fl}_edge_rec": erec.astype(np.float32),
-                  f"{fl}_surf_rows": srows, f"{fl}_edge_rows": erows})
+        d.update({f"{key}_t0": i["t0"], f"{key}_q0": i["q0"], f"{key}_Q2": i["Q2"], f"{key}_T2": i["T2"],
+                  f"{key}_surf_rec": srec[:, :7].astype(np.float32), f"{key}_surf_score": srec[:, 7], f"{key}_edge_rec": erec.astype(np.float32),
+                  f"{key}_surf_rows": srows, f"{key}_edge_rows": erows})
         assert np.array_equal(srec[:, :7].astype(np.float32).astype(np.float64), srec[:, :7]) and np.array_equal(erec.astype(np.float32).astype(np.float64), erec)
     return d
 
@@ -293,7 +356,8 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ref_format.npz"), **run_format())
     np.savez_compressed(os.path.join(HERE, "ref_marg.npz"), **run_marg())
     np.savez_compressed(os.path.join(HERE, "ref_localmap.npz"), **run_localmap())
-    for f in ("ref_rot.npz", "ref_livox.npz", "ref_factors.npz", "ref_frontend.npz", "ref_backend.npz", "ref_format.npz", "ref_marg.npz", "ref_localmap.npz"):
+    np.savez_compressed(os.path.join(HERE, "ref_cfg2.npz"), **run_cfg2())
+    for f in ("ref_cfg2.npz", "ref_rot.npz", "ref_livox.npz", "ref_factors.npz", "ref_frontend.npz", "ref_backend.npz", "ref_format.npz", "ref_marg.npz", "ref_localmap.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 
