@@ -296,6 +296,11 @@ def config4(L, ctx, torch, synth, cpu=True):
     evals = sum(len(s["log"]) + 1 for s in summ) / K
     sec_lm = _wall(lm, 20, torch)
     t_pose = _wall(lambda: [m.pose_set(k, ts[k], qs[k]) for k in range(K)], 20, torch)
+    # the same solves allowed to run to convergence (the reference's max_num_iter 15 / 20 ends most of its solves by the iteration cap; VERDICT r3 #7 asks
+    # for a case that exercises a tolerance exit): Ceres defaults otherwise
+    for k in range(K):
+        m.pose_set(k, ts[k], qs[k])
+    conv = m.solve_lm_window(slots, mask, options=m.lm_options(max_iterations=100))
     alg_eval = 41 * (room["q_xyz"].shape[0] + room["eq_xyz"].shape[0]) * K
     out = {"value": round(1.0 / sec_eval, 1), "unit": "window evaluations/s", "us_per_window_evaluation": round(sec_eval * 1e6, 2),
            "workload": f"configs[4] substitute (no FR_IOSB bag offline): sliding window of {K} keyframes x ({room['q_xyz'].shape[0]} surf + {room['eq_xyz'].shape[0]} edge features), Livox back-end flavour, "
@@ -305,8 +310,11 @@ def config4(L, ctx, torch, synth, cpu=True):
            "device_lm": {"us_per_window_solve": round((sec_lm - t_pose) * 1e6, 2), "evaluations_per_keyframe": round(evals, 2),
                          "us_per_evaluation": round((sec_lm - t_pose) * 1e6 / max(evals, 1), 2),
                          "termination": [s["termination"] for s in summ], "successful_steps": [s["successful_steps"] for s in summ],
+                         "run_to_convergence": {"max_iterations": 100, "termination": [s["termination"] for s in conv], "iterations": [s["iterations"] for s in conv],
+                                                "successful_steps": [s["successful_steps"] for s in conv], "final_cost": [s["final_cost"] for s in conv]},
                          "note": "lili_s2m_solve_lm_window: the three keyframes' lidar-only LM solves (Ceres defaults, <= 15 iterations) as three persistent launches side by side, no host round trip per evaluation"},
            "algorithmic_bytes": int(alg_eval), "roofline": {"bound": "hbm", "frac": _frac(alg_eval, sec_eval), "peak": HBM_PEAK_GBS, "unit": "GB/s"}}
+    out["cpp_seam"] = _cpp_window_seam(L, room, K)
     if cpu:
         try:
             from oracle import oracle as O
@@ -344,6 +352,31 @@ def config4(L, ctx, torch, synth, cpu=True):
         except Exception as e:      # noqa: BLE001
             out["cpu"] = {"error": repr(e)}
     return out
+
+
+def _cpp_window_seam(L, room, K):
+    """The same seam timed from C++ (examples/s2m_demo --window: no ctypes between the caller and the C ABI): K slots of the room's surf features (ROT
+    flavour), one lili_s2m_linearize_window per evaluation next to K lili_s2m_linearize calls.  Its own process, its own context."""
+    import json, os, struct, subprocess, tempfile
+    demo = os.path.join(os.path.dirname(os.path.abspath(__file__)), "examples", "s2m_demo")
+    if not os.path.exists(demo):
+        return {"error": "examples/s2m_demo not built"}
+    P = L.make_params("rot")
+    tb, qb = L.api.body_pose_from_lidar(room["t_true"], room["q_true"], P)
+    try:
+        with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+            f.write(struct.pack("<qqii", room["map_xyz"].shape[0], room["q_xyz"].shape[0], int(P.variant), 0))
+            f.write(np.concatenate([tb, qb]).astype("<f8").tobytes())
+            f.write(np.ascontiguousarray(room["map_xyz"], "<f4").tobytes())
+            f.write(np.ascontiguousarray(room["q_xyz"], "<f4").tobytes())
+            path = f.name
+        r = subprocess.run([demo, path, "--window", str(K), "300"], capture_output=True, text=True, timeout=120)
+        os.unlink(path)
+        if r.returncode != 0:
+            return {"error": f"rc {r.returncode}: {r.stderr[-300:]} {r.stdout[-300:]}"}
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:      # noqa: BLE001
+        return {"error": repr(e)}
 
 
 # ------------------------------------------------------------------------------------------------------------------------------

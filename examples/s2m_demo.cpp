@@ -2,13 +2,18 @@
 // maintainer places in BackendFusion / LidarOdometry, here fed from a small binary file.
 //
 //   s2m_demo <input.bin> [n_iters]
+//   s2m_demo <input.bin> --window K [reps]     the blocking Ceres seam of a K-keyframe window timed from C++ (no ctypes in the way): the same scan in K
+//                                              slots, lili_s2m_associate_window once, then `reps` evaluations through lili_s2m_linearize_window (ONE call per
+//                                              evaluation of the window, what lili::LidarWindowFactor::Evaluate issues) next to K lili_s2m_linearize calls
 // input.bin (little endian): int64 n_map, int64 n_query, int32 variant, int32 pad, double pose[7] (t xyz, q wxyz),
 //                            float map[n_map][3], float query[n_query][3]
 // Prints the pose after n_iters outer Gauss-Newton iterations with 17 significant digits (one line), the GN status
 // and the correspondence count of the last association.
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "lili_hip.h"
@@ -54,6 +59,51 @@ int main(int argc, char** argv) {
     lili_cloud cm{map.data(), (size_t)n_map, 12, -1, LILI_MEM_HOST};
     lili_cloud cq{qry.data(), (size_t)n_q, 12, -1, LILI_MEM_HOST};
     CHECK(lili_map_set(ctx, LILI_KIND_SURF, &cm, P.kd_max_radius));       // kd_tree_surf_local_map->setInputCloud
+    if (argc > 3 && std::strcmp(argv[2], "--window") == 0) {
+        const int K = std::atoi(argv[3]), reps = argc > 4 ? std::atoi(argv[4]) : 300;
+        if (K < 1 || K > LILI_MAX_SLOTS) { std::fprintf(stderr, "--window K: 1..%d\n", LILI_MAX_SLOTS); return 1; }
+        int slots[LILI_MAX_SLOTS]; double ts[3 * LILI_MAX_SLOTS], qs[4 * LILI_MAX_SLOTS], Ta[3 * LILI_MAX_SLOTS], Qa[4 * LILI_MAX_SLOTS];
+        for (int k = 0; k < K; k++) {
+            slots[k] = k;
+            CHECK(lili_s2m_set_queries(ctx, k, LILI_KIND_SURF, &cq));
+            for (int i = 0; i < 3; i++) ts[3 * k + i] = pose[i] + 0.001 * k;
+            for (int i = 0; i < 4; i++) qs[4 * k + i] = pose[3 + i];
+            // association pose (Q2, T2) = (Q q_lb^-1, T - Q2 t_lb), L/src/BackendFusion.cpp:929-930
+            const double* b = P.q_lb; const double* q = qs + 4 * k; const double* t = ts + 3 * k;
+            const double n2 = b[0] * b[0] + b[1] * b[1] + b[2] * b[2] + b[3] * b[3];
+            const double iw = b[0] / n2, ix = -b[1] / n2, iy = -b[2] / n2, iz = -b[3] / n2;
+            double* Q2 = Qa + 4 * k; double* T2 = Ta + 3 * k;
+            Q2[0] = q[0] * iw - q[1] * ix - q[2] * iy - q[3] * iz;
+            Q2[1] = q[0] * ix + q[1] * iw + q[2] * iz - q[3] * iy;
+            Q2[2] = q[0] * iy - q[1] * iz + q[2] * iw + q[3] * ix;
+            Q2[3] = q[0] * iz + q[1] * iy - q[2] * ix + q[3] * iw;
+            const double ux = Q2[1], uy = Q2[2], uz = Q2[3], w = Q2[0], vx = P.t_lb[0], vy = P.t_lb[1], vz = P.t_lb[2];
+            const double cx = 2 * (uy * vz - uz * vy), cy = 2 * (uz * vx - ux * vz), cz = 2 * (ux * vy - uy * vx);
+            T2[0] = t[0] - (vx + w * cx + (uy * cz - uz * cy));
+            T2[1] = t[1] - (vy + w * cy + (uz * cx - ux * cz));
+            T2[2] = t[2] - (vz + w * cz + (ux * cy - uy * cx));
+        }
+        int n_res[2 * LILI_MAX_SLOTS];
+        auto us = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count(); };
+        CHECK(lili_s2m_associate_window(ctx, slots, K, LILI_MASK_SURF, Ta, Qa, &P, n_res));
+        auto t0 = std::chrono::steady_clock::now();
+        for (int r = 0; r < 50; r++) CHECK(lili_s2m_associate_window(ctx, slots, K, LILI_MASK_SURF, Ta, Qa, &P, n_res));
+        const double us_assoc = us(t0) / 50;
+        double gram[64 * LILI_MAX_SLOTS], cost[LILI_MAX_SLOTS], g1[64 * LILI_MAX_SLOTS], c1[LILI_MAX_SLOTS]; int cnt[2 * LILI_MAX_SLOTS], n1[2 * LILI_MAX_SLOTS];
+        for (int r = 0; r < 20; r++) CHECK(lili_s2m_linearize_window(ctx, slots, K, LILI_MASK_SURF, ts, qs, &P, gram, cost, cnt));
+        t0 = std::chrono::steady_clock::now();
+        for (int r = 0; r < reps; r++) CHECK(lili_s2m_linearize_window(ctx, slots, K, LILI_MASK_SURF, ts, qs, &P, gram, cost, cnt));
+        const double us_win = us(t0) / reps;
+        for (int r = 0; r < 20; r++) for (int k = 0; k < K; k++) CHECK(lili_s2m_linearize(ctx, k, LILI_MASK_SURF, ts + 3 * k, qs + 4 * k, &P, g1 + 64 * k, c1 + k, n1 + 2 * k));
+        t0 = std::chrono::steady_clock::now();
+        for (int r = 0; r < reps; r++) for (int k = 0; k < K; k++) CHECK(lili_s2m_linearize(ctx, k, LILI_MASK_SURF, ts + 3 * k, qs + 4 * k, &P, g1 + 64 * k, c1 + k, n1 + 2 * k));
+        const double us_per_slot = us(t0) / reps;
+        const bool same = std::memcmp(gram, g1, sizeof(double) * 64 * K) == 0 && std::memcmp(cost, c1, sizeof(double) * K) == 0 && std::memcmp(cnt, n1, sizeof(int) * 2 * K) == 0;
+        std::printf("{\"window_slots\": %d, \"features_per_slot\": %lld, \"correspondences_slot0\": %d, \"us_per_window_evaluation\": %.2f, \"us_per_evaluation_as_K_single_calls\": %.2f, "
+                    "\"us_per_window_association\": %.2f, \"window_equals_single_calls_bit_for_bit\": %s}\n", K, (long long)n_q, n_res[0], us_win, us_per_slot, us_assoc, same ? "true" : "false");
+        lili_ctx_destroy(ctx);
+        return same ? 0 : 3;
+    }
     CHECK(lili_s2m_set_queries(ctx, 0, LILI_KIND_SURF, &cq));
     CHECK(lili_s2m_pose_set(ctx, 0, pose, pose + 3));
     CHECK(lili_s2m_iterate(ctx, 0, LILI_MASK_SURF, &P, n_iters));          // n x (findCorrespondingSurfFeatures + linearise + GN)

@@ -307,7 +307,8 @@ int lili_s2m_last_step(lili_ctx* ctx, int slot, double delta[6], int* n_updates,
  * monotonic steps, function / gradient / parameter tolerances 1e-6 / 1e-10 / 1e-8).  lili_s2m_solve_lm runs that loop for
  * the lidar blocks of ONE slot — both kinds in kind_mask, robustified by params->loss — as ONE persistent launch: every iteration evaluates
  * all records at the candidate pose (robust cost + Gram), the workgroups exchange their partials inside the launch and each takes the same
- * accept / reject decision; the pose of the slot ends at the last accepted point.  Decisions and final pose equal the oracle's restatement
+ * accept / reject decision; the pose of the slot ends at the last accepted point — a candidate that triggers the parameter or the function
+ * tolerance is NOT taken (Ceres returns before HandleSuccessfulStep).  Decisions and final pose equal the oracle's restatement
  * of Ceres' loop on per-residual rows (oracle/lo_window.py::ceres_lm; tests/test_lm_gpu.py).  Needs lili_s2m_associate* first.
  * options == NULL: the defaults above with max_iterations = 15.  summary (host memory, optional): filled after a synchronisation of the
  * context's stream; with summary == NULL the call is asynchronous.  Not to be overlapped with other persistent launches of the same
@@ -315,7 +316,8 @@ int lili_s2m_last_step(lili_ctx* ctx, int slot, double delta[6], int* n_updates,
  * LILI_LM_STALLED rather than a hang). */
 #define LILI_LM_MAX_LOG 32
 enum { LILI_LM_MAX_ITERATIONS = 0, LILI_LM_GRADIENT_TOLERANCE = 1, LILI_LM_PARAMETER_TOLERANCE = 2, LILI_LM_FUNCTION_TOLERANCE = 3,
-       LILI_LM_STALLED = 4, LILI_LM_NUMERICAL_FAILURE = 5 };
+       LILI_LM_STALLED = 4, LILI_LM_NUMERICAL_FAILURE = 5 /* a non-positive pivot, or 5 consecutive invalid steps (Ceres: FAILURE) */,
+       LILI_LM_MIN_RADIUS = 6 /* trust-region radius <= min_radius (Ceres: CONVERGENCE, "minimum trust region radius reached") */ };
 typedef struct lili_lm_options {
     int32_t max_iterations;
     int32_t reserved_;

@@ -41,7 +41,7 @@ class LivoxParams(C.Structure):
 
 
 LM_MAX_LOG = 32
-LM_TERMINATION = {0: "max_iterations", 1: "gradient_tolerance", 2: "parameter_tolerance", 3: "function_tolerance", 4: "stalled", 5: "numerical_failure"}
+LM_TERMINATION = {0: "max_iterations", 1: "gradient_tolerance", 2: "parameter_tolerance", 3: "function_tolerance", 4: "stalled", 5: "numerical_failure", 6: "min_radius"}
 
 
 class LmOptions(C.Structure):

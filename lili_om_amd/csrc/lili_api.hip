@@ -40,6 +40,7 @@ __global__ void k_sum_counts(const int*, int, const int*, int, SlotState*, int*,
 __global__ void k_gn_update(const double*, SlotState*);
 __global__ void k_pose_copy(SlotState*, const SlotState*);
 __global__ void k_window_reduce(WindowArgs, double*, int, P2PView);
+__global__ void k_linearize_window(WinLinArgs, MatchParams);
 __global__ void k_window_gn(WindowArgs, const double*);
 __global__ void k_window_counts(WindowArgs, int*, P2PView);
 // lili_s2m_lm.hip: the Levenberg-Marquardt loop on fixed correspondences, one persistent launch
@@ -194,7 +195,7 @@ void lili_ctx_destroy(lili_ctx* ctx) {
     for (auto& s : ctx->slots) for (auto& k : s.k) { k.q.release(); k.rec0.release(); k.rec1.release(); k.valid.release(); k.dbg_idx.release(); k.dbg_d2.release(); k.partials.release(); k.partials_wave.release(); k.perm.release(); k.keys.release(); k.block_counts.release(); k.tiles.release(); }
     if (ctx->h_records) { (void)hipHostFree(ctx->h_records); ctx->h_records = nullptr; }
     if (ctx->h_pin) { (void)hipHostFree(ctx->h_pin); ctx->h_pin = nullptr; }
-    ctx->states.release(); ctx->staging.release(); ctx->gram.release(); ctx->misc.release(); ctx->bin_hist.release(); ctx->bin_start.release(); ctx->bin_sums.release(); ctx->bin_tcnt.release(); ctx->bin_toff.release();
+    ctx->states.release(); ctx->staging.release(); ctx->gram.release(); ctx->win_rec.release(); ctx->win_counts.release(); ctx->misc.release(); ctx->bin_hist.release(); ctx->bin_start.release(); ctx->bin_sums.release(); ctx->bin_tcnt.release(); ctx->bin_toff.release();
     if (ctx->ext_rot && ctx->ext_rot_free) ctx->ext_rot_free(ctx->ext_rot);
     if (ctx->ext_livox && ctx->ext_livox_free) ctx->ext_livox_free(ctx->ext_livox);
     if (ctx->ext_voxel && ctx->ext_voxel_free) ctx->ext_voxel_free(ctx->ext_voxel);
@@ -339,9 +340,15 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
 
 }  // extern "C"
 
+static int map_set_hinted_impl(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq_radius, const unsigned* box6, bool in_place);
 int lili_map_set_hinted(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq_radius, const unsigned* box6, bool in_place) {
     if (!ctx) return LILI_E_ARG;
     ARGCHK(kind == LILI_KIND_SURF || kind == LILI_KIND_EDGE, "map_set: bad kind");
+    const int rc = map_set_hinted_impl(ctx, kind, cloud, max_sq_radius, box6, in_place);
+    ctx->map[kind].pts_ext = nullptr;        // only meaningful DURING the build: whatever way it ended, nothing keeps a pointer into the caller's array
+    return rc;
+}
+static int map_set_hinted_impl(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq_radius, const unsigned* box6, bool in_place) {
     ARGCHK(cloud, "map_set: null cloud");
     ARGCHK(max_sq_radius > 0 && std::isfinite(max_sq_radius), "map_set: max_sq_radius must be positive");
     ARGCHK(cloud->n < (1ll << 28), "map_set: at most 2^28 - 1 map points (32-bit byte offsets into the sorted array)");
@@ -1036,6 +1043,7 @@ int lili_s2m_associate(lili_ctx* ctx, int slot, int kind, const double t_assoc[3
     return LILI_OK;
 }
 
+static int window_args(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, WindowArgs& w, const char* who);
 // Association of SEVERAL slots in one call (the keyframes of the sliding window, L/src/BackendFusion.cpp:919-936: findCorrespondingSurfFeatures +
 // findCorrespondingCornerFeatures per keyframe): both kinds of a slot share a launch where possible, the slots run on forked streams, the
 // correspondence counts come back in ONE synchronisation.  Results are those of lili_s2m_associate per slot and kind.
@@ -1054,8 +1062,6 @@ int lili_s2m_associate_window(lili_ctx* ctx, const int* slots, int n_slots, int 
     HIPCHK(hipEventRecord(ctx->fork_ev, ctx->stream));
     hipStream_t main_stream = ctx->stream;
     const MatchParams P = to_device_params(params);
-    if (!ctx->h_records) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_records), (size_t)LILI_MAX_SLOTS * LILI_GRAM_DOUBLES * sizeof(double), hipHostMallocDefault));
-    int* host = reinterpret_cast<int*>(ctx->h_records);
     int rc = LILI_OK;
     for (int i = 0; i < n_slots && rc == LILI_OK; i++) {
         if (i > 0) {
@@ -1075,70 +1081,56 @@ int lili_s2m_associate_window(lili_ctx* ctx, const int* slots, int n_slots, int 
             for (int kind = 0; kind < 2 && rc == LILI_OK; kind++) if (kind_mask & (1 << kind)) rc = launch_associate(ctx, slots[i], kind, pa, P);
         }
         hipError_t e = hipSuccess;
-        if (rc == LILI_OK && n_res) {
-            rc = launch_sum_counts(ctx, slots[i], kind_mask);
-            if (rc == LILI_OK) e = hipMemcpyAsync(host + 2 * i, ctx->state(slots[i])->n_res, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
-        }
         if (i > 0) {
-            if (e == hipSuccess) e = hipEventRecord(ctx->join_ev[i], ctx->side[i]);
+            e = hipEventRecord(ctx->join_ev[i], ctx->side[i]);
             ctx->stream = main_stream;
             if (e == hipSuccess) e = hipStreamWaitEvent(main_stream, ctx->join_ev[i], 0);
         }
         if (e != hipSuccess) { ctx->stream = main_stream; return ctx->fail(LILI_E_HIP, std::string("associate_window: ") + hipGetErrorString(e)); }
     }
     ctx->stream = main_stream;
-    if (n_res || rc != LILI_OK) HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (rc != LILI_OK) return rc;
-    if (n_res) for (int i = 0; i < n_slots; i++) {
-        n_res[2 * i] = (kind_mask & LILI_MASK_SURF) ? host[2 * i] : 0;
-        n_res[2 * i + 1] = (kind_mask & LILI_MASK_EDGE) ? host[2 * i + 1] : 0;
+    if (rc != LILI_OK) { HIPCHK(hipStreamSynchronize(ctx->stream)); return rc; }      // nothing of this call stays in flight
+    if (n_res) {
+        // the counts of every slot in ONE launch (k_window_counts: [surf, edge] per slot, also left in the slots' states) and ONE read-back
+        // through the page-locked scratch — it was one k_sum_counts + one copy per slot on the forked streams
+        WindowArgs w;
+        if ((rc = window_args(ctx, slots, n_slots, kind_mask, w, "associate_window")) != LILI_OK) return rc;
+        HIPCHK(ctx->win_counts.ensure(sizeof(int) * 2 * LILI_MAX_SLOTS));
+        hipLaunchKernelGGL(k_window_counts, dim3(1), dim3(kBlock), 0, ctx->stream, w, ctx->win_counts.as<int>(), P2PView{});
+        HIPCHK(hipGetLastError());
+        int host[2 * LILI_MAX_SLOTS];
+        rc = lili_readback_add(ctx, host, ctx->win_counts.p, sizeof(int) * 2 * n_slots);
+        if (rc == LILI_OK) rc = lili_readback_finish(ctx);
+        if (rc != LILI_OK) return rc;
+        for (int i = 0; i < n_slots; i++) {
+            n_res[2 * i] = (kind_mask & LILI_MASK_SURF) ? host[2 * i] : 0;
+            n_res[2 * i + 1] = (kind_mask & LILI_MASK_EDGE) ? host[2 * i + 1] : 0;
+        }
     }
     return LILI_OK;
 }
 
 // Linearisation of SEVERAL slots in one call (one evaluation of the joint sliding window: a Gram per keyframe, L/src/BackendFusion.cpp:919-980 under
-// ceres::Solve's up to 15 evaluations): the slots' launches go out on forked streams like lili_s2m_iterate_window, the records come back in ONE
-// synchronisation instead of one per keyframe.  Results are those of lili_s2m_linearize per slot, bit for bit.
+// ceres::Solve's up to 15 evaluations; the body of lili::LidarWindowFactor::Evaluate in include/lili_ceres_adapter.h).  Round 4: TWO launches and
+// ONE read-back whatever the number of keyframes — k_linearize_window (every slot's records, the slot in the block index), k_window_reduce (every
+// slot's block partials -> n x 72 doubles), one copy through the page-locked scratch, one synchronisation.  It was three forked streams, three
+// event pairs, 2 n launches and n copies (80 us per 3-keyframe evaluation against 29 us for one keyframe alone).  Results are those of
+// lili_s2m_linearize per slot, bit for bit (same bodies, same block geometry, the additions of reduce_partials_block in the same order).
+static int linearize_window_impl(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, const lili_s2m_params* params, const double* t, const double* q,
+                                 lili_allreduce_fn allreduce, void* comm, double* d_gram, int do_gn);
 int lili_s2m_linearize_window(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, const double* t /*3 per slot*/, const double* q /*4 per slot*/,
                               const lili_s2m_params* params, double* gram /*64 per slot*/, double* cost /*1 per slot, optional*/, int* counts /*2 per slot, optional*/) {
     if (!ctx) return LILI_E_ARG;
     ARGCHK(slots && n_slots >= 1 && n_slots <= LILI_MAX_SLOTS, "linearize_window: 1..LILI_MAX_SLOTS slots");
     ARGCHK((kind_mask & ~3) == 0 && kind_mask != 0, "linearize_window: bad kind mask");
     ARGCHK(t && q && params && gram, "linearize_window: null argument");
-    for (int i = 0; i < n_slots; i++) {
-        ARGCHK(slots[i] >= 0 && slots[i] < LILI_MAX_SLOTS, "linearize_window: bad slot");
-        for (int k = 0; k < i; k++) ARGCHK(slots[k] != slots[i], "linearize_window: duplicate slot");
-    }
     HIPCHK(hipSetDevice(ctx->device));
-    if (!ctx->fork_ev) HIPCHK(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(ctx->fork_ev, ctx->stream));
-    hipStream_t main_stream = ctx->stream;
-    const MatchParams P = to_device_params(params);
-    if (!ctx->h_records) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_records), (size_t)LILI_MAX_SLOTS * LILI_GRAM_DOUBLES * sizeof(double), hipHostMallocDefault));
-    double* host = ctx->h_records;
-    int rc = LILI_OK;
-    for (int i = 0; i < n_slots && rc == LILI_OK; i++) {
-        if (i > 0) {
-            if (!ctx->side[i]) HIPCHK(hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking));
-            if (!ctx->join_ev[i]) HIPCHK(hipEventCreateWithFlags(&ctx->join_ev[i], hipEventDisableTiming));
-            HIPCHK(hipStreamWaitEvent(ctx->side[i], ctx->fork_ev, 0));
-            ctx->stream = ctx->side[i];          // the launch helpers enqueue on ctx->stream (one thread per context)
-        }
-        PoseArg pa{};
-        for (int k = 0; k < 3; k++) pa.t[k] = t[3 * i + k];
-        for (int k = 0; k < 4; k++) pa.q[k] = q[4 * i + k];
-        rc = launch_linearize_reduce(ctx, slots[i], kind_mask, pa, P, ctx->gram_of(slots[i]), 0);
-        hipError_t e = rc == LILI_OK ? hipMemcpyAsync(host + (size_t)i * LILI_GRAM_DOUBLES, ctx->gram_of(slots[i]), LILI_GRAM_DOUBLES * sizeof(double),
-                                                       hipMemcpyDeviceToHost, ctx->stream) : hipSuccess;
-        if (i > 0) {
-            if (e == hipSuccess) e = hipEventRecord(ctx->join_ev[i], ctx->side[i]);
-            ctx->stream = main_stream;
-            if (e == hipSuccess) e = hipStreamWaitEvent(main_stream, ctx->join_ev[i], 0);
-        }
-        if (e != hipSuccess) { ctx->stream = main_stream; return ctx->fail(LILI_E_HIP, std::string("linearize_window: ") + hipGetErrorString(e)); }
-    }
-    ctx->stream = main_stream;
-    HIPCHK(hipStreamSynchronize(ctx->stream));       // also when a launch failed: nothing of this call stays in flight
+    HIPCHK(ctx->win_rec.ensure(sizeof(double) * LILI_GRAM_DOUBLES * LILI_MAX_SLOTS));
+    int rc = linearize_window_impl(ctx, slots, n_slots, kind_mask, params, t, q, nullptr, nullptr, ctx->win_rec.as<double>(), 0);
+    if (rc != LILI_OK) return rc;
+    double host[LILI_GRAM_DOUBLES * LILI_MAX_SLOTS];
+    rc = lili_readback_add(ctx, host, ctx->win_rec.p, sizeof(double) * LILI_GRAM_DOUBLES * n_slots);
+    if (rc == LILI_OK) rc = lili_readback_finish(ctx);
     if (rc != LILI_OK) return rc;
     for (int i = 0; i < n_slots; i++) {
         const double* h = host + (size_t)i * LILI_GRAM_DOUBLES;
@@ -1425,6 +1417,8 @@ static int launch_solve_lm(lili_ctx* ctx, int slot, int kind_mask, const lili_s2
     constexpr int kLmThreads = 512;      // must match lili_s2m_lm.hip
     const int want_s = a.S.n_q > 0 ? nblocks(a.S.n_q, kLmThreads) : 0, want_e = a.E.n_q > 0 ? nblocks(a.E.n_q, kLmThreads) : 0;
     int nb_s = want_s, nb_e = want_e;
+    if (want_s > 0 && want_e > 0 && max_blocks < 2)     // every kind present needs a workgroup of its own, and all of them must be resident
+        return ctx->fail(LILI_E_STATE, "solve_lm: fewer resident workgroups available than feature kinds (too many slots side by side)");
     if (nb_s + nb_e > max_blocks) {
         nb_e = want_e ? std::max(1, (int)((int64_t)max_blocks * want_e / (want_s + want_e))) : 0;
         nb_s = want_s ? std::max(1, max_blocks - nb_e) : 0;
@@ -1671,6 +1665,43 @@ static int launch_linearize_only(lili_ctx* ctx, int slot, int kind_mask, const P
     HIPCHK(hipGetLastError());
     return LILI_OK;
 }
+// k_linearize of EVERY slot of a window in ONE launch (k_linearize_window), block partials left in the slots' buffers.  t / q: 3 / 4 doubles per
+// slot (host poses), or both null for the slots' device poses.  Bit-identical to launch_linearize_only slot by slot (same bodies, same block geometry).
+static int launch_linearize_window(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, const double* t, const double* q, const MatchParams& P) {
+    if (n_slots == 1) {
+        PoseArg pa{};
+        if (t && q) { for (int k = 0; k < 3; k++) pa.t[k] = t[k]; for (int k = 0; k < 4; k++) pa.q[k] = q[k]; }
+        else pa.state = ctx->state(slots[0]);
+        return launch_linearize_only(ctx, slots[0], kind_mask, pa, P);
+    }
+    WinLinArgs W{};
+    int nb = 0;
+    for (int i = 0; i < n_slots; i++) {
+        Slot& s = ctx->slots[slots[i]];
+        WinLinSlot& ws = W.s[W.n];
+        ws = WinLinSlot{};
+        int n_kinds = 0;
+        for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) {
+            KindSlot& ks = s.k[kind];
+            if (!ks.has_records) return ctx->fail(LILI_E_STATE, "linearize: associate first");
+            if (ks.n_q == 0) continue;
+            (kind == 0 ? ws.S : ws.E) = lin_args_of(ctx, slots[i], kind);
+            n_kinds++;
+        }
+        if (n_kinds == 0) continue;             // nothing to linearise for this slot: k_window_reduce sees nb = 0 and writes a zero record
+        if (t && q) { for (int k = 0; k < 3; k++) ws.pa.t[k] = t[3 * i + k]; for (int k = 0; k < 4; k++) ws.pa.q[k] = q[4 * i + k]; }
+        else ws.pa.state = ctx->state(slots[i]);
+        ws.state = ctx->state(slots[i]);
+        ws.n_global = s.use_global_counts ? s.global_counts : nullptr;
+        ws.first_block = nb;
+        nb += ws.S.nb + ws.E.nb;
+        W.n++;
+    }
+    if (nb == 0) return LILI_OK;
+    hipLaunchKernelGGL(k_linearize_window, dim3(nb), dim3(kLinBlock), lds_linearize(kLinBlock), ctx->stream, W, P);
+    HIPCHK(hipGetLastError());
+    return LILI_OK;
+}
 static bool p2p_comm(lili_ctx* ctx, lili_allreduce_fn allreduce, void* comm, lili_p2p** out) {
     *out = (allreduce == &lili_p2p_allreduce && lili_p2p_usable(reinterpret_cast<lili_p2p*>(comm), ctx) && !ctx->no_p2p_fusion) ? reinterpret_cast<lili_p2p*>(comm) : nullptr;
     return !(allreduce == &lili_p2p_allreduce && comm && lili_p2p_status(reinterpret_cast<lili_p2p*>(comm)) != 0);      // false: the communicator has failed
@@ -1707,12 +1738,7 @@ static int linearize_window_impl(lili_ctx* ctx, const int* slots, int n_slots, i
     if (!p2p_comm(ctx, allreduce, comm, &p2p)) return ctx->fail(LILI_E_STATE, "linearize_window_sharded: the lili_p2p communicator has failed");
     MatchParams P = to_device_params(params);
     if (do_gn) P.no_cost = 1;
-    for (int i = 0; i < n_slots; i++) {
-        PoseArg pa{};
-        if (t && q) { for (int k = 0; k < 3; k++) pa.t[k] = t[3 * i + k]; for (int k = 0; k < 4; k++) pa.q[k] = q[4 * i + k]; }
-        else pa.state = ctx->state(slots[i]);
-        if ((rc = launch_linearize_only(ctx, slots[i], kind_mask, pa, P)) != LILI_OK) return rc;
-    }
+    if ((rc = launch_linearize_window(ctx, slots, n_slots, kind_mask, t, q, P)) != LILI_OK) return rc;
     const bool in_kernel = p2p != nullptr || allreduce == nullptr;        // exchange (or none: one rank) and GN inside the reduction launch
     hipLaunchKernelGGL(k_window_reduce, dim3(1), dim3(1024), 0, ctx->stream, w, d_gram, (do_gn && in_kernel) ? 1 : 0, p2p ? lili_p2p_next_view(p2p) : P2PView{});
     HIPCHK(hipGetLastError());

@@ -117,6 +117,8 @@ struct lili_ctx {
     DevBuf staging;      // raw host clouds
     DevBuf fmt_out;      // lili_livox_custom_to_cloud output when the caller wants it on the host
     DevBuf gram;         // LILI_GRAM_DOUBLES per slot
+    DevBuf win_rec;      // lili_s2m_linearize_window: the n x LILI_GRAM_DOUBLES records of one evaluation of the window (k_window_reduce's output)
+    DevBuf win_counts;   // lili_s2m_associate_window: [surf, edge] counts of every slot (k_window_counts' output)
     DevBuf misc;         // bbox words etc.
     // Small device-to-host reads (counts, boxes, states) land in a page-locked scratch and are copied out after the synchronisation: a D2H into
     // pageable memory is staged by the runtime and blocks, which costs ~10 us more per read (64 KB; lili_readback_* in lili_api.hip).

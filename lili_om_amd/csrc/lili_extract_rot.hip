@@ -1381,6 +1381,9 @@ int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4
     auto* R = rot_of(ctx);
     R->have = false;
     bool full_early = false;      // the full cloud's copy to the host was started behind k_rot_scatter (see there)
+    // Whatever way this call ends, no DMA into the caller's buffer may outlive it: every return between the early copy and its join —
+    // a HIP error, a failed read-back, the second passes — drains the side stream first.
+    struct DrainSide { hipStream_t s = nullptr; ~DrainSide() { if (s) (void)hipStreamSynchronize(s); } } drain_side;
     // a scan that is already in HBM as float4 rows is read in place (no staging copy, one launch less)
     const bool in_place = scan->mem == LILI_MEM_DEVICE && scan->stride == sizeof(float4) && scan->aux_offset == 12 && (reinterpret_cast<uintptr_t>(scan->data) & 15) == 0;
     int rc = in_place ? LILI_OK : lili_ingest_cloud(ctx, scan, R->in);
@@ -1418,13 +1421,22 @@ int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4
                            R->block_hist.as<int>(), R->block_half.as<int>(), R->full.as<float4>(), R->full_src.as<int>(), R->vkey.as<unsigned>(), X.ring_ncand);
         // the deskewed cloud is final here: its copy to the host (3.2 MB for a 200 k-point scan, ~60 us) runs on a side stream under the feature
         // selection instead of behind it.  All n entries travel (the count is known only at the end); entries behind `count` are unspecified.
-        if (full && full->data && full->mem == LILI_MEM_HOST && (full->stride == 0 || full->stride == sizeof(float4)) && full->capacity > 0) {
+        // Only into PAGE-LOCKED memory (lili_host_alloc / hipHostMalloc / hipHostRegister): a copy into pageable memory is staged by the runtime and
+        // blocks the host right here, before k_rot_segments is even launched — then the plain copy at the end is the better one.
+        bool full_pinned = false;
+        if (full && full->data && full->mem == LILI_MEM_HOST) {
+            hipPointerAttribute_t attr{};
+            if (hipPointerGetAttributes(&attr, full->data) == hipSuccess) full_pinned = attr.type == hipMemoryTypeHost;
+            else (void)hipGetLastError();          // pageable memory is unknown to the runtime: not an error of this call
+        }
+        if (full_pinned && (full->stride == 0 || full->stride == sizeof(float4)) && full->capacity > 0) {
             if (!ctx->fork_ev) HIPCHK(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
             if (!ctx->side[1]) HIPCHK(hipStreamCreateWithFlags(&ctx->side[1], hipStreamNonBlocking));
             if (!ctx->join_ev[1]) HIPCHK(hipEventCreateWithFlags(&ctx->join_ev[1], hipEventDisableTiming));
             HIPCHK(hipEventRecord(ctx->fork_ev, ctx->stream));
             HIPCHK(hipStreamWaitEvent(ctx->side[1], ctx->fork_ev, 0));
             HIPCHK(hipMemcpyAsync(full->data, R->full.as<float4>(), std::min((size_t)n, full->capacity) * sizeof(float4), hipMemcpyDeviceToHost, ctx->side[1]));
+            drain_side.s = ctx->side[1];
             HIPCHK(hipEventRecord(ctx->join_ev[1], ctx->side[1]));
             full_early = true;
         }
@@ -1489,6 +1501,7 @@ int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4
     if (edge) { edge->count = (size_t)R->host.n_edge; rc = copy_out_f4(ctx, edge, R->edge_pts.as<float4>(), edge->count); if (rc) return rc; }
     if (surf) { surf->count = (size_t)R->host.n_surf; rc = copy_out_f4(ctx, surf, R->surf.as<float4>(), surf->count); if (rc) return rc; }
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    drain_side.s = nullptr;          // joined into the context's stream above and drained with it
     return LILI_OK;
 }
 

@@ -97,6 +97,17 @@ struct WindowSlot {
     SlotState* state;
 };
 struct WindowArgs { WindowSlot s[kWindowMaxSlots]; int n; };
+// The linearisation of EVERY slot of the window in ONE launch (k_linearize_window): slot i owns the blocks [first_block, first_block + S.nb + E.nb)
+// of the grid and runs exactly the bodies k_linearize runs for it (same block geometry, same partial buffers) — one launch boundary per
+// evaluation of the joint window instead of one per keyframe (the reference evaluates all keyframes per solver evaluation, L/src/BackendFusion.cpp:919-992).
+struct WinLinSlot {
+    LinArgs S, E;
+    PoseArg pa;
+    const SlotState* state;
+    const int* n_global;           // all-reduced correspondence counts of a multi-GPU caller, else nullptr
+    int first_block;
+};
+struct WinLinArgs { WinLinSlot s[kWindowMaxSlots]; int n; };
 
 constexpr int kPartialDoubles = 40;  // per-block partial: 36 upper-triangle Gram entries, cost, count, 2 spare
 constexpr int kPartialStride = 80;   // doubles per block slot of the partial buffers: 40 plain doubles, or 40 16-byte granules {value, value ^ key}

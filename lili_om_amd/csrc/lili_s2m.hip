@@ -917,6 +917,20 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize(LinArgs S, LinArgs E, P
     fused_tail(fz, key);
 }
 
+// All slots of a sliding window in one launch: block b belongs to the last slot whose first_block <= b (uniform per workgroup: the slot's
+// arguments are scalar loads from the kernel-argument segment) and is that slot's block b - first_block of k_linearize.
+__global__ __launch_bounds__(kLinBlock) void k_linearize_window(WinLinArgs W, MatchParams P) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int bid = (int)blockIdx.x;
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < kWindowMaxSlots; k++) if (k < W.n && bid >= W.s[k].first_block) i = k;
+    const WinLinSlot& ws = W.s[i];
+    const int b = bid - ws.first_block;
+    if (b < ws.S.nb) lin_surf_body(ws.S, b, ws.pa, P, ws.state, ws.n_global, lds, 0ull);
+    else lin_edge_body(ws.E, b - ws.S.nb, ws.pa, P, ws.state, ws.n_global, lds, 0ull);
+}
+
 // ================================================================================================
 // Final reduction of block partials (fixed order) -> 72-double record, optionally followed by the
 // Gauss-Newton update in the same launch (single-GPU path; multi-GPU callers all-reduce in between).

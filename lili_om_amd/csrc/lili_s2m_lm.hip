@@ -59,6 +59,7 @@ struct LmShared {
     double cost, radius, decrease, model_change, step_norm;
     int it, n_ok, term, go;    // go: 1 = evaluate the candidate next, 0 = finished
     int counts[2];
+    int n_invalid;             // consecutive invalid steps (model cost change <= 0)
     int stalled;               // a bounded wait gave up
     int take;                  // the candidate was accepted: `tot` becomes `cur`
     int max_iter;
@@ -124,6 +125,7 @@ __device__ __forceinline__ void lm_propose(LmShared& sh) {
         for (int i = 0; i < 6; i++) gmax = fmax(gmax, fabs(sh.gv[i]));
         if (gmax <= sh.gradient_tolerance) { if (lane == 0) { sh.term = LILI_LM_GRADIENT_TOLERANCE; sh.it = it + 1; sh.go = 0; } return; }      // (Ceres counts the iteration it stops in)
         const double radius = sh.radius;
+        if (!(radius > sh.min_radius)) { if (lane == 0) { sh.term = LILI_LM_MIN_RADIUS; sh.go = 0; } return; }      // MinTrustRegionRadiusReached (after an invalid step)
         double a = 0.0;
         if (in) {
             if (cj < 6) {
@@ -167,16 +169,23 @@ __device__ __forceinline__ void lm_propose(LmShared& sh) {
 #pragma unroll
         for (int i = 0; i < 6; i++) mc += lm_bcast(tr, i);
         mc = -mc;
-        if (!(mc > 0.0)) {       // not a descent step of the model: shrink, no evaluation (the iteration counts)
-            if (lane == 0) { sh.radius = fmax(sh.min_radius, radius / sh.decrease); sh.decrease *= 2.0; sh.it = it + 1; }
+        if (!(mc > 0.0)) {
+            // not a descent step of the model = Ceres' INVALID step (TrustRegionMinimizer::HandleInvalidStep): the iteration counts, nothing is evaluated,
+            // LevenbergMarquardtStrategy::StepIsInvalid halves the radius (the rejection divisor is left alone); max_num_consecutive_invalid_steps (5) of
+            // them in a row end the solve with FAILURE
+            const int n_inv = sh.n_invalid + 1;
             LILI_WAVE_SYNC();
-            continue;
+            if (lane == 0) { sh.n_invalid = n_inv; sh.radius = radius * 0.5; sh.it = it + 1; }
+            if (n_inv >= 5) { if (lane == 0) { sh.term = LILI_LM_NUMERICAL_FAILURE; sh.go = 0; } return; }
+            LILI_WAVE_SYNC();
+            continue;          // (the loop head checks max_iterations, then the radius, in FinalizeIterationAndCheckIfMinimizerCanContinue's order)
         }
         if (lane == 0) {
             double n2 = 0.0;
 #pragma unroll
             for (int i = 0; i < 6; i++) { d[i] = d[i] * sh.scale[i]; n2 += d[i] * d[i]; }      // delta in the unscaled local coordinates
             sh.model_change = mc;
+            sh.n_invalid = 0;
             sh.step_norm = sqrt(n2);
             // x (+) delta: ceres::QuaternionParameterization::Plus
             sh.xn[0] = sh.x[0] + d[0]; sh.xn[1] = sh.x[1] + d[1]; sh.xn[2] = sh.x[2] + d[2];
@@ -224,7 +233,7 @@ __global__ __launch_bounds__(kLmThreads) void k_solve_lm(LmArgs a, MatchParams P
             sh.function_tolerance = a.function_tolerance; sh.gradient_tolerance = a.gradient_tolerance; sh.parameter_tolerance = a.parameter_tolerance;
             sh.max_radius = a.max_radius; sh.min_radius = a.min_radius; sh.min_relative_decrease = a.min_relative_decrease;
             sh.min_lm_diagonal = a.min_lm_diagonal; sh.max_lm_diagonal = a.max_lm_diagonal;
-            sh.radius = a.initial_radius; sh.decrease = 2.0; sh.it = 0; sh.n_ok = 0; sh.term = LILI_LM_MAX_ITERATIONS; sh.go = 1; sh.stalled = 0; sh.take = 0;
+            sh.radius = a.initial_radius; sh.decrease = 2.0; sh.it = 0; sh.n_ok = 0; sh.term = LILI_LM_MAX_ITERATIONS; sh.go = 1; sh.stalled = 0; sh.take = 0; sh.n_invalid = 0;
             sh.cost = 0.0; sh.model_change = 0.0; sh.step_norm = 0.0;
         }
         __syncthreads();
@@ -286,13 +295,20 @@ __global__ __launch_bounds__(kLmThreads) void k_solve_lm(LmArgs a, MatchParams P
                     const double xnorm = sqrt(sh.x[0] * sh.x[0] + sh.x[1] * sh.x[1] + sh.x[2] * sh.x[2] + sh.x[3] * sh.x[3] + sh.x[4] * sh.x[4] + sh.x[5] * sh.x[5] + sh.x[6] * sh.x[6]);
                     if (sh.stalled) { sh.term = LILI_LM_STALLED; stop = 1; }
                     else if (sh.step_norm <= sh.parameter_tolerance * (xnorm + sh.parameter_tolerance)) { sh.term = LILI_LM_PARAMETER_TOLERANCE; stop = 1; }
-                    else if (fabs(sh.cost - new_cost) <= sh.function_tolerance * sh.cost) { sh.term = LILI_LM_FUNCTION_TOLERANCE; stop = 1; accepted = rho > sh.min_relative_decrease ? 1 : 0; }
+                    // Ceres returns from ParameterToleranceReached / FunctionToleranceReached BEFORE IsStepSuccessful / HandleSuccessfulStep
+                    // (TrustRegionMinimizer::Minimize): the candidate that triggers a tolerance is never taken, x stays at the last accepted point
+                    else if (fabs(sh.cost - new_cost) <= sh.function_tolerance * sh.cost) { sh.term = LILI_LM_FUNCTION_TOLERANCE; stop = 1; }
                     else if (rho > sh.min_relative_decrease) {
                         accepted = 1;
                         const double f = 2.0 * rho - 1.0;
                         sh.radius = fmin(sh.max_radius, sh.radius / fmax(1.0 / 3.0, 1.0 - f * f * f));
                         sh.decrease = 2.0;
-                    } else { sh.radius = fmax(sh.min_radius, sh.radius / sh.decrease); sh.decrease *= 2.0; }
+                    } else {
+                        // LevenbergMarquardtStrategy::StepRejected: no clamp; MinTrustRegionRadiusReached ends the solve (CONVERGENCE) once the radius is
+                        // at or below min_trust_region_radius
+                        sh.radius = sh.radius / sh.decrease; sh.decrease *= 2.0;
+                        if (!(sh.radius > sh.min_radius)) { sh.term = sh.it + 1 >= sh.max_iter ? LILI_LM_MAX_ITERATIONS : LILI_LM_MIN_RADIUS; stop = 1; }      // (max iterations is checked first)
+                    }
                     if (accepted) { for (int i = 0; i < 7; i++) sh.x[i] = sh.xn[i]; sh.cost = new_cost; sh.n_ok++; }
                     if (boss && a.summary && n_log < LILI_LM_MAX_LOG) a.summary->it[n_log].accepted = accepted;
                     n_log++;

@@ -697,7 +697,22 @@ int lili_localmap_commit(lili_ctx* ctx, int kind, float leaf, double max_sq_radi
         if (rc == LILI_OK) rc = lili_readback_add(ctx, &bad, d_bad, 4);
         { const int rb = lili_readback_finish(ctx); if (rc != LILI_OK) return rc; if (rb != LILI_OK) return rb; }
         if (bad) { S.valid = false; inc = false; have_box = false; }      // a point beyond the absolute key range: the box-relative rebuild below handles it
-        else V->incremental_commits++;
+        else {
+            // The guards of the full rebuild (voxel_sort: "no finite point", PCL's int32 voxel-index overflow) apply to the same ring content whichever
+            // way the map is produced: no centroid at all, or a box of centroids whose voxel count — with one voxel of slack per side and axis,
+            // a centroid may round across its voxel's face — would not fit int32, hands the commit to the rebuild, which decides exactly and reports the
+            // error a first commit would report.
+            bool guard = total > 0 && V->n_out == 0;
+            if (!guard && have_box) {
+                auto dec = [](unsigned u) { unsigned b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u; float f; std::memcpy(&f, &b, 4); return f; };
+                const float inv_leaf = 1.0f / leaf;
+                double cells = 1.0;
+                for (int k = 0; k < 3; k++) cells *= (double)((long long)std::floor(dec(V->out_box[3 + k]) * inv_leaf) - (long long)std::floor(dec(V->out_box[k]) * inv_leaf) + 3);
+                guard = !(cells <= 2147483647.0);
+            }
+            if (guard) { S.valid = false; inc = false; have_box = false; }
+            else V->incremental_commits++;
+        }
     }
     if (!inc) {
         // ---- full rebuild: concatenate, sort, reduce

@@ -320,11 +320,12 @@ def ceres_lm(problem, max_num_iterations=50, function_tolerance=1e-6, gradient_t
     cost, r, J = problem.evaluate(x)
     scale = 1.0 / (1.0 + np.sqrt((J * J).sum(0)))               # jacobi_scaling
     radius, decrease = initial_radius, 2.0
-    n_ok = 0
+    n_ok, n_invalid, termination = 0, 0, "max_iterations"
     for it in range(max_num_iterations):
         Js = J * scale
         g = Js.T @ r
         if np.abs(J.T @ r).max() <= gradient_tolerance:         # gradient max-norm (all blocks here are unconstrained)
+            termination = "gradient_tolerance"
             break
         # LM step: min |Js d + r|^2 + |D d|^2, D^2 = clamp(diag(Js^T Js)) / radius
         diag = np.clip((Js * Js).sum(0), min_lm_diagonal, max_lm_diagonal)
@@ -335,8 +336,18 @@ def ceres_lm(problem, max_num_iterations=50, function_tolerance=1e-6, gradient_t
         delta = d_s * scale
         model_change = -(d_s @ (g + 0.5 * (Js.T @ (Js @ d_s))))   # model_cost_change = -step^T (g + J^T J step / 2)
         if model_change <= 0:
-            radius = max(min_radius, radius / decrease); decrease *= 2.0
+            # invalid step (TrustRegionMinimizer::HandleInvalidStep): LevenbergMarquardtStrategy::StepIsInvalid halves the radius;
+            # max_num_consecutive_invalid_steps (5) in a row -> FAILURE; MinTrustRegionRadiusReached -> CONVERGENCE
+            n_invalid += 1
+            radius *= 0.5
+            if n_invalid >= 5:
+                termination = "numerical_failure"
+                break
+            if radius <= min_radius and it + 1 < max_num_iterations:
+                termination = "min_radius"
+                break
             continue
+        n_invalid = 0
         x_new = problem.plus(x, delta)
         new_cost = problem.evaluate(x_new, want_jac=False)[0]
         rho = (cost - new_cost) / model_change
@@ -344,13 +355,13 @@ def ceres_lm(problem, max_num_iterations=50, function_tolerance=1e-6, gradient_t
             log.append(dict(it=it, cost=cost, new_cost=new_cost, rho=rho, radius=radius, step=float(np.linalg.norm(delta))))
         # Ceres checks both tolerances on the CANDIDATE, before it decides whether to take the step
         xnorm = np.sqrt(sum(float(v @ v) for v in x.values()))
+        # (TrustRegionMinimizer::Minimize returns from ParameterToleranceReached / FunctionToleranceReached before IsStepSuccessful /
+        # HandleSuccessfulStep: the candidate that triggers a tolerance is NOT taken — x, cost and the successful-step count stay)
         if float(np.linalg.norm(delta)) <= parameter_tolerance * (xnorm + parameter_tolerance):
+            termination = "parameter_tolerance"
             break
         if abs(cost - new_cost) <= function_tolerance * cost:
-            if rho > min_relative_decrease:
-                x = x_new
-                cost, r, J = problem.evaluate(x)
-                n_ok += 1
+            termination = "function_tolerance"
             break
         if rho > min_relative_decrease:                          # successful step
             x = x_new
@@ -359,9 +370,12 @@ def ceres_lm(problem, max_num_iterations=50, function_tolerance=1e-6, gradient_t
             decrease = 2.0
             n_ok += 1
         else:
-            radius = max(min_radius, radius / decrease)
+            radius = radius / decrease                           # LevenbergMarquardtStrategy::StepRejected (no clamp)
             decrease *= 2.0
-    return x, dict(cost=cost, iterations=it + 1, successful_steps=n_ok)
+            if radius <= min_radius and it + 1 < max_num_iterations:   # MinTrustRegionRadiusReached (checked after max_num_iterations)
+                termination = "min_radius"
+                break
+    return x, dict(cost=cost, iterations=it + 1, successful_steps=n_ok, termination=termination)
 
 
 # ---------------------------------------------------------------- marginalisation (MarginalizationFactor.cpp:128-287)

@@ -47,3 +47,26 @@ def test_cpp_host_matches_python_binding(gpu_ctx, tmp_path, variant):
     assert status_c == st == 0
     assert np.array_equal(pose_c, np.concatenate([tp, qp]))          # %.17g round-trips doubles exactly
     assert n_c == n_p > 1000
+
+
+def test_cpp_host_window_seam_one_call_equals_single_calls(gpu_ctx, tmp_path):
+    """examples/s2m_demo --window 3: the blocking seam of a 3-keyframe window from C++ — ONE lili_s2m_linearize_window per evaluation returns the bits of
+    three lili_s2m_linearize calls (the program exits 3 otherwise) and prints both timings."""
+    import json
+    if not os.path.exists(DEMO):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "-s"])
+    room = synth.make_room(seed=41, n_query=2750, n_edge_query=10)
+    P = L.make_params("rot")
+    t, q = L.api.body_pose_from_lidar(room["t_true"], room["q_true"], P)
+    path = tmp_path / "win.bin"
+    with open(path, "wb") as f:
+        f.write(struct.pack("<qqii", room["map_xyz"].shape[0], room["q_xyz"].shape[0], int(P.variant), 0))
+        f.write(np.concatenate([t, q]).astype("<f8").tobytes())
+        f.write(np.ascontiguousarray(room["map_xyz"], "<f4").tobytes())
+        f.write(np.ascontiguousarray(room["q_xyz"], "<f4").tobytes())
+    out = subprocess.run([DEMO, str(path), "--window", "3", "100"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, (out.stdout, out.stderr)
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    print(r)
+    assert r["window_equals_single_calls_bit_for_bit"] is True and r["correspondences_slot0"] > 1500
+    assert r["us_per_window_evaluation"] < r["us_per_evaluation_as_K_single_calls"]
