@@ -490,6 +490,7 @@ def main():
     # torch's).  A candidate is used only if EVERY rank could set it up and one native iteration reproduces the torch.distributed
     # iteration from the same pose — otherwise the Python loop above stays.
     native, native_kind = None, "torch.distributed from the Python loop"
+    p2p_round_trip = None
     if dist is not None and args.collective != "torch":
         def flag_all(ok):
             f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
@@ -517,6 +518,26 @@ def main():
                 log(f"[bench] rank {rank}: {kind}: unavailable ({e!r})")
             if not flag_all(comm is not None):
                 continue
+            if hasattr(comm, "all_reduce"):
+                # lili_p2p only: a mailbox round trip with a known pattern BEFORE anything depends on it — every rank contributes
+                # rank * 1000 + i + 0.5 (exact in f64, so is the sum), one exchange on the bench's stream, and every rank must read back exactly
+                # world * (i + 0.5) + 1000 * world * (world - 1) / 2 for all 72 words.  A link that does not carry the stores (or carries stale
+                # ones) fails here instead of in the middle of a registration.
+                rt_ok = False
+                try:
+                    torch.cuda.synchronize(); dist.barrier()
+                    pat = torch.arange(L.api.GRAM_DOUBLES, dtype=torch.float64, device=dev) + 0.5 + 1000.0 * rank
+                    comm.all_reduce(pat.data_ptr(), L.api.GRAM_DOUBLES, 8, tstream.cuda_stream)
+                    torch.cuda.synchronize()
+                    want = world * (torch.arange(L.api.GRAM_DOUBLES, dtype=torch.float64, device=dev) + 0.5) + 1000.0 * world * (world - 1) / 2
+                    rt_ok = bool(torch.equal(pat, want)) and comm.status() == 0
+                except Exception as e:          # noqa: BLE001
+                    log(f"[bench] rank {rank}: {kind}: mailbox round trip failed ({e!r})")
+                p2p_round_trip = flag_all(rt_ok)
+                if not p2p_round_trip:
+                    if rank == 0:
+                        log(f"[bench] {kind}: the mailbox round trip did not return the written bits on every rank, skipped")
+                    continue
             m.pose_copy(0, 1); step_multi(); torch.cuda.synchronize()
             ta, qa, _ = m.pose_get(0)
             m.pose_copy(0, 1)
@@ -655,6 +676,39 @@ def main():
                       "weak_scaling_note": f"{world} x {qw.shape[0]}-point shards of an (N x 200k)-point scan, value = steps x N / time"}
         m.set_queries(0, L.KIND_SURF, queries)
 
+    # Replica mode (what scales for a 35 us iteration is independent work): EVERY rank registers the whole 200 k-point scan
+    # against its replica of the map with the single-GPU loop — no collective anywhere in the timed region — value = steps x N / max-over-ranks time.
+    # Self-check: the ranks run the same deterministic code on the same data, so their final poses must be identical bit for bit (and equal to
+    # the N = 1 run's final_pose for the same --steps / --warmup).
+    replica_extra, replica_pose = None, None
+    if world > 1:
+        m.set_queries(0, L.KIND_SURF, scan)
+        m.pose_set(1, t0, q0)
+
+        def run_replica(k):
+            m.iterate_restart(0, k, ips, 1, L.MASK_SURF)
+        run_replica(args.warmup)
+        fence(); fence()
+        tic = time.perf_counter()
+        run_replica(args.steps)
+        fence()
+        el_r = time.perf_counter() - tic
+        tmax = torch.tensor([el_r], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        el_r = float(tmax.item())
+        tr, qr, str_ = m.pose_get(0)
+        rb = torch.from_numpy(np.concatenate([np.asarray(tr, np.float64), np.asarray(qr, np.float64)]).view(np.int64).copy()).to(dev)
+        lo_r, hi_r = rb.clone(), rb.clone()
+        dist.all_reduce(lo_r, op=dist.ReduceOp.MIN); dist.all_reduce(hi_r, op=dist.ReduceOp.MAX)
+        st_r = torch.tensor([int(str_)], dtype=torch.int32, device=dev)
+        dist.all_reduce(st_r, op=dist.ReduceOp.MAX)
+        replica_extra = {"replicas_iterations_per_s": round(args.steps * world / el_r, 3), "replicas_ms_per_step": round(el_r / args.steps * 1e3, 5),
+                         "replicas_note": f"{world} ranks x the whole {n_scan}-pt scan each (one scan per GPU, map replicated), single-GPU loop, NO collective in the timed region; "
+                                          "value = steps x N / max-over-ranks time",
+                         "replicas_final_pose_bit_identical_on_all_ranks": bool(torch.equal(lo_r, hi_r)), "replicas_max_gn_status": int(st_r.item()),
+                         "replicas_final_pose": {"t": [float(x) for x in tr], "q": [float(x) for x in qr]}}
+        m.set_queries(0, L.KIND_SURF, queries)
+
     # Multi-GPU self-check: every rank must hold the SAME final pose, bit for bit (strong split: one scan, all ranks apply the same
     # update to the same reduced record).  all-reduce MIN and MAX of the pose bit patterns: equal <=> identical on every rank.
     multi = None
@@ -666,7 +720,11 @@ def main():
         st_all = torch.tensor([int(gn_status)], dtype=torch.int32, device=dev)
         dist.all_reduce(st_all, op=dist.ReduceOp.MAX)
         multi = {"ranks": world, "rccl_ranks": world if dist.get_backend() == "nccl" else 0, "backend": dist.get_backend(),
-                 "final_pose_bit_identical_on_all_ranks": bool(torch.equal(lo, hi)), "max_gn_status": int(st_all.item())}
+                 "final_pose_bit_identical_on_all_ranks": bool(torch.equal(lo, hi)), "max_gn_status": int(st_all.item()),
+                 "p2p_mailbox_round_trip": p2p_round_trip}
+        if replica_extra:
+            multi["replicas_final_pose_bit_identical_on_all_ranks"] = replica_extra["replicas_final_pose_bit_identical_on_all_ranks"]
+            multi["replicas_max_gn_status"] = replica_extra["replicas_max_gn_status"]
     if rank == 0:
         units = args.steps * (world if args.scaling == "weak" else 1)
         value = units / elapsed
@@ -691,9 +749,11 @@ def main():
             failures.append(f"headline gn_status {int(gn_status)}")
         if multi:
             out["multi_gpu_check"] = multi
-            if not multi["final_pose_bit_identical_on_all_ranks"] or multi["max_gn_status"] != 0:
+            if not multi["final_pose_bit_identical_on_all_ranks"] or multi["max_gn_status"] != 0 or multi.get("replicas_final_pose_bit_identical_on_all_ranks") is False \
+                    or multi.get("replicas_max_gn_status", 0) != 0:
                 failures.append(f"multi_gpu_check {multi}")
         extras = dict(weak_extra or {})
+        extras.update(replica_extra or {})
         if regions:
             extras["headline_regions"] = regions
         if world == 1 and dist is None:

@@ -59,6 +59,7 @@ struct LmArgs {      // must match lili_s2m_lm.hip
 __global__ void k_solve_lm(LmArgs, MatchParams);
 // lili_s2m_coop.hip: L lanes per query (small launches)
 template <int L, bool LIN> __global__ void k_associate_coop(AssocArgs, AssocArgs, PoseArg, MatchParams, double*, double*, SlotState*, int);
+template <int L> __global__ void k_associate_coop_window(WinAssocArgs, MatchParams);
 struct IterArgs {      // must match lili_s2m_coop.hip
     SlotState* state;
     double* part;
@@ -829,6 +830,72 @@ static int launch_associate_coop(lili_ctx* ctx, int slot, int kind_mask, const P
     return LILI_OK;
 }
 
+// The cooperative association of EVERY slot of a window in ONE launch (k_associate_coop_window): the conditions of launch_associate_coop for every slot,
+// one L for all (by the total number of queries: the records do not depend on it).  Returns 1 if not eligible — the caller then launches slot by slot.
+static int launch_associate_coop_window(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, const double* t_assoc, const double* q_assoc, const MatchParams& P) {
+    if (n_slots < 2 || ctx->bin_queries || ctx->tiled || ctx->balance || ctx->nn_cache || (P.debug & (1 | 2 | 4096))) return 1;
+    int64_t n_all = 0;
+    bool first = false;
+    for (int i = 0; i < n_slots; i++) {
+        Slot& sl = ctx->slots[slots[i]];
+        for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) {
+            KindSlot& ks = sl.k[kind];
+            MapIndex& m = ctx->map[kind];
+            if (!ks.has_queries || !m.valid || ks.n_q == 0 || m.n < 5 || m.has_fine) return 1;
+            const double gate = kind == LILI_KIND_SURF ? P.kd_max_radius : P.edge_gate;
+            if (!(std::sqrt(gate) * 1.0099 <= m.cell * (double)m.view.reach)) return 1;     // the per-kind path reports the error
+            if (kind == LILI_KIND_SURF && P.variant == LILI_VARIANT_LIVOX && (!m.has_aux || !ks.has_aux)) return 1;
+            n_all += ks.n_q;
+        }
+        first = first || sl.assoc_since_pose == 0;
+    }
+    const int L = coop_lanes(ctx, n_all, first);
+    if (L < 2 || n_all == 0) return 1;
+    const int qpb = 256 / L;
+    WinAssocArgs W{};
+    for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) W.g[kind] = ctx->map[kind].view;
+    int nb = 0;
+    for (int i = 0; i < n_slots; i++) {
+        Slot& sl = ctx->slots[slots[i]];
+        WinAssocSlot& ws = W.s[i];
+        ws = WinAssocSlot{};
+        for (int k = 0; k < 3; k++) ws.pa.t[k] = t_assoc[3 * i + k];
+        for (int k = 0; k < 4; k++) ws.pa.q[k] = q_assoc[4 * i + k];
+        ws.first_block = nb;
+        // (edge workgroups first, then surf: the order of k_associate_coop's grid)
+        for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) {
+            KindSlot& ks = sl.k[kind];
+            const int n = (int)ks.n_q;
+            WinAssocKind& a = ws.k[kind];
+            a.queries = ks.q.as<float4>(); a.n_q = n;
+            a.rec0 = ks.rec0.as<float4>(); a.rec1 = ks.rec1.p; a.valid = ks.valid.as<unsigned char>();
+            if (ctx->keep_nn) {
+                HIPCHK(ks.dbg_idx.ensure((size_t)n * 5 * sizeof(int)));
+                HIPCHK(ks.dbg_d2.ensure((size_t)n * 5 * sizeof(float)));
+                a.dbg_idx = ks.dbg_idx.as<int>(); a.dbg_d2 = ks.dbg_d2.as<float>();
+            }
+            a.nb = nblocks(n, qpb);
+            HIPCHK(ks.block_counts.ensure((size_t)a.nb * sizeof(int)));
+            a.block_counts = ks.block_counts.as<int>();
+            ks.n_assoc_blocks = a.nb; ks.has_records = true; ks.launches++;
+            nb += a.nb;
+        }
+        sl.assoc_since_pose++;
+        sl.use_global_counts = false; sl.sticky_global_counts = false;
+    }
+    W.n = n_slots;
+    const dim3 grid(nb), block(256);
+    switch (L) {
+        case 2: hipLaunchKernelGGL((k_associate_coop_window<2>), grid, block, 0, ctx->stream, W, P); break;
+        case 4: hipLaunchKernelGGL((k_associate_coop_window<4>), grid, block, 0, ctx->stream, W, P); break;
+        case 8: hipLaunchKernelGGL((k_associate_coop_window<8>), grid, block, 0, ctx->stream, W, P); break;
+        case 16: hipLaunchKernelGGL((k_associate_coop_window<16>), grid, block, 0, ctx->stream, W, P); break;
+        default: return 1;
+    }
+    HIPCHK(hipGetLastError());
+    return LILI_OK;
+}
+
 // n_iters outer iterations of a SMALL scan as ONE persistent launch (k_iterate_coop, lili_s2m_coop.hip): every workgroup keeps the pose in LDS,
 // the workgroups exchange counts and Gram partials inside the launch and each applies the same Gauss-Newton step.  Returns 1 if not eligible
 // (the caller then iterates launch by launch).  Eligible: the configurations of launch_associate_coop with at most 256 workgroups.
@@ -1058,12 +1125,17 @@ int lili_s2m_associate_window(lili_ctx* ctx, const int* slots, int n_slots, int 
         for (int k = 0; k < i; k++) ARGCHK(slots[k] != slots[i], "associate_window: duplicate slot");
     }
     HIPCHK(hipSetDevice(ctx->device));
-    if (!ctx->fork_ev) HIPCHK(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(ctx->fork_ev, ctx->stream));
     hipStream_t main_stream = ctx->stream;
     const MatchParams P = to_device_params(params);
-    int rc = LILI_OK;
-    for (int i = 0; i < n_slots && rc == LILI_OK; i++) {
+    int rc = launch_associate_coop_window(ctx, slots, n_slots, kind_mask, t_assoc, q_assoc, P);      // every keyframe in ONE launch where the cooperative kernel applies
+    const bool one_launch = rc == LILI_OK;
+    if (rc != LILI_OK && rc != 1) return rc;
+    rc = LILI_OK;
+    if (!one_launch) {
+        if (!ctx->fork_ev) HIPCHK(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(ctx->fork_ev, ctx->stream));
+    }
+    for (int i = 0; i < n_slots && rc == LILI_OK && !one_launch; i++) {
         if (i > 0) {
             if (!ctx->side[i]) HIPCHK(hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking));
             if (!ctx->join_ev[i]) HIPCHK(hipEventCreateWithFlags(&ctx->join_ev[i], hipEventDisableTiming));

@@ -1342,6 +1342,7 @@ struct RotBuffers {
     lili::RotState host{};
     int n_in = 0;
     bool have = false;
+    const void* pin_ptr = nullptr; bool pin_is = false;      // last host `full` buffer looked up with hipPointerGetAttributes (a query costs far more than a launch: once per buffer, not per scan)
     void release() {
         for (DevBuf* b : {&in, &scan_id, &ori_raw, &block_hist, &block_half, &state, &full, &full_src, &curv, &label, &sort_ind, &vkey, &seg_out, &ring_ncand, &sorted_k, &sorted_vox,
                           &sorted_len, &big_mark, &big_vidx, &big_ord_a, &big_ord_b, &big_rcnt, &ring_edge, &ring_sharp, &ring_flat,
@@ -1425,9 +1426,14 @@ int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4
         // blocks the host right here, before k_rot_segments is even launched — then the plain copy at the end is the better one.
         bool full_pinned = false;
         if (full && full->data && full->mem == LILI_MEM_HOST) {
-            hipPointerAttribute_t attr{};
-            if (hipPointerGetAttributes(&attr, full->data) == hipSuccess) full_pinned = attr.type == hipMemoryTypeHost;
-            else (void)hipGetLastError();          // pageable memory is unknown to the runtime: not an error of this call
+            if (R->pin_ptr != full->data) {        // a driver's DMA buffer is the same one scan after scan
+                hipPointerAttribute_t attr{};
+                R->pin_is = false;
+                if (hipPointerGetAttributes(&attr, full->data) == hipSuccess) R->pin_is = attr.type == hipMemoryTypeHost;
+                else (void)hipGetLastError();      // pageable memory is unknown to the runtime: not an error of this call
+                R->pin_ptr = full->data;
+            }
+            full_pinned = R->pin_is;
         }
         if (full_pinned && (full->stride == 0 || full->stride == sizeof(float4)) && full->capacity > 0) {
             if (!ctx->fork_ev) HIPCHK(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));

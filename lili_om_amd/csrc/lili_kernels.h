@@ -108,6 +108,16 @@ struct WinLinSlot {
     int first_block;
 };
 struct WinLinArgs { WinLinSlot s[kWindowMaxSlots]; int n; };
+// The cooperative association of EVERY slot of the window in ONE launch (k_associate_coop_window in lili_s2m_coop.hip): per slot and kind what
+// AssocArgs holds minus the map view, which all slots share.
+struct WinAssocKind {
+    const float4* queries; int n_q;
+    float4* rec0; void* rec1; unsigned char* valid;
+    int* dbg_idx; float* dbg_d2; int* block_counts;
+    int nb;
+};
+struct WinAssocSlot { WinAssocKind k[2]; PoseArg pa; int first_block; };
+struct WinAssocArgs { GridView g[2]; WinAssocSlot s[kWindowMaxSlots]; int n; };
 
 constexpr int kPartialDoubles = 40;  // per-block partial: 36 upper-triangle Gram entries, cost, count, 2 spare
 constexpr int kPartialStride = 80;   // doubles per block slot of the partial buffers: 40 plain doubles, or 40 16-byte granules {value, value ^ key}

@@ -181,13 +181,12 @@ __device__ __forceinline__ void knn5_coop(const GridView& g, bool live, int sub,
 // (a relaxed agent-scope atomic and a poll: only the VALUE is exchanged, no other data, hence no fence).  Small grids only (<= 256
 // workgroups, all resident); the wait is bounded — a workgroup that gives up contributes no rows and flags the slot.
 template <int L, bool LIN>
-__global__ __launch_bounds__(kCoopBlock) void k_associate_coop(AssocArgs S, AssocArgs E, PoseArg pa, MatchParams P, double* __restrict__ part_surf, double* __restrict__ part_edge,
-                                                               SlotState* cb_state, int cb_blocks) {
+__device__ __forceinline__ void assoc_coop_block(const AssocArgs& A /*the arguments of THIS workgroup's kind*/, const bool edge, const int vb /*workgroup index within the kind*/,
+                                                 const int b /*workgroup index within the slot's launch*/, const PoseArg& pa, const MatchParams& P,
+                                                 double* __restrict__ part_surf, double* __restrict__ part_edge, SlotState* cb_state, int cb_blocks) {
+    // (the caller selects A: a select between two by-value kernel arguments stays an address select in the kernel-argument segment only when it is
+    // written in the kernel itself — through this function's parameters it put both structs into scratch, 408 bytes per lane)
     constexpr int QPB = kCoopBlock / L;
-    const int b = (int)blockIdx.x;
-    const bool edge = b < E.nb;
-    const AssocArgs& A = edge ? E : S;
-    const int vb = edge ? b : b - E.nb;
     const int sub = (int)threadIdx.x & (L - 1);
     const int i = vb * QPB + ((int)threadIdx.x / L);
     const bool live = i < A.n_q;
@@ -259,6 +258,40 @@ __global__ __launch_bounds__(kCoopBlock) void k_associate_coop(AssocArgs S, Asso
         ga.finish(lds, edge ? part_edge + (size_t)vb * kPartialStride : part_surf + (size_t)vb * kPartialStride);
     }
 }
+template <int L, bool LIN>
+__global__ __launch_bounds__(kCoopBlock) void k_associate_coop(AssocArgs S, AssocArgs E, PoseArg pa, MatchParams P, double* __restrict__ part_surf, double* __restrict__ part_edge,
+                                                               SlotState* cb_state, int cb_blocks) {
+    const int b = (int)blockIdx.x;
+    const bool edge = b < E.nb;
+    const AssocArgs& A = edge ? E : S;
+    assoc_coop_block<L, LIN>(A, edge, edge ? b : b - E.nb, b, pa, P, part_surf, part_edge, cb_state, cb_blocks);
+}
+// The association of EVERY keyframe of a sliding window in ONE launch (round 4; lili_s2m_associate_window): workgroup b belongs to the last slot
+// whose first_block <= b and is that slot's workgroup b - first_block of k_associate_coop<L, false> — same lanes per query for all slots (the
+// records do not depend on L), the two map views shared by all slots.  It was one launch per keyframe on forked streams (two event
+// waits per slot cost more than the launches themselves at the sizes a keyframe has).
+template <int L>
+__global__ __launch_bounds__(kCoopBlock) void k_associate_coop_window(WinAssocArgs W, MatchParams P) {
+    const int bid = (int)blockIdx.x;
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < kWindowMaxSlots; k++) if (k < W.n && bid >= W.s[k].first_block) i = k;
+    const WinAssocSlot& ws = W.s[i];
+    const int b = bid - ws.first_block;
+    const bool edge = b < ws.k[1].nb;
+    const WinAssocKind& k = ws.k[edge ? 1 : 0];           // uniform per workgroup: scalar loads from the kernel-argument segment
+    AssocArgs A{};
+    A.queries = k.queries; A.n_q = k.n_q; A.g = W.g[edge ? 1 : 0];
+    A.rec0 = k.rec0; A.rec1 = k.rec1; A.valid = k.valid;
+    A.dbg_idx = k.dbg_idx; A.dbg_d2 = k.dbg_d2; A.block_counts = k.block_counts; A.nn_cache = nullptr;
+    A.nb = k.nb;
+    assoc_coop_block<L, false>(A, edge, edge ? b : b - ws.k[1].nb, b, ws.pa, P, nullptr, nullptr, nullptr, 0);
+}
+template __global__ void k_associate_coop_window<2>(WinAssocArgs, MatchParams);
+template __global__ void k_associate_coop_window<4>(WinAssocArgs, MatchParams);
+template __global__ void k_associate_coop_window<8>(WinAssocArgs, MatchParams);
+template __global__ void k_associate_coop_window<16>(WinAssocArgs, MatchParams);
+
 // ================================================================================================
 // Persistent outer iterations for small scans (round 3): n_iters x [re-associate, linearise, reduce, Gauss-Newton update] in ONE launch.
 //
