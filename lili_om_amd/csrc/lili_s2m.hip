@@ -679,6 +679,8 @@ __device__ __forceinline__ void assoc_surf_body(
     int t = tile.x + threadIdx.x;
     int i = live ? (perm ? perm[t] : t) : 0;
     float4 ql = queries[live ? i : 0];     // requested before the (dependent, scalar) pose loads: the two latencies overlap
+    KeepRec krec;
+    keep_load(nn_cache, n_q, i, live && !TILED && nn_cache && P.nn_keep == 2, krec);      // the query's record of the verified neighbour cache travels with it
     dq Q2; d3 T2;
     load_assoc_pose(pa, P, Q2, T2);
     d3 pmd = qrot(Q2, d3{(double)ql.x, (double)ql.y, (double)ql.z}) + T2;   // transformPoint, L:695-711
@@ -697,7 +699,7 @@ __device__ __forceinline__ void assoc_surf_body(
 #pragma unroll
         for (int k = 0; k < 5; k++) { nn.d[k] = 0.01f * (k + 1); nn.j[k] = (i * 7 + k) % g.n_points; }
     } else if constexpr (TILED) knn5_tiled(g, L, tab, live, px, py, pz, nn, P.debug);
-    else if (live) { knn5_grid(g, tab, px, py, pz, seeded_bound(g, P.kd_max_radius, nn_cache, n_q, i, px, py, pz), nn, P.debug, pp); store_nn_cache(nn_cache, n_q, i, nn); }
+    else if (live) knn5_keep(g, tab, nn_cache, n_q, i, P.nn_keep, krec, px, py, pz, gate_bound(P.kd_max_radius), nn, P.debug, pp);
     if (BS == 64 && !TILED && sched.block_cost) {   // cost of this block for the next launch's dispatch order
         int c = live ? nn.aux : 0;
 #pragma unroll
@@ -755,13 +757,15 @@ __device__ __forceinline__ void assoc_edge_body(
     int t = tile.x + threadIdx.x;
     int i = live ? (perm ? perm[t] : t) : 0;
     float4 ql = queries[live ? i : 0];     // requested before the (dependent, scalar) pose loads: the two latencies overlap
+    KeepRec krec;
+    keep_load(nn_cache, n_q, i, live && !TILED && nn_cache && P.nn_keep == 2, krec);
     dq Q2; d3 T2;
     load_assoc_pose(pa, P, Q2, T2);
     d3 pmd = qrot(Q2, d3{(double)ql.x, (double)ql.y, (double)ql.z}) + T2;
     float px = (float)pmd.x, py = (float)pmd.y, pz = (float)pmd.z;
     Top5 nn; nn.have = false;
     if constexpr (TILED) knn5_tiled(g, L, tab, live, px, py, pz, nn, P.debug);
-    else if (live) { knn5_grid(g, tab, px, py, pz, seeded_bound(g, P.edge_gate, nn_cache, n_q, i, px, py, pz), nn); store_nn_cache(nn_cache, n_q, i, nn); }
+    else if (live) knn5_keep(g, tab, nn_cache, n_q, i, P.nn_keep, krec, px, py, pz, gate_bound(P.edge_gate), nn, 0, (PhaseProbe*)nullptr);
     bool ok = false;
     if (live) {
         store_debug_nn(g, nn, i, dbg_idx, dbg_d2);

@@ -103,8 +103,12 @@ __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) { 
 // their exact f32 distances are then recomputed from the re-loaded points and put into the oracle's (d2, index) order.
 // If the buckets coincide, or the fifth lies in the bucket of the search bound, the query is repeated with the exact
 // selector (about once in 1e5 queries on voxel-filtered maps; always on lattice ties).
+// What the full search hands to the verified neighbour cache (see keep_* below): the margin by which the cached members beat everything else, how many
+// members that cut keeps (5 or 6) and the array position of the sixth.
+struct KeepOut { float m; int cnt; int j5; };
 struct Sel5K {
     unsigned k[6];
+    unsigned k6v;    // the SEVENTH smallest key seen (value only: its bucket is a lower bound for every candidate outside the held six)
     int tc;          // chunks processed by this lane
     int* T;          // this lane's column of the chunk table (row stride ts ints)
     int ts;
@@ -115,6 +119,7 @@ struct Sel5K {
         bb = __float_as_uint(bnd) >> 6;
 #pragma unroll
         for (int s = 0; s < 6; s++) k[s] = ((bb + 1u + (unsigned)s) << 6) | 63u;   // six distinct buckets above the bound
+        k6v = ((bb + 7u) << 6) | 63u;
         tc = 0; T = nullptr; ts = 0;
     }
     __device__ __forceinline__ void attach(int* col, int stride) { T = col; ts = stride; T[15 * stride] = -4; }
@@ -126,6 +131,7 @@ struct Sel5K {
         t.have = false;
     }
     __device__ __forceinline__ void push(unsigned key) {
+        k6v = min(k6v, max(k[5], key));        // what falls off the held six (the larger of the old sixth and the newcomer): its running minimum is the seventh
         const unsigned m5 = umed3(k[4], k[5], key), m4 = umed3(k[3], k[4], key), m3 = umed3(k[2], k[3], key);
         const unsigned m2 = umed3(k[1], k[2], key), m1 = umed3(k[0], k[1], key);
         k[0] = min(k[0], key); k[1] = m1; k[2] = m2; k[3] = m3; k[4] = m4; k[5] = m5;
@@ -151,7 +157,10 @@ struct Sel5K {
     }
     // Resolves the five best, recomputes their exact distances and orders them by (d2, original index).
     // Returns true if the query has to be repeated with the exact selector.
-    __device__ __forceinline__ bool finish(const GridView& g, float qx, float qy, float qz, Top5& t) const {
+    // lbo / ko (verified neighbour cache): lbo = a lower bound of the squared distance of every map point that was NOT offered to this selector (0 = unknown);
+    // *ko receives the margin sqrt(lower bound of everything outside the cut) - sqrt(upper bound of the members inside it) for the better of the two cuts
+    // "five members | rest" and "six members | rest" (0 = no usable margin).
+    __device__ __forceinline__ bool finish(const GridView& g, float qx, float qy, float qz, Top5& t, float lbo = 0.f, KeepOut* ko = nullptr) const {
         const bool redo = ((k[5] ^ k[4]) < 64u) || ((k[4] >> 6) == bb);
         unsigned long long e[5];
         int jr[5];
@@ -180,6 +189,17 @@ struct Sel5K {
         for (int s = 0; s < 5; s++) { t.d[s] = __uint_as_float((unsigned)(e[s] >> 32)); t.j[s] = jr[s]; t.p[s] = pp[s]; }
         t.aux = tc;
         t.have = !redo;
+        if (ko) {
+            const int j5 = where(k[5]);
+            const float d5 = __uint_as_float((unsigned)(e[4] >> 32));                       // exact, the largest of the five
+            const float lb6 = fminf(__uint_as_float(k[5] & ~63u), lbo), ub6 = __uint_as_float(k[5] | 63u), lb7 = fminf(__uint_as_float(k6v & ~63u), lbo);
+            const float m56 = sqrtf(lb6) - sqrtf(d5);
+            const float m67 = j5 >= 0 ? sqrtf(lb7) - sqrtf(ub6) : -1.f;
+            const bool six = m67 > m56;
+            const float m = (six ? m67 : m56) * 0.998f - 1e-6f;                              // conservative against the f32 roundings above
+            const bool usable = !redo && jr[4] >= 0 && lbo > 0.f && m > 0.f;                // (NaN margins — non-finite map points — compare false)
+            ko->m = usable ? m : 0.f; ko->cnt = six ? 6 : 5; ko->j5 = j5;
+        }
         return redo;
     }
 };
@@ -269,9 +289,11 @@ __device__ __forceinline__ float gate_bound(double gate) {   // smallest f32 >= 
 __device__ constexpr int kShellDy[16] = {0, 0, -2, 2, -1, 1, -1, 1, -2, -2, 2, 2, -2, -2, 2, 2};
 __device__ constexpr int kShellDz[16] = {-2, 2, 0, 0, -2, -2, 2, 2, -1, 1, -1, 1, -2, 2, -2, 2};
 template <class SEL, class TAB>
-__device__ __forceinline__ bool knn5_grid_sel(const GridView& g, TAB& tab, float qx, float qy, float qz, float bound, Top5& best, PhaseProbe* pp = nullptr) {
+__device__ __forceinline__ bool knn5_grid_sel(const GridView& g, TAB& tab, float qx, float qy, float qz, float bound, Top5& best, PhaseProbe* pp = nullptr, KeepOut* ko = nullptr) {
     SEL sel; sel.init(bound);
     sel.to_top5(best);
+    if (ko) { ko->m = 0.f; ko->cnt = 5; ko->j5 = -1; }
+    float lbo = 0.f;        // lower bound (squared) of everything the selector was NOT offered: known only on the super-row path with the shell ruled out
     if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) return false;
     if constexpr (std::is_same<SEL, Sel5K>::value) sel.attach(&tab.cj[0][threadIdx.x], (int)(sizeof(tab.cj[0]) / sizeof(int)));
     const int R = g.reach;
@@ -377,6 +399,7 @@ __device__ __forceinline__ bool knn5_grid_sel(const GridView& g, TAB& tab, float
         const double fym = (double)qy - (g.oy + (double)cy * c), fyp = (g.oy + (double)(cy + 1) * c) - (double)qy;
         const double fzm = (double)qz - (g.oz + (double)cz * c), fzp = (g.oz + (double)(cz + 1) * c) - (double)qz;
         const double margin = c + fmax(fmin(fmin(fmin(fxm, fxp), fmin(fym, fyp)), fmin(fzm, fzp)), 0.0);
+        if (inner9 && sel.worst() < (float)(0.999 * margin * margin)) lbo = (float)(0.999 * margin * margin);   // every point outside the inner block is at least `margin` away
         if (!(sel.worst() < (float)(0.999 * margin * margin))) {
             // super-row layout: the 18 single-cell runs x = cx -+ 2 of the nine inner rows are two runs (one super cell each)
             const bool side9 = inner9 && (cx - 2 < 0 || cx - 2 >= g.bx0) && (cx + 2 >= g.nx || cx + 2 < g.bx0 + g.bnx);
@@ -453,17 +476,103 @@ __device__ __forceinline__ bool knn5_grid_sel(const GridView& g, TAB& tab, float
         }
     }
     PHASE_STAMP(pp, 4, sel.worst());                                        // shell decided / walked
-    if constexpr (std::is_same<SEL, Sel5K>::value) return sel.finish(g, qx, qy, qz, best);
+    if constexpr (std::is_same<SEL, Sel5K>::value) return sel.finish(g, qx, qy, qz, best, lbo, ko);
     else { sel.to_top5(best); return sel.final_tie(); }
 }
 // Fast selection first; the rare queries with an exact distance tie that could matter are repeated with the exact
 // (distance, original index) selector, so the result is always the oracle's.
 template <class TAB>
-__device__ __forceinline__ void knn5_grid(const GridView& g, TAB& tab, float qx, float qy, float qz, float bound, Top5& best, int dbg = 0, PhaseProbe* pp = nullptr) {
+__device__ __forceinline__ void knn5_grid(const GridView& g, TAB& tab, float qx, float qy, float qz, float bound, Top5& best, int dbg = 0, PhaseProbe* pp = nullptr, KeepOut* ko = nullptr) {
+    if (ko) { ko->m = 0.f; ko->cnt = 5; ko->j5 = -1; }
     if (dbg & 32768) { knn5_grid_sel<Sel5>(g, tab, qx, qy, qz, bound, best); return; }   // A/B: exact selector only
-    const bool redo = knn5_grid_sel<Sel5K>(g, tab, qx, qy, qz, bound, best, pp);
+    const bool redo = knn5_grid_sel<Sel5K>(g, tab, qx, qy, qz, bound, best, pp, ko);
     PHASE_STAMP(pp, 5, best.d[4]);                                          // five winners resolved (exact distances, order)
     if (redo && !(dbg & 8192)) knn5_grid_sel<Sel5>(g, tab, qx, qy, qz, bound, best);   // bit 8192: profiling only (results then inexact on ties)
+}
+
+// ================================================================================================
+// Verified neighbour cache (round 4).  Outer iterations re-associate the SAME queries against the SAME map at poses that soon differ by
+// micrometres (the bench registration: 0.3 m, 6 cm, 4 mm, 0.1 mm, then below the f32 resolution of the transformed points), yet every
+// launch walked ~25 candidates per query again.  A full search now leaves, per query: the position p0 it was made at, the array
+// positions of its nearest 5 (or 6) map points, and a MARGIN m such that at p0 every other map point is farther than the farthest kept
+// member by more than m:  sqrt(lower bound of all others) - sqrt(upper bound of the members) > m.  The lower bound is exact knowledge
+// of the search — the bucket of the first key that fell off the selector (all candidates of the inner 27 cells are offered to it) and
+// the distance to the faces of the inner block when the shell was ruled out; the cut (5 | rest or 6 | rest) is the one with the wider gap.
+// At a new position p with |p - p0| = delta every member is at most delta farther and every other point at most delta nearer, so
+// 2 delta < m  =>  the kept members are STILL strictly nearer than every other map point: the exact 5-NN are the five nearest of them.
+// Their exact f32 distances are recomputed with the search's own dist2 and ordered by (distance, original index), i.e. the Top5 is
+// the one the full search would produce, bit for bit (tests/test_nn_keep_gpu.py) — the launch skips range words, the walk and the winners'
+// resolution for that query.  A miss (margin used up, record absent, a member beyond the gate) simply searches and refreshes the record.
+// Layout per (slot, kind): a[n] float4 (p0, m), b[n] int4 (j0..j3), c[n] int4 (j4, j5, -, count) in one buffer; records are tied to the
+// map index and the query cloud (reset by lili_map_set / lili_s2m_set_queries), not to any pose.  MatchParams::nn_keep: 0 off, 1 write
+// only (first launch after a pose reset: nothing can hit, save the loads), 2 read + write.
+// ================================================================================================
+struct KeepRec { float4 a; int4 b; int4 c; };
+__device__ __forceinline__ void keep_load(const int* __restrict__ keep, int n_q, int i, bool on, KeepRec& r) {
+    r.a = make_float4(0.f, 0.f, 0.f, 0.f); r.b = make_int4(0, 0, 0, 0); r.c = make_int4(0, 0, 0, 5);
+    if (on) {
+        r.a = reinterpret_cast<const float4*>(keep)[i];
+        r.b = reinterpret_cast<const int4*>(keep)[(size_t)n_q + i];
+        r.c = reinterpret_cast<const int4*>(keep)[(size_t)2 * n_q + i];
+    }
+}
+__device__ __forceinline__ void keep_store(int* __restrict__ keep, int n_q, int i, float px, float py, float pz, const Top5& nn, const KeepOut& ko) {
+    reinterpret_cast<float4*>(keep)[i] = make_float4(px, py, pz, ko.m);
+    reinterpret_cast<int4*>(keep)[(size_t)n_q + i] = make_int4(nn.j[0], nn.j[1], nn.j[2], nn.j[3]);
+    reinterpret_cast<int4*>(keep)[(size_t)2 * n_q + i] = make_int4(nn.j[4], ko.j5, 0, ko.cnt);
+}
+// the test alone (no memory access): the record's margin covers the move from p0 to (px, py, pz)
+__device__ __forceinline__ bool keep_covers(const KeepRec& r, float px, float py, float pz) {
+    const float dx = px - r.a.x, dy = py - r.a.y, dz = pz - r.a.z;
+    const float delta = sqrtf(dx * dx + dy * dy + dz * dz) * 1.001f + 1e-7f;          // conservative against the f32 roundings
+    return r.a.w > 0.f && 2.f * delta < r.a.w;
+}
+// Lanes whose record covers the move: the members' points, exact distances, oracle order -> nn.  Returns false (nn untouched in meaning) if a member
+// lies beyond `bound`, where the bounded search would have reported "no fifth neighbour" instead of the point.
+__device__ __forceinline__ bool keep_fill(const GridView& g, const KeepRec& r, float px, float py, float pz, float bound, Top5& nn) {
+    const bool six = r.c.w == 6;
+    int jm[6] = {r.b.x, r.b.y, r.b.z, r.b.w, r.c.x, six ? r.c.y : r.c.x};
+    float4 pm[6];
+    unsigned long long e[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) pm[k] = load_pt(g, jm[k]);
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        asm volatile("" : "+v"(pm[k].w));
+        e[k] = ((unsigned long long)__float_as_uint(dist2(pm[k], px, py, pz)) << 32) | (unsigned)__float_as_int(pm[k].w);
+    }
+    if (!six) e[5] = ~0ull;
+    const bool unsorted = !(e[0] <= e[1] && e[1] <= e[2] && e[2] <= e[3] && e[3] <= e[4] && e[4] <= e[5]);
+    if (__any(unsorted)) {      // the members changed their order since the record was made (rare at the moves that hit): 12 compare-exchanges
+#define LILI_CE6(a, b) { const bool sw = e[b] < e[a]; const unsigned long long ea = e[a], eb = e[b]; const int ja = jm[a], jb = jm[b]; \
+                         const float4 pa_ = pm[a], pb_ = pm[b]; \
+                         e[a] = sw ? eb : ea; e[b] = sw ? ea : eb; jm[a] = sw ? jb : ja; jm[b] = sw ? ja : jb; \
+                         pm[a].x = sw ? pb_.x : pa_.x; pm[a].y = sw ? pb_.y : pa_.y; pm[a].z = sw ? pb_.z : pa_.z; pm[a].w = sw ? pb_.w : pa_.w; \
+                         pm[b].x = sw ? pa_.x : pb_.x; pm[b].y = sw ? pa_.y : pb_.y; pm[b].z = sw ? pa_.z : pb_.z; pm[b].w = sw ? pa_.w : pb_.w; }
+        LILI_CE6(0, 5) LILI_CE6(1, 3) LILI_CE6(2, 4) LILI_CE6(1, 2) LILI_CE6(3, 4) LILI_CE6(0, 3) LILI_CE6(2, 5) LILI_CE6(0, 1) LILI_CE6(2, 3) LILI_CE6(4, 5) LILI_CE6(1, 2) LILI_CE6(3, 4)
+#undef LILI_CE6
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) { nn.d[k] = __uint_as_float((unsigned)(e[k] >> 32)); nn.j[k] = jm[k]; nn.p[k] = pm[k]; }
+    nn.have = true; nn.aux = 0;
+    return nn.d[4] <= bound;
+}
+// the association's neighbour search with the cache in front of it: `rec` was loaded with the query (keep_load), `mode` = MatchParams::nn_keep
+template <class TAB>
+__device__ __forceinline__ void knn5_keep(const GridView& g, TAB& tab, int* __restrict__ keep, int n_q, int i, int mode, const KeepRec& rec,
+                                          float px, float py, float pz, float bound, Top5& nn, int dbg, PhaseProbe* pp) {
+    if (!keep || mode == 0) { knn5_grid(g, tab, px, py, pz, bound, nn, dbg, pp); return; }
+    // All or nothing per wave: a wave in which one lane has to search lives as long as the search anyway, so the others search with it — no
+    // divergent double work, and every record of the wave is refreshed at the current position (the smallest possible delta next time).
+    const unsigned long long active = __ballot(1);
+    bool hit = mode == 2 && __ballot(keep_covers(rec, px, py, pz)) == active;
+    if (hit) hit = __ballot(keep_fill(g, rec, px, py, pz, bound, nn)) == active;
+    if (hit) { PHASE_STAMP(pp, 2, nn.d[4]); PHASE_STAMP(pp, 3, nn.d[4]); PHASE_STAMP(pp, 4, nn.d[4]); PHASE_STAMP(pp, 5, nn.d[4]); }      // (phase-probe builds only)
+    if (!hit) {
+        KeepOut ko;
+        knn5_grid(g, tab, px, py, pz, bound, nn, dbg, pp, &ko);
+        keep_store(keep, n_q, i, px, py, pz, nn, ko);
+    }
 }
 
 // Correspondence counting without atomics on a shared word (3128 same-address atomics cost ~40 us on
@@ -530,40 +639,13 @@ __device__ __forceinline__ void store_debug_nn(const GridView& g, const Top5& nn
     }
 }
 
-// Search bound of one query: the reference's gate, tightened by the query's 5 neighbours of the previous association
-// of the same scan against the same map index (positions in the cell-sorted array, -1 = none).  Those are five real
-// map points, so the true 5th-nearest distance cannot exceed their largest distance w at the new pose; everything
-// farther is irrelevant and rows / shell cells beyond it are pruned from the first candidate on.  The result is the
-// same exact 5-NN for any pose change — the cache only makes the bound tight when the pose moved little.
-__device__ __forceinline__ float seeded_bound(const GridView& g, double gate, const int* __restrict__ nn_cache, int n_q, int i,
-                                              float px, float py, float pz) {
-    float bound = gate_bound(gate);
-    if (nn_cache) {
-        int c0 = nn_cache[i], c1 = nn_cache[(size_t)n_q + i], c2 = nn_cache[(size_t)2 * n_q + i], c3 = nn_cache[(size_t)3 * n_q + i],
-            c4 = nn_cache[(size_t)4 * n_q + i];
-        if ((c0 | c1 | c2 | c3 | c4) >= 0) {
-            float w = dist2(load_pt(g, c0), px, py, pz);
-            w = fmaxf(w, dist2(load_pt(g, c1), px, py, pz));
-            w = fmaxf(w, dist2(load_pt(g, c2), px, py, pz));
-            w = fmaxf(w, dist2(load_pt(g, c3), px, py, pz));
-            w = fmaxf(w, dist2(load_pt(g, c4), px, py, pz));
-            if (w < bound) bound = __uint_as_float(__float_as_uint(w) + 1u);   // strictly above w: the five seeds themselves must enter
-        }
-    }
-    return bound;
-}
-__device__ __forceinline__ void store_nn_cache(int* __restrict__ nn_cache, int n_q, int i, const Top5& nn) {
-    if (!nn_cache) return;
-#pragma unroll
-    for (int k = 0; k < 5; k++) nn_cache[(size_t)k * n_q + i] = nn.j[k];
-}
-
 // findCorrespondingSurfFeatures body after the kNN (L/src/BackendFusion.cpp:1613-1679 and variants)
 __device__ __forceinline__ bool surf_fit(const GridView& g, const MatchParams& P, const Top5& nn, float4 ql, float px, float py, float pz,
                                          float4& rn, double& score) {
     rn = make_float4(0.f, 0.f, 0.f, 0.f);
     score = 0.0;
     if ((P.debug & 1) && nn.j[4] >= 0) { rn.x = nn.d[4]; return nn.d[4] < 0.5f; }
+    if (P.debug & 65536) { rn.x = nn.d[4]; return nn.j[4] >= 0 && (double)nn.d[4] < P.kd_max_radius; }   // ablation (tools/assoc_split_probe.sh): the search alone, every path incl. the cooperative kernels
     if (!(nn.j[4] >= 0 && (double)nn.d[4] < P.kd_max_radius)) return false;   // L:1615
     float4 m[5];
 #pragma unroll
