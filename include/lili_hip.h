@@ -293,7 +293,8 @@ int lili_s2m_get_neighbors(lili_ctx* ctx, int slot, int kind, size_t n_q, int32_
 /* The verified neighbour cache (option "nn_cache") of (slot, kind): per query (x, y, z, margin) = the map-frame position of its last FULL neighbour search
  * and the margin that search left (0 = no usable record).  A record that is unchanged after an association means that query kept its neighbours
  * without a search.  Tests / tools.  Blocking. */
-int lili_s2m_debug_nn_cache(lili_ctx* ctx, int slot, int kind, size_t n_q, float* pos_margin /*4 per query*/);
+int lili_s2m_debug_nn_cache(lili_ctx* ctx, int slot, int kind, size_t n_q, float* pos_margin /*4 per query*/,
+                            int32_t* tail /*4 per query, optional: 5th and 6th member, bits of the fit margin, member count | has_fit << 8 | fit_ok << 9*/);
 
 /* ---- device-resident outer iterations (no host round trip) ----------------------------------- */
 

@@ -619,19 +619,21 @@ static int bin_queries(lili_ctx* ctx, KindSlot& ks, MapIndex& m, const PoseArg& 
     return LILI_OK;
 }
 
-// the verified neighbour cache of (slot, kind): buffer of 48 bytes per query, zeroed = no record (lili_s2m_dev.h); *out = nullptr when the option is off
+// the verified neighbour cache of (slot, kind): buffer of 96 bytes per query, zeroed = no record (lili_s2m_dev.h); *out = nullptr when the option is off
 static int keep_buffer(lili_ctx* ctx, KindSlot& ks, int** out) {
     *out = nullptr;
     if (!ctx->nn_cache || ks.n_q == 0) return LILI_OK;
-    HIPCHK(ks.nn_cache.ensure((size_t)ks.n_q * 48));
-    if (!ks.nn_cache_valid) { HIPCHK(hipMemsetAsync(ks.nn_cache.p, 0, (size_t)ks.n_q * 48, ctx->stream)); ks.nn_cache_valid = true; }
+    HIPCHK(ks.nn_cache.ensure((size_t)ks.n_q * 96));       // kKeepBytes of lili_s2m_dev.h
+    if (!ks.nn_cache_valid) { HIPCHK(hipMemsetAsync(ks.nn_cache.p, 0, (size_t)ks.n_q * 96, ctx->stream)); ks.nn_cache_valid = true; }
     *out = ks.nn_cache.as<int>();
     return LILI_OK;
 }
-// MatchParams::nn_keep of the next one-lane association launch of `slot`: write-only right after a pose reset (nothing can hit), else read + write
+// MatchParams::nn_keep of the next one-lane association launch of `slot`: 0 right after a pose reset — a registration starts decimetres away from the
+// records of its scan's previous registration (nothing can hit) and ends next to them, so that launch neither reads nor REPLACES them: the launches that
+// follow find records made near the pose they are converging to —, else 2 (read + write).
 static int keep_mode(lili_ctx* ctx, KindSlot& ks) {
     if (!ctx->nn_cache) return 0;
-    const int mode = ks.keep_skip_read ? 1 : 2;
+    const int mode = ks.keep_skip_read ? 0 : 2;
     ks.keep_skip_read = false;
     return mode;
 }
@@ -1335,14 +1337,18 @@ int lili_s2m_get_neighbors(lili_ctx* ctx, int slot, int kind, size_t n_q, int32_
 
 // The verified neighbour cache of (slot, kind) as it stands (tests / tools): per query (p0.x, p0.y, p0.z, margin) — the map-frame position of the query's
 // last FULL search and the margin that search left (0: no usable record); a query whose record did not change across a launch was served from the cache.
-int lili_s2m_debug_nn_cache(lili_ctx* ctx, int slot, int kind, size_t n_q, float* pos_margin /*4 per query*/) {
+int lili_s2m_debug_nn_cache(lili_ctx* ctx, int slot, int kind, size_t n_q, float* pos_margin /*4 per query*/, int32_t* tail /*4 per query, optional*/) {
     if (!ctx) return LILI_E_ARG;
     ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS && (kind == 0 || kind == 1) && pos_margin, "debug_nn_cache: bad argument");
     KindSlot& ks = ctx->slots[slot].k[kind];
     ARGCHK(n_q == (size_t)ks.n_q, "debug_nn_cache: n_q mismatch");
     if (!ctx->nn_cache || !ks.nn_cache_valid || !ks.nn_cache.p) return ctx->fail(LILI_E_STATE, "debug_nn_cache: no cache (option nn_cache off, or no one-lane association since set_queries / map_set)");
     HIPCHK(hipSetDevice(ctx->device));
-    if (n_q) { HIPCHK(hipMemcpyAsync(pos_margin, ks.nn_cache.p, n_q * 16, hipMemcpyDeviceToHost, ctx->stream)); HIPCHK(hipStreamSynchronize(ctx->stream)); }
+    if (n_q) {
+        HIPCHK(hipMemcpyAsync(pos_margin, ks.nn_cache.p, n_q * 16, hipMemcpyDeviceToHost, ctx->stream));
+        if (tail) HIPCHK(hipMemcpyAsync(tail, static_cast<const char*>(ks.nn_cache.p) + n_q * 32, n_q * 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
     return LILI_OK;
 }
 

@@ -26,13 +26,19 @@ for reg in range(2):
     for it in range(10):
         m.iterate(0, 1, L.MASK_SURF)
         try:
-            rec = m.nn_cache_records(0, L.KIND_SURF, n)
+            rec, tail = m.nn_cache_records(0, L.KIND_SURF, n, with_tail=True)
         except Exception as e:
             print("iteration", it, "no cache yet:", e); continue
         usable = rec[:, 3] > 0
         nw = n // 64
         row = {"registration": reg, "iteration": it + 1, "usable_lanes": round(float(usable.mean()), 5), "waves_all_usable": round(float(usable[:nw * 64].reshape(nw, 64).all(1).mean()), 4),
                "margin_median_m": round(float(np.median(rec[usable, 3])), 5) if usable.any() else None}
+        mo = tail[:, 2].copy().view(np.float32)
+        has_fit, fit_ok = (tail[:, 3] & 256) != 0, (tail[:, 3] & 512) != 0
+        row.update(has_fit=round(float(has_fit.mean()), 5), fit_ok=round(float(fit_ok.mean()), 5), six=round(float(((tail[:, 3] & 255) == 6).mean()), 4),
+                   fit_margin_gt_1e_6=round(float((mo > 1e-6).mean()), 5), fit_margin_median=float(np.median(mo[mo > 0])) if (mo > 0).any() else None,
+                   waves_all_fit_margin=round(float((mo > 1e-6)[:nw * 64].reshape(nw, 64).all(1).mean()), 4),
+                   lanes_without_fit_margin_but_usable=int((usable & ~(mo > 1e-6)).sum()))
         if prev is not None:
             same = (rec == prev).all(1)
             row["lanes_served"] = round(float(same.mean()), 5)
