@@ -721,7 +721,7 @@ __device__ __forceinline__ void assoc_surf_body(
         bool need_search = true;
         if (kmode == 2 && !TILED && !(P.debug & 2) && __ballot(!live || keep_covers(krec, px, py, pz)) == ~0ull) {
             bool same_order = false, filled = true;
-            if (live) { keep_load_members(nn_cache, n_q, i, krec); filled = keep_fill<false>(g, krec, px, py, pz, gate_bound(P.kd_max_radius), nn, same_order) && same_order && (krec.c.w & 256); }
+            if (live) { keep_load_members(nn_cache, n_q, i, krec); filled = keep_fill<false>(g, krec, px, py, pz, gate_bound(P.kd_max_radius), nn, same_order) && same_order && ((krec.c.w & 256) || !((double)nn.d[4] < P.kd_max_radius)); }      // (a record without a fit — its fifth neighbour was beyond the gate — serves as long as it still is)
             if (__ballot(filled) == ~0ull) {
                 need_search = false;
                 PHASE_STAMP(pp, 2, nn.d[4]); PHASE_STAMP(pp, 3, nn.d[4]); PHASE_STAMP(pp, 4, nn.d[4]); PHASE_STAMP(pp, 5, nn.d[4]);
@@ -730,7 +730,7 @@ __device__ __forceinline__ void assoc_surf_body(
                     float4 rn; double score;
                     PlaneFit used;
                     store_debug_nn(g, nn, i, dbg_idx, dbg_d2);
-                    ok = surf_fit_keep(g, P, nn, ql, px, py, pz, rn, score, true, nn_cache, n_q, i, krec.c.w, used);
+                    ok = surf_fit_keep(g, P, nn, ql, px, py, pz, rn, score, (krec.c.w & 256) != 0, nn_cache, n_q, i, krec.c.w, used);
                     PHASE_STAMP(pp, 6, rn.w);
                     rec_nd[i] = rn;
                     rec_score[i] = score;
@@ -740,7 +740,7 @@ __device__ __forceinline__ void assoc_surf_body(
             }
         }
         if (need_search) {
-            KeepOut ko; ko.m = 0.f; ko.cnt = 5; ko.j5 = -1; ko.m_ord = 0.f;
+            KeepOut ko; ko.m = 0.f; ko.cnt = 5; ko.j5 = -1; ko.m_ord = 0.f; ko.want = kmode != 0;
             if (P.debug & 2) {
 #pragma unroll
                 for (int k = 0; k < 5; k++) { nn.d[k] = 0.01f * (k + 1); nn.j[k] = (i * 7 + k) % g.n_points; }
@@ -826,7 +826,7 @@ __device__ __forceinline__ void assoc_edge_body(
     float px = (float)pmd.x, py = (float)pmd.y, pz = (float)pmd.z;
     Top5 nn; nn.have = false;
     int how = 0;
-    KeepOut ko; ko.m = 0.f; ko.cnt = 5; ko.j5 = -1; ko.m_ord = 0.f;
+    KeepOut ko; ko.m = 0.f; ko.cnt = 5; ko.j5 = -1; ko.m_ord = 0.f; ko.want = true;
     if constexpr (TILED) knn5_tiled(g, L, tab, live, px, py, pz, nn, P.debug);
     else if (live) how = knn5_keep(g, tab, nn_cache, n_q, i, kmode, krec, px, py, pz, gate_bound(P.edge_gate), nn, 0, (PhaseProbe*)nullptr, ko);
     bool ok = false;

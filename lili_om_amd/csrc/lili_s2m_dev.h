@@ -106,7 +106,7 @@ __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) { 
 // What the full search hands to the verified neighbour cache (see keep_* below): the margin by which the cached members beat everything else, how many
 // members that cut keeps (5 or 6) and the array position of the sixth.
 struct PlaneFit { double nv[3]; double ninv; double sum_w; bool ok; bool have; };      // ok = false: rejected whatever the query's position (reflectivity / plane gates); have: a fit was made at all
-struct KeepOut { float m; int cnt; int j5; float m_ord; };     // m_ord: the margin within which even the ORDER of the five (and which five) cannot change
+struct KeepOut { float m; int cnt; int j5; float m_ord; bool want; };     // m_ord: the margin within which even the ORDER of the five (and which five) cannot change
 struct Sel5K {
     unsigned k[6];
     unsigned k6v;    // the SEVENTH smallest key seen (value only: its bucket is a lower bound for every candidate outside the held six)
@@ -190,7 +190,7 @@ struct Sel5K {
         for (int s = 0; s < 5; s++) { t.d[s] = __uint_as_float((unsigned)(e[s] >> 32)); t.j[s] = jr[s]; t.p[s] = pp[s]; }
         t.aux = tc;
         t.have = !redo;
-        if (ko) {
+        if (ko && ko->want) {
             const int j5 = where(k[5]);
             const float d5 = __uint_as_float((unsigned)(e[4] >> 32));                       // exact, the largest of the five
             const float lb6 = fminf(__uint_as_float(k[5] & ~63u), lbo), ub6 = __uint_as_float(k[5] | 63u), lb7 = fminf(__uint_as_float(k6v & ~63u), lbo);
@@ -632,7 +632,7 @@ __device__ __forceinline__ bool keep_fill(const GridView& g, const KeepRec& r, f
 template <class TAB>
 __device__ __forceinline__ int knn5_keep(const GridView& g, TAB& tab, const int* __restrict__ keep, int n_q, int i, int mode, KeepRec& rec,
                                          float px, float py, float pz, float bound, Top5& nn, int dbg, PhaseProbe* pp, KeepOut& ko) {
-    ko.m = 0.f; ko.cnt = 5; ko.j5 = -1; ko.m_ord = 0.f;
+    ko.m = 0.f; ko.cnt = 5; ko.j5 = -1; ko.m_ord = 0.f; ko.want = true;
     if (!keep || mode == 0) { knn5_grid(g, tab, px, py, pz, bound, nn, dbg, pp); return 0; }
     const unsigned long long active = __ballot(1);
     bool hit = __ballot(keep_covers(rec, px, py, pz)) == active;
