@@ -95,11 +95,8 @@ int lili_set_debug(lili_ctx* ctx, int keep_neighbors);
  * bin_queries; default 0), "max_cells" (cap on grid cells of the map index; coarser cells stay exact),
  * "grid_reach" (1 = cells of the gate radius, 27-cell search; 2 = smaller cells, inner 27 cells first and the shell of
  * the 125-cell block on demand; default 2; takes effect at the next lili_map_set), "cell_pct" (reach 2: cell edge in %
- * of the gate radius, 50..100, default 65), "nn_cache" (1 = verified neighbour cache of the one-lane association kernels: a full search leaves, per
- * query, its position, its nearest 5-6 map points and the margin by which they beat every other map point; a later association of the same
- * queries against the same map index at a pose that moves the query by less than half that margin keeps those neighbours — provably the exact
- * 5-NN, distances recomputed, same (distance, index) order — without range words, candidate walk and winners' resolution; default 1;
- * 0 = every launch searches; the records are dropped by lili_map_set / lili_s2m_set_queries), "fuse_tail" (1 = the reduction of the block
+ * of the gate radius, 50..100, default 65), "nn_cache" (1 = tighten each query's search bound with its neighbours of
+ * the previous association of the same scan; default 0, measured slower), "fuse_tail" (1 = the reduction of the block
  * partials and the GN update run inside the linearisation launch, in its last block; default 0 = separate launch, which is
  * faster on MI355X; may be changed at any time), "merge_kinds" (1 = surf and edge of a keyframe share ONE association launch and ONE
  * linearisation launch; default 1), "p2p_fusion" (0 = lili_s2m_iterate_sharded runs lili_p2p_allreduce as its own launches like any
@@ -290,11 +287,6 @@ int lili_s2m_get_edge_records(lili_ctx* ctx, int slot, size_t capacity, int32_t*
                               float* pt_a /*3*/, float* pt_b /*3*/, float* s, size_t* n_out);
 /* Per-query neighbour lists of the last associate (requires lili_set_debug(ctx, 1)): idx/d2 are n_q x 5. */
 int lili_s2m_get_neighbors(lili_ctx* ctx, int slot, int kind, size_t n_q, int32_t* idx, float* d2);
-/* The verified neighbour cache (option "nn_cache") of (slot, kind): per query (x, y, z, margin) = the map-frame position of its last FULL neighbour search
- * and the margin that search left (0 = no usable record).  A record that is unchanged after an association means that query kept its neighbours
- * without a search.  Tests / tools.  Blocking. */
-int lili_s2m_debug_nn_cache(lili_ctx* ctx, int slot, int kind, size_t n_q, float* pos_margin /*4 per query*/,
-                            int32_t* tail /*4 per query, optional: 5th and 6th member, bits of the fit margin, member count | has_fit << 8 | fit_ok << 9*/);
 
 /* ---- device-resident outer iterations (no host round trip) ----------------------------------- */
 

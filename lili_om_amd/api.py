@@ -147,7 +147,6 @@ _SIGS = {
     "lili_s2m_get_surf_records": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]),
     "lili_s2m_get_edge_records": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t)]),
     "lili_s2m_get_neighbors": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]),
-    "lili_s2m_debug_nn_cache": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]),
     "lili_s2m_pose_set": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "lili_s2m_pose_get": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "lili_s2m_last_step": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -427,13 +426,6 @@ class ScanToMapMatcher:
         d2 = np.zeros((n_q, 5), np.float32)
         self.ctx._chk(self.lib.lili_s2m_get_neighbors(self.ctx.h, slot, kind, n_q, _ptr(idx), _ptr(d2)))
         return idx, d2
-
-    def nn_cache_records(self, slot, kind, n_q, with_tail=False):
-        """(n_q, 4) float32: map-frame position of every query's last FULL neighbour search and the margin it left (0 = no usable record)."""
-        out = np.zeros((n_q, 4), np.float32)
-        tail = np.zeros((n_q, 4), np.int32) if with_tail else None
-        self.ctx._chk(self.lib.lili_s2m_debug_nn_cache(self.ctx.h, slot, kind, n_q, _ptr(out), _ptr(tail) if with_tail else None))
-        return (out, tail) if with_tail else out
 
     # -- device-resident iterations -------------------------------------------------------------
     def pose_set(self, slot, t, q):

@@ -619,26 +619,7 @@ static int bin_queries(lili_ctx* ctx, KindSlot& ks, MapIndex& m, const PoseArg& 
     return LILI_OK;
 }
 
-// the verified neighbour cache of (slot, kind): buffer of 96 bytes per query, zeroed = no record (lili_s2m_dev.h); *out = nullptr when the option is off
-static int keep_buffer(lili_ctx* ctx, KindSlot& ks, int** out) {
-    *out = nullptr;
-    if (!ctx->nn_cache || ks.n_q == 0) return LILI_OK;
-    HIPCHK(ks.nn_cache.ensure((size_t)ks.n_q * 96));       // kKeepBytes of lili_s2m_dev.h
-    if (!ks.nn_cache_valid) { HIPCHK(hipMemsetAsync(ks.nn_cache.p, 0, (size_t)ks.n_q * 96, ctx->stream)); ks.nn_cache_valid = true; }
-    *out = ks.nn_cache.as<int>();
-    return LILI_OK;
-}
-// MatchParams::nn_keep of the next one-lane association launch of `slot`: 0 right after a pose reset — a registration starts decimetres away from the
-// records of its scan's previous registration (nothing can hit) and ends next to them, so that launch neither reads nor REPLACES them: the launches that
-// follow find records made near the pose they are converging to —, else 2 (read + write).
-static int keep_mode(lili_ctx* ctx, KindSlot& ks) {
-    if (!ctx->nn_cache) return 0;
-    const int mode = ks.keep_skip_read ? 0 : 2;
-    ks.keep_skip_read = false;
-    return mode;
-}
-static int launch_associate(lili_ctx* ctx, int slot, int kind, const PoseArg& pa, const MatchParams& P_in) {
-    MatchParams P = P_in;
+static int launch_associate(lili_ctx* ctx, int slot, int kind, const PoseArg& pa, const MatchParams& P) {
     KindSlot& ks = ctx->slots[slot].k[kind];
     if (!ks.has_queries) return ctx->fail(LILI_E_STATE, "associate: set_queries first");
     MapIndex& m = ctx->map[kind];
@@ -665,10 +646,13 @@ static int launch_associate(lili_ctx* ctx, int slot, int kind, const PoseArg& pa
     const int* perm = nullptr;
     const int2* tiles = nullptr;
     ks.n_assoc_blocks = ks.n_blocks;
-    // verified neighbour cache (lili_s2m_dev.h): records of this scan's last full searches against this map index
+    // neighbour cache of the previous association of this scan against this map index (seeds the search bound)
     int* nnc = nullptr;
-    { const int rk = keep_buffer(ctx, ks, &nnc); if (rk != LILI_OK) return rk; }
-    P.nn_keep = nnc ? keep_mode(ctx, ks) : 0;
+    if (ctx->nn_cache) {
+        HIPCHK(ks.nn_cache.ensure((size_t)n * 5 * sizeof(int)));
+        if (!ks.nn_cache_valid) { HIPCHK(hipMemsetAsync(ks.nn_cache.p, 0xFF, (size_t)n * 5 * sizeof(int), ctx->stream)); ks.nn_cache_valid = true; }
+        nnc = ks.nn_cache.as<int>();
+    }
     if (m.has_fine && !ctx->bin_queries && !ctx->balance) {      // dense map: fine index first, gate-sized index for the queries it cannot settle
         if (kind == LILI_KIND_SURF && P.variant == LILI_VARIANT_LIVOX && (!m.has_aux || !ks.has_aux))
             return ctx->fail(LILI_E_STATE, "associate: Livox variant needs reflectivity (aux_offset) on the surf map and the surf queries");
@@ -737,11 +721,9 @@ static int launch_sum_counts(lili_ctx* ctx, int slot, int kind_mask, int* d_out 
 
 // Both kinds of a keyframe in one launch (k_associate_both): only the plain direct path — one wave per workgroup, caller's
 // query order, no dispatch-order or binning experiments.  Returns 1 if the slot is not eligible (the caller then launches per kind).
-static int launch_associate_both(lili_ctx* ctx, int slot, const PoseArg& pa, const MatchParams& P_in) {
+static int launch_associate_both(lili_ctx* ctx, int slot, const PoseArg& pa, const MatchParams& P) {
     if (ctx->bin_queries || ctx->tiled || ctx->balance) return 1;
-    const MatchParams& P = P_in;
     AssocArgs A[2];
-    int keep = 2;
     for (int kind = 0; kind < 2; kind++) {
         KindSlot& ks = ctx->slots[slot].k[kind];
         MapIndex& m = ctx->map[kind];
@@ -762,14 +744,15 @@ static int launch_associate_both(lili_ctx* ctx, int slot, const PoseArg& pa, con
             HIPCHK(ks.dbg_d2.ensure((size_t)n * 5 * sizeof(float)));
             a.dbg_idx = ks.dbg_idx.as<int>(); a.dbg_d2 = ks.dbg_d2.as<float>();
         }
-        { const int rk = keep_buffer(ctx, ks, &a.nn_cache); if (rk != LILI_OK) return rk; }
-        if (a.nn_cache) keep = std::min(keep, keep_mode(ctx, ks));
+        if (ctx->nn_cache) {
+            HIPCHK(ks.nn_cache.ensure((size_t)n * 5 * sizeof(int)));
+            if (!ks.nn_cache_valid) { HIPCHK(hipMemsetAsync(ks.nn_cache.p, 0xFF, (size_t)n * 5 * sizeof(int), ctx->stream)); ks.nn_cache_valid = true; }
+            a.nn_cache = ks.nn_cache.as<int>();
+        }
         a.block_counts = ks.block_counts.as<int>(); a.nb = ks.n_blocks;
         ks.n_assoc_blocks = ks.n_blocks; ks.has_records = true; ks.launches++;
     }
-    MatchParams Pk = P_in;
-    Pk.nn_keep = ctx->nn_cache ? keep : 0;
-    hipLaunchKernelGGL(k_associate_both, dim3(A[0].nb + A[1].nb), dim3(kAssocBlock), 0, ctx->stream, A[0], A[1], pa, Pk);
+    hipLaunchKernelGGL(k_associate_both, dim3(A[0].nb + A[1].nb), dim3(kAssocBlock), 0, ctx->stream, A[0], A[1], pa, P);
     HIPCHK(hipGetLastError());
     return LILI_OK;
 }
@@ -792,7 +775,7 @@ static int coop_lanes(const lili_ctx* ctx, int64_t n, bool first_after_reset) {
 // Association of the kinds in kind_mask by k_associate_coop (lili_s2m_coop.hip); `lin`: also linearise (flavours without count scaling) and
 // reduce + GN-update in a second launch.  Returns 1 if the configuration is not eligible — the caller then takes the one-lane kernels.
 static int launch_associate_coop(lili_ctx* ctx, int slot, int kind_mask, const PoseArg& pa, const MatchParams& P, bool lin, double* d_out) {
-    if (ctx->bin_queries || ctx->tiled || ctx->balance || (P.debug & (1 | 2 | 4096))) return 1;
+    if (ctx->bin_queries || ctx->tiled || ctx->balance || ctx->nn_cache || (P.debug & (1 | 2 | 4096))) return 1;
     Slot& sl = ctx->slots[slot];
     int64_t n_all = 0;
     for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) {
@@ -850,7 +833,7 @@ static int launch_associate_coop(lili_ctx* ctx, int slot, int kind_mask, const P
 // The cooperative association of EVERY slot of a window in ONE launch (k_associate_coop_window): the conditions of launch_associate_coop for every slot,
 // one L for all (by the total number of queries: the records do not depend on it).  Returns 1 if not eligible — the caller then launches slot by slot.
 static int launch_associate_coop_window(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, const double* t_assoc, const double* q_assoc, const MatchParams& P) {
-    if (n_slots < 2 || ctx->bin_queries || ctx->tiled || ctx->balance || (P.debug & (1 | 2 | 4096))) return 1;
+    if (n_slots < 2 || ctx->bin_queries || ctx->tiled || ctx->balance || ctx->nn_cache || (P.debug & (1 | 2 | 4096))) return 1;
     int64_t n_all = 0;
     bool first = false;
     for (int i = 0; i < n_slots; i++) {
@@ -918,7 +901,7 @@ static int launch_associate_coop_window(lili_ctx* ctx, const int* slots, int n_s
 // (the caller then iterates launch by launch).  Eligible: the configurations of launch_associate_coop with at most 256 workgroups.
 static int launch_iterate_persistent(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, int n_iters) {
     if (!ctx->persistent_iterate || n_iters < 2 || n_iters > 2000) return 1;
-    if (ctx->bin_queries || ctx->tiled || ctx->balance || ctx->fuse_tail) return 1;
+    if (ctx->bin_queries || ctx->tiled || ctx->balance || ctx->nn_cache || ctx->fuse_tail) return 1;
     MatchParams P = to_device_params(params);
     if (P.debug & (1 | 2 | 256 | 512 | 4096)) return 1;
     P.no_cost = 1;
@@ -1033,7 +1016,6 @@ static int launch_associate_lin_reduce(lili_ctx* ctx, int slot, int kind_mask, c
     // separate linearisation launch (which runs on otherwise idle SIMDs at four waves each).
     if (waves > 1600 && !ctx->fuse_lin_block) return 1;
     const int bs = ctx->fuse_lin_block ? ctx->fuse_lin_block : (waves <= 800 ? kAssocBlock : kBlock);
-    int keep = 2;
     for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) {
         KindSlot& ks = sl.k[kind];
         const int n = (int)ks.n_q;
@@ -1045,18 +1027,19 @@ static int launch_associate_lin_reduce(lili_ctx* ctx, int slot, int kind_mask, c
             HIPCHK(ks.dbg_d2.ensure((size_t)n * 5 * sizeof(float)));
             a.dbg_idx = ks.dbg_idx.as<int>(); a.dbg_d2 = ks.dbg_d2.as<float>();
         }
-        { const int rk = keep_buffer(ctx, ks, &a.nn_cache); if (rk != LILI_OK) return rk; }
-        if (a.nn_cache) keep = std::min(keep, keep_mode(ctx, ks));
+        if (ctx->nn_cache) {
+            HIPCHK(ks.nn_cache.ensure((size_t)n * 5 * sizeof(int)));
+            if (!ks.nn_cache_valid) { HIPCHK(hipMemsetAsync(ks.nn_cache.p, 0xFF, (size_t)n * 5 * sizeof(int), ctx->stream)); ks.nn_cache_valid = true; }
+            a.nn_cache = ks.nn_cache.as<int>();
+        }
         HIPCHK(ks.partials_wave.ensure((size_t)ks.n_blocks * kPartialStride * sizeof(double)));
         a.block_counts = ks.block_counts.as<int>(); a.nb = nblocks(n, bs);
         ks.n_assoc_blocks = a.nb; ks.has_records = true; ks.launches++;
     }
     // k_associate_lin: blocks [0, E.nb) edge, the rest surf
-    MatchParams Pk = P;
-    Pk.nn_keep = ctx->nn_cache ? keep : 0;
-    if (bs == kAssocBlock) hipLaunchKernelGGL(k_associate_lin<kAssocBlock>, dim3(A[0].nb + A[1].nb), dim3(kAssocBlock), 0, ctx->stream, A[0], A[1], pa, Pk,
+    if (bs == kAssocBlock) hipLaunchKernelGGL(k_associate_lin<kAssocBlock>, dim3(A[0].nb + A[1].nb), dim3(kAssocBlock), 0, ctx->stream, A[0], A[1], pa, P,
                                               sl.k[0].partials_wave.as<double>(), sl.k[1].partials_wave.as<double>());
-    else hipLaunchKernelGGL(k_associate_lin<kBlock>, dim3(A[0].nb + A[1].nb), dim3(kBlock), 0, ctx->stream, A[0], A[1], pa, Pk,
+    else hipLaunchKernelGGL(k_associate_lin<kBlock>, dim3(A[0].nb + A[1].nb), dim3(kBlock), 0, ctx->stream, A[0], A[1], pa, P,
                             sl.k[0].partials_wave.as<double>(), sl.k[1].partials_wave.as<double>());
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx->stream, (const double*)sl.k[0].partials_wave.as<double>(), A[0].nb,
                        (const double*)sl.k[1].partials_wave.as<double>(), A[1].nb, d_out, ctx->state(slot), 1 | (P.debug & 256), P2PView{});
@@ -1335,23 +1318,6 @@ int lili_s2m_get_neighbors(lili_ctx* ctx, int slot, int kind, size_t n_q, int32_
     return LILI_OK;
 }
 
-// The verified neighbour cache of (slot, kind) as it stands (tests / tools): per query (p0.x, p0.y, p0.z, margin) — the map-frame position of the query's
-// last FULL search and the margin that search left (0: no usable record); a query whose record did not change across a launch was served from the cache.
-int lili_s2m_debug_nn_cache(lili_ctx* ctx, int slot, int kind, size_t n_q, float* pos_margin /*4 per query*/, int32_t* tail /*4 per query, optional*/) {
-    if (!ctx) return LILI_E_ARG;
-    ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS && (kind == 0 || kind == 1) && pos_margin, "debug_nn_cache: bad argument");
-    KindSlot& ks = ctx->slots[slot].k[kind];
-    ARGCHK(n_q == (size_t)ks.n_q, "debug_nn_cache: n_q mismatch");
-    if (!ctx->nn_cache || !ks.nn_cache_valid || !ks.nn_cache.p) return ctx->fail(LILI_E_STATE, "debug_nn_cache: no cache (option nn_cache off, or no one-lane association since set_queries / map_set)");
-    HIPCHK(hipSetDevice(ctx->device));
-    if (n_q) {
-        HIPCHK(hipMemcpyAsync(pos_margin, ks.nn_cache.p, n_q * 16, hipMemcpyDeviceToHost, ctx->stream));
-        if (tail) HIPCHK(hipMemcpyAsync(tail, static_cast<const char*>(ks.nn_cache.p) + n_q * 32, n_q * 16, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-    }
-    return LILI_OK;
-}
-
 // --------------------------------------------------------------------------------------------
 // device-resident iterations
 // --------------------------------------------------------------------------------------------
@@ -1367,7 +1333,6 @@ int lili_s2m_pose_set(lili_ctx* ctx, int slot, const double t[3], const double q
     HIPCHK(hipMemcpyAsync(ctx->state(slot), &s, offsetof(SlotState, epoch), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));   // `s` is on this stack frame
     ctx->slots[slot].assoc_since_pose = 0;
-    for (auto& k : ctx->slots[slot].k) k.keep_skip_read = true;      // the next one-lane association cannot hit the neighbour cache: it only writes it
     return LILI_OK;
 }
 
@@ -1626,7 +1591,6 @@ int lili_s2m_pose_copy(lili_ctx* ctx, int dst_slot, int src_slot) {
     hipLaunchKernelGGL(k_pose_copy, dim3(1), dim3(8), 0, ctx->stream, ctx->state(dst_slot), ctx->state(src_slot));
     HIPCHK(hipGetLastError());
     ctx->slots[dst_slot].assoc_since_pose = 0;
-    for (auto& k : ctx->slots[dst_slot].k) k.keep_skip_read = true;
     return LILI_OK;
 }
 

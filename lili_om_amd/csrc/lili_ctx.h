@@ -67,8 +67,7 @@ struct KindSlot {
     DevBuf q, rec0, rec1, valid, dbg_idx, dbg_d2, partials, partials_wave, perm, keys, block_counts, tiles, nn_cache, order, block_cost;
     int launches = 0;        // association launches since set_queries (the dispatch order is rebuilt before launches 2 and 4)
     bool order_valid = false;
-    bool nn_cache_valid = false;   // nn_cache (the verified neighbour cache, 48 bytes per query: lili_s2m_dev.h) has been initialised for THIS scan against the CURRENT map index
-    bool keep_skip_read = true;    // the slot's pose was (re)set since this kind's last one-lane association: that launch cannot hit the neighbour cache, it only writes it
+    bool nn_cache_valid = false;   // nn_cache holds the neighbours of the last association of THIS scan against the CURRENT map index
     int n_assoc_blocks = 0;  // grid of the last association launch (= number of per-block counts)
     int n_tiles = 0;       // association grid when binned (tiles never span two super-cells)
     bool binned = false;   // perm holds the super-cell (Morton) order of the queries for the current scan
@@ -138,8 +137,7 @@ struct lili_ctx {
                                  // of freshly published partials through sc1 loads costs one block 3.4 us, a kernel boundary 1.5 us) — A/B only
     bool no_p2p_fusion = false;  // A/B: lili_s2m_iterate_sharded with lili_p2p_allreduce as separate launches (the generic path) instead of inside the count / reduce kernels
     bool merge_kinds = true;     // surf and edge of one keyframe in ONE association launch / ONE linearisation launch
-    bool nn_cache = true;        // verified neighbour cache of the one-lane association kernels (lili_s2m_dev.h, round 4): a query whose last full search left a margin larger than
-                                 // twice its move since keeps its neighbours without searching — exact, bit-identical results (option "nn_cache" = 0: every launch searches)
+    bool nn_cache = false;       // seed each query's search bound with its previous 5 neighbours (exact for any pose change)
     int cell_pct = 65;           // reach 2: cell edge in % of 1.01 * gate radius (>= 50)
     bool fine_grid = true;       // measure the map density in lili_map_set and build the fine index when a gate-sized cell holds more than fine_occupancy points
     int fine_occupancy = 12;

@@ -63,7 +63,6 @@ struct MatchParams {     // device copy of lili_s2m_params (+ derived values)
     double q_lb_inv[4];   // Eigen inverse() of q_lb (conjugate / squared norm), computed once on the host: IEEE divisions, same bits
     double q_lb_inv_jet[4];   // the same inverse as the plane factor sees it on ceres::Jet (LidarKeyframeFactor.h:86): conjugate * (1 / n2)
     double scale_surf_num, scale_edge_num;
-    int nn_keep;   // verified neighbour cache of the one-lane association kernels (lili_s2m_dev.h): 0 off, 1 write only, 2 read + write — set per launch
     int no_cost;   // 1: the robust cost value (slot 64 of the Gram record) is not computed — the fused iterate loops, whose record never leaves the library
     int debug;   // ablation switches for profiling only (LILI_DEBUG env): 1 = skip the plane/line fit, 2 = skip the search,
                  // 2048 = never fall back to the pivoted QR, 4096 = per-workgroup timestamps (tools/assoc_blocks.py), 8192 = no exact-selector

@@ -679,9 +679,6 @@ __device__ __forceinline__ void assoc_surf_body(
     int t = tile.x + threadIdx.x;
     int i = live ? (perm ? perm[t] : t) : 0;
     float4 ql = queries[live ? i : 0];     // requested before the (dependent, scalar) pose loads: the two latencies overlap
-    const int kmode = (TILED || !nn_cache || (P.debug & (1 | 2 | 65536))) ? 0 : P.nn_keep;      // verified neighbour cache (lili_s2m_dev.h): 0 off, 2 read + write
-    KeepRec krec;
-    keep_load(nn_cache, n_q, i, live && kmode == 2, krec);      // the query's record travels with it
     dq Q2; d3 T2;
     load_assoc_pose(pa, P, Q2, T2);
     d3 pmd = qrot(Q2, d3{(double)ql.x, (double)ql.y, (double)ql.z}) + T2;   // transformPoint, L:695-711
@@ -696,86 +693,27 @@ __device__ __forceinline__ void assoc_surf_body(
     PhaseProbe* const pp = nullptr;
 #endif
     PHASE_STAMP(pp, 1, px);                                                 // query loaded and moved into the map frame
+    if (P.debug & 2) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) { nn.d[k] = 0.01f * (k + 1); nn.j[k] = (i * 7 + k) % g.n_points; }
+    } else if constexpr (TILED) knn5_tiled(g, L, tab, live, px, py, pz, nn, P.debug);
+    else if (live) { knn5_grid(g, tab, px, py, pz, seeded_bound(g, P.kd_max_radius, nn_cache, n_q, i, px, py, pz), nn, P.debug, pp); store_nn_cache(nn_cache, n_q, i, nn); }
+    if (BS == 64 && !TILED && sched.block_cost) {   // cost of this block for the next launch's dispatch order
+        int c = live ? nn.aux : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c = max(c, __shfl_xor(c, o));
+        if (threadIdx.x == 0) sched.block_cost[bid] = c;
+    }
     bool ok = false;
-    // Path 3 of the verified neighbour cache, decided per wave before anything else: every lane's record says "same five neighbours, same order, same side of
-    // the gate" (keep_covers_fit) and nobody needs the neighbours themselves — the kept fit goes straight to the position-dependent tail.  A branch of its own
-    // from here to the stores, so that its few registers do not add to the search path's.
-    const bool need_nn = (dbg_idx != nullptr && !(P.debug & 131072)) || sched.block_cost != nullptr || (P.debug & 2) != 0 || TILED;      // (bit 131072: profiling with the debug rows as stamp storage only)
-    const bool fit_only = !need_nn && kmode == 2 && __ballot(!live || (keep_covers(krec, px, py, pz) && keep_covers_fit(krec, px, py, pz))) == ~0ull;
-    if (fit_only) {
-        PHASE_STAMP(pp, 2, krec.a.w); PHASE_STAMP(pp, 3, krec.a.w); PHASE_STAMP(pp, 4, krec.a.w); PHASE_STAMP(pp, 5, krec.a.w);
-        if (live) {
-            const PlaneFit kept = keep_fit(nn_cache, n_q, i, krec.c.w);
-            float4 rn = make_float4(0.f, 0.f, 0.f, 0.f); double score = 0.0;
-            ok = surf_finish(P, kept, px, py, pz, rn, score);
-            PHASE_STAMP(pp, 6, rn.w);
-            rec_nd[i] = rn;
-            rec_score[i] = score;
-            valid[i] = ok ? 1 : 0;
-            if (rec_out) { rec_out->ql = ql; rec_out->r0 = rn; rec_out->score = score; }
-        }
-    } else {
-        // Path H: every lane's record covers its move (keep_covers) and its members are still in the record's order — their points and exact distances from the
-        // record (keep_fill), the record's fit.  A wave in which a pair of members changed places (or a member left the gate) searches: a second copy of the
-        // plane fit in this branch cost the kernel 20 registers, i.e. the fourth wave of a SIMD.  A branch of its own down to the stores, like path 3.
-        bool need_search = true;
-        if (kmode == 2 && !TILED && !(P.debug & 2) && __ballot(!live || keep_covers(krec, px, py, pz)) == ~0ull) {
-            bool same_order = false, filled = true;
-            if (live) { keep_load_members(nn_cache, n_q, i, krec); filled = keep_fill<false>(g, krec, px, py, pz, gate_bound(P.kd_max_radius), nn, same_order) && same_order && ((krec.c.w & 256) || !((double)nn.d[4] < P.kd_max_radius)); }      // (a record without a fit — its fifth neighbour was beyond the gate — serves as long as it still is)
-            if (__ballot(filled) == ~0ull) {
-                need_search = false;
-                PHASE_STAMP(pp, 2, nn.d[4]); PHASE_STAMP(pp, 3, nn.d[4]); PHASE_STAMP(pp, 4, nn.d[4]); PHASE_STAMP(pp, 5, nn.d[4]);
-                if (BS == 64 && sched.block_cost && threadIdx.x == 0) sched.block_cost[bid] = 0;
-                if (live) {
-                    float4 rn; double score;
-                    PlaneFit used;
-                    store_debug_nn(g, nn, i, dbg_idx, dbg_d2);
-                    ok = surf_fit_keep(g, P, nn, ql, px, py, pz, rn, score, (krec.c.w & 256) != 0, nn_cache, n_q, i, krec.c.w, used);
-                    PHASE_STAMP(pp, 6, rn.w);
-                    rec_nd[i] = rn;
-                    rec_score[i] = score;
-                    valid[i] = ok ? 1 : 0;
-                    if (rec_out) { rec_out->ql = ql; rec_out->r0 = rn; rec_out->score = score; }
-                }
-            }
-        }
-        if (need_search) {
-            KeepOut ko; ko.m = 0.f; ko.cnt = 5; ko.j5 = -1; ko.m_ord = 0.f; ko.want = kmode != 0;
-            if (P.debug & 2) {
-#pragma unroll
-                for (int k = 0; k < 5; k++) { nn.d[k] = 0.01f * (k + 1); nn.j[k] = (i * 7 + k) % g.n_points; }
-            } else if constexpr (TILED) knn5_tiled(g, L, tab, live, px, py, pz, nn, P.debug);
-            else if (live) knn5_grid(g, tab, px, py, pz, gate_bound(P.kd_max_radius), nn, P.debug, pp, &ko);
-            if (BS == 64 && !TILED && sched.block_cost) {   // cost of this block for the next launch's dispatch order
-                int c = live ? nn.aux : 0;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) c = max(c, __shfl_xor(c, o));
-                if (threadIdx.x == 0) sched.block_cost[bid] = c;
-            }
-            if (live) {
-                float4 rn; double score;
-                PlaneFit fresh;
-                store_debug_nn(g, nn, i, dbg_idx, dbg_d2);
-                // a search that ends with the record's own five members in the record's order (a lane that merely had no margin to show for them) takes the
-                // record's fit: the record is read again here rather than held across the search
-                bool own = false; int oflags = 0;
-                if (kmode == 2) {
-                    const int4 mb = reinterpret_cast<const int4*>(nn_cache)[(size_t)n_q + i], mc = reinterpret_cast<const int4*>(nn_cache)[(size_t)2 * n_q + i];
-                    oflags = mc.w;
-                    own = (mc.w & 256) && nn.j[0] == mb.x && nn.j[1] == mb.y && nn.j[2] == mb.z && nn.j[3] == mb.w && nn.j[4] == mc.x;
-                }
-                ok = surf_fit_keep(g, P, nn, ql, px, py, pz, rn, score, own, nn_cache, n_q, i, oflags, fresh);
-                PHASE_STAMP(pp, 6, rn.w);                                           // plane fitted, gates evaluated
-                rec_nd[i] = rn;
-                rec_score[i] = score;
-                valid[i] = ok ? 1 : 0;
-                if (rec_out) { rec_out->ql = ql; rec_out->r0 = rn; rec_out->score = score; }
-                if (kmode != 0) {         // the search's record, with the fit and the margin within which the fit stays the fit
-                    const float mg = 2.f * (sqrtf((float)P.kd_max_radius) - sqrtf(nn.d[4])) * 0.998f - 1e-6f;       // ... incl. staying on this side of the gate (L:1615)
-                    keep_store(nn_cache, n_q, i, px, py, pz, nn, ko, fresh, fminf(ko.m_ord, mg));
-                }
-            }
-        }
+    if (live) {
+        store_debug_nn(g, nn, i, dbg_idx, dbg_d2);
+        float4 rn; double score;
+        ok = surf_fit(g, P, nn, ql, px, py, pz, rn, score);
+        PHASE_STAMP(pp, 6, rn.w);                                           // plane fitted, gates evaluated
+        rec_nd[i] = rn;
+        rec_score[i] = score;
+        valid[i] = ok ? 1 : 0;
+        if (rec_out) { rec_out->ql = ql; rec_out->r0 = rn; rec_out->score = score; }
     }
     if (rec_out) rec_out->ok = ok;
     store_block_count<BS>(ok, block_counts, vbid);
@@ -817,18 +755,13 @@ __device__ __forceinline__ void assoc_edge_body(
     int t = tile.x + threadIdx.x;
     int i = live ? (perm ? perm[t] : t) : 0;
     float4 ql = queries[live ? i : 0];     // requested before the (dependent, scalar) pose loads: the two latencies overlap
-    const int kmode = (TILED || !nn_cache) ? 0 : P.nn_keep;      // verified neighbour cache: the neighbours only (the line fit is redone; lili_s2m_dev.h)
-    KeepRec krec;
-    keep_load(nn_cache, n_q, i, live && kmode == 2, krec);
     dq Q2; d3 T2;
     load_assoc_pose(pa, P, Q2, T2);
     d3 pmd = qrot(Q2, d3{(double)ql.x, (double)ql.y, (double)ql.z}) + T2;
     float px = (float)pmd.x, py = (float)pmd.y, pz = (float)pmd.z;
     Top5 nn; nn.have = false;
-    int how = 0;
-    KeepOut ko; ko.m = 0.f; ko.cnt = 5; ko.j5 = -1; ko.m_ord = 0.f; ko.want = true;
     if constexpr (TILED) knn5_tiled(g, L, tab, live, px, py, pz, nn, P.debug);
-    else if (live) how = knn5_keep(g, tab, nn_cache, n_q, i, kmode, krec, px, py, pz, gate_bound(P.edge_gate), nn, 0, (PhaseProbe*)nullptr, ko);
+    else if (live) { knn5_grid(g, tab, px, py, pz, seeded_bound(g, P.edge_gate, nn_cache, n_q, i, px, py, pz), nn); store_nn_cache(nn_cache, n_q, i, nn); }
     bool ok = false;
     if (live) {
         store_debug_nn(g, nn, i, dbg_idx, dbg_d2);
@@ -836,7 +769,6 @@ __device__ __forceinline__ void assoc_edge_body(
         ok = edge_fit(g, P, nn, px, py, pz, ra, rb);
         rec_a[i] = ra; rec_b[i] = rb; valid[i] = ok ? 1 : 0;
         if (rec_out) { rec_out->ql = ql; rec_out->r0 = ra; rec_out->r1 = rb; }
-        if ((how == 0 || how == 4) && kmode != 0) { PlaneFit none; none.have = false; none.ok = false; none.nv[0] = none.nv[1] = none.nv[2] = none.ninv = none.sum_w = 0.0; keep_store(nn_cache, n_q, i, px, py, pz, nn, ko, none, 0.f); }
     }
     if (rec_out) rec_out->ok = ok;
     store_block_count<BS>(ok, block_counts, vbid);

@@ -103,13 +103,8 @@ __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) { 
 // their exact f32 distances are then recomputed from the re-loaded points and put into the oracle's (d2, index) order.
 // If the buckets coincide, or the fifth lies in the bucket of the search bound, the query is repeated with the exact
 // selector (about once in 1e5 queries on voxel-filtered maps; always on lattice ties).
-// What the full search hands to the verified neighbour cache (see keep_* below): the margin by which the cached members beat everything else, how many
-// members that cut keeps (5 or 6) and the array position of the sixth.
-struct PlaneFit { double nv[3]; double ninv; double sum_w; bool ok; bool have; };      // ok = false: rejected whatever the query's position (reflectivity / plane gates); have: a fit was made at all
-struct KeepOut { float m; int cnt; int j5; float m_ord; bool want; };     // m_ord: the margin within which even the ORDER of the five (and which five) cannot change
 struct Sel5K {
     unsigned k[6];
-    unsigned k6v;    // the SEVENTH smallest key seen (value only: its bucket is a lower bound for every candidate outside the held six)
     int tc;          // chunks processed by this lane
     int* T;          // this lane's column of the chunk table (row stride ts ints)
     int ts;
@@ -120,7 +115,6 @@ struct Sel5K {
         bb = __float_as_uint(bnd) >> 6;
 #pragma unroll
         for (int s = 0; s < 6; s++) k[s] = ((bb + 1u + (unsigned)s) << 6) | 63u;   // six distinct buckets above the bound
-        k6v = ((bb + 7u) << 6) | 63u;
         tc = 0; T = nullptr; ts = 0;
     }
     __device__ __forceinline__ void attach(int* col, int stride) { T = col; ts = stride; T[15 * stride] = -4; }
@@ -132,7 +126,6 @@ struct Sel5K {
         t.have = false;
     }
     __device__ __forceinline__ void push(unsigned key) {
-        k6v = min(k6v, max(k[5], key));        // what falls off the held six (the larger of the old sixth and the newcomer): its running minimum is the seventh
         const unsigned m5 = umed3(k[4], k[5], key), m4 = umed3(k[3], k[4], key), m3 = umed3(k[2], k[3], key);
         const unsigned m2 = umed3(k[1], k[2], key), m1 = umed3(k[0], k[1], key);
         k[0] = min(k[0], key); k[1] = m1; k[2] = m2; k[3] = m3; k[4] = m4; k[5] = m5;
@@ -158,10 +151,7 @@ struct Sel5K {
     }
     // Resolves the five best, recomputes their exact distances and orders them by (d2, original index).
     // Returns true if the query has to be repeated with the exact selector.
-    // lbo / ko (verified neighbour cache): lbo = a lower bound of the squared distance of every map point that was NOT offered to this selector (0 = unknown);
-    // *ko receives the margin sqrt(lower bound of everything outside the cut) - sqrt(upper bound of the members inside it) for the better of the two cuts
-    // "five members | rest" and "six members | rest" (0 = no usable margin).
-    __device__ __forceinline__ bool finish(const GridView& g, float qx, float qy, float qz, Top5& t, float lbo = 0.f, KeepOut* ko = nullptr) const {
+    __device__ __forceinline__ bool finish(const GridView& g, float qx, float qy, float qz, Top5& t) const {
         const bool redo = ((k[5] ^ k[4]) < 64u) || ((k[4] >> 6) == bb);
         unsigned long long e[5];
         int jr[5];
@@ -190,23 +180,6 @@ struct Sel5K {
         for (int s = 0; s < 5; s++) { t.d[s] = __uint_as_float((unsigned)(e[s] >> 32)); t.j[s] = jr[s]; t.p[s] = pp[s]; }
         t.aux = tc;
         t.have = !redo;
-        if (ko && ko->want) {
-            const int j5 = where(k[5]);
-            const float d5 = __uint_as_float((unsigned)(e[4] >> 32));                       // exact, the largest of the five
-            const float lb6 = fminf(__uint_as_float(k[5] & ~63u), lbo), ub6 = __uint_as_float(k[5] | 63u), lb7 = fminf(__uint_as_float(k6v & ~63u), lbo);
-            const float m56 = sqrtf(lb6) - sqrtf(d5);
-            const float m67 = j5 >= 0 ? sqrtf(lb7) - sqrtf(ub6) : -1.f;
-            const bool six = m67 > m56;
-            const float m = (six ? m67 : m56) * 0.998f - 1e-6f;                              // conservative against the f32 roundings above
-            const bool usable = !redo && jr[4] >= 0 && lbo > 0.f && m > 0.f;                // (NaN margins — non-finite map points — compare false)
-            ko->m = usable ? m : 0.f; ko->cnt = six ? 6 : 5; ko->j5 = j5;
-            // order margin: the smallest gap between consecutive members (exact distances of the five; the fifth against everything else through m56)
-            float r[5];
-#pragma unroll
-            for (int s2 = 0; s2 < 5; s2++) r[s2] = sqrtf(__uint_as_float((unsigned)(e[s2] >> 32)));
-            const float go = fminf(fminf(fminf(r[1] - r[0], r[2] - r[1]), fminf(r[3] - r[2], r[4] - r[3])), m56) * 0.998f - 1e-6f;
-            ko->m_ord = usable && go > 0.f ? go : 0.f;
-        }
         return redo;
     }
 };
@@ -296,11 +269,9 @@ __device__ __forceinline__ float gate_bound(double gate) {   // smallest f32 >= 
 __device__ constexpr int kShellDy[16] = {0, 0, -2, 2, -1, 1, -1, 1, -2, -2, 2, 2, -2, -2, 2, 2};
 __device__ constexpr int kShellDz[16] = {-2, 2, 0, 0, -2, -2, 2, 2, -1, 1, -1, 1, -2, 2, -2, 2};
 template <class SEL, class TAB>
-__device__ __forceinline__ bool knn5_grid_sel(const GridView& g, TAB& tab, float qx, float qy, float qz, float bound, Top5& best, PhaseProbe* pp = nullptr, KeepOut* ko = nullptr) {
+__device__ __forceinline__ bool knn5_grid_sel(const GridView& g, TAB& tab, float qx, float qy, float qz, float bound, Top5& best, PhaseProbe* pp = nullptr) {
     SEL sel; sel.init(bound);
     sel.to_top5(best);
-    if (ko) { ko->m = 0.f; ko->cnt = 5; ko->j5 = -1; ko->m_ord = 0.f; }
-    float lbo = 0.f;        // lower bound (squared) of everything the selector was NOT offered: known only on the super-row path with the shell ruled out
     if (!(isfinite(qx) && isfinite(qy) && isfinite(qz))) return false;
     if constexpr (std::is_same<SEL, Sel5K>::value) sel.attach(&tab.cj[0][threadIdx.x], (int)(sizeof(tab.cj[0]) / sizeof(int)));
     const int R = g.reach;
@@ -406,19 +377,14 @@ __device__ __forceinline__ bool knn5_grid_sel(const GridView& g, TAB& tab, float
         const double fym = (double)qy - (g.oy + (double)cy * c), fyp = (g.oy + (double)(cy + 1) * c) - (double)qy;
         const double fzm = (double)qz - (g.oz + (double)cz * c), fzp = (g.oz + (double)(cz + 1) * c) - (double)qz;
         const double margin = c + fmax(fmin(fmin(fmin(fxm, fxp), fmin(fym, fyp)), fmin(fzm, fzp)), 0.0);
-        if (inner9 && sel.worst() < (float)(0.999 * margin * margin)) lbo = (float)(0.999 * margin * margin);   // every point outside the inner block is at least `margin` away
         if (!(sel.worst() < (float)(0.999 * margin * margin))) {
-            // lsk: lower bound (squared, 0.1 % conservative like every pruning bound here) of whatever the shell walk below does NOT offer to the selector —
-            // rows / cells skipped because their box distance exceeds the fifth best at that moment, cells trimmed off a row in x.  With everything beyond the
-            // 5x5x5 block (at least margin + c away) it is the verified neighbour cache's "everything else" bound for queries that needed the shell.
-            float lsk = 3.0e38f;
             // super-row layout: the 18 single-cell runs x = cx -+ 2 of the nine inner rows are two runs (one super cell each)
             const bool side9 = inner9 && (cx - 2 < 0 || cx - 2 >= g.bx0) && (cx + 2 >= g.nx || cx + 2 < g.bx0 + g.bnx);
             if (side9) {
                 const int* row = g.cell_start9 + srow_index(g, g.bx0, cy, cz) - g.bx0;
                 const int xl = cx - 2, xr = cx + 2;
-                if (xl >= 0 && xl < g.nx) { const double gx = fmax(fxm + c, 0.0); const float lb = (float)(0.999 * gx * gx); if (!(lb > sel.worst())) scan_run(g, sel, row[xl], row[xl + 1], qx, qy, qz); else lsk = fminf(lsk, lb); }
-                if (xr >= 0 && xr < g.nx) { const double gx = fmax(fxp + c, 0.0); const float lb = (float)(0.999 * gx * gx); if (!(lb > sel.worst())) scan_run(g, sel, row[xr], row[xr + 1], qx, qy, qz); else lsk = fminf(lsk, lb); }
+                if (xl >= 0 && xl < g.nx) { const double gx = fmax(fxm + c, 0.0); if (!((float)(0.999 * gx * gx) > sel.worst())) scan_run(g, sel, row[xl], row[xl + 1], qx, qy, qz); }
+                if (xr >= 0 && xr < g.nx) { const double gx = fmax(fxp + c, 0.0); if (!((float)(0.999 * gx * gx) > sel.worst())) scan_run(g, sel, row[xr], row[xr + 1], qx, qy, qz); }
             }
             // How many lanes of the wave are here?  A handful (a converged pose: one lane in a few waves) is bound by the dependent round trips
             // of the 16 shell rows — the batched form below; many (the first iterations of a registration) are bound by instruction issue on
@@ -446,13 +412,6 @@ __device__ __forceinline__ bool knn5_grid_sel(const GridView& g, TAB& tab, float
                         const int dr = (float)(lbr + 0.999 * g2p * g2p) > wv ? ((float)(lbr + 0.999 * g1p * g1p) > wv ? 0 : 1) : 2;
                         const int x0 = max(cx - dl, 0), x1 = min(cx + dr, g.nx - 1);
                         const bool keep = y >= 0 && y < g.ny && z >= 0 && z < g.nz && !((float)lbr > wv) && x0 <= x1;
-                        if (y >= 0 && y < g.ny && z >= 0 && z < g.nz) {         // what this row does not contribute: all of it, or the cells trimmed off its ends
-                            if ((float)lbr > wv) lsk = fminf(lsk, (float)lbr);
-                            else {
-                                if (dl < 2) lsk = fminf(lsk, (float)(lbr + 0.999 * (dl == 0 ? g1m * g1m : g2m * g2m)));
-                                if (dr < 2) lsk = fminf(lsk, (float)(lbr + 0.999 * (dr == 0 ? g1p * g1p : g2p * g2p)));
-                            }
-                        }
                         const int* cs = g.cell_start + (size_t)(keep ? z * g.ny + y : 0) * g.nx;
                         const int b = cs[keep ? x0 : 0], e = cs[keep ? x1 + 1 : 0];
                         rb[i] = b; re[i] = keep ? e : b; rl[i] = (float)lbr;
@@ -461,7 +420,7 @@ __device__ __forceinline__ bool knn5_grid_sel(const GridView& g, TAB& tab, float
                     for (int i = 0; i < 8; i++) { tab.b[i][tid] = rb[i]; tab.e[i][tid] = re[i]; tab.lb[i][tid] = rl[i]; }
                     for (int i = 0; i < 8; i++) {
                         const int b = tab.b[i][tid], e = tab.e[i][tid];
-                        if (b < e) { if (!(tab.lb[i][tid] > sel.worst())) scan_run(g, sel, b, e, qx, qy, qz); else lsk = fminf(lsk, tab.lb[i][tid]); }
+                        if (b < e && !(tab.lb[i][tid] > sel.worst())) scan_run(g, sel, b, e, qx, qy, qz);
                     }
                 }
             } else
@@ -474,7 +433,7 @@ __device__ __forceinline__ bool knn5_grid_sel(const GridView& g, TAB& tab, float
                     if (y < 0 || y >= g.ny) continue;
                     const double gy = dy == 0 ? 0.0 : fmax(dy < 0 ? fym + (double)(-dy - 1) * c : fyp + (double)(dy - 1) * c, 0.0);
                     const double lbr = 0.999 * (gy * gy + gz * gz);
-                    if ((float)lbr > sel.worst()) { if (dy == -2 || dy == 2 || dz == -2 || dz == 2 || !side9) lsk = fminf(lsk, (float)lbr); continue; }   // (an inner row's cells were offered already, its outer two with side9 as well)
+                    if ((float)lbr > sel.worst()) continue;
                     const int* cs = g.cell_start + (size_t)(z * g.ny + y) * g.nx;
                     if (dy == -2 || dy == 2 || dz == -2 || dz == 2) {            // a row of the shell: up to 5 cells,
                         // trimmed to the cells whose box distance (row gap + x gap) can still beat the 5th best
@@ -483,168 +442,28 @@ __device__ __forceinline__ bool knn5_grid_sel(const GridView& g, TAB& tab, float
                         const int dl = (float)(lbr + 0.999 * g2m * g2m) > wv ? ((float)(lbr + 0.999 * g1m * g1m) > wv ? 0 : 1) : 2;
                         const int dr = (float)(lbr + 0.999 * g2p * g2p) > wv ? ((float)(lbr + 0.999 * g1p * g1p) > wv ? 0 : 1) : 2;
                         const int x0 = max(cx - dl, 0), x1 = min(cx + dr, g.nx - 1);
-                        if (dl < 2) lsk = fminf(lsk, (float)(lbr + 0.999 * (dl == 0 ? g1m * g1m : g2m * g2m)));
-                        if (dr < 2) lsk = fminf(lsk, (float)(lbr + 0.999 * (dr == 0 ? g1p * g1p : g2p * g2p)));
                         if (x0 <= x1) scan_run(g, sel, cs[x0], cs[x1 + 1], qx, qy, qz);
                     } else if (!side9) {                                         // inner row: only its two outer cells are new
                         const int xl = cx - 2, xr = cx + 2;
-                        if (xl >= 0 && xl < g.nx) { double gx = fmax(fxm + c, 0.0); const float lb = (float)(lbr + 0.999 * gx * gx); if (!(lb > sel.worst())) scan_run(g, sel, cs[xl], cs[xl + 1], qx, qy, qz); else lsk = fminf(lsk, lb); }
-                        if (xr >= 0 && xr < g.nx) { double gx = fmax(fxp + c, 0.0); const float lb = (float)(lbr + 0.999 * gx * gx); if (!(lb > sel.worst())) scan_run(g, sel, cs[xr], cs[xr + 1], qx, qy, qz); else lsk = fminf(lsk, lb); }
+                        if (xl >= 0 && xl < g.nx) { double gx = fmax(fxm + c, 0.0); if (!((float)(lbr + 0.999 * gx * gx) > sel.worst())) scan_run(g, sel, cs[xl], cs[xl + 1], qx, qy, qz); }
+                        if (xr >= 0 && xr < g.nx) { double gx = fmax(fxp + c, 0.0); if (!((float)(lbr + 0.999 * gx * gx) > sel.worst())) scan_run(g, sel, cs[xr], cs[xr + 1], qx, qy, qz); }
                     }
                 }
             }
-            if (inner9) { const double far = margin + c; lbo = fminf(lsk, (float)(0.999 * far * far)); }      // (the inner block went to the selector completely only on the super-row path)
         }
     }
     PHASE_STAMP(pp, 4, sel.worst());                                        // shell decided / walked
-    if constexpr (std::is_same<SEL, Sel5K>::value) return sel.finish(g, qx, qy, qz, best, lbo, ko);
+    if constexpr (std::is_same<SEL, Sel5K>::value) return sel.finish(g, qx, qy, qz, best);
     else { sel.to_top5(best); return sel.final_tie(); }
 }
 // Fast selection first; the rare queries with an exact distance tie that could matter are repeated with the exact
 // (distance, original index) selector, so the result is always the oracle's.
 template <class TAB>
-__device__ __forceinline__ void knn5_grid(const GridView& g, TAB& tab, float qx, float qy, float qz, float bound, Top5& best, int dbg = 0, PhaseProbe* pp = nullptr, KeepOut* ko = nullptr) {
-    if (ko) { ko->m = 0.f; ko->cnt = 5; ko->j5 = -1; ko->m_ord = 0.f; }
+__device__ __forceinline__ void knn5_grid(const GridView& g, TAB& tab, float qx, float qy, float qz, float bound, Top5& best, int dbg = 0, PhaseProbe* pp = nullptr) {
     if (dbg & 32768) { knn5_grid_sel<Sel5>(g, tab, qx, qy, qz, bound, best); return; }   // A/B: exact selector only
-    const bool redo = knn5_grid_sel<Sel5K>(g, tab, qx, qy, qz, bound, best, pp, ko);
+    const bool redo = knn5_grid_sel<Sel5K>(g, tab, qx, qy, qz, bound, best, pp);
     PHASE_STAMP(pp, 5, best.d[4]);                                          // five winners resolved (exact distances, order)
     if (redo && !(dbg & 8192)) knn5_grid_sel<Sel5>(g, tab, qx, qy, qz, bound, best);   // bit 8192: profiling only (results then inexact on ties)
-}
-
-// ================================================================================================
-// Verified neighbour cache (round 4).  Outer iterations re-associate the SAME queries against the SAME map at poses that soon differ by
-// micrometres (the bench registration: 0.3 m, 6 cm, 4 mm, 0.1 mm, then below the f32 resolution of the transformed points), yet every
-// launch walked ~25 candidates per query again.  A full search now leaves, per query: the position p0 it was made at, the array
-// positions of its nearest 5 (or 6) map points, and a MARGIN m such that at p0 every other map point is farther than the farthest kept
-// member by more than m:  sqrt(lower bound of all others) - sqrt(upper bound of the members) > m.  The lower bound is exact knowledge
-// of the search — the bucket of the first key that fell off the selector (all candidates of the inner 27 cells are offered to it) and
-// the distance to the faces of the inner block when the shell was ruled out; the cut (5 | rest or 6 | rest) is the one with the wider gap.
-// At a new position p with |p - p0| = delta every member is at most delta farther and every other point at most delta nearer, so
-// 2 delta < m  =>  the kept members are STILL strictly nearer than every other map point: the exact 5-NN are the five nearest of them.
-// Their exact f32 distances are recomputed with the search's own dist2 and ordered by (distance, original index), i.e. the Top5 is
-// the one the full search would produce, bit for bit (tests/test_nn_keep_gpu.py) — the launch skips range words, the walk and the winners'
-// resolution for that query.  A miss (margin used up, record absent, a member beyond the gate) simply searches and refreshes the record.
-// Records live in one buffer per (slot, kind) (layout below) and are tied to the map index and the query cloud (reset by lili_map_set /
-// lili_s2m_set_queries), not to any pose.  MatchParams::nn_keep: 0 off, 1 write
-// only (first launch after a pose reset: nothing can hit, save the loads), 2 read + write.
-// ================================================================================================
-// Round 4, second step — the fit travels with the neighbours.  c.z holds a second margin m_ord <= m: while 2 delta < m_ord not even the ORDER of the
-// five by distance (nor which five of six) can have changed, and the query still passes / fails the gate on its fifth neighbour as before; the plane
-// fit (surf_plane: the f64 bulk of the association) is a function of the five points in that order alone, so the record also keeps ITS result
-// (d[3]: 40 bytes + flags in c.w) and such a query goes straight to the position-dependent tail (surf_finish) — no gathers, no fit.
-//   a[n] float4 (p0, m) | b[n] int4 (j0..j3) | c[n] int4 (j4, j5, m_ord bits, count | has_fit << 8 | fit_ok << 9) | d[3 n] 16-byte words (nv0 nv1 | nv2 ninv | sum_w -)
-constexpr int kKeepBytes = 96;
-struct KeepRec { float4 a; int4 b; int4 c; };       // a and c travel with the query; the members (b) and the fit (d) are fetched by the paths that use them
-__device__ __forceinline__ void keep_load(const int* __restrict__ keep, int n_q, int i, bool on, KeepRec& r) {
-    r.a = make_float4(0.f, 0.f, 0.f, 0.f); r.b = make_int4(0, 0, 0, 0); r.c = make_int4(0, 0, 0, 5);
-    if (on) {
-        r.a = reinterpret_cast<const float4*>(keep)[i];
-        r.c = reinterpret_cast<const int4*>(keep)[(size_t)2 * n_q + i];
-    }
-}
-__device__ __forceinline__ void keep_load_members(const int* __restrict__ keep, int n_q, int i, KeepRec& r) {      // only the paths that gather need j0..j3
-    r.b = reinterpret_cast<const int4*>(keep)[(size_t)n_q + i];
-}
-__device__ __forceinline__ void keep_store(int* __restrict__ keep, int n_q, int i, float px, float py, float pz, const Top5& nn, const KeepOut& ko, const PlaneFit& f, float m_ord) {
-    reinterpret_cast<float4*>(keep)[i] = make_float4(px, py, pz, ko.m);
-    reinterpret_cast<int4*>(keep)[(size_t)n_q + i] = make_int4(nn.j[0], nn.j[1], nn.j[2], nn.j[3]);
-    const bool have = f.have;
-    reinterpret_cast<int4*>(keep)[(size_t)2 * n_q + i] = make_int4(nn.j[4], ko.j5, __float_as_int(have ? m_ord : 0.f), ko.cnt | (have ? 256 : 0) | (have && f.ok ? 512 : 0));
-    if (have) {
-        double2* dp = reinterpret_cast<double2*>(keep) + (size_t)3 * n_q + (size_t)3 * i;
-        dp[0] = make_double2(f.nv[0], f.nv[1]); dp[1] = make_double2(f.nv[2], f.ninv); dp[2] = make_double2(f.sum_w, 0.0);
-    }
-}
-__device__ __forceinline__ float keep_delta(const KeepRec& r, float px, float py, float pz) {      // |p - p0|, conservative against the f32 roundings
-    const float dx = px - r.a.x, dy = py - r.a.y, dz = pz - r.a.z;
-    return sqrtf(dx * dx + dy * dy + dz * dz) * 1.001f + 1e-7f;
-}
-// the record's margin covers the move from p0 to (px, py, pz): its members are still the nearest
-__device__ __forceinline__ bool keep_covers(const KeepRec& r, float px, float py, float pz) { return r.a.w > 0.f && 2.f * keep_delta(r, px, py, pz) < r.a.w; }
-// ... and so does the order margin: same five, same order, same side of the gate — the kept fit is the fit
-__device__ __forceinline__ bool keep_covers_fit(const KeepRec& r, float px, float py, float pz) {
-    const float mo = __int_as_float(r.c.z);
-    return (r.c.w & 256) && mo > 0.f && 2.f * keep_delta(r, px, py, pz) < mo;
-}
-struct PlaneFit;
-__device__ __forceinline__ void keep_fit_load(const int* __restrict__ keep, int n_q, int i, double v[5]) {       // the record's fit (three 16-byte loads)
-    const double2* dp = reinterpret_cast<const double2*>(keep) + (size_t)3 * n_q + (size_t)3 * i;
-    const double2 d0 = dp[0], d1 = dp[1], d2 = dp[2];
-    v[0] = d0.x; v[1] = d0.y; v[2] = d1.x; v[3] = d1.y; v[4] = d2.x;
-}
-// Lanes whose record covers the move: the members' points, exact distances, oracle order -> nn.  Returns false (nn untouched in meaning) if a member
-// lies beyond `bound`, where the bounded search would have reported "no fifth neighbour" instead of the point.
-// `same_order` (out): the members are still in the order of the search that made the record — then, and only then, the record's fit (a function of the
-// five points IN THAT ORDER) is the fit a new search would be followed by.  Members that changed their order (a pair nearer to each other than the move)
-// are put into the order of the moment: ranks by counting, the five nearest re-fetched in that order (the keys, not the points, are what is held meanwhile —
-// a sorting network with its payload cost the kernel the fourth wave of a SIMD).
-template <bool REORDER>
-__device__ __forceinline__ bool keep_fill(const GridView& g, const KeepRec& r, float px, float py, float pz, float bound, Top5& nn, bool& same_order) {
-    const bool six = (r.c.w & 255) == 6;
-    nn.j[0] = r.b.x; nn.j[1] = r.b.y; nn.j[2] = r.b.z; nn.j[3] = r.b.w; nn.j[4] = r.c.x;
-    const int j5 = six ? r.c.y : r.c.x;
-#pragma unroll
-    for (int k = 0; k < 5; k++) nn.p[k] = load_pt(g, nn.j[k]);
-    const float4 p5 = load_pt(g, j5);
-    unsigned long long e[6];
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-        asm volatile("" : "+v"(nn.p[k].w));
-        nn.d[k] = dist2(nn.p[k], px, py, pz);
-        e[k] = ((unsigned long long)__float_as_uint(nn.d[k]) << 32) | (unsigned)__float_as_int(nn.p[k].w);
-    }
-    e[5] = six ? (((unsigned long long)__float_as_uint(dist2(p5, px, py, pz)) << 32) | (unsigned)__float_as_int(p5.w)) : ~0ull;
-    same_order = e[0] <= e[1] && e[1] <= e[2] && e[2] <= e[3] && e[3] <= e[4] && e[4] <= e[5];
-    if (REORDER && __any(!same_order)) {
-        if (!same_order) {
-            // rank of every member among the six (keys of distinct map points are distinct; the filler of a five-member record is the largest key)
-            int jm[6] = {nn.j[0], nn.j[1], nn.j[2], nn.j[3], nn.j[4], j5};
-            int rk[6];
-#pragma unroll
-            for (int k = 0; k < 6; k++) {
-                int c = 0;
-#pragma unroll
-                for (int l = 0; l < 6; l++) if (l != k) c += e[l] < e[k] ? 1 : 0;
-                rk[k] = c;
-            }
-#pragma unroll
-            for (int s2 = 0; s2 < 5; s2++) {          // slot s2 takes the member of rank s2
-                int js = jm[0]; unsigned long long es = e[0];
-#pragma unroll
-                for (int k = 1; k < 6; k++) { const bool t = rk[k] == s2; js = t ? jm[k] : js; es = t ? e[k] : es; }
-                nn.j[s2] = js; nn.d[s2] = __uint_as_float((unsigned)(es >> 32));
-            }
-#pragma unroll
-            for (int s2 = 0; s2 < 5; s2++) nn.p[s2] = load_pt(g, nn.j[s2]);      // (lines just fetched)
-        }
-    }
-    nn.have = true; nn.aux = 0;
-    return nn.d[4] <= bound;
-}
-// The association's neighbour search with the cache in front of it: `rec` was loaded with the query (keep_load), `mode` = MatchParams::nn_keep.  Returns
-//   0  searched (the caller stores the record with keep_store once it has the fit; ko filled)
-//   4  searched and ended with the record's own five members in the record's order (a lane that merely had no margin to show for them): the record's fit is theirs
-//   1  neighbours from the record (nn filled as the search would fill it), in another order than the record's: the fit has to be made again
-//   2  neighbours from the record in the record's order: its fit applies (keep_fit) if it has one
-// (the case "the fit applies and nobody needs the neighbours" is taken by the caller before it gets here).  All or nothing per wave: a wave in which one
-// lane has to search lives as long as the search anyway, so the others search with it — no divergent double work, and every record of the wave is
-// refreshed at the current position (the smallest possible delta next time).
-template <class TAB>
-__device__ __forceinline__ int knn5_keep(const GridView& g, TAB& tab, const int* __restrict__ keep, int n_q, int i, int mode, KeepRec& rec,
-                                         float px, float py, float pz, float bound, Top5& nn, int dbg, PhaseProbe* pp, KeepOut& ko) {
-    ko.m = 0.f; ko.cnt = 5; ko.j5 = -1; ko.m_ord = 0.f; ko.want = true;
-    if (!keep || mode == 0) { knn5_grid(g, tab, px, py, pz, bound, nn, dbg, pp); return 0; }
-    const unsigned long long active = __ballot(1);
-    bool hit = __ballot(keep_covers(rec, px, py, pz)) == active;
-    bool same_order = false;
-    if (hit) { keep_load_members(keep, n_q, i, rec); hit = __ballot(keep_fill<true>(g, rec, px, py, pz, bound, nn, same_order)) == active; }
-    if (hit) { PHASE_STAMP(pp, 2, nn.d[4]); PHASE_STAMP(pp, 3, nn.d[4]); PHASE_STAMP(pp, 4, nn.d[4]); PHASE_STAMP(pp, 5, nn.d[4]); return same_order ? 2 : 1; }      // (stamps: phase-probe builds only)
-    knn5_grid(g, tab, px, py, pz, bound, nn, dbg, pp, &ko);
-    // (the record is read again here rather than held in registers across the search)
-    const int4 mb = reinterpret_cast<const int4*>(keep)[(size_t)n_q + i], mc = reinterpret_cast<const int4*>(keep)[(size_t)2 * n_q + i];
-    rec.c = mc;
-    const bool own = (mc.w & 256) && nn.j[0] == mb.x && nn.j[1] == mb.y && nn.j[2] == mb.z && nn.j[3] == mb.w && nn.j[4] == mc.x;
-    return own ? 4 : 0;
 }
 
 // Correspondence counting without atomics on a shared word (3128 same-address atomics cost ~40 us on
@@ -711,14 +530,42 @@ __device__ __forceinline__ void store_debug_nn(const GridView& g, const Top5& nn
     }
 }
 
-// findCorrespondingSurfFeatures body after the kNN (L/src/BackendFusion.cpp:1613-1679 and variants), in two parts:
-//   surf_plane   everything that depends on the five neighbours (and the query's reflectivity) only: weights, plane fit, normalisation, the five
-//                point-to-plane gates — the f64 bulk of the function;
-//   surf_finish  what depends on the query's position: distance to the plane, weight, its gate, the record.
-// The verified neighbour cache keeps surf_plane's result with the neighbours (PlaneFit: 40 bytes): as long as the same five neighbours are found in the
-// same order, the same statements would run on the same inputs, so the cached result IS the recomputed one.
-__device__ __forceinline__ PlaneFit surf_plane(const GridView& g, const MatchParams& P, const Top5& nn, float4 ql) {
-    PlaneFit f; f.nv[0] = f.nv[1] = f.nv[2] = 0.0; f.ninv = 0.0; f.sum_w = 0.0; f.ok = false; f.have = true;
+// Search bound of one query: the reference's gate, tightened by the query's 5 neighbours of the previous association
+// of the same scan against the same map index (positions in the cell-sorted array, -1 = none).  Those are five real
+// map points, so the true 5th-nearest distance cannot exceed their largest distance w at the new pose; everything
+// farther is irrelevant and rows / shell cells beyond it are pruned from the first candidate on.  The result is the
+// same exact 5-NN for any pose change — the cache only makes the bound tight when the pose moved little.
+__device__ __forceinline__ float seeded_bound(const GridView& g, double gate, const int* __restrict__ nn_cache, int n_q, int i,
+                                              float px, float py, float pz) {
+    float bound = gate_bound(gate);
+    if (nn_cache) {
+        int c0 = nn_cache[i], c1 = nn_cache[(size_t)n_q + i], c2 = nn_cache[(size_t)2 * n_q + i], c3 = nn_cache[(size_t)3 * n_q + i],
+            c4 = nn_cache[(size_t)4 * n_q + i];
+        if ((c0 | c1 | c2 | c3 | c4) >= 0) {
+            float w = dist2(load_pt(g, c0), px, py, pz);
+            w = fmaxf(w, dist2(load_pt(g, c1), px, py, pz));
+            w = fmaxf(w, dist2(load_pt(g, c2), px, py, pz));
+            w = fmaxf(w, dist2(load_pt(g, c3), px, py, pz));
+            w = fmaxf(w, dist2(load_pt(g, c4), px, py, pz));
+            if (w < bound) bound = __uint_as_float(__float_as_uint(w) + 1u);   // strictly above w: the five seeds themselves must enter
+        }
+    }
+    return bound;
+}
+__device__ __forceinline__ void store_nn_cache(int* __restrict__ nn_cache, int n_q, int i, const Top5& nn) {
+    if (!nn_cache) return;
+#pragma unroll
+    for (int k = 0; k < 5; k++) nn_cache[(size_t)k * n_q + i] = nn.j[k];
+}
+
+// findCorrespondingSurfFeatures body after the kNN (L/src/BackendFusion.cpp:1613-1679 and variants)
+__device__ __forceinline__ bool surf_fit(const GridView& g, const MatchParams& P, const Top5& nn, float4 ql, float px, float py, float pz,
+                                         float4& rn, double& score) {
+    rn = make_float4(0.f, 0.f, 0.f, 0.f);
+    score = 0.0;
+    if ((P.debug & 1) && nn.j[4] >= 0) { rn.x = nn.d[4]; return nn.d[4] < 0.5f; }
+    if (P.debug & 65536) { rn.x = nn.d[4]; return nn.j[4] >= 0 && (double)nn.d[4] < P.kd_max_radius; }   // ablation (tools/assoc_split_probe.sh): the search alone, every path incl. the cooperative kernels
+    if (!(nn.j[4] >= 0 && (double)nn.d[4] < P.kd_max_radius)) return false;   // L:1615
     float4 m[5];
 #pragma unroll
     for (int k = 0; k < 5; k++) m[k] = nn.p[k];
@@ -739,8 +586,7 @@ __device__ __forceinline__ PlaneFit surf_plane(const GridView& g, const MatchPar
             sum_w += tmp_w;
             w[k] = 1.0 / tmp_w;
         }
-        f.sum_w = sum_w;
-        if (sum_w > P.reflect_thres) return f;
+        if (sum_w > P.reflect_thres) return false;
 #pragma unroll
         for (int k = 0; k < 5; k++) wk[k] = w[k] / sum_w;
     }
@@ -768,49 +614,18 @@ __device__ __forceinline__ PlaneFit surf_plane(const GridView& g, const MatchPar
     for (int k = 0; k < 5; k++) {
         if (fabs(nv[0] * (double)m[k].x + nv[1] * (double)m[k].y + nv[2] * (double)m[k].z + normInverse) > P.surf_dist_thres) planeValid = false;
     }
-    f.nv[0] = nv[0]; f.nv[1] = nv[1]; f.nv[2] = nv[2]; f.ninv = normInverse;
-    f.ok = planeValid;
-    return f;
-}
-__device__ __forceinline__ bool surf_finish(const MatchParams& P, const PlaneFit& f, float px, float py, float pz, float4& rn, double& score) {
-    if (!f.ok) return false;
+    if (!planeValid) return false;
     // L:1661-1662: float pd, float weight; sqrt(sqrt()) on a float argument is the float overload
-    float pd = (float)(f.nv[0] * (double)px + f.nv[1] * (double)py + f.nv[2] * (double)pz + f.ninv);
+    float pd = (float)(nv[0] * (double)px + nv[1] * (double)py + nv[2] * (double)pz + normInverse);
     float r2 = px * px + py * py + pz * pz;
     float weight = (float)(1.0 - 0.9 * (double)fabsf(pd) / (double)sqrtf(sqrtf(r2)));
     if (!((double)weight > P.surf_weight_min)) return false;
-    rn.x = (float)((double)weight * f.nv[0]); rn.y = (float)((double)weight * f.nv[1]); rn.z = (float)((double)weight * f.nv[2]);
-    rn.w = (float)((double)weight * f.ninv);
-    if (P.variant == 0) score = P.lidar_const * ((double)weight + exp(-f.sum_w));   // L:1676
+    rn.x = (float)((double)weight * nv[0]); rn.y = (float)((double)weight * nv[1]); rn.z = (float)((double)weight * nv[2]);
+    rn.w = (float)((double)weight * normInverse);
+    if (P.variant == 0) score = P.lidar_const * ((double)weight + exp(-sum_w));   // L:1676
     else if (P.variant == 1) score = P.lidar_const * (double)weight;                // R:1515
     else score = 1.0;
     return true;
-}
-// keep / n_q / i: where the lane's record of the verified neighbour cache lies; `reuse` (per lane): its fit applies (same five neighbours, same order) and is
-// fetched instead of a new fit.  The new fits of a wave are made FIRST and the kept ones fetched afterwards, so that no lane has to hold ten registers
-// of fit across the other lanes' plane_fit.  `out`: the fit that was used (kept in the record by the caller after a search).
-__device__ __forceinline__ PlaneFit keep_fit(const int* __restrict__ keep, int n_q, int i, int flags);
-__device__ __forceinline__ bool surf_fit_keep(const GridView& g, const MatchParams& P, const Top5& nn, float4 ql, float px, float py, float pz,
-                                              float4& rn, double& score, bool reuse, const int* __restrict__ keep, int n_q, int i, int flags, PlaneFit& out) {
-    rn = make_float4(0.f, 0.f, 0.f, 0.f);
-    score = 0.0;
-    out.ok = false; out.have = false; out.nv[0] = out.nv[1] = out.nv[2] = out.ninv = out.sum_w = 0.0;
-    if ((P.debug & 1) && nn.j[4] >= 0) { rn.x = nn.d[4]; return nn.d[4] < 0.5f; }
-    if (P.debug & 65536) { rn.x = nn.d[4]; return nn.j[4] >= 0 && (double)nn.d[4] < P.kd_max_radius; }   // ablation (tools/assoc_split_probe.sh): the search alone, every path incl. the cooperative kernels
-    if (!(nn.j[4] >= 0 && (double)nn.d[4] < P.kd_max_radius)) return false;   // L:1615
-    if (!reuse) out = surf_plane(g, P, nn, ql);
-    if (reuse) out = keep_fit(keep, n_q, i, flags);
-    return surf_finish(P, out, px, py, pz, rn, score);
-}
-__device__ __forceinline__ PlaneFit keep_fit(const int* __restrict__ keep, int n_q, int i, int flags) {
-    double v[5];
-    keep_fit_load(keep, n_q, i, v);
-    PlaneFit f; f.nv[0] = v[0]; f.nv[1] = v[1]; f.nv[2] = v[2]; f.ninv = v[3]; f.sum_w = v[4]; f.ok = (flags & 512) != 0; f.have = true;
-    return f;
-}
-__device__ __forceinline__ bool surf_fit(const GridView& g, const MatchParams& P, const Top5& nn, float4 ql, float px, float py, float pz, float4& rn, double& score) {
-    PlaneFit out;
-    return surf_fit_keep(g, P, nn, ql, px, py, pz, rn, score, false, nullptr, 0, 0, 0, out);
 }
 
 // findCorrespondingCornerFeatures body after the kNN (L/src/BackendFusion.cpp:1543-1596, R:1404-1458)

@@ -411,12 +411,12 @@ def test_window_iteration_equals_sequential(gpu_ctx, oracle):
         m.iterate_window([0, 0], 1, L.MASK_SURF)
 
 
-_OPTION_DEFAULTS = {"nn_cache": 1, "fuse_tail": 0, "merge_kinds": 1}
+_OPTION_DEFAULTS = {"nn_cache": 0, "fuse_tail": 0, "merge_kinds": 1}
 
 
 @pytest.mark.parametrize("opt", ["nn_cache", "fuse_tail", "merge_kinds"])
 def test_tuning_options_do_not_change_results(gpu_ctx, oracle, opt, launch_by_launch):
-    """Launch-structure switches change no result bit: the verified neighbour cache (nn_cache; tests/test_nn_keep_gpu.py exercises it on the one-lane kernels), the reduction + GN update inside the
+    """Launch-structure switches change no result bit: neighbour-cache bound seeding, the reduction + GN update inside the
     linearisation launch (fuse_tail: last block to arrive, write-through partials, sharded tickets) against the separate
     k_reduce_partials launch, and one launch for both kinds (merge_kinds) against one launch per kind.  All add the same
     numbers in the same order."""

@@ -23,8 +23,6 @@ t0, q0 = synth.perturbed_pose(t_body, q_body, np.random.default_rng(synth.SEED_P
 scan = bench.ring_major(w["scan_xyz"], w["scan_ring"])
 ctx = L.Context(0)
 ctx.set_debug(True)
-if os.environ.get("LILI_NN_CACHE") is not None:
-    ctx.set_option("nn_cache", int(os.environ["LILI_NN_CACHE"]))
 m = L.ScanToMapMatcher(ctx, P)
 m.set_input_cloud(L.KIND_SURF, w["map_xyz"])
 m.set_queries(0, L.KIND_SURF, scan)
