@@ -481,10 +481,9 @@ __device__ __forceinline__ void store_block_count(bool ok, int* __restrict__ blo
         block_counts[bid] = s;
     }
 }
-// Sum of the per-block counts of one association launch (every thread of the block gets the total).
-__device__ __forceinline__ int sum_block_counts(const int* __restrict__ block_counts, int nb) {
-    __shared__ int part[16];
-    __shared__ int total;
+// Sum of the per-block counts of one association launch (every thread of the block gets the total).  In two steps so that a caller can put work
+// between the loads and the barriers: sum_block_counts_begin returns this wave's sum (loads + shuffles), sum_block_counts_end the block's.
+__device__ __forceinline__ int sum_block_counts_begin(const int* __restrict__ block_counts, int nb) {
     int s = 0;
     // four independent loads per trip (the plain strided loop serialises one L2 round trip per element)
     const int bd = blockDim.x;
@@ -494,12 +493,18 @@ __device__ __forceinline__ int sum_block_counts(const int* __restrict__ block_co
         s += (v0 + v1) + (v2 + v3);
     }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    return s;
+}
+__device__ __forceinline__ int sum_block_counts_end(int wave_sum) {
+    __shared__ int part[16];
+    __shared__ int total;
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = wave_sum;
     __syncthreads();
     if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += part[w]; total = t; }
     __syncthreads();
     return total;
 }
+__device__ __forceinline__ int sum_block_counts(const int* __restrict__ block_counts, int nb) { return sum_block_counts_end(sum_block_counts_begin(block_counts, nb)); }
 
 __device__ __forceinline__ void load_assoc_pose(const PoseArg& pa, const MatchParams& P, dq& Q2, d3& T2) {
     if (pa.state) {
@@ -771,22 +776,35 @@ __device__ __forceinline__ void load_body_pose(const PoseArg& pa, dq& Q, d3& T) 
 // Residual, 1x7 Jacobian row and loss corrector of ONE correspondence (Jr[0..6] = robustified Jacobian, Jr[7] = residual; returns the robust
 // cost) — shared by the linearisation launch and by the association launch that linearises on the fly (k_associate_lin).
 //   surf: LidarPlaneNormFactor / LidarPlaneNormIncreFactor, L/include/factors/LidarKeyframeFactor.h:86-90, 118-128; `score` is the (count-scaled) weight
-__device__ __forceinline__ double surf_lin_row(const MatchParams& P, const dq& Q, const d3& T, const dq& qlb_inv, float4 ql, float4 nd, double score, double Jr[8]) {
+// In two parts since round 4: the geometry (rotations, Jacobian of the rotation) does not depend on the weight, and for the count-scaled flavour the weight
+// exists only after the block has summed the association's block counts — surf_lin_geom runs while those counts travel, surf_lin_scale afterwards.  The
+// same operations on the same operands as before: `score` multiplies finished values.
+struct SurfLinGeom { d3 n; double base; double jq[4]; };       // base = n . pw + d  (the unweighted residual)
+__device__ __forceinline__ SurfLinGeom surf_lin_geom(const MatchParams& P, const dq& Q, const d3& T, const dq& qlb_inv, float4 ql, float4 nd) {
+    SurfLinGeom gm;
     d3 cp{(double)ql.x, (double)ql.y, (double)ql.z};
-    d3 n{(double)nd.x, (double)nd.y, (double)nd.z};
+    gm.n = d3{(double)nd.x, (double)nd.y, (double)nd.z};
     d3 v;
-    if (P.variant == 2) { v = cp; score = 1.0; }   // LidarPlaneNormIncreFactor, LidarKeyframeFactor.h:118-128
+    if (P.variant == 2) v = cp;   // LidarPlaneNormIncreFactor, LidarKeyframeFactor.h:118-128
     else v = qrot(qlb_inv, cp - d3{P.t_lb[0], P.t_lb[1], P.t_lb[2]});                                  // :86
     d3 pw = qrot(Q, v) + T;                                                                              // :87
-    double r = score * (dot3(n, pw) + (double)nd.w);                                                    // :90
-    double jq[4];
-    qrot_jac_row(Q, v, n, jq);
-    double J[7] = {score * n.x, score * n.y, score * n.z, score * jq[0], score * jq[1], score * jq[2], score * jq[3]};
+    gm.base = dot3(gm.n, pw) + (double)nd.w;
+    qrot_jac_row(Q, v, gm.n, gm.jq);
+    return gm;
+}
+__device__ __forceinline__ double surf_lin_scale(const MatchParams& P, const SurfLinGeom& gm, double score, double Jr[8]) {
+    if (P.variant == 2) score = 1.0;
+    double r = score * gm.base;                                                                          // :90
+    double J[7] = {score * gm.n.x, score * gm.n.y, score * gm.n.z, score * gm.jq[0], score * gm.jq[1], score * gm.jq[2], score * gm.jq[3]};
     const double cost = robustify(P.loss, P.loss_a, J, r, P.no_cost == 0);
 #pragma unroll
     for (int k = 0; k < 7; k++) Jr[k] = J[k];
     Jr[7] = r;
     return cost;
+}
+__device__ __forceinline__ double surf_lin_row(const MatchParams& P, const dq& Q, const d3& T, const dq& qlb_inv, float4 ql, float4 nd, double score, double Jr[8]) {
+    const SurfLinGeom gm = surf_lin_geom(P, Q, T, qlb_inv, ql, nd);
+    return surf_lin_scale(P, gm, score, Jr);
 }
 //   edge: LidarEdgeFactor, LidarKeyframeFactor.h:38-44 (no extrinsic: SURVEY F6); `s` is the (count-scaled) weight
 __device__ __forceinline__ double edge_lin_row(const MatchParams& P, const dq& Q, const d3& T, float4 ql, float4 fa, float4 fb, double s, double Jr[8]) {
@@ -865,23 +883,30 @@ __device__ __forceinline__ void lin_surf_body(const LinArgs& A, int bid, const P
     float4 ql0 = queries[i0c], nd0 = rec_nd[i0c];
     double sc0 = rec_score[i0c];
     // ROT count scaling exactly as the reference writes it (R/src/BackendFusion.cpp:861, pinned by tests/test_reference_*.py against the reference text):
-    // vec_surf_scores[i] * 1000 / vec_surf_res_cnt  =  (score * 1000.0) / (double)N — a multiply, then a true division
+    // vec_surf_scores[i] * 1000 / vec_surf_res_cnt  =  (score * 1000.0) / (double)N — a multiply, then a true division.
+    // The block counts are requested first, the geometry of the first tile (which does not depend on N) runs while they travel, the barriers of the
+    // count sum come after it (round 4: they used to stand in front of all the arithmetic).
+    const bool sum_counts = !(P.debug & 128) && P.scale_surf_num > 0 && A.block_counts;
+    const int wave_cnt = sum_counts ? sum_block_counts_begin(A.block_counts, A.n_bc) : 0;
+    const bool ok0 = i0 < n_q && v0;
+    SurfLinGeom g0;
+    if (ok0) g0 = surf_lin_geom(P, Q, T, qlb_inv, ql0, nd0);
     double n_den = 1.0;
     if (P.debug & 128) n_den = 190000.0;
-    else if (P.scale_surf_num > 0) n_den = (double)(A.block_counts ? sum_block_counts(A.block_counts, A.n_bc) : (n_global ? n_global[0] : state->n_res[0]));
+    else if (P.scale_surf_num > 0) n_den = (double)(A.block_counts ? sum_block_counts_end(wave_cnt) : (n_global ? n_global[0] : state->n_res[0]));
     tstamp(state, P.debug, 100, 1);
     for (int base = bid * BS; base < n_q; base += A.nb * BS) {
         int i = base + threadIdx.x;
         const bool first = base == bid * BS;
         const int ic = min(i, n_q - 1);
-        bool ok = i < n_q && (first ? v0 : valid[ic]);
+        bool ok = first ? ok0 : (i < n_q && valid[ic]);
         double Jr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         double cost = 0.0;
         if (ok) {
-            float4 ql = first ? ql0 : queries[i]; float4 nd = first ? nd0 : rec_nd[i];
             double score = first ? sc0 : rec_score[i];
             if (P.scale_surf_num > 0) score = score * P.scale_surf_num / n_den;
-            cost = surf_lin_row(P, Q, T, qlb_inv, ql, nd, score, Jr);
+            if (first) cost = surf_lin_scale(P, g0, score, Jr);
+            else cost = surf_lin_row(P, Q, T, qlb_inv, queries[i], rec_nd[i], score, Jr);
         }
         tstamp(state, P.debug, 100, 2);
         ga.add_rows(Jr, cost, ok, lds);
