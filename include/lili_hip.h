@@ -130,12 +130,20 @@ void lili_host_free(void* p);
  * L/src/LidarOdometry.cpp:490).  Copies the cloud (if on the host), bins it into a uniform grid whose
  * cell edge covers sqrt(max_sq_radius) so that the 27-cell neighbourhood of a query contains every
  * point the reference's gate `d2[4] < max_sq_radius` can accept — the search is EXACT for all queries
- * the reference keeps.  Blocking (reads the bounding box back once). */
+ * the reference keeps.  Blocking.  The points are read where they lie (a device cloud is not copied; it must stay valid until the
+ * call returns).  The first build of a kind measures the cloud's bounding box and reads it back before the grid exists; later builds of a cloud
+ * of about the same size and gate start from the previous build's box grown by a margin of cells, and check at their final read-back — the one with
+ * the density — that no point of THIS cloud lay outside it; if one did, the index is rebuilt with the true box before the call returns and the margin
+ * doubles (option "map_guess_box" = 0: always measure first; lili_map_build_stats counts both).  Search results do not depend on where the grid's
+ * origin lies. */
 int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq_radius);
+/* Diagnostics of the index builds of this context: builds that started from a guessed box, those of them that had to be repeated with the true
+ * box, builds repeated with the three-kernel scan because a single-pass scan gave up (never expected).  Any pointer may be NULL. */
+int lili_map_build_stats(lili_ctx* ctx, int32_t* box_guesses, int32_t* box_guess_misses, int32_t* scan_fallbacks);
 /* The same in two steps for pipelines that rebuild the local map every keyframe (L/src/BackendFusion.cpp:839-840 runs once per keyframe, before
  * the window's iterations): _begin builds the NEXT index of `kind` on a side stream into a second set of buffers — work already enqueued on the
  * context's stream (the previous keyframe's iterations, lili_s2m_iterate*) keeps the current index and overlaps with the build —, _end makes the
- * new index the current one for everything enqueued after it.  _begin waits for the build's two small read-backs only (bounding box, density).
+ * new index the current one for everything enqueued after it.  _begin waits for the build's small read-backs only (density and box check; the box itself on a first build).
  * The cloud must stay valid until _end.  Results are those of lili_map_set. */
 int lili_map_set_begin(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq_radius);
 int lili_map_set_end(lili_ctx* ctx, int kind);

@@ -141,6 +141,7 @@ _SIGS = {
     "lili_map_set_end": (C.c_int, [C.c_void_p, C.c_int]),
     "lili_map_focus": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_double]),
     "lili_map_info": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "lili_map_build_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "lili_s2m_set_queries": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Cloud)]),
     "lili_s2m_associate": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(S2MParams), C.POINTER(C.c_int)]),
     "lili_s2m_linearize": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(S2MParams), C.c_void_p, C.POINTER(C.c_double), C.c_void_p]),
@@ -355,6 +356,12 @@ class ScanToMapMatcher:
         n, nc, ce = C.c_int64(), C.c_int64(), C.c_double()
         self.ctx._chk(self.lib.lili_map_info(self.ctx.h, kind, C.byref(n), C.byref(nc), C.byref(ce)))
         return n.value, nc.value, ce.value
+
+    def map_build_stats(self):
+        """(index builds started from a guessed box, those repeated with the true box, builds repeated with the three-kernel scan)."""
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        self.ctx._chk(self.lib.lili_map_build_stats(self.ctx.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def map_focus(self, center=None, radius=0.0):
         """Hint for the following set_input_cloud calls: build the super-row copy only within `radius` of `center` (None / 0: everywhere)."""

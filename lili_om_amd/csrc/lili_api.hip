@@ -15,13 +15,15 @@ namespace lili {
 // kernels (lili_s2m.hip)
 __global__ void k_cloud_to_f4(const unsigned char*, int, int, int, float4*, unsigned*);
 __global__ void k_bbox(const float4*, int, unsigned*);
-__global__ void k_cell_count(const float4*, int, GridView, int*, int2*, unsigned long long*);
+__global__ void k_bbox_src(SrcCloud, int, unsigned*);
+__global__ void k_cell_count(SrcCloud, int, GridView, int*, int*, unsigned long long*, int, float);
 __global__ void k_associate_fine(AssocArgs, GridView, float, int, PoseArg, MatchParams);
 __global__ void k_scan_block_sums(const int*, int64_t, int*);
 __global__ void k_scan_sums(int*, int);
 __global__ void k_scan_apply(const int*, int64_t, const int*, int*);
-__global__ void k_scan_lookback(int*, int64_t, unsigned long long*, unsigned*);
-__global__ void k_scatter(const float4*, int, const int2*, const int*, float4*, float*);
+template <bool NARROW> __global__ void k_scan_lookback_t(int*, const unsigned char*, int64_t, unsigned long long*, unsigned*);
+__global__ void k_cell_count_narrow(SrcCloud, int, GridView, unsigned*, unsigned char*, unsigned long long*, int, float);
+template <typename RankT> __global__ void k_scatter_t(SrcCloud, int, GridView, const RankT*, const int*, float4*, float*);
 __global__ void k_start9(const int*, GridView, const int*, int*);
 __global__ void k_rowtot9(const int*, GridView, int*);
 template <int BS> __global__ void k_associate_lin(AssocArgs, AssocArgs, PoseArg, MatchParams, double*, double*);
@@ -124,6 +126,7 @@ int lili_readback_finish(lili_ctx* ctx, hipStream_t stream) {
 }
 
 // copies / converts a described cloud into a device float4 array (x, y, z, aux)
+constexpr size_t kMiscAlloc = 2 * 64 * 128 + 256 + 2 * ((8192 + 2) * 8 + 112);      // scratch words of a map build, laid out where lili_map_set is defined
 int lili_ingest_cloud(lili_ctx* ctx, const lili_cloud* c, DevBuf& out_f4, unsigned* d_bbox) {
     ARGCHK(c && (c->n == 0 || c->data), "cloud: null data");
     ARGCHK(c->stride >= 12 && c->stride % 4 == 0, "cloud: stride must be a multiple of 4 and >= 12");
@@ -176,7 +179,7 @@ int lili_ctx_create(lili_ctx** out, int device, void* stream) {
     }
     bool ok = ctx->states.ensure(sizeof(SlotState) * LILI_MAX_SLOTS) == hipSuccess &&
               ctx->gram.ensure(sizeof(double) * LILI_GRAM_DOUBLES * LILI_MAX_SLOTS) == hipSuccess &&
-              ctx->misc.ensure(2 * 64 * 128 + 256) == hipSuccess &&
+              ctx->misc.ensure(kMiscAlloc) == hipSuccess &&
 
               hipMemsetAsync(ctx->states.p, 0, sizeof(SlotState) * LILI_MAX_SLOTS, ctx->stream) == hipSuccess &&
               hipMemsetAsync(ctx->gram.p, 0, sizeof(double) * LILI_GRAM_DOUBLES * LILI_MAX_SLOTS, ctx->stream) == hipSuccess;
@@ -192,7 +195,7 @@ void lili_ctx_destroy(lili_ctx* ctx) {
     if (ctx->build_stream) { (void)hipStreamSynchronize(ctx->build_stream); (void)hipStreamDestroy(ctx->build_stream); }
     for (int k = 0; k < 2; k++) { if (ctx->build_done[k]) (void)hipEventDestroy(ctx->build_done[k]); if (ctx->main_mark[k]) (void)hipEventDestroy(ctx->main_mark[k]); }
     if (ctx->cloud_ready) (void)hipEventDestroy(ctx->cloud_ready);
-    for (auto& m : ctx->map) { m.sorted_f.release(); m.aux_sorted_f.release(); m.cell_start_f.release(); m.cell_start9.release(); m.cell_start9_f.release(); m.row9.release(); m.pts.release(); m.sorted.release(); m.aux_sorted.release(); m.cell_start.release(); m.cell_tmp.release(); m.pt_cell.release(); m.block_sums.release(); }
+    for (auto& m : ctx->map) { m.sorted_f.release(); m.aux_sorted_f.release(); m.cell_start_f.release(); m.cell_start9.release(); m.cell_start9_f.release(); m.row9.release(); m.sorted.release(); m.aux_sorted.release(); m.cell_start.release(); m.cell_tmp.release(); m.pt_cell.release(); m.block_sums.release(); }
     for (auto& s : ctx->slots) for (auto& k : s.k) { k.q.release(); k.rec0.release(); k.rec1.release(); k.valid.release(); k.dbg_idx.release(); k.dbg_d2.release(); k.partials.release(); k.partials_wave.release(); k.perm.release(); k.keys.release(); k.block_counts.release(); k.tiles.release(); }
     if (ctx->h_records) { (void)hipHostFree(ctx->h_records); ctx->h_records = nullptr; }
     if (ctx->h_pin) { (void)hipHostFree(ctx->h_pin); ctx->h_pin = nullptr; }
@@ -244,6 +247,8 @@ int lili_set_option(lili_ctx* ctx, const char* name, int value) {
     if (std::strcmp(name, "super_rows") == 0) { ctx->super_rows = value != 0; return LILI_OK; }   // takes effect at the next lili_map_set
     if (std::strcmp(name, "fine_occupancy") == 0) { if (value < 2) return ctx->fail(LILI_E_ARG, "fine_occupancy must be >= 2"); ctx->fine_occupancy = value; return LILI_OK; }
     if (std::strcmp(name, "scan_lookback") == 0) { ctx->scan_lookback = value != 0; return LILI_OK; }
+    if (std::strcmp(name, "map_narrow_counts") == 0) { ctx->map_narrow_counts = value != 0; for (auto& b : ctx->spec_box) b.wide_counts = false; return LILI_OK; }   // 0: 32-bit cell counters always (A/B)
+    if (std::strcmp(name, "map_guess_box") == 0) { ctx->map_guess_box = value != 0; for (auto& b : ctx->spec_box) { const bool w = b.wide_counts; b = SpecBox{}; b.wide_counts = w; } return LILI_OK; }   // 0: every lili_map_set measures its box first (A/B)
     if (std::strcmp(name, "localmap_super_rows") == 0) { ctx->localmap_super_rows = value != 0; return LILI_OK; }
     if (std::strcmp(name, "localmap_incremental") == 0) { ctx->localmap_incremental = value != 0; return LILI_OK; }
     if (std::strcmp(name, "sort_digit_bits") == 0) { if (value != 4 && value != 8) return ctx->fail(LILI_E_ARG, "sort_digit_bits must be 4 or 8"); ctx->sort_digit_bits = value; return LILI_OK; }
@@ -257,14 +262,21 @@ int lili_set_option(lili_ctx* ctx, const char* name, int value) {
 // --------------------------------------------------------------------------------------------
 // map index
 // --------------------------------------------------------------------------------------------
-// Uniform-grid index of m.pts (already ingested) with cells of edge `cell` (grown if the bounding box needs more than max_cells cells):
-// count (one atomic per run of equal cells, the returned value = the point's rank), in-place single-pass scan, atomic-free scatter.
+// Uniform-grid index of the caller's cloud `src` (read where it lies: device memory, or the staging copy of a host cloud) with cells of edge `cell` (grown if the
+// bounding box needs more than max_cells cells): count (one atomic per run of equal cells, the returned value = the point's rank), in-place single-pass scan,
+// atomic-free scatter.
 // scratch words of a map build (ctx->misc): [0, 8192) bounding-box banks, [8192, 16384) density banks, then the sticky error word of the look-back scans
+// then the status words of the two single-pass scans of a build (cell table, super-rows; <= 8192 tiles each).
+// ONE memset arms all of it (round 4: five small fills and a host-to-device copy per build were ~25 us of serialised launches).
 constexpr size_t kMiscBytes = 2 * 64 * 128 + 256;
+constexpr size_t kScanStatusTiles = 8192, kScanStatusBytes = (kScanStatusTiles + 2) * sizeof(unsigned long long) + 112 /* -> a multiple of 128 */;
+constexpr size_t kMiscTotal = kMiscBytes + 2 * kScanStatusBytes;
+static_assert(kMiscTotal == kMiscAlloc, "ctx->misc is allocated in lili_ctx_create");
 static unsigned* scan_err_word(lili_ctx* ctx) { return reinterpret_cast<unsigned*>(ctx->misc.as<char>() + 2 * 64 * 128); }
-static int build_grid(lili_ctx* ctx, MapIndex& m, const double mn[3], const double mx[3], double cell, int reach, DevBuf& sorted, DevBuf& aux_sorted,
-                      DevBuf& cell_start, DevBuf& cell_start9, GridView& out, int64_t& n_cells, double& cell_used, unsigned long long* d_rank_sum,
-                      const void* zeroed_p = nullptr, size_t zeroed_bytes = 0 /* the caller already cleared this much of cell_start (while the bounding box travelled) */) {
+static unsigned long long* scan_status(lili_ctx* ctx, int which) { return reinterpret_cast<unsigned long long*>(ctx->misc.as<char>() + kMiscBytes + (size_t)which * kScanStatusBytes); }
+static int build_grid(lili_ctx* ctx, MapIndex& m, const SrcCloud& src, const double mn[3], const double mx[3], double cell, int reach, DevBuf& sorted, DevBuf& aux_sorted,
+                      DevBuf& cell_start, DevBuf& cell_start9, GridView& out, int64_t& n_cells, double& cell_used, unsigned long long* d_rank_sum, bool box_check, float touch_cells, bool narrow /* 8-bit count table (k_cell_count_narrow) */,
+                      bool status_armed /* the scans' status words (ctx->misc) are still zero from the build's one memset */, const void* zeroed_p = nullptr, size_t zeroed_bytes = 0 /* the caller already cleared this much of cell_start (while the bounding box travelled) */) {
     const int n = (int)m.n;
     int64_t nx, ny, nz;
     for (;;) {
@@ -283,7 +295,7 @@ static int build_grid(lili_ctx* ctx, MapIndex& m, const double mn[3], const doub
     const int64_t nc = n_cells;
     // ONE cell array: counts -> (in-place exclusive scan) -> cell_start; the atomic of the count pass also hands every point its rank
     HIPCHK(cell_start.ensure((size_t)(nc + 1) * sizeof(int)));
-    HIPCHK(m.pt_cell.ensure((size_t)n * sizeof(int2)));
+    HIPCHK(m.pt_cell.ensure((size_t)n * sizeof(int)));
     // super-rows: the sorted array continues with the 3x3-row copy of the box (<= 9n entries); positions stay 32-bit byte offsets, so 10n < 2^28.
     // The box: the whole grid, or the cells within the focus radius (+ one gate radius and a cell) of the focus point.
     int b0[3] = {0, 0, 0}, b1[3] = {(int)nx - 1, (int)ny - 1, (int)nz - 1};
@@ -305,24 +317,37 @@ static int build_grid(lili_ctx* ctx, MapIndex& m, const double mn[3], const doub
     if (srows) { HIPCHK(cell_start9.ensure((size_t)(nc9 + 2) * sizeof(int))); HIPCHK(m.row9.ensure((size_t)(rows9 + 2) * sizeof(int))); }
     const int nb_scan = nblocks(nc, 2048);
     HIPCHK(m.block_sums.ensure((size_t)(nb_scan + 2) * sizeof(unsigned long long)));
-    if (!(cell_start.p == zeroed_p && (size_t)nc * sizeof(int) <= zeroed_bytes)) HIPCHK(hipMemsetAsync(cell_start.p, 0, (size_t)nc * sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(k_cell_count, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, m.pts_ext ? static_cast<const float4*>(m.pts_ext) : m.pts.as<float4>(), n, g, cell_start.as<int>(), m.pt_cell.as<int2>(), d_rank_sum);
+    const size_t nc_pad = ((size_t)nc + 16383) / 16384 * 16384;      // whole scan tiles
+    if (narrow) {
+        HIPCHK(m.cell_tmp.ensure(nc_pad));
+        if (!(m.cell_tmp.p == zeroed_p && nc_pad <= zeroed_bytes)) HIPCHK(hipMemsetAsync(m.cell_tmp.p, 0, nc_pad, ctx->stream));
+        hipLaunchKernelGGL(k_cell_count_narrow, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, src, n, g, m.cell_tmp.as<unsigned>(), m.pt_cell.as<unsigned char>(), d_rank_sum,
+                           box_check ? 1 : 0, touch_cells);
+    } else {
+        if (!(cell_start.p == zeroed_p && (size_t)nc * sizeof(int) <= zeroed_bytes)) HIPCHK(hipMemsetAsync(cell_start.p, 0, (size_t)nc * sizeof(int), ctx->stream));
+        hipLaunchKernelGGL(k_cell_count, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, src, n, g, cell_start.as<int>(), m.pt_cell.as<int>(), d_rank_sum, box_check ? 1 : 0, touch_cells);
+    }
     if (ctx->scan_lookback) {      // one pass over the cell array (status words: one per 16384-cell tile)
         const int nb_lb = nblocks(nc, 16384);
-        HIPCHK(hipMemsetAsync(m.block_sums.p, 0, (size_t)(nb_lb + 2) * sizeof(unsigned long long), ctx->stream));
-        hipLaunchKernelGGL(k_scan_lookback, dim3(nb_lb), dim3(kBlock), 0, ctx->stream, cell_start.as<int>(), nc, m.block_sums.as<unsigned long long>(), scan_err_word(ctx));
+        unsigned long long* st = (size_t)nb_lb <= kScanStatusTiles ? scan_status(ctx, 0) : m.block_sums.as<unsigned long long>();
+        if (!(status_armed && st == scan_status(ctx, 0))) HIPCHK(hipMemsetAsync(st, 0, (size_t)(nb_lb + 2) * sizeof(unsigned long long), ctx->stream));
+        if (narrow) hipLaunchKernelGGL(k_scan_lookback_t<true>, dim3(nb_lb), dim3(kBlock), 0, ctx->stream, cell_start.as<int>(), m.cell_tmp.as<unsigned char>(), nc, st, scan_err_word(ctx));
+        else hipLaunchKernelGGL(k_scan_lookback_t<false>, dim3(nb_lb), dim3(kBlock), 0, ctx->stream, cell_start.as<int>(), (const unsigned char*)nullptr, nc, st, scan_err_word(ctx));
     } else {
         hipLaunchKernelGGL(k_scan_block_sums, dim3(nb_scan), dim3(kBlock), 0, ctx->stream, cell_start.as<int>(), nc, m.block_sums.as<int>());
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, ctx->stream, m.block_sums.as<int>(), nb_scan);
         hipLaunchKernelGGL(k_scan_apply, dim3(nb_scan), dim3(kBlock), 0, ctx->stream, cell_start.as<int>(), nc, m.block_sums.as<int>(), cell_start.as<int>());
     }
-    hipLaunchKernelGGL(k_scatter, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, m.pts_ext ? static_cast<const float4*>(m.pts_ext) : m.pts.as<float4>(), n, m.pt_cell.as<int2>(), cell_start.as<int>(),
-                       sorted.as<float4>(), m.has_aux ? aux_sorted.as<float>() : nullptr);
+    if (narrow) hipLaunchKernelGGL(k_scatter_t<unsigned char>, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, src, n, g, m.pt_cell.as<unsigned char>(), cell_start.as<int>(),
+                                   sorted.as<float4>(), m.has_aux ? aux_sorted.as<float>() : nullptr);
+    else hipLaunchKernelGGL(k_scatter_t<int>, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, src, n, g, m.pt_cell.as<int>(), cell_start.as<int>(),
+                            sorted.as<float4>(), m.has_aux ? aux_sorted.as<float>() : nullptr);
     if (srows) {      // first positions of the super-rows (populations -> scan), positions of the super cells, then the copy
         hipLaunchKernelGGL(k_rowtot9, dim3(nblocks(rows9, kBlock)), dim3(kBlock), 0, ctx->stream, cell_start.as<int>(), g, m.row9.as<int>());
         const int nb_lb = nblocks(rows9, 16384);
-        HIPCHK(hipMemsetAsync(m.block_sums.p, 0, (size_t)(nb_lb + 2) * sizeof(unsigned long long), ctx->stream));
-        hipLaunchKernelGGL(k_scan_lookback, dim3(nb_lb), dim3(kBlock), 0, ctx->stream, m.row9.as<int>(), rows9, m.block_sums.as<unsigned long long>(), scan_err_word(ctx));
+        unsigned long long* st = (size_t)nb_lb <= kScanStatusTiles ? scan_status(ctx, 1) : m.block_sums.as<unsigned long long>();
+        if (!(status_armed && st == scan_status(ctx, 1))) HIPCHK(hipMemsetAsync(st, 0, (size_t)(nb_lb + 2) * sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL(k_scan_lookback_t<false>, dim3(nb_lb), dim3(kBlock), 0, ctx->stream, m.row9.as<int>(), (const unsigned char*)nullptr, rows9, st, scan_err_word(ctx));
         hipLaunchKernelGGL(k_start9, dim3(nblocks(g.bnx, 64), nblocks(g.bny, 4 * 8), (unsigned)g.bnz), dim3(256), 0, ctx->stream, cell_start.as<int>(), g, m.row9.as<int>(),
                            cell_start9.as<int>());
         hipLaunchKernelGGL(k_scatter9, dim3(nblocks(g.bnx, 64), nblocks(g.bny, 4), nblocks(g.bnz, 4)), dim3(1024), 0, ctx->stream, cell_start.as<int>(), g, cell_start9.as<int>(),
@@ -341,83 +366,139 @@ int lili_map_set(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq
 
 }  // extern "C"
 
-static int map_set_hinted_impl(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq_radius, const unsigned* box6, bool in_place);
-int lili_map_set_hinted(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq_radius, const unsigned* box6, bool in_place) {
+// where the box of a build comes from
+enum BoxSource { kBoxMeasure = 0,   // a bounding-box pass over the cloud and a read-back before the grid exists
+                 kBoxGiven,         // the caller's (lili_localmap_commit: the centroids' box travels with their count), or the true box of a build whose guess failed
+                 kBoxGuess };       // the previous build's true box + a margin, checked against this cloud's true box at the build's final read-back
+static int map_set_impl(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq_radius, const unsigned* box6, bool allow_guess);
+int lili_map_set_hinted(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq_radius, const unsigned* box6, bool /*in_place: every device cloud is read in place since round 4*/) {
     if (!ctx) return LILI_E_ARG;
     ARGCHK(kind == LILI_KIND_SURF || kind == LILI_KIND_EDGE, "map_set: bad kind");
-    const int rc = map_set_hinted_impl(ctx, kind, cloud, max_sq_radius, box6, in_place);
-    ctx->map[kind].pts_ext = nullptr;        // only meaningful DURING the build: whatever way it ended, nothing keeps a pointer into the caller's array
-    return rc;
+    return map_set_impl(ctx, kind, cloud, max_sq_radius, box6, true);
 }
-static int map_set_hinted_impl(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq_radius, const unsigned* box6, bool in_place) {
+static float ord2f(unsigned u) { unsigned b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u; float f; std::memcpy(&f, &b, 4); return f; }
+static int map_set_impl(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq_radius, const unsigned* box6, bool allow_guess) {
     ARGCHK(cloud, "map_set: null cloud");
     ARGCHK(max_sq_radius > 0 && std::isfinite(max_sq_radius), "map_set: max_sq_radius must be positive");
     ARGCHK(cloud->n < (1ll << 28), "map_set: at most 2^28 - 1 map points (32-bit byte offsets into the sorted array)");
+    ARGCHK(cloud->n == 0 || cloud->data, "cloud: null data");
+    ARGCHK(cloud->stride >= 12 && cloud->stride % 4 == 0, "cloud: stride must be a multiple of 4 and >= 12");
+    ARGCHK(cloud->aux_offset < 0 || (size_t)cloud->aux_offset + 4 <= cloud->stride, "cloud: aux_offset outside the point");
+    ARGCHK(cloud->mem == LILI_MEM_HOST || cloud->mem == LILI_MEM_DEVICE, "cloud: bad mem");
     HIPCHK(hipSetDevice(ctx->device));
     MapIndex& m = ctx->map[kind];
     m.valid = false;
     for (auto& s : ctx->slots) { s.k[kind].binned = false; s.k[kind].nn_cache_valid = false; s.k[kind].order_valid = false; s.k[kind].launches = 0; }
-    // bounding box: reduced inside the ingestion pass (one read of the cloud for both)
-    struct BboxInit { unsigned w[64 * 32]; BboxInit() { for (int i = 0; i < 64 * 32; i++) w[i] = (i & 31) < 3 ? 0xFFFFFFFFu : 0u; } };
-    static const BboxInit bbox_init;             // 64 banks of 128 bytes: min xyz = ~0, max xyz = 0 (ordered-uint encoding)
-    unsigned* d_mm = ctx->misc.as<unsigned>();
-    if (!box6) HIPCHK(hipMemcpyAsync(d_mm, bbox_init.w, sizeof(bbox_init.w), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemsetAsync(scan_err_word(ctx), 0, sizeof(unsigned), ctx->stream));
-    in_place = in_place && box6 && cloud->n > 0 && cloud->mem == LILI_MEM_DEVICE && cloud->stride == sizeof(float4) && (cloud->aux_offset == 12 || cloud->aux_offset < 0) &&
-               (reinterpret_cast<uintptr_t>(cloud->data) & 15) == 0;
-    m.pts_ext = in_place ? cloud->data : nullptr;
-    int rc = in_place ? LILI_OK : lili_ingest_cloud(ctx, cloud, m.pts, box6 ? nullptr : d_mm);
-    if (rc != LILI_OK) return rc;
     m.n = (int64_t)cloud->n;
     m.has_aux = cloud->aux_offset >= 0;
     m.view = GridView{};
     m.n_cells = 0; m.cell = 0;
     if (m.n == 0) { m.valid = true; return LILI_OK; }
     const int n = (int)m.n;
-    unsigned banks[64 * 32], mm[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
-    // the cell table of the previous build is cleared NOW, while the bounding box travels to the host and the GPU has nothing else to do (its size is only
-    // known afterwards; a table that has to grow is cleared again in build_grid)
-    const void* zeroed_p = m.cell_start.p;
-    const size_t zeroed_bytes = m.cell_start.p ? m.cell_start.cap : 0;
-    if (zeroed_bytes) HIPCHK(hipMemsetAsync(m.cell_start.p, 0, zeroed_bytes, ctx->stream));
-    if (box6) for (int k = 0; k < 6; k++) mm[k] = box6[k];
-    else {
-        int rb = lili_readback_add(ctx, banks, d_mm, sizeof(banks)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb;
-        for (int b = 0; b < 64; b++) for (int k = 0; k < 3; k++) { mm[k] = std::min(mm[k], banks[b * 32 + k]); mm[3 + k] = std::max(mm[3 + k], banks[b * 32 + 3 + k]); }
+    // The points are read where they lie — the caller's device array, or the staging copy of a host cloud — by the box pass, the count pass and the scatter
+    // pass (round 4; rounds 1-3 first copied the map into a float4 array of the library's: 60-80 MB read + 80 MB written per 5 M points, 18 us).
+    SrcCloud src{};
+    src.p = reinterpret_cast<const unsigned char*>(cloud->data); src.stride = (int)cloud->stride; src.aux_off = cloud->aux_offset;
+    if (cloud->mem == LILI_MEM_HOST) {
+        HIPCHK(ctx->staging.ensure(cloud->n * cloud->stride));
+        HIPCHK(hipMemcpyAsync(ctx->staging.p, cloud->data, cloud->n * cloud->stride, hipMemcpyHostToDevice, ctx->stream));
+        src.p = ctx->staging.as<unsigned char>();
     }
-    auto dec = [](unsigned u) { unsigned b = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u; float f; std::memcpy(&f, &b, 4); return f; };
-    double mn[3], mx[3];
-    bool any = true;
-    for (int k = 0; k < 3; k++) { mn[k] = dec(mm[k]); mx[k] = dec(mm[3 + k]); if (!(mn[k] <= mx[k])) any = false; }
-    if (!any) { mn[0] = mn[1] = mn[2] = 0; mx[0] = mx[1] = mx[2] = 0; }   // no finite point: one empty-ish cell
+    src.f4 = cloud->stride == sizeof(float4) && (reinterpret_cast<uintptr_t>(src.p) & 15) == 0 && (cloud->aux_offset == 12 || cloud->aux_offset < 0);
     // cell edge: >= 1.01 * gate radius so that the 27-cell neighbourhood covers the gate ball
     const int reach = ctx->grid_reach == 2 ? 2 : 1;
     // reach * cell >= 1.01 * gate radius; with reach 2 the cell edge is cell_pct % of the gate radius (50..100)
     double cell = std::sqrt(max_sq_radius) * 1.01 * (reach == 2 ? (double)ctx->cell_pct / 100.0 : 1.0);
     if (!(cell > 1e-6)) cell = 1e-6;
+    // The box.  A build with no box from its caller GUESSES it when the previous build of this kind was of a cloud of about this size (a pipeline rebuilds the index of
+    // a slowly changing map per keyframe, L/src/BackendFusion.cpp:839-840): that build's true box, grown by a margin of cells.  The count pass reduces this cloud's true
+    // box on the side; it comes back with the density at the END of the build (the one synchronisation a build has anyway) and must lie inside the grid — every point
+    // then got its cell without clamping, exactly as with a measured box — else the index is rebuilt with the true box (and the margin doubles).  A build that guesses
+    // has no host round trip before its kernels: -30 us per build.
+    unsigned* d_mm = ctx->misc.as<unsigned>();
+    SpecBox& sb = ctx->spec_box[kind];
+    // 8-bit cell counters (k_cell_count_narrow) unless a build of this kind has met a cell of more than 255 points (or the single-pass scan is off: A/B, fallback)
+    const bool narrow = ctx->map_narrow_counts && !sb.wide_counts && ctx->scan_lookback;
+    BoxSource source = box6 ? kBoxGiven : kBoxMeasure;
+    if (!box6 && allow_guess && ctx->map_guess_box && sb.valid && sb.max_sq_radius == max_sq_radius &&
+        (double)n <= 1.25 * (double)sb.n && (double)n >= 0.8 * (double)sb.n) source = kBoxGuess;
+    // every scratch word of the build — box banks, density banks, the scans' error word and status words, the guess's flags — starts from zero: one fill
+    HIPCHK(hipMemsetAsync(ctx->misc.p, 0, kMiscTotal, ctx->stream));
+    unsigned banks[64 * 32], mm[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
+    const void* zeroed_p = nullptr;
+    size_t zeroed_bytes = 0;
+    double mn[3], mx[3];
+    auto decode_box = [&](const unsigned w[6]) {
+        bool any = true;
+        for (int k = 0; k < 3; k++) { mn[k] = ord2f(w[k]); mx[k] = ord2f(w[3 + k]); if (!(mn[k] <= mx[k])) any = false; }
+        if (!any) { mn[0] = mn[1] = mn[2] = 0; mx[0] = mx[1] = mx[2] = 0; }   // no finite point: one empty-ish cell
+        return any;
+    };
+    if (source == kBoxGiven) { for (int k = 0; k < 6; k++) mm[k] = box6[k]; decode_box(mm); }
+    else if (source == kBoxGuess) {
+        decode_box(sb.mm);
+        // 3/4 of a cell per side to begin with (x 2 after every failed guess): the table grows by 1.5 cells per axis, the cloud may drift by half a cell before the
+        // count pass reports it within a quarter cell of a face
+        const double margin = 0.75 * (double)sb.margin_cells * cell;
+        for (int k = 0; k < 3; k++) { mn[k] -= margin; mx[k] += margin; }
+    } else {
+        hipLaunchKernelGGL(k_bbox_src, dim3(std::min(nblocks((int64_t)n, kBlock), 4096)), dim3(kBlock), 0, ctx->stream, src, n, d_mm);
+        // the cell table of the previous build is cleared NOW, while the bounding box travels to the host and the GPU has nothing else to do (its size is only
+        // known afterwards; a table that has to grow is cleared again in build_grid)
+        DevBuf& table = narrow ? m.cell_tmp : m.cell_start;
+        zeroed_p = table.p;
+        zeroed_bytes = table.p ? table.cap : 0;
+        if (zeroed_bytes) HIPCHK(hipMemsetAsync(table.p, 0, zeroed_bytes, ctx->stream));
+        int rb = lili_readback_add(ctx, banks, d_mm, sizeof(banks)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb;
+        unsigned inv_min[3] = {0u, 0u, 0u};          // the banks hold ~ordered(min) and ordered(max), both maximised from zero (bbox_to_banks)
+        for (int b = 0; b < 64; b++) for (int k = 0; k < 3; k++) { inv_min[k] = std::max(inv_min[k], banks[b * 32 + k]); mm[3 + k] = std::max(mm[3 + k], banks[b * 32 + 3 + k]); }
+        for (int k = 0; k < 3; k++) mm[k] = ~inv_min[k];
+        decode_box(mm);
+    }
     m.has_fine = false; m.fview = GridView{}; m.fbound = 0.f; m.fine_cell = 0; m.mean_occupancy = 0;
-    constexpr size_t kRankBanks = 64, kRankBytes = kRankBanks * 128;                       // k_cell_count: one bank per 128 bytes
-    unsigned long long* d_rank = ctx->fine_grid ? reinterpret_cast<unsigned long long*>(ctx->misc.as<char>() + 8192) : nullptr;
-    if (d_rank) HIPCHK(hipMemsetAsync(d_rank, 0, kRankBytes, ctx->stream));
+    constexpr size_t kRankBanks = 64;                       // k_cell_count: one bank per 128 bytes
+    unsigned long long* d_rank = reinterpret_cast<unsigned long long*>(ctx->misc.as<char>() + 8192);
     unsigned scan_err = 0;
     bool err_read = false;
-    rc = build_grid(ctx, m, mn, mx, cell, reach, m.sorted, m.aux_sorted, m.cell_start, m.cell_start9, m.view, m.n_cells, m.cell, d_rank, zeroed_p, zeroed_bytes);
+    int rc = build_grid(ctx, m, src, mn, mx, cell, reach, m.sorted, m.aux_sorted, m.cell_start, m.cell_start9, m.view, m.n_cells, m.cell, d_rank, source == kBoxGuess,
+                        (float)(1.5 * (double)sb.margin_cells + 0.5) /* twice the margin: a cloud that moved towards one face moved away from the other */, narrow, true, zeroed_p, zeroed_bytes);
     if (rc != LILI_OK) return rc;
+    // The build's read-back: [density banks, with the check word of a guessed box in every bank | sticky error word of the look-back scans] lie side by side in ctx->misc.
     // Density adaptation (SURVEY §7 step 4, §8d Config 2 variant B): the point-weighted mean cell occupancy falls out of the count pass.
     // A map with many points per gate-sized cell gets a second, fine index whose cells hold ~3 points; k_associate_fine searches it first.
-    if (d_rank) {
-        unsigned long long banks[kRankBanks * 16 + 1], rank_sum = 0;      // + the sticky error word of the look-back scans, which follows the banks
-        { int rb = lili_readback_add(ctx, banks, d_rank, kRankBytes + sizeof(unsigned long long)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }
-        scan_err = (unsigned)banks[kRankBanks * 16];
+    {
+        struct Back { unsigned long long rank[kRankBanks * 16]; unsigned err, pad; } back;
+        static_assert(sizeof(Back) == 64 * 128 + 8, "layout of ctx->misc");
+        { int rb = lili_readback_add(ctx, &back, ctx->misc.as<char>() + 8192, sizeof(back)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }
+        scan_err = back.err;
         err_read = true;
-        for (size_t b = 0; b < kRankBanks; b++) rank_sum += banks[b * 16];
-        m.mean_occupancy = 1.0 + 2.0 * (double)rank_sum / (double)n;
-        if (m.mean_occupancy > (double)ctx->fine_occupancy && m.cell == cell) {          // (a grid coarsened by max_cells is not refined)
+        unsigned chk = 0;
+        for (size_t b = 0; b < kRankBanks; b++) chk |= (unsigned)back.rank[b * 16 + 1];
+        if (narrow && (chk & 256u)) {          // a cell of more than 255 points: this kind of map gets 32-bit counters from now on
+            sb.wide_counts = true;
+            ctx->narrow_overflows++;
+            return map_set_impl(ctx, kind, cloud, max_sq_radius, source == kBoxGuess ? nullptr : mm, source == kBoxGuess);
+        }
+        if (source == kBoxGuess) {
+            ctx->box_guesses++;
+            if ((chk & 1u) || (chk & 0xFCu) != 0xFCu) {          // a point outside the guessed box, or a face of it that no point comes near (another cloud's box): measure, build again
+                ctx->box_guess_misses++;
+                if (chk & 1u) sb.margin_cells = std::min(sb.margin_cells * 2, 64);
+                return map_set_impl(ctx, kind, cloud, max_sq_radius, nullptr, false);
+            }
+            if (chk & 2u) sb.valid = false;      // the cloud comes within a quarter cell of a face of the grid: the next build measures its box again
+        }
+        if (ctx->fine_grid) {
+            unsigned long long rank_sum = 0;
+            for (size_t b = 0; b < kRankBanks; b++) rank_sum += back.rank[b * 16];
+            m.mean_occupancy = 1.0 + 2.0 * (double)rank_sum / (double)n;
+        }
+        if (ctx->fine_grid && m.mean_occupancy > (double)ctx->fine_occupancy && m.cell == cell) {          // (a grid coarsened by max_cells is not refined)
             // surfaces: occupancy ~ cell^2; aim at ~3 points per fine cell, at least 4x and at most 64x finer cells per axis ... clamped
             double fc = cell * std::sqrt(3.0 / m.mean_occupancy);
             fc = std::min(std::max(fc, cell / 16.0), cell / 1.5);
             int64_t fcells = 0; double fcell_used = 0;
-            rc = build_grid(ctx, m, mn, mx, fc, reach, m.sorted_f, m.aux_sorted_f, m.cell_start_f, m.cell_start9_f, m.fview, fcells, fcell_used, nullptr);
+            rc = build_grid(ctx, m, src, mn, mx, fc, reach, m.sorted_f, m.aux_sorted_f, m.cell_start_f, m.cell_start9_f, m.fview, fcells, fcell_used, nullptr, false, 0.f, false /* the fine index keeps 32-bit counters: its check would need a read-back of its own */, false);
             if (rc != LILI_OK) return rc;
             const double rb = (double)reach * fcell_used / 1.01;
             float fb = (float)(rb * rb * (1.0 - 1e-6));
@@ -438,12 +519,19 @@ static int map_set_hinted_impl(lili_ctx* ctx, int kind, const lili_cloud* cloud,
         if (scan_err) {
             ctx->scan_lookback = false;
             ctx->scan_fallbacks++;
-            rc = lili_map_set_hinted(ctx, kind, cloud, max_sq_radius, box6, in_place);
+            rc = map_set_impl(ctx, kind, cloud, max_sq_radius, source == kBoxGuess ? nullptr : mm, false);
             ctx->scan_lookback = true;
             return rc;
         }
     }
-    m.pts_ext = nullptr;
+    // what the next build of this kind may start from: this cloud's TRUE box (a given box is the caller's, taken as true: lili_localmap_commit hands over the centroids'
+    // own).  A build from a guess keeps the box it guessed from — margins do not pile up.
+    if (source != kBoxGuess) {
+        for (int k = 0; k < 6; k++) sb.mm[k] = mm[k];
+        sb.valid = mm[0] <= mm[3] && mm[1] <= mm[4] && mm[2] <= mm[5];
+        sb.max_sq_radius = max_sq_radius;
+        sb.n = n;
+    }
     m.valid = true;
     return LILI_OK;
 }
@@ -465,7 +553,7 @@ int lili_map_set_begin(lili_ctx* ctx, int kind, const lili_cloud* cloud, double 
     }
     if (!ctx->build_done[kind]) HIPCHK(hipEventCreateWithFlags(&ctx->build_done[kind], hipEventDisableTiming));
     if (!ctx->main_mark[kind]) HIPCHK(hipEventCreateWithFlags(&ctx->main_mark[kind], hipEventDisableTiming));
-    if (ctx->misc_build.ensure(kMiscBytes) != hipSuccess) return ctx->fail(LILI_E_NOMEM, "map_set_begin: scratch allocation failed");
+    if (ctx->misc_build.ensure(kMiscTotal) != hipSuccess) return ctx->fail(LILI_E_NOMEM, "map_set_begin: scratch allocation failed");
     // the buffers being rebuilt are the ones the index before the current one lived in: everything enqueued up to the swap that retired
     // them (main_mark, recorded by lili_map_set_end) has to be through before they are overwritten — NOT what was enqueued since, which
     // uses the current index and is what the build overlaps with
@@ -514,6 +602,14 @@ int lili_map_focus(lili_ctx* ctx, const double center[3], double radius) {
     ARGCHK(std::isfinite(center[0]) && std::isfinite(center[1]) && std::isfinite(center[2]) && std::isfinite(radius), "map_focus: non-finite argument");
     for (int k = 0; k < 3; k++) ctx->focus[k] = center[k];
     ctx->focus_radius = radius;
+    return LILI_OK;
+}
+
+int lili_map_build_stats(lili_ctx* ctx, int32_t* box_guesses, int32_t* box_guess_misses, int32_t* scan_fallbacks) {
+    if (!ctx) return LILI_E_ARG;
+    if (box_guesses) *box_guesses = ctx->box_guesses;
+    if (box_guess_misses) *box_guess_misses = ctx->box_guess_misses;
+    if (scan_fallbacks) *scan_fallbacks = ctx->scan_fallbacks;
     return LILI_OK;
 }
 

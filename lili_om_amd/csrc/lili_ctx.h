@@ -41,8 +41,7 @@ struct MapIndex {
     int64_t n = 0, n_cells = 0;
     double cell = 0;
     GridView view{};
-    DevBuf pts, sorted, aux_sorted, cell_start, cell_tmp, pt_cell, block_sums, cell_start9, row9;
-    const void* pts_ext = nullptr;   // during a build: the points are read in place from a library-owned float4 array instead of from `pts`
+    DevBuf sorted, aux_sorted, cell_start, cell_tmp, pt_cell /* rank of every point inside its cell (int), between the count and the scatter pass */, block_sums, cell_start9, row9;
     bool has_aux = false;
     // density adaptation: a second index with cells sized from the measured density (dense maps only), searched first
     bool has_fine = false;
@@ -52,12 +51,23 @@ struct MapIndex {
     double fine_cell = 0, mean_occupancy = 0;
     void swap(MapIndex& o) {     // lili_map_set_begin / _end: the index under construction and the current one trade places
         std::swap(valid, o.valid); std::swap(n, o.n); std::swap(n_cells, o.n_cells); std::swap(cell, o.cell); std::swap(view, o.view);
-        pts.swap(o.pts); sorted.swap(o.sorted); aux_sorted.swap(o.aux_sorted); cell_start.swap(o.cell_start); cell_tmp.swap(o.cell_tmp); pt_cell.swap(o.pt_cell);
+        sorted.swap(o.sorted); aux_sorted.swap(o.aux_sorted); cell_start.swap(o.cell_start); cell_tmp.swap(o.cell_tmp); pt_cell.swap(o.pt_cell);
         block_sums.swap(o.block_sums); cell_start9.swap(o.cell_start9); row9.swap(o.row9);
         std::swap(has_aux, o.has_aux); std::swap(has_fine, o.has_fine); std::swap(fview, o.fview);
         sorted_f.swap(o.sorted_f); aux_sorted_f.swap(o.aux_sorted_f); cell_start_f.swap(o.cell_start_f); cell_start9_f.swap(o.cell_start9_f);
         std::swap(fbound, o.fbound); std::swap(fine_cell, o.fine_cell); std::swap(mean_occupancy, o.mean_occupancy);
     }
+};
+
+// What the next index build of a kind may start from (lili_map_set): the previous build's TRUE bounding box (ordered-uint words as the
+// device reduces them), the size and gate radius of that cloud, and the margin (in cells) a guessed box adds on every side (doubles whenever a guess fails).
+struct SpecBox {
+    bool valid = false;
+    unsigned mm[6] = {0, 0, 0, 0, 0, 0};
+    int64_t n = 0;
+    double max_sq_radius = 0;
+    int margin_cells = 1;
+    bool wide_counts = false;      // a build of this kind met a cell of more than 255 points: 32-bit cell counters from then on (k_cell_count instead of k_cell_count_narrow)
 };
 
 struct KindSlot {
@@ -109,6 +119,10 @@ struct lili_ctx {
     hipEvent_t build_done[2] = {}, main_mark[2] = {};
     hipEvent_t cloud_ready = nullptr;      // lili_map_set_begin with a device cloud: the build stream waits for what the context's stream has enqueued so far
     unsigned long long lm_launches = 0;    // lili_s2m_solve_lm launches of this context: part of the granule keys, so no launch ever sees an older one's partials as its own
+    SpecBox spec_box[2];
+    bool map_guess_box = true;             // lili_map_set without a box from its caller starts from the previous build's box (+ margin) and checks it at its final read-back (0: measure first, A/B)
+    int box_guesses = 0, box_guess_misses = 0, narrow_overflows = 0;
+    bool map_narrow_counts = true;         // 8-bit cell counters in the index build (a quarter of the table to clear, fill and scan; 0: 32-bit always, A/B)
     int scan_fallbacks = 0;                // map builds repeated with the three-kernel scan because a look-back scan gave up (never expected; lili_map_info reports it)
     bool build_pending[2] = {false, false}, main_marked[2] = {false, false};
     DevBuf staging_build, misc_build;

@@ -24,6 +24,14 @@ struct GridView {
     int reach;              // neighbourhood half-width in cells: reach * cell edge >= 1.01 * gate radius (1 or 2)
 };
 
+// A caller's point cloud as the map-index build reads it (round 4: no float4 copy of the map any more): device pointer, byte stride, byte offset of the
+// auxiliary float or < 0.  `f4`: stride 16, 16-byte aligned, aux at offset 12 or absent — one 16-byte load per point.
+struct SrcCloud {
+    const unsigned char* p;
+    int stride, aux_off;
+    int f4;
+};
+
 // Per-slot state that lives in device memory so that outer iterations need no host round trip.
 struct SlotState {
     double pose[7];   // body pose: t(3), q(w,x,y,z)

@@ -117,17 +117,88 @@ __global__ void k_bbox_dev(const float4* __restrict__ pts, const int* __restrict
 }
 
 
-// One global atomic per point in the WHOLE build: the value it returns is the point's rank inside its cell, kept next to the cell id,
-// so the scatter pass needs no second counter array, no second 108 MB memset and no atomics (round 1: an atomic here, whose result
-// was dropped, and another one in k_scatter).
+__device__ __forceinline__ float4 load_src(const SrcCloud& s, int i) {
+    if (s.f4) { float4 v = reinterpret_cast<const float4*>(s.p)[i]; if (s.aux_off < 0) v.w = 0.f; return v; }
+    const unsigned char* q = s.p + (size_t)i * s.stride;
+    const float* f = reinterpret_cast<const float*>(q);
+    float4 v;
+    v.x = f[0]; v.y = f[1]; v.z = f[2];
+    v.w = s.aux_off >= 0 ? *reinterpret_cast<const float*>(q + s.aux_off) : 0.f;
+    return v;
+}
+// 64 banks x 32 words, all reduced with atomicMax from ZERO (one memset arms every scratch word of a build): words 0..2 = ~ordered-uint of min xyz, words 3..5 =
+// ordered-uint of max xyz; one atomic set per workgroup; the host folds the banks.
+__device__ __forceinline__ void bbox_to_banks(float mn[3], float mx[3], unsigned* __restrict__ mm, float (*smn)[3], float (*smx)[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        for (int o = 32; o > 0; o >>= 1) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], o)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o)); }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { smn[threadIdx.x >> 6][k] = mn[k]; smx[threadIdx.x >> 6][k] = mx[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        float a = smn[0][k], b = smx[0][k];
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++) { a = fminf(a, smn[w][k]); b = fmaxf(b, smx[w][k]); }
+        unsigned* bank = mm + (size_t)(blockIdx.x & 63) * 32;
+        if (a <= b) { atomicMax(&bank[k], ~f2ord(a)); atomicMax(&bank[3 + k], f2ord(b)); }
+    }
+}
+// Bounding box of the finite points of a caller's cloud, read where it lies (the first build of a map; later builds of a similar cloud start from
+// the previous build's box and check it afterwards: lili_map_set).
+__global__ __launch_bounds__(kBlock) void k_bbox_src(SrcCloud src, int n, unsigned* __restrict__ mm) {
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 v = load_src(src, i);
+        if (isfinite(v.x) && isfinite(v.y) && isfinite(v.z)) {
+            mn[0] = fminf(mn[0], v.x); mn[1] = fminf(mn[1], v.y); mn[2] = fminf(mn[2], v.z);
+            mx[0] = fmaxf(mx[0], v.x); mx[1] = fmaxf(mx[1], v.y); mx[2] = fmaxf(mx[2], v.z);
+        }
+    }
+    __shared__ float smn[kBlock / 64][3], smx[kBlock / 64][3];
+    bbox_to_banks(mn, mx, mm, smn, smx);
+}
+
+// One global atomic per point in the WHOLE build: the value it returns is the point's rank inside its cell, kept for the scatter pass,
+// which therefore needs no second counter array, no second 108 MB memset and no atomics (round 1: an atomic here, whose result
+// was dropped, and another one in k_scatter).  Round 4: the points are read from the caller's cloud where it lies (no float4 copy of the map: -160 MB
+// per 5 M points) and only the rank is stored (the scatter pass recomputes the cell: -40 MB).
 // Neighbouring lanes that fall into the same cell (maps come out of the voxel filter in voxel order: consecutive points are
 // neighbours in x) share ONE atomic: run heads add the run length, the members take base + offset.  No loop, ~10 instructions;
 // an unordered cloud degenerates to one atomic per point.  All 64 lanes of a wave must be active.
-__global__ void k_cell_count(const float4* __restrict__ pts, int n, GridView g, int* __restrict__ cell_count, int2* __restrict__ pt_cell,
-                             unsigned long long* __restrict__ rank_sum /*optional*/) {
+// `check` (a build whose box is a GUESS — the previous build's true box plus a margin, lili_map_set): every workgroup ORs a word into its bank (next to its rank sum:
+// the same line, one more fire-and-forget atomic): bit 0 if a finite point lies outside the grid (its cell is a clamped one: the build is repeated with the measured box),
+// bit 1 if a point lies within a quarter cell of the grid's faces (the cloud has grown into the margin: the next build measures again), bits 2..7 if a point lies within
+// `touch` cells of the faces x-, x+, y-, y+, z-, z+ (a face nothing comes near: the guess was the box of some other cloud — too loose, the build is repeated as well).
+__global__ __launch_bounds__(kBlock) void k_cell_count(SrcCloud src, int n, GridView g, int* __restrict__ cell_count, int* __restrict__ pt_rank,
+                                                        unsigned long long* __restrict__ banks /*64 x 16 words: [0] rank sum, [1] box check*/, int check, float touch) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const int c = i < n ? cell_of(pts[i], g) : -1;
+    int c = -1;
+    unsigned want = 0;
+    if (i < n) {
+        const float4 p = load_src(src, i);
+        c = 0;                                                              // non-finite: never selected (its distance is NaN), as cell_of
+        if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+            // cell_of's arithmetic (lili_s2m_dev.h), with the position in cells kept for the checks
+            const double u[3] = {((double)p.x - g.ox) * g.inv_cell, ((double)p.y - g.oy) * g.inv_cell, ((double)p.z - g.oz) * g.inv_cell};
+            const int dims[3] = {g.nx, g.ny, g.nz};
+            int cc[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int raw = (int)floor(u[k]);
+                cc[k] = min(max(raw, 0), dims[k] - 1);
+                if (check) {
+                    if (raw != cc[k]) want |= 3u;
+                    if (u[k] < 0.25 || u[k] > (double)dims[k] - 0.25) want |= 2u;
+                    if (u[k] < (double)touch) want |= 4u << (2 * k);
+                    if (u[k] > (double)dims[k] - 1.0 - (double)touch) want |= 8u << (2 * k);
+                }
+            }
+            c = (cc[2] * g.ny + cc[1]) * g.nx + cc[0];
+        }
+    }
     const int prev = __shfl_up(c, 1);
     const bool head = lane == 0 || c != prev;
     const unsigned long long hm = __ballot(head);
@@ -139,18 +210,102 @@ __global__ void k_cell_count(const float4* __restrict__ pts, int n, GridView g, 
     if (head && c >= 0) base = atomicAdd(&cell_count[c], len);
     base = __shfl(base, hl);
     const int rank = base + (lane - hl);
-    if (i < n) pt_cell[i] = make_int2(c, rank);
+    if (i < n) pt_rank[i] = rank;
     // density estimate for free: a point's rank is its position inside its cell, so sum(rank) = sum over cells of occ (occ - 1) / 2 and the
     // point-weighted mean cell occupancy is 1 + 2 sum(rank) / n (lili_map_set decides on the fine grid with it).  One atomic per block,
     // spread over 64 banks that the host adds up.
-    if (rank_sum) {
+    if (banks) {
         unsigned long long r64 = i < n && c >= 0 ? (unsigned long long)rank : 0ull;
         for (int o = 32; o > 0; o >>= 1) r64 += __shfl_xor(r64, o);
+        unsigned w = 0;
+        if (check) {
+#pragma unroll
+            for (int b = 0; b < 8; b++) if (__ballot((want >> b) & 1u)) w |= 1u << b;
+        }
         __shared__ unsigned long long wsum[kBlock / 64];
-        if (lane == 0) wsum[threadIdx.x >> 6] = r64;
+        __shared__ unsigned wchk[kBlock / 64];
+        if (lane == 0) { wsum[threadIdx.x >> 6] = r64; wchk[threadIdx.x >> 6] = w; }
         __syncthreads();
         // 64 banks, 128 bytes apart (same-address atomics cost ~12 ns each: 19.5 k blocks on ONE word were 0.2 ms of a 5 M-point build)
-        if (threadIdx.x == 0) { unsigned long long t = 0; for (int w = 0; w < kBlock / 64; w++) t += wsum[w]; atomicAdd(rank_sum + (size_t)(blockIdx.x & 63) * 16, t); }
+        if (threadIdx.x == 0) {
+            unsigned long long t = 0; unsigned f = 0;
+            for (int k = 0; k < kBlock / 64; k++) { t += wsum[k]; f |= wchk[k]; }
+            unsigned long long* bank = banks + (size_t)(blockIdx.x & 63) * 16;
+            atomicAdd(bank, t);
+            if (check) atomicOr(bank + 1, (unsigned long long)f);
+        }
+    }
+}
+
+// The same pass on the NARROW count table (round 4): four 8-bit counters per 32-bit word — a voxel-filtered map holds a handful of points per cell —, so the table the
+// count pass clears, fills and the scan reads is a quarter of the 32-bit one (24 MB instead of 97 MB for the bench map's 24 M cells), and lanes whose cells share a WORD
+// share one atomic (cells along x are neighbours in the table: the pipeline's voxel-ordered maps need one atomic per ~6 points instead of one per 1.6).  The atomic
+// returns the word's four old counts; a lane's rank = the old count of its cell + the lanes of its word run before it that fall into the same cell (ballots, no loop).
+// Ranks are bytes.  A cell that would exceed 255 points raises bit 8 of the check word: lili_map_set then repeats the build with the 32-bit table and keeps to it for
+// this kind of map (dense maps: their coarse index is rebuilt once).
+__global__ __launch_bounds__(kBlock) void k_cell_count_narrow(SrcCloud src, int n, GridView g, unsigned* __restrict__ count4, unsigned char* __restrict__ pt_rank,
+                                                               unsigned long long* __restrict__ banks /*64 x 16 words: [0] rank sum, [1] check word*/, int check, float touch) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int c = -1;
+    unsigned want = 0;
+    if (i < n) {
+        const float4 p = load_src(src, i);
+        c = 0;
+        if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+            const double u[3] = {((double)p.x - g.ox) * g.inv_cell, ((double)p.y - g.oy) * g.inv_cell, ((double)p.z - g.oz) * g.inv_cell};
+            const int dims[3] = {g.nx, g.ny, g.nz};
+            int cc[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int raw = (int)floor(u[k]);
+                cc[k] = min(max(raw, 0), dims[k] - 1);
+                if (check) {
+                    if (raw != cc[k]) want |= 3u;
+                    if (u[k] < 0.25 || u[k] > (double)dims[k] - 0.25) want |= 2u;
+                    if (u[k] < (double)touch) want |= 4u << (2 * k);
+                    if (u[k] > (double)dims[k] - 1.0 - (double)touch) want |= 8u << (2 * k);
+                }
+            }
+            c = (cc[2] * g.ny + cc[1]) * g.nx + cc[0];
+        }
+    }
+    const int w = c >> 2;                                                  // (-1 for the lanes past the end)
+    const int sub = c & 3;
+    const int prevw = __shfl_up(w, 1);
+    const bool head = lane == 0 || w != prevw;
+    const unsigned long long hm = __ballot(head);
+    const unsigned long long upto = (2ull << lane) - 1ull;                 // lanes <= mine (lane 63: all)
+    const unsigned long long below = upto >> 1;                            // lanes < mine
+    const int hl = 63 - __clzll((long long)(hm & upto));                   // my word run's head lane
+    const unsigned long long above = hm & ~upto;
+    const int nxt = above ? __ffsll((long long)above) - 1 : 64;            // first lane of the next run
+    const unsigned long long run = (nxt == 64 ? ~0ull : ((1ull << nxt) - 1ull)) & ~((1ull << hl) - 1ull);
+    const unsigned long long m0 = __ballot(c >= 0 && sub == 0), m1 = __ballot(c >= 0 && sub == 1), m2 = __ballot(c >= 0 && sub == 2), m3 = __ballot(c >= 0 && sub == 3);
+    const unsigned add = (unsigned)__popcll(m0 & run) | ((unsigned)__popcll(m1 & run) << 8) | ((unsigned)__popcll(m2 & run) << 16) | ((unsigned)__popcll(m3 & run) << 24);
+    unsigned old = 0;
+    if (head && c >= 0) old = atomicAdd(&count4[w], add);
+    old = __shfl(old, hl);
+    const unsigned long long mine = sub == 0 ? m0 : sub == 1 ? m1 : sub == 2 ? m2 : m3;
+    const unsigned before = (old >> (8 * sub)) & 0xffu;
+    const int rank = (int)before + __popcll(mine & run & below);
+    if (c >= 0 && before + ((add >> (8 * sub)) & 0xffu) > 255u) want |= 256u;          // the counter would wrap (and carry into its neighbour)
+    if (i < n) pt_rank[i] = (unsigned char)rank;
+    unsigned long long r64 = i < n && c >= 0 ? (unsigned long long)rank : 0ull;
+    for (int o = 32; o > 0; o >>= 1) r64 += __shfl_xor(r64, o);
+    unsigned f = 0;
+#pragma unroll
+    for (int b = 0; b < 9; b++) if (__ballot((want >> b) & 1u)) f |= 1u << b;
+    __shared__ unsigned long long wsum[kBlock / 64];
+    __shared__ unsigned wchk[kBlock / 64];
+    if (lane == 0) { wsum[threadIdx.x >> 6] = r64; wchk[threadIdx.x >> 6] = f; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0; unsigned ff = 0;
+        for (int k = 0; k < kBlock / 64; k++) { t += wsum[k]; ff |= wchk[k]; }
+        unsigned long long* bank = banks + (size_t)(blockIdx.x & 63) * 16;
+        atomicAdd(bank, t);
+        if (ff) atomicOr(bank + 1, (unsigned long long)ff);
     }
 }
 
@@ -202,7 +357,7 @@ __global__ void k_scan_apply(const int* in, int64_t n, const int* __restrict__ b
 }
 
 // In-place exclusive scan of n ints in ONE pass (decoupled look-back): the dense cell array (27 M cells = 108 MB for the 5 M-point
-// map) is read once and written once, where the three-kernel scan above reads it twice and writes it once.  Tile b (4096 items) belongs
+// map) is read once and written once, where the three-kernel scan above reads it twice and writes it once.  Tile b (16384 items) belongs
 // to workgroup b — no ticket: 6.6 k same-address atomics cost ~12 ns each on MI355X, more than the whole scan (measured: 183 us with a
 // ticket against 170 us for the three kernels).  Workgroups are dispatched in index order per XCD, so the lowest unfinished tile is
 // always resident and a tile only ever waits for lower ones; should that ever not hold (HIP promises no dispatch order), the bounded spin
@@ -211,34 +366,60 @@ __global__ void k_scan_apply(const int* in, int64_t n, const int* __restrict__ b
 // prefix up to and including the tile), written and read with agent-scope atomics — the word is its own flag, no fence.  One wave
 // per tile looks back 64 predecessors at a time.  `ws`: [0], [1] = error flag, [2 ...] one status word per tile — zeroed by the
 // caller.  data[n] receives the total.
-constexpr int kLbItems = 64;
-constexpr int kLbTile = kBlock * kLbItems;
-__global__ __launch_bounds__(kBlock) void k_scan_lookback(int* data, int64_t n, unsigned long long* __restrict__ ws, unsigned* __restrict__ err /*sticky: set if a look-back gave up*/) {
-    __shared__ int lds[kBlock / 64 + 1];
+// Round 4: the items of a tile are taken ROW-WISE — a wave owns 4096 contiguous items as 16 rows of 256, lane l holding items 4 l .. 4 l + 3 of every row — so that
+// every load and store instruction of a wave covers one contiguous kilobyte (256 bytes of the narrow table).  Before, a lane owned 64 consecutive items: 16-byte
+// accesses 256 bytes apart, 64 partial lines per instruction (52 us for the 24 M-cell table; the row-wise pass is bound by the 107 MB it writes).
+// NARROW: the input is the byte-per-cell count table of k_cell_count_narrow (`in8`), the output the 32-bit `data` — 5 bytes moved per cell instead of 8.
+constexpr int kLbRows = 16;
+constexpr int kLbTile = kBlock * kLbRows * 4;      // 16384 items per workgroup of 256
+template <bool NARROW>
+__global__ __launch_bounds__(kBlock) void k_scan_lookback_t(int* data, const unsigned char* __restrict__ in8, int64_t n, unsigned long long* __restrict__ ws, unsigned* __restrict__ err /*sticky: set if a look-back gave up*/) {
+    __shared__ int wtot[kBlock / 64];
     __shared__ int s_prefix;
     const int tile = (int)blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long* status = ws + 2;
-    const int64_t base = (int64_t)tile * kLbTile + (int64_t)threadIdx.x * kLbItems;
-    int v[kLbItems]; int s = 0;
-    if (base + kLbItems <= n) {
-        const int4* p4 = reinterpret_cast<const int4*>(data + base);        // 16-byte loads: base is a multiple of 16 items
+    const int64_t wbase = (int64_t)tile * kLbTile + (int64_t)wave * (kLbRows * 256) + lane * 4;      // this lane's items of row r: wbase + 256 r .. + 3
+    const bool whole = (int64_t)(tile + 1) * kLbTile <= n;
+    int v[kLbRows][4];
+    if (NARROW) {            // the table is padded to whole tiles (and cleared up to there): no bounds on the loads
 #pragma unroll
-        for (int k = 0; k < kLbItems / 4; k++) { const int4 q = p4[k]; v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w; }
+        for (int r = 0; r < kLbRows; r++) {
+            const unsigned q = *reinterpret_cast<const unsigned*>(in8 + wbase + 256 * r);
+            v[r][0] = (int)(q & 0xffu); v[r][1] = (int)((q >> 8) & 0xffu); v[r][2] = (int)((q >> 16) & 0xffu); v[r][3] = (int)(q >> 24);
+        }
+    } else if (whole) {
+#pragma unroll
+        for (int r = 0; r < kLbRows; r++) { const int4 q = *reinterpret_cast<const int4*>(data + wbase + 256 * r); v[r][0] = q.x; v[r][1] = q.y; v[r][2] = q.z; v[r][3] = q.w; }
     } else {
 #pragma unroll
-        for (int k = 0; k < kLbItems; k++) v[k] = base + k < n ? data[base + k] : 0;
-    }
+        for (int r = 0; r < kLbRows; r++)
 #pragma unroll
-    for (int k = 0; k < kLbItems; k++) s += v[k];
-    int tot;
-    const int ex = block_exclusive_scan(s, lds, tot);
+            for (int k = 0; k < 4; k++) { const int64_t i = wbase + 256 * r + k; v[r][k] = i < n ? data[i] : 0; }
+    }
+    // exclusive prefix of every item inside its wave's stretch: 4 items per lane serially, 64 lanes by a wave scan, the 16 rows by a running carry
+    int ex[kLbRows];
+    int carry = 0;
+#pragma unroll
+    for (int r = 0; r < kLbRows; r++) {
+        const int s4 = (v[r][0] + v[r][1]) + (v[r][2] + v[r][3]);
+        int inc = s4;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+        ex[r] = carry + inc - s4;
+        carry += __shfl(inc, 63);
+    }
+    if (lane == 0) wtot[wave] = carry;
+    __syncthreads();
+    int wofs = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; w++) { const int t = wtot[w]; if (w < wave) wofs += t; tot += t; }
     if (threadIdx.x == 0) {
         const unsigned long long w = ((tile == 0 ? 2ull : 1ull) << 32) | (unsigned long long)(unsigned)tot;
         __hip_atomic_store(&status[tile], w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tile == 0) s_prefix = 0;
     }
     if (tile > 0 && threadIdx.x < 64) {          // one wave walks back until it meets an inclusive prefix
-        const int lane = threadIdx.x;
         int acc = 0;
         for (int hi = tile - 1; ; hi -= 64) {
             const int t = hi - lane;
@@ -264,21 +445,24 @@ __global__ __launch_bounds__(kBlock) void k_scan_lookback(int* data, int64_t n, 
         }
     }
     __syncthreads();
-    int run = s_prefix + ex;
-    if (base + kLbItems <= n) {
-        int4* p4 = reinterpret_cast<int4*>(data + base);
+    const int base = s_prefix + wofs;
 #pragma unroll
-        for (int k = 0; k < kLbItems / 4; k++) {
-            int4 q;
-            q.x = run; run += v[4 * k]; q.y = run; run += v[4 * k + 1]; q.z = run; run += v[4 * k + 2]; q.w = run; run += v[4 * k + 3];
-            p4[k] = q;
+    for (int r = 0; r < kLbRows; r++) {
+        int4 q;
+        q.x = base + ex[r]; q.y = q.x + v[r][0]; q.z = q.y + v[r][1]; q.w = q.z + v[r][2];
+        const int64_t i = wbase + 256 * r;
+        if (whole) *reinterpret_cast<int4*>(data + i) = q;
+        else {
+            if (i < n) data[i] = q.x;
+            if (i + 1 < n) data[i + 1] = q.y;
+            if (i + 2 < n) data[i + 2] = q.z;
+            if (i + 3 < n) data[i + 3] = q.w;
         }
-    } else {
-#pragma unroll
-        for (int k = 0; k < kLbItems; k++) { if (base + k < n) data[base + k] = run; run += v[k]; }
     }
-    if (base <= n - 1 && n - 1 < base + kLbItems) data[n] = s_prefix + ex + s;     // the thread that owns the last item: total
+    if (tile == (int)gridDim.x - 1 && threadIdx.x == 0) data[n] = s_prefix + tot;      // the total (items past n count as zero)
 }
+template __global__ void k_scan_lookback_t<false>(int*, const unsigned char*, int64_t, unsigned long long*, unsigned*);
+template __global__ void k_scan_lookback_t<true>(int*, const unsigned char*, int64_t, unsigned long long*, unsigned*);
 
 // Population of every super-row of the box (its nine source rows, box columns only); the scan of these is the row's first position.
 __global__ void k_rowtot9(const int* __restrict__ cell_start, GridView g, int* __restrict__ rowtot) {
@@ -330,17 +514,20 @@ __global__ __launch_bounds__(256) void k_start9(const int* __restrict__ cell_sta
         start9[(size_t)g.bnx * g.bny * g.bnz] = g.n_points + rowbase[g.bny * g.bnz];          // end of the array
 }
 
-__global__ void k_scatter(const float4* __restrict__ pts, int n, const int2* __restrict__ pt_cell, const int* __restrict__ cell_start,
-                          float4* __restrict__ sorted, float* __restrict__ aux_sorted) {
+template <typename RankT>
+__global__ __launch_bounds__(kBlock) void k_scatter_t(SrcCloud src, int n, GridView g, const RankT* __restrict__ pt_rank, const int* __restrict__ cell_start,
+                                                      float4* __restrict__ sorted, float* __restrict__ aux_sorted) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int2 cr = pt_cell[i];
-    const int pos = cell_start[cr.x] + cr.y;
-    float4 p = pts[i];
+    const int rank = (int)pt_rank[i];
+    float4 p = load_src(src, i);
+    const int pos = cell_start[cell_of(p, g)] + rank;
     if (aux_sorted) aux_sorted[pos] = p.w;
     p.w = __int_as_float(i);
     sorted[pos] = p;
 }
+template __global__ void k_scatter_t<int>(SrcCloud, int, GridView, const int*, const int*, float4*, float*);
+template __global__ void k_scatter_t<unsigned char>(SrcCloud, int, GridView, const unsigned char*, const int*, float4*, float*);
 
 // Super-row copy, by DESTINATION: one wave owns the stretch of 64 consecutive super cells (x0..x0+63, y', z') — a contiguous piece of the
 // super-row array — and fills it from its nine source rows, each a contiguous run of the base array.  The nine runs are walked as ONE

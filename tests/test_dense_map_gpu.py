@@ -50,6 +50,7 @@ def test_dense_map_fine_index_is_exact(gpu_ctx, oracle):
     P, PO = L.make_params("rot"), oracle.params("rot")
     res = {}
     try:
+        gpu_ctx.set_option("map_guess_box", 0)      # both builds on the measured box: with 1 862 cells the timing below depends on where the walls fall inside the cells
         for fine in (1, 0):
             gpu_ctx.set_option("fine_grid", fine)
             gpu_ctx.set_debug(True)
@@ -79,6 +80,7 @@ def test_dense_map_fine_index_is_exact(gpu_ctx, oracle):
             dt = (time.perf_counter() - tic) / 10
             res[fine] = (n, idx, d2, rec, G, cost, dt, occ, fcell)
     finally:
+        gpu_ctx.set_option("map_guess_box", 1)
         gpu_ctx.set_option("fine_grid", 1)
         gpu_ctx.set_debug(False)
     print(f"dense map: {mp.shape[0]} points, mean occupancy {res[1][7]:.0f} per gate-sized cell, fine cell {res[1][8]:.3f} m; "
