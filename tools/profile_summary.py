@@ -41,7 +41,7 @@ for k, d in pmc.items():
         e["l2_hit_rate"] = m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
     if k in stats:
         e["avg_us"] = stats[k]["avg_us"]
-    summary[k.split("<")[0]] = e
+    summary[k if "_t<" in k else k.split("<")[0]] = e      # (k_scan_lookback_t<true> / <false>, k_scatter_t<...>: different kernels)
 json.dump(summary, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
 for k, s in sorted(stats.items(), key=lambda kv: -kv[1]["pct"])[:12]:
     print(f"{k[:44]:46s} {s['calls']:6d} {s['avg_us']:10.2f} us {s['pct']:6.2f} %")

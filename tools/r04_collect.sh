@@ -19,5 +19,6 @@ cp $S/rot_phases.log                $D/r04_extract_phases.txt
 cp $S/iter_time.json                $D/r04_iter_time.json
 [ -f $S/window_seam.json ] && cp $S/window_seam.json $D/r04_window_seam_cpp.json
 [ -f $S/k7_kernel_stats.csv ] && cp $S/k7_kernel_stats.csv $D/r04_k7_kernel_stats.csv
+[ -f $S/k7_time.jsonl ] && cp $S/k7_time.jsonl $D/r04_k7_time.jsonl
 grep -E "passed|failed" $S/pytest_all.log | tail -1 > $D/r04_gpu_tests.txt
 ls -la $D/r04_*

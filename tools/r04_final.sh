@@ -23,3 +23,6 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o extr
 echo "== ROT extractor"; python tools/kstats.py $OUT/extract_kernel_stats.csv | head -8; grep "blocking call" $OUT/rot_phases.log
 timeout 300 python tools/iter_time.py $OUT/iter_time.json > $OUT/iter_time.log 2>&1; tail -6 $OUT/iter_time.log
 timeout 120 tools/_probe/launch_floor 2000 > $OUT/launch_floor.txt 2>&1
+timeout 300 python tools/k7_time.py > $OUT/k7_time.jsonl 2> $OUT/k7_time.err; echo "== map index build"; cat $OUT/k7_time.jsonl
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o k7 -- python tools/k7_time.py > /dev/null 2> $OUT/k7_prof.err
+python tools/kstats.py $OUT/k7_kernel_stats.csv | head -12
