@@ -218,7 +218,8 @@ typedef struct lili_livox_params {
  *   cutted: every deskewed point with a valid line (/lidar_cloud_cutted), edge: /edge_features (normal = line
  *   direction), surf: /surf_features (normal = plane normal).  Blocking.  The rows are read as they are (one transfer for host memory);
  *   a `cutted` buffer in host memory receives min(scan->n, capacity) records while the features are selected — the records behind
- *   cutted->count are unspecified. */
+ *   cutted->count are unspecified.  `edge` and `surf` buffers in PAGE-LOCKED host memory (lili_host_alloc, 16-byte aligned) are written by the
+ *   packing kernel itself, `count` records each, and the call synchronises once; pageable buffers are served by copies after the counts have arrived. */
 int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offset, const double q_imu[4], const lili_livox_params* params,
                        lili_feature_out* cutted, lili_feature_out* edge, lili_feature_out* surf);
 /* counts = {n_cutted, n_edge, n_surf}; cut_src[n_cutted]; cell_src[24000] (input index owning each grid cell or -1);

@@ -285,12 +285,13 @@ __global__ void k_livox_pack(const float4* __restrict__ a, const float4* __restr
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= min(*n_dev, cap)) return;
     float4 u = a[i], v = b[i];
+    // 16-byte stores (every destination — the library's pack buffers, a caller's page-locked buffer written across PCIe — is 16-byte aligned)
     if (pcl_layout) {
-        float* o = out + (size_t)i * 12;
-        o[0] = u.x; o[1] = u.y; o[2] = u.z; o[3] = 1.f; o[4] = u.w; o[5] = v.x; o[6] = v.y; o[7] = 0.f; o[8] = v.z; o[9] = v.w; o[10] = 0.f; o[11] = 0.f;
+        float4* o = reinterpret_cast<float4*>(out + (size_t)i * 12);
+        o[0] = make_float4(u.x, u.y, u.z, 1.f); o[1] = make_float4(u.w, v.x, v.y, 0.f); o[2] = make_float4(v.z, v.w, 0.f, 0.f);
     } else {
-        float* o = out + (size_t)i * 8;
-        o[0] = u.x; o[1] = u.y; o[2] = u.z; o[3] = u.w; o[4] = v.x; o[5] = v.y; o[6] = v.z; o[7] = v.w;
+        float4* o = reinterpret_cast<float4*>(out + (size_t)i * 8);
+        o[0] = u; o[1] = v;
     }
 }
 
@@ -308,10 +309,13 @@ struct LivoxBuffers {
     DevBuf edge_a, edge_b, edge_cell, surf_a, surf_b, surf_cell, pack, pack_e, pack_s, xyzc_edge, xyzc_surf;
     lili::LivoxState host{};
     bool have = false;
+    // a caller's page-locked feature buffers (edge, surf) as the device sees them: looked up once per buffer (hipPointerGetAttributes costs far more than a launch)
+    const void* pin_host[4] = {nullptr, nullptr, nullptr, nullptr};      // edge out, surf out, scan in, cutted out
+    void* pin_dev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool armed = false;      // the ownership table holds "no owner" everywhere (k_livox_init once, k_livox_grid after every scan)
     void release() {
         for (DevBuf* b : {&und, &curv, &keep, &owner, &state, &cut_a, &cut_b, &cut_src, &cell_pt, &cell_curv, &cell_src, &blk_nedge, &blk_edge_cell,
-                          &blk_edge_dir, &blk_nsurf, &blk_surf_cell, &blk_surf_nrm, &edge_a, &edge_b, &edge_cell, &surf_a, &surf_b, &surf_cell, &pack, &xyzc_edge, &xyzc_surf}) b->release();
+                          &blk_edge_dir, &blk_nsurf, &blk_surf_cell, &blk_surf_nrm, &edge_a, &edge_b, &edge_cell, &surf_a, &surf_b, &surf_cell, &pack, &pack_e, &pack_s, &blk_keep, &xyzc_edge, &xyzc_surf}) b->release();
     }
 };
 }  // namespace lili_detail
@@ -325,18 +329,43 @@ static lili_detail::LivoxBuffers* livox_of(lili_ctx* ctx) {
 __device__ __forceinline__ void livox_pack_one(int i, const float4* __restrict__ a, const float4* __restrict__ b, int n, int pcl_layout, float* __restrict__ out) {
     if (i >= n) return;
     float4 u = a[i], v = b[i];
+    // 16-byte stores (every destination — the library's pack buffers, a caller's page-locked buffer written across PCIe — is 16-byte aligned)
     if (pcl_layout) {
-        float* o = out + (size_t)i * 12;
-        o[0] = u.x; o[1] = u.y; o[2] = u.z; o[3] = 1.f; o[4] = u.w; o[5] = v.x; o[6] = v.y; o[7] = 0.f; o[8] = v.z; o[9] = v.w; o[10] = 0.f; o[11] = 0.f;
+        float4* o = reinterpret_cast<float4*>(out + (size_t)i * 12);
+        o[0] = make_float4(u.x, u.y, u.z, 1.f); o[1] = make_float4(u.w, v.x, v.y, 0.f); o[2] = make_float4(v.z, v.w, 0.f, 0.f);
     } else {
-        float* o = out + (size_t)i * 8;
-        o[0] = u.x; o[1] = u.y; o[2] = u.z; o[3] = u.w; o[4] = v.x; o[5] = v.y; o[6] = v.z; o[7] = v.w;
+        float4* o = reinterpret_cast<float4*>(out + (size_t)i * 8);
+        o[0] = u; o[1] = v;
     }
 }
 __global__ void k_livox_pack2(int nb0, const float4* __restrict__ a0, const float4* __restrict__ b0, const int* __restrict__ n0_dev, int cap0, int layout0, float* __restrict__ out0,
                               const float4* __restrict__ a1, const float4* __restrict__ b1, const int* __restrict__ n1_dev, int cap1, int layout1, float* __restrict__ out1) {
     if ((int)blockIdx.x < nb0) livox_pack_one(blockIdx.x * blockDim.x + threadIdx.x, a0, b0, min(*n0_dev, cap0), layout0, out0);
     else livox_pack_one(((int)blockIdx.x - nb0) * blockDim.x + threadIdx.x, a1, b1, min(*n1_dev, cap1), layout1, out1);
+}
+
+// The device-side address of a caller's PAGE-LOCKED host buffer (lili_host_alloc / hipHostMalloc / hipHostRegister), or nullptr: pageable, or not 16-byte aligned.
+static void* livox_pinned_dev_ptr(lili_detail::LivoxBuffers* B, int which, void* host) {
+    if (B->pin_host[which] != host) {
+        B->pin_host[which] = host; B->pin_dev[which] = nullptr;
+        hipPointerAttribute_t attr{};
+        void* d = nullptr;
+        if (hipPointerGetAttributes(&attr, host) == hipSuccess && attr.type == hipMemoryTypeHost && hipHostGetDevicePointer(&d, host, 0) == hipSuccess &&
+            (reinterpret_cast<uintptr_t>(d) & 15) == 0) B->pin_dev[which] = d;
+        else (void)hipGetLastError();      // pageable memory is unknown to the runtime: not an error of this call
+    }
+    return B->pin_dev[which];
+}
+
+// all three lists in ONE launch (workgroups [0, nbc): lidar_cloud_cutted, [nbc, nbc + nb0): the edge list, then the surf list) — round 4: straight into the caller's
+// page-locked buffers
+__global__ void k_livox_pack3(int nbc, const float4* __restrict__ ac, const float4* __restrict__ bc, const int* __restrict__ nc_dev, int capc, int layoutc, float* __restrict__ outc,
+                              int nb0, const float4* __restrict__ a0, const float4* __restrict__ b0, const int* __restrict__ n0_dev, int cap0, int layout0, float* __restrict__ out0,
+                              const float4* __restrict__ a1, const float4* __restrict__ b1, const int* __restrict__ n1_dev, int cap1, int layout1, float* __restrict__ out1) {
+    const int b = (int)blockIdx.x;
+    if (b < nbc) livox_pack_one(b * blockDim.x + threadIdx.x, ac, bc, min(*nc_dev, capc), layoutc, outc);
+    else if (b < nbc + nb0) livox_pack_one((b - nbc) * blockDim.x + threadIdx.x, a0, b0, min(*n0_dev, cap0), layout0, out0);
+    else livox_pack_one((b - nbc - nb0) * blockDim.x + threadIdx.x, a1, b1, min(*n1_dev, cap1), layout1, out1);
 }
 
 // Packs one list into the caller's record layout (enqueued before the counts are read back; `bound` = an upper bound of the list length)...
@@ -378,10 +407,17 @@ int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offs
     int rc = LILI_OK;
     const int n = (int)scan->n;
     const unsigned char* raw = static_cast<const unsigned char*>(scan->data);
-    if (scan->mem == LILI_MEM_HOST && n > 0) {       // ONE transfer of the rows as they are; k_livox_prep picks the fields
-        HIPCHK(ctx->staging.ensure(scan->n * scan->stride));
-        HIPCHK(hipMemcpyAsync(ctx->staging.p, scan->data, scan->n * scan->stride, hipMemcpyHostToDevice, ctx->stream));
-        raw = ctx->staging.as<unsigned char>();
+    if (scan->mem == LILI_MEM_HOST && n > 0) {
+        // A PAGE-LOCKED scan (a driver's DMA buffer, lili_host_alloc) is read by k_livox_prep where it lies, across PCIe (round 4: the copy engine's transfer + the
+        // ~11 us before a kernel sees its completion were 28 us of the call; the kernel reads the same 1.15 MB in its own time).  Pageable memory: ONE transfer of the
+        // rows as they are; k_livox_prep picks the fields.
+        void* d = livox_pinned_dev_ptr(B, 2, const_cast<void*>(scan->data));
+        if (d) raw = static_cast<const unsigned char*>(d);
+        else {
+            HIPCHK(ctx->staging.ensure(scan->n * scan->stride));
+            HIPCHK(hipMemcpyAsync(ctx->staging.p, scan->data, scan->n * scan->stride, hipMemcpyHostToDevice, ctx->stream));
+            raw = ctx->staging.as<unsigned char>();
+        }
     }
     HIPCHK(B->state.ensure(sizeof(LivoxState))); HIPCHK(B->owner.ensure(kLvCells * 4));
     HIPCHK(B->cell_pt.ensure(kLvCells * 16)); HIPCHK(B->cell_curv.ensure(kLvCells * 4)); HIPCHK(B->cell_src.ensure(kLvCells * 4));
@@ -410,53 +446,102 @@ int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offs
     B->armed = true;
     // lidar_cloud_cutted is final here: it is packed now and travels to the host on a side stream under the grid / block / compaction kernels (768 KB for
     // a 24 k-point scan).  All min(n, capacity) records travel — the count is known only at the end; records behind `count` are unspecified.
+    // Round 4: the host's stream / event calls for that copy (~15 us of API time) are issued AFTER the block and compaction kernels have been launched — the event that
+    // releases the copy is recorded here, the copy itself is enqueued below while the GPU already works on the blocks.
+    // All three outputs in page-locked host memory (what a node that publishes them would use): ONE packing launch writes them across PCIe after the compaction — no
+    // staging copies, no side stream, no count round trip (k_livox_pack3).
+    const auto out_ok = [](const lili_feature_out* o) { return o && o->data && o->capacity > 0 && o->mem == LILI_MEM_HOST && (o->stride == 0 || o->stride == 32 || o->stride == 48); };
+    void *dc = nullptr, *de3 = nullptr, *ds3 = nullptr;
+    bool all3 = n > 0 && out_ok(cutted) && out_ok(edge) && out_ok(surf);
+    if (all3) { dc = livox_pinned_dev_ptr(B, 3, cutted->data); de3 = livox_pinned_dev_ptr(B, 0, edge->data); ds3 = livox_pinned_dev_ptr(B, 1, surf->data); all3 = dc && de3 && ds3; }
     bool cut_early = false;
-    if (n > 0 && cutted && cutted->data && cutted->mem == LILI_MEM_HOST && cutted->capacity > 0) {
+    if (!all3 && n > 0 && cutted && cutted->data && cutted->mem == LILI_MEM_HOST && cutted->capacity > 0) {
         rc = livox_pack(ctx, B->pack, cutted, B->cut_a.as<float4>(), B->cut_b.as<float4>(), &st->n_cut, (size_t)n);
         if (rc != LILI_OK) return rc;
         if (!ctx->fork_ev) HIPCHK(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
         if (!ctx->side[1]) HIPCHK(hipStreamCreateWithFlags(&ctx->side[1], hipStreamNonBlocking));
         if (!ctx->join_ev[1]) HIPCHK(hipEventCreateWithFlags(&ctx->join_ev[1], hipEventDisableTiming));
         HIPCHK(hipEventRecord(ctx->fork_ev, ctx->stream));
-        HIPCHK(hipStreamWaitEvent(ctx->side[1], ctx->fork_ev, 0));
-        HIPCHK(hipMemcpyAsync(cutted->data, B->pack.p, std::min((size_t)n, cutted->capacity) * (cutted->stride ? cutted->stride : 32), hipMemcpyDeviceToHost, ctx->side[1]));
-        HIPCHK(hipEventRecord(ctx->join_ev[1], ctx->side[1]));
         cut_early = true;
     }
     hipLaunchKernelGGL(k_livox_blocks, dim3(kLvBlocks), dim3(64), 0, ctx->stream, B->cell_pt.as<float4>(), B->cell_curv.as<float>(), P,
                        B->blk_nedge.as<int>(), B->blk_edge_cell.as<int>(), B->blk_edge_dir.as<float>(), B->blk_nsurf.as<int>(), B->blk_surf_cell.as<int>(),
                        B->blk_surf_nrm.as<float>());
+    if (cut_early) {          // the side stream's copy of lidar_cloud_cutted, enqueued while the GPU works on the blocks (which use no PCIe); joined before the call's ONE synchronisation
+        hipError_t e = hipStreamWaitEvent(ctx->side[1], ctx->fork_ev, 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(cutted->data, B->pack.p, std::min((size_t)n, cutted->capacity) * (cutted->stride ? cutted->stride : 32), hipMemcpyDeviceToHost, ctx->side[1]);
+        if (e == hipSuccess) e = hipEventRecord(ctx->join_ev[1], ctx->side[1]);
+        if (e != hipSuccess) return ctx->fail(LILI_E_HIP, std::string("extract_livox: ") + hipGetErrorString(e));
+    }
     hipLaunchKernelGGL(k_livox_compact, dim3((kLvBlocks + 15) / 16), dim3(1024), 0, ctx->stream, B->cell_pt.as<float4>(), B->cell_curv.as<float>(), B->blk_nedge.as<int>(),
                        B->blk_edge_cell.as<int>(), B->blk_edge_dir.as<float>(), B->blk_nsurf.as<int>(), B->blk_surf_cell.as<int>(), B->blk_surf_nrm.as<float>(),
                        B->edge_a.as<float4>(), B->edge_b.as<float4>(), B->edge_cell.as<int>(), B->surf_a.as<float4>(), B->surf_b.as<float4>(), B->surf_cell.as<int>(), st);
     HIPCHK(hipGetLastError());
-    rc = lili_readback_add(ctx, &B->host, st, sizeof(LivoxState)); if (rc) return rc;
-    // the three lists are packed into the caller's layout while the counts travel
-    if (!cut_early) rc = livox_pack(ctx, B->pack, cutted, B->cut_a.as<float4>(), B->cut_b.as<float4>(), &st->n_cut, (size_t)n);
-    const bool both = edge && edge->data && edge->capacity && surf && surf->data && surf->capacity;
-    if (rc == LILI_OK && both) {
+    // the three lists are packed into the caller's layout (the kernels read the counts where they lie); then the counts travel
+    bool direct = false;      // the packing kernel wrote the caller's (page-locked) edge / surf buffers itself
+    if (all3) {
+        const size_t kc = std::min((size_t)n, cutted->capacity), k0 = std::min((size_t)kLvCells, edge->capacity), k1 = std::min((size_t)kLvCells, surf->capacity);
+        const int nbc = nblocks((int64_t)kc, 256), nb0 = nblocks((int64_t)k0, 256), nb1 = nblocks((int64_t)k1, 256);
+        hipLaunchKernelGGL(k_livox_pack3, dim3(nbc + nb0 + nb1), dim3(256), 0, ctx->stream,
+                           nbc, B->cut_a.as<float4>(), B->cut_b.as<float4>(), &st->n_cut, (int)kc, cutted->stride == 48 ? 1 : 0, static_cast<float*>(dc),
+                           nb0, B->edge_a.as<float4>(), B->edge_b.as<float4>(), &st->n_edge, (int)k0, edge->stride == 48 ? 1 : 0, static_cast<float*>(de3),
+                           B->surf_a.as<float4>(), B->surf_b.as<float4>(), &st->n_surf, (int)k1, surf->stride == 48 ? 1 : 0, static_cast<float*>(ds3));
+        if (hipGetLastError() != hipSuccess) rc = ctx->fail(LILI_E_HIP, "extract_livox: pack launch failed");
+        direct = true;
+    }
+    if (!all3 && !cut_early) rc = livox_pack(ctx, B->pack, cutted, B->cut_a.as<float4>(), B->cut_b.as<float4>(), &st->n_cut, (size_t)n);
+    const bool both = !all3 && edge && edge->data && edge->capacity && surf && surf->data && surf->capacity;
+    if (all3) {}
+    else if (rc == LILI_OK && both) {
         const size_t k0 = std::min((size_t)kLvCells, edge->capacity), k1 = std::min((size_t)kLvCells, surf->capacity);
         const size_t s0 = edge->stride ? edge->stride : 32, s1 = surf->stride ? surf->stride : 32;
         ARGCHK((s0 == 32 || s0 == 48) && (s1 == 32 || s1 == 48), "feature_out: Livox records are 32 B (packed x,y,z,nx,ny,nz,intensity,curvature) or 48 B (pcl::PointXYZINormal)");
         HIPCHK(B->pack_e.ensure(k0 * s0)); HIPCHK(B->pack_s.ensure(k1 * s1));
         const int nb0 = nblocks((int64_t)k0, 256), nb1 = nblocks((int64_t)k1, 256);
+        // Round 4: page-locked feature buffers are written by the packing kernel ITSELF, across PCIe, exactly `count` records each: no staging copy, no count round
+        // trip before the transfers, one synchronisation per call (the count round trip + a second one were ~35 us of 120).
+        float* out_e = B->pack_e.as<float>(); float* out_s = B->pack_s.as<float>();
+        if (edge->mem == LILI_MEM_HOST && surf->mem == LILI_MEM_HOST) {
+            void* de = livox_pinned_dev_ptr(B, 0, edge->data); void* ds = livox_pinned_dev_ptr(B, 1, surf->data);
+            if (de && ds) { out_e = static_cast<float*>(de); out_s = static_cast<float*>(ds); direct = true; }
+        }
         hipLaunchKernelGGL(k_livox_pack2, dim3(nb0 + nb1), dim3(256), 0, ctx->stream, nb0, B->edge_a.as<float4>(), B->edge_b.as<float4>(), &st->n_edge, (int)k0, s0 == 48 ? 1 : 0,
-                           B->pack_e.as<float>(), B->surf_a.as<float4>(), B->surf_b.as<float4>(), &st->n_surf, (int)k1, s1 == 48 ? 1 : 0, B->pack_s.as<float>());
+                           out_e, B->surf_a.as<float4>(), B->surf_b.as<float4>(), &st->n_surf, (int)k1, s1 == 48 ? 1 : 0, out_s);
         if (hipGetLastError() != hipSuccess) rc = ctx->fail(LILI_E_HIP, "extract_livox: pack launch failed");
     } else {
         if (rc == LILI_OK) rc = livox_pack(ctx, B->pack_e, edge, B->edge_a.as<float4>(), B->edge_b.as<float4>(), &st->n_edge, (size_t)kLvCells);
         if (rc == LILI_OK) rc = livox_pack(ctx, B->pack_s, surf, B->surf_a.as<float4>(), B->surf_b.as<float4>(), &st->n_surf, (size_t)kLvCells);
     }
-    { const int rb = lili_readback_finish(ctx); if (rc) return rc; if (rb) return rb; }      // (the pending read is always finished)
+    if (rc != LILI_OK) return rc;
+    rc = lili_readback_add(ctx, &B->host, st, sizeof(LivoxState)); if (rc) return rc;
+    if (cut_early) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->join_ev[1], 0));
+    size_t sent_e = 0, sent_s = 0;      // records already in the caller's buffers when the counts arrive
+    auto send = [&](DevBuf& pack, const lili_feature_out* o, size_t first, size_t last) -> int {      // records [first, last) of a packed list
+        if (!o || !o->data || last <= first) return LILI_OK;
+        const size_t stride = o->stride ? o->stride : 32;
+        HIPCHK(hipMemcpyAsync(static_cast<char*>(o->data) + first * stride, pack.as<char>() + first * stride, (last - first) * stride,
+                              o->mem == LILI_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+        return LILI_OK;
+    };
+    if (direct) { sent_e = std::min((size_t)kLvCells, edge->capacity); sent_s = std::min((size_t)kLvCells, surf->capacity); }
+    { const int rb = lili_readback_finish(ctx); if (rc) return rc; if (rb) return rb; }      // (the pending read is always finished)  — the call's synchronisation
     B->have = true;
+    bool more = false;
     if (cutted) {
         cutted->count = (size_t)B->host.n_cut;
-        if (cut_early) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->join_ev[1], 0));
-        else { rc = livox_copy_out(ctx, B->pack, cutted, cutted->count); if (rc) return rc; }
+        if (!all3 && !cut_early && cutted->data && cutted->count) { rc = livox_copy_out(ctx, B->pack, cutted, cutted->count); if (rc) return rc; more = true; }
     }
-    if (edge) { edge->count = (size_t)B->host.n_edge; rc = livox_copy_out(ctx, B->pack_e, edge, edge->count); if (rc) return rc; }
-    if (surf) { surf->count = (size_t)B->host.n_surf; rc = livox_copy_out(ctx, B->pack_s, surf, surf->count); if (rc) return rc; }
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (edge) {
+        edge->count = (size_t)B->host.n_edge;
+        const size_t want = std::min(edge->count, edge->capacity);
+        if (want > sent_e) { rc = send(B->pack_e, edge, sent_e, want); if (rc) return rc; more = true; }
+    }
+    if (surf) {
+        surf->count = (size_t)B->host.n_surf;
+        const size_t want = std::min(surf->count, surf->capacity);
+        if (want > sent_s) { rc = send(B->pack_s, surf, sent_s, want); if (rc) return rc; more = true; }
+    }
+    if (more) HIPCHK(hipStreamSynchronize(ctx->stream));
     return LILI_OK;
 }
 

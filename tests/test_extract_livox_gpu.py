@@ -83,3 +83,45 @@ def test_livox_extractor_layouts_and_repeats(gpu_ctx, oracle):
                                                     C.byref(outs[0]), C.byref(outs[1]), C.byref(outs[2])))
         for b, o_, k in zip(bufs, outs, ("cutted", "edge", "surf")):
             assert o_.count == ref[k].shape[0] and np.array_equal(b[:o_.count], ref[k]), (stride, k)
+
+
+def test_livox_extractor_page_locked_buffers(gpu_ctx):
+    """Page-locked host memory takes its own ways through lili_extract_livox (round 4): the scan is read by k_livox_prep across PCIe instead of being copied first,
+    and the three outputs are written by ONE packing launch (k_livox_pack3) straight into the caller's buffers.  Same records, bit for bit, as the staged paths
+    pageable memory takes — in both record layouts, for every mix of page-locked and pageable arguments, and with a capacity below the count."""
+    import ctypes as C
+    scan = synth.make_livox_scan(9)
+    ex = L.LivoxExtractor(gpu_ctx)
+    for pcl_layout in (False, True):
+        ref = ex.extract(scan, pcl_layout=pcl_layout)                 # pageable in, pageable out
+        pin_in = L.api.PinnedArray(scan.shape, np.float32)
+        pin_in.array[...] = scan
+        for src in (pin_in.array, scan):
+            got = ex.extract(src, pcl_layout=pcl_layout, reuse=True)  # page-locked out (all three: one packing launch)
+            for k in ("cutted", "edge", "surf"):
+                assert np.array_equal(got[k], ref[k]), (pcl_layout, k)
+        got = ex.extract(pin_in.array, pcl_layout=pcl_layout)         # page-locked in, pageable out
+        for k in ("cutted", "edge", "surf"):
+            assert np.array_equal(got[k], ref[k]), (pcl_layout, k)
+        # one output pageable, two page-locked; and a surf capacity below the count: `count` still reports what was available
+        w = 12 if pcl_layout else 8
+        n = scan.shape[0]
+        pins = [L.api.PinnedArray((24000, w), np.float32) for _ in range(2)]
+        page = np.zeros((24000, w), np.float32)
+        small = 1000
+        cloud = L.api.Cloud(pin_in.array.ctypes.data, n, 20, 12, L.api.MEM_HOST)
+        qi = np.array([1.0, 0.0, 0.0, 0.0])
+        for bufs, caps in (((pins[0].array, page, pins[1].array), (24000, 24000, 24000)), ((pins[0].array, pins[1].array, page), (24000, 24000, 24000)),
+                           ((pins[0].array, page, pins[1].array), (24000, 24000, small))):
+            for b in bufs:
+                b[...] = -7.0
+            outs = [L.api.FeatureOut(b.ctypes.data, c, 4 * w, L.api.MEM_HOST, 0) for b, c in zip(bufs, caps)]
+            gpu_ctx._chk(gpu_ctx.lib.lili_extract_livox(gpu_ctx.h, C.byref(cloud), 16, qi.ctypes.data_as(C.c_void_p), C.byref(ex.params),
+                                                        C.byref(outs[0]), C.byref(outs[1]), C.byref(outs[2])))
+            for b, o_, c, k in zip(bufs, outs, caps, ("cutted", "edge", "surf")):
+                assert o_.count == ref[k].shape[0], k
+                m = min(o_.count, c)
+                assert np.array_equal(b[:m], ref[k][:m]), (k, c)
+        for p in pins:
+            p.close()
+        pin_in.close()
