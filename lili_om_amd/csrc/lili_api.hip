@@ -1180,6 +1180,18 @@ static int launch_linearize_reduce(lili_ctx* ctx, int slot, int kind_mask, const
     return LILI_OK;
 }
 
+// Page-locked landing area of the blocking calls' results, written by their last kernel across PCIe (a record is 576 bytes): the host reads it after the one
+// synchronisation of the call — no device-to-host copy launch in between (~4 us of GPU time and an API call per blocking evaluation).
+constexpr size_t kHRecordDoubles = (size_t)LILI_MAX_SLOTS * LILI_GRAM_DOUBLES + 2 * LILI_MAX_SLOTS;
+static int ensure_h_records(lili_ctx* ctx) {
+    if (ctx->h_records) return LILI_OK;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_records), kHRecordDoubles * sizeof(double), hipHostMallocDefault));
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, ctx->h_records, 0) != hipSuccess) { (void)hipGetLastError(); d = nullptr; }
+    ctx->h_records_dev = static_cast<double*>(d);
+    return LILI_OK;
+}
+
 int lili_s2m_associate(lili_ctx* ctx, int slot, int kind, const double t_assoc[3], const double q_assoc[4],
                        const lili_s2m_params* params, int* n_res) {
     if (!ctx) return LILI_E_ARG;
@@ -1263,13 +1275,22 @@ int lili_s2m_associate_window(lili_ctx* ctx, const int* slots, int n_slots, int 
         // through the page-locked scratch — it was one k_sum_counts + one copy per slot on the forked streams
         WindowArgs w;
         if ((rc = window_args(ctx, slots, n_slots, kind_mask, w, "associate_window")) != LILI_OK) return rc;
-        HIPCHK(ctx->win_counts.ensure(sizeof(int) * 2 * LILI_MAX_SLOTS));
-        hipLaunchKernelGGL(k_window_counts, dim3(1), dim3(kBlock), 0, ctx->stream, w, ctx->win_counts.as<int>(), P2PView{});
-        HIPCHK(hipGetLastError());
+        if ((rc = ensure_h_records(ctx)) != LILI_OK) return rc;
         int host[2 * LILI_MAX_SLOTS];
-        rc = lili_readback_add(ctx, host, ctx->win_counts.p, sizeof(int) * 2 * n_slots);
-        if (rc == LILI_OK) rc = lili_readback_finish(ctx);
-        if (rc != LILI_OK) return rc;
+        if (ctx->h_records_dev) {          // the counts land in page-locked memory straight from the kernel
+            int* d_out = reinterpret_cast<int*>(ctx->h_records_dev + (size_t)LILI_MAX_SLOTS * LILI_GRAM_DOUBLES);
+            hipLaunchKernelGGL(k_window_counts, dim3(1), dim3(kBlock), 0, ctx->stream, w, d_out, P2PView{});
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            std::memcpy(host, ctx->h_records + (size_t)LILI_MAX_SLOTS * LILI_GRAM_DOUBLES, sizeof(int) * 2 * n_slots);
+        } else {
+            HIPCHK(ctx->win_counts.ensure(sizeof(int) * 2 * LILI_MAX_SLOTS));
+            hipLaunchKernelGGL(k_window_counts, dim3(1), dim3(kBlock), 0, ctx->stream, w, ctx->win_counts.as<int>(), P2PView{});
+            HIPCHK(hipGetLastError());
+            rc = lili_readback_add(ctx, host, ctx->win_counts.p, sizeof(int) * 2 * n_slots);
+            if (rc == LILI_OK) rc = lili_readback_finish(ctx);
+            if (rc != LILI_OK) return rc;
+        }
         for (int i = 0; i < n_slots; i++) {
             n_res[2 * i] = (kind_mask & LILI_MASK_SURF) ? host[2 * i] : 0;
             n_res[2 * i + 1] = (kind_mask & LILI_MASK_EDGE) ? host[2 * i + 1] : 0;
@@ -1293,13 +1314,22 @@ int lili_s2m_linearize_window(lili_ctx* ctx, const int* slots, int n_slots, int 
     ARGCHK((kind_mask & ~3) == 0 && kind_mask != 0, "linearize_window: bad kind mask");
     ARGCHK(t && q && params && gram, "linearize_window: null argument");
     HIPCHK(hipSetDevice(ctx->device));
-    HIPCHK(ctx->win_rec.ensure(sizeof(double) * LILI_GRAM_DOUBLES * LILI_MAX_SLOTS));
-    int rc = linearize_window_impl(ctx, slots, n_slots, kind_mask, params, t, q, nullptr, nullptr, ctx->win_rec.as<double>(), 0);
+    int rc = ensure_h_records(ctx);
     if (rc != LILI_OK) return rc;
     double host[LILI_GRAM_DOUBLES * LILI_MAX_SLOTS];
-    rc = lili_readback_add(ctx, host, ctx->win_rec.p, sizeof(double) * LILI_GRAM_DOUBLES * n_slots);
-    if (rc == LILI_OK) rc = lili_readback_finish(ctx);
-    if (rc != LILI_OK) return rc;
+    if (ctx->h_records_dev) {              // k_window_reduce writes the n records into page-locked memory itself
+        rc = linearize_window_impl(ctx, slots, n_slots, kind_mask, params, t, q, nullptr, nullptr, ctx->h_records_dev, 0);
+        if (rc != LILI_OK) return rc;
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        std::memcpy(host, ctx->h_records, sizeof(double) * LILI_GRAM_DOUBLES * n_slots);
+    } else {
+        HIPCHK(ctx->win_rec.ensure(sizeof(double) * LILI_GRAM_DOUBLES * LILI_MAX_SLOTS));
+        rc = linearize_window_impl(ctx, slots, n_slots, kind_mask, params, t, q, nullptr, nullptr, ctx->win_rec.as<double>(), 0);
+        if (rc != LILI_OK) return rc;
+        rc = lili_readback_add(ctx, host, ctx->win_rec.p, sizeof(double) * LILI_GRAM_DOUBLES * n_slots);
+        if (rc == LILI_OK) rc = lili_readback_finish(ctx);
+        if (rc != LILI_OK) return rc;
+    }
     for (int i = 0; i < n_slots; i++) {
         const double* h = host + (size_t)i * LILI_GRAM_DOUBLES;
         std::memcpy(gram + (size_t)64 * i, h, 64 * sizeof(double));
@@ -1320,12 +1350,22 @@ int lili_s2m_linearize(lili_ctx* ctx, int slot, int kind_mask, const double t[3]
     for (int i = 0; i < 3; i++) pa.t[i] = t[i];
     for (int i = 0; i < 4; i++) pa.q[i] = q[i];
     MatchParams P = to_device_params(params);
-    int rc = launch_linearize_reduce(ctx, slot, kind_mask, pa, P, ctx->gram_of(slot), 0);
+    int rc = ensure_h_records(ctx);
     if (rc != LILI_OK) return rc;
     double host[LILI_GRAM_DOUBLES];
-    rc = lili_readback_add(ctx, host, ctx->gram_of(slot), sizeof(host));
-    if (rc == LILI_OK) rc = lili_readback_finish(ctx);
-    if (rc != LILI_OK) return rc;
+    if (ctx->h_records_dev) {              // k_reduce_partials writes the record into page-locked memory itself
+        double* d_out = ctx->h_records_dev + (size_t)slot * LILI_GRAM_DOUBLES;
+        rc = launch_linearize_reduce(ctx, slot, kind_mask, pa, P, d_out, 0);
+        if (rc != LILI_OK) return rc;
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        std::memcpy(host, ctx->h_records + (size_t)slot * LILI_GRAM_DOUBLES, sizeof(host));
+    } else {
+        rc = launch_linearize_reduce(ctx, slot, kind_mask, pa, P, ctx->gram_of(slot), 0);
+        if (rc != LILI_OK) return rc;
+        rc = lili_readback_add(ctx, host, ctx->gram_of(slot), sizeof(host));
+        if (rc == LILI_OK) rc = lili_readback_finish(ctx);
+        if (rc != LILI_OK) return rc;
+    }
     std::memcpy(gram, host, 64 * sizeof(double));
     if (cost) *cost = host[64];
     if (counts) { counts[0] = (int)host[65]; counts[1] = (int)host[66]; }
@@ -1934,7 +1974,7 @@ int lili_s2m_linearize_window_sharded(lili_ctx* ctx, const int* slots, int n_slo
     HIPCHK(hipSetDevice(ctx->device));
     int rc = linearize_window_impl(ctx, slots, n_slots, kind_mask, params, t, q, allreduce, comm, d_gram, 0);
     if (rc != LILI_OK) return rc;
-    if (!ctx->h_records) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_records), (size_t)LILI_MAX_SLOTS * LILI_GRAM_DOUBLES * sizeof(double), hipHostMallocDefault));
+    { const int rc_h = ensure_h_records(ctx); if (rc_h != LILI_OK) return rc_h; }
     HIPCHK(hipMemcpyAsync(ctx->h_records, d_gram, (size_t)n_slots * LILI_GRAM_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < n_slots; i++) {

@@ -140,7 +140,8 @@ struct lili_ctx {
     size_t h_pin_used = 0;
     struct PinItem { void* dst; size_t off, bytes; };
     std::vector<PinItem> h_pin_items;
-    double* h_records = nullptr;   // page-locked landing area for LILI_MAX_SLOTS Gram records (lili_s2m_linearize_window: copies that do not block the host)
+    double* h_records = nullptr;   // page-locked landing area for LILI_MAX_SLOTS Gram records (+ 2 x LILI_MAX_SLOTS counts behind them)
+    double* h_records_dev = nullptr;   // the same memory as the device sees it: the blocking calls' reduction kernels write their records THERE (round 4: no copy launch between the kernel and the host)
     DevBuf bin_hist, bin_start, bin_sums, bin_tcnt, bin_toff;   // query binning scratch
     bool bin_queries = false;   // trust the caller's order (extractor output is ring-/voxel-ordered, i.e. coherent)
     bool tiled = false;         // LDS-staged tiles: measured slower than the direct path once selection is branch-free
