@@ -141,14 +141,20 @@ def secondary_stages(L, ctx, w, torch):
     out = {}
 
     def rate(fn, reps, warm=2):
+        """Steady-state time per call: the timed loop runs twice and the faster pass counts — the first pass of a transfer-heavy stage after other work still
+        pays for the PCIe link / clocks ramping up (ROT from page-locked buffers: 0.36 ms in the first 50 calls, 0.22 ms from then on; tools/rot_host_time.py)."""
         for _ in range(warm):
             fn()
-        torch.cuda.synchronize()
-        tic = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - tic) / reps
+        best = None
+        for _ in range(2):
+            torch.cuda.synchronize()
+            tic = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            sec = (time.perf_counter() - tic) / reps
+            best = sec if best is None else min(best, sec)
+        return best
 
     def entry(sec, alg_bytes, unit, note):
         return {"value": round(1.0 / sec, 1), "unit": unit, "ms": round(sec * 1e3, 4), "algorithmic_bytes": int(alg_bytes),

@@ -126,6 +126,19 @@ int lili_readback_finish(lili_ctx* ctx, hipStream_t stream) {
 }
 
 // copies / converts a described cloud into a device float4 array (x, y, z, aux)
+// The device-side address of a caller's PAGE-LOCKED host buffer (lili_host_alloc / hipHostMalloc / hipHostRegister), or nullptr: pageable memory, or not aligned to
+// `align` bytes.  Asked on EVERY call that wants to let a kernel read or write the buffer across PCIe (0.06-0.16 us: tools/ptr_attr_cost.hip) — a cached "page-locked"
+// would outlive the buffer: the address of a freed page-locked buffer can come back from malloc as pageable memory, and a kernel would fault on it.
+void* lili_pinned_dev_ptr(const void* host, size_t align) {
+    if (!host) return nullptr;
+    hipPointerAttribute_t attr{};
+    void* d = nullptr;
+    if (hipPointerGetAttributes(&attr, host) == hipSuccess && attr.type == hipMemoryTypeHost && hipHostGetDevicePointer(&d, const_cast<void*>(host), 0) == hipSuccess &&
+        d && (reinterpret_cast<uintptr_t>(d) & (align - 1)) == 0) return d;
+    (void)hipGetLastError();      // pageable memory is unknown to the runtime: not an error of the call
+    return nullptr;
+}
+
 constexpr size_t kMiscAlloc = 2 * 64 * 128 + 256 + 2 * ((8192 + 2) * 8 + 112);      // scratch words of a map build, laid out where lili_map_set is defined
 int lili_ingest_cloud(lili_ctx* ctx, const lili_cloud* c, DevBuf& out_f4, unsigned* d_bbox) {
     ARGCHK(c && (c->n == 0 || c->data), "cloud: null data");
@@ -136,9 +149,17 @@ int lili_ingest_cloud(lili_ctx* ctx, const lili_cloud* c, DevBuf& out_f4, unsign
     HIPCHK(out_f4.ensure(c->n * sizeof(float4)));
     const unsigned char* src = reinterpret_cast<const unsigned char*>(c->data);
     if (c->mem == LILI_MEM_HOST) {
-        HIPCHK(ctx->staging.ensure(c->n * c->stride));
-        HIPCHK(hipMemcpyAsync(ctx->staging.p, c->data, c->n * c->stride, hipMemcpyHostToDevice, ctx->stream));
-        src = ctx->staging.as<unsigned char>();
+        // Round 4: a PAGE-LOCKED cloud (a driver's DMA buffer, lili_host_alloc) is read by the conversion kernel where it lies, across PCIe — no copy-engine transfer,
+        // no wait for its completion signal before the kernel may start.  Measured (tools/rot_host_time.py, tools/livox_timeline.py): a 1.15 MB Livox scan -28 us per call;
+        // a 3.2 MB ROT scan +9 us (the kernel reads PCIe at ~41 GB/s, the copy engine at ~55) — but the call then takes the same time from the first scan on, where a
+        // copy-engine upload next to a download of the same call ran 0.35-0.45 ms for its first fifty-odd calls (the bench's bimodal extract_rot).  Pageable memory:
+        // one staged transfer of the rows as they are.
+        if (void* d = lili_pinned_dev_ptr(c->data, 4)) src = static_cast<const unsigned char*>(d);
+        else {
+            HIPCHK(ctx->staging.ensure(c->n * c->stride));
+            HIPCHK(hipMemcpyAsync(ctx->staging.p, c->data, c->n * c->stride, hipMemcpyHostToDevice, ctx->stream));
+            src = ctx->staging.as<unsigned char>();
+        }
     } else ARGCHK(c->mem == LILI_MEM_DEVICE, "cloud: bad mem");
     // with a bounding box: a bounded grid (grid-stride loop) so that the box costs a few thousand atomics, not one set per 256 points
     const int nb = d_bbox ? std::min(nblocks((int64_t)c->n, kBlock), 4096) : nblocks((int64_t)c->n, kBlock);
@@ -410,11 +431,12 @@ static int map_set_impl(lili_ctx* ctx, int kind, const lili_cloud* cloud, double
     // reach * cell >= 1.01 * gate radius; with reach 2 the cell edge is cell_pct % of the gate radius (50..100)
     double cell = std::sqrt(max_sq_radius) * 1.01 * (reach == 2 ? (double)ctx->cell_pct / 100.0 : 1.0);
     if (!(cell > 1e-6)) cell = 1e-6;
-    // The box.  A build with no box from its caller GUESSES it when the previous build of this kind was of a cloud of about this size (a pipeline rebuilds the index of
-    // a slowly changing map per keyframe, L/src/BackendFusion.cpp:839-840): that build's true box, grown by a margin of cells.  The count pass reduces this cloud's true
-    // box on the side; it comes back with the density at the END of the build (the one synchronisation a build has anyway) and must lie inside the grid — every point
-    // then got its cell without clamping, exactly as with a measured box — else the index is rebuilt with the true box (and the margin doubles).  A build that guesses
-    // has no host round trip before its kernels: -30 us per build.
+    // The box.  A build with no box from its caller GUESSES it when the previous build of this kind was of a cloud of about this size and the same gate (a pipeline
+    // rebuilds the index of a slowly changing map per keyframe, L/src/BackendFusion.cpp:839-840): that build's true box, grown by 3/4 cell per side.  The count pass
+    // checks the guess point by point (k_cell_count*: outside the grid / within a quarter cell of a face / near each face at all) and ORs the verdict into the density
+    // banks; it comes back with the density at the END of the build — the one synchronisation a build has anyway.  A point outside (its cell would be a clamped one,
+    // which the search's cell-distance bounds do not allow) or a face nothing comes near (some other cloud's box: correct, but a needlessly large grid) -> the box is
+    // measured and the index built again before the call returns.  A build that guesses has no box pass and no host round trip before its kernels.
     unsigned* d_mm = ctx->misc.as<unsigned>();
     SpecBox& sb = ctx->spec_box[kind];
     // 8-bit cell counters (k_cell_count_narrow) unless a build of this kind has met a cell of more than 255 points (or the single-pass scan is off: A/B, fallback)

@@ -309,9 +309,6 @@ struct LivoxBuffers {
     DevBuf edge_a, edge_b, edge_cell, surf_a, surf_b, surf_cell, pack, pack_e, pack_s, xyzc_edge, xyzc_surf;
     lili::LivoxState host{};
     bool have = false;
-    // a caller's page-locked feature buffers (edge, surf) as the device sees them: looked up once per buffer (hipPointerGetAttributes costs far more than a launch)
-    const void* pin_host[4] = {nullptr, nullptr, nullptr, nullptr};      // edge out, surf out, scan in, cutted out
-    void* pin_dev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool armed = false;      // the ownership table holds "no owner" everywhere (k_livox_init once, k_livox_grid after every scan)
     void release() {
         for (DevBuf* b : {&und, &curv, &keep, &owner, &state, &cut_a, &cut_b, &cut_src, &cell_pt, &cell_curv, &cell_src, &blk_nedge, &blk_edge_cell,
@@ -342,19 +339,6 @@ __global__ void k_livox_pack2(int nb0, const float4* __restrict__ a0, const floa
                               const float4* __restrict__ a1, const float4* __restrict__ b1, const int* __restrict__ n1_dev, int cap1, int layout1, float* __restrict__ out1) {
     if ((int)blockIdx.x < nb0) livox_pack_one(blockIdx.x * blockDim.x + threadIdx.x, a0, b0, min(*n0_dev, cap0), layout0, out0);
     else livox_pack_one(((int)blockIdx.x - nb0) * blockDim.x + threadIdx.x, a1, b1, min(*n1_dev, cap1), layout1, out1);
-}
-
-// The device-side address of a caller's PAGE-LOCKED host buffer (lili_host_alloc / hipHostMalloc / hipHostRegister), or nullptr: pageable, or not 16-byte aligned.
-static void* livox_pinned_dev_ptr(lili_detail::LivoxBuffers* B, int which, void* host) {
-    if (B->pin_host[which] != host) {
-        B->pin_host[which] = host; B->pin_dev[which] = nullptr;
-        hipPointerAttribute_t attr{};
-        void* d = nullptr;
-        if (hipPointerGetAttributes(&attr, host) == hipSuccess && attr.type == hipMemoryTypeHost && hipHostGetDevicePointer(&d, host, 0) == hipSuccess &&
-            (reinterpret_cast<uintptr_t>(d) & 15) == 0) B->pin_dev[which] = d;
-        else (void)hipGetLastError();      // pageable memory is unknown to the runtime: not an error of this call
-    }
-    return B->pin_dev[which];
 }
 
 // all three lists in ONE launch (workgroups [0, nbc): lidar_cloud_cutted, [nbc, nbc + nb0): the edge list, then the surf list) — round 4: straight into the caller's
@@ -411,7 +395,7 @@ int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offs
         // A PAGE-LOCKED scan (a driver's DMA buffer, lili_host_alloc) is read by k_livox_prep where it lies, across PCIe (round 4: the copy engine's transfer + the
         // ~11 us before a kernel sees its completion were 28 us of the call; the kernel reads the same 1.15 MB in its own time).  Pageable memory: ONE transfer of the
         // rows as they are; k_livox_prep picks the fields.
-        void* d = livox_pinned_dev_ptr(B, 2, const_cast<void*>(scan->data));
+        void* d = lili_pinned_dev_ptr(scan->data, 4);
         if (d) raw = static_cast<const unsigned char*>(d);
         else {
             HIPCHK(ctx->staging.ensure(scan->n * scan->stride));
@@ -453,7 +437,7 @@ int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offs
     const auto out_ok = [](const lili_feature_out* o) { return o && o->data && o->capacity > 0 && o->mem == LILI_MEM_HOST && (o->stride == 0 || o->stride == 32 || o->stride == 48); };
     void *dc = nullptr, *de3 = nullptr, *ds3 = nullptr;
     bool all3 = n > 0 && out_ok(cutted) && out_ok(edge) && out_ok(surf);
-    if (all3) { dc = livox_pinned_dev_ptr(B, 3, cutted->data); de3 = livox_pinned_dev_ptr(B, 0, edge->data); ds3 = livox_pinned_dev_ptr(B, 1, surf->data); all3 = dc && de3 && ds3; }
+    if (all3) { dc = lili_pinned_dev_ptr(cutted->data, 16); de3 = lili_pinned_dev_ptr(edge->data, 16); ds3 = lili_pinned_dev_ptr(surf->data, 16); all3 = dc && de3 && ds3; }
     bool cut_early = false;
     if (!all3 && n > 0 && cutted && cutted->data && cutted->mem == LILI_MEM_HOST && cutted->capacity > 0) {
         rc = livox_pack(ctx, B->pack, cutted, B->cut_a.as<float4>(), B->cut_b.as<float4>(), &st->n_cut, (size_t)n);
@@ -502,7 +486,7 @@ int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offs
         // trip before the transfers, one synchronisation per call (the count round trip + a second one were ~35 us of 120).
         float* out_e = B->pack_e.as<float>(); float* out_s = B->pack_s.as<float>();
         if (edge->mem == LILI_MEM_HOST && surf->mem == LILI_MEM_HOST) {
-            void* de = livox_pinned_dev_ptr(B, 0, edge->data); void* ds = livox_pinned_dev_ptr(B, 1, surf->data);
+            void* de = lili_pinned_dev_ptr(edge->data, 16); void* ds = lili_pinned_dev_ptr(surf->data, 16);
             if (de && ds) { out_e = static_cast<float*>(de); out_s = static_cast<float*>(ds); direct = true; }
         }
         hipLaunchKernelGGL(k_livox_pack2, dim3(nb0 + nb1), dim3(256), 0, ctx->stream, nb0, B->edge_a.as<float4>(), B->edge_b.as<float4>(), &st->n_edge, (int)k0, s0 == 48 ? 1 : 0,

@@ -147,3 +147,51 @@ def test_rot_extractor_ragged_scans(gpu_ctx, oracle, seed):
         o = oracle.extract_rot(raw, P=oracle.rot_params(ds_rate=ds_rate, ds_v=ds_v, atan_mode=2, stable_sort=1))
         assert o["full"].shape[0] > 100
         _compare(g, o)
+
+
+def test_rot_extractor_page_locked_buffers(gpu_ctx):
+    """Page-locked host memory takes its own ways through lili_extract_rot (round 4): the scan is read by the conversion kernel across PCIe instead of being copied
+    first, the deskewed cloud leaves through a thin copy kernel on a side stream, the feature lists are written by k_rot_send behind the concatenation and the call
+    synchronises once.  Same clouds, bit for bit, as the staged copies pageable memory takes — for every mix of page-locked and pageable arguments, with 32-byte
+    PointXYZI rows (only the first 16 bytes of a row are written) and with a capacity below the count."""
+    import ctypes as C
+    w = synth.make_workload(n_map=50_000, n_az=1100, half_extent=(60.0, 60.0))
+    raw = np.ascontiguousarray(np.concatenate([w["scan_xyz"], np.full((w["scan_xyz"].shape[0], 1), 10.0, np.float32)], 1))
+    ex = L.RotExtractor(gpu_ctx, n_scans=64, ds_rate=4)
+    ref = ex.extract(raw)                                                  # pageable in, pageable out
+    assert len(ref["edge"]) > 50 and len(ref["surf"]) > 500
+    pin_in = L.api.PinnedArray(raw.shape, np.float32)
+    pin_in.array[...] = raw
+    for src in (pin_in.array, raw):
+        got = ex.extract(src, reuse=True)                                   # page-locked out
+        for k in ("full", "edge", "surf"):
+            assert np.array_equal(got[k], ref[k]), k
+    got = ex.extract(pin_in.array)                                          # page-locked in, pageable out
+    for k in ("full", "edge", "surf"):
+        assert np.array_equal(got[k], ref[k]), k
+    n = raw.shape[0]
+    qi = np.array([1.0, 0.0, 0.0, 0.0]); ql = np.array([1.0, 0.0, 0.0, 0.0])
+    cloud = L.api.Cloud(pin_in.array.ctypes.data, n, 16, 12, L.api.MEM_HOST)
+    pins = [L.api.PinnedArray((n, 8), np.float32) for _ in range(3)]       # 32-byte rows
+    page = np.zeros((n, 8), np.float32)
+    small = 100
+    for bufs, caps, strides in (((pins[0].array, pins[1].array, pins[2].array), (n, n, n), (16, 32, 32)),
+                                ((pins[0].array, page, pins[2].array), (n, n, n), (16, 32, 32)),
+                                ((pins[0].array, pins[1].array, pins[2].array), (n, n, small), (16, 16, 32))):
+        for b in bufs:
+            b[...] = -7.0
+        outs = [L.api.FeatureOut(b.ctypes.data, c, s, L.api.MEM_HOST, 0) for b, c, s in zip(bufs, caps, strides)]
+        gpu_ctx._chk(gpu_ctx.lib.lili_extract_rot(gpu_ctx.h, C.byref(cloud), qi.ctypes.data_as(C.c_void_p), ql.ctypes.data_as(C.c_void_p), C.byref(ex.params),
+                                                  C.byref(outs[0]), C.byref(outs[1]), C.byref(outs[2])))
+        for b, o_, c, s, k in zip(bufs, outs, caps, strides, ("full", "edge", "surf")):
+            assert o_.count == ref[k].shape[0], k
+            m = min(o_.count, c)
+            rows = b.reshape(-1)[: m * (s // 4)].reshape(m, s // 4) if s == 16 else b[:m]
+            assert np.array_equal(rows[:, :4], ref[k][:m]), (k, c, s)
+            if s == 32:
+                assert np.all(rows[:, 4:] == -7.0), k                        # bytes 16..31 of a row are the caller's
+            if m < b.shape[0] and s == 32:
+                assert np.all(b[m:] == -7.0), k                              # nothing behind the records that were asked for
+    for p in pins:
+        p.close()
+    pin_in.close()
