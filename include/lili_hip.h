@@ -193,8 +193,11 @@ typedef struct lili_rot_params {
  *   edge  : cornerPointsLessSharp, in push order            (/edge_features)
  *   surf  : voxel-filtered less-flat points, ring by ring   (/surf_features)
  * Points are written as (x, y, z, intensity = ring + 0.1 * relTime).  Blocking.  A LILI_MEM_DEVICE scan of 16-byte rows (x, y, z, intensity)
- * is read in place; a `full` buffer in host memory receives min(scan->n, capacity) records while the features are selected — the records
- * behind full->count are unspecified. */
+ * is read in place; a scan in PAGE-LOCKED host memory (lili_host_alloc) is read by the first kernel where it lies instead of being uploaded first; a
+ * `full` buffer in page-locked host memory receives min(scan->n, capacity) records while the features are selected — the records behind full->count
+ * are unspecified —, `edge` / `surf` buffers in page-locked memory (16-byte aligned, stride a multiple of 16) are written by a kernel behind the
+ * selection, `count` records each (only the first 16 bytes of a row), and the call synchronises once; pageable buffers are served by copies after the
+ * counts have arrived. */
 int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4], const double q_lb[4], const lili_rot_params* params,
                      lili_feature_out* full, lili_feature_out* edge, lili_feature_out* surf);
 /* Intermediate products of the last lili_extract_rot for parity tests (any pointer may be NULL):
