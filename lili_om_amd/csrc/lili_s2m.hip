@@ -552,12 +552,20 @@ __global__ __launch_bounds__(1024) void k_scatter9(const int* __restrict__ cell_
     if (len == 0) return;                                  // nothing lives here
     int off[9], pre[10];
     pre[0] = 0;
+    // all 27 range words of the nine source rows are requested BEFORE the first is used (round 4: 70.9 -> 64.4 us per focused copy)
+    int ra[9], rbn[9], rend[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) {
         const int y = ys + k % 3 - 1, z = zs + k / 3 - 1;
         const bool in = y >= 0 && y < g.ny && z >= 0 && z < g.nz;
         const int* cs = cell_start + ((size_t)(in ? z : 0) * g.ny + (in ? y : 0)) * g.nx + x0;
-        const int a = cs[lc], b = cs[lc + 1], e = cs[xn];
+        ra[k] = cs[lc]; rbn[k] = cs[lc + 1]; rend[k] = cs[xn];
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const int y = ys + k % 3 - 1, z = zs + k / 3 - 1;
+        const bool in = y >= 0 && y < g.ny && z >= 0 && z < g.nz;
+        const int a = ra[k], b = rbn[k], e = rend[k];
         delta[w][k][lane] = dnext - a;
         dnext += in ? b - a : 0;
         const int rb = in ? __shfl(a, 0) : 0, re = in ? e : 0;
@@ -565,7 +573,7 @@ __global__ __launch_bounds__(1024) void k_scatter9(const int* __restrict__ cell_
         pre[k + 1] = pre[k] + (re - rb);
     }
     __builtin_amdgcn_wave_barrier();
-    for (int t0 = 0; t0 < len; t0 += 64) {                 // pre[9] == len
+    for (int t0 = 0; t0 < len; t0 += 64) {                 // pre[9] == len   (four trips in flight were measured: no change, 64.4 vs 63.4 us)
         const int t = t0 + lane;
         const bool live = t < len;
         int k = 0, o = off[0];
