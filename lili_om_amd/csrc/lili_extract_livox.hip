@@ -308,11 +308,14 @@ struct LivoxBuffers {
     DevBuf blk_nedge, blk_edge_cell, blk_edge_dir, blk_nsurf, blk_surf_cell, blk_surf_nrm;
     DevBuf edge_a, edge_b, edge_cell, surf_a, surf_b, surf_cell, pack, pack_e, pack_s, xyzc_edge, xyzc_surf;
     lili::LivoxState host{};
+    int* h_counts = nullptr;          // page-locked {n_cut, n_edge, n_surf}, written by k_livox_pack3; h_counts_dev: the same memory as the device sees it
+    int* h_counts_dev = nullptr;
     bool have = false;
     bool armed = false;      // the ownership table holds "no owner" everywhere (k_livox_init once, k_livox_grid after every scan)
     void release() {
         for (DevBuf* b : {&und, &curv, &keep, &owner, &state, &cut_a, &cut_b, &cut_src, &cell_pt, &cell_curv, &cell_src, &blk_nedge, &blk_edge_cell,
                           &blk_edge_dir, &blk_nsurf, &blk_surf_cell, &blk_surf_nrm, &edge_a, &edge_b, &edge_cell, &surf_a, &surf_b, &surf_cell, &pack, &pack_e, &pack_s, &blk_keep, &xyzc_edge, &xyzc_surf}) b->release();
+        if (h_counts) { (void)hipHostFree(h_counts); h_counts = nullptr; h_counts_dev = nullptr; }
     }
 };
 }  // namespace lili_detail
@@ -345,8 +348,10 @@ __global__ void k_livox_pack2(int nb0, const float4* __restrict__ a0, const floa
 // page-locked buffers
 __global__ void k_livox_pack3(int nbc, const float4* __restrict__ ac, const float4* __restrict__ bc, const int* __restrict__ nc_dev, int capc, int layoutc, float* __restrict__ outc,
                               int nb0, const float4* __restrict__ a0, const float4* __restrict__ b0, const int* __restrict__ n0_dev, int cap0, int layout0, float* __restrict__ out0,
-                              const float4* __restrict__ a1, const float4* __restrict__ b1, const int* __restrict__ n1_dev, int cap1, int layout1, float* __restrict__ out1) {
+                              const float4* __restrict__ a1, const float4* __restrict__ b1, const int* __restrict__ n1_dev, int cap1, int layout1, float* __restrict__ out1,
+                              int* __restrict__ counts_host /*page-locked: {n_cut, n_edge, n_surf} for the host, no copy launch before the synchronisation*/) {
     const int b = (int)blockIdx.x;
+    if (b == 0 && threadIdx.x == 0 && counts_host) { counts_host[0] = *nc_dev; counts_host[1] = *n0_dev; counts_host[2] = *n1_dev; }
     if (b < nbc) livox_pack_one(b * blockDim.x + threadIdx.x, ac, bc, min(*nc_dev, capc), layoutc, outc);
     else if (b < nbc + nb0) livox_pack_one((b - nbc) * blockDim.x + threadIdx.x, a0, b0, min(*n0_dev, cap0), layout0, out0);
     else livox_pack_one((b - nbc - nb0) * blockDim.x + threadIdx.x, a1, b1, min(*n1_dev, cap1), layout1, out1);
@@ -435,6 +440,12 @@ int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offs
     // All three outputs in page-locked host memory (what a node that publishes them would use): ONE packing launch writes them across PCIe after the compaction — no
     // staging copies, no side stream, no count round trip (k_livox_pack3).
     const auto out_ok = [](const lili_feature_out* o) { return o && o->data && o->capacity > 0 && o->mem == LILI_MEM_HOST && (o->stride == 0 || o->stride == 32 || o->stride == 48); };
+    if (!B->h_counts) {
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&B->h_counts), 4 * sizeof(int), hipHostMallocDefault));
+        void* d = nullptr;
+        if (hipHostGetDevicePointer(&d, B->h_counts, 0) != hipSuccess) { (void)hipGetLastError(); d = nullptr; }
+        B->h_counts_dev = static_cast<int*>(d);
+    }
     void *dc = nullptr, *de3 = nullptr, *ds3 = nullptr;
     bool all3 = n > 0 && out_ok(cutted) && out_ok(edge) && out_ok(surf);
     if (all3) { dc = lili_pinned_dev_ptr(cutted->data, 16); de3 = lili_pinned_dev_ptr(edge->data, 16); ds3 = lili_pinned_dev_ptr(surf->data, 16); all3 = dc && de3 && ds3; }
@@ -469,7 +480,7 @@ int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offs
         hipLaunchKernelGGL(k_livox_pack3, dim3(nbc + nb0 + nb1), dim3(256), 0, ctx->stream,
                            nbc, B->cut_a.as<float4>(), B->cut_b.as<float4>(), &st->n_cut, (int)kc, cutted->stride == 48 ? 1 : 0, static_cast<float*>(dc),
                            nb0, B->edge_a.as<float4>(), B->edge_b.as<float4>(), &st->n_edge, (int)k0, edge->stride == 48 ? 1 : 0, static_cast<float*>(de3),
-                           B->surf_a.as<float4>(), B->surf_b.as<float4>(), &st->n_surf, (int)k1, surf->stride == 48 ? 1 : 0, static_cast<float*>(ds3));
+                           B->surf_a.as<float4>(), B->surf_b.as<float4>(), &st->n_surf, (int)k1, surf->stride == 48 ? 1 : 0, static_cast<float*>(ds3), B->h_counts_dev);
         if (hipGetLastError() != hipSuccess) rc = ctx->fail(LILI_E_HIP, "extract_livox: pack launch failed");
         direct = true;
     }
@@ -497,7 +508,8 @@ int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offs
         if (rc == LILI_OK) rc = livox_pack(ctx, B->pack_s, surf, B->surf_a.as<float4>(), B->surf_b.as<float4>(), &st->n_surf, (size_t)kLvCells);
     }
     if (rc != LILI_OK) return rc;
-    rc = lili_readback_add(ctx, &B->host, st, sizeof(LivoxState)); if (rc) return rc;
+    const bool counts_direct = all3 && B->h_counts_dev != nullptr;      // the counts arrive with the packing kernel
+    if (!counts_direct) { rc = lili_readback_add(ctx, &B->host, st, sizeof(LivoxState)); if (rc) return rc; }
     if (cut_early) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->join_ev[1], 0));
     size_t sent_e = 0, sent_s = 0;      // records already in the caller's buffers when the counts arrive
     auto send = [&](DevBuf& pack, const lili_feature_out* o, size_t first, size_t last) -> int {      // records [first, last) of a packed list
@@ -508,7 +520,8 @@ int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offs
         return LILI_OK;
     };
     if (direct) { sent_e = std::min((size_t)kLvCells, edge->capacity); sent_s = std::min((size_t)kLvCells, surf->capacity); }
-    { const int rb = lili_readback_finish(ctx); if (rc) return rc; if (rb) return rb; }      // (the pending read is always finished)  — the call's synchronisation
+    if (counts_direct) { HIPCHK(hipStreamSynchronize(ctx->stream)); B->host.n_cut = B->h_counts[0]; B->host.n_edge = B->h_counts[1]; B->host.n_surf = B->h_counts[2]; }
+    else { const int rb = lili_readback_finish(ctx); if (rc) return rc; if (rb) return rb; }      // (the pending read is always finished)  — the call's synchronisation
     B->have = true;
     bool more = false;
     if (cutted) {

@@ -1308,7 +1308,8 @@ __global__ __launch_bounds__(256) void k_rot_compact(RotState* st, const float4*
                                                      const int* __restrict__ ring_edge, const int* __restrict__ ring_sharp, const int* __restrict__ ring_flat,
                                                      const int* __restrict__ lessflat_tmp, const float4* __restrict__ surf_tmp, const int* __restrict__ surf_cnt_tmp,
                                                      int* __restrict__ edge_idx, float4* __restrict__ edge_pts, int* __restrict__ sharp_idx, int* __restrict__ flat_idx,
-                                                     int* __restrict__ lessflat_idx, float4* __restrict__ surf, int* __restrict__ surf_cnt) {
+                                                     int* __restrict__ lessflat_idx, float4* __restrict__ surf, int* __restrict__ surf_cnt,
+                                                     RotState* __restrict__ mirror /*optional: page-locked host copy of *st, written by the first workgroup (round 4: no copy launch before the call's synchronisation)*/) {
     __shared__ int off[5], tot[5];
     const int r = blockIdx.x;
     if (threadIdx.x < 5) {
@@ -1319,6 +1320,12 @@ __global__ __launch_bounds__(256) void k_rot_compact(RotState* st, const float4*
     }
     __syncthreads();
     if (r == 0 && threadIdx.x == 0) { st->n_edge = tot[0]; st->n_sharp = tot[1]; st->n_flat = tot[2]; st->n_lessflat = tot[3]; st->n_surf = tot[4]; }
+    if (r == 0 && mirror) {          // every other field of *st was final before this launch; the five totals are thread 0's, ordered by the barrier
+        __syncthreads();
+        const int* src = reinterpret_cast<const int*>(st);
+        int* dst = reinterpret_cast<int*>(mirror);
+        for (int k = threadIdx.x; k < (int)(sizeof(RotState) / sizeof(int)); k += blockDim.x) dst[k] = src[k];
+    }
     const int rb = st->ring_base[r];
     for (int k = threadIdx.x; k < st->ring_nedge[r]; k += blockDim.x) { int g = ring_edge[r * kRingEdgeCap + k]; edge_idx[off[0] + k] = g; edge_pts[off[0] + k] = full[g]; }
     for (int k = threadIdx.x; k < st->ring_nsharp[r]; k += blockDim.x) sharp_idx[off[1] + k] = ring_sharp[r * kRingSharpCap + k];
@@ -1351,12 +1358,15 @@ struct RotBuffers {
     DevBuf edge_idx, edge_pts, sharp_idx, flat_idx, lessflat_idx, surf, surf_cnt;
     DevBuf big_mark, big_vidx, big_ord_a, big_ord_b, big_rcnt;   // working set of rings beyond the LDS budget (k_rot_select_big)
     lili::RotState host{};
+    lili::RotState* h_state = nullptr;       // page-locked mirror of the device state, written by k_rot_compact; h_state_dev: the same memory as the device sees it
+    lili::RotState* h_state_dev = nullptr;
     int n_in = 0;
     bool have = false;
     void release() {
         for (DevBuf* b : {&in, &scan_id, &ori_raw, &block_hist, &block_half, &state, &full, &full_src, &curv, &label, &sort_ind, &vkey, &seg_out, &ring_ncand, &sorted_k, &sorted_vox,
                           &sorted_len, &big_mark, &big_vidx, &big_ord_a, &big_ord_b, &big_rcnt, &ring_edge, &ring_sharp, &ring_flat,
                           &lessflat_tmp, &surf_tmp, &surf_cnt_tmp, &edge_idx, &edge_pts, &sharp_idx, &flat_idx, &lessflat_idx, &surf, &surf_cnt}) b->release();
+        if (h_state) { (void)hipHostFree(h_state); h_state = nullptr; h_state_dev = nullptr; }
     }
 };
 }  // namespace lili_detail
@@ -1404,6 +1414,12 @@ int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4
     R->n_in = n;
     HIPCHK(R->state.ensure(sizeof(RotState)));
     RotState* st = R->state.as<RotState>();
+    if (!R->h_state) {
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&R->h_state), sizeof(RotState), hipHostMallocDefault));
+        void* d = nullptr;
+        if (hipHostGetDevicePointer(&d, R->h_state, 0) != hipSuccess) { (void)hipGetLastError(); d = nullptr; }
+        R->h_state_dev = static_cast<RotState*>(d);
+    }
     if (n == 0) HIPCHK(hipMemsetAsync(st, 0, sizeof(RotState), ctx->stream));      // (the kernels below write every field they later read; an empty scan launches none)
     RotRingScratch X{};
     if (n > 0) {
@@ -1455,7 +1471,7 @@ int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4
                            R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>(), X);
         hipLaunchKernelGGL(k_rot_compact, dim3(kMaxRings), dim3(256), 0, ctx->stream, st, R->full.as<float4>(), R->ring_edge.as<int>(), R->ring_sharp.as<int>(),
                            R->ring_flat.as<int>(), R->lessflat_tmp.as<int>(), R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>(), R->edge_idx.as<int>(),
-                           R->edge_pts.as<float4>(), R->sharp_idx.as<int>(), R->flat_idx.as<int>(), R->lessflat_idx.as<int>(), R->surf.as<float4>(), R->surf_cnt.as<int>());
+                           R->edge_pts.as<float4>(), R->sharp_idx.as<int>(), R->flat_idx.as<int>(), R->lessflat_idx.as<int>(), R->surf.as<float4>(), R->surf_cnt.as<int>(), R->h_state_dev);
         HIPCHK(hipGetLastError());
         // page-locked feature buffers are written right behind the concatenation, `count` records each, before the host has seen the counts: the state's read-back below
         // is then the call's only synchronisation (it was: read-back, two sized copies, second synchronisation).  The second passes further down redo the copies.
@@ -1474,7 +1490,10 @@ int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4
         }
         if (full_early) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->join_ev[1], 0));      // the read-back's synchronisation then also covers the side stream's copy
     }
-    { int rb = lili_readback_add(ctx, &R->host, st, sizeof(RotState)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }
+    if (n > 0 && R->h_state_dev) {          // the state came with the concatenation kernel: wait, read it where it landed
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        std::memcpy(&R->host, R->h_state, sizeof(RotState));
+    } else { int rb = lili_readback_add(ctx, &R->host, st, sizeof(RotState)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }
     if (n == 0) { R->host.first_valid = R->host.half_idx = 0x7fffffff; R->host.last_valid = -1; }
     if (n > 0 && (R->host.vox_overflow || R->host.fallback_rings > 0)) sent_edge = sent_surf = false;      // the lists are about to change: copied again below
     if (n > 0 && R->host.vox_overflow) {   // voxel coordinates beyond the packed keys: order by the radix pass, then the ring stage and the concatenation again
@@ -1487,7 +1506,7 @@ int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4
                            R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>(), X);
         hipLaunchKernelGGL(k_rot_compact, dim3(kMaxRings), dim3(256), 0, ctx->stream, st, R->full.as<float4>(), R->ring_edge.as<int>(), R->ring_sharp.as<int>(),
                            R->ring_flat.as<int>(), R->lessflat_tmp.as<int>(), R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>(), R->edge_idx.as<int>(),
-                           R->edge_pts.as<float4>(), R->sharp_idx.as<int>(), R->flat_idx.as<int>(), R->lessflat_idx.as<int>(), R->surf.as<float4>(), R->surf_cnt.as<int>());
+                           R->edge_pts.as<float4>(), R->sharp_idx.as<int>(), R->flat_idx.as<int>(), R->lessflat_idx.as<int>(), R->surf.as<float4>(), R->surf_cnt.as<int>(), nullptr);
         HIPCHK(hipGetLastError());
         { int rb = lili_readback_add(ctx, &R->host, st, sizeof(RotState)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }
     }
@@ -1513,7 +1532,7 @@ int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4
                            R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>(), B);
         hipLaunchKernelGGL(k_rot_compact, dim3(kMaxRings), dim3(256), 0, ctx->stream, st, R->full.as<float4>(), R->ring_edge.as<int>(), R->ring_sharp.as<int>(),
                            R->ring_flat.as<int>(), R->lessflat_tmp.as<int>(), R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>(), R->edge_idx.as<int>(),
-                           R->edge_pts.as<float4>(), R->sharp_idx.as<int>(), R->flat_idx.as<int>(), R->lessflat_idx.as<int>(), R->surf.as<float4>(), R->surf_cnt.as<int>());
+                           R->edge_pts.as<float4>(), R->sharp_idx.as<int>(), R->flat_idx.as<int>(), R->lessflat_idx.as<int>(), R->surf.as<float4>(), R->surf_cnt.as<int>(), nullptr);
         HIPCHK(hipGetLastError());
         { int rb = lili_readback_add(ctx, &R->host, st, sizeof(RotState)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }
     }
