@@ -1204,7 +1204,7 @@ static int launch_linearize_reduce(lili_ctx* ctx, int slot, int kind_mask, const
 
 // Page-locked landing area of the blocking calls' results, written by their last kernel across PCIe (a record is 576 bytes): the host reads it after the one
 // synchronisation of the call — no device-to-host copy launch in between (~4 us of GPU time and an API call per blocking evaluation).
-constexpr size_t kHRecordDoubles = (size_t)LILI_MAX_SLOTS * LILI_GRAM_DOUBLES + 2 * LILI_MAX_SLOTS;
+constexpr size_t kHRecordDoubles = (size_t)LILI_MAX_SLOTS * LILI_GRAM_DOUBLES + 2 * LILI_MAX_SLOTS;      // records | 2 x MAX_SLOTS window counts | 2 x MAX_SLOTS per-slot counts (ints)
 static int ensure_h_records(lili_ctx* ctx) {
     if (ctx->h_records) return LILI_OK;
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_records), kHRecordDoubles * sizeof(double), hipHostMallocDefault));
@@ -1231,11 +1231,20 @@ int lili_s2m_associate(lili_ctx* ctx, int slot, int kind, const double t_assoc[3
     if (rc == 1) rc = launch_associate(ctx, slot, kind, pa, P);
     if (rc != LILI_OK) return rc;
     if (n_res) {
-        rc = launch_sum_counts(ctx, slot, 1 << kind);
-        if (rc != LILI_OK) return rc;
-        rc = lili_readback_add(ctx, n_res, &ctx->state(slot)->n_res[kind], sizeof(int));
-        if (rc == LILI_OK) rc = lili_readback_finish(ctx);
-        if (rc != LILI_OK) return rc;
+        if ((rc = ensure_h_records(ctx)) != LILI_OK) return rc;
+        if (ctx->h_records_dev) {              // k_sum_counts writes the two counts into page-locked memory itself: no copy launch before the synchronisation
+            const size_t off = (size_t)LILI_MAX_SLOTS * LILI_GRAM_DOUBLES * sizeof(double) + (size_t)(2 * LILI_MAX_SLOTS + 2 * slot) * sizeof(int);
+            rc = launch_sum_counts(ctx, slot, 1 << kind, reinterpret_cast<int*>(reinterpret_cast<char*>(ctx->h_records_dev) + off));
+            if (rc != LILI_OK) return rc;
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            *n_res = reinterpret_cast<const int*>(reinterpret_cast<const char*>(ctx->h_records) + off)[kind];
+        } else {
+            rc = launch_sum_counts(ctx, slot, 1 << kind);
+            if (rc != LILI_OK) return rc;
+            rc = lili_readback_add(ctx, n_res, &ctx->state(slot)->n_res[kind], sizeof(int));
+            if (rc == LILI_OK) rc = lili_readback_finish(ctx);
+            if (rc != LILI_OK) return rc;
+        }
     }
     return LILI_OK;
 }
