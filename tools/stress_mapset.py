@@ -32,4 +32,5 @@ for it in range(300):
         assert np.array_equal(t, ref[0]) and np.array_equal(q, ref[1]), (it, t, ref[0])
     if it == 20: free0 = torch.cuda.mem_get_info()[0]
 free1 = torch.cuda.mem_get_info()[0]
-print("ok: 300 map rebuilds, full-map results bit-stable, free memory change since rebuild 20:", (free1 - free0) / 1e6, "MB")
+print("ok: 300 map rebuilds, full-map results bit-stable, free memory change since rebuild 20:", (free1 - free0) / 1e6, "MB;",
+      "index builds from a guessed box / repeated with the measured box / repeated with the three-kernel scan:", m.map_build_stats())
