@@ -1,4 +1,4 @@
-"""Timing driver of the two extractors and the voxel filter (run under rocprofv3 by tools/r02_rot.sh)."""
+"""Timing driver of the two extractors and the voxel filter (run it under rocprofv3 --kernel-trace --stats)."""
 import sys, time, numpy as np
 sys.path.insert(0, '.')
 import torch
