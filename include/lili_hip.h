@@ -257,6 +257,49 @@ int lili_localmap_stats(lili_ctx* ctx, int32_t* incremental_commits, int32_t* fu
  * out->capacity rows are copied).  Blocking. */
 int lili_localmap_get(lili_ctx* ctx, lili_feature_out* out);
 
+/* ---- front-end frame: the whole per-scan chain of the odometry node in ONE call ------------------ */
+
+/* Replaces the body of LidarOdometry::run for one Livox scan (L/src/LidarOdometry.cpp:652-707) together with the extraction node in front of
+ * it (L/src/Preprocessing.cpp:219-401): extraction -> down_size_filter_surf (L:155, 320-322) -> scan-to-map iterations against the local map
+ * of the last `width` frames (buildLocalMap L:280-303, downSampleCloud L:314-318, kd_tree_surf_last->setInputCloud L:490,
+ * findCorrespondingSurfFeatures + LidarPlaneNormIncreFactor + HuberLoss L:352-413, 483-561) -> the frame joins the ring at the pose found
+ * (transformCloud, L:292-297) and the NEXT frame's local map (concatenate + VoxelGrid + index) is built before the call returns.
+ * Everything between the scan and the returned pose stays in HBM: features, down-sampled queries, ring, map and pose never visit the host;
+ * the host synchronises only for the counts that size the next launches and for the result.
+ *   scan / curvature_offset / q_imu / livox : as lili_extract_livox
+ *   match   : matcher parameters (LILI_VARIANT_FRONTEND for the reference's front end)
+ *   t_pred, q_pred : poseInitialization's guess (L:415-441: constant-velocity extrapolation, caller side); a frame that is not matched
+ *                    (n_iters = 0, or a map of fewer than 10 points, L:485-488) keeps it.
+ * `res` receives the pose, the solver status of the last update and the sizes; res->stage_us (opt->want_timing) the host-side time stamps
+ * of the stages in microseconds since the call began (extraction counts known, queries known, iterations enqueued, result + next map known,
+ * map index built).  lili_frontend_reset empties the ring (a new sequence). */
+typedef struct lili_frontend_options {
+    float leaf_query;   /* down_size_filter_surf: 0.4 (L/src/LidarOdometry.cpp:155) */
+    float leaf_map;     /* down_size_filter_surf_map: 0.4 (L:156) */
+    int width;          /* frames in the local map: 20 (L:290) */
+    int n_iters;        /* outer iterations (association + Gauss-Newton update) per frame */
+    int slot;           /* matcher slot used for the frame's queries and pose */
+    int want_timing;
+    int flags;          /* LILI_FRAME_* */
+} lili_frontend_options;
+/* The reference node's start-up (L/src/LidarOdometry.cpp:659-663, 283-289, 501-504), expressed per call so that the caller's frame counter decides:
+ *   frame 0 (system not initialised: savePoses + checkInitialization only): n_iters = 0 and LILI_FRAME_PUSH_EMPTY — the pose is the given one and the ring
+ *            receives an EMPTY keyframe (surf_frames[0] is the not-yet-filled surf_last_ds);
+ *   frame 1 (pose_cloud_frame holds one pose): LILI_FRAME_SELF_MAP — the local map is the frame's own surf features (L:286-289), n_iters = 8 (L:501-502);
+ *   later frames: flags = 0, n_iters = scan_match_cnt. */
+enum { LILI_FRAME_SELF_MAP = 1, LILI_FRAME_PUSH_EMPTY = 2 };
+typedef struct lili_frontend_result {
+    double t[3], q[4];
+    int gn_status;      /* of the last update; 0 when the frame was not matched */
+    int matched;        /* 0: first frame of a sequence, or a map of fewer than 10 points (L:485-488): pose = prediction */
+    int32_t n_edge, n_surf, n_query, n_map_raw, n_map;   /* features, down-sampled queries, ring points and map points of the NEXT frame's map */
+    double stage_us[8];
+} lili_frontend_result;
+int lili_frontend_frame(lili_ctx* ctx, const lili_cloud* scan, int curvature_offset, const double q_imu[4], const lili_livox_params* livox,
+                        const lili_s2m_params* match, const lili_frontend_options* opt, const double t_pred[3], const double q_pred[4],
+                        lili_frontend_result* res);
+int lili_frontend_reset(lili_ctx* ctx);
+
 /* ---- scan-to-map matcher -------------------------------------------------------------------- */
 
 /* Uploads the feature points of keyframe `slot` (surf_lasts_ds[idx] / edge_lasts_ds[idx],

@@ -40,6 +40,18 @@ class LivoxParams(C.Structure):
     _fields_ = [("surf_thres", C.c_double), ("edge_thres", C.c_double), ("near_range", C.c_float)]
 
 
+class FrontendOptions(C.Structure):
+    _fields_ = [("leaf_query", C.c_float), ("leaf_map", C.c_float), ("width", C.c_int), ("n_iters", C.c_int), ("slot", C.c_int), ("want_timing", C.c_int), ("flags", C.c_int)]
+
+
+FRAME_SELF_MAP, FRAME_PUSH_EMPTY = 1, 2
+
+
+class FrontendResult(C.Structure):
+    _fields_ = [("t", C.c_double * 3), ("q", C.c_double * 4), ("gn_status", C.c_int), ("matched", C.c_int), ("n_edge", C.c_int32), ("n_surf", C.c_int32),
+                ("n_query", C.c_int32), ("n_map_raw", C.c_int32), ("n_map", C.c_int32), ("stage_us", C.c_double * 8)]
+
+
 LM_MAX_LOG = 32
 LM_TERMINATION = {0: "max_iterations", 1: "gradient_tolerance", 2: "parameter_tolerance", 3: "function_tolerance", 4: "stalled", 5: "numerical_failure", 6: "min_radius"}
 
@@ -127,6 +139,9 @@ _SIGS = {
     "lili_extract_livox_debug": (C.c_int, [C.c_void_p] * 6),
     "lili_extract_rot_device": (C.c_int, [C.c_void_p, C.POINTER(Cloud), C.POINTER(Cloud), C.POINTER(Cloud)]),
     "lili_extract_livox_device": (C.c_int, [C.c_void_p, C.POINTER(Cloud), C.POINTER(Cloud)]),
+    "lili_frontend_frame": (C.c_int, [C.c_void_p, C.POINTER(Cloud), C.c_int, C.c_void_p, C.POINTER(LivoxParams), C.POINTER(S2MParams), C.POINTER(FrontendOptions), C.c_void_p, C.c_void_p,
+                                      C.POINTER(FrontendResult)]),
+    "lili_frontend_reset": (C.c_int, [C.c_void_p]),
     "lili_voxel_filter": (C.c_int, [C.c_void_p, C.POINTER(Cloud), C.c_float, C.POINTER(FeatureOut), C.c_void_p]),
     "lili_localmap_reset": (C.c_int, [C.c_void_p, C.c_int]),
     "lili_localmap_push": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Cloud), C.c_void_p, C.c_void_p, C.c_int]),
@@ -733,6 +748,56 @@ class LivoxExtractor:
             arr["cell_src"] = arr["cell_src"].reshape(6, 4000)
             res.update(arr)
         return res
+
+
+class FrontendOdometry:
+    """Host-side mirror of LidarOdometry::run (L/src/LidarOdometry.cpp:652-707) behind the extraction node (L/src/Preprocessing.cpp:219-401): one
+    lili_frontend_frame call per Livox scan — extraction, down_size_filter_surf, the outer iterations against the local map of the last `width`
+    frames, the ring push at the pose found and the next frame's local map, all device-resident.  The frame counter reproduces the node's start-up:
+    frame 0 is only stored (system not initialised, L:659-663; its surf_frames entry is empty), frame 1 is matched against its own surf features with
+    8 iterations (L:283-289, 501-502), later frames against the ring with `scan_match_cnt`.  The caller keeps poseInitialization's constant-velocity
+    prediction (L:415-441)."""
+
+    def __init__(self, ctx, params=None, surf_thres=0.28, edge_thres=4.0, near_range=0.1, leaf_query=0.4, leaf_map=0.4, width=20, slot=0,
+                 scan_match_cnt=6, first_match_cnt=8, reference_startup=True):
+        """reference_startup = False: the replay tools' simpler start (frame 0 enters the ring with its features at the given pose, frame 1 is matched
+        against it with `first_match_cnt` iterations) — same C call, other flags."""
+        self.reference_startup = bool(reference_startup)
+        self.ctx, self.lib = ctx, ctx.lib
+        self.params = params if params is not None else make_params("frontend")
+        self.livox = LivoxParams(surf_thres, edge_thres, near_range)
+        self.opt = FrontendOptions(leaf_query, leaf_map, width, scan_match_cnt, slot, 0, 0)
+        self.res = FrontendResult()
+        self.scan_match_cnt, self.first_match_cnt = int(scan_match_cnt), int(first_match_cnt)
+        self.n_frames = 0
+
+    def reset(self):
+        self.ctx._chk(self.lib.lili_frontend_reset(self.ctx.h))
+        self.n_frames = 0
+
+    def frame(self, scan, t_pred, q_pred, q_imu=(1.0, 0, 0, 0), timing=False):
+        """scan: (n,5) float32 rows x, y, z, intensity, curvature (host; page-locked memory is read in place) or a Cloud.  Returns (t, q, info)."""
+        if isinstance(scan, Cloud):
+            cloud, curv_off = scan, 16
+        else:
+            n = scan.shape[0]
+            cloud, curv_off = Cloud(scan.ctypes.data if n else None, n, 20, 12, MEM_HOST), 16
+        k = self.n_frames
+        self.opt.n_iters = 0 if k == 0 else (self.first_match_cnt if k == 1 else self.scan_match_cnt)
+        self.opt.flags = (FRAME_PUSH_EMPTY if k == 0 else (FRAME_SELF_MAP if k == 1 else 0)) if self.reference_startup else 0
+        self.opt.want_timing = 1 if timing else 0
+        qi, tp, qp = _f64(q_imu, 4), _f64(t_pred, 3), _f64(q_pred, 4)
+        r = self.res
+        self.ctx._chk(self.lib.lili_frontend_frame(self.ctx.h, C.byref(cloud), curv_off, _ptr(qi), C.byref(self.livox), C.byref(self.params), C.byref(self.opt),
+                                                   _ptr(tp), _ptr(qp), C.byref(r)))
+        self.n_frames += 1
+        info = dict(gn_status=r.gn_status, matched=bool(r.matched), n_edge=r.n_edge, n_surf=r.n_surf, n_query=r.n_query, n_map_raw=r.n_map_raw, n_map=r.n_map)
+        if timing:
+            info["stage_us"] = [r.stage_us[j] for j in range(4)]
+        t, q = np.array(r.t[:], np.float64), np.array(r.q[:], np.float64)
+        if q[0] < 0:
+            q = -q                    # unifyQuaternion (L:538-548)
+        return t, q, info
 
 
 def gn_step_host(gram, t, q):

@@ -443,7 +443,10 @@ static int map_set_impl(lili_ctx* ctx, int kind, const lili_cloud* cloud, double
     const bool narrow = ctx->map_narrow_counts && !sb.wide_counts && ctx->scan_lookback;
     BoxSource source = box6 ? kBoxGiven : kBoxMeasure;
     if (!box6 && allow_guess && ctx->map_guess_box && sb.valid && sb.max_sq_radius == max_sq_radius &&
-        (double)n <= 1.25 * (double)sb.n && (double)n >= 0.8 * (double)sb.n) source = kBoxGuess;
+        (double)n <= 1.25 * (double)sb.n && (double)n >= 0.8 * (double)sb.n) {
+        if (sb.skip_guesses > 0) sb.skip_guesses--;      // this kind missed three guesses in a row: measure for the next few builds
+        else source = kBoxGuess;
+    }
     // every scratch word of the build — box banks, density banks, the scans' error word and status words, the guess's flags — starts from zero: one fill
     HIPCHK(hipMemsetAsync(ctx->misc.p, 0, kMiscTotal, ctx->stream));
     unsigned banks[64 * 32], mm[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
@@ -505,9 +508,15 @@ static int map_set_impl(lili_ctx* ctx, int kind, const lili_cloud* cloud, double
             ctx->box_guesses++;
             if ((chk & 1u) || (chk & 0xFCu) != 0xFCu) {          // a point outside the guessed box, or a face of it that no point comes near (another cloud's box): measure, build again
                 ctx->box_guess_misses++;
-                if (chk & 1u) sb.margin_cells = std::min(sb.margin_cells * 2, 64);
+                // the margin grows after a miss but is capped where measuring is cheaper than a grid that much larger (8 cells per side; the
+                // too-loose test scales with it), shrinks again after a run of hits (below), and a kind that keeps missing stops guessing for a while
+                if (chk & 1u) sb.margin_cells = std::min(sb.margin_cells * 2, 8);
+                sb.hits = 0;
+                if (++sb.misses_in_a_row >= 3) { sb.skip_guesses = 8; sb.misses_in_a_row = 0; }
                 return map_set_impl(ctx, kind, cloud, max_sq_radius, nullptr, false);
             }
+            sb.misses_in_a_row = 0;
+            if (++sb.hits >= 4 && sb.margin_cells > 1) { sb.margin_cells /= 2; sb.hits = 0; }      // four guesses in a row held: half the margin (towards 1)
             if (chk & 2u) sb.valid = false;      // the cloud comes within a quarter cell of a face of the grid: the next build measures its box again
         }
         if (ctx->fine_grid) {
@@ -546,6 +555,9 @@ static int map_set_impl(lili_ctx* ctx, int kind, const lili_cloud* cloud, double
             return rc;
         }
     }
+    // with scan_lookback = 0 the fine index's kernels (which read the CALLER's device cloud in place) were enqueued after the build's last read-back: the
+    // header promises the cloud is free when the call returns, so the call waits for them
+    else if (m.has_fine && cloud->mem == LILI_MEM_DEVICE) HIPCHK(hipStreamSynchronize(ctx->stream));
     // what the next build of this kind may start from: this cloud's TRUE box (a given box is the caller's, taken as true: lili_localmap_commit hands over the centroids'
     // own).  A build from a guess keeps the box it guessed from — margins do not pile up.
     if (source != kBoxGuess) {
@@ -553,6 +565,7 @@ static int map_set_impl(lili_ctx* ctx, int kind, const lili_cloud* cloud, double
         sb.valid = mm[0] <= mm[3] && mm[1] <= mm[4] && mm[2] <= mm[5];
         sb.max_sq_radius = max_sq_radius;
         sb.n = n;
+        if (source == kBoxMeasure) { sb.hits = 0; }
     }
     m.valid = true;
     return LILI_OK;

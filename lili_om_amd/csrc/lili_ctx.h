@@ -67,6 +67,7 @@ struct SpecBox {
     int64_t n = 0;
     double max_sq_radius = 0;
     int margin_cells = 1;
+    int hits = 0, misses_in_a_row = 0, skip_guesses = 0;      // guesses that held since the margin last changed / consecutive misses / builds that measure before guessing resumes
     bool wide_counts = false;      // a build of this kind met a cell of more than 255 points: 32-bit cell counters from then on (k_cell_count instead of k_cell_count_narrow)
 };
 
@@ -210,3 +211,7 @@ int lili_ingest_cloud(lili_ctx* ctx, const lili_cloud* c, lili_detail::DevBuf& o
 // lili_p2p.hip: the view of the NEXT exchange of a communicator (advances its sequence number); usable = connected and on this context
 lili::P2PView lili_p2p_next_view(lili_p2p* c);
 bool lili_p2p_usable(const lili_p2p* c, const lili_ctx* ctx);
+// lili_voxel.hip -> lili_pipeline.hip: the voxel filter and the keyframe ring on device clouds (no host copies, the pose read on the device)
+int lili_voxel_filter_dev(lili_ctx* ctx, const float4* d_pts, int n, float leaf, const float4** d_out, int* n_out);
+int lili_localmap_push_dev(lili_ctx* ctx, int kind, const float4* d_pts, int n, const lili::SlotState* d_state, int width);
+int lili_localmap_ring_size(lili_ctx* ctx, int kind);

@@ -450,6 +450,9 @@ int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offs
     bool all3 = n > 0 && out_ok(cutted) && out_ok(edge) && out_ok(surf);
     if (all3) { dc = lili_pinned_dev_ptr(cutted->data, 16); de3 = lili_pinned_dev_ptr(edge->data, 16); ds3 = lili_pinned_dev_ptr(surf->data, 16); all3 = dc && de3 && ds3; }
     bool cut_early = false;
+    // Whatever way this call ends, no DMA into the caller's `cutted` buffer may outlive it (lili_extract_rot has the same guard): every return between
+    // the side-stream copy and its join — a HIP error, a stride the packing rejects, a failed read-back — drains the side stream first.
+    struct DrainSide { hipStream_t s = nullptr; ~DrainSide() { if (s) (void)hipStreamSynchronize(s); } } drain_side;
     if (!all3 && n > 0 && cutted && cutted->data && cutted->mem == LILI_MEM_HOST && cutted->capacity > 0) {
         rc = livox_pack(ctx, B->pack, cutted, B->cut_a.as<float4>(), B->cut_b.as<float4>(), &st->n_cut, (size_t)n);
         if (rc != LILI_OK) return rc;
@@ -464,6 +467,7 @@ int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offs
                        B->blk_surf_nrm.as<float>());
     if (cut_early) {          // the side stream's copy of lidar_cloud_cutted, enqueued while the GPU works on the blocks (which use no PCIe); joined before the call's ONE synchronisation
         hipError_t e = hipStreamWaitEvent(ctx->side[1], ctx->fork_ev, 0);
+        drain_side.s = ctx->side[1];
         if (e == hipSuccess) e = hipMemcpyAsync(cutted->data, B->pack.p, std::min((size_t)n, cutted->capacity) * (cutted->stride ? cutted->stride : 32), hipMemcpyDeviceToHost, ctx->side[1]);
         if (e == hipSuccess) e = hipEventRecord(ctx->join_ev[1], ctx->side[1]);
         if (e != hipSuccess) return ctx->fail(LILI_E_HIP, std::string("extract_livox: ") + hipGetErrorString(e));
@@ -522,6 +526,7 @@ int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offs
     if (direct) { sent_e = std::min((size_t)kLvCells, edge->capacity); sent_s = std::min((size_t)kLvCells, surf->capacity); }
     if (counts_direct) { HIPCHK(hipStreamSynchronize(ctx->stream)); B->host.n_cut = B->h_counts[0]; B->host.n_edge = B->h_counts[1]; B->host.n_surf = B->h_counts[2]; }
     else { const int rb = lili_readback_finish(ctx); if (rc) return rc; if (rb) return rb; }      // (the pending read is always finished)  — the call's synchronisation
+    drain_side.s = nullptr;      // joined: the synchronisation above covered the side stream's copy (hipStreamWaitEvent on its join event)
     B->have = true;
     bool more = false;
     if (cutted) {

@@ -1,0 +1,115 @@
+// Front-end frame pipeline: the per-scan chain of the reference's odometry node as ONE C-ABI call whose data never leaves HBM.
+//
+// Reference behaviour replaced (L/ = LiLi-OM/):
+//   Preprocessing::cloudHandler            L/src/Preprocessing.cpp:219-401     (lili_extract_livox)
+//   LidarOdometry::run                     L/src/LidarOdometry.cpp:652-707
+//     buildLocalMap / downSampleCloud      L:280-303, 314-322                  (keyframe ring + VoxelGrid(0.4) + setInputCloud, lili_voxel.hip)
+//     updateTransformationWithCeres        L:483-561                           (outer iterations of the front-end flavour, lili_s2m*.hip)
+//     savePoses + transformCloud           L:324-350, 292-297                  (the frame joins the ring at the pose found)
+// The stages are the library's own entry points; what this file adds is the ORDER (the next frame's local map is built behind this frame's
+// iterations, the ring push reads the pose on the device) and the absence of host copies between them.
+#include <chrono>
+
+#include "lili_ctx.h"
+
+namespace lili {
+
+// lili_s2m_pose_set without the host staging copy and its synchronisation: the pose travels in the kernel-argument segment
+struct PoseVal { double v[7]; };
+__global__ void k_pose_set(SlotState* __restrict__ s, PoseVal p) {
+    const int i = threadIdx.x;
+    if (i < 7) s->pose[i] = p.v[i];
+    if (i < 6) s->last_delta[i] = 0.0;
+    if (i == 7) { s->n_res[0] = 0; s->n_res[1] = 0; s->gn_status = 0; s->iters = 0; s->cnt_word = 0ull; }
+}
+
+}  // namespace lili
+
+extern "C" {
+
+int lili_frontend_reset(lili_ctx* ctx) {
+    if (!ctx) return LILI_E_ARG;
+    return lili_localmap_reset(ctx, LILI_KIND_SURF);
+}
+
+int lili_frontend_frame(lili_ctx* ctx, const lili_cloud* scan, int curvature_offset, const double q_imu[4], const lili_livox_params* livox,
+                        const lili_s2m_params* match, const lili_frontend_options* opt, const double t_pred[3], const double q_pred[4],
+                        lili_frontend_result* res) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(scan && q_imu && livox && match && opt && t_pred && q_pred && res, "frontend_frame: null argument");
+    ARGCHK(opt->leaf_query > 0 && opt->leaf_map > 0 && opt->width >= 1 && opt->n_iters >= 0 && opt->slot >= 0 && opt->slot < LILI_MAX_SLOTS, "frontend_frame: bad options");
+    HIPCHK(hipSetDevice(ctx->device));
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto stamp = [&](int k) { if (opt->want_timing) res->stage_us[k] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(); };
+    *res = lili_frontend_result{};
+    const int slot = opt->slot;
+    // ---- extraction (Preprocessing::cloudHandler): features stay in the extractor's device lists; ONE synchronisation for their counts
+    int rc = lili_extract_livox(ctx, scan, curvature_offset, q_imu, livox, nullptr, nullptr, nullptr);
+    if (rc != LILI_OK) return rc;
+    lili_cloud d_edge{}, d_surf{};
+    rc = lili_extract_livox_device(ctx, &d_edge, &d_surf);
+    if (rc != LILI_OK) return rc;
+    res->n_edge = (int32_t)d_edge.n; res->n_surf = (int32_t)d_surf.n;
+    stamp(0);
+    // ---- down_size_filter_surf (L:320-322) on the device list; the centroids become the frame's queries AND its keyframe
+    const float4* d_q = nullptr; int n_q = 0;
+    rc = lili_voxel_filter_dev(ctx, static_cast<const float4*>(d_surf.data), (int)d_surf.n, opt->leaf_query, &d_q, &n_q);
+    if (rc != LILI_OK) return rc;
+    res->n_query = n_q;
+    stamp(1);
+    const bool self_map = (opt->flags & LILI_FRAME_SELF_MAP) != 0;
+    if (self_map) {
+        // buildLocalMap's initialisation branch (L:283-289): the map is this frame's own surf features; downSampleCloud filters them with the MAP filter (L:314-318)
+        const float4* d_m = d_q; int n_m = n_q;
+        if (opt->leaf_map != opt->leaf_query) {
+            rc = lili_voxel_filter_dev(ctx, static_cast<const float4*>(d_surf.data), (int)d_surf.n, opt->leaf_map, &d_m, &n_m);
+            if (rc != LILI_OK) return rc;
+        }
+        const lili_cloud mc{d_m, (size_t)n_m, 16, 12, LILI_MEM_DEVICE};
+        const bool srows = ctx->super_rows;
+        if (!ctx->localmap_super_rows && n_m < 400000 && !(ctx->focus_radius > 0)) ctx->super_rows = false;      // as lili_localmap_commit: small maps go without the 9x copy
+        rc = lili_map_set(ctx, LILI_KIND_SURF, &mc, match->kd_max_radius);
+        ctx->super_rows = srows;
+        if (rc != LILI_OK) return rc;
+        if (opt->leaf_map != opt->leaf_query) {      // the filter's buffer now holds the map: the queries again
+            rc = lili_voxel_filter_dev(ctx, static_cast<const float4*>(d_surf.data), (int)d_surf.n, opt->leaf_query, &d_q, &n_q);
+            if (rc != LILI_OK) return rc;
+        }
+    }
+    const lili_cloud qc{d_q, (size_t)n_q, 16, 12, LILI_MEM_DEVICE};
+    rc = lili_s2m_set_queries(ctx, slot, LILI_KIND_SURF, &qc);      // device-to-device: the filter's buffer is reused by the map commit below
+    if (rc != LILI_OK) return rc;
+    PoseVal pv{};
+    for (int i = 0; i < 3; i++) pv.v[i] = t_pred[i];
+    for (int i = 0; i < 4; i++) pv.v[3 + i] = q_pred[i];
+    hipLaunchKernelGGL(k_pose_set, dim3(1), dim3(8), 0, ctx->stream, ctx->state(slot), pv);
+    HIPCHK(hipGetLastError());
+    ctx->slots[slot].assoc_since_pose = 0;
+    // ---- updateTransformationWithCeres (L:483-561): needs a map of at least 10 points (L:485-488); the first frame of a sequence has none
+    const bool matched = (self_map || lili_localmap_ring_size(ctx, LILI_KIND_SURF) > 0) && ctx->map[LILI_KIND_SURF].valid && ctx->map[LILI_KIND_SURF].n >= 10 && n_q > 0 && opt->n_iters > 0;
+    if (matched) {
+        rc = lili_s2m_iterate(ctx, slot, LILI_MASK_SURF, match, opt->n_iters);
+        if (rc != LILI_OK) return rc;
+    }
+    res->matched = matched ? 1 : 0;
+    stamp(2);
+    // ---- the frame joins the ring at the pose the iterations reached (read by the kernel from the slot's device state), and the NEXT frame's
+    //      local map is built now: its read-backs (sizes, box) and the pose come back in the same synchronisation
+    rc = lili_localmap_push_dev(ctx, LILI_KIND_SURF, ctx->slots[slot].k[LILI_KIND_SURF].q.as<float4>(), (opt->flags & LILI_FRAME_PUSH_EMPTY) ? 0 : n_q, ctx->state(slot), opt->width);
+    if (rc != LILI_OK) return rc;
+    SlotState st{};
+    rc = lili_readback_add(ctx, &st, ctx->state(slot), sizeof(st));
+    if (rc != LILI_OK) return rc;
+    int64_t n_raw = 0, n_map = 0;
+    rc = lili_localmap_commit(ctx, LILI_KIND_SURF, opt->leaf_map, match->kd_max_radius, &n_raw, &n_map);
+    if (!ctx->h_pin_items.empty()) { const int rb = lili_readback_finish(ctx); if (rc == LILI_OK) rc = rb; }      // (a commit without a read-back of its own)
+    if (rc != LILI_OK) return rc;
+    stamp(3);
+    for (int i = 0; i < 3; i++) res->t[i] = st.pose[i];
+    for (int i = 0; i < 4; i++) res->q[i] = st.pose[3 + i];
+    res->gn_status = matched ? st.gn_status : 0;
+    res->n_map_raw = (int32_t)n_raw; res->n_map = (int32_t)n_map;
+    return LILI_OK;
+}
+
+}  // extern "C"

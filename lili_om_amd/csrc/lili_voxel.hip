@@ -333,6 +333,18 @@ __global__ void k_transform_cloud(const float4* __restrict__ in, int n, dq q, d3
     out[i] = make_float4((float)r.x, (float)r.y, (float)r.z, p.w);
 }
 
+// the same with the pose read from a slot's device state (lili_frontend_frame: the keyframe is pushed at the pose the matcher has just reached, before the
+// host has seen it) — same expression, same operands
+__global__ void k_transform_cloud_state(const float4* __restrict__ in, int n, const SlotState* __restrict__ st, float4* __restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const dq q{st->pose[3], st->pose[4], st->pose[5], st->pose[6]};
+    const d3 t{st->pose[0], st->pose[1], st->pose[2]};
+    float4 p = in[i];
+    d3 r = qrot(q, d3{(double)p.x, (double)p.y, (double)p.z}) + t;
+    out[i] = make_float4((float)r.x, (float)r.y, (float)r.z, p.w);
+}
+
 }  // namespace lili
 
 namespace lili_detail {
@@ -557,24 +569,21 @@ int lili_localmap_reset(lili_ctx* ctx, int kind) {
     return LILI_OK;
 }
 
-int lili_localmap_push(lili_ctx* ctx, int kind, const lili_cloud* features, const double t[3], const double q[4], int width) {
-    if (!ctx) return LILI_E_ARG;
-    ARGCHK((kind == 0 || kind == 1) && features && t && q && width >= 1, "localmap_push: bad argument");
-    HIPCHK(hipSetDevice(ctx->device));
+// the ring step of lili_localmap_push on a device float4 cloud; the pose either by value (t, q) or read by the kernel from `d_state`
+static int localmap_push_f4(lili_ctx* ctx, int kind, const float4* d_in, int n, const double* t, const double* q, const SlotState* d_state, int width) {
     auto* V = vox_of(ctx);
-    int rc = lili_ingest_cloud(ctx, features, V->in);
-    if (rc != LILI_OK) return rc;
     // a buffer from the pool of popped keyframes if one is large enough (the steady state: keyframes of similar size), else a new one
     lili_detail::Keyframe* kf = nullptr;
-    for (size_t i = 0; i < V->pool.size(); i++) if (V->pool[i]->pts.cap >= features->n * 16) { kf = V->pool[i]; V->pool.erase(V->pool.begin() + (long)i); break; }
+    for (size_t i = 0; i < V->pool.size(); i++) if (V->pool[i]->pts.cap >= (size_t)n * 16) { kf = V->pool[i]; V->pool.erase(V->pool.begin() + (long)i); break; }
     if (!kf) kf = new lili_detail::Keyframe();
-    kf->n = (int)features->n;
+    kf->n = n;
     kf->seq = V->next_seq++;
     if (kf->n > 0) {
         hipError_t e = kf->pts.ensure((size_t)kf->n * 16);
         if (e != hipSuccess) { delete kf; return ctx->fail(LILI_E_HIP, "localmap_push: allocation failed"); }
-        hipLaunchKernelGGL(k_transform_cloud, dim3(nblocks(kf->n, 256)), dim3(256), 0, ctx->stream, V->in.as<float4>(), kf->n,
-                           dq{q[0], q[1], q[2], q[3]}, d3{t[0], t[1], t[2]}, kf->pts.as<float4>());
+        if (d_state) hipLaunchKernelGGL(k_transform_cloud_state, dim3(nblocks(kf->n, 256)), dim3(256), 0, ctx->stream, d_in, kf->n, d_state, kf->pts.as<float4>());
+        else hipLaunchKernelGGL(k_transform_cloud, dim3(nblocks(kf->n, 256)), dim3(256), 0, ctx->stream, d_in, kf->n,
+                                dq{q[0], q[1], q[2], q[3]}, d3{t[0], t[1], t[2]}, kf->pts.as<float4>());
         hipError_t le = hipGetLastError();
         if (le != hipSuccess) { delete kf; return ctx->fail(LILI_E_HIP, std::string("localmap_push: ") + hipGetErrorString(le)); }
     }
@@ -587,6 +596,16 @@ int lili_localmap_push(lili_ctx* ctx, int kind, const lili_cloud* features, cons
         else { HIPCHK(hipStreamSynchronize(ctx->stream)); old->pts.release(); delete old; }
     }
     return LILI_OK;
+}
+
+int lili_localmap_push(lili_ctx* ctx, int kind, const lili_cloud* features, const double t[3], const double q[4], int width) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK((kind == 0 || kind == 1) && features && t && q && width >= 1, "localmap_push: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    auto* V = vox_of(ctx);
+    int rc = lili_ingest_cloud(ctx, features, V->in);
+    if (rc != LILI_OK) return rc;
+    return localmap_push_f4(ctx, kind, V->in.as<float4>(), (int)features->n, t, q, nullptr, width);
 }
 
 // One keyframe step on the sorted ring: drop the entries of the keyframes in `drop`, merge the keyframe `add` (may be null) in.
@@ -795,3 +814,20 @@ int lili_localmap_stats(lili_ctx* ctx, int32_t* incremental_commits, int32_t* fu
 }
 
 }  // extern "C"
+
+// ---- internal hooks of lili_pipeline.hip (declared in lili_ctx.h; not part of the ABI) ----
+// pcl::VoxelGrid of a device float4 cloud; the centroids stay in the filter's own output buffer (valid until the next filter / commit on this context)
+int lili_voxel_filter_dev(lili_ctx* ctx, const float4* d_pts, int n, float leaf, const float4** d_out, int* n_out) {
+    auto* V = vox_of(ctx);
+    const int rc = voxel_filter_device(ctx, V, d_pts, n, leaf);
+    if (rc != LILI_OK) return rc;
+    if (d_out) *d_out = V->out.as<float4>();
+    if (n_out) *n_out = V->n_out;
+    return LILI_OK;
+}
+// lili_localmap_push of a device float4 cloud at the pose held in a slot's DEVICE state (async: no host round trip for the pose)
+int lili_localmap_push_dev(lili_ctx* ctx, int kind, const float4* d_pts, int n, const SlotState* d_state, int width) {
+    return localmap_push_f4(ctx, kind, d_pts, n, nullptr, nullptr, d_state, width);
+}
+int lili_localmap_ring_size(lili_ctx* ctx, int kind) { return (int)vox_of(ctx)->ring[kind].size(); }
+

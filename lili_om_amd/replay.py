@@ -4,10 +4,10 @@ Livox configuration, one scan in flight like the reference's `ros::spin` nodes.
     /livox/lidar (livox_ros_driver/CustomMsg)  --lili_livox_custom_to_cloud-->  PointXYZINormal cloud
     or /livox_ros_points (sensor_msgs/PointCloud2) directly
     /imu (sensor_msgs/Imu)                      --lili_imu_integrate-->          q_imu of the scan
-    cloud, q_imu                                --lili_extract_livox-->          edge / surf features
-    surf features                               --lili_voxel_filter(0.4)-->      queries          (L/src/LidarOdometry.cpp:280-323)
-    last `map_width` frames' queries            --LocalMap push / commit-->      local map index
-    queries vs local map                        --lili_s2m_iterate (front-end variant)-->  pose    (L:483-561)
+    cloud, q_imu, predicted pose                --lili_frontend_frame-->         pose
+        (one C call per scan, device-resident: lili_extract_livox -> VoxelGrid(0.4) of the surf features = queries (L/src/LidarOdometry.cpp:280-323)
+         -> outer iterations of the front-end variant against the local map of the last `map_width` frames (L:483-561) -> ring push at the pose
+         found + the next frame's local map; `staged=True` keeps the round-4 chain of separate calls with host copies in between, for A/B)
 
 The scan queue follows Preprocessing::cloudHandler (L/src/Preprocessing.cpp:194-215): scan k is processed when scan
 k+2 has arrived, `time_scan_next` = stamp of scan k+1, and only once IMU data reaches that time.  The pose prediction
@@ -30,12 +30,14 @@ def _predict(poses):
 
 
 def replay(bag_path, ctx, lidar_topic="/livox/lidar", imu_topic="/imu", first_pose=None, n_outer=6, n_outer_first=12,
-           map_width=20, leaf=0.4, max_scans=None, on_frame=None):
+           map_width=20, leaf=0.4, max_scans=None, on_frame=None, staged=False):
     """Returns a list of dicts (stamp, t, q, n_surf, n_edge, n_query, q_imu) — one per processed scan."""
     P = A.make_params("frontend")
     ex = A.LivoxExtractor(ctx)
     matcher = A.ScanToMapMatcher(ctx, P)
     local = A.LocalMap(ctx, A.KIND_SURF, map_width, leaf, P.kd_max_radius)
+    odo = A.FrontendOdometry(ctx, P, leaf_query=leaf, leaf_map=leaf, width=map_width, scan_match_cnt=n_outer, first_match_cnt=n_outer_first, reference_startup=False)
+    odo.reset()
     imu = A.ImuIntegrator()
     imu_t, imu_w = [], []
     queue, out, poses = [], [], []
@@ -43,6 +45,20 @@ def replay(bag_path, ctx, lidar_topic="/livox/lidar", imu_topic="/imu", first_po
 
     def process(stamp, pts5, t_next):
         q_imu = imu.integrate(np.array(imu_t), np.array(imu_w).reshape(-1, 3), t_next)
+        if not staged:
+            if not poses:
+                t0, q0 = first_pose if first_pose is not None else (np.zeros(3), np.array([1.0, 0, 0, 0]))
+            else:
+                t0, q0 = _predict(poses)
+            t, q, info = odo.frame(pts5, t0, q0, q_imu)
+            if info["gn_status"] != 0:
+                t, q = np.asarray(t0, np.float64), np.asarray(q0, np.float64)
+            poses.append((t, q))
+            rec = dict(stamp=stamp, t=t, q=q, n_surf=info["n_surf"], n_edge=info["n_edge"], n_query=info["n_query"], q_imu=q_imu)
+            out.append(rec)
+            if on_frame:
+                on_frame(rec)
+            return
         f = ex.extract(pts5, q_imu)
         surf = np.ascontiguousarray(f["surf"][:, [0, 1, 2, 7]])
         qry, _ = A.voxel_filter(ctx, surf, leaf) if surf.shape[0] else (surf, None)
