@@ -3,6 +3,8 @@
 // without a gfx950 device lili_ctx_create fails with LILI_E_NODEVICE.
 #include "lili_ctx.h"
 
+#include <hip/hip_ext.h>
+
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -37,7 +39,7 @@ template <bool TILED, int BS> __global__ void k_associate_edge(const float4*, co
 __global__ void k_block_order(const int*, int, int, int*);
 __global__ void k_associate_both(AssocArgs, AssocArgs, PoseArg, MatchParams);
 __global__ void k_linearize(LinArgs, LinArgs, PoseArg, MatchParams, const SlotState*, const int*, FuseTail);
-__global__ void k_reduce_partials(const double*, int, const double*, int, double*, SlotState*, int, P2PView);
+__global__ void k_reduce_partials(const double*, int, const double*, int, double*, SlotState*, int, P2PView, unsigned long long);
 __global__ void k_sum_counts(const int*, int, const int*, int, SlotState*, int*, P2PView);
 __global__ void k_gn_update(const double*, SlotState*);
 __global__ void k_pose_copy(SlotState*, const SlotState*);
@@ -75,6 +77,15 @@ template <int L> __global__ void k_iterate_coop(AssocArgs, AssocArgs, MatchParam
 
 #include "lili_ctx.h"
 
+
+// A kernel launch that may drop the barrier against the kernels enqueued before it on the stream (`any_order`: hipExtAnyOrderLaunch — the AQL packet goes without the
+// barrier bit, so it is dispatched as soon as the packets in front of it have been DISPATCHED, not completed).  Only the association that follows a reduction + GN
+// kernel uses it (option "overlap_gn"): its waves poll for the pose that kernel publishes.  Where the runtime ignores the flag the launch is an ordinary one.
+template <typename K, typename... A>
+static inline void launch_k(hipStream_t stream, bool any_order, K kernel, dim3 grid, dim3 block, size_t lds, A... args) {
+    if (any_order) hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, stream, nullptr, nullptr, hipExtAnyOrderLaunch, args...);
+    else hipLaunchKernelGGL(kernel, grid, block, lds, stream, args...);
+}
 
 static MatchParams to_device_params(const lili_s2m_params* p) {
     MatchParams m{};
@@ -276,6 +287,7 @@ int lili_set_option(lili_ctx* ctx, const char* name, int value) {
     if (std::strcmp(name, "rot_atan") == 0) { if (value != 1 && value != 2) return ctx->fail(LILI_E_ARG, "rot_atan must be 1 or 2"); ctx->rot_atan = value; return LILI_OK; }
     if (std::strcmp(name, "p2p_fusion") == 0) { ctx->no_p2p_fusion = value == 0; return LILI_OK; }
     if (std::strcmp(name, "nn_cache") == 0) { ctx->nn_cache = value != 0; for (auto& s : ctx->slots) for (auto& k : s.k) k.nn_cache_valid = false; return LILI_OK; }
+    if (std::strcmp(name, "overlap_gn") == 0) { ctx->overlap_gn = value != 0; return LILI_OK; }      // lili_s2m_iterate*: the association behind a reduction + GN kernel starts without waiting for it (0: three barriers per iteration)
     if (std::strcmp(name, "max_cells") == 0) { if (value < 1) return ctx->fail(LILI_E_ARG, "max_cells must be positive"); ctx->max_cells = value; return LILI_OK; }
     return ctx->fail(LILI_E_ARG, std::string("unknown option ") + name);
 }
@@ -792,7 +804,7 @@ static int launch_associate(lili_ctx* ctx, int slot, int kind, const PoseArg& pa
         a.rec0 = ks.rec0.as<float4>(); a.rec1 = ks.rec1.p; a.valid = ks.valid.as<unsigned char>();
         a.dbg_idx = dbg_i; a.dbg_d2 = dbg_d; a.block_counts = ks.block_counts.as<int>(); a.nb = ks.n_blocks;
         ks.launches++;
-        hipLaunchKernelGGL(k_associate_fine, dim3(ks.n_blocks), dim3(kAssocBlock), 0, ctx->stream, a, m.fview, m.fbound, kind, pa, P);
+        launch_k(ctx->stream, pa.wait_key != 0ull, k_associate_fine, dim3(ks.n_blocks), dim3(kAssocBlock), 0, a, m.fview, m.fbound, kind, pa, P);
         HIPCHK(hipGetLastError());
         return LILI_OK;
     }
@@ -818,13 +830,14 @@ static int launch_associate(lili_ctx* ctx, int slot, int kind, const PoseArg& pa
     ks.launches++;
     // default: one wave per workgroup (kAssocBlock); the binned / tiled variants keep kBlock-sized tiles
     const dim3 grid(ks.n_assoc_blocks);
+    const bool any_order = pa.wait_key != 0ull;
 #define LILI_LAUNCH_ASSOC(KERNEL, REC1T)                                                                                                   \
     do {                                                                                                                                   \
-        if (tiled) hipLaunchKernelGGL((KERNEL<true, kBlock>), grid, dim3(kBlock), 0, ctx->stream, ks.q.as<float4>(), perm, tiles, n, m.view, pa, P, \
+        if (tiled) launch_k(ctx->stream, any_order, (KERNEL<true, kBlock>), grid, dim3(kBlock), 0, (const float4*)ks.q.as<float4>(), perm, tiles, n, m.view, pa, P, \
                                       ks.rec0.as<float4>(), ks.rec1.as<REC1T>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>(), nnc, sched); \
-        else if (perm) hipLaunchKernelGGL((KERNEL<false, kBlock>), grid, dim3(kBlock), 0, ctx->stream, ks.q.as<float4>(), perm, tiles, n, m.view, pa, P, \
+        else if (perm) launch_k(ctx->stream, any_order, (KERNEL<false, kBlock>), grid, dim3(kBlock), 0, (const float4*)ks.q.as<float4>(), perm, tiles, n, m.view, pa, P, \
                                       ks.rec0.as<float4>(), ks.rec1.as<REC1T>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>(), nnc, sched); \
-        else hipLaunchKernelGGL((KERNEL<false, kAssocBlock>), grid, dim3(kAssocBlock), 0, ctx->stream, ks.q.as<float4>(), perm, tiles, n, m.view, pa, P, \
+        else launch_k(ctx->stream, any_order, (KERNEL<false, kAssocBlock>), grid, dim3(kAssocBlock), 0, (const float4*)ks.q.as<float4>(), perm, tiles, n, m.view, pa, P, \
                                       ks.rec0.as<float4>(), ks.rec1.as<REC1T>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>(), nnc, sched); \
     } while (0)
     if (kind == LILI_KIND_SURF) {
@@ -883,7 +896,7 @@ static int launch_associate_both(lili_ctx* ctx, int slot, const PoseArg& pa, con
         a.block_counts = ks.block_counts.as<int>(); a.nb = ks.n_blocks;
         ks.n_assoc_blocks = ks.n_blocks; ks.has_records = true; ks.launches++;
     }
-    hipLaunchKernelGGL(k_associate_both, dim3(A[0].nb + A[1].nb), dim3(kAssocBlock), 0, ctx->stream, A[0], A[1], pa, P);
+    launch_k(ctx->stream, pa.wait_key != 0ull, k_associate_both, dim3(A[0].nb + A[1].nb), dim3(kAssocBlock), 0, A[0], A[1], pa, P);
     HIPCHK(hipGetLastError());
     return LILI_OK;
 }
@@ -951,11 +964,11 @@ static int launch_associate_coop(lili_ctx* ctx, int slot, int kind_mask, const P
     const dim3 grid(A[0].nb + A[1].nb), block(256);
     double* ps = sl.k[0].partials_wave.as<double>(); double* pe = sl.k[1].partials_wave.as<double>();
 #define LILI_COOP_CASE(LL) case LL: if (lin) hipLaunchKernelGGL((k_associate_coop<LL, true>), grid, block, 0, ctx->stream, A[0], A[1], pa, P, ps, pe, ctx->state(slot), cb_blocks); \
-                                    else hipLaunchKernelGGL((k_associate_coop<LL, false>), grid, block, 0, ctx->stream, A[0], A[1], pa, P, ps, pe, ctx->state(slot), 0); break;
+                                    else launch_k(ctx->stream, pa.wait_key != 0ull, (k_associate_coop<LL, false>), grid, block, 0, A[0], A[1], pa, P, ps, pe, ctx->state(slot), 0); break;
     switch (L) { LILI_COOP_CASE(2) LILI_COOP_CASE(4) LILI_COOP_CASE(8) LILI_COOP_CASE(16) default: return 1; }
 #undef LILI_COOP_CASE
     if (lin) hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx->stream, (const double*)ps, A[0].nb, (const double*)pe, A[1].nb, d_out, ctx->state(slot),
-                                1 | (P.debug & 256), P2PView{});
+                                1 | (P.debug & 256), P2PView{}, 0ull);
     HIPCHK(hipGetLastError());
     sl.use_global_counts = false;
     return LILI_OK;
@@ -1173,14 +1186,16 @@ static int launch_associate_lin_reduce(lili_ctx* ctx, int slot, int kind_mask, c
     else hipLaunchKernelGGL(k_associate_lin<kBlock>, dim3(A[0].nb + A[1].nb), dim3(kBlock), 0, ctx->stream, A[0], A[1], pa, P,
                             sl.k[0].partials_wave.as<double>(), sl.k[1].partials_wave.as<double>());
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx->stream, (const double*)sl.k[0].partials_wave.as<double>(), A[0].nb,
-                       (const double*)sl.k[1].partials_wave.as<double>(), A[1].nb, d_out, ctx->state(slot), 1 | (P.debug & 256), P2PView{});
+                       (const double*)sl.k[1].partials_wave.as<double>(), A[1].nb, d_out, ctx->state(slot), 1 | (P.debug & 256), P2PView{}, 0ull);
     HIPCHK(hipGetLastError());
     sl.use_global_counts = false;
     return LILI_OK;
 }
 
+// pub_key (in / out, optional): != 0 asks the reduction + GN kernel to publish the new pose for an association launch that starts without waiting for it (option
+// "overlap_gn", iterate_impl); set to 0 here when this call's structure has no such kernel (fused tail) — the caller then launches the association the plain way.
 static int launch_linearize_reduce(lili_ctx* ctx, int slot, int kind_mask, const PoseArg& pa, const MatchParams& P, double* d_out, int do_gn,
-                                   const P2PView* xv = nullptr) {
+                                   const P2PView* xv = nullptr, unsigned long long* pub_key = nullptr) {
     Slot& s = ctx->slots[slot];
     LinArgs A[2] = {LinArgs{}, LinArgs{}};
     int n_kinds = 0;
@@ -1209,9 +1224,10 @@ static int launch_linearize_reduce(lili_ctx* ctx, int slot, int kind_mask, const
     HIPCHK(hipGetLastError());
     if (!fz.mode) {
         hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx->stream, fz.part_surf, fz.nb_surf, fz.part_edge, fz.nb_edge, d_out, ctx->state(slot), (do_gn ? 1 : 0) | (P.debug & 256),
-                           xv ? *xv : P2PView{});
+                           xv ? *xv : P2PView{}, (pub_key && do_gn) ? *pub_key : 0ull);
         HIPCHK(hipGetLastError());
-    }
+    } else if (pub_key) *pub_key = 0ull;
+    if (pub_key && !do_gn) *pub_key = 0ull;
     return LILI_OK;
 }
 
@@ -1525,6 +1541,8 @@ int lili_s2m_pose_get(lili_ctx* ctx, int slot, double t[3], double q[4], int* gn
     if (t) for (int i = 0; i < 3; i++) t[i] = s.pose[i];
     if (q) for (int i = 0; i < 4; i++) q[i] = s.pose[3 + i];
     if (gn_status) *gn_status = s.gn_status;
+    if (s.wait_failed) return ctx->fail(LILI_E_STATE, "pose_get: an association launched ahead of its Gauss-Newton update (option overlap_gn) gave up waiting for the published pose; "
+                                                       "the slot's results since then are not valid — set_option(\"overlap_gn\", 0) and restart the registration");
     return LILI_OK;
 }
 
@@ -1554,7 +1572,11 @@ int lili_s2m_debug_times(lili_ctx* ctx, int slot, long long out[16]) {
     return LILI_OK;
 }
 
-int lili_s2m_associate_dev(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params) {
+static int associate_dev_impl(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, unsigned long long wait_key);
+int lili_s2m_associate_dev(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params) { return associate_dev_impl(ctx, slot, kind_mask, params, 0ull); }
+// wait_key != 0 (iterate_impl, option "overlap_gn"): the launch carries no barrier against the reduction + GN kernel enqueued right before it and takes the pose from
+// the granules that kernel publishes (load_assoc_pose / wait_published_pose)
+static int associate_dev_impl(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, unsigned long long wait_key) {
     if (!ctx) return LILI_E_ARG;
     ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS, "associate_dev: bad slot");
     ARGCHK((kind_mask & ~3) == 0 && kind_mask != 0, "associate_dev: bad kind mask");
@@ -1565,6 +1587,7 @@ int lili_s2m_associate_dev(lili_ctx* ctx, int slot, int kind_mask, const lili_s2
     PoseArg pa{};
     pa.state = ctx->state(slot);
     pa.derive_assoc = params->variant == LILI_VARIANT_FRONTEND ? 0 : 1;
+    pa.wait_key = wait_key;
     MatchParams P = to_device_params(params);
     {   // small launches: several lanes per query
         int rc = launch_associate_coop(ctx, slot, kind_mask, pa, P, false, nullptr);
@@ -1597,7 +1620,7 @@ int lili_s2m_counts_import(lili_ctx* ctx, int slot, const int32_t* d_counts) {
     return LILI_OK;
 }
 
-static int linearize_dev_impl(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, double* d_gram, int do_gn, int want_cost = 0) {
+static int linearize_dev_impl(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, double* d_gram, int do_gn, int want_cost = 0, unsigned long long* pub_key = nullptr) {
     if (!ctx) return LILI_E_ARG;
     ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS, "linearize_dev: bad slot");
     ARGCHK((kind_mask & ~3) == 0 && kind_mask != 0, "linearize_dev: bad kind mask");
@@ -1607,7 +1630,7 @@ static int linearize_dev_impl(lili_ctx* ctx, int slot, int kind_mask, const lili
     pa.state = ctx->state(slot);
     MatchParams P = to_device_params(params);
     if (do_gn && d_gram == ctx->gram_of(slot) && !want_cost) P.no_cost = 1;   // lili_s2m_iterate*: the record stays inside the library, only the GN step is used
-    int rc = launch_linearize_reduce(ctx, slot, kind_mask, pa, P, d_gram, do_gn);
+    int rc = launch_linearize_reduce(ctx, slot, kind_mask, pa, P, d_gram, do_gn, nullptr, pub_key);
     if (rc != LILI_OK) return rc;
     ctx->slots[slot].use_global_counts = false;
     return LILI_OK;
@@ -1801,25 +1824,32 @@ static int iterate_impl(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_p
         ev.assign((size_t)2 * n_iters, nullptr);
         for (auto& e : ev) HIPCHK(hipEventCreate(&e));
     }
+    unsigned long long wait_key = 0ull;      // != 0: the reduction + GN kernel of the previous iteration publishes its pose under this key (option "overlap_gn")
     for (int it = 0; it < n_iters; it++) {   // 3 launches per outer iteration: associate, linearise, reduce+GN
-        if (restart_every > 0 && it % restart_every == 0) { int rc = lili_s2m_pose_copy(ctx, slot, restart_slot); if (rc != LILI_OK) return rc; }
+        if (restart_every > 0 && it % restart_every == 0) { int rc = lili_s2m_pose_copy(ctx, slot, restart_slot); if (rc != LILI_OK) return rc; wait_key = 0ull; }
         if (!assoc_ms) {        // small scans: the whole registration (up to the next restart) as ONE persistent launch
             const int seg = restart_every > 0 ? std::min(restart_every - it % restart_every, n_iters - it) : n_iters - it;
             const int rcp = launch_iterate_persistent(ctx, slot, kind_mask, params, seg);
-            if (rcp == LILI_OK) { it += seg - 1; continue; }
+            if (rcp == LILI_OK) { it += seg - 1; wait_key = 0ull; continue; }
             if (rcp != 1) return rcp;
         }
         if (!assoc_ms) {        // flavours without count scaling: association + linearisation in one launch (2 launches per iteration)
             int rc2 = iterate_fused_lin(ctx, slot, kind_mask, params);
-            if (rc2 == LILI_OK) continue;
+            if (rc2 == LILI_OK) { wait_key = 0ull; continue; }
             if (rc2 != 1) return rc2;
         }
         if (assoc_ms) HIPCHK(hipEventRecord(ev[2 * it], ctx->stream));
-        int rc = lili_s2m_associate_dev(ctx, slot, kind_mask, params);
+        int rc = associate_dev_impl(ctx, slot, kind_mask, params, wait_key);
         if (rc != LILI_OK) return rc;
         if (assoc_ms) HIPCHK(hipEventRecord(ev[2 * it + 1], ctx->stream));
-        rc = linearize_dev_impl(ctx, slot, kind_mask, params, ctx->gram_of(slot), 1);
+        // Round 5, "overlap_gn": when the NEXT thing on the stream is this slot's next association, the reduction + GN kernel publishes the new pose as keyed granules and
+        // that association is launched WITHOUT a barrier against it: its 3 125 waves are dispatched, load their queries and poll for the pose while the one-workgroup
+        // reduction still runs — two barriers and one flag hop per iteration instead of three barriers.  Keys never repeat within a context.
+        unsigned long long pub_key = 0ull;
+        if (ctx->overlap_gn && !assoc_ms && it + 1 < n_iters && !(restart_every > 0 && (it + 1) % restart_every == 0)) pub_key = (++ctx->gn_seq) * 0x9E3779B97F4A7C15ull;
+        rc = linearize_dev_impl(ctx, slot, kind_mask, params, ctx->gram_of(slot), 1, 0, &pub_key);
         if (rc != LILI_OK) return rc;
+        wait_key = pub_key;
     }
     if (assoc_ms) {
         HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -166,6 +166,9 @@ struct lili_ctx {
     bool persistent_iterate = false;  // lili_s2m_iterate* of small scans (<= 128 cooperative workgroups): one persistent launch per registration (k_iterate_coop).
                                       // Measured (tools/iter_time.py, profiles/r03_iter_time.json): 21.3 vs 19.6 us per outer iteration at 2 k queries (ROT), 17.2 vs 14.9
                                       // (front end) — two exchange hops through memory across the XCDs cost more than the launch boundaries they replace; off by default
+    bool overlap_gn = false;     // lili_s2m_iterate*, three-launch path: the reduction + GN kernel publishes the pose as keyed granules and the next association is launched without a
+                                 // barrier against it (hipExtAnyOrderLaunch): its waves are dispatched and poll for the pose while the reduction still runs
+    unsigned long long gn_seq = 0;   // published poses of this context so far (their keys never repeat)
     bool fuse_lin = true;        // lili_s2m_iterate*: flavours without count scaling linearise inside the association launch (k_associate_lin)
     bool super_rows = true;      // lili_map_set also stores the super-row copy of the map (9x the points): the inner 27-cell block of a query is one run
     bool scan_lookback = true;   // map index: single-pass (decoupled look-back) scan of the cell array; 0 = the three-kernel scan (A/B)

@@ -506,9 +506,48 @@ __device__ __forceinline__ int sum_block_counts_end(int wave_sum) {
 }
 __device__ __forceinline__ int sum_block_counts(const int* __restrict__ block_counts, int nb) { return sum_block_counts_end(sum_block_counts_begin(block_counts, nb)); }
 
+// 16-byte granule {value, value ^ key}: one write-through store / two relaxed agent-scope (sc1) loads
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned long long launch_key(unsigned long long epoch) { return (epoch + 1ull) * 0x9E3779B97F4A7C15ull; }   // never 0 for epoch < 2^64 - 1
+__device__ __forceinline__ void store_granule(double* g, double v, unsigned long long key) {
+    const unsigned long long lo = (unsigned long long)__double_as_longlong(v), hi = lo ^ key;
+    const u32x4 d = {(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(g), "v"(d) : "memory");
+}
+__device__ __forceinline__ void load_granule(const double* g, unsigned long long& lo, unsigned long long& hi) {
+    const unsigned long long* p = reinterpret_cast<const unsigned long long*>(g);
+    lo = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    hi = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// The body pose of a slot as the kernel in front published it (gn_update_block, `pub_key`): lanes 0..6 of the wave poll one granule each until all seven carry the key.
+// The wait is bounded; a wave that gives up raises SlotState::wait_failed (sticky; lili_s2m_pose_get reports it) and carries on with what the slot holds.
+__device__ __forceinline__ void wait_published_pose(const SlotState* st, unsigned long long key, double pose[7]) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long lo = 0ull, hi = 0ull;
+    bool ok = false;
+    for (unsigned sweep = 0; sweep < (1u << 22); sweep++) {
+        if (lane < 7) load_granule(st->pose_pub + 2 * lane, lo, hi);
+        ok = lane >= 7 || ((lo ^ hi) == key);
+        if (__all(ok)) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if (!__all(ok)) {
+        if (lane == 0) const_cast<SlotState*>(st)->wait_failed = 1ull;
+        if (lane < 7) lo = (unsigned long long)__double_as_longlong(st->pose[lane]);
+    }
+#pragma unroll
+    for (int k = 0; k < 7; k++) pose[k] = __longlong_as_double((long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(lo >> 32), k) << 32) |
+                                                                            (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)lo, k)));
+}
 __device__ __forceinline__ void load_assoc_pose(const PoseArg& pa, const MatchParams& P, dq& Q2, d3& T2) {
     if (pa.state) {
-        const double* s = pa.state->pose;
+        double pp[7];
+        if (pa.wait_key) wait_published_pose(pa.state, pa.wait_key, pp);
+        else {
+#pragma unroll
+            for (int k = 0; k < 7; k++) pp[k] = pa.state->pose[k];
+        }
+        const double* s = pp;
         dq Q{s[3], s[4], s[5], s[6]};
         d3 T{s[0], s[1], s[2]};
         if (pa.derive_assoc) {   // L/src/BackendFusion.cpp:929-930
@@ -692,19 +731,6 @@ constexpr int kLinBlock = 1024;   // linearisation block (16 waves; the launch c
 __device__ __forceinline__ void tstamp(const SlotState* state, int debug, int probe_block, int slot) {
     if ((debug & 256) && (int)blockIdx.x == probe_block && threadIdx.x == 0)
         const_cast<SlotState*>(state)->tprof[slot] = (long long)__builtin_amdgcn_s_memrealtime();
-}
-// 16-byte granule {value, value ^ key}: one write-through store / two relaxed agent-scope (sc1) loads
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ unsigned long long launch_key(unsigned long long epoch) { return (epoch + 1ull) * 0x9E3779B97F4A7C15ull; }   // never 0 for epoch < 2^64 - 1
-__device__ __forceinline__ void store_granule(double* g, double v, unsigned long long key) {
-    const unsigned long long lo = (unsigned long long)__double_as_longlong(v), hi = lo ^ key;
-    const u32x4 d = {(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(g), "v"(d) : "memory");
-}
-__device__ __forceinline__ void load_granule(const double* g, unsigned long long& lo, unsigned long long& hi) {
-    const unsigned long long* p = reinterpret_cast<const unsigned long long*>(g);
-    lo = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    hi = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // result lane of partial entry e: e < 36 = upper triangle of the 8x8 Gram (row-major), 36 = cost, 37 = count, 38 / 39 = always zero
 __device__ __forceinline__ int gram_lane(int e) {

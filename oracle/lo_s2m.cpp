@@ -18,6 +18,10 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -132,16 +136,70 @@ static void knn5_one(const KdTree* t, const float* q, int* idx, float* d2) {
     for (int k = 0; k < 5; k++) { idx[k] = best.i[k]; d2[k] = best.d[k]; }
 }
 
-template <class F> static void parallel_for(int n, int nthreads, F f) {
-    if (nthreads <= 1 || n < 2 * nthreads) { f(0, n); return; }
+// Persistent worker pool with dynamic chunks (round 5, VERDICT r4 #5: the all-core CPU figure spawned `nthreads` std::threads per call and gave each one a static
+// n / nthreads-sized range — 9x on 64 cores).  Workers are created once (lazily, so they inherit the affinity mask the caller has set: bench.py pins the process to
+// one socket's physical cores first; lo_pool_reset drops them when the mask changes) and pull chunks of kChunk queries from an atomic counter, so a thread that
+// drew expensive queries (far rings walk more of the tree) does not hold the others up.  The caller's thread works too.
+namespace {
+constexpr int kChunk = 1024;
+struct Pool {
     std::vector<std::thread> th;
-    int chunk = (n + nthreads - 1) / nthreads;
-    for (int t = 0; t < nthreads; t++) {
-        int lo = t * chunk, hi = std::min(n, lo + chunk);
-        if (lo >= hi) break;
-        th.emplace_back([=]() { f(lo, hi); });
+    std::mutex m;
+    std::condition_variable cv, cv_done;
+    const std::function<void(int)>* job = nullptr;
+    int n_chunks = 0, use = 0, running = 0;
+    std::atomic<int> next{0};
+    unsigned long gen = 0;
+    bool stop = false;
+    void worker(int id, unsigned long seen) {      // seen: the generation at creation — a new worker must not take a finished job's stale generation for a new one
+        for (;;) {
+            const std::function<void(int)>* f;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen;
+                if (id >= use) continue;
+                f = job;
+            }
+            for (int c; (c = next.fetch_add(1, std::memory_order_relaxed)) < n_chunks;) (*f)(c);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (--running == 0) cv_done.notify_one();
+            }
+        }
     }
-    for (auto& x : th) x.join();
+    void run(int chunks, int nthreads, const std::function<void(int)>& f) {
+        const int helpers = std::max(0, std::min(nthreads, chunks) - 1);
+        while ((int)th.size() < helpers) { const int id = (int)th.size(); const unsigned long g0 = gen; th.emplace_back([this, id, g0] { worker(id, g0); }); }
+        {
+            std::lock_guard<std::mutex> lk(m);
+            job = &f; n_chunks = chunks; use = helpers; running = helpers; next.store(0, std::memory_order_relaxed); gen++;
+        }
+        cv.notify_all();
+        for (int c; (c = next.fetch_add(1, std::memory_order_relaxed)) < chunks;) f(c);
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [&] { return running == 0; });
+    }
+    void reset() {
+        { std::lock_guard<std::mutex> lk(m); stop = true; }
+        cv.notify_all();
+        for (auto& t : th) t.join();
+        th.clear();
+        stop = false;
+    }
+    ~Pool() { reset(); }
+};
+Pool& pool() { static Pool p; return p; }
+}  // namespace
+extern "C" void lo_pool_reset() { pool().reset(); }
+extern "C" int lo_pool_threads() { return (int)pool().th.size(); }
+
+template <class F> static void parallel_for(int n, int nthreads, F f) {
+    if (nthreads <= 1 || n < 2 * kChunk) { f(0, n); return; }
+    const int chunks = (n + kChunk - 1) / kChunk;
+    const std::function<void(int)> job = [&](int c) { f(c * kChunk, std::min(n, (c + 1) * kChunk)); };
+    pool().run(chunks, nthreads, job);
 }
 
 extern "C" void lo_knn5(void* tree, const float* q, int m, int* idx, float* d2, int nthreads) {
@@ -545,30 +603,63 @@ extern "C" void lo_linearize_surf_mt(const unsigned char* valid, const float* re
                                      int n_q, const double t[3], const double q[4], const lo_params* P, double scale, int scale_den, int nthreads,
                                      double gram[64], double* cost, int* count) {
     if (nthreads < 1) nthreads = 1;
-    std::vector<double> G((size_t)nthreads * 64, 0.0), C(nthreads, 0.0);
-    std::vector<int> N(nthreads, 0);
-    int chunk = (n_q + nthreads - 1) / nthreads;
-    std::vector<std::thread> th;
-    for (int w = 0; w < nthreads; w++) {
-        int lo = w * chunk, hi = std::min(n_q, lo + chunk);
-        if (lo >= hi) break;
-        th.emplace_back([=, &G, &C, &N]() {
-            double* g = G.data() + (size_t)w * 64; double c = 0; int cnt = 0;
-            for (int i = lo; i < hi; i++) {
-                if (!valid[i]) continue;
-                double Jr[8];
-                lo_eval_plane(t, q, rec_cp + 3 * (size_t)i, rec_n + 3 * (size_t)i, rec_d[i], scaled_score(rec_score[i], scale, scale_den), P->q_lb, P->t_lb,
-                              P->variant == LO_VARIANT_FRONTEND, Jr);
-                double ci; robustify(P->loss, P->loss_a, Jr, &ci);
-                c += ci; cnt++;
-                for (int a = 0; a < 8; a++) for (int b = 0; b < 8; b++) g[a * 8 + b] += Jr[a] * Jr[b];
-            }
-            C[w] = c; N[w] = cnt;
-        });
-    }
-    for (auto& x : th) x.join();
+    // one partial per chunk of kChunk queries, added in chunk order: the record does not depend on the number of threads or on who drew which chunk
+    const int chunks = std::max(1, (n_q + kChunk - 1) / kChunk);
+    std::vector<double> G((size_t)chunks * 64, 0.0), C(chunks, 0.0);
+    std::vector<int> N(chunks, 0);
+    const std::function<void(int)> job = [&](int w) {
+        const int lo = w * kChunk, hi = std::min(n_q, lo + kChunk);
+        double* g = G.data() + (size_t)w * 64; double c = 0; int cnt = 0;
+        for (int i = lo; i < hi; i++) {
+            if (!valid[i]) continue;
+            double Jr[8];
+            lo_eval_plane(t, q, rec_cp + 3 * (size_t)i, rec_n + 3 * (size_t)i, rec_d[i], scaled_score(rec_score[i], scale, scale_den), P->q_lb, P->t_lb,
+                          P->variant == LO_VARIANT_FRONTEND, Jr);
+            double ci; robustify(P->loss, P->loss_a, Jr, &ci);
+            c += ci; cnt++;
+            for (int a = 0; a < 8; a++) for (int b = 0; b < 8; b++) g[a * 8 + b] += Jr[a] * Jr[b];
+        }
+        C[w] = c; N[w] = cnt;
+    };
+    if (nthreads <= 1 || chunks < 2) for (int w = 0; w < chunks; w++) job(w);
+    else pool().run(chunks, nthreads, job);
     for (int k = 0; k < 64; k++) gram[k] = 0;
     double c = 0; int cnt = 0;
-    for (int w = 0; w < nthreads; w++) { for (int k = 0; k < 64; k++) gram[k] += G[(size_t)w * 64 + k]; c += C[w]; cnt += N[w]; }
+    for (int w = 0; w < chunks; w++) { for (int k = 0; k < 64; k++) gram[k] += G[(size_t)w * 64 + k]; c += C[w]; cnt += N[w]; }
     *cost = c; *count = cnt;
 }
+
+// ------------------------------------------------------------------------------------------
+// One scan registration entirely in C (round 5, the CPU baseline of bench.py): `n_iters` outer iterations of the ROT / Livox / front-end surf matcher
+// — association pose from the body pose (L/src/BackendFusion.cpp:929-930), findCorrespondingSurfFeatures over all queries, linearisation with the count scaling
+// of R/src/BackendFusion.cpp:861 when scale_num > 0, one Gauss-Newton step — on the persistent pool, no allocation and no interpreter between the stages.
+// The same functions as the per-stage entry points above; the record of every iteration is the chunk-ordered sum of lo_linearize_surf_mt.
+// t, q: body pose, in / out.  Returns the number of iterations whose step was applied; counts_out (optional, n_iters ints) receives the correspondences per iteration.
+// ------------------------------------------------------------------------------------------
+extern "C" int lo_register_surf(void* tree, const float* map_xyz, int n_map, const float* q_xyz, int n_q, double t[3], double q[4], const lo_params* P,
+                                double scale_num, int n_iters, int nthreads, int* counts_out) {
+    std::vector<unsigned char> valid((size_t)n_q);
+    std::vector<int> nn_idx((size_t)n_q * 5);
+    std::vector<float> nn_d2((size_t)n_q * 5), cp((size_t)n_q * 3), nrm((size_t)n_q * 3), d((size_t)n_q);
+    std::vector<double> score((size_t)n_q);
+    int applied = 0;
+    for (int it = 0; it < n_iters; it++) {
+        Q4 Q{q[0], q[1], q[2], q[3]}, Q2 = Q; V3 T{t[0], t[1], t[2]}, T2 = T;
+        if (P->variant != LO_VARIANT_FRONTEND) {
+            const double n2 = P->q_lb[0] * P->q_lb[0] + P->q_lb[1] * P->q_lb[1] + P->q_lb[2] * P->q_lb[2] + P->q_lb[3] * P->q_lb[3];
+            const Q4 qi{P->q_lb[0] / n2, -P->q_lb[1] / n2, -P->q_lb[2] / n2, -P->q_lb[3] / n2};
+            Q2 = qmul(Q, qi);
+            T2 = T - qrot(Q2, V3{P->t_lb[0], P->t_lb[1], P->t_lb[2]});
+        }
+        const double pq[4] = {Q2.w, Q2.x, Q2.y, Q2.z}, pt[3] = {T2.x, T2.y, T2.z};
+        const int cnt = lo_associate_surf(tree, map_xyz, nullptr, n_map, q_xyz, nullptr, n_q, pq, pt, P, nthreads, valid.data(), nn_idx.data(), nn_d2.data(),
+                                          cp.data(), nrm.data(), d.data(), score.data());
+        if (counts_out) counts_out[it] = cnt;
+        double gram[64], cost; int c2;
+        lo_linearize_surf_mt(valid.data(), cp.data(), nrm.data(), d.data(), score.data(), n_q, t, q, P, scale_num > 0 ? scale_num : 1.0, scale_num > 0 ? std::max(cnt, 1) : 0, nthreads,
+                             gram, &cost, &c2);
+        if (lo_gn_step(gram, t, q, nullptr) == 0) applied++;
+    }
+    return applied;
+}
+

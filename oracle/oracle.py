@@ -166,6 +166,23 @@ def associate_edge(tree, q_xyz, pose_q, pose_t, P, nthreads=1):
     return out
 
 
+def pool_reset():
+    """Drops the worker threads of the persistent pool (they are re-created lazily and inherit the affinity mask of the calling thread at that moment)."""
+    lib().lo_pool_reset()
+
+
+def register_surf(tree, q_xyz, t, q, P, scale_num=0.0, n_iters=10, nthreads=1):
+    """One scan registration entirely in C (lo_register_surf): n_iters x (association pose, findCorrespondingSurfFeatures, linearisation, GN step) on the
+    persistent pool.  Returns (t, q, steps applied, correspondences per iteration)."""
+    q_xyz = _f32(q_xyz, 3)
+    t, q = _f64(t).copy(), _f64(q).copy()
+    counts = np.zeros(n_iters, np.int32)
+    lib().lo_register_surf.restype = C.c_int
+    applied = lib().lo_register_surf(C.c_void_p(tree.h), _p(tree.xyz), tree.n, _p(q_xyz), q_xyz.shape[0], _p(t), _p(q), C.byref(P), C.c_double(float(scale_num)),
+                                     int(n_iters), int(nthreads), _p(counts))
+    return t, q, int(applied), counts
+
+
 def linearize_surf(rec, t, q, P, scale=1.0, nthreads=1):
     gram = np.zeros(64, np.float64)
     cost = C.c_double(0)
