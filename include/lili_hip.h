@@ -472,6 +472,17 @@ int lili_s2m_iterate_window_sharded(lili_ctx* ctx, const int* slots, int n_slots
  *   lili_p2p_set_timeout  how long an exchange may wait for a peer (device time, default 10 s).  The FIRST exchange absorbs the ranks'
  *                     start-up skew (code-object load, data loading): keep it generous, or barrier the control plane first. */
 #define LILI_P2P_HANDLE_BYTES 64
+/* Slot-per-rank window (the split of the sliding window that scales, SURVEY §8e / L/src/BackendFusion.cpp:919-980): keyframe slots[i] lives on rank owner[i] at FULL
+ * size (all its queries; the other ranks hold only its pose slot) and every evaluation ends with ONE exchange of the n x LILI_GRAM_DOUBLES doubles in which each record has
+ * a single non-zero contributor — an all-gather carried by the rank-order sum of `allreduce` (lili_p2p_allreduce: inside the reduction launch).  No count exchange: the
+ * owner's count is the global one.  _linearize_: records of one evaluation at the slots' DEVICE poses into d_gram (device, n x LILI_GRAM_DOUBLES; identical on every
+ * rank, slot i's record = what lili_s2m_linearize_window returns for it on the owner, a -0.0 entry read as +0.0); _iterate_: n_iters x (association of the owned
+ * keyframes, their linearisation, exchange, Gauss-Newton update of EVERY slot on every rank).  Every rank must have set the same pose in every slot.  Async. */
+int lili_s2m_linearize_window_gather(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, const lili_s2m_params* params, const int* owner, int rank,
+                                     lili_allreduce_fn allreduce, void* comm, double* d_gram);
+int lili_s2m_iterate_window_gather(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, const lili_s2m_params* params, int n_iters, const int* owner, int rank,
+                                   lili_allreduce_fn allreduce, void* comm, double* d_gram);
+
 typedef struct lili_p2p lili_p2p;
 int lili_p2p_create(lili_ctx* ctx, int rank, int world, lili_p2p** out);
 int lili_p2p_handle(lili_p2p* comm, void* handle);

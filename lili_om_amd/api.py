@@ -187,6 +187,8 @@ _SIGS = {
     "lili_s2m_linearize_window_sharded": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(S2MParams), C.c_void_p, C.c_void_p,
                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lili_s2m_iterate_window_sharded": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(S2MParams), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lili_s2m_linearize_window_gather": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(S2MParams), C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lili_s2m_iterate_window_gather": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(S2MParams), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lili_host_alloc": (C.c_void_p, [C.c_size_t]),
     "lili_host_free": (None, [C.c_void_p]),
     "lili_p2p_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
@@ -512,6 +514,16 @@ class ScanToMapMatcher:
         arr = (C.c_int * len(slots))(*slots)
         self.ctx._chk(self.lib.lili_s2m_iterate_window_sharded(self.ctx.h, arr, len(slots), kind_mask, C.byref(self.params), int(n_iters), C.c_void_p(allreduce_fn),
                                                                C.c_void_p(comm), C.c_void_p(d_counts_ptr), C.c_void_p(d_gram_ptr)))
+
+    def linearize_window_gather(self, slots, owner, rank, d_gram_ptr, allreduce_fn=None, comm=None, kind_mask=MASK_SURF | MASK_EDGE):
+        """Slot-per-rank window: the records of one evaluation at the slots' device poses, gathered into d_gram (n x GRAM_DOUBLES, device)."""
+        arr, own = (C.c_int * len(slots))(*slots), (C.c_int * len(slots))(*owner)
+        self.ctx._chk(self.lib.lili_s2m_linearize_window_gather(self.ctx.h, arr, len(slots), kind_mask, C.byref(self.params), own, int(rank), allreduce_fn, comm, d_gram_ptr))
+
+    def iterate_window_gather(self, slots, n_iters, owner, rank, d_gram_ptr, allreduce_fn=None, comm=None, kind_mask=MASK_SURF | MASK_EDGE):
+        arr, own = (C.c_int * len(slots))(*slots), (C.c_int * len(slots))(*owner)
+        self.ctx._chk(self.lib.lili_s2m_iterate_window_gather(self.ctx.h, arr, len(slots), kind_mask, C.byref(self.params), int(n_iters), own, int(rank), allreduce_fn, comm,
+                                                              d_gram_ptr))
 
     def iterate_window(self, slots, n_iters, kind_mask=MASK_SURF):
         arr = (C.c_int * len(slots))(*[int(s) for s in slots])

@@ -39,7 +39,7 @@ template <bool TILED, int BS> __global__ void k_associate_edge(const float4*, co
 __global__ void k_block_order(const int*, int, int, int*);
 __global__ void k_associate_both(AssocArgs, AssocArgs, PoseArg, MatchParams);
 __global__ void k_linearize(LinArgs, LinArgs, PoseArg, MatchParams, const SlotState*, const int*, FuseTail);
-__global__ void k_reduce_partials(const double*, int, const double*, int, double*, SlotState*, int, P2PView, unsigned long long);
+__global__ void k_reduce_partials(const double*, int, const double*, int, double*, SlotState*, int, P2PView, unsigned long long, double*);
 __global__ void k_sum_counts(const int*, int, const int*, int, SlotState*, int*, P2PView);
 __global__ void k_gn_update(const double*, SlotState*);
 __global__ void k_pose_copy(SlotState*, const SlotState*);
@@ -212,7 +212,8 @@ int lili_ctx_create(lili_ctx** out, int device, void* stream) {
     bool ok = ctx->states.ensure(sizeof(SlotState) * LILI_MAX_SLOTS) == hipSuccess &&
               ctx->gram.ensure(sizeof(double) * LILI_GRAM_DOUBLES * LILI_MAX_SLOTS) == hipSuccess &&
               ctx->misc.ensure(kMiscAlloc) == hipSuccess &&
-
+              ctx->pose_pub.ensure(sizeof(double) * kPubReplicas * kPubStride * LILI_MAX_SLOTS) == hipSuccess &&
+              hipMemsetAsync(ctx->pose_pub.p, 0, sizeof(double) * kPubReplicas * kPubStride * LILI_MAX_SLOTS, ctx->stream) == hipSuccess &&
               hipMemsetAsync(ctx->states.p, 0, sizeof(SlotState) * LILI_MAX_SLOTS, ctx->stream) == hipSuccess &&
               hipMemsetAsync(ctx->gram.p, 0, sizeof(double) * LILI_GRAM_DOUBLES * LILI_MAX_SLOTS, ctx->stream) == hipSuccess;
     if (!ok) { lili_ctx_destroy(ctx); return LILI_E_HIP; }
@@ -968,7 +969,7 @@ static int launch_associate_coop(lili_ctx* ctx, int slot, int kind_mask, const P
     switch (L) { LILI_COOP_CASE(2) LILI_COOP_CASE(4) LILI_COOP_CASE(8) LILI_COOP_CASE(16) default: return 1; }
 #undef LILI_COOP_CASE
     if (lin) hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx->stream, (const double*)ps, A[0].nb, (const double*)pe, A[1].nb, d_out, ctx->state(slot),
-                                1 | (P.debug & 256), P2PView{}, 0ull);
+                                1 | (P.debug & 256), P2PView{}, 0ull, (double*)nullptr);
     HIPCHK(hipGetLastError());
     sl.use_global_counts = false;
     return LILI_OK;
@@ -1186,7 +1187,7 @@ static int launch_associate_lin_reduce(lili_ctx* ctx, int slot, int kind_mask, c
     else hipLaunchKernelGGL(k_associate_lin<kBlock>, dim3(A[0].nb + A[1].nb), dim3(kBlock), 0, ctx->stream, A[0], A[1], pa, P,
                             sl.k[0].partials_wave.as<double>(), sl.k[1].partials_wave.as<double>());
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx->stream, (const double*)sl.k[0].partials_wave.as<double>(), A[0].nb,
-                       (const double*)sl.k[1].partials_wave.as<double>(), A[1].nb, d_out, ctx->state(slot), 1 | (P.debug & 256), P2PView{}, 0ull);
+                       (const double*)sl.k[1].partials_wave.as<double>(), A[1].nb, d_out, ctx->state(slot), 1 | (P.debug & 256), P2PView{}, 0ull, (double*)nullptr);
     HIPCHK(hipGetLastError());
     sl.use_global_counts = false;
     return LILI_OK;
@@ -1224,7 +1225,7 @@ static int launch_linearize_reduce(lili_ctx* ctx, int slot, int kind_mask, const
     HIPCHK(hipGetLastError());
     if (!fz.mode) {
         hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx->stream, fz.part_surf, fz.nb_surf, fz.part_edge, fz.nb_edge, d_out, ctx->state(slot), (do_gn ? 1 : 0) | (P.debug & 256),
-                           xv ? *xv : P2PView{}, (pub_key && do_gn) ? *pub_key : 0ull);
+                           xv ? *xv : P2PView{}, (pub_key && do_gn) ? *pub_key : 0ull, ctx->pub_of(slot));
         HIPCHK(hipGetLastError());
     } else if (pub_key) *pub_key = 0ull;
     if (pub_key && !do_gn) *pub_key = 0ull;
@@ -1588,6 +1589,7 @@ static int associate_dev_impl(lili_ctx* ctx, int slot, int kind_mask, const lili
     pa.state = ctx->state(slot);
     pa.derive_assoc = params->variant == LILI_VARIANT_FRONTEND ? 0 : 1;
     pa.wait_key = wait_key;
+    pa.pub = ctx->pub_of(slot);
     MatchParams P = to_device_params(params);
     {   // small launches: several lanes per query
         int rc = launch_associate_coop(ctx, slot, kind_mask, pa, P, false, nullptr);
@@ -2078,6 +2080,74 @@ int lili_s2m_iterate_window_sharded(lili_ctx* ctx, const int* slots, int n_slots
         }
         if (count_scaled && (rc = lili_s2m_counts_window_sharded(ctx, slots, n_slots, kind_mask, allreduce, comm, d_counts)) != LILI_OK) return rc;
         if ((rc = linearize_window_impl(ctx, slots, n_slots, kind_mask, params, nullptr, nullptr, allreduce, comm, d_gram, 1)) != LILI_OK) return rc;
+    }
+    return LILI_OK;
+}
+
+// ---- slot-per-rank window (round 5; SURVEY §8e "the three keyframes of the window are also independent"): keyframe i of the window lives on rank
+// owner[i] at FULL size — all its queries, no shard — and every evaluation ends with ONE exchange of the n x 72 doubles in which every record has exactly one
+// non-zero contributor, i.e. an all-gather carried by the same rank-order sum (x + 0 + ... + 0: the owner's bits, except that a -0.0 entry becomes +0.0).  The ranks
+// that do not own a keyframe need neither its queries nor its records, only its pose slot (every rank applies the same Gauss-Newton update to the same record).
+// Counts need no exchange: the owner's count IS the global one (ROT residual scale, R/src/BackendFusion.cpp:843,861).  The latency floor of an iteration is the one of a
+// single full-size keyframe (the query-sharded modes shrink the association's throughput part but keep its latency chain — DESIGN §5), and K keyframes advance on K ranks.
+static int window_gather_impl(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, const lili_s2m_params* params, const int* owner, int rank,
+                              lili_allreduce_fn allreduce, void* comm, double* d_gram, int do_gn) {
+    ARGCHK(slots && n_slots >= 1 && n_slots <= LILI_MAX_SLOTS, "window_gather: 1..LILI_MAX_SLOTS slots");
+    ARGCHK((kind_mask & ~3) == 0 && kind_mask != 0 && owner && rank >= 0, "window_gather: bad argument");
+    int mine[LILI_MAX_SLOTS], n_mine = 0;
+    WindowArgs w{};
+    w.n = n_slots;
+    for (int i = 0; i < n_slots; i++) {
+        ARGCHK(slots[i] >= 0 && slots[i] < LILI_MAX_SLOTS && owner[i] >= 0, "window_gather: bad slot / owner");
+        for (int k = 0; k < i; k++) ARGCHK(slots[k] != slots[i], "window_gather: duplicate slot");
+        w.s[i].state = ctx->state(slots[i]);
+        if (owner[i] != rank) continue;             // a zero record from this rank: no partials (k_window_reduce sums nothing)
+        mine[n_mine++] = slots[i];
+        Slot& sl = ctx->slots[slots[i]];
+        sl.use_global_counts = false; sl.sticky_global_counts = false;
+        for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) {
+            KindSlot& ks = sl.k[kind];
+            if (!ks.has_records) return ctx->fail(LILI_E_STATE, "window_gather: associate the owned keyframes first");
+            if (ks.n_q == 0) continue;
+            if (kind == 0) { w.s[i].part_surf = ks.partials.as<double>(); w.s[i].nb_surf = ks.n_lin_blocks; }
+            else { w.s[i].part_edge = ks.partials.as<double>(); w.s[i].nb_edge = ks.n_lin_blocks; }
+        }
+    }
+    lili_p2p* p2p = nullptr;
+    if (!p2p_comm(ctx, allreduce, comm, &p2p)) return ctx->fail(LILI_E_STATE, "window_gather: the lili_p2p communicator has failed");
+    MatchParams P = to_device_params(params);
+    if (do_gn) P.no_cost = 1;
+    if (n_mine > 0) { const int rc = launch_linearize_window(ctx, mine, n_mine, kind_mask, nullptr, nullptr, P); if (rc != LILI_OK) return rc; }
+    const bool in_kernel = p2p != nullptr || allreduce == nullptr;
+    hipLaunchKernelGGL(k_window_reduce, dim3(1), dim3(1024), 0, ctx->stream, w, d_gram, (do_gn && in_kernel) ? 1 : 0, p2p ? lili_p2p_next_view(p2p) : P2PView{});
+    HIPCHK(hipGetLastError());
+    if (!in_kernel) {
+        if (allreduce(d_gram, d_gram, (size_t)LILI_GRAM_DOUBLES * n_slots, /*ncclFloat64*/ 8, /*ncclSum*/ 0, comm, (void*)ctx->stream) != 0)
+            return ctx->fail(LILI_E_HIP, "window_gather: exchange of the Gram records failed");
+        if (do_gn) { hipLaunchKernelGGL(k_window_gn, dim3(1), dim3(64), 0, ctx->stream, w, (const double*)d_gram); HIPCHK(hipGetLastError()); }
+    }
+    return LILI_OK;
+}
+int lili_s2m_linearize_window_gather(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, const lili_s2m_params* params, const int* owner, int rank,
+                                     lili_allreduce_fn allreduce, void* comm, double* d_gram) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(params && d_gram, "linearize_window_gather: null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    return window_gather_impl(ctx, slots, n_slots, kind_mask, params, owner, rank, allreduce, comm, d_gram, 0);
+}
+int lili_s2m_iterate_window_gather(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, const lili_s2m_params* params, int n_iters, const int* owner, int rank,
+                                   lili_allreduce_fn allreduce, void* comm, double* d_gram) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(n_iters >= 0 && params && d_gram && owner && slots, "iterate_window_gather: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    for (int it = 0; it < n_iters; it++) {
+        for (int i = 0; i < n_slots; i++) if (owner[i] == rank) {
+            ARGCHK(slots[i] >= 0 && slots[i] < LILI_MAX_SLOTS, "iterate_window_gather: bad slot");
+            const int rc = lili_s2m_associate_dev(ctx, slots[i], kind_mask, params);
+            if (rc != LILI_OK) return rc;
+        }
+        const int rc = window_gather_impl(ctx, slots, n_slots, kind_mask, params, owner, rank, allreduce, comm, d_gram, 1);
+        if (rc != LILI_OK) return rc;
     }
     return LILI_OK;
 }

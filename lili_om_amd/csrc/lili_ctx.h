@@ -132,6 +132,7 @@ struct lili_ctx {
     DevBuf staging;      // raw host clouds
     DevBuf fmt_out;      // lili_livox_custom_to_cloud output when the caller wants it on the host
     DevBuf gram;         // LILI_GRAM_DOUBLES per slot
+    DevBuf pose_pub;     // kPubReplicas x kPubStride doubles per slot: the pose a Gauss-Newton kernel publishes for the association launched behind it without a barrier (overlap_gn)
     DevBuf win_rec;      // lili_s2m_linearize_window: the n x LILI_GRAM_DOUBLES records of one evaluation of the window (k_window_reduce's output)
     DevBuf win_counts;   // lili_s2m_associate_window: [surf, edge] counts of every slot (k_window_counts' output)
     DevBuf misc;         // bbox words etc.
@@ -190,6 +191,7 @@ struct lili_ctx {
     int fail(int code, const std::string& m) { err = m; return code; }
     SlotState* state(int slot) { return states.as<SlotState>() + slot; }
     double* gram_of(int slot) { return gram.as<double>() + (size_t)slot * LILI_GRAM_DOUBLES; }
+    double* pub_of(int slot) { return pose_pub.as<double>() + (size_t)slot * kPubReplicas * kPubStride; }      // option overlap_gn: the slot's published-pose copies
 };
 
 #define HIPCHK(expr)                                                                                         \

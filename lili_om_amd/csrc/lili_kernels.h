@@ -43,12 +43,16 @@ struct SlotState {
     unsigned int reserved_;
     unsigned long long cnt_word;   // k_associate_coop's in-launch count barrier: [0,24) surf correspondences, [24,48) edge, [48,64) workgroups arrived; k_reduce_partials zeroes it
     unsigned long long epoch;   // fused linearisation launches of this slot so far: launch_key(epoch) tags the granules of the next one
-    // Round 5 — the pose of the last Gauss-Newton update PUBLISHED for an association launch that is already running (option "overlap_gn"): seven 16-byte granules
-    // {value, value ^ key}, key unique per update (the data is its own flag, as the partials of the fused tail); `wait_failed` is raised (sticky) by an association that
-    // gave up waiting.  Behind `epoch`: lili_s2m_pose_set does not touch them.
-    double pose_pub[14];
+    // Round 5, option "overlap_gn": raised (sticky) by an association launch that gave up waiting for the pose the Gauss-Newton kernel in front of it publishes
+    // (PosePub below).  Behind `epoch`: lili_s2m_pose_set does not touch it.
     unsigned long long wait_failed;
 };
+// The pose of the last Gauss-Newton update PUBLISHED for an association launch that is already running (option "overlap_gn"): seven 16-byte granules
+// {value, value ^ key}, key unique per update (the data is its own flag, as the partials of the fused tail), in kPubReplicas copies 128 bytes apart — the 3 125 waves
+// of the association poll, and all of them on ONE line queue up on one memory channel behind each other (and the publishing store behind them: measured, the overlap
+// then gains nothing); workgroup b polls copy b mod kPubReplicas.
+constexpr int kPubReplicas = 64;
+constexpr int kPubStride = 16;      // doubles per copy: 7 granules + padding to 128 bytes
 
 // Fused tail of a linearisation launch (see fused_tail in lili_s2m.hip)
 struct FuseTail {
@@ -67,6 +71,7 @@ struct PoseArg {
     double q[4];
     const SlotState* state;  // if non-null, the body pose is read from state->pose
     int derive_assoc;        // associate only: derive (Q2,T2) = (Q*q_lb^-1, T - Q2*t_lb) from the body pose
+    const double* pub;             // the slot's kPubReplicas x kPubStride published-pose copies (wait_key != 0)
     unsigned long long wait_key;   // associate only, != 0: the launch may have started BEFORE the reduction + GN kernel in front of it has finished (no barrier between the two
                                    // dispatches): the pose is taken from state->pose_pub once all seven granules carry this key
 };

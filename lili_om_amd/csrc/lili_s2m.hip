@@ -1091,7 +1091,7 @@ __global__ __launch_bounds__(1024) void k_block_order(const int* __restrict__ bl
 template <bool XCHG>
 __device__ __forceinline__ void reduce_partials_block(const double* part_surf, int nb_surf, const double* part_edge, int nb_edge,
                                                       double* __restrict__ out, SlotState* __restrict__ state, int do_gn, unsigned long long key, const P2PView& xv,
-                                                      unsigned long long pub_key = 0ull);   // defined below
+                                                      unsigned long long pub_key = 0ull, double* pub = nullptr);   // defined below
 __device__ __forceinline__ void fused_tail(const FuseTail& fz, unsigned long long key) {
     if (fz.mode != 1 && fz.mode != 2) return;      // 0: plain partials for k_reduce_partials; 3: publish only (the per-kind launches of merge_kinds = 0: the second launch reduces)
     if (blockIdx.x != gridDim.x - 1) return;
@@ -1177,9 +1177,9 @@ template __global__ void k_associate_lin<kBlock>(AssocArgs, AssocArgs, PoseArg, 
 
 // xq: the quaternion of state->pose, loaded by the caller at kernel start (its latency hides behind the partial loads).
 // Must be called by exactly ONE wave (lanes 0..63 of it).
-// pub_key != 0: the resulting pose (the unchanged one if the step was rejected) is also PUBLISHED as seven keyed granules in state->pose_pub for an association launch
-// that is already running behind this kernel (wait_published_pose, option "overlap_gn").
-__device__ void gn_update_block(const double* gram /*LDS or global, 64+*/, SlotState* __restrict__ state, const double xq[4], unsigned long long pub_key = 0ull) {
+// pub_key != 0: the resulting pose (the unchanged one if the step was rejected) is also PUBLISHED as seven keyed granules, kPubReplicas copies (lane l writes copy l), for
+// an association launch that is already running behind this kernel (wait_published_pose, option "overlap_gn").
+__device__ void gn_update_block(const double* gram /*LDS or global, 64+*/, SlotState* __restrict__ state, const double xq[4], unsigned long long pub_key = 0ull, double* pub = nullptr) {
     __shared__ double H[6][6];
     __shared__ double gvec[6];
     int tid = threadIdx.x & 63;
@@ -1208,6 +1208,7 @@ __device__ void gn_update_block(const double* gram /*LDS or global, 64+*/, SlotS
         if (tid < 36) H[a][b] = v; else gvec[a] = -v;
     }
     LILI_WAVE_SYNC();
+    double pz[7] = {0, 0, 0, x0, x1, x2, x3};
     if (tid == 0) {
         // 6x6 LDL^T solve entirely in registers (all indices are compile-time constants after unrolling): six dependent
         // divisions (1/d_j) instead of the 6 square roots + 27 divisions of a Cholesky with per-element divides — the
@@ -1254,7 +1255,6 @@ __device__ void gn_update_block(const double* gram /*LDS or global, 64+*/, SlotS
         }
 #pragma unroll
         for (int i = 0; i < 6; i++) if (!(d[i] == d[i])) okc = false;
-        double pz[7] = {0, 0, 0, x0, x1, x2, x3};
         if (pub_key) { pz[0] = state->pose[0]; pz[1] = state->pose[1]; pz[2] = state->pose[2]; }
         if (okc) {
             if (pub_key) { pz[0] += d[0]; pz[1] += d[1]; pz[2] += d[2]; state->pose[0] = pz[0]; state->pose[1] = pz[1]; state->pose[2] = pz[2]; }
@@ -1273,11 +1273,15 @@ __device__ void gn_update_block(const double* gram /*LDS or global, 64+*/, SlotS
             for (int i = 0; i < 6; i++) state->last_delta[i] = d[i];
             state->gn_status = 0;
         } else state->gn_status = 1;
-        if (pub_key) {
-#pragma unroll
-            for (int k = 0; k < 7; k++) store_granule(state->pose_pub + 2 * k, pz[k], pub_key);
-        }
         state->iters += 1;
+    }
+    if (pub_key) {          // lane 0's result to every lane, then one copy per lane: 7 x 64 sixteen-byte write-through stores
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)__double_as_longlong(pz[k]) & 0xffffffffull));
+            const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)__double_as_longlong(pz[k]) >> 32));
+            store_granule(pub + (size_t)tid * kPubStride + 2 * k, __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)), pub_key);
+        }
     }
 }
 
@@ -1331,7 +1335,7 @@ __device__ __forceinline__ bool sum_partial_chunk(const double* part, int nb, in
 template <bool XCHG>
 __device__ __forceinline__ void reduce_partials_block(const double* part_surf, int nb_surf, const double* part_edge, int nb_edge,
                                                       double* __restrict__ out, SlotState* __restrict__ state, int do_gn, unsigned long long key, const P2PView& xv,
-                                                      unsigned long long pub_key) {
+                                                      unsigned long long pub_key, double* pub) {
     tstamp(state, do_gn, (int)blockIdx.x, 8);
     const unsigned long long was_dead = XCHG ? p2p_dead_word(xv) : 0ull;      // requested first: the round trip hides behind the partial loads
     const double xq[4] = {state->pose[3], state->pose[4], state->pose[5], state->pose[6]};
@@ -1405,14 +1409,14 @@ __device__ __forceinline__ void reduce_partials_block(const double* part_surf, i
     if (key && lane == 0) state->epoch = state->epoch + 1ull;      // the next fused launch of this slot gets a new key (stream order)
     if (lane == 0) state->cnt_word = 0ull;                          // re-arms the count barrier of k_associate_coop (the next association of this slot comes after this launch)
     tstamp(state, do_gn, (int)blockIdx.x, 10);
-    if (do_gn & 1) gn_update_block(full, state, xq, pub_key);
+    if (do_gn & 1) gn_update_block(full, state, xq, pub_key, pub);
     tstamp(state, do_gn, (int)blockIdx.x, 11);
 }
 
 __global__ __launch_bounds__(kReduceThreads) void k_reduce_partials(const double* __restrict__ part_surf, int nb_surf,
                                                             const double* __restrict__ part_edge, int nb_edge,
-                                                            double* __restrict__ out, SlotState* __restrict__ state, int do_gn, P2PView v, unsigned long long pub_key) {
-    reduce_partials_block<true>(part_surf, nb_surf, part_edge, nb_edge, out, state, do_gn, 0ull, v, pub_key);
+                                                            double* __restrict__ out, SlotState* __restrict__ state, int do_gn, P2PView v, unsigned long long pub_key, double* pub) {
+    reduce_partials_block<true>(part_surf, nb_surf, part_edge, nb_edge, out, state, do_gn, 0ull, v, pub_key, pub);
 }
 
 // ================================================================================================

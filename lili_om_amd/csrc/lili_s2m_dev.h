@@ -519,17 +519,21 @@ __device__ __forceinline__ void load_granule(const double* g, unsigned long long
     lo = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     hi = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// The body pose of a slot as the kernel in front published it (gn_update_block, `pub_key`): lanes 0..6 of the wave poll one granule each until all seven carry the key.
-// The wait is bounded; a wave that gives up raises SlotState::wait_failed (sticky; lili_s2m_pose_get reports it) and carries on with what the slot holds.
-__device__ __forceinline__ void wait_published_pose(const SlotState* st, unsigned long long key, double pose[7]) {
+// The body pose of a slot as the kernel in front published it (gn_update_block, `pub_key`): lanes 0..6 of the wave read one granule each of the workgroup's copy — ONE
+// coalesced 112-byte request per poll, agent scope — until all seven carry the key.  The wait is bounded; a wave that gives up raises SlotState::wait_failed (sticky;
+// lili_s2m_pose_get reports it) and carries on with what the slot holds.
+__device__ __forceinline__ void wait_published_pose(const SlotState* st, const double* pub, unsigned long long key, double pose[7]) {
     const int lane = threadIdx.x & 63;
+    const double* g = pub + (size_t)(blockIdx.x & (kPubReplicas - 1)) * kPubStride + 2 * (lane < 7 ? lane : 0);
     unsigned long long lo = 0ull, hi = 0ull;
     bool ok = false;
-    for (unsigned sweep = 0; sweep < (1u << 22); sweep++) {
-        if (lane < 7) load_granule(st->pose_pub + 2 * lane, lo, hi);
+    for (unsigned sweep = 0; sweep < (1u << 21); sweep++) {
+        u32x4 d;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(d) : "v"(g) : "memory");
+        lo = ((unsigned long long)d.y << 32) | d.x; hi = ((unsigned long long)d.w << 32) | d.z;
         ok = lane >= 7 || ((lo ^ hi) == key);
         if (__all(ok)) break;
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(2);
     }
     if (!__all(ok)) {
         if (lane == 0) const_cast<SlotState*>(st)->wait_failed = 1ull;
@@ -542,7 +546,7 @@ __device__ __forceinline__ void wait_published_pose(const SlotState* st, unsigne
 __device__ __forceinline__ void load_assoc_pose(const PoseArg& pa, const MatchParams& P, dq& Q2, d3& T2) {
     if (pa.state) {
         double pp[7];
-        if (pa.wait_key) wait_published_pose(pa.state, pa.wait_key, pp);
+        if (pa.wait_key) wait_published_pose(pa.state, pa.pub, pa.wait_key, pp);
         else {
 #pragma unroll
             for (int k = 0; k < 7; k++) pp[k] = pa.state->pose[k];

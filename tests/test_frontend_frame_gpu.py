@@ -183,8 +183,8 @@ def test_cpp_host_runs_the_frame_loop(tmp_path):
         subprocess.check_call(["make", "-C", os.path.join(root, "examples"), "-s"])
     n_frames = 6
     frames = [synth.make_livox_scan(100 + f, origin=_circuit(f)[0], yaw=_circuit(f)[2], inject_bad=False) for f in range(n_frames)]
-    t_first, q_first = _circuit(0)[:2]
-    path = tmp_path / "frames.bin"
+    t_first, q_first = np.zeros(3), np.array([1.0, 0.0, 0.0, 0.0])      # the reference node's world frame IS the first scan's frame (abs_pose starts at identity): the
+    path = tmp_path / "frames.bin"                                       # start-up's self-map (frame 1 against its own features) presumes it
     write_frames_bin(path, frames, (t_first, q_first), reference_startup=True)
     out = subprocess.run([demo, str(path), "3"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, (out.stdout, out.stderr)
@@ -211,6 +211,6 @@ def test_cpp_host_runs_the_frame_loop(tmp_path):
             tok = lines[k]
             pose_c = np.array([float(v) for v in tok[3:10]])
             assert np.array_equal(pose_c, np.r_[t, q]), (k, pose_c, t, q)
-            assert int(tok[11]) == info["gn_status"] == 0 and int(tok[13]) == int(info["matched"]) and int(tok[17]) == info["n_query"]
+            assert (int(tok[11]), int(tok[13]), int(tok[17])) == (info["gn_status"], int(info["matched"]), info["n_query"]) and info["gn_status"] == 0, (k, tok[10:], info)
     finally:
         ctx.close()
