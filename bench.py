@@ -482,8 +482,9 @@ def main():
         m.iterate(0, 8, L.MASK_SURF)
         tp = m.debug_times(0)
         names = {0: "lin start", 1: "lin counts+loads done", 2: "lin math done", 3: "lin gram done", 4: "lin partial stored",
-                 8: "red start", 9: "red loads done", 10: "red record built", 11: "red gn done", 12: "reducer block start", 13: "red flags seen"}
-        base = tp[0]
+                 8: "red start", 9: "red loads done", 10: "red record built", 11: "red gn done",
+                 13: "PREVIOUS red start", 14: "PREVIOUS red record built", 5: "assoc workgroup 0 start", 6: "assoc workgroup 0 holds the pose"}
+        base = tp[13] if tp[13] else tp[0]
         for k in sorted(names, key=lambda k: tp[k]):
             print(f"{names[k]:26s} {(tp[k] - base) * 0.01:8.2f} us", file=sys.stderr)
         ctx.close()

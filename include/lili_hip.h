@@ -263,7 +263,7 @@ int lili_localmap_get(lili_ctx* ctx, lili_feature_out* out);
  * it (L/src/Preprocessing.cpp:219-401): extraction -> down_size_filter_surf (L:155, 320-322) -> scan-to-map iterations against the local map
  * of the last `width` frames (buildLocalMap L:280-303, downSampleCloud L:314-318, kd_tree_surf_last->setInputCloud L:490,
  * findCorrespondingSurfFeatures + LidarPlaneNormIncreFactor + HuberLoss L:352-413, 483-561) -> the frame joins the ring at the pose found
- * (transformCloud, L:292-297) and the NEXT frame's local map (concatenate + VoxelGrid + index) is built before the call returns.
+ * (transformCloud, L:292-297); the local map that includes it (concatenate + VoxelGrid + index) is built at the start of the next call, under that frame's extraction.
  * Everything between the scan and the returned pose stays in HBM: features, down-sampled queries, ring, map and pose never visit the host;
  * the host synchronises only for the counts that size the next launches and for the result.
  *   scan / curvature_offset / q_imu / livox : as lili_extract_livox
@@ -292,13 +292,17 @@ typedef struct lili_frontend_result {
     double t[3], q[4];
     int gn_status;      /* of the last update; 0 when the frame was not matched */
     int matched;        /* 0: first frame of a sequence, or a map of fewer than 10 points (L:485-488): pose = prediction */
-    int32_t n_edge, n_surf, n_query, n_map_raw, n_map;   /* features, down-sampled queries, ring points and map points of the NEXT frame's map */
+    int32_t n_edge, n_surf, n_query, n_map_raw, n_map;   /* features, down-sampled queries; ring points and map points of the map built in this call (0 when none was pending) */
     double stage_us[8];
 } lili_frontend_result;
 int lili_frontend_frame(lili_ctx* ctx, const lili_cloud* scan, int curvature_offset, const double q_imu[4], const lili_livox_params* livox,
                         const lili_s2m_params* match, const lili_frontend_options* opt, const double t_pred[3], const double q_pred[4],
                         lili_frontend_result* res);
 int lili_frontend_reset(lili_ctx* ctx);
+/* lili_frontend_frame leaves the local map WITH the frame it has just pushed to the next call, which builds it under its own extraction (res->n_map_raw / n_map
+ * describe the map the frame was matched against).  lili_frontend_flush builds it now — for a caller that reads the map between frames (lili_localmap_get,
+ * lili_map_info) or ends a sequence.  Blocking; n_map_raw / n_map optional. */
+int lili_frontend_flush(lili_ctx* ctx, const lili_s2m_params* match, const lili_frontend_options* opt, int32_t* n_map_raw, int32_t* n_map);
 
 /* ---- scan-to-map matcher -------------------------------------------------------------------- */
 

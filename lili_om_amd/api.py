@@ -142,6 +142,7 @@ _SIGS = {
     "lili_frontend_frame": (C.c_int, [C.c_void_p, C.POINTER(Cloud), C.c_int, C.c_void_p, C.POINTER(LivoxParams), C.POINTER(S2MParams), C.POINTER(FrontendOptions), C.c_void_p, C.c_void_p,
                                       C.POINTER(FrontendResult)]),
     "lili_frontend_reset": (C.c_int, [C.c_void_p]),
+    "lili_frontend_flush": (C.c_int, [C.c_void_p, C.POINTER(S2MParams), C.POINTER(FrontendOptions), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "lili_voxel_filter": (C.c_int, [C.c_void_p, C.POINTER(Cloud), C.c_float, C.POINTER(FeatureOut), C.c_void_p]),
     "lili_localmap_reset": (C.c_int, [C.c_void_p, C.c_int]),
     "lili_localmap_push": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Cloud), C.c_void_p, C.c_void_p, C.c_int]),
@@ -786,6 +787,12 @@ class FrontendOdometry:
     def reset(self):
         self.ctx._chk(self.lib.lili_frontend_reset(self.ctx.h))
         self.n_frames = 0
+
+    def flush(self):
+        """Builds the local map of everything pushed so far (the frame call leaves that to the next frame); returns (ring points, map points)."""
+        a, b = C.c_int32(0), C.c_int32(0)
+        self.ctx._chk(self.lib.lili_frontend_flush(self.ctx.h, C.byref(self.params), C.byref(self.opt), C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def frame(self, scan, t_pred, q_pred, q_imu=(1.0, 0, 0, 0), timing=False):
         """scan: (n,5) float32 rows x, y, z, intensity, curvature (host; page-locked memory is read in place) or a Cloud.  Returns (t, q, info)."""

@@ -113,22 +113,58 @@ static MatchParams to_device_params(const lili_s2m_params* p) {
 }
 
 constexpr size_t kPinBytes = 64 * 1024;
+// Round 5: the small reads of a synchronisation are gathered by ONE kernel that writes them into the page-locked scratch across PCIe (k_readback_gather), enqueued by
+// lili_readback_finish right before it synchronises — a frame of the front-end pipeline issued eleven 4-us copy launches for its counts, boxes, flags and pose.  The
+// sources are therefore read at FINISH time: every caller adds its items behind the kernels that produce them and enqueues nothing that rewrites them before the finish.
+// An item on another stream than the context's, a large one, or a full table goes the old way (a copy enqueued at add time).
+namespace lili {
+constexpr int kGatherMax = 12;
+struct GatherTable { const unsigned char* src[kGatherMax]; unsigned off[kGatherMax], bytes[kGatherMax]; int n; };
+__global__ __launch_bounds__(256) void k_readback_gather(GatherTable t, unsigned char* __restrict__ dst) {
+    for (int k = 0; k < t.n; k++) {
+        const unsigned char* s = t.src[k];
+        unsigned char* d = dst + t.off[k];
+        const unsigned nb = t.bytes[k];
+        if (((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d) | nb) & 3u) == 0) {
+            for (unsigned i = threadIdx.x; i < nb / 4; i += 256) reinterpret_cast<unsigned*>(d)[i] = reinterpret_cast<const unsigned*>(s)[i];
+        } else for (unsigned i = threadIdx.x; i < nb; i += 256) d[i] = s[i];
+    }
+}
+}  // namespace lili
 int lili_readback_add(lili_ctx* ctx, void* dst, const void* d_src, size_t bytes, hipStream_t stream) {
     if (bytes == 0) return LILI_OK;
     hipStream_t s = stream ? stream : ctx->stream;
-    if (!ctx->h_pin) HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pin), kPinBytes, hipHostMallocDefault));
+    if (!ctx->h_pin) {
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pin), kPinBytes, hipHostMallocDefault));
+        void* d = nullptr;
+        if (hipHostGetDevicePointer(&d, ctx->h_pin, 0) != hipSuccess) { (void)hipGetLastError(); d = nullptr; }
+        ctx->h_pin_dev = static_cast<unsigned char*>(d);
+    }
     const size_t off = (ctx->h_pin_used + 15) & ~(size_t)15;
     if (off + bytes > kPinBytes) {        // (does not happen with the library's own reads; a large one goes the plain way)
         HIPCHK(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, s));
         return LILI_OK;
     }
-    HIPCHK(hipMemcpyAsync(ctx->h_pin + off, d_src, bytes, hipMemcpyDeviceToHost, s));
+    const bool lazy = ctx->h_pin_dev && s == ctx->stream && bytes <= 16384 && ctx->readback_gather && (int)ctx->h_pin_lazy.size() < lili::kGatherMax;
+    if (lazy) ctx->h_pin_lazy.push_back({d_src, off, bytes});
+    else HIPCHK(hipMemcpyAsync(ctx->h_pin + off, d_src, bytes, hipMemcpyDeviceToHost, s));
     ctx->h_pin_items.push_back({dst, off, bytes});
     ctx->h_pin_used = off + bytes;
     return LILI_OK;
 }
 int lili_readback_finish(lili_ctx* ctx, hipStream_t stream) {
-    const hipError_t e = hipStreamSynchronize(stream ? stream : ctx->stream);
+    hipStream_t s = stream ? stream : ctx->stream;
+    hipError_t e = hipSuccess;
+    if (!ctx->h_pin_lazy.empty()) {      // (lazy items are always on the context's stream; a finish of another stream synchronises the context's as well)
+        lili::GatherTable t{};
+        t.n = (int)ctx->h_pin_lazy.size();
+        for (int k = 0; k < t.n; k++) { t.src[k] = static_cast<const unsigned char*>(ctx->h_pin_lazy[k].src); t.off[k] = (unsigned)ctx->h_pin_lazy[k].off; t.bytes[k] = (unsigned)ctx->h_pin_lazy[k].bytes; }
+        hipLaunchKernelGGL(lili::k_readback_gather, dim3(1), dim3(256), 0, ctx->stream, t, ctx->h_pin_dev);
+        e = hipGetLastError();
+        ctx->h_pin_lazy.clear();
+        if (e == hipSuccess && s != ctx->stream) e = hipStreamSynchronize(ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e == hipSuccess) for (const auto& it : ctx->h_pin_items) std::memcpy(it.dst, ctx->h_pin + it.off, it.bytes);
     ctx->h_pin_items.clear();
     ctx->h_pin_used = 0;
@@ -288,6 +324,8 @@ int lili_set_option(lili_ctx* ctx, const char* name, int value) {
     if (std::strcmp(name, "rot_atan") == 0) { if (value != 1 && value != 2) return ctx->fail(LILI_E_ARG, "rot_atan must be 1 or 2"); ctx->rot_atan = value; return LILI_OK; }
     if (std::strcmp(name, "p2p_fusion") == 0) { ctx->no_p2p_fusion = value == 0; return LILI_OK; }
     if (std::strcmp(name, "nn_cache") == 0) { ctx->nn_cache = value != 0; for (auto& s : ctx->slots) for (auto& k : s.k) k.nn_cache_valid = false; return LILI_OK; }
+    if (std::strcmp(name, "readback_gather") == 0) { ctx->readback_gather = value != 0; return LILI_OK; }      // small device-to-host reads of one synchronisation in ONE gather launch (0: a copy launch each, A/B)
+    if (std::strcmp(name, "voxel_small") == 0) { ctx->voxel_small = value != 0; return LILI_OK; }      // VoxelGrid of <= 8192 points in one single-workgroup launch (0: the general chain, A/B)
     if (std::strcmp(name, "overlap_gn") == 0) { ctx->overlap_gn = value != 0; return LILI_OK; }      // lili_s2m_iterate*: the association behind a reduction + GN kernel starts without waiting for it (0: three barriers per iteration)
     if (std::strcmp(name, "max_cells") == 0) { if (value < 1) return ctx->fail(LILI_E_ARG, "max_cells must be positive"); ctx->max_cells = value; return LILI_OK; }
     return ctx->fail(LILI_E_ARG, std::string("unknown option ") + name);

@@ -142,6 +142,10 @@ struct lili_ctx {
     size_t h_pin_used = 0;
     struct PinItem { void* dst; size_t off, bytes; };
     std::vector<PinItem> h_pin_items;
+    struct LazyItem { const void* src; size_t off, bytes; };
+    std::vector<LazyItem> h_pin_lazy;          // items whose device-side read happens in lili_readback_finish's gather launch (k_readback_gather)
+    unsigned char* h_pin_dev = nullptr;        // the scratch as the device sees it
+    bool readback_gather = true;
     double* h_records = nullptr;   // page-locked landing area for LILI_MAX_SLOTS Gram records (+ 2 x LILI_MAX_SLOTS counts behind them)
     double* h_records_dev = nullptr;   // the same memory as the device sees it: the blocking calls' reduction kernels write their records THERE (round 4: no copy launch between the kernel and the host)
     DevBuf bin_hist, bin_start, bin_sums, bin_tcnt, bin_toff;   // query binning scratch
@@ -167,6 +171,8 @@ struct lili_ctx {
     bool persistent_iterate = false;  // lili_s2m_iterate* of small scans (<= 128 cooperative workgroups): one persistent launch per registration (k_iterate_coop).
                                       // Measured (tools/iter_time.py, profiles/r03_iter_time.json): 21.3 vs 19.6 us per outer iteration at 2 k queries (ROT), 17.2 vs 14.9
                                       // (front end) — two exchange hops through memory across the XCDs cost more than the launch boundaries they replace; off by default
+    bool frontend_commit_pending = false;   // lili_frontend_frame: the ring has a keyframe the local map does not hold yet (the commit runs at the start of the next frame, under its extraction)
+    bool voxel_small = true;     // lili_voxel_filter / lili_frontend_frame: clouds of <= 8192 points are filtered by ONE single-workgroup launch (k_voxel_small; 0: the general chain, A/B)
     bool overlap_gn = false;     // lili_s2m_iterate*, three-launch path: the reduction + GN kernel publishes the pose as keyed granules and the next association is launched without a
                                  // barrier against it (hipExtAnyOrderLaunch): its waves are dispatched and poll for the pose while the reduction still runs
     unsigned long long gn_seq = 0;   // published poses of this context so far (their keys never repeat)
@@ -220,3 +226,6 @@ bool lili_p2p_usable(const lili_p2p* c, const lili_ctx* ctx);
 int lili_voxel_filter_dev(lili_ctx* ctx, const float4* d_pts, int n, float leaf, const float4** d_out, int* n_out);
 int lili_localmap_push_dev(lili_ctx* ctx, int kind, const float4* d_pts, int n, const lili::SlotState* d_state, int width);
 int lili_localmap_ring_size(lili_ctx* ctx, int kind);
+// lili_extract_livox.hip -> lili_pipeline.hip: the extraction enqueued without its synchronisation, and the counts taken afterwards
+int lili_extract_livox_enqueue(lili_ctx* ctx, const lili_cloud* scan, int curvature_offset, const double q_imu[4], const lili_livox_params* params);
+int lili_extract_livox_complete(lili_ctx* ctx);

@@ -311,6 +311,7 @@ struct LivoxBuffers {
     int* h_counts = nullptr;          // page-locked {n_cut, n_edge, n_surf}, written by k_livox_pack3; h_counts_dev: the same memory as the device sees it
     int* h_counts_dev = nullptr;
     bool have = false;
+    bool pending = false;    // lili_extract_livox_enqueue: the counts' read-back is on the stream, lili_extract_livox_complete has not taken it yet
     bool armed = false;      // the ownership table holds "no owner" everywhere (k_livox_init once, k_livox_grid after every scan)
     void release() {
         for (DevBuf* b : {&und, &curv, &keep, &owner, &state, &cut_a, &cut_b, &cut_src, &cell_pt, &cell_curv, &cell_src, &blk_nedge, &blk_edge_cell,
@@ -379,16 +380,41 @@ static int livox_copy_out(lili_ctx* ctx, DevBuf& pack, const lili_feature_out* o
     return LILI_OK;
 }
 
+static int extract_livox_impl(lili_ctx* ctx, const lili_cloud* scan, int curvature_offset, const double q_imu[4], const lili_livox_params* params,
+                              lili_feature_out* cutted, lili_feature_out* edge, lili_feature_out* surf, bool defer);
+
+// Internal (lili_ctx.h -> lili_pipeline.hip): the extraction ENQUEUED only — kernels and the read-back of its counts are on the stream, nothing is waited for; the features
+// stay in the extractor's device lists.  lili_extract_livox_complete takes the counts once a synchronisation of the context's stream has delivered them (it
+// synchronises itself if none has) — lili_frontend_frame puts the previous frame's local-map commit, which synchronises anyway, between the two.
+int lili_extract_livox_enqueue(lili_ctx* ctx, const lili_cloud* scan, int curvature_offset, const double q_imu[4], const lili_livox_params* params) {
+    return extract_livox_impl(ctx, scan, curvature_offset, q_imu, params, nullptr, nullptr, nullptr, true);
+}
+int lili_extract_livox_complete(lili_ctx* ctx) {
+    auto* B = livox_of(ctx);
+    if (!B->pending) return ctx->fail(LILI_E_STATE, "extract_livox_complete: nothing enqueued");
+    B->pending = false;
+    if (!ctx->h_pin_items.empty()) { const int rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }
+    B->have = true;
+    return LILI_OK;
+}
+
 extern "C" {
 
 int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offset, const double q_imu[4], const lili_livox_params* params,
                        lili_feature_out* cutted, lili_feature_out* edge, lili_feature_out* surf) {
+    return extract_livox_impl(ctx, scan, curvature_offset, q_imu, params, cutted, edge, surf, false);
+}
+
+}  // extern "C"
+
+static int extract_livox_impl(lili_ctx* ctx, const lili_cloud* scan, int curvature_offset, const double q_imu[4], const lili_livox_params* params,
+                              lili_feature_out* cutted, lili_feature_out* edge, lili_feature_out* surf, bool defer) {
     if (!ctx) return LILI_E_ARG;
     ARGCHK(scan && q_imu && params, "extract_livox: null argument");
     ARGCHK(scan->aux_offset >= 0 && curvature_offset >= 0 && (size_t)curvature_offset + 4 <= scan->stride, "extract_livox: intensity (aux_offset) and curvature offsets are required");
     HIPCHK(hipSetDevice(ctx->device));
     auto* B = livox_of(ctx);
-    B->have = false;
+    B->have = false; B->pending = false;
     ARGCHK(scan->n == 0 || scan->data, "cloud: null data");
     ARGCHK(scan->stride >= 12 && scan->stride % 4 == 0 && (size_t)scan->aux_offset + 4 <= scan->stride, "cloud: stride must be a multiple of 4 and >= 12, offsets inside the point");
     ARGCHK(scan->n < (size_t)1 << 31, "cloud: too many points");
@@ -514,6 +540,7 @@ int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offs
     if (rc != LILI_OK) return rc;
     const bool counts_direct = all3 && B->h_counts_dev != nullptr;      // the counts arrive with the packing kernel
     if (!counts_direct) { rc = lili_readback_add(ctx, &B->host, st, sizeof(LivoxState)); if (rc) return rc; }
+    if (defer && !counts_direct && !cut_early) { B->pending = true; return LILI_OK; }      // (no caller buffers in this mode: nothing else to do once the counts are there)
     if (cut_early) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->join_ev[1], 0));
     size_t sent_e = 0, sent_s = 0;      // records already in the caller's buffers when the counts arrive
     auto send = [&](DevBuf& pack, const lili_feature_out* o, size_t first, size_t last) -> int {      // records [first, last) of a packed list
@@ -546,6 +573,8 @@ int lili_extract_livox(lili_ctx* ctx, const lili_cloud* scan, int curvature_offs
     if (more) HIPCHK(hipStreamSynchronize(ctx->stream));
     return LILI_OK;
 }
+
+extern "C" {
 
 // Intermediate products of the last lili_extract_livox (parity tests): counts = {n_cut, n_edge, n_surf};
 // cut_src[n_cut], cell_src[24000] (-1 = empty), edge_cell[n_edge], surf_cell[n_surf] (cell = line * 4000 + column).

@@ -29,7 +29,24 @@ extern "C" {
 
 int lili_frontend_reset(lili_ctx* ctx) {
     if (!ctx) return LILI_E_ARG;
+    ctx->frontend_commit_pending = false;
     return lili_localmap_reset(ctx, LILI_KIND_SURF);
+}
+
+// Builds the local map of the keyframes pushed so far if the last lili_frontend_frame left that to the next one (it does: the commit runs under the next frame's
+// extraction).  A caller that wants the map between frames (lili_localmap_get, lili_map_info) calls this first.  Blocking.
+int lili_frontend_flush(lili_ctx* ctx, const lili_s2m_params* match, const lili_frontend_options* opt, int32_t* n_map_raw, int32_t* n_map) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(match && opt && opt->leaf_map > 0, "frontend_flush: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    if (!ctx->frontend_commit_pending) return LILI_OK;
+    int64_t a = 0, b = 0;
+    const int rc = lili_localmap_commit(ctx, LILI_KIND_SURF, opt->leaf_map, match->kd_max_radius, &a, &b);
+    if (rc != LILI_OK) return rc;
+    ctx->frontend_commit_pending = false;
+    if (n_map_raw) *n_map_raw = (int32_t)a;
+    if (n_map) *n_map = (int32_t)b;
+    return LILI_OK;
 }
 
 int lili_frontend_frame(lili_ctx* ctx, const lili_cloud* scan, int curvature_offset, const double q_imu[4], const lili_livox_params* livox,
@@ -43,8 +60,18 @@ int lili_frontend_frame(lili_ctx* ctx, const lili_cloud* scan, int curvature_off
     auto stamp = [&](int k) { if (opt->want_timing) res->stage_us[k] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(); };
     *res = lili_frontend_result{};
     const int slot = opt->slot;
-    // ---- extraction (Preprocessing::cloudHandler): features stay in the extractor's device lists; ONE synchronisation for their counts
-    int rc = lili_extract_livox(ctx, scan, curvature_offset, q_imu, livox, nullptr, nullptr, nullptr);
+    // ---- extraction (Preprocessing::cloudHandler), enqueued only: features stay in the extractor's device lists.  Under its kernels the host builds the local map the
+    //      previous frame left pending (buildLocalMap + downSampleCloud + setInputCloud, L:280-318, 490) — that commit synchronises anyway and delivers the extraction's
+    //      counts with its own read-backs.
+    int rc = lili_extract_livox_enqueue(ctx, scan, curvature_offset, q_imu, livox);
+    if (rc != LILI_OK) return rc;
+    int64_t n_raw = 0, n_map = 0;
+    if (ctx->frontend_commit_pending && !(opt->flags & LILI_FRAME_SELF_MAP)) {
+        rc = lili_localmap_commit(ctx, LILI_KIND_SURF, opt->leaf_map, match->kd_max_radius, &n_raw, &n_map);
+        if (rc != LILI_OK) return rc;
+        ctx->frontend_commit_pending = false;
+    }
+    rc = lili_extract_livox_complete(ctx);
     if (rc != LILI_OK) return rc;
     lili_cloud d_edge{}, d_surf{};
     rc = lili_extract_livox_device(ctx, &d_edge, &d_surf);
@@ -93,16 +120,15 @@ int lili_frontend_frame(lili_ctx* ctx, const lili_cloud* scan, int curvature_off
     }
     res->matched = matched ? 1 : 0;
     stamp(2);
-    // ---- the frame joins the ring at the pose the iterations reached (read by the kernel from the slot's device state), and the NEXT frame's
-    //      local map is built now: its read-backs (sizes, box) and the pose come back in the same synchronisation
+    // ---- the frame joins the ring at the pose the iterations reached (read by the kernel from the slot's device state); the local map with it is built at the start of
+    //      the next frame (or by lili_frontend_flush).  ONE synchronisation: the pose.
     rc = lili_localmap_push_dev(ctx, LILI_KIND_SURF, ctx->slots[slot].k[LILI_KIND_SURF].q.as<float4>(), (opt->flags & LILI_FRAME_PUSH_EMPTY) ? 0 : n_q, ctx->state(slot), opt->width);
     if (rc != LILI_OK) return rc;
     SlotState st{};
     rc = lili_readback_add(ctx, &st, ctx->state(slot), sizeof(st));
     if (rc != LILI_OK) return rc;
-    int64_t n_raw = 0, n_map = 0;
-    rc = lili_localmap_commit(ctx, LILI_KIND_SURF, opt->leaf_map, match->kd_max_radius, &n_raw, &n_map);
-    if (!ctx->h_pin_items.empty()) { const int rb = lili_readback_finish(ctx); if (rc == LILI_OK) rc = rb; }      // (a commit without a read-back of its own)
+    ctx->frontend_commit_pending = true;
+    rc = lili_readback_finish(ctx);
     if (rc != LILI_OK) return rc;
     stamp(3);
     for (int i = 0; i < 3; i++) res->t[i] = st.pose[i];

@@ -546,10 +546,19 @@ __device__ __forceinline__ void wait_published_pose(const SlotState* st, const d
 __device__ __forceinline__ void load_assoc_pose(const PoseArg& pa, const MatchParams& P, dq& Q2, d3& T2) {
     if (pa.state) {
         double pp[7];
+        // profiling aid (LILI_DEBUG bit 256, bench.py LILI_PHASES): workgroup 0 stamps its start and the moment it holds the pose, and snapshots the stamps the
+        // reduction + GN kernel in front of it left (its start / record built), which that kernel's next launch overwrites
+        const bool probe = (P.debug & 256) && blockIdx.x == 0 && threadIdx.x == 0;
+        if (probe) const_cast<SlotState*>(pa.state)->tprof[5] = (long long)__builtin_amdgcn_s_memrealtime();
         if (pa.wait_key) wait_published_pose(pa.state, pa.pub, pa.wait_key, pp);
         else {
 #pragma unroll
             for (int k = 0; k < 7; k++) pp[k] = pa.state->pose[k];
+        }
+        if (probe) {
+            SlotState* w = const_cast<SlotState*>(pa.state);
+            long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(pp[0]) : "memory");
+            w->tprof[6] = t_; w->tprof[13] = w->tprof[8]; w->tprof[14] = w->tprof[10];
         }
         const double* s = pp;
         dq Q{s[3], s[4], s[5], s[6]};

@@ -157,6 +157,10 @@ __global__ __launch_bounds__(kSortBlock) void k_sort_scatter8(const unsigned* __
     }
 }
 
+// arms the six ordered-uint words of a bounding box (min xyz = all ones, max xyz = 0) — a kernel, not a host-to-device copy of 24 bytes from pageable memory, which the
+// runtime stages and serialises (~6 us of API time each)
+__global__ void k_box_init(unsigned* __restrict__ mm) { if (threadIdx.x < 6) mm[threadIdx.x] = threadIdx.x < 3 ? 0xFFFFFFFFu : 0u; }
+
 struct VoxDev { float inv_leaf; int min_b[3]; int mul[3]; unsigned sentinel; };   // sentinel = number of voxels of the bounding box: key of non-finite points
 
 __global__ void k_vox_key(const float4* __restrict__ pts, int n, VoxDev V, unsigned* __restrict__ keys, int* __restrict__ vals) {
@@ -193,26 +197,28 @@ __global__ void k_vox_heads(const unsigned* __restrict__ keys, int n, unsigned s
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) flags[i] = (keys[i] != sentinel && (i == 0 || keys[i] != keys[i - 1])) ? 1 : 0;
 }
-__global__ void k_vox_centroid(const unsigned* __restrict__ keys, const int* __restrict__ vals, const int* __restrict__ slot /*exclusive scan of flags, [n+1]*/,
+__global__ __launch_bounds__(256) void k_vox_centroid(const unsigned* __restrict__ keys, const int* __restrict__ vals, const int* __restrict__ slot /*exclusive scan of flags, [n+1]*/,
                                const float4* __restrict__ pts, int n, unsigned sentinel, float4* __restrict__ out, int* __restrict__ out_cnt) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (!(i == 0 || keys[i] != keys[i - 1])) return;
     unsigned k = keys[i];
     if (k == sentinel) return;
-    // CentroidPoint: float accumulators, members added in sorted (= input) order.  Eight members per trip: their keys and values are
-    // requested together and the eight point gathers after them — two memory round trips per eight members instead of three per
-    // member (voxels next to the sensor hold hundreds of points of a raw scan; the sum itself has to stay sequential).
+    // CentroidPoint: float accumulators, members added in sorted (= input) order.  kMem members per trip: their keys and values are requested together and the point
+    // gathers after them — two memory round trips per kMem members instead of three per member (voxels next to the sensor hold hundreds of points of a raw scan; the
+    // sum itself has to stay sequential).  Round 5: 32 per trip (8 before): the launch lasts as long as its fullest voxel's chain of trips — 31 us for the 20 k surf
+    // features of a Livox frame.
+    constexpr int kMem = 32;
     float sx = 0.f, sy = 0.f, sz = 0.f, sa = 0.f; int c = 0;
     bool more = true;
-    for (int m = i; more && m < n; m += 8) {
-        unsigned kk[8]; int vv[8]; float4 pp[8];
+    for (int m = i; more && m < n; m += kMem) {
+        unsigned kk[kMem]; int vv[kMem]; float4 pp[kMem];
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const int mm = min(m + u, n - 1); kk[u] = keys[mm]; vv[u] = vals[mm]; }
+        for (int u = 0; u < kMem; u++) { const int mm = min(m + u, n - 1); kk[u] = keys[mm]; vv[u] = vals[mm]; }
 #pragma unroll
-        for (int u = 0; u < 8; u++) pp[u] = pts[vv[u]];
+        for (int u = 0; u < kMem; u++) pp[u] = pts[vv[u]];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < kMem; u++) {
             if (more && m + u < n && kk[u] == k) { sx += pp[u].x; sy += pp[u].y; sz += pp[u].z; sa += pp[u].w; c++; }
             else more = false;
         }
@@ -221,6 +227,110 @@ __global__ void k_vox_centroid(const unsigned* __restrict__ keys, const int* __r
     int o = slot[i];
     out[o] = make_float4(sx / fn, sy / fn, sz / fn, sa / fn);
     if (out_cnt) out_cnt[o] = c;
+}
+
+// pcl::VoxelGrid of a SMALL cloud (<= kVoxSmallMax points: a Livox frame's surf features, the queries of the front end — L/src/LidarOdometry.cpp:320-322) in ONE
+// launch of one workgroup (round 5): bounding box, PCL's voxel index, stable sort, voxel heads, centroids.  The general path is a chain of ~14 launches with two host
+// round trips (box, count) — 115 us for 3 k points, of which the GPU works ~30.  Same arithmetic as k_vox_key / k_vox_centroid: the index
+// (i0 - min0) + (i1 - min1) * dx + (i2 - min2) * dx * dy with i = floor(p * inverse_leaf), points sorted by (index, input position) — a bitonic network on 64-bit keys
+// in LDS —, members of a voxel summed in input order with float accumulators, non-finite points skipped.  res[0] = number of voxels, res[1] = 1 if the voxel index
+// would not fit 31 bits (the caller then takes the general path, which reports PCL's overflow error), 2 if no point is finite.
+constexpr int kVoxSmallMax = 8192, kVoxSmallThreads = 1024;
+__global__ __launch_bounds__(kVoxSmallThreads) void k_voxel_small(const float4* __restrict__ pts, int n, float inv_leaf, float4* __restrict__ out, int* __restrict__ out_cnt,
+                                                                   int* __restrict__ res) {
+    __shared__ unsigned long long key[kVoxSmallMax];
+    __shared__ int red[6][kVoxSmallThreads / 64];
+    __shared__ int box[6];
+    __shared__ int wsum[kVoxSmallThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int np2 = 64; while (np2 < n) np2 <<= 1;
+    // ---- bounding box of the finite points in voxel coordinates
+    int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {-0x7fffffff, -0x7fffffff, -0x7fffffff};
+    for (int i = tid; i < n; i += kVoxSmallThreads) {
+        const float4 p = pts[i];
+        if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+            const int c[3] = {(int)floorf(p.x * inv_leaf), (int)floorf(p.y * inv_leaf), (int)floorf(p.z * inv_leaf)};
+#pragma unroll
+            for (int k = 0; k < 3; k++) { mn[k] = min(mn[k], c[k]); mx[k] = max(mx[k], c[k]); }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        for (int o = 32; o > 0; o >>= 1) { mn[k] = min(mn[k], __shfl_xor(mn[k], o)); mx[k] = max(mx[k], __shfl_xor(mx[k], o)); }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { red[k][wave] = mn[k]; red[3 + k][wave] = mx[k]; }
+    }
+    __syncthreads();
+    if (tid < 6) {
+        int v = red[tid][0];
+        for (int w = 1; w < kVoxSmallThreads / 64; w++) v = tid < 3 ? min(v, red[tid][w]) : max(v, red[tid][w]);
+        box[tid] = v;
+    }
+    __syncthreads();
+    const bool any = box[0] <= box[3];
+    const long long dx = any ? (long long)box[3] - box[0] + 1 : 1, dy = any ? (long long)box[4] - box[1] + 1 : 1, dz = any ? (long long)box[5] - box[2] + 1 : 1;
+    const bool overflow = (double)dx * (double)dy * (double)dz > 2147483647.0;
+    if (overflow || !any) {
+        if (tid == 0) { res[0] = 0; res[1] = overflow ? 1 : 2; }      // 2: no finite point at all (an error, as in the general path)
+        return;
+    }
+    // ---- keys: (voxel index << 13) | input position; non-finite points and the padding sort last
+    for (int i = tid; i < np2; i += kVoxSmallThreads) {
+        unsigned long long k = ~0ull;
+        if (i < n) {
+            const float4 p = pts[i];
+            if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+                const long long i0 = (long long)(int)floorf(p.x * inv_leaf) - box[0], i1 = (long long)(int)floorf(p.y * inv_leaf) - box[1], i2 = (long long)(int)floorf(p.z * inv_leaf) - box[2];
+                k = ((unsigned long long)(i0 + i1 * dx + i2 * dx * dy) << 13) | (unsigned long long)i;
+            }
+        }
+        key[i] = k;
+    }
+    __syncthreads();
+    // ---- bitonic sort (ascending)
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < np2 / 2; t += kVoxSmallThreads) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));      // the lower partner of the t-th pair at distance j
+                const int l = i | j;
+                const unsigned long long a = key[i], b = key[l];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) { key[i] = b; key[l] = a; }
+            }
+            __syncthreads();
+        }
+    // ---- voxel heads and their output slots (exclusive scan of the head flags over the sorted positions)
+    const int per = (np2 + kVoxSmallThreads - 1) / kVoxSmallThreads;      // consecutive positions per thread (<= 8)
+    const int base = tid * per;
+    int heads = 0;
+    for (int u = 0; u < per; u++) {
+        const int i = base + u;
+        if (i < np2 && key[i] != ~0ull && (i == 0 || (key[i] >> 13) != (key[i - 1] >> 13))) heads++;
+    }
+    int inc = heads;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int wofs = 0, total = 0;
+    for (int w = 0; w < kVoxSmallThreads / 64; w++) { const int t = wsum[w]; if (w < wave) wofs += t; total += t; }
+    int slot = wofs + inc - heads;
+    // ---- centroids: the thread that owns a head walks its voxel's members in sorted (= input) order
+    for (int u = 0; u < per; u++) {
+        const int i = base + u;
+        if (!(i < np2 && key[i] != ~0ull && (i == 0 || (key[i] >> 13) != (key[i - 1] >> 13)))) continue;
+        const unsigned long long v = key[i] >> 13;
+        float sx = 0.f, sy = 0.f, sz = 0.f, sa = 0.f; int c = 0;
+        for (int m = i; m < np2 && (key[m] >> 13) == v && key[m] != ~0ull; m++) {
+            const float4 p = pts[(int)(key[m] & 8191ull)];
+            sx += p.x; sy += p.y; sz += p.z; sa += p.w; c++;
+        }
+        const float fn = (float)c;
+        out[slot] = make_float4(sx / fn, sy / fn, sz / fn, sa / fn);
+        if (out_cnt) out_cnt[slot] = c;
+        slot++;
+    }
+    if (tid == 0) { res[0] = total; res[1] = 0; }
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
@@ -256,6 +366,38 @@ __global__ void k_sorted_gather(const float4* __restrict__ pts, const int* __res
     }
     out_pt[r] = p; out_key[r] = key; out_seq[r] = sq;
 }
+// The new keyframe of an incremental commit (<= kVoxSmallMax points: a frame's down-sampled features) sorted by absolute voxel key in ONE single-workgroup launch
+// (round 5): what k_bbox + k_vox_key_packed + four radix passes + k_sorted_gather produce in twelve launches — the points in (key, input position) order with
+// their keys and the keyframe's sequence number; *bad is raised for a point beyond the key range (the commit then rebuilds).  Bitonic network on (64-bit key,
+// 16-bit position) pairs in LDS.
+__global__ __launch_bounds__(kVoxSmallThreads) void k_sort_keyframe_small(const float4* __restrict__ pts, int n, float inv_leaf, unsigned seq, float4* __restrict__ out_pt,
+                                                                           unsigned long long* __restrict__ out_key, unsigned* __restrict__ out_seq, unsigned* __restrict__ bad) {
+    __shared__ unsigned long long key[kVoxSmallMax];
+    __shared__ unsigned short pos[kVoxSmallMax];
+    const int tid = threadIdx.x;
+    int np2 = 64; while (np2 < n) np2 <<= 1;
+    for (int i = tid; i < np2; i += kVoxSmallThreads) {
+        unsigned long long k = ~0ull;
+        if (i < n) { k = abs_voxel_key(pts[i], inv_leaf); if (k == ~0ull - 1ull) *bad = 1u; }
+        key[i] = k; pos[i] = (unsigned short)i;
+    }
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < np2 / 2; t += kVoxSmallThreads) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const unsigned long long a = key[i], b = key[l];
+                const unsigned short pa = pos[i], pb = pos[l];
+                const bool gt = a > b || (a == b && pa > pb);      // (key, input position): stable; the padding (key ~0, position >= n) sorts behind everything
+                const bool up = (i & k) == 0;
+                if (gt == up) { key[i] = b; key[l] = a; pos[i] = pb; pos[l] = pa; }
+            }
+            __syncthreads();
+        }
+    for (int r = tid; r < n; r += kVoxSmallThreads) { out_pt[r] = pts[pos[r]]; out_key[r] = key[r]; out_seq[r] = seq; }
+}
+
 struct DropSeqs { unsigned s[4]; int n; };
 __global__ void k_keep_flags(const unsigned* __restrict__ seq, long long n, DropSeqs d, int* __restrict__ flags) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -400,47 +542,50 @@ static lili_detail::VoxelBuffers* vox_of(lili_ctx* ctx) {
 // exclusive scan of a SHORT array (the digit histograms of a radix pass: 16 words per 2048 keys) by one workgroup in one launch — the
 // three-kernel scan spends ~10 us of launches on a few thousand words
 __global__ __launch_bounds__(1024) void k_scan_single(const int* __restrict__ in, int n, int* __restrict__ out /*[n+1]*/) {
-    __shared__ int wsum[16];
-    __shared__ int carry_s;
+    // Round 5: ONE pass with every item in registers — wave w owns the contiguous stretch [w R 256, (w + 1) R 256), R = ceil(n / 4096) <= 16 rows of 256 items, lane l
+    // items 4 l .. 4 l + 3 of every row (16-byte accesses, a contiguous kilobyte per wave instruction) — a wave scan per row with a running carry, ONE block barrier
+    // for the sixteen wave totals, then the stores.  Before: trips of 4096 items with three block barriers each (19 us for the 20-40 k flags of a frame's
+    // voxel filter / ring merge, three times per frame of the front-end pipeline).
+    __shared__ int wtot[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    // 4096 words per trip, 16 bytes per lane; the NEXT trip's words are requested before this trip's barriers (a trip used to cost ~2.8 us, most of it
-    // the load round trip that started only after the previous trip's last barrier)
-    int nx[4];
-    {
-        const int i0 = threadIdx.x * 4;
+    const int R = (n + 4095) / 4096;
+    const int w0 = wave * R * 256 + lane * 4;
+    int v[16][4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) nx[k] = i0 + k < n ? in[i0 + k] : 0;
+    for (int r = 0; r < 16; r++) {
+        const int i = w0 + 256 * r;
+        // one 16-byte load per lane and row (`in` is a DevBuf: 16-byte aligned, >= 256 bytes of slack behind its n words); words behind n count as zero
+        int4 q = make_int4(0, 0, 0, 0);
+        if (r < R && i < n) q = *reinterpret_cast<const int4*>(in + i);
+        v[r][0] = q.x; v[r][1] = i + 1 < n ? q.y : 0; v[r][2] = i + 2 < n ? q.z : 0; v[r][3] = i + 3 < n ? q.w : 0;
     }
-    for (int base = 0; base < n; base += 4096) {
-        const int i0 = base + threadIdx.x * 4;
-        int v[4];
+    int carry = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = nx[k];
-        {
-            const int j0 = i0 + 4096;
+    for (int r = 0; r < 16; r++) {      // the items become their exclusive prefixes inside the wave's stretch, in place (no second register array)
+        const int a0 = v[r][0], a1 = v[r][1], a2 = v[r][2], a3 = v[r][3];
+        const int s4 = (a0 + a1) + (a2 + a3);
+        int inc = s4;
+        if (r < R) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) nx[k] = j0 + k < n ? in[j0 + k] : 0;
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
         }
-        const int s = (v[0] + v[1]) + (v[2] + v[3]);
-        int inc = s;
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
-        if (lane == 63) wsum[wave] = inc;
-        __syncthreads();
-        int wbase = 0, tot = 0;
-#pragma unroll
-        for (int w = 0; w < 16; w++) { const int x = wsum[w]; if (w < wave) wbase += x; tot += x; }
-        int run = carry_s + wbase + inc - s;
-#pragma unroll
-        for (int k = 0; k < 4; k++) { if (i0 + k < n) out[i0 + k] = run; run += v[k]; }
-        __syncthreads();
-        if (threadIdx.x == 0) carry_s += tot;
-        __syncthreads();
+        const int e0 = carry + inc - s4;
+        v[r][0] = e0; v[r][1] = e0 + a0; v[r][2] = e0 + a0 + a1; v[r][3] = e0 + a0 + a1 + a2;
+        if (r < R) carry += __shfl(inc, 63);
     }
-    if (threadIdx.x == 0) out[n] = carry_s;
+    if (lane == 0) wtot[wave] = carry;
+    __syncthreads();
+    int wofs = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) { const int t = wtot[w]; if (w < wave) wofs += t; tot += t; }
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int i = w0 + 256 * r;
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (r < R && i + k < n) out[i + k] = wofs + v[r][k];
+    }
+    if (threadIdx.x == 0) out[n] = tot;
 }
-
 static int exclusive_scan(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const int* in, int64_t n, int* out /*[n+1]*/) {
     if (n <= 65536) {
         hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, ctx->stream, in, (int)n, out);
@@ -488,9 +633,8 @@ static int radix_sort(lili_ctx* ctx, lili_detail::VoxelBuffers* V, int n, int bi
 // Stable order of a device cloud by pcl::VoxelGrid's voxel index (box-relative, App. B2): keys in V->keys_a, the order (source indices) in
 // V->vals_a.  Blocking: the bounding box is read back.
 static int voxel_sort(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const float4* d_pts, int n, float leaf, VoxDev& P) {
-    unsigned init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
     unsigned* d_mm = ctx->misc.as<unsigned>();
-    HIPCHK(hipMemcpyAsync(d_mm, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_box_init, dim3(1), dim3(64), 0, ctx->stream, d_mm);
     hipLaunchKernelGGL(k_bbox, dim3(std::min(nblocks(n, kBlock), 512)), dim3(kBlock), 0, ctx->stream, d_pts, n, d_mm);
     unsigned mm[6];
     { int rb = lili_readback_add(ctx, mm, d_mm, sizeof(mm)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }
@@ -515,9 +659,21 @@ static int voxel_sort(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const float4*
 }
 
 // VoxelGrid of a device float4 cloud; result in V->out / V->out_cnt, V->n_out.  Blocking (two small read-backs).
-static int voxel_filter_device(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const float4* d_pts, int n, float leaf) {
+// need_order: the caller goes on to use the sort's order (V->vals_a: lili_localmap_commit builds its sorted ring from it) — only the general chain leaves one
+static int voxel_filter_device(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const float4* d_pts, int n, float leaf, bool need_order = false) {
     V->n_out = 0;
     if (n == 0) return LILI_OK;
+    if (n <= kVoxSmallMax && ctx->voxel_small && !need_order) {      // one launch, one synchronisation (k_voxel_small)
+        HIPCHK(V->out.ensure((size_t)n * 16)); HIPCHK(V->out_cnt.ensure((size_t)n * 4));
+        int* d_res = reinterpret_cast<int*>(ctx->misc.as<char>() + 1024);
+        hipLaunchKernelGGL(k_voxel_small, dim3(1), dim3(kVoxSmallThreads), 0, ctx->stream, d_pts, n, 1.0f / leaf, V->out.as<float4>(), V->out_cnt.as<int>(), d_res);
+        HIPCHK(hipGetLastError());
+        int res[2] = {0, 0};
+        { int rb = lili_readback_add(ctx, res, d_res, sizeof(res)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }
+        if (!res[1]) { V->n_out = res[0]; return LILI_OK; }
+        if (res[1] == 2) return ctx->fail(LILI_E_ARG, "voxel_filter: cloud holds no finite point");
+        // (voxel index beyond 31 bits: the general path below reports it the way PCL does)
+    }
     VoxDev P;
     int rc = voxel_sort(ctx, V, d_pts, n, leaf, P);
     if (rc != LILI_OK) return rc;
@@ -612,10 +768,15 @@ int lili_localmap_push(lili_ctx* ctx, int kind, const lili_cloud* features, cons
 static int sorted_ring_step(lili_ctx* ctx, lili_detail::VoxelBuffers* V, lili_detail::SortedRing& S, const DropSeqs& drop, long long n_drop, lili_detail::Keyframe* add, float leaf,
                             unsigned* d_bad) {
     int n_new = add ? add->n : 0;
+    if (n_new > 0 && n_new <= kVoxSmallMax && ctx->voxel_small) {      // a frame's worth of features: one launch (k_sort_keyframe_small)
+        HIPCHK(V->kf_key.ensure((size_t)n_new * 8)); HIPCHK(V->kf_pt.ensure((size_t)n_new * 16)); HIPCHK(V->flags.ensure((size_t)std::max<long long>(n_new, S.n) * 4));
+        hipLaunchKernelGGL(k_sort_keyframe_small, dim3(1), dim3(kVoxSmallThreads), 0, ctx->stream, add->pts.as<float4>(), n_new, 1.0f / leaf, add->seq, V->kf_pt.as<float4>(),
+                           V->kf_key.as<unsigned long long>(), V->flags.as<unsigned>(), d_bad);
+        HIPCHK(hipGetLastError());
+    } else
     if (n_new > 0) {       // the new keyframe alone, sorted by voxel (stable): 20 k points, no host round trip (the bounding box stays on the device)
-        static const unsigned init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
         unsigned* d_mm = ctx->misc.as<unsigned>();
-        HIPCHK(hipMemcpyAsync(d_mm, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_box_init, dim3(1), dim3(64), 0, ctx->stream, d_mm);
         hipLaunchKernelGGL(k_bbox, dim3(std::min(nblocks(n_new, kBlock), 512)), dim3(kBlock), 0, ctx->stream, add->pts.as<float4>(), n_new, d_mm);
         HIPCHK(V->keys_a.ensure((size_t)n_new * 4)); HIPCHK(V->vals_a.ensure((size_t)n_new * 4));
         hipLaunchKernelGGL(k_vox_key_packed, dim3(nblocks(n_new, 256)), dim3(256), 0, ctx->stream, add->pts.as<float4>(), n_new, 1.0f / leaf, (const unsigned*)d_mm,
@@ -703,9 +864,8 @@ int lili_localmap_commit(lili_ctx* ctx, int kind, float leaf, double max_sq_radi
             rc = lili_readback_add(ctx, &V->n_out, V->slots.as<int>() + n, sizeof(int));
             // the bounding box of the centroids travels with their count: the index build below starts without a read-back of its own
             if (rc == LILI_OK) {
-                static const unsigned init[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
-                unsigned* d_box = reinterpret_cast<unsigned*>(ctx->misc.as<char>() + 512);
-                HIPCHK(hipMemcpyAsync(d_box, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+                        unsigned* d_box = reinterpret_cast<unsigned*>(ctx->misc.as<char>() + 512);
+                hipLaunchKernelGGL(k_box_init, dim3(1), dim3(64), 0, ctx->stream, d_box);
                 hipLaunchKernelGGL(k_bbox_dev, dim3((unsigned)std::min<long long>(nblocks(n, kBlock), 128)), dim3(kBlock), 0, ctx->stream, V->out.as<float4>(),
                                    (const int*)(V->slots.as<int>() + n), (int)n, d_box);
                 HIPCHK(hipGetLastError());
@@ -750,7 +910,7 @@ int lili_localmap_commit(lili_ctx* ctx, int kind, float leaf, double max_sq_radi
                                (long long)total, V->concat.as<float4>());
             HIPCHK(hipGetLastError());
         }
-        int rc = voxel_filter_device(ctx, V, V->concat.as<float4>(), (int)total, leaf);   // ds_filter_*_map.filter (L:1488-1492)
+        int rc = voxel_filter_device(ctx, V, V->concat.as<float4>(), (int)total, leaf, true);   // ds_filter_*_map.filter (L:1488-1492); the sorted ring below needs the order
         if (rc != LILI_OK) return rc;
         V->full_commits++;
         // the sorted ring for the following steps: the order the sort has just produced, with absolute keys and the keyframe of every point

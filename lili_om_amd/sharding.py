@@ -45,6 +45,25 @@ def allreduce_window(dist, tensor):
     return tensor
 
 
+def window_owners(n_slots, world):
+    """Slot-per-rank window (lili_s2m_*_window_gather): keyframe i of the window lives on rank i mod world at full size."""
+    return [i % world for i in range(n_slots)]
+
+
+def gather_window_records(dist, records, owner, rank):
+    """The K x 72 records of one evaluation in slot-per-rank mode: this rank contributes the records of the slots it owns (`records[i]` for owner[i] == rank, anything
+    else is ignored) and zeros elsewhere; ONE all-reduce(sum) in which every record has a single non-zero contributor, i.e. an all-gather — the owner's bits on
+    every rank (a -0.0 entry reads +0.0).  Returns the unpacked list."""
+    import torch
+    buf = np.zeros((len(owner), 72))
+    for i, o in enumerate(owner):
+        if o == rank:
+            buf[i] = np.asarray(records[i], np.float64).reshape(72)
+    t = torch.from_numpy(buf.reshape(-1))
+    dist.all_reduce(t)
+    return unpack_window_records(t.numpy(), len(owner))
+
+
 def plus_jacobian(q):
     """ceres::QuaternionParameterization::ComputeJacobian for q = (w,x,y,z): 4x3."""
     w, x, y, z = q

@@ -24,6 +24,8 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+#include <pthread.h>
+#include <sched.h>
 
 using namespace lo;
 
@@ -171,7 +173,18 @@ struct Pool {
     }
     void run(int chunks, int nthreads, const std::function<void(int)>& f) {
         const int helpers = std::max(0, std::min(nthreads, chunks) - 1);
-        while ((int)th.size() < helpers) { const int id = (int)th.size(); const unsigned long g0 = gen; th.emplace_back([this, id, g0] { worker(id, g0); }); }
+        while ((int)th.size() < helpers) {
+            const int id = (int)th.size(); const unsigned long g0 = gen;
+            th.emplace_back([this, id, g0] { worker(id, g0); });
+            // one core per worker: the (id + 1)-th CPU of the mask the CALLER runs under (bench.py: the physical cores of one socket) — unpinned workers were
+            // seen to share cores for whole registrations (five runs of the same registration: 112 ... 310 it/s)
+            cpu_set_t mask;
+            if (sched_getaffinity(0, sizeof(mask), &mask) == 0) {
+                const int ncpu = CPU_COUNT(&mask);
+                int want = ncpu > 0 ? (id + 1) % ncpu : 0, seen = 0;
+                for (int c = 0; c < CPU_SETSIZE; c++) if (CPU_ISSET(c, &mask)) { if (seen == want) { cpu_set_t one; CPU_ZERO(&one); CPU_SET(c, &one); pthread_setaffinity_np(th.back().native_handle(), sizeof(one), &one); break; } seen++; }
+            }
+        }
         {
             std::lock_guard<std::mutex> lk(m);
             job = &f; n_chunks = chunks; use = helpers; running = helpers; next.store(0, std::memory_order_relaxed); gen++;

@@ -164,3 +164,43 @@ def test_sharded_window_evaluation_matches_single_rank(oracle, world):
             assert cnt == ref[k][2] and cnt[0] > 400
             assert np.abs(G - ref[k][0]).max() <= 1e-12 * np.abs(ref[k][0]).max() and abs(cost - ref[k][1]) <= 1e-12 * ref[k][1]
             assert np.array_equal(G, out[0][0][k][0])               # the ranks agree bit for bit (gloo reduces in one order for all)
+
+
+# ---- slot-per-rank window (round 5: lili_s2m_*_window_gather): keyframe k lives on rank k mod world at FULL size; ONE exchange of K x 72 doubles per evaluation in
+# which every record has a single non-zero contributor = an all-gather; no count exchange (the owner's count is the global one)
+def _gather_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    room, P, poses, qs = _window_scene()
+    PO = O.params("rot")
+    owner = sharding.window_owners(N_KF, world)
+    tree = O.KdTree(room["map_xyz"])
+    rows = [None] * N_KF
+    for k in range(N_KF):
+        if owner[k] != rank:
+            continue                                                # this rank holds neither the queries nor the records of keyframe k
+        Q2, T2 = L.api.assoc_transform(poses[k][0], poses[k][1], P)
+        rec = O.associate_surf(tree, None, qs[k], None, Q2, T2, PO)
+        G, cost, n = O.linearize_surf(rec, poses[k][0], poses[k][1], PO, (1000.0, max(rec["count"], 1)))      # the owner's count IS the global count
+        row = np.zeros(72)
+        row[:64], row[64], row[65] = G.reshape(-1), cost, n
+        rows[k] = row
+    out[rank] = sharding.gather_window_records(dist, rows, owner, rank)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_slot_per_rank_window_gathers_the_owners_records(oracle, world):
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_gather_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    room, P, poses, qs = _window_scene()
+    ref = _window_evaluation(oracle, room, P, oracle.params("rot"), poses, qs, 1, 0, lambda x: x)
+    assert sharding.window_owners(N_KF, world) == [k % world for k in range(N_KF)]
+    for r in range(world):
+        for k in range(N_KF):
+            G, cost, cnt = out[r][k]
+            assert cnt == ref[k][2] and cnt[0] > 400
+            assert np.array_equal(G, ref[k][0]) and cost == ref[k][1]          # a gather: the single-rank evaluation's bits, on every rank
+

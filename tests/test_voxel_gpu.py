@@ -246,3 +246,38 @@ def test_index_behind_an_incremental_commit_equals_a_plain_map_set(gpu_ctx):
     assert np.array_equal(a[0][inside], b[0][inside]) and np.array_equal(a[1][inside], b[1][inside])
     assert a[2]["count"] == b[2]["count"] and np.array_equal(a[2]["n"], b[2]["n"]) and np.array_equal(a[2]["query_index"], b[2]["query_index"])
     assert np.array_equal(a[3], b[3]) and a[4] == b[4] and np.array_equal(a[5], b[5])
+
+
+@pytest.mark.parametrize("n,leaf,scale", [(1, 0.4, 5.0), (63, 0.4, 5.0), (64, 0.4, 30.0), (65, 0.2, 30.0), (3000, 0.4, 60.0), (4097, 0.4, 100.0), (8192, 0.6, 200.0), (8192, 0.05, 2.0)])
+def test_single_launch_filter_of_small_clouds_equals_the_general_chain(oracle, n, leaf, scale):
+    """k_voxel_small (round 5: clouds of <= 8192 points — a Livox frame's features — in ONE single-workgroup launch) against the general chain of launches
+    (option voxel_small = 0) and against the oracle's PCL restatement: same voxels, same order, same counts, centroids bit for bit; duplicates, non-finite
+    points, many points per voxel (leaf >> spacing) and one point per voxel."""
+    rng = np.random.default_rng(1000 + n)
+    pts = np.concatenate([rng.uniform(-scale, scale, (n, 2)), rng.normal(0, 0.5, (n, 1)), rng.uniform(0, 25, (n, 1))], 1).astype(np.float32)
+    if n >= 64:
+        pts[: n // 8] = pts[n // 8: 2 * (n // 8)][: n // 8]          # exact duplicates
+        pts[n // 2] = [np.nan, 0, 0, 1]; pts[n // 2 + 1] = [0, np.inf, 0, 1]; pts[n - 1] = [0, 0, -np.inf, 1]
+    res = []
+    ctx = L.Context(0)          # (its own context: the session's shared one may carry another test's A/B options)
+    try:
+        # a larger cloud first, so that the filter's scratch buffers hold another cloud's keys / flags / counts when the small one arrives
+        big = np.concatenate([rng.uniform(-80, 80, (50_000, 2)), rng.normal(0, 0.5, (50_000, 1)), rng.uniform(0, 25, (50_000, 1))], 1).astype(np.float32)
+        L.api.voxel_filter(ctx, big, 0.3)
+        for opt in (1, 0):
+            ctx.set_option("voxel_small", opt)
+            res.append(L.api.voxel_filter(ctx, pts, leaf))
+    finally:
+        ctx.close()
+    (g1, c1), (g0, c0) = res
+    assert g1.shape == g0.shape and np.array_equal(c1, c0) and np.array_equal(g1.view(np.uint32), g0.view(np.uint32))
+    fin = np.isfinite(pts[:, :3]).all(1)
+    o, oc = oracle.voxel_grid(np.ascontiguousarray(pts[fin]), leaf, stable=True)          # PCL skips non-finite points of a non-dense cloud
+    assert g1.shape == o.shape and np.array_equal(c1, oc) and np.array_equal(g1.view(np.uint32), o.view(np.uint32))
+
+
+def test_single_launch_filter_hands_an_index_overflow_to_the_general_path(gpu_ctx):
+    """a leaf far too small for the extent: PCL's "leaf size too small" (voxel index beyond int32) is reported whichever path sees the cloud first"""
+    pts = np.array([[0, 0, 0, 1], [5000, 5000, 5000, 1]], np.float32)
+    with pytest.raises(L.LiliError):
+        L.api.voxel_filter(gpu_ctx, pts, 0.001)
