@@ -331,13 +331,10 @@ def main():
                     help="N > 1: who does the two tiny all-reduces per iteration — auto = lili_p2p, else RCCL from C, else torch.distributed")
     ap.add_argument("--no-native-rccl", action="store_true", help="same as --collective torch (A/B: the two all-reduces stay in the Python loop)")
     ap.add_argument("--split-path", action="store_true", help="use the multi-GPU code path (export/import counts, separate GN kernel) even at N=1")
-    ap.add_argument("--bin", action="store_true", help="enable the once-per-scan query binning (A/B only)")
     ap.add_argument("--opt", action="append", default=[], help="A/B: lili_set_option name=value (repeatable), e.g. --opt warm=0")
     ap.add_argument("--no-focus", action="store_true", help="A/B: build the super-row copy for the whole map instead of the sensor's surroundings (lili_map_focus)")
     ap.add_argument("--reach", type=int, default=0, help="map grid reach (1 = cells of the gate radius, 2 = half-size cells); 0 = library default")
     ap.add_argument("--cell-pct", type=int, default=0, help="reach-2 cell edge in %% of the gate radius (50..100); 0 = library default")
-    ap.add_argument("--no-nn-cache", action="store_true", help="A/B: do not seed the search bound with the previous neighbours")
-    ap.add_argument("--tile", action="store_true", help="enable the LDS-tiled search (A/B only; implies --bin)")
     args = ap.parse_args()
     if args.no_native_rccl:
         args.collective = "torch"
@@ -425,15 +422,9 @@ def main():
         ctx.set_option("grid_reach", args.reach)
     if args.cell_pct:
         ctx.set_option("cell_pct", args.cell_pct)
-    if args.no_nn_cache:
-        ctx.set_option("nn_cache", 0)
     for kv in args.opt:
         k, v = kv.split("=")
         ctx.set_option(k, int(v))
-    if args.bin or args.tile:
-        ctx.set_option("bin_queries", 1)
-    if args.tile:
-        ctx.set_option("tiled", 1)
     m = L.ScanToMapMatcher(ctx, P)
     # the scan reaches ~1/10 of the 920 m x 760 m map: the super-row copy is built around the sensor only (a hint: results do not depend on it)
     focus_r = float(np.linalg.norm(w["scan_xyz"], axis=1).max()) + 3.0

@@ -30,13 +30,8 @@ __global__ void k_start9(const int*, GridView, const int*, int*);
 __global__ void k_rowtot9(const int*, GridView, int*);
 template <int BS> __global__ void k_associate_lin(AssocArgs, AssocArgs, PoseArg, MatchParams, double*, double*);
 __global__ void k_scatter9(const int*, GridView, const int*, float4*, float*);
-__global__ void k_bin_count(const float4*, int, GridView, PoseArg, MatchParams, int, int, int*, int*);
-__global__ void k_bin_scatter(const int*, int, const int*, int*, int*);
-__global__ void k_tile_count(const int*, int, int*);
-__global__ void k_tile_fill(const int*, const int*, const int*, int, int2*);
-template <bool TILED, int BS> __global__ void k_associate_surf(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, int*, int*, AssocSched);
-template <bool TILED, int BS> __global__ void k_associate_edge(const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, int*, int*, AssocSched);
-__global__ void k_block_order(const int*, int, int, int*);
+template <int BS> __global__ void k_associate_surf(const float4*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, int*);
+template <int BS> __global__ void k_associate_edge(const float4*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, int*);
 __global__ void k_associate_both(AssocArgs, AssocArgs, PoseArg, MatchParams);
 __global__ void k_linearize(LinArgs, LinArgs, PoseArg, MatchParams, const SlotState*, const int*, FuseTail);
 __global__ void k_reduce_partials(const double*, int, const double*, int, double*, SlotState*, int, P2PView, unsigned long long, double*);
@@ -265,10 +260,10 @@ void lili_ctx_destroy(lili_ctx* ctx) {
     for (int k = 0; k < 2; k++) { if (ctx->build_done[k]) (void)hipEventDestroy(ctx->build_done[k]); if (ctx->main_mark[k]) (void)hipEventDestroy(ctx->main_mark[k]); }
     if (ctx->cloud_ready) (void)hipEventDestroy(ctx->cloud_ready);
     for (auto& m : ctx->map) { m.sorted_f.release(); m.aux_sorted_f.release(); m.cell_start_f.release(); m.cell_start9.release(); m.cell_start9_f.release(); m.row9.release(); m.sorted.release(); m.aux_sorted.release(); m.cell_start.release(); m.cell_tmp.release(); m.pt_cell.release(); m.block_sums.release(); }
-    for (auto& s : ctx->slots) for (auto& k : s.k) { k.q.release(); k.rec0.release(); k.rec1.release(); k.valid.release(); k.dbg_idx.release(); k.dbg_d2.release(); k.partials.release(); k.partials_wave.release(); k.perm.release(); k.keys.release(); k.block_counts.release(); k.tiles.release(); }
+    for (auto& s : ctx->slots) for (auto& k : s.k) { k.q.release(); k.rec0.release(); k.rec1.release(); k.valid.release(); k.dbg_idx.release(); k.dbg_d2.release(); k.partials.release(); k.partials_wave.release(); k.block_counts.release(); }
     if (ctx->h_records) { (void)hipHostFree(ctx->h_records); ctx->h_records = nullptr; }
     if (ctx->h_pin) { (void)hipHostFree(ctx->h_pin); ctx->h_pin = nullptr; }
-    ctx->states.release(); ctx->staging.release(); ctx->gram.release(); ctx->win_rec.release(); ctx->win_counts.release(); ctx->misc.release(); ctx->bin_hist.release(); ctx->bin_start.release(); ctx->bin_sums.release(); ctx->bin_tcnt.release(); ctx->bin_toff.release();
+    ctx->states.release(); ctx->staging.release(); ctx->gram.release(); ctx->win_rec.release(); ctx->win_counts.release(); ctx->misc.release();
     if (ctx->ext_rot && ctx->ext_rot_free) ctx->ext_rot_free(ctx->ext_rot);
     if (ctx->ext_livox && ctx->ext_livox_free) ctx->ext_livox_free(ctx->ext_livox);
     if (ctx->ext_voxel && ctx->ext_voxel_free) ctx->ext_voxel_free(ctx->ext_voxel);
@@ -295,11 +290,8 @@ int lili_set_debug(lili_ctx* ctx, int keep_neighbors) {
 
 int lili_set_option(lili_ctx* ctx, const char* name, int value) {
     if (!ctx || !name) return LILI_E_ARG;
-    if (std::strcmp(name, "bin_queries") == 0) { ctx->bin_queries = value != 0; for (auto& s : ctx->slots) for (auto& k : s.k) k.binned = false; return LILI_OK; }
     if (std::strcmp(name, "grid_reach") == 0) { if (value != 1 && value != 2) return ctx->fail(LILI_E_ARG, "grid_reach must be 1 or 2"); ctx->grid_reach = value; return LILI_OK; }
     if (std::strcmp(name, "cell_pct") == 0) { if (value < 50 || value > 100) return ctx->fail(LILI_E_ARG, "cell_pct must be in 50..100"); ctx->cell_pct = value; return LILI_OK; }
-    if (std::strcmp(name, "tiled") == 0) { ctx->tiled = value != 0; return LILI_OK; }
-    if (std::strcmp(name, "balance") == 0) { ctx->balance = value != 0; for (auto& sl : ctx->slots) for (auto& k : sl.k) { k.order_valid = false; k.launches = 0; } return LILI_OK; }
     if (std::strcmp(name, "fuse_tail") == 0) { ctx->fuse_tail = value != 0; return LILI_OK; }   // any time: the block partition does not depend on it
     if (std::strcmp(name, "merge_kinds") == 0) { ctx->merge_kinds = value != 0; return LILI_OK; }
     if (std::strcmp(name, "fuse_lin") == 0) { ctx->fuse_lin = value != 0; return LILI_OK; }
@@ -323,7 +315,6 @@ int lili_set_option(lili_ctx* ctx, const char* name, int value) {
     if (std::strcmp(name, "sort_digit_bits") == 0) { if (value != 4 && value != 8) return ctx->fail(LILI_E_ARG, "sort_digit_bits must be 4 or 8"); ctx->sort_digit_bits = value; return LILI_OK; }
     if (std::strcmp(name, "rot_atan") == 0) { if (value != 1 && value != 2) return ctx->fail(LILI_E_ARG, "rot_atan must be 1 or 2"); ctx->rot_atan = value; return LILI_OK; }
     if (std::strcmp(name, "p2p_fusion") == 0) { ctx->no_p2p_fusion = value == 0; return LILI_OK; }
-    if (std::strcmp(name, "nn_cache") == 0) { ctx->nn_cache = value != 0; for (auto& s : ctx->slots) for (auto& k : s.k) k.nn_cache_valid = false; return LILI_OK; }
     if (std::strcmp(name, "readback_gather") == 0) { ctx->readback_gather = value != 0; return LILI_OK; }      // small device-to-host reads of one synchronisation in ONE gather launch (0: a copy launch each, A/B)
     if (std::strcmp(name, "voxel_small") == 0) { ctx->voxel_small = value != 0; return LILI_OK; }      // VoxelGrid of <= 8192 points in one single-workgroup launch (0: the general chain, A/B)
     if (std::strcmp(name, "overlap_gn") == 0) { ctx->overlap_gn = value != 0; return LILI_OK; }      // lili_s2m_iterate*: the association behind a reduction + GN kernel starts without waiting for it (0: three barriers per iteration)
@@ -460,7 +451,7 @@ static int map_set_impl(lili_ctx* ctx, int kind, const lili_cloud* cloud, double
     HIPCHK(hipSetDevice(ctx->device));
     MapIndex& m = ctx->map[kind];
     m.valid = false;
-    for (auto& s : ctx->slots) { s.k[kind].binned = false; s.k[kind].nn_cache_valid = false; s.k[kind].order_valid = false; s.k[kind].launches = 0; }
+    for (auto& s : ctx->slots) { s.k[kind].launches = 0; }
     m.n = (int64_t)cloud->n;
     m.has_aux = cloud->aux_offset >= 0;
     m.view = GridView{};
@@ -675,7 +666,7 @@ int lili_map_set_end(lili_ctx* ctx, int kind) {
     ctx->map[kind].swap(ctx->map_next[kind]);
     HIPCHK(hipEventRecord(ctx->main_mark[kind], ctx->stream));             // everything that may still read the retired index is before this mark
     ctx->main_marked[kind] = true;
-    for (auto& s : ctx->slots) { s.k[kind].binned = false; s.k[kind].nn_cache_valid = false; s.k[kind].order_valid = false; s.k[kind].launches = 0; }
+    for (auto& s : ctx->slots) { s.k[kind].launches = 0; }
     ctx->build_pending[kind] = false;
     return LILI_OK;
 }
@@ -730,7 +721,7 @@ int lili_s2m_set_queries(lili_ctx* ctx, int slot, int kind, const lili_cloud* cl
     ARGCHK(cloud, "set_queries: null cloud");
     HIPCHK(hipSetDevice(ctx->device));
     KindSlot& ks = ctx->slots[slot].k[kind];
-    ks.has_queries = false; ks.has_records = false; ks.binned = false; ks.nn_cache_valid = false; ks.order_valid = false; ks.launches = 0;
+    ks.has_queries = false; ks.has_records = false; ks.launches = 0;
     int rc = lili_ingest_cloud(ctx, cloud, ks.q);
     if (rc != LILI_OK) return rc;
     ks.n_q = (int64_t)cloud->n;
@@ -749,55 +740,6 @@ int lili_s2m_set_queries(lili_ctx* ctx, int slot, int kind, const lili_cloud* cl
         HIPCHK(ks.block_counts.ensure((size_t)ks.n_blocks * sizeof(int)));
     }
     ks.has_queries = true;
-    return LILI_OK;
-}
-
-// Orders the queries of one scan by the Morton code of the map super-cell they fall into at the pose of
-// their first association (counting sort: histogram, exclusive scan, scatter).  Done once per set_queries;
-// later poses of the same scan move the points by centimetres..metres, which keeps the order coherent.
-static int bin_queries(lili_ctx* ctx, KindSlot& ks, MapIndex& m, const PoseArg& pa, const MatchParams& P) {
-    const int n = (int)ks.n_q;
-    int sb_shift = 3;   // 8 x 8 cells per super-cell
-    int bits;
-    for (;;) {
-        int nsx = ((m.view.nx - 1) >> sb_shift) + 1, nsy = ((m.view.ny - 1) >> sb_shift) + 1;
-        int mx = std::max(nsx, nsy);
-        bits = 0; while ((1 << bits) < mx) bits++;
-        if (2 * bits <= 20) break;
-        sb_shift++;
-    }
-    const int n_bins = (1 << (2 * bits)) + 1;
-    HIPCHK(ks.perm.ensure((size_t)n * sizeof(int)));
-    HIPCHK(ks.keys.ensure((size_t)n * sizeof(int)));
-    HIPCHK(ctx->bin_hist.ensure((size_t)n_bins * sizeof(int)));
-    HIPCHK(ctx->bin_start.ensure((size_t)(n_bins + 1) * sizeof(int)));
-    const int nb_scan = nblocks(n_bins, 2048);
-    HIPCHK(ctx->bin_sums.ensure((size_t)nb_scan * sizeof(int)));
-    HIPCHK(hipMemsetAsync(ctx->bin_hist.p, 0, (size_t)n_bins * sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(k_bin_count, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, ks.q.as<float4>(), n, m.view, pa, P, sb_shift, n_bins,
-                       ks.keys.as<int>(), ctx->bin_hist.as<int>());
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb_scan), dim3(kBlock), 0, ctx->stream, ctx->bin_hist.as<int>(), (int64_t)n_bins, ctx->bin_sums.as<int>());
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->bin_sums.as<int>(), nb_scan);
-    hipLaunchKernelGGL(k_scan_apply, dim3(nb_scan), dim3(kBlock), 0, ctx->stream, ctx->bin_hist.as<int>(), (int64_t)n_bins, ctx->bin_sums.as<int>(), ctx->bin_start.as<int>());
-    HIPCHK(hipMemsetAsync(ctx->bin_hist.p, 0, (size_t)n_bins * sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(k_bin_scatter, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, ks.keys.as<int>(), n, ctx->bin_start.as<int>(), ctx->bin_hist.as<int>(), ks.perm.as<int>());
-    // tile list: after the scatter bin_hist holds the per-bin counts again
-    HIPCHK(ctx->bin_tcnt.ensure((size_t)n_bins * sizeof(int)));
-    HIPCHK(ctx->bin_toff.ensure((size_t)(n_bins + 1) * sizeof(int)));
-    hipLaunchKernelGGL(k_tile_count, dim3(nblocks(n_bins, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->bin_hist.as<int>(), n_bins, ctx->bin_tcnt.as<int>());
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(nb_scan), dim3(kBlock), 0, ctx->stream, ctx->bin_tcnt.as<int>(), (int64_t)n_bins, ctx->bin_sums.as<int>());
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, ctx->stream, ctx->bin_sums.as<int>(), nb_scan);
-    hipLaunchKernelGGL(k_scan_apply, dim3(nb_scan), dim3(kBlock), 0, ctx->stream, ctx->bin_tcnt.as<int>(), (int64_t)n_bins, ctx->bin_sums.as<int>(), ctx->bin_toff.as<int>());
-    HIPCHK(hipGetLastError());
-    int n_tiles = 0;
-    { int rb = lili_readback_add(ctx, &n_tiles, ctx->bin_toff.as<int>() + n_bins, sizeof(int)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }   // once per scan
-    if (n_tiles <= 0 || n_tiles > n) return ctx->fail(LILI_E_HIP, "bin_queries: inconsistent tile count");
-    HIPCHK(ks.tiles.ensure((size_t)n_tiles * sizeof(int2)));
-    HIPCHK(ks.block_counts.ensure((size_t)std::max(n_tiles, ks.n_blocks) * sizeof(int)));
-    hipLaunchKernelGGL(k_tile_fill, dim3(nblocks(n_bins, kBlock)), dim3(kBlock), 0, ctx->stream, ctx->bin_hist.as<int>(), ctx->bin_start.as<int>(), ctx->bin_toff.as<int>(), n_bins, ks.tiles.as<int2>());
-    HIPCHK(hipGetLastError());
-    ks.n_tiles = n_tiles;
-    ks.binned = true;
     return LILI_OK;
 }
 
@@ -825,17 +767,9 @@ static int launch_associate(lili_ctx* ctx, int slot, int kind, const PoseArg& pa
         if (dbg_i) { HIPCHK(hipMemsetAsync(dbg_i, 0xFF, (size_t)n * 5 * sizeof(int), ctx->stream)); HIPCHK(hipMemsetAsync(dbg_d, 0x7F, (size_t)n * 5 * sizeof(float), ctx->stream)); }
         return LILI_OK;
     }
-    const int* perm = nullptr;
-    const int2* tiles = nullptr;
     ks.n_assoc_blocks = ks.n_blocks;
-    // neighbour cache of the previous association of this scan against this map index (seeds the search bound)
-    int* nnc = nullptr;
-    if (ctx->nn_cache) {
-        HIPCHK(ks.nn_cache.ensure((size_t)n * 5 * sizeof(int)));
-        if (!ks.nn_cache_valid) { HIPCHK(hipMemsetAsync(ks.nn_cache.p, 0xFF, (size_t)n * 5 * sizeof(int), ctx->stream)); ks.nn_cache_valid = true; }
-        nnc = ks.nn_cache.as<int>();
-    }
-    if (m.has_fine && !ctx->bin_queries && !ctx->balance) {      // dense map: fine index first, gate-sized index for the queries it cannot settle
+    const bool any_order = pa.wait_key != 0ull;
+    if (m.has_fine) {      // dense map: fine index first, gate-sized index for the queries it cannot settle
         if (kind == LILI_KIND_SURF && P.variant == LILI_VARIANT_LIVOX && (!m.has_aux || !ks.has_aux))
             return ctx->fail(LILI_E_STATE, "associate: Livox variant needs reflectivity (aux_offset) on the surf map and the surf queries");
         AssocArgs a{};
@@ -843,50 +777,22 @@ static int launch_associate(lili_ctx* ctx, int slot, int kind, const PoseArg& pa
         a.rec0 = ks.rec0.as<float4>(); a.rec1 = ks.rec1.p; a.valid = ks.valid.as<unsigned char>();
         a.dbg_idx = dbg_i; a.dbg_d2 = dbg_d; a.block_counts = ks.block_counts.as<int>(); a.nb = ks.n_blocks;
         ks.launches++;
-        launch_k(ctx->stream, pa.wait_key != 0ull, k_associate_fine, dim3(ks.n_blocks), dim3(kAssocBlock), 0, a, m.fview, m.fbound, kind, pa, P);
+        launch_k(ctx->stream, any_order, k_associate_fine, dim3(ks.n_blocks), dim3(kAssocBlock), 0, a, m.fview, m.fbound, kind, pa, P);
         HIPCHK(hipGetLastError());
         return LILI_OK;
     }
-    const bool tiled = ctx->tiled && ctx->bin_queries && n >= 4 * kBlock && m.view.reach == 1;   // tiles need spatially compact blocks
-    if (ctx->bin_queries && n >= 4 * kBlock) {
-        if (!ks.binned) { int rc = bin_queries(ctx, ks, m, pa, P); if (rc != LILI_OK) return rc; }
-        perm = ks.perm.as<int>();
-        tiles = ks.tiles.as<int2>();
-        ks.n_assoc_blocks = ks.n_tiles;
-    }
-    // cost-ordered dispatch (one-wave workgroups only): costs of launch k order launch k+1; rebuilt before launches 2 and 4 of a scan
-    AssocSched sched{nullptr, nullptr};
-    if (ctx->balance && !perm && kind == LILI_KIND_SURF && ks.n_blocks > ctx->n_simd && ks.n_blocks <= 8192 && ctx->n_simd > 0) {
-        HIPCHK(ks.block_cost.ensure((size_t)ks.n_blocks * sizeof(int)));
-        HIPCHK(ks.order.ensure((size_t)ks.n_blocks * sizeof(int)));
-        if (ks.launches == 1 || ks.launches == 3) {
-            hipLaunchKernelGGL(k_block_order, dim3(1), dim3(1024), 0, ctx->stream, ks.block_cost.as<int>(), ks.n_blocks, ctx->n_simd, ks.order.as<int>());
-            ks.order_valid = true;
-        }
-        sched.block_cost = ks.block_cost.as<int>();
-        if (ks.order_valid) sched.order = ks.order.as<int>();
-    }
     ks.launches++;
-    // default: one wave per workgroup (kAssocBlock); the binned / tiled variants keep kBlock-sized tiles
+    // one wave per workgroup (kAssocBlock): the dispatcher balances the SIMDs wave by wave
     const dim3 grid(ks.n_assoc_blocks);
-    const bool any_order = pa.wait_key != 0ull;
-#define LILI_LAUNCH_ASSOC(KERNEL, REC1T)                                                                                                   \
-    do {                                                                                                                                   \
-        if (tiled) launch_k(ctx->stream, any_order, (KERNEL<true, kBlock>), grid, dim3(kBlock), 0, (const float4*)ks.q.as<float4>(), perm, tiles, n, m.view, pa, P, \
-                                      ks.rec0.as<float4>(), ks.rec1.as<REC1T>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>(), nnc, sched); \
-        else if (perm) launch_k(ctx->stream, any_order, (KERNEL<false, kBlock>), grid, dim3(kBlock), 0, (const float4*)ks.q.as<float4>(), perm, tiles, n, m.view, pa, P, \
-                                      ks.rec0.as<float4>(), ks.rec1.as<REC1T>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>(), nnc, sched); \
-        else launch_k(ctx->stream, any_order, (KERNEL<false, kAssocBlock>), grid, dim3(kAssocBlock), 0, (const float4*)ks.q.as<float4>(), perm, tiles, n, m.view, pa, P, \
-                                      ks.rec0.as<float4>(), ks.rec1.as<REC1T>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>(), nnc, sched); \
-    } while (0)
     if (kind == LILI_KIND_SURF) {
         if (P.variant == LILI_VARIANT_LIVOX && !m.has_aux) return ctx->fail(LILI_E_STATE, "associate: Livox variant needs reflectivity (aux_offset) on the surf map");
         if (P.variant == LILI_VARIANT_LIVOX && !ks.has_aux) return ctx->fail(LILI_E_STATE, "associate: Livox variant needs reflectivity (aux_offset) on the surf queries");
-        LILI_LAUNCH_ASSOC(k_associate_surf, double);
+        launch_k(ctx->stream, any_order, k_associate_surf<kAssocBlock>, grid, dim3(kAssocBlock), 0, (const float4*)ks.q.as<float4>(), n, m.view, pa, P,
+                 ks.rec0.as<float4>(), ks.rec1.as<double>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>());
     } else {
-        LILI_LAUNCH_ASSOC(k_associate_edge, float4);
+        launch_k(ctx->stream, any_order, k_associate_edge<kAssocBlock>, grid, dim3(kAssocBlock), 0, (const float4*)ks.q.as<float4>(), n, m.view, pa, P,
+                 ks.rec0.as<float4>(), ks.rec1.as<float4>(), ks.valid.as<unsigned char>(), dbg_i, dbg_d, ks.block_counts.as<int>());
     }
-#undef LILI_LAUNCH_ASSOC
     HIPCHK(hipGetLastError());
     return LILI_OK;
 }
@@ -905,7 +811,6 @@ static int launch_sum_counts(lili_ctx* ctx, int slot, int kind_mask, int* d_out 
 // Both kinds of a keyframe in one launch (k_associate_both): only the plain direct path — one wave per workgroup, caller's
 // query order, no dispatch-order or binning experiments.  Returns 1 if the slot is not eligible (the caller then launches per kind).
 static int launch_associate_both(lili_ctx* ctx, int slot, const PoseArg& pa, const MatchParams& P) {
-    if (ctx->bin_queries || ctx->tiled || ctx->balance) return 1;
     AssocArgs A[2];
     for (int kind = 0; kind < 2; kind++) {
         KindSlot& ks = ctx->slots[slot].k[kind];
@@ -926,11 +831,6 @@ static int launch_associate_both(lili_ctx* ctx, int slot, const PoseArg& pa, con
             HIPCHK(ks.dbg_idx.ensure((size_t)n * 5 * sizeof(int)));
             HIPCHK(ks.dbg_d2.ensure((size_t)n * 5 * sizeof(float)));
             a.dbg_idx = ks.dbg_idx.as<int>(); a.dbg_d2 = ks.dbg_d2.as<float>();
-        }
-        if (ctx->nn_cache) {
-            HIPCHK(ks.nn_cache.ensure((size_t)n * 5 * sizeof(int)));
-            if (!ks.nn_cache_valid) { HIPCHK(hipMemsetAsync(ks.nn_cache.p, 0xFF, (size_t)n * 5 * sizeof(int), ctx->stream)); ks.nn_cache_valid = true; }
-            a.nn_cache = ks.nn_cache.as<int>();
         }
         a.block_counts = ks.block_counts.as<int>(); a.nb = ks.n_blocks;
         ks.n_assoc_blocks = ks.n_blocks; ks.has_records = true; ks.launches++;
@@ -958,7 +858,7 @@ static int coop_lanes(const lili_ctx* ctx, int64_t n, bool first_after_reset) {
 // Association of the kinds in kind_mask by k_associate_coop (lili_s2m_coop.hip); `lin`: also linearise (flavours without count scaling) and
 // reduce + GN-update in a second launch.  Returns 1 if the configuration is not eligible — the caller then takes the one-lane kernels.
 static int launch_associate_coop(lili_ctx* ctx, int slot, int kind_mask, const PoseArg& pa, const MatchParams& P, bool lin, double* d_out) {
-    if (ctx->bin_queries || ctx->tiled || ctx->balance || ctx->nn_cache || (P.debug & (1 | 2 | 4096))) return 1;
+    if (P.debug & 4096) return 1;
     Slot& sl = ctx->slots[slot];
     int64_t n_all = 0;
     for (int kind = 0; kind < 2; kind++) if (kind_mask & (1 << kind)) {
@@ -1016,7 +916,7 @@ static int launch_associate_coop(lili_ctx* ctx, int slot, int kind_mask, const P
 // The cooperative association of EVERY slot of a window in ONE launch (k_associate_coop_window): the conditions of launch_associate_coop for every slot,
 // one L for all (by the total number of queries: the records do not depend on it).  Returns 1 if not eligible — the caller then launches slot by slot.
 static int launch_associate_coop_window(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, const double* t_assoc, const double* q_assoc, const MatchParams& P) {
-    if (n_slots < 2 || ctx->bin_queries || ctx->tiled || ctx->balance || ctx->nn_cache || (P.debug & (1 | 2 | 4096))) return 1;
+    if (n_slots < 2 || (P.debug & 4096)) return 1;
     int64_t n_all = 0;
     bool first = false;
     for (int i = 0; i < n_slots; i++) {
@@ -1084,7 +984,7 @@ static int launch_associate_coop_window(lili_ctx* ctx, const int* slots, int n_s
 // (the caller then iterates launch by launch).  Eligible: the configurations of launch_associate_coop with at most 256 workgroups.
 static int launch_iterate_persistent(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, int n_iters) {
     if (!ctx->persistent_iterate || n_iters < 2 || n_iters > 2000) return 1;
-    if (ctx->bin_queries || ctx->tiled || ctx->balance || ctx->nn_cache || ctx->fuse_tail) return 1;
+    if (ctx->fuse_tail) return 1;
     MatchParams P = to_device_params(params);
     if (P.debug & (1 | 2 | 256 | 512 | 4096)) return 1;
     P.no_cost = 1;
@@ -1171,7 +1071,7 @@ static LinArgs lin_args_of(lili_ctx* ctx, int slot, int kind) {
 // reduction + GN update).  Returns 1 if the configuration is not eligible (the caller then takes the three-launch path).
 static int launch_associate_lin_reduce(lili_ctx* ctx, int slot, int kind_mask, const PoseArg& pa, const MatchParams& P, double* d_out) {
     if (!ctx->fuse_lin || !pa.state) return 1;
-    if (ctx->bin_queries || ctx->tiled || ctx->balance || ctx->fuse_tail || (P.debug & 4096)) return 1;
+    if (ctx->fuse_tail || (P.debug & 4096)) return 1;
     const bool scaled = P.scale_surf_num > 0 || P.scale_edge_num > 0;      // ROT: only through the count barrier of the cooperative kernel (small launches)
     Slot& sl = ctx->slots[slot];
     AssocArgs A[2] = {AssocArgs{}, AssocArgs{}};
@@ -1209,11 +1109,6 @@ static int launch_associate_lin_reduce(lili_ctx* ctx, int slot, int kind_mask, c
             HIPCHK(ks.dbg_idx.ensure((size_t)n * 5 * sizeof(int)));
             HIPCHK(ks.dbg_d2.ensure((size_t)n * 5 * sizeof(float)));
             a.dbg_idx = ks.dbg_idx.as<int>(); a.dbg_d2 = ks.dbg_d2.as<float>();
-        }
-        if (ctx->nn_cache) {
-            HIPCHK(ks.nn_cache.ensure((size_t)n * 5 * sizeof(int)));
-            if (!ks.nn_cache_valid) { HIPCHK(hipMemsetAsync(ks.nn_cache.p, 0xFF, (size_t)n * 5 * sizeof(int), ctx->stream)); ks.nn_cache_valid = true; }
-            a.nn_cache = ks.nn_cache.as<int>();
         }
         HIPCHK(ks.partials_wave.ensure((size_t)ks.n_blocks * kPartialStride * sizeof(double)));
         a.block_counts = ks.block_counts.as<int>(); a.nb = nblocks(n, bs);

@@ -75,13 +75,9 @@ struct KindSlot {
     int64_t n_q = 0;
     bool has_queries = false, has_records = false;
     bool has_aux = false;    // the query cloud carried the auxiliary float (Livox: reflectivity)
-    DevBuf q, rec0, rec1, valid, dbg_idx, dbg_d2, partials, partials_wave, perm, keys, block_counts, tiles, nn_cache, order, block_cost;
-    int launches = 0;        // association launches since set_queries (the dispatch order is rebuilt before launches 2 and 4)
-    bool order_valid = false;
-    bool nn_cache_valid = false;   // nn_cache holds the neighbours of the last association of THIS scan against the CURRENT map index
+    DevBuf q, rec0, rec1, valid, dbg_idx, dbg_d2, partials, partials_wave, block_counts;
+    int launches = 0;        // association launches since set_queries
     int n_assoc_blocks = 0;  // grid of the last association launch (= number of per-block counts)
-    int n_tiles = 0;       // association grid when binned (tiles never span two super-cells)
-    bool binned = false;   // perm holds the super-cell (Morton) order of the queries for the current scan
     int n_blocks = 0;      // association grid (one thread per query)
     int n_lin_blocks = 0;  // linearisation grid (grid-stride, <= kMaxLinBlocks partials)
 };
@@ -148,9 +144,6 @@ struct lili_ctx {
     bool readback_gather = true;
     double* h_records = nullptr;   // page-locked landing area for LILI_MAX_SLOTS Gram records (+ 2 x LILI_MAX_SLOTS counts behind them)
     double* h_records_dev = nullptr;   // the same memory as the device sees it: the blocking calls' reduction kernels write their records THERE (round 4: no copy launch between the kernel and the host)
-    DevBuf bin_hist, bin_start, bin_sums, bin_tcnt, bin_toff;   // query binning scratch
-    bool bin_queries = false;   // trust the caller's order (extractor output is ring-/voxel-ordered, i.e. coherent)
-    bool tiled = false;         // LDS-staged tiles: measured slower than the direct path once selection is branch-free
     int max_cells = 1 << 27;
     int grid_reach = 2;          // 2: cells smaller than the gate radius, inner 3x3x3 block first, shell on demand (knn5_grid)
     bool fuse_tail = false;      // reduce (+ GN) inside the linearisation launch (its last block sweeps the other blocks' granule-tagged partials):
@@ -158,7 +151,6 @@ struct lili_ctx {
                                  // of freshly published partials through sc1 loads costs one block 3.4 us, a kernel boundary 1.5 us) — A/B only
     bool no_p2p_fusion = false;  // A/B: lili_s2m_iterate_sharded with lili_p2p_allreduce as separate launches (the generic path) instead of inside the count / reduce kernels
     bool merge_kinds = true;     // surf and edge of one keyframe in ONE association launch / ONE linearisation launch
-    bool nn_cache = false;       // seed each query's search bound with its previous 5 neighbours (exact for any pose change)
     int cell_pct = 65;           // reach 2: cell edge in % of 1.01 * gate radius (>= 50)
     bool fine_grid = true;       // measure the map density in lili_map_set and build the fine index when a gate-sized cell holds more than fine_occupancy points
     int fine_occupancy = 12;
@@ -185,7 +177,6 @@ struct lili_ctx {
     bool sort_fused_scan = true;      // radix passes of at most sort_fused_max_tiles tiles: the scatter kernel derives its offsets from the count table itself (no scan launch)
     int sort_digit_bits = 8;     // radix sort of the voxel filter: 8-bit digits (4 = the round-2 passes, A/B)
     int rot_atan = 2;            // ROT extractor: 2 = glibc fdlibm float atan / atan2 (the reference build's bits), 1 = f64 functions rounded to f32
-    bool balance = false;        // cost-ordered dispatch of the association workgroups (AssocSched): measured, no gain — A/B only
     int n_simd = 0;              // SIMDs of the device (CUs x 4)
     void* ext_rot = nullptr;                 // extractor state (lili_extract_rot.hip), freed through ext_rot_free
     void (*ext_rot_free)(void*) = nullptr;

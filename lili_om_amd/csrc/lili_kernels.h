@@ -84,9 +84,9 @@ struct MatchParams {     // device copy of lili_s2m_params (+ derived values)
     double q_lb_inv_jet[4];   // the same inverse as the plane factor sees it on ceres::Jet (LidarKeyframeFactor.h:86): conjugate * (1 / n2)
     double scale_surf_num, scale_edge_num;
     int no_cost;   // 1: the robust cost value (slot 64 of the Gram record) is not computed — the fused iterate loops, whose record never leaves the library
-    int debug;   // ablation switches for profiling only (LILI_DEBUG env): 1 = skip the plane/line fit, 2 = skip the search,
-                 // 2048 = never fall back to the pivoted QR, 4096 = per-workgroup timestamps (tools/assoc_blocks.py), 8192 = no exact-selector
-                 // redo (inexact on ties), 16384 = always the pivoted QR, 32768 = exact (d2, index) selector only
+    int debug;   // LILI_DEBUG env, tests and profiling builds only: 256 / 512 = clock stamps of the linearisation / reduction / association prologue into SlotState::tprof,
+                 // 2048 = never fall back to the pivoted QR, 16384 = always the pivoted QR, 32768 = exact (d2, index) selector only (the tier tests force both tiers and
+                 // compare bit for bit), 4096 = per-workgroup timestamps (only in a -DLILI_PHASE_PROBE build: tools/assoc_blocks.py, tools/assoc_phases.sh)
 };
 
 // Arguments of one kind (surf or edge) of the combined linearisation launch k_linearize.
@@ -103,7 +103,7 @@ struct LinArgs {
 struct AssocArgs {
     const float4* queries; int n_q; GridView g;
     float4* rec0; void* rec1; unsigned char* valid;
-    int* dbg_idx; float* dbg_d2; int* block_counts; int* nn_cache;
+    int* dbg_idx; float* dbg_d2; int* block_counts;
     int nb;
 };
 
@@ -142,12 +142,6 @@ struct WinAssocArgs { GridView g[2]; WinAssocSlot s[kWindowMaxSlots]; int n; };
 constexpr int kPartialDoubles = 40;  // per-block partial: 36 upper-triangle Gram entries, cost, count, 2 spare
 constexpr int kPartialStride = 80;   // doubles per block slot of the partial buffers: 40 plain doubles, or 40 16-byte granules {value, value ^ key}
 constexpr int kBlock = 256;
-// Dispatch-order control of the association kernels (one wave per workgroup).  The hardware places workgroup b on SIMD
-// (b mod #SIMDs) — measured: tools/assoc_blocks.py — so with 3125 waves on 1024 SIMDs the kernel ends when the SIMDs that
-// got 4 waves, or a wave with an unusually long candidate walk, end.  `order[slot]` = index of the 64-query block processed
-// by the workgroup in dispatch slot `slot` (built by k_block_order from the per-block cost of the previous launch of the
-// same scan); `block_cost[block]` = largest number of 4-candidate chunks any lane of the block went through.
-struct AssocSched { const int* order; int* block_cost; };
 constexpr int kAssocBlock = 64;   // association (one query per thread): one wave per workgroup, so the dispatcher balances SIMDs wave by wave
 
 }  // namespace lili

@@ -592,90 +592,6 @@ __global__ __launch_bounds__(1024) void k_scatter9(const int* __restrict__ cell_
     }
 }
 
-// ================================================================================================
-// Query binning (once per scan): order the queries by the Morton code of the map super-cell
-// (sb x sb cells in x,y) they fall into at the association pose, so that the 64 lanes of a wave walk
-// the same cell runs (coalesced / broadcast loads, uniform loop trip counts).  The order only decides
-// which thread handles which query — every per-query result is written at the query's own index, so
-// results do not depend on it.
-// ================================================================================================
-__device__ __forceinline__ unsigned part1by1(unsigned x) {
-    x &= 0x0000ffffu;
-    x = (x | (x << 8)) & 0x00ff00ffu;
-    x = (x | (x << 4)) & 0x0f0f0f0fu;
-    x = (x | (x << 2)) & 0x33333333u;
-    x = (x | (x << 1)) & 0x55555555u;
-    return x;
-}
-
-// atomicAdd(&arr[key], 1) for every active lane, issued as ONE atomic per distinct key per wave (queries
-// of a wave mostly share a bin; 200 k same-address atomics cost milliseconds).  Returns the value before
-// this wave's add for the lane's key; rank = the lane's position among the wave's lanes with that key.
-// Must be called by all 64 lanes.
-__device__ __forceinline__ int wave_aggregated_add(int* __restrict__ arr, int key, bool active, int& rank) {
-    const int lane = threadIdx.x & 63;
-    int result = 0;
-    rank = 0;
-    unsigned long long todo = __ballot(active);
-    while (todo) {
-        int leader = __ffsll((long long)todo) - 1;
-        int k0 = __shfl(key, leader);
-        unsigned long long m = __ballot(active && key == k0);
-        int old = 0;
-        if (lane == leader) old = atomicAdd(&arr[k0], __popcll(m));
-        old = __shfl(old, leader);
-        if (active && key == k0) { result = old; rank = __popcll(m & ((1ull << lane) - 1ull)); }
-        todo &= ~m;
-    }
-    return result;
-}
-
-__global__ void k_bin_count(const float4* __restrict__ queries, int n_q, GridView g, PoseArg pa, MatchParams P, int sb_shift, int n_bins,
-                            int* __restrict__ keys, int* __restrict__ hist) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_q) i = n_q - 1;   // keep whole waves alive for the aggregated atomics; duplicates are masked below
-    const bool live = blockIdx.x * blockDim.x + threadIdx.x < n_q;
-    dq Q2; d3 T2;
-    load_assoc_pose(pa, P, Q2, T2);
-    float4 ql = queries[i];
-    d3 pm = qrot(Q2, d3{(double)ql.x, (double)ql.y, (double)ql.z}) + T2;
-    float px = (float)pm.x, py = (float)pm.y;
-    int key = n_bins - 1;   // non-finite queries go last
-    if (isfinite(px) && isfinite(py)) {
-        double fx = ((double)px - g.ox) * g.inv_cell, fy = ((double)py - g.oy) * g.inv_cell;
-        int cx = (int)fmin(fmax(fx, 0.0), (double)(g.nx - 1));
-        int cy = (int)fmin(fmax(fy, 0.0), (double)(g.ny - 1));
-        unsigned k = part1by1((unsigned)(cx >> sb_shift)) | (part1by1((unsigned)(cy >> sb_shift)) << 1);
-        key = (int)min(k, (unsigned)(n_bins - 1));
-    }
-    if (live) keys[i] = key;
-    int rank;
-    wave_aggregated_add(hist, key, live, rank);
-}
-__global__ void k_bin_scatter(const int* __restrict__ keys, int n_q, const int* __restrict__ starts, int* __restrict__ fill, int* __restrict__ perm) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = i < n_q;
-    int k = live ? keys[i] : 0;
-    int rank;
-    int base = wave_aggregated_add(fill, k, live, rank);
-    if (live) perm[starts[k] + base + rank] = i;
-}
-
-// Tile list: a tile is <= kBlock consecutive entries of `perm` that all belong to ONE bin (super-cell), so a
-// block's neighbourhood is bounded by the super-cell size.  counts[b] = queries in bin b.
-__global__ void k_tile_count(const int* __restrict__ counts, int n_bins, int* __restrict__ tile_cnt) {
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < n_bins) tile_cnt[b] = (counts[b] + kBlock - 1) / kBlock;
-}
-__global__ void k_tile_fill(const int* __restrict__ counts, const int* __restrict__ starts, const int* __restrict__ tile_off, int n_bins,
-                            int2* __restrict__ tiles) {
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= n_bins) return;
-    int c = counts[b], s0 = starts[b], t0 = tile_off[b];
-    for (int k = 0; k * kBlock < c; k++) tiles[t0 + k] = make_int2(s0 + k * kBlock, min(kBlock, c - k * kBlock));
-}
-
-
 // A kind without records counts 0.  `out` (optional): a caller-owned int[2] that receives the same totals (multi-GPU
 // callers all-reduce it in place).
 // `v.seq != 0`: the totals are all-reduced over the ranks inside this launch (lili_p2p_dev.h) — one launch instead of count kernel +
@@ -701,179 +617,18 @@ __global__ __launch_bounds__(kBlock) void k_sum_counts(const int* __restrict__ b
 
 
 
-// ------------------------------------------------------------------------------------------------
-// Tiled exact 5-NN: the 256 queries of a block (consecutive in the binned order, hence spatially
-// compact) share one neighbourhood = bounding box of their cells +-1.  Each (y,z) row of that box is ONE
-// contiguous run of the cell-sorted map (x-fastest cells), so the block stages the rows in LDS with
-// coalesced 16-B loads and every thread then scans its own 3x3x3-cell window from LDS instead of
-// issuing ~100 dependent, divergent global loads.  Rows are staged in batches of <= kTileCap points;
-// degenerate tiles (too many rows / batches) use the direct path.  The candidate set per query is exactly
-// the 27-cell set of knn5_grid, so results are identical.
-// ------------------------------------------------------------------------------------------------
-constexpr int kTileCap = 2048;        // float4 slots staged per batch (32 KiB)
-constexpr int kTileHalf = kTileCap / 2;
-constexpr int kTileRows = kBlock;     // one row descriptor per thread
-constexpr int kTileBatches = 32;
-
-struct TileLds {
-    float4 pts[kTileCap];
-    int row_gbeg[kTileRows];
-    int row_len[kTileRows];
-    int row_off[kTileRows];
-    int batch_base[kTileBatches];
-    int bbox[6];
-    int scan[kBlock / 64 + 1];
-};
-
-template <class TAB>
-__device__ __forceinline__ void knn5_tiled(const GridView& g, TileLds& L, TAB& tab, bool live, float qx, float qy, float qz, Top5& best, int dbg) {
-    const int tid = threadIdx.x;
-    Sel5 sel; sel.init();
-    sel.to_top5(best);
-    // ---- phase 0: cell of every query, block bounding box
-    int cx = 0, cy = 0, cz = 0;
-    bool inr = false;
-    if (live && isfinite(qx) && isfinite(qy) && isfinite(qz)) {
-        cx = cell_coord(qx, g.ox, g.inv_cell); cy = cell_coord(qy, g.oy, g.inv_cell); cz = cell_coord(qz, g.oz, g.inv_cell);
-        inr = !(cx < -1 || cx > g.nx || cy < -1 || cy > g.ny || cz < -1 || cz > g.nz);
-    }
-    if (tid < 3) { L.bbox[tid] = 0x7fffffff; L.bbox[3 + tid] = -0x7fffffff; }
-    if (tid < kTileBatches) L.batch_base[tid] = 0x7fffffff;
-    __syncthreads();
-    {
-        int mnx = inr ? cx : 0x7fffffff, mny = inr ? cy : 0x7fffffff, mnz = inr ? cz : 0x7fffffff;
-        int mxx = inr ? cx : -0x7fffffff, mxy = inr ? cy : -0x7fffffff, mxz = inr ? cz : -0x7fffffff;
-        for (int o = 32; o > 0; o >>= 1) {
-            mnx = min(mnx, __shfl_xor(mnx, o)); mny = min(mny, __shfl_xor(mny, o)); mnz = min(mnz, __shfl_xor(mnz, o));
-            mxx = max(mxx, __shfl_xor(mxx, o)); mxy = max(mxy, __shfl_xor(mxy, o)); mxz = max(mxz, __shfl_xor(mxz, o));
-        }
-        if ((tid & 63) == 0) {
-            atomicMin(&L.bbox[0], mnx); atomicMin(&L.bbox[1], mny); atomicMin(&L.bbox[2], mnz);
-            atomicMax(&L.bbox[3], mxx); atomicMax(&L.bbox[4], mxy); atomicMax(&L.bbox[5], mxz);
-        }
-    }
-    __syncthreads();
-    if (L.bbox[0] > L.bbox[3]) return;   // no query of this block can have a neighbour (uniform exit)
-    const int xa = max(L.bbox[0] - 1, 0), xb = min(L.bbox[3] + 1, g.nx - 1);
-    const int ya = max(L.bbox[1] - 1, 0), yb = min(L.bbox[4] + 1, g.ny - 1);
-    const int za = max(L.bbox[2] - 1, 0), zb = min(L.bbox[5] + 1, g.nz - 1);
-    const int nyt = yb - ya + 1, nzt = zb - za + 1;
-    const long long nrows_ll = (long long)nyt * (long long)nzt;
-    bool direct = xa > xb || nyt <= 0 || nzt <= 0 || nrows_ll > kTileRows;
-    int total = 0;
-    if (!direct) {
-        // ---- phase 1: row descriptors (one per thread) + exclusive scan of the row lengths
-        const int nrows = (int)nrows_ll;
-        int len = 0, gbeg = 0;
-        if (tid < nrows) {
-            int y = ya + tid / nzt, z = za + tid % nzt;
-            int row = (z * g.ny + y) * g.nx;
-            gbeg = g.cell_start[row + xa];
-            len = g.cell_start[row + xb + 1] - gbeg;
-        }
-        int off = block_exclusive_scan(len, L.scan, total);
-        if (tid < nrows) {
-            L.row_gbeg[tid] = gbeg; L.row_len[tid] = len; L.row_off[tid] = off;
-            if (len > 0 && len <= kTileHalf) {
-                int bq = (off + len - 1) / kTileHalf;
-                if (bq < kTileBatches) atomicMin(&L.batch_base[bq], off);
-            }
-        }
-        if ((total + kTileHalf - 1) / kTileHalf > kTileBatches) direct = true;   // uniform: `total` is block-wide
-        __syncthreads();
-    }
-    if (direct) {   // degenerate tile: per-thread search in global memory (identical candidate set)
-        if (inr) {
-            Top5 t; knn5_grid(g, tab, qx, qy, qz, __uint_as_float(0x7f800000u), t);
-            best = t;
-        }
-        return;
-    }
-    if (dbg & 16) return;
-    // ---- phase 2: this thread's 9 windows (global index ranges) and the tile rows they live in
-    int wbeg[9], wend[9], wrow[9];
-    float wlb[9];
-    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
-#pragma unroll
-    for (int n = 0; n < 9; n++) {
-        const int w = n;   // slot n holds row row_order(n): centre first, so later rows can be pruned
-        const int ro = row_order(n);
-        int y = cy + (ro / 3 - 1), z = cz + (ro % 3 - 1);
-        wlb[n] = row_lower_bound(g, qy, qz, cy, cz, ro / 3 - 1, ro % 3 - 1);
-        bool okw = inr && x0 <= x1 && y >= 0 && y < g.ny && z >= 0 && z < g.nz;
-        wrow[w] = okw ? (y - ya) * nzt + (z - za) : -1;
-        int row = (z * g.ny + y) * g.nx;
-        wbeg[w] = okw ? g.cell_start[row + x0] : 0;
-        wend[w] = okw ? g.cell_start[row + x1 + 1] : 0;
-    }
-    if (dbg & 32) return;
-    // ---- phase 3: batches of rows through LDS
-    const int nrows = (int)nrows_ll;
-    const int nbatch = (total + kTileHalf - 1) / kTileHalf;
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int k = 0; k < nbatch; k++) {
-        const int base = L.batch_base[k];
-        if (base != 0x7fffffff && !(dbg & 8)) {
-            for (int r = wave; r < nrows; r += kBlock / 64) {
-                int len = L.row_len[r];
-                if (len <= 0 || len > kTileHalf) continue;
-                int off = L.row_off[r];
-                if ((off + len - 1) / kTileHalf != k) continue;
-                const float4* src = g.pts + L.row_gbeg[r];
-                float4* dst = L.pts + (off - base);
-                for (int l = lane; l < len; l += 64) dst[l] = src[l];
-            }
-        }
-        __syncthreads();
-        if (base != 0x7fffffff && !(dbg & 4)) {
-#pragma unroll
-            for (int w = 0; w < 9; w++) {
-                int r = wrow[w];
-                if (r < 0 || wbeg[w] >= wend[w]) continue;
-                int len = L.row_len[r], off = L.row_off[r];
-                if (len > kTileHalf || (off + len - 1) / kTileHalf != k) continue;
-                if (wlb[w] > sel.worst()) continue;
-                const int shift = (off - base) - L.row_gbeg[r];   // LDS slot = global index + shift
-                int j = wbeg[w];
-                for (; j + 1 < wend[w]; j += 2) {
-                    float4 p0 = L.pts[j + shift], p1 = L.pts[j + 1 + shift];
-                    float d0 = dist2(p0, qx, qy, qz), d1 = dist2(p1, qx, qy, qz);
-                    sel.insert(d0, p0, j);
-                    sel.insert(d1, p1, j + 1);
-                }
-                if (j < wend[w]) { float4 p0 = L.pts[j + shift]; sel.insert(dist2(p0, qx, qy, qz), p0, j); }
-            }
-        }
-        __syncthreads();
-    }
-    // ---- phase 4: rows longer than half a batch are scanned straight from global memory
-#pragma unroll
-    for (int w = 0; w < 9; w++) {
-        int r = wrow[w];
-        if (r < 0 || wbeg[w] >= wend[w]) continue;
-        if (L.row_len[r] <= kTileHalf) continue;
-        if (wlb[w] > sel.worst()) continue;
-        for (int j = wbeg[w]; j < wend[w]; j++) {
-            float4 p = g.pts[j];
-            sel.insert(dist2(p, qx, qy, qz), p, j);
-        }
-    }
-    sel.to_top5(best);
-}
-
-template <bool TILED, int BS, class TILE, class TAB>
+template <int BS, class TAB>
 __device__ __forceinline__ void assoc_surf_body(
-        const float4* __restrict__ queries, const int* __restrict__ perm, const int2* __restrict__ tiles, int n_q, const GridView& g, const PoseArg& pa, const MatchParams& P,
+        const float4* __restrict__ queries, int n_q, const GridView& g, const PoseArg& pa, const MatchParams& P,
         float4* __restrict__ rec_nd, double* __restrict__ rec_score, unsigned char* __restrict__ valid,
-        int* __restrict__ dbg_idx, float* __restrict__ dbg_d2, int* __restrict__ block_counts, int* __restrict__ nn_cache, const AssocSched& sched,
-        int vbid, TILE& L, TAB& tab, LaneRec* rec_out = nullptr) {
-    const long long t_begin = (P.debug & 4096) ? (long long)__builtin_amdgcn_s_memrealtime() : 0ll;   // profiling aid (tools/assoc_blocks.py)
-    const int bid = sched.order ? sched.order[vbid] : vbid;
-    const int2 tile = tiles ? tiles[bid] : make_int2(bid * BS, min(BS, n_q - bid * BS));
-    const bool live = (int)threadIdx.x < tile.y;
-    int t = tile.x + threadIdx.x;
-    int i = live ? (perm ? perm[t] : t) : 0;
-    float4 ql = queries[live ? i : 0];     // requested before the (dependent, scalar) pose loads: the two latencies overlap
+        int* __restrict__ dbg_idx, float* __restrict__ dbg_d2, int* __restrict__ block_counts, int bid, TAB& tab, LaneRec* rec_out = nullptr) {
+#ifdef LILI_PHASE_PROBE
+    const long long t_begin = (P.debug & 4096) ? (long long)__builtin_amdgcn_s_memrealtime() : 0ll;   // profiling build only (tools/assoc_blocks.py)
+#endif
+    const int i0 = bid * BS;
+    const bool live = i0 + (int)threadIdx.x < n_q;
+    const int i = live ? i0 + (int)threadIdx.x : 0;
+    float4 ql = queries[i];     // requested before the (dependent, scalar) pose loads: the two latencies overlap
     dq Q2; d3 T2;
     load_assoc_pose(pa, P, Q2, T2);
     d3 pmd = qrot(Q2, d3{(double)ql.x, (double)ql.y, (double)ql.z}) + T2;   // transformPoint, L:695-711
@@ -888,17 +643,7 @@ __device__ __forceinline__ void assoc_surf_body(
     PhaseProbe* const pp = nullptr;
 #endif
     PHASE_STAMP(pp, 1, px);                                                 // query loaded and moved into the map frame
-    if (P.debug & 2) {
-#pragma unroll
-        for (int k = 0; k < 5; k++) { nn.d[k] = 0.01f * (k + 1); nn.j[k] = (i * 7 + k) % g.n_points; }
-    } else if constexpr (TILED) knn5_tiled(g, L, tab, live, px, py, pz, nn, P.debug);
-    else if (live) { knn5_grid(g, tab, px, py, pz, seeded_bound(g, P.kd_max_radius, nn_cache, n_q, i, px, py, pz), nn, P.debug, pp); store_nn_cache(nn_cache, n_q, i, nn); }
-    if (BS == 64 && !TILED && sched.block_cost) {   // cost of this block for the next launch's dispatch order
-        int c = live ? nn.aux : 0;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c = max(c, __shfl_xor(c, o));
-        if (threadIdx.x == 0) sched.block_cost[bid] = c;
-    }
+    if (live) knn5_grid(g, tab, px, py, pz, gate_bound(P.kd_max_radius), nn, P.debug, pp);
     bool ok = false;
     if (live) {
         store_debug_nn(g, nn, i, dbg_idx, dbg_d2);
@@ -911,52 +656,46 @@ __device__ __forceinline__ void assoc_surf_body(
         if (rec_out) { rec_out->ql = ql; rec_out->r0 = rn; rec_out->score = score; }
     }
     if (rec_out) rec_out->ok = ok;
-    store_block_count<BS>(ok, block_counts, vbid);
+    store_block_count<BS>(ok, block_counts, bid);
 #ifdef LILI_PHASE_PROBE
     if ((P.debug & 4096) && dbg_d2 && threadIdx.x == 0) {   // phase stamps as ticks since the block began, over the d2 debug rows of the block's first two queries
-        for (int k = 1; k <= 6; k++) dbg_d2[(size_t)tile.x * 5 + k] = probe.t[k] ? (float)(probe.t[k] - t_begin) : -1.0f;
+        for (int k = 1; k <= 6; k++) dbg_d2[(size_t)i0 * 5 + k] = probe.t[k] ? (float)(probe.t[k] - t_begin) : -1.0f;
     }
-#endif
     if ((P.debug & 4096) && dbg_idx && threadIdx.x == 0) {   // per-workgroup begin / end ticks (100 MHz) and hardware id into the debug rows of the block's first query
-        long long* o = (long long*)(dbg_idx + (size_t)tile.x * 5);
+        long long* o = (long long*)(dbg_idx + (size_t)i0 * 5);
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         o[0] = t_begin; o[1] = (long long)__builtin_amdgcn_s_memrealtime();
-        dbg_idx[(size_t)tile.x * 5 + 4] = (int)((hw & 0xffffu) | (xcc << 16));
+        dbg_idx[(size_t)i0 * 5 + 4] = (int)((hw & 0xffffu) | (xcc << 16));
     }
     if ((P.debug & 4096) && dbg_idx && live && threadIdx.x != 0) dbg_idx[(size_t)i * 5] = nn.aux;
+#endif
 }
-struct NoTile {};
-template <bool TILED, int BS>
+template <int BS>
 __global__ __launch_bounds__(BS) void k_associate_surf(
-        const float4* __restrict__ queries, const int* __restrict__ perm, const int2* __restrict__ tiles, int n_q, GridView g, PoseArg pa, MatchParams P,
+        const float4* __restrict__ queries, int n_q, GridView g, PoseArg pa, MatchParams P,
         float4* __restrict__ rec_nd, double* __restrict__ rec_score, unsigned char* __restrict__ valid,
-        int* __restrict__ dbg_idx, float* __restrict__ dbg_d2, int* __restrict__ block_counts, int* __restrict__ nn_cache, AssocSched sched) {
-    __shared__ typename std::conditional<TILED, TileLds, NoTile>::type L;
+        int* __restrict__ dbg_idx, float* __restrict__ dbg_d2, int* __restrict__ block_counts) {
     __shared__ RowTabT<BS> tab;
-    assoc_surf_body<TILED, BS>(queries, perm, tiles, n_q, g, pa, P, rec_nd, rec_score, valid, dbg_idx, dbg_d2, block_counts, nn_cache, sched, (int)blockIdx.x, L, tab);
+    assoc_surf_body<BS>(queries, n_q, g, pa, P, rec_nd, rec_score, valid, dbg_idx, dbg_d2, block_counts, (int)blockIdx.x, tab);
 }
 
-template <bool TILED, int BS, class TILE, class TAB>
+template <int BS, class TAB>
 __device__ __forceinline__ void assoc_edge_body(
-        const float4* __restrict__ queries, const int* __restrict__ perm, const int2* __restrict__ tiles, int n_q, const GridView& g, const PoseArg& pa, const MatchParams& P,
+        const float4* __restrict__ queries, int n_q, const GridView& g, const PoseArg& pa, const MatchParams& P,
         float4* __restrict__ rec_a, float4* __restrict__ rec_b, unsigned char* __restrict__ valid,
-        int* __restrict__ dbg_idx, float* __restrict__ dbg_d2, int* __restrict__ block_counts, int* __restrict__ nn_cache, const AssocSched& sched,
-        int vbid, TILE& L, TAB& tab, LaneRec* rec_out = nullptr) {
-    const int bid = sched.order ? sched.order[vbid] : vbid;
-    const int2 tile = tiles ? tiles[bid] : make_int2(bid * BS, min(BS, n_q - bid * BS));
-    const bool live = (int)threadIdx.x < tile.y;
-    int t = tile.x + threadIdx.x;
-    int i = live ? (perm ? perm[t] : t) : 0;
-    float4 ql = queries[live ? i : 0];     // requested before the (dependent, scalar) pose loads: the two latencies overlap
+        int* __restrict__ dbg_idx, float* __restrict__ dbg_d2, int* __restrict__ block_counts, int bid, TAB& tab, LaneRec* rec_out = nullptr) {
+    const int i0 = bid * BS;
+    const bool live = i0 + (int)threadIdx.x < n_q;
+    const int i = live ? i0 + (int)threadIdx.x : 0;
+    float4 ql = queries[i];     // requested before the (dependent, scalar) pose loads: the two latencies overlap
     dq Q2; d3 T2;
     load_assoc_pose(pa, P, Q2, T2);
     d3 pmd = qrot(Q2, d3{(double)ql.x, (double)ql.y, (double)ql.z}) + T2;
     float px = (float)pmd.x, py = (float)pmd.y, pz = (float)pmd.z;
     Top5 nn; nn.have = false;
-    if constexpr (TILED) knn5_tiled(g, L, tab, live, px, py, pz, nn, P.debug);
-    else if (live) { knn5_grid(g, tab, px, py, pz, seeded_bound(g, P.edge_gate, nn_cache, n_q, i, px, py, pz), nn); store_nn_cache(nn_cache, n_q, i, nn); }
+    if (live) knn5_grid(g, tab, px, py, pz, gate_bound(P.edge_gate), nn);
     bool ok = false;
     if (live) {
         store_debug_nn(g, nn, i, dbg_idx, dbg_d2);
@@ -966,30 +705,25 @@ __device__ __forceinline__ void assoc_edge_body(
         if (rec_out) { rec_out->ql = ql; rec_out->r0 = ra; rec_out->r1 = rb; }
     }
     if (rec_out) rec_out->ok = ok;
-    store_block_count<BS>(ok, block_counts, vbid);
+    store_block_count<BS>(ok, block_counts, bid);
 }
-template <bool TILED, int BS>
+template <int BS>
 __global__ __launch_bounds__(BS) void k_associate_edge(
-        const float4* __restrict__ queries, const int* __restrict__ perm, const int2* __restrict__ tiles, int n_q, GridView g, PoseArg pa, MatchParams P,
+        const float4* __restrict__ queries, int n_q, GridView g, PoseArg pa, MatchParams P,
         float4* __restrict__ rec_a, float4* __restrict__ rec_b, unsigned char* __restrict__ valid,
-        int* __restrict__ dbg_idx, float* __restrict__ dbg_d2, int* __restrict__ block_counts, int* __restrict__ nn_cache, AssocSched sched) {
-    __shared__ typename std::conditional<TILED, TileLds, NoTile>::type L;
+        int* __restrict__ dbg_idx, float* __restrict__ dbg_d2, int* __restrict__ block_counts) {
     __shared__ RowTabT<BS> tab;
-    assoc_edge_body<TILED, BS>(queries, perm, tiles, n_q, g, pa, P, rec_a, rec_b, valid, dbg_idx, dbg_d2, block_counts, nn_cache, sched, (int)blockIdx.x, L, tab);
+    assoc_edge_body<BS>(queries, n_q, g, pa, P, rec_a, rec_b, valid, dbg_idx, dbg_d2, block_counts, (int)blockIdx.x, tab);
 }
 
 // Both kinds of one keyframe in ONE launch (the reference back-end associates corners and planes of a keyframe back to back,
 // L/src/BackendFusion.cpp:935-936): workgroups [0, E.nb) take the (few) edge queries, the rest the surf queries — one wave per
 // workgroup, direct search path.  Saves a kernel boundary and the fill / drain of a second grid per outer iteration.
 __global__ __launch_bounds__(kAssocBlock) void k_associate_both(AssocArgs S, AssocArgs E, PoseArg pa, MatchParams P) {
-    __shared__ NoTile L;
     __shared__ RowTabT<kAssocBlock> tab;
-    const AssocSched sched{nullptr, nullptr};
     const int b = (int)blockIdx.x;
-    if (b < E.nb) assoc_edge_body<false, kAssocBlock>(E.queries, nullptr, nullptr, E.n_q, E.g, pa, P, E.rec0, reinterpret_cast<float4*>(E.rec1), E.valid, E.dbg_idx, E.dbg_d2,
-                                                      E.block_counts, E.nn_cache, sched, b, L, tab);
-    else assoc_surf_body<false, kAssocBlock>(S.queries, nullptr, nullptr, S.n_q, S.g, pa, P, S.rec0, reinterpret_cast<double*>(S.rec1), S.valid, S.dbg_idx, S.dbg_d2,
-                                             S.block_counts, S.nn_cache, sched, b - E.nb, L, tab);
+    if (b < E.nb) assoc_edge_body<kAssocBlock>(E.queries, E.n_q, E.g, pa, P, E.rec0, reinterpret_cast<float4*>(E.rec1), E.valid, E.dbg_idx, E.dbg_d2, E.block_counts, b, tab);
+    else assoc_surf_body<kAssocBlock>(S.queries, S.n_q, S.g, pa, P, S.rec0, reinterpret_cast<double*>(S.rec1), S.valid, S.dbg_idx, S.dbg_d2, S.block_counts, b - E.nb, tab);
 }
 // Association on a map that is much denser than the gate radius (SURVEY §8d Config 2, variant B: 5 M points at a 0.05 m leaf — ~170
 // points per gate-sized cell, ~1500 candidates in the inner 27 cells).  The map then carries a SECOND index with cells sized from the
@@ -1030,55 +764,8 @@ __global__ __launch_bounds__(kAssocBlock) void k_associate_fine(AssocArgs A, Gri
     }
     store_block_count<kAssocBlock>(ok, A.block_counts, (int)blockIdx.x);
 }
-#define LILI_ASSOC_ARGS_SURF const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, int*, int*, AssocSched
-#define LILI_ASSOC_ARGS_EDGE const float4*, const int*, const int2*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, int*, int*, AssocSched
-template __global__ void k_associate_surf<true, kBlock>(LILI_ASSOC_ARGS_SURF);
-template __global__ void k_associate_surf<false, kBlock>(LILI_ASSOC_ARGS_SURF);
-template __global__ void k_associate_surf<false, kAssocBlock>(LILI_ASSOC_ARGS_SURF);
-template __global__ void k_associate_edge<true, kBlock>(LILI_ASSOC_ARGS_EDGE);
-template __global__ void k_associate_edge<false, kBlock>(LILI_ASSOC_ARGS_EDGE);
-template __global__ void k_associate_edge<false, kAssocBlock>(LILI_ASSOC_ARGS_EDGE);
-
-// Dispatch order for the next association launch of the same scan (see AssocSched).  One workgroup: bitonic sort of
-// (cost descending, block index) keys in LDS, then the assignment
-//   * the r = n mod S SIMDs that receive one wave more than the others (slots s, S+s, ... with s < r) take the (q+1) r
-//     LIGHTEST blocks (q = n / S),
-//   * the other S - r SIMDs take q blocks each from the rest in snake order (heaviest with lightest).
-// n <= kMaxOrderBlocks.  Cost model: a block's work ~ kCostBase + its chunk count (skeleton + fit + chunks).
-constexpr int kMaxOrderBlocks = 8192;
-__global__ __launch_bounds__(1024) void k_block_order(const int* __restrict__ block_cost, int n, int S, int* __restrict__ order) {
-    __shared__ unsigned key[kMaxOrderBlocks];
-    int np2 = 1; while (np2 < n) np2 <<= 1;
-    for (int i = threadIdx.x; i < np2; i += blockDim.x)
-        key[i] = i < n ? ((unsigned)(255 - min(max(block_cost[i], 0), 255)) << 16) | (unsigned)i : 0xffffffffu;
-    __syncthreads();
-    for (int k = 2; k <= np2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < np2; i += blockDim.x) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const unsigned a = key[i], b = key[l];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { key[i] = b; key[l] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    const int q = n / S, r = n % S;
-    const int nl = (q + 1) * r, nh = n - nl;          // light blocks: ranks nh .. n-1 of the descending order
-    for (int rank = threadIdx.x; rank < n; rank += blockDim.x) {
-        const int blk = (int)(key[rank] & 0xffffu);
-        int slot;
-        if (rank >= nh) { const int t = rank - nh; slot = (t / r) * S + (t % r); }
-        else {
-            const int w = S - r, tier = rank / w;
-            int pos = rank % w;
-            if (tier & 1) pos = w - 1 - pos;
-            slot = tier * S + r + pos;
-        }
-        order[slot] = blk;
-    }
-}
+template __global__ void k_associate_surf<kAssocBlock>(const float4*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, int*);
+template __global__ void k_associate_edge<kAssocBlock>(const float4*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, int*);
 
 
 // ---- fused tail: the whole inner iteration (linearise + reduce + solve + pose update) is ONE launch.  The block with the highest
@@ -1147,17 +834,13 @@ __global__ __launch_bounds__(kLinBlock) void k_linearize_window(WinLinArgs W, Ma
 // four waves, for larger scans).
 template <int BS>
 __global__ __launch_bounds__(BS) void k_associate_lin(AssocArgs S, AssocArgs E, PoseArg pa, MatchParams P, double* __restrict__ part_surf, double* __restrict__ part_edge) {
-    __shared__ NoTile L;
     __shared__ __attribute__((aligned(16))) RowTabT<BS> tab;
     static_assert(sizeof(RowTabT<BS>) >= (size_t)BS * kRow * sizeof(double), "Gram staging rows must fit the row table");
-    const AssocSched sched{nullptr, nullptr};
     const int b = (int)blockIdx.x;
     const bool edge = b < E.nb;
     LaneRec rec{};
-    if (edge) assoc_edge_body<false, BS>(E.queries, nullptr, nullptr, E.n_q, E.g, pa, P, E.rec0, reinterpret_cast<float4*>(E.rec1), E.valid, E.dbg_idx, E.dbg_d2,
-                                         E.block_counts, E.nn_cache, sched, b, L, tab, &rec);
-    else assoc_surf_body<false, BS>(S.queries, nullptr, nullptr, S.n_q, S.g, pa, P, S.rec0, reinterpret_cast<double*>(S.rec1), S.valid, S.dbg_idx, S.dbg_d2,
-                                    S.block_counts, S.nn_cache, sched, b - E.nb, L, tab, &rec);
+    if (edge) assoc_edge_body<BS>(E.queries, E.n_q, E.g, pa, P, E.rec0, reinterpret_cast<float4*>(E.rec1), E.valid, E.dbg_idx, E.dbg_d2, E.block_counts, b, tab, &rec);
+    else assoc_surf_body<BS>(S.queries, S.n_q, S.g, pa, P, S.rec0, reinterpret_cast<double*>(S.rec1), S.valid, S.dbg_idx, S.dbg_d2, S.block_counts, b - E.nb, tab, &rec);
     dq Q; d3 T;
     load_body_pose(pa, Q, T);
     double Jr[8] = {0, 0, 0, 0, 0, 0, 0, 0};

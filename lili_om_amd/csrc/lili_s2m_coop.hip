@@ -283,7 +283,7 @@ __global__ __launch_bounds__(kCoopBlock) void k_associate_coop_window(WinAssocAr
     AssocArgs A{};
     A.queries = k.queries; A.n_q = k.n_q; A.g = W.g[edge ? 1 : 0];
     A.rec0 = k.rec0; A.rec1 = k.rec1; A.valid = k.valid;
-    A.dbg_idx = k.dbg_idx; A.dbg_d2 = k.dbg_d2; A.block_counts = k.block_counts; A.nn_cache = nullptr;
+    A.dbg_idx = k.dbg_idx; A.dbg_d2 = k.dbg_d2; A.block_counts = k.block_counts;
     A.nb = k.nb;
     assoc_coop_block<L, false>(A, edge, edge ? b : b - ws.k[1].nb, b, ws.pa, P, nullptr, nullptr, nullptr, 0);
 }

@@ -463,7 +463,7 @@ __device__ __forceinline__ void knn5_grid(const GridView& g, TAB& tab, float qx,
     if (dbg & 32768) { knn5_grid_sel<Sel5>(g, tab, qx, qy, qz, bound, best); return; }   // A/B: exact selector only
     const bool redo = knn5_grid_sel<Sel5K>(g, tab, qx, qy, qz, bound, best, pp);
     PHASE_STAMP(pp, 5, best.d[4]);                                          // five winners resolved (exact distances, order)
-    if (redo && !(dbg & 8192)) knn5_grid_sel<Sel5>(g, tab, qx, qy, qz, bound, best);   // bit 8192: profiling only (results then inexact on ties)
+    if (redo) knn5_grid_sel<Sel5>(g, tab, qx, qy, qz, bound, best);
 }
 
 // Correspondence counting without atomics on a shared word (3128 same-address atomics cost ~40 us on
@@ -587,41 +587,11 @@ __device__ __forceinline__ void store_debug_nn(const GridView& g, const Top5& nn
     }
 }
 
-// Search bound of one query: the reference's gate, tightened by the query's 5 neighbours of the previous association
-// of the same scan against the same map index (positions in the cell-sorted array, -1 = none).  Those are five real
-// map points, so the true 5th-nearest distance cannot exceed their largest distance w at the new pose; everything
-// farther is irrelevant and rows / shell cells beyond it are pruned from the first candidate on.  The result is the
-// same exact 5-NN for any pose change — the cache only makes the bound tight when the pose moved little.
-__device__ __forceinline__ float seeded_bound(const GridView& g, double gate, const int* __restrict__ nn_cache, int n_q, int i,
-                                              float px, float py, float pz) {
-    float bound = gate_bound(gate);
-    if (nn_cache) {
-        int c0 = nn_cache[i], c1 = nn_cache[(size_t)n_q + i], c2 = nn_cache[(size_t)2 * n_q + i], c3 = nn_cache[(size_t)3 * n_q + i],
-            c4 = nn_cache[(size_t)4 * n_q + i];
-        if ((c0 | c1 | c2 | c3 | c4) >= 0) {
-            float w = dist2(load_pt(g, c0), px, py, pz);
-            w = fmaxf(w, dist2(load_pt(g, c1), px, py, pz));
-            w = fmaxf(w, dist2(load_pt(g, c2), px, py, pz));
-            w = fmaxf(w, dist2(load_pt(g, c3), px, py, pz));
-            w = fmaxf(w, dist2(load_pt(g, c4), px, py, pz));
-            if (w < bound) bound = __uint_as_float(__float_as_uint(w) + 1u);   // strictly above w: the five seeds themselves must enter
-        }
-    }
-    return bound;
-}
-__device__ __forceinline__ void store_nn_cache(int* __restrict__ nn_cache, int n_q, int i, const Top5& nn) {
-    if (!nn_cache) return;
-#pragma unroll
-    for (int k = 0; k < 5; k++) nn_cache[(size_t)k * n_q + i] = nn.j[k];
-}
-
 // findCorrespondingSurfFeatures body after the kNN (L/src/BackendFusion.cpp:1613-1679 and variants)
 __device__ __forceinline__ bool surf_fit(const GridView& g, const MatchParams& P, const Top5& nn, float4 ql, float px, float py, float pz,
                                          float4& rn, double& score) {
     rn = make_float4(0.f, 0.f, 0.f, 0.f);
     score = 0.0;
-    if ((P.debug & 1) && nn.j[4] >= 0) { rn.x = nn.d[4]; return nn.d[4] < 0.5f; }
-    if (P.debug & 65536) { rn.x = nn.d[4]; return nn.j[4] >= 0 && (double)nn.d[4] < P.kd_max_radius; }   // ablation (tools/assoc_split_probe.sh): the search alone, every path incl. the cooperative kernels
     if (!(nn.j[4] >= 0 && (double)nn.d[4] < P.kd_max_radius)) return false;   // L:1615
     float4 m[5];
 #pragma unroll
@@ -925,14 +895,13 @@ __device__ __forceinline__ void lin_surf_body(const LinArgs& A, int bid, const P
     // vec_surf_scores[i] * 1000 / vec_surf_res_cnt  =  (score * 1000.0) / (double)N — a multiply, then a true division.
     // The block counts are requested first, the geometry of the first tile (which does not depend on N) runs while they travel, the barriers of the
     // count sum come after it (round 4: they used to stand in front of all the arithmetic).
-    const bool sum_counts = !(P.debug & 128) && P.scale_surf_num > 0 && A.block_counts;
+    const bool sum_counts = P.scale_surf_num > 0 && A.block_counts;
     const int wave_cnt = sum_counts ? sum_block_counts_begin(A.block_counts, A.n_bc) : 0;
     const bool ok0 = i0 < n_q && v0;
     SurfLinGeom g0;
     if (ok0) g0 = surf_lin_geom(P, Q, T, qlb_inv, ql0, nd0);
     double n_den = 1.0;
-    if (P.debug & 128) n_den = 190000.0;
-    else if (P.scale_surf_num > 0) n_den = (double)(A.block_counts ? sum_block_counts_end(wave_cnt) : (n_global ? n_global[0] : state->n_res[0]));
+    if (P.scale_surf_num > 0) n_den = (double)(A.block_counts ? sum_block_counts_end(wave_cnt) : (n_global ? n_global[0] : state->n_res[0]));
     tstamp(state, P.debug, 100, 1);
     for (int base = bid * BS; base < n_q; base += A.nb * BS) {
         int i = base + threadIdx.x;

@@ -313,110 +313,12 @@ def test_mid_size_outdoor_scene(gpu_ctx, oracle):
     assert np.abs(G - Go).max() <= 2e-6 * np.abs(Go).max()
 
 
-@pytest.mark.parametrize("opts", [dict(bin_queries=1, tiled=0), dict(bin_queries=1, tiled=1)])
-def test_query_order_options_do_not_change_results(gpu_ctx, oracle, opts):
-    """Binning / LDS tiling only change which thread handles which query: neighbour lists, records and the
-    Gram must be identical to the default path (and to the oracle)."""
-    w = synth.make_workload(n_map=600_000, n_az=391, half_extent=(150.0, 150.0))
-    P = L.make_params("rot")
-    PO = oracle.params("rot")
-    rng = np.random.default_rng(4)
-    scan = w["scan_xyz"][rng.permutation(w["scan_xyz"].shape[0])]     # incoherent order on purpose
-    tb, qb = L.api.body_pose_from_lidar(w["lidar_t"], w["lidar_q"], P)
-    t0, q0 = synth.perturbed_pose(tb, qb, np.random.default_rng(synth.SEED_POSE), 0.3, 2.0)
-    Q2, T2 = L.api.assoc_transform(t0, q0, P)
-    out = []
-    try:
-        for o in (dict(bin_queries=0, tiled=0), opts):
-            for k, v in o.items():
-                gpu_ctx.set_option(k, v)
-            gpu_ctx.set_debug(True)
-            m = L.ScanToMapMatcher(gpu_ctx, P)
-            m.set_input_cloud(L.KIND_SURF, w["map_xyz"])
-            m.set_queries(0, L.KIND_SURF, scan)
-            n = m.find_corresponding_surf_features(0, Q2, T2)
-            idx, d2 = m.neighbors(0, L.KIND_SURF, scan.shape[0])
-            rec = m.surf_records(0, scan.shape[0])
-            G, cost, counts = m.linearize(0, t0, q0, L.MASK_SURF)
-            out.append((n, idx, d2, rec, G, cost))
-    finally:
-        gpu_ctx.set_option("bin_queries", 0)
-        gpu_ctx.set_option("tiled", 0)
-    a, b = out
-    assert a[0] == b[0] > 5000
-    inside = a[2][:, 4] < 1.0
-    assert np.array_equal(a[1][inside], b[1][inside]) and np.array_equal(a[2][inside], b[2][inside])
-    for k in ("query_index", "cp", "n", "d", "score"):
-        assert np.array_equal(a[3][k], b[3][k])
-    assert np.array_equal(a[4], b[4]) and a[5] == b[5]
-    tree = oracle.KdTree(w["map_xyz"])
-    rs = oracle.associate_surf(tree, None, scan, None, Q2, T2, PO, nthreads=8)
-    assert rs["count"] == b[0]
-    assert np.array_equal(b[1][inside], rs["nn_idx"][inside])
+_OPTION_DEFAULTS = {"fuse_tail": 0, "merge_kinds": 1}
 
 
-def test_split_multi_gpu_path_equals_fused_path(gpu_ctx, oracle, launch_by_launch):
-    """The stage-by-stage path a multi-GPU caller uses (associate_dev, counts export / [all-reduce] / import,
-    linearize_dev, [all-reduce], gn_update) with world size 1 must give exactly the fused iterate() result."""
-    import torch
-    room = synth.make_room(seed=17, n_query=6000, n_edge_query=100)
-    P, PO, m = _setup(gpu_ctx, oracle, "rot", room, with_refl=False)
-    tb, qb = L.api.body_pose_from_lidar(room["t_true"], room["q_true"], P)
-    t0, q0 = synth.perturbed_pose(tb, qb, np.random.default_rng(5), 0.1, 0.8)
-    m.pose_set(0, t0, q0)
-    m.iterate(0, 4, L.MASK_SURF)
-    tf, qf, st = m.pose_get(0)
-    assert st == 0
-    dev = torch.device("cuda", 0)
-    gram = torch.zeros(L.api.GRAM_DOUBLES, dtype=torch.float64, device=dev)
-    counts = torch.zeros(2, dtype=torch.int32, device=dev)
-    m.pose_set(0, t0, q0)
-    for _ in range(4):
-        m.associate_dev(0, L.MASK_SURF)
-        m.counts_export(0, counts.data_ptr())
-        gpu_ctx.sync()                       # (a real caller all-reduces `counts` on the context's stream here)
-        m.counts_import(0, counts.data_ptr())
-        m.linearize_dev(0, gram.data_ptr(), L.MASK_SURF)
-        gpu_ctx.sync()
-        m.gn_update(0, gram.data_ptr())
-    ts, qs, st = m.pose_get(0)
-    assert st == 0
-    assert np.array_equal(tf, ts) and np.array_equal(qf, qs)
-    assert int(counts[0]) == int(gram[65].item()) > 1000
-
-
-def test_window_iteration_equals_sequential(gpu_ctx, oracle):
-    """lili_s2m_iterate_window (one stream per slot, forked/joined on the context's stream) gives exactly the poses of
-    iterating the slots one after the other."""
-    room = synth.make_room(seed=23, n_query=6000, n_edge_query=100)
-    P, PO, m = _setup(gpu_ctx, oracle, "rot", room, with_refl=False)
-    tb, qb = L.api.body_pose_from_lidar(room["t_true"], room["q_true"], P)
-    rng = np.random.default_rng(11)
-    starts = [synth.perturbed_pose(tb, qb, rng, 0.1, 0.8) for _ in range(3)]
-    shards = [room["q_xyz"][k::3] for k in range(3)]
-    for k in range(3):
-        m.set_queries(k, L.KIND_SURF, shards[k])
-    ref = []
-    for k in range(3):
-        m.pose_set(k, *starts[k])
-        m.iterate(k, 5, L.MASK_SURF)
-        ref.append(m.pose_get(k))
-    for k in range(3):
-        m.pose_set(k, *starts[k])
-    m.iterate_window([0, 1, 2], 5, L.MASK_SURF)
-    for k in range(3):
-        t, q, st = m.pose_get(k)
-        assert st == 0 and np.array_equal(t, ref[k][0]) and np.array_equal(q, ref[k][1])
-    with pytest.raises(L.LiliError):
-        m.iterate_window([0, 0], 1, L.MASK_SURF)
-
-
-_OPTION_DEFAULTS = {"nn_cache": 0, "fuse_tail": 0, "merge_kinds": 1}
-
-
-@pytest.mark.parametrize("opt", ["nn_cache", "fuse_tail", "merge_kinds"])
+@pytest.mark.parametrize("opt", ["fuse_tail", "merge_kinds"])
 def test_tuning_options_do_not_change_results(gpu_ctx, oracle, opt, launch_by_launch):
-    """Launch-structure switches change no result bit: neighbour-cache bound seeding, the reduction + GN update inside the
+    """Launch-structure switches change no result bit: the reduction + GN update inside the
     linearisation launch (fuse_tail: last block to arrive, write-through partials, sharded tickets) against the separate
     k_reduce_partials launch, and one launch for both kinds (merge_kinds) against one launch per kind.  All add the same
     numbers in the same order."""
@@ -821,24 +723,3 @@ def test_native_rccl_communicator_single_rank(gpu_ctx, oracle, launch_by_launch)
         comm.close()
 
 
-def test_balance_option_same_results(gpu_ctx, oracle):
-    """Cost-ordered dispatch (lili_set_option 'balance', off by default: measured without gain) only changes WHICH workgroup
-    handles which 64-query block — records, counts and the Gram are those of the default order bit for bit."""
-    room = synth.make_room(seed=16, n_query=80_000, n_edge_query=100)       # > 1024 one-wave workgroups, so that the order kernel runs
-    P, PO, m = _setup(gpu_ctx, oracle, "rot", room, with_refl=False)
-    t, q, Q2, T2 = _pose(room, P, "rot", np.random.default_rng(11), 0.05, 0.6)
-    nq = room["q_xyz"].shape[0]
-    out = []
-    try:
-        for bal in (0, 1):
-            gpu_ctx.set_option("balance", bal)
-            for _ in range(3):                                               # launches 2 and 4 of a scan rebuild the order
-                n = m.find_corresponding_surf_features(0, Q2, T2)
-            G, cost, counts = m.linearize(0, t, q, L.MASK_SURF)
-            out.append((n, m.surf_records(0, nq), G.copy(), cost))
-    finally:
-        gpu_ctx.set_option("balance", 0)
-    (n0, r0, G0, c0), (n1, r1, G1, c1) = out
-    assert n0 == n1 > 10_000 and np.array_equal(r0["query_index"], r1["query_index"])
-    assert np.array_equal(r0["n"], r1["n"]) and np.array_equal(r0["score"], r1["score"])
-    assert np.array_equal(G0, G1) and c0 == c1

@@ -11,7 +11,7 @@ if [ "$1" = "build" ]; then
     mkdir -p $OUT
     make -C $CS -s
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -DLILI_PHASE_PROBE -c $CS/lili_s2m.hip -o $OUT/lili_s2m_probe.o
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/liblili_hip.so $OUT/lili_s2m_probe.o $CS/lili_api.o $CS/lili_s2m_coop.o $CS/lili_s2m_lm.o $CS/lili_extract_rot.o $CS/lili_extract_livox.o $CS/lili_voxel.o $CS/lili_formats.o $CS/lili_p2p.o
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/liblili_hip.so $OUT/lili_s2m_probe.o $CS/lili_api.o $CS/lili_s2m_coop.o $CS/lili_s2m_lm.o $CS/lili_extract_rot.o $CS/lili_extract_livox.o $CS/lili_voxel.o $CS/lili_formats.o $CS/lili_p2p.o $CS/lili_pipeline.o
     echo built $OUT/liblili_hip.so
 else
     shift || true
