@@ -746,6 +746,49 @@ def main():
                          "replicas_final_pose": {"t": [float(x) for x in tr], "q": [float(x) for x in qr]}}
         m.set_queries(0, L.KIND_SURF, queries)
 
+    # Slot-per-rank window (round 5; configs[4]'s split that scales): N keyframes = N registrations of the whole 200 k-point scan, keyframe i at FULL size on
+    # rank i, every iteration ONE exchange of the N x 72 doubles (an all-gather carried by the rank-order sum) and the Gauss-Newton update of every slot on every rank.
+    # value = N slot-iterations per window iteration / max-over-ranks time.  Self-check: all ranks hold bit-identical poses for all slots.
+    gather_extra = None
+    if world > 1 and world <= 8 and native is not None:
+        try:
+            from lili_om_amd import sharding
+            owner = sharding.window_owners(world, world)
+            slots_g = list(range(world))
+            m.set_queries(rank, L.KIND_SURF, scan)                      # this rank's keyframe: the whole scan, no shard
+            wgram = torch.zeros(world * L.api.GRAM_DOUBLES, dtype=torch.float64, device=dev)
+            starts = [synth.perturbed_pose(t_body, q_body, np.random.default_rng(synth.SEED_POSE + 17 * k), 0.3, 2.0) for k in range(world)]
+
+            def reset_slots():
+                for k in range(world):
+                    m.pose_set(k, starts[k][0], starts[k][1])
+            reset_slots()
+            m.iterate_window_gather(slots_g, args.warmup, owner, rank, wgram.data_ptr(), native.allreduce_fn, native.handle, kind_mask=L.MASK_SURF)
+            reset_slots()
+            fence(); fence()
+            tic = time.perf_counter()
+            m.iterate_window_gather(slots_g, ips, owner, rank, wgram.data_ptr(), native.allreduce_fn, native.handle, kind_mask=L.MASK_SURF)
+            fence()
+            el_g = time.perf_counter() - tic
+            tmax = torch.tensor([el_g], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el_g = float(tmax.item())
+            fin_g = [m.pose_get(k) for k in range(world)]
+            gb = torch.from_numpy(np.concatenate([np.r_[np.asarray(t, np.float64), np.asarray(q, np.float64)] for t, q, _ in fin_g]).view(np.int64).copy()).to(dev)
+            lo_g, hi_g = gb.clone(), gb.clone()
+            dist.all_reduce(lo_g, op=dist.ReduceOp.MIN); dist.all_reduce(hi_g, op=dist.ReduceOp.MAX)
+            st_g = torch.tensor([max(int(st) for _, _, st in fin_g)], dtype=torch.int32, device=dev)
+            dist.all_reduce(st_g, op=dist.ReduceOp.MAX)
+            gather_extra = {"window_gather_slot_iterations_per_s": round(world * ips / el_g, 3), "window_gather_us_per_window_iteration": round(el_g / ips * 1e6, 2),
+                            "window_gather_poses_bit_identical_on_all_ranks": bool(torch.equal(lo_g, hi_g)), "window_gather_max_gn_status": int(st_g.item()),
+                            "window_gather_dt_truth_m": float(max(np.abs(np.asarray(t) - t_body).max() for t, _, _ in fin_g)),
+                            "window_gather_note": f"slot-per-rank window (lili_s2m_iterate_window_gather): {world} keyframes = {world} registrations of the whole {n_scan}-pt scan from {world} start poses, keyframe i at full "
+                                                  f"size on rank i; per iteration every rank associates + linearises ITS keyframe, ONE exchange of {world} x 72 doubles, GN update of every slot on every rank; "
+                                                  f"one registration of {ips} iterations timed; value = {world} x iterations / max-over-ranks time"}
+            m.set_queries(0, L.KIND_SURF, queries)
+        except Exception as e:      # noqa: BLE001
+            gather_extra = {"window_gather_error": repr(e)}
+
     # Multi-GPU self-check: every rank must hold the SAME final pose, bit for bit (strong split: one scan, all ranks apply the same
     # update to the same reduced record).  all-reduce MIN and MAX of the pose bit patterns: equal <=> identical on every rank.
     multi = None
@@ -792,6 +835,9 @@ def main():
                 failures.append(f"multi_gpu_check {multi}")
         extras = dict(weak_extra or {})
         extras.update(replica_extra or {})
+        extras.update(gather_extra or {})
+        if gather_extra and "window_gather_error" not in gather_extra and (not gather_extra["window_gather_poses_bit_identical_on_all_ranks"] or gather_extra["window_gather_max_gn_status"] != 0):
+            failures.append(f"window_gather {gather_extra}")
         if regions:
             extras["headline_regions"] = regions
         if world == 1 and dist is None:

@@ -317,7 +317,9 @@ int lili_set_option(lili_ctx* ctx, const char* name, int value) {
     if (std::strcmp(name, "p2p_fusion") == 0) { ctx->no_p2p_fusion = value == 0; return LILI_OK; }
     if (std::strcmp(name, "readback_gather") == 0) { ctx->readback_gather = value != 0; return LILI_OK; }      // small device-to-host reads of one synchronisation in ONE gather launch (0: a copy launch each, A/B)
     if (std::strcmp(name, "voxel_small") == 0) { ctx->voxel_small = value != 0; return LILI_OK; }      // VoxelGrid of <= 8192 points in one single-workgroup launch (0: the general chain, A/B)
-    if (std::strcmp(name, "overlap_gn") == 0) { ctx->overlap_gn = value != 0; return LILI_OK; }      // lili_s2m_iterate*: the association behind a reduction + GN kernel starts without waiting for it (0: three barriers per iteration)
+#ifdef LILI_OVERLAP_GN
+    if (std::strcmp(name, "overlap_gn") == 0) { ctx->overlap_gn = value != 0; return LILI_OK; }
+#endif      // lili_s2m_iterate*: the association behind a reduction + GN kernel starts without waiting for it (0: three barriers per iteration)
     if (std::strcmp(name, "max_cells") == 0) { if (value < 1) return ctx->fail(LILI_E_ARG, "max_cells must be positive"); ctx->max_cells = value; return LILI_OK; }
     return ctx->fail(LILI_E_ARG, std::string("unknown option ") + name);
 }

@@ -550,8 +550,11 @@ __device__ __forceinline__ void load_assoc_pose(const PoseArg& pa, const MatchPa
         // reduction + GN kernel in front of it left (its start / record built), which that kernel's next launch overwrites
         const bool probe = (P.debug & 256) && blockIdx.x == 0 && threadIdx.x == 0;
         if (probe) const_cast<SlotState*>(pa.state)->tprof[5] = (long long)__builtin_amdgcn_s_memrealtime();
+#ifdef LILI_OVERLAP_GN      // experiment build only (profiles/EXPERIMENTS.md: no gain in situ, so the polling path stays out of the product kernels)
         if (pa.wait_key) wait_published_pose(pa.state, pa.pub, pa.wait_key, pp);
-        else {
+        else
+#endif
+        {
 #pragma unroll
             for (int k = 0; k < 7; k++) pp[k] = pa.state->pose[k];
         }

@@ -68,3 +68,7 @@ def test_bench_ranks_sharing_one_gpu(world):
     assert mg["replicas_final_pose_bit_identical_on_all_ranks"] and mg["replicas_max_gn_status"] == 0
     ex = d["extras"]
     assert ex["replicas_iterations_per_s"] > 0 and ex["weak_scaling_iterations_per_s"] > 0
+    # the slot-per-rank window (one keyframe per rank at full size, one gather per iteration): all ranks end with the same bits for every slot
+    assert ex.get("window_gather_error") is None, ex.get("window_gather_error")
+    assert ex["window_gather_slot_iterations_per_s"] > 0 and ex["window_gather_poses_bit_identical_on_all_ranks"] is True and ex["window_gather_max_gn_status"] == 0
+    assert ex["window_gather_dt_truth_m"] < 0.05
