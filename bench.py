@@ -14,6 +14,7 @@ Prints ONE JSON line on rank 0 (see DESIGN.md §6 for the roofline / cpu_baselin
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -79,13 +80,21 @@ def cpu_baseline(w, queries, t0, q0):
     import lili_om_amd as L
     PO = O.params("rot")
     P = L.make_params("rot")
-    t_build = time.perf_counter()
-    tree = O.KdTree(w["map_xyz"])
-    t_build = time.perf_counter() - t_build
+    import bench_configs as BC
     cpus = single_socket_cpus()
+    quota = BC.cpu_quota_cores()
+    if cpus and quota and quota < len(cpus):
+        cpus = cpus[:quota]                 # the container's CPU quota (cgroup): more threads than that are throttled, not run
     old_aff = os.sched_getaffinity(0)
-    n_threads = len(cpus) if cpus else (os.cpu_count() or 1)
-    q32 = np.ascontiguousarray(queries, np.float32)
+    n_threads = len(cpus) if cpus else min(os.cpu_count() or 1, quota or (os.cpu_count() or 1))
+    if cpus:
+        os.sched_setaffinity(0, cpus)       # BEFORE the map copy and the tree build: their pages are first touched by this thread, i.e. land on the socket whose cores will
+                                            # search them (round 5: with the map on the other socket four of five registrations ran at 100 it/s and one at 255)
+    map_local = np.array(w["map_xyz"], dtype=np.float32, order="C", copy=True)
+    t_build = time.perf_counter()
+    tree = O.KdTree(map_local)
+    t_build = time.perf_counter() - t_build
+    q32 = np.array(queries, dtype=np.float32, order="C", copy=True)
 
     def run(nth, iters):
         tic = time.perf_counter()
@@ -93,14 +102,15 @@ def cpu_baseline(w, queries, t0, q0):
         return (time.perf_counter() - tic) / iters, t, q, applied
 
     try:
-        if cpus:
-            os.sched_setaffinity(0, cpus)
-        O.pool_reset()                                      # workers are created under the socket's affinity mask
+        O.pool_reset()                                      # workers are created under the socket's affinity mask, one pinned per core (cores 1 .. n-1 of the mask)
         run(n_threads, 2); run(n_threads, 2)                # warm-up (page-in, thread start and placement)
+        if cpus:
+            os.sched_setaffinity(0, {cpus[0]})              # the calling thread works too: on the one core of the mask that has no worker
         rates, t_fin, q_fin = [], None, None
         for _ in range(5):
             it, t_fin, q_fin, _ = run(n_threads, 10)
             rates.append(1.0 / it)
+        runs_in_order = [round(r, 2) for r in rates]
         it1 = min(run(1, 2)[0] for _ in range(2))
     finally:
         O.pool_reset()
@@ -126,12 +136,12 @@ def cpu_baseline(w, queries, t0, q0):
         ref = dict(error=repr(e))
     med = rates[len(rates) // 2]
     return dict(value=round(med, 3), unit="scan-to-map iterations/s", cores=n_threads, kind="port",
-                runs=[round(r, 2) for r in rates], pinned=bool(cpus), single_thread_value=round(1.0 / it1, 3),
+                runs=[round(r, 2) for r in rates], runs_in_order=runs_in_order, pinned=bool(cpus), cpu_quota_cores=quota, single_thread_value=round(1.0 / it1, 3),
                 parallel_efficiency=round(med * it1 / n_threads, 3),
                 kdtree_build_s=round(t_build, 3), reference_1thread=ref,
                 sample=(f"oracle (g++ -O3, no -march, exact kd-tree): median of 5 registrations x 10 full outer iterations of the same 200k-query / "
-                        f"5M-point workload, each registration one C call on a persistent pool of {n_threads} threads (dynamic 1 k-query chunks) pinned to the physical "
-                        f"cores of one socket; kd-tree build excluded (once per keyframe)")), t_fin, q_fin
+                        f"5M-point workload, each registration one C call on a persistent pool of {n_threads} threads (dynamic 256-query chunks) pinned to physical "
+                        f"cores of one socket (as many as the container's CPU quota allows: {quota if quota else 'no quota'}); kd-tree build excluded (once per keyframe)")), t_fin, q_fin
 
 
 def secondary_stages(L, ctx, w, torch):
@@ -629,11 +639,12 @@ def main():
     # Whole registrations of the SAME loop, untimed, then the contract's W warm-up steps and the K timed steps as before.
     preheat_steps = 0
     if args.preheat_ms > 0:
-        t_ph = time.perf_counter()
-        while (time.perf_counter() - t_ph) * 1e3 < args.preheat_ms:
-            run_steps(10 * ips)
-            fence()
-            preheat_steps += 10 * ips
+        # a FIXED number of steps (every rank must enqueue the same collectives): the milliseconds asked for at ~30 us per step, in whole blocks of 10 registrations
+        blk = 10 * ips
+        preheat_steps = max(1, int(math.ceil(args.preheat_ms * 1e3 / 30.0 / blk))) * blk
+        for _ in range(preheat_steps // blk):
+            run_steps(blk)
+        fence()
     elapsed, t_enqueue = timed(args.warmup, args.steps)
     if rank == 0:
         log(f"[bench] host enqueue {t_enqueue / args.steps * 1e6:.1f} us/step, wall {elapsed / args.steps * 1e6:.1f} us/step")

@@ -12,6 +12,32 @@ import numpy as np
 HBM_PEAK_GBS = 8000.0
 
 
+def cpu_quota_cores():
+    """CPUs' worth of time the container may use (cgroup cpu.max / cfs quota), or None if unlimited / unknown.  The GPU boxes of this pool expose 256 logical CPUs
+    under a quota of 16: threads beyond the quota are throttled, not run (round 5: 64 pinned threads ran at 0.14 parallel efficiency)."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, int(int(q) // int(per)))
+    except Exception:       # noqa: BLE001
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return max(1, q // per)
+    except Exception:       # noqa: BLE001
+        pass
+    return None
+
+
+def usable_threads():
+    import os
+    n = len(os.sched_getaffinity(0))
+    q = cpu_quota_cores()
+    return min(n, q) if q else n
+
+
 def _wall(fn, reps, torch, warm=2):
     for _ in range(warm):
         fn()
@@ -251,7 +277,7 @@ def config1(L, ctx, torch, synth, n_frames=100, cpu=True):
                           "sample": "the oracle, one thread, ONE frame: extraction + 6 outer iterations vs a 20-frame local map (kd-tree build excluded)"}
             # the whole chain on the oracle (extraction -> VoxelGrid -> 20-frame ring local map -> outer iterations, same host loop): pose delta at EVERY frame
             import os
-            nth = min(32, os.cpu_count() or 1)
+            nth = min(32, usable_threads())
             po, kept = [], []
             for f in range(n_frames):
                 fo = O.extract_livox(frames[f])
@@ -553,7 +579,7 @@ def config2b(L, ctx, torch, synth, cpu=True, ips=10):
             import os
             from oracle import oracle as O
             PO = O.params("rot")
-            nth = len(os.sched_getaffinity(0))
+            nth = usable_threads()
             tree = O.KdTree(mp)
             m.pose_set(0, t0, q0)
             m.iterate(0, ips, L.MASK_SURF)
@@ -629,7 +655,7 @@ def scan_pipeline_200k(L, ctx, torch, synth, w, focus_r, cpu=True, ips=10):
             import os
             from oracle import oracle as O
             PO = O.params("rot")
-            nth = len(os.sched_getaffinity(0))
+            nth = usable_threads()
             tic = time.perf_counter()
             o = O.extract_rot(raw, (1.0, 0, 0, 0), list(P.q_lb), O.rot_params(ds_rate=4, atan_mode=2, stable_sort=1))
             t_ex = time.perf_counter() - tic
