@@ -90,29 +90,30 @@ int lili_sync(lili_ctx* ctx);
 /* When enabled, associate also stores the 5 neighbour indices / squared distances per query so that
  * lili_s2m_get_neighbors can return them (parity tests).  Off by default (extra HBM writes). */
 int lili_set_debug(lili_ctx* ctx, int keep_neighbors);
-/* Tuning knobs that never change any result bit: "bin_queries" (1 = order queries by map super-cell once per scan; use it
- * when the query order is not spatially coherent; default 0), "tiled" (1 = LDS-staged neighbourhood tiles, needs
- * bin_queries; default 0), "max_cells" (cap on grid cells of the map index; coarser cells stay exact),
- * "grid_reach" (1 = cells of the gate radius, 27-cell search; 2 = smaller cells, inner 27 cells first and the shell of
- * the 125-cell block on demand; default 2; takes effect at the next lili_map_set), "cell_pct" (reach 2: cell edge in %
- * of the gate radius, 50..100, default 65), "nn_cache" (1 = tighten each query's search bound with its neighbours of
- * the previous association of the same scan; default 0, measured slower), "fuse_tail" (1 = the reduction of the block
- * partials and the GN update run inside the linearisation launch, in its last block; default 0 = separate launch, which is
- * faster on MI355X; may be changed at any time), "merge_kinds" (1 = surf and edge of a keyframe share ONE association launch and ONE
- * linearisation launch; default 1), "p2p_fusion" (0 = lili_s2m_iterate_sharded runs lili_p2p_allreduce as its own launches like any
- * other lili_allreduce_fn instead of inside the count / reduce kernels; default 1), "fuse_lin" (1 = lili_s2m_iterate / _restart run the
- * flavours without count scaling — Livox back end, front end — in two launches per iteration: the association launch linearises on the fly;
- * scans above ~100 k queries and the ROT back end keep three launches; default 1), "super_rows" (1 = lili_map_set also stores the map in
- * the super-row layout, see lili_map_focus; default 1; takes effect at the next lili_map_set).
- * "fine_grid" (1 = lili_map_set measures the point density and gives a map with more than "fine_occupancy" (default 12) points per
- * gate-sized cell a second index with density-sized cells that the association searches first — exact; default 1).
- * Round 3: "assoc_lpq" (lanes of a wave per query in the association of small scans: 0 = by size (default), 1 / 2 / 4 / 8 / 16 forces a value),
- * "count_barrier" (1 = small ROT launches exchange their counts inside the association launch; default 0, measured no gain), "persistent_iterate"
- * (1 = lili_s2m_iterate* of scans of <= 128 cooperative workgroups run a whole registration as ONE persistent launch; default 0, measured slower
- * than the launches; poses then differ from the launch-per-stage loop by the partition of the Gram sum, <= 1e-10), "localmap_incremental" (default 1,
- * see lili_localmap_commit), "localmap_super_rows" (1 = ring maps below 400 k points get the super-row copy too; default 0), "sort_digit_bits"
- * (8, or 4 = the round-2 radix passes), "sort_fused_scan" (1 = radix passes of at most "sort_fused_max_tiles" (256) tiles derive their offsets inside the scatter
- * kernel instead of in a scan launch; default 1).
+/* Tuning knobs that never change any result bit (the closed experiments "bin_queries", "tiled", "nn_cache" and "balance" were removed in round 5:
+ * profiles/EXPERIMENTS.md; an unknown name returns LILI_E_ARG):
+ *   map index     "max_cells" (cap on grid cells; coarser cells stay exact), "grid_reach" (1 = cells of the gate radius, 27-cell search; 2 = smaller
+ *                 cells, inner 27 first and the shell of the 125-cell block on demand; default 2), "cell_pct" (reach 2: cell edge in % of the gate radius,
+ *                 50..100, default 65), "super_rows" (1 = the map is also stored in the super-row layout, see lili_map_focus; default 1), "fine_grid" (1 = a
+ *                 map with more than "fine_occupancy" (default 12) points per gate-sized cell gets a second index with density-sized cells that the
+ *                 association searches first — exact; default 1), "scan_lookback" (1 = single-pass decoupled look-back scans; default 1),
+ *                 "map_narrow_counts" (1 = byte-wide cell counts while they fit; default 1), "map_guess_box" (1 = a rebuild guesses its bounding box from the
+ *                 previous map of the kind and verifies it on the device; default 1; setting it resets the guess state).  All take effect at the next
+ *                 lili_map_set;
+ *   iteration     "fuse_tail" (1 = reduction + GN update run in the last block of the linearisation launch; default 0 = separate launch, faster on
+ *                 MI355X), "merge_kinds" (1 = surf and edge of a keyframe share ONE association and ONE linearisation launch; default 1), "fuse_lin"
+ *                 (1 = flavours without count scaling run two launches per iteration below ~100 k queries, the association linearises on the fly;
+ *                 default 1; "fuse_lin_block" its workgroup size), "assoc_lpq" (lanes per query in the association of small scans: 0 = by size,
+ *                 1 / 2 / 4 / 8 / 16 forces a value), "count_barrier" (default 0, measured no gain), "persistent_iterate" (1 = scans of <= 128
+ *                 cooperative workgroups run a whole registration as ONE persistent launch; default 0, measured slower; poses then differ by the
+ *                 partition of the Gram sum, <= 1e-10), "p2p_fusion" (0 = lili_s2m_iterate_sharded runs lili_p2p_allreduce as its own launches;
+ *                 default 1);
+ *   local map     "localmap_incremental" (default 1, see lili_localmap_commit), "localmap_super_rows" (1 = ring maps below 400 k points get the
+ *                 super-row copy too; default 0), "sort_digit_bits" (8, or 4 = the round-2 radix passes), "sort_fused_scan" (1 = radix passes of at most
+ *                 "sort_fused_max_tiles" (256) tiles derive their offsets inside the scatter kernel; default 1), "voxel_small" (1 = clouds of <= 8192
+ *                 points are voxel-filtered / keyframe-sorted by ONE workgroup in LDS; default 1);
+ *   host          "readback_gather" (1 = the small reads of a synchronisation are gathered by one kernel writing into page-locked memory instead of
+ *                 one copy launch each; default 1).
  * One knob that DOES choose between two definitions of a result: "rot_atan" — lili_extract_rot's atan / atan2 on float arguments
  * (R/src/Preprocessing.cpp:285-288,315,349): 2 (default) = glibc's float routines statement for statement (atanf / atan2f of
  * every glibc up to 2.40 — the bits a build of the reference produces), 1 = the f64 functions rounded to f32 (libm-independent). */

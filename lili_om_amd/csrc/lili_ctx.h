@@ -100,6 +100,7 @@ inline size_t lds_linearize(int threads) { return (size_t)threads * 12 * sizeof(
 }  // namespace lili_detail
 using namespace lili_detail;
 
+constexpr size_t kMiscAlloc = 2 * 64 * 128 + 256 + 2 * ((8192 + 2) * 8 + 112);      // ctx->misc: scratch words of a map build, laid out in lili_map.hip
 struct lili_ctx {
     int device = 0;
     hipStream_t stream = nullptr;

@@ -155,7 +155,7 @@ void lili_p2p_destroy(lili_p2p* c) {
 
 }  // extern "C"
 
-// internal (lili_api.hip): the view of the NEXT exchange of this communicator (advances its sequence number)
+// internal (lili_match.hip): the view of the NEXT exchange of this communicator (advances its sequence number)
 lili::P2PView lili_p2p_next_view(lili_p2p* c) {
     P2PView v = c->view;
     v.seq = ++c->seq;
