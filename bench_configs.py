@@ -242,7 +242,7 @@ def config1(L, ctx, torch, synth, n_frames=100, cpu=True):
     alg = 48 * n_pts + 48 * 24000 + 6 * (96 + 41) * int(np.mean(nq))
     out = {"value": round(1.0 / sec, 1), "unit": "frames/s", "ms_per_frame": round(sec * 1e3, 4), "frames": n_frames, "gn_status": worst[0],
            "staged_calls_ms_per_frame": round(sec_staged * 1e3, 4), "fused_call_poses_equal_staged_calls_bit_for_bit": bool(fused_equals_staged),
-           "stage_us_per_frame": {k: round(float(v) / n_frames, 1) for k, v in zip(("extraction_with_the_pending_local_map_built_under_it", "query_voxel_filter", "queries_pose_iterations_enqueued", "ring_push_and_pose_read_back"), stage_acc)},
+           "stage_us_per_frame": {k: round(float(v) / n_frames, 1) for k, v in zip(("extraction_enqueued_pending_local_map_built_query_filter_enqueued_behind_its_index", "query_filter_outcome", "queries_pose_iterations_enqueued", "ring_push_and_pose_read_back"), stage_acc)},
            "workload": f"configs[1] substitute (no FR_IOSB bag offline): {n_frames} synthetic Livox-Horizon frames (~{n_pts} points, 6 lines) on a circuit, ONE lili_frontend_frame call per frame "
                        f"(scan read from page-locked host memory; everything behind it device-resident): extraction -> VoxelGrid(0.4) -> ~{int(np.mean(nq))} queries vs the local map of the last 20 frames -> "
                        f"6 outer iterations (front-end flavour) -> ring push at the pose found (the local map with it is built under the next frame's extraction); the caller predicts the pose (constant velocity) as tools/replay_bag.py does; "

@@ -111,7 +111,7 @@ int lili_set_debug(lili_ctx* ctx, int keep_neighbors);
  *   local map     "localmap_incremental" (default 1, see lili_localmap_commit), "localmap_super_rows" (1 = ring maps below 400 k points get the
  *                 super-row copy too; default 0), "sort_digit_bits" (8, or 4 = the round-2 radix passes), "sort_fused_scan" (1 = radix passes of at most
  *                 "sort_fused_max_tiles" (256) tiles derive their offsets inside the scatter kernel; default 1), "voxel_small" (1 = clouds of <= 8192
- *                 points are voxel-filtered / keyframe-sorted by ONE workgroup in LDS; default 1);
+ *                 points are voxel-filtered / keyframe-sorted by ONE workgroup in LDS; default 1), "voxel_guess_bits" (see lili_voxel_filter_stats; default 1);
  *   host          "readback_gather" (1 = the small reads of a synchronisation are gathered by one kernel writing into page-locked memory instead of
  *                 one copy launch each; default 1).
  * One knob that DOES choose between two definitions of a result: "rot_atan" — lili_extract_rot's atan / atan2 on float arguments
@@ -254,6 +254,10 @@ int lili_localmap_commit(lili_ctx* ctx, int kind, float leaf, double max_sq_radi
  * reference's steady state, L/src/BackendFusion.cpp:1407-1477) against full rebuilds (first commit, several keyframes pending, another leaf).
  * The map is the same bit for bit either way (option "localmap_incremental" = 0 forces rebuilds). */
 int lili_localmap_stats(lili_ctx* ctx, int32_t* incremental_commits, int32_t* full_commits);
+/* How the VoxelGrid filters of more than 8192 points (lili_voxel_filter, lili_localmap_commit's rebuild, lili_frontend_frame's query filter) were served: a filter
+ * whose leaf size has been seen before keeps its bounding box on the device and sorts by as many key bits as the previous one needed ("voxel_guess_bits", default 1);
+ * the device checks the guess, a filter it does not hold for is repeated with the box measured (key_guess_misses).  The output never depends on it. */
+int lili_voxel_filter_stats(lili_ctx* ctx, int32_t* key_guesses, int32_t* key_guess_misses);
 /* The down-sampled local map of the last lili_localmap_commit as (x, y, z, aux) rows in map order (out->count = its size; at most
  * out->capacity rows are copied).  Blocking. */
 int lili_localmap_get(lili_ctx* ctx, lili_feature_out* out);
@@ -266,14 +270,15 @@ int lili_localmap_get(lili_ctx* ctx, lili_feature_out* out);
  * findCorrespondingSurfFeatures + LidarPlaneNormIncreFactor + HuberLoss L:352-413, 483-561) -> the frame joins the ring at the pose found
  * (transformCloud, L:292-297); the local map that includes it (concatenate + VoxelGrid + index) is built at the start of the next call, under that frame's extraction.
  * Everything between the scan and the returned pose stays in HBM: features, down-sampled queries, ring, map and pose never visit the host;
- * the host synchronises only for the counts that size the next launches and for the result.
+ * the host synchronises three times per frame, for the counts that size the next launches (ring merge; index build + query filter, whose launches are enqueued
+ * behind the build's so that both outcomes come back together) and for the result.
  *   scan / curvature_offset / q_imu / livox : as lili_extract_livox
  *   match   : matcher parameters (LILI_VARIANT_FRONTEND for the reference's front end)
  *   t_pred, q_pred : poseInitialization's guess (L:415-441: constant-velocity extrapolation, caller side); a frame that is not matched
  *                    (n_iters = 0, or a map of fewer than 10 points, L:485-488) keeps it.
  * `res` receives the pose, the solver status of the last update and the sizes; res->stage_us (opt->want_timing) the host-side time stamps
- * of the stages in microseconds since the call began (extraction counts known, queries known, iterations enqueued, result + next map known,
- * map index built).  lili_frontend_reset empties the ring (a new sequence). */
+ * of the stages in microseconds since the call began ([0] pending local map built and query filter enqueued, [1] queries known, [2] iterations enqueued,
+ * [3] pose known).  lili_frontend_reset empties the ring (a new sequence). */
 typedef struct lili_frontend_options {
     float leaf_query;   /* down_size_filter_surf: 0.4 (L/src/LidarOdometry.cpp:155) */
     float leaf_map;     /* down_size_filter_surf_map: 0.4 (L:156) */

@@ -149,6 +149,7 @@ _SIGS = {
     "lili_localmap_commit": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_double, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "lili_localmap_get": (C.c_int, [C.c_void_p, C.POINTER(FeatureOut)]),
     "lili_localmap_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "lili_voxel_filter_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "lili_map_set": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Cloud), C.c_double]),
     "lili_map_density": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "lili_s2m_linearize_window": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -626,6 +627,13 @@ def voxel_filter(ctx, pts_xyza, leaf):
     fo = FeatureOut(out.ctypes.data, cap, 16, MEM_HOST, 0)
     ctx._chk(ctx.lib.lili_voxel_filter(ctx.h, C.byref(cloud), float(leaf), C.byref(fo), _ptr(cnt)))
     return out[:fo.count], cnt[:fo.count]
+
+
+def voxel_filter_stats(ctx):
+    """(filters served with guessed key bits — no host round trip for the bounding box —, guesses that did not hold) of this context so far."""
+    a, b = C.c_int32(0), C.c_int32(0)
+    ctx._chk(ctx.lib.lili_voxel_filter_stats(ctx.h, C.byref(a), C.byref(b)))
+    return a.value, b.value
 
 
 class LocalMap:

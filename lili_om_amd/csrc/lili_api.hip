@@ -67,6 +67,7 @@ int lili_readback_finish(lili_ctx* ctx, hipStream_t stream) {
     if (e == hipSuccess) for (const auto& it : ctx->h_pin_items) std::memcpy(it.dst, ctx->h_pin + it.off, it.bytes);
     ctx->h_pin_items.clear();
     ctx->h_pin_used = 0;
+    ctx->readback_gen++;
     HIPCHK(e);
     return LILI_OK;
 }
@@ -219,6 +220,7 @@ int lili_set_option(lili_ctx* ctx, const char* name, int value) {
     if (std::strcmp(name, "rot_atan") == 0) { if (value != 1 && value != 2) return ctx->fail(LILI_E_ARG, "rot_atan must be 1 or 2"); ctx->rot_atan = value; return LILI_OK; }
     if (std::strcmp(name, "p2p_fusion") == 0) { ctx->no_p2p_fusion = value == 0; return LILI_OK; }
     if (std::strcmp(name, "readback_gather") == 0) { ctx->readback_gather = value != 0; return LILI_OK; }      // small device-to-host reads of one synchronisation in ONE gather launch (0: a copy launch each, A/B)
+    if (std::strcmp(name, "voxel_guess_bits") == 0) { ctx->voxel_guess_bits = value != 0; return LILI_OK; }      // VoxelGrid of > 8192 points without the host round trip for its box (0: measured, A/B)
     if (std::strcmp(name, "voxel_small") == 0) { ctx->voxel_small = value != 0; return LILI_OK; }      // VoxelGrid of <= 8192 points in one single-workgroup launch (0: the general chain, A/B)
 #ifdef LILI_OVERLAP_GN
     if (std::strcmp(name, "overlap_gn") == 0) { ctx->overlap_gn = value != 0; return LILI_OK; }

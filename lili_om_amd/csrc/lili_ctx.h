@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <utility>
 #include <vector>
@@ -137,6 +138,7 @@ struct lili_ctx {
     // pageable memory is staged by the runtime and blocks, which costs ~10 us more per read (64 KB; lili_readback_* in lili_api.hip).
     unsigned char* h_pin = nullptr;
     size_t h_pin_used = 0;
+    unsigned long long readback_gen = 0;      // number of lili_readback_finish calls so far: a deferred reader knows whether its items have been delivered
     struct PinItem { void* dst; size_t off, bytes; };
     std::vector<PinItem> h_pin_items;
     struct LazyItem { const void* src; size_t off, bytes; };
@@ -165,6 +167,8 @@ struct lili_ctx {
                                       // Measured (tools/iter_time.py, profiles/r03_iter_time.json): 21.3 vs 19.6 us per outer iteration at 2 k queries (ROT), 17.2 vs 14.9
                                       // (front end) — two exchange hops through memory across the XCDs cost more than the launch boundaries they replace; off by default
     bool frontend_commit_pending = false;   // lili_frontend_frame: the ring has a keyframe the local map does not hold yet (the commit runs at the start of the next frame, under its extraction)
+    bool voxel_guess_bits = true;      // a VoxelGrid of more than 8192 points keeps its bounding box on the device and guesses its key bits from the previous filter (k_vox_key_dev; 0: measured, A/B)
+    std::function<int()> pre_sync_hook;      // one-shot: called by the next map build right before its read-back synchronises, so that the caller's launches and read-backs share that synchronisation (lili_pipeline.hip)
     bool voxel_small = true;     // lili_voxel_filter / lili_frontend_frame: clouds of <= 8192 points are filtered by ONE single-workgroup launch (k_voxel_small; 0: the general chain, A/B)
     bool overlap_gn = false;     // lili_s2m_iterate*, three-launch path: the reduction + GN kernel publishes the pose as keyed granules and the next association is launched without a
                                  // barrier against it (hipExtAnyOrderLaunch): its waves are dispatched and poll for the pose while the reduction still runs
@@ -216,6 +220,8 @@ lili::P2PView lili_p2p_next_view(lili_p2p* c);
 bool lili_p2p_usable(const lili_p2p* c, const lili_ctx* ctx);
 // lili_voxel.hip -> lili_pipeline.hip: the voxel filter and the keyframe ring on device clouds (no host copies, the pose read on the device)
 int lili_voxel_filter_dev(lili_ctx* ctx, const float4* d_pts, int n, float leaf, const float4** d_out, int* n_out);
+int lili_voxel_filter_dev_enqueue(lili_ctx* ctx, const float4* d_pts, int n, float leaf, bool* pending);
+int lili_voxel_filter_dev_complete(lili_ctx* ctx, const float4** d_out, int* n_out);
 int lili_localmap_push_dev(lili_ctx* ctx, int kind, const float4* d_pts, int n, const lili::SlotState* d_state, int width);
 int lili_localmap_ring_size(lili_ctx* ctx, int kind);
 // lili_extract_livox.hip -> lili_pipeline.hip: the extraction enqueued without its synchronisation, and the counts taken afterwards

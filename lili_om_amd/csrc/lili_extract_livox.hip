@@ -311,6 +311,7 @@ struct LivoxBuffers {
     int* h_counts = nullptr;          // page-locked {n_cut, n_edge, n_surf}, written by k_livox_pack3; h_counts_dev: the same memory as the device sees it
     int* h_counts_dev = nullptr;
     bool have = false;
+    unsigned long long pending_gen = 0;      // ctx->readback_gen when the counts' read-back joined the pending list
     bool pending = false;    // lili_extract_livox_enqueue: the counts' read-back is on the stream, lili_extract_livox_complete has not taken it yet
     bool armed = false;      // the ownership table holds "no owner" everywhere (k_livox_init once, k_livox_grid after every scan)
     void release() {
@@ -393,7 +394,7 @@ int lili_extract_livox_complete(lili_ctx* ctx) {
     auto* B = livox_of(ctx);
     if (!B->pending) return ctx->fail(LILI_E_STATE, "extract_livox_complete: nothing enqueued");
     B->pending = false;
-    if (!ctx->h_pin_items.empty()) { const int rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }
+    if (ctx->readback_gen == B->pending_gen) { const int rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }      // (else a synchronisation of the caller's has delivered the counts)
     B->have = true;
     return LILI_OK;
 }
@@ -540,7 +541,7 @@ static int extract_livox_impl(lili_ctx* ctx, const lili_cloud* scan, int curvatu
     if (rc != LILI_OK) return rc;
     const bool counts_direct = all3 && B->h_counts_dev != nullptr;      // the counts arrive with the packing kernel
     if (!counts_direct) { rc = lili_readback_add(ctx, &B->host, st, sizeof(LivoxState)); if (rc) return rc; }
-    if (defer && !counts_direct && !cut_early) { B->pending = true; return LILI_OK; }      // (no caller buffers in this mode: nothing else to do once the counts are there)
+    if (defer && !counts_direct && !cut_early) { B->pending = true; B->pending_gen = ctx->readback_gen; return LILI_OK; }      // (no caller buffers in this mode: nothing else to do once the counts are there)
     if (cut_early) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->join_ev[1], 0));
     size_t sent_e = 0, sent_s = 0;      // records already in the caller's buffers when the counts arrive
     auto send = [&](DevBuf& pack, const lili_feature_out* o, size_t first, size_t last) -> int {      // records [first, last) of a packed list

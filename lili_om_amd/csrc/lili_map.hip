@@ -225,7 +225,15 @@ static int map_set_impl(lili_ctx* ctx, int kind, const lili_cloud* cloud, double
     {
         struct Back { unsigned long long rank[kRankBanks * 16]; unsigned err, pad; } back;
         static_assert(sizeof(Back) == 64 * 128 + 8, "layout of ctx->misc");
-        { int rb = lili_readback_add(ctx, &back, ctx->misc.as<char>() + 8192, sizeof(back)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }
+        {
+            int rb = lili_readback_add(ctx, &back, ctx->misc.as<char>() + 8192, sizeof(back));
+            // the caller's launches and read-backs that want to share this synchronisation (one shot; they must leave ctx->misc + 8192 onwards and the cloud alone)
+            int hk = LILI_OK;
+            if (rb == LILI_OK && ctx->pre_sync_hook) { auto hook = std::move(ctx->pre_sync_hook); ctx->pre_sync_hook = nullptr; hk = hook(); }
+            if (rb == LILI_OK) rb = lili_readback_finish(ctx);      // (also behind a failed hook: `back` must not stay on the pending list)
+            if (hk != LILI_OK) return hk;
+            if (rb != LILI_OK) return rb;
+        }
         scan_err = back.err;
         err_read = true;
         unsigned chk = 0;

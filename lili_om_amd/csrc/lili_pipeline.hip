@@ -61,35 +61,52 @@ int lili_frontend_frame(lili_ctx* ctx, const lili_cloud* scan, int curvature_off
     *res = lili_frontend_result{};
     const int slot = opt->slot;
     // ---- extraction (Preprocessing::cloudHandler), enqueued only: features stay in the extractor's device lists.  Under its kernels the host builds the local map the
-    //      previous frame left pending (buildLocalMap + downSampleCloud + setInputCloud, L:280-318, 490) — that commit synchronises anyway and delivers the extraction's
-    //      counts with its own read-backs.
+    //      previous frame left pending (buildLocalMap + downSampleCloud + setInputCloud, L:280-318, 490).  That commit synchronises twice anyway: its first read-back
+    //      delivers the extraction's counts with its own; behind the index build's kernels — before the build's read-back synchronises — the frame's QUERY filter is
+    //      enqueued (down_size_filter_surf, L:320-322, on the extractor's device list, into the filter's second output) so that its voxel count comes back with the
+    //      build's density words.  Three synchronisations per frame (ring merge, index build + query filter, pose) where the stages called one by one take five.
     int rc = lili_extract_livox_enqueue(ctx, scan, curvature_offset, q_imu, livox);
     if (rc != LILI_OK) return rc;
+    const bool self_map = (opt->flags & LILI_FRAME_SELF_MAP) != 0;
+    lili_cloud d_edge{}, d_surf{};
+    bool lists = false, filter_enqueued = false, filter_pending = false;
+    // extraction's counts -> device lists -> query filter enqueued (no synchronisation of its own unless the counts have not come back yet)
+    auto enqueue_query_filter = [&]() -> int {
+        int r = lili_extract_livox_complete(ctx);
+        if (r != LILI_OK) return r;
+        r = lili_extract_livox_device(ctx, &d_edge, &d_surf);
+        if (r != LILI_OK) return r;
+        lists = true;
+        r = lili_voxel_filter_dev_enqueue(ctx, static_cast<const float4*>(d_surf.data), (int)d_surf.n, opt->leaf_query, &filter_pending);
+        filter_enqueued = r == LILI_OK;
+        return r;
+    };
     int64_t n_raw = 0, n_map = 0;
-    if (ctx->frontend_commit_pending && !(opt->flags & LILI_FRAME_SELF_MAP)) {
+    if (ctx->frontend_commit_pending && !self_map) {
+        ctx->pre_sync_hook = enqueue_query_filter;
         rc = lili_localmap_commit(ctx, LILI_KIND_SURF, opt->leaf_map, match->kd_max_radius, &n_raw, &n_map);
+        ctx->pre_sync_hook = nullptr;      // (a commit that built no index has not called it)
         if (rc != LILI_OK) return rc;
         ctx->frontend_commit_pending = false;
     }
-    rc = lili_extract_livox_complete(ctx);
-    if (rc != LILI_OK) return rc;
-    lili_cloud d_edge{}, d_surf{};
-    rc = lili_extract_livox_device(ctx, &d_edge, &d_surf);
-    if (rc != LILI_OK) return rc;
-    res->n_edge = (int32_t)d_edge.n; res->n_surf = (int32_t)d_surf.n;
     stamp(0);
-    // ---- down_size_filter_surf (L:320-322) on the device list; the centroids become the frame's queries AND its keyframe
+    if (!filter_enqueued) {
+        rc = enqueue_query_filter();
+        if (rc != LILI_OK) return rc;
+        if (filter_pending) { rc = lili_readback_finish(ctx); if (rc != LILI_OK) return rc; }
+    }
+    res->n_edge = (int32_t)d_edge.n; res->n_surf = (int32_t)d_surf.n;
+    // ---- the centroids become the frame's queries AND its keyframe
     const float4* d_q = nullptr; int n_q = 0;
-    rc = lili_voxel_filter_dev(ctx, static_cast<const float4*>(d_surf.data), (int)d_surf.n, opt->leaf_query, &d_q, &n_q);
+    rc = lili_voxel_filter_dev_complete(ctx, &d_q, &n_q);
     if (rc != LILI_OK) return rc;
     res->n_query = n_q;
     stamp(1);
-    const bool self_map = (opt->flags & LILI_FRAME_SELF_MAP) != 0;
     if (self_map) {
         // buildLocalMap's initialisation branch (L:283-289): the map is this frame's own surf features; downSampleCloud filters them with the MAP filter (L:314-318)
         const float4* d_m = d_q; int n_m = n_q;
         if (opt->leaf_map != opt->leaf_query) {
-            rc = lili_voxel_filter_dev(ctx, static_cast<const float4*>(d_surf.data), (int)d_surf.n, opt->leaf_map, &d_m, &n_m);
+            rc = lili_voxel_filter_dev(ctx, static_cast<const float4*>(d_surf.data), (int)d_surf.n, opt->leaf_map, &d_m, &n_m);      // (the filter's first output: the queries stay)
             if (rc != LILI_OK) return rc;
         }
         const lili_cloud mc{d_m, (size_t)n_m, 16, 12, LILI_MEM_DEVICE};
@@ -98,10 +115,6 @@ int lili_frontend_frame(lili_ctx* ctx, const lili_cloud* scan, int curvature_off
         rc = lili_map_set(ctx, LILI_KIND_SURF, &mc, match->kd_max_radius);
         ctx->super_rows = srows;
         if (rc != LILI_OK) return rc;
-        if (opt->leaf_map != opt->leaf_query) {      // the filter's buffer now holds the map: the queries again
-            rc = lili_voxel_filter_dev(ctx, static_cast<const float4*>(d_surf.data), (int)d_surf.n, opt->leaf_query, &d_q, &n_q);
-            if (rc != LILI_OK) return rc;
-        }
     }
     const lili_cloud qc{d_q, (size_t)n_q, 16, 12, LILI_MEM_DEVICE};
     rc = lili_s2m_set_queries(ctx, slot, LILI_KIND_SURF, &qc);      // device-to-device: the filter's buffer is reused by the map commit below

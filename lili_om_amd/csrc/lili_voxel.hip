@@ -177,6 +177,44 @@ __global__ void k_vox_key(const float4* __restrict__ pts, int n, VoxDev V, unsig
     int i2 = (int)(floorf(p.z * V.inv_leaf) - (float)V.min_b[2]);
     keys[i] = (unsigned)(i0 * V.mul[0] + i1 * V.mul[1] + i2 * V.mul[2]);
 }
+// k_vox_key with the bounding box read where k_bbox left it (ordered-uint words `mm`) — no host round trip before the sort (round 5).  The host does not know the
+// box, so it cannot know how many key bits the sort has to cover: it GUESSES them (`bits_guess`: what the previous filter of this leaf size needed, rounded up to whole
+// radix passes) and every thread checks the guess against the box it finds; res[0] = 0 (the keys fit), 1 (they do not: the caller repeats the filter the measured way),
+// 2 (no finite point), 3 (PCL's int32 voxel-index overflow) and res[1] = the bits the keys need come back with the filter's voxel count.  Same arithmetic as the host
+// code of voxel_sort + k_vox_key; non-finite points get the key 2^bits_guess - 1, above every voxel index.
+__global__ void k_vox_key_dev(const float4* __restrict__ pts, int n, float inv_leaf, const unsigned* __restrict__ mm, int bits_guess, unsigned* __restrict__ keys,
+                              int* __restrict__ vals, int* __restrict__ res) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    auto dec = [](unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); };
+    int min_b[3], div_b[3];
+    bool any = true;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float mn = dec(mm[k]), mx = dec(mm[3 + k]);
+        if (!(mn <= mx)) any = false;
+        min_b[k] = (int)floorf(mn * inv_leaf);
+        div_b[k] = (int)floorf(mx * inv_leaf) - min_b[k] + 1;
+    }
+    const double total = any ? (double)div_b[0] * (double)div_b[1] * (double)div_b[2] : 0.0;
+    const unsigned sentinel = bits_guess >= 32 ? 0xFFFFFFFFu : (1u << bits_guess) - 1u;
+    int status = 0;
+    if (!any) status = 2;
+    else if (total > 2147483647.0) status = 3;
+    else if (total > (double)sentinel) status = 1;      // voxel indices 0 .. total - 1 and the sentinel above them
+    if (i == 0) {
+        int bits = 1;
+        if (status == 0 || status == 1) while (bits < 32 && (double)(1ull << bits) < total + 1.0) bits++;
+        res[0] = status; res[1] = bits;
+    }
+    if (i >= n) return;
+    vals[i] = i;
+    const float4 p = pts[i];
+    if (status != 0 || !(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) { keys[i] = sentinel; return; }
+    const int i0 = (int)(floorf(p.x * inv_leaf) - (float)min_b[0]);
+    const int i1 = (int)(floorf(p.y * inv_leaf) - (float)min_b[1]);
+    const int i2 = (int)(floorf(p.z * inv_leaf) - (float)min_b[2]);
+    keys[i] = (unsigned)(i0 * 1 + i1 * div_b[0] + i2 * (div_b[0] * div_b[1]));
+}
 // Key of one keyframe's points for the sorted ring WITHOUT a host round trip: voxel coordinates relative to the keyframe's own bounding box
 // (ordered-uint words `mm` left in device memory by k_bbox), packed (i2 : 10 bits, i1 : 11, i0 : 11) — the same lexicographic order as the
 // box-relative voxel index.  A keyframe wider than 2047 x 2047 x 1023 voxels raises *bad (the commit then takes the full rebuild).
@@ -193,30 +231,33 @@ __global__ void k_vox_key_packed(const float4* __restrict__ pts, int n, float in
     if (i0 < 0 || i0 > 2047 || i1 < 0 || i1 > 2047 || i2 < 0 || i2 > 1022) { *bad = 1u; keys[i] = 0xFFFFFFFEu; return; }
     keys[i] = ((unsigned)i2 << 22) | ((unsigned)i1 << 11) | (unsigned)i0;
 }
-__global__ void k_vox_heads(const unsigned* __restrict__ keys, int n, unsigned sentinel, int* __restrict__ flags) {
+// head flags of the sorted keys; the points are copied into sorted order on the way (round 5: k_vox_centroid then reads a voxel's members as ONE contiguous run
+// instead of chasing an index per member)
+__global__ void k_vox_heads(const unsigned* __restrict__ keys, const int* __restrict__ vals, const float4* __restrict__ pts, int n, unsigned sentinel, int* __restrict__ flags,
+                            float4* __restrict__ spts) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) flags[i] = (keys[i] != sentinel && (i == 0 || keys[i] != keys[i - 1])) ? 1 : 0;
+    if (i >= n) return;
+    spts[i] = pts[vals[i]];
+    flags[i] = (keys[i] != sentinel && (i == 0 || keys[i] != keys[i - 1])) ? 1 : 0;
 }
-__global__ __launch_bounds__(256) void k_vox_centroid(const unsigned* __restrict__ keys, const int* __restrict__ vals, const int* __restrict__ slot /*exclusive scan of flags, [n+1]*/,
-                               const float4* __restrict__ pts, int n, unsigned sentinel, float4* __restrict__ out, int* __restrict__ out_cnt) {
+__global__ __launch_bounds__(256) void k_vox_centroid(const unsigned* __restrict__ keys, const int* __restrict__ slot /*exclusive scan of flags, [n+1]*/,
+                               const float4* __restrict__ spts /*points in sorted order*/, int n, unsigned sentinel, float4* __restrict__ out, int* __restrict__ out_cnt) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (!(i == 0 || keys[i] != keys[i - 1])) return;
     unsigned k = keys[i];
     if (k == sentinel) return;
-    // CentroidPoint: float accumulators, members added in sorted (= input) order.  kMem members per trip: their keys and values are requested together and the point
-    // gathers after them — two memory round trips per kMem members instead of three per member (voxels next to the sensor hold hundreds of points of a raw scan; the
-    // sum itself has to stay sequential).  Round 5: 32 per trip (8 before): the launch lasts as long as its fullest voxel's chain of trips — 31 us for the 20 k surf
-    // features of a Livox frame.
+    // CentroidPoint: float accumulators, members added in sorted (= input) order.  kMem members per trip, their keys and points requested together: ONE memory round trip
+    // per kMem members (voxels next to the sensor hold hundreds of points of a raw scan; the sum itself has to stay sequential, and the launch lasts as long as its
+    // fullest voxel's chain of trips).  Round 5: 32 per trip (8 before), points read from the sorted copy (two dependent round trips per trip before: 26 us for the
+    // 20 k surf features of a Livox frame).
     constexpr int kMem = 32;
     float sx = 0.f, sy = 0.f, sz = 0.f, sa = 0.f; int c = 0;
     bool more = true;
     for (int m = i; more && m < n; m += kMem) {
-        unsigned kk[kMem]; int vv[kMem]; float4 pp[kMem];
+        unsigned kk[kMem]; float4 pp[kMem];
 #pragma unroll
-        for (int u = 0; u < kMem; u++) { const int mm = min(m + u, n - 1); kk[u] = keys[mm]; vv[u] = vals[mm]; }
-#pragma unroll
-        for (int u = 0; u < kMem; u++) pp[u] = pts[vv[u]];
+        for (int u = 0; u < kMem; u++) { const int mm = min(m + u, n - 1); kk[u] = keys[mm]; pp[u] = spts[mm]; }
 #pragma unroll
         for (int u = 0; u < kMem; u++) {
             if (more && m + u < n && kk[u] == k) { sx += pp[u].x; sy += pp[u].y; sz += pp[u].z; sa += pp[u].w; c++; }
@@ -236,6 +277,8 @@ __global__ __launch_bounds__(256) void k_vox_centroid(const unsigned* __restrict
 // in LDS —, members of a voxel summed in input order with float accumulators, non-finite points skipped.  res[0] = number of voxels, res[1] = 1 if the voxel index
 // would not fit 31 bits (the caller then takes the general path, which reports PCL's overflow error), 2 if no point is finite.
 constexpr int kVoxSmallMax = 8192, kVoxSmallThreads = 1024;
+// between two steps of a sort in which a wave reads what only ITS OWN lanes wrote: the LDS serves a wave's accesses in order; the compiler must keep them in order too
+__device__ __forceinline__ void wave_lds_order() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 __global__ __launch_bounds__(kVoxSmallThreads) void k_voxel_small(const float4* __restrict__ pts, int n, float inv_leaf, float4* __restrict__ out, int* __restrict__ out_cnt,
                                                                    int* __restrict__ res) {
     __shared__ unsigned long long key[kVoxSmallMax];
@@ -288,18 +331,25 @@ __global__ __launch_bounds__(kVoxSmallThreads) void k_voxel_small(const float4* 
         key[i] = k;
     }
     __syncthreads();
-    // ---- bitonic sort (ascending)
-    for (int k = 2; k <= np2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < np2 / 2; t += kVoxSmallThreads) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));      // the lower partner of the t-th pair at distance j
-                const int l = i | j;
-                const unsigned long long a = key[i], b = key[l];
-                const bool up = (i & k) == 0;
-                if ((a > b) == up) { key[i] = b; key[l] = a; }
-            }
+    // ---- bitonic sort (ascending).  Partner distances <= 64: the 64 pairs a wave handles per trip lie in ONE aligned run of 128 keys that no other wave touches
+    //      until the next distance > 64 — those steps (51 of the 66 of 2 k keys) need no block barrier, only the wave's own LDS order
+    auto step = [&](int t, int j, int k) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));      // the lower partner of the t-th pair at distance j
+        const int l = i | j;
+        const unsigned long long a = key[i], b = key[l];
+        const bool up = (i & k) == 0;
+        if ((a > b) == up) { key[i] = b; key[l] = a; }
+    };
+    for (int k = 2; k <= np2; k <<= 1) {
+        int j = k >> 1;
+        for (; j > 64; j >>= 1) {
+            for (int t = tid; t < np2 / 2; t += kVoxSmallThreads) step(t, j, k);
             __syncthreads();
         }
+        for (int t = tid; t < np2 / 2; t += kVoxSmallThreads)
+            for (int jj = j; jj > 0; jj >>= 1) { step(t, jj, k); wave_lds_order(); }
+        __syncthreads();
+    }
     // ---- voxel heads and their output slots (exclusive scan of the head flags over the sorted positions)
     const int per = (np2 + kVoxSmallThreads - 1) / kVoxSmallThreads;      // consecutive positions per thread (<= 8)
     const int base = tid * per;
@@ -382,19 +432,25 @@ __global__ __launch_bounds__(kVoxSmallThreads) void k_sort_keyframe_small(const 
         key[i] = k; pos[i] = (unsigned short)i;
     }
     __syncthreads();
-    for (int k = 2; k <= np2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < np2 / 2; t += kVoxSmallThreads) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                const int l = i | j;
-                const unsigned long long a = key[i], b = key[l];
-                const unsigned short pa = pos[i], pb = pos[l];
-                const bool gt = a > b || (a == b && pa > pb);      // (key, input position): stable; the padding (key ~0, position >= n) sorts behind everything
-                const bool up = (i & k) == 0;
-                if (gt == up) { key[i] = b; key[l] = a; pos[i] = pb; pos[l] = pa; }
-            }
+    auto step = [&](int t, int j, int k) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int l = i | j;
+        const unsigned long long a = key[i], b = key[l];
+        const unsigned short pa = pos[i], pb = pos[l];
+        const bool gt = a > b || (a == b && pa > pb);      // (key, input position): stable; the padding (key ~0, position >= n) sorts behind everything
+        const bool up = (i & k) == 0;
+        if (gt == up) { key[i] = b; key[l] = a; pos[i] = pb; pos[l] = pa; }
+    };
+    for (int k = 2; k <= np2; k <<= 1) {      // (block barriers only behind partner distances > 64: see k_voxel_small)
+        int j = k >> 1;
+        for (; j > 64; j >>= 1) {
+            for (int t = tid; t < np2 / 2; t += kVoxSmallThreads) step(t, j, k);
             __syncthreads();
         }
+        for (int t = tid; t < np2 / 2; t += kVoxSmallThreads)
+            for (int jj = j; jj > 0; jj >>= 1) { step(t, jj, k); wave_lds_order(); }
+        __syncthreads();
+    }
     for (int r = tid; r < n; r += kVoxSmallThreads) { out_pt[r] = pts[pos[r]]; out_key[r] = key[r]; out_seq[r] = seq; }
 }
 
@@ -513,6 +569,13 @@ struct VoxelBuffers {
     int incremental_commits = 0, full_commits = 0;
     std::vector<ConcatSeg> seg_host;   // the table k_concat reads, kept alive until the upload has certainly happened (an async copy from a local vector)
     int n_out = 0;
+    // round 5: a filter whose launches are enqueued but whose count has not come back yet (voxel_filter_enqueue / _complete); the second output (`alt`: the queries of
+    // the frame pipeline, filtered while the local map in `out` is still being indexed); the key bits the last measured filter of `guess_leaf` needed
+    struct Pending { int mode = 0; const float4* d_pts = nullptr; int n = 0; float leaf = 0; bool need_order = false, alt = false; int res[2] = {0, 0}; int n_out = 0; } pend;
+    DevBuf spts, qout, qout_cnt;
+    int qn_out = 0;
+    int bits_guess = 0; float guess_leaf = 0;
+    int key_guesses = 0, key_guess_misses = 0;
     unsigned out_box[6] = {0, 0, 0, 0, 0, 0};   // bounding box of `out` (ordered-uint words, k_bbox_dev) after an incremental commit
     void release() {
         for (DevBuf* b : {&keys_a, &keys_b, &vals_a, &vals_b, &hist, &hist_scan, &sums, &flags, &slots, &out, &out_cnt, &in, &concat, &concat_tab}) b->release();
@@ -520,7 +583,7 @@ struct VoxelBuffers {
         for (auto* k : pool) { k->pts.release(); delete k; }
         pool.clear();
         for (auto& sr : sorted) sr.release();
-        kf_key.release(); kf_pt.release(); seg_seq.release(); head_pos.release();
+        kf_key.release(); kf_pt.release(); seg_seq.release(); head_pos.release(); spts.release(); qout.release(); qout_cnt.release();
     }
 };
 }  // namespace lili_detail
@@ -539,56 +602,55 @@ static lili_detail::VoxelBuffers* vox_of(lili_ctx* ctx) {
     return static_cast<lili_detail::VoxelBuffers*>(ctx->ext_voxel);
 }
 
-// exclusive scan of a SHORT array (the digit histograms of a radix pass: 16 words per 2048 keys) by one workgroup in one launch — the
-// three-kernel scan spends ~10 us of launches on a few thousand words
-__global__ __launch_bounds__(1024) void k_scan_single(const int* __restrict__ in, int n, int* __restrict__ out /*[n+1]*/) {
-    // Round 5: ONE pass with every item in registers — wave w owns the contiguous stretch [w R 256, (w + 1) R 256), R = ceil(n / 4096) <= 16 rows of 256 items, lane l
-    // items 4 l .. 4 l + 3 of every row (16-byte accesses, a contiguous kilobyte per wave instruction) — a wave scan per row with a running carry, ONE block barrier
-    // for the sixteen wave totals, then the stores.  Before: trips of 4096 items with three block barriers each (19 us for the 20-40 k flags of a frame's
-    // voxel filter / ring merge, three times per frame of the front-end pipeline).
-    __shared__ int wtot[16];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int R = (n + 4095) / 4096;
-    const int w0 = wave * R * 256 + lane * 4;
-    int v[16][4];
+// Exclusive scan of a SHORT array (<= 64 k words: the head / keep flags of a frame's voxel filter and ring merge, the digit histograms of a radix pass) in ONE launch
+// with NO communication between workgroups (round 5, second version): tile t (2048 words, 256 threads) sums the words in FRONT of it itself — at most 30 tiles of
+// 8 KB out of the L2, read with 16-byte loads by every lane at once — and scans its own words behind that offset.  The one-workgroup scan it replaces (k_scan_single)
+// took 10-16 us for the 20-40 k flags: one CU reads and writes 160 KB each at ~50 GB/s; the tiles take the read side of the LAST tile, ~3 us, with nothing to wait for.
+constexpr int kScanTile = 2048;
+__global__ __launch_bounds__(256) void k_scan_tiles(const int* __restrict__ in, int n, int* __restrict__ out /*[n+1]*/) {
+    __shared__ int w_front[4], w_own[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int base = blockIdx.x * kScanTile;
+    // (`in` is a DevBuf: 16-byte aligned, >= 256 bytes of slack behind its n words; words behind n count as zero)
+    int front = 0;
+    for (int i = tid * 4; i < base; i += 1024) { const int4 q = *reinterpret_cast<const int4*>(in + i); front += (q.x + q.y) + (q.z + q.w); }
+    const int i0 = base + tid * 8;
+    int v[8];
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int i = w0 + 256 * r;
-        // one 16-byte load per lane and row (`in` is a DevBuf: 16-byte aligned, >= 256 bytes of slack behind its n words); words behind n count as zero
+    for (int h = 0; h < 2; h++) {
+        const int i = i0 + 4 * h;
         int4 q = make_int4(0, 0, 0, 0);
-        if (r < R && i < n) q = *reinterpret_cast<const int4*>(in + i);
-        v[r][0] = q.x; v[r][1] = i + 1 < n ? q.y : 0; v[r][2] = i + 2 < n ? q.z : 0; v[r][3] = i + 3 < n ? q.w : 0;
+        if (i < n) q = *reinterpret_cast<const int4*>(in + i);
+        v[4 * h] = q.x; v[4 * h + 1] = i + 1 < n ? q.y : 0; v[4 * h + 2] = i + 2 < n ? q.z : 0; v[4 * h + 3] = i + 3 < n ? q.w : 0;
     }
-    int carry = 0;
+    int s8 = 0;
 #pragma unroll
-    for (int r = 0; r < 16; r++) {      // the items become their exclusive prefixes inside the wave's stretch, in place (no second register array)
-        const int a0 = v[r][0], a1 = v[r][1], a2 = v[r][2], a3 = v[r][3];
-        const int s4 = (a0 + a1) + (a2 + a3);
-        int inc = s4;
-        if (r < R) {
+    for (int k = 0; k < 8; k++) { const int t = v[k]; v[k] = s8; s8 += t; }      // the items become their exclusive prefixes inside the thread
+    int inc = s8;
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
-        }
-        const int e0 = carry + inc - s4;
-        v[r][0] = e0; v[r][1] = e0 + a0; v[r][2] = e0 + a0 + a1; v[r][3] = e0 + a0 + a1 + a2;
-        if (r < R) carry += __shfl(inc, 63);
-    }
-    if (lane == 0) wtot[wave] = carry;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) front += __shfl_xor(front, o);
+    if (lane == 63) w_own[wave] = inc;
+    if (lane == 0) w_front[wave] = front;
     __syncthreads();
-    int wofs = 0, tot = 0;
+    int ofs = (w_front[0] + w_front[1]) + (w_front[2] + w_front[3]);
+    int tile_total = 0;
 #pragma unroll
-    for (int w = 0; w < 16; w++) { const int t = wtot[w]; if (w < wave) wofs += t; tot += t; }
+    for (int w = 0; w < 4; w++) { const int t = w_own[w]; if (w < wave) ofs += t; tile_total += t; }
+    const int e0 = ofs + inc - s8;
+    if (i0 + 8 <= n) {
+        *reinterpret_cast<int4*>(out + i0) = make_int4(e0 + v[0], e0 + v[1], e0 + v[2], e0 + v[3]);
+        *reinterpret_cast<int4*>(out + i0 + 4) = make_int4(e0 + v[4], e0 + v[5], e0 + v[6], e0 + v[7]);
+    } else {
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int i = w0 + 256 * r;
-#pragma unroll
-        for (int k = 0; k < 4; k++) if (r < R && i + k < n) out[i + k] = wofs + v[r][k];
+        for (int k = 0; k < 8; k++) if (i0 + k < n) out[i0 + k] = e0 + v[k];
     }
-    if (threadIdx.x == 0) out[n] = tot;
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) out[n] = (w_front[0] + w_front[1]) + (w_front[2] + w_front[3]) + tile_total;
 }
 static int exclusive_scan(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const int* in, int64_t n, int* out /*[n+1]*/) {
     if (n <= 65536) {
-        hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, ctx->stream, in, (int)n, out);
+        hipLaunchKernelGGL(k_scan_tiles, dim3(std::max(1, nblocks(n, kScanTile))), dim3(256), 0, ctx->stream, in, (int)n, out);
         HIPCHK(hipGetLastError());
         return LILI_OK;
     }
@@ -653,40 +715,106 @@ static int voxel_sort(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const float4*
     P.mul[0] = 1; P.mul[1] = div_b[0]; P.mul[2] = div_b[0] * div_b[1];
     P.sentinel = (unsigned)total;                 // <= 2^31 - 1
     int bits = 1; while (bits < 32 && (1ull << bits) < (unsigned long long)total + 1ull) bits++;   // keys 0 .. total (sentinel included)
+    V->bits_guess = std::max(8, (bits + 7) / 8 * 8); V->guess_leaf = leaf;      // what the next filter of this leaf size may assume (voxel_filter_enqueue)
     HIPCHK(V->keys_a.ensure((size_t)n * 4)); HIPCHK(V->vals_a.ensure((size_t)n * 4));
     hipLaunchKernelGGL(k_vox_key, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, d_pts, n, P, V->keys_a.as<unsigned>(), V->vals_a.as<int>());
     return radix_sort(ctx, V, n, bits);
 }
 
-// VoxelGrid of a device float4 cloud; result in V->out / V->out_cnt, V->n_out.  Blocking (two small read-backs).
-// need_order: the caller goes on to use the sort's order (V->vals_a: lili_localmap_commit builds its sorted ring from it) — only the general chain leaves one
-static int voxel_filter_device(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const float4* d_pts, int n, float leaf, bool need_order = false) {
-    V->n_out = 0;
-    if (n == 0) return LILI_OK;
-    if (n <= kVoxSmallMax && ctx->voxel_small && !need_order) {      // one launch, one synchronisation (k_voxel_small)
-        HIPCHK(V->out.ensure((size_t)n * 16)); HIPCHK(V->out_cnt.ensure((size_t)n * 4));
-        int* d_res = reinterpret_cast<int*>(ctx->misc.as<char>() + 1024);
-        hipLaunchKernelGGL(k_voxel_small, dim3(1), dim3(kVoxSmallThreads), 0, ctx->stream, d_pts, n, 1.0f / leaf, V->out.as<float4>(), V->out_cnt.as<int>(), d_res);
-        HIPCHK(hipGetLastError());
-        int res[2] = {0, 0};
-        { int rb = lili_readback_add(ctx, res, d_res, sizeof(res)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }
-        if (!res[1]) { V->n_out = res[0]; return LILI_OK; }
-        if (res[1] == 2) return ctx->fail(LILI_E_ARG, "voxel_filter: cloud holds no finite point");
-        // (voxel index beyond 31 bits: the general path below reports it the way PCL does)
-    }
+// the launches behind the sort: head flags (and the points in sorted order), their scan, the centroids
+static int voxel_filter_tail(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const float4* d_pts, int n, unsigned sentinel, bool alt) {
+    DevBuf& out = alt ? V->qout : V->out; DevBuf& out_cnt = alt ? V->qout_cnt : V->out_cnt;
+    HIPCHK(V->flags.ensure((size_t)n * 4)); HIPCHK(V->slots.ensure(((size_t)n + 1) * 4)); HIPCHK(V->spts.ensure((size_t)n * 16));
+    HIPCHK(out.ensure((size_t)n * 16)); HIPCHK(out_cnt.ensure((size_t)n * 4));
+    hipLaunchKernelGGL(k_vox_heads, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, V->keys_a.as<unsigned>(), V->vals_a.as<int>(), d_pts, n, sentinel, V->flags.as<int>(), V->spts.as<float4>());
+    const int rc = exclusive_scan(ctx, V, V->flags.as<int>(), n, V->slots.as<int>());
+    if (rc != LILI_OK) return rc;
+    hipLaunchKernelGGL(k_vox_centroid, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, V->keys_a.as<unsigned>(), V->slots.as<int>(), V->spts.as<float4>(), n, sentinel,
+                       out.as<float4>(), out_cnt.as<int>());
+    HIPCHK(hipGetLastError());
+    return LILI_OK;
+}
+
+// VoxelGrid of a device float4 cloud the measured way: the bounding box comes to the host, the host sizes the keys.  Blocking (two small read-backs).
+static int voxel_filter_measured(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const float4* d_pts, int n, float leaf, bool alt) {
     VoxDev P;
     int rc = voxel_sort(ctx, V, d_pts, n, leaf, P);
     if (rc != LILI_OK) return rc;
-    HIPCHK(V->flags.ensure((size_t)n * 4)); HIPCHK(V->slots.ensure(((size_t)n + 1) * 4));
-    HIPCHK(V->out.ensure((size_t)n * 16)); HIPCHK(V->out_cnt.ensure((size_t)n * 4));
-    hipLaunchKernelGGL(k_vox_heads, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, V->keys_a.as<unsigned>(), n, P.sentinel, V->flags.as<int>());
-    rc = exclusive_scan(ctx, V, V->flags.as<int>(), n, V->slots.as<int>());
+    rc = voxel_filter_tail(ctx, V, d_pts, n, P.sentinel, alt);
     if (rc != LILI_OK) return rc;
-    hipLaunchKernelGGL(k_vox_centroid, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, V->keys_a.as<unsigned>(), V->vals_a.as<int>(), V->slots.as<int>(), d_pts, n, P.sentinel,
-                       V->out.as<float4>(), V->out_cnt.as<int>());
-    HIPCHK(hipGetLastError());
-    { int rb = lili_readback_add(ctx, &V->n_out, V->slots.as<int>() + n, sizeof(int)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }
+    int& n_out = alt ? V->qn_out : V->n_out;
+    { int rb = lili_readback_add(ctx, &n_out, V->slots.as<int>() + n, sizeof(int)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }
     return LILI_OK;
+}
+
+// VoxelGrid of a device float4 cloud in two halves (round 5): _enqueue launches what can be launched without knowing anything about the cloud and adds the read-backs
+// of the outcome to the context's pending list; the caller synchronises (lili_readback_finish — or lets a synchronisation it has anyway deliver them: the frame pipeline
+// enqueues its query filter behind the local map's index build) and calls _complete, which accepts the outcome or repeats the filter the measured way.
+//   <= 8192 points (and no caller that needs the sort's order): k_voxel_small, one launch;
+//   else, when a filter of this leaf size has been measured before: the box stays on the device (k_vox_key_dev) and the key bits are guessed from that filter;
+//   else nothing is enqueued and _complete runs the measured filter.
+// Result in V->out / V->out_cnt / V->n_out, or in V->qout / V->qout_cnt / V->qn_out (`alt`).
+enum { kPendDone = 0, kPendMeasure = 1, kPendSmall = 2, kPendGuess = 3 };
+static int voxel_filter_enqueue(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const float4* d_pts, int n, float leaf, bool need_order, bool alt) {
+    auto& Q = V->pend;
+    Q = lili_detail::VoxelBuffers::Pending{};
+    Q.d_pts = d_pts; Q.n = n; Q.leaf = leaf; Q.need_order = need_order; Q.alt = alt;
+    (alt ? V->qn_out : V->n_out) = 0;
+    if (n == 0) { Q.mode = kPendDone; return LILI_OK; }
+    DevBuf& out = alt ? V->qout : V->out; DevBuf& out_cnt = alt ? V->qout_cnt : V->out_cnt;
+    int* d_res = reinterpret_cast<int*>(ctx->misc.as<char>() + 1024);
+    if (n <= kVoxSmallMax && ctx->voxel_small && !need_order) {
+        HIPCHK(out.ensure((size_t)n * 16)); HIPCHK(out_cnt.ensure((size_t)n * 4));
+        hipLaunchKernelGGL(k_voxel_small, dim3(1), dim3(kVoxSmallThreads), 0, ctx->stream, d_pts, n, 1.0f / leaf, out.as<float4>(), out_cnt.as<int>(), d_res);
+        HIPCHK(hipGetLastError());
+        Q.mode = kPendSmall;
+        return lili_readback_add(ctx, Q.res, d_res, sizeof(Q.res));
+    }
+    if (ctx->voxel_guess_bits && V->bits_guess > 0 && V->guess_leaf == leaf) {
+        unsigned* d_mm = ctx->misc.as<unsigned>();
+        hipLaunchKernelGGL(k_box_init, dim3(1), dim3(64), 0, ctx->stream, d_mm);
+        hipLaunchKernelGGL(k_bbox, dim3(std::min(nblocks(n, kBlock), 512)), dim3(kBlock), 0, ctx->stream, d_pts, n, d_mm);
+        HIPCHK(V->keys_a.ensure((size_t)n * 4)); HIPCHK(V->vals_a.ensure((size_t)n * 4));
+        const int bits = V->bits_guess;
+        hipLaunchKernelGGL(k_vox_key_dev, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, d_pts, n, 1.0f / leaf, (const unsigned*)d_mm, bits, V->keys_a.as<unsigned>(),
+                           V->vals_a.as<int>(), d_res);
+        int rc = radix_sort(ctx, V, n, bits);
+        if (rc != LILI_OK) return rc;
+        rc = voxel_filter_tail(ctx, V, d_pts, n, bits >= 32 ? 0xFFFFFFFFu : (1u << bits) - 1u, alt);
+        if (rc != LILI_OK) return rc;
+        Q.mode = kPendGuess;
+        rc = lili_readback_add(ctx, &Q.n_out, V->slots.as<int>() + n, sizeof(int));
+        if (rc == LILI_OK) rc = lili_readback_add(ctx, Q.res, d_res, sizeof(Q.res));
+        return rc;
+    }
+    Q.mode = kPendMeasure;
+    return LILI_OK;
+}
+static int voxel_filter_complete(lili_ctx* ctx, lili_detail::VoxelBuffers* V) {
+    auto& Q = V->pend;
+    int& n_out = Q.alt ? V->qn_out : V->n_out;
+    const int mode = Q.mode;
+    Q.mode = kPendDone;
+    if (mode == kPendDone) return LILI_OK;
+    if (mode == kPendSmall) {
+        if (!Q.res[1]) { n_out = Q.res[0]; return LILI_OK; }
+        if (Q.res[1] == 2) return ctx->fail(LILI_E_ARG, "voxel_filter: cloud holds no finite point");
+        // (voxel index beyond 31 bits: the measured path reports it the way PCL does)
+    }
+    if (mode == kPendGuess) {
+        V->key_guesses++;
+        if (Q.res[0] == 0) { n_out = Q.n_out; V->bits_guess = std::max(8, (Q.res[1] + 7) / 8 * 8); return LILI_OK; }
+        V->key_guess_misses++;      // more key bits than guessed, or one of the error cases: the measured path sorts it out
+    }
+    return voxel_filter_measured(ctx, V, Q.d_pts, Q.n, Q.leaf, Q.alt);
+}
+// Blocking: result in V->out / V->out_cnt, V->n_out.
+// need_order: the caller goes on to use the sort's order (V->vals_a: lili_localmap_commit builds its sorted ring from it) — k_voxel_small leaves none
+static int voxel_filter_device(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const float4* d_pts, int n, float leaf, bool need_order = false, bool alt = false) {
+    int rc = voxel_filter_enqueue(ctx, V, d_pts, n, leaf, need_order, alt);
+    if (rc != LILI_OK) return rc;
+    if (V->pend.mode == kPendSmall || V->pend.mode == kPendGuess) { rc = lili_readback_finish(ctx); if (rc != LILI_OK) return rc; }
+    return voxel_filter_complete(ctx, V);
 }
 
 extern "C" {
@@ -973,6 +1101,15 @@ int lili_localmap_stats(lili_ctx* ctx, int32_t* incremental_commits, int32_t* fu
     return LILI_OK;
 }
 
+// how the VoxelGrid filters of more than 8192 points were served so far: with guessed key bits (no host round trip for the box) / guesses that did not hold
+int lili_voxel_filter_stats(lili_ctx* ctx, int32_t* key_guesses, int32_t* key_guess_misses) {
+    if (!ctx) return LILI_E_ARG;
+    auto* V = vox_of(ctx);
+    if (key_guesses) *key_guesses = V->key_guesses;
+    if (key_guess_misses) *key_guess_misses = V->key_guess_misses;
+    return LILI_OK;
+}
+
 }  // extern "C"
 
 // ---- internal hooks of lili_pipeline.hip (declared in lili_ctx.h; not part of the ABI) ----
@@ -983,6 +1120,22 @@ int lili_voxel_filter_dev(lili_ctx* ctx, const float4* d_pts, int n, float leaf,
     if (rc != LILI_OK) return rc;
     if (d_out) *d_out = V->out.as<float4>();
     if (n_out) *n_out = V->n_out;
+    return LILI_OK;
+}
+// the same in two halves, into the filter's SECOND output buffer (so that it may be enqueued while the first still holds a local map that is being indexed):
+// _enqueue never blocks; *pending = a read-back has joined the context's list and wants a lili_readback_finish before _complete
+int lili_voxel_filter_dev_enqueue(lili_ctx* ctx, const float4* d_pts, int n, float leaf, bool* pending) {
+    auto* V = vox_of(ctx);
+    const int rc = voxel_filter_enqueue(ctx, V, d_pts, n, leaf, false, true);
+    if (pending) *pending = V->pend.mode == kPendSmall || V->pend.mode == kPendGuess;
+    return rc;
+}
+int lili_voxel_filter_dev_complete(lili_ctx* ctx, const float4** d_out, int* n_out) {
+    auto* V = vox_of(ctx);
+    const int rc = voxel_filter_complete(ctx, V);
+    if (rc != LILI_OK) return rc;
+    if (d_out) *d_out = V->qout.as<float4>();
+    if (n_out) *n_out = V->qn_out;
     return LILI_OK;
 }
 // lili_localmap_push of a device float4 cloud at the pose held in a slot's DEVICE state (async: no host round trip for the pose)

@@ -281,3 +281,39 @@ def test_single_launch_filter_hands_an_index_overflow_to_the_general_path(gpu_ct
     pts = np.array([[0, 0, 0, 1], [5000, 5000, 5000, 1]], np.float32)
     with pytest.raises(L.LiliError):
         L.api.voxel_filter(gpu_ctx, pts, 0.001)
+
+
+def test_filter_with_guessed_key_bits_equals_the_measured_filter(oracle):
+    """Round 5: a VoxelGrid of more than 8192 points whose leaf size has been filtered before keeps its bounding box on the device and sorts by as many key bits as that
+    filter needed (k_vox_key_dev; option voxel_guess_bits).  Same voxels, order, counts and centroids as the measured filter and the oracle — for a cloud the guess
+    holds for, one that needs FEWER bits, one that needs MORE (the device notices, the filter is repeated the measured way), non-finite points, and the error cases."""
+    rng = np.random.default_rng(2024)
+
+    def cloud(n, scale):
+        pts = np.concatenate([rng.uniform(-scale, scale, (n, 2)), rng.normal(0, 0.5, (n, 1)), rng.uniform(0, 25, (n, 1))], 1).astype(np.float32)
+        pts[: n // 10] = pts[n // 10: 2 * (n // 10)][: n // 10]
+        pts[n // 2] = [np.nan, 0, 0, 1]; pts[n // 3] = [0, -np.inf, 0, 1]
+        return pts
+    seq = [cloud(20_000, 50.0), cloud(24_000, 52.0), cloud(20_000, 4.0), cloud(30_000, 900.0), cloud(30_000, 880.0), cloud(9_000, 50.0)]
+    ctx = L.Context(0)
+    try:
+        got = [L.api.voxel_filter(ctx, p, 0.4) for p in seq]
+        guesses, misses = L.api.voxel_filter_stats(ctx)
+        # the first filter measures; the others guess; 50 -> 4 m needs fewer bits (the guess holds), 4 -> 900 m more (a miss)
+        assert guesses == len(seq) - 1 and misses == 1, (guesses, misses)
+        with pytest.raises(L.LiliError):      # PCL's int32 overflow, reported through the guessed path's fallback
+            L.api.voxel_filter(ctx, np.concatenate([seq[0], np.array([[3e5, 3e5, 3e5, 0]], np.float32)]), 0.4)
+        with pytest.raises(L.LiliError):      # no finite point at all
+            L.api.voxel_filter(ctx, np.full((9000, 4), np.nan, np.float32), 0.4)
+        again = L.api.voxel_filter(ctx, seq[0], 0.4)      # and the filter still works afterwards
+        ctx.set_option("voxel_guess_bits", 0)
+        ref = [L.api.voxel_filter(ctx, p, 0.4) for p in seq]
+        assert L.api.voxel_filter_stats(ctx)[0] == guesses + 3      # (the two error cases and `again` guessed; nothing since)
+    finally:
+        ctx.close()
+    for p, (g, c), (g0, c0) in zip(seq, got, ref):
+        assert g.shape == g0.shape and np.array_equal(c, c0) and np.array_equal(g.view(np.uint32), g0.view(np.uint32))
+        fin = np.isfinite(p[:, :3]).all(1)
+        o, oc = oracle.voxel_grid(np.ascontiguousarray(p[fin]), 0.4, stable=True)
+        assert g.shape == o.shape and np.array_equal(c, oc) and np.array_equal(g.view(np.uint32), o.view(np.uint32))
+    assert np.array_equal(again[0].view(np.uint32), got[0][0].view(np.uint32))
