@@ -21,7 +21,7 @@ struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
     hipError_t ensure(size_t bytes) {
-        if (bytes <= cap) return hipSuccess;
+        if (bytes + 256 <= cap) return hipSuccess;      // (every buffer keeps >= 256 bytes of slack behind what was asked for: kernels may read whole 16-byte vectors at the end)
         if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
         size_t want = bytes + bytes / 8 + 256;
         hipError_t e = hipMalloc(&p, want);

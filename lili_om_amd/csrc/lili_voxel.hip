@@ -240,34 +240,98 @@ __global__ void k_vox_heads(const unsigned* __restrict__ keys, const int* __rest
     spts[i] = pts[vals[i]];
     flags[i] = (keys[i] != sentinel && (i == 0 || keys[i] != keys[i - 1])) ? 1 : 0;
 }
-__global__ __launch_bounds__(256) void k_vox_centroid(const unsigned* __restrict__ keys, const int* __restrict__ slot /*exclusive scan of flags, [n+1]*/,
+__device__ __forceinline__ void wave_lds_order();
+// CentroidPoint over the sorted cloud: float accumulators, members added in sorted (= input) order — the sum itself has to stay sequential, so the launch lasts as long as
+// its fullest voxel (next to the sensor: up to ~600 of a Livox frame's 21 k surf features; nine voxels of ten hold 4 or fewer).  Round 5: the launch is a chain of THREE
+// memory round trips whatever the voxel's size —
+//   1. every position asks for its two slot words (a head is where the scan of the head flags steps) and, speculatively, the kFirst points from itself on;
+//   2. a head asks for the next head's position (k_scan_flags left them compacted in head_pos): the voxel's length is known, no key is compared any more;
+//   3. a voxel of up to kFirst + kMem members is finished by its head's thread with all its loads in flight at once; a longer one joins the workgroup's list, which the four
+//      waves share out (the fullest voxels of a frame are neighbours in the sorted order): the wave requests ALL the voxel's remaining members at once (16 per lane),
+//      parks them in LDS and every lane adds them up in the same order from a wave-uniform address, the next eight requested before the sums —
+// where rounds 1-4 walked a voxel in trips of 8 / 32 members with one or two dependent round trips each (31 -> 20 -> 17 us per frame for the trips alone).
+__global__ __launch_bounds__(256) void k_vox_centroid(const unsigned* __restrict__ keys, const int* __restrict__ slot /*exclusive scan of the head flags, [n+1]*/,
+                               const int* __restrict__ head_pos /*position of voxel o's head; [number of voxels] = where the voxels end if has_end*/, int has_end,
                                const float4* __restrict__ spts /*points in sorted order*/, int n, unsigned sentinel, float4* __restrict__ out, int* __restrict__ out_cnt) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (!(i == 0 || keys[i] != keys[i - 1])) return;
-    unsigned k = keys[i];
-    if (k == sentinel) return;
-    // CentroidPoint: float accumulators, members added in sorted (= input) order.  kMem members per trip, their keys and points requested together: ONE memory round trip
-    // per kMem members (voxels next to the sensor hold hundreds of points of a raw scan; the sum itself has to stay sequential, and the launch lasts as long as its
-    // fullest voxel's chain of trips).  Round 5: 32 per trip (8 before), points read from the sorted copy (two dependent round trips per trip before: 26 us for the
-    // 20 k surf features of a Livox frame).
-    constexpr int kMem = 32;
-    float sx = 0.f, sy = 0.f, sz = 0.f, sa = 0.f; int c = 0;
-    bool more = true;
-    for (int m = i; more && m < n; m += kMem) {
-        unsigned kk[kMem]; float4 pp[kMem];
+    constexpr int kFirst = 4, kMem = 32, kStage = 1024;
+    __shared__ float4 stage[4][kStage];
+    __shared__ int q_n, q_o[8], q_m[8], q_end[8];
+    __shared__ float4 q_s[8];
+    if (threadIdx.x == 0) q_n = 0;
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ic = min(i, n - 1);
+    const int s0 = slot[ic], s1 = slot[ic + 1], n_out = slot[n];
+    float4 f[kFirst];
 #pragma unroll
-        for (int u = 0; u < kMem; u++) { const int mm = min(m + u, n - 1); kk[u] = keys[mm]; pp[u] = spts[mm]; }
+    for (int u = 0; u < kFirst; u++) f[u] = spts[min(i + u, n - 1)];
+    const bool head = i < n && s1 != s0;
+    int end = i + 1;
+    if (head) {
+        if (has_end || s0 + 1 < n_out) end = head_pos[s0 + 1];
+        else { const unsigned k = keys[i]; while (end < n && keys[end] == k) end++; }      // (heads compacted by k_vox_head_pos: the last voxel ends where the keys stop being voxels; a chain of dependent loads)
+    }
+    const int len = end - i;
+    float sx = 0.f, sy = 0.f, sz = 0.f, sa = 0.f;
 #pragma unroll
-        for (int u = 0; u < kMem; u++) {
-            if (more && m + u < n && kk[u] == k) { sx += pp[u].x; sy += pp[u].y; sz += pp[u].z; sa += pp[u].w; c++; }
-            else more = false;
+    for (int u = 0; u < kFirst; u++) if (u < len) { sx += f[u].x; sy += f[u].y; sz += f[u].z; sa += f[u].w; }
+    if (head && len > kFirst && len <= kFirst + kMem) {
+        float4 pp[kMem];
+#pragma unroll
+        for (int u = 0; u < kMem; u++) pp[u] = spts[min(i + kFirst + u, end - 1)];
+#pragma unroll
+        for (int u = 0; u < kMem; u++) if (kFirst + u < len) { sx += pp[u].x; sy += pp[u].y; sz += pp[u].z; sa += pp[u].w; }
+    }
+    if (head && len <= kFirst + kMem) {
+        const float fn = (float)len;
+        out[s0] = make_float4(sx / fn, sy / fn, sz / fn, sa / fn);
+        if (out_cnt) out_cnt[s0] = len;
+    }
+    if (head && len > kFirst + kMem) {
+        const int j = atomicAdd(&q_n, 1);      // (at most 256 / (kFirst + kMem + 1) = 6 entries)
+        q_o[j] = s0; q_m[j] = i + kFirst; q_end[j] = end; q_s[j] = make_float4(sx, sy, sz, sa);
+    }
+    __syncthreads();
+    const int nq = q_n;
+    for (int j = wave; j < nq; j += 4) {      // (wave-uniform)
+        int mL = q_m[j];
+        const int eL = q_end[j], oL = q_o[j];
+        // lane c (of every four) carries component c of the sum: ONE dependent addition per member instead of four (the fullest voxel's ~600 members are the launch's tail)
+        const int comp = lane & 3;
+        float acc = comp == 0 ? q_s[j].x : comp == 1 ? q_s[j].y : comp == 2 ? q_s[j].z : q_s[j].w;
+        const float* st = reinterpret_cast<const float*>(stage[wave]) + comp;
+        while (mL < eL) {
+            const int cnt = min(eL - mL, kStage);
+            float4 reg[kStage / 64];
+#pragma unroll
+            for (int r = 0; r < kStage / 64; r++) reg[r] = spts[min(mL + 64 * r + lane, eL - 1)];      // (no branch: every request leaves before the first answer is awaited; rows behind the end re-read its last point)
+#pragma unroll
+            for (int r = 0; r < kStage / 64; r++) stage[wave][64 * r + lane] = reg[r];
+            wave_lds_order();
+            float p[16];
+#pragma unroll
+            for (int t = 0; t < 16; t++) p[t] = st[4 * t];
+            for (int u = 0; u < cnt; u += 16) {
+                float nx[16];
+#pragma unroll
+                for (int t = 0; t < 16; t++) nx[t] = st[4 * min(u + 16 + t, kStage - 1)];
+#pragma unroll
+                for (int t = 0; t < 16; t++) if (u + t < cnt) acc += p[t];
+#pragma unroll
+                for (int t = 0; t < 16; t++) p[t] = nx[t];
+            }
+            mL += cnt;
+            wave_lds_order();      // the next members overwrite the stage
+        }
+        const float ax = __shfl(acc, 0), ay = __shfl(acc, 1), az = __shfl(acc, 2), aw = __shfl(acc, 3);
+        if (lane == 0) {
+            const int len_l = eL - (q_m[j] - kFirst);
+            const float fn = (float)len_l;
+            out[oL] = make_float4(ax / fn, ay / fn, az / fn, aw / fn);
+            if (out_cnt) out_cnt[oL] = len_l;
         }
     }
-    float fn = (float)c;
-    int o = slot[i];
-    out[o] = make_float4(sx / fn, sy / fn, sz / fn, sa / fn);
-    if (out_cnt) out_cnt[o] = c;
 }
 
 // pcl::VoxelGrid of a SMALL cloud (<= kVoxSmallMax points: a Livox frame's surf features, the queries of the front end — L/src/LidarOdometry.cpp:320-322) in ONE
@@ -416,42 +480,50 @@ __global__ void k_sorted_gather(const float4* __restrict__ pts, const int* __res
     }
     out_pt[r] = p; out_key[r] = key; out_seq[r] = sq;
 }
-// The new keyframe of an incremental commit (<= kVoxSmallMax points: a frame's down-sampled features) sorted by absolute voxel key in ONE single-workgroup launch
-// (round 5): what k_bbox + k_vox_key_packed + four radix passes + k_sorted_gather produce in twelve launches — the points in (key, input position) order with
-// their keys and the keyframe's sequence number; *bad is raised for a point beyond the key range (the commit then rebuilds).  Bitonic network on (64-bit key,
-// 16-bit position) pairs in LDS.
-__global__ __launch_bounds__(kVoxSmallThreads) void k_sort_keyframe_small(const float4* __restrict__ pts, int n, float inv_leaf, unsigned seq, float4* __restrict__ out_pt,
-                                                                           unsigned long long* __restrict__ out_key, unsigned* __restrict__ out_seq, unsigned* __restrict__ bad) {
-    __shared__ unsigned long long key[kVoxSmallMax];
-    __shared__ unsigned short pos[kVoxSmallMax];
-    const int tid = threadIdx.x;
-    int np2 = 64; while (np2 < n) np2 <<= 1;
-    for (int i = tid; i < np2; i += kVoxSmallThreads) {
-        unsigned long long k = ~0ull;
-        if (i < n) { k = abs_voxel_key(pts[i], inv_leaf); if (k == ~0ull - 1ull) *bad = 1u; }
-        key[i] = k; pos[i] = (unsigned short)i;
-    }
-    __syncthreads();
-    auto step = [&](int t, int j, int k) {
-        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        const int l = i | j;
-        const unsigned long long a = key[i], b = key[l];
-        const unsigned short pa = pos[i], pb = pos[l];
-        const bool gt = a > b || (a == b && pa > pb);      // (key, input position): stable; the padding (key ~0, position >= n) sorts behind everything
-        const bool up = (i & k) == 0;
-        if (gt == up) { key[i] = b; key[l] = a; pos[i] = pb; pos[l] = pa; }
-    };
-    for (int k = 2; k <= np2; k <<= 1) {      // (block barriers only behind partner distances > 64: see k_voxel_small)
-        int j = k >> 1;
-        for (; j > 64; j >>= 1) {
-            for (int t = tid; t < np2 / 2; t += kVoxSmallThreads) step(t, j, k);
-            __syncthreads();
+// The new keyframe of an incremental commit (<= kVoxSmallMax points: a frame's down-sampled features) sorted by absolute voxel key (round 5): what k_bbox +
+// k_vox_key_packed + four radix passes + k_sorted_gather produce in twelve launches — the points in (key, input position) order with their keys and the keyframe's
+// sequence number; *bad is raised for a point beyond the key range (the commit then rebuilds).  Sorting by COUNTING, spread over the chip: a wave holds 64 points (one
+// per lane) and 64 keys of the keyframe (one per lane, broadcast lane by lane through SGPRs) and counts, per point, the (key, position) pairs below it among those 64;
+// workgroup (bx, by) covers points 64 bx .. and the eight 64-key slices 8 by ..; the counts of a point add up in `rank` (zeroed by the caller), which k_rank_scatter turns
+// into places.  n^2 / 4096 wave tasks of ~1.5 us each on n^2 / 32768 workgroups: ~4 us for the 2 k points of a Livox frame, where a single-workgroup bitonic network
+// took 22-27 us and counting inside n / 64 workgroups 19.
+constexpr int kRankWaves = 8;
+constexpr size_t kRankOff = 2 * 64 * 128 + 256;      // ctx->misc behind the box / density banks (lili_map.hip: kMiscBytes): the scan-status words of a map build
+static_assert(kRankOff + (size_t)kVoxSmallMax * 4 <= kMiscAlloc, "rank words of k_rank_count");
+__global__ __launch_bounds__(64 * kRankWaves) void k_rank_count(const float4* __restrict__ pts, int n, float inv_leaf, int* __restrict__ rank, unsigned* __restrict__ bad) {
+    __shared__ int part[kRankWaves][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    unsigned long long ke = ~0ull;
+    if (e < n) { ke = abs_voxel_key(pts[e], inv_leaf); if (ke == ~0ull - 1ull && wave == 0 && blockIdx.y == 0) *bad = 1u; }
+    const int s0 = (blockIdx.y * kRankWaves + wave) * 64;      // this wave's slice of the keyframe
+    int cnt = 0;
+    if (s0 < n) {
+        const unsigned long long ks = s0 + lane < n ? abs_voxel_key(pts[s0 + lane], inv_leaf) : ~0ull;
+        const int len = min(64, n - s0);
+        const unsigned ks_lo = (unsigned)ks, ks_hi = (unsigned)(ks >> 32);
+#pragma unroll
+        for (int u = 0; u < 64; u++) {
+            const unsigned long long ku = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)ks_hi, u) << 32) | (unsigned)__builtin_amdgcn_readlane((int)ks_lo, u);
+            const int idx = s0 + u;
+            if (u < len) cnt += (ku < ke || (ku == ke && idx < e)) ? 1 : 0;      // (key, input position): stable
         }
-        for (int t = tid; t < np2 / 2; t += kVoxSmallThreads)
-            for (int jj = j; jj > 0; jj >>= 1) { step(t, jj, k); wave_lds_order(); }
-        __syncthreads();
     }
-    for (int r = tid; r < n; r += kVoxSmallThreads) { out_pt[r] = pts[pos[r]]; out_key[r] = key[r]; out_seq[r] = seq; }
+    part[wave][lane] = cnt;
+    __syncthreads();
+    if (wave != 0 || e >= n) return;
+    int r = 0;
+#pragma unroll
+    for (int w = 0; w < kRankWaves; w++) r += part[w][lane];
+    if (r) atomicAdd(&rank[e], r);
+}
+__global__ void k_rank_scatter(const float4* __restrict__ pts, int n, float inv_leaf, unsigned seq, const int* __restrict__ rank, float4* __restrict__ out_pt,
+                               unsigned long long* __restrict__ out_key, unsigned* __restrict__ out_seq) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const float4 p = pts[e];
+    const int r = rank[e];
+    out_pt[r] = p; out_key[r] = abs_voxel_key(p, inv_leaf); out_seq[r] = seq;
 }
 
 struct DropSeqs { unsigned s[4]; int n; };
@@ -465,11 +537,10 @@ __global__ void k_keep_flags(const unsigned* __restrict__ seq, long long n, Drop
     flags[i] = drop ? 0 : 1;
 }
 // kept entry i of the old list goes to (kept entries before it) + (new entries with a SMALLER key: new ones follow old ones of the same voxel)
-__global__ void k_merge_old(const unsigned long long* __restrict__ key, const float4* __restrict__ pt, const unsigned* __restrict__ seq, const int* __restrict__ flags,
-                            const int* __restrict__ rank /*exclusive scan of flags, [n+1]*/, long long n, const unsigned long long* __restrict__ nkey, int n_new,
+__device__ __forceinline__ void merge_old_item(const unsigned long long* __restrict__ key, const float4* __restrict__ pt, const unsigned* __restrict__ seq, bool keep,
+                            const int* __restrict__ rank /*exclusive scan of the keep flags, [n+1]*/, long long i, const unsigned long long* __restrict__ nkey, int n_new,
                             unsigned long long* __restrict__ okey, float4* __restrict__ opt, unsigned* __restrict__ oseq) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !flags[i]) return;
+    if (!keep) return;
     const unsigned long long k = key[i];
     int lo = 0, hi = n_new;                       // lower_bound(nkey, k)
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (nkey[mid] < k) lo = mid + 1; else hi = mid; }
@@ -477,15 +548,32 @@ __global__ void k_merge_old(const unsigned long long* __restrict__ key, const fl
     okey[pos] = k; opt[pos] = pt[i]; oseq[pos] = seq[i];
 }
 // new entry j goes to j + (kept old entries with key <= its key)
-__global__ void k_merge_new(const unsigned long long* __restrict__ nkey, const float4* __restrict__ npt, int n_new, unsigned nseq, const unsigned long long* __restrict__ key,
+__device__ __forceinline__ void merge_new_item(const unsigned long long* __restrict__ nkey, const float4* __restrict__ npt, int j, unsigned nseq, const unsigned long long* __restrict__ key,
                             const int* __restrict__ rank, long long n, unsigned long long* __restrict__ okey, float4* __restrict__ opt, unsigned* __restrict__ oseq) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n_new) return;
     const unsigned long long k = nkey[j];
     long long lo = 0, hi = n;                     // upper_bound(key, k)
     while (lo < hi) { const long long mid = (lo + hi) >> 1; if (key[mid] <= k) lo = mid + 1; else hi = mid; }
     const long long pos = (long long)j + (long long)rank[lo];
     okey[pos] = k; opt[pos] = npt[j]; oseq[pos] = nseq;
+}
+// both halves of the merge in ONE launch: threads [0, n) place the old list's entries, threads [n, n + n_new) the new keyframe's.  `flags` (the keep flags in memory) or,
+// when null, the keyframes dropped (`drop`: the scan derived the flags itself, k_scan_flags<kScanKeep>)
+__global__ void k_merge(const unsigned long long* __restrict__ key, const float4* __restrict__ pt, const unsigned* __restrict__ seq, const int* __restrict__ flags, DropSeqs drop,
+                        const int* __restrict__ rank, long long n, const unsigned long long* __restrict__ nkey, const float4* __restrict__ npt, int n_new, unsigned nseq,
+                        unsigned long long* __restrict__ okey, float4* __restrict__ opt, unsigned* __restrict__ oseq) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        bool keep;
+        if (flags) keep = flags[i] != 0;
+        else {
+            const unsigned q = seq[i];
+            bool d = false;
+#pragma unroll
+            for (int k = 0; k < 4; k++) d = d || (k < drop.n && q == drop.s[k]);
+            keep = !d;
+        }
+        merge_old_item(key, pt, seq, keep, rank, i, nkey, n_new, okey, opt, oseq);
+    } else if (i < n + n_new) merge_new_item(nkey, npt, (int)(i - n), nseq, key, rank, n, okey, opt, oseq);
 }
 __global__ void k_vox_heads64(const unsigned long long* __restrict__ keys, long long n, int* __restrict__ flags) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -498,15 +586,15 @@ __global__ void k_vox_head_pos(const int* __restrict__ flags, const int* __restr
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && flags[i]) head_pos[slot[i]] = (int)i;
 }
-__global__ void k_vox_centroid64(const unsigned long long* __restrict__ keys, const float4* __restrict__ pts, const int* __restrict__ head_pos, const int* __restrict__ n_out_p, long long n,
-                                 float4* __restrict__ out, int* __restrict__ out_cnt) {
+__global__ void k_vox_centroid64(const unsigned long long* __restrict__ keys, const float4* __restrict__ pts, const int* __restrict__ head_pos /*[n_out] = where the voxels end if has_end*/,
+                                 int has_end, const int* __restrict__ n_out_p, long long n, float4* __restrict__ out, int* __restrict__ out_cnt) {
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
     const int n_out = *n_out_p;
     if (o >= n_out) return;
     const long long i = head_pos[o];
     // the voxel's members are [i, end): up to the next voxel's head; the last voxel ends where the keys stop being voxels (non-finite points sort last)
     long long end;
-    if (o + 1 < n_out) end = head_pos[o + 1];
+    if (has_end || o + 1 < n_out) end = head_pos[o + 1];
     else { const unsigned long long k = keys[i]; end = i + 1; while (end < n && keys[end] == k) end++; }
     // sequential f32 sums in list order (CentroidPoint); the member count is known, so the loads of a trip do not wait for a key comparison
     float sx = 0.f, sy = 0.f, sz = 0.f, sa = 0.f;
@@ -613,7 +701,14 @@ __global__ __launch_bounds__(256) void k_scan_tiles(const int* __restrict__ in, 
     const int base = blockIdx.x * kScanTile;
     // (`in` is a DevBuf: 16-byte aligned, >= 256 bytes of slack behind its n words; words behind n count as zero)
     int front = 0;
-    for (int i = tid * 4; i < base; i += 1024) { const int4 q = *reinterpret_cast<const int4*>(in + i); front += (q.x + q.y) + (q.z + q.w); }
+    for (int i = tid * 4; i < base; i += 8 * 1024) {      // eight independent 16-byte loads in flight per lane (one after the other they were most of the launch)
+        int4 q[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) q[u] = *reinterpret_cast<const int4*>(in + min(i + u * 1024, base - 4));      // (a group beyond the front re-reads its last one and is not counted)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; u++) front += i + u * 1024 < base ? (q[u].x + q[u].y) + (q[u].z + q[u].w) : 0;
+    }
     const int i0 = base + tid * 8;
     int v[8];
 #pragma unroll
@@ -648,6 +743,151 @@ __global__ __launch_bounds__(256) void k_scan_tiles(const int* __restrict__ in, 
     }
     if (blockIdx.x == gridDim.x - 1 && tid == 0) out[n] = (w_front[0] + w_front[1]) + (w_front[2] + w_front[3]) + tile_total;
 }
+// k_scan_tiles over flags that are never stored (round 5): the launches that only wrote a flag per item for the scan to read are folded into it.  MODE
+//   kScanKeep   : item i of the sorted ring survives the merge (its keyframe is not one of `drop`)                       — was k_keep_flags + scan
+//   kScanHead64 : item i starts a voxel of the sorted ring (64-bit absolute keys); head_pos[its slot] = i on the way      — was k_vox_heads64 + scan + k_vox_head_pos
+//   kScanHead32 : item i starts a voxel of a sorted cloud (32-bit keys, `sentinel` = no voxel); spts[i] = pts[vals[i]]     — was k_vox_heads + scan
+// Same tiles, same sums; the items in front of a tile are re-derived from the keys (the same bytes the flags would have been, twice for 64-bit keys).
+enum { kScanKeep = 1, kScanHead64 = 2, kScanHead32 = 3 };
+struct ScanFlagArgs { const void* a; DropSeqs drop; unsigned sentinel; const int* vals; const float4* pts; float4* spts; int* head_pos; };
+// the raw words behind four consecutive flags (two steps, so that a caller can request several groups before it looks at any: a load behind a branch, or mixed with
+// the arithmetic of the previous group, waits for its own round trip)
+struct ScanRaw { uint4 a, b; unsigned long long prev; };
+template <int MODE> __device__ __forceinline__ ScanRaw scan_flags_load(const ScanFlagArgs& A, int i /*multiple of 4*/) {
+    ScanRaw r{};
+    if (MODE == kScanKeep) r.a = *reinterpret_cast<const uint4*>(static_cast<const unsigned*>(A.a) + i);
+    else if (MODE == kScanHead64) {
+        const unsigned long long* key = static_cast<const unsigned long long*>(A.a);
+        r.a = *reinterpret_cast<const uint4*>(key + i); r.b = *reinterpret_cast<const uint4*>(key + i + 2); r.prev = key[max(i - 1, 0)];
+    } else {
+        const unsigned* key = static_cast<const unsigned*>(A.a);
+        r.a = *reinterpret_cast<const uint4*>(key + i); r.prev = key[max(i - 1, 0)];
+    }
+    return r;
+}
+// v[k] = flag of item i + k; endm (head modes) = bit k set where item i + k is the FIRST item that is no voxel (non-finite points sort last): where the last voxel ends
+template <int MODE> __device__ __forceinline__ void scan_flags_eval(const ScanFlagArgs& A, const ScanRaw& r, int i, int n, int v[4], unsigned* endm = nullptr) {
+    if (MODE == kScanKeep) {
+        const unsigned s[4] = {r.a.x, r.a.y, r.a.z, r.a.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            bool drop = false;
+#pragma unroll
+            for (int d = 0; d < 4; d++) drop = drop || (d < A.drop.n && s[k] == A.drop.s[d]);
+            v[k] = (i + k < n && !drop) ? 1 : 0;
+        }
+    } else if (MODE == kScanHead64) {
+        const unsigned long long kk[5] = {r.prev, ((unsigned long long)r.a.y << 32) | r.a.x, ((unsigned long long)r.a.w << 32) | r.a.z, ((unsigned long long)r.b.y << 32) | r.b.x,
+                                          ((unsigned long long)r.b.w << 32) | r.b.z};
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = (i + k < n && kk[k + 1] < ~0ull - 1ull && (i + k == 0 || kk[k + 1] != kk[k])) ? 1 : 0;
+        if (endm) { *endm = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (i + k < n && kk[k + 1] >= ~0ull - 1ull && (i + k == 0 || kk[k] < ~0ull - 1ull)) *endm |= 1u << k; }
+    } else {
+        const unsigned kk[5] = {(unsigned)r.prev, r.a.x, r.a.y, r.a.z, r.a.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = (i + k < n && kk[k + 1] != A.sentinel && (i + k == 0 || kk[k + 1] != kk[k])) ? 1 : 0;
+        if (endm) { *endm = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (i + k < n && kk[k + 1] == A.sentinel && (i + k == 0 || kk[k] != A.sentinel)) *endm |= 1u << k; }
+    }
+}
+template <int MODE> __device__ __forceinline__ void scan_flags4(const ScanFlagArgs& A, int i /*multiple of 4*/, int n, int v[4]) {
+    const ScanRaw r = scan_flags_load<MODE>(A, i);
+    scan_flags_eval<MODE>(A, r, i, n, v);
+}
+// 1024 threads: the items in FRONT of the tile are read by sixteen waves in one batch of loads per lane (two for the 64-bit keys of a 40 k ring) — the launch lasts as
+// long as its last tile's chain of dependent round trips, ~2 us each on data another launch has just written; with 256 threads and one group in flight it was 39 of them.
+// The tile's own 2048 items belong to the first four waves, eight per lane.
+constexpr int kScanFlagThreads = 1024;
+template <int MODE> __global__ __launch_bounds__(kScanFlagThreads) void k_scan_flags(ScanFlagArgs A, int n, int* __restrict__ out /*[n+1]*/) {
+    __shared__ int w_front[kScanFlagThreads / 64], w_own[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int base = blockIdx.x * kScanTile;
+    constexpr int kB = MODE == kScanHead64 ? 5 : MODE == kScanHead32 ? 8 : 16;      // groups of four items in flight per lane (1024 threads: 128 registers each)
+    // the tile's own items (first four waves, eight per lane) are requested first, so that they travel with the front's
+    const int i0 = base + tid * 8;
+    const int last4 = (n - 1) & ~3;      // (n >= 1) a group behind the end re-reads the last one; its flags are zero by position
+    const ScanRaw r0 = scan_flags_load<MODE>(A, min(i0, last4)), r1 = scan_flags_load<MODE>(A, min(i0 + 4, last4));      // (the other twelve waves load too and drop it: no branch in front of the batch)
+    int src[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) src[k] = MODE == kScanHead32 ? A.vals[min(i0 + k, n - 1)] : 0;
+    int front = 0;
+    for (int i = tid * 4; i < base; i += kB * 4 * kScanFlagThreads) {
+        ScanRaw raw[kB];
+#pragma unroll
+        for (int u = 0; u < kB; u++) raw[u] = scan_flags_load<MODE>(A, min(i + u * 4 * kScanFlagThreads, base - 4));      // (a group beyond the front re-reads its last one and is not counted)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < kB; u++) {
+            int f[4];
+            scan_flags_eval<MODE>(A, raw[u], min(i + u * 4 * kScanFlagThreads, base - 4), n, f);
+            front += i + u * 4 * kScanFlagThreads < base ? (f[0] + f[1]) + (f[2] + f[3]) : 0;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) front += __shfl_xor(front, o);
+    if (lane == 0) w_front[wave] = front;
+    int v[8], flag[8];
+    unsigned endm = 0;
+    int s8 = 0, inc = 0;
+    if (wave < 4) {
+        unsigned e0m = 0, e1m = 0;
+        scan_flags_eval<MODE>(A, r0, i0, n, v, MODE == kScanKeep ? nullptr : &e0m);
+        scan_flags_eval<MODE>(A, r1, i0 + 4, n, v + 4, MODE == kScanKeep ? nullptr : &e1m);
+        endm = e0m | (e1m << 4);
+        if (MODE == kScanHead32) {
+            const float4* __restrict__ gp = A.pts;
+            float4* __restrict__ sp = A.spts;
+            const float4 g0 = gp[src[0]], g1 = gp[src[1]], g2 = gp[src[2]], g3 = gp[src[3]], g4 = gp[src[4]], g5 = gp[src[5]], g6 = gp[src[6]], g7 = gp[src[7]];
+            if (i0 < n) {      // (up to seven points behind the end land in the buffer's slack: DevBuf keeps 256 bytes)
+                sp[i0] = g0; sp[i0 + 1] = g1; sp[i0 + 2] = g2; sp[i0 + 3] = g3; sp[i0 + 4] = g4; sp[i0 + 5] = g5; sp[i0 + 6] = g6; sp[i0 + 7] = g7;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { flag[k] = v[k]; v[k] = s8; s8 += flag[k]; }
+        inc = s8;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+        if (lane == 63) w_own[wave] = inc;
+    }
+    __syncthreads();
+    if (wave >= 4) return;
+    int ofs = 0;
+#pragma unroll
+    for (int w = 0; w < kScanFlagThreads / 64; w++) ofs += w_front[w];
+    const int front_total = ofs;
+    int tile_total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { const int t = w_own[w]; if (w < wave) ofs += t; tile_total += t; }
+    const int e0 = ofs + inc - s8;
+    if (i0 + 8 <= n) {
+        *reinterpret_cast<int4*>(out + i0) = make_int4(e0 + v[0], e0 + v[1], e0 + v[2], e0 + v[3]);
+        *reinterpret_cast<int4*>(out + i0 + 4) = make_int4(e0 + v[4], e0 + v[5], e0 + v[6], e0 + v[7]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (i0 + k < n) out[i0 + k] = e0 + v[k];
+    }
+    if (MODE != kScanKeep && A.head_pos) {      // (wave-uniform) compacted head positions, closed by the position where the voxels end: head_pos[number of voxels]
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (flag[k]) A.head_pos[e0 + v[k]] = i0 + k;
+            if (endm & (1u << k)) A.head_pos[e0 + v[k]] = i0 + k;      // (no head at or behind it: its prefix is the number of voxels)
+        }
+    }
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+        out[n] = front_total + tile_total;
+        if (MODE != kScanKeep && A.head_pos) {      // no item that is no voxel: the voxels end at n
+            bool none;
+            if (MODE == kScanHead64) none = static_cast<const unsigned long long*>(A.a)[n - 1] < ~0ull - 1ull;
+            else none = static_cast<const unsigned*>(A.a)[n - 1] != A.sentinel;
+            if (none) A.head_pos[front_total + tile_total] = n;
+        }
+    }
+}
+constexpr long long kScanFlagsMax = 65536;      // (beyond: flags in memory and the three-kernel scan)
+
 static int exclusive_scan(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const int* in, int64_t n, int* out /*[n+1]*/) {
     if (n <= 65536) {
         hipLaunchKernelGGL(k_scan_tiles, dim3(std::max(1, nblocks(n, kScanTile))), dim3(256), 0, ctx->stream, in, (int)n, out);
@@ -724,12 +964,18 @@ static int voxel_sort(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const float4*
 // the launches behind the sort: head flags (and the points in sorted order), their scan, the centroids
 static int voxel_filter_tail(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const float4* d_pts, int n, unsigned sentinel, bool alt) {
     DevBuf& out = alt ? V->qout : V->out; DevBuf& out_cnt = alt ? V->qout_cnt : V->out_cnt;
-    HIPCHK(V->flags.ensure((size_t)n * 4)); HIPCHK(V->slots.ensure(((size_t)n + 1) * 4)); HIPCHK(V->spts.ensure((size_t)n * 16));
+    HIPCHK(V->flags.ensure((size_t)n * 4)); HIPCHK(V->slots.ensure(((size_t)n + 1) * 4)); HIPCHK(V->spts.ensure((size_t)n * 16)); HIPCHK(V->head_pos.ensure(((size_t)n + 1) * 4));
     HIPCHK(out.ensure((size_t)n * 16)); HIPCHK(out_cnt.ensure((size_t)n * 4));
-    hipLaunchKernelGGL(k_vox_heads, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, V->keys_a.as<unsigned>(), V->vals_a.as<int>(), d_pts, n, sentinel, V->flags.as<int>(), V->spts.as<float4>());
-    const int rc = exclusive_scan(ctx, V, V->flags.as<int>(), n, V->slots.as<int>());
-    if (rc != LILI_OK) return rc;
-    hipLaunchKernelGGL(k_vox_centroid, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, V->keys_a.as<unsigned>(), V->slots.as<int>(), V->spts.as<float4>(), n, sentinel,
+    if (n <= kScanFlagsMax) {      // head flags, the points in sorted order and the scan in one launch
+        ScanFlagArgs A{}; A.a = V->keys_a.p; A.sentinel = sentinel; A.vals = V->vals_a.as<int>(); A.pts = d_pts; A.spts = V->spts.as<float4>(); A.head_pos = V->head_pos.as<int>();
+        hipLaunchKernelGGL(k_scan_flags<kScanHead32>, dim3(nblocks(n, kScanTile)), dim3(kScanFlagThreads), 0, ctx->stream, A, n, V->slots.as<int>());
+    } else {
+        hipLaunchKernelGGL(k_vox_heads, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, V->keys_a.as<unsigned>(), V->vals_a.as<int>(), d_pts, n, sentinel, V->flags.as<int>(), V->spts.as<float4>());
+        const int rc = exclusive_scan(ctx, V, V->flags.as<int>(), n, V->slots.as<int>());
+        if (rc != LILI_OK) return rc;
+        hipLaunchKernelGGL(k_vox_head_pos, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, V->flags.as<int>(), V->slots.as<int>(), (long long)n, V->head_pos.as<int>());
+    }
+    hipLaunchKernelGGL(k_vox_centroid, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, V->keys_a.as<unsigned>(), V->slots.as<int>(), V->head_pos.as<int>(), n <= kScanFlagsMax ? 1 : 0, V->spts.as<float4>(), n, sentinel,
                        out.as<float4>(), out_cnt.as<int>());
     HIPCHK(hipGetLastError());
     return LILI_OK;
@@ -898,8 +1144,12 @@ static int sorted_ring_step(lili_ctx* ctx, lili_detail::VoxelBuffers* V, lili_de
     int n_new = add ? add->n : 0;
     if (n_new > 0 && n_new <= kVoxSmallMax && ctx->voxel_small) {      // a frame's worth of features: one launch (k_sort_keyframe_small)
         HIPCHK(V->kf_key.ensure((size_t)n_new * 8)); HIPCHK(V->kf_pt.ensure((size_t)n_new * 16)); HIPCHK(V->flags.ensure((size_t)std::max<long long>(n_new, S.n) * 4));
-        hipLaunchKernelGGL(k_sort_keyframe_small, dim3(1), dim3(kVoxSmallThreads), 0, ctx->stream, add->pts.as<float4>(), n_new, 1.0f / leaf, add->seq, V->kf_pt.as<float4>(),
-                           V->kf_key.as<unsigned long long>(), V->flags.as<unsigned>(), d_bad);
+        // (`rank`: the scan-status words of a map build, idle during a commit; lili_localmap_commit zeroes them together with *bad)
+        int* d_rank = reinterpret_cast<int*>(ctx->misc.as<char>() + kRankOff);
+        const int slices = nblocks(n_new, 64);
+        hipLaunchKernelGGL(k_rank_count, dim3(slices, nblocks(slices, kRankWaves)), dim3(64 * kRankWaves), 0, ctx->stream, add->pts.as<float4>(), n_new, 1.0f / leaf, d_rank, d_bad);
+        hipLaunchKernelGGL(k_rank_scatter, dim3(nblocks(n_new, 256)), dim3(256), 0, ctx->stream, add->pts.as<float4>(), n_new, 1.0f / leaf, add->seq, (const int*)d_rank,
+                           V->kf_pt.as<float4>(), V->kf_key.as<unsigned long long>(), V->flags.as<unsigned>());
         HIPCHK(hipGetLastError());
     } else
     if (n_new > 0) {       // the new keyframe alone, sorted by voxel (stable): 20 k points, no host round trip (the bounding box stays on the device)
@@ -919,17 +1169,21 @@ static int sorted_ring_step(lili_ctx* ctx, lili_detail::VoxelBuffers* V, lili_de
     const int dst = 1 - S.cur;
     HIPCHK(S.key[dst].ensure((size_t)std::max<long long>(n_out, 1) * 8)); HIPCHK(S.pt[dst].ensure((size_t)std::max<long long>(n_out, 1) * 16)); HIPCHK(S.seq[dst].ensure((size_t)std::max<long long>(n_out, 1) * 4));
     HIPCHK(V->flags.ensure((size_t)std::max<long long>(n_old, 1) * 4)); HIPCHK(V->slots.ensure(((size_t)n_old + 1) * 4));
+    const bool fused_flags = n_old <= kScanFlagsMax;      // the scan derives the keep flags itself; the merge does too
     if (n_old > 0) {
-        hipLaunchKernelGGL(k_keep_flags, dim3(nblocks(n_old, 256)), dim3(256), 0, ctx->stream, S.seq[S.cur].as<unsigned>(), n_old, drop, V->flags.as<int>());
-        int rc = exclusive_scan(ctx, V, V->flags.as<int>(), n_old, V->slots.as<int>());
-        if (rc != LILI_OK) return rc;
-        hipLaunchKernelGGL(k_merge_old, dim3(nblocks(n_old, 256)), dim3(256), 0, ctx->stream, S.key[S.cur].as<unsigned long long>(), S.pt[S.cur].as<float4>(), S.seq[S.cur].as<unsigned>(),
-                           V->flags.as<int>(), V->slots.as<int>(), n_old, V->kf_key.as<unsigned long long>(), n_new, S.key[dst].as<unsigned long long>(), S.pt[dst].as<float4>(),
-                           S.seq[dst].as<unsigned>());
+        if (fused_flags) {
+            ScanFlagArgs A{}; A.a = S.seq[S.cur].p; A.drop = drop;
+            hipLaunchKernelGGL(k_scan_flags<kScanKeep>, dim3(nblocks(n_old, kScanTile)), dim3(kScanFlagThreads), 0, ctx->stream, A, (int)n_old, V->slots.as<int>());
+        } else {
+            hipLaunchKernelGGL(k_keep_flags, dim3(nblocks(n_old, 256)), dim3(256), 0, ctx->stream, S.seq[S.cur].as<unsigned>(), n_old, drop, V->flags.as<int>());
+            int rc = exclusive_scan(ctx, V, V->flags.as<int>(), n_old, V->slots.as<int>());
+            if (rc != LILI_OK) return rc;
+        }
     } else HIPCHK(hipMemsetAsync(V->slots.p, 0, 4, ctx->stream));
-    if (n_new > 0)
-        hipLaunchKernelGGL(k_merge_new, dim3(nblocks(n_new, 256)), dim3(256), 0, ctx->stream, V->kf_key.as<unsigned long long>(), V->kf_pt.as<float4>(), n_new, add->seq,
-                           S.key[S.cur].as<unsigned long long>(), V->slots.as<int>(), n_old, S.key[dst].as<unsigned long long>(), S.pt[dst].as<float4>(), S.seq[dst].as<unsigned>());
+    if (n_old + n_new > 0)
+        hipLaunchKernelGGL(k_merge, dim3(nblocks(n_old + n_new, 256)), dim3(256), 0, ctx->stream, S.key[S.cur].as<unsigned long long>(), S.pt[S.cur].as<float4>(), S.seq[S.cur].as<unsigned>(),
+                           fused_flags ? (const int*)nullptr : (const int*)V->flags.as<int>(), drop, (const int*)V->slots.as<int>(), n_old, V->kf_key.as<unsigned long long>(), V->kf_pt.as<float4>(),
+                           n_new, add ? add->seq : 0u, S.key[dst].as<unsigned long long>(), S.pt[dst].as<float4>(), S.seq[dst].as<unsigned>());
     HIPCHK(hipGetLastError());
     S.cur = dst; S.n = n_out;
     return LILI_OK;
@@ -967,10 +1221,13 @@ int lili_localmap_commit(lili_ctx* ctx, int kind, float leaf, double max_sq_radi
     bool have_box = false;
     if (inc) {
         // ---- incremental step(s): the merge, then the centroid pass over the sorted ring
-        HIPCHK(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+        HIPCHK(hipMemsetAsync(d_bad, 0, kRankOff - 256 + (size_t)kVoxSmallMax * 4, ctx->stream));      // *bad ... the rank words of k_rank_count: one fill
         int rc = LILI_OK;
         if (add.empty()) rc = sorted_ring_step(ctx, V, S, drop, n_drop, nullptr, leaf, d_bad);
-        for (size_t i = 0; i < add.size() && rc == LILI_OK; i++) rc = sorted_ring_step(ctx, V, S, i == 0 ? drop : DropSeqs{}, i == 0 ? n_drop : 0, add[i], leaf, d_bad);
+        for (size_t i = 0; i < add.size() && rc == LILI_OK; i++) {
+            if (i > 0) HIPCHK(hipMemsetAsync(ctx->misc.as<char>() + kRankOff, 0, (size_t)kVoxSmallMax * 4, ctx->stream));      // (a second pending keyframe counts from zero again)
+            rc = sorted_ring_step(ctx, V, S, i == 0 ? drop : DropSeqs{}, i == 0 ? n_drop : 0, add[i], leaf, d_bad);
+        }
         if (rc != LILI_OK) { S.valid = false; return rc; }
         S.members.clear();
         for (auto* k : ring) S.members.push_back({k->seq, k->n});
@@ -980,14 +1237,19 @@ int lili_localmap_commit(lili_ctx* ctx, int kind, float leaf, double max_sq_radi
         if (n > 0) {
             HIPCHK(V->flags.ensure((size_t)n * 4)); HIPCHK(V->slots.ensure(((size_t)n + 1) * 4));
             HIPCHK(V->out.ensure((size_t)n * 16)); HIPCHK(V->out_cnt.ensure((size_t)n * 4));
-            hipLaunchKernelGGL(k_vox_heads64, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, S.key[S.cur].as<unsigned long long>(), n, V->flags.as<int>());
-            rc = exclusive_scan(ctx, V, V->flags.as<int>(), n, V->slots.as<int>());
-            if (rc != LILI_OK) return rc;
-            HIPCHK(V->head_pos.ensure((size_t)n * 4));
-            hipLaunchKernelGGL(k_vox_head_pos, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, V->flags.as<int>(), V->slots.as<int>(), n, V->head_pos.as<int>());
+            HIPCHK(V->head_pos.ensure(((size_t)n + 1) * 4));
+            if (n <= kScanFlagsMax) {      // heads, their scan and the compaction of the heads' positions in one launch
+                ScanFlagArgs A{}; A.a = S.key[S.cur].p; A.head_pos = V->head_pos.as<int>();
+                hipLaunchKernelGGL(k_scan_flags<kScanHead64>, dim3(nblocks(n, kScanTile)), dim3(kScanFlagThreads), 0, ctx->stream, A, (int)n, V->slots.as<int>());
+            } else {
+                hipLaunchKernelGGL(k_vox_heads64, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, S.key[S.cur].as<unsigned long long>(), n, V->flags.as<int>());
+                rc = exclusive_scan(ctx, V, V->flags.as<int>(), n, V->slots.as<int>());
+                if (rc != LILI_OK) return rc;
+                hipLaunchKernelGGL(k_vox_head_pos, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, V->flags.as<int>(), V->slots.as<int>(), n, V->head_pos.as<int>());
+            }
             // one thread per voxel: the grid covers the upper bound (every point its own voxel), threads beyond the count on the device leave at once
             hipLaunchKernelGGL(k_vox_centroid64, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, S.key[S.cur].as<unsigned long long>(), S.pt[S.cur].as<float4>(), V->head_pos.as<int>(),
-                               (const int*)(V->slots.as<int>() + n), n, V->out.as<float4>(), V->out_cnt.as<int>());
+                               n <= kScanFlagsMax ? 1 : 0, (const int*)(V->slots.as<int>() + n), n, V->out.as<float4>(), V->out_cnt.as<int>());
             HIPCHK(hipGetLastError());
             rc = lili_readback_add(ctx, &V->n_out, V->slots.as<int>() + n, sizeof(int));
             // the bounding box of the centroids travels with their count: the index build below starts without a read-back of its own
