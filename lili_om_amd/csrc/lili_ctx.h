@@ -168,6 +168,7 @@ struct lili_ctx {
                                       // (front end) — two exchange hops through memory across the XCDs cost more than the launch boundaries they replace; off by default
     bool frontend_commit_pending = false;   // lili_frontend_frame: the ring has a keyframe the local map does not hold yet (the commit runs at the start of the next frame, under its extraction)
     bool voxel_guess_bits = true;      // a VoxelGrid of more than 8192 points keeps its bounding box on the device and guesses its key bits from the previous filter (k_vox_key_dev; 0: measured, A/B)
+    bool hook_box_words_zero = false;      // valid inside pre_sync_hook: the first words of ctx->misc are still zero from the build's scratch fill
     std::function<int()> pre_sync_hook;      // one-shot: called by the next map build right before its read-back synchronises, so that the caller's launches and read-backs share that synchronisation (lili_pipeline.hip)
     bool voxel_small = true;     // lili_voxel_filter / lili_frontend_frame: clouds of <= 8192 points are filtered by ONE single-workgroup launch (k_voxel_small; 0: the general chain, A/B)
     bool overlap_gn = false;     // lili_s2m_iterate*, three-launch path: the reduction + GN kernel publishes the pose as keyed granules and the next association is launched without a
@@ -220,7 +221,7 @@ lili::P2PView lili_p2p_next_view(lili_p2p* c);
 bool lili_p2p_usable(const lili_p2p* c, const lili_ctx* ctx);
 // lili_voxel.hip -> lili_pipeline.hip: the voxel filter and the keyframe ring on device clouds (no host copies, the pose read on the device)
 int lili_voxel_filter_dev(lili_ctx* ctx, const float4* d_pts, int n, float leaf, const float4** d_out, int* n_out);
-int lili_voxel_filter_dev_enqueue(lili_ctx* ctx, const float4* d_pts, int n, float leaf, bool* pending);
+int lili_voxel_filter_dev_enqueue(lili_ctx* ctx, const float4* d_pts, int n, float leaf, bool box_zeroed, bool* pending);
 int lili_voxel_filter_dev_complete(lili_ctx* ctx, const float4** d_out, int* n_out);
 int lili_localmap_push_dev(lili_ctx* ctx, int kind, const float4* d_pts, int n, const lili::SlotState* d_state, int width);
 int lili_localmap_ring_size(lili_ctx* ctx, int kind);

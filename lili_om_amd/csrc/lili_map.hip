@@ -229,6 +229,7 @@ static int map_set_impl(lili_ctx* ctx, int kind, const lili_cloud* cloud, double
             int rb = lili_readback_add(ctx, &back, ctx->misc.as<char>() + 8192, sizeof(back));
             // the caller's launches and read-backs that want to share this synchronisation (one shot; they must leave ctx->misc + 8192 onwards and the cloud alone)
             int hk = LILI_OK;
+            ctx->hook_box_words_zero = source != kBoxMeasure;      // the box banks at the head of ctx->misc: written only by a build that measures its box
             if (rb == LILI_OK && ctx->pre_sync_hook) { auto hook = std::move(ctx->pre_sync_hook); ctx->pre_sync_hook = nullptr; hk = hook(); }
             if (rb == LILI_OK) rb = lili_readback_finish(ctx);      // (also behind a failed hook: `back` must not stay on the pending list)
             if (hk != LILI_OK) return hk;

@@ -71,19 +71,20 @@ int lili_frontend_frame(lili_ctx* ctx, const lili_cloud* scan, int curvature_off
     lili_cloud d_edge{}, d_surf{};
     bool lists = false, filter_enqueued = false, filter_pending = false;
     // extraction's counts -> device lists -> query filter enqueued (no synchronisation of its own unless the counts have not come back yet)
+    bool in_hook = false;      // called from inside the index build: its scratch fill has just zeroed the filter's box words
     auto enqueue_query_filter = [&]() -> int {
         int r = lili_extract_livox_complete(ctx);
         if (r != LILI_OK) return r;
         r = lili_extract_livox_device(ctx, &d_edge, &d_surf);
         if (r != LILI_OK) return r;
         lists = true;
-        r = lili_voxel_filter_dev_enqueue(ctx, static_cast<const float4*>(d_surf.data), (int)d_surf.n, opt->leaf_query, &filter_pending);
+        r = lili_voxel_filter_dev_enqueue(ctx, static_cast<const float4*>(d_surf.data), (int)d_surf.n, opt->leaf_query, in_hook, &filter_pending);
         filter_enqueued = r == LILI_OK;
         return r;
     };
     int64_t n_raw = 0, n_map = 0;
     if (ctx->frontend_commit_pending && !self_map) {
-        ctx->pre_sync_hook = enqueue_query_filter;
+        ctx->pre_sync_hook = [&]() -> int { in_hook = ctx->hook_box_words_zero; const int r = enqueue_query_filter(); in_hook = false; return r; };
         rc = lili_localmap_commit(ctx, LILI_KIND_SURF, opt->leaf_map, match->kd_max_radius, &n_raw, &n_map);
         ctx->pre_sync_hook = nullptr;      // (a commit that built no index has not called it)
         if (rc != LILI_OK) return rc;

@@ -177,20 +177,48 @@ __global__ void k_vox_key(const float4* __restrict__ pts, int n, VoxDev V, unsig
     int i2 = (int)(floorf(p.z * V.inv_leaf) - (float)V.min_b[2]);
     keys[i] = (unsigned)(i0 * V.mul[0] + i1 * V.mul[1] + i2 * V.mul[2]);
 }
+// k_bbox into words that start from ZERO (words 0-2: ~ordered(min), 3-5: ordered(max), all maximised): a caller whose scratch has just been cleared by a fill it needs
+// anyway saves the launch that arms the box (k_box_init)
+__global__ __launch_bounds__(256) void k_bbox_z(const float4* __restrict__ pts, int n, unsigned* __restrict__ mmz) {
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 p = pts[i];
+        if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+            mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+            mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        for (int o = 32; o > 0; o >>= 1) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], o)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o)); }
+    __shared__ float smn[4][3], smx[4][3];
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { smn[threadIdx.x >> 6][k] = mn[k]; smx[threadIdx.x >> 6][k] = mx[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        float a = smn[0][k], b = smx[0][k];
+        for (int w = 1; w < 4; w++) { a = fminf(a, smn[w][k]); b = fmaxf(b, smx[w][k]); }
+        auto ord = [](float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
+        if (a <= b) { atomicMax(&mmz[k], ~ord(a)); atomicMax(&mmz[3 + k], ord(b)); }
+    }
+}
 // k_vox_key with the bounding box read where k_bbox left it (ordered-uint words `mm`) — no host round trip before the sort (round 5).  The host does not know the
 // box, so it cannot know how many key bits the sort has to cover: it GUESSES them (`bits_guess`: what the previous filter of this leaf size needed, rounded up to whole
 // radix passes) and every thread checks the guess against the box it finds; res[0] = 0 (the keys fit), 1 (they do not: the caller repeats the filter the measured way),
 // 2 (no finite point), 3 (PCL's int32 voxel-index overflow) and res[1] = the bits the keys need come back with the filter's voxel count.  Same arithmetic as the host
 // code of voxel_sort + k_vox_key; non-finite points get the key 2^bits_guess - 1, above every voxel index.
-__global__ void k_vox_key_dev(const float4* __restrict__ pts, int n, float inv_leaf, const unsigned* __restrict__ mm, int bits_guess, unsigned* __restrict__ keys,
-                              int* __restrict__ vals, int* __restrict__ res) {
+__global__ void k_vox_key_dev(const float4* __restrict__ pts, int n, float inv_leaf, const unsigned* __restrict__ mm, int zform /*1: the minima are stored inverted (k_bbox_z)*/,
+                              int bits_guess, unsigned* __restrict__ keys, int* __restrict__ vals, int* __restrict__ res) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     auto dec = [](unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); };
     int min_b[3], div_b[3];
     bool any = true;
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        const float mn = dec(mm[k]), mx = dec(mm[3 + k]);
+        const float mn = dec(zform ? ~mm[k] : mm[k]), mx = dec(mm[3 + k]);
         if (!(mn <= mx)) any = false;
         min_b[k] = (int)floorf(mn * inv_leaf);
         div_b[k] = (int)floorf(mx * inv_leaf) - min_b[k] + 1;
@@ -586,28 +614,43 @@ __global__ void k_vox_head_pos(const int* __restrict__ flags, const int* __restr
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && flags[i]) head_pos[slot[i]] = (int)i;
 }
+__device__ __forceinline__ unsigned f2ord_v(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }      // order-preserving float -> uint (as lili_s2m.hip)
+// `boxz` (may be null): bounding box of the centroids in the ZERO-INITIALISED form — words 0-2 hold ~ordered(min), words 3-5 ordered(max), all six maximised from zero —
+// so that the fill that arms the commit's other scratch words arms it too (round 5: k_box_init + k_bbox_dev were two launches of the frame pipeline's commit)
 __global__ void k_vox_centroid64(const unsigned long long* __restrict__ keys, const float4* __restrict__ pts, const int* __restrict__ head_pos /*[n_out] = where the voxels end if has_end*/,
-                                 int has_end, const int* __restrict__ n_out_p, long long n, float4* __restrict__ out, int* __restrict__ out_cnt) {
+                                 int has_end, const int* __restrict__ n_out_p, long long n, float4* __restrict__ out, int* __restrict__ out_cnt, unsigned* __restrict__ boxz) {
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
     const int n_out = *n_out_p;
-    if (o >= n_out) return;
-    const long long i = head_pos[o];
-    // the voxel's members are [i, end): up to the next voxel's head; the last voxel ends where the keys stop being voxels (non-finite points sort last)
-    long long end;
-    if (has_end || o + 1 < n_out) end = head_pos[o + 1];
-    else { const unsigned long long k = keys[i]; end = i + 1; while (end < n && keys[end] == k) end++; }
-    // sequential f32 sums in list order (CentroidPoint); the member count is known, so the loads of a trip do not wait for a key comparison
-    float sx = 0.f, sy = 0.f, sz = 0.f, sa = 0.f;
-    for (long long m = i; m < end; m += 8) {
-        float4 pp[8];
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (o < n_out) {
+        const long long i = head_pos[o];
+        // the voxel's members are [i, end): up to the next voxel's head; the last voxel ends where the keys stop being voxels (non-finite points sort last)
+        long long end;
+        if (has_end || o + 1 < n_out) end = head_pos[o + 1];
+        else { const unsigned long long k = keys[i]; end = i + 1; while (end < n && keys[end] == k) end++; }
+        // sequential f32 sums in list order (CentroidPoint); the member count is known, so the loads of a trip do not wait for a key comparison
+        float sx = 0.f, sy = 0.f, sz = 0.f, sa = 0.f;
+        for (long long m = i; m < end; m += 8) {
+            float4 pp[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) pp[u] = pts[m + u < end ? m + u : end - 1];
+            for (int u = 0; u < 8; u++) pp[u] = pts[m + u < end ? m + u : end - 1];
 #pragma unroll
-        for (int u = 0; u < 8; u++) if (m + u < end) { sx += pp[u].x; sy += pp[u].y; sz += pp[u].z; sa += pp[u].w; }
+            for (int u = 0; u < 8; u++) if (m + u < end) { sx += pp[u].x; sy += pp[u].y; sz += pp[u].z; sa += pp[u].w; }
+        }
+        const float fn = (float)(int)(end - i);
+        const float4 c = make_float4(sx / fn, sy / fn, sz / fn, sa / fn);
+        out[o] = c;
+        if (out_cnt) out_cnt[o] = (int)(end - i);
+        if (isfinite(c.x) && isfinite(c.y) && isfinite(c.z)) { mn[0] = mx[0] = c.x; mn[1] = mx[1] = c.y; mn[2] = mx[2] = c.z; }
     }
-    const float fn = (float)(int)(end - i);
-    out[o] = make_float4(sx / fn, sy / fn, sz / fn, sa / fn);
-    if (out_cnt) out_cnt[o] = (int)(end - i);
+    if (!boxz) return;
+    if (__ballot(o < n_out) == 0ull) return;
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        for (int s = 32; s > 0; s >>= 1) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], s)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], s)); }
+    const int lane = threadIdx.x & 63;      // six atomics per wave (~100 waves on the ring map of a Livox sequence; same-address atomics take ~12 ns each)
+    if (lane < 3) { if (mn[lane] <= mx[lane]) atomicMax(&boxz[lane], ~f2ord_v(mn[lane])); }
+    else if (lane < 6) { if (mn[lane - 3] <= mx[lane - 3]) atomicMax(&boxz[lane], f2ord_v(mx[lane - 3])); }
 }
 
 // transformCloud — L/src/BackendFusion.cpp:713-790: p' = q * p + t in f64, stored f32; aux carried along
@@ -1001,7 +1044,7 @@ static int voxel_filter_measured(lili_ctx* ctx, lili_detail::VoxelBuffers* V, co
 //   else nothing is enqueued and _complete runs the measured filter.
 // Result in V->out / V->out_cnt / V->n_out, or in V->qout / V->qout_cnt / V->qn_out (`alt`).
 enum { kPendDone = 0, kPendMeasure = 1, kPendSmall = 2, kPendGuess = 3 };
-static int voxel_filter_enqueue(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const float4* d_pts, int n, float leaf, bool need_order, bool alt) {
+static int voxel_filter_enqueue(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const float4* d_pts, int n, float leaf, bool need_order, bool alt, bool box_zeroed = false) {
     auto& Q = V->pend;
     Q = lili_detail::VoxelBuffers::Pending{};
     Q.d_pts = d_pts; Q.n = n; Q.leaf = leaf; Q.need_order = need_order; Q.alt = alt;
@@ -1018,11 +1061,15 @@ static int voxel_filter_enqueue(lili_ctx* ctx, lili_detail::VoxelBuffers* V, con
     }
     if (ctx->voxel_guess_bits && V->bits_guess > 0 && V->guess_leaf == leaf) {
         unsigned* d_mm = ctx->misc.as<unsigned>();
-        hipLaunchKernelGGL(k_box_init, dim3(1), dim3(64), 0, ctx->stream, d_mm);
-        hipLaunchKernelGGL(k_bbox, dim3(std::min(nblocks(n, kBlock), 512)), dim3(kBlock), 0, ctx->stream, d_pts, n, d_mm);
+        // (box_zeroed: the caller vouches that the first six words of ctx->misc are zero — the frame pipeline enqueues this behind an index build's scratch fill)
+        if (box_zeroed) hipLaunchKernelGGL(k_bbox_z, dim3(std::min(nblocks(n, 256), 512)), dim3(256), 0, ctx->stream, d_pts, n, d_mm);
+        else {
+            hipLaunchKernelGGL(k_box_init, dim3(1), dim3(64), 0, ctx->stream, d_mm);
+            hipLaunchKernelGGL(k_bbox, dim3(std::min(nblocks(n, kBlock), 512)), dim3(kBlock), 0, ctx->stream, d_pts, n, d_mm);
+        }
         HIPCHK(V->keys_a.ensure((size_t)n * 4)); HIPCHK(V->vals_a.ensure((size_t)n * 4));
         const int bits = V->bits_guess;
-        hipLaunchKernelGGL(k_vox_key_dev, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, d_pts, n, 1.0f / leaf, (const unsigned*)d_mm, bits, V->keys_a.as<unsigned>(),
+        hipLaunchKernelGGL(k_vox_key_dev, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, d_pts, n, 1.0f / leaf, (const unsigned*)d_mm, box_zeroed ? 1 : 0, bits, V->keys_a.as<unsigned>(),
                            V->vals_a.as<int>(), d_res);
         int rc = radix_sort(ctx, V, n, bits);
         if (rc != LILI_OK) return rc;
@@ -1248,23 +1295,17 @@ int lili_localmap_commit(lili_ctx* ctx, int kind, float leaf, double max_sq_radi
                 hipLaunchKernelGGL(k_vox_head_pos, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, V->flags.as<int>(), V->slots.as<int>(), n, V->head_pos.as<int>());
             }
             // one thread per voxel: the grid covers the upper bound (every point its own voxel), threads beyond the count on the device leave at once
+            // the bounding box of the centroids falls out of the centroid pass and travels with their count: the index build below starts without a read-back of its own
+            unsigned* d_box = reinterpret_cast<unsigned*>(ctx->misc.as<char>() + 512);      // (zeroed with *bad above)
             hipLaunchKernelGGL(k_vox_centroid64, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, S.key[S.cur].as<unsigned long long>(), S.pt[S.cur].as<float4>(), V->head_pos.as<int>(),
-                               n <= kScanFlagsMax ? 1 : 0, (const int*)(V->slots.as<int>() + n), n, V->out.as<float4>(), V->out_cnt.as<int>());
+                               n <= kScanFlagsMax ? 1 : 0, (const int*)(V->slots.as<int>() + n), n, V->out.as<float4>(), V->out_cnt.as<int>(), d_box);
             HIPCHK(hipGetLastError());
             rc = lili_readback_add(ctx, &V->n_out, V->slots.as<int>() + n, sizeof(int));
-            // the bounding box of the centroids travels with their count: the index build below starts without a read-back of its own
-            if (rc == LILI_OK) {
-                        unsigned* d_box = reinterpret_cast<unsigned*>(ctx->misc.as<char>() + 512);
-                hipLaunchKernelGGL(k_box_init, dim3(1), dim3(64), 0, ctx->stream, d_box);
-                hipLaunchKernelGGL(k_bbox_dev, dim3((unsigned)std::min<long long>(nblocks(n, kBlock), 128)), dim3(kBlock), 0, ctx->stream, V->out.as<float4>(),
-                                   (const int*)(V->slots.as<int>() + n), (int)n, d_box);
-                HIPCHK(hipGetLastError());
-                rc = lili_readback_add(ctx, V->out_box, d_box, sizeof(V->out_box));
-                have_box = rc == LILI_OK;
-            }
+            if (rc == LILI_OK) { rc = lili_readback_add(ctx, V->out_box, d_box, sizeof(V->out_box)); have_box = rc == LILI_OK; }
         }
         if (rc == LILI_OK) rc = lili_readback_add(ctx, &bad, d_bad, 4);
         { const int rb = lili_readback_finish(ctx); if (rc != LILI_OK) return rc; if (rb != LILI_OK) return rb; }
+        if (have_box) for (int k = 0; k < 3; k++) V->out_box[k] = ~V->out_box[k];      // (the minima travel inverted: see k_vox_centroid64)
         if (bad) { S.valid = false; inc = false; have_box = false; }      // a point beyond the absolute key range: the box-relative rebuild below handles it
         else {
             // The guards of the full rebuild (voxel_sort: "no finite point", PCL's int32 voxel-index overflow) apply to the same ring content whichever
@@ -1386,9 +1427,9 @@ int lili_voxel_filter_dev(lili_ctx* ctx, const float4* d_pts, int n, float leaf,
 }
 // the same in two halves, into the filter's SECOND output buffer (so that it may be enqueued while the first still holds a local map that is being indexed):
 // _enqueue never blocks; *pending = a read-back has joined the context's list and wants a lili_readback_finish before _complete
-int lili_voxel_filter_dev_enqueue(lili_ctx* ctx, const float4* d_pts, int n, float leaf, bool* pending) {
+int lili_voxel_filter_dev_enqueue(lili_ctx* ctx, const float4* d_pts, int n, float leaf, bool box_zeroed, bool* pending) {
     auto* V = vox_of(ctx);
-    const int rc = voxel_filter_enqueue(ctx, V, d_pts, n, leaf, false, true);
+    const int rc = voxel_filter_enqueue(ctx, V, d_pts, n, leaf, false, true, box_zeroed);
     if (pending) *pending = V->pend.mode == kPendSmall || V->pend.mode == kPendGuess;
     return rc;
 }
