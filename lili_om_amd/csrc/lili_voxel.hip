@@ -614,6 +614,7 @@ __global__ void k_vox_head_pos(const int* __restrict__ flags, const int* __restr
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && flags[i]) head_pos[slot[i]] = (int)i;
 }
+constexpr int kBoxBanks = 32;      // x 128 bytes
 __device__ __forceinline__ unsigned f2ord_v(float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }      // order-preserving float -> uint (as lili_s2m.hip)
 // `boxz` (may be null): bounding box of the centroids in the ZERO-INITIALISED form — words 0-2 hold ~ordered(min), words 3-5 ordered(max), all six maximised from zero —
 // so that the fill that arms the commit's other scratch words arms it too (round 5: k_box_init + k_bbox_dev were two launches of the frame pipeline's commit)
@@ -644,13 +645,25 @@ __global__ void k_vox_centroid64(const unsigned long long* __restrict__ keys, co
         if (isfinite(c.x) && isfinite(c.y) && isfinite(c.z)) { mn[0] = mx[0] = c.x; mn[1] = mx[1] = c.y; mn[2] = mx[2] = c.z; }
     }
     if (!boxz) return;
-    if (__ballot(o < n_out) == 0ull) return;
+    // one set of six atomics per WORKGROUP, spread over kBoxBanks banks of 128 bytes (same-address atomics serialise at 12-20 ns each: one set per wave into one
+    // bank made this launch 4.7 -> 13.7 us on a frame's ring map and 5 -> 52 us on the back end's 152 k-voxel map); the host folds the banks
+    __shared__ float smn[4][3], smx[4][3];
 #pragma unroll
     for (int k = 0; k < 3; k++)
         for (int s = 32; s > 0; s >>= 1) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], s)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], s)); }
-    const int lane = threadIdx.x & 63;      // six atomics per wave (~100 waves on the ring map of a Livox sequence; same-address atomics take ~12 ns each)
-    if (lane < 3) { if (mn[lane] <= mx[lane]) atomicMax(&boxz[lane], ~f2ord_v(mn[lane])); }
-    else if (lane < 6) { if (mn[lane - 3] <= mx[lane - 3]) atomicMax(&boxz[lane], f2ord_v(mx[lane - 3])); }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { smn[wave][k] = mn[k]; smx[wave][k] = mx[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        float a = smn[0][k], b = smx[0][k];
+        for (int w = 1; w < 4; w++) { a = fminf(a, smn[w][k]); b = fmaxf(b, smx[w][k]); }
+        unsigned* bank = boxz + (blockIdx.x % kBoxBanks) * 32;
+        if (a <= b) { atomicMax(&bank[k], ~f2ord_v(a)); atomicMax(&bank[3 + k], f2ord_v(b)); }
+    }
 }
 
 // transformCloud — L/src/BackendFusion.cpp:713-790: p' = q * p + t in f64, stored f32; aux carried along
@@ -1281,6 +1294,8 @@ int lili_localmap_commit(lili_ctx* ctx, int kind, float leaf, double max_sq_radi
         const long long n = S.n;
         V->n_out = 0;
         unsigned bad = 0;
+        static_assert(2048 + kBoxBanks * 128 <= 8192, "box banks of the commit inside the first 8 KB of ctx->misc");
+        unsigned box_banks[kBoxBanks * 32];
         if (n > 0) {
             HIPCHK(V->flags.ensure((size_t)n * 4)); HIPCHK(V->slots.ensure(((size_t)n + 1) * 4));
             HIPCHK(V->out.ensure((size_t)n * 16)); HIPCHK(V->out_cnt.ensure((size_t)n * 4));
@@ -1296,16 +1311,20 @@ int lili_localmap_commit(lili_ctx* ctx, int kind, float leaf, double max_sq_radi
             }
             // one thread per voxel: the grid covers the upper bound (every point its own voxel), threads beyond the count on the device leave at once
             // the bounding box of the centroids falls out of the centroid pass and travels with their count: the index build below starts without a read-back of its own
-            unsigned* d_box = reinterpret_cast<unsigned*>(ctx->misc.as<char>() + 512);      // (zeroed with *bad above)
+            unsigned* d_box = reinterpret_cast<unsigned*>(ctx->misc.as<char>() + 2048);      // (kBoxBanks x 128 bytes, zeroed with *bad above)
             hipLaunchKernelGGL(k_vox_centroid64, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, S.key[S.cur].as<unsigned long long>(), S.pt[S.cur].as<float4>(), V->head_pos.as<int>(),
                                n <= kScanFlagsMax ? 1 : 0, (const int*)(V->slots.as<int>() + n), n, V->out.as<float4>(), V->out_cnt.as<int>(), d_box);
             HIPCHK(hipGetLastError());
             rc = lili_readback_add(ctx, &V->n_out, V->slots.as<int>() + n, sizeof(int));
-            if (rc == LILI_OK) { rc = lili_readback_add(ctx, V->out_box, d_box, sizeof(V->out_box)); have_box = rc == LILI_OK; }
+            if (rc == LILI_OK) { rc = lili_readback_add(ctx, box_banks, d_box, sizeof(box_banks)); have_box = rc == LILI_OK; }
         }
         if (rc == LILI_OK) rc = lili_readback_add(ctx, &bad, d_bad, 4);
         { const int rb = lili_readback_finish(ctx); if (rc != LILI_OK) return rc; if (rb != LILI_OK) return rb; }
-        if (have_box) for (int k = 0; k < 3; k++) V->out_box[k] = ~V->out_box[k];      // (the minima travel inverted: see k_vox_centroid64)
+        if (have_box) {      // fold the banks; the minima travel inverted (k_vox_centroid64)
+            unsigned w[6] = {0, 0, 0, 0, 0, 0};
+            for (int b = 0; b < kBoxBanks; b++) for (int k = 0; k < 6; k++) w[k] = std::max(w[k], box_banks[b * 32 + k]);
+            for (int k = 0; k < 3; k++) { V->out_box[k] = ~w[k]; V->out_box[3 + k] = w[3 + k]; }
+        }
         if (bad) { S.valid = false; inc = false; have_box = false; }      // a point beyond the absolute key range: the box-relative rebuild below handles it
         else {
             // The guards of the full rebuild (voxel_sort: "no finite point", PCL's int32 voxel-index overflow) apply to the same ring content whichever
