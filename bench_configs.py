@@ -231,16 +231,22 @@ def config1(L, ctx, torch, synth, n_frames=100, cpu=True):
     torch.cuda.synchronize()
     sec_staged = (time.perf_counter() - tic) / n_frames
     run()
-    torch.cuda.synchronize()
-    tic = time.perf_counter()
-    poses, nq = run()
-    torch.cuda.synchronize()
-    sec = (time.perf_counter() - tic) / n_frames
+    passes, in_call = [], []
+    for _ in range(3):      # three timed passes over the sequence; the median is reported, all three are listed
+        torch.cuda.synchronize()
+        tic = time.perf_counter()
+        poses, nq = run()
+        torch.cuda.synchronize()
+        passes.append((time.perf_counter() - tic) / n_frames)
+        in_call.append(float(stage_acc.sum()) / n_frames * 1e-6)      # the C call's own clock: begin -> pose known (what a C++ caller pays per frame)
+    sec = float(np.median(passes))
     fused_equals_staged = all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(poses, poses_staged))
     err = [float(np.linalg.norm(p[0] - _circuit(f)[0])) for f, p in enumerate(poses)]
     n_pts = int(np.mean([fr.shape[0] for fr in frames]))
     alg = 48 * n_pts + 48 * 24000 + 6 * (96 + 41) * int(np.mean(nq))
     out = {"value": round(1.0 / sec, 1), "unit": "frames/s", "ms_per_frame": round(sec * 1e3, 4), "frames": n_frames, "gn_status": worst[0],
+           "passes_ms_per_frame": [round(x * 1e3, 4) for x in passes], "inside_the_call_ms_per_frame": round(float(np.median(in_call)) * 1e3, 4),
+           "cpp_loop": _cpp_frame_loop(frames, _circuit(0)[:2]),
            "staged_calls_ms_per_frame": round(sec_staged * 1e3, 4), "fused_call_poses_equal_staged_calls_bit_for_bit": bool(fused_equals_staged),
            "stage_us_per_frame": {k: round(float(v) / n_frames, 1) for k, v in zip(("extraction_enqueued_pending_local_map_built_query_filter_enqueued_behind_its_index", "query_filter_outcome", "queries_pose_iterations_enqueued", "ring_push_and_pose_read_back"), stage_acc)},
            "workload": f"configs[1] substitute (no FR_IOSB bag offline): {n_frames} synthetic Livox-Horizon frames (~{n_pts} points, 6 lines) on a circuit, ONE lili_frontend_frame call per frame "
@@ -411,6 +417,35 @@ def config4(L, ctx, torch, synth, cpu=True):
         except Exception as e:      # noqa: BLE001
             out["cpu"] = {"error": repr(e)}
     return out
+
+
+def _cpp_frame_loop(frames, first_pose):
+    """configs[1]'s sequence through examples/frontend_demo: the frame loop of a merged Preprocessing + LidarOdometry nodelet in plain C++ on the C ABI (pose prediction in
+    Eigen's operation order, no interpreter between the frames).  Its own process and context; first repetition untimed, three timed."""
+    import os, struct, subprocess, tempfile
+    demo = os.path.join(os.path.dirname(os.path.abspath(__file__)), "examples", "frontend_demo")
+    if not os.path.exists(demo):
+        return {"error": "examples/frontend_demo not built"}
+    try:
+        with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+            f.write(struct.pack("<ii", len(frames), 0))      # 0: not the reference node's start-up (the first pose is given, frame 1 is matched against frame 0's map)
+            for fr in frames:
+                fr = np.ascontiguousarray(fr, "<f4")
+                f.write(struct.pack("<i", fr.shape[0]))
+                f.write(np.asarray(first_pose[0], "<f8").tobytes()); f.write(np.asarray(first_pose[1], "<f8").tobytes())
+                f.write(fr.tobytes())
+            path = f.name
+        r = subprocess.run([demo, path, "4"], capture_output=True, text=True, timeout=300)
+        os.unlink(path)
+        if r.returncode != 0:
+            return {"error": f"rc {r.returncode}: {r.stderr[-300:]} {r.stdout[-300:]}"}
+        ms = [float(l.split()[1]) for l in r.stdout.splitlines() if l.startswith("ms_per_frame")]
+        rows = [l.split() for l in r.stdout.splitlines() if l.startswith("frame ")]
+        err = [float(np.linalg.norm(np.array([float(v) for v in tok[3:6]]) - _circuit(k)[0])) for k, tok in enumerate(rows)]
+        return {"ms_per_frame": ms[-1], "frames": len(rows), "repetitions_timed": 3, "ate_rms_m": round(float(np.sqrt(np.mean(np.square(err)))), 4),
+                "worst_gn_status": max(int(tok[11]) for tok in rows), "what": "examples/frontend_demo.cpp on the same frames: one lili_frontend_frame call per frame from C++"}
+    except Exception as e:      # noqa: BLE001
+        return {"error": repr(e)}
 
 
 def _cpp_window_seam(L, room, K):

@@ -118,7 +118,7 @@ int lili_frontend_frame(lili_ctx* ctx, const lili_cloud* scan, int curvature_off
         if (rc != LILI_OK) return rc;
     }
     const lili_cloud qc{d_q, (size_t)n_q, 16, 12, LILI_MEM_DEVICE};
-    rc = lili_s2m_set_queries(ctx, slot, LILI_KIND_SURF, &qc);      // device-to-device: the filter's buffer is reused by the map commit below
+    rc = lili_s2m_set_queries(ctx, slot, LILI_KIND_SURF, &qc);      // device-to-device copy into the slot (the filter's second output is rewritten by the next frame's filter)
     if (rc != LILI_OK) return rc;
     PoseVal pv{};
     for (int i = 0; i < 3; i++) pv.v[i] = t_pred[i];
@@ -134,16 +134,17 @@ int lili_frontend_frame(lili_ctx* ctx, const lili_cloud* scan, int curvature_off
     }
     res->matched = matched ? 1 : 0;
     stamp(2);
-    // ---- the frame joins the ring at the pose the iterations reached (read by the kernel from the slot's device state); the local map with it is built at the start of
-    //      the next frame (or by lili_frontend_flush).  ONE synchronisation: the pose.
-    rc = lili_localmap_push_dev(ctx, LILI_KIND_SURF, ctx->slots[slot].k[LILI_KIND_SURF].q.as<float4>(), (opt->flags & LILI_FRAME_PUSH_EMPTY) ? 0 : n_q, ctx->state(slot), opt->width);
-    if (rc != LILI_OK) return rc;
+    // ---- ONE synchronisation: the pose.  The frame then joins the ring at that pose (read by the push kernel from the slot's device state) BEHIND the read-back — the
+    //      caller has its pose while the push is still on the stream; the local map with the new keyframe is built at the start of the next frame (or by
+    //      lili_frontend_flush).
     SlotState st{};
     rc = lili_readback_add(ctx, &st, ctx->state(slot), sizeof(st));
     if (rc != LILI_OK) return rc;
-    ctx->frontend_commit_pending = true;
     rc = lili_readback_finish(ctx);
     if (rc != LILI_OK) return rc;
+    rc = lili_localmap_push_dev(ctx, LILI_KIND_SURF, ctx->slots[slot].k[LILI_KIND_SURF].q.as<float4>(), (opt->flags & LILI_FRAME_PUSH_EMPTY) ? 0 : n_q, ctx->state(slot), opt->width);
+    if (rc != LILI_OK) return rc;
+    ctx->frontend_commit_pending = true;
     stamp(3);
     for (int i = 0; i < 3; i++) res->t[i] = st.pose[i];
     for (int i = 0; i < 4; i++) res->q[i] = st.pose[3 + i];
