@@ -1,11 +1,11 @@
 #!/usr/bin/env python
-"""Re-flows a markdown file to 150 characters (<= 160 bytes per line with the usual share of multi-byte signs): paragraphs and list items are joined and wrapped with a hanging indent, tables whose rows would be longer than the limit
+"""Re-flows a markdown file to 146 characters (<= 160 bytes per line with the usual share of multi-byte signs): paragraphs and list items are joined and wrapped with a hanging indent, tables whose rows would be longer than the limit
 become bullet lines ("* cell — cell — cell"), headings / fenced code / short tables are left alone.  usage: python tools/wrap_md.py FILE [...]"""
 import re
 import sys
 import textwrap
 
-LIMIT = 150
+LIMIT = 146
 ITEM = re.compile(r"^(\s*)([*-]|\d+\.)\s+")
 
 
