@@ -149,6 +149,63 @@ def test_frontend_frame_equals_the_chain_of_separate_calls(pinned):
         ctx.close()
 
 
+def test_frontend_frame_survives_small_featureless_and_stretched_frames():
+    """The frame call's deferred stages on inputs that leave the steady state: a SMALL frame (its surf features go through the one-workgroup filter, enqueued behind the
+    index build like the general chain), a frame WITHOUT features (no queries: not matched, the pose is the prediction, an empty keyframe joins the ring), a frame
+    with three times the ranges (another bounding box and voxel count than the guess was made from; the range gate keeps a Livox frame within the guessed 24 key bits,
+    so the guess holds — the miss itself is tests/test_voxel_gpu.py's).  Wherever the chain of separate calls is defined the fused call equals it bit for bit; the
+    sequence goes on afterwards."""
+    def scan(f, **kw):
+        return synth.make_livox_scan(100 + f, origin=_circuit(f)[0], yaw=_circuit(f)[2], inject_bad=False, **kw)
+    frames = [scan(f) for f in range(9)]
+    frames[3] = np.ascontiguousarray(frames[3][:6000])                     # a quarter of the sweep: a few thousand features at most
+    frames[5] = np.ascontiguousarray(frames[5][:40])                       # 40 points of one line: no block reaches 25 valid cells
+    wide = frames[7].copy(); wide[:, :3] *= 3.0; frames[7] = wide          # same directions, three times the ranges
+    ctx = L.Context(0)
+    try:
+        P = L.make_params("frontend")
+        ex = L.LivoxExtractor(ctx)
+        m = L.ScanToMapMatcher(ctx, P)
+        local = L.api.LocalMap(ctx, L.KIND_SURF, 5, 0.4, P.kd_max_radius)
+        staged, nq_staged = [], []
+        for f in range(len(frames)):
+            feats = ex.extract(frames[f])
+            surf = np.ascontiguousarray(feats["surf"][:, [0, 1, 2, 7]])
+            qry = L.api.voxel_filter(ctx, surf, 0.4)[0] if surf.shape[0] else np.zeros((0, 4), np.float32)
+            if f == 0:
+                t, q = _circuit(0)[:2]
+            else:
+                t0, q0 = _predict(staged)
+                local.commit()
+                if qry.shape[0]:
+                    m.set_queries(0, L.KIND_SURF, qry)
+                    m.pose_set(0, t0, q0)
+                    m.iterate(0, 12 if f == 1 else 6, L.MASK_SURF)
+                    t, q, st = m.pose_get(0)
+                    if q[0] < 0:
+                        q = -q
+                else:
+                    t, q = t0, q0                                           # (updateTransformationWithCeres returns before it touches the pose)
+            staged.append((np.asarray(t, np.float64), np.asarray(q, np.float64)))
+            nq_staged.append(qry.shape[0])
+            local.push(qry, t, q)
+        assert nq_staged[5] == 0 and 0 < nq_staged[3] < nq_staged[2]
+        guesses0 = L.api.voxel_filter_stats(ctx)[0]
+        odo = L.FrontendOdometry(ctx, P, width=5, scan_match_cnt=6, first_match_cnt=12, reference_startup=False)
+        odo.reset()
+        fused = []
+        for f in range(len(frames)):
+            t0, q0 = _circuit(0)[:2] if f == 0 else _predict(fused)
+            t, q, info = odo.frame(frames[f], t0, q0)
+            assert info["n_query"] == nq_staged[f] and info["matched"] == (f > 0 and nq_staged[f] > 0), (f, info)
+            fused.append((t, q))
+        assert L.api.voxel_filter_stats(ctx)[0] > guesses0          # the filters of the large frames kept their boxes on the device
+        for f, (a, b) in enumerate(zip(fused, staged)):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (f, a, b)
+    finally:
+        ctx.close()
+
+
 def test_frontend_frame_rejects_bad_arguments(gpu_ctx):
     odo = L.FrontendOdometry(gpu_ctx)
     scan = synth.make_livox_scan(5, inject_bad=False)
