@@ -849,10 +849,6 @@ template <int MODE> __device__ __forceinline__ void scan_flags_eval(const ScanFl
             for (int k = 0; k < 4; k++) if (i + k < n && kk[k + 1] == A.sentinel && (i + k == 0 || kk[k] != A.sentinel)) *endm |= 1u << k; }
     }
 }
-template <int MODE> __device__ __forceinline__ void scan_flags4(const ScanFlagArgs& A, int i /*multiple of 4*/, int n, int v[4]) {
-    const ScanRaw r = scan_flags_load<MODE>(A, i);
-    scan_flags_eval<MODE>(A, r, i, n, v);
-}
 // 1024 threads: the items in FRONT of the tile are read by sixteen waves in one batch of loads per lane (two for the 64-bit keys of a 40 k ring) — the launch lasts as
 // long as its last tile's chain of dependent round trips, ~2 us each on data another launch has just written; with 256 threads and one group in flight it was 39 of them.
 // The tile's own 2048 items belong to the first four waves, eight per lane.
