@@ -144,7 +144,7 @@ __device__ __forceinline__ double bcast_f64(double v, int src) {
 // owns cell (line k, column i + j) — the order in which the reference visits the 36 cells (L:271-296: j outer, k inner) — so all
 // loads are one round trip.  The f64 sums keep the reference's ORDER: every lane forms its own term, then the terms are added lane
 // by lane (v_readlane broadcast), i.e. exactly the sequence of additions the serial loop performs; empty cells contribute +0.0, which
-// leaves an accumulator that is never -0.0 unchanged.  The 3x3 eigen-decompositions run redundantly on all lanes (wave-uniform).
+// leaves an accumulator that is never -0.0 unchanged.  The two 3x3 eigen-decompositions of a block run side by side, one per half of the wave.
 __global__ __launch_bounds__(64) void k_livox_blocks(const float4* __restrict__ cell_pt, const float* __restrict__ cell_curv, LivoxDev P,
                                                      int* __restrict__ blk_nedge, int* __restrict__ blk_edge_cell, float* __restrict__ blk_edge_dir,
                                                      int* __restrict__ blk_nsurf, int* __restrict__ blk_surf_cell, float* __restrict__ blk_surf_nrm) {
@@ -178,8 +178,6 @@ __global__ __launch_bounds__(64) void k_livox_blocks(const float4* __restrict__ 
         a00 += bcast_f64(t00, o); a01 += bcast_f64(t01, o); a02 += bcast_f64(t02, o);
         a11 += bcast_f64(t11, o); a12 += bcast_f64(t12, o); a22 += bcast_f64(t22, o);
     }
-    double ev[3]; d3 vmin, vmax;
-    eig3_sym(a00, a01, a02, a11, a12, a22, ev, vmin, vmax);
     // edge candidate per line (L:302-331): every lane scores its own cell, the line's winner is the FIRST column with the largest score
     double g1 = 0.0;
     if (valid) {
@@ -201,20 +199,32 @@ __global__ __launch_bounds__(64) void k_livox_blocks(const float4* __restrict__ 
         }
         if (max_s != 0) { ex[ne] = kk; ey[ne] = idx; ne++; }
     }
-    unsigned tomb_cells = 0u;   // bit (line): the edge cell of that line is removed from this block's plane set (curvature *= -1, L:363)
-    if (ne > 3) {          // with <= 3 candidates the reference's test fails whatever the eigenvalues are (App. A6)
+    // the edge candidates' scatter matrix (with <= 3 candidates the reference's test fails whatever the eigenvalues are, App. A6: no matrix, no decomposition)
+    double e00 = 0, e01 = 0, e02 = 0, e11 = 0, e12 = 0, e22 = 0;
+    if (ne > 3) {
         d3 ce{0, 0, 0};
         for (int q = 0; q < ne; q++) { float4 e = cell_pt[ex[q] * kLvCols + ey[q]]; ce = ce + d3{(double)e.x, (double)e.y, (double)e.z}; }
         const double ned = (double)ne;
         ce = d3{ce.x / ned, ce.y / ned, ce.z / ned};
-        double e00 = 0, e01 = 0, e02 = 0, e11 = 0, e12 = 0, e22 = 0;
         for (int q = 0; q < ne; q++) {
             float4 e = cell_pt[ex[q] * kLvCols + ey[q]];
             d3 zz = d3{(double)e.x, (double)e.y, (double)e.z} - ce;
             e00 += zz.x * zz.x; e01 += zz.x * zz.y; e02 += zz.x * zz.z; e11 += zz.y * zz.y; e12 += zz.y * zz.z; e22 += zz.z * zz.z;
         }
-        double eve[3]; d3 vmn, vmx;
-        eig3_sym(e00, e01, e02, e11, e12, e22, eve, vmn, vmx);
+    }
+    // BOTH 3x3 eigen-decompositions of the block in ONE pass of the Jacobi code (round 5): lanes 0-31 take the patch's scatter matrix, lanes 32-63 the edge
+    // candidates' (a diagonal zero matrix when there is none: the sweep loop leaves at once) — the same instructions on different operands, so the launch's slowest
+    // waves (blocks with edge candidates on more than three lines) run one decomposition's worth of dependent divisions and square roots instead of two.
+    const bool hi_half = lane >= 32;
+    double evx[3]; d3 vmn_x, vmx_x;
+    eig3_sym(hi_half ? e00 : a00, hi_half ? e01 : a01, hi_half ? e02 : a02, hi_half ? e11 : a11, hi_half ? e12 : a12, hi_half ? e22 : a22, evx, vmn_x, vmx_x);
+    double ev[3], eve[3]; d3 vmin, vmx;
+#pragma unroll
+    for (int t = 0; t < 3; t++) { ev[t] = bcast_f64(evx[t], 0); eve[t] = bcast_f64(evx[t], 32); }
+    vmin = d3{bcast_f64(vmn_x.x, 0), bcast_f64(vmn_x.y, 0), bcast_f64(vmn_x.z, 0)};
+    vmx = d3{bcast_f64(vmx_x.x, 32), bcast_f64(vmx_x.y, 32), bcast_f64(vmx_x.z, 32)};
+    unsigned tomb_cells = 0u;   // bit (line): the edge cell of that line is removed from this block's plane set (curvature *= -1, L:363)
+    if (ne > 3) {
         if (eve[2] > P.edge_thres * eve[1]) {                                                    // L:353
             d3 u = canon_sign(vmx);
             if (lane == 0) { blk_edge_dir[3 * b] = (float)u.x; blk_edge_dir[3 * b + 1] = (float)u.y; blk_edge_dir[3 * b + 2] = (float)u.z; blk_nedge[b] = ne; }
