@@ -45,6 +45,26 @@ def test_struct_layouts_match_header(tmp_path):
                     P.kd_max_radius.offset]
 
 
+def test_documented_options_are_the_implemented_ones():
+    """include/lili_hip.h lists every name lili_set_option accepts and no name it does not (round 4's header still advertised knobs whose experiments had been
+    closed and removed): names compared between the comment block above the declaration and the strcmp chain in lili_api.hip (names behind an #ifdef are build
+    variants, not options of the shipped library)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "lili_om_amd", "csrc", "lili_api.hip")).read()
+    body = src[src.index("int lili_set_option("):]
+    body = body[:body.index("\n}\n")]
+    body = re.sub(r"#ifdef.*?#endif", "", body, flags=re.S)
+    implemented = set(re.findall(r'strcmp\(name, "([a-z0-9_]+)"\)', body))
+    hdr = open(os.path.join(root, "include", "lili_hip.h")).read()
+    doc = hdr[:hdr.index("int lili_set_option(")]
+    doc = doc[doc.rindex("/* Tuning knobs"):]
+    removed = doc[doc.index("(the closed experiments"):doc.index("an unknown name")]
+    documented = set(re.findall(r'"([a-z0-9_]+)"', doc)) - set(re.findall(r'"([a-z0-9_]+)"', removed))
+    assert implemented == documented, (sorted(implemented - documented), sorted(documented - implemented))
+    assert len(implemented) >= 20
+
+
 def test_no_gpu_means_loud_failure():
     import torch
     if torch.cuda.is_available():
