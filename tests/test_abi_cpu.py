@@ -45,6 +45,28 @@ def test_struct_layouts_match_header(tmp_path):
                     P.kd_max_radius.offset]
 
 
+def test_every_struct_mirror_matches_the_header(tmp_path):
+    """size and the offset of EVERY field of every structure the ctypes binding mirrors, against the C header compiled as plain C: a mirror that drifts from
+    its struct corrupts memory silently (lili_frontend_result, lili_lm_summary and the others joined the ABI after the first layout test was written)."""
+    import subprocess
+    pairs = [("lili_cloud", L.api.Cloud), ("lili_feature_out", L.api.FeatureOut), ("lili_rot_params", L.api.RotParams), ("lili_livox_params", L.api.LivoxParams),
+             ("lili_frontend_options", L.api.FrontendOptions), ("lili_frontend_result", L.api.FrontendResult), ("lili_lm_options", L.api.LmOptions),
+             ("lili_lm_iteration", L.api.LmIteration), ("lili_lm_summary", L.api.LmSummary), ("lili_s2m_params", L.api.S2MParams), ("lili_imu_state", L.api.ImuState)]
+    lines, expect = [], []
+    for cname, T in pairs:
+        lines.append(f'printf("%zu\\n", sizeof({cname}));')
+        expect.append(C.sizeof(T))
+        for fname, _ in T._fields_:
+            lines.append(f'printf("%zu\\n", offsetof({cname}, {fname}));')
+            expect.append(getattr(T, fname).offset)
+    src = tmp_path / "lay_all.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "lili_hip.h"\nint main(void){' + "".join(lines) + "return 0;}")
+    exe = tmp_path / "lay_all"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert got == expect, [(i, a, b) for i, (a, b) in enumerate(zip(got, expect)) if a != b]
+
+
 def test_documented_options_are_the_implemented_ones():
     """include/lili_hip.h lists every name lili_set_option accepts and no name it does not (round 4's header still advertised knobs whose experiments had been
     closed and removed): names compared between the comment block above the declaration and the strcmp chain in lili_api.hip (names behind an #ifdef are build
