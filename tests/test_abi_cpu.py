@@ -67,6 +67,22 @@ def test_every_struct_mirror_matches_the_header(tmp_path):
     assert got == expect, [(i, a, b) for i, (a, b) in enumerate(zip(got, expect)) if a != b]
 
 
+def test_every_bound_function_has_a_declared_signature():
+    """every lili_* entry point the Python package calls has argtypes / restype in api._SIGS (ctypes' default would pass a 64-bit pointer as a C int), and every
+    signature names a function the header declares"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    used = set()
+    for f in os.listdir(os.path.join(root, "lili_om_amd")):
+        if f.endswith(".py"):
+            used |= set(re.findall(r"lib\.(lili_[a-z0-9_]+)", open(os.path.join(root, "lili_om_amd", f)).read()))
+    sigs = set(L.api._SIGS.keys())
+    assert used <= sigs, sorted(used - sigs)
+    hdr = open(os.path.join(root, "include", "lili_hip.h")).read()
+    declared = set(re.findall(r"\b(lili_[a-z0-9_]+)\s*\(", hdr))
+    assert sigs <= declared, sorted(sigs - declared)
+
+
 def test_documented_options_are_the_implemented_ones():
     """include/lili_hip.h lists every name lili_set_option accepts and no name it does not (round 4's header still advertised knobs whose experiments had been
     closed and removed): names compared between the comment block above the declaration and the strcmp chain in lili_api.hip (names behind an #ifdef are build
