@@ -69,6 +69,7 @@ struct SpecBox {
     double max_sq_radius = 0;
     int margin_cells = 1;
     int hits = 0, misses_in_a_row = 0, skip_guesses = 0;      // guesses that held since the margin last changed / consecutive misses / builds that measure before guessing resumes
+    bool dense = false;            // the last build of this kind found a dense map and gave it the fine index (lili_map_set then skips the super-row copy of the gate-sized index)
     bool wide_counts = false;      // a build of this kind met a cell of more than 255 points: 32-bit cell counters from then on (k_cell_count instead of k_cell_count_narrow)
 };
 

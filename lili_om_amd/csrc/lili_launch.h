@@ -10,7 +10,6 @@ __global__ void k_cloud_to_f4(const unsigned char*, int, int, int, float4*, unsi
 __global__ void k_bbox(const float4*, int, unsigned*);
 __global__ void k_bbox_src(SrcCloud, int, unsigned*);
 __global__ void k_cell_count(SrcCloud, int, GridView, int*, int*, unsigned long long*, int, float);
-__global__ void k_associate_fine(AssocArgs, GridView, float, int, PoseArg, MatchParams);
 __global__ void k_scan_block_sums(const int*, int64_t, int*);
 __global__ void k_scan_sums(int*, int);
 __global__ void k_scan_apply(const int*, int64_t, const int*, int*);
@@ -20,7 +19,7 @@ template <typename RankT> __global__ void k_scatter_t(SrcCloud, int, GridView, c
 __global__ void k_start9(const int*, GridView, const int*, int*);
 __global__ void k_rowtot9(const int*, GridView, int*);
 template <int BS> __global__ void k_associate_lin(AssocArgs, AssocArgs, PoseArg, MatchParams, double*, double*);
-__global__ void k_scatter9(const int*, GridView, const int*, float4*, float*);
+__global__ void k_scatter9(const int*, GridView, const int*, float4*, float*, int);
 template <int BS> __global__ void k_associate_surf(const float4*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, int*);
 template <int BS> __global__ void k_associate_edge(const float4*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, int*);
 __global__ void k_associate_both(AssocArgs, AssocArgs, PoseArg, MatchParams);
@@ -33,6 +32,8 @@ __global__ void k_window_reduce(WindowArgs, double*, int, P2PView);
 __global__ void k_linearize_window(WinLinArgs, MatchParams);
 __global__ void k_window_gn(WindowArgs, const double*);
 __global__ void k_window_counts(WindowArgs, int*, P2PView);
+// lili_s2m_dense.hip: the association on a dense map (fine index)
+__global__ void k_associate_fine(AssocArgs, int, int, int, PoseArg, MatchParams);
 // lili_s2m_lm.hip: the Levenberg-Marquardt loop on fixed correspondences, one persistent launch
 struct LmArgs {      // must match lili_s2m_lm.hip
     LinArgs S, E;

@@ -28,7 +28,7 @@ static unsigned* scan_err_word(lili_ctx* ctx) { return reinterpret_cast<unsigned
 static unsigned long long* scan_status(lili_ctx* ctx, int which) { return reinterpret_cast<unsigned long long*>(ctx->misc.as<char>() + kMiscBytes + (size_t)which * kScanStatusBytes); }
 static int build_grid(lili_ctx* ctx, MapIndex& m, const SrcCloud& src, const double mn[3], const double mx[3], double cell, int reach, DevBuf& sorted, DevBuf& aux_sorted,
                       DevBuf& cell_start, DevBuf& cell_start9, GridView& out, int64_t& n_cells, double& cell_used, unsigned long long* d_rank_sum, bool box_check, float touch_cells, bool narrow /* 8-bit count table (k_cell_count_narrow) */,
-                      bool status_armed /* the scans' status words (ctx->misc) are still zero from the build's one memset */, const void* zeroed_p = nullptr, size_t zeroed_bytes = 0 /* the caller already cleared this much of cell_start (while the bounding box travelled) */) {
+                      bool status_armed /* the scans' status words (ctx->misc) are still zero from the build's one memset */, bool want_srows /* super-row copy (if the options and the sizes allow it) */, const void* zeroed_p = nullptr, size_t zeroed_bytes = 0 /* the caller already cleared this much of cell_start (while the bounding box travelled) */) {
     const int n = (int)m.n;
     int64_t nx, ny, nz;
     for (;;) {
@@ -62,7 +62,7 @@ static int build_grid(lili_ctx* ctx, MapIndex& m, const SrcCloud& src, const dou
     g.bx0 = b0[0]; g.by0 = b0[1]; g.bz0 = b0[2];
     g.bnx = b1[0] - b0[0] + 1; g.bny = b1[1] - b0[1] + 1; g.bnz = b1[2] - b0[2] + 1;
     const int64_t nc9 = (int64_t)g.bnx * g.bny * g.bnz, rows9 = (int64_t)g.bny * g.bnz;
-    const bool srows = ctx->super_rows && (int64_t)n * 10 < (1ll << 28) && nc9 + 2 < (1ll << 31);
+    const bool srows = want_srows && ctx->super_rows && (int64_t)n * 10 < (1ll << 28) && nc9 + 2 < (1ll << 31);
     const size_t n_all = srows ? (size_t)n * 10 : (size_t)n;
     HIPCHK(sorted.ensure((n_all + 8) * sizeof(float4)));      // + slack: the super-row walk loads whole chunks of four, one of them past the run's end
     if (m.has_aux) HIPCHK(aux_sorted.ensure(n_all * sizeof(float)));
@@ -102,8 +102,14 @@ static int build_grid(lili_ctx* ctx, MapIndex& m, const SrcCloud& src, const dou
         hipLaunchKernelGGL(k_scan_lookback_t<false>, dim3(nb_lb), dim3(kBlock), 0, ctx->stream, m.row9.as<int>(), (const unsigned char*)nullptr, rows9, st, scan_err_word(ctx));
         hipLaunchKernelGGL(k_start9, dim3(nblocks(g.bnx, 64), nblocks(g.bny, 4 * 8), (unsigned)g.bnz), dim3(256), 0, ctx->stream, cell_start.as<int>(), g, m.row9.as<int>(),
                            cell_start9.as<int>());
-        hipLaunchKernelGGL(k_scatter9, dim3(nblocks(g.bnx, 64), nblocks(g.bny, 4), nblocks(g.bnz, 4)), dim3(1024), 0, ctx->stream, cell_start.as<int>(), g, cell_start9.as<int>(),
-                           sorted.as<float4>(), m.has_aux ? aux_sorted.as<float>() : nullptr);
+        {   // stretches per wave: more than one only where the index has so many (mostly empty) stretches that a wave per stretch is launch-bound — the fine index of
+            // a dense map: 1.39 M stretches, 18 % of them populated (the walls at the ends of x put a few points into every stretch there) -> 8 per wave
+            const int64_t n_str = (int64_t)nblocks(g.bnx, 64) * g.bny * g.bnz;
+            int spw = 1;
+            while (spw < 64 && n_str / (spw * 2) >= 131072) spw *= 2;
+            hipLaunchKernelGGL(k_scatter9, dim3((unsigned)((n_str + (int64_t)spw * 4 - 1) / ((int64_t)spw * 4))), dim3(256), 0, ctx->stream, cell_start.as<int>(), g, cell_start9.as<int>(),
+                               sorted.as<float4>(), m.has_aux ? aux_sorted.as<float>() : nullptr, spw);
+        }
     }
     HIPCHK(hipGetLastError());
     g.pts = sorted.as<float4>();
@@ -172,6 +178,8 @@ static int map_set_impl(lili_ctx* ctx, int kind, const lili_cloud* cloud, double
     SpecBox& sb = ctx->spec_box[kind];
     // 8-bit cell counters (k_cell_count_narrow) unless a build of this kind has met a cell of more than 255 points (or the single-pass scan is off: A/B, fallback)
     const bool narrow = ctx->map_narrow_counts && !sb.wide_counts && ctx->scan_lookback;
+    // a map of this kind, size and gate was dense at its last build: its gate-sized index goes without the super-row copy (nothing searches it while the fine index exists)
+    const bool dense_hint = ctx->fine_grid && sb.dense && sb.max_sq_radius == max_sq_radius && (double)n <= 1.25 * (double)sb.n && (double)n >= 0.8 * (double)sb.n;
     BoxSource source = box6 ? kBoxGiven : kBoxMeasure;
     if (!box6 && allow_guess && ctx->map_guess_box && sb.valid && sb.max_sq_radius == max_sq_radius &&
         (double)n <= 1.25 * (double)sb.n && (double)n >= 0.8 * (double)sb.n) {
@@ -217,7 +225,8 @@ static int map_set_impl(lili_ctx* ctx, int kind, const lili_cloud* cloud, double
     unsigned scan_err = 0;
     bool err_read = false;
     int rc = build_grid(ctx, m, src, mn, mx, cell, reach, m.sorted, m.aux_sorted, m.cell_start, m.cell_start9, m.view, m.n_cells, m.cell, d_rank, source == kBoxGuess,
-                        (float)(1.5 * (double)sb.margin_cells + 0.5) /* twice the margin: a cloud that moved towards one face moved away from the other */, narrow, true, zeroed_p, zeroed_bytes);
+                        (float)(1.5 * (double)sb.margin_cells + 0.5) /* twice the margin: a cloud that moved towards one face moved away from the other */, narrow, true,
+                        !dense_hint /* a dense map is searched through its fine index alone (lili_s2m_dense.hip): its gate-sized index only measures the density */, zeroed_p, zeroed_bytes);
     if (rc != LILI_OK) return rc;
     // The build's read-back: [density banks, with the check word of a guessed box in every bank | sticky error word of the look-back scans] lie side by side in ctx->misc.
     // Density adaptation (SURVEY §7 step 4, §8d Config 2 variant B): the point-weighted mean cell occupancy falls out of the count pass.
@@ -269,7 +278,7 @@ static int map_set_impl(lili_ctx* ctx, int kind, const lili_cloud* cloud, double
             double fc = cell * std::sqrt(3.0 / m.mean_occupancy);
             fc = std::min(std::max(fc, cell / 16.0), cell / 1.5);
             int64_t fcells = 0; double fcell_used = 0;
-            rc = build_grid(ctx, m, src, mn, mx, fc, reach, m.sorted_f, m.aux_sorted_f, m.cell_start_f, m.cell_start9_f, m.fview, fcells, fcell_used, nullptr, false, 0.f, false /* the fine index keeps 32-bit counters: its check would need a read-back of its own */, false);
+            rc = build_grid(ctx, m, src, mn, mx, fc, reach, m.sorted_f, m.aux_sorted_f, m.cell_start_f, m.cell_start9_f, m.fview, fcells, fcell_used, nullptr, false, 0.f, false /* the fine index keeps 32-bit counters: its check would need a read-back of its own */, false, true);
             if (rc != LILI_OK) return rc;
             const double rb = (double)reach * fcell_used / 1.01;
             float fb = (float)(rb * rb * (1.0 - 1e-6));
@@ -298,6 +307,9 @@ static int map_set_impl(lili_ctx* ctx, int kind, const lili_cloud* cloud, double
     // with scan_lookback = 0 the fine index's kernels (which read the CALLER's device cloud in place) were enqueued after the build's last read-back: the
     // header promises the cloud is free when the call returns, so the call waits for them
     else if (m.has_fine && cloud->mem == LILI_MEM_DEVICE) HIPCHK(hipStreamSynchronize(ctx->stream));
+    // the hint was wrong (the map is not dense any more): its gate-sized index is the one that is searched and needs the super-row copy after all
+    if (dense_hint && !m.has_fine) { sb.dense = false; return map_set_impl(ctx, kind, cloud, max_sq_radius, source == kBoxGuess ? nullptr : mm, source == kBoxGuess); }
+    sb.dense = m.has_fine;
     // what the next build of this kind may start from: this cloud's TRUE box (a given box is the caller's, taken as true: lili_localmap_commit hands over the centroids'
     // own).  A build from a guess keeps the box it guessed from — margins do not pile up.
     if (source != kBoxGuess) {

@@ -98,12 +98,19 @@ static int launch_associate(lili_ctx* ctx, int slot, int kind, const PoseArg& pa
     if (m.has_fine) {      // dense map: fine index first, gate-sized index for the queries it cannot settle
         if (kind == LILI_KIND_SURF && P.variant == LILI_VARIANT_LIVOX && (!m.has_aux || !ks.has_aux))
             return ctx->fail(LILI_E_STATE, "associate: Livox variant needs reflectivity (aux_offset) on the surf map and the surf queries");
+        // the fine index alone (lili_s2m_dense.hip): one lane per query for the queries their inner 27 fine cells settle, then the wave serves the rest 16 lanes per query
         AssocArgs a{};
-        a.queries = ks.q.as<float4>(); a.n_q = n; a.g = m.view;
+        a.queries = ks.q.as<float4>(); a.n_q = n; a.g = m.fview;
         a.rec0 = ks.rec0.as<float4>(); a.rec1 = ks.rec1.p; a.valid = ks.valid.as<unsigned char>();
         a.dbg_idx = dbg_i; a.dbg_d2 = dbg_d; a.block_counts = ks.block_counts.as<int>(); a.nb = ks.n_blocks;
         ks.launches++;
-        launch_k(ctx->stream, any_order, k_associate_fine, dim3(ks.n_blocks), dim3(kAssocBlock), 0, a, m.fview, m.fbound, kind, pa, P);
+        const int r_max = std::max(1, (int)std::ceil(std::sqrt(gate) * 1.01 / m.fine_cell));      // fine cells the search has to reach for the gate ball
+        const int qpw = ks.n_blocks < std::max(ctx->n_simd, 256) ? 16 : kAssocBlock;                // queries per wave (see the kernel)
+        const int nb = nblocks(n, qpw);
+        HIPCHK(ks.block_counts.ensure((size_t)nb * sizeof(int)));
+        a.nb = nb; a.block_counts = ks.block_counts.as<int>();
+        ks.n_assoc_blocks = nb;
+        launch_k(ctx->stream, any_order, k_associate_fine, dim3(nb), dim3(kAssocBlock), 0, a, r_max, qpw, kind, pa, P);
         HIPCHK(hipGetLastError());
         return LILI_OK;
     }

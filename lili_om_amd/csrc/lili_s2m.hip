@@ -490,6 +490,23 @@ __global__ __launch_bounds__(256) void k_start9(const int* __restrict__ cell_sta
     if (y0 >= g.by0 + g.bny) return;
     const int xc = min(x, g.bx0 + g.bnx - 1);
     int c3[kS9Rows + 2];                                                            // per source row y: box-relative prefix at x, summed over the three planes
+    // Round 6: most stretches of a sparse index (the fine index of a dense map: 98 %) have no point in any of their (kS9Rows + 2) x 3 source rows — then every lane
+    // of the wave holds the SAME prefixes, those at the stretch's first cell.  Lane r * 3 + p tests source row r of plane p (two words) and holds that prefix; the
+    // sums come from shuffles: two loads per lane for 30 lanes instead of 60 per lane (329 -> ~90 us for the 84 M super cells of configs[2] variant B).
+    const int xa = g.bx0 + (int)blockIdx.x * 64, xb = min(xa + 64, g.bx0 + g.bnx);      // the stretch: cells [xa, xb)
+    int pfx = 0; bool occ = false;
+    if (lane < (kS9Rows + 2) * 3) {
+        const int r = lane / 3, y = y0 - 1 + r, z = zs + lane % 3 - 1;
+        if (y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
+            const int* cs = cell_start + ((size_t)z * g.ny + y) * g.nx;
+            const int a = cs[xa], b = cs[xb];
+            pfx = a - cs[g.bx0]; occ = b != a;
+        }
+    }
+    if (!__any(occ)) {
+#pragma unroll
+        for (int r = 0; r < kS9Rows + 2; r++) c3[r] = __shfl(pfx, 3 * r) + __shfl(pfx, 3 * r + 1) + __shfl(pfx, 3 * r + 2);
+    } else {
 #pragma unroll
     for (int r = 0; r < kS9Rows + 2; r++) {
         const int y = y0 - 1 + r;
@@ -503,6 +520,7 @@ __global__ __launch_bounds__(256) void k_start9(const int* __restrict__ cell_sta
             s += in ? b - a : 0;
         }
         c3[r] = s;
+    }
     }
     if (x >= g.bx0 + g.bnx) return;
 #pragma unroll
@@ -529,65 +547,84 @@ __global__ __launch_bounds__(kBlock) void k_scatter_t(SrcCloud src, int n, GridV
 template __global__ void k_scatter_t<int>(SrcCloud, int, GridView, const int*, const int*, float4*, float*);
 template __global__ void k_scatter_t<unsigned char>(SrcCloud, int, GridView, const unsigned char*, const int*, float4*, float*);
 
-// Super-row copy, by DESTINATION: one wave owns the stretch of 64 consecutive super cells (x0..x0+63, y', z') — a contiguous piece of the
-// super-row array — and fills it from its nine source rows, each a contiguous run of the base array.  The nine runs are walked as ONE
-// sequence, 64 points per trip; a point finds its super cell through its own x cell and its place through a 9 x 64 table (LDS) of
-// "destination minus source" per (source row, cell).  The 16 waves of a workgroup take a 4 x 4 tile of (y', z'), whose 36 source rows
-// they share through the L2 of the XCD the workgroup runs on.
-__global__ __launch_bounds__(1024) void k_scatter9(const int* __restrict__ cell_start, GridView g, const int* __restrict__ start9,
-                                                   float4* __restrict__ sorted, float* __restrict__ aux_sorted) {
-    __shared__ int delta[16][9][64];
+// Super-row copy, by DESTINATION: a stretch = 64 consecutive super cells (x0..x0+63, y', z') — a contiguous piece of the super-row array — is filled by ONE wave
+// from its nine source rows, each a contiguous run of the base array.  The nine runs are walked as ONE sequence, 64 points per trip; a point finds its super cell
+// through its own x cell and its place through a 9 x 64 table (LDS) of "destination minus source" per (source row, cell).
+// Round 6: a wave takes 64 stretches in linear order (x block fastest, then y', then z'); every lane tests ONE of them for emptiness (two words of start9) and the
+// wave copies the non-empty ones one after the other.  Before, every stretch had a wave of its own that loaded the two words and left: on an index whose cells are
+// mostly empty (the fine index of a dense map: 1.39 M stretches, 2 % of them populated) the copy spent its time launching waves — 639 us for 5 M points.
+// spw (1 .. 64): stretches per wave — 64 for a sparse index, 1 (one wave per stretch, as before) where there are too few stretches to fill the chip otherwise.
+__global__ __launch_bounds__(256) void k_scatter9(const int* __restrict__ cell_start, GridView g, const int* __restrict__ start9,
+                                                  float4* __restrict__ sorted, float* __restrict__ aux_sorted, int spw) {
+    __shared__ int delta[4][9][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int x0 = g.bx0 + blockIdx.x * 64;
-    const int ys = g.by0 + (int)blockIdx.y * 4 + (w & 3);
-    const int zs = g.bz0 + (int)blockIdx.z * 4 + (w >> 2);
-    if (ys >= g.by0 + g.bny || zs >= g.bz0 + g.bnz) return;
-    const int xn = min(64, g.bx0 + g.bnx - x0);            // cells of this stretch
-    const int* s9 = start9 + srow_index(g, x0, ys, zs);
-    const int lc = min(lane, xn - 1);
-    int dnext = s9[lc];                                    // where the next source's points of cell x0+lane go
-    const int d_end = s9[xn];
-    const int D0 = __shfl(dnext, 0);
-    const int len = d_end - D0;
-    if (len == 0) return;                                  // nothing lives here
-    int off[9], pre[10];
-    pre[0] = 0;
-    // all 27 range words of the nine source rows are requested BEFORE the first is used (round 4: 70.9 -> 64.4 us per focused copy)
-    int ra[9], rbn[9], rend[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-        const int y = ys + k % 3 - 1, z = zs + k / 3 - 1;
-        const bool in = y >= 0 && y < g.ny && z >= 0 && z < g.nz;
-        const int* cs = cell_start + ((size_t)(in ? z : 0) * g.ny + (in ? y : 0)) * g.nx + x0;
-        ra[k] = cs[lc]; rbn[k] = cs[lc + 1]; rend[k] = cs[xn];
+    const int nxb = (g.bnx + 63) / 64;
+    const long long n_str = (long long)nxb * g.bny * g.bnz;
+    const long long s0 = ((long long)blockIdx.x * 4 + w) * spw;
+    bool ne = false;
+    {
+        const long long sid = s0 + lane;
+        if (lane < spw && sid < n_str) {
+            const int xb = (int)(sid % nxb); const long long r = sid / nxb;
+            const int ys = g.by0 + (int)(r % g.bny), zs = g.bz0 + (int)(r / g.bny), x0 = g.bx0 + xb * 64;
+            const int xn = min(64, g.bx0 + g.bnx - x0);
+            const int* s9 = start9 + srow_index(g, x0, ys, zs);
+            ne = s9[xn] != s9[0];
+        }
     }
+    unsigned long long todo = __ballot(ne);
+    while (todo) {
+        const long long sid = s0 + __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const int xb = (int)(sid % nxb); const long long rr = sid / nxb;
+        const int ys = g.by0 + (int)(rr % g.bny), zs = g.bz0 + (int)(rr / g.bny), x0 = g.bx0 + xb * 64;
+        const int xn = min(64, g.bx0 + g.bnx - x0);            // cells of this stretch
+        const int* s9 = start9 + srow_index(g, x0, ys, zs);
+        const int lc = min(lane, xn - 1);
+        int dnext = s9[lc];                                    // where the next source's points of cell x0+lane go
+        const int d_end = s9[xn];
+        const int D0 = __shfl(dnext, 0);
+        const int len = d_end - D0;
+        int off[9], pre[10];
+        pre[0] = 0;
+        // all 27 range words of the nine source rows are requested BEFORE the first is used (round 4: 70.9 -> 64.4 us per focused copy)
+        int ra[9], rbn[9], rend[9];
 #pragma unroll
-    for (int k = 0; k < 9; k++) {
-        const int y = ys + k % 3 - 1, z = zs + k / 3 - 1;
-        const bool in = y >= 0 && y < g.ny && z >= 0 && z < g.nz;
-        const int a = ra[k], b = rbn[k], e = rend[k];
-        delta[w][k][lane] = dnext - a;
-        dnext += in ? b - a : 0;
-        const int rb = in ? __shfl(a, 0) : 0, re = in ? e : 0;
-        off[k] = rb - pre[k];                              // position in the base array = position in the merged sequence + off[k]
-        pre[k + 1] = pre[k] + (re - rb);
-    }
-    __builtin_amdgcn_wave_barrier();
-    for (int t0 = 0; t0 < len; t0 += 64) {                 // pre[9] == len   (four trips in flight were measured: no change, 64.4 vs 63.4 us)
-        const int t = t0 + lane;
-        const bool live = t < len;
-        int k = 0, o = off[0];
+        for (int k = 0; k < 9; k++) {
+            const int y = ys + k % 3 - 1, z = zs + k / 3 - 1;
+            const bool in = y >= 0 && y < g.ny && z >= 0 && z < g.nz;
+            const int* cs = cell_start + ((size_t)(in ? z : 0) * g.ny + (in ? y : 0)) * g.nx + x0;
+            ra[k] = cs[lc]; rbn[k] = cs[lc + 1]; rend[k] = cs[xn];
+        }
+        __builtin_amdgcn_wave_barrier();                       // the table of the stretch before has been read
 #pragma unroll
-        for (int i = 1; i < 9; i++) { const bool ge = t >= pre[i]; k += ge ? 1 : 0; o = ge ? off[i] : o; }
-        const int j = live ? t + o : 0;
-        const float4 p = sorted[j];
-        int xc = 0;
-        if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) xc = min(max(cell_coord(p.x, g.ox, g.inv_cell), 0), g.nx - 1);   // as cell_of
-        const int l = min(max(xc - x0, 0), 63);
-        const int d = j + delta[w][k][l];
-        if (live) {
-            sorted[d] = p;
-            if (aux_sorted) aux_sorted[d] = aux_sorted[j];
+        for (int k = 0; k < 9; k++) {
+            const int y = ys + k % 3 - 1, z = zs + k / 3 - 1;
+            const bool in = y >= 0 && y < g.ny && z >= 0 && z < g.nz;
+            const int a = ra[k], b = rbn[k], e = rend[k];
+            delta[w][k][lane] = dnext - a;
+            dnext += in ? b - a : 0;
+            const int rb = in ? __shfl(a, 0) : 0, re = in ? e : 0;
+            off[k] = rb - pre[k];                              // position in the base array = position in the merged sequence + off[k]
+            pre[k + 1] = pre[k] + (re - rb);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int t0 = 0; t0 < len; t0 += 64) {                 // pre[9] == len   (four trips in flight were measured: no change, 64.4 vs 63.4 us)
+            const int t = t0 + lane;
+            const bool live = t < len;
+            int k = 0, o = off[0];
+#pragma unroll
+            for (int i = 1; i < 9; i++) { const bool ge = t >= pre[i]; k += ge ? 1 : 0; o = ge ? off[i] : o; }
+            const int j = live ? t + o : 0;
+            const float4 p = sorted[j];
+            int xc = 0;
+            if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) xc = min(max(cell_coord(p.x, g.ox, g.inv_cell), 0), g.nx - 1);   // as cell_of
+            const int l = min(max(xc - x0, 0), 63);
+            const int d = j + delta[w][k][l];
+            if (live) {
+                sorted[d] = p;
+                if (aux_sorted) aux_sorted[d] = aux_sorted[j];
+            }
         }
     }
 }
@@ -724,45 +761,6 @@ __global__ __launch_bounds__(kAssocBlock) void k_associate_both(AssocArgs S, Ass
     const int b = (int)blockIdx.x;
     if (b < E.nb) assoc_edge_body<kAssocBlock>(E.queries, E.n_q, E.g, pa, P, E.rec0, reinterpret_cast<float4*>(E.rec1), E.valid, E.dbg_idx, E.dbg_d2, E.block_counts, b, tab);
     else assoc_surf_body<kAssocBlock>(S.queries, S.n_q, S.g, pa, P, S.rec0, reinterpret_cast<double*>(S.rec1), S.valid, S.dbg_idx, S.dbg_d2, S.block_counts, b - E.nb, tab);
-}
-// Association on a map that is much denser than the gate radius (SURVEY §8d Config 2, variant B: 5 M points at a 0.05 m leaf — ~170
-// points per gate-sized cell, ~1500 candidates in the inner 27 cells).  The map then carries a SECOND index with cells sized from the
-// measured point density (lili_map_set: ~3 points per cell), searched first with the selection bounded by fbound = (reach * fine cell /
-// 1.01)^2: everything within sqrt(fbound) of the query lies inside the fine 5x5x5 block, so if five points are found strictly inside
-// fbound no unseen point can beat the fifth — they ARE the global 5 nearest.  Only queries that do not find five (map borders, holes)
-// repeat the search on the gate-sized index with the reference's gate; both searches are the exact knn5_grid.  `kind`: 0 surf, 1 edge.
-__global__ __launch_bounds__(kAssocBlock) void k_associate_fine(AssocArgs A, GridView gf, float fbound, int kind, PoseArg pa, MatchParams P) {
-    __shared__ RowTabT<kAssocBlock> tab;
-    const int i = (int)blockIdx.x * kAssocBlock + (int)threadIdx.x;
-    const bool live = i < A.n_q;
-    const float4 ql = A.queries[live ? i : 0];
-    dq Q2; d3 T2;
-    load_assoc_pose(pa, P, Q2, T2);
-    const d3 pmd = qrot(Q2, d3{(double)ql.x, (double)ql.y, (double)ql.z}) + T2;
-    const float px = (float)pmd.x, py = (float)pmd.y, pz = (float)pmd.z;
-    const float gate = gate_bound(kind == 0 ? P.kd_max_radius : P.edge_gate);
-    Top5 nn; nn.aux = 0; nn.have = false;
-    bool fine_hit = false;
-    if (live) {
-        knn5_grid(gf, tab, px, py, pz, fminf(fbound, gate), nn, P.debug);
-        fine_hit = nn.j[4] >= 0 && nn.d[4] < fbound;
-    }
-    if (live && !fine_hit) knn5_grid(A.g, tab, px, py, pz, gate, nn, P.debug);
-    bool ok = false;
-    if (live) {
-        const GridView& u = fine_hit ? gf : A.g;
-        store_debug_nn(u, nn, i, A.dbg_idx, A.dbg_d2);
-        if (kind == 0) {
-            float4 rn; double score;
-            ok = surf_fit(u, P, nn, ql, px, py, pz, rn, score);
-            A.rec0[i] = rn; reinterpret_cast<double*>(A.rec1)[i] = score; A.valid[i] = ok ? 1 : 0;
-        } else {
-            float4 ra, rb;
-            ok = edge_fit(u, P, nn, px, py, pz, ra, rb);
-            A.rec0[i] = ra; reinterpret_cast<float4*>(A.rec1)[i] = rb; A.valid[i] = ok ? 1 : 0;
-        }
-    }
-    store_block_count<kAssocBlock>(ok, A.block_counts, (int)blockIdx.x);
 }
 template __global__ void k_associate_surf<kAssocBlock>(const float4*, int, GridView, PoseArg, MatchParams, float4*, double*, unsigned char*, int*, float*, int*);
 template __global__ void k_associate_edge<kAssocBlock>(const float4*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, int*);

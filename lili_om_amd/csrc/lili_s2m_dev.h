@@ -188,6 +188,85 @@ __device__ __forceinline__ void process_chunk(Sel5K& sel, float4 p0, float4 p1, 
     sel.chunk(p0, p1, p2, p3, j, end, qx, qy, qz);
 }
 
+// Key selector WITH a payload pool (round 6; the dense-map association k_associate_fine): the same 32-bit keys and the same five-median network as
+// Sel5K, but the code of a key names one of SEVEN slots of a per-lane pool in LDS that holds the candidate itself (point + array position).  A
+// candidate takes the free slot when (and only when) its key enters the six held ones, and the slot of the key it pushes out becomes the free one:
+// the six held codes and the free slot are always a permutation of 0..6.  Nothing is re-loaded from the map when the walk ends.  Why: on a map
+// whose index does not fit L2 + Infinity Cache (5 M points at 0.05 m: 1.1 GB of super-rows) the lines of a lane's run have left the caches by the
+// time Sel5K::finish gathers the five winners again — 7.6 of 46 us per 200 k-query launch (profiles/r06_2B_experiments.md).  Exactness as Sel5K:
+// buckets are monotone in the distance; a tie of the fifth and sixth bucket, or a fifth in the bucket of the bound, reports `redo`.
+struct Sel5P {
+    unsigned k[6];
+    unsigned fr;     // the free slot
+    unsigned bb;     // bucket of the bound
+    float bnd;
+    float4* P;       // this lane's column of the pool: slot s at P[s * STRIDE]
+    int* J;
+    int tc;
+    static constexpr int STRIDE = 64;      // lanes per pool row (one wave per workgroup)
+    __device__ __forceinline__ void init(float bound, float4* pcol, int* jcol) {
+        bnd = fminf(bound, 3.0e38f);
+        bb = __float_as_uint(bnd) >> 6;
+        P = pcol; J = jcol;
+#pragma unroll
+        for (int s = 0; s < 6; s++) { k[s] = ((bb + 1u + (unsigned)s) << 6) | (unsigned)s; J[s * STRIDE] = -1; }   // six distinct buckets above the bound, slots without a candidate
+        fr = 6u; tc = 0;
+    }
+    __device__ __forceinline__ float worst() const { return __uint_as_float(k[4] | 63u); }
+    __device__ __forceinline__ void push(unsigned u, float4 p, int j) {
+        const unsigned key = (u & ~63u) | fr;
+        const unsigned old5 = k[5];
+        const bool enter = key < old5;      // codes differ, so never equal
+        if (enter) { P[fr * STRIDE] = p; J[fr * STRIDE] = j; }
+        const unsigned m5 = umed3(k[4], k[5], key), m4 = umed3(k[3], k[4], key), m3 = umed3(k[2], k[3], key);
+        const unsigned m2 = umed3(k[1], k[2], key), m1 = umed3(k[0], k[1], key);
+        k[0] = min(k[0], key); k[1] = m1; k[2] = m2; k[3] = m3; k[4] = m4; k[5] = m5;
+        fr = enter ? (old5 & 63u) : fr;
+    }
+    // four consecutive candidates [j, j + 4) of a run ending at `end`
+    __device__ __forceinline__ void chunk(float4 p0, float4 p1, float4 p2, float4 p3, int j, int end, float qx, float qy, float qz) {
+        tc++;
+        const unsigned u0 = j < end ? __float_as_uint(dist2(p0, qx, qy, qz)) : 0x7f800000u;
+        const unsigned u1 = j + 1 < end ? __float_as_uint(dist2(p1, qx, qy, qz)) : 0x7f800000u;
+        const unsigned u2 = j + 2 < end ? __float_as_uint(dist2(p2, qx, qy, qz)) : 0x7f800000u;
+        const unsigned u3 = j + 3 < end ? __float_as_uint(dist2(p3, qx, qy, qz)) : 0x7f800000u;
+        push(u0, p0, j); push(u1, p1, j + 1); push(u2, p2, j + 2); push(u3, p3, j + 3);
+    }
+    // The five best with exact distances in the oracle's (d2, original index) order.  Returns true if the query has to be repeated with the exact selector.
+    __device__ __forceinline__ bool finish(float qx, float qy, float qz, Top5& t) const {
+        const bool redo = ((k[5] ^ k[4]) < 64u) || ((k[4] >> 6) == bb);
+        unsigned long long e[5];
+        int jr[5];
+        float4 pp[5];
+#pragma unroll
+        for (int s = 0; s < 5; s++) {
+            const unsigned c = k[s] & 63u;
+            jr[s] = J[c * STRIDE];
+            const bool real = jr[s] >= 0;
+            const float4 p = P[c * STRIDE];
+            pp[s] = p;
+            const unsigned du = real ? __float_as_uint(dist2(p, qx, qy, qz)) : __float_as_uint(bnd);
+            const unsigned lo = real ? (unsigned)__float_as_int(p.w) : 0x7fffffffu;
+            e[s] = ((unsigned long long)du << 32) | lo;
+        }
+        const bool unsorted = !(e[0] <= e[1] && e[1] <= e[2] && e[2] <= e[3] && e[3] <= e[4]);
+        if (__any(unsorted)) {
+#define LILI_CE(a, b) { const bool sw = e[b] < e[a]; const unsigned long long ea = e[a], eb = e[b]; const int ja = jr[a], jb = jr[b]; \
+                        const float4 pa_ = pp[a], pb_ = pp[b]; \
+                        e[a] = sw ? eb : ea; e[b] = sw ? ea : eb; jr[a] = sw ? jb : ja; jr[b] = sw ? ja : jb; \
+                        pp[a].x = sw ? pb_.x : pa_.x; pp[a].y = sw ? pb_.y : pa_.y; pp[a].z = sw ? pb_.z : pa_.z; pp[a].w = sw ? pb_.w : pa_.w; \
+                        pp[b].x = sw ? pa_.x : pb_.x; pp[b].y = sw ? pa_.y : pb_.y; pp[b].z = sw ? pa_.z : pb_.z; pp[b].w = sw ? pa_.w : pb_.w; }
+            LILI_CE(0, 1) LILI_CE(3, 4) LILI_CE(2, 4) LILI_CE(2, 3) LILI_CE(0, 3) LILI_CE(0, 2) LILI_CE(1, 4) LILI_CE(1, 3) LILI_CE(1, 2)
+#undef LILI_CE
+        }
+#pragma unroll
+        for (int s = 0; s < 5; s++) { t.d[s] = __uint_as_float((unsigned)(e[s] >> 32)); t.j[s] = jr[s]; t.p[s] = pp[s]; }
+        t.aux = tc;
+        t.have = !redo;
+        return redo;
+    }
+};
+
 // Lower bound (conservative by 0.1 %) of the f32 squared distance from the query to any point of the cell row
 // (cy+dy, cz+dz): the gap to the own cell's boundary in y and z.  Rows whose bound exceeds the current 5th best
 // cannot contribute (a candidate enters only with d <= that value) — skipping them keeps the search exact.

@@ -101,3 +101,76 @@ def test_dense_map_fine_index_is_exact(gpu_ctx, oracle):
         assert np.array_equal(a[3][k], b[3][k]), k
     assert np.array_equal(a[4], b[4]) and a[5] == b[5]
     assert a[6] < b[6]                                                # and it is the faster of the two on this map
+
+
+def _brute_knn5(mp, qw):
+    """exact (d2, index)-ordered 5-NN with FLANN's f32 L2_Simple arithmetic, by brute force (small query sets)."""
+    idx = np.zeros((qw.shape[0], 5), np.int32); d2 = np.zeros((qw.shape[0], 5), np.float32)
+    m = mp.astype(np.float32)
+    for i, q in enumerate(qw.astype(np.float32)):
+        dx = q[0] - m[:, 0]; dy = q[1] - m[:, 1]; dz = q[2] - m[:, 2]
+        d = (dx * dx + dy * dy) + dz * dz
+        o = np.lexsort((np.arange(m.shape[0]), d))[:5]
+        idx[i] = o; d2[i] = d[o]
+    return idx, d2
+
+
+def test_dense_map_borders_focus_box_and_both_selectors(gpu_ctx, oracle):
+    """Round 6: the dense-map association searches the fine index alone — inner 27 fine cells per lane, then rings of super-rows by 16 lanes per query.  Exercised here:
+    queries outside the grid and at its faces, a NaN query, queries between 0.2 and 0.9 m off every surface (several ring levels), a focus box that leaves most of the
+    map without super-rows (blocks walked row by row), both kinds, and the exact-key selector against the bucket-key one (LILI_DEBUG bit 32768)."""
+    import os
+    mp = _dense_room(seed=5, size=(6.0, 5.0, 3.0))
+    rng = np.random.default_rng(11)
+    n_q = 1500
+    qw = mp[rng.choice(mp.shape[0], n_q)].astype(np.float64) + rng.normal(0, 0.01, (n_q, 3))
+    qw[:400] += rng.uniform(-1, 1, (400, 3)) * rng.uniform(0.2, 0.9, (400, 1))     # off the surfaces, inside and outside the room
+    qw[400:430] = rng.uniform(-1, 1, (30, 3)) * np.array([3.6, 3.1, 0.4]) + np.array([0, 0, -0.5])      # below the floor: outside the grid in z
+    qw[430:460, 0] = 3.0 + rng.uniform(0.0, 2.6, 30)                                 # beyond the +x wall, some of them beyond the gate
+    qw[460] = np.nan
+    t_true = np.array([0.2, -0.1, 1.2]); q_true = np.array([1.0, 0, 0, 0])
+    q_local = (qw - t_true).astype(np.float32)
+    qm = q_local.astype(np.float64) + t_true                                         # what the device sees after the (identity-rotation) transform, up to f32 rounding
+    P = L.make_params("rot")
+    want_idx, want_d2 = _brute_knn5(mp, (q_local.astype(np.float64) + t_true).astype(np.float32))
+    results = {}
+    try:
+        gpu_ctx.set_option("map_guess_box", 0)
+        gpu_ctx.set_debug(True)
+        for name, focus, dbg in (("whole", None, "0"), ("focus", ((1.0, 0.5, 1.0), 1.2), "0"), ("exact", None, "32768")):
+            os.environ["LILI_DEBUG"] = dbg
+            m = L.ScanToMapMatcher(gpu_ctx, P)
+            m.map_focus(*focus) if focus else m.map_focus(None)
+            m.set_input_cloud(L.KIND_SURF, mp)
+            m.set_input_cloud(L.KIND_EDGE, mp, max_sq_radius=1.0)
+            assert m.map_density(L.KIND_SURF)[1] > 0 and m.map_density(L.KIND_EDGE)[1] > 0      # both kinds got the fine index
+            out = {}
+            for kind, find in ((L.KIND_SURF, m.find_corresponding_surf_features), (L.KIND_EDGE, m.find_corresponding_corner_features)):
+                m.set_queries(0, kind, q_local)
+                n = find(0, q_true, t_true)
+                idx, d2 = m.neighbors(0, kind, n_q)
+                out[kind] = (n, idx, d2)
+            rec = m.surf_records(0, n_q)
+            results[name] = (out, rec)
+    finally:
+        os.environ.pop("LILI_DEBUG", None)
+        gpu_ctx.set_option("map_guess_box", 1)
+        gpu_ctx.set_debug(False)
+        L.ScanToMapMatcher(gpu_ctx, P).map_focus(None)
+    gate = 1.0
+    inside = want_d2[:, 4] < gate
+    inside[460] = False
+    assert inside.sum() > 1300 and (~inside).sum() > 10
+    for name, (out, rec) in results.items():
+        for kind in (L.KIND_SURF, L.KIND_EDGE):
+            n, idx, d2 = out[kind]
+            assert np.array_equal(idx[inside], want_idx[inside]), (name, kind, np.nonzero((idx != want_idx).any(1) & inside)[0][:10])
+            assert np.array_equal(d2[inside], want_d2[inside]), (name, kind)
+            assert (idx[460] == -1).all()
+    base_out, base_rec = results["whole"]
+    for name in ("focus", "exact"):
+        out, rec = results[name]
+        for kind in (L.KIND_SURF, L.KIND_EDGE):
+            assert out[kind][0] == base_out[kind][0], (name, kind)
+        for k in ("query_index", "n", "d", "score"):
+            assert np.array_equal(rec[k], base_rec[k]), (name, k)

@@ -1,0 +1,19 @@
+"""Per-launch means of the PMC passes of tools/pmc_2b.sh, split by phase of tools/dense_2b_probe.py: the launches of outer iteration 0 (far from converged: the
+fine index leaves a share of the queries unsettled) and those of iterations 1.. (all settled).  Rows are in dispatch order; the probe issues 7 association launches
+per iteration (1 with neighbour debug rows + 1 + 5)."""
+import csv, glob, sys, collections, json
+d = sys.argv[1]
+out = {}
+for path in sorted(glob.glob(d + "/p*_counter_collection.csv")):
+    per = collections.defaultdict(lambda: collections.defaultdict(list))       # kernel -> counter -> values in dispatch order
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if k.startswith("lili::k_associate"):
+            per[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, cs in per.items():
+        for c, v in cs.items():
+            n_it = 7
+            first = v[1:n_it]              # iteration 0 without the debug launch
+            rest = [x for i in range(1, 10) for x in v[i * n_it + 1:(i + 1) * n_it]]
+            out.setdefault(k, {})[c] = {"iteration0": round(sum(first) / max(len(first), 1), 1), "settled": round(sum(rest) / max(len(rest), 1), 1), "launches": len(v)}
+print(json.dumps(out, indent=1))
