@@ -135,7 +135,22 @@ def cpu_baseline(w, queries, t0, q0):
     except Exception as e:      # noqa: BLE001
         ref = dict(error=repr(e))
     med = rates[len(rates) // 2]
-    return dict(value=round(med, 3), unit="scan-to-map iterations/s", cores=n_threads, kind="port",
+    host_logical = os.cpu_count() or 0
+    try:      # physical cores of the first socket, whether this process may run on them or not
+        socket_cores = len({open(f"/sys/devices/system/cpu/{d}/topology/core_id").read().strip() for d in os.listdir("/sys/devices/system/cpu")
+                            if d[3:].isdigit() and d.startswith("cpu") and os.path.exists(f"/sys/devices/system/cpu/{d}/topology/physical_package_id")
+                            and open(f"/sys/devices/system/cpu/{d}/topology/physical_package_id").read().strip() == "0"})
+    except Exception:   # noqa: BLE001
+        socket_cores = 0
+    eff = med * it1 / n_threads
+    extrap = None
+    if socket_cores > n_threads:      # say what a whole socket would give if it kept this efficiency (upper) or lost a third of it (lower) — not measured
+        extrap = dict(socket_physical_cores=socket_cores, iterations_per_s_range=[round(socket_cores / it1 * eff * 0.67, 1), round(socket_cores / it1 * eff, 1)],
+                      note="extrapolation: (cores of one socket) x (single-thread rate) x (measured parallel efficiency, and 2/3 of it); the container cannot run more threads than its quota")
+    return dict(value=round(med, 3), unit="scan-to-map iterations/s", cores=n_threads, kind="port", host_logical_cpus=host_logical,
+                cores_note=(f"{n_threads} of the host's {host_logical} logical CPUs: the container's cgroup CPU quota, not a socket — a full-socket figure cannot be measured here"
+                            if quota and quota < host_logical else f"{n_threads} physical cores of one socket"),
+                full_socket_extrapolation=extrap,
                 runs=[round(r, 2) for r in rates], runs_in_order=runs_in_order, pinned=bool(cpus), cpu_quota_cores=quota, single_thread_value=round(1.0 / it1, 3),
                 parallel_efficiency=round(med * it1 / n_threads, 3),
                 kdtree_build_s=round(t_build, 3), reference_1thread=ref,
@@ -833,7 +848,10 @@ def main():
                        "map_index_build_s": round(t_map, 4),
                        "device_preheat_ms": args.preheat_ms, "device_preheat_steps": preheat_steps,
                        "map_focus_m": None if args.no_focus else round(focus_r, 1)},
-            "roofline": roofline,
+            "roofline": (dict(roofline, whole_step_frac=round(roofline["algorithmic_bytes_per_launch"] / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 6),
+                              whole_step_note="algorithmic bytes of one outer iteration's association / ms_per_step: the fraction of the HBM peak the WHOLE step (association + linearise + "
+                                              "reduce + three kernel boundaries) reaches on the same byte count; `frac` is the dominant kernel alone")
+                         if roofline and world == 1 else roofline),
             "final_pose": {"t": [float(x) for x in t_fin], "q": [float(x) for x in q_fin], "gn_status": int(gn_status)},
         }
         failures = []       # parity / solver-status violations: the JSON line is still printed, then the run exits with status 3
@@ -847,6 +865,12 @@ def main():
         extras = dict(weak_extra or {})
         extras.update(replica_extra or {})
         extras.update(gather_extra or {})
+        if world > 1:      # which mode a SCALE record's `value` has to be read against
+            extras["scaling_modes_note"] = ("`value` is the " + ("STRONG split of ONE 200k-pt scan over the ranks (configs[3]): per-rank work shrinks with N while three dependent "
+                                            "kernel chains per iteration do not, so ~1.1-1.2x at 8 GPUs is the expected ceiling (DESIGN §5)" if args.scaling == "strong" else
+                                            "weak split (one 200k-pt shard per rank)") + "; the modes that scale by construction are printed beside it: replicas_iterations_per_s "
+                                            "(one whole scan per GPU, no collective) and window_gather_slot_iterations_per_s (one full-size keyframe of the sliding window per GPU, one "
+                                            "exchange per iteration)")
         if gather_extra and "window_gather_error" not in gather_extra and (not gather_extra["window_gather_poses_bit_identical_on_all_ranks"] or gather_extra["window_gather_max_gn_status"] != 0):
             failures.append(f"window_gather {gather_extra}")
         if regions:

@@ -110,11 +110,19 @@ public:
     // K x 72 doubles, identical bits on every rank, so the ranks' solvers take identical steps.  allreduce / comm: lili_p2p_allreduce + the
     // lili_p2p*, or ncclAllReduce + the ncclComm_t; d_gram: device buffer of K x LILI_GRAM_DOUBLES doubles owned by the caller.  Call
     // lili_s2m_counts_window_sharded after the associations (ROT flavour) before the solve.
-    void shard_over_ranks(lili_allreduce_fn allreduce, void* comm, double* d_gram) { allreduce_ = allreduce; comm_ = comm; d_gram_ = d_gram; }
+    void shard_over_ranks(lili_allreduce_fn allreduce, void* comm, double* d_gram) { allreduce_ = allreduce; comm_ = comm; d_gram_ = d_gram; owner_.clear(); }
+    // The window with ONE WHOLE keyframe per rank (the split that scales, lili_hip.h "slot-per-rank window"): slot k lives on rank owner[k] with all its features, the
+    // other ranks hold only its pose.  Evaluate becomes ONE lili_s2m_linearize_window_gather_at — every owner linearises its keyframe at the solver's parameter values,
+    // one exchange of K x 72 doubles in which every record has a single contributor, identical bits on every rank.  No count exchange (the owner's count is the global one).
+    void gather_over_ranks(lili_allreduce_fn allreduce, void* comm, double* d_gram, const std::vector<int>& owner, int rank) {
+        allreduce_ = allreduce; comm_ = comm; d_gram_ = d_gram; owner_ = owner; rank_ = rank;
+    }
 
 private:
     int linearize(const std::vector<double>& t, const std::vector<double>& q, std::vector<double>& gram, std::vector<double>& cost) const {
         const int K = (int)slots_.size();
+        if (d_gram_ && (int)owner_.size() == K)
+            return lili_s2m_linearize_window_gather_at(ctx_, slots_.data(), K, mask_, t.data(), q.data(), &params_, owner_.data(), rank_, allreduce_, comm_, d_gram_, gram.data(), cost.data(), nullptr);
         if (d_gram_) return lili_s2m_linearize_window_sharded(ctx_, slots_.data(), K, mask_, t.data(), q.data(), &params_, allreduce_, comm_, d_gram_, gram.data(), cost.data(), nullptr);
         return lili_s2m_linearize_window(ctx_, slots_.data(), K, mask_, t.data(), q.data(), &params_, gram.data(), cost.data(), nullptr);
     }
@@ -125,6 +133,8 @@ private:
     lili_allreduce_fn allreduce_ = nullptr;
     void* comm_ = nullptr;
     double* d_gram_ = nullptr;
+    std::vector<int> owner_;
+    int rank_ = 0;
 };
 
 }  // namespace lili

@@ -293,17 +293,28 @@ typedef struct lili_frontend_options {
  *            receives an EMPTY keyframe (surf_frames[0] is the not-yet-filled surf_last_ds);
  *   frame 1 (pose_cloud_frame holds one pose): LILI_FRAME_SELF_MAP — the local map is the frame's own surf features (L:286-289), n_iters = 8 (L:501-502);
  *   later frames: flags = 0, n_iters = scan_match_cnt. */
-enum { LILI_FRAME_SELF_MAP = 1, LILI_FRAME_PUSH_EMPTY = 2 };
+enum { LILI_FRAME_SELF_MAP = 1, LILI_FRAME_PUSH_EMPTY = 2,
+       /* round 6 — the frame call for a caller that keeps its own maps (the BACK end's matcher on one scan: BASELINE configs[0]):
+        *   LILI_FRAME_EXTERNAL_MAP  match against the index(es) the caller set with lili_map_set; nothing joins the ring, no local map is built;
+        *   LILI_FRAME_EDGES         (with EXTERNAL_MAP) the edge features are queries too (kind mask surf | edge, findCorrespondingCornerFeatures);
+        *   leaf_query = 0           (with EXTERNAL_MAP) the surf features themselves are the queries (no down_size_filter_surf). */
+       LILI_FRAME_EXTERNAL_MAP = 4, LILI_FRAME_EDGES = 8 };
 typedef struct lili_frontend_result {
     double t[3], q[4];
     int gn_status;      /* of the last update; 0 when the frame was not matched */
     int matched;        /* 0: first frame of a sequence, or a map of fewer than 10 points (L:485-488): pose = prediction */
-    int32_t n_edge, n_surf, n_query, n_map_raw, n_map;   /* features, down-sampled queries; ring points and map points of the map built in this call (0 when none was pending) */
+    int32_t n_edge, n_surf, n_query, n_map_raw, n_map;   /* features, down-sampled queries; ring points and map points of the map the frame was MATCHED AGAINST (whichever call built it;
+                                                          * a LILI_FRAME_SELF_MAP frame: its own features and their filtered cloud; LILI_FRAME_EXTERNAL_MAP: the caller's map, twice) */
     double stage_us[8];
 } lili_frontend_result;
 int lili_frontend_frame(lili_ctx* ctx, const lili_cloud* scan, int curvature_offset, const double q_imu[4], const lili_livox_params* livox,
                         const lili_s2m_params* match, const lili_frontend_options* opt, const double t_pred[3], const double q_pred[4],
                         lili_frontend_result* res);
+/* The same chain behind the LOAM-style extractor of the LiLi-OM-ROT package (scan / q_imu / q_lb / rot: as lili_extract_rot; R/src/Preprocessing.cpp:248-535 in front of
+ * R/src/LidarOdometry.cpp:638-693 — that node is the Livox package's but for the point type).  One call per spinning-LiDAR scan. */
+int lili_frontend_frame_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4], const double q_lb[4], const lili_rot_params* rot,
+                            const lili_s2m_params* match, const lili_frontend_options* opt, const double t_pred[3], const double q_pred[4],
+                            lili_frontend_result* res);
 int lili_frontend_reset(lili_ctx* ctx);
 /* lili_frontend_frame leaves the local map WITH the frame it has just pushed to the next call, which builds it under its own extraction (res->n_map_raw / n_map
  * describe the map the frame was matched against).  lili_frontend_flush builds it now — for a caller that reads the map between frames (lili_localmap_get,
@@ -492,6 +503,11 @@ int lili_s2m_linearize_window_gather(lili_ctx* ctx, const int* slots, int n_slot
                                      lili_allreduce_fn allreduce, void* comm, double* d_gram);
 int lili_s2m_iterate_window_gather(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, const lili_s2m_params* params, int n_iters, const int* owner, int rank,
                                    lili_allreduce_fn allreduce, void* comm, double* d_gram);
+/* _linearize_ at the body poses (t[3 n], q[4 n]) of the call instead of the device poses, records copied out as lili_s2m_linearize_window returns them (gram 64 n, cost n,
+ * counts 2 n; one synchronisation): one solver evaluation of the slot-per-rank window (ceres::CostFunction::Evaluate of the joint window, L/src/BackendFusion.cpp:919-992;
+ * include/lili_ceres_adapter.h LidarWindowFactor::gather_over_ranks). */
+int lili_s2m_linearize_window_gather_at(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, const double* t, const double* q, const lili_s2m_params* params,
+                                        const int* owner, int rank, lili_allreduce_fn allreduce, void* comm, double* d_gram, double* gram, double* cost, int32_t* counts);
 
 typedef struct lili_p2p lili_p2p;
 int lili_p2p_create(lili_ctx* ctx, int rank, int world, lili_p2p** out);

@@ -44,7 +44,7 @@ class FrontendOptions(C.Structure):
     _fields_ = [("leaf_query", C.c_float), ("leaf_map", C.c_float), ("width", C.c_int), ("n_iters", C.c_int), ("slot", C.c_int), ("want_timing", C.c_int), ("flags", C.c_int)]
 
 
-FRAME_SELF_MAP, FRAME_PUSH_EMPTY = 1, 2
+FRAME_SELF_MAP, FRAME_PUSH_EMPTY, FRAME_EXTERNAL_MAP, FRAME_EDGES = 1, 2, 4, 8
 
 
 class FrontendResult(C.Structure):
@@ -141,6 +141,8 @@ _SIGS = {
     "lili_extract_livox_device": (C.c_int, [C.c_void_p, C.POINTER(Cloud), C.POINTER(Cloud)]),
     "lili_frontend_frame": (C.c_int, [C.c_void_p, C.POINTER(Cloud), C.c_int, C.c_void_p, C.POINTER(LivoxParams), C.POINTER(S2MParams), C.POINTER(FrontendOptions), C.c_void_p, C.c_void_p,
                                       C.POINTER(FrontendResult)]),
+    "lili_frontend_frame_rot": (C.c_int, [C.c_void_p, C.POINTER(Cloud), C.c_void_p, C.c_void_p, C.POINTER(RotParams), C.POINTER(S2MParams), C.POINTER(FrontendOptions), C.c_void_p, C.c_void_p,
+                                          C.POINTER(FrontendResult)]),
     "lili_frontend_reset": (C.c_int, [C.c_void_p]),
     "lili_frontend_flush": (C.c_int, [C.c_void_p, C.POINTER(S2MParams), C.POINTER(FrontendOptions), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "lili_voxel_filter": (C.c_int, [C.c_void_p, C.POINTER(Cloud), C.c_float, C.POINTER(FeatureOut), C.c_void_p]),
@@ -190,6 +192,8 @@ _SIGS = {
                                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lili_s2m_iterate_window_sharded": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(S2MParams), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lili_s2m_linearize_window_gather": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(S2MParams), C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "lili_s2m_linearize_window_gather_at": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(S2MParams), C.POINTER(C.c_int), C.c_int,
+                                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lili_s2m_iterate_window_gather": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(S2MParams), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "lili_host_alloc": (C.c_void_p, [C.c_size_t]),
     "lili_host_free": (None, [C.c_void_p]),
@@ -522,6 +526,16 @@ class ScanToMapMatcher:
         arr, own = (C.c_int * len(slots))(*slots), (C.c_int * len(slots))(*owner)
         self.ctx._chk(self.lib.lili_s2m_linearize_window_gather(self.ctx.h, arr, len(slots), kind_mask, C.byref(self.params), own, int(rank), allreduce_fn, comm, d_gram_ptr))
 
+    def linearize_window_gather_at(self, slots, ts, qs, owner, rank, d_gram_ptr, allreduce_fn=None, comm=None, kind_mask=MASK_SURF | MASK_EDGE):
+        """One solver evaluation of the slot-per-rank window at the body poses (ts[k], qs[k]): [(gram 8x8, cost, counts)] per slot, the same bits on every rank."""
+        n = len(slots)
+        arr, own = (C.c_int * n)(*slots), (C.c_int * n)(*owner)
+        t = np.ascontiguousarray(np.asarray(ts, np.float64).reshape(n, 3)); q = np.ascontiguousarray(np.asarray(qs, np.float64).reshape(n, 4))
+        G = np.zeros((n, 64)); cost = np.zeros(n); cnt = np.zeros((n, 2), np.int32)
+        self.ctx._chk(self.lib.lili_s2m_linearize_window_gather_at(self.ctx.h, arr, n, kind_mask, _ptr(t), _ptr(q), C.byref(self.params), own, int(rank), allreduce_fn, comm,
+                                                                   d_gram_ptr, _ptr(G), _ptr(cost), _ptr(cnt)))
+        return [(G[i].reshape(8, 8), float(cost[i]), cnt[i].copy()) for i in range(n)]
+
     def iterate_window_gather(self, slots, n_iters, owner, rank, d_gram_ptr, allreduce_fn=None, comm=None, kind_mask=MASK_SURF | MASK_EDGE):
         arr, own = (C.c_int * len(slots))(*slots), (C.c_int * len(slots))(*owner)
         self.ctx._chk(self.lib.lili_s2m_iterate_window_gather(self.ctx.h, arr, len(slots), kind_mask, C.byref(self.params), int(n_iters), own, int(rank), allreduce_fn, comm,
@@ -824,6 +838,48 @@ class FrontendOdometry:
         t, q = np.array(r.t[:], np.float64), np.array(r.q[:], np.float64)
         if q[0] < 0:
             q = -q                    # unifyQuaternion (L:538-548)
+        return t, q, info
+
+
+class RotFrontendOdometry(FrontendOdometry):
+    """The same node behind the LOAM-style extractor of LiLi-OM-ROT (R/src/Preprocessing.cpp:248-535 + R/src/LidarOdometry.cpp:638-693): one lili_frontend_frame_rot call
+    per spinning-LiDAR scan.  external_map = True: the call for a caller that keeps its own maps (the back end's matcher on one scan, BASELINE configs[0]) — the scan is
+    matched against the indices set with ScanToMapMatcher.set_input_cloud, nothing joins the ring; edges = True: the edge features are queries too; leaf_query = 0: the
+    surf features themselves are the queries."""
+
+    def __init__(self, ctx, params=None, n_scans=64, ds_rate=4, ds_v=0.6, near_range=3.0, q_lb=(1.0, 0, 0, 0), leaf_query=0.4, leaf_map=0.4, width=20, slot=0,
+                 scan_match_cnt=6, first_match_cnt=8, reference_startup=True, external_map=False, edges=False):
+        super().__init__(ctx, params, leaf_query=leaf_query, leaf_map=leaf_map, width=width, slot=slot, scan_match_cnt=scan_match_cnt, first_match_cnt=first_match_cnt,
+                         reference_startup=reference_startup)
+        self.rot = RotParams(n_scans, ds_rate, ds_v, near_range)
+        self.q_lb = _f64(q_lb, 4)
+        self.base_flags = (FRAME_EXTERNAL_MAP if external_map else 0) | (FRAME_EDGES if edges else 0)
+
+    def frame(self, scan, t_pred, q_pred, q_imu=(1.0, 0, 0, 0), timing=False):
+        """scan: (n,4) float32 rows x, y, z, intensity (host) or a Cloud (e.g. a device float4 array).  Returns (t, q, info)."""
+        if isinstance(scan, Cloud):
+            cloud = scan
+        else:
+            n = scan.shape[0]
+            cloud = Cloud(scan.ctypes.data if n else None, n, 16, 12, MEM_HOST)
+        k = self.n_frames
+        if self.base_flags & FRAME_EXTERNAL_MAP:
+            self.opt.n_iters, self.opt.flags = self.scan_match_cnt, self.base_flags
+        else:
+            self.opt.n_iters = 0 if k == 0 else (self.first_match_cnt if k == 1 else self.scan_match_cnt)
+            self.opt.flags = (FRAME_PUSH_EMPTY if k == 0 else (FRAME_SELF_MAP if k == 1 else 0)) if self.reference_startup else 0
+        self.opt.want_timing = 1 if timing else 0
+        qi, tp, qp = _f64(q_imu, 4), _f64(t_pred, 3), _f64(q_pred, 4)
+        r = self.res
+        self.ctx._chk(self.lib.lili_frontend_frame_rot(self.ctx.h, C.byref(cloud), _ptr(qi), _ptr(self.q_lb), C.byref(self.rot), C.byref(self.params), C.byref(self.opt),
+                                                       _ptr(tp), _ptr(qp), C.byref(r)))
+        self.n_frames += 1
+        info = dict(gn_status=r.gn_status, matched=bool(r.matched), n_edge=r.n_edge, n_surf=r.n_surf, n_query=r.n_query, n_map_raw=r.n_map_raw, n_map=r.n_map)
+        if timing:
+            info["stage_us"] = [r.stage_us[j] for j in range(4)]
+        t, q = np.array(r.t[:], np.float64), np.array(r.q[:], np.float64)
+        if q[0] < 0:
+            q = -q                    # unifyQuaternion (R/src/LidarOdometry.cpp:524-534)
         return t, q, info
 
 

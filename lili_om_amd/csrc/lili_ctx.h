@@ -168,6 +168,7 @@ struct lili_ctx {
                                       // Measured (tools/iter_time.py, profiles/r03_iter_time.json): 21.3 vs 19.6 us per outer iteration at 2 k queries (ROT), 17.2 vs 14.9
                                       // (front end) — two exchange hops through memory across the XCDs cost more than the launch boundaries they replace; off by default
     bool frontend_commit_pending = false;   // lili_frontend_frame: the ring has a keyframe the local map does not hold yet (the commit runs at the start of the next frame, under its extraction)
+    int32_t frontend_map_raw = 0;          // ring points of the local map the front-end frames are matched against (the last commit's)
     bool voxel_guess_bits = true;      // a VoxelGrid of more than 8192 points keeps its bounding box on the device and guesses its key bits from the previous filter (k_vox_key_dev; 0: measured, A/B)
     bool hook_box_words_zero = false;      // valid inside pre_sync_hook: the first words of ctx->misc are still zero from the build's scratch fill
     std::function<int()> pre_sync_hook;      // one-shot: called by the next map build right before its read-back synchronises, so that the caller's launches and read-backs share that synchronisation (lili_pipeline.hip)
@@ -229,3 +230,5 @@ int lili_localmap_ring_size(lili_ctx* ctx, int kind);
 // lili_extract_livox.hip -> lili_pipeline.hip: the extraction enqueued without its synchronisation, and the counts taken afterwards
 int lili_extract_livox_enqueue(lili_ctx* ctx, const lili_cloud* scan, int curvature_offset, const double q_imu[4], const lili_livox_params* params);
 int lili_extract_livox_complete(lili_ctx* ctx);
+int lili_extract_rot_enqueue(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4], const double q_lb[4], const lili_rot_params* params);
+int lili_extract_rot_complete(lili_ctx* ctx);

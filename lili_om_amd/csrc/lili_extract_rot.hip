@@ -1362,6 +1362,9 @@ struct RotBuffers {
     lili::RotState* h_state_dev = nullptr;
     int n_in = 0;
     bool have = false;
+    // an extraction that has been enqueued but not completed (lili_extract_rot_enqueue / _complete: the front-end frame pipeline overlaps its kernels with the local map's)
+    struct Pending { bool on = false; lili_rot_params params{}; double q_imu[4] = {1, 0, 0, 0}, q_lb[4] = {1, 0, 0, 0}; lili::RotRingScratch X{}; bool full_early = false, sent_edge = false, sent_surf = false;
+                     unsigned long long gen = 0; } pend;
     void release() {
         for (DevBuf* b : {&in, &scan_id, &ori_raw, &block_hist, &block_half, &state, &full, &full_src, &curv, &label, &sort_ind, &vkey, &seg_out, &ring_ncand, &sorted_k, &sorted_vox,
                           &sorted_len, &big_mark, &big_vidx, &big_ord_a, &big_ord_b, &big_rcnt, &ring_edge, &ring_sharp, &ring_flat,
@@ -1390,8 +1393,11 @@ static int copy_out_f4(lili_ctx* ctx, const lili_feature_out* o, const float4* d
 
 extern "C" {
 
-int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4], const double q_lb[4], const lili_rot_params* params,
-                     lili_feature_out* full, lili_feature_out* edge, lili_feature_out* surf) {
+// The extraction up to (not including) its synchronisation: every kernel of the first pass is on the context's stream, the state travels to the page-locked mirror
+// with the concatenation kernel.  rot_complete takes the counts (and runs the rare second passes).  `side`: the side stream a copy into the caller's full-cloud
+// buffer was started on (the caller of this function drains it on every exit), or nullptr.
+static int rot_enqueue(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4], const double q_lb[4], const lili_rot_params* params,
+                       lili_feature_out* full, lili_feature_out* edge, lili_feature_out* surf, hipStream_t* side) {
     if (!ctx) return LILI_E_ARG;
     ARGCHK(scan && q_imu && q_lb && params, "extract_rot: null argument");
     ARGCHK(params->n_scans == 16 || params->n_scans == 32 || params->n_scans == 64, "extract_rot: n_scans must be 16, 32 or 64");
@@ -1403,9 +1409,6 @@ int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4
     R->have = false;
     bool full_early = false;      // the full cloud's copy to the host was started behind k_rot_scatter (see there)
     bool sent_edge = false, sent_surf = false;      // the feature lists already lie in the caller's (page-locked) buffers
-    // Whatever way this call ends, no DMA into the caller's buffer may outlive it (ADVICE r3): every return between the early copy and its join —
-    // a HIP error, a failed read-back, the second passes — drains the side stream first.
-    struct DrainSide { hipStream_t s = nullptr; ~DrainSide() { if (s) (void)hipStreamSynchronize(s); } } drain_side;
     // a scan that is already in HBM as float4 rows is read in place (no staging copy, one launch less)
     const bool in_place = scan->mem == LILI_MEM_DEVICE && scan->stride == sizeof(float4) && scan->aux_offset == 12 && (reinterpret_cast<uintptr_t>(scan->data) & 15) == 0;
     int rc = in_place ? LILI_OK : lili_ingest_cloud(ctx, scan, R->in);
@@ -1460,7 +1463,7 @@ int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4
             HIPCHK(hipStreamWaitEvent(ctx->side[1], ctx->fork_ev, 0));
             // (the runtime's copy: a thin copy kernel of the library's own was measured 21 us per call slower)
             HIPCHK(hipMemcpyAsync(full->data, R->full.as<float4>(), std::min((size_t)n, full->capacity) * sizeof(float4), hipMemcpyDeviceToHost, ctx->side[1]));
-            drain_side.s = ctx->side[1];
+            *side = ctx->side[1];
             HIPCHK(hipEventRecord(ctx->join_ev[1], ctx->side[1]));
             full_early = true;
         }
@@ -1490,8 +1493,27 @@ int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4
         }
         if (full_early) HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->join_ev[1], 0));      // the read-back's synchronisation then also covers the side stream's copy
     }
+    R->pend.on = true; R->pend.params = *params; R->pend.X = X; R->pend.full_early = full_early; R->pend.sent_edge = sent_edge; R->pend.sent_surf = sent_surf;
+    for (int i = 0; i < 4; i++) { R->pend.q_imu[i] = q_imu[i]; R->pend.q_lb[i] = q_lb[i]; }
+    R->pend.gen = ctx->readback_gen;
+    return LILI_OK;
+}
+
+// `synced`: the context's stream has been synchronised since rot_enqueue (the state lies in the page-locked mirror already)
+static int rot_complete(lili_ctx* ctx, lili_feature_out* full, lili_feature_out* edge, lili_feature_out* surf, bool synced) {
+    auto* R = rot_of(ctx);
+    if (!R->pend.on) return ctx->fail(LILI_E_STATE, "extract_rot: nothing enqueued");
+    R->pend.on = false;
+    const int n = R->n_in;
+    const lili_rot_params* params = &R->pend.params;
+    const double* q_imu = R->pend.q_imu; const double* q_lb = R->pend.q_lb;
+    RotRingScratch X = R->pend.X;
+    const bool full_early = R->pend.full_early;
+    bool sent_edge = R->pend.sent_edge, sent_surf = R->pend.sent_surf;
+    RotState* st = R->state.as<RotState>();
+    int rc = LILI_OK;
     if (n > 0 && R->h_state_dev) {          // the state came with the concatenation kernel: wait, read it where it landed
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (!synced) HIPCHK(hipStreamSynchronize(ctx->stream));
         std::memcpy(&R->host, R->h_state, sizeof(RotState));
     } else { int rb = lili_readback_add(ctx, &R->host, st, sizeof(RotState)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }
     if (n == 0) { R->host.first_valid = R->host.half_idx = 0x7fffffff; R->host.last_valid = -1; }
@@ -1545,9 +1567,36 @@ int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4
     if (edge) { edge->count = (size_t)R->host.n_edge; if (!sent_edge && edge->data && edge->count && edge->capacity) { rc = copy_out_f4(ctx, edge, R->edge_pts.as<float4>(), edge->count); if (rc) return rc; more = true; } }
     if (surf) { surf->count = (size_t)R->host.n_surf; if (!sent_surf && surf->data && surf->count && surf->capacity) { rc = copy_out_f4(ctx, surf, R->surf.as<float4>(), surf->count); if (rc) return rc; more = true; } }
     if (more) HIPCHK(hipStreamSynchronize(ctx->stream));
-    drain_side.s = nullptr;          // joined into the context's stream before the state's read-back and drained with it
     return LILI_OK;
 }
+
+
+int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4], const double q_lb[4], const lili_rot_params* params,
+                     lili_feature_out* full, lili_feature_out* edge, lili_feature_out* surf) {
+    if (!ctx) return LILI_E_ARG;
+    // Whatever way this call ends, no DMA into the caller's buffer may outlive it (ADVICE r3): every return between the early copy and its join —
+    // a HIP error, a failed read-back, the second passes — drains the side stream first.
+    struct DrainSide { hipStream_t s = nullptr; ~DrainSide() { if (s) (void)hipStreamSynchronize(s); } } drain_side;
+    int rc = rot_enqueue(ctx, scan, q_imu, q_lb, params, full, edge, surf, &drain_side.s);
+    if (rc != LILI_OK) return rc;
+    rc = rot_complete(ctx, full, edge, surf, false);
+    if (rc == LILI_OK) drain_side.s = nullptr;          // joined into the context's stream before the state's read-back and drained with it
+    return rc;
+}
+}  // extern "C"
+// lili_pipeline.hip: the extraction without outputs and without its synchronisation; the counts afterwards (no wait of its own if a read-back has synchronised the
+// context's stream in between)
+int lili_extract_rot_enqueue(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4], const double q_lb[4], const lili_rot_params* params) {
+    if (!ctx) return LILI_E_ARG;
+    hipStream_t side = nullptr;
+    return rot_enqueue(ctx, scan, q_imu, q_lb, params, nullptr, nullptr, nullptr, &side);
+}
+int lili_extract_rot_complete(lili_ctx* ctx) {
+    if (!ctx) return LILI_E_ARG;
+    auto* R = rot_of(ctx);
+    return rot_complete(ctx, nullptr, nullptr, nullptr, R->pend.on && ctx->readback_gen != R->pend.gen);
+}
+extern "C" {
 
 // Intermediate products of the last lili_extract_rot (parity tests / debugging).  Any pointer may be NULL.
 int lili_extract_rot_debug(lili_ctx* ctx, int32_t counts[8], int32_t* ring_start, int32_t* ring_end, int32_t* full_src, float* curvature, int32_t* label,

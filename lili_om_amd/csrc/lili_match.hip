@@ -1357,10 +1357,11 @@ int lili_s2m_iterate_window_sharded(lili_ctx* ctx, const int* slots, int n_slots
 // Counts need no exchange: the owner's count IS the global one (ROT residual scale, R/src/BackendFusion.cpp:843,861).  The latency floor of an iteration is the one of a
 // single full-size keyframe (the query-sharded modes shrink the association's throughput part but keep its latency chain — DESIGN §5), and K keyframes advance on K ranks.
 static int window_gather_impl(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, const lili_s2m_params* params, const int* owner, int rank,
-                              lili_allreduce_fn allreduce, void* comm, double* d_gram, int do_gn) {
+                              lili_allreduce_fn allreduce, void* comm, double* d_gram, int do_gn, const double* t = nullptr, const double* q = nullptr /* body poses of ALL slots (else the device poses) */) {
     ARGCHK(slots && n_slots >= 1 && n_slots <= LILI_MAX_SLOTS, "window_gather: 1..LILI_MAX_SLOTS slots");
     ARGCHK((kind_mask & ~3) == 0 && kind_mask != 0 && owner && rank >= 0, "window_gather: bad argument");
     int mine[LILI_MAX_SLOTS], n_mine = 0;
+    double t_mine[3 * LILI_MAX_SLOTS], q_mine[4 * LILI_MAX_SLOTS];
     WindowArgs w{};
     w.n = n_slots;
     for (int i = 0; i < n_slots; i++) {
@@ -1368,6 +1369,7 @@ static int window_gather_impl(lili_ctx* ctx, const int* slots, int n_slots, int 
         for (int k = 0; k < i; k++) ARGCHK(slots[k] != slots[i], "window_gather: duplicate slot");
         w.s[i].state = ctx->state(slots[i]);
         if (owner[i] != rank) continue;             // a zero record from this rank: no partials (k_window_reduce sums nothing)
+        if (t && q) { for (int k = 0; k < 3; k++) t_mine[3 * n_mine + k] = t[3 * i + k]; for (int k = 0; k < 4; k++) q_mine[4 * n_mine + k] = q[4 * i + k]; }
         mine[n_mine++] = slots[i];
         Slot& sl = ctx->slots[slots[i]];
         sl.use_global_counts = false; sl.sticky_global_counts = false;
@@ -1383,7 +1385,7 @@ static int window_gather_impl(lili_ctx* ctx, const int* slots, int n_slots, int 
     if (!p2p_comm(ctx, allreduce, comm, &p2p)) return ctx->fail(LILI_E_STATE, "window_gather: the lili_p2p communicator has failed");
     MatchParams P = to_device_params(params);
     if (do_gn) P.no_cost = 1;
-    if (n_mine > 0) { const int rc = launch_linearize_window(ctx, mine, n_mine, kind_mask, nullptr, nullptr, P); if (rc != LILI_OK) return rc; }
+    if (n_mine > 0) { const int rc = launch_linearize_window(ctx, mine, n_mine, kind_mask, t && q ? t_mine : nullptr, t && q ? q_mine : nullptr, P); if (rc != LILI_OK) return rc; }
     const bool in_kernel = p2p != nullptr || allreduce == nullptr;
     hipLaunchKernelGGL(k_window_reduce, dim3(1), dim3(1024), 0, ctx->stream, w, d_gram, (do_gn && in_kernel) ? 1 : 0, p2p ? lili_p2p_next_view(p2p) : P2PView{});
     HIPCHK(hipGetLastError());
@@ -1400,6 +1402,26 @@ int lili_s2m_linearize_window_gather(lili_ctx* ctx, const int* slots, int n_slot
     ARGCHK(params && d_gram, "linearize_window_gather: null argument");
     HIPCHK(hipSetDevice(ctx->device));
     return window_gather_impl(ctx, slots, n_slots, kind_mask, params, owner, rank, allreduce, comm, d_gram, 0);
+}
+// The evaluation a host solver asks for (Ceres' Evaluate at ITS parameter values, include/lili_ceres_adapter.h LidarWindowFactor::gather_over_ranks): the owned keyframes
+// are linearised at the body poses (t, q) of the call, the records exchanged and copied out — what lili_s2m_linearize_window_sharded is for the query-sharded window.
+int lili_s2m_linearize_window_gather_at(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, const double* t, const double* q, const lili_s2m_params* params,
+                                        const int* owner, int rank, lili_allreduce_fn allreduce, void* comm, double* d_gram, double* gram, double* cost, int* counts) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(t && q && params && d_gram && gram, "linearize_window_gather_at: null argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    int rc = window_gather_impl(ctx, slots, n_slots, kind_mask, params, owner, rank, allreduce, comm, d_gram, 0, t, q);
+    if (rc != LILI_OK) return rc;
+    { const int rc_h = ensure_h_records(ctx); if (rc_h != LILI_OK) return rc_h; }
+    HIPCHK(hipMemcpyAsync(ctx->h_records, d_gram, (size_t)n_slots * LILI_GRAM_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n_slots; i++) {
+        const double* h = ctx->h_records + (size_t)i * LILI_GRAM_DOUBLES;
+        std::memcpy(gram + (size_t)64 * i, h, 64 * sizeof(double));
+        if (cost) cost[i] = h[64];
+        if (counts) { counts[2 * i] = (int)h[65]; counts[2 * i + 1] = (int)h[66]; }
+    }
+    return LILI_OK;
 }
 int lili_s2m_iterate_window_gather(lili_ctx* ctx, const int* slots, int n_slots, int kind_mask, const lili_s2m_params* params, int n_iters, const int* owner, int rank,
                                    lili_allreduce_fn allreduce, void* comm, double* d_gram) {

@@ -9,6 +9,7 @@
 // The stages are the library's own entry points; what this file adds is the ORDER (the next frame's local map is built behind this frame's
 // iterations, the ring push reads the pose on the device) and the absence of host copies between them.
 #include <chrono>
+#include <functional>
 
 #include "lili_ctx.h"
 
@@ -44,17 +45,27 @@ int lili_frontend_flush(lili_ctx* ctx, const lili_s2m_params* match, const lili_
     const int rc = lili_localmap_commit(ctx, LILI_KIND_SURF, opt->leaf_map, match->kd_max_radius, &a, &b);
     if (rc != LILI_OK) return rc;
     ctx->frontend_commit_pending = false;
+    ctx->frontend_map_raw = (int32_t)a;
     if (n_map_raw) *n_map_raw = (int32_t)a;
     if (n_map) *n_map = (int32_t)b;
     return LILI_OK;
 }
 
-int lili_frontend_frame(lili_ctx* ctx, const lili_cloud* scan, int curvature_offset, const double q_imu[4], const lili_livox_params* livox,
-                        const lili_s2m_params* match, const lili_frontend_options* opt, const double t_pred[3], const double q_pred[4],
-                        lili_frontend_result* res) {
-    if (!ctx) return LILI_E_ARG;
-    ARGCHK(scan && q_imu && livox && match && opt && t_pred && q_pred && res, "frontend_frame: null argument");
-    ARGCHK(opt->leaf_query > 0 && opt->leaf_map > 0 && opt->width >= 1 && opt->n_iters >= 0 && opt->slot >= 0 && opt->slot < LILI_MAX_SLOTS, "frontend_frame: bad options");
+}  // extern "C"
+
+// What a frame needs from its extractor: the kernels enqueued (no synchronisation), the counts taken afterwards, the feature lists as device clouds.
+struct FrameExtractor {
+    std::function<int()> enqueue, complete;
+    std::function<int(lili_cloud* edge, lili_cloud* surf)> lists;
+};
+static int frame_impl(lili_ctx* ctx, const FrameExtractor& ex, const lili_s2m_params* match, const lili_frontend_options* opt, const double t_pred[3], const double q_pred[4],
+                      lili_frontend_result* res) {
+    ARGCHK(match && opt && t_pred && q_pred && res, "frontend_frame: null argument");
+    ARGCHK(opt->leaf_query >= 0 && opt->leaf_map > 0 && opt->width >= 1 && opt->n_iters >= 0 && opt->slot >= 0 && opt->slot < LILI_MAX_SLOTS, "frontend_frame: bad options");
+    const bool ext_map = (opt->flags & LILI_FRAME_EXTERNAL_MAP) != 0, edges = (opt->flags & LILI_FRAME_EDGES) != 0;
+    ARGCHK(!edges || ext_map, "frontend_frame: LILI_FRAME_EDGES needs LILI_FRAME_EXTERNAL_MAP (the front end keeps a surf ring only)");
+    ARGCHK(!(ext_map && (opt->flags & LILI_FRAME_SELF_MAP)), "frontend_frame: LILI_FRAME_EXTERNAL_MAP and LILI_FRAME_SELF_MAP exclude each other");
+    ARGCHK(opt->leaf_query > 0 || ext_map, "frontend_frame: leaf_query = 0 (the features themselves are the queries) only with LILI_FRAME_EXTERNAL_MAP");
     HIPCHK(hipSetDevice(ctx->device));
     const auto t_begin = std::chrono::steady_clock::now();
     auto stamp = [&](int k) { if (opt->want_timing) res->stage_us[k] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(); };
@@ -65,7 +76,7 @@ int lili_frontend_frame(lili_ctx* ctx, const lili_cloud* scan, int curvature_off
     //      delivers the extraction's counts with its own; behind the index build's kernels — before the build's read-back synchronises — the frame's QUERY filter is
     //      enqueued (down_size_filter_surf, L:320-322, on the extractor's device list, into the filter's second output) so that its voxel count comes back with the
     //      build's density words.  Three synchronisations per frame (ring merge, index build + query filter, pose) where the stages called one by one take five.
-    int rc = lili_extract_livox_enqueue(ctx, scan, curvature_offset, q_imu, livox);
+    int rc = ex.enqueue();
     if (rc != LILI_OK) return rc;
     const bool self_map = (opt->flags & LILI_FRAME_SELF_MAP) != 0;
     lili_cloud d_edge{}, d_surf{};
@@ -73,17 +84,18 @@ int lili_frontend_frame(lili_ctx* ctx, const lili_cloud* scan, int curvature_off
     // extraction's counts -> device lists -> query filter enqueued (no synchronisation of its own unless the counts have not come back yet)
     bool in_hook = false;      // called from inside the index build: its scratch fill has just zeroed the filter's box words
     auto enqueue_query_filter = [&]() -> int {
-        int r = lili_extract_livox_complete(ctx);
+        int r = ex.complete();
         if (r != LILI_OK) return r;
-        r = lili_extract_livox_device(ctx, &d_edge, &d_surf);
+        r = ex.lists(&d_edge, &d_surf);
         if (r != LILI_OK) return r;
         lists = true;
+        if (!(opt->leaf_query > 0)) { filter_enqueued = true; return LILI_OK; }      // the features themselves are the queries
         r = lili_voxel_filter_dev_enqueue(ctx, static_cast<const float4*>(d_surf.data), (int)d_surf.n, opt->leaf_query, in_hook, &filter_pending);
         filter_enqueued = r == LILI_OK;
         return r;
     };
     int64_t n_raw = 0, n_map = 0;
-    if (ctx->frontend_commit_pending && !self_map) {
+    if (ctx->frontend_commit_pending && !self_map && !ext_map) {
         ctx->pre_sync_hook = [&]() -> int { in_hook = ctx->hook_box_words_zero; const int r = enqueue_query_filter(); in_hook = false; return r; };
         rc = lili_localmap_commit(ctx, LILI_KIND_SURF, opt->leaf_map, match->kd_max_radius, &n_raw, &n_map);
         ctx->pre_sync_hook = nullptr;      // (a commit that built no index has not called it)
@@ -98,9 +110,11 @@ int lili_frontend_frame(lili_ctx* ctx, const lili_cloud* scan, int curvature_off
     }
     res->n_edge = (int32_t)d_edge.n; res->n_surf = (int32_t)d_surf.n;
     // ---- the centroids become the frame's queries AND its keyframe
-    const float4* d_q = nullptr; int n_q = 0;
-    rc = lili_voxel_filter_dev_complete(ctx, &d_q, &n_q);
-    if (rc != LILI_OK) return rc;
+    const float4* d_q = static_cast<const float4*>(d_surf.data); int n_q = (int)d_surf.n;
+    if (opt->leaf_query > 0) {
+        rc = lili_voxel_filter_dev_complete(ctx, &d_q, &n_q);
+        if (rc != LILI_OK) return rc;
+    }
     res->n_query = n_q;
     stamp(1);
     if (self_map) {
@@ -120,6 +134,8 @@ int lili_frontend_frame(lili_ctx* ctx, const lili_cloud* scan, int curvature_off
     const lili_cloud qc{d_q, (size_t)n_q, 16, 12, LILI_MEM_DEVICE};
     rc = lili_s2m_set_queries(ctx, slot, LILI_KIND_SURF, &qc);      // device-to-device copy into the slot (the filter's second output is rewritten by the next frame's filter)
     if (rc != LILI_OK) return rc;
+    if (edges) { rc = lili_s2m_set_queries(ctx, slot, LILI_KIND_EDGE, &d_edge); if (rc != LILI_OK) return rc; }
+    const int mask = LILI_MASK_SURF | (edges ? LILI_MASK_EDGE : 0);
     PoseVal pv{};
     for (int i = 0; i < 3; i++) pv.v[i] = t_pred[i];
     for (int i = 0; i < 4; i++) pv.v[3 + i] = q_pred[i];
@@ -127,9 +143,10 @@ int lili_frontend_frame(lili_ctx* ctx, const lili_cloud* scan, int curvature_off
     HIPCHK(hipGetLastError());
     ctx->slots[slot].assoc_since_pose = 0;
     // ---- updateTransformationWithCeres (L:483-561): needs a map of at least 10 points (L:485-488); the first frame of a sequence has none
-    const bool matched = (self_map || lili_localmap_ring_size(ctx, LILI_KIND_SURF) > 0) && ctx->map[LILI_KIND_SURF].valid && ctx->map[LILI_KIND_SURF].n >= 10 && n_q > 0 && opt->n_iters > 0;
+    const bool matched = (self_map || ext_map || lili_localmap_ring_size(ctx, LILI_KIND_SURF) > 0) && ctx->map[LILI_KIND_SURF].valid && ctx->map[LILI_KIND_SURF].n >= 10 && n_q > 0 &&
+                         opt->n_iters > 0 && (!edges || ctx->map[LILI_KIND_EDGE].valid);
     if (matched) {
-        rc = lili_s2m_iterate(ctx, slot, LILI_MASK_SURF, match, opt->n_iters);
+        rc = lili_s2m_iterate(ctx, slot, mask, match, opt->n_iters);
         if (rc != LILI_OK) return rc;
     }
     res->matched = matched ? 1 : 0;
@@ -142,15 +159,49 @@ int lili_frontend_frame(lili_ctx* ctx, const lili_cloud* scan, int curvature_off
     if (rc != LILI_OK) return rc;
     rc = lili_readback_finish(ctx);
     if (rc != LILI_OK) return rc;
-    rc = lili_localmap_push_dev(ctx, LILI_KIND_SURF, ctx->slots[slot].k[LILI_KIND_SURF].q.as<float4>(), (opt->flags & LILI_FRAME_PUSH_EMPTY) ? 0 : n_q, ctx->state(slot), opt->width);
-    if (rc != LILI_OK) return rc;
-    ctx->frontend_commit_pending = true;
+    if (!ext_map) {
+        rc = lili_localmap_push_dev(ctx, LILI_KIND_SURF, ctx->slots[slot].k[LILI_KIND_SURF].q.as<float4>(), (opt->flags & LILI_FRAME_PUSH_EMPTY) ? 0 : n_q, ctx->state(slot), opt->width);
+        if (rc != LILI_OK) return rc;
+        ctx->frontend_commit_pending = true;
+    }
     stamp(3);
     for (int i = 0; i < 3; i++) res->t[i] = st.pose[i];
     for (int i = 0; i < 4; i++) res->q[i] = st.pose[3 + i];
     res->gn_status = matched ? st.gn_status : 0;
-    res->n_map_raw = (int32_t)n_raw; res->n_map = (int32_t)n_map;
+    // the map the frame was matched against (also when it was not built in this call — a self-map frame, a caller's map, a map built by lili_frontend_flush)
+    res->n_map = matched ? (int32_t)ctx->map[LILI_KIND_SURF].n : (int32_t)n_map;
+    if (n_raw) ctx->frontend_map_raw = (int32_t)n_raw; else if (self_map) ctx->frontend_map_raw = (int32_t)d_surf.n;
+    res->n_map_raw = ext_map ? res->n_map : ctx->frontend_map_raw;
     return LILI_OK;
 }
+
+extern "C" {
+
+int lili_frontend_frame(lili_ctx* ctx, const lili_cloud* scan, int curvature_offset, const double q_imu[4], const lili_livox_params* livox,
+                        const lili_s2m_params* match, const lili_frontend_options* opt, const double t_pred[3], const double q_pred[4],
+                        lili_frontend_result* res) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(scan && q_imu && livox, "frontend_frame: null argument");
+    FrameExtractor ex;
+    ex.enqueue = [&]() { return lili_extract_livox_enqueue(ctx, scan, curvature_offset, q_imu, livox); };
+    ex.complete = [&]() { return lili_extract_livox_complete(ctx); };
+    ex.lists = [&](lili_cloud* e, lili_cloud* s) { return lili_extract_livox_device(ctx, e, s); };
+    return frame_impl(ctx, ex, match, opt, t_pred, q_pred, res);
+}
+
+// The same chain behind the LOAM-style extractor of LiLi-OM-ROT (R/src/Preprocessing.cpp:248-535 in front of R/src/LidarOdometry.cpp:638-693 — the ROT package's odometry
+// node is the Livox package's but for the point type: no normals to rotate in transformCloud).
+int lili_frontend_frame_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4], const double q_lb[4], const lili_rot_params* rot,
+                            const lili_s2m_params* match, const lili_frontend_options* opt, const double t_pred[3], const double q_pred[4],
+                            lili_frontend_result* res) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(scan && q_imu && q_lb && rot, "frontend_frame_rot: null argument");
+    FrameExtractor ex;
+    ex.enqueue = [&]() { return lili_extract_rot_enqueue(ctx, scan, q_imu, q_lb, rot); };
+    ex.complete = [&]() { return lili_extract_rot_complete(ctx); };
+    ex.lists = [&](lili_cloud* e, lili_cloud* s) { return lili_extract_rot_device(ctx, nullptr, e, s); };
+    return frame_impl(ctx, ex, match, opt, t_pred, q_pred, res);
+}
+
 
 }  // extern "C"

@@ -165,8 +165,10 @@ class LidarOdometry:
     step (oracle/refshim/ref_lo.cpp).  frame() takes the three clouds of Preprocessing as (n, 12) float32 rows in the
     48-byte PointXYZINormal layout."""
 
-    def __init__(self, params=None, verbose=False):
-        L = self.lib = _lib("lo")
+    def __init__(self, params=None, verbose=False, flavour="livox"):
+        """flavour "rot": LiLi-OM-ROT/src/LidarOdometry.cpp (libref_lo_R.so; rows are 32-byte PointXYZI: 8 floats)."""
+        L = self.lib = _lib("lo_R" if flavour == "rot" else "lo")
+        self.row_floats = int(L.ref_lo_point_floats())
         L.ref_lo_create.restype = C.c_void_p
         L.ref_param_num.argtypes = [C.c_char_p, C.c_double]
         L.ref_param_str.argtypes = [C.c_char_p, C.c_char_p]
@@ -192,7 +194,7 @@ class LidarOdometry:
             self.h = None
 
     def frame(self, stamp, edge12, surf12, full12):
-        a = [np.ascontiguousarray(x, np.float32).reshape(-1, 12) for x in (edge12, surf12, full12)]
+        a = [np.ascontiguousarray(x, np.float32).reshape(-1, self.row_floats) for x in (edge12, surf12, full12)]
         self.lib.ref_lo_frame(self.h, float(stamp), _p(a[0]), a[0].shape[0], _p(a[1]), a[1].shape[0], _p(a[2]), a[2].shape[0])
         ap, rp, kf = np.zeros(7), np.zeros(7), C.c_int(0)
         self.lib.ref_lo_pose(self.h, _p(ap), _p(rp), C.byref(kf))

@@ -19,6 +19,8 @@
 #include <string>
 #include <vector>
 #include "refshim_deps.h"
+// Built twice (oracle/refshim/Makefile): libref_lo.so from LiLi-OM/src/LidarOdometry.cpp (PointType = pcl::PointXYZINormal, 48-byte rows) and, with
+// -DREF_FLAVOUR_ROT, libref_lo_R.so from LiLi-OM-ROT/src/LidarOdometry.cpp (PointType = pcl::PointXYZI, 32-byte rows) — the include path decides which file this is.
 #define private public
 #define main ref_lo_node_main
 #include "src/LidarOdometry.cpp"
@@ -79,7 +81,11 @@ void hook(const ceres::Solver::Options&, ceres::Problem* p, ceres::Solver::Summa
         for (int a = 0; a < 8; a++) for (int c = 0; c < 8; c++) gram[a * 8 + c] += Jr[a] * Jr[c];
     }
     L.map_xyzc = refshim::last_tree_input();
+#ifdef REF_FLAVOUR_ROT
+    if (g_node) for (const auto& pt : g_node->surf_last_ds->points) { const float v[4] = {pt.x, pt.y, pt.z, pt.intensity}; L.queries.insert(L.queries.end(), v, v + 4); }
+#else
     if (g_node) for (const auto& pt : g_node->surf_last_ds->points) { const float v[4] = {pt.x, pt.y, pt.z, pt.curvature}; L.queries.insert(L.queries.end(), v, v + 4); }
+#endif
     L.gn_status = -1;
     if (q && t) {
         for (int k = 0; k < 4; k++) L.pose_in[k] = q[k];
@@ -108,13 +114,19 @@ void* ref_lo_create() {
 }
 void ref_lo_destroy(void* h) { delete (LidarOdometry*)h; g_node = nullptr; }
 
+#ifdef REF_FLAVOUR_ROT
+constexpr uint32_t kStep = 32;      // pcl::PointXYZI
+#else
+constexpr uint32_t kStep = 48;      // pcl::PointXYZINormal
+#endif
+int ref_lo_point_floats() { return (int)(kStep / 4); }
 static std::shared_ptr<sensor_msgs::PointCloud2> msg48(double stamp, const float* rows12, int n) {
     auto m = std::make_shared<sensor_msgs::PointCloud2>();
-    m->header.stamp.t = stamp; m->point_step = 48; m->width = (uint32_t)n; m->row_step = 48u * (uint32_t)n;
-    m->data.assign((const uint8_t*)rows12, (const uint8_t*)rows12 + (size_t)n * 48);
+    m->header.stamp.t = stamp; m->point_step = kStep; m->width = (uint32_t)n; m->row_step = kStep * (uint32_t)n;
+    m->data.assign((const uint8_t*)rows12, (const uint8_t*)rows12 + (size_t)n * kStep);
     return m;
 }
-// One frame = the three clouds Preprocessing publishes (48-byte PointXYZINormal rows), then the node's run().
+// One frame = the three clouds Preprocessing publishes (rows in the node's PointType layout: 48-byte PointXYZINormal, ROT flavour 32-byte PointXYZI), then the node's run().
 void ref_lo_frame(void* h, double stamp, const float* edge, int n_edge, const float* surf, int n_surf, const float* full, int n_full) {
     LidarOdometry* lo = (LidarOdometry*)h;
     lo->laserCloudLessSharpHandler(msg48(stamp, edge, n_edge));

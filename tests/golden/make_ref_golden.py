@@ -169,6 +169,53 @@ def run_frontend(pre_params=None, lo_params=None, full_solves=None):
     return d
 
 
+# ---- the ROT package's odometry node (R/src/LidarOdometry.cpp compiled as is: libref_lo_R.so) behind its own Preprocessing node -> ref_frontend_R.npz (VERDICT r5 #3b)
+FRONTEND_R_PARAMS = {"/common/frame_id": "lili_om_rot", "/lidar_odometry/if_to_deskew": 0, "/lidar_odometry/max_num_iter": 12,       # R/config/config_fr_iosb.yaml:16-18
+                     "/lidar_odometry/scan_match_cnt": 6}
+FRONTEND_R_FRAMES = 6
+
+
+def frontend_rot_inputs():
+    """A 64-ring spinning LiDAR driving through the outdoor scene (0.45 m and 0.6 deg per scan), 500 azimuth steps per revolution, 2 cm range noise; zero-rate gyro."""
+    sc = synth.OutdoorScene()
+    n = FRONTEND_R_FRAMES + 2
+    scans = []
+    for f in range(n):
+        rng = np.random.default_rng(700 + f)
+        yaw = 0.0105 * f
+        origin = np.array([0.45 * f, 3.5 + 0.2 * np.sin(0.3 * f), 1.8])
+        dirs, ring, rel = synth.spinning_rays(500, synth.hdl64_elevations_deg(), az0=0.004 * f)
+        c, s_ = np.cos(yaw), np.sin(yaw)
+        wd = np.stack([c * dirs[:, 0] - s_ * dirs[:, 1], s_ * dirs[:, 0] + c * dirs[:, 1], dirs[:, 2]], 1)
+        t = sc.raycast(origin, wd)
+        ok = np.isfinite(t)
+        t = t + rng.normal(0, 0.02, t.shape)
+        pts = (dirs * t[:, None])[ok].astype(np.float32)
+        scans.append(np.concatenate([pts, np.full((pts.shape[0], 1), 30.0, np.float32)], 1).astype(np.float32))
+    stamps = 300.0 + 0.1 * np.arange(n)
+    imu_t = 299.97 + 0.005 * np.arange(20 * n + 20)
+    return scans, stamps, imu_t, np.zeros((imu_t.shape[0], 3))
+
+
+def run_frontend_rot():
+    scans, stamps, imu_t, gyr = frontend_rot_inputs()
+    pre = R.run_scans("rot", ROT_PARAMS, scans, stamps, imu_t, gyr)
+    lo = R.LidarOdometry(FRONTEND_R_PARAMS, flavour="rot")
+    d = dict(n_frames=len(pre))
+    abs_pose, rel_pose, kf = [], [], []
+    for o in pre:
+        ap, rp, k = lo.frame(o["stamp"], o["edge"], o["surf"], o["cutted"])
+        abs_pose.append(ap); rel_pose.append(rp); kf.append(k)
+    S = lo.solves()
+    d.update(abs_pose=np.array(abs_pose), rel_pose=np.array(rel_pose), kf=np.array(kf), n_solves=len(S),
+             pose_in=np.array([s["pose_in"] for s in S]), pose_out=np.array([s["pose_out"] for s in S]),
+             n_blocks=np.array([len(s["records"]) for s in S]), n_map=np.array([len(s["map"]) for s in S]),
+             n_queries=np.array([len(s["queries"]) for s in S]), gn_status=np.array([s["gn_status"] for s in S]),
+             records_sha=np.array([sha(s["records"]) for s in S]), n_edge=np.array([o["edge"].shape[0] for o in pre]), n_surf=np.array([o["surf"].shape[0] for o in pre]))
+    lo.close()
+    return d
+
+
 BACKEND_PARAMS = {   # L/config/config_fr_iosb.yaml, R/config/config_fr_iosb.yaml (SURVEY App. C): kd_max_radius, surf_dist_thres, lidar_const, reflect_thres, q_lb, t_lb
     "livox": dict(kd_max_radius=1.0, surf_dist_thres=0.12, lidar_const=20.0, reflect_thres=15.0, q_lb=[0.0, 0.0, 0.0, 1.0], t_lb=[-0.0265, 0.0202, 0.05309]),
     "rot": dict(kd_max_radius=1.0, surf_dist_thres=0.12, lidar_const=7.5, reflect_thres=0.0, q_lb=[0.7071, 0.0, 0.0, 0.7071], t_lb=[-0.18, 0.0, -0.095]),
@@ -352,12 +399,13 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ref_livox.npz"), **run_livox())
     np.savez_compressed(os.path.join(HERE, "ref_factors.npz"), **run_factors())
     np.savez_compressed(os.path.join(HERE, "ref_frontend.npz"), **run_frontend())
+    np.savez_compressed(os.path.join(HERE, "ref_frontend_R.npz"), **run_frontend_rot())
     np.savez_compressed(os.path.join(HERE, "ref_backend.npz"), **run_backend())
     np.savez_compressed(os.path.join(HERE, "ref_format.npz"), **run_format())
     np.savez_compressed(os.path.join(HERE, "ref_marg.npz"), **run_marg())
     np.savez_compressed(os.path.join(HERE, "ref_localmap.npz"), **run_localmap())
     np.savez_compressed(os.path.join(HERE, "ref_cfg2.npz"), **run_cfg2())
-    for f in ("ref_cfg2.npz", "ref_rot.npz", "ref_livox.npz", "ref_factors.npz", "ref_frontend.npz", "ref_backend.npz", "ref_format.npz", "ref_marg.npz", "ref_localmap.npz"):
+    for f in ("ref_cfg2.npz", "ref_rot.npz", "ref_livox.npz", "ref_factors.npz", "ref_frontend.npz", "ref_frontend_R.npz", "ref_backend.npz", "ref_format.npz", "ref_marg.npz", "ref_localmap.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
 
 

@@ -73,6 +73,87 @@ def test_frontend_frame_follows_the_reference_node():
         ctx.close()
 
 
+def test_frontend_frame_rot_follows_the_reference_rot_node():
+    """Round 6: raw 64-ring scans in, poses out, ONE lili_frontend_frame_rot call per scan — the poses LiLi-OM-ROT's own odometry node
+    (R/src/LidarOdometry.cpp compiled as is behind R/src/Preprocessing.cpp, tests/golden/ref_frontend_R.npz) held after every frame, within 1e-4 m / 1e-4 rad; feature
+    counts equal the reference node's."""
+    from tests import frontend_chain as F
+    g = np.load(os.path.join(G, "ref_frontend_R.npz"))
+    scans, stamps, imu_t, gyr = M.frontend_rot_inputs()
+    ctx = L.Context(0)
+    try:
+        integ = L.api.ImuIntegrator()
+        odo = L.RotFrontendOdometry(ctx, n_scans=64, ds_rate=4, q_lb=M.ROT_QLB, scan_match_cnt=int(M.FRONTEND_R_PARAMS["/lidar_odometry/scan_match_cnt"]), first_match_cnt=8,
+                                    reference_startup=True)
+        odo.reset()
+        abs_pose = np.array([1.0, 0, 0, 0, 0, 0, 0])
+        rel_pose = np.array([1.0, 0, 0, 0, 0, 0, 0])
+        poses, out_abs, out_rel = [], [], []
+        for k in range(M.FRONTEND_R_FRAMES):
+            q_imu = _q_imu(integ, stamps, imu_t, gyr, k)
+            scan = np.ascontiguousarray(scans[k], np.float32)
+            if k == 0:
+                t, q, info = odo.frame(scan, abs_pose[4:], abs_pose[:4], q_imu)
+                assert not info["matched"]
+            else:
+                q0, t0, dq, dt = abs_pose[:4], abs_pose[4:], rel_pose[:4], rel_pose[4:]
+                t0 = F.eigen_qrot(q0, dt[None, :])[0] + t0      # poseInitialization
+                q0 = F.eigen_qmul(q0, dq)
+                t, q, info = odo.frame(scan, t0, q0, q_imu)
+                assert info["gn_status"] == 0 and info["matched"]
+                abs_pose = np.r_[q, t]
+            assert (info["n_edge"], info["n_surf"]) == (int(g["n_edge"][k]), int(g["n_surf"][k])), (k, info)
+            poses.append(abs_pose.copy())
+            if k > 0:                       # computeRelative
+                q1, t1 = poses[-2][:4], poses[-2][4:]
+                q1i = F.eigen_qinv(q1)
+                rel_pose = np.r_[F.eigen_qmul(q1i, abs_pose[:4]), F.eigen_qrot(q1i, (abs_pose[4:] - t1)[None, :])[0]]
+            out_abs.append(abs_pose.copy()); out_rel.append(rel_pose.copy())
+        a, r = np.array(out_abs), np.array(out_rel)
+        ref = g["abs_pose"]
+        assert np.abs(a[:, 4:] - ref[:, 4:]).max() < 1e-4, np.abs(a[:, 4:] - ref[:, 4:]).max()
+        assert np.abs(a[:, :4] - ref[:, :4]).max() < 5e-5
+        assert np.abs(r - g["rel_pose"]).max() < 1e-4
+        assert np.linalg.norm(a[-1][4:] - a[1][4:]) > 1.5
+        print("lili_frontend_frame_rot vs reference ROT node: max |dt| = %.3g m, max |dq| = %.3g" % (np.abs(a[:, 4:] - ref[:, 4:]).max(), np.abs(a[:, :4] - ref[:, :4]).max()))
+    finally:
+        ctx.close()
+
+
+def test_frontend_frame_rot_with_the_callers_maps_equals_the_separate_calls():
+    """LILI_FRAME_EXTERNAL_MAP | LILI_FRAME_EDGES, leaf_query = 0 (BASELINE configs[0] as ONE call): extraction, both feature kinds as queries, one outer iteration against the
+    caller's surf + edge indices — the pose equals lili_extract_rot -> lili_s2m_set_queries x 2 -> lili_s2m_pose_set -> lili_s2m_iterate bit for bit."""
+    import torch
+    w = synth.make_workload(n_map=200_000, n_az=400, half_extent=(150.0, 150.0), verbose=False)
+    raw = np.concatenate([w["scan_xyz"], np.full((w["scan_xyz"].shape[0], 1), 50.0, np.float32)], 1)
+    P = L.make_params("rot")
+    q_lb = np.array(list(P.q_lb))
+    ctx = L.Context(0)
+    try:
+        m = L.ScanToMapMatcher(ctx, P)
+        m.set_input_cloud(L.KIND_SURF, w["map_xyz"])
+        m.set_input_cloud(L.KIND_EDGE, w["edge_map_xyz"])
+        tb, qb = L.api.body_pose_from_lidar(w["lidar_t"], w["lidar_q"], P)
+        t0, q0 = synth.perturbed_pose(tb, qb, np.random.default_rng(synth.SEED_POSE), 0.2, 1.0)
+        d_raw = torch.from_numpy(raw).cuda()
+        ex = L.RotExtractor(ctx, n_scans=64, ds_rate=4)
+        ex.extract_device(d_raw.data_ptr(), raw.shape[0], (1.0, 0, 0, 0), q_lb)
+        _, d_edge, d_surf = L.api.extract_rot_device(ctx)
+        m.set_queries(0, L.KIND_SURF, d_surf); m.set_queries(0, L.KIND_EDGE, d_edge)
+        m.pose_set(0, t0, q0)
+        m.iterate(0, 2, L.MASK_SURF | L.MASK_EDGE)
+        t_sep, q_sep, st = m.pose_get(0)
+        assert st == 0
+        odo = L.RotFrontendOdometry(ctx, params=P, n_scans=64, ds_rate=4, q_lb=q_lb, leaf_query=0.0, scan_match_cnt=2, external_map=True, edges=True, slot=1)
+        cloud = L.api.cloud_from_device(d_raw.data_ptr(), raw.shape[0], 16, 12)
+        t_one, q_one, info = odo.frame(cloud, t0, q0)
+        assert info["matched"] and info["gn_status"] == 0 and info["n_surf"] == int(d_surf.n) and info["n_edge"] == int(d_edge.n) and info["n_query"] == int(d_surf.n)
+        assert np.array_equal(t_one, t_sep) and np.array_equal(q_one * np.sign(q_one[0]), q_sep * np.sign(q_sep[0]))
+        assert np.linalg.norm(t_one - t0) > 0.01
+    finally:
+        ctx.close()
+
+
 def _circuit(f, radius=4.0, step=0.03):
     a = step * f
     yaw = a + math.pi / 2

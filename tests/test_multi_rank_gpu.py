@@ -396,6 +396,32 @@ def _gather_single_rank():
     return ev, fin
 
 
+def test_window_gather_at_the_solvers_poses_equals_the_plain_window_evaluation():
+    """lili_s2m_linearize_window_gather_at (round 6: what LidarWindowFactor::gather_over_ranks calls per Ceres evaluation): one rank owning every keyframe, no exchange —
+    the records at the poses of the call are those of lili_s2m_linearize_window, bit for bit (a -0.0 entry reads +0.0)."""
+    import torch
+    room, P, poses, sq, eq = _window_scene()
+    ctx = L.Context(0)
+    try:
+        m = _window_setup(ctx, room, P, sq, eq, 1, 0)
+        mask = L.MASK_SURF | L.MASK_EDGE
+        slots = list(range(N_KF))
+        for k in range(N_KF):
+            m.pose_set(k, poses[k][0], poses[k][1])
+            m.associate_dev(k, mask)
+        rng = np.random.default_rng(5)
+        ts = [np.asarray(poses[k][0]) + rng.normal(0, 0.01, 3) for k in range(N_KF)]      # NOT the device poses: the solver's trial point
+        qs = [np.asarray(poses[k][1]) for k in range(N_KF)]
+        want = m.linearize_window(slots, ts, qs, kind_mask=mask)
+        gram = torch.zeros(N_KF * L.api.GRAM_DOUBLES, dtype=torch.float64, device="cuda")
+        got = m.linearize_window_gather_at(slots, ts, qs, [0] * N_KF, 0, gram.data_ptr(), None, None, kind_mask=mask)
+        for (G0, c0, n0), (G1, c1, n1) in zip(want, got):
+            assert np.array_equal(G0 + 0.0, G1 + 0.0) and c0 == c1 and tuple(int(x) for x in n0) == tuple(int(x) for x in n1)
+            assert n0[0] > 100
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("mode,world", [("gloo", 3), ("p2p", 3), ("p2p", 2)])
 def test_slot_per_rank_window_equals_single_rank_window(mode, world):
     import torch.multiprocessing as mp
