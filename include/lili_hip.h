@@ -321,6 +321,38 @@ int lili_frontend_reset(lili_ctx* ctx);
  * lili_map_info) or ends a sequence.  Blocking; n_map_raw / n_map optional. */
 int lili_frontend_flush(lili_ctx* ctx, const lili_s2m_params* match, const lili_frontend_options* opt, int32_t* n_map_raw, int32_t* n_map);
 
+/* ---- back-end keyframe: everything between "a keyframe has arrived" and ceres::Solve in ONE call ---------------- */
+
+/* Replaces, for one keyframe of the reference's back end (L/src/BackendFusion.cpp:830-980):
+ *   buildLocalMapWithLandMark (L:1387-1484, steady state :1444-1476) — the keyframe whose pose the previous solve fixed (`join_*`, its LiDAR pose in the map frame
+ *       t_join / q_join = q_po * q_bl, q_po * t_bl + t_po; NULL: nothing joins, e.g. the first call) is transformed and appended to both rings, the oldest leaves
+ *       beyond opt->width;
+ *   downSampleCloud (L:1486-1519) — both rings -> VoxelGrid(leaf_*_map) -> kd_tree_*_local_map->setInputCloud (L:839-840); the NEW keyframe's features
+ *       (`new_surf`, `new_edge`, LiDAR frame) -> VoxelGrid(leaf_surf / leaf_edge) = surf_lasts_ds / edge_lasts_ds -> the queries of slots[n_slots - 1];
+ *   findCorrespondingCornerFeatures / findCorrespondingSurfFeatures (L:919-936) — every keyframe of the window (slots[i], oldest first; the older slots keep the
+ *       queries earlier calls gave them) at its association pose (t_assoc 3, q_assoc 4 values per slot: q * q_lb^-1, t - Q2 t_lb, L:929-930).
+ * Rings, maps, indices, queries and correspondence records stay in HBM; afterwards the window is ready for lili_s2m_linearize_window (LidarWindowFactor),
+ * lili_s2m_solve_lm_window or lili_marg_add_lidar.  n_res (optional): 2 per slot {surf, edge}.  Records and counts equal the calls one by one
+ * (lili_localmap_push x 2, lili_localmap_commit x 2, lili_voxel_filter x 2, lili_s2m_set_queries x 2, lili_s2m_associate_window) bit for bit. */
+typedef struct lili_backend_options {
+    float leaf_surf, leaf_edge;           /* ds_filter_surf / ds_filter_edge: surf_ds 0.4, edge_ds 0.2 (L/config/config_fr_iosb.yaml:22-23) */
+    float leaf_surf_map, leaf_edge_map;   /* ds_filter_surf_map / ds_filter_edge_map: the same values in the reference (L:491-494) */
+    int width;                            /* local_map_width: 40 (L/config :16) */
+    int want_timing;
+    int join_slot;                        /* >= 0 (and join_surf = join_edge = NULL): the joining keyframe's features are the QUERIES of that matcher slot — the reference stores
+                                           * surf_lasts_ds / edge_lasts_ds of a keyframe as its surf_frames / edge_frames entry (L:1505-1519, saveKeyFramesAndFactors), i.e. what an
+                                           * earlier call left in the slot that was then the newest: the keyframe never leaves HBM.  < 0: not used */
+} lili_backend_options;
+typedef struct lili_backend_result {
+    int32_t n_map_raw[2], n_map[2];       /* ring points and map points per kind {surf, edge} */
+    int32_t n_query[2];                   /* the new keyframe's down-sampled features per kind */
+    int32_t associated;                   /* 0: a map was missing (first keyframes), nothing associated */
+    double stage_us[8];                   /* opt->want_timing: host time since the call began after [0] the surf side, [1] the edge side, [2] the associations */
+} lili_backend_result;
+int lili_backend_keyframe_prepare(lili_ctx* ctx, const lili_cloud* join_surf, const lili_cloud* join_edge, const double t_join[3], const double q_join[4],
+                                  const lili_cloud* new_surf, const lili_cloud* new_edge, const int* slots, int n_slots, const double* t_assoc, const double* q_assoc,
+                                  const lili_s2m_params* match, const lili_backend_options* opt, int32_t* n_res, lili_backend_result* res);
+
 /* ---- scan-to-map matcher -------------------------------------------------------------------- */
 
 /* Uploads the feature points of keyframe `slot` (surf_lasts_ds[idx] / edge_lasts_ds[idx],

@@ -4,8 +4,8 @@ The product is liblili_hip.so (hand-written HIP kernels behind the C ABI of incl
 this package is the thin host-side binding used by tests and bench.py.  No CPU fallback exists.
 """
 from . import api  # noqa: F401
-from .api import (Context, ScanToMapMatcher, RotExtractor, LivoxExtractor, LocalMap, FrontendOdometry, RotFrontendOdometry, LiliError, make_params, load_library,  # noqa: F401
+from .api import (Context, ScanToMapMatcher, RotExtractor, LivoxExtractor, LocalMap, FrontendOdometry, RotFrontendOdometry, BackendKeyframes, LiliError, make_params, load_library,  # noqa: F401
                   KIND_SURF, KIND_EDGE, MASK_SURF, MASK_EDGE)
 
-__all__ = ["api", "Context", "ScanToMapMatcher", "RotExtractor", "LivoxExtractor", "LocalMap", "FrontendOdometry", "RotFrontendOdometry", "LiliError", "make_params", "load_library",
+__all__ = ["api", "Context", "ScanToMapMatcher", "RotExtractor", "LivoxExtractor", "LocalMap", "FrontendOdometry", "RotFrontendOdometry", "BackendKeyframes", "LiliError", "make_params", "load_library",
            "KIND_SURF", "KIND_EDGE", "MASK_SURF", "MASK_EDGE"]

@@ -56,6 +56,14 @@ LM_MAX_LOG = 32
 LM_TERMINATION = {0: "max_iterations", 1: "gradient_tolerance", 2: "parameter_tolerance", 3: "function_tolerance", 4: "stalled", 5: "numerical_failure", 6: "min_radius"}
 
 
+class BackendOptions(C.Structure):
+    _fields_ = [("leaf_surf", C.c_float), ("leaf_edge", C.c_float), ("leaf_surf_map", C.c_float), ("leaf_edge_map", C.c_float), ("width", C.c_int), ("want_timing", C.c_int), ("join_slot", C.c_int)]
+
+
+class BackendResult(C.Structure):
+    _fields_ = [("n_map_raw", C.c_int32 * 2), ("n_map", C.c_int32 * 2), ("n_query", C.c_int32 * 2), ("associated", C.c_int32), ("stage_us", C.c_double * 8)]
+
+
 class LmOptions(C.Structure):
     _fields_ = [("max_iterations", C.c_int32), ("reserved_", C.c_int32), ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
                 ("parameter_tolerance", C.c_double), ("initial_radius", C.c_double), ("max_radius", C.c_double), ("min_radius", C.c_double),
@@ -143,6 +151,8 @@ _SIGS = {
                                       C.POINTER(FrontendResult)]),
     "lili_frontend_frame_rot": (C.c_int, [C.c_void_p, C.POINTER(Cloud), C.c_void_p, C.c_void_p, C.POINTER(RotParams), C.POINTER(S2MParams), C.POINTER(FrontendOptions), C.c_void_p, C.c_void_p,
                                           C.POINTER(FrontendResult)]),
+    "lili_backend_keyframe_prepare": (C.c_int, [C.c_void_p, C.POINTER(Cloud), C.POINTER(Cloud), C.c_void_p, C.c_void_p, C.POINTER(Cloud), C.POINTER(Cloud), C.POINTER(C.c_int), C.c_int,
+                                                C.c_void_p, C.c_void_p, C.POINTER(S2MParams), C.POINTER(BackendOptions), C.c_void_p, C.POINTER(BackendResult)]),
     "lili_frontend_reset": (C.c_int, [C.c_void_p]),
     "lili_frontend_flush": (C.c_int, [C.c_void_p, C.POINTER(S2MParams), C.POINTER(FrontendOptions), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "lili_voxel_filter": (C.c_int, [C.c_void_p, C.POINTER(Cloud), C.c_float, C.POINTER(FeatureOut), C.c_void_p]),
@@ -881,6 +891,49 @@ class RotFrontendOdometry(FrontendOdometry):
         if q[0] < 0:
             q = -q                    # unifyQuaternion (R/src/LidarOdometry.cpp:524-534)
         return t, q, info
+
+
+class BackendKeyframes:
+    """Host-side mirror of what BackendFusion does per keyframe before ceres::Solve (L/src/BackendFusion.cpp:830-980, 1387-1528): ONE lili_backend_keyframe_prepare call —
+    the keyframe of the previous solve joins both local-map rings, both maps are voxel-filtered and indexed, the new keyframe's features are down-sampled into the newest
+    window slot, every keyframe of the window is associated.  Everything stays in HBM."""
+
+    def __init__(self, ctx, params, leaf_surf=0.4, leaf_edge=0.2, width=40):
+        self.ctx, self.lib, self.params = ctx, ctx.lib, params
+        self.opt = BackendOptions(leaf_surf, leaf_edge, leaf_surf, leaf_edge, width, 0, -1)
+        self.res = BackendResult()
+
+    @staticmethod
+    def _cloud(a):
+        return a if isinstance(a, Cloud) else cloud_from_numpy(a, aux_col=3 if (np.ndim(a) == 2 and np.shape(a)[1] > 3) else None)
+
+    def prepare(self, join, new_surf, new_edge, slots, ts_assoc, qs_assoc, timing=False):
+        """join: None, (surf features, edge features, t, q) of the keyframe that joins the local map at its LiDAR pose, or (slot, t, q): the down-sampled features an earlier
+        call left in that matcher slot (device to device); new_surf / new_edge: the new keyframe's features
+        (numpy rows or Clouds); slots: the window, oldest first (the new keyframe takes slots[-1]).  Returns ([(n_surf, n_edge)] per slot, info)."""
+        n = len(slots)
+        arr = (C.c_int * n)(*[int(v) for v in slots])
+        t = np.ascontiguousarray(np.asarray(ts_assoc, np.float64).reshape(n, 3)); q = np.ascontiguousarray(np.asarray(qs_assoc, np.float64).reshape(n, 4))
+        counts = np.zeros((n, 2), np.int32)
+        keep = [self._cloud(new_surf), self._cloud(new_edge)]
+        js = je = tj = qj = None
+        self.opt.join_slot = -1
+        if join is not None and len(join) == 3:
+            self.opt.join_slot = int(join[0])
+            tj, qj = _f64(join[1], 3), _f64(join[2], 4)
+        elif join is not None:
+            keep += [self._cloud(join[0]), self._cloud(join[1])]
+            js, je = C.byref(keep[2]), C.byref(keep[3])
+            tj, qj = _f64(join[2], 3), _f64(join[3], 4)
+        self.opt.want_timing = 1 if timing else 0
+        r = self.res
+        self.ctx._chk(self.lib.lili_backend_keyframe_prepare(self.ctx.h, js, je, _ptr(tj) if tj is not None else None, _ptr(qj) if qj is not None else None,
+                                                             C.byref(keep[0]), C.byref(keep[1]), arr, n, _ptr(t), _ptr(q), C.byref(self.params), C.byref(self.opt), _ptr(counts),
+                                                             C.byref(r)))
+        info = dict(n_map_raw=tuple(r.n_map_raw), n_map=tuple(r.n_map), n_query=tuple(r.n_query), associated=bool(r.associated))
+        if timing:
+            info["stage_us"] = [r.stage_us[j] for j in range(3)]
+        return [(int(counts[k, 0]), int(counts[k, 1])) for k in range(n)], info
 
 
 def gn_step_host(gram, t, q):

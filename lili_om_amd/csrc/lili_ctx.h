@@ -129,6 +129,7 @@ struct lili_ctx {
     Slot slots[LILI_MAX_SLOTS];
     DevBuf states;       // SlotState[LILI_MAX_SLOTS]
     DevBuf staging;      // raw host clouds
+    DevBuf kf_in[2];     // lili_backend_keyframe_prepare: the new keyframe's surf / edge features as float4 rows
     DevBuf fmt_out;      // lili_livox_custom_to_cloud output when the caller wants it on the host
     DevBuf gram;         // LILI_GRAM_DOUBLES per slot
     DevBuf pose_pub;     // kPubReplicas x kPubStride doubles per slot: the pose a Gauss-Newton kernel publishes for the association launched behind it without a barrier (overlap_gn)

@@ -204,4 +204,99 @@ int lili_frontend_frame_rot(lili_ctx* ctx, const lili_cloud* scan, const double 
 }
 
 
+// ------------------------------------------------------------------------------------------------------------------------------------------------
+// Back-end keyframe preparation (SURVEY §8 f-1 + a-13 / a-14 as ONE call): what BackendFusion does between "a new keyframe has arrived" and
+// "ceres::Solve" (L/src/BackendFusion.cpp:830-980 with buildLocalMapWithLandMark :1387-1484 and downSampleCloud :1486-1528):
+//   1. the keyframe whose pose the last solve fixed joins both local-map rings at that pose (recent_{surf,edge}_keyframes.push_back(transformCloud(...)), the oldest
+//      leaves beyond local_map_width),
+//   2. both rings -> VoxelGrid(surf_ds / edge_ds) -> kd_tree_*_local_map->setInputCloud (:1488-1492, 839-840): lili_localmap_commit per kind,
+//   3. the NEW keyframe's features -> ds_filter_surf / ds_filter_edge (:1505-1519) -> the queries of the window's newest slot,
+//   4. findCorrespondingCornerFeatures / findCorrespondingSurfFeatures of every keyframe of the window at its association pose (:919-936).
+// All of it on the device: the features arrive once (host or device clouds), rings, maps, indices, down-sampled queries and correspondence records stay in HBM.  The
+// two feature filters ride on the index builds of the two commits (behind their kernels, before their read-backs: lili_ctx::pre_sync_hook), so a keyframe costs the
+// synchronisations of the two commits and the one of the association — five — where the calls one by one take eleven and move every cloud through host buffers.
+// ------------------------------------------------------------------------------------------------------------------------------------------------
+int lili_backend_keyframe_prepare(lili_ctx* ctx, const lili_cloud* join_surf, const lili_cloud* join_edge, const double t_join[3], const double q_join[4],
+                                  const lili_cloud* new_surf, const lili_cloud* new_edge, const int* slots, int n_slots, const double* t_assoc, const double* q_assoc,
+                                  const lili_s2m_params* match, const lili_backend_options* opt, int32_t* n_res, lili_backend_result* res) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(new_surf && new_edge && slots && n_slots >= 1 && n_slots <= LILI_MAX_SLOTS && t_assoc && q_assoc && match && opt, "backend_keyframe_prepare: null argument");
+    ARGCHK(opt->leaf_surf > 0 && opt->leaf_edge > 0 && opt->leaf_surf_map > 0 && opt->leaf_edge_map > 0 && opt->width >= 1, "backend_keyframe_prepare: bad options");
+    ARGCHK((join_surf == nullptr) == (join_edge == nullptr) && (!join_surf || (t_join && q_join)), "backend_keyframe_prepare: the joining keyframe needs both feature kinds and its pose");
+    ARGCHK(opt->join_slot < LILI_MAX_SLOTS && (opt->join_slot < 0 || (!join_surf && t_join && q_join)), "backend_keyframe_prepare: join_slot excludes join_surf / join_edge and needs the pose");
+    for (int i = 0; i < n_slots; i++) {
+        ARGCHK(slots[i] >= 0 && slots[i] < LILI_MAX_SLOTS, "backend_keyframe_prepare: bad slot");
+        for (int k = 0; k < i; k++) ARGCHK(slots[k] != slots[i], "backend_keyframe_prepare: duplicate slot");
+    }
+    HIPCHK(hipSetDevice(ctx->device));
+    const auto t_begin = std::chrono::steady_clock::now();
+    lili_backend_result R{};
+    auto stamp = [&](int k) { if (opt->want_timing) R.stage_us[k] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(); };
+    int rc;
+    // 1. the keyframe of the previous solve joins the rings (asynchronous: ingestion + transform on the stream)
+    if (join_surf) {
+        if ((rc = lili_localmap_push(ctx, LILI_KIND_SURF, join_surf, t_join, q_join, opt->width)) != LILI_OK) return rc;
+        if ((rc = lili_localmap_push(ctx, LILI_KIND_EDGE, join_edge, t_join, q_join, opt->width)) != LILI_OK) return rc;
+    } else if (opt->join_slot >= 0) {      // the down-sampled features an earlier call left in that slot (device to device)
+        for (int kind = 0; kind < 2; kind++) {
+            const KindSlot& ks = ctx->slots[opt->join_slot].k[kind];
+            if (!ks.has_queries) return ctx->fail(LILI_E_STATE, "backend_keyframe_prepare: join_slot holds no queries");
+            const lili_cloud jc{ks.q.p, (size_t)ks.n_q, 16, 12, LILI_MEM_DEVICE};
+            if ((rc = lili_localmap_push(ctx, kind, &jc, t_join, q_join, opt->width)) != LILI_OK) return rc;
+        }
+    }
+    // the new keyframe's features as device float4 rows (a device cloud in that layout is read where it lies)
+    const lili_cloud* feats[2] = {new_surf, new_edge};
+    const float4* d_feat[2] = {nullptr, nullptr};
+    for (int kind = 0; kind < 2; kind++) {
+        const lili_cloud* c = feats[kind];
+        const bool in_place = c->mem == LILI_MEM_DEVICE && c->stride == sizeof(float4) && c->aux_offset == 12 && (reinterpret_cast<uintptr_t>(c->data) & 15) == 0;
+        if (in_place || c->n == 0) { d_feat[kind] = static_cast<const float4*>(c->data); continue; }
+        if ((rc = lili_ingest_cloud(ctx, c, ctx->kf_in[kind])) != LILI_OK) return rc;
+        d_feat[kind] = ctx->kf_in[kind].as<float4>();
+    }
+    const int slot_new = slots[n_slots - 1];
+    ARGCHK(slot_new >= 0 && slot_new < LILI_MAX_SLOTS, "backend_keyframe_prepare: bad slot");
+    // 2 + 3. per kind: commit (ring -> VoxelGrid -> index); the new keyframe's filter of that kind is enqueued behind the index build's kernels
+    const float leaf_q[2] = {opt->leaf_surf, opt->leaf_edge}, leaf_m[2] = {opt->leaf_surf_map, opt->leaf_edge_map};
+    const double gate[2] = {match->kd_max_radius, match->edge_gate};
+    for (int kind = 0; kind < 2; kind++) {
+        bool enq = false, pending = false, in_hook = false;
+        const int n_f = (int)feats[kind]->n;
+        auto enqueue_filter = [&]() -> int {
+            const int r = n_f > 0 ? lili_voxel_filter_dev_enqueue(ctx, d_feat[kind], n_f, leaf_q[kind], in_hook, &pending) : LILI_OK;
+            enq = r == LILI_OK;
+            return r;
+        };
+        int64_t a = 0, b = 0;
+        if (lili_localmap_ring_size(ctx, kind) > 0) {
+            ctx->pre_sync_hook = [&]() -> int { in_hook = ctx->hook_box_words_zero; const int r = enqueue_filter(); in_hook = false; return r; };
+            rc = lili_localmap_commit(ctx, kind, leaf_m[kind], gate[kind], &a, &b);
+            ctx->pre_sync_hook = nullptr;
+            if (rc != LILI_OK) return rc;
+        }
+        R.n_map_raw[kind] = (int32_t)a; R.n_map[kind] = (int32_t)b;
+        if (!enq) {
+            if ((rc = enqueue_filter()) != LILI_OK) return rc;
+            if (pending) { rc = lili_readback_finish(ctx); if (rc != LILI_OK) return rc; }
+        }
+        const float4* d_q = d_feat[kind]; int n_q = 0;
+        if (n_f > 0) { if ((rc = lili_voxel_filter_dev_complete(ctx, &d_q, &n_q)) != LILI_OK) return rc; }
+        R.n_query[kind] = n_q;
+        const lili_cloud qc{d_q, (size_t)n_q, 16, 12, LILI_MEM_DEVICE};
+        if ((rc = lili_s2m_set_queries(ctx, slot_new, kind, &qc)) != LILI_OK) return rc;      // device-to-device: the filter's buffer is free for the other kind
+        stamp(kind);
+    }
+    // 4. the window's associations (one launch for all keyframes where the sizes allow it), ONE synchronisation for the 2 n counts
+    const int mask = LILI_MASK_SURF | LILI_MASK_EDGE;
+    const bool maps = ctx->map[LILI_KIND_SURF].valid && ctx->map[LILI_KIND_EDGE].valid;
+    if (maps) {
+        if ((rc = lili_s2m_associate_window(ctx, slots, n_slots, mask, t_assoc, q_assoc, match, n_res)) != LILI_OK) return rc;
+    } else if (n_res) for (int i = 0; i < 2 * n_slots; i++) n_res[i] = 0;
+    R.associated = maps ? 1 : 0;
+    stamp(2);
+    if (res) *res = R;
+    return LILI_OK;
+}
+
 }  // extern "C"

@@ -70,3 +70,19 @@ def test_cpp_host_window_seam_one_call_equals_single_calls(gpu_ctx, tmp_path):
     print(r)
     assert r["window_equals_single_calls_bit_for_bit"] is True and r["correspondences_slot0"] > 1500
     assert r["us_per_window_evaluation"] < r["us_per_evaluation_as_K_single_calls"]
+
+
+def test_cpp_host_backend_keyframe_one_call_equals_separate_calls():
+    """examples/backend_demo: the back end's per-keyframe work before ceres::Solve as ONE lili_backend_keyframe_prepare (the joining keyframe taken from its slot on the
+    device) against the calls one by one through host buffers, from plain C++: counts and the window's Gram records bit for bit (the program exits 3 otherwise),
+    ring popping included (width 5 < 14 keyframes)."""
+    import json
+    demo = os.path.join(ROOT, "examples", "backend_demo")
+    if not os.path.exists(demo):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "-s"])
+    out = subprocess.run([demo, "14", "1500", "200", "5", "2"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout, out.stderr)
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    print(r)
+    assert r["one_call_equals_separate_calls_bit_for_bit"] is True and r["correspondences_total"] > 20000
+    assert r["ms_per_keyframe_one_call"] < r["ms_per_keyframe_separate_calls"]
