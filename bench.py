@@ -1015,6 +1015,12 @@ def main():
                 failures.extend(f"scan_pipeline_200k: {f}" for f in BC.parity_failures(extras["scan_pipeline_200k"]))
             except Exception as e:      # noqa: BLE001
                 extras["scan_pipeline_200k"] = {"error": repr(e)}
+            try:
+                extras["keyframe_real_size"] = BC.keyframe_real_size(L, cpu=not args.no_cpu_baseline)
+                if extras["keyframe_real_size"].get("parity", {}).get("pass") is False:
+                    failures.append("keyframe_real_size: the one-call keyframe differs from the separate calls")
+            except Exception as e:      # noqa: BLE001
+                extras["keyframe_real_size"] = {"error": repr(e)}
             finally:
                 if cx is not None:
                     cx.close(); cx = None

@@ -752,3 +752,83 @@ def scan_pipeline_200k(L, ctx, torch, synth, w, focus_r, cpu=True, ips=10):
         except Exception as e:      # noqa: BLE001
             out["cpu"] = {"error": repr(e)}
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# The back end's per-keyframe work before ceres::Solve at the reference's own sizes: 3 x (2 500 surf + 250 edge) features, 40-keyframe ring.
+# GPU: examples/backend_demo (plain C++ on the C ABI) — ONE lili_backend_keyframe_prepare per keyframe against the calls one by one through host buffers, compared bit for
+# bit by the program itself.  CPU: the oracle on one thread doing the same steps for keyframes of the same sizes in an analogous hall (numpy generator below).
+# ------------------------------------------------------------------------------------------------------------------------------
+def _hall_keyframe(k, n_surf, n_edge, rng):
+    a = 0.05 * k
+    yaw = a + math.pi / 2
+    tl = np.array([8.0 * math.cos(a), 5.0 * math.sin(a), 1.6])
+    ql = np.array([math.cos(yaw / 2), 0.0, 0.0, math.sin(yaw / 2)])
+    face = rng.integers(0, 6, n_surf)
+    u, v = rng.uniform(size=n_surf), rng.uniform(size=n_surf)
+    w = np.zeros((n_surf, 3))
+    f = face < 2
+    w[f] = np.c_[-20 + 40 * u[f], -14 + 28 * v[f], np.where(face[f] == 1, 6.0, 0.0)]
+    f = (face >= 2) & (face < 4)
+    w[f] = np.c_[np.where(face[f] == 2, -20.0, 20.0), -14 + 28 * u[f], 6 * v[f]]
+    f = face >= 4
+    w[f] = np.c_[-20 + 40 * u[f], np.where(face[f] == 4, -14.0, 14.0), 6 * v[f]]
+    px, py, c = rng.integers(0, 4, n_edge), rng.integers(0, 3, n_edge), rng.integers(0, 4, n_edge)
+    e = np.c_[-15.0 + 10.0 * px + np.where(c & 1, 0.3, -0.3), -9.0 + 9.0 * py + np.where(c & 2, 0.3, -0.3), 6 * rng.uniform(size=n_edge)]
+    from lili_om_amd import synth
+    qi = ql * np.array([1, -1, -1, -1])
+    loc = lambda p: np.c_[synth.quat_rot(qi, p + rng.normal(0, 0.01, p.shape) - tl), np.full(p.shape[0], k % 64 + 0.05)].astype(np.float32)      # noqa: E731
+    return loc(w), loc(e), tl, ql
+
+
+def keyframe_real_size(L, cpu=True, n_kf=60, n_surf=2500, n_edge=250, width=40):
+    import json
+    import os
+    import subprocess
+    demo = os.path.join(os.path.dirname(os.path.abspath(__file__)), "examples", "backend_demo")
+    out = {"workload": f"{n_kf} keyframes of {n_surf} surf + {n_edge} edge features (the reference's own sizes, L/src/BackendFusion.cpp:1601-1681), local_map_width {width}, window of 3, "
+                       "ROT back-end flavour; per keyframe: the previous keyframe joins both rings, VoxelGrid(0.4 / 0.2) + index of both local maps, the new keyframe's "
+                       "VoxelGrid(0.4 / 0.2), association of the 3 window keyframes (both kinds)"}
+    if not os.path.exists(demo):
+        out["error"] = "examples/backend_demo not built"
+        return out
+    try:
+        r = subprocess.run([demo, str(n_kf), str(n_surf), str(n_edge), str(width), "4"], capture_output=True, text=True, timeout=300)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        out.update({"value": round(1e3 / d["ms_per_keyframe_one_call"], 1), "unit": "keyframes/s", "ms_per_keyframe": d["ms_per_keyframe_one_call"],
+                    "ms_per_keyframe_separate_calls": d["ms_per_keyframe_separate_calls"], "correspondences_total": d["correspondences_total"],
+                    "one_call": "lili_backend_keyframe_prepare (join_slot: the joining keyframe never leaves HBM), from examples/backend_demo (C++)",
+                    "parity": {"pass": bool(d["one_call_equals_separate_calls_bit_for_bit"]) and r.returncode == 0,
+                               "what": "counts of every window keyframe and the Gram records of one window evaluation after every keyframe: one call vs the calls one by one, bit for bit"}})
+    except Exception as e:      # noqa: BLE001
+        out["error"] = repr(e)
+        return out
+    if cpu:
+        try:
+            from oracle import oracle as O
+            PO = O.params("rot")
+            rng = np.random.default_rng(77)
+            kfs = [_hall_keyframe(k, n_surf, n_edge, rng) for k in range(n_kf)]
+            ring_s, ring_e, ds = [], [], []
+            t_tot, n_t = 0.0, 0
+            for k in range(n_kf):
+                tic = time.perf_counter()
+                if k:
+                    js, je, tj, qj = ds[k - 1][0], ds[k - 1][1], kfs[k - 1][2], kfs[k - 1][3]
+                    ring_s.append(O.transform_cloud(js, qj, tj)); ring_e.append(O.transform_cloud(je, qj, tj))
+                    ring_s, ring_e = ring_s[-width:], ring_e[-width:]
+                    ms, me = O.voxel_grid(np.concatenate(ring_s), 0.4)[0], O.voxel_grid(np.concatenate(ring_e), 0.2)[0]
+                    tree_s, tree_e = O.KdTree(np.ascontiguousarray(ms[:, :3])), O.KdTree(np.ascontiguousarray(me[:, :3]))
+                ds.append((O.voxel_grid(kfs[k][0], 0.4)[0], O.voxel_grid(kfs[k][1], 0.2)[0]))
+                if k:
+                    for j in range(max(0, k - 2), k + 1):
+                        O.associate_surf(tree_s, None, np.ascontiguousarray(ds[j][0][:, :3]), None, kfs[j][3], kfs[j][2], PO)
+                        O.associate_edge(tree_e, np.ascontiguousarray(ds[j][1][:, :3]), kfs[j][3], kfs[j][2], PO)
+                if k >= n_kf // 2:
+                    t_tot += time.perf_counter() - tic; n_t += 1
+            out["cpu"] = {"value": round(n_t / t_tot, 2), "unit": "keyframes/s", "ms_per_keyframe": round(t_tot / n_t * 1e3, 3), "cores": 1, "kind": "port",
+                          "sample": f"the oracle, one thread, the last {n_t} keyframes (ring full or nearly): transformCloud, both VoxelGrids, both kd-tree builds, the new keyframe's "
+                                    "VoxelGrids, 3 x (surf + edge) association — keyframes of the same sizes in the same hall (numpy generator, not the C++ program's random stream)"}
+        except Exception as e:      # noqa: BLE001
+            out["cpu"] = {"error": repr(e)}
+    return out
