@@ -1016,6 +1016,12 @@ def main():
             except Exception as e:      # noqa: BLE001
                 extras["scan_pipeline_200k"] = {"error": repr(e)}
             try:
+                extras["scan_pipeline_200k_concurrent"] = BC.scan_pipeline_200k_concurrent(L, torch, synth, w, focus_r, device=local_rank, ips=ips)
+                if extras["scan_pipeline_200k_concurrent"].get("gn_status", 0) != 0:
+                    failures.append("scan_pipeline_200k_concurrent: poses differ between the contexts / gn_status")
+            except Exception as e:      # noqa: BLE001
+                extras["scan_pipeline_200k_concurrent"] = {"error": repr(e)}
+            try:
                 extras["keyframe_real_size"] = BC.keyframe_real_size(L, cpu=not args.no_cpu_baseline)
                 if extras["keyframe_real_size"].get("parity", {}).get("pass") is False:
                     failures.append("keyframe_real_size: the one-call keyframe differs from the separate calls")

@@ -51,6 +51,14 @@ int lili_readback_add(lili_ctx* ctx, void* dst, const void* d_src, size_t bytes,
     ctx->h_pin_used = off + bytes;
     return LILI_OK;
 }
+int lili_lazy_sources_clear_of(lili_ctx* ctx, const void* p, size_t bytes) {
+    const char* a = static_cast<const char*>(p);
+    for (const auto& it : ctx->h_pin_lazy) {
+        const char* s = static_cast<const char*>(it.src);
+        if (a < s + it.bytes && s < a + bytes) return ctx->fail(LILI_E_STATE, "internal: a fill of the scratch words would overwrite the source of a pending read-back");
+    }
+    return LILI_OK;
+}
 int lili_readback_finish(lili_ctx* ctx, hipStream_t stream) {
     hipStream_t s = stream ? stream : ctx->stream;
     hipError_t e = hipSuccess;

@@ -217,6 +217,10 @@ static inline int nblocks(int64_t n, int per) { return (int)((n + per - 1) / per
 int lili_map_set_hinted(lili_ctx* ctx, int kind, const lili_cloud* cloud, double max_sq_radius, const unsigned* box6, bool in_place);
 int lili_readback_add(lili_ctx* ctx, void* dst, const void* d_src, size_t bytes, hipStream_t stream = nullptr);
 int lili_readback_finish(lili_ctx* ctx, hipStream_t stream = nullptr);
+// a lazy read-back reads its device source when the FINISH launches its gather kernel, so nothing enqueued in between may rewrite that source.  Every fill of
+// the shared scratch words (ctx->misc) asks here first: LILI_E_STATE if [p, p + bytes) overlaps the source of a read-back that is still pending (a programming error in
+// the library — a hook or a commit that clears words another stage has yet to deliver), LILI_OK otherwise.  Host-side, a loop over at most twelve items.
+int lili_lazy_sources_clear_of(lili_ctx* ctx, const void* p, size_t bytes);
 void* lili_pinned_dev_ptr(const void* host, size_t align = 4);      // device-side address of a PAGE-LOCKED host buffer, or nullptr (pageable / misaligned); asked per call: ~0.1 us
 int lili_ingest_cloud(lili_ctx* ctx, const lili_cloud* c, lili_detail::DevBuf& out_f4, unsigned* d_bbox = nullptr);   // d_bbox: also reduce the bounding box (6 ordered-uint words, initialised by the caller)
 // lili_p2p.hip: the view of the NEXT exchange of a communicator (advances its sequence number); usable = connected and on this context

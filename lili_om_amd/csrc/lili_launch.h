@@ -47,7 +47,9 @@ struct LmArgs {      // must match lili_s2m_lm.hip
     double function_tolerance, gradient_tolerance, parameter_tolerance;
     double initial_radius, max_radius, min_radius, min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
 };
+struct WinLmArgs { LmArgs a[kWindowMaxSlots]; int first_block[kWindowMaxSlots]; int n; };      // must match lili_s2m_lm.hip
 __global__ void k_solve_lm(LmArgs, MatchParams);
+__global__ void k_solve_lm_window(WinLmArgs, MatchParams);
 // lili_s2m_coop.hip: L lanes per query (small launches)
 template <int L, bool LIN> __global__ void k_associate_coop(AssocArgs, AssocArgs, PoseArg, MatchParams, double*, double*, SlotState*, int);
 template <int L> __global__ void k_associate_coop_window(WinAssocArgs, MatchParams);

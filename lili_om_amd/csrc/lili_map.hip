@@ -90,9 +90,9 @@ static int build_grid(lili_ctx* ctx, MapIndex& m, const SrcCloud& src, const dou
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(kBlock), 0, ctx->stream, m.block_sums.as<int>(), nb_scan);
         hipLaunchKernelGGL(k_scan_apply, dim3(nb_scan), dim3(kBlock), 0, ctx->stream, cell_start.as<int>(), nc, m.block_sums.as<int>(), cell_start.as<int>());
     }
-    if (narrow) hipLaunchKernelGGL(k_scatter_t<unsigned char>, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, src, n, g, m.pt_cell.as<unsigned char>(), cell_start.as<int>(),
+    if (narrow) hipLaunchKernelGGL(k_scatter_t<unsigned char>, dim3(8 * nblocks(nblocks(n, kBlock), 8)), dim3(kBlock), 0, ctx->stream, src, n, g, m.pt_cell.as<unsigned char>(), cell_start.as<int>(),
                                    sorted.as<float4>(), m.has_aux ? aux_sorted.as<float>() : nullptr);
-    else hipLaunchKernelGGL(k_scatter_t<int>, dim3(nblocks(n, kBlock)), dim3(kBlock), 0, ctx->stream, src, n, g, m.pt_cell.as<int>(), cell_start.as<int>(),
+    else hipLaunchKernelGGL(k_scatter_t<int>, dim3(8 * nblocks(nblocks(n, kBlock), 8)), dim3(kBlock), 0, ctx->stream, src, n, g, m.pt_cell.as<int>(), cell_start.as<int>(),
                             sorted.as<float4>(), m.has_aux ? aux_sorted.as<float>() : nullptr);
     if (srows) {      // first positions of the super-rows (populations -> scan), positions of the super cells, then the copy
         hipLaunchKernelGGL(k_rowtot9, dim3(nblocks(rows9, kBlock)), dim3(kBlock), 0, ctx->stream, cell_start.as<int>(), g, m.row9.as<int>());
@@ -107,7 +107,8 @@ static int build_grid(lili_ctx* ctx, MapIndex& m, const SrcCloud& src, const dou
             const int64_t n_str = (int64_t)nblocks(g.bnx, 64) * g.bny * g.bnz;
             int spw = 1;
             while (spw < 64 && n_str / (spw * 2) >= 131072) spw *= 2;
-            hipLaunchKernelGGL(k_scatter9, dim3((unsigned)((n_str + (int64_t)spw * 4 - 1) / ((int64_t)spw * 4))), dim3(256), 0, ctx->stream, cell_start.as<int>(), g, cell_start9.as<int>(),
+            const int64_t n_tiles = (int64_t)nblocks(g.bnx, 64) * nblocks(g.bny, 4) * nblocks(g.bnz, 4);
+            hipLaunchKernelGGL(k_scatter9, dim3((unsigned)((n_tiles + spw - 1) / spw)), dim3(1024), 0, ctx->stream, cell_start.as<int>(), g, cell_start9.as<int>(),
                                sorted.as<float4>(), m.has_aux ? aux_sorted.as<float>() : nullptr, spw);
         }
     }
@@ -187,6 +188,7 @@ static int map_set_impl(lili_ctx* ctx, int kind, const lili_cloud* cloud, double
         else source = kBoxGuess;
     }
     // every scratch word of the build — box banks, density banks, the scans' error word and status words, the guess's flags — starts from zero: one fill
+    { const int rl = lili_lazy_sources_clear_of(ctx, ctx->misc.p, kMiscTotal); if (rl != LILI_OK) return rl; }
     HIPCHK(hipMemsetAsync(ctx->misc.p, 0, kMiscTotal, ctx->stream));
     unsigned banks[64 * 32], mm[6] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u};
     const void* zeroed_p = nullptr;

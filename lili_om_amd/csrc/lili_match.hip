@@ -934,7 +934,7 @@ void lili_lm_default_options(lili_lm_options* o) {      // Ceres 2.0 Solver::Opt
 }
 
 // enqueues the persistent launch of one slot on ctx->stream; max_blocks bounds the grid (all workgroups have to be resident)
-static int launch_solve_lm(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, const lili_lm_options* options, int max_blocks) {
+static int launch_solve_lm(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, const lili_lm_options* options, int max_blocks, LmArgs* prepared = nullptr /* fill the arguments only: the caller launches (k_solve_lm_window) */) {
     ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS, "solve_lm: bad slot");
     ARGCHK((kind_mask & ~3) == 0 && kind_mask != 0, "solve_lm: bad kind mask");
     ARGCHK(params, "solve_lm: null params");
@@ -980,11 +980,13 @@ static int launch_solve_lm(lili_ctx* ctx, int slot, int kind_mask, const lili_s2
     a.function_tolerance = opt.function_tolerance; a.gradient_tolerance = opt.gradient_tolerance; a.parameter_tolerance = opt.parameter_tolerance;
     a.initial_radius = opt.initial_radius; a.max_radius = opt.max_radius; a.min_radius = opt.min_radius; a.min_relative_decrease = opt.min_relative_decrease;
     a.min_lm_diagonal = opt.min_lm_diagonal; a.max_lm_diagonal = opt.max_lm_diagonal;
+    sl.use_global_counts = false;
+    sl.assoc_since_pose = 1;
+    if (prepared) { *prepared = a; return LILI_OK; }
     MatchParams P = to_device_params(params);
     P.no_cost = 0;                              // the robust cost drives the accept / reject decisions
     hipLaunchKernelGGL(k_solve_lm, dim3(a.nb), dim3(kLmThreads), lds_linearize(kLmThreads), ctx->stream, a, P);
     HIPCHK(hipGetLastError());
-    sl.use_global_counts = false;
     sl.assoc_since_pose = 1;                    // the pose moved, but stays near the association's: the next association is no "first" one
     return LILI_OK;
 }
@@ -1012,32 +1014,26 @@ int lili_s2m_solve_lm_window(lili_ctx* ctx, const int* slots, int n_slots, int k
         for (int k = 0; k < i; k++) ARGCHK(slots[k] != slots[i], "solve_lm_window: duplicate slot");
     }
     HIPCHK(hipSetDevice(ctx->device));
-    if (!ctx->fork_ev) HIPCHK(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(ctx->fork_ev, ctx->stream));
-    hipStream_t main_stream = ctx->stream;
-    // the launches of the slots run side by side and every one needs all its workgroups resident: share the CUs out
+    // ONE launch for all slots (round 6: k_solve_lm_window); every slot needs all its workgroups resident: the CUs are shared out
     const int max_blocks = std::max(1, std::min(ctx->n_simd / 4 - 16, 240) / n_slots);
-    int rc = LILI_OK;
-    for (int i = 0; i < n_slots && rc == LILI_OK; i++) {
-        if (i > 0) {
-            if (!ctx->side[i]) HIPCHK(hipStreamCreateWithFlags(&ctx->side[i], hipStreamNonBlocking));
-            if (!ctx->join_ev[i]) HIPCHK(hipEventCreateWithFlags(&ctx->join_ev[i], hipEventDisableTiming));
-            HIPCHK(hipStreamWaitEvent(ctx->side[i], ctx->fork_ev, 0));
-            ctx->stream = ctx->side[i];
-        }
-        rc = launch_solve_lm(ctx, slots[i], kind_mask, params, options, max_blocks);
-        hipError_t e = hipSuccess;
-        if (rc == LILI_OK && summaries && lili_readback_add(ctx, summaries + i, ctx->slots[slots[i]].lm_summary.p, sizeof(lili_lm_summary), ctx->stream) != LILI_OK) e = hipErrorUnknown;
-        if (i > 0) {
-            if (e == hipSuccess) e = hipEventRecord(ctx->join_ev[i], ctx->side[i]);
-            ctx->stream = main_stream;
-            if (e == hipSuccess) e = hipStreamWaitEvent(main_stream, ctx->join_ev[i], 0);
-        }
-        if (e != hipSuccess) { ctx->stream = main_stream; (void)lili_readback_finish(ctx); return ctx->fail(LILI_E_HIP, std::string("solve_lm_window: ") + hipGetErrorString(e)); }
+    WinLmArgs W{};
+    W.n = n_slots;
+    int nb = 0;
+    for (int i = 0; i < n_slots; i++) {
+        const int rc = launch_solve_lm(ctx, slots[i], kind_mask, params, options, max_blocks, &W.a[i]);
+        if (rc != LILI_OK) return rc;
+        W.first_block[i] = nb;
+        nb += W.a[i].nb;
     }
-    ctx->stream = main_stream;
-    if (summaries || rc != LILI_OK) { const int rb = lili_readback_finish(ctx); if (rc == LILI_OK) rc = rb; }      // (the side streams were joined into this one)
-    return rc;
+    MatchParams P = to_device_params(params);
+    P.no_cost = 0;                              // the robust cost drives the accept / reject decisions
+    hipLaunchKernelGGL(k_solve_lm_window, dim3(nb), dim3(512 /* kLmThreads of lili_s2m_lm.hip */), lds_linearize(512), ctx->stream, W, P);
+    HIPCHK(hipGetLastError());
+    if (summaries) {
+        for (int i = 0; i < n_slots; i++) { const int rb = lili_readback_add(ctx, summaries + i, ctx->slots[slots[i]].lm_summary.p, sizeof(lili_lm_summary)); if (rb != LILI_OK) { (void)lili_readback_finish(ctx); return rb; } }
+        return lili_readback_finish(ctx);
+    }
+    return LILI_OK;
 }
 
 int lili_s2m_accumulate(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_params* params, double* d_gram) {

@@ -535,8 +535,14 @@ __global__ __launch_bounds__(256) void k_start9(const int* __restrict__ cell_sta
 template <typename RankT>
 __global__ __launch_bounds__(kBlock) void k_scatter_t(SrcCloud src, int n, GridView g, const RankT* __restrict__ pt_rank, const int* __restrict__ cell_start,
                                                       float4* __restrict__ sorted, float* __restrict__ aux_sorted) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    // XCD-aware order (round 6): workgroup ids go round-robin over the eight XCDs, each with its own L2.  A map that arrives in voxel order puts the points of one cell row
+    // into ~2.7 runs thousands of points apart: with consecutive workgroups on different XCDs the partial writes of one destination line came from different L2s
+    // and reached HBM as three partial writes (269 MB for 80 MB of output).  Here XCD x takes the x-th EIGHTH of the input — a slab of the map — so that the runs that share
+    // destination lines meet in one L2 before the line is evicted.  (The grid covers 8 x ceil(blocks / 8) workgroups; the surplus ones leave.)
+    const int nb = (n + (int)blockDim.x - 1) / (int)blockDim.x, per = (nb + 7) / 8;
+    const int b = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    int i = b * blockDim.x + threadIdx.x;
+    if (b >= nb || i >= n) return;
     const int rank = (int)pt_rank[i];
     float4 p = load_src(src, i);
     const int pos = cell_start[cell_of(p, g)] + rank;
@@ -550,34 +556,40 @@ template __global__ void k_scatter_t<unsigned char>(SrcCloud, int, GridView, con
 // Super-row copy, by DESTINATION: a stretch = 64 consecutive super cells (x0..x0+63, y', z') — a contiguous piece of the super-row array — is filled by ONE wave
 // from its nine source rows, each a contiguous run of the base array.  The nine runs are walked as ONE sequence, 64 points per trip; a point finds its super cell
 // through its own x cell and its place through a 9 x 64 table (LDS) of "destination minus source" per (source row, cell).
-// Round 6: a wave takes 64 stretches in linear order (x block fastest, then y', then z'); every lane tests ONE of them for emptiness (two words of start9) and the
-// wave copies the non-empty ones one after the other.  Before, every stretch had a wave of its own that loaded the two words and left: on an index whose cells are
-// mostly empty (the fine index of a dense map: 1.39 M stretches, 2 % of them populated) the copy spent its time launching waves — 639 us for 5 M points.
-// spw (1 .. 64): stretches per wave — 64 for a sparse index, 1 (one wave per stretch, as before) where there are too few stretches to fill the chip otherwise.
-__global__ __launch_bounds__(256) void k_scatter9(const int* __restrict__ cell_start, GridView g, const int* __restrict__ start9,
-                                                  float4* __restrict__ sorted, float* __restrict__ aux_sorted, int spw) {
-    __shared__ int delta[4][9][64];
+// The 16 waves of a workgroup take a 4 x 4 tile of (y', z') at one x block, whose 36 source rows they share through the L2 of the XCD the workgroup runs on.
+// Round 6: a workgroup takes `spw` consecutive tiles (x block fastest); lane j < spw of wave w tests the stretch at tile position w of the workgroup's j-th tile for
+// emptiness (two words of start9) and the wave copies the non-empty ones one after the other.  spw = 1 is the one-stretch-per-wave kernel of rounds 3-5.  On an index whose
+// cells are mostly empty (the fine index of a dense map: 1.39 M stretches, 18 % of them populated) a wave per stretch spent its time launching waves that load two words
+// and leave: 639 us for 5 M points.
+__global__ __launch_bounds__(1024) void k_scatter9(const int* __restrict__ cell_start, GridView g, const int* __restrict__ start9,
+                                                   float4* __restrict__ sorted, float* __restrict__ aux_sorted, int spw) {
+    __shared__ int delta[16][9][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int nxb = (g.bnx + 63) / 64;
-    const long long n_str = (long long)nxb * g.bny * g.bnz;
-    const long long s0 = ((long long)blockIdx.x * 4 + w) * spw;
+    const int nxb = (g.bnx + 63) / 64, nty = (g.bny + 3) / 4, ntz = (g.bnz + 3) / 4;
+    const long long n_tiles = (long long)nxb * nty * ntz;
+    const long long tile0 = (long long)blockIdx.x * spw;
+    auto stretch_of = [&](long long tile, int& x0, int& ys, int& zs) -> bool {
+        const int xb = (int)(tile % nxb); const long long r = tile / nxb;
+        ys = g.by0 + (int)(r % nty) * 4 + (w & 3); zs = g.bz0 + (int)(r / nty) * 4 + (w >> 2); x0 = g.bx0 + xb * 64;
+        return tile < n_tiles && ys < g.by0 + g.bny && zs < g.bz0 + g.bnz;
+    };
     bool ne = false;
-    {
-        const long long sid = s0 + lane;
-        if (lane < spw && sid < n_str) {
-            const int xb = (int)(sid % nxb); const long long r = sid / nxb;
-            const int ys = g.by0 + (int)(r % g.bny), zs = g.bz0 + (int)(r / g.bny), x0 = g.bx0 + xb * 64;
-            const int xn = min(64, g.bx0 + g.bnx - x0);
-            const int* s9 = start9 + srow_index(g, x0, ys, zs);
-            ne = s9[xn] != s9[0];
+    if (lane < spw) {
+        int x0, ys, zs;
+        if (stretch_of(tile0 + lane, x0, ys, zs)) {
+            ne = true;
+            if (spw > 1) {      // (one stretch per wave: its emptiness shows in the loads the copy starts with — no dependent round trip in front of them)
+                const int xn = min(64, g.bx0 + g.bnx - x0);
+                const int* s9 = start9 + srow_index(g, x0, ys, zs);
+                ne = s9[xn] != s9[0];
+            }
         }
     }
     unsigned long long todo = __ballot(ne);
     while (todo) {
-        const long long sid = s0 + __builtin_ctzll(todo);
+        int x0, ys, zs;
+        stretch_of(tile0 + __builtin_ctzll(todo), x0, ys, zs);
         todo &= todo - 1ull;
-        const int xb = (int)(sid % nxb); const long long rr = sid / nxb;
-        const int ys = g.by0 + (int)(rr % g.bny), zs = g.bz0 + (int)(rr / g.bny), x0 = g.bx0 + xb * 64;
         const int xn = min(64, g.bx0 + g.bnx - x0);            // cells of this stretch
         const int* s9 = start9 + srow_index(g, x0, ys, zs);
         const int lc = min(lane, xn - 1);
@@ -585,6 +597,7 @@ __global__ __launch_bounds__(256) void k_scatter9(const int* __restrict__ cell_s
         const int d_end = s9[xn];
         const int D0 = __shfl(dnext, 0);
         const int len = d_end - D0;
+        if (len == 0) continue;                                // (spw = 1: nothing lives here)
         int off[9], pre[10];
         pre[0] = 0;
         // all 27 range words of the nine source rows are requested BEFORE the first is used (round 4: 70.9 -> 64.4 us per focused copy)

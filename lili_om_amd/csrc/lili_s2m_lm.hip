@@ -46,6 +46,7 @@ struct LmArgs {
     double function_tolerance, gradient_tolerance, parameter_tolerance;
     double initial_radius, max_radius, min_radius, min_relative_decrease, min_lm_diagonal, max_lm_diagonal;
 };
+struct WinLmArgs { LmArgs a[kWindowMaxSlots]; int first_block[kWindowMaxSlots]; int n; };      // must match lili_launch.h
 
 struct LmShared {
     double vals[kLmGroup][40];
@@ -213,11 +214,8 @@ __device__ __forceinline__ void lm_propose(LmShared& sh) {
     }
 }
 
-// persistent launch: grid = S.nb + E.nb workgroups of kLmThreads threads; dynamic LDS = kLmThreads * kRow doubles (Gram staging rows)
-__global__ __launch_bounds__(kLmThreads) void k_solve_lm(LmArgs a, MatchParams P) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    __shared__ LmShared sh;
-    const int b = (int)blockIdx.x;
+// one slot's solve, by the workgroups [0, a.nb) of that slot (b = the workgroup's index within the slot)
+__device__ __forceinline__ void solve_lm_body(const LmArgs& a, const MatchParams& P, const int b, double* lds, LmShared& sh) {
     const bool surf = b < a.S.nb;
     const bool wave0 = threadIdx.x < 64;
     const bool boss = b == 0 && threadIdx.x == 0;
@@ -346,6 +344,25 @@ __global__ __launch_bounds__(kLmThreads) void k_solve_lm(LmArgs a, MatchParams P
             a.summary->n_surf = sh.counts[0]; a.summary->n_edge = sh.counts[1];
         }
     }
+}
+
+// persistent launch: grid = S.nb + E.nb workgroups of kLmThreads threads; dynamic LDS = kLmThreads * kRow doubles (Gram staging rows)
+__global__ __launch_bounds__(kLmThreads) void k_solve_lm(LmArgs a, MatchParams P) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ LmShared sh;
+    solve_lm_body(a, P, (int)blockIdx.x, lds, sh);
+}
+// The solves of ALL keyframes of a sliding window in ONE launch (round 6): workgroup bid belongs to the last slot whose first_block <= bid and is that slot's workgroup
+// bid - first_block of k_solve_lm — the slots' solves are independent (own records, own partial buffers, own keys) and run side by side, one slot's exchange under another's
+// arithmetic.  It was one launch per slot on forked streams: 65 us of fork / join / launch overhead per window solve around 9 us per evaluation of all three keyframes.
+__global__ __launch_bounds__(kLmThreads) void k_solve_lm_window(WinLmArgs W, MatchParams P) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ LmShared sh;
+    const int bid = (int)blockIdx.x;
+    int i = 0;
+#pragma unroll
+    for (int k = 1; k < kWindowMaxSlots; k++) if (k < W.n && bid >= W.first_block[k]) i = k;
+    solve_lm_body(W.a[i], P, bid - W.first_block[i], lds, sh);
 }
 
 }  // namespace lili

@@ -718,7 +718,9 @@ struct VoxelBuffers {
     struct Pending { int mode = 0; const float4* d_pts = nullptr; int n = 0; float leaf = 0; bool need_order = false, alt = false; int res[2] = {0, 0}; int n_out = 0; } pend;
     DevBuf spts, qout, qout_cnt;
     int qn_out = 0;
-    int bits_guess = 0; float guess_leaf = 0;
+    // per use site: [0] the first output (local-map rebuild, lili_voxel_filter), [1] the second (`alt`: the frame pipeline's query filter) — a large-extent map
+    // and a small-extent scan of the same leaf size no longer undo each other's guess.  A guess only GROWS at once; it shrinks after eight filters in a row needed fewer bits.
+    int bits_guess[2] = {0, 0}; float guess_leaf[2] = {0, 0}; int guess_low[2] = {0, 0};
     int key_guesses = 0, key_guess_misses = 0;
     unsigned out_box[6] = {0, 0, 0, 0, 0, 0};   // bounding box of `out` (ordered-uint words, k_bbox_dev) after an incremental commit
     void release() {
@@ -986,7 +988,7 @@ static int radix_sort(lili_ctx* ctx, lili_detail::VoxelBuffers* V, int n, int bi
 
 // Stable order of a device cloud by pcl::VoxelGrid's voxel index (box-relative, App. B2): keys in V->keys_a, the order (source indices) in
 // V->vals_a.  Blocking: the bounding box is read back.
-static int voxel_sort(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const float4* d_pts, int n, float leaf, VoxDev& P) {
+static int voxel_sort(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const float4* d_pts, int n, float leaf, VoxDev& P, bool alt = false) {
     unsigned* d_mm = ctx->misc.as<unsigned>();
     hipLaunchKernelGGL(k_box_init, dim3(1), dim3(64), 0, ctx->stream, d_mm);
     hipLaunchKernelGGL(k_bbox, dim3(std::min(nblocks(n, kBlock), 512)), dim3(kBlock), 0, ctx->stream, d_pts, n, d_mm);
@@ -1007,7 +1009,7 @@ static int voxel_sort(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const float4*
     P.mul[0] = 1; P.mul[1] = div_b[0]; P.mul[2] = div_b[0] * div_b[1];
     P.sentinel = (unsigned)total;                 // <= 2^31 - 1
     int bits = 1; while (bits < 32 && (1ull << bits) < (unsigned long long)total + 1ull) bits++;   // keys 0 .. total (sentinel included)
-    V->bits_guess = std::max(8, (bits + 7) / 8 * 8); V->guess_leaf = leaf;      // what the next filter of this leaf size may assume (voxel_filter_enqueue)
+    V->bits_guess[alt ? 1 : 0] = std::max(8, (bits + 7) / 8 * 8); V->guess_leaf[alt ? 1 : 0] = leaf; V->guess_low[alt ? 1 : 0] = 0;      // what the next filter of this site and leaf size may assume (voxel_filter_enqueue)
     HIPCHK(V->keys_a.ensure((size_t)n * 4)); HIPCHK(V->vals_a.ensure((size_t)n * 4));
     hipLaunchKernelGGL(k_vox_key, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, d_pts, n, P, V->keys_a.as<unsigned>(), V->vals_a.as<int>());
     return radix_sort(ctx, V, n, bits);
@@ -1036,7 +1038,7 @@ static int voxel_filter_tail(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const 
 // VoxelGrid of a device float4 cloud the measured way: the bounding box comes to the host, the host sizes the keys.  Blocking (two small read-backs).
 static int voxel_filter_measured(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const float4* d_pts, int n, float leaf, bool alt) {
     VoxDev P;
-    int rc = voxel_sort(ctx, V, d_pts, n, leaf, P);
+    int rc = voxel_sort(ctx, V, d_pts, n, leaf, P, alt);
     if (rc != LILI_OK) return rc;
     rc = voxel_filter_tail(ctx, V, d_pts, n, P.sentinel, alt);
     if (rc != LILI_OK) return rc;
@@ -1068,7 +1070,7 @@ static int voxel_filter_enqueue(lili_ctx* ctx, lili_detail::VoxelBuffers* V, con
         Q.mode = kPendSmall;
         return lili_readback_add(ctx, Q.res, d_res, sizeof(Q.res));
     }
-    if (ctx->voxel_guess_bits && V->bits_guess > 0 && V->guess_leaf == leaf) {
+    if (ctx->voxel_guess_bits && V->bits_guess[alt ? 1 : 0] > 0 && V->guess_leaf[alt ? 1 : 0] == leaf) {
         unsigned* d_mm = ctx->misc.as<unsigned>();
         // (box_zeroed: the caller vouches that the first six words of ctx->misc are zero — the frame pipeline enqueues this behind an index build's scratch fill)
         if (box_zeroed) hipLaunchKernelGGL(k_bbox_z, dim3(std::min(nblocks(n, 256), 512)), dim3(256), 0, ctx->stream, d_pts, n, d_mm);
@@ -1077,7 +1079,7 @@ static int voxel_filter_enqueue(lili_ctx* ctx, lili_detail::VoxelBuffers* V, con
             hipLaunchKernelGGL(k_bbox, dim3(std::min(nblocks(n, kBlock), 512)), dim3(kBlock), 0, ctx->stream, d_pts, n, d_mm);
         }
         HIPCHK(V->keys_a.ensure((size_t)n * 4)); HIPCHK(V->vals_a.ensure((size_t)n * 4));
-        const int bits = V->bits_guess;
+        const int bits = V->bits_guess[alt ? 1 : 0];
         hipLaunchKernelGGL(k_vox_key_dev, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, d_pts, n, 1.0f / leaf, (const unsigned*)d_mm, box_zeroed ? 1 : 0, bits, V->keys_a.as<unsigned>(),
                            V->vals_a.as<int>(), d_res);
         int rc = radix_sort(ctx, V, n, bits);
@@ -1105,7 +1107,13 @@ static int voxel_filter_complete(lili_ctx* ctx, lili_detail::VoxelBuffers* V) {
     }
     if (mode == kPendGuess) {
         V->key_guesses++;
-        if (Q.res[0] == 0) { n_out = Q.n_out; V->bits_guess = std::max(8, (Q.res[1] + 7) / 8 * 8); return LILI_OK; }
+        if (Q.res[0] == 0) {
+            n_out = Q.n_out;
+            const int site = Q.alt ? 1 : 0, need = std::max(8, (Q.res[1] + 7) / 8 * 8);
+            if (need >= V->bits_guess[site]) { V->bits_guess[site] = need; V->guess_low[site] = 0; }
+            else if (++V->guess_low[site] >= 8) { V->bits_guess[site] = need; V->guess_low[site] = 0; }
+            return LILI_OK;
+        }
         V->key_guess_misses++;      // more key bits than guessed, or one of the error cases: the measured path sorts it out
     }
     return voxel_filter_measured(ctx, V, Q.d_pts, Q.n, Q.leaf, Q.alt);
@@ -1277,6 +1285,7 @@ int lili_localmap_commit(lili_ctx* ctx, int kind, float leaf, double max_sq_radi
     bool have_box = false;
     if (inc) {
         // ---- incremental step(s): the merge, then the centroid pass over the sorted ring
+        { const int rl = lili_lazy_sources_clear_of(ctx, d_bad, kRankOff - 256 + (size_t)kVoxSmallMax * 4); if (rl != LILI_OK) return rl; }
         HIPCHK(hipMemsetAsync(d_bad, 0, kRankOff - 256 + (size_t)kVoxSmallMax * 4, ctx->stream));      // *bad ... the rank words of k_rank_count: one fill
         int rc = LILI_OK;
         if (add.empty()) rc = sorted_ring_step(ctx, V, S, drop, n_drop, nullptr, leaf, d_bad);

@@ -51,8 +51,8 @@ def replay(bag_path, ctx, lidar_topic="/livox/lidar", imu_topic="/imu", first_po
             else:
                 t0, q0 = _predict(poses)
             t, q, info = odo.frame(pts5, t0, q0, q_imu)
-            if info["gn_status"] != 0:
-                t, q = np.asarray(t0, np.float64), np.asarray(q0, np.float64)
+            # (a frame whose last Gauss-Newton step was rejected keeps the pose the slot holds — the last accepted iterate, which is also the pose the frame
+            #  joined the ring at; the staged path below does the same, so trajectory, next prediction and local map agree on such frames)
             poses.append((t, q))
             rec = dict(stamp=stamp, t=t, q=q, n_surf=info["n_surf"], n_edge=info["n_edge"], n_query=info["n_query"], q_imu=q_imu)
             out.append(rec)
@@ -71,9 +71,7 @@ def replay(bag_path, ctx, lidar_topic="/livox/lidar", imu_topic="/imu", first_po
             matcher.set_queries(0, A.KIND_SURF, qry)
             matcher.pose_set(0, t0, q0)
             matcher.iterate(0, n_outer_first if len(poses) == 1 else n_outer, A.MASK_SURF)
-            t, q, st = matcher.pose_get(0)
-            if st != 0:
-                t, q = t0, q0
+            t, q, st = matcher.pose_get(0)      # status != 0: the last accepted iterate (as the fused path)
         poses.append((t, q))
         local.push(qry, t, q)
         rec = dict(stamp=stamp, t=t, q=q, n_surf=int(f["surf"].shape[0]), n_edge=int(f["edge"].shape[0]), n_query=int(qry.shape[0]), q_imu=q_imu)

@@ -400,6 +400,7 @@ def test_window_gather_at_the_solvers_poses_equals_the_plain_window_evaluation()
     """lili_s2m_linearize_window_gather_at (round 6: what LidarWindowFactor::gather_over_ranks calls per Ceres evaluation): one rank owning every keyframe, no exchange —
     the records at the poses of the call are those of lili_s2m_linearize_window, bit for bit (a -0.0 entry reads +0.0)."""
     import torch
+    import lili_om_amd as L
     room, P, poses, sq, eq = _window_scene()
     ctx = L.Context(0)
     try:

@@ -30,8 +30,6 @@ m.pose_set(0, t0, q0)
 m.iterate(0, after, L.MASK_SURF)
 ctx.sync()
 os.environ["LILI_DEBUG"] = str(4096 | extra)
-if len(sys.argv) > 3:
-    ctx.set_option("balance", int(sys.argv[3]))
 for rep in range(5):
     m.associate_dev(0, L.MASK_SURF)
     ctx.sync()
