@@ -348,9 +348,87 @@ def config1(L, ctx, torch, synth, n_frames=100, cpu=True):
                                     oracle_ate_rms_m=round(float(np.sqrt(np.mean([np.sum((p[0] - _circuit(f)[0]) ** 2) for f, p in enumerate(po)]))), 4))
         except Exception as e:      # noqa: BLE001
             out["cpu"] = {"error": repr(e)}
+    try:
+        out["backend_keyframes"] = _config1_backend(L, synth, frames, poses, cpu=cpu)
+        if out["backend_keyframes"].get("parity", {}).get("pass") is False:
+            out["gn_status"] = max(out["gn_status"], 1)
+    except Exception as e:      # noqa: BLE001
+        out["backend_keyframes"] = {"error": repr(e)}
     for p in pins:
         p.close()
     return out
+
+
+def _config1_backend(L, synth, frames, poses, every=10, cpu=True):
+    """SURVEY Config 1 also names the Livox BACK-END matcher (reflectivity-weighted surf + edges, L/src/BackendFusion.cpp:1531-1681, lidar_const 20, reflect_thres 15): every
+    `every`-th frame of the same sequence is a keyframe — its surf + edge features (reflectivity in the auxiliary float) go through ONE lili_backend_keyframe_prepare (both
+    rings, both maps, down-sampling, association of the 3-keyframe window) and one evaluation of the window; parity per keyframe against the oracle's Livox flavour: the
+    Gauss-Newton step the GPU's Gram implies vs the step from the oracle's Gram of the oracle's own maps and correspondences."""
+    P = L.make_params("livox")
+    ctx = L.Context(0)
+    try:
+        ex = L.LivoxExtractor(ctx)
+        m = L.ScanToMapMatcher(ctx, P)
+        m.map_focus(None)
+        bk = L.BackendKeyframes(ctx, P, leaf_surf=0.4, leaf_edge=0.2, width=40)
+        mask = L.MASK_SURF | L.MASK_EDGE
+        ids = list(range(0, len(frames), every))
+        feats = []
+        for f in ids:
+            o = ex.extract(frames[f])
+            feats.append((np.ascontiguousarray(o["surf"][:, [0, 1, 2, 7]]), np.ascontiguousarray(o["edge"][:, [0, 1, 2, 7]])))
+        K = 3
+        rows, t_acc, n_t = [], 0.0, 0
+        for rep in range(2):      # first pass untimed
+            ctx._chk(ctx.lib.lili_localmap_reset(ctx.h, L.KIND_SURF)); ctx._chk(ctx.lib.lili_localmap_reset(ctx.h, L.KIND_EDGE))
+            rows = []
+            for k, f in enumerate(ids):
+                win = list(range(max(0, k - K + 1), k + 1))
+                slots = [j % K for j in win]
+                lid = [poses[ids[j]] for j in win]                                   # the odometry's LiDAR poses (map frame)
+                body = [L.api.body_pose_from_lidar(t, q, P) for t, q in lid]
+                assoc = [L.api.assoc_transform(t, q, P) for t, q in body]
+                join = None if k == 0 else ((k - 1) % K, poses[ids[k - 1]][0], poses[ids[k - 1]][1])
+                ctx.sync(); tic = time.perf_counter()
+                counts, info = bk.prepare(join, feats[k][0], feats[k][1], slots, [a[1] for a in assoc], [a[0] for a in assoc])
+                win_eval = m.linearize_window(slots, [b[0] for b in body], [b[1] for b in body], mask) if k else None
+                if rep and k:
+                    t_acc += time.perf_counter() - tic; n_t += 1
+                rows.append((counts, info, win_eval, body, assoc, slots))
+        out = {"keyframes": len(ids), "every_nth_frame": every, "ms_per_keyframe": round(t_acc / max(n_t, 1) * 1e3, 4),
+               "correspondences_per_keyframe_window": int(np.mean([sum(a + b for a, b in r[0]) for r in rows[1:]])),
+               "what": "Livox back-end flavour on the configs[1] sequence: lili_backend_keyframe_prepare + one lili_s2m_linearize_window per keyframe (3-keyframe window, 40-keyframe rings)"}
+        if cpu:
+            from oracle import oracle as O
+            PO = O.params("livox")
+            ring_s, ring_e, ds, dts, das, cnt_ok = [], [], [], [], [], True
+            for k, f in enumerate(ids):
+                if k:
+                    tj, qj = poses[ids[k - 1]]
+                    ring_s.append(O.transform_cloud(ds[k - 1][0], qj, tj)); ring_e.append(O.transform_cloud(ds[k - 1][1], qj, tj))
+                    ms, me = O.voxel_grid(np.concatenate(ring_s[-40:]), 0.4, stable=True)[0], O.voxel_grid(np.concatenate(ring_e[-40:]), 0.2, stable=True)[0]
+                    tree_s, tree_e = O.KdTree(np.ascontiguousarray(ms[:, :3])), O.KdTree(np.ascontiguousarray(me[:, :3]))
+                ds.append((O.voxel_grid(feats[k][0], 0.4, stable=True)[0], O.voxel_grid(feats[k][1], 0.2, stable=True)[0]))
+                if not k:
+                    continue
+                counts, info, win_eval, body, assoc, slots = rows[k]
+                win = list(range(max(0, k - K + 1), k + 1))
+                for i, j in enumerate(win):
+                    rs = O.associate_surf(tree_s, np.ascontiguousarray(ms[:, 3]), np.ascontiguousarray(ds[j][0][:, :3]), np.ascontiguousarray(ds[j][0][:, 3]), assoc[i][0], assoc[i][1], PO)
+                    re_ = O.associate_edge(tree_e, np.ascontiguousarray(ds[j][1][:, :3]), assoc[i][0], assoc[i][1], PO)
+                    Gs, _, _ = O.linearize_surf(rs, body[i][0], body[i][1], PO)
+                    Ge, _, _ = O.linearize_edge(re_, body[i][0], body[i][1], PO)
+                    cnt_ok = cnt_ok and (int(rs["count"]), int(re_["count"])) == counts[i]
+                    _, tg_, qg_, _ = O.gn_step(np.asarray(win_eval[i][0], np.float64).reshape(8, 8), body[i][0], body[i][1])
+                    _, to_, qo_, _ = O.gn_step(Gs + Ge, body[i][0], body[i][1])
+                    d = _pose_delta(tg_, qg_, to_, qo_)
+                    dts.append(d[0]); das.append(d[1])
+            out["parity"] = _parity(max(dts), max(das), what="per keyframe of every window: Gauss-Newton step from the GPU's Gram (device rings, maps, down-sampling, Livox-flavour "
+                                                              "association) vs the step from the oracle's Gram of the oracle's own maps and correspondences, same pose",
+                                    counts_equal=bool(cnt_ok), window_evaluations=len(dts))
+        return out
+    finally:
+        ctx.close()
 
 
 # ------------------------------------------------------------------------------------------------------------------------------

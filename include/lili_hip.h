@@ -110,7 +110,8 @@ int lili_set_debug(lili_ctx* ctx, int keep_neighbors);
  *                 default 1);
  *   local map     "localmap_incremental" (default 1, see lili_localmap_commit), "localmap_super_rows" (1 = ring maps below 400 k points get the
  *                 super-row copy too; default 0), "sort_digit_bits" (8, or 4 = the round-2 radix passes), "sort_fused_scan" (1 = radix passes of at most
- *                 "sort_fused_max_tiles" (256) tiles derive their offsets inside the scatter kernel; default 1), "voxel_small" (1 = clouds of <= 8192
+ *                 "sort_fused_max_tiles" (256) tiles derive their offsets inside the scatter kernel; default 1), "sort_ride_hist" (1 = in the frame pipeline's query filter the
+ *                 digit histograms ride on the key kernel and the scatter passes, one launch per pass; default 1), "voxel_small" (1 = clouds of <= 8192
  *                 points are voxel-filtered / keyframe-sorted by ONE workgroup in LDS; default 1), "voxel_guess_bits" (see lili_voxel_filter_stats; default 1);
  *   host          "readback_gather" (1 = the small reads of a synchronisation are gathered by one kernel writing into page-locked memory instead of
  *                 one copy launch each; default 1).

@@ -184,6 +184,7 @@ struct lili_ctx {
     bool localmap_incremental = true;   // lili_localmap_commit keeps the ring sorted by voxel and merges one keyframe per step (0: rebuild every time, A/B)
     int sort_fused_max_tiles = 256;   // (measured: 200 k keys 212 -> 190 us per filter, 1 M keys 301 -> 296; 489 tiles of a 2 M-key sort: 290 -> 475 us)
     bool sort_fused_scan = true;      // radix passes of at most sort_fused_max_tiles tiles: the scatter kernel derives its offsets from the count table itself (no scan launch)
+    bool sort_ride_hist = true;         // the radix sort's digit histograms ride on the key kernel and on the scatter passes (a pass = one launch; 0: a histogram launch per pass, A/B)
     int sort_digit_bits = 8;     // radix sort of the voxel filter: 8-bit digits (4 = the round-2 passes, A/B)
     int rot_atan = 2;            // ROT extractor: 2 = glibc fdlibm float atan / atan2 (the reference build's bits), 1 = f64 functions rounded to f32
     int n_simd = 0;              // SIMDs of the device (CUs x 4)

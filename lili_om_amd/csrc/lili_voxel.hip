@@ -23,6 +23,19 @@ __global__ void k_bbox_dev(const float4*, const int*, int, unsigned*);
 
 constexpr int kSortBlock = 256, kSortItems = 8, kSortTile = kSortBlock * kSortItems;
 
+// One atomic per DISTINCT table entry and wave: the lanes of a wave that count the same entry (`idx` < 2^16) are found with sixteen ballots and the lowest of them adds
+// their number.  (Plain per-lane atomics on the digit tables serialised on a few hot counters — neighbouring points share voxels: +85 us per frame of the front-end pipeline.)
+__device__ __forceinline__ void wave_hist_add(int* __restrict__ hist, unsigned idx, bool live) {
+    unsigned long long peers = __ballot(live);
+#pragma unroll
+    for (int b = 0; b < 16; b++) {
+        const unsigned long long m = __ballot((idx >> b) & 1u);
+        peers &= ((idx >> b) & 1u) ? m : ~m;
+    }
+    const int lane = threadIdx.x & 63;
+    if (live && (peers & ((1ull << lane) - 1ull)) == 0ull) atomicAdd(&hist[idx], __popcll(peers));
+}
+
 __global__ __launch_bounds__(kSortBlock) void k_sort_hist(const unsigned* __restrict__ keys, int n, int shift, int nb, int* __restrict__ hist /*[16][nb]*/) {
     __shared__ int h[16];
     if (threadIdx.x < 16) h[threadIdx.x] = 0;
@@ -109,7 +122,8 @@ __global__ __launch_bounds__(kSortBlock) void k_sort_hist8(const unsigned* __res
 // table reads cost more than the scan, option sort_fused_max_tiles).
 __global__ __launch_bounds__(kSortBlock) void k_sort_scatter8(const unsigned* __restrict__ keys_in, const int* __restrict__ vals_in, int n, int shift, int nb, int items,
                                                               const int* __restrict__ offs /*[256][nb] exclusive, or counts*/, int raw_hist, unsigned* __restrict__ keys_out,
-                                                              int* __restrict__ vals_out) {
+                                                              int* __restrict__ vals_out, int* __restrict__ hist_next /*[256][nb] counts of the NEXT pass's digit per OUTPUT tile (zeroed by the
+                                                              caller), or nullptr*/, int next_shift) {
     __shared__ int base[256];                 // running offset of each digit inside this tile
     __shared__ int wcnt[kSortBlock / 64][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -145,12 +159,15 @@ __global__ __launch_bounds__(kSortBlock) void k_sort_scatter8(const unsigned* __
         __syncthreads();
         if (live && rank == 0) wcnt[wave][d] = __popcll(peers);
         __syncthreads();
+        int opos = 0;
         if (live) {
             int off = base[d];
             for (int w = 0; w < wave; w++) off += wcnt[w][d];
             keys_out[off + rank] = key;
             vals_out[off + rank] = val;
+            opos = off + rank;
         }
+        if (hist_next) wave_hist_add(hist_next, ((key >> next_shift) & 255u) * (unsigned)nb + (unsigned)(opos / (kSortBlock * items)), live);      // (round 6: saves the next pass's k_sort_hist8 launch)
         __syncthreads();
         { int s = 0; for (int w = 0; w < kSortBlock / 64; w++) s += wcnt[w][threadIdx.x]; base[threadIdx.x] += s; }
         __syncthreads();
@@ -179,7 +196,9 @@ __global__ void k_vox_key(const float4* __restrict__ pts, int n, VoxDev V, unsig
 }
 // k_bbox into words that start from ZERO (words 0-2: ~ordered(min), 3-5: ordered(max), all maximised): a caller whose scratch has just been cleared by a fill it needs
 // anyway saves the launch that arms the box (k_box_init)
-__global__ __launch_bounds__(256) void k_bbox_z(const float4* __restrict__ pts, int n, unsigned* __restrict__ mmz) {
+// `zero` / `n_zero` (round 6): words this launch clears on the way — the digit tables of the radix sort behind it (the histograms ride on the key and scatter kernels)
+__global__ __launch_bounds__(256) void k_bbox_z(const float4* __restrict__ pts, int n, unsigned* __restrict__ mmz, int* __restrict__ zero, int n_zero) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_zero; i += gridDim.x * blockDim.x) zero[i] = 0;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float4 p = pts[i];
@@ -211,7 +230,8 @@ __global__ __launch_bounds__(256) void k_bbox_z(const float4* __restrict__ pts, 
 // 2 (no finite point), 3 (PCL's int32 voxel-index overflow) and res[1] = the bits the keys need come back with the filter's voxel count.  Same arithmetic as the host
 // code of voxel_sort + k_vox_key; non-finite points get the key 2^bits_guess - 1, above every voxel index.
 __global__ void k_vox_key_dev(const float4* __restrict__ pts, int n, float inv_leaf, const unsigned* __restrict__ mm, int zform /*1: the minima are stored inverted (k_bbox_z)*/,
-                              int bits_guess, unsigned* __restrict__ keys, int* __restrict__ vals, int* __restrict__ res) {
+                              int bits_guess, unsigned* __restrict__ keys, int* __restrict__ vals, int* __restrict__ res,
+                              int* __restrict__ hist0 /*[256][nb] counts of the lowest digit per sort tile, or nullptr*/, int nb, int tile) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     auto dec = [](unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); };
     int min_b[3], div_b[3];
@@ -234,14 +254,21 @@ __global__ void k_vox_key_dev(const float4* __restrict__ pts, int n, float inv_l
         if (status == 0 || status == 1) while (bits < 32 && (double)(1ull << bits) < total + 1.0) bits++;
         res[0] = status; res[1] = bits;
     }
-    if (i >= n) return;
-    vals[i] = i;
-    const float4 p = pts[i];
-    if (status != 0 || !(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) { keys[i] = sentinel; return; }
-    const int i0 = (int)(floorf(p.x * inv_leaf) - (float)min_b[0]);
-    const int i1 = (int)(floorf(p.y * inv_leaf) - (float)min_b[1]);
-    const int i2 = (int)(floorf(p.z * inv_leaf) - (float)min_b[2]);
-    keys[i] = (unsigned)(i0 * 1 + i1 * div_b[0] + i2 * (div_b[0] * div_b[1]));
+    const bool live = i < n;
+    unsigned key = sentinel;
+    if (live) {
+        vals[i] = i;
+        const float4 p = pts[i];
+        if (status == 0 && isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+            const int i0 = (int)(floorf(p.x * inv_leaf) - (float)min_b[0]);
+            const int i1 = (int)(floorf(p.y * inv_leaf) - (float)min_b[1]);
+            const int i2 = (int)(floorf(p.z * inv_leaf) - (float)min_b[2]);
+            key = (unsigned)(i0 * 1 + i1 * div_b[0] + i2 * (div_b[0] * div_b[1]));
+        }
+        keys[i] = key;
+    }
+    // the first pass's digit counts (k_sort_hist8 would count the same); table entry = digit * nb + tile, nb <= 256 tiles
+    if (hist0) wave_hist_add(hist0, (key & 255u) * (unsigned)nb + (unsigned)(live ? i / tile : 0), live);
 }
 // Key of one keyframe's points for the sorted ring WITHOUT a host round trip: voxel coordinates relative to the keyframe's own bounding box
 // (ordered-uint words `mm` left in device memory by k_bbox), packed (i2 : 10 bits, i1 : 11, i0 : 11) — the same lexicographic order as the
@@ -959,16 +986,34 @@ static int exclusive_scan(lili_ctx* ctx, lili_detail::VoxelBuffers* V, const int
 
 // sorts (keys_a, vals_a) by the low `bits` bits, stable; result ends in (keys_a, vals_a).  8-bit digits (option sort_digit_bits = 4: the
 // round-2 passes, for A/B)
-static int radix_sort(lili_ctx* ctx, lili_detail::VoxelBuffers* V, int n, int bits) {
+// `ride`: the digit counts of pass 0 are already in table 0 of V->hist (k_vox_key_dev counted them) and tables 1 .. are zero: every scatter pass counts the next pass's
+// digits as it places its keys — a pass is ONE launch (round 6; the caller has sized and cleared V->hist through radix_ride_tables).
+static bool radix_can_ride(const lili_ctx* ctx, int n) {
+    if (ctx->sort_digit_bits == 4 || !ctx->sort_fused_scan || !ctx->sort_ride_hist) return false;
+    const int items8 = n <= 262144 ? 4 : 16;
+    return (n + 256 * items8 - 1) / (256 * items8) <= ctx->sort_fused_max_tiles;
+}
+static void radix_geometry(int n, int& items8, int& nb) { items8 = n <= 262144 ? 4 : 16; nb = (n + 256 * items8 - 1) / (256 * items8); }
+static int radix_sort(lili_ctx* ctx, lili_detail::VoxelBuffers* V, int n, int bits, bool ride = false) {
     const int dbits = ctx->sort_digit_bits == 4 ? 4 : 8, ndig = 1 << dbits;
     // 8-bit digits: keys per tile by size — a tile is walked in rounds of 256 keys (one block barrier set per round), so a keyframe's 20 k keys
     // spread over 20 four-round tiles sort in a third of the time five 16-round tiles take; 1 M keys keep 4096-key tiles (digit table 62 k words)
     const int items8 = n <= 262144 ? 4 : kSortItems8;      // (one-round tiles made the digit table — 256 words per tile — the bottleneck: its scan is one workgroup)
     const int nb = nblocks(n, dbits == 8 ? kSortBlock * items8 : kSortTile);
-    HIPCHK(V->hist.ensure((size_t)ndig * nb * sizeof(int)));
+    if (!ride) HIPCHK(V->hist.ensure((size_t)ndig * nb * sizeof(int)));
     HIPCHK(V->hist_scan.ensure(((size_t)ndig * nb + 1) * sizeof(int)));
     HIPCHK(V->keys_b.ensure((size_t)n * 4)); HIPCHK(V->vals_b.ensure((size_t)n * 4));
     const int passes = std::max(1, (bits + dbits - 1) / dbits);
+    if (ride) {
+        for (int p = 0; p < passes; p++) {
+            int* tab = V->hist.as<int>() + (size_t)p * ndig * nb;
+            hipLaunchKernelGGL(k_sort_scatter8, dim3(nb), dim3(kSortBlock), 0, ctx->stream, V->keys_a.as<unsigned>(), V->vals_a.as<int>(), n, dbits * p, nb, items8, (const int*)tab, 1,
+                               V->keys_b.as<unsigned>(), V->vals_b.as<int>(), p + 1 < passes ? tab + (size_t)ndig * nb : (int*)nullptr, dbits * (p + 1));
+            HIPCHK(hipGetLastError());
+            V->keys_a.swap(V->keys_b); V->vals_a.swap(V->vals_b);
+        }
+        return LILI_OK;
+    }
     for (int p = 0; p < passes; p++) {
         const int shift = dbits * p;
         unsigned *ka = V->keys_a.as<unsigned>(), *kb = V->keys_b.as<unsigned>();
@@ -978,7 +1023,7 @@ static int radix_sort(lili_ctx* ctx, lili_detail::VoxelBuffers* V, int n, int bi
         const bool fused_scan = ctx->sort_fused_scan && dbits == 8 && nb <= ctx->sort_fused_max_tiles;      // (see k_sort_scatter8)
         if (!fused_scan) { const int rc = exclusive_scan(ctx, V, V->hist.as<int>(), (int64_t)ndig * nb, V->hist_scan.as<int>()); if (rc != LILI_OK) return rc; }
         if (dbits == 8) hipLaunchKernelGGL(k_sort_scatter8, dim3(nb), dim3(kSortBlock), 0, ctx->stream, ka, va, n, shift, nb, items8,
-                                           fused_scan ? V->hist.as<int>() : V->hist_scan.as<int>(), fused_scan ? 1 : 0, kb, vb);
+                                           fused_scan ? V->hist.as<int>() : V->hist_scan.as<int>(), fused_scan ? 1 : 0, kb, vb, (int*)nullptr, 0);
         else hipLaunchKernelGGL(k_sort_scatter, dim3(nb), dim3(kSortBlock), 0, ctx->stream, ka, va, n, shift, nb, V->hist_scan.as<int>(), kb, vb);
         HIPCHK(hipGetLastError());
         V->keys_a.swap(V->keys_b); V->vals_a.swap(V->vals_b);      // the sorted pairs are the new `a` (buffers trade places, nothing is copied)
@@ -1073,16 +1118,23 @@ static int voxel_filter_enqueue(lili_ctx* ctx, lili_detail::VoxelBuffers* V, con
     if (ctx->voxel_guess_bits && V->bits_guess[alt ? 1 : 0] > 0 && V->guess_leaf[alt ? 1 : 0] == leaf) {
         unsigned* d_mm = ctx->misc.as<unsigned>();
         // (box_zeroed: the caller vouches that the first six words of ctx->misc are zero — the frame pipeline enqueues this behind an index build's scratch fill)
-        if (box_zeroed) hipLaunchKernelGGL(k_bbox_z, dim3(std::min(nblocks(n, 256), 512)), dim3(256), 0, ctx->stream, d_pts, n, d_mm);
+        const int bits = V->bits_guess[alt ? 1 : 0];
+        // round 6: the sort's histograms ride on the key kernel and on the scatter passes (three launches fewer per filter); the box pass clears their tables
+        const bool ride = box_zeroed && radix_can_ride(ctx, n);
+        int items8 = 0, nb_sort = 0;
+        radix_geometry(n, items8, nb_sort);
+        const int passes = std::max(1, (bits + 7) / 8);
+        if (ride) HIPCHK(V->hist.ensure((size_t)passes * 256 * nb_sort * sizeof(int)));
+        if (box_zeroed) hipLaunchKernelGGL(k_bbox_z, dim3(std::min(nblocks(n, 256), 512)), dim3(256), 0, ctx->stream, d_pts, n, d_mm, ride ? V->hist.as<int>() : (int*)nullptr,
+                                           ride ? passes * 256 * nb_sort : 0);
         else {
             hipLaunchKernelGGL(k_box_init, dim3(1), dim3(64), 0, ctx->stream, d_mm);
             hipLaunchKernelGGL(k_bbox, dim3(std::min(nblocks(n, kBlock), 512)), dim3(kBlock), 0, ctx->stream, d_pts, n, d_mm);
         }
         HIPCHK(V->keys_a.ensure((size_t)n * 4)); HIPCHK(V->vals_a.ensure((size_t)n * 4));
-        const int bits = V->bits_guess[alt ? 1 : 0];
         hipLaunchKernelGGL(k_vox_key_dev, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, d_pts, n, 1.0f / leaf, (const unsigned*)d_mm, box_zeroed ? 1 : 0, bits, V->keys_a.as<unsigned>(),
-                           V->vals_a.as<int>(), d_res);
-        int rc = radix_sort(ctx, V, n, bits);
+                           V->vals_a.as<int>(), d_res, ride ? V->hist.as<int>() : (int*)nullptr, nb_sort, kSortBlock * items8);
+        int rc = radix_sort(ctx, V, n, bits, ride);
         if (rc != LILI_OK) return rc;
         rc = voxel_filter_tail(ctx, V, d_pts, n, bits >= 32 ? 0xFFFFFFFFu : (1u << bits) - 1u, alt);
         if (rc != LILI_OK) return rc;
