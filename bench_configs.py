@@ -737,7 +737,7 @@ def config2b(L, ctx, torch, synth, cpu=True, ips=10):
             out["cpu"] = {"value": round(1.0 / t_cpu, 2), "unit": "scan-to-map iterations/s", "cores": nth, "kind": "port",
                           "sample": f"the oracle: ONE registration of {ips} outer iterations of the same workload on {nth} threads (lo_register_surf; kd-tree build excluded)"}
             dt, da = _pose_delta(tg1, qg1, to, qo)
-            out["parity"] = _parity(dt, da, what=f"pose after one registration ({ips} outer iterations from the same start): GPU (fine index first, gate-sized index for the rest) vs the oracle's exact kd-tree",
+            out["parity"] = _parity(dt, da, what=f"pose after one registration ({ips} outer iterations from the same start): GPU (the density-sized fine index alone: inner 27 cells per lane, rings of super-rows by 16 lanes per query for the rest) vs the oracle's exact kd-tree",
                                     correspondences_oracle_last_iteration=int(counts[-1]), gn_status=int(st1))
             if int(st1) != 0:
                 out["gn_status"] = int(st1)

@@ -44,7 +44,7 @@ struct MapIndex {
     GridView view{};
     DevBuf sorted, aux_sorted, cell_start, cell_tmp, pt_cell /* rank of every point inside its cell (int), between the count and the scatter pass */, block_sums, cell_start9, row9;
     bool has_aux = false;
-    // density adaptation: a second index with cells sized from the measured density (dense maps only), searched first
+    // density adaptation: a second index with cells sized from the measured density (dense maps only) — the ONLY one the association of a dense map searches (lili_s2m_dense.hip)
     bool has_fine = false;
     GridView fview{};
     DevBuf sorted_f, aux_sorted_f, cell_start_f, cell_start9_f;

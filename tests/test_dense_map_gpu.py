@@ -1,7 +1,8 @@
 """SURVEY §8d Config 2, variant B — a map far denser than the gate radius (0.05 m spacing against a 1 m gate: ~170 points per gate-sized
-cell).  lili_map_set measures the density and builds the second, density-sized index; the association searches it first and falls back to
-the gate-sized index only where it cannot find five points inside the radius it covers.  Exactness: neighbours (indices, f32 distances),
-records and the Gram are those of the oracle's exact kd-tree, and identical — bit for bit — to the gate-sized index alone."""
+cell).  lili_map_set measures the density and builds the second, density-sized index; the association searches THAT index alone (round 6:
+inner 27 fine cells per lane, then rings of super-rows by 16 lanes per query for the queries that are not settled; lili_s2m_dense.hip).
+Exactness: neighbours (indices, f32 distances), records and the Gram are those of the oracle's exact kd-tree, and identical — bit for bit —
+to the gate-sized index alone (option fine_grid = 0)."""
 import time
 
 import numpy as np

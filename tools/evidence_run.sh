@@ -4,7 +4,7 @@
 # driver's command, kernel traces of the front-end frame pipeline (configs[1]), small launches, device LM, local map, ROT extractor, index build, the any-order launch probe.
 # Outputs under gpurun_out/<tag>; tools/collect.sh <tag> <round> copies the judged ones to profiles/.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-TAG=${1:-r05x}
+TAG=${1:-r06x}
 OUT=gpurun_out/$TAG; mkdir -p $OUT tools/_probe
 ( time timeout 1500 python -m pytest tests -m gpu -q ) > $OUT/pytest_all.log 2>&1
 grep -E "passed|failed" $OUT/pytest_all.log | tail -2
@@ -30,3 +30,14 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o k7 -
 python tools/kstats.py $OUT/k7_kernel_stats.csv | head -12
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 tools/anyorder_probe.hip -o tools/_probe/anyorder_probe > /dev/null 2>&1 && timeout 120 tools/_probe/anyorder_probe > $OUT/anyorder_probe.txt 2>&1
 LILI_PHASES=1 timeout 200 python bench.py --no-extras --no-cpu-baseline 2> $OUT/iteration_phases.txt > /dev/null; grep -v "synth\|bench\]\|amdgpu" $OUT/iteration_phases.txt | tail -14
+# ---- round 6: configs[2] variant B (dense map) launch by launch, its PMC passes, the memory-pattern probe behind its roofline, the index build's traffic kernel by kernel
+echo "== dense map (configs[2] variant B)"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o dense2b -- python tools/dense_2b_probe.py > $OUT/dense2b_probe.jsonl 2> $OUT/dense2b.err
+tail -2 $OUT/dense2b_probe.jsonl; python tools/kstats.py $OUT/dense2b_kernel_stats.csv | head -6
+bash tools/pmc_2b.sh $TAG/pmc2b > $OUT/dense2b_pmc.json 2> $OUT/dense2b_pmc.err; tail -40 $OUT/dense2b_pmc.json | head -60
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/randrun_probe.hip -o tools/_probe/randrun_probe > /dev/null 2>&1 && timeout 120 tools/_probe/randrun_probe > $OUT/randrun_probe.txt 2>&1; cat $OUT/randrun_probe.txt
+echo "== index build traffic"
+bash tools/k7_pmc.sh $TAG/k7pmc > $OUT/k7_pmc.log 2>&1; cp gpurun_out/$TAG/k7pmc/k7_traffic.json $OUT/k7_traffic.json 2>/dev/null; tail -12 $OUT/k7_pmc.log
+echo "== frame pipeline probe"; python tools/frame_probe.py 2>/dev/null | tail -1
+echo "== back-end keyframe"; ./examples/backend_demo 60 2500 250 40 3
+

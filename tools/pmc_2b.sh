@@ -8,5 +8,4 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/$TAG
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d gpurun_out/$TAG -o p3 -- $B > /dev/null 2> gpurun_out/$TAG/p3.err
 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_REQ_sum --kernel-trace --output-format csv -d gpurun_out/$TAG -o p4 -- $B > /dev/null 2> gpurun_out/$TAG/p4.err
 rocprofv3 --pmc SQ_WAIT_ANY SQ_INSTS_SALU SQ_INSTS_LDS SQ_INST_CYCLES_VMEM TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum --kernel-trace --output-format csv -d gpurun_out/$TAG -o p5 -- $B > /dev/null 2> gpurun_out/$TAG/p5.err
-tail -2 gpurun_out/$TAG/p*.err | grep -v "^$" | head -20
 python tools/pmc_2b_summary.py gpurun_out/$TAG
