@@ -175,3 +175,38 @@ def test_dense_map_borders_focus_box_and_both_selectors(gpu_ctx, oracle):
             assert out[kind][0] == base_out[kind][0], (name, kind)
         for k in ("query_index", "n", "d", "score"):
             assert np.array_equal(rec[k], base_rec[k]), (name, k)
+
+
+def test_dense_map_livox_flavour_reads_reflectivity_through_the_fine_index(gpu_ctx, oracle):
+    """The Livox back-end flavour weights the plane fit by reflectivity differences (L/src/BackendFusion.cpp:1617-1638): on a dense map the neighbours' reflectivity comes from the
+    fine index's own sorted auxiliary array.  Records equal the gate-sized index alone bit for bit, counts and neighbours equal the oracle's."""
+    mp = _dense_room(seed=9, size=(7.0, 6.0, 3.0))
+    rng = np.random.default_rng(21)
+    refl = (10.0 + 2.0 * np.sin(0.7 * mp[:, 0]) + 2.0 * np.cos(0.5 * mp[:, 1]) + rng.normal(0, 0.3, mp.shape[0])).astype(np.float32)      # smooth: the five neighbours pass reflect_thres
+    n_q = 3000
+    pick = rng.choice(mp.shape[0], n_q)
+    qw = mp[pick].astype(np.float64) + rng.normal(0, 0.01, (n_q, 3)) + rng.uniform(-0.15, 0.15, (n_q, 3))
+    q_refl = (refl[pick] + rng.normal(0, 0.4, n_q)).astype(np.float32)
+    t_true = np.array([0.3, 0.2, 1.4]); ang = np.radians(-10.0)
+    q_true = np.array([np.cos(ang / 2), 0, 0, np.sin(ang / 2)])
+    q_local = synth.quat_rot(q_true * np.array([1, -1, -1, -1]), qw - t_true).astype(np.float32)
+    P, PO = L.make_params("livox"), oracle.params("livox")
+    res = {}
+    try:
+        gpu_ctx.set_option("map_guess_box", 0)
+        for fine in (1, 0):
+            gpu_ctx.set_option("fine_grid", fine)
+            m = L.ScanToMapMatcher(gpu_ctx, P)
+            m.set_input_cloud(L.KIND_SURF, np.c_[mp, refl])
+            assert (m.map_density(L.KIND_SURF)[1] > 0) == bool(fine)
+            m.set_queries(0, L.KIND_SURF, np.c_[q_local, q_refl])
+            n = m.find_corresponding_surf_features(0, q_true, t_true)
+            res[fine] = (n, m.surf_records(0, n_q))
+    finally:
+        gpu_ctx.set_option("map_guess_box", 1)
+        gpu_ctx.set_option("fine_grid", 1)
+    assert res[1][0] == res[0][0] > 500
+    for k in ("query_index", "cp", "n", "d", "score"):
+        assert np.array_equal(res[1][1][k], res[0][1][k]), k
+    o = oracle.associate_surf(oracle.KdTree(mp), refl, q_local, q_refl, q_true, t_true, PO)
+    assert res[1][0] == o["count"] and np.array_equal(res[1][1]["query_index"], np.nonzero(o["valid"])[0])
