@@ -640,8 +640,9 @@ def blocking_seam(L, ctx, torch, m, P, queries, t, q):
 # configs[2], variant B: the same 200 k-query / 5 M-point sizes on a map voxelised at 0.05 m — ~170 points per gate-sized cell, the
 # density-adaptive fine index.  VERDICT r4 #5a: inside the default bench run, with its own parity and roofline fraction.
 # ------------------------------------------------------------------------------------------------------------------------------
-def make_variant_b(n_map=5_000_000, n_q=200_000, seed=0x11110):
-    """An 80 x 60 x 12 m room sampled at ~0.05 m and queries near its surfaces (tools/bench_variant_b.py shares this generator)."""
+def make_variant_b(n_map=5_000_000, n_q=200_000, seed=0x11110, scan_order=False):
+    """An 80 x 60 x 12 m room sampled at ~0.05 m and queries near its surfaces (tools/bench_variant_b.py shares this generator).  scan_order: the SAME queries sorted by the map
+    point they were drawn from (the map is stored surface by surface, row by row) — neighbouring queries lie next to each other in space, as the returns of a real scan do."""
     from lili_om_amd import synth
     rng = np.random.default_rng(seed)
     leaf = 0.05
@@ -662,7 +663,10 @@ def make_variant_b(n_map=5_000_000, n_q=200_000, seed=0x11110):
     mp = np.concatenate(parts)
     if mp.shape[0] > n_map:
         mp = mp[np.sort(rng.permutation(mp.shape[0])[:n_map])]          # keeps the surface-by-surface order a voxel filter leaves
-    qw = mp[rng.choice(mp.shape[0], n_q)].astype(np.float64) + rng.normal(0, 0.02, (n_q, 3))
+    pick = rng.choice(mp.shape[0], n_q)
+    qw = mp[pick].astype(np.float64) + rng.normal(0, 0.02, (n_q, 3))
+    if scan_order:
+        qw = qw[np.argsort(pick, kind="stable")]
     t_true = np.array([1.0, -2.0, 1.8])
     ang = np.radians(20.0)
     q_true = np.array([np.cos(ang / 2), 0, 0, np.sin(ang / 2)])

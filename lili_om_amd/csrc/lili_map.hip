@@ -280,7 +280,11 @@ static int map_set_impl(lili_ctx* ctx, int kind, const lili_cloud* cloud, double
             double fc = cell * std::sqrt(3.0 / m.mean_occupancy);
             fc = std::min(std::max(fc, cell / 16.0), cell / 1.5);
             int64_t fcells = 0; double fcell_used = 0;
-            rc = build_grid(ctx, m, src, mn, mx, fc, reach, m.sorted_f, m.aux_sorted_f, m.cell_start_f, m.cell_start9_f, m.fview, fcells, fcell_used, nullptr, false, 0.f, false /* the fine index keeps 32-bit counters: its check would need a read-back of its own */, false, true);
+            // four EMPTY cells of margin on every side (round 6): the blocks of 3 x 3 rows that level 1 of the dense-map association walks lane by lane (k_associate_fine) then lie
+            // inside the grid for every query inside the map's bounding box — surfaces ARE the faces of that box, and a block that straddles a face has no super-row of its own
+            double fmn[3], fmx[3];
+            for (int k = 0; k < 3; k++) { fmn[k] = mn[k] - 4.0 * fc; fmx[k] = mx[k] + 4.0 * fc; }
+            rc = build_grid(ctx, m, src, fmn, fmx, fc, reach, m.sorted_f, m.aux_sorted_f, m.cell_start_f, m.cell_start9_f, m.fview, fcells, fcell_used, nullptr, false, 0.f, false /* the fine index keeps 32-bit counters: its check would need a read-back of its own */, false, true);
             if (rc != LILI_OK) return rc;
             const double rb = (double)reach * fcell_used / 1.01;
             float fb = (float)(rb * rb * (1.0 - 1e-6));

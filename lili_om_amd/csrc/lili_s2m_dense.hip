@@ -33,9 +33,9 @@ template <int CTRL> __device__ __forceinline__ void dense_kmin_step(unsigned& lo
     const bool take = b < a;
     lo = take ? olo : lo; hi = take ? ohi : hi; j = take ? oj : j;
 }
-struct PoolTab {      // Sel5P's pool: seven slots per lane
-    float4 p[7][kAssocBlock];
-    int j[7][kAssocBlock];
+struct PoolTab {      // Sel5P's pool: six slots per lane
+    float4 p[6][kAssocBlock];
+    int j[6][kAssocBlock];
 };
 
 __device__ __forceinline__ void store_record(const AssocArgs& A, int kind, int i, bool ok, const float4& r0, const float4& rb, double score) {
@@ -52,8 +52,10 @@ constexpr int kFarG = kAssocBlock / kFarL;         // queries per round
 constexpr int kFarU = 8;                           // candidates per lane and trip
 constexpr int kFarRuns = 2 * kFarL;                // runs a group can publish per batch of blocks (two x segments per lane)
 
-struct FarTab {
-    int run_b[kFarG][kFarRuns], run_n[kFarG][kFarRuns];   // the group's non-empty runs of the batch: first position, length
+constexpr int kSerialMin = 16;                     // unsettled lanes of a wave from which level 1 is walked by the lanes themselves (see k_associate_fine)
+union FarTab {
+    struct { int run_b[kFarG][kFarRuns], run_n[kFarG][kFarRuns]; } grp;   // cooperative rounds: the group's non-empty runs of the batch: first position, length
+    struct { int b[9][kAssocBlock], n[9][kAssocBlock]; } ser;            // lane-serial level 1: the lane's nine runs (first position, length)
 };
 __device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src) {
     return ((unsigned long long)(unsigned)__shfl((int)(unsigned)(v >> 32), src) << 32) | (unsigned)__shfl((int)(unsigned)v, src);
@@ -139,16 +141,16 @@ __device__ __forceinline__ bool far_level(const GridView& g, int m, bool live, i
             // together (run by run with two loads per lane in flight a round was a chain of 9 to 25 dependent memory round trips).
             const unsigned b0 = (unsigned)(__ballot(sn[0] > 0) >> grp0) & gbits, b1 = (unsigned)(__ballot(sn[1] > 0) >> grp0) & gbits;
             const int S = __popc(b0) + __popc(b1);
-            if (sn[0] > 0) { const int k = __popc(b0 & ((1u << sub) - 1u)); tab.run_b[grp][k] = sb[0]; tab.run_n[grp][k] = sn[0]; }
-            if (sn[1] > 0) { const int k = __popc(b0) + __popc(b1 & ((1u << sub) - 1u)); tab.run_b[grp][k] = sb[1]; tab.run_n[grp][k] = sn[1]; }
+            if (sn[0] > 0) { const int k = __popc(b0 & ((1u << sub) - 1u)); tab.grp.run_b[grp][k] = sb[0]; tab.grp.run_n[grp][k] = sn[0]; }
+            if (sn[1] > 0) { const int k = __popc(b0) + __popc(b1 & ((1u << sub) - 1u)); tab.grp.run_b[grp][k] = sb[1]; tab.grp.run_n[grp][k] = sn[1]; }
             const int N = group_sum_d<L>(sn[0] + sn[1]);
             __builtin_amdgcn_wave_barrier();      // (one wave per workgroup: LDS writes of the wave are in order with its reads; this only pins the compiler)
             if (N > 0) {
                 const int q = (N + L - 1) / L, n_l = sub * q;
                 int k = 0, pos = 0, endk = 0, acc = 0;
                 for (int kk = 0; kk < S; kk++) {      // the run that holds this lane's first candidate
-                    const int len = tab.run_n[grp][kk];
-                    if (n_l >= acc && n_l < acc + len) { k = kk; pos = tab.run_b[grp][kk] + (n_l - acc); endk = tab.run_b[grp][kk] + len; }
+                    const int len = tab.grp.run_n[grp][kk];
+                    if (n_l >= acc && n_l < acc + len) { k = kk; pos = tab.grp.run_b[grp][kk] + (n_l - acc); endk = tab.grp.run_b[grp][kk] + len; }
                     acc += len;
                 }
                 const int rem = max(min(q, N - n_l), 0);
@@ -160,7 +162,7 @@ __device__ __forceinline__ bool far_level(const GridView& g, int m, bool live, i
                         at[u] = v ? pos : -1;
                         if (v) {
                             pos++;
-                            if (pos == endk && k + 1 < S) { k++; pos = tab.run_b[grp][k]; endk = pos + tab.run_n[grp][k]; }
+                            if (pos == endk && k + 1 < S) { k++; pos = tab.grp.run_b[grp][k]; endk = pos + tab.grp.run_n[grp][k]; }
                         }
                     }
                     float4 pt[kFarU];
@@ -293,8 +295,87 @@ __global__ __launch_bounds__(kAssocBlock) void k_associate_fine(AssocArgs A, int
         unsigned long long oK[5]; int oJ[5];      // this lane's own query: the five best so far as exact (distance, original index) keys and their positions
 #pragma unroll
         for (int r = 0; r < 5; r++) { oK[r] = ((unsigned long long)__float_as_uint(gate) << 32) | 0x7fffffffull; oJ[r] = -1; }
+        int lvl = 1;                               // the next level this lane's query needs
+        // Many unsettled lanes (the first association of a registration: two thirds of the wave): level 1 is walked BY THE LANES THEMSELVES — nine runs per lane, one
+        // after the other with the next chunk in flight, Sel5P — and only what level 1 leaves open (0.7 % of the queries) goes through the cooperative rounds.  A
+        // cooperative round costs ~1 500 wave-instructions for four queries whatever they need (block geometry, compaction, merge): eleven rounds per wave made the first
+        // launch instruction-bound (51.9 M wave-instructions, 226 us); the lane-serial walk is ~6 000 for up to 64 queries.  Few unsettled lanes (settled launches: one lane
+        // in one wave of eighteen): the cooperative round is the shorter chain.
+        if (__popcll(mask) >= kSerialMin && !exact_only) {
+            bool walk = false;
+            const double c = g.cell;
+            const double fxm = (double)px - (g.ox + (double)cx * c), fxp = (g.ox + (double)(cx + 1) * c) - (double)px;
+            const double fym = (double)py - (g.oy + (double)cy * c), fyp = (g.oy + (double)(cy + 1) * c) - (double)py;
+            const double fzm = (double)pz - (g.oz + (double)cz * c), fzp = (g.oz + (double)(cz + 1) * c) - (double)pz;
+            const double gap0 = fmax(fmin(fmin(fmin(fxm, fxp), fmin(fym, fyp)), fmin(fzm, fzp)), 0.0);
+            if (far) {
+                // the nine blocks of level 1 as runs of the unified array (all 18 range words requested together); a block without super-rows (grid border, outside the
+                // focus box) leaves the whole query to the cooperative rounds
+                walk = g.cell_start9 != nullptr && !(cx < -r_max || cx > g.nx - 1 + r_max || cy < -r_max || cy > g.ny - 1 + r_max || cz < -r_max || cz > g.nz - 1 + r_max);
+                const int xs = max(cx - 4, 0), xe = min(cx + 4, g.nx - 1);
+                int rb[9], rn[9];
+#pragma unroll
+                for (int k = 0; k < 9; k++) {
+                    const int a = k / 3 - 1, b = k % 3 - 1;
+                    const int Y = cy + 3 * a, Z = cz + 3 * b;
+                    const bool blk = Y + 1 >= 0 && Y - 1 < g.ny && Z + 1 >= 0 && Z - 1 < g.nz && xs <= xe;
+                    const bool has9 = blk && Y >= g.by0 && Y < g.by0 + g.bny && Z >= g.bz0 && Z < g.bz0 + g.bnz && xs >= g.bx0 && xe < g.bx0 + g.bnx;
+                    if (blk && !has9) walk = false;
+                    const int* row = g.cell_start9 + (has9 && walk ? srow_index(g, g.bx0, Y, Z) - g.bx0 : 0);
+                    const int b0 = has9 && walk ? row[xs] : 0, b1 = has9 && walk ? row[xe + 1] : 0;
+                    rb[k] = b0; rn[k] = b1 - b0;
+                }
+#pragma unroll
+                for (int k = 0; k < 9; k++) { tab.ser.b[k][lane] = rb[k]; tab.ser.n[k][lane] = walk ? rn[k] : 0; }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (walk) {
+                Sel5P sel; sel.init(gate, &pool.p[0][lane], &pool.j[0][lane]);
+                int k = 0, cj = 0, ce = 0;
+                auto fetch = [&](float4& p0, float4& p1, float4& p2, float4& p3, int& pj, int& pe) {
+                    while (cj >= ce && k < 9) {      // the next run that holds points (no pruning by box distance: with the gate as the only bound nothing is dropped)
+                        const int b = tab.ser.b[k][lane], n = tab.ser.n[k][lane];
+                        k++;
+                        if (n > 0) { cj = b; ce = b + n; }
+                    }
+                    pj = cj; pe = ce;
+                    const float4* q = (const float4*)((const char*)g.pts + ((unsigned)min(cj, max(ce - 1, 0)) << 4));
+                    p0 = q[0]; p1 = q[1]; p2 = q[2]; p3 = q[3];
+                    cj += 4;
+                };
+                float4 a0, a1, a2, a3, b0, b1, b2, b3;
+                int aj = 0, ae = 0, bj = 0, be = 0;
+                fetch(a0, a1, a2, a3, aj, ae);
+                for (;;) {
+                    if (!(aj < ae)) break;
+                    fetch(b0, b1, b2, b3, bj, be);
+                    asm volatile("" : "+v"(a0.w), "+v"(a1.w), "+v"(a2.w), "+v"(a3.w));
+                    sel.chunk(a0, a1, a2, a3, aj, ae, px, py, pz);
+                    if (!(bj < be)) break;
+                    fetch(a0, a1, a2, a3, aj, ae);
+                    asm volatile("" : "+v"(b0.w), "+v"(b1.w), "+v"(b2.w), "+v"(b3.w));
+                    sel.chunk(b0, b1, b2, b3, bj, be, px, py, pz);
+                }
+                Top5 t1;
+                const bool redo = sel.finish(px, py, pz, t1);
+                if (!redo) {      // (a bucket tie: the cooperative rounds repeat level 1 for this query)
+                    const double margin = 4.0 * c + gap0;
+                    const bool done = t1.d[4] < (float)(0.999 * margin * margin) || 4 >= r_max;
+#pragma unroll
+                    for (int r = 0; r < 5; r++) {
+                        oK[r] = t1.j[r] >= 0 ? (((unsigned long long)__float_as_uint(t1.d[r]) << 32) | (unsigned)__float_as_int(t1.p[r].w)) : oK[r];
+                        oJ[r] = t1.j[r];
+                    }
+                    lvl = 2;
+                    if (done) { nn = t1; lvl = 0; }      // else: level 2 and beyond by the cooperative rounds
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            mask = __ballot(far && lvl != 0);
+        }
+        const bool served = far && lvl == 0;      // settled by the lane-serial level 1: nn is final
         for (int m = 1; mask; m++) {
-            unsigned long long todo = mask, next = 0ull;
+            unsigned long long todo = __ballot(far && lvl == m);
             while (todo) {
                 // the first kFarG raised bits of the round: group r serves the r-th; an owner lane knows its rank among them
                 const int rank = __popcll(todo & ((1ull << lane) - 1ull));
@@ -340,11 +421,11 @@ __global__ __launch_bounds__(kAssocBlock) void k_associate_fine(AssocArgs A, int
                     const int rj = __shfl(J[r], from);
                     if (mine) { oK[r] = rk; oJ[r] = rj; }
                 }
-                next |= __ballot(mine && !dn);
+                if (mine) lvl = dn ? 0 : m + 1;
             }
-            mask = next;
+            mask = __ballot(far && lvl != 0);
         }
-        if (far) {
+        if (far && !served) {
 #pragma unroll
             for (int r = 0; r < 5; r++) { nn.d[r] = __uint_as_float((unsigned)(oK[r] >> 32)); nn.j[r] = oJ[r]; }
             nn.have = false;

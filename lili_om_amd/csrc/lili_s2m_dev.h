@@ -189,15 +189,14 @@ __device__ __forceinline__ void process_chunk(Sel5K& sel, float4 p0, float4 p1, 
 }
 
 // Key selector WITH a payload pool (round 6; the dense-map association k_associate_fine): the same 32-bit keys and the same five-median network as
-// Sel5K, but the code of a key names one of SEVEN slots of a per-lane pool in LDS that holds the candidate itself (point + array position).  A
-// candidate takes the free slot when (and only when) its key enters the six held ones, and the slot of the key it pushes out becomes the free one:
-// the six held codes and the free slot are always a permutation of 0..6.  Nothing is re-loaded from the map when the walk ends.  Why: on a map
-// whose index does not fit L2 + Infinity Cache (5 M points at 0.05 m: 1.1 GB of super-rows) the lines of a lane's run have left the caches by the
-// time Sel5K::finish gathers the five winners again — 7.6 of 46 us per 200 k-query launch (profiles/r06_2B_experiments.md).  Exactness as Sel5K:
+// Sel5K, but the code of a key names one of SIX slots of a per-lane pool in LDS that holds the candidate itself (point + array position).  A
+// candidate that enters the six held keys takes the slot — and the code — of the key it pushes out, so it enters iff its BUCKET is smaller than the sixth's (a candidate in
+// the sixth's bucket stays out: everything outside the held six then has a bucket >= the sixth's, which is all the exactness argument needs).  Nothing is re-loaded from
+// the map when the walk ends.  Why: on a map whose index does not fit L2 + Infinity Cache (5 M points at 0.05 m: 1.1 GB of super-rows) the lines of a lane's run have left
+// the caches by the time Sel5K::finish gathers the five winners again — 7.6 of 46 us per 200 k-query launch (profiles/r06_2B_experiments.md).  Exactness as Sel5K:
 // buckets are monotone in the distance; a tie of the fifth and sixth bucket, or a fifth in the bucket of the bound, reports `redo`.
 struct Sel5P {
     unsigned k[6];
-    unsigned fr;     // the free slot
     unsigned bb;     // bucket of the bound
     float bnd;
     float4* P;       // this lane's column of the pool: slot s at P[s * STRIDE]
@@ -210,18 +209,17 @@ struct Sel5P {
         P = pcol; J = jcol;
 #pragma unroll
         for (int s = 0; s < 6; s++) { k[s] = ((bb + 1u + (unsigned)s) << 6) | (unsigned)s; J[s * STRIDE] = -1; }   // six distinct buckets above the bound, slots without a candidate
-        fr = 6u; tc = 0;
+        tc = 0;
     }
     __device__ __forceinline__ float worst() const { return __uint_as_float(k[4] | 63u); }
     __device__ __forceinline__ void push(unsigned u, float4 p, int j) {
-        const unsigned key = (u & ~63u) | fr;
         const unsigned old5 = k[5];
-        const bool enter = key < old5;      // codes differ, so never equal
-        if (enter) { P[fr * STRIDE] = p; J[fr * STRIDE] = j; }
+        const unsigned slot = old5 & 63u;                    // the slot that becomes free if this candidate enters
+        const unsigned key = (u & ~63u) | slot;
+        if (key < old5) { P[slot * STRIDE] = p; J[slot * STRIDE] = j; }      // same code: the comparison is one of the buckets
         const unsigned m5 = umed3(k[4], k[5], key), m4 = umed3(k[3], k[4], key), m3 = umed3(k[2], k[3], key);
         const unsigned m2 = umed3(k[1], k[2], key), m1 = umed3(k[0], k[1], key);
         k[0] = min(k[0], key); k[1] = m1; k[2] = m2; k[3] = m3; k[4] = m4; k[5] = m5;
-        fr = enter ? (old5 & 63u) : fr;
     }
     // four consecutive candidates [j, j + 4) of a run ending at `end`
     __device__ __forceinline__ void chunk(float4 p0, float4 p1, float4 p2, float4 p3, int j, int end, float qx, float qy, float qz) {

@@ -13,7 +13,8 @@ import bench_configs as BC
 opts = dict(a.split("=") for a in sys.argv[1:])
 ips = int(opts.pop("ips", 10))
 quick = int(opts.pop("quick", 0))
-mp, q_local, t_true, q_true = BC.make_variant_b()
+scan_order = int(opts.pop("scan_order", 0))
+mp, q_local, t_true, q_true = BC.make_variant_b(scan_order=bool(scan_order))
 P = L.make_params("rot")
 tb, qb = L.api.body_pose_from_lidar(t_true, q_true, P)
 t0, q0 = synth.perturbed_pose(tb, qb, np.random.default_rng(synth.SEED_POSE), 0.1, 0.5)
