@@ -41,10 +41,12 @@ struct RotState {
     int fallback_rings;   // rings that did not fit the LDS budget and took the global-memory path
     int vox_overflow;     // a point's voxel coordinates did not fit the packed 32-bit key (k_rot_scatter): the radix ordering pass takes over
     int redo_segments;    // segments whose concurrent greedy run had to be repeated with the previous segment's marks (diagnostics)
+    int fold_failed;      // a ring of k_rot_ring gave up waiting for the counts of the rings below it: the host repeats the concatenation (k_rot_compact)
     long long tphase[8];  // profiling: per-phase clock ticks of ring 0's workgroup (wall_clock64)
     int ring_ticks[kMaxRings];   // profiling: ticks k_rot_ring spent on each ring
     int order_ticks[kMaxRings];  // profiling: ticks of the ring's voxel-ordering item; seg_ticks: its slowest segment item
     int seg_ticks[kMaxRings];
+    long long tjoin[4], tseg[4];   // profiling: inside the join of the probe ring (working set in LDS | border check | pick lists)
 };
 
 // f32 atan / atan2.  Mode 2 (default): glibc's fdlibm float routines, statement for statement (sysdeps/ieee754/flt-32/s_atanf.c,
@@ -189,8 +191,7 @@ __device__ void rot_first_last_valid(const float4* __restrict__ in, int n, float
     }
 }
 
-__device__ __forceinline__ void start_end_ori(const float4* __restrict__ in, int first_valid, int last_valid, int am, float& startOri, float& endOri) {
-    float4 a = in[first_valid], b = in[last_valid];
+__device__ __forceinline__ void start_end_ori(float4 a /*first surviving point*/, float4 b /*last*/, int am, float& startOri, float& endOri) {
     startOri = -atan2_r(a.y, a.x, am);                                 // R:285
     endOri = (float)((double)(-atan2_r(b.y, b.x, am)) + 2 * M_PI);       // R:286-288
     if ((double)(endOri - startOri) > 3 * M_PI) endOri = (float)((double)endOri - 2 * M_PI);
@@ -216,7 +217,7 @@ __device__ __forceinline__ int ring_of(float4 p, int n_scans, int am) {
     return scanID;
 }
 
-// Launch 1 of 5.  Per point: NaN / near-range filter, ring id, raw azimuth; per workgroup of 1024 points: ring histogram and the first point that
+// Launch 1 of 4.  Per point: NaN / near-range filter, ring id, raw azimuth; per workgroup of 1024 points: ring histogram and the first point that
 // would latch `halfPassed` (R:351-357).  Nothing is read that another workgroup writes (start azimuth: rot_first_last_valid), nothing needs
 // zeroing first.
 __global__ __launch_bounds__(kRotBlock) void k_rot_classify(const float4* __restrict__ in, int n, RotDev P, RotState* st, signed char* __restrict__ scan_id,
@@ -225,18 +226,19 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_classify(const float4* __rest
     __shared__ int half_min;
     if (threadIdx.x < kMaxRings) hist[threadIdx.x] = 0;
     if (threadIdx.x == 0) half_min = 0x7fffffff;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float4 p = i < n ? in[i] : make_float4(0.f, 0.f, 0.f, 0.f);      // (requested before the search below waits for its own loads)
     int first, last;
     rot_first_last_valid(in, n, P.near_thres, first, last);          // (its barriers also publish the two initialisations above)
     if (blockIdx.x == 0 && threadIdx.x == 0) { st->first_valid = first; st->last_valid = last; st->vox_overflow = 0; }
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const float4 pa = last >= 0 ? in[first] : p, pb = last >= 0 ? in[last] : p;
     int id = -1;
     if (last >= 0 && i < n) {
-        const float4 p = in[i];
         if (rot_point_ok(p, P.near_thres)) {
             id = ring_of(p, P.n_scans, P.atan_mode);
             if (id >= 0) {
                 float startOri, endOri;
-                start_end_ori(in, first, last, P.atan_mode, startOri, endOri);
+                start_end_ori(pa, pb, P.atan_mode, startOri, endOri);
                 float ori = -atan2_r(p.y, p.x, P.atan_mode);                       // R:349
                 ori_raw[i] = ori;
                 // would this point set halfPassed if it were reached with halfPassed == false?  (R:351-357)
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_classify(const float4* __rest
     if (threadIdx.x == 0) block_half[blockIdx.x] = half_min;
 }
 
-// Launch 2 of 5.  Every workgroup sums the ring histograms itself (all of them: ring sizes; those of the workgroups before it: its own offsets) —
+// Launch 2 of 4.  Every workgroup sums the ring histograms itself (all of them: ring sizes; those of the workgroups before it: its own offsets) —
 // 50 KB of L2 reads instead of a one-workgroup scan launch in between —, then: relTime / intensity, IMU deskew (slerp, f64), stable scatter into
 // the ring-concatenated cloud (R:367-382, 153-177).  Workgroup 0 also writes the ring table of the scan state.
 __global__ __launch_bounds__(kRotBlock) void k_rot_scatter(const float4* __restrict__ in, int n, int nb, const signed char* __restrict__ scan_id,
@@ -267,11 +269,24 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_scatter(const float4* __restr
     __shared__ int half_w[kRotBlock / 64];
     __shared__ SlerpConst slerp_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // this thread's point and what k_rot_classify left about it: requested here, used behind the histogram sums (every dependent round trip of this launch is ~1-2 us)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int id = i < n ? (int)scan_id[i] : -1;
+    const float ori_in = i < n ? ori_raw[i] : 0.f;                                  // (written for surviving points only)
+    const float4 p_in = i < n ? in[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int first_valid = st->first_valid, last_valid = st->last_valid;       // k_rot_classify, workgroup 0
     if (threadIdx.x == kRotBlock - 1) slerp_s = qslerp_prepare(dq{P.q_imu[0], P.q_imu[1], P.q_imu[2], P.q_imu[3]});
     for (int k = threadIdx.x; k < (kRotBlock / 64) * kMaxRings; k += blockDim.x) (&wave_hist[0][0])[k] = 0;
     {
         int pre = 0, tot = 0;
-        for (int b = wave; b < nb; b += kRotBlock / 64) { const int c = block_hist[b * kMaxRings + lane]; tot += c; if (b < (int)blockIdx.x) pre += c; }
+        constexpr int kW = kRotBlock / 64;
+        for (int b0 = wave; b0 < nb; b0 += 8 * kW) {            // eight loads in flight per trip (a plain loop waits for every load before it issues the next)
+            int c[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int b = b0 + u * kW; c[u] = b < nb ? block_hist[b * kMaxRings + lane] : 0; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) { tot += c[u]; if (b0 + u * kW < (int)blockIdx.x) pre += c[u]; }
+        }
         part_pre[wave][lane] = pre; part_tot[wave][lane] = tot;
         int hm = 0x7fffffff;
         for (int b = threadIdx.x; b < nb; b += kRotBlock) hm = min(hm, block_half[b]);
@@ -289,7 +304,7 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_scatter(const float4* __restr
     __syncthreads();
     int half_idx = 0x7fffffff;
     for (int w = 0; w < kRotBlock / 64; w++) half_idx = min(half_idx, half_w[w]);
-    const int first_valid = st->first_valid, last_valid = st->last_valid;       // k_rot_classify, workgroup 0
+    const float4 pa = last_valid >= 0 ? in[first_valid] : p_in, pb = last_valid >= 0 ? in[last_valid] : p_in;
     const SlerpConst slerp_c = slerp_s;
     if (blockIdx.x == 0) {
         if (threadIdx.x < kMaxRings) {
@@ -301,21 +316,21 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_scatter(const float4* __restr
         }
         if (threadIdx.x == 0) {
             st->n_full = ring_base[kMaxRings - 1] + ring_cnt[kMaxRings - 1]; st->half_idx = half_idx;
-            st->n_edge = st->n_sharp = st->n_flat = st->n_lessflat = st->n_surf = 0; st->fallback_rings = 0; st->redo_segments = 0;
+            st->n_edge = st->n_sharp = st->n_flat = st->n_lessflat = st->n_surf = 0; st->fallback_rings = 0; st->redo_segments = 0; st->fold_failed = 0;
         }
     }
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int id = i < n ? (int)scan_id[i] : -1;
     // stable rank of the point among the points of its ring inside this wave
+    // (six ballots — the lanes that agree with this one on every bit of the ring id — instead of one trip per distinct ring: the 64 lanes of a wave
+    // hold a spinning sensor's firing order, i.e. up to 64 different rings)
     int rank = 0;
-    unsigned long long todo = __ballot(id >= 0);
-    while (todo) {
-        int leader = __ffsll((long long)todo) - 1;
-        int r0 = __shfl(id, leader);
-        unsigned long long m = __ballot(id == r0);
-        if (id == r0) rank = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == leader) wave_hist[wave][r0] = __popcll(m);
-        todo &= ~m;
+    {
+        unsigned long long m = __ballot(id >= 0);
+#pragma unroll
+        for (int b = 0; b < 6; b++) { const unsigned long long bal = __ballot((id >> b) & 1); m &= ((id >> b) & 1) ? bal : ~bal; }
+        if (id >= 0) {
+            rank = __popcll(m & ((1ull << lane) - 1ull));
+            if (rank == 0) wave_hist[wave][id] = __popcll(m);
+        }
     }
     __syncthreads();
     if (threadIdx.x < kMaxRings) {   // exclusive prefix over the waves of the block, per ring
@@ -326,8 +341,8 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_scatter(const float4* __restr
     if (id < 0) return;
     const int pos = ring_base[id] + my_base[id] + wave_hist[wave][id] + rank;
     float startOri, endOri;
-    start_end_ori(in, first_valid, last_valid, P.atan_mode, startOri, endOri);
-    float ori = ori_raw[i];
+    start_end_ori(pa, pb, P.atan_mode, startOri, endOri);
+    float ori = ori_in;
     if (i <= half_idx) {   // halfPassed was still false when the reference reached this point (R:350-358)
         if ((double)ori < (double)startOri - M_PI / 2) ori = (float)((double)ori + 2 * M_PI);
         else if ((double)ori > (double)startOri + M_PI * 3 / 2) ori = (float)((double)ori - 2 * M_PI);
@@ -339,7 +354,7 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_scatter(const float4* __restr
     float relTime = (ori - startOri) / (endOri - startOri);          // R:367
     float intensity = (float)((double)id + 0.1 * (double)relTime);  // R:368
     // undistortion, R:153-177
-    float4 p = in[i];
+    const float4 p = p_in;
     int line = (int)intensity;
     double dt_i = (double)(intensity - (float)line);
     double ratio = dt_i / 0.1;
@@ -388,6 +403,7 @@ __device__ __forceinline__ float gap2(const float4* __restrict__ P, int a, int b
 __device__ __forceinline__ float range2(const float4* __restrict__ P, int k) { return P[k].x * P[k].x + P[k].y * P[k].y + P[k].z * P[k].z; }
 
 constexpr int kSegEdge = 10, kSegFlat = 4;
+constexpr int kGapWords = (kSegCap + 63) / 64;      // 12
 constexpr int kProbeRing = 12;                     // LILI_ROT_PHASES: the ring whose k_rot_ring phases are recorded
 constexpr int kStage3Blocks = 480;                 // workgroups of k_rot_segments (two per CU are resident)
 
@@ -398,10 +414,13 @@ struct SegLds {
     float curv[kSegCap];
     alignas(16) float key[kSegCap + 16];   // the segment's curvatures, 16-byte aligned and padded with +inf (rank sort)
     int sort_ind[kSegCap];
-    int hrank[kSegCap];                    // rank sort: the count of the upper half of the keys
+    int hrank[kSegCap];                    // rank sort: element numbers in bin order
+    int cnt[kRotBlock + 1];                // rank sort: elements per bin, then the bins' first positions
+    int scan[kRotBlock / 64 + 1];
     signed char mark[kSegCap + 16];        // cloudNeighborPicked of this segment: [sp - 5, ep + 5]
     signed char label[kSegCap];
     int edge[kSegEdge], flat[kSegFlat], ne, nf;      // picks in push order
+    unsigned long long gapw[kGapWords];    // bit k & 63 of word k >> 6: gap2(k + 1, k) > 0.05 — the break test of every suppression (R:441-452), once per window
 };
 // What k_rot_segments hands to k_rot_ring per (ring, segment): picks as RING-LOCAL indices, counts, and the marks spilled into the next segment.
 struct SegOut { int edge[kSegEdge]; int flat[kSegFlat]; int ne, nf, spill, pad; };
@@ -447,29 +466,35 @@ __device__ void greedy_segment(SegLds& L, int sp, int ep, unsigned spill) {
 
 #define LILI_ROT_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
-// The same picks by a whole WAVE (all 64 lanes call it with the same arguments): the serial loops above spend their time in dependent
-// LDS round trips on one lane.  Here 64 candidates of the sorted order are examined at a time (the first eligible one = first set bit of a
-// ballot), and the +-5 suppression of a pick is ten gap tests on ten lanes followed by two "first break" bit scans.  Picks, labels,
-// lists and marks are exactly those of greedy_segment: a pick only ever ADDS marks, the candidates are visited in the same order, and
-// after every pick the eligibility of the remaining lanes is re-read.
-__device__ void greedy_segment_wave(SegLds& L, int sp, int ep, unsigned spill = 0u) {
+// The same picks by a whole WAVE (all 64 lanes call it with the same arguments), without a memory round trip per pick (round 6; the version of rounds 3-5 kept
+// cloudNeighborPicked as bytes in LDS and spent ~0.4 us per pick in four dependent LDS round trips: eligibility, broadcast, two points per gap test, marks):
+//   * 64 candidates of the sorted order are examined at a time, the first eligible one = first set bit of a ballot;
+//   * the break tests of a suppression (R:441-452) are bits of L.gapw (evaluated for the whole window before the call), a word per lane, fetched by v_readlane: the
+//     marks of a pick at `ind` are the range [ind - nb, ind + nf], nb / nf = the zero bits below / from `ind` (at most five) — scalar arithmetic;
+//   * a lane learns that ITS candidate got marked by comparing it with the range of every pick (no mark array); the ranges stay in registers (lane r: range r) for the
+//     candidates of a later batch and for the marks spilled behind `ep`.
+// Picks, labels and lists are exactly those of greedy_segment: a pick only ever ADDS marks and the candidates are visited in the same order.  Returns the marks
+// spilled into the next segment (bit l: element ep + 1 + l).  Caller: LILI_ROT_WAVE_SYNC() before reading the lists.
+__device__ unsigned greedy_segment_wave(SegLds& L, int sp, int ep, unsigned spill = 0u) {
     const int lane = threadIdx.x & 63;
-    const float4* Pp = L.pts;
-    signed char* M = L.mark;
-    if (lane < 5 && ((spill >> lane) & 1u)) M[sp + lane] = 1;          // marks the previous segment's picks left in this one
-    LILI_ROT_WAVE_SYNC();
-    // marks the +-5 neighbourhood of `ind` up to the first gap > 0.05 on either side (R:441-452)
-    auto suppress = [&](int ind) {
-        bool brk = false;
-        if (lane < 5) brk = (double)gap2(Pp, ind + lane + 1, ind + lane) > 0.05;                  // l = lane + 1: gap(ind + l, ind + l - 1)
-        else if (lane >= 8 && lane < 13) brk = (double)gap2(Pp, ind - (lane - 8) - 1, ind - (lane - 8)) > 0.05;   // l = -(lane - 8) - 1: gap(ind + l, ind + l + 1)
-        const unsigned long long bal = __ballot(brk);
-        const unsigned fw = (unsigned)(bal & 31ull), bw = (unsigned)((bal >> 8) & 31ull);
-        const int nf = fw ? __ffs((int)fw) - 1 : 5, nb = bw ? __ffs((int)bw) - 1 : 5;               // marks before the first break
-        if (lane == 0) M[ind] = 1;
-        if (lane >= 1 && lane <= nf) M[ind + lane] = 1;
-        if (lane >= 16 && lane - 16 < nb) M[ind - (lane - 16) - 1] = 1;
-        LILI_ROT_WAVE_SYNC();
+    const unsigned long long Gw = lane < kGapWords ? L.gapw[lane] : 0ull;
+    const int Glo = (int)(unsigned)Gw, Ghi = (int)(unsigned)(Gw >> 32);
+    int ra = 0, rb = -1, nr = 0;                     // lane r: marks of pick r (nr picks so far, uniform)
+    int epick = 0, fpick = 0;                        // lane q: q-th edge / flat pick
+    const auto reach = [&](int ind, int& a, int& b) {       // `ind` uniform
+        const int p0 = ind - 5, w = __builtin_amdgcn_readfirstlane(p0 >> 6), sh = p0 & 63;     // (p0 >= 0: the window starts five points before the segment)
+        const unsigned long long g0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(Ghi, w) << 32) | (unsigned)__builtin_amdgcn_readlane(Glo, w);
+        const unsigned long long g1 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(Ghi, w + 1) << 32) | (unsigned)__builtin_amdgcn_readlane(Glo, w + 1);
+        const unsigned bits = (unsigned)((g0 >> sh) | (sh ? g1 << (64 - sh) : 0ull)) & 1023u;      // bit i: gap2(p0 + i + 1, p0 + i) > 0.05
+        const unsigned fw = bits >> 5, bw = bits & 31u;
+        const int nf = fw ? __ffs((int)fw) - 1 : 5;            // l = 1 .. 5: gap(ind + l, ind + l - 1) = bit 4 + l
+        const int nb = bw ? __clz((int)bw) - 27 : 5;           // l = -1 .. -5: gap(ind + l, ind + l + 1) = bit 5 + l; highest set bit h: 4 - h marks
+        a = ind - nb; b = ind + nf;
+    };
+    const auto marked = [&](int cand) -> bool {                // is `cand` (per lane) under a mark of the picks so far / of the previous segment's spill?
+        bool d = cand >= sp && cand < sp + 5 && ((spill >> (cand - sp)) & 1u);
+        for (int r = 0; r < nr; r++) { const int a = __builtin_amdgcn_readlane(ra, r), b = __builtin_amdgcn_readlane(rb, r); d = d || (cand >= a && cand <= b); }
+        return d;
     };
     int ne = 0, nf_ = 0, largest = 0;
     bool done = false;
@@ -478,19 +503,23 @@ __device__ void greedy_segment_wave(SegLds& L, int sp, int ep, unsigned spill = 
         const bool in = k >= sp;
         const int ind = in ? L.sort_ind[k] : sp;
         const bool big = in && (double)L.curv[ind] > 2.0;
+        bool dead = marked(ind);
         const unsigned long long stop = __ballot(!big);                     // first lane that ends the loop (curvature too small, or the segment's end)
         const unsigned long long live = stop ? ((stop & (0ull - stop)) - 1ull) : ~0ull;       // lanes before it
         unsigned long long todo = live;
         while (todo) {
-            const unsigned long long el = __ballot(big && M[ind] == 0) & todo;
+            const unsigned long long el = __ballot(big && !dead) & todo;
             if (!el) break;
             const int l = __ffsll((long long)el) - 1;
-            const int pick = __shfl(ind, l);
+            const int pick = __builtin_amdgcn_readlane(ind, l);
             largest++;
             if (largest > 10) { done = true; break; }
-            if (lane == 0) { L.label[pick] = largest <= 2 ? 2 : 1; L.edge[ne] = pick; }
+            if (lane == ne) epick = pick;
             ne++;
-            suppress(pick);
+            int a, b; reach(pick, a, b);
+            if (lane == nr) { ra = a; rb = b; }
+            nr++;
+            dead = dead || (ind >= a && ind <= b);
             todo &= ~((2ull << l) - 1ull);                                  // lanes behind the pick
         }
         if (stop) done = true;
@@ -502,25 +531,36 @@ __device__ void greedy_segment_wave(SegLds& L, int sp, int ep, unsigned spill = 
         const bool in = k <= ep;
         const int ind = in ? L.sort_ind[k] : sp;
         const bool small = in && (double)L.curv[ind] < 0.1;
-        const bool far = in && !((double)range2(Pp, ind) < 0.25);
+        const bool far = in && !((double)range2(L.pts, ind) < 0.25);
+        bool dead = marked(ind);
         const unsigned long long stop = __ballot(!small);
         const unsigned long long live = stop ? ((stop & (0ull - stop)) - 1ull) : ~0ull;
         unsigned long long todo = live;
         while (todo) {
-            const unsigned long long el = __ballot(small && far && M[ind] == 0) & todo;
+            const unsigned long long el = __ballot(small && far && !dead) & todo;
             if (!el) break;
             const int l = __ffsll((long long)el) - 1;
-            const int pick = __shfl(ind, l);
-            if (lane == 0) { L.label[pick] = -1; L.flat[nf_] = pick; }
+            const int pick = __builtin_amdgcn_readlane(ind, l);
+            if (lane == nf_) fpick = pick;
             nf_++;
             smallest++;
             if (smallest >= 4) { done = true; break; }                      // before the suppression (R:468-470)
-            suppress(pick);
+            int a, b; reach(pick, a, b);
+            if (lane == nr) { ra = a; rb = b; }
+            nr++;
+            dead = dead || (ind >= a && ind <= b);
             todo &= ~((2ull << l) - 1ull);
         }
         if (stop) done = true;
     }
+    if (lane < ne) { L.edge[lane] = epick; L.label[epick] = lane < 2 ? 2 : 1; }
+    if (lane < nf_) { L.flat[lane] = fpick; L.label[fpick] = -1; }
     if (lane == 0) { L.ne = ne; L.nf = nf_; }
+    // marks behind the segment's end
+    bool sp_l = false;
+    const int pos = ep + 1 + lane;
+    for (int r = 0; r < nr; r++) { const int a = __builtin_amdgcn_readlane(ra, r), b = __builtin_amdgcn_readlane(rb, r); sp_l = sp_l || (pos >= a && pos <= b); }
+    return (unsigned)(__ballot(sp_l) & 31ull);
 }
 __device__ __forceinline__ int block_excl_scan_1024(int v, int* lds, int& total) {
     int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -697,7 +737,7 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_voxel_order(const float4* __r
     }
 }
 
-// Launch 3 of 5: everything about a ring that does not need the picks of the WHOLE ring.  Work items (ring, by):
+// Launch 3 of 4: everything about a ring that does not need the picks of the WHOLE ring.  Work items (ring, by):
 //   by < 6 — segment j:
 //   * the 11-tap curvatures of its stretch of the ring (R:385-394; the six workgroups cover the ring, also of rings that are not selected:
 //     the curvature array is complete);
@@ -863,8 +903,15 @@ __device__ void rot_stage3_item(int ring, int by, unsigned char* smem, const flo
         L.label[w] = 0; L.mark[w] = 0;
     }
     if (tid < 16) L.mark[wlen + tid] = 0;
+    L.cnt[tid] = 0;
     __syncthreads();
+    if (ring == 0 && j == 0 && tid == 0) st->tseg[0] = wall_clock64();
     const int spw = sp - w0, epw = ep - w0, len = ep - sp + 1;
+    {   // the break tests of the suppressions, one bit per gap of the window (wlen <= kSegCap < kRotBlock: one per thread)
+        const bool brk = tid + 1 < wlen && (double)gap2(L.pts, tid + 1, tid) > 0.05;
+        const unsigned long long bal = __ballot(brk);
+        if ((tid & 63) == 0 && (tid >> 6) < kGapWords) L.gapw[tid >> 6] = bal;
+    }
     for (int w = 5 + tid; w < wlen - 5; w += kRotBlock) {
         const int g = rbase + w0 + w;
         const float c = (g >= 5 && g < n - 5) ? curvature11(L.pts, w) : 0.f;
@@ -872,34 +919,34 @@ __device__ void rot_stage3_item(int ring, int by, unsigned char* smem, const flo
         curv_g[g] = c;
     }
     __syncthreads();
-    // rank sort of [sp, ep]: keys copied to a 16-byte aligned stretch padded with +inf; lane = (element, half of the keys)
-    const int len16 = (len + 15) & ~15;
-    for (int m = tid; m < len16; m += kRotBlock) L.key[m] = m < len ? L.curv[spw + m] : INFINITY;
-    __syncthreads();
+    // Rank sort of [sp, ep] by (curvature, index) (len <= kSegCap: one element per thread).  Round 6: the elements are binned first — a curvature is a sum of
+    // squares, its float bits order like its value, bin = exponent and two mantissa bits (LDS atomics, one block scan) — and every element counts its exact rank among
+    // the few elements of its bin.  (Rounds 3-5 counted every key against every key: len^2 = 122 k compares at two instructions each, 6.2-6.9 us of a segment's 15;
+    // a segment whose curvatures all fall into one bin — a perfectly flat wall — still costs that.)
+    if (ring == 0 && j == 0 && tid == 0) st->tseg[1] = wall_clock64();
     {
-        const float4* K4 = reinterpret_cast<const float4*>(L.key);
-        const int half = __builtin_amdgcn_readfirstlane(tid >> 9), nc = len16 / 4, c0 = half * (nc / 2), c1 = half ? nc : nc / 2;
-        for (int et = 0; et < len; et += kRotBlock / 2) {           // (one trip for up to 512 elements, two for the longest segments)
-            const int e = et + (tid & 511);
-            const int eb = et + ((tid & 511) & ~63);                 // first element of this wave
-            int rank = 0;
-            if (eb < len) {
-                const float ck = e < len ? L.key[e] : INFINITY;
-                const int b0 = min(max(eb >> 2, c0), c1), b1 = min(max((eb + 64 + 3) >> 2, c0), c1);
-                for (int c = c0; c < b0; c++) { const float4 u = K4[c]; rank += (u.x <= ck ? 1 : 0) + (u.y <= ck ? 1 : 0) + (u.z <= ck ? 1 : 0) + (u.w <= ck ? 1 : 0); }
-                for (int c = b0; c < b1; c++) {
-                    const float4 u = K4[c];
-                    const int m = 4 * c;
-                    rank += (u.x < ck || (u.x == ck && m < e)) ? 1 : 0;
-                    rank += (u.y < ck || (u.y == ck && m + 1 < e)) ? 1 : 0;
-                    rank += (u.z < ck || (u.z == ck && m + 2 < e)) ? 1 : 0;
-                    rank += (u.w < ck || (u.w == ck && m + 3 < e)) ? 1 : 0;
-                }
-                for (int c = b1; c < c1; c++) { const float4 u = K4[c]; rank += (u.x < ck ? 1 : 0) + (u.y < ck ? 1 : 0) + (u.z < ck ? 1 : 0) + (u.w < ck ? 1 : 0); }
+        const int m = tid;
+        const bool act = m < len;
+        const float ck = act ? L.curv[spw + m] : 0.f;
+        const int bkt = act ? (int)((__float_as_uint(ck) >> 21) & (unsigned)(kRotBlock - 1)) : 0;
+        const int slot = act ? atomicAdd(&L.cnt[bkt], 1) : 0;            // (cleared with the window's labels; arrival order inside a bin is arbitrary: the ranks below do not depend on it)
+        __syncthreads();
+        int tot; const int ex = block_excl_scan_1024(L.cnt[tid], L.scan, tot);
+        L.cnt[tid] = ex;
+        if (tid == kRotBlock - 1) L.cnt[kRotBlock] = tot;
+        __syncthreads();
+        if (act) { const int at = L.cnt[bkt] + slot; L.key[at] = ck; L.hrank[at] = m; }
+        __syncthreads();
+        if (act) {
+            const int t0 = L.cnt[bkt], t1 = L.cnt[bkt + 1];
+            int rank = t0, t = t0;
+            for (; t + 4 <= t1; t += 4) {
+                const float u0 = L.key[t], u1 = L.key[t + 1], u2 = L.key[t + 2], u3 = L.key[t + 3];
+                const int m0 = L.hrank[t], m1 = L.hrank[t + 1], m2 = L.hrank[t + 2], m3 = L.hrank[t + 3];
+                rank += ((u0 < ck || (u0 == ck && m0 < m)) ? 1 : 0) + ((u1 < ck || (u1 == ck && m1 < m)) ? 1 : 0) + ((u2 < ck || (u2 == ck && m2 < m)) ? 1 : 0) + ((u3 < ck || (u3 == ck && m3 < m)) ? 1 : 0);
             }
-            if (half && e < len) L.hrank[e] = rank;
-            __syncthreads();
-            if (!half && e < len) { rank += L.hrank[e]; L.sort_ind[spw + rank] = spw + e; sort_ind_g[rbase + sp + rank] = rbase + sp + e; }
+            for (; t < t1; t++) { const float u = L.key[t]; const int mi = L.hrank[t]; rank += (u < ck || (u == ck && mi < m)) ? 1 : 0; }
+            L.sort_ind[spw + rank] = spw + m; sort_ind_g[rbase + sp + rank] = rbase + sp + m;
         }
     }
     __syncthreads();
@@ -907,16 +954,12 @@ __device__ void rot_stage3_item(int ring, int by, unsigned char* smem, const flo
     if (ring == 0 && j == 0 && tid == 0) st->tphase[1] = wall_clock64();
     if (tid < 64) {
         if (par_seg) {
-            greedy_segment_wave(L, spw, epw);
+            const unsigned spill = greedy_segment_wave(L, spw, epw);
             LILI_ROT_WAVE_SYNC();
             SegOut& O = X.seg_out[ring * 6 + j];
             if (tid < L.ne) O.edge[tid] = L.edge[tid] + w0;
             if (tid < L.nf) O.flat[tid] = L.flat[tid] + w0;
-            if (tid == 0) {
-                unsigned spill = 0;
-                for (int l = 0; l < 5; l++) if (L.mark[epw + 1 + l]) spill |= 1u << l;
-                O.ne = L.ne; O.nf = L.nf; O.spill = (int)spill; O.pad = 0;
-            }
+            if (tid == 0) { O.ne = L.ne; O.nf = L.nf; O.spill = (int)spill; O.pad = 0; }
         }
         if (ring == 0 && j == 0 && tid == 0) st->tphase[2] = wall_clock64();
     }
@@ -964,168 +1007,307 @@ struct RingLds {
     unsigned short rs[kRingLdsCap + 8], rl[kRingLdsCap + 8];   //                   first point, number of points
     SegOut so[6];
     int scan[kRotBlock / 64 + 1];
-    int flag, spill;
+    int flag, spill, hits;
+    int off[5];                              // lists of the lower rings: edge, sharp, flat, less-flat, surf
 };
 
-// Launch 4 of 5, one workgroup per selected ring: joins the six segments (spill check, R:401-492 order), writes the ring's pick lists, the
-// less-flat list in index order (R:494-499) and the VoxelGrid centroids of the less-flat points in the order k_rot_segments prepared
-// (f32 sums in list order, like pcl's CentroidPoint; PCL >= 1.8 semantics).
+// Round 6 — k_rot_ring puts a ring's lists where the SCAN's lists want them itself (no concatenation launch behind it): every ring publishes its five counts as ONE
+// 64-bit word {tag of this extraction | counts} (agent-scope relaxed atomic: the word is its own flag, as in k_scan_lookback_t) and sums the words of the rings
+// below it — 64 workgroups, one per CU, dispatched in index order, a ring only ever waits for lower ones; a bounded spin gives up, raises `give_up` and the host repeats
+// the concatenation with k_rot_compact.  The last ring's workgroup has then seen every word: it writes the totals and the page-locked mirror of the state.
+// Word: surf [12:0] | less-flat [25:13] | flat [30:26] | sharp [34:31] | edge [40:35] | beyond-LDS ring [41] | tag [63:48].
+struct RotFold {
+    unsigned long long* words;               // [kMaxRings]; nullptr: lists stay per ring (second passes: k_rot_compact follows)
+    unsigned tag;                            // 1 .. 65535
+    int* edge_idx; float4* edge_pts; int* sharp_idx; int* flat_idx; int* lessflat_idx; float4* surf; int* surf_cnt;
+    RotState* mirror;                        // page-locked copy of the state as the device sees it, or nullptr
+    int* give_up;                            // page-locked word behind the mirror, or nullptr
+};
+
+// Launch 4 of 4, one workgroup per ring: joins the six segments (spill check, R:401-492 order), the ring's pick lists, the less-flat list in index order
+// (R:494-499) and the VoxelGrid centroids of the less-flat points in the order k_rot_segments prepared (f32 sums in list order, like pcl's CentroidPoint;
+// PCL >= 1.8 semantics) — into the per-ring scratch lists and, with `F`, into the scan's lists.
 __global__ __launch_bounds__(kRotBlock) void k_rot_ring(const float4* __restrict__ full, const float* __restrict__ curv_g, const int* __restrict__ sort_ind_g, RotDev P, RotState* st,
                                                         int* __restrict__ label_g, int* __restrict__ ring_edge /*[64][60]*/,
                                                         int* __restrict__ ring_sharp /*[64][12]*/, int* __restrict__ ring_flat /*[64][24]*/,
                                                         int* __restrict__ lessflat_tmp /*[n]*/, float4* __restrict__ surf_tmp /*[n]*/,
-                                                        int* __restrict__ surf_cnt_tmp /*[n]*/, RotRingScratch X) {
+                                                        int* __restrict__ surf_cnt_tmp /*[n]*/, RotRingScratch X, RotFold F) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     RingLds& L = *reinterpret_cast<RingLds*>(smem);
     const int ring = blockIdx.x, tid = threadIdx.x;
     const int rbase = st->ring_base[ring], rcount = st->ring_count[ring];
     const int rs = st->ring_start[ring], re = st->ring_end[ring];
-    if (ring >= P.n_scans || re - rs < 6 || ring % P.ds_rate != 0) return;      // R:402
-    if (rcount > kRingLdsCap) {     // does not fit the LDS working set: k_rot_select_big takes this ring (global-memory arrays)
-        if (tid == 0) atomicAdd(&st->fallback_rings, 1);
+    const int n_runs = X.ring_ncand[ring];       // (k_rot_segments ordered the runs of every selected ring that fits LDS, nearly empty ones included)
+    const bool selected = !(ring >= P.n_scans || re - rs < 6 || ring % P.ds_rate != 0);      // R:402
+    const bool big = selected && rcount > kRingLdsCap;     // does not fit the LDS working set: k_rot_select_big takes this ring (global-memory arrays)
+    if (!F.words && (!selected || big)) {
+        if (big && tid == 0) atomicAdd(&st->fallback_rings, 1);
         return;
     }
-    const long long t_start = wall_clock64();
-    if (ring == kProbeRing && tid == 0) st->tphase[4] = t_start;
-    const int s0 = rs - rbase, e0 = re - rbase;
-    const bool par_seg = (e0 - s0) >= 64;
-    const int n_runs = X.ring_ncand[ring];       // (k_rot_segments ordered the runs of every selected ring that fits LDS, nearly empty ones included)
-    for (int k = tid; k < rcount; k += kRotBlock) { L.label[k] = (signed char)label_g[rbase + k]; L.pts[k] = full[rbase + k]; }
-    for (int i = tid; i < n_runs + 4; i += kRotBlock) {
-        const bool in = i < n_runs;
-        L.rk[i] = in ? X.sorted_vox[rbase + i] : 0xffffffffu;            // (sentinels end the last voxel)
-        L.rs[i] = in ? (unsigned short)X.sorted_k[rbase + i] : 0; L.rl[i] = in ? (unsigned short)X.sorted_len[rbase + i] : 0;
-    }
-    if (par_seg && tid < 6 * (int)(sizeof(SegOut) / sizeof(int))) reinterpret_cast<int*>(L.so)[tid] = reinterpret_cast<const int*>(X.seg_out + ring * 6)[tid];
-    __syncthreads();
-    bool relabel = false;
-    // stages segment j's window (or the whole of a nearly empty ring) for a serial greedy run
-    auto stage = [&](int lo, int hi, int sp, int ep) {       // ring-local [lo, hi) answered for, segment [sp, ep]
-        const int w0 = lo - 5, wlen = hi + 5 - w0;
-        for (int w = tid; w < wlen; w += kRotBlock) {
-            const int g = rbase + w0 + w;
-            const bool in = g >= rbase && g < rbase + rcount;
-            L.seg.pts[w] = in ? full[g] : make_float4(0.f, 0.f, 0.f, 0.f);
-            L.seg.curv[w] = in ? curv_g[g] : 0.f;
-            L.seg.label[w] = 0; L.seg.mark[w] = 0;
-        }
-        for (int k = sp + tid; k <= ep; k += kRotBlock) L.seg.sort_ind[k - w0] = sort_ind_g[rbase + k] - rbase - w0;
-        if (tid < 16) L.seg.mark[wlen + tid] = 0;
-        return w0;
-    };
-    if (!par_seg) {                             // a nearly empty ring (< 75 points): the reference's order, one shared mark array
-        const int w0 = stage(0, rcount, s0, e0 - 1);
-        __syncthreads();
-        if (tid == 0) {
-            for (int j = 0; j < 6; j++) {
-                greedy_segment(L.seg, s0 + (e0 - s0) * j / 6 - w0, s0 + (e0 - s0) * (j + 1) / 6 - 1 - w0, 0u);
-                SegOut& O = L.so[j];
-                for (int q = 0; q < L.seg.ne; q++) O.edge[q] = L.seg.edge[q] + w0;
-                for (int q = 0; q < L.seg.nf; q++) O.flat[q] = L.seg.flat[q] + w0;
-                O.ne = L.seg.ne; O.nf = L.seg.nf;
+    int ne = 0, nsh = 0, nfl = 0, n_lf = 0, n_out = 0;
+    // what waits in registers for the offsets of the scan's lists
+    unsigned lf_keep = 0; int lf_off = 0, lf_k0 = 0;
+    float4 c_cen[4]; int c_cnt[4] = {0, 0, 0, 0}; int c_off = 0;
+    int pj = 0, pq = 0, p_ne = 0, p_nsh = 0, p_nfl = 0, p_mine = 0, p_minf = 0;     // this thread's slot of the pick lists: segment, position, picks of the segments before
+    if (selected && !big) {
+        const long long t_start = wall_clock64();
+        if (ring == kProbeRing && tid == 0) st->tphase[4] = t_start;
+        const int s0 = rs - rbase, e0 = re - rbase;
+        const bool par_seg = (e0 - s0) >= 64;
+        {   // the ring's working set: EVERY load of the thread requested before the first is used (a `for (k = tid; k < rcount; k += 1024)` loop waits for each trip's loads
+            // before it issues the next trip's: five to six dependent round trips of ~2 us where this is one)
+            constexpr int kPer = kRingLdsCap / kRotBlock;
+            int lab[kPer]; float4 pt[kPer]; unsigned vk[kPer]; int vs[kPer], vl[kPer];
+            int so_w = 0;
+#pragma unroll
+            for (int i = 0; i < kPer; i++) {
+                const int k = tid + i * kRotBlock;
+                const bool in = k < rcount, inr = k < n_runs;
+                lab[i] = in ? label_g[rbase + k] : 0; pt[i] = in ? full[rbase + k] : make_float4(0.f, 0.f, 0.f, 0.f);
+                vk[i] = inr ? X.sorted_vox[rbase + k] : 0xffffffffu; vs[i] = inr ? X.sorted_k[rbase + k] : 0; vl[i] = inr ? X.sorted_len[rbase + k] : 0;
             }
+            if (par_seg && tid < 6 * (int)(sizeof(SegOut) / sizeof(int))) so_w = reinterpret_cast<const int*>(X.seg_out + ring * 6)[tid];
+#pragma unroll
+            for (int i = 0; i < kPer; i++) {
+                const int k = tid + i * kRotBlock;
+                if (k < rcount) { L.label[k] = (signed char)lab[i]; L.pts[k] = pt[i]; }
+                if (k < n_runs + 4) { L.rk[k] = vk[i]; L.rs[k] = (unsigned short)vs[i]; L.rl[k] = (unsigned short)vl[i]; }      // (sentinels end the last voxel; n_runs + 4 <= rcount - 7)
+            }
+            if (par_seg && tid < 6 * (int)(sizeof(SegOut) / sizeof(int))) reinterpret_cast<int*>(L.so)[tid] = so_w;
         }
+        if (tid == 0) L.hits = 0;
         __syncthreads();
-        for (int k = tid; k < rcount; k += kRotBlock) L.label[k] = L.seg.label[k - w0];
-        relabel = true;
-        __syncthreads();
-    } else {
-        for (int j = 1; j < 6; j++) {           // (uniform trip count; the redo is rare)
+        if (ring == kProbeRing && tid == 0) st->tjoin[0] = wall_clock64();
+        bool relabel = false;
+        // stages segment j's window (or the whole of a nearly empty ring) for a greedy run: points from the ring's copy in LDS, curvatures and sorted order as
+        // k_rot_segments left them, the break bits of the window (wlen <= kSegCap: one element per thread)
+        auto stage = [&](int lo, int hi, int sp, int ep) {       // ring-local [lo, hi) answered for, segment [sp, ep]
+            const int w0 = lo - 5, wlen = hi + 5 - w0;
+            for (int w = tid; w < wlen; w += kRotBlock) {
+                const int kk = w0 + w;
+                const bool in = kk >= 0 && kk < rcount;
+                L.seg.pts[w] = in ? L.pts[kk] : make_float4(0.f, 0.f, 0.f, 0.f);
+                L.seg.curv[w] = in ? curv_g[rbase + kk] : 0.f;
+                L.seg.label[w] = 0; L.seg.mark[w] = 0;
+            }
+            for (int k = sp + tid; k <= ep; k += kRotBlock) L.seg.sort_ind[k - w0] = sort_ind_g[rbase + k] - rbase - w0;
+            if (tid < 16) L.seg.mark[wlen + tid] = 0;
+            {
+                const int ka = w0 + tid, kb = ka + 1;
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 pa = (tid < wlen && ka >= 0 && ka < rcount) ? L.pts[ka] : z, pb = (tid + 1 < wlen && kb >= 0 && kb < rcount) ? L.pts[kb] : z;
+                const float dX = pb.x - pa.x, dY = pb.y - pa.y, dZ = pb.z - pa.z;
+                const bool brk = tid + 1 < wlen && (double)(dX * dX + dY * dY + dZ * dZ) > 0.05;
+                const unsigned long long bal = __ballot(brk);
+                if ((tid & 63) == 0 && (tid >> 6) < kGapWords) L.seg.gapw[tid >> 6] = bal;
+            }
+            return w0;
+        };
+        if (!par_seg) {                             // a nearly empty ring (< 75 points): the reference's order, one shared mark array
+            const int w0 = stage(0, rcount, s0, e0 - 1);
+            __syncthreads();
             if (tid == 0) {
-                const int sp = s0 + (e0 - s0) * j / 6;
-                const unsigned spill = (unsigned)L.so[j - 1].spill;
-                bool hit = false;
-                if (spill) {
-                    for (int q = 0; q < L.so[j].ne; q++) { const int d = L.so[j].edge[q] - sp; if (d >= 0 && d < 5 && ((spill >> d) & 1u)) hit = true; }
-                    for (int q = 0; q < L.so[j].nf; q++) { const int d = L.so[j].flat[q] - sp; if (d >= 0 && d < 5 && ((spill >> d) & 1u)) hit = true; }
+                for (int j = 0; j < 6; j++) {
+                    greedy_segment(L.seg, s0 + (e0 - s0) * j / 6 - w0, s0 + (e0 - s0) * (j + 1) / 6 - 1 - w0, 0u);
+                    SegOut& O = L.so[j];
+                    for (int q = 0; q < L.seg.ne; q++) O.edge[q] = L.seg.edge[q] + w0;
+                    for (int q = 0; q < L.seg.nf; q++) O.flat[q] = L.seg.flat[q] + w0;
+                    O.ne = L.seg.ne; O.nf = L.seg.nf;
                 }
-                L.flag = hit ? 1 : 0; L.spill = (int)spill;
             }
             __syncthreads();
-            if (L.flag) {
+            for (int k = tid; k < rcount; k += kRotBlock) L.label[k] = L.seg.label[k - w0];
+            relabel = true;
+            __syncthreads();
+        } else {
+            // Did a pick of segment j fall on a mark the picks of segment j - 1 spilled across the border?  All five borders at once (one pick per thread); only then
+            // the walk over the borders from the first such segment on: a redo changes what THAT segment spills — its successor is checked again —, nothing else.
+            // `pick_hit(j, q)`: is pick q of segment j (q < 10: edge, else flat) among the marks segment j - 1 spills?
+            const auto pick_hit = [&](int j, int q) -> bool {
+                const unsigned spill = (unsigned)L.so[j - 1].spill;
+                const int sp = s0 + (e0 - s0) * j / 6;
+                int d = -1;
+                if (q < kSegEdge) { if (q < L.so[j].ne) d = L.so[j].edge[q] - sp; }
+                else if (q - kSegEdge < kSegFlat) { if (q - kSegEdge < L.so[j].nf) d = L.so[j].flat[q - kSegEdge] - sp; }
+                return spill && d >= 0 && d < 5 && ((spill >> d) & 1u);
+            };
+            if (tid < 5 * 16 && pick_hit(1 + (tid >> 4), tid & 15)) atomicOr(&L.hits, 1 << (1 + (tid >> 4)));
+            __syncthreads();
+            if (ring == kProbeRing && tid == 0) st->tjoin[1] = wall_clock64();
+            const int hits = L.hits;
+            int j = hits ? __ffs(hits) - 1 : 6;
+            while (j < 6) {                          // (uniform)
                 const int sp = s0 + (e0 - s0) * j / 6, ep = s0 + (e0 - s0) * (j + 1) / 6 - 1;
                 const int w0 = stage(sp, j == 5 ? rcount : ep + 1, sp, ep);
                 __syncthreads();
-                if (tid < 64) greedy_segment_wave(L.seg, sp - w0, ep - w0, (unsigned)L.spill);       // (wave 0; same picks as the serial loop)
-                __syncthreads();
-                if (tid == 0) {
+                if (tid < 64) {                      // wave 0: the segment again, with the marks of its predecessor; its lists and labels replaced; is the next border hit now?
+                    const unsigned spill = greedy_segment_wave(L.seg, sp - w0, ep - w0, (unsigned)L.so[j - 1].spill);
+                    LILI_ROT_WAVE_SYNC();
                     SegOut& O = L.so[j];
-                    for (int q = 0; q < O.ne; q++) L.label[O.edge[q]] = 0;
-                    for (int q = 0; q < O.nf; q++) L.label[O.flat[q]] = 0;
-                    for (int q = 0; q < L.seg.ne; q++) { O.edge[q] = L.seg.edge[q] + w0; L.label[O.edge[q]] = L.seg.label[L.seg.edge[q]]; }
-                    for (int q = 0; q < L.seg.nf; q++) { O.flat[q] = L.seg.flat[q] + w0; L.label[O.flat[q]] = L.seg.label[L.seg.flat[q]]; }
-                    O.ne = L.seg.ne; O.nf = L.seg.nf;
-                    unsigned spill = 0;
-                    for (int l = 0; l < 5; l++) if (L.seg.mark[ep - w0 + 1 + l]) spill |= 1u << l;
-                    O.spill = (int)spill;
-                    atomicAdd(&st->redo_segments, 1);
+                    const int one = O.ne, onf = O.nf;
+                    if (tid < one) L.label[O.edge[tid]] = 0;
+                    if (tid >= 16 && tid - 16 < onf) L.label[O.flat[tid - 16]] = 0;
+                    LILI_ROT_WAVE_SYNC();
+                    if (tid < L.seg.ne) { const int e = L.seg.edge[tid]; O.edge[tid] = e + w0; L.label[e + w0] = L.seg.label[e]; }
+                    if (tid >= 16 && tid - 16 < L.seg.nf) { const int f = L.seg.flat[tid - 16]; O.flat[tid - 16] = f + w0; L.label[f + w0] = L.seg.label[f]; }
+                    if (tid == 0) { O.ne = L.seg.ne; O.nf = L.seg.nf; O.spill = (int)spill; atomicAdd(&st->redo_segments, 1); }
+                    LILI_ROT_WAVE_SYNC();
+                    int next = 6;
+                    if (j < 5) {
+                        const bool h = tid < 16 && pick_hit(j + 1, tid);
+                        const int later = hits & ~((2 << (j + 1)) - 1);           // borders behind j + 1: their predecessors are unchanged
+                        next = __ballot(h) ? j + 1 : (later ? __ffs(later) - 1 : 6);
+                    }
+                    if (tid == 0) L.flag = next;
                 }
                 relabel = true;
+                __syncthreads();
+                j = L.flag;          // (the next trip writes it behind its own first barrier)
             }
-            __syncthreads();
         }
-    }
-    if (tid == 0) {
-        int ne = 0, nsh = 0, nfl = 0;
-        for (int j = 0; j < 6; j++) {
-            for (int q = 0; q < L.so[j].ne; q++) {
-                const int g = rbase + L.so[j].edge[q];
-                if (q < 2) ring_sharp[ring * kRingSharpCap + nsh++] = g;
-                ring_edge[ring * kRingEdgeCap + ne++] = g;
+        if (ring == kProbeRing && tid == 0) st->tjoin[2] = wall_clock64();
+        // ---- the ring's pick lists in the reference's push order (segment by segment): one pick per thread
+        {
+            int sne[6], snf[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) { sne[j] = L.so[j].ne; snf[j] = L.so[j].nf; }
+            pj = min(tid >> 4, 5); pq = tid & 15;
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                ne += sne[j]; nsh += min(sne[j], 2); nfl += snf[j];
+                if (j < pj) { p_ne += sne[j]; p_nsh += min(sne[j], 2); p_nfl += snf[j]; }
+                if (j == pj) { p_mine = sne[j]; p_minf = snf[j]; }
             }
-            for (int q = 0; q < L.so[j].nf; q++) ring_flat[ring * kRingFlatCap + nfl++] = rbase + L.so[j].flat[q];
-        }
-        st->ring_nedge[ring] = ne; st->ring_nsharp[ring] = nsh; st->ring_nflat[ring] = nfl;
-    }
-    if (relabel) for (int k = tid; k < rcount; k += kRotBlock) label_g[rbase + k] = L.label[k];
-    // ---- less-flat list in index order (R:494-499), compacted with a block scan
-    if (ring == kProbeRing && tid == 0) st->tphase[5] = wall_clock64();
-    int n_lf = 0;
-    for (int k0 = s0; k0 <= e0 - 1; k0 += kRotBlock) {
-        const int k = k0 + tid;
-        const bool keep = k <= e0 - 1 && L.label[k] <= 0 && !((double)range2(L.pts[k]) < 0.25);
-        int tot; const int off = block_excl_scan_1024(keep ? 1 : 0, L.scan, tot);
-        if (keep) lessflat_tmp[rbase + n_lf + off] = rbase + k;
-        n_lf += tot;
-    }
-    if (tid == 0) st->ring_nlf[ring] = n_lf;
-    // ---- pcl::VoxelGrid(ds_v) on the less-flat points (R:502-508): the runs of candidates in (voxel, first index) order — a voxel's
-    // points in list order are its runs one after the other — minus the picked points (R:494-499)
-    if (ring == kProbeRing && tid == 0) st->tphase[6] = wall_clock64();
-    int n_out = 0;
-    for (int i0 = 0; i0 < n_runs; i0 += kRotBlock) {
-        const int i = i0 + tid;
-        const bool first = i < n_runs && (i == 0 || L.rk[i - 1] != L.rk[i]);     // first run of its voxel
-        float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f; int cnt = 0;
-        if (first) {
-            const unsigned vox = L.rk[i];
-            unsigned nk = vox; int na = L.rs[i], nl = L.rl[i];          // (the next run's descriptor is loaded while this run is summed)
-            for (int j = i; nk == vox; j++) {
-                const int a = na, e = na + nl;
-                nk = L.rk[j + 1]; na = L.rs[j + 1]; nl = L.rl[j + 1];
-                int k = a;
-                for (; k + 4 <= e; k += 4) {          // four loads in flight; the sums stay strictly sequential (f32, like CentroidPoint)
-                    const float4 p0 = L.pts[k], p1 = L.pts[k + 1], p2 = L.pts[k + 2], p3 = L.pts[k + 3];
-                    const signed char l0 = L.label[k], l1 = L.label[k + 1], l2 = L.label[k + 2], l3 = L.label[k + 3];
-                    if (l0 <= 0) { sx += p0.x; sy += p0.y; sz += p0.z; si += p0.w; cnt++; }
-                    if (l1 <= 0) { sx += p1.x; sy += p1.y; sz += p1.z; si += p1.w; cnt++; }
-                    if (l2 <= 0) { sx += p2.x; sy += p2.y; sz += p2.z; si += p2.w; cnt++; }
-                    if (l3 <= 0) { sx += p3.x; sy += p3.y; sz += p3.z; si += p3.w; cnt++; }
+            if (tid >= 6 * 16) { p_mine = 0; p_minf = 0; }
+            if (pq < kSegEdge) {
+                if (pq < p_mine) {
+                    const int g = rbase + L.so[pj].edge[pq];
+                    if (pq < 2) ring_sharp[ring * kRingSharpCap + p_nsh + pq] = g;
+                    ring_edge[ring * kRingEdgeCap + p_ne + pq] = g;
                 }
-                for (; k < e; k++) if (L.label[k] <= 0) { const float4 p = L.pts[k]; sx += p.x; sy += p.y; sz += p.z; si += p.w; cnt++; }
+            } else if (pq - kSegEdge < p_minf) ring_flat[ring * kRingFlatCap + p_nfl + pq - kSegEdge] = rbase + L.so[pj].flat[pq - kSegEdge];
+            if (tid == 0) { st->ring_nedge[ring] = ne; st->ring_nsharp[ring] = nsh; st->ring_nflat[ring] = nfl; }
+        }
+        if (relabel) for (int k = tid; k < rcount; k += kRotBlock) label_g[rbase + k] = L.label[k];
+        // ---- less-flat list in index order (R:494-499): every thread a contiguous stretch of the candidates, ONE block scan
+        if (ring == kProbeRing && tid == 0) st->tphase[5] = wall_clock64();
+        {
+            const int per = (e0 - s0 + kRotBlock - 1) / kRotBlock;            // <= 4: the ring fits kRingLdsCap
+            lf_k0 = s0 + per * tid;
+            int cnt = 0;
+#pragma unroll
+            for (int i = 0; i < kRingLdsCap / kRotBlock; i++) {
+                const int k = lf_k0 + i;
+                if (i < per && k <= e0 - 1 && L.label[k] <= 0 && !((double)range2(L.pts[k]) < 0.25)) { lf_keep |= 1u << i; cnt++; }
+            }
+            lf_off = block_excl_scan_1024(cnt, L.scan, n_lf);
+            int o = rbase + lf_off;
+#pragma unroll
+            for (int i = 0; i < kRingLdsCap / kRotBlock; i++) if ((lf_keep >> i) & 1u) lessflat_tmp[o++] = rbase + lf_k0 + i;
+        }
+        if (tid == 0) st->ring_nlf[ring] = n_lf;
+        // ---- pcl::VoxelGrid(ds_v) on the less-flat points (R:502-508): the runs of candidates in (voxel, first index) order — a voxel's
+        // points in list order are its runs one after the other — minus the picked points (R:494-499).  Every thread a contiguous stretch of the runs, ONE block scan.
+        if (ring == kProbeRing && tid == 0) st->tphase[6] = wall_clock64();
+        {
+            const int rper = (n_runs + kRotBlock - 1) / kRotBlock;          // <= 4
+            int nout_t = 0;
+#pragma unroll
+            for (int c = 0; c < kRingLdsCap / kRotBlock; c++) {
+                const int i = rper * tid + c;
+                const bool first = c < rper && i < n_runs && (i == 0 || L.rk[i - 1] != L.rk[i]);     // first run of its voxel
+                float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f; int cnt = 0;
+                if (first) {
+                    const unsigned vox = L.rk[i];
+                    unsigned nk = vox; int na = L.rs[i], nl = L.rl[i];          // (the next run's descriptor is loaded while this run is summed)
+                    for (int j = i; nk == vox; j++) {
+                        const int a = na, e = na + nl;
+                        nk = L.rk[j + 1]; na = L.rs[j + 1]; nl = L.rl[j + 1];
+                        int k = a;
+                        for (; k + 4 <= e; k += 4) {          // four loads in flight; the sums stay strictly sequential (f32, like CentroidPoint)
+                            const float4 p0 = L.pts[k], p1 = L.pts[k + 1], p2 = L.pts[k + 2], p3 = L.pts[k + 3];
+                            const signed char l0 = L.label[k], l1 = L.label[k + 1], l2 = L.label[k + 2], l3 = L.label[k + 3];
+                            if (l0 <= 0) { sx += p0.x; sy += p0.y; sz += p0.z; si += p0.w; cnt++; }
+                            if (l1 <= 0) { sx += p1.x; sy += p1.y; sz += p1.z; si += p1.w; cnt++; }
+                            if (l2 <= 0) { sx += p2.x; sy += p2.y; sz += p2.z; si += p2.w; cnt++; }
+                            if (l3 <= 0) { sx += p3.x; sy += p3.y; sz += p3.z; si += p3.w; cnt++; }
+                        }
+                        for (; k < e; k++) if (L.label[k] <= 0) { const float4 p = L.pts[k]; sx += p.x; sy += p.y; sz += p.z; si += p.w; cnt++; }
+                    }
+                }
+                c_cnt[c] = cnt;                               // (a voxel whose points were all picked as edge points has no centroid)
+                if (cnt > 0) { const float fn = (float)cnt; c_cen[c] = make_float4(sx / fn, sy / fn, sz / fn, si / fn); nout_t++; }
+            }
+            c_off = block_excl_scan_1024(nout_t, L.scan, n_out);
+            int o = rbase + c_off;
+#pragma unroll
+            for (int c = 0; c < kRingLdsCap / kRotBlock; c++) if (c_cnt[c] > 0) { surf_tmp[o] = c_cen[c]; surf_cnt_tmp[o] = c_cnt[c]; o++; }
+        }
+        if (tid == 0) { st->ring_nsurf[ring] = n_out; st->ring_ticks[ring] = (int)(wall_clock64() - t_start); }
+        if (ring == kProbeRing && tid == 0) st->tphase[7] = wall_clock64();
+    }
+    if (!F.words) return;
+    // ---- the scan's lists: this ring's counts out, the lower rings' counts in
+    const unsigned long long own = ((unsigned long long)(F.tag & 0xffffu) << 48) | ((unsigned long long)(big ? 1 : 0) << 41) | ((unsigned long long)ne << 35) | ((unsigned long long)nsh << 31)
+                                 | ((unsigned long long)nfl << 26) | ((unsigned long long)n_lf << 13) | (unsigned long long)n_out;
+    if (tid == 0) __hip_atomic_store(&F.words[ring], own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 64) {
+        unsigned long long w = tid == ring ? own : 0ull;
+        if (tid < ring) {
+            int spins = 0;
+            do {
+                w = __hip_atomic_load(&F.words[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (++spins > (1 << 20)) {      // cannot happen while lower rings run; never hang the GPU — the host repeats the concatenation (k_rot_compact)
+                    atomicOr(&st->fold_failed, 1);
+                    if (F.give_up) *F.give_up = 1;
+                    w = (unsigned long long)(F.tag & 0xffffu) << 48;
+                }
+            } while ((unsigned)(w >> 48) != (F.tag & 0xffffu));
+        }
+        const int f[6] = {(int)((w >> 35) & 63u), (int)((w >> 31) & 15u), (int)((w >> 26) & 31u), (int)((w >> 13) & 0x1fffu), (int)(w & 0x1fffu), (int)((w >> 41) & 1u)};
+        int below[6], all[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            int b = tid < ring ? f[c] : 0, a = tid <= ring ? f[c] : 0;
+            for (int o = 32; o > 0; o >>= 1) { b += __shfl_xor(b, o); a += __shfl_xor(a, o); }
+            below[c] = b; all[c] = a;
+        }
+        if (tid < 5) L.off[tid] = tid == 0 ? below[0] : tid == 1 ? below[1] : tid == 2 ? below[2] : tid == 3 ? below[3] : below[4];
+        if (ring == kMaxRings - 1) {      // every word has been seen here: totals, and the state's page-locked copy (fields other workgroups of THIS launch write come from the words)
+            if (tid == 0) { st->n_edge = all[0]; st->n_sharp = all[1]; st->n_flat = all[2]; st->n_lessflat = all[3]; st->n_surf = all[4]; st->fallback_rings = all[5]; }
+            if (F.mirror) {
+                const int* src = reinterpret_cast<const int*>(st);
+                int* dst = reinterpret_cast<int*>(F.mirror);
+                constexpr int kHead = (int)(offsetof(RotState, ring_nedge) / sizeof(int)), kTail = (int)(offsetof(RotState, vox_overflow) / sizeof(int));
+                for (int k = tid; k < kHead; k += 64) dst[k] = src[k];                                   // first / last point, ring tables (k_rot_classify, k_rot_scatter)
+                for (int k = kTail + tid; k < (int)(sizeof(RotState) / sizeof(int)); k += 64) dst[k] = src[k];      // overflow flag; diagnostics (those of this launch may be stale)
+                F.mirror->ring_nedge[tid] = f[0]; F.mirror->ring_nsharp[tid] = f[1]; F.mirror->ring_nflat[tid] = f[2]; F.mirror->ring_nlf[tid] = f[3]; F.mirror->ring_nsurf[tid] = f[4];
+                if (tid == 0) {
+                    F.mirror->n_edge = all[0]; F.mirror->n_sharp = all[1]; F.mirror->n_flat = all[2]; F.mirror->n_lessflat = all[3]; F.mirror->n_surf = all[4];
+                    F.mirror->fallback_rings = all[5];
+                }
             }
         }
-        const bool out = cnt > 0;                     // (a voxel whose points were all picked as edge points has no centroid)
-        int tot; const int off = block_excl_scan_1024(out ? 1 : 0, L.scan, tot);
-        if (out) {
-            const float fn = (float)cnt;
-            surf_tmp[rbase + n_out + off] = make_float4(sx / fn, sy / fn, sz / fn, si / fn);
-            surf_cnt_tmp[rbase + n_out + off] = cnt;
-        }
-        n_out += tot;
     }
-    if (tid == 0) { st->ring_nsurf[ring] = n_out; st->ring_ticks[ring] = (int)(wall_clock64() - t_start); }
-    if (ring == kProbeRing && tid == 0) st->tphase[7] = wall_clock64();
+    __syncthreads();
+    if (!selected || big) return;
+    if (pq < kSegEdge) {
+        if (pq < p_mine) {
+            const int k = L.so[pj].edge[pq], at = L.off[0] + p_ne + pq;
+            F.edge_idx[at] = rbase + k; F.edge_pts[at] = L.pts[k];
+            if (pq < 2) F.sharp_idx[L.off[1] + p_nsh + pq] = rbase + k;
+        }
+    } else if (pq - kSegEdge < p_minf) F.flat_idx[L.off[2] + p_nfl + pq - kSegEdge] = rbase + L.so[pj].flat[pq - kSegEdge];
+    {
+        int o = L.off[3] + lf_off;
+#pragma unroll
+        for (int i = 0; i < kRingLdsCap / kRotBlock; i++) if ((lf_keep >> i) & 1u) F.lessflat_idx[o++] = rbase + lf_k0 + i;
+    }
+    {
+        int o = L.off[4] + c_off;
+#pragma unroll
+        for (int c = 0; c < kRingLdsCap / kRotBlock; c++) if (c_cnt[c] > 0) { F.surf[o] = c_cen[c]; F.surf_cnt[o] = c_cnt[c]; o++; }
+    }
 }
 
 // ---- rings that do not fit the LDS working set (more than kRingLdsCap = 4096 points on one ring: a 16-ring sensor at 0.1 deg, merged
@@ -1356,6 +1538,8 @@ struct RotBuffers {
     DevBuf vkey, seg_out, ring_ncand, sorted_k, sorted_vox, sorted_len;      // k_rot_scatter -> k_rot_segments -> k_rot_ring
     DevBuf ring_edge, ring_sharp, ring_flat, lessflat_tmp, surf_tmp, surf_cnt_tmp;
     DevBuf edge_idx, edge_pts, sharp_idx, flat_idx, lessflat_idx, surf, surf_cnt;
+    DevBuf fold_words;          // k_rot_ring: one status word per ring (RotFold)
+    unsigned fold_tag = 0;
     DevBuf big_mark, big_vidx, big_ord_a, big_ord_b, big_rcnt;   // working set of rings beyond the LDS budget (k_rot_select_big)
     lili::RotState host{};
     lili::RotState* h_state = nullptr;       // page-locked mirror of the device state, written by k_rot_compact; h_state_dev: the same memory as the device sees it
@@ -1368,7 +1552,7 @@ struct RotBuffers {
     void release() {
         for (DevBuf* b : {&in, &scan_id, &ori_raw, &block_hist, &block_half, &state, &full, &full_src, &curv, &label, &sort_ind, &vkey, &seg_out, &ring_ncand, &sorted_k, &sorted_vox,
                           &sorted_len, &big_mark, &big_vidx, &big_ord_a, &big_ord_b, &big_rcnt, &ring_edge, &ring_sharp, &ring_flat,
-                          &lessflat_tmp, &surf_tmp, &surf_cnt_tmp, &edge_idx, &edge_pts, &sharp_idx, &flat_idx, &lessflat_idx, &surf, &surf_cnt}) b->release();
+                          &lessflat_tmp, &surf_tmp, &surf_cnt_tmp, &edge_idx, &edge_pts, &sharp_idx, &flat_idx, &lessflat_idx, &surf, &surf_cnt, &fold_words}) b->release();
         if (h_state) { (void)hipHostFree(h_state); h_state = nullptr; h_state_dev = nullptr; }
     }
 };
@@ -1418,7 +1602,7 @@ static int rot_enqueue(lili_ctx* ctx, const lili_cloud* scan, const double q_imu
     HIPCHK(R->state.ensure(sizeof(RotState)));
     RotState* st = R->state.as<RotState>();
     if (!R->h_state) {
-        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&R->h_state), sizeof(RotState), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&R->h_state), sizeof(RotState) + 64, hipHostMallocDefault));      // (+ the word k_rot_ring raises when a look-back gave up)
         void* d = nullptr;
         if (hipHostGetDevicePointer(&d, R->h_state, 0) != hipSuccess) { (void)hipGetLastError(); d = nullptr; }
         R->h_state_dev = static_cast<RotState*>(d);
@@ -1438,6 +1622,7 @@ static int rot_enqueue(lili_ctx* ctx, const lili_cloud* scan, const double q_imu
         HIPCHK(R->edge_idx.ensure(kMaxRings * kRingEdgeCap * 4)); HIPCHK(R->edge_pts.ensure(kMaxRings * kRingEdgeCap * 16));
         HIPCHK(R->sharp_idx.ensure(kMaxRings * kRingSharpCap * 4)); HIPCHK(R->flat_idx.ensure(kMaxRings * kRingFlatCap * 4));
         HIPCHK(R->lessflat_idx.ensure(cap * 4)); HIPCHK(R->surf.ensure(cap * 16)); HIPCHK(R->surf_cnt.ensure(cap * 4));
+        if (!R->fold_words.p) { HIPCHK(R->fold_words.ensure(kMaxRings * 8)); HIPCHK(hipMemsetAsync(R->fold_words.p, 0, kMaxRings * 8, ctx->stream)); }
         X.seg_out = R->seg_out.as<SegOut>(); X.ring_ncand = R->ring_ncand.as<int>(); X.sorted_k = R->sorted_k.as<int>(); X.sorted_vox = R->sorted_vox.as<unsigned>();
         X.sorted_len = R->sorted_len.as<int>();
         RotDev P{};
@@ -1445,7 +1630,7 @@ static int rot_enqueue(lili_ctx* ctx, const lili_cloud* scan, const double q_imu
         P.atan_mode = ctx->rot_atan;
         for (int i = 0; i < 4; i++) { P.q_imu[i] = q_imu[i]; P.q_lb[i] = q_lb[i]; }
         const float4* in = in_place ? static_cast<const float4*>(scan->data) : R->in.as<float4>();
-        // five launches (round 2: nine): classify | scatter | segments + voxel ordering (7 workgroups per ring) | ring | concatenation
+        // four launches (round 2: nine, rounds 3-5: five): classify | scatter | segments + voxel ordering (7 workgroups per ring) | ring (writes the scan's lists itself since round 6)
         hipLaunchKernelGGL(k_rot_classify, dim3(nb), dim3(kRotBlock), 0, ctx->stream, in, n, P, st, R->scan_id.as<signed char>(), R->ori_raw.as<float>(),
                            R->block_hist.as<int>(), R->block_half.as<int>());
         hipLaunchKernelGGL(k_rot_scatter, dim3(nb), dim3(kRotBlock), 0, ctx->stream, in, n, nb, R->scan_id.as<signed char>(), R->ori_raw.as<float>(), P, st,
@@ -1469,12 +1654,20 @@ static int rot_enqueue(lili_ctx* ctx, const lili_cloud* scan, const double q_imu
         }
         hipLaunchKernelGGL(k_rot_segments, dim3(kStage3Blocks), dim3(kRotBlock), std::max(sizeof(SegLds), sizeof(OrderLds)), ctx->stream, R->full.as<float4>(), R->vkey.as<unsigned>(), P, st, R->curv.as<float>(),
                            R->sort_ind.as<int>(), R->label.as<int>(), X);
-        hipLaunchKernelGGL(k_rot_ring, dim3(kMaxRings), dim3(kRotBlock), sizeof(RingLds), ctx->stream, R->full.as<float4>(), R->curv.as<float>(), R->sort_ind.as<int>(), P, st,
-                           R->label.as<int>(), R->ring_edge.as<int>(), R->ring_sharp.as<int>(), R->ring_flat.as<int>(), R->lessflat_tmp.as<int>(),
-                           R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>(), X);
-        hipLaunchKernelGGL(k_rot_compact, dim3(kMaxRings), dim3(256), 0, ctx->stream, st, R->full.as<float4>(), R->ring_edge.as<int>(), R->ring_sharp.as<int>(),
-                           R->ring_flat.as<int>(), R->lessflat_tmp.as<int>(), R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>(), R->edge_idx.as<int>(),
-                           R->edge_pts.as<float4>(), R->sharp_idx.as<int>(), R->flat_idx.as<int>(), R->lessflat_idx.as<int>(), R->surf.as<float4>(), R->surf_cnt.as<int>(), R->h_state_dev);
+        {   // the ring stage writes the scan's lists itself (RotFold): four launches
+            RotFold F{};
+            F.words = R->fold_words.as<unsigned long long>();
+            R->fold_tag = R->fold_tag >= 0xffffu ? 1u : R->fold_tag + 1u;
+            F.tag = R->fold_tag;
+            F.edge_idx = R->edge_idx.as<int>(); F.edge_pts = R->edge_pts.as<float4>(); F.sharp_idx = R->sharp_idx.as<int>(); F.flat_idx = R->flat_idx.as<int>();
+            F.lessflat_idx = R->lessflat_idx.as<int>(); F.surf = R->surf.as<float4>(); F.surf_cnt = R->surf_cnt.as<int>();
+            F.mirror = R->h_state_dev;
+            F.give_up = R->h_state_dev ? reinterpret_cast<int*>(R->h_state_dev + 1) : nullptr;
+            if (R->h_state) *reinterpret_cast<volatile int*>(R->h_state + 1) = 0;
+            hipLaunchKernelGGL(k_rot_ring, dim3(kMaxRings), dim3(kRotBlock), sizeof(RingLds), ctx->stream, R->full.as<float4>(), R->curv.as<float>(), R->sort_ind.as<int>(), P, st,
+                               R->label.as<int>(), R->ring_edge.as<int>(), R->ring_sharp.as<int>(), R->ring_flat.as<int>(), R->lessflat_tmp.as<int>(),
+                               R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>(), X, F);
+        }
         HIPCHK(hipGetLastError());
         // page-locked feature buffers are written right behind the concatenation, `count` records each, before the host has seen the counts: the state's read-back below
         // is then the call's only synchronisation (it was: read-back, two sized copies, second synchronisation).  The second passes further down redo the copies.
@@ -1512,12 +1705,21 @@ static int rot_complete(lili_ctx* ctx, lili_feature_out* full, lili_feature_out*
     bool sent_edge = R->pend.sent_edge, sent_surf = R->pend.sent_surf;
     RotState* st = R->state.as<RotState>();
     int rc = LILI_OK;
-    if (n > 0 && R->h_state_dev) {          // the state came with the concatenation kernel: wait, read it where it landed
+    static const bool phases = getenv("LILI_ROT_PHASES") != nullptr;      // (the mirror's diagnostics of the last launch may be stale: the profiling tool reads the state itself)
+    if (n > 0 && R->h_state_dev && !phases) {          // the state came with the ring kernel's last workgroup: wait, read it where it landed
         if (!synced) HIPCHK(hipStreamSynchronize(ctx->stream));
         std::memcpy(&R->host, R->h_state, sizeof(RotState));
+        if (*reinterpret_cast<volatile int*>(R->h_state + 1)) R->host.fold_failed = 1;
     } else { int rb = lili_readback_add(ctx, &R->host, st, sizeof(RotState)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }
     if (n == 0) { R->host.first_valid = R->host.half_idx = 0x7fffffff; R->host.last_valid = -1; }
-    if (n > 0 && (R->host.vox_overflow || R->host.fallback_rings > 0)) sent_edge = sent_surf = false;      // the lists are about to change: copied again below
+    if (n > 0 && (R->host.vox_overflow || R->host.fallback_rings > 0 || R->host.fold_failed)) sent_edge = sent_surf = false;      // the lists are about to change: copied again below
+    if (n > 0 && R->host.fold_failed && !R->host.vox_overflow && R->host.fallback_rings == 0) {      // a ring gave up its look-back (never seen): the per-ring lists are complete, concatenate them
+        hipLaunchKernelGGL(k_rot_compact, dim3(kMaxRings), dim3(256), 0, ctx->stream, st, R->full.as<float4>(), R->ring_edge.as<int>(), R->ring_sharp.as<int>(),
+                           R->ring_flat.as<int>(), R->lessflat_tmp.as<int>(), R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>(), R->edge_idx.as<int>(),
+                           R->edge_pts.as<float4>(), R->sharp_idx.as<int>(), R->flat_idx.as<int>(), R->lessflat_idx.as<int>(), R->surf.as<float4>(), R->surf_cnt.as<int>(), nullptr);
+        HIPCHK(hipGetLastError());
+        { int rb = lili_readback_add(ctx, &R->host, st, sizeof(RotState)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }
+    }
     if (n > 0 && R->host.vox_overflow) {   // voxel coordinates beyond the packed keys: order by the radix pass, then the ring stage and the concatenation again
         RotDev P{};
         P.n_scans = params->n_scans; P.ds_rate = params->ds_rate; P.ds_v = params->ds_v; P.near_thres = params->near_range; P.atan_mode = ctx->rot_atan;
@@ -1525,7 +1727,7 @@ static int rot_complete(lili_ctx* ctx, lili_feature_out* full, lili_feature_out*
         hipLaunchKernelGGL(k_rot_voxel_order, dim3(kMaxRings), dim3(kRotBlock), sizeof(SortLds), ctx->stream, R->full.as<float4>(), P, st, X);
         hipLaunchKernelGGL(k_rot_ring, dim3(kMaxRings), dim3(kRotBlock), sizeof(RingLds), ctx->stream, R->full.as<float4>(), R->curv.as<float>(), R->sort_ind.as<int>(), P, st,
                            R->label.as<int>(), R->ring_edge.as<int>(), R->ring_sharp.as<int>(), R->ring_flat.as<int>(), R->lessflat_tmp.as<int>(),
-                           R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>(), X);
+                           R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>(), X, RotFold{});
         hipLaunchKernelGGL(k_rot_compact, dim3(kMaxRings), dim3(256), 0, ctx->stream, st, R->full.as<float4>(), R->ring_edge.as<int>(), R->ring_sharp.as<int>(),
                            R->ring_flat.as<int>(), R->lessflat_tmp.as<int>(), R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>(), R->edge_idx.as<int>(),
                            R->edge_pts.as<float4>(), R->sharp_idx.as<int>(), R->flat_idx.as<int>(), R->lessflat_idx.as<int>(), R->surf.as<float4>(), R->surf_cnt.as<int>(), nullptr);
@@ -1609,6 +1811,8 @@ int lili_extract_rot_debug(lili_ctx* ctx, int32_t counts[8], int32_t* ring_start
     if (getenv("LILI_ROT_PHASES")) { fprintf(stderr, "ring 0, 100 MHz ticks: segment 0 (curvature + rank sort | greedy)"); fprintf(stderr, " %lld %lld; voxel ordering (binning | total) %lld %lld", h.tphase[1] - h.tphase[0], h.tphase[2] - h.tphase[1], h.tphase[3] >> 32, h.tphase[3] & 0xffffffff);
                                     fprintf(stderr, "; ring (join | less-flat | centroids)"); for (int k = 5; k < 8; k++) fprintf(stderr, " %lld", h.tphase[k] - h.tphase[k-1]);
                                     fprintf(stderr, "\n  from segment 0's start to k_rot_ring's start: %lld", h.tphase[4] - h.tphase[0]);
+                                    fprintf(stderr, "\n  segment 0 of ring 0 (points in LDS | gap bits + curvature | rank sort): %lld %lld %lld", h.tseg[0] - h.tphase[0], h.tseg[1] - h.tseg[0], h.tphase[1] - h.tseg[1]);
+                                    fprintf(stderr, "\n  segments redone in k_rot_ring: %d; join of the probe ring (working set | border check | redo | pick lists): %lld %lld %lld %lld", h.redo_segments, h.tjoin[0] - h.tphase[4], h.tjoin[1] - h.tjoin[0], h.tjoin[2] - h.tjoin[1], h.tphase[5] - h.tjoin[2]);
                                     fprintf(stderr, "\n  k_rot_ring ticks per ring:"); for (int k = 0; k < kMaxRings; k++) if (h.ring_ticks[k]) fprintf(stderr, " %d", h.ring_ticks[k]);
                                     fprintf(stderr, "\n  ordering ticks per ring:"); for (int k = 0; k < kMaxRings; k++) if (h.order_ticks[k]) fprintf(stderr, " %d", h.order_ticks[k]);
                                     fprintf(stderr, "\n  slowest segment per ring:"); for (int k = 0; k < kMaxRings; k++) if (h.seg_ticks[k]) fprintf(stderr, " %d", h.seg_ticks[k]); fprintf(stderr, "\n"); }
