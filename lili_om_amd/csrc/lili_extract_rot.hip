@@ -406,6 +406,7 @@ constexpr int kSegEdge = 10, kSegFlat = 4;
 constexpr int kGapWords = (kSegCap + 63) / 64;      // 12
 constexpr int kProbeRing = 12;                     // LILI_ROT_PHASES: the ring whose k_rot_ring phases are recorded
 constexpr int kStage3Blocks = 480;                 // workgroups of k_rot_segments (two per CU are resident)
+static_assert(kStage3Blocks >= 7 * kMaxRings, "k_rot_segments: every work item its own workgroup, item i in workgroup i (a segment waits for the workgroup before it)");
 
 // One segment's working set in LDS, indexed in WINDOW coordinates (window = the segment, +-5 points, and the ring's first / last five with
 // its first / last segment; for a nearly empty ring the window is the whole ring).
@@ -630,6 +631,8 @@ struct RotRingScratch {        // products of k_rot_segments for k_rot_ring, all
     int* sorted_k;             // the i-th run of the ring in (voxel, first index) order, at [ring_base + i]: ring-local index of its first point
     int* sorted_len;           //   its number of points (consecutive indices)
     unsigned* sorted_vox;      //   its voxel number
+    unsigned long long* seg_final;   // [64 * 6] {tag << 48 | marks finally spilled into the next segment}: k_rot_segments, segment j waiting for segment j - 1 (nullptr: no waiting)
+    unsigned tag;                    // this extraction's (1 .. 65535)
 };
 
 // The same ordering by a stable LSD radix sort with the voxel numbering of the ring's bounding box (what round 2 ran for every ring): second pass,
@@ -954,8 +957,38 @@ __device__ void rot_stage3_item(int ring, int by, unsigned char* smem, const flo
     if (ring == 0 && j == 0 && tid == 0) st->tphase[1] = wall_clock64();
     if (tid < 64) {
         if (par_seg) {
-            const unsigned spill = greedy_segment_wave(L, spw, epw);
+            unsigned spill = greedy_segment_wave(L, spw, epw);
             LILI_ROT_WAVE_SYNC();
+            // The picks above assumed that segment j - 1 left no mark in this one (the reference runs the six one after the other, R:401-492).  Only a pick among the
+            // segment's FIRST FIVE elements can sit under such a mark: then — rare — this segment waits for what its predecessor finally spills (one 64-bit word per
+            // segment, {tag | spill}, agent-scope relaxed like RotFold's; the predecessor is the workgroup before this one: resident or done) and, if a pick is hit,
+            // runs again with those marks while everything still lies in LDS.  (Rounds 3-5 left this to k_rot_ring: re-staging and a second run on ITS critical path,
+            // 6.5-10.7 us whenever any ring of the scan had such a pick.)  A spin that gives up publishes what it has; k_rot_ring's border check still catches the hit.
+            if (X.seg_final) {
+                const int q = tid;
+                int d = -1;
+                if (q < L.ne) d = L.edge[q] - spw; else if (q >= 16 && q - 16 < L.nf) d = L.flat[q - 16] - spw;
+                const bool first5 = d >= 0 && d < 5;
+                if (j > 0 && __ballot(first5)) {
+                    unsigned long long w = 0ull;
+                    if (tid == 0) {
+                        int spins = 0;
+                        do {
+                            w = __hip_atomic_load(&X.seg_final[ring * 6 + j - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (++spins > (1 << 20)) w = (unsigned long long)(X.tag & 0xffffu) << 48;      // never hang: as if nothing were spilled (k_rot_ring checks again)
+                        } while ((unsigned)(w >> 48) != (X.tag & 0xffffu));
+                    }
+                    const unsigned pspill = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(w & 31ull));
+                    if (__ballot(first5 && ((pspill >> d) & 1u))) {
+                        if (q < L.ne) L.label[L.edge[q]] = 0; else if (q >= 16 && q - 16 < L.nf) L.label[L.flat[q - 16]] = 0;
+                        LILI_ROT_WAVE_SYNC();
+                        spill = greedy_segment_wave(L, spw, epw, pspill);
+                        LILI_ROT_WAVE_SYNC();
+                        if (tid == 0) atomicAdd(&st->redo_segments, 1);
+                    }
+                }
+                if (tid == 0) __hip_atomic_store(&X.seg_final[ring * 6 + j], ((unsigned long long)(X.tag & 0xffffu) << 48) | (unsigned long long)spill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             SegOut& O = X.seg_out[ring * 6 + j];
             if (tid < L.ne) O.edge[tid] = L.edge[tid] + w0;
             if (tid < L.nf) O.flat[tid] = L.flat[tid] + w0;
@@ -1009,6 +1042,8 @@ struct RingLds {
     int scan[kRotBlock / 64 + 1];
     int flag, spill, hits;
     int off[5];                              // lists of the lower rings: edge, sharp, flat, less-flat, surf
+    unsigned long long pmask[kRingLdsCap / 64];                // bit k: ring point k is an edge pick (leaves the less-flat list)
+    unsigned short task[kRingLdsCap], vcnt[kRingLdsCap];      // VoxelGrid: the o-th centroid of the ring belongs to the voxel that starts with run task[o] and has vcnt[o] points
 };
 
 // Round 6 — k_rot_ring puts a ring's lists where the SCAN's lists want them itself (no concatenation launch behind it): every ring publishes its five counts as ONE
@@ -1047,10 +1082,11 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_ring(const float4* __restrict
     int ne = 0, nsh = 0, nfl = 0, n_lf = 0, n_out = 0;
     // what waits in registers for the offsets of the scan's lists
     unsigned lf_keep = 0; int lf_off = 0, lf_k0 = 0;
-    float4 c_cen[4]; int c_cnt[4] = {0, 0, 0, 0}; int c_off = 0;
+    long long t_start = 0;
+    float4 my_edge = make_float4(0.f, 0.f, 0.f, 0.f);
     int pj = 0, pq = 0, p_ne = 0, p_nsh = 0, p_nfl = 0, p_mine = 0, p_minf = 0;     // this thread's slot of the pick lists: segment, position, picks of the segments before
     if (selected && !big) {
-        const long long t_start = wall_clock64();
+        t_start = wall_clock64();
         if (ring == kProbeRing && tid == 0) st->tphase[4] = t_start;
         const int s0 = rs - rbase, e0 = re - rbase;
         const bool par_seg = (e0 - s0) >= 64;
@@ -1076,6 +1112,7 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_ring(const float4* __restrict
             if (par_seg && tid < 6 * (int)(sizeof(SegOut) / sizeof(int))) reinterpret_cast<int*>(L.so)[tid] = so_w;
         }
         if (tid == 0) L.hits = 0;
+        if (tid < kRingLdsCap / 64) L.pmask[tid] = 0ull;
         __syncthreads();
         if (ring == kProbeRing && tid == 0) st->tjoin[0] = wall_clock64();
         bool relabel = false;
@@ -1181,9 +1218,10 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_ring(const float4* __restrict
             if (tid >= 6 * 16) { p_mine = 0; p_minf = 0; }
             if (pq < kSegEdge) {
                 if (pq < p_mine) {
-                    const int g = rbase + L.so[pj].edge[pq];
+                    const int k = L.so[pj].edge[pq], g = rbase + k;
                     if (pq < 2) ring_sharp[ring * kRingSharpCap + p_nsh + pq] = g;
                     ring_edge[ring * kRingEdgeCap + p_ne + pq] = g;
+                    atomicOr(&L.pmask[k >> 6], 1ull << (k & 63));          // (read in step 1 of the VoxelGrid, behind the barriers of the less-flat scan)
                 }
             } else if (pq - kSegEdge < p_minf) ring_flat[ring * kRingFlatCap + p_nfl + pq - kSegEdge] = rbase + L.so[pj].flat[pq - kSegEdge];
             if (tid == 0) { st->ring_nedge[ring] = ne; st->ring_nsharp[ring] = nsh; st->ring_nflat[ring] = nfl; }
@@ -1206,95 +1244,133 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_ring(const float4* __restrict
             for (int i = 0; i < kRingLdsCap / kRotBlock; i++) if ((lf_keep >> i) & 1u) lessflat_tmp[o++] = rbase + lf_k0 + i;
         }
         if (tid == 0) st->ring_nlf[ring] = n_lf;
-        // ---- pcl::VoxelGrid(ds_v) on the less-flat points (R:502-508): the runs of candidates in (voxel, first index) order — a voxel's
-        // points in list order are its runs one after the other — minus the picked points (R:494-499).  Every thread a contiguous stretch of the runs, ONE block scan.
+        // the edge picks leave the ring's copy (nobody reads it between the scan above and step 2 of the VoxelGrid, which then adds +0.0f for them); their points stay
+        // with the threads that write the pick lists
+        if (pq < kSegEdge && pq < p_mine) { const int k = L.so[pj].edge[pq]; my_edge = L.pts[k]; L.pts[k] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        // ---- pcl::VoxelGrid(ds_v) on the less-flat points (R:502-508): the runs of candidates in (voxel, first index) order — a voxel's points in list order are
+        // its runs one after the other — minus the picked points (R:494-499).  Step 1 here: which voxels have a centroid (their members' labels only) and where it
+        // goes — every thread a contiguous stretch of the runs, ONE block scan.  Step 2 (the sums) follows the exchange of the counts below.
         if (ring == kProbeRing && tid == 0) st->tphase[6] = wall_clock64();
         {
             const int rper = (n_runs + kRotBlock - 1) / kRotBlock;          // <= 4
+            int cn[kRingLdsCap / kRotBlock];
             int nout_t = 0;
 #pragma unroll
             for (int c = 0; c < kRingLdsCap / kRotBlock; c++) {
                 const int i = rper * tid + c;
                 const bool first = c < rper && i < n_runs && (i == 0 || L.rk[i - 1] != L.rk[i]);     // first run of its voxel
-                float sx = 0.f, sy = 0.f, sz = 0.f, si = 0.f; int cnt = 0;
+                int cnt = 0;
                 if (first) {
                     const unsigned vox = L.rk[i];
-                    unsigned nk = vox; int na = L.rs[i], nl = L.rl[i];          // (the next run's descriptor is loaded while this run is summed)
+                    unsigned nk = vox; int na = L.rs[i], nl = L.rl[i];          // (the next run's descriptor is loaded while this run is counted)
                     for (int j = i; nk == vox; j++) {
-                        const int a = na, e = na + nl;
+                        const int a = na, e = na + nl;                           // the run's points [a, e): its length minus the edge picks among them (bits of pmask)
                         nk = L.rk[j + 1]; na = L.rs[j + 1]; nl = L.rl[j + 1];
-                        int k = a;
-                        for (; k + 4 <= e; k += 4) {          // four loads in flight; the sums stay strictly sequential (f32, like CentroidPoint)
-                            const float4 p0 = L.pts[k], p1 = L.pts[k + 1], p2 = L.pts[k + 2], p3 = L.pts[k + 3];
-                            const signed char l0 = L.label[k], l1 = L.label[k + 1], l2 = L.label[k + 2], l3 = L.label[k + 3];
-                            if (l0 <= 0) { sx += p0.x; sy += p0.y; sz += p0.z; si += p0.w; cnt++; }
-                            if (l1 <= 0) { sx += p1.x; sy += p1.y; sz += p1.z; si += p1.w; cnt++; }
-                            if (l2 <= 0) { sx += p2.x; sy += p2.y; sz += p2.z; si += p2.w; cnt++; }
-                            if (l3 <= 0) { sx += p3.x; sy += p3.y; sz += p3.z; si += p3.w; cnt++; }
+                        cnt += e - a;
+                        const int w0 = a >> 6, w1 = (e - 1) >> 6;
+                        for (int w = w0; w <= w1; w++) {
+                            unsigned long long mk = L.pmask[w];
+                            if (!mk) continue;
+                            const int lo = w == w0 ? (a & 63) : 0, hi = w == w1 ? ((e - 1) & 63) : 63;
+                            mk >>= lo;
+                            if (hi - lo < 63) mk &= (1ull << (hi - lo + 1)) - 1ull;
+                            cnt -= __popcll(mk);
                         }
-                        for (; k < e; k++) if (L.label[k] <= 0) { const float4 p = L.pts[k]; sx += p.x; sy += p.y; sz += p.z; si += p.w; cnt++; }
                     }
                 }
-                c_cnt[c] = cnt;                               // (a voxel whose points were all picked as edge points has no centroid)
-                if (cnt > 0) { const float fn = (float)cnt; c_cen[c] = make_float4(sx / fn, sy / fn, sz / fn, si / fn); nout_t++; }
+                cn[c] = cnt;                                  // (a voxel whose points were all picked as edge points has no centroid)
+                nout_t += cnt > 0 ? 1 : 0;
             }
-            c_off = block_excl_scan_1024(nout_t, L.scan, n_out);
-            int o = rbase + c_off;
+            int o = block_excl_scan_1024(nout_t, L.scan, n_out);
 #pragma unroll
-            for (int c = 0; c < kRingLdsCap / kRotBlock; c++) if (c_cnt[c] > 0) { surf_tmp[o] = c_cen[c]; surf_cnt_tmp[o] = c_cnt[c]; o++; }
+            for (int c = 0; c < kRingLdsCap / kRotBlock; c++) if (cn[c] > 0) { L.task[o] = (unsigned short)(rper * tid + c); L.vcnt[o] = (unsigned short)cn[c]; o++; }
         }
-        if (tid == 0) { st->ring_nsurf[ring] = n_out; st->ring_ticks[ring] = (int)(wall_clock64() - t_start); }
+        if (tid == 0) st->ring_nsurf[ring] = n_out;
         if (ring == kProbeRing && tid == 0) st->tphase[7] = wall_clock64();
     }
-    if (!F.words) return;
     // ---- the scan's lists: this ring's counts out, the lower rings' counts in
-    const unsigned long long own = ((unsigned long long)(F.tag & 0xffffu) << 48) | ((unsigned long long)(big ? 1 : 0) << 41) | ((unsigned long long)ne << 35) | ((unsigned long long)nsh << 31)
-                                 | ((unsigned long long)nfl << 26) | ((unsigned long long)n_lf << 13) | (unsigned long long)n_out;
-    if (tid == 0) __hip_atomic_store(&F.words[ring], own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tid < 64) {
-        unsigned long long w = tid == ring ? own : 0ull;
-        if (tid < ring) {
-            int spins = 0;
-            do {
-                w = __hip_atomic_load(&F.words[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (++spins > (1 << 20)) {      // cannot happen while lower rings run; never hang the GPU — the host repeats the concatenation (k_rot_compact)
-                    atomicOr(&st->fold_failed, 1);
-                    if (F.give_up) *F.give_up = 1;
-                    w = (unsigned long long)(F.tag & 0xffffu) << 48;
-                }
-            } while ((unsigned)(w >> 48) != (F.tag & 0xffffu));
-        }
-        const int f[6] = {(int)((w >> 35) & 63u), (int)((w >> 31) & 15u), (int)((w >> 26) & 31u), (int)((w >> 13) & 0x1fffu), (int)(w & 0x1fffu), (int)((w >> 41) & 1u)};
-        int below[6], all[6];
+    if (F.words) {
+        const unsigned long long own = ((unsigned long long)(F.tag & 0xffffu) << 48) | ((unsigned long long)(big ? 1 : 0) << 41) | ((unsigned long long)ne << 35) | ((unsigned long long)nsh << 31)
+                                     | ((unsigned long long)nfl << 26) | ((unsigned long long)n_lf << 13) | (unsigned long long)n_out;
+        if (tid == 0) __hip_atomic_store(&F.words[ring], own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < 64 && ((selected && !big) || ring == kMaxRings - 1)) {
+            unsigned long long w = tid == ring ? own : 0ull;
+            if (tid < ring) {
+                int spins = 0;
+                do {
+                    w = __hip_atomic_load(&F.words[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (++spins > (1 << 20)) {      // cannot happen while lower rings run; never hang the GPU — the host repeats the concatenation (k_rot_compact)
+                        atomicOr(&st->fold_failed, 1);
+                        if (F.give_up) *F.give_up = 1;
+                        w = (unsigned long long)(F.tag & 0xffffu) << 48;
+                    }
+                } while ((unsigned)(w >> 48) != (F.tag & 0xffffu));
+            }
+            const int f[6] = {(int)((w >> 35) & 63u), (int)((w >> 31) & 15u), (int)((w >> 26) & 31u), (int)((w >> 13) & 0x1fffu), (int)(w & 0x1fffu), (int)((w >> 41) & 1u)};
+            int below[6], all[6];
 #pragma unroll
-        for (int c = 0; c < 6; c++) {
-            int b = tid < ring ? f[c] : 0, a = tid <= ring ? f[c] : 0;
-            for (int o = 32; o > 0; o >>= 1) { b += __shfl_xor(b, o); a += __shfl_xor(a, o); }
-            below[c] = b; all[c] = a;
-        }
-        if (tid < 5) L.off[tid] = tid == 0 ? below[0] : tid == 1 ? below[1] : tid == 2 ? below[2] : tid == 3 ? below[3] : below[4];
-        if (ring == kMaxRings - 1) {      // every word has been seen here: totals, and the state's page-locked copy (fields other workgroups of THIS launch write come from the words)
-            if (tid == 0) { st->n_edge = all[0]; st->n_sharp = all[1]; st->n_flat = all[2]; st->n_lessflat = all[3]; st->n_surf = all[4]; st->fallback_rings = all[5]; }
-            if (F.mirror) {
-                const int* src = reinterpret_cast<const int*>(st);
-                int* dst = reinterpret_cast<int*>(F.mirror);
-                constexpr int kHead = (int)(offsetof(RotState, ring_nedge) / sizeof(int)), kTail = (int)(offsetof(RotState, vox_overflow) / sizeof(int));
-                for (int k = tid; k < kHead; k += 64) dst[k] = src[k];                                   // first / last point, ring tables (k_rot_classify, k_rot_scatter)
-                for (int k = kTail + tid; k < (int)(sizeof(RotState) / sizeof(int)); k += 64) dst[k] = src[k];      // overflow flag; diagnostics (those of this launch may be stale)
-                F.mirror->ring_nedge[tid] = f[0]; F.mirror->ring_nsharp[tid] = f[1]; F.mirror->ring_nflat[tid] = f[2]; F.mirror->ring_nlf[tid] = f[3]; F.mirror->ring_nsurf[tid] = f[4];
-                if (tid == 0) {
-                    F.mirror->n_edge = all[0]; F.mirror->n_sharp = all[1]; F.mirror->n_flat = all[2]; F.mirror->n_lessflat = all[3]; F.mirror->n_surf = all[4];
-                    F.mirror->fallback_rings = all[5];
+            for (int c = 0; c < 6; c++) {
+                int b = tid < ring ? f[c] : 0, a = tid <= ring ? f[c] : 0;
+                for (int o = 32; o > 0; o >>= 1) { b += __shfl_xor(b, o); a += __shfl_xor(a, o); }
+                below[c] = b; all[c] = a;
+            }
+            if (tid < 5) L.off[tid] = tid == 0 ? below[0] : tid == 1 ? below[1] : tid == 2 ? below[2] : tid == 3 ? below[3] : below[4];
+            if (ring == kMaxRings - 1) {      // every word has been seen here: totals, and the state's page-locked copy (fields other workgroups of THIS launch write come from the words)
+                if (tid == 0) { st->n_edge = all[0]; st->n_sharp = all[1]; st->n_flat = all[2]; st->n_lessflat = all[3]; st->n_surf = all[4]; st->fallback_rings = all[5]; }
+                if (F.mirror) {
+                    const int* src = reinterpret_cast<const int*>(st);
+                    int* dst = reinterpret_cast<int*>(F.mirror);
+                    constexpr int kHead = (int)(offsetof(RotState, ring_nedge) / sizeof(int)), kTail = (int)(offsetof(RotState, vox_overflow) / sizeof(int));
+                    for (int k = tid; k < kHead; k += 64) dst[k] = src[k];                                   // first / last point, ring tables (k_rot_classify, k_rot_scatter)
+                    for (int k = kTail + tid; k < (int)(sizeof(RotState) / sizeof(int)); k += 64) dst[k] = src[k];      // overflow flag; diagnostics (those of this launch may be stale)
+                    F.mirror->ring_nedge[tid] = f[0]; F.mirror->ring_nsharp[tid] = f[1]; F.mirror->ring_nflat[tid] = f[2]; F.mirror->ring_nlf[tid] = f[3]; F.mirror->ring_nsurf[tid] = f[4];
+                    if (tid == 0) {
+                        F.mirror->n_edge = all[0]; F.mirror->n_sharp = all[1]; F.mirror->n_flat = all[2]; F.mirror->n_lessflat = all[3]; F.mirror->n_surf = all[4];
+                        F.mirror->fallback_rings = all[5];
+                    }
                 }
             }
         }
     }
-    __syncthreads();
     if (!selected || big) return;
+    __syncthreads();              // (L.vo; with F.words also L.off)
+    // ---- step 2 of the VoxelGrid: the centroids.  CentroidPoint's f32 sums are sequential by definition, so a ring lasts as long as its fullest voxel (next to the
+    // sensor a 0.6 m voxel holds 100-200 points of a ring).  FOUR lanes per centroid, a component each: one load and ONE dependent addition per member — the picked
+    // members were zeroed in the ring's copy above (adding +0.0f is exact: a sum that starts at +0.0f is never -0.0f), the count comes from step 1.  Rounds 3-5: one lane
+    // per voxel, label tests and four sums per member: 3-12 us per ring.
+    {
+        const int quad = tid >> 2, comp = tid & 3;
+        const float* PC = reinterpret_cast<const float*>(L.pts);
+        float* tmp_c = reinterpret_cast<float*>(surf_tmp + rbase);
+        float* fin_c = F.words ? reinterpret_cast<float*>(F.surf + L.off[4]) : nullptr;
+        for (int o = quad; o < n_out; o += kRotBlock / 4) {
+            const int i = L.task[o], cnt = L.vcnt[o];
+            const unsigned vox = L.rk[i];
+            unsigned nk = vox; int na = L.rs[i], nl = L.rl[i];
+            float s = 0.f;
+            for (int j = i; nk == vox; j++) {
+                const int a = na, e = na + nl;
+                nk = L.rk[j + 1]; na = L.rs[j + 1]; nl = L.rl[j + 1];
+                int k = a;
+                for (; k + 8 <= e; k += 8) {
+                    const float v0 = PC[4 * k + comp], v1 = PC[4 * k + 4 + comp], v2 = PC[4 * k + 8 + comp], v3 = PC[4 * k + 12 + comp];
+                    const float v4 = PC[4 * k + 16 + comp], v5 = PC[4 * k + 20 + comp], v6 = PC[4 * k + 24 + comp], v7 = PC[4 * k + 28 + comp];
+                    s += v0; s += v1; s += v2; s += v3; s += v4; s += v5; s += v6; s += v7;
+                }
+                for (; k < e; k++) s += PC[4 * k + comp];
+            }
+            const float c = s / (float)cnt;
+            tmp_c[4 * o + comp] = c;
+            if (comp == 0) surf_cnt_tmp[rbase + o] = cnt;
+            if (fin_c) { fin_c[4 * o + comp] = c; if (comp == 0) F.surf_cnt[L.off[4] + o] = cnt; }
+        }
+    }
+    if (tid == 0) st->ring_ticks[ring] = (int)(wall_clock64() - t_start);
+    if (!F.words) return;
     if (pq < kSegEdge) {
         if (pq < p_mine) {
             const int k = L.so[pj].edge[pq], at = L.off[0] + p_ne + pq;
-            F.edge_idx[at] = rbase + k; F.edge_pts[at] = L.pts[k];
+            F.edge_idx[at] = rbase + k; F.edge_pts[at] = my_edge;
             if (pq < 2) F.sharp_idx[L.off[1] + p_nsh + pq] = rbase + k;
         }
     } else if (pq - kSegEdge < p_minf) F.flat_idx[L.off[2] + p_nfl + pq - kSegEdge] = rbase + L.so[pj].flat[pq - kSegEdge];
@@ -1302,11 +1378,6 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_ring(const float4* __restrict
         int o = L.off[3] + lf_off;
 #pragma unroll
         for (int i = 0; i < kRingLdsCap / kRotBlock; i++) if ((lf_keep >> i) & 1u) F.lessflat_idx[o++] = rbase + lf_k0 + i;
-    }
-    {
-        int o = L.off[4] + c_off;
-#pragma unroll
-        for (int c = 0; c < kRingLdsCap / kRotBlock; c++) if (c_cnt[c] > 0) { F.surf[o] = c_cen[c]; F.surf_cnt[o] = c_cnt[c]; o++; }
     }
 }
 
@@ -1538,7 +1609,7 @@ struct RotBuffers {
     DevBuf vkey, seg_out, ring_ncand, sorted_k, sorted_vox, sorted_len;      // k_rot_scatter -> k_rot_segments -> k_rot_ring
     DevBuf ring_edge, ring_sharp, ring_flat, lessflat_tmp, surf_tmp, surf_cnt_tmp;
     DevBuf edge_idx, edge_pts, sharp_idx, flat_idx, lessflat_idx, surf, surf_cnt;
-    DevBuf fold_words;          // k_rot_ring: one status word per ring (RotFold)
+    DevBuf fold_words;          // k_rot_ring: one status word per ring (RotFold); behind them k_rot_segments' word per segment (RotRingScratch::seg_final)
     unsigned fold_tag = 0;
     DevBuf big_mark, big_vidx, big_ord_a, big_ord_b, big_rcnt;   // working set of rings beyond the LDS budget (k_rot_select_big)
     lili::RotState host{};
@@ -1622,9 +1693,11 @@ static int rot_enqueue(lili_ctx* ctx, const lili_cloud* scan, const double q_imu
         HIPCHK(R->edge_idx.ensure(kMaxRings * kRingEdgeCap * 4)); HIPCHK(R->edge_pts.ensure(kMaxRings * kRingEdgeCap * 16));
         HIPCHK(R->sharp_idx.ensure(kMaxRings * kRingSharpCap * 4)); HIPCHK(R->flat_idx.ensure(kMaxRings * kRingFlatCap * 4));
         HIPCHK(R->lessflat_idx.ensure(cap * 4)); HIPCHK(R->surf.ensure(cap * 16)); HIPCHK(R->surf_cnt.ensure(cap * 4));
-        if (!R->fold_words.p) { HIPCHK(R->fold_words.ensure(kMaxRings * 8)); HIPCHK(hipMemsetAsync(R->fold_words.p, 0, kMaxRings * 8, ctx->stream)); }
+        if (!R->fold_words.p) { HIPCHK(R->fold_words.ensure(kMaxRings * 7 * 8)); HIPCHK(hipMemsetAsync(R->fold_words.p, 0, kMaxRings * 7 * 8, ctx->stream)); }
         X.seg_out = R->seg_out.as<SegOut>(); X.ring_ncand = R->ring_ncand.as<int>(); X.sorted_k = R->sorted_k.as<int>(); X.sorted_vox = R->sorted_vox.as<unsigned>();
         X.sorted_len = R->sorted_len.as<int>();
+        R->fold_tag = R->fold_tag >= 0xffffu ? 1u : R->fold_tag + 1u;      // tag of this extraction's status words (k_rot_segments, k_rot_ring)
+        X.seg_final = R->fold_words.as<unsigned long long>() + kMaxRings; X.tag = R->fold_tag;
         RotDev P{};
         P.n_scans = params->n_scans; P.ds_rate = params->ds_rate; P.ds_v = params->ds_v; P.near_thres = params->near_range;
         P.atan_mode = ctx->rot_atan;
@@ -1657,7 +1730,6 @@ static int rot_enqueue(lili_ctx* ctx, const lili_cloud* scan, const double q_imu
         {   // the ring stage writes the scan's lists itself (RotFold): four launches
             RotFold F{};
             F.words = R->fold_words.as<unsigned long long>();
-            R->fold_tag = R->fold_tag >= 0xffffu ? 1u : R->fold_tag + 1u;
             F.tag = R->fold_tag;
             F.edge_idx = R->edge_idx.as<int>(); F.edge_pts = R->edge_pts.as<float4>(); F.sharp_idx = R->sharp_idx.as<int>(); F.flat_idx = R->flat_idx.as<int>();
             F.lessflat_idx = R->lessflat_idx.as<int>(); F.surf = R->surf.as<float4>(); F.surf_cnt = R->surf_cnt.as<int>();
