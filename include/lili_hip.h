@@ -114,7 +114,9 @@ int lili_set_debug(lili_ctx* ctx, int keep_neighbors);
  *                 digit histograms ride on the key kernel and the scatter passes, one launch per pass; default 1), "voxel_small" (1 = clouds of <= 8192
  *                 points are voxel-filtered / keyframe-sorted by ONE workgroup in LDS; default 1), "voxel_guess_bits" (see lili_voxel_filter_stats; default 1);
  *   host          "readback_gather" (1 = the small reads of a synchronisation are gathered by one kernel writing into page-locked memory instead of
- *                 one copy launch each; default 1).
+ *                 one copy launch each; default 1), "frame_guess_counts" (1 = lili_frontend_frame_rot with LILI_FRAME_EXTERNAL_MAP and leaf_query 0 enqueues the
+ *                 matcher behind the extractor for GUESSED feature counts — the previous scan's plus a margin, padding rows select nothing — and synchronises once;
+ *                 a scan with more features than guessed is matched again the plain way; results identical either way; default 1).
  * One knob that DOES choose between two definitions of a result: "rot_atan" — lili_extract_rot's atan / atan2 on float arguments
  * (R/src/Preprocessing.cpp:285-288,315,349): 2 (default) = glibc's float routines statement for statement (atanf / atan2f of
  * every glibc up to 2.40 — the bits a build of the reference produces), 1 = the f64 functions rounded to f32 (libm-independent). */

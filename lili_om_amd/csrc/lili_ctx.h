@@ -184,6 +184,8 @@ struct lili_ctx {
     bool localmap_incremental = true;   // lili_localmap_commit keeps the ring sorted by voxel and merges one keyframe per step (0: rebuild every time, A/B)
     int sort_fused_max_tiles = 256;   // (measured: 200 k keys 212 -> 190 us per filter, 1 M keys 301 -> 296; 489 tiles of a 2 M-key sort: 290 -> 475 us)
     bool sort_fused_scan = true;      // radix passes of at most sort_fused_max_tiles tiles: the scatter kernel derives its offsets from the count table itself (no scan launch)
+    int frame_guess_misses = 0;         // frames whose guessed feature counts were too small (matched again the plain way)
+    bool frame_guess_counts = true;     // lili_frontend_frame_rot on a caller's maps: the matcher is enqueued behind the extractor with GUESSED feature counts (one synchronisation per scan; 0: wait for the counts first, A/B)
     bool sort_ride_hist = true;         // the radix sort's digit histograms ride on the key kernel and on the scatter passes (a pass = one launch; 0: a histogram launch per pass, A/B)
     int sort_digit_bits = 8;     // radix sort of the voxel filter: 8-bit digits (4 = the round-2 passes, A/B)
     int rot_atan = 2;            // ROT extractor: 2 = glibc fdlibm float atan / atan2 (the reference build's bits), 1 = f64 functions rounded to f32
@@ -238,3 +240,10 @@ int lili_extract_livox_enqueue(lili_ctx* ctx, const lili_cloud* scan, int curvat
 int lili_extract_livox_complete(lili_ctx* ctx);
 int lili_extract_rot_enqueue(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4], const double q_lb[4], const lili_rot_params* params);
 int lili_extract_rot_complete(lili_ctx* ctx);
+// the ROT extraction's device lists and the words their lengths will be in, BEFORE the counts have come back (lili_extract_rot_enqueue has been called); the lengths of the
+// previous extraction on this context as guesses (0: none).  lili_extract_rot_redone: did lili_extract_rot_complete rewrite the lists (second passes)?
+int lili_extract_rot_early(lili_ctx* ctx, lili_cloud* edge, lili_cloud* surf, const int** d_n_edge, const int** d_n_surf, int* prev_edge, int* prev_surf);
+bool lili_extract_rot_redone(lili_ctx* ctx);
+// lili_match.hip -> lili_pipeline.hip: queries whose number is still on the device
+int lili_s2m_set_queries_counted(lili_ctx* ctx, int slot, int kind, const float4* d_src, const int* d_count, int n_guess, bool launch = true);
+int lili_s2m_trim_queries(lili_ctx* ctx, int slot, int kind, int n);

@@ -1008,6 +1008,9 @@ __device__ void rot_stage3_item(int ring, int by, unsigned char* smem, const flo
 __global__ __launch_bounds__(kRotBlock) void k_rot_segments(const float4* __restrict__ full, const unsigned* __restrict__ vkey_g, RotDev P, RotState* st, float* __restrict__ curv_g,
                                                             int* __restrict__ sort_ind_g, int* __restrict__ label_g, RotRingScratch X) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // (every work item has a workgroup of its own — kStage3Blocks >= 7 * kMaxRings —: a segment's workgroup knows its item from its index and starts at once; only
+    // the workgroups of the ordering items first have to find out which rings are selected)
+    if (blockIdx.x < 6 * kMaxRings) { rot_stage3_item(blockIdx.x / 6, blockIdx.x % 6, smem, full, vkey_g, P, st, curv_g, sort_ind_g, label_g, X); return; }
     __shared__ int chunk_pref[kMaxRings + 1];
     if (threadIdx.x < 64) {
         const int r = threadIdx.x;
@@ -1019,17 +1022,11 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_segments(const float4* __rest
         if (r == 0) chunk_pref[0] = 0;
     }
     __syncthreads();
-    const int n_items = 6 * kMaxRings + chunk_pref[kMaxRings];
-    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
-        if (it < 6 * kMaxRings) rot_stage3_item(it / 6, it % 6, smem, full, vkey_g, P, st, curv_g, sort_ind_g, label_g, X);
-        else {
-            const int c = it - 6 * kMaxRings;
-            int r = 0;
-            while (chunk_pref[r + 1] <= c) r++;
-            rot_stage3_item(r, 6 + c - chunk_pref[r], smem, full, vkey_g, P, st, curv_g, sort_ind_g, label_g, X);
-        }
-        __syncthreads();
-    }
+    const int c = (int)blockIdx.x - 6 * kMaxRings;
+    if (c >= chunk_pref[kMaxRings]) return;
+    int r = 0;
+    while (chunk_pref[r + 1] <= c) r++;
+    rot_stage3_item(r, 6 + c - chunk_pref[r], smem, full, vkey_g, P, st, curv_g, sort_ind_g, label_g, X);
 }
 
 struct RingLds {
@@ -1611,6 +1608,8 @@ struct RotBuffers {
     DevBuf edge_idx, edge_pts, sharp_idx, flat_idx, lessflat_idx, surf, surf_cnt;
     DevBuf fold_words;          // k_rot_ring: one status word per ring (RotFold); behind them k_rot_segments' word per segment (RotRingScratch::seg_final)
     unsigned fold_tag = 0;
+    bool prev_ok = false, redone = false;      // the previous extraction completed (prev_edge / prev_surf: its list lengths); the last completion ran a second pass (lists rewritten)
+    int prev_edge = 0, prev_surf = 0;
     DevBuf big_mark, big_vidx, big_ord_a, big_ord_b, big_rcnt;   // working set of rings beyond the LDS budget (k_rot_select_big)
     lili::RotState host{};
     lili::RotState* h_state = nullptr;       // page-locked mirror of the device state, written by k_rot_compact; h_state_dev: the same memory as the device sees it
@@ -1833,6 +1832,8 @@ static int rot_complete(lili_ctx* ctx, lili_feature_out* full, lili_feature_out*
         { int rb = lili_readback_add(ctx, &R->host, st, sizeof(RotState)); if (rb == LILI_OK) rb = lili_readback_finish(ctx); if (rb != LILI_OK) return rb; }
     }
     R->have = true;
+    R->redone = n > 0 && (R->host.vox_overflow || R->host.fallback_rings > 0 || R->host.fold_failed);
+    R->prev_ok = n > 0; R->prev_edge = R->host.n_edge; R->prev_surf = R->host.n_surf;
     bool more = false;      // copies enqueued after the state's read-back: a second synchronisation
     if (full) {
         full->count = (size_t)R->host.n_full;
@@ -1870,6 +1871,20 @@ int lili_extract_rot_complete(lili_ctx* ctx) {
     auto* R = rot_of(ctx);
     return rot_complete(ctx, nullptr, nullptr, nullptr, R->pend.on && ctx->readback_gen != R->pend.gen);
 }
+// The lists of the enqueued extraction as the device will fill them, the device words their lengths will stand in (k_rot_ring's last workgroup), and the lengths of
+// the previous extraction on this context (0 / 0: there was none): for a caller that sizes its next launches by a guess and checks it afterwards.
+int lili_extract_rot_early(lili_ctx* ctx, lili_cloud* edge, lili_cloud* surf, const int** d_n_edge, const int** d_n_surf, int* prev_edge, int* prev_surf) {
+    if (!ctx) return LILI_E_ARG;
+    auto* R = rot_of(ctx);
+    if (!R->pend.on || R->n_in <= 0) return ctx->fail(LILI_E_STATE, "extract_rot_early: nothing enqueued");
+    const RotState* st = R->state.as<RotState>();
+    *edge = lili_cloud{R->edge_pts.p, 0, 16, 12, LILI_MEM_DEVICE};
+    *surf = lili_cloud{R->surf.p, 0, 16, 12, LILI_MEM_DEVICE};
+    *d_n_edge = &st->n_edge; *d_n_surf = &st->n_surf;
+    *prev_edge = R->prev_ok ? R->prev_edge : 0; *prev_surf = R->prev_ok ? R->prev_surf : 0;
+    return LILI_OK;
+}
+bool lili_extract_rot_redone(lili_ctx* ctx) { auto* R = rot_of(ctx); return R->redone; }
 extern "C" {
 
 // Intermediate products of the last lili_extract_rot (parity tests / debugging).  Any pointer may be NULL.

@@ -69,6 +69,57 @@ int lili_s2m_set_queries(lili_ctx* ctx, int slot, int kind, const lili_cloud* cl
     return LILI_OK;
 }
 
+}  // extern "C"
+
+// Queries whose NUMBER the host does not know yet (lili_pipeline.hip: a frame's features while the extractor's kernels are still on the stream): the slot is sized for
+// `n_guess` queries, the kernel takes the first min(*d_count, n_guess) rows of `d_src` and fills the rest with NaN rows — a non-finite query selects nothing (cell_of,
+// the key selector), leaves no record and no count, so every sum of the iteration is the sum over the real queries in the order a slot of exactly *d_count queries
+// would take it (the partition of the queries into association / linearisation workgroups depends on the query's index alone; the padding workgroups add +0.0).
+// lili_s2m_trim_queries afterwards, once the count is known (count <= n_guess, else the caller sets the queries again).
+namespace lili {
+__global__ __launch_bounds__(256) void k_queries_counted(const float4* __restrict__ src, const int* __restrict__ d_count, int n_guess, float4* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_guess) return;
+    const float qn = __builtin_nanf("");
+    out[i] = i < *d_count ? src[i] : make_float4(qn, qn, qn, 0.f);
+}
+}  // namespace lili
+int lili_s2m_set_queries_counted(lili_ctx* ctx, int slot, int kind, const float4* d_src, const int* d_count, int n_guess, bool launch) {
+    if (!ctx) return LILI_E_ARG;
+    ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS && (kind == 0 || kind == 1) && d_src && d_count && n_guess > 0, "set_queries_counted: bad argument");
+    KindSlot& ks = ctx->slots[slot].k[kind];
+    ks.has_queries = false; ks.has_records = false; ks.launches = 0;
+    const size_t n = (size_t)n_guess;
+    HIPCHK(ks.q.ensure(n * sizeof(float4)));
+    if (launch) {      // (lili_pipeline.hip fills both kinds and sets the pose in ONE launch of its own)
+        hipLaunchKernelGGL(k_queries_counted, dim3(nblocks(n_guess, 256)), dim3(256), 0, ctx->stream, d_src, d_count, n_guess, ks.q.as<float4>());
+        HIPCHK(hipGetLastError());
+    }
+    ks.n_q = n_guess;
+    ks.has_aux = true;
+    ks.n_blocks = nblocks(ks.n_q, kAssocBlock);
+    ks.n_lin_blocks = std::min(nblocks(ks.n_q, kLinBlock), kMaxLinBlocks);
+    HIPCHK(ks.rec0.ensure(n * sizeof(float4)));
+    HIPCHK(ks.rec1.ensure(n * sizeof(float4)));
+    HIPCHK(ks.valid.ensure(n));
+    HIPCHK(ks.partials.ensure((size_t)ks.n_lin_blocks * kPartialStride * sizeof(double)));
+    HIPCHK(ks.block_counts.ensure((size_t)ks.n_blocks * sizeof(int)));
+    ks.has_queries = true;
+    return LILI_OK;
+}
+// the slot's query count after the fact (n <= the count the slot was sized for): what lies behind n was padding
+int lili_s2m_trim_queries(lili_ctx* ctx, int slot, int kind, int n) {
+    if (!ctx) return LILI_E_ARG;
+    KindSlot& ks = ctx->slots[slot].k[kind];
+    ARGCHK(ks.has_queries && n >= 0 && n <= ks.n_q, "trim_queries: bad argument");
+    ks.n_q = n;
+    ks.n_blocks = nblocks(ks.n_q, kAssocBlock);
+    ks.n_assoc_blocks = std::min(ks.n_assoc_blocks, ks.n_blocks);
+    ks.n_lin_blocks = std::min(nblocks(ks.n_q, kLinBlock), kMaxLinBlocks);
+    return LILI_OK;
+}
+extern "C" {
+
 static int launch_associate(lili_ctx* ctx, int slot, int kind, const PoseArg& pa, const MatchParams& P) {
     KindSlot& ks = ctx->slots[slot].k[kind];
     if (!ks.has_queries) return ctx->fail(LILI_E_STATE, "associate: set_queries first");

@@ -154,6 +154,48 @@ def test_frontend_frame_rot_with_the_callers_maps_equals_the_separate_calls():
         ctx.close()
 
 
+def test_frontend_frame_rot_guessed_feature_counts_change_nothing():
+    """Round 6: with the caller's maps and the features as queries the matcher is enqueued behind the extractor for GUESSED feature counts (the previous scan's + 1/8 + 64,
+    padding rows are NaN) and the call synchronises once.  The pose must be the one of the exactly sized slot — on a hit (same scan again), on a miss (a scan with many
+    more features than the one before: matched again the plain way) and with the option off."""
+    import torch
+    w = synth.make_workload(n_map=200_000, n_az=400, half_extent=(150.0, 150.0), verbose=False)
+    raw = np.concatenate([w["scan_xyz"], np.full((w["scan_xyz"].shape[0], 1), 50.0, np.float32)], 1)
+    n_az = raw.shape[0] // 64
+    thin = np.ascontiguousarray(raw.reshape(n_az, 64, 4)[:, ::4].reshape(-1, 4))      # a quarter of the rings: about a quarter of the features
+    P = L.make_params("rot")
+    q_lb = np.array(list(P.q_lb))
+    tb, qb = L.api.body_pose_from_lidar(w["lidar_t"], w["lidar_q"], P)
+    t0, q0 = synth.perturbed_pose(tb, qb, np.random.default_rng(synth.SEED_POSE), 0.2, 1.0)
+    d_raw, d_thin = torch.from_numpy(raw).cuda(), torch.from_numpy(thin).cuda()
+    cloud = L.api.cloud_from_device(d_raw.data_ptr(), raw.shape[0], 16, 12)
+    cloud_thin = L.api.cloud_from_device(d_thin.data_ptr(), thin.shape[0], 16, 12)
+
+    def run(guess, seq):
+        ctx = L.Context(0)
+        try:
+            ctx.set_option("frame_guess_counts", guess)
+            m = L.ScanToMapMatcher(ctx, P)
+            m.set_input_cloud(L.KIND_SURF, w["map_xyz"]); m.set_input_cloud(L.KIND_EDGE, w["edge_map_xyz"])
+            odo = L.RotFrontendOdometry(ctx, params=P, n_scans=64, ds_rate=1, q_lb=q_lb, leaf_query=0.0, scan_match_cnt=2, external_map=True, edges=True, slot=1)
+            out = []
+            for c in seq:
+                t, q, info = odo.frame(c, t0, q0)
+                assert info["matched"] and info["gn_status"] == 0
+                out.append((t.copy(), q.copy(), info["n_surf"], info["n_edge"], info["n_query"]))
+            return out
+        finally:
+            ctx.close()
+
+    plain = run(0, [cloud, cloud_thin])
+    full, small = plain
+    assert small[2] < 0.6 * full[2] and full[2] > 1000              # the thin scan has far fewer features: the full one behind it overflows the guess
+    got = run(1, [cloud, cloud, cloud_thin, cloud, cloud_thin, cloud_thin])      # first (no guess) | hit | hit (fewer than guessed) | MISS | hit | hit
+    for g, want in zip(got, [full, full, small, full, small, small]):
+        assert g[2:] == want[2:]
+        assert np.array_equal(g[0], want[0]) and np.array_equal(g[1], want[1])
+
+
 def _circuit(f, radius=4.0, step=0.03):
     a = step * f
     yaw = a + math.pi / 2
