@@ -1013,6 +1013,8 @@ def main():
                 cx = own_ctx()
                 extras["scan_pipeline_200k"] = BC.scan_pipeline_200k(L, cx, torch, synth, w, focus_r, cpu=not args.no_cpu_baseline, ips=ips)
                 failures.extend(f"scan_pipeline_200k: {f}" for f in BC.parity_failures(extras["scan_pipeline_200k"]))
+                if (extras["scan_pipeline_200k"].get("one_call") or {}).get("pose_equals_separate_calls_bit_for_bit") is False:
+                    failures.append("scan_pipeline_200k: the one-call pose differs from the separate calls")
             except Exception as e:      # noqa: BLE001
                 extras["scan_pipeline_200k"] = {"error": repr(e)}
             try:
