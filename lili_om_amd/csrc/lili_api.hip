@@ -219,6 +219,8 @@ int lili_set_option(lili_ctx* ctx, const char* name, int value) {
     if (std::strcmp(name, "fine_grid") == 0) { ctx->fine_grid = value != 0; return LILI_OK; }
     if (std::strcmp(name, "sort_ride_hist") == 0) { ctx->sort_ride_hist = value != 0; return LILI_OK; }
     if (std::strcmp(name, "frame_guess_counts") == 0) { ctx->frame_guess_counts = value != 0; return LILI_OK; }
+    if (std::strcmp(name, "rot_fold") == 0) { ctx->rot_fold = value != 0; return LILI_OK; }
+    if (std::strcmp(name, "rot_segment_wait") == 0) { ctx->rot_segment_wait = value != 0; return LILI_OK; }
     if (std::strcmp(name, "super_rows") == 0) { ctx->super_rows = value != 0; return LILI_OK; }   // takes effect at the next lili_map_set
     if (std::strcmp(name, "fine_occupancy") == 0) { if (value < 2) return ctx->fail(LILI_E_ARG, "fine_occupancy must be >= 2"); ctx->fine_occupancy = value; return LILI_OK; }
     if (std::strcmp(name, "scan_lookback") == 0) { ctx->scan_lookback = value != 0; return LILI_OK; }

@@ -184,6 +184,7 @@ struct lili_ctx {
     bool localmap_incremental = true;   // lili_localmap_commit keeps the ring sorted by voxel and merges one keyframe per step (0: rebuild every time, A/B)
     int sort_fused_max_tiles = 256;   // (measured: 200 k keys 212 -> 190 us per filter, 1 M keys 301 -> 296; 489 tiles of a 2 M-key sort: 290 -> 475 us)
     bool sort_fused_scan = true;      // radix passes of at most sort_fused_max_tiles tiles: the scatter kernel derives its offsets from the count table itself (no scan launch)
+    bool rot_fold = true, rot_segment_wait = true;      // lili_extract_rot: k_rot_ring writes the scan's lists itself (0: k_rot_compact behind it) / a segment whose pick may lie under its predecessor's marks waits for them in k_rot_segments (0: k_rot_ring redoes it) — A/B and fallback paths
     int frame_guess_misses = 0;         // frames whose guessed feature counts were too small (matched again the plain way)
     bool frame_guess_counts = true;     // lili_frontend_frame_rot on a caller's maps: the matcher is enqueued behind the extractor with GUESSED feature counts (one synchronisation per scan; 0: wait for the counts first, A/B)
     bool sort_ride_hist = true;         // the radix sort's digit histograms ride on the key kernel and on the scatter passes (a pass = one launch; 0: a histogram launch per pass, A/B)

@@ -1696,7 +1696,7 @@ static int rot_enqueue(lili_ctx* ctx, const lili_cloud* scan, const double q_imu
         X.seg_out = R->seg_out.as<SegOut>(); X.ring_ncand = R->ring_ncand.as<int>(); X.sorted_k = R->sorted_k.as<int>(); X.sorted_vox = R->sorted_vox.as<unsigned>();
         X.sorted_len = R->sorted_len.as<int>();
         R->fold_tag = R->fold_tag >= 0xffffu ? 1u : R->fold_tag + 1u;      // tag of this extraction's status words (k_rot_segments, k_rot_ring)
-        X.seg_final = R->fold_words.as<unsigned long long>() + kMaxRings; X.tag = R->fold_tag;
+        X.seg_final = ctx->rot_segment_wait ? R->fold_words.as<unsigned long long>() + kMaxRings : nullptr; X.tag = R->fold_tag;
         RotDev P{};
         P.n_scans = params->n_scans; P.ds_rate = params->ds_rate; P.ds_v = params->ds_v; P.near_thres = params->near_range;
         P.atan_mode = ctx->rot_atan;
@@ -1726,7 +1726,7 @@ static int rot_enqueue(lili_ctx* ctx, const lili_cloud* scan, const double q_imu
         }
         hipLaunchKernelGGL(k_rot_segments, dim3(kStage3Blocks), dim3(kRotBlock), std::max(sizeof(SegLds), sizeof(OrderLds)), ctx->stream, R->full.as<float4>(), R->vkey.as<unsigned>(), P, st, R->curv.as<float>(),
                            R->sort_ind.as<int>(), R->label.as<int>(), X);
-        {   // the ring stage writes the scan's lists itself (RotFold): four launches
+        if (ctx->rot_fold) {   // the ring stage writes the scan's lists itself (RotFold): four launches
             RotFold F{};
             F.words = R->fold_words.as<unsigned long long>();
             F.tag = R->fold_tag;
@@ -1738,6 +1738,14 @@ static int rot_enqueue(lili_ctx* ctx, const lili_cloud* scan, const double q_imu
             hipLaunchKernelGGL(k_rot_ring, dim3(kMaxRings), dim3(kRotBlock), sizeof(RingLds), ctx->stream, R->full.as<float4>(), R->curv.as<float>(), R->sort_ind.as<int>(), P, st,
                                R->label.as<int>(), R->ring_edge.as<int>(), R->ring_sharp.as<int>(), R->ring_flat.as<int>(), R->lessflat_tmp.as<int>(),
                                R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>(), X, F);
+        } else {               // option "rot_fold" = 0 (A/B, and the path a ring's given-up look-back falls back to): per-ring lists, then the concatenation launch of rounds 3-5
+            if (R->h_state) *reinterpret_cast<volatile int*>(R->h_state + 1) = 0;
+            hipLaunchKernelGGL(k_rot_ring, dim3(kMaxRings), dim3(kRotBlock), sizeof(RingLds), ctx->stream, R->full.as<float4>(), R->curv.as<float>(), R->sort_ind.as<int>(), P, st,
+                               R->label.as<int>(), R->ring_edge.as<int>(), R->ring_sharp.as<int>(), R->ring_flat.as<int>(), R->lessflat_tmp.as<int>(),
+                               R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>(), X, RotFold{});
+            hipLaunchKernelGGL(k_rot_compact, dim3(kMaxRings), dim3(256), 0, ctx->stream, st, R->full.as<float4>(), R->ring_edge.as<int>(), R->ring_sharp.as<int>(),
+                               R->ring_flat.as<int>(), R->lessflat_tmp.as<int>(), R->surf_tmp.as<float4>(), R->surf_cnt_tmp.as<int>(), R->edge_idx.as<int>(),
+                               R->edge_pts.as<float4>(), R->sharp_idx.as<int>(), R->flat_idx.as<int>(), R->lessflat_idx.as<int>(), R->surf.as<float4>(), R->surf_cnt.as<int>(), R->h_state_dev);
         }
         HIPCHK(hipGetLastError());
         // page-locked feature buffers are written right behind the concatenation, `count` records each, before the host has seen the counts: the state's read-back below

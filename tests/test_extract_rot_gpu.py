@@ -58,6 +58,24 @@ def test_rot_extractor_parity(gpu_ctx, oracle, n_az, ds_rate):
         np.testing.assert_allclose(lit["surf"], o["surf"], rtol=2e-6, atol=2e-5)
 
 
+@pytest.mark.parametrize("fold,wait", [(0, 1), (1, 0), (0, 0)])
+def test_rot_extractor_fallback_paths(gpu_ctx, oracle, fold, wait):
+    """Round 6 moved two steps into kernels that wait for other workgroups (the ring stage writes the scan's lists behind a look-back over the lower rings; a segment
+    whose pick may lie under its predecessor's marks waits for them).  Both waits are bounded and fall back to the launches of rounds 3-5 — k_rot_compact, the redo in
+    k_rot_ring — which options "rot_fold" / "rot_segment_wait" = 0 select outright: the same features, bit for bit."""
+    raw = _raw_scan(3125)      # (the 200 k-point scan: several of its segments need the redo)
+    q_lb = [0.7071, 0.0, 0.0, 0.7071]
+    q_imu = [0.9998, 0.004, -0.007, 0.012]
+    o = oracle.extract_rot(raw, q_imu, q_lb, oracle.rot_params(ds_rate=1, atan_mode=2, stable_sort=1))
+    gpu_ctx.set_option("rot_fold", fold); gpu_ctx.set_option("rot_segment_wait", wait)
+    try:
+        ex = L.RotExtractor(gpu_ctx, n_scans=64, ds_rate=1)
+        for _ in range(2):
+            _compare(ex.extract(raw, q_imu, q_lb, debug=True), o)
+    finally:
+        gpu_ctx.set_option("rot_fold", 1); gpu_ctx.set_option("rot_segment_wait", 1)
+
+
 def test_rot_extractor_edge_cases(gpu_ctx, oracle):
     ex = L.RotExtractor(gpu_ctx, n_scans=64, ds_rate=1)
     raw = _raw_scan(391, seed=3)
