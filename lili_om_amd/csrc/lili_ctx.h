@@ -239,11 +239,14 @@ int lili_localmap_ring_size(lili_ctx* ctx, int kind);
 // lili_extract_livox.hip -> lili_pipeline.hip: the extraction enqueued without its synchronisation, and the counts taken afterwards
 int lili_extract_livox_enqueue(lili_ctx* ctx, const lili_cloud* scan, int curvature_offset, const double q_imu[4], const lili_livox_params* params);
 int lili_extract_livox_complete(lili_ctx* ctx);
-int lili_extract_rot_enqueue(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4], const double q_lb[4], const lili_rot_params* params);
+// Where an extraction may put its feature lists IN ADDITION to its own device lists (lili_pipeline.hip: a frame with guessed feature counts): the query arrays of a matcher
+// slot — rows behind the lists' ends are filled with NaN up to the capacities (lili_s2m_set_queries_counted) —, and the slot's state, set to `pose` like lili_s2m_pose_set.
+struct lili_query_sink { float4* q_surf = nullptr; int cap_surf = 0; float4* q_edge = nullptr; int cap_edge = 0; lili::SlotState* state = nullptr; double pose[7] = {0, 0, 0, 1, 0, 0, 0}; };
+int lili_extract_rot_enqueue(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4], const double q_lb[4], const lili_rot_params* params, const lili_query_sink* sink = nullptr);
+// list lengths of the previous completed extraction on this context (0 / 0: none)
+void lili_extract_rot_prev(lili_ctx* ctx, int* prev_edge, int* prev_surf);
 int lili_extract_rot_complete(lili_ctx* ctx);
-// the ROT extraction's device lists and the words their lengths will be in, BEFORE the counts have come back (lili_extract_rot_enqueue has been called); the lengths of the
-// previous extraction on this context as guesses (0: none).  lili_extract_rot_redone: did lili_extract_rot_complete rewrite the lists (second passes)?
-int lili_extract_rot_early(lili_ctx* ctx, lili_cloud* edge, lili_cloud* surf, const int** d_n_edge, const int** d_n_surf, int* prev_edge, int* prev_surf);
+// did the last lili_extract_rot_complete rewrite the lists (second passes)?
 bool lili_extract_rot_redone(lili_ctx* ctx);
 // lili_match.hip -> lili_pipeline.hip: queries whose number is still on the device
 int lili_s2m_set_queries_counted(lili_ctx* ctx, int slot, int kind, const float4* d_src, const int* d_count, int n_guess, bool launch = true);

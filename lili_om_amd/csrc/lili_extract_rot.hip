@@ -1039,6 +1039,7 @@ struct RingLds {
     int scan[kRotBlock / 64 + 1];
     int flag, spill, hits;
     int off[5];                              // lists of the lower rings: edge, sharp, flat, less-flat, surf
+    int tot[2];                              // last ring: the scan's edge / surf totals
     unsigned long long pmask[kRingLdsCap / 64];                // bit k: ring point k is an edge pick (leaves the less-flat list)
     unsigned short task[kRingLdsCap], vcnt[kRingLdsCap];      // VoxelGrid: the o-th centroid of the ring belongs to the voxel that starts with run task[o] and has vcnt[o] points
 };
@@ -1054,6 +1055,9 @@ struct RotFold {
     int* edge_idx; float4* edge_pts; int* sharp_idx; int* flat_idx; int* lessflat_idx; float4* surf; int* surf_cnt;
     RotState* mirror;                        // page-locked copy of the state as the device sees it, or nullptr
     int* give_up;                            // page-locked word behind the mirror, or nullptr
+    // optional second destination of the surf / edge lists: the query arrays of a matcher slot (lili_query_sink; rows behind the lists NaN up to the capacities, the
+    // slot's pose set by the last ring's workgroup) — a frame whose matcher is enqueued behind this launch needs no launch in between
+    float4* q_surf; int cap_surf; float4* q_edge; int cap_edge; SlotState* q_state; double q_pose[7];
 };
 
 // Launch 4 of 4, one workgroup per ring: joins the six segments (spill check, R:401-492 order), the ring's pick lists, the less-flat list in index order
@@ -1326,6 +1330,19 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_ring(const float4* __restrict
                         F.mirror->fallback_rings = all[5];
                     }
                 }
+                if (tid == 0) { L.tot[0] = all[0]; L.tot[1] = all[4]; }
+            }
+        }
+        if (ring == kMaxRings - 1 && (F.q_surf || F.q_edge || F.q_state)) {      // the matcher slot behind this launch: padding rows and the pose (lili_s2m_pose_set's fields)
+            __syncthreads();
+            const int tot_e = L.tot[0], tot_s = L.tot[1];
+            const float qn = __builtin_nanf("");
+            if (F.q_surf) for (int k = tot_s + tid; k < F.cap_surf; k += kRotBlock) F.q_surf[k] = make_float4(qn, qn, qn, 0.f);
+            if (F.q_edge) for (int k = tot_e + tid; k < F.cap_edge; k += kRotBlock) F.q_edge[k] = make_float4(qn, qn, qn, 0.f);
+            if (F.q_state) {
+                if (tid < 7) F.q_state->pose[tid] = F.q_pose[tid];
+                if (tid < 6) F.q_state->last_delta[tid] = 0.0;
+                if (tid == 7) { F.q_state->n_res[0] = 0; F.q_state->n_res[1] = 0; F.q_state->gn_status = 0; F.q_state->iters = 0; F.q_state->cnt_word = 0ull; }
             }
         }
     }
@@ -1359,7 +1376,10 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_ring(const float4* __restrict
             const float c = s / (float)cnt;
             tmp_c[4 * o + comp] = c;
             if (comp == 0) surf_cnt_tmp[rbase + o] = cnt;
-            if (fin_c) { fin_c[4 * o + comp] = c; if (comp == 0) F.surf_cnt[L.off[4] + o] = cnt; }
+            if (fin_c) {
+                fin_c[4 * o + comp] = c; if (comp == 0) F.surf_cnt[L.off[4] + o] = cnt;
+                if (F.q_surf && L.off[4] + o < F.cap_surf) reinterpret_cast<float*>(F.q_surf + L.off[4] + o)[comp] = c;
+            }
         }
     }
     if (tid == 0) st->ring_ticks[ring] = (int)(wall_clock64() - t_start);
@@ -1368,6 +1388,7 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_ring(const float4* __restrict
         if (pq < p_mine) {
             const int k = L.so[pj].edge[pq], at = L.off[0] + p_ne + pq;
             F.edge_idx[at] = rbase + k; F.edge_pts[at] = my_edge;
+            if (F.q_edge && at < F.cap_edge) F.q_edge[at] = my_edge;
             if (pq < 2) F.sharp_idx[L.off[1] + p_nsh + pq] = rbase + k;
         }
     } else if (pq - kSegEdge < p_minf) F.flat_idx[L.off[2] + p_nfl + pq - kSegEdge] = rbase + L.so[pj].flat[pq - kSegEdge];
@@ -1651,7 +1672,7 @@ extern "C" {
 // with the concatenation kernel.  rot_complete takes the counts (and runs the rare second passes).  `side`: the side stream a copy into the caller's full-cloud
 // buffer was started on (the caller of this function drains it on every exit), or nullptr.
 static int rot_enqueue(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4], const double q_lb[4], const lili_rot_params* params,
-                       lili_feature_out* full, lili_feature_out* edge, lili_feature_out* surf, hipStream_t* side) {
+                       lili_feature_out* full, lili_feature_out* edge, lili_feature_out* surf, hipStream_t* side, const lili_query_sink* sink = nullptr) {
     if (!ctx) return LILI_E_ARG;
     ARGCHK(scan && q_imu && q_lb && params, "extract_rot: null argument");
     ARGCHK(params->n_scans == 16 || params->n_scans == 32 || params->n_scans == 64, "extract_rot: n_scans must be 16, 32 or 64");
@@ -1734,6 +1755,7 @@ static int rot_enqueue(lili_ctx* ctx, const lili_cloud* scan, const double q_imu
             F.lessflat_idx = R->lessflat_idx.as<int>(); F.surf = R->surf.as<float4>(); F.surf_cnt = R->surf_cnt.as<int>();
             F.mirror = R->h_state_dev;
             F.give_up = R->h_state_dev ? reinterpret_cast<int*>(R->h_state_dev + 1) : nullptr;
+            if (sink) { F.q_surf = sink->q_surf; F.cap_surf = sink->cap_surf; F.q_edge = sink->q_edge; F.cap_edge = sink->cap_edge; F.q_state = sink->state; for (int i = 0; i < 7; i++) F.q_pose[i] = sink->pose[i]; }
             if (R->h_state) *reinterpret_cast<volatile int*>(R->h_state + 1) = 0;
             hipLaunchKernelGGL(k_rot_ring, dim3(kMaxRings), dim3(kRotBlock), sizeof(RingLds), ctx->stream, R->full.as<float4>(), R->curv.as<float>(), R->sort_ind.as<int>(), P, st,
                                R->label.as<int>(), R->ring_edge.as<int>(), R->ring_sharp.as<int>(), R->ring_flat.as<int>(), R->lessflat_tmp.as<int>(),
@@ -1869,28 +1891,20 @@ int lili_extract_rot(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4
 }  // extern "C"
 // lili_pipeline.hip: the extraction without outputs and without its synchronisation; the counts afterwards (no wait of its own if a read-back has synchronised the
 // context's stream in between)
-int lili_extract_rot_enqueue(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4], const double q_lb[4], const lili_rot_params* params) {
+int lili_extract_rot_enqueue(lili_ctx* ctx, const lili_cloud* scan, const double q_imu[4], const double q_lb[4], const lili_rot_params* params, const lili_query_sink* sink) {
     if (!ctx) return LILI_E_ARG;
+    if (sink && !(ctx->rot_fold && scan && scan->n > 0)) return ctx->fail(LILI_E_STATE, "extract_rot_enqueue: a query sink needs the ring stage that writes the scan's lists (rot_fold) and a non-empty scan");
     hipStream_t side = nullptr;
-    return rot_enqueue(ctx, scan, q_imu, q_lb, params, nullptr, nullptr, nullptr, &side);
+    return rot_enqueue(ctx, scan, q_imu, q_lb, params, nullptr, nullptr, nullptr, &side, sink);
+}
+void lili_extract_rot_prev(lili_ctx* ctx, int* prev_edge, int* prev_surf) {
+    auto* R = rot_of(ctx);
+    *prev_edge = R->prev_ok ? R->prev_edge : 0; *prev_surf = R->prev_ok ? R->prev_surf : 0;
 }
 int lili_extract_rot_complete(lili_ctx* ctx) {
     if (!ctx) return LILI_E_ARG;
     auto* R = rot_of(ctx);
     return rot_complete(ctx, nullptr, nullptr, nullptr, R->pend.on && ctx->readback_gen != R->pend.gen);
-}
-// The lists of the enqueued extraction as the device will fill them, the device words their lengths will stand in (k_rot_ring's last workgroup), and the lengths of
-// the previous extraction on this context (0 / 0: there was none): for a caller that sizes its next launches by a guess and checks it afterwards.
-int lili_extract_rot_early(lili_ctx* ctx, lili_cloud* edge, lili_cloud* surf, const int** d_n_edge, const int** d_n_surf, int* prev_edge, int* prev_surf) {
-    if (!ctx) return LILI_E_ARG;
-    auto* R = rot_of(ctx);
-    if (!R->pend.on || R->n_in <= 0) return ctx->fail(LILI_E_STATE, "extract_rot_early: nothing enqueued");
-    const RotState* st = R->state.as<RotState>();
-    *edge = lili_cloud{R->edge_pts.p, 0, 16, 12, LILI_MEM_DEVICE};
-    *surf = lili_cloud{R->surf.p, 0, 16, 12, LILI_MEM_DEVICE};
-    *d_n_edge = &st->n_edge; *d_n_surf = &st->n_surf;
-    *prev_edge = R->prev_ok ? R->prev_edge : 0; *prev_surf = R->prev_ok ? R->prev_surf : 0;
-    return LILI_OK;
 }
 bool lili_extract_rot_redone(lili_ctx* ctx) { auto* R = rot_of(ctx); return R->redone; }
 extern "C" {

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void k_queries_counted(const float4* __restric
 }  // namespace lili
 int lili_s2m_set_queries_counted(lili_ctx* ctx, int slot, int kind, const float4* d_src, const int* d_count, int n_guess, bool launch) {
     if (!ctx) return LILI_E_ARG;
-    ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS && (kind == 0 || kind == 1) && d_src && d_count && n_guess > 0, "set_queries_counted: bad argument");
+    ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS && (kind == 0 || kind == 1) && (!launch || (d_src && d_count)) && n_guess > 0, "set_queries_counted: bad argument");
     KindSlot& ks = ctx->slots[slot].k[kind];
     ks.has_queries = false; ks.has_records = false; ks.launches = 0;
     const size_t n = (size_t)n_guess;

@@ -24,22 +24,6 @@ __global__ void k_pose_set(SlotState* __restrict__ s, PoseVal p) {
     if (i == 7) { s->n_res[0] = 0; s->n_res[1] = 0; s->gn_status = 0; s->iters = 0; s->cnt_word = 0ull; }
 }
 
-// A frame with guessed feature counts (frame_impl): both query arrays (rows behind the true count are NaN: lili_s2m_set_queries_counted) and the pose in ONE launch
-__global__ __launch_bounds__(256) void k_frame_queries(const float4* __restrict__ src_s, const int* __restrict__ cnt_s, int n_s, float4* __restrict__ out_s,
-                                                       const float4* __restrict__ src_e, const int* __restrict__ cnt_e, int n_e, float4* __restrict__ out_e,
-                                                       SlotState* __restrict__ s, PoseVal p) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const float qn = __builtin_nanf("");
-    if (i < n_s) out_s[i] = i < *cnt_s ? src_s[i] : make_float4(qn, qn, qn, 0.f);
-    else if (i - n_s < n_e) { const int k = i - n_s; out_e[k] = k < *cnt_e ? src_e[k] : make_float4(qn, qn, qn, 0.f); }
-    if (blockIdx.x == 0) {
-        const int t = threadIdx.x;
-        if (t < 7) s->pose[t] = p.v[t];
-        if (t < 6) s->last_delta[t] = 0.0;
-        if (t == 7) { s->n_res[0] = 0; s->n_res[1] = 0; s->gn_status = 0; s->iters = 0; s->cnt_word = 0ull; }
-    }
-}
-
 }  // namespace lili
 
 extern "C" {
@@ -75,7 +59,8 @@ struct FrameExtractor {
     std::function<int(lili_cloud* edge, lili_cloud* surf)> lists;
     // optional (frame_guess_counts): the lists before their lengths are known — device words that will hold the lengths, the previous scan's lengths as guesses; and whether
     // `complete` rewrote the lists (second passes of the extractor)
-    std::function<int(lili_cloud* edge, lili_cloud* surf, const int** d_n_edge, const int** d_n_surf, int* prev_edge, int* prev_surf)> early;
+    std::function<void(int* prev_edge, int* prev_surf)> prev;
+    std::function<int(const lili_query_sink*)> enqueue_sink;      // the extraction enqueued with the matcher slot as a second destination of its lists
     std::function<bool()> redone;
 };
 static int frame_impl(lili_ctx* ctx, const FrameExtractor& ex, const lili_s2m_params* match, const lili_frontend_options* opt, const double t_pred[3], const double q_pred[4],
@@ -96,62 +81,68 @@ static int frame_impl(lili_ctx* ctx, const FrameExtractor& ex, const lili_s2m_pa
     //      delivers the extraction's counts with its own; behind the index build's kernels — before the build's read-back synchronises — the frame's QUERY filter is
     //      enqueued (down_size_filter_surf, L:320-322, on the extractor's device list, into the filter's second output) so that its voxel count comes back with the
     //      build's density words.  Three synchronisations per frame (ring merge, index build + query filter, pose) where the stages called one by one take five.
-    int rc = ex.enqueue();
-    if (rc != LILI_OK) return rc;
     const bool self_map = (opt->flags & LILI_FRAME_SELF_MAP) != 0;
     lili_cloud d_edge{}, d_surf{};
     bool lists = false, filter_enqueued = false, filter_pending = false;
+    int rc = LILI_OK;
     // ---- A caller's maps and the features themselves as queries (BASELINE configs[0]): nothing between the extraction and the matcher needs the host — except the NUMBER
-    //      of features, which sizes the matcher's launches.  Guess it (the previous scan's counts + 1/8 + 64), enqueue the matcher behind the extractor's kernels for
-    //      that many rows (lili_s2m_set_queries_counted: rows behind the true count are NaN and select nothing, so every sum is the one an exactly sized slot takes)
-    //      and synchronise ONCE: the pose comes back with the counts.  A scan with more features than guessed, or one whose lists a second pass of the extractor
-    //      rewrote, is matched again below the plain way.
-    if (ctx->frame_guess_counts && ext_map && !(opt->leaf_query > 0) && ex.early && opt->n_iters > 0 && ctx->map[LILI_KIND_SURF].valid && ctx->map[LILI_KIND_SURF].n >= 10 &&
-        (!edges || ctx->map[LILI_KIND_EDGE].valid)) {
-        const int* d_ne = nullptr; const int* d_ns = nullptr; int pe = 0, ps = 0;
-        rc = ex.early(&d_edge, &d_surf, &d_ne, &d_ns, &pe, &ps);
-        if (rc == LILI_OK && ps > 0) {
-            const int ge = ((pe + pe / 8 + 64 + 63) / 64) * 64, gs = ((ps + ps / 8 + 64 + 63) / 64) * 64;
-            rc = lili_s2m_set_queries_counted(ctx, slot, LILI_KIND_SURF, static_cast<const float4*>(d_surf.data), d_ns, gs, false);
+    //      of features, which sizes the matcher's launches.  Guess it (the previous scan's counts + 1/8 + 64): the slot is sized for that many rows, the extractor's last
+    //      kernel writes its lists into the slot's query arrays as well, fills the rows behind them with NaN (such a row selects nothing, so every sum is the one an exactly
+    //      sized slot takes: lili_s2m_set_queries_counted) and sets the slot's pose; the matcher is enqueued right behind it and the call synchronises ONCE — the pose comes
+    //      back with the counts.  A scan with more features than guessed, or one whose lists a second pass of the extractor rewrote, is matched again below the plain way.
+    bool guessed = false;
+    int ge = 0, gs = 0;
+    if (ctx->frame_guess_counts && ctx->rot_fold && ext_map && !(opt->leaf_query > 0) && ex.prev && ex.enqueue_sink && opt->n_iters > 0 && ctx->map[LILI_KIND_SURF].valid &&
+        ctx->map[LILI_KIND_SURF].n >= 10 && (!edges || ctx->map[LILI_KIND_EDGE].valid)) {
+        int pe = 0, ps = 0;
+        ex.prev(&pe, &ps);
+        if (ps > 0) {
+            ge = ((pe + pe / 8 + 64 + 63) / 64) * 64; gs = ((ps + ps / 8 + 64 + 63) / 64) * 64;
+            rc = lili_s2m_set_queries_counted(ctx, slot, LILI_KIND_SURF, nullptr, nullptr, gs, false);
+            if (rc == LILI_OK && edges) rc = lili_s2m_set_queries_counted(ctx, slot, LILI_KIND_EDGE, nullptr, nullptr, ge, false);
             if (rc != LILI_OK) return rc;
-            if (edges) { rc = lili_s2m_set_queries_counted(ctx, slot, LILI_KIND_EDGE, static_cast<const float4*>(d_edge.data), d_ne, ge, false); if (rc != LILI_OK) return rc; }
-            PoseVal pv{};
-            for (int i = 0; i < 3; i++) pv.v[i] = t_pred[i];
-            for (int i = 0; i < 4; i++) pv.v[3 + i] = q_pred[i];
-            hipLaunchKernelGGL(k_frame_queries, dim3(nblocks(gs + (edges ? ge : 0), 256)), dim3(256), 0, ctx->stream, static_cast<const float4*>(d_surf.data), d_ns, gs,
-                               ctx->slots[slot].k[LILI_KIND_SURF].q.as<float4>(), static_cast<const float4*>(d_edge.data), d_ne, edges ? ge : 0,
-                               edges ? ctx->slots[slot].k[LILI_KIND_EDGE].q.as<float4>() : nullptr, ctx->state(slot), pv);
-            HIPCHK(hipGetLastError());
-            ctx->slots[slot].assoc_since_pose = 0;
-            rc = lili_s2m_iterate(ctx, slot, LILI_MASK_SURF | (edges ? LILI_MASK_EDGE : 0), match, opt->n_iters);
+            lili_query_sink sink{};
+            sink.q_surf = ctx->slots[slot].k[LILI_KIND_SURF].q.as<float4>(); sink.cap_surf = gs;
+            if (edges) { sink.q_edge = ctx->slots[slot].k[LILI_KIND_EDGE].q.as<float4>(); sink.cap_edge = ge; }
+            sink.state = ctx->state(slot);
+            for (int i = 0; i < 3; i++) sink.pose[i] = t_pred[i];
+            for (int i = 0; i < 4; i++) sink.pose[3 + i] = q_pred[i];
+            rc = ex.enqueue_sink(&sink);
             if (rc != LILI_OK) return rc;
-            stamp(0); stamp(1); stamp(2);
-            SlotState st{};
-            rc = lili_readback_add(ctx, &st, ctx->state(slot), sizeof(st));
+            guessed = true;
+        }
+    }
+    if (!guessed) { rc = ex.enqueue(); if (rc != LILI_OK) return rc; }
+    if (guessed) {
+        ctx->slots[slot].assoc_since_pose = 0;
+        rc = lili_s2m_iterate(ctx, slot, LILI_MASK_SURF | (edges ? LILI_MASK_EDGE : 0), match, opt->n_iters);
+        if (rc != LILI_OK) return rc;
+        stamp(0); stamp(1); stamp(2);
+        SlotState st{};
+        rc = lili_readback_add(ctx, &st, ctx->state(slot), sizeof(st));
+        if (rc != LILI_OK) return rc;
+        rc = lili_readback_finish(ctx);
+        if (rc != LILI_OK) return rc;
+        rc = ex.complete();                  // (the stream has been synchronised: the counts lie in the extractor's page-locked state)
+        if (rc != LILI_OK) return rc;
+        rc = ex.lists(&d_edge, &d_surf);
+        if (rc != LILI_OK) return rc;
+        lists = true;
+        if (!(ex.redone && ex.redone()) && d_surf.n > 0 && (int64_t)d_surf.n <= gs && (!edges || (int64_t)d_edge.n <= ge)) {
+            rc = lili_s2m_trim_queries(ctx, slot, LILI_KIND_SURF, (int)d_surf.n);
+            if (rc == LILI_OK && edges) rc = lili_s2m_trim_queries(ctx, slot, LILI_KIND_EDGE, (int)d_edge.n);
             if (rc != LILI_OK) return rc;
-            rc = lili_readback_finish(ctx);
-            if (rc != LILI_OK) return rc;
-            rc = ex.complete();                  // (the stream has been synchronised: the counts lie in the extractor's page-locked state)
-            if (rc != LILI_OK) return rc;
-            rc = ex.lists(&d_edge, &d_surf);
-            if (rc != LILI_OK) return rc;
-            lists = true;
-            if (!(ex.redone && ex.redone()) && d_surf.n > 0 && (int64_t)d_surf.n <= gs && (!edges || (int64_t)d_edge.n <= ge)) {
-                rc = lili_s2m_trim_queries(ctx, slot, LILI_KIND_SURF, (int)d_surf.n);
-                if (rc == LILI_OK && edges) rc = lili_s2m_trim_queries(ctx, slot, LILI_KIND_EDGE, (int)d_edge.n);
-                if (rc != LILI_OK) return rc;
-                stamp(3);
-                res->n_edge = (int32_t)d_edge.n; res->n_surf = (int32_t)d_surf.n; res->n_query = (int32_t)d_surf.n;
-                res->matched = 1;
-                for (int i = 0; i < 3; i++) res->t[i] = st.pose[i];
-                for (int i = 0; i < 4; i++) res->q[i] = st.pose[3 + i];
-                res->gn_status = st.gn_status;
-                res->n_map = (int32_t)ctx->map[LILI_KIND_SURF].n; res->n_map_raw = res->n_map;
-                return LILI_OK;
-            }
-            ctx->frame_guess_misses++;
-            filter_enqueued = true;              // the lists are known; the features themselves are the queries: on with the plain chain
-        } else if (rc != LILI_OK) return rc;
+            stamp(3);
+            res->n_edge = (int32_t)d_edge.n; res->n_surf = (int32_t)d_surf.n; res->n_query = (int32_t)d_surf.n;
+            res->matched = 1;
+            for (int i = 0; i < 3; i++) res->t[i] = st.pose[i];
+            for (int i = 0; i < 4; i++) res->q[i] = st.pose[3 + i];
+            res->gn_status = st.gn_status;
+            res->n_map = (int32_t)ctx->map[LILI_KIND_SURF].n; res->n_map_raw = res->n_map;
+            return LILI_OK;
+        }
+        ctx->frame_guess_misses++;
+        filter_enqueued = true;              // the lists are known; the features themselves are the queries: on with the plain chain
     }
     // extraction's counts -> device lists -> query filter enqueued (no synchronisation of its own unless the counts have not come back yet)
     bool in_hook = false;      // called from inside the index build: its scratch fill has just zeroed the filter's box words
@@ -272,7 +263,8 @@ int lili_frontend_frame_rot(lili_ctx* ctx, const lili_cloud* scan, const double 
     ex.enqueue = [&]() { return lili_extract_rot_enqueue(ctx, scan, q_imu, q_lb, rot); };
     ex.complete = [&]() { return lili_extract_rot_complete(ctx); };
     ex.lists = [&](lili_cloud* e, lili_cloud* s) { return lili_extract_rot_device(ctx, nullptr, e, s); };
-    ex.early = [&](lili_cloud* e, lili_cloud* s, const int** ne, const int** ns, int* pe, int* ps) { return lili_extract_rot_early(ctx, e, s, ne, ns, pe, ps); };
+    ex.prev = [&](int* pe, int* ps) { lili_extract_rot_prev(ctx, pe, ps); };
+    ex.enqueue_sink = [&](const lili_query_sink* sink) { return lili_extract_rot_enqueue(ctx, scan, q_imu, q_lb, rot, sink); };
     ex.redone = [&]() { return lili_extract_rot_redone(ctx); };
     return frame_impl(ctx, ex, match, opt, t_pred, q_pred, res);
 }

@@ -29,4 +29,5 @@ grep -E "passed|failed" $S/pytest_all.log | tail -1 > $D/${R}_gpu_tests.txt
 [ -f $S/dense2b_pmc.json ] && cp $S/dense2b_pmc.json $D/${R}_2B_pmc.json
 [ -f $S/randrun_probe.txt ] && cp $S/randrun_probe.txt $D/${R}_randrun_probe.txt
 [ -f $S/k7_traffic.json ] && cp $S/k7_traffic.json $D/${R}_k7_traffic.json
+[ -f $S/config0_timeline.txt ] && cp $S/config0_timeline.txt $D/${R}_config0_timeline.txt
 ls -la $D/${R}_*

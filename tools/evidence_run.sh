@@ -40,4 +40,8 @@ echo "== index build traffic"
 bash tools/k7_pmc.sh $TAG/k7pmc > $OUT/k7_pmc.log 2>&1; cp gpurun_out/$TAG/k7pmc/k7_traffic.json $OUT/k7_traffic.json 2>/dev/null; tail -12 $OUT/k7_pmc.log
 echo "== frame pipeline probe"; python tools/frame_probe.py 2>/dev/null | tail -1
 echo "== back-end keyframe"; ./examples/backend_demo 60 2500 250 40 3
+# ---- round 6, second half: BASELINE configs[0] as one call (guessed feature counts): kernel timeline of the steady state
+echo "== configs[0] timeline"
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT -o c0 -- python bench.py --config 0 --no-cpu-baseline > $OUT/c0_bench.json 2> $OUT/c0.err
+python tools/trace_gaps.py $OUT/c0_kernel_trace.csv > $OUT/config0_timeline.txt; cat $OUT/config0_timeline.txt
 
