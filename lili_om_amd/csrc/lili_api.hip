@@ -175,6 +175,7 @@ void lili_ctx_destroy(lili_ctx* ctx) {
     for (auto& s : ctx->slots) for (auto& k : s.k) { k.q.release(); k.rec0.release(); k.rec1.release(); k.valid.release(); k.dbg_idx.release(); k.dbg_d2.release(); k.partials.release(); k.partials_wave.release(); k.block_counts.release(); }
     if (ctx->h_records) { (void)hipHostFree(ctx->h_records); ctx->h_records = nullptr; }
     if (ctx->h_pin) { (void)hipHostFree(ctx->h_pin); ctx->h_pin = nullptr; }
+    if (ctx->h_state_mirror) { (void)hipHostFree(ctx->h_state_mirror); ctx->h_state_mirror = nullptr; ctx->h_state_mirror_dev = nullptr; }
     ctx->states.release(); ctx->staging.release(); ctx->gram.release(); ctx->win_rec.release(); ctx->win_counts.release(); ctx->misc.release();
     if (ctx->ext_rot && ctx->ext_rot_free) ctx->ext_rot_free(ctx->ext_rot);
     if (ctx->ext_livox && ctx->ext_livox_free) ctx->ext_livox_free(ctx->ext_livox);

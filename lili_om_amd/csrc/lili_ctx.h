@@ -201,6 +201,11 @@ struct lili_ctx {
     int fail(int code, const std::string& m) { err = m; return code; }
     SlotState* state(int slot) { return states.as<SlotState>() + slot; }
     double* gram_of(int slot) { return gram.as<double>() + (size_t)slot * LILI_GRAM_DOUBLES; }
+    // Page-locked copy of the slots' states for "iterate, then read the pose" without a copy launch (lili_pipeline.hip): `state_mirror_want` asks the next lili_s2m_iterate to
+    // hand the mirror to the reduction + GN kernel of its LAST iteration (take_state_mirror: one shot); a path without such a kernel leaves the host's sentinel in place.
+    lili::SlotState* h_state_mirror = nullptr; lili::SlotState* h_state_mirror_dev = nullptr;
+    bool state_mirror_want = false, state_mirror_armed = false;
+    lili::SlotState* take_state_mirror(int slot) { if (!state_mirror_armed || !h_state_mirror_dev) return nullptr; state_mirror_armed = false; return h_state_mirror_dev + slot; }
     double* pub_of(int slot) { return pose_pub.as<double>() + (size_t)slot * kPubReplicas * kPubStride; }      // option overlap_gn: the slot's published-pose copies
 };
 

@@ -24,7 +24,7 @@ template <int BS> __global__ void k_associate_surf(const float4*, int, GridView,
 template <int BS> __global__ void k_associate_edge(const float4*, int, GridView, PoseArg, MatchParams, float4*, float4*, unsigned char*, int*, float*, int*);
 __global__ void k_associate_both(AssocArgs, AssocArgs, PoseArg, MatchParams);
 __global__ void k_linearize(LinArgs, LinArgs, PoseArg, MatchParams, const SlotState*, const int*, FuseTail);
-__global__ void k_reduce_partials(const double*, int, const double*, int, double*, SlotState*, int, P2PView, unsigned long long, double*);
+__global__ void k_reduce_partials(const double*, int, const double*, int, double*, SlotState*, int, P2PView, unsigned long long, double*, SlotState*);
 __global__ void k_sum_counts(const int*, int, const int*, int, SlotState*, int*, P2PView);
 __global__ void k_gn_update(const double*, SlotState*);
 __global__ void k_pose_copy(SlotState*, const SlotState*);

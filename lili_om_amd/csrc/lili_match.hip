@@ -291,7 +291,7 @@ static int launch_associate_coop(lili_ctx* ctx, int slot, int kind_mask, const P
     switch (L) { LILI_COOP_CASE(2) LILI_COOP_CASE(4) LILI_COOP_CASE(8) LILI_COOP_CASE(16) default: return 1; }
 #undef LILI_COOP_CASE
     if (lin) hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx->stream, (const double*)ps, A[0].nb, (const double*)pe, A[1].nb, d_out, ctx->state(slot),
-                                1 | (P.debug & 256), P2PView{}, 0ull, (double*)nullptr);
+                                1 | (P.debug & 256), P2PView{}, 0ull, (double*)nullptr, ctx->take_state_mirror(slot));
     HIPCHK(hipGetLastError());
     sl.use_global_counts = false;
     return LILI_OK;
@@ -504,7 +504,7 @@ static int launch_associate_lin_reduce(lili_ctx* ctx, int slot, int kind_mask, c
     else hipLaunchKernelGGL(k_associate_lin<kBlock>, dim3(A[0].nb + A[1].nb), dim3(kBlock), 0, ctx->stream, A[0], A[1], pa, P,
                             sl.k[0].partials_wave.as<double>(), sl.k[1].partials_wave.as<double>());
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx->stream, (const double*)sl.k[0].partials_wave.as<double>(), A[0].nb,
-                       (const double*)sl.k[1].partials_wave.as<double>(), A[1].nb, d_out, ctx->state(slot), 1 | (P.debug & 256), P2PView{}, 0ull, (double*)nullptr);
+                       (const double*)sl.k[1].partials_wave.as<double>(), A[1].nb, d_out, ctx->state(slot), 1 | (P.debug & 256), P2PView{}, 0ull, (double*)nullptr, ctx->take_state_mirror(slot));
     HIPCHK(hipGetLastError());
     sl.use_global_counts = false;
     return LILI_OK;
@@ -542,7 +542,7 @@ static int launch_linearize_reduce(lili_ctx* ctx, int slot, int kind_mask, const
     HIPCHK(hipGetLastError());
     if (!fz.mode) {
         hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(1024), 0, ctx->stream, fz.part_surf, fz.nb_surf, fz.part_edge, fz.nb_edge, d_out, ctx->state(slot), (do_gn ? 1 : 0) | (P.debug & 256),
-                           xv ? *xv : P2PView{}, (pub_key && do_gn) ? *pub_key : 0ull, ctx->pub_of(slot));
+                           xv ? *xv : P2PView{}, (pub_key && do_gn) ? *pub_key : 0ull, ctx->pub_of(slot), do_gn ? ctx->take_state_mirror(slot) : nullptr);
         HIPCHK(hipGetLastError());
     } else if (pub_key) *pub_key = 0ull;
     if (pub_key && !do_gn) *pub_key = 0ull;
@@ -1140,7 +1140,10 @@ static int iterate_impl(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_p
         for (auto& e : ev) HIPCHK(hipEventCreate(&e));
     }
     unsigned long long wait_key = 0ull;      // != 0: the reduction + GN kernel of the previous iteration publishes its pose under this key (option "overlap_gn")
+    const bool want_mirror = ctx->state_mirror_want;      // (lili_pipeline.hip: the pose of the LAST update also into the page-locked mirror; one shot)
+    ctx->state_mirror_want = false; ctx->state_mirror_armed = false;
     for (int it = 0; it < n_iters; it++) {   // 3 launches per outer iteration: associate, linearise, reduce+GN
+        ctx->state_mirror_armed = want_mirror && it == n_iters - 1;
         if (restart_every > 0 && it % restart_every == 0) { int rc = lili_s2m_pose_copy(ctx, slot, restart_slot); if (rc != LILI_OK) return rc; wait_key = 0ull; }
         if (!assoc_ms) {        // small scans: the whole registration (up to the next restart) as ONE persistent launch
             const int seg = restart_every > 0 ? std::min(restart_every - it % restart_every, n_iters - it) : n_iters - it;
@@ -1166,6 +1169,7 @@ static int iterate_impl(lili_ctx* ctx, int slot, int kind_mask, const lili_s2m_p
         if (rc != LILI_OK) return rc;
         wait_key = pub_key;
     }
+    ctx->state_mirror_armed = false;      // (a path without a reduction + GN kernel has not taken it)
     if (assoc_ms) {
         HIPCHK(hipStreamSynchronize(ctx->stream));
         double tot = 0;

@@ -53,6 +53,31 @@ int lili_frontend_flush(lili_ctx* ctx, const lili_s2m_params* match, const lili_
 
 }  // extern "C"
 
+// "Iterate, then read the pose" with ONE synchronisation and no copy launch: the reduction + GN kernel of the last iteration writes pose and status into a page-locked mirror
+// of the slot's state as well (gn_update_block).  arm_pose_mirror before lili_s2m_iterate; read_pose_after_iterate synchronises and takes the mirror — or, if the
+// iteration ran a path without that kernel (the sentinel is still there), reads the state back the plain way.
+static int arm_pose_mirror(lili_ctx* ctx, int slot) {
+    if (!ctx->h_state_mirror) {
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_state_mirror), sizeof(SlotState) * LILI_MAX_SLOTS, hipHostMallocDefault));
+        void* d = nullptr;
+        if (hipHostGetDevicePointer(&d, ctx->h_state_mirror, 0) != hipSuccess) { (void)hipGetLastError(); d = nullptr; }
+        ctx->h_state_mirror_dev = static_cast<SlotState*>(d);
+    }
+    *reinterpret_cast<volatile int*>(&ctx->h_state_mirror[slot].gn_status) = -1;
+    ctx->state_mirror_want = ctx->h_state_mirror_dev != nullptr;
+    return LILI_OK;
+}
+static int read_pose_after_iterate(lili_ctx* ctx, int slot, SlotState* st) {
+    ctx->state_mirror_want = false;
+    int rc = lili_readback_finish(ctx);
+    if (rc != LILI_OK) return rc;
+    const int status = ctx->h_state_mirror ? *reinterpret_cast<volatile int*>(&ctx->h_state_mirror[slot].gn_status) : -1;
+    if (status != -1) { for (int i = 0; i < 7; i++) st->pose[i] = ctx->h_state_mirror[slot].pose[i]; st->gn_status = status; return LILI_OK; }
+    rc = lili_readback_add(ctx, st, ctx->state(slot), sizeof(*st));
+    if (rc != LILI_OK) return rc;
+    return lili_readback_finish(ctx);
+}
+
 // What a frame needs from its extractor: the kernels enqueued (no synchronisation), the counts taken afterwards, the feature lists as device clouds.
 struct FrameExtractor {
     std::function<int()> enqueue, complete;
@@ -115,13 +140,13 @@ static int frame_impl(lili_ctx* ctx, const FrameExtractor& ex, const lili_s2m_pa
     if (!guessed) { rc = ex.enqueue(); if (rc != LILI_OK) return rc; }
     if (guessed) {
         ctx->slots[slot].assoc_since_pose = 0;
+        rc = arm_pose_mirror(ctx, slot);
+        if (rc != LILI_OK) return rc;
         rc = lili_s2m_iterate(ctx, slot, LILI_MASK_SURF | (edges ? LILI_MASK_EDGE : 0), match, opt->n_iters);
         if (rc != LILI_OK) return rc;
         stamp(0); stamp(1); stamp(2);
         SlotState st{};
-        rc = lili_readback_add(ctx, &st, ctx->state(slot), sizeof(st));
-        if (rc != LILI_OK) return rc;
-        rc = lili_readback_finish(ctx);
+        rc = read_pose_after_iterate(ctx, slot, &st);
         if (rc != LILI_OK) return rc;
         rc = ex.complete();                  // (the stream has been synchronised: the counts lie in the extractor's page-locked state)
         if (rc != LILI_OK) return rc;
@@ -209,6 +234,8 @@ static int frame_impl(lili_ctx* ctx, const FrameExtractor& ex, const lili_s2m_pa
     const bool matched = (self_map || ext_map || lili_localmap_ring_size(ctx, LILI_KIND_SURF) > 0) && ctx->map[LILI_KIND_SURF].valid && ctx->map[LILI_KIND_SURF].n >= 10 && n_q > 0 &&
                          opt->n_iters > 0 && (!edges || ctx->map[LILI_KIND_EDGE].valid);
     if (matched) {
+        rc = arm_pose_mirror(ctx, slot);
+        if (rc != LILI_OK) return rc;
         rc = lili_s2m_iterate(ctx, slot, mask, match, opt->n_iters);
         if (rc != LILI_OK) return rc;
     }
@@ -218,9 +245,8 @@ static int frame_impl(lili_ctx* ctx, const FrameExtractor& ex, const lili_s2m_pa
     //      caller has its pose while the push is still on the stream; the local map with the new keyframe is built at the start of the next frame (or by
     //      lili_frontend_flush).
     SlotState st{};
-    rc = lili_readback_add(ctx, &st, ctx->state(slot), sizeof(st));
-    if (rc != LILI_OK) return rc;
-    rc = lili_readback_finish(ctx);
+    if (matched) rc = read_pose_after_iterate(ctx, slot, &st);
+    else { rc = lili_readback_add(ctx, &st, ctx->state(slot), sizeof(st)); if (rc == LILI_OK) rc = lili_readback_finish(ctx); }
     if (rc != LILI_OK) return rc;
     if (!ext_map) {
         rc = lili_localmap_push_dev(ctx, LILI_KIND_SURF, ctx->slots[slot].k[LILI_KIND_SURF].q.as<float4>(), (opt->flags & LILI_FRAME_PUSH_EMPTY) ? 0 : n_q, ctx->state(slot), opt->width);

@@ -789,7 +789,7 @@ template __global__ void k_associate_edge<kAssocBlock>(const float4*, int, GridV
 template <bool XCHG>
 __device__ __forceinline__ void reduce_partials_block(const double* part_surf, int nb_surf, const double* part_edge, int nb_edge,
                                                       double* __restrict__ out, SlotState* __restrict__ state, int do_gn, unsigned long long key, const P2PView& xv,
-                                                      unsigned long long pub_key = 0ull, double* pub = nullptr);   // defined below
+                                                      unsigned long long pub_key = 0ull, double* pub = nullptr, SlotState* __restrict__ mirror = nullptr);   // defined below
 __device__ __forceinline__ void fused_tail(const FuseTail& fz, unsigned long long key) {
     if (fz.mode != 1 && fz.mode != 2) return;      // 0: plain partials for k_reduce_partials; 3: publish only (the per-kind launches of merge_kinds = 0: the second launch reduces)
     if (blockIdx.x != gridDim.x - 1) return;
@@ -873,7 +873,11 @@ template __global__ void k_associate_lin<kBlock>(AssocArgs, AssocArgs, PoseArg, 
 // Must be called by exactly ONE wave (lanes 0..63 of it).
 // pub_key != 0: the resulting pose (the unchanged one if the step was rejected) is also PUBLISHED as seven keyed granules, kPubReplicas copies (lane l writes copy l), for
 // an association launch that is already running behind this kernel (wait_published_pose, option "overlap_gn").
-__device__ void gn_update_block(const double* gram /*LDS or global, 64+*/, SlotState* __restrict__ state, const double xq[4], unsigned long long pub_key = 0ull, double* pub = nullptr) {
+// `mirror` (optional): a page-locked copy of the slot's state as the device sees it — the lane that updates the pose writes pose and status there as well, so that a caller
+// whose next step is "read the pose" synchronises without a copy launch in between (lili_pipeline.hip; gn_status there stays at the host's sentinel if this function is
+// not reached).
+__device__ void gn_update_block(const double* gram /*LDS or global, 64+*/, SlotState* __restrict__ state, const double xq[4], unsigned long long pub_key = 0ull, double* pub = nullptr,
+                                SlotState* __restrict__ mirror = nullptr) {
     __shared__ double H[6][6];
     __shared__ double gvec[6];
     int tid = threadIdx.x & 63;
@@ -952,7 +956,10 @@ __device__ void gn_update_block(const double* gram /*LDS or global, 64+*/, SlotS
         if (pub_key) { pz[0] = state->pose[0]; pz[1] = state->pose[1]; pz[2] = state->pose[2]; }
         if (okc) {
             if (pub_key) { pz[0] += d[0]; pz[1] += d[1]; pz[2] += d[2]; state->pose[0] = pz[0]; state->pose[1] = pz[1]; state->pose[2] = pz[2]; }
-            else { state->pose[0] += d[0]; state->pose[1] += d[1]; state->pose[2] += d[2]; }
+            else if (mirror) {
+                const double p0 = state->pose[0] + d[0], p1 = state->pose[1] + d[1], p2 = state->pose[2] + d[2];
+                state->pose[0] = p0; state->pose[1] = p1; state->pose[2] = p2; mirror->pose[0] = p0; mirror->pose[1] = p1; mirror->pose[2] = p2;
+            } else { state->pose[0] += d[0]; state->pose[1] += d[1]; state->pose[2] += d[2]; }
             const double nd2 = d[3] * d[3] + d[4] * d[4] + d[5] * d[5];
             if (nd2 > 0.0) {
                 double sbd, cw;
@@ -962,11 +969,16 @@ __device__ void gn_update_block(const double* gram /*LDS or global, 64+*/, SlotS
                 dq r = qmul(qd, dq{x0, x1, x2, x3});
                 state->pose[3] = r.w; state->pose[4] = r.x; state->pose[5] = r.y; state->pose[6] = r.z;
                 pz[3] = r.w; pz[4] = r.x; pz[5] = r.y; pz[6] = r.z;
-            }
+                if (mirror) { mirror->pose[3] = r.w; mirror->pose[4] = r.x; mirror->pose[5] = r.y; mirror->pose[6] = r.z; }
+            } else if (mirror) { mirror->pose[3] = x0; mirror->pose[4] = x1; mirror->pose[5] = x2; mirror->pose[6] = x3; }
 #pragma unroll
             for (int i = 0; i < 6; i++) state->last_delta[i] = d[i];
             state->gn_status = 0;
-        } else state->gn_status = 1;
+            if (mirror) mirror->gn_status = 0;
+        } else {
+            state->gn_status = 1;
+            if (mirror) { for (int i = 0; i < 3; i++) mirror->pose[i] = state->pose[i]; mirror->pose[3] = x0; mirror->pose[4] = x1; mirror->pose[5] = x2; mirror->pose[6] = x3; mirror->gn_status = 1; }
+        }
         state->iters += 1;
     }
     if (pub_key) {          // lane 0's result to every lane, then one copy per lane: 7 x 64 sixteen-byte write-through stores
@@ -1029,7 +1041,7 @@ __device__ __forceinline__ bool sum_partial_chunk(const double* part, int nb, in
 template <bool XCHG>
 __device__ __forceinline__ void reduce_partials_block(const double* part_surf, int nb_surf, const double* part_edge, int nb_edge,
                                                       double* __restrict__ out, SlotState* __restrict__ state, int do_gn, unsigned long long key, const P2PView& xv,
-                                                      unsigned long long pub_key, double* pub) {
+                                                      unsigned long long pub_key, double* pub, SlotState* __restrict__ mirror) {
     tstamp(state, do_gn, (int)blockIdx.x, 8);
     const unsigned long long was_dead = XCHG ? p2p_dead_word(xv) : 0ull;      // requested first: the round trip hides behind the partial loads
     const double xq[4] = {state->pose[3], state->pose[4], state->pose[5], state->pose[6]};
@@ -1103,14 +1115,15 @@ __device__ __forceinline__ void reduce_partials_block(const double* part_surf, i
     if (key && lane == 0) state->epoch = state->epoch + 1ull;      // the next fused launch of this slot gets a new key (stream order)
     if (lane == 0) state->cnt_word = 0ull;                          // re-arms the count barrier of k_associate_coop (the next association of this slot comes after this launch)
     tstamp(state, do_gn, (int)blockIdx.x, 10);
-    if (do_gn & 1) gn_update_block(full, state, xq, pub_key, pub);
+    if (do_gn & 1) gn_update_block(full, state, xq, pub_key, pub, mirror);
     tstamp(state, do_gn, (int)blockIdx.x, 11);
 }
 
 __global__ __launch_bounds__(kReduceThreads) void k_reduce_partials(const double* __restrict__ part_surf, int nb_surf,
                                                             const double* __restrict__ part_edge, int nb_edge,
-                                                            double* __restrict__ out, SlotState* __restrict__ state, int do_gn, P2PView v, unsigned long long pub_key, double* pub) {
-    reduce_partials_block<true>(part_surf, nb_surf, part_edge, nb_edge, out, state, do_gn, 0ull, v, pub_key, pub);
+                                                            double* __restrict__ out, SlotState* __restrict__ state, int do_gn, P2PView v, unsigned long long pub_key, double* pub,
+                                                            SlotState* __restrict__ mirror /*page-locked copy of the pose and status for the host, or nullptr*/) {
+    reduce_partials_block<true>(part_surf, nb_surf, part_edge, nb_edge, out, state, do_gn, 0ull, v, pub_key, pub, mirror);
 }
 
 // ================================================================================================
