@@ -132,9 +132,9 @@ static int frame_impl(lili_ctx* ctx, const FrameExtractor& ex, const lili_s2m_pa
             sink.state = ctx->state(slot);
             for (int i = 0; i < 3; i++) sink.pose[i] = t_pred[i];
             for (int i = 0; i < 4; i++) sink.pose[3 + i] = q_pred[i];
-            rc = ex.enqueue_sink(&sink);
-            if (rc != LILI_OK) return rc;
-            guessed = true;
+            rc = ex.enqueue_sink(&sink);      // (1: not applicable — an empty scan —: the plain chain)
+            if (rc != LILI_OK && rc != 1) return rc;
+            guessed = rc == LILI_OK;
         }
     }
     if (!guessed) { rc = ex.enqueue(); if (rc != LILI_OK) return rc; }
@@ -290,7 +290,7 @@ int lili_frontend_frame_rot(lili_ctx* ctx, const lili_cloud* scan, const double 
     ex.complete = [&]() { return lili_extract_rot_complete(ctx); };
     ex.lists = [&](lili_cloud* e, lili_cloud* s) { return lili_extract_rot_device(ctx, nullptr, e, s); };
     ex.prev = [&](int* pe, int* ps) { lili_extract_rot_prev(ctx, pe, ps); };
-    ex.enqueue_sink = [&](const lili_query_sink* sink) { return lili_extract_rot_enqueue(ctx, scan, q_imu, q_lb, rot, sink); };
+    ex.enqueue_sink = [&](const lili_query_sink* sink) { return scan->n == 0 ? 1 : lili_extract_rot_enqueue(ctx, scan, q_imu, q_lb, rot, sink); };
     ex.redone = [&]() { return lili_extract_rot_redone(ctx); };
     return frame_impl(ctx, ex, match, opt, t_pred, q_pred, res);
 }

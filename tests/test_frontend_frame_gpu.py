@@ -183,6 +183,9 @@ def test_frontend_frame_rot_guessed_feature_counts_change_nothing():
                 t, q, info = odo.frame(c, t0, q0)
                 assert info["matched"] and info["gn_status"] == 0
                 out.append((t.copy(), q.copy(), info["n_surf"], info["n_edge"], info["n_query"]))
+            # an EMPTY scan behind scans with features (a guess exists): nothing to match, the predicted pose comes back
+            t, q, info = odo.frame(L.api.cloud_from_device(d_raw.data_ptr(), 0, 16, 12), t0, q0)
+            assert not info["matched"] and info["n_surf"] == 0 and np.array_equal(t, t0) and np.array_equal(q, q0)
             return out
         finally:
             ctx.close()
