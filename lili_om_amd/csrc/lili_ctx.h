@@ -253,6 +253,6 @@ void lili_extract_rot_prev(lili_ctx* ctx, int* prev_edge, int* prev_surf);
 int lili_extract_rot_complete(lili_ctx* ctx);
 // did the last lili_extract_rot_complete rewrite the lists (second passes)?
 bool lili_extract_rot_redone(lili_ctx* ctx);
-// lili_match.hip -> lili_pipeline.hip: queries whose number is still on the device
-int lili_s2m_set_queries_counted(lili_ctx* ctx, int slot, int kind, const float4* d_src, const int* d_count, int n_guess, bool launch = true);
+// lili_match.hip -> lili_pipeline.hip: a slot sized for a GUESSED number of queries (the producer pads with NaN rows), trimmed once the number is known
+int lili_s2m_set_queries_counted(lili_ctx* ctx, int slot, int kind, int n_guess);
 int lili_s2m_trim_queries(lili_ctx* ctx, int slot, int kind, int n);

@@ -72,29 +72,17 @@ int lili_s2m_set_queries(lili_ctx* ctx, int slot, int kind, const lili_cloud* cl
 }  // extern "C"
 
 // Queries whose NUMBER the host does not know yet (lili_pipeline.hip: a frame's features while the extractor's kernels are still on the stream): the slot is sized for
-// `n_guess` queries, the kernel takes the first min(*d_count, n_guess) rows of `d_src` and fills the rest with NaN rows — a non-finite query selects nothing (cell_of,
-// the key selector), leaves no record and no count, so every sum of the iteration is the sum over the real queries in the order a slot of exactly *d_count queries
-// would take it (the partition of the queries into association / linearisation workgroups depends on the query's index alone; the padding workgroups add +0.0).
-// lili_s2m_trim_queries afterwards, once the count is known (count <= n_guess, else the caller sets the queries again).
-namespace lili {
-__global__ __launch_bounds__(256) void k_queries_counted(const float4* __restrict__ src, const int* __restrict__ d_count, int n_guess, float4* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_guess) return;
-    const float qn = __builtin_nanf("");
-    out[i] = i < *d_count ? src[i] : make_float4(qn, qn, qn, 0.f);
-}
-}  // namespace lili
-int lili_s2m_set_queries_counted(lili_ctx* ctx, int slot, int kind, const float4* d_src, const int* d_count, int n_guess, bool launch) {
+// `n_guess` queries; the producer (k_rot_ring through a lili_query_sink) writes the first min(count, n_guess) rows and fills the rest with NaN rows — a non-finite query
+// selects nothing (cell_of, the key selector), leaves no record and no count, so every sum of the iteration is the sum over the real queries in the order a slot of exactly
+// `count` queries would take it (the partition of the queries into association / linearisation workgroups depends on the query's index alone; the padding workgroups add
+// +0.0).  lili_s2m_trim_queries afterwards, once the count is known (count <= n_guess, else the caller sets the queries again).
+int lili_s2m_set_queries_counted(lili_ctx* ctx, int slot, int kind, int n_guess) {
     if (!ctx) return LILI_E_ARG;
-    ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS && (kind == 0 || kind == 1) && (!launch || (d_src && d_count)) && n_guess > 0, "set_queries_counted: bad argument");
+    ARGCHK(slot >= 0 && slot < LILI_MAX_SLOTS && (kind == 0 || kind == 1) && n_guess > 0, "set_queries_counted: bad argument");
     KindSlot& ks = ctx->slots[slot].k[kind];
     ks.has_queries = false; ks.has_records = false; ks.launches = 0;
     const size_t n = (size_t)n_guess;
     HIPCHK(ks.q.ensure(n * sizeof(float4)));
-    if (launch) {      // (lili_pipeline.hip fills both kinds and sets the pose in ONE launch of its own)
-        hipLaunchKernelGGL(k_queries_counted, dim3(nblocks(n_guess, 256)), dim3(256), 0, ctx->stream, d_src, d_count, n_guess, ks.q.as<float4>());
-        HIPCHK(hipGetLastError());
-    }
     ks.n_q = n_guess;
     ks.has_aux = true;
     ks.n_blocks = nblocks(ks.n_q, kAssocBlock);

@@ -123,8 +123,8 @@ static int frame_impl(lili_ctx* ctx, const FrameExtractor& ex, const lili_s2m_pa
         ex.prev(&pe, &ps);
         if (ps > 0) {
             ge = ((pe + pe / 8 + 64 + 63) / 64) * 64; gs = ((ps + ps / 8 + 64 + 63) / 64) * 64;
-            rc = lili_s2m_set_queries_counted(ctx, slot, LILI_KIND_SURF, nullptr, nullptr, gs, false);
-            if (rc == LILI_OK && edges) rc = lili_s2m_set_queries_counted(ctx, slot, LILI_KIND_EDGE, nullptr, nullptr, ge, false);
+            rc = lili_s2m_set_queries_counted(ctx, slot, LILI_KIND_SURF, gs);
+            if (rc == LILI_OK && edges) rc = lili_s2m_set_queries_counted(ctx, slot, LILI_KIND_EDGE, ge);
             if (rc != LILI_OK) return rc;
             lili_query_sink sink{};
             sink.q_surf = ctx->slots[slot].k[LILI_KIND_SURF].q.as<float4>(); sink.cap_surf = gs;
