@@ -21,12 +21,21 @@ constexpr int kLvBlocks = 664;   // i = 5, 11, ... < 3988 (L:270)
 struct LivoxDev { double q_imu[4]; double surf_thres, edge_thres; float near_thres; };
 struct LivoxState { int n_cut, n_edge, n_surf; };
 
-__device__ __forceinline__ dq lv_slerp_identity(double t, dq b) {
+// Eigen 3.3 slerp of Identity towards b, in two parts (as in lili_extract_rot.hip): what depends on b alone — the angle and its sine, the same for every point of a scan,
+// computed once per workgroup (round 6: every point paid an acos and a sin for them) — and what depends on t.
+struct LvSlerpConst { double th, sn; int linear; };
+__device__ __forceinline__ LvSlerpConst lv_slerp_prepare(dq b) {
     const double one = 1.0 - 2.220446049250313e-16;
-    double d = b.w, absD = fabs(d), s0, s1;
-    if (absD >= one) { s0 = 1.0 - t; s1 = t; }
-    else { double th = acos(absD), sn = sin(th); s0 = sin((1.0 - t) * th) / sn; s1 = sin(t * th) / sn; }
-    if (d < 0) s1 = -s1;
+    const double absD = fabs(b.w);
+    LvSlerpConst c{0.0, 1.0, 1};
+    if (!(absD >= one)) { c.th = acos(absD); c.sn = sin(c.th); c.linear = 0; }
+    return c;
+}
+__device__ __forceinline__ dq lv_slerp_identity(double t, dq b, LvSlerpConst c) {
+    double s0, s1;
+    if (c.linear) { s0 = 1.0 - t; s1 = t; }
+    else { s0 = sin((1.0 - t) * c.th) / c.sn; s1 = sin(t * c.th) / c.sn; }
+    if (b.w < 0) s1 = -s1;
     return dq{s0 + s1 * b.w, s1 * b.x, s1 * b.y, s1 * b.z};
 }
 
@@ -40,10 +49,12 @@ __global__ void k_livox_init(int* __restrict__ owner, LivoxState* st) {
 __global__ __launch_bounds__(256) void k_livox_prep(const unsigned char* __restrict__ raw, int stride, int off_intensity, int off_curvature, int n,
                                                     LivoxDev P, float4* __restrict__ und, float* __restrict__ curv, unsigned char* __restrict__ keep,
                                                     int* __restrict__ owner, int* __restrict__ blk_keep /*[gridDim.x]: kept points of this block (for k_livox_cut)*/) {
+    __shared__ LvSlerpConst slerp_s;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < n;
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
     float c = 0.f;
+    if (threadIdx.x == blockDim.x - 1) slerp_s = lv_slerp_prepare(dq{P.q_imu[0], P.q_imu[1], P.q_imu[2], P.q_imu[3]});      // (published by the barrier of the count below)
     if (live) {
         const unsigned char* row = raw + (size_t)i * (size_t)stride;
         const float* xyz = reinterpret_cast<const float*>(row);
@@ -61,7 +72,7 @@ __global__ __launch_bounds__(256) void k_livox_prep(const unsigned char* __restr
     double dt_i = (double)(p.w - (float)scan_id);
     double ratio = dt_i / 0.1;
     if (ratio >= 1.0) ratio = 1.0;
-    dq qs = lv_slerp_identity(ratio, dq{P.q_imu[0], P.q_imu[1], P.q_imu[2], P.q_imu[3]});
+    dq qs = lv_slerp_identity(ratio, dq{P.q_imu[0], P.q_imu[1], P.q_imu[2], P.q_imu[3]}, slerp_s);
     d3 r = qrot(qs, d3{(double)p.x, (double)p.y, (double)p.z});
     float ux = (float)r.x, uy = (float)r.y, uz = (float)r.z;
     und[i] = make_float4(ux, uy, uz, p.w);
