@@ -1,14 +1,18 @@
 // LOAM-style feature extractor of LiLi-OM-ROT on gfx950 — replaces R/src/Preprocessing.cpp:277-509
 // (R/ = LiLi-OM-ROT/) behind lili_extract_rot():
-//   k_rot_valid      NaN / near-range filter, first & last surviving point            (R:280-294)
-//   k_rot_classify   elevation -> ring id, azimuth, `halfPassed` latch index, per-block ring histogram   (R:308-365)
-//   k_rot_ring_scan  ring offsets (stable per-ring compaction = laserCloudScans[] + concatenation)        (R:371-382)
-//   k_rot_scatter    relTime / intensity, IMU deskew (slerp, f64), scatter into the ring-concatenated cloud (R:367-372,153-177)
-//   k_rot_curvature  11-tap curvature over the concatenated cloud, LDS-staged tile + 5-point halo         (R:385-394)
-//   k_rot_select     one workgroup per ring: 6 segments rank-sorted by (curvature, index), greedy sharp /
-//                    less-sharp / flat picks with +-5 neighbour suppression, less-flat list, per-ring
-//                    VoxelGrid(ds_v) (bitonic sort of (voxel, index) keys in LDS, in-order centroids)     (R:401-508)
-//   k_rot_compact    ordered concatenation of the per-ring lists
+//   k_rot_classify   NaN / near-range filter, first & last surviving point (every workgroup for itself), elevation -> ring id, azimuth, `halfPassed` latch
+//                    index, per-workgroup ring histogram                                                                     (R:280-294, 308-365)
+//   k_rot_scatter    ring offsets from the histograms (every workgroup for itself: stable per-ring compaction = laserCloudScans[] + concatenation), relTime /
+//                    intensity, IMU deskew (slerp, f64), scatter into the ring-concatenated cloud, packed voxel keys                  (R:367-382, 153-177)
+//   k_rot_segments   one workgroup per work item.  Segment (ring, j): 11-tap curvature, binned rank sort by (curvature, index), greedy sharp / less-sharp / flat
+//                    picks with +-5 neighbour suppression on one wave (break bits + mark ranges in registers); a segment whose pick may lie under marks of the
+//                    segment before it waits for them and runs again.  Ordering (ring): the order pcl::VoxelGrid(ds_v) needs, on runs of candidates
+//                                                                                                                             (R:385-394, 401-492, 502-508)
+//   k_rot_ring       one workgroup per ring: joins the six segments, pick lists, less-flat list, in-order f32 VoxelGrid centroids (four lanes per voxel) — written
+//                    where the SCAN's lists want them behind a look-back over the lower rings (no concatenation launch), optionally into a matcher slot as well
+//                                                                                                                             (R:401-508)
+//   (k_rot_compact: ordered concatenation of the per-ring lists — second passes and the fallback of a look-back that gave up; k_rot_voxel_order, k_rot_rank,
+//   k_rot_select_big: scans beyond the packed voxel keys / rings beyond the LDS working set)
 // Decisions are integer / f32 exact; the only transcendental inputs to a decision (atan for the ring id,
 // atan2 for relTime) follow glibc's float routines statement for statement (fd_atanf / fd_atan2f below) — the
 // reference build's bits; option "rot_atan" = 1 selects the f64 functions rounded to f32 instead.
