@@ -62,7 +62,11 @@ int lili_lazy_sources_clear_of(lili_ctx* ctx, const void* p, size_t bytes) {
 int lili_readback_finish(lili_ctx* ctx, hipStream_t stream) {
     hipStream_t s = stream ? stream : ctx->stream;
     hipError_t e = hipSuccess;
-    if (!ctx->h_pin_lazy.empty()) {      // (lazy items are always on the context's stream; a finish of another stream synchronises the context's as well)
+    if (ctx->extract_join_pending) {      // an extraction on its own stream (frame_extract_stream): its products and counts are read from here on
+        ctx->extract_join_pending = false;
+        e = hipStreamWaitEvent(ctx->stream, ctx->join_ev[lili_ctx::kExtractSide], 0);
+    }
+    if (e == hipSuccess && !ctx->h_pin_lazy.empty()) {      // (lazy items are always on the context's stream; a finish of another stream synchronises the context's as well)
         lili::GatherTable t{};
         t.n = (int)ctx->h_pin_lazy.size();
         for (int k = 0; k < t.n; k++) { t.src[k] = static_cast<const unsigned char*>(ctx->h_pin_lazy[k].src); t.off[k] = (unsigned)ctx->h_pin_lazy[k].off; t.bytes[k] = (unsigned)ctx->h_pin_lazy[k].bytes; }
@@ -182,6 +186,7 @@ void lili_ctx_destroy(lili_ctx* ctx) {
     if (ctx->ext_voxel && ctx->ext_voxel_free) ctx->ext_voxel_free(ctx->ext_voxel);
     for (auto& st : ctx->side) if (st) (void)hipStreamDestroy(st);
     if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
+    if (ctx->extract_fork_ev) (void)hipEventDestroy(ctx->extract_fork_ev);
     for (auto& e : ctx->join_ev) if (e) (void)hipEventDestroy(e);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -220,6 +225,7 @@ int lili_set_option(lili_ctx* ctx, const char* name, int value) {
     if (std::strcmp(name, "fine_grid") == 0) { ctx->fine_grid = value != 0; return LILI_OK; }
     if (std::strcmp(name, "sort_ride_hist") == 0) { ctx->sort_ride_hist = value != 0; return LILI_OK; }
     if (std::strcmp(name, "frame_guess_counts") == 0) { ctx->frame_guess_counts = value != 0; return LILI_OK; }
+    if (std::strcmp(name, "frame_extract_stream") == 0) { ctx->frame_extract_stream = value != 0; return LILI_OK; }
     if (std::strcmp(name, "rot_fold") == 0) { ctx->rot_fold = value != 0; return LILI_OK; }
     if (std::strcmp(name, "rot_segment_wait") == 0) { ctx->rot_segment_wait = value != 0; return LILI_OK; }
     if (std::strcmp(name, "super_rows") == 0) { ctx->super_rows = value != 0; return LILI_OK; }   // takes effect at the next lili_map_set

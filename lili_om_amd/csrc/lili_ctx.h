@@ -184,6 +184,12 @@ struct lili_ctx {
     bool localmap_incremental = true;   // lili_localmap_commit keeps the ring sorted by voxel and merges one keyframe per step (0: rebuild every time, A/B)
     int sort_fused_max_tiles = 256;   // (measured: 200 k keys 212 -> 190 us per filter, 1 M keys 301 -> 296; 489 tiles of a 2 M-key sort: 290 -> 475 us)
     bool sort_fused_scan = true;      // radix passes of at most sort_fused_max_tiles tiles: the scatter kernel derives its offsets from the count table itself (no scan launch)
+    // A frame's extraction on a stream of its own (lili_pipeline.hip, option "frame_extract_stream"): the extractor's kernels run next to the ring merge of the local map the
+    // previous frame left pending — they share nothing — instead of in front of it.  `extract_side_next`: the next deferred extraction may take side[kExtractSide] (one shot,
+    // set by the frame); `extract_join_pending`: the context's stream has not yet waited for that extraction — lili_readback_finish does, before it gathers.
+    static constexpr int kExtractSide = 2;
+    hipEvent_t extract_fork_ev = nullptr;
+    bool frame_extract_stream = true, extract_side_next = false, extract_join_pending = false;
     bool rot_fold = true, rot_segment_wait = true;      // lili_extract_rot: k_rot_ring writes the scan's lists itself (0: k_rot_compact behind it) / a segment whose pick may lie under its predecessor's marks waits for them in k_rot_segments (0: k_rot_ring redoes it) — A/B and fallback paths
     int frame_guess_misses = 0;         // frames whose guessed feature counts were too small (matched again the plain way)
     bool frame_guess_counts = true;     // lili_frontend_frame_rot on a caller's maps: the matcher is enqueued behind the extractor with GUESSED feature counts (one synchronisation per scan; 0: wait for the counts first, A/B)

@@ -466,18 +466,32 @@ static int extract_livox_impl(lili_ctx* ctx, const lili_cloud* scan, int curvatu
     HIPCHK(B->und.ensure(cap * 16)); HIPCHK(B->curv.ensure(cap * 4)); HIPCHK(B->keep.ensure(cap));
     HIPCHK(B->cut_a.ensure(cap * 16)); HIPCHK(B->cut_b.ensure(cap * 16)); HIPCHK(B->cut_src.ensure(cap * 4));
     LivoxState* st = B->state.as<LivoxState>();
+    // A deferred extraction of a frame (lili_pipeline.hip) on a stream of its own: its kernels then run NEXT TO the ring merge the frame enqueues on the context's stream
+    // right behind this call; the context's stream waits for them at its next read-back (lili_readback_finish), before anything reads the lists or the counts.
+    hipStream_t xs = ctx->stream;
+    const bool on_side = defer && ctx->extract_side_next && n > 0 && raw != ctx->staging.as<unsigned char>() && !cutted && !edge && !surf;
+    ctx->extract_side_next = false;
+    if (on_side) {
+        constexpr int kS = lili_ctx::kExtractSide;
+        if (!ctx->side[kS]) HIPCHK(hipStreamCreateWithFlags(&ctx->side[kS], hipStreamNonBlocking));
+        if (!ctx->join_ev[kS]) HIPCHK(hipEventCreateWithFlags(&ctx->join_ev[kS], hipEventDisableTiming));
+        if (!ctx->extract_fork_ev) HIPCHK(hipEventCreateWithFlags(&ctx->extract_fork_ev, hipEventDisableTiming));
+        xs = ctx->side[kS];
+        HIPCHK(hipEventRecord(ctx->extract_fork_ev, ctx->stream));      // (behind whatever the previous frame left on the context's stream: its ring push)
+        HIPCHK(hipStreamWaitEvent(xs, ctx->extract_fork_ev, 0));
+    }
     LivoxDev P{};
     for (int i = 0; i < 4; i++) P.q_imu[i] = q_imu[i];
     P.surf_thres = params->surf_thres; P.edge_thres = params->edge_thres; P.near_thres = params->near_range;
-    if (!B->armed) { hipLaunchKernelGGL(k_livox_init, dim3(nblocks(kLvCells, 256)), dim3(256), 0, ctx->stream, B->owner.as<int>(), st); }   // first scan (or after a failed call) only: k_livox_grid re-arms the table
+    if (!B->armed) { hipLaunchKernelGGL(k_livox_init, dim3(nblocks(kLvCells, 256)), dim3(256), 0, xs, B->owner.as<int>(), st); }   // first scan (or after a failed call) only: k_livox_grid re-arms the table
     B->armed = false;
     if (n > 0) {
         HIPCHK(B->blk_keep.ensure((size_t)nblocks(n, 256) * 4));
-        hipLaunchKernelGGL(k_livox_prep, dim3(nblocks(n, 256)), dim3(256), 0, ctx->stream, raw, (int)scan->stride, (int)scan->aux_offset, curvature_offset, n, P, B->und.as<float4>(),
+        hipLaunchKernelGGL(k_livox_prep, dim3(nblocks(n, 256)), dim3(256), 0, xs, raw, (int)scan->stride, (int)scan->aux_offset, curvature_offset, n, P, B->und.as<float4>(),
                            B->curv.as<float>(), B->keep.as<unsigned char>(), B->owner.as<int>(), B->blk_keep.as<int>());
     }
     const int n_cut_blocks = n > 0 ? nblocks(n, 256) : 0;
-    hipLaunchKernelGGL(k_livox_cut_grid, dim3(n_cut_blocks + nblocks(kLvCells, 256)), dim3(256), 0, ctx->stream, n_cut_blocks, B->owner.as<int>(), B->und.as<float4>(), B->curv.as<float>(),
+    hipLaunchKernelGGL(k_livox_cut_grid, dim3(n_cut_blocks + nblocks(kLvCells, 256)), dim3(256), 0, xs, n_cut_blocks, B->owner.as<int>(), B->und.as<float4>(), B->curv.as<float>(),
                        B->keep.as<unsigned char>(), B->blk_keep.as<int>(), B->cut_a.as<float4>(), B->cut_b.as<float4>(), B->cut_src.as<int>(),
                        B->cell_pt.as<float4>(), B->cell_curv.as<float>(), B->cell_src.as<int>(), n, st);
     B->armed = true;
@@ -510,7 +524,7 @@ static int extract_livox_impl(lili_ctx* ctx, const lili_cloud* scan, int curvatu
         HIPCHK(hipEventRecord(ctx->fork_ev, ctx->stream));
         cut_early = true;
     }
-    hipLaunchKernelGGL(k_livox_blocks, dim3(kLvBlocks), dim3(64), 0, ctx->stream, B->cell_pt.as<float4>(), B->cell_curv.as<float>(), P,
+    hipLaunchKernelGGL(k_livox_blocks, dim3(kLvBlocks), dim3(64), 0, xs, B->cell_pt.as<float4>(), B->cell_curv.as<float>(), P,
                        B->blk_nedge.as<int>(), B->blk_edge_cell.as<int>(), B->blk_edge_dir.as<float>(), B->blk_nsurf.as<int>(), B->blk_surf_cell.as<int>(),
                        B->blk_surf_nrm.as<float>());
     if (cut_early) {          // the side stream's copy of lidar_cloud_cutted, enqueued while the GPU works on the blocks (which use no PCIe); joined before the call's ONE synchronisation
@@ -520,10 +534,11 @@ static int extract_livox_impl(lili_ctx* ctx, const lili_cloud* scan, int curvatu
         if (e == hipSuccess) e = hipEventRecord(ctx->join_ev[1], ctx->side[1]);
         if (e != hipSuccess) return ctx->fail(LILI_E_HIP, std::string("extract_livox: ") + hipGetErrorString(e));
     }
-    hipLaunchKernelGGL(k_livox_compact, dim3((kLvBlocks + 15) / 16), dim3(1024), 0, ctx->stream, B->cell_pt.as<float4>(), B->cell_curv.as<float>(), B->blk_nedge.as<int>(),
+    hipLaunchKernelGGL(k_livox_compact, dim3((kLvBlocks + 15) / 16), dim3(1024), 0, xs, B->cell_pt.as<float4>(), B->cell_curv.as<float>(), B->blk_nedge.as<int>(),
                        B->blk_edge_cell.as<int>(), B->blk_edge_dir.as<float>(), B->blk_nsurf.as<int>(), B->blk_surf_cell.as<int>(), B->blk_surf_nrm.as<float>(),
                        B->edge_a.as<float4>(), B->edge_b.as<float4>(), B->edge_cell.as<int>(), B->surf_a.as<float4>(), B->surf_b.as<float4>(), B->surf_cell.as<int>(), st);
     HIPCHK(hipGetLastError());
+    if (on_side) { HIPCHK(hipEventRecord(ctx->join_ev[lili_ctx::kExtractSide], xs)); ctx->extract_join_pending = true; }
     // the three lists are packed into the caller's layout (the kernels read the counts where they lie); then the counts travel
     bool direct = false;      // the packing kernel wrote the caller's (page-locked) edge / surf buffers itself
     if (all3) {

@@ -137,7 +137,13 @@ static int frame_impl(lili_ctx* ctx, const FrameExtractor& ex, const lili_s2m_pa
             guessed = rc == LILI_OK;
         }
     }
-    if (!guessed) { rc = ex.enqueue(); if (rc != LILI_OK) return rc; }
+    if (!guessed) {
+        // (the local map of the previous frame is still to be built: its ring merge and this extraction share nothing — the extraction takes a stream of its own)
+        ctx->extract_side_next = ctx->frame_extract_stream && ctx->frontend_commit_pending && !((opt->flags & LILI_FRAME_SELF_MAP) != 0) && !ext_map;
+        rc = ex.enqueue();
+        ctx->extract_side_next = false;
+        if (rc != LILI_OK) return rc;
+    }
     if (guessed) {
         ctx->slots[slot].assoc_since_pose = 0;
         rc = arm_pose_mirror(ctx, slot);
