@@ -250,6 +250,7 @@ int lili_localmap_ring_size(lili_ctx* ctx, int kind);
 // lili_extract_livox.hip -> lili_pipeline.hip: the extraction enqueued without its synchronisation, and the counts taken afterwards
 int lili_extract_livox_enqueue(lili_ctx* ctx, const lili_cloud* scan, int curvature_offset, const double q_imu[4], const lili_livox_params* params);
 int lili_extract_livox_complete(lili_ctx* ctx);
+int lili_extract_livox_device_ex(lili_ctx* ctx, lili_cloud* edge, lili_cloud* surf, bool convert_edge);      // lili_extract_livox_device; convert_edge = false: the edge cloud's count only
 // Where an extraction may put its feature lists IN ADDITION to its own device lists (lili_pipeline.hip: a frame with guessed feature counts): the query arrays of a matcher
 // slot — rows behind the lists' ends are filled with NaN up to the capacities (lili_s2m_set_queries_counted) —, and the slot's state, set to `pose` like lili_s2m_pose_set.
 struct lili_query_sink { float4* q_surf = nullptr; int cap_surf = 0; float4* q_edge = nullptr; int cap_edge = 0; lili::SlotState* state = nullptr; double pose[7] = {0, 0, 0, 1, 0, 0, 0}; };

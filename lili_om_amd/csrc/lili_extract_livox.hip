@@ -631,19 +631,22 @@ int lili_extract_livox_debug(lili_ctx* ctx, int32_t counts[3], int32_t* cut_src,
 
 // Device views of the last lili_extract_livox results as (x, y, z, curvature) float4 arrays — the fields the
 // Livox matcher consumes (L/src/BackendFusion.cpp:1608-1622); valid until the next extract on this context.
-int lili_extract_livox_device(lili_ctx* ctx, lili_cloud* edge, lili_cloud* surf) {
+int lili_extract_livox_device(lili_ctx* ctx, lili_cloud* edge, lili_cloud* surf) { return lili_extract_livox_device_ex(ctx, edge, surf, true); }
+
+}  // extern "C"
+// (internal, lili_pipeline.hip) convert_edge = false: the edge cloud comes back with its count and NO data — a front-end frame matches surf features only, the edge
+// list's conversion was a launch per frame for nothing
+int lili_extract_livox_device_ex(lili_ctx* ctx, lili_cloud* edge, lili_cloud* surf, bool convert_edge) {
     if (!ctx) return LILI_E_ARG;
     auto* B = livox_of(ctx);
     if (!B->have) return ctx->fail(LILI_E_STATE, "extract_livox_device: run lili_extract_livox first");
     HIPCHK(hipSetDevice(ctx->device));
     const int ne = B->host.n_edge, ns = B->host.n_surf;
     HIPCHK(B->xyzc_edge.ensure((size_t)std::max(ne, 1) * 16)); HIPCHK(B->xyzc_surf.ensure((size_t)std::max(ns, 1) * 16));
-    if (ne) hipLaunchKernelGGL(k_livox_xyzc, dim3(nblocks(ne, 256)), dim3(256), 0, ctx->stream, B->edge_a.as<float4>(), B->edge_b.as<float4>(), ne, B->xyzc_edge.as<float4>());
+    if (ne && convert_edge) hipLaunchKernelGGL(k_livox_xyzc, dim3(nblocks(ne, 256)), dim3(256), 0, ctx->stream, B->edge_a.as<float4>(), B->edge_b.as<float4>(), ne, B->xyzc_edge.as<float4>());
     if (ns) hipLaunchKernelGGL(k_livox_xyzc, dim3(nblocks(ns, 256)), dim3(256), 0, ctx->stream, B->surf_a.as<float4>(), B->surf_b.as<float4>(), ns, B->xyzc_surf.as<float4>());
     HIPCHK(hipGetLastError());
-    if (edge) *edge = lili_cloud{B->xyzc_edge.p, (size_t)ne, 16, 12, LILI_MEM_DEVICE};
+    if (edge) *edge = lili_cloud{convert_edge ? B->xyzc_edge.p : nullptr, (size_t)ne, 16, 12, LILI_MEM_DEVICE};
     if (surf) *surf = lili_cloud{B->xyzc_surf.p, (size_t)ns, 16, 12, LILI_MEM_DEVICE};
     return LILI_OK;
 }
-
-}  // extern "C"

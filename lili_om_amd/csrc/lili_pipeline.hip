@@ -24,6 +24,20 @@ __global__ void k_pose_set(SlotState* __restrict__ s, PoseVal p) {
     if (i == 7) { s->n_res[0] = 0; s->n_res[1] = 0; s->gn_status = 0; s->iters = 0; s->cnt_word = 0ull; }
 }
 
+// A frame's queries (device float4 rows) into the matcher slot's arrays and the slot's pose in ONE launch (it was a conversion launch per kind and one for the pose)
+__global__ __launch_bounds__(256) void k_frame_queries(const float4* __restrict__ src_s, int n_s, float4* __restrict__ out_s, const float4* __restrict__ src_e, int n_e,
+                                                       float4* __restrict__ out_e, SlotState* __restrict__ s, PoseVal p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_s) out_s[i] = src_s[i];
+    else if (i - n_s < n_e) out_e[i - n_s] = src_e[i - n_s];
+    if (blockIdx.x == 0) {
+        const int t = threadIdx.x;
+        if (t < 7) s->pose[t] = p.v[t];
+        if (t < 6) s->last_delta[t] = 0.0;
+        if (t == 7) { s->n_res[0] = 0; s->n_res[1] = 0; s->gn_status = 0; s->iters = 0; s->cnt_word = 0ull; }
+    }
+}
+
 }  // namespace lili
 
 extern "C" {
@@ -225,15 +239,24 @@ static int frame_impl(lili_ctx* ctx, const FrameExtractor& ex, const lili_s2m_pa
         ctx->super_rows = srows;
         if (rc != LILI_OK) return rc;
     }
-    const lili_cloud qc{d_q, (size_t)n_q, 16, 12, LILI_MEM_DEVICE};
-    rc = lili_s2m_set_queries(ctx, slot, LILI_KIND_SURF, &qc);      // device-to-device copy into the slot (the filter's second output is rewritten by the next frame's filter)
-    if (rc != LILI_OK) return rc;
-    if (edges) { rc = lili_s2m_set_queries(ctx, slot, LILI_KIND_EDGE, &d_edge); if (rc != LILI_OK) return rc; }
     const int mask = LILI_MASK_SURF | (edges ? LILI_MASK_EDGE : 0);
     PoseVal pv{};
     for (int i = 0; i < 3; i++) pv.v[i] = t_pred[i];
     for (int i = 0; i < 4; i++) pv.v[3 + i] = q_pred[i];
-    hipLaunchKernelGGL(k_pose_set, dim3(1), dim3(8), 0, ctx->stream, ctx->state(slot), pv);
+    const int n_e = edges ? (int)d_edge.n : 0;
+    if (n_q > 0 && (!edges || n_e > 0)) {      // the slot sized (lili_s2m_set_queries' bookkeeping), then queries (the filter's second output is rewritten by the next frame's filter) and pose in one launch
+        rc = lili_s2m_set_queries_counted(ctx, slot, LILI_KIND_SURF, n_q);
+        if (rc == LILI_OK && edges) rc = lili_s2m_set_queries_counted(ctx, slot, LILI_KIND_EDGE, n_e);
+        if (rc != LILI_OK) return rc;
+        hipLaunchKernelGGL(k_frame_queries, dim3(nblocks(n_q + n_e, 256)), dim3(256), 0, ctx->stream, d_q, n_q, ctx->slots[slot].k[LILI_KIND_SURF].q.as<float4>(),
+                           static_cast<const float4*>(d_edge.data), n_e, edges ? ctx->slots[slot].k[LILI_KIND_EDGE].q.as<float4>() : nullptr, ctx->state(slot), pv);
+    } else {
+        const lili_cloud qc{d_q, (size_t)n_q, 16, 12, LILI_MEM_DEVICE};
+        rc = lili_s2m_set_queries(ctx, slot, LILI_KIND_SURF, &qc);
+        if (rc != LILI_OK) return rc;
+        if (edges) { rc = lili_s2m_set_queries(ctx, slot, LILI_KIND_EDGE, &d_edge); if (rc != LILI_OK) return rc; }
+        hipLaunchKernelGGL(k_pose_set, dim3(1), dim3(8), 0, ctx->stream, ctx->state(slot), pv);
+    }
     HIPCHK(hipGetLastError());
     ctx->slots[slot].assoc_since_pose = 0;
     // ---- updateTransformationWithCeres (L:483-561): needs a map of at least 10 points (L:485-488); the first frame of a sequence has none
@@ -280,7 +303,8 @@ int lili_frontend_frame(lili_ctx* ctx, const lili_cloud* scan, int curvature_off
     FrameExtractor ex;
     ex.enqueue = [&]() { return lili_extract_livox_enqueue(ctx, scan, curvature_offset, q_imu, livox); };
     ex.complete = [&]() { return lili_extract_livox_complete(ctx); };
-    ex.lists = [&](lili_cloud* e, lili_cloud* s) { return lili_extract_livox_device(ctx, e, s); };
+    const bool want_edges = opt && (opt->flags & LILI_FRAME_EDGES) != 0;
+    ex.lists = [&](lili_cloud* e, lili_cloud* s) { return lili_extract_livox_device_ex(ctx, e, s, want_edges); };
     return frame_impl(ctx, ex, match, opt, t_pred, q_pred, res);
 }
 
