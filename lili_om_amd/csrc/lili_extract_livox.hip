@@ -468,6 +468,10 @@ static int extract_livox_impl(lili_ctx* ctx, const lili_cloud* scan, int curvatu
     LivoxState* st = B->state.as<LivoxState>();
     // A deferred extraction of a frame (lili_pipeline.hip) on a stream of its own: its kernels then run NEXT TO the ring merge the frame enqueues on the context's stream
     // right behind this call; the context's stream waits for them at its next read-back (lili_readback_finish), before anything reads the lists or the counts.
+    if (ctx->extract_join_pending) {      // (a frame that ended before its read-back — an error path: the previous extraction may still run on the side stream, and this one reuses its buffers)
+        ctx->extract_join_pending = false;
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->join_ev[lili_ctx::kExtractSide], 0));
+    }
     hipStream_t xs = ctx->stream;
     const bool on_side = defer && ctx->extract_side_next && n > 0 && raw != ctx->staging.as<unsigned char>() && !cutted && !edge && !surf;
     ctx->extract_side_next = false;
