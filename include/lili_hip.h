@@ -117,7 +117,8 @@ int lili_set_debug(lili_ctx* ctx, int keep_neighbors);
  *                 one copy launch each; default 1), "frame_guess_counts" (1 = lili_frontend_frame_rot with LILI_FRAME_EXTERNAL_MAP and leaf_query 0 enqueues the
  *                 matcher behind the extractor for GUESSED feature counts — the previous scan's plus a margin, padding rows select nothing — and synchronises once;
  *                 a scan with more features than guessed is matched again the plain way; results identical either way; default 1), "frame_extract_stream" (1 = a frame whose
- *                 local map is still to be built runs its extraction on a stream of its own, next to the ring merge instead of in front of it; default 1).
+ *                 local map is still to be built runs its extraction on a stream of its own, next to the ring merge instead of in front of it: 15-30 us per frame faster in a
+ *                 process with one context, ~100 us SLOWER in a process that holds many streams (they share the runtime's few hardware queues); default 0).
  *   extraction    "rot_fold" (1 = the ring stage of lili_extract_rot writes the scan's feature lists itself, four launches; 0 = per-ring lists and a concatenation
  *                 launch, also the fallback of a look-back that gave up; default 1), "rot_segment_wait" (1 = a segment whose pick may lie under marks of the
  *                 segment before it waits for them inside the segment stage; 0 = the ring stage repeats such a segment; default 1).

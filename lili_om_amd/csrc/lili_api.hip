@@ -151,6 +151,7 @@ int lili_ctx_create(lili_ctx** out, int device, void* stream) {
     if (!ctx) return LILI_E_NOMEM;
     ctx->device = device;
     ctx->n_simd = prop.multiProcessorCount * 4;   // CDNA: four SIMDs per CU
+    if (const char* e = std::getenv("LILI_FRAME_EXTRACT_STREAM")) ctx->frame_extract_stream = std::atoi(e) != 0;      // (A/B aid for whole-bench runs; lili_set_option "frame_extract_stream" otherwise)
     if (stream) ctx->stream = reinterpret_cast<hipStream_t>(stream);
     else {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return LILI_E_HIP; }

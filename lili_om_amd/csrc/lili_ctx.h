@@ -189,7 +189,7 @@ struct lili_ctx {
     // set by the frame); `extract_join_pending`: the context's stream has not yet waited for that extraction — lili_readback_finish does, before it gathers.
     static constexpr int kExtractSide = 2;
     hipEvent_t extract_fork_ev = nullptr;
-    bool frame_extract_stream = true, extract_side_next = false, extract_join_pending = false;
+    bool frame_extract_stream = false, extract_side_next = false, extract_join_pending = false;      // (default OFF: measured -15..30 us per frame in a process with one context, +100 us in one that holds a dozen streams — the whole bench —)
     bool rot_fold = true, rot_segment_wait = true;      // lili_extract_rot: k_rot_ring writes the scan's lists itself (0: k_rot_compact behind it) / a segment whose pick may lie under its predecessor's marks waits for them in k_rot_segments (0: k_rot_ring redoes it) — A/B and fallback paths
     int frame_guess_misses = 0;         // frames whose guessed feature counts were too small (matched again the plain way)
     bool frame_guess_counts = true;     // lili_frontend_frame_rot on a caller's maps: the matcher is enqueued behind the extractor with GUESSED feature counts (one synchronisation per scan; 0: wait for the counts first, A/B)
