@@ -1038,6 +1038,8 @@ def main():
                     cx = own_ctx()
                     cfgs[key] = fn(L, cx, torch, synth, cpu=not args.no_cpu_baseline)
                     failures.extend(f"configs[{key}]: {f}" for f in BC.parity_failures(cfgs[key]))
+                    if isinstance(cfgs[key].get("cpp_loop"), dict) and cfgs[key]["cpp_loop"].get("poses_equal_bit_for_bit") is False:
+                        failures.append(f"configs[{key}]: the C++ program's one-call pose differs from its separate calls")
                 except Exception as e:      # noqa: BLE001
                     cfgs[key] = {"error": repr(e)}
                 finally:

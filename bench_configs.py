@@ -87,6 +87,32 @@ def parity_failures(r):
 # ------------------------------------------------------------------------------------------------------------------------------
 # configs[0]: one HDL-64E-like scan (~130 k points): ROT extraction + 1 outer GN iteration (edge + surf) vs a 500 k-point map
 # ------------------------------------------------------------------------------------------------------------------------------
+def _cpp_rot_scan(raw, surf_map, edge_map, t0, q0, reps=31):
+    """configs[0] through examples/rot_scan_demo: the same scan, maps and predicted pose from plain C++ on the C ABI — one lili_frontend_frame_rot call per scan and the chain of
+    separate calls beside it (no ctypes, no interpreter between the calls).  Its own process and context; first repetition untimed."""
+    import os, struct, subprocess, tempfile
+    demo = os.path.join(os.path.dirname(os.path.abspath(__file__)), "examples", "rot_scan_demo")
+    if not os.path.exists(demo):
+        return {"error": "examples/rot_scan_demo not built"}
+    try:
+        with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+            sm, em = np.ascontiguousarray(surf_map, "<f4"), np.ascontiguousarray(edge_map, "<f4")
+            f.write(struct.pack("<iii", raw.shape[0], sm.shape[0], em.shape[0]))
+            f.write(np.asarray(t0, "<f8").tobytes()); f.write(np.asarray(q0, "<f8").tobytes())
+            f.write(np.ascontiguousarray(raw, "<f4").tobytes()); f.write(sm.tobytes()); f.write(em.tobytes())
+            path = f.name
+        r = subprocess.run([demo, path, str(reps), "1"], capture_output=True, text=True, timeout=300)
+        os.unlink(path)
+        lines = r.stdout.strip().splitlines()
+        if r.returncode != 0 or len(lines) < 4:
+            return {"error": f"rc {r.returncode}: {r.stdout[-300:]} {r.stderr[-300:]}"}
+        tok = lines[3].split()
+        return {"ms_per_scan": float(tok[2]), "separate_calls_ms_per_scan": float(tok[4]), "repetitions_timed": reps - 1, "poses_equal_bit_for_bit": lines[2].strip().endswith("1"),
+                "what": "examples/rot_scan_demo.cpp on the same scan: one lili_frontend_frame_rot call per scan from C++, the separate calls beside it"}
+    except Exception as e:      # noqa: BLE001
+        return {"error": repr(e)}
+
+
 def config0(L, ctx, torch, synth, cpu=True):
     import ctypes as C
     w = synth.make_workload(n_map=500_000, n_az=2031, half_extent=(150.0, 150.0), verbose=False)
@@ -137,6 +163,7 @@ def config0(L, ctx, torch, synth, cpu=True):
            "separate_calls_ms_per_scan": round(sec_staged * 1e3, 4), "pose_equals_separate_calls_bit_for_bit": same}
     if not same or int(st_s) != 0:
         out["gn_status"] = max(int(st), int(st_s), 1)
+    out["cpp_loop"] = _cpp_rot_scan(raw, w["map_xyz"], w["edge_map_xyz"], t0, q0)
     if cpu:
         try:
             from oracle import oracle as O

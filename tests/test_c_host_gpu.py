@@ -86,3 +86,41 @@ def test_cpp_host_backend_keyframe_one_call_equals_separate_calls():
     print(r)
     assert r["one_call_equals_separate_calls_bit_for_bit"] is True and r["correspondences_total"] > 20000
     assert r["ms_per_keyframe_one_call"] < r["ms_per_keyframe_separate_calls"]
+
+
+def _write_rot_scan_file(path, n_az=400, n_map=200_000):
+    """scan.bin of examples/rot_scan_demo: a synthetic 64-ring scan, surf + edge maps, the perturbed body pose as the prediction"""
+    import struct
+    import numpy as np
+    import lili_om_amd as L
+    from lili_om_amd import synth
+    w = synth.make_workload(n_map=n_map, n_az=n_az, half_extent=(150.0, 150.0), verbose=False)
+    raw = np.concatenate([w["scan_xyz"], np.full((w["scan_xyz"].shape[0], 1), 50.0, np.float32)], 1).astype("<f4")
+    P = L.make_params("rot")
+    tb, qb = L.api.body_pose_from_lidar(w["lidar_t"], w["lidar_q"], P)
+    t0, q0 = synth.perturbed_pose(tb, qb, np.random.default_rng(synth.SEED_POSE), 0.2, 1.0)
+    sm, em = np.ascontiguousarray(w["map_xyz"], "<f4"), np.ascontiguousarray(w["edge_map_xyz"], "<f4")
+    with open(path, "wb") as f:
+        f.write(struct.pack("<iii", raw.shape[0], sm.shape[0], em.shape[0]))
+        f.write(np.asarray(t0, "<f8").tobytes()); f.write(np.asarray(q0, "<f8").tobytes())
+        f.write(raw.tobytes()); f.write(sm.tobytes()); f.write(em.tobytes())
+    return raw.shape[0]
+
+
+def test_cpp_host_rot_scan_one_call_equals_separate_calls(tmp_path):
+    """examples/rot_scan_demo (BASELINE configs[0] from plain C++): lili_frontend_frame_rot on the caller's maps — the matcher enqueued behind the extractor for guessed
+    feature counts from the second repetition on — against lili_extract_rot -> lili_s2m_set_queries x 2 -> lili_s2m_pose_set -> lili_s2m_iterate -> lili_s2m_pose_get:
+    the same pose to the last bit (the program exits 3 otherwise)."""
+    demo = os.path.join(ROOT, "examples", "rot_scan_demo")
+    if not os.path.exists(demo):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "-s"])
+    path = str(tmp_path / "scan.bin")
+    _write_rot_scan_file(path)
+    out = subprocess.run([demo, path, "6", "2"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout, out.stderr)
+    print(out.stdout)
+    lines = out.stdout.strip().splitlines()
+    assert "poses_equal_bit_for_bit 1" in lines[2]
+    one, sep = lines[0].split(), lines[1].split()
+    assert one[2:9] == sep[2:9] and int(one[10]) == 0 and int(one[14]) > 300
+
