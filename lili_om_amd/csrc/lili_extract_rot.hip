@@ -284,12 +284,12 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_scatter(const float4* __restr
     {
         int pre = 0, tot = 0;
         constexpr int kW = kRotBlock / 64;
-        for (int b0 = wave; b0 < nb; b0 += 8 * kW) {            // eight loads in flight per trip (a plain loop waits for every load before it issues the next)
-            int c[8];
+        for (int b0 = wave; b0 < nb; b0 += 16 * kW) {           // sixteen loads in flight per trip: ONE trip for scans of up to 262 144 points (a plain loop waits for every load before it issues the next)
+            int c[16];
 #pragma unroll
-            for (int u = 0; u < 8; u++) { const int b = b0 + u * kW; c[u] = b < nb ? block_hist[b * kMaxRings + lane] : 0; }
+            for (int u = 0; u < 16; u++) { const int b = b0 + u * kW; c[u] = b < nb ? block_hist[b * kMaxRings + lane] : 0; }
 #pragma unroll
-            for (int u = 0; u < 8; u++) { tot += c[u]; if (b0 + u * kW < (int)blockIdx.x) pre += c[u]; }
+            for (int u = 0; u < 16; u++) { tot += c[u]; if (b0 + u * kW < (int)blockIdx.x) pre += c[u]; }
         }
         part_pre[wave][lane] = pre; part_tot[wave][lane] = tot;
         int hm = 0x7fffffff;
