@@ -337,13 +337,12 @@ __global__ __launch_bounds__(kRotBlock) void k_rot_scatter(const float4* __restr
         }
     }
     __syncthreads();
-    if (threadIdx.x < kMaxRings) {   // exclusive prefix over the waves of the block, per ring
-        int run = 0;
-        for (int w = 0; w < kRotBlock / 64; w++) { int c = wave_hist[w][threadIdx.x]; wave_hist[w][threadIdx.x] = run; run += c; }
-    }
-    __syncthreads();
     if (id < 0) return;
-    const int pos = ring_base[id] + my_base[id] + wave_hist[wave][id] + rank;
+    // the points of this ring in the waves in front of this one: up to fifteen independent LDS reads per thread (a serial prefix by 64 threads and a second barrier before)
+    int wave_base = 0;
+#pragma unroll
+    for (int w = 0; w < kRotBlock / 64; w++) wave_base += w < wave ? wave_hist[w][id] : 0;
+    const int pos = ring_base[id] + my_base[id] + wave_base + rank;
     float startOri, endOri;
     start_end_ori(pa, pb, P.atan_mode, startOri, endOri);
     float ori = ori_in;
