@@ -199,6 +199,42 @@ def test_frontend_frame_rot_guessed_feature_counts_change_nothing():
         assert np.array_equal(g[0], want[0]) and np.array_equal(g[1], want[1])
 
 
+@pytest.mark.parametrize("edges", [False, True])
+def test_frontend_frame_rot_guess_behind_a_second_pass_of_the_extractor(edges):
+    """The guessed-count frame when the extractor REWRITES its lists after the matcher has been enqueued: with a 5 cm VoxelGrid leaf the voxel keys of a 150 m scene leave
+    the packed range, lili_extract_rot_complete runs the radix ordering pass and the ring stage again — the frame must notice (the lists its matcher read are stale), match
+    again the plain way and return the pose of the plain chain; also without edge queries (no edge sink)."""
+    import torch
+    w = synth.make_workload(n_map=200_000, n_az=400, half_extent=(150.0, 150.0), verbose=False)
+    raw = np.concatenate([w["scan_xyz"], np.full((w["scan_xyz"].shape[0], 1), 50.0, np.float32)], 1)
+    P = L.make_params("rot")
+    q_lb = np.array(list(P.q_lb))
+    tb, qb = L.api.body_pose_from_lidar(w["lidar_t"], w["lidar_q"], P)
+    t0, q0 = synth.perturbed_pose(tb, qb, np.random.default_rng(synth.SEED_POSE), 0.2, 1.0)
+    d_raw = torch.from_numpy(raw).cuda()
+    cloud = L.api.cloud_from_device(d_raw.data_ptr(), raw.shape[0], 16, 12)
+
+    def run(guess):
+        ctx = L.Context(0)
+        try:
+            ctx.set_option("frame_guess_counts", guess)
+            m = L.ScanToMapMatcher(ctx, P)
+            m.set_input_cloud(L.KIND_SURF, w["map_xyz"]); m.set_input_cloud(L.KIND_EDGE, w["edge_map_xyz"])
+            odo = L.RotFrontendOdometry(ctx, params=P, n_scans=64, ds_rate=2, ds_v=0.05, q_lb=q_lb, leaf_query=0.0, scan_match_cnt=2, external_map=True, edges=edges, slot=1)
+            out = []
+            for _ in range(3):
+                t, q, info = odo.frame(cloud, t0, q0)
+                assert info["matched"] and info["gn_status"] == 0 and info["n_surf"] > 1000
+                out.append((t.copy(), q.copy(), info["n_surf"], info["n_edge"]))
+            return out
+        finally:
+            ctx.close()
+
+    plain, guessed = run(0), run(1)
+    for a, b in zip(plain, guessed):
+        assert a[2:] == b[2:] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
 def _circuit(f, radius=4.0, step=0.03):
     a = step * f
     yaw = a + math.pi / 2
